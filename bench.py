@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path (filtered GROUP-BY aggregate) on N MI355X GPUs of one node.
+
+A "step" = one execution of the workload's aggregate query over the table shard(s)
+resident in HBM: plan upload -> scan/filter/aggregate kernel -> [per-XCD merge] ->
+[N>1: RCCL reduce of the dense partial tables to rank 0 over xGMI] -> group
+materialisation in host memory (SURVEY.md §8(d) timing window).
+
+Workload (BASELINE.json): N=1 runs configs[2] "C3" — 1 B rows / 12 columns (60 GB in HBM),
+conjunctive 3-predicate filter (~5 %), GROUP BY 2 dims (~100 K groups), SUM + COUNT — the
+configuration the metric (rows/s + achieved HBM GB/s) is quoted on.  N>1 runs configs[3]
+"C4": the SAME 1 B rows sharded as contiguous blocks of segments across the ranks (strong
+scaling: total work fixed), with an RCCL reduce of the per-GPU partial aggregates.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+class _DevArray:
+    """Zero-copy view of a device buffer for torch (RCCL collectives on the partial tables)."""
+
+    def __init__(self, ptr, count, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _torch_view(torch, ptr, count, elem):
+    # two's-complement adds are the same bits signed or unsigned: reduce u32/u64 sums as i32/i64
+    typestr = {0: "|u1", 2: "<i4", 3: "<i8", 6: "<i4", 7: "<i8", 8: "<f4", 9: "<f8"}[elem]
+    return torch.as_tensor(_DevArray(ptr, count, typestr), device="cuda")
+
+
+def cpu_baseline(w, sample_segments: int):
+    """The reference's algorithm (oracle/cpu_twin.py: emitted C++, the reference's g++ flags,
+    one thread) on a bounded sample of the same synthetic rows. Checker-side code only."""
+    from oracle import cpu_twin
+    from tests.parity import build_oracle_table
+    rows_per_seg = w.segment_rows
+    ot = build_oracle_table(w, sample_segments, rows_per_seg)
+    tw = cpu_twin.Twin(ot, w.query)
+    tw.run()  # warm-up (page-in)
+    secs = []
+    for _ in range(3):
+        tw.run()
+        secs.append(tw.last_seconds)
+    best = sorted(secs)[len(secs) // 2]
+    rows = sample_segments * rows_per_seg
+    return {"value": rows / best, "unit": "rows/s", "cores": 1, "kind": "port",
+            "sample": "%d segments x %d rows of %s (same generator, same query), median of 3 runs, "
+                      "g++ -O2 -funroll-loops -march=native, 1 thread; %.2f GB/s of referenced bytes"
+                      % (sample_segments, rows_per_seg, w.name, rows * w.bytes_per_row_referenced / best / 1e9),
+            "cpu": _cpu_model()}
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="C3")
+    ap.add_argument("--segments", type=int, default=0, help="total segments (default: 1000 for C3, 100 for C2, 10 for C1)")
+    ap.add_argument("--segment-rows", type=int, default=1_000_000)
+    ap.add_argument("--cpu-segments", type=int, default=40)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--flags", type=int, default=0)
+    ap.add_argument("--check", action="store_true", help="verify the result against the CPU twin on the sample")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from viyadb_amd import capi, executor, synth
+    executor.init(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+
+    w = synth.WORKLOADS[args.workload](segment_rows=args.segment_rows)
+    total_segments = args.segments or {"C1": 10, "C2": 100, "C3": 1000}[args.workload]
+    # contiguous block of segments per rank; global row ids are preserved
+    seg_lo = total_segments * rank // world
+    seg_hi = total_segments * (rank + 1) // world
+    my_segments = seg_hi - seg_lo
+    t_gen = time.time()
+    table = synth.create_device_table(w, my_segments, w.segment_rows, row_base=seg_lo * w.segment_rows)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t_gen
+    plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics,
+                            flags=args.flags, groups_hint=w.plan.groups_hint)
+
+    red_op = None
+    if world > 1:
+        red_op = {capi.U8: dist.ReduceOp.MAX}
+
+    def step():
+        if world == 1:
+            return table.query_agg(plan)
+        res = table.query_launch(plan)
+        for ptr, count, elem, reduce in table.device_buffers(res):
+            if reduce != 0 and elem in (capi.U32, capi.U64):
+                raise SystemExit("unsigned MIN/MAX partials need an order-preserving view; not in this workload")
+            tns = _torch_view(torch, ptr, count, elem)
+            op = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}[reduce]
+            dist.reduce(tns, dst=0, op=op)
+        return table.finalize(res, plan)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    last = None
+    for _ in range(args.warmup):
+        last = step()
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(args.steps):
+        last = step()
+        kernel_ms.append(last.scan_kernel_ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    total_rows = total_segments * w.segment_rows
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_rows / (elapsed / args.steps)
+    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    algo_bytes = last.algorithmic_bytes  # per launch on this rank: rows x referenced bytes/row
+    achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
+
+    if rank == 0:
+        out = {
+            "metric": "rows/sec, filtered GROUP-BY SUM (+ achieved HBM GB/s in roofline)",
+            "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "strong" if world > 1 or True else "weak",
+            "vs_baseline": None, "dtype": "u32 predicates / int64+u32 integer atomics", "data": "synthetic",
+            "config": {"workload": "%s: %s" % (w.name if world == 1 else w.name + " sharded (C4)", w.description),
+                       "rows": total_rows, "segments": total_segments, "segment_rows": w.segment_rows,
+                       "columns": len(w.columns), "table_bytes": total_rows * w.table_bytes_per_row,
+                       "groups": last.ngroups, "passed_rows_rank0": last.passed_recs,
+                       "table_path": last.path, "parallelism": "segments sharded x%d, RCCL reduce to rank 0" % world if world > 1 else "1 GPU",
+                       "generate_seconds": round(t_gen, 3)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "scan_agg_kernel", "kernel_ms": avg_kernel_ms,
+                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "note": "achieved = B_ref (rows x 32 B referenced, SURVEY 8d) / mean HIP-event kernel time on rank 0; "
+                                 "traffic (PMC) is in profiles/"},
+        }
+        if world == 1 and not args.no_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(w, min(args.cpu_segments, total_segments))
+            except Exception as e:  # the CPU leg must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "unit": "rows/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    table.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,265 @@
+/*
+ * viya_hip.h — C ABI of the MI355X-native scan / filter / aggregate executor.
+ *
+ * This is the drop-in boundary for ONE path of the reference: the body of the
+ * generated `viya_query_agg` function between "for (auto* s : segments_copy())"
+ * and "stats.aggregated_recs = agg_map.size()"
+ *   (reference: src/codegen/query/scan.cc:40-66,168-247; the JIT entry point it
+ *    lives in is declared at src/query/runner.h:33-35 and emitted by
+ *    src/codegen/query/agg_query.cc:26-75).
+ * Everything here is plain C: opaque handles, POD structs, pointers and sizes.
+ * No C++ types, no exceptions and no torch types cross this boundary.
+ *
+ * Error convention: every function returns 0 on success, a negative VH_E_* code
+ * otherwise; vh_last_error() returns a thread-local message for the last
+ * failure on the calling thread (reference: C++ exceptions out of the generated
+ * function become HTTP 400, src/server/http/service.cc:129-133 — the host shim
+ * rethrows a non-zero status as std::runtime_error).
+ *
+ * Ownership: the library owns device mirrors behind vh_table; the caller owns
+ * every host buffer it passes in; vh_result objects are library-allocated and
+ * must be released with vh_result_free().
+ */
+#ifndef VIYA_HIP_H_
+#define VIYA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VH_API __attribute__((visibility("default")))
+
+/* ---- status codes -------------------------------------------------------- */
+enum {
+  VH_OK = 0,
+  VH_E_INVALID = -1,     /* bad argument / unsupported plan                  */
+  VH_E_DEVICE = -2,      /* HIP runtime failure                              */
+  VH_E_NOMEM = -3,       /* device or host allocation failed                 */
+  VH_E_UNSUPPORTED = -4, /* valid in the reference, not yet on the GPU path  */
+  VH_E_RANGE = -5        /* data violated a bound the plan relied on         */
+};
+
+/* ---- element types --------------------------------------------------------
+ * One per C++ storage type the reference can generate for a column
+ * (src/db/column.cc:121-153 numeric types; :54-62 dict-code widths;
+ *  :328-333 time/microtime; :357-359 bool; :275-286 count width). */
+enum vh_elem {
+  VH_U8 = 0, VH_U16 = 1, VH_U32 = 2, VH_U64 = 3,
+  VH_I8 = 4, VH_I16 = 5, VH_I32 = 6, VH_I64 = 7,
+  VH_F32 = 8, VH_F64 = 9,
+  VH_BITSET32 = 10, /* util::Bitset<4> per row, mirrored as CSR (offsets,u32) */
+  VH_BITSET64 = 11  /* util::Bitset<8> per row, mirrored as CSR (offsets,u64) */
+};
+
+/* Column kinds (reference: db::Dimension::DimType src/db/column.h:148-162 and
+ * db::Metric::AggregationType :242-254). Dimension kinds matter for segment
+ * skipping: only NUMERIC and TIME dimensions carry min/max stats
+ * (src/codegen/db/store.cc:171-201, src/codegen/query/filter.cc:263-335). */
+enum vh_kind {
+  VH_DIM_STRING = 0, VH_DIM_NUMERIC = 1, VH_DIM_TIME = 2, VH_DIM_BOOLEAN = 3,
+  VH_METRIC_MAX = 16, VH_METRIC_MIN = 17, VH_METRIC_SUM = 18,
+  VH_METRIC_AVG = 19, VH_METRIC_COUNT = 20, VH_METRIC_BITSET = 21,
+  VH_METRIC_HIDDEN_COUNT = 22 /* the uint64_t _count[] array that exists when
+                                 a table has an AVG metric and no COUNT metric
+                                 (src/codegen/db/store.cc:126-129,298-301)   */
+};
+
+typedef struct vh_col_desc {
+  int32_t kind; /* enum vh_kind */
+  int32_t elem; /* enum vh_elem */
+} vh_col_desc;
+
+/* 8-byte scalar, bit-compatible with db::AnyNum (src/db/column.h:98-121):
+ * the value is stored in the low bytes in the column's own type. */
+typedef union vh_anynum {
+  uint8_t u8; uint16_t u16; uint32_t u32; uint64_t u64;
+  int8_t i8; int16_t i16; int32_t i32; int64_t i64;
+  float f32; double f64;
+} vh_anynum;
+
+/* ---- filter program --------------------------------------------------------
+ * The query::Filter tree (src/query/filter.h:38-134) AFTER FilterFactory has
+ * eliminated NOT and sorted children (src/query/filter.cc:36-108), flattened to
+ * postfix. Literals are already decoded to the column's type by the host
+ * (FilterArgsPacker/ValueDecoder, src/codegen/query/filter.cc:100-204). */
+enum vh_fkind {
+  VH_F_TRUE = 0, /* EmptyFilter -> "true"      (filter.cc:258-261)           */
+  VH_F_REL = 1,  /* (col OP lit)               (filter.cc:206-221)           */
+  VH_F_IN = 2,   /* OR of == / AND of !=       (filter.cc:223-241)           */
+  VH_F_AND = 3,  /* bitwise & of `count` operands, no short circuit (:243-256)*/
+  VH_F_OR = 4    /* bitwise | of `count` operands                            */
+};
+enum vh_relop { /* same order as query::RelOpFilter::Operator filter.h:60-67 */
+  VH_OP_EQ = 0, VH_OP_NE = 1, VH_OP_LT = 2, VH_OP_LE = 3, VH_OP_GT = 4, VH_OP_GE = 5
+};
+typedef struct vh_filter_node {
+  int32_t kind;   /* enum vh_fkind                                           */
+  int32_t col;    /* table column index (REL, IN)                            */
+  int32_t op;     /* enum vh_relop (REL); for IN: 1 = IN, 0 = NOT IN         */
+  int32_t count;  /* IN: number of literals; AND/OR: number of operands      */
+  int32_t lit;    /* REL/IN: index of first literal in vh_plan.lits          */
+  int32_t reserved;
+} vh_filter_node;
+
+/* ---- group-by columns ------------------------------------------------------
+ * One per AggTuple::Dimensions field, in QUERY order
+ * (src/codegen/db/store.cc:42-50, src/codegen/query/agg_query.cc:50-58). */
+enum vh_time_unit { /* util::TimeUnit src/util/time.h:27 */
+  VH_T_YEAR = 0, VH_T_MONTH = 1, VH_T_WEEK = 2, VH_T_DAY = 3, VH_T_HOUR = 4,
+  VH_T_MINUTE = 5, VH_T_SECOND = 6, VH_T_NONE = 7
+};
+#define VH_MAX_ROLLUP 8
+typedef struct vh_group_col {
+  int32_t col;          /* table column index (a dimension)                  */
+  int32_t granularity;  /* query-level trunc unit or VH_T_NONE
+                           (src/codegen/query/scan.cc:209-214)               */
+  int32_t nrollup;      /* rollup rules, sorted as the reference sorts them
+                           (`after` descending, src/db/column.cc:346-349)    */
+  int32_t rollup_unit[VH_MAX_ROLLUP];  /* trunc unit of rule i              */
+  uint64_t rollup_before[VH_MAX_ROLLUP]; /* rule i applies when ts < this
+                           (rollup_bN_i, src/codegen/db/rollup.cc:44-95);
+                           in the column's unit (seconds or microseconds)    */
+  int32_t micro;        /* 1: microtime column (util::Time64)                */
+  int32_t reserved;
+  uint64_t cardinality; /* string dim: dict->c2v().size(); bool: 2;
+                           0 = unknown (library uses per-segment min/max)    */
+} vh_group_col;
+
+/* ---- the plan --------------------------------------------------------------*/
+enum vh_plan_flags {
+  VH_PLAN_FORCE_HASH = 1u << 0,   /* testing: never take the dense path     */
+  VH_PLAN_FORCE_GLOBAL = 1u << 1, /* testing: dense table in HBM, not LDS   */
+  VH_PLAN_NO_XCD_PRIVATE = 1u << 2/* testing: one device-scope dense table  */
+};
+typedef struct vh_plan {
+  const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */
+  const vh_anynum* lits;        int32_t nlits;
+  const vh_group_col* groups;   int32_t ngroups;
+  const int32_t* metrics;       int32_t nmetrics;  /* table column indices in
+                                   QUERY order (AggTuple::Metrics fields)    */
+  /* Snapshot of SegmentBase::size() per segment taken by the caller under the
+   * reference's read locks (src/db/store.h:40-44, src/db/segment.h:34-39).
+   * NULL: use the row counts of the last vh_segment_sync of each segment.   */
+  const uint64_t* seg_rows;     uint32_t nseg;
+  uint32_t flags;
+  uint64_t groups_hint;         /* expected number of groups (0 = unknown)   */
+} vh_plan;
+
+/* ---- results ---------------------------------------------------------------*/
+typedef struct vh_table vh_table;
+typedef struct vh_result vh_result;
+
+enum vh_path { VH_PATH_SCALAR = 0, VH_PATH_DENSE_LDS = 1, VH_PATH_DENSE_GLOBAL = 2,
+               VH_PATH_HASH = 3 };
+
+typedef struct vh_result_info {
+  uint64_t ngroups;          /* agg_map.size()  -> stats.aggregated_recs     */
+  uint64_t scanned_recs;     /* scan.cc:44 — every segment, skipped or not   */
+  uint64_t scanned_segments; /* scan.cc:51 — segments that were not skipped  */
+  uint64_t passed_recs;      /* rows for which the predicate held            */
+  int32_t path;              /* enum vh_path                                 */
+  int32_t ngroup_cols;
+  int32_t nmetrics;
+  int32_t has_hidden_count;  /* AVG selected without COUNT (store.cc:126-129)*/
+  float scan_kernel_ms;      /* HIP-event time of the scan/aggregate kernel  */
+  float total_ms;            /* HIP-event time launch .. results in host mem */
+  uint64_t algorithmic_bytes;/* B_ref of SURVEY §8(d) for this query         */
+  uint32_t retries;          /* hash-table regrows                           */
+  uint32_t reserved;
+} vh_result_info;
+
+/* Device-side view of a partial (not yet finalised) result, for the caller to
+ * run a collective over (RCCL all-reduce of identically indexed dense arrays,
+ * SURVEY §8(e)). Only valid for dense paths. */
+enum vh_reduce_op { VH_RED_SUM = 0, VH_RED_MIN = 1, VH_RED_MAX = 2 };
+typedef struct vh_device_buffer {
+  void* ptr; uint64_t count; int32_t elem; /* enum vh_elem */ int32_t reduce; /* enum vh_reduce_op */
+} vh_device_buffer;
+
+/* ---- synthetic data (bench / tests): SURVEY §8(d) counter-based generator --
+ * value(col c, global row r) = splitmix64(seed ^ (c * 0x9E3779B97F4A7C15) ^ r),
+ * reduced to the column's domain. */
+enum vh_gen_mode {
+  VH_GEN_UNIFORM = 0, /* add + (h % mod)   (floating columns: * scale)       */
+  VH_GEN_ROWID = 1,   /* global row index r                                  */
+  VH_GEN_CONST = 2    /* add                                                 */
+};
+typedef struct vh_gen_spec {
+  int32_t mode; int32_t reserved; uint64_t mod; int64_t add; double scale;
+} vh_gen_spec;
+
+/* ---- entry points ----------------------------------------------------------*/
+
+/* Bind the calling process to one GPU (one process per GPU). */
+VH_API int vh_init(int device_id);
+/* Run all subsequent work of this process on an externally owned hipStream_t
+ * (e.g. torch's current stream, so RCCL collectives issued by the caller are
+ * ordered with the kernels). NULL restores the library's own stream. */
+VH_API int vh_set_stream(void* hip_stream);
+VH_API const char* vh_last_error(void);
+VH_API const char* vh_version(void);
+
+/* Mirror of db::Table's storage shape (src/db/table.h:53-91): column list in
+ * table order (dimensions, then metrics, then the hidden count if present) and
+ * segment capacity (src/db/table.cc:48). */
+VH_API int vh_table_create(const vh_col_desc* cols, int32_t ncols,
+                           uint64_t segment_rows, uint32_t reserve_segments,
+                           vh_table** out);
+VH_API void vh_table_destroy(vh_table* t);
+
+/* Copy the first `nrows` rows of segment `seg` into HBM. col_ptrs[c] is the host
+ * address of the segment's column array (&segment->d._i[0] / &segment->m._j[0]
+ * in the generated Segment class, src/codegen/db/store.cc:214-356); a NULL entry
+ * leaves that column's mirror untouched. Bitset columns are not passed here
+ * (see vh_segment_sync_bitset). Also refreshes the per-segment min/max stats
+ * used for segment skipping. */
+VH_API int vh_segment_sync(vh_table* t, uint32_t seg, uint64_t nrows,
+                           const void* const* col_ptrs);
+/* Bitset metric column of one segment as CSR: offsets[nrows+1], values[].   */
+VH_API int vh_segment_sync_bitset(vh_table* t, uint32_t seg, int32_t col,
+                                  uint64_t nrows, const uint64_t* offsets,
+                                  const void* values);
+/* Fill segments [seg_first, seg_first+nseg) directly in HBM with synthetic
+ * data; every segment gets `rows_per_seg` rows (<= segment_rows). The global
+ * row index of row i of segment s is row_base + (s - seg_first) * rows_per_seg + i. */
+VH_API int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nseg,
+                               uint64_t rows_per_seg, uint64_t row_base,
+                               const vh_gen_spec* specs, uint64_t seed);
+/* Copy a mirrored column back to the host (tests). */
+VH_API int vh_segment_read(vh_table* t, uint32_t seg, int32_t col, uint64_t nrows,
+                           void* dst);
+VH_API int vh_table_info(vh_table* t, uint32_t* nseg, uint64_t* segment_rows,
+                         uint64_t* device_bytes);
+/* Per-segment min/max of a column as mirrored (SegmentStats). */
+VH_API int vh_segment_stats(vh_table* t, uint32_t seg, int32_t col,
+                            vh_anynum* min_out, vh_anynum* max_out);
+
+/* The hot path. vh_query_agg = vh_query_launch + vh_result_finalize. */
+VH_API int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out);
+/* Launch only: partial aggregate stays in HBM (multi-GPU: reduce, then finalise). */
+VH_API int vh_query_launch(vh_table* t, const vh_plan* plan, vh_result** out);
+VH_API int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs,
+                                    int32_t max_bufs, int32_t* nbufs);
+VH_API int vh_result_finalize(vh_result* r);
+
+VH_API int vh_result_get_info(vh_result* r, vh_result_info* info);
+/* Copy out: key_cols[i] receives ngroups elements of group column i's element
+ * type; state_cols[j] receives ngroups elements of metric j's element type
+ * (bitset metrics: uint64 cardinality); hidden_count (may be NULL) receives the
+ * summed uint64 _count. Row k of every array belongs to the same group. */
+VH_API int vh_result_copy(vh_result* r, void* const* key_cols,
+                          void* const* state_cols, uint64_t* hidden_count);
+VH_API void vh_result_free(vh_result* r);
+
+/* Streaming-read ceiling of this device in bytes/s (a plain 16 B/lane read
+ * kernel over `bytes` of HBM) — the "achievable" figure quoted next to every
+ * roofline fraction. */
+VH_API int vh_measure_read_bandwidth(uint64_t bytes, int32_t iters, double* bytes_per_sec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIYA_HIP_H_ */

@@ -1,0 +1,39 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY.
+
+numpy twin of the device-side synthetic data generator:
+    value(col c, global row r) = splitmix64(seed ^ (c * GAMMA) ^ r) reduced to the column domain.
+The product generates the same bytes directly in HBM (gen_kernel, viyadb_amd/csrc/vh_kernels.h);
+this file exists so that the oracle can be fed identical inputs without copying 60 GB around.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+GAMMA = np.uint64(0x9E3779B97F4A7C15)
+GEN_UNIFORM, GEN_ROWID, GEN_CONST = 0, 1, 2
+
+
+def splitmix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        x = x + GAMMA
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def gen_column(col_index: int, dtype, spec, seed: int, row_base: int, nrows: int) -> np.ndarray:
+    """spec = (mode, mod, add, scale) — same meaning as vh_gen_spec (include/viya_hip.h)."""
+    mode, mod, add, scale = spec
+    dtype = np.dtype(dtype)
+    r = np.arange(row_base, row_base + nrows, dtype=np.uint64)
+    if mode == GEN_ROWID:
+        return r.astype(dtype)
+    if mode == GEN_CONST:
+        return np.full(nrows, add).astype(dtype)
+    with np.errstate(over="ignore"):
+        colseed = np.uint64(seed) ^ (np.uint64(col_index) * GAMMA)
+    h = splitmix64(colseed ^ r)
+    iv = (h % np.uint64(mod)).astype(np.int64) + np.int64(add)
+    if dtype.kind == "f":
+        return (iv.astype(np.float64) * float(scale)).astype(dtype)
+    return iv.astype(dtype)

@@ -1,0 +1,118 @@
+// vh_internal.h — device-visible plan layout and small helpers shared by the
+// kernels and the C-ABI host code. Not part of the public boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/viya_hip.h"
+
+#define VH_MAX_PROG 48    // postfix nodes per filter
+#define VH_MAX_LITS 96    // literal pool
+#define VH_MAX_GROUP 8    // group-by columns
+#define VH_MAX_METRIC 12  // selected metrics (+ hidden count)
+#define VH_MAX_SLOTS 24   // distinct columns a query may reference
+#define VH_MAX_STACK 8    // predicate mask stack depth
+#define VH_MAX_XCD 8
+#define VH_KEY_WORDS 8    // widest group key: 8 x u64
+
+// Row geometry of one block step (see DESIGN.md "scan geometry"):
+// a wave covers 1024 consecutive rows per step as 4 sub-steps of 256 rows;
+// lane l owns rows {k*256 + l*4 + j | k,j in 0..3} -> 16 rows, 16 mask bits.
+#define VH_WAVE 64
+#define VH_ROWS_PER_LANE_VEC 4
+#define VH_SUBSTEPS 4
+#define VH_WAVE_STEP_ROWS 1024
+
+// state-update opcodes (what one surviving row does to one metric state)
+enum vh_state_op : uint8_t {
+  SOP_ADD32 = 0,  // integer += in a <=32-bit type (wraps mod 2^w after truncation)
+  SOP_ADD64,      // integer += in a 64-bit type
+  SOP_ADDF32, SOP_ADDF64,
+  SOP_MIN_I32, SOP_MAX_I32, SOP_MIN_U32, SOP_MAX_U32,
+  SOP_MIN_I64, SOP_MAX_I64, SOP_MIN_U64, SOP_MAX_U64,
+  SOP_MIN_F32, SOP_MAX_F32, SOP_MIN_F64, SOP_MAX_F64,
+  SOP_BITSET      // emit (group, value) pairs; handled out of line
+};
+
+struct VhProgOp {      // 8 bytes
+  uint8_t kind;        // vh_fkind
+  uint8_t type;        // vh_elem of the column
+  uint8_t op;          // vh_relop / IN polarity
+  uint8_t count;       // IN: literals; AND/OR: operands
+  uint16_t slot;       // referenced-column slot
+  uint16_t lit;        // first literal
+};
+
+struct VhGroupDev {
+  uint16_t slot;
+  uint8_t type;        // vh_elem
+  uint8_t gran;        // vh_time_unit or VH_T_NONE
+  uint8_t nroll;
+  uint8_t micro;
+  uint8_t key_word;    // hash path: which u64 word of the key holds this column
+  uint8_t key_shift;   // hash path: bit offset inside that word
+  uint8_t roll_unit[VH_MAX_ROLLUP];
+  uint64_t roll_before[VH_MAX_ROLLUP];
+  uint64_t lo;         // dense path: value - lo is the digit
+  uint64_t extent;     // dense path: digit < extent
+  uint64_t stride;     // dense path: gid += digit * stride
+};
+
+struct VhMetricDev {
+  uint16_t slot;
+  uint8_t type;        // vh_elem of the source column
+  uint8_t sop;         // vh_state_op
+  uint32_t lds_off;    // DENSE_LDS: byte offset of this metric's state array in LDS
+  void* state;         // global state array (G or capacity elements, 4 or 8 B each)
+  uint64_t ident;      // identity bits: 0 (SUM/AVG/COUNT), type max (MIN), cpp_min_value (MAX)
+};
+
+struct VhPlanDev {
+  // ---- filter
+  int32_t nprog;
+  int32_t nslots;
+  VhProgOp prog[VH_MAX_PROG];
+  uint64_t lits[VH_MAX_LITS];
+  // ---- columns (slot -> arena)
+  const char* colbase[VH_MAX_SLOTS];
+  uint64_t colstride[VH_MAX_SLOTS];  // bytes between consecutive segments
+  // ---- work decomposition
+  const uint32_t* seg_rows;  // per segment: rows to scan (0 = skipped)
+  uint32_t nseg;
+  uint32_t unit_rows;        // multiple of 4096
+  uint32_t units_per_seg;
+  uint32_t total_units;
+  // ---- grouping
+  int32_t ngroup;
+  int32_t nmetric;
+  int32_t key_words;         // hash path: u64 words per key
+  int32_t nxcd;              // dense-global: number of private table copies
+  VhGroupDev g[VH_MAX_GROUP];
+  VhMetricDev m[VH_MAX_METRIC];
+  uint64_t G;                // dense: number of group ids
+  uint64_t xcd_stride;       // dense-global: elements between per-XCD copies
+  uint8_t* present;          // dense: G (x nxcd) presence bytes
+  uint32_t lds_present_off;  // DENSE_LDS: byte offset of presence words
+  uint32_t lds_bytes;        // DENSE_LDS: total dynamic LDS
+  // ---- hash
+  uint64_t* hkeys;           // capacity(+1) x key_words
+  uint32_t* htags;           // wide keys: slot state words
+  uint64_t hmask;            // capacity - 1
+  uint32_t max_probe;
+  uint32_t pad0;
+  // ---- counters: [0] passed rows, [1] new groups (hash), [2] error flags,
+  //                [3] reserved hash slot (key == sentinel) in use
+  unsigned long long* counters;
+};
+
+#define VH_ERR_RANGE 1ull      // dense digit out of range
+#define VH_ERR_HASH_FULL 2ull  // probe limit hit
+
+static inline int vh_elem_size(int e) {
+  switch (e) {
+    case VH_U8: case VH_I8: return 1;
+    case VH_U16: case VH_I16: return 2;
+    case VH_U32: case VH_I32: case VH_F32: return 4;
+    case VH_U64: case VH_I64: case VH_F64: return 8;
+    default: return 0;
+  }
+}

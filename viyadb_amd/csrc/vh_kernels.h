@@ -1,0 +1,772 @@
+// vh_kernels.h — hand-written gfx950 (CDNA4, wave64) kernels of the aggregate path.
+//
+// What they replace in the reference (all emitted as C++ text and JIT-compiled
+// per query by g++, then run on ONE host thread):
+//   scan_agg_kernel    <- the segment/row loops of ScanVisitor::IterationStart
+//                         (src/codegen/query/scan.cc:40-66), the row predicate of
+//                         ComparisonBuilder (src/codegen/query/filter.cc:206-261),
+//                         the key/metric copy + `agg_map[key].Update(m)` of
+//                         ScanVisitor::Visit(AggregateQuery*) (scan.cc:168-247) with
+//                         the Update semantics of TupleStruct (src/codegen/db/store.cc:131-161)
+//   vh_time_rollup     <- TimestampRollup + util::Time32/Time64/Truncator
+//                         (src/codegen/db/rollup.cc:77-95, src/util/time.h:57-137)
+//   seg_minmax_kernel  <- SegmentStats::Update (src/codegen/db/store.cc:171-201)
+//
+// No MFMA anywhere: the path is compares, integer adds and table probes; the
+// bound is HBM bandwidth.
+#pragma once
+#include "vh_internal.h"
+#include <type_traits>
+
+// ------------------------------------------------------------------ utilities
+__host__ __device__ __forceinline__ uint64_t vh_splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+template <typename T> struct VhVec4 { typedef T type __attribute__((ext_vector_type(4))); };
+
+template <typename T> __device__ __forceinline__ T vh_lit(uint64_t bits) {
+  T v; __builtin_memcpy(&v, &bits, sizeof(T)); return v;   // low bytes, like db::AnyNum
+}
+
+__device__ __forceinline__ int vh_xcc_id() {
+  // s_getreg_b32 HW_REG_XCC_ID (id 20), bits [3:0]; used for table placement only:
+  // any value is correct, the right value is fast (MI355X_MICROARCH.md §dispatch).
+  return (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);
+}
+
+// ------------------------------------------------------- time truncation (a8)
+// civil-from-days / days-from-civil, proleptic Gregorian, integer exact. Equivalent
+// to gmtime_r -> zero tm fields -> timegm for every non-negative time_t
+// (checked against the reference's own util/time.cc in tests/golden/time_*.json).
+__host__ __device__ __forceinline__ int64_t vh_days_from_civil(int64_t y, int64_t m, int64_t d) {
+  y -= m <= 2;
+  const int64_t era = (y >= 0 ? y : y - 399) / 400;
+  const int64_t yoe = y - era * 400;
+  const int64_t doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
+  const int64_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
+  return era * 146097 + doe - 719468;
+}
+__host__ __device__ __forceinline__ void vh_civil_from_days(int64_t z, int64_t& y, int64_t& m, int64_t& d) {
+  z += 719468;
+  const int64_t era = (z >= 0 ? z : z - 146096) / 146097;
+  const int64_t doe = z - era * 146097;
+  const int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
+  y = yoe + era * 400;
+  const int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
+  const int64_t mp = (5 * doy + 2) / 153;
+  d = doy - (153 * mp + 2) / 5 + 1;
+  m = mp + (mp < 10 ? 3 : -9);
+  y += m <= 2;
+}
+// Truncator::trunc<U> on seconds since the epoch (src/util/time.h:57-89). WEEK has no
+// specialisation in the reference and is rejected when the plan is built.
+__host__ __device__ __forceinline__ uint64_t vh_trunc_secs(uint64_t t, int unit) {
+  switch (unit) {
+    case VH_T_SECOND: return t;
+    case VH_T_MINUTE: return t - t % 60u;
+    case VH_T_HOUR: return t - t % 3600u;
+    case VH_T_DAY: return t - t % 86400u;
+    default: {
+      int64_t y, m, d;
+      vh_civil_from_days((int64_t)(t / 86400u), y, m, d);
+      if (unit == VH_T_YEAR) m = 1;
+      return (uint64_t)vh_days_from_civil(y, m, 1) * 86400u;
+    }
+  }
+}
+// set_ts -> first matching rollup rule truncates -> query granularity truncates -> get_ts
+// (src/codegen/query/scan.cc:197-218; Time64::trunc also zeroes the microseconds).
+__host__ __device__ __forceinline__ uint64_t vh_time_rollup(uint64_t ts, const VhGroupDev& g) {
+  uint64_t secs = g.micro ? ts / 1000000ull : ts;
+  uint64_t micros = g.micro ? ts % 1000000ull : 0;
+  for (int i = 0; i < g.nroll; ++i) {
+    if (ts < g.roll_before[i]) {
+      secs = vh_trunc_secs(secs, g.roll_unit[i]);
+      micros = 0;
+      break;
+    }
+  }
+  if (g.gran != VH_T_NONE) {
+    secs = vh_trunc_secs(secs, g.gran);
+    micros = 0;
+  }
+  return g.micro ? secs * 1000000ull + micros : (uint64_t)(uint32_t)secs;
+}
+
+// -------------------------------------------------------------- column loads
+// 4 consecutive rows (row % 4 == 0) as one naturally aligned vector load:
+// 4 B types -> global_load_dwordx4, 8 B -> 2x dwordx4, 2 B -> dwordx2, 1 B -> dword.
+template <typename T>
+__device__ __forceinline__ void vh_load4(const T* __restrict__ p, T* out) {
+  typedef typename VhVec4<T>::type V;
+  V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+  out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+
+template <typename T, bool FULL>
+__device__ __forceinline__ void vh_load16(const T* __restrict__ col, uint32_t row_l,
+                                          uint32_t seg_rows, T (&v)[16]) {
+#pragma unroll
+  for (int k = 0; k < VH_SUBSTEPS; ++k) {
+    const uint32_t r = row_l + k * 256u;
+    if (FULL || r < seg_rows) {
+      vh_load4<T>(col + r, &v[k * 4]);
+    } else {
+      v[k * 4] = v[k * 4 + 1] = v[k * 4 + 2] = v[k * 4 + 3] = T(0);
+    }
+  }
+}
+
+// (col OP lit) for 16 rows, in the column's own C++ type, like the generated
+// `(tuple_dims._i[tuple_idx] OP fargK)` (filter.cc:206-221).
+template <typename T>
+__device__ __forceinline__ uint32_t vh_cmp16(const T (&v)[16], T lit, int op) {
+  uint32_t m = 0;
+  switch (op) {
+    case VH_OP_EQ:
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m |= (uint32_t)(v[i] == lit) << i;
+      break;
+    case VH_OP_NE:
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m |= (uint32_t)(v[i] != lit) << i;
+      break;
+    case VH_OP_LT:
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m |= (uint32_t)(v[i] < lit) << i;
+      break;
+    case VH_OP_LE:
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m |= (uint32_t)(v[i] <= lit) << i;
+      break;
+    case VH_OP_GT:
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m |= (uint32_t)(v[i] > lit) << i;
+      break;
+    default:
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m |= (uint32_t)(v[i] >= lit) << i;
+      break;
+  }
+  return m;
+}
+
+template <typename T, bool FULL>
+__device__ __forceinline__ uint32_t vh_leaf(const VhPlanDev& P, const VhProgOp o, const char* base,
+                                            uint32_t row_l, uint32_t seg_rows) {
+  T v[16];
+  vh_load16<T, FULL>(reinterpret_cast<const T*>(base), row_l, seg_rows, v);
+  if (o.kind == VH_F_REL) return vh_cmp16<T>(v, vh_lit<T>(P.lits[o.lit]), o.op);
+  // IN: OR of ==, NOT IN: AND of != (filter.cc:223-241)
+  uint32_t m = o.op ? 0u : 0xFFFFu;
+  for (int i = 0; i < o.count; ++i) {
+    const T lit = vh_lit<T>(P.lits[o.lit + i]);
+    if (o.op) m |= vh_cmp16<T>(v, lit, VH_OP_EQ);
+    else m &= vh_cmp16<T>(v, lit, VH_OP_NE);
+  }
+  return m;
+}
+
+// Evaluate the postfix filter program for the 16 rows this lane owns in the current
+// wave step. Returns a 16-bit pass mask (bit k*4+j <-> row k*256 + lane*4 + j).
+// Composites are bitwise AND / OR with no short circuit, exactly like the reference.
+template <bool FULL>
+__device__ __forceinline__ uint32_t vh_eval_filter(const VhPlanDev& P, uint32_t seg, uint32_t row_l,
+                                                   uint32_t seg_rows) {
+  uint32_t st[VH_MAX_STACK];
+  int sp = 0;
+  for (int pc = 0; pc < P.nprog; ++pc) {
+    const VhProgOp o = P.prog[pc];
+    switch (o.kind) {
+      case VH_F_TRUE: st[sp++] = 0xFFFFu; break;
+      case VH_F_AND: {
+        uint32_t a = st[--sp];
+        for (int i = 1; i < o.count; ++i) a &= st[--sp];
+        st[sp++] = a;
+      } break;
+      case VH_F_OR: {
+        uint32_t a = st[--sp];
+        for (int i = 1; i < o.count; ++i) a |= st[--sp];
+        st[sp++] = a;
+      } break;
+      default: {
+        const char* base = P.colbase[o.slot] + (uint64_t)seg * P.colstride[o.slot];
+        uint32_t m;
+        switch (o.type) {
+          case VH_U8: m = vh_leaf<uint8_t, FULL>(P, o, base, row_l, seg_rows); break;
+          case VH_U16: m = vh_leaf<uint16_t, FULL>(P, o, base, row_l, seg_rows); break;
+          case VH_U32: m = vh_leaf<uint32_t, FULL>(P, o, base, row_l, seg_rows); break;
+          case VH_U64: m = vh_leaf<uint64_t, FULL>(P, o, base, row_l, seg_rows); break;
+          case VH_I8: m = vh_leaf<int8_t, FULL>(P, o, base, row_l, seg_rows); break;
+          case VH_I16: m = vh_leaf<int16_t, FULL>(P, o, base, row_l, seg_rows); break;
+          case VH_I32: m = vh_leaf<int32_t, FULL>(P, o, base, row_l, seg_rows); break;
+          case VH_I64: m = vh_leaf<int64_t, FULL>(P, o, base, row_l, seg_rows); break;
+          case VH_F32: m = vh_leaf<float, FULL>(P, o, base, row_l, seg_rows); break;
+          default: m = vh_leaf<double, FULL>(P, o, base, row_l, seg_rows); break;
+        }
+        st[sp++] = m;
+      } break;
+    }
+  }
+  uint32_t m = st[0];
+  if (!FULL) {
+    // rows at or beyond the segment's snapshotted size() never pass
+#pragma unroll
+    for (int k = 0; k < VH_SUBSTEPS; ++k) {
+      const uint32_t r = row_l + k * 256u;
+      const uint32_t n = r >= seg_rows ? 0u : (seg_rows - r >= 4u ? 4u : seg_rows - r);
+      m &= ~(((0xFu << n) & 0xFu) << (k * 4));
+    }
+  }
+  return m;
+}
+
+// ------------------------------------------------------------ scalar gathers
+// One element of a column as raw bits, zero-extended (hash keys) or sign-extended
+// (dense digits, min/max on small signed types).
+__device__ __forceinline__ uint64_t vh_load_bits(const char* base, int type, uint32_t row, bool sext) {
+  switch (type) {
+    case VH_U8: return *reinterpret_cast<const uint8_t*>(base + row);
+    case VH_I8: { int8_t v = *reinterpret_cast<const int8_t*>(base + row);
+                  return sext ? (uint64_t)(int64_t)v : (uint64_t)(uint8_t)v; }
+    case VH_U16: return *reinterpret_cast<const uint16_t*>(base + 2ull * row);
+    case VH_I16: { int16_t v = *reinterpret_cast<const int16_t*>(base + 2ull * row);
+                   return sext ? (uint64_t)(int64_t)v : (uint64_t)(uint16_t)v; }
+    case VH_U32: case VH_F32: return *reinterpret_cast<const uint32_t*>(base + 4ull * row);
+    case VH_I32: { int32_t v = *reinterpret_cast<const int32_t*>(base + 4ull * row);
+                   return sext ? (uint64_t)(int64_t)v : (uint64_t)(uint32_t)v; }
+    default: return *reinterpret_cast<const uint64_t*>(base + 8ull * row);
+  }
+}
+
+// ----------------------------------------------------------- state updates
+// One surviving row's contribution to one metric state: TupleStruct::Metrics::Update
+// (src/codegen/db/store.cc:131-161): += for SUM/AVG/COUNT (in the metric's own type:
+// a narrower integer wraps, which a wider modular accumulator truncated at the end
+// reproduces bit for bit), std::max / std::min for MAX / MIN.
+template <int SCOPE>
+__device__ __forceinline__ void vh_state_update(void* state, uint64_t idx, int sop, uint64_t bits) {
+  switch (sop) {
+    case SOP_ADD32:
+      __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(state) + idx, (uint32_t)bits, __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_ADD64:
+      __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(state) + idx, (unsigned long long)bits,
+                             __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_ADDF32:
+      __hip_atomic_fetch_add(reinterpret_cast<float*>(state) + idx, __uint_as_float((uint32_t)bits),
+                             __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_ADDF64:
+      __hip_atomic_fetch_add(reinterpret_cast<double*>(state) + idx, __longlong_as_double((long long)bits),
+                             __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_MIN_I32:
+      __hip_atomic_fetch_min(reinterpret_cast<int32_t*>(state) + idx, (int32_t)bits, __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_MAX_I32:
+      __hip_atomic_fetch_max(reinterpret_cast<int32_t*>(state) + idx, (int32_t)bits, __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_MIN_U32:
+      __hip_atomic_fetch_min(reinterpret_cast<uint32_t*>(state) + idx, (uint32_t)bits, __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_MAX_U32:
+      __hip_atomic_fetch_max(reinterpret_cast<uint32_t*>(state) + idx, (uint32_t)bits, __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_MIN_I64:
+      __hip_atomic_fetch_min(reinterpret_cast<long long*>(state) + idx, (long long)bits, __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_MAX_I64:
+      __hip_atomic_fetch_max(reinterpret_cast<long long*>(state) + idx, (long long)bits, __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_MIN_U64:
+      __hip_atomic_fetch_min(reinterpret_cast<unsigned long long*>(state) + idx, (unsigned long long)bits,
+                             __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_MAX_U64:
+      __hip_atomic_fetch_max(reinterpret_cast<unsigned long long*>(state) + idx, (unsigned long long)bits,
+                             __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_MIN_F32:
+      __hip_atomic_fetch_min(reinterpret_cast<float*>(state) + idx, __uint_as_float((uint32_t)bits),
+                             __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_MAX_F32:
+      __hip_atomic_fetch_max(reinterpret_cast<float*>(state) + idx, __uint_as_float((uint32_t)bits),
+                             __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_MIN_F64:
+      __hip_atomic_fetch_min(reinterpret_cast<double*>(state) + idx, __longlong_as_double((long long)bits),
+                             __ATOMIC_RELAXED, SCOPE);
+      break;
+    case SOP_MAX_F64:
+      __hip_atomic_fetch_max(reinterpret_cast<double*>(state) + idx, __longlong_as_double((long long)bits),
+                             __ATOMIC_RELAXED, SCOPE);
+      break;
+    default: break;
+  }
+}
+
+__host__ __device__ __forceinline__ int vh_sop_bytes(int sop) {
+  switch (sop) {
+    case SOP_ADD32: case SOP_ADDF32: case SOP_MIN_I32: case SOP_MAX_I32: case SOP_MIN_U32:
+    case SOP_MAX_U32: case SOP_MIN_F32: case SOP_MAX_F32: return 4;
+    default: return 8;
+  }
+}
+__host__ __device__ __forceinline__ bool vh_sop_sext(int sop) {
+  return sop == SOP_MIN_I32 || sop == SOP_MAX_I32 || sop == SOP_MIN_I64 || sop == SOP_MAX_I64;
+}
+
+// --------------------------------------------------------------- hash insert
+#define VH_HASH_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+// Open-addressing insert of a <=64-bit packed key; returns the slot. The table is in
+// HBM (the group count that sends a query here exceeds what LDS or the dense table
+// can hold); device-scope CAS on the key word is the only synchronisation.
+__device__ __forceinline__ uint64_t vh_hash_insert64(const VhPlanDev& P, uint64_t key, bool& ok, bool& fresh) {
+  fresh = false;
+  if (key == VH_HASH_EMPTY) {          // the one key that collides with the sentinel
+    atomicOr(P.counters + 3, 1ull);    // marks the reserved extra slot as used
+    return P.hmask + 1;
+  }
+  uint64_t slot = vh_splitmix64(key) & P.hmask;
+  for (uint32_t probe = 0; probe <= P.max_probe; ++probe) {
+    unsigned long long expect = VH_HASH_EMPTY;
+    const bool won = __hip_atomic_compare_exchange_strong(
+        reinterpret_cast<unsigned long long*>(P.hkeys) + slot, &expect, (unsigned long long)key,
+        __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (won) { fresh = true; return slot; }
+    if (expect == key) return slot;
+    slot = (slot + 1) & P.hmask;
+  }
+  ok = false;
+  return 0;
+}
+
+// Wide keys (> 64 bits): slot tag word 0 = empty, 1 = being written, 2 = ready.
+// A lane that wins the tag writes the key words, releases, and is done inside the same
+// loop iteration, so lanes of its own wave that spin on the tag cannot starve it.
+__device__ __forceinline__ uint64_t vh_hash_insert_wide(const VhPlanDev& P, const uint64_t* key, int kw,
+                                                        bool& ok, bool& fresh) {
+  fresh = false;
+  uint64_t h = 0x243F6A8885A308D3ull;
+  for (int i = 0; i < kw; ++i) h = vh_splitmix64(h ^ key[i]);
+  uint64_t slot = h & P.hmask;
+  uint32_t probe = 0;
+  while (probe <= P.max_probe) {
+    uint32_t tag = __hip_atomic_load(P.htags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tag == 0) {
+      uint32_t expect = 0;
+      if (__hip_atomic_compare_exchange_strong(P.htags + slot, &expect, 1u, __ATOMIC_RELAXED,
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        for (int i = 0; i < kw; ++i)
+          __hip_atomic_store(P.hkeys + slot * kw + i, key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(P.htags + slot, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        fresh = true;
+        return slot;
+      }
+      continue;  // lost the race: re-read the tag
+    }
+    if (tag == 1) continue;  // writer in flight
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    bool same = true;
+    for (int i = 0; i < kw; ++i)
+      same &= __hip_atomic_load(P.hkeys + slot * kw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key[i];
+    if (same) return slot;
+    slot = (slot + 1) & P.hmask;
+    ++probe;
+  }
+  ok = false;
+  return 0;
+}
+
+// ------------------------------------------------------------ scan + aggregate
+enum { VH_MODE_DENSE_LDS = 1, VH_MODE_DENSE_GLOBAL = 2, VH_MODE_HASH = 3 };
+
+// One surviving row (one per active lane, lanes are dense after compaction):
+// build the AggTuple key, then Update every selected metric.
+template <int MODE, int SCOPE>
+__device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active,
+                                           char* lds, uint64_t xoff, unsigned long long& nfresh) {
+  uint64_t gid = 0;
+  uint64_t key[VH_KEY_WORDS];
+  if (MODE == VH_MODE_HASH) {
+#pragma unroll
+    for (int i = 0; i < VH_KEY_WORDS; ++i) key[i] = 0;
+  }
+  bool bad = false;
+  if (!active) row = 0;
+  for (int i = 0; i < P.ngroup; ++i) {
+    const VhGroupDev& g = P.g[i];
+    const char* base = P.colbase[g.slot] + (uint64_t)seg * P.colstride[g.slot];
+    uint64_t v = vh_load_bits(base, g.type, row, MODE != VH_MODE_HASH);
+    if (g.gran != VH_T_NONE || g.nroll) v = vh_time_rollup(v, g);
+    if (MODE == VH_MODE_HASH) {
+      if (g.type == VH_F32 && (uint32_t)v == 0x80000000u) v = 0;            // -0.0f == 0.0f
+      if (g.type == VH_F64 && v == 0x8000000000000000ull) v = 0;
+      key[g.key_word] |= v << g.key_shift;
+    } else {
+      const uint64_t d = v - g.lo;
+      bad |= d >= g.extent;
+      gid += d * g.stride;
+    }
+  }
+  if (MODE == VH_MODE_HASH) {
+    bool ok = true, fresh = false;
+    if (active) {
+      gid = P.key_words == 1 ? vh_hash_insert64(P, key[0], ok, fresh)
+                             : vh_hash_insert_wide(P, key, P.key_words, ok, fresh);
+    }
+    bad = !ok;
+    nfresh += __popcll(__ballot(active && fresh));
+    if (__ballot(active && bad)) {
+      if (active && bad) atomicOr(P.counters + 2, VH_ERR_HASH_FULL);
+    }
+  } else if (__ballot(active && bad)) {
+    if (active && bad) atomicOr(P.counters + 2, VH_ERR_RANGE);
+  }
+  active = active && !bad;
+  if (MODE == VH_MODE_DENSE_LDS) {
+    if (active) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[gid] = 1;
+  } else if (MODE == VH_MODE_DENSE_GLOBAL) {
+    if (active) P.present[xoff + gid] = 1;
+  }
+  for (int j = 0; j < P.nmetric; ++j) {
+    const VhMetricDev& m = P.m[j];
+    const char* base = P.colbase[m.slot] + (uint64_t)seg * P.colstride[m.slot];
+    const uint64_t bits = vh_load_bits(base, m.type, row, vh_sop_sext(m.sop));
+    if (active) {
+      if (MODE == VH_MODE_DENSE_LDS) {
+        vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, gid, m.sop, bits);
+      } else if (MODE == VH_MODE_DENSE_GLOBAL) {
+        vh_state_update<SCOPE>(m.state, xoff + gid, m.sop, bits);
+      } else {
+        vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, gid, m.sop, bits);
+      }
+    }
+  }
+}
+
+template <int BLOCK>
+struct VhScanCfg {
+  static constexpr int kWaves = BLOCK / 64;
+  static constexpr int kStepRows = BLOCK * 16;
+  static constexpr int kQueueCap = 64 + 256;  // carry-over (<64) + one sub-step (<=256)
+};
+
+// The fused kernel. Grid-stride over work units (unit = unit_rows consecutive rows of one
+// segment). Per wave and step: stream the predicate columns (coalesced 16 B/lane loads,
+// 4 in flight per column), evaluate the filter to a 16-bit mask per lane, compact the
+// passing row offsets into this wave's LDS queue with wave64 ballots + mbcnt prefix
+// sums, and whenever 64 survivors are queued let all 64 lanes gather the group/metric
+// values of one survivor each and update the aggregate table. No block-wide barrier in
+// the loop: queues are per wave.
+template <int MODE, int BLOCK, int SCOPE>
+__global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef VhScanCfg<BLOCK> C;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  // queues live behind the (optional) LDS aggregate table
+  uint16_t* q = reinterpret_cast<uint16_t*>(lds + (MODE == VH_MODE_DENSE_LDS ? P.lds_bytes : 0)) +
+                wave * C::kQueueCap;
+
+  if (MODE == VH_MODE_DENSE_LDS) {
+    // identities: 0 for SUM/AVG/COUNT, type max for MIN, cpp_min_value for MAX
+    // (src/codegen/db/store.cc:107-117)
+    for (int j = 0; j < P.nmetric; ++j) {
+      const VhMetricDev& m = P.m[j];
+      const uint64_t ident = m.ident;
+      if (vh_sop_bytes(m.sop) == 4) {
+        for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK)
+          reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)ident;
+      } else {
+        for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK)
+          reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = ident;
+      }
+    }
+    for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
+    __syncthreads();
+  }
+
+  const uint64_t xoff = (MODE == VH_MODE_DENSE_GLOBAL && P.nxcd > 1) ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;
+  const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+  unsigned long long npassed = 0, nfresh = 0;
+
+  for (uint32_t unit = blockIdx.x; unit < P.total_units; unit += gridDim.x) {
+    const uint32_t seg = unit / P.units_per_seg;
+    const uint32_t unit_base = (unit - seg * P.units_per_seg) * P.unit_rows;
+    const uint32_t seg_rows = P.seg_rows[seg];
+    if (unit_base >= seg_rows) continue;
+    uint32_t cnt = 0;  // queued survivors of this wave (wave-uniform)
+    for (uint32_t step_base = unit_base; step_base < unit_base + P.unit_rows && step_base < seg_rows;
+         step_base += C::kStepRows) {
+      const uint32_t wave_base = step_base + wave * VH_WAVE_STEP_ROWS;
+      if (wave_base >= seg_rows) break;
+      const uint32_t row_l = wave_base + lane * 4;
+      const bool full = wave_base + VH_WAVE_STEP_ROWS <= seg_rows;
+      const uint32_t mask = full ? vh_eval_filter<true>(P, seg, row_l, seg_rows)
+                                 : vh_eval_filter<false>(P, seg, row_l, seg_rows);
+      npassed += __popc(mask);
+#pragma unroll
+      for (int k = 0; k < VH_SUBSTEPS; ++k) {
+        const uint32_t mk = (mask >> (4 * k)) & 0xFu;
+        if (__ballot(mk != 0) == 0) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool b = (mk >> j) & 1u;
+          const uint64_t bal = __ballot(b);
+          if (b) q[cnt + __popcll(bal & lanemask_lt)] = (uint16_t)(row_l + k * 256u + j - unit_base);
+          cnt += __popcll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (cnt >= 64) {
+          cnt -= 64;
+          const uint32_t r = unit_base + q[cnt + lane];
+          vh_consume<MODE, SCOPE>(P, seg, r, true, lds, xoff, nfresh);
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+    }
+    if (cnt) {
+      const bool act = lane < (int)cnt;
+      const uint32_t r = unit_base + (act ? q[lane] : 0);
+      vh_consume<MODE, SCOPE>(P, seg, r, act, lds, xoff, nfresh);
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  // wave totals -> one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) npassed += __shfl_down(npassed, off);
+  if (lane == 0) {
+    if (npassed) atomicAdd(P.counters + 0, npassed);
+    if (nfresh) atomicAdd(P.counters + 1, nfresh);
+  }
+
+  if (MODE == VH_MODE_DENSE_LDS) {
+    // flush this block's LDS table: one global update per (block, present group)
+    __syncthreads();
+    const uint64_t xo = P.nxcd > 1 ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;
+    for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) {
+      if (!reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g]) continue;
+      P.present[xo + g] = 1;
+      for (int j = 0; j < P.nmetric; ++j) {
+        const VhMetricDev& m = P.m[j];
+        const uint64_t bits = vh_sop_bytes(m.sop) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
+                                                       : reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
+        vh_state_update<SCOPE>(m.state, xo + g, m.sop, bits);
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------- table finalisation
+// Combine the per-XCD private copies of a dense table into copy 0 (they were only ever
+// touched through their own XCD's L2; the kernel boundary made them visible).
+__device__ __forceinline__ uint64_t vh_combine(int sop, uint64_t a, uint64_t b) {
+  switch (sop) {
+    case SOP_ADD32: return (uint32_t)((uint32_t)a + (uint32_t)b);
+    case SOP_ADD64: return a + b;
+    case SOP_ADDF32: return __float_as_uint(__uint_as_float((uint32_t)a) + __uint_as_float((uint32_t)b));
+    case SOP_ADDF64: return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
+    case SOP_MIN_I32: return (uint32_t)((int32_t)b < (int32_t)a ? b : a);
+    case SOP_MAX_I32: return (uint32_t)((int32_t)a < (int32_t)b ? b : a);
+    case SOP_MIN_U32: return (uint32_t)b < (uint32_t)a ? (uint32_t)b : (uint32_t)a;
+    case SOP_MAX_U32: return (uint32_t)a < (uint32_t)b ? (uint32_t)b : (uint32_t)a;
+    case SOP_MIN_I64: return (int64_t)b < (int64_t)a ? b : a;
+    case SOP_MAX_I64: return (int64_t)a < (int64_t)b ? b : a;
+    case SOP_MIN_U64: return b < a ? b : a;
+    case SOP_MAX_U64: return a < b ? b : a;
+    case SOP_MIN_F32: return __uint_as_float((uint32_t)b) < __uint_as_float((uint32_t)a) ? (uint32_t)b : (uint32_t)a;
+    case SOP_MAX_F32: return __uint_as_float((uint32_t)a) < __uint_as_float((uint32_t)b) ? (uint32_t)b : (uint32_t)a;
+    case SOP_MIN_F64: return __longlong_as_double((long long)b) < __longlong_as_double((long long)a) ? b : a;
+    default: return __longlong_as_double((long long)a) < __longlong_as_double((long long)b) ? b : a;
+  }
+}
+
+struct VhMergeArgs {
+  int32_t nmetric; int32_t nxcd;
+  uint64_t G; uint64_t xcd_stride;
+  uint8_t* present;
+  void* state[VH_MAX_METRIC];
+  uint8_t sop[VH_MAX_METRIC];
+};
+
+__global__ __launch_bounds__(256) void dense_merge_kernel(const VhMergeArgs A) {
+  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= A.G) return;
+  uint8_t p = A.present[g];
+  for (int x = 1; x < A.nxcd; ++x) p |= A.present[x * A.xcd_stride + g];
+  A.present[g] = p;
+  if (!p) return;
+  for (int j = 0; j < A.nmetric; ++j) {
+    const int sop = A.sop[j];
+    if (vh_sop_bytes(sop) == 4) {
+      uint32_t* s = reinterpret_cast<uint32_t*>(A.state[j]);
+      uint64_t a = s[g];
+      for (int x = 1; x < A.nxcd; ++x) a = vh_combine(sop, a, s[x * A.xcd_stride + g]);
+      s[g] = (uint32_t)a;
+    } else {
+      uint64_t* s = reinterpret_cast<uint64_t*>(A.state[j]);
+      uint64_t a = s[g];
+      for (int x = 1; x < A.nxcd; ++x) a = vh_combine(sop, a, s[x * A.xcd_stride + g]);
+      s[g] = a;
+    }
+  }
+}
+
+// Emit one (key columns, metric states) row per existing group into dense output arrays,
+// already in each column's own element type.
+struct VhEmitArgs {
+  int32_t mode;  // VH_MODE_*
+  int32_t ngroup; int32_t nmetric; int32_t key_words;
+  uint64_t n;    // dense: G; hash: capacity + 1
+  const uint8_t* present;
+  const uint64_t* hkeys; const uint32_t* htags;
+  const unsigned long long* counters;
+  unsigned long long* out_count;
+  VhGroupDev g[VH_MAX_GROUP];
+  void* out_key[VH_MAX_GROUP];
+  const void* state[VH_MAX_METRIC];
+  void* out_state[VH_MAX_METRIC];
+  uint8_t sop[VH_MAX_METRIC];
+  uint8_t mtype[VH_MAX_METRIC];   // output element type of metric j
+};
+
+__device__ __forceinline__ void vh_store_elem(void* base, int type, uint64_t idx, uint64_t bits) {
+  switch (type) {
+    case VH_U8: case VH_I8: reinterpret_cast<uint8_t*>(base)[idx] = (uint8_t)bits; break;
+    case VH_U16: case VH_I16: reinterpret_cast<uint16_t*>(base)[idx] = (uint16_t)bits; break;
+    case VH_U32: case VH_I32: case VH_F32: reinterpret_cast<uint32_t*>(base)[idx] = (uint32_t)bits; break;
+    default: reinterpret_cast<uint64_t*>(base)[idx] = bits; break;
+  }
+}
+
+__global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool have = false;
+  if (i < A.n) {
+    if (A.mode == VH_MODE_HASH) {
+      if (i + 1 == A.n) have = A.key_words == 1 && A.counters[3] != 0;  // reserved slot
+      else have = A.key_words == 1 ? A.hkeys[i] != VH_HASH_EMPTY : A.htags[i] == 2u;
+    } else {
+      have = A.present[i] != 0;
+    }
+  }
+  const uint64_t bal = __ballot(have);
+  if (bal == 0) return;
+  const int lane = threadIdx.x & 63;
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(A.out_count, (unsigned long long)__popcll(bal));
+  base = __shfl(base, 0);
+  if (!have) return;
+  const uint64_t pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+  for (int c = 0; c < A.ngroup; ++c) {
+    const VhGroupDev& g = A.g[c];
+    uint64_t v;
+    if (A.mode == VH_MODE_HASH) {
+      uint64_t w = A.hkeys[i * A.key_words + g.key_word];
+      if (A.key_words == 1 && i + 1 == A.n) w = VH_HASH_EMPTY;
+      v = w >> g.key_shift;
+    } else {
+      v = g.lo + (i / g.stride) % g.extent;
+    }
+    vh_store_elem(A.out_key[c], g.type, pos, v);
+  }
+  for (int j = 0; j < A.nmetric; ++j) {
+    const uint64_t bits = vh_sop_bytes(A.sop[j]) == 4 ? reinterpret_cast<const uint32_t*>(A.state[j])[i]
+                                                      : reinterpret_cast<const uint64_t*>(A.state[j])[i];
+    vh_store_elem(A.out_state[j], A.mtype[j], pos, bits);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fill_kernel(T* p, uint64_t n, T v) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = v;
+}
+
+// ----------------------------------------------------------- synthetic data
+// value(c, r) = splitmix64(seed ^ c*GAMMA ^ r) reduced to the column domain.
+template <typename T>
+__global__ __launch_bounds__(256) void gen_kernel(T* base, uint64_t seg_stride_elems, uint64_t rows_per_seg,
+                                                  uint64_t row_base, vh_gen_spec spec, uint64_t colseed) {
+  const uint32_t seg = blockIdx.y;
+  T* col = base + (uint64_t)seg * seg_stride_elems;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < rows_per_seg; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t r = row_base + (uint64_t)seg * rows_per_seg + i;
+    T out;
+    if (spec.mode == VH_GEN_ROWID) {
+      out = (T)r;
+    } else if (spec.mode == VH_GEN_CONST) {
+      out = (T)spec.add;
+    } else {
+      const uint64_t h = vh_splitmix64(colseed ^ r);
+      const int64_t iv = spec.add + (int64_t)(h % spec.mod);
+      if (std::is_floating_point<T>::value) out = (T)((double)iv * spec.scale);
+      else out = (T)iv;
+    }
+    col[i] = out;
+  }
+}
+
+// ------------------------------------------------------------ segment stats
+// Order-preserving map of a column value to u64 so one pair of u64 atomics does min/max.
+template <typename T> __device__ __forceinline__ uint64_t vh_order_key(T v);
+template <> __device__ __forceinline__ uint64_t vh_order_key<uint8_t>(uint8_t v) { return v; }
+template <> __device__ __forceinline__ uint64_t vh_order_key<uint16_t>(uint16_t v) { return v; }
+template <> __device__ __forceinline__ uint64_t vh_order_key<uint32_t>(uint32_t v) { return v; }
+template <> __device__ __forceinline__ uint64_t vh_order_key<uint64_t>(uint64_t v) { return v; }
+template <> __device__ __forceinline__ uint64_t vh_order_key<int8_t>(int8_t v) { return (uint64_t)(int64_t)v ^ (1ull << 63); }
+template <> __device__ __forceinline__ uint64_t vh_order_key<int16_t>(int16_t v) { return (uint64_t)(int64_t)v ^ (1ull << 63); }
+template <> __device__ __forceinline__ uint64_t vh_order_key<int32_t>(int32_t v) { return (uint64_t)(int64_t)v ^ (1ull << 63); }
+template <> __device__ __forceinline__ uint64_t vh_order_key<int64_t>(int64_t v) { return (uint64_t)v ^ (1ull << 63); }
+template <> __device__ __forceinline__ uint64_t vh_order_key<float>(float v) {
+  const uint32_t b = __float_as_uint(v);
+  return (b & 0x80000000u) ? (uint32_t)~b : (b | 0x80000000u);
+}
+template <> __device__ __forceinline__ uint64_t vh_order_key<double>(double v) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  return (b & (1ull << 63)) ? ~b : (b | (1ull << 63));
+}
+
+// stats[(seg*2)+0] = min key, +1 = max key; pre-filled with ~0 / 0.
+template <typename T>
+__global__ __launch_bounds__(256) void seg_minmax_kernel(const T* base, uint64_t seg_stride_elems,
+                                                         const uint32_t* seg_rows, uint32_t seg_first,
+                                                         unsigned long long* stats) {
+  const uint32_t seg = seg_first + blockIdx.y;
+  const T* col = base + (uint64_t)seg * seg_stride_elems;
+  const uint64_t n = seg_rows[blockIdx.y];
+  uint64_t lo = ~0ull, hi = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t k = vh_order_key<T>(col[i]);
+    lo = k < lo ? k : lo;
+    hi = k > hi ? k : hi;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint64_t l2 = __shfl_down(lo, off), h2 = __shfl_down(hi, off);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0 && n) {
+    atomicMin(stats + 2ull * blockIdx.y, (unsigned long long)lo);
+    atomicMax(stats + 2ull * blockIdx.y + 1, (unsigned long long)hi);
+  }
+}
+
+// ------------------------------------------------------- bandwidth ceiling
+typedef uint32_t vh_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void read_bw_kernel(const vh_u32x4* p, uint64_t n16, unsigned long long* sink) {
+  uint32_t acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) {
+    const vh_u32x4 v = __builtin_nontemporal_load(p + i);
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9E3779B9u) atomicAdd(sink, 1ull);  // defeat dead-code elimination
+}

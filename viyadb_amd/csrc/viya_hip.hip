@@ -1,0 +1,994 @@
+// viya_hip.hip — C-ABI implementation (include/viya_hip.h) over the gfx950 kernels.
+//
+// Host-side responsibilities that the reference performs inside the generated
+// function and that therefore live on this side of the boundary:
+//   * segment skipping from per-segment min/max (SegmentSkipBuilder,
+//     src/codegen/query/filter.cc:263-335; use at src/codegen/query/scan.cc:48-51)
+//   * stats.scanned_recs / scanned_segments / aggregated_recs bookkeeping
+//     (scan.cc:44,51,246)
+//   * choosing the aggregate-table organisation (the reference always uses
+//     std::unordered_map, scan.cc:174-177; here: LDS-resident dense table, per-XCD
+//     private dense tables in HBM/L2, or an open-addressing hash table in HBM).
+#include "vh_kernels.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+static int vh_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return vh_fail(e_ == hipErrorOutOfMemory ? VH_E_NOMEM : VH_E_DEVICE, "%s failed: %s (%s:%d)", \
+                     #expr, hipGetErrorString(e_), __FILE__, __LINE__);                        \
+  } while (0)
+
+// ------------------------------------------------------------------ context
+struct VhContext {
+  bool inited = false;
+  int device = 0;
+  int num_cu = 256;
+  int num_xcd = 8;
+  size_t lds_per_block = 65536;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+};
+static VhContext g_ctx;
+static std::mutex g_mu;
+
+extern "C" const char* vh_last_error(void) { return g_err; }
+extern "C" const char* vh_version(void) { return "viya_hip 0.1 (gfx950)"; }
+
+extern "C" int vh_init(int device_id) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  HIP_TRY(hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device_id));
+  g_ctx.device = device_id;
+  g_ctx.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  g_ctx.lds_per_block = prop.sharedMemPerBlock ? prop.sharedMemPerBlock : 65536;
+  g_ctx.num_xcd = 8;
+  if (!g_ctx.own_stream) HIP_TRY(hipStreamCreateWithFlags(&g_ctx.own_stream, hipStreamNonBlocking));
+  if (!g_ctx.stream) g_ctx.stream = g_ctx.own_stream;
+  g_ctx.inited = true;
+  return VH_OK;
+}
+
+extern "C" int vh_set_stream(void* hip_stream) {
+  if (!g_ctx.inited) return vh_fail(VH_E_INVALID, "vh_init has not been called");
+  g_ctx.stream = hip_stream ? (hipStream_t)hip_stream : g_ctx.own_stream;
+  return VH_OK;
+}
+
+// -------------------------------------------------------------------- table
+struct VhColumn {
+  int kind = 0, elem = 0, esize = 0;
+  char* base = nullptr;     // arena: cap_seg x stride bytes (+ tail pad)
+  uint64_t stride = 0;      // bytes between segments
+  // bitset CSR mirrors (one pair per segment)
+  std::vector<uint64_t*> bs_offsets;
+  std::vector<void*> bs_values;
+  std::vector<uint64_t> bs_nvalues;
+};
+struct VhSegStat {          // order keys as produced by seg_minmax_kernel
+  uint64_t lo = ~0ull, hi = 0;
+};
+struct vh_table {
+  std::vector<VhColumn> cols;
+  uint64_t segment_rows = 0;
+  uint64_t padded_rows = 0;
+  uint32_t cap_seg = 0;
+  uint32_t nseg = 0;
+  std::vector<uint64_t> seg_rows;               // last synced row count
+  std::vector<std::vector<VhSegStat>> stats;    // [col][seg]
+  // per-query device scratch (grow-only) and pinned staging
+  char* scratch = nullptr; size_t scratch_bytes = 0;
+  uint32_t* h_segrows = nullptr; size_t h_segrows_cap = 0;
+  unsigned long long* h_counters = nullptr;     // pinned, 8 words
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::mutex mu;
+  uint64_t device_bytes = 0;
+};
+
+static bool is_dim(int kind) { return kind <= VH_DIM_BOOLEAN; }
+static bool is_bitset_elem(int e) { return e == VH_BITSET32 || e == VH_BITSET64; }
+
+static int table_grow(vh_table* t, uint32_t need_seg) {
+  if (need_seg <= t->cap_seg) return VH_OK;
+  uint32_t ncap = std::max<uint32_t>(need_seg, std::max<uint32_t>(4, t->cap_seg * 2));
+  for (auto& c : t->cols) {
+    if (is_bitset_elem(c.elem)) {
+      c.bs_offsets.resize(ncap, nullptr); c.bs_values.resize(ncap, nullptr); c.bs_nvalues.resize(ncap, 0);
+      continue;
+    }
+    char* nb = nullptr;
+    const size_t bytes = (size_t)ncap * c.stride + 256;
+    HIP_TRY(hipMalloc(&nb, bytes));
+    if (c.base && t->nseg) {
+      HIP_TRY(hipMemcpyAsync(nb, c.base, (size_t)t->nseg * c.stride, hipMemcpyDeviceToDevice, g_ctx.stream));
+      HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    }
+    if (c.base) { HIP_TRY(hipFree(c.base)); t->device_bytes -= (size_t)t->cap_seg * c.stride + 256; }
+    c.base = nb;
+    t->device_bytes += bytes;
+  }
+  t->cap_seg = ncap;
+  t->seg_rows.resize(ncap, 0);
+  for (auto& s : t->stats) s.resize(ncap);
+  return VH_OK;
+}
+
+extern "C" int vh_table_create(const vh_col_desc* cols, int32_t ncols, uint64_t segment_rows,
+                               uint32_t reserve_segments, vh_table** out) {
+  if (!g_ctx.inited) return vh_fail(VH_E_INVALID, "vh_init has not been called");
+  if (!cols || ncols <= 0 || !out || segment_rows == 0 || segment_rows > 0xFFFF0000ull)
+    return vh_fail(VH_E_INVALID, "vh_table_create: bad arguments");
+  vh_table* t = new vh_table();
+  t->segment_rows = segment_rows;
+  t->padded_rows = (segment_rows + 63) / 64 * 64;
+  t->cols.resize(ncols);
+  t->stats.resize(ncols);
+  for (int i = 0; i < ncols; ++i) {
+    VhColumn& c = t->cols[i];
+    c.kind = cols[i].kind; c.elem = cols[i].elem;
+    if (is_bitset_elem(c.elem)) { c.esize = 0; continue; }
+    c.esize = vh_elem_size(c.elem);
+    if (!c.esize) { delete t; return vh_fail(VH_E_INVALID, "column %d: bad element type %d", i, c.elem); }
+    c.stride = t->padded_rows * c.esize;
+  }
+  int rc = table_grow(t, std::max<uint32_t>(1, reserve_segments));
+  if (rc) { vh_table_destroy(t); return rc; }
+  (void)hipHostMalloc((void**)&t->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault);
+  for (auto& e : t->ev) (void)hipEventCreate(&e);
+  *out = t;
+  return VH_OK;
+}
+
+extern "C" void vh_table_destroy(vh_table* t) {
+  if (!t) return;
+  (void)hipStreamSynchronize(g_ctx.stream);
+  for (auto& c : t->cols) {
+    if (c.base) (void)hipFree(c.base);
+    for (auto p : c.bs_offsets) if (p) (void)hipFree(p);
+    for (auto p : c.bs_values) if (p) (void)hipFree(p);
+  }
+  if (t->scratch) (void)hipFree(t->scratch);
+  if (t->h_segrows) (void)hipHostFree(t->h_segrows);
+  if (t->h_counters) (void)hipHostFree(t->h_counters);
+  for (auto& e : t->ev) if (e) (void)hipEventDestroy(e);
+  delete t;
+}
+
+static int ensure_scratch(vh_table* t, size_t bytes) {
+  if (bytes <= t->scratch_bytes) return VH_OK;
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->scratch = nullptr; t->scratch_bytes = 0; }
+  size_t nb = std::max(bytes + bytes / 4, (size_t)1 << 20);
+  HIP_TRY(hipMalloc(&t->scratch, nb));
+  t->scratch_bytes = nb;
+  return VH_OK;
+}
+static int ensure_segrows(vh_table* t, size_t n) {
+  if (n <= t->h_segrows_cap) return VH_OK;
+  if (t->h_segrows) (void)hipHostFree(t->h_segrows);
+  size_t cap = std::max<size_t>(n * 2, 1024);
+  HIP_TRY(hipHostMalloc((void**)&t->h_segrows, cap * sizeof(uint32_t), hipHostMallocDefault));
+  t->h_segrows_cap = cap;
+  return VH_OK;
+}
+
+#define VH_ELEM_SWITCH(elem, CALL)                       \
+  switch (elem) {                                        \
+    case VH_U8: { typedef uint8_t T; CALL; } break;      \
+    case VH_U16: { typedef uint16_t T; CALL; } break;    \
+    case VH_U32: { typedef uint32_t T; CALL; } break;    \
+    case VH_U64: { typedef uint64_t T; CALL; } break;    \
+    case VH_I8: { typedef int8_t T; CALL; } break;       \
+    case VH_I16: { typedef int16_t T; CALL; } break;     \
+    case VH_I32: { typedef int32_t T; CALL; } break;     \
+    case VH_I64: { typedef int64_t T; CALL; } break;     \
+    case VH_F32: { typedef float T; CALL; } break;       \
+    default: { typedef double T; CALL; } break;          \
+  }
+
+// Refresh SegmentStats of dimension columns for segments [first, first+n).
+static int refresh_stats(vh_table* t, uint32_t first, uint32_t n) {
+  int ndim = 0;
+  for (auto& c : t->cols) ndim += is_dim(c.kind) && !is_bitset_elem(c.elem);
+  if (!ndim || !n) return VH_OK;
+  const size_t stat_bytes = (size_t)ndim * n * 2 * sizeof(unsigned long long);
+  const size_t rows_bytes = (size_t)n * sizeof(uint32_t);
+  int rc = ensure_scratch(t, stat_bytes + rows_bytes + 256);
+  if (rc) return rc;
+  rc = ensure_segrows(t, n);
+  if (rc) return rc;
+  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(t->scratch);
+  uint32_t* d_rows = reinterpret_cast<uint32_t*>(t->scratch + stat_bytes);
+  std::vector<unsigned long long> init((size_t)ndim * n * 2);
+  for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ull; init[i + 1] = 0; }
+  for (uint32_t s = 0; s < n; ++s) t->h_segrows[s] = (uint32_t)t->seg_rows[first + s];
+  HIP_TRY(hipMemcpyAsync(d_stats, init.data(), stat_bytes, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(d_rows, t->h_segrows, rows_bytes, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));  // init is a stack/heap buffer
+  int di = 0;
+  for (auto& c : t->cols) {
+    if (!is_dim(c.kind) || is_bitset_elem(c.elem)) continue;
+    dim3 grid((unsigned)std::min<uint64_t>(64, (t->segment_rows + 4095) / 4096), n);
+    unsigned long long* st = d_stats + (size_t)di * n * 2;
+    VH_ELEM_SWITCH(c.elem, (seg_minmax_kernel<T><<<grid, dim3(256), 0, g_ctx.stream>>>(
+                               reinterpret_cast<const T*>(c.base), c.stride / c.esize, d_rows, first, st)));
+    ++di;
+  }
+  HIP_TRY(hipGetLastError());
+  std::vector<unsigned long long> host((size_t)ndim * n * 2);
+  HIP_TRY(hipMemcpyAsync(host.data(), d_stats, stat_bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  di = 0;
+  for (size_t ci = 0; ci < t->cols.size(); ++ci) {
+    auto& c = t->cols[ci];
+    if (!is_dim(c.kind) || is_bitset_elem(c.elem)) continue;
+    for (uint32_t s = 0; s < n; ++s) {
+      t->stats[ci][first + s].lo = host[((size_t)di * n + s) * 2];
+      t->stats[ci][first + s].hi = host[((size_t)di * n + s) * 2 + 1];
+    }
+    ++di;
+  }
+  return VH_OK;
+}
+
+extern "C" int vh_segment_sync(vh_table* t, uint32_t seg, uint64_t nrows, const void* const* col_ptrs) {
+  if (!t || !col_ptrs) return vh_fail(VH_E_INVALID, "vh_segment_sync: null argument");
+  if (nrows > t->segment_rows) return vh_fail(VH_E_INVALID, "vh_segment_sync: nrows %llu > segment_rows", (unsigned long long)nrows);
+  std::lock_guard<std::mutex> lk(t->mu);
+  int rc = table_grow(t, seg + 1);
+  if (rc) return rc;
+  for (size_t i = 0; i < t->cols.size(); ++i) {
+    auto& c = t->cols[i];
+    if (is_bitset_elem(c.elem) || !col_ptrs[i] || !nrows) continue;
+    HIP_TRY(hipMemcpyAsync(c.base + (size_t)seg * c.stride, col_ptrs[i], (size_t)nrows * c.esize,
+                           hipMemcpyHostToDevice, g_ctx.stream));
+  }
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  t->seg_rows[seg] = nrows;
+  t->nseg = std::max(t->nseg, seg + 1);
+  return refresh_stats(t, seg, 1);
+}
+
+extern "C" int vh_segment_sync_bitset(vh_table* t, uint32_t seg, int32_t col, uint64_t nrows,
+                                      const uint64_t* offsets, const void* values) {
+  if (!t || col < 0 || (size_t)col >= t->cols.size() || !offsets) return vh_fail(VH_E_INVALID, "vh_segment_sync_bitset: bad argument");
+  auto& c = t->cols[col];
+  if (!is_bitset_elem(c.elem)) return vh_fail(VH_E_INVALID, "column %d is not a bitset column", col);
+  std::lock_guard<std::mutex> lk(t->mu);
+  int rc = table_grow(t, seg + 1);
+  if (rc) return rc;
+  if (c.bs_offsets[seg]) { HIP_TRY(hipFree(c.bs_offsets[seg])); c.bs_offsets[seg] = nullptr; }
+  if (c.bs_values[seg]) { HIP_TRY(hipFree(c.bs_values[seg])); c.bs_values[seg] = nullptr; }
+  const uint64_t nvals = offsets[nrows];
+  const size_t vsz = c.elem == VH_BITSET32 ? 4 : 8;
+  HIP_TRY(hipMalloc((void**)&c.bs_offsets[seg], (nrows + 1) * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void**)&c.bs_values[seg], std::max<size_t>(nvals * vsz, 8)));
+  HIP_TRY(hipMemcpy(c.bs_offsets[seg], offsets, (nrows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
+  if (nvals) HIP_TRY(hipMemcpy(c.bs_values[seg], values, nvals * vsz, hipMemcpyHostToDevice));
+  c.bs_nvalues[seg] = nvals;
+  t->nseg = std::max(t->nseg, seg + 1);
+  return VH_OK;
+}
+
+extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nseg, uint64_t rows_per_seg,
+                                   uint64_t row_base, const vh_gen_spec* specs, uint64_t seed) {
+  if (!t || !specs || !nseg) return vh_fail(VH_E_INVALID, "vh_segment_generate: bad argument");
+  if (rows_per_seg > t->segment_rows) return vh_fail(VH_E_INVALID, "rows_per_seg exceeds segment_rows");
+  std::lock_guard<std::mutex> lk(t->mu);
+  int rc = table_grow(t, seg_first + nseg);
+  if (rc) return rc;
+  for (size_t i = 0; i < t->cols.size(); ++i) {
+    auto& c = t->cols[i];
+    if (is_bitset_elem(c.elem)) return vh_fail(VH_E_UNSUPPORTED, "synthetic bitset columns are generated by the caller");
+    if (specs[i].mode == VH_GEN_UNIFORM && specs[i].mod == 0) return vh_fail(VH_E_INVALID, "column %zu: mod == 0", i);
+    const uint64_t colseed = seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull);
+    dim3 grid((unsigned)std::min<uint64_t>(256, (rows_per_seg + 255) / 256), nseg);
+    VH_ELEM_SWITCH(c.elem, (gen_kernel<T><<<grid, dim3(256), 0, g_ctx.stream>>>(
+                               reinterpret_cast<T*>(c.base + (size_t)seg_first * c.stride), c.stride / c.esize,
+                               rows_per_seg, row_base, specs[i], colseed)));
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  for (uint32_t s = 0; s < nseg; ++s) t->seg_rows[seg_first + s] = rows_per_seg;
+  t->nseg = std::max(t->nseg, seg_first + nseg);
+  // stats in batches so the staging buffers stay small
+  for (uint32_t s = 0; s < nseg; s += 256) {
+    rc = refresh_stats(t, seg_first + s, std::min<uint32_t>(256, nseg - s));
+    if (rc) return rc;
+  }
+  return VH_OK;
+}
+
+extern "C" int vh_segment_read(vh_table* t, uint32_t seg, int32_t col, uint64_t nrows, void* dst) {
+  if (!t || col < 0 || (size_t)col >= t->cols.size() || seg >= t->nseg || !dst) return vh_fail(VH_E_INVALID, "vh_segment_read: bad argument");
+  auto& c = t->cols[col];
+  if (is_bitset_elem(c.elem)) return vh_fail(VH_E_UNSUPPORTED, "vh_segment_read: bitset column");
+  HIP_TRY(hipMemcpy(dst, c.base + (size_t)seg * c.stride, (size_t)nrows * c.esize, hipMemcpyDeviceToHost));
+  return VH_OK;
+}
+
+extern "C" int vh_table_info(vh_table* t, uint32_t* nseg, uint64_t* segment_rows, uint64_t* device_bytes) {
+  if (!t) return vh_fail(VH_E_INVALID, "null table");
+  if (nseg) *nseg = t->nseg;
+  if (segment_rows) *segment_rows = t->segment_rows;
+  if (device_bytes) *device_bytes = t->device_bytes;
+  return VH_OK;
+}
+
+// ------------------------------------------------------- typed host helpers
+static uint64_t order_key_of_bits(int elem, uint64_t bits) {
+  switch (elem) {
+    case VH_U8: return (uint8_t)bits;
+    case VH_U16: return (uint16_t)bits;
+    case VH_U32: return (uint32_t)bits;
+    case VH_U64: return bits;
+    case VH_I8: return (uint64_t)(int64_t)(int8_t)bits ^ (1ull << 63);
+    case VH_I16: return (uint64_t)(int64_t)(int16_t)bits ^ (1ull << 63);
+    case VH_I32: return (uint64_t)(int64_t)(int32_t)bits ^ (1ull << 63);
+    case VH_I64: return bits ^ (1ull << 63);
+    case VH_F32: { uint32_t b = (uint32_t)bits; return (b & 0x80000000u) ? (uint32_t)~b : (b | 0x80000000u); }
+    default: return (bits & (1ull << 63)) ? ~bits : (bits | (1ull << 63));
+  }
+}
+static uint64_t bits_of_order_key(int elem, uint64_t k) {
+  switch (elem) {
+    case VH_U8: case VH_U16: case VH_U32: case VH_U64: return k;
+    case VH_I8: case VH_I16: case VH_I32: case VH_I64: return k ^ (1ull << 63);  // sign-extended 64-bit
+    case VH_F32: { uint32_t b = (uint32_t)k; return (b & 0x80000000u) ? (b & 0x7FFFFFFFu) : (uint32_t)~b; }
+    default: return (k & (1ull << 63)) ? (k & ~(1ull << 63)) : ~k;
+  }
+}
+// identities of SegmentStats (src/codegen/db/store.cc:171-186): dmax = cpp_min_value,
+// dmin = cpp_max_value — FLT_MIN / DBL_MIN (smallest positive) for floating dims.
+static uint64_t stat_min_identity_key(int elem) {  // dmin initial = type max
+  switch (elem) {
+    case VH_F32: { float f = FLT_MAX; uint32_t b; memcpy(&b, &f, 4); return order_key_of_bits(elem, b); }
+    case VH_F64: { double d = DBL_MAX; uint64_t b; memcpy(&b, &d, 8); return order_key_of_bits(elem, b); }
+    case VH_U8: return 0xFFull; case VH_U16: return 0xFFFFull; case VH_U32: return 0xFFFFFFFFull;
+    case VH_U64: return ~0ull;
+    case VH_I8: return order_key_of_bits(elem, (uint64_t)(int64_t)INT8_MAX);
+    case VH_I16: return order_key_of_bits(elem, (uint64_t)(int64_t)INT16_MAX);
+    case VH_I32: return order_key_of_bits(elem, (uint64_t)(int64_t)INT32_MAX);
+    default: return order_key_of_bits(elem, (uint64_t)INT64_MAX);
+  }
+}
+static uint64_t stat_max_identity_key(int elem) {  // dmax initial = cpp_min_value
+  switch (elem) {
+    case VH_F32: { float f = FLT_MIN; uint32_t b; memcpy(&b, &f, 4); return order_key_of_bits(elem, b); }
+    case VH_F64: { double d = DBL_MIN; uint64_t b; memcpy(&b, &d, 8); return order_key_of_bits(elem, b); }
+    case VH_U8: case VH_U16: case VH_U32: case VH_U64: return 0;
+    case VH_I8: return order_key_of_bits(elem, (uint64_t)(int64_t)INT8_MIN);
+    case VH_I16: return order_key_of_bits(elem, (uint64_t)(int64_t)INT16_MIN);
+    case VH_I32: return order_key_of_bits(elem, (uint64_t)(int64_t)INT32_MIN);
+    default: return order_key_of_bits(elem, (uint64_t)INT64_MIN);
+  }
+}
+
+extern "C" int vh_segment_stats(vh_table* t, uint32_t seg, int32_t col, vh_anynum* min_out, vh_anynum* max_out) {
+  if (!t || col < 0 || (size_t)col >= t->cols.size() || seg >= t->nseg) return vh_fail(VH_E_INVALID, "vh_segment_stats: bad argument");
+  auto& c = t->cols[col];
+  if (!is_dim(c.kind)) return vh_fail(VH_E_INVALID, "column %d is not a dimension", col);
+  const VhSegStat& s = t->stats[col][seg];
+  const uint64_t lo = std::min(s.lo, stat_min_identity_key(c.elem));
+  const uint64_t hi = std::max(s.hi, stat_max_identity_key(c.elem));
+  if (min_out) { min_out->u64 = 0; uint64_t b = bits_of_order_key(c.elem, lo); memcpy(min_out, &b, c.esize); }
+  if (max_out) { max_out->u64 = 0; uint64_t b = bits_of_order_key(c.elem, hi); memcpy(max_out, &b, c.esize); }
+  return VH_OK;
+}
+
+// ------------------------------------------------------------------ results
+struct vh_result {
+  vh_table* table = nullptr;
+  vh_result_info info{};
+  int mode = 0;
+  bool finalized = false;
+  // device-side partial state
+  VhPlanDev plan{};
+  int nxcd = 1;
+  std::vector<int> metric_elem;        // output element type per metric
+  std::vector<int> group_elem;
+  uint64_t out_cap = 0;                // rows the output arrays can hold
+  unsigned long long* d_out_count = nullptr;
+  void* d_out_key[VH_MAX_GROUP] = {};
+  void* d_out_state[VH_MAX_METRIC] = {};
+  // host copies after finalize
+  std::vector<std::vector<char>> h_keys, h_states;
+};
+
+extern "C" void vh_result_free(vh_result* r) { delete r; }
+
+extern "C" int vh_result_get_info(vh_result* r, vh_result_info* info) {
+  if (!r || !info) return vh_fail(VH_E_INVALID, "null argument");
+  *info = r->info;
+  return VH_OK;
+}
+
+extern "C" int vh_result_copy(vh_result* r, void* const* key_cols, void* const* state_cols, uint64_t* hidden_count) {
+  if (!r || !r->finalized) return vh_fail(VH_E_INVALID, "result is not finalised");
+  for (size_t i = 0; i < r->h_keys.size(); ++i)
+    if (key_cols && key_cols[i] && !r->h_keys[i].empty()) memcpy(key_cols[i], r->h_keys[i].data(), r->h_keys[i].size());
+  const size_t nuser = r->info.nmetrics;
+  for (size_t j = 0; j < nuser; ++j)
+    if (state_cols && state_cols[j] && !r->h_states[j].empty()) memcpy(state_cols[j], r->h_states[j].data(), r->h_states[j].size());
+  if (hidden_count && r->info.has_hidden_count && !r->h_states[nuser].empty())
+    memcpy(hidden_count, r->h_states[nuser].data(), r->h_states[nuser].size());
+  return VH_OK;
+}
+
+// ----------------------------------------------------------------- planning
+static int sop_for(int kind, int elem, int* sop, uint64_t* ident) {
+  const bool sum = kind == VH_METRIC_SUM || kind == VH_METRIC_AVG || kind == VH_METRIC_COUNT || kind == VH_METRIC_HIDDEN_COUNT;
+  const bool mx = kind == VH_METRIC_MAX, mn = kind == VH_METRIC_MIN;
+  if (!sum && !mx && !mn) return -1;
+  *ident = 0;
+  auto fbits = [](float f) { uint32_t b; memcpy(&b, &f, 4); return (uint64_t)b; };
+  auto dbits = [](double d) { uint64_t b; memcpy(&b, &d, 8); return b; };
+  switch (elem) {
+    case VH_U8: case VH_U16: case VH_U32:
+      if (sum) *sop = SOP_ADD32;
+      else if (mx) { *sop = SOP_MAX_U32; *ident = 0; }
+      else { *sop = SOP_MIN_U32; *ident = elem == VH_U8 ? 0xFFu : elem == VH_U16 ? 0xFFFFu : 0xFFFFFFFFu; }
+      return 0;
+    case VH_I8: case VH_I16: case VH_I32:
+      if (sum) *sop = SOP_ADD32;
+      else if (mx) { *sop = SOP_MAX_I32; *ident = (uint32_t)(elem == VH_I8 ? INT8_MIN : elem == VH_I16 ? INT16_MIN : INT32_MIN); }
+      else { *sop = SOP_MIN_I32; *ident = (uint32_t)(elem == VH_I8 ? INT8_MAX : elem == VH_I16 ? INT16_MAX : INT32_MAX); }
+      return 0;
+    case VH_U64:
+      if (sum) *sop = SOP_ADD64;
+      else if (mx) { *sop = SOP_MAX_U64; *ident = 0; }
+      else { *sop = SOP_MIN_U64; *ident = ~0ull; }
+      return 0;
+    case VH_I64:
+      if (sum) *sop = SOP_ADD64;
+      else if (mx) { *sop = SOP_MAX_I64; *ident = (uint64_t)INT64_MIN; }
+      else { *sop = SOP_MIN_I64; *ident = (uint64_t)INT64_MAX; }
+      return 0;
+    case VH_F32:
+      if (sum) *sop = SOP_ADDF32;
+      else if (mx) { *sop = SOP_MAX_F32; *ident = fbits(FLT_MIN); }   // reference quirk: cpp_min_value
+      else { *sop = SOP_MIN_F32; *ident = fbits(FLT_MAX); }
+      return 0;
+    case VH_F64:
+      if (sum) *sop = SOP_ADDF64;
+      else if (mx) { *sop = SOP_MAX_F64; *ident = dbits(DBL_MIN); }
+      else { *sop = SOP_MIN_F64; *ident = dbits(DBL_MAX); }
+      return 0;
+    default: return -1;
+  }
+}
+
+// typed comparison a <= b of two literals/stats given as raw bits
+static bool typed_le(int elem, uint64_t a_bits, uint64_t b_bits) {
+  if (elem == VH_F32) { float a, b; uint32_t x = (uint32_t)a_bits, y = (uint32_t)b_bits; memcpy(&a, &x, 4); memcpy(&b, &y, 4); return a <= b; }
+  if (elem == VH_F64) { double a, b; memcpy(&a, &a_bits, 8); memcpy(&b, &b_bits, 8); return a <= b; }
+  return order_key_of_bits(elem, a_bits) <= order_key_of_bits(elem, b_bits);
+}
+
+// SegmentSkipBuilder (src/codegen/query/filter.cc:263-335) for one segment.
+static bool segment_passes(const vh_table* t, const vh_plan* p, uint32_t seg) {
+  if (p->nfilter <= 0) return true;
+  bool st[VH_MAX_PROG];
+  int sp = 0;
+  for (int i = 0; i < p->nfilter; ++i) {
+    const vh_filter_node& n = p->filter[i];
+    switch (n.kind) {
+      case VH_F_TRUE: st[sp++] = true; break;
+      case VH_F_AND: { bool a = st[--sp]; for (int k = 1; k < n.count; ++k) a = a & st[--sp]; st[sp++] = a; } break;
+      case VH_F_OR: { bool a = st[--sp]; for (int k = 1; k < n.count; ++k) a = a | st[--sp]; st[sp++] = a; } break;
+      default: {
+        const VhColumn& c = t->cols[n.col];
+        bool r = true;
+        if (c.kind == VH_DIM_NUMERIC || c.kind == VH_DIM_TIME) {
+          const VhSegStat& s = t->stats[n.col][seg];
+          const uint64_t dmin = bits_of_order_key(c.elem, std::min(s.lo, stat_min_identity_key(c.elem)));
+          const uint64_t dmax = bits_of_order_key(c.elem, std::max(s.hi, stat_max_identity_key(c.elem)));
+          if (n.kind == VH_F_REL) {
+            const uint64_t v = p->lits[n.lit].u64;
+            switch (n.op) {
+              case VH_OP_EQ: r = typed_le(c.elem, dmin, v) & typed_le(c.elem, v, dmax); break;
+              case VH_OP_LT: case VH_OP_LE: r = typed_le(c.elem, dmin, v); break;
+              case VH_OP_GT: case VH_OP_GE: r = typed_le(c.elem, v, dmax); break;
+              default: r = true; break;
+            }
+          } else {  // IN and NOT IN alike (the reference does not look at equal())
+            r = false;
+            for (int k = 0; k < n.count; ++k) {
+              const uint64_t v = p->lits[n.lit + k].u64;
+              r = r | (typed_le(c.elem, dmin, v) & typed_le(c.elem, v, dmax));
+            }
+            if (n.count == 0) r = false;
+          }
+        }
+        st[sp++] = r;
+      } break;
+    }
+  }
+  return st[0];
+}
+
+struct ScratchPlan {
+  size_t off = 0;
+  size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; }
+};
+
+template <int MODE, int BLOCK>
+static void launch_scan(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s) {
+  if (xcd_private)
+    hipLaunchKernelGGL((scan_agg_kernel<MODE, BLOCK, __HIP_MEMORY_SCOPE_WORKGROUP>), dim3(grid), dim3(BLOCK), lds, s, P);
+  else
+    hipLaunchKernelGGL((scan_agg_kernel<MODE, BLOCK, __HIP_MEMORY_SCOPE_AGENT>), dim3(grid), dim3(BLOCK), lds, s, P);
+}
+
+static int fill_states(void* p, uint64_t n, int bytes, uint64_t ident, hipStream_t s) {
+  if (ident == 0) { HIP_TRY(hipMemsetAsync(p, 0, n * bytes, s)); return VH_OK; }
+  const int grid = (int)std::min<uint64_t>(2048, (n + 255) / 256);
+  if (bytes == 4) hipLaunchKernelGGL(fill_kernel<uint32_t>, dim3(grid), dim3(256), 0, s, (uint32_t*)p, n, (uint32_t)ident);
+  else hipLaunchKernelGGL(fill_kernel<uint64_t>, dim3(grid), dim3(256), 0, s, (uint64_t*)p, n, ident);
+  return VH_OK;
+}
+
+static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, uint64_t hash_capacity_override,
+                               bool force_hash) {
+  // ---------------- validate
+  if (p->nfilter > VH_MAX_PROG) return vh_fail(VH_E_UNSUPPORTED, "filter has %d nodes (max %d)", p->nfilter, VH_MAX_PROG);
+  if (p->nlits > VH_MAX_LITS) return vh_fail(VH_E_UNSUPPORTED, "filter has %d literals (max %d)", p->nlits, VH_MAX_LITS);
+  if (p->ngroups > VH_MAX_GROUP) return vh_fail(VH_E_UNSUPPORTED, "%d group columns (max %d)", p->ngroups, VH_MAX_GROUP);
+  if (p->nmetrics > VH_MAX_METRIC - 1) return vh_fail(VH_E_UNSUPPORTED, "%d metrics (max %d)", p->nmetrics, VH_MAX_METRIC - 1);
+  const uint32_t nseg = p->seg_rows ? p->nseg : t->nseg;
+  if (nseg > t->nseg) return vh_fail(VH_E_INVALID, "plan snapshots %u segments, table mirrors %u", nseg, t->nseg);
+  const int ncols = (int)t->cols.size();
+
+  vh_result* r = new vh_result();
+  r->table = t;
+  VhPlanDev& P = r->plan;
+  memset(&P, 0, sizeof(P));
+
+  // ---------------- column slots
+  int slot_of[256];
+  for (int i = 0; i < 256; ++i) slot_of[i] = -1;
+  uint64_t bytes_per_row = 0;
+  auto slot = [&](int col) -> int {
+    if (col < 0 || col >= ncols || col >= 256) return -1;
+    if (slot_of[col] >= 0) return slot_of[col];
+    if (P.nslots >= VH_MAX_SLOTS) return -1;
+    const VhColumn& c = t->cols[col];
+    if (is_bitset_elem(c.elem)) return -2;
+    slot_of[col] = P.nslots;
+    P.colbase[P.nslots] = c.base;
+    P.colstride[P.nslots] = c.stride;
+    bytes_per_row += c.esize;
+    return P.nslots++;
+  };
+
+  // ---------------- filter program (+ stack depth check)
+  int depth = 0, maxdepth = 0;
+  for (int i = 0; i < p->nfilter; ++i) {
+    const vh_filter_node& n = p->filter[i];
+    VhProgOp& o = P.prog[i];
+    o.kind = (uint8_t)n.kind; o.op = (uint8_t)n.op; o.count = (uint8_t)n.count;
+    if (n.kind == VH_F_REL || n.kind == VH_F_IN) {
+      const int s = slot(n.col);
+      if (s == -2) { delete r; return vh_fail(VH_E_UNSUPPORTED, "filter on a bitset metric (cardinality) is evaluated host-side"); }
+      if (s < 0) { delete r; return vh_fail(VH_E_INVALID, "filter node %d: bad column %d", i, n.col); }
+      const int cnt = n.kind == VH_F_REL ? 1 : n.count;
+      if (n.lit < 0 || n.lit + cnt > p->nlits || n.count > 255) { delete r; return vh_fail(VH_E_INVALID, "filter node %d: literal range", i); }
+      o.slot = (uint16_t)s; o.type = (uint8_t)t->cols[n.col].elem; o.lit = (uint16_t)n.lit;
+      ++depth;
+    } else if (n.kind == VH_F_TRUE) {
+      ++depth;
+    } else if (n.kind == VH_F_AND || n.kind == VH_F_OR) {
+      if (n.count < 1 || n.count > depth || n.count > 255) { delete r; return vh_fail(VH_E_INVALID, "filter node %d: operand count %d", i, n.count); }
+      depth -= n.count - 1;
+    } else { delete r; return vh_fail(VH_E_INVALID, "filter node %d: kind %d", i, n.kind); }
+    maxdepth = std::max(maxdepth, depth);
+  }
+  if (p->nfilter == 0) { P.prog[0].kind = VH_F_TRUE; P.nprog = 1; depth = 1; }
+  else P.nprog = p->nfilter;
+  if (depth != 1) { delete r; return vh_fail(VH_E_INVALID, "filter program leaves %d values on the stack", depth); }
+  if (maxdepth > VH_MAX_STACK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "filter needs stack depth %d (max %d)", maxdepth, VH_MAX_STACK); }
+  for (int i = 0; i < p->nlits; ++i) P.lits[i] = p->lits[i].u64;
+
+  // ---------------- segments: snapshot + skip
+  int rc = ensure_segrows(t, std::max<uint32_t>(nseg, 1));
+  if (rc) { delete r; return rc; }
+  uint64_t scanned_recs = 0, scanned_segments = 0, rows_to_scan = 0;
+  std::vector<uint32_t> live;
+  for (uint32_t s = 0; s < nseg; ++s) {
+    uint64_t rows = p->seg_rows ? p->seg_rows[s] : t->seg_rows[s];
+    if (rows > t->seg_rows[s]) { delete r; return vh_fail(VH_E_INVALID, "segment %u: snapshot %llu rows > mirrored %llu", s, (unsigned long long)rows, (unsigned long long)t->seg_rows[s]); }
+    scanned_recs += rows;
+    const bool keep = segment_passes(t, p, s);
+    if (keep) { ++scanned_segments; rows_to_scan += rows; if (rows) live.push_back(s); }
+    t->h_segrows[s] = keep ? (uint32_t)rows : 0u;
+  }
+  r->info.scanned_recs = scanned_recs;
+  r->info.scanned_segments = scanned_segments;
+
+  // ---------------- group columns
+  P.ngroup = p->ngroups;
+  bool dense_ok = !force_hash && !(p->flags & VH_PLAN_FORCE_HASH);
+  uint64_t G = 1;
+  int key_bits_total = 0;
+  for (int i = 0; i < p->ngroups; ++i) {
+    const vh_group_col& gc = p->groups[i];
+    const int s = slot(gc.col);
+    if (s < 0 || !is_dim(t->cols[gc.col].kind)) { delete r; return vh_fail(VH_E_INVALID, "group column %d: bad column %d", i, gc.col); }
+    const VhColumn& c = t->cols[gc.col];
+    VhGroupDev& g = P.g[i];
+    g.slot = (uint16_t)s; g.type = (uint8_t)c.elem;
+    g.gran = (uint8_t)(gc.granularity < 0 ? VH_T_NONE : gc.granularity);
+    g.nroll = (uint8_t)gc.nrollup; g.micro = (uint8_t)gc.micro;
+    if (gc.nrollup < 0 || gc.nrollup > VH_MAX_ROLLUP) { delete r; return vh_fail(VH_E_UNSUPPORTED, "group column %d: %d rollup rules", i, gc.nrollup); }
+    if (g.gran == VH_T_WEEK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "week granularity: the reference has no Truncator::trunc<WEEK> (src/util/time.h:57-89)"); }
+    for (int k = 0; k < gc.nrollup; ++k) {
+      if (gc.rollup_unit[k] == VH_T_WEEK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "week rollup granularity is not supported by the reference"); }
+      g.roll_unit[k] = (uint8_t)gc.rollup_unit[k]; g.roll_before[k] = gc.rollup_before[k];
+    }
+    const bool timey = g.gran != VH_T_NONE || g.nroll;
+    if (timey && c.kind != VH_DIM_TIME) { delete r; return vh_fail(VH_E_INVALID, "group column %d: truncation on a non-time dimension", i); }
+    r->group_elem.push_back(c.elem);
+    key_bits_total += c.esize * 8;
+    // dense digit range
+    uint64_t lo = 0, extent = 0;
+    if (c.elem == VH_F32 || c.elem == VH_F64 || timey) {
+      dense_ok = false;
+    } else if (gc.cardinality > 0 && (c.kind == VH_DIM_STRING || c.kind == VH_DIM_BOOLEAN)) {
+      lo = 0; extent = gc.cardinality;
+    } else {
+      uint64_t klo = ~0ull, khi = 0;
+      for (uint32_t sgi : live) { klo = std::min(klo, t->stats[gc.col][sgi].lo); khi = std::max(khi, t->stats[gc.col][sgi].hi); }
+      if (live.empty() || klo > khi) { lo = 0; extent = 1; }
+      else {
+        lo = bits_of_order_key(c.elem, klo);
+        const uint64_t span = khi - klo;
+        extent = span == ~0ull ? 0 : span + 1;
+        if (extent == 0) dense_ok = false;
+      }
+    }
+    g.lo = lo; g.extent = extent;
+    if (dense_ok) {
+      if (extent == 0 || G > (1ull << 40) / std::max<uint64_t>(extent, 1)) dense_ok = false;
+      else G *= extent;
+    }
+  }
+  const uint64_t dense_limit = std::max<uint64_t>(4096, std::min<uint64_t>(1ull << 24, rows_to_scan * 4));
+  if (G > dense_limit) dense_ok = false;
+  if (dense_ok) {
+    uint64_t stride = 1;
+    for (int i = p->ngroups - 1; i >= 0; --i) { P.g[i].stride = stride; stride *= P.g[i].extent; }
+  } else {
+    // pack key columns into u64 words, widest first within a word, never straddling
+    int word = 0, used = 0;
+    for (int i = 0; i < p->ngroups; ++i) {
+      const int bits = vh_elem_size(P.g[i].type) * 8;
+      if (used + bits > 64) { ++word; used = 0; }
+      P.g[i].key_word = (uint8_t)word; P.g[i].key_shift = (uint8_t)used;
+      used += bits;
+    }
+    P.key_words = p->ngroups ? word + 1 : 1;
+    if (P.key_words > VH_KEY_WORDS) { delete r; return vh_fail(VH_E_UNSUPPORTED, "group key of %d bits is too wide", key_bits_total); }
+  }
+
+  // ---------------- metrics
+  P.nmetric = p->nmetrics;
+  bool has_avg = false, has_count = false;
+  for (int j = 0; j < p->nmetrics; ++j) {
+    const int col = p->metrics[j];
+    if (col < 0 || col >= ncols || is_dim(t->cols[col].kind)) { delete r; return vh_fail(VH_E_INVALID, "metric %d: bad column %d", j, col); }
+    const VhColumn& c = t->cols[col];
+    if (c.kind == VH_METRIC_BITSET) { delete r; return vh_fail(VH_E_UNSUPPORTED, "bitset metrics are not on the GPU path yet"); }
+    const int s = slot(col);
+    if (s < 0) { delete r; return vh_fail(VH_E_UNSUPPORTED, "too many referenced columns"); }
+    int sop; uint64_t ident;
+    if (sop_for(c.kind, c.elem, &sop, &ident)) { delete r; return vh_fail(VH_E_INVALID, "metric %d: kind %d / elem %d", j, c.kind, c.elem); }
+    P.m[j].slot = (uint16_t)s; P.m[j].type = (uint8_t)c.elem; P.m[j].sop = (uint8_t)sop; P.m[j].ident = ident;
+    r->metric_elem.push_back(c.elem);
+    has_avg |= c.kind == VH_METRIC_AVG; has_count |= c.kind == VH_METRIC_COUNT;
+  }
+  if (has_avg && !has_count) {
+    // hidden uint64_t _count (src/codegen/query/scan.cc:239-241)
+    int hc = -1;
+    for (int c = 0; c < ncols; ++c) if (t->cols[c].kind == VH_METRIC_HIDDEN_COUNT) hc = c;
+    if (hc < 0) { delete r; return vh_fail(VH_E_INVALID, "AVG selected without COUNT but the table has no hidden count column"); }
+    const int s = slot(hc);
+    if (s < 0) { delete r; return vh_fail(VH_E_UNSUPPORTED, "too many referenced columns"); }
+    VhMetricDev& m = P.m[P.nmetric++];
+    m.slot = (uint16_t)s; m.type = VH_U64; m.sop = SOP_ADD64; m.ident = 0;
+    r->metric_elem.push_back(VH_U64);
+    r->info.has_hidden_count = 1;
+  }
+  r->info.ngroup_cols = p->ngroups;
+  r->info.nmetrics = p->nmetrics;
+  r->info.algorithmic_bytes = rows_to_scan * bytes_per_row;
+
+  // ---------------- choose the table organisation
+  size_t state_bytes_per_group = 1;  // presence byte
+  for (int j = 0; j < P.nmetric; ++j) state_bytes_per_group += vh_sop_bytes(P.m[j].sop);
+  int mode;
+  size_t lds_table = 0;
+  if (dense_ok) {
+    // LDS layout: [8-byte states][4-byte states][presence bytes], 16 B aligned
+    size_t off = 0;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int j = 0; j < P.nmetric; ++j) {
+        const int b = vh_sop_bytes(P.m[j].sop);
+        if ((pass == 0) != (b == 8)) continue;
+        P.m[j].lds_off = (uint32_t)off; off += G * b;
+      }
+    off = (off + 7) / 8 * 8;
+    P.lds_present_off = (uint32_t)off; off += G;
+    lds_table = (off + 15) / 16 * 16;
+    const size_t lds_budget = 40 * 1024;
+    mode = (lds_table <= lds_budget && !(p->flags & VH_PLAN_FORCE_GLOBAL)) ? VH_MODE_DENSE_LDS : VH_MODE_DENSE_GLOBAL;
+    P.G = G;
+    P.lds_bytes = (uint32_t)lds_table;
+  } else {
+    mode = VH_MODE_HASH;
+  }
+  r->mode = mode;
+  r->info.path = mode == VH_MODE_DENSE_LDS ? (p->ngroups ? VH_PATH_DENSE_LDS : VH_PATH_SCALAR)
+               : mode == VH_MODE_DENSE_GLOBAL ? VH_PATH_DENSE_GLOBAL : VH_PATH_HASH;
+
+  // per-XCD private copies only while they stay cache-sized
+  int nxcd = 1;
+  if (mode != VH_MODE_HASH && !(p->flags & VH_PLAN_NO_XCD_PRIVATE) && G * state_bytes_per_group * g_ctx.num_xcd <= (64ull << 20))
+    nxcd = g_ctx.num_xcd;
+  P.nxcd = nxcd; r->nxcd = nxcd;
+  P.xcd_stride = (G + 63) / 64 * 64;
+
+  uint64_t capacity = 0;
+  if (mode == VH_MODE_HASH) {
+    uint64_t want = hash_capacity_override ? hash_capacity_override
+                  : std::max<uint64_t>(p->groups_hint ? p->groups_hint * 2 : (1ull << 20), 1ull << 12);
+    const uint64_t cap_rows = std::max<uint64_t>(rows_to_scan * 2, 1ull << 12);
+    if (!hash_capacity_override) want = std::min(want, cap_rows);
+    capacity = 1; while (capacity < want) capacity <<= 1;
+    P.hmask = capacity - 1;
+    P.max_probe = (uint32_t)std::min<uint64_t>(capacity - 1, 2048);
+  }
+
+  // ---------------- work decomposition
+  const int BLOCK = mode == VH_MODE_DENSE_LDS ? 1024 : 256;
+  const uint32_t step = BLOCK * 16;
+  const uint64_t padded = (t->segment_rows + step - 1) / step * step;
+  uint32_t unit_rows = step;
+  const uint64_t want_units = (uint64_t)g_ctx.num_cu * (BLOCK == 1024 ? 2 : 8) * 4;
+  while (unit_rows * 2 <= 65536 && unit_rows * 2 <= padded &&
+         (uint64_t)nseg * ((padded + unit_rows * 2 - 1) / (unit_rows * 2)) >= want_units) unit_rows *= 2;
+  P.unit_rows = unit_rows;
+  P.units_per_seg = (uint32_t)((t->segment_rows + unit_rows - 1) / unit_rows);
+  P.nseg = nseg;
+  P.total_units = nseg * P.units_per_seg;
+
+  // ---------------- scratch layout
+  ScratchPlan sp;
+  const size_t o_counters = sp.take(8 * sizeof(unsigned long long));
+  const size_t o_segrows = sp.take(std::max<uint32_t>(nseg, 1) * sizeof(uint32_t));
+  size_t o_present = 0, o_hkeys = 0, o_htags = 0;
+  size_t o_state[VH_MAX_METRIC];
+  const uint64_t table_n = mode == VH_MODE_HASH ? capacity + 1 : P.xcd_stride * nxcd;
+  if (mode == VH_MODE_HASH) {
+    o_hkeys = sp.take(table_n * P.key_words * sizeof(uint64_t));
+    if (P.key_words > 1) o_htags = sp.take(table_n * sizeof(uint32_t));
+  } else {
+    o_present = sp.take(table_n);
+  }
+  for (int j = 0; j < P.nmetric; ++j) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop));
+  // outputs
+  r->out_cap = mode == VH_MODE_HASH ? capacity + 1 : G;
+  const size_t o_outcount = sp.take(sizeof(unsigned long long));
+  size_t o_okey[VH_MAX_GROUP], o_ostate[VH_MAX_METRIC];
+  for (int i = 0; i < P.ngroup; ++i) o_okey[i] = sp.take(r->out_cap * vh_elem_size(P.g[i].type));
+  for (int j = 0; j < P.nmetric; ++j) o_ostate[j] = sp.take(r->out_cap * vh_elem_size(r->metric_elem[j]));
+  rc = ensure_scratch(t, sp.off);
+  if (rc) { delete r; return rc; }
+  char* S = t->scratch;
+  P.counters = reinterpret_cast<unsigned long long*>(S + o_counters);
+  P.seg_rows = reinterpret_cast<const uint32_t*>(S + o_segrows);
+  if (mode == VH_MODE_HASH) {
+    P.hkeys = reinterpret_cast<uint64_t*>(S + o_hkeys);
+    P.htags = P.key_words > 1 ? reinterpret_cast<uint32_t*>(S + o_htags) : nullptr;
+  } else {
+    P.present = reinterpret_cast<uint8_t*>(S + o_present);
+  }
+  for (int j = 0; j < P.nmetric; ++j) P.m[j].state = S + o_state[j];
+  r->d_out_count = reinterpret_cast<unsigned long long*>(S + o_outcount);
+  for (int i = 0; i < P.ngroup; ++i) r->d_out_key[i] = S + o_okey[i];
+  for (int j = 0; j < P.nmetric; ++j) r->d_out_state[j] = S + o_ostate[j];
+
+  // ---------------- init + launch
+  hipStream_t st = g_ctx.stream;
+  HIP_TRY(hipEventRecord(t->ev[0], st));
+  HIP_TRY(hipMemsetAsync(P.counters, 0, 8 * sizeof(unsigned long long), st));
+  HIP_TRY(hipMemsetAsync(r->d_out_count, 0, sizeof(unsigned long long), st));
+  if (nseg) HIP_TRY(hipMemcpyAsync(S + o_segrows, t->h_segrows, nseg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  if (mode == VH_MODE_HASH) {
+    if (P.key_words == 1) HIP_TRY(hipMemsetAsync(P.hkeys, 0xFF, table_n * sizeof(uint64_t), st));
+    else HIP_TRY(hipMemsetAsync(P.htags, 0, table_n * sizeof(uint32_t), st));
+  } else {
+    HIP_TRY(hipMemsetAsync(P.present, 0, table_n, st));
+  }
+  for (int j = 0; j < P.nmetric; ++j) {
+    rc = fill_states(P.m[j].state, table_n, vh_sop_bytes(P.m[j].sop), P.m[j].ident, st);
+    if (rc) { delete r; return rc; }
+  }
+  const int blocks_per_cu = BLOCK == 1024 ? 2 : 8;
+  const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(P.total_units, (uint64_t)g_ctx.num_cu * blocks_per_cu));
+  const size_t qbytes = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint16_t);
+  HIP_TRY(hipEventRecord(t->ev[1], st));
+  if (P.total_units) {
+    if (mode == VH_MODE_DENSE_LDS) launch_scan<VH_MODE_DENSE_LDS, 1024>(P, grid, lds_table + qbytes, nxcd > 1, st);
+    else if (mode == VH_MODE_DENSE_GLOBAL) launch_scan<VH_MODE_DENSE_GLOBAL, 256>(P, grid, qbytes, nxcd > 1, st);
+    else launch_scan<VH_MODE_HASH, 256>(P, grid, qbytes, false, st);
+  }
+  HIP_TRY(hipEventRecord(t->ev[2], st));
+  HIP_TRY(hipGetLastError());
+  if (mode != VH_MODE_HASH && nxcd > 1) {
+    VhMergeArgs A{};
+    A.nmetric = P.nmetric; A.nxcd = nxcd; A.G = G; A.xcd_stride = P.xcd_stride; A.present = P.present;
+    for (int j = 0; j < P.nmetric; ++j) { A.state[j] = P.m[j].state; A.sop[j] = P.m[j].sop; }
+    hipLaunchKernelGGL(dense_merge_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, A);
+    HIP_TRY(hipGetLastError());
+  }
+  *out = r;
+  return VH_OK;
+}
+
+extern "C" int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs, int32_t max_bufs, int32_t* nbufs) {
+  if (!r || !bufs || !nbufs) return vh_fail(VH_E_INVALID, "null argument");
+  if (r->mode == VH_MODE_HASH) return vh_fail(VH_E_UNSUPPORTED, "hash-path partials are exchanged by key, not reduced in place");
+  const VhPlanDev& P = r->plan;
+  int n = 0;
+  if (max_bufs < P.nmetric + 1) return vh_fail(VH_E_INVALID, "need %d buffers", P.nmetric + 1);
+  bufs[n++] = vh_device_buffer{P.present, P.G, VH_U8, VH_RED_MAX};
+  for (int j = 0; j < P.nmetric; ++j) {
+    vh_device_buffer b{P.m[j].state, P.G, 0, VH_RED_SUM};
+    switch (P.m[j].sop) {
+      case SOP_ADD32: b.elem = VH_U32; break;
+      case SOP_ADD64: b.elem = VH_U64; break;
+      case SOP_ADDF32: b.elem = VH_F32; break;
+      case SOP_ADDF64: b.elem = VH_F64; break;
+      case SOP_MIN_I32: b.elem = VH_I32; b.reduce = VH_RED_MIN; break;
+      case SOP_MAX_I32: b.elem = VH_I32; b.reduce = VH_RED_MAX; break;
+      case SOP_MIN_U32: b.elem = VH_U32; b.reduce = VH_RED_MIN; break;
+      case SOP_MAX_U32: b.elem = VH_U32; b.reduce = VH_RED_MAX; break;
+      case SOP_MIN_I64: b.elem = VH_I64; b.reduce = VH_RED_MIN; break;
+      case SOP_MAX_I64: b.elem = VH_I64; b.reduce = VH_RED_MAX; break;
+      case SOP_MIN_U64: b.elem = VH_U64; b.reduce = VH_RED_MIN; break;
+      case SOP_MAX_U64: b.elem = VH_U64; b.reduce = VH_RED_MAX; break;
+      case SOP_MIN_F32: b.elem = VH_F32; b.reduce = VH_RED_MIN; break;
+      case SOP_MAX_F32: b.elem = VH_F32; b.reduce = VH_RED_MAX; break;
+      case SOP_MIN_F64: b.elem = VH_F64; b.reduce = VH_RED_MIN; break;
+      default: b.elem = VH_F64; b.reduce = VH_RED_MAX; break;
+    }
+    bufs[n++] = b;
+  }
+  *nbufs = n;
+  return VH_OK;
+}
+
+// returns VH_OK, or a positive "retry" request: 1 = grow hash table, 2 = fall back to hash
+static int result_finalize_locked(vh_result* r, int* retry) {
+  vh_table* t = r->table;
+  const VhPlanDev& P = r->plan;
+  hipStream_t st = g_ctx.stream;
+  *retry = 0;
+  VhEmitArgs A{};
+  A.mode = r->mode; A.ngroup = P.ngroup; A.nmetric = P.nmetric; A.key_words = P.key_words;
+  A.n = r->out_cap; A.present = P.present; A.hkeys = P.hkeys; A.htags = P.htags; A.counters = P.counters;
+  A.out_count = r->d_out_count;
+  for (int i = 0; i < P.ngroup; ++i) { A.g[i] = P.g[i]; A.out_key[i] = r->d_out_key[i]; }
+  for (int j = 0; j < P.nmetric; ++j) {
+    A.state[j] = P.m[j].state; A.out_state[j] = r->d_out_state[j]; A.sop[j] = P.m[j].sop; A.mtype[j] = (uint8_t)r->metric_elem[j];
+  }
+  hipLaunchKernelGGL(emit_groups_kernel, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(t->h_counters, P.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(t->h_counters + 4, r->d_out_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  const unsigned long long err = t->h_counters[2];
+  if (err & VH_ERR_HASH_FULL) { *retry = 1; return VH_OK; }
+  if (err & VH_ERR_RANGE) { *retry = 2; return VH_OK; }
+  const uint64_t ng = t->h_counters[4];
+  r->info.ngroups = ng;
+  r->info.passed_recs = t->h_counters[0];
+  r->h_keys.assign(P.ngroup, {});
+  r->h_states.assign(P.nmetric, {});
+  for (int i = 0; i < P.ngroup; ++i) {
+    r->h_keys[i].resize(ng * vh_elem_size(P.g[i].type));
+    if (ng) HIP_TRY(hipMemcpyAsync(r->h_keys[i].data(), r->d_out_key[i], r->h_keys[i].size(), hipMemcpyDeviceToHost, st));
+  }
+  for (int j = 0; j < P.nmetric; ++j) {
+    r->h_states[j].resize(ng * vh_elem_size(r->metric_elem[j]));
+    if (ng) HIP_TRY(hipMemcpyAsync(r->h_states[j].data(), r->d_out_state[j], r->h_states[j].size(), hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipEventRecord(t->ev[3], st));
+  HIP_TRY(hipStreamSynchronize(st));
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, t->ev[1], t->ev[2]); r->info.scan_kernel_ms = ms;
+  (void)hipEventElapsedTime(&ms, t->ev[0], t->ev[3]); r->info.total_ms = ms;
+  r->finalized = true;
+  return VH_OK;
+}
+
+extern "C" int vh_query_launch(vh_table* t, const vh_plan* plan, vh_result** out) {
+  if (!t || !plan || !out) return vh_fail(VH_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(t->mu);
+  return query_launch_locked(t, plan, out, 0, false);
+}
+
+extern "C" int vh_result_finalize(vh_result* r) {
+  if (!r) return vh_fail(VH_E_INVALID, "null result");
+  if (r->finalized) return VH_OK;
+  std::lock_guard<std::mutex> lk(r->table->mu);
+  int retry = 0;
+  int rc = result_finalize_locked(r, &retry);
+  if (rc) return rc;
+  if (retry) return vh_fail(VH_E_RANGE, "partial result needs a re-plan (code %d); use vh_query_agg", retry);
+  return VH_OK;
+}
+
+extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
+  if (!t || !plan || !out) return vh_fail(VH_E_INVALID, "null argument");
+  std::lock_guard<std::mutex> lk(t->mu);
+  uint64_t cap_override = 0;
+  bool force_hash = false;
+  for (uint32_t attempt = 0; attempt < 12; ++attempt) {
+    vh_result* r = nullptr;
+    int rc = query_launch_locked(t, plan, &r, cap_override, force_hash);
+    if (rc) return rc;
+    int retry = 0;
+    rc = result_finalize_locked(r, &retry);
+    if (rc) { delete r; return rc; }
+    if (!retry) { r->info.retries = attempt; *out = r; return VH_OK; }
+    if (retry == 1) cap_override = (r->plan.hmask + 1) * 4;   // table too small: regrow
+    else force_hash = true;                                    // a digit left its planned range
+    delete r;
+  }
+  return vh_fail(VH_E_NOMEM, "aggregate table kept overflowing");
+}
+
+extern "C" int vh_measure_read_bandwidth(uint64_t bytes, int32_t iters, double* bytes_per_sec) {
+  if (!g_ctx.inited || !bytes_per_sec || iters <= 0) return vh_fail(VH_E_INVALID, "bad argument");
+  bytes = bytes / 16 * 16;
+  char* buf = nullptr; unsigned long long* sink = nullptr;
+  HIP_TRY(hipMalloc(&buf, bytes));
+  HIP_TRY(hipMalloc(&sink, 8));
+  HIP_TRY(hipMemsetAsync(buf, 1, bytes, g_ctx.stream));
+  HIP_TRY(hipMemsetAsync(sink, 0, 8, g_ctx.stream));
+  hipEvent_t a, b;
+  HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
+  const int grid = g_ctx.num_cu * 8;
+  hipLaunchKernelGGL(read_bw_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const vh_u32x4*)buf, bytes / 16, sink);
+  HIP_TRY(hipEventRecord(a, g_ctx.stream));
+  for (int i = 0; i < iters; ++i)
+    hipLaunchKernelGGL(read_bw_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const vh_u32x4*)buf, bytes / 16, sink);
+  HIP_TRY(hipEventRecord(b, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, a, b));
+  *bytes_per_sec = (double)bytes * iters / (ms * 1e-3);
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  (void)hipFree(buf); (void)hipFree(sink);
+  return VH_OK;
+}

@@ -1,0 +1,257 @@
+"""Thin Python handle over the C-ABI (viyadb_amd.capi): a device-resident table mirror
+and the aggregate call.  Used by bench.py, the parity tests and the smoke test; the
+production host shim is the C++ one in viyadb_amd/host/ (same C-ABI underneath).
+
+Mirrors, in shape, what the reference's generated ``viya_query_agg`` consumes and
+produces (src/codegen/query/agg_query.cc:26-75): a table of SoA segments in, a set of
+(group key, metric state) rows + QueryStats counters out.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from .capi import VhError  # noqa: F401  (re-export)
+
+
+def init(device: int = 0, stream: Optional[int] = None) -> None:
+    lib = capi.load()
+    capi.check(lib.vh_init(device))
+    if stream is not None:
+        capi.check(lib.vh_set_stream(C.c_void_p(stream)))
+
+
+def set_stream(stream: Optional[int]) -> None:
+    capi.check(capi.load().vh_set_stream(C.c_void_p(stream) if stream else None))
+
+
+def anynum(elem: int, value) -> capi.AnyNum:
+    """Pack a literal the way db::AnyNum does: the column's own type in the low bytes."""
+    a = capi.AnyNum()
+    a.u64 = 0
+    raw = np.array([value]).astype(capi.ELEM_NP[elem]).tobytes()
+    C.memmove(C.byref(a), raw, len(raw))
+    return a
+
+
+@dataclass
+class GroupSpec:
+    col: int
+    granularity: int = capi.T_NONE
+    rollup: Sequence = ()          # [(unit, before_ts), ...] in the reference's rule order
+    micro: bool = False
+    cardinality: int = 0
+
+
+@dataclass
+class AggPlan:
+    """Postfix filter + group columns + metric columns (see include/viya_hip.h)."""
+    filter: Sequence = ()          # ("rel", col, op, value) | ("in", col, equal, [values]) | ("and"|"or", n) | ("true",)
+    groups: Sequence[GroupSpec] = ()
+    metrics: Sequence[int] = ()
+    seg_rows: Optional[Sequence[int]] = None
+    flags: int = 0
+    groups_hint: int = 0
+
+
+@dataclass
+class AggResult:
+    keys: List[np.ndarray]
+    states: List[np.ndarray]
+    hidden_count: Optional[np.ndarray]
+    ngroups: int
+    scanned_recs: int
+    scanned_segments: int
+    passed_recs: int
+    path: str
+    scan_kernel_ms: float
+    total_ms: float
+    algorithmic_bytes: int
+    retries: int
+
+
+class DeviceTable:
+    """vh_table: the HBM mirror of a db::Table's segment store."""
+
+    def __init__(self, cols: Sequence, segment_rows: int, reserve_segments: int = 1):
+        """cols: [(kind, elem), ...] in table order (dimensions, metrics[, hidden count])."""
+        self.lib = capi.load()
+        self.cols = [(int(k), int(e)) for k, e in cols]
+        self.segment_rows = int(segment_rows)
+        arr = (capi.ColDesc * len(self.cols))(*[capi.ColDesc(k, e) for k, e in self.cols])
+        h = C.c_void_p()
+        capi.check(self.lib.vh_table_create(arr, len(self.cols), self.segment_rows, int(reserve_segments), C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self.lib.vh_table_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- data in
+    def sync_segment(self, seg: int, columns: Sequence[Optional[np.ndarray]], nrows: Optional[int] = None):
+        ptrs = (C.c_void_p * len(self.cols))()
+        keep = []
+        n = nrows
+        for i, a in enumerate(columns):
+            if a is None or self.cols[i][1] >= capi.BITSET32:
+                ptrs[i] = None
+                continue
+            a = np.ascontiguousarray(a, dtype=capi.ELEM_NP[self.cols[i][1]])
+            keep.append(a)
+            ptrs[i] = a.ctypes.data
+            if n is None:
+                n = len(a)
+        capi.check(self.lib.vh_segment_sync(self.handle, seg, int(n or 0), ptrs))
+
+    def sync_bitset(self, seg: int, col: int, offsets: np.ndarray, values: np.ndarray):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        vdt = np.uint32 if self.cols[col][1] == capi.BITSET32 else np.uint64
+        values = np.ascontiguousarray(values, dtype=vdt)
+        capi.check(self.lib.vh_segment_sync_bitset(self.handle, seg, col, len(offsets) - 1,
+                                                   offsets.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                   values.ctypes.data if len(values) else None))
+
+    def generate(self, seg_first: int, nseg: int, rows_per_seg: int, row_base: int, specs: Sequence, seed: int):
+        """specs: per column (mode, mod, add, scale)."""
+        arr = (capi.GenSpec * len(self.cols))()
+        for i, (mode, mod, add, scale) in enumerate(specs):
+            arr[i] = capi.GenSpec(int(mode), 0, int(mod), int(add), float(scale))
+        capi.check(self.lib.vh_segment_generate(self.handle, seg_first, nseg, rows_per_seg, row_base, arr, seed))
+
+    def read_column(self, seg: int, col: int, nrows: int) -> np.ndarray:
+        out = np.empty(nrows, dtype=capi.ELEM_NP[self.cols[col][1]])
+        capi.check(self.lib.vh_segment_read(self.handle, seg, col, nrows, out.ctypes.data))
+        return out
+
+    def info(self):
+        nseg, srows, dbytes = C.c_uint32(), C.c_uint64(), C.c_uint64()
+        capi.check(self.lib.vh_table_info(self.handle, C.byref(nseg), C.byref(srows), C.byref(dbytes)))
+        return nseg.value, srows.value, dbytes.value
+
+    def segment_stats(self, seg: int, col: int):
+        lo, hi = capi.AnyNum(), capi.AnyNum()
+        capi.check(self.lib.vh_segment_stats(self.handle, seg, col, C.byref(lo), C.byref(hi)))
+        dt = np.dtype(capi.ELEM_NP[self.cols[col][1]])
+        f = lambda a: np.frombuffer(bytes(a), dtype=dt, count=1)[0]
+        return f(lo), f(hi)
+
+    # ---- the hot path
+    def _build_plan(self, plan: AggPlan):
+        keep = []
+        nodes, lits = [], []
+        for f in plan.filter:
+            k = f[0]
+            if k == "true":
+                nodes.append(capi.FilterNode(capi.F_TRUE, 0, 0, 0, 0, 0))
+            elif k == "rel":
+                _, col, op, val = f
+                nodes.append(capi.FilterNode(capi.F_REL, col, op, 1, len(lits), 0))
+                lits.append(val if isinstance(val, capi.AnyNum) else anynum(self.cols[col][1], val))
+            elif k == "in":
+                _, col, equal, vals = f
+                nodes.append(capi.FilterNode(capi.F_IN, col, 1 if equal else 0, len(vals), len(lits), 0))
+                for v in vals:
+                    lits.append(v if isinstance(v, capi.AnyNum) else anynum(self.cols[col][1], v))
+            elif k in ("and", "or"):
+                nodes.append(capi.FilterNode(capi.F_AND if k == "and" else capi.F_OR, 0, 0, int(f[1]), 0, 0))
+            else:
+                raise ValueError(f"unknown filter node {f!r}")
+        p = capi.Plan()
+        if nodes:
+            fa = (capi.FilterNode * len(nodes))(*nodes)
+            keep.append(fa)
+            p.filter = fa
+        p.nfilter = len(nodes)
+        if lits:
+            la = (capi.AnyNum * len(lits))(*lits)
+            keep.append(la)
+            p.lits = la
+        p.nlits = len(lits)
+        if plan.groups:
+            ga = (capi.GroupCol * len(plan.groups))()
+            for i, g in enumerate(plan.groups):
+                ga[i].col = g.col
+                ga[i].granularity = g.granularity
+                ga[i].nrollup = len(g.rollup)
+                for k, (unit, before) in enumerate(g.rollup):
+                    ga[i].rollup_unit[k] = int(unit)
+                    ga[i].rollup_before[k] = int(before)
+                ga[i].micro = 1 if g.micro else 0
+                ga[i].cardinality = int(g.cardinality)
+            keep.append(ga)
+            p.groups = ga
+        p.ngroups = len(plan.groups)
+        if plan.metrics:
+            ma = (C.c_int32 * len(plan.metrics))(*[int(m) for m in plan.metrics])
+            keep.append(ma)
+            p.metrics = ma
+        p.nmetrics = len(plan.metrics)
+        if plan.seg_rows is not None:
+            sa = (C.c_uint64 * max(1, len(plan.seg_rows)))(*[int(x) for x in plan.seg_rows])
+            keep.append(sa)
+            p.seg_rows = sa
+            p.nseg = len(plan.seg_rows)
+        p.flags = int(plan.flags)
+        p.groups_hint = int(plan.groups_hint)
+        return p, keep
+
+    def _collect(self, res, plan: AggPlan) -> AggResult:
+        info = capi.ResultInfo()
+        capi.check(self.lib.vh_result_get_info(res, C.byref(info)))
+        ng = info.ngroups
+        keys = [np.empty(ng, dtype=capi.ELEM_NP[self.cols[g.col][1]]) for g in plan.groups]
+        states = [np.empty(ng, dtype=capi.ELEM_NP[self.cols[m][1]]) for m in plan.metrics]
+        hidden = np.empty(ng, dtype=np.uint64) if info.has_hidden_count else None
+        kp = (C.c_void_p * max(1, len(keys)))(*[k.ctypes.data for k in keys])
+        spp = (C.c_void_p * max(1, len(states)))(*[s.ctypes.data for s in states])
+        hp = hidden.ctypes.data_as(C.POINTER(C.c_uint64)) if hidden is not None else None
+        capi.check(self.lib.vh_result_copy(res, kp, spp, hp))
+        return AggResult(keys, states, hidden, int(ng), int(info.scanned_recs), int(info.scanned_segments),
+                         int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
+                         float(info.total_ms), int(info.algorithmic_bytes), int(info.retries))
+
+    def query_agg(self, plan: AggPlan) -> AggResult:
+        p, keep = self._build_plan(plan)
+        res = C.c_void_p()
+        capi.check(self.lib.vh_query_agg(self.handle, C.byref(p), C.byref(res)))
+        try:
+            return self._collect(res, plan)
+        finally:
+            self.lib.vh_result_free(res)
+
+    # ---- split form for multi-GPU: launch -> (caller reduces device buffers) -> finalize
+    def query_launch(self, plan: AggPlan):
+        p, keep = self._build_plan(plan)
+        res = C.c_void_p()
+        capi.check(self.lib.vh_query_launch(self.handle, C.byref(p), C.byref(res)))
+        return res
+
+    def device_buffers(self, res):
+        bufs = (capi.DeviceBuffer * 16)()
+        n = C.c_int32()
+        capi.check(self.lib.vh_result_device_buffers(res, bufs, 16, C.byref(n)))
+        return [(bufs[i].ptr, bufs[i].count, bufs[i].elem, bufs[i].reduce) for i in range(n.value)]
+
+    def finalize(self, res, plan: AggPlan) -> AggResult:
+        try:
+            capi.check(self.lib.vh_result_finalize(res))
+            return self._collect(res, plan)
+        finally:
+            self.lib.vh_result_free(res)
+
+
+def measure_read_bandwidth(nbytes: int = 4 << 30, iters: int = 5) -> float:
+    out = C.c_double()
+    capi.check(capi.load().vh_measure_read_bandwidth(int(nbytes), int(iters), C.byref(out)))
+    return out.value

@@ -1,0 +1,113 @@
+"""Synthetic workloads of SURVEY.md §8(d) / BASELINE.json `configs` — data definitions only.
+
+A workload is: a table shape (column kinds/element types + a generator spec per column,
+consumed by vh_segment_generate and, identically, by oracle/synth.py) and one aggregate
+query in two equivalent forms: the C-ABI plan (executor.AggPlan) and the reference's JSON
+descriptor (so the oracle can parse it like any other query).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Tuple
+
+from . import capi
+from .executor import AggPlan, GroupSpec
+
+U, ROWID, CONST = capi.GEN_UNIFORM, capi.GEN_ROWID, capi.GEN_CONST
+SEED = 42
+
+
+@dataclass
+class SynthColumn:
+    name: str
+    kind: int
+    elem: int
+    gen: Tuple[int, int, int, float]      # (mode, mod, add, scale)
+    json_type: str                        # the reference's column type string
+
+
+@dataclass
+class Workload:
+    name: str
+    description: str
+    columns: List[SynthColumn]
+    segment_rows: int
+    plan: AggPlan
+    query: dict                           # reference JSON descriptor of the same query
+    bytes_per_row_referenced: int         # B_ref per row
+    table_bytes_per_row: int
+
+    def table_json(self, name="synth"):
+        dims = [{"name": c.name, "type": c.json_type} for c in self.columns if c.kind < 16]
+        mets = [{"name": c.name, "type": c.json_type} for c in self.columns if c.kind >= 16]
+        return {"name": name, "segment_size": self.segment_rows, "dimensions": dims, "metrics": mets}
+
+    def col(self, name: str) -> int:
+        return [c.name for c in self.columns].index(name)
+
+
+def _dim(name, mod, add=0):
+    return SynthColumn(name, capi.DIM_NUMERIC, capi.U32, (U, mod, add, 1.0), "uint")
+
+
+def _rowid(name="id"):
+    return SynthColumn(name, capi.DIM_NUMERIC, capi.U32, (ROWID, 1, 0, 1.0), "uint")
+
+
+def c1(segment_rows=1_000_000) -> Workload:
+    """C1: 4 columns, SELECT SUM(v) WHERE k = 7 (plumbing case; the reference's own CPU-runnable shape)."""
+    cols = [_dim("k", 1000), _rowid(),
+            SynthColumn("v", capi.METRIC_SUM, capi.I64, (U, 1001, 0, 1.0), "long_sum"),
+            SynthColumn("count", capi.METRIC_COUNT, capi.U32, (CONST, 1, 1, 1.0), "count")]
+    plan = AggPlan(filter=[("rel", 0, capi.OP_EQ, 7)], groups=[], metrics=[2])
+    q = {"type": "aggregate", "table": "synth", "dimensions": [], "metrics": ["v"],
+         "filter": {"op": "eq", "column": "k", "value": "7"}}
+    return Workload("C1", "10M-row/4-col SUM(v) WHERE k=7", cols, segment_rows, plan, q, 4 + 8, 4 + 4 + 8 + 4)
+
+
+def c2(segment_rows=1_000_000) -> Workload:
+    """C2: 8 columns, range filter (50 %) + GROUP BY d0 (1 K groups), SUM m0, SUM m1."""
+    cols = [_dim("d0", 1000), _dim("d1", 1_000_000), _dim("d2", 100), _rowid(),
+            SynthColumn("m0", capi.METRIC_SUM, capi.I64, (U, 1001, 0, 1.0), "long_sum"),
+            SynthColumn("m1", capi.METRIC_SUM, capi.I32, (U, 101, 0, 1.0), "int_sum"),
+            SynthColumn("count", capi.METRIC_COUNT, capi.U32, (U, 3, 1, 1.0), "count"),
+            SynthColumn("m3", capi.METRIC_MAX, capi.U32, (U, 1_000_000, 0, 1.0), "uint_max")]
+    plan = AggPlan(filter=[("rel", 1, capi.OP_GE, 250000), ("rel", 1, capi.OP_LT, 750000), ("and", 2)],
+                   groups=[GroupSpec(0)], metrics=[4, 5])
+    q = {"type": "aggregate", "table": "synth", "dimensions": ["d0"], "metrics": ["m0", "m1"],
+         "filter": {"op": "and", "filters": [{"op": "ge", "column": "d1", "value": "250000"},
+                                             {"op": "lt", "column": "d1", "value": "750000"}]}}
+    return Workload("C2", "100M-row/8-col range filter + GROUP BY d0 (~1K groups), SUM m0, SUM m1",
+                    cols, segment_rows, plan, q, 4 + 4 + 8 + 4, 4 * 4 + 8 + 4 + 4 + 4)
+
+
+def c3(segment_rows=1_000_000) -> Workload:
+    """C3: 12 columns (60 B/row), 3-predicate conjunction (~5 %) + GROUP BY d0,d1 (100 K groups), SUM m0 + COUNT."""
+    cols = [_dim("d0", 1000), _dim("d1", 100), _dim("d2", 4), _dim("d3", 1000), _dim("d4", 1000),
+            _dim("d5", 1 << 20), _rowid(),
+            SynthColumn("m0", capi.METRIC_SUM, capi.I64, (U, 1001, 0, 1.0), "long_sum"),
+            SynthColumn("m1", capi.METRIC_MAX, capi.I64, (U, 1_000_000, 0, 1.0), "long_max"),
+            SynthColumn("count", capi.METRIC_COUNT, capi.U32, (U, 3, 1, 1.0), "count"),
+            SynthColumn("m3", capi.METRIC_SUM, capi.F64, (U, 10000, 0, 0.01), "double_sum"),
+            SynthColumn("m4", capi.METRIC_MIN, capi.U32, (U, 1_000_000, 0, 1.0), "uint_min")]
+    plan = AggPlan(filter=[("rel", 2, capi.OP_EQ, 1), ("rel", 3, capi.OP_LT, 447), ("rel", 4, capi.OP_GE, 553), ("and", 3)],
+                   groups=[GroupSpec(0), GroupSpec(1)], metrics=[7, 9], groups_hint=100_000)
+    q = {"type": "aggregate", "table": "synth", "dimensions": ["d0", "d1"], "metrics": ["m0", "count"],
+         "filter": {"op": "and", "filters": [{"op": "eq", "column": "d2", "value": "1"},
+                                             {"op": "lt", "column": "d3", "value": "447"},
+                                             {"op": "ge", "column": "d4", "value": "553"}]}}
+    return Workload("C3", "1B-row/12-col 3-predicate filter (~5%) + GROUP BY d0,d1 (~100K groups), SUM m0 + COUNT",
+                    cols, segment_rows, plan, q, 3 * 4 + 2 * 4 + 8 + 4, 7 * 4 + 8 + 8 + 4 + 8 + 4)
+
+
+WORKLOADS = {"C1": c1, "C2": c2, "C3": c3}
+
+
+def create_device_table(w: Workload, nseg: int, rows_per_seg=None, row_base=0, seed=SEED):
+    """Build the HBM mirror and fill it with the workload's synthetic rows."""
+    from .executor import DeviceTable
+    t = DeviceTable([(c.kind, c.elem) for c in w.columns], w.segment_rows, reserve_segments=nseg)
+    rps = w.segment_rows if rows_per_seg is None else rows_per_seg
+    if nseg:
+        t.generate(0, nseg, rps, row_base, [c.gen for c in w.columns], seed)
+    return t
