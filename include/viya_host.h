@@ -1,0 +1,45 @@
+/*
+ * viya_host.h — C facade over the C++ host shim (viyadb_amd/host/), for tests and bindings.
+ *
+ * The host shim itself is C++ and mirrors the reference's own interfaces
+ * (db::Database / db::Table / input::SimpleLoader / query::AggregateQuery / query::RowOutput,
+ * see viyadb_amd/host/viya_db.h and viya_query.h); this facade is the JSON-in / rows-out surface the
+ * reference exposes over HTTP (POST /tables, /load, /query — src/server/http/service.cc:46-162),
+ * flattened to C so that pytest can drive it through ctypes.
+ *
+ * Rows are returned as one malloc'ed buffer: fields separated by 0x1F, rows by 0x1E.
+ */
+#ifndef VIYA_HOST_H_
+#define VIYA_HOST_H_
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+#define VDB_API __attribute__((visibility("default")))
+
+typedef struct vdb vdb;
+
+enum { VDB_OK = 0, VDB_E_INVALID_ARGUMENT = 1, /* std::invalid_argument in the reference */
+       VDB_E_RUNTIME = 2 /* std::runtime_error / anything else */ };
+
+typedef struct vdb_stats {          /* query::QueryStats (src/query/stats.h:35-58) + GPU extras */
+  uint64_t scanned_segments, scanned_recs, aggregated_recs, output_recs, passed_recs;
+  double compile_time, whole_time, scan_kernel_ms, device_total_ms;
+  int32_t path, reserved;
+} vdb_stats;
+
+VDB_API int vdb_open(const char* config_json, int device, vdb** out);        /* db::Database(config) */
+VDB_API void vdb_close(vdb* db);
+VDB_API int vdb_create_table(vdb* db, const char* table_json);              /* Database::CreateTable */
+/* input::SimpleLoader::Load: rows in the facade's row encoding; now < 0 = wall clock
+ * (the reference's VIYA_TEST_ROLLUP_TS test hook, src/codegen/db/rollup.cc:47-49) */
+VDB_API int vdb_load(vdb* db, const char* table, const char* rows, size_t rows_len, int64_t now);
+VDB_API int vdb_query(vdb* db, const char* query_json, int64_t now, char** rows_out, size_t* rows_len, vdb_stats* stats);
+VDB_API int vdb_table_info(vdb* db, const char* table, uint64_t* nsegments, uint64_t* first_segment_size);
+VDB_API void vdb_free(char* p);
+VDB_API const char* vdb_last_error(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

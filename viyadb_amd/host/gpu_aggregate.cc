@@ -1,0 +1,404 @@
+// gpu_aggregate.cc — the host shim that stands where the JIT-compiled `viya_query_agg` stood.
+//
+// Reference flow being replaced (src/codegen/query/agg_query.cc:26-71 assembles it):
+//   ScanVisitor   (scan.cc:168-247)  : segment loop, predicate, agg_map[key].Update(m)   -> GPU, via the C-ABI
+//   PostAggVisitor(post_agg.cc:26-147): skip/limit window, HAVING, stringification       -> here, on the host
+//   SortVisitor   (sort.cc:24-75)    : string sort + skip/limit                          -> here, on the host
+//
+// The device mirror of the table is kept behind Table::gpu_mirror; a segment is re-synced when
+// its version counter moved since the last sync (upsert appends AND updates rows in place).
+#include <algorithm>
+#include <cstring>
+#include <ctime>
+#include <stdexcept>
+
+#include "../../include/viya_hip.h"
+#include "viya_query.h"
+
+namespace viya {
+namespace query {
+
+namespace {
+
+struct GpuMirror {
+  vh_table* handle = nullptr;
+  std::vector<uint64_t> synced_version;
+  ~GpuMirror() { if (handle) vh_table_destroy(handle); }
+};
+void free_mirror(void* p) { delete static_cast<GpuMirror*>(p); }
+
+void vh_check(int rc) {
+  if (rc != VH_OK) throw std::runtime_error(std::string("viya_hip: ") + vh_last_error());
+}
+
+int dim_kind(const db::Column* d) {
+  switch (d->dim_type()) {
+    case db::Column::DIM_STRING: return VH_DIM_STRING;
+    case db::Column::DIM_NUMERIC: return VH_DIM_NUMERIC;
+    case db::Column::DIM_TIME: return VH_DIM_TIME;
+    default: return VH_DIM_BOOLEAN;
+  }
+}
+int metric_kind(const db::Column* m) {
+  switch (m->agg_type()) {
+    case db::Column::MAX: return VH_METRIC_MAX;
+    case db::Column::MIN: return VH_METRIC_MIN;
+    case db::Column::SUM: return VH_METRIC_SUM;
+    case db::Column::AVG: return VH_METRIC_AVG;
+    case db::Column::COUNT: return VH_METRIC_COUNT;
+    default: return VH_METRIC_BITSET;
+  }
+}
+
+GpuMirror* ensure_mirror(db::Table& t) {
+  if (!t.gpu_mirror) {
+    static std::once_flag once;
+    std::call_once(once, [] {
+      const char* dev = getenv("VIYA_HIP_DEVICE");
+      vh_check(vh_init(dev ? atoi(dev) : 0));
+    });
+    std::vector<vh_col_desc> cols;
+    for (auto* d : t.dimensions()) cols.push_back({dim_kind(d), d->num_type().vh_elem()});
+    for (auto* m : t.metrics()) {
+      int elem = m->num_type().vh_elem();
+      if (m->agg_type() == db::Column::BITSET) elem = m->num_type().size() == 8 ? VH_BITSET64 : VH_BITSET32;
+      cols.push_back({metric_kind(m), elem});
+    }
+    if (t.has_hidden_count()) cols.push_back({VH_METRIC_HIDDEN_COUNT, VH_U64});
+    auto* mir = new GpuMirror();
+    vh_check(vh_table_create(cols.data(), (int32_t)cols.size(), t.segment_size(), 1, &mir->handle));
+    t.gpu_mirror = mir;
+    t.gpu_mirror_free = free_mirror;
+  }
+  return static_cast<GpuMirror*>(t.gpu_mirror);
+}
+
+// Bring the HBM mirror up to date with the host segments; returns the per-segment size() snapshot.
+std::vector<uint64_t> sync_mirror(db::Table& t, GpuMirror* mir) {
+  auto& segs = t.segments();
+  std::vector<uint64_t> rows(segs.size());
+  mir->synced_version.resize(segs.size(), ~0ull);
+  const size_t ncols = t.storage_columns();
+  for (size_t s = 0; s < segs.size(); ++s) {
+    db::Segment& seg = *segs[s];
+    rows[s] = seg.size();
+    if (mir->synced_version[s] == seg.version) continue;
+    std::vector<const void*> ptrs(ncols, nullptr);
+    for (size_t c = 0; c < ncols; ++c)
+      if (t.storage_elem_size(c)) ptrs[c] = seg.column(c);
+    vh_check(vh_segment_sync(mir->handle, (uint32_t)s, seg.size(), ptrs.data()));
+    for (auto* m : t.metrics()) {
+      if (m->agg_type() != db::Column::BITSET) continue;
+      const auto& sets = seg.bitsets(m->index());
+      std::vector<uint64_t> offsets(seg.size() + 1, 0);
+      for (size_t r = 0; r < seg.size(); ++r) offsets[r + 1] = offsets[r] + sets[r].size();
+      const bool wide = m->num_type().size() == 8;
+      std::vector<uint64_t> v64;
+      std::vector<uint32_t> v32;
+      for (size_t r = 0; r < seg.size(); ++r)
+        for (uint64_t id : sets[r]) { if (wide) v64.push_back(id); else v32.push_back((uint32_t)id); }
+      vh_check(vh_segment_sync_bitset(mir->handle, (uint32_t)s, (int32_t)m->storage_index, seg.size(), offsets.data(),
+                                      wide ? (const void*)v64.data() : (const void*)v32.data()));
+    }
+    mir->synced_version[s] = seg.version;
+  }
+  return rows;
+}
+
+// query::Filter -> postfix vh_filter_node program; literals are consumed in FilterArgsPacker order.
+class PlanFilterBuilder : public FilterVisitor {
+public:
+  PlanFilterBuilder(const db::Table& t, const std::vector<db::AnyNum>& args) : table(t), args_(args) {}
+  void Visit(const RelOpFilter* f) override {
+    const db::Column* c = table.column(f->column());
+    check_column(c);
+    nodes.push_back({VH_F_REL, (int32_t)c->storage_index, (int32_t)f->op(), 1, (int32_t)lits.size(), 0});
+    push_lit();
+  }
+  void Visit(const InFilter* f) override {
+    const db::Column* c = table.column(f->column());
+    check_column(c);
+    if (f->values().empty()) throw std::runtime_error("IN filter with no values does not compile in the reference");
+    nodes.push_back({VH_F_IN, (int32_t)c->storage_index, f->equal() ? 1 : 0, (int32_t)f->values().size(), (int32_t)lits.size(), 0});
+    for (size_t i = 0; i < f->values().size(); ++i) push_lit();
+  }
+  void Visit(const CompositeFilter* f) override {
+    for (auto& c : f->filters()) c->Accept(*this);
+    nodes.push_back({f->op() == CompositeFilter::AND ? VH_F_AND : VH_F_OR, 0, 0, (int32_t)f->filters().size(), 0, 0});
+  }
+  void Visit(const EmptyFilter*) override { nodes.push_back({VH_F_TRUE, 0, 0, 0, 0, 0}); }
+  const db::Table& table;
+  std::vector<vh_filter_node> nodes;
+  std::vector<vh_anynum> lits;
+
+private:
+  void check_column(const db::Column* c) {
+    if (c->type() == db::Column::METRIC && c->agg_type() == db::Column::BITSET)
+      throw std::runtime_error("filtering on a bitset metric's cardinality is not supported on the GPU path");
+  }
+  void push_lit() {
+    vh_anynum a;
+    a.u64 = args_.at(next_++).bits;
+    lits.push_back(a);
+  }
+  const std::vector<db::AnyNum>& args_;
+  size_t next_ = 0;
+};
+
+// One aggregated group as the post-aggregation sees it.
+struct Groups {
+  size_t n = 0;
+  std::vector<std::vector<char>> keys;    // per dimension_cols entry, n elements of the dim's type
+  std::vector<std::vector<char>> states;  // per metric_cols entry, n elements of the metric's type (bitset: u64)
+  std::vector<uint64_t> hidden;
+};
+
+// HAVING on aggregated tuples: same ComparisonBuilder semantics, applied to key / state values
+// (AVG compares the raw sum, bitsets compare the cardinality; post_agg.cc:77-83).
+class HavingEval : public FilterVisitor {
+public:
+  HavingEval(AggregateQuery& q, const Groups& g, const std::vector<db::AnyNum>& hargs) : q_(q), g_(g), hargs_(hargs) {}
+  bool Eval(const Filter* f, size_t row) {
+    row_ = row; next_ = 0; stack_.clear();
+    f->Accept(*this);
+    return stack_.back();
+  }
+  void Visit(const RelOpFilter* f) override { stack_.push_back(cmp(q_.table().column(f->column()), f->op(), hargs_.at(next_++))); }
+  void Visit(const InFilter* f) override {
+    const db::Column* c = q_.table().column(f->column());
+    bool r = !f->equal();
+    for (size_t i = 0; i < f->values().size(); ++i) {
+      const bool e = cmp(c, f->equal() ? RelOpFilter::EQUAL : RelOpFilter::NOT_EQUAL, hargs_.at(next_++));
+      r = f->equal() ? (r | e) : (r & e);
+    }
+    stack_.push_back(r);
+  }
+  void Visit(const CompositeFilter* f) override {
+    const size_t base = stack_.size();
+    for (auto& c : f->filters()) c->Accept(*this);
+    bool r = f->op() == CompositeFilter::AND;
+    for (size_t i = base; i < stack_.size(); ++i) r = f->op() == CompositeFilter::AND ? (r & stack_[i]) : (r | stack_[i]);
+    stack_.resize(base);
+    stack_.push_back(r);
+  }
+  void Visit(const EmptyFilter*) override { stack_.push_back(true); }
+
+private:
+  bool cmp(const db::Column* c, RelOpFilter::Operator op, db::AnyNum lit) {
+    db::AnyNum v;
+    db::Num t = c->num_type().type();
+    bool found = false;
+    if (c->type() == db::Column::DIMENSION) {
+      for (size_t k = 0; k < q_.dimension_cols().size(); ++k)
+        if (q_.dimension_cols()[k].dim() == c) { memcpy(&v.bits, &g_.keys[k][row_ * c->num_type().size()], c->num_type().size()); found = true; break; }
+    } else {
+      for (size_t k = 0; k < q_.metric_cols().size(); ++k)
+        if (q_.metric_cols()[k].metric() == c) {
+          if (c->agg_type() == db::Column::BITSET) { memcpy(&v.bits, &g_.states[k][row_ * 8], 8); t = c->num_type().size() == 8 ? db::Num::ULONG : db::Num::UINT; }
+          else memcpy(&v.bits, &g_.states[k][row_ * c->num_type().size()], c->num_type().size());
+          found = true;
+          break;
+        }
+    }
+    if (!found) throw std::invalid_argument("Column '" + c->name() + " is not selected");
+    const int r = db::compare_typed(t, v, lit);  // 2 = unordered (NaN)
+    switch (op) {
+      case RelOpFilter::EQUAL: return r == 0;
+      case RelOpFilter::NOT_EQUAL: return r != 0;
+      case RelOpFilter::LESS: return r == -1;
+      case RelOpFilter::LESS_EQUAL: return r == -1 || r == 0;
+      case RelOpFilter::GREATER: return r == 1;
+      default: return r == 1 || r == 0;
+    }
+  }
+  AggregateQuery& q_;
+  const Groups& g_;
+  const std::vector<db::AnyNum>& hargs_;
+  size_t row_ = 0, next_ = 0;
+  std::vector<bool> stack_;
+};
+
+// util::StringNumCmp (src/util/string.h:28-49)
+bool str_less(db::Column::SortType st, bool asc, const std::string& a, const std::string& b) {
+  if (st == db::Column::STRING) return asc ? a < b : a > b;
+  if (st == db::Column::INTEGER) {
+    if (a.size() != b.size()) return asc ? a.size() < b.size() : a.size() > b.size();
+    return asc ? a < b : a > b;
+  }
+  return asc ? std::stod(a) < std::stod(b) : std::stod(a) > std::stod(b);
+}
+
+std::string format_date(const std::string& fmt, uint32_t ts) {  // Format::date(const char*, uint32_t)
+  char buf[250];
+  std::tm tm;
+  time_t t = (time_t)ts;
+  gmtime_r(&t, &tm);
+  strftime(buf, sizeof(buf), fmt.c_str(), &tm);
+  return buf;
+}
+
+}  // namespace
+
+void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, std::vector<db::AnyNum> fargs,
+                  size_t skip, size_t limit, std::vector<db::AnyNum> hargs, int64_t now) {
+  db::Table& table = query.table();
+  Groups groups;
+  {
+    std::lock_guard<std::mutex> lk(table.mu);
+    GpuMirror* mir = ensure_mirror(table);
+    std::vector<uint64_t> seg_rows = sync_mirror(table, mir);  // segments_copy() + size() snapshot
+
+    PlanFilterBuilder fb(table, fargs);
+    query.filter()->Accept(fb);
+
+    std::vector<vh_group_col> gcols(query.dimension_cols().size());
+    for (size_t k = 0; k < gcols.size(); ++k) {
+      const DimOutputColumn& dc = query.dimension_cols()[k];
+      const db::Dimension* d = dc.dim();
+      vh_group_col& g = gcols[k];
+      memset(&g, 0, sizeof(g));
+      g.col = (int32_t)d->storage_index;
+      g.granularity = VH_T_NONE;
+      if (d->dim_type() == db::Column::DIM_TIME && (!d->rollup_rules().empty() || dc.has_granularity())) {
+        // RollupDefs + RollupReset + TimestampRollup (src/codegen/db/rollup.cc:25-95)
+        if (d->rollup_rules().size() > VH_MAX_ROLLUP) throw std::runtime_error("too many rollup rules");
+        const auto bounds = db::rollup_boundaries(*d, now);
+        g.nrollup = (int32_t)bounds.size();
+        for (size_t i = 0; i < bounds.size(); ++i) { g.rollup_unit[i] = d->rollup_rules()[i].granularity; g.rollup_before[i] = bounds[i]; }
+        if (dc.has_granularity()) g.granularity = dc.granularity();
+      }
+      g.micro = d->micro_precision() ? 1 : 0;
+      if (d->dim_type() == db::Column::DIM_STRING) g.cardinality = d->dict()->c2v().size();
+      else if (d->dim_type() == db::Column::DIM_BOOLEAN) g.cardinality = 2;
+    }
+    std::vector<int32_t> mcols;
+    for (auto& mc : query.metric_cols()) mcols.push_back((int32_t)mc.metric()->storage_index);
+
+    vh_plan plan;
+    memset(&plan, 0, sizeof(plan));
+    plan.filter = fb.nodes.data(); plan.nfilter = (int32_t)fb.nodes.size();
+    plan.lits = fb.lits.data(); plan.nlits = (int32_t)fb.lits.size();
+    plan.groups = gcols.data(); plan.ngroups = (int32_t)gcols.size();
+    plan.metrics = mcols.data(); plan.nmetrics = (int32_t)mcols.size();
+    plan.seg_rows = seg_rows.data(); plan.nseg = (uint32_t)seg_rows.size();
+    const char* force = getenv("VIYA_HIP_PLAN_FLAGS");
+    plan.flags = force ? (uint32_t)atoi(force) : 0;
+
+    vh_result* res = nullptr;
+    vh_check(vh_query_agg(mir->handle, &plan, &res));
+    std::unique_ptr<vh_result, void (*)(vh_result*)> guard(res, vh_result_free);
+    vh_result_info info;
+    vh_check(vh_result_get_info(res, &info));
+    stats.scanned_recs += info.scanned_recs;          // scan.cc:44
+    stats.scanned_segments += info.scanned_segments;  // scan.cc:51
+    stats.aggregated_recs = info.ngroups;             // scan.cc:246
+    stats.passed_recs = info.passed_recs;
+    stats.scan_kernel_ms = info.scan_kernel_ms;
+    stats.device_total_ms = info.total_ms;
+    stats.path = info.path;
+
+    groups.n = info.ngroups;
+    std::vector<void*> kp, sp;
+    for (auto& dc : query.dimension_cols()) { groups.keys.emplace_back(groups.n * dc.dim()->num_type().size()); kp.push_back(groups.keys.back().data()); }
+    for (auto& mc : query.metric_cols()) {
+      const int es = mc.metric()->agg_type() == db::Column::BITSET ? 8 : mc.metric()->num_type().size();
+      groups.states.emplace_back(groups.n * es);
+      sp.push_back(groups.states.back().data());
+    }
+    if (info.has_hidden_count) groups.hidden.resize(groups.n);
+    vh_check(vh_result_copy(res, kp.data(), sp.data(), info.has_hidden_count ? groups.hidden.data() : nullptr));
+  }
+
+  // ---- post aggregation (post_agg.cc:26-147)
+  output.Start();
+  typedef std::vector<std::string> Row;
+  const size_t ncols = query.dimension_cols().size() + query.metric_cols().size();
+  Row row(ncols);
+  const bool sorted = !query.sort_cols().empty();
+  skip = std::min(groups.n, skip);
+  limit = std::min(limit, groups.n - skip);
+  size_t it = 0, end = groups.n;
+  if (!sorted) {  // unsorted: the window is cut BEFORE the HAVING filter (reference behaviour)
+    it = skip;
+    if (limit > 0) end = it + limit;
+  }
+  std::vector<Row> post_agg;
+  if (query.header()) {
+    for (auto& dc : query.dimension_cols()) row[dc.index()] = dc.dim()->name();
+    for (auto& mc : query.metric_cols()) row[mc.index()] = mc.metric()->name();
+    output.Send(row);
+  }
+  int count_k = -1;
+  for (size_t k = 0; k < query.metric_cols().size(); ++k)
+    if (query.metric_cols()[k].metric()->agg_type() == db::Column::COUNT) { count_k = (int)k; break; }
+  HavingEval having(query, groups, hargs);
+  for (; it != end; ++it) {
+    if (query.having() != nullptr && !having.Eval(query.having(), it)) continue;
+    for (size_t k = 0; k < query.dimension_cols().size(); ++k) {
+      const DimOutputColumn& dc = query.dimension_cols()[k];
+      const db::Dimension* d = dc.dim();
+      const int es = d->num_type().size();
+      const char* p = &groups.keys[k][it * es];
+      if (d->dim_type() == db::Column::DIM_STRING) {
+        uint64_t code = 0;
+        memcpy(&code, p, es);
+        row[dc.index()] = d->dict()->c2v().at(code);
+      } else if (d->dim_type() == db::Column::DIM_TIME && !dc.format().empty()) {
+        uint64_t ts = 0;
+        memcpy(&ts, p, es);
+        row[dc.index()] = format_date(dc.format(), (uint32_t)ts);
+      } else if (d->dim_type() == db::Column::DIM_BOOLEAN) {
+        row[dc.index()] = *p ? "true" : "false";
+      } else {
+        row[dc.index()] = db::format_num(p, d->num_type().type());
+      }
+    }
+    for (size_t k = 0; k < query.metric_cols().size(); ++k) {
+      const MetricOutputColumn& mc = query.metric_cols()[k];
+      const db::Metric* m = mc.metric();
+      if (m->agg_type() == db::Column::BITSET) {
+        uint64_t card;
+        memcpy(&card, &groups.states[k][it * 8], 8);
+        row[mc.index()] = std::to_string(card);
+        continue;
+      }
+      const int es = m->num_type().size();
+      const char* p = &groups.states[k][it * es];
+      if (m->agg_type() == db::Column::AVG) {  // sum / (double) count   (post_agg.cc:126-128)
+        double cnt;
+        if (count_k >= 0) {
+          const db::Metric* cm = query.metric_cols()[count_k].metric();
+          cnt = db::load_as_double(&groups.states[count_k][it * cm->num_type().size()], cm->num_type().type());
+        } else {
+          cnt = (double)groups.hidden[it];
+        }
+        const double avg = db::load_as_double(p, m->num_type().type()) / cnt;
+        row[mc.index()] = db::format_num(reinterpret_cast<const char*>(&avg), db::Num::DOUBLE);
+      } else {
+        row[mc.index()] = db::format_num(p, m->num_type().type());
+      }
+    }
+    if (!sorted) { output.Send(row); ++stats.output_recs; }
+    else post_agg.push_back(row);
+  }
+  if (sorted) {  // SortVisitor (sort.cc:24-75): compares the STRINGS
+    const auto& sc = query.sort_cols();
+    std::stable_sort(post_agg.begin(), post_agg.end(), [&sc](const Row& a, const Row& b) {
+      for (size_t i = 0; i < sc.size(); ++i) {
+        const db::Column::SortType st = sc[i].col()->sort_type();
+        if (str_less(st, sc[i].ascending(), a[sc[i].index()], b[sc[i].index()])) return true;
+        if (i + 1 < sc.size() && str_less(st, sc[i].ascending(), b[sc[i].index()], a[sc[i].index()])) return false;
+        if (i + 1 == sc.size()) return false;
+      }
+      return false;
+    });
+    // the reference computes begin()+skip+limit from the PRE-having size and can overrun; clamp
+    const size_t lo = std::min(skip, post_agg.size());
+    const size_t hi = limit > 0 ? std::min(skip + limit, post_agg.size()) : post_agg.size();
+    for (size_t i = lo; i < hi; ++i) { output.Send(post_agg[i]); ++stats.output_recs; }
+  }
+  output.Flush();
+}
+
+}  // namespace query
+}  // namespace viya

@@ -1,0 +1,213 @@
+// viya_query.cc — filter factory, aggregate-query descriptor parsing, literal decoding, Database.
+#include "viya_query.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cstring>
+
+namespace viya {
+namespace query {
+
+void RelOpFilter::Accept(FilterVisitor& v) const { v.Visit(this); }
+void InFilter::Accept(FilterVisitor& v) const { v.Visit(this); }
+void CompositeFilter::Accept(FilterVisitor& v) const { v.Visit(this); }
+void EmptyFilter::Accept(FilterVisitor& v) const { v.Visit(this); }
+
+// NOT never survives: it flips and/or (De Morgan), negates relational operators and turns IN into
+// NOT IN; children of a composite are ordered by precedence (RelOp < AND < OR < IN).
+std::unique_ptr<Filter> FilterFactory::Create(const util::Config& config, bool negate) {
+  if (!config.exists("op")) return std::make_unique<EmptyFilter>();
+  const std::string op = config.str("op");
+  if (op == "and" || op == "or") {
+    std::vector<std::unique_ptr<Filter>> kids;
+    for (const util::Config& fc : config.sublist("filters")) kids.push_back(Create(fc, negate));
+    std::stable_sort(kids.begin(), kids.end(),
+                     [](const std::unique_ptr<Filter>& a, const std::unique_ptr<Filter>& b) { return a->precedence() < b->precedence(); });
+    const bool is_and = (op == "and") != negate;
+    return std::make_unique<CompositeFilter>(is_and ? CompositeFilter::AND : CompositeFilter::OR, std::move(kids));
+  }
+  if (op == "not") return Create(config.sub("filter"), !negate);
+  const std::string column = config.str("column");
+  if (op == "in") return std::make_unique<InFilter>(column, config.strlist("values"), !negate);
+  const std::string value = config.str("value");
+  static const char* names[6] = {"eq", "ne", "lt", "le", "gt", "ge"};
+  static const RelOpFilter::Operator negated[6] = {RelOpFilter::NOT_EQUAL, RelOpFilter::EQUAL, RelOpFilter::GREATER_EQUAL,
+                                                   RelOpFilter::GREATER, RelOpFilter::LESS_EQUAL, RelOpFilter::LESS};
+  for (int i = 0; i < 6; ++i)
+    if (op == names[i])
+      return std::make_unique<RelOpFilter>(negate ? negated[i] : static_cast<RelOpFilter::Operator>(i), column, value);
+  throw std::invalid_argument("Unsupported filter operataor: " + op);
+}
+
+namespace {
+
+class ColumnsCollector : public FilterVisitor {
+public:
+  void Visit(const RelOpFilter* f) override { cols.push_back(f->column()); }
+  void Visit(const InFilter* f) override { cols.push_back(f->column()); }
+  void Visit(const CompositeFilter* f) override { for (auto& c : f->filters()) c->Accept(*this); }
+  void Visit(const EmptyFilter*) override {}
+  std::vector<std::string> cols;
+};
+
+// ValueDecoder (src/codegen/query/filter.cc:154-204)
+db::AnyNum DecodeValue(const db::Column* col, const std::string& value) {
+  using db::Column;
+  if (col->type() == Column::DIMENSION) {
+    switch (col->dim_type()) {
+      case Column::DIM_STRING: return col->dict()->Decode(value);
+      case Column::DIM_BOOLEAN: return db::AnyNum::of<uint8_t>(value == "true");
+      case Column::DIM_TIME: {
+        if (std::all_of(value.begin(), value.end(), ::isdigit)) return col->num_type().Parse(value);
+        const uint64_t mult = col->micro_precision() ? 1000000L : 1L;
+        uint64_t ts = 0;
+        std::tm tm;
+        memset(&tm, 0, sizeof(tm));
+        const char* r = strptime(value.c_str(), "%Y-%m-%d %T", &tm);
+        if (r != nullptr && *r == '\0') {
+          ts = timegm(&tm) * mult;
+        } else if (r != nullptr && col->micro_precision() && *r == '.') {
+          ts = timegm(&tm) * mult + std::stoul(r);  // stoul(".xyz") throws, exactly as in the reference
+        } else {
+          memset(&tm, 0, sizeof(tm));
+          r = strptime(value.c_str(), "%Y-%m-%d", &tm);
+          if (r != nullptr && *r == '\0') ts = timegm(&tm) * mult;
+        }
+        if (ts == 0) throw std::invalid_argument("Unrecognized time format: " + value);
+        db::AnyNum a;
+        a.bits = col->micro_precision() ? ts : (uint64_t)(uint32_t)ts;
+        return a;
+      }
+      default: break;
+    }
+  }
+  const db::Num t = col->num_type().type();
+  if (t == db::Num::BYTE || t == db::Num::SHORT)
+    // the reference's generated code calls AnyNum::get_int8_t()/get_int16_t(), which do not exist
+    // (src/db/column.h:110-117 vs src/codegen/query/filter.cc:126-132): such a query fails to compile
+    throw std::runtime_error("filters on byte/short columns do not compile in the reference");
+  return col->num_type().Parse(value);
+}
+
+class ArgsPacker : public FilterVisitor {
+public:
+  explicit ArgsPacker(const db::Table& t) : table(t) {}
+  void Visit(const RelOpFilter* f) override { args.push_back(DecodeValue(table.column(f->column()), f->value())); }
+  void Visit(const InFilter* f) override {
+    const db::Column* c = table.column(f->column());
+    for (auto& v : f->values()) args.push_back(DecodeValue(c, v));
+  }
+  void Visit(const CompositeFilter* f) override { for (auto& c : f->filters()) c->Accept(*this); }
+  void Visit(const EmptyFilter*) override {}
+  const db::Table& table;
+  std::vector<db::AnyNum> args;
+};
+
+}  // namespace
+
+std::vector<db::AnyNum> PackFilterArgs(const db::Table& table, const Filter* filter) {
+  ArgsPacker p(table);
+  if (filter) filter->Accept(p);
+  return p.args;
+}
+
+DimOutputColumn::DimOutputColumn(const util::Config& config, const db::Dimension* dim, size_t index) : index_(index), dim_(dim) {
+  if (dim->dim_type() == db::Column::DIM_TIME) {
+    format_ = config.str("format", dim->format());
+    if (config.exists("granularity")) granularity_ = util::time_unit_by_name(config.str("granularity"));
+  }
+}
+
+AggregateQuery::AggregateQuery(const util::Config& config, db::Table& table)
+    : table_(table), header_(config.boolean("header", false)), skip_((size_t)config.num("skip", 0)), limit_((size_t)config.num("limit", 0)) {
+  FilterFactory ff;
+  filter_ = ff.Create(config.sub("filter", true));
+  size_t out_idx = 0;
+  if (config.exists("select")) {
+    for (const util::Config& sc : config.sublist("select")) {
+      const std::string name = sc.str("column");
+      std::vector<const db::Column*> cols;
+      if (name == "*") cols = table.columns();
+      else cols.push_back(table.column(name));
+      for (auto* c : cols) {
+        if (c->type() == db::Column::DIMENSION) dimension_cols_.emplace_back(sc, c, out_idx++);
+        else metric_cols_.emplace_back(c, out_idx++);
+      }
+    }
+  } else {
+    for (auto& n : config.strlist("dimensions")) dimension_cols_.emplace_back(table.dimension(n), out_idx++);
+    for (auto& n : config.strlist("metrics")) metric_cols_.emplace_back(table.metric(n), out_idx++);
+  }
+  if (config.exists("sort")) {
+    for (const util::Config& sc : config.sublist("sort")) {
+      const std::string name = sc.str("column");
+      const db::Column* col = table.column(name);
+      int idx = -1;
+      for (auto& d : dimension_cols_) if (d.dim() == col) { idx = (int)d.index(); break; }
+      if (idx == -1) for (auto& m : metric_cols_) if (m.metric() == col) { idx = (int)m.index(); break; }
+      if (idx == -1) throw std::invalid_argument("Sort column '" + name + "' is not selected");
+      sort_cols_.emplace_back(col, (size_t)idx, sc.boolean("ascending", false));
+    }
+  }
+  if (config.exists("having")) {
+    having_ = ff.Create(config.sub("having"));
+    ColumnsCollector cc;
+    having_->Accept(cc);
+    auto names = column_names();
+    for (auto& h : cc.cols)
+      if (std::find(names.begin(), names.end(), h) == names.end()) throw std::invalid_argument("Column '" + h + " is not selected");
+  }
+}
+
+std::vector<std::string> AggregateQuery::column_names() const {
+  std::vector<std::string> out;
+  for (auto& d : dimension_cols_) out.push_back(d.dim()->name());
+  for (auto& m : metric_cols_) out.push_back(m.metric()->name());
+  return out;
+}
+
+}  // namespace query
+
+namespace db {
+
+Database::Database(const util::Config& config, int device) {
+  (void)device;
+  if (config.exists("tables"))
+    for (const util::Config& tc : config.sublist("tables")) CreateTable(tc);
+}
+Database::~Database() {}
+
+void Database::CreateTable(const util::Config& tc) {
+  const std::string name = tc.str("name");
+  if (tables_.count(name)) throw std::runtime_error("Table already exists: " + name);
+  tables_[name] = std::make_unique<Table>(tc, dicts_);
+}
+
+Table* Database::GetTable(const std::string& name) {
+  auto it = tables_.find(name);
+  if (it == tables_.end()) throw std::invalid_argument("No such table: " + name);
+  return it->second.get();
+}
+
+void Database::Load(const std::string& table, const std::vector<std::vector<std::string>>& rows, int64_t now) {
+  GetTable(table)->Load(rows, nullptr, now);
+}
+
+// Database::Query -> QueryFactory::Create -> QueryRunner::Visit(AggregateQuery*)
+query::QueryStats Database::Query(const util::Config& conf, query::RowOutput& output, int64_t now) {
+  const std::string type = conf.str("type");
+  if (type != "aggregate") throw std::invalid_argument("unsupported query type: " + type + " (this build accelerates aggregate queries)");
+  Table* table = GetTable(conf.str("table"));
+  auto t0 = std::chrono::steady_clock::now();
+  query::AggregateQuery q(conf, *table);
+  query::QueryStats stats;
+  std::vector<AnyNum> fargs = query::PackFilterArgs(*table, q.filter());
+  std::vector<AnyNum> hargs = query::PackFilterArgs(*table, q.having());
+  stats.compile_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  query::GpuAggregate(q, output, stats, fargs, q.skip(), q.limit(), hargs, now);
+  stats.whole_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return stats;
+}
+
+}  // namespace db
+}  // namespace viya

@@ -1,0 +1,99 @@
+"""ctypes handle on the C++ host shim (include/viya_host.h): JSON in, rows of strings out —
+the same surface the reference's tests use (db::Database + SimpleLoader + MemoryRowOutput)."""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libviya_host.so")
+FS, RS = "\x1f", "\x1e"
+
+
+class Stats(C.Structure):
+    _fields_ = [("scanned_segments", C.c_uint64), ("scanned_recs", C.c_uint64), ("aggregated_recs", C.c_uint64),
+                ("output_recs", C.c_uint64), ("passed_recs", C.c_uint64), ("compile_time", C.c_double),
+                ("whole_time", C.c_double), ("scan_kernel_ms", C.c_double), ("device_total_ms", C.c_double),
+                ("path", C.c_int32), ("reserved", C.c_int32)]
+
+
+class HostError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+        self.reference_exception = "invalid_argument" if code == 1 else "runtime_error"
+
+
+SYMBOLS = ["vdb_open", "vdb_close", "vdb_create_table", "vdb_load", "vdb_query", "vdb_table_info", "vdb_free", "vdb_last_error"]
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HostError(2, LIB_PATH + " is missing: run __graft_entry__.build()")
+        from . import capi
+        capi.load()  # libviya_hip.so first (RTLD_GLOBAL)
+        lib = C.CDLL(LIB_PATH)
+        lib.vdb_last_error.restype = C.c_char_p
+        lib.vdb_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        lib.vdb_close.argtypes = [C.c_void_p]
+        lib.vdb_close.restype = None
+        lib.vdb_create_table.argtypes = [C.c_void_p, C.c_char_p]
+        lib.vdb_load.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int64]
+        lib.vdb_query.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Stats)]
+        lib.vdb_table_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        lib.vdb_free.argtypes = [C.c_void_p]
+        lib.vdb_free.restype = None
+        _lib = lib
+    return _lib
+
+
+def _check(rc):
+    if rc:
+        raise HostError(rc, load().vdb_last_error().decode("utf-8", "replace"))
+
+
+class Database:
+    def __init__(self, conf: dict, device: int = 0):
+        self.lib = load()
+        h = C.c_void_p()
+        _check(self.lib.vdb_open(json.dumps(conf).encode(), device, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.vdb_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def create_table(self, conf: dict):
+        _check(self.lib.vdb_create_table(self.h, json.dumps(conf).encode()))
+
+    def load(self, table: str, rows, now=None):
+        buf = "".join(FS.join(r) + FS + RS for r in rows).encode()
+        _check(self.lib.vdb_load(self.h, table.encode(), buf, len(buf), -1 if now is None else int(now)))
+
+    def query(self, q: dict, now=None):
+        out, n, st = C.c_void_p(), C.c_size_t(), Stats()
+        _check(self.lib.vdb_query(self.h, json.dumps(q).encode(), -1 if now is None else int(now), C.byref(out),
+                                  C.byref(n), C.byref(st)))
+        try:
+            raw = C.string_at(out, n.value).decode("utf-8", "replace")
+        finally:
+            self.lib.vdb_free(out)
+        rows = [r.split(FS)[:-1] for r in raw.split(RS)[:-1]]
+        stats = {k: getattr(st, k) for k, _ in Stats._fields_}
+        return rows, stats
+
+    def table_info(self, table: str):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(self.lib.vdb_table_info(self.h, table.encode(), C.byref(a), C.byref(b)))
+        return {"segments": a.value, "first_segment_size": b.value}
