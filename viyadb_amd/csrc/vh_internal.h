@@ -13,6 +13,7 @@
 #define VH_MAX_STACK 8    // predicate mask stack depth
 #define VH_MAX_XCD 8
 #define VH_KEY_WORDS 8    // widest group key: 8 x u64
+#define VH_MAX_BITSET 2   // bitset (count-distinct) metrics per query
 
 // Row geometry of one block step (see DESIGN.md "scan geometry"):
 // a wave covers 1024 consecutive rows per step as 4 sub-steps of 256 rows;
@@ -99,8 +100,16 @@ struct VhPlanDev {
   uint64_t hmask;            // capacity - 1
   uint32_t max_probe;
   uint32_t pad0;
+  // ---- bitset metrics (COUNT DISTINCT): per-row id sets mirrored as CSR per segment; the scan
+  // emits (metric|group, id) pairs, the distinct count is finished after the scan
+  int32_t nbitset;
+  int32_t bs_wide[VH_MAX_BITSET];                 // 1: uint64 ids, 0: uint32 ids
+  const uint64_t* const* bs_offs[VH_MAX_BITSET];  // [nseg] -> offsets[rows + 1]
+  const void* const* bs_vals[VH_MAX_BITSET];      // [nseg] -> ids
+  uint64_t* pairs;                                // 2 x pair_cap words
+  uint64_t pair_cap;
   // ---- counters: [0] passed rows, [1] new groups (hash), [2] error flags,
-  //                [3] reserved hash slot (key == sentinel) in use
+  //                [3] reserved hash slot (key == sentinel) in use, [4] emitted pairs
   unsigned long long* counters;
 };
 

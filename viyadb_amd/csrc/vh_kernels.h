@@ -437,6 +437,22 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
   } else if (MODE == VH_MODE_DENSE_GLOBAL) {
     if (active) P.present[xoff + gid] = 1;
   }
+  // bitset metrics: Metrics::Update does `_j |= metrics._j` (store.cc:153-155); here every id of the
+  // row's set is emitted as a (metric|group, id) pair and the union's cardinality is taken afterwards
+  for (int b = 0; b < P.nbitset; ++b) {
+    if (!active) continue;
+    const uint64_t* offs = P.bs_offs[b][seg];
+    const uint64_t o0 = offs[row], o1 = offs[row + 1];
+    if (o1 == o0) continue;
+    const unsigned long long at = atomicAdd(P.counters + 4, (unsigned long long)(o1 - o0));
+    const void* vals = P.bs_vals[b][seg];
+    for (uint64_t k = o0; k < o1; ++k) {
+      const uint64_t w = at + (k - o0);
+      if (w >= P.pair_cap) break;
+      P.pairs[2 * w] = ((uint64_t)b << 56) | gid;
+      P.pairs[2 * w + 1] = P.bs_wide[b] ? reinterpret_cast<const uint64_t*>(vals)[k] : reinterpret_cast<const uint32_t*>(vals)[k];
+    }
+  }
   for (int j = 0; j < P.nmetric; ++j) {
     const VhMetricDev& m = P.m[j];
     const char* base = P.colbase[m.slot] + (uint64_t)seg * P.colstride[m.slot];
@@ -631,6 +647,7 @@ struct VhEmitArgs {
   const uint64_t* hkeys; const uint32_t* htags;
   const unsigned long long* counters;
   unsigned long long* out_count;
+  uint64_t* out_gid;              // optional: table index of output row `pos` (bitset metrics)
   VhGroupDev g[VH_MAX_GROUP];
   void* out_key[VH_MAX_GROUP];
   const void* state[VH_MAX_METRIC];
@@ -667,6 +684,7 @@ __global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
   base = __shfl(base, 0);
   if (!have) return;
   const uint64_t pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+  if (A.out_gid) A.out_gid[pos] = i;
   for (int c = 0; c < A.ngroup; ++c) {
     const VhGroupDev& g = A.g[c];
     uint64_t v;

@@ -404,8 +404,11 @@ struct vh_result {
   // device-side partial state
   VhPlanDev plan{};
   int nxcd = 1;
-  std::vector<int> metric_elem;        // output element type per metric
+  std::vector<int> metric_elem;        // output element type per device metric (P.m order)
   std::vector<int> group_elem;
+  std::vector<int> user_metric;        // per plan metric: >= 0 index into P.m, < 0: -(bitset index + 1)
+  uint64_t* d_out_gid = nullptr;
+  std::vector<std::vector<uint64_t>> h_bitset_card;  // per bitset metric: cardinality per output row
   uint64_t out_cap = 0;                // rows the output arrays can hold
   unsigned long long* d_out_count = nullptr;
   void* d_out_key[VH_MAX_GROUP] = {};
@@ -426,11 +429,15 @@ extern "C" int vh_result_copy(vh_result* r, void* const* key_cols, void* const* 
   if (!r || !r->finalized) return vh_fail(VH_E_INVALID, "result is not finalised");
   for (size_t i = 0; i < r->h_keys.size(); ++i)
     if (key_cols && key_cols[i] && !r->h_keys[i].empty()) memcpy(key_cols[i], r->h_keys[i].data(), r->h_keys[i].size());
-  const size_t nuser = r->info.nmetrics;
-  for (size_t j = 0; j < nuser; ++j)
-    if (state_cols && state_cols[j] && !r->h_states[j].empty()) memcpy(state_cols[j], r->h_states[j].data(), r->h_states[j].size());
-  if (hidden_count && r->info.has_hidden_count && !r->h_states[nuser].empty())
-    memcpy(hidden_count, r->h_states[nuser].data(), r->h_states[nuser].size());
+  const size_t nuser = r->user_metric.size();
+  for (size_t j = 0; j < nuser; ++j) {
+    if (!state_cols || !state_cols[j]) continue;
+    const int u = r->user_metric[j];
+    if (u >= 0) { if (!r->h_states[u].empty()) memcpy(state_cols[j], r->h_states[u].data(), r->h_states[u].size()); }
+    else { const auto& c = r->h_bitset_card[-u - 1]; if (!c.empty()) memcpy(state_cols[j], c.data(), c.size() * sizeof(uint64_t)); }
+  }
+  if (hidden_count && r->info.has_hidden_count && !r->h_states.back().empty())
+    memcpy(hidden_count, r->h_states.back().data(), r->h_states.back().size());
   return VH_OK;
 }
 
@@ -690,21 +697,37 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   }
 
   // ---------------- metrics
-  P.nmetric = p->nmetrics;
+  P.nmetric = 0;
   bool has_avg = false, has_count = false;
+  int bitset_col[VH_MAX_BITSET];
+  uint64_t pair_cap = 0;
   for (int j = 0; j < p->nmetrics; ++j) {
     const int col = p->metrics[j];
     if (col < 0 || col >= ncols || is_dim(t->cols[col].kind)) { delete r; return vh_fail(VH_E_INVALID, "metric %d: bad column %d", j, col); }
     const VhColumn& c = t->cols[col];
-    if (c.kind == VH_METRIC_BITSET) { delete r; return vh_fail(VH_E_UNSUPPORTED, "bitset metrics are not on the GPU path yet"); }
+    if (c.kind == VH_METRIC_BITSET) {
+      if (P.nbitset >= VH_MAX_BITSET) { delete r; return vh_fail(VH_E_UNSUPPORTED, "more than %d bitset metrics in one query", VH_MAX_BITSET); }
+      for (uint32_t sgi : live) {
+        if (!c.bs_offsets[sgi]) { delete r; return vh_fail(VH_E_INVALID, "bitset column %d of segment %u was never synced", col, sgi); }
+        pair_cap += c.bs_nvalues[sgi];
+      }
+      bitset_col[P.nbitset] = col;
+      P.bs_wide[P.nbitset] = c.elem == VH_BITSET64;
+      r->user_metric.push_back(-(P.nbitset + 1));
+      ++P.nbitset;
+      continue;
+    }
     const int s = slot(col);
     if (s < 0) { delete r; return vh_fail(VH_E_UNSUPPORTED, "too many referenced columns"); }
     int sop; uint64_t ident;
     if (sop_for(c.kind, c.elem, &sop, &ident)) { delete r; return vh_fail(VH_E_INVALID, "metric %d: kind %d / elem %d", j, c.kind, c.elem); }
-    P.m[j].slot = (uint16_t)s; P.m[j].type = (uint8_t)c.elem; P.m[j].sop = (uint8_t)sop; P.m[j].ident = ident;
+    VhMetricDev& m = P.m[P.nmetric];
+    m.slot = (uint16_t)s; m.type = (uint8_t)c.elem; m.sop = (uint8_t)sop; m.ident = ident;
+    r->user_metric.push_back(P.nmetric++);
     r->metric_elem.push_back(c.elem);
     has_avg |= c.kind == VH_METRIC_AVG; has_count |= c.kind == VH_METRIC_COUNT;
   }
+  P.pair_cap = pair_cap;
   if (has_avg && !has_count) {
     // hidden uint64_t _count (src/codegen/query/scan.cc:239-241)
     int hc = -1;
@@ -796,6 +819,12 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   for (int j = 0; j < P.nmetric; ++j) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop));
   // outputs
   r->out_cap = mode == VH_MODE_HASH ? capacity + 1 : G;
+  size_t o_pairs = 0, o_outgid = 0, o_bsptr[VH_MAX_BITSET][2] = {};
+  if (P.nbitset) {
+    o_pairs = sp.take(std::max<uint64_t>(pair_cap, 1) * 16);
+    o_outgid = sp.take(r->out_cap * sizeof(uint64_t));
+    for (int b = 0; b < P.nbitset; ++b) { o_bsptr[b][0] = sp.take(std::max<uint32_t>(nseg, 1) * 8); o_bsptr[b][1] = sp.take(std::max<uint32_t>(nseg, 1) * 8); }
+  }
   const size_t o_outcount = sp.take(sizeof(unsigned long long));
   size_t o_okey[VH_MAX_GROUP], o_ostate[VH_MAX_METRIC];
   for (int i = 0; i < P.ngroup; ++i) o_okey[i] = sp.take(r->out_cap * vh_elem_size(P.g[i].type));
@@ -813,6 +842,19 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   }
   for (int j = 0; j < P.nmetric; ++j) P.m[j].state = S + o_state[j];
   r->d_out_count = reinterpret_cast<unsigned long long*>(S + o_outcount);
+  if (P.nbitset) {
+    P.pairs = reinterpret_cast<uint64_t*>(S + o_pairs);
+    r->d_out_gid = reinterpret_cast<uint64_t*>(S + o_outgid);
+    for (int b = 0; b < P.nbitset; ++b) {
+      const VhColumn& c = t->cols[bitset_col[b]];
+      P.bs_offs[b] = reinterpret_cast<const uint64_t* const*>(S + o_bsptr[b][0]);
+      P.bs_vals[b] = reinterpret_cast<const void* const*>(S + o_bsptr[b][1]);
+      if (nseg) {
+        HIP_TRY(hipMemcpy(S + o_bsptr[b][0], c.bs_offsets.data(), nseg * 8, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(S + o_bsptr[b][1], c.bs_values.data(), nseg * 8, hipMemcpyHostToDevice));
+      }
+    }
+  }
   for (int i = 0; i < P.ngroup; ++i) r->d_out_key[i] = S + o_okey[i];
   for (int j = 0; j < P.nmetric; ++j) r->d_out_state[j] = S + o_ostate[j];
 
@@ -897,6 +939,7 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   A.mode = r->mode; A.ngroup = P.ngroup; A.nmetric = P.nmetric; A.key_words = P.key_words;
   A.n = r->out_cap; A.present = P.present; A.hkeys = P.hkeys; A.htags = P.htags; A.counters = P.counters;
   A.out_count = r->d_out_count;
+  A.out_gid = r->d_out_gid;
   for (int i = 0; i < P.ngroup; ++i) { A.g[i] = P.g[i]; A.out_key[i] = r->d_out_key[i]; }
   for (int j = 0; j < P.nmetric; ++j) {
     A.state[j] = P.m[j].state; A.out_state[j] = r->d_out_state[j]; A.sop[j] = P.m[j].sop; A.mtype[j] = (uint8_t)r->metric_elem[j];
@@ -905,6 +948,7 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(t->h_counters, P.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipMemcpyAsync(t->h_counters + 4, r->d_out_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(t->h_counters + 5, P.counters + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   const unsigned long long err = t->h_counters[2];
   if (err & VH_ERR_HASH_FULL) { *retry = 1; return VH_OK; }
@@ -921,6 +965,32 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   for (int j = 0; j < P.nmetric; ++j) {
     r->h_states[j].resize(ng * vh_elem_size(r->metric_elem[j]));
     if (ng) HIP_TRY(hipMemcpyAsync(r->h_states[j].data(), r->d_out_state[j], r->h_states[j].size(), hipMemcpyDeviceToHost, st));
+  }
+  if (P.nbitset) {
+    // COUNT DISTINCT finish ("bitset metrics materialised host-side", north_star): the scan left
+    // (metric|group, id) pairs in HBM; sort + unique them and count per group.
+    const uint64_t npairs = std::min<uint64_t>(t->h_counters[5], P.pair_cap);
+    std::vector<uint64_t> pairs(npairs * 2), gids(ng);
+    if (npairs) HIP_TRY(hipMemcpyAsync(pairs.data(), P.pairs, npairs * 16, hipMemcpyDeviceToHost, st));
+    if (ng) HIP_TRY(hipMemcpyAsync(gids.data(), r->d_out_gid, ng * 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<std::pair<uint64_t, uint64_t>> pv(npairs);
+    for (uint64_t i = 0; i < npairs; ++i) pv[i] = {pairs[2 * i], pairs[2 * i + 1]};
+    std::sort(pv.begin(), pv.end());
+    pv.erase(std::unique(pv.begin(), pv.end()), pv.end());
+    std::vector<std::pair<uint64_t, uint64_t>> order(ng);  // (table index, output row)
+    for (uint64_t i = 0; i < ng; ++i) order[i] = {gids[i], i};
+    std::sort(order.begin(), order.end());
+    r->h_bitset_card.assign(P.nbitset, std::vector<uint64_t>(ng, 0));
+    for (size_t i = 0; i < pv.size();) {
+      size_t j = i;
+      while (j < pv.size() && pv[j].first == pv[i].first) ++j;
+      const int b = (int)(pv[i].first >> 56);
+      const uint64_t gid = pv[i].first & ((1ull << 56) - 1);
+      auto it = std::lower_bound(order.begin(), order.end(), std::make_pair(gid, (uint64_t)0));
+      if (it != order.end() && it->first == gid) r->h_bitset_card[b][it->second] = j - i;
+      i = j;
+    }
   }
   HIP_TRY(hipEventRecord(t->ev[3], st));
   HIP_TRY(hipStreamSynchronize(st));

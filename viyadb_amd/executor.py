@@ -211,7 +211,8 @@ class DeviceTable:
         capi.check(self.lib.vh_result_get_info(res, C.byref(info)))
         ng = info.ngroups
         keys = [np.empty(ng, dtype=capi.ELEM_NP[self.cols[g.col][1]]) for g in plan.groups]
-        states = [np.empty(ng, dtype=capi.ELEM_NP[self.cols[m][1]]) for m in plan.metrics]
+        states = [np.empty(ng, dtype=(np.uint64 if self.cols[m][1] >= capi.BITSET32 else capi.ELEM_NP[self.cols[m][1]]))
+                  for m in plan.metrics]
         hidden = np.empty(ng, dtype=np.uint64) if info.has_hidden_count else None
         kp = (C.c_void_p * max(1, len(keys)))(*[k.ctypes.data for k in keys])
         spp = (C.c_void_p * max(1, len(states)))(*[s.ctypes.data for s in states])
