@@ -29,18 +29,17 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
-class _DevArray:
-    """Zero-copy view of a device buffer for torch (RCCL collectives on the partial tables)."""
-
-    def __init__(self, ptr, count, typestr):
-        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(ptr), False),
-                                         "version": 2, "strides": None}
-
-
-def _torch_view(torch, ptr, count, elem):
-    # two's-complement adds are the same bits signed or unsigned: reduce u32/u64 sums as i32/i64
-    typestr = {0: "|u1", 2: "<i4", 3: "<i8", 6: "<i4", 7: "<i8", 8: "<f4", 9: "<f8"}[elem]
-    return torch.as_tensor(_DevArray(ptr, count, typestr), device="cuda")
+def measured_traffic(workload: str, rows_on_rank: int):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), scaled by rows.
+    PMC counters cannot be read inside a normal run; see profiles/*/c3_1gpu_pmc_hbm.json."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "%s_1gpu_pmc_hbm.json" % workload.lower()))):
+        best = f
+    if not best:
+        return None, None
+    d = json.load(open(best))
+    return d["B_meas_per_launch"] * rows_on_rank / d["rows"], os.path.relpath(best, ROOT)
 
 
 def cpu_baseline(w, sample_segments: int):
@@ -102,14 +101,13 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from viyadb_amd import capi, executor, synth
+    from viyadb_amd import capi, distributed, executor, synth
     executor.init(local_rank, stream=torch.cuda.current_stream().cuda_stream)
 
     w = synth.WORKLOADS[args.workload](segment_rows=args.segment_rows)
     total_segments = args.segments or {"C1": 10, "C2": 100, "C3": 1000}[args.workload]
     # contiguous block of segments per rank; global row ids are preserved
-    seg_lo = total_segments * rank // world
-    seg_hi = total_segments * (rank + 1) // world
+    seg_lo, seg_hi = distributed.shard_segments(total_segments, rank, world)
     my_segments = seg_hi - seg_lo
     t_gen = time.time()
     table = synth.create_device_table(w, my_segments, w.segment_rows, row_base=seg_lo * w.segment_rows)
@@ -118,21 +116,8 @@ def main():
     plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics,
                             flags=args.flags, groups_hint=w.plan.groups_hint)
 
-    red_op = None
-    if world > 1:
-        red_op = {capi.U8: dist.ReduceOp.MAX}
-
     def step():
-        if world == 1:
-            return table.query_agg(plan)
-        res = table.query_launch(plan)
-        for ptr, count, elem, reduce in table.device_buffers(res):
-            if reduce != 0 and elem in (capi.U32, capi.U64):
-                raise SystemExit("unsigned MIN/MAX partials need an order-preserving view; not in this workload")
-            tns = _torch_view(torch, ptr, count, elem)
-            op = {0: dist.ReduceOp.SUM, 1: dist.ReduceOp.MIN, 2: dist.ReduceOp.MAX}[reduce]
-            dist.reduce(tns, dst=0, op=op)
-        return table.finalize(res, plan)
+        return distributed.sharded_query(torch, dist, table, plan, world)
 
     def barrier():
         torch.cuda.synchronize()
@@ -160,15 +145,17 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rows / (elapsed / args.steps)
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-    algo_bytes = last.algorithmic_bytes  # per launch on this rank: rows x referenced bytes/row
-    achieved = algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
+    algo_bytes = last.algorithmic_bytes  # B_ref per launch on this rank: rows x referenced bytes/row
+    traffic, traffic_src = measured_traffic(args.workload, my_segments * w.segment_rows)
+    credited = min(algo_bytes, traffic) if traffic else algo_bytes  # never credit more than was moved
+    achieved = credited / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
 
     if rank == 0:
         out = {
             "metric": "rows/sec, filtered GROUP-BY SUM (+ achieved HBM GB/s in roofline)",
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong" if world > 1 or True else "weak",
+            "scaling": "strong",
             "vs_baseline": None, "dtype": "u32 predicates / int64+u32 integer atomics", "data": "synthetic",
             "config": {"workload": "%s: %s" % (w.name if world == 1 else w.name + " sharded (C4)", w.description),
                        "rows": total_rows, "segments": total_segments, "segment_rows": w.segment_rows,
@@ -177,11 +164,14 @@ def main():
                        "table_path": last.path, "parallelism": "segments sharded x%d, RCCL reduce to rank 0" % world if world > 1 else "1 GPU",
                        "generate_seconds": round(t_gen, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "scan_agg_kernel", "kernel_ms": avg_kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
-                         "note": "achieved = B_ref (rows x 32 B referenced, SURVEY 8d) / mean HIP-event kernel time on rank 0; "
-                                 "traffic (PMC) is in profiles/"},
+                         "bref_over_t_GBs": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0,
+                         "traffic_source": traffic_src,
+                         "note": "achieved = min(B_ref, B_meas) / mean HIP-event time of scan_agg_kernel on rank 0 "
+                                 "(SURVEY 8d); B_ref = rows x referenced bytes/row; B_meas = rocprofv3 FETCH_SIZE x2 "
+                                 "(gfx950 correction, MI355X_MICROARCH.md) from the committed PMC pass, scaled by rows"},
         }
         if world == 1 and not args.no_cpu:
             try:
