@@ -132,7 +132,8 @@ typedef struct vh_group_col {
 enum vh_plan_flags {
   VH_PLAN_FORCE_HASH = 1u << 0,   /* testing: never take the dense path     */
   VH_PLAN_FORCE_GLOBAL = 1u << 1, /* testing: dense table in HBM, not LDS   */
-  VH_PLAN_NO_XCD_PRIVATE = 1u << 2/* testing: one device-scope dense table  */
+  VH_PLAN_NO_XCD_PRIVATE = 1u << 2,/* testing: one device-scope dense table */
+  VH_PLAN_NO_FAST = 1u << 3       /* testing: always the generic scan kernel */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */
@@ -168,7 +169,7 @@ typedef struct vh_result_info {
   float total_ms;            /* HIP-event time launch .. results in host mem */
   uint64_t algorithmic_bytes;/* B_ref of SURVEY §8(d) for this query         */
   uint32_t retries;          /* hash-table regrows                           */
-  uint32_t reserved;
+  uint32_t reserved;         /* bit 0: the register-resident fast scan kernel ran */
 } vh_result_info;
 
 /* Device-side view of a partial (not yet finalised) result, for the caller to

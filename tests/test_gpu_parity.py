@@ -21,15 +21,17 @@ def test_workload_small(name):
     check_workload(w, nseg=5)
 
 
+@pytest.mark.parametrize("flags", [0, 8])
 @pytest.mark.parametrize("name", ["C1", "C2", "C3"])
-def test_workload_ragged(name):
+def test_workload_ragged(name, flags):
     """Segment size not a multiple of anything; last rows of every segment are beyond size()."""
     from viyadb_amd import synth
     w = synth.WORKLOADS[name](segment_rows=100_003)
-    check_workload(w, nseg=4, rows_per_seg=99_991)
+    check_workload(w, nseg=4, rows_per_seg=99_991, flags=flags)
 
 
-@pytest.mark.parametrize("flags,path", [(0, "dense_global"), (1, "hash"), (4, "dense_global"), (2, "dense_global")])
+@pytest.mark.parametrize("flags,path", [(0, "dense_global"), (1, "hash"), (4, "dense_global"), (2, "dense_global"),
+                                        (8, "dense_global"), (9, "hash"), (12, "dense_global")])
 def test_c3_table_organisations(flags, path):
     """Same query through: per-XCD private dense tables, the open-addressing hash table,
     one device-scope dense table."""
@@ -38,16 +40,21 @@ def test_c3_table_organisations(flags, path):
     check_workload(w, nseg=4, flags=flags, expect_path=path)
 
 
-@pytest.mark.parametrize("flags,path", [(0, "dense_lds"), (2, "dense_global"), (1, "hash")])
+@pytest.mark.parametrize("flags,path", [(0, "dense_lds"), (2, "dense_global"), (1, "hash"), (8, "dense_lds"), (10, "dense_global"),
+                                        (9, "hash")])
 def test_c2_table_organisations(flags, path):
     from viyadb_amd import synth
     w = synth.c2(segment_rows=250_000)
     check_workload(w, nseg=4, flags=flags, expect_path=path)
 
 
-def test_empty_table_and_tiny_segments():
+@pytest.mark.parametrize("flags", [0, 8])
+def test_empty_table_and_tiny_segments(flags):
     from viyadb_amd import synth
-    w = synth.c2(segment_rows=1000)
-    check_workload(w, nseg=1, rows_per_seg=1)
-    check_workload(w, nseg=3, rows_per_seg=63)
-    check_workload(w, nseg=2, rows_per_seg=1000)
+    for w in (synth.c2(segment_rows=1000), synth.c3(segment_rows=1000), synth.c1(segment_rows=1000)):
+        check_workload(w, nseg=1, rows_per_seg=1, flags=flags)
+        check_workload(w, nseg=3, rows_per_seg=63, flags=flags)
+        check_workload(w, nseg=2, rows_per_seg=1000, flags=flags)
+    w = synth.c3(segment_rows=70_001)
+    check_workload(w, nseg=3, rows_per_seg=70_001, flags=flags)   # several units per segment, ragged tail
+    check_workload(w, nseg=2, rows_per_seg=65_537, flags=flags)

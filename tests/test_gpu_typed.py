@@ -88,7 +88,23 @@ def F(op, col, val):
 def test_predicate_on_every_type(typed, t, op):
     tab, dt = typed
     val = "3.5" if t in ("float", "double") else "7"
-    run(tab, dt, {"dimensions": ["s8"], "metrics": ["count", "long_sum"], "filter": F(op, "d_" + t, val)})
+    q = {"dimensions": ["s8"], "metrics": ["count", "long_sum"], "filter": F(op, "d_" + t, val)}
+    r0, _ = run(tab, dt, q)
+    run(tab, dt, q, flags=8)
+
+
+def test_fast_kernel_is_taken_when_eligible(typed):
+    """4-byte predicate columns (u32 / i32 / f32 / time) take the register-resident kernel; others do not."""
+    tab, dt = typed
+    q4 = {"dimensions": ["s8"], "metrics": ["count"], "filter": {"op": "and", "filters": [
+        F("lt", "d_uint", "40"), F("gt", "d_int", "-40"), F("ne", "d_float", "1.5"), F("gt", "ts", "1000")]}}
+    for flags, want in ((0, True), (8, False)):
+        aq = vo.parse_query(tab, dict({"type": "aggregate", "table": "t"}, **q4))
+        res = dt.query_agg(plan_from_query(tab, aq, now=NOW, flags=flags))
+        compare(res, vo.scan_aggregate(aq, now=NOW), "fast=%s" % want)
+        assert res.fast == want
+    aq = vo.parse_query(tab, {"type": "aggregate", "table": "t", "dimensions": ["s8"], "metrics": ["count"], "filter": F("lt", "d_ulong", "5")})
+    assert dt.query_agg(plan_from_query(tab, aq, now=NOW)).fast is False
 
 
 @pytest.mark.parametrize("t", [x for x in TYPES if x not in ("byte", "short")])
@@ -99,7 +115,7 @@ def test_metric_predicates(typed, t):
 
 
 @pytest.mark.parametrize("t", TYPES)
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1, 8, 9])
 def test_all_aggregations_per_type(typed, t, flags):
     tab, dt = typed
     run(tab, dt, {"dimensions": ["s8", "flag"], "metrics": ["count"] + [f"{t}_{a}" for a in ("sum", "min", "max", "avg")],

@@ -23,7 +23,7 @@ def main():
     for name in args.workloads.split(","):
         w = synth.WORKLOADS[name]()
         t = synth.create_device_table(w, args.segments)
-        for flags, label in [(0, "default"), (4, "no_xcd_private"), (2, "force_global"), (6, "global_no_xcd"), (1, "hash")]:
+        for flags, label in [(0, "default"), (8, "generic_kernel"), (4, "no_xcd_private"), (2, "force_global"), (10, "generic_force_global"), (1, "hash"), (9, "generic_hash")]:
             plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=flags,
                                     groups_hint=w.plan.groups_hint)
             ms, tot = [], []
@@ -36,7 +36,7 @@ def main():
             print(json.dumps({"workload": name, "variant": label, "path": r.path, "kernel_ms": round(k, 4),
                               "total_ms": round(sorted(tot)[len(tot) // 2], 4), "rows_per_s": rows / (k * 1e-3),
                               "bref_GBs": r.algorithmic_bytes / (k * 1e-3) / 1e9, "groups": r.ngroups,
-                              "passed": r.passed_recs, "retries": r.retries}), flush=True)
+                              "passed": r.passed_recs, "retries": r.retries, "fast": r.fast}), flush=True)
         t.close()
 
 

@@ -27,7 +27,7 @@ OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE = range(6)
 T_YEAR, T_MONTH, T_WEEK, T_DAY, T_HOUR, T_MINUTE, T_SECOND, T_NONE = range(8)
 MAX_ROLLUP = 8
 # plan flags
-PLAN_FORCE_HASH, PLAN_FORCE_GLOBAL, PLAN_NO_XCD_PRIVATE = 1, 2, 4
+PLAN_FORCE_HASH, PLAN_FORCE_GLOBAL, PLAN_NO_XCD_PRIVATE, PLAN_NO_FAST = 1, 2, 4, 8
 # paths
 PATH_SCALAR, PATH_DENSE_LDS, PATH_DENSE_GLOBAL, PATH_HASH = range(4)
 PATH_NAMES = ["scalar", "dense_lds", "dense_global", "hash"]

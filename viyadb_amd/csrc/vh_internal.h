@@ -14,6 +14,8 @@
 #define VH_MAX_XCD 8
 #define VH_KEY_WORDS 8    // widest group key: 8 x u64
 #define VH_MAX_BITSET 2   // bitset (count-distinct) metrics per query
+#define VH_MAX_PRED 4     // fast path: distinct 4-byte predicate columns held in registers
+#define VH_FAST_COLS 4    // fast path: group / metric columns gathered up front
 
 // Row geometry of one block step (see DESIGN.md "scan geometry"):
 // a wave covers 1024 consecutive rows per step as 4 sub-steps of 256 rows;
@@ -39,7 +41,8 @@ struct VhProgOp {      // 8 bytes
   uint8_t type;        // vh_elem of the column
   uint8_t op;          // vh_relop / IN polarity
   uint8_t count;       // IN: literals; AND/OR: operands
-  uint16_t slot;       // referenced-column slot
+  uint8_t slot;        // referenced-column slot
+  uint8_t pslot;       // fast path: index among the distinct predicate columns
   uint16_t lit;        // first literal
 };
 
@@ -73,6 +76,10 @@ struct VhPlanDev {
   int32_t nslots;
   VhProgOp prog[VH_MAX_PROG];
   uint64_t lits[VH_MAX_LITS];
+  // ---- fast path (all predicate columns 4 bytes wide, <= VH_MAX_PRED of them): their slots
+  int32_t npred;
+  int32_t pad1;
+  uint8_t pred_slot[8];
   // ---- columns (slot -> arena)
   const char* colbase[VH_MAX_SLOTS];
   uint64_t colstride[VH_MAX_SLOTS];  // bytes between consecutive segments

@@ -582,6 +582,292 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
   }
 }
 
+
+// =====================================================================================
+// Fast variant: every predicate column is 4 bytes wide (u32 / i32 / f32 — dict codes, uint
+// dims, time) and at most VH_MAX_PRED distinct ones are referenced. Differences to the generic
+// kernel above, all aimed at keeping more HBM bytes in flight per wave:
+//   * all predicate columns of a step are loaded up front into registers (NP x 4 x 16 B per
+//     lane in flight at once) instead of one column per filter leaf;
+//   * the loads of the NEXT step are issued right after the current step's masks are computed,
+//     so they are in flight during the compaction and the survivor gathers / atomics;
+//   * a survivor's group and metric values are all gathered before the first dependent use.
+// Same results, same table organisations, same C-ABI.
+template <typename T>
+__device__ __forceinline__ uint32_t vh_cmp16_bits(const uint32_t (&bits)[16], uint64_t litbits, int op) {
+  T v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = __builtin_bit_cast(T, bits[i]);
+  return vh_cmp16<T>(v, vh_lit<T>(litbits), op);
+}
+
+__device__ __forceinline__ uint32_t vh_leaf_bits(const VhPlanDev& P, const VhProgOp o, const uint32_t (&bits)[16]) {
+  if (o.kind == VH_F_REL) {
+    switch (o.type) {
+      case VH_I32: return vh_cmp16_bits<int32_t>(bits, P.lits[o.lit], o.op);
+      case VH_F32: return vh_cmp16_bits<float>(bits, P.lits[o.lit], o.op);
+      default: return vh_cmp16_bits<uint32_t>(bits, P.lits[o.lit], o.op);
+    }
+  }
+  uint32_t m = o.op ? 0u : 0xFFFFu;
+  for (int i = 0; i < o.count; ++i) {
+    const uint64_t lit = P.lits[o.lit + i];
+    uint32_t e;
+    switch (o.type) {
+      case VH_I32: e = vh_cmp16_bits<int32_t>(bits, lit, o.op ? VH_OP_EQ : VH_OP_NE); break;
+      case VH_F32: e = vh_cmp16_bits<float>(bits, lit, o.op ? VH_OP_EQ : VH_OP_NE); break;
+      default: e = vh_cmp16_bits<uint32_t>(bits, lit, o.op ? VH_OP_EQ : VH_OP_NE); break;
+    }
+    if (o.op) m |= e; else m &= e;
+  }
+  return m;
+}
+
+template <int NP>
+__device__ __forceinline__ void vh_preload(const VhPlanDev& P, uint32_t seg, uint32_t row_l, uint32_t seg_rows,
+                                           uint32_t (&v)[NP][16]) {
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    const uint32_t* col = reinterpret_cast<const uint32_t*>(P.colbase[P.pred_slot[p]] + (uint64_t)seg * P.colstride[P.pred_slot[p]]);
+#pragma unroll
+    for (int k = 0; k < VH_SUBSTEPS; ++k) {
+      const uint32_t r = row_l + k * 256u;
+      if (r < seg_rows) {
+        vh_load4<uint32_t>(col + r, &v[p][k * 4]);
+      } else {
+        v[p][k * 4] = v[p][k * 4 + 1] = v[p][k * 4 + 2] = v[p][k * 4 + 3] = 0u;
+      }
+    }
+  }
+}
+
+template <int NP>
+__device__ __forceinline__ uint32_t vh_eval_filter_fast(const VhPlanDev& P, const uint32_t (&v)[NP][16], uint32_t row_l,
+                                                        uint32_t seg_rows) {
+  uint32_t st[VH_MAX_STACK];
+  int sp = 0;
+  for (int pc = 0; pc < P.nprog; ++pc) {
+    const VhProgOp o = P.prog[pc];
+    switch (o.kind) {
+      case VH_F_TRUE: st[sp++] = 0xFFFFu; break;
+      case VH_F_AND: {
+        uint32_t a = st[--sp];
+        for (int i = 1; i < o.count; ++i) a &= st[--sp];
+        st[sp++] = a;
+      } break;
+      case VH_F_OR: {
+        uint32_t a = st[--sp];
+        for (int i = 1; i < o.count; ++i) a |= st[--sp];
+        st[sp++] = a;
+      } break;
+      default: {
+        uint32_t m = 0;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          if (o.pslot == p) m = vh_leaf_bits(P, o, v[p]);
+        st[sp++] = m;
+      } break;
+    }
+  }
+  uint32_t m = st[0];
+  if (row_l + 3 * 256u + 4u > seg_rows) {
+#pragma unroll
+    for (int k = 0; k < VH_SUBSTEPS; ++k) {
+      const uint32_t r = row_l + k * 256u;
+      const uint32_t n = r >= seg_rows ? 0u : (seg_rows - r >= 4u ? 4u : seg_rows - r);
+      m &= ~(((0xFu << n) & 0xFu) << (k * 4));
+    }
+  }
+  return m;
+}
+
+template <int MODE, int SCOPE>
+__device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, char* lds,
+                                                uint64_t xoff, unsigned long long& nfresh) {
+  if (!active) row = 0;
+  uint64_t gv[VH_FAST_COLS], mv[VH_FAST_COLS];
+#pragma unroll
+  for (int i = 0; i < VH_FAST_COLS; ++i) {
+    gv[i] = 0;
+    if (i < P.ngroup) {
+      const VhGroupDev& g = P.g[i];
+      gv[i] = vh_load_bits(P.colbase[g.slot] + (uint64_t)seg * P.colstride[g.slot], g.type, row, MODE != VH_MODE_HASH);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VH_FAST_COLS; ++j) {
+    mv[j] = 0;
+    if (j < P.nmetric) {
+      const VhMetricDev& m = P.m[j];
+      mv[j] = vh_load_bits(P.colbase[m.slot] + (uint64_t)seg * P.colstride[m.slot], m.type, row, vh_sop_sext(m.sop));
+    }
+  }
+  uint64_t gid = 0;
+  uint64_t key[VH_KEY_WORDS];
+  if (MODE == VH_MODE_HASH) {
+#pragma unroll
+    for (int i = 0; i < VH_KEY_WORDS; ++i) key[i] = 0;
+  }
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < VH_FAST_COLS; ++i) {
+    if (i < P.ngroup) {
+      const VhGroupDev& g = P.g[i];
+      uint64_t v = gv[i];
+      if (g.gran != VH_T_NONE || g.nroll) v = vh_time_rollup(v, g);
+      if (MODE == VH_MODE_HASH) {
+        if (g.type == VH_F32 && (uint32_t)v == 0x80000000u) v = 0;
+        if (g.type == VH_F64 && v == 0x8000000000000000ull) v = 0;
+        key[g.key_word] |= v << g.key_shift;
+      } else {
+        const uint64_t d = v - g.lo;
+        bad |= d >= g.extent;
+        gid += d * g.stride;
+      }
+    }
+  }
+  if (MODE == VH_MODE_HASH) {
+    bool ok = true, fresh = false;
+    if (active) {
+      gid = P.key_words == 1 ? vh_hash_insert64(P, key[0], ok, fresh) : vh_hash_insert_wide(P, key, P.key_words, ok, fresh);
+    }
+    bad = !ok;
+    nfresh += __popcll(__ballot(active && fresh));
+    if (__ballot(active && bad)) {
+      if (active && bad) atomicOr(P.counters + 2, VH_ERR_HASH_FULL);
+    }
+  } else if (__ballot(active && bad)) {
+    if (active && bad) atomicOr(P.counters + 2, VH_ERR_RANGE);
+  }
+  active = active && !bad;
+  if (MODE == VH_MODE_DENSE_LDS) {
+    if (active) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[gid] = 1;
+  } else if (MODE == VH_MODE_DENSE_GLOBAL) {
+    if (active) P.present[xoff + gid] = 1;
+  }
+#pragma unroll
+  for (int j = 0; j < VH_FAST_COLS; ++j) {
+    if (j < P.nmetric && active) {
+      const VhMetricDev& m = P.m[j];
+      if (MODE == VH_MODE_DENSE_LDS) vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, gid, m.sop, mv[j]);
+      else if (MODE == VH_MODE_DENSE_GLOBAL) vh_state_update<SCOPE>(m.state, xoff + gid, m.sop, mv[j]);
+      else vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, gid, m.sop, mv[j]);
+    }
+  }
+}
+
+template <int MODE, int BLOCK, int SCOPE, int NP>
+__global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef VhScanCfg<BLOCK> C;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint16_t* q = reinterpret_cast<uint16_t*>(lds + (MODE == VH_MODE_DENSE_LDS ? P.lds_bytes : 0)) + wave * C::kQueueCap;
+
+  if (MODE == VH_MODE_DENSE_LDS) {
+    for (int j = 0; j < P.nmetric; ++j) {
+      const VhMetricDev& m = P.m[j];
+      const uint64_t ident = m.ident;
+      if (vh_sop_bytes(m.sop) == 4) {
+        for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)ident;
+      } else {
+        for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = ident;
+      }
+    }
+    for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
+    __syncthreads();
+  }
+
+  const uint64_t xoff = (MODE == VH_MODE_DENSE_GLOBAL && P.nxcd > 1) ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;
+  const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+  unsigned long long npassed = 0, nfresh = 0;
+  const uint32_t spu = P.unit_rows / C::kStepRows;  // steps per unit
+
+  // flattened step index t of this block -> (segment, unit base, this wave's first row)
+  uint32_t t = 0, seg = 0, unit_base = 0, wave_base = 0, seg_rows = 0;
+  bool have;
+  {
+    const uint32_t unit = blockIdx.x;
+    have = unit < P.total_units;
+    if (have) {
+      seg = unit / P.units_per_seg;
+      unit_base = (unit - seg * P.units_per_seg) * P.unit_rows;
+      seg_rows = P.seg_rows[seg];
+      wave_base = unit_base + wave * VH_WAVE_STEP_ROWS;
+    }
+  }
+  uint32_t v[NP][16];
+  if (have) vh_preload<NP>(P, seg, wave_base + lane * 4, seg_rows, v);
+  uint32_t cnt = 0;
+  while (have) {
+    const uint32_t row_l = wave_base + lane * 4;
+    const uint32_t mask = vh_eval_filter_fast<NP>(P, v, row_l, seg_rows);
+    npassed += __popc(mask);
+    // locate the next step and put its predicate columns in flight now
+    ++t;
+    uint32_t nseg = seg, nunit_base = unit_base, nwave_base = 0, nseg_rows = seg_rows;
+    bool nhave;
+    {
+      const uint32_t unit = blockIdx.x + (t / spu) * gridDim.x;
+      nhave = unit < P.total_units;
+      if (nhave) {
+        nseg = unit / P.units_per_seg;
+        nunit_base = (unit - nseg * P.units_per_seg) * P.unit_rows;
+        nseg_rows = P.seg_rows[nseg];
+        nwave_base = nunit_base + (t % spu) * C::kStepRows + wave * VH_WAVE_STEP_ROWS;
+      }
+    }
+    if (nhave) vh_preload<NP>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
+#pragma unroll
+    for (int k = 0; k < VH_SUBSTEPS; ++k) {
+      const uint32_t mk = (mask >> (4 * k)) & 0xFu;
+      if (__ballot(mk != 0) == 0) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool b = (mk >> j) & 1u;
+        const uint64_t bal = __ballot(b);
+        if (b) q[cnt + __popcll(bal & lanemask_lt)] = (uint16_t)(row_l + k * 256u + j - unit_base);
+        cnt += __popcll(bal);
+      }
+      __builtin_amdgcn_wave_barrier();
+      while (cnt >= 64) {
+        cnt -= 64;
+        const uint32_t r = unit_base + q[cnt + lane];
+        vh_consume_fast<MODE, SCOPE>(P, seg, r, true, lds, xoff, nfresh);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (cnt && (!nhave || nseg != seg || nunit_base != unit_base)) {  // queue entries are relative to the unit
+      const bool act = lane < (int)cnt;
+      const uint32_t r = unit_base + (act ? q[lane] : 0);
+      vh_consume_fast<MODE, SCOPE>(P, seg, r, act, lds, xoff, nfresh);
+      __builtin_amdgcn_wave_barrier();
+      cnt = 0;
+    }
+    have = nhave; seg = nseg; unit_base = nunit_base; wave_base = nwave_base; seg_rows = nseg_rows;
+  }
+
+  for (int off = 32; off > 0; off >>= 1) npassed += __shfl_down(npassed, off);
+  if (lane == 0) {
+    if (npassed) atomicAdd(P.counters + 0, npassed);
+    if (nfresh) atomicAdd(P.counters + 1, nfresh);
+  }
+  if (MODE == VH_MODE_DENSE_LDS) {
+    __syncthreads();
+    const uint64_t xo = P.nxcd > 1 ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;
+    for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) {
+      if (!reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g]) continue;
+      P.present[xo + g] = 1;
+      for (int j = 0; j < P.nmetric; ++j) {
+        const VhMetricDev& m = P.m[j];
+        const uint64_t bits = vh_sop_bytes(m.sop) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
+                                                       : reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
+        vh_state_update<SCOPE>(m.state, xo + g, m.sop, bits);
+      }
+    }
+  }
+}
+
 // ----------------------------------------------------------- table finalisation
 // Combine the per-XCD private copies of a dense table into copy 0 (they were only ever
 // touched through their own XCD's L2; the kernel boundary made them visible).

@@ -546,6 +546,21 @@ static void launch_scan(const VhPlanDev& P, int grid, size_t lds, bool xcd_priva
     hipLaunchKernelGGL((scan_agg_kernel<MODE, BLOCK, __HIP_MEMORY_SCOPE_AGENT>), dim3(grid), dim3(BLOCK), lds, s, P);
 }
 
+template <int MODE, int BLOCK, int SCOPE>
+static void launch_fast_np(const VhPlanDev& P, int grid, size_t lds, hipStream_t s) {
+  switch (P.npred) {
+    case 1: hipLaunchKernelGGL((scan_agg_fast_kernel<MODE, BLOCK, SCOPE, 1>), dim3(grid), dim3(BLOCK), lds, s, P); break;
+    case 2: hipLaunchKernelGGL((scan_agg_fast_kernel<MODE, BLOCK, SCOPE, 2>), dim3(grid), dim3(BLOCK), lds, s, P); break;
+    case 3: hipLaunchKernelGGL((scan_agg_fast_kernel<MODE, BLOCK, SCOPE, 3>), dim3(grid), dim3(BLOCK), lds, s, P); break;
+    default: hipLaunchKernelGGL((scan_agg_fast_kernel<MODE, BLOCK, SCOPE, 4>), dim3(grid), dim3(BLOCK), lds, s, P); break;
+  }
+}
+template <int MODE, int BLOCK>
+static void launch_scan_fast(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s) {
+  if (xcd_private) launch_fast_np<MODE, BLOCK, __HIP_MEMORY_SCOPE_WORKGROUP>(P, grid, lds, s);
+  else launch_fast_np<MODE, BLOCK, __HIP_MEMORY_SCOPE_AGENT>(P, grid, lds, s);
+}
+
 static int fill_states(void* p, uint64_t n, int bytes, uint64_t ident, hipStream_t s) {
   if (ident == 0) { HIP_TRY(hipMemsetAsync(p, 0, n * bytes, s)); return VH_OK; }
   const int grid = (int)std::min<uint64_t>(2048, (n + 255) / 256);
@@ -588,6 +603,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   };
 
   // ---------------- filter program (+ stack depth check)
+  bool fast_ok = !(p->flags & VH_PLAN_NO_FAST);
   int depth = 0, maxdepth = 0;
   for (int i = 0; i < p->nfilter; ++i) {
     const vh_filter_node& n = p->filter[i];
@@ -599,7 +615,15 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       if (s < 0) { delete r; return vh_fail(VH_E_INVALID, "filter node %d: bad column %d", i, n.col); }
       const int cnt = n.kind == VH_F_REL ? 1 : n.count;
       if (n.lit < 0 || n.lit + cnt > p->nlits || n.count > 255) { delete r; return vh_fail(VH_E_INVALID, "filter node %d: literal range", i); }
-      o.slot = (uint16_t)s; o.type = (uint8_t)t->cols[n.col].elem; o.lit = (uint16_t)n.lit;
+      o.slot = (uint8_t)s; o.type = (uint8_t)t->cols[n.col].elem; o.lit = (uint16_t)n.lit;
+      // fast path bookkeeping: distinct 4-byte predicate columns
+      if (vh_elem_size(t->cols[n.col].elem) != 4) fast_ok = false;
+      if (fast_ok) {
+        int ps = -1;
+        for (int k = 0; k < P.npred; ++k) if (P.pred_slot[k] == s) ps = k;
+        if (ps < 0) { if (P.npred < VH_MAX_PRED) { ps = P.npred; P.pred_slot[P.npred++] = (uint8_t)s; } else fast_ok = false; }
+        o.pslot = (uint8_t)std::max(ps, 0);
+      }
       ++depth;
     } else if (n.kind == VH_F_TRUE) {
       ++depth;
@@ -878,10 +902,18 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(P.total_units, (uint64_t)g_ctx.num_cu * blocks_per_cu));
   const size_t qbytes = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint16_t);
   HIP_TRY(hipEventRecord(t->ev[1], st));
+  const bool fast = fast_ok && P.npred >= 1 && P.ngroup <= VH_FAST_COLS && P.nmetric <= VH_FAST_COLS && P.nbitset == 0;
+  r->info.reserved = fast ? 1 : 0;
   if (P.total_units) {
-    if (mode == VH_MODE_DENSE_LDS) launch_scan<VH_MODE_DENSE_LDS, 1024>(P, grid, lds_table + qbytes, nxcd > 1, st);
-    else if (mode == VH_MODE_DENSE_GLOBAL) launch_scan<VH_MODE_DENSE_GLOBAL, 256>(P, grid, qbytes, nxcd > 1, st);
-    else launch_scan<VH_MODE_HASH, 256>(P, grid, qbytes, false, st);
+    if (fast) {
+      if (mode == VH_MODE_DENSE_LDS) launch_scan_fast<VH_MODE_DENSE_LDS, 1024>(P, grid, lds_table + qbytes, nxcd > 1, st);
+      else if (mode == VH_MODE_DENSE_GLOBAL) launch_scan_fast<VH_MODE_DENSE_GLOBAL, 256>(P, grid, qbytes, nxcd > 1, st);
+      else launch_scan_fast<VH_MODE_HASH, 256>(P, grid, qbytes, false, st);
+    } else {
+      if (mode == VH_MODE_DENSE_LDS) launch_scan<VH_MODE_DENSE_LDS, 1024>(P, grid, lds_table + qbytes, nxcd > 1, st);
+      else if (mode == VH_MODE_DENSE_GLOBAL) launch_scan<VH_MODE_DENSE_GLOBAL, 256>(P, grid, qbytes, nxcd > 1, st);
+      else launch_scan<VH_MODE_HASH, 256>(P, grid, qbytes, false, st);
+    }
   }
   HIP_TRY(hipEventRecord(t->ev[2], st));
   HIP_TRY(hipGetLastError());

@@ -72,6 +72,7 @@ class AggResult:
     total_ms: float
     algorithmic_bytes: int
     retries: int
+    fast: bool = False
 
 
 class DeviceTable:
@@ -220,7 +221,7 @@ class DeviceTable:
         capi.check(self.lib.vh_result_copy(res, kp, spp, hp))
         return AggResult(keys, states, hidden, int(ng), int(info.scanned_recs), int(info.scanned_segments),
                          int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
-                         float(info.total_ms), int(info.algorithmic_bytes), int(info.retries))
+                         float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1))
 
     def query_agg(self, plan: AggPlan) -> AggResult:
         p, keep = self._build_plan(plan)
