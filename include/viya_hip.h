@@ -133,7 +133,9 @@ enum vh_plan_flags {
   VH_PLAN_FORCE_HASH = 1u << 0,   /* testing: never take the dense path     */
   VH_PLAN_FORCE_GLOBAL = 1u << 1, /* testing: dense table in HBM, not LDS   */
   VH_PLAN_NO_XCD_PRIVATE = 1u << 2,/* testing: one device-scope dense table */
-  VH_PLAN_NO_FAST = 1u << 3       /* testing: always the generic scan kernel */
+  VH_PLAN_NO_FAST = 1u << 3,      /* testing: always the generic scan kernel */
+  VH_PLAN_NO_PART = 1u << 4       /* testing: direct global atomics instead of
+                                     radix-partitioned LDS aggregation        */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */
@@ -154,7 +156,7 @@ typedef struct vh_table vh_table;
 typedef struct vh_result vh_result;
 
 enum vh_path { VH_PATH_SCALAR = 0, VH_PATH_DENSE_LDS = 1, VH_PATH_DENSE_GLOBAL = 2,
-               VH_PATH_HASH = 3 };
+               VH_PATH_HASH = 3, VH_PATH_DENSE_PART = 4 };
 
 typedef struct vh_result_info {
   uint64_t ngroups;          /* agg_map.size()  -> stats.aggregated_recs     */

@@ -115,7 +115,7 @@ def test_metric_predicates(typed, t):
 
 
 @pytest.mark.parametrize("t", TYPES)
-@pytest.mark.parametrize("flags", [0, 1, 8, 9])
+@pytest.mark.parametrize("flags", [0, 1, 8, 9, 16])
 def test_all_aggregations_per_type(typed, t, flags):
     tab, dt = typed
     run(tab, dt, {"dimensions": ["s8", "flag"], "metrics": ["count"] + [f"{t}_{a}" for a in ("sum", "min", "max", "avg")],
@@ -146,6 +146,38 @@ def test_group_key_shapes(typed, dims, flags):
     """Narrow, 64-bit-packed and wide (multi-word, incl. float/double) keys."""
     tab, dt = typed
     run(tab, dt, {"dimensions": dims, "metrics": ["count", "int_sum", "double_max"], "filter": F("ge", "d_int", "-30")}, flags=flags)
+
+
+@pytest.mark.parametrize("flags", [0, 16])
+def test_partitioned_aggregation_shapes(typed, flags):
+    """Group-id spaces of 10K-150K ids with 1-4 metrics of mixed widths (tuple packing), through the
+    radix-partitioned path and, for comparison, direct global atomics."""
+    tab, dt = typed
+    for dims, mets in ((["s16", "flag"], ["count"]), (["s16", "d_ubyte"], ["long_sum", "count", "int_min", "double_max"]),
+                       (["s32", "flag"], ["float_sum", "uint_max", "short_sum"]), (["s16"], ["ulong_min", "long_max"]),
+                       (["s8", "s16"], ["int_avg", "count"])):
+        res, _ = run(tab, dt, {"dimensions": dims, "metrics": mets, "filter": F("lt", "d_uint", "45")}, flags=flags)
+        if flags == 0 and res.ngroups > 5000:
+            assert res.path in ("dense_part", "dense_global", "hash")
+
+
+def test_partition_buffer_regrows():
+    """Every row survives: the tuple extents planned for 1/8 of the rows overflow and the query is re-run."""
+    rng = np.random.default_rng(21)
+    n = 60000
+    tab = vo.Table({"name": "t", "segment_size": n, "dimensions": [{"name": "a", "type": "uint"}, {"name": "b", "type": "uint"}],
+                    "metrics": [{"name": "v", "type": "long_sum"}, {"name": "count", "type": "count"}]})
+    for _ in range(3):
+        tab.add_segment_arrays([rng.integers(0, 300, n).astype(np.uint32), rng.integers(0, 200, n).astype(np.uint32)],
+                               [rng.integers(-1000, 1000, n).astype(np.int64), np.ones(n, dtype=np.uint32)], None, n)
+    dt = mirror_table(tab)
+    try:
+        res, _ = run(tab, dt, {"dimensions": ["a", "b"], "metrics": ["v", "count"], "filter": F("ge", "a", "0")})
+        assert res.path == "dense_part" and res.retries >= 1
+        # skew: everything lands in one partition
+        res, _ = run(tab, dt, {"dimensions": ["a", "b"], "metrics": ["v", "count"], "filter": F("eq", "a", "7")})
+    finally:
+        dt.close()
 
 
 def test_in_and_not_in(typed):

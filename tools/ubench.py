@@ -16,6 +16,7 @@ def main():
     ap.add_argument("--segments", type=int, default=100)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--workloads", default="C3,C2,C1")
+    ap.add_argument("--variants", default="")
     args = ap.parse_args()
     executor.init(0)
     bw = executor.measure_read_bandwidth(8 << 30, 5)
@@ -23,7 +24,10 @@ def main():
     for name in args.workloads.split(","):
         w = synth.WORKLOADS[name]()
         t = synth.create_device_table(w, args.segments)
-        for flags, label in [(0, "default"), (8, "generic_kernel"), (4, "no_xcd_private"), (2, "force_global"), (10, "generic_force_global"), (1, "hash"), (9, "generic_hash")]:
+        want = set(args.variants.split(",")) if args.variants else None
+        for flags, label in [(0, "default"), (16, "no_part"), (8, "generic_kernel"), (4, "no_xcd_private"), (2, "force_global"), (10, "generic_force_global"), (1, "hash"), (9, "generic_hash")]:
+            if want and label not in want:
+                continue
             plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=flags,
                                     groups_hint=w.plan.groups_hint)
             ms, tot = [], []

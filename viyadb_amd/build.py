@@ -24,13 +24,30 @@ def hip_sources():
 
 
 def build_hip(force: bool = False, verbose: bool = False) -> str:
-    """libviya_hip.so: kernels + C-ABI, one translation unit, gfx950 only."""
+    """libviya_hip.so: kernels + C-ABI for gfx950. One object per .hip (compiled in parallel), then linked."""
     srcs = hip_sources()
     if not force and _newer(LIB, srcs):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
-           "-Wno-unused-result", os.path.join(CSRC, "viya_hip.hip"), "-o", LIB + ".tmp"]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = [s for s in srcs if s.endswith(".h")]
+    units = [s for s in srcs if s.endswith(".hip")]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result"]
+    procs, objs = [], []
+    for u in units:
+        o = os.path.join(objdir, os.path.basename(u)[:-4] + ".o")
+        objs.append(o)
+        if not force and _newer(o, [u] + hdrs):
+            continue
+        cmd = [hipcc] + flags + ["-c", u, "-o", o]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -27,10 +27,10 @@ OP_EQ, OP_NE, OP_LT, OP_LE, OP_GT, OP_GE = range(6)
 T_YEAR, T_MONTH, T_WEEK, T_DAY, T_HOUR, T_MINUTE, T_SECOND, T_NONE = range(8)
 MAX_ROLLUP = 8
 # plan flags
-PLAN_FORCE_HASH, PLAN_FORCE_GLOBAL, PLAN_NO_XCD_PRIVATE, PLAN_NO_FAST = 1, 2, 4, 8
+PLAN_FORCE_HASH, PLAN_FORCE_GLOBAL, PLAN_NO_XCD_PRIVATE, PLAN_NO_FAST, PLAN_NO_PART = 1, 2, 4, 8, 16
 # paths
-PATH_SCALAR, PATH_DENSE_LDS, PATH_DENSE_GLOBAL, PATH_HASH = range(4)
-PATH_NAMES = ["scalar", "dense_lds", "dense_global", "hash"]
+PATH_SCALAR, PATH_DENSE_LDS, PATH_DENSE_GLOBAL, PATH_HASH, PATH_DENSE_PART = range(5)
+PATH_NAMES = ["scalar", "dense_lds", "dense_global", "hash", "dense_part"]
 # generator
 GEN_UNIFORM, GEN_ROWID, GEN_CONST = range(3)
 

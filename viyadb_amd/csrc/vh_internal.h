@@ -16,6 +16,9 @@
 #define VH_MAX_BITSET 2   // bitset (count-distinct) metrics per query
 #define VH_MAX_PRED 4     // fast path: distinct 4-byte predicate columns held in registers
 #define VH_FAST_COLS 4    // fast path: group / metric columns gathered up front
+#define VH_MAX_PART 32     // DENSE_PART: partitions (one LDS staging buffer per wave and partition)
+#define VH_EXT_FLUSHES 4  // DENSE_PART: staging flushes per extent
+#define VH_EXT_CHUNK 8    // DENSE_PART: extents a wave reserves per global allocation
 
 // Row geometry of one block step (see DESIGN.md "scan geometry"):
 // a wave covers 1024 consecutive rows per step as 4 sub-steps of 256 rows;
@@ -65,7 +68,11 @@ struct VhMetricDev {
   uint16_t slot;
   uint8_t type;        // vh_elem of the source column
   uint8_t sop;         // vh_state_op
-  uint32_t lds_off;    // DENSE_LDS: byte offset of this metric's state array in LDS
+  uint8_t tword;       // DENSE_PART: tuple word that carries this metric's value
+  uint8_t tshift;      // DENSE_PART: bit offset inside that word (0 or 32)
+  uint16_t pad0;
+  uint32_t lds_off;    // DENSE_LDS / DENSE_PART phase 2: byte offset of this metric's state array in LDS
+  uint32_t pad1;
   void* state;         // global state array (G or capacity elements, 4 or 8 B each)
   uint64_t ident;      // identity bits: 0 (SUM/AVG/COUNT), type max (MIN), cpp_min_value (MAX)
 };
@@ -115,13 +122,27 @@ struct VhPlanDev {
   const void* const* bs_vals[VH_MAX_BITSET];      // [nseg] -> ids
   uint64_t* pairs;                                // 2 x pair_cap words
   uint64_t pair_cap;
+  // ---- partitioned aggregation (DENSE_PART): survivors become (gid, values) tuples, radix-partitioned
+  // by gid >> part_shift into extents in HBM; a second kernel aggregates each partition in LDS
+  int32_t npart;             // <= VH_MAX_PART
+  int32_t part_shift;        // groups per partition = 1 << part_shift
+  int32_t tw;                // 64-bit words per tuple (word 0 low half = gid)
+  int32_t stage_cap;         // tuples per (wave, partition) LDS staging buffer = one flush
+  uint64_t* tuples;          // max_extents x VH_EXT_FLUSHES x stage_cap x tw words
+  uint32_t* part_count;      // [npart] extents recorded per partition
+  uint32_t* part_extents;    // [npart][part_cap] extent ids
+  uint16_t* extent_missing;  // [max_extents] tuples NOT filled in an extent (0 = full)
+  uint32_t part_cap;
+  uint32_t max_extents;
   // ---- counters: [0] passed rows, [1] new groups (hash), [2] error flags,
-  //                [3] reserved hash slot (key == sentinel) in use, [4] emitted pairs
+  //                [3] reserved hash slot (key == sentinel) in use, [4] emitted pairs,
+  //                [5] extent allocation cursor (DENSE_PART)
   unsigned long long* counters;
 };
 
 #define VH_ERR_RANGE 1ull      // dense digit out of range
 #define VH_ERR_HASH_FULL 2ull  // probe limit hit
+#define VH_ERR_PART_FULL 4ull  // tuple extents exhausted
 
 static inline int vh_elem_size(int e) {
   switch (e) {

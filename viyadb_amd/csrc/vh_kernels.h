@@ -387,7 +387,7 @@ __device__ __forceinline__ uint64_t vh_hash_insert_wide(const VhPlanDev& P, cons
 }
 
 // ------------------------------------------------------------ scan + aggregate
-enum { VH_MODE_DENSE_LDS = 1, VH_MODE_DENSE_GLOBAL = 2, VH_MODE_HASH = 3 };
+enum { VH_MODE_DENSE_LDS = 1, VH_MODE_DENSE_GLOBAL = 2, VH_MODE_HASH = 3, VH_MODE_DENSE_PART = 4 };
 
 // One surviving row (one per active lane, lanes are dense after compaction):
 // build the AggTuple key, then Update every selected metric.
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   // queues live behind the (optional) LDS aggregate table
-  uint16_t* q = reinterpret_cast<uint16_t*>(lds + (MODE == VH_MODE_DENSE_LDS ? P.lds_bytes : 0)) +
+  uint32_t* q = reinterpret_cast<uint32_t*>(lds + (MODE == VH_MODE_DENSE_LDS ? P.lds_bytes : 0)) +
                 wave * C::kQueueCap;
 
   if (MODE == VH_MODE_DENSE_LDS) {
@@ -538,13 +538,13 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
         for (int j = 0; j < 4; ++j) {
           const bool b = (mk >> j) & 1u;
           const uint64_t bal = __ballot(b);
-          if (b) q[cnt + __popcll(bal & lanemask_lt)] = (uint16_t)(row_l + k * 256u + j - unit_base);
+          if (b) q[cnt + __popcll(bal & lanemask_lt)] = row_l + k * 256u + j;
           cnt += __popcll(bal);
         }
         __builtin_amdgcn_wave_barrier();
         while (cnt >= 64) {
           cnt -= 64;
-          const uint32_t r = unit_base + q[cnt + lane];
+          const uint32_t r = q[cnt + lane];
           vh_consume<MODE, SCOPE>(P, seg, r, true, lds, xoff, nfresh);
           __builtin_amdgcn_wave_barrier();
         }
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
     }
     if (cnt) {
       const bool act = lane < (int)cnt;
-      const uint32_t r = unit_base + (act ? q[lane] : 0);
+      const uint32_t r = act ? q[lane] : 0;
       vh_consume<MODE, SCOPE>(P, seg, r, act, lds, xoff, nfresh);
       __builtin_amdgcn_wave_barrier();
     }
@@ -582,6 +582,111 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
   }
 }
 
+
+
+// ------------------------------------------------- partitioned aggregation, phase 1 helpers
+// Global atomics are written through to the fabric on this part (~28 B of HBM write traffic per
+// atomic even on a 12 KB table, profiles/r01), so for group-id spaces that do not fit one CU's LDS
+// the survivors are NOT aggregated with global atomics: each becomes a (gid, values) tuple, staged
+// per (wave, partition) in LDS and flushed in 128-256 B pieces into per-partition extents in HBM;
+// part_agg_kernel then aggregates every partition with LDS atomics only.
+struct VhPartWave {
+  uint64_t* stage;     // [npart][stage_cap][tw]
+  uint32_t* scnt;      // [npart] staged tuples (may overshoot stage_cap while a flush is pending)
+  uint32_t* ext_base;  // [npart] current extent id or ~0u
+  uint32_t* ext_used;  // [npart] flushes already written into the current extent
+  uint32_t chunk_next, chunk_end;
+};
+
+__device__ __forceinline__ size_t vh_part_wave_bytes(const VhPlanDev& P) {
+  return (size_t)P.npart * ((size_t)P.stage_cap * P.tw * 8 + 12);
+}
+
+__device__ __forceinline__ void vh_part_wave_init(const VhPlanDev& P, char* area, VhPartWave& W, int lane) {
+  W.stage = reinterpret_cast<uint64_t*>(area);
+  W.scnt = reinterpret_cast<uint32_t*>(area + (size_t)P.npart * P.stage_cap * P.tw * 8);
+  W.ext_base = W.scnt + P.npart;
+  W.ext_used = W.ext_base + P.npart;
+  W.chunk_next = W.chunk_end = 0;
+  if (lane < P.npart) { W.scnt[lane] = 0; W.ext_base[lane] = ~0u; W.ext_used[lane] = 0; }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Write the first n staged tuples of partition p (wave-uniform p, n) to HBM.
+__device__ __forceinline__ void vh_part_flush(const VhPlanDev& P, VhPartWave& W, int p, uint32_t n, int lane) {
+  uint32_t ext = W.ext_base[p], used = W.ext_used[p];
+  if (ext == ~0u || used == VH_EXT_FLUSHES) {
+    if (W.chunk_next == W.chunk_end) {
+      unsigned long long c = 0;
+      if (lane == 0) c = atomicAdd(P.counters + 5, (unsigned long long)VH_EXT_CHUNK);
+      c = __shfl(c, 0);
+      W.chunk_next = (uint32_t)c;
+      W.chunk_end = (uint32_t)c + VH_EXT_CHUNK;
+    }
+    ext = W.chunk_next++;
+    used = 0;
+    bool ok = ext < P.max_extents;
+    if (ok && lane == 0) {
+      const uint32_t pos = atomicAdd(P.part_count + p, 1u);
+      if (pos < P.part_cap) P.part_extents[(uint64_t)p * P.part_cap + pos] = ext; else ok = false;
+    }
+    ok = __shfl((int)ok, 0) != 0 && ext < P.max_extents;
+    if (!ok) {  // out of space: the host re-runs with a larger tuple buffer
+      if (lane == 0) { atomicOr(P.counters + 2, VH_ERR_PART_FULL); W.scnt[p] = 0; W.ext_base[p] = ~0u; }
+      __builtin_amdgcn_wave_barrier();
+      return;
+    }
+    if (lane == 0) W.ext_base[p] = ext;
+  }
+  const uint32_t tw = (uint32_t)P.tw, cap = (uint32_t)P.stage_cap;
+  uint64_t* dst = P.tuples + ((uint64_t)ext * VH_EXT_FLUSHES + used) * cap * tw;
+  const uint64_t* src = W.stage + (size_t)p * cap * tw;
+  for (uint32_t i = lane; i < n * tw; i += 64) dst[i] = src[i];
+  if (lane == 0) {
+    W.ext_used[p] = used + 1;
+    W.scnt[p] = 0;
+    if (n < cap) P.extent_missing[ext] = (uint16_t)((VH_EXT_FLUSHES - used) * cap - n);
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void vh_part_append(const VhPlanDev& P, VhPartWave& W, bool active, uint32_t p,
+                                               const uint64_t (&words)[1 + VH_FAST_COLS], int lane) {
+  bool pending = active;
+  const uint32_t cap = (uint32_t)P.stage_cap, tw = (uint32_t)P.tw;
+  while (__ballot(pending)) {
+    uint32_t pos = ~0u;
+    if (pending) pos = atomicAdd(W.scnt + p, 1u);
+    if (pending && pos < cap) {
+      uint64_t* d = W.stage + ((size_t)p * cap + pos) * tw;
+#pragma unroll
+      for (int w = 0; w < 1 + VH_FAST_COLS; ++w)
+        if ((uint32_t)w < tw) d[w] = words[w];
+      pending = false;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint64_t full = __ballot(lane < P.npart && W.scnt[lane < P.npart ? lane : 0] >= cap);
+    while (full) {
+      const int fp = __builtin_ctzll(full);
+      full &= full - 1;
+      vh_part_flush(P, W, fp, cap, lane);
+    }
+  }
+}
+
+// end of kernel: flush partial staging buffers and publish how much of each open extent is valid
+__device__ __forceinline__ void vh_part_finish(const VhPlanDev& P, VhPartWave& W, int lane) {
+  for (int p = 0; p < P.npart; ++p) {
+    const uint32_t n = W.scnt[p];
+    if (n) {
+      vh_part_flush(P, W, p, n < (uint32_t)P.stage_cap ? n : (uint32_t)P.stage_cap, lane);
+    } else {
+      const uint32_t ext = W.ext_base[p], used = W.ext_used[p];
+      if (ext != ~0u && used < VH_EXT_FLUSHES && lane == 0)
+        P.extent_missing[ext] = (uint16_t)((VH_EXT_FLUSHES - used) * P.stage_cap);
+    }
+  }
+}
 
 // =====================================================================================
 // Fast variant: every predicate column is 4 bytes wide (u32 / i32 / f32 — dict codes, uint
@@ -683,7 +788,7 @@ __device__ __forceinline__ uint32_t vh_eval_filter_fast(const VhPlanDev& P, cons
 
 template <int MODE, int SCOPE>
 __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, char* lds,
-                                                uint64_t xoff, unsigned long long& nfresh) {
+                                                uint64_t xoff, unsigned long long& nfresh, VhPartWave& W) {
   if (!active) row = 0;
   uint64_t gv[VH_FAST_COLS], mv[VH_FAST_COLS];
 #pragma unroll
@@ -740,6 +845,24 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
     if (active && bad) atomicOr(P.counters + 2, VH_ERR_RANGE);
   }
   active = active && !bad;
+  if (MODE == VH_MODE_DENSE_PART) {
+    uint64_t words[1 + VH_FAST_COLS];
+    words[0] = gid & 0xFFFFFFFFull;
+#pragma unroll
+    for (int w = 1; w < 1 + VH_FAST_COLS; ++w) words[w] = 0;
+#pragma unroll
+    for (int j = 0; j < VH_FAST_COLS; ++j) {
+      if (j < P.nmetric) {
+        const VhMetricDev& m = P.m[j];
+        const uint64_t v = (vh_sop_bytes(m.sop) == 4 ? (mv[j] & 0xFFFFFFFFull) : mv[j]) << m.tshift;
+#pragma unroll
+        for (int w = 0; w < 1 + VH_FAST_COLS; ++w)
+          if (m.tword == w) words[w] |= v;
+      }
+    }
+    vh_part_append(P, W, active, (uint32_t)(gid >> P.part_shift), words, (int)(threadIdx.x & 63));
+    return;
+  }
   if (MODE == VH_MODE_DENSE_LDS) {
     if (active) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[gid] = 1;
   } else if (MODE == VH_MODE_DENSE_GLOBAL) {
@@ -762,7 +885,12 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
   typedef VhScanCfg<BLOCK> C;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  uint16_t* q = reinterpret_cast<uint16_t*>(lds + (MODE == VH_MODE_DENSE_LDS ? P.lds_bytes : 0)) + wave * C::kQueueCap;
+  uint32_t* q = reinterpret_cast<uint32_t*>(lds + (MODE == VH_MODE_DENSE_LDS ? P.lds_bytes : 0)) + wave * C::kQueueCap;
+  VhPartWave W;
+  if (MODE == VH_MODE_DENSE_PART) {
+    char* area = lds + (size_t)C::kWaves * C::kQueueCap * sizeof(uint32_t) + (size_t)wave * ((vh_part_wave_bytes(P) + 15) / 16 * 16);
+    vh_part_wave_init(P, area, W, lane);
+  }
 
   if (MODE == VH_MODE_DENSE_LDS) {
     for (int j = 0; j < P.nmetric; ++j) {
@@ -826,27 +954,28 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
       for (int j = 0; j < 4; ++j) {
         const bool b = (mk >> j) & 1u;
         const uint64_t bal = __ballot(b);
-        if (b) q[cnt + __popcll(bal & lanemask_lt)] = (uint16_t)(row_l + k * 256u + j - unit_base);
+        if (b) q[cnt + __popcll(bal & lanemask_lt)] = row_l + k * 256u + j;
         cnt += __popcll(bal);
       }
       __builtin_amdgcn_wave_barrier();
       while (cnt >= 64) {
         cnt -= 64;
-        const uint32_t r = unit_base + q[cnt + lane];
-        vh_consume_fast<MODE, SCOPE>(P, seg, r, true, lds, xoff, nfresh);
+        const uint32_t r = q[cnt + lane];
+        vh_consume_fast<MODE, SCOPE>(P, seg, r, true, lds, xoff, nfresh, W);
         __builtin_amdgcn_wave_barrier();
       }
     }
-    if (cnt && (!nhave || nseg != seg || nunit_base != unit_base)) {  // queue entries are relative to the unit
+    if (cnt && (!nhave || nseg != seg)) {  // queue entries are rows of the current segment
       const bool act = lane < (int)cnt;
-      const uint32_t r = unit_base + (act ? q[lane] : 0);
-      vh_consume_fast<MODE, SCOPE>(P, seg, r, act, lds, xoff, nfresh);
+      const uint32_t r = act ? q[lane] : 0;
+      vh_consume_fast<MODE, SCOPE>(P, seg, r, act, lds, xoff, nfresh, W);
       __builtin_amdgcn_wave_barrier();
       cnt = 0;
     }
     have = nhave; seg = nseg; unit_base = nunit_base; wave_base = nwave_base; seg_rows = nseg_rows;
   }
 
+  if (MODE == VH_MODE_DENSE_PART) vh_part_finish(P, W, lane);
   for (int off = 32; off > 0; off >>= 1) npassed += __shfl_down(npassed, off);
   if (lane == 0) {
     if (npassed) atomicAdd(P.counters + 0, npassed);
@@ -868,209 +997,70 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
   }
 }
 
-// ----------------------------------------------------------- table finalisation
-// Combine the per-XCD private copies of a dense table into copy 0 (they were only ever
-// touched through their own XCD's L2; the kernel boundary made them visible).
-__device__ __forceinline__ uint64_t vh_combine(int sop, uint64_t a, uint64_t b) {
-  switch (sop) {
-    case SOP_ADD32: return (uint32_t)((uint32_t)a + (uint32_t)b);
-    case SOP_ADD64: return a + b;
-    case SOP_ADDF32: return __float_as_uint(__uint_as_float((uint32_t)a) + __uint_as_float((uint32_t)b));
-    case SOP_ADDF64: return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
-    case SOP_MIN_I32: return (uint32_t)((int32_t)b < (int32_t)a ? b : a);
-    case SOP_MAX_I32: return (uint32_t)((int32_t)a < (int32_t)b ? b : a);
-    case SOP_MIN_U32: return (uint32_t)b < (uint32_t)a ? (uint32_t)b : (uint32_t)a;
-    case SOP_MAX_U32: return (uint32_t)a < (uint32_t)b ? (uint32_t)b : (uint32_t)a;
-    case SOP_MIN_I64: return (int64_t)b < (int64_t)a ? b : a;
-    case SOP_MAX_I64: return (int64_t)a < (int64_t)b ? b : a;
-    case SOP_MIN_U64: return b < a ? b : a;
-    case SOP_MAX_U64: return a < b ? b : a;
-    case SOP_MIN_F32: return __uint_as_float((uint32_t)b) < __uint_as_float((uint32_t)a) ? (uint32_t)b : (uint32_t)a;
-    case SOP_MAX_F32: return __uint_as_float((uint32_t)a) < __uint_as_float((uint32_t)b) ? (uint32_t)b : (uint32_t)a;
-    case SOP_MIN_F64: return __longlong_as_double((long long)b) < __longlong_as_double((long long)a) ? b : a;
-    default: return __longlong_as_double((long long)a) < __longlong_as_double((long long)b) ? b : a;
-  }
-}
-
-struct VhMergeArgs {
-  int32_t nmetric; int32_t nxcd;
-  uint64_t G; uint64_t xcd_stride;
-  uint8_t* present;
-  void* state[VH_MAX_METRIC];
-  uint8_t sop[VH_MAX_METRIC];
-};
-
-__global__ __launch_bounds__(256) void dense_merge_kernel(const VhMergeArgs A) {
-  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  if (g >= A.G) return;
-  uint8_t p = A.present[g];
-  for (int x = 1; x < A.nxcd; ++x) p |= A.present[x * A.xcd_stride + g];
-  A.present[g] = p;
-  if (!p) return;
-  for (int j = 0; j < A.nmetric; ++j) {
-    const int sop = A.sop[j];
-    if (vh_sop_bytes(sop) == 4) {
-      uint32_t* s = reinterpret_cast<uint32_t*>(A.state[j]);
-      uint64_t a = s[g];
-      for (int x = 1; x < A.nxcd; ++x) a = vh_combine(sop, a, s[x * A.xcd_stride + g]);
-      s[g] = (uint32_t)a;
+// ------------------------------------------------- partitioned aggregation, phase 2
+// grid = npart x blocks_per_part. A block owns an LDS table for its partition's 2^part_shift groups,
+// its waves walk the partition's extents (64 tuples each, one coalesced 16 B/lane load for 2-word
+// tuples), every tuple is an LDS-atomic update, and the block finally merges its table into the dense
+// global table (one update per present group and block).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int blocks_per_part) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int part = blockIdx.x / blocks_per_part, b = blockIdx.x % blocks_per_part;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = BLOCK / 64;
+  const uint64_t gpp = 1ull << P.part_shift;
+  const uint64_t g0 = (uint64_t)part << P.part_shift;
+  const uint64_t ng = g0 >= P.G ? 0 : (P.G - g0 < gpp ? P.G - g0 : gpp);
+  for (int j = 0; j < P.nmetric; ++j) {
+    const VhMetricDev& m = P.m[j];
+    if (vh_sop_bytes(m.sop) == 4) {
+      for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)m.ident;
     } else {
-      uint64_t* s = reinterpret_cast<uint64_t*>(A.state[j]);
-      uint64_t a = s[g];
-      for (int x = 1; x < A.nxcd; ++x) a = vh_combine(sop, a, s[x * A.xcd_stride + g]);
-      s[g] = a;
+      for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = m.ident;
+    }
+  }
+  for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
+  __syncthreads();
+  const uint32_t next = P.part_count[part] < P.part_cap ? P.part_count[part] : P.part_cap;
+  const uint32_t ext_tuples = VH_EXT_FLUSHES * (uint32_t)P.stage_cap;
+  const uint32_t tw = (uint32_t)P.tw;
+  for (uint32_t e = (uint32_t)b * nwaves + wave; e < next; e += (uint32_t)blocks_per_part * nwaves) {
+    const uint32_t ext = P.part_extents[(uint64_t)part * P.part_cap + e];
+    const uint32_t valid = ext_tuples - P.extent_missing[ext];
+    const uint64_t* base = P.tuples + (uint64_t)ext * ext_tuples * tw;
+    for (uint32_t i = lane; i < valid; i += 64) {
+      uint64_t w[1 + VH_FAST_COLS];
+#pragma unroll
+      for (int x = 0; x < 1 + VH_FAST_COLS; ++x) w[x] = (uint32_t)x < tw ? __builtin_nontemporal_load(base + (uint64_t)i * tw + x) : 0;
+      const uint64_t local = (w[0] & 0xFFFFFFFFull) - g0;
+      if (local >= ng) continue;  // cannot happen; keeps a corrupt tuple from writing outside the table
+      reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[local] = 1;
+#pragma unroll
+      for (int j = 0; j < VH_FAST_COLS; ++j) {
+        if (j < P.nmetric) {
+          const VhMetricDev& m = P.m[j];
+          uint64_t v = 0;
+#pragma unroll
+          for (int x = 0; x < 1 + VH_FAST_COLS; ++x)
+            if (m.tword == x) v = w[x] >> m.tshift;
+          if (vh_sop_bytes(m.sop) == 4) {
+            v &= 0xFFFFFFFFull;
+            if (vh_sop_sext(m.sop)) v = (uint64_t)(int64_t)(int32_t)v;
+          }
+          vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, local, m.sop, v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) {
+    if (!reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g]) continue;
+    P.present[g0 + g] = 1;
+    for (int j = 0; j < P.nmetric; ++j) {
+      const VhMetricDev& m = P.m[j];
+      const uint64_t bits = vh_sop_bytes(m.sop) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
+                                                     : reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
+      vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, g0 + g, m.sop, bits);
     }
   }
 }
 
-// Emit one (key columns, metric states) row per existing group into dense output arrays,
-// already in each column's own element type.
-struct VhEmitArgs {
-  int32_t mode;  // VH_MODE_*
-  int32_t ngroup; int32_t nmetric; int32_t key_words;
-  uint64_t n;    // dense: G; hash: capacity + 1
-  const uint8_t* present;
-  const uint64_t* hkeys; const uint32_t* htags;
-  const unsigned long long* counters;
-  unsigned long long* out_count;
-  uint64_t* out_gid;              // optional: table index of output row `pos` (bitset metrics)
-  VhGroupDev g[VH_MAX_GROUP];
-  void* out_key[VH_MAX_GROUP];
-  const void* state[VH_MAX_METRIC];
-  void* out_state[VH_MAX_METRIC];
-  uint8_t sop[VH_MAX_METRIC];
-  uint8_t mtype[VH_MAX_METRIC];   // output element type of metric j
-};
-
-__device__ __forceinline__ void vh_store_elem(void* base, int type, uint64_t idx, uint64_t bits) {
-  switch (type) {
-    case VH_U8: case VH_I8: reinterpret_cast<uint8_t*>(base)[idx] = (uint8_t)bits; break;
-    case VH_U16: case VH_I16: reinterpret_cast<uint16_t*>(base)[idx] = (uint16_t)bits; break;
-    case VH_U32: case VH_I32: case VH_F32: reinterpret_cast<uint32_t*>(base)[idx] = (uint32_t)bits; break;
-    default: reinterpret_cast<uint64_t*>(base)[idx] = bits; break;
-  }
-}
-
-__global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  bool have = false;
-  if (i < A.n) {
-    if (A.mode == VH_MODE_HASH) {
-      if (i + 1 == A.n) have = A.key_words == 1 && A.counters[3] != 0;  // reserved slot
-      else have = A.key_words == 1 ? A.hkeys[i] != VH_HASH_EMPTY : A.htags[i] == 2u;
-    } else {
-      have = A.present[i] != 0;
-    }
-  }
-  const uint64_t bal = __ballot(have);
-  if (bal == 0) return;
-  const int lane = threadIdx.x & 63;
-  unsigned long long base = 0;
-  if (lane == 0) base = atomicAdd(A.out_count, (unsigned long long)__popcll(bal));
-  base = __shfl(base, 0);
-  if (!have) return;
-  const uint64_t pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-  if (A.out_gid) A.out_gid[pos] = i;
-  for (int c = 0; c < A.ngroup; ++c) {
-    const VhGroupDev& g = A.g[c];
-    uint64_t v;
-    if (A.mode == VH_MODE_HASH) {
-      uint64_t w = A.hkeys[i * A.key_words + g.key_word];
-      if (A.key_words == 1 && i + 1 == A.n) w = VH_HASH_EMPTY;
-      v = w >> g.key_shift;
-    } else {
-      v = g.lo + (i / g.stride) % g.extent;
-    }
-    vh_store_elem(A.out_key[c], g.type, pos, v);
-  }
-  for (int j = 0; j < A.nmetric; ++j) {
-    const uint64_t bits = vh_sop_bytes(A.sop[j]) == 4 ? reinterpret_cast<const uint32_t*>(A.state[j])[i]
-                                                      : reinterpret_cast<const uint64_t*>(A.state[j])[i];
-    vh_store_elem(A.out_state[j], A.mtype[j], pos, bits);
-  }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void fill_kernel(T* p, uint64_t n, T v) {
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = v;
-}
-
-// ----------------------------------------------------------- synthetic data
-// value(c, r) = splitmix64(seed ^ c*GAMMA ^ r) reduced to the column domain.
-template <typename T>
-__global__ __launch_bounds__(256) void gen_kernel(T* base, uint64_t seg_stride_elems, uint64_t rows_per_seg,
-                                                  uint64_t row_base, vh_gen_spec spec, uint64_t colseed) {
-  const uint32_t seg = blockIdx.y;
-  T* col = base + (uint64_t)seg * seg_stride_elems;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < rows_per_seg; i += (uint64_t)gridDim.x * 256) {
-    const uint64_t r = row_base + (uint64_t)seg * rows_per_seg + i;
-    T out;
-    if (spec.mode == VH_GEN_ROWID) {
-      out = (T)r;
-    } else if (spec.mode == VH_GEN_CONST) {
-      out = (T)spec.add;
-    } else {
-      const uint64_t h = vh_splitmix64(colseed ^ r);
-      const int64_t iv = spec.add + (int64_t)(h % spec.mod);
-      if (std::is_floating_point<T>::value) out = (T)((double)iv * spec.scale);
-      else out = (T)iv;
-    }
-    col[i] = out;
-  }
-}
-
-// ------------------------------------------------------------ segment stats
-// Order-preserving map of a column value to u64 so one pair of u64 atomics does min/max.
-template <typename T> __device__ __forceinline__ uint64_t vh_order_key(T v);
-template <> __device__ __forceinline__ uint64_t vh_order_key<uint8_t>(uint8_t v) { return v; }
-template <> __device__ __forceinline__ uint64_t vh_order_key<uint16_t>(uint16_t v) { return v; }
-template <> __device__ __forceinline__ uint64_t vh_order_key<uint32_t>(uint32_t v) { return v; }
-template <> __device__ __forceinline__ uint64_t vh_order_key<uint64_t>(uint64_t v) { return v; }
-template <> __device__ __forceinline__ uint64_t vh_order_key<int8_t>(int8_t v) { return (uint64_t)(int64_t)v ^ (1ull << 63); }
-template <> __device__ __forceinline__ uint64_t vh_order_key<int16_t>(int16_t v) { return (uint64_t)(int64_t)v ^ (1ull << 63); }
-template <> __device__ __forceinline__ uint64_t vh_order_key<int32_t>(int32_t v) { return (uint64_t)(int64_t)v ^ (1ull << 63); }
-template <> __device__ __forceinline__ uint64_t vh_order_key<int64_t>(int64_t v) { return (uint64_t)v ^ (1ull << 63); }
-template <> __device__ __forceinline__ uint64_t vh_order_key<float>(float v) {
-  const uint32_t b = __float_as_uint(v);
-  return (b & 0x80000000u) ? (uint32_t)~b : (b | 0x80000000u);
-}
-template <> __device__ __forceinline__ uint64_t vh_order_key<double>(double v) {
-  const uint64_t b = (uint64_t)__double_as_longlong(v);
-  return (b & (1ull << 63)) ? ~b : (b | (1ull << 63));
-}
-
-// stats[(seg*2)+0] = min key, +1 = max key; pre-filled with ~0 / 0.
-template <typename T>
-__global__ __launch_bounds__(256) void seg_minmax_kernel(const T* base, uint64_t seg_stride_elems,
-                                                         const uint32_t* seg_rows, uint32_t seg_first,
-                                                         unsigned long long* stats) {
-  const uint32_t seg = seg_first + blockIdx.y;
-  const T* col = base + (uint64_t)seg * seg_stride_elems;
-  const uint64_t n = seg_rows[blockIdx.y];
-  uint64_t lo = ~0ull, hi = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-    const uint64_t k = vh_order_key<T>(col[i]);
-    lo = k < lo ? k : lo;
-    hi = k > hi ? k : hi;
-  }
-  for (int off = 32; off > 0; off >>= 1) {
-    const uint64_t l2 = __shfl_down(lo, off), h2 = __shfl_down(hi, off);
-    lo = l2 < lo ? l2 : lo;
-    hi = h2 > hi ? h2 : hi;
-  }
-  if ((threadIdx.x & 63) == 0 && n) {
-    atomicMin(stats + 2ull * blockIdx.y, (unsigned long long)lo);
-    atomicMax(stats + 2ull * blockIdx.y + 1, (unsigned long long)hi);
-  }
-}
-
-// ------------------------------------------------------- bandwidth ceiling
-typedef uint32_t vh_u32x4 __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(256) void read_bw_kernel(const vh_u32x4* p, uint64_t n16, unsigned long long* sink) {
-  uint32_t acc = 0;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) {
-    const vh_u32x4 v = __builtin_nontemporal_load(p + i);
-    acc ^= v.x ^ v.y ^ v.z ^ v.w;
-  }
-  if (acc == 0x9E3779B9u) atomicAdd(sink, 1ull);  // defeat dead-code elimination
-}

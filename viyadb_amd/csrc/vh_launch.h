@@ -1,0 +1,11 @@
+// vh_launch.h — launch entry points of the scan kernels; each lives in its own translation unit so
+// the 30-odd template instantiations compile in parallel (viyadb_amd/build.py).
+#pragma once
+#include "vh_internal.h"
+
+void vh_launch_scan_generic(int mode, const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s);
+void vh_launch_scan_fast_lds(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s);
+void vh_launch_scan_fast_global(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s);
+void vh_launch_scan_fast_hash(const VhPlanDev& P, int grid, size_t lds, hipStream_t s);
+void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s);
+void vh_launch_part_agg(const VhPlanDev& P, int blocks_per_part, size_t lds, hipStream_t s);

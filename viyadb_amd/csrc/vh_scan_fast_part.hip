@@ -1,0 +1,16 @@
+// Fast scan kernel instantiations: radix-partitioned tuples (phase 1) + LDS aggregation (phase 2).
+#include "vh_kernels.h"
+#include "vh_launch.h"
+
+void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s) {
+  switch (P.npred) {
+    case 1: hipLaunchKernelGGL((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 1>), dim3(grid), dim3(256), lds, s, P); break;
+    case 2: hipLaunchKernelGGL((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 2>), dim3(grid), dim3(256), lds, s, P); break;
+    case 3: hipLaunchKernelGGL((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 3>), dim3(grid), dim3(256), lds, s, P); break;
+    default: hipLaunchKernelGGL((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 4>), dim3(grid), dim3(256), lds, s, P); break;
+  }
+}
+
+void vh_launch_part_agg(const VhPlanDev& P, int blocks_per_part, size_t lds, hipStream_t s) {
+  hipLaunchKernelGGL((part_agg_kernel<1024>), dim3(P.npart * blocks_per_part), dim3(1024), lds, s, P, blocks_per_part);
+}

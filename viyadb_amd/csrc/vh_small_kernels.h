@@ -1,0 +1,211 @@
+// vh_small_kernels.h — the non-hot kernels: table finalisation, group emission, synthetic data,
+// segment stats, bandwidth probe. Included by viya_hip.hip only (non-template __global__ symbols).
+#pragma once
+#include "vh_kernels.h"
+
+// ----------------------------------------------------------- table finalisation
+// Combine the per-XCD private copies of a dense table into copy 0 (they were only ever
+// touched through their own XCD's L2; the kernel boundary made them visible).
+__device__ __forceinline__ uint64_t vh_combine(int sop, uint64_t a, uint64_t b) {
+  switch (sop) {
+    case SOP_ADD32: return (uint32_t)((uint32_t)a + (uint32_t)b);
+    case SOP_ADD64: return a + b;
+    case SOP_ADDF32: return __float_as_uint(__uint_as_float((uint32_t)a) + __uint_as_float((uint32_t)b));
+    case SOP_ADDF64: return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
+    case SOP_MIN_I32: return (uint32_t)((int32_t)b < (int32_t)a ? b : a);
+    case SOP_MAX_I32: return (uint32_t)((int32_t)a < (int32_t)b ? b : a);
+    case SOP_MIN_U32: return (uint32_t)b < (uint32_t)a ? (uint32_t)b : (uint32_t)a;
+    case SOP_MAX_U32: return (uint32_t)a < (uint32_t)b ? (uint32_t)b : (uint32_t)a;
+    case SOP_MIN_I64: return (int64_t)b < (int64_t)a ? b : a;
+    case SOP_MAX_I64: return (int64_t)a < (int64_t)b ? b : a;
+    case SOP_MIN_U64: return b < a ? b : a;
+    case SOP_MAX_U64: return a < b ? b : a;
+    case SOP_MIN_F32: return __uint_as_float((uint32_t)b) < __uint_as_float((uint32_t)a) ? (uint32_t)b : (uint32_t)a;
+    case SOP_MAX_F32: return __uint_as_float((uint32_t)a) < __uint_as_float((uint32_t)b) ? (uint32_t)b : (uint32_t)a;
+    case SOP_MIN_F64: return __longlong_as_double((long long)b) < __longlong_as_double((long long)a) ? b : a;
+    default: return __longlong_as_double((long long)a) < __longlong_as_double((long long)b) ? b : a;
+  }
+}
+
+struct VhMergeArgs {
+  int32_t nmetric; int32_t nxcd;
+  uint64_t G; uint64_t xcd_stride;
+  uint8_t* present;
+  void* state[VH_MAX_METRIC];
+  uint8_t sop[VH_MAX_METRIC];
+};
+
+__global__ __launch_bounds__(256) void dense_merge_kernel(const VhMergeArgs A) {
+  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g >= A.G) return;
+  uint8_t p = A.present[g];
+  for (int x = 1; x < A.nxcd; ++x) p |= A.present[x * A.xcd_stride + g];
+  A.present[g] = p;
+  if (!p) return;
+  for (int j = 0; j < A.nmetric; ++j) {
+    const int sop = A.sop[j];
+    if (vh_sop_bytes(sop) == 4) {
+      uint32_t* s = reinterpret_cast<uint32_t*>(A.state[j]);
+      uint64_t a = s[g];
+      for (int x = 1; x < A.nxcd; ++x) a = vh_combine(sop, a, s[x * A.xcd_stride + g]);
+      s[g] = (uint32_t)a;
+    } else {
+      uint64_t* s = reinterpret_cast<uint64_t*>(A.state[j]);
+      uint64_t a = s[g];
+      for (int x = 1; x < A.nxcd; ++x) a = vh_combine(sop, a, s[x * A.xcd_stride + g]);
+      s[g] = a;
+    }
+  }
+}
+
+// Emit one (key columns, metric states) row per existing group into dense output arrays,
+// already in each column's own element type.
+struct VhEmitArgs {
+  int32_t mode;  // VH_MODE_*
+  int32_t ngroup; int32_t nmetric; int32_t key_words;
+  uint64_t n;    // dense: G; hash: capacity + 1
+  const uint8_t* present;
+  const uint64_t* hkeys; const uint32_t* htags;
+  const unsigned long long* counters;
+  unsigned long long* out_count;
+  uint64_t* out_gid;              // optional: table index of output row `pos` (bitset metrics)
+  VhGroupDev g[VH_MAX_GROUP];
+  void* out_key[VH_MAX_GROUP];
+  const void* state[VH_MAX_METRIC];
+  void* out_state[VH_MAX_METRIC];
+  uint8_t sop[VH_MAX_METRIC];
+  uint8_t mtype[VH_MAX_METRIC];   // output element type of metric j
+};
+
+__device__ __forceinline__ void vh_store_elem(void* base, int type, uint64_t idx, uint64_t bits) {
+  switch (type) {
+    case VH_U8: case VH_I8: reinterpret_cast<uint8_t*>(base)[idx] = (uint8_t)bits; break;
+    case VH_U16: case VH_I16: reinterpret_cast<uint16_t*>(base)[idx] = (uint16_t)bits; break;
+    case VH_U32: case VH_I32: case VH_F32: reinterpret_cast<uint32_t*>(base)[idx] = (uint32_t)bits; break;
+    default: reinterpret_cast<uint64_t*>(base)[idx] = bits; break;
+  }
+}
+
+__global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  bool have = false;
+  if (i < A.n) {
+    if (A.mode == VH_MODE_HASH) {
+      if (i + 1 == A.n) have = A.key_words == 1 && A.counters[3] != 0;  // reserved slot
+      else have = A.key_words == 1 ? A.hkeys[i] != VH_HASH_EMPTY : A.htags[i] == 2u;
+    } else {
+      have = A.present[i] != 0;
+    }
+  }
+  const uint64_t bal = __ballot(have);
+  if (bal == 0) return;
+  const int lane = threadIdx.x & 63;
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(A.out_count, (unsigned long long)__popcll(bal));
+  base = __shfl(base, 0);
+  if (!have) return;
+  const uint64_t pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+  if (A.out_gid) A.out_gid[pos] = i;
+  for (int c = 0; c < A.ngroup; ++c) {
+    const VhGroupDev& g = A.g[c];
+    uint64_t v;
+    if (A.mode == VH_MODE_HASH) {
+      uint64_t w = A.hkeys[i * A.key_words + g.key_word];
+      if (A.key_words == 1 && i + 1 == A.n) w = VH_HASH_EMPTY;
+      v = w >> g.key_shift;
+    } else {
+      v = g.lo + (i / g.stride) % g.extent;
+    }
+    vh_store_elem(A.out_key[c], g.type, pos, v);
+  }
+  for (int j = 0; j < A.nmetric; ++j) {
+    const uint64_t bits = vh_sop_bytes(A.sop[j]) == 4 ? reinterpret_cast<const uint32_t*>(A.state[j])[i]
+                                                      : reinterpret_cast<const uint64_t*>(A.state[j])[i];
+    vh_store_elem(A.out_state[j], A.mtype[j], pos, bits);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fill_kernel(T* p, uint64_t n, T v) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = v;
+}
+
+// ----------------------------------------------------------- synthetic data
+// value(c, r) = splitmix64(seed ^ c*GAMMA ^ r) reduced to the column domain.
+template <typename T>
+__global__ __launch_bounds__(256) void gen_kernel(T* base, uint64_t seg_stride_elems, uint64_t rows_per_seg,
+                                                  uint64_t row_base, vh_gen_spec spec, uint64_t colseed) {
+  const uint32_t seg = blockIdx.y;
+  T* col = base + (uint64_t)seg * seg_stride_elems;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < rows_per_seg; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t r = row_base + (uint64_t)seg * rows_per_seg + i;
+    T out;
+    if (spec.mode == VH_GEN_ROWID) {
+      out = (T)r;
+    } else if (spec.mode == VH_GEN_CONST) {
+      out = (T)spec.add;
+    } else {
+      const uint64_t h = vh_splitmix64(colseed ^ r);
+      const int64_t iv = spec.add + (int64_t)(h % spec.mod);
+      if (std::is_floating_point<T>::value) out = (T)((double)iv * spec.scale);
+      else out = (T)iv;
+    }
+    col[i] = out;
+  }
+}
+
+// ------------------------------------------------------------ segment stats
+// Order-preserving map of a column value to u64 so one pair of u64 atomics does min/max.
+template <typename T> __device__ __forceinline__ uint64_t vh_order_key(T v);
+template <> __device__ __forceinline__ uint64_t vh_order_key<uint8_t>(uint8_t v) { return v; }
+template <> __device__ __forceinline__ uint64_t vh_order_key<uint16_t>(uint16_t v) { return v; }
+template <> __device__ __forceinline__ uint64_t vh_order_key<uint32_t>(uint32_t v) { return v; }
+template <> __device__ __forceinline__ uint64_t vh_order_key<uint64_t>(uint64_t v) { return v; }
+template <> __device__ __forceinline__ uint64_t vh_order_key<int8_t>(int8_t v) { return (uint64_t)(int64_t)v ^ (1ull << 63); }
+template <> __device__ __forceinline__ uint64_t vh_order_key<int16_t>(int16_t v) { return (uint64_t)(int64_t)v ^ (1ull << 63); }
+template <> __device__ __forceinline__ uint64_t vh_order_key<int32_t>(int32_t v) { return (uint64_t)(int64_t)v ^ (1ull << 63); }
+template <> __device__ __forceinline__ uint64_t vh_order_key<int64_t>(int64_t v) { return (uint64_t)v ^ (1ull << 63); }
+template <> __device__ __forceinline__ uint64_t vh_order_key<float>(float v) {
+  const uint32_t b = __float_as_uint(v);
+  return (b & 0x80000000u) ? (uint32_t)~b : (b | 0x80000000u);
+}
+template <> __device__ __forceinline__ uint64_t vh_order_key<double>(double v) {
+  const uint64_t b = (uint64_t)__double_as_longlong(v);
+  return (b & (1ull << 63)) ? ~b : (b | (1ull << 63));
+}
+
+// stats[(seg*2)+0] = min key, +1 = max key; pre-filled with ~0 / 0.
+template <typename T>
+__global__ __launch_bounds__(256) void seg_minmax_kernel(const T* base, uint64_t seg_stride_elems,
+                                                         const uint32_t* seg_rows, uint32_t seg_first,
+                                                         unsigned long long* stats) {
+  const uint32_t seg = seg_first + blockIdx.y;
+  const T* col = base + (uint64_t)seg * seg_stride_elems;
+  const uint64_t n = seg_rows[blockIdx.y];
+  uint64_t lo = ~0ull, hi = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t k = vh_order_key<T>(col[i]);
+    lo = k < lo ? k : lo;
+    hi = k > hi ? k : hi;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint64_t l2 = __shfl_down(lo, off), h2 = __shfl_down(hi, off);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0 && n) {
+    atomicMin(stats + 2ull * blockIdx.y, (unsigned long long)lo);
+    atomicMax(stats + 2ull * blockIdx.y + 1, (unsigned long long)hi);
+  }
+}
+
+// ------------------------------------------------------- bandwidth ceiling
+typedef uint32_t vh_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void read_bw_kernel(const vh_u32x4* p, uint64_t n16, unsigned long long* sink) {
+  uint32_t acc = 0;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) {
+    const vh_u32x4 v = __builtin_nontemporal_load(p + i);
+    acc ^= v.x ^ v.y ^ v.z ^ v.w;
+  }
+  if (acc == 0x9E3779B9u) atomicAdd(sink, 1ull);  // defeat dead-code elimination
+}

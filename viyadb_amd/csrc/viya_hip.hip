@@ -9,7 +9,8 @@
 //   * choosing the aggregate-table organisation (the reference always uses
 //     std::unordered_map, scan.cc:174-177; here: LDS-resident dense table, per-XCD
 //     private dense tables in HBM/L2, or an open-addressing hash table in HBM).
-#include "vh_kernels.h"
+#include "vh_small_kernels.h"
+#include "vh_launch.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -538,29 +539,6 @@ struct ScratchPlan {
   size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; }
 };
 
-template <int MODE, int BLOCK>
-static void launch_scan(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s) {
-  if (xcd_private)
-    hipLaunchKernelGGL((scan_agg_kernel<MODE, BLOCK, __HIP_MEMORY_SCOPE_WORKGROUP>), dim3(grid), dim3(BLOCK), lds, s, P);
-  else
-    hipLaunchKernelGGL((scan_agg_kernel<MODE, BLOCK, __HIP_MEMORY_SCOPE_AGENT>), dim3(grid), dim3(BLOCK), lds, s, P);
-}
-
-template <int MODE, int BLOCK, int SCOPE>
-static void launch_fast_np(const VhPlanDev& P, int grid, size_t lds, hipStream_t s) {
-  switch (P.npred) {
-    case 1: hipLaunchKernelGGL((scan_agg_fast_kernel<MODE, BLOCK, SCOPE, 1>), dim3(grid), dim3(BLOCK), lds, s, P); break;
-    case 2: hipLaunchKernelGGL((scan_agg_fast_kernel<MODE, BLOCK, SCOPE, 2>), dim3(grid), dim3(BLOCK), lds, s, P); break;
-    case 3: hipLaunchKernelGGL((scan_agg_fast_kernel<MODE, BLOCK, SCOPE, 3>), dim3(grid), dim3(BLOCK), lds, s, P); break;
-    default: hipLaunchKernelGGL((scan_agg_fast_kernel<MODE, BLOCK, SCOPE, 4>), dim3(grid), dim3(BLOCK), lds, s, P); break;
-  }
-}
-template <int MODE, int BLOCK>
-static void launch_scan_fast(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s) {
-  if (xcd_private) launch_fast_np<MODE, BLOCK, __HIP_MEMORY_SCOPE_WORKGROUP>(P, grid, lds, s);
-  else launch_fast_np<MODE, BLOCK, __HIP_MEMORY_SCOPE_AGENT>(P, grid, lds, s);
-}
-
 static int fill_states(void* p, uint64_t n, int bytes, uint64_t ident, hipStream_t s) {
   if (ident == 0) { HIP_TRY(hipMemsetAsync(p, 0, n * bytes, s)); return VH_OK; }
   const int grid = (int)std::min<uint64_t>(2048, (n + 255) / 256);
@@ -570,7 +548,7 @@ static int fill_states(void* p, uint64_t n, int bytes, uint64_t ident, hipStream
 }
 
 static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, uint64_t hash_capacity_override,
-                               bool force_hash) {
+                               bool force_hash, uint64_t part_tuples_override = 0, bool no_part = false) {
   // ---------------- validate
   if (p->nfilter > VH_MAX_PROG) return vh_fail(VH_E_UNSUPPORTED, "filter has %d nodes (max %d)", p->nfilter, VH_MAX_PROG);
   if (p->nlits > VH_MAX_LITS) return vh_fail(VH_E_UNSUPPORTED, "filter has %d literals (max %d)", p->nlits, VH_MAX_LITS);
@@ -792,13 +770,56 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   } else {
     mode = VH_MODE_HASH;
   }
+  const bool fast = fast_ok && P.npred >= 1 && P.ngroup <= VH_FAST_COLS && P.nmetric <= VH_FAST_COLS && P.nbitset == 0;
+  // Global atomics are written through to the fabric one by one; when the group-id space is too big
+  // for one LDS table but splits into <= VH_MAX_PART LDS-sized ranges, radix-partition the survivors
+  // and aggregate each range in LDS instead (DENSE_PART).
+  uint64_t part_tuple_cap = 0;
+  if (mode == VH_MODE_DENSE_GLOBAL && fast && !no_part && !(p->flags & (VH_PLAN_NO_PART | VH_PLAN_FORCE_GLOBAL)) && P.nmetric >= 1) {
+    int shift = 0;
+    while (((size_t)2 << shift) * state_bytes_per_group <= 56 * 1024) ++shift;
+    const uint64_t np = (G + (1ull << shift) - 1) >> shift;
+    if (np <= VH_MAX_PART && G <= 0xFFFFFFFFull) {
+      mode = VH_MODE_DENSE_PART;
+      P.part_shift = shift;
+      P.npart = (int32_t)np;
+      // tuple words: word 0 = gid | first 32-bit value << 32; 64-bit values own a word; 32-bit values pair up
+      int tw = 1, half_free_word = 0;  // word 0 has its upper half free
+      bool have_half = true;
+      for (int j = 0; j < P.nmetric; ++j) {
+        if (vh_sop_bytes(P.m[j].sop) == 8) { P.m[j].tword = (uint8_t)tw++; P.m[j].tshift = 0; }
+        else if (have_half) { P.m[j].tword = (uint8_t)half_free_word; P.m[j].tshift = 32; have_half = false; }
+        else { P.m[j].tword = (uint8_t)tw; P.m[j].tshift = 0; half_free_word = tw++; have_half = true; }
+      }
+      P.tw = tw;
+      int cap = 16;
+      while (cap > 4 && 4 * ((size_t)P.npart * ((size_t)cap * tw * 8 + 12) + 16) + 4 * VhScanCfg<256>::kQueueCap * 4 > 40 * 1024) cap /= 2;
+      P.stage_cap = cap;
+      // phase-2 LDS table for one partition
+      const uint64_t gpp = 1ull << shift;
+      size_t off = 0;
+      for (int pass = 0; pass < 2; ++pass)
+        for (int j = 0; j < P.nmetric; ++j) {
+          const int b = vh_sop_bytes(P.m[j].sop);
+          if ((pass == 0) != (b == 8)) continue;
+          P.m[j].lds_off = (uint32_t)off; off += gpp * b;
+        }
+      off = (off + 7) / 8 * 8;
+      P.lds_present_off = (uint32_t)off; off += gpp;
+      lds_table = (off + 15) / 16 * 16;
+      P.lds_bytes = (uint32_t)lds_table;
+      part_tuple_cap = part_tuples_override ? part_tuples_override : std::max<uint64_t>(rows_to_scan / 8, 1ull << 16);
+      part_tuple_cap = std::min<uint64_t>(part_tuple_cap, rows_to_scan + 1);
+    }
+  }
   r->mode = mode;
   r->info.path = mode == VH_MODE_DENSE_LDS ? (p->ngroups ? VH_PATH_DENSE_LDS : VH_PATH_SCALAR)
-               : mode == VH_MODE_DENSE_GLOBAL ? VH_PATH_DENSE_GLOBAL : VH_PATH_HASH;
+               : mode == VH_MODE_DENSE_GLOBAL ? VH_PATH_DENSE_GLOBAL : mode == VH_MODE_DENSE_PART ? VH_PATH_DENSE_PART : VH_PATH_HASH;
 
   // per-XCD private copies only while they stay cache-sized
   int nxcd = 1;
-  if (mode != VH_MODE_HASH && !(p->flags & VH_PLAN_NO_XCD_PRIVATE) && G * state_bytes_per_group * g_ctx.num_xcd <= (64ull << 20))
+  if (mode != VH_MODE_HASH && mode != VH_MODE_DENSE_PART && !(p->flags & VH_PLAN_NO_XCD_PRIVATE) &&
+      G * state_bytes_per_group * g_ctx.num_xcd <= (64ull << 20))
     nxcd = g_ctx.num_xcd;
   P.nxcd = nxcd; r->nxcd = nxcd;
   P.xcd_stride = (G + 63) / 64 * 64;
@@ -818,14 +839,21 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   const int BLOCK = mode == VH_MODE_DENSE_LDS ? 1024 : 256;
   const uint32_t step = BLOCK * 16;
   const uint64_t padded = (t->segment_rows + step - 1) / step * step;
+  // all blocks co-resident (the kernels need ~100-130 VGPRs: 4 waves/SIMD), units small enough
+  // that the static round-robin leaves < 2 % imbalance
+  static const int env_bpc = getenv("VH_BLOCKS_PER_CU") ? atoi(getenv("VH_BLOCKS_PER_CU")) : 0;
+  static const int env_unit = getenv("VH_UNIT_ROWS") ? atoi(getenv("VH_UNIT_ROWS")) : 0;
+  const int blocks_per_cu = env_bpc > 0 ? env_bpc : (BLOCK == 1024 ? 1 : 4);
   uint32_t unit_rows = step;
-  const uint64_t want_units = (uint64_t)g_ctx.num_cu * (BLOCK == 1024 ? 2 : 8) * 4;
+  const uint64_t want_units = (uint64_t)g_ctx.num_cu * blocks_per_cu * 64;
   while (unit_rows * 2 <= 65536 && unit_rows * 2 <= padded &&
          (uint64_t)nseg * ((padded + unit_rows * 2 - 1) / (unit_rows * 2)) >= want_units) unit_rows *= 2;
+  if (env_unit >= (int)step) unit_rows = (uint32_t)env_unit / step * step;
   P.unit_rows = unit_rows;
   P.units_per_seg = (uint32_t)((t->segment_rows + unit_rows - 1) / unit_rows);
   P.nseg = nseg;
   P.total_units = nseg * P.units_per_seg;
+  const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(P.total_units, (uint64_t)g_ctx.num_cu * blocks_per_cu));
 
   // ---------------- scratch layout
   ScratchPlan sp;
@@ -843,6 +871,21 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   for (int j = 0; j < P.nmetric; ++j) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop));
   // outputs
   r->out_cap = mode == VH_MODE_HASH ? capacity + 1 : G;
+  size_t o_tuples = 0, o_pcount = 0, o_pext = 0, o_emiss = 0;
+  if (mode == VH_MODE_DENSE_PART) {
+    const uint64_t ext_tuples = (uint64_t)VH_EXT_FLUSHES * P.stage_cap;
+    const uint64_t waves = (uint64_t)grid * 4;
+    uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
+    if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
+    P.max_extents = (uint32_t)max_ext;
+    uint64_t pcap = max_ext;                                  // skew-proof: one partition may take every extent
+    if (pcap * P.npart * 4 > (512ull << 20)) pcap = std::max<uint64_t>((512ull << 20) / (4ull * P.npart), max_ext / P.npart * 4);
+    P.part_cap = (uint32_t)std::min<uint64_t>(pcap, max_ext);
+    o_tuples = sp.take(max_ext * ext_tuples * P.tw * 8);
+    o_pcount = sp.take(VH_MAX_PART * sizeof(uint32_t));
+    o_pext = sp.take((uint64_t)P.npart * P.part_cap * sizeof(uint32_t));
+    o_emiss = sp.take(max_ext * sizeof(uint16_t));
+  }
   size_t o_pairs = 0, o_outgid = 0, o_bsptr[VH_MAX_BITSET][2] = {};
   if (P.nbitset) {
     o_pairs = sp.take(std::max<uint64_t>(pair_cap, 1) * 16);
@@ -866,6 +909,12 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   }
   for (int j = 0; j < P.nmetric; ++j) P.m[j].state = S + o_state[j];
   r->d_out_count = reinterpret_cast<unsigned long long*>(S + o_outcount);
+  if (mode == VH_MODE_DENSE_PART) {
+    P.tuples = reinterpret_cast<uint64_t*>(S + o_tuples);
+    P.part_count = reinterpret_cast<uint32_t*>(S + o_pcount);
+    P.part_extents = reinterpret_cast<uint32_t*>(S + o_pext);
+    P.extent_missing = reinterpret_cast<uint16_t*>(S + o_emiss);
+  }
   if (P.nbitset) {
     P.pairs = reinterpret_cast<uint64_t*>(S + o_pairs);
     r->d_out_gid = reinterpret_cast<uint64_t*>(S + o_outgid);
@@ -894,26 +943,29 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   } else {
     HIP_TRY(hipMemsetAsync(P.present, 0, table_n, st));
   }
+  if (mode == VH_MODE_DENSE_PART) {
+    HIP_TRY(hipMemsetAsync(P.part_count, 0, VH_MAX_PART * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(P.extent_missing, 0, (size_t)P.max_extents * sizeof(uint16_t), st));
+  }
   for (int j = 0; j < P.nmetric; ++j) {
     rc = fill_states(P.m[j].state, table_n, vh_sop_bytes(P.m[j].sop), P.m[j].ident, st);
     if (rc) { delete r; return rc; }
   }
-  const int blocks_per_cu = BLOCK == 1024 ? 2 : 8;
-  const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(P.total_units, (uint64_t)g_ctx.num_cu * blocks_per_cu));
-  const size_t qbytes = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint16_t);
+  const size_t qbytes = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint32_t);
   HIP_TRY(hipEventRecord(t->ev[1], st));
-  const bool fast = fast_ok && P.npred >= 1 && P.ngroup <= VH_FAST_COLS && P.nmetric <= VH_FAST_COLS && P.nbitset == 0;
   r->info.reserved = fast ? 1 : 0;
   if (P.total_units) {
-    if (fast) {
-      if (mode == VH_MODE_DENSE_LDS) launch_scan_fast<VH_MODE_DENSE_LDS, 1024>(P, grid, lds_table + qbytes, nxcd > 1, st);
-      else if (mode == VH_MODE_DENSE_GLOBAL) launch_scan_fast<VH_MODE_DENSE_GLOBAL, 256>(P, grid, qbytes, nxcd > 1, st);
-      else launch_scan_fast<VH_MODE_HASH, 256>(P, grid, qbytes, false, st);
-    } else {
-      if (mode == VH_MODE_DENSE_LDS) launch_scan<VH_MODE_DENSE_LDS, 1024>(P, grid, lds_table + qbytes, nxcd > 1, st);
-      else if (mode == VH_MODE_DENSE_GLOBAL) launch_scan<VH_MODE_DENSE_GLOBAL, 256>(P, grid, qbytes, nxcd > 1, st);
-      else launch_scan<VH_MODE_HASH, 256>(P, grid, qbytes, false, st);
+    const size_t lds = (mode == VH_MODE_DENSE_LDS ? lds_table : 0) + qbytes;
+    if (mode == VH_MODE_DENSE_PART) {
+      const size_t wave_area = ((size_t)P.npart * ((size_t)P.stage_cap * P.tw * 8 + 12) + 15) / 16 * 16;
+      vh_launch_scan_fast_part(P, grid, qbytes + 4 * wave_area, st);
+      const int bpp = std::max(1, std::min(16, g_ctx.num_cu / std::max(1, P.npart)));
+      vh_launch_part_agg(P, bpp, lds_table, st);
     }
+    else if (!fast) vh_launch_scan_generic(mode, P, grid, lds, nxcd > 1, st);
+    else if (mode == VH_MODE_DENSE_LDS) vh_launch_scan_fast_lds(P, grid, lds, nxcd > 1, st);
+    else if (mode == VH_MODE_DENSE_GLOBAL) vh_launch_scan_fast_global(P, grid, lds, nxcd > 1, st);
+    else vh_launch_scan_fast_hash(P, grid, lds, st);
   }
   HIP_TRY(hipEventRecord(t->ev[2], st));
   HIP_TRY(hipGetLastError());
@@ -968,7 +1020,7 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   hipStream_t st = g_ctx.stream;
   *retry = 0;
   VhEmitArgs A{};
-  A.mode = r->mode; A.ngroup = P.ngroup; A.nmetric = P.nmetric; A.key_words = P.key_words;
+  A.mode = r->mode == VH_MODE_DENSE_PART ? VH_MODE_DENSE_GLOBAL : r->mode; A.ngroup = P.ngroup; A.nmetric = P.nmetric; A.key_words = P.key_words;
   A.n = r->out_cap; A.present = P.present; A.hkeys = P.hkeys; A.htags = P.htags; A.counters = P.counters;
   A.out_count = r->d_out_count;
   A.out_gid = r->d_out_gid;
@@ -984,6 +1036,7 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   HIP_TRY(hipStreamSynchronize(st));
   const unsigned long long err = t->h_counters[2];
   if (err & VH_ERR_HASH_FULL) { *retry = 1; return VH_OK; }
+  if (err & VH_ERR_PART_FULL) { *retry = 3; return VH_OK; }
   if (err & VH_ERR_RANGE) { *retry = 2; return VH_OK; }
   const uint64_t ng = t->h_counters[4];
   r->info.ngroups = ng;
@@ -1053,17 +1106,21 @@ extern "C" int vh_result_finalize(vh_result* r) {
 extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
   if (!t || !plan || !out) return vh_fail(VH_E_INVALID, "null argument");
   std::lock_guard<std::mutex> lk(t->mu);
-  uint64_t cap_override = 0;
-  bool force_hash = false;
+  uint64_t cap_override = 0, part_override = 0;
+  bool force_hash = false, no_part = false;
   for (uint32_t attempt = 0; attempt < 12; ++attempt) {
     vh_result* r = nullptr;
-    int rc = query_launch_locked(t, plan, &r, cap_override, force_hash);
+    int rc = query_launch_locked(t, plan, &r, cap_override, force_hash, part_override, no_part);
     if (rc) return rc;
     int retry = 0;
     rc = result_finalize_locked(r, &retry);
     if (rc) { delete r; return rc; }
     if (!retry) { r->info.retries = attempt; *out = r; return VH_OK; }
     if (retry == 1) cap_override = (r->plan.hmask + 1) * 4;   // table too small: regrow
+    else if (retry == 3) {                                     // tuple extents exhausted: more room, then give up on partitioning
+      const uint64_t had = (uint64_t)r->plan.max_extents * VH_EXT_FLUSHES * r->plan.stage_cap;
+      if (part_override && had >= r->info.scanned_recs) no_part = true; else part_override = had * 4;
+    }
     else force_hash = true;                                    // a digit left its planned range
     delete r;
   }
