@@ -134,8 +134,12 @@ enum vh_plan_flags {
   VH_PLAN_FORCE_GLOBAL = 1u << 1, /* testing: dense table in HBM, not LDS   */
   VH_PLAN_NO_XCD_PRIVATE = 1u << 2,/* testing: one device-scope dense table */
   VH_PLAN_NO_FAST = 1u << 3,      /* testing: always the generic scan kernel */
-  VH_PLAN_NO_PART = 1u << 4       /* testing: direct global atomics instead of
+  VH_PLAN_NO_PART = 1u << 4,      /* testing: direct global atomics instead of
                                      radix-partitioned LDS aggregation        */
+  VH_PLAN_NO_CARRIER = 1u << 5,   /* testing: separate presence bytes even when a
+                                     32-bit SUM state could carry the flag    */
+  VH_PLAN_FORCE_PART = 1u << 6    /* testing: radix-partitioned aggregation
+                                     regardless of the estimated selectivity  */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */

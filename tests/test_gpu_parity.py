@@ -30,8 +30,9 @@ def test_workload_ragged(name, flags):
     check_workload(w, nseg=4, rows_per_seg=99_991, flags=flags)
 
 
-@pytest.mark.parametrize("flags,path", [(0, "dense_part"), (16, "dense_global"), (20, "dense_global"), (1, "hash"), (4, "dense_part"),
-                                        (2, "dense_global"), (8, "dense_global"), (9, "hash"), (12, "dense_global")])
+@pytest.mark.parametrize("flags,path", [(0, "dense_global"), (64, "dense_part"), (16, "dense_global"), (20, "dense_global"), (48, "dense_global"),
+                                        (1, "hash"), (68, "dense_part"), (2, "dense_global"), (8, "dense_global"), (9, "hash"), (12, "dense_global"),
+                                        (40, "dense_global")])
 def test_c3_table_organisations(flags, path):
     """Same query through: radix-partitioned LDS aggregation, per-XCD private dense tables with global
     atomics, one device-scope dense table, the open-addressing hash table; fast and generic scan kernels."""

@@ -17,7 +17,6 @@
 #define VH_MAX_PRED 4     // fast path: distinct 4-byte predicate columns held in registers
 #define VH_FAST_COLS 4    // fast path: group / metric columns gathered up front
 #define VH_MAX_PART 32     // DENSE_PART: partitions (one LDS staging buffer per wave and partition)
-#define VH_EXT_FLUSHES 4  // DENSE_PART: staging flushes per extent
 #define VH_EXT_CHUNK 8    // DENSE_PART: extents a wave reserves per global allocation
 
 // Row geometry of one block step (see DESIGN.md "scan geometry"):
@@ -36,7 +35,10 @@ enum vh_state_op : uint8_t {
   SOP_MIN_I32, SOP_MAX_I32, SOP_MIN_U32, SOP_MAX_U32,
   SOP_MIN_I64, SOP_MAX_I64, SOP_MIN_U64, SOP_MAX_U64,
   SOP_MIN_F32, SOP_MAX_F32, SOP_MIN_F64, SOP_MAX_F64,
-  SOP_BITSET      // emit (group, value) pairs; handled out of line
+  SOP_BITSET,     // emit (group, value) pairs; handled out of line
+  SOP_ADD32P      // 32-bit integer += widened to a 64-bit word that also counts rows in its upper half:
+                  // state += (1 << 32) | v. Low half = the wrapped 32-bit sum, word != 0 <=> group exists,
+                  // so the dense HBM table needs no separate presence store (one write transaction less per row)
 };
 
 struct VhProgOp {      // 8 bytes
@@ -106,6 +108,8 @@ struct VhPlanDev {
   uint64_t G;                // dense: number of group ids
   uint64_t xcd_stride;       // dense-global: elements between per-XCD copies
   uint8_t* present;          // dense: G (x nxcd) presence bytes
+  int32_t present_carrier;   // >= 0: metric whose SOP_ADD32P state doubles as the presence flag
+  int32_t pad3;
   uint32_t lds_present_off;  // DENSE_LDS: byte offset of presence words
   uint32_t lds_bytes;        // DENSE_LDS: total dynamic LDS
   // ---- hash
@@ -113,7 +117,7 @@ struct VhPlanDev {
   uint32_t* htags;           // wide keys: slot state words
   uint64_t hmask;            // capacity - 1
   uint32_t max_probe;
-  uint32_t pad0;
+  uint32_t debug;            // experiment knobs (env VH_DEBUG), 0 in production
   // ---- bitset metrics (COUNT DISTINCT): per-row id sets mirrored as CSR per segment; the scan
   // emits (metric|group, id) pairs, the distinct count is finished after the scan
   int32_t nbitset;
@@ -128,7 +132,9 @@ struct VhPlanDev {
   int32_t part_shift;        // groups per partition = 1 << part_shift
   int32_t tw;                // 64-bit words per tuple (word 0 low half = gid)
   int32_t stage_cap;         // tuples per (wave, partition) LDS staging buffer = one flush
-  uint64_t* tuples;          // max_extents x VH_EXT_FLUSHES x stage_cap x tw words
+  int32_t ext_flushes;       // flushes per extent (extent = ext_flushes x stage_cap tuples, <= 4096)
+  int32_t ext_tuples;        // tuples per extent; stage_cap == 0: tuples are scattered straight into the extent
+  uint64_t* tuples;          // max_extents x ext_flushes x stage_cap x tw words
   uint32_t* part_count;      // [npart] extents recorded per partition
   uint32_t* part_extents;    // [npart][part_cap] extent ids
   uint16_t* extent_missing;  // [max_extents] tuples NOT filled in an extent (0 = full)

@@ -258,6 +258,10 @@ __device__ __forceinline__ void vh_state_update(void* state, uint64_t idx, int s
       __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(state) + idx, (unsigned long long)bits,
                              __ATOMIC_RELAXED, SCOPE);
       break;
+    case SOP_ADD32P:
+      __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(state) + idx,
+                             (1ull << 32) | (unsigned long long)(uint32_t)bits, __ATOMIC_RELAXED, SCOPE);
+      break;
     case SOP_ADDF32:
       __hip_atomic_fetch_add(reinterpret_cast<float*>(state) + idx, __uint_as_float((uint32_t)bits),
                              __ATOMIC_RELAXED, SCOPE);
@@ -435,7 +439,7 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
   if (MODE == VH_MODE_DENSE_LDS) {
     if (active) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[gid] = 1;
   } else if (MODE == VH_MODE_DENSE_GLOBAL) {
-    if (active) P.present[xoff + gid] = 1;
+    if (active && P.present_carrier < 0) P.present[xoff + gid] = 1;
   }
   // bitset metrics: Metrics::Update does `_j |= metrics._j` (store.cc:153-155); here every id of the
   // row's set is emitted as a (metric|group, id) pair and the union's cardinality is taken afterwards
@@ -591,10 +595,12 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
 // per (wave, partition) in LDS and flushed in 128-256 B pieces into per-partition extents in HBM;
 // part_agg_kernel then aggregates every partition with LDS atomics only.
 struct VhPartWave {
-  uint64_t* stage;     // [npart][stage_cap][tw]
-  uint32_t* scnt;      // [npart] staged tuples (may overshoot stage_cap while a flush is pending)
-  uint32_t* ext_base;  // [npart] current extent id or ~0u
-  uint32_t* ext_used;  // [npart] flushes already written into the current extent
+  uint64_t* stage;     // LDS [npart][stage_cap][tw]
+  uint32_t* scnt;      // LDS [npart] staged tuples (may overshoot stage_cap while a flush is pending);
+                       //     unstaged variant: tuples written into the current extent
+  uint32_t* ext_base;  // LDS [npart] current extent id or ~0u (unstaged variant only)
+  uint32_t r_ext;      // staged variant: lane p holds partition p's current extent id (~0u: none) ...
+  uint32_t r_used;     // ... and the flushes already written into it (bookkeeping without LDS round trips)
   uint32_t chunk_next, chunk_end;
 };
 
@@ -606,46 +612,59 @@ __device__ __forceinline__ void vh_part_wave_init(const VhPlanDev& P, char* area
   W.stage = reinterpret_cast<uint64_t*>(area);
   W.scnt = reinterpret_cast<uint32_t*>(area + (size_t)P.npart * P.stage_cap * P.tw * 8);
   W.ext_base = W.scnt + P.npart;
-  W.ext_used = W.ext_base + P.npart;
   W.chunk_next = W.chunk_end = 0;
-  if (lane < P.npart) { W.scnt[lane] = 0; W.ext_base[lane] = ~0u; W.ext_used[lane] = 0; }
+  W.r_ext = ~0u;
+  W.r_used = 0;
+  if (lane < P.npart) { W.scnt[lane] = 0; W.ext_base[lane] = ~0u; }
   __builtin_amdgcn_wave_barrier();
+}
+
+// Open a new extent for partition p (wave-uniform). Returns ~0u when the buffer is exhausted.
+__device__ __forceinline__ uint32_t vh_part_new_extent(const VhPlanDev& P, VhPartWave& W, int p, int lane) {
+  if (W.chunk_next == W.chunk_end) {
+    unsigned long long c = 0;
+    if (lane == 0) c = atomicAdd(P.counters + 5, (unsigned long long)VH_EXT_CHUNK);
+    c = __shfl(c, 0);
+    W.chunk_next = (uint32_t)c;
+    W.chunk_end = (uint32_t)c + VH_EXT_CHUNK;
+  }
+  const uint32_t ext = W.chunk_next++;
+  bool ok = ext < P.max_extents;
+  if (ok && lane == 0) {
+    const uint32_t pos = atomicAdd(P.part_count + p, 1u);
+    if (pos < P.part_cap) P.part_extents[(uint64_t)p * P.part_cap + pos] = ext; else ok = false;
+  }
+  ok = __shfl((int)ok, 0) != 0 && ext < P.max_extents;
+  if (!ok) {
+    if (lane == 0) atomicOr(P.counters + 2, VH_ERR_PART_FULL);  // the host re-runs with a larger tuple buffer
+    return ~0u;
+  }
+  return ext;
 }
 
 // Write the first n staged tuples of partition p (wave-uniform p, n) to HBM.
 __device__ __forceinline__ void vh_part_flush(const VhPlanDev& P, VhPartWave& W, int p, uint32_t n, int lane) {
-  uint32_t ext = W.ext_base[p], used = W.ext_used[p];
-  if (ext == ~0u || used == VH_EXT_FLUSHES) {
-    if (W.chunk_next == W.chunk_end) {
-      unsigned long long c = 0;
-      if (lane == 0) c = atomicAdd(P.counters + 5, (unsigned long long)VH_EXT_CHUNK);
-      c = __shfl(c, 0);
-      W.chunk_next = (uint32_t)c;
-      W.chunk_end = (uint32_t)c + VH_EXT_CHUNK;
-    }
-    ext = W.chunk_next++;
+  if (P.debug & 4) { if (lane == 0) W.scnt[p] = 0; __builtin_amdgcn_wave_barrier(); return; }  // experiment: drop flushes
+  uint32_t ext = __builtin_amdgcn_readlane(W.r_ext, p), used = __builtin_amdgcn_readlane(W.r_used, p);
+  if (ext == ~0u || used == (uint32_t)P.ext_flushes) {
+    ext = vh_part_new_extent(P, W, p, lane);
     used = 0;
-    bool ok = ext < P.max_extents;
-    if (ok && lane == 0) {
-      const uint32_t pos = atomicAdd(P.part_count + p, 1u);
-      if (pos < P.part_cap) P.part_extents[(uint64_t)p * P.part_cap + pos] = ext; else ok = false;
-    }
-    ok = __shfl((int)ok, 0) != 0 && ext < P.max_extents;
-    if (!ok) {  // out of space: the host re-runs with a larger tuple buffer
-      if (lane == 0) { atomicOr(P.counters + 2, VH_ERR_PART_FULL); W.scnt[p] = 0; W.ext_base[p] = ~0u; }
+    if (lane == p) { W.r_ext = ext; W.r_used = 0; }
+    if (ext == ~0u) {
+      if (lane == 0) W.scnt[p] = 0;
       __builtin_amdgcn_wave_barrier();
       return;
     }
-    if (lane == 0) W.ext_base[p] = ext;
   }
   const uint32_t tw = (uint32_t)P.tw, cap = (uint32_t)P.stage_cap;
-  uint64_t* dst = P.tuples + ((uint64_t)ext * VH_EXT_FLUSHES + used) * cap * tw;
+  uint64_t* dst = P.tuples + ((uint64_t)ext * (uint32_t)P.ext_flushes + used) * cap * tw;
   const uint64_t* src = W.stage + (size_t)p * cap * tw;
-  for (uint32_t i = lane; i < n * tw; i += 64) dst[i] = src[i];
+  if (!(P.debug & 2))
+    for (uint32_t i = lane; i < n * tw; i += 64) dst[i] = src[i];
+  if (lane == p) W.r_used = n < cap ? (uint32_t)P.ext_flushes : used + 1;  // a partial flush closes the extent
   if (lane == 0) {
-    W.ext_used[p] = used + 1;
     W.scnt[p] = 0;
-    if (n < cap) P.extent_missing[ext] = (uint16_t)((VH_EXT_FLUSHES - used) * cap - n);
+    if (n < cap) P.extent_missing[ext] = (uint16_t)(((uint32_t)P.ext_flushes - used) * cap - n);
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -674,18 +693,64 @@ __device__ __forceinline__ void vh_part_append(const VhPlanDev& P, VhPartWave& W
   }
 }
 
+// Unstaged variant (stage_cap == 0): every survivor stores its tuple straight into the current extent of
+// its partition; the slot comes from an LDS counter per (wave, partition), so tuples of one partition
+// written by one drain are adjacent and leave as one write request.
+__device__ __forceinline__ void vh_part_scatter(const VhPlanDev& P, VhPartWave& W, bool active, uint32_t p,
+                                                const uint64_t (&words)[1 + VH_FAST_COLS], int lane) {
+  bool pending = active;
+  const uint32_t et = (uint32_t)P.ext_tuples, tw = (uint32_t)P.tw;
+  while (__ballot(pending)) {
+    uint32_t pos = 0, ext = ~0u;
+    if (pending) { pos = atomicAdd(W.scnt + p, 1u); ext = W.ext_base[p]; }
+    if (pending && ext != ~0u && pos < et) {
+      uint64_t* d = P.tuples + ((uint64_t)ext * et + pos) * tw;
+      if (tw == 2) {
+        typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+        u64x2 v; v.x = words[0]; v.y = words[1];
+        *reinterpret_cast<u64x2*>(d) = v;
+      } else {
+#pragma unroll
+        for (int w = 0; w < 1 + VH_FAST_COLS; ++w)
+          if ((uint32_t)w < tw) d[w] = words[w];
+      }
+      pending = false;
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint64_t need = __ballot(pending);
+    while (need) {  // rare: a partition's extent is full (or was never opened): open a new one
+      const int src = __builtin_ctzll(need);
+      const uint32_t np = (uint32_t)__shfl((int)p, src);
+      need &= ~__ballot(pending && p == np);
+      const uint32_t next = vh_part_new_extent(P, W, (int)np, lane);
+      const bool ok = next != ~0u;
+      if (!ok) {
+        if (pending && p == np) pending = false;  // dropped: the host re-runs with more room
+      } else if (lane == 0) {
+        W.ext_base[np] = next;
+        W.scnt[np] = 0;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+__device__ __forceinline__ void vh_part_scatter_finish(const VhPlanDev& P, VhPartWave& W, int lane) {
+  if (lane < P.npart) {
+    const uint32_t ext = W.ext_base[lane], n = W.scnt[lane];
+    if (ext != ~0u && n < (uint32_t)P.ext_tuples) P.extent_missing[ext] = (uint16_t)((uint32_t)P.ext_tuples - n);
+  }
+}
+
 // end of kernel: flush partial staging buffers and publish how much of each open extent is valid
 __device__ __forceinline__ void vh_part_finish(const VhPlanDev& P, VhPartWave& W, int lane) {
   for (int p = 0; p < P.npart; ++p) {
     const uint32_t n = W.scnt[p];
-    if (n) {
-      vh_part_flush(P, W, p, n < (uint32_t)P.stage_cap ? n : (uint32_t)P.stage_cap, lane);
-    } else {
-      const uint32_t ext = W.ext_base[p], used = W.ext_used[p];
-      if (ext != ~0u && used < VH_EXT_FLUSHES && lane == 0)
-        P.extent_missing[ext] = (uint16_t)((VH_EXT_FLUSHES - used) * P.stage_cap);
-    }
+    if (n) vh_part_flush(P, W, p, n < (uint32_t)P.stage_cap ? n : (uint32_t)P.stage_cap, lane);
   }
+  // open extents whose last flush was a full one still have unused room
+  if (lane < P.npart && W.r_ext != ~0u && W.r_used < (uint32_t)P.ext_flushes)
+    P.extent_missing[W.r_ext] = (uint16_t)(((uint32_t)P.ext_flushes - W.r_used) * (uint32_t)P.stage_cap);
 }
 
 // =====================================================================================
@@ -860,13 +925,15 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
           if (m.tword == w) words[w] |= v;
       }
     }
-    vh_part_append(P, W, active, (uint32_t)(gid >> P.part_shift), words, (int)(threadIdx.x & 63));
+    if (P.debug & 1) { if (active && words[1] == 0x123456789ull) P.tuples[0] = words[0]; return; }  // experiment: no staging
+    if (P.stage_cap == 0) vh_part_scatter(P, W, active, (uint32_t)(gid >> P.part_shift), words, (int)(threadIdx.x & 63));
+    else vh_part_append(P, W, active, (uint32_t)(gid >> P.part_shift), words, (int)(threadIdx.x & 63));
     return;
   }
   if (MODE == VH_MODE_DENSE_LDS) {
     if (active) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[gid] = 1;
   } else if (MODE == VH_MODE_DENSE_GLOBAL) {
-    if (active) P.present[xoff + gid] = 1;
+    if (active && P.present_carrier < 0) P.present[xoff + gid] = 1;
   }
 #pragma unroll
   for (int j = 0; j < VH_FAST_COLS; ++j) {
@@ -975,7 +1042,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
     have = nhave; seg = nseg; unit_base = nunit_base; wave_base = nwave_base; seg_rows = nseg_rows;
   }
 
-  if (MODE == VH_MODE_DENSE_PART) vh_part_finish(P, W, lane);
+  if (MODE == VH_MODE_DENSE_PART) { if (P.stage_cap == 0) vh_part_scatter_finish(P, W, lane); else vh_part_finish(P, W, lane); }
   for (int off = 32; off > 0; off >>= 1) npassed += __shfl_down(npassed, off);
   if (lane == 0) {
     if (npassed) atomicAdd(P.counters + 0, npassed);
@@ -1021,7 +1088,7 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
   for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
   __syncthreads();
   const uint32_t next = P.part_count[part] < P.part_cap ? P.part_count[part] : P.part_cap;
-  const uint32_t ext_tuples = VH_EXT_FLUSHES * (uint32_t)P.stage_cap;
+  const uint32_t ext_tuples = (uint32_t)P.ext_tuples;
   const uint32_t tw = (uint32_t)P.tw;
   for (uint32_t e = (uint32_t)b * nwaves + wave; e < next; e += (uint32_t)blocks_per_part * nwaves) {
     const uint32_t ext = P.part_extents[(uint64_t)part * P.part_cap + e];

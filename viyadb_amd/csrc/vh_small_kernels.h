@@ -9,7 +9,7 @@
 __device__ __forceinline__ uint64_t vh_combine(int sop, uint64_t a, uint64_t b) {
   switch (sop) {
     case SOP_ADD32: return (uint32_t)((uint32_t)a + (uint32_t)b);
-    case SOP_ADD64: return a + b;
+    case SOP_ADD64: case SOP_ADD32P: return a + b;
     case SOP_ADDF32: return __float_as_uint(__uint_as_float((uint32_t)a) + __uint_as_float((uint32_t)b));
     case SOP_ADDF64: return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
     case SOP_MIN_I32: return (uint32_t)((int32_t)b < (int32_t)a ? b : a);
@@ -29,6 +29,7 @@ __device__ __forceinline__ uint64_t vh_combine(int sop, uint64_t a, uint64_t b) 
 
 struct VhMergeArgs {
   int32_t nmetric; int32_t nxcd;
+  int32_t present_carrier; int32_t pad;
   uint64_t G; uint64_t xcd_stride;
   uint8_t* present;
   void* state[VH_MAX_METRIC];
@@ -38,9 +39,17 @@ struct VhMergeArgs {
 __global__ __launch_bounds__(256) void dense_merge_kernel(const VhMergeArgs A) {
   const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (g >= A.G) return;
-  uint8_t p = A.present[g];
-  for (int x = 1; x < A.nxcd; ++x) p |= A.present[x * A.xcd_stride + g];
-  A.present[g] = p;
+  uint8_t p;
+  if (A.present_carrier >= 0) {
+    const uint64_t* s = reinterpret_cast<const uint64_t*>(A.state[A.present_carrier]);
+    uint64_t any = 0;
+    for (int x = 0; x < A.nxcd; ++x) any |= s[x * A.xcd_stride + g];
+    p = any != 0;
+  } else {
+    p = A.present[g];
+    for (int x = 1; x < A.nxcd; ++x) p |= A.present[x * A.xcd_stride + g];
+    A.present[g] = p;
+  }
   if (!p) return;
   for (int j = 0; j < A.nmetric; ++j) {
     const int sop = A.sop[j];
@@ -64,6 +73,7 @@ struct VhEmitArgs {
   int32_t mode;  // VH_MODE_*
   int32_t ngroup; int32_t nmetric; int32_t key_words;
   uint64_t n;    // dense: G; hash: capacity + 1
+  int32_t present_carrier; int32_t pad;
   const uint8_t* present;
   const uint64_t* hkeys; const uint32_t* htags;
   const unsigned long long* counters;
@@ -93,6 +103,8 @@ __global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
     if (A.mode == VH_MODE_HASH) {
       if (i + 1 == A.n) have = A.key_words == 1 && A.counters[3] != 0;  // reserved slot
       else have = A.key_words == 1 ? A.hkeys[i] != VH_HASH_EMPTY : A.htags[i] == 2u;
+    } else if (A.present_carrier >= 0) {
+      have = reinterpret_cast<const uint64_t*>(A.state[A.present_carrier])[i] != 0;
     } else {
       have = A.present[i] != 0;
     }

@@ -99,7 +99,8 @@ struct vh_table {
   // per-query device scratch (grow-only) and pinned staging
   char* scratch = nullptr; size_t scratch_bytes = 0;
   uint32_t* h_segrows = nullptr; size_t h_segrows_cap = 0;
-  unsigned long long* h_counters = nullptr;     // pinned, 8 words
+  unsigned long long* h_counters = nullptr;     // pinned, 16 words
+  char* d_sample = nullptr; size_t d_sample_bytes = 0;   // selectivity probe: counters + presence + seg rows
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::mutex mu;
   uint64_t device_bytes = 0;
@@ -168,6 +169,7 @@ extern "C" void vh_table_destroy(vh_table* t) {
     for (auto p : c.bs_values) if (p) (void)hipFree(p);
   }
   if (t->scratch) (void)hipFree(t->scratch);
+  if (t->d_sample) (void)hipFree(t->d_sample);
   if (t->h_segrows) (void)hipHostFree(t->h_segrows);
   if (t->h_counters) (void)hipHostFree(t->h_counters);
   for (auto& e : t->ev) if (e) (void)hipEventDestroy(e);
@@ -534,6 +536,42 @@ static bool segment_passes(const vh_table* t, const vh_plan* p, uint32_t seg) {
   return st[0];
 }
 
+// Fraction of rows that pass the filter, estimated by running the scan kernel in counting mode over
+// the first 16 K rows of up to 64 evenly spaced segments (one extra ~20 us launch + a 64-byte read-back).
+// Decides between direct global atomics (cheap per query, ~30-60 G updates/s) and radix-partitioned
+// LDS aggregation (two passes over 16 B per survivor, but no global atomics).
+static int estimate_selectivity(vh_table* t, const VhPlanDev& P, uint32_t nseg, double* sel) {
+  const uint32_t kRows = 16384;
+  const size_t need = 256 + 256 + (size_t)std::max<uint32_t>(nseg, 1) * sizeof(uint32_t);
+  if (need > t->d_sample_bytes) {
+    if (t->d_sample) HIP_TRY(hipFree(t->d_sample));
+    HIP_TRY(hipMalloc(&t->d_sample, need * 2));
+    t->d_sample_bytes = need * 2;
+  }
+  std::vector<uint32_t> rows(std::max<uint32_t>(nseg, 1), 0);
+  const uint32_t stride = std::max<uint32_t>(1, nseg / 64);
+  uint64_t sampled = 0;
+  for (uint32_t s = 0; s < nseg; s += stride) { rows[s] = std::min<uint32_t>(t->h_segrows[s], kRows); sampled += rows[s]; }
+  if (!sampled) { *sel = 0; return VH_OK; }
+  VhPlanDev S = P;
+  S.ngroup = 0; S.nmetric = 0; S.nbitset = 0; S.G = 1; S.nxcd = 1; S.xcd_stride = 64;
+  S.lds_present_off = 0; S.lds_bytes = 16; S.present_carrier = -1;
+  S.counters = reinterpret_cast<unsigned long long*>(t->d_sample);
+  S.present = reinterpret_cast<uint8_t*>(t->d_sample + 256);
+  S.seg_rows = reinterpret_cast<const uint32_t*>(t->d_sample + 512);
+  S.nseg = nseg; S.unit_rows = kRows; S.units_per_seg = 1; S.total_units = nseg;
+  hipStream_t st = g_ctx.stream;
+  HIP_TRY(hipMemsetAsync(t->d_sample, 0, 512, st));
+  HIP_TRY(hipMemcpyAsync(t->d_sample + 512, rows.data(), nseg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  const size_t qbytes = (size_t)16 * VhScanCfg<1024>::kQueueCap * sizeof(uint32_t);
+  vh_launch_scan_fast_lds(S, (int)std::min<uint32_t>(nseg, (uint32_t)g_ctx.num_cu), 16 + qbytes, false, st);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(t->h_counters + 8, S.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *sel = (double)t->h_counters[8] / (double)sampled;
+  return VH_OK;
+}
+
 struct ScratchPlan {
   size_t off = 0;
   size_t take(size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; }
@@ -779,7 +817,14 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     int shift = 0;
     while (((size_t)2 << shift) * state_bytes_per_group <= 56 * 1024) ++shift;
     const uint64_t np = (G + (1ull << shift) - 1) >> shift;
-    if (np <= VH_MAX_PART && G <= 0xFFFFFFFFull) {
+    bool want_part = np <= VH_MAX_PART && G <= 0xFFFFFFFFull;
+    double sel = 0;
+    if (want_part && !(p->flags & VH_PLAN_FORCE_PART) && !part_tuples_override) {
+      rc = estimate_selectivity(t, P, nseg, &sel);
+      if (rc) { delete r; return rc; }
+      want_part = sel >= 0.08;   // crossover measured on C3 (profiles/r01): 5 % direct wins, 11 % partitioned wins
+    }
+    if (want_part) {
       mode = VH_MODE_DENSE_PART;
       P.part_shift = shift;
       P.npart = (int32_t)np;
@@ -794,7 +839,8 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       P.tw = tw;
       int cap = 16;
       while (cap > 4 && 4 * ((size_t)P.npart * ((size_t)cap * tw * 8 + 12) + 16) + 4 * VhScanCfg<256>::kQueueCap * 4 > 40 * 1024) cap /= 2;
-      P.stage_cap = cap;
+      static const bool staged = !(getenv("VH_PART_STAGED") && atoi(getenv("VH_PART_STAGED")) == 0);
+      P.stage_cap = staged ? cap : 0;   // 0: tuples are scattered straight into the extents
       // phase-2 LDS table for one partition
       const uint64_t gpp = 1ull << shift;
       size_t off = 0;
@@ -808,9 +854,16 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       P.lds_present_off = (uint32_t)off; off += gpp;
       lds_table = (off + 15) / 16 * 16;
       P.lds_bytes = (uint32_t)lds_table;
-      part_tuple_cap = part_tuples_override ? part_tuples_override : std::max<uint64_t>(rows_to_scan / 8, 1ull << 16);
+      part_tuple_cap = part_tuples_override ? part_tuples_override
+                     : std::max<uint64_t>((uint64_t)((double)rows_to_scan * std::max(sel, 0.02) * 1.25), 1ull << 16);
       part_tuple_cap = std::min<uint64_t>(part_tuple_cap, rows_to_scan + 1);
     }
+  }
+  // direct global atomics: fold the presence flag into a 32-bit SUM state (SOP_ADD32P) when there is one
+  P.present_carrier = -1;
+  if (mode == VH_MODE_DENSE_GLOBAL && !(p->flags & VH_PLAN_NO_CARRIER)) {
+    for (int j = 0; j < P.nmetric; ++j)
+      if (P.m[j].sop == SOP_ADD32) { P.m[j].sop = SOP_ADD32P; P.present_carrier = j; state_bytes_per_group += 4; break; }
   }
   r->mode = mode;
   r->info.path = mode == VH_MODE_DENSE_LDS ? (p->ngroups ? VH_PATH_DENSE_LDS : VH_PATH_SCALAR)
@@ -873,8 +926,14 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   r->out_cap = mode == VH_MODE_HASH ? capacity + 1 : G;
   size_t o_tuples = 0, o_pcount = 0, o_pext = 0, o_emiss = 0;
   if (mode == VH_MODE_DENSE_PART) {
-    const uint64_t ext_tuples = (uint64_t)VH_EXT_FLUSHES * P.stage_cap;
+    // extent size: big enough that a wave allocates rarely (every allocation is a returning global
+    // atomic = a full round trip the wave sits out), small enough that open extents do not waste HBM
     const uint64_t waves = (uint64_t)grid * 4;
+    uint64_t et = 64;
+    while (et < 4096 && et * 2 <= part_tuple_cap / (waves * P.npart) / 2) et *= 2;
+    P.ext_flushes = P.stage_cap ? (int32_t)std::max<uint64_t>(1, et / P.stage_cap) : 1;
+    const uint64_t ext_tuples = P.stage_cap ? (uint64_t)P.ext_flushes * P.stage_cap : et;
+    P.ext_tuples = (int32_t)ext_tuples;
     uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
     if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
     P.max_extents = (uint32_t)max_ext;
@@ -931,6 +990,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   for (int i = 0; i < P.ngroup; ++i) r->d_out_key[i] = S + o_okey[i];
   for (int j = 0; j < P.nmetric; ++j) r->d_out_state[j] = S + o_ostate[j];
 
+  P.debug = getenv("VH_DEBUG") ? (uint32_t)atoi(getenv("VH_DEBUG")) : 0u;
   // ---------------- init + launch
   hipStream_t st = g_ctx.stream;
   HIP_TRY(hipEventRecord(t->ev[0], st));
@@ -972,6 +1032,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   if (mode != VH_MODE_HASH && nxcd > 1) {
     VhMergeArgs A{};
     A.nmetric = P.nmetric; A.nxcd = nxcd; A.G = G; A.xcd_stride = P.xcd_stride; A.present = P.present;
+    A.present_carrier = P.present_carrier;
     for (int j = 0; j < P.nmetric; ++j) { A.state[j] = P.m[j].state; A.sop[j] = P.m[j].sop; }
     hipLaunchKernelGGL(dense_merge_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, A);
     HIP_TRY(hipGetLastError());
@@ -991,7 +1052,7 @@ extern "C" int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs, in
     vh_device_buffer b{P.m[j].state, P.G, 0, VH_RED_SUM};
     switch (P.m[j].sop) {
       case SOP_ADD32: b.elem = VH_U32; break;
-      case SOP_ADD64: b.elem = VH_U64; break;
+      case SOP_ADD64: case SOP_ADD32P: b.elem = VH_U64; break;
       case SOP_ADDF32: b.elem = VH_F32; break;
       case SOP_ADDF64: b.elem = VH_F64; break;
       case SOP_MIN_I32: b.elem = VH_I32; b.reduce = VH_RED_MIN; break;
@@ -1021,7 +1082,7 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   *retry = 0;
   VhEmitArgs A{};
   A.mode = r->mode == VH_MODE_DENSE_PART ? VH_MODE_DENSE_GLOBAL : r->mode; A.ngroup = P.ngroup; A.nmetric = P.nmetric; A.key_words = P.key_words;
-  A.n = r->out_cap; A.present = P.present; A.hkeys = P.hkeys; A.htags = P.htags; A.counters = P.counters;
+  A.n = r->out_cap; A.present = P.present; A.present_carrier = r->mode == VH_MODE_DENSE_GLOBAL ? P.present_carrier : -1; A.hkeys = P.hkeys; A.htags = P.htags; A.counters = P.counters;
   A.out_count = r->d_out_count;
   A.out_gid = r->d_out_gid;
   for (int i = 0; i < P.ngroup; ++i) { A.g[i] = P.g[i]; A.out_key[i] = r->d_out_key[i]; }
@@ -1118,7 +1179,7 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
     if (!retry) { r->info.retries = attempt; *out = r; return VH_OK; }
     if (retry == 1) cap_override = (r->plan.hmask + 1) * 4;   // table too small: regrow
     else if (retry == 3) {                                     // tuple extents exhausted: more room, then give up on partitioning
-      const uint64_t had = (uint64_t)r->plan.max_extents * VH_EXT_FLUSHES * r->plan.stage_cap;
+      const uint64_t had = (uint64_t)r->plan.max_extents * r->plan.ext_tuples;
       if (part_override && had >= r->info.scanned_recs) no_part = true; else part_override = had * 4;
     }
     else force_hash = true;                                    // a digit left its planned range
