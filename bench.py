@@ -165,7 +165,8 @@ def main():
                        "generate_seconds": round(t_gen, 3)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "scan_agg_kernel", "kernel_ms": avg_kernel_ms,
+                         "kernel": ("scan_agg_fast_kernel" if last.fast else "scan_agg_kernel") + (" + part_agg_kernel" if last.path == "dense_part" else ""),
+                         "kernel_ms": avg_kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes,
                          "bref_over_t_GBs": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0,
                          "traffic_source": traffic_src,

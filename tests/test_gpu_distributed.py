@@ -1,0 +1,65 @@
+"""The N>1 flow on real device memory: two ranks (both on cuda:0, gloo backend, because this box has one
+GPU) each mirror half of the segments, run vh_query_launch, reduce the library-owned dense partial tables
+in place through zero-copy views, and rank 0 finalises. Must equal the oracle on the whole table."""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, {root!r})
+    import numpy as np, torch, torch.distributed as dist
+    from viyadb_amd import distributed, executor, synth
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    executor.init(0, stream=torch.cuda.current_stream().cuda_stream)
+    w = synth.WORKLOADS[{wl!r}](segment_rows=50000)
+    total = 9
+    lo, hi = distributed.shard_segments(total, rank, world)
+    t = synth.create_device_table(w, hi - lo, 50000, row_base=lo * 50000)
+    plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags={flags})
+    for _ in range(2):
+        res = distributed.sharded_query(torch, dist, t, plan, world)
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.savez({out!r}, *(res.keys + res.states), ngroups=res.ngroups, nk=len(res.keys))
+    dist.barrier()
+    t.close()
+    dist.destroy_process_group()
+''')
+
+
+@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 64), ("C2", 0), ("C2", 2), ("C1", 0)])
+def test_two_ranks_one_gpu(tmp_path, wl, flags):
+    out = str(tmp_path / "res.npz")
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, out=out, wl=wl, flags=flags))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    got = np.load(out)
+    from oracle import viya_oracle as vo
+    from tests.parity import build_oracle_table, sort_rows
+    from viyadb_amd import synth
+    w = synth.WORKLOADS[wl](segment_rows=50000)
+    st = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 9, 50000), w.query))
+    nk = int(got["nk"])
+    arrs = [got["arr_%d" % i] for i in range(nk + len(st.states))]
+    keys, states = arrs[:nk], arrs[nk:]
+    assert int(got["ngroups"]) == st.ngroups
+    pg, po = sort_rows(keys, states), sort_rows(st.keys, st.states)
+    for a, b in zip(keys + states, st.keys + st.states):
+        assert np.array_equal(a[pg], b[po])

@@ -39,9 +39,13 @@ def reduce_view_typestr(elem: int, reduce: int) -> str:
 def reduce_partials(torch, dist, buffers: List[tuple], dst: int = 0):
     """buffers: [(ptr, count, elem, reduce)] from DeviceTable.device_buffers(). In-place reduce to `dst`."""
     ops = {RED_SUM: dist.ReduceOp.SUM, RED_MIN: dist.ReduceOp.MIN, RED_MAX: dist.ReduceOp.MAX}
+    gloo = dist.get_backend() == "gloo"   # test rigs without RCCL: gloo has no device-side reduce-to-root
     for ptr, count, elem, reduce in buffers:
         t = torch.as_tensor(_DevArray(ptr, count, reduce_view_typestr(elem, reduce)), device="cuda")
-        dist.reduce(t, dst=dst, op=ops[reduce])
+        if gloo:
+            dist.all_reduce(t, op=ops[reduce])
+        else:
+            dist.reduce(t, dst=dst, op=ops[reduce])
 
 
 def reduce_host_partials(torch, dist, arrays: List[tuple], dst: int = 0):
