@@ -204,7 +204,9 @@ typedef struct vh_gen_spec {
 VH_API int vh_init(int device_id);
 /* Run all subsequent work of this process on an externally owned hipStream_t
  * (e.g. torch's current stream, so RCCL collectives issued by the caller are
- * ordered with the kernels). NULL restores the library's own stream. */
+ * ordered with the kernels). NULL is the legacy default stream; VH_OWN_STREAM
+ * restores the library's private non-blocking stream (the default after vh_init). */
+#define VH_OWN_STREAM ((void*)(intptr_t)-1)
 VH_API int vh_set_stream(void* hip_stream);
 VH_API const char* vh_last_error(void);
 VH_API const char* vh_version(void);

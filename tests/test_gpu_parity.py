@@ -14,6 +14,15 @@ def _init():
     executor.init(0)
 
 
+@pytest.mark.parametrize("flags", [0, 8])
+def test_c5_time_rollup_hash_path(flags):
+    """C5 shape: time dimension with rollup rules, hour granularity, sparse (t, u) keys -> hash table."""
+    from viyadb_amd import synth
+    w = synth.c5t(segment_rows=150_000)
+    res, st = check_workload(w, nseg=3, flags=flags, expect_path="hash")
+    assert res.ngroups > 100_000
+
+
 @pytest.mark.parametrize("name", ["C1", "C2", "C3"])
 def test_workload_small(name):
     from viyadb_amd import synth

@@ -23,6 +23,8 @@ def main():
     print(json.dumps({"read_bw_GBs": bw / 1e9}), flush=True)
     for name in args.workloads.split(","):
         w = synth.WORKLOADS[name]()
+        if name == "C5t" and args.segments > 200:
+            pass
         t = synth.create_device_table(w, args.segments)
         want = set(args.variants.split(",")) if args.variants else None
         for flags, label in [(0, "default"), (16, "no_part"), (8, "generic_kernel"), (4, "no_xcd_private"), (2, "force_global"), (10, "generic_force_global"), (1, "hash"), (9, "generic_hash")]:

@@ -71,7 +71,9 @@ extern "C" int vh_init(int device_id) {
 
 extern "C" int vh_set_stream(void* hip_stream) {
   if (!g_ctx.inited) return vh_fail(VH_E_INVALID, "vh_init has not been called");
-  g_ctx.stream = hip_stream ? (hipStream_t)hip_stream : g_ctx.own_stream;
+  // NULL is a real stream (the legacy default stream, which is what torch.cuda.current_stream() is unless
+  // the caller changed it); VH_OWN_STREAM restores the library's private stream
+  g_ctx.stream = hip_stream == VH_OWN_STREAM ? g_ctx.own_stream : (hipStream_t)hip_stream;
   return VH_OK;
 }
 

@@ -63,6 +63,10 @@ def sharded_query(torch, dist, table, plan, world: int):
     (other ranks return their local finalisation of the reduced-away buffers and should ignore it)."""
     if world == 1:
         return table.query_agg(plan)
+    # The library must run on torch's current stream (executor.init(..., stream=...)): the collective is
+    # then ordered after the scan kernels and the finalisation after the collective by stream order alone.
     res = table.query_launch(plan)
     reduce_partials(torch, dist, table.device_buffers(res))
+    if dist.get_backend() == "gloo":
+        torch.cuda.current_stream().synchronize()
     return table.finalize(res, plan)

@@ -26,7 +26,8 @@ def init(device: int = 0, stream: Optional[int] = None) -> None:
 
 
 def set_stream(stream: Optional[int]) -> None:
-    capi.check(capi.load().vh_set_stream(C.c_void_p(stream) if stream else None))
+    """stream: a hipStream_t as int (0 = the legacy default stream); None = the library's own stream."""
+    capi.check(capi.load().vh_set_stream(C.c_void_p(-1 & 0xFFFFFFFFFFFFFFFF) if stream is None else C.c_void_p(stream)))
 
 
 def anynum(elem: int, value) -> capi.AnyNum:

@@ -39,6 +39,9 @@ class Workload:
 
     def table_json(self, name="synth"):
         dims = [{"name": c.name, "type": c.json_type} for c in self.columns if c.kind < 16]
+        for d in dims:
+            if d["type"] == "time" and getattr(self, "rollup_rules", None):
+                d["rollup_rules"] = self.rollup_rules
         mets = [{"name": c.name, "type": c.json_type} for c in self.columns if c.kind >= 16]
         return {"name": name, "segment_size": self.segment_rows, "dimensions": dims, "metrics": mets}
 
@@ -100,7 +103,40 @@ def c3(segment_rows=1_000_000) -> Workload:
                     cols, segment_rows, plan, q, 3 * 4 + 2 * 4 + 8 + 4, 7 * 4 + 8 + 8 + 4 + 8 + 4)
 
 
-WORKLOADS = {"C1": c1, "C2": c2, "C3": c3}
+C5_NOW = 1496570140  # the reference's own rollup test constant (test/time.cc:320)
+
+
+def _rollup_before(now: int):
+    """rollup_bN_i for the rules hour/1 day, day/1 week, month/1 year, in the reference's order
+    (`after` descending: month/1y, day/1w, hour/1d): Duration.add_to(now, -1) (src/codegen/db/rollup.cc:44-75)."""
+    import calendar
+    import time
+    tm = time.gmtime(now)
+    year_ago = calendar.timegm((tm.tm_year - 1, tm.tm_mon, tm.tm_mday, tm.tm_hour, tm.tm_min, tm.tm_sec))
+    return [(capi.T_MONTH, year_ago), (capi.T_DAY, now - 7 * 86400), (capi.T_HOUR, now - 86400)]
+
+
+def c5t(segment_rows=1_000_000) -> Workload:
+    """C5 without the bitset metric: time dimension with rollup rules + query granularity `hour`,
+    GROUP BY (t, u) -> millions of sparse groups (hash path), COUNT."""
+    two_years = 2 * 365 * 86400
+    cols = [SynthColumn("t", capi.DIM_TIME, capi.U32, (U, two_years, C5_NOW - two_years, 1.0), "time"),
+            _dim("u", 1_000_000), _rowid(),
+            SynthColumn("count", capi.METRIC_COUNT, capi.U32, (U, 3, 1, 1.0), "count")]
+    plan = AggPlan(filter=[("rel", 1, capi.OP_LT, 500_000)],
+                   groups=[GroupSpec(0, granularity=capi.T_HOUR, rollup=_rollup_before(C5_NOW)), GroupSpec(1)], metrics=[3],
+                   groups_hint=0)
+    q = {"type": "aggregate", "table": "synth", "select": [{"column": "t", "granularity": "hour"}, {"column": "u"}, {"column": "count"}],
+         "filter": {"op": "lt", "column": "u", "value": "500000"}}
+    w = Workload("C5t", "time dim + rollup rules + hour granularity, GROUP BY (t,u): sparse keys, hash path, COUNT",
+                 cols, segment_rows, plan, q, 4 + 4 + 4, 16)
+    w.rollup_rules = [{"granularity": "hour", "after": "1 days"}, {"granularity": "day", "after": "1 weeks"},
+                      {"granularity": "month", "after": "1 years"}]
+    w.now = C5_NOW
+    return w
+
+
+WORKLOADS = {"C1": c1, "C2": c2, "C3": c3, "C5t": c5t}
 
 
 def create_device_table(w: Workload, nseg: int, rows_per_seg=None, row_base=0, seed=SEED):
