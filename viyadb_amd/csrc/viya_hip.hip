@@ -17,6 +17,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -103,6 +104,7 @@ struct vh_table {
   uint32_t* h_segrows = nullptr; size_t h_segrows_cap = 0;
   unsigned long long* h_counters = nullptr;     // pinned, 16 words
   char* d_sample = nullptr; size_t d_sample_bytes = 0;   // selectivity probe: counters + presence + seg rows
+  std::map<std::string, uint64_t> groups_seen;           // group-column signature -> groups of the last query (hash sizing)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::mutex mu;
   uint64_t device_bytes = 0;
@@ -411,6 +413,7 @@ struct vh_result {
   int nxcd = 1;
   std::vector<int> metric_elem;        // output element type per device metric (P.m order)
   std::vector<int> group_elem;
+  std::string group_sig;
   std::vector<int> user_metric;        // per plan metric: >= 0 index into P.m, < 0: -(bitset index + 1)
   uint64_t* d_out_gid = nullptr;
   std::vector<std::vector<uint64_t>> h_bitset_card;  // per bitset metric: cardinality per output row
@@ -881,8 +884,14 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
 
   uint64_t capacity = 0;
   if (mode == VH_MODE_HASH) {
+    // sizing: explicit override (regrow) > caller's hint > what the same group columns produced last time > 1 M
+    std::string sig;
+    for (int i = 0; i < p->ngroups; ++i) sig += std::to_string(p->groups[i].col) + ":" + std::to_string(P.g[i].gran) + ":" + std::to_string(P.g[i].nroll) + ",";
+    r->group_sig = sig;
+    const auto seen = t->groups_seen.find(sig);
+    const uint64_t hint = p->groups_hint ? p->groups_hint : (seen != t->groups_seen.end() ? seen->second + seen->second / 4 : 0);
     uint64_t want = hash_capacity_override ? hash_capacity_override
-                  : std::max<uint64_t>(p->groups_hint ? p->groups_hint * 2 : (1ull << 20), 1ull << 12);
+                  : std::max<uint64_t>(hint ? hint * 2 : (1ull << 20), 1ull << 12);
     const uint64_t cap_rows = std::max<uint64_t>(rows_to_scan * 2, 1ull << 12);
     if (!hash_capacity_override) want = std::min(want, cap_rows);
     capacity = 1; while (capacity < want) capacity <<= 1;
@@ -1178,8 +1187,26 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
     int retry = 0;
     rc = result_finalize_locked(r, &retry);
     if (rc) { delete r; return rc; }
-    if (!retry) { r->info.retries = attempt; *out = r; return VH_OK; }
-    if (retry == 1) cap_override = (r->plan.hmask + 1) * 4;   // table too small: regrow
+    if (!retry) {
+      r->info.retries = attempt;
+      if (r->mode == VH_MODE_HASH) t->groups_seen[r->group_sig] = r->info.ngroups;
+      *out = r;
+      return VH_OK;
+    }
+    if (retry == 1) {
+      // table too small. The number of groups is bounded by the number of surviving rows: estimate those
+      // once with the selectivity probe and size for them, instead of quadrupling blindly
+      uint64_t next = (r->plan.hmask + 1) * 4;
+      if (!cap_override) {
+        double sel = 1.0;
+        if (r->info.reserved & 1) (void)estimate_selectivity(t, r->plan, r->plan.nseg, &sel);
+        uint64_t survivors = (uint64_t)((double)r->info.scanned_recs * std::min(1.0, sel * 1.1)) + 1024;
+        uint64_t sized = 1;
+        while (sized < survivors * 2) sized <<= 1;
+        next = std::max(next, sized);
+      }
+      cap_override = next;
+    }
     else if (retry == 3) {                                     // tuple extents exhausted: more room, then give up on partitioning
       const uint64_t had = (uint64_t)r->plan.max_extents * r->plan.ext_tuples;
       if (part_override && had >= r->info.scanned_recs) no_part = true; else part_override = had * 4;
