@@ -261,6 +261,10 @@ VH_API int vh_result_get_info(vh_result* r, vh_result_info* info);
  * summed uint64 _count. Row k of every array belongs to the same group. */
 VH_API int vh_result_copy(vh_result* r, void* const* key_cols,
                           void* const* state_cols, uint64_t* hidden_count);
+/* Zero-copy variant of vh_result_copy: pointers into the table's pinned staging buffer, valid until the
+ * second-next query on the same table (two buffers alternate) or vh_table_destroy. */
+VH_API int vh_result_view(vh_result* r, const void** key_cols, const void** state_cols,
+                          const uint64_t** hidden_count);
 VH_API void vh_result_free(vh_result* r);
 
 /* Streaming-read ceiling of this device in bytes/s (a plain 16 B/lane read

@@ -30,6 +30,7 @@ WORKER = textwrap.dedent('''
     for _ in range(2):
         res = distributed.sharded_query(torch, dist, t, plan, world)
     torch.cuda.synchronize()
+    assert (res is None) == (rank != 0)
     if rank == 0:
         np.savez({out!r}, *(res.keys + res.states), ngroups=res.ngroups, nk=len(res.keys))
     dist.barrier()

@@ -109,6 +109,7 @@ SYMBOLS = {
     "vh_result_finalize": (C.c_int, [_VP]),
     "vh_result_get_info": (C.c_int, [_VP, C.POINTER(ResultInfo)]),
     "vh_result_copy": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_uint64)]),
+    "vh_result_view": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.POINTER(C.c_uint64))]),
     "vh_result_free": (None, [_VP]),
     "vh_measure_read_bandwidth": (C.c_int, [C.c_uint64, C.c_int32, C.POINTER(C.c_double)]),
 }

@@ -105,6 +105,9 @@ struct vh_table {
   unsigned long long* h_counters = nullptr;     // pinned, 16 words
   char* d_sample = nullptr; size_t d_sample_bytes = 0;   // selectivity probe: counters + presence + seg rows
   std::map<std::string, uint64_t> groups_seen;           // group-column signature -> groups of the last query (hash sizing)
+  std::map<std::string, double> sel_cache;               // filter signature + table state -> probed selectivity
+  char* h_out[2] = {nullptr, nullptr}; size_t h_out_bytes[2] = {0, 0}; int h_out_next = 0;  // pinned result staging
+  uint64_t sync_epoch = 0;   // bumped by every vh_segment_sync / generate: invalidates cached estimates
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::mutex mu;
   uint64_t device_bytes = 0;
@@ -174,6 +177,7 @@ extern "C" void vh_table_destroy(vh_table* t) {
   }
   if (t->scratch) (void)hipFree(t->scratch);
   if (t->d_sample) (void)hipFree(t->d_sample);
+  for (auto& hp : t->h_out) if (hp) (void)hipHostFree(hp);
   if (t->h_segrows) (void)hipHostFree(t->h_segrows);
   if (t->h_counters) (void)hipHostFree(t->h_counters);
   for (auto& e : t->ev) if (e) (void)hipEventDestroy(e);
@@ -272,6 +276,7 @@ extern "C" int vh_segment_sync(vh_table* t, uint32_t seg, uint64_t nrows, const 
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   t->seg_rows[seg] = nrows;
   t->nseg = std::max(t->nseg, seg + 1);
+  ++t->sync_epoch;
   return refresh_stats(t, seg, 1);
 }
 
@@ -317,6 +322,7 @@ extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nse
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   for (uint32_t s = 0; s < nseg; ++s) t->seg_rows[seg_first + s] = rows_per_seg;
   t->nseg = std::max(t->nseg, seg_first + nseg);
+  ++t->sync_epoch;
   // stats in batches so the staging buffers stay small
   for (uint32_t s = 0; s < nseg; s += 256) {
     rc = refresh_stats(t, seg_first + s, std::min<uint32_t>(256, nseg - s));
@@ -421,8 +427,12 @@ struct vh_result {
   unsigned long long* d_out_count = nullptr;
   void* d_out_key[VH_MAX_GROUP] = {};
   void* d_out_state[VH_MAX_METRIC] = {};
-  // host copies after finalize
-  std::vector<std::vector<char>> h_keys, h_states;
+  // host side after finalize: key / state arrays live in the table's pinned staging buffer `h_base`
+  // (valid until the second-next query on the same table) at these offsets
+  size_t out_region_off = 0, out_region_bytes = 0;   // device scratch: [counters | out_count | keys | states]
+  size_t off_key[VH_MAX_GROUP] = {}, off_state[VH_MAX_METRIC] = {};
+  char* h_base = nullptr;
+  uint64_t ngroups_host = 0;
 };
 
 extern "C" void vh_result_free(vh_result* r) { delete r; }
@@ -433,19 +443,33 @@ extern "C" int vh_result_get_info(vh_result* r, vh_result_info* info) {
   return VH_OK;
 }
 
+extern "C" int vh_result_view(vh_result* r, const void** key_cols, const void** state_cols, const uint64_t** hidden_count) {
+  if (!r || !r->finalized) return vh_fail(VH_E_INVALID, "result is not finalised");
+  for (int i = 0; i < r->plan.ngroup; ++i)
+    if (key_cols) key_cols[i] = r->h_base + r->off_key[i];
+  for (size_t j = 0; j < r->user_metric.size(); ++j) {
+    if (!state_cols) break;
+    const int u = r->user_metric[j];
+    state_cols[j] = u >= 0 ? (const void*)(r->h_base + r->off_state[u]) : (const void*)r->h_bitset_card[-u - 1].data();
+  }
+  if (hidden_count) *hidden_count = r->info.has_hidden_count ? reinterpret_cast<const uint64_t*>(r->h_base + r->off_state[r->plan.nmetric - 1]) : nullptr;
+  return VH_OK;
+}
+
 extern "C" int vh_result_copy(vh_result* r, void* const* key_cols, void* const* state_cols, uint64_t* hidden_count) {
   if (!r || !r->finalized) return vh_fail(VH_E_INVALID, "result is not finalised");
-  for (size_t i = 0; i < r->h_keys.size(); ++i)
-    if (key_cols && key_cols[i] && !r->h_keys[i].empty()) memcpy(key_cols[i], r->h_keys[i].data(), r->h_keys[i].size());
-  const size_t nuser = r->user_metric.size();
-  for (size_t j = 0; j < nuser; ++j) {
-    if (!state_cols || !state_cols[j]) continue;
+  const void* kp[VH_MAX_GROUP]; const void* sp[VH_MAX_METRIC]; const uint64_t* hp = nullptr;
+  int rc = vh_result_view(r, kp, sp, &hp);
+  if (rc) return rc;
+  const uint64_t ng = r->ngroups_host;
+  for (int i = 0; i < r->plan.ngroup; ++i)
+    if (key_cols && key_cols[i] && ng) memcpy(key_cols[i], kp[i], ng * vh_elem_size(r->plan.g[i].type));
+  for (size_t j = 0; j < r->user_metric.size(); ++j) {
+    if (!state_cols || !state_cols[j] || !ng) continue;
     const int u = r->user_metric[j];
-    if (u >= 0) { if (!r->h_states[u].empty()) memcpy(state_cols[j], r->h_states[u].data(), r->h_states[u].size()); }
-    else { const auto& c = r->h_bitset_card[-u - 1]; if (!c.empty()) memcpy(state_cols[j], c.data(), c.size() * sizeof(uint64_t)); }
+    memcpy(state_cols[j], sp[j], ng * (u >= 0 ? vh_elem_size(r->metric_elem[u]) : 8));
   }
-  if (hidden_count && r->info.has_hidden_count && !r->h_states.back().empty())
-    memcpy(hidden_count, r->h_states.back().data(), r->h_states.back().size());
+  if (hidden_count && hp && ng) memcpy(hidden_count, hp, ng * 8);
   return VH_OK;
 }
 
@@ -825,8 +849,18 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     bool want_part = np <= VH_MAX_PART && G <= 0xFFFFFFFFull;
     double sel = 0;
     if (want_part && !(p->flags & VH_PLAN_FORCE_PART) && !part_tuples_override) {
-      rc = estimate_selectivity(t, P, nseg, &sel);
-      if (rc) { delete r; return rc; }
+      // the estimate only depends on the filter and the rows: cache it until the table changes
+      std::string key((const char*)P.prog, sizeof(VhProgOp) * P.nprog);
+      key.append((const char*)P.lits, sizeof(uint64_t) * std::max(p->nlits, 0));
+      key += "|" + std::to_string(nseg) + "|" + std::to_string(rows_to_scan) + "|" + std::to_string(t->sync_epoch);
+      auto hit = t->sel_cache.find(key);
+      if (hit != t->sel_cache.end()) sel = hit->second;
+      else {
+        rc = estimate_selectivity(t, P, nseg, &sel);
+        if (rc) { delete r; return rc; }
+        if (t->sel_cache.size() > 256) t->sel_cache.clear();
+        t->sel_cache[key] = sel;
+      }
       want_part = sel >= 0.08;   // crossover measured on C3 (profiles/r01): 5 % direct wins, 11 % partitioned wins
     }
     if (want_part) {
@@ -877,8 +911,8 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   // per-XCD private copies only while they stay cache-sized
   int nxcd = 1;
   if (mode != VH_MODE_HASH && mode != VH_MODE_DENSE_PART && !(p->flags & VH_PLAN_NO_XCD_PRIVATE) &&
-      G * state_bytes_per_group * g_ctx.num_xcd <= (64ull << 20))
-    nxcd = g_ctx.num_xcd;
+      G <= 16384)   // private copies pay off only against same-address contention (C2 forced to HBM: 3.4 vs 10 ms);
+    nxcd = g_ctx.num_xcd;   // with >= 100 K groups one table is as fast and needs no merge pass
   P.nxcd = nxcd; r->nxcd = nxcd;
   P.xcd_stride = (G + 63) / 64 * 64;
 
@@ -921,7 +955,18 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
 
   // ---------------- scratch layout
   ScratchPlan sp;
+  // [counters | out_count | output key arrays | output state arrays] is one region: it is read back with a
+  // single D2H copy when small, and its head is cleared with a single memset
   const size_t o_counters = sp.take(8 * sizeof(unsigned long long));
+  const size_t o_outcount = sp.take(sizeof(unsigned long long));
+  r->out_cap = mode == VH_MODE_HASH ? capacity + 1 : G;
+  size_t o_okey[VH_MAX_GROUP], o_ostate[VH_MAX_METRIC];
+  for (int i = 0; i < P.ngroup; ++i) o_okey[i] = sp.take(r->out_cap * vh_elem_size(P.g[i].type));
+  for (int j = 0; j < P.nmetric; ++j) o_ostate[j] = sp.take(r->out_cap * vh_elem_size(r->metric_elem[j]));
+  r->out_region_off = o_counters;
+  r->out_region_bytes = sp.off - o_counters;
+  for (int i = 0; i < P.ngroup; ++i) r->off_key[i] = o_okey[i] - o_counters;
+  for (int j = 0; j < P.nmetric; ++j) r->off_state[j] = o_ostate[j] - o_counters;
   const size_t o_segrows = sp.take(std::max<uint32_t>(nseg, 1) * sizeof(uint32_t));
   size_t o_present = 0, o_hkeys = 0, o_htags = 0;
   size_t o_state[VH_MAX_METRIC];
@@ -932,9 +977,12 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   } else {
     o_present = sp.take(table_n);
   }
-  for (int j = 0; j < P.nmetric; ++j) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop));
+  // zero-identity states (every SUM) sit right behind the presence bytes: one memset clears them all
+  const size_t zero_begin = mode == VH_MODE_HASH ? sp.off : o_present;
+  for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident == 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop));
+  const size_t zero_end = sp.off;
+  for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident != 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop));
   // outputs
-  r->out_cap = mode == VH_MODE_HASH ? capacity + 1 : G;
   size_t o_tuples = 0, o_pcount = 0, o_pext = 0, o_emiss = 0;
   if (mode == VH_MODE_DENSE_PART) {
     // extent size: big enough that a wave allocates rarely (every allocation is a returning global
@@ -962,10 +1010,6 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     o_outgid = sp.take(r->out_cap * sizeof(uint64_t));
     for (int b = 0; b < P.nbitset; ++b) { o_bsptr[b][0] = sp.take(std::max<uint32_t>(nseg, 1) * 8); o_bsptr[b][1] = sp.take(std::max<uint32_t>(nseg, 1) * 8); }
   }
-  const size_t o_outcount = sp.take(sizeof(unsigned long long));
-  size_t o_okey[VH_MAX_GROUP], o_ostate[VH_MAX_METRIC];
-  for (int i = 0; i < P.ngroup; ++i) o_okey[i] = sp.take(r->out_cap * vh_elem_size(P.g[i].type));
-  for (int j = 0; j < P.nmetric; ++j) o_ostate[j] = sp.take(r->out_cap * vh_elem_size(r->metric_elem[j]));
   rc = ensure_scratch(t, sp.off);
   if (rc) { delete r; return rc; }
   char* S = t->scratch;
@@ -1005,20 +1049,19 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   // ---------------- init + launch
   hipStream_t st = g_ctx.stream;
   HIP_TRY(hipEventRecord(t->ev[0], st));
-  HIP_TRY(hipMemsetAsync(P.counters, 0, 8 * sizeof(unsigned long long), st));
-  HIP_TRY(hipMemsetAsync(r->d_out_count, 0, sizeof(unsigned long long), st));
+  HIP_TRY(hipMemsetAsync(P.counters, 0, 512, st));   // counters + out_count (adjacent 256 B slots)
   if (nseg) HIP_TRY(hipMemcpyAsync(S + o_segrows, t->h_segrows, nseg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   if (mode == VH_MODE_HASH) {
     if (P.key_words == 1) HIP_TRY(hipMemsetAsync(P.hkeys, 0xFF, table_n * sizeof(uint64_t), st));
     else HIP_TRY(hipMemsetAsync(P.htags, 0, table_n * sizeof(uint32_t), st));
-  } else {
-    HIP_TRY(hipMemsetAsync(P.present, 0, table_n, st));
   }
+  if (zero_end > zero_begin) HIP_TRY(hipMemsetAsync(S + zero_begin, 0, zero_end - zero_begin, st));
   if (mode == VH_MODE_DENSE_PART) {
     HIP_TRY(hipMemsetAsync(P.part_count, 0, VH_MAX_PART * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(P.extent_missing, 0, (size_t)P.max_extents * sizeof(uint16_t), st));
   }
   for (int j = 0; j < P.nmetric; ++j) {
+    if (P.m[j].ident == 0) continue;
     rc = fill_states(P.m[j].state, table_n, vh_sop_bytes(P.m[j].sop), P.m[j].ident, st);
     if (rc) { delete r; return rc; }
   }
@@ -1102,31 +1145,42 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   }
   hipLaunchKernelGGL(emit_groups_kernel, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(t->h_counters, P.counters, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(t->h_counters + 4, r->d_out_count, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipMemcpyAsync(t->h_counters + 5, P.counters + 4, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  // pinned staging buffer (two alternate, so a result stays readable while the next query runs)
+  const int slot = t->h_out_next; t->h_out_next ^= 1;
+  if (t->h_out_bytes[slot] < r->out_region_bytes) {
+    if (t->h_out[slot]) HIP_TRY(hipHostFree(t->h_out[slot]));
+    t->h_out[slot] = nullptr; t->h_out_bytes[slot] = 0;
+    const size_t nb = std::max<size_t>(r->out_region_bytes + r->out_region_bytes / 4, 1 << 20);
+    HIP_TRY(hipHostMalloc((void**)&t->h_out[slot], nb, hipHostMallocDefault));
+    t->h_out_bytes[slot] = nb;
+  }
+  char* H = t->h_out[slot];
+  const char* D = t->scratch + r->out_region_off;
+  const bool one_shot = r->out_region_bytes <= (8u << 20);
+  // small results: counters, group count and every output array come back in ONE copy + ONE sync
+  HIP_TRY(hipMemcpyAsync(H, D, one_shot ? r->out_region_bytes : 512, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  const unsigned long long err = t->h_counters[2];
+  const unsigned long long* hc = reinterpret_cast<const unsigned long long*>(H);
+  const unsigned long long err = hc[2];
   if (err & VH_ERR_HASH_FULL) { *retry = 1; return VH_OK; }
   if (err & VH_ERR_PART_FULL) { *retry = 3; return VH_OK; }
   if (err & VH_ERR_RANGE) { *retry = 2; return VH_OK; }
-  const uint64_t ng = t->h_counters[4];
+  const uint64_t ng = *reinterpret_cast<const unsigned long long*>(H + 256);
+  const uint64_t npairs_emitted = hc[4];
   r->info.ngroups = ng;
-  r->info.passed_recs = t->h_counters[0];
-  r->h_keys.assign(P.ngroup, {});
-  r->h_states.assign(P.nmetric, {});
-  for (int i = 0; i < P.ngroup; ++i) {
-    r->h_keys[i].resize(ng * vh_elem_size(P.g[i].type));
-    if (ng) HIP_TRY(hipMemcpyAsync(r->h_keys[i].data(), r->d_out_key[i], r->h_keys[i].size(), hipMemcpyDeviceToHost, st));
-  }
-  for (int j = 0; j < P.nmetric; ++j) {
-    r->h_states[j].resize(ng * vh_elem_size(r->metric_elem[j]));
-    if (ng) HIP_TRY(hipMemcpyAsync(r->h_states[j].data(), r->d_out_state[j], r->h_states[j].size(), hipMemcpyDeviceToHost, st));
+  r->ngroups_host = ng;
+  r->info.passed_recs = hc[0];
+  r->h_base = H;
+  if (!one_shot && ng) {
+    for (int i = 0; i < P.ngroup; ++i)
+      HIP_TRY(hipMemcpyAsync(H + r->off_key[i], D + r->off_key[i], ng * vh_elem_size(P.g[i].type), hipMemcpyDeviceToHost, st));
+    for (int j = 0; j < P.nmetric; ++j)
+      HIP_TRY(hipMemcpyAsync(H + r->off_state[j], D + r->off_state[j], ng * vh_elem_size(r->metric_elem[j]), hipMemcpyDeviceToHost, st));
   }
   if (P.nbitset) {
     // COUNT DISTINCT finish ("bitset metrics materialised host-side", north_star): the scan left
     // (metric|group, id) pairs in HBM; sort + unique them and count per group.
-    const uint64_t npairs = std::min<uint64_t>(t->h_counters[5], P.pair_cap);
+    const uint64_t npairs = std::min<uint64_t>(npairs_emitted, P.pair_cap);
     std::vector<uint64_t> pairs(npairs * 2), gids(ng);
     if (npairs) HIP_TRY(hipMemcpyAsync(pairs.data(), P.pairs, npairs * 16, hipMemcpyDeviceToHost, st));
     if (ng) HIP_TRY(hipMemcpyAsync(gids.data(), r->d_out_gid, ng * 8, hipMemcpyDeviceToHost, st));

@@ -58,15 +58,18 @@ def reduce_host_partials(torch, dist, arrays: List[tuple], dst: int = 0):
         dist.reduce(t, dst=dst, op=ops[reduce])
 
 
-def sharded_query(torch, dist, table, plan, world: int):
-    """One query over a table sharded across `world` ranks; the merged result lands on rank 0
-    (other ranks return their local finalisation of the reduced-away buffers and should ignore it)."""
+def sharded_query(torch, dist, table, plan, world: int, copy: bool = True):
+    """One query over a table sharded across `world` ranks; the merged result lands on rank 0, the other
+    ranks return None (they only contribute their partial tables to the collective)."""
     if world == 1:
-        return table.query_agg(plan)
+        return table.query_agg(plan, copy=copy)
     # The library must run on torch's current stream (executor.init(..., stream=...)): the collective is
     # then ordered after the scan kernels and the finalisation after the collective by stream order alone.
     res = table.query_launch(plan)
     reduce_partials(torch, dist, table.device_buffers(res))
     if dist.get_backend() == "gloo":
         torch.cuda.current_stream().synchronize()
-    return table.finalize(res, plan)
+    if dist.get_rank() != 0:
+        table.discard(res)
+        return None
+    return table.finalize(res, plan, copy=copy)

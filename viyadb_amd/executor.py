@@ -208,28 +208,40 @@ class DeviceTable:
         p.groups_hint = int(plan.groups_hint)
         return p, keep
 
-    def _collect(self, res, plan: AggPlan) -> AggResult:
+    def _collect(self, res, plan: AggPlan, copy: bool = True) -> AggResult:
+        """copy=False: the arrays alias the library's pinned staging buffer (valid until the second-next
+        query on this table); copy=True: private numpy arrays."""
         info = capi.ResultInfo()
         capi.check(self.lib.vh_result_get_info(res, C.byref(info)))
         ng = info.ngroups
-        keys = [np.empty(ng, dtype=capi.ELEM_NP[self.cols[g.col][1]]) for g in plan.groups]
-        states = [np.empty(ng, dtype=(np.uint64 if self.cols[m][1] >= capi.BITSET32 else capi.ELEM_NP[self.cols[m][1]]))
-                  for m in plan.metrics]
-        hidden = np.empty(ng, dtype=np.uint64) if info.has_hidden_count else None
-        kp = (C.c_void_p * max(1, len(keys)))(*[k.ctypes.data for k in keys])
-        spp = (C.c_void_p * max(1, len(states)))(*[s.ctypes.data for s in states])
-        hp = hidden.ctypes.data_as(C.POINTER(C.c_uint64)) if hidden is not None else None
-        capi.check(self.lib.vh_result_copy(res, kp, spp, hp))
+        nk, nm = len(plan.groups), len(plan.metrics)
+        kp = (C.c_void_p * max(1, nk))()
+        spp = (C.c_void_p * max(1, nm))()
+        hp = C.POINTER(C.c_uint64)()
+        capi.check(self.lib.vh_result_view(res, kp, spp, C.byref(hp)))
+
+        def view(ptr, dtype):
+            dtype = np.dtype(dtype)
+            if not ng or not ptr:
+                return np.empty(0, dtype=dtype)
+            buf = (C.c_char * (ng * dtype.itemsize)).from_address(ptr)
+            a = np.frombuffer(buf, dtype=dtype, count=ng)
+            return a.copy() if copy else a
+
+        keys = [view(kp[i], capi.ELEM_NP[self.cols[g.col][1]]) for i, g in enumerate(plan.groups)]
+        states = [view(spp[j], np.uint64 if self.cols[m][1] >= capi.BITSET32 else capi.ELEM_NP[self.cols[m][1]])
+                  for j, m in enumerate(plan.metrics)]
+        hidden = view(C.cast(hp, C.c_void_p).value, np.uint64) if info.has_hidden_count else None
         return AggResult(keys, states, hidden, int(ng), int(info.scanned_recs), int(info.scanned_segments),
                          int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
                          float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1))
 
-    def query_agg(self, plan: AggPlan) -> AggResult:
+    def query_agg(self, plan: AggPlan, copy: bool = True) -> AggResult:
         p, keep = self._build_plan(plan)
         res = C.c_void_p()
         capi.check(self.lib.vh_query_agg(self.handle, C.byref(p), C.byref(res)))
         try:
-            return self._collect(res, plan)
+            return self._collect(res, plan, copy)
         finally:
             self.lib.vh_result_free(res)
 
@@ -246,12 +258,16 @@ class DeviceTable:
         capi.check(self.lib.vh_result_device_buffers(res, bufs, 16, C.byref(n)))
         return [(bufs[i].ptr, bufs[i].count, bufs[i].elem, bufs[i].reduce) for i in range(n.value)]
 
-    def finalize(self, res, plan: AggPlan) -> AggResult:
+    def finalize(self, res, plan: AggPlan, copy: bool = True) -> AggResult:
         try:
             capi.check(self.lib.vh_result_finalize(res))
-            return self._collect(res, plan)
+            return self._collect(res, plan, copy)
         finally:
             self.lib.vh_result_free(res)
+
+    def discard(self, res) -> None:
+        """Drop a launched (not finalised) partial result: non-root ranks after the collective."""
+        self.lib.vh_result_free(res)
 
 
 def measure_read_bandwidth(nbytes: int = 4 << 30, iters: int = 5) -> float:
