@@ -1,0 +1,98 @@
+"""BASELINE.json's full sizes (C3: 1 B rows / 12 columns / 60 GB in HBM; C2: 100 M rows): the oracle cannot
+follow there in seconds, so parity is carried by size-independent properties — totals that must agree across
+independent kernel paths, linearity over segment ranges, idempotence — plus an exact oracle comparison on a
+contiguous sample of the same generated rows."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def c3_full():
+    from viyadb_amd import executor, synth
+    executor.init(0)
+    w = synth.c3()
+    t = synth.create_device_table(w, 1000)
+    yield w, t
+    t.close()
+
+
+def _plan(w, **kw):
+    from viyadb_amd.executor import AggPlan
+    d = dict(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, groups_hint=w.plan.groups_hint)
+    d.update(kw)
+    return AggPlan(**d)
+
+
+def _canon(res):
+    order = np.lexsort([k for k in reversed(res.keys)]) if res.keys else np.arange(res.ngroups)
+    return [k[order] for k in res.keys], [s[order] for s in res.states]
+
+
+def test_c3_full_size_properties(c3_full):
+    w, t = c3_full
+    full = t.query_agg(_plan(w))
+    assert full.scanned_recs == 1_000_000_000 and full.scanned_segments == 1000
+    assert full.ngroups == 100_000          # d0 x d1 = 1000 x 100, every cell is hit at 50 M survivors
+    # (1) totals through an independent path: no GROUP BY -> LDS scalar table, different kernel instantiation
+    tot = t.query_agg(_plan(w, groups=[]))
+    assert tot.ngroups == 1 and tot.passed_recs == full.passed_recs
+    assert int(full.states[0].sum(dtype=np.int64)) == int(tot.states[0][0])
+    assert int(full.states[1].sum(dtype=np.uint64) & 0xFFFFFFFF) == int(tot.states[1][0])   # uint32 COUNT wraps mod 2^32
+    # (2) every table organisation gives the same groups and states bit for bit
+    kf, sf = _canon(full)
+    for flags in (1, 8, 16 | 32, 64):       # hash table; generic kernel; no presence carrier; radix-partitioned
+        other = t.query_agg(_plan(w, flags=flags))
+        ko, so = _canon(other)
+        assert other.ngroups == full.ngroups, flags
+        for a, b in zip(kf + sf, ko + so):
+            assert np.array_equal(a, b), flags
+    # (3) linearity over segment ranges (size() snapshots of 0 hide a segment)
+    lo = t.query_agg(_plan(w, seg_rows=[1_000_000] * 400 + [0] * 600))
+    hi = t.query_agg(_plan(w, seg_rows=[0] * 400 + [1_000_000] * 600))
+    assert lo.scanned_recs + hi.scanned_recs == full.scanned_recs and lo.passed_recs + hi.passed_recs == full.passed_recs
+    acc = {}
+    for part in (lo, hi):
+        g = part.keys[0].astype(np.int64) * 100 + part.keys[1]
+        for j in (0, 1):
+            a = acc.setdefault(j, np.zeros(100_000, dtype=np.int64))
+            np.add.at(a, g, part.states[j].astype(np.int64))
+    g = kf[0].astype(np.int64) * 100 + kf[1]
+    assert np.array_equal(acc[0][g], sf[0]) and np.array_equal((acc[1][g] & 0xFFFFFFFF).astype(np.uint32), sf[1])
+    # (4) idempotence
+    again = t.query_agg(_plan(w))
+    for a, b in zip(kf + sf, sum(map(list, _canon(again)), [])):
+        assert np.array_equal(a, b)
+
+
+def test_c3_full_size_sample_against_oracle(c3_full):
+    """Segments 497..499 of the 1 B-row table vs the oracle on the same generated rows."""
+    from oracle import viya_oracle as vo
+    from tests.parity import build_oracle_table, compare
+    w, t = c3_full
+    snap = [0] * 1000
+    for s in (497, 498, 499):
+        snap[s] = 1_000_000
+    res = t.query_agg(_plan(w, seg_rows=snap))
+    ot = build_oracle_table(w, 3, 1_000_000, row_base=497 * 1_000_000)
+    st = vo.scan_aggregate(vo.parse_query(ot, w.query))
+    st.scanned_recs, st.scanned_segments = res.scanned_recs, res.scanned_segments   # 997 hidden segments are still "scanned"
+    compare(res, st, "C3 full table, 3-segment window")
+
+
+def test_c2_full_size_against_twin():
+    """C2 at its full 100 M rows: the CPU twin finishes this one in seconds, so compare exactly."""
+    from oracle import cpu_twin
+    from tests.parity import build_oracle_table, compare
+    from viyadb_amd import synth
+    w = synth.c2()
+    t = synth.create_device_table(w, 100)
+    try:
+        res = t.query_agg(_plan(w))
+        ot = build_oracle_table(w, 100, 1_000_000)
+        st = cpu_twin.Twin(ot, w.query).run()
+        st.passed_recs = res.passed_recs
+        compare(res, st, "C2 100M")
+    finally:
+        t.close()
