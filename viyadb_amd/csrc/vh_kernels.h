@@ -1025,6 +1025,9 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
         cnt += __popcll(bal);
       }
       __builtin_amdgcn_wave_barrier();
+      // Tried and measured slower (profiles/r01/NOTES.md): draining two survivors per lane with both gathers
+      // in flight (+8..50 %: register pressure), and a "dense lane" path with coalesced 4-row payload loads
+      // for wave steps where most rows pass (179-242 VGPRs, scratch spills in the LDS variant).
       while (cnt >= 64) {
         cnt -= 64;
         const uint32_t r = q[cnt + lane];
