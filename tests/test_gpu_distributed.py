@@ -39,7 +39,7 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 64), ("C2", 0), ("C2", 2), ("C1", 0)])
+@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 64), ("C2", 0), ("C2", 2), ("C1", 0), ("C3", 1), ("C5t", 0)])
 def test_two_ranks_one_gpu(tmp_path, wl, flags):
     out = str(tmp_path / "res.npz")
     script = tmp_path / "worker.py"
@@ -56,7 +56,7 @@ def test_two_ranks_one_gpu(tmp_path, wl, flags):
     from tests.parity import build_oracle_table, sort_rows
     from viyadb_amd import synth
     w = synth.WORKLOADS[wl](segment_rows=50000)
-    st = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 9, 50000), w.query))
+    st = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 9, 50000), w.query), now=getattr(w, "now", None))
     nk = int(got["nk"])
     arrs = [got["arr_%d" % i] for i in range(nk + len(st.states))]
     keys, states = arrs[:nk], arrs[nk:]

@@ -58,6 +58,50 @@ def reduce_host_partials(torch, dist, arrays: List[tuple], dst: int = 0):
         dist.reduce(t, dst=dst, op=ops[reduce])
 
 
+def _merge_kind(kind: int) -> int:
+    """Aggregation that merges two partial states of a metric of this kind (the reference retypes `count`
+    as `long_sum` in its cluster merge table for the same reason: src/cluster/query/agg_runner.cc:66-76)."""
+    if kind == capi.METRIC_MAX:
+        return capi.METRIC_MAX
+    if kind == capi.METRIC_MIN:
+        return capi.METRIC_MIN
+    if kind == capi.METRIC_BITSET:
+        raise NotImplementedError("bitset (count-distinct) partials are cardinalities, not sets: they cannot be merged "
+                                  "(the reference's cluster path has the same limitation)")
+    return capi.METRIC_SUM
+
+
+def merge_partials_by_reaggregation(table, plan, partials):
+    """Merge per-rank partial aggregates that are NOT identically indexed (hash path: sparse keys): load them
+    as segments of a temporary device table [group columns..., metric states...] and run the aggregate kernel
+    over it with no filter — "partial aggregates are merged by re-aggregation", the reference's own cluster
+    algebra (src/cluster/query/agg_runner.cc:93-140), on the GPU instead of over HTTP + upsert.
+    partials: [(keys [np arrays], states [np arrays], hidden_count or None), ...]"""
+    from .executor import AggPlan, DeviceTable, GroupSpec
+    nk, nm = len(plan.groups), len(plan.metrics)
+    has_hidden = any(p[2] is not None for p in partials)
+    cols = [(capi.DIM_NUMERIC, table.cols[g.col][1]) for g in plan.groups]
+    cols += [(_merge_kind(table.cols[m][0]), table.cols[m][1]) for m in plan.metrics]
+    if has_hidden:
+        cols.append((capi.METRIC_SUM, capi.U64))
+    rows = max([len(p[1][0]) if p[1] else (len(p[0][0]) if p[0] else 0) for p in partials] + [1])
+    tmp = DeviceTable(cols, segment_rows=rows, reserve_segments=len(partials))
+    try:
+        for s, (keys, states, hidden) in enumerate(partials):
+            arrs = list(keys) + list(states) + ([hidden] if has_hidden else [])
+            n = len(arrs[0]) if arrs else 0
+            tmp.sync_segment(s, arrs, n)
+        mplan = AggPlan(filter=[], groups=[GroupSpec(i) for i in range(nk)], metrics=list(range(nk, nk + nm + (1 if has_hidden else 0))),
+                        groups_hint=sum(len(p[0][0]) if p[0] else 1 for p in partials))
+        res = tmp.query_agg(mplan)
+    finally:
+        tmp.close()
+    if has_hidden:
+        res.hidden_count = res.states[-1]
+        res.states = res.states[:-1]
+    return res
+
+
 def sharded_query(torch, dist, table, plan, world: int, copy: bool = True):
     """One query over a table sharded across `world` ranks; the merged result lands on rank 0, the other
     ranks return None (they only contribute their partial tables to the collective)."""
@@ -66,10 +110,33 @@ def sharded_query(torch, dist, table, plan, world: int, copy: bool = True):
     # The library must run on torch's current stream (executor.init(..., stream=...)): the collective is
     # then ordered after the scan kernels and the finalisation after the collective by stream order alone.
     res = table.query_launch(plan)
-    reduce_partials(torch, dist, table.device_buffers(res))
-    if dist.get_backend() == "gloo":
-        torch.cuda.current_stream().synchronize()
+    try:
+        bufs = table.device_buffers(res)
+    except capi.VhError:
+        bufs = None   # hash path: keys are sparse, partial tables are not identically indexed
+    if bufs is not None:
+        reduce_partials(torch, dist, bufs)
+        if dist.get_backend() == "gloo":
+            torch.cuda.current_stream().synchronize()
+        if dist.get_rank() != 0:
+            table.discard(res)
+            return None
+        return table.finalize(res, plan, copy=copy)
+    # hash path: every rank finalises its own groups, rank 0 gathers them and re-aggregates on its GPU
+    # (SURVEY 8e's key-partitioned all-to-all is the bandwidth-optimal form for ~10 M groups; this is the
+    #  simple, always-correct one)
+    mine = table.finalize(res, plan, copy=True)
+    part = (mine.keys, mine.states, mine.hidden_count)
+    gathered = [None] * world if dist.get_rank() == 0 else None
+    dist.gather_object(part, gathered, dst=0)
+    stats = torch.tensor([mine.scanned_recs, mine.scanned_segments, mine.passed_recs], dtype=torch.int64)
+    if dist.get_backend() != "gloo":
+        stats = stats.cuda()
+    dist.reduce(stats, dst=0) if dist.get_backend() != "gloo" else dist.all_reduce(stats)
     if dist.get_rank() != 0:
-        table.discard(res)
         return None
-    return table.finalize(res, plan, copy=copy)
+    merged = merge_partials_by_reaggregation(table, plan, gathered)
+    merged.scanned_recs, merged.scanned_segments, merged.passed_recs = (int(x) for x in stats.tolist())
+    merged.path = "hash+reaggregate"
+    merged.scan_kernel_ms, merged.algorithmic_bytes = mine.scan_kernel_ms, mine.algorithmic_bytes
+    return merged
