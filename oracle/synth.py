@@ -37,3 +37,17 @@ def gen_column(col_index: int, dtype, spec, seed: int, row_base: int, nrows: int
     if dtype.kind == "f":
         return (iv.astype(np.float64) * float(scale)).astype(dtype)
     return iv.astype(dtype)
+
+
+def gen_bitset_column(col_index: int, spec, seed: int, row_base: int, nrows: int, wide: bool = False):
+    """Twin of gen_csr_kernel: `add` ids per row from [0, mod). Returns a list of Python sets (one per row)."""
+    mode, mod, add, scale = spec
+    k = max(1, min(int(add), 8))
+    r = np.arange(row_base, row_base + nrows, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        colseed = np.uint64(seed) ^ (np.uint64(col_index) * GAMMA)
+        cols = [splitmix64(colseed ^ (r * np.uint64(8) + np.uint64(j))) % np.uint64(mod) for j in range(k)]
+    vals = np.stack(cols, axis=1)
+    if not wide:
+        vals = vals.astype(np.uint32)
+    return [set(int(v) for v in row) for row in vals]

@@ -23,6 +23,14 @@ def test_c5_time_rollup_hash_path(flags):
     assert res.ngroups > 100_000
 
 
+def test_c5_count_distinct_on_sparse_time_keys():
+    """C5 proper: time rollup + hour granularity + COUNT DISTINCT (device-side (group, id) set) + COUNT."""
+    from viyadb_amd import synth
+    w = synth.c5(segment_rows=60_000)
+    res, st = check_workload(w, nseg=3, expect_path="hash")
+    assert res.ngroups > 50_000 and int(res.states[0].max()) >= 2
+
+
 @pytest.mark.parametrize("name", ["C1", "C2", "C3"])
 def test_workload_small(name):
     from viyadb_amd import synth

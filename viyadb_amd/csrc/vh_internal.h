@@ -118,14 +118,17 @@ struct VhPlanDev {
   uint64_t hmask;            // capacity - 1
   uint32_t max_probe;
   uint32_t debug;            // experiment knobs (env VH_DEBUG), 0 in production
-  // ---- bitset metrics (COUNT DISTINCT): per-row id sets mirrored as CSR per segment; the scan
-  // emits (metric|group, id) pairs, the distinct count is finished after the scan
+  // ---- bitset metrics (COUNT DISTINCT): per-row id sets mirrored as CSR per segment. Every id of a
+  // surviving row is inserted into a device-wide open-addressing SET keyed by (group, id); the first
+  // insertion of a pair bumps the group's cardinality (the metric's u64 state). Union semantics of
+  // `_j |= metrics._j` + cardinality() (src/codegen/db/store.cc:153-155, src/util/bitset.h:26-67), no host pass.
   int32_t nbitset;
   int32_t bs_wide[VH_MAX_BITSET];                 // 1: uint64 ids, 0: uint32 ids
   const uint64_t* const* bs_offs[VH_MAX_BITSET];  // [nseg] -> offsets[rows + 1]
   const void* const* bs_vals[VH_MAX_BITSET];      // [nseg] -> ids
-  uint64_t* pairs;                                // 2 x pair_cap words
-  uint64_t pair_cap;
+  uint64_t* dset_keys[VH_MAX_BITSET];             // narrow ids: (group << 32 | id); wide ids: 2 words per slot
+  uint32_t* dset_tags[VH_MAX_BITSET];             // wide ids only
+  uint64_t dset_mask[VH_MAX_BITSET];
   // ---- partitioned aggregation (DENSE_PART): survivors become (gid, values) tuples, radix-partitioned
   // by gid >> part_shift into extents in HBM; a second kernel aggregates each partition in LDS
   int32_t npart;             // <= VH_MAX_PART
@@ -141,7 +144,7 @@ struct VhPlanDev {
   uint32_t part_cap;
   uint32_t max_extents;
   // ---- counters: [0] passed rows, [1] new groups (hash), [2] error flags,
-  //                [3] reserved hash slot (key == sentinel) in use, [4] emitted pairs,
+  //                [3] reserved hash slot (key == sentinel) in use, [4] distinct (group, id) pairs,
   //                [5] extent allocation cursor (DENSE_PART)
   unsigned long long* counters;
 };

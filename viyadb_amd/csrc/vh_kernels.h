@@ -330,48 +330,44 @@ __host__ __device__ __forceinline__ bool vh_sop_sext(int sop) {
 // --------------------------------------------------------------- hash insert
 #define VH_HASH_EMPTY 0xFFFFFFFFFFFFFFFFull
 
-// Open-addressing insert of a <=64-bit packed key; returns the slot. The table is in
-// HBM (the group count that sends a query here exceeds what LDS or the dense table
-// can hold); device-scope CAS on the key word is the only synchronisation.
-__device__ __forceinline__ uint64_t vh_hash_insert64(const VhPlanDev& P, uint64_t key, bool& ok, bool& fresh) {
+// Open-addressing insert of a 64-bit key (never the all-ones sentinel) into `keys`; returns the slot.
+// Device-scope CAS on the key word is the only synchronisation.
+__device__ __forceinline__ uint64_t vh_set_insert64(uint64_t* keys, uint64_t mask, uint32_t max_probe, uint64_t key,
+                                                   bool& ok, bool& fresh) {
   fresh = false;
-  if (key == VH_HASH_EMPTY) {          // the one key that collides with the sentinel
-    atomicOr(P.counters + 3, 1ull);    // marks the reserved extra slot as used
-    return P.hmask + 1;
-  }
-  uint64_t slot = vh_splitmix64(key) & P.hmask;
-  for (uint32_t probe = 0; probe <= P.max_probe; ++probe) {
+  uint64_t slot = vh_splitmix64(key) & mask;
+  for (uint32_t probe = 0; probe <= max_probe; ++probe) {
     unsigned long long expect = VH_HASH_EMPTY;
-    const bool won = __hip_atomic_compare_exchange_strong(
-        reinterpret_cast<unsigned long long*>(P.hkeys) + slot, &expect, (unsigned long long)key,
-        __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool won = __hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long*>(keys) + slot, &expect,
+                                                          (unsigned long long)key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
     if (won) { fresh = true; return slot; }
     if (expect == key) return slot;
-    slot = (slot + 1) & P.hmask;
+    slot = (slot + 1) & mask;
   }
   ok = false;
   return 0;
 }
 
-// Wide keys (> 64 bits): slot tag word 0 = empty, 1 = being written, 2 = ready.
+// Multi-word keys: slot tag word 0 = empty, 1 = being written, 2 = ready.
 // A lane that wins the tag writes the key words, releases, and is done inside the same
 // loop iteration, so lanes of its own wave that spin on the tag cannot starve it.
-__device__ __forceinline__ uint64_t vh_hash_insert_wide(const VhPlanDev& P, const uint64_t* key, int kw,
-                                                        bool& ok, bool& fresh) {
+__device__ __forceinline__ uint64_t vh_set_insert_wide(uint64_t* keys, uint32_t* tags, uint64_t mask, uint32_t max_probe,
+                                                      const uint64_t* key, int kw, bool& ok, bool& fresh) {
   fresh = false;
   uint64_t h = 0x243F6A8885A308D3ull;
   for (int i = 0; i < kw; ++i) h = vh_splitmix64(h ^ key[i]);
-  uint64_t slot = h & P.hmask;
+  uint64_t slot = h & mask;
   uint32_t probe = 0;
-  while (probe <= P.max_probe) {
-    uint32_t tag = __hip_atomic_load(P.htags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (probe <= max_probe) {
+    uint32_t tag = __hip_atomic_load(tags + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tag == 0) {
       uint32_t expect = 0;
-      if (__hip_atomic_compare_exchange_strong(P.htags + slot, &expect, 1u, __ATOMIC_RELAXED,
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+      if (__hip_atomic_compare_exchange_strong(tags + slot, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT)) {
         for (int i = 0; i < kw; ++i)
-          __hip_atomic_store(P.hkeys + slot * kw + i, key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(P.htags + slot, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(keys + slot * kw + i, key[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tags + slot, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         fresh = true;
         return slot;
       }
@@ -381,13 +377,47 @@ __device__ __forceinline__ uint64_t vh_hash_insert_wide(const VhPlanDev& P, cons
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     bool same = true;
     for (int i = 0; i < kw; ++i)
-      same &= __hip_atomic_load(P.hkeys + slot * kw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key[i];
+      same &= __hip_atomic_load(keys + slot * kw + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == key[i];
     if (same) return slot;
-    slot = (slot + 1) & P.hmask;
+    slot = (slot + 1) & mask;
     ++probe;
   }
   ok = false;
   return 0;
+}
+
+// group table: the table is in HBM (the group count that sends a query here exceeds what LDS or the dense
+// table can hold)
+__device__ __forceinline__ uint64_t vh_hash_insert64(const VhPlanDev& P, uint64_t key, bool& ok, bool& fresh) {
+  fresh = false;
+  if (key == VH_HASH_EMPTY) {          // the one key that collides with the sentinel
+    atomicOr(P.counters + 3, 1ull);    // marks the reserved extra slot as used
+    return P.hmask + 1;
+  }
+  return vh_set_insert64(P.hkeys, P.hmask, P.max_probe, key, ok, fresh);
+}
+__device__ __forceinline__ uint64_t vh_hash_insert_wide(const VhPlanDev& P, const uint64_t* key, int kw, bool& ok, bool& fresh) {
+  return vh_set_insert_wide(P.hkeys, P.htags, P.hmask, P.max_probe, key, kw, ok, fresh);
+}
+
+// COUNT DISTINCT: insert every id of the row's set into metric b's (group, id) set; first sight bumps card[gid]
+__device__ __forceinline__ void vh_distinct_update(const VhPlanDev& P, int b, unsigned long long* card, uint64_t gid,
+                                                   uint32_t seg, uint32_t row) {
+  const uint64_t* offs = P.bs_offs[b][seg];
+  const uint64_t o0 = offs[row], o1 = offs[row + 1];
+  const void* vals = P.bs_vals[b][seg];
+  for (uint64_t k = o0; k < o1; ++k) {
+    bool ok = true, fresh = false;
+    if (P.bs_wide[b]) {
+      const uint64_t key[2] = {gid, reinterpret_cast<const uint64_t*>(vals)[k]};
+      vh_set_insert_wide(P.dset_keys[b], P.dset_tags[b], P.dset_mask[b], 4096u, key, 2, ok, fresh);
+    } else {
+      const uint64_t key = (gid << 32) | reinterpret_cast<const uint32_t*>(vals)[k];   // gid < 2^32 - 1 (host checks)
+      vh_set_insert64(P.dset_keys[b], P.dset_mask[b], 4096u, key, ok, fresh);
+    }
+    if (!ok) atomicOr(P.counters + 2, VH_ERR_HASH_FULL);
+    if (fresh) { atomicAdd(card + gid, 1ull); atomicAdd(P.counters + 4, 1ull); }
+  }
 }
 
 // ------------------------------------------------------------ scan + aggregate
@@ -441,24 +471,12 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
   } else if (MODE == VH_MODE_DENSE_GLOBAL) {
     if (active && P.present_carrier < 0) P.present[xoff + gid] = 1;
   }
-  // bitset metrics: Metrics::Update does `_j |= metrics._j` (store.cc:153-155); here every id of the
-  // row's set is emitted as a (metric|group, id) pair and the union's cardinality is taken afterwards
-  for (int b = 0; b < P.nbitset; ++b) {
-    if (!active) continue;
-    const uint64_t* offs = P.bs_offs[b][seg];
-    const uint64_t o0 = offs[row], o1 = offs[row + 1];
-    if (o1 == o0) continue;
-    const unsigned long long at = atomicAdd(P.counters + 4, (unsigned long long)(o1 - o0));
-    const void* vals = P.bs_vals[b][seg];
-    for (uint64_t k = o0; k < o1; ++k) {
-      const uint64_t w = at + (k - o0);
-      if (w >= P.pair_cap) break;
-      P.pairs[2 * w] = ((uint64_t)b << 56) | gid;
-      P.pairs[2 * w + 1] = P.bs_wide[b] ? reinterpret_cast<const uint64_t*>(vals)[k] : reinterpret_cast<const uint32_t*>(vals)[k];
-    }
-  }
   for (int j = 0; j < P.nmetric; ++j) {
     const VhMetricDev& m = P.m[j];
+    if (m.sop == SOP_BITSET) {   // m.slot = bitset index, m.state = u64 cardinality per group
+      if (active) vh_distinct_update(P, m.slot, reinterpret_cast<unsigned long long*>(m.state), MODE == VH_MODE_HASH ? gid : xoff + gid, seg, row);
+      continue;
+    }
     const char* base = P.colbase[m.slot] + (uint64_t)seg * P.colstride[m.slot];
     const uint64_t bits = vh_load_bits(base, m.type, row, vh_sop_sext(m.sop));
     if (active) {

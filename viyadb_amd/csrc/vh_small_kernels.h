@@ -9,7 +9,7 @@
 __device__ __forceinline__ uint64_t vh_combine(int sop, uint64_t a, uint64_t b) {
   switch (sop) {
     case SOP_ADD32: return (uint32_t)((uint32_t)a + (uint32_t)b);
-    case SOP_ADD64: case SOP_ADD32P: return a + b;
+    case SOP_ADD64: case SOP_ADD32P: case SOP_BITSET: return a + b;
     case SOP_ADDF32: return __float_as_uint(__uint_as_float((uint32_t)a) + __uint_as_float((uint32_t)b));
     case SOP_ADDF64: return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
     case SOP_MIN_I32: return (uint32_t)((int32_t)b < (int32_t)a ? b : a);
@@ -78,7 +78,6 @@ struct VhEmitArgs {
   const uint64_t* hkeys; const uint32_t* htags;
   const unsigned long long* counters;
   unsigned long long* out_count;
-  uint64_t* out_gid;              // optional: table index of output row `pos` (bitset metrics)
   VhGroupDev g[VH_MAX_GROUP];
   void* out_key[VH_MAX_GROUP];
   const void* state[VH_MAX_METRIC];
@@ -117,7 +116,6 @@ __global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
   base = __shfl(base, 0);
   if (!have) return;
   const uint64_t pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-  if (A.out_gid) A.out_gid[pos] = i;
   for (int c = 0; c < A.ngroup; ++c) {
     const VhGroupDev& g = A.g[c];
     uint64_t v;
@@ -163,6 +161,18 @@ __global__ __launch_bounds__(256) void gen_kernel(T* base, uint64_t seg_stride_e
       else out = (T)iv;
     }
     col[i] = out;
+  }
+}
+
+// synthetic bitset (count-distinct) column as CSR: exactly `k` ids per row, id = splitmix64(colseed ^ (r * 8 + i)) % mod
+template <typename T>
+__global__ __launch_bounds__(256) void gen_csr_kernel(uint64_t* offsets, T* values, uint64_t rows, uint32_t k,
+                                                      uint64_t row_base, uint64_t mod, uint64_t colseed) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i <= rows; i += (uint64_t)gridDim.x * 256) {
+    offsets[i] = i * k;
+    if (i == rows) break;
+    const uint64_t r = row_base + i;
+    for (uint32_t j = 0; j < k; ++j) values[i * k + j] = (T)(vh_splitmix64(colseed ^ (r * 8 + j)) % mod);
   }
 }
 

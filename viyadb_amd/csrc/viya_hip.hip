@@ -310,9 +310,26 @@ extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nse
   if (rc) return rc;
   for (size_t i = 0; i < t->cols.size(); ++i) {
     auto& c = t->cols[i];
-    if (is_bitset_elem(c.elem)) return vh_fail(VH_E_UNSUPPORTED, "synthetic bitset columns are generated by the caller");
     if (specs[i].mode == VH_GEN_UNIFORM && specs[i].mod == 0) return vh_fail(VH_E_INVALID, "column %zu: mod == 0", i);
     const uint64_t colseed = seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull);
+    if (is_bitset_elem(c.elem)) {   // CSR per segment: `add` ids per row drawn from [0, mod)
+      const uint32_t k = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(specs[i].add, 8));
+      const size_t vsz = c.elem == VH_BITSET32 ? 4 : 8;
+      for (uint32_t sgi = 0; sgi < nseg; ++sgi) {
+        const uint32_t seg = seg_first + sgi;
+        if (c.bs_offsets[seg]) { HIP_TRY(hipFree(c.bs_offsets[seg])); c.bs_offsets[seg] = nullptr; }
+        if (c.bs_values[seg]) { HIP_TRY(hipFree(c.bs_values[seg])); c.bs_values[seg] = nullptr; }
+        HIP_TRY(hipMalloc((void**)&c.bs_offsets[seg], (rows_per_seg + 1) * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc((void**)&c.bs_values[seg], std::max<size_t>(rows_per_seg * k * vsz, 8)));
+        const unsigned grid = (unsigned)std::min<uint64_t>(512, (rows_per_seg + 256) / 256);
+        const uint64_t rb = row_base + (uint64_t)sgi * rows_per_seg;
+        if (vsz == 4) gen_csr_kernel<uint32_t><<<grid, 256, 0, g_ctx.stream>>>(c.bs_offsets[seg], (uint32_t*)c.bs_values[seg], rows_per_seg, k, rb, specs[i].mod, colseed);
+        else gen_csr_kernel<uint64_t><<<grid, 256, 0, g_ctx.stream>>>(c.bs_offsets[seg], (uint64_t*)c.bs_values[seg], rows_per_seg, k, rb, specs[i].mod, colseed);
+        c.bs_nvalues[seg] = rows_per_seg * k;
+        t->device_bytes += (rows_per_seg + 1) * 8 + rows_per_seg * k * vsz;
+      }
+      continue;
+    }
     dim3 grid((unsigned)std::min<uint64_t>(256, (rows_per_seg + 255) / 256), nseg);
     VH_ELEM_SWITCH(c.elem, (gen_kernel<T><<<grid, dim3(256), 0, g_ctx.stream>>>(
                                reinterpret_cast<T*>(c.base + (size_t)seg_first * c.stride), c.stride / c.esize,
@@ -421,8 +438,6 @@ struct vh_result {
   std::vector<int> group_elem;
   std::string group_sig;
   std::vector<int> user_metric;        // per plan metric: >= 0 index into P.m, < 0: -(bitset index + 1)
-  uint64_t* d_out_gid = nullptr;
-  std::vector<std::vector<uint64_t>> h_bitset_card;  // per bitset metric: cardinality per output row
   uint64_t out_cap = 0;                // rows the output arrays can hold
   unsigned long long* d_out_count = nullptr;
   void* d_out_key[VH_MAX_GROUP] = {};
@@ -450,7 +465,7 @@ extern "C" int vh_result_view(vh_result* r, const void** key_cols, const void** 
   for (size_t j = 0; j < r->user_metric.size(); ++j) {
     if (!state_cols) break;
     const int u = r->user_metric[j];
-    state_cols[j] = u >= 0 ? (const void*)(r->h_base + r->off_state[u]) : (const void*)r->h_bitset_card[-u - 1].data();
+    state_cols[j] = r->h_base + r->off_state[u];
   }
   if (hidden_count) *hidden_count = r->info.has_hidden_count ? reinterpret_cast<const uint64_t*>(r->h_base + r->off_state[r->plan.nmetric - 1]) : nullptr;
   return VH_OK;
@@ -467,7 +482,7 @@ extern "C" int vh_result_copy(vh_result* r, void* const* key_cols, void* const* 
   for (size_t j = 0; j < r->user_metric.size(); ++j) {
     if (!state_cols || !state_cols[j] || !ng) continue;
     const int u = r->user_metric[j];
-    memcpy(state_cols[j], sp[j], ng * (u >= 0 ? vh_elem_size(r->metric_elem[u]) : 8));
+    memcpy(state_cols[j], sp[j], ng * vh_elem_size(r->metric_elem[u]));
   }
   if (hidden_count && hp && ng) memcpy(hidden_count, hp, ng * 8);
   return VH_OK;
@@ -769,6 +784,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   P.nmetric = 0;
   bool has_avg = false, has_count = false;
   int bitset_col[VH_MAX_BITSET];
+  uint64_t bitset_ids[VH_MAX_BITSET] = {}, bitset_ids_before = 0;   // ids stored in the scanned segments, per bitset metric
   uint64_t pair_cap = 0;
   for (int j = 0; j < p->nmetrics; ++j) {
     const int col = p->metrics[j];
@@ -781,8 +797,13 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
         pair_cap += c.bs_nvalues[sgi];
       }
       bitset_col[P.nbitset] = col;
+      bitset_ids[P.nbitset] = pair_cap - bitset_ids_before;
+      bitset_ids_before = pair_cap;
       P.bs_wide[P.nbitset] = c.elem == VH_BITSET64;
-      r->user_metric.push_back(-(P.nbitset + 1));
+      VhMetricDev& m = P.m[P.nmetric];
+      m.slot = (uint16_t)P.nbitset; m.type = VH_U64; m.sop = SOP_BITSET; m.ident = 0;
+      r->user_metric.push_back(P.nmetric++);
+      r->metric_elem.push_back(VH_U64);
       ++P.nbitset;
       continue;
     }
@@ -796,7 +817,6 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     r->metric_elem.push_back(c.elem);
     has_avg |= c.kind == VH_METRIC_AVG; has_count |= c.kind == VH_METRIC_COUNT;
   }
-  P.pair_cap = pair_cap;
   if (has_avg && !has_count) {
     // hidden uint64_t _count (src/codegen/query/scan.cc:239-241)
     int hc = -1;
@@ -831,7 +851,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     P.lds_present_off = (uint32_t)off; off += G;
     lds_table = (off + 15) / 16 * 16;
     const size_t lds_budget = 40 * 1024;
-    mode = (lds_table <= lds_budget && !(p->flags & VH_PLAN_FORCE_GLOBAL)) ? VH_MODE_DENSE_LDS : VH_MODE_DENSE_GLOBAL;
+    mode = (lds_table <= lds_budget && !(p->flags & VH_PLAN_FORCE_GLOBAL) && P.nbitset == 0) ? VH_MODE_DENSE_LDS : VH_MODE_DENSE_GLOBAL;
     P.G = G;
     P.lds_bytes = (uint32_t)lds_table;
   } else {
@@ -910,7 +930,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
 
   // per-XCD private copies only while they stay cache-sized
   int nxcd = 1;
-  if (mode != VH_MODE_HASH && mode != VH_MODE_DENSE_PART && !(p->flags & VH_PLAN_NO_XCD_PRIVATE) &&
+  if (mode != VH_MODE_HASH && mode != VH_MODE_DENSE_PART && P.nbitset == 0 && !(p->flags & VH_PLAN_NO_XCD_PRIVATE) &&
       G <= 16384)   // private copies pay off only against same-address contention (C2 forced to HBM: 3.4 vs 10 ms);
     nxcd = g_ctx.num_xcd;   // with >= 100 K groups one table is as fast and needs no merge pass
   P.nxcd = nxcd; r->nxcd = nxcd;
@@ -1004,11 +1024,19 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     o_pext = sp.take((uint64_t)P.npart * P.part_cap * sizeof(uint32_t));
     o_emiss = sp.take(max_ext * sizeof(uint16_t));
   }
-  size_t o_pairs = 0, o_outgid = 0, o_bsptr[VH_MAX_BITSET][2] = {};
-  if (P.nbitset) {
-    o_pairs = sp.take(std::max<uint64_t>(pair_cap, 1) * 16);
-    o_outgid = sp.take(r->out_cap * sizeof(uint64_t));
-    for (int b = 0; b < P.nbitset; ++b) { o_bsptr[b][0] = sp.take(std::max<uint32_t>(nseg, 1) * 8); o_bsptr[b][1] = sp.take(std::max<uint32_t>(nseg, 1) * 8); }
+  size_t o_bsptr[VH_MAX_BITSET][2] = {}, o_dkeys[VH_MAX_BITSET] = {}, o_dtags[VH_MAX_BITSET] = {};
+  for (int b = 0; b < P.nbitset; ++b) {
+    o_bsptr[b][0] = sp.take(std::max<uint32_t>(nseg, 1) * 8);
+    o_bsptr[b][1] = sp.take(std::max<uint32_t>(nseg, 1) * 8);
+    // the (group, id) set can never hold more pairs than there are ids in the scanned segments
+    uint64_t cap = 1024;
+    while (cap < bitset_ids[b] * 2) cap <<= 1;
+    P.dset_mask[b] = cap - 1;
+    if (P.bs_wide[b]) { o_dkeys[b] = sp.take(cap * 16); o_dtags[b] = sp.take(cap * 4); }
+    else {
+      if (table_n >= 0xFFFFFFFFull) { delete r; return vh_fail(VH_E_UNSUPPORTED, "count-distinct over more than 2^32 group slots"); }
+      o_dkeys[b] = sp.take(cap * 8);
+    }
   }
   rc = ensure_scratch(t, sp.off);
   if (rc) { delete r; return rc; }
@@ -1030,9 +1058,9 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     P.extent_missing = reinterpret_cast<uint16_t*>(S + o_emiss);
   }
   if (P.nbitset) {
-    P.pairs = reinterpret_cast<uint64_t*>(S + o_pairs);
-    r->d_out_gid = reinterpret_cast<uint64_t*>(S + o_outgid);
     for (int b = 0; b < P.nbitset; ++b) {
+      P.dset_keys[b] = reinterpret_cast<uint64_t*>(S + o_dkeys[b]);
+      P.dset_tags[b] = P.bs_wide[b] ? reinterpret_cast<uint32_t*>(S + o_dtags[b]) : nullptr;
       const VhColumn& c = t->cols[bitset_col[b]];
       P.bs_offs[b] = reinterpret_cast<const uint64_t* const*>(S + o_bsptr[b][0]);
       P.bs_vals[b] = reinterpret_cast<const void* const*>(S + o_bsptr[b][1]);
@@ -1056,6 +1084,10 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     else HIP_TRY(hipMemsetAsync(P.htags, 0, table_n * sizeof(uint32_t), st));
   }
   if (zero_end > zero_begin) HIP_TRY(hipMemsetAsync(S + zero_begin, 0, zero_end - zero_begin, st));
+  for (int b = 0; b < P.nbitset; ++b) {
+    if (P.bs_wide[b]) HIP_TRY(hipMemsetAsync(P.dset_tags[b], 0, (P.dset_mask[b] + 1) * 4, st));
+    else HIP_TRY(hipMemsetAsync(P.dset_keys[b], 0xFF, (P.dset_mask[b] + 1) * 8, st));
+  }
   if (mode == VH_MODE_DENSE_PART) {
     HIP_TRY(hipMemsetAsync(P.part_count, 0, VH_MAX_PART * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(P.extent_missing, 0, (size_t)P.max_extents * sizeof(uint16_t), st));
@@ -1097,6 +1129,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
 
 extern "C" int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs, int32_t max_bufs, int32_t* nbufs) {
   if (!r || !bufs || !nbufs) return vh_fail(VH_E_INVALID, "null argument");
+  if (r->plan.nbitset) return vh_fail(VH_E_UNSUPPORTED, "count-distinct partials are cardinalities: they cannot be reduced across GPUs");
   if (r->mode == VH_MODE_HASH) return vh_fail(VH_E_UNSUPPORTED, "hash-path partials are exchanged by key, not reduced in place");
   const VhPlanDev& P = r->plan;
   int n = 0;
@@ -1138,7 +1171,6 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   A.mode = r->mode == VH_MODE_DENSE_PART ? VH_MODE_DENSE_GLOBAL : r->mode; A.ngroup = P.ngroup; A.nmetric = P.nmetric; A.key_words = P.key_words;
   A.n = r->out_cap; A.present = P.present; A.present_carrier = r->mode == VH_MODE_DENSE_GLOBAL ? P.present_carrier : -1; A.hkeys = P.hkeys; A.htags = P.htags; A.counters = P.counters;
   A.out_count = r->d_out_count;
-  A.out_gid = r->d_out_gid;
   for (int i = 0; i < P.ngroup; ++i) { A.g[i] = P.g[i]; A.out_key[i] = r->d_out_key[i]; }
   for (int j = 0; j < P.nmetric; ++j) {
     A.state[j] = P.m[j].state; A.out_state[j] = r->d_out_state[j]; A.sop[j] = P.m[j].sop; A.mtype[j] = (uint8_t)r->metric_elem[j];
@@ -1166,7 +1198,6 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   if (err & VH_ERR_PART_FULL) { *retry = 3; return VH_OK; }
   if (err & VH_ERR_RANGE) { *retry = 2; return VH_OK; }
   const uint64_t ng = *reinterpret_cast<const unsigned long long*>(H + 256);
-  const uint64_t npairs_emitted = hc[4];
   r->info.ngroups = ng;
   r->ngroups_host = ng;
   r->info.passed_recs = hc[0];
@@ -1176,32 +1207,6 @@ static int result_finalize_locked(vh_result* r, int* retry) {
       HIP_TRY(hipMemcpyAsync(H + r->off_key[i], D + r->off_key[i], ng * vh_elem_size(P.g[i].type), hipMemcpyDeviceToHost, st));
     for (int j = 0; j < P.nmetric; ++j)
       HIP_TRY(hipMemcpyAsync(H + r->off_state[j], D + r->off_state[j], ng * vh_elem_size(r->metric_elem[j]), hipMemcpyDeviceToHost, st));
-  }
-  if (P.nbitset) {
-    // COUNT DISTINCT finish ("bitset metrics materialised host-side", north_star): the scan left
-    // (metric|group, id) pairs in HBM; sort + unique them and count per group.
-    const uint64_t npairs = std::min<uint64_t>(npairs_emitted, P.pair_cap);
-    std::vector<uint64_t> pairs(npairs * 2), gids(ng);
-    if (npairs) HIP_TRY(hipMemcpyAsync(pairs.data(), P.pairs, npairs * 16, hipMemcpyDeviceToHost, st));
-    if (ng) HIP_TRY(hipMemcpyAsync(gids.data(), r->d_out_gid, ng * 8, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    std::vector<std::pair<uint64_t, uint64_t>> pv(npairs);
-    for (uint64_t i = 0; i < npairs; ++i) pv[i] = {pairs[2 * i], pairs[2 * i + 1]};
-    std::sort(pv.begin(), pv.end());
-    pv.erase(std::unique(pv.begin(), pv.end()), pv.end());
-    std::vector<std::pair<uint64_t, uint64_t>> order(ng);  // (table index, output row)
-    for (uint64_t i = 0; i < ng; ++i) order[i] = {gids[i], i};
-    std::sort(order.begin(), order.end());
-    r->h_bitset_card.assign(P.nbitset, std::vector<uint64_t>(ng, 0));
-    for (size_t i = 0; i < pv.size();) {
-      size_t j = i;
-      while (j < pv.size() && pv[j].first == pv[i].first) ++j;
-      const int b = (int)(pv[i].first >> 56);
-      const uint64_t gid = pv[i].first & ((1ull << 56) - 1);
-      auto it = std::lower_bound(order.begin(), order.end(), std::make_pair(gid, (uint64_t)0));
-      if (it != order.end() && it->first == gid) r->h_bitset_card[b][it->second] = j - i;
-      i = j;
-    }
   }
   HIP_TRY(hipEventRecord(t->ev[3], st));
   HIP_TRY(hipStreamSynchronize(st));

@@ -136,7 +136,21 @@ def c5t(segment_rows=1_000_000) -> Workload:
     return w
 
 
-WORKLOADS = {"C1": c1, "C2": c2, "C3": c3, "C5t": c5t}
+def c5(segment_rows=1_000_000) -> Workload:
+    """C5: C5t plus the count-distinct (bitset) metric: 2 user ids per stored row from [0, 10^7)."""
+    w = c5t(segment_rows)
+    w.columns = w.columns[:3] + [SynthColumn("users", capi.METRIC_BITSET, capi.BITSET32, (U, 10_000_000, 2, 1.0), "bitset"),
+                                 w.columns[3]]
+    w.plan = AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=[3, 4], groups_hint=0)
+    w.query = dict(w.query, select=[{"column": "t", "granularity": "hour"}, {"column": "u"}, {"column": "users"}, {"column": "count"}])
+    w.name = "C5"
+    w.description = "time dim + rollup rules + hour granularity, GROUP BY (t,u), COUNT DISTINCT users + COUNT (hash path)"
+    w.bytes_per_row_referenced = 4 + 4 + 4 + 8 + 2 * 4
+    w.table_bytes_per_row = 16 + 8 + 2 * 4
+    return w
+
+
+WORKLOADS = {"C1": c1, "C2": c2, "C3": c3, "C5t": c5t, "C5": c5}
 
 
 def create_device_table(w: Workload, nseg: int, rows_per_seg=None, row_base=0, seed=SEED):
