@@ -227,6 +227,12 @@ VH_API void vh_table_destroy(vh_table* t);
  * used for segment skipping. */
 VH_API int vh_segment_sync(vh_table* t, uint32_t seg, uint64_t nrows,
                            const void* const* col_ptrs);
+/* Dirty-range form of vh_segment_sync: upsert appends to the last segment and updates
+ * metrics of existing rows in place (src/codegen/db/upsert.cc:384-411), so a caller that tracks the touched
+ * row range per segment only ships that range. col_ptrs[c] is still the BASE of the segment's column array;
+ * rows [row_first, row_first + nrows) are copied and the segment then has `new_size` valid rows. */
+VH_API int vh_segment_sync_range(vh_table* t, uint32_t seg, uint64_t row_first, uint64_t nrows,
+                                 uint64_t new_size, const void* const* col_ptrs);
 /* Bitset metric column of one segment as CSR: offsets[nrows+1], values[].   */
 VH_API int vh_segment_sync_bitset(vh_table* t, uint32_t seg, int32_t col,
                                   uint64_t nrows, const uint64_t* offsets,

@@ -35,3 +35,33 @@ def test_reference_case_forced_table_organisation(cid, flags, monkeypatch):
     """Same answers from the hash table (1), the HBM dense table (2) and without XCD-private copies (4)."""
     monkeypatch.setenv("VIYA_HIP_PLAN_FLAGS", flags)
     gc.check_case(gc.case_by_id(cid), run_gpu)
+
+
+def test_mirror_follows_upserts():
+    """queries interleaved with loads. Upsert appends rows AND updates metrics of existing rows in
+    place; the HBM mirror must track both (dirty-range sync), across a segment boundary."""
+    import random
+    from oracle import viya_oracle as vo
+    from viyadb_amd import hostdb
+    tconf = {"name": "events", "segment_size": 500,
+             "dimensions": [{"name": "country"}, {"name": "event_name"}, {"name": "day", "type": "uint"}],
+             "metrics": [{"name": "count", "type": "count"}, {"name": "revenue", "type": "double_sum"},
+                         {"name": "best", "type": "int_max"}, {"name": "users", "type": "bitset"}]}
+    q = {"type": "aggregate", "table": "events", "dimensions": ["country", "event_name"],
+         "metrics": ["count", "revenue", "best", "users"], "filter": {"op": "ge", "column": "day", "value": "3"}}
+    rnd = random.Random(4)
+    gdb = hostdb.Database({"tables": [tconf]})
+    odb = vo.Database({"tables": [tconf]})
+    try:
+        for batch in range(6):
+            rows = [[rnd.choice(["US", "IL", "KZ", "RU", "AZ"]), rnd.choice(["open", "buy", "quit"]), str(rnd.randrange(0, 90)),
+                     str(rnd.randrange(0, 500) / 4), str(rnd.randrange(-50, 50)), str(rnd.randrange(0, 40))] for _ in range(350)]
+            gdb.load("events", rows)
+            odb.table("events").load(rows)
+            got, gst = gdb.query(q)
+            want, ost = odb.query(q)
+            assert sorted(got) == sorted(want), batch
+            assert gst["scanned_recs"] == ost["scanned_recs"] and gst["aggregated_recs"] == ost["aggregated_recs"]
+        assert gdb.table_info("events")["segments"] >= 2
+    finally:
+        gdb.close()

@@ -98,6 +98,7 @@ SYMBOLS = {
     "vh_table_create": (C.c_int, [C.POINTER(ColDesc), C.c_int32, C.c_uint64, C.c_uint32, C.POINTER(_VP)]),
     "vh_table_destroy": (None, [_VP]),
     "vh_segment_sync": (C.c_int, [_VP, C.c_uint32, C.c_uint64, C.POINTER(_VP)]),
+    "vh_segment_sync_range": (C.c_int, [_VP, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(_VP)]),
     "vh_segment_sync_bitset": (C.c_int, [_VP, C.c_uint32, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64), _VP]),
     "vh_segment_generate": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(GenSpec), C.c_uint64]),
     "vh_segment_read": (C.c_int, [_VP, C.c_uint32, C.c_int32, C.c_uint64, _VP]),

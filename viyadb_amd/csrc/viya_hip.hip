@@ -280,6 +280,32 @@ extern "C" int vh_segment_sync(vh_table* t, uint32_t seg, uint64_t nrows, const 
   return refresh_stats(t, seg, 1);
 }
 
+extern "C" int vh_segment_sync_range(vh_table* t, uint32_t seg, uint64_t row_first, uint64_t nrows, uint64_t new_size,
+                                     const void* const* col_ptrs) {
+  if (!t || !col_ptrs) return vh_fail(VH_E_INVALID, "vh_segment_sync_range: null argument");
+  if (new_size > t->segment_rows || row_first + nrows > new_size)
+    return vh_fail(VH_E_INVALID, "vh_segment_sync_range: rows [%llu, %llu) do not fit a segment of %llu rows",
+                   (unsigned long long)row_first, (unsigned long long)(row_first + nrows), (unsigned long long)new_size);
+  std::lock_guard<std::mutex> lk(t->mu);
+  int rc = table_grow(t, seg + 1);
+  if (rc) return rc;
+  if (row_first > t->seg_rows[seg])
+    return vh_fail(VH_E_INVALID, "vh_segment_sync_range: segment %u has %llu mirrored rows, range starts at %llu (gap)",
+                   seg, (unsigned long long)t->seg_rows[seg], (unsigned long long)row_first);
+  for (size_t i = 0; i < t->cols.size(); ++i) {
+    auto& c = t->cols[i];
+    if (is_bitset_elem(c.elem) || !col_ptrs[i] || !nrows) continue;
+    HIP_TRY(hipMemcpyAsync(c.base + (size_t)seg * c.stride + row_first * c.esize,
+                           static_cast<const char*>(col_ptrs[i]) + row_first * c.esize, (size_t)nrows * c.esize,
+                           hipMemcpyHostToDevice, g_ctx.stream));
+  }
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  t->seg_rows[seg] = new_size;
+  t->nseg = std::max(t->nseg, seg + 1);
+  ++t->sync_epoch;
+  return refresh_stats(t, seg, 1);   // one pass over the segment's dimension columns in HBM
+}
+
 extern "C" int vh_segment_sync_bitset(vh_table* t, uint32_t seg, int32_t col, uint64_t nrows,
                                       const uint64_t* offsets, const void* values) {
   if (!t || col < 0 || (size_t)col >= t->cols.size() || !offsets) return vh_fail(VH_E_INVALID, "vh_segment_sync_bitset: bad argument");

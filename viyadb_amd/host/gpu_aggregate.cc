@@ -86,7 +86,12 @@ std::vector<uint64_t> sync_mirror(db::Table& t, GpuMirror* mir) {
     std::vector<const void*> ptrs(ncols, nullptr);
     for (size_t c = 0; c < ncols; ++c)
       if (t.storage_elem_size(c)) ptrs[c] = seg.column(c);
-    vh_check(vh_segment_sync(mir->handle, (uint32_t)s, seg.size(), ptrs.data()));
+    // ship only the rows upsert touched since the last sync (appends at the tail, in-place metric updates)
+    if (mir->synced_version[s] == ~0ull || seg.dirty_lo >= seg.dirty_hi)
+      vh_check(vh_segment_sync(mir->handle, (uint32_t)s, seg.size(), ptrs.data()));
+    else
+      vh_check(vh_segment_sync_range(mir->handle, (uint32_t)s, seg.dirty_lo, seg.dirty_hi - seg.dirty_lo, seg.size(), ptrs.data()));
+    seg.dirty_lo = SIZE_MAX; seg.dirty_hi = 0;
     for (auto* m : t.metrics()) {
       if (m->agg_type() != db::Column::BITSET) continue;
       const auto& sets = seg.bitsets(m->index());

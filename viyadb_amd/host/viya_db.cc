@@ -578,7 +578,7 @@ void Table::Upsert(std::vector<std::string>& values, const std::vector<size_t>& 
       uint64_t* p = reinterpret_cast<uint64_t*>(seg.column(hidden_count_storage_index())) + ti;
       *p += 1;
     }
-    ++seg.version;
+    seg.touch(ti);
   } else {
     Segment& seg = *LastSegment();
     const size_t ti = seg.size_;
@@ -596,7 +596,7 @@ void Table::Upsert(std::vector<std::string>& values, const std::vector<size_t>& 
       if (compare_typed(t, dvals[dp->index()], s.dmax) == 1) s.dmax = dvals[dp->index()];
       if (compare_typed(t, dvals[dp->index()], s.dmin) == -1) s.dmin = dvals[dp->index()];
     }
-    ++seg.version;
+    seg.touch(ti);
     tuple_offsets_.emplace(key, (segments_.size() - 1) * segment_size_ + ti);
   }
 }

@@ -193,6 +193,8 @@ public:
   const std::vector<std::vector<uint64_t>>& bitsets(size_t metric_index) const { return bitsets_.at(metric_index); }
   std::vector<SegmentStat> stats;  // per dimension
   uint64_t version = 0;            // bumped on every append / in-place update
+  size_t dirty_lo = SIZE_MAX, dirty_hi = 0;  // rows touched since the GPU mirror last synced this segment
+  void touch(size_t row) { dirty_lo = row < dirty_lo ? row : dirty_lo; dirty_hi = row + 1 > dirty_hi ? row + 1 : dirty_hi; ++version; }
 
 private:
   friend class Table;
