@@ -153,6 +153,11 @@ typedef struct vh_plan {
   const uint64_t* seg_rows;     uint32_t nseg;
   uint32_t flags;
   uint64_t groups_hint;         /* expected number of groups (0 = unknown)   */
+  /* Optional HAVING pushed down to the device: same node format as `filter`, literals in
+   * `lits`, but `col` is a RESULT column: i < ngroups = group column i, else metric (col - ngroups) of this
+   * plan. Semantics of post_agg.cc:77-83: AVG compares its raw sum, a bitset its cardinality. Only groups that
+   * pass are returned; vh_result_info.ngroups still counts every group (agg_map.size()). */
+  const vh_filter_node* having; int32_t nhaving; int32_t reserved2;
 } vh_plan;
 
 /* ---- results ---------------------------------------------------------------*/
@@ -176,6 +181,7 @@ typedef struct vh_result_info {
   uint64_t algorithmic_bytes;/* B_ref of SURVEY §8(d) for this query         */
   uint32_t retries;          /* hash-table regrows                           */
   uint32_t reserved;         /* bit 0: the register-resident fast scan kernel ran */
+  uint64_t returned_groups;  /* rows vh_result_copy delivers (= ngroups without HAVING) */
 } vh_result_info;
 
 /* Device-side view of a partial (not yet finalised) result, for the caller to

@@ -220,6 +220,55 @@ def test_rollup_rules_at_query_time(micro):
         dt.close()
 
 
+@pytest.mark.parametrize("flags", [0, 1, 64])
+def test_having_on_device(typed, flags):
+    """HAVING evaluated by the group-emission kernel. Keys, SUM, AVG (raw sum), MIN/MAX, IN, nested and/or."""
+    from tests.planner import capi_anynum
+    tab, dt = typed
+    cases = [
+        ({"dimensions": ["s8", "flag"], "metrics": ["count", "long_sum", "double_max", "int_avg"]},
+         {"op": "and", "filters": [F("gt", "count", "300"), {"op": "or", "filters": [F("lt", "long_sum", "0"), F("ge", "double_max", "200")]}]}),
+        ({"dimensions": ["s16"], "metrics": ["int_avg", "count"]}, F("gt", "int_avg", "5")),
+        ({"dimensions": ["d_byte", "d_float"], "metrics": ["ushort_min"]}, {"op": "or", "filters": [F("lt", "d_byte", "-10"), F("eq", "d_float", "2.5")]}),
+        ({"dimensions": ["s8"], "metrics": ["count"]}, {"op": "in", "column": "s8", "values": ["v3", "v4", "zzz"]}),
+        ({"dimensions": ["s8"], "metrics": ["count"]}, {"op": "not", "filter": {"op": "in", "column": "s8", "values": ["v3", "v4"]}}),
+    ]
+    for sel, hv in cases:
+        q = dict({"type": "aggregate", "table": "t", "filter": F("lt", "d_uint", "50"), "having": hv}, **sel)
+        aq = vo.parse_query(tab, q)
+        st = vo.scan_aggregate(aq, now=NOW)
+        total = st.ngroups
+        # oracle side: the same ComparisonBuilder semantics on the aggregated tuples (post_agg.cc:77-83)
+        cols = {oc.col.name: st.keys[k] for k, oc in enumerate(aq.dim_cols)}
+        cols.update({oc.col.name: st.states[k] for k, oc in enumerate(aq.metric_cols)})
+        keep = vo.eval_filter(tab, aq.having, lambda c: cols[c.name])
+        st.keys = [k[keep] for k in st.keys]
+        st.states = [s[keep] for s in st.states]
+        if st.hidden_count is not None:
+            st.hidden_count = st.hidden_count[keep]
+        plan = plan_from_query(tab, aq, now=NOW, flags=flags)
+        names = [oc.col.name for oc in aq.dim_cols] + [oc.col.name for oc in aq.metric_cols]
+        nodes = []
+
+        def walk(f):
+            if isinstance(f, vo.Rel):
+                c = tab.column(f.column)
+                nodes.append(("rel", names.index(f.column), {"eq": 0, "ne": 1, "lt": 2, "le": 3, "gt": 4, "ge": 5}[f.op], capi_anynum(c, vo.decode_value(tab, c, f.value))))
+            elif isinstance(f, vo.In):
+                c = tab.column(f.column)
+                nodes.append(("in", names.index(f.column), f.equal, [capi_anynum(c, vo.decode_value(tab, c, v)) for v in f.values]))
+            else:
+                for ch in f.filters:
+                    walk(ch)
+                nodes.append((f.op, len(f.filters)))
+        walk(aq.having)
+        plan.having = nodes
+        res = dt.query_agg(plan)
+        assert res.ngroups == total and res.returned == int(keep.sum()), (q, res.ngroups, total, res.returned, int(keep.sum()))
+        res.ngroups = res.returned
+        compare(res, st, str(q))
+
+
 def test_hash_table_regrows(typed):
     tab, dt = typed
     res, _ = run(tab, dt, {"dimensions": ["id", "d_double"], "metrics": ["count"]}, flags=1, groups_hint=1)

@@ -62,7 +62,8 @@ class Plan(C.Structure):
                 ("groups", C.POINTER(GroupCol)), ("ngroups", C.c_int32),
                 ("metrics", C.POINTER(C.c_int32)), ("nmetrics", C.c_int32),
                 ("seg_rows", C.POINTER(C.c_uint64)), ("nseg", C.c_uint32),
-                ("flags", C.c_uint32), ("groups_hint", C.c_uint64)]
+                ("flags", C.c_uint32), ("groups_hint", C.c_uint64),
+                ("having", C.POINTER(FilterNode)), ("nhaving", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class ResultInfo(C.Structure):
@@ -70,7 +71,7 @@ class ResultInfo(C.Structure):
                 ("passed_recs", C.c_uint64), ("path", C.c_int32), ("ngroup_cols", C.c_int32),
                 ("nmetrics", C.c_int32), ("has_hidden_count", C.c_int32), ("scan_kernel_ms", C.c_float),
                 ("total_ms", C.c_float), ("algorithmic_bytes", C.c_uint64), ("retries", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("reserved", C.c_uint32), ("returned_groups", C.c_uint64)]
 
 
 class DeviceBuffer(C.Structure):

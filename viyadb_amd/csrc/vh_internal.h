@@ -11,6 +11,8 @@
 #define VH_MAX_METRIC 12  // selected metrics (+ hidden count)
 #define VH_MAX_SLOTS 24   // distinct columns a query may reference
 #define VH_MAX_STACK 8    // predicate mask stack depth
+#define VH_MAX_HAVING 16       // postfix nodes of a pushed-down HAVING
+#define VH_MAX_HAVING_LITS 24
 #define VH_MAX_XCD 8
 #define VH_KEY_WORDS 8    // widest group key: 8 x u64
 #define VH_MAX_BITSET 2   // bitset (count-distinct) metrics per query

@@ -84,7 +84,36 @@ struct VhEmitArgs {
   void* out_state[VH_MAX_METRIC];
   uint8_t sop[VH_MAX_METRIC];
   uint8_t mtype[VH_MAX_METRIC];   // output element type of metric j
+  // HAVING pushed down: the reference evaluates it on the aggregated tuples, one group at a
+  // time, with ComparisonBuilder semantics (src/codegen/query/post_agg.cc:77-83); `slot` of a node is the
+  // result column: < ngroup = key column, else metric (AVG compares its raw sum, bitset its cardinality).
+  int32_t nhaving; int32_t pad2;
+  unsigned long long* total_groups;   // groups before HAVING = agg_map.size()
+  VhProgOp hprog[VH_MAX_HAVING];
+  uint8_t htype[VH_MAX_HAVING];       // element type the comparison happens in
+  uint64_t hlits[VH_MAX_HAVING_LITS];
 };
+
+__device__ __forceinline__ bool vh_cmp_bits(int type, uint64_t a, uint64_t b, int op) {
+  int r;  // -1 / 0 / +1 / 2 (unordered)
+#define VH_C(T) { const T x = vh_lit<T>(a), y = vh_lit<T>(b); r = x < y ? -1 : (x > y ? 1 : (x == y ? 0 : 2)); }
+  switch (type) {
+    case VH_U8: VH_C(uint8_t) break;   case VH_U16: VH_C(uint16_t) break;
+    case VH_U32: VH_C(uint32_t) break; case VH_U64: VH_C(uint64_t) break;
+    case VH_I8: VH_C(int8_t) break;    case VH_I16: VH_C(int16_t) break;
+    case VH_I32: VH_C(int32_t) break;  case VH_I64: VH_C(int64_t) break;
+    case VH_F32: VH_C(float) break;    default: VH_C(double) break;
+  }
+#undef VH_C
+  switch (op) {
+    case VH_OP_EQ: return r == 0;
+    case VH_OP_NE: return r != 0;
+    case VH_OP_LT: return r == -1;
+    case VH_OP_LE: return r == -1 || r == 0;
+    case VH_OP_GT: return r == 1;
+    default: return r == 1 || r == 0;
+  }
+}
 
 __device__ __forceinline__ void vh_store_elem(void* base, int type, uint64_t idx, uint64_t bits) {
   switch (type) {
@@ -108,31 +137,61 @@ __global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
       have = A.present[i] != 0;
     }
   }
+  const int lane = threadIdx.x & 63;
+  const uint64_t all = __ballot(have);
+  if (all == 0) return;
+  if (A.nhaving && lane == 0) atomicAdd(A.total_groups, (unsigned long long)__popcll(all));
+  uint64_t kv[VH_MAX_GROUP], mv[VH_MAX_METRIC];
+  if (have) {
+    for (int c = 0; c < A.ngroup; ++c) {
+      const VhGroupDev& g = A.g[c];
+      if (A.mode == VH_MODE_HASH) {
+        uint64_t w = A.hkeys[i * A.key_words + g.key_word];
+        if (A.key_words == 1 && i + 1 == A.n) w = VH_HASH_EMPTY;
+        kv[c] = w >> g.key_shift;
+      } else {
+        kv[c] = g.lo + (i / g.stride) % g.extent;
+      }
+    }
+    for (int j = 0; j < A.nmetric; ++j)
+      mv[j] = vh_sop_bytes(A.sop[j]) == 4 ? reinterpret_cast<const uint32_t*>(A.state[j])[i]
+                                          : reinterpret_cast<const uint64_t*>(A.state[j])[i];
+    if (A.nhaving) {   // postfix, bitwise & / | like the filter
+      bool st[VH_MAX_STACK];
+      int sp = 0;
+      for (int pc = 0; pc < A.nhaving; ++pc) {
+        const VhProgOp o = A.hprog[pc];
+        if (o.kind == VH_F_TRUE) st[sp++] = true;
+        else if (o.kind == VH_F_AND || o.kind == VH_F_OR) {
+          bool a = st[--sp];
+          for (int k = 1; k < o.count; ++k) { const bool b = st[--sp]; a = o.kind == VH_F_AND ? (a & b) : (a | b); }
+          st[sp++] = a;
+        } else {
+          const uint64_t v = o.slot < A.ngroup ? kv[o.slot] : mv[o.slot - A.ngroup];
+          bool r;
+          if (o.kind == VH_F_REL) r = vh_cmp_bits(A.htype[pc], v, A.hlits[o.lit], o.op);
+          else {
+            r = !o.op;
+            for (int k = 0; k < o.count; ++k) {
+              const bool e = vh_cmp_bits(A.htype[pc], v, A.hlits[o.lit + k], o.op ? VH_OP_EQ : VH_OP_NE);
+              r = o.op ? (r | e) : (r & e);
+            }
+          }
+          st[sp++] = r;
+        }
+      }
+      have = st[0];
+    }
+  }
   const uint64_t bal = __ballot(have);
   if (bal == 0) return;
-  const int lane = threadIdx.x & 63;
   unsigned long long base = 0;
   if (lane == 0) base = atomicAdd(A.out_count, (unsigned long long)__popcll(bal));
   base = __shfl(base, 0);
   if (!have) return;
   const uint64_t pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-  for (int c = 0; c < A.ngroup; ++c) {
-    const VhGroupDev& g = A.g[c];
-    uint64_t v;
-    if (A.mode == VH_MODE_HASH) {
-      uint64_t w = A.hkeys[i * A.key_words + g.key_word];
-      if (A.key_words == 1 && i + 1 == A.n) w = VH_HASH_EMPTY;
-      v = w >> g.key_shift;
-    } else {
-      v = g.lo + (i / g.stride) % g.extent;
-    }
-    vh_store_elem(A.out_key[c], g.type, pos, v);
-  }
-  for (int j = 0; j < A.nmetric; ++j) {
-    const uint64_t bits = vh_sop_bytes(A.sop[j]) == 4 ? reinterpret_cast<const uint32_t*>(A.state[j])[i]
-                                                      : reinterpret_cast<const uint64_t*>(A.state[j])[i];
-    vh_store_elem(A.out_state[j], A.mtype[j], pos, bits);
-  }
+  for (int c = 0; c < A.ngroup; ++c) vh_store_elem(A.out_key[c], A.g[c].type, pos, kv[c]);
+  for (int j = 0; j < A.nmetric; ++j) vh_store_elem(A.out_state[j], A.mtype[j], pos, mv[j]);
 }
 
 template <typename T>

@@ -463,6 +463,10 @@ struct vh_result {
   std::vector<int> metric_elem;        // output element type per device metric (P.m order)
   std::vector<int> group_elem;
   std::string group_sig;
+  int nhaving = 0;
+  VhProgOp hprog[VH_MAX_HAVING] = {};
+  uint8_t htype[VH_MAX_HAVING] = {};
+  uint64_t hlits[VH_MAX_HAVING_LITS] = {};
   std::vector<int> user_metric;        // per plan metric: >= 0 index into P.m, < 0: -(bitset index + 1)
   uint64_t out_cap = 0;                // rows the output arrays can hold
   unsigned long long* d_out_count = nullptr;
@@ -859,6 +863,38 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   r->info.nmetrics = p->nmetrics;
   r->info.algorithmic_bytes = rows_to_scan * bytes_per_row;
 
+  // ---------------- HAVING pushed down to the group-emission kernel
+  if (p->nhaving > 0) {
+    if (p->nhaving > VH_MAX_HAVING) { delete r; return vh_fail(VH_E_UNSUPPORTED, "having has %d nodes (max %d)", p->nhaving, VH_MAX_HAVING); }
+    int hdepth = 0, nl = 0;
+    for (int i = 0; i < p->nhaving; ++i) {
+      const vh_filter_node& n = p->having[i];
+      VhProgOp& o = r->hprog[i];
+      o.kind = (uint8_t)n.kind; o.op = (uint8_t)n.op; o.count = (uint8_t)n.count;
+      if (n.kind == VH_F_REL || n.kind == VH_F_IN) {
+        const int cnt = n.kind == VH_F_REL ? 1 : n.count;
+        if (n.col < 0 || n.col >= p->ngroups + p->nmetrics || n.lit < 0 || n.lit + cnt > p->nlits || nl + cnt > VH_MAX_HAVING_LITS) {
+          delete r; return vh_fail(VH_E_INVALID, "having node %d: bad result column / literal range", i);
+        }
+        if (n.col < p->ngroups) { o.slot = (uint8_t)n.col; r->htype[i] = (uint8_t)t->cols[p->groups[n.col].col].elem; }
+        else {
+          const int dj = r->user_metric[n.col - p->ngroups];
+          o.slot = (uint8_t)(p->ngroups + dj);
+          const VhColumn& mc = t->cols[p->metrics[n.col - p->ngroups]];
+          r->htype[i] = (uint8_t)(mc.kind == VH_METRIC_BITSET ? (mc.elem == VH_BITSET64 ? VH_U64 : VH_U32) : mc.elem);
+        }
+        o.lit = (uint16_t)nl;
+        for (int k = 0; k < cnt; ++k) r->hlits[nl++] = p->lits[n.lit + k].u64;
+        ++hdepth;
+      } else if (n.kind == VH_F_TRUE) ++hdepth;
+      else if ((n.kind == VH_F_AND || n.kind == VH_F_OR) && n.count >= 1 && n.count <= hdepth) hdepth -= n.count - 1;
+      else { delete r; return vh_fail(VH_E_INVALID, "having node %d: kind %d / count %d", i, n.kind, n.count); }
+      if (hdepth > VH_MAX_STACK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "having needs stack depth %d", hdepth); }
+    }
+    if (hdepth != 1) { delete r; return vh_fail(VH_E_INVALID, "having program leaves %d values on the stack", hdepth); }
+    r->nhaving = p->nhaving;
+  }
+
   // ---------------- choose the table organisation
   size_t state_bytes_per_group = 1;  // presence byte
   for (int j = 0; j < P.nmetric; ++j) state_bytes_per_group += vh_sop_bytes(P.m[j].sop);
@@ -1201,6 +1237,10 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   for (int j = 0; j < P.nmetric; ++j) {
     A.state[j] = P.m[j].state; A.out_state[j] = r->d_out_state[j]; A.sop[j] = P.m[j].sop; A.mtype[j] = (uint8_t)r->metric_elem[j];
   }
+  A.nhaving = r->nhaving;
+  A.total_groups = P.counters + 6;
+  for (int i = 0; i < r->nhaving; ++i) { A.hprog[i] = r->hprog[i]; A.htype[i] = r->htype[i]; }
+  for (int i = 0; i < VH_MAX_HAVING_LITS; ++i) A.hlits[i] = r->hlits[i];
   hipLaunchKernelGGL(emit_groups_kernel, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A);
   HIP_TRY(hipGetLastError());
   // pinned staging buffer (two alternate, so a result stays readable while the next query runs)
@@ -1223,8 +1263,9 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   if (err & VH_ERR_HASH_FULL) { *retry = 1; return VH_OK; }
   if (err & VH_ERR_PART_FULL) { *retry = 3; return VH_OK; }
   if (err & VH_ERR_RANGE) { *retry = 2; return VH_OK; }
-  const uint64_t ng = *reinterpret_cast<const unsigned long long*>(H + 256);
-  r->info.ngroups = ng;
+  const uint64_t ng = *reinterpret_cast<const unsigned long long*>(H + 256);   // rows emitted (after HAVING)
+  r->info.ngroups = r->nhaving ? hc[6] : ng;                                     // agg_map.size()
+  r->info.returned_groups = ng;
   r->ngroups_host = ng;
   r->info.passed_recs = hc[0];
   r->h_base = H;

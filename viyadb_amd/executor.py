@@ -57,6 +57,7 @@ class AggPlan:
     seg_rows: Optional[Sequence[int]] = None
     flags: int = 0
     groups_hint: int = 0
+    having: Sequence = ()          # same node tuples; `col` = result column (group i, or len(groups) + metric j)
 
 
 @dataclass
@@ -74,6 +75,7 @@ class AggResult:
     algorithmic_bytes: int
     retries: int
     fast: bool = False
+    returned: int = 0              # rows delivered (= ngroups unless a HAVING was pushed down)
 
 
 class DeviceTable:
@@ -152,6 +154,25 @@ class DeviceTable:
     def _build_plan(self, plan: AggPlan):
         keep = []
         nodes, lits = [], []
+        hnodes = []
+        result_elem = [self.cols[g.col][1] for g in plan.groups] + \
+                      [(capi.U64 if self.cols[m][1] == capi.BITSET64 else capi.U32) if self.cols[m][1] >= capi.BITSET32 else self.cols[m][1]
+                       for m in plan.metrics]
+        for f in plan.having:
+            k = f[0]
+            if k == "true":
+                hnodes.append(capi.FilterNode(capi.F_TRUE, 0, 0, 0, 0, 0))
+            elif k == "rel":
+                _, col, op, val = f
+                hnodes.append(capi.FilterNode(capi.F_REL, col, op, 1, len(lits), 0))
+                lits.append(val if isinstance(val, capi.AnyNum) else anynum(result_elem[col], val))
+            elif k == "in":
+                _, col, equal, vals = f
+                hnodes.append(capi.FilterNode(capi.F_IN, col, 1 if equal else 0, len(vals), len(lits), 0))
+                for v in vals:
+                    lits.append(v if isinstance(v, capi.AnyNum) else anynum(result_elem[col], v))
+            else:
+                hnodes.append(capi.FilterNode(capi.F_AND if k == "and" else capi.F_OR, 0, 0, int(f[1]), 0, 0))
         for f in plan.filter:
             k = f[0]
             if k == "true":
@@ -206,6 +227,11 @@ class DeviceTable:
             p.nseg = len(plan.seg_rows)
         p.flags = int(plan.flags)
         p.groups_hint = int(plan.groups_hint)
+        if hnodes:
+            ha = (capi.FilterNode * len(hnodes))(*hnodes)
+            keep.append(ha)
+            p.having = ha
+        p.nhaving = len(hnodes)
         return p, keep
 
     def _collect(self, res, plan: AggPlan, copy: bool = True) -> AggResult:
@@ -213,7 +239,7 @@ class DeviceTable:
         query on this table); copy=True: private numpy arrays."""
         info = capi.ResultInfo()
         capi.check(self.lib.vh_result_get_info(res, C.byref(info)))
-        ng = info.ngroups
+        ng = info.returned_groups
         nk, nm = len(plan.groups), len(plan.metrics)
         kp = (C.c_void_p * max(1, nk))()
         spp = (C.c_void_p * max(1, nm))()
@@ -232,9 +258,10 @@ class DeviceTable:
         states = [view(spp[j], np.uint64 if self.cols[m][1] >= capi.BITSET32 else capi.ELEM_NP[self.cols[m][1]])
                   for j, m in enumerate(plan.metrics)]
         hidden = view(C.cast(hp, C.c_void_p).value, np.uint64) if info.has_hidden_count else None
-        return AggResult(keys, states, hidden, int(ng), int(info.scanned_recs), int(info.scanned_segments),
+        return AggResult(keys, states, hidden, int(info.ngroups), int(info.scanned_recs), int(info.scanned_segments),
                          int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
-                         float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1))
+                         float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1),
+                         int(ng))
 
     def query_agg(self, plan: AggPlan, copy: bool = True) -> AggResult:
         p, keep = self._build_plan(plan)

@@ -150,6 +150,47 @@ private:
   size_t next_ = 0;
 };
 
+// HAVING -> postfix program over RESULT columns (group column k, or ngroups + metric k), for the device.
+class PlanHavingBuilder : public FilterVisitor {
+public:
+  PlanHavingBuilder(AggregateQuery& q, const std::vector<db::AnyNum>& args, std::vector<vh_anynum>& lits)
+      : q_(q), args_(args), lits_(lits) {}
+  void Visit(const RelOpFilter* f) override {
+    nodes.push_back({VH_F_REL, result_col(f->column()), (int32_t)f->op(), 1, (int32_t)lits_.size(), 0});
+    push_lit();
+  }
+  void Visit(const InFilter* f) override {
+    if (f->values().empty()) throw std::runtime_error("IN filter with no values does not compile in the reference");
+    nodes.push_back({VH_F_IN, result_col(f->column()), f->equal() ? 1 : 0, (int32_t)f->values().size(), (int32_t)lits_.size(), 0});
+    for (size_t i = 0; i < f->values().size(); ++i) push_lit();
+  }
+  void Visit(const CompositeFilter* f) override {
+    for (auto& c : f->filters()) c->Accept(*this);
+    nodes.push_back({f->op() == CompositeFilter::AND ? VH_F_AND : VH_F_OR, 0, 0, (int32_t)f->filters().size(), 0, 0});
+  }
+  void Visit(const EmptyFilter*) override { nodes.push_back({VH_F_TRUE, 0, 0, 0, 0, 0}); }
+  std::vector<vh_filter_node> nodes;
+
+private:
+  int32_t result_col(const std::string& name) {
+    const db::Column* c = q_.table().column(name);
+    for (size_t k = 0; k < q_.dimension_cols().size(); ++k)
+      if (q_.dimension_cols()[k].dim() == c) return (int32_t)k;
+    for (size_t k = 0; k < q_.metric_cols().size(); ++k)
+      if (q_.metric_cols()[k].metric() == c) return (int32_t)(q_.dimension_cols().size() + k);
+    throw std::invalid_argument("Column '" + name + " is not selected");
+  }
+  void push_lit() {
+    vh_anynum a;
+    a.u64 = args_.at(next_++).bits;
+    lits_.push_back(a);
+  }
+  AggregateQuery& q_;
+  const std::vector<db::AnyNum>& args_;
+  std::vector<vh_anynum>& lits_;
+  size_t next_ = 0;
+};
+
 // One aggregated group as the post-aggregation sees it.
 struct Groups {
   size_t n = 0;
@@ -248,6 +289,11 @@ void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, s
                   size_t skip, size_t limit, std::vector<db::AnyNum> hargs, int64_t now) {
   db::Table& table = query.table();
   Groups groups;
+  // HAVING runs on the device when that cannot change which rows the reference would return: the reference cuts
+  // the unsorted skip/limit window BEFORE it applies HAVING (post_agg.cc:56-83), so only push down when there is
+  // no such window, or when the rows are sorted first (then HAVING precedes the window in the reference too).
+  const bool having_on_device = query.having() != nullptr && (!query.sort_cols().empty() || (skip == 0 && limit == 0)) &&
+                                !getenv("VIYA_HOST_HAVING");
   {
     std::lock_guard<std::mutex> lk(table.mu);
     GpuMirror* mir = ensure_mirror(table);
@@ -279,10 +325,14 @@ void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, s
     std::vector<int32_t> mcols;
     for (auto& mc : query.metric_cols()) mcols.push_back((int32_t)mc.metric()->storage_index);
 
+    PlanHavingBuilder hb(query, hargs, fb.lits);
+    if (having_on_device) query.having()->Accept(hb);
+
     vh_plan plan;
     memset(&plan, 0, sizeof(plan));
     plan.filter = fb.nodes.data(); plan.nfilter = (int32_t)fb.nodes.size();
     plan.lits = fb.lits.data(); plan.nlits = (int32_t)fb.lits.size();
+    plan.having = hb.nodes.empty() ? nullptr : hb.nodes.data(); plan.nhaving = (int32_t)hb.nodes.size();
     plan.groups = gcols.data(); plan.ngroups = (int32_t)gcols.size();
     plan.metrics = mcols.data(); plan.nmetrics = (int32_t)mcols.size();
     plan.seg_rows = seg_rows.data(); plan.nseg = (uint32_t)seg_rows.size();
@@ -302,7 +352,7 @@ void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, s
     stats.device_total_ms = info.total_ms;
     stats.path = info.path;
 
-    groups.n = info.ngroups;
+    groups.n = info.returned_groups;
     std::vector<void*> kp, sp;
     for (auto& dc : query.dimension_cols()) { groups.keys.emplace_back(groups.n * dc.dim()->num_type().size()); kp.push_back(groups.keys.back().data()); }
     for (auto& mc : query.metric_cols()) {
@@ -320,8 +370,9 @@ void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, s
   const size_t ncols = query.dimension_cols().size() + query.metric_cols().size();
   Row row(ncols);
   const bool sorted = !query.sort_cols().empty();
-  skip = std::min(groups.n, skip);
-  limit = std::min(limit, groups.n - skip);
+  const size_t total = stats.aggregated_recs;   // agg_map.size(): HAVING may already have run on the device
+  skip = std::min(total, skip);
+  limit = std::min(limit, total - skip);
   size_t it = 0, end = groups.n;
   if (!sorted) {  // unsorted: the window is cut BEFORE the HAVING filter (reference behaviour)
     it = skip;
@@ -338,7 +389,7 @@ void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, s
     if (query.metric_cols()[k].metric()->agg_type() == db::Column::COUNT) { count_k = (int)k; break; }
   HavingEval having(query, groups, hargs);
   for (; it != end; ++it) {
-    if (query.having() != nullptr && !having.Eval(query.having(), it)) continue;
+    if (query.having() != nullptr && !having_on_device && !having.Eval(query.having(), it)) continue;
     for (size_t k = 0; k < query.dimension_cols().size(); ++k) {
       const DimOutputColumn& dc = query.dimension_cols()[k];
       const db::Dimension* d = dc.dim();
