@@ -229,7 +229,7 @@ def test_having_on_device(typed, flags):
         ({"dimensions": ["s8", "flag"], "metrics": ["count", "long_sum", "double_max", "int_avg"]},
          {"op": "and", "filters": [F("gt", "count", "300"), {"op": "or", "filters": [F("lt", "long_sum", "0"), F("ge", "double_max", "200")]}]}),
         ({"dimensions": ["s16"], "metrics": ["int_avg", "count"]}, F("gt", "int_avg", "5")),
-        ({"dimensions": ["d_byte", "d_float"], "metrics": ["ushort_min"]}, {"op": "or", "filters": [F("lt", "d_byte", "-10"), F("eq", "d_float", "2.5")]}),
+        ({"dimensions": ["d_int", "d_float"], "metrics": ["ushort_min"]}, {"op": "or", "filters": [F("lt", "d_int", "-10"), F("eq", "d_float", "2.5")]}),
         ({"dimensions": ["s8"], "metrics": ["count"]}, {"op": "in", "column": "s8", "values": ["v3", "v4", "zzz"]}),
         ({"dimensions": ["s8"], "metrics": ["count"]}, {"op": "not", "filter": {"op": "in", "column": "s8", "values": ["v3", "v4"]}}),
     ]

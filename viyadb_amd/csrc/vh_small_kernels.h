@@ -78,19 +78,24 @@ struct VhEmitArgs {
   const uint64_t* hkeys; const uint32_t* htags;
   const unsigned long long* counters;
   unsigned long long* out_count;
-  VhGroupDev g[VH_MAX_GROUP];
+  // Key decode parameters as dword-aligned arrays of their own, NOT VhGroupDev: with the byte-sized members of
+  // that struct next to the 64-bit ones, hipcc (ROCm 7.2) formed `s_load_dwordx2 sN, s[&g.type], 0x5e` —
+  // a scalar load off a base that is 2 mod 4. SMEM ignores the low address bits of the base, so lo / extent /
+  // stride were read 2 bytes early (tests/test_isa_hazards.py greps the disassembly for that pattern).
+  uint64_t glo[VH_MAX_GROUP], gextent[VH_MAX_GROUP], gstride[VH_MAX_GROUP];
+  uint32_t gtype[VH_MAX_GROUP], gkey_word[VH_MAX_GROUP], gkey_shift[VH_MAX_GROUP];
   void* out_key[VH_MAX_GROUP];
   const void* state[VH_MAX_METRIC];
   void* out_state[VH_MAX_METRIC];
-  uint8_t sop[VH_MAX_METRIC];
-  uint8_t mtype[VH_MAX_METRIC];   // output element type of metric j
+  uint32_t sop[VH_MAX_METRIC];
+  uint32_t mtype[VH_MAX_METRIC];  // output element type of metric j
   // HAVING pushed down: the reference evaluates it on the aggregated tuples, one group at a
   // time, with ComparisonBuilder semantics (src/codegen/query/post_agg.cc:77-83); `slot` of a node is the
   // result column: < ngroup = key column, else metric (AVG compares its raw sum, bitset its cardinality).
   int32_t nhaving; int32_t pad2;
   unsigned long long* total_groups;   // groups before HAVING = agg_map.size()
   VhProgOp hprog[VH_MAX_HAVING];
-  uint8_t htype[VH_MAX_HAVING];       // element type the comparison happens in
+  uint32_t htype[VH_MAX_HAVING];      // element type the comparison happens in
   uint64_t hlits[VH_MAX_HAVING_LITS];
 };
 
@@ -124,6 +129,20 @@ __device__ __forceinline__ void vh_store_elem(void* base, int type, uint64_t idx
   }
 }
 
+// value of group column c / state of metric j for table entry i
+__device__ __forceinline__ uint64_t vh_emit_key(const VhEmitArgs& A, uint64_t i, int c) {
+  if (A.mode == VH_MODE_HASH) {
+    uint64_t w = A.hkeys[i * A.key_words + A.gkey_word[c]];
+    if (A.key_words == 1 && i + 1 == A.n) w = VH_HASH_EMPTY;
+    return w >> A.gkey_shift[c];
+  }
+  return A.glo[c] + (i / A.gstride[c]) % A.gextent[c];
+}
+__device__ __forceinline__ uint64_t vh_emit_state(const VhEmitArgs& A, uint64_t i, int j) {
+  return vh_sop_bytes(A.sop[j]) == 4 ? reinterpret_cast<const uint32_t*>(A.state[j])[i]
+                                     : reinterpret_cast<const uint64_t*>(A.state[j])[i];
+}
+
 __global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   bool have = false;
@@ -141,21 +160,7 @@ __global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
   const uint64_t all = __ballot(have);
   if (all == 0) return;
   if (A.nhaving && lane == 0) atomicAdd(A.total_groups, (unsigned long long)__popcll(all));
-  uint64_t kv[VH_MAX_GROUP], mv[VH_MAX_METRIC];
   if (have) {
-    for (int c = 0; c < A.ngroup; ++c) {
-      const VhGroupDev& g = A.g[c];
-      if (A.mode == VH_MODE_HASH) {
-        uint64_t w = A.hkeys[i * A.key_words + g.key_word];
-        if (A.key_words == 1 && i + 1 == A.n) w = VH_HASH_EMPTY;
-        kv[c] = w >> g.key_shift;
-      } else {
-        kv[c] = g.lo + (i / g.stride) % g.extent;
-      }
-    }
-    for (int j = 0; j < A.nmetric; ++j)
-      mv[j] = vh_sop_bytes(A.sop[j]) == 4 ? reinterpret_cast<const uint32_t*>(A.state[j])[i]
-                                          : reinterpret_cast<const uint64_t*>(A.state[j])[i];
     if (A.nhaving) {   // postfix, bitwise & / | like the filter
       bool st[VH_MAX_STACK];
       int sp = 0;
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
           for (int k = 1; k < o.count; ++k) { const bool b = st[--sp]; a = o.kind == VH_F_AND ? (a & b) : (a | b); }
           st[sp++] = a;
         } else {
-          const uint64_t v = o.slot < A.ngroup ? kv[o.slot] : mv[o.slot - A.ngroup];
+          const uint64_t v = o.slot < A.ngroup ? vh_emit_key(A, i, o.slot) : vh_emit_state(A, i, o.slot - A.ngroup);
           bool r;
           if (o.kind == VH_F_REL) r = vh_cmp_bits(A.htype[pc], v, A.hlits[o.lit], o.op);
           else {
@@ -190,8 +195,8 @@ __global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
   base = __shfl(base, 0);
   if (!have) return;
   const uint64_t pos = base + __popcll(bal & ((1ull << lane) - 1ull));
-  for (int c = 0; c < A.ngroup; ++c) vh_store_elem(A.out_key[c], A.g[c].type, pos, kv[c]);
-  for (int j = 0; j < A.nmetric; ++j) vh_store_elem(A.out_state[j], A.mtype[j], pos, mv[j]);
+  for (int c = 0; c < A.ngroup; ++c) vh_store_elem(A.out_key[c], A.gtype[c], pos, vh_emit_key(A, i, c));
+  for (int j = 0; j < A.nmetric; ++j) vh_store_elem(A.out_state[j], A.mtype[j], pos, vh_emit_state(A, i, j));
 }
 
 template <typename T>

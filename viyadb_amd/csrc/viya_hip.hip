@@ -1233,7 +1233,11 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   A.mode = r->mode == VH_MODE_DENSE_PART ? VH_MODE_DENSE_GLOBAL : r->mode; A.ngroup = P.ngroup; A.nmetric = P.nmetric; A.key_words = P.key_words;
   A.n = r->out_cap; A.present = P.present; A.present_carrier = r->mode == VH_MODE_DENSE_GLOBAL ? P.present_carrier : -1; A.hkeys = P.hkeys; A.htags = P.htags; A.counters = P.counters;
   A.out_count = r->d_out_count;
-  for (int i = 0; i < P.ngroup; ++i) { A.g[i] = P.g[i]; A.out_key[i] = r->d_out_key[i]; }
+  for (int i = 0; i < P.ngroup; ++i) {
+    A.glo[i] = P.g[i].lo; A.gextent[i] = P.g[i].extent; A.gstride[i] = P.g[i].stride;
+    A.gtype[i] = P.g[i].type; A.gkey_word[i] = P.g[i].key_word; A.gkey_shift[i] = P.g[i].key_shift;
+    A.out_key[i] = r->d_out_key[i];
+  }
   for (int j = 0; j < P.nmetric; ++j) {
     A.state[j] = P.m[j].state; A.out_state[j] = r->d_out_state[j]; A.sop[j] = P.m[j].sop; A.mtype[j] = (uint8_t)r->metric_elem[j];
   }
