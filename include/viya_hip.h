@@ -230,7 +230,8 @@ VH_API void vh_table_destroy(vh_table* t);
  * in the generated Segment class, src/codegen/db/store.cc:214-356); a NULL entry
  * leaves that column's mirror untouched. Bitset columns are not passed here
  * (see vh_segment_sync_bitset). Also refreshes the per-segment min/max stats
- * used for segment skipping. */
+ * used for segment skipping. A col_ptrs entry may also be a DEVICE address (unified
+ * addressing): that is how exchanged partial aggregates become a segment without a host hop. */
 VH_API int vh_segment_sync(vh_table* t, uint32_t seg, uint64_t nrows,
                            const void* const* col_ptrs);
 /* Dirty-range form of vh_segment_sync: upsert appends to the last segment and updates
@@ -265,6 +266,19 @@ VH_API int vh_query_launch(vh_table* t, const vh_plan* plan, vh_result** out);
 VH_API int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs,
                                     int32_t max_bufs, int32_t* nbufs);
 VH_API int vh_result_finalize(vh_result* r);
+/* Multi-GPU, hash path (sparse keys: partial tables are not identically indexed, so they
+ * cannot be reduced in place). Regroups the emitted rows of a FINALISED result by
+ * owner = mix(key columns) % nparts, in HBM: rows of owner p are
+ * [part_offsets[p], part_offsets[p+1]) of every returned column buffer, i.e. one contiguous
+ * send buffer per destination for an all-to-all (grouped ncclSend/ncclRecv). The owner
+ * merges what it receives by re-aggregation (vh_segment_sync accepts device pointers, so the
+ * received columns become a segment of a temporary table without leaving HBM). Replaces
+ * the reference's cluster merge over HTTP + temp-table upsert
+ * (src/cluster/query/agg_runner.cc:83-140). bufs: the key columns, then the plan's metrics
+ * in plan order, then the hidden count if the plan carries one; `reduce` of a key column is
+ * -1, of a metric the operator that merges two partial states. part_offsets: nparts + 1. */
+VH_API int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part_offsets,
+                               vh_device_buffer* bufs, int32_t max_bufs, int32_t* nbufs);
 
 VH_API int vh_result_get_info(vh_result* r, vh_result_info* info);
 /* Copy out: key_cols[i] receives ngroups elements of group column i's element

@@ -19,36 +19,54 @@ WORKER = textwrap.dedent('''
     import numpy as np, torch, torch.distributed as dist
     from viyadb_amd import distributed, executor, synth
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo")
+    dist.init_process_group({backend!r}, **({{"device_id": torch.device("cuda", 0)}} if {backend!r} == "nccl" else {{}}))
     rank, world = dist.get_rank(), dist.get_world_size()
     executor.init(0, stream=torch.cuda.current_stream().cuda_stream)
     w = synth.WORKLOADS[{wl!r}](segment_rows=50000)
     total = 9
     lo, hi = distributed.shard_segments(total, rank, world)
     t = synth.create_device_table(w, hi - lo, 50000, row_base=lo * 50000)
-    plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags={flags})
+    nk = len(w.plan.groups)
+    having = [("rel", nk + len(w.plan.metrics) - 1, 4, 1)] if {having} else []    # last metric (a count) > 1, on MERGED groups
+    plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags={flags}, having=having)
     for _ in range(2):
-        res = distributed.sharded_query(torch, dist, t, plan, world)
+        res = distributed.sharded_query(torch, dist, t, plan, world, force_collectives=True)
     torch.cuda.synchronize()
     assert (res is None) == (rank != 0)
     if rank == 0:
-        np.savez({out!r}, *(res.keys + res.states), ngroups=res.ngroups, nk=len(res.keys))
+        np.savez({out!r}, *(res.keys + res.states), ngroups=res.ngroups, nk=len(res.keys), returned=res.returned)
     dist.barrier()
     t.close()
     dist.destroy_process_group()
 ''')
 
 
+def test_one_rank_rccl(tmp_path):
+    """The same flow through the nccl (= RCCL) backend with a single rank: dtype views, in-place reduce on the
+    library's buffers and the all-to-all of the hash path go through RCCL itself (this box has one GPU)."""
+    for wl, flags in (("C3", 0), ("C5t", 0)):
+        _run(tmp_path, wl, flags, "nccl", 1)
+
+
 @pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 64), ("C2", 0), ("C2", 2), ("C1", 0), ("C3", 1), ("C5t", 0)])
 def test_two_ranks_one_gpu(tmp_path, wl, flags):
+    _run(tmp_path, wl, flags, "gloo", 2)
+
+
+@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 1), ("C5t", 0)])
+def test_two_ranks_having_on_merged_groups(tmp_path, wl, flags):
+    _run(tmp_path, wl, flags, "gloo", 2, having=True)
+
+
+def _run(tmp_path, wl, flags, backend, nproc, having=False):
     out = str(tmp_path / "res.npz")
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT, out=out, wl=wl, flags=flags))
+    script.write_text(WORKER.format(root=ROOT, out=out, wl=wl, flags=flags, backend=backend, having=having))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
                         "127.0.0.1", "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     got = np.load(out)
@@ -61,6 +79,11 @@ def test_two_ranks_one_gpu(tmp_path, wl, flags):
     arrs = [got["arr_%d" % i] for i in range(nk + len(st.states))]
     keys, states = arrs[:nk], arrs[nk:]
     assert int(got["ngroups"]) == st.ngroups
+    if having:
+        keep = st.states[-1] > 1
+        st.keys = [k[keep] for k in st.keys]
+        st.states = [x[keep] for x in st.states]
+        assert int(got["returned"]) == int(keep.sum())
     pg, po = sort_rows(keys, states), sort_rows(st.keys, st.states)
     for a, b in zip(keys + states, st.keys + st.states):
         assert np.array_equal(a[pg], b[po])

@@ -109,6 +109,7 @@ SYMBOLS = {
     "vh_query_launch": (C.c_int, [_VP, C.POINTER(Plan), C.POINTER(_VP)]),
     "vh_result_device_buffers": (C.c_int, [_VP, C.POINTER(DeviceBuffer), C.c_int32, C.POINTER(C.c_int32)]),
     "vh_result_finalize": (C.c_int, [_VP]),
+    "vh_result_partition": (C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(DeviceBuffer), C.c_int32, C.POINTER(C.c_int32)]),
     "vh_result_get_info": (C.c_int, [_VP, C.POINTER(ResultInfo)]),
     "vh_result_copy": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_uint64)]),
     "vh_result_view": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.POINTER(C.c_uint64))]),

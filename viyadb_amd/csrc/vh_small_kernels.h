@@ -199,6 +199,63 @@ __global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
   for (int j = 0; j < A.nmetric; ++j) vh_store_elem(A.out_state[j], A.mtype[j], pos, vh_emit_state(A, i, j));
 }
 
+// ------------------------------------------------- key-partitioned exchange (hash path)
+// Emitted groups of one GPU are regrouped by owner = mix(key columns) % nparts so that every column can be
+// shipped with one all-to-all; the owner then merges what it received by re-aggregation. Two passes of the
+// same kernel: pass 0 counts rows per owner, pass 1 scatters (wave-aggregated cursor bumps).
+#define VH_MAX_XCHG_COLS (VH_MAX_GROUP + VH_MAX_METRIC)
+struct VhPartitionArgs {
+  uint64_t n;
+  uint32_t nparts; int32_t nkeys; int32_t ncols; int32_t pass;
+  const void* src[VH_MAX_XCHG_COLS];
+  void* dst[VH_MAX_XCHG_COLS];
+  uint32_t esize[VH_MAX_XCHG_COLS];
+  unsigned long long* counts;            // [nparts], pass 0
+  unsigned long long* cursors;           // [nparts], pass 1
+  const unsigned long long* offsets;     // [nparts + 1], pass 1
+};
+
+__device__ __forceinline__ uint64_t vh_load_sized(const void* base, uint32_t esize, uint64_t i) {
+  switch (esize) {
+    case 1: return reinterpret_cast<const uint8_t*>(base)[i];
+    case 2: return reinterpret_cast<const uint16_t*>(base)[i];
+    case 4: return reinterpret_cast<const uint32_t*>(base)[i];
+    default: return reinterpret_cast<const uint64_t*>(base)[i];
+  }
+}
+__device__ __forceinline__ void vh_store_sized(void* base, uint32_t esize, uint64_t i, uint64_t v) {
+  switch (esize) {
+    case 1: reinterpret_cast<uint8_t*>(base)[i] = (uint8_t)v; break;
+    case 2: reinterpret_cast<uint16_t*>(base)[i] = (uint16_t)v; break;
+    case 4: reinterpret_cast<uint32_t*>(base)[i] = (uint32_t)v; break;
+    default: reinterpret_cast<uint64_t*>(base)[i] = v; break;
+  }
+}
+
+__global__ __launch_bounds__(256) void partition_groups_kernel(const VhPartitionArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool have = i < A.n;
+  uint32_t owner = 0;
+  if (have) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (int c = 0; c < A.nkeys; ++c) h = vh_splitmix64(h ^ vh_load_sized(A.src[c], A.esize[c], i));
+    owner = (uint32_t)(h % A.nparts);
+  }
+  uint64_t pos = 0;
+  for (uint32_t p = 0; p < A.nparts; ++p) {     // nparts = number of GPUs: a handful
+    const uint64_t bal = __ballot(have && owner == p);
+    if (bal == 0) continue;
+    const int leader = __ffsll((unsigned long long)bal) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd((A.pass == 0 ? A.counts : A.cursors) + p, (unsigned long long)__popcll(bal));
+    base = __shfl(base, leader);
+    if (have && owner == p) pos = A.offsets ? A.offsets[p] + base + __popcll(bal & ((1ull << lane) - 1ull)) : 0;
+  }
+  if (A.pass == 0 || !have) return;
+  for (int c = 0; c < A.ncols; ++c) vh_store_sized(A.dst[c], A.esize[c], pos, vh_load_sized(A.src[c], A.esize[c], i));
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void fill_kernel(T* p, uint64_t n, T v) {
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = v;

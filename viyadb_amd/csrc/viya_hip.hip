@@ -271,7 +271,7 @@ extern "C" int vh_segment_sync(vh_table* t, uint32_t seg, uint64_t nrows, const 
     auto& c = t->cols[i];
     if (is_bitset_elem(c.elem) || !col_ptrs[i] || !nrows) continue;
     HIP_TRY(hipMemcpyAsync(c.base + (size_t)seg * c.stride, col_ptrs[i], (size_t)nrows * c.esize,
-                           hipMemcpyHostToDevice, g_ctx.stream));
+                           hipMemcpyDefault, g_ctx.stream));   // host or device source (unified addressing)
   }
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   t->seg_rows[seg] = nrows;
@@ -478,6 +478,8 @@ struct vh_result {
   size_t off_key[VH_MAX_GROUP] = {}, off_state[VH_MAX_METRIC] = {};
   char* h_base = nullptr;
   uint64_t ngroups_host = 0;
+  char* d_xchg = nullptr;              // vh_result_partition: rows regrouped by owner (own allocation)
+  ~vh_result() { if (d_xchg) (void)hipFree(d_xchg); }
 };
 
 extern "C" void vh_result_free(vh_result* r) { delete r; }
@@ -1220,6 +1222,81 @@ extern "C" int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs, in
     bufs[n++] = b;
   }
   *nbufs = n;
+  return VH_OK;
+}
+
+// SURVEY 8(e), hash path: "each GPU radix-partitions its partial table by hash(key) mod nGPU -> all-to-all ->
+// local merge on the owned partition". This is the first step, on a finalised result: its emitted rows are
+// regrouped by owner in HBM so that every column is one contiguous send buffer per destination.
+extern "C" int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part_offsets, vh_device_buffer* bufs,
+                                   int32_t max_bufs, int32_t* nbufs) {
+  if (!r || !part_offsets || !bufs || !nbufs) return vh_fail(VH_E_INVALID, "null argument");
+  if (!r->finalized) return vh_fail(VH_E_INVALID, "result is not finalised");
+  if (nparts == 0 || nparts > 64) return vh_fail(VH_E_INVALID, "nparts must be 1..64");
+  if (r->plan.nbitset) return vh_fail(VH_E_UNSUPPORTED, "count-distinct partials are cardinalities: they cannot be merged across GPUs");
+  if (r->nhaving) return vh_fail(VH_E_UNSUPPORTED, "HAVING applies to merged groups: run the partial query without it");
+  std::lock_guard<std::mutex> lk(r->table->mu);
+  const VhPlanDev& P = r->plan;
+  hipStream_t st = g_ctx.stream;
+  const uint64_t ng = r->ngroups_host;
+  const int ncols = P.ngroup + P.nmetric;
+  if (max_bufs < ncols) return vh_fail(VH_E_INVALID, "need %d buffers", ncols);
+  VhPartitionArgs A{};
+  A.n = ng; A.nparts = nparts; A.nkeys = P.ngroup; A.ncols = ncols;
+  // output order: key columns, then the plan's metrics in plan order, then the hidden count (if any)
+  std::vector<int> order;
+  for (size_t j = 0; j < r->user_metric.size(); ++j) order.push_back(r->user_metric[j]);
+  if (r->info.has_hidden_count) order.push_back(P.nmetric - 1);
+  if ((int)order.size() != P.nmetric) return vh_fail(VH_E_DEVICE, "metric bookkeeping is inconsistent");
+  size_t bytes = 0;
+  std::vector<size_t> off(ncols);
+  for (int c = 0; c < ncols; ++c) {
+    const int elem = c < P.ngroup ? P.g[c].type : r->metric_elem[order[c - P.ngroup]];
+    A.esize[c] = (uint32_t)vh_elem_size(elem);
+    A.src[c] = c < P.ngroup ? r->d_out_key[c] : r->d_out_state[order[c - P.ngroup]];
+    off[c] = bytes;
+    bytes += ((size_t)std::max<uint64_t>(ng, 1) * A.esize[c] + 255) / 256 * 256;
+  }
+  const size_t ctr_off = bytes;
+  bytes += 3 * 64 * sizeof(unsigned long long) + 8;
+  if (r->d_xchg) { (void)hipFree(r->d_xchg); r->d_xchg = nullptr; }
+  HIP_TRY(hipMalloc((void**)&r->d_xchg, bytes));
+  unsigned long long* ctr = reinterpret_cast<unsigned long long*>(r->d_xchg + ctr_off);
+  HIP_TRY(hipMemsetAsync(ctr, 0, 3 * 64 * sizeof(unsigned long long) + 8, st));
+  for (int c = 0; c < ncols; ++c) A.dst[c] = r->d_xchg + off[c];
+  A.counts = ctr; A.cursors = ctr + 64;
+  std::vector<unsigned long long> counts(nparts, 0), offs(nparts + 1, 0);
+  if (ng) {
+    const unsigned grid = (unsigned)((ng + 255) / 256);
+    A.pass = 0; A.offsets = nullptr;
+    hipLaunchKernelGGL(partition_groups_kernel, dim3(grid), dim3(256), 0, st, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(counts.data(), ctr, nparts * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t p = 0; p < nparts; ++p) offs[p + 1] = offs[p] + counts[p];
+    if (offs[nparts] != ng) return vh_fail(VH_E_DEVICE, "partition counted %llu of %llu rows", offs[nparts], (unsigned long long)ng);
+    HIP_TRY(hipMemcpyAsync(ctr + 128, offs.data(), (nparts + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    A.pass = 1; A.offsets = ctr + 128;
+    hipLaunchKernelGGL(partition_groups_kernel, dim3(grid), dim3(256), 0, st, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));   // offs lives on this frame
+  }
+  for (uint32_t p = 0; p <= nparts; ++p) part_offsets[p] = offs[p];
+  for (int c = 0; c < ncols; ++c) {
+    vh_device_buffer b{A.dst[c], ng, 0, -1};
+    if (c < P.ngroup) b.elem = P.g[c].type;
+    else {
+      const int u = order[c - P.ngroup];
+      b.elem = r->metric_elem[u];
+      switch (P.m[u].sop) {
+        case SOP_MIN_I32: case SOP_MIN_U32: case SOP_MIN_I64: case SOP_MIN_U64: case SOP_MIN_F32: case SOP_MIN_F64: b.reduce = VH_RED_MIN; break;
+        case SOP_MAX_I32: case SOP_MAX_U32: case SOP_MAX_I64: case SOP_MAX_U64: case SOP_MAX_F32: case SOP_MAX_F64: b.reduce = VH_RED_MAX; break;
+        default: b.reduce = VH_RED_SUM; break;
+      }
+    }
+    bufs[c] = b;
+  }
+  *nbufs = ncols;
   return VH_OK;
 }
 

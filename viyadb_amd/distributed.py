@@ -102,10 +102,74 @@ def merge_partials_by_reaggregation(table, plan, partials):
     return res
 
 
-def sharded_query(torch, dist, table, plan, world: int, copy: bool = True):
+def _merge_table(table, plan, has_hidden, rows, nseg):
+    """Temporary device table [group columns..., metric states..., hidden count] + the plan that re-aggregates it."""
+    from .executor import AggPlan, DeviceTable, GroupSpec
+    nk, nm = len(plan.groups), len(plan.metrics)
+    cols = [(capi.DIM_NUMERIC, table.cols[g.col][1]) for g in plan.groups]
+    cols += [(_merge_kind(table.cols[m][0]), table.cols[m][1]) for m in plan.metrics]
+    if has_hidden:
+        cols.append((capi.METRIC_SUM, capi.U64))
+    tmp = DeviceTable(cols, segment_rows=max(int(rows), 1), reserve_segments=nseg)
+    mplan = AggPlan(filter=[], groups=[GroupSpec(i) for i in range(nk)],
+                    metrics=list(range(nk, nk + nm + (1 if has_hidden else 0))))
+    return tmp, mplan
+
+
+def exchange_hash_partials(torch, dist, table, plan, handle, world: int, having=None):
+    """SURVEY 8(e), hash path: this rank's finalised groups are regrouped by owner = mix(key) % world in HBM
+    (vh_result_partition), every column is shipped with one all-to-all (RCCL grouped send/recv over xGMI), and
+    the owner merges what it received by re-aggregation on its own GPU, straight from the receive buffers
+    (vh_segment_sync takes device addresses). Returns this rank's OWNED groups (results stay sharded)."""
+    import numpy as np
+    offs, bufs = table.partition(handle, world)
+    send = np.diff(offs.astype(np.int64))
+    gloo = dist.get_backend() == "gloo"      # CPU test rig: gloo moves host tensors only
+    send_t = torch.from_numpy(send.copy())
+    send_t = send_t if gloo else send_t.cuda()
+    recv_t = torch.empty_like(send_t)
+    dist.all_to_all_single(recv_t, send_t)
+    recv = recv_t.cpu().numpy().astype(np.int64)
+    nrecv = int(recv.sum())
+    received = []
+    for ptr, count, elem, _red in bufs:
+        es = capi.ELEM_SIZE[elem]
+        src = (torch.as_tensor(_DevArray(ptr, count * es, "|u1"), device="cuda") if count
+               else torch.empty(0, dtype=torch.uint8, device="cuda"))
+        out = torch.empty(nrecv * es, dtype=torch.uint8, device="cuda")
+        ins, outs = (send * es).tolist(), (recv * es).tolist()
+        if gloo:
+            host_out = torch.empty(nrecv * es, dtype=torch.uint8)
+            dist.all_to_all_single(host_out, src.cpu(), outs, ins)
+            out.copy_(host_out)
+        else:
+            dist.all_to_all_single(out, src, outs, ins)
+        received.append(out)
+    torch.cuda.current_stream().synchronize()
+    has_hidden = len(bufs) > len(plan.groups) + len(plan.metrics)
+    tmp, mplan = _merge_table(table, plan, has_hidden, nrecv, 1)
+    try:
+        if nrecv:
+            tmp.sync_segment_device(0, [t.data_ptr() for t in received], nrecv)
+        mplan.groups_hint = nrecv
+        if having:
+            mplan.having = list(having)   # result-column indices are the same in the merge table
+        res = tmp.query_agg(mplan)
+    finally:
+        tmp.close()
+    if has_hidden:
+        res.hidden_count = res.states[-1]
+        res.states = res.states[:-1]
+    return res
+
+
+def sharded_query(torch, dist, table, plan, world: int, copy: bool = True, gather: bool = True,
+                  force_collectives: bool = False):
     """One query over a table sharded across `world` ranks; the merged result lands on rank 0, the other
-    ranks return None (they only contribute their partial tables to the collective)."""
-    if world == 1:
+    ranks return None (they only contribute their partial tables to the collective). Hash-path queries with
+    gather=False leave the result sharded: every rank returns the groups it owns."""
+    import numpy as np
+    if world == 1 and not force_collectives:
         return table.query_agg(plan, copy=copy)
     # The library must run on torch's current stream (executor.init(..., stream=...)): the collective is
     # then ordered after the scan kernels and the finalisation after the collective by stream order alone.
@@ -122,21 +186,44 @@ def sharded_query(torch, dist, table, plan, world: int, copy: bool = True):
             table.discard(res)
             return None
         return table.finalize(res, plan, copy=copy)
-    # hash path: every rank finalises its own groups, rank 0 gathers them and re-aggregates on its GPU
-    # (SURVEY 8e's key-partitioned all-to-all is the bandwidth-optimal form for ~10 M groups; this is the
-    #  simple, always-correct one)
-    mine = table.finalize(res, plan, copy=True)
-    part = (mine.keys, mine.states, mine.hidden_count)
-    gathered = [None] * world if dist.get_rank() == 0 else None
-    dist.gather_object(part, gathered, dst=0)
-    stats = torch.tensor([mine.scanned_recs, mine.scanned_segments, mine.passed_recs], dtype=torch.int64)
+    # hash path: key-partitioned all-to-all, owner-computes merge
+    pplan = plan
+    if plan.having:                 # HAVING is a predicate on MERGED groups: partials run without it
+        import dataclasses
+        pplan = dataclasses.replace(plan, having=[])
+        table.discard(res)
+        res = table.query_agg_keep(pplan)
+    else:
+        try:
+            table.finalize_keep(res)
+        except capi.VhError:        # the partial table overflowed: vh_query_agg owns the re-plan loop
+            table.discard(res)
+            res = table.query_agg_keep(pplan)
+    try:
+        mine = table.collect(res, pplan, copy=False)
+        local = (mine.scanned_recs, mine.scanned_segments, mine.passed_recs, mine.scan_kernel_ms, mine.algorithmic_bytes)
+        owned = exchange_hash_partials(torch, dist, table, pplan, res, world, having=plan.having)
+    finally:
+        table.discard(res)
+    stats = torch.tensor(local[:3], dtype=torch.int64)
     if dist.get_backend() != "gloo":
         stats = stats.cuda()
-    dist.reduce(stats, dst=0) if dist.get_backend() != "gloo" else dist.all_reduce(stats)
+    dist.all_reduce(stats)
+    owned.scanned_recs, owned.scanned_segments, owned.passed_recs = (int(x) for x in stats.tolist())
+    owned.path = "hash+all_to_all"
+    owned.scan_kernel_ms, owned.algorithmic_bytes = local[3], local[4]
+    if not gather:
+        return owned
+    part = (owned.keys, owned.states, owned.hidden_count, owned.ngroups)
+    gathered = [None] * world if dist.get_rank() == 0 else None
+    dist.gather_object(part, gathered, dst=0)
     if dist.get_rank() != 0:
         return None
-    merged = merge_partials_by_reaggregation(table, plan, gathered)
-    merged.scanned_recs, merged.scanned_segments, merged.passed_recs = (int(x) for x in stats.tolist())
-    merged.path = "hash+reaggregate"
-    merged.scan_kernel_ms, merged.algorithmic_bytes = mine.scan_kernel_ms, mine.algorithmic_bytes
-    return merged
+    nk, nm = len(plan.groups), len(plan.metrics)
+    owned.keys = [np.concatenate([g[0][i] for g in gathered]) for i in range(nk)]
+    owned.states = [np.concatenate([g[1][j] for g in gathered]) for j in range(nm)]
+    if owned.hidden_count is not None:
+        owned.hidden_count = np.concatenate([g[2] for g in gathered])
+    owned.returned = len(owned.keys[0]) if nk else len(owned.states[0])
+    owned.ngroups = sum(g[3] for g in gathered)     # groups before HAVING, over all owners
+    return owned

@@ -292,6 +292,37 @@ class DeviceTable:
         finally:
             self.lib.vh_result_free(res)
 
+    # ---- hash-path exchange: finalised handle -> rows regrouped by owner -> all-to-all -> merge
+    def query_agg_keep(self, plan: AggPlan):
+        """vh_query_agg (with its re-plan loop) returning the finalised handle; free it with discard()."""
+        p, keep = self._build_plan(plan)
+        res = C.c_void_p()
+        capi.check(self.lib.vh_query_agg(self.handle, C.byref(p), C.byref(res)))
+        return res
+
+    def finalize_keep(self, res) -> None:
+        """vh_result_finalize on a launched handle, keeping it (raises VhError if the partial needs a re-plan)."""
+        capi.check(self.lib.vh_result_finalize(res))
+
+    def collect(self, res, plan: AggPlan, copy: bool = True) -> AggResult:
+        return self._collect(res, plan, copy)
+
+    def partition(self, res, nparts: int):
+        """-> (offsets[nparts + 1], [(device ptr, rows, elem, merge op)]) : key columns, metrics, hidden count."""
+        offs = (C.c_uint64 * (nparts + 1))()
+        bufs = (capi.DeviceBuffer * 24)()
+        n = C.c_int32()
+        capi.check(self.lib.vh_result_partition(res, nparts, offs, bufs, 24, C.byref(n)))
+        return (np.array(list(offs), dtype=np.uint64),
+                [(bufs[i].ptr, bufs[i].count, bufs[i].elem, bufs[i].reduce) for i in range(n.value)])
+
+    def sync_segment_device(self, seg: int, ptrs: Sequence[Optional[int]], nrows: int):
+        """vh_segment_sync with DEVICE source addresses (one per column, None = leave untouched)."""
+        arr = (C.c_void_p * len(self.cols))()
+        for i, ptr in enumerate(ptrs):
+            arr[i] = ptr or None
+        capi.check(self.lib.vh_segment_sync(self.handle, seg, int(nrows), arr))
+
     def discard(self, res) -> None:
         """Drop a launched (not finalised) partial result: non-root ranks after the collective."""
         self.lib.vh_result_free(res)
