@@ -280,6 +280,43 @@ VH_API int vh_result_finalize(vh_result* r);
 VH_API int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part_offsets,
                                vh_device_buffer* bufs, int32_t max_bufs, int32_t* nbufs);
 
+/* ---- the other two FilterBasedQuery kinds on the same scan ------------
+ *
+ * search (viya_query_search, src/codegen/query/scan.cc:249-299): the distinct values of one
+ * dimension among the passing rows, in first-occurrence order. That is an aggregate query
+ * GROUP BY the dimension with MIN over the row's storage position: put VH_COL_ROWID in
+ * vh_plan.metrics; its state is a u64 (segment << 32 | row). The caller orders the groups by
+ * it, matches the term against the decoded values and applies the limit
+ * (viyadb_amd/host/gpu_aggregate.cc: GpuSearch).
+ *
+ * select (viya_query_select, scan.cc:75-166): the passing rows themselves, in storage order,
+ * through the reference's skip / limit window, as one dense array per selected column (the
+ * column's own element type; a bitset column yields its per-row cardinality as u64).
+ * Formatting stays with the caller. `limit` 0 = none. The reference's `break` leaves the tuple
+ * loop only, so after the limit is reached each later segment still contributes its first
+ * passing row; that is reproduced. */
+#define VH_COL_ROWID (-2)
+typedef struct vh_rows vh_rows;
+typedef struct vh_select_plan {
+  const vh_filter_node* filter; int32_t nfilter;
+  const vh_anynum* lits;        int32_t nlits;
+  const int32_t* cols;          int32_t ncols;   /* table column indices, output order */
+  const uint64_t* seg_rows;     uint32_t nseg;   /* size() snapshot, as in vh_plan      */
+  uint32_t flags;
+  uint64_t skip, limit;
+} vh_select_plan;
+typedef struct vh_rows_info {
+  uint64_t nrows;             /* stats.output_recs                          */
+  uint64_t scanned_recs, scanned_segments;
+  uint64_t passed_recs;       /* rows that satisfied the filter             */
+  float kernel_ms, total_ms;
+} vh_rows_info;
+VH_API int vh_query_select(vh_table* t, const vh_select_plan* plan, vh_rows** out);
+VH_API int vh_rows_get_info(vh_rows* r, vh_rows_info* info);
+/* cols[c] = host array (pinned, owned by the vh_rows) of nrows elements of column c. */
+VH_API int vh_rows_view(vh_rows* r, const void** cols);
+VH_API void vh_rows_free(vh_rows* r);
+
 VH_API int vh_result_get_info(vh_result* r, vh_result_info* info);
 /* Copy out: key_cols[i] receives ngroups elements of group column i's element
  * type; state_cols[j] receives ngroups elements of metric j's element type

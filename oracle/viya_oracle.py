@@ -752,9 +752,14 @@ class Database:
         return self.tables[name]
 
     def query(self, q: dict, now: Optional[int] = None):
-        if q.get("type") != "aggregate":
-            raise Unsupported("oracle covers aggregate queries only")
-        return aggregate_query(self.table(q["table"]), q, now)
+        t = q.get("type")
+        if t == "aggregate":
+            return aggregate_query(self.table(q["table"]), q, now)
+        if t == "select":
+            return select_query(self.table(q["table"]), q)
+        if t == "search":
+            return search_query(self.table(q["table"]), q)
+        raise Unsupported("oracle covers aggregate, select and search queries only")
 
 
 # ---------------------------------------------------------------------------------
@@ -1238,3 +1243,142 @@ def aggregate_query(table: Table, q: dict, now: Optional[int] = None):
     rows, out = post_aggregate(aq, st)
     return rows, {"scanned_recs": st.scanned_recs, "scanned_segments": st.scanned_segments,
                   "aggregated_recs": st.ngroups, "output_recs": out, "passed_recs": st.passed_recs}
+
+
+# ---------------------------------------------------------------------------------
+# select / search — the other two FilterBasedQuery kinds on the same scan
+# ---------------------------------------------------------------------------------
+def _passing_rows(table: Table, flt, seg, size):
+    def getcol(c, seg=seg, size=size):
+        if c.is_dim:
+            return seg["d"][c.index][:size]
+        if c.agg == "bitset":
+            dt = np.uint64 if c.num_type.size == 8 else np.uint32
+            return np.array([len(x) for x in seg["m"][c.index][:size]], dtype=dt)
+        return seg["m"][c.index][:size]
+    r = eval_filter(table, flt, getcol)
+    return np.arange(size) if r is None else np.nonzero(r)[0]
+
+
+def scan_select(aq: AggQuery, seg_rows: Optional[List[int]] = None):
+    """ScanVisitor::Visit(SelectQuery*) (scan.cc:75-166) up to the point where a row is formatted:
+    -> ([(segment index, row index)...] in send order, stats). `break` leaves the tuple loop only
+    (scan.cc:158-160), so once the limit is reached every later segment still sends one row."""
+    table = aq.table
+    picked = []
+    stats = {"scanned_recs": 0, "scanned_segments": 0, "passed_recs": 0}
+    row_index, output_recs = 0, 0
+    for si, seg in enumerate(table.segments):
+        size = seg["size"] if seg_rows is None else int(seg_rows[si])
+        stats["scanned_recs"] += size
+        if not segment_skip(table, aq.filter, seg):
+            continue
+        stats["scanned_segments"] += 1
+        idx = _passing_rows(table, aq.filter, seg, size)
+        stats["passed_recs"] += len(idx)
+        for i in idx:
+            if aq.skip > 0:
+                skipit = row_index < aq.skip
+                row_index += 1
+                if skipit:
+                    continue
+            picked.append((si, int(i)))
+            output_recs += 1
+            if aq.limit > 0 and output_recs >= aq.limit:
+                break
+    stats["output_recs"] = output_recs
+    stats["aggregated_recs"] = 0
+    return picked, stats
+
+
+def select_query(table: Table, q: dict):
+    """Database::Query for type=select: rows of strings in send order (header first if asked)."""
+    aq = parse_query(table, {k: v for k, v in q.items() if k not in ("sort", "having")})
+    picked, stats = scan_select(aq)
+    ncols = len(aq.dim_cols) + len(aq.metric_cols)
+    rows = []
+    if aq.header:
+        hdr = [""] * ncols
+        for oc in aq.dim_cols + aq.metric_cols:
+            hdr[oc.index] = oc.col.name
+        rows.append(hdr)
+    count_col = None
+    for oc in aq.metric_cols:
+        if oc.col.agg == "count":
+            count_col = oc.col
+            break
+    for si, i in picked:
+        seg = table.segments[si]
+        row = [""] * ncols
+        for oc in aq.dim_cols:
+            d, v = oc.col, seg["d"][oc.col.index][i]
+            if d.dim_type == "string":
+                row[oc.index] = table.dicts[d.name].c2v[int(v)]
+            elif d.dim_type == "time" and oc.format:
+                row[oc.index] = fmt_date(oc.format, int(v))
+            elif d.dim_type == "boolean":
+                row[oc.index] = "true" if v else "false"
+            else:
+                row[oc.index] = fmt_num(v)
+        for oc in aq.metric_cols:
+            m = oc.col
+            if m.agg == "bitset":
+                row[oc.index] = str(len(seg["m"][m.index][i]))
+            elif m.agg == "avg":   # `_j[idx] / (double) _<count field>[idx]`, count field = a selected COUNT metric or `_count`
+                if count_col is not None:
+                    cnt = seg["m"][count_col.index][i]
+                elif seg.get("count") is not None:
+                    cnt = seg["count"][i]
+                else:
+                    raise Unsupported("AVG in a select without a COUNT metric or hidden count does not compile in the reference")
+                row[oc.index] = fmt_num(np.float64(float(seg["m"][m.index][i]) / float(cnt)))
+            else:
+                row[oc.index] = fmt_num(seg["m"][m.index][i])
+        rows.append(row)
+    return rows, stats
+
+
+def scan_search(table: Table, dim: Column, flt, term: str, limit: int, seg_rows: Optional[List[int]] = None):
+    """ScanVisitor::Visit(SearchQuery*) (scan.cc:249-299): -> (values in push order, stats)."""
+    codes = set()
+    values = []
+    stats = {"scanned_recs": 0, "scanned_segments": 0, "passed_recs": 0}
+    for si, seg in enumerate(table.segments):
+        size = seg["size"] if seg_rows is None else int(seg_rows[si])
+        stats["scanned_recs"] += size
+        if not segment_skip(table, flt, seg):
+            continue
+        stats["scanned_segments"] += 1
+        idx = _passing_rows(table, flt, seg, size)
+        stats["passed_recs"] += len(idx)
+        col = seg["d"][dim.index]
+        for i in idx:
+            v = col[i]
+            key = _hashable(v)
+            if key in codes:
+                continue
+            codes.add(key)
+            if dim.dim_type == "string":
+                check = table.dicts[dim.name].c2v[int(v)]
+            elif dim.dim_type == "boolean":
+                check = "true" if v else "false"
+            else:
+                check = fmt_num(v)
+            if term in check:
+                values.append(check)
+                if limit > 0 and len(values) >= limit:
+                    break
+    stats["aggregated_recs"] = len(codes)
+    stats["output_recs"] = len(values)
+    return values, stats
+
+
+def search_query(table: Table, q: dict):
+    """Database::Query for type=search: optional header row, then ONE row holding all values (SendAsCol)."""
+    dim = table.dimension(q["dimension"])
+    values, stats = scan_search(table, dim, make_filter(q.get("filter")), q["term"], int(q.get("limit", 0)))
+    rows = []
+    if q.get("header", False):
+        rows.append([dim.name])
+    rows.append(values)
+    return rows, stats

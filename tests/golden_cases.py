@@ -77,6 +77,8 @@ def check_case(case, run):
     if "rows" in case:
         exp = [list(r) for r in case["rows"]]
         got = [list(r) for r in rows]
+        if case.get("sort_values"):
+            exp, got = [sorted(r) for r in exp], [sorted(r) for r in got]
         if not case.get("ordered"):
             exp, got = sorted(exp), sorted(got)
         assert got == exp, f"{case['id']} ({case['source']}): got {got} expected {exp}"

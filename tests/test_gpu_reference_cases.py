@@ -65,3 +65,76 @@ def test_mirror_follows_upserts():
         assert gdb.table_info("events")["segments"] >= 2
     finally:
         gdb.close()
+
+
+def _events_pair(segment_size=300, nrows=2000, seed=9):
+    """The same random events loaded into the product (host shim + GPU) and the oracle; several segments."""
+    import random
+    from oracle import viya_oracle as vo
+    from viyadb_amd import hostdb
+    tconf = {"name": "events", "segment_size": segment_size,
+             "dimensions": [{"name": "country"}, {"name": "event_name"}, {"name": "day", "type": "uint"},
+                            {"name": "ok", "type": "boolean"}, {"name": "ts", "type": "time", "format": "%Y-%m-%d %H:%M:%S"},
+                            {"name": "id", "type": "uint"}],
+             "metrics": [{"name": "count", "type": "count"}, {"name": "revenue", "type": "double_sum"},
+                         {"name": "best", "type": "int_max"}, {"name": "avg_len", "type": "long_avg"}, {"name": "users", "type": "bitset"}]}
+    rnd = random.Random(seed)
+    names = ["open", "buy", "quit", "refund", "review", "rate", "share", "purchase", "donate", "browse"]
+    rows = [[rnd.choice(["US", "IL", "KZ", "RU", "AZ", "CH"]), rnd.choice(names[: 3 + (i * 7 // nrows)]), str(rnd.randrange(0, 90)),
+             rnd.choice(["true", "false"]), "2017-06-%02d 10:%02d:00" % (1 + i % 28, i % 60), str(i),
+             str(rnd.randrange(0, 500) / 4), str(rnd.randrange(-50, 50)), str(rnd.randrange(1, 30)), str(rnd.randrange(0, 40))]
+            for i in range(nrows)]
+    gdb = hostdb.Database({"tables": [tconf]})
+    odb = vo.Database({"tables": [tconf]})
+    gdb.load("events", rows)
+    odb.table("events").load(rows)
+    return gdb, odb
+
+
+def test_select_matches_oracle_across_segments():
+    """select = the passing rows in storage order through skip/limit, including the reference's rule
+    that `break` leaves the tuple loop only (every later segment still sends one row once the limit is reached)."""
+    gdb, odb = _events_pair()
+    try:
+        assert gdb.table_info("events")["segments"] >= 6
+        base = {"type": "select", "table": "events", "dimensions": ["country", "event_name", "day", "ok", "ts", "id"],
+                "metrics": ["count", "revenue", "best", "avg_len", "users"]}
+        flt = {"op": "and", "filters": [{"op": "lt", "column": "day", "value": "30"}, {"op": "ne", "column": "country", "value": "US"}]}
+        for extra in ({}, {"limit": 7}, {"skip": 5}, {"skip": 450, "limit": 20}, {"limit": 1}, {"skip": 100000}, {"header": True, "limit": 3},
+                      {"filter": {"op": "eq", "column": "country", "value": "nowhere"}},
+                      {"filter": {"op": "gt", "column": "id", "value": "1500"}, "limit": 2}):   # segment skipping by id range
+            q = dict(base, filter=flt)
+            q.update(extra)
+            got, gst = gdb.query(q)
+            want, ost = odb.query(q)
+            assert got == want, extra
+            for k in ("scanned_recs", "scanned_segments", "output_recs"):
+                assert gst[k] == ost[k], (extra, k)
+        # the `select` column form with a time format override and `*`
+        q = {"type": "select", "table": "events", "select": [{"column": "ts", "format": "%d/%m"}, {"column": "*"}], "limit": 4, "skip": 298}
+        assert gdb.query(q)[0] == odb.query(q)[0]
+    finally:
+        gdb.close()
+
+
+def test_search_matches_oracle_across_segments():
+    """search = distinct values of a dimension among passing rows in first-occurrence order, term match,
+    limit (with the same tuple-loop-only `break`), on string / numeric / boolean dimensions."""
+    gdb, odb = _events_pair()
+    try:
+        flt = {"op": "ge", "column": "day", "value": "10"}
+        for dim, term, limit in (("event_name", "", 0), ("event_name", "r", 0), ("event_name", "", 2), ("event_name", "e", 1),
+                                 ("event_name", "zzz", 3), ("country", "", 4), ("day", "1", 0), ("day", "", 5), ("ok", "", 0),
+                                 ("ok", "tr", 1), ("id", "99", 3)):
+            q = {"type": "search", "table": "events", "dimension": dim, "term": term, "filter": flt}
+            if limit:
+                q["limit"] = limit
+            got, gst = gdb.query(q)
+            want, ost = odb.query(q)
+            assert got == want, (dim, term, limit)        # push order is storage order of first occurrence: exact
+            for k in ("scanned_recs", "scanned_segments", "aggregated_recs", "output_recs"):
+                assert gst[k] == ost[k], (dim, term, limit, k)
+        q = {"type": "search", "table": "events", "dimension": "event_name", "term": "o", "header": True}
+        assert gdb.query(q)[0] == odb.query(q)[0]
+    finally:
+        gdb.close()

@@ -74,6 +74,22 @@ class ResultInfo(C.Structure):
                 ("reserved", C.c_uint32), ("returned_groups", C.c_uint64)]
 
 
+class SelectPlan(C.Structure):
+    _fields_ = [("filter", C.POINTER(FilterNode)), ("nfilter", C.c_int32),
+                ("lits", C.POINTER(AnyNum)), ("nlits", C.c_int32),
+                ("cols", C.POINTER(C.c_int32)), ("ncols", C.c_int32),
+                ("seg_rows", C.POINTER(C.c_uint64)), ("nseg", C.c_uint32),
+                ("flags", C.c_uint32), ("skip", C.c_uint64), ("limit", C.c_uint64)]
+
+
+class RowsInfo(C.Structure):
+    _fields_ = [("nrows", C.c_uint64), ("scanned_recs", C.c_uint64), ("scanned_segments", C.c_uint64),
+                ("passed_recs", C.c_uint64), ("kernel_ms", C.c_float), ("total_ms", C.c_float)]
+
+
+COL_ROWID = -2
+
+
 class DeviceBuffer(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("count", C.c_uint64), ("elem", C.c_int32), ("reduce", C.c_int32)]
 
@@ -110,6 +126,10 @@ SYMBOLS = {
     "vh_result_device_buffers": (C.c_int, [_VP, C.POINTER(DeviceBuffer), C.c_int32, C.POINTER(C.c_int32)]),
     "vh_result_finalize": (C.c_int, [_VP]),
     "vh_result_partition": (C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(DeviceBuffer), C.c_int32, C.POINTER(C.c_int32)]),
+    "vh_query_select": (C.c_int, [_VP, C.POINTER(SelectPlan), C.POINTER(_VP)]),
+    "vh_rows_get_info": (C.c_int, [_VP, C.POINTER(RowsInfo)]),
+    "vh_rows_view": (C.c_int, [_VP, C.POINTER(_VP)]),
+    "vh_rows_free": (None, [_VP]),
     "vh_result_get_info": (C.c_int, [_VP, C.POINTER(ResultInfo)]),
     "vh_result_copy": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_uint64)]),
     "vh_result_view": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.POINTER(C.c_uint64))]),

@@ -151,6 +151,9 @@ struct VhPlanDev {
   unsigned long long* counters;
 };
 
+// VhMetricDev::slot of the virtual row-id column (VH_COL_ROWID): value = (segment << 32) | row
+#define VH_SLOT_ROWID 0xFFFFu
+
 #define VH_ERR_RANGE 1ull      // dense digit out of range
 #define VH_ERR_HASH_FULL 2ull  // probe limit hit
 #define VH_ERR_PART_FULL 4ull  // tuple extents exhausted

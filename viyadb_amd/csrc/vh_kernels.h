@@ -477,8 +477,9 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
       if (active) vh_distinct_update(P, m.slot, reinterpret_cast<unsigned long long*>(m.state), MODE == VH_MODE_HASH ? gid : xoff + gid, seg, row);
       continue;
     }
-    const char* base = P.colbase[m.slot] + (uint64_t)seg * P.colstride[m.slot];
-    const uint64_t bits = vh_load_bits(base, m.type, row, vh_sop_sext(m.sop));
+    uint64_t bits;
+    if (m.slot == VH_SLOT_ROWID) bits = ((uint64_t)seg << 32) | row;   // storage order of the row (search: first occurrence)
+    else bits = vh_load_bits(P.colbase[m.slot] + (uint64_t)seg * P.colstride[m.slot], m.type, row, vh_sop_sext(m.sop));
     if (active) {
       if (MODE == VH_MODE_DENSE_LDS) {
         vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, gid, m.sop, bits);
@@ -887,7 +888,8 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
     mv[j] = 0;
     if (j < P.nmetric) {
       const VhMetricDev& m = P.m[j];
-      mv[j] = vh_load_bits(P.colbase[m.slot] + (uint64_t)seg * P.colstride[m.slot], m.type, row, vh_sop_sext(m.sop));
+      if (m.slot == VH_SLOT_ROWID) mv[j] = ((uint64_t)seg << 32) | row;
+      else mv[j] = vh_load_bits(P.colbase[m.slot] + (uint64_t)seg * P.colstride[m.slot], m.type, row, vh_sop_sext(m.sop));
     }
   }
   uint64_t gid = 0;

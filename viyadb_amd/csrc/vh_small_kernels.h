@@ -256,6 +256,115 @@ __global__ __launch_bounds__(256) void partition_groups_kernel(const VhPartition
   for (int c = 0; c < A.ncols; ++c) vh_store_sized(A.dst[c], A.esize[c], pos, vh_load_sized(A.src[c], A.esize[c], i));
 }
 
+// ------------------------------------------------- select: ordered row emission
+// The reference's SelectQuery (src/codegen/query/scan.cc:75-166) sends the passing rows in storage order through
+// a skip/limit window. Same scan geometry and predicate code as the aggregate kernels, different sink:
+//   1. select_count_kernel : passing rows per chunk (one wave-step = 1024 rows)
+//   2. select_scan_kernel  : per segment, exclusive prefix over its chunks + segment total
+//      (host turns the totals into one ordinal window per segment — the reference's skip/limit/break rules)
+//   3. select_emit_kernel  : predicate again; ordinal of a passing row = chunk prefix + ballot prefix; rows
+//      inside the segment's window gather the selected columns into dense output arrays, in order.
+#define VH_MAX_SELECT 32
+struct VhSelectDev {              // lives in device scratch, read through a pointer
+  int32_t ncols; int32_t pad;
+  const char* base[VH_MAX_SELECT];          // column arena (segment 0), or NULL for a bitset column
+  uint64_t stride[VH_MAX_SELECT];
+  const uint64_t* const* bs_offs[VH_MAX_SELECT];   // bitset column: [nseg] -> offsets[rows + 1] (value = cardinality)
+  uint32_t esize[VH_MAX_SELECT];
+  void* out[VH_MAX_SELECT];
+};
+struct VhSelectWindow { uint64_t lo, hi, out_base; };   // ordinals [lo, hi) of the segment's passing rows -> out_base + (o - lo)
+
+__device__ __forceinline__ uint32_t vh_select_mask(const VhPlanDev& P, uint32_t seg, uint32_t wave_base, uint32_t seg_rows, int lane) {
+  const uint32_t row_l = wave_base + lane * 4;
+  return wave_base + VH_WAVE_STEP_ROWS <= seg_rows ? vh_eval_filter<true>(P, seg, row_l, seg_rows)
+                                                    : vh_eval_filter<false>(P, seg, row_l, seg_rows);
+}
+
+__global__ __launch_bounds__(256) void select_count_kernel(const VhPlanDev P, uint32_t chunks_per_seg, uint32_t* counts) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t nchunks = (uint64_t)P.nseg * chunks_per_seg;
+  unsigned long long npassed = 0;
+  for (uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); c < nchunks; c += (uint64_t)gridDim.x * 4) {
+    const uint32_t seg = (uint32_t)(c / chunks_per_seg);
+    const uint32_t wave_base = (uint32_t)(c - (uint64_t)seg * chunks_per_seg) * VH_WAVE_STEP_ROWS;
+    const uint32_t seg_rows = P.seg_rows[seg];
+    uint32_t n = 0;
+    if (wave_base < seg_rows) {
+      n = __popc(vh_select_mask(P, seg, wave_base, seg_rows, lane));
+      for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off);
+    }
+    if (lane == 0) { counts[c] = n; npassed += n; }
+  }
+  if (lane == 0 && npassed) atomicAdd(P.counters + 0, npassed);
+}
+
+__global__ __launch_bounds__(256) void select_scan_kernel(uint32_t* counts, uint32_t chunks_per_seg, unsigned long long* seg_totals) {
+  __shared__ uint32_t wsum[4];
+  uint32_t* c = counts + (uint64_t)blockIdx.x * chunks_per_seg;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long carry = 0;
+  for (uint32_t t0 = 0; t0 < chunks_per_seg; t0 += 256) {
+    const uint32_t i = t0 + threadIdx.x;
+    const uint32_t v = i < chunks_per_seg ? c[i] : 0u;
+    uint32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, tile = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wave) before += wsum[w]; tile += wsum[w]; }
+    if (i < chunks_per_seg) c[i] = (uint32_t)(carry + before + incl - v);   // < 2^32: a segment holds < 2^32 rows
+    carry += tile;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) seg_totals[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(256) void select_emit_kernel(const VhPlanDev P, uint32_t chunks_per_seg, const uint32_t* prefix,
+                                                          const VhSelectWindow* win, const VhSelectDev* S) {
+  const int lane = threadIdx.x & 63;
+  const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+  const uint64_t nchunks = (uint64_t)P.nseg * chunks_per_seg;
+  const int ncols = S->ncols;
+  for (uint64_t c = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6); c < nchunks; c += (uint64_t)gridDim.x * 4) {
+    const uint32_t seg = (uint32_t)(c / chunks_per_seg);
+    const uint32_t wave_base = (uint32_t)(c - (uint64_t)seg * chunks_per_seg) * VH_WAVE_STEP_ROWS;
+    const uint32_t seg_rows = P.seg_rows[seg];
+    if (wave_base >= seg_rows) continue;
+    const VhSelectWindow w = win[seg];
+    uint64_t ord = prefix[c];                       // ordinal (within the segment) of this chunk's first passing row
+    if (w.lo >= w.hi || ord >= w.hi) continue;
+    const uint32_t mask = vh_select_mask(P, seg, wave_base, seg_rows, lane);
+#pragma unroll
+    for (int k = 0; k < VH_SUBSTEPS; ++k) {
+      const uint32_t mk = (mask >> (4 * k)) & 0xFu;
+      uint32_t below = 0, total = 0;                // passing rows of this sub-step in lower lanes / in all lanes
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint64_t bal = __ballot((mk >> j) & 1u);
+        below += __popcll(bal & lanemask_lt);
+        total += __popcll(bal);
+      }
+      uint64_t o = ord + below;
+      for (int j = 0; j < 4; ++j) {
+        if (!((mk >> j) & 1u)) continue;
+        if (o >= w.lo && o < w.hi) {
+          const uint32_t row = wave_base + lane * 4 + k * 256u + j;
+          const uint64_t dst = w.out_base + (o - w.lo);
+          for (int cidx = 0; cidx < ncols; ++cidx) {
+            uint64_t v;
+            if (S->base[cidx]) v = vh_load_sized(S->base[cidx] + (uint64_t)seg * S->stride[cidx], S->esize[cidx], row);
+            else { const uint64_t* offs = S->bs_offs[cidx][seg]; v = offs[row + 1] - offs[row]; }
+            vh_store_sized(S->out[cidx], S->esize[cidx], dst, v);
+          }
+        }
+        ++o;
+      }
+      ord += total;
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void fill_kernel(T* p, uint64_t n, T v) {
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = v;

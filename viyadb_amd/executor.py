@@ -156,7 +156,8 @@ class DeviceTable:
         nodes, lits = [], []
         hnodes = []
         result_elem = [self.cols[g.col][1] for g in plan.groups] + \
-                      [(capi.U64 if self.cols[m][1] == capi.BITSET64 else capi.U32) if self.cols[m][1] >= capi.BITSET32 else self.cols[m][1]
+                      [capi.U64 if m == capi.COL_ROWID else
+                       (capi.U64 if self.cols[m][1] == capi.BITSET64 else capi.U32) if self.cols[m][1] >= capi.BITSET32 else self.cols[m][1]
                        for m in plan.metrics]
         for f in plan.having:
             k = f[0]
@@ -255,7 +256,7 @@ class DeviceTable:
             return a.copy() if copy else a
 
         keys = [view(kp[i], capi.ELEM_NP[self.cols[g.col][1]]) for i, g in enumerate(plan.groups)]
-        states = [view(spp[j], np.uint64 if self.cols[m][1] >= capi.BITSET32 else capi.ELEM_NP[self.cols[m][1]])
+        states = [view(spp[j], np.uint64 if m == capi.COL_ROWID or self.cols[m][1] >= capi.BITSET32 else capi.ELEM_NP[self.cols[m][1]])
                   for j, m in enumerate(plan.metrics)]
         hidden = view(C.cast(hp, C.c_void_p).value, np.uint64) if info.has_hidden_count else None
         return AggResult(keys, states, hidden, int(info.ngroups), int(info.scanned_recs), int(info.scanned_segments),
@@ -271,6 +272,36 @@ class DeviceTable:
             return self._collect(res, plan, copy)
         finally:
             self.lib.vh_result_free(res)
+
+    # ---- select: the passing rows themselves, in storage order, through the reference's skip/limit window
+    def query_select(self, filter: Sequence, cols: Sequence[int], skip: int = 0, limit: int = 0,
+                     seg_rows: Optional[Sequence[int]] = None, flags: int = 0):
+        """-> ([one numpy array per selected column], RowsInfo)."""
+        p, keep = self._build_plan(AggPlan(filter=filter, seg_rows=seg_rows, flags=flags))
+        sp = capi.SelectPlan()
+        sp.filter, sp.nfilter, sp.lits, sp.nlits = p.filter, p.nfilter, p.lits, p.nlits
+        sp.seg_rows, sp.nseg, sp.flags = p.seg_rows, p.nseg, p.flags
+        ca = (C.c_int32 * max(1, len(cols)))(*[int(c) for c in cols])
+        sp.cols, sp.ncols = ca, len(cols)
+        sp.skip, sp.limit = int(skip), int(limit)
+        rows = C.c_void_p()
+        capi.check(self.lib.vh_query_select(self.handle, C.byref(sp), C.byref(rows)))
+        try:
+            info = capi.RowsInfo()
+            capi.check(self.lib.vh_rows_get_info(rows, C.byref(info)))
+            ptrs = (C.c_void_p * max(1, len(cols)))()
+            capi.check(self.lib.vh_rows_view(rows, ptrs))
+            out = []
+            for i, c in enumerate(cols):
+                dt = np.dtype(np.uint64 if self.cols[c][1] >= capi.BITSET32 else capi.ELEM_NP[self.cols[c][1]])
+                if info.nrows and ptrs[i]:
+                    buf = (C.c_char * (info.nrows * dt.itemsize)).from_address(ptrs[i])
+                    out.append(np.frombuffer(buf, dtype=dt, count=info.nrows).copy())
+                else:
+                    out.append(np.empty(0, dtype=dt))
+            return out, info
+        finally:
+            self.lib.vh_rows_free(rows)
 
     # ---- split form for multi-GPU: launch -> (caller reduces device buffers) -> finalize
     def query_launch(self, plan: AggPlan):

@@ -1,4 +1,5 @@
-// gpu_aggregate.cc — the host shim that stands where the JIT-compiled `viya_query_agg` stood.
+// gpu_aggregate.cc — the host shim that stands where the JIT-compiled `viya_query_agg` (and, further down,
+// `viya_query_select` / `viya_query_search`) stood.
 //
 // Reference flow being replaced (src/codegen/query/agg_query.cc:26-71 assembles it):
 //   ScanVisitor   (scan.cc:168-247)  : segment loop, predicate, agg_map[key].Update(m)   -> GPU, via the C-ABI
@@ -10,6 +11,7 @@
 #include <algorithm>
 #include <cstring>
 #include <ctime>
+#include <set>
 #include <stdexcept>
 
 #include "../../include/viya_hip.h"
@@ -453,6 +455,222 @@ void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, s
     const size_t hi = limit > 0 ? std::min(skip + limit, post_agg.size()) : post_agg.size();
     for (size_t i = lo; i < hi; ++i) { output.Send(post_agg[i]); ++stats.output_recs; }
   }
+  output.Flush();
+}
+
+// ------------------------------------------------------------------------------------------------
+// select: ScanVisitor::Visit(SelectQuery*) (src/codegen/query/scan.cc:75-166). The scan, the ordered
+// compaction and the skip/limit window (including the reference's "break leaves the tuple loop only"
+// rule) run on the GPU (vh_query_select); the rows come back as typed columns and are formatted here.
+void GpuSelect(SelectQuery& query, RowOutput& output, QueryStats& stats, std::vector<db::AnyNum> fargs, size_t skip,
+               size_t limit) {
+  db::Table& table = query.table();
+  typedef std::vector<std::string> Row;
+  const size_t ncols = query.dimension_cols().size() + query.metric_cols().size();
+  std::vector<int32_t> cols;
+  for (auto& dc : query.dimension_cols()) cols.push_back((int32_t)dc.dim()->storage_index);
+  for (auto& mc : query.metric_cols()) cols.push_back((int32_t)mc.metric()->storage_index);
+  // `_j[idx] / (double) _<count field>[idx]`: a selected COUNT metric, else the hidden `_count` (scan.cc:136-152)
+  int count_pos = -1;
+  const db::Metric* count_metric = nullptr;
+  bool has_avg = false;
+  for (size_t k = 0; k < query.metric_cols().size(); ++k) {
+    const db::Metric* m = query.metric_cols()[k].metric();
+    has_avg |= m->agg_type() == db::Column::AVG;
+    if (count_pos < 0 && m->agg_type() == db::Column::COUNT) { count_pos = (int)(query.dimension_cols().size() + k); count_metric = m; }
+  }
+  if (has_avg && count_pos < 0) {
+    if (!table.has_hidden_count()) throw std::runtime_error("AVG in a select needs a COUNT metric or the hidden count (the reference's generated code would not compile)");
+    count_pos = (int)cols.size();
+    cols.push_back((int32_t)table.hidden_count_storage_index());
+  }
+
+  std::vector<std::vector<char>> data(cols.size());
+  std::vector<int> esize(cols.size());
+  uint64_t nrows = 0;
+  {
+    std::lock_guard<std::mutex> lk(table.mu);
+    GpuMirror* mir = ensure_mirror(table);
+    std::vector<uint64_t> seg_rows = sync_mirror(table, mir);
+    PlanFilterBuilder fb(table, fargs);
+    query.filter()->Accept(fb);
+    vh_select_plan plan;
+    memset(&plan, 0, sizeof(plan));
+    plan.filter = fb.nodes.data(); plan.nfilter = (int32_t)fb.nodes.size();
+    plan.lits = fb.lits.data(); plan.nlits = (int32_t)fb.lits.size();
+    plan.cols = cols.data(); plan.ncols = (int32_t)cols.size();
+    plan.seg_rows = seg_rows.data(); plan.nseg = (uint32_t)seg_rows.size();
+    plan.skip = skip; plan.limit = limit;
+    vh_rows* rows = nullptr;
+    vh_check(vh_query_select(mir->handle, &plan, &rows));
+    std::unique_ptr<vh_rows, void (*)(vh_rows*)> guard(rows, vh_rows_free);
+    vh_rows_info info;
+    vh_check(vh_rows_get_info(rows, &info));
+    stats.scanned_recs += info.scanned_recs;
+    stats.scanned_segments += info.scanned_segments;
+    stats.passed_recs = info.passed_recs;
+    stats.scan_kernel_ms = info.kernel_ms;
+    stats.device_total_ms = info.total_ms;
+    nrows = info.nrows;
+    std::vector<const void*> ptrs(cols.size() + 1, nullptr);
+    vh_check(vh_rows_view(rows, ptrs.data()));
+    for (size_t c = 0; c < cols.size(); ++c) {
+      int es = table.storage_elem_size(cols[c]);
+      if (es == 0) es = 8;   // bitset column: per-row cardinality as u64
+      esize[c] = es;
+      data[c].resize(nrows * es);
+      if (nrows) memcpy(data[c].data(), ptrs[c], nrows * es);
+    }
+  }
+
+  output.Start();
+  Row row(ncols);
+  if (query.header()) {
+    for (auto& dc : query.dimension_cols()) row[dc.index()] = dc.dim()->name();
+    for (auto& mc : query.metric_cols()) row[mc.index()] = mc.metric()->name();
+    output.Send(row);
+  }
+  for (uint64_t i = 0; i < nrows; ++i) {
+    size_t c = 0;
+    for (auto& dc : query.dimension_cols()) {
+      const db::Dimension* d = dc.dim();
+      const char* p = &data[c][i * esize[c]];
+      if (d->dim_type() == db::Column::DIM_STRING) {
+        uint64_t code = 0;
+        memcpy(&code, p, esize[c]);
+        row[dc.index()] = d->dict()->c2v().at(code);
+      } else if (d->dim_type() == db::Column::DIM_TIME && !dc.format().empty()) {
+        uint64_t ts = 0;
+        memcpy(&ts, p, esize[c]);
+        row[dc.index()] = format_date(dc.format(), (uint32_t)ts);
+      } else if (d->dim_type() == db::Column::DIM_BOOLEAN) {
+        row[dc.index()] = *p ? "true" : "false";
+      } else {
+        row[dc.index()] = db::format_num(p, d->num_type().type());
+      }
+      ++c;
+    }
+    for (auto& mc : query.metric_cols()) {
+      const db::Metric* m = mc.metric();
+      const char* p = &data[c][i * esize[c]];
+      if (m->agg_type() == db::Column::BITSET) {
+        uint64_t card;
+        memcpy(&card, p, 8);
+        row[mc.index()] = std::to_string(card);
+      } else if (m->agg_type() == db::Column::AVG) {
+        const char* cp = &data[count_pos][i * esize[count_pos]];
+        const double cnt = count_metric ? db::load_as_double(cp, count_metric->num_type().type()) : (double)*reinterpret_cast<const uint64_t*>(cp);
+        const double avg = db::load_as_double(p, m->num_type().type()) / cnt;
+        row[mc.index()] = db::format_num(reinterpret_cast<const char*>(&avg), db::Num::DOUBLE);
+      } else {
+        row[mc.index()] = db::format_num(p, m->num_type().type());
+      }
+      ++c;
+    }
+    output.Send(row);
+    ++stats.output_recs;
+  }
+  output.Flush();
+}
+
+// ------------------------------------------------------------------------------------------------
+// search: ScanVisitor::Visit(SearchQuery*) + PostAggVisitor::Visit(SearchQuery*) (scan.cc:249-299,
+// post_agg.cc:149-166). `codes.insert(value).second` in storage order == GROUP BY the dimension with MIN over the
+// row's storage position (VH_COL_ROWID), groups taken in that order. The term match runs on the decoded values
+// here. Limit: the reference's `break` leaves the tuple loop only — the rest of THAT segment is not scanned (codes
+// first seen there are not inserted) and every later segment is scanned up to its first new matching value; that
+// tail is reproduced with one single-segment query per later segment.
+void GpuSearch(SearchQuery& query, RowOutput& output, QueryStats& stats, std::vector<db::AnyNum> fargs,
+               const std::string& term, size_t limit) {
+  db::Table& table = query.table();
+  const db::Dimension* dim = query.dimension();
+  const int es = dim->num_type().size();
+  std::vector<std::string> values;
+  std::set<uint64_t> codes;   // value bits (the reference's unordered_set<T>)
+  auto decode = [&](uint64_t bits) -> std::string {
+    if (dim->dim_type() == db::Column::DIM_STRING) return dim->dict()->c2v().at(bits);
+    if (dim->dim_type() == db::Column::DIM_BOOLEAN) return (bits & 0xff) ? "true" : "false";
+    return db::format_num(reinterpret_cast<const char*>(&bits), dim->num_type().type());
+  };
+  {
+    std::lock_guard<std::mutex> lk(table.mu);
+    GpuMirror* mir = ensure_mirror(table);
+    std::vector<uint64_t> seg_rows = sync_mirror(table, mir);
+    PlanFilterBuilder fb(table, fargs);
+    query.filter()->Accept(fb);
+    vh_group_col g;
+    memset(&g, 0, sizeof(g));
+    g.col = (int32_t)dim->storage_index;
+    g.granularity = VH_T_NONE;
+    if (dim->dim_type() == db::Column::DIM_STRING) g.cardinality = dim->dict()->c2v().size();
+    else if (dim->dim_type() == db::Column::DIM_BOOLEAN) g.cardinality = 2;
+    int32_t rowid = VH_COL_ROWID;
+
+    // -> (first storage position, value bits) of every distinct value among the passing rows, in storage order
+    auto first_occurrences = [&](const std::vector<uint64_t>& rows, bool count_stats) {
+      vh_plan plan;
+      memset(&plan, 0, sizeof(plan));
+      plan.filter = fb.nodes.data(); plan.nfilter = (int32_t)fb.nodes.size();
+      plan.lits = fb.lits.data(); plan.nlits = (int32_t)fb.lits.size();
+      plan.groups = &g; plan.ngroups = 1;
+      plan.metrics = &rowid; plan.nmetrics = 1;
+      plan.seg_rows = rows.data(); plan.nseg = (uint32_t)rows.size();
+      vh_result* res = nullptr;
+      vh_check(vh_query_agg(mir->handle, &plan, &res));
+      std::unique_ptr<vh_result, void (*)(vh_result*)> guard(res, vh_result_free);
+      vh_result_info info;
+      vh_check(vh_result_get_info(res, &info));
+      if (count_stats) {
+        stats.scanned_recs += info.scanned_recs;
+        stats.scanned_segments += info.scanned_segments;
+        stats.passed_recs = info.passed_recs;
+        stats.scan_kernel_ms = info.scan_kernel_ms;
+        stats.device_total_ms = info.total_ms;
+        stats.path = info.path;
+      }
+      std::vector<char> keys(info.returned_groups * es);
+      std::vector<uint64_t> pos(info.returned_groups);
+      void* kp[1] = {keys.data()};
+      void* sp[1] = {pos.data()};
+      vh_check(vh_result_copy(res, kp, sp, nullptr));
+      std::vector<std::pair<uint64_t, uint64_t>> out(info.returned_groups);
+      for (size_t i = 0; i < out.size(); ++i) {
+        uint64_t bits = 0;
+        memcpy(&bits, &keys[i * es], es);
+        out[i] = {pos[i], bits};
+      }
+      std::sort(out.begin(), out.end());
+      return out;
+    };
+
+    bool limit_hit = false;
+    uint64_t hit_segment = 0;
+    for (auto& pv : first_occurrences(seg_rows, true)) {
+      codes.insert(pv.second);
+      const std::string check = decode(pv.second);
+      if (check.find(term) != std::string::npos) {
+        values.push_back(check);
+        if (limit > 0 && values.size() >= limit) { limit_hit = true; hit_segment = pv.first >> 32; break; }
+      }
+    }
+    if (limit_hit) {
+      for (uint64_t s = hit_segment + 1; s < seg_rows.size(); ++s) {
+        if (!seg_rows[s]) continue;
+        std::vector<uint64_t> only(seg_rows.size(), 0);
+        only[s] = seg_rows[s];
+        for (auto& pv : first_occurrences(only, false)) {
+          if (!codes.insert(pv.second).second) continue;
+          const std::string check = decode(pv.second);
+          if (check.find(term) != std::string::npos) { values.push_back(check); break; }   // size >= limit holds
+        }
+      }
+    }
+  }
+  stats.aggregated_recs = codes.size();   // scan.cc:298
+  output.Start();
+  if (query.header()) output.Send(std::vector<std::string>{dim->name()});
+  output.SendAsCol(values);
+  stats.output_recs = values.size();
   output.Flush();
 }
 

@@ -118,7 +118,7 @@ DimOutputColumn::DimOutputColumn(const util::Config& config, const db::Dimension
   }
 }
 
-AggregateQuery::AggregateQuery(const util::Config& config, db::Table& table)
+AggregateQuery::AggregateQuery(const util::Config& config, db::Table& table, bool select_only)
     : table_(table), header_(config.boolean("header", false)), skip_((size_t)config.num("skip", 0)), limit_((size_t)config.num("limit", 0)) {
   FilterFactory ff;
   filter_ = ff.Create(config.sub("filter", true));
@@ -138,6 +138,7 @@ AggregateQuery::AggregateQuery(const util::Config& config, db::Table& table)
     for (auto& n : config.strlist("dimensions")) dimension_cols_.emplace_back(table.dimension(n), out_idx++);
     for (auto& n : config.strlist("metrics")) metric_cols_.emplace_back(table.metric(n), out_idx++);
   }
+  if (select_only) return;
   if (config.exists("sort")) {
     for (const util::Config& sc : config.sublist("sort")) {
       const std::string name = sc.str("column");
@@ -157,6 +158,13 @@ AggregateQuery::AggregateQuery(const util::Config& config, db::Table& table)
     for (auto& h : cc.cols)
       if (std::find(names.begin(), names.end(), h) == names.end()) throw std::invalid_argument("Column '" + h + " is not selected");
   }
+}
+
+SearchQuery::SearchQuery(const util::Config& config, db::Table& table)
+    : table_(table), header_(config.boolean("header", false)), dimension_(table.dimension(config.str("dimension"))),
+      term_(config.str("term")), limit_((size_t)config.num("limit", 0)) {
+  FilterFactory ff;
+  filter_ = ff.Create(config.sub("filter", true));
 }
 
 std::vector<std::string> AggregateQuery::column_names() const {
@@ -196,9 +204,28 @@ void Database::Load(const std::string& table, const std::vector<std::vector<std:
 // Database::Query -> QueryFactory::Create -> QueryRunner::Visit(AggregateQuery*)
 query::QueryStats Database::Query(const util::Config& conf, query::RowOutput& output, int64_t now) {
   const std::string type = conf.str("type");
-  if (type != "aggregate") throw std::invalid_argument("unsupported query type: " + type + " (this build accelerates aggregate queries)");
+  if (type != "aggregate" && type != "select" && type != "search")
+    throw std::invalid_argument("unsupported query type: " + type + " (this build accelerates aggregate, select and search queries)");
   Table* table = GetTable(conf.str("table"));
   auto t0 = std::chrono::steady_clock::now();
+  if (type == "select") {      // QueryRunner::Visit(SelectQuery*)  (src/query/runner.cc:29-43)
+    query::SelectQuery q(conf, *table);
+    query::QueryStats stats;
+    std::vector<AnyNum> fargs = query::PackFilterArgs(*table, q.filter());
+    stats.compile_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    query::GpuSelect(q, output, stats, fargs, q.skip(), q.limit());
+    stats.whole_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return stats;
+  }
+  if (type == "search") {      // QueryRunner::Visit(SearchQuery*)  (src/query/runner.cc:66-80)
+    query::SearchQuery q(conf, *table);
+    query::QueryStats stats;
+    std::vector<AnyNum> fargs = query::PackFilterArgs(*table, q.filter());
+    stats.compile_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    query::GpuSearch(q, output, stats, fargs, q.term(), q.limit());
+    stats.whole_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return stats;
+  }
   query::AggregateQuery q(conf, *table);
   query::QueryStats stats;
   std::vector<AnyNum> fargs = query::PackFilterArgs(*table, q.filter());

@@ -1,4 +1,4 @@
-// viya_query.h — host-side mirror of the reference's query layer for aggregate queries.
+// viya_query.h — host-side mirror of the reference's query layer for aggregate (and select / search) queries.
 //
 //   query::Filter tree + FilterFactory      src/query/filter.h:38-134, src/query/filter.cc:36-108
 //   query::AggregateQuery (+ SelectQuery)   src/query/query.h:152-205, src/query/query.cc:48-135
@@ -172,7 +172,8 @@ private:
 
 class AggregateQuery {
 public:
-  AggregateQuery(const util::Config& config, db::Table& table);
+  // select_only: the SelectQuery base of the reference (src/query/query.cc:48-83) — no sort / having parsing
+  AggregateQuery(const util::Config& config, db::Table& table, bool select_only = false);
   db::Table& table() { return table_; }
   bool header() const { return header_; }
   const Filter* filter() const { return filter_.get(); }
@@ -194,6 +195,32 @@ private:
   size_t skip_, limit_;
 };
 
+// query::SelectQuery (src/query/query.h:152-183): the column list, filter, skip and limit of an AggregateQuery.
+class SelectQuery : public AggregateQuery {
+public:
+  SelectQuery(const util::Config& config, db::Table& table) : AggregateQuery(config, table, true) {}
+};
+
+// query::SearchQuery (src/query/query.h:207-224, query.cc:139-144)
+class SearchQuery {
+public:
+  SearchQuery(const util::Config& config, db::Table& table);
+  db::Table& table() { return table_; }
+  bool header() const { return header_; }
+  const Filter* filter() const { return filter_.get(); }
+  const db::Dimension* dimension() const { return dimension_; }
+  const std::string& term() const { return term_; }
+  size_t limit() const { return limit_; }
+
+private:
+  db::Table& table_;
+  bool header_;
+  std::unique_ptr<Filter> filter_;
+  const db::Dimension* dimension_;
+  std::string term_;
+  size_t limit_;
+};
+
 // FilterArgsPacker: literals decoded to the column's type, in traversal order.
 std::vector<db::AnyNum> PackFilterArgs(const db::Table& table, const Filter* filter);
 
@@ -201,6 +228,12 @@ std::vector<db::AnyNum> PackFilterArgs(const db::Table& table, const Filter* fil
 // same argument meaning; `now` < 0 means std::time(nullptr) (VIYA_TEST_ROLLUP_TS in the reference).
 void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, std::vector<db::AnyNum> fargs,
                   size_t skip, size_t limit, std::vector<db::AnyNum> hargs, int64_t now);
+
+// ... and where viya_query_select / viya_query_search stood (src/query/runner.h:29-31,37-39): same arguments.
+void GpuSelect(SelectQuery& query, RowOutput& output, QueryStats& stats, std::vector<db::AnyNum> fargs, size_t skip,
+               size_t limit);
+void GpuSearch(SearchQuery& query, RowOutput& output, QueryStats& stats, std::vector<db::AnyNum> fargs,
+               const std::string& term, size_t limit);
 
 }  // namespace query
 
