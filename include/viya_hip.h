@@ -158,6 +158,13 @@ typedef struct vh_plan {
    * plan. Semantics of post_agg.cc:77-83: AVG compares its raw sum, a bitset its cardinality. Only groups that
    * pass are returned; vh_result_info.ngroups still counts every group (agg_map.size()). */
   const vh_filter_node* having; int32_t nhaving; int32_t reserved2;
+  /* Optional device-side top-N, for `sort` + `limit` whose FIRST sort column is numeric (the
+   * reference's INTEGER / FLOAT sort types, src/db/column.h:198-200,270-272; not string, time, boolean or AVG
+   * columns, whose order is an order of formatted strings): top_k = skip + limit (0 = off), top_col = RESULT
+   * column as in `having`, top_desc = !ascending. The result then holds a SUPERSET of the rows the reference
+   * would send — every group whose key ties with or beats the top_k-th, after HAVING — in no particular order;
+   * the caller still runs the reference's comparators (sort.cc:24-75) on them, now on few rows. */
+  int32_t top_col; int32_t top_desc; uint64_t top_k;
 } vh_plan;
 
 /* ---- results ---------------------------------------------------------------*/

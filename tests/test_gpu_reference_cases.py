@@ -138,3 +138,43 @@ def test_search_matches_oracle_across_segments():
         assert gdb.query(q)[0] == odb.query(q)[0]
     finally:
         gdb.close()
+
+
+def test_sorted_limit_with_device_top_n(monkeypatch):
+    """`sort` + `limit` over ~400 K group slots. The device keeps only the groups that can make the
+    window; rows must equal the oracle's exactly (the second sort column makes the order total), with and without it."""
+    import random
+    from oracle import viya_oracle as vo
+    from viyadb_amd import hostdb
+    tconf = {"name": "events", "segment_size": 40000,
+             "dimensions": [{"name": "country"}, {"name": "id", "type": "uint"}],
+             "metrics": [{"name": "count", "type": "count"}, {"name": "revenue", "type": "double_sum"}, {"name": "best", "type": "int_max"},
+                         {"name": "spread", "type": "long_avg"}]}
+    rnd = random.Random(21)
+    rows = [[rnd.choice(["US", "IL", "KZ", "RU", "AZ", "CH"]), str(i % 70000), str(rnd.randrange(0, 100000) / 8), str(rnd.randrange(-3000, 3000)),
+             str(rnd.randrange(1, 50))] for i in range(90000)]
+    gdb = hostdb.Database({"tables": [tconf]})
+    odb = vo.Database({"tables": [tconf]})
+    try:
+        gdb.load("events", rows)
+        odb.table("events").load(rows)
+        base = {"type": "aggregate", "table": "events", "dimensions": ["id", "country"], "metrics": ["count", "revenue", "best", "spread"]}
+        for sort, extra in (([{"column": "best"}, {"column": "id", "ascending": True}, {"column": "country"}], {"limit": 20}),
+                            ([{"column": "best", "ascending": True}, {"column": "id"}, {"column": "country"}], {"limit": 7, "skip": 5}),
+                            ([{"column": "revenue"}, {"column": "id"}, {"column": "country"}], {"limit": 15}),
+                            ([{"column": "id"}, {"column": "country"}], {"limit": 9, "skip": 3}),
+                            ([{"column": "count"}, {"column": "id", "ascending": True}, {"column": "country"}], {"limit": 11, "having": {"op": "lt", "column": "best", "value": "0"}}),
+                            ([{"column": "spread"}, {"column": "id"}, {"column": "country"}], {"limit": 5}),      # AVG: host-side order
+                            ([{"column": "country"}, {"column": "id"}], {"limit": 5})):                             # string: host-side order
+            q = dict(base, sort=sort, **extra)
+            want, ost = odb.query(q)
+            for host_only in ("", "1"):
+                if host_only:
+                    monkeypatch.setenv("VIYA_HOST_TOPN", "1")
+                else:
+                    monkeypatch.delenv("VIYA_HOST_TOPN", raising=False)
+                got, gst = gdb.query(q)
+                assert got == want, (sort, extra, host_only)
+                assert gst["aggregated_recs"] == ost["aggregated_recs"] and gst["output_recs"] == ost["output_recs"]
+    finally:
+        gdb.close()

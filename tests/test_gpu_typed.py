@@ -318,3 +318,41 @@ def test_count_distinct(wide, flags):
         run(tab, dt, {"dimensions": [], "metrics": ["users"]}, flags=flags)
     finally:
         dt.close()
+
+
+def _ref_sort_key(v, dtype):
+    """The reference's sort order of a formatted value: INTEGER columns compare (length, text) (src/util/string.h:28-49),
+    FLOAT columns compare stod of the "%.15g" / "%g" text."""
+    if np.dtype(dtype).kind == "f":
+        return float(("%g" if np.dtype(dtype) == np.float32 else "%.15g") % float(v))
+    s = str(int(v))
+    return (len(s), s)
+
+
+@pytest.mark.parametrize("metric", ["long_max", "int_min", "ulong_sum", "uint_max", "short_sum", "float_sum", "double_min", "count"])
+@pytest.mark.parametrize("desc", [True, False])
+def test_device_top_n_keeps_a_superset(typed, metric, desc):
+    """sort + limit on a numeric column. The device must return every group that ties with or beats
+    the k-th in the REFERENCE's order (string length first for integers, so -5 > 3), and far fewer than all groups."""
+    import dataclasses
+    tab, dt = typed
+    q = {"type": "aggregate", "table": "t", "dimensions": ["id"], "metrics": [metric, "count"], "filter": F("ge", "d_int", "-50")}
+    aq = vo.parse_query(tab, q)
+    st = vo.scan_aggregate(aq, now=NOW)
+    assert st.ngroups > 100_000
+    vals = st.states[0]
+    keys = [_ref_sort_key(v, vals.dtype) for v in vals]
+    for k in (1, 10, 1000):
+        plan = dataclasses.replace(plan_from_query(tab, aq, now=NOW), top=(1, desc, k))
+        res = dt.query_agg(plan)
+        assert res.ngroups == st.ngroups
+        order = sorted(range(len(keys)), key=lambda i: keys[i], reverse=desc)
+        kth = keys[order[k - 1]]
+        required = {int(st.keys[0][i]) for i in range(len(keys)) if (keys[i] >= kth if desc else keys[i] <= kth)}
+        got = {int(x) for x in res.keys[0]}
+        assert required <= got, (metric, desc, k, len(required - got))
+        assert res.returned == len(got) and len(got) <= len(required) + 3000, (metric, desc, k, len(got), len(required))
+        # the kept rows carry their true states
+        pos = {int(x): i for i, x in enumerate(st.keys[0])}
+        idx = np.array([pos[int(x)] for x in res.keys[0]])
+        assert np.array_equal(res.states[0], vals[idx]) and np.array_equal(res.states[1], st.states[1][idx])

@@ -63,7 +63,8 @@ class Plan(C.Structure):
                 ("metrics", C.POINTER(C.c_int32)), ("nmetrics", C.c_int32),
                 ("seg_rows", C.POINTER(C.c_uint64)), ("nseg", C.c_uint32),
                 ("flags", C.c_uint32), ("groups_hint", C.c_uint64),
-                ("having", C.POINTER(FilterNode)), ("nhaving", C.c_int32), ("reserved2", C.c_int32)]
+                ("having", C.POINTER(FilterNode)), ("nhaving", C.c_int32), ("reserved2", C.c_int32),
+                ("top_col", C.c_int32), ("top_desc", C.c_int32), ("top_k", C.c_uint64)]
 
 
 class ResultInfo(C.Structure):

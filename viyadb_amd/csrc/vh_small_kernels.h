@@ -199,22 +199,6 @@ __global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
   for (int j = 0; j < A.nmetric; ++j) vh_store_elem(A.out_state[j], A.mtype[j], pos, vh_emit_state(A, i, j));
 }
 
-// ------------------------------------------------- key-partitioned exchange (SURVEY 8(e), hash path)
-// Emitted groups of one GPU are regrouped by owner = mix(key columns) % nparts so that every column can be
-// shipped with one all-to-all; the owner then merges what it received by re-aggregation. Two passes of the
-// same kernel: pass 0 counts rows per owner, pass 1 scatters (wave-aggregated cursor bumps).
-#define VH_MAX_XCHG_COLS (VH_MAX_GROUP + VH_MAX_METRIC)
-struct VhPartitionArgs {
-  uint64_t n;
-  uint32_t nparts; int32_t nkeys; int32_t ncols; int32_t pass;
-  const void* src[VH_MAX_XCHG_COLS];
-  void* dst[VH_MAX_XCHG_COLS];
-  uint32_t esize[VH_MAX_XCHG_COLS];
-  unsigned long long* counts;            // [nparts], pass 0
-  unsigned long long* cursors;           // [nparts], pass 1
-  const unsigned long long* offsets;     // [nparts + 1], pass 1
-};
-
 __device__ __forceinline__ uint64_t vh_load_sized(const void* base, uint32_t esize, uint64_t i) {
   switch (esize) {
     case 1: return reinterpret_cast<const uint8_t*>(base)[i];
@@ -231,6 +215,132 @@ __device__ __forceinline__ void vh_store_sized(void* base, uint32_t esize, uint6
     default: reinterpret_cast<uint64_t*>(base)[i] = v; break;
   }
 }
+
+// ------------------------------------------------- device top-N over emitted groups
+// `sort` + `limit` on a numeric column: instead of shipping every group to the host to be formatted and string-
+// sorted (src/codegen/query/post_agg.cc:50-147, sort.cc:24-75 — what dominates at ~10 M groups), the device keeps
+// a SUPERSET of the rows the reference would return: every group whose primary sort key is at least the K-th
+// best (K = skip + limit), ties and a rounding slack included. The host then runs the reference's exact string
+// comparators on those few rows. Keys only have to be MONOTONE in the reference's order, not exact:
+//   INTEGER columns compare as strings by (length, lexicographic) (src/util/string.h:28-49): ascending order is
+//     0..9, -1..-9, 10..99, -10..-99, ...  ->  key = class(digits, sign) : |v|
+//   FLOAT columns compare stod("%.15g" / "%g" text): numeric order up to the rounding of the formatter, which the
+//     slack covers.
+enum { VH_TOPK_INT = 0, VH_TOPK_FLOAT = 1 };
+struct VhTopkState { unsigned long long k_remaining, prefix, out_count, pad; unsigned long long hist[256]; };
+
+__device__ __forceinline__ uint64_t vh_topk_key(int cls, int elem, uint64_t bits) {
+  if (cls == VH_TOPK_FLOAT) {
+    if (elem == VH_F32) {
+      uint32_t b = (uint32_t)bits;
+      if (b == 0x80000000u) b = 0;                                  // "-0" and "0" compare equal through stod
+      b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+      return (uint64_t)b << 32;
+    }
+    uint64_t b = bits;
+    if (b == 0x8000000000000000ull) b = 0;
+    return (b & 0x8000000000000000ull) ? ~b : (b | 0x8000000000000000ull);
+  }
+  bool neg = false;
+  uint64_t mag = bits;
+  switch (elem) {
+    case VH_I8: { const int64_t v = (int8_t)bits; neg = v < 0; mag = neg ? (uint64_t)(-v) : (uint64_t)v; } break;
+    case VH_I16: { const int64_t v = (int16_t)bits; neg = v < 0; mag = neg ? (uint64_t)(-v) : (uint64_t)v; } break;
+    case VH_I32: { const int64_t v = (int32_t)bits; neg = v < 0; mag = neg ? (uint64_t)(-v) : (uint64_t)v; } break;
+    case VH_I64: { const int64_t v = (int64_t)bits; neg = v < 0; mag = neg ? 0ull - (uint64_t)v : (uint64_t)v; } break;
+    case VH_U8: mag = bits & 0xFFull; break;
+    case VH_U16: mag = bits & 0xFFFFull; break;
+    case VH_U32: mag = bits & 0xFFFFFFFFull; break;
+    default: break;
+  }
+  int nd = 1;                                                        // decimal digits of |v|
+  uint64_t base = 1;                                                 // 10^(nd-1)
+  while (nd < 20 && mag / 10 >= base) { base *= 10; ++nd; }
+  const uint64_t cls_rank = neg ? 2ull * nd + 1 : 2ull * nd;       // string length, '-' sorts before digits
+  // 58 bits for the magnitude: exact up to 17 digits; the 18..20-digit classes keep (|v| - 10^(nd-1)) >> 6,
+  // still monotone inside the class (the low bits only merge near-ties, which a superset tolerates)
+  return (cls_rank << 58) | (nd <= 17 ? mag : (mag - base) >> 6);
+}
+
+__global__ __launch_bounds__(256) void topk_keys_kernel(const void* src, int elem, uint32_t esize, int cls, int desc,
+                                                        const unsigned long long* n_ptr, uint64_t* keys) {
+  const uint64_t n = *n_ptr;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t k = vh_topk_key(cls, elem, vh_load_sized(src, esize, i));
+    keys[i] = desc ? k : ~k;                                         // always select the LARGEST keys
+  }
+}
+
+// one radix-select pass: histogram of the byte at `shift` among keys that match the prefix chosen so far
+__global__ __launch_bounds__(256) void topk_hist_kernel(const uint64_t* keys, const unsigned long long* n_ptr, int shift, VhTopkState* S) {
+  __shared__ unsigned int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint64_t n = *n_ptr;
+  const uint64_t prefix = S->prefix;
+  const uint64_t hi_mask = shift >= 56 ? 0ull : ~0ull << (shift + 8);
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+    const uint64_t k = keys[i];
+    if ((k & hi_mask) == (prefix & hi_mask)) atomicAdd(&h[(k >> shift) & 0xFF], 1u);
+  }
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&S->hist[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+__global__ void topk_pick_kernel(int shift, VhTopkState* S) {
+  if (threadIdx.x != 0) return;
+  unsigned long long need = S->k_remaining, cum = 0;
+  int d = 255;
+  for (; d > 0; --d) {
+    if (cum + S->hist[d] >= need) break;
+    cum += S->hist[d];
+  }
+  S->k_remaining = need - cum;                 // rank inside the chosen digit's bucket
+  S->prefix |= (unsigned long long)d << shift;
+  for (int i = 0; i < 256; ++i) S->hist[i] = 0;
+}
+
+struct VhTopkCompact {
+  int32_t ncols; int32_t pad;
+  uint64_t slack;
+  const void* src[VH_MAX_GROUP + VH_MAX_METRIC];
+  void* dst[VH_MAX_GROUP + VH_MAX_METRIC];
+  uint32_t esize[VH_MAX_GROUP + VH_MAX_METRIC];
+};
+
+__global__ __launch_bounds__(256) void topk_compact_kernel(const VhTopkCompact A, const uint64_t* keys, const unsigned long long* n_ptr,
+                                                           unsigned long long k, VhTopkState* S) {
+  const uint64_t n = *n_ptr;
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const uint64_t T = n > k ? S->prefix : 0ull;
+  const uint64_t thr = T > A.slack ? T - A.slack : 0ull;
+  const bool have = i < n && keys[i] >= thr;
+  const uint64_t bal = __ballot(have);
+  if (bal == 0) return;
+  unsigned long long base = 0;
+  if (lane == 0) base = atomicAdd(&S->out_count, (unsigned long long)__popcll(bal));
+  base = __shfl(base, 0);
+  if (!have) return;
+  const uint64_t pos = base + __popcll(bal & ((1ull << lane) - 1ull));
+  for (int c = 0; c < A.ncols; ++c) vh_store_sized(A.dst[c], A.esize[c], pos, vh_load_sized(A.src[c], A.esize[c], i));
+}
+
+// ------------------------------------------------- key-partitioned exchange (SURVEY 8(e), hash path)
+// Emitted groups of one GPU are regrouped by owner = mix(key columns) % nparts so that every column can be
+// shipped with one all-to-all; the owner then merges what it received by re-aggregation. Two passes of the
+// same kernel: pass 0 counts rows per owner, pass 1 scatters (wave-aggregated cursor bumps).
+#define VH_MAX_XCHG_COLS (VH_MAX_GROUP + VH_MAX_METRIC)
+struct VhPartitionArgs {
+  uint64_t n;
+  uint32_t nparts; int32_t nkeys; int32_t ncols; int32_t pass;
+  const void* src[VH_MAX_XCHG_COLS];
+  void* dst[VH_MAX_XCHG_COLS];
+  uint32_t esize[VH_MAX_XCHG_COLS];
+  unsigned long long* counts;            // [nparts], pass 0
+  unsigned long long* cursors;           // [nparts], pass 1
+  const unsigned long long* offsets;     // [nparts + 1], pass 1
+};
 
 __global__ __launch_bounds__(256) void partition_groups_kernel(const VhPartitionArgs A) {
   const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;

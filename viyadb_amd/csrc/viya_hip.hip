@@ -479,6 +479,14 @@ struct vh_result {
   size_t off_key[VH_MAX_GROUP] = {}, off_state[VH_MAX_METRIC] = {};
   char* h_base = nullptr;
   uint64_t ngroups_host = 0;
+  // device top-N (vh_plan.top_k): a second set of output arrays holding the kept superset
+  uint64_t topk = 0;
+  bool topk_active = false;
+  int topk_src = 0; bool topk_src_is_key = false; int topk_elem = 0, topk_cls = 0, topk_desc = 0;
+  uint64_t* d_topk_keys = nullptr;
+  VhTopkState* d_topk_state = nullptr;
+  void* d_out_key2[VH_MAX_GROUP] = {};
+  void* d_out_state2[VH_MAX_METRIC] = {};
   char* d_xchg = nullptr;              // vh_result_partition: rows regrouped by owner (own allocation)
   ~vh_result() { if (d_xchg) (void)hipFree(d_xchg); }
 };
@@ -915,6 +923,27 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     if (hdepth != 1) { delete r; return vh_fail(VH_E_INVALID, "having program leaves %d values on the stack", hdepth); }
     r->nhaving = p->nhaving;
   }
+  // ---------------- device top-N request (vh_plan.top_*)
+  if (p->top_k > 0) {
+    if (p->top_col < 0 || p->top_col >= p->ngroups + p->nmetrics) { delete r; return vh_fail(VH_E_INVALID, "top_col %d is not a result column", p->top_col); }
+    int kind, elem;
+    if (p->top_col < p->ngroups) {
+      const VhColumn& c = t->cols[p->groups[p->top_col].col];
+      kind = c.kind; elem = c.elem;
+      r->topk_src = p->top_col; r->topk_src_is_key = true;
+    } else {
+      const int mcol = p->metrics[p->top_col - p->ngroups];
+      kind = mcol == VH_COL_ROWID ? (int)VH_METRIC_MIN : t->cols[mcol].kind;
+      r->topk_src = r->user_metric[p->top_col - p->ngroups]; r->topk_src_is_key = false;
+      elem = r->metric_elem[r->topk_src];
+    }
+    if (kind == VH_DIM_STRING || kind == VH_DIM_TIME || kind == VH_DIM_BOOLEAN || kind == VH_METRIC_AVG) {
+      delete r;
+      return vh_fail(VH_E_UNSUPPORTED, "top-N on a string / time / boolean / AVG column: the reference orders those as formatted strings");
+    }
+    r->topk = p->top_k; r->topk_elem = elem; r->topk_desc = p->top_desc ? 1 : 0;
+    r->topk_cls = (elem == VH_F32 || elem == VH_F64) ? VH_TOPK_FLOAT : VH_TOPK_INT;
+  }
 
   // ---------------- choose the table organisation
   size_t state_bytes_per_group = 1;  // presence byte
@@ -1085,6 +1114,15 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident == 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop));
   const size_t zero_end = sp.off;
   for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident != 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop));
+  // device top-N: worth it only when the group table is big (small results are read back whole anyway)
+  size_t o_tkkeys = 0, o_tkstate = 0, o_okey2[VH_MAX_GROUP] = {}, o_ostate2[VH_MAX_METRIC] = {};
+  r->topk_active = r->topk > 0 && r->out_cap > 65536 && !getenv("VH_NO_TOPK");
+  if (r->topk_active) {
+    o_tkkeys = sp.take(r->out_cap * sizeof(uint64_t));
+    o_tkstate = sp.take(sizeof(VhTopkState));
+    for (int i = 0; i < P.ngroup; ++i) o_okey2[i] = sp.take(r->out_cap * vh_elem_size(P.g[i].type));
+    for (int j = 0; j < P.nmetric; ++j) o_ostate2[j] = sp.take(r->out_cap * vh_elem_size(r->metric_elem[j]));
+  }
   // outputs
   size_t o_tuples = 0, o_pcount = 0, o_pext = 0, o_emiss = 0;
   if (mode == VH_MODE_DENSE_PART) {
@@ -1155,6 +1193,12 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   }
   for (int i = 0; i < P.ngroup; ++i) r->d_out_key[i] = S + o_okey[i];
   for (int j = 0; j < P.nmetric; ++j) r->d_out_state[j] = S + o_ostate[j];
+  if (r->topk_active) {
+    r->d_topk_keys = reinterpret_cast<uint64_t*>(S + o_tkkeys);
+    r->d_topk_state = reinterpret_cast<VhTopkState*>(S + o_tkstate);
+    for (int i = 0; i < P.ngroup; ++i) r->d_out_key2[i] = S + o_okey2[i];
+    for (int j = 0; j < P.nmetric; ++j) r->d_out_state2[j] = S + o_ostate2[j];
+  }
 
   P.debug = getenv("VH_DEBUG") ? (uint32_t)atoi(getenv("VH_DEBUG")) : 0u;
   // ---------------- init + launch
@@ -1254,6 +1298,7 @@ extern "C" int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part
   if (nparts == 0 || nparts > 64) return vh_fail(VH_E_INVALID, "nparts must be 1..64");
   if (r->plan.nbitset) return vh_fail(VH_E_UNSUPPORTED, "count-distinct partials are cardinalities: they cannot be merged across GPUs");
   if (r->nhaving) return vh_fail(VH_E_UNSUPPORTED, "HAVING applies to merged groups: run the partial query without it");
+  if (r->topk) return vh_fail(VH_E_UNSUPPORTED, "top-N applies to merged groups: run the partial query without it");
   std::lock_guard<std::mutex> lk(r->table->mu);
   const VhPlanDev& P = r->plan;
   hipStream_t st = g_ctx.stream;
@@ -1343,6 +1388,34 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   for (int i = 0; i < VH_MAX_HAVING_LITS; ++i) A.hlits[i] = r->hlits[i];
   hipLaunchKernelGGL(emit_groups_kernel, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A);
   HIP_TRY(hipGetLastError());
+  if (r->topk_active) {
+    // radix select of the top_k-th best sort key among the emitted rows (8 x 8 bits, no host round trip), then keep
+    // every row that ties with or beats it. Row count is only known on the device: grids are sized by out_cap.
+    VhTopkState init{};
+    init.k_remaining = r->topk;
+    HIP_TRY(hipMemcpyAsync(r->d_topk_state, &init, sizeof(init), hipMemcpyHostToDevice, st));
+    const unsigned g1 = (unsigned)std::min<uint64_t>((r->out_cap + 255) / 256, (uint64_t)g_ctx.num_cu * 8);
+    const void* src = r->topk_src_is_key ? r->d_out_key[r->topk_src] : r->d_out_state[r->topk_src];
+    hipLaunchKernelGGL(topk_keys_kernel, dim3(g1), dim3(256), 0, st, src, r->topk_elem, (uint32_t)vh_elem_size(r->topk_elem),
+                       r->topk_cls, r->topk_desc, (const unsigned long long*)r->d_out_count, r->d_topk_keys);
+    for (int shift = 56; shift >= 0; shift -= 8) {
+      hipLaunchKernelGGL(topk_hist_kernel, dim3(g1), dim3(256), 0, st, (const uint64_t*)r->d_topk_keys,
+                         (const unsigned long long*)r->d_out_count, shift, r->d_topk_state);
+      hipLaunchKernelGGL(topk_pick_kernel, dim3(1), dim3(64), 0, st, shift, r->d_topk_state);
+    }
+    VhTopkCompact C{};
+    C.ncols = P.ngroup + P.nmetric;
+    // formatter rounding ("%.15g" / "%g") can make nearby values compare equal in the reference: keep a margin
+    C.slack = r->topk_cls == VH_TOPK_FLOAT ? (r->topk_elem == VH_F32 ? (256ull << 32) : 64ull) : 0ull;
+    for (int i = 0; i < P.ngroup; ++i) { C.src[i] = r->d_out_key[i]; C.dst[i] = r->d_out_key2[i]; C.esize[i] = (uint32_t)vh_elem_size(P.g[i].type); }
+    for (int j = 0; j < P.nmetric; ++j) {
+      C.src[P.ngroup + j] = r->d_out_state[j]; C.dst[P.ngroup + j] = r->d_out_state2[j];
+      C.esize[P.ngroup + j] = (uint32_t)vh_elem_size(r->metric_elem[j]);
+    }
+    hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((r->out_cap + 255) / 256)), dim3(256), 0, st, C,
+                       (const uint64_t*)r->d_topk_keys, (const unsigned long long*)r->d_out_count, (unsigned long long)r->topk, r->d_topk_state);
+    HIP_TRY(hipGetLastError());
+  }
   // pinned staging buffer (two alternate, so a result stays readable while the next query runs)
   const int slot = t->h_out_next; t->h_out_next ^= 1;
   if (t->h_out_bytes[slot] < r->out_region_bytes) {
@@ -1354,7 +1427,9 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   }
   char* H = t->h_out[slot];
   const char* D = t->scratch + r->out_region_off;
-  const bool one_shot = r->out_region_bytes <= (8u << 20);
+  const bool one_shot = r->out_region_bytes <= (8u << 20) && !r->topk_active;
+  VhTopkState tk{};
+  if (r->topk_active) HIP_TRY(hipMemcpyAsync(&tk, r->d_topk_state, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   // small results: counters, group count and every output array come back in ONE copy + ONE sync
   HIP_TRY(hipMemcpyAsync(H, D, one_shot ? r->out_region_bytes : 512, hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -1363,17 +1438,20 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   if (err & VH_ERR_HASH_FULL) { *retry = 1; return VH_OK; }
   if (err & VH_ERR_PART_FULL) { *retry = 3; return VH_OK; }
   if (err & VH_ERR_RANGE) { *retry = 2; return VH_OK; }
-  const uint64_t ng = *reinterpret_cast<const unsigned long long*>(H + 256);   // rows emitted (after HAVING)
+  uint64_t ng = *reinterpret_cast<const unsigned long long*>(H + 256);          // rows emitted (after HAVING)
   r->info.ngroups = r->nhaving ? hc[6] : ng;                                     // agg_map.size()
+  if (r->topk_active) ng = tk.out_count;                                          // rows kept by the top-N superset
   r->info.returned_groups = ng;
   r->ngroups_host = ng;
   r->info.passed_recs = hc[0];
   r->h_base = H;
   if (!one_shot && ng) {
     for (int i = 0; i < P.ngroup; ++i)
-      HIP_TRY(hipMemcpyAsync(H + r->off_key[i], D + r->off_key[i], ng * vh_elem_size(P.g[i].type), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(H + r->off_key[i], r->topk_active ? (const char*)r->d_out_key2[i] : D + r->off_key[i],
+                             ng * vh_elem_size(P.g[i].type), hipMemcpyDeviceToHost, st));
     for (int j = 0; j < P.nmetric; ++j)
-      HIP_TRY(hipMemcpyAsync(H + r->off_state[j], D + r->off_state[j], ng * vh_elem_size(r->metric_elem[j]), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipMemcpyAsync(H + r->off_state[j], r->topk_active ? (const char*)r->d_out_state2[j] : D + r->off_state[j],
+                             ng * vh_elem_size(r->metric_elem[j]), hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipEventRecord(t->ev[3], st));
   HIP_TRY(hipStreamSynchronize(st));

@@ -58,6 +58,7 @@ class AggPlan:
     flags: int = 0
     groups_hint: int = 0
     having: Sequence = ()          # same node tuples; `col` = result column (group i, or len(groups) + metric j)
+    top: Optional[tuple] = None    # (result column, descending, k): device top-N superset (see include/viya_hip.h)
 
 
 @dataclass
@@ -233,6 +234,8 @@ class DeviceTable:
             keep.append(ha)
             p.having = ha
         p.nhaving = len(hnodes)
+        if plan.top:
+            p.top_col, p.top_desc, p.top_k = int(plan.top[0]), 1 if plan.top[1] else 0, int(plan.top[2])
         return p, keep
 
     def _collect(self, res, plan: AggPlan, copy: bool = True) -> AggResult:

@@ -340,6 +340,23 @@ void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, s
     plan.seg_rows = seg_rows.data(); plan.nseg = (uint32_t)seg_rows.size();
     const char* force = getenv("VIYA_HIP_PLAN_FLAGS");
     plan.flags = force ? (uint32_t)atoi(force) : 0;
+    // sort + limit on a numeric first sort column: let the device keep only the groups that can make the window
+    // (a superset, ties included); the string sort below then runs on those few rows. Columns the reference orders
+    // as formatted strings (string / time / boolean dims, AVG = "%.15g" text compared by length) stay on the host.
+    if (!query.sort_cols().empty() && limit > 0 && (query.having() == nullptr || having_on_device) && !getenv("VIYA_HOST_TOPN")) {
+      const SortColumn& sc = query.sort_cols()[0];
+      const db::Column* c = sc.col();
+      int rc = -1;
+      if (c->type() == db::Column::DIMENSION) {
+        if (c->dim_type() == db::Column::DIM_NUMERIC)
+          for (size_t k = 0; k < query.dimension_cols().size(); ++k)
+            if (query.dimension_cols()[k].dim() == c) { rc = (int)k; break; }
+      } else if (c->agg_type() != db::Column::AVG) {
+        for (size_t k = 0; k < query.metric_cols().size(); ++k)
+          if (query.metric_cols()[k].metric() == c) { rc = (int)(query.dimension_cols().size() + k); break; }
+      }
+      if (rc >= 0) { plan.top_col = rc; plan.top_desc = sc.ascending() ? 0 : 1; plan.top_k = (uint64_t)skip + limit; }
+    }
 
     vh_result* res = nullptr;
     vh_check(vh_query_agg(mir->handle, &plan, &res));
