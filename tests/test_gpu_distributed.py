@@ -87,3 +87,25 @@ def _run(tmp_path, wl, flags, backend, nproc, having=False):
     pg, po = sort_rows(keys, states), sort_rows(st.keys, st.states)
     for a, b in zip(keys + states, st.keys + st.states):
         assert np.array_equal(a[pg], b[po])
+
+
+def test_dense_partials_are_one_collective_for_c3():
+    """C3/C4: SUM(int64) + COUNT carried as SOP_ADD32P, both 64-bit integer sums laid out back to back -> the
+    library hands the caller ONE reduce buffer (no presence bytes, no second call): the collective is latency-bound."""
+    from viyadb_amd import capi, executor, synth
+    executor.init(0)
+    w = synth.WORKLOADS["C3"](segment_rows=50000)
+    t = synth.create_device_table(w, 4, 50000)
+    try:
+        plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics)
+        res = t.query_launch(plan)
+        bufs = t.device_buffers(res)
+        assert len(bufs) == 1 and bufs[0][2] == capi.U64 and bufs[0][3] == 0 and bufs[0][1] >= 2 * 100_000
+        out = t.finalize(res, plan)
+        assert out.ngroups > 0
+        # without the presence carrier the layout is [presence | states...]: still correct, more buffers
+        res = t.query_launch(executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=capi.PLAN_NO_CARRIER))
+        assert len(t.device_buffers(res)) >= 2
+        t.discard(res)
+    finally:
+        t.close()

@@ -487,6 +487,7 @@ struct vh_result {
   VhTopkState* d_topk_state = nullptr;
   void* d_out_key2[VH_MAX_GROUP] = {};
   void* d_out_state2[VH_MAX_METRIC] = {};
+  const char* zero_begin = nullptr; const char* zero_end = nullptr;   // scratch range cleared by the one state memset
   char* d_xchg = nullptr;              // vh_result_partition: rows regrouped by owner (own allocation)
   ~vh_result() { if (d_xchg) (void)hipFree(d_xchg); }
 };
@@ -1211,6 +1212,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     else HIP_TRY(hipMemsetAsync(P.htags, 0, table_n * sizeof(uint32_t), st));
   }
   if (zero_end > zero_begin) HIP_TRY(hipMemsetAsync(S + zero_begin, 0, zero_end - zero_begin, st));
+  r->zero_begin = S + zero_begin; r->zero_end = S + zero_end;
   for (int b = 0; b < P.nbitset; ++b) {
     if (P.bs_wide[b]) HIP_TRY(hipMemsetAsync(P.dset_tags[b], 0, (P.dset_mask[b] + 1) * 4, st));
     else HIP_TRY(hipMemsetAsync(P.dset_keys[b], 0xFF, (P.dset_mask[b] + 1) * 8, st));
@@ -1261,7 +1263,8 @@ extern "C" int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs, in
   const VhPlanDev& P = r->plan;
   int n = 0;
   if (max_bufs < P.nmetric + 1) return vh_fail(VH_E_INVALID, "need %d buffers", P.nmetric + 1);
-  bufs[n++] = vh_device_buffer{P.present, P.G, VH_U8, VH_RED_MAX};
+  // presence bytes are only written when no SUM state carries the flag (SOP_ADD32P): one collective less
+  if (!(r->mode == VH_MODE_DENSE_GLOBAL && P.present_carrier >= 0)) bufs[n++] = vh_device_buffer{P.present, P.G, VH_U8, VH_RED_MAX};
   for (int j = 0; j < P.nmetric; ++j) {
     vh_device_buffer b{P.m[j].state, P.G, 0, VH_RED_SUM};
     switch (P.m[j].sop) {
@@ -1281,6 +1284,20 @@ extern "C" int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs, in
       case SOP_MAX_F32: b.elem = VH_F32; b.reduce = VH_RED_MAX; break;
       case SOP_MIN_F64: b.elem = VH_F64; b.reduce = VH_RED_MIN; break;
       default: b.elem = VH_F64; b.reduce = VH_RED_MAX; break;
+    }
+    // Integer SUM states of the same width that sit back to back in scratch (they do: all zero-identity states are
+    // laid out contiguously and cleared by one memset, alignment gaps included) merge into ONE buffer — the
+    // collective is latency-bound at this size (C4: 2 x 800 KB), so fewer, larger calls is the whole game.
+    if (n > 0 && b.reduce == VH_RED_SUM && bufs[n - 1].reduce == VH_RED_SUM && (b.elem == VH_U64 || b.elem == VH_U32) &&
+        bufs[n - 1].elem == b.elem && P.m[j].ident == 0 && r->nxcd == 1) {
+      const size_t es = vh_elem_size(b.elem);
+      char* prev_end = static_cast<char*>(bufs[n - 1].ptr) + bufs[n - 1].count * es;
+      char* cur = static_cast<char*>(b.ptr);
+      if (cur >= prev_end && (size_t)(cur - prev_end) < 4096 && (size_t)(cur - prev_end) % es == 0 && r->zero_begin <= bufs[n - 1].ptr &&
+          cur + b.count * es <= r->zero_end) {
+        bufs[n - 1].count = (uint64_t)((cur + b.count * es) - static_cast<char*>(bufs[n - 1].ptr)) / es;
+        continue;
+      }
     }
     bufs[n++] = b;
   }
