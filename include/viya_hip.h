@@ -138,8 +138,12 @@ enum vh_plan_flags {
                                      radix-partitioned LDS aggregation        */
   VH_PLAN_NO_CARRIER = 1u << 5,   /* testing: separate presence bytes even when a
                                      32-bit SUM state could carry the flag    */
-  VH_PLAN_FORCE_PART = 1u << 6    /* testing: radix-partitioned aggregation
+  VH_PLAN_FORCE_PART = 1u << 6,   /* testing: radix-partitioned aggregation
                                      regardless of the estimated selectivity  */
+  VH_PLAN_NO_LANES = 1u << 7,     /* ablation: always compact survivors, even
+                                     when most rows pass                      */
+  VH_PLAN_FORCE_LANES = 1u << 8   /* testing: the no-compaction "lanes" kernel
+                                     whenever the plan is eligible            */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */
@@ -187,7 +191,7 @@ typedef struct vh_result_info {
   float total_ms;            /* HIP-event time launch .. results in host mem */
   uint64_t algorithmic_bytes;/* B_ref of SURVEY §8(d) for this query         */
   uint32_t retries;          /* hash-table regrows                           */
-  uint32_t reserved;         /* bit 0: the register-resident fast scan kernel ran */
+  uint32_t reserved;         /* bit 0: the register-resident fast scan kernel ran; bit 1: its no-compaction "lanes" variant */
   uint64_t returned_groups;  /* rows vh_result_copy delivers (= ngroups without HAVING) */
 } vh_result_info;
 

@@ -38,7 +38,7 @@ def test_workload_small(name):
     check_workload(w, nseg=5)
 
 
-@pytest.mark.parametrize("flags", [0, 8])
+@pytest.mark.parametrize("flags", [0, 8, 128, 256])
 @pytest.mark.parametrize("name", ["C1", "C2", "C3"])
 def test_workload_ragged(name, flags):
     """Segment size not a multiple of anything; last rows of every segment are beyond size()."""
@@ -59,7 +59,7 @@ def test_c3_table_organisations(flags, path):
 
 
 @pytest.mark.parametrize("flags,path", [(0, "dense_lds"), (2, "dense_global"), (1, "hash"), (8, "dense_lds"), (10, "dense_global"),
-                                        (9, "hash")])
+                                        (9, "hash"), (128, "dense_lds"), (256, "dense_lds")])
 def test_c2_table_organisations(flags, path):
     from viyadb_amd import synth
     w = synth.c2(segment_rows=250_000)

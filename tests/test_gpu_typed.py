@@ -356,3 +356,25 @@ def test_device_top_n_keeps_a_superset(typed, metric, desc):
         pos = {int(x): i for i, x in enumerate(st.keys[0])}
         idx = np.array([pos[int(x)] for x in res.keys[0]])
         assert np.array_equal(res.states[0], vals[idx]) and np.array_equal(res.states[1], st.states[1][idx])
+
+
+@pytest.mark.parametrize("dims,metrics,eligible", [
+    (["d_int"], ["long_sum", "int_min"], True), (["d_long"], ["float_sum", "double_max"], True),
+    (["d_uint"], ["uint_max", "ulong_min"], True), (["d_ulong"], ["count", "int_avg"], True),
+    (["d_int"], ["double_sum"], True), (["d_uint"], ["long_max", "float_min"], True),
+    (["d_int"], ["short_sum", "long_sum"], False),       # 2-byte payload column
+    (["d_int", "flag"], ["long_sum"], False),            # 1-byte group column
+    (["d_int"], ["long_sum", "int_min", "count"], False)])  # 3 metrics
+def test_lanes_kernel_matches_oracle(typed, dims, metrics, eligible):
+    """The no-compaction kernel (high selectivity, LDS table): every 4/8-byte element type as group / metric column,
+    segment tails, the fall-back to the compacting kernel when the plan is not eligible, and the probe-driven choice."""
+    tab, dt = typed
+    many, few = F("ge", "d_int", "-30"), F("lt", "d_uint", "3")      # ~75 % / ~5 % of the rows pass
+    for flt in (many, few):
+        q = {"dimensions": dims, "metrics": metrics, "filter": flt}
+        res, _ = run(tab, dt, q, flags=256)       # forced whenever eligible
+        assert res.path == "dense_lds" and res.lanes == eligible, (dims, metrics)
+        res, _ = run(tab, dt, q, flags=128)       # never
+        assert not res.lanes
+        res, _ = run(tab, dt, q)                  # by the selectivity probe
+        assert res.lanes == (eligible and flt is many)

@@ -1087,6 +1087,142 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
   }
 }
 
+// ------------------------------------------------- "lanes" variant: no compaction (high selectivity, LDS table)
+// When a large fraction of the rows pass (C2: 50 %), compacting survivors into a queue and gathering their payload
+// one scalar load per survivor and column costs more than it saves: every payload line is touched anyway. This
+// variant keeps a lane on its own 4 consecutive rows of each sub-step, loads the group / metric columns for them
+// with the same coalesced 16 B/lane vector loads as the predicate columns, and lets the lanes whose mask bit is set
+// update the LDS table directly. Restricted (host side) to DENSE_LDS plans with <= VH_LANES_COLS group and metric
+// columns of 4 or 8 bytes and no time truncation, chosen when the selectivity probe says >= 25 % of the rows pass.
+#define VH_LANES_COLS 2
+
+__device__ __forceinline__ void vh_load_rows4(const char* base, int type, uint32_t r0, bool sext, uint64_t (&out)[4]) {
+  if (type == VH_U64 || type == VH_I64 || type == VH_F64) {
+    vh_load4<uint64_t>(reinterpret_cast<const uint64_t*>(base) + r0, out);
+  } else {
+    uint32_t t[4];
+    vh_load4<uint32_t>(reinterpret_cast<const uint32_t*>(base) + r0, t);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = (type == VH_I32 && sext) ? (uint64_t)(int64_t)(int32_t)t[j] : (uint64_t)t[j];
+  }
+}
+
+template <int SCOPE, int NP>
+__global__ __launch_bounds__(1024) void scan_agg_lanes_kernel(const VhPlanDev P) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int BLOCK = 1024;
+  typedef VhScanCfg<BLOCK> C;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int j = 0; j < P.nmetric; ++j) {
+    const VhMetricDev& m = P.m[j];
+    const uint64_t ident = m.ident;
+    if (vh_sop_bytes(m.sop) == 4) {
+      for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)ident;
+    } else {
+      for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = ident;
+    }
+  }
+  for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
+  __syncthreads();
+
+  unsigned long long npassed = 0;
+  const uint32_t spu = P.unit_rows / C::kStepRows;
+  uint32_t t = 0, seg = 0, unit_base = 0, wave_base = 0, seg_rows = 0;
+  bool have;
+  {
+    const uint32_t unit = blockIdx.x;
+    have = unit < P.total_units;
+    if (have) {
+      seg = unit / P.units_per_seg;
+      unit_base = (unit - seg * P.units_per_seg) * P.unit_rows;
+      seg_rows = P.seg_rows[seg];
+      wave_base = unit_base + wave * VH_WAVE_STEP_ROWS;
+    }
+  }
+  uint32_t v[NP][16];
+  if (have) vh_preload<NP>(P, seg, wave_base + lane * 4, seg_rows, v);
+  bool range_err = false;
+  while (have) {
+    const uint32_t row_l = wave_base + lane * 4;
+    const uint32_t mask = vh_eval_filter_fast<NP>(P, v, row_l, seg_rows);
+    npassed += __popc(mask);
+    ++t;
+    uint32_t nseg = seg, nunit_base = unit_base, nwave_base = 0, nseg_rows = seg_rows;
+    bool nhave;
+    {
+      const uint32_t unit = blockIdx.x + (t / spu) * gridDim.x;
+      nhave = unit < P.total_units;
+      if (nhave) {
+        nseg = unit / P.units_per_seg;
+        nunit_base = (unit - nseg * P.units_per_seg) * P.unit_rows;
+        nseg_rows = P.seg_rows[nseg];
+        nwave_base = nunit_base + (t % spu) * C::kStepRows + wave * VH_WAVE_STEP_ROWS;
+      }
+    }
+    if (nhave) vh_preload<NP>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
+#pragma unroll
+    for (int k = 0; k < VH_SUBSTEPS; ++k) {
+      const uint32_t mk = (mask >> (4 * k)) & 0xFu;
+      if (__ballot(mk != 0) == 0) continue;
+      const uint32_t r0 = row_l + k * 256u;
+      uint64_t gv[VH_LANES_COLS][4], mv[VH_LANES_COLS][4];
+#pragma unroll
+      for (int i = 0; i < VH_LANES_COLS; ++i) {
+        gv[i][0] = gv[i][1] = gv[i][2] = gv[i][3] = 0;
+        if (i < P.ngroup && mk) {     // mk == 0 also covers rows at or beyond size(): nothing is loaded out of bounds
+          const VhGroupDev& g = P.g[i];
+          vh_load_rows4(P.colbase[g.slot] + (uint64_t)seg * P.colstride[g.slot], g.type, r0, true, gv[i]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < VH_LANES_COLS; ++j) {
+        mv[j][0] = mv[j][1] = mv[j][2] = mv[j][3] = 0;
+        if (j < P.nmetric && mk) {
+          const VhMetricDev& m = P.m[j];
+          vh_load_rows4(P.colbase[m.slot] + (uint64_t)seg * P.colstride[m.slot], m.type, r0, vh_sop_sext(m.sop), mv[j]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (!((mk >> r) & 1u)) continue;
+        uint64_t gid = 0;
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < VH_LANES_COLS; ++i) {
+          if (i < P.ngroup) {
+            const VhGroupDev& g = P.g[i];
+            const uint64_t d = gv[i][r] - g.lo;
+            bad |= d >= g.extent;
+            gid += d * g.stride;
+          }
+        }
+        if (bad) { range_err = true; continue; }
+        reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[gid] = 1;
+#pragma unroll
+        for (int j = 0; j < VH_LANES_COLS; ++j)
+          if (j < P.nmetric) vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + P.m[j].lds_off, gid, P.m[j].sop, mv[j][r]);
+      }
+    }
+    have = nhave; seg = nseg; unit_base = nunit_base; wave_base = nwave_base; seg_rows = nseg_rows;
+  }
+  if (__ballot(range_err)) { if (range_err) atomicOr(P.counters + 2, VH_ERR_RANGE); }
+  for (int off = 32; off > 0; off >>= 1) npassed += __shfl_down(npassed, off);
+  if (lane == 0 && npassed) atomicAdd(P.counters + 0, npassed);
+  __syncthreads();
+  const uint64_t xo = P.nxcd > 1 ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;
+  for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) {
+    if (!reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g]) continue;
+    P.present[xo + g] = 1;
+    for (int j = 0; j < P.nmetric; ++j) {
+      const VhMetricDev& m = P.m[j];
+      const uint64_t bits = vh_sop_bytes(m.sop) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
+                                                     : reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
+      vh_state_update<SCOPE>(m.state, xo + g, m.sop, bits);
+    }
+  }
+}
+
 // ------------------------------------------------- partitioned aggregation, phase 2
 // grid = npart x blocks_per_part. A block owns an LDS table for its partition's 2^part_shift groups,
 // its waves walk the partition's extents (64 tuples each, one coalesced 16 B/lane load for 2-word

@@ -1,0 +1,18 @@
+// "Lanes" scan kernel instantiations (no compaction; dense table in LDS, 1024-thread blocks).
+#include "vh_kernels.h"
+#include "vh_launch.h"
+
+template <int SCOPE>
+static void launch_np(const VhPlanDev& P, int grid, size_t lds, hipStream_t s) {
+  switch (P.npred) {
+    case 1: hipLaunchKernelGGL((scan_agg_lanes_kernel<SCOPE, 1>), dim3(grid), dim3(1024), lds, s, P); break;
+    case 2: hipLaunchKernelGGL((scan_agg_lanes_kernel<SCOPE, 2>), dim3(grid), dim3(1024), lds, s, P); break;
+    case 3: hipLaunchKernelGGL((scan_agg_lanes_kernel<SCOPE, 3>), dim3(grid), dim3(1024), lds, s, P); break;
+    default: hipLaunchKernelGGL((scan_agg_lanes_kernel<SCOPE, 4>), dim3(grid), dim3(1024), lds, s, P); break;
+  }
+}
+
+void vh_launch_scan_lanes_lds(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s) {
+  if (xcd_private) launch_np<__HIP_MEMORY_SCOPE_WORKGROUP>(P, grid, lds, s);
+  else launch_np<__HIP_MEMORY_SCOPE_AGENT>(P, grid, lds, s);
+}

@@ -971,6 +971,37 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     mode = VH_MODE_HASH;
   }
   const bool fast = fast_ok && P.npred >= 1 && P.ngroup <= VH_FAST_COLS && P.nmetric <= VH_FAST_COLS && P.nbitset == 0;
+  // selectivity of the filter, from a one-launch probe; it only depends on the filter and the rows, so it is cached
+  // until the table changes
+  auto probed_selectivity = [&](double* sel) -> int {
+    std::string key((const char*)P.prog, sizeof(VhProgOp) * P.nprog);
+    key.append((const char*)P.lits, sizeof(uint64_t) * std::max(p->nlits, 0));
+    key += "|" + std::to_string(nseg) + "|" + std::to_string(rows_to_scan) + "|" + std::to_string(t->sync_epoch);
+    auto hit = t->sel_cache.find(key);
+    if (hit != t->sel_cache.end()) { *sel = hit->second; return VH_OK; }
+    const int prc = estimate_selectivity(t, P, nseg, sel);
+    if (prc) return prc;
+    if (t->sel_cache.size() > 256) t->sel_cache.clear();
+    t->sel_cache[key] = *sel;
+    return VH_OK;
+  };
+  // "Lanes" kernel (no compaction) for small LDS tables when most rows pass: see scan_agg_lanes_kernel
+  bool lanes = false;
+  if (mode == VH_MODE_DENSE_LDS && fast && !(p->flags & VH_PLAN_NO_LANES) && P.ngroup <= VH_LANES_COLS && P.nmetric <= VH_LANES_COLS &&
+      P.nmetric >= 1 && rows_to_scan) {
+    bool ok = true;
+    for (int i = 0; i < P.ngroup; ++i) ok &= vh_elem_size(P.g[i].type) >= 4 && P.g[i].gran == VH_T_NONE && P.g[i].nroll == 0;
+    for (int j = 0; j < P.nmetric; ++j) ok &= P.m[j].slot != VH_SLOT_ROWID && P.m[j].sop != SOP_BITSET && vh_elem_size(P.m[j].type) >= 4;
+    if (ok) {
+      if (p->flags & VH_PLAN_FORCE_LANES) lanes = true;
+      else {
+        double sel = 0;
+        rc = probed_selectivity(&sel);
+        if (rc) { delete r; return rc; }
+        lanes = sel >= 0.25;
+      }
+    }
+  }
   // Global atomics are written through to the fabric one by one; when the group-id space is too big
   // for one LDS table but splits into <= VH_MAX_PART LDS-sized ranges, radix-partition the survivors
   // and aggregate each range in LDS instead (DENSE_PART).
@@ -982,18 +1013,8 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     bool want_part = np <= VH_MAX_PART && G <= 0xFFFFFFFFull;
     double sel = 0;
     if (want_part && !(p->flags & VH_PLAN_FORCE_PART) && !part_tuples_override) {
-      // the estimate only depends on the filter and the rows: cache it until the table changes
-      std::string key((const char*)P.prog, sizeof(VhProgOp) * P.nprog);
-      key.append((const char*)P.lits, sizeof(uint64_t) * std::max(p->nlits, 0));
-      key += "|" + std::to_string(nseg) + "|" + std::to_string(rows_to_scan) + "|" + std::to_string(t->sync_epoch);
-      auto hit = t->sel_cache.find(key);
-      if (hit != t->sel_cache.end()) sel = hit->second;
-      else {
-        rc = estimate_selectivity(t, P, nseg, &sel);
-        if (rc) { delete r; return rc; }
-        if (t->sel_cache.size() > 256) t->sel_cache.clear();
-        t->sel_cache[key] = sel;
-      }
+      rc = probed_selectivity(&sel);
+      if (rc) { delete r; return rc; }
       want_part = sel >= 0.08;   // crossover measured on C3 (profiles/r01): 5 % direct wins, 11 % partitioned wins
     }
     if (want_part) {
@@ -1228,7 +1249,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   }
   const size_t qbytes = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint32_t);
   HIP_TRY(hipEventRecord(t->ev[1], st));
-  r->info.reserved = fast ? 1 : 0;
+  r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0);
   if (P.total_units) {
     const size_t lds = (mode == VH_MODE_DENSE_LDS ? lds_table : 0) + qbytes;
     if (mode == VH_MODE_DENSE_PART) {
@@ -1238,6 +1259,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       vh_launch_part_agg(P, bpp, lds_table, st);
     }
     else if (!fast) vh_launch_scan_generic(mode, P, grid, lds, nxcd > 1, st);
+    else if (lanes) vh_launch_scan_lanes_lds(P, grid, lds, nxcd > 1, st);
     else if (mode == VH_MODE_DENSE_LDS) vh_launch_scan_fast_lds(P, grid, lds, nxcd > 1, st);
     else if (mode == VH_MODE_DENSE_GLOBAL) vh_launch_scan_fast_global(P, grid, lds, nxcd > 1, st);
     else vh_launch_scan_fast_hash(P, grid, lds, st);

@@ -76,6 +76,7 @@ class AggResult:
     algorithmic_bytes: int
     retries: int
     fast: bool = False
+    lanes: bool = False            # the no-compaction variant of the fast kernel ran
     returned: int = 0              # rows delivered (= ngroups unless a HAVING was pushed down)
 
 
@@ -265,7 +266,7 @@ class DeviceTable:
         return AggResult(keys, states, hidden, int(info.ngroups), int(info.scanned_recs), int(info.scanned_segments),
                          int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
                          float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1),
-                         int(ng))
+                         bool(info.reserved & 2), int(ng))
 
     def query_agg(self, plan: AggPlan, copy: bool = True) -> AggResult:
         p, keep = self._build_plan(plan)
