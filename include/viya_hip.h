@@ -142,8 +142,10 @@ enum vh_plan_flags {
                                      regardless of the estimated selectivity  */
   VH_PLAN_NO_LANES = 1u << 7,     /* ablation: always compact survivors, even
                                      when most rows pass                      */
-  VH_PLAN_FORCE_LANES = 1u << 8   /* testing: the no-compaction "lanes" kernel
+  VH_PLAN_FORCE_LANES = 1u << 8,  /* testing: the no-compaction "lanes" kernel
                                      whenever the plan is eligible            */
+  VH_PLAN_NO_LDS_HASH = 1u << 9   /* ablation: hash path without the per-block
+                                     LDS front table                          */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */

@@ -43,25 +43,42 @@ enum vh_state_op : uint8_t {
                   // so the dense HBM table needs no separate presence store (one write transaction less per row)
 };
 
+// Every member of the structs below is a 32- or 64-bit word; the byte-sized attributes are packed into words
+// and read through accessors. Reason (profiles/r01/NOTES.md, tests/test_isa_hazards.py): with byte-sized MEMBERS in a
+// kernel-argument struct that is indexed dynamically, hipcc (ROCm 7.2) forms scalar loads off the address of a
+// byte member (`s_load_dwordx2 sN, s[&m.sop], 0x15`); SMEM drops the low two bits of the base and the load returns
+// the wrong bytes. Without sub-dword members no such base exists.
+#define VH_PACKED_FIELD(name, word, shift, bits)                                                           \
+  __host__ __device__ __forceinline__ uint32_t name() const { return (word >> shift) & ((1u << bits) - 1u); } \
+  __host__ __device__ __forceinline__ void set_##name(uint32_t v) {                                          \
+    word = (word & ~(((1u << bits) - 1u) << shift)) | ((v & ((1u << bits) - 1u)) << shift);                  \
+  }
+
 struct VhProgOp {      // 8 bytes
-  uint8_t kind;        // vh_fkind
-  uint8_t type;        // vh_elem of the column
-  uint8_t op;          // vh_relop / IN polarity
-  uint8_t count;       // IN: literals; AND/OR: operands
-  uint8_t slot;        // referenced-column slot
-  uint8_t pslot;       // fast path: index among the distinct predicate columns
-  uint16_t lit;        // first literal
+  uint32_t w0, w1;
+  VH_PACKED_FIELD(kind, w0, 0, 8)     // vh_fkind
+  VH_PACKED_FIELD(type, w0, 8, 8)     // vh_elem of the column
+  VH_PACKED_FIELD(op, w0, 16, 8)      // vh_relop / IN polarity
+  VH_PACKED_FIELD(count, w0, 24, 8)   // IN: literals; AND/OR: operands
+  VH_PACKED_FIELD(slot, w1, 0, 8)     // referenced-column slot
+  VH_PACKED_FIELD(pslot, w1, 8, 8)    // fast path: index among the distinct predicate columns
+  VH_PACKED_FIELD(lit, w1, 16, 16)    // first literal
 };
 
 struct VhGroupDev {
-  uint16_t slot;
-  uint8_t type;        // vh_elem
-  uint8_t gran;        // vh_time_unit or VH_T_NONE
-  uint8_t nroll;
-  uint8_t micro;
-  uint8_t key_word;    // hash path: which u64 word of the key holds this column
-  uint8_t key_shift;   // hash path: bit offset inside that word
-  uint8_t roll_unit[VH_MAX_ROLLUP];
+  uint32_t w0, w1;
+  uint64_t roll_units;                 // 8 x 8 bits: vh_time_unit of rollup rule k
+  VH_PACKED_FIELD(slot, w0, 0, 16)
+  VH_PACKED_FIELD(type, w0, 16, 8)     // vh_elem
+  VH_PACKED_FIELD(gran, w0, 24, 8)     // vh_time_unit or VH_T_NONE
+  VH_PACKED_FIELD(nroll, w1, 0, 8)
+  VH_PACKED_FIELD(micro, w1, 8, 8)
+  VH_PACKED_FIELD(key_word, w1, 16, 8)   // hash path: which u64 word of the key holds this column
+  VH_PACKED_FIELD(key_shift, w1, 24, 8)  // hash path: bit offset inside that word
+  __host__ __device__ __forceinline__ uint32_t roll_unit(int k) const { return (uint32_t)(roll_units >> (8 * k)) & 0xFFu; }
+  __host__ __device__ __forceinline__ void set_roll_unit(int k, uint32_t v) {
+    roll_units = (roll_units & ~(0xFFull << (8 * k))) | ((uint64_t)(v & 0xFFu) << (8 * k));
+  }
   uint64_t roll_before[VH_MAX_ROLLUP];
   uint64_t lo;         // dense path: value - lo is the digit
   uint64_t extent;     // dense path: digit < extent
@@ -69,13 +86,13 @@ struct VhGroupDev {
 };
 
 struct VhMetricDev {
-  uint16_t slot;
-  uint8_t type;        // vh_elem of the source column
-  uint8_t sop;         // vh_state_op
-  uint8_t tword;       // DENSE_PART: tuple word that carries this metric's value
-  uint8_t tshift;      // DENSE_PART: bit offset inside that word (0 or 32)
-  uint16_t pad0;
-  uint32_t lds_off;    // DENSE_LDS / DENSE_PART phase 2: byte offset of this metric's state array in LDS
+  uint32_t w0, w1;
+  VH_PACKED_FIELD(slot, w0, 0, 16)
+  VH_PACKED_FIELD(type, w0, 16, 8)     // vh_elem of the source column
+  VH_PACKED_FIELD(sop, w0, 24, 8)      // vh_state_op
+  VH_PACKED_FIELD(tword, w1, 0, 8)     // DENSE_PART: tuple word that carries this metric's value
+  VH_PACKED_FIELD(tshift, w1, 8, 8)    // DENSE_PART: bit offset inside that word (0 or 32)
+  uint32_t lds_off;    // DENSE_LDS / DENSE_PART phase 2 / hash front table: byte offset of this metric's state array in LDS
   uint32_t pad1;
   void* state;         // global state array (G or capacity elements, 4 or 8 B each)
   uint64_t ident;      // identity bits: 0 (SUM/AVG/COUNT), type max (MIN), cpp_min_value (MAX)
@@ -113,7 +130,11 @@ struct VhPlanDev {
   int32_t present_carrier;   // >= 0: metric whose SOP_ADD32P state doubles as the presence flag
   int32_t pad3;
   uint32_t lds_present_off;  // DENSE_LDS: byte offset of presence words
-  uint32_t lds_bytes;        // DENSE_LDS: total dynamic LDS
+  uint32_t lds_bytes;        // DENSE_LDS / HASH with an LDS front table: bytes of the table (queues sit behind it)
+  // HASH: per-block open-addressing front table in LDS (0 slots = none). Rows whose key finds a slot there are
+  // aggregated with LDS atomics; the block merges its table into the HBM table once, at the end.
+  uint32_t lds_hash_slots;   // power of two
+  uint32_t lds_hkeys_off;    // byte offset of the u64 key array (metric states at m[j].lds_off, one per slot)
   // ---- hash
   uint64_t* hkeys;           // capacity(+1) x key_words
   uint32_t* htags;           // wide keys: slot state words

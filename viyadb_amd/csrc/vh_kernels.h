@@ -81,20 +81,20 @@ __host__ __device__ __forceinline__ uint64_t vh_trunc_secs(uint64_t t, int unit)
 // set_ts -> first matching rollup rule truncates -> query granularity truncates -> get_ts
 // (src/codegen/query/scan.cc:197-218; Time64::trunc also zeroes the microseconds).
 __host__ __device__ __forceinline__ uint64_t vh_time_rollup(uint64_t ts, const VhGroupDev& g) {
-  uint64_t secs = g.micro ? ts / 1000000ull : ts;
-  uint64_t micros = g.micro ? ts % 1000000ull : 0;
-  for (int i = 0; i < g.nroll; ++i) {
+  uint64_t secs = g.micro() ? ts / 1000000ull : ts;
+  uint64_t micros = g.micro() ? ts % 1000000ull : 0;
+  for (int i = 0; i < g.nroll(); ++i) {
     if (ts < g.roll_before[i]) {
-      secs = vh_trunc_secs(secs, g.roll_unit[i]);
+      secs = vh_trunc_secs(secs, g.roll_unit(i));
       micros = 0;
       break;
     }
   }
-  if (g.gran != VH_T_NONE) {
-    secs = vh_trunc_secs(secs, g.gran);
+  if (g.gran() != VH_T_NONE) {
+    secs = vh_trunc_secs(secs, g.gran());
     micros = 0;
   }
-  return g.micro ? secs * 1000000ull + micros : (uint64_t)(uint32_t)secs;
+  return g.micro() ? secs * 1000000ull + micros : (uint64_t)(uint32_t)secs;
 }
 
 // -------------------------------------------------------------- column loads
@@ -160,12 +160,12 @@ __device__ __forceinline__ uint32_t vh_leaf(const VhPlanDev& P, const VhProgOp o
                                             uint32_t row_l, uint32_t seg_rows) {
   T v[16];
   vh_load16<T, FULL>(reinterpret_cast<const T*>(base), row_l, seg_rows, v);
-  if (o.kind == VH_F_REL) return vh_cmp16<T>(v, vh_lit<T>(P.lits[o.lit]), o.op);
+  if (o.kind() == VH_F_REL) return vh_cmp16<T>(v, vh_lit<T>(P.lits[o.lit()]), o.op());
   // IN: OR of ==, NOT IN: AND of != (filter.cc:223-241)
-  uint32_t m = o.op ? 0u : 0xFFFFu;
-  for (int i = 0; i < o.count; ++i) {
-    const T lit = vh_lit<T>(P.lits[o.lit + i]);
-    if (o.op) m |= vh_cmp16<T>(v, lit, VH_OP_EQ);
+  uint32_t m = o.op() ? 0u : 0xFFFFu;
+  for (int i = 0; i < o.count(); ++i) {
+    const T lit = vh_lit<T>(P.lits[o.lit() + i]);
+    if (o.op()) m |= vh_cmp16<T>(v, lit, VH_OP_EQ);
     else m &= vh_cmp16<T>(v, lit, VH_OP_NE);
   }
   return m;
@@ -181,22 +181,22 @@ __device__ __forceinline__ uint32_t vh_eval_filter(const VhPlanDev& P, uint32_t 
   int sp = 0;
   for (int pc = 0; pc < P.nprog; ++pc) {
     const VhProgOp o = P.prog[pc];
-    switch (o.kind) {
+    switch (o.kind()) {
       case VH_F_TRUE: st[sp++] = 0xFFFFu; break;
       case VH_F_AND: {
         uint32_t a = st[--sp];
-        for (int i = 1; i < o.count; ++i) a &= st[--sp];
+        for (int i = 1; i < o.count(); ++i) a &= st[--sp];
         st[sp++] = a;
       } break;
       case VH_F_OR: {
         uint32_t a = st[--sp];
-        for (int i = 1; i < o.count; ++i) a |= st[--sp];
+        for (int i = 1; i < o.count(); ++i) a |= st[--sp];
         st[sp++] = a;
       } break;
       default: {
-        const char* base = P.colbase[o.slot] + (uint64_t)seg * P.colstride[o.slot];
+        const char* base = P.colbase[o.slot()] + (uint64_t)seg * P.colstride[o.slot()];
         uint32_t m;
-        switch (o.type) {
+        switch (o.type()) {
           case VH_U8: m = vh_leaf<uint8_t, FULL>(P, o, base, row_l, seg_rows); break;
           case VH_U16: m = vh_leaf<uint16_t, FULL>(P, o, base, row_l, seg_rows); break;
           case VH_U32: m = vh_leaf<uint32_t, FULL>(P, o, base, row_l, seg_rows); break;
@@ -425,9 +425,63 @@ enum { VH_MODE_DENSE_LDS = 1, VH_MODE_DENSE_GLOBAL = 2, VH_MODE_HASH = 3, VH_MOD
 
 // One surviving row (one per active lane, lanes are dense after compaction):
 // build the AggTuple key, then Update every selected metric.
+// ---------------------------------------------------------- LDS front table of the hash path
+// Low-cardinality sparse keys (GROUP BY a time bucket, a float, ...) would otherwise hammer a handful of HBM slots
+// with device-scope atomics (measured: 100 M rows into 25 month buckets = 26 ms, 50x off the roofline). Each block
+// therefore keeps a small open-addressing table in LDS; a row whose key finds (or claims) a slot there costs LDS
+// atomics only, everything else falls through to the HBM table. A wave that mostly falls through (high-cardinality
+// keys: the table fills up at once) stops probing LDS after a warm-up.
+struct VhLdsHashWave { uint32_t hits, misses; bool bypass; };
+
+__device__ __forceinline__ bool vh_lds_hash_find(const VhPlanDev& P, char* lds, uint64_t key, uint32_t& slot_out) {
+  unsigned long long* lk = reinterpret_cast<unsigned long long*>(lds + P.lds_hkeys_off);
+  const uint32_t smask = P.lds_hash_slots - 1u;
+  uint32_t slot = (uint32_t)(vh_splitmix64(key) >> 32) & smask;
+  for (int probe = 0; probe < 8; ++probe) {
+    unsigned long long old = lk[slot];
+    if (old == VH_HASH_EMPTY) old = atomicCAS(&lk[slot], (unsigned long long)VH_HASH_EMPTY, (unsigned long long)key);
+    if (old == VH_HASH_EMPTY || old == key) { slot_out = slot; return true; }
+    slot = (slot + 1u) & smask;
+  }
+  return false;
+}
+
+__device__ __forceinline__ void vh_lds_hash_init(const VhPlanDev& P, char* lds, int nthreads) {
+  for (uint32_t g = threadIdx.x; g < P.lds_hash_slots; g += nthreads) {
+    reinterpret_cast<uint64_t*>(lds + P.lds_hkeys_off)[g] = VH_HASH_EMPTY;
+    for (int j = 0; j < P.nmetric; ++j) {
+      const VhMetricDev& m = P.m[j];
+      if (vh_sop_bytes(m.sop()) == 4) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)m.ident;
+      else reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = m.ident;
+    }
+  }
+  __syncthreads();
+}
+
+// merge the block's LDS table into the HBM hash table: one insert + one update per (block, group, metric)
+__device__ __forceinline__ void vh_lds_hash_flush(const VhPlanDev& P, char* lds, int nthreads) {
+  __syncthreads();
+  unsigned long long nfresh = 0;
+  for (uint32_t g = threadIdx.x; g < P.lds_hash_slots; g += nthreads) {
+    const uint64_t key = reinterpret_cast<uint64_t*>(lds + P.lds_hkeys_off)[g];
+    if (key == VH_HASH_EMPTY) continue;
+    bool ok = true, fresh = false;
+    const uint64_t gid = vh_hash_insert64(P, key, ok, fresh);
+    if (!ok) { atomicOr(P.counters + 2, VH_ERR_HASH_FULL); continue; }
+    nfresh += fresh ? 1 : 0;
+    for (int j = 0; j < P.nmetric; ++j) {
+      const VhMetricDev& m = P.m[j];
+      const uint64_t bits = vh_sop_bytes(m.sop()) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
+                                                     : reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
+      vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, gid, m.sop(), bits);
+    }
+  }
+  if (nfresh) atomicAdd(P.counters + 1, nfresh);
+}
+
 template <int MODE, int SCOPE>
 __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active,
-                                           char* lds, uint64_t xoff, unsigned long long& nfresh) {
+                                           char* lds, uint64_t xoff, unsigned long long& nfresh, VhLdsHashWave& H) {
   uint64_t gid = 0;
   uint64_t key[VH_KEY_WORDS];
   if (MODE == VH_MODE_HASH) {
@@ -438,20 +492,37 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
   if (!active) row = 0;
   for (int i = 0; i < P.ngroup; ++i) {
     const VhGroupDev& g = P.g[i];
-    const char* base = P.colbase[g.slot] + (uint64_t)seg * P.colstride[g.slot];
-    uint64_t v = vh_load_bits(base, g.type, row, MODE != VH_MODE_HASH);
-    if (g.gran != VH_T_NONE || g.nroll) v = vh_time_rollup(v, g);
+    const char* base = P.colbase[g.slot()] + (uint64_t)seg * P.colstride[g.slot()];
+    uint64_t v = vh_load_bits(base, g.type(), row, MODE != VH_MODE_HASH);
+    if (g.gran() != VH_T_NONE || g.nroll()) v = vh_time_rollup(v, g);
     if (MODE == VH_MODE_HASH) {
-      if (g.type == VH_F32 && (uint32_t)v == 0x80000000u) v = 0;            // -0.0f == 0.0f
-      if (g.type == VH_F64 && v == 0x8000000000000000ull) v = 0;
-      key[g.key_word] |= v << g.key_shift;
+      if (g.type() == VH_F32 && (uint32_t)v == 0x80000000u) v = 0;            // -0.0f == 0.0f
+      if (g.type() == VH_F64 && v == 0x8000000000000000ull) v = 0;
+      key[g.key_word()] |= v << g.key_shift();
     } else {
       const uint64_t d = v - g.lo;
       bad |= d >= g.extent;
       gid += d * g.stride;
     }
   }
+  bool in_lds = false;
   if (MODE == VH_MODE_HASH) {
+    if (P.lds_hash_slots && !H.bypass) {
+      uint32_t ls = 0;
+      in_lds = active && key[0] != VH_HASH_EMPTY && vh_lds_hash_find(P, lds, key[0], ls);
+      const uint32_t nh = __popcll(__ballot(in_lds)), nm = __popcll(__ballot(active && !in_lds));
+      H.hits += nh; H.misses += nm;
+      if (H.hits + H.misses >= 4096u && H.misses > H.hits) H.bypass = true;
+      if (in_lds) {
+        for (int j = 0; j < P.nmetric; ++j) {
+          const VhMetricDev& m = P.m[j];
+          const uint64_t bits = m.slot() == VH_SLOT_ROWID ? (((uint64_t)seg << 32) | row)
+                                                        : vh_load_bits(P.colbase[m.slot()] + (uint64_t)seg * P.colstride[m.slot()], m.type(), row, vh_sop_sext(m.sop()));
+          vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, ls, m.sop(), bits);
+        }
+      }
+      active = active && !in_lds;
+    }
     bool ok = true, fresh = false;
     if (active) {
       gid = P.key_words == 1 ? vh_hash_insert64(P, key[0], ok, fresh)
@@ -473,20 +544,20 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
   }
   for (int j = 0; j < P.nmetric; ++j) {
     const VhMetricDev& m = P.m[j];
-    if (m.sop == SOP_BITSET) {   // m.slot = bitset index, m.state = u64 cardinality per group
-      if (active) vh_distinct_update(P, m.slot, reinterpret_cast<unsigned long long*>(m.state), MODE == VH_MODE_HASH ? gid : xoff + gid, seg, row);
+    if (m.sop() == SOP_BITSET) {   // slot() is the bitset index, m.state the u64 cardinality per group
+      if (active) vh_distinct_update(P, m.slot(), reinterpret_cast<unsigned long long*>(m.state), MODE == VH_MODE_HASH ? gid : xoff + gid, seg, row);
       continue;
     }
     uint64_t bits;
-    if (m.slot == VH_SLOT_ROWID) bits = ((uint64_t)seg << 32) | row;   // storage order of the row (search: first occurrence)
-    else bits = vh_load_bits(P.colbase[m.slot] + (uint64_t)seg * P.colstride[m.slot], m.type, row, vh_sop_sext(m.sop));
+    if (m.slot() == VH_SLOT_ROWID) bits = ((uint64_t)seg << 32) | row;   // storage order of the row (search: first occurrence)
+    else bits = vh_load_bits(P.colbase[m.slot()] + (uint64_t)seg * P.colstride[m.slot()], m.type(), row, vh_sop_sext(m.sop()));
     if (active) {
       if (MODE == VH_MODE_DENSE_LDS) {
-        vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, gid, m.sop, bits);
+        vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, gid, m.sop(), bits);
       } else if (MODE == VH_MODE_DENSE_GLOBAL) {
-        vh_state_update<SCOPE>(m.state, xoff + gid, m.sop, bits);
+        vh_state_update<SCOPE>(m.state, xoff + gid, m.sop(), bits);
       } else {
-        vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, gid, m.sop, bits);
+        vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, gid, m.sop(), bits);
       }
     }
   }
@@ -513,8 +584,10 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   // queues live behind the (optional) LDS aggregate table
-  uint32_t* q = reinterpret_cast<uint32_t*>(lds + (MODE == VH_MODE_DENSE_LDS ? P.lds_bytes : 0)) +
+  uint32_t* q = reinterpret_cast<uint32_t*>(lds + ((MODE == VH_MODE_DENSE_LDS || MODE == VH_MODE_HASH) ? P.lds_bytes : 0)) +
                 wave * C::kQueueCap;
+  VhLdsHashWave H{0u, 0u, false};
+  if (MODE == VH_MODE_HASH && P.lds_hash_slots) vh_lds_hash_init(P, lds, BLOCK);
 
   if (MODE == VH_MODE_DENSE_LDS) {
     // identities: 0 for SUM/AVG/COUNT, type max for MIN, cpp_min_value for MAX
@@ -522,7 +595,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
     for (int j = 0; j < P.nmetric; ++j) {
       const VhMetricDev& m = P.m[j];
       const uint64_t ident = m.ident;
-      if (vh_sop_bytes(m.sop) == 4) {
+      if (vh_sop_bytes(m.sop()) == 4) {
         for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK)
           reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)ident;
       } else {
@@ -568,7 +641,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
         while (cnt >= 64) {
           cnt -= 64;
           const uint32_t r = q[cnt + lane];
-          vh_consume<MODE, SCOPE>(P, seg, r, true, lds, xoff, nfresh);
+          vh_consume<MODE, SCOPE>(P, seg, r, true, lds, xoff, nfresh, H);
           __builtin_amdgcn_wave_barrier();
         }
       }
@@ -576,7 +649,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
     if (cnt) {
       const bool act = lane < (int)cnt;
       const uint32_t r = act ? q[lane] : 0;
-      vh_consume<MODE, SCOPE>(P, seg, r, act, lds, xoff, nfresh);
+      vh_consume<MODE, SCOPE>(P, seg, r, act, lds, xoff, nfresh, H);
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -587,6 +660,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
     if (npassed) atomicAdd(P.counters + 0, npassed);
     if (nfresh) atomicAdd(P.counters + 1, nfresh);
   }
+  if (MODE == VH_MODE_HASH && P.lds_hash_slots) vh_lds_hash_flush(P, lds, BLOCK);
 
   if (MODE == VH_MODE_DENSE_LDS) {
     // flush this block's LDS table: one global update per (block, present group)
@@ -597,9 +671,9 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
       P.present[xo + g] = 1;
       for (int j = 0; j < P.nmetric; ++j) {
         const VhMetricDev& m = P.m[j];
-        const uint64_t bits = vh_sop_bytes(m.sop) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
+        const uint64_t bits = vh_sop_bytes(m.sop()) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
                                                        : reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
-        vh_state_update<SCOPE>(m.state, xo + g, m.sop, bits);
+        vh_state_update<SCOPE>(m.state, xo + g, m.sop(), bits);
       }
     }
   }
@@ -791,23 +865,23 @@ __device__ __forceinline__ uint32_t vh_cmp16_bits(const uint32_t (&bits)[16], ui
 }
 
 __device__ __forceinline__ uint32_t vh_leaf_bits(const VhPlanDev& P, const VhProgOp o, const uint32_t (&bits)[16]) {
-  if (o.kind == VH_F_REL) {
-    switch (o.type) {
-      case VH_I32: return vh_cmp16_bits<int32_t>(bits, P.lits[o.lit], o.op);
-      case VH_F32: return vh_cmp16_bits<float>(bits, P.lits[o.lit], o.op);
-      default: return vh_cmp16_bits<uint32_t>(bits, P.lits[o.lit], o.op);
+  if (o.kind() == VH_F_REL) {
+    switch (o.type()) {
+      case VH_I32: return vh_cmp16_bits<int32_t>(bits, P.lits[o.lit()], o.op());
+      case VH_F32: return vh_cmp16_bits<float>(bits, P.lits[o.lit()], o.op());
+      default: return vh_cmp16_bits<uint32_t>(bits, P.lits[o.lit()], o.op());
     }
   }
-  uint32_t m = o.op ? 0u : 0xFFFFu;
-  for (int i = 0; i < o.count; ++i) {
-    const uint64_t lit = P.lits[o.lit + i];
+  uint32_t m = o.op() ? 0u : 0xFFFFu;
+  for (int i = 0; i < o.count(); ++i) {
+    const uint64_t lit = P.lits[o.lit() + i];
     uint32_t e;
-    switch (o.type) {
-      case VH_I32: e = vh_cmp16_bits<int32_t>(bits, lit, o.op ? VH_OP_EQ : VH_OP_NE); break;
-      case VH_F32: e = vh_cmp16_bits<float>(bits, lit, o.op ? VH_OP_EQ : VH_OP_NE); break;
-      default: e = vh_cmp16_bits<uint32_t>(bits, lit, o.op ? VH_OP_EQ : VH_OP_NE); break;
+    switch (o.type()) {
+      case VH_I32: e = vh_cmp16_bits<int32_t>(bits, lit, o.op() ? VH_OP_EQ : VH_OP_NE); break;
+      case VH_F32: e = vh_cmp16_bits<float>(bits, lit, o.op() ? VH_OP_EQ : VH_OP_NE); break;
+      default: e = vh_cmp16_bits<uint32_t>(bits, lit, o.op() ? VH_OP_EQ : VH_OP_NE); break;
     }
-    if (o.op) m |= e; else m &= e;
+    if (o.op()) m |= e; else m &= e;
   }
   return m;
 }
@@ -837,23 +911,23 @@ __device__ __forceinline__ uint32_t vh_eval_filter_fast(const VhPlanDev& P, cons
   int sp = 0;
   for (int pc = 0; pc < P.nprog; ++pc) {
     const VhProgOp o = P.prog[pc];
-    switch (o.kind) {
+    switch (o.kind()) {
       case VH_F_TRUE: st[sp++] = 0xFFFFu; break;
       case VH_F_AND: {
         uint32_t a = st[--sp];
-        for (int i = 1; i < o.count; ++i) a &= st[--sp];
+        for (int i = 1; i < o.count(); ++i) a &= st[--sp];
         st[sp++] = a;
       } break;
       case VH_F_OR: {
         uint32_t a = st[--sp];
-        for (int i = 1; i < o.count; ++i) a |= st[--sp];
+        for (int i = 1; i < o.count(); ++i) a |= st[--sp];
         st[sp++] = a;
       } break;
       default: {
         uint32_t m = 0;
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-          if (o.pslot == p) m = vh_leaf_bits(P, o, v[p]);
+          if (o.pslot() == p) m = vh_leaf_bits(P, o, v[p]);
         st[sp++] = m;
       } break;
     }
@@ -872,7 +946,7 @@ __device__ __forceinline__ uint32_t vh_eval_filter_fast(const VhPlanDev& P, cons
 
 template <int MODE, int SCOPE>
 __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, char* lds,
-                                                uint64_t xoff, unsigned long long& nfresh, VhPartWave& W) {
+                                                uint64_t xoff, unsigned long long& nfresh, VhPartWave& W, VhLdsHashWave& H) {
   if (!active) row = 0;
   uint64_t gv[VH_FAST_COLS], mv[VH_FAST_COLS];
 #pragma unroll
@@ -880,7 +954,7 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
     gv[i] = 0;
     if (i < P.ngroup) {
       const VhGroupDev& g = P.g[i];
-      gv[i] = vh_load_bits(P.colbase[g.slot] + (uint64_t)seg * P.colstride[g.slot], g.type, row, MODE != VH_MODE_HASH);
+      gv[i] = vh_load_bits(P.colbase[g.slot()] + (uint64_t)seg * P.colstride[g.slot()], g.type(), row, MODE != VH_MODE_HASH);
     }
   }
 #pragma unroll
@@ -888,8 +962,8 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
     mv[j] = 0;
     if (j < P.nmetric) {
       const VhMetricDev& m = P.m[j];
-      if (m.slot == VH_SLOT_ROWID) mv[j] = ((uint64_t)seg << 32) | row;
-      else mv[j] = vh_load_bits(P.colbase[m.slot] + (uint64_t)seg * P.colstride[m.slot], m.type, row, vh_sop_sext(m.sop));
+      if (m.slot() == VH_SLOT_ROWID) mv[j] = ((uint64_t)seg << 32) | row;
+      else mv[j] = vh_load_bits(P.colbase[m.slot()] + (uint64_t)seg * P.colstride[m.slot()], m.type(), row, vh_sop_sext(m.sop()));
     }
   }
   uint64_t gid = 0;
@@ -904,11 +978,11 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
     if (i < P.ngroup) {
       const VhGroupDev& g = P.g[i];
       uint64_t v = gv[i];
-      if (g.gran != VH_T_NONE || g.nroll) v = vh_time_rollup(v, g);
+      if (g.gran() != VH_T_NONE || g.nroll()) v = vh_time_rollup(v, g);
       if (MODE == VH_MODE_HASH) {
-        if (g.type == VH_F32 && (uint32_t)v == 0x80000000u) v = 0;
-        if (g.type == VH_F64 && v == 0x8000000000000000ull) v = 0;
-        key[g.key_word] |= v << g.key_shift;
+        if (g.type() == VH_F32 && (uint32_t)v == 0x80000000u) v = 0;
+        if (g.type() == VH_F64 && v == 0x8000000000000000ull) v = 0;
+        key[g.key_word()] |= v << g.key_shift();
       } else {
         const uint64_t d = v - g.lo;
         bad |= d >= g.extent;
@@ -917,6 +991,19 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
     }
   }
   if (MODE == VH_MODE_HASH) {
+    if (P.lds_hash_slots && !H.bypass) {
+      uint32_t ls = 0;
+      const bool in_lds = active && key[0] != VH_HASH_EMPTY && vh_lds_hash_find(P, lds, key[0], ls);
+      const uint32_t nh = __popcll(__ballot(in_lds)), nm = __popcll(__ballot(active && !in_lds));
+      H.hits += nh; H.misses += nm;
+      if (H.hits + H.misses >= 4096u && H.misses > H.hits) H.bypass = true;
+      if (in_lds) {
+#pragma unroll
+        for (int j = 0; j < VH_FAST_COLS; ++j)
+          if (j < P.nmetric) vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + P.m[j].lds_off, ls, P.m[j].sop(), mv[j]);
+      }
+      active = active && !in_lds;
+    }
     bool ok = true, fresh = false;
     if (active) {
       gid = P.key_words == 1 ? vh_hash_insert64(P, key[0], ok, fresh) : vh_hash_insert_wide(P, key, P.key_words, ok, fresh);
@@ -939,10 +1026,10 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
     for (int j = 0; j < VH_FAST_COLS; ++j) {
       if (j < P.nmetric) {
         const VhMetricDev& m = P.m[j];
-        const uint64_t v = (vh_sop_bytes(m.sop) == 4 ? (mv[j] & 0xFFFFFFFFull) : mv[j]) << m.tshift;
+        const uint64_t v = (vh_sop_bytes(m.sop()) == 4 ? (mv[j] & 0xFFFFFFFFull) : mv[j]) << m.tshift();
 #pragma unroll
         for (int w = 0; w < 1 + VH_FAST_COLS; ++w)
-          if (m.tword == w) words[w] |= v;
+          if (m.tword() == w) words[w] |= v;
       }
     }
     if (P.debug & 1) { if (active && words[1] == 0x123456789ull) P.tuples[0] = words[0]; return; }  // experiment: no staging
@@ -959,9 +1046,9 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
   for (int j = 0; j < VH_FAST_COLS; ++j) {
     if (j < P.nmetric && active) {
       const VhMetricDev& m = P.m[j];
-      if (MODE == VH_MODE_DENSE_LDS) vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, gid, m.sop, mv[j]);
-      else if (MODE == VH_MODE_DENSE_GLOBAL) vh_state_update<SCOPE>(m.state, xoff + gid, m.sop, mv[j]);
-      else vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, gid, m.sop, mv[j]);
+      if (MODE == VH_MODE_DENSE_LDS) vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, gid, m.sop(), mv[j]);
+      else if (MODE == VH_MODE_DENSE_GLOBAL) vh_state_update<SCOPE>(m.state, xoff + gid, m.sop(), mv[j]);
+      else vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, gid, m.sop(), mv[j]);
     }
   }
 }
@@ -972,7 +1059,9 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
   typedef VhScanCfg<BLOCK> C;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  uint32_t* q = reinterpret_cast<uint32_t*>(lds + (MODE == VH_MODE_DENSE_LDS ? P.lds_bytes : 0)) + wave * C::kQueueCap;
+  uint32_t* q = reinterpret_cast<uint32_t*>(lds + ((MODE == VH_MODE_DENSE_LDS || MODE == VH_MODE_HASH) ? P.lds_bytes : 0)) + wave * C::kQueueCap;
+  VhLdsHashWave H{0u, 0u, false};
+  if (MODE == VH_MODE_HASH && P.lds_hash_slots) vh_lds_hash_init(P, lds, BLOCK);
   VhPartWave W;
   if (MODE == VH_MODE_DENSE_PART) {
     char* area = lds + (size_t)C::kWaves * C::kQueueCap * sizeof(uint32_t) + (size_t)wave * ((vh_part_wave_bytes(P) + 15) / 16 * 16);
@@ -983,7 +1072,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
     for (int j = 0; j < P.nmetric; ++j) {
       const VhMetricDev& m = P.m[j];
       const uint64_t ident = m.ident;
-      if (vh_sop_bytes(m.sop) == 4) {
+      if (vh_sop_bytes(m.sop()) == 4) {
         for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)ident;
       } else {
         for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = ident;
@@ -1051,14 +1140,14 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
       while (cnt >= 64) {
         cnt -= 64;
         const uint32_t r = q[cnt + lane];
-        vh_consume_fast<MODE, SCOPE>(P, seg, r, true, lds, xoff, nfresh, W);
+        vh_consume_fast<MODE, SCOPE>(P, seg, r, true, lds, xoff, nfresh, W, H);
         __builtin_amdgcn_wave_barrier();
       }
     }
     if (cnt && (!nhave || nseg != seg)) {  // queue entries are rows of the current segment
       const bool act = lane < (int)cnt;
       const uint32_t r = act ? q[lane] : 0;
-      vh_consume_fast<MODE, SCOPE>(P, seg, r, act, lds, xoff, nfresh, W);
+      vh_consume_fast<MODE, SCOPE>(P, seg, r, act, lds, xoff, nfresh, W, H);
       __builtin_amdgcn_wave_barrier();
       cnt = 0;
     }
@@ -1071,6 +1160,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
     if (npassed) atomicAdd(P.counters + 0, npassed);
     if (nfresh) atomicAdd(P.counters + 1, nfresh);
   }
+  if (MODE == VH_MODE_HASH && P.lds_hash_slots) vh_lds_hash_flush(P, lds, BLOCK);
   if (MODE == VH_MODE_DENSE_LDS) {
     __syncthreads();
     const uint64_t xo = P.nxcd > 1 ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;
@@ -1079,9 +1169,9 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
       P.present[xo + g] = 1;
       for (int j = 0; j < P.nmetric; ++j) {
         const VhMetricDev& m = P.m[j];
-        const uint64_t bits = vh_sop_bytes(m.sop) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
+        const uint64_t bits = vh_sop_bytes(m.sop()) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
                                                        : reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
-        vh_state_update<SCOPE>(m.state, xo + g, m.sop, bits);
+        vh_state_update<SCOPE>(m.state, xo + g, m.sop(), bits);
       }
     }
   }
@@ -1117,7 +1207,7 @@ __global__ __launch_bounds__(1024) void scan_agg_lanes_kernel(const VhPlanDev P)
   for (int j = 0; j < P.nmetric; ++j) {
     const VhMetricDev& m = P.m[j];
     const uint64_t ident = m.ident;
-    if (vh_sop_bytes(m.sop) == 4) {
+    if (vh_sop_bytes(m.sop()) == 4) {
       for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)ident;
     } else {
       for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = ident;
@@ -1164,7 +1254,6 @@ __global__ __launch_bounds__(1024) void scan_agg_lanes_kernel(const VhPlanDev P)
 #pragma unroll
     for (int k = 0; k < VH_SUBSTEPS; ++k) {
       const uint32_t mk = (mask >> (4 * k)) & 0xFu;
-      if (__ballot(mk != 0) == 0) continue;
       const uint32_t r0 = row_l + k * 256u;
       uint64_t gv[VH_LANES_COLS][4], mv[VH_LANES_COLS][4];
 #pragma unroll
@@ -1172,7 +1261,7 @@ __global__ __launch_bounds__(1024) void scan_agg_lanes_kernel(const VhPlanDev P)
         gv[i][0] = gv[i][1] = gv[i][2] = gv[i][3] = 0;
         if (i < P.ngroup && mk) {     // mk == 0 also covers rows at or beyond size(): nothing is loaded out of bounds
           const VhGroupDev& g = P.g[i];
-          vh_load_rows4(P.colbase[g.slot] + (uint64_t)seg * P.colstride[g.slot], g.type, r0, true, gv[i]);
+          vh_load_rows4(P.colbase[g.slot()] + (uint64_t)seg * P.colstride[g.slot()], g.type(), r0, true, gv[i]);
         }
       }
 #pragma unroll
@@ -1180,7 +1269,7 @@ __global__ __launch_bounds__(1024) void scan_agg_lanes_kernel(const VhPlanDev P)
         mv[j][0] = mv[j][1] = mv[j][2] = mv[j][3] = 0;
         if (j < P.nmetric && mk) {
           const VhMetricDev& m = P.m[j];
-          vh_load_rows4(P.colbase[m.slot] + (uint64_t)seg * P.colstride[m.slot], m.type, r0, vh_sop_sext(m.sop), mv[j]);
+          vh_load_rows4(P.colbase[m.slot()] + (uint64_t)seg * P.colstride[m.slot()], m.type(), r0, vh_sop_sext(m.sop()), mv[j]);
         }
       }
 #pragma unroll
@@ -1201,7 +1290,7 @@ __global__ __launch_bounds__(1024) void scan_agg_lanes_kernel(const VhPlanDev P)
         reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[gid] = 1;
 #pragma unroll
         for (int j = 0; j < VH_LANES_COLS; ++j)
-          if (j < P.nmetric) vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + P.m[j].lds_off, gid, P.m[j].sop, mv[j][r]);
+          if (j < P.nmetric) vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + P.m[j].lds_off, gid, P.m[j].sop(), mv[j][r]);
       }
     }
     have = nhave; seg = nseg; unit_base = nunit_base; wave_base = nwave_base; seg_rows = nseg_rows;
@@ -1216,9 +1305,9 @@ __global__ __launch_bounds__(1024) void scan_agg_lanes_kernel(const VhPlanDev P)
     P.present[xo + g] = 1;
     for (int j = 0; j < P.nmetric; ++j) {
       const VhMetricDev& m = P.m[j];
-      const uint64_t bits = vh_sop_bytes(m.sop) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
+      const uint64_t bits = vh_sop_bytes(m.sop()) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
                                                      : reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
-      vh_state_update<SCOPE>(m.state, xo + g, m.sop, bits);
+      vh_state_update<SCOPE>(m.state, xo + g, m.sop(), bits);
     }
   }
 }
@@ -1238,7 +1327,7 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
   const uint64_t ng = g0 >= P.G ? 0 : (P.G - g0 < gpp ? P.G - g0 : gpp);
   for (int j = 0; j < P.nmetric; ++j) {
     const VhMetricDev& m = P.m[j];
-    if (vh_sop_bytes(m.sop) == 4) {
+    if (vh_sop_bytes(m.sop()) == 4) {
       for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)m.ident;
     } else {
       for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = m.ident;
@@ -1267,12 +1356,12 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
           uint64_t v = 0;
 #pragma unroll
           for (int x = 0; x < 1 + VH_FAST_COLS; ++x)
-            if (m.tword == x) v = w[x] >> m.tshift;
-          if (vh_sop_bytes(m.sop) == 4) {
+            if (m.tword() == x) v = w[x] >> m.tshift();
+          if (vh_sop_bytes(m.sop()) == 4) {
             v &= 0xFFFFFFFFull;
-            if (vh_sop_sext(m.sop)) v = (uint64_t)(int64_t)(int32_t)v;
+            if (vh_sop_sext(m.sop())) v = (uint64_t)(int64_t)(int32_t)v;
           }
-          vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, local, m.sop, v);
+          vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, local, m.sop(), v);
         }
       }
     }
@@ -1283,9 +1372,9 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
     P.present[g0 + g] = 1;
     for (int j = 0; j < P.nmetric; ++j) {
       const VhMetricDev& m = P.m[j];
-      const uint64_t bits = vh_sop_bytes(m.sop) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
+      const uint64_t bits = vh_sop_bytes(m.sop()) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
                                                      : reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
-      vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, g0 + g, m.sop, bits);
+      vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, g0 + g, m.sop(), bits);
     }
   }
 }

@@ -79,7 +79,7 @@ struct VhEmitArgs {
   const unsigned long long* counters;
   unsigned long long* out_count;
   // Key decode parameters as dword-aligned arrays of their own, NOT VhGroupDev: with the byte-sized members of
-  // that struct next to the 64-bit ones, hipcc (ROCm 7.2) formed `s_load_dwordx2 sN, s[&g.type], 0x5e` —
+  // that struct next to the 64-bit ones, hipcc (ROCm 7.2) formed `s_load_dwordx2 sN, s[&g.type()], 0x5e` —
   // a scalar load off a base that is 2 mod 4. SMEM ignores the low address bits of the base, so lo / extent /
   // stride were read 2 bytes early (tests/test_isa_hazards.py greps the disassembly for that pattern).
   uint64_t glo[VH_MAX_GROUP], gextent[VH_MAX_GROUP], gstride[VH_MAX_GROUP];
@@ -166,20 +166,20 @@ __global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
       int sp = 0;
       for (int pc = 0; pc < A.nhaving; ++pc) {
         const VhProgOp o = A.hprog[pc];
-        if (o.kind == VH_F_TRUE) st[sp++] = true;
-        else if (o.kind == VH_F_AND || o.kind == VH_F_OR) {
+        if (o.kind() == VH_F_TRUE) st[sp++] = true;
+        else if (o.kind() == VH_F_AND || o.kind() == VH_F_OR) {
           bool a = st[--sp];
-          for (int k = 1; k < o.count; ++k) { const bool b = st[--sp]; a = o.kind == VH_F_AND ? (a & b) : (a | b); }
+          for (int k = 1; k < o.count(); ++k) { const bool b = st[--sp]; a = o.kind() == VH_F_AND ? (a & b) : (a | b); }
           st[sp++] = a;
         } else {
-          const uint64_t v = o.slot < A.ngroup ? vh_emit_key(A, i, o.slot) : vh_emit_state(A, i, o.slot - A.ngroup);
+          const uint64_t v = o.slot() < A.ngroup ? vh_emit_key(A, i, o.slot()) : vh_emit_state(A, i, o.slot() - A.ngroup);
           bool r;
-          if (o.kind == VH_F_REL) r = vh_cmp_bits(A.htype[pc], v, A.hlits[o.lit], o.op);
+          if (o.kind() == VH_F_REL) r = vh_cmp_bits(A.htype[pc], v, A.hlits[o.lit()], o.op());
           else {
-            r = !o.op;
-            for (int k = 0; k < o.count; ++k) {
-              const bool e = vh_cmp_bits(A.htype[pc], v, A.hlits[o.lit + k], o.op ? VH_OP_EQ : VH_OP_NE);
-              r = o.op ? (r | e) : (r & e);
+            r = !o.op();
+            for (int k = 0; k < o.count(); ++k) {
+              const bool e = vh_cmp_bits(A.htype[pc], v, A.hlits[o.lit() + k], o.op() ? VH_OP_EQ : VH_OP_NE);
+              r = o.op() ? (r | e) : (r & e);
             }
           }
           st[sp++] = r;

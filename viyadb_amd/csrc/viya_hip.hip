@@ -520,7 +520,7 @@ extern "C" int vh_result_copy(vh_result* r, void* const* key_cols, void* const* 
   if (rc) return rc;
   const uint64_t ng = r->ngroups_host;
   for (int i = 0; i < r->plan.ngroup; ++i)
-    if (key_cols && key_cols[i] && ng) memcpy(key_cols[i], kp[i], ng * vh_elem_size(r->plan.g[i].type));
+    if (key_cols && key_cols[i] && ng) memcpy(key_cols[i], kp[i], ng * vh_elem_size(r->plan.g[i].type()));
   for (size_t j = 0; j < r->user_metric.size(); ++j) {
     if (!state_cols || !state_cols[j] || !ng) continue;
     const int u = r->user_metric[j];
@@ -711,21 +711,21 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   for (int i = 0; i < p->nfilter; ++i) {
     const vh_filter_node& n = p->filter[i];
     VhProgOp& o = P.prog[i];
-    o.kind = (uint8_t)n.kind; o.op = (uint8_t)n.op; o.count = (uint8_t)n.count;
+    o.set_kind((uint8_t)n.kind); o.set_op((uint8_t)n.op); o.set_count((uint8_t)n.count);
     if (n.kind == VH_F_REL || n.kind == VH_F_IN) {
       const int s = slot(n.col);
       if (s == -2) { delete r; return vh_fail(VH_E_UNSUPPORTED, "filter on a bitset metric (cardinality) is evaluated host-side"); }
       if (s < 0) { delete r; return vh_fail(VH_E_INVALID, "filter node %d: bad column %d", i, n.col); }
       const int cnt = n.kind == VH_F_REL ? 1 : n.count;
       if (n.lit < 0 || n.lit + cnt > p->nlits || n.count > 255) { delete r; return vh_fail(VH_E_INVALID, "filter node %d: literal range", i); }
-      o.slot = (uint8_t)s; o.type = (uint8_t)t->cols[n.col].elem; o.lit = (uint16_t)n.lit;
+      o.set_slot((uint8_t)s); o.set_type((uint8_t)t->cols[n.col].elem); o.set_lit((uint16_t)n.lit);
       // fast path bookkeeping: distinct 4-byte predicate columns
       if (vh_elem_size(t->cols[n.col].elem) != 4) fast_ok = false;
       if (fast_ok) {
         int ps = -1;
         for (int k = 0; k < P.npred; ++k) if (P.pred_slot[k] == s) ps = k;
         if (ps < 0) { if (P.npred < VH_MAX_PRED) { ps = P.npred; P.pred_slot[P.npred++] = (uint8_t)s; } else fast_ok = false; }
-        o.pslot = (uint8_t)std::max(ps, 0);
+        o.set_pslot((uint8_t)std::max(ps, 0));
       }
       ++depth;
     } else if (n.kind == VH_F_TRUE) {
@@ -736,7 +736,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     } else { delete r; return vh_fail(VH_E_INVALID, "filter node %d: kind %d", i, n.kind); }
     maxdepth = std::max(maxdepth, depth);
   }
-  if (p->nfilter == 0) { P.prog[0].kind = VH_F_TRUE; P.nprog = 1; depth = 1; }
+  if (p->nfilter == 0) { P.prog[0].set_kind(VH_F_TRUE); P.nprog = 1; depth = 1; }
   else P.nprog = p->nfilter;
   if (depth != 1) { delete r; return vh_fail(VH_E_INVALID, "filter program leaves %d values on the stack", depth); }
   if (maxdepth > VH_MAX_STACK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "filter needs stack depth %d (max %d)", maxdepth, VH_MAX_STACK); }
@@ -775,16 +775,16 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     if (s < 0 || !is_dim(t->cols[gc.col].kind)) { delete r; return vh_fail(VH_E_INVALID, "group column %d: bad column %d", i, gc.col); }
     const VhColumn& c = t->cols[gc.col];
     VhGroupDev& g = P.g[i];
-    g.slot = (uint16_t)s; g.type = (uint8_t)c.elem;
-    g.gran = (uint8_t)(gc.granularity < 0 ? VH_T_NONE : gc.granularity);
-    g.nroll = (uint8_t)gc.nrollup; g.micro = (uint8_t)gc.micro;
+    g.set_slot((uint16_t)s); g.set_type((uint8_t)c.elem);
+    g.set_gran((uint8_t)(gc.granularity < 0 ? VH_T_NONE : gc.granularity));
+    g.set_nroll((uint8_t)gc.nrollup); g.set_micro((uint8_t)gc.micro);
     if (gc.nrollup < 0 || gc.nrollup > VH_MAX_ROLLUP) { delete r; return vh_fail(VH_E_UNSUPPORTED, "group column %d: %d rollup rules", i, gc.nrollup); }
-    if (g.gran == VH_T_WEEK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "week granularity: the reference has no Truncator::trunc<WEEK> (src/util/time.h:57-89)"); }
+    if (g.gran() == VH_T_WEEK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "week granularity: the reference has no Truncator::trunc<WEEK> (src/util/time.h:57-89)"); }
     for (int k = 0; k < gc.nrollup; ++k) {
       if (gc.rollup_unit[k] == VH_T_WEEK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "week rollup granularity is not supported by the reference"); }
-      g.roll_unit[k] = (uint8_t)gc.rollup_unit[k]; g.roll_before[k] = gc.rollup_before[k];
+      g.set_roll_unit(k, (uint8_t)gc.rollup_unit[k]); g.roll_before[k] = gc.rollup_before[k];
     }
-    const bool timey = g.gran != VH_T_NONE || g.nroll;
+    const bool timey = g.gran() != VH_T_NONE || g.nroll();
     if (timey && c.kind != VH_DIM_TIME) { delete r; return vh_fail(VH_E_INVALID, "group column %d: truncation on a non-time dimension", i); }
     r->group_elem.push_back(c.elem);
     key_bits_total += c.esize * 8;
@@ -820,9 +820,9 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     // pack key columns into u64 words, widest first within a word, never straddling
     int word = 0, used = 0;
     for (int i = 0; i < p->ngroups; ++i) {
-      const int bits = vh_elem_size(P.g[i].type) * 8;
+      const int bits = vh_elem_size(P.g[i].type()) * 8;
       if (used + bits > 64) { ++word; used = 0; }
-      P.g[i].key_word = (uint8_t)word; P.g[i].key_shift = (uint8_t)used;
+      P.g[i].set_key_word((uint8_t)word); P.g[i].set_key_shift((uint8_t)used);
       used += bits;
     }
     P.key_words = p->ngroups ? word + 1 : 1;
@@ -839,7 +839,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     const int col = p->metrics[j];
     if (col == VH_COL_ROWID) {   // virtual column: storage position of the row, aggregated with MIN (first occurrence)
       VhMetricDev& m = P.m[P.nmetric];
-      m.slot = VH_SLOT_ROWID; m.type = VH_U64; m.sop = SOP_MIN_U64; m.ident = ~0ull;
+      m.set_slot(VH_SLOT_ROWID); m.set_type(VH_U64); m.set_sop(SOP_MIN_U64); m.ident = ~0ull;
       r->user_metric.push_back(P.nmetric++);
       r->metric_elem.push_back(VH_U64);
       continue;
@@ -857,7 +857,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       bitset_ids_before = pair_cap;
       P.bs_wide[P.nbitset] = c.elem == VH_BITSET64;
       VhMetricDev& m = P.m[P.nmetric];
-      m.slot = (uint16_t)P.nbitset; m.type = VH_U64; m.sop = SOP_BITSET; m.ident = 0;
+      m.set_slot((uint16_t)P.nbitset); m.set_type(VH_U64); m.set_sop(SOP_BITSET); m.ident = 0;
       r->user_metric.push_back(P.nmetric++);
       r->metric_elem.push_back(VH_U64);
       ++P.nbitset;
@@ -868,7 +868,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     int sop; uint64_t ident;
     if (sop_for(c.kind, c.elem, &sop, &ident)) { delete r; return vh_fail(VH_E_INVALID, "metric %d: kind %d / elem %d", j, c.kind, c.elem); }
     VhMetricDev& m = P.m[P.nmetric];
-    m.slot = (uint16_t)s; m.type = (uint8_t)c.elem; m.sop = (uint8_t)sop; m.ident = ident;
+    m.set_slot((uint16_t)s); m.set_type((uint8_t)c.elem); m.set_sop((uint8_t)sop); m.ident = ident;
     r->user_metric.push_back(P.nmetric++);
     r->metric_elem.push_back(c.elem);
     has_avg |= c.kind == VH_METRIC_AVG; has_count |= c.kind == VH_METRIC_COUNT;
@@ -881,7 +881,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     const int s = slot(hc);
     if (s < 0) { delete r; return vh_fail(VH_E_UNSUPPORTED, "too many referenced columns"); }
     VhMetricDev& m = P.m[P.nmetric++];
-    m.slot = (uint16_t)s; m.type = VH_U64; m.sop = SOP_ADD64; m.ident = 0;
+    m.set_slot((uint16_t)s); m.set_type(VH_U64); m.set_sop(SOP_ADD64); m.ident = 0;
     r->metric_elem.push_back(VH_U64);
     r->info.has_hidden_count = 1;
   }
@@ -896,16 +896,16 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     for (int i = 0; i < p->nhaving; ++i) {
       const vh_filter_node& n = p->having[i];
       VhProgOp& o = r->hprog[i];
-      o.kind = (uint8_t)n.kind; o.op = (uint8_t)n.op; o.count = (uint8_t)n.count;
+      o.set_kind((uint8_t)n.kind); o.set_op((uint8_t)n.op); o.set_count((uint8_t)n.count);
       if (n.kind == VH_F_REL || n.kind == VH_F_IN) {
         const int cnt = n.kind == VH_F_REL ? 1 : n.count;
         if (n.col < 0 || n.col >= p->ngroups + p->nmetrics || n.lit < 0 || n.lit + cnt > p->nlits || nl + cnt > VH_MAX_HAVING_LITS) {
           delete r; return vh_fail(VH_E_INVALID, "having node %d: bad result column / literal range", i);
         }
-        if (n.col < p->ngroups) { o.slot = (uint8_t)n.col; r->htype[i] = (uint8_t)t->cols[p->groups[n.col].col].elem; }
+        if (n.col < p->ngroups) { o.set_slot((uint8_t)n.col); r->htype[i] = (uint8_t)t->cols[p->groups[n.col].col].elem; }
         else {
           const int dj = r->user_metric[n.col - p->ngroups];
-          o.slot = (uint8_t)(p->ngroups + dj);
+          o.set_slot((uint8_t)(p->ngroups + dj));
           const int mcol = p->metrics[n.col - p->ngroups];
           if (mcol == VH_COL_ROWID) r->htype[i] = VH_U64;
           else {
@@ -913,7 +913,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
             r->htype[i] = (uint8_t)(mc.kind == VH_METRIC_BITSET ? (mc.elem == VH_BITSET64 ? VH_U64 : VH_U32) : mc.elem);
           }
         }
-        o.lit = (uint16_t)nl;
+        o.set_lit((uint16_t)nl);
         for (int k = 0; k < cnt; ++k) r->hlits[nl++] = p->lits[n.lit + k].u64;
         ++hdepth;
       } else if (n.kind == VH_F_TRUE) ++hdepth;
@@ -948,7 +948,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
 
   // ---------------- choose the table organisation
   size_t state_bytes_per_group = 1;  // presence byte
-  for (int j = 0; j < P.nmetric; ++j) state_bytes_per_group += vh_sop_bytes(P.m[j].sop);
+  for (int j = 0; j < P.nmetric; ++j) state_bytes_per_group += vh_sop_bytes(P.m[j].sop());
   int mode;
   size_t lds_table = 0;
   if (dense_ok) {
@@ -956,7 +956,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     size_t off = 0;
     for (int pass = 0; pass < 2; ++pass)
       for (int j = 0; j < P.nmetric; ++j) {
-        const int b = vh_sop_bytes(P.m[j].sop);
+        const int b = vh_sop_bytes(P.m[j].sop());
         if ((pass == 0) != (b == 8)) continue;
         P.m[j].lds_off = (uint32_t)off; off += G * b;
       }
@@ -990,8 +990,8 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   if (mode == VH_MODE_DENSE_LDS && fast && !(p->flags & VH_PLAN_NO_LANES) && P.ngroup <= VH_LANES_COLS && P.nmetric <= VH_LANES_COLS &&
       P.nmetric >= 1 && rows_to_scan) {
     bool ok = true;
-    for (int i = 0; i < P.ngroup; ++i) ok &= vh_elem_size(P.g[i].type) >= 4 && P.g[i].gran == VH_T_NONE && P.g[i].nroll == 0;
-    for (int j = 0; j < P.nmetric; ++j) ok &= P.m[j].slot != VH_SLOT_ROWID && P.m[j].sop != SOP_BITSET && vh_elem_size(P.m[j].type) >= 4;
+    for (int i = 0; i < P.ngroup; ++i) ok &= vh_elem_size(P.g[i].type()) >= 4 && P.g[i].gran() == VH_T_NONE && P.g[i].nroll() == 0;
+    for (int j = 0; j < P.nmetric; ++j) ok &= P.m[j].slot() != VH_SLOT_ROWID && P.m[j].sop() != SOP_BITSET && vh_elem_size(P.m[j].type()) >= 4;
     if (ok) {
       if (p->flags & VH_PLAN_FORCE_LANES) lanes = true;
       else {
@@ -1025,9 +1025,9 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       int tw = 1, half_free_word = 0;  // word 0 has its upper half free
       bool have_half = true;
       for (int j = 0; j < P.nmetric; ++j) {
-        if (vh_sop_bytes(P.m[j].sop) == 8) { P.m[j].tword = (uint8_t)tw++; P.m[j].tshift = 0; }
-        else if (have_half) { P.m[j].tword = (uint8_t)half_free_word; P.m[j].tshift = 32; have_half = false; }
-        else { P.m[j].tword = (uint8_t)tw; P.m[j].tshift = 0; half_free_word = tw++; have_half = true; }
+        if (vh_sop_bytes(P.m[j].sop()) == 8) { P.m[j].set_tword((uint8_t)tw++); P.m[j].set_tshift(0); }
+        else if (have_half) { P.m[j].set_tword((uint8_t)half_free_word); P.m[j].set_tshift(32); have_half = false; }
+        else { P.m[j].set_tword((uint8_t)tw); P.m[j].set_tshift(0); half_free_word = tw++; have_half = true; }
       }
       P.tw = tw;
       int cap = 16;
@@ -1039,7 +1039,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       size_t off = 0;
       for (int pass = 0; pass < 2; ++pass)
         for (int j = 0; j < P.nmetric; ++j) {
-          const int b = vh_sop_bytes(P.m[j].sop);
+          const int b = vh_sop_bytes(P.m[j].sop());
           if ((pass == 0) != (b == 8)) continue;
           P.m[j].lds_off = (uint32_t)off; off += gpp * b;
         }
@@ -1056,7 +1056,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   P.present_carrier = -1;
   if (mode == VH_MODE_DENSE_GLOBAL && !(p->flags & VH_PLAN_NO_CARRIER)) {
     for (int j = 0; j < P.nmetric; ++j)
-      if (P.m[j].sop == SOP_ADD32) { P.m[j].sop = SOP_ADD32P; P.present_carrier = j; state_bytes_per_group += 4; break; }
+      if (P.m[j].sop() == SOP_ADD32) { P.m[j].set_sop(SOP_ADD32P); P.present_carrier = j; state_bytes_per_group += 4; break; }
   }
   r->mode = mode;
   r->info.path = mode == VH_MODE_DENSE_LDS ? (p->ngroups ? VH_PATH_DENSE_LDS : VH_PATH_SCALAR)
@@ -1074,7 +1074,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   if (mode == VH_MODE_HASH) {
     // sizing: explicit override (regrow) > caller's hint > what the same group columns produced last time > 1 M
     std::string sig;
-    for (int i = 0; i < p->ngroups; ++i) sig += std::to_string(p->groups[i].col) + ":" + std::to_string(P.g[i].gran) + ":" + std::to_string(P.g[i].nroll) + ",";
+    for (int i = 0; i < p->ngroups; ++i) sig += std::to_string(p->groups[i].col) + ":" + std::to_string(P.g[i].gran()) + ":" + std::to_string(P.g[i].nroll()) + ",";
     r->group_sig = sig;
     const auto seen = t->groups_seen.find(sig);
     const uint64_t hint = p->groups_hint ? p->groups_hint : (seen != t->groups_seen.end() ? seen->second + seen->second / 4 : 0);
@@ -1085,6 +1085,29 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     capacity = 1; while (capacity < want) capacity <<= 1;
     P.hmask = capacity - 1;
     P.max_probe = (uint32_t)std::min<uint64_t>(capacity - 1, 2048);
+    // LDS front table (north_star's "LDS-bucketed open-address tables"): single-word keys, no count-distinct (its
+    // sets are keyed by the HBM slot). Skipped when the same group columns are known to produce far more groups
+    // than it holds; otherwise every wave decides for itself after a warm-up (VhLdsHashWave).
+    if (P.key_words == 1 && P.nbitset == 0 && P.nmetric >= 1 && !(p->flags & VH_PLAN_NO_LDS_HASH)) {
+      size_t sb = 8;
+      for (int j = 0; j < P.nmetric; ++j) sb += vh_sop_bytes(P.m[j].sop());
+      uint32_t slots = 2048;
+      while (slots > 256 && (size_t)slots * sb > 24 * 1024) slots >>= 1;
+      const uint64_t known = p->groups_hint ? p->groups_hint : (seen != t->groups_seen.end() ? seen->second : 0);
+      if ((size_t)slots * sb <= 24 * 1024 && known <= (uint64_t)slots * 4) {
+        size_t off = 0;
+        P.lds_hkeys_off = 0; off += (size_t)slots * 8;
+        for (int pass = 0; pass < 2; ++pass)
+          for (int j = 0; j < P.nmetric; ++j) {
+            const int b = vh_sop_bytes(P.m[j].sop());
+            if ((pass == 0) != (b == 8)) continue;
+            P.m[j].lds_off = (uint32_t)off; off += (size_t)slots * b;
+          }
+        P.lds_hash_slots = slots;
+        lds_table = (off + 15) / 16 * 16;
+        P.lds_bytes = (uint32_t)lds_table;
+      }
+    }
   }
 
   // ---------------- work decomposition
@@ -1115,7 +1138,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   const size_t o_outcount = sp.take(sizeof(unsigned long long));
   r->out_cap = mode == VH_MODE_HASH ? capacity + 1 : G;
   size_t o_okey[VH_MAX_GROUP], o_ostate[VH_MAX_METRIC];
-  for (int i = 0; i < P.ngroup; ++i) o_okey[i] = sp.take(r->out_cap * vh_elem_size(P.g[i].type));
+  for (int i = 0; i < P.ngroup; ++i) o_okey[i] = sp.take(r->out_cap * vh_elem_size(P.g[i].type()));
   for (int j = 0; j < P.nmetric; ++j) o_ostate[j] = sp.take(r->out_cap * vh_elem_size(r->metric_elem[j]));
   r->out_region_off = o_counters;
   r->out_region_bytes = sp.off - o_counters;
@@ -1133,16 +1156,16 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   }
   // zero-identity states (every SUM) sit right behind the presence bytes: one memset clears them all
   const size_t zero_begin = mode == VH_MODE_HASH ? sp.off : o_present;
-  for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident == 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop));
+  for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident == 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop()));
   const size_t zero_end = sp.off;
-  for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident != 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop));
+  for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident != 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop()));
   // device top-N: worth it only when the group table is big (small results are read back whole anyway)
   size_t o_tkkeys = 0, o_tkstate = 0, o_okey2[VH_MAX_GROUP] = {}, o_ostate2[VH_MAX_METRIC] = {};
   r->topk_active = r->topk > 0 && r->out_cap > 65536 && !getenv("VH_NO_TOPK");
   if (r->topk_active) {
     o_tkkeys = sp.take(r->out_cap * sizeof(uint64_t));
     o_tkstate = sp.take(sizeof(VhTopkState));
-    for (int i = 0; i < P.ngroup; ++i) o_okey2[i] = sp.take(r->out_cap * vh_elem_size(P.g[i].type));
+    for (int i = 0; i < P.ngroup; ++i) o_okey2[i] = sp.take(r->out_cap * vh_elem_size(P.g[i].type()));
     for (int j = 0; j < P.nmetric; ++j) o_ostate2[j] = sp.take(r->out_cap * vh_elem_size(r->metric_elem[j]));
   }
   // outputs
@@ -1244,14 +1267,14 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   }
   for (int j = 0; j < P.nmetric; ++j) {
     if (P.m[j].ident == 0) continue;
-    rc = fill_states(P.m[j].state, table_n, vh_sop_bytes(P.m[j].sop), P.m[j].ident, st);
+    rc = fill_states(P.m[j].state, table_n, vh_sop_bytes(P.m[j].sop()), P.m[j].ident, st);
     if (rc) { delete r; return rc; }
   }
   const size_t qbytes = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint32_t);
   HIP_TRY(hipEventRecord(t->ev[1], st));
-  r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0);
+  r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0);
   if (P.total_units) {
-    const size_t lds = (mode == VH_MODE_DENSE_LDS ? lds_table : 0) + qbytes;
+    const size_t lds = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + qbytes;
     if (mode == VH_MODE_DENSE_PART) {
       const size_t wave_area = ((size_t)P.npart * ((size_t)P.stage_cap * P.tw * 8 + 12) + 15) / 16 * 16;
       vh_launch_scan_fast_part(P, grid, qbytes + 4 * wave_area, st);
@@ -1270,7 +1293,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     VhMergeArgs A{};
     A.nmetric = P.nmetric; A.nxcd = nxcd; A.G = G; A.xcd_stride = P.xcd_stride; A.present = P.present;
     A.present_carrier = P.present_carrier;
-    for (int j = 0; j < P.nmetric; ++j) { A.state[j] = P.m[j].state; A.sop[j] = P.m[j].sop; }
+    for (int j = 0; j < P.nmetric; ++j) { A.state[j] = P.m[j].state; A.sop[j] = P.m[j].sop(); }
     hipLaunchKernelGGL(dense_merge_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, A);
     HIP_TRY(hipGetLastError());
   }
@@ -1289,7 +1312,7 @@ extern "C" int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs, in
   if (!(r->mode == VH_MODE_DENSE_GLOBAL && P.present_carrier >= 0)) bufs[n++] = vh_device_buffer{P.present, P.G, VH_U8, VH_RED_MAX};
   for (int j = 0; j < P.nmetric; ++j) {
     vh_device_buffer b{P.m[j].state, P.G, 0, VH_RED_SUM};
-    switch (P.m[j].sop) {
+    switch (P.m[j].sop()) {
       case SOP_ADD32: b.elem = VH_U32; break;
       case SOP_ADD64: case SOP_ADD32P: b.elem = VH_U64; break;
       case SOP_ADDF32: b.elem = VH_F32; break;
@@ -1354,7 +1377,7 @@ extern "C" int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part
   size_t bytes = 0;
   std::vector<size_t> off(ncols);
   for (int c = 0; c < ncols; ++c) {
-    const int elem = c < P.ngroup ? P.g[c].type : r->metric_elem[order[c - P.ngroup]];
+    const int elem = c < P.ngroup ? P.g[c].type() : r->metric_elem[order[c - P.ngroup]];
     A.esize[c] = (uint32_t)vh_elem_size(elem);
     A.src[c] = c < P.ngroup ? r->d_out_key[c] : r->d_out_state[order[c - P.ngroup]];
     off[c] = bytes;
@@ -1387,11 +1410,11 @@ extern "C" int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part
   for (uint32_t p = 0; p <= nparts; ++p) part_offsets[p] = offs[p];
   for (int c = 0; c < ncols; ++c) {
     vh_device_buffer b{A.dst[c], ng, 0, -1};
-    if (c < P.ngroup) b.elem = P.g[c].type;
+    if (c < P.ngroup) b.elem = P.g[c].type();
     else {
       const int u = order[c - P.ngroup];
       b.elem = r->metric_elem[u];
-      switch (P.m[u].sop) {
+      switch (P.m[u].sop()) {
         case SOP_MIN_I32: case SOP_MIN_U32: case SOP_MIN_I64: case SOP_MIN_U64: case SOP_MIN_F32: case SOP_MIN_F64: b.reduce = VH_RED_MIN; break;
         case SOP_MAX_I32: case SOP_MAX_U32: case SOP_MAX_I64: case SOP_MAX_U64: case SOP_MAX_F32: case SOP_MAX_F64: b.reduce = VH_RED_MAX; break;
         default: b.reduce = VH_RED_SUM; break;
@@ -1415,11 +1438,11 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   A.out_count = r->d_out_count;
   for (int i = 0; i < P.ngroup; ++i) {
     A.glo[i] = P.g[i].lo; A.gextent[i] = P.g[i].extent; A.gstride[i] = P.g[i].stride;
-    A.gtype[i] = P.g[i].type; A.gkey_word[i] = P.g[i].key_word; A.gkey_shift[i] = P.g[i].key_shift;
+    A.gtype[i] = P.g[i].type(); A.gkey_word[i] = P.g[i].key_word(); A.gkey_shift[i] = P.g[i].key_shift();
     A.out_key[i] = r->d_out_key[i];
   }
   for (int j = 0; j < P.nmetric; ++j) {
-    A.state[j] = P.m[j].state; A.out_state[j] = r->d_out_state[j]; A.sop[j] = P.m[j].sop; A.mtype[j] = (uint8_t)r->metric_elem[j];
+    A.state[j] = P.m[j].state; A.out_state[j] = r->d_out_state[j]; A.sop[j] = P.m[j].sop(); A.mtype[j] = (uint8_t)r->metric_elem[j];
   }
   A.nhaving = r->nhaving;
   A.total_groups = P.counters + 6;
@@ -1446,7 +1469,7 @@ static int result_finalize_locked(vh_result* r, int* retry) {
     C.ncols = P.ngroup + P.nmetric;
     // formatter rounding ("%.15g" / "%g") can make nearby values compare equal in the reference: keep a margin
     C.slack = r->topk_cls == VH_TOPK_FLOAT ? (r->topk_elem == VH_F32 ? (256ull << 32) : 64ull) : 0ull;
-    for (int i = 0; i < P.ngroup; ++i) { C.src[i] = r->d_out_key[i]; C.dst[i] = r->d_out_key2[i]; C.esize[i] = (uint32_t)vh_elem_size(P.g[i].type); }
+    for (int i = 0; i < P.ngroup; ++i) { C.src[i] = r->d_out_key[i]; C.dst[i] = r->d_out_key2[i]; C.esize[i] = (uint32_t)vh_elem_size(P.g[i].type()); }
     for (int j = 0; j < P.nmetric; ++j) {
       C.src[P.ngroup + j] = r->d_out_state[j]; C.dst[P.ngroup + j] = r->d_out_state2[j];
       C.esize[P.ngroup + j] = (uint32_t)vh_elem_size(r->metric_elem[j]);
@@ -1487,7 +1510,7 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   if (!one_shot && ng) {
     for (int i = 0; i < P.ngroup; ++i)
       HIP_TRY(hipMemcpyAsync(H + r->off_key[i], r->topk_active ? (const char*)r->d_out_key2[i] : D + r->off_key[i],
-                             ng * vh_elem_size(P.g[i].type), hipMemcpyDeviceToHost, st));
+                             ng * vh_elem_size(P.g[i].type()), hipMemcpyDeviceToHost, st));
     for (int j = 0; j < P.nmetric; ++j)
       HIP_TRY(hipMemcpyAsync(H + r->off_state[j], r->topk_active ? (const char*)r->d_out_state2[j] : D + r->off_state[j],
                              ng * vh_elem_size(r->metric_elem[j]), hipMemcpyDeviceToHost, st));
