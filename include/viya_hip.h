@@ -292,6 +292,18 @@ VH_API int vh_result_finalize(vh_result* r);
  * -1, of a metric the operator that merges two partial states. part_offsets: nparts + 1. */
 VH_API int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part_offsets,
                                vh_device_buffer* bufs, int32_t max_bufs, int32_t* nbufs);
+/* Count-distinct across GPUs: a rank's partial for a bitset metric is the SET of distinct
+ * (group, id) pairs it saw ("(group,value) pairs take the same route;
+ * distinct-count is finalised on the owner"). Returns, for plan metric `metric`, the pairs as
+ * the group's key columns + an id column (u32 / u64), regrouped by the owner of the GROUP
+ * (the same function as vh_result_partition). The owner loads what it receives with
+ * vh_segment_sync (key columns, device addresses) + vh_segment_sync_ids_device (one id per
+ * row) and runs the aggregate query again: its count-distinct is the merged cardinality. */
+VH_API int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t nparts,
+                                     uint64_t* part_offsets, vh_device_buffer* bufs,
+                                     int32_t max_bufs, int32_t* nbufs);
+VH_API int vh_segment_sync_ids_device(vh_table* t, uint32_t seg, int32_t col, uint64_t nrows,
+                                      const void* d_ids);
 
 /* ---- the other two FilterBasedQuery kinds on the same scan ------------
  *

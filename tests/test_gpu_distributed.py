@@ -44,11 +44,11 @@ WORKER = textwrap.dedent('''
 def test_one_rank_rccl(tmp_path):
     """The same flow through the nccl (= RCCL) backend with a single rank: dtype views, in-place reduce on the
     library's buffers and the all-to-all of the hash path go through RCCL itself (this box has one GPU)."""
-    for wl, flags in (("C3", 0), ("C5t", 0)):
+    for wl, flags in (("C3", 0), ("C5t", 0), ("C5", 0)):
         _run(tmp_path, wl, flags, "nccl", 1)
 
 
-@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 64), ("C2", 0), ("C2", 2), ("C1", 0), ("C3", 1), ("C5t", 0)])
+@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 64), ("C2", 0), ("C2", 2), ("C1", 0), ("C3", 1), ("C5t", 0), ("C5", 0)])
 def test_two_ranks_one_gpu(tmp_path, wl, flags):
     _run(tmp_path, wl, flags, "gloo", 2)
 

@@ -128,6 +128,8 @@ SYMBOLS = {
     "vh_result_device_buffers": (C.c_int, [_VP, C.POINTER(DeviceBuffer), C.c_int32, C.POINTER(C.c_int32)]),
     "vh_result_finalize": (C.c_int, [_VP]),
     "vh_result_partition": (C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(DeviceBuffer), C.c_int32, C.POINTER(C.c_int32)]),
+    "vh_result_partition_pairs": (C.c_int, [_VP, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(DeviceBuffer), C.c_int32, C.POINTER(C.c_int32)]),
+    "vh_segment_sync_ids_device": (C.c_int, [_VP, C.c_uint32, C.c_int32, C.c_uint64, _VP]),
     "vh_query_select": (C.c_int, [_VP, C.POINTER(SelectPlan), C.POINTER(_VP)]),
     "vh_rows_get_info": (C.c_int, [_VP, C.POINTER(RowsInfo)]),
     "vh_rows_view": (C.c_int, [_VP, C.POINTER(_VP)]),

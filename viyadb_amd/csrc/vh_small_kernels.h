@@ -475,6 +475,70 @@ __global__ __launch_bounds__(256) void select_emit_kernel(const VhPlanDev P, uin
   }
 }
 
+// Count-distinct across GPUs ("(group, value) pairs take the same route; distinct-count is finalised
+// on the owner"). A rank's partial for a bitset metric is not its cardinalities but the SET of distinct
+// (group, id) pairs it saw — the device-wide set the scan kernel filled. This kernel walks that set, turns the
+// group slot back into the group's key columns, and regroups the pairs by the SAME owner function as the groups
+// (partition_groups_kernel), so the owner of a group receives its states and its pairs.
+struct VhPairArgs {
+  int32_t mode, ngroup, key_words, wide;
+  uint64_t nslots;                 // capacity of the (group, id) set
+  uint64_t hcap;                   // hash mode: capacity of the group table (slot hcap = the reserved sentinel group)
+  const uint64_t* hkeys;
+  const uint64_t* dkeys; const uint32_t* dtags;
+  uint64_t glo[VH_MAX_GROUP], gextent[VH_MAX_GROUP], gstride[VH_MAX_GROUP];
+  uint32_t gkey_word[VH_MAX_GROUP], gkey_shift[VH_MAX_GROUP], gesize[VH_MAX_GROUP];
+  uint32_t nparts; int32_t pass;
+  void* dst[VH_MAX_GROUP + 1];     // key columns, then the id column (u32 / u64)
+  unsigned long long* counts; unsigned long long* cursors; const unsigned long long* offsets;
+};
+
+__global__ __launch_bounds__(256) void partition_pairs_kernel(const VhPairArgs A) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  bool have = false;
+  uint64_t gid = 0, id = 0;
+  if (i < A.nslots) {
+    if (A.wide) { have = A.dtags[i] == 2u; if (have) { gid = A.dkeys[2 * i]; id = A.dkeys[2 * i + 1]; } }
+    else { const uint64_t w = A.dkeys[i]; have = w != VH_HASH_EMPTY; gid = w >> 32; id = w & 0xFFFFFFFFull; }
+  }
+  uint64_t kv[VH_MAX_GROUP];
+  uint32_t owner = 0;
+  if (have) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (int c = 0; c < A.ngroup; ++c) {
+      uint64_t v;
+      if (A.mode == VH_MODE_HASH) {
+        uint64_t w = gid == A.hcap ? VH_HASH_EMPTY : A.hkeys[gid * A.key_words + A.gkey_word[c]];
+        v = w >> A.gkey_shift[c];
+      } else {
+        v = A.glo[c] + (gid / A.gstride[c]) % A.gextent[c];
+      }
+      if (A.gesize[c] < 8) v &= (1ull << (8 * A.gesize[c])) - 1ull;     // what the emitted column holds
+      kv[c] = v;
+      h = vh_splitmix64(h ^ v);
+    }
+    owner = (uint32_t)(h % A.nparts);
+  }
+  uint64_t pos = 0;
+  for (uint32_t p = 0; p < A.nparts; ++p) {
+    const uint64_t bal = __ballot(have && owner == p);
+    if (bal == 0) continue;
+    const int leader = __ffsll((unsigned long long)bal) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd((A.pass == 0 ? A.counts : A.cursors) + p, (unsigned long long)__popcll(bal));
+    base = __shfl(base, leader);
+    if (have && owner == p) pos = A.offsets ? A.offsets[p] + base + __popcll(bal & ((1ull << lane) - 1ull)) : 0;
+  }
+  if (A.pass == 0 || !have) return;
+  for (int c = 0; c < A.ngroup; ++c) vh_store_sized(A.dst[c], A.gesize[c], pos, kv[c]);
+  vh_store_sized(A.dst[A.ngroup], A.wide ? 8u : 4u, pos, id);
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(uint64_t* p, uint64_t n) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = i;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void fill_kernel(T* p, uint64_t n, T v) {
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = v;

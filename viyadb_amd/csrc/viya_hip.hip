@@ -328,6 +328,30 @@ extern "C" int vh_segment_sync_bitset(vh_table* t, uint32_t seg, int32_t col, ui
   return VH_OK;
 }
 
+// One id per row, ids already in HBM (exchanged (group, id) pairs on their owner): offsets are 0, 1, 2, ... n.
+extern "C" int vh_segment_sync_ids_device(vh_table* t, uint32_t seg, int32_t col, uint64_t nrows, const void* d_ids) {
+  if (!t || col < 0 || (size_t)col >= t->cols.size()) return vh_fail(VH_E_INVALID, "vh_segment_sync_ids_device: bad argument");
+  auto& c = t->cols[col];
+  if (!is_bitset_elem(c.elem)) return vh_fail(VH_E_INVALID, "column %d is not a bitset column", col);
+  if (nrows > t->segment_rows) return vh_fail(VH_E_INVALID, "nrows exceeds segment_rows");
+  std::lock_guard<std::mutex> lk(t->mu);
+  int rc = table_grow(t, seg + 1);
+  if (rc) return rc;
+  if (c.bs_offsets[seg]) { HIP_TRY(hipFree(c.bs_offsets[seg])); c.bs_offsets[seg] = nullptr; }
+  if (c.bs_values[seg]) { HIP_TRY(hipFree(c.bs_values[seg])); c.bs_values[seg] = nullptr; }
+  const size_t vsz = c.elem == VH_BITSET32 ? 4 : 8;
+  HIP_TRY(hipMalloc((void**)&c.bs_offsets[seg], (nrows + 1) * sizeof(uint64_t)));
+  HIP_TRY(hipMalloc((void**)&c.bs_values[seg], std::max<size_t>(nrows * vsz, 8)));
+  hipLaunchKernelGGL(iota_kernel, dim3((unsigned)std::min<uint64_t>((nrows + 256) / 256, 65535)), dim3(256), 0, g_ctx.stream,
+                     c.bs_offsets[seg], nrows + 1);
+  HIP_TRY(hipGetLastError());
+  if (nrows) HIP_TRY(hipMemcpyAsync(c.bs_values[seg], d_ids, nrows * vsz, hipMemcpyDefault, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  c.bs_nvalues[seg] = nrows;
+  t->nseg = std::max(t->nseg, seg + 1);
+  return VH_OK;
+}
+
 extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nseg, uint64_t rows_per_seg,
                                    uint64_t row_base, const vh_gen_spec* specs, uint64_t seed) {
   if (!t || !specs || !nseg) return vh_fail(VH_E_INVALID, "vh_segment_generate: bad argument");
@@ -489,7 +513,8 @@ struct vh_result {
   void* d_out_state2[VH_MAX_METRIC] = {};
   const char* zero_begin = nullptr; const char* zero_end = nullptr;   // scratch range cleared by the one state memset
   char* d_xchg = nullptr;              // vh_result_partition: rows regrouped by owner (own allocation)
-  ~vh_result() { if (d_xchg) (void)hipFree(d_xchg); }
+  std::vector<char*> d_pairs;          // vh_result_partition_pairs: one allocation per call
+  ~vh_result() { if (d_xchg) (void)hipFree(d_xchg); for (char* p : d_pairs) (void)hipFree(p); }
 };
 
 extern "C" void vh_result_free(vh_result* r) { delete r; }
@@ -1358,7 +1383,6 @@ extern "C" int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part
   if (!r || !part_offsets || !bufs || !nbufs) return vh_fail(VH_E_INVALID, "null argument");
   if (!r->finalized) return vh_fail(VH_E_INVALID, "result is not finalised");
   if (nparts == 0 || nparts > 64) return vh_fail(VH_E_INVALID, "nparts must be 1..64");
-  if (r->plan.nbitset) return vh_fail(VH_E_UNSUPPORTED, "count-distinct partials are cardinalities: they cannot be merged across GPUs");
   if (r->nhaving) return vh_fail(VH_E_UNSUPPORTED, "HAVING applies to merged groups: run the partial query without it");
   if (r->topk) return vh_fail(VH_E_UNSUPPORTED, "top-N applies to merged groups: run the partial query without it");
   std::lock_guard<std::mutex> lk(r->table->mu);
@@ -1417,12 +1441,80 @@ extern "C" int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part
       switch (P.m[u].sop()) {
         case SOP_MIN_I32: case SOP_MIN_U32: case SOP_MIN_I64: case SOP_MIN_U64: case SOP_MIN_F32: case SOP_MIN_F64: b.reduce = VH_RED_MIN; break;
         case SOP_MAX_I32: case SOP_MAX_U32: case SOP_MAX_I64: case SOP_MAX_U64: case SOP_MAX_F32: case SOP_MAX_F64: b.reduce = VH_RED_MAX; break;
+        case SOP_BITSET: b.reduce = -2; break;   // cardinalities do not merge: exchange the pairs (vh_result_partition_pairs)
         default: b.reduce = VH_RED_SUM; break;
       }
     }
     bufs[c] = b;
   }
   *nbufs = ncols;
+  return VH_OK;
+}
+
+// Count-distinct partials for the exchange: the distinct (group, id) pairs of bitset metric `metric` (index into the
+// plan's metrics), as key columns + an id column, regrouped by the owner of the GROUP (same function as
+// vh_result_partition). See partition_pairs_kernel.
+extern "C" int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t nparts, uint64_t* part_offsets,
+                                         vh_device_buffer* bufs, int32_t max_bufs, int32_t* nbufs) {
+  if (!r || !part_offsets || !bufs || !nbufs) return vh_fail(VH_E_INVALID, "null argument");
+  if (!r->finalized) return vh_fail(VH_E_INVALID, "result is not finalised");
+  if (nparts == 0 || nparts > 64) return vh_fail(VH_E_INVALID, "nparts must be 1..64");
+  if (metric < 0 || metric >= (int)r->user_metric.size()) return vh_fail(VH_E_INVALID, "metric %d is not in the plan", metric);
+  const VhPlanDev& P = r->plan;
+  const int dj = r->user_metric[metric];
+  if (P.m[dj].sop() != SOP_BITSET) return vh_fail(VH_E_INVALID, "metric %d is not a bitset (count-distinct) metric", metric);
+  const int b = (int)P.m[dj].slot();
+  if (max_bufs < P.ngroup + 1) return vh_fail(VH_E_INVALID, "need %d buffers", P.ngroup + 1);
+  if (r->mode != VH_MODE_HASH && r->nxcd != 1) return vh_fail(VH_E_UNSUPPORTED, "pairs of an XCD-private dense table");
+  std::lock_guard<std::mutex> lk(r->table->mu);
+  hipStream_t st = g_ctx.stream;
+  // number of pairs = sum of the emitted cardinalities would need a reduction; the set's fill count is counters[4],
+  // read back with the result header (h_base): every pair bumps it exactly once
+  const uint64_t npairs = reinterpret_cast<const unsigned long long*>(r->h_base)[4];
+  VhPairArgs A{};
+  A.mode = r->mode == VH_MODE_DENSE_PART ? VH_MODE_DENSE_GLOBAL : r->mode; A.ngroup = P.ngroup; A.key_words = P.key_words; A.wide = P.bs_wide[b];
+  A.nslots = P.dset_mask[b] + 1; A.hcap = P.hmask + 1; A.hkeys = P.hkeys;
+  A.dkeys = P.dset_keys[b]; A.dtags = P.dset_tags[b];
+  size_t bytes = 0;
+  std::vector<size_t> off(P.ngroup + 1);
+  for (int c = 0; c <= P.ngroup; ++c) {
+    const uint32_t es = c < P.ngroup ? (uint32_t)vh_elem_size(P.g[c].type()) : (A.wide ? 8u : 4u);
+    if (c < P.ngroup) {
+      A.glo[c] = P.g[c].lo; A.gextent[c] = P.g[c].extent; A.gstride[c] = P.g[c].stride;
+      A.gkey_word[c] = P.g[c].key_word(); A.gkey_shift[c] = P.g[c].key_shift(); A.gesize[c] = es;
+    }
+    off[c] = bytes;
+    bytes += ((size_t)std::max<uint64_t>(npairs, 1) * es + 255) / 256 * 256;
+  }
+  const size_t ctr_off = bytes;
+  bytes += 3 * 64 * sizeof(unsigned long long) + 8;
+  char* buf = nullptr;
+  HIP_TRY(hipMalloc((void**)&buf, bytes));
+  r->d_pairs.push_back(buf);
+  unsigned long long* ctr = reinterpret_cast<unsigned long long*>(buf + ctr_off);
+  HIP_TRY(hipMemsetAsync(ctr, 0, 3 * 64 * sizeof(unsigned long long) + 8, st));
+  for (int c = 0; c <= P.ngroup; ++c) A.dst[c] = buf + off[c];
+  A.nparts = nparts; A.counts = ctr; A.cursors = ctr + 64;
+  std::vector<unsigned long long> counts(nparts, 0), offs(nparts + 1, 0);
+  if (npairs) {
+    const unsigned grid = (unsigned)((A.nslots + 255) / 256);
+    A.pass = 0; A.offsets = nullptr;
+    hipLaunchKernelGGL(partition_pairs_kernel, dim3(grid), dim3(256), 0, st, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(counts.data(), ctr, nparts * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t p = 0; p < nparts; ++p) offs[p + 1] = offs[p] + counts[p];
+    if (offs[nparts] != npairs) return vh_fail(VH_E_DEVICE, "pair partition counted %llu of %llu pairs", offs[nparts], (unsigned long long)npairs);
+    HIP_TRY(hipMemcpyAsync(ctr + 128, offs.data(), (nparts + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+    A.pass = 1; A.offsets = ctr + 128;
+    hipLaunchKernelGGL(partition_pairs_kernel, dim3(grid), dim3(256), 0, st, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  for (uint32_t p = 0; p <= nparts; ++p) part_offsets[p] = offs[p];
+  for (int c = 0; c <= P.ngroup; ++c)
+    bufs[c] = vh_device_buffer{A.dst[c], npairs, c < P.ngroup ? (int32_t)P.g[c].type() : (A.wide ? VH_U64 : VH_U32), -1};
+  *nbufs = P.ngroup + 1;
   return VH_OK;
 }
 

@@ -66,8 +66,8 @@ def _merge_kind(kind: int) -> int:
     if kind == capi.METRIC_MIN:
         return capi.METRIC_MIN
     if kind == capi.METRIC_BITSET:
-        raise NotImplementedError("bitset (count-distinct) partials are cardinalities, not sets: they cannot be merged "
-                                  "(the reference's cluster path has the same limitation)")
+        raise NotImplementedError("bitset (count-distinct) partials are cardinalities, not sets: they merge through their "
+                                  "(group, id) pairs (exchange_hash_partials), not through host partials")
     return capi.METRIC_SUM
 
 
@@ -102,27 +102,26 @@ def merge_partials_by_reaggregation(table, plan, partials):
     return res
 
 
-def _merge_table(table, plan, has_hidden, rows, nseg):
-    """Temporary device table [group columns..., metric states..., hidden count] + the plan that re-aggregates it."""
+def _merge_table(table, plan, has_hidden, rows, nseg, metrics=None):
+    """Temporary device table [group columns..., metric states..., hidden count] + the plan that re-aggregates it.
+    `metrics`: indices into plan.metrics to carry (default: all)."""
     from .executor import AggPlan, DeviceTable, GroupSpec
-    nk, nm = len(plan.groups), len(plan.metrics)
+    nk = len(plan.groups)
+    metrics = list(range(len(plan.metrics))) if metrics is None else list(metrics)
     cols = [(capi.DIM_NUMERIC, table.cols[g.col][1]) for g in plan.groups]
-    cols += [(_merge_kind(table.cols[m][0]), table.cols[m][1]) for m in plan.metrics]
+    cols += [(_merge_kind(table.cols[plan.metrics[j]][0]), table.cols[plan.metrics[j]][1]) for j in metrics]
     if has_hidden:
         cols.append((capi.METRIC_SUM, capi.U64))
     tmp = DeviceTable(cols, segment_rows=max(int(rows), 1), reserve_segments=nseg)
     mplan = AggPlan(filter=[], groups=[GroupSpec(i) for i in range(nk)],
-                    metrics=list(range(nk, nk + nm + (1 if has_hidden else 0))))
+                    metrics=list(range(nk, nk + len(metrics) + (1 if has_hidden else 0))))
     return tmp, mplan
 
 
-def exchange_hash_partials(torch, dist, table, plan, handle, world: int, having=None):
-    """SURVEY 8(e), hash path: this rank's finalised groups are regrouped by owner = mix(key) % world in HBM
-    (vh_result_partition), every column is shipped with one all-to-all (RCCL grouped send/recv over xGMI), and
-    the owner merges what it received by re-aggregation on its own GPU, straight from the receive buffers
-    (vh_segment_sync takes device addresses). Returns this rank's OWNED groups (results stay sharded)."""
+def _all_to_all_columns(torch, dist, bufs, offs, world):
+    """Ship every column buffer (rows of owner p at [offs[p], offs[p+1])) with one all-to-all; -> (received uint8
+    device tensors, rows received)."""
     import numpy as np
-    offs, bufs = table.partition(handle, world)
     send = np.diff(offs.astype(np.int64))
     gloo = dist.get_backend() == "gloo"      # CPU test rig: gloo moves host tensors only
     send_t = torch.from_numpy(send.copy())
@@ -146,8 +145,39 @@ def exchange_hash_partials(torch, dist, table, plan, handle, world: int, having=
             dist.all_to_all_single(out, src, outs, ins)
         received.append(out)
     torch.cuda.current_stream().synchronize()
-    has_hidden = len(bufs) > len(plan.groups) + len(plan.metrics)
-    tmp, mplan = _merge_table(table, plan, has_hidden, nrecv, 1)
+    return received, nrecv
+
+
+def _row_keys(keys):
+    """Group-key columns -> one sortable record per row (bit patterns, so float keys compare exactly)."""
+    import numpy as np
+    if not keys:
+        return np.zeros(0, dtype=[("k0", np.uint64)])
+    n = len(keys[0])
+    rec = np.zeros(n, dtype=[("k%d" % i, np.uint64) for i in range(len(keys))])
+    for i, k in enumerate(keys):
+        rec["k%d" % i] = k.view(np.dtype("u%d" % k.dtype.itemsize)).astype(np.uint64)
+    return rec
+
+
+def exchange_hash_partials(torch, dist, table, plan, handle, world: int, having=None):
+    """SURVEY 8(e), hash path: this rank's finalised groups are regrouped by owner = mix(key) % world in HBM
+    (vh_result_partition), every column is shipped with one all-to-all (RCCL grouped send/recv over xGMI), and
+    the owner merges what it received by re-aggregation on its own GPU, straight from the receive buffers
+    (vh_segment_sync takes device addresses). Count-distinct metrics travel as their distinct (group, id) pairs
+    (vh_result_partition_pairs) to the same owner, which counts them again. Returns this rank's OWNED groups."""
+    import numpy as np
+    from .executor import DeviceTable
+    nk, nm = len(plan.groups), len(plan.metrics)
+    bitset_js = [j for j, m in enumerate(plan.metrics) if m != capi.COL_ROWID and table.cols[m][0] == capi.METRIC_BITSET]
+    plain_js = [j for j in range(nm) if j not in bitset_js]
+    if bitset_js and having:
+        raise NotImplementedError("HAVING over merged count-distinct values")
+    offs, bufs = table.partition(handle, world)
+    has_hidden = len(bufs) > nk + nm
+    keep = list(range(nk)) + [nk + j for j in plain_js] + ([nk + nm] if has_hidden else [])
+    received, nrecv = _all_to_all_columns(torch, dist, [bufs[i] for i in keep], offs, world)
+    tmp, mplan = _merge_table(table, plan, has_hidden, nrecv, 1, plain_js)
     try:
         if nrecv:
             tmp.sync_segment_device(0, [t.data_ptr() for t in received], nrecv)
@@ -160,6 +190,40 @@ def exchange_hash_partials(torch, dist, table, plan, handle, world: int, having=
     if has_hidden:
         res.hidden_count = res.states[-1]
         res.states = res.states[:-1]
+    if not bitset_js:
+        return res
+    # count-distinct: the owner re-counts the pairs it received
+    plain_states = res.states
+    states = [None] * nm
+    for j, s_ in zip(plain_js, plain_states):
+        states[j] = s_
+    mine = _row_keys(res.keys)
+    for j in bitset_js:
+        poffs, pbufs = table.partition_pairs(handle, j, world)
+        cols_recv, npairs = _all_to_all_columns(torch, dist, pbufs, poffs, world)
+        wide = pbufs[-1][2] == capi.U64
+        pcols = [(capi.DIM_NUMERIC, table.cols[g.col][1]) for g in plan.groups] + \
+                [(capi.METRIC_BITSET, capi.BITSET64 if wide else capi.BITSET32)]
+        ptab = DeviceTable(pcols, segment_rows=max(npairs, 1), reserve_segments=1)
+        try:
+            card = np.zeros(len(mine), dtype=np.uint64)
+            if npairs:
+                ptab.sync_segment_device(0, [t.data_ptr() for t in cols_recv[:nk]] + [None], npairs)
+                ptab.sync_ids_device(0, nk, npairs, cols_recv[nk].data_ptr())
+                from .executor import AggPlan, GroupSpec
+                pres = ptab.query_agg(AggPlan(filter=[], groups=[GroupSpec(i) for i in range(nk)], metrics=[nk], groups_hint=len(mine)))
+                theirs = _row_keys(pres.keys)
+                _, inv = np.unique(np.concatenate([mine, theirs]), return_inverse=True)   # join on the key columns
+                lookup = np.full(int(inv.max()) + 1, -1, dtype=np.int64)
+                lookup[inv[:len(mine)]] = np.arange(len(mine))
+                pos = lookup[inv[len(mine):]]
+                if (pos < 0).any():
+                    raise RuntimeError("count-distinct pairs arrived for a group this rank does not own")
+                card[pos] = pres.states[0]
+            states[j] = card
+        finally:
+            ptab.close()
+    res.states = states
     return res
 
 

@@ -351,6 +351,20 @@ class DeviceTable:
         return (np.array(list(offs), dtype=np.uint64),
                 [(bufs[i].ptr, bufs[i].count, bufs[i].elem, bufs[i].reduce) for i in range(n.value)])
 
+    def partition_pairs(self, res, metric: int, nparts: int):
+        """Distinct (group, id) pairs of bitset metric `metric`, regrouped by the group's owner:
+        -> (offsets[nparts + 1], [(device ptr, pairs, elem, -1)]) : key columns, then the id column."""
+        offs = (C.c_uint64 * (nparts + 1))()
+        bufs = (capi.DeviceBuffer * 16)()
+        n = C.c_int32()
+        capi.check(self.lib.vh_result_partition_pairs(res, int(metric), nparts, offs, bufs, 16, C.byref(n)))
+        return (np.array(list(offs), dtype=np.uint64),
+                [(bufs[i].ptr, bufs[i].count, bufs[i].elem, bufs[i].reduce) for i in range(n.value)])
+
+    def sync_ids_device(self, seg: int, col: int, nrows: int, ptr: Optional[int]):
+        """A bitset column holding ONE id per row, ids at a device address (see vh_segment_sync_ids_device)."""
+        capi.check(self.lib.vh_segment_sync_ids_device(self.handle, seg, col, int(nrows), ptr or None))
+
     def sync_segment_device(self, seg: int, ptrs: Sequence[Optional[int]], nrows: int):
         """vh_segment_sync with DEVICE source addresses (one per column, None = leave untouched)."""
         arr = (C.c_void_p * len(self.cols))()
