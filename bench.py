@@ -64,6 +64,29 @@ def cpu_baseline(w, sample_segments: int):
             "cpu": _cpu_model()}
 
 
+def cpu_baseline_parallel(w, seconds: float = 3.0, segments_per_worker: int = 2):
+    """Courtesy baseline #2 of SURVEY 8(d) — NOT reference behaviour (the reference runs a query on one thread): the
+    same emitted loop, segment-parallel, one process per core, each over its own segments inside a common window."""
+    import subprocess
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = max(1, min(cores, 64))
+    start = time.time() + 20.0 + 0.05 * workers          # generation of the shards happens before the window opens
+    procs = [subprocess.Popen([sys.executable, "-m", "oracle.parallel_worker", w.name, str(segments_per_worker),
+                               str(i * segments_per_worker), repr(start), repr(seconds)], cwd=ROOT, stdout=subprocess.PIPE,
+                              stderr=subprocess.DEVNULL, text=True) for i in range(workers)]
+    rows, ok = 0, 0
+    for p in procs:
+        out, _ = p.communicate(timeout=180)
+        try:
+            d = json.loads(out.strip().splitlines()[-1])
+            rows += d["rows"]
+            ok += 1
+        except Exception:
+            pass
+    return {"value": rows / seconds if ok else None, "unit": "rows/s", "cores": ok, "kind": "port, segment-parallel (not reference behaviour)",
+            "sample": "%d processes x %d segments of %s, all running the emitted loop for the same %.0f s window" % (ok, segments_per_worker, w.name, seconds)}
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -84,6 +107,7 @@ def main():
     ap.add_argument("--segment-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-segments", type=int, default=40)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-parallel", action="store_true", help="also time the courtesy all-cores CPU baseline (adds ~30 s)")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--check", action="store_true", help="verify the result against the CPU twin on the sample")
     args = ap.parse_args()
@@ -105,7 +129,7 @@ def main():
     executor.init(local_rank, stream=torch.cuda.current_stream().cuda_stream)
 
     w = synth.WORKLOADS[args.workload](segment_rows=args.segment_rows)
-    total_segments = args.segments or {"C1": 10, "C2": 100, "C3": 1000}[args.workload]
+    total_segments = args.segments or {"C1": 10, "C2": 100, "C3": 1000, "C5t": 100, "C5": 100}[args.workload]
     # contiguous block of segments per rank; global row ids are preserved
     seg_lo, seg_hi = distributed.shard_segments(total_segments, rank, world)
     my_segments = seg_hi - seg_lo
@@ -185,6 +209,11 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(w, min(args.cpu_segments, total_segments))
             except Exception as e:  # the CPU leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "rows/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+            if args.cpu_parallel:
+                try:
+                    out["cpu_baseline_all_cores"] = cpu_baseline_parallel(w)
+                except Exception as e:
+                    out["cpu_baseline_all_cores"] = {"value": None, "sample": "failed: %r" % (e,)}
         print(json.dumps(out), flush=True)
     table.close()
     if world > 1:
