@@ -378,3 +378,6 @@ def test_lanes_kernel_matches_oracle(typed, dims, metrics, eligible):
         assert not res.lanes
         res, _ = run(tab, dt, q)                  # by the selectivity probe
         assert res.lanes == (eligible and flt is many)
+    # no filter at all: every row passes, no predicate column is loaded, still the register-resident kernels
+    res, _ = run(tab, dt, {"dimensions": dims, "metrics": metrics})
+    assert res.fast and res.lanes == eligible

@@ -892,10 +892,11 @@ __device__ __forceinline__ void vh_preload(const VhPlanDev& P, uint32_t seg, uin
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const uint32_t* col = reinterpret_cast<const uint32_t*>(P.colbase[P.pred_slot[p]] + (uint64_t)seg * P.colstride[P.pred_slot[p]]);
+    const bool used = p < P.npred;     // a filter-less query runs the NP = 1 instantiation and loads nothing here
 #pragma unroll
     for (int k = 0; k < VH_SUBSTEPS; ++k) {
       const uint32_t r = row_l + k * 256u;
-      if (r < seg_rows) {
+      if (used && r < seg_rows) {
         vh_load4<uint32_t>(col + r, &v[p][k * 4]);
       } else {
         v[p][k * 4] = v[p][k * 4 + 1] = v[p][k * 4 + 2] = v[p][k * 4 + 3] = 0u;

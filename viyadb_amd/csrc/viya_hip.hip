@@ -995,10 +995,11 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   } else {
     mode = VH_MODE_HASH;
   }
-  const bool fast = fast_ok && P.npred >= 1 && P.ngroup <= VH_FAST_COLS && P.nmetric <= VH_FAST_COLS && P.nbitset == 0;
+  const bool fast = fast_ok && P.ngroup <= VH_FAST_COLS && P.nmetric <= VH_FAST_COLS && P.nbitset == 0;   // npred == 0: no filter
   // selectivity of the filter, from a one-launch probe; it only depends on the filter and the rows, so it is cached
   // until the table changes
   auto probed_selectivity = [&](double* sel) -> int {
+    if (p->nfilter == 0) { *sel = 1.0; return VH_OK; }   // no filter: every row passes
     std::string key((const char*)P.prog, sizeof(VhProgOp) * P.nprog);
     key.append((const char*)P.lits, sizeof(uint64_t) * std::max(p->nlits, 0));
     key += "|" + std::to_string(nseg) + "|" + std::to_string(rows_to_scan) + "|" + std::to_string(t->sync_epoch);
