@@ -381,3 +381,29 @@ def test_lanes_kernel_matches_oracle(typed, dims, metrics, eligible):
     # no filter at all: every row passes, no predicate column is loaded, still the register-resident kernels
     res, _ = run(tab, dt, {"dimensions": dims, "metrics": metrics})
     assert res.fast and res.lanes == eligible
+
+
+@pytest.mark.parametrize("sel,eligible", [
+    ([{"column": "ts", "granularity": "day"}, {"column": "count"}, {"column": "long_sum"}], True),
+    ([{"column": "uts", "granularity": "month"}, {"column": "double_max"}], True),
+    ([{"column": "d_float"}, {"column": "count"}, {"column": "float_min"}], True),
+    ([{"column": "ts", "granularity": "hour"}, {"column": "d_uint"}, {"column": "int_sum"}, {"column": "ulong_max"}], True),
+    ([{"column": "d_double"}, {"column": "d_int"}, {"column": "count"}], False),          # 96-bit key: two words, no LDS front table
+    ([{"column": "ts", "granularity": "day"}, {"column": "flag"}, {"column": "count"}], False)])   # 1-byte group column
+def test_lanes_kernel_on_the_hash_path(typed, sel, eligible):
+    """Time buckets / float keys with most rows passing: the no-compaction kernel over the LDS front table, rows that
+    find no LDS slot falling through to the HBM table; against the oracle, forced on, forced off, and by the probe."""
+    tab, dt = typed
+    many, few = F("ge", "d_int", "-30"), F("lt", "d_uint", "3")
+    for flt in (many, few, None):
+        q = {"select": sel}
+        if flt:
+            q["filter"] = flt
+        res, st = run(tab, dt, q, flags=256)
+        small = st.ngroups <= 2000      # the host skips the front table once it has seen far more groups than it holds
+        assert res.path == "hash" and (res.lanes == eligible or not small), sel
+        assert not run(tab, dt, q, flags=128)[0].lanes
+        assert not run(tab, dt, q, flags=512)[0].lanes        # no LDS front table -> nothing for the lanes kernel to use
+        res = run(tab, dt, q)[0]         # probe-driven: only when (nearly) every row passes; 75 % is too close to call
+        if small and flt is not many:
+            assert res.lanes == (eligible and flt is None)

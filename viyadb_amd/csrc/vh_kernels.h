@@ -1198,26 +1198,32 @@ __device__ __forceinline__ void vh_load_rows4(const char* base, int type, uint32
   }
 }
 
-template <int SCOPE, int NP>
-__global__ __launch_bounds__(1024) void scan_agg_lanes_kernel(const VhPlanDev P) {
+template <int MODE, int BLOCK, int SCOPE, int NP>
+__global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P) {
+  // MODE = VH_MODE_DENSE_LDS: direct-indexed LDS table. MODE = VH_MODE_HASH: the LDS front table (time buckets,
+  // float keys, ...), rows that find no slot there go to the HBM table — same rules as the compacting kernel.
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  constexpr int BLOCK = 1024;
   typedef VhScanCfg<BLOCK> C;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  for (int j = 0; j < P.nmetric; ++j) {
-    const VhMetricDev& m = P.m[j];
-    const uint64_t ident = m.ident;
-    if (vh_sop_bytes(m.sop()) == 4) {
-      for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)ident;
-    } else {
-      for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = ident;
+  if (MODE == VH_MODE_HASH) {
+    vh_lds_hash_init(P, lds, BLOCK);
+  } else {
+    for (int j = 0; j < P.nmetric; ++j) {
+      const VhMetricDev& m = P.m[j];
+      const uint64_t ident = m.ident;
+      if (vh_sop_bytes(m.sop()) == 4) {
+        for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)ident;
+      } else {
+        for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = ident;
+      }
     }
+    for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
+    __syncthreads();
   }
-  for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
-  __syncthreads();
 
-  unsigned long long npassed = 0;
+  unsigned long long npassed = 0, nfresh = 0;
+  uint32_t lane_hits = 0, lane_misses = 0;     // HASH: this lane's luck with the LDS front table
   const uint32_t spu = P.unit_rows / C::kStepRows;
   uint32_t t = 0, seg = 0, unit_base = 0, wave_base = 0, seg_rows = 0;
   bool have;
@@ -1233,7 +1239,7 @@ __global__ __launch_bounds__(1024) void scan_agg_lanes_kernel(const VhPlanDev P)
   }
   uint32_t v[NP][16];
   if (have) vh_preload<NP>(P, seg, wave_base + lane * 4, seg_rows, v);
-  bool range_err = false;
+  bool range_err = false, full_err = false;
   while (have) {
     const uint32_t row_l = wave_base + lane * 4;
     const uint32_t mask = vh_eval_filter_fast<NP>(P, v, row_l, seg_rows);
@@ -1262,7 +1268,7 @@ __global__ __launch_bounds__(1024) void scan_agg_lanes_kernel(const VhPlanDev P)
         gv[i][0] = gv[i][1] = gv[i][2] = gv[i][3] = 0;
         if (i < P.ngroup && mk) {     // mk == 0 also covers rows at or beyond size(): nothing is loaded out of bounds
           const VhGroupDev& g = P.g[i];
-          vh_load_rows4(P.colbase[g.slot()] + (uint64_t)seg * P.colstride[g.slot()], g.type(), r0, true, gv[i]);
+          vh_load_rows4(P.colbase[g.slot()] + (uint64_t)seg * P.colstride[g.slot()], g.type(), r0, MODE != VH_MODE_HASH, gv[i]);
         }
       }
 #pragma unroll
@@ -1276,29 +1282,66 @@ __global__ __launch_bounds__(1024) void scan_agg_lanes_kernel(const VhPlanDev P)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (!((mk >> r) & 1u)) continue;
-        uint64_t gid = 0;
-        bool bad = false;
+        if (MODE == VH_MODE_HASH) {
+          uint64_t key = 0;
 #pragma unroll
-        for (int i = 0; i < VH_LANES_COLS; ++i) {
-          if (i < P.ngroup) {
-            const VhGroupDev& g = P.g[i];
-            const uint64_t d = gv[i][r] - g.lo;
-            bad |= d >= g.extent;
-            gid += d * g.stride;
+          for (int i = 0; i < VH_LANES_COLS; ++i) {
+            if (i < P.ngroup) {
+              const VhGroupDev& g = P.g[i];
+              uint64_t x = gv[i][r];
+              if (g.gran() != VH_T_NONE || g.nroll()) x = vh_time_rollup(x, g);
+              if (g.type() == VH_F32 && (uint32_t)x == 0x80000000u) x = 0;            // -0.0f == 0.0f
+              if (g.type() == VH_F64 && x == 0x8000000000000000ull) x = 0;
+              key |= x << g.key_shift();
+            }
           }
-        }
-        if (bad) { range_err = true; continue; }
-        reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[gid] = 1;
+          uint32_t ls = 0;
+          const bool bypass = lane_hits + lane_misses >= 64u && lane_misses > lane_hits;
+          if (!bypass && key != VH_HASH_EMPTY && vh_lds_hash_find(P, lds, key, ls)) {
+            ++lane_hits;
 #pragma unroll
-        for (int j = 0; j < VH_LANES_COLS; ++j)
-          if (j < P.nmetric) vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + P.m[j].lds_off, gid, P.m[j].sop(), mv[j][r]);
+            for (int j = 0; j < VH_LANES_COLS; ++j)
+              if (j < P.nmetric) vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + P.m[j].lds_off, ls, P.m[j].sop(), mv[j][r]);
+          } else {
+            ++lane_misses;
+            bool ok = true, fresh = false;
+            const uint64_t gid = vh_hash_insert64(P, key, ok, fresh);
+            if (!ok) { full_err = true; continue; }
+            nfresh += fresh ? 1 : 0;
+#pragma unroll
+            for (int j = 0; j < VH_LANES_COLS; ++j)
+              if (j < P.nmetric) vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(P.m[j].state, gid, P.m[j].sop(), mv[j][r]);
+          }
+        } else {
+          uint64_t gid = 0;
+          bool bad = false;
+#pragma unroll
+          for (int i = 0; i < VH_LANES_COLS; ++i) {
+            if (i < P.ngroup) {
+              const VhGroupDev& g = P.g[i];
+              const uint64_t d = gv[i][r] - g.lo;
+              bad |= d >= g.extent;
+              gid += d * g.stride;
+            }
+          }
+          if (bad) { range_err = true; continue; }
+          reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[gid] = 1;
+#pragma unroll
+          for (int j = 0; j < VH_LANES_COLS; ++j)
+            if (j < P.nmetric) vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + P.m[j].lds_off, gid, P.m[j].sop(), mv[j][r]);
+        }
       }
     }
     have = nhave; seg = nseg; unit_base = nunit_base; wave_base = nwave_base; seg_rows = nseg_rows;
   }
   if (__ballot(range_err)) { if (range_err) atomicOr(P.counters + 2, VH_ERR_RANGE); }
-  for (int off = 32; off > 0; off >>= 1) npassed += __shfl_down(npassed, off);
-  if (lane == 0 && npassed) atomicAdd(P.counters + 0, npassed);
+  if (__ballot(full_err)) { if (full_err) atomicOr(P.counters + 2, VH_ERR_HASH_FULL); }
+  for (int off = 32; off > 0; off >>= 1) { npassed += __shfl_down(npassed, off); nfresh += __shfl_down(nfresh, off); }
+  if (lane == 0) {
+    if (npassed) atomicAdd(P.counters + 0, npassed);
+    if (nfresh) atomicAdd(P.counters + 1, nfresh);
+  }
+  if (MODE == VH_MODE_HASH) { vh_lds_hash_flush(P, lds, BLOCK); return; }
   __syncthreads();
   const uint64_t xo = P.nxcd > 1 ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;
   for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) {
@@ -1307,7 +1350,7 @@ __global__ __launch_bounds__(1024) void scan_agg_lanes_kernel(const VhPlanDev P)
     for (int j = 0; j < P.nmetric; ++j) {
       const VhMetricDev& m = P.m[j];
       const uint64_t bits = vh_sop_bytes(m.sop()) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
-                                                     : reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
+                                                       : reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
       vh_state_update<SCOPE>(m.state, xo + g, m.sop(), bits);
     }
   }

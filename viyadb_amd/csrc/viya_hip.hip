@@ -1134,6 +1134,24 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
         P.lds_bytes = (uint32_t)lds_table;
       }
     }
+    // the no-compaction kernel over the LDS front table (time-bucket GROUP BYs over most of the data)
+    if (P.lds_hash_slots && fast && !(p->flags & VH_PLAN_NO_LANES) && P.ngroup >= 1 && P.ngroup <= VH_LANES_COLS &&
+        P.nmetric <= VH_LANES_COLS && rows_to_scan) {
+      bool ok = true;
+      for (int i = 0; i < P.ngroup; ++i) ok &= vh_elem_size(P.g[i].type()) >= 4;
+      for (int j = 0; j < P.nmetric; ++j) ok &= P.m[j].slot() != VH_SLOT_ROWID && vh_elem_size(P.m[j].type()) >= 4;
+      if (ok) {
+        if (p->flags & VH_PLAN_FORCE_LANES) lanes = true;
+        else {
+          double sel = 0;
+          rc = probed_selectivity(&sel);
+          if (rc) { delete r; return rc; }
+          // per-row work here is heavy (calendar arithmetic, LDS probe) and runs once per ROW SLOT, passing or not:
+          // measured on 100 M rows into day buckets, 50 % pass: 1.05 ms compacted vs 1.38 ms lanes; 100 %: 2.29 vs 1.92
+          lanes = sel >= 0.7;
+        }
+      }
+    }
   }
 
   // ---------------- work decomposition
@@ -1308,6 +1326,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       vh_launch_part_agg(P, bpp, lds_table, st);
     }
     else if (!fast) vh_launch_scan_generic(mode, P, grid, lds, nxcd > 1, st);
+    else if (lanes && mode == VH_MODE_HASH) vh_launch_scan_lanes_hash(P, grid, lds, st);
     else if (lanes) vh_launch_scan_lanes_lds(P, grid, lds, nxcd > 1, st);
     else if (mode == VH_MODE_DENSE_LDS) vh_launch_scan_fast_lds(P, grid, lds, nxcd > 1, st);
     else if (mode == VH_MODE_DENSE_GLOBAL) vh_launch_scan_fast_global(P, grid, lds, nxcd > 1, st);
