@@ -402,7 +402,7 @@ __device__ __forceinline__ uint64_t vh_hash_insert_wide(const VhPlanDev& P, cons
 
 // COUNT DISTINCT: insert every id of the row's set into metric b's (group, id) set; first sight bumps card[gid]
 __device__ __forceinline__ void vh_distinct_update(const VhPlanDev& P, int b, unsigned long long* card, uint64_t gid,
-                                                   uint32_t seg, uint32_t row) {
+                                                   uint32_t seg, uint32_t row, unsigned long long& npairs) {
   const uint64_t* offs = P.bs_offs[b][seg];
   const uint64_t o0 = offs[row], o1 = offs[row + 1];
   const void* vals = P.bs_vals[b][seg];
@@ -416,7 +416,7 @@ __device__ __forceinline__ void vh_distinct_update(const VhPlanDev& P, int b, un
       vh_set_insert64(P.dset_keys[b], P.dset_mask[b], 4096u, key, ok, fresh);
     }
     if (!ok) atomicOr(P.counters + 2, VH_ERR_HASH_FULL);
-    if (fresh) { atomicAdd(card + gid, 1ull); atomicAdd(P.counters + 4, 1ull); }
+    if (fresh) { atomicAdd(card + gid, 1ull); ++npairs; }   // pairs are totalled per lane: one hot-spot atomic per wave, not per pair
   }
 }
 
@@ -431,7 +431,7 @@ enum { VH_MODE_DENSE_LDS = 1, VH_MODE_DENSE_GLOBAL = 2, VH_MODE_HASH = 3, VH_MOD
 // therefore keeps a small open-addressing table in LDS; a row whose key finds (or claims) a slot there costs LDS
 // atomics only, everything else falls through to the HBM table. A wave that mostly falls through (high-cardinality
 // keys: the table fills up at once) stops probing LDS after a warm-up.
-struct VhLdsHashWave { uint32_t hits, misses; bool bypass; };
+struct VhLdsHashWave { uint32_t hits, misses; bool bypass; unsigned long long npairs; /* per lane: fresh (group, id) pairs */ };
 
 __device__ __forceinline__ bool vh_lds_hash_find(const VhPlanDev& P, char* lds, uint64_t key, uint32_t& slot_out) {
   unsigned long long* lk = reinterpret_cast<unsigned long long*>(lds + P.lds_hkeys_off);
@@ -545,7 +545,7 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
   for (int j = 0; j < P.nmetric; ++j) {
     const VhMetricDev& m = P.m[j];
     if (m.sop() == SOP_BITSET) {   // slot() is the bitset index, m.state the u64 cardinality per group
-      if (active) vh_distinct_update(P, m.slot(), reinterpret_cast<unsigned long long*>(m.state), MODE == VH_MODE_HASH ? gid : xoff + gid, seg, row);
+      if (active) vh_distinct_update(P, m.slot(), reinterpret_cast<unsigned long long*>(m.state), MODE == VH_MODE_HASH ? gid : xoff + gid, seg, row, H.npairs);
       continue;
     }
     uint64_t bits;
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
   // queues live behind the (optional) LDS aggregate table
   uint32_t* q = reinterpret_cast<uint32_t*>(lds + ((MODE == VH_MODE_DENSE_LDS || MODE == VH_MODE_HASH) ? P.lds_bytes : 0)) +
                 wave * C::kQueueCap;
-  VhLdsHashWave H{0u, 0u, false};
+  VhLdsHashWave H{0u, 0u, false, 0ull};
   if (MODE == VH_MODE_HASH && P.lds_hash_slots) vh_lds_hash_init(P, lds, BLOCK);
 
   if (MODE == VH_MODE_DENSE_LDS) {
@@ -655,10 +655,11 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
   }
 
   // wave totals -> one atomic per wave
-  for (int off = 32; off > 0; off >>= 1) npassed += __shfl_down(npassed, off);
+  for (int off = 32; off > 0; off >>= 1) { npassed += __shfl_down(npassed, off); H.npairs += __shfl_down(H.npairs, off); }
   if (lane == 0) {
     if (npassed) atomicAdd(P.counters + 0, npassed);
     if (nfresh) atomicAdd(P.counters + 1, nfresh);
+    if (H.npairs) atomicAdd(P.counters + 4, H.npairs);
   }
   if (MODE == VH_MODE_HASH && P.lds_hash_slots) vh_lds_hash_flush(P, lds, BLOCK);
 
@@ -1061,7 +1062,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   uint32_t* q = reinterpret_cast<uint32_t*>(lds + ((MODE == VH_MODE_DENSE_LDS || MODE == VH_MODE_HASH) ? P.lds_bytes : 0)) + wave * C::kQueueCap;
-  VhLdsHashWave H{0u, 0u, false};
+  VhLdsHashWave H{0u, 0u, false, 0ull};
   if (MODE == VH_MODE_HASH && P.lds_hash_slots) vh_lds_hash_init(P, lds, BLOCK);
   VhPartWave W;
   if (MODE == VH_MODE_DENSE_PART) {
