@@ -109,3 +109,24 @@ def test_dense_partials_are_one_collective_for_c3():
         t.discard(res)
     finally:
         t.close()
+
+
+def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
+    """bench.py's N>1 path end to end (sharding, collective, barrier + max-over-ranks timing, one JSON line from
+    rank 0), with two gloo ranks sharing this box's single GPU (VH_BENCH_BACKEND=gloo); the real run uses RCCL."""
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, VH_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--segments", "40"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 1e9
+    assert d["config"]["rows"] == 40_000_000 and d["config"]["groups"] == 100_000
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
