@@ -1207,7 +1207,11 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P
   typedef VhScanCfg<BLOCK> C;
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  if (MODE == VH_MODE_HASH) {
+  VhPartWave W;
+  if (MODE == VH_MODE_DENSE_PART) {       // phase 1 of the radix-partitioned aggregation: tuples staged per (wave, partition)
+    char* area = lds + (size_t)wave * ((vh_part_wave_bytes(P) + 15) / 16 * 16);
+    vh_part_wave_init(P, area, W, lane);
+  } else if (MODE == VH_MODE_HASH) {
     vh_lds_hash_init(P, lds, BLOCK);
   } else {
     for (int j = 0; j < P.nmetric; ++j) {
@@ -1282,6 +1286,39 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
+        if (MODE == VH_MODE_DENSE_PART) {   // wave-uniform: the staging code works with ballots
+          bool act = (mk >> r) & 1u;
+          if (__ballot(act) == 0) continue;
+          uint64_t gid = 0;
+          bool bad = false;
+#pragma unroll
+          for (int i = 0; i < VH_LANES_COLS; ++i) {
+            if (i < P.ngroup) {
+              const VhGroupDev& g = P.g[i];
+              const uint64_t d = gv[i][r] - g.lo;
+              bad |= d >= g.extent;
+              gid += d * g.stride;
+            }
+          }
+          if (act && bad) range_err = true;
+          act = act && !bad;
+          uint64_t words[1 + VH_FAST_COLS];
+          words[0] = gid & 0xFFFFFFFFull;
+#pragma unroll
+          for (int w = 1; w < 1 + VH_FAST_COLS; ++w) words[w] = 0;
+#pragma unroll
+          for (int j = 0; j < VH_LANES_COLS; ++j) {
+            if (j < P.nmetric) {
+              const VhMetricDev& m = P.m[j];
+              const uint64_t x = (vh_sop_bytes(m.sop()) == 4 ? (mv[j][r] & 0xFFFFFFFFull) : mv[j][r]) << m.tshift();
+#pragma unroll
+              for (int w = 0; w < 1 + VH_FAST_COLS; ++w)
+                if (m.tword() == (uint32_t)w) words[w] |= x;
+            }
+          }
+          vh_part_append(P, W, act, (uint32_t)(gid >> P.part_shift), words, lane);
+          continue;
+        }
         if (!((mk >> r) & 1u)) continue;
         if (MODE == VH_MODE_HASH) {
           uint64_t key = 0;
@@ -1342,6 +1379,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P
     if (npassed) atomicAdd(P.counters + 0, npassed);
     if (nfresh) atomicAdd(P.counters + 1, nfresh);
   }
+  if (MODE == VH_MODE_DENSE_PART) { vh_part_finish(P, W, lane); return; }
   if (MODE == VH_MODE_HASH) { vh_lds_hash_flush(P, lds, BLOCK); return; }
   __syncthreads();
   const uint64_t xo = P.nxcd > 1 ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;

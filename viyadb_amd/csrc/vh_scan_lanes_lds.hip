@@ -21,3 +21,7 @@ void vh_launch_scan_lanes_lds(const VhPlanDev& P, int grid, size_t lds, bool xcd
 void vh_launch_scan_lanes_hash(const VhPlanDev& P, int grid, size_t lds, hipStream_t s) {
   launch_np<VH_MODE_HASH, 256, __HIP_MEMORY_SCOPE_AGENT>(P, grid, lds, s);
 }
+
+void vh_launch_scan_lanes_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s) {
+  launch_np<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT>(P, grid, lds, s);
+}

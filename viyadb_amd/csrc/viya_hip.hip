@@ -1034,7 +1034,8 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   uint64_t part_tuple_cap = 0;
   if (mode == VH_MODE_DENSE_GLOBAL && fast && !no_part && !(p->flags & (VH_PLAN_NO_PART | VH_PLAN_FORCE_GLOBAL)) && P.nmetric >= 1) {
     int shift = 0;
-    while (((size_t)2 << shift) * state_bytes_per_group <= 56 * 1024) ++shift;
+    static const size_t part_table_bytes = getenv("VH_PART_TABLE_KB") ? (size_t)atoi(getenv("VH_PART_TABLE_KB")) * 1024 : 120 * 1024;   // one 1024-thread block per CU in phase 2 (160 KB LDS)
+    while (((size_t)2 << shift) * state_bytes_per_group <= part_table_bytes) ++shift;
     const uint64_t np = (G + (1ull << shift) - 1) >> shift;
     bool want_part = np <= VH_MAX_PART && G <= 0xFFFFFFFFull;
     double sel = 0;
@@ -1044,6 +1045,20 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       want_part = sel >= 0.08;   // crossover measured on C3 (profiles/r01): 5 % direct wins, 11 % partitioned wins
     }
     if (want_part) {
+      // most rows pass: build the tuples without compacting survivors first (lanes kernel, phase 1 only)
+      if (!(p->flags & VH_PLAN_NO_LANES) && P.ngroup <= VH_LANES_COLS && P.nmetric <= VH_LANES_COLS && rows_to_scan) {
+        bool ok = true;
+        for (int i = 0; i < P.ngroup; ++i) ok &= vh_elem_size(P.g[i].type()) >= 4;
+        for (int j = 0; j < P.nmetric; ++j) ok &= P.m[j].slot() != VH_SLOT_ROWID && vh_elem_size(P.m[j].type()) >= 4;
+        if (ok) {
+          if (p->flags & VH_PLAN_FORCE_LANES) lanes = true;
+          else {
+            double s2 = sel;
+            if (s2 == 0) { rc = probed_selectivity(&s2); if (rc) { delete r; return rc; } }
+            lanes = s2 >= 0.5;
+          }
+        }
+      }
       mode = VH_MODE_DENSE_PART;
       P.part_shift = shift;
       P.npart = (int32_t)np;
@@ -1056,7 +1071,8 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
         else { P.m[j].set_tword((uint8_t)tw); P.m[j].set_tshift(0); half_free_word = tw++; have_half = true; }
       }
       P.tw = tw;
-      int cap = 16;
+      static const int part_cap_max = getenv("VH_PART_CAP") ? atoi(getenv("VH_PART_CAP")) : 32;   // fewer, fuller partitions: 10 % faster than 56 KB / 16 (profiles/r01/NOTES.md)
+      int cap = part_cap_max;
       while (cap > 4 && 4 * ((size_t)P.npart * ((size_t)cap * tw * 8 + 12) + 16) + 4 * VhScanCfg<256>::kQueueCap * 4 > 40 * 1024) cap /= 2;
       static const bool staged = !(getenv("VH_PART_STAGED") && atoi(getenv("VH_PART_STAGED")) == 0);
       P.stage_cap = staged ? cap : 0;   // 0: tuples are scattered straight into the extents
@@ -1316,12 +1332,14 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   }
   const size_t qbytes = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint32_t);
   HIP_TRY(hipEventRecord(t->ev[1], st));
+  if (mode == VH_MODE_DENSE_PART && P.stage_cap == 0) lanes = false;   // the unstaged experiment has no lanes form
   r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0);
   if (P.total_units) {
     const size_t lds = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + qbytes;
     if (mode == VH_MODE_DENSE_PART) {
       const size_t wave_area = ((size_t)P.npart * ((size_t)P.stage_cap * P.tw * 8 + 12) + 15) / 16 * 16;
-      vh_launch_scan_fast_part(P, grid, qbytes + 4 * wave_area, st);
+      if (lanes && P.stage_cap > 0) vh_launch_scan_lanes_part(P, grid, 4 * wave_area, st);
+      else { lanes = false; vh_launch_scan_fast_part(P, grid, qbytes + 4 * wave_area, st); }
       const int bpp = std::max(1, std::min(16, g_ctx.num_cu / std::max(1, P.npart)));
       vh_launch_part_agg(P, bpp, lds_table, st);
     }
