@@ -173,8 +173,10 @@ def test_partition_buffer_regrows():
     try:
         res, _ = run(tab, dt, {"dimensions": ["a", "b"], "metrics": ["v", "count"], "filter": F("ge", "a", "0")})
         assert res.path == "dense_part"          # the selectivity probe sees ~100 % and picks partitioning
+        res, _ = run(tab, dt, {"dimensions": ["a", "b"], "metrics": ["v", "count"], "filter": F("ge", "a", "0")}, flags=64 | 128)
+        assert res.path == "dense_part" and res.retries >= 1   # staged form, forced without an estimate: first buffer too small
         res, _ = run(tab, dt, {"dimensions": ["a", "b"], "metrics": ["v", "count"], "filter": F("ge", "a", "0")}, flags=64)
-        assert res.path == "dense_part" and res.retries >= 1   # forced without an estimate: first buffer too small
+        assert res.path == "dense_part" and res.lanes          # lanes form (tile sort): extents sized for whole runs
         # skew: everything lands in one partition
         res, _ = run(tab, dt, {"dimensions": ["a", "b"], "metrics": ["v", "count"], "filter": F("eq", "a", "7")}, flags=64)
         res, _ = run(tab, dt, {"dimensions": ["a", "b"], "metrics": ["v", "count"], "filter": F("lt", "a", "3")})

@@ -160,6 +160,8 @@ struct VhPlanDev {
   int32_t stage_cap;         // tuples per (wave, partition) LDS staging buffer = one flush
   int32_t ext_flushes;       // flushes per extent (extent = ext_flushes x stage_cap tuples, <= 4096)
   int32_t ext_tuples;        // tuples per extent; stage_cap == 0: tuples are scattered straight into the extent
+  int32_t part_tile;         // lanes form of phase 1: row slots per wave tile (counting sort by partition in LDS), 0 = staged form
+  int32_t pad_part;
   uint64_t* tuples;          // max_extents x ext_flushes x stage_cap x tw words
   uint32_t* part_count;      // [npart] extents recorded per partition
   uint32_t* part_extents;    // [npart][part_cap] extent ids

@@ -1187,6 +1187,18 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
 // update the LDS table directly. Restricted (host side) to DENSE_LDS plans with <= VH_LANES_COLS group and metric
 // columns of 4 or 8 bytes and no time truncation, chosen when the selectivity probe says >= 25 % of the rows pass.
 #define VH_LANES_COLS 2
+#define VH_PART_TILE 256     // row slots per wave tile of the lanes form of DENSE_PART phase 1 (= one sub-step)
+struct VhPartTile {
+  uint64_t* sorted;    // LDS [VH_PART_TILE][tw]: this tile's tuples, ordered by partition
+  uint64_t* dst;       // LDS [64]: per partition, HBM tuple slot of its run minus the run's start
+  uint32_t* hist;      // LDS [64]: counts, then scatter cursors
+  uint8_t* spart;      // LDS [VH_PART_TILE]: partition of sorted[e]
+  uint32_t r_ext;      // lane p: partition p's current extent (~0u: none) ...
+  uint32_t r_fill;     // ... and the tuples already in it
+};
+__host__ __device__ __forceinline__ size_t vh_part_tile_bytes(const VhPlanDev& P) {
+  return ((size_t)VH_PART_TILE * P.tw * 8 + 64 * 8 + 64 * 4 + VH_PART_TILE + 15) / 16 * 16;
+}
 
 __device__ __forceinline__ void vh_load_rows4(const char* base, int type, uint32_t r0, bool sext, uint64_t (&out)[4]) {
   if (type == VH_U64 || type == VH_I64 || type == VH_F64) {
@@ -1208,9 +1220,15 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   VhPartWave W;
-  if (MODE == VH_MODE_DENSE_PART) {       // phase 1 of the radix-partitioned aggregation: tuples staged per (wave, partition)
-    char* area = lds + (size_t)wave * ((vh_part_wave_bytes(P) + 15) / 16 * 16);
-    vh_part_wave_init(P, area, W, lane);
+  VhPartTile T;
+  if (MODE == VH_MODE_DENSE_PART) {       // phase 1 of the radix-partitioned aggregation: one LDS tile per wave
+    char* area = lds + (size_t)wave * vh_part_tile_bytes(P);
+    T.sorted = reinterpret_cast<uint64_t*>(area);
+    T.dst = reinterpret_cast<uint64_t*>(area + (size_t)VH_PART_TILE * P.tw * 8);
+    T.hist = reinterpret_cast<uint32_t*>(area + (size_t)VH_PART_TILE * P.tw * 8 + 64 * 8);
+    T.spart = reinterpret_cast<uint8_t*>(area + (size_t)VH_PART_TILE * P.tw * 8 + 64 * 8 + 64 * 4);
+    T.r_ext = ~0u; T.r_fill = 0;
+    W.chunk_next = W.chunk_end = 0;
   } else if (MODE == VH_MODE_HASH) {
     vh_lds_hash_init(P, lds, BLOCK);
   } else {
@@ -1284,11 +1302,18 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P
           vh_load_rows4(P.colbase[m.slot()] + (uint64_t)seg * P.colstride[m.slot()], m.type(), r0, vh_sop_sext(m.sop()), mv[j]);
         }
       }
+      if (MODE == VH_MODE_DENSE_PART) {
+        // Phase 1 of the radix-partitioned aggregation, one wave tile = this sub-step's 256 row slots: counting
+        // sort of the passing rows' tuples by partition in LDS (histogram -> prefix -> scatter), then every run
+        // leaves for its partition's current extent as one contiguous, coalesced write. No per-tuple flush logic.
+        if (__ballot(mk != 0) == 0) continue;
+        uint32_t* hist = T.hist;
+        if (lane < 64) hist[lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        uint64_t words[4][1 + VH_LANES_COLS];
+        uint32_t part[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (MODE == VH_MODE_DENSE_PART) {   // wave-uniform: the staging code works with ballots
-          bool act = (mk >> r) & 1u;
-          if (__ballot(act) == 0) continue;
+        for (int r = 0; r < 4; ++r) {
           uint64_t gid = 0;
           bool bad = false;
 #pragma unroll
@@ -1300,25 +1325,72 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P
               gid += d * g.stride;
             }
           }
-          if (act && bad) range_err = true;
-          act = act && !bad;
-          uint64_t words[1 + VH_FAST_COLS];
-          words[0] = gid & 0xFFFFFFFFull;
+          const bool act = ((mk >> r) & 1u) && !bad;
+          if (((mk >> r) & 1u) && bad) range_err = true;
+          words[r][0] = gid & 0xFFFFFFFFull;
 #pragma unroll
-          for (int w = 1; w < 1 + VH_FAST_COLS; ++w) words[w] = 0;
+          for (int w = 1; w < 1 + VH_LANES_COLS; ++w) words[r][w] = 0;
 #pragma unroll
           for (int j = 0; j < VH_LANES_COLS; ++j) {
             if (j < P.nmetric) {
               const VhMetricDev& m = P.m[j];
               const uint64_t x = (vh_sop_bytes(m.sop()) == 4 ? (mv[j][r] & 0xFFFFFFFFull) : mv[j][r]) << m.tshift();
 #pragma unroll
-              for (int w = 0; w < 1 + VH_FAST_COLS; ++w)
-                if (m.tword() == (uint32_t)w) words[w] |= x;
+              for (int w = 0; w < 1 + VH_LANES_COLS; ++w)
+                if (m.tword() == (uint32_t)w) words[r][w] |= x;
             }
           }
-          vh_part_append(P, W, act, (uint32_t)(gid >> P.part_shift), words, lane);
-          continue;
+          part[r] = act ? (uint32_t)(gid >> P.part_shift) : 0xFFFFFFFFu;
+          if (act) atomicAdd(&hist[part[r]], 1u);
         }
+        __builtin_amdgcn_wave_barrier();
+        // lane p owns partition p: count, exclusive prefix (wave scan), cursor
+        const uint32_t cnt = hist[lane];                       // lanes >= npart read 0
+        uint32_t incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+        const uint32_t base = incl - cnt;
+        const uint32_t total = __shfl(incl, 63);
+        __builtin_amdgcn_wave_barrier();
+        hist[lane] = base;                                     // becomes the scatter cursor
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t tw = (uint32_t)P.tw;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (part[r] != 0xFFFFFFFFu) {
+            const uint32_t pos = atomicAdd(&hist[part[r]], 1u);
+            T.spart[pos] = (uint8_t)part[r];
+#pragma unroll
+            for (int w = 0; w < 1 + VH_LANES_COLS; ++w)
+              if ((uint32_t)w < tw) T.sorted[pos * tw + w] = words[r][w];
+          }
+        }
+        // room in the partitions' current extents? (lane p decides for partition p; a run never straddles extents)
+        const uint32_t et = (uint32_t)P.ext_tuples;
+        uint64_t need = __ballot(cnt != 0 && (T.r_ext == ~0u || T.r_fill + cnt > et));
+        while (need) {
+          const int p = __builtin_ctzll(need);
+          need &= need - 1;
+          const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, p), oldfill = __builtin_amdgcn_readlane(T.r_fill, p);
+          if (old != ~0u && lane == 0) P.extent_missing[old] = (uint16_t)(et - oldfill);
+          const uint32_t ext = vh_part_new_extent(P, W, p, lane);
+          if (lane == p) { T.r_ext = ext; T.r_fill = 0; }
+        }
+        // dst[p] = first tuple slot of this run in HBM, minus the run's start in the sorted buffer
+        T.dst[lane] = T.r_ext == ~0u ? ~0ull : (uint64_t)T.r_ext * et + T.r_fill - base;
+        if (T.r_ext != ~0u) T.r_fill += cnt;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t e = lane; e < total; e += 64) {
+          const uint64_t d0 = T.dst[T.spart[e]];
+          if (d0 == ~0ull) continue;                           // tuple buffer exhausted: the host re-runs (VH_ERR_PART_FULL)
+          uint64_t* dst = P.tuples + (d0 + e) * tw;
+          for (uint32_t w = 0; w < tw; ++w) dst[w] = T.sorted[e * tw + w];
+        }
+        __builtin_amdgcn_wave_barrier();
+        continue;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
         if (!((mk >> r) & 1u)) continue;
         if (MODE == VH_MODE_HASH) {
           uint64_t key = 0;
@@ -1379,7 +1451,10 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P
     if (npassed) atomicAdd(P.counters + 0, npassed);
     if (nfresh) atomicAdd(P.counters + 1, nfresh);
   }
-  if (MODE == VH_MODE_DENSE_PART) { vh_part_finish(P, W, lane); return; }
+  if (MODE == VH_MODE_DENSE_PART) {       // open extents are closed with what they hold
+    if (T.r_ext != ~0u && T.r_fill < (uint32_t)P.ext_tuples) P.extent_missing[T.r_ext] = (uint16_t)((uint32_t)P.ext_tuples - T.r_fill);
+    return;
+  }
   if (MODE == VH_MODE_HASH) { vh_lds_hash_flush(P, lds, BLOCK); return; }
   __syncthreads();
   const uint64_t xo = P.nxcd > 1 ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;

@@ -1234,7 +1234,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     // extent size: big enough that a wave allocates rarely (every allocation is a returning global
     // atomic = a full round trip the wave sits out), small enough that open extents do not waste HBM
     const uint64_t waves = (uint64_t)grid * 4;
-    uint64_t et = 64;
+    uint64_t et = lanes ? 1024 : 64;   // the lanes form writes whole runs (<= VH_PART_TILE tuples) that must fit a fresh extent
     while (et < 4096 && et * 2 <= part_tuple_cap / (waves * P.npart) / 2) et *= 2;
     P.ext_flushes = P.stage_cap ? (int32_t)std::max<uint64_t>(1, et / P.stage_cap) : 1;
     const uint64_t ext_tuples = P.stage_cap ? (uint64_t)P.ext_flushes * P.stage_cap : et;
@@ -1338,7 +1338,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     const size_t lds = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + qbytes;
     if (mode == VH_MODE_DENSE_PART) {
       const size_t wave_area = ((size_t)P.npart * ((size_t)P.stage_cap * P.tw * 8 + 12) + 15) / 16 * 16;
-      if (lanes && P.stage_cap > 0) vh_launch_scan_lanes_part(P, grid, 4 * wave_area, st);
+      if (lanes && P.stage_cap > 0) { P.part_tile = VH_PART_TILE; vh_launch_scan_lanes_part(P, grid, 4 * vh_part_tile_bytes(P), st); }
       else { lanes = false; vh_launch_scan_fast_part(P, grid, qbytes + 4 * wave_area, st); }
       const int bpp = std::max(1, std::min(16, g_ctx.num_cu / std::max(1, P.npart)));
       vh_launch_part_agg(P, bpp, lds_table, st);
