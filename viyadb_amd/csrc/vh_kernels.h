@@ -1307,6 +1307,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P
         // sort of the passing rows' tuples by partition in LDS (histogram -> prefix -> scatter), then every run
         // leaves for its partition's current extent as one contiguous, coalesced write. No per-tuple flush logic.
         if (__ballot(mk != 0) == 0) continue;
+        if (P.debug & 4) continue;                             // experiment: scan + payload loads only
         uint32_t* hist = T.hist;
         if (lane < 64) hist[lane] = 0;
         __builtin_amdgcn_wave_barrier();
@@ -1384,7 +1385,8 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P
           const uint64_t d0 = T.dst[T.spart[e]];
           if (d0 == ~0ull) continue;                           // tuple buffer exhausted: the host re-runs (VH_ERR_PART_FULL)
           uint64_t* dst = P.tuples + (d0 + e) * tw;
-          for (uint32_t w = 0; w < tw; ++w) dst[w] = T.sorted[e * tw + w];
+          if (!(P.debug & 2))                                  // experiment: everything but the HBM writes
+            for (uint32_t w = 0; w < tw; ++w) dst[w] = T.sorted[e * tw + w];
         }
         __builtin_amdgcn_wave_barrier();
         continue;
@@ -1500,26 +1502,35 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
     const uint32_t ext = P.part_extents[(uint64_t)part * P.part_cap + e];
     const uint32_t valid = ext_tuples - P.extent_missing[ext];
     const uint64_t* base = P.tuples + (uint64_t)ext * ext_tuples * tw;
-    for (uint32_t i = lane; i < valid; i += 64) {
-      uint64_t w[1 + VH_FAST_COLS];
+    // four tuples per lane in flight: with one, a 16-wave block keeps ~16 KB outstanding and the kernel is latency bound
+    for (uint32_t i0 = 0; i0 < valid; i0 += 256) {
+      uint64_t w[4][1 + VH_FAST_COLS];
 #pragma unroll
-      for (int x = 0; x < 1 + VH_FAST_COLS; ++x) w[x] = (uint32_t)x < tw ? __builtin_nontemporal_load(base + (uint64_t)i * tw + x) : 0;
-      const uint64_t local = (w[0] & 0xFFFFFFFFull) - g0;
-      if (local >= ng) continue;  // cannot happen; keeps a corrupt tuple from writing outside the table
-      reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[local] = 1;
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t i = i0 + u * 64 + lane;
 #pragma unroll
-      for (int j = 0; j < VH_FAST_COLS; ++j) {
-        if (j < P.nmetric) {
-          const VhMetricDev& m = P.m[j];
-          uint64_t v = 0;
+        for (int x = 0; x < 1 + VH_FAST_COLS; ++x)
+          w[u][x] = (i < valid && (uint32_t)x < tw) ? __builtin_nontemporal_load(base + (uint64_t)i * tw + x) : (x == 0 ? ~0ull : 0ull);
+      }
 #pragma unroll
-          for (int x = 0; x < 1 + VH_FAST_COLS; ++x)
-            if (m.tword() == x) v = w[x] >> m.tshift();
-          if (vh_sop_bytes(m.sop()) == 4) {
-            v &= 0xFFFFFFFFull;
-            if (vh_sop_sext(m.sop())) v = (uint64_t)(int64_t)(int32_t)v;
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t local = (w[u][0] & 0xFFFFFFFFull) - g0;
+        if (w[u][0] == ~0ull || local >= ng) continue;  // past the extent's fill; (a corrupt tuple cannot write outside the table)
+        reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[local] = 1;
+#pragma unroll
+        for (int j = 0; j < VH_FAST_COLS; ++j) {
+          if (j < P.nmetric) {
+            const VhMetricDev& m = P.m[j];
+            uint64_t v = 0;
+#pragma unroll
+            for (int x = 0; x < 1 + VH_FAST_COLS; ++x)
+              if (m.tword() == (uint32_t)x) v = w[u][x] >> m.tshift();
+            if (vh_sop_bytes(m.sop()) == 4) {
+              v &= 0xFFFFFFFFull;
+              if (vh_sop_sext(m.sop())) v = (uint64_t)(int64_t)(int32_t)v;
+            }
+            vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, local, m.sop(), v);
           }
-          vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, local, m.sop(), v);
         }
       }
     }
