@@ -183,6 +183,11 @@ def main():
         return
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
     algo_bytes = last.algorithmic_bytes  # B_ref per launch on this rank: rows x referenced bytes/row
+    # B_min of SURVEY 8(d): filter columns in full + the other referenced columns for passing rows only
+    rows_rank0 = my_segments * w.segment_rows
+    fcols = sorted({f[1] for f in w.plan.filter if f[0] in ("rel", "in")})
+    fbytes = sum(capi.ELEM_SIZE[w.columns[c].elem] for c in fcols)
+    b_min = rows_rank0 * fbytes + last.passed_recs * max(0, w.bytes_per_row_referenced - fbytes)
     traffic, traffic_src = measured_traffic(args.workload, my_segments * w.segment_rows)
     credited = min(algo_bytes, traffic) if traffic else algo_bytes  # never credit more than was moved
     achieved = credited / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
@@ -204,7 +209,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": ("scan_agg_fast_kernel" if last.fast else "scan_agg_kernel") + (" + part_agg_kernel" if last.path == "dense_part" else ""),
                          "kernel_ms": avg_kernel_ms,
-                         "algorithmic_bytes_per_launch": algo_bytes,
+                         "algorithmic_bytes_per_launch": algo_bytes, "b_min_bytes_per_launch": b_min,
                          "bref_over_t_GBs": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0,
                          "traffic_source": traffic_src,
                          "note": "achieved = min(B_ref, B_meas) / mean HIP-event time of scan_agg_kernel on rank 0 "
