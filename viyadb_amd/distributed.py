@@ -36,12 +36,25 @@ def reduce_view_typestr(elem: int, reduce: int) -> str:
     raise NotImplementedError("unsigned 32/64-bit MIN/MAX partials need an order-preserving view")
 
 
+_VIEW_CACHE = {}   # (ptr, count, typestr) -> torch view; the library's scratch is grow-only, so views repeat query after query
+
+
+def _device_view(torch, ptr, count, typestr):
+    key = (int(ptr), int(count), typestr)
+    t = _VIEW_CACHE.get(key)
+    if t is None:
+        if len(_VIEW_CACHE) > 64:
+            _VIEW_CACHE.clear()
+        t = _VIEW_CACHE[key] = torch.as_tensor(_DevArray(ptr, count, typestr), device="cuda")
+    return t
+
+
 def reduce_partials(torch, dist, buffers: List[tuple], dst: int = 0):
     """buffers: [(ptr, count, elem, reduce)] from DeviceTable.device_buffers(). In-place reduce to `dst`."""
     ops = {RED_SUM: dist.ReduceOp.SUM, RED_MIN: dist.ReduceOp.MIN, RED_MAX: dist.ReduceOp.MAX}
     gloo = dist.get_backend() == "gloo"   # test rigs without RCCL: gloo has no device-side reduce-to-root
     for ptr, count, elem, reduce in buffers:
-        t = torch.as_tensor(_DevArray(ptr, count, reduce_view_typestr(elem, reduce)), device="cuda")
+        t = _device_view(torch, ptr, count, reduce_view_typestr(elem, reduce))
         if gloo:
             dist.all_reduce(t, op=ops[reduce])
         else:
