@@ -1190,14 +1190,12 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
 #define VH_PART_TILE 256     // row slots per wave tile of the lanes form of DENSE_PART phase 1 (= one sub-step)
 struct VhPartTile {
   uint64_t* sorted;    // LDS [VH_PART_TILE][tw]: this tile's tuples, ordered by partition
-  uint64_t* dst;       // LDS [64]: per partition, HBM tuple slot of its run minus the run's start
   uint32_t* hist;      // LDS [64]: counts, then scatter cursors
-  uint8_t* spart;      // LDS [VH_PART_TILE]: partition of sorted[e]
   uint32_t r_ext;      // lane p: partition p's current extent (~0u: none) ...
   uint32_t r_fill;     // ... and the tuples already in it
 };
 __host__ __device__ __forceinline__ size_t vh_part_tile_bytes(const VhPlanDev& P) {
-  return ((size_t)VH_PART_TILE * P.tw * 8 + 64 * 8 + 64 * 4 + VH_PART_TILE + 15) / 16 * 16;
+  return ((size_t)VH_PART_TILE * P.tw * 8 + 64 * 4 + 15) / 16 * 16;
 }
 
 __device__ __forceinline__ void vh_load_rows4(const char* base, int type, uint32_t r0, bool sext, uint64_t (&out)[4]) {
@@ -1224,9 +1222,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P
   if (MODE == VH_MODE_DENSE_PART) {       // phase 1 of the radix-partitioned aggregation: one LDS tile per wave
     char* area = lds + (size_t)wave * vh_part_tile_bytes(P);
     T.sorted = reinterpret_cast<uint64_t*>(area);
-    T.dst = reinterpret_cast<uint64_t*>(area + (size_t)VH_PART_TILE * P.tw * 8);
-    T.hist = reinterpret_cast<uint32_t*>(area + (size_t)VH_PART_TILE * P.tw * 8 + 64 * 8);
-    T.spart = reinterpret_cast<uint8_t*>(area + (size_t)VH_PART_TILE * P.tw * 8 + 64 * 8 + 64 * 4);
+    T.hist = reinterpret_cast<uint32_t*>(area + (size_t)VH_PART_TILE * P.tw * 8);
     T.r_ext = ~0u; T.r_fill = 0;
     W.chunk_next = W.chunk_end = 0;
   } else if (MODE == VH_MODE_HASH) {
@@ -1306,6 +1302,9 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P
         // Phase 1 of the radix-partitioned aggregation, one wave tile = this sub-step's 256 row slots: counting
         // sort of the passing rows' tuples by partition in LDS (histogram -> prefix -> scatter), then every run
         // leaves for its partition's current extent as one contiguous, coalesced write. No per-tuple flush logic.
+        // (A first version looked the destination of sorted[e] up through two more LDS arrays — partition of e,
+        // destination of the partition — and lost a tuple now and then when an extent was opened inside the tile;
+        // per-partition state now stays in lane p's registers and is handed out with v_readlane.)
         if (__ballot(mk != 0) == 0) continue;
         if (P.debug & 4) continue;                             // experiment: scan + payload loads only
         uint32_t* hist = T.hist;
@@ -1360,7 +1359,6 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P
         for (int r = 0; r < 4; ++r) {
           if (part[r] != 0xFFFFFFFFu) {
             const uint32_t pos = atomicAdd(&hist[part[r]], 1u);
-            T.spart[pos] = (uint8_t)part[r];
 #pragma unroll
             for (int w = 0; w < 1 + VH_LANES_COLS; ++w)
               if ((uint32_t)w < tw) T.sorted[pos * tw + w] = words[r][w];
@@ -1377,16 +1375,22 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P
           const uint32_t ext = vh_part_new_extent(P, W, p, lane);
           if (lane == p) { T.r_ext = ext; T.r_fill = 0; }
         }
-        // dst[p] = first tuple slot of this run in HBM, minus the run's start in the sorted buffer
-        T.dst[lane] = T.r_ext == ~0u ? ~0ull : (uint64_t)T.r_ext * et + T.r_fill - base;
+        // write every partition's run to its extent: lane p holds (extent, fill, base, count) of partition p, the loop
+        // is wave-uniform over the partitions present in this tile
+        const uint64_t mydst = T.r_ext == ~0u ? ~0ull : (uint64_t)T.r_ext * et + T.r_fill;
         if (T.r_ext != ~0u) T.r_fill += cnt;
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t e = lane; e < total; e += 64) {
-          const uint64_t d0 = T.dst[T.spart[e]];
-          if (d0 == ~0ull) continue;                           // tuple buffer exhausted: the host re-runs (VH_ERR_PART_FULL)
-          uint64_t* dst = P.tuples + (d0 + e) * tw;
-          if (!(P.debug & 2))                                  // experiment: everything but the HBM writes
-            for (uint32_t w = 0; w < tw; ++w) dst[w] = T.sorted[e * tw + w];
+        uint64_t runs = __ballot(cnt != 0);
+        while (runs) {
+          const int p = __builtin_ctzll(runs);
+          runs &= runs - 1;
+          const uint32_t pb = __builtin_amdgcn_readlane(base, p), pc = __builtin_amdgcn_readlane(cnt, p);
+          const uint64_t pd = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(mydst >> 32), p) << 32) | __builtin_amdgcn_readlane((uint32_t)mydst, p);
+          if (pd == ~0ull) continue;                           // tuple buffer exhausted: the host re-runs (VH_ERR_PART_FULL)
+          for (uint32_t i = lane; i < pc; i += 64) {
+            uint64_t* dst = P.tuples + (pd + i) * tw;
+            if (!(P.debug & 2))                                // experiment: everything but the HBM writes
+              for (uint32_t w = 0; w < tw; ++w) dst[w] = T.sorted[(pb + i) * tw + w];
+          }
         }
         __builtin_amdgcn_wave_barrier();
         continue;

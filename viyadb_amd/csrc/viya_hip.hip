@@ -192,6 +192,7 @@ static int ensure_scratch(vh_table* t, size_t bytes) {
   size_t nb = std::max(bytes + bytes / 4, (size_t)1 << 20);
   HIP_TRY(hipMalloc(&t->scratch, nb));
   t->scratch_bytes = nb;
+  if (getenv("VH_POISON")) HIP_TRY(hipMemset(t->scratch, 0xA5, nb));   // tests: nothing may depend on what fresh scratch holds
   return VH_OK;
 }
 static int ensure_segrows(vh_table* t, size_t n) {
@@ -1188,7 +1189,8 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   P.units_per_seg = (uint32_t)((t->segment_rows + unit_rows - 1) / unit_rows);
   P.nseg = nseg;
   P.total_units = nseg * P.units_per_seg;
-  const int grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(P.total_units, (uint64_t)g_ctx.num_cu * blocks_per_cu));
+  static const int env_grid = getenv("VH_GRID") ? atoi(getenv("VH_GRID")) : 0;
+  const int grid = env_grid > 0 ? env_grid : (int)std::max<uint64_t>(1, std::min<uint64_t>(P.total_units, (uint64_t)g_ctx.num_cu * blocks_per_cu));
 
   // ---------------- scratch layout
   ScratchPlan sp;
