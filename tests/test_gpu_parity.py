@@ -76,3 +76,17 @@ def test_empty_table_and_tiny_segments(flags):
     w = synth.c3(segment_rows=70_001)
     check_workload(w, nseg=3, rows_per_seg=70_001, flags=flags)   # several units per segment, ragged tail
     check_workload(w, nseg=2, rows_per_seg=65_537, flags=flags)
+
+
+def test_nothing_depends_on_what_fresh_scratch_holds():
+    """The table-organisation tests again in a fresh process whose device scratch is filled with 0xA5 at allocation
+    (VH_POISON): a kernel that reads a word nobody wrote shows up as a wrong result or a fault instead of passing by luck
+    (fresh HBM is usually zero). This is how a lost tuple in the radix-partition tile code was pinned down."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VH_POISON="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-k",
+                        "table_organisations or ragged or c5_"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -192,7 +192,10 @@ static int ensure_scratch(vh_table* t, size_t bytes) {
   size_t nb = std::max(bytes + bytes / 4, (size_t)1 << 20);
   HIP_TRY(hipMalloc(&t->scratch, nb));
   t->scratch_bytes = nb;
-  if (getenv("VH_POISON")) HIP_TRY(hipMemset(t->scratch, 0xA5, nb));   // tests: nothing may depend on what fresh scratch holds
+  if (getenv("VH_POISON")) {   // tests: nothing may depend on what fresh scratch holds
+    HIP_TRY(hipMemsetAsync(t->scratch, 0xA5, nb, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  }
   return VH_OK;
 }
 static int ensure_segrows(vh_table* t, size_t n) {
