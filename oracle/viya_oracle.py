@@ -1044,6 +1044,10 @@ def scan_aggregate(aq: AggQuery, now: Optional[int] = None, seg_rows: Optional[L
     has_avg = any(oc.col.agg == "avg" for oc in aq.metric_cols)
     has_count = any(oc.col.agg == "count" for oc in aq.metric_cols)
     need_hidden = has_avg and not has_count
+    if need_hidden and not table.has_hidden_count:
+        # the generated loop copies tuple_metrics._count, which the table's Metrics struct only has when the TABLE has an
+        # AVG and no COUNT metric (src/codegen/db/store.cc:126-129, src/codegen/query/scan.cc:239-241)
+        raise Unsupported("AVG selected without the table's COUNT metric does not compile in the reference")
     key_parts = [[] for _ in aq.dim_cols]
     val_parts = [[] for _ in aq.metric_cols]
     hid_parts = []
