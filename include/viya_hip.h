@@ -7,6 +7,11 @@
  *   (reference: src/codegen/query/scan.cc:40-66,168-247; the JIT entry point it
  *    lives in is declared at src/query/runner.h:33-35 and emitted by
  *    src/codegen/query/agg_query.cc:26-75).
+ * Built on the same scan: the select and search query functions
+ * (viya_query_select / viya_query_search, scan.cc:75-166,249-299: vh_query_select and
+ * VH_COL_ROWID below), a HAVING and a top-N that run on the device before the groups
+ * are read back (post_agg.cc:77-83, sort.cc:24-75), and the exchange primitives for
+ * multi-GPU runs (vh_result_device_buffers, vh_result_partition[_pairs]).
  * Everything here is plain C: opaque handles, POD structs, pointers and sizes.
  * No C++ types, no exceptions and no torch types cross this boundary.
  *
@@ -17,8 +22,11 @@
  * rethrows a non-zero status as std::runtime_error).
  *
  * Ownership: the library owns device mirrors behind vh_table; the caller owns
- * every host buffer it passes in; vh_result objects are library-allocated and
- * must be released with vh_result_free().
+ * every host buffer it passes in; vh_result / vh_rows objects are library-allocated
+ * and must be released with vh_result_free() / vh_rows_free().
+ *
+ * Threading: calls on one vh_table serialise on a per-table lock; all device work goes
+ * to one HIP stream (vh_set_stream), so results of a call are complete when it returns.
  */
 #ifndef VIYA_HIP_H_
 #define VIYA_HIP_H_
