@@ -18,7 +18,7 @@
 #define VH_MAX_BITSET 2   // bitset (count-distinct) metrics per query
 #define VH_MAX_PRED 4     // fast path: distinct 4-byte predicate columns held in registers
 #define VH_FAST_COLS 4    // fast path: group / metric columns gathered up front
-#define VH_MAX_PART 32     // DENSE_PART: partitions (one LDS staging buffer per wave and partition)
+#define VH_MAX_PART 64     // DENSE_PART: partitions (lane p of a wave keeps partition p's state, so at most one per lane)
 #define VH_EXT_CHUNK 8    // DENSE_PART: extents a wave reserves per global allocation
 
 // Row geometry of one block step (see DESIGN.md "scan geometry"):
