@@ -1583,7 +1583,7 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   A.total_groups = P.counters + 6;
   for (int i = 0; i < r->nhaving; ++i) { A.hprog[i] = r->hprog[i]; A.htype[i] = r->htype[i]; }
   for (int i = 0; i < VH_MAX_HAVING_LITS; ++i) A.hlits[i] = r->hlits[i];
-  hipLaunchKernelGGL(emit_groups_kernel, dim3((unsigned)((A.n + 255) / 256)), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(emit_groups_kernel, dim3((unsigned)((A.n + 256 * VH_EMIT_SPAN - 1) / (256 * VH_EMIT_SPAN))), dim3(256), 0, st, A);
   HIP_TRY(hipGetLastError());
   if (r->topk_active) {
     // radix select of the top_k-th best sort key among the emitted rows (8 x 8 bits, no host round trip), then keep
@@ -1655,6 +1655,12 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   float ms = 0;
   (void)hipEventElapsedTime(&ms, t->ev[1], t->ev[2]); r->info.scan_kernel_ms = ms;
   (void)hipEventElapsedTime(&ms, t->ev[0], t->ev[3]); r->info.total_ms = ms;
+  if (getenv("VH_TIMES")) {   // where a query's device time goes: setup (clears, uploads) | scan | emission + read-back
+    float a = 0, b = 0;
+    (void)hipEventElapsedTime(&a, t->ev[0], t->ev[1]); (void)hipEventElapsedTime(&b, t->ev[2], t->ev[3]);
+    fprintf(stderr, "vh times: setup %.3f ms, scan %.3f ms, emit+readback %.3f ms (groups %llu, returned %llu)\n", a, r->info.scan_kernel_ms, b,
+            (unsigned long long)r->info.ngroups, (unsigned long long)r->info.returned_groups);
+  }
   r->finalized = true;
   return VH_OK;
 }
