@@ -365,28 +365,58 @@ struct VhPartitionArgs {
   const unsigned long long* offsets;     // [nparts + 1], pass 1
 };
 
+// Owner bookkeeping shared by the two partition kernels. A block handles VH_XCHG_SPAN x 256 rows: owners are counted
+// in an LDS histogram, each owner's block total takes ONE global atomic (a returning atomic per wave and owner on a
+// handful of addresses serialises, like the emission kernel's used to), and rows get their slot from an LDS cursor.
+#define VH_XCHG_SPAN 16
+__device__ __forceinline__ void vh_xchg_positions(uint32_t nparts, int pass, unsigned long long* counts, unsigned long long* cursors,
+                                                  const unsigned long long* offsets, const uint32_t (&owner)[VH_XCHG_SPAN],
+                                                  uint64_t (&pos)[VH_XCHG_SPAN]) {
+  __shared__ unsigned int hist[64];
+  __shared__ unsigned long long basep[64];
+  if (threadIdx.x < 64) hist[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < VH_XCHG_SPAN; ++k)
+    if (owner[k] != 0xFFFFFFFFu) atomicAdd(&hist[owner[k]], 1u);
+  __syncthreads();
+  if (threadIdx.x < nparts) {
+    const unsigned int c = hist[threadIdx.x];
+    unsigned long long b = 0;
+    if (c) b = atomicAdd((pass == 0 ? counts : cursors) + threadIdx.x, (unsigned long long)c);
+    basep[threadIdx.x] = (offsets ? offsets[threadIdx.x] : 0ull) + b;
+    hist[threadIdx.x] = 0;   // becomes the cursor inside the block
+  }
+  __syncthreads();
+  if (pass == 0) return;
+#pragma unroll
+  for (int k = 0; k < VH_XCHG_SPAN; ++k)
+    if (owner[k] != 0xFFFFFFFFu) pos[k] = basep[owner[k]] + atomicAdd(&hist[owner[k]], 1u);
+}
+
 __global__ __launch_bounds__(256) void partition_groups_kernel(const VhPartitionArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const bool have = i < A.n;
-  uint32_t owner = 0;
-  if (have) {
-    uint64_t h = 0x9E3779B97F4A7C15ull;
-    for (int c = 0; c < A.nkeys; ++c) h = vh_splitmix64(h ^ vh_load_sized(A.src[c], A.esize[c], i));
-    owner = (uint32_t)(h % A.nparts);
+  const uint64_t first = (uint64_t)blockIdx.x * (256 * VH_XCHG_SPAN) + threadIdx.x;
+  uint32_t owner[VH_XCHG_SPAN];
+  uint64_t pos[VH_XCHG_SPAN];
+#pragma unroll
+  for (int k = 0; k < VH_XCHG_SPAN; ++k) {
+    const uint64_t i = first + (uint64_t)k * 256;
+    owner[k] = 0xFFFFFFFFu;
+    pos[k] = 0;
+    if (i < A.n) {
+      uint64_t h = 0x9E3779B97F4A7C15ull;
+      for (int c = 0; c < A.nkeys; ++c) h = vh_splitmix64(h ^ vh_load_sized(A.src[c], A.esize[c], i));
+      owner[k] = (uint32_t)(h % A.nparts);
+    }
   }
-  uint64_t pos = 0;
-  for (uint32_t p = 0; p < A.nparts; ++p) {     // nparts = number of GPUs: a handful
-    const uint64_t bal = __ballot(have && owner == p);
-    if (bal == 0) continue;
-    const int leader = __ffsll((unsigned long long)bal) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd((A.pass == 0 ? A.counts : A.cursors) + p, (unsigned long long)__popcll(bal));
-    base = __shfl(base, leader);
-    if (have && owner == p) pos = A.offsets ? A.offsets[p] + base + __popcll(bal & ((1ull << lane) - 1ull)) : 0;
+  vh_xchg_positions(A.nparts, A.pass, A.counts, A.cursors, A.offsets, owner, pos);
+  if (A.pass == 0) return;
+#pragma unroll
+  for (int k = 0; k < VH_XCHG_SPAN; ++k) {
+    if (owner[k] == 0xFFFFFFFFu) continue;
+    const uint64_t i = first + (uint64_t)k * 256;
+    for (int c = 0; c < A.ncols; ++c) vh_store_sized(A.dst[c], A.esize[c], pos[k], vh_load_sized(A.src[c], A.esize[c], i));
   }
-  if (A.pass == 0 || !have) return;
-  for (int c = 0; c < A.ncols; ++c) vh_store_sized(A.dst[c], A.esize[c], pos, vh_load_sized(A.src[c], A.esize[c], i));
 }
 
 // ------------------------------------------------- select: ordered row emission
@@ -516,46 +546,51 @@ struct VhPairArgs {
   unsigned long long* counts; unsigned long long* cursors; const unsigned long long* offsets;
 };
 
+__device__ __forceinline__ bool vh_pair_at(const VhPairArgs& A, uint64_t i, uint64_t& gid, uint64_t& id) {
+  if (i >= A.nslots) return false;
+  if (A.wide) { if (A.dtags[i] != 2u) return false; gid = A.dkeys[2 * i]; id = A.dkeys[2 * i + 1]; return true; }
+  const uint64_t w = A.dkeys[i];
+  if (w == VH_HASH_EMPTY) return false;
+  gid = w >> 32; id = w & 0xFFFFFFFFull;
+  return true;
+}
+__device__ __forceinline__ uint64_t vh_pair_key(const VhPairArgs& A, uint64_t gid, int c) {
+  uint64_t v;
+  if (A.mode == VH_MODE_HASH) {
+    const uint64_t w = gid == A.hcap ? VH_HASH_EMPTY : A.hkeys[gid * A.key_words + A.gkey_word[c]];
+    v = w >> A.gkey_shift[c];
+  } else {
+    v = A.glo[c] + (gid / A.gstride[c]) % A.gextent[c];
+  }
+  if (A.gesize[c] < 8) v &= (1ull << (8 * A.gesize[c])) - 1ull;     // what the emitted column holds
+  return v;
+}
+
 __global__ __launch_bounds__(256) void partition_pairs_kernel(const VhPairArgs A) {
-  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  bool have = false;
-  uint64_t gid = 0, id = 0;
-  if (i < A.nslots) {
-    if (A.wide) { have = A.dtags[i] == 2u; if (have) { gid = A.dkeys[2 * i]; id = A.dkeys[2 * i + 1]; } }
-    else { const uint64_t w = A.dkeys[i]; have = w != VH_HASH_EMPTY; gid = w >> 32; id = w & 0xFFFFFFFFull; }
-  }
-  uint64_t kv[VH_MAX_GROUP];
-  uint32_t owner = 0;
-  if (have) {
-    uint64_t h = 0x9E3779B97F4A7C15ull;
-    for (int c = 0; c < A.ngroup; ++c) {
-      uint64_t v;
-      if (A.mode == VH_MODE_HASH) {
-        uint64_t w = gid == A.hcap ? VH_HASH_EMPTY : A.hkeys[gid * A.key_words + A.gkey_word[c]];
-        v = w >> A.gkey_shift[c];
-      } else {
-        v = A.glo[c] + (gid / A.gstride[c]) % A.gextent[c];
-      }
-      if (A.gesize[c] < 8) v &= (1ull << (8 * A.gesize[c])) - 1ull;     // what the emitted column holds
-      kv[c] = v;
-      h = vh_splitmix64(h ^ v);
+  const uint64_t first = (uint64_t)blockIdx.x * (256 * VH_XCHG_SPAN) + threadIdx.x;
+  uint32_t owner[VH_XCHG_SPAN];
+  uint64_t pos[VH_XCHG_SPAN];
+#pragma unroll
+  for (int k = 0; k < VH_XCHG_SPAN; ++k) {
+    uint64_t gid = 0, id = 0;
+    owner[k] = 0xFFFFFFFFu;
+    pos[k] = 0;
+    if (vh_pair_at(A, first + (uint64_t)k * 256, gid, id)) {
+      uint64_t h = 0x9E3779B97F4A7C15ull;
+      for (int c = 0; c < A.ngroup; ++c) h = vh_splitmix64(h ^ vh_pair_key(A, gid, c));
+      owner[k] = (uint32_t)(h % A.nparts);
     }
-    owner = (uint32_t)(h % A.nparts);
   }
-  uint64_t pos = 0;
-  for (uint32_t p = 0; p < A.nparts; ++p) {
-    const uint64_t bal = __ballot(have && owner == p);
-    if (bal == 0) continue;
-    const int leader = __ffsll((unsigned long long)bal) - 1;
-    unsigned long long base = 0;
-    if (lane == leader) base = atomicAdd((A.pass == 0 ? A.counts : A.cursors) + p, (unsigned long long)__popcll(bal));
-    base = __shfl(base, leader);
-    if (have && owner == p) pos = A.offsets ? A.offsets[p] + base + __popcll(bal & ((1ull << lane) - 1ull)) : 0;
+  vh_xchg_positions(A.nparts, A.pass, A.counts, A.cursors, A.offsets, owner, pos);
+  if (A.pass == 0) return;
+#pragma unroll
+  for (int k = 0; k < VH_XCHG_SPAN; ++k) {
+    if (owner[k] == 0xFFFFFFFFu) continue;
+    uint64_t gid = 0, id = 0;
+    (void)vh_pair_at(A, first + (uint64_t)k * 256, gid, id);
+    for (int c = 0; c < A.ngroup; ++c) vh_store_sized(A.dst[c], A.gesize[c], pos[k], vh_pair_key(A, gid, c));
+    vh_store_sized(A.dst[A.ngroup], A.wide ? 8u : 4u, pos[k], id);
   }
-  if (A.pass == 0 || !have) return;
-  for (int c = 0; c < A.ngroup; ++c) vh_store_sized(A.dst[c], A.gesize[c], pos, kv[c]);
-  vh_store_sized(A.dst[A.ngroup], A.wide ? 8u : 4u, pos, id);
 }
 
 __global__ __launch_bounds__(256) void iota_kernel(uint64_t* p, uint64_t n) {

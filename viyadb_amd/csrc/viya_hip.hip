@@ -1460,7 +1460,7 @@ extern "C" int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part
   A.counts = ctr; A.cursors = ctr + 64;
   std::vector<unsigned long long> counts(nparts, 0), offs(nparts + 1, 0);
   if (ng) {
-    const unsigned grid = (unsigned)((ng + 255) / 256);
+    const unsigned grid = (unsigned)((ng + 256 * VH_XCHG_SPAN - 1) / (256 * VH_XCHG_SPAN));
     A.pass = 0; A.offsets = nullptr;
     hipLaunchKernelGGL(partition_groups_kernel, dim3(grid), dim3(256), 0, st, A);
     HIP_TRY(hipGetLastError());
@@ -1540,7 +1540,7 @@ extern "C" int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t 
   A.nparts = nparts; A.counts = ctr; A.cursors = ctr + 64;
   std::vector<unsigned long long> counts(nparts, 0), offs(nparts + 1, 0);
   if (npairs) {
-    const unsigned grid = (unsigned)((A.nslots + 255) / 256);
+    const unsigned grid = (unsigned)((A.nslots + 256 * VH_XCHG_SPAN - 1) / (256 * VH_XCHG_SPAN));
     A.pass = 0; A.offsets = nullptr;
     hipLaunchKernelGGL(partition_pairs_kernel, dim3(grid), dim3(256), 0, st, A);
     HIP_TRY(hipGetLastError());
