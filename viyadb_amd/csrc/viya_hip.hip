@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -1561,6 +1562,18 @@ extern "C" int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t 
   return VH_OK;
 }
 
+// The end of a query is a host wait for a few hundred microseconds to a few milliseconds of device work: poll the event
+// (a blocking hipStreamSynchronize adds tens of microseconds of wake-up latency to every query), fall back to a
+// blocking wait when the work turns out to be long.
+static hipError_t wait_event_spinning(hipEvent_t ev) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return hipEventSynchronize(ev);
+  }
+}
+
 // returns VH_OK, or a positive "retry" request: 1 = grow hash table, 2 = fall back to hash
 static int result_finalize_locked(vh_result* r, int* retry) {
   vh_table* t = r->table;
@@ -1629,7 +1642,8 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   if (r->topk_active) HIP_TRY(hipMemcpyAsync(&tk, r->d_topk_state, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   // small results: counters, group count and every output array come back in ONE copy + ONE sync
   HIP_TRY(hipMemcpyAsync(H, D, one_shot ? r->out_region_bytes : 512, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
+  HIP_TRY(hipEventRecord(t->ev[3], st));
+  HIP_TRY(wait_event_spinning(t->ev[3]));
   const unsigned long long* hc = reinterpret_cast<const unsigned long long*>(H);
   const unsigned long long err = hc[2];
   if (err & VH_ERR_HASH_FULL) { *retry = 1; return VH_OK; }
@@ -1650,8 +1664,10 @@ static int result_finalize_locked(vh_result* r, int* retry) {
       HIP_TRY(hipMemcpyAsync(H + r->off_state[j], r->topk_active ? (const char*)r->d_out_state2[j] : D + r->off_state[j],
                              ng * vh_elem_size(r->metric_elem[j]), hipMemcpyDeviceToHost, st));
   }
-  HIP_TRY(hipEventRecord(t->ev[3], st));
-  HIP_TRY(hipStreamSynchronize(st));
+  if (!one_shot) {
+    HIP_TRY(hipEventRecord(t->ev[3], st));
+    HIP_TRY(wait_event_spinning(t->ev[3]));
+  }
   float ms = 0;
   (void)hipEventElapsedTime(&ms, t->ev[1], t->ev[2]); r->info.scan_kernel_ms = ms;
   (void)hipEventElapsedTime(&ms, t->ev[0], t->ev[3]); r->info.total_ms = ms;
