@@ -312,6 +312,9 @@ VH_API int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t npar
                                      int32_t max_bufs, int32_t* nbufs);
 VH_API int vh_segment_sync_ids_device(vh_table* t, uint32_t seg, int32_t col, uint64_t nrows,
                                       const void* d_ids);
+/* Host copy of `bytes` bytes of a vh_device_buffer (e.g. to put an exchanged partial on a wire that is not
+ * xGMI: SURVEY 8(f)-4, viyadb_amd/host/partial_state.cc). */
+VH_API int vh_device_read(void* dst, const void* device_src, uint64_t bytes);
 
 /* ---- the other two FilterBasedQuery kinds on the same scan ------------
  *

@@ -36,6 +36,13 @@ VDB_API int vdb_create_table(vdb* db, const char* table_json);              /* D
  * (the reference's VIYA_TEST_ROLLUP_TS test hook, src/codegen/db/rollup.cc:47-49) */
 VDB_API int vdb_load(vdb* db, const char* table, const char* rows, size_t rows_len, int64_t now);
 VDB_API int vdb_query(vdb* db, const char* query_json, int64_t now, char** rows_out, size_t* rows_len, vdb_stats* stats);
+/* Cluster aggregate with binary partial states (replaces the TSV hop of
+ * src/cluster/query/agg_runner.cc:83-140 — see viyadb_amd/host/partial_state.h for the wire layout).
+ * Worker: the query's partial state as one malloc'ed blob (free with vdb_free). Controller: merges the
+ * workers' blobs on the GPU and finishes the query (having / sort / skip / limit / formatting). */
+VDB_API int vdb_query_partial(vdb* db, const char* query_json, int64_t now, char** blob_out, size_t* blob_len, vdb_stats* stats);
+VDB_API int vdb_query_merge(vdb* db, const char* query_json, const char* const* blobs, const size_t* blob_lens, int32_t nblobs,
+                            char** rows_out, size_t* rows_len, vdb_stats* stats);
 VDB_API int vdb_table_info(vdb* db, const char* table, uint64_t* nsegments, uint64_t* first_segment_size);
 VDB_API void vdb_free(char* p);
 VDB_API const char* vdb_last_error(void);

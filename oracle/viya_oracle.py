@@ -1016,6 +1016,7 @@ class AggState:
     scanned_recs: int = 0
     scanned_segments: int = 0
     passed_recs: int = 0
+    bitsets: Optional[Dict[int, list]] = None   # metric_cols position -> per group, the set itself (cluster partial states)
 
     @property
     def ngroups(self):
@@ -1110,6 +1111,8 @@ def scan_aggregate(aq: AggQuery, now: Optional[int] = None, seg_rows: Optional[L
             for pos, oi in enumerate(order):
                 sets[gid_sorted[pos]] |= flat[oi]
             st.states.append(np.array([len(s) for s in sets], dtype=np.uint64))
+            st.bitsets = st.bitsets or {}
+            st.bitsets[k] = sets
             continue
         vals = np.concatenate(val_parts[k]) if val_parts[k] else np.zeros(0, dtype=m.num_type.dtype)
         vals = vals[order]

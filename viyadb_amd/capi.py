@@ -121,6 +121,7 @@ SYMBOLS = {
     "vh_segment_sync_bitset": (C.c_int, [_VP, C.c_uint32, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64), _VP]),
     "vh_segment_generate": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(GenSpec), C.c_uint64]),
     "vh_segment_read": (C.c_int, [_VP, C.c_uint32, C.c_int32, C.c_uint64, _VP]),
+    "vh_device_read": (C.c_int, [_VP, _VP, C.c_uint64]),
     "vh_table_info": (C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vh_segment_stats": (C.c_int, [_VP, C.c_uint32, C.c_int32, C.POINTER(AnyNum), C.POINTER(AnyNum)]),
     "vh_query_agg": (C.c_int, [_VP, C.POINTER(Plan), C.POINTER(_VP)]),

@@ -412,6 +412,15 @@ extern "C" int vh_segment_read(vh_table* t, uint32_t seg, int32_t col, uint64_t 
   return VH_OK;
 }
 
+// Host copy of a vh_device_buffer (the exchange buffers of vh_result_partition[_pairs]); ordered after the library's stream.
+extern "C" int vh_device_read(void* dst, const void* device_src, uint64_t bytes) {
+  if (!bytes) return VH_OK;
+  if (!dst || !device_src) return vh_fail(VH_E_INVALID, "vh_device_read: null argument");
+  HIP_TRY(hipMemcpyAsync(dst, device_src, (size_t)bytes, hipMemcpyDeviceToHost, g_ctx.stream));
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return VH_OK;
+}
+
 extern "C" int vh_table_info(vh_table* t, uint32_t* nseg, uint64_t* segment_rows, uint64_t* device_bytes) {
   if (!t) return vh_fail(VH_E_INVALID, "null table");
   if (nseg) *nseg = t->nseg;

@@ -14,51 +14,24 @@
 #include <set>
 #include <stdexcept>
 
-#include "../../include/viya_hip.h"
-#include "viya_query.h"
+#include "gpu_internal.h"
 
 namespace viya {
 namespace query {
 
-namespace {
+namespace detail {
 
-struct GpuMirror {
-  vh_table* handle = nullptr;
-  std::vector<uint64_t> synced_version;
-  ~GpuMirror() { if (handle) vh_table_destroy(handle); }
-};
-void free_mirror(void* p) { delete static_cast<GpuMirror*>(p); }
-
-void vh_check(int rc) {
-  if (rc != VH_OK) throw std::runtime_error(std::string("viya_hip: ") + vh_last_error());
-}
-
-int dim_kind(const db::Column* d) {
-  switch (d->dim_type()) {
-    case db::Column::DIM_STRING: return VH_DIM_STRING;
-    case db::Column::DIM_NUMERIC: return VH_DIM_NUMERIC;
-    case db::Column::DIM_TIME: return VH_DIM_TIME;
-    default: return VH_DIM_BOOLEAN;
-  }
-}
-int metric_kind(const db::Column* m) {
-  switch (m->agg_type()) {
-    case db::Column::MAX: return VH_METRIC_MAX;
-    case db::Column::MIN: return VH_METRIC_MIN;
-    case db::Column::SUM: return VH_METRIC_SUM;
-    case db::Column::AVG: return VH_METRIC_AVG;
-    case db::Column::COUNT: return VH_METRIC_COUNT;
-    default: return VH_METRIC_BITSET;
-  }
+void ensure_device() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const char* dev = getenv("VIYA_HIP_DEVICE");
+    vh_check(vh_init(dev ? atoi(dev) : 0));
+  });
 }
 
 GpuMirror* ensure_mirror(db::Table& t) {
   if (!t.gpu_mirror) {
-    static std::once_flag once;
-    std::call_once(once, [] {
-      const char* dev = getenv("VIYA_HIP_DEVICE");
-      vh_check(vh_init(dev ? atoi(dev) : 0));
-    });
+    ensure_device();
     std::vector<vh_col_desc> cols;
     for (auto* d : t.dimensions()) cols.push_back({dim_kind(d), d->num_type().vh_elem()});
     for (auto* m : t.metrics()) {
@@ -112,94 +85,11 @@ std::vector<uint64_t> sync_mirror(db::Table& t, GpuMirror* mir) {
   return rows;
 }
 
-// query::Filter -> postfix vh_filter_node program; literals are consumed in FilterArgsPacker order.
-class PlanFilterBuilder : public FilterVisitor {
-public:
-  PlanFilterBuilder(const db::Table& t, const std::vector<db::AnyNum>& args) : table(t), args_(args) {}
-  void Visit(const RelOpFilter* f) override {
-    const db::Column* c = table.column(f->column());
-    check_column(c);
-    nodes.push_back({VH_F_REL, (int32_t)c->storage_index, (int32_t)f->op(), 1, (int32_t)lits.size(), 0});
-    push_lit();
-  }
-  void Visit(const InFilter* f) override {
-    const db::Column* c = table.column(f->column());
-    check_column(c);
-    if (f->values().empty()) throw std::runtime_error("IN filter with no values does not compile in the reference");
-    nodes.push_back({VH_F_IN, (int32_t)c->storage_index, f->equal() ? 1 : 0, (int32_t)f->values().size(), (int32_t)lits.size(), 0});
-    for (size_t i = 0; i < f->values().size(); ++i) push_lit();
-  }
-  void Visit(const CompositeFilter* f) override {
-    for (auto& c : f->filters()) c->Accept(*this);
-    nodes.push_back({f->op() == CompositeFilter::AND ? VH_F_AND : VH_F_OR, 0, 0, (int32_t)f->filters().size(), 0, 0});
-  }
-  void Visit(const EmptyFilter*) override { nodes.push_back({VH_F_TRUE, 0, 0, 0, 0, 0}); }
-  const db::Table& table;
-  std::vector<vh_filter_node> nodes;
-  std::vector<vh_anynum> lits;
+}  // namespace detail
 
-private:
-  void check_column(const db::Column* c) {
-    if (c->type() == db::Column::METRIC && c->agg_type() == db::Column::BITSET)
-      throw std::runtime_error("filtering on a bitset metric's cardinality is not supported on the GPU path");
-  }
-  void push_lit() {
-    vh_anynum a;
-    a.u64 = args_.at(next_++).bits;
-    lits.push_back(a);
-  }
-  const std::vector<db::AnyNum>& args_;
-  size_t next_ = 0;
-};
+using namespace detail;
 
-// HAVING -> postfix program over RESULT columns (group column k, or ngroups + metric k), for the device.
-class PlanHavingBuilder : public FilterVisitor {
-public:
-  PlanHavingBuilder(AggregateQuery& q, const std::vector<db::AnyNum>& args, std::vector<vh_anynum>& lits)
-      : q_(q), args_(args), lits_(lits) {}
-  void Visit(const RelOpFilter* f) override {
-    nodes.push_back({VH_F_REL, result_col(f->column()), (int32_t)f->op(), 1, (int32_t)lits_.size(), 0});
-    push_lit();
-  }
-  void Visit(const InFilter* f) override {
-    if (f->values().empty()) throw std::runtime_error("IN filter with no values does not compile in the reference");
-    nodes.push_back({VH_F_IN, result_col(f->column()), f->equal() ? 1 : 0, (int32_t)f->values().size(), (int32_t)lits_.size(), 0});
-    for (size_t i = 0; i < f->values().size(); ++i) push_lit();
-  }
-  void Visit(const CompositeFilter* f) override {
-    for (auto& c : f->filters()) c->Accept(*this);
-    nodes.push_back({f->op() == CompositeFilter::AND ? VH_F_AND : VH_F_OR, 0, 0, (int32_t)f->filters().size(), 0, 0});
-  }
-  void Visit(const EmptyFilter*) override { nodes.push_back({VH_F_TRUE, 0, 0, 0, 0, 0}); }
-  std::vector<vh_filter_node> nodes;
-
-private:
-  int32_t result_col(const std::string& name) {
-    const db::Column* c = q_.table().column(name);
-    for (size_t k = 0; k < q_.dimension_cols().size(); ++k)
-      if (q_.dimension_cols()[k].dim() == c) return (int32_t)k;
-    for (size_t k = 0; k < q_.metric_cols().size(); ++k)
-      if (q_.metric_cols()[k].metric() == c) return (int32_t)(q_.dimension_cols().size() + k);
-    throw std::invalid_argument("Column '" + name + " is not selected");
-  }
-  void push_lit() {
-    vh_anynum a;
-    a.u64 = args_.at(next_++).bits;
-    lits_.push_back(a);
-  }
-  AggregateQuery& q_;
-  const std::vector<db::AnyNum>& args_;
-  std::vector<vh_anynum>& lits_;
-  size_t next_ = 0;
-};
-
-// One aggregated group as the post-aggregation sees it.
-struct Groups {
-  size_t n = 0;
-  std::vector<std::vector<char>> keys;    // per dimension_cols entry, n elements of the dim's type
-  std::vector<std::vector<char>> states;  // per metric_cols entry, n elements of the metric's type (bitset: u64)
-  std::vector<uint64_t> hidden;
-};
+namespace {
 
 // HAVING on aggregated tuples: same ComparisonBuilder semantics, applied to key / state values
 // (AVG compares the raw sum, bitsets compare the cardinality; post_agg.cc:77-83).
@@ -287,15 +177,65 @@ std::string format_date(const std::string& fmt, uint32_t ts) {  // Format::date(
 
 }  // namespace
 
+namespace detail {
+
+// HAVING runs on the device when that cannot change which rows the reference would return: the reference cuts
+// the unsorted skip/limit window BEFORE it applies HAVING (post_agg.cc:56-83), so only push down when there is
+// no such window, or when the rows are sorted first (then HAVING precedes the window in the reference too).
+bool HavingOnDevice(AggregateQuery& query, size_t skip, size_t limit) {
+  return query.having() != nullptr && (!query.sort_cols().empty() || (skip == 0 && limit == 0)) && !getenv("VIYA_HOST_HAVING");
+}
+
+// sort + limit on a numeric first sort column: let the device keep only the groups that can make the window
+// (a superset, ties included); the string sort in PostAggregate then runs on those few rows. Columns the reference
+// orders as formatted strings (string / time / boolean dims, AVG = "%.15g" text compared by length) stay on the host.
+void ConfigureTopN(AggregateQuery& query, size_t skip, size_t limit, bool having_on_device, vh_plan& plan) {
+  if (query.sort_cols().empty() || limit == 0 || (query.having() != nullptr && !having_on_device) || getenv("VIYA_HOST_TOPN")) return;
+  const SortColumn& sc = query.sort_cols()[0];
+  const db::Column* c = sc.col();
+  int rc = -1;
+  if (c->type() == db::Column::DIMENSION) {
+    if (c->dim_type() == db::Column::DIM_NUMERIC)
+      for (size_t k = 0; k < query.dimension_cols().size(); ++k)
+        if (query.dimension_cols()[k].dim() == c) { rc = (int)k; break; }
+  } else if (c->agg_type() != db::Column::AVG) {
+    for (size_t k = 0; k < query.metric_cols().size(); ++k)
+      if (query.metric_cols()[k].metric() == c) { rc = (int)(query.dimension_cols().size() + k); break; }
+  }
+  if (rc >= 0) { plan.top_col = rc; plan.top_desc = sc.ascending() ? 0 : 1; plan.top_k = (uint64_t)skip + limit; }
+}
+
+void FetchGroups(vh_result* res, AggregateQuery& query, Groups& groups, QueryStats& stats, bool extra_count_state) {
+  vh_result_info info;
+  vh_check(vh_result_get_info(res, &info));
+  stats.scanned_recs += info.scanned_recs;          // scan.cc:44
+  stats.scanned_segments += info.scanned_segments;  // scan.cc:51
+  stats.aggregated_recs = info.ngroups;             // scan.cc:246
+  stats.passed_recs = info.passed_recs;
+  stats.scan_kernel_ms = info.scan_kernel_ms;
+  stats.device_total_ms = info.total_ms;
+  stats.path = info.path;
+
+  groups.n = info.returned_groups;
+  std::vector<void*> kp, sp;
+  for (auto& dc : query.dimension_cols()) { groups.keys.emplace_back(groups.n * dc.dim()->num_type().size()); kp.push_back(groups.keys.back().data()); }
+  for (auto& mc : query.metric_cols()) {
+    const int es = mc.metric()->agg_type() == db::Column::BITSET ? 8 : mc.metric()->num_type().size();
+    groups.states.emplace_back(groups.n * es);
+    sp.push_back(groups.states.back().data());
+  }
+  if (info.has_hidden_count || extra_count_state) groups.hidden.resize(groups.n);
+  if (extra_count_state) sp.push_back(groups.hidden.data());   // the plan's last metric is a u64 SUM standing in for it
+  vh_check(vh_result_copy(res, kp.data(), sp.data(), info.has_hidden_count ? groups.hidden.data() : nullptr));
+}
+
+}  // namespace detail
+
 void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, std::vector<db::AnyNum> fargs,
                   size_t skip, size_t limit, std::vector<db::AnyNum> hargs, int64_t now) {
   db::Table& table = query.table();
   Groups groups;
-  // HAVING runs on the device when that cannot change which rows the reference would return: the reference cuts
-  // the unsorted skip/limit window BEFORE it applies HAVING (post_agg.cc:56-83), so only push down when there is
-  // no such window, or when the rows are sorted first (then HAVING precedes the window in the reference too).
-  const bool having_on_device = query.having() != nullptr && (!query.sort_cols().empty() || (skip == 0 && limit == 0)) &&
-                                !getenv("VIYA_HOST_HAVING");
+  const bool having_on_device = HavingOnDevice(query, skip, limit);
   {
     std::lock_guard<std::mutex> lk(table.mu);
     GpuMirror* mir = ensure_mirror(table);
@@ -303,27 +243,7 @@ void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, s
 
     PlanFilterBuilder fb(table, fargs);
     query.filter()->Accept(fb);
-
-    std::vector<vh_group_col> gcols(query.dimension_cols().size());
-    for (size_t k = 0; k < gcols.size(); ++k) {
-      const DimOutputColumn& dc = query.dimension_cols()[k];
-      const db::Dimension* d = dc.dim();
-      vh_group_col& g = gcols[k];
-      memset(&g, 0, sizeof(g));
-      g.col = (int32_t)d->storage_index;
-      g.granularity = VH_T_NONE;
-      if (d->dim_type() == db::Column::DIM_TIME && (!d->rollup_rules().empty() || dc.has_granularity())) {
-        // RollupDefs + RollupReset + TimestampRollup (src/codegen/db/rollup.cc:25-95)
-        if (d->rollup_rules().size() > VH_MAX_ROLLUP) throw std::runtime_error("too many rollup rules");
-        const auto bounds = db::rollup_boundaries(*d, now);
-        g.nrollup = (int32_t)bounds.size();
-        for (size_t i = 0; i < bounds.size(); ++i) { g.rollup_unit[i] = d->rollup_rules()[i].granularity; g.rollup_before[i] = bounds[i]; }
-        if (dc.has_granularity()) g.granularity = dc.granularity();
-      }
-      g.micro = d->micro_precision() ? 1 : 0;
-      if (d->dim_type() == db::Column::DIM_STRING) g.cardinality = d->dict()->c2v().size();
-      else if (d->dim_type() == db::Column::DIM_BOOLEAN) g.cardinality = 2;
-    }
+    std::vector<vh_group_col> gcols = PlanGroupCols(query, now);
     std::vector<int32_t> mcols;
     for (auto& mc : query.metric_cols()) mcols.push_back((int32_t)mc.metric()->storage_index);
 
@@ -340,50 +260,46 @@ void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, s
     plan.seg_rows = seg_rows.data(); plan.nseg = (uint32_t)seg_rows.size();
     const char* force = getenv("VIYA_HIP_PLAN_FLAGS");
     plan.flags = force ? (uint32_t)atoi(force) : 0;
-    // sort + limit on a numeric first sort column: let the device keep only the groups that can make the window
-    // (a superset, ties included); the string sort below then runs on those few rows. Columns the reference orders
-    // as formatted strings (string / time / boolean dims, AVG = "%.15g" text compared by length) stay on the host.
-    if (!query.sort_cols().empty() && limit > 0 && (query.having() == nullptr || having_on_device) && !getenv("VIYA_HOST_TOPN")) {
-      const SortColumn& sc = query.sort_cols()[0];
-      const db::Column* c = sc.col();
-      int rc = -1;
-      if (c->type() == db::Column::DIMENSION) {
-        if (c->dim_type() == db::Column::DIM_NUMERIC)
-          for (size_t k = 0; k < query.dimension_cols().size(); ++k)
-            if (query.dimension_cols()[k].dim() == c) { rc = (int)k; break; }
-      } else if (c->agg_type() != db::Column::AVG) {
-        for (size_t k = 0; k < query.metric_cols().size(); ++k)
-          if (query.metric_cols()[k].metric() == c) { rc = (int)(query.dimension_cols().size() + k); break; }
-      }
-      if (rc >= 0) { plan.top_col = rc; plan.top_desc = sc.ascending() ? 0 : 1; plan.top_k = (uint64_t)skip + limit; }
-    }
+    ConfigureTopN(query, skip, limit, having_on_device, plan);
 
     vh_result* res = nullptr;
     vh_check(vh_query_agg(mir->handle, &plan, &res));
     std::unique_ptr<vh_result, void (*)(vh_result*)> guard(res, vh_result_free);
-    vh_result_info info;
-    vh_check(vh_result_get_info(res, &info));
-    stats.scanned_recs += info.scanned_recs;          // scan.cc:44
-    stats.scanned_segments += info.scanned_segments;  // scan.cc:51
-    stats.aggregated_recs = info.ngroups;             // scan.cc:246
-    stats.passed_recs = info.passed_recs;
-    stats.scan_kernel_ms = info.scan_kernel_ms;
-    stats.device_total_ms = info.total_ms;
-    stats.path = info.path;
-
-    groups.n = info.returned_groups;
-    std::vector<void*> kp, sp;
-    for (auto& dc : query.dimension_cols()) { groups.keys.emplace_back(groups.n * dc.dim()->num_type().size()); kp.push_back(groups.keys.back().data()); }
-    for (auto& mc : query.metric_cols()) {
-      const int es = mc.metric()->agg_type() == db::Column::BITSET ? 8 : mc.metric()->num_type().size();
-      groups.states.emplace_back(groups.n * es);
-      sp.push_back(groups.states.back().data());
-    }
-    if (info.has_hidden_count) groups.hidden.resize(groups.n);
-    vh_check(vh_result_copy(res, kp.data(), sp.data(), info.has_hidden_count ? groups.hidden.data() : nullptr));
+    FetchGroups(res, query, groups, stats);
   }
+  PostAggregate(query, groups, having_on_device, hargs, skip, limit, output, stats);
+}
 
-  // ---- post aggregation (post_agg.cc:26-147)
+namespace detail {
+
+// The plan's GROUP BY columns: storage column + query-time rollup / granularity of time dimensions
+// (RollupDefs + RollupReset + TimestampRollup, src/codegen/db/rollup.cc:25-95).
+std::vector<vh_group_col> PlanGroupCols(AggregateQuery& query, int64_t now) {
+  std::vector<vh_group_col> gcols(query.dimension_cols().size());
+  for (size_t k = 0; k < gcols.size(); ++k) {
+    const DimOutputColumn& dc = query.dimension_cols()[k];
+    const db::Dimension* d = dc.dim();
+    vh_group_col& g = gcols[k];
+    memset(&g, 0, sizeof(g));
+    g.col = (int32_t)d->storage_index;
+    g.granularity = VH_T_NONE;
+    if (d->dim_type() == db::Column::DIM_TIME && (!d->rollup_rules().empty() || dc.has_granularity())) {
+      if (d->rollup_rules().size() > VH_MAX_ROLLUP) throw std::runtime_error("too many rollup rules");
+      const auto bounds = db::rollup_boundaries(*d, now);
+      g.nrollup = (int32_t)bounds.size();
+      for (size_t i = 0; i < bounds.size(); ++i) { g.rollup_unit[i] = d->rollup_rules()[i].granularity; g.rollup_before[i] = bounds[i]; }
+      if (dc.has_granularity()) g.granularity = dc.granularity();
+    }
+    g.micro = d->micro_precision() ? 1 : 0;
+    if (d->dim_type() == db::Column::DIM_STRING) g.cardinality = d->dict()->c2v().size();
+    else if (d->dim_type() == db::Column::DIM_BOOLEAN) g.cardinality = 2;
+  }
+  return gcols;
+}
+
+// ---- post aggregation (post_agg.cc:26-147)
+void PostAggregate(AggregateQuery& query, const Groups& groups, bool having_on_device, const std::vector<db::AnyNum>& hargs,
+                   size_t skip, size_t limit, RowOutput& output, QueryStats& stats) {
   output.Start();
   typedef std::vector<std::string> Row;
   const size_t ncols = query.dimension_cols().size() + query.metric_cols().size();
@@ -474,6 +390,8 @@ void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, s
   }
   output.Flush();
 }
+
+}  // namespace detail
 
 // ------------------------------------------------------------------------------------------------
 // select: ScanVisitor::Visit(SelectQuery*) (src/codegen/query/scan.cc:75-166). The scan, the ordered

@@ -1,0 +1,154 @@
+// gpu_internal.h — pieces shared by the host shim's translation units (gpu_aggregate.cc: single-node queries;
+// partial_state.cc: the cluster partial-state exchange). Not part of the mirrored reference interface.
+#pragma once
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+
+#include "../../include/viya_hip.h"
+#include "viya_query.h"
+
+namespace viya {
+namespace query {
+namespace detail {
+
+struct GpuMirror {
+  vh_table* handle = nullptr;
+  std::vector<uint64_t> synced_version;
+  ~GpuMirror() { if (handle) vh_table_destroy(handle); }
+};
+inline void free_mirror(void* p) { delete static_cast<GpuMirror*>(p); }
+
+inline void vh_check(int rc) {
+  if (rc != VH_OK) throw std::runtime_error(std::string("viya_hip: ") + vh_last_error());
+}
+
+inline int dim_kind(const db::Column* d) {
+  switch (d->dim_type()) {
+    case db::Column::DIM_STRING: return VH_DIM_STRING;
+    case db::Column::DIM_NUMERIC: return VH_DIM_NUMERIC;
+    case db::Column::DIM_TIME: return VH_DIM_TIME;
+    default: return VH_DIM_BOOLEAN;
+  }
+}
+inline int metric_kind(const db::Column* m) {
+  switch (m->agg_type()) {
+    case db::Column::MAX: return VH_METRIC_MAX;
+    case db::Column::MIN: return VH_METRIC_MIN;
+    case db::Column::SUM: return VH_METRIC_SUM;
+    case db::Column::AVG: return VH_METRIC_AVG;
+    case db::Column::COUNT: return VH_METRIC_COUNT;
+    default: return VH_METRIC_BITSET;
+  }
+}
+
+void ensure_device();   // vh_init once per process (VIYA_HIP_DEVICE)
+GpuMirror* ensure_mirror(db::Table& t);
+// Bring the HBM mirror up to date with the host segments; returns the per-segment size() snapshot.
+std::vector<uint64_t> sync_mirror(db::Table& t, GpuMirror* mir);
+
+// query::Filter -> postfix vh_filter_node program; literals are consumed in FilterArgsPacker order.
+class PlanFilterBuilder : public FilterVisitor {
+public:
+  PlanFilterBuilder(const db::Table& t, const std::vector<db::AnyNum>& args) : table(t), args_(args) {}
+  void Visit(const RelOpFilter* f) override {
+    const db::Column* c = table.column(f->column());
+    check_column(c);
+    nodes.push_back({VH_F_REL, (int32_t)c->storage_index, (int32_t)f->op(), 1, (int32_t)lits.size(), 0});
+    push_lit();
+  }
+  void Visit(const InFilter* f) override {
+    const db::Column* c = table.column(f->column());
+    check_column(c);
+    if (f->values().empty()) throw std::runtime_error("IN filter with no values does not compile in the reference");
+    nodes.push_back({VH_F_IN, (int32_t)c->storage_index, f->equal() ? 1 : 0, (int32_t)f->values().size(), (int32_t)lits.size(), 0});
+    for (size_t i = 0; i < f->values().size(); ++i) push_lit();
+  }
+  void Visit(const CompositeFilter* f) override {
+    for (auto& c : f->filters()) c->Accept(*this);
+    nodes.push_back({f->op() == CompositeFilter::AND ? VH_F_AND : VH_F_OR, 0, 0, (int32_t)f->filters().size(), 0, 0});
+  }
+  void Visit(const EmptyFilter*) override { nodes.push_back({VH_F_TRUE, 0, 0, 0, 0, 0}); }
+  const db::Table& table;
+  std::vector<vh_filter_node> nodes;
+  std::vector<vh_anynum> lits;
+
+private:
+  void check_column(const db::Column* c) {
+    if (c->type() == db::Column::METRIC && c->agg_type() == db::Column::BITSET)
+      throw std::runtime_error("filtering on a bitset metric's cardinality is not supported on the GPU path");
+  }
+  void push_lit() {
+    vh_anynum a;
+    a.u64 = args_.at(next_++).bits;
+    lits.push_back(a);
+  }
+  const std::vector<db::AnyNum>& args_;
+  size_t next_ = 0;
+};
+
+// HAVING -> postfix program over RESULT columns (group column k, or ngroups + metric k), for the device.
+class PlanHavingBuilder : public FilterVisitor {
+public:
+  PlanHavingBuilder(AggregateQuery& q, const std::vector<db::AnyNum>& args, std::vector<vh_anynum>& lits)
+      : q_(q), args_(args), lits_(lits) {}
+  void Visit(const RelOpFilter* f) override {
+    nodes.push_back({VH_F_REL, result_col(f->column()), (int32_t)f->op(), 1, (int32_t)lits_.size(), 0});
+    push_lit();
+  }
+  void Visit(const InFilter* f) override {
+    if (f->values().empty()) throw std::runtime_error("IN filter with no values does not compile in the reference");
+    nodes.push_back({VH_F_IN, result_col(f->column()), f->equal() ? 1 : 0, (int32_t)f->values().size(), (int32_t)lits_.size(), 0});
+    for (size_t i = 0; i < f->values().size(); ++i) push_lit();
+  }
+  void Visit(const CompositeFilter* f) override {
+    for (auto& c : f->filters()) c->Accept(*this);
+    nodes.push_back({f->op() == CompositeFilter::AND ? VH_F_AND : VH_F_OR, 0, 0, (int32_t)f->filters().size(), 0, 0});
+  }
+  void Visit(const EmptyFilter*) override { nodes.push_back({VH_F_TRUE, 0, 0, 0, 0, 0}); }
+  std::vector<vh_filter_node> nodes;
+
+private:
+  int32_t result_col(const std::string& name) {
+    const db::Column* c = q_.table().column(name);
+    for (size_t k = 0; k < q_.dimension_cols().size(); ++k)
+      if (q_.dimension_cols()[k].dim() == c) return (int32_t)k;
+    for (size_t k = 0; k < q_.metric_cols().size(); ++k)
+      if (q_.metric_cols()[k].metric() == c) return (int32_t)(q_.dimension_cols().size() + k);
+    throw std::invalid_argument("Column '" + name + " is not selected");
+  }
+  void push_lit() {
+    vh_anynum a;
+    a.u64 = args_.at(next_++).bits;
+    lits_.push_back(a);
+  }
+  AggregateQuery& q_;
+  const std::vector<db::AnyNum>& args_;
+  std::vector<vh_anynum>& lits_;
+  size_t next_ = 0;
+};
+
+// One aggregated group as the post-aggregation sees it.
+struct Groups {
+  size_t n = 0;
+  std::vector<std::vector<char>> keys;    // per dimension_cols entry, n elements of the dim's type
+  std::vector<std::vector<char>> states;  // per metric_cols entry, n elements of the metric's type (bitset: u64)
+  std::vector<uint64_t> hidden;
+};
+
+
+// HAVING runs on the device when that cannot change which rows the reference would return (see GpuAggregate).
+bool HavingOnDevice(AggregateQuery& query, size_t skip, size_t limit);
+// sort + limit on a numeric first sort column: ask the device for the superset of groups that can make the window.
+void ConfigureTopN(AggregateQuery& query, size_t skip, size_t limit, bool having_on_device, vh_plan& plan);
+std::vector<vh_group_col> PlanGroupCols(AggregateQuery& query, int64_t now);
+// vh_result -> typed host columns (query column order) + stats.
+// extra_count_state: the plan carries one more metric than the query, a u64 SUM that plays the hidden count (cluster merge).
+void FetchGroups(vh_result* res, AggregateQuery& query, Groups& groups, QueryStats& stats, bool extra_count_state = false);
+// PostAggVisitor + SortVisitor (post_agg.cc:26-147, sort.cc:24-75) over fetched groups.
+void PostAggregate(AggregateQuery& query, const Groups& groups, bool having_on_device, const std::vector<db::AnyNum>& hargs,
+                   size_t skip, size_t limit, RowOutput& output, QueryStats& stats);
+
+}  // namespace detail
+}  // namespace query
+}  // namespace viya

@@ -89,6 +89,48 @@ int vdb_query(vdb* db, const char* query_json, int64_t now, char** rows_out, siz
   });
 }
 
+static void fill_stats(vdb_stats* stats, const viya::query::QueryStats& st) {
+  if (!stats) return;
+  memset(stats, 0, sizeof(*stats));
+  stats->scanned_segments = st.scanned_segments; stats->scanned_recs = st.scanned_recs;
+  stats->aggregated_recs = st.aggregated_recs; stats->output_recs = st.output_recs; stats->passed_recs = st.passed_recs;
+  stats->compile_time = st.compile_time; stats->whole_time = st.whole_time;
+  stats->scan_kernel_ms = st.scan_kernel_ms; stats->device_total_ms = st.device_total_ms; stats->path = st.path;
+}
+
+int vdb_query_partial(vdb* db, const char* query_json, int64_t now, char** blob_out, size_t* blob_len, vdb_stats* stats) {
+  return vdbimpl::guard([&] {
+    viya::query::QueryStats st;
+    std::string blob = db->db->QueryPartial(viya::util::Config(std::string(query_json)), st, now);
+    *blob_out = (char*)malloc(blob.size() + 1);
+    memcpy(*blob_out, blob.data(), blob.size());
+    *blob_len = blob.size();
+    fill_stats(stats, st);
+  });
+}
+
+int vdb_query_merge(vdb* db, const char* query_json, const char* const* blobs, const size_t* blob_lens, int32_t nblobs,
+                    char** rows_out, size_t* rows_len, vdb_stats* stats) {
+  return vdbimpl::guard([&] {
+    std::vector<std::string> partials;
+    for (int32_t i = 0; i < nblobs; ++i) partials.emplace_back(blobs[i], blob_lens[i]);
+    viya::query::MemoryRowOutput out;
+    viya::query::QueryStats st = db->db->QueryMerge(viya::util::Config(std::string(query_json)), partials, out);
+    std::string buf;
+    for (auto& r : out.rows()) {
+      for (auto& f : r) { buf += f; buf += (char)0x1F; }
+      buf += (char)0x1E;
+    }
+    if (rows_out) {
+      *rows_out = (char*)malloc(buf.size() + 1);
+      memcpy(*rows_out, buf.data(), buf.size());
+      (*rows_out)[buf.size()] = 0;
+    }
+    if (rows_len) *rows_len = buf.size();
+    fill_stats(stats, st);
+  });
+}
+
 int vdb_table_info(vdb* db, const char* table, uint64_t* nsegments, uint64_t* first_segment_size) {
   return vdbimpl::guard([&] {
     viya::db::Table* t = db->db->GetTable(table);

@@ -1,5 +1,6 @@
 // viya_query.cc — filter factory, aggregate-query descriptor parsing, literal decoding, Database.
 #include "viya_query.h"
+#include "partial_state.h"
 
 #include <algorithm>
 #include <cctype>
@@ -232,6 +233,29 @@ query::QueryStats Database::Query(const util::Config& conf, query::RowOutput& ou
   std::vector<AnyNum> hargs = query::PackFilterArgs(*table, q.having());
   stats.compile_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   query::GpuAggregate(q, output, stats, fargs, q.skip(), q.limit(), hargs, now);
+  stats.whole_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return stats;
+}
+
+std::string Database::QueryPartial(const util::Config& conf, query::QueryStats& stats, int64_t now) {
+  if (conf.str("type") != "aggregate") throw std::invalid_argument("partial states exist for aggregate queries only");
+  Table* table = GetTable(conf.str("table"));
+  auto t0 = std::chrono::steady_clock::now();
+  query::AggregateQuery q(conf, *table);
+  std::vector<AnyNum> fargs = query::PackFilterArgs(*table, q.filter());
+  stats.compile_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::string blob = cluster::query::AggregatePartial(q, stats, fargs, now);
+  stats.whole_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return blob;
+}
+
+query::QueryStats Database::QueryMerge(const util::Config& conf, const std::vector<std::string>& partials, query::RowOutput& output) {
+  if (conf.str("type") != "aggregate") throw std::invalid_argument("partial states exist for aggregate queries only");
+  Table* table = GetTable(conf.str("table"));
+  auto t0 = std::chrono::steady_clock::now();
+  query::AggregateQuery q(conf, *table);
+  query::QueryStats stats;
+  cluster::query::MergePartials(q, partials, output, stats);
   stats.whole_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return stats;
 }

@@ -247,6 +247,10 @@ public:
   Table* GetTable(const std::string& name);
   query::QueryStats Query(const util::Config& query_conf, query::RowOutput& output, int64_t now = -1);
   void Load(const std::string& table, const std::vector<std::vector<std::string>>& rows, int64_t now = -1);
+  // Cluster aggregate (src/cluster/query/agg_runner.cc:83-140) with binary partial states (partial_state.h):
+  // a worker answers QueryPartial; the controller hands all answers to QueryMerge, which finishes the query.
+  std::string QueryPartial(const util::Config& query_conf, query::QueryStats& stats, int64_t now = -1);
+  query::QueryStats QueryMerge(const util::Config& query_conf, const std::vector<std::string>& partials, query::RowOutput& output);
 
 private:
   Dictionaries dicts_;

@@ -25,7 +25,8 @@ class HostError(RuntimeError):
         self.reference_exception = "invalid_argument" if code == 1 else "runtime_error"
 
 
-SYMBOLS = ["vdb_open", "vdb_close", "vdb_create_table", "vdb_load", "vdb_query", "vdb_table_info", "vdb_free", "vdb_last_error"]
+SYMBOLS = ["vdb_open", "vdb_close", "vdb_create_table", "vdb_load", "vdb_query", "vdb_query_partial", "vdb_query_merge",
+           "vdb_table_info", "vdb_free", "vdb_last_error"]
 _lib = None
 
 
@@ -44,6 +45,9 @@ def load():
         lib.vdb_create_table.argtypes = [C.c_void_p, C.c_char_p]
         lib.vdb_load.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int64]
         lib.vdb_query.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Stats)]
+        lib.vdb_query_partial.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Stats)]
+        lib.vdb_query_merge.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int32,
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Stats)]
         lib.vdb_table_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         lib.vdb_free.argtypes = [C.c_void_p]
         lib.vdb_free.restype = None
@@ -92,6 +96,38 @@ class Database:
         rows = [r.split(FS)[:-1] for r in raw.split(RS)[:-1]]
         stats = {k: getattr(st, k) for k, _ in Stats._fields_}
         return rows, stats
+
+    # ---- cluster aggregate with binary partial states (host/partial_state.h)
+    def query_partial(self, q: dict, now=None):
+        """Worker side: -> (partial-state blob, stats)."""
+        out, n, st = C.c_void_p(), C.c_size_t(), Stats()
+        _check(self.lib.vdb_query_partial(self.h, json.dumps(q).encode(), -1 if now is None else int(now), C.byref(out),
+                                          C.byref(n), C.byref(st)))
+        try:
+            blob = C.string_at(out, n.value)
+        finally:
+            self.lib.vdb_free(out)
+        return blob, {k: getattr(st, k) for k, _ in Stats._fields_}
+
+    def query_merge(self, q: dict, blobs):
+        """Controller side: merges the workers' blobs on the GPU and finishes the query -> (rows, stats)."""
+        blobs = [bytes(b) for b in blobs]
+        arr = (C.c_char_p * max(1, len(blobs)))()
+        lens = (C.c_size_t * max(1, len(blobs)))()
+        keep = []
+        for i, b in enumerate(blobs):
+            buf = C.create_string_buffer(b, len(b))
+            keep.append(buf)
+            arr[i] = C.cast(buf, C.c_char_p)
+            lens[i] = len(b)
+        out, n, st = C.c_void_p(), C.c_size_t(), Stats()
+        _check(self.lib.vdb_query_merge(self.h, json.dumps(q).encode(), arr, lens, len(blobs), C.byref(out), C.byref(n), C.byref(st)))
+        try:
+            raw = C.string_at(out, n.value).decode("utf-8", "replace")
+        finally:
+            self.lib.vdb_free(out)
+        rows = [r.split(FS)[:-1] for r in raw.split(RS)[:-1]]
+        return rows, {k: getattr(st, k) for k, _ in Stats._fields_}
 
     def table_info(self, table: str):
         a, b = C.c_uint64(), C.c_uint64()
