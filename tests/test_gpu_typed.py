@@ -466,3 +466,38 @@ def test_random_plans_against_oracle(typed, seed):
         except vo.Unsupported:     # e.g. a filter on a byte / short column
             continue
     assert done >= 30
+
+
+def test_stale_result_handles_are_refused(typed):
+    """A result's device state lives in the table's scratch arena and its host view in one of two staging buffers:
+    using a handle after later queries reused them must fail, not read someone else's data; bad table descriptors
+    and segment indices are rejected too."""
+    import ctypes as C
+    from viyadb_amd import capi
+    tab, dt = typed
+    q = dict({"type": "aggregate", "table": "t"}, dimensions=["s8"], metrics=["count", "long_sum"])
+    plan = plan_from_query(tab, vo.parse_query(tab, q), now=NOW)
+    launched = dt.query_launch(plan)
+    dt.query_agg(plan)                                      # reuses the scratch arena
+    with pytest.raises(capi.VhError, match="stale"):
+        dt.finalize(launched, plan)
+    kept = dt.query_agg_keep(plan)
+    try:
+        first = dt.collect(kept, plan)
+        dt.query_agg(plan)
+        again = dt.collect(kept, plan)                      # one query later: the other staging buffer was used
+        assert all((a == b).all() for a, b in zip(first.states, again.states))
+        with pytest.raises(capi.VhError, match="stale"):
+            dt.partition(kept, 2)                           # ... but the device-side rows are gone
+        dt.query_agg(plan)
+        with pytest.raises(capi.VhError, match="stale"):
+            dt.collect(kept, plan)
+    finally:
+        dt.discard(kept)
+    lib, h = capi.load(), C.c_void_p()
+    bad = (capi.ColDesc * 2)(capi.ColDesc(capi.DIM_NUMERIC, capi.U32), capi.ColDesc(capi.METRIC_SUM, capi.BITSET32))
+    assert lib.vh_table_create(bad, 2, 1000, 1, C.byref(h)) == -1 and b"bad kind" in lib.vh_last_error()
+    bad = (capi.ColDesc * 1)(capi.ColDesc(7, capi.U32))
+    assert lib.vh_table_create(bad, 1, 1000, 1, C.byref(h)) == -1
+    with pytest.raises(capi.VhError, match="out of range"):
+        dt.sync_segment(1 << 30, [None] * len(dt.cols), 0)

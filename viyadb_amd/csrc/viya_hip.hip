@@ -110,11 +110,14 @@ struct vh_table {
   std::map<std::string, double> sel_cache;               // filter signature + table state -> probed selectivity
   char* h_out[2] = {nullptr, nullptr}; size_t h_out_bytes[2] = {0, 0}; int h_out_next = 0;  // pinned result staging
   uint64_t sync_epoch = 0;   // bumped by every vh_segment_sync / generate: invalidates cached estimates
+  uint64_t launch_epoch = 0; // bumped by every query launch: a result's device state lives in `scratch` until the next one
+  uint64_t staged_seq = 0;   // bumped by every finalisation: host views alternate between the two staging buffers
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::mutex mu;
   uint64_t device_bytes = 0;
 };
 
+static const uint32_t VH_MAX_SEGMENTS = 1u << 24;   // (segment << 32 | row) positions and u32 segment loops stay far from overflow
 static bool is_dim(int kind) { return kind <= VH_DIM_BOOLEAN; }
 static bool is_bitset_elem(int e) { return e == VH_BITSET32 || e == VH_BITSET64; }
 
@@ -156,6 +159,11 @@ extern "C" int vh_table_create(const vh_col_desc* cols, int32_t ncols, uint64_t 
   for (int i = 0; i < ncols; ++i) {
     VhColumn& c = t->cols[i];
     c.kind = cols[i].kind; c.elem = cols[i].elem;
+    const bool dim_kind = c.kind >= VH_DIM_STRING && c.kind <= VH_DIM_BOOLEAN, metric_kind = c.kind >= VH_METRIC_MAX && c.kind <= VH_METRIC_HIDDEN_COUNT;
+    if ((!dim_kind && !metric_kind) || (is_bitset_elem(c.elem) != (c.kind == VH_METRIC_BITSET))) {
+      delete t;
+      return vh_fail(VH_E_INVALID, "column %d: bad kind %d / element type %d", i, cols[i].kind, cols[i].elem);
+    }
     if (is_bitset_elem(c.elem)) { c.esize = 0; continue; }
     c.esize = vh_elem_size(c.elem);
     if (!c.esize) { delete t; return vh_fail(VH_E_INVALID, "column %d: bad element type %d", i, c.elem); }
@@ -163,8 +171,12 @@ extern "C" int vh_table_create(const vh_col_desc* cols, int32_t ncols, uint64_t 
   }
   int rc = table_grow(t, std::max<uint32_t>(1, reserve_segments));
   if (rc) { vh_table_destroy(t); return rc; }
-  (void)hipHostMalloc((void**)&t->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault);
-  for (auto& e : t->ev) (void)hipEventCreate(&e);
+  hipError_t he = hipHostMalloc((void**)&t->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault);
+  for (auto& e : t->ev) if (he == hipSuccess) he = hipEventCreate(&e);
+  if (he != hipSuccess) {
+    vh_table_destroy(t);
+    return vh_fail(VH_E_DEVICE, "vh_table_create: pinned staging / events: %s", hipGetErrorString(he));
+  }
   *out = t;
   return VH_OK;
 }
@@ -270,6 +282,7 @@ static int refresh_stats(vh_table* t, uint32_t first, uint32_t n) {
 extern "C" int vh_segment_sync(vh_table* t, uint32_t seg, uint64_t nrows, const void* const* col_ptrs) {
   if (!t || !col_ptrs) return vh_fail(VH_E_INVALID, "vh_segment_sync: null argument");
   if (nrows > t->segment_rows) return vh_fail(VH_E_INVALID, "vh_segment_sync: nrows %llu > segment_rows", (unsigned long long)nrows);
+  if (seg >= VH_MAX_SEGMENTS) return vh_fail(VH_E_INVALID, "vh_segment_sync: segment index %u out of range", seg);
   std::lock_guard<std::mutex> lk(t->mu);
   int rc = table_grow(t, seg + 1);
   if (rc) return rc;
@@ -292,6 +305,7 @@ extern "C" int vh_segment_sync_range(vh_table* t, uint32_t seg, uint64_t row_fir
   if (new_size > t->segment_rows || row_first + nrows > new_size)
     return vh_fail(VH_E_INVALID, "vh_segment_sync_range: rows [%llu, %llu) do not fit a segment of %llu rows",
                    (unsigned long long)row_first, (unsigned long long)(row_first + nrows), (unsigned long long)new_size);
+  if (seg >= VH_MAX_SEGMENTS) return vh_fail(VH_E_INVALID, "vh_segment_sync_range: segment index %u out of range", seg);
   std::lock_guard<std::mutex> lk(t->mu);
   int rc = table_grow(t, seg + 1);
   if (rc) return rc;
@@ -317,6 +331,8 @@ extern "C" int vh_segment_sync_bitset(vh_table* t, uint32_t seg, int32_t col, ui
   if (!t || col < 0 || (size_t)col >= t->cols.size() || !offsets) return vh_fail(VH_E_INVALID, "vh_segment_sync_bitset: bad argument");
   auto& c = t->cols[col];
   if (!is_bitset_elem(c.elem)) return vh_fail(VH_E_INVALID, "column %d is not a bitset column", col);
+  if (nrows > t->segment_rows || seg >= VH_MAX_SEGMENTS) return vh_fail(VH_E_INVALID, "vh_segment_sync_bitset: segment %u / %llu rows out of range", seg, (unsigned long long)nrows);
+  if (offsets[0] != 0 || (offsets[nrows] && !values)) return vh_fail(VH_E_INVALID, "vh_segment_sync_bitset: offsets must start at 0 and values must be given");
   std::lock_guard<std::mutex> lk(t->mu);
   int rc = table_grow(t, seg + 1);
   if (rc) return rc;
@@ -338,7 +354,8 @@ extern "C" int vh_segment_sync_ids_device(vh_table* t, uint32_t seg, int32_t col
   if (!t || col < 0 || (size_t)col >= t->cols.size()) return vh_fail(VH_E_INVALID, "vh_segment_sync_ids_device: bad argument");
   auto& c = t->cols[col];
   if (!is_bitset_elem(c.elem)) return vh_fail(VH_E_INVALID, "column %d is not a bitset column", col);
-  if (nrows > t->segment_rows) return vh_fail(VH_E_INVALID, "nrows exceeds segment_rows");
+  if (nrows > t->segment_rows || seg >= VH_MAX_SEGMENTS) return vh_fail(VH_E_INVALID, "vh_segment_sync_ids_device: segment %u / %llu rows out of range", seg, (unsigned long long)nrows);
+  if (nrows && !d_ids) return vh_fail(VH_E_INVALID, "vh_segment_sync_ids_device: null ids");
   std::lock_guard<std::mutex> lk(t->mu);
   int rc = table_grow(t, seg + 1);
   if (rc) return rc;
@@ -361,6 +378,7 @@ extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nse
                                    uint64_t row_base, const vh_gen_spec* specs, uint64_t seed) {
   if (!t || !specs || !nseg) return vh_fail(VH_E_INVALID, "vh_segment_generate: bad argument");
   if (rows_per_seg > t->segment_rows) return vh_fail(VH_E_INVALID, "rows_per_seg exceeds segment_rows");
+  if (seg_first >= VH_MAX_SEGMENTS || nseg > VH_MAX_SEGMENTS - seg_first) return vh_fail(VH_E_INVALID, "vh_segment_generate: segments [%u, +%u) out of range", seg_first, nseg);
   std::lock_guard<std::mutex> lk(t->mu);
   int rc = table_grow(t, seg_first + nseg);
   if (rc) return rc;
@@ -496,6 +514,7 @@ struct vh_result {
   vh_result_info info{};
   int mode = 0;
   bool finalized = false;
+  uint64_t launch_epoch = 0, staged_seq = 0;   // see vh_table: used to refuse stale handles instead of reading reused memory
   // device-side partial state
   VhPlanDev plan{};
   int nxcd = 1;
@@ -533,6 +552,19 @@ struct vh_result {
 
 extern "C" void vh_result_free(vh_result* r) { delete r; }
 
+// A result's device-side state lives in its table's scratch arena, which the next query on that table reuses.
+static int check_device_state(const vh_result* r, const char* what) {
+  if (r->launch_epoch != r->table->launch_epoch)
+    return vh_fail(VH_E_INVALID, "%s: stale result handle (another query has run on this table since)", what);
+  return VH_OK;
+}
+// ... and its host views alias one of the table's two pinned staging buffers.
+static int check_host_view(const vh_result* r, const char* what) {
+  if (r->table->staged_seq - r->staged_seq >= 2)
+    return vh_fail(VH_E_INVALID, "%s: stale result handle (two or more queries have been finalised on this table since)", what);
+  return VH_OK;
+}
+
 extern "C" int vh_result_get_info(vh_result* r, vh_result_info* info) {
   if (!r || !info) return vh_fail(VH_E_INVALID, "null argument");
   *info = r->info;
@@ -541,6 +573,7 @@ extern "C" int vh_result_get_info(vh_result* r, vh_result_info* info) {
 
 extern "C" int vh_result_view(vh_result* r, const void** key_cols, const void** state_cols, const uint64_t** hidden_count) {
   if (!r || !r->finalized) return vh_fail(VH_E_INVALID, "result is not finalised");
+  if (int rc = check_host_view(r, "vh_result_view")) return rc;
   for (int i = 0; i < r->plan.ngroup; ++i)
     if (key_cols) key_cols[i] = r->h_base + r->off_key[i];
   for (size_t j = 0; j < r->user_metric.size(); ++j) {
@@ -714,6 +747,10 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
                                bool force_hash, uint64_t part_tuples_override = 0, bool no_part = false,
                                bool plan_only = false) {
   // ---------------- validate
+  if (p->nfilter < 0 || p->nlits < 0 || p->ngroups < 0 || p->nmetrics < 0 || p->nhaving < 0)
+    return vh_fail(VH_E_INVALID, "plan has a negative count");
+  if ((p->nfilter && !p->filter) || (p->nlits && !p->lits) || (p->ngroups && !p->groups) || (p->nmetrics && !p->metrics) || (p->nhaving && !p->having))
+    return vh_fail(VH_E_INVALID, "plan has a count without its array");
   if (p->nfilter > VH_MAX_PROG) return vh_fail(VH_E_UNSUPPORTED, "filter has %d nodes (max %d)", p->nfilter, VH_MAX_PROG);
   if (p->nlits > VH_MAX_LITS) return vh_fail(VH_E_UNSUPPORTED, "filter has %d literals (max %d)", p->nlits, VH_MAX_LITS);
   if (p->ngroups > VH_MAX_GROUP) return vh_fail(VH_E_UNSUPPORTED, "%d group columns (max %d)", p->ngroups, VH_MAX_GROUP);
@@ -724,6 +761,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
 
   vh_result* r = new vh_result();
   r->table = t;
+  r->launch_epoch = ++t->launch_epoch;
   VhPlanDev& P = r->plan;
   memset(&P, 0, sizeof(P));
 
@@ -813,11 +851,15 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     const int s = slot(gc.col);
     if (s < 0 || !is_dim(t->cols[gc.col].kind)) { delete r; return vh_fail(VH_E_INVALID, "group column %d: bad column %d", i, gc.col); }
     const VhColumn& c = t->cols[gc.col];
+    if (gc.nrollup < 0 || gc.nrollup > VH_MAX_ROLLUP) { delete r; return vh_fail(VH_E_UNSUPPORTED, "group column %d: %d rollup rules", i, gc.nrollup); }
+    if (gc.granularity > VH_T_NONE) { delete r; return vh_fail(VH_E_INVALID, "group column %d: granularity %d", i, gc.granularity); }
+    for (int k = 0; k < gc.nrollup; ++k)
+      if (gc.rollup_unit[k] < VH_T_YEAR || gc.rollup_unit[k] > VH_T_SECOND) { delete r; return vh_fail(VH_E_INVALID, "group column %d: rollup unit %d", i, gc.rollup_unit[k]); }
     VhGroupDev& g = P.g[i];
     g.set_slot((uint16_t)s); g.set_type((uint8_t)c.elem);
     g.set_gran((uint8_t)(gc.granularity < 0 ? VH_T_NONE : gc.granularity));
     g.set_nroll((uint8_t)gc.nrollup); g.set_micro((uint8_t)gc.micro);
-    if (gc.nrollup < 0 || gc.nrollup > VH_MAX_ROLLUP) { delete r; return vh_fail(VH_E_UNSUPPORTED, "group column %d: %d rollup rules", i, gc.nrollup); }
+
     if (g.gran() == VH_T_WEEK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "week granularity: the reference has no Truncator::trunc<WEEK> (src/util/time.h:57-89)"); }
     for (int k = 0; k < gc.nrollup; ++k) {
       if (gc.rollup_unit[k] == VH_T_WEEK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "week rollup granularity is not supported by the reference"); }
@@ -1381,6 +1423,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
 
 extern "C" int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs, int32_t max_bufs, int32_t* nbufs) {
   if (!r || !bufs || !nbufs) return vh_fail(VH_E_INVALID, "null argument");
+  if (int rc = check_device_state(r, "vh_result_device_buffers")) return rc;
   if (r->plan.nbitset) return vh_fail(VH_E_UNSUPPORTED, "count-distinct partials are cardinalities: they cannot be reduced across GPUs");
   if (r->mode == VH_MODE_HASH) return vh_fail(VH_E_UNSUPPORTED, "hash-path partials are exchanged by key, not reduced in place");
   const VhPlanDev& P = r->plan;
@@ -1439,6 +1482,7 @@ extern "C" int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part
   if (r->nhaving) return vh_fail(VH_E_UNSUPPORTED, "HAVING applies to merged groups: run the partial query without it");
   if (r->topk) return vh_fail(VH_E_UNSUPPORTED, "top-N applies to merged groups: run the partial query without it");
   std::lock_guard<std::mutex> lk(r->table->mu);
+  if (int rc = check_device_state(r, "vh_result_partition")) return rc;
   const VhPlanDev& P = r->plan;
   hipStream_t st = g_ctx.stream;
   const uint64_t ng = r->ngroups_host;
@@ -1520,6 +1564,8 @@ extern "C" int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t 
   if (max_bufs < P.ngroup + 1) return vh_fail(VH_E_INVALID, "need %d buffers", P.ngroup + 1);
   if (r->mode != VH_MODE_HASH && r->nxcd != 1) return vh_fail(VH_E_UNSUPPORTED, "pairs of an XCD-private dense table");
   std::lock_guard<std::mutex> lk(r->table->mu);
+  if (int rc = check_device_state(r, "vh_result_partition_pairs")) return rc;
+  if (int rc = check_host_view(r, "vh_result_partition_pairs")) return rc;
   hipStream_t st = g_ctx.stream;
   // number of pairs = sum of the emitted cardinalities would need a reduction; the set's fill count is counters[4],
   // read back with the result header (h_base): every pair bumps it exactly once
@@ -1687,6 +1733,7 @@ static int result_finalize_locked(vh_result* r, int* retry) {
             (unsigned long long)r->info.ngroups, (unsigned long long)r->info.returned_groups);
   }
   r->finalized = true;
+  r->staged_seq = ++t->staged_seq;
   return VH_OK;
 }
 
@@ -1700,6 +1747,7 @@ extern "C" int vh_result_finalize(vh_result* r) {
   if (!r) return vh_fail(VH_E_INVALID, "null result");
   if (r->finalized) return VH_OK;
   std::lock_guard<std::mutex> lk(r->table->mu);
+  if (int rc = check_device_state(r, "vh_result_finalize")) return rc;
   int retry = 0;
   int rc = result_finalize_locked(r, &retry);
   if (rc) return rc;
