@@ -1,0 +1,227 @@
+"""Differential fuzz at the reference's own interface level: random table descriptors, SimpleLoader-style loads,
+random aggregate / select / search query JSON — product (C++ host shim -> C-ABI -> HIP kernels -> host
+post-aggregation) against the oracle. Rows must be identical (in order under `sort`, as sets otherwise), stats equal,
+and a query the oracle rejects must be rejected by the product too."""
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+NOW = 1496570140
+COUNTRIES = ["US", "IL", "KZ", "RU", "AZ", "CH", "DE", "FR", "JP", "BR", "IN", "CN"]
+EVENTS = ["open", "buy", "quit", "refund", "review", "rate", "share", "purchase", "donate", "browse", "login", "logout"]
+NUM_DIM_TYPES = ["ubyte", "ushort", "uint", "ulong", "int", "long", "float", "double"]
+METRIC_TYPES = ["int", "uint", "long", "ulong", "float", "double"]
+
+
+def make_table(rnd):
+    dims = [{"name": "country"}, {"name": "event", "cardinality": rnd.choice([8, 200, 70000])},
+            {"name": "flag", "type": "boolean"}, {"name": "id", "type": "uint"}]
+    for i in range(rnd.randrange(1, 4)):
+        dims.append({"name": "n%d" % i, "type": rnd.choice(NUM_DIM_TYPES)})
+    tdim = {"name": "ts", "type": rnd.choice(["time", "microtime"]), "format": "%Y-%m-%d %H:%M:%S"}
+    if rnd.random() < 0.4:
+        tdim["granularity"] = rnd.choice(["hour", "day", "month"])
+    elif rnd.random() < 0.4:
+        tdim["rollup_rules"] = [{"granularity": "hour", "after": "1 days"}, {"granularity": "day", "after": "1 weeks"},
+                                {"granularity": "month", "after": "1 years"}][: rnd.randrange(1, 4)]
+    dims.append(tdim)
+    metrics = []
+    if rnd.random() < 0.7:
+        metrics.append({"name": "count", "type": "count"})
+    for i in range(rnd.randrange(2, 6)):
+        agg = rnd.choice(["sum", "min", "max", "avg"])
+        metrics.append({"name": "m%d" % i, "type": "%s_%s" % (rnd.choice(METRIC_TYPES), agg)})
+    if rnd.random() < 0.6:
+        metrics.append({"name": "users", "type": "bitset"})
+    return {"name": "t", "segment_size": rnd.choice([300, 1000, 5000]), "dimensions": dims, "metrics": metrics}
+
+
+def dim_value(rnd, d, i):
+    t = d.get("type", "string")
+    if d["name"] == "country":
+        return rnd.choice(COUNTRIES)
+    if d["name"] == "event":
+        return rnd.choice(EVENTS)
+    if t == "boolean":
+        return rnd.choice(["true", "false"])
+    if d["name"] == "id":
+        return str(i % 700)
+    if t in ("time", "microtime"):
+        # spread over ~2 years before NOW so that rollup rules hit every bucket
+        ts = NOW - rnd.choice([rnd.randrange(0, 86400), rnd.randrange(0, 7 * 86400), rnd.randrange(0, 700 * 86400)])
+        import time
+        return time.strftime("%Y-%m-%d %H:%M:%S", time.gmtime(ts))
+    if t in ("float", "double"):
+        return str(rnd.randrange(-40, 40) / 4)
+    if t in ("int", "long"):
+        return str(rnd.randrange(-30, 30))
+    return str(rnd.randrange(0, 50 if t != "ubyte" else 20))
+
+
+def metric_value(rnd, m):
+    t, agg = m["type"].rsplit("_", 1) if "_" in m["type"] else (m["type"], "")
+    if m["type"] == "bitset":
+        return str(rnd.randrange(0, 40))
+    if t in ("float", "double"):
+        return str(rnd.randrange(-400, 400) / 8)        # exact in binary: sums do not depend on the order
+    if t in ("uint", "ulong"):
+        return str(rnd.randrange(0, 1000))
+    return str(rnd.randrange(-1000, 1000))
+
+
+def make_rows(rnd, tconf, n):
+    rows = []
+    for i in range(n):
+        r = [dim_value(rnd, d, i) for d in tconf["dimensions"]]
+        r += [metric_value(rnd, m) for m in tconf["metrics"] if m["type"] != "count"]
+        rows.append(r)
+    return rows
+
+
+def literal(rnd, tconf, col, rows):
+    """A literal that exists in the data most of the time (taken from a random row), sometimes one that does not."""
+    names = [d["name"] for d in tconf["dimensions"]] + [m["name"] for m in tconf["metrics"] if m["type"] != "count"]
+    if col == "count":
+        return str(rnd.randrange(0, 4))
+    v = rnd.choice(rows)[names.index(col)]
+    if rnd.random() < 0.15:
+        d = next((d for d in tconf["dimensions"] if d["name"] == col), None)
+        if d is not None and d.get("type", "string") == "string":
+            return "nowhere"
+    return v
+
+
+def make_filter(rnd, tconf, cols, rows, depth=0):
+    k = rnd.random()
+    if depth < 2 and k < 0.35:
+        return {"op": rnd.choice(["and", "or"]), "filters": [make_filter(rnd, tconf, cols, rows, depth + 1) for _ in range(rnd.randrange(2, 4))]}
+    if depth < 2 and k < 0.45:
+        return {"op": "not", "filter": make_filter(rnd, tconf, cols, rows, depth + 1)}
+    col = rnd.choice(cols)
+    if k < 0.6:
+        return {"op": "in", "column": col, "values": [literal(rnd, tconf, col, rows) for _ in range(rnd.randrange(1, 4))]}
+    d = next((d for d in tconf["dimensions"] if d["name"] == col), None)
+    ops = ["eq", "ne"] if d is not None and d.get("type", "string") in ("string", "boolean") and rnd.random() < 0.8 else ["eq", "ne", "lt", "le", "gt", "ge"]
+    return {"op": rnd.choice(ops), "column": col, "value": literal(rnd, tconf, col, rows)}
+
+
+def make_query(rnd, tconf, rows):
+    dims = [d["name"] for d in tconf["dimensions"]]
+    mets = [m["name"] for m in tconf["metrics"]]
+    filterable = [d["name"] for d in tconf["dimensions"]] + [m["name"] for m in tconf["metrics"] if m["type"] != "bitset"]
+    kind = rnd.random()
+    q = {"table": "t"}
+    if rnd.random() < 0.75:
+        q["filter"] = make_filter(rnd, tconf, filterable, rows)
+    if kind < 0.12:
+        q.update(type="search", dimension=rnd.choice([d for d in dims if d != "ts"]), term=rnd.choice(["", "o", "1", "e", "true", "U"]))
+        if rnd.random() < 0.4:
+            q["limit"] = rnd.randrange(1, 6)
+        return q
+    qd = rnd.sample(dims, rnd.randrange(0, min(4, len(dims)) + 1))
+    qm = rnd.sample(mets, rnd.randrange(1, min(4, len(mets)) + 1))
+    if kind < 0.27:
+        q.update(type="select", dimensions=qd or [dims[0]], metrics=qm)
+        if rnd.random() < 0.6:
+            q["limit"] = rnd.randrange(1, 40)
+        if rnd.random() < 0.4:
+            q["skip"] = rnd.randrange(0, 60)
+        return q
+    q.update(type="aggregate")
+    if "ts" in qd and rnd.random() < 0.6:
+        sel = []
+        for d in qd:
+            c = {"column": d}
+            if d == "ts":
+                if rnd.random() < 0.7:
+                    c["granularity"] = rnd.choice(["year", "month", "day", "hour", "minute"])
+                if rnd.random() < 0.5:
+                    c["format"] = rnd.choice(["%Y-%m", "%d/%m/%Y %H", "%Y"])
+            sel.append(c)
+        q["select"] = sel + [{"column": m} for m in qm]
+    else:
+        q.update(dimensions=qd, metrics=qm)
+    selected = qd + qm
+    if rnd.random() < 0.3:
+        hcols = [c for c in selected if c != "ts"]
+        if hcols:
+            q["having"] = make_filter(rnd, tconf, hcols, rows, depth=1)
+    if rnd.random() < 0.5:
+        first = rnd.sample(selected, rnd.randrange(1, min(3, len(selected)) + 1))
+        order = first + [c for c in selected if c not in first]         # every column: the order is total
+        q["sort"] = [{"column": c, "ascending": rnd.random() < 0.5} for c in order]
+        if rnd.random() < 0.7:
+            q["limit"] = rnd.randrange(1, 30)
+        if rnd.random() < 0.3:
+            q["skip"] = rnd.randrange(0, 10)
+    if rnd.random() < 0.2:
+        q["header"] = True
+    return q
+
+
+def _stod_throws(cell):
+    from oracle import viya_oracle as vo
+    try:
+        vo._stod(cell)
+    except vo.OutOfRange:
+        return True
+    except Exception:
+        return False
+    return False
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_descriptors_and_queries(seed):
+    from oracle import viya_oracle as vo
+    from viyadb_amd import hostdb
+    rnd = random.Random(1000 + seed)
+    tconf = make_table(rnd)
+    rows = make_rows(rnd, tconf, rnd.choice([400, 2500, 9000]))
+    gdb = hostdb.Database({"tables": [tconf]})
+    odb = vo.Database({"tables": [tconf]})
+    try:
+        half = len(rows) // 2
+        for batch in (rows[:half], rows[half:]):
+            gdb.load("t", batch, now=NOW)
+            odb.table("t").load(batch, now=NOW)
+        checked = rejected = 0
+        for qi in range(45):
+            q = make_query(rnd, tconf, rows)
+            try:
+                want, ost = odb.query(q, now=NOW)
+            except vo.OutOfRange:
+                # std::stod threw inside the sort comparator (a double MAX that kept its DBL_MIN identity prints as a
+                # subnormal). Which pairs a sort compares depends on its algorithm, so beyond the first sort column
+                # the product (std::stable_sort) and the reference (std::sort) need not agree on WHETHER it throws.
+                try:
+                    gdb.query(q, now=NOW)
+                except hostdb.HostError as e:
+                    assert "stod" in str(e)
+                rejected += 1
+                continue
+            except (vo.Unsupported, vo.InvalidArgument, ValueError, OverflowError) as e:
+                with pytest.raises(hostdb.HostError):
+                    gdb.query(q, now=NOW)
+                rejected += 1
+                continue
+            ctx = (seed, qi, q)
+            try:
+                got, gst = gdb.query(q, now=NOW)
+            except hostdb.HostError as e:
+                assert "stod" in str(e) and any(_stod_throws(c) for r in want for c in r), (str(e), ctx)
+                rejected += 1
+                continue
+            if q["type"] == "aggregate" and "sort" not in q and ("limit" in q or "skip" in q):
+                assert len(got) == len(want), ctx
+            elif q["type"] == "aggregate" and "sort" not in q:
+                assert sorted(got) == sorted(want), ctx
+            else:
+                assert got == want, ctx
+            for k in ("scanned_recs", "scanned_segments", "aggregated_recs", "output_recs"):
+                assert gst[k] == ost[k], (k, ctx)
+            checked += 1
+        assert checked >= 25, (checked, rejected)
+    finally:
+        gdb.close()
