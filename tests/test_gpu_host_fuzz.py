@@ -225,3 +225,83 @@ def test_random_descriptors_and_queries(seed):
         assert checked >= 25, (checked, rejected)
     finally:
         gdb.close()
+
+
+def _layout_dependent(f, tconf, scan_filter=True, negate=False):
+    """Queries whose answer depends on how rows are laid out, so that three workers and one database legitimately differ
+    (as they do in the reference's own cluster):
+    * lt / le / gt / ge on a string dimension compares dictionary CODES, i.e. arrival order;
+    * a scan filter on a METRIC sees the stored rows, and upsert merges different rows on different workers;
+    * NOT IN on a numeric / time dimension: the reference's segment skipping evaluates it like IN (filter.cc:263-335
+      ignores equal()), so which segments are dropped depends on what each segment happens to hold."""
+    if not isinstance(f, dict) or "op" not in f:
+        return False
+    if f["op"] in ("and", "or"):
+        return any(_layout_dependent(x, tconf, scan_filter, negate) for x in f["filters"])
+    if f["op"] == "not":
+        return _layout_dependent(f["filter"], tconf, scan_filter, not negate)
+    d = next((d for d in tconf["dimensions"] if d["name"] == f.get("column")), None)
+    if d is None:
+        return scan_filter
+    kind = d.get("type", "string")
+    if kind == "string" and f["op"] in ("lt", "le", "gt", "ge"):
+        return True
+    return scan_filter and f["op"] == "in" and negate and kind not in ("string", "boolean")
+
+
+def _cluster_comparable(q, tconf):
+    return q["type"] == "aggregate" and not _layout_dependent(q.get("filter"), tconf) and not _layout_dependent(q.get("having"), tconf, scan_filter=False)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_cluster_merges(seed):
+    """SURVEY 8(f)-4 under the same generator: the rows split at random over three workers (own dictionaries, shared
+    groups), every aggregate query answered through partial states + GPU merge, against ONE oracle database."""
+    from oracle import viya_oracle as vo
+    from viyadb_amd import hostdb
+    rnd = random.Random(3000 + seed)
+    tconf = make_table(rnd)
+    for d in tconf["dimensions"]:
+        if d["name"] == "event":
+            d["cardinality"] = 200      # "__exceeded" depends on arrival order, which differs per worker by construction
+    rows = make_rows(rnd, tconf, rnd.choice([400, 2500]))
+    workers = [hostdb.Database({"tables": [tconf]}) for _ in range(3)]
+    odb = vo.Database({"tables": [tconf]})
+    try:
+        parts = [[], [], []]
+        for r in rows:
+            parts[rnd.randrange(3)].append(r)
+        for w, p in zip(workers, parts):
+            w.load("t", p, now=NOW)
+        odb.table("t").load(rows, now=NOW)
+        checked = 0
+        for qi in range(80):
+            q = make_query(rnd, tconf, rows)
+            if not _cluster_comparable(q, tconf):
+                continue
+            ctx = (seed, qi, q)
+            try:
+                want, ost = odb.query(q, now=NOW)
+            except vo.OutOfRange:
+                continue
+            except (vo.Unsupported, vo.InvalidArgument, ValueError, OverflowError):
+                with pytest.raises(hostdb.HostError):
+                    workers[0].query_merge(q, [w.query_partial(q, now=NOW)[0] for w in workers])
+                continue
+            try:
+                got, gst = workers[qi % 3].query_merge(q, [w.query_partial(q, now=NOW)[0] for w in workers])
+            except hostdb.HostError as e:
+                assert "stod" in str(e) and any(_stod_throws(c) for r in want for c in r), (str(e), ctx)
+                continue
+            if "sort" not in q and ("limit" in q or "skip" in q):
+                assert len(got) == len(want), ctx
+            elif "sort" not in q:
+                assert sorted(got) == sorted(want), ctx
+            else:
+                assert got == want, ctx
+            assert gst["aggregated_recs"] == ost["aggregated_recs"] and gst["output_recs"] == ost["output_recs"], ctx
+            checked += 1
+        assert checked >= 12
+    finally:
+        for w in workers:
+            w.close()
