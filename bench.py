@@ -52,13 +52,13 @@ def cpu_baseline(w, sample_segments: int):
     tw = cpu_twin.Twin(ot, w.query)
     tw.run()  # warm-up (page-in)
     secs = []
-    for _ in range(3):
+    for _ in range(7):
         tw.run()
         secs.append(tw.last_seconds)
     best = sorted(secs)[len(secs) // 2]
     rows = sample_segments * rows_per_seg
     return {"value": rows / best, "unit": "rows/s", "cores": 1, "kind": "port",
-            "sample": "%d segments x %d rows of %s (same generator, same query), median of 3 runs, "
+            "sample": "%d segments x %d rows of %s (same generator, same query), median of 7 runs, "
                       "g++ -O2 -funroll-loops -march=native, 1 thread; %.2f GB/s of referenced bytes"
                       % (sample_segments, rows_per_seg, w.name, rows * w.bytes_per_row_referenced / best / 1e9),
             "cpu": _cpu_model()}
@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--workload", default="C3")
     ap.add_argument("--segments", type=int, default=0, help="total segments (default: 1000 for C3, 100 for C2, 10 for C1)")
     ap.add_argument("--segment-rows", type=int, default=1_000_000)
-    ap.add_argument("--cpu-segments", type=int, default=40)
+    ap.add_argument("--cpu-segments", type=int, default=100, help="CPU baseline sample: this many segments of the same workload")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-parallel", action="store_true", help="also time the courtesy all-cores CPU baseline (adds ~30 s)")
     ap.add_argument("--flags", type=int, default=0)
