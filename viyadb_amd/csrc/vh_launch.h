@@ -5,9 +5,10 @@
 
 void vh_launch_scan_generic(int mode, const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s);
 void vh_launch_scan_fast_lds(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s);
-void vh_launch_scan_lanes_lds(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s);
-void vh_launch_scan_lanes_hash(const VhPlanDev& P, int grid, size_t lds, hipStream_t s);
-void vh_launch_scan_lanes_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s);
+// occ != nullptr: no launch; *occ = blocks of that instantiation that fit one CU with `lds` bytes of dynamic LDS
+void vh_launch_scan_lanes_lds(const VhPlanDev& P, int block, int grid, size_t lds, bool xcd_private, hipStream_t s, int* occ = nullptr);
+void vh_launch_scan_lanes_hash(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ = nullptr);
+void vh_launch_scan_lanes_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ = nullptr);
 void vh_launch_scan_fast_global(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s);
 void vh_launch_scan_fast_hash(const VhPlanDev& P, int grid, size_t lds, hipStream_t s);
 void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s);
