@@ -1187,6 +1187,9 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
 // update the LDS table directly. Restricted (host side) to DENSE_LDS plans with <= VH_LANES_COLS group and metric
 // columns of 4 or 8 bytes and no time truncation, chosen when the selectivity probe says >= 25 % of the rows pass.
 #define VH_LANES_COLS 2
+#ifndef VH_LANES_WAVES
+#define VH_LANES_WAVES(MODE, BLOCK, NP) ((MODE) == VH_MODE_DENSE_LDS && (BLOCK) == 256 && (NP) == 1 ? 6 : 0)
+#endif
 #define VH_PART_TILE 256     // row slots per wave tile of the lanes form of DENSE_PART phase 1 (= one sub-step)
 struct VhPartTile {
   uint64_t* sorted;    // LDS [VH_PART_TILE][tw]: this tile's tuples, ordered by partition
@@ -1210,7 +1213,7 @@ __device__ __forceinline__ void vh_load_rows4(const char* base, int type, uint32
 }
 
 template <int MODE, int BLOCK, int SCOPE, int NP>
-__global__ __launch_bounds__(BLOCK) void scan_agg_lanes_kernel(const VhPlanDev P) {
+__global__ __launch_bounds__(BLOCK, VH_LANES_WAVES(MODE, BLOCK, NP)) void scan_agg_lanes_kernel(const VhPlanDev P) {
   // MODE = VH_MODE_DENSE_LDS: direct-indexed LDS table. MODE = VH_MODE_HASH: the LDS front table (time buckets,
   // float keys, ...), rows that find no slot there go to the HBM table — same rules as the compacting kernel.
   extern __shared__ __attribute__((aligned(16))) char lds[];

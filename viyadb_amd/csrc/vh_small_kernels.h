@@ -593,6 +593,12 @@ __global__ __launch_bounds__(256) void partition_pairs_kernel(const VhPairArgs A
   }
 }
 
+// The first 512 bytes of a result region — scan counters and the emitted-row count — into the pinned host buffer
+// the emission kernel wrote its rows to (direct emission, see result_finalize_locked).
+__global__ __launch_bounds__(64) void publish_header_kernel(unsigned long long* host, const unsigned long long* dev) {
+  host[threadIdx.x] = dev[threadIdx.x];
+}
+
 __global__ __launch_bounds__(256) void iota_kernel(uint64_t* p, uint64_t n) {
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = i;
 }

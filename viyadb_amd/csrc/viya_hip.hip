@@ -1500,6 +1500,7 @@ extern "C" int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part
   if (r->topk) return vh_fail(VH_E_UNSUPPORTED, "top-N applies to merged groups: run the partial query without it");
   std::lock_guard<std::mutex> lk(r->table->mu);
   if (int rc = check_device_state(r, "vh_result_partition")) return rc;
+  if (int rc = check_host_view(r, "vh_result_partition")) return rc;   // small dense results were emitted straight into host staging
   const VhPlanDev& P = r->plan;
   hipStream_t st = g_ctx.stream;
   const uint64_t ng = r->ngroups_host;
@@ -1652,6 +1653,25 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   const VhPlanDev& P = r->plan;
   hipStream_t st = g_ctx.stream;
   *retry = 0;
+  // pinned staging buffer (two alternate, so a result stays readable while the next query runs)
+  const int slot = t->h_out_next; t->h_out_next ^= 1;
+  if (t->h_out_bytes[slot] < r->out_region_bytes) {
+    if (t->h_out[slot]) HIP_TRY(hipHostFree(t->h_out[slot]));
+    t->h_out[slot] = nullptr; t->h_out_bytes[slot] = 0;
+    const size_t nb = std::max<size_t>(r->out_region_bytes + r->out_region_bytes / 4, 1 << 20);
+    HIP_TRY(hipHostMalloc((void**)&t->h_out[slot], nb, hipHostMallocDefault));
+    t->h_out_bytes[slot] = nb;
+  }
+  // Small results of the dense paths are written by the emission kernel straight into that pinned host buffer
+  // (posted PCIe writes, coalesced per column) and a one-wave kernel publishes the 512-byte header behind them: no
+  // DMA-engine copy at the end of the query (its start-up costs 20-100 us, more than the 2 MB it moves).
+  static const bool env_no_direct = getenv("VH_NO_DIRECT_EMIT") != nullptr;
+  const bool one_shot = r->out_region_bytes <= (8u << 20) && !r->topk_active;
+  const bool direct = one_shot && r->mode != VH_MODE_HASH && !env_no_direct;
+  if (direct) {
+    for (int i = 0; i < P.ngroup; ++i) r->d_out_key[i] = t->h_out[slot] + r->off_key[i];
+    for (int j = 0; j < P.nmetric; ++j) r->d_out_state[j] = t->h_out[slot] + r->off_state[j];
+  }
   VhEmitArgs A{};
   A.mode = r->mode == VH_MODE_DENSE_PART ? VH_MODE_DENSE_GLOBAL : r->mode; A.ngroup = P.ngroup; A.nmetric = P.nmetric; A.key_words = P.key_words;
   A.n = r->out_cap; A.present = P.present; A.present_carrier = r->mode == VH_MODE_DENSE_GLOBAL ? P.present_carrier : -1; A.hkeys = P.hkeys; A.htags = P.htags; A.counters = P.counters;
@@ -1698,22 +1718,18 @@ static int result_finalize_locked(vh_result* r, int* retry) {
                        (const uint64_t*)r->d_topk_keys, (const unsigned long long*)r->d_out_count, (unsigned long long)r->topk, r->d_topk_state);
     HIP_TRY(hipGetLastError());
   }
-  // pinned staging buffer (two alternate, so a result stays readable while the next query runs)
-  const int slot = t->h_out_next; t->h_out_next ^= 1;
-  if (t->h_out_bytes[slot] < r->out_region_bytes) {
-    if (t->h_out[slot]) HIP_TRY(hipHostFree(t->h_out[slot]));
-    t->h_out[slot] = nullptr; t->h_out_bytes[slot] = 0;
-    const size_t nb = std::max<size_t>(r->out_region_bytes + r->out_region_bytes / 4, 1 << 20);
-    HIP_TRY(hipHostMalloc((void**)&t->h_out[slot], nb, hipHostMallocDefault));
-    t->h_out_bytes[slot] = nb;
-  }
   char* H = t->h_out[slot];
   const char* D = t->scratch + r->out_region_off;
-  const bool one_shot = r->out_region_bytes <= (8u << 20) && !r->topk_active;
   VhTopkState tk{};
   if (r->topk_active) HIP_TRY(hipMemcpyAsync(&tk, r->d_topk_state, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   // small results: counters, group count and every output array come back in ONE copy + ONE sync
-  HIP_TRY(hipMemcpyAsync(H, D, one_shot ? r->out_region_bytes : 512, hipMemcpyDeviceToHost, st));
+  if (direct) {
+    hipLaunchKernelGGL(publish_header_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long*>(H),
+                       reinterpret_cast<const unsigned long long*>(D));
+    HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(hipMemcpyAsync(H, D, one_shot ? r->out_region_bytes : 512, hipMemcpyDeviceToHost, st));
+  }
   HIP_TRY(hipEventRecord(t->ev[3], st));
   HIP_TRY(wait_event_spinning(t->ev[3]));
   const unsigned long long* hc = reinterpret_cast<const unsigned long long*>(H);
