@@ -9,7 +9,18 @@ void vh_launch_scan_fast_lds(const VhPlanDev& P, int grid, size_t lds, bool xcd_
 void vh_launch_scan_lanes_lds(const VhPlanDev& P, int block, int grid, size_t lds, bool xcd_private, hipStream_t s, int* occ = nullptr);
 void vh_launch_scan_lanes_hash(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ = nullptr);
 void vh_launch_scan_lanes_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ = nullptr);
-void vh_launch_scan_fast_global(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s);
-void vh_launch_scan_fast_hash(const VhPlanDev& P, int grid, size_t lds, hipStream_t s);
-void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s);
+void vh_launch_scan_fast_global(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s, int* occ = nullptr);
+void vh_launch_scan_fast_hash(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ = nullptr);
+void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ = nullptr);
 void vh_launch_part_agg(const VhPlanDev& P, int blocks_per_part, size_t lds, hipStream_t s);
+
+// Launch KERNEL (parenthesised template-id), or — occ != nullptr — only ask the runtime how many of its blocks fit one CU.
+#define VH_LAUNCH_OR_OCC(KERNEL, BLOCK, grid, lds, s, P, occ)                                             \
+  do {                                                                                                     \
+    auto k_ = KERNEL;                                                                                      \
+    if (occ) {                                                                                             \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(occ, k_, BLOCK, lds) != hipSuccess) *(occ) = 0;     \
+    } else {                                                                                               \
+      hipLaunchKernelGGL(k_, dim3(grid), dim3(BLOCK), lds, s, P);                                          \
+    }                                                                                                      \
+  } while (0)

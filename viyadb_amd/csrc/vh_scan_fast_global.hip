@@ -3,16 +3,16 @@
 #include "vh_launch.h"
 
 template <int SCOPE>
-static void launch_np(const VhPlanDev& P, int grid, size_t lds, hipStream_t s) {
+static void launch_np(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ) {
   switch (P.npred) {
-    case 0: case 1: hipLaunchKernelGGL((scan_agg_fast_kernel<VH_MODE_DENSE_GLOBAL, 256, SCOPE, 1>), dim3(grid), dim3(256), lds, s, P); break;
-    case 2: hipLaunchKernelGGL((scan_agg_fast_kernel<VH_MODE_DENSE_GLOBAL, 256, SCOPE, 2>), dim3(grid), dim3(256), lds, s, P); break;
-    case 3: hipLaunchKernelGGL((scan_agg_fast_kernel<VH_MODE_DENSE_GLOBAL, 256, SCOPE, 3>), dim3(grid), dim3(256), lds, s, P); break;
-    default: hipLaunchKernelGGL((scan_agg_fast_kernel<VH_MODE_DENSE_GLOBAL, 256, SCOPE, 4>), dim3(grid), dim3(256), lds, s, P); break;
+    case 0: case 1: VH_LAUNCH_OR_OCC((scan_agg_fast_kernel<VH_MODE_DENSE_GLOBAL, 256, SCOPE, 1>), 256, grid, lds, s, P, occ); break;
+    case 2: VH_LAUNCH_OR_OCC((scan_agg_fast_kernel<VH_MODE_DENSE_GLOBAL, 256, SCOPE, 2>), 256, grid, lds, s, P, occ); break;
+    case 3: VH_LAUNCH_OR_OCC((scan_agg_fast_kernel<VH_MODE_DENSE_GLOBAL, 256, SCOPE, 3>), 256, grid, lds, s, P, occ); break;
+    default: VH_LAUNCH_OR_OCC((scan_agg_fast_kernel<VH_MODE_DENSE_GLOBAL, 256, SCOPE, 4>), 256, grid, lds, s, P, occ); break;
   }
 }
 
-void vh_launch_scan_fast_global(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s) {
-  if (xcd_private) launch_np<__HIP_MEMORY_SCOPE_WORKGROUP>(P, grid, lds, s);
-  else launch_np<__HIP_MEMORY_SCOPE_AGENT>(P, grid, lds, s);
+void vh_launch_scan_fast_global(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s, int* occ) {
+  if (xcd_private) launch_np<__HIP_MEMORY_SCOPE_WORKGROUP>(P, grid, lds, s, occ);
+  else launch_np<__HIP_MEMORY_SCOPE_AGENT>(P, grid, lds, s, occ);
 }

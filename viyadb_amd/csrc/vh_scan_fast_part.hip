@@ -2,12 +2,12 @@
 #include "vh_kernels.h"
 #include "vh_launch.h"
 
-void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s) {
+void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ) {
   switch (P.npred) {
-    case 0: case 1: hipLaunchKernelGGL((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 1>), dim3(grid), dim3(256), lds, s, P); break;
-    case 2: hipLaunchKernelGGL((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 2>), dim3(grid), dim3(256), lds, s, P); break;
-    case 3: hipLaunchKernelGGL((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 3>), dim3(grid), dim3(256), lds, s, P); break;
-    default: hipLaunchKernelGGL((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 4>), dim3(grid), dim3(256), lds, s, P); break;
+    case 0: case 1: VH_LAUNCH_OR_OCC((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 1>), 256, grid, lds, s, P, occ); break;
+    case 2: VH_LAUNCH_OR_OCC((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 2>), 256, grid, lds, s, P, occ); break;
+    case 3: VH_LAUNCH_OR_OCC((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 3>), 256, grid, lds, s, P, occ); break;
+    default: VH_LAUNCH_OR_OCC((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 4>), 256, grid, lds, s, P, occ); break;
   }
 }
 

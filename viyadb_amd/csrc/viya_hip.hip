@@ -1240,13 +1240,26 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     if (env_lanes_block == 256 || env_lanes_block == 512 || env_lanes_block == 1024) BLOCK = env_lanes_block;
     else if ((uint64_t)g_ctx.num_cu * 5 * G * std::max(1, P.nmetric) <= rows_to_scan / 32) BLOCK = 256;
   }
-  int occupancy = 0;
-  if (lanes && fast && env_bpc <= 0) {
+  if (mode == VH_MODE_DENSE_PART && P.stage_cap == 0) lanes = false;   // the unstaged experiment has no lanes form
+  // One place decides which scan kernel runs; with `occ` it only asks how many of its blocks fit a CU.
+  auto scan_dispatch = [&](int grid_, int* occ) {
     const size_t qb = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint32_t);
-    if (mode == VH_MODE_DENSE_LDS) vh_launch_scan_lanes_lds(P, BLOCK, 0, lds_table + qb, nxcd > 1, nullptr, &occupancy);
-    else if (mode == VH_MODE_HASH) vh_launch_scan_lanes_hash(P, 0, lds_table + qb, nullptr, &occupancy);
-    else if (mode == VH_MODE_DENSE_PART && P.stage_cap > 0) vh_launch_scan_lanes_part(P, 0, 4 * vh_part_tile_bytes(P), nullptr, &occupancy);
-  }
+    const size_t lds_ = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + qb;
+    hipStream_t s_ = g_ctx.stream;
+    if (mode == VH_MODE_DENSE_PART) {
+      const size_t wave_area = ((size_t)P.npart * ((size_t)P.stage_cap * P.tw * 8 + 12) + 15) / 16 * 16;
+      if (lanes) { P.part_tile = VH_PART_TILE; vh_launch_scan_lanes_part(P, grid_, 4 * vh_part_tile_bytes(P), s_, occ); }
+      else vh_launch_scan_fast_part(P, grid_, qb + 4 * wave_area, s_, occ);
+    }
+    else if (!fast) { if (!occ) vh_launch_scan_generic(mode, P, grid_, lds_, nxcd > 1, s_); }
+    else if (lanes && mode == VH_MODE_HASH) vh_launch_scan_lanes_hash(P, grid_, lds_, s_, occ);
+    else if (lanes) vh_launch_scan_lanes_lds(P, BLOCK, grid_, lds_, nxcd > 1, s_, occ);
+    else if (mode == VH_MODE_DENSE_LDS) { if (!occ) vh_launch_scan_fast_lds(P, grid_, lds_, nxcd > 1, s_); }   // 1024-thread blocks: one per CU
+    else if (mode == VH_MODE_DENSE_GLOBAL) vh_launch_scan_fast_global(P, grid_, lds_, nxcd > 1, s_, occ);
+    else vh_launch_scan_fast_hash(P, grid_, lds_, s_, occ);
+  };
+  int occupancy = 0;
+  if (env_bpc <= 0) scan_dispatch(0, &occupancy);
   const uint32_t step = BLOCK * 16;
   const uint64_t padded = (t->segment_rows + step - 1) / step * step;
   // all blocks co-resident (the compacting kernels need ~100-130 VGPRs: 4 waves/SIMD), units small enough
@@ -1404,25 +1417,14 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     rc = fill_states(P.m[j].state, table_n, vh_sop_bytes(P.m[j].sop()), P.m[j].ident, st);
     if (rc) { delete r; return rc; }
   }
-  const size_t qbytes = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint32_t);
   HIP_TRY(hipEventRecord(t->ev[1], st));
-  if (mode == VH_MODE_DENSE_PART && P.stage_cap == 0) lanes = false;   // the unstaged experiment has no lanes form
   r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0);
   if (P.total_units) {
-    const size_t lds = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + qbytes;
+    scan_dispatch(grid, nullptr);
     if (mode == VH_MODE_DENSE_PART) {
-      const size_t wave_area = ((size_t)P.npart * ((size_t)P.stage_cap * P.tw * 8 + 12) + 15) / 16 * 16;
-      if (lanes && P.stage_cap > 0) { P.part_tile = VH_PART_TILE; vh_launch_scan_lanes_part(P, grid, 4 * vh_part_tile_bytes(P), st); }
-      else { lanes = false; vh_launch_scan_fast_part(P, grid, qbytes + 4 * wave_area, st); }
       const int bpp = std::max(1, std::min(16, g_ctx.num_cu / std::max(1, P.npart)));
       vh_launch_part_agg(P, bpp, lds_table, st);
     }
-    else if (!fast) vh_launch_scan_generic(mode, P, grid, lds, nxcd > 1, st);
-    else if (lanes && mode == VH_MODE_HASH) vh_launch_scan_lanes_hash(P, grid, lds, st);
-    else if (lanes) vh_launch_scan_lanes_lds(P, BLOCK, grid, lds, nxcd > 1, st);
-    else if (mode == VH_MODE_DENSE_LDS) vh_launch_scan_fast_lds(P, grid, lds, nxcd > 1, st);
-    else if (mode == VH_MODE_DENSE_GLOBAL) vh_launch_scan_fast_global(P, grid, lds, nxcd > 1, st);
-    else vh_launch_scan_fast_hash(P, grid, lds, st);
   }
   HIP_TRY(hipEventRecord(t->ev[2], st));
   HIP_TRY(hipGetLastError());
