@@ -15,3 +15,5 @@ REPO=$PWD
 python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/c3_1gpu_pmc_hbm.json --rows 1000000000 --bref 32e9
 python tools/pmc_summary.py --kernel-stats $(find $OUT/kt -name "*_results.db" | head -1) $OUT/c3_1gpu_kernel_stats.csv; head -4 $OUT/c3_1gpu_kernel_stats.csv
 python bench.py --workload C2 --no-cpu > $OUT/bench_c2_1gpu.json 2>> $OUT/bench_c3.err; tail -c 400 $OUT/bench_c2_1gpu.json
+(cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/$OUT/kt_c2 -o c2 -- python $REPO/bench.py --workload C2 --steps 20 --warmup 2 --no-cpu > $REPO/$OUT/kt_c2.log 2>&1)
+python tools/pmc_summary.py --kernel-stats $(find $OUT/kt_c2 -name "*_results.db" | head -1) $OUT/c2_1gpu_kernel_stats.csv; head -3 $OUT/c2_1gpu_kernel_stats.csv
