@@ -96,3 +96,51 @@ def test_c2_full_size_against_twin():
         compare(res, st, "C2 100M")
     finally:
         t.close()
+
+
+def test_c5_per_gpu_share_properties():
+    """BASELINE config 5 (time rollup + COUNT DISTINCT, millions of sparse groups) at one GPU's share of the 8-GPU run:
+    125 M rows. Size-independent properties: COUNT is linear over segment ranges group by group, a distinct count is
+    bounded by max / sum of the halves' distinct counts and by the ids stored, nothing depends on the run, and a
+    two-segment window equals the oracle exactly."""
+    from oracle import viya_oracle as vo
+    from tests.parity import build_oracle_table, compare
+    from viyadb_amd import executor, synth
+    executor.init(0)
+    w = synth.c5()
+    nseg, rows = 125, 1_000_000
+    t = synth.create_device_table(w, nseg)
+    try:
+        def run(snap=None):
+            r = t.query_agg(_plan(w, seg_rows=snap))
+            key = (r.keys[0].astype(np.uint64) << np.uint64(32)) | r.keys[1].astype(np.uint64)
+            o = np.argsort(key, kind="stable")
+            return r, key[o], r.states[0][o].astype(np.int64), r.states[1][o].astype(np.int64)
+
+        full, kf, df, cf = run()
+        assert full.path == "hash" and full.scanned_recs == nseg * rows
+        assert full.ngroups == len(kf) == len(np.unique(kf)) > 20_000_000
+        assert int(cf.sum()) >= full.passed_recs            # every stored row counts 1..3 (the generator's count column)
+        assert (df >= 1).all() and (df <= 2 * cf).all()      # a stored row holds 2 ids; a group cannot see more than 2 per counted row
+        lo, kl, dl, cl = run([rows] * 60 + [0] * 65)
+        hi, kh, dh, ch = run([0] * 60 + [rows] * 65)
+        assert lo.passed_recs + hi.passed_recs == full.passed_recs
+        il, ih = np.searchsorted(kf, kl), np.searchsorted(kf, kh)
+        assert (kf[il] == kl).all() and (kf[ih] == kh).all()
+        c2, dsum, dmax = np.zeros_like(cf), np.zeros_like(df), np.zeros_like(df)
+        c2[il] += cl; c2[ih] += ch
+        dsum[il] += dl; dsum[ih] += dh
+        dmax[il] = dl; dmax[ih] = np.maximum(dmax[ih], dh)
+        assert np.array_equal(c2, cf)                        # COUNT: linear
+        assert (df <= dsum).all() and (df >= dmax).all()     # COUNT DISTINCT: sub-additive, monotone
+        again, ka, da, ca = run()
+        assert np.array_equal(ka, kf) and np.array_equal(da, df) and np.array_equal(ca, cf)
+        snap = [0] * nseg
+        snap[61] = snap[62] = rows
+        res = t.query_agg(_plan(w, seg_rows=snap))
+        ot = build_oracle_table(w, 2, rows, row_base=61 * rows)
+        st = vo.scan_aggregate(vo.parse_query(ot, w.query), now=w.now)
+        st.scanned_recs, st.scanned_segments = res.scanned_recs, res.scanned_segments
+        compare(res, st, "C5 125-segment table, 2-segment window")
+    finally:
+        t.close()
