@@ -406,7 +406,28 @@ __device__ __forceinline__ void vh_distinct_update(const VhPlanDev& P, int b, un
   const uint64_t* offs = P.bs_offs[b][seg];
   const uint64_t o0 = offs[row], o1 = offs[row + 1];
   const void* vals = P.bs_vals[b][seg];
-  for (uint64_t k = o0; k < o1; ++k) {
+  uint64_t k = o0;
+  if (!P.bs_wide[b]) {
+    // Two ids at a time with both first probes in flight (the common shape: a couple of ids per stored row): the
+    // CAS round trips overlap instead of queueing behind each other, and the row's fresh pairs bump the group's
+    // cardinality with ONE atomic. Whatever does not settle on its first probe takes the general loop below.
+    unsigned long long* tab = reinterpret_cast<unsigned long long*>(P.dset_keys[b]);
+    const uint32_t* ids = reinterpret_cast<const uint32_t*>(vals);
+    unsigned long long nfresh = 0;
+    for (; k + 2 <= o1; k += 2) {
+      const uint64_t ka = (gid << 32) | ids[k], kb = (gid << 32) | ids[k + 1];
+      const uint64_t sa = vh_splitmix64(ka) & P.dset_mask[b], sb = vh_splitmix64(kb) & P.dset_mask[b];
+      unsigned long long ea = VH_HASH_EMPTY, eb = VH_HASH_EMPTY;
+      const bool wa = __hip_atomic_compare_exchange_strong(tab + sa, &ea, (unsigned long long)ka, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // identical ids in one row would race for the same slot: the second one must see the first one's write
+      const bool wb = ka == kb ? false : __hip_atomic_compare_exchange_strong(tab + sb, &eb, (unsigned long long)kb, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      nfresh += (wa ? 1 : 0) + (wb ? 1 : 0);
+      if (!wa && ea != ka) { bool ok = true, fresh = false; vh_set_insert64(P.dset_keys[b], P.dset_mask[b], 4096u, ka, ok, fresh); if (!ok) atomicOr(P.counters + 2, VH_ERR_HASH_FULL); nfresh += fresh ? 1 : 0; }
+      if (ka != kb && !wb && eb != kb) { bool ok = true, fresh = false; vh_set_insert64(P.dset_keys[b], P.dset_mask[b], 4096u, kb, ok, fresh); if (!ok) atomicOr(P.counters + 2, VH_ERR_HASH_FULL); nfresh += fresh ? 1 : 0; }
+    }
+    if (nfresh) { atomicAdd(card + gid, nfresh); npairs += nfresh; }
+  }
+  for (; k < o1; ++k) {
     bool ok = true, fresh = false;
     if (P.bs_wide[b]) {
       const uint64_t key[2] = {gid, reinterpret_cast<const uint64_t*>(vals)[k]};
