@@ -1,0 +1,97 @@
+"""SURVEY 8(b) threading row: the reference enters the aggregate function from several read_pool threads while one writer
+appends (src/db/database.cc:28-34). The library serialises per table handle; different tables run concurrently on the
+shared stream. Threads hammer their own tables and one shared table (ctypes drops the GIL inside the calls) while a writer
+keeps syncing new segments into the shared one; every answer must equal the single-threaded answer for the snapshot used."""
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_concurrent_queries_and_a_writer():
+    from viyadb_amd import capi, executor
+    from viyadb_amd.executor import AggPlan, DeviceTable, GroupSpec
+    executor.init(0)
+    rows, nseg = 50_000, 6
+    rng = np.random.default_rng(11)
+
+    def make_table(seed):
+        r = np.random.default_rng(seed)
+        t = DeviceTable([(capi.DIM_NUMERIC, capi.U32), (capi.DIM_NUMERIC, capi.U32), (capi.METRIC_SUM, capi.I64), (capi.METRIC_COUNT, capi.U32)],
+                        rows, reserve_segments=nseg)
+        data = []
+        for s in range(nseg):
+            cols = [r.integers(0, 300, rows).astype(np.uint32), r.integers(0, 1000, rows).astype(np.uint32),
+                    r.integers(-1000, 1000, rows).astype(np.int64), np.ones(rows, dtype=np.uint32)]
+            t.sync_segment(s, cols, rows)
+            data.append(cols)
+        return t, data
+
+    def expected(data, nsegs, thresh):
+        k = np.concatenate([d[0] for d in data[:nsegs]])
+        f = np.concatenate([d[1] for d in data[:nsegs]])
+        v = np.concatenate([d[2] for d in data[:nsegs]])
+        m = f < thresh
+        sums = np.zeros(300, dtype=np.int64)
+        cnts = np.zeros(300, dtype=np.int64)
+        np.add.at(sums, k[m], v[m])
+        np.add.at(cnts, k[m], 1)
+        return sums, cnts
+
+    def check(t, data, nsegs, thresh, flags=0):
+        res = t.query_agg(AggPlan(filter=[("rel", 1, capi.OP_LT, thresh)], groups=[GroupSpec(0)], metrics=[2, 3], seg_rows=[rows] * nsegs,
+                                  flags=flags))
+        sums, cnts = expected(data, nsegs, thresh)
+        got_s = np.zeros(300, dtype=np.int64)
+        got_c = np.zeros(300, dtype=np.int64)
+        got_s[res.keys[0]] = res.states[0]
+        got_c[res.keys[0]] = res.states[1]
+        assert np.array_equal(got_s, sums) and np.array_equal(got_c, cnts), (nsegs, thresh, flags)
+
+    own = [make_table(100 + i) for i in range(3)]
+    shared, shared_data = make_table(7)
+    extra = [[rng.integers(0, 300, rows).astype(np.uint32), rng.integers(0, 1000, rows).astype(np.uint32),
+              rng.integers(-1000, 1000, rows).astype(np.int64), np.ones(rows, dtype=np.uint32)] for _ in range(6)]
+    errors = []
+    synced = [nseg]            # segments of the shared table that are completely synced (only the writer appends)
+
+    def reader_own(i):
+        try:
+            t, data = own[i]
+            for it in range(60):
+                check(t, data, 1 + (it % nseg), 100 + 37 * (it % 20), flags=[0, 1, 2, 8][it % 4])
+        except Exception as e:   # noqa: BLE001
+            errors.append(("own", i, repr(e)))
+
+    def reader_shared(i):
+        try:
+            for it in range(60):
+                n = synced[0]     # size() snapshot: whatever the writer finished before this query
+                check(shared, shared_data, n, 150 + 41 * ((it + i) % 20), flags=[0, 1][it % 2])
+        except Exception as e:   # noqa: BLE001
+            errors.append(("shared", i, repr(e)))
+
+    def writer():
+        try:
+            for s, cols in enumerate(extra):
+                shared_data.append(cols)
+                shared.sync_segment(nseg + s, cols, rows)
+                synced[0] = nseg + s + 1
+        except Exception as e:   # noqa: BLE001
+            errors.append(("writer", 0, repr(e)))
+
+    threads = [threading.Thread(target=reader_own, args=(i,)) for i in range(3)]
+    threads += [threading.Thread(target=reader_shared, args=(i,)) for i in range(3)] + [threading.Thread(target=writer)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    try:
+        assert not errors, errors[:3]
+        check(shared, shared_data, nseg + len(extra), 500)
+    finally:
+        for t, _ in own:
+            t.close()
+        shared.close()

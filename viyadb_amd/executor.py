@@ -9,6 +9,7 @@ produces (src/codegen/query/agg_query.cc:26-75): a table of SoA segments in, a s
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -92,6 +93,10 @@ class DeviceTable:
         h = C.c_void_p()
         capi.check(self.lib.vh_table_create(arr, len(self.cols), self.segment_rows, int(reserve_segments), C.byref(h)))
         self.handle = h
+        # a result's host view aliases one of the table's two staging buffers (valid until the second-next query on the
+        # table): query + collect is one critical section per table when threads share a DeviceTable, as the C++ host
+        # shim does with Table::mu
+        self._lock = threading.RLock()
 
     def close(self):
         if self.handle:
@@ -271,11 +276,12 @@ class DeviceTable:
     def query_agg(self, plan: AggPlan, copy: bool = True) -> AggResult:
         p, keep = self._build_plan(plan)
         res = C.c_void_p()
-        capi.check(self.lib.vh_query_agg(self.handle, C.byref(p), C.byref(res)))
-        try:
-            return self._collect(res, plan, copy)
-        finally:
-            self.lib.vh_result_free(res)
+        with self._lock:
+            capi.check(self.lib.vh_query_agg(self.handle, C.byref(p), C.byref(res)))
+            try:
+                return self._collect(res, plan, copy)
+            finally:
+                self.lib.vh_result_free(res)
 
     # ---- select: the passing rows themselves, in storage order, through the reference's skip/limit window
     def query_select(self, filter: Sequence, cols: Sequence[int], skip: int = 0, limit: int = 0,
