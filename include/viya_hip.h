@@ -27,6 +27,15 @@
  *
  * Threading: calls on one vh_table serialise on a per-table lock; all device work goes
  * to one HIP stream (vh_set_stream), so results of a call are complete when it returns.
+ *
+ * Lifetime of a vh_result: its device-side state (what vh_result_finalize,
+ * vh_result_device_buffers and vh_result_partition[_pairs] read) lives in the table's
+ * scratch arena until the NEXT query is launched on that table; its host view
+ * (vh_result_view / vh_result_copy) lives in one of the table's two pinned staging
+ * buffers until the SECOND-next query is finalised on it. A handle used past either
+ * point is refused with VH_E_INVALID ("stale result handle"), never served from reused
+ * memory; callers that share a table between threads take their own lock around
+ * query + copy (the C++ host shim: Table::mu). A vh_result must not outlive its table.
  */
 #ifndef VIYA_HIP_H_
 #define VIYA_HIP_H_
