@@ -34,6 +34,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     hdrs = [s for s in srcs if s.endswith(".h")]
     units = [s for s in srcs if s.endswith(".hip")]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result"]
+    flags += os.environ.get("VH_EXTRA_HIPCC_FLAGS", "").split()   # experiments (e.g. -DVH_SUBSTEPS=2); force=True to apply
     procs, objs = [], []
     for u in units:
         o = os.path.join(objdir, os.path.basename(u)[:-4] + ".o")

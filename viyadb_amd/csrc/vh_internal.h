@@ -26,8 +26,12 @@
 // lane l owns rows {k*256 + l*4 + j | k,j in 0..3} -> 16 rows, 16 mask bits.
 #define VH_WAVE 64
 #define VH_ROWS_PER_LANE_VEC 4
-#define VH_SUBSTEPS 4
-#define VH_WAVE_STEP_ROWS 1024
+#ifndef VH_SUBSTEPS
+#define VH_SUBSTEPS 4                              // sub-steps of 256 rows a wave handles per step (4 rows per lane each)
+#endif
+#define VH_LANE_ROWS (4 * VH_SUBSTEPS)             // rows a lane owns per wave step
+#define VH_WAVE_STEP_ROWS (256 * VH_SUBSTEPS)
+#define VH_ROWMASK ((1u << VH_LANE_ROWS) - 1u)     // pass-mask bits of one lane
 
 // state-update opcodes (what one surviving row does to one metric state)
 enum vh_state_op : uint8_t {

@@ -109,7 +109,7 @@ __device__ __forceinline__ void vh_load4(const T* __restrict__ p, T* out) {
 
 template <typename T, bool FULL>
 __device__ __forceinline__ void vh_load16(const T* __restrict__ col, uint32_t row_l,
-                                          uint32_t seg_rows, T (&v)[16]) {
+                                          uint32_t seg_rows, T (&v)[VH_LANE_ROWS]) {
 #pragma unroll
   for (int k = 0; k < VH_SUBSTEPS; ++k) {
     const uint32_t r = row_l + k * 256u;
@@ -124,32 +124,32 @@ __device__ __forceinline__ void vh_load16(const T* __restrict__ col, uint32_t ro
 // (col OP lit) for 16 rows, in the column's own C++ type, like the generated
 // `(tuple_dims._i[tuple_idx] OP fargK)` (filter.cc:206-221).
 template <typename T>
-__device__ __forceinline__ uint32_t vh_cmp16(const T (&v)[16], T lit, int op) {
+__device__ __forceinline__ uint32_t vh_cmp16(const T (&v)[VH_LANE_ROWS], T lit, int op) {
   uint32_t m = 0;
   switch (op) {
     case VH_OP_EQ:
 #pragma unroll
-      for (int i = 0; i < 16; ++i) m |= (uint32_t)(v[i] == lit) << i;
+      for (int i = 0; i < VH_LANE_ROWS; ++i) m |= (uint32_t)(v[i] == lit) << i;
       break;
     case VH_OP_NE:
 #pragma unroll
-      for (int i = 0; i < 16; ++i) m |= (uint32_t)(v[i] != lit) << i;
+      for (int i = 0; i < VH_LANE_ROWS; ++i) m |= (uint32_t)(v[i] != lit) << i;
       break;
     case VH_OP_LT:
 #pragma unroll
-      for (int i = 0; i < 16; ++i) m |= (uint32_t)(v[i] < lit) << i;
+      for (int i = 0; i < VH_LANE_ROWS; ++i) m |= (uint32_t)(v[i] < lit) << i;
       break;
     case VH_OP_LE:
 #pragma unroll
-      for (int i = 0; i < 16; ++i) m |= (uint32_t)(v[i] <= lit) << i;
+      for (int i = 0; i < VH_LANE_ROWS; ++i) m |= (uint32_t)(v[i] <= lit) << i;
       break;
     case VH_OP_GT:
 #pragma unroll
-      for (int i = 0; i < 16; ++i) m |= (uint32_t)(v[i] > lit) << i;
+      for (int i = 0; i < VH_LANE_ROWS; ++i) m |= (uint32_t)(v[i] > lit) << i;
       break;
     default:
 #pragma unroll
-      for (int i = 0; i < 16; ++i) m |= (uint32_t)(v[i] >= lit) << i;
+      for (int i = 0; i < VH_LANE_ROWS; ++i) m |= (uint32_t)(v[i] >= lit) << i;
       break;
   }
   return m;
@@ -158,11 +158,11 @@ __device__ __forceinline__ uint32_t vh_cmp16(const T (&v)[16], T lit, int op) {
 template <typename T, bool FULL>
 __device__ __forceinline__ uint32_t vh_leaf(const VhPlanDev& P, const VhProgOp o, const char* base,
                                             uint32_t row_l, uint32_t seg_rows) {
-  T v[16];
+  T v[VH_LANE_ROWS];
   vh_load16<T, FULL>(reinterpret_cast<const T*>(base), row_l, seg_rows, v);
   if (o.kind() == VH_F_REL) return vh_cmp16<T>(v, vh_lit<T>(P.lits[o.lit()]), o.op());
   // IN: OR of ==, NOT IN: AND of != (filter.cc:223-241)
-  uint32_t m = o.op() ? 0u : 0xFFFFu;
+  uint32_t m = o.op() ? 0u : VH_ROWMASK;
   for (int i = 0; i < o.count(); ++i) {
     const T lit = vh_lit<T>(P.lits[o.lit() + i]);
     if (o.op()) m |= vh_cmp16<T>(v, lit, VH_OP_EQ);
@@ -182,7 +182,7 @@ __device__ __forceinline__ uint32_t vh_eval_filter(const VhPlanDev& P, uint32_t 
   for (int pc = 0; pc < P.nprog; ++pc) {
     const VhProgOp o = P.prog[pc];
     switch (o.kind()) {
-      case VH_F_TRUE: st[sp++] = 0xFFFFu; break;
+      case VH_F_TRUE: st[sp++] = VH_ROWMASK; break;
       case VH_F_AND: {
         uint32_t a = st[--sp];
         for (int i = 1; i < o.count(); ++i) a &= st[--sp];
@@ -587,7 +587,7 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
 template <int BLOCK>
 struct VhScanCfg {
   static constexpr int kWaves = BLOCK / 64;
-  static constexpr int kStepRows = BLOCK * 16;
+  static constexpr int kStepRows = BLOCK * VH_LANE_ROWS;
   static constexpr int kQueueCap = 64 + 256;  // carry-over (<64) + one sub-step (<=256)
 };
 
@@ -879,14 +879,14 @@ __device__ __forceinline__ void vh_part_finish(const VhPlanDev& P, VhPartWave& W
 //   * a survivor's group and metric values are all gathered before the first dependent use.
 // Same results, same table organisations, same C-ABI.
 template <typename T>
-__device__ __forceinline__ uint32_t vh_cmp16_bits(const uint32_t (&bits)[16], uint64_t litbits, int op) {
-  T v[16];
+__device__ __forceinline__ uint32_t vh_cmp16_bits(const uint32_t (&bits)[VH_LANE_ROWS], uint64_t litbits, int op) {
+  T v[VH_LANE_ROWS];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) v[i] = __builtin_bit_cast(T, bits[i]);
+  for (int i = 0; i < VH_LANE_ROWS; ++i) v[i] = __builtin_bit_cast(T, bits[i]);
   return vh_cmp16<T>(v, vh_lit<T>(litbits), op);
 }
 
-__device__ __forceinline__ uint32_t vh_leaf_bits(const VhPlanDev& P, const VhProgOp o, const uint32_t (&bits)[16]) {
+__device__ __forceinline__ uint32_t vh_leaf_bits(const VhPlanDev& P, const VhProgOp o, const uint32_t (&bits)[VH_LANE_ROWS]) {
   if (o.kind() == VH_F_REL) {
     switch (o.type()) {
       case VH_I32: return vh_cmp16_bits<int32_t>(bits, P.lits[o.lit()], o.op());
@@ -894,7 +894,7 @@ __device__ __forceinline__ uint32_t vh_leaf_bits(const VhPlanDev& P, const VhPro
       default: return vh_cmp16_bits<uint32_t>(bits, P.lits[o.lit()], o.op());
     }
   }
-  uint32_t m = o.op() ? 0u : 0xFFFFu;
+  uint32_t m = o.op() ? 0u : VH_ROWMASK;
   for (int i = 0; i < o.count(); ++i) {
     const uint64_t lit = P.lits[o.lit() + i];
     uint32_t e;
@@ -910,7 +910,7 @@ __device__ __forceinline__ uint32_t vh_leaf_bits(const VhPlanDev& P, const VhPro
 
 template <int NP>
 __device__ __forceinline__ void vh_preload(const VhPlanDev& P, uint32_t seg, uint32_t row_l, uint32_t seg_rows,
-                                           uint32_t (&v)[NP][16]) {
+                                           uint32_t (&v)[NP][VH_LANE_ROWS]) {
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
     const uint32_t* col = reinterpret_cast<const uint32_t*>(P.colbase[P.pred_slot[p]] + (uint64_t)seg * P.colstride[P.pred_slot[p]]);
@@ -928,14 +928,14 @@ __device__ __forceinline__ void vh_preload(const VhPlanDev& P, uint32_t seg, uin
 }
 
 template <int NP>
-__device__ __forceinline__ uint32_t vh_eval_filter_fast(const VhPlanDev& P, const uint32_t (&v)[NP][16], uint32_t row_l,
+__device__ __forceinline__ uint32_t vh_eval_filter_fast(const VhPlanDev& P, const uint32_t (&v)[NP][VH_LANE_ROWS], uint32_t row_l,
                                                         uint32_t seg_rows) {
   uint32_t st[VH_MAX_STACK];
   int sp = 0;
   for (int pc = 0; pc < P.nprog; ++pc) {
     const VhProgOp o = P.prog[pc];
     switch (o.kind()) {
-      case VH_F_TRUE: st[sp++] = 0xFFFFu; break;
+      case VH_F_TRUE: st[sp++] = VH_ROWMASK; break;
       case VH_F_AND: {
         uint32_t a = st[--sp];
         for (int i = 1; i < o.count(); ++i) a &= st[--sp];
@@ -956,7 +956,7 @@ __device__ __forceinline__ uint32_t vh_eval_filter_fast(const VhPlanDev& P, cons
     }
   }
   uint32_t m = st[0];
-  if (row_l + 3 * 256u + 4u > seg_rows) {
+  if (row_l + (VH_SUBSTEPS - 1) * 256u + 4u > seg_rows) {
 #pragma unroll
     for (int k = 0; k < VH_SUBSTEPS; ++k) {
       const uint32_t r = row_l + k * 256u;
@@ -1076,8 +1076,11 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
   }
 }
 
+#ifndef VH_FAST_WAVES
+#define VH_FAST_WAVES(MODE, BLOCK, NP) 0      // waves per SIMD asked of the compiler (0: no request); experiments override it
+#endif
 template <int MODE, int BLOCK, int SCOPE, int NP>
-__global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P) {
+__global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_agg_fast_kernel(const VhPlanDev P) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef VhScanCfg<BLOCK> C;
   const int lane = threadIdx.x & 63;
@@ -1123,7 +1126,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_fast_kernel(const VhPlanDev P)
       wave_base = unit_base + wave * VH_WAVE_STEP_ROWS;
     }
   }
-  uint32_t v[NP][16];
+  uint32_t v[NP][VH_LANE_ROWS];
   if (have) vh_preload<NP>(P, seg, wave_base + lane * 4, seg_rows, v);
   uint32_t cnt = 0;
   while (have) {
@@ -1280,7 +1283,7 @@ __global__ __launch_bounds__(BLOCK, VH_LANES_WAVES(MODE, BLOCK, NP)) void scan_a
       wave_base = unit_base + wave * VH_WAVE_STEP_ROWS;
     }
   }
-  uint32_t v[NP][16];
+  uint32_t v[NP][VH_LANE_ROWS];
   if (have) vh_preload<NP>(P, seg, wave_base + lane * 4, seg_rows, v);
   bool range_err = false, full_err = false;
   while (have) {

@@ -1260,7 +1260,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   };
   int occupancy = 0;
   if (env_bpc <= 0) scan_dispatch(0, &occupancy);
-  const uint32_t step = BLOCK * 16;
+  const uint32_t step = BLOCK * VH_LANE_ROWS;
   const uint64_t padded = (t->segment_rows + step - 1) / step * step;
   // all blocks co-resident (the compacting kernels need ~100-130 VGPRs: 4 waves/SIMD), units small enough
   // that the static round-robin leaves < 2 % imbalance
@@ -1976,7 +1976,7 @@ extern "C" int vh_measure_read_bandwidth(uint64_t bytes, int32_t iters, double* 
   HIP_TRY(hipMemsetAsync(sink, 0, 8, g_ctx.stream));
   hipEvent_t a, b;
   HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-  const int grid = g_ctx.num_cu * 8;
+  const int grid = g_ctx.num_cu * (getenv("VH_BW_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("VH_BW_BLOCKS_PER_CU"))) : 8);   // 256-thread blocks: 8 per CU = 8 waves/SIMD
   hipLaunchKernelGGL(read_bw_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const vh_u32x4*)buf, bytes / 16, sink);
   HIP_TRY(hipEventRecord(a, g_ctx.stream));
   for (int i = 0; i < iters; ++i)
