@@ -161,12 +161,8 @@ enum vh_plan_flags {
                                      when most rows pass                      */
   VH_PLAN_FORCE_LANES = 1u << 8,  /* testing: the no-compaction "lanes" kernel
                                      whenever the plan is eligible            */
-  VH_PLAN_NO_LDS_HASH = 1u << 9,  /* ablation: hash path without the per-block
+  VH_PLAN_NO_LDS_HASH = 1u << 9   /* ablation: hash path without the per-block
                                      LDS front table                          */
-  VH_PLAN_TWO_PASS = 1u << 10,    /* compacting scan over a dense HBM table in two
-                                     kernels: predicate columns -> pass masks,
-                                     then gathers + updates from the masks      */
-  VH_PLAN_NO_TWO_PASS = 1u << 11  /* ablation: always the fused kernel          */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */
@@ -214,7 +210,7 @@ typedef struct vh_result_info {
   float total_ms;            /* HIP-event time launch .. results in host mem */
   uint64_t algorithmic_bytes;/* B_ref of SURVEY §8(d) for this query         */
   uint32_t retries;          /* hash-table regrows                           */
-  uint32_t reserved;         /* bit 0: the register-resident fast scan kernel ran; bit 1: its no-compaction "lanes" variant; bit 2: LDS front table; bit 3: two-pass form */
+  uint32_t reserved;         /* bit 0: the register-resident fast scan kernel ran; bit 1: its no-compaction "lanes" variant */
   uint64_t returned_groups;  /* rows vh_result_copy delivers (= ngroups without HAVING) */
 } vh_result_info;
 

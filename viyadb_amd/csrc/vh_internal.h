@@ -176,11 +176,6 @@ struct VhPlanDev {
   //                [3] reserved hash slot (key == sentinel) in use, [4] distinct (group, id) pairs,
   //                [5] extent allocation cursor (DENSE_PART)
   unsigned long long* counters;
-  // ---- two-pass form of the compacting scan (VH_PLAN_TWO_PASS): pass 1 (scan_mask_kernel) streams the predicate
-  // columns and leaves one 16-bit pass mask per lane and wave step; pass 2 is the compacting kernel reading them
-  uint16_t* premask;            // [nseg][mask_steps_per_seg][64]
-  uint32_t mask_steps_per_seg;  // wave steps per (padded) segment
-  uint32_t pad_mask;
 };
 
 // VhMetricDev::slot of the virtual row-id column (VH_COL_ROWID): value = (segment << 32) | row

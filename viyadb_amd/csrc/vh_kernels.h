@@ -1079,12 +1079,7 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
 #ifndef VH_FAST_WAVES
 #define VH_FAST_WAVES(MODE, BLOCK, NP) 0      // waves per SIMD asked of the compiler (0: no request); experiments override it
 #endif
-// PREMASK: the pass masks were computed by scan_mask_kernel (two-pass form); nothing is preloaded or evaluated here.
-__device__ __forceinline__ uint32_t vh_premask_load(const VhPlanDev& P, uint32_t seg, uint32_t wave_base, int lane) {
-  return P.premask[((uint64_t)seg * P.mask_steps_per_seg + wave_base / VH_WAVE_STEP_ROWS) * 64u + lane];
-}
-
-template <int MODE, int BLOCK, int SCOPE, int NP, bool PREMASK = false>
+template <int MODE, int BLOCK, int SCOPE, int NP>
 __global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_agg_fast_kernel(const VhPlanDev P) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef VhScanCfg<BLOCK> C;
@@ -1132,12 +1127,11 @@ __global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_ag
     }
   }
   uint32_t v[NP][VH_LANE_ROWS];
-  uint32_t pm = 0;
-  if (have) { if (PREMASK) pm = vh_premask_load(P, seg, wave_base, lane); else vh_preload<NP>(P, seg, wave_base + lane * 4, seg_rows, v); }
+  if (have) vh_preload<NP>(P, seg, wave_base + lane * 4, seg_rows, v);
   uint32_t cnt = 0;
   while (have) {
     const uint32_t row_l = wave_base + lane * 4;
-    const uint32_t mask = PREMASK ? pm : vh_eval_filter_fast<NP>(P, v, row_l, seg_rows);
+    const uint32_t mask = vh_eval_filter_fast<NP>(P, v, row_l, seg_rows);
     npassed += __popc(mask);
     // locate the next step and put its predicate columns in flight now
     ++t;
@@ -1153,7 +1147,7 @@ __global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_ag
         nwave_base = nunit_base + (t % spu) * C::kStepRows + wave * VH_WAVE_STEP_ROWS;
       }
     }
-    if (nhave) { if (PREMASK) pm = vh_premask_load(P, nseg, nwave_base, lane); else vh_preload<NP>(P, nseg, nwave_base + lane * 4, nseg_rows, v); }
+    if (nhave) vh_preload<NP>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
 #pragma unroll
     for (int k = 0; k < VH_SUBSTEPS; ++k) {
       const uint32_t mk = (mask >> (4 * k)) & 0xFu;
@@ -1206,41 +1200,6 @@ __global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_ag
         vh_state_update<SCOPE>(m.state, xo + g, m.sop(), bits);
       }
     }
-  }
-}
-
-// ------------------------------------------------- two-pass form, pass 1: predicate columns -> pass masks
-// A lean streaming kernel (nothing but the prefetch registers and the filter interpreter: more resident waves than the
-// fused kernel can have, so it streams closer to the HBM ceiling). One wave step = 1024 rows = one 128-byte row of
-// masks, in exactly the bit layout the compacting kernel builds in registers.
-template <int NP>
-__global__ __launch_bounds__(256) void scan_mask_kernel(const VhPlanDev P) {
-  const int lane = threadIdx.x & 63;
-  const uint64_t nsteps = (uint64_t)P.nseg * P.mask_steps_per_seg;
-  const uint64_t stride = (uint64_t)gridDim.x * 4;
-  uint64_t s = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  uint32_t v[NP][VH_LANE_ROWS];
-  uint32_t seg = 0, wave_base = 0, seg_rows = 0;
-  bool have = s < nsteps;
-  if (have) {
-    seg = (uint32_t)(s / P.mask_steps_per_seg);
-    wave_base = (uint32_t)(s - (uint64_t)seg * P.mask_steps_per_seg) * VH_WAVE_STEP_ROWS;
-    seg_rows = P.seg_rows[seg];
-    if (wave_base < seg_rows) vh_preload<NP>(P, seg, wave_base + lane * 4, seg_rows, v);
-  }
-  while (have) {
-    const uint32_t row_l = wave_base + lane * 4;
-    const uint32_t mask = wave_base < seg_rows ? vh_eval_filter_fast<NP>(P, v, row_l, seg_rows) : 0u;
-    uint16_t* dst = P.premask + s * 64u + lane;
-    s += stride;
-    have = s < nsteps;
-    if (have) {
-      seg = (uint32_t)(s / P.mask_steps_per_seg);
-      wave_base = (uint32_t)(s - (uint64_t)seg * P.mask_steps_per_seg) * VH_WAVE_STEP_ROWS;
-      seg_rows = P.seg_rows[seg];
-      if (wave_base < seg_rows) vh_preload<NP>(P, seg, wave_base + lane * 4, seg_rows, v);
-    }
-    *dst = (uint16_t)mask;
   }
 }
 

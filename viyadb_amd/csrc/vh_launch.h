@@ -12,8 +12,6 @@ void vh_launch_scan_lanes_part(const VhPlanDev& P, int grid, size_t lds, hipStre
 void vh_launch_scan_fast_global(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s, int* occ = nullptr);
 void vh_launch_scan_fast_hash(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ = nullptr);
 void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ = nullptr);
-void vh_launch_scan_mask(const VhPlanDev& P, int grid, hipStream_t s, int* occ = nullptr);
-void vh_launch_scan_premask_global(const VhPlanDev& P, int grid, size_t lds, bool xcd_private, hipStream_t s, int* occ = nullptr);
 void vh_launch_part_agg(const VhPlanDev& P, int blocks_per_part, size_t lds, hipStream_t s);
 
 // Launch KERNEL (parenthesised template-id), or — occ != nullptr — only ask the runtime how many of its blocks fit one CU.

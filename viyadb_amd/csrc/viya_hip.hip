@@ -1241,11 +1241,6 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     else if ((uint64_t)g_ctx.num_cu * 5 * G * std::max(1, P.nmetric) <= rows_to_scan / 32) BLOCK = 256;
   }
   if (mode == VH_MODE_DENSE_PART && P.stage_cap == 0) lanes = false;   // the unstaged experiment has no lanes form
-  // Two-pass form of the compacting scan over a dense HBM table: a lean streaming kernel turns the predicate columns into
-  // pass masks (5-8 resident waves per SIMD instead of the fused kernel's 4), the compacting kernel then reads 2 bytes per
-  // lane and step instead of prefetching and evaluating (63 VGPRs: 7 waves for its gathers).
-  const bool two_pass = mode == VH_MODE_DENSE_GLOBAL && fast && !lanes && P.nbitset == 0 && P.npred >= 1 && rows_to_scan &&
-                        (p->flags & VH_PLAN_TWO_PASS) && !(p->flags & VH_PLAN_NO_TWO_PASS);
   // One place decides which scan kernel runs; with `occ` it only asks how many of its blocks fit a CU.
   auto scan_dispatch = [&](int grid_, int* occ) {
     const size_t qb = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint32_t);
@@ -1260,7 +1255,6 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     else if (lanes && mode == VH_MODE_HASH) vh_launch_scan_lanes_hash(P, grid_, lds_, s_, occ);
     else if (lanes) vh_launch_scan_lanes_lds(P, BLOCK, grid_, lds_, nxcd > 1, s_, occ);
     else if (mode == VH_MODE_DENSE_LDS) { if (!occ) vh_launch_scan_fast_lds(P, grid_, lds_, nxcd > 1, s_); }   // 1024-thread blocks: one per CU
-    else if (mode == VH_MODE_DENSE_GLOBAL && two_pass) vh_launch_scan_premask_global(P, grid_, lds_, nxcd > 1, s_, occ);
     else if (mode == VH_MODE_DENSE_GLOBAL) vh_launch_scan_fast_global(P, grid_, lds_, nxcd > 1, s_, occ);
     else vh_launch_scan_fast_hash(P, grid_, lds_, s_, occ);
   };
@@ -1322,11 +1316,6 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     for (int j = 0; j < P.nmetric; ++j) o_ostate2[j] = sp.take(r->out_cap * vh_elem_size(r->metric_elem[j]));
   }
   // outputs
-  size_t o_premask = 0;
-  if (two_pass) {
-    P.mask_steps_per_seg = (uint32_t)(padded / VH_WAVE_STEP_ROWS);
-    o_premask = sp.take((size_t)std::max<uint32_t>(nseg, 1) * P.mask_steps_per_seg * 64 * sizeof(uint16_t));
-  }
   size_t o_tuples = 0, o_pcount = 0, o_pext = 0, o_emiss = 0;
   if (mode == VH_MODE_DENSE_PART) {
     // extent size: big enough that a wave allocates rarely (every allocation is a returning global
@@ -1367,7 +1356,6 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   char* S = t->scratch;
   P.counters = reinterpret_cast<unsigned long long*>(S + o_counters);
   P.seg_rows = reinterpret_cast<const uint32_t*>(S + o_segrows);
-  if (two_pass) P.premask = reinterpret_cast<uint16_t*>(S + o_premask);
   if (mode == VH_MODE_HASH) {
     P.hkeys = reinterpret_cast<uint64_t*>(S + o_hkeys);
     P.htags = P.key_words > 1 ? reinterpret_cast<uint32_t*>(S + o_htags) : nullptr;
@@ -1430,13 +1418,8 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     if (rc) { delete r; return rc; }
   }
   HIP_TRY(hipEventRecord(t->ev[1], st));
-  r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (two_pass ? 8 : 0);
+  r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0);
   if (P.total_units) {
-    if (two_pass) {
-      int occ1 = 0;
-      vh_launch_scan_mask(P, 0, st, &occ1);
-      vh_launch_scan_mask(P, g_ctx.num_cu * std::max(1, std::min(occ1, 8)), st, nullptr);
-    }
     scan_dispatch(grid, nullptr);
     if (mode == VH_MODE_DENSE_PART) {
       const int bpp = std::max(1, std::min(16, g_ctx.num_cu / std::max(1, P.npart)));

@@ -79,7 +79,6 @@ class AggResult:
     fast: bool = False
     lanes: bool = False            # the no-compaction variant of the fast kernel ran
     returned: int = 0              # rows delivered (= ngroups unless a HAVING was pushed down)
-    two_pass: bool = False         # predicate columns -> pass masks, then the compacting kernel over the masks
 
 
 class DeviceTable:
@@ -272,7 +271,7 @@ class DeviceTable:
         return AggResult(keys, states, hidden, int(info.ngroups), int(info.scanned_recs), int(info.scanned_segments),
                          int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
                          float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1),
-                         bool(info.reserved & 2), int(ng), bool(info.reserved & 8))
+                         bool(info.reserved & 2), int(ng))
 
     def query_agg(self, plan: AggPlan, copy: bool = True) -> AggResult:
         p, keep = self._build_plan(plan)
