@@ -1,0 +1,62 @@
+// How fast can gfx950 serve uncoalesced dword loads? (profiles/r01/NOTES.md: what bounds the C3 drain)
+// Every lane loads ONE u32; patterns differ in how many distinct 128-byte lines a wave instruction touches.
+//   build: hipcc --offload-arch=gfx950 -O3 -o gather_bw tools/experiments/gather_bw.hip ; run: ./gather_bw
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+// lane i of "global thread" g loads p[(g * stride_elems + jitter(g)) % n]; UNROLL independent loads in flight per lane
+template <int UNROLL>
+__global__ __launch_bounds__(256) void gather_kernel(const uint32_t* __restrict__ p, uint64_t n, uint64_t per_thread, uint32_t stride_elems,
+                                                     uint32_t jitter_mask, unsigned long long* sink) {
+  const uint64_t nthreads = (uint64_t)gridDim.x * 256;
+  uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t acc = 0;
+  for (uint64_t it = 0; it < per_thread; it += UNROLL) {
+    uint32_t v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      const uint64_t k = g + (it + u) * nthreads;                         // consecutive lanes -> consecutive k
+      const uint64_t h = k * 0x9E3779B97F4A7C15ull;
+      const uint64_t idx = (k * stride_elems + ((h >> 40) & jitter_mask)) % n;
+      v[u] = __builtin_nontemporal_load(p + idx);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) acc ^= v[u];
+  }
+  if (acc == 0x12345u) atomicAdd(sink, 1ull);
+}
+
+int main() {
+  const uint64_t bytes = 16ull << 30, n = bytes / 4;
+  uint32_t* buf; unsigned long long* sink;
+  CHECK(hipMalloc(&buf, bytes)); CHECK(hipMalloc(&sink, 8));
+  CHECK(hipMemset(buf, 1, bytes)); CHECK(hipMemset(sink, 0, 8));
+  hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+  const int cus = prop.multiProcessorCount;
+  hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  struct Case { const char* name; uint32_t stride, jitter; };
+  const Case cases[] = {{"coalesced dword (32 lanes per line)", 1, 0}, {"2 lanes per line", 16, 0}, {"1 lane per line, consecutive lines", 32, 0},
+                        {"1 lane per line, every other line", 64, 0}, {"~5 % density (stride 20 +- jitter): C3-like", 20, 15},
+                        {"1 lane per line, lines 4 KB apart", 1024, 0}};
+  for (int bpc : {4, 7, 8}) {
+    for (const Case& c : cases) {
+      const uint64_t loads = 1ull << 30;                                  // lane loads per launch
+      const int grid = cus * bpc;
+      const uint64_t per_thread = loads / ((uint64_t)grid * 256) / 4 * 4;
+      gather_kernel<4><<<grid, 256>>>(buf, n, per_thread, c.stride, c.jitter, sink);
+      CHECK(hipEventRecord(a));
+      for (int i = 0; i < 3; ++i) gather_kernel<4><<<grid, 256>>>(buf, n, per_thread, c.stride, c.jitter, sink);
+      CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+      float ms; CHECK(hipEventElapsedTime(&ms, a, b)); ms /= 3;
+      const double nloads = (double)per_thread * grid * 256;
+      const double lines = c.stride >= 32 ? nloads : nloads * c.stride / 32.0 * (c.jitter ? 1.0 : 1.0);
+      printf("blocks/CU %d  %-52s %7.3f ms  %6.1f G lane-loads/s  ~%6.1f G lines/s  ~%5.2f TB/s of 128 B lines\n", bpc, c.name, ms,
+             nloads / ms / 1e6, lines / ms / 1e6, lines * 128 / ms / 1e9);
+    }
+  }
+  return 0;
+}
