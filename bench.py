@@ -147,6 +147,8 @@ def main():
     plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics,
                             flags=args.flags, groups_hint=w.plan.groups_hint)
 
+    table.prepare(plan)   # the plan's C structs are built once, like a prepared statement
+
     def step():
         # copy=False: result arrays alias the library's pinned staging buffer (no second host copy)
         return distributed.sharded_query(torch, dist, table, plan, world, copy=False)
