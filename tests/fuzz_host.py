@@ -1,5 +1,5 @@
 """Bug hunt with the JSON-level differential fuzzer of tests/test_gpu_host_fuzz.py over many seeds (GPU box):
-python tools/fuzz_host.py [first_seed] [nseeds] [queries_per_seed]  — prints every discrepancy with its query.
+python tests/fuzz_host.py [first_seed] [nseeds] [queries_per_seed]  — prints every discrepancy with its query.
 FUZZ_CLUSTER=1: every aggregate query goes through three workers' partial states and the GPU merge instead."""
 import json
 import os
@@ -7,7 +7,7 @@ import random
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import viya_oracle as vo            # noqa: E402  (tool = test infrastructure)
+from oracle import viya_oracle as vo            # noqa: E402  (lives under tests/: only test code may use the oracle)
 from tests import test_gpu_host_fuzz as f       # noqa: E402
 from viyadb_amd import hostdb                   # noqa: E402
 
