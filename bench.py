@@ -109,7 +109,6 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-parallel", action="store_true", help="also time the courtesy all-cores CPU baseline (adds ~30 s)")
     ap.add_argument("--flags", type=int, default=0)
-    ap.add_argument("--check", action="store_true", help="verify the result against the CPU twin on the sample")
     args = ap.parse_args()
 
     import torch
