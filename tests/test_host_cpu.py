@@ -17,6 +17,11 @@ def test_facade_symbols():
     g.build()
     from viyadb_amd import hostdb
     lib = hostdb.load()
+    import os
+    import re
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "viya_host.h")).read()
+    declared = set(re.findall(r"VDB_API\s+[\w\s\*]+?\b(vdb_\w+)\s*\(", header))
+    assert declared and declared == set(hostdb.SYMBOLS), declared ^ set(hostdb.SYMBOLS)
     for s in hostdb.SYMBOLS:
         assert getattr(lib, s) is not None
 
