@@ -1661,7 +1661,9 @@ static int result_finalize_locked(vh_result* r, int* retry) {
     if (t->h_out[slot]) HIP_TRY(hipHostFree(t->h_out[slot]));
     t->h_out[slot] = nullptr; t->h_out_bytes[slot] = 0;
     const size_t nb = std::max<size_t>(r->out_region_bytes + r->out_region_bytes / 4, 1 << 20);
-    HIP_TRY(hipHostMalloc((void**)&t->h_out[slot], nb, hipHostMallocDefault));
+    // coherent (fine-grained): the emission kernel writes small results straight into this buffer, and the host must see
+    // them when the event behind the kernel has completed, whatever HIP_HOST_COHERENT says
+    HIP_TRY(hipHostMalloc((void**)&t->h_out[slot], nb, hipHostMallocCoherent));
     t->h_out_bytes[slot] = nb;
   }
   // Small results of the dense paths are written by the emission kernel straight into that pinned host buffer
