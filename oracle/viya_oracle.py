@@ -8,7 +8,8 @@ import it, and only as the checker.  The product path (``viyadb_amd``) never doe
 Parity status: PINNED.  The oracle is checked (tests/test_oracle_golden.py) against
 every known-answer test the reference's own suite holds for this path, transcribed
 as data into tests/golden/reference_cases.json (test/aggregation.cc, filter.cc,
-metrics.cc, time.cc, bitset.cc, boolean.cc, index.cc, limits.cc, sort.cc), and its
+metrics.cc, time.cc, bitset.cc, boolean.cc, index.cc, limits.cc, sort.cc, select.cc, search.cc,
+the upsert tests of load.cc, and the query tests of sql.cc as the descriptors parser.y builds: 85 cases), and its
 calendar arithmetic against vectors produced by the reference's own
 src/util/time.cc compiled in this container (oracle/_ref, tests/golden/time_golden.json).
 
