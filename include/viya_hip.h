@@ -161,8 +161,12 @@ enum vh_plan_flags {
                                      when most rows pass                      */
   VH_PLAN_FORCE_LANES = 1u << 8,  /* testing: the no-compaction "lanes" kernel
                                      whenever the plan is eligible            */
-  VH_PLAN_NO_LDS_HASH = 1u << 9   /* ablation: hash path without the per-block
+  VH_PLAN_NO_LDS_HASH = 1u << 9,  /* ablation: hash path without the per-block
                                      LDS front table                          */
+  VH_PLAN_NO_HASH_RECORDS = 1u << 10,/* ablation: hash table with separate key and
+                                     state arrays even when it is big (>= 4 M slots:
+                                     one record per slot for single-word keys)  */
+  VH_PLAN_FORCE_HASH_RECORDS = 1u << 11 /* testing: records whatever the size    */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */

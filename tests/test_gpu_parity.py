@@ -14,7 +14,7 @@ def _init():
     executor.init(0)
 
 
-@pytest.mark.parametrize("flags", [0, 8])
+@pytest.mark.parametrize("flags", [0, 8, 2048, 2048 | 8, 1024])
 def test_c5_time_rollup_hash_path(flags):
     """C5 shape: time dimension with rollup rules, hour granularity, sparse (t, u) keys -> hash table."""
     from viyadb_amd import synth
@@ -23,11 +23,13 @@ def test_c5_time_rollup_hash_path(flags):
     assert res.ngroups > 100_000
 
 
-def test_c5_count_distinct_on_sparse_time_keys():
-    """C5 proper: time rollup + hour granularity + COUNT DISTINCT (device-side (group, id) set) + COUNT."""
+@pytest.mark.parametrize("flags", [0, 2048])
+def test_c5_count_distinct_on_sparse_time_keys(flags):
+    """C5 proper: time rollup + hour granularity + COUNT DISTINCT (device-side (group, id) set) + COUNT; with the hash
+    table as separate arrays and as one record per slot."""
     from viyadb_amd import synth
     w = synth.c5(segment_rows=60_000)
-    res, st = check_workload(w, nseg=3, expect_path="hash")
+    res, st = check_workload(w, nseg=3, flags=flags, expect_path="hash")
     assert res.ngroups > 50_000 and int(res.states[0].max()) >= 2
 
 
@@ -49,7 +51,8 @@ def test_workload_ragged(name, flags):
 
 @pytest.mark.parametrize("flags,path", [(0, "dense_global"), (64, "dense_part"), (16, "dense_global"), (20, "dense_global"), (48, "dense_global"),
                                         (1, "hash"), (68, "dense_part"), (2, "dense_global"), (8, "dense_global"), (9, "hash"), (12, "dense_global"),
-                                        (40, "dense_global"), (64 | 256, "dense_part"), (64 | 128, "dense_part")])
+                                        (40, "dense_global"), (64 | 256, "dense_part"), (64 | 128, "dense_part"),
+                                        (1 | 2048, "hash"), (9 | 2048, "hash"), (1 | 2048 | 512, "hash")])
 def test_c3_table_organisations(flags, path):
     """Same query through: radix-partitioned LDS aggregation, per-XCD private dense tables with global
     atomics, one device-scope dense table, the open-addressing hash table; fast and generic scan kernels."""

@@ -275,6 +275,8 @@ def test_hash_table_regrows(typed):
     tab, dt = typed
     res, _ = run(tab, dt, {"dimensions": ["id", "d_double"], "metrics": ["count"]}, flags=1, groups_hint=1)
     assert res.retries >= 1 and res.ngroups == 120000
+    res, _ = run(tab, dt, {"dimensions": ["id"], "metrics": ["count", "long_sum", "int_min", "double_max"]}, flags=1 | 2048, groups_hint=1)
+    assert res.retries >= 1 and res.path == "hash"       # single-word key: the table of records regrows as well
 
 
 def test_segment_skipping_and_snapshot():
@@ -303,7 +305,7 @@ def test_segment_skipping_and_snapshot():
 
 
 @pytest.mark.parametrize("wide", [False, True])
-@pytest.mark.parametrize("flags", [0, 1])
+@pytest.mark.parametrize("flags", [0, 1, 1 | 2048])      # dense table; hash table as arrays; hash table as records
 def test_count_distinct(wide, flags):
     rng = np.random.default_rng(9)
     n = 8000
@@ -442,7 +444,7 @@ def test_random_plans_against_oracle(typed, seed):
             f = {"op": rnd.choice(["and", "or"]), "filters": [tree(depth - 1) for _ in range(rnd.randrange(2, 4))]}
         return {"op": "not", "filter": f} if rnd.random() < 0.15 else f
 
-    flag_pool = [0, 0, 0, 1, 2, 8, 9, 16, 48, 64, 128, 256, 512, 64 | 256, 1 | 512, 8 | 64]
+    flag_pool = [0, 0, 0, 1, 2, 8, 9, 16, 48, 64, 128, 256, 512, 64 | 256, 1 | 512, 8 | 64, 1 | 2048, 9 | 2048, 1 | 2048 | 512, 2048]
     done = 0
     for _ in range(40):
         sel = []

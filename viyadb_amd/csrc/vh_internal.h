@@ -145,6 +145,10 @@ struct VhPlanDev {
   uint64_t hmask;            // capacity - 1
   uint32_t max_probe;
   uint32_t debug;            // experiment knobs (env VH_DEBUG), 0 in production
+  // single-word keys: key and metric states of a slot are ONE record of hrec_bytes (key at +0, m[j].state = table + the
+  // state's offset inside the record), so an insert and its updates touch one line; 0 = separate arrays (wide keys)
+  uint32_t hrec_bytes;
+  uint32_t pad_hrec;
   // ---- bitset metrics (COUNT DISTINCT): per-row id sets mirrored as CSR per segment. Every id of a
   // surviving row is inserted into a device-wide open-addressing SET keyed by (group, id); the first
   // insertion of a pair bumps the group's cardinality (the metric's u64 state). Union semantics of

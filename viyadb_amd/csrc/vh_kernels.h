@@ -333,12 +333,12 @@ __host__ __device__ __forceinline__ bool vh_sop_sext(int sop) {
 // Open-addressing insert of a 64-bit key (never the all-ones sentinel) into `keys`; returns the slot.
 // Device-scope CAS on the key word is the only synchronisation.
 __device__ __forceinline__ uint64_t vh_set_insert64(uint64_t* keys, uint64_t mask, uint32_t max_probe, uint64_t key,
-                                                   bool& ok, bool& fresh) {
+                                                   bool& ok, bool& fresh, uint32_t stride_words = 1) {
   fresh = false;
   uint64_t slot = vh_splitmix64(key) & mask;
   for (uint32_t probe = 0; probe <= max_probe; ++probe) {
     unsigned long long expect = VH_HASH_EMPTY;
-    const bool won = __hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long*>(keys) + slot, &expect,
+    const bool won = __hip_atomic_compare_exchange_strong(reinterpret_cast<unsigned long long*>(keys) + slot * stride_words, &expect,
                                                           (unsigned long long)key, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                           __HIP_MEMORY_SCOPE_AGENT);
     if (won) { fresh = true; return slot; }
@@ -394,7 +394,11 @@ __device__ __forceinline__ uint64_t vh_hash_insert64(const VhPlanDev& P, uint64_
     atomicOr(P.counters + 3, 1ull);    // marks the reserved extra slot as used
     return P.hmask + 1;
   }
-  return vh_set_insert64(P.hkeys, P.hmask, P.max_probe, key, ok, fresh);
+  return vh_set_insert64(P.hkeys, P.hmask, P.max_probe, key, ok, fresh, P.hrec_bytes ? P.hrec_bytes / 8u : 1u);
+}
+// HBM address of metric m's state of hash slot gid (records of hrec_bytes, or one array per metric)
+__device__ __forceinline__ char* vh_hash_state(const VhPlanDev& P, const VhMetricDev& m, uint64_t gid) {
+  return static_cast<char*>(m.state) + gid * (P.hrec_bytes ? P.hrec_bytes : (uint32_t)vh_sop_bytes(m.sop()));
 }
 __device__ __forceinline__ uint64_t vh_hash_insert_wide(const VhPlanDev& P, const uint64_t* key, int kw, bool& ok, bool& fresh) {
   return vh_set_insert_wide(P.hkeys, P.htags, P.hmask, P.max_probe, key, kw, ok, fresh);
@@ -425,7 +429,7 @@ __device__ __forceinline__ void vh_distinct_update(const VhPlanDev& P, int b, un
       if (!wa && ea != ka) { bool ok = true, fresh = false; vh_set_insert64(P.dset_keys[b], P.dset_mask[b], 4096u, ka, ok, fresh); if (!ok) atomicOr(P.counters + 2, VH_ERR_HASH_FULL); nfresh += fresh ? 1 : 0; }
       if (ka != kb && !wb && eb != kb) { bool ok = true, fresh = false; vh_set_insert64(P.dset_keys[b], P.dset_mask[b], 4096u, kb, ok, fresh); if (!ok) atomicOr(P.counters + 2, VH_ERR_HASH_FULL); nfresh += fresh ? 1 : 0; }
     }
-    if (nfresh) { atomicAdd(card + gid, nfresh); npairs += nfresh; }
+    if (nfresh) { atomicAdd(card, nfresh); npairs += nfresh; }
   }
   for (; k < o1; ++k) {
     bool ok = true, fresh = false;
@@ -437,7 +441,7 @@ __device__ __forceinline__ void vh_distinct_update(const VhPlanDev& P, int b, un
       vh_set_insert64(P.dset_keys[b], P.dset_mask[b], 4096u, key, ok, fresh);
     }
     if (!ok) atomicOr(P.counters + 2, VH_ERR_HASH_FULL);
-    if (fresh) { atomicAdd(card + gid, 1ull); ++npairs; }   // pairs are totalled per lane: one hot-spot atomic per wave, not per pair
+    if (fresh) { atomicAdd(card, 1ull); ++npairs; }   // pairs are totalled per lane: one hot-spot atomic per wave, not per pair
   }
 }
 
@@ -494,7 +498,7 @@ __device__ __forceinline__ void vh_lds_hash_flush(const VhPlanDev& P, char* lds,
       const VhMetricDev& m = P.m[j];
       const uint64_t bits = vh_sop_bytes(m.sop()) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
                                                      : reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
-      vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, gid, m.sop(), bits);
+      vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(vh_hash_state(P, m, gid), 0, m.sop(), bits);
     }
   }
   if (nfresh) atomicAdd(P.counters + 1, nfresh);
@@ -566,7 +570,9 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
   for (int j = 0; j < P.nmetric; ++j) {
     const VhMetricDev& m = P.m[j];
     if (m.sop() == SOP_BITSET) {   // slot() is the bitset index, m.state the u64 cardinality per group
-      if (active) vh_distinct_update(P, m.slot(), reinterpret_cast<unsigned long long*>(m.state), MODE == VH_MODE_HASH ? gid : xoff + gid, seg, row, H.npairs);
+      if (active) vh_distinct_update(P, m.slot(), MODE == VH_MODE_HASH ? reinterpret_cast<unsigned long long*>(vh_hash_state(P, m, gid))
+                                                                         : reinterpret_cast<unsigned long long*>(m.state) + xoff + gid,
+                                       MODE == VH_MODE_HASH ? gid : xoff + gid, seg, row, H.npairs);
       continue;
     }
     uint64_t bits;
@@ -578,7 +584,7 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
       } else if (MODE == VH_MODE_DENSE_GLOBAL) {
         vh_state_update<SCOPE>(m.state, xoff + gid, m.sop(), bits);
       } else {
-        vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, gid, m.sop(), bits);
+        vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(vh_hash_state(P, m, gid), 0, m.sop(), bits);
       }
     }
   }
@@ -1071,7 +1077,7 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
       const VhMetricDev& m = P.m[j];
       if (MODE == VH_MODE_DENSE_LDS) vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, gid, m.sop(), mv[j]);
       else if (MODE == VH_MODE_DENSE_GLOBAL) vh_state_update<SCOPE>(m.state, xoff + gid, m.sop(), mv[j]);
-      else vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, gid, m.sop(), mv[j]);
+      else vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(vh_hash_state(P, m, gid), 0, m.sop(), mv[j]);
     }
   }
 }
@@ -1453,7 +1459,7 @@ __global__ __launch_bounds__(BLOCK, VH_LANES_WAVES(MODE, BLOCK, NP)) void scan_a
             nfresh += fresh ? 1 : 0;
 #pragma unroll
             for (int j = 0; j < VH_LANES_COLS; ++j)
-              if (j < P.nmetric) vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(P.m[j].state, gid, P.m[j].sop(), mv[j][r]);
+              if (j < P.nmetric) vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(vh_hash_state(P, P.m[j], gid), 0, P.m[j].sop(), mv[j][r]);
           }
         } else {
           uint64_t gid = 0;

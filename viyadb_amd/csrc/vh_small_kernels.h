@@ -73,6 +73,8 @@ struct VhEmitArgs {
   int32_t mode;  // VH_MODE_*
   int32_t ngroup; int32_t nmetric; int32_t key_words;
   uint64_t n;    // dense: G; hash: capacity + 1
+  uint32_t hstride;               // hash: u64 words between the keys of consecutive slots (key_words, or the record size)
+  uint32_t state_stride[VH_MAX_METRIC];   // bytes between consecutive entries' states (the state's size, or the record size)
   int32_t present_carrier; int32_t pad;
   const uint8_t* present;
   const uint64_t* hkeys; const uint32_t* htags;
@@ -132,15 +134,15 @@ __device__ __forceinline__ void vh_store_elem(void* base, int type, uint64_t idx
 // value of group column c / state of metric j for table entry i
 __device__ __forceinline__ uint64_t vh_emit_key(const VhEmitArgs& A, uint64_t i, int c) {
   if (A.mode == VH_MODE_HASH) {
-    uint64_t w = A.hkeys[i * A.key_words + A.gkey_word[c]];
+    uint64_t w = A.hkeys[i * A.hstride + A.gkey_word[c]];
     if (A.key_words == 1 && i + 1 == A.n) w = VH_HASH_EMPTY;
     return w >> A.gkey_shift[c];
   }
   return A.glo[c] + (i / A.gstride[c]) % A.gextent[c];
 }
 __device__ __forceinline__ uint64_t vh_emit_state(const VhEmitArgs& A, uint64_t i, int j) {
-  return vh_sop_bytes(A.sop[j]) == 4 ? reinterpret_cast<const uint32_t*>(A.state[j])[i]
-                                     : reinterpret_cast<const uint64_t*>(A.state[j])[i];
+  const char* p = static_cast<const char*>(A.state[j]) + i * A.state_stride[j];
+  return vh_sop_bytes(A.sop[j]) == 4 ? *reinterpret_cast<const uint32_t*>(p) : *reinterpret_cast<const uint64_t*>(p);
 }
 
 // does table entry i hold a group that passes the (optional) HAVING?
@@ -149,7 +151,7 @@ __device__ __forceinline__ bool vh_emit_have(const VhEmitArgs& A, uint64_t i, bo
   if (i < A.n) {
     if (A.mode == VH_MODE_HASH) {
       if (i + 1 == A.n) have = A.key_words == 1 && A.counters[3] != 0;  // reserved slot
-      else have = A.key_words == 1 ? A.hkeys[i] != VH_HASH_EMPTY : A.htags[i] == 2u;
+      else have = A.key_words == 1 ? A.hkeys[i * A.hstride] != VH_HASH_EMPTY : A.htags[i] == 2u;
     } else if (A.present_carrier >= 0) {
       have = reinterpret_cast<const uint64_t*>(A.state[A.present_carrier])[i] != 0;
     } else {
@@ -538,6 +540,7 @@ struct VhPairArgs {
   uint64_t nslots;                 // capacity of the (group, id) set
   uint64_t hcap;                   // hash mode: capacity of the group table (slot hcap = the reserved sentinel group)
   const uint64_t* hkeys;
+  uint64_t hstride;                // u64 words between the keys of consecutive group slots
   const uint64_t* dkeys; const uint32_t* dtags;
   uint64_t glo[VH_MAX_GROUP], gextent[VH_MAX_GROUP], gstride[VH_MAX_GROUP];
   uint32_t gkey_word[VH_MAX_GROUP], gkey_shift[VH_MAX_GROUP], gesize[VH_MAX_GROUP];
@@ -557,7 +560,7 @@ __device__ __forceinline__ bool vh_pair_at(const VhPairArgs& A, uint64_t i, uint
 __device__ __forceinline__ uint64_t vh_pair_key(const VhPairArgs& A, uint64_t gid, int c) {
   uint64_t v;
   if (A.mode == VH_MODE_HASH) {
-    const uint64_t w = gid == A.hcap ? VH_HASH_EMPTY : A.hkeys[gid * A.key_words + A.gkey_word[c]];
+    const uint64_t w = gid == A.hcap ? VH_HASH_EMPTY : A.hkeys[gid * A.hstride + A.gkey_word[c]];
     v = w >> A.gkey_shift[c];
   } else {
     v = A.glo[c] + (gid / A.gstride[c]) % A.gextent[c];
@@ -597,6 +600,12 @@ __global__ __launch_bounds__(256) void partition_pairs_kernel(const VhPairArgs A
 // the emission kernel wrote its rows to (direct emission, see result_finalize_locked).
 __global__ __launch_bounds__(64) void publish_header_kernel(unsigned long long* host, const unsigned long long* dev) {
   host[threadIdx.x] = dev[threadIdx.x];
+}
+
+// Hash table of records (VhPlanDev::hrec_bytes): every slot gets the same `words`-word template (empty key, state identities).
+struct VhRecordTemplate { uint64_t w[8]; };
+__global__ __launch_bounds__(256) void fill_records_kernel(uint64_t* p, uint64_t nwords, uint32_t words, VhRecordTemplate T) {
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * 256) p[i] = T.w[i % words];
 }
 
 __global__ __launch_bounds__(256) void iota_kernel(uint64_t* p, uint64_t n) {

@@ -1295,17 +1295,34 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   size_t o_present = 0, o_hkeys = 0, o_htags = 0;
   size_t o_state[VH_MAX_METRIC];
   const uint64_t table_n = mode == VH_MODE_HASH ? capacity + 1 : P.xcd_stride * nxcd;
+  // single-word keys: one record per slot = key + every metric state (8-byte states first), so that an insert and its
+  // updates touch ONE line of a table that is far bigger than any cache
+  size_t rec_off[VH_MAX_METRIC] = {};
+  // Only for tables far bigger than the caches: with few, hot groups three atomics on ONE line serialise more than on three
+  // (C2 forced onto the hash table, 1 K groups: 1.75 ms with separate arrays, 2.21 ms with records).
+  if (mode == VH_MODE_HASH && P.key_words == 1 && (capacity >= (1ull << 22) || (p->flags & VH_PLAN_FORCE_HASH_RECORDS)) && !(p->flags & VH_PLAN_NO_HASH_RECORDS)) {
+    size_t off = 8;
+    for (int pass = 0; pass < 2; ++pass)
+      for (int j = 0; j < P.nmetric; ++j) {
+        const int b = vh_sop_bytes(P.m[j].sop());
+        if ((pass == 0) != (b == 8)) continue;
+        rec_off[j] = off; off += b;
+      }
+    off = (off + 7) / 8 * 8;
+    if (off <= 64) P.hrec_bytes = (uint32_t)off;
+  }
   if (mode == VH_MODE_HASH) {
-    o_hkeys = sp.take(table_n * P.key_words * sizeof(uint64_t));
+    o_hkeys = sp.take(P.hrec_bytes ? table_n * P.hrec_bytes : table_n * P.key_words * sizeof(uint64_t));
     if (P.key_words > 1) o_htags = sp.take(table_n * sizeof(uint32_t));
   } else {
     o_present = sp.take(table_n);
   }
   // zero-identity states (every SUM) sit right behind the presence bytes: one memset clears them all
   const size_t zero_begin = mode == VH_MODE_HASH ? sp.off : o_present;
-  for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident == 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop()));
+  if (P.hrec_bytes) { for (int j = 0; j < P.nmetric; ++j) o_state[j] = o_hkeys + rec_off[j]; }
+  else for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident == 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop()));
   const size_t zero_end = sp.off;
-  for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident != 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop()));
+  if (!P.hrec_bytes) for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident != 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop()));
   // device top-N: worth it only when the group table is big (small results are read back whole anyway)
   size_t o_tkkeys = 0, o_tkstate = 0, o_okey2[VH_MAX_GROUP] = {}, o_ostate2[VH_MAX_METRIC] = {};
   r->topk_active = r->topk > 0 && r->out_cap > 65536 && !getenv("VH_NO_TOPK");
@@ -1399,7 +1416,17 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   HIP_TRY(hipMemsetAsync(P.counters, 0, 512, st));   // counters + out_count (adjacent 256 B slots)
   if (nseg) HIP_TRY(hipMemcpyAsync(S + o_segrows, t->h_segrows, nseg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   if (mode == VH_MODE_HASH) {
-    if (P.key_words == 1) HIP_TRY(hipMemsetAsync(P.hkeys, 0xFF, table_n * sizeof(uint64_t), st));
+    if (P.hrec_bytes) {          // records: empty key + the metrics' identities, one template for every slot
+      VhRecordTemplate T{};
+      T.w[0] = VH_HASH_EMPTY;
+      for (int j = 0; j < P.nmetric; ++j)
+        memcpy(reinterpret_cast<char*>(T.w) + rec_off[j], &P.m[j].ident, vh_sop_bytes(P.m[j].sop()));
+      const uint64_t nwords = table_n * (P.hrec_bytes / 8);
+      hipLaunchKernelGGL(fill_records_kernel, dim3((unsigned)std::min<uint64_t>((nwords + 255) / 256, (uint64_t)g_ctx.num_cu * 16)), dim3(256), 0, st,
+                         P.hkeys, nwords, P.hrec_bytes / 8, T);
+      HIP_TRY(hipGetLastError());
+    }
+    else if (P.key_words == 1) HIP_TRY(hipMemsetAsync(P.hkeys, 0xFF, table_n * sizeof(uint64_t), st));
     else HIP_TRY(hipMemsetAsync(P.htags, 0, table_n * sizeof(uint32_t), st));
   }
   if (zero_end > zero_begin) HIP_TRY(hipMemsetAsync(S + zero_begin, 0, zero_end - zero_begin, st));
@@ -1413,7 +1440,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     HIP_TRY(hipMemsetAsync(P.extent_missing, 0, (size_t)P.max_extents * sizeof(uint16_t), st));
   }
   for (int j = 0; j < P.nmetric; ++j) {
-    if (P.m[j].ident == 0) continue;
+    if (P.m[j].ident == 0 || P.hrec_bytes) continue;
     rc = fill_states(P.m[j].state, table_n, vh_sop_bytes(P.m[j].sop()), P.m[j].ident, st);
     if (rc) { delete r; return rc; }
   }
@@ -1592,7 +1619,7 @@ extern "C" int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t 
   const uint64_t npairs = reinterpret_cast<const unsigned long long*>(r->h_base)[4];
   VhPairArgs A{};
   A.mode = r->mode == VH_MODE_DENSE_PART ? VH_MODE_DENSE_GLOBAL : r->mode; A.ngroup = P.ngroup; A.key_words = P.key_words; A.wide = P.bs_wide[b];
-  A.nslots = P.dset_mask[b] + 1; A.hcap = P.hmask + 1; A.hkeys = P.hkeys;
+  A.nslots = P.dset_mask[b] + 1; A.hcap = P.hmask + 1; A.hkeys = P.hkeys; A.hstride = P.hrec_bytes ? P.hrec_bytes / 8u : (uint64_t)P.key_words;
   A.dkeys = P.dset_keys[b]; A.dtags = P.dset_tags[b];
   size_t bytes = 0;
   std::vector<size_t> off(P.ngroup + 1);
@@ -1678,6 +1705,7 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   }
   VhEmitArgs A{};
   A.mode = r->mode == VH_MODE_DENSE_PART ? VH_MODE_DENSE_GLOBAL : r->mode; A.ngroup = P.ngroup; A.nmetric = P.nmetric; A.key_words = P.key_words;
+  A.hstride = P.hrec_bytes ? P.hrec_bytes / 8u : (uint32_t)P.key_words;
   A.n = r->out_cap; A.present = P.present; A.present_carrier = r->mode == VH_MODE_DENSE_GLOBAL ? P.present_carrier : -1; A.hkeys = P.hkeys; A.htags = P.htags; A.counters = P.counters;
   A.out_count = r->d_out_count;
   for (int i = 0; i < P.ngroup; ++i) {
@@ -1687,6 +1715,7 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   }
   for (int j = 0; j < P.nmetric; ++j) {
     A.state[j] = P.m[j].state; A.out_state[j] = r->d_out_state[j]; A.sop[j] = P.m[j].sop(); A.mtype[j] = (uint8_t)r->metric_elem[j];
+    A.state_stride[j] = r->mode == VH_MODE_HASH && P.hrec_bytes ? P.hrec_bytes : (uint32_t)vh_sop_bytes(P.m[j].sop());
   }
   A.nhaving = r->nhaving;
   A.total_groups = P.counters + 6;
