@@ -100,6 +100,13 @@ def test_merged_partials_equal_one_database(qi):
             d.close()
 
 
+@pytest.mark.parametrize("flags", ["1", "2049"])      # hash table as separate arrays / as records, on workers and controller alike
+def test_merged_partials_through_the_hash_table(flags, monkeypatch):
+    monkeypatch.setenv("VIYA_HIP_PLAN_FLAGS", flags)
+    for qi in (0, 3, 6):
+        test_merged_partials_equal_one_database(qi)
+
+
 def test_partial_state_content_matches_oracle_partials():
     """A worker's blob, decoded by the independent reader in tests/partial_wire.py, holds exactly the oracle's
     aggregation states for that worker's rows: sums (not averages), the dividing count, the distinct (group, id) pairs."""

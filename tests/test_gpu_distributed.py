@@ -48,7 +48,8 @@ def test_one_rank_rccl(tmp_path):
         _run(tmp_path, wl, flags, "nccl", 1)
 
 
-@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 64), ("C2", 0), ("C2", 2), ("C1", 0), ("C3", 1), ("C5t", 0), ("C5", 0)])
+@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 64), ("C2", 0), ("C2", 2), ("C1", 0), ("C3", 1), ("C5t", 0), ("C5", 0),
+                                      ("C5t", 2048), ("C5", 2048), ("C3", 1 | 2048)])      # 2048: the hash table as records
 def test_two_ranks_one_gpu(tmp_path, wl, flags):
     _run(tmp_path, wl, flags, "gloo", 2)
 
