@@ -30,6 +30,46 @@ __global__ __launch_bounds__(256) void gather_kernel(const uint32_t* __restrict_
   if (acc == 0x12345u) atomicAdd(sink, 1ull);
 }
 
+// non-returning 64-bit atomic adds into a table of `slots` u64 (pseudo-random slot per lane): the C3 table update in isolation
+__global__ __launch_bounds__(256) void atomic_kernel(unsigned long long* table, uint64_t slots, uint64_t per_thread) {
+  const uint64_t nthreads = (uint64_t)gridDim.x * 256;
+  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  for (uint64_t it = 0; it < per_thread; ++it) {
+    uint64_t h = (g + it * nthreads) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    __hip_atomic_fetch_add(table + h % slots, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// the same update with the cache-policy bits spelled out (for an atomic sc0 means "return the old value" and is refused on the
+// non-returning form; sc1 and nt remain) — does any of them change where the update is executed?
+template <int SC>
+__global__ __launch_bounds__(256) void atomic_sc_kernel(unsigned long long* table, uint64_t slots, uint64_t per_thread) {
+  const uint64_t nthreads = (uint64_t)gridDim.x * 256;
+  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long one = 1ull;
+  for (uint64_t it = 0; it < per_thread; ++it) {
+    uint64_t h = (g + it * nthreads) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    unsigned long long* addr = table + h % slots;
+    if (SC == 0) asm volatile("global_atomic_add_x2 %0, %1, off" :: "v"(addr), "v"(one) : "memory");
+    else if (SC == 1) asm volatile("global_atomic_add_x2 %0, %1, off nt" :: "v"(addr), "v"(one) : "memory");
+    else if (SC == 2) asm volatile("global_atomic_add_x2 %0, %1, off sc1" :: "v"(addr), "v"(one) : "memory");
+    else asm volatile("global_atomic_add_x2 %0, %1, off sc1 nt" :: "v"(addr), "v"(one) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int SC>
+static float time_sc(unsigned long long* table, uint64_t slots, int grid, uint64_t per_thread, hipEvent_t a, hipEvent_t b) {
+  atomic_sc_kernel<SC><<<grid, 256>>>(table, slots, per_thread);
+  (void)hipEventRecord(a);
+  for (int i = 0; i < 3; ++i) atomic_sc_kernel<SC><<<grid, 256>>>(table, slots, per_thread);
+  (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+  float ms = 0; (void)hipEventElapsedTime(&ms, a, b);
+  return ms / 3;
+}
+
 int main() {
   const uint64_t bytes = 16ull << 30, n = bytes / 4;
   uint32_t* buf; unsigned long long* sink;
@@ -57,6 +97,32 @@ int main() {
       printf("blocks/CU %d  %-52s %7.3f ms  %6.1f G lane-loads/s  ~%6.1f G lines/s  ~%5.2f TB/s of 128 B lines\n", bpc, c.name, ms,
              nloads / ms / 1e6, lines / ms / 1e6, lines * 128 / ms / 1e9);
     }
+  }
+  for (uint64_t slots : {100000ull, 4000000ull, 64000000ull}) {
+    for (int bpc : {4, 8}) {
+      const uint64_t n_at = 1ull << 28;
+      const int grid = cus * bpc;
+      const uint64_t per_thread = n_at / ((uint64_t)grid * 256);
+      unsigned long long* table = reinterpret_cast<unsigned long long*>(buf);
+      atomic_kernel<<<grid, 256>>>(table, slots, per_thread);
+      CHECK(hipEventRecord(a));
+      for (int i = 0; i < 3; ++i) atomic_kernel<<<grid, 256>>>(table, slots, per_thread);
+      CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+      float ms; CHECK(hipEventElapsedTime(&ms, a, b)); ms /= 3;
+      printf("blocks/CU %d  atomic add u64, %9llu slots (%6.1f MB)  %7.3f ms  %6.1f G atomics/s\n", bpc, (unsigned long long)slots, slots * 8 / 1e6, ms,
+             (double)per_thread * grid * 256 / ms / 1e6);
+    }
+  }
+  for (uint64_t slots : {100000ull, 64000000ull}) {
+    const uint64_t n_at = 1ull << 28;
+    const int grid = cus * 8;
+    const uint64_t per_thread = n_at / ((uint64_t)grid * 256);
+    unsigned long long* table = reinterpret_cast<unsigned long long*>(buf);
+    const float t0 = time_sc<0>(table, slots, grid, per_thread, a, b), t1 = time_sc<1>(table, slots, grid, per_thread, a, b),
+                t2 = time_sc<2>(table, slots, grid, per_thread, a, b), t3 = time_sc<3>(table, slots, grid, per_thread, a, b);
+    const double n = (double)per_thread * grid * 256;
+    printf("asm atomics, %9llu slots: no bits %6.1f | nt %6.1f | sc1 %6.1f | sc1 nt %6.1f  G atomics/s\n", (unsigned long long)slots,
+           n / t0 / 1e6, n / t1 / 1e6, n / t2 / 1e6, n / t3 / 1e6);
   }
   return 0;
 }
