@@ -41,6 +41,20 @@ __global__ __launch_bounds__(256) void atomic_kernel(unsigned long long* table, 
   }
 }
 
+// 32-bit atomic adds and plain byte stores to pseudo-random slots, for comparison with the 64-bit atomics
+template <int KIND>
+__global__ __launch_bounds__(256) void update32_kernel(unsigned char* table, uint64_t slots, uint64_t per_thread) {
+  const uint64_t nthreads = (uint64_t)gridDim.x * 256;
+  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  for (uint64_t it = 0; it < per_thread; ++it) {
+    uint64_t h = (g + it * nthreads) * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    const uint64_t i = h % slots;
+    if (KIND == 0) __hip_atomic_fetch_add(reinterpret_cast<unsigned int*>(table) + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else table[i] = 1;
+  }
+}
+
 // the same update with the cache-policy bits spelled out (for an atomic sc0 means "return the old value" and is refused on the
 // non-returning form; sc1 and nt remain) — does any of them change where the update is executed?
 template <int SC>
@@ -112,6 +126,22 @@ int main() {
       printf("blocks/CU %d  atomic add u64, %9llu slots (%6.1f MB)  %7.3f ms  %6.1f G atomics/s\n", bpc, (unsigned long long)slots, slots * 8 / 1e6, ms,
              (double)per_thread * grid * 256 / ms / 1e6);
     }
+  }
+  for (uint64_t slots : {100000ull, 64000000ull}) {
+    const uint64_t n_at = 1ull << 28;
+    const int grid = cus * 8;
+    const uint64_t per_thread = n_at / ((uint64_t)grid * 256);
+    float ms32, ms8;
+    update32_kernel<0><<<grid, 256>>>(reinterpret_cast<unsigned char*>(buf), slots, per_thread);
+    CHECK(hipEventRecord(a));
+    for (int i = 0; i < 3; ++i) update32_kernel<0><<<grid, 256>>>(reinterpret_cast<unsigned char*>(buf), slots, per_thread);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b)); CHECK(hipEventElapsedTime(&ms32, a, b));
+    update32_kernel<1><<<grid, 256>>>(reinterpret_cast<unsigned char*>(buf), slots, per_thread);
+    CHECK(hipEventRecord(a));
+    for (int i = 0; i < 3; ++i) update32_kernel<1><<<grid, 256>>>(reinterpret_cast<unsigned char*>(buf), slots, per_thread);
+    CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b)); CHECK(hipEventElapsedTime(&ms8, a, b));
+    const double n = (double)per_thread * grid * 256;
+    printf("%9llu slots: u32 atomic add %6.1f G/s | plain byte store %6.1f G/s\n", (unsigned long long)slots, n / (ms32 / 3) / 1e6, n / (ms8 / 3) / 1e6);
   }
   for (uint64_t slots : {100000ull, 64000000ull}) {
     const uint64_t n_at = 1ull << 28;
