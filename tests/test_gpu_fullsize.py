@@ -42,7 +42,7 @@ def test_c3_full_size_properties(c3_full):
     assert int(full.states[1].sum(dtype=np.uint64) & 0xFFFFFFFF) == int(tot.states[1][0])   # uint32 COUNT wraps mod 2^32
     # (2) every table organisation gives the same groups and states bit for bit
     kf, sf = _canon(full)
-    for flags in (1, 8, 16 | 32, 64):       # hash table; generic kernel; no presence carrier; radix-partitioned
+    for flags in (1, 1 | 2048, 8, 16 | 32, 64):   # hash table (arrays / records); generic kernel; no presence carrier; radix-partitioned
         other = t.query_agg(_plan(w, flags=flags))
         ko, so = _canon(other)
         assert other.ngroups == full.ngroups, flags
