@@ -1098,7 +1098,9 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     if (want_part && !(p->flags & VH_PLAN_FORCE_PART) && !part_tuples_override) {
       rc = probed_selectivity(&sel);
       if (rc) { delete r; return rc; }
-      want_part = sel >= 0.08;   // crossover measured on C3 (profiles/r01): 5 % direct wins, 11 % partitioned wins
+      // crossover measured on the C3 table (profiles/r01/NOTES.md): direct atomics cost 2 x survivors / 23.3 G/s on top of the
+      // scan (5 %: 5.0-5.15 ms, 6 %: 5.63, 7 %: 6.51, 8 %: 7.41), partitioned 4.97 / 5.30 / 5.56 / 5.86 ms
+      want_part = sel >= 0.055;
     }
     if (want_part) {
       // most rows pass: build the tuples without compacting survivors first (lanes kernel, phase 1 only)
