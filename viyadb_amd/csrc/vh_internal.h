@@ -174,6 +174,8 @@ struct VhPlanDev {
   uint32_t* part_count;      // [npart] extents recorded per partition
   uint32_t* part_extents;    // [npart][part_cap] extent ids
   uint16_t* extent_missing;  // [max_extents] tuples NOT filled in an extent (0 = full)
+  uint8_t* extent_part;      // [max_extents] partition an extent belongs to (0xFF: never opened). A plain store when the extent is
+                             // opened; phase 2 scans the tags. (A per-partition list needed a returning atomic on npart hot counters.)
   uint32_t part_cap;
   uint32_t max_extents;
   // ---- counters: [0] passed rows, [1] new groups (hash), [2] error flags,

@@ -750,12 +750,8 @@ __device__ __forceinline__ uint32_t vh_part_new_extent(const VhPlanDev& P, VhPar
     W.chunk_end = (uint32_t)c + VH_EXT_CHUNK;
   }
   const uint32_t ext = W.chunk_next++;
-  bool ok = ext < P.max_extents;
-  if (ok && lane == 0) {
-    const uint32_t pos = atomicAdd(P.part_count + p, 1u);
-    if (pos < P.part_cap) P.part_extents[(uint64_t)p * P.part_cap + pos] = ext; else ok = false;
-  }
-  ok = __shfl((int)ok, 0) != 0 && ext < P.max_extents;
+  const bool ok = ext < P.max_extents;
+  if (ok && lane == 0) P.extent_part[ext] = (uint8_t)p;
   if (!ok) {
     if (lane == 0) atomicOr(P.counters + 2, VH_ERR_PART_FULL);  // the host re-runs with a larger tuple buffer
     return ~0u;
@@ -1532,11 +1528,16 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
   }
   for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
   __syncthreads();
-  const uint32_t next = P.part_count[part] < P.part_cap ? P.part_count[part] : P.part_cap;
+  const unsigned long long allocated = P.counters[5];
+  const uint32_t total = allocated < P.max_extents ? (uint32_t)allocated : P.max_extents;   // extents handed out (opened or only reserved)
   const uint32_t ext_tuples = (uint32_t)P.ext_tuples;
   const uint32_t tw = (uint32_t)P.tw;
-  for (uint32_t e = (uint32_t)b * nwaves + wave; e < next; e += (uint32_t)blocks_per_part * nwaves) {
-    const uint32_t ext = P.part_extents[(uint64_t)part * P.part_cap + e];
+  // the waves of this partition's blocks share the tag array 64 extents at a time; a tag that equals `part` is an extent to aggregate
+  for (uint32_t c0 = ((uint32_t)b * nwaves + wave) * 64u; c0 < total; c0 += (uint32_t)blocks_per_part * nwaves * 64u) {
+   uint64_t mine = __ballot(c0 + lane < total && P.extent_part[c0 + lane] == (uint8_t)part);
+   while (mine) {
+    const uint32_t ext = c0 + (uint32_t)__builtin_ctzll(mine);
+    mine &= mine - 1;
     const uint32_t valid = ext_tuples - P.extent_missing[ext];
     const uint64_t* base = P.tuples + (uint64_t)ext * ext_tuples * tw;
     // four tuples per lane in flight: with one, a 16-wave block keeps ~16 KB outstanding and the kernel is latency bound
@@ -1571,6 +1572,7 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
         }
       }
     }
+   }
   }
   __syncthreads();
   for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) {

@@ -1335,7 +1335,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     for (int j = 0; j < P.nmetric; ++j) o_ostate2[j] = sp.take(r->out_cap * vh_elem_size(r->metric_elem[j]));
   }
   // outputs
-  size_t o_tuples = 0, o_pcount = 0, o_pext = 0, o_emiss = 0;
+  size_t o_tuples = 0, o_pcount = 0, o_pext = 0, o_emiss = 0, o_epart = 0;
   if (mode == VH_MODE_DENSE_PART) {
     // extent size: big enough that a wave allocates rarely (every allocation is a returning global
     // atomic = a full round trip the wave sits out), small enough that open extents do not waste HBM
@@ -1348,13 +1348,12 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
     if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
     P.max_extents = (uint32_t)max_ext;
-    uint64_t pcap = max_ext;                                  // skew-proof: one partition may take every extent
-    if (pcap * P.npart * 4 > (512ull << 20)) pcap = std::max<uint64_t>((512ull << 20) / (4ull * P.npart), max_ext / P.npart * 4);
-    P.part_cap = (uint32_t)std::min<uint64_t>(pcap, max_ext);
+    P.part_cap = 0;                                           // extents carry their partition as a tag: no per-partition lists
     o_tuples = sp.take(max_ext * ext_tuples * P.tw * 8);
     o_pcount = sp.take(VH_MAX_PART * sizeof(uint32_t));
-    o_pext = sp.take((uint64_t)P.npart * P.part_cap * sizeof(uint32_t));
+    o_pext = sp.take(256);
     o_emiss = sp.take(max_ext * sizeof(uint16_t));
+    o_epart = sp.take(max_ext);
   }
   size_t o_bsptr[VH_MAX_BITSET][2] = {}, o_dkeys[VH_MAX_BITSET] = {}, o_dtags[VH_MAX_BITSET] = {};
   for (int b = 0; b < P.nbitset; ++b) {
@@ -1388,6 +1387,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     P.part_count = reinterpret_cast<uint32_t*>(S + o_pcount);
     P.part_extents = reinterpret_cast<uint32_t*>(S + o_pext);
     P.extent_missing = reinterpret_cast<uint16_t*>(S + o_emiss);
+    P.extent_part = reinterpret_cast<uint8_t*>(S + o_epart);
   }
   if (P.nbitset) {
     for (int b = 0; b < P.nbitset; ++b) {
@@ -1440,6 +1440,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   if (mode == VH_MODE_DENSE_PART) {
     HIP_TRY(hipMemsetAsync(P.part_count, 0, VH_MAX_PART * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(P.extent_missing, 0, (size_t)P.max_extents * sizeof(uint16_t), st));
+    HIP_TRY(hipMemsetAsync(P.extent_part, 0xFF, (size_t)P.max_extents, st));
   }
   for (int j = 0; j < P.nmetric; ++j) {
     if (P.m[j].ident == 0 || P.hrec_bytes) continue;
