@@ -166,7 +166,13 @@ enum vh_plan_flags {
   VH_PLAN_NO_HASH_RECORDS = 1u << 10,/* ablation: hash table with separate key and
                                      state arrays even when it is big (>= 4 M slots:
                                      one record per slot for single-word keys)  */
-  VH_PLAN_FORCE_HASH_RECORDS = 1u << 11 /* testing: records whatever the size    */
+  VH_PLAN_FORCE_HASH_RECORDS = 1u << 11,/* testing: records whatever the size    */
+  VH_PLAN_NO_PACK = 1u << 12,     /* ablation: gather group / metric values from the
+                                     column arenas even when a payload projection
+                                     (vh_table_pack) covers them               */
+  VH_PLAN_FORCE_PACK = 1u << 13   /* testing: gather from a payload projection whatever
+                                     the selectivity, building one if none covers
+                                     the query's columns                       */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */
@@ -214,7 +220,8 @@ typedef struct vh_result_info {
   float total_ms;            /* HIP-event time launch .. results in host mem */
   uint64_t algorithmic_bytes;/* B_ref of SURVEY §8(d) for this query         */
   uint32_t retries;          /* hash-table regrows                           */
-  uint32_t reserved;         /* bit 0: the register-resident fast scan kernel ran; bit 1: its no-compaction "lanes" variant */
+  uint32_t reserved;         /* bit 0: the register-resident fast scan kernel ran; bit 1: its no-compaction "lanes" variant;
+                                bit 2: LDS front table of the hash path; bit 3: payload gathered from a projection (vh_table_pack) */
   uint64_t returned_groups;  /* rows vh_result_copy delivers (= ngroups without HAVING) */
 } vh_result_info;
 
@@ -284,6 +291,20 @@ VH_API int vh_segment_sync_bitset(vh_table* t, uint32_t seg, int32_t col,
 VH_API int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nseg,
                                uint64_t rows_per_seg, uint64_t row_base,
                                const vh_gen_spec* specs, uint64_t seed);
+/* Payload projection ("pack"): a second, row-major mirror of a FEW columns — record r of a segment holds the values
+ * of row r, widest column first, padded to a power of two <= 64 B. The reference has no such thing: its Segment is
+ * column arrays only (src/codegen/db/store.cc:214-356) and its loop touches `tuple_dims._i[idx]` / `tuple_metrics._j[idx]`
+ * of a passing row in as many cache lines as there are columns (scan.cc:220-241). On the GPU that is the dominant
+ * traffic of a selective GROUP BY (C3: four 128 B lines per survivor for 20 useful bytes), so the layout of the
+ * mirror is widened: queries whose group + metric columns are all in one projection, and whose filter passes few
+ * rows, gather a survivor's values from ONE record. Results are identical; vh_segment_sync* keeps projections
+ * coherent (a changed segment is re-packed from HBM before the next query that uses it). Cost: rows x record bytes
+ * of HBM (C3: 32 GB next to the 60 GB table). The library also builds one by itself for a column set it has seen in
+ * VH_AUTO_PACK (default 3, 0 = never) selective queries when a quarter of the device stays free; vh_table_unpack
+ * drops them all. Analogue in the reference: the per-query g++ compile that is cached on first use
+ * (src/query/runner.cc:45-64) — work done once for a query shape, outside its steady-state cost. */
+VH_API int vh_table_pack(vh_table* t, const int32_t* cols, int32_t ncols);
+VH_API int vh_table_unpack(vh_table* t);
 /* Copy a mirrored column back to the host (tests). */
 VH_API int vh_segment_read(vh_table* t, uint32_t seg, int32_t col, uint64_t nrows,
                            void* dst);

@@ -1,0 +1,172 @@
+"""Payload projections (vh_table_pack): a second, row-major mirror of a few columns from which the compacting scan
+kernels gather a survivor's group / metric values. Results must be those of the column arenas — i.e. the oracle's —
+for every table organisation and element type, and the projection must follow vh_segment_sync*."""
+import numpy as np
+import pytest
+
+from oracle import viya_oracle as vo
+from tests.parity import check_workload, compare
+from tests.planner import mirror_table, plan_from_query
+from tests.test_gpu_typed import F, NOW, TYPES, _rand, run, typed_table
+from viyadb_amd import capi
+
+pytestmark = pytest.mark.gpu
+PACK = capi.PLAN_FORCE_PACK
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    from viyadb_amd import executor
+    executor.init(0)
+
+
+@pytest.fixture(scope="module")
+def typed():
+    tab = typed_table()
+    dt = mirror_table(tab)
+    yield tab, dt
+    dt.close()
+
+
+@pytest.mark.parametrize("flags,path", [(0, "dense_global"), (64, "dense_part"), (1, "hash"), (8, "dense_global"), (2, "dense_global"),
+                                        (16 | 32, "dense_global"), (1 | 2048, "hash"), (9, "hash"), (8 | 64, "dense_global")])
+def test_c3_through_a_projection(flags, path):
+    from viyadb_amd import synth
+    w = synth.c3(segment_rows=250_000)
+    res, _ = check_workload(w, nseg=4, rows_per_seg=249_991, flags=flags | PACK, expect_path=path)
+    assert res.packed
+
+
+@pytest.mark.parametrize("flags,path", [(128, "dense_lds"), (128 | 2, "dense_global"), (128 | 1, "hash"), (8, "dense_lds")])
+def test_c2_through_a_projection(flags, path):
+    from viyadb_amd import synth
+    w = synth.c2(segment_rows=250_000)
+    res, _ = check_workload(w, nseg=3, flags=flags | PACK, expect_path=path)
+    assert res.packed
+    # the lanes kernels read column ranges, never records
+    res, _ = check_workload(w, nseg=3, flags=256 | PACK)
+    assert res.lanes and not res.packed
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("flags", [0, 1, 8, 64])
+def test_every_type_as_packed_metric(typed, t, flags):
+    tab, dt = typed
+    res, _ = run(tab, dt, {"dimensions": ["s8", "flag"], "metrics": ["count"] + [f"{t}_{a}" for a in ("sum", "min", "max", "avg")],
+                           "filter": F("lt", "d_uint", "20")}, flags=flags | PACK)
+    assert res.packed
+
+
+@pytest.mark.parametrize("dims", [["d_byte", "d_float", "d_double"], ["d_ulong", "d_long"], ["s8", "s16", "s32", "flag", "d_short"],
+                                  ["d_ubyte", "d_ushort", "id"], ["uts", "ts"]])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_every_type_as_packed_key(typed, dims, flags):
+    tab, dt = typed
+    res, _ = run(tab, dt, {"dimensions": dims, "metrics": ["count", "int_sum", "double_max"], "filter": F("ge", "d_int", "-30")}, flags=flags | PACK)
+    assert res.packed
+
+
+def test_time_truncation_reads_the_projection(typed):
+    tab, dt = typed
+    res, _ = run(tab, dt, {"select": [{"column": "ts", "granularity": "day"}, {"column": "s8"}, {"column": "count"}],
+                           "filter": F("lt", "d_uint", "30")}, flags=PACK)
+    assert res.packed and res.path == "hash"
+
+
+def test_wide_payloads_fall_back_to_the_arenas(typed):
+    tab, dt = typed
+    # 10 gather columns > VH_PACK_MAX_COLS: no projection can cover them; the query still answers from the arenas
+    res, _ = run(tab, dt, {"dimensions": ["s8"], "metrics": ["count", "long_sum", "long_min", "long_max", "double_sum", "ulong_max", "int_sum",
+                                                             "double_min", "ulong_min"], "filter": F("lt", "d_uint", "20")}, flags=PACK)
+    assert not res.packed
+
+
+@pytest.mark.parametrize("t", ["int", "double", "ubyte"])
+def test_hidden_count_travels_in_the_projection(t):
+    rng = np.random.default_rng(5)
+    tab = vo.Table({"name": "t", "segment_size": 20000, "dimensions": [{"name": "k", "type": "ushort"}, {"name": "f", "type": "uint"}],
+                    "metrics": [{"name": "a", "type": t + "_avg"}]})
+    for _ in range(2):
+        n = 15000
+        tab.add_segment_arrays([rng.integers(0, 300, n).astype(np.uint16), rng.integers(0, 100, n).astype(np.uint32)],
+                               [_rand(rng, vo.NUMERIC_TYPES[t][0], n, small=True)], rng.integers(1, 5, n).astype(np.uint64), n)
+    dt = mirror_table(tab)
+    try:
+        res, _ = run(tab, dt, {"dimensions": ["k"], "metrics": ["a"], "filter": F("lt", "f", "10")}, flags=PACK)
+        assert res.hidden_count is not None and res.packed
+    finally:
+        dt.close()
+
+
+def test_projection_follows_segment_syncs():
+    """vh_segment_sync / _sync_range after the projection was built: the changed segment is re-packed before the next query
+    that gathers from it (upsert appends rows and updates metrics of existing rows in place, src/codegen/db/upsert.cc:384-411)."""
+    rng = np.random.default_rng(11)
+    desc = {"name": "t", "segment_size": 30000, "dimensions": [{"name": "a", "type": "uint"}, {"name": "b", "type": "ushort"}, {"name": "f", "type": "uint"}],
+            "metrics": [{"name": "v", "type": "long_sum"}, {"name": "count", "type": "count"}]}
+
+    def seg(n):
+        return ([rng.integers(0, 50, n).astype(np.uint32), rng.integers(0, 40, n).astype(np.uint16), rng.integers(0, 100, n).astype(np.uint32)],
+                [rng.integers(-1000, 1000, n).astype(np.int64), rng.integers(1, 4, n).astype(np.uint32)])
+
+    tab = vo.Table(desc)
+    for n in (30000, 20000):
+        d, m = seg(n)
+        tab.add_segment_arrays(d, m, None, n)
+    dt = mirror_table(tab, reserve=2)
+    q = {"dimensions": ["a", "b"], "metrics": ["v", "count"], "filter": F("lt", "f", "8")}
+    try:
+        dt.pack([0, 1, 3, 4])
+        res, _ = run(tab, dt, q)                       # 8 % pass, a projection covers a, b, v, count: taken without being forced
+        assert res.packed
+        # in-place metric update of rows [100, 5000) of segment 0 + 5000 appended rows in segment 1
+        s0, s1 = tab.segments[0], tab.segments[1]
+        s0["m"][0][100:5000] += 7
+        d, m = seg(5000)
+        for i in range(3):
+            s1["d"][i] = np.concatenate([s1["d"][i][:20000], d[i]])
+        for j in range(2):
+            s1["m"][j] = np.concatenate([s1["m"][j][:20000], m[j]])
+        s1["size"] = 25000
+        import ctypes as C
+        cols0 = [s0["d"][0], s0["d"][1], s0["d"][2], s0["m"][0], s0["m"][1]]
+        ptrs = (C.c_void_p * 5)(*[np.ascontiguousarray(c).ctypes.data for c in cols0])
+        capi.check(dt.lib.vh_segment_sync_range(dt.handle, 0, 100, 4900, 30000, ptrs))
+        dt.sync_segment(1, [s1["d"][0], s1["d"][1], s1["d"][2], s1["m"][0], s1["m"][1]], 25000)
+        res, _ = run(tab, dt, q)
+        assert res.packed
+        # a third segment appears (the table grows past its reserve: arenas and the projection move)
+        d, m = seg(30000)
+        tab.add_segment_arrays(d, m, None, 30000)
+        dt.sync_segment(2, d + m, 30000)
+        res, _ = run(tab, dt, q)
+        assert res.packed and res.scanned_segments == 3
+        dt.unpack()
+        assert not run(tab, dt, q, flags=0)[0].packed
+    finally:
+        dt.close()
+
+
+def test_library_builds_a_projection_for_a_repeated_selective_query():
+    """VH_AUTO_PACK (default 3): the third selective query over the same payload columns gets a projection built for it."""
+    from viyadb_amd import synth
+    from viyadb_amd.executor import AggPlan
+    from tests.parity import build_oracle_table
+    w = synth.c3(segment_rows=100_000)
+    dt = synth.create_device_table(w, 3, 100_000)
+    try:
+        st = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 3, 100_000), w.query))
+        seen = []
+        for _ in range(4):
+            res = dt.query_agg(AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics))
+            compare(res, st, "auto pack")
+            seen.append(res.packed)
+        assert seen == [False, False, True, True]
+        # an unselective query over the same columns keeps reading the arenas
+        res = dt.query_agg(AggPlan(filter=[("rel", 3, capi.OP_LT, 900)], groups=w.plan.groups, metrics=w.plan.metrics))
+        assert not res.packed
+        res = dt.query_agg(AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=capi.PLAN_NO_PACK))
+        assert not res.packed
+        compare(res, st, "no pack")
+    finally:
+        dt.close()

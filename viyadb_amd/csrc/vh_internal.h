@@ -115,6 +115,7 @@ struct VhPlanDev {
   // ---- columns (slot -> arena)
   const char* colbase[VH_MAX_SLOTS];
   uint64_t colstride[VH_MAX_SLOTS];  // bytes between consecutive segments
+  uint32_t colpitch[VH_MAX_SLOTS];   // bytes between consecutive rows: the element size, or the record size of a payload projection
   // ---- work decomposition
   const uint32_t* seg_rows;  // per segment: rows to scan (0 = skipped)
   uint32_t nseg;

@@ -27,6 +27,7 @@ __host__ __device__ __forceinline__ uint64_t vh_splitmix64(uint64_t x) {
 }
 
 template <typename T> struct VhVec4 { typedef T type __attribute__((ext_vector_type(4))); };
+typedef uint32_t vh_u32x4 __attribute__((ext_vector_type(4)));
 
 template <typename T> __device__ __forceinline__ T vh_lit(uint64_t bits) {
   T v; __builtin_memcpy(&v, &bits, sizeof(T)); return v;   // low bytes, like db::AnyNum
@@ -228,6 +229,19 @@ __device__ __forceinline__ uint32_t vh_eval_filter(const VhPlanDev& P, uint32_t 
 // ------------------------------------------------------------ scalar gathers
 // One element of a column as raw bits, zero-extended (hash keys) or sign-extended
 // (dense digits, min/max on small signed types).
+// `at`: address of the element. A column arena is indexed with the element size, a payload projection (VhPlanDev::colpitch,
+// vh_table_pack) with its record size: the caller forms the address, the switch only picks width and extension.
+__device__ __forceinline__ uint64_t vh_load_at(const char* at, int type, bool sext) {
+  switch (type) {
+    case VH_U8: return *reinterpret_cast<const uint8_t*>(at);
+    case VH_I8: { int8_t v = *reinterpret_cast<const int8_t*>(at); return sext ? (uint64_t)(int64_t)v : (uint64_t)(uint8_t)v; }
+    case VH_U16: return *reinterpret_cast<const uint16_t*>(at);
+    case VH_I16: { int16_t v = *reinterpret_cast<const int16_t*>(at); return sext ? (uint64_t)(int64_t)v : (uint64_t)(uint16_t)v; }
+    case VH_U32: case VH_F32: return *reinterpret_cast<const uint32_t*>(at);
+    case VH_I32: { int32_t v = *reinterpret_cast<const int32_t*>(at); return sext ? (uint64_t)(int64_t)v : (uint64_t)(uint32_t)v; }
+    default: return *reinterpret_cast<const uint64_t*>(at);
+  }
+}
 __device__ __forceinline__ uint64_t vh_load_bits(const char* base, int type, uint32_t row, bool sext) {
   switch (type) {
     case VH_U8: return *reinterpret_cast<const uint8_t*>(base + row);
@@ -241,6 +255,12 @@ __device__ __forceinline__ uint64_t vh_load_bits(const char* base, int type, uin
                    return sext ? (uint64_t)(int64_t)v : (uint64_t)(uint32_t)v; }
     default: return *reinterpret_cast<const uint64_t*>(base + 8ull * row);
   }
+}
+
+// One value of row `row` of the column in slot `slot`: out of its arena, or out of a payload projection's record
+// (colpitch = record size, colbase = arena + the column's offset inside the record).
+__device__ __forceinline__ uint64_t vh_gather(const VhPlanDev& P, uint32_t slot, uint32_t seg, uint32_t row, int type, bool sext) {
+  return vh_load_at(P.colbase[slot] + (uint64_t)seg * P.colstride[slot] + (uint64_t)row * P.colpitch[slot], type, sext);
 }
 
 // ----------------------------------------------------------- state updates
@@ -517,8 +537,7 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
   if (!active) row = 0;
   for (int i = 0; i < P.ngroup; ++i) {
     const VhGroupDev& g = P.g[i];
-    const char* base = P.colbase[g.slot()] + (uint64_t)seg * P.colstride[g.slot()];
-    uint64_t v = vh_load_bits(base, g.type(), row, MODE != VH_MODE_HASH);
+    uint64_t v = vh_gather(P, g.slot(), seg, row, g.type(), MODE != VH_MODE_HASH);
     if (g.gran() != VH_T_NONE || g.nroll()) v = vh_time_rollup(v, g);
     if (MODE == VH_MODE_HASH) {
       if (g.type() == VH_F32 && (uint32_t)v == 0x80000000u) v = 0;            // -0.0f == 0.0f
@@ -542,7 +561,7 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
         for (int j = 0; j < P.nmetric; ++j) {
           const VhMetricDev& m = P.m[j];
           const uint64_t bits = m.slot() == VH_SLOT_ROWID ? (((uint64_t)seg << 32) | row)
-                                                        : vh_load_bits(P.colbase[m.slot()] + (uint64_t)seg * P.colstride[m.slot()], m.type(), row, vh_sop_sext(m.sop()));
+                                                        : vh_gather(P, m.slot(), seg, row, m.type(), vh_sop_sext(m.sop()));
           vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, ls, m.sop(), bits);
         }
       }
@@ -577,7 +596,7 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
     }
     uint64_t bits;
     if (m.slot() == VH_SLOT_ROWID) bits = ((uint64_t)seg << 32) | row;   // storage order of the row (search: first occurrence)
-    else bits = vh_load_bits(P.colbase[m.slot()] + (uint64_t)seg * P.colstride[m.slot()], m.type(), row, vh_sop_sext(m.sop()));
+    else bits = vh_gather(P, m.slot(), seg, row, m.type(), vh_sop_sext(m.sop()));
     if (active) {
       if (MODE == VH_MODE_DENSE_LDS) {
         vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, gid, m.sop(), bits);
@@ -979,7 +998,7 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
     gv[i] = 0;
     if (i < P.ngroup) {
       const VhGroupDev& g = P.g[i];
-      gv[i] = vh_load_bits(P.colbase[g.slot()] + (uint64_t)seg * P.colstride[g.slot()], g.type(), row, MODE != VH_MODE_HASH);
+      gv[i] = vh_gather(P, g.slot(), seg, row, g.type(), MODE != VH_MODE_HASH);
     }
   }
 #pragma unroll
@@ -988,7 +1007,7 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
     if (j < P.nmetric) {
       const VhMetricDev& m = P.m[j];
       if (m.slot() == VH_SLOT_ROWID) mv[j] = ((uint64_t)seg << 32) | row;
-      else mv[j] = vh_load_bits(P.colbase[m.slot()] + (uint64_t)seg * P.colstride[m.slot()], m.type(), row, vh_sop_sext(m.sop()));
+      else mv[j] = vh_gather(P, m.slot(), seg, row, m.type(), vh_sop_sext(m.sop()));
     }
   }
   uint64_t gid = 0;

@@ -612,6 +612,49 @@ __global__ __launch_bounds__(256) void iota_kernel(uint64_t* p, uint64_t n) {
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = i;
 }
 
+// ----------------------------------------------------------- payload projection ("pack")
+// Row-major copy of a few columns of a table (vh_table_pack): record r of a segment holds the values of row r, every
+// column at a fixed, naturally aligned offset; records are a power of two <= 64 B, so one never straddles a 128 B line.
+// The compacting scan kernels gather a survivor's group / metric values from it with ONE line touched instead of one
+// per column (C3: four lines of four column arenas -> one 32 B record). Built from the column arenas in HBM; a block
+// stages 256 records in LDS so that both the column reads and the record writes are coalesced.
+#define VH_PACK_MAX_COLS 8
+struct VhPackArgs {
+  int32_t ncols; uint32_t rec_bytes;
+  const char* src[VH_PACK_MAX_COLS];   // column arenas
+  uint64_t src_stride[VH_PACK_MAX_COLS];
+  uint32_t esize[VH_PACK_MAX_COLS], off[VH_PACK_MAX_COLS];
+  char* dst; uint64_t dst_stride;      // pack arena, bytes between segments
+  const uint32_t* rows;                // [gridDim.y] rows to pack of segment seg_first + blockIdx.y
+  uint32_t seg_first, pad;
+};
+__global__ __launch_bounds__(256) void pack_kernel(const VhPackArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const uint32_t seg = A.seg_first + blockIdx.y, nrows = A.rows[blockIdx.y], rec = A.rec_bytes;
+  for (uint32_t i = threadIdx.x; i < 256u * rec / 16u; i += 256u) reinterpret_cast<vh_u32x4*>(lds)[i] = vh_u32x4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  char* dst = A.dst + (uint64_t)seg * A.dst_stride;
+  for (uint32_t row0 = blockIdx.x * 256u; row0 < nrows; row0 += gridDim.x * 256u) {
+    const uint32_t row = row0 + threadIdx.x;
+    if (row < nrows) {
+      for (int c = 0; c < A.ncols; ++c) {
+        const char* s = A.src[c] + (uint64_t)seg * A.src_stride[c] + (uint64_t)row * A.esize[c];
+        char* d = lds + threadIdx.x * rec + A.off[c];
+        switch (A.esize[c]) {
+          case 1: *reinterpret_cast<uint8_t*>(d) = *reinterpret_cast<const uint8_t*>(s); break;
+          case 2: *reinterpret_cast<uint16_t*>(d) = *reinterpret_cast<const uint16_t*>(s); break;
+          case 4: *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<const uint32_t*>(s); break;
+          default: *reinterpret_cast<uint64_t*>(d) = *reinterpret_cast<const uint64_t*>(s); break;
+        }
+      }
+    }
+    __syncthreads();
+    vh_u32x4* out = reinterpret_cast<vh_u32x4*>(dst + (uint64_t)row0 * rec);
+    for (uint32_t i = threadIdx.x; i < 256u * rec / 16u; i += 256u) out[i] = reinterpret_cast<const vh_u32x4*>(lds)[i];
+    __syncthreads();
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void fill_kernel(T* p, uint64_t n, T v) {
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = v;
@@ -699,7 +742,6 @@ __global__ __launch_bounds__(256) void seg_minmax_kernel(const T* base, uint64_t
 }
 
 // ------------------------------------------------------- bandwidth ceiling
-typedef uint32_t vh_u32x4 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void read_bw_kernel(const vh_u32x4* p, uint64_t n16, unsigned long long* sink) {
   uint32_t acc = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) {

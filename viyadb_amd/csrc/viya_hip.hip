@@ -93,6 +93,16 @@ struct VhColumn {
 struct VhSegStat {          // order keys as produced by seg_minmax_kernel
   uint64_t lo = ~0ull, hi = 0;
 };
+// Payload projection (vh_table_pack): a row-major copy of a few columns, see pack_kernel.
+struct VhPack {
+  std::vector<int> cols;            // table column indices, in record order (widest first)
+  std::vector<uint32_t> off;        // byte offset of each column inside a record
+  uint32_t rec_bytes = 0;           // power of two, 8..64
+  char* base = nullptr; uint64_t stride = 0; uint32_t cap_seg = 0;
+  std::vector<uint64_t> seg_mod;    // value of vh_table::seg_mod[s] the segment was packed at (0: never)
+  bool automatic = false;
+  int col_index(int col) const { for (size_t i = 0; i < cols.size(); ++i) if (cols[i] == col) return (int)i; return -1; }
+};
 struct vh_table {
   std::vector<VhColumn> cols;
   uint64_t segment_rows = 0;
@@ -109,6 +119,10 @@ struct vh_table {
   std::map<std::string, uint64_t> groups_seen;           // group-column signature -> groups of the last query (hash sizing)
   std::map<std::string, double> sel_cache;               // filter signature + table state -> probed selectivity
   char* h_out[2] = {nullptr, nullptr}; size_t h_out_bytes[2] = {0, 0}; int h_out_next = 0;  // pinned result staging
+  std::vector<std::unique_ptr<VhPack>> packs;
+  std::vector<uint64_t> seg_mod;                          // sync_epoch of the last change to a segment's columns
+  uint32_t* d_packrows = nullptr; size_t d_packrows_cap = 0;
+  std::map<std::string, uint32_t> gather_seen;            // payload column set -> low-selectivity queries seen (automatic packs)
   uint64_t sync_epoch = 0;   // bumped by every vh_segment_sync / generate: invalidates cached estimates
   uint64_t launch_epoch = 0; // bumped by every query launch: a result's device state lives in `scratch` until the next one
   uint64_t staged_seq = 0;   // bumped by every finalisation: host views alternate between the two staging buffers
@@ -142,6 +156,7 @@ static int table_grow(vh_table* t, uint32_t need_seg) {
   }
   t->cap_seg = ncap;
   t->seg_rows.resize(ncap, 0);
+  t->seg_mod.resize(ncap, 0);
   for (auto& s : t->stats) s.resize(ncap);
   return VH_OK;
 }
@@ -191,6 +206,8 @@ extern "C" void vh_table_destroy(vh_table* t) {
   }
   if (t->scratch) (void)hipFree(t->scratch);
   if (t->d_sample) (void)hipFree(t->d_sample);
+  for (auto& pk : t->packs) if (pk->base) (void)hipFree(pk->base);
+  if (t->d_packrows) (void)hipFree(t->d_packrows);
   for (auto& hp : t->h_out) if (hp) (void)hipHostFree(hp);
   if (t->h_segrows) (void)hipHostFree(t->h_segrows);
   if (t->h_counters) (void)hipHostFree(t->h_counters);
@@ -295,7 +312,7 @@ extern "C" int vh_segment_sync(vh_table* t, uint32_t seg, uint64_t nrows, const 
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   t->seg_rows[seg] = nrows;
   t->nseg = std::max(t->nseg, seg + 1);
-  ++t->sync_epoch;
+  t->seg_mod[seg] = ++t->sync_epoch;
   return refresh_stats(t, seg, 1);
 }
 
@@ -322,7 +339,7 @@ extern "C" int vh_segment_sync_range(vh_table* t, uint32_t seg, uint64_t row_fir
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   t->seg_rows[seg] = new_size;
   t->nseg = std::max(t->nseg, seg + 1);
-  ++t->sync_epoch;
+  t->seg_mod[seg] = ++t->sync_epoch;
   return refresh_stats(t, seg, 1);   // one pass over the segment's dimension columns in HBM
 }
 
@@ -411,9 +428,9 @@ extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nse
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-  for (uint32_t s = 0; s < nseg; ++s) t->seg_rows[seg_first + s] = rows_per_seg;
-  t->nseg = std::max(t->nseg, seg_first + nseg);
   ++t->sync_epoch;
+  for (uint32_t s = 0; s < nseg; ++s) { t->seg_rows[seg_first + s] = rows_per_seg; t->seg_mod[seg_first + s] = t->sync_epoch; }
+  t->nseg = std::max(t->nseg, seg_first + nseg);
   // stats in batches so the staging buffers stay small
   for (uint32_t s = 0; s < nseg; s += 256) {
     rc = refresh_stats(t, seg_first + s, std::min<uint32_t>(256, nseg - s));
@@ -444,6 +461,102 @@ extern "C" int vh_table_info(vh_table* t, uint32_t* nseg, uint64_t* segment_rows
   if (nseg) *nseg = t->nseg;
   if (segment_rows) *segment_rows = t->segment_rows;
   if (device_bytes) *device_bytes = t->device_bytes;
+  return VH_OK;
+}
+
+// ------------------------------------------------------- payload projections (vh_table_pack)
+// (Re)pack the segments of [first, first + n) whose columns changed since they were last packed.
+static int pack_refresh(vh_table* t, VhPack* pk, uint32_t first, uint32_t n) {
+  if (first + n > t->nseg) n = t->nseg > first ? t->nseg - first : 0;
+  if (!n) return VH_OK;
+  if (pk->cap_seg < t->cap_seg) {                      // the table grew: move the arena
+    char* nb = nullptr;
+    const size_t bytes = (size_t)t->cap_seg * pk->stride + 256;
+    HIP_TRY(hipMalloc(&nb, bytes));
+    if (pk->base) {
+      HIP_TRY(hipMemcpyAsync(nb, pk->base, (size_t)pk->cap_seg * pk->stride, hipMemcpyDeviceToDevice, g_ctx.stream));
+      HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+      HIP_TRY(hipFree(pk->base));
+      t->device_bytes -= (size_t)pk->cap_seg * pk->stride + 256;
+    }
+    pk->base = nb; pk->cap_seg = t->cap_seg;
+    pk->seg_mod.resize(t->cap_seg, 0);
+    t->device_bytes += bytes;
+  }
+  uint32_t s = first;
+  while (s < first + n) {
+    if (pk->seg_mod[s] == t->seg_mod[s]) { ++s; continue; }
+    uint32_t e = s;
+    while (e < first + n && pk->seg_mod[e] != t->seg_mod[e] && e - s < 4096) ++e;
+    const uint32_t cnt = e - s;
+    if (t->d_packrows_cap < cnt) {
+      HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+      if (t->d_packrows) HIP_TRY(hipFree(t->d_packrows));
+      t->d_packrows = nullptr; t->d_packrows_cap = 0;
+      HIP_TRY(hipMalloc((void**)&t->d_packrows, (size_t)std::max<uint32_t>(cnt, 1024) * sizeof(uint32_t)));
+      t->d_packrows_cap = std::max<uint32_t>(cnt, 1024);
+    }
+    std::vector<uint32_t> rows(cnt);
+    for (uint32_t i = 0; i < cnt; ++i) rows[i] = (uint32_t)t->seg_rows[s + i];
+    HIP_TRY(hipMemcpyAsync(t->d_packrows, rows.data(), (size_t)cnt * sizeof(uint32_t), hipMemcpyHostToDevice, g_ctx.stream));
+    VhPackArgs A{};
+    A.ncols = (int32_t)pk->cols.size(); A.rec_bytes = pk->rec_bytes;
+    for (size_t c = 0; c < pk->cols.size(); ++c) {
+      const VhColumn& col = t->cols[pk->cols[c]];
+      A.src[c] = col.base; A.src_stride[c] = col.stride; A.esize[c] = (uint32_t)col.esize; A.off[c] = pk->off[c];
+    }
+    A.dst = pk->base; A.dst_stride = pk->stride; A.rows = t->d_packrows; A.seg_first = s;
+    dim3 grid((unsigned)std::min<uint64_t>(64, (t->segment_rows + 255) / 256), cnt);
+    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 256 * pk->rec_bytes, g_ctx.stream, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));        // `rows` lives on this frame; d_packrows is reused by the next batch
+    for (uint32_t i = s; i < e; ++i) pk->seg_mod[i] = t->seg_mod[i];
+    s = e;
+  }
+  return VH_OK;
+}
+
+static int table_pack_locked(vh_table* t, const int32_t* cols, int32_t ncols, bool automatic, VhPack** out) {
+  if (!cols || ncols <= 0 || ncols > VH_PACK_MAX_COLS) return vh_fail(VH_E_INVALID, "vh_table_pack: 1..%d columns", VH_PACK_MAX_COLS);
+  std::vector<int> order;
+  for (int i = 0; i < ncols; ++i) {
+    const int c = cols[i];
+    if (c < 0 || (size_t)c >= t->cols.size() || is_bitset_elem(t->cols[c].elem)) return vh_fail(VH_E_INVALID, "vh_table_pack: column %d cannot be packed", c);
+    if (std::find(order.begin(), order.end(), c) == order.end()) order.push_back(c);
+  }
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return t->cols[a].esize > t->cols[b].esize; });   // widest first: every field naturally aligned
+  uint32_t bytes = 0;
+  std::vector<uint32_t> off;
+  for (int c : order) { off.push_back(bytes); bytes += (uint32_t)t->cols[c].esize; }
+  if (bytes > 64) return vh_fail(VH_E_UNSUPPORTED, "vh_table_pack: %u payload bytes per row (max 64)", bytes);
+  uint32_t rec = 8;
+  while (rec < bytes) rec <<= 1;
+  for (auto& pk : t->packs)
+    if (pk->cols == order) { if (out) *out = pk.get(); return pack_refresh(t, pk.get(), 0, t->nseg); }
+  std::unique_ptr<VhPack> pk(new VhPack());
+  pk->cols = order; pk->off = off; pk->rec_bytes = rec; pk->automatic = automatic;
+  pk->stride = (t->segment_rows + 255) / 256 * 256 * (uint64_t)rec;
+  VhPack* raw = pk.get();
+  t->packs.push_back(std::move(pk));
+  int rc = pack_refresh(t, raw, 0, t->nseg);
+  if (rc) { if (raw->base) { (void)hipFree(raw->base); t->device_bytes -= (size_t)raw->cap_seg * raw->stride + 256; } t->packs.pop_back(); return rc; }
+  if (out) *out = raw;
+  return VH_OK;
+}
+
+extern "C" int vh_table_pack(vh_table* t, const int32_t* cols, int32_t ncols) {
+  if (!t) return vh_fail(VH_E_INVALID, "null table");
+  std::lock_guard<std::mutex> lk(t->mu);
+  return table_pack_locked(t, cols, ncols, false, nullptr);
+}
+
+extern "C" int vh_table_unpack(vh_table* t) {
+  if (!t) return vh_fail(VH_E_INVALID, "null table");
+  std::lock_guard<std::mutex> lk(t->mu);
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  for (auto& pk : t->packs) if (pk->base) { (void)hipFree(pk->base); t->device_bytes -= (size_t)pk->cap_seg * pk->stride + 256; }
+  t->packs.clear();
+  t->gather_seen.clear();
   return VH_OK;
 }
 
@@ -778,6 +891,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     slot_of[col] = P.nslots;
     P.colbase[P.nslots] = c.base;
     P.colstride[P.nslots] = c.stride;
+    P.colpitch[P.nslots] = (uint32_t)c.esize;
     bytes_per_row += c.esize;
     return P.nslots++;
   };
@@ -914,6 +1028,8 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   P.nmetric = 0;
   bool has_avg = false, has_count = false;
   int bitset_col[VH_MAX_BITSET];
+  int metric_col[VH_MAX_METRIC];   // table column behind device metric j (-1: virtual row id / bitset)
+  for (int j = 0; j < VH_MAX_METRIC; ++j) metric_col[j] = -1;
   uint64_t bitset_ids[VH_MAX_BITSET] = {}, bitset_ids_before = 0;   // ids stored in the scanned segments, per bitset metric
   uint64_t pair_cap = 0;
   for (int j = 0; j < p->nmetrics; ++j) {
@@ -950,6 +1066,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     if (sop_for(c.kind, c.elem, &sop, &ident)) { delete r; return vh_fail(VH_E_INVALID, "metric %d: kind %d / elem %d", j, c.kind, c.elem); }
     VhMetricDev& m = P.m[P.nmetric];
     m.set_slot((uint16_t)s); m.set_type((uint8_t)c.elem); m.set_sop((uint8_t)sop); m.ident = ident;
+    metric_col[P.nmetric] = col;
     r->user_metric.push_back(P.nmetric++);
     r->metric_elem.push_back(c.elem);
     has_avg |= c.kind == VH_METRIC_AVG; has_count |= c.kind == VH_METRIC_COUNT;
@@ -961,6 +1078,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     if (hc < 0) { delete r; return vh_fail(VH_E_INVALID, "AVG selected without COUNT but the table has no hidden count column"); }
     const int s = slot(hc);
     if (s < 0) { delete r; return vh_fail(VH_E_UNSUPPORTED, "too many referenced columns"); }
+    metric_col[P.nmetric] = hc;
     VhMetricDev& m = P.m[P.nmetric++];
     m.set_slot((uint16_t)s); m.set_type(VH_U64); m.set_sop(SOP_ADD64); m.ident = 0;
     r->metric_elem.push_back(VH_U64);
@@ -1161,6 +1279,72 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   r->mode = mode;
   r->info.path = mode == VH_MODE_DENSE_LDS ? (p->ngroups ? VH_PATH_DENSE_LDS : VH_PATH_SCALAR)
                : mode == VH_MODE_DENSE_GLOBAL ? VH_PATH_DENSE_GLOBAL : mode == VH_MODE_DENSE_PART ? VH_PATH_DENSE_PART : VH_PATH_HASH;
+
+  // ---------------- payload projection: when few rows pass, a survivor's group / metric values come out of ONE packed
+  // record (vh_table_pack) instead of one line per column arena. Only the compacting kernels gather by row; the lanes
+  // kernels read whole column ranges and keep the arenas.
+  bool packed = false;
+  {
+    std::vector<int32_t> gcols;
+    for (int i = 0; i < p->ngroups; ++i) gcols.push_back(p->groups[i].col);
+    for (int j = 0; j < P.nmetric; ++j) if (metric_col[j] >= 0) gcols.push_back(metric_col[j]);
+    std::sort(gcols.begin(), gcols.end());
+    gcols.erase(std::unique(gcols.begin(), gcols.end()), gcols.end());
+    bool want = !lanes && !(p->flags & VH_PLAN_NO_PACK) && !gcols.empty() && gcols.size() <= VH_PACK_MAX_COLS && rows_to_scan &&
+                P.nslots + (int)gcols.size() <= VH_MAX_SLOTS;
+    const bool forced = (p->flags & VH_PLAN_FORCE_PACK) != 0;
+    if (want && !forced) {
+      // lines touched per survivor: one record vs one per column; the projection stops paying off once most lines of
+      // the arenas are touched anyway (C3 columns: ~20 % of the rows passing)
+      want = fast && p->nfilter > 0;
+      if (want) {
+        double sel = 1.0;
+        rc = probed_selectivity(&sel);
+        if (rc) { delete r; return rc; }
+        want = sel <= 0.15;
+      }
+    }
+    VhPack* use = nullptr;
+    if (want) {
+      for (auto& pk : t->packs) {
+        bool all = true;
+        for (int c : gcols) all &= pk->col_index(c) >= 0;
+        if (all && (!use || pk->rec_bytes < use->rec_bytes)) use = pk.get();
+      }
+      static const int auto_after = getenv("VH_AUTO_PACK") ? atoi(getenv("VH_AUTO_PACK")) : 3;   // 0: never build one unasked
+      if (!use && (forced || auto_after > 0)) {
+        std::string sig;
+        for (int c : gcols) sig += std::to_string(c) + ",";
+        bool build = forced || ++t->gather_seen[sig] >= (uint32_t)auto_after;
+        if (build && !forced) {        // room: the projection must leave a quarter of the device free and not outgrow the table
+          uint32_t bytes = 0; for (int c : gcols) bytes += (uint32_t)t->cols[c].esize;
+          uint32_t rec = 8; while (rec < bytes) rec <<= 1;
+          const size_t need = (size_t)t->cap_seg * ((t->segment_rows + 255) / 256 * 256) * rec;
+          size_t free_b = 0, total_b = 0;
+          build = bytes <= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= t->device_bytes && free_b > need + total_b / 4;
+          if (!build) t->gather_seen[sig] = 0;
+        }
+        if (build && table_pack_locked(t, gcols.data(), (int32_t)gcols.size(), !forced, &use) != VH_OK) use = nullptr;
+      }
+    }
+    if (use) {
+      rc = pack_refresh(t, use, 0, nseg);
+      if (rc) { delete r; return rc; }
+      int pslot_of[256];
+      for (int i = 0; i < 256; ++i) pslot_of[i] = -1;
+      auto pslot = [&](int col) {
+        if (pslot_of[col] >= 0) return pslot_of[col];
+        const int k = use->col_index(col);
+        P.colbase[P.nslots] = use->base + use->off[k];
+        P.colstride[P.nslots] = use->stride;
+        P.colpitch[P.nslots] = use->rec_bytes;
+        return pslot_of[col] = P.nslots++;
+      };
+      for (int i = 0; i < p->ngroups; ++i) P.g[i].set_slot((uint16_t)pslot(p->groups[i].col));
+      for (int j = 0; j < P.nmetric; ++j) if (metric_col[j] >= 0) P.m[j].set_slot((uint16_t)pslot(metric_col[j]));
+      packed = true;
+    }
+  }
 
   // per-XCD private copies only while they stay cache-sized
   int nxcd = 1;
@@ -1448,7 +1632,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     if (rc) { delete r; return rc; }
   }
   HIP_TRY(hipEventRecord(t->ev[1], st));
-  r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0);
+  r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0);
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
     if (mode == VH_MODE_DENSE_PART) {

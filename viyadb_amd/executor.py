@@ -78,7 +78,9 @@ class AggResult:
     retries: int
     fast: bool = False
     lanes: bool = False            # the no-compaction variant of the fast kernel ran
+    packed: bool = False           # group / metric values were gathered from a payload projection (vh_table_pack)
     returned: int = 0              # rows delivered (= ngroups unless a HAVING was pushed down)
+
 
 
 class DeviceTable:
@@ -156,6 +158,19 @@ class DeviceTable:
         dt = np.dtype(capi.ELEM_NP[self.cols[col][1]])
         f = lambda a: np.frombuffer(bytes(a), dtype=dt, count=1)[0]
         return f(lo), f(hi)
+
+    def pack(self, cols: Sequence[int]) -> None:
+        """Payload projection over `cols` (vh_table_pack): selective queries gather these columns from one record per row."""
+        arr = (C.c_int32 * len(cols))(*[int(c) for c in cols])
+        capi.check(self.lib.vh_table_pack(self.handle, arr, len(cols)))
+
+    def unpack(self) -> None:
+        capi.check(self.lib.vh_table_unpack(self.handle))
+
+    def gather_columns(self, plan: AggPlan) -> List[int]:
+        """Columns a survivor's values are gathered from: group columns + value metrics (not bitsets, not the row id)."""
+        cols = [g.col for g in plan.groups] + [m for m in plan.metrics if m != capi.COL_ROWID and self.cols[m][1] < capi.BITSET32]
+        return sorted(set(cols))
 
     # ---- the hot path
     def prepare(self, plan: AggPlan) -> AggPlan:
@@ -282,7 +297,7 @@ class DeviceTable:
         return AggResult(keys, states, hidden, int(info.ngroups), int(info.scanned_recs), int(info.scanned_segments),
                          int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
                          float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1),
-                         bool(info.reserved & 2), int(ng))
+                         bool(info.reserved & 2), bool(info.reserved & 8), int(ng))
 
     def query_agg(self, plan: AggPlan, copy: bool = True) -> AggResult:
         p, keep = self._build_plan(plan)
