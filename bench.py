@@ -29,17 +29,55 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
-def measured_traffic(workload: str, rows_on_rank: int):
-    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/), scaled by rows.
-    PMC counters cannot be read inside a normal run; see profiles/*/c3_1gpu_pmc_hbm.json."""
+def measured_traffic(workload: str, rows_on_rank: int, kernel: str):
+    """HBM bytes per launch from the newest committed rocprofv3 PMC summary (profiles/rNN/) whose recorded kernel is the
+    kernel that just ran, scaled by rows. PMC counters cannot be read inside a normal run (tools/profile_round.sh collects
+    them with the same command line); a summary taken with another kernel is refused: traffic = null."""
     import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "%s_1gpu_pmc_hbm.json" % workload.lower()))):
-        best = f
-    if not best:
-        return None, None
-    d = json.load(open(best))
-    return d["B_meas_per_launch"] * rows_on_rank / d["rows"], os.path.relpath(best, ROOT)
+    first = kernel.split(" + ")[0]
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "%s_1gpu_pmc_hbm.json" % workload.lower())), reverse=True):
+        d = json.load(open(f))
+        if first and first in d.get("kernel", ""):
+            return d["B_meas_per_launch"] * rows_on_rank / d["rows"], os.path.relpath(f, ROOT), d.get("head")
+    return None, None, None
+
+
+def parity_gate(table, w, plan, my_segments, executor):
+    """Before anything is timed ("parity gate before any number is reported"), on this rank's shard, through the
+    library calls the timed loop makes: (1) an exact comparison with the oracle on a window of segments of the SAME generated
+    rows; (2) size-independent properties over the whole shard — the plan's result against an independent table organisation
+    (the open-addressing hash table) bit for bit, and its totals against a GROUP-BY-less query (another kernel instantiation)."""
+    import numpy as np
+    from oracle import viya_oracle as vo
+    from tests.parity import build_oracle_table, compare
+    t0 = time.time()
+    win = min(2, my_segments)
+    first = max(0, my_segments // 2 - 1)
+    snap = [0] * my_segments
+    for s in range(first, first + win):
+        snap[s] = w.segment_rows
+    p = executor.AggPlan(filter=plan.filter, groups=plan.groups, metrics=plan.metrics, flags=plan.flags, groups_hint=plan.groups_hint, seg_rows=snap)
+    res = table.query_agg(p)
+    base = getattr(table, "_row_base", 0) + first * w.segment_rows
+    st = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, win, w.segment_rows, row_base=base), w.query), now=getattr(w, "now", None))
+    st.scanned_recs, st.scanned_segments = res.scanned_recs, res.scanned_segments     # hidden segments still count as scanned
+    compare(res, st, "bench parity gate (oracle window)")
+    full = table.query_agg(plan)
+    other = table.query_agg(executor.AggPlan(filter=plan.filter, groups=plan.groups, metrics=plan.metrics, flags=1, groups_hint=plan.groups_hint))
+    assert full.ngroups == other.ngroups and full.passed_recs == other.passed_recs, "table organisations disagree"
+
+    def canon(r):
+        o = np.lexsort([k for k in reversed(r.keys)]) if r.keys else np.arange(r.ngroups)
+        return [k[o] for k in r.keys] + [x[o] for x in r.states]
+    for a, b in zip(canon(full), canon(other)):
+        assert np.array_equal(a, b), "table organisations disagree"
+    tot = table.query_agg(executor.AggPlan(filter=plan.filter, groups=[], metrics=plan.metrics))
+    for j, sj in enumerate(full.states):
+        if sj.dtype.kind in "iu" and table.cols[plan.metrics[j]][0] in (18, 20):       # SUM / COUNT: wrap like the column's own type
+            assert int(sj.sum(dtype=np.uint64 if sj.dtype.kind == "u" else np.int64)) & ((1 << (8 * sj.dtype.itemsize)) - 1) == \
+                int(tot.states[j][0]) & ((1 << (8 * sj.dtype.itemsize)) - 1), "totals disagree"
+    return {"oracle_window_segments": win, "oracle_window_rows": win * w.segment_rows, "oracle_groups": st.ngroups,
+            "cross_path": "dense vs hash organisation, bit-exact over %d rows" % full.scanned_recs, "seconds": round(time.time() - t0, 2)}
 
 
 def cpu_baseline(w, sample_segments: int):
@@ -110,6 +148,7 @@ def main():
     ap.add_argument("--cpu-parallel", action="store_true", help="also time the courtesy all-cores CPU baseline (adds ~30 s)")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-pack", action="store_true", help="ablation: no payload projection (survivors gather from the column arenas)")
+    ap.add_argument("--no-check", action="store_true", help="skip the parity gate (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -119,7 +158,10 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    # one rank per GPU; VH_BENCH_BACKEND=gloo lets the N>1 flow be exercised on a box with fewer GPUs than ranks
+    # One rank per GPU. torch.distributed (gloo) is the CONTROL plane only: rendezvous, the RCCL unique id, barriers and the
+    # max-over-ranks of the timing. The data plane — plan agreement, verdict all-reduce, ncclReduce of the partial tables — is
+    # the library's own RCCL communicator behind vh_query_agg_sharded. VH_BENCH_BACKEND=gloo swaps that transport for
+    # callbacks over gloo so the N>1 flow can run on a box with fewer GPUs than ranks (tests).
     backend = os.environ.get("VH_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= max(1, torch.cuda.device_count())
@@ -127,13 +169,13 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
+        dist.init_process_group("gloo")
 
     from viyadb_amd import capi, distributed, executor, synth
-    executor.init(local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    executor.init(local_rank)
+    comm = None
+    if world > 1:
+        comm = distributed.Comm.rccl(dist) if backend == "nccl" else distributed.Comm.gloo(dist)
 
     w = synth.WORKLOADS[args.workload](segment_rows=args.segment_rows)
     total_segments = args.segments or {"C1": 10, "C2": 100, "C3": 1000, "C5t": 100, "C5": 100}[args.workload]
@@ -142,10 +184,11 @@ def main():
     my_segments = seg_hi - seg_lo
     t_gen = time.time()
     table = synth.create_device_table(w, my_segments, w.segment_rows, row_base=seg_lo * w.segment_rows)
+    table._row_base = seg_lo * w.segment_rows
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics,
-                            flags=args.flags, groups_hint=w.plan.groups_hint)
+                            flags=args.flags | (capi.PLAN_NO_PACK if args.no_pack else 0), groups_hint=w.plan.groups_hint)
 
     table.prepare(plan)   # the plan's C structs are built once, like a prepared statement
     # ... and so is the payload projection of its group + metric columns (vh_table_pack): part of the resident mirror,
@@ -156,9 +199,15 @@ def main():
     torch.cuda.synchronize()
     t_pack = time.time() - t_pack
 
+    checked = None
+    if not args.no_check:
+        checked = parity_gate(table, w, plan, my_segments, executor)   # every rank checks its own shard; raises on any difference
+
     def step():
         # copy=False: result arrays alias the library's pinned staging buffer (no second host copy)
-        return distributed.sharded_query(torch, dist, table, plan, world, copy=False)
+        if world == 1:
+            return table.query_agg(plan, copy=False)
+        return distributed.sharded_query(table, plan, comm, root=0, copy=False)
 
     def barrier():
         torch.cuda.synchronize()
@@ -179,7 +228,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -188,6 +237,7 @@ def main():
     value = total_rows / (elapsed / args.steps)
     if rank != 0:
         table.close()
+        comm.close()
         dist.destroy_process_group()
         return
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
@@ -197,7 +247,7 @@ def main():
     fcols = sorted({f[1] for f in w.plan.filter if f[0] in ("rel", "in")})
     fbytes = sum(capi.ELEM_SIZE[w.columns[c].elem] for c in fcols)
     b_min = rows_rank0 * fbytes + last.passed_recs * max(0, w.bytes_per_row_referenced - fbytes)
-    traffic, traffic_src = measured_traffic(args.workload, my_segments * w.segment_rows)
+    traffic, traffic_src, traffic_head = measured_traffic(args.workload, my_segments * w.segment_rows, last.kernel)
     credited = min(algo_bytes, traffic) if traffic else algo_bytes  # never credit more than was moved
     achieved = credited / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
 
@@ -207,24 +257,28 @@ def main():
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong",
+            "parity_checked": bool(checked), "parity": checked,
             "vs_baseline": None, "dtype": "u32 predicates / int64+u32 integer atomics", "data": "synthetic",
             "config": {"workload": "%s: %s" % (w.name if world == 1 else w.name + " sharded (C4)", w.description),
                        "rows": total_rows, "segments": total_segments, "segment_rows": w.segment_rows,
                        "columns": len(w.columns), "table_bytes": total_rows * w.table_bytes_per_row,
                        "groups": last.ngroups, "passed_rows_rank0": last.passed_recs,
-                       "table_path": last.path, "parallelism": "segments sharded x%d, RCCL reduce to rank 0" % world if world > 1 else "1 GPU",
+                       "table_path": last.path, "parallelism": ("segments sharded x%d, vh_query_agg_sharded: plan agreement + ncclReduce of the partial tables to rank 0 (%s transport)"
+                                                                % (world, "RCCL" if backend == "nccl" else "gloo callback")) if world > 1 else "1 GPU",
                        "generate_seconds": round(t_gen, 3), "payload_projection": bool(last.packed),
                        "pack_seconds": round(t_pack, 3), "device_bytes": table.info()[2]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("scan_agg_fast_kernel" if last.fast else "scan_agg_kernel") + (" + part_agg_kernel" if last.path == "dense_part" else ""),
+                         "kernel": last.kernel,
                          "kernel_ms": avg_kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes, "b_min_bytes_per_launch": b_min,
                          "bref_over_t_GBs": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0,
-                         "traffic_source": traffic_src,
-                         "note": "achieved = min(B_ref, B_meas) / mean HIP-event time of scan_agg_kernel on rank 0 "
-                                 "(SURVEY 8d); B_ref = rows x referenced bytes/row; B_meas = rocprofv3 FETCH_SIZE x2 "
-                                 "(gfx950 correction, MI355X_MICROARCH.md) from the committed PMC pass, scaled by rows"},
+                         "traffic_source": traffic_src, "traffic_head": traffic_head,
+                         "note": "achieved = min(B_ref, B_meas) / mean HIP-event time of the scan kernel(s) on rank 0 "
+                                 "(SURVEY 8d: never more than was moved, never more than the algorithm references); B_ref = rows x "
+                                 "referenced bytes/row; B_meas = rocprofv3 FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) from "
+                                 "the committed PMC pass of this kernel, scaled by rows; traffic null = no pass of this kernel committed "
+                                 "(then B_ref is credited)"},
         }
         if world == 1 and not args.no_cpu:
             try:
@@ -239,6 +293,7 @@ def main():
         print(json.dumps(out), flush=True)
     table.close()
     if world > 1:
+        comm.close()
         dist.destroy_process_group()
 
 

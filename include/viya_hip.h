@@ -25,17 +25,21 @@
  * every host buffer it passes in; vh_result / vh_rows objects are library-allocated
  * and must be released with vh_result_free() / vh_rows_free().
  *
- * Threading: calls on one vh_table serialise on a per-table lock; all device work goes
- * to one HIP stream (vh_set_stream), so results of a call are complete when it returns.
+ * Threading ("re-entrant per handle"; the reference runs queries of one table from several read_pool
+ * threads, src/db/database.cc:28-34): every entry point may be called from any thread. A query is PLANNED and LAUNCHED
+ * under a per-table lock (tens of microseconds of host work) and then runs, and is read back, on its own execution
+ * context — a HIP stream, device scratch, pinned staging buffers and events taken from a grow-only pool of the table
+ * (VH_MAX_EXEC, default 16) — so queries of different threads on one table overlap on the device. vh_segment_sync*,
+ * vh_segment_generate, vh_table_pack/unpack take the same lock and first wait for every launched query that may still
+ * read the arenas they replace. With an externally owned stream (vh_set_stream) all contexts share that stream.
  *
- * Lifetime of a vh_result: its device-side state (what vh_result_finalize,
- * vh_result_device_buffers and vh_result_partition[_pairs] read) lives in the table's
- * scratch arena until the NEXT query is launched on that table; its host view
- * (vh_result_view / vh_result_copy) lives in one of the table's two pinned staging
- * buffers until the SECOND-next query is finalised on it. A handle used past either
- * point is refused with VH_E_INVALID ("stale result handle"), never served from reused
- * memory; callers that share a table between threads take their own lock around
- * query + copy (the C++ host shim: Table::mu). A vh_result must not outlive its table.
+ * Lifetime of a vh_result: it OWNS its execution context from vh_query_launch / vh_query_agg until vh_result_free. Its
+ * device-side state (what vh_result_finalize, vh_result_device_buffers and vh_result_partition[_pairs] read) and its host
+ * view (vh_result_view / vh_result_copy) stay valid for exactly that long, whatever other queries run on the table
+ * meanwhile. (Pointers obtained with vh_result_view additionally stay readable after vh_result_free until the
+ * second-next query that happens to take the same context: enough for a single-threaded caller that frees before it
+ * reads, nothing a multi-threaded one should rely on.) A vh_result must not outlive its table. Holding more live
+ * results on one table than the pool may grow to blocks the next launch (and fails after 60 s).
  */
 #ifndef VIYA_HIP_H_
 #define VIYA_HIP_H_
@@ -247,12 +251,15 @@ typedef struct vh_gen_spec {
 
 /* ---- entry points ----------------------------------------------------------*/
 
-/* Bind the calling process to one GPU (one process per GPU). */
+/* Bind the calling process to one GPU. SURVEY 8(b) sketched vh_init(ndev, dev_ids); the deployment unit here is one
+ * PROCESS per GPU (north_star; bench.py and vh_comm_* below follow it), so a process names exactly one device.
+ * The HIP current device is per thread: every entry point re-binds its calling thread to this device. */
 VH_API int vh_init(int device_id);
 /* Run all subsequent work of this process on an externally owned hipStream_t
  * (e.g. torch's current stream, so RCCL collectives issued by the caller are
  * ordered with the kernels). NULL is the legacy default stream; VH_OWN_STREAM
- * restores the library's private non-blocking stream (the default after vh_init). */
+ * restores the library's private non-blocking streams (the default after vh_init:
+ * one for table maintenance, one per execution context). */
 #define VH_OWN_STREAM ((void*)(intptr_t)-1)
 VH_API int vh_set_stream(void* hip_stream);
 VH_API const char* vh_last_error(void);
@@ -266,7 +273,10 @@ VH_API int vh_table_create(const vh_col_desc* cols, int32_t ncols,
                            vh_table** out);
 VH_API void vh_table_destroy(vh_table* t);
 
-/* Copy the first `nrows` rows of segment `seg` into HBM. col_ptrs[c] is the host
+/* Copy the first `nrows` rows of segment `seg` into HBM. (SURVEY 8(b) sketched a `version` argument: change tracking —
+ * per-segment version + dirty row range — is the CALLER's, who knows what upsert touched (viyadb_amd/host/gpu_aggregate.cc:
+ * SyncMirror); the library is told what to copy and stamps the segment itself for its projections.)
+ * col_ptrs[c] is the host
  * address of the segment's column array (&segment->d._i[0] / &segment->m._j[0]
  * in the generated Segment class, src/codegen/db/store.cc:214-356); a NULL entry
  * leaves that column's mirror untouched. Bitset columns are not passed here
@@ -350,6 +360,56 @@ VH_API int vh_segment_sync_ids_device(vh_table* t, uint32_t seg, int32_t col, ui
  * xGMI: SURVEY 8(f)-4, viyadb_amd/host/partial_state.cc). */
 VH_API int vh_device_read(void* dst, const void* device_src, uint64_t bytes);
 
+/* ---- one query over a table sharded across GPUs (north_star: "segments shard naturally one-per-GPU ...
+ * with a final RCCL reduce of per-GPU partial aggregates over xGMI") -------------------------------------------------
+ * One process per GPU; every rank mirrors ITS segments in its own vh_table (same column list everywhere) and all ranks
+ * call vh_query_agg_sharded with the same plan. Replaces the reference's cluster merge — worker queries over HTTP, TSV
+ * text re-upserted into a temporary table on the controller (src/cluster/query/agg_runner.cc:83-140) — inside one node.
+ *
+ *  1. plan agreement: the table organisation must not depend on what one shard happens to hold. Each rank summarises
+ *     what its planner would look at (per group column the min / max of the segments it will scan, rows to scan, the
+ *     selectivity probe's counts, re-plan requests of the previous attempt); the summaries are all-gathered and every
+ *     rank plans from the MERGED summary: same dense digit ranges, same dense-vs-hash decision, same partitioning,
+ *     same state layout on every rank.
+ *  2. every rank scans its shard (the kernels of vh_query_agg).
+ *  3. a 128-byte all-reduce carries error flags and row counters: if ANY rank overflowed a table or met a value outside
+ *     the agreed range, ALL ranks re-plan together and run again — never a mismatched collective.
+ *  4a. dense organisations: the identically indexed partial tables are reduced to `root` in place (ncclReduce per state
+ *     array: SUM / MIN / MAX in the state's own type, unsigned 32/64-bit MIN/MAX included) and root emits the groups
+ *     (HAVING / top-N run there, on merged states).
+ *  4b. hash organisation (sparse keys) and count-distinct: every rank regroups its groups — and, per bitset metric, its
+ *     distinct (group, id) pairs — by owner = mix(key columns) % world (vh_result_partition[_pairs]), one grouped
+ *     ncclSend/ncclRecv exchange moves every column straight into the column arenas of a temporary table on the owner,
+ *     which merges by re-aggregation (SUM of sums and counts, MIN / MAX, set union — the reference's own algebra,
+ *     agg_runner.cc:66-76) with HAVING / top-N applied to the merged groups; the owners' rows are then gathered on root.
+ *
+ * root >= 0: the merged groups are delivered on that rank; the other ranks get a result with no rows. root = -1 (hash
+ * organisation only): results stay sharded, every rank gets the groups it owns. vh_result_info's row counters are
+ * global sums on every rank; ngroups counts all groups of all owners.
+ *
+ * The transport is RCCL (vh_comm_init; the id comes from vh_comm_unique_id on one rank and reaches the others by whatever
+ * means the host has — MPI, a file, torch.distributed's store) or a table of callbacks (vh_comm_init_custom: tests run two
+ * ranks on one GPU over gloo that way; a deployment could put MPI behind it). librccl.so.1 is resolved at run time. */
+typedef struct vh_comm vh_comm;
+#define VH_COMM_ID_BYTES 128
+typedef struct vh_comm_ops {
+  void* ctx;
+  /* every rank contributes `bytes` host bytes; recv = world x bytes, rank-major. Returns 0 or an error code. */
+  int (*allgather_host)(void* ctx, const void* send, void* recv, uint64_t bytes);
+  /* in-place on a device buffer of `count` elements of enum vh_elem `elem`, op = enum vh_reduce_op; root < 0: all-reduce,
+   * else the result need only be valid on root. Enqueued on (or ordered after) `stream`. */
+  int (*reduce_device)(void* ctx, void* buf, uint64_t count, int32_t elem, int32_t op, int32_t root, void* stream);
+  /* all-to-all-v over `ncols` device columns at once: rows [send_off[p], send_off[p+1]) of send[c] (esize[c] bytes each) go
+   * to rank p and land at rows [recv_off[q], ...) of recv[c] on the receiver, q = the sender. Offsets have world + 1 entries. */
+  int (*alltoallv_device)(void* ctx, int32_t ncols, const void* const* send, void* const* recv, const uint32_t* esize,
+                          const uint64_t* send_off, const uint64_t* recv_off, void* stream);
+} vh_comm_ops;
+VH_API int vh_comm_unique_id(void* id_out /* VH_COMM_ID_BYTES */);
+VH_API int vh_comm_init(const void* id, int32_t rank, int32_t world, vh_comm** out);
+VH_API int vh_comm_init_custom(const vh_comm_ops* ops, int32_t rank, int32_t world, vh_comm** out);
+VH_API void vh_comm_destroy(vh_comm* c);
+VH_API int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* comm, int32_t root, vh_result** out);
+
 /* ---- the other two FilterBasedQuery kinds on the same scan ------------
  *
  * search (viya_query_search, src/codegen/query/scan.cc:249-299): the distinct values of one
@@ -388,6 +448,9 @@ VH_API int vh_rows_view(vh_rows* r, const void** cols);
 VH_API void vh_rows_free(vh_rows* r);
 
 VH_API int vh_result_get_info(vh_result* r, vh_result_info* info);
+/* Symbol(s) of the scan kernel(s) this query launched, spelled as rocprofv3 prints them ("scan_agg_fast_kernel<4, 256, 4, 3> +
+ * part_agg_kernel<1024>"): what a profile of the same command must show. Valid until vh_result_free. */
+VH_API const char* vh_result_kernel(vh_result* r);
 /* Copy out: key_cols[i] receives ngroups elements of group column i's element
  * type; state_cols[j] receives ngroups elements of metric j's element type
  * (bitset metrics: uint64 cardinality); hidden_count (may be NULL) receives the

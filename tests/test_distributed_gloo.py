@@ -1,6 +1,7 @@
-"""N>1 path on CPU: two gloo ranks shard a table's segments, build dense partial aggregate tables
-(oracle-side, numpy), reduce them with the product's reduction glue and must reproduce the
-single-process result bit for bit (integer wrap-around included)."""
+"""N>1 on CPU (no GPU here): segment sharding, and the callback transport the two-ranks-on-one-GPU tests run the sharded
+protocol over — two gloo ranks reduce dense partial tables (built oracle-side) and exchange ragged columns through exactly
+the functions vh_comm_init_custom is given; the merged tables must reproduce the single-process result bit for bit
+(integer wrap-around and unsigned MIN / MAX included)."""
 import os
 import socket
 import subprocess
@@ -24,7 +25,7 @@ def test_shard_segments_partition():
 
 
 WORKER = textwrap.dedent('''
-    import os, sys
+    import os, sys, ctypes as C
     sys.path.insert(0, {root!r})
     import numpy as np, torch, torch.distributed as dist
     from viyadb_amd import capi, distributed, synth
@@ -32,27 +33,42 @@ WORKER = textwrap.dedent('''
     from oracle import viya_oracle as vo
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
+    tr = distributed.GlooTransport(dist)          # host pointers stand in for device pointers on this box
     w = synth.c3(segment_rows=20000)
-    total = 7
-    lo, hi = distributed.shard_segments(total, rank, world)
-    # this rank's shard, same global row ids as the unsharded table
-    ot = build_oracle_table(w, hi - lo, 20000, row_base=lo * 20000)
+    lo, hi = distributed.shard_segments(7, rank, world)
+    ot = build_oracle_table(w, hi - lo, 20000, row_base=lo * 20000)      # this rank's shard, same global row ids as the unsharded table
     st = vo.scan_aggregate(vo.parse_query(ot, w.query))
     G = 1000 * 100
     gid = st.keys[0].astype(np.int64) * 100 + st.keys[1].astype(np.int64)
     present = np.zeros(G, dtype=np.uint8); present[gid] = 1
     s0 = np.zeros(G, dtype=np.uint64); s0[gid] = st.states[0].astype(np.int64).view(np.uint64) + np.uint64(2**63 + 12345)  # force wrap-around
     s1 = np.zeros(G, dtype=np.uint32); s1[gid] = st.states[1] + np.uint32(4294960000)
-    distributed.reduce_host_partials(torch, dist, [(present, capi.U8, distributed.RED_MAX), (s0, capi.U64, distributed.RED_SUM),
-                                                   (s1, capi.U32, distributed.RED_SUM)])
-    if rank == 0:
-        np.savez({out!r}, present=present, s0=s0, s1=s1)
+    umin = np.full(G, 2**32 - 1, dtype=np.uint32); umin[gid] = (st.states[1].astype(np.uint64) * 1500000000 % (2**32)).astype(np.uint32)   # values on both sides of 2^31
+    lmax = np.zeros(G, dtype=np.uint64); lmax[gid] = st.states[0].astype(np.int64).view(np.uint64) * np.uint64(2**40 + 7)
+    for arr, elem, op in ((present, capi.U8, distributed.RED_MAX), (s0, capi.U64, distributed.RED_SUM), (s1, capi.U32, distributed.RED_SUM),
+                          (umin, capi.U32, distributed.RED_MIN), (lmax, capi.U64, distributed.RED_MAX)):
+        assert tr.ops.reduce_device(None, arr.ctypes.data, len(arr), elem, op, 0, None) == 0, tr.errors
+    # all-gather of a small POD, and a ragged two-column exchange: rank r sends r + 1 + p rows to rank p
+    mine = np.array([rank, 10 + rank, 20 + rank], dtype=np.uint64)
+    everyone = np.zeros(3 * world, dtype=np.uint64)
+    assert tr.ops.allgather_host(None, mine.ctypes.data, everyone.ctypes.data, mine.nbytes) == 0, tr.errors
+    send_counts = [rank + 1 + p for p in range(world)]
+    recv_counts = [q + 1 + rank for q in range(world)]
+    so = np.concatenate([[0], np.cumsum(send_counts)]).astype(np.uint64)
+    ro = np.concatenate([[0], np.cumsum(recv_counts)]).astype(np.uint64)
+    c0 = (np.arange(so[-1], dtype=np.uint32) + 1000 * rank)
+    c1 = (np.arange(so[-1], dtype=np.uint64) * 3 + 7 * rank)
+    r0 = np.zeros(int(ro[-1]), dtype=np.uint32); r1 = np.zeros(int(ro[-1]), dtype=np.uint64)
+    sp = (C.c_void_p * 2)(c0.ctypes.data, c1.ctypes.data); rp = (C.c_void_p * 2)(r0.ctypes.data, r1.ctypes.data)
+    es = (C.c_uint32 * 2)(4, 8)
+    assert tr.ops.alltoallv_device(None, 2, sp, rp, es, so.ctypes.data_as(C.POINTER(C.c_uint64)), ro.ctypes.data_as(C.POINTER(C.c_uint64)), None) == 0, tr.errors
+    np.savez({out!r} + ".%d.npz" % rank, present=present, s0=s0, s1=s1, umin=umin, lmax=lmax, everyone=everyone, r0=r0, r1=r1)
     dist.destroy_process_group()
 ''')
 
 
-def test_two_rank_reduce_matches_single_process(tmp_path):
-    out = str(tmp_path / "reduced.npz")
+def test_two_rank_transport_matches_single_process(tmp_path):
+    out = str(tmp_path / "reduced")
     script = tmp_path / "worker.py"
     script.write_text(WORKER.format(root=ROOT, out=out))
     s = socket.socket()
@@ -63,7 +79,7 @@ def test_two_rank_reduce_matches_single_process(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    got = np.load(out)
+    got, other = np.load(out + ".0.npz"), np.load(out + ".1.npz")
     # single-process reference: whole table, each rank's offset counted once per rank that had the group
     from oracle import viya_oracle as vo
     from tests.parity import build_oracle_table
@@ -73,6 +89,8 @@ def test_two_rank_reduce_matches_single_process(tmp_path):
     want_p = np.zeros(G, dtype=np.uint8)
     want0 = np.zeros(G, dtype=np.uint64)
     want1 = np.zeros(G, dtype=np.uint32)
+    want_umin = np.full(G, 2 ** 32 - 1, dtype=np.uint32)
+    want_lmax = np.zeros(G, dtype=np.uint64)
     with np.errstate(over="ignore"):
         for rank in range(2):
             lo, hi = distributed.shard_segments(7, rank, 2)
@@ -82,11 +100,26 @@ def test_two_rank_reduce_matches_single_process(tmp_path):
             want_p[gid] = 1
             want0[gid] += st.states[0].astype(np.int64).view(np.uint64) + np.uint64(2 ** 63 + 12345)
             want1[gid] += st.states[1] + np.uint32(4294960000)
+            want_umin[gid] = np.minimum(want_umin[gid], (st.states[1].astype(np.uint64) * 1500000000 % (2 ** 32)).astype(np.uint32))
+            want_lmax[gid] = np.maximum(want_lmax[gid], st.states[0].astype(np.int64).view(np.uint64) * np.uint64(2 ** 40 + 7))
     assert np.array_equal(got["present"], want_p)
     assert np.array_equal(got["s0"], want0)
     assert np.array_equal(got["s1"], want1)
+    assert np.array_equal(got["umin"], want_umin) and (want_umin[want_p == 1] > 2 ** 31).any() and (want_umin[want_p == 1] < 2 ** 31).any()
+    assert np.array_equal(got["lmax"], want_lmax)
     # and the merged table equals the unsharded aggregate (without the artificial offsets)
     ot = build_oracle_table(w, 7, 20000)
     st = vo.scan_aggregate(vo.parse_query(ot, w.query))
     gid = st.keys[0].astype(np.int64) * 100 + st.keys[1].astype(np.int64)
     assert np.array_equal(np.nonzero(want_p)[0], np.sort(gid))
+    # transport: all-gather is rank-major; the ragged exchange delivers sender q's block for me, in rank order
+    assert np.array_equal(got["everyone"], np.array([0, 10, 20, 1, 11, 21], dtype=np.uint64))
+    for me, g in enumerate((got, other)):
+        exp0, exp1 = [], []
+        for q in range(2):
+            counts = [q + 1 + p for p in range(2)]
+            start = sum(counts[:me])
+            idx = np.arange(start, start + counts[me])
+            exp0.append(idx.astype(np.uint32) + 1000 * q)
+            exp1.append(idx.astype(np.uint64) * 3 + 7 * q)
+        assert np.array_equal(g["r0"], np.concatenate(exp0)) and np.array_equal(g["r1"], np.concatenate(exp1))

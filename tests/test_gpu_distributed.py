@@ -1,6 +1,6 @@
-"""The N>1 flow on real device memory: two ranks (both on cuda:0, gloo backend, because this box has one
-GPU) each mirror half of the segments, run vh_query_launch, reduce the library-owned dense partial tables
-in place through zero-copy views, and rank 0 finalises. Must equal the oracle on the whole table."""
+"""vh_query_agg_sharded on real device memory. This box has one GPU, so: two ranks share cuda:0 and talk through the callback
+transport over gloo (every line of the sharded protocol except the RCCL calls themselves), and one rank goes through RCCL
+proper (world 1 with the protocol forced on). Every scenario must equal the oracle on the union of the ranks' rows."""
 import os
 import socket
 import subprocess
@@ -14,107 +14,162 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 WORKER = textwrap.dedent('''
-    import os, sys
+    import os, sys, json
     sys.path.insert(0, {root!r})
     import numpy as np, torch, torch.distributed as dist
-    from viyadb_amd import distributed, executor, synth
+    from viyadb_amd import capi, distributed, executor, synth
     torch.cuda.set_device(0)
-    dist.init_process_group({backend!r}, **({{"device_id": torch.device("cuda", 0)}} if {backend!r} == "nccl" else {{}}))
+    dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    executor.init(0, stream=torch.cuda.current_stream().cuda_stream)
-    w = synth.WORKLOADS[{wl!r}](segment_rows=50000)
-    total = 9
-    lo, hi = distributed.shard_segments(total, rank, world)
-    t = synth.create_device_table(w, hi - lo, 50000, row_base=lo * 50000)
-    nk = len(w.plan.groups)
-    having = [("rel", nk + len(w.plan.metrics) - 1, 4, 1)] if {having} else []    # last metric (a count) > 1, on MERGED groups
-    plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags={flags}, having=having)
+    executor.init(0)
+    comm = distributed.Comm.rccl(dist) if {backend!r} == "rccl" else distributed.Comm.gloo(dist)
+    spec = {spec!r}
+    root = spec.get("root", 0)
+    if spec["kind"] == "synth":
+        w = synth.WORKLOADS[spec["wl"]](segment_rows=50000)
+        lo, hi = distributed.shard_segments(9, rank, world)
+        t = synth.create_device_table(w, hi - lo, 50000, row_base=lo * 50000)
+        nk = len(w.plan.groups)
+        having = [("rel", nk + len(w.plan.metrics) - 1, 4, 1)] if spec.get("having") else []    # last metric (a count) > 1, on MERGED groups
+        plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=spec.get("flags", 0), having=having)
+    else:
+        from oracle import viya_oracle as vo
+        from tests import shard_scenarios
+        from tests.planner import mirror_table, plan_from_query
+        tab, q, flags, hint = shard_scenarios.build(spec["name"], [rank], world)
+        t = mirror_table(tab)
+        plan = plan_from_query(tab, vo.parse_query(tab, q), now=1496570140, flags=flags | spec.get("flags", 0), groups_hint=hint)
     for _ in range(2):
-        res = distributed.sharded_query(torch, dist, t, plan, world, force_collectives=True)
+        res = distributed.sharded_query(t, plan, comm, root=root)
     torch.cuda.synchronize()
-    assert (res is None) == (rank != 0)
-    if rank == 0:
-        np.savez({out!r}, *(res.keys + res.states), ngroups=res.ngroups, nk=len(res.keys), returned=res.returned)
+    if root >= 0:
+        assert (res.returned == 0) == (rank != root or res.ngroups == 0), (rank, res.returned)
+    np.savez({out!r} + ".%d.npz" % rank, *(res.keys + res.states), ngroups=res.ngroups, nk=len(res.keys), returned=res.returned, path=res.path,
+             scanned=res.scanned_recs, passed=res.passed_recs, retries=res.retries,
+             calls=json.dumps(comm.transport.calls if comm.transport else {{}}))
     dist.barrier()
     t.close()
+    comm.close()
     dist.destroy_process_group()
 ''')
 
 
-def test_one_rank_rccl(tmp_path):
-    """The same flow through the nccl (= RCCL) backend with a single rank: dtype views, in-place reduce on the
-    library's buffers and the all-to-all of the hash path go through RCCL itself (this box has one GPU)."""
-    for wl, flags in (("C3", 0), ("C5t", 0), ("C5", 0)):
-        _run(tmp_path, wl, flags, "nccl", 1)
-
-
-@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 64), ("C2", 0), ("C2", 2), ("C1", 0), ("C3", 1), ("C5t", 0), ("C5", 0),
-                                      ("C5t", 2048), ("C5", 2048), ("C3", 1 | 2048)])      # 2048: the hash table as records
-def test_two_ranks_one_gpu(tmp_path, wl, flags):
-    _run(tmp_path, wl, flags, "gloo", 2)
-
-
-@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 1), ("C5t", 0)])
-def test_two_ranks_having_on_merged_groups(tmp_path, wl, flags):
-    _run(tmp_path, wl, flags, "gloo", 2, having=True)
-
-
-def _run(tmp_path, wl, flags, backend, nproc, having=False):
-    out = str(tmp_path / "res.npz")
+def _launch(tmp_path, spec, backend, nproc, env=None):
+    out = str(tmp_path / "res")
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT, out=out, wl=wl, flags=flags, backend=backend, having=having))
+    script.write_text(WORKER.format(root=ROOT, out=out, spec=spec, backend=backend))
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr",
-                        "127.0.0.1", "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=600)
+                        "127.0.0.1", "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    got = np.load(out)
-    from oracle import viya_oracle as vo
-    from tests.parity import build_oracle_table, sort_rows
-    from viyadb_amd import synth
-    w = synth.WORKLOADS[wl](segment_rows=50000)
-    st = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 9, 50000), w.query), now=getattr(w, "now", None))
+    return [np.load(out + ".%d.npz" % k) for k in range(nproc)]
+
+
+def _rows(got):
     nk = int(got["nk"])
-    arrs = [got["arr_%d" % i] for i in range(nk + len(st.states))]
-    keys, states = arrs[:nk], arrs[nk:]
-    assert int(got["ngroups"]) == st.ngroups
-    if having:
-        keep = st.states[-1] > 1
-        st.keys = [k[keep] for k in st.keys]
-        st.states = [x[keep] for x in st.states]
-        assert int(got["returned"]) == int(keep.sum())
+    arrs = [got["arr_%d" % i] for i in range(len([k for k in got.files if k.startswith("arr_")]))]
+    return arrs[:nk], arrs[nk:]
+
+
+def _check(gots, st, root=0, having_keep=None):
+    from tests.parity import sort_rows
+    if having_keep is not None:
+        st.keys = [k[having_keep] for k in st.keys]
+        st.states = [x[having_keep] for x in st.states]
+    if root >= 0:
+        keys, states = _rows(gots[root])
+        for k, g in enumerate(gots):
+            if k != root:
+                assert int(g["returned"]) == 0
+    else:                                             # results left with their owners: the union must be the answer, owners disjoint
+        parts = [_rows(g) for g in gots]
+        keys = [np.concatenate([p[0][i] for p in parts]) for i in range(len(parts[0][0]))]
+        states = [np.concatenate([p[1][j] for p in parts]) for j in range(len(parts[0][1]))]
+        assert all(int(g["returned"]) > 0 for g in gots)
+    assert len(states[0]) == len(st.states[0]), (len(states[0]), len(st.states[0]))
     pg, po = sort_rows(keys, states), sort_rows(st.keys, st.states)
     for a, b in zip(keys + states, st.keys + st.states):
-        assert np.array_equal(a[pg], b[po])
+        if a.dtype.kind == "f":
+            np.testing.assert_allclose(a[pg], b[po], rtol=1e-9)
+        else:
+            assert np.array_equal(a[pg], b[po].astype(a.dtype))
+    for g in gots:                                    # counters are global on every rank
+        assert int(g["scanned"]) == st.scanned_recs and int(g["passed"]) == st.passed_recs
 
 
-def test_dense_partials_are_one_collective_for_c3():
-    """C3/C4: SUM(int64) + COUNT carried as SOP_ADD32P, both 64-bit integer sums laid out back to back -> the
-    library hands the caller ONE reduce buffer (no presence bytes, no second call): the collective is latency-bound."""
-    from viyadb_amd import capi, executor, synth
-    executor.init(0)
-    w = synth.WORKLOADS["C3"](segment_rows=50000)
-    t = synth.create_device_table(w, 4, 50000)
-    try:
-        plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics)
-        res = t.query_launch(plan)
-        bufs = t.device_buffers(res)
-        assert len(bufs) == 1 and bufs[0][2] == capi.U64 and bufs[0][3] == 0 and bufs[0][1] >= 2 * 100_000
-        out = t.finalize(res, plan)
-        assert out.ngroups > 0
-        # without the presence carrier the layout is [presence | states...]: still correct, more buffers
-        res = t.query_launch(executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=capi.PLAN_NO_CARRIER))
-        assert len(t.device_buffers(res)) >= 2
-        t.discard(res)
-    finally:
-        t.close()
+def _synth_oracle(wl):
+    from oracle import viya_oracle as vo
+    from tests.parity import build_oracle_table
+    from viyadb_amd import synth
+    w = synth.WORKLOADS[wl](segment_rows=50000)
+    return vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 9, 50000), w.query), now=getattr(w, "now", None))
+
+
+@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 64), ("C2", 0), ("C2", 2), ("C1", 0), ("C3", 1), ("C5t", 0), ("C5", 0),
+                                      ("C5t", 2048), ("C5", 2048), ("C3", 1 | 2048), ("C3", 16 | 32)])      # 2048: the hash table as records
+def test_two_ranks_one_gpu(tmp_path, wl, flags):
+    gots = _launch(tmp_path, {"kind": "synth", "wl": wl, "flags": flags}, "gloo", 2)
+    st = _synth_oracle(wl)
+    assert int(gots[0]["ngroups"]) == st.ngroups
+    _check(gots, st)
+
+
+def test_one_rank_through_rccl(tmp_path):
+    """The whole protocol through RCCL itself — ncclAllGather, ncclAllReduce, ncclReduce with the states' own types, grouped
+    ncclSend / ncclRecv — with the single rank this box allows."""
+    for wl in ("C3", "C5t", "C5", "C2"):
+        gots = _launch(tmp_path, {"kind": "synth", "wl": wl}, "rccl", 1, env={"VH_TEST_SHARDED_WORLD1": "1"})
+        _check(gots, _synth_oracle(wl))
+
+
+@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 1), ("C5t", 0), ("C5", 0)])
+def test_two_ranks_having_on_merged_groups(tmp_path, wl, flags):
+    gots = _launch(tmp_path, {"kind": "synth", "wl": wl, "flags": flags, "having": True}, "gloo", 2)
+    st = _synth_oracle(wl)
+    assert int(gots[0]["ngroups"]) == st.ngroups
+    _check(gots, st, having_keep=st.states[-1] > 1)
+
+
+@pytest.mark.parametrize("wl", ["C5t", "C5", "C3"])
+def test_sparse_results_stay_with_their_owners(tmp_path, wl):
+    gots = _launch(tmp_path, {"kind": "synth", "wl": wl, "flags": 1, "root": -1}, "gloo", 2)
+    st = _synth_oracle(wl)
+    assert all(int(g["ngroups"]) == st.ngroups for g in gots)
+    _check(gots, st, root=-1)
+
+
+def _scenario_oracle(name):
+    from oracle import viya_oracle as vo
+    from tests import shard_scenarios
+    tab, q, _, _ = shard_scenarios.build(name, [0, 1])
+    return vo.scan_aggregate(vo.parse_query(tab, q), now=1496570140)
+
+
+@pytest.mark.parametrize("name,flags,path", [("disjoint_ranges", 0, None), ("disjoint_ranges", 64, "dense_part"), ("disjoint_ranges", 2, "dense_global"),
+                                             ("part_vs_global", 0, None), ("part_vs_global", 8, None), ("one_rank_overflows", 0, "hash"),
+                                             ("empty_shard", 0, None), ("empty_shard", 1, "hash"), ("uniform", 16 | 32, None)])
+def test_ranks_that_see_different_data_agree_on_one_plan(tmp_path, name, flags, path):
+    """Shards whose group columns span disjoint ranges, whose filters pass 100 % vs 1 % of the rows, of which one overflows
+    its hash table or holds no rows at all: left to themselves the ranks would plan different dense ranges and different
+    organisations (silently wrong sums, or mismatched collectives). Unsigned MIN / MAX metrics ride along."""
+    gots = _launch(tmp_path, {"kind": "scenario", "name": name, "flags": flags}, "gloo", 2)
+    st = _scenario_oracle(name)
+    assert int(gots[0]["ngroups"]) == st.ngroups
+    _check(gots, st)
+    assert str(gots[0]["path"]) == str(gots[1]["path"])
+    if path:
+        assert str(gots[0]["path"]) == path
+    if name == "one_rank_overflows":
+        assert int(gots[0]["retries"]) >= 1 and int(gots[1]["retries"]) == int(gots[0]["retries"])   # one rank's overflow re-plans both
 
 
 def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
-    """bench.py's N>1 path end to end (sharding, collective, barrier + max-over-ranks timing, one JSON line from
-    rank 0), with two gloo ranks sharing this box's single GPU (VH_BENCH_BACKEND=gloo); the real run uses RCCL."""
+    """bench.py's N>1 path end to end (sharding, vh_query_agg_sharded, barrier + max-over-ranks timing, one JSON line from
+    rank 0), with two ranks sharing this box's single GPU over the callback transport (VH_BENCH_BACKEND=gloo); the real run uses RCCL."""
     import json
     s = socket.socket()
     s.bind(("127.0.0.1", 0))

@@ -1,6 +1,6 @@
 """SURVEY 8(b) threading row: the reference enters the aggregate function from several read_pool threads while one writer
-appends (src/db/database.cc:28-34). The library serialises per table handle; different tables run concurrently on the
-shared stream. Threads hammer their own tables and one shared table (ctypes drops the GIL inside the calls) while a writer
+appends (src/db/database.cc:28-34). The library plans and launches under a per-table lock and runs every query on its own
+execution context (stream + scratch + staging), so queries of one table overlap on the device. Threads hammer their own tables and one shared table (ctypes drops the GIL inside the calls) while a writer
 keeps syncing new segments into the shared one; every answer must equal the single-threaded answer for the snapshot used."""
 import threading
 
@@ -95,3 +95,45 @@ def test_concurrent_queries_and_a_writer():
         for t, _ in own:
             t.close()
         shared.close()
+
+
+def test_queries_of_one_table_overlap():
+    """Two threads on ONE table finish 2 x N queries sooner than one thread finishes 2N: planning is serialised per table,
+    but a launched query waits for the device and reads its groups back outside the lock, on its own context."""
+    import time
+    from viyadb_amd import capi, executor, synth
+    from viyadb_amd.executor import AggPlan
+    executor.init(0)
+    w = synth.c2()
+    t = synth.create_device_table(w, 16)                     # 16 M rows: ~0.1 ms of kernel under ~0.2 ms of launch / emission / read-back latency
+    try:
+        plans = [t.prepare(AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics)) for _ in range(2)]
+        want = t.query_agg(plans[0])
+        n = 400
+
+        def loop(plan, count, out):
+            for _ in range(count):
+                r = t.query_agg(plan)
+                if r.ngroups != want.ngroups or int(r.states[0].sum()) != int(want.states[0].sum()):
+                    out.append("mismatch")
+
+        for _ in range(50):
+            t.query_agg(plans[0])
+        best_serial, best_par = 1e9, 1e9
+        for _ in range(3):
+            errs = []
+            t0 = time.perf_counter()
+            loop(plans[0], 2 * n, errs)
+            best_serial = min(best_serial, time.perf_counter() - t0)
+            ths = [threading.Thread(target=loop, args=(plans[i], n, errs)) for i in range(2)]
+            t0 = time.perf_counter()
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            best_par = min(best_par, time.perf_counter() - t0)
+            assert not errs
+        print("serial %.1f ms, two threads %.1f ms" % (best_serial * 1e3, best_par * 1e3))
+        assert best_par < 0.9 * best_serial, (best_serial, best_par)
+    finally:
+        t.close()

@@ -1,0 +1,109 @@
+"""The drop-in boundary, proven by a compiler: tools/gen_shim_tu.py emits — per table and query, the way
+AggQueryGenerator::GenerateCode does (src/codegen/query/agg_query.cc:26-71) — the translation unit that stands where the
+reference's JIT-compiled function stands: extern "C" viya_query_agg with the exact query::AggQueryFn signature
+(src/query/runner.h:33-35) and the generated per-table `Segment` class (src/codegen/db/store.cc:203-356). Here the text is
+checked with `g++ -std=c++17 -fsyntax-only` against the reference's REAL headers — db/table.h, db/dictionary.h, db/store.h,
+db/segment.h, query/output.h, query/stats.h — plus a forward declaration standing for <nlohmann/json_fwd.hpp> (the JSON
+submodule is not in the mount). Skipped where /root/reference does not exist (the GPU box)."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/src"
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+needs_ref = pytest.mark.skipif(not os.path.isdir(REF), reason="the reference tree is only present in the build container")
+
+TABLES = {
+    "inapp": {"name": "events", "dimensions": [{"name": "country"}, {"name": "event_name", "cardinality": 200}, {"name": "install_time", "type": "time"},
+                                                {"name": "is_organic", "type": "boolean"}],
+              "metrics": [{"name": "count", "type": "count"}, {"name": "revenue", "type": "double_sum"}]},
+    "numeric": {"name": "nums", "segment_size": 5000,
+                "dimensions": [{"name": "b", "type": "byte"}, {"name": "f", "type": "float"}, {"name": "d", "type": "double"}, {"name": "ul", "type": "ulong"},
+                               {"name": "ts", "type": "microtime"}, {"name": "wide", "cardinality": 100000000000}],
+                "metrics": [{"name": "count", "type": "count", "max": 100000000000}, {"name": "mx", "type": "short_max"}, {"name": "mn", "type": "ulong_min"},
+                            {"name": "s", "type": "float_sum"}]},
+    "avg_only": {"name": "avgs", "dimensions": [{"name": "country"}], "metrics": [{"name": "avg_revenue", "type": "double_avg"}]},   # hidden _count array
+}
+QUERIES = {
+    "inapp": {"type": "aggregate", "table": "events", "dimensions": ["event_name", "country"], "metrics": ["revenue", "count"],
+              "filter": {"op": "eq", "column": "country", "value": "US"},
+              "having": {"op": "and", "filters": [{"op": "gt", "column": "revenue", "value": "1"}, {"op": "ge", "column": "count", "value": "2"}]}},
+    "numeric": {"type": "aggregate", "table": "nums", "dimensions": ["b", "f", "d"], "metrics": ["count", "mx"], "filter": {"op": "gt", "column": "count", "value": "0"}},
+    "avg_only": {"type": "aggregate", "table": "avgs", "dimensions": ["country"], "metrics": ["avg_revenue"], "filter": {"op": "ge", "column": "avg_revenue", "value": "1"}},
+}
+
+
+def _syntax_check(text, tmp_path, name):
+    src = tmp_path / (name + ".cc")
+    src.write_text(text)
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + REF, "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "tools", "shim_include"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[:4000]
+
+
+@needs_ref
+@pytest.mark.parametrize("name", sorted(TABLES))
+def test_generated_shim_compiles_against_the_reference_headers(tmp_path, name):
+    import gen_shim_tu
+    _syntax_check(gen_shim_tu.emit(TABLES[name], QUERIES[name]), tmp_path, name)
+
+
+@needs_ref
+def test_signature_is_the_one_the_reference_emits():
+    """The declaration text of the swap point, character for character (modulo whitespace): agg_query.cc:35-44."""
+    import gen_shim_tu
+    ref = open(os.path.join(REF, "codegen/query/agg_query.cc")).read()
+    pieces = re.findall(r'code << ((?:"(?:[^"\\]|\\.)*"\s*)+);', ref)
+    emitted = ["".join(re.findall(r'"((?:[^"\\]|\\.)*)"', p)).replace('\\"', '"').replace("\\n", "\n") for p in pieces]
+    sigs = [e for e in emitted if "viya_query_agg" in e]
+    assert len(sigs) == 2
+    text = gen_shim_tu.emit(TABLES["inapp"], QUERIES["inapp"])
+    norm = lambda s: re.sub(r"\s+", "", s)
+    for s in sigs:
+        assert norm(s) in norm(text), s
+    # and the function type it is called through (runner.h:33-35) has the same parameter list
+    runner = open(os.path.join(REF, "query/runner.h")).read()
+    m = re.search(r"using AggQueryFn = void \(\*\)\(([^;]*)\);", runner, re.S)
+    params = [norm(x) for x in m.group(1).split(",")]
+    assert params == ["db::Table&", "RowOutput&", "QueryStats&", "std::vector<db::AnyNum>", "size_t", "size_t", "std::vector<db::AnyNum>"]
+
+
+@needs_ref
+def test_every_reference_test_table_gets_a_compilable_shim(tmp_path):
+    """The tables and aggregate queries of the reference's own known-answer tests (tests/golden/reference_cases.json),
+    bitset tables aside (util/bitset.h needs CRoaring, which the mount does not carry)."""
+    import gen_shim_tu
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_cases.json")))
+    tables = cases["tables"] if isinstance(cases, dict) and "tables" in cases else {}
+    done = 0
+    seen = set()
+    for case in (cases["cases"] if isinstance(cases, dict) else cases):
+        q = case.get("query") or {}
+        t = case.get("table") if isinstance(case.get("table"), dict) else tables.get(case.get("table") or q.get("table"))
+        if not isinstance(t, dict) or q.get("type") != "aggregate" or any(m.get("type") == "bitset" for m in t.get("metrics", [])):
+            continue
+        key = json.dumps([t, q], sort_keys=True)
+        if key in seen:
+            continue
+        seen.add(key)
+        _syntax_check(gen_shim_tu.emit(t, q), tmp_path, "case%d" % done)
+        done += 1
+        if done >= 12:
+            break
+    assert done >= 5, done
+
+
+def test_shim_header_is_plain_cxx_without_reference_types():
+    """include/viya_shim.h must compile on its own (no reference header, no HIP): it is included by generated code."""
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", os.path.join(ROOT, "include", "viya_shim.h")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    lib = os.path.join(ROOT, "viyadb_amd", "libviya_host.so")
+    syms = subprocess.run(["nm", "-DC", lib], capture_output=True, text=True).stdout
+    for fn in ("viya::shim::Open(", "viya::shim::Sync(", "viya::shim::Touch(", "viya::shim::BindDict(", "viya::shim::Run(", "viya::shim::Close("):
+        assert fn in syms, fn

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libviya_hip.so")
+LIB_PATH = os.environ.get("VIYA_HIP_LIB") or os.path.join(_HERE, "libviya_hip.so")   # VIYA_HIP_LIB: a measurement build (tools/build_variant.py)
 
 # enum vh_elem
 U8, U16, U32, U64, I8, I16, I32, I64, F32, F64, BITSET32, BITSET64 = range(12)
@@ -102,6 +102,18 @@ class GenSpec(C.Structure):
                 ("scale", C.c_double)]
 
 
+class CommOps(C.Structure):
+    """vh_comm_ops: a transport as a table of callbacks (tests: gloo; see viyadb_amd/distributed.py)."""
+    ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+    REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p)
+    ALLTOALLV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
+                            C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p)
+    _fields_ = [("ctx", C.c_void_p), ("allgather_host", ALLGATHER), ("reduce_device", REDUCE), ("alltoallv_device", ALLTOALLV)]
+
+
+COMM_ID_BYTES = 128
+
+
 class VhError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"viya_hip error {code}: {msg}")
@@ -134,11 +146,17 @@ SYMBOLS = {
     "vh_result_partition": (C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(DeviceBuffer), C.c_int32, C.POINTER(C.c_int32)]),
     "vh_result_partition_pairs": (C.c_int, [_VP, C.c_int32, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(DeviceBuffer), C.c_int32, C.POINTER(C.c_int32)]),
     "vh_segment_sync_ids_device": (C.c_int, [_VP, C.c_uint32, C.c_int32, C.c_uint64, _VP]),
+    "vh_comm_unique_id": (C.c_int, [_VP]),
+    "vh_comm_init": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(_VP)]),
+    "vh_comm_init_custom": (C.c_int, [C.POINTER(CommOps), C.c_int32, C.c_int32, C.POINTER(_VP)]),
+    "vh_comm_destroy": (None, [_VP]),
+    "vh_query_agg_sharded": (C.c_int, [_VP, C.POINTER(Plan), _VP, C.c_int32, C.POINTER(_VP)]),
     "vh_query_select": (C.c_int, [_VP, C.POINTER(SelectPlan), C.POINTER(_VP)]),
     "vh_rows_get_info": (C.c_int, [_VP, C.POINTER(RowsInfo)]),
     "vh_rows_view": (C.c_int, [_VP, C.POINTER(_VP)]),
     "vh_rows_free": (None, [_VP]),
     "vh_result_get_info": (C.c_int, [_VP, C.POINTER(ResultInfo)]),
+    "vh_result_kernel": (C.c_char_p, [_VP]),
     "vh_result_copy": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_uint64)]),
     "vh_result_view": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.POINTER(C.c_uint64))]),
     "vh_result_free": (None, [_VP]),

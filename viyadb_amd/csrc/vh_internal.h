@@ -17,7 +17,9 @@
 #define VH_KEY_WORDS 8    // widest group key: 8 x u64
 #define VH_MAX_BITSET 2   // bitset (count-distinct) metrics per query
 #define VH_MAX_PRED 4     // fast path: distinct 4-byte predicate columns held in registers
+#ifndef VH_FAST_COLS
 #define VH_FAST_COLS 4    // fast path: group / metric columns gathered up front
+#endif
 #define VH_MAX_PART 64     // DENSE_PART: partitions (lane p of a wave keeps partition p's state, so at most one per lane)
 #define VH_EXT_CHUNK 8    // DENSE_PART: extents a wave reserves per global allocation
 
@@ -145,7 +147,7 @@ struct VhPlanDev {
   uint32_t* htags;           // wide keys: slot state words
   uint64_t hmask;            // capacity - 1
   uint32_t max_probe;
-  uint32_t debug;            // experiment knobs (env VH_DEBUG), 0 in production
+  uint32_t pad_probe;
   // single-word keys: key and metric states of a slot are ONE record of hrec_bytes (key at +0, m[j].state = table + the
   // state's offset inside the record), so an insert and its updates touch one line; 0 = separate arrays (wide keys)
   uint32_t hrec_bytes;
@@ -166,12 +168,8 @@ struct VhPlanDev {
   int32_t npart;             // <= VH_MAX_PART
   int32_t part_shift;        // groups per partition = 1 << part_shift
   int32_t tw;                // 64-bit words per tuple (word 0 low half = gid)
-  int32_t stage_cap;         // tuples per (wave, partition) LDS staging buffer = one flush
-  int32_t ext_flushes;       // flushes per extent (extent = ext_flushes x stage_cap tuples, <= 4096)
-  int32_t ext_tuples;        // tuples per extent; stage_cap == 0: tuples are scattered straight into the extent
-  int32_t part_tile;         // lanes form of phase 1: row slots per wave tile (counting sort by partition in LDS), 0 = staged form
-  int32_t pad_part;
-  uint64_t* tuples;          // max_extents x ext_flushes x stage_cap x tw words
+  int32_t ext_tuples;        // tuples per extent (a tile's run of one partition never straddles extents)
+  uint64_t* tuples;          // max_extents x ext_tuples x tw words
   uint32_t* part_count;      // [npart] extents recorded per partition
   uint32_t* part_extents;    // [npart][part_cap] extent ids
   uint16_t* extent_missing;  // [max_extents] tuples NOT filled in an extent (0 = full)

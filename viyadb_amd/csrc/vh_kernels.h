@@ -257,6 +257,25 @@ __device__ __forceinline__ uint64_t vh_load_bits(const char* base, int type, uin
   }
 }
 
+// Type-agnostic half of a gather: the naturally aligned 8-byte word that holds the element (arenas and projections are
+// padded, so the word is always inside the allocation) and the bit offset of the element inside it.
+__device__ __forceinline__ uint64_t vh_gather_raw(const VhPlanDev& P, uint32_t slot, uint32_t seg, uint32_t row, uint32_t& shift) {
+  const uint64_t a = reinterpret_cast<uint64_t>(P.colbase[slot]) + (uint64_t)seg * P.colstride[slot] + (uint64_t)row * P.colpitch[slot];
+  shift = ((uint32_t)a & 7u) * 8u;
+  return *reinterpret_cast<const uint64_t*>(a & ~7ull);
+}
+// ... and the typed half: width and extension of the element sitting in the low bits of `v`.
+__device__ __forceinline__ uint64_t vh_decode_bits(uint64_t v, int type, bool sext) {
+  switch (type) {
+    case VH_U8: return v & 0xFFull;
+    case VH_I8: return sext ? (uint64_t)(int64_t)(int8_t)v : (v & 0xFFull);
+    case VH_U16: return v & 0xFFFFull;
+    case VH_I16: return sext ? (uint64_t)(int64_t)(int16_t)v : (v & 0xFFFFull);
+    case VH_U32: case VH_F32: return v & 0xFFFFFFFFull;
+    case VH_I32: return sext ? (uint64_t)(int64_t)(int32_t)v : (v & 0xFFFFFFFFull);
+    default: return v;
+  }
+}
 // One value of row `row` of the column in slot `slot`: out of its arena, or out of a payload projection's record
 // (colpitch = record size, colbase = arena + the column's offset inside the record).
 __device__ __forceinline__ uint64_t vh_gather(const VhPlanDev& P, uint32_t slot, uint32_t seg, uint32_t row, int type, bool sext) {
@@ -728,35 +747,31 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
 
 
 
-// ------------------------------------------------- partitioned aggregation, phase 1 helpers
-// Global atomics are written through to the fabric on this part (~28 B of HBM write traffic per
-// atomic even on a 12 KB table, profiles/r01), so for group-id spaces that do not fit one CU's LDS
-// the survivors are NOT aggregated with global atomics: each becomes a (gid, values) tuple, staged
-// per (wave, partition) in LDS and flushed in 128-256 B pieces into per-partition extents in HBM;
-// part_agg_kernel then aggregates every partition with LDS atomics only.
-struct VhPartWave {
-  uint64_t* stage;     // LDS [npart][stage_cap][tw]
-  uint32_t* scnt;      // LDS [npart] staged tuples (may overshoot stage_cap while a flush is pending);
-                       //     unstaged variant: tuples written into the current extent
-  uint32_t* ext_base;  // LDS [npart] current extent id or ~0u (unstaged variant only)
-  uint32_t r_ext;      // staged variant: lane p holds partition p's current extent id (~0u: none) ...
-  uint32_t r_used;     // ... and the flushes already written into it (bookkeeping without LDS round trips)
-  uint32_t chunk_next, chunk_end;
+// ------------------------------------------------- partitioned aggregation, phase 1
+// Global atomics execute at the memory side on this part (per-XCD L2s are not coherent with each other): ~23 G
+// read-modify-writes per second whatever the table size (profiles/r01/NOTES.md, "The atomic roofline"). For group-id
+// spaces that do not fit one CU's LDS the survivors are therefore NOT aggregated with global atomics: each becomes a
+// (gid, values) tuple; a wave collects VH_PART_TILE of them in LDS, counting-sorts the tile by partition
+// (histogram -> wave prefix -> scatter) and writes every partition's run to that partition's current extent in HBM
+// as one contiguous, coalesced store; part_agg_kernel then aggregates every partition with LDS atomics only.
+// Per-partition state (current extent, fill) lives in lane p's registers and is handed out with v_readlane: an
+// earlier version that went through LDS arrays lost a tuple now and then when an extent was opened inside a tile.
+#define VH_PART_TILE 256     // tuples per wave tile
+struct VhPartWave { uint32_t chunk_next, chunk_end; };   // extents this wave has reserved and not yet opened
+struct VhPartTile {
+  uint64_t* sorted;    // LDS [VH_PART_TILE][tw], lanes form only: the tile's tuples ordered by partition
+  uint32_t* hist;      // LDS [64], lanes form only: counts, then scatter cursors
+  uint32_t r_ext;      // lane p: partition p's current extent (~0u: none) ...
+  uint32_t r_fill;     // ... and the tuples already in it
 };
-
-__device__ __forceinline__ size_t vh_part_wave_bytes(const VhPlanDev& P) {
-  return (size_t)P.npart * ((size_t)P.stage_cap * P.tw * 8 + 12);
+__host__ __device__ __forceinline__ size_t vh_part_tile_bytes(const VhPlanDev& P) {
+  return ((size_t)VH_PART_TILE * P.tw * 8 + 64 * 4 + 15) / 16 * 16;
 }
-
-__device__ __forceinline__ void vh_part_wave_init(const VhPlanDev& P, char* area, VhPartWave& W, int lane) {
-  W.stage = reinterpret_cast<uint64_t*>(area);
-  W.scnt = reinterpret_cast<uint32_t*>(area + (size_t)P.npart * P.stage_cap * P.tw * 8);
-  W.ext_base = W.scnt + P.npart;
+__device__ __forceinline__ void vh_part_tile_init(const VhPlanDev& P, char* area, VhPartTile& T, VhPartWave& W) {
+  T.sorted = reinterpret_cast<uint64_t*>(area);      // (the compacting kernels pass no area: they only use the register state)
+  T.hist = reinterpret_cast<uint32_t*>(area + (size_t)VH_PART_TILE * P.tw * 8);
+  T.r_ext = ~0u; T.r_fill = 0;
   W.chunk_next = W.chunk_end = 0;
-  W.r_ext = ~0u;
-  W.r_used = 0;
-  if (lane < P.npart) { W.scnt[lane] = 0; W.ext_base[lane] = ~0u; }
-  __builtin_amdgcn_wave_barrier();
 }
 
 // Open a new extent for partition p (wave-uniform). Returns ~0u when the buffer is exhausted.
@@ -778,115 +793,128 @@ __device__ __forceinline__ uint32_t vh_part_new_extent(const VhPlanDev& P, VhPar
   return ext;
 }
 
-// Write the first n staged tuples of partition p (wave-uniform p, n) to HBM.
-__device__ __forceinline__ void vh_part_flush(const VhPlanDev& P, VhPartWave& W, int p, uint32_t n, int lane) {
-  if (P.debug & 4) { if (lane == 0) W.scnt[p] = 0; __builtin_amdgcn_wave_barrier(); return; }  // experiment: drop flushes
-  uint32_t ext = __builtin_amdgcn_readlane(W.r_ext, p), used = __builtin_amdgcn_readlane(W.r_used, p);
-  if (ext == ~0u || used == (uint32_t)P.ext_flushes) {
-    ext = vh_part_new_extent(P, W, p, lane);
-    used = 0;
-    if (lane == p) { W.r_ext = ext; W.r_used = 0; }
-    if (ext == ~0u) {
-      if (lane == 0) W.scnt[p] = 0;
-      __builtin_amdgcn_wave_barrier();
-      return;
+__device__ __forceinline__ void vh_part_tile_runs(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, uint32_t cnt, uint32_t base, int lane);
+// One tile: every lane brings up to four tuples (part[r] == ~0u: none) in registers; they leave for HBM grouped by partition.
+template <int NW>
+__device__ __forceinline__ void vh_part_tile_write(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, const uint64_t (&words)[4][NW],
+                                                   const uint32_t (&part)[4], int lane) {
+  uint32_t* hist = T.hist;
+  hist[lane] = 0;
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (part[r] != 0xFFFFFFFFu) atomicAdd(&hist[part[r]], 1u);
+  __builtin_amdgcn_wave_barrier();
+  // lane p owns partition p: count, exclusive prefix (wave scan), cursor
+  const uint32_t cnt = hist[lane];                       // lanes >= npart read 0
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+  const uint32_t base = incl - cnt;
+  __builtin_amdgcn_wave_barrier();
+  hist[lane] = base;                                     // becomes the scatter cursor
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t tw = (uint32_t)P.tw;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (part[r] != 0xFFFFFFFFu) {
+      const uint32_t pos = atomicAdd(&hist[part[r]], 1u);
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
+        if ((uint32_t)w < tw) T.sorted[pos * tw + w] = words[r][w];
     }
   }
-  const uint32_t tw = (uint32_t)P.tw, cap = (uint32_t)P.stage_cap;
-  uint64_t* dst = P.tuples + ((uint64_t)ext * (uint32_t)P.ext_flushes + used) * cap * tw;
-  const uint64_t* src = W.stage + (size_t)p * cap * tw;
-  if (!(P.debug & 2))
-    for (uint32_t i = lane; i < n * tw; i += 64) dst[i] = src[i];
-  if (lane == p) W.r_used = n < cap ? (uint32_t)P.ext_flushes : used + 1;  // a partial flush closes the extent
-  if (lane == 0) {
-    W.scnt[p] = 0;
-    if (n < cap) P.extent_missing[ext] = (uint16_t)(((uint32_t)P.ext_flushes - used) * cap - n);
+  vh_part_tile_runs(P, T, W, cnt, base, lane);
+}
+
+// Run write-out shared by both forms: T.sorted holds the tile ordered by partition; lane p holds partition p's count and
+// exclusive prefix.
+__device__ __forceinline__ void vh_part_tile_runs(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, uint32_t cnt, uint32_t base, int lane) {
+  const uint32_t tw = (uint32_t)P.tw;
+  // room in the partitions' current extents? (lane p decides for partition p; a run never straddles extents)
+  const uint32_t et = (uint32_t)P.ext_tuples;
+  uint64_t need = __ballot(cnt != 0 && (T.r_ext == ~0u || T.r_fill + cnt > et));
+  while (need) {
+    const int p = __builtin_ctzll(need);
+    need &= need - 1;
+    const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, p), oldfill = __builtin_amdgcn_readlane(T.r_fill, p);
+    if (old != ~0u && lane == 0) P.extent_missing[old] = (uint16_t)(et - oldfill);
+    const uint32_t ext = vh_part_new_extent(P, W, p, lane);
+    if (lane == p) { T.r_ext = ext; T.r_fill = 0; }
+  }
+  // lane p holds (extent, fill, base, count) of partition p, the loop is wave-uniform over the partitions present in this tile
+  const uint64_t mydst = T.r_ext == ~0u ? ~0ull : (uint64_t)T.r_ext * et + T.r_fill;
+  if (T.r_ext != ~0u) T.r_fill += cnt;
+  uint64_t runs = __ballot(cnt != 0);
+  __builtin_amdgcn_wave_barrier();
+  while (runs) {
+    const int p = __builtin_ctzll(runs);
+    runs &= runs - 1;
+    const uint32_t pb = __builtin_amdgcn_readlane(base, p), pc = __builtin_amdgcn_readlane(cnt, p);
+    const uint64_t pd = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(mydst >> 32), p) << 32) | __builtin_amdgcn_readlane((uint32_t)mydst, p);
+    if (pd == ~0ull) continue;                           // tuple buffer exhausted: the host re-runs (VH_ERR_PART_FULL)
+    if (tw == 2) {                                       // the common shape (gid + one 32-bit and one 64-bit value): 16 B per lane
+      typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+      for (uint32_t i = lane; i < pc; i += 64)
+        *reinterpret_cast<u64x2*>(P.tuples + (pd + i) * 2) = *reinterpret_cast<const u64x2*>(T.sorted + (size_t)(pb + i) * 2);
+    } else {
+      for (uint32_t i = lane; i < pc * tw; i += 64) P.tuples[pd * tw + i] = T.sorted[(size_t)pb * tw + i];
+    }
   }
   __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void vh_part_append(const VhPlanDev& P, VhPartWave& W, bool active, uint32_t p,
-                                               const uint64_t (&words)[1 + VH_FAST_COLS], int lane) {
-  bool pending = active;
-  const uint32_t cap = (uint32_t)P.stage_cap, tw = (uint32_t)P.tw;
-  while (__ballot(pending)) {
-    uint32_t pos = ~0u;
-    if (pending) pos = atomicAdd(W.scnt + p, 1u);
-    if (pending && pos < cap) {
-      uint64_t* d = W.stage + ((size_t)p * cap + pos) * tw;
+// Compacting kernels: no tile at all. The 64 survivors of a drain find their peers of the same partition
+// with one ballot per partition-id bit (rank = mbcnt among the peers), fetch their partition's write cursor from the
+// lane that owns it (two ds_bpermute) and store their 16-byte tuple straight into the extent: ~60 VALU and no LDS
+// atomics, barriers or staging per drain. A partition's tuples of one drain are adjacent (a few tens of bytes); the next
+// drain of the wave continues the same line, and L2 merges the pieces before the line leaves for HBM (a wave keeps
+// npart lines open: 4096 waves x 13 partitions x 128 B = 7 MB over eight L2s). Measured against collecting 256 tuples in LDS
+// and counting-sorting them like the lanes form does: 4.16 vs 4.38 ms on C3 (profiles/r02/NOTES.md).
+template <int NW>
+__device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, bool active,
+                                                   const uint64_t (&words)[NW], uint32_t p, int lane) {
+  const uint32_t npart = (uint32_t)P.npart, et = (uint32_t)P.ext_tuples, tw = (uint32_t)P.tw;
+  const uint64_t act = __ballot(active);
+  uint64_t peers = act, mine = act;          // lanes in my survivor's partition / lanes in the partition this lane OWNS
 #pragma unroll
-      for (int w = 0; w < 1 + VH_FAST_COLS; ++w)
+  for (int b = 0; b < 6; ++b) {
+    if ((npart - 1u) >> b) {                 // wave-uniform: only the bits partition ids use
+      const uint64_t bal = __ballot((p >> b) & 1u);
+      peers &= ((p >> b) & 1u) ? bal : ~bal;
+      mine &= (((uint32_t)lane >> b) & 1u) ? bal : ~bal;
+    }
+  }
+  const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
+  const uint32_t cnt = (uint32_t)lane < npart ? (uint32_t)__popcll(mine) : 0u;
+  // room in the owned partition's extent? (a drain's tuples of one partition never straddle extents)
+  uint64_t need = __ballot(cnt != 0 && (T.r_ext == ~0u || T.r_fill + cnt > et));
+  while (need) {
+    const int q = __builtin_ctzll(need);
+    need &= need - 1;
+    const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, q), oldfill = __builtin_amdgcn_readlane(T.r_fill, q);
+    if (old != ~0u && lane == 0) P.extent_missing[old] = (uint16_t)(et - oldfill);
+    const uint32_t ext = vh_part_new_extent(P, W, q, lane);
+    if (lane == q) { T.r_ext = ext; T.r_fill = 0; }
+  }
+  const uint32_t pe = (uint32_t)__shfl((int)T.r_ext, (int)(active ? p : 0u)), pf = (uint32_t)__shfl((int)T.r_fill, (int)(active ? p : 0u));
+  if (T.r_ext != ~0u) T.r_fill += cnt;
+  if (active && pe != ~0u) {                 // ~0: tuple buffer exhausted, the host re-runs (VH_ERR_PART_FULL)
+    uint64_t* d = P.tuples + ((uint64_t)pe * et + pf + rank) * tw;
+    if (tw == 2) {
+      typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+      u64x2 v; v.x = words[0]; v.y = words[1];
+      *reinterpret_cast<u64x2*>(d) = v;
+    } else {
+#pragma unroll
+      for (int w = 0; w < NW; ++w)
         if ((uint32_t)w < tw) d[w] = words[w];
-      pending = false;
-    }
-    __builtin_amdgcn_wave_barrier();
-    uint64_t full = __ballot(lane < P.npart && W.scnt[lane < P.npart ? lane : 0] >= cap);
-    while (full) {
-      const int fp = __builtin_ctzll(full);
-      full &= full - 1;
-      vh_part_flush(P, W, fp, cap, lane);
     }
   }
 }
 
-// Unstaged variant (stage_cap == 0): every survivor stores its tuple straight into the current extent of
-// its partition; the slot comes from an LDS counter per (wave, partition), so tuples of one partition
-// written by one drain are adjacent and leave as one write request.
-__device__ __forceinline__ void vh_part_scatter(const VhPlanDev& P, VhPartWave& W, bool active, uint32_t p,
-                                                const uint64_t (&words)[1 + VH_FAST_COLS], int lane) {
-  bool pending = active;
-  const uint32_t et = (uint32_t)P.ext_tuples, tw = (uint32_t)P.tw;
-  while (__ballot(pending)) {
-    uint32_t pos = 0, ext = ~0u;
-    if (pending) { pos = atomicAdd(W.scnt + p, 1u); ext = W.ext_base[p]; }
-    if (pending && ext != ~0u && pos < et) {
-      uint64_t* d = P.tuples + ((uint64_t)ext * et + pos) * tw;
-      if (tw == 2) {
-        typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
-        u64x2 v; v.x = words[0]; v.y = words[1];
-        *reinterpret_cast<u64x2*>(d) = v;
-      } else {
-#pragma unroll
-        for (int w = 0; w < 1 + VH_FAST_COLS; ++w)
-          if ((uint32_t)w < tw) d[w] = words[w];
-      }
-      pending = false;
-    }
-    __builtin_amdgcn_wave_barrier();
-    uint64_t need = __ballot(pending);
-    while (need) {  // rare: a partition's extent is full (or was never opened): open a new one
-      const int src = __builtin_ctzll(need);
-      const uint32_t np = (uint32_t)__shfl((int)p, src);
-      need &= ~__ballot(pending && p == np);
-      const uint32_t next = vh_part_new_extent(P, W, (int)np, lane);
-      const bool ok = next != ~0u;
-      if (!ok) {
-        if (pending && p == np) pending = false;  // dropped: the host re-runs with more room
-      } else if (lane == 0) {
-        W.ext_base[np] = next;
-        W.scnt[np] = 0;
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
-}
-
-__device__ __forceinline__ void vh_part_scatter_finish(const VhPlanDev& P, VhPartWave& W, int lane) {
-  if (lane < P.npart) {
-    const uint32_t ext = W.ext_base[lane], n = W.scnt[lane];
-    if (ext != ~0u && n < (uint32_t)P.ext_tuples) P.extent_missing[ext] = (uint16_t)((uint32_t)P.ext_tuples - n);
-  }
-}
-
-// end of kernel: flush partial staging buffers and publish how much of each open extent is valid
-__device__ __forceinline__ void vh_part_finish(const VhPlanDev& P, VhPartWave& W, int lane) {
-  for (int p = 0; p < P.npart; ++p) {
-    const uint32_t n = W.scnt[p];
-    if (n) vh_part_flush(P, W, p, n < (uint32_t)P.stage_cap ? n : (uint32_t)P.stage_cap, lane);
-  }
-  // open extents whose last flush was a full one still have unused room
-  if (lane < P.npart && W.r_ext != ~0u && W.r_used < (uint32_t)P.ext_flushes)
-    P.extent_missing[W.r_ext] = (uint16_t)(((uint32_t)P.ext_flushes - W.r_used) * (uint32_t)P.stage_cap);
+__device__ __forceinline__ void vh_part_tile_finish(const VhPlanDev& P, VhPartTile& T, int lane) {   // open extents are closed with what they hold
+  if (T.r_ext != ~0u && T.r_fill < (uint32_t)P.ext_tuples) P.extent_missing[T.r_ext] = (uint16_t)((uint32_t)P.ext_tuples - T.r_fill);
 }
 
 // =====================================================================================
@@ -990,25 +1018,43 @@ __device__ __forceinline__ uint32_t vh_eval_filter_fast(const VhPlanDev& P, cons
 
 template <int MODE, int SCOPE>
 __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, char* lds,
-                                                uint64_t xoff, unsigned long long& nfresh, VhPartWave& W, VhLdsHashWave& H) {
+                                                uint64_t xoff, unsigned long long& nfresh, VhPartWave& W, VhPartTile& T, VhLdsHashWave& H) {
   if (!active) row = 0;
+  // All of a survivor's values are requested before the first one is looked at: the aligned 8-byte word around each
+  // element is loaded whatever the column's type (no type switch, hence no branch and no wait, between the loads), and
+  // only then shifted / masked / sign-extended. One memory round trip per drain instead of one per column — the drain
+  // is a dependent chain (queue -> gather -> table), so its latency is what a wave's survivors cost.
   uint64_t gv[VH_FAST_COLS], mv[VH_FAST_COLS];
+  uint32_t gsh[VH_FAST_COLS], msh[VH_FAST_COLS];
+#ifndef VH_ABLATE
+#define VH_ABLATE 0      // measurement builds only (tools/build_variant.py): 1 = no payload gathers, 2 = no aggregate sink
+#endif
 #pragma unroll
   for (int i = 0; i < VH_FAST_COLS; ++i) {
-    gv[i] = 0;
-    if (i < P.ngroup) {
-      const VhGroupDev& g = P.g[i];
-      gv[i] = vh_gather(P, g.slot(), seg, row, g.type(), MODE != VH_MODE_HASH);
-    }
+    gv[i] = 0; gsh[i] = 0;
+    if (i < P.ngroup) { if (VH_ABLATE & 1) gv[i] = P.g[i].lo + (row & 63u); else gv[i] = vh_gather_raw(P, P.g[i].slot(), seg, row, gsh[i]); }
   }
 #pragma unroll
   for (int j = 0; j < VH_FAST_COLS; ++j) {
-    mv[j] = 0;
+    mv[j] = 0; msh[j] = 0;
+    if (j < P.nmetric && P.m[j].slot() != VH_SLOT_ROWID) { if (VH_ABLATE & 1) mv[j] = row; else mv[j] = vh_gather_raw(P, P.m[j].slot(), seg, row, msh[j]); }
+  }
+#pragma unroll
+  for (int i = 0; i < VH_FAST_COLS; ++i)
+    if (i < P.ngroup) gv[i] = vh_decode_bits(gv[i] >> gsh[i], P.g[i].type(), MODE != VH_MODE_HASH);
+#pragma unroll
+  for (int j = 0; j < VH_FAST_COLS; ++j) {
     if (j < P.nmetric) {
       const VhMetricDev& m = P.m[j];
-      if (m.slot() == VH_SLOT_ROWID) mv[j] = ((uint64_t)seg << 32) | row;
-      else mv[j] = vh_gather(P, m.slot(), seg, row, m.type(), vh_sop_sext(m.sop()));
+      mv[j] = m.slot() == VH_SLOT_ROWID ? (((uint64_t)seg << 32) | row) : vh_decode_bits(mv[j] >> msh[j], m.type(), vh_sop_sext(m.sop()));
     }
+  }
+  if (VH_ABLATE & 2) {     // keep the loads alive, drop everything behind them
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < VH_FAST_COLS; ++i) acc += gv[i] + mv[i];
+    if (acc == 0x123456789ABCDEFull) P.counters[7] = acc;
+    return;
   }
   uint64_t gid = 0;
   uint64_t key[VH_KEY_WORDS];
@@ -1076,9 +1122,7 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
           if (m.tword() == w) words[w] |= v;
       }
     }
-    if (P.debug & 1) { if (active && words[1] == 0x123456789ull) P.tuples[0] = words[0]; return; }  // experiment: no staging
-    if (P.stage_cap == 0) vh_part_scatter(P, W, active, (uint32_t)(gid >> P.part_shift), words, (int)(threadIdx.x & 63));
-    else vh_part_append(P, W, active, (uint32_t)(gid >> P.part_shift), words, (int)(threadIdx.x & 63));
+    vh_part_direct_add<1 + VH_FAST_COLS>(P, T, W, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
     return;
   }
   if (MODE == VH_MODE_DENSE_LDS) {
@@ -1110,10 +1154,9 @@ __global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_ag
   VhLdsHashWave H{0u, 0u, false, 0ull};
   if (MODE == VH_MODE_HASH && P.lds_hash_slots) vh_lds_hash_init(P, lds, BLOCK);
   VhPartWave W;
-  if (MODE == VH_MODE_DENSE_PART) {
-    char* area = lds + (size_t)C::kWaves * C::kQueueCap * sizeof(uint32_t) + (size_t)wave * ((vh_part_wave_bytes(P) + 15) / 16 * 16);
-    vh_part_wave_init(P, area, W, lane);
-  }
+  VhPartTile T;
+  if (MODE == VH_MODE_DENSE_PART)
+    vh_part_tile_init(P, lds, T, W);
 
   if (MODE == VH_MODE_DENSE_LDS) {
     for (int j = 0; j < P.nmetric; ++j) {
@@ -1187,21 +1230,21 @@ __global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_ag
       while (cnt >= 64) {
         cnt -= 64;
         const uint32_t r = q[cnt + lane];
-        vh_consume_fast<MODE, SCOPE>(P, seg, r, true, lds, xoff, nfresh, W, H);
+        vh_consume_fast<MODE, SCOPE>(P, seg, r, true, lds, xoff, nfresh, W, T, H);
         __builtin_amdgcn_wave_barrier();
       }
     }
     if (cnt && (!nhave || nseg != seg)) {  // queue entries are rows of the current segment
       const bool act = lane < (int)cnt;
       const uint32_t r = act ? q[lane] : 0;
-      vh_consume_fast<MODE, SCOPE>(P, seg, r, act, lds, xoff, nfresh, W, H);
+      vh_consume_fast<MODE, SCOPE>(P, seg, r, act, lds, xoff, nfresh, W, T, H);
       __builtin_amdgcn_wave_barrier();
       cnt = 0;
     }
     have = nhave; seg = nseg; unit_base = nunit_base; wave_base = nwave_base; seg_rows = nseg_rows;
   }
 
-  if (MODE == VH_MODE_DENSE_PART) { if (P.stage_cap == 0) vh_part_scatter_finish(P, W, lane); else vh_part_finish(P, W, lane); }
+  if (MODE == VH_MODE_DENSE_PART) vh_part_tile_finish(P, T, lane);
   for (int off = 32; off > 0; off >>= 1) npassed += __shfl_down(npassed, off);
   if (lane == 0) {
     if (npassed) atomicAdd(P.counters + 0, npassed);
@@ -1235,17 +1278,6 @@ __global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_ag
 #ifndef VH_LANES_WAVES
 #define VH_LANES_WAVES(MODE, BLOCK, NP) ((MODE) == VH_MODE_DENSE_LDS && (BLOCK) == 256 && (NP) == 1 ? 6 : 0)
 #endif
-#define VH_PART_TILE 256     // row slots per wave tile of the lanes form of DENSE_PART phase 1 (= one sub-step)
-struct VhPartTile {
-  uint64_t* sorted;    // LDS [VH_PART_TILE][tw]: this tile's tuples, ordered by partition
-  uint32_t* hist;      // LDS [64]: counts, then scatter cursors
-  uint32_t r_ext;      // lane p: partition p's current extent (~0u: none) ...
-  uint32_t r_fill;     // ... and the tuples already in it
-};
-__host__ __device__ __forceinline__ size_t vh_part_tile_bytes(const VhPlanDev& P) {
-  return ((size_t)VH_PART_TILE * P.tw * 8 + 64 * 4 + 15) / 16 * 16;
-}
-
 __device__ __forceinline__ void vh_load_rows4(const char* base, int type, uint32_t r0, bool sext, uint64_t (&out)[4]) {
   if (type == VH_U64 || type == VH_I64 || type == VH_F64) {
     vh_load4<uint64_t>(reinterpret_cast<const uint64_t*>(base) + r0, out);
@@ -1268,11 +1300,7 @@ __global__ __launch_bounds__(BLOCK, VH_LANES_WAVES(MODE, BLOCK, NP)) void scan_a
   VhPartWave W;
   VhPartTile T;
   if (MODE == VH_MODE_DENSE_PART) {       // phase 1 of the radix-partitioned aggregation: one LDS tile per wave
-    char* area = lds + (size_t)wave * vh_part_tile_bytes(P);
-    T.sorted = reinterpret_cast<uint64_t*>(area);
-    T.hist = reinterpret_cast<uint32_t*>(area + (size_t)VH_PART_TILE * P.tw * 8);
-    T.r_ext = ~0u; T.r_fill = 0;
-    W.chunk_next = W.chunk_end = 0;
+    vh_part_tile_init(P, lds + (size_t)wave * vh_part_tile_bytes(P), T, W);
   } else if (MODE == VH_MODE_HASH) {
     vh_lds_hash_init(P, lds, BLOCK);
   } else {
@@ -1347,17 +1375,8 @@ __global__ __launch_bounds__(BLOCK, VH_LANES_WAVES(MODE, BLOCK, NP)) void scan_a
         }
       }
       if (MODE == VH_MODE_DENSE_PART) {
-        // Phase 1 of the radix-partitioned aggregation, one wave tile = this sub-step's 256 row slots: counting
-        // sort of the passing rows' tuples by partition in LDS (histogram -> prefix -> scatter), then every run
-        // leaves for its partition's current extent as one contiguous, coalesced write. No per-tuple flush logic.
-        // (A first version looked the destination of sorted[e] up through two more LDS arrays — partition of e,
-        // destination of the partition — and lost a tuple now and then when an extent was opened inside the tile;
-        // per-partition state now stays in lane p's registers and is handed out with v_readlane.)
+        // Phase 1 of the radix-partitioned aggregation, one wave tile = this sub-step's 256 row slots (vh_part_tile_write).
         if (__ballot(mk != 0) == 0) continue;
-        if (P.debug & 4) continue;                             // experiment: scan + payload loads only
-        uint32_t* hist = T.hist;
-        if (lane < 64) hist[lane] = 0;
-        __builtin_amdgcn_wave_barrier();
         uint64_t words[4][1 + VH_LANES_COLS];
         uint32_t part[4];
 #pragma unroll
@@ -1389,58 +1408,8 @@ __global__ __launch_bounds__(BLOCK, VH_LANES_WAVES(MODE, BLOCK, NP)) void scan_a
             }
           }
           part[r] = act ? (uint32_t)(gid >> P.part_shift) : 0xFFFFFFFFu;
-          if (act) atomicAdd(&hist[part[r]], 1u);
         }
-        __builtin_amdgcn_wave_barrier();
-        // lane p owns partition p: count, exclusive prefix (wave scan), cursor
-        const uint32_t cnt = hist[lane];                       // lanes >= npart read 0
-        uint32_t incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
-        const uint32_t base = incl - cnt;
-        const uint32_t total = __shfl(incl, 63);
-        __builtin_amdgcn_wave_barrier();
-        hist[lane] = base;                                     // becomes the scatter cursor
-        __builtin_amdgcn_wave_barrier();
-        const uint32_t tw = (uint32_t)P.tw;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (part[r] != 0xFFFFFFFFu) {
-            const uint32_t pos = atomicAdd(&hist[part[r]], 1u);
-#pragma unroll
-            for (int w = 0; w < 1 + VH_LANES_COLS; ++w)
-              if ((uint32_t)w < tw) T.sorted[pos * tw + w] = words[r][w];
-          }
-        }
-        // room in the partitions' current extents? (lane p decides for partition p; a run never straddles extents)
-        const uint32_t et = (uint32_t)P.ext_tuples;
-        uint64_t need = __ballot(cnt != 0 && (T.r_ext == ~0u || T.r_fill + cnt > et));
-        while (need) {
-          const int p = __builtin_ctzll(need);
-          need &= need - 1;
-          const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, p), oldfill = __builtin_amdgcn_readlane(T.r_fill, p);
-          if (old != ~0u && lane == 0) P.extent_missing[old] = (uint16_t)(et - oldfill);
-          const uint32_t ext = vh_part_new_extent(P, W, p, lane);
-          if (lane == p) { T.r_ext = ext; T.r_fill = 0; }
-        }
-        // write every partition's run to its extent: lane p holds (extent, fill, base, count) of partition p, the loop
-        // is wave-uniform over the partitions present in this tile
-        const uint64_t mydst = T.r_ext == ~0u ? ~0ull : (uint64_t)T.r_ext * et + T.r_fill;
-        if (T.r_ext != ~0u) T.r_fill += cnt;
-        uint64_t runs = __ballot(cnt != 0);
-        while (runs) {
-          const int p = __builtin_ctzll(runs);
-          runs &= runs - 1;
-          const uint32_t pb = __builtin_amdgcn_readlane(base, p), pc = __builtin_amdgcn_readlane(cnt, p);
-          const uint64_t pd = ((uint64_t)__builtin_amdgcn_readlane((uint32_t)(mydst >> 32), p) << 32) | __builtin_amdgcn_readlane((uint32_t)mydst, p);
-          if (pd == ~0ull) continue;                           // tuple buffer exhausted: the host re-runs (VH_ERR_PART_FULL)
-          for (uint32_t i = lane; i < pc; i += 64) {
-            uint64_t* dst = P.tuples + (pd + i) * tw;
-            if (!(P.debug & 2))                                // experiment: everything but the HBM writes
-              for (uint32_t w = 0; w < tw; ++w) dst[w] = T.sorted[(pb + i) * tw + w];
-          }
-        }
-        __builtin_amdgcn_wave_barrier();
+        vh_part_tile_write<1 + VH_LANES_COLS>(P, T, W, words, part, lane);
         continue;
       }
 #pragma unroll
@@ -1505,10 +1474,7 @@ __global__ __launch_bounds__(BLOCK, VH_LANES_WAVES(MODE, BLOCK, NP)) void scan_a
     if (npassed) atomicAdd(P.counters + 0, npassed);
     if (nfresh) atomicAdd(P.counters + 1, nfresh);
   }
-  if (MODE == VH_MODE_DENSE_PART) {       // open extents are closed with what they hold
-    if (T.r_ext != ~0u && T.r_fill < (uint32_t)P.ext_tuples) P.extent_missing[T.r_ext] = (uint16_t)((uint32_t)P.ext_tuples - T.r_fill);
-    return;
-  }
+  if (MODE == VH_MODE_DENSE_PART) { vh_part_tile_finish(P, T, lane); return; }
   if (MODE == VH_MODE_HASH) { vh_lds_hash_flush(P, lds, BLOCK); return; }
   __syncthreads();
   const uint64_t xo = P.nxcd > 1 ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -53,6 +54,10 @@ struct VhContext {
 };
 static VhContext g_ctx;
 static std::mutex g_mu;
+
+// The HIP current device is per thread: every entry point that allocates or launches binds the calling thread to the
+// library's device first (query threads of a server pool never called vh_init themselves).
+#define VH_ENTER() do { if (g_ctx.inited) (void)hipSetDevice(g_ctx.device); } while (0)
 
 extern "C" const char* vh_last_error(void) { return g_err; }
 extern "C" const char* vh_version(void) { return "viya_hip 0.1 (gfx950)"; }
@@ -93,6 +98,25 @@ struct VhColumn {
 struct VhSegStat {          // order keys as produced by seg_minmax_kernel
   uint64_t lo = ~0ull, hi = 0;
 };
+// Execution context: everything ONE in-flight query needs besides the table's columns — a stream, device scratch,
+// pinned staging, events. A table keeps a pool of them; a vh_result owns one from launch until vh_result_free, so
+// queries of different threads on one table overlap on the device (the reference's read_pool runs queries of one table
+// concurrently: src/db/database.cc:28-34, src/server/http/service.cc:119) and a handle's device state and host view are
+// never reused under it.
+struct VhExec {
+  hipStream_t own_stream = nullptr;
+  char* scratch = nullptr; size_t scratch_bytes = 0;
+  uint32_t* h_segrows = nullptr; size_t h_segrows_cap = 0;
+  unsigned long long* h_counters = nullptr;     // pinned, 16 words
+  char* d_sample = nullptr; size_t d_sample_bytes = 0;   // selectivity probe: counters + presence + seg rows
+  char* h_out[2] = {nullptr, nullptr}; size_t h_out_bytes[2] = {0, 0}; int h_out_next = 0;  // pinned result staging (two alternate: a
+                                                                                            // zero-copy view outlives vh_result_free until the second-next query)
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool busy = false;
+  // an externally owned stream (vh_set_stream) carries all work; otherwise every context has its own
+  hipStream_t stream() const { return g_ctx.stream != g_ctx.own_stream ? g_ctx.stream : own_stream; }
+};
+
 // Payload projection (vh_table_pack): a row-major copy of a few columns, see pack_kernel.
 struct VhPack {
   std::vector<int> cols;            // table column indices, in record order (widest first)
@@ -111,23 +135,20 @@ struct vh_table {
   uint32_t nseg = 0;
   std::vector<uint64_t> seg_rows;               // last synced row count
   std::vector<std::vector<VhSegStat>> stats;    // [col][seg]
-  // per-query device scratch (grow-only) and pinned staging
-  char* scratch = nullptr; size_t scratch_bytes = 0;
-  uint32_t* h_segrows = nullptr; size_t h_segrows_cap = 0;
-  unsigned long long* h_counters = nullptr;     // pinned, 16 words
-  char* d_sample = nullptr; size_t d_sample_bytes = 0;   // selectivity probe: counters + presence + seg rows
+  // per-query resources live in execution contexts (grow-only pool)
+  std::vector<std::unique_ptr<VhExec>> execs;
+  std::mutex pool_mu; std::condition_variable pool_cv;
+  char* d_stats = nullptr; size_t d_stats_bytes = 0;      // vh_segment_sync*: min/max pass (its own buffer: a sync never touches a query's scratch)
   std::map<std::string, uint64_t> groups_seen;           // group-column signature -> groups of the last query (hash sizing)
-  std::map<std::string, double> sel_cache;               // filter signature + table state -> probed selectivity
+  std::map<std::string, std::pair<uint64_t, uint64_t>> sel_cache;   // filter signature + table state -> (passed, sampled) of the selectivity probe
   char* h_out[2] = {nullptr, nullptr}; size_t h_out_bytes[2] = {0, 0}; int h_out_next = 0;  // pinned result staging
   std::vector<std::unique_ptr<VhPack>> packs;
   std::vector<uint64_t> seg_mod;                          // sync_epoch of the last change to a segment's columns
   uint32_t* d_packrows = nullptr; size_t d_packrows_cap = 0;
   std::map<std::string, uint32_t> gather_seen;            // payload column set -> low-selectivity queries seen (automatic packs)
   uint64_t sync_epoch = 0;   // bumped by every vh_segment_sync / generate: invalidates cached estimates
-  uint64_t launch_epoch = 0; // bumped by every query launch: a result's device state lives in `scratch` until the next one
-  uint64_t staged_seq = 0;   // bumped by every finalisation: host views alternate between the two staging buffers
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-  std::mutex mu;
+  std::mutex mu;             // table metadata, column arenas, projections, planner caches: held while a query is PLANNED and
+                             // LAUNCHED and by every sync; not while a launched query runs or is read back
   uint64_t device_bytes = 0;
 };
 
@@ -164,6 +185,7 @@ static int table_grow(vh_table* t, uint32_t need_seg) {
 extern "C" int vh_table_create(const vh_col_desc* cols, int32_t ncols, uint64_t segment_rows,
                                uint32_t reserve_segments, vh_table** out) {
   if (!g_ctx.inited) return vh_fail(VH_E_INVALID, "vh_init has not been called");
+  VH_ENTER();
   if (!cols || ncols <= 0 || !out || segment_rows == 0 || segment_rows > 0xFFFF0000ull)
     return vh_fail(VH_E_INVALID, "vh_table_create: bad arguments");
   vh_table* t = new vh_table();
@@ -186,54 +208,87 @@ extern "C" int vh_table_create(const vh_col_desc* cols, int32_t ncols, uint64_t 
   }
   int rc = table_grow(t, std::max<uint32_t>(1, reserve_segments));
   if (rc) { vh_table_destroy(t); return rc; }
-  hipError_t he = hipHostMalloc((void**)&t->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault);
-  for (auto& e : t->ev) if (he == hipSuccess) he = hipEventCreate(&e);
-  if (he != hipSuccess) {
-    vh_table_destroy(t);
-    return vh_fail(VH_E_DEVICE, "vh_table_create: pinned staging / events: %s", hipGetErrorString(he));
-  }
   *out = t;
   return VH_OK;
 }
 
+// ------------------------------------------------------------------ execution contexts
+static void exec_free(VhExec* x) {
+  if (x->scratch) (void)hipFree(x->scratch);
+  if (x->d_sample) (void)hipFree(x->d_sample);
+  for (auto& hp : x->h_out) if (hp) (void)hipHostFree(hp);
+  if (x->h_segrows) (void)hipHostFree(x->h_segrows);
+  if (x->h_counters) (void)hipHostFree(x->h_counters);
+  for (auto& e : x->ev) if (e) (void)hipEventDestroy(e);
+  if (x->own_stream) (void)hipStreamDestroy(x->own_stream);
+}
+// A free context of the table's pool, a new one while the pool may grow, else wait for one to come back.
+static int exec_acquire(vh_table* t, VhExec** out) {
+  static const size_t max_exec = getenv("VH_MAX_EXEC") ? (size_t)std::max(1, atoi(getenv("VH_MAX_EXEC"))) : 16;
+  std::unique_lock<std::mutex> lk(t->pool_mu);
+  for (;;) {
+    for (auto& x : t->execs) if (!x->busy) { x->busy = true; *out = x.get(); return VH_OK; }
+    if (t->execs.size() < max_exec) break;
+    if (t->pool_cv.wait_for(lk, std::chrono::seconds(60)) == std::cv_status::timeout)
+      return vh_fail(VH_E_NOMEM, "all %zu execution contexts of this table are held by live vh_result / running queries (vh_result_free them)", max_exec);
+  }
+  std::unique_ptr<VhExec> x(new VhExec());
+  hipError_t he = hipStreamCreateWithFlags(&x->own_stream, hipStreamNonBlocking);
+  if (he == hipSuccess) he = hipHostMalloc((void**)&x->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault);
+  for (auto& e : x->ev) if (he == hipSuccess) he = hipEventCreate(&e);
+  if (he != hipSuccess) { exec_free(x.get()); return vh_fail(VH_E_DEVICE, "execution context: stream / pinned staging / events: %s", hipGetErrorString(he)); }
+  x->busy = true;
+  *out = x.get();
+  t->execs.push_back(std::move(x));
+  return VH_OK;
+}
+static void exec_release(vh_table* t, VhExec* x) {
+  if (!x) return;
+  { std::lock_guard<std::mutex> lk(t->pool_mu); x->busy = false; }
+  t->pool_cv.notify_one();
+}
+// Before column arenas, CSR mirrors or projections are replaced: wait for every launched query that may still read them.
+// Called with t->mu held (no new launch can start).
+static void table_quiesce(vh_table* t) {
+  std::lock_guard<std::mutex> lk(t->pool_mu);
+  for (auto& x : t->execs) if (x->busy) (void)hipStreamSynchronize(x->stream());
+}
+
 extern "C" void vh_table_destroy(vh_table* t) {
   if (!t) return;
+  VH_ENTER();
   (void)hipStreamSynchronize(g_ctx.stream);
+  for (auto& x : t->execs) { (void)hipStreamSynchronize(x->stream()); exec_free(x.get()); }
   for (auto& c : t->cols) {
     if (c.base) (void)hipFree(c.base);
     for (auto p : c.bs_offsets) if (p) (void)hipFree(p);
     for (auto p : c.bs_values) if (p) (void)hipFree(p);
   }
-  if (t->scratch) (void)hipFree(t->scratch);
-  if (t->d_sample) (void)hipFree(t->d_sample);
+  if (t->d_stats) (void)hipFree(t->d_stats);
   for (auto& pk : t->packs) if (pk->base) (void)hipFree(pk->base);
   if (t->d_packrows) (void)hipFree(t->d_packrows);
-  for (auto& hp : t->h_out) if (hp) (void)hipHostFree(hp);
-  if (t->h_segrows) (void)hipHostFree(t->h_segrows);
-  if (t->h_counters) (void)hipHostFree(t->h_counters);
-  for (auto& e : t->ev) if (e) (void)hipEventDestroy(e);
   delete t;
 }
 
-static int ensure_scratch(vh_table* t, size_t bytes) {
-  if (bytes <= t->scratch_bytes) return VH_OK;
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-  if (t->scratch) { HIP_TRY(hipFree(t->scratch)); t->scratch = nullptr; t->scratch_bytes = 0; }
+static int ensure_scratch(VhExec* x, size_t bytes) {
+  if (bytes <= x->scratch_bytes) return VH_OK;
+  HIP_TRY(hipStreamSynchronize(x->stream()));
+  if (x->scratch) { HIP_TRY(hipFree(x->scratch)); x->scratch = nullptr; x->scratch_bytes = 0; }
   size_t nb = std::max(bytes + bytes / 4, (size_t)1 << 20);
-  HIP_TRY(hipMalloc(&t->scratch, nb));
-  t->scratch_bytes = nb;
+  HIP_TRY(hipMalloc(&x->scratch, nb));
+  x->scratch_bytes = nb;
   if (getenv("VH_POISON")) {   // tests: nothing may depend on what fresh scratch holds
-    HIP_TRY(hipMemsetAsync(t->scratch, 0xA5, nb, g_ctx.stream));
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+    HIP_TRY(hipMemsetAsync(x->scratch, 0xA5, nb, x->stream()));
+    HIP_TRY(hipStreamSynchronize(x->stream()));
   }
   return VH_OK;
 }
-static int ensure_segrows(vh_table* t, size_t n) {
-  if (n <= t->h_segrows_cap) return VH_OK;
-  if (t->h_segrows) (void)hipHostFree(t->h_segrows);
+static int ensure_segrows(VhExec* x, size_t n) {
+  if (n <= x->h_segrows_cap) return VH_OK;
+  if (x->h_segrows) (void)hipHostFree(x->h_segrows);
   size_t cap = std::max<size_t>(n * 2, 1024);
-  HIP_TRY(hipHostMalloc((void**)&t->h_segrows, cap * sizeof(uint32_t), hipHostMallocDefault));
-  t->h_segrows_cap = cap;
+  HIP_TRY(hipHostMalloc((void**)&x->h_segrows, cap * sizeof(uint32_t), hipHostMallocDefault));
+  x->h_segrows_cap = cap;
   return VH_OK;
 }
 
@@ -258,17 +313,20 @@ static int refresh_stats(vh_table* t, uint32_t first, uint32_t n) {
   if (!ndim || !n) return VH_OK;
   const size_t stat_bytes = (size_t)ndim * n * 2 * sizeof(unsigned long long);
   const size_t rows_bytes = (size_t)n * sizeof(uint32_t);
-  int rc = ensure_scratch(t, stat_bytes + rows_bytes + 256);
-  if (rc) return rc;
-  rc = ensure_segrows(t, n);
-  if (rc) return rc;
-  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(t->scratch);
-  uint32_t* d_rows = reinterpret_cast<uint32_t*>(t->scratch + stat_bytes);
+  if (stat_bytes + rows_bytes + 256 > t->d_stats_bytes) {
+    if (t->d_stats) { HIP_TRY(hipFree(t->d_stats)); t->d_stats = nullptr; t->d_stats_bytes = 0; }
+    const size_t nb = std::max<size_t>((stat_bytes + rows_bytes + 256) * 2, 1 << 16);
+    HIP_TRY(hipMalloc(&t->d_stats, nb));
+    t->d_stats_bytes = nb;
+  }
+  unsigned long long* d_stats = reinterpret_cast<unsigned long long*>(t->d_stats);
+  uint32_t* d_rows = reinterpret_cast<uint32_t*>(t->d_stats + stat_bytes);
   std::vector<unsigned long long> init((size_t)ndim * n * 2);
   for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ull; init[i + 1] = 0; }
-  for (uint32_t s = 0; s < n; ++s) t->h_segrows[s] = (uint32_t)t->seg_rows[first + s];
+  std::vector<uint32_t> hrows(n);
+  for (uint32_t s = 0; s < n; ++s) hrows[s] = (uint32_t)t->seg_rows[first + s];
   HIP_TRY(hipMemcpyAsync(d_stats, init.data(), stat_bytes, hipMemcpyHostToDevice, g_ctx.stream));
-  HIP_TRY(hipMemcpyAsync(d_rows, t->h_segrows, rows_bytes, hipMemcpyHostToDevice, g_ctx.stream));
+  HIP_TRY(hipMemcpyAsync(d_rows, hrows.data(), rows_bytes, hipMemcpyHostToDevice, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));  // init is a stack/heap buffer
   int di = 0;
   for (auto& c : t->cols) {
@@ -300,7 +358,9 @@ extern "C" int vh_segment_sync(vh_table* t, uint32_t seg, uint64_t nrows, const 
   if (!t || !col_ptrs) return vh_fail(VH_E_INVALID, "vh_segment_sync: null argument");
   if (nrows > t->segment_rows) return vh_fail(VH_E_INVALID, "vh_segment_sync: nrows %llu > segment_rows", (unsigned long long)nrows);
   if (seg >= VH_MAX_SEGMENTS) return vh_fail(VH_E_INVALID, "vh_segment_sync: segment index %u out of range", seg);
+  VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
+  table_quiesce(t);
   int rc = table_grow(t, seg + 1);
   if (rc) return rc;
   for (size_t i = 0; i < t->cols.size(); ++i) {
@@ -323,7 +383,9 @@ extern "C" int vh_segment_sync_range(vh_table* t, uint32_t seg, uint64_t row_fir
     return vh_fail(VH_E_INVALID, "vh_segment_sync_range: rows [%llu, %llu) do not fit a segment of %llu rows",
                    (unsigned long long)row_first, (unsigned long long)(row_first + nrows), (unsigned long long)new_size);
   if (seg >= VH_MAX_SEGMENTS) return vh_fail(VH_E_INVALID, "vh_segment_sync_range: segment index %u out of range", seg);
+  VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
+  table_quiesce(t);
   int rc = table_grow(t, seg + 1);
   if (rc) return rc;
   if (row_first > t->seg_rows[seg])
@@ -350,7 +412,9 @@ extern "C" int vh_segment_sync_bitset(vh_table* t, uint32_t seg, int32_t col, ui
   if (!is_bitset_elem(c.elem)) return vh_fail(VH_E_INVALID, "column %d is not a bitset column", col);
   if (nrows > t->segment_rows || seg >= VH_MAX_SEGMENTS) return vh_fail(VH_E_INVALID, "vh_segment_sync_bitset: segment %u / %llu rows out of range", seg, (unsigned long long)nrows);
   if (offsets[0] != 0 || (offsets[nrows] && !values)) return vh_fail(VH_E_INVALID, "vh_segment_sync_bitset: offsets must start at 0 and values must be given");
+  VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
+  table_quiesce(t);
   int rc = table_grow(t, seg + 1);
   if (rc) return rc;
   if (c.bs_offsets[seg]) { HIP_TRY(hipFree(c.bs_offsets[seg])); c.bs_offsets[seg] = nullptr; }
@@ -373,7 +437,9 @@ extern "C" int vh_segment_sync_ids_device(vh_table* t, uint32_t seg, int32_t col
   if (!is_bitset_elem(c.elem)) return vh_fail(VH_E_INVALID, "column %d is not a bitset column", col);
   if (nrows > t->segment_rows || seg >= VH_MAX_SEGMENTS) return vh_fail(VH_E_INVALID, "vh_segment_sync_ids_device: segment %u / %llu rows out of range", seg, (unsigned long long)nrows);
   if (nrows && !d_ids) return vh_fail(VH_E_INVALID, "vh_segment_sync_ids_device: null ids");
+  VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
+  table_quiesce(t);
   int rc = table_grow(t, seg + 1);
   if (rc) return rc;
   if (c.bs_offsets[seg]) { HIP_TRY(hipFree(c.bs_offsets[seg])); c.bs_offsets[seg] = nullptr; }
@@ -396,7 +462,9 @@ extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nse
   if (!t || !specs || !nseg) return vh_fail(VH_E_INVALID, "vh_segment_generate: bad argument");
   if (rows_per_seg > t->segment_rows) return vh_fail(VH_E_INVALID, "rows_per_seg exceeds segment_rows");
   if (seg_first >= VH_MAX_SEGMENTS || nseg > VH_MAX_SEGMENTS - seg_first) return vh_fail(VH_E_INVALID, "vh_segment_generate: segments [%u, +%u) out of range", seg_first, nseg);
+  VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
+  table_quiesce(t);
   int rc = table_grow(t, seg_first + nseg);
   if (rc) return rc;
   for (size_t i = 0; i < t->cols.size(); ++i) {
@@ -443,6 +511,8 @@ extern "C" int vh_segment_read(vh_table* t, uint32_t seg, int32_t col, uint64_t 
   if (!t || col < 0 || (size_t)col >= t->cols.size() || seg >= t->nseg || !dst) return vh_fail(VH_E_INVALID, "vh_segment_read: bad argument");
   auto& c = t->cols[col];
   if (is_bitset_elem(c.elem)) return vh_fail(VH_E_UNSUPPORTED, "vh_segment_read: bitset column");
+  VH_ENTER();
+  std::lock_guard<std::mutex> lk(t->mu);
   HIP_TRY(hipMemcpy(dst, c.base + (size_t)seg * c.stride, (size_t)nrows * c.esize, hipMemcpyDeviceToHost));
   return VH_OK;
 }
@@ -451,8 +521,8 @@ extern "C" int vh_segment_read(vh_table* t, uint32_t seg, int32_t col, uint64_t 
 extern "C" int vh_device_read(void* dst, const void* device_src, uint64_t bytes) {
   if (!bytes) return VH_OK;
   if (!dst || !device_src) return vh_fail(VH_E_INVALID, "vh_device_read: null argument");
-  HIP_TRY(hipMemcpyAsync(dst, device_src, (size_t)bytes, hipMemcpyDeviceToHost, g_ctx.stream));
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  VH_ENTER();
+  HIP_TRY(hipMemcpy(dst, device_src, (size_t)bytes, hipMemcpyDeviceToHost));   // the buffers were produced by calls that completed on their own stream
   return VH_OK;
 }
 
@@ -470,6 +540,7 @@ static int pack_refresh(vh_table* t, VhPack* pk, uint32_t first, uint32_t n) {
   if (first + n > t->nseg) n = t->nseg > first ? t->nseg - first : 0;
   if (!n) return VH_OK;
   if (pk->cap_seg < t->cap_seg) {                      // the table grew: move the arena
+    table_quiesce(t);
     char* nb = nullptr;
     const size_t bytes = (size_t)t->cap_seg * pk->stride + 256;
     HIP_TRY(hipMalloc(&nb, bytes));
@@ -546,13 +617,16 @@ static int table_pack_locked(vh_table* t, const int32_t* cols, int32_t ncols, bo
 
 extern "C" int vh_table_pack(vh_table* t, const int32_t* cols, int32_t ncols) {
   if (!t) return vh_fail(VH_E_INVALID, "null table");
+  VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
   return table_pack_locked(t, cols, ncols, false, nullptr);
 }
 
 extern "C" int vh_table_unpack(vh_table* t) {
   if (!t) return vh_fail(VH_E_INVALID, "null table");
+  VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
+  table_quiesce(t);
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   for (auto& pk : t->packs) if (pk->base) { (void)hipFree(pk->base); t->device_bytes -= (size_t)pk->cap_seg * pk->stride + 256; }
   t->packs.clear();
@@ -561,6 +635,7 @@ extern "C" int vh_table_unpack(vh_table* t) {
 }
 
 // ------------------------------------------------------- typed host helpers
+template <typename T> static T vh_lit_host(uint64_t bits) { T v; memcpy(&v, &bits, sizeof(T)); return v; }
 static uint64_t order_key_of_bits(int elem, uint64_t bits) {
   switch (elem) {
     case VH_U8: return (uint8_t)bits;
@@ -627,7 +702,10 @@ struct vh_result {
   vh_result_info info{};
   int mode = 0;
   bool finalized = false;
-  uint64_t launch_epoch = 0, staged_seq = 0;   // see vh_table: used to refuse stale handles instead of reading reused memory
+  int h_slot = -1;                             // staging buffer of `exec` this query finalises into
+  std::string kernel;                          // symbol(s) of the scan kernel(s) launched for this query
+  bool device_rows = false;                    // emitted rows must (also) exist in device memory: they are exchanged or gathered next
+  VhExec* exec = nullptr;                      // owned from launch to vh_result_free: stream, scratch (device-side state), staging (host view)
   // device-side partial state
   VhPlanDev plan{};
   int nxcd = 1;
@@ -660,23 +738,20 @@ struct vh_result {
   const char* zero_begin = nullptr; const char* zero_end = nullptr;   // scratch range cleared by the one state memset
   char* d_xchg = nullptr;              // vh_result_partition: rows regrouped by owner (own allocation)
   std::vector<char*> d_pairs;          // vh_result_partition_pairs: one allocation per call
-  ~vh_result() { if (d_xchg) (void)hipFree(d_xchg); for (char* p : d_pairs) (void)hipFree(p); }
+  // sharded queries: a merged result lives on a temporary merge table (owned), a gathered one in buffers of its own
+  vh_table* owned_table = nullptr;
+  char* d_own = nullptr; char* h_own = nullptr;
+  ~vh_result() {
+    if (d_xchg) (void)hipFree(d_xchg);
+    for (char* p : d_pairs) (void)hipFree(p);
+    if (exec) { (void)hipStreamSynchronize(exec->stream()); exec_release(table, exec); }   // nothing of this query may still run on a context the next one takes
+    if (d_own) (void)hipFree(d_own);
+    if (h_own) (void)hipHostFree(h_own);
+    if (owned_table) vh_table_destroy(owned_table);
+  }
 };
 
-extern "C" void vh_result_free(vh_result* r) { delete r; }
-
-// A result's device-side state lives in its table's scratch arena, which the next query on that table reuses.
-static int check_device_state(const vh_result* r, const char* what) {
-  if (r->launch_epoch != r->table->launch_epoch)
-    return vh_fail(VH_E_INVALID, "%s: stale result handle (another query has run on this table since)", what);
-  return VH_OK;
-}
-// ... and its host views alias one of the table's two pinned staging buffers.
-static int check_host_view(const vh_result* r, const char* what) {
-  if (r->table->staged_seq - r->staged_seq >= 2)
-    return vh_fail(VH_E_INVALID, "%s: stale result handle (two or more queries have been finalised on this table since)", what);
-  return VH_OK;
-}
+extern "C" void vh_result_free(vh_result* r) { if (r) { VH_ENTER(); delete r; } }
 
 extern "C" int vh_result_get_info(vh_result* r, vh_result_info* info) {
   if (!r || !info) return vh_fail(VH_E_INVALID, "null argument");
@@ -684,9 +759,10 @@ extern "C" int vh_result_get_info(vh_result* r, vh_result_info* info) {
   return VH_OK;
 }
 
+extern "C" const char* vh_result_kernel(vh_result* r) { return r ? r->kernel.c_str() : ""; }
+
 extern "C" int vh_result_view(vh_result* r, const void** key_cols, const void** state_cols, const uint64_t** hidden_count) {
   if (!r || !r->finalized) return vh_fail(VH_E_INVALID, "result is not finalised");
-  if (int rc = check_host_view(r, "vh_result_view")) return rc;
   for (int i = 0; i < r->plan.ngroup; ++i)
     if (key_cols) key_cols[i] = r->h_base + r->off_key[i];
   for (size_t j = 0; j < r->user_metric.size(); ++j) {
@@ -811,35 +887,38 @@ static bool segment_passes(const vh_table* t, const vh_plan* p, uint32_t seg) {
 // the first 16 K rows of up to 64 evenly spaced segments (one extra ~20 us launch + a 64-byte read-back).
 // Decides between direct global atomics (cheap per query, ~30-60 G updates/s) and radix-partitioned
 // LDS aggregation (two passes over 16 B per survivor, but no global atomics).
-static int estimate_selectivity(vh_table* t, const VhPlanDev& P, uint32_t nseg, double* sel) {
+static int estimate_selectivity(vh_table* t, VhExec* x, const VhPlanDev& P, uint32_t nseg, double* sel, uint64_t* passed_out = nullptr, uint64_t* sampled_out = nullptr) {
   const uint32_t kRows = 16384;
   const size_t need = 256 + 256 + (size_t)std::max<uint32_t>(nseg, 1) * sizeof(uint32_t);
-  if (need > t->d_sample_bytes) {
-    if (t->d_sample) HIP_TRY(hipFree(t->d_sample));
-    HIP_TRY(hipMalloc(&t->d_sample, need * 2));
-    t->d_sample_bytes = need * 2;
+  if (need > x->d_sample_bytes) {
+    if (x->d_sample) HIP_TRY(hipFree(x->d_sample));
+    HIP_TRY(hipMalloc(&x->d_sample, need * 2));
+    x->d_sample_bytes = need * 2;
   }
   std::vector<uint32_t> rows(std::max<uint32_t>(nseg, 1), 0);
   const uint32_t stride = std::max<uint32_t>(1, nseg / 64);
   uint64_t sampled = 0;
-  for (uint32_t s = 0; s < nseg; s += stride) { rows[s] = std::min<uint32_t>(t->h_segrows[s], kRows); sampled += rows[s]; }
+  for (uint32_t s = 0; s < nseg; s += stride) { rows[s] = std::min<uint32_t>(x->h_segrows[s], kRows); sampled += rows[s]; }
+  if (passed_out) *passed_out = 0;
+  if (sampled_out) *sampled_out = sampled;
   if (!sampled) { *sel = 0; return VH_OK; }
   VhPlanDev S = P;
   S.ngroup = 0; S.nmetric = 0; S.nbitset = 0; S.G = 1; S.nxcd = 1; S.xcd_stride = 64;
   S.lds_present_off = 0; S.lds_bytes = 16; S.present_carrier = -1;
-  S.counters = reinterpret_cast<unsigned long long*>(t->d_sample);
-  S.present = reinterpret_cast<uint8_t*>(t->d_sample + 256);
-  S.seg_rows = reinterpret_cast<const uint32_t*>(t->d_sample + 512);
+  S.counters = reinterpret_cast<unsigned long long*>(x->d_sample);
+  S.present = reinterpret_cast<uint8_t*>(x->d_sample + 256);
+  S.seg_rows = reinterpret_cast<const uint32_t*>(x->d_sample + 512);
   S.nseg = nseg; S.unit_rows = kRows; S.units_per_seg = 1; S.total_units = nseg;
-  hipStream_t st = g_ctx.stream;
-  HIP_TRY(hipMemsetAsync(t->d_sample, 0, 512, st));
-  HIP_TRY(hipMemcpyAsync(t->d_sample + 512, rows.data(), nseg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  hipStream_t st = x->stream();
+  HIP_TRY(hipMemsetAsync(x->d_sample, 0, 512, st));
+  HIP_TRY(hipMemcpyAsync(x->d_sample + 512, rows.data(), nseg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   const size_t qbytes = (size_t)16 * VhScanCfg<1024>::kQueueCap * sizeof(uint32_t);
   vh_launch_scan_fast_lds(S, (int)std::min<uint32_t>(nseg, (uint32_t)g_ctx.num_cu), 16 + qbytes, false, st);
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipMemcpyAsync(t->h_counters + 8, S.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(x->h_counters + 8, S.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  *sel = (double)t->h_counters[8] / (double)sampled;
+  *sel = (double)x->h_counters[8] / (double)sampled;
+  if (passed_out) *passed_out = x->h_counters[8];
   return VH_OK;
 }
 
@@ -856,9 +935,24 @@ static int fill_states(void* p, uint64_t n, int bytes, uint64_t ident, hipStream
   return VH_OK;
 }
 
-static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, uint64_t hash_capacity_override,
+// Multi-GPU (vh_query_agg_sharded): what a rank's planner looks at, exchanged between the ranks ...
+struct VhSummary {
+  uint64_t klo[VH_MAX_GROUP], khi[VH_MAX_GROUP];   // order keys of a group column over the segments this rank will scan; klo > khi: none
+  uint64_t rows_to_scan, probe_passed, probe_sampled;
+  uint64_t cap_override, part_override;            // re-plan requests of the previous attempt (VhReplan)
+  uint32_t force_hash, no_part, fatal, pad;
+};
+// ... and what every rank plans with instead of its own view, so that all of them build the same table organisation.
+struct VhAgreed {
+  uint64_t klo[VH_MAX_GROUP], khi[VH_MAX_GROUP];
+  uint64_t rows_to_scan;
+  double sel;
+};
+
+static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_result** out, uint64_t hash_capacity_override,
                                bool force_hash, uint64_t part_tuples_override = 0, bool no_part = false,
-                               bool plan_only = false) {
+                               bool plan_only = false, VhSummary* summary_out = nullptr, const VhAgreed* ag = nullptr,
+                               bool device_rows = false) {
   // ---------------- validate
   if (p->nfilter < 0 || p->nlits < 0 || p->ngroups < 0 || p->nmetrics < 0 || p->nhaving < 0)
     return vh_fail(VH_E_INVALID, "plan has a negative count");
@@ -872,9 +966,9 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   if (nseg > t->nseg) return vh_fail(VH_E_INVALID, "plan snapshots %u segments, table mirrors %u", nseg, t->nseg);
   const int ncols = (int)t->cols.size();
 
-  vh_result* r = new vh_result();
+  std::unique_ptr<vh_result> holder(new vh_result());   // every early return below drops it
+  vh_result* r = holder.get();
   r->table = t;
-  r->launch_epoch = ++t->launch_epoch;
   VhPlanDev& P = r->plan;
   memset(&P, 0, sizeof(P));
 
@@ -905,10 +999,10 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     o.set_kind((uint8_t)n.kind); o.set_op((uint8_t)n.op); o.set_count((uint8_t)n.count);
     if (n.kind == VH_F_REL || n.kind == VH_F_IN) {
       const int s = slot(n.col);
-      if (s == -2) { delete r; return vh_fail(VH_E_UNSUPPORTED, "filter on a bitset metric (cardinality) is evaluated host-side"); }
-      if (s < 0) { delete r; return vh_fail(VH_E_INVALID, "filter node %d: bad column %d", i, n.col); }
+      if (s == -2) { return vh_fail(VH_E_UNSUPPORTED, "filter on a bitset metric (cardinality) is evaluated host-side"); }
+      if (s < 0) { return vh_fail(VH_E_INVALID, "filter node %d: bad column %d", i, n.col); }
       const int cnt = n.kind == VH_F_REL ? 1 : n.count;
-      if (n.lit < 0 || n.lit + cnt > p->nlits || n.count > 255) { delete r; return vh_fail(VH_E_INVALID, "filter node %d: literal range", i); }
+      if (n.lit < 0 || n.lit + cnt > p->nlits || n.count > 255) { return vh_fail(VH_E_INVALID, "filter node %d: literal range", i); }
       o.set_slot((uint8_t)s); o.set_type((uint8_t)t->cols[n.col].elem); o.set_lit((uint16_t)n.lit);
       // fast path bookkeeping: distinct 4-byte predicate columns
       if (vh_elem_size(t->cols[n.col].elem) != 4) fast_ok = false;
@@ -922,65 +1016,85 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     } else if (n.kind == VH_F_TRUE) {
       ++depth;
     } else if (n.kind == VH_F_AND || n.kind == VH_F_OR) {
-      if (n.count < 1 || n.count > depth || n.count > 255) { delete r; return vh_fail(VH_E_INVALID, "filter node %d: operand count %d", i, n.count); }
+      if (n.count < 1 || n.count > depth || n.count > 255) { return vh_fail(VH_E_INVALID, "filter node %d: operand count %d", i, n.count); }
       depth -= n.count - 1;
-    } else { delete r; return vh_fail(VH_E_INVALID, "filter node %d: kind %d", i, n.kind); }
+    } else { return vh_fail(VH_E_INVALID, "filter node %d: kind %d", i, n.kind); }
     maxdepth = std::max(maxdepth, depth);
   }
   if (p->nfilter == 0) { P.prog[0].set_kind(VH_F_TRUE); P.nprog = 1; depth = 1; }
   else P.nprog = p->nfilter;
-  if (depth != 1) { delete r; return vh_fail(VH_E_INVALID, "filter program leaves %d values on the stack", depth); }
-  if (maxdepth > VH_MAX_STACK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "filter needs stack depth %d (max %d)", maxdepth, VH_MAX_STACK); }
+  if (depth != 1) { return vh_fail(VH_E_INVALID, "filter program leaves %d values on the stack", depth); }
+  if (maxdepth > VH_MAX_STACK) { return vh_fail(VH_E_UNSUPPORTED, "filter needs stack depth %d (max %d)", maxdepth, VH_MAX_STACK); }
   for (int i = 0; i < p->nlits; ++i) P.lits[i] = p->lits[i].u64;
 
   // ---------------- segments: snapshot + skip
-  int rc = ensure_segrows(t, std::max<uint32_t>(nseg, 1));
-  if (rc) { delete r; return rc; }
+  int rc = ensure_segrows(x, std::max<uint32_t>(nseg, 1));
+  if (rc) { return rc; }
   uint64_t scanned_recs = 0, scanned_segments = 0, rows_to_scan = 0;
   std::vector<uint32_t> live;
   for (uint32_t s = 0; s < nseg; ++s) {
     uint64_t rows = p->seg_rows ? p->seg_rows[s] : t->seg_rows[s];
-    if (rows > t->seg_rows[s]) { delete r; return vh_fail(VH_E_INVALID, "segment %u: snapshot %llu rows > mirrored %llu", s, (unsigned long long)rows, (unsigned long long)t->seg_rows[s]); }
+    if (rows > t->seg_rows[s]) { return vh_fail(VH_E_INVALID, "segment %u: snapshot %llu rows > mirrored %llu", s, (unsigned long long)rows, (unsigned long long)t->seg_rows[s]); }
     scanned_recs += rows;
     const bool keep = segment_passes(t, p, s);
     if (keep) { ++scanned_segments; rows_to_scan += rows; if (rows) live.push_back(s); }
-    t->h_segrows[s] = keep ? (uint32_t)rows : 0u;
+    x->h_segrows[s] = keep ? (uint32_t)rows : 0u;
   }
   r->info.scanned_recs = scanned_recs;
   r->info.scanned_segments = scanned_segments;
   if (plan_only) {   // vh_query_select: filter program, column slots and the segment snapshot are all it shares
     P.nseg = nseg;
     r->info.algorithmic_bytes = rows_to_scan * bytes_per_row;
-    *out = r;
+    *out = holder.release();
     return VH_OK;
   }
 
+  // selectivity of the filter, from a one-launch probe; it only depends on the filter and the rows, so it is cached
+  // until the table changes. Sharded queries plan with the estimate all ranks agreed on.
+  uint64_t probe_passed = 0, probe_sampled = 0;
+  auto probed_selectivity = [&](double* sel) -> int {
+    if (ag) { *sel = ag->sel; return VH_OK; }
+    if (p->nfilter == 0) { *sel = 1.0; probe_passed = probe_sampled = rows_to_scan; return VH_OK; }   // no filter: every row passes
+    std::string key((const char*)P.prog, sizeof(VhProgOp) * P.nprog);
+    key.append((const char*)P.lits, sizeof(uint64_t) * std::max(p->nlits, 0));
+    key += "|" + std::to_string(nseg) + "|" + std::to_string(rows_to_scan) + "|" + std::to_string(t->sync_epoch);
+    auto hit = t->sel_cache.find(key);
+    if (hit != t->sel_cache.end()) { probe_passed = hit->second.first; probe_sampled = hit->second.second; *sel = probe_sampled ? (double)probe_passed / (double)probe_sampled : 0.0; return VH_OK; }
+    const int prc = estimate_selectivity(t, x, P, nseg, sel, &probe_passed, &probe_sampled);
+    if (prc) return prc;
+    if (t->sel_cache.size() > 256) t->sel_cache.clear();
+    t->sel_cache[key] = std::make_pair(probe_passed, probe_sampled);
+    return VH_OK;
+  };
+
   // ---------------- group columns
   P.ngroup = p->ngroups;
+  if (summary_out) for (int i = 0; i < VH_MAX_GROUP; ++i) { summary_out->klo[i] = ~0ull; summary_out->khi[i] = 0; }
+  r->device_rows = device_rows;
   bool dense_ok = !force_hash && !(p->flags & VH_PLAN_FORCE_HASH);
   uint64_t G = 1;
   int key_bits_total = 0;
   for (int i = 0; i < p->ngroups; ++i) {
     const vh_group_col& gc = p->groups[i];
     const int s = slot(gc.col);
-    if (s < 0 || !is_dim(t->cols[gc.col].kind)) { delete r; return vh_fail(VH_E_INVALID, "group column %d: bad column %d", i, gc.col); }
+    if (s < 0 || !is_dim(t->cols[gc.col].kind)) { return vh_fail(VH_E_INVALID, "group column %d: bad column %d", i, gc.col); }
     const VhColumn& c = t->cols[gc.col];
-    if (gc.nrollup < 0 || gc.nrollup > VH_MAX_ROLLUP) { delete r; return vh_fail(VH_E_UNSUPPORTED, "group column %d: %d rollup rules", i, gc.nrollup); }
-    if (gc.granularity > VH_T_NONE) { delete r; return vh_fail(VH_E_INVALID, "group column %d: granularity %d", i, gc.granularity); }
+    if (gc.nrollup < 0 || gc.nrollup > VH_MAX_ROLLUP) { return vh_fail(VH_E_UNSUPPORTED, "group column %d: %d rollup rules", i, gc.nrollup); }
+    if (gc.granularity > VH_T_NONE) { return vh_fail(VH_E_INVALID, "group column %d: granularity %d", i, gc.granularity); }
     for (int k = 0; k < gc.nrollup; ++k)
-      if (gc.rollup_unit[k] < VH_T_YEAR || gc.rollup_unit[k] > VH_T_SECOND) { delete r; return vh_fail(VH_E_INVALID, "group column %d: rollup unit %d", i, gc.rollup_unit[k]); }
+      if (gc.rollup_unit[k] < VH_T_YEAR || gc.rollup_unit[k] > VH_T_SECOND) { return vh_fail(VH_E_INVALID, "group column %d: rollup unit %d", i, gc.rollup_unit[k]); }
     VhGroupDev& g = P.g[i];
     g.set_slot((uint16_t)s); g.set_type((uint8_t)c.elem);
     g.set_gran((uint8_t)(gc.granularity < 0 ? VH_T_NONE : gc.granularity));
     g.set_nroll((uint8_t)gc.nrollup); g.set_micro((uint8_t)gc.micro);
 
-    if (g.gran() == VH_T_WEEK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "week granularity: the reference has no Truncator::trunc<WEEK> (src/util/time.h:57-89)"); }
+    if (g.gran() == VH_T_WEEK) { return vh_fail(VH_E_UNSUPPORTED, "week granularity: the reference has no Truncator::trunc<WEEK> (src/util/time.h:57-89)"); }
     for (int k = 0; k < gc.nrollup; ++k) {
-      if (gc.rollup_unit[k] == VH_T_WEEK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "week rollup granularity is not supported by the reference"); }
+      if (gc.rollup_unit[k] == VH_T_WEEK) { return vh_fail(VH_E_UNSUPPORTED, "week rollup granularity is not supported by the reference"); }
       g.set_roll_unit(k, (uint8_t)gc.rollup_unit[k]); g.roll_before[k] = gc.rollup_before[k];
     }
     const bool timey = g.gran() != VH_T_NONE || g.nroll();
-    if (timey && c.kind != VH_DIM_TIME) { delete r; return vh_fail(VH_E_INVALID, "group column %d: truncation on a non-time dimension", i); }
+    if (timey && c.kind != VH_DIM_TIME) { return vh_fail(VH_E_INVALID, "group column %d: truncation on a non-time dimension", i); }
     r->group_elem.push_back(c.elem);
     key_bits_total += c.esize * 8;
     // dense digit range
@@ -992,7 +1106,9 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     } else {
       uint64_t klo = ~0ull, khi = 0;
       for (uint32_t sgi : live) { klo = std::min(klo, t->stats[gc.col][sgi].lo); khi = std::max(khi, t->stats[gc.col][sgi].hi); }
-      if (live.empty() || klo > khi) { lo = 0; extent = 1; }
+      if (summary_out) { summary_out->klo[i] = klo; summary_out->khi[i] = khi; }
+      if (ag) { klo = ag->klo[i]; khi = ag->khi[i]; }      // the range over ALL ranks' segments: identically indexed tables everywhere
+      if (klo > khi) { lo = 0; extent = 1; }
       else {
         lo = bits_of_order_key(c.elem, klo);
         const uint64_t span = khi - klo;
@@ -1006,7 +1122,15 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       else G *= extent;
     }
   }
-  const uint64_t dense_limit = std::max<uint64_t>(4096, std::min<uint64_t>(1ull << 24, rows_to_scan * 4));
+  if (summary_out) {       // sharded queries, first half: report and stop
+    summary_out->rows_to_scan = rows_to_scan;
+    double sel = 0;
+    if (fast_ok || p->nfilter == 0) { rc = probed_selectivity(&sel); if (rc) return rc; }
+    summary_out->probe_passed = probe_passed; summary_out->probe_sampled = probe_sampled;
+    return VH_OK;
+  }
+  const uint64_t plan_rows = ag ? ag->rows_to_scan : rows_to_scan;
+  const uint64_t dense_limit = std::max<uint64_t>(4096, std::min<uint64_t>(1ull << 24, plan_rows * 4));
   if (G > dense_limit) dense_ok = false;
   if (dense_ok) {
     uint64_t stride = 1;
@@ -1021,7 +1145,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       used += bits;
     }
     P.key_words = p->ngroups ? word + 1 : 1;
-    if (P.key_words > VH_KEY_WORDS) { delete r; return vh_fail(VH_E_UNSUPPORTED, "group key of %d bits is too wide", key_bits_total); }
+    if (P.key_words > VH_KEY_WORDS) { return vh_fail(VH_E_UNSUPPORTED, "group key of %d bits is too wide", key_bits_total); }
   }
 
   // ---------------- metrics
@@ -1041,12 +1165,12 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       r->metric_elem.push_back(VH_U64);
       continue;
     }
-    if (col < 0 || col >= ncols || is_dim(t->cols[col].kind)) { delete r; return vh_fail(VH_E_INVALID, "metric %d: bad column %d", j, col); }
+    if (col < 0 || col >= ncols || is_dim(t->cols[col].kind)) { return vh_fail(VH_E_INVALID, "metric %d: bad column %d", j, col); }
     const VhColumn& c = t->cols[col];
     if (c.kind == VH_METRIC_BITSET) {
-      if (P.nbitset >= VH_MAX_BITSET) { delete r; return vh_fail(VH_E_UNSUPPORTED, "more than %d bitset metrics in one query", VH_MAX_BITSET); }
+      if (P.nbitset >= VH_MAX_BITSET) { return vh_fail(VH_E_UNSUPPORTED, "more than %d bitset metrics in one query", VH_MAX_BITSET); }
       for (uint32_t sgi : live) {
-        if (!c.bs_offsets[sgi]) { delete r; return vh_fail(VH_E_INVALID, "bitset column %d of segment %u was never synced", col, sgi); }
+        if (!c.bs_offsets[sgi]) { return vh_fail(VH_E_INVALID, "bitset column %d of segment %u was never synced", col, sgi); }
         pair_cap += c.bs_nvalues[sgi];
       }
       bitset_col[P.nbitset] = col;
@@ -1061,9 +1185,9 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       continue;
     }
     const int s = slot(col);
-    if (s < 0) { delete r; return vh_fail(VH_E_UNSUPPORTED, "too many referenced columns"); }
+    if (s < 0) { return vh_fail(VH_E_UNSUPPORTED, "too many referenced columns"); }
     int sop; uint64_t ident;
-    if (sop_for(c.kind, c.elem, &sop, &ident)) { delete r; return vh_fail(VH_E_INVALID, "metric %d: kind %d / elem %d", j, c.kind, c.elem); }
+    if (sop_for(c.kind, c.elem, &sop, &ident)) { return vh_fail(VH_E_INVALID, "metric %d: kind %d / elem %d", j, c.kind, c.elem); }
     VhMetricDev& m = P.m[P.nmetric];
     m.set_slot((uint16_t)s); m.set_type((uint8_t)c.elem); m.set_sop((uint8_t)sop); m.ident = ident;
     metric_col[P.nmetric] = col;
@@ -1075,9 +1199,9 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     // hidden uint64_t _count (src/codegen/query/scan.cc:239-241)
     int hc = -1;
     for (int c = 0; c < ncols; ++c) if (t->cols[c].kind == VH_METRIC_HIDDEN_COUNT) hc = c;
-    if (hc < 0) { delete r; return vh_fail(VH_E_INVALID, "AVG selected without COUNT but the table has no hidden count column"); }
+    if (hc < 0) { return vh_fail(VH_E_INVALID, "AVG selected without COUNT but the table has no hidden count column"); }
     const int s = slot(hc);
-    if (s < 0) { delete r; return vh_fail(VH_E_UNSUPPORTED, "too many referenced columns"); }
+    if (s < 0) { return vh_fail(VH_E_UNSUPPORTED, "too many referenced columns"); }
     metric_col[P.nmetric] = hc;
     VhMetricDev& m = P.m[P.nmetric++];
     m.set_slot((uint16_t)s); m.set_type(VH_U64); m.set_sop(SOP_ADD64); m.ident = 0;
@@ -1090,7 +1214,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
 
   // ---------------- HAVING pushed down to the group-emission kernel
   if (p->nhaving > 0) {
-    if (p->nhaving > VH_MAX_HAVING) { delete r; return vh_fail(VH_E_UNSUPPORTED, "having has %d nodes (max %d)", p->nhaving, VH_MAX_HAVING); }
+    if (p->nhaving > VH_MAX_HAVING) { return vh_fail(VH_E_UNSUPPORTED, "having has %d nodes (max %d)", p->nhaving, VH_MAX_HAVING); }
     int hdepth = 0, nl = 0;
     for (int i = 0; i < p->nhaving; ++i) {
       const vh_filter_node& n = p->having[i];
@@ -1117,15 +1241,15 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
         ++hdepth;
       } else if (n.kind == VH_F_TRUE) ++hdepth;
       else if ((n.kind == VH_F_AND || n.kind == VH_F_OR) && n.count >= 1 && n.count <= hdepth) hdepth -= n.count - 1;
-      else { delete r; return vh_fail(VH_E_INVALID, "having node %d: kind %d / count %d", i, n.kind, n.count); }
-      if (hdepth > VH_MAX_STACK) { delete r; return vh_fail(VH_E_UNSUPPORTED, "having needs stack depth %d", hdepth); }
+      else { return vh_fail(VH_E_INVALID, "having node %d: kind %d / count %d", i, n.kind, n.count); }
+      if (hdepth > VH_MAX_STACK) { return vh_fail(VH_E_UNSUPPORTED, "having needs stack depth %d", hdepth); }
     }
-    if (hdepth != 1) { delete r; return vh_fail(VH_E_INVALID, "having program leaves %d values on the stack", hdepth); }
+    if (hdepth != 1) { return vh_fail(VH_E_INVALID, "having program leaves %d values on the stack", hdepth); }
     r->nhaving = p->nhaving;
   }
   // ---------------- device top-N request (vh_plan.top_*)
   if (p->top_k > 0) {
-    if (p->top_col < 0 || p->top_col >= p->ngroups + p->nmetrics) { delete r; return vh_fail(VH_E_INVALID, "top_col %d is not a result column", p->top_col); }
+    if (p->top_col < 0 || p->top_col >= p->ngroups + p->nmetrics) { return vh_fail(VH_E_INVALID, "top_col %d is not a result column", p->top_col); }
     int kind, elem;
     if (p->top_col < p->ngroups) {
       const VhColumn& c = t->cols[p->groups[p->top_col].col];
@@ -1138,8 +1262,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       elem = r->metric_elem[r->topk_src];
     }
     if (kind == VH_DIM_STRING || kind == VH_DIM_TIME || kind == VH_DIM_BOOLEAN || kind == VH_METRIC_AVG) {
-      delete r;
-      return vh_fail(VH_E_UNSUPPORTED, "top-N on a string / time / boolean / AVG column: the reference orders those as formatted strings");
+        return vh_fail(VH_E_UNSUPPORTED, "top-N on a string / time / boolean / AVG column: the reference orders those as formatted strings");
     }
     r->topk = p->top_k; r->topk_elem = elem; r->topk_desc = p->top_desc ? 1 : 0;
     r->topk_cls = (elem == VH_F32 || elem == VH_F64) ? VH_TOPK_FLOAT : VH_TOPK_INT;
@@ -1170,21 +1293,6 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     mode = VH_MODE_HASH;
   }
   const bool fast = fast_ok && P.ngroup <= VH_FAST_COLS && P.nmetric <= VH_FAST_COLS && P.nbitset == 0;   // npred == 0: no filter
-  // selectivity of the filter, from a one-launch probe; it only depends on the filter and the rows, so it is cached
-  // until the table changes
-  auto probed_selectivity = [&](double* sel) -> int {
-    if (p->nfilter == 0) { *sel = 1.0; return VH_OK; }   // no filter: every row passes
-    std::string key((const char*)P.prog, sizeof(VhProgOp) * P.nprog);
-    key.append((const char*)P.lits, sizeof(uint64_t) * std::max(p->nlits, 0));
-    key += "|" + std::to_string(nseg) + "|" + std::to_string(rows_to_scan) + "|" + std::to_string(t->sync_epoch);
-    auto hit = t->sel_cache.find(key);
-    if (hit != t->sel_cache.end()) { *sel = hit->second; return VH_OK; }
-    const int prc = estimate_selectivity(t, P, nseg, sel);
-    if (prc) return prc;
-    if (t->sel_cache.size() > 256) t->sel_cache.clear();
-    t->sel_cache[key] = *sel;
-    return VH_OK;
-  };
   // "Lanes" kernel (no compaction) for small LDS tables when most rows pass: see scan_agg_lanes_kernel
   bool lanes = false;
   if (mode == VH_MODE_DENSE_LDS && fast && !(p->flags & VH_PLAN_NO_LANES) && P.ngroup <= VH_LANES_COLS && P.nmetric <= VH_LANES_COLS &&
@@ -1197,7 +1305,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       else {
         double sel = 0;
         rc = probed_selectivity(&sel);
-        if (rc) { delete r; return rc; }
+        if (rc) { return rc; }
         lanes = sel >= 0.25;
       }
     }
@@ -1213,12 +1321,25 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     const uint64_t np = (G + (1ull << shift) - 1) >> shift;
     bool want_part = np <= VH_MAX_PART && G <= 0xFFFFFFFFull;
     double sel = 0;
-    if (want_part && !(p->flags & VH_PLAN_FORCE_PART) && !part_tuples_override) {
+    if (want_part && !part_tuples_override) {       // (a forced plan still sizes its tuple buffer from the estimate)
       rc = probed_selectivity(&sel);
-      if (rc) { delete r; return rc; }
+      if (rc) { return rc; }
+    }
+    if (want_part && !(p->flags & VH_PLAN_FORCE_PART) && !part_tuples_override) {
       // crossover measured on the C3 table (profiles/r01/NOTES.md): direct atomics cost 2 x survivors / 23.3 G/s on top of the
       // scan (5 %: 5.0-5.15 ms, 6 %: 5.63, 7 %: 6.51, 8 %: 7.41), partitioned 4.97 / 5.30 / 5.56 / 5.86 ms
-      want_part = sel >= 0.055;
+      // ... with a payload projection covering the query the gathers shrink for both, which exposes the atomic bound of the
+      // direct form sooner (profiles/r02/NOTES.md: 3 % 3.25 vs 3.59 ms, 5 % 4.60 vs 4.07-4.22, 8 % 7.38 vs 5.2-5.6): switch at 4 %
+      bool covered = false;
+      if (!(p->flags & VH_PLAN_NO_PACK)) {
+        for (auto& pk : t->packs) {
+          bool all = true;
+          for (int i = 0; i < p->ngroups; ++i) all &= pk->col_index(p->groups[i].col) >= 0;
+          for (int j = 0; j < P.nmetric; ++j) if (metric_col[j] >= 0) all &= pk->col_index(metric_col[j]) >= 0;
+          covered |= all;
+        }
+      }
+      want_part = sel >= (covered ? 0.04 : 0.055);
     }
     if (want_part) {
       // most rows pass: build the tuples without compacting survivors first (lanes kernel, phase 1 only)
@@ -1230,7 +1351,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
           if (p->flags & VH_PLAN_FORCE_LANES) lanes = true;
           else {
             double s2 = sel;
-            if (s2 == 0) { rc = probed_selectivity(&s2); if (rc) { delete r; return rc; } }
+            if (s2 == 0) { rc = probed_selectivity(&s2); if (rc) { return rc; } }
             lanes = s2 >= 0.5;
           }
         }
@@ -1247,11 +1368,6 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
         else { P.m[j].set_tword((uint8_t)tw); P.m[j].set_tshift(0); half_free_word = tw++; have_half = true; }
       }
       P.tw = tw;
-      static const int part_cap_max = getenv("VH_PART_CAP") ? atoi(getenv("VH_PART_CAP")) : 32;   // fewer, fuller partitions: 10 % faster than 56 KB / 16 (profiles/r01/NOTES.md)
-      int cap = part_cap_max;
-      while (cap > 4 && 4 * ((size_t)P.npart * ((size_t)cap * tw * 8 + 12) + 16) + 4 * VhScanCfg<256>::kQueueCap * 4 > 40 * 1024) cap /= 2;
-      static const bool staged = !(getenv("VH_PART_STAGED") && atoi(getenv("VH_PART_STAGED")) == 0);
-      P.stage_cap = staged ? cap : 0;   // 0: tuples are scattered straight into the extents
       // phase-2 LDS table for one partition
       const uint64_t gpp = 1ull << shift;
       size_t off = 0;
@@ -1279,72 +1395,6 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   r->mode = mode;
   r->info.path = mode == VH_MODE_DENSE_LDS ? (p->ngroups ? VH_PATH_DENSE_LDS : VH_PATH_SCALAR)
                : mode == VH_MODE_DENSE_GLOBAL ? VH_PATH_DENSE_GLOBAL : mode == VH_MODE_DENSE_PART ? VH_PATH_DENSE_PART : VH_PATH_HASH;
-
-  // ---------------- payload projection: when few rows pass, a survivor's group / metric values come out of ONE packed
-  // record (vh_table_pack) instead of one line per column arena. Only the compacting kernels gather by row; the lanes
-  // kernels read whole column ranges and keep the arenas.
-  bool packed = false;
-  {
-    std::vector<int32_t> gcols;
-    for (int i = 0; i < p->ngroups; ++i) gcols.push_back(p->groups[i].col);
-    for (int j = 0; j < P.nmetric; ++j) if (metric_col[j] >= 0) gcols.push_back(metric_col[j]);
-    std::sort(gcols.begin(), gcols.end());
-    gcols.erase(std::unique(gcols.begin(), gcols.end()), gcols.end());
-    bool want = !lanes && !(p->flags & VH_PLAN_NO_PACK) && !gcols.empty() && gcols.size() <= VH_PACK_MAX_COLS && rows_to_scan &&
-                P.nslots + (int)gcols.size() <= VH_MAX_SLOTS;
-    const bool forced = (p->flags & VH_PLAN_FORCE_PACK) != 0;
-    if (want && !forced) {
-      // lines touched per survivor: one record vs one per column; the projection stops paying off once most lines of
-      // the arenas are touched anyway (C3 columns: ~20 % of the rows passing)
-      want = fast && p->nfilter > 0;
-      if (want) {
-        double sel = 1.0;
-        rc = probed_selectivity(&sel);
-        if (rc) { delete r; return rc; }
-        want = sel <= 0.15;
-      }
-    }
-    VhPack* use = nullptr;
-    if (want) {
-      for (auto& pk : t->packs) {
-        bool all = true;
-        for (int c : gcols) all &= pk->col_index(c) >= 0;
-        if (all && (!use || pk->rec_bytes < use->rec_bytes)) use = pk.get();
-      }
-      static const int auto_after = getenv("VH_AUTO_PACK") ? atoi(getenv("VH_AUTO_PACK")) : 3;   // 0: never build one unasked
-      if (!use && (forced || auto_after > 0)) {
-        std::string sig;
-        for (int c : gcols) sig += std::to_string(c) + ",";
-        bool build = forced || ++t->gather_seen[sig] >= (uint32_t)auto_after;
-        if (build && !forced) {        // room: the projection must leave a quarter of the device free and not outgrow the table
-          uint32_t bytes = 0; for (int c : gcols) bytes += (uint32_t)t->cols[c].esize;
-          uint32_t rec = 8; while (rec < bytes) rec <<= 1;
-          const size_t need = (size_t)t->cap_seg * ((t->segment_rows + 255) / 256 * 256) * rec;
-          size_t free_b = 0, total_b = 0;
-          build = bytes <= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= t->device_bytes && free_b > need + total_b / 4;
-          if (!build) t->gather_seen[sig] = 0;
-        }
-        if (build && table_pack_locked(t, gcols.data(), (int32_t)gcols.size(), !forced, &use) != VH_OK) use = nullptr;
-      }
-    }
-    if (use) {
-      rc = pack_refresh(t, use, 0, nseg);
-      if (rc) { delete r; return rc; }
-      int pslot_of[256];
-      for (int i = 0; i < 256; ++i) pslot_of[i] = -1;
-      auto pslot = [&](int col) {
-        if (pslot_of[col] >= 0) return pslot_of[col];
-        const int k = use->col_index(col);
-        P.colbase[P.nslots] = use->base + use->off[k];
-        P.colstride[P.nslots] = use->stride;
-        P.colpitch[P.nslots] = use->rec_bytes;
-        return pslot_of[col] = P.nslots++;
-      };
-      for (int i = 0; i < p->ngroups; ++i) P.g[i].set_slot((uint16_t)pslot(p->groups[i].col));
-      for (int j = 0; j < P.nmetric; ++j) if (metric_col[j] >= 0) P.m[j].set_slot((uint16_t)pslot(metric_col[j]));
-      packed = true;
-    }
-  }
 
   // per-XCD private copies only while they stay cache-sized
   int nxcd = 1;
@@ -1403,12 +1453,78 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
         else {
           double sel = 0;
           rc = probed_selectivity(&sel);
-          if (rc) { delete r; return rc; }
+          if (rc) { return rc; }
           // per-row work here is heavy (calendar arithmetic, LDS probe) and runs once per ROW SLOT, passing or not:
           // measured on 100 M rows into day buckets, 50 % pass: 1.05 ms compacted vs 1.38 ms lanes; 100 %: 2.29 vs 1.92
           lanes = sel >= 0.7;
         }
       }
+    }
+  }
+
+  // ---------------- payload projection: when few rows pass, a survivor's group / metric values come out of ONE packed
+  // record (vh_table_pack) instead of one line per column arena. Only the compacting kernels gather by row; the lanes
+  // kernels read whole column ranges and keep the arenas.
+  bool packed = false;
+  {
+    std::vector<int32_t> gcols;
+    for (int i = 0; i < p->ngroups; ++i) gcols.push_back(p->groups[i].col);
+    for (int j = 0; j < P.nmetric; ++j) if (metric_col[j] >= 0) gcols.push_back(metric_col[j]);
+    std::sort(gcols.begin(), gcols.end());
+    gcols.erase(std::unique(gcols.begin(), gcols.end()), gcols.end());
+    bool want = !lanes && !(p->flags & VH_PLAN_NO_PACK) && !gcols.empty() && gcols.size() <= VH_PACK_MAX_COLS && rows_to_scan &&
+                P.nslots + (int)gcols.size() <= VH_MAX_SLOTS;
+    const bool forced = (p->flags & VH_PLAN_FORCE_PACK) != 0;
+    if (want && !forced) {
+      // lines touched per survivor: one record vs one per column; the projection stops paying off once most lines of
+      // the arenas are touched anyway (C3 columns: ~20 % of the rows passing)
+      want = fast && p->nfilter > 0;
+      if (want) {
+        double sel = 1.0;
+        rc = probed_selectivity(&sel);
+        if (rc) { return rc; }
+        want = sel <= 0.15;
+      }
+    }
+    VhPack* use = nullptr;
+    if (want) {
+      for (auto& pk : t->packs) {
+        bool all = true;
+        for (int c : gcols) all &= pk->col_index(c) >= 0;
+        if (all && (!use || pk->rec_bytes < use->rec_bytes)) use = pk.get();
+      }
+      static const int auto_after = getenv("VH_AUTO_PACK") ? atoi(getenv("VH_AUTO_PACK")) : 3;   // 0: never build one unasked
+      if (!use && (forced || auto_after > 0)) {
+        std::string sig;
+        for (int c : gcols) sig += std::to_string(c) + ",";
+        bool build = forced || ++t->gather_seen[sig] >= (uint32_t)auto_after;
+        if (build && !forced) {        // room: the projection must leave a quarter of the device free and not outgrow the table
+          uint32_t bytes = 0; for (int c : gcols) bytes += (uint32_t)t->cols[c].esize;
+          uint32_t rec = 8; while (rec < bytes) rec <<= 1;
+          const size_t need = (size_t)t->cap_seg * ((t->segment_rows + 255) / 256 * 256) * rec;
+          size_t free_b = 0, total_b = 0;
+          build = bytes <= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= t->device_bytes && free_b > need + total_b / 4;
+          if (!build) t->gather_seen[sig] = 0;
+        }
+        if (build && table_pack_locked(t, gcols.data(), (int32_t)gcols.size(), !forced, &use) != VH_OK) use = nullptr;
+      }
+    }
+    if (use) {
+      rc = pack_refresh(t, use, 0, nseg);   // on the table's main stream, complete when it returns
+      if (rc) { return rc; }
+      int pslot_of[256];
+      for (int i = 0; i < 256; ++i) pslot_of[i] = -1;
+      auto pslot = [&](int col) {
+        if (pslot_of[col] >= 0) return pslot_of[col];
+        const int k = use->col_index(col);
+        P.colbase[P.nslots] = use->base + use->off[k];
+        P.colstride[P.nslots] = use->stride;
+        P.colpitch[P.nslots] = use->rec_bytes;
+        return pslot_of[col] = P.nslots++;
+      };
+      for (int i = 0; i < p->ngroups; ++i) P.g[i].set_slot((uint16_t)pslot(p->groups[i].col));
+      for (int j = 0; j < P.nmetric; ++j) if (metric_col[j] >= 0) P.m[j].set_slot((uint16_t)pslot(metric_col[j]));
+      packed = true;
     }
   }
 
@@ -1426,16 +1542,14 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     if (env_lanes_block == 256 || env_lanes_block == 512 || env_lanes_block == 1024) BLOCK = env_lanes_block;
     else if ((uint64_t)g_ctx.num_cu * 5 * G * std::max(1, P.nmetric) <= rows_to_scan / 32) BLOCK = 256;
   }
-  if (mode == VH_MODE_DENSE_PART && P.stage_cap == 0) lanes = false;   // the unstaged experiment has no lanes form
   // One place decides which scan kernel runs; with `occ` it only asks how many of its blocks fit a CU.
   auto scan_dispatch = [&](int grid_, int* occ) {
     const size_t qb = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint32_t);
     const size_t lds_ = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + qb;
-    hipStream_t s_ = g_ctx.stream;
+    hipStream_t s_ = x->stream();
     if (mode == VH_MODE_DENSE_PART) {
-      const size_t wave_area = ((size_t)P.npart * ((size_t)P.stage_cap * P.tw * 8 + 12) + 15) / 16 * 16;
-      if (lanes) { P.part_tile = VH_PART_TILE; vh_launch_scan_lanes_part(P, grid_, 4 * vh_part_tile_bytes(P), s_, occ); }
-      else vh_launch_scan_fast_part(P, grid_, qb + 4 * wave_area, s_, occ);
+      if (lanes) vh_launch_scan_lanes_part(P, grid_, 4 * vh_part_tile_bytes(P), s_, occ);
+      else vh_launch_scan_fast_part(P, grid_, qb, s_, occ);   // the compacting form appends straight to the extents: no tile in LDS
     }
     else if (!fast) { if (!occ) vh_launch_scan_generic(mode, P, grid_, lds_, nxcd > 1, s_); }
     else if (lanes && mode == VH_MODE_HASH) vh_launch_scan_lanes_hash(P, grid_, lds_, s_, occ);
@@ -1444,6 +1558,15 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     else if (mode == VH_MODE_DENSE_GLOBAL) vh_launch_scan_fast_global(P, grid_, lds_, nxcd > 1, s_, occ);
     else vh_launch_scan_fast_hash(P, grid_, lds_, s_, occ);
   };
+  {   // the kernel symbol(s) this query runs, as rocprofv3 prints them (vh_result_kernel: bench.py's roofline.kernel)
+    const int np_ = std::max(1, (int)P.npred), scope = (mode == VH_MODE_DENSE_GLOBAL || mode == VH_MODE_DENSE_LDS) && nxcd > 1 ? (int)__HIP_MEMORY_SCOPE_WORKGROUP : (int)__HIP_MEMORY_SCOPE_AGENT;
+    char nm[160];
+    if (!fast) snprintf(nm, sizeof(nm), "scan_agg_kernel<%d, %d, %d>", mode, BLOCK, scope);
+    else snprintf(nm, sizeof(nm), "%s<%d, %d, %d, %d>", lanes ? "scan_agg_lanes_kernel" : "scan_agg_fast_kernel", mode, BLOCK,
+                  (mode == VH_MODE_HASH || mode == VH_MODE_DENSE_PART) ? (int)__HIP_MEMORY_SCOPE_AGENT : scope, np_);
+    r->kernel = nm;
+    if (mode == VH_MODE_DENSE_PART) r->kernel += " + part_agg_kernel<1024>";
+  }
   int occupancy = 0;
   if (env_bpc <= 0) scan_dispatch(0, &occupancy);
   const uint32_t step = BLOCK * VH_LANE_ROWS;
@@ -1524,13 +1647,13 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     // extent size: big enough that a wave allocates rarely (every allocation is a returning global
     // atomic = a full round trip the wave sits out), small enough that open extents do not waste HBM
     const uint64_t waves = (uint64_t)grid * 4;
-    uint64_t et = lanes ? 1024 : 64;   // the lanes form writes whole runs (<= VH_PART_TILE tuples) that must fit a fresh extent
+    uint64_t et = 1024;                // a tile writes whole runs (<= VH_PART_TILE tuples) that must fit a fresh extent
     while (et < 4096 && et * 2 <= part_tuple_cap / (waves * P.npart) / 2) et *= 2;
-    P.ext_flushes = P.stage_cap ? (int32_t)std::max<uint64_t>(1, et / P.stage_cap) : 1;
-    const uint64_t ext_tuples = P.stage_cap ? (uint64_t)P.ext_flushes * P.stage_cap : et;
+    const uint64_t ext_tuples = et;
     P.ext_tuples = (int32_t)ext_tuples;
     uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
     if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
+    if (!part_tuples_override && getenv("VH_TEST_PART_EXTENTS")) max_ext = std::max(1, atoi(getenv("VH_TEST_PART_EXTENTS")));   // tests: make the first attempt run out of extents
     P.max_extents = (uint32_t)max_ext;
     P.part_cap = 0;                                           // extents carry their partition as a tag: no per-partition lists
     o_tuples = sp.take(max_ext * ext_tuples * P.tw * 8);
@@ -1549,13 +1672,13 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     P.dset_mask[b] = cap - 1;
     if (P.bs_wide[b]) { o_dkeys[b] = sp.take(cap * 16); o_dtags[b] = sp.take(cap * 4); }
     else {
-      if (table_n >= 0xFFFFFFFFull) { delete r; return vh_fail(VH_E_UNSUPPORTED, "count-distinct over more than 2^32 group slots"); }
+      if (table_n >= 0xFFFFFFFFull) { return vh_fail(VH_E_UNSUPPORTED, "count-distinct over more than 2^32 group slots"); }
       o_dkeys[b] = sp.take(cap * 8);
     }
   }
-  rc = ensure_scratch(t, sp.off);
-  if (rc) { delete r; return rc; }
-  char* S = t->scratch;
+  rc = ensure_scratch(x, sp.off);
+  if (rc) { return rc; }
+  char* S = x->scratch;
   P.counters = reinterpret_cast<unsigned long long*>(S + o_counters);
   P.seg_rows = reinterpret_cast<const uint32_t*>(S + o_segrows);
   if (mode == VH_MODE_HASH) {
@@ -1595,12 +1718,11 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     for (int j = 0; j < P.nmetric; ++j) r->d_out_state2[j] = S + o_ostate2[j];
   }
 
-  P.debug = getenv("VH_DEBUG") ? (uint32_t)atoi(getenv("VH_DEBUG")) : 0u;
   // ---------------- init + launch
-  hipStream_t st = g_ctx.stream;
-  HIP_TRY(hipEventRecord(t->ev[0], st));
+  hipStream_t st = x->stream();
+  HIP_TRY(hipEventRecord(x->ev[0], st));
   HIP_TRY(hipMemsetAsync(P.counters, 0, 512, st));   // counters + out_count (adjacent 256 B slots)
-  if (nseg) HIP_TRY(hipMemcpyAsync(S + o_segrows, t->h_segrows, nseg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  if (nseg) HIP_TRY(hipMemcpyAsync(S + o_segrows, x->h_segrows, nseg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   if (mode == VH_MODE_HASH) {
     if (P.hrec_bytes) {          // records: empty key + the metrics' identities, one template for every slot
       VhRecordTemplate T{};
@@ -1629,9 +1751,9 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
   for (int j = 0; j < P.nmetric; ++j) {
     if (P.m[j].ident == 0 || P.hrec_bytes) continue;
     rc = fill_states(P.m[j].state, table_n, vh_sop_bytes(P.m[j].sop()), P.m[j].ident, st);
-    if (rc) { delete r; return rc; }
+    if (rc) { return rc; }
   }
-  HIP_TRY(hipEventRecord(t->ev[1], st));
+  HIP_TRY(hipEventRecord(x->ev[1], st));
   r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0);
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
@@ -1640,7 +1762,7 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
       vh_launch_part_agg(P, bpp, lds_table, st);
     }
   }
-  HIP_TRY(hipEventRecord(t->ev[2], st));
+  HIP_TRY(hipEventRecord(x->ev[2], st));
   HIP_TRY(hipGetLastError());
   if (mode != VH_MODE_HASH && nxcd > 1) {
     VhMergeArgs A{};
@@ -1650,13 +1772,12 @@ static int query_launch_locked(vh_table* t, const vh_plan* p, vh_result** out, u
     hipLaunchKernelGGL(dense_merge_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, A);
     HIP_TRY(hipGetLastError());
   }
-  *out = r;
+  *out = holder.release();
   return VH_OK;
 }
 
 extern "C" int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs, int32_t max_bufs, int32_t* nbufs) {
   if (!r || !bufs || !nbufs) return vh_fail(VH_E_INVALID, "null argument");
-  if (int rc = check_device_state(r, "vh_result_device_buffers")) return rc;
   if (r->plan.nbitset) return vh_fail(VH_E_UNSUPPORTED, "count-distinct partials are cardinalities: they cannot be reduced across GPUs");
   if (r->mode == VH_MODE_HASH) return vh_fail(VH_E_UNSUPPORTED, "hash-path partials are exchanged by key, not reduced in place");
   const VhPlanDev& P = r->plan;
@@ -1714,11 +1835,9 @@ extern "C" int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part
   if (nparts == 0 || nparts > 64) return vh_fail(VH_E_INVALID, "nparts must be 1..64");
   if (r->nhaving) return vh_fail(VH_E_UNSUPPORTED, "HAVING applies to merged groups: run the partial query without it");
   if (r->topk) return vh_fail(VH_E_UNSUPPORTED, "top-N applies to merged groups: run the partial query without it");
-  std::lock_guard<std::mutex> lk(r->table->mu);
-  if (int rc = check_device_state(r, "vh_result_partition")) return rc;
-  if (int rc = check_host_view(r, "vh_result_partition")) return rc;   // small dense results were emitted straight into host staging
+  VH_ENTER();
   const VhPlanDev& P = r->plan;
-  hipStream_t st = g_ctx.stream;
+  hipStream_t st = r->exec->stream();
   const uint64_t ng = r->ngroups_host;
   const int ncols = P.ngroup + P.nmetric;
   if (max_bufs < ncols) return vh_fail(VH_E_INVALID, "need %d buffers", ncols);
@@ -1797,10 +1916,8 @@ extern "C" int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t 
   const int b = (int)P.m[dj].slot();
   if (max_bufs < P.ngroup + 1) return vh_fail(VH_E_INVALID, "need %d buffers", P.ngroup + 1);
   if (r->mode != VH_MODE_HASH && r->nxcd != 1) return vh_fail(VH_E_UNSUPPORTED, "pairs of an XCD-private dense table");
-  std::lock_guard<std::mutex> lk(r->table->mu);
-  if (int rc = check_device_state(r, "vh_result_partition_pairs")) return rc;
-  if (int rc = check_host_view(r, "vh_result_partition_pairs")) return rc;
-  hipStream_t st = g_ctx.stream;
+  VH_ENTER();
+  hipStream_t st = r->exec->stream();
   // number of pairs = sum of the emitted cardinalities would need a reduction; the set's fill count is counters[4],
   // read back with the result header (h_base): every pair bumps it exactly once
   const uint64_t npairs = reinterpret_cast<const unsigned long long*>(r->h_base)[4];
@@ -1864,31 +1981,33 @@ static hipError_t wait_event_spinning(hipEvent_t ev) {
 }
 
 // returns VH_OK, or a positive "retry" request: 1 = grow hash table, 2 = fall back to hash
-static int result_finalize_locked(vh_result* r, int* retry) {
-  vh_table* t = r->table;
+static int result_finalize(vh_result* r, int* retry) {
+  VhExec* x = r->exec;   // staging buffers, scratch and events of this query's context
   const VhPlanDev& P = r->plan;
-  hipStream_t st = g_ctx.stream;
+  hipStream_t st = x->stream();
   *retry = 0;
-  // pinned staging buffer (two alternate, so a result stays readable while the next query runs)
-  const int slot = t->h_out_next; t->h_out_next ^= 1;
-  if (t->h_out_bytes[slot] < r->out_region_bytes) {
-    if (t->h_out[slot]) HIP_TRY(hipHostFree(t->h_out[slot]));
-    t->h_out[slot] = nullptr; t->h_out_bytes[slot] = 0;
+  // pinned staging buffer (two alternate per context: a zero-copy view stays readable after vh_result_free until the
+  // second-next query); a re-planned attempt of the same query reuses its slot
+  const int slot = r->h_slot >= 0 ? r->h_slot : (x->h_out_next ^= 1);
+  r->h_slot = slot;
+  if (x->h_out_bytes[slot] < r->out_region_bytes) {
+    if (x->h_out[slot]) HIP_TRY(hipHostFree(x->h_out[slot]));
+    x->h_out[slot] = nullptr; x->h_out_bytes[slot] = 0;
     const size_t nb = std::max<size_t>(r->out_region_bytes + r->out_region_bytes / 4, 1 << 20);
     // coherent (fine-grained): the emission kernel writes small results straight into this buffer, and the host must see
     // them when the event behind the kernel has completed, whatever HIP_HOST_COHERENT says
-    HIP_TRY(hipHostMalloc((void**)&t->h_out[slot], nb, hipHostMallocCoherent));
-    t->h_out_bytes[slot] = nb;
+    HIP_TRY(hipHostMalloc((void**)&x->h_out[slot], nb, hipHostMallocCoherent));
+    x->h_out_bytes[slot] = nb;
   }
   // Small results of the dense paths are written by the emission kernel straight into that pinned host buffer
   // (posted PCIe writes, coalesced per column) and a one-wave kernel publishes the 512-byte header behind them: no
   // DMA-engine copy at the end of the query (its start-up costs 20-100 us, more than the 2 MB it moves).
   static const bool env_no_direct = getenv("VH_NO_DIRECT_EMIT") != nullptr;
   const bool one_shot = r->out_region_bytes <= (8u << 20) && !r->topk_active;
-  const bool direct = one_shot && r->mode != VH_MODE_HASH && !env_no_direct;
+  const bool direct = one_shot && r->mode != VH_MODE_HASH && !env_no_direct && !r->device_rows;
   if (direct) {
-    for (int i = 0; i < P.ngroup; ++i) r->d_out_key[i] = t->h_out[slot] + r->off_key[i];
-    for (int j = 0; j < P.nmetric; ++j) r->d_out_state[j] = t->h_out[slot] + r->off_state[j];
+    for (int i = 0; i < P.ngroup; ++i) r->d_out_key[i] = x->h_out[slot] + r->off_key[i];
+    for (int j = 0; j < P.nmetric; ++j) r->d_out_state[j] = x->h_out[slot] + r->off_state[j];
   }
   VhEmitArgs A{};
   A.mode = r->mode == VH_MODE_DENSE_PART ? VH_MODE_DENSE_GLOBAL : r->mode; A.ngroup = P.ngroup; A.nmetric = P.nmetric; A.key_words = P.key_words;
@@ -1938,8 +2057,8 @@ static int result_finalize_locked(vh_result* r, int* retry) {
                        (const uint64_t*)r->d_topk_keys, (const unsigned long long*)r->d_out_count, (unsigned long long)r->topk, r->d_topk_state);
     HIP_TRY(hipGetLastError());
   }
-  char* H = t->h_out[slot];
-  const char* D = t->scratch + r->out_region_off;
+  char* H = x->h_out[slot];
+  const char* D = x->scratch + r->out_region_off;
   VhTopkState tk{};
   if (r->topk_active) HIP_TRY(hipMemcpyAsync(&tk, r->d_topk_state, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   // small results: counters, group count and every output array come back in ONE copy + ONE sync
@@ -1950,8 +2069,8 @@ static int result_finalize_locked(vh_result* r, int* retry) {
   } else {
     HIP_TRY(hipMemcpyAsync(H, D, one_shot ? r->out_region_bytes : 512, hipMemcpyDeviceToHost, st));
   }
-  HIP_TRY(hipEventRecord(t->ev[3], st));
-  HIP_TRY(wait_event_spinning(t->ev[3]));
+  HIP_TRY(hipEventRecord(x->ev[3], st));
+  HIP_TRY(wait_event_spinning(x->ev[3]));
   const unsigned long long* hc = reinterpret_cast<const unsigned long long*>(H);
   const unsigned long long err = hc[2];
   if (err & VH_ERR_HASH_FULL) { *retry = 1; return VH_OK; }
@@ -1973,81 +2092,102 @@ static int result_finalize_locked(vh_result* r, int* retry) {
                              ng * vh_elem_size(r->metric_elem[j]), hipMemcpyDeviceToHost, st));
   }
   if (!one_shot) {
-    HIP_TRY(hipEventRecord(t->ev[3], st));
-    HIP_TRY(wait_event_spinning(t->ev[3]));
+    HIP_TRY(hipEventRecord(x->ev[3], st));
+    HIP_TRY(wait_event_spinning(x->ev[3]));
   }
   float ms = 0;
-  (void)hipEventElapsedTime(&ms, t->ev[1], t->ev[2]); r->info.scan_kernel_ms = ms;
-  (void)hipEventElapsedTime(&ms, t->ev[0], t->ev[3]); r->info.total_ms = ms;
+  (void)hipEventElapsedTime(&ms, x->ev[1], x->ev[2]); r->info.scan_kernel_ms = ms;
+  (void)hipEventElapsedTime(&ms, x->ev[0], x->ev[3]); r->info.total_ms = ms;
   if (getenv("VH_TIMES")) {   // where a query's device time goes: setup (clears, uploads) | scan | emission + read-back
     float a = 0, b = 0;
-    (void)hipEventElapsedTime(&a, t->ev[0], t->ev[1]); (void)hipEventElapsedTime(&b, t->ev[2], t->ev[3]);
+    (void)hipEventElapsedTime(&a, x->ev[0], x->ev[1]); (void)hipEventElapsedTime(&b, x->ev[2], x->ev[3]);
     fprintf(stderr, "vh times: setup %.3f ms, scan %.3f ms, emit+readback %.3f ms (groups %llu, returned %llu)\n", a, r->info.scan_kernel_ms, b,
             (unsigned long long)r->info.ngroups, (unsigned long long)r->info.returned_groups);
   }
   r->finalized = true;
-  r->staged_seq = ++t->staged_seq;
   return VH_OK;
 }
 
 extern "C" int vh_query_launch(vh_table* t, const vh_plan* plan, vh_result** out) {
   if (!t || !plan || !out) return vh_fail(VH_E_INVALID, "null argument");
-  std::lock_guard<std::mutex> lk(t->mu);
-  return query_launch_locked(t, plan, out, 0, false);
+  VH_ENTER();
+  VhExec* x = nullptr;
+  if (int rc = exec_acquire(t, &x)) return rc;
+  vh_result* r = nullptr;
+  int rc;
+  { std::lock_guard<std::mutex> lk(t->mu); rc = query_launch_locked(t, x, plan, &r, 0, false); }
+  if (rc) { (void)hipStreamSynchronize(x->stream()); exec_release(t, x); return rc; }
+  r->exec = x;
+  *out = r;
+  return VH_OK;
 }
 
 extern "C" int vh_result_finalize(vh_result* r) {
   if (!r) return vh_fail(VH_E_INVALID, "null result");
   if (r->finalized) return VH_OK;
-  std::lock_guard<std::mutex> lk(r->table->mu);
-  if (int rc = check_device_state(r, "vh_result_finalize")) return rc;
+  VH_ENTER();
   int retry = 0;
-  int rc = result_finalize_locked(r, &retry);
+  int rc = result_finalize(r, &retry);
   if (rc) return rc;
   if (retry) return vh_fail(VH_E_RANGE, "partial result needs a re-plan (code %d); use vh_query_agg", retry);
   return VH_OK;
 }
 
+// One attempt's verdict -> the overrides of the next one. Shared by vh_query_agg and the sharded form.
+struct VhReplan { uint64_t cap_override = 0, part_override = 0; bool force_hash = false, no_part = false; };
+static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
+  if (retry == 1) {
+    // table too small. The number of groups is bounded by the number of surviving rows: estimate those
+    // once with the selectivity probe and size for them, instead of quadrupling blindly
+    uint64_t next = (r->plan.hmask + 1) * 4;
+    if (!rp->cap_override) {
+      double sel = 1.0;
+      if (r->info.reserved & 1) { std::lock_guard<std::mutex> lk(t->mu); (void)estimate_selectivity(t, r->exec, r->plan, r->plan.nseg, &sel); }
+      uint64_t survivors = (uint64_t)((double)r->info.scanned_recs * std::min(1.0, sel * 1.1)) + 1024;
+      uint64_t sized = 1;
+      while (sized < survivors * 2) sized <<= 1;
+      next = std::max(next, sized);
+    }
+    rp->cap_override = next;
+  }
+  else if (retry == 3) {                                     // tuple extents exhausted: more room, then give up on partitioning
+    const uint64_t had = (uint64_t)r->plan.max_extents * r->plan.ext_tuples;
+    if (rp->part_override && had >= r->info.scanned_recs) rp->no_part = true; else rp->part_override = std::max<uint64_t>(had * 4, 1ull << 16);
+  }
+  else rp->force_hash = true;                                // a digit left its planned range
+}
+
 extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
   if (!t || !plan || !out) return vh_fail(VH_E_INVALID, "null argument");
-  std::lock_guard<std::mutex> lk(t->mu);
-  uint64_t cap_override = 0, part_override = 0;
-  bool force_hash = false, no_part = false;
+  VH_ENTER();
+  VhExec* x = nullptr;
+  if (int rc = exec_acquire(t, &x)) return rc;
+  VhReplan rp;
+  int rc = VH_OK;
   for (uint32_t attempt = 0; attempt < 12; ++attempt) {
     vh_result* r = nullptr;
-    int rc = query_launch_locked(t, plan, &r, cap_override, force_hash, part_override, no_part);
-    if (rc) return rc;
+    // planned and launched under the table lock; the wait for the device and the read-back happen outside it, so
+    // queries of other threads on this table run meanwhile (each on its own context)
+    { std::lock_guard<std::mutex> lk(t->mu); rc = query_launch_locked(t, x, plan, &r, rp.cap_override, rp.force_hash, rp.part_override, rp.no_part); }
+    if (rc) break;
+    r->exec = x;
     int retry = 0;
-    rc = result_finalize_locked(r, &retry);
-    if (rc) { delete r; return rc; }
+    rc = result_finalize(r, &retry);
+    if (rc) { r->exec = nullptr; delete r; break; }
     if (!retry) {
       r->info.retries = attempt;
-      if (r->mode == VH_MODE_HASH) t->groups_seen[r->group_sig] = r->info.ngroups;
+      if (r->mode == VH_MODE_HASH) { std::lock_guard<std::mutex> lk(t->mu); t->groups_seen[r->group_sig] = r->info.ngroups; }
       *out = r;
       return VH_OK;
     }
-    if (retry == 1) {
-      // table too small. The number of groups is bounded by the number of surviving rows: estimate those
-      // once with the selectivity probe and size for them, instead of quadrupling blindly
-      uint64_t next = (r->plan.hmask + 1) * 4;
-      if (!cap_override) {
-        double sel = 1.0;
-        if (r->info.reserved & 1) (void)estimate_selectivity(t, r->plan, r->plan.nseg, &sel);
-        uint64_t survivors = (uint64_t)((double)r->info.scanned_recs * std::min(1.0, sel * 1.1)) + 1024;
-        uint64_t sized = 1;
-        while (sized < survivors * 2) sized <<= 1;
-        next = std::max(next, sized);
-      }
-      cap_override = next;
-    }
-    else if (retry == 3) {                                     // tuple extents exhausted: more room, then give up on partitioning
-      const uint64_t had = (uint64_t)r->plan.max_extents * r->plan.ext_tuples;
-      if (part_override && had >= r->info.scanned_recs) no_part = true; else part_override = had * 4;
-    }
-    else force_hash = true;                                    // a digit left its planned range
+    replan_after(t, r, retry, &rp);
+    r->exec = nullptr;                                       // the next attempt runs on the same context
     delete r;
+    rc = vh_fail(VH_E_NOMEM, "aggregate table kept overflowing");
   }
-  return vh_fail(VH_E_NOMEM, "aggregate table kept overflowing");
+  (void)hipStreamSynchronize(x->stream());
+  exec_release(t, x);
+  return rc;
 }
 
 // ----------------------------------------------------------------- select (ordered row emission)
@@ -2060,7 +2200,7 @@ struct vh_rows {
   ~vh_rows() { if (d_out) (void)hipFree(d_out); if (h_out) (void)hipHostFree(h_out); }
 };
 
-extern "C" void vh_rows_free(vh_rows* r) { delete r; }
+extern "C" void vh_rows_free(vh_rows* r) { if (r) { VH_ENTER(); delete r; } }
 
 extern "C" int vh_rows_get_info(vh_rows* r, vh_rows_info* info) {
   if (!r || !info) return vh_fail(VH_E_INVALID, "null argument");
@@ -2077,6 +2217,11 @@ extern "C" int vh_rows_view(vh_rows* r, const void** cols) {
 extern "C" int vh_query_select(vh_table* t, const vh_select_plan* sp, vh_rows** out) {
   if (!t || !sp || !out) return vh_fail(VH_E_INVALID, "null argument");
   if (sp->ncols < 0 || sp->ncols > VH_MAX_SELECT) return vh_fail(VH_E_UNSUPPORTED, "%d selected columns (max %d)", sp->ncols, VH_MAX_SELECT);
+  VH_ENTER();
+  VhExec* x = nullptr;
+  if (int rc = exec_acquire(t, &x)) return rc;
+  struct Release { vh_table* t; VhExec* x; ~Release() { (void)hipStreamSynchronize(x->stream()); exec_release(t, x); } } release{t, x};
+  // select launches twice with a host decision in between: it keeps the table lock throughout (not the hot path)
   std::lock_guard<std::mutex> lk(t->mu);
   const int ncols_t = (int)t->cols.size();
   for (int c = 0; c < sp->ncols; ++c)
@@ -2085,12 +2230,12 @@ extern "C" int vh_query_select(vh_table* t, const vh_select_plan* sp, vh_rows** 
   p.filter = sp->filter; p.nfilter = sp->nfilter; p.lits = sp->lits; p.nlits = sp->nlits;
   p.seg_rows = sp->seg_rows; p.nseg = sp->nseg; p.flags = sp->flags;
   vh_result* pr = nullptr;
-  int rc = query_launch_locked(t, &p, &pr, 0, false, 0, false, true);
+  int rc = query_launch_locked(t, x, &p, &pr, 0, false, 0, false, true);
   if (rc) return rc;
   std::unique_ptr<vh_result> plan_holder(pr);
   VhPlanDev P = pr->plan;
   const uint32_t nseg = P.nseg;
-  hipStream_t st = g_ctx.stream;
+  hipStream_t st = x->stream();
   std::unique_ptr<vh_rows> rows(new vh_rows());
   rows->info.scanned_recs = pr->info.scanned_recs;
   rows->info.scanned_segments = pr->info.scanned_segments;
@@ -2106,18 +2251,18 @@ extern "C" int vh_query_select(vh_table* t, const vh_select_plan* sp, vh_rows** 
                o_sel = spn.take(sizeof(VhSelectDev));
   size_t o_bs[VH_MAX_SELECT] = {};
   for (int c = 0; c < sp->ncols; ++c) if (is_bitset_elem(t->cols[sp->cols[c]].elem)) o_bs[c] = spn.take((size_t)nseg * 8);
-  rc = ensure_scratch(t, spn.off);
+  rc = ensure_scratch(x, spn.off);
   if (rc) return rc;
-  char* S = t->scratch;
-  HIP_TRY(hipEventRecord(t->ev[0], st));
+  char* S = x->scratch;
+  HIP_TRY(hipEventRecord(x->ev[0], st));
   HIP_TRY(hipMemsetAsync(S + o_ctr, 0, 256, st));
-  HIP_TRY(hipMemcpyAsync(S + o_segrows, t->h_segrows, (size_t)nseg * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S + o_segrows, x->h_segrows, (size_t)nseg * 4, hipMemcpyHostToDevice, st));
   P.seg_rows = reinterpret_cast<const uint32_t*>(S + o_segrows);
   P.counters = reinterpret_cast<unsigned long long*>(S + o_ctr);
   uint32_t* d_counts = reinterpret_cast<uint32_t*>(S + o_counts);
   unsigned long long* d_totals = reinterpret_cast<unsigned long long*>(S + o_totals);
   const unsigned grid = (unsigned)std::min<uint64_t>((nchunks + 3) / 4, (uint64_t)g_ctx.num_cu * 8);
-  HIP_TRY(hipEventRecord(t->ev[1], st));
+  HIP_TRY(hipEventRecord(x->ev[1], st));
   hipLaunchKernelGGL(select_count_kernel, dim3(grid), dim3(256), 0, st, P, cps, d_counts);
   hipLaunchKernelGGL(select_scan_kernel, dim3(nseg), dim3(256), 0, st, d_counts, cps, d_totals);
   HIP_TRY(hipGetLastError());
@@ -2160,7 +2305,7 @@ extern "C" int vh_query_select(vh_table* t, const vh_select_plan* sp, vh_rows** 
       D.out[c] = rows->d_out + rows->off[c];
       if (is_bitset_elem(col.elem)) {
         for (uint32_t s = 0; s < nseg; ++s)
-          if (t->h_segrows[s] && !col.bs_offsets[s]) return vh_fail(VH_E_INVALID, "bitset column %d of segment %u was never synced", sp->cols[c], s);
+          if (x->h_segrows[s] && !col.bs_offsets[s]) return vh_fail(VH_E_INVALID, "bitset column %d of segment %u was never synced", sp->cols[c], s);
         HIP_TRY(hipMemcpyAsync(S + o_bs[c], col.bs_offsets.data(), (size_t)nseg * 8, hipMemcpyHostToDevice, st));
         D.base[c] = nullptr; D.bs_offs[c] = reinterpret_cast<const uint64_t* const*>(S + o_bs[c]);
       } else { D.base[c] = col.base; D.stride[c] = col.stride; }
@@ -2170,22 +2315,23 @@ extern "C" int vh_query_select(vh_table* t, const vh_select_plan* sp, vh_rows** 
     hipLaunchKernelGGL(select_emit_kernel, dim3(grid), dim3(256), 0, st, P, cps, (const uint32_t*)d_counts,
                        reinterpret_cast<const VhSelectWindow*>(S + o_win), reinterpret_cast<const VhSelectDev*>(S + o_sel));
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(t->ev[2], st));
+    HIP_TRY(hipEventRecord(x->ev[2], st));
     if (bytes) HIP_TRY(hipMemcpyAsync(rows->h_out, rows->d_out, bytes, hipMemcpyDeviceToHost, st));
   } else {
-    HIP_TRY(hipEventRecord(t->ev[2], st));
+    HIP_TRY(hipEventRecord(x->ev[2], st));
   }
-  HIP_TRY(hipEventRecord(t->ev[3], st));
+  HIP_TRY(hipEventRecord(x->ev[3], st));
   HIP_TRY(hipStreamSynchronize(st));   // D and win live on this frame
   float ms = 0;
-  (void)hipEventElapsedTime(&ms, t->ev[1], t->ev[2]); rows->info.kernel_ms = ms;
-  (void)hipEventElapsedTime(&ms, t->ev[0], t->ev[3]); rows->info.total_ms = ms;
+  (void)hipEventElapsedTime(&ms, x->ev[1], x->ev[2]); rows->info.kernel_ms = ms;
+  (void)hipEventElapsedTime(&ms, x->ev[0], x->ev[3]); rows->info.total_ms = ms;
   *out = rows.release();
   return VH_OK;
 }
 
 extern "C" int vh_measure_read_bandwidth(uint64_t bytes, int32_t iters, double* bytes_per_sec) {
   if (!g_ctx.inited || !bytes_per_sec || iters <= 0) return vh_fail(VH_E_INVALID, "bad argument");
+  VH_ENTER();
   bytes = bytes / 16 * 16;
   char* buf = nullptr; unsigned long long* sink = nullptr;
   HIP_TRY(hipMalloc(&buf, bytes));
@@ -2208,3 +2354,5 @@ extern "C" int vh_measure_read_bandwidth(uint64_t bytes, int32_t iters, double* 
   (void)hipFree(buf); (void)hipFree(sink);
   return VH_OK;
 }
+
+#include "vh_sharded.h"

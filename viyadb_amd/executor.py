@@ -9,7 +9,6 @@ produces (src/codegen/query/agg_query.cc:26-75): a table of SoA segments in, a s
 from __future__ import annotations
 
 import ctypes as C
-import threading
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -80,6 +79,7 @@ class AggResult:
     lanes: bool = False            # the no-compaction variant of the fast kernel ran
     packed: bool = False           # group / metric values were gathered from a payload projection (vh_table_pack)
     returned: int = 0              # rows delivered (= ngroups unless a HAVING was pushed down)
+    kernel: str = ""               # symbol(s) of the scan kernel(s) that ran, as rocprofv3 prints them
 
 
 
@@ -95,10 +95,9 @@ class DeviceTable:
         h = C.c_void_p()
         capi.check(self.lib.vh_table_create(arr, len(self.cols), self.segment_rows, int(reserve_segments), C.byref(h)))
         self.handle = h
-        # a result's host view aliases one of the table's two staging buffers (valid until the second-next query on the
-        # table): query + collect is one critical section per table when threads share a DeviceTable, as the C++ host
-        # shim does with Table::mu
-        self._lock = threading.RLock()
+        # a vh_result owns its execution context (stream, device scratch, pinned staging) until vh_result_free: threads
+        # that share a DeviceTable need no lock of their own. copy=False views alias the context's staging buffer and
+        # outlive the free only until the second-next query that takes the same context: single-threaded callers only.
 
     def close(self):
         if self.handle:
@@ -297,17 +296,16 @@ class DeviceTable:
         return AggResult(keys, states, hidden, int(info.ngroups), int(info.scanned_recs), int(info.scanned_segments),
                          int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
                          float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1),
-                         bool(info.reserved & 2), bool(info.reserved & 8), int(ng))
+                         bool(info.reserved & 2), bool(info.reserved & 8), int(ng), (self.lib.vh_result_kernel(res) or b"").decode())
 
     def query_agg(self, plan: AggPlan, copy: bool = True) -> AggResult:
         p, keep = self._build_plan(plan)
         res = C.c_void_p()
-        with self._lock:
-            capi.check(self.lib.vh_query_agg(self.handle, C.byref(p), C.byref(res)))
-            try:
-                return self._collect(res, plan, copy)
-            finally:
-                self.lib.vh_result_free(res)
+        capi.check(self.lib.vh_query_agg(self.handle, C.byref(p), C.byref(res)))
+        try:
+            return self._collect(res, plan, copy)
+        finally:
+            self.lib.vh_result_free(res)
 
     # ---- select: the passing rows themselves, in storage order, through the reference's skip/limit window
     def query_select(self, filter: Sequence, cols: Sequence[int], skip: int = 0, limit: int = 0,

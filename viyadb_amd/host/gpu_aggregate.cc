@@ -231,6 +231,40 @@ void FetchGroups(vh_result* res, AggregateQuery& query, Groups& groups, QuerySta
 
 }  // namespace detail
 
+namespace detail {
+// The body of GpuAggregate on a mirror that is already up to date: plan -> vh_query_agg -> typed groups.
+void AggregateOnMirror(AggregateQuery& query, vh_table* mirror, const std::vector<uint64_t>& seg_rows, bool having_on_device,
+                       const std::vector<db::AnyNum>& fargs, const std::vector<db::AnyNum>& hargs, size_t skip, size_t limit,
+                       int64_t now, Groups& groups, QueryStats& stats) {
+  db::Table& table = query.table();
+  PlanFilterBuilder fb(table, fargs);
+  query.filter()->Accept(fb);
+  std::vector<vh_group_col> gcols = PlanGroupCols(query, now);
+  std::vector<int32_t> mcols;
+  for (auto& mc : query.metric_cols()) mcols.push_back((int32_t)mc.metric()->storage_index);
+
+  PlanHavingBuilder hb(query, hargs, fb.lits);
+  if (having_on_device) query.having()->Accept(hb);
+
+  vh_plan plan;
+  memset(&plan, 0, sizeof(plan));
+  plan.filter = fb.nodes.data(); plan.nfilter = (int32_t)fb.nodes.size();
+  plan.lits = fb.lits.data(); plan.nlits = (int32_t)fb.lits.size();
+  plan.having = hb.nodes.empty() ? nullptr : hb.nodes.data(); plan.nhaving = (int32_t)hb.nodes.size();
+  plan.groups = gcols.data(); plan.ngroups = (int32_t)gcols.size();
+  plan.metrics = mcols.data(); plan.nmetrics = (int32_t)mcols.size();
+  plan.seg_rows = seg_rows.data(); plan.nseg = (uint32_t)seg_rows.size();
+  const char* force = getenv("VIYA_HIP_PLAN_FLAGS");
+  plan.flags = force ? (uint32_t)atoi(force) : 0;
+  ConfigureTopN(query, skip, limit, having_on_device, plan);
+
+  vh_result* res = nullptr;
+  vh_check(vh_query_agg(mirror, &plan, &res));
+  std::unique_ptr<vh_result, void (*)(vh_result*)> guard(res, vh_result_free);
+  FetchGroups(res, query, groups, stats);
+}
+}  // namespace detail
+
 void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, std::vector<db::AnyNum> fargs,
                   size_t skip, size_t limit, std::vector<db::AnyNum> hargs, int64_t now) {
   db::Table& table = query.table();
@@ -240,32 +274,7 @@ void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, s
     std::lock_guard<std::mutex> lk(table.mu);
     GpuMirror* mir = ensure_mirror(table);
     std::vector<uint64_t> seg_rows = sync_mirror(table, mir);  // segments_copy() + size() snapshot
-
-    PlanFilterBuilder fb(table, fargs);
-    query.filter()->Accept(fb);
-    std::vector<vh_group_col> gcols = PlanGroupCols(query, now);
-    std::vector<int32_t> mcols;
-    for (auto& mc : query.metric_cols()) mcols.push_back((int32_t)mc.metric()->storage_index);
-
-    PlanHavingBuilder hb(query, hargs, fb.lits);
-    if (having_on_device) query.having()->Accept(hb);
-
-    vh_plan plan;
-    memset(&plan, 0, sizeof(plan));
-    plan.filter = fb.nodes.data(); plan.nfilter = (int32_t)fb.nodes.size();
-    plan.lits = fb.lits.data(); plan.nlits = (int32_t)fb.lits.size();
-    plan.having = hb.nodes.empty() ? nullptr : hb.nodes.data(); plan.nhaving = (int32_t)hb.nodes.size();
-    plan.groups = gcols.data(); plan.ngroups = (int32_t)gcols.size();
-    plan.metrics = mcols.data(); plan.nmetrics = (int32_t)mcols.size();
-    plan.seg_rows = seg_rows.data(); plan.nseg = (uint32_t)seg_rows.size();
-    const char* force = getenv("VIYA_HIP_PLAN_FLAGS");
-    plan.flags = force ? (uint32_t)atoi(force) : 0;
-    ConfigureTopN(query, skip, limit, having_on_device, plan);
-
-    vh_result* res = nullptr;
-    vh_check(vh_query_agg(mir->handle, &plan, &res));
-    std::unique_ptr<vh_result, void (*)(vh_result*)> guard(res, vh_result_free);
-    FetchGroups(res, query, groups, stats);
+    AggregateOnMirror(query, mir->handle, seg_rows, having_on_device, fargs, hargs, skip, limit, now, groups, stats);
   }
   PostAggregate(query, groups, having_on_device, hargs, skip, limit, output, stats);
 }
