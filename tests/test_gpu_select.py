@@ -84,3 +84,25 @@ def test_select_full_size_properties():
         assert info2.kernel_ms < 50
     finally:
         dt.close()
+
+
+def test_select_with_a_bitset_cardinality_predicate():
+    """C5 rows whose count-distinct set holds exactly two ids (filter.cc:216: `tuple_metrics._j[idx].cardinality() == farg`):
+    the synthetic generator draws two ids per row, equal now and then."""
+    w = synth.WORKLOADS["C5"](segment_rows=4000)
+    dt = synth.create_device_table(w, 3, 4000, 0, 42)
+    try:
+        ot = build_oracle_table(w, 3, 4000, 0, 42)
+        users = w.col("users")
+        from viyadb_amd.executor import anynum
+        for filt, q in (([("rel", users, capi.OP_EQ, anynum(capi.U32, 2))], {"op": "eq", "column": "users", "value": "2"}),
+                        ([("rel", users, capi.OP_GE, anynum(capi.U32, 2)), ("rel", w.col("u"), capi.OP_LT, 500000), ("and", 2)],
+                         {"op": "and", "filters": [{"op": "ge", "column": "users", "value": "2"}, {"op": "lt", "column": "u", "value": "500000"}]})):
+            cols = [w.col("u"), users]
+            got, info = dt.query_select(filt, cols, skip=3, limit=500)
+            want, stats = oracle_select(ot, dict(w.query, filter=q), cols, 3, 500)
+            assert info.nrows == stats["output_recs"] and info.passed_recs == stats["passed_recs"] and info.nrows > 0
+            for a, b in zip(got, want):
+                assert np.array_equal(a, b.astype(a.dtype))
+    finally:
+        dt.close()

@@ -102,4 +102,4 @@ def test_session_api_matches_the_database_path(tmp_path):
         want = [[e, c, ("%.15g" % rev), str(cnt), str(b)] for e, c, rev, cnt, b in rows[:7]]
         assert r["rows"] == want, (k, r["rows"][:3], want[:3])
         assert r["stats"][0] == 2 and r["stats"][1] == len(r["data"]) and r["stats"][2] == len(agg) and r["stats"][3] == len(want)
-    assert any(row[1] == "AZ" for row in rounds[1]["data"])
+    assert any(row[0] == "AZ" for row in rounds[1]["data"])

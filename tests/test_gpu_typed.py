@@ -326,6 +326,12 @@ def test_count_distinct(wide, flags):
     try:
         run(tab, dt, {"dimensions": ["c"], "metrics": ["users", "count"], "filter": F("lt", "x", "60")}, flags=flags)
         run(tab, dt, {"dimensions": [], "metrics": ["users"]}, flags=flags)
+        # the bitset metric in the FILTER: the predicate compares the row's own cardinality (filter.cc:216,235)
+        res, st = run(tab, dt, {"dimensions": ["c"], "metrics": ["users", "count"], "filter": F("ge", "users", "2")}, flags=flags)
+        assert 0 < st.passed_recs < st.scanned_recs
+        run(tab, dt, {"dimensions": ["c"], "metrics": ["count"],
+                      "filter": {"op": "and", "filters": [{"op": "in", "column": "users", "values": ["1", "3"]}, F("lt", "x", "80")]}}, flags=flags)
+        run(tab, dt, {"dimensions": ["c"], "metrics": ["count"], "filter": {"op": "not", "filter": {"op": "in", "column": "users", "values": ["0", "2"]}}}, flags=flags)
     finally:
         dt.close()
 
@@ -512,3 +518,26 @@ def test_result_handles_own_their_state(typed):
     assert lib.vh_table_create(bad, 1, 1000, 1, C.byref(h)) == -1
     with pytest.raises(capi.VhError, match="out of range"):
         dt.sync_segment(1 << 30, [None] * len(dt.cols), 0)
+
+
+def test_limits_the_reference_does_not_have(typed):
+    """IN lists of hundreds of values (one comparison per value in the reference, filter.cc:223-241), more group columns
+    and more metrics than one pass of the kernels carries: answers, not VH_E_UNSUPPORTED."""
+    tab, dt = typed
+    vals = [str(v) for v in range(-60, 61, 2)] + [str(1000 + v) for v in range(600)]
+    for flags in (0, 8, 1):
+        res, st = run(tab, dt, {"dimensions": ["s8"], "metrics": ["count", "long_sum"], "filter": {"op": "in", "column": "d_int", "values": vals}}, flags=flags)
+        assert 0 < st.passed_recs < st.scanned_recs
+        run(tab, dt, {"dimensions": ["flag"], "metrics": ["count"],
+                      "filter": {"op": "and", "filters": [{"op": "not", "filter": {"op": "in", "column": "d_uint", "values": vals}}, F("lt", "d_long", "30")]}}, flags=flags)
+    run(tab, dt, {"dimensions": ["s8"], "metrics": ["count"], "filter": {"op": "or", "filters": [F("eq", "d_int", str(v)) for v in range(-60, 60)]}})   # 120 operands, 120 literals
+    # 11 group columns (49-byte key), then every metric of the table at once: 41 states per group, several passes joined on the key
+    dims = ["s8", "s16", "flag", "d_ubyte", "d_short", "d_ushort", "d_int", "d_uint", "d_float", "d_long", "d_double"]
+    run(tab, dt, {"dimensions": dims, "metrics": ["count", "int_sum"], "filter": F("lt", "d_uint", "12")})
+    allm = ["count"] + [f"{t}_{a}" for t in TYPES for a in ("sum", "min", "max", "avg")]
+    for flags in (0, 1):
+        res, _ = run(tab, dt, {"dimensions": ["s8", "flag"], "metrics": allm, "filter": F("lt", "d_uint", "30")}, flags=flags)
+        assert len(res.states) == 41
+    noc = [m for m in allm if m != "count"][:30]          # AVG without COUNT: the hidden count travels with one of the passes
+    if tab.has_hidden_count:
+        res, _ = run(tab, dt, {"dimensions": ["s8"], "metrics": noc}, flags=0)

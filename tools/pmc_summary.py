@@ -32,21 +32,25 @@ def main():
     ap.add_argument("out")
     ap.add_argument("--rows", type=int, required=True)
     ap.add_argument("--bref", type=float, required=True)
-    ap.add_argument("--kernel", default="scan_agg_fast_kernel<2")
+    ap.add_argument("--kernel", default="scan_agg_fast_kernel<2", help="substring of the kernel symbol; 'a + b' sums the kernels of one query (e.g. bench.py's roofline.kernel)")
     ap.add_argument("--command", default="")
+    ap.add_argument("--head", default="", help="git revision the pass was taken at (bench.py reports it as traffic_head)")
     a = ap.parse_args()
     fetch, write = collect(a.fetch_dir, "FETCH_SIZE"), collect(a.write_dir, "WRITE_SIZE")
-    kname = max((k for k in fetch if a.kernel in k), key=lambda k: fetch[k]["mean_KiB"])
-    fb = fetch[kname]["mean_KiB"] * 1024.0
-    wb = write.get(kname, {"mean_KiB": 0.0})["mean_KiB"] * 1024.0
+    names = []
+    for part in a.kernel.split(" + "):
+        names.append(max((k for k in fetch if part.strip() in k), key=lambda k: fetch[k]["mean_KiB"]))
+    kname = " + ".join(names)
+    fb = sum(fetch[k]["mean_KiB"] for k in names) * 1024.0
+    wb = sum(write.get(k, {"mean_KiB": 0.0})["mean_KiB"] for k in names) * 1024.0
     out = {
         "command": a.command or "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 --no-cpu",
-        "kernel": kname,
+        "kernel": kname, "head": a.head,
         "raw": {"FETCH_SIZE": fetch, "WRITE_SIZE": write},
         "fetch_bytes_raw": fb, "fetch_bytes_corrected_x2": fb * 2, "write_bytes_raw": wb,
         "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming "
-                      "reads -> doubled (the narrow gathers fetch whole 128 B lines too: 12 GB streamed + ~14.6 GB of payload lines "
-                      "matches the line-touch model at 5 % selectivity); WRITE_SIZE uncalibrated (100M atomics ~= 32 B each)",
+                      "reads -> doubled (the narrow gathers fetch whole 128 B lines too: the sum matches the line-touch model of the "
+                      "query); WRITE_SIZE uncalibrated, reported raw",
         "rows": a.rows, "B_ref": a.bref, "B_meas_per_launch": fb * 2,
     }
     json.dump(out, open(a.out, "w"), indent=1)

@@ -1,22 +1,30 @@
 #!/bin/bash
-# One gpurun call that refreshes profiles/<round>/ for the bench workload (C3, 1 GPU):
-#   bench line, rocprofv3 kernel-trace stats of the same command, PMC passes (FETCH_SIZE / WRITE_SIZE separately).
-# usage (on the GPU box, from the repo root): bash tools/profile_round.sh r01
-R=${1:-r01}
+# One gpurun call that refreshes profiles/<round>/ for the bench workloads on 1 GPU: the bench line, rocprofv3 kernel-trace stats of
+# the same command, PMC passes (FETCH_SIZE / WRITE_SIZE in SEPARATE runs, as MI355X_MICROARCH.md prescribes) summed over the kernels
+# the bench line names (roofline.kernel comes from the library: vh_result_kernel).
+# usage (on the GPU box, from the repo root): bash tools/profile_round.sh r02 <git head>
+R=${1:-r02}
+HEAD=${2:-unknown}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
-python bench.py > $OUT/bench_c3_1gpu.json 2> $OUT/bench_c3.err
-tail -c 600 $OUT/bench_c3_1gpu.json
 REPO=$PWD
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/$OUT/kt -o c3 -- python $REPO/bench.py --steps 10 --warmup 2 --no-cpu > $REPO/$OUT/kt.log 2>&1)
-(cd /tmp && rocprofv3 --pmc FETCH_SIZE -d $REPO/$OUT/pmc_fetch -o c3 -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu > $REPO/$OUT/pmc_fetch.log 2>&1)
-(cd /tmp && rocprofv3 --pmc WRITE_SIZE -d $REPO/$OUT/pmc_write -o c3 -- python $REPO/bench.py --steps 3 --warmup 1 --no-cpu > $REPO/$OUT/pmc_write.log 2>&1)
-python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/c3_1gpu_pmc_hbm.json --rows 1000000000 --bref 32e9
-python tools/pmc_summary.py --kernel-stats $(find $OUT/kt -name "*_results.db" | head -1) $OUT/c3_1gpu_kernel_stats.csv; head -4 $OUT/c3_1gpu_kernel_stats.csv
-python bench.py --workload C2 --no-cpu > $OUT/bench_c2_1gpu.json 2>> $OUT/bench_c3.err; tail -c 400 $OUT/bench_c2_1gpu.json
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/$OUT/kt_c2 -o c2 -- python $REPO/bench.py --workload C2 --steps 20 --warmup 2 --no-cpu > $REPO/$OUT/kt_c2.log 2>&1)
-python tools/pmc_summary.py --kernel-stats $(find $OUT/kt_c2 -name "*_results.db" | head -1) $OUT/c2_1gpu_kernel_stats.csv; head -3 $OUT/c2_1gpu_kernel_stats.csv
-(cd /tmp && rocprofv3 --pmc FETCH_SIZE -d $REPO/$OUT/pmc_fetch_c2 -o c2 -- python $REPO/bench.py --workload C2 --steps 3 --warmup 1 --no-cpu > $REPO/$OUT/pmc_fetch_c2.log 2>&1)
-(cd /tmp && rocprofv3 --pmc WRITE_SIZE -d $REPO/$OUT/pmc_write_c2 -o c2 -- python $REPO/bench.py --workload C2 --steps 3 --warmup 1 --no-cpu > $REPO/$OUT/pmc_write_c2.log 2>&1)
-python tools/pmc_summary.py $OUT/pmc_fetch_c2 $OUT/pmc_write_c2 $OUT/c2_1gpu_pmc_hbm.json --rows 100000000 --bref 2e9 --kernel scan_agg_lanes_kernel --command 'rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --workload C2 --steps 3 --warmup 1 --no-cpu'
+one() {   # name, rows, bref, bench args...
+  local W=$1 ROWS=$2 BREF=$3; shift 3
+  python bench.py "$@" > $OUT/bench_${W}_1gpu.json 2> $OUT/bench_${W}.err
+  tail -c 300 $OUT/bench_${W}_1gpu.json; echo
+  local K=$(python -c "import json; print(json.load(open('$OUT/bench_${W}_1gpu.json'))['roofline']['kernel'])")
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/$OUT/kt_$W -o $W -- python $REPO/bench.py "$@" --steps 10 --warmup 2 --no-cpu --no-check > $REPO/$OUT/kt_$W.log 2>&1)
+  python tools/pmc_summary.py --kernel-stats $(find $OUT/kt_$W -name "*_results.db" | head -1) $OUT/${W}_1gpu_kernel_stats.csv; head -4 $OUT/${W}_1gpu_kernel_stats.csv | cut -c1-160
+  for C in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && rocprofv3 --pmc $C -d $REPO/$OUT/pmc_${C}_$W -o $W -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-check > $REPO/$OUT/pmc_${C}_$W.log 2>&1)
+  done
+  python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE_$W $OUT/pmc_WRITE_SIZE_$W $OUT/${W}_1gpu_pmc_hbm.json --rows $ROWS --bref $BREF --kernel "$K" --head $HEAD \
+    --command "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py $* --steps 3 --warmup 1 --no-cpu --no-check"
+}
+one c3 1000000000 32e9
+one c2 100000000 2e9 --workload C2 --no-cpu
+one c5 125000000 3.5e9 --workload C5 --segments 125 --no-cpu --steps 5 --warmup 1
+one c5t 125000000 1.5e9 --workload C5t --segments 125 --no-cpu --steps 5 --warmup 1
+rm -rf $OUT/kt_* $OUT/pmc_FETCH_SIZE_* $OUT/pmc_WRITE_SIZE_*
+ls $OUT

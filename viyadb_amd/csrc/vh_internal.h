@@ -5,11 +5,12 @@
 #include <stdint.h>
 #include "../../include/viya_hip.h"
 
-#define VH_MAX_PROG 48    // postfix nodes per filter
-#define VH_MAX_LITS 96    // literal pool
-#define VH_MAX_GROUP 8    // group-by columns
-#define VH_MAX_METRIC 12  // selected metrics (+ hidden count)
-#define VH_MAX_SLOTS 24   // distinct columns a query may reference
+#define VH_MAX_LITS 65535  // literal pool (VhProgOp::lit is 16 bits)
+#define VH_INLINE_PROG 24  // filter programs up to this size (and VH_INLINE_LITS literals) also travel in the kernel arguments, where the
+#define VH_INLINE_LITS 32  // register-resident kernels read them: loads off the kernarg segment are hoisted out of the scan loop, loads through a pointer are not
+#define VH_MAX_GROUP 16   // group-by columns
+#define VH_MAX_METRIC 20  // selected metrics (+ hidden count)
+#define VH_MAX_SLOTS 32   // distinct columns a query may reference (a payload projection adds one slot per gathered column)
 #define VH_MAX_STACK 8    // predicate mask stack depth
 #define VH_MAX_HAVING 16       // postfix nodes of a pushed-down HAVING
 #define VH_MAX_HAVING_LITS 24
@@ -105,11 +106,14 @@ struct VhMetricDev {
 };
 
 struct VhPlanDev {
-  // ---- filter
+  // ---- filter: postfix program + literal pool, uploaded next to the segment snapshot (uniform addresses: scalar loads, like
+  // kernel arguments, but without their 4 KB ceiling: an IN list may hold thousands of values)
   int32_t nprog;
   int32_t nslots;
-  VhProgOp prog[VH_MAX_PROG];
-  uint64_t lits[VH_MAX_LITS];
+  const VhProgOp* prog;       // generic kernels (scan_agg_kernel, select_*): any length
+  const uint64_t* lits;
+  VhProgOp iprog[VH_INLINE_PROG];   // register-resident kernels (scan_agg_fast_kernel, scan_agg_lanes_kernel): the same program when it fits
+  uint64_t ilits[VH_INLINE_LITS];
   // ---- fast path (all predicate columns 4 bytes wide, <= VH_MAX_PRED of them): their slots
   int32_t npred;
   int32_t pad1;
@@ -160,6 +164,9 @@ struct VhPlanDev {
   int32_t bs_wide[VH_MAX_BITSET];                 // 1: uint64 ids, 0: uint32 ids
   const uint64_t* const* bs_offs[VH_MAX_BITSET];  // [nseg] -> offsets[rows + 1]
   const void* const* bs_vals[VH_MAX_BITSET];      // [nseg] -> ids
+  // a bitset metric in the FILTER: the predicate sees the row's cardinality (filter.cc:216,235) = offsets[r + 1] - offsets[r];
+  // VhProgOp::type() is VH_BITSET32 / VH_BITSET64 and slot() indexes this array
+  const uint64_t* const* fbs_offs[VH_MAX_BITSET]; // [nseg] -> offsets[rows + 1]
   uint64_t* dset_keys[VH_MAX_BITSET];             // narrow ids: (group << 32 | id); wide ids: 2 words per slot
   uint32_t* dset_tags[VH_MAX_BITSET];             // wide ids only
   uint64_t dset_mask[VH_MAX_BITSET];

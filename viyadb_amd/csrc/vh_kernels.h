@@ -172,6 +172,27 @@ __device__ __forceinline__ uint32_t vh_leaf(const VhPlanDev& P, const VhProgOp o
   return m;
 }
 
+// (bitset-metric OP lit): the row's cardinality in the metric's own number type (`tuple_metrics._j[idx].cardinality()`,
+// filter.cc:216,235; util::Bitset<N>::cardinality returns NumType). In the CSR mirror that is offsets[r + 1] - offsets[r].
+template <typename T, bool FULL>
+__device__ __forceinline__ uint32_t vh_leaf_card(const VhPlanDev& P, const VhProgOp o, const uint64_t* offs, uint32_t row_l, uint32_t seg_rows) {
+  T v[VH_LANE_ROWS];
+#pragma unroll
+  for (int k = 0; k < VH_SUBSTEPS; ++k) {
+    const uint32_t r = row_l + k * 256u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[k * 4 + j] = (r + j < seg_rows) ? (T)(offs[r + j + 1] - offs[r + j]) : T(0);   // (rows at or beyond size() are masked off below)
+  }
+  if (o.kind() == VH_F_REL) return vh_cmp16<T>(v, vh_lit<T>(P.lits[o.lit()]), o.op());
+  uint32_t m = o.op() ? 0u : VH_ROWMASK;
+  for (int i = 0; i < o.count(); ++i) {
+    const T lit = vh_lit<T>(P.lits[o.lit() + i]);
+    if (o.op()) m |= vh_cmp16<T>(v, lit, VH_OP_EQ);
+    else m &= vh_cmp16<T>(v, lit, VH_OP_NE);
+  }
+  return m;
+}
+
 // Evaluate the postfix filter program for the 16 rows this lane owns in the current
 // wave step. Returns a 16-bit pass mask (bit k*4+j <-> row k*256 + lane*4 + j).
 // Composites are bitwise AND / OR with no short circuit, exactly like the reference.
@@ -195,6 +216,12 @@ __device__ __forceinline__ uint32_t vh_eval_filter(const VhPlanDev& P, uint32_t 
         st[sp++] = a;
       } break;
       default: {
+        if (o.type() == VH_BITSET32 || o.type() == VH_BITSET64) {
+          const uint64_t* offs = P.fbs_offs[o.slot()][seg];
+          st[sp++] = o.type() == VH_BITSET32 ? vh_leaf_card<uint32_t, FULL>(P, o, offs, row_l, seg_rows)
+                                             : vh_leaf_card<uint64_t, FULL>(P, o, offs, row_l, seg_rows);
+          break;
+        }
         const char* base = P.colbase[o.slot()] + (uint64_t)seg * P.colstride[o.slot()];
         uint32_t m;
         switch (o.type()) {
@@ -938,14 +965,14 @@ __device__ __forceinline__ uint32_t vh_cmp16_bits(const uint32_t (&bits)[VH_LANE
 __device__ __forceinline__ uint32_t vh_leaf_bits(const VhPlanDev& P, const VhProgOp o, const uint32_t (&bits)[VH_LANE_ROWS]) {
   if (o.kind() == VH_F_REL) {
     switch (o.type()) {
-      case VH_I32: return vh_cmp16_bits<int32_t>(bits, P.lits[o.lit()], o.op());
-      case VH_F32: return vh_cmp16_bits<float>(bits, P.lits[o.lit()], o.op());
-      default: return vh_cmp16_bits<uint32_t>(bits, P.lits[o.lit()], o.op());
+      case VH_I32: return vh_cmp16_bits<int32_t>(bits, P.ilits[o.lit()], o.op());
+      case VH_F32: return vh_cmp16_bits<float>(bits, P.ilits[o.lit()], o.op());
+      default: return vh_cmp16_bits<uint32_t>(bits, P.ilits[o.lit()], o.op());
     }
   }
   uint32_t m = o.op() ? 0u : VH_ROWMASK;
   for (int i = 0; i < o.count(); ++i) {
-    const uint64_t lit = P.lits[o.lit() + i];
+    const uint64_t lit = P.ilits[o.lit() + i];
     uint32_t e;
     switch (o.type()) {
       case VH_I32: e = vh_cmp16_bits<int32_t>(bits, lit, o.op() ? VH_OP_EQ : VH_OP_NE); break;
@@ -982,7 +1009,7 @@ __device__ __forceinline__ uint32_t vh_eval_filter_fast(const VhPlanDev& P, cons
   uint32_t st[VH_MAX_STACK];
   int sp = 0;
   for (int pc = 0; pc < P.nprog; ++pc) {
-    const VhProgOp o = P.prog[pc];
+    const VhProgOp o = P.iprog[pc];
     switch (o.kind()) {
       case VH_F_TRUE: st[sp++] = VH_ROWMASK; break;
       case VH_F_AND: {

@@ -376,7 +376,8 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
   if (has_hidden) { rm->user_metric.resize(nm); rm->info.has_hidden_count = 1; rm->info.nmetrics = nm; }
   rm->info.scanned_recs = gflags[4]; rm->info.scanned_segments = gflags[5]; rm->info.passed_recs = gflags[6];
   rm->info.path = VH_PATH_HASH;
-  rm->info.scan_kernel_ms = r->info.scan_kernel_ms; rm->info.algorithmic_bytes = r->info.algorithmic_bytes;
+  rm->info.scan_kernel_ms = r->info.scan_kernel_ms; rm->info.algorithmic_bytes = r->info.algorithmic_bytes; rm->info.retries = r->info.retries;
+  rm->kernel = r->kernel;
 
   // ---- 7. how many groups everywhere; leave the rows with their owners or gather them on root
   uint64_t cnt[2] = {rm->ngroups_host, rm->info.ngroups};

@@ -23,6 +23,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 // ------------------------------------------------------------------- errors
@@ -702,8 +703,11 @@ struct vh_result {
   vh_result_info info{};
   int mode = 0;
   bool finalized = false;
+  size_t plan_words = 0, seg_words = 0;        // layout of the pinned staging block [segment snapshot | program | literals] in u32 words
   int h_slot = -1;                             // staging buffer of `exec` this query finalises into
   std::string kernel;                          // symbol(s) of the scan kernel(s) launched for this query
+  std::vector<VhProgOp> h_prog; std::vector<uint64_t> h_lits;   // the filter program as uploaded (VhPlanDev::prog / lits point into device scratch)
+  std::vector<int> filter_bitset_cols;         // bitset metrics the filter compares the cardinality of (VhPlanDev::fbs_offs order)
   bool device_rows = false;                    // emitted rows must (also) exist in device memory: they are exchanged or gathered next
   VhExec* exec = nullptr;                      // owned from launch to vh_result_free: stream, scratch (device-side state), staging (host view)
   // device-side partial state
@@ -725,6 +729,7 @@ struct vh_result {
   // (valid until the second-next query on the same table) at these offsets
   size_t out_region_off = 0, out_region_bytes = 0;   // device scratch: [counters | out_count | keys | states]
   size_t off_key[VH_MAX_GROUP] = {}, off_state[VH_MAX_METRIC] = {};
+  std::vector<size_t> wide_off_state;   // a multi-pass result (more than VH_MAX_METRIC states): offsets of ALL its state arrays
   char* h_base = nullptr;
   uint64_t ngroups_host = 0;
   // device top-N (vh_plan.top_k): a second set of output arrays holding the kept superset
@@ -768,15 +773,18 @@ extern "C" int vh_result_view(vh_result* r, const void** key_cols, const void** 
   for (size_t j = 0; j < r->user_metric.size(); ++j) {
     if (!state_cols) break;
     const int u = r->user_metric[j];
-    state_cols[j] = r->h_base + r->off_state[u];
+    state_cols[j] = r->h_base + (r->wide_off_state.empty() ? r->off_state[u] : r->wide_off_state[u]);
   }
-  if (hidden_count) *hidden_count = r->info.has_hidden_count ? reinterpret_cast<const uint64_t*>(r->h_base + r->off_state[r->plan.nmetric - 1]) : nullptr;
+  if (hidden_count) *hidden_count = !r->info.has_hidden_count ? nullptr
+      : reinterpret_cast<const uint64_t*>(r->h_base + (r->wide_off_state.empty() ? r->off_state[r->plan.nmetric - 1] : r->wide_off_state.back()));
   return VH_OK;
 }
 
 extern "C" int vh_result_copy(vh_result* r, void* const* key_cols, void* const* state_cols, uint64_t* hidden_count) {
   if (!r || !r->finalized) return vh_fail(VH_E_INVALID, "result is not finalised");
-  const void* kp[VH_MAX_GROUP]; const void* sp[VH_MAX_METRIC]; const uint64_t* hp = nullptr;
+  const void* kp[VH_MAX_GROUP]; const uint64_t* hp = nullptr;
+  std::vector<const void*> spv(std::max<size_t>(r->user_metric.size(), 1));
+  const void** sp = spv.data();
   int rc = vh_result_view(r, kp, sp, &hp);
   if (rc) return rc;
   const uint64_t ng = r->ngroups_host;
@@ -844,7 +852,7 @@ static bool typed_le(int elem, uint64_t a_bits, uint64_t b_bits) {
 // SegmentSkipBuilder (src/codegen/query/filter.cc:263-335) for one segment.
 static bool segment_passes(const vh_table* t, const vh_plan* p, uint32_t seg) {
   if (p->nfilter <= 0) return true;
-  bool st[VH_MAX_PROG];
+  std::vector<char> st((size_t)p->nfilter + 1);
   int sp = 0;
   for (int i = 0; i < p->nfilter; ++i) {
     const vh_filter_node& n = p->filter[i];
@@ -887,9 +895,11 @@ static bool segment_passes(const vh_table* t, const vh_plan* p, uint32_t seg) {
 // the first 16 K rows of up to 64 evenly spaced segments (one extra ~20 us launch + a 64-byte read-back).
 // Decides between direct global atomics (cheap per query, ~30-60 G updates/s) and radix-partitioned
 // LDS aggregation (two passes over 16 B per survivor, but no global atomics).
-static int estimate_selectivity(vh_table* t, VhExec* x, const VhPlanDev& P, uint32_t nseg, double* sel, uint64_t* passed_out = nullptr, uint64_t* sampled_out = nullptr) {
+static int estimate_selectivity(vh_table* t, VhExec* x, const VhPlanDev& P, const std::vector<VhProgOp>& prog, const std::vector<uint64_t>& lits, uint32_t nseg,
+                                double* sel, uint64_t* passed_out = nullptr, uint64_t* sampled_out = nullptr) {
   const uint32_t kRows = 16384;
-  const size_t need = 256 + 256 + (size_t)std::max<uint32_t>(nseg, 1) * sizeof(uint32_t);
+  const size_t rows_bytes = ((size_t)std::max<uint32_t>(nseg, 1) * sizeof(uint32_t) + 7) / 8 * 8;
+  const size_t need = 256 + 256 + rows_bytes + prog.size() * sizeof(VhProgOp) + lits.size() * sizeof(uint64_t);
   if (need > x->d_sample_bytes) {
     if (x->d_sample) HIP_TRY(hipFree(x->d_sample));
     HIP_TRY(hipMalloc(&x->d_sample, need * 2));
@@ -912,6 +922,10 @@ static int estimate_selectivity(vh_table* t, VhExec* x, const VhPlanDev& P, uint
   hipStream_t st = x->stream();
   HIP_TRY(hipMemsetAsync(x->d_sample, 0, 512, st));
   HIP_TRY(hipMemcpyAsync(x->d_sample + 512, rows.data(), nseg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  S.prog = reinterpret_cast<const VhProgOp*>(x->d_sample + 512 + rows_bytes);
+  S.lits = reinterpret_cast<const uint64_t*>(x->d_sample + 512 + rows_bytes + prog.size() * sizeof(VhProgOp));
+  HIP_TRY(hipMemcpyAsync(const_cast<VhProgOp*>(S.prog), prog.data(), prog.size() * sizeof(VhProgOp), hipMemcpyHostToDevice, st));
+  if (!lits.empty()) HIP_TRY(hipMemcpyAsync(const_cast<uint64_t*>(S.lits), lits.data(), lits.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
   const size_t qbytes = (size_t)16 * VhScanCfg<1024>::kQueueCap * sizeof(uint32_t);
   vh_launch_scan_fast_lds(S, (int)std::min<uint32_t>(nseg, (uint32_t)g_ctx.num_cu), 16 + qbytes, false, st);
   HIP_TRY(hipGetLastError());
@@ -958,10 +972,9 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     return vh_fail(VH_E_INVALID, "plan has a negative count");
   if ((p->nfilter && !p->filter) || (p->nlits && !p->lits) || (p->ngroups && !p->groups) || (p->nmetrics && !p->metrics) || (p->nhaving && !p->having))
     return vh_fail(VH_E_INVALID, "plan has a count without its array");
-  if (p->nfilter > VH_MAX_PROG) return vh_fail(VH_E_UNSUPPORTED, "filter has %d nodes (max %d)", p->nfilter, VH_MAX_PROG);
   if (p->nlits > VH_MAX_LITS) return vh_fail(VH_E_UNSUPPORTED, "filter has %d literals (max %d)", p->nlits, VH_MAX_LITS);
   if (p->ngroups > VH_MAX_GROUP) return vh_fail(VH_E_UNSUPPORTED, "%d group columns (max %d)", p->ngroups, VH_MAX_GROUP);
-  if (p->nmetrics > VH_MAX_METRIC - 1) return vh_fail(VH_E_UNSUPPORTED, "%d metrics (max %d)", p->nmetrics, VH_MAX_METRIC - 1);
+  if (p->nmetrics > VH_MAX_METRIC - 1) return vh_fail(VH_E_UNSUPPORTED, "%d metrics in one pass (max %d; vh_query_agg splits wider queries into passes)", p->nmetrics, VH_MAX_METRIC - 1);
   const uint32_t nseg = p->seg_rows ? p->nseg : t->nseg;
   if (nseg > t->nseg) return vh_fail(VH_E_INVALID, "plan snapshots %u segments, table mirrors %u", nseg, t->nseg);
   const int ncols = (int)t->cols.size();
@@ -993,43 +1006,103 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   // ---------------- filter program (+ stack depth check)
   bool fast_ok = !(p->flags & VH_PLAN_NO_FAST);
   int depth = 0, maxdepth = 0;
+  std::vector<VhProgOp>& prog = r->h_prog;
+  std::vector<size_t> seg_start;          // where the piece of program behind each value on the (simulated) stack begins
   for (int i = 0; i < p->nfilter; ++i) {
     const vh_filter_node& n = p->filter[i];
-    VhProgOp& o = P.prog[i];
-    o.set_kind((uint8_t)n.kind); o.set_op((uint8_t)n.op); o.set_count((uint8_t)n.count);
+    VhProgOp o{};
+    if (n.kind == VH_F_REL || n.kind == VH_F_IN || n.kind == VH_F_TRUE) seg_start.push_back(prog.size());
+    o.set_kind((uint8_t)n.kind); o.set_op((uint8_t)n.op); o.set_count((uint8_t)std::min(n.count, 255));
     if (n.kind == VH_F_REL || n.kind == VH_F_IN) {
-      const int s = slot(n.col);
-      if (s == -2) { return vh_fail(VH_E_UNSUPPORTED, "filter on a bitset metric (cardinality) is evaluated host-side"); }
+      int s = slot(n.col);
+      if (s == -2) {     // a bitset metric: the predicate compares the row's cardinality (offsets of the CSR mirror)
+        s = -1;
+        for (size_t k = 0; k < r->filter_bitset_cols.size(); ++k) if (r->filter_bitset_cols[k] == n.col) s = (int)k;
+        if (s < 0) {
+          if (r->filter_bitset_cols.size() >= VH_MAX_BITSET) return vh_fail(VH_E_UNSUPPORTED, "more than %d bitset metrics in one filter", VH_MAX_BITSET);
+          s = (int)r->filter_bitset_cols.size();
+          r->filter_bitset_cols.push_back(n.col);
+          bytes_per_row += 8;
+        }
+        fast_ok = false;
+      }
       if (s < 0) { return vh_fail(VH_E_INVALID, "filter node %d: bad column %d", i, n.col); }
       const int cnt = n.kind == VH_F_REL ? 1 : n.count;
-      if (n.lit < 0 || n.lit + cnt > p->nlits || n.count > 255) { return vh_fail(VH_E_INVALID, "filter node %d: literal range", i); }
+      if (n.lit < 0 || n.count < 0 || n.lit + cnt > p->nlits) { return vh_fail(VH_E_INVALID, "filter node %d: literal range", i); }
       o.set_slot((uint8_t)s); o.set_type((uint8_t)t->cols[n.col].elem); o.set_lit((uint16_t)n.lit);
       // fast path bookkeeping: distinct 4-byte predicate columns
-      if (vh_elem_size(t->cols[n.col].elem) != 4) fast_ok = false;
+      if (is_bitset_elem(t->cols[n.col].elem) || vh_elem_size(t->cols[n.col].elem) != 4) fast_ok = false;
       if (fast_ok) {
         int ps = -1;
         for (int k = 0; k < P.npred; ++k) if (P.pred_slot[k] == s) ps = k;
         if (ps < 0) { if (P.npred < VH_MAX_PRED) { ps = P.npred; P.pred_slot[P.npred++] = (uint8_t)s; } else fast_ok = false; }
         o.set_pslot((uint8_t)std::max(ps, 0));
       }
+      if (n.kind == VH_F_IN && n.count > 255) {
+        // a long IN list (the reference emits one comparison per value, filter.cc:223-241): chunks of 255 literals, folded
+        // pairwise — OR of the chunks for IN, AND for NOT IN — so the mask stack grows by one entry only
+        for (int first = 0; first < n.count; first += 255) {
+          VhProgOp c = o;
+          c.set_count((uint8_t)std::min(255, n.count - first)); c.set_lit((uint16_t)(n.lit + first));
+          prog.push_back(c);
+          if (first) { VhProgOp f{}; f.set_kind(n.op ? VH_F_OR : VH_F_AND); f.set_count(2); prog.push_back(f); }
+        }
+        ++depth;
+        continue;
+      }
       ++depth;
     } else if (n.kind == VH_F_TRUE) {
       ++depth;
     } else if (n.kind == VH_F_AND || n.kind == VH_F_OR) {
-      if (n.count < 1 || n.count > depth || n.count > 255) { return vh_fail(VH_E_INVALID, "filter node %d: operand count %d", i, n.count); }
+      if (n.count < 1 || n.count > depth) { return vh_fail(VH_E_INVALID, "filter node %d: operand count %d", i, n.count); }
+      if (n.count > 3) {
+        // Bitwise & and | are associative: a composite of n operands is folded pairwise (a b OP c OP ...), so the mask stack of
+        // the kernels holds one entry per NESTING level, not per operand — an OR of 120 comparisons needs depth 2, not 120.
+        // The operands are the last n contiguous pieces of the program emitted so far (seg_start remembers where each begins).
+        std::vector<VhProgOp> folded;
+        const size_t first = seg_start.size() - (size_t)n.count;
+        folded.reserve(prog.size() - seg_start[first] + (size_t)n.count);
+        for (int k = 0; k < n.count; ++k) {
+          const size_t b = seg_start[first + k], e = k + 1 < n.count ? seg_start[first + k + 1] : prog.size();
+          folded.insert(folded.end(), prog.begin() + b, prog.begin() + e);
+          if (k) { VhProgOp f{}; f.set_kind((uint8_t)n.kind); f.set_count(2); folded.push_back(f); }
+        }
+        prog.resize(seg_start[first]);
+        prog.insert(prog.end(), folded.begin(), folded.end());
+        seg_start.resize(first + 1);
+        depth -= n.count - 1;
+        continue;
+      }
+      seg_start.resize(seg_start.size() - (size_t)n.count + 1);
       depth -= n.count - 1;
     } else { return vh_fail(VH_E_INVALID, "filter node %d: kind %d", i, n.kind); }
-    maxdepth = std::max(maxdepth, depth);
+    prog.push_back(o);
   }
-  if (p->nfilter == 0) { P.prog[0].set_kind(VH_F_TRUE); P.nprog = 1; depth = 1; }
-  else P.nprog = p->nfilter;
+  if (p->nfilter == 0) { VhProgOp o{}; o.set_kind(VH_F_TRUE); prog.push_back(o); depth = 1; }
+  P.nprog = (int32_t)prog.size();
   if (depth != 1) { return vh_fail(VH_E_INVALID, "filter program leaves %d values on the stack", depth); }
+  for (int d = 0, k = 0; k < P.nprog; ++k) {     // depth of the program as the kernels will run it
+    const int kind = prog[k].kind();
+    d += (kind == VH_F_AND || kind == VH_F_OR) ? 1 - (int)prog[k].count() : 1;
+    maxdepth = std::max(maxdepth, d);
+  }
   if (maxdepth > VH_MAX_STACK) { return vh_fail(VH_E_UNSUPPORTED, "filter needs stack depth %d (max %d)", maxdepth, VH_MAX_STACK); }
-  for (int i = 0; i < p->nlits; ++i) P.lits[i] = p->lits[i].u64;
+  r->h_lits.resize(std::max(p->nlits, 0));
+  for (int i = 0; i < p->nlits; ++i) r->h_lits[i] = p->lits[i].u64;
+  if (prog.size() <= VH_INLINE_PROG && r->h_lits.size() <= VH_INLINE_LITS) {   // the register-resident kernels read the program from the kernel arguments
+    memcpy(P.iprog, prog.data(), prog.size() * sizeof(VhProgOp));
+    memcpy(P.ilits, r->h_lits.data(), r->h_lits.size() * sizeof(uint64_t));
+  } else fast_ok = false;                                                       // long programs (IN lists of hundreds of values): the generic kernel
 
   // ---------------- segments: snapshot + skip
-  int rc = ensure_segrows(x, std::max<uint32_t>(nseg, 1));
+  // one pinned staging block [segment snapshot | program | literals] -> one upload per query
+  const size_t seg_words = ((size_t)std::max<uint32_t>(nseg, 1) + 1) / 2 * 2;
+  const size_t plan_words = seg_words + 2 * (prog.size() + r->h_lits.size());
+  int rc = ensure_segrows(x, plan_words);
   if (rc) { return rc; }
+  memcpy(x->h_segrows + seg_words, prog.data(), prog.size() * sizeof(VhProgOp));
+  memcpy(x->h_segrows + seg_words + 2 * prog.size(), r->h_lits.data(), r->h_lits.size() * sizeof(uint64_t));
+  r->plan_words = plan_words; r->seg_words = seg_words;
   uint64_t scanned_recs = 0, scanned_segments = 0, rows_to_scan = 0;
   std::vector<uint32_t> live;
   for (uint32_t s = 0; s < nseg; ++s) {
@@ -1055,12 +1128,12 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   auto probed_selectivity = [&](double* sel) -> int {
     if (ag) { *sel = ag->sel; return VH_OK; }
     if (p->nfilter == 0) { *sel = 1.0; probe_passed = probe_sampled = rows_to_scan; return VH_OK; }   // no filter: every row passes
-    std::string key((const char*)P.prog, sizeof(VhProgOp) * P.nprog);
-    key.append((const char*)P.lits, sizeof(uint64_t) * std::max(p->nlits, 0));
+    std::string key((const char*)prog.data(), sizeof(VhProgOp) * prog.size());
+    key.append((const char*)r->h_lits.data(), sizeof(uint64_t) * r->h_lits.size());
     key += "|" + std::to_string(nseg) + "|" + std::to_string(rows_to_scan) + "|" + std::to_string(t->sync_epoch);
     auto hit = t->sel_cache.find(key);
     if (hit != t->sel_cache.end()) { probe_passed = hit->second.first; probe_sampled = hit->second.second; *sel = probe_sampled ? (double)probe_passed / (double)probe_sampled : 0.0; return VH_OK; }
-    const int prc = estimate_selectivity(t, x, P, nseg, sel, &probe_passed, &probe_sampled);
+    const int prc = estimate_selectivity(t, x, P, r->h_prog, r->h_lits, nseg, sel, &probe_passed, &probe_sampled);
     if (prc) return prc;
     if (t->sel_cache.size() > 256) t->sel_cache.clear();
     t->sel_cache[key] = std::make_pair(probe_passed, probe_sampled);
@@ -1600,7 +1673,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   r->out_region_bytes = sp.off - o_counters;
   for (int i = 0; i < P.ngroup; ++i) r->off_key[i] = o_okey[i] - o_counters;
   for (int j = 0; j < P.nmetric; ++j) r->off_state[j] = o_ostate[j] - o_counters;
-  const size_t o_segrows = sp.take(std::max<uint32_t>(nseg, 1) * sizeof(uint32_t));
+  const size_t o_segrows = sp.take(r->plan_words * sizeof(uint32_t));   // [segment snapshot | program | literals]
   size_t o_present = 0, o_hkeys = 0, o_htags = 0;
   size_t o_state[VH_MAX_METRIC];
   const uint64_t table_n = mode == VH_MODE_HASH ? capacity + 1 : P.xcd_stride * nxcd;
@@ -1662,6 +1735,8 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     o_emiss = sp.take(max_ext * sizeof(uint16_t));
     o_epart = sp.take(max_ext);
   }
+  size_t o_fbs[VH_MAX_BITSET] = {};
+  for (size_t k = 0; k < r->filter_bitset_cols.size(); ++k) o_fbs[k] = sp.take(std::max<uint32_t>(nseg, 1) * 8);
   size_t o_bsptr[VH_MAX_BITSET][2] = {}, o_dkeys[VH_MAX_BITSET] = {}, o_dtags[VH_MAX_BITSET] = {};
   for (int b = 0; b < P.nbitset; ++b) {
     o_bsptr[b][0] = sp.take(std::max<uint32_t>(nseg, 1) * 8);
@@ -1681,6 +1756,8 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   char* S = x->scratch;
   P.counters = reinterpret_cast<unsigned long long*>(S + o_counters);
   P.seg_rows = reinterpret_cast<const uint32_t*>(S + o_segrows);
+  P.prog = reinterpret_cast<const VhProgOp*>(S + o_segrows + r->seg_words * 4);
+  P.lits = reinterpret_cast<const uint64_t*>(S + o_segrows + r->seg_words * 4 + r->h_prog.size() * sizeof(VhProgOp));
   if (mode == VH_MODE_HASH) {
     P.hkeys = reinterpret_cast<uint64_t*>(S + o_hkeys);
     P.htags = P.key_words > 1 ? reinterpret_cast<uint32_t*>(S + o_htags) : nullptr;
@@ -1695,6 +1772,12 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     P.part_extents = reinterpret_cast<uint32_t*>(S + o_pext);
     P.extent_missing = reinterpret_cast<uint16_t*>(S + o_emiss);
     P.extent_part = reinterpret_cast<uint8_t*>(S + o_epart);
+  }
+  for (size_t k = 0; k < r->filter_bitset_cols.size(); ++k) {
+    const VhColumn& c = t->cols[r->filter_bitset_cols[k]];
+    for (uint32_t sgi : live) if (!c.bs_offsets[sgi]) return vh_fail(VH_E_INVALID, "bitset column %d of segment %u was never synced", r->filter_bitset_cols[k], sgi);
+    P.fbs_offs[k] = reinterpret_cast<const uint64_t* const*>(S + o_fbs[k]);
+    if (nseg) HIP_TRY(hipMemcpy(S + o_fbs[k], c.bs_offsets.data(), nseg * 8, hipMemcpyHostToDevice));
   }
   if (P.nbitset) {
     for (int b = 0; b < P.nbitset; ++b) {
@@ -1722,7 +1805,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   hipStream_t st = x->stream();
   HIP_TRY(hipEventRecord(x->ev[0], st));
   HIP_TRY(hipMemsetAsync(P.counters, 0, 512, st));   // counters + out_count (adjacent 256 B slots)
-  if (nseg) HIP_TRY(hipMemcpyAsync(S + o_segrows, x->h_segrows, nseg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S + o_segrows, x->h_segrows, r->plan_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   if (mode == VH_MODE_HASH) {
     if (P.hrec_bytes) {          // records: empty key + the metrics' identities, one template for every slot
       VhRecordTemplate T{};
@@ -2142,7 +2225,7 @@ static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
     uint64_t next = (r->plan.hmask + 1) * 4;
     if (!rp->cap_override) {
       double sel = 1.0;
-      if (r->info.reserved & 1) { std::lock_guard<std::mutex> lk(t->mu); (void)estimate_selectivity(t, r->exec, r->plan, r->plan.nseg, &sel); }
+      if (r->info.reserved & 1) { std::lock_guard<std::mutex> lk(t->mu); (void)estimate_selectivity(t, r->exec, r->plan, r->h_prog, r->h_lits, r->plan.nseg, &sel); }
       uint64_t survivors = (uint64_t)((double)r->info.scanned_recs * std::min(1.0, sel * 1.1)) + 1024;
       uint64_t sized = 1;
       while (sized < survivors * 2) sized <<= 1;
@@ -2157,9 +2240,80 @@ static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
   else rp->force_hash = true;                                // a digit left its planned range
 }
 
+// More metrics than one pass carries (VH_MAX_METRIC states per group in the kernel arguments): several passes over
+// the same snapshot, each with a slice of the metrics, joined on the group key. The reference has no such limit
+// (AggTuple::Metrics is a generated struct of any width, store.cc:31-169).
+static int query_agg_multipass(vh_table* t, const vh_plan* plan, vh_result** out) {
+  if (plan->nhaving || plan->top_k)
+    return vh_fail(VH_E_UNSUPPORTED, "%d metrics take several passes: apply HAVING / top-N to the returned groups", plan->nmetrics);
+  const int per = VH_MAX_METRIC - 4;
+  std::vector<std::unique_ptr<vh_result>> parts;
+  for (int off = 0; off < plan->nmetrics; off += per) {
+    vh_plan cp = *plan;
+    cp.metrics = plan->metrics + off; cp.nmetrics = std::min(per, plan->nmetrics - off);
+    vh_result* r = nullptr;
+    if (int rc = vh_query_agg(t, &cp, &r)) return rc;
+    parts.emplace_back(r);
+  }
+  vh_result* base = parts[0].get();
+  const uint64_t n = base->ngroups_host;
+  const int nk = base->plan.ngroup;
+  std::unique_ptr<vh_result> rf(new vh_result());
+  rf->table = t; rf->info = base->info; rf->mode = base->mode; rf->kernel = base->kernel;
+  rf->plan.ngroup = nk; rf->plan.key_words = base->plan.key_words;
+  for (int i = 0; i < nk; ++i) rf->plan.g[i] = base->plan.g[i];
+  rf->group_elem = base->group_elem;
+  auto key_of = [&](const vh_result* r, uint64_t row) {
+    std::string k;
+    for (int i = 0; i < nk; ++i) { const int es = vh_elem_size(r->plan.g[i].type()); k.append(r->h_base + r->off_key[i] + row * es, es); }
+    return k;
+  };
+  std::unordered_map<std::string, uint64_t> where;
+  if (parts.size() > 1) { where.reserve(n * 2); for (uint64_t row = 0; row < n; ++row) where.emplace(key_of(base, row), row); }
+  // layout of the joined result: keys, then every pass's user metrics in plan order, then the hidden count (if the plan has one)
+  const vh_result* hidden_from = nullptr;
+  bool any_count = false;
+  for (int j = 0; j < plan->nmetrics; ++j) any_count |= plan->metrics[j] >= 0 && t->cols[plan->metrics[j]].kind == VH_METRIC_COUNT;
+  for (auto& pr : parts) if (pr->info.has_hidden_count && !any_count && !hidden_from) hidden_from = pr.get();
+  size_t bytes = 0;
+  for (int i = 0; i < nk; ++i) { rf->off_key[i] = bytes; bytes += (std::max<uint64_t>(n, 1) * vh_elem_size(base->plan.g[i].type()) + 255) / 256 * 256; }
+  std::vector<std::pair<const vh_result*, int>> src;      // joined device-metric index -> (pass, its device metric)
+  for (auto& pr : parts) for (int u : pr->user_metric) src.push_back({pr.get(), u});
+  if (hidden_from) src.push_back({hidden_from, hidden_from->plan.nmetric - 1});
+  if (src.size() > 4096) return vh_fail(VH_E_UNSUPPORTED, "too many metrics");
+  std::vector<size_t> off_state(src.size());
+  for (size_t u = 0; u < src.size(); ++u) {
+    rf->metric_elem.push_back(src[u].first->metric_elem[src[u].second]);
+    off_state[u] = bytes; bytes += (std::max<uint64_t>(n, 1) * vh_elem_size(rf->metric_elem.back()) + 255) / 256 * 256;
+  }
+  HIP_TRY(hipHostMalloc((void**)&rf->h_own, bytes, hipHostMallocDefault));
+  for (int i = 0; i < nk; ++i) if (n) memcpy(rf->h_own + rf->off_key[i], base->h_base + base->off_key[i], n * vh_elem_size(base->plan.g[i].type()));
+  for (size_t u = 0; u < src.size(); ++u) {
+    const vh_result* pr = src[u].first;
+    const int es = vh_elem_size(rf->metric_elem[u]);
+    const char* from = pr->h_base + pr->off_state[src[u].second];
+    char* to = rf->h_own + off_state[u];
+    if (pr == base) { if (n) memcpy(to, from, n * es); continue; }
+    if (pr->ngroups_host != n) return vh_fail(VH_E_DEVICE, "passes of one query returned %llu and %llu groups", (unsigned long long)n, (unsigned long long)pr->ngroups_host);
+    for (uint64_t row = 0; row < n; ++row) {
+      auto it = where.find(key_of(pr, row));
+      if (it == where.end()) return vh_fail(VH_E_DEVICE, "passes of one query returned different groups");
+      memcpy(to + it->second * es, from + row * es, es);
+    }
+  }
+  rf->wide_off_state = off_state;
+  for (int j = 0; j < plan->nmetrics; ++j) rf->user_metric.push_back(j);
+  rf->info.nmetrics = plan->nmetrics; rf->info.has_hidden_count = hidden_from ? 1 : 0;
+  rf->plan.nmetric = (int32_t)std::min<size_t>(src.size(), VH_MAX_METRIC);
+  rf->h_base = rf->h_own; rf->ngroups_host = n; rf->finalized = true;
+  *out = rf.release();
+  return VH_OK;
+}
+
 extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
   if (!t || !plan || !out) return vh_fail(VH_E_INVALID, "null argument");
   VH_ENTER();
+  if (plan->nmetrics > VH_MAX_METRIC - 1 && plan->metrics) return query_agg_multipass(t, plan, out);
   VhExec* x = nullptr;
   if (int rc = exec_acquire(t, &x)) return rc;
   VhReplan rp;
@@ -2246,17 +2400,27 @@ extern "C" int vh_query_select(vh_table* t, const vh_select_plan* sp, vh_rows** 
   const uint32_t cps = (uint32_t)((t->padded_rows + VH_WAVE_STEP_ROWS - 1) / VH_WAVE_STEP_ROWS);
   const uint64_t nchunks = (uint64_t)nseg * cps;
   ScratchPlan spn;
-  const size_t o_ctr = spn.take(256), o_segrows = spn.take((size_t)nseg * 4), o_counts = spn.take(nchunks * 4),
+  const size_t o_ctr = spn.take(256), o_segrows = spn.take(pr->plan_words * 4), o_counts = spn.take(nchunks * 4),
                o_totals = spn.take((size_t)nseg * 8), o_win = spn.take((size_t)nseg * sizeof(VhSelectWindow)),
                o_sel = spn.take(sizeof(VhSelectDev));
-  size_t o_bs[VH_MAX_SELECT] = {};
+  size_t o_bs[VH_MAX_SELECT] = {}, o_fbs[VH_MAX_BITSET] = {};
   for (int c = 0; c < sp->ncols; ++c) if (is_bitset_elem(t->cols[sp->cols[c]].elem)) o_bs[c] = spn.take((size_t)nseg * 8);
+  for (size_t k = 0; k < pr->filter_bitset_cols.size(); ++k) o_fbs[k] = spn.take((size_t)nseg * 8);
   rc = ensure_scratch(x, spn.off);
   if (rc) return rc;
   char* S = x->scratch;
   HIP_TRY(hipEventRecord(x->ev[0], st));
   HIP_TRY(hipMemsetAsync(S + o_ctr, 0, 256, st));
-  HIP_TRY(hipMemcpyAsync(S + o_segrows, x->h_segrows, (size_t)nseg * 4, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipMemcpyAsync(S + o_segrows, x->h_segrows, pr->plan_words * 4, hipMemcpyHostToDevice, st));
+  P.prog = reinterpret_cast<const VhProgOp*>(S + o_segrows + pr->seg_words * 4);
+  P.lits = reinterpret_cast<const uint64_t*>(S + o_segrows + pr->seg_words * 4 + pr->h_prog.size() * sizeof(VhProgOp));
+  for (size_t k = 0; k < pr->filter_bitset_cols.size(); ++k) {     // bitset metrics in the filter: per-segment CSR offsets
+    const VhColumn& fc = t->cols[pr->filter_bitset_cols[k]];
+    for (uint32_t s = 0; s < nseg; ++s)
+      if (x->h_segrows[s] && !fc.bs_offsets[s]) return vh_fail(VH_E_INVALID, "bitset column %d of segment %u was never synced", pr->filter_bitset_cols[k], s);
+    HIP_TRY(hipMemcpy(S + o_fbs[k], fc.bs_offsets.data(), (size_t)nseg * 8, hipMemcpyHostToDevice));
+    P.fbs_offs[k] = reinterpret_cast<const uint64_t* const*>(S + o_fbs[k]);
+  }
   P.seg_rows = reinterpret_cast<const uint32_t*>(S + o_segrows);
   P.counters = reinterpret_cast<unsigned long long*>(S + o_ctr);
   uint32_t* d_counts = reinterpret_cast<uint32_t*>(S + o_counts);

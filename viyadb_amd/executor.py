@@ -345,9 +345,9 @@ class DeviceTable:
         return res
 
     def device_buffers(self, res):
-        bufs = (capi.DeviceBuffer * 16)()
+        bufs = (capi.DeviceBuffer * 32)()
         n = C.c_int32()
-        capi.check(self.lib.vh_result_device_buffers(res, bufs, 16, C.byref(n)))
+        capi.check(self.lib.vh_result_device_buffers(res, bufs, 32, C.byref(n)))
         return [(bufs[i].ptr, bufs[i].count, bufs[i].elem, bufs[i].reduce) for i in range(n.value)]
 
     def finalize(self, res, plan: AggPlan, copy: bool = True) -> AggResult:
@@ -375,9 +375,9 @@ class DeviceTable:
     def partition(self, res, nparts: int):
         """-> (offsets[nparts + 1], [(device ptr, rows, elem, merge op)]) : key columns, metrics, hidden count."""
         offs = (C.c_uint64 * (nparts + 1))()
-        bufs = (capi.DeviceBuffer * 24)()
+        bufs = (capi.DeviceBuffer * 48)()
         n = C.c_int32()
-        capi.check(self.lib.vh_result_partition(res, nparts, offs, bufs, 24, C.byref(n)))
+        capi.check(self.lib.vh_result_partition(res, nparts, offs, bufs, 48, C.byref(n)))
         return (np.array(list(offs), dtype=np.uint64),
                 [(bufs[i].ptr, bufs[i].count, bufs[i].elem, bufs[i].reduce) for i in range(n.value)])
 
@@ -385,9 +385,9 @@ class DeviceTable:
         """Distinct (group, id) pairs of bitset metric `metric`, regrouped by the group's owner:
         -> (offsets[nparts + 1], [(device ptr, pairs, elem, -1)]) : key columns, then the id column."""
         offs = (C.c_uint64 * (nparts + 1))()
-        bufs = (capi.DeviceBuffer * 16)()
+        bufs = (capi.DeviceBuffer * 24)()
         n = C.c_int32()
-        capi.check(self.lib.vh_result_partition_pairs(res, int(metric), nparts, offs, bufs, 16, C.byref(n)))
+        capi.check(self.lib.vh_result_partition_pairs(res, int(metric), nparts, offs, bufs, 24, C.byref(n)))
         return (np.array(list(offs), dtype=np.uint64),
                 [(bufs[i].ptr, bufs[i].count, bufs[i].elem, bufs[i].reduce) for i in range(n.value)])
 
