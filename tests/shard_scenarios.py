@@ -17,7 +17,7 @@ def _rng(name, rank, seg):
     return np.random.default_rng(abs(hash((name, rank, seg))) % (2 ** 32)) if False else np.random.default_rng([sum(map(ord, name)), rank, seg])
 
 
-def build(name, ranks, world=2):
+def build(name, ranks, world=2, grown=False):
     U = [{"name": "a", "type": "uint"}, {"name": "b", "type": "uint"}, {"name": "f", "type": "uint"}]
     M = [{"name": "v", "type": "long_sum"}, {"name": "count", "type": "count"}, {"name": "umin", "type": "uint_min"},
          {"name": "lmax", "type": "ulong_max"}, {"name": "d", "type": "double_sum"}]
@@ -27,7 +27,7 @@ def build(name, ranks, world=2):
     t = _table(U, M)
     segs_per_rank = 2
     for rank in ranks:
-        for s in range(segs_per_rank):
+        for s in range(segs_per_rank + (1 if grown and rank == 1 else 0)):
             r = _rng(name, rank, s)
             n = SEG - 17 * (rank + 1)
             a = r.integers(0, 60, n)
@@ -36,6 +36,9 @@ def build(name, ranks, world=2):
             if name == "disjoint_ranges":            # rank r only holds a in [1000 r, 1000 r + 60), b in [7 r, 7 r + 50)
                 a = a + 1000 * rank
                 b = b + 7 * rank
+                if s >= segs_per_rank:               # the segment that appears between two queries: outside every range agreed so far
+                    a = a + 700
+                    b = b + 90
             elif name == "part_vs_global":           # rank 0: everything passes; rank 1: 1 % passes. 200 x 200 groups: too big for LDS
                 a = r.integers(0, 200, n)
                 b = r.integers(0, 200, n)

@@ -40,7 +40,11 @@ WORKER = textwrap.dedent('''
         t = mirror_table(tab)
         plan = plan_from_query(tab, vo.parse_query(tab, q), now=1496570140, flags=flags | spec.get("flags", 0), groups_hint=hint)
     retries = 0
-    for _ in range(2):
+    for it in range(2):
+        if it == 1 and spec.get("grow") and rank == 1:      # one rank's table changes between two runs of the same plan
+            tab2 = shard_scenarios.build(spec["name"], [rank], world, grown=True)[0]
+            seg = tab2.segments[-1]
+            t.sync_segment(len(tab2.segments) - 1, [a[:seg["size"]] for a in seg["d"]] + [a[:seg["size"]] for a in seg["m"]], seg["size"])
         res = distributed.sharded_query(t, plan, comm, root=root)
         retries = max(retries, res.retries)      # (the second run already knows how many groups to expect)
     torch.cuda.synchronize()
@@ -167,6 +171,29 @@ def test_ranks_that_see_different_data_agree_on_one_plan(tmp_path, name, flags, 
         assert str(gots[0]["path"]) == path
     if name == "one_rank_overflows":
         assert int(gots[0]["retries"]) >= 1 and int(gots[1]["retries"]) == int(gots[0]["retries"])   # one rank's overflow re-plans both
+
+
+def test_cached_agreement_is_dropped_when_one_rank_changes(tmp_path):
+    """The second run of a plan takes the agreement of the first from the communicator's cache — unless a rank's table changed in
+    between (here: a new segment whose group values lie outside every range agreed before): that rank says so in the verdict,
+    all ranks agree afresh, and the answer covers the new rows."""
+    from oracle import viya_oracle as vo
+    from tests import shard_scenarios
+    for flags in (0, 2):
+        gots = _launch(tmp_path, {"kind": "scenario", "name": "disjoint_ranges", "flags": flags, "grow": True}, "gloo", 2)
+        tab, q, _, _ = shard_scenarios.build("disjoint_ranges", [0, 1], grown=True)
+        st = vo.scan_aggregate(vo.parse_query(tab, q), now=1496570140)
+        assert int(gots[0]["ngroups"]) == st.ngroups
+        _check(gots, st)
+        calls = __import__("json").loads(str(gots[0]["calls"]))
+        assert calls["allgather"] == 2, calls          # first run + the re-agreement; a steady second run would have made it 1
+
+
+def test_steady_state_needs_no_allgather(tmp_path):
+    """Same plan, unchanged tables: the second run's only host-visible collective is the verdict all-reduce."""
+    gots = _launch(tmp_path, {"kind": "synth", "wl": "C3"}, "gloo", 2)
+    calls = __import__("json").loads(str(gots[0]["calls"]))
+    assert calls["allgather"] == 1 and calls["reduce"] >= 4, calls   # 2 runs x (verdict + one state buffer)
 
 
 def test_bench_multi_rank_flow_on_one_gpu(tmp_path):

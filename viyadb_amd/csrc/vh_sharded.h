@@ -63,7 +63,27 @@ struct vh_comm {
   unsigned long long* d_flags = nullptr;             // verdict words, all-reduced (SUM) after every attempt
   unsigned long long* h_flags = nullptr;             // pinned copy
   std::mutex mu;                                     // one sharded query at a time per communicator (collectives must not interleave)
+  // Agreements of earlier queries, by plan. Entries appear and disappear at collective points only, so every rank holds the
+  // same set: a query whose plan is in the cache skips the all-gather of step 1 (a 128-byte verdict all-reduce is then the
+  // only host-visible collective of a dense query). A rank whose table changed since still plans with the cached agreement
+  // and says so in the verdict; all ranks then drop the entry and agree afresh.
+  struct Agreement { VhAgreed ag; uint64_t sync_epoch; };
+  std::map<std::string, Agreement> agreed;
 };
+
+static std::string plan_signature(const vh_plan* p) {
+  std::string k;
+  auto add = [&](const void* d, size_t n) { k.append(static_cast<const char*>(d), n); k.push_back('|'); };
+  if (p->nfilter) add(p->filter, sizeof(vh_filter_node) * p->nfilter);
+  if (p->nlits) add(p->lits, sizeof(vh_anynum) * p->nlits);
+  if (p->ngroups) add(p->groups, sizeof(vh_group_col) * p->ngroups);
+  if (p->nmetrics) add(p->metrics, sizeof(int32_t) * p->nmetrics);
+  if (p->nhaving) add(p->having, sizeof(vh_filter_node) * p->nhaving);
+  if (p->seg_rows) add(p->seg_rows, sizeof(uint64_t) * p->nseg);
+  const uint64_t tail[6] = {p->flags, p->groups_hint, (uint64_t)p->top_col, (uint64_t)p->top_desc, p->top_k, p->seg_rows ? p->nseg : ~0ull};
+  add(tail, sizeof(tail));
+  return k;
+}
 
 static int rccl_allgather_host(void* ctx, const void* send, void* recv, uint64_t bytes) {
   vh_comm* c = static_cast<vh_comm*>(ctx);
@@ -178,26 +198,28 @@ extern "C" int vh_comm_init_custom(const vh_comm_ops* ops, int32_t rank, int32_t
 // Pure host arithmetic, also reachable from tests without a device (vh_plan_agree below is not part of the C ABI).
 static void merge_summaries(const VhSummary* all, int world, int ngroups, VhAgreed* ag, VhReplan* rp, bool* fatal) {
   for (int i = 0; i < VH_MAX_GROUP; ++i) { ag->klo[i] = ~0ull; ag->khi[i] = 0; }
-  uint64_t rows = 0, passed = 0, sampled = 0;
+  uint64_t rows = 0, passed = 0, sampled = 0, rows_max = 0;
   *fatal = false;
   for (int r = 0; r < world; ++r) {
     const VhSummary& s = all[r];
     for (int i = 0; i < ngroups; ++i) { ag->klo[i] = std::min(ag->klo[i], s.klo[i]); ag->khi[i] = std::max(ag->khi[i], s.khi[i]); }
     rows += s.rows_to_scan; passed += s.probe_passed; sampled += s.probe_sampled;
+    rows_max = std::max(rows_max, s.rows_to_scan);
     rp->cap_override = std::max(rp->cap_override, s.cap_override);
     rp->part_override = std::max(rp->part_override, s.part_override);
     rp->force_hash |= s.force_hash != 0; rp->no_part |= s.no_part != 0;
     *fatal |= s.fatal != 0;
   }
-  ag->rows_to_scan = rows;
+  ag->rows_to_scan = rows; ag->rows_max = rows_max;
   ag->sel = sampled ? (double)passed / (double)sampled : 0.0;
 }
 
 // verdict words (all-reduced with SUM): [0] range error, [1] hash table full, [2] tuple extents exhausted, [3] fatal,
-// [4] scanned_recs, [5] scanned_segments, [6] passed rows, [7] table organisation, [8] its square, [9] groups (hash path)
+// [4] scanned_recs, [5] scanned_segments, [6] passed rows, [7] table organisation, [8] its square, [9] groups (hash path),
+// [10] this rank's table changed since the cached agreement was made
 __global__ void sharded_flags_kernel(const unsigned long long* counters, unsigned long long* flags, unsigned long long host_err,
                                      unsigned long long fatal, unsigned long long scanned_recs, unsigned long long scanned_segments,
-                                     unsigned long long mode, unsigned long long ngroups) {
+                                     unsigned long long mode, unsigned long long ngroups, unsigned long long changed) {
   if (threadIdx.x != 0) return;
   const unsigned long long err = (counters ? counters[2] : 0ull) | host_err;
   flags[0] = (err & VH_ERR_RANGE) ? 1 : 0;
@@ -208,7 +230,8 @@ __global__ void sharded_flags_kernel(const unsigned long long* counters, unsigne
   flags[6] = counters ? counters[0] : 0ull;
   flags[7] = mode; flags[8] = mode * mode;
   flags[9] = ngroups;
-  for (int i = 10; i < VH_FLAG_WORDS; ++i) flags[i] = 0;
+  flags[10] = changed;
+  for (int i = 11; i < VH_FLAG_WORDS; ++i) flags[i] = 0;
 }
 
 // vh_query_agg with the rows kept in device memory (they are exchanged or gathered next). Same re-plan loop.
@@ -442,25 +465,36 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
   const int W = comm->world, R = comm->rank;
   VhReplan rp;
   char local_err[sizeof(g_err)] = "";
+  const std::string sig = plan_signature(plan);
   for (uint32_t attempt = 0; attempt < 12; ++attempt) {
-    // ---- 1. agree on what to plan with
-    VhSummary mine{};
-    int lrc;
-    { std::lock_guard<std::mutex> lk(t->mu); vh_result* none = nullptr; lrc = query_launch_locked(t, x, plan, &none, 0, false, 0, false, false, &mine); }
-    if (lrc && !local_err[0]) snprintf(local_err, sizeof(local_err), "%s", g_err);
-    mine.cap_override = rp.cap_override; mine.part_override = rp.part_override;
-    mine.force_hash = rp.force_hash; mine.no_part = rp.no_part; mine.fatal = lrc ? 1 : 0;
-    std::vector<VhSummary> all(W);
-    if (int rc = comm->ops.allgather_host(comm->ops.ctx, &mine, all.data(), sizeof(VhSummary)))
-      return rc < 0 ? rc : vh_fail(VH_E_DEVICE, "all-gather of the plan summaries failed (%d)", rc);
+    // ---- 1. agree on what to plan with (or take the agreement this plan got last time)
     VhAgreed ag{};
-    bool fatal = false;
-    merge_summaries(all.data(), W, plan->ngroups, &ag, &rp, &fatal);
-    if (fatal) return lrc ? vh_fail(lrc, "%s", local_err) : vh_fail(VH_E_INVALID, "another rank rejected the plan");
+    int lrc = VH_OK;
+    bool cached = false, changed = false;
+    if (attempt == 0) {
+      auto hit = comm->agreed.find(sig);
+      if (hit != comm->agreed.end()) { ag = hit->second.ag; cached = true; changed = hit->second.sync_epoch != t->sync_epoch; }
+    }
+    if (!cached) {
+      VhSummary mine{};
+      { std::lock_guard<std::mutex> lk(t->mu); vh_result* none = nullptr; lrc = query_launch_locked(t, x, plan, &none, 0, false, 0, false, false, &mine); }
+      if (lrc && !local_err[0]) snprintf(local_err, sizeof(local_err), "%s", g_err);
+      mine.cap_override = rp.cap_override; mine.part_override = rp.part_override;
+      mine.force_hash = rp.force_hash; mine.no_part = rp.no_part; mine.fatal = lrc ? 1 : 0;
+      std::vector<VhSummary> all(W);
+      if (int rc = comm->ops.allgather_host(comm->ops.ctx, &mine, all.data(), sizeof(VhSummary)))
+        return rc < 0 ? rc : vh_fail(VH_E_DEVICE, "all-gather of the plan summaries failed (%d)", rc);
+      bool fatal = false;
+      merge_summaries(all.data(), W, plan->ngroups, &ag, &rp, &fatal);
+      if (fatal) { comm->agreed.clear(); return lrc ? vh_fail(lrc, "%s", local_err) : vh_fail(VH_E_INVALID, "another rank rejected the plan"); }
+      if (comm->agreed.size() >= 64) comm->agreed.clear();
+      comm->agreed[sig] = vh_comm::Agreement{ag, t->sync_epoch};
+    }
 
     // ---- 2. scan this rank's shard with the agreed plan
     vh_result* r = nullptr;
     { std::lock_guard<std::mutex> lk(t->mu); lrc = query_launch_locked(t, x, plan, &r, rp.cap_override, rp.force_hash, rp.part_override, rp.no_part, false, nullptr, &ag, true); }
+    if (lrc && cached && changed) { lrc = VH_OK; r = nullptr; }          // a stale agreement may not even plan: not an error, everyone re-agrees below
     if (lrc && !local_err[0]) snprintf(local_err, sizeof(local_err), "%s", g_err);
     std::unique_ptr<vh_result> holder(r);
     struct Detach { vh_result* r; ~Detach() { if (r) r->exec = nullptr; } } detach{r};   // unless handed out, the partial never owns the context (the guard does)
@@ -477,7 +511,8 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
     const unsigned long long host_err = retry == 1 ? VH_ERR_HASH_FULL : retry == 2 ? VH_ERR_RANGE : retry == 3 ? VH_ERR_PART_FULL : 0ull;
     hipLaunchKernelGGL(sharded_flags_kernel, dim3(1), dim3(64), 0, st, r && !sparse ? r->plan.counters : nullptr, comm->d_flags, host_err,
                        (unsigned long long)(lrc ? 1 : 0), r ? r->info.scanned_recs : 0ull, r ? r->info.scanned_segments : 0ull,
-                       (unsigned long long)(r ? (sparse ? 100 + (r->mode == VH_MODE_HASH ? 0 : r->mode) : r->mode) : 0), r && sparse ? r->info.ngroups : 0ull);
+                       (unsigned long long)(r ? (sparse ? 100 + (r->mode == VH_MODE_HASH ? 0 : r->mode) : r->mode) : 0), r && sparse ? r->info.ngroups : 0ull,
+                       (unsigned long long)(changed ? 1 : 0));
     HIP_TRY(hipGetLastError());
     if (r && sparse) {   // the row counter of a finalised result is on the host already
       HIP_TRY(hipMemcpyAsync(comm->d_flags + 6, &r->info.passed_recs, sizeof(uint64_t), hipMemcpyHostToDevice, st));
@@ -487,7 +522,8 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
     HIP_TRY(hipMemcpyAsync(comm->h_flags, comm->d_flags, VH_FLAG_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     const unsigned long long* f = comm->h_flags;
-    if (f[3]) return lrc ? vh_fail(lrc, "%s", local_err) : vh_fail(VH_E_DEVICE, "the query failed on another rank");
+    if (f[10]) { comm->agreed.erase(sig); continue; }             // some rank's table changed: the agreement is void for all, this attempt is dropped
+    if (f[3]) { comm->agreed.clear(); return lrc ? vh_fail(lrc, "%s", local_err) : vh_fail(VH_E_DEVICE, "the query failed on another rank"); }
     const unsigned long long my_mode = r ? (sparse ? 100 + (r->mode == VH_MODE_HASH ? 0 : r->mode) : r->mode) : 0;
     if (f[7] != (unsigned long long)W * my_mode || f[8] != (unsigned long long)W * my_mode * my_mode)
       return vh_fail(VH_E_DEVICE, "ranks planned different table organisations for one query (this rank: %llu): plans or table shapes differ between ranks", my_mode);

@@ -191,7 +191,10 @@ __device__ __forceinline__ bool vh_emit_have(const VhEmitArgs& A, uint64_t i, bo
 // Compacted emission of the groups. A wave covers VH_EMIT_SPAN x 64 consecutive table entries and takes ONE output
 // range for all of them: a position atomic per 64 entries (the first version) is a returning atomic on a single address
 // and serialises at ~20 ns each — 26 ms for a 64 M-slot hash table, five times the scan that filled it.
-#define VH_EMIT_SPAN 16
+// VH_EMIT_SPAN x 64 table entries per wave and ONE position atomic for all of them: the atomic is a returning one on a single
+// address (~20 ns each; 64 M-slot hash tables used to spend 26 ms there with one per 64 entries). Small tables take SPAN = 2
+// instead: 100 K entries are then 780 waves instead of 98, which is what keeps the PCIe writes of a direct emission in flight.
+template <int VH_EMIT_SPAN>
 __global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
   const int lane = threadIdx.x & 63;
   const uint64_t wave_first = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * (VH_EMIT_SPAN * 64ull);

@@ -959,7 +959,8 @@ struct VhSummary {
 // ... and what every rank plans with instead of its own view, so that all of them build the same table organisation.
 struct VhAgreed {
   uint64_t klo[VH_MAX_GROUP], khi[VH_MAX_GROUP];
-  uint64_t rows_to_scan;
+  uint64_t rows_to_scan;      // over all ranks
+  uint64_t rows_max;          // the largest shard: what one rank's kernels will see
   double sel;
 };
 
@@ -1413,6 +1414,11 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         }
       }
       want_part = sel >= (covered ? 0.04 : 0.055);
+      // ... and the second phase has a price that does not depend on the rows (every block clears and merges a 120 KB LDS
+      // table: ~0.25 ms for 13 partitions), while what partitioning saves grows with the survivors: ~50 ms per 1 G rows and
+      // point of selectivity beyond the crossover. A 125 M-row shard of C3 (8 GPUs) stays on direct atomics, 1 G rows do not.
+      const double shard_rows = (double)(ag ? ag->rows_max : rows_to_scan);
+      if (want_part && shard_rows * (sel - (covered ? 0.03 : 0.045)) < 5e6) want_part = false;
     }
     if (want_part) {
       // most rows pass: build the tuples without compacting survivors first (lanes kernel, phase 1 only)
@@ -2110,7 +2116,8 @@ static int result_finalize(vh_result* r, int* retry) {
   A.total_groups = P.counters + 6;
   for (int i = 0; i < r->nhaving; ++i) { A.hprog[i] = r->hprog[i]; A.htype[i] = r->htype[i]; }
   for (int i = 0; i < VH_MAX_HAVING_LITS; ++i) A.hlits[i] = r->hlits[i];
-  hipLaunchKernelGGL(emit_groups_kernel, dim3((unsigned)((A.n + 256 * VH_EMIT_SPAN - 1) / (256 * VH_EMIT_SPAN))), dim3(256), 0, st, A);
+  if (A.n <= (4u << 20)) hipLaunchKernelGGL(emit_groups_kernel<2>, dim3((unsigned)((A.n + 256 * 2 - 1) / (256 * 2))), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(emit_groups_kernel<16>, dim3((unsigned)((A.n + 256 * 16 - 1) / (256 * 16))), dim3(256), 0, st, A);
   HIP_TRY(hipGetLastError());
   if (r->topk_active) {
     // radix select of the top_k-th best sort key among the emitted rows (8 x 8 bits, no host round trip), then keep
@@ -2248,12 +2255,22 @@ static int query_agg_multipass(vh_table* t, const vh_plan* plan, vh_result** out
     return vh_fail(VH_E_UNSUPPORTED, "%d metrics take several passes: apply HAVING / top-N to the returned groups", plan->nmetrics);
   const int per = VH_MAX_METRIC - 4;
   std::vector<std::unique_ptr<vh_result>> parts;
+  int count_col = -1;
+  for (int j = 0; j < plan->nmetrics; ++j)
+    if (plan->metrics[j] >= 0 && (size_t)plan->metrics[j] < t->cols.size() && t->cols[plan->metrics[j]].kind == VH_METRIC_COUNT) count_col = plan->metrics[j];
+  std::vector<int> part_user;                                  // metrics of each pass that belong to the caller's list
   for (int off = 0; off < plan->nmetrics; off += per) {
+    const int nm = std::min(per, plan->nmetrics - off);
+    std::vector<int32_t> cm(plan->metrics + off, plan->metrics + off + nm);
+    bool avg = false, cnt = false;
+    for (int32_t c : cm) if (c >= 0 && (size_t)c < t->cols.size()) { avg |= t->cols[c].kind == VH_METRIC_AVG; cnt |= t->cols[c].kind == VH_METRIC_COUNT; }
+    if (avg && !cnt && count_col >= 0) cm.push_back(count_col);   // an AVG slice still divides by the query's COUNT (scan.cc:239-241): it rides along
     vh_plan cp = *plan;
-    cp.metrics = plan->metrics + off; cp.nmetrics = std::min(per, plan->nmetrics - off);
+    cp.metrics = cm.data(); cp.nmetrics = (int32_t)cm.size();
     vh_result* r = nullptr;
     if (int rc = vh_query_agg(t, &cp, &r)) return rc;
     parts.emplace_back(r);
+    part_user.push_back(nm);
   }
   vh_result* base = parts[0].get();
   const uint64_t n = base->ngroups_host;
@@ -2278,7 +2295,7 @@ static int query_agg_multipass(vh_table* t, const vh_plan* plan, vh_result** out
   size_t bytes = 0;
   for (int i = 0; i < nk; ++i) { rf->off_key[i] = bytes; bytes += (std::max<uint64_t>(n, 1) * vh_elem_size(base->plan.g[i].type()) + 255) / 256 * 256; }
   std::vector<std::pair<const vh_result*, int>> src;      // joined device-metric index -> (pass, its device metric)
-  for (auto& pr : parts) for (int u : pr->user_metric) src.push_back({pr.get(), u});
+  for (size_t k = 0; k < parts.size(); ++k) for (int j = 0; j < part_user[k]; ++j) src.push_back({parts[k].get(), parts[k]->user_metric[j]});
   if (hidden_from) src.push_back({hidden_from, hidden_from->plan.nmetric - 1});
   if (src.size() > 4096) return vh_fail(VH_E_UNSUPPORTED, "too many metrics");
   std::vector<size_t> off_state(src.size());
