@@ -176,6 +176,8 @@ struct VhPlanDev {
   int32_t part_shift;        // groups per partition = 1 << part_shift
   int32_t tw;                // 64-bit words per tuple (word 0 low half = gid)
   int32_t ext_tuples;        // tuples per extent (a tile's run of one partition never straddles extents)
+  int32_t part_split;        // partitions phase 2 aggregates (= npart)
+  int32_t pad_split;
   uint64_t* tuples;          // max_extents x ext_tuples x tw words
   uint32_t* part_count;      // [npart] extents recorded per partition
   uint32_t* part_extents;    // [npart][part_cap] extent ids

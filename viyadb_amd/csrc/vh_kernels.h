@@ -18,6 +18,10 @@
 #include "vh_internal.h"
 #include <type_traits>
 
+#ifndef VH_ABLATE
+#define VH_ABLATE 0      // measurement builds only (tools/build_variant.py -DVH_ABLATE=n -> viyadb_amd/build/variants/, never the shipped library):
+#endif                   // 1 = no payload gathers, 2 = no aggregate sink, 4 = no tuple store in phase 1 of DENSE_PART, 8 = that store non-temporal
+
 // ------------------------------------------------------------------ utilities
 __host__ __device__ __forceinline__ uint64_t vh_splitmix64(uint64_t x) {
   x += 0x9E3779B97F4A7C15ull;
@@ -531,7 +535,7 @@ enum { VH_MODE_DENSE_LDS = 1, VH_MODE_DENSE_GLOBAL = 2, VH_MODE_HASH = 3, VH_MOD
 // therefore keeps a small open-addressing table in LDS; a row whose key finds (or claims) a slot there costs LDS
 // atomics only, everything else falls through to the HBM table. A wave that mostly falls through (high-cardinality
 // keys: the table fills up at once) stops probing LDS after a warm-up.
-struct VhLdsHashWave { uint32_t hits, misses; bool bypass; unsigned long long npairs; /* per lane: fresh (group, id) pairs */ };
+struct VhLdsHashWave { uint32_t hits, misses; bool bypass; unsigned long long npairs; /* per lane: fresh (group, id) pairs */ bool dead = false; /* wave-uniform: an insert of this wave found the table full */ };
 
 __device__ __forceinline__ bool vh_lds_hash_find(const VhPlanDev& P, char* lds, uint64_t key, uint32_t& slot_out) {
   unsigned long long* lk = reinterpret_cast<unsigned long long*>(lds + P.lds_hkeys_off);
@@ -631,6 +635,7 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
     nfresh += __popcll(__ballot(active && fresh));
     if (__ballot(active && bad)) {
       if (active && bad) atomicOr(P.counters + 2, VH_ERR_HASH_FULL);
+      H.dead = true;
     }
   } else if (__ballot(active && bad)) {
     if (active && bad) atomicOr(P.counters + 2, VH_ERR_RANGE);
@@ -713,6 +718,11 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
   unsigned long long npassed = 0, nfresh = 0;
 
   for (uint32_t unit = blockIdx.x; unit < P.total_units; unit += gridDim.x) {
+    // An aggregate table that has overflowed makes every further insert walk its whole probe limit (a 1 M-slot table under
+    // 37 M groups: seconds instead of milliseconds before the host could re-plan). A wave that has seen an insert fail
+    // knows the attempt is void and stops; no wave looks at the global flag (a vector load in the scan loop would drain
+    // the prefetched predicate columns behind it: measured 0.4 ms on C3).
+    if (MODE == VH_MODE_HASH && H.dead) break;
     const uint32_t seg = unit / P.units_per_seg;
     const uint32_t unit_base = (unit - seg * P.units_per_seg) * P.unit_rows;
     const uint32_t seg_rows = P.seg_rows[seg];
@@ -937,10 +947,17 @@ __device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTil
   if (T.r_ext != ~0u) T.r_fill += cnt;
   if (active && pe != ~0u) {                 // ~0: tuple buffer exhausted, the host re-runs (VH_ERR_PART_FULL)
     uint64_t* d = P.tuples + ((uint64_t)pe * et + pf + rank) * tw;
-    if (tw == 2) {
+    if (VH_ABLATE & 4) { if (words[0] == 0x123456789ABCDEFull) d[0] = 1; }   // measurement build: everything but the tuple store
+    else if (tw == 2) {
       typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
       u64x2 v; v.x = words[0]; v.y = words[1];
-      *reinterpret_cast<u64x2*>(d) = v;
+      if (VH_ABLATE & 8) __builtin_nontemporal_store(v, reinterpret_cast<u64x2*>(d));
+      else *reinterpret_cast<u64x2*>(d) = v;
+    } else if (tw == 4) {
+      typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+      u64x2 v0, v1; v0.x = words[0]; v0.y = words[1]; v1.x = NW > 2 ? words[NW > 2 ? 2 : 0] : 0; v1.y = NW > 3 ? words[NW > 3 ? 3 : 0] : 0;
+      if (VH_ABLATE & 8) { __builtin_nontemporal_store(v0, reinterpret_cast<u64x2*>(d)); __builtin_nontemporal_store(v1, reinterpret_cast<u64x2*>(d) + 1); }
+      else { reinterpret_cast<u64x2*>(d)[0] = v0; reinterpret_cast<u64x2*>(d)[1] = v1; }
     } else {
 #pragma unroll
       for (int w = 0; w < NW; ++w)
@@ -1062,9 +1079,6 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
   // is a dependent chain (queue -> gather -> table), so its latency is what a wave's survivors cost.
   uint64_t gv[VH_FAST_COLS], mv[VH_FAST_COLS];
   uint32_t gsh[VH_FAST_COLS], msh[VH_FAST_COLS];
-#ifndef VH_ABLATE
-#define VH_ABLATE 0      // measurement builds only (tools/build_variant.py): 1 = no payload gathers, 2 = no aggregate sink
-#endif
 #pragma unroll
   for (int i = 0; i < VH_FAST_COLS; ++i) {
     gv[i] = 0; gsh[i] = 0;
@@ -1138,6 +1152,7 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
     nfresh += __popcll(__ballot(active && fresh));
     if (__ballot(active && bad)) {
       if (active && bad) atomicOr(P.counters + 2, VH_ERR_HASH_FULL);
+      H.dead = true;
     }
   } else if (__ballot(active && bad)) {
     if (active && bad) atomicOr(P.counters + 2, VH_ERR_RANGE);
@@ -1278,6 +1293,7 @@ __global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_ag
       cnt = 0;
     }
     have = nhave; seg = nseg; unit_base = nunit_base; wave_base = nwave_base; seg_rows = nseg_rows;
+    if (MODE == VH_MODE_HASH && H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
   }
 
   if (MODE == VH_MODE_DENSE_PART) vh_part_tile_finish(P, T, lane);

@@ -14,5 +14,5 @@ void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStrea
 void vh_launch_part_agg(const VhPlanDev& P, int blocks_per_part, size_t lds, hipStream_t s) {
   if (lds > 64 * 1024)   // a workgroup may own up to 160 KB of LDS on gfx950, but dynamic LDS above 64 KB has to be asked for
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&part_agg_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((part_agg_kernel<1024>), dim3(P.npart * blocks_per_part), dim3(1024), lds, s, P, blocks_per_part);
+  hipLaunchKernelGGL((part_agg_kernel<1024>), dim3(P.part_split * blocks_per_part), dim3(1024), lds, s, P, blocks_per_part);   // only the partitions that were sent through tuples
 }

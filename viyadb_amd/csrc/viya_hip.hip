@@ -1400,10 +1400,6 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       if (rc) { return rc; }
     }
     if (want_part && !(p->flags & VH_PLAN_FORCE_PART) && !part_tuples_override) {
-      // crossover measured on the C3 table (profiles/r01/NOTES.md): direct atomics cost 2 x survivors / 23.3 G/s on top of the
-      // scan (5 %: 5.0-5.15 ms, 6 %: 5.63, 7 %: 6.51, 8 %: 7.41), partitioned 4.97 / 5.30 / 5.56 / 5.86 ms
-      // ... with a payload projection covering the query the gathers shrink for both, which exposes the atomic bound of the
-      // direct form sooner (profiles/r02/NOTES.md: 3 % 3.25 vs 3.59 ms, 5 % 4.60 vs 4.07-4.22, 8 % 7.38 vs 5.2-5.6): switch at 4 %
       bool covered = false;
       if (!(p->flags & VH_PLAN_NO_PACK)) {
         for (auto& pk : t->packs) {
@@ -1413,6 +1409,13 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
           covered |= all;
         }
       }
+      // Crossover on the C3 table (1 B rows; profiles/r02/NOTES.md). Direct atomics cost 2 x survivors / 23.3 G/s on top of the
+      // scan and are the same on every box: 3 % 3.26 ms, 5 % 4.60, 6 % 5.58, 8 % 7.38, 11 % 10.2. Partitioned, with the payload
+      // gathered from a projection: 3.40-3.55 / 4.05-4.5 / 4.45-4.85 / 5.2-5.6 / 6.5-6.7 (it varies by +-5 % from run to run: it
+      // lives off scattered writes, whose cost depends on where the tuple extents land). Without a projection the gathers
+      // dominate both and the switch stays at 5.5 %. A split — some partitions through tuples, the rest straight to the table, so
+      // that the atomic unit and the write path work side by side — was measured too: SLOWER than either pure form at every
+      // selectivity (5 %: 4.8 ms, 8 %: 6.1, 11 %: 7.3): written-through atomics and tuple stores queue for the same thing.
       want_part = sel >= (covered ? 0.04 : 0.055);
       // ... and the second phase has a price that does not depend on the rows (every block clears and merges a 120 KB LDS
       // table: ~0.25 ms for 13 partitions), while what partitioning saves grows with the survivors: ~50 ms per 1 G rows and
@@ -1438,6 +1441,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       mode = VH_MODE_DENSE_PART;
       P.part_shift = shift;
       P.npart = (int32_t)np;
+      P.part_split = (int32_t)np;    // every partition goes through tuples (a split with direct atomics for the rest lost to both pure forms)
       // tuple words: word 0 = gid | first 32-bit value << 32; 64-bit values own a word; 32-bit values pair up
       int tw = 1, half_free_word = 0;  // word 0 has its upper half free
       bool have_half = true;
@@ -1446,6 +1450,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         else if (have_half) { P.m[j].set_tword((uint8_t)half_free_word); P.m[j].set_tshift(32); have_half = false; }
         else { P.m[j].set_tword((uint8_t)tw); P.m[j].set_tshift(0); half_free_word = tw++; have_half = true; }
       }
+      if (getenv("VH_EXP_TW4") && tw == 2) tw = 4;   // experiment: 32-byte tuples (no partial 32-byte HBM words)
       P.tw = tw;
       // phase-2 LDS table for one partition
       const uint64_t gpp = 1ull << shift;
@@ -1847,7 +1852,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
     if (mode == VH_MODE_DENSE_PART) {
-      const int bpp = std::max(1, std::min(16, g_ctx.num_cu / std::max(1, P.npart)));
+      const int bpp = std::max(1, std::min(16, g_ctx.num_cu / std::max(1, P.part_split)));
       vh_launch_part_agg(P, bpp, lds_table, st);
     }
   }
