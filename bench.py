@@ -29,15 +29,15 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
-def measured_traffic(workload: str, rows_on_rank: int, kernel: str):
+def measured_traffic(workload: str, rows_on_rank: int, kernel: str, packed: bool):
     """HBM bytes per launch from the newest committed rocprofv3 PMC summary (profiles/rNN/) whose recorded kernel is the
     kernel that just ran, scaled by rows. PMC counters cannot be read inside a normal run (tools/profile_round.sh collects
     them with the same command line); a summary taken with another kernel is refused: traffic = null."""
     import glob
     first = kernel.split(" + ")[0]
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "%s_1gpu_pmc_hbm.json" % workload.lower())), reverse=True):
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "%s_1gpu_pmc_hbm*.json" % workload.lower())), reverse=True):
         d = json.load(open(f))
-        if first and first in d.get("kernel", ""):
+        if first and first in d.get("kernel", "") and bool(d.get("packed", False)) == bool(packed):
             return d["B_meas_per_launch"] * rows_on_rank / d["rows"], os.path.relpath(f, ROOT), d.get("head")
     return None, None, None
 
@@ -249,7 +249,7 @@ def main():
     fcols = sorted({f[1] for f in w.plan.filter if f[0] in ("rel", "in")})
     fbytes = sum(capi.ELEM_SIZE[w.columns[c].elem] for c in fcols)
     b_min = rows_rank0 * fbytes + last.passed_recs * max(0, w.bytes_per_row_referenced - fbytes)
-    traffic, traffic_src, traffic_head = measured_traffic(args.workload, my_segments * w.segment_rows, last.kernel)
+    traffic, traffic_src, traffic_head = measured_traffic(args.workload, my_segments * w.segment_rows, last.kernel, last.packed)
     credited = min(algo_bytes, traffic) if traffic else algo_bytes  # never credit more than was moved
     achieved = credited / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
 

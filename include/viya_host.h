@@ -32,6 +32,11 @@ typedef struct vdb_stats {          /* query::QueryStats (src/query/stats.h:35-5
 VDB_API int vdb_open(const char* config_json, int device, vdb** out);        /* db::Database(config) */
 VDB_API void vdb_close(vdb* db);
 VDB_API int vdb_create_table(vdb* db, const char* table_json);              /* Database::CreateTable */
+/* One process per GPU of a node, each holding ITS rows of the tables: from here on aggregate queries run over all ranks'
+ * rows (the same vdb_query on every rank, rows on rank 0; vh_query_agg_sharded underneath). `vh_comm_handle` comes from
+ * vh_comm_init / vh_comm_init_custom (include/viya_hip.h) and stays the caller's; NULL leaves the node. Dictionary codes of
+ * string dimensions must agree between the ranks (one ingest order, or numeric / time dimensions). */
+VDB_API int vdb_join_node(vdb* db, void* vh_comm_handle);
 /* input::SimpleLoader::Load: rows in the facade's row encoding; now < 0 = wall clock
  * (the reference's VIYA_TEST_ROLLUP_TS test hook, src/codegen/db/rollup.cc:47-49) */
 VDB_API int vdb_load(vdb* db, const char* table, const char* rows, size_t rows_len, int64_t now);

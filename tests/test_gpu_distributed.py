@@ -215,3 +215,92 @@ def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "strong" and d["value"] > 1e9
     assert d["config"]["rows"] == 40_000_000 and d["config"]["groups"] == 100_000
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+
+
+HOST_WORKER = textwrap.dedent('''
+    import os, sys, json
+    sys.path.insert(0, {root!r})
+    import numpy as np, torch, torch.distributed as dist
+    from viyadb_amd import distributed, executor, hostdb
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    executor.init(0)
+    comm = distributed.Comm.gloo(dist)
+    spec = json.load(open({spec!r}))
+    db = hostdb.Database({{}}, device=0)
+    db.create_table(spec["table"])
+    db.load("events", spec["rows"][rank], now=spec["now"])
+    db.join_node(comm)
+    out = []
+    for q in spec["queries"]:
+        rows, stats = db.query(q, now=spec["now"])
+        out.append({{"rows": rows, "stats": {{k: stats[k] for k in ("scanned_recs", "scanned_segments", "aggregated_recs", "output_recs")}}}})
+    json.dump(out, open({out!r} + ".%d.json" % rank, "w"))
+    dist.barrier()
+    db.close()
+    comm.close()
+    dist.destroy_process_group()
+''')
+
+
+def test_cxx_database_queries_all_ranks_rows(tmp_path):
+    """The C++ host shim end to end over two ranks (Database::JoinNode -> GpuAggregate -> vh_query_agg_sharded): every rank loaded
+    its own rows, the same vdb_query runs on both, rank 0 returns what ONE database holding all rows returns — string and time
+    dimensions, AVG over the hidden count, count-distinct, HAVING, sort + limit."""
+    import json
+    import random
+    from viyadb_amd import executor, hostdb
+    rnd = random.Random(5)
+    now = 1496570140
+    table = {"name": "events", "segment_size": 5000,
+             "dimensions": [{"name": "country"}, {"name": "event", "cardinality": 100}, {"name": "t", "type": "time", "format": "posix"}, {"name": "n", "type": "uint"}],
+             "metrics": [{"name": "count", "type": "count"}, {"name": "revenue", "type": "double_sum"}, {"name": "best", "type": "int_max"},
+                         {"name": "avg_len", "type": "long_avg"}, {"name": "users", "type": "bitset"}]}
+    countries, events = ["US", "RU", "IL", "KZ", "CH", "AZ"], ["open", "purchase", "refund", "donate"]
+
+    def make_rows(n, seed):
+        r = random.Random(seed)
+        # every rank first sees every string once, in the same order: the same dictionary codes everywhere
+        rows = [[c, e, str(now - 1), "0", "0.5", "1", "7", "1"] for c in countries for e in events]
+        for _ in range(n):
+            rows.append([r.choice(countries), r.choice(events), str(now - r.randrange(0, 40 * 86400)), str(r.randrange(0, 50)),
+                         str(r.randrange(0, 4000) / 8.0), str(r.randrange(-1000, 1000)), str(r.randrange(1, 500)), str(r.randrange(0, 300))])
+        return rows
+    rows = [make_rows(7000, 11), make_rows(9000, 12)]
+    queries = [
+        {"type": "aggregate", "table": "events", "dimensions": ["country", "event"], "metrics": ["count", "revenue", "best", "avg_len"],
+         "filter": {"op": "ne", "column": "country", "value": "RU"}, "sort": [{"column": "revenue"}, {"column": "country", "ascending": True}]},
+        {"type": "aggregate", "table": "events", "select": [{"column": "t", "granularity": "day"}, {"column": "country"}, {"column": "users"}, {"column": "count"}],
+         "filter": {"op": "lt", "column": "n", "value": "25"}, "having": {"op": "ge", "column": "count", "value": "3"},
+         "sort": [{"column": "count"}, {"column": "country", "ascending": True}, {"column": "t", "ascending": True}], "limit": 40},
+        {"type": "aggregate", "table": "events", "dimensions": ["n"], "metrics": ["count", "users"], "filter": {"op": "gt", "column": "count", "value": "0"},
+         "sort": [{"column": "n", "ascending": True}]},
+    ]
+    spec = str(tmp_path / "spec.json")
+    json.dump({"table": table, "rows": rows, "queries": queries, "now": now}, open(spec, "w"))
+    out = str(tmp_path / "out")
+    script = tmp_path / "worker.py"
+    script.write_text(HOST_WORKER.format(root=ROOT, spec=spec, out=out))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    got = [json.load(open(out + ".%d.json" % k)) for k in range(2)]
+    executor.init(0)
+    db = hostdb.Database({}, device=0)
+    try:
+        db.create_table(table)
+        db.load("events", rows[0], now=now)
+        db.load("events", rows[1], now=now)
+        for k, q in enumerate(queries):
+            want, st = db.query(q, now=now)
+            assert got[0][k]["rows"] == want, (k, got[0][k]["rows"][:3], want[:3])
+            assert got[1][k]["rows"] == []
+            assert got[0][k]["stats"]["output_recs"] == len(want) and len(want) > 0
+            assert got[0][k]["stats"]["aggregated_recs"] == st["aggregated_recs"]
+    finally:
+        db.close()

@@ -9,20 +9,24 @@ OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
-one() {   # name, rows, bref, bench args...
+one() {   # name (workload[_variant]), rows, bref, bench args...
   local W=$1 ROWS=$2 BREF=$3; shift 3
   python bench.py "$@" > $OUT/bench_${W}_1gpu.json 2> $OUT/bench_${W}.err
   tail -c 300 $OUT/bench_${W}_1gpu.json; echo
   local K=$(python -c "import json; print(json.load(open('$OUT/bench_${W}_1gpu.json'))['roofline']['kernel'])")
+  local PK=$(python -c "import json; print(int(json.load(open('$OUT/bench_${W}_1gpu.json'))['config']['payload_projection']))")
   (cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/$OUT/kt_$W -o $W -- python $REPO/bench.py "$@" --steps 10 --warmup 2 --no-cpu --no-check > $REPO/$OUT/kt_$W.log 2>&1)
   python tools/pmc_summary.py --kernel-stats $(find $OUT/kt_$W -name "*_results.db" | head -1) $OUT/${W}_1gpu_kernel_stats.csv; head -4 $OUT/${W}_1gpu_kernel_stats.csv | cut -c1-160
   for C in FETCH_SIZE WRITE_SIZE; do
     (cd /tmp && rocprofv3 --pmc $C -d $REPO/$OUT/pmc_${C}_$W -o $W -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-check > $REPO/$OUT/pmc_${C}_$W.log 2>&1)
   done
-  python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE_$W $OUT/pmc_WRITE_SIZE_$W $OUT/${W}_1gpu_pmc_hbm.json --rows $ROWS --bref $BREF --kernel "$K" --head $HEAD \
+  local J=$OUT/${W}_1gpu_pmc_hbm.json
+  case $W in *_*) J=$OUT/${W%%_*}_1gpu_pmc_hbm_${W#*_}.json;; esac
+  python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE_$W $OUT/pmc_WRITE_SIZE_$W $J --rows $ROWS --bref $BREF --kernel "$K" --head $HEAD --packed $PK \
     --command "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py $* --steps 3 --warmup 1 --no-cpu --no-check"
 }
 one c3 1000000000 32e9
+one c3_direct 1000000000 32e9 --flags 16 --no-cpu             # the same query forced onto direct atomics (what a slower box or a smaller shard runs)
 one c2 100000000 2e9 --workload C2 --no-cpu
 one c5 125000000 3.5e9 --workload C5 --segments 125 --no-cpu --steps 5 --warmup 1
 one c5t 125000000 1.5e9 --workload C5t --segments 125 --no-cpu --steps 5 --warmup 1

@@ -235,7 +235,7 @@ namespace detail {
 // The body of GpuAggregate on a mirror that is already up to date: plan -> vh_query_agg -> typed groups.
 void AggregateOnMirror(AggregateQuery& query, vh_table* mirror, const std::vector<uint64_t>& seg_rows, bool having_on_device,
                        const std::vector<db::AnyNum>& fargs, const std::vector<db::AnyNum>& hargs, size_t skip, size_t limit,
-                       int64_t now, Groups& groups, QueryStats& stats) {
+                       int64_t now, Groups& groups, QueryStats& stats, void* node_comm) {
   db::Table& table = query.table();
   PlanFilterBuilder fb(table, fargs);
   query.filter()->Accept(fb);
@@ -259,14 +259,15 @@ void AggregateOnMirror(AggregateQuery& query, vh_table* mirror, const std::vecto
   ConfigureTopN(query, skip, limit, having_on_device, plan);
 
   vh_result* res = nullptr;
-  vh_check(vh_query_agg(mirror, &plan, &res));
+  if (node_comm) vh_check(vh_query_agg_sharded(mirror, &plan, static_cast<vh_comm*>(node_comm), /*root*/0, &res));   // all ranks' rows; groups land on rank 0
+  else vh_check(vh_query_agg(mirror, &plan, &res));
   std::unique_ptr<vh_result, void (*)(vh_result*)> guard(res, vh_result_free);
   FetchGroups(res, query, groups, stats);
 }
 }  // namespace detail
 
 void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, std::vector<db::AnyNum> fargs,
-                  size_t skip, size_t limit, std::vector<db::AnyNum> hargs, int64_t now) {
+                  size_t skip, size_t limit, std::vector<db::AnyNum> hargs, int64_t now, void* node_comm) {
   db::Table& table = query.table();
   Groups groups;
   const bool having_on_device = HavingOnDevice(query, skip, limit);
@@ -274,7 +275,7 @@ void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, s
     std::lock_guard<std::mutex> lk(table.mu);
     GpuMirror* mir = ensure_mirror(table);
     std::vector<uint64_t> seg_rows = sync_mirror(table, mir);  // segments_copy() + size() snapshot
-    AggregateOnMirror(query, mir->handle, seg_rows, having_on_device, fargs, hargs, skip, limit, now, groups, stats);
+    AggregateOnMirror(query, mir->handle, seg_rows, having_on_device, fargs, hargs, skip, limit, now, groups, stats, node_comm);
   }
   PostAggregate(query, groups, having_on_device, hargs, skip, limit, output, stats);
 }

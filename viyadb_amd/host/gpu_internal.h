@@ -144,7 +144,7 @@ std::vector<vh_group_col> PlanGroupCols(AggregateQuery& query, int64_t now);
 void FetchGroups(vh_result* res, AggregateQuery& query, Groups& groups, QueryStats& stats, bool extra_count_state = false);
 void AggregateOnMirror(AggregateQuery& query, vh_table* mirror, const std::vector<uint64_t>& seg_rows, bool having_on_device,
                        const std::vector<db::AnyNum>& fargs, const std::vector<db::AnyNum>& hargs, size_t skip, size_t limit,
-                       int64_t now, Groups& groups, QueryStats& stats);
+                       int64_t now, Groups& groups, QueryStats& stats, void* node_comm = nullptr);
 // PostAggVisitor + SortVisitor (post_agg.cc:26-147, sort.cc:24-75) over fetched groups.
 void PostAggregate(AggregateQuery& query, const Groups& groups, bool having_on_device, const std::vector<db::AnyNum>& hargs,
                    size_t skip, size_t limit, RowOutput& output, QueryStats& stats);

@@ -56,6 +56,10 @@ int vdb_open(const char* config_json, int device, vdb** out) {
 }
 void vdb_close(vdb* db) { delete db; }
 
+int vdb_join_node(vdb* db, void* vh_comm_handle) {
+  return vdbimpl::guard([&] { db->db->JoinNode(vh_comm_handle); });
+}
+
 int vdb_create_table(vdb* db, const char* table_json) {
   return vdbimpl::guard([&] { db->db->CreateTable(viya::util::Config(std::string(table_json))); });
 }

@@ -232,7 +232,7 @@ query::QueryStats Database::Query(const util::Config& conf, query::RowOutput& ou
   std::vector<AnyNum> fargs = query::PackFilterArgs(*table, q.filter());
   std::vector<AnyNum> hargs = query::PackFilterArgs(*table, q.having());
   stats.compile_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  query::GpuAggregate(q, output, stats, fargs, q.skip(), q.limit(), hargs, now);
+  query::GpuAggregate(q, output, stats, fargs, q.skip(), q.limit(), hargs, now, comm_);
   stats.whole_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   return stats;
 }

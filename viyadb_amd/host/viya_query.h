@@ -227,7 +227,7 @@ std::vector<db::AnyNum> PackFilterArgs(const db::Table& table, const Filter* fil
 // The function that stands where the JIT-compiled viya_query_agg stood (src/query/runner.h:33-35):
 // same argument meaning; `now` < 0 means std::time(nullptr) (VIYA_TEST_ROLLUP_TS in the reference).
 void GpuAggregate(AggregateQuery& query, RowOutput& output, QueryStats& stats, std::vector<db::AnyNum> fargs,
-                  size_t skip, size_t limit, std::vector<db::AnyNum> hargs, int64_t now);
+                  size_t skip, size_t limit, std::vector<db::AnyNum> hargs, int64_t now, void* node_comm = nullptr);
 
 // ... and where viya_query_select / viya_query_search stood (src/query/runner.h:29-31,37-39): same arguments.
 void GpuSelect(SelectQuery& query, RowOutput& output, QueryStats& stats, std::vector<db::AnyNum> fargs, size_t skip,
@@ -246,6 +246,12 @@ public:
   void CreateTable(const util::Config& table_conf);
   Table* GetTable(const std::string& name);
   query::QueryStats Query(const util::Config& query_conf, query::RowOutput& output, int64_t now = -1);
+  // One node, one process per GPU, every process holding ITS segments of the tables (same descriptors and the same
+  // dictionary codes everywhere): after JoinNode, aggregate queries run over all ranks' rows — the same Query() on every
+  // rank, rows delivered on rank 0 (vh_query_agg_sharded; replaces the HTTP + TSV merge of src/cluster/query/agg_runner.cc:83-140
+  // inside a node). `comm` is a vh_comm* (include/viya_hip.h: vh_comm_init / vh_comm_init_custom), owned by the caller.
+  void JoinNode(void* comm) { comm_ = comm; }
+  void* node_comm() const { return comm_; }
   void Load(const std::string& table, const std::vector<std::vector<std::string>>& rows, int64_t now = -1);
   // Cluster aggregate (src/cluster/query/agg_runner.cc:83-140) with binary partial states (partial_state.h):
   // a worker answers QueryPartial; the controller hands all answers to QueryMerge, which finishes the query.
@@ -255,6 +261,7 @@ public:
 private:
   Dictionaries dicts_;
   std::map<std::string, std::unique_ptr<Table>> tables_;
+  void* comm_ = nullptr;
 };
 
 }  // namespace db

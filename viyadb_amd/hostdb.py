@@ -25,7 +25,7 @@ class HostError(RuntimeError):
         self.reference_exception = "invalid_argument" if code == 1 else "runtime_error"
 
 
-SYMBOLS = ["vdb_open", "vdb_close", "vdb_create_table", "vdb_load", "vdb_query", "vdb_query_partial", "vdb_query_merge",
+SYMBOLS = ["vdb_open", "vdb_close", "vdb_join_node", "vdb_create_table", "vdb_load", "vdb_query", "vdb_query_partial", "vdb_query_merge",
            "vdb_table_info", "vdb_free", "vdb_last_error"]
 _lib = None
 
@@ -43,6 +43,7 @@ def load():
         lib.vdb_close.argtypes = [C.c_void_p]
         lib.vdb_close.restype = None
         lib.vdb_create_table.argtypes = [C.c_void_p, C.c_char_p]
+        lib.vdb_join_node.argtypes = [C.c_void_p, C.c_void_p]
         lib.vdb_load.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_int64]
         lib.vdb_query.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Stats)]
         lib.vdb_query_partial.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Stats)]
@@ -66,6 +67,10 @@ class Database:
         h = C.c_void_p()
         _check(self.lib.vdb_open(json.dumps(conf).encode(), device, C.byref(h)))
         self.h = h
+
+    def join_node(self, comm):
+        """comm: viyadb_amd.distributed.Comm (or None to leave): aggregate queries then cover every rank's rows, rows on rank 0."""
+        _check(self.lib.vdb_join_node(self.h, comm.handle if comm is not None else None))
 
     def close(self):
         if self.h:
