@@ -38,8 +38,9 @@ def measured_traffic(workload: str, rows_on_rank: int, kernel: str, packed: bool
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "%s_1gpu_pmc_hbm*.json" % workload.lower())), reverse=True):
         d = json.load(open(f))
         if first and first in d.get("kernel", "") and bool(d.get("packed", False)) == bool(packed):
-            return d["B_meas_per_launch"] * rows_on_rank / d["rows"], os.path.relpath(f, ROOT), d.get("head")
-    return None, None, None
+            scale = rows_on_rank / d["rows"]
+            return d["B_meas_per_launch"] * scale, os.path.relpath(f, ROOT), d.get("head"), d.get("write_bytes_raw", 0) * scale
+    return None, None, None, None
 
 
 def parity_gate(table, w, plan, my_segments, executor):
@@ -249,7 +250,7 @@ def main():
     fcols = sorted({f[1] for f in w.plan.filter if f[0] in ("rel", "in")})
     fbytes = sum(capi.ELEM_SIZE[w.columns[c].elem] for c in fcols)
     b_min = rows_rank0 * fbytes + last.passed_recs * max(0, w.bytes_per_row_referenced - fbytes)
-    traffic, traffic_src, traffic_head = measured_traffic(args.workload, my_segments * w.segment_rows, last.kernel, last.packed)
+    traffic, traffic_src, traffic_head, traffic_write = measured_traffic(args.workload, my_segments * w.segment_rows, last.kernel, last.packed)
     credited = min(algo_bytes, traffic) if traffic else algo_bytes  # never credit more than was moved
     achieved = credited / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
 
@@ -275,12 +276,15 @@ def main():
                          "kernel_ms": avg_kernel_ms,
                          "algorithmic_bytes_per_launch": algo_bytes, "b_min_bytes_per_launch": b_min,
                          "bref_over_t_GBs": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0,
+                         "frac_ref": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_kernel_ms > 0 else 0.0,
+                         "traffic_write": traffic_write,
                          "traffic_source": traffic_src, "traffic_head": traffic_head,
                          "note": "achieved = min(B_ref, B_meas) / mean HIP-event time of the scan kernel(s) on rank 0 "
                                  "(SURVEY 8d: never more than was moved, never more than the algorithm references); B_ref = rows x "
                                  "referenced bytes/row; B_meas = rocprofv3 FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) from "
-                                 "the committed PMC pass of this kernel, scaled by rows; traffic null = no pass of this kernel committed "
-                                 "(then B_ref is credited)"},
+                                 "the committed PMC pass of this kernel (same payload source), scaled by rows; traffic_write = WRITE_SIZE of "
+                                 "that pass, raw; traffic null = no pass of this kernel committed (then B_ref is credited); "
+                                 "bref_over_t_GBs / frac_ref = B_ref / t, what round 1 and SURVEY's >= 60 % target were quoted on"},
         }
         if world == 1 and not args.no_cpu:
             try:

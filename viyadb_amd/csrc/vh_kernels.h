@@ -797,9 +797,14 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
 // Global atomics execute at the memory side on this part (per-XCD L2s are not coherent with each other): ~23 G
 // read-modify-writes per second whatever the table size (profiles/r01/NOTES.md, "The atomic roofline"). For group-id
 // spaces that do not fit one CU's LDS the survivors are therefore NOT aggregated with global atomics: each becomes a
-// (gid, values) tuple; a wave collects VH_PART_TILE of them in LDS, counting-sorts the tile by partition
-// (histogram -> wave prefix -> scatter) and writes every partition's run to that partition's current extent in HBM
-// as one contiguous, coalesced store; part_agg_kernel then aggregates every partition with LDS atomics only.
+// (gid, values) tuple appended to its partition's current extent in HBM; part_agg_kernel then aggregates every
+// partition with LDS atomics only. Two writers:
+//  - the compaction kernels hand the 64 survivors of one drain to vh_part_direct_add: a ballot per partition-id bit
+//    gives every lane its rank inside its partition, the partition's cursor is fetched from the lane that owns it
+//    (ds_bpermute) and each lane stores its tuple with one 16-byte store — no LDS tile, no second pass;
+//  - the lanes form (no compaction, survivors arrive a few per step) collects VH_PART_TILE tuples in LDS,
+//    counting-sorts the tile by partition (histogram -> wave prefix -> scatter) and writes every partition's run as
+//    one contiguous, coalesced store (vh_part_tile_write / vh_part_tile_runs).
 // Per-partition state (current extent, fill) lives in lane p's registers and is handed out with v_readlane: an
 // earlier version that went through LDS arrays lost a tuple now and then when an extent was opened inside a tile.
 #define VH_PART_TILE 256     // tuples per wave tile
@@ -955,7 +960,7 @@ __device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTil
       else *reinterpret_cast<u64x2*>(d) = v;
     } else if (tw == 4) {
       typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
-      u64x2 v0, v1; v0.x = words[0]; v0.y = words[1]; v1.x = NW > 2 ? words[NW > 2 ? 2 : 0] : 0; v1.y = NW > 3 ? words[NW > 3 ? 3 : 0] : 0;
+      u64x2 v0, v1; v0.x = words[0]; v0.y = words[1]; v1.x = words[NW > 2 ? 2 : 0]; v1.y = words[NW > 3 ? 3 : 0];   // four-word tuples: two 16-byte stores
       if (VH_ABLATE & 8) { __builtin_nontemporal_store(v0, reinterpret_cast<u64x2*>(d)); __builtin_nontemporal_store(v1, reinterpret_cast<u64x2*>(d) + 1); }
       else { reinterpret_cast<u64x2*>(d)[0] = v0; reinterpret_cast<u64x2*>(d)[1] = v1; }
     } else {

@@ -1450,7 +1450,6 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         else if (have_half) { P.m[j].set_tword((uint8_t)half_free_word); P.m[j].set_tshift(32); have_half = false; }
         else { P.m[j].set_tword((uint8_t)tw); P.m[j].set_tshift(0); half_free_word = tw++; have_half = true; }
       }
-      if (getenv("VH_EXP_TW4") && tw == 2) tw = 4;   // experiment: 32-byte tuples (no partial 32-byte HBM words)
       P.tw = tw;
       // phase-2 LDS table for one partition
       const uint64_t gpp = 1ull << shift;
