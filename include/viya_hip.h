@@ -174,9 +174,12 @@ enum vh_plan_flags {
   VH_PLAN_NO_PACK = 1u << 12,     /* ablation: gather group / metric values from the
                                      column arenas even when a payload projection
                                      (vh_table_pack) covers them               */
-  VH_PLAN_FORCE_PACK = 1u << 13   /* testing: gather from a payload projection whatever
+  VH_PLAN_FORCE_PACK = 1u << 13,  /* testing: gather from a payload projection whatever
                                      the selectivity, building one if none covers
                                      the query's columns                       */
+  VH_PLAN_NO_PART2 = 1u << 14     /* ablation: no second partition level (group-id
+                                     spaces of more than 64 LDS-sized ranges stay on
+                                     direct global atomics)                    */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */

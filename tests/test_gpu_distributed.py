@@ -254,7 +254,7 @@ def test_cxx_database_queries_all_ranks_rows(tmp_path):
     rnd = random.Random(5)
     now = 1496570140
     table = {"name": "events", "segment_size": 5000,
-             "dimensions": [{"name": "country"}, {"name": "event", "cardinality": 100}, {"name": "t", "type": "time", "format": "posix"}, {"name": "n", "type": "uint"}],
+             "dimensions": [{"name": "country"}, {"name": "event", "cardinality": 100}, {"name": "t", "type": "time"}, {"name": "n", "type": "uint"}],
              "metrics": [{"name": "count", "type": "count"}, {"name": "revenue", "type": "double_sum"}, {"name": "best", "type": "int_max"},
                          {"name": "avg_len", "type": "long_avg"}, {"name": "users", "type": "bitset"}]}
     countries, events = ["US", "RU", "IL", "KZ", "CH", "AZ"], ["open", "purchase", "refund", "donate"]

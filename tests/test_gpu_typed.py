@@ -191,6 +191,60 @@ def test_partition_buffer_regrows():
         dt.close()
 
 
+def test_two_level_partitioning():
+    """Group-id spaces of more than 64 LDS-sized ranges: phase 1 partitions coarsely, part_split_kernel splits every partition 64
+    ways, phase 2 aggregates up to 4096 ranges in LDS. Compacting and lanes form of phase 1, both pools overflowing, skew (one
+    coarse partition, one sub-partition), sparse occupancy, against the oracle and the direct-atomics plan."""
+    import os
+    from viyadb_amd import capi
+    rng = np.random.default_rng(33)
+    n = 400000
+    tab = vo.Table({"name": "t", "segment_size": n, "dimensions": [{"name": "a", "type": "uint"}, {"name": "b", "type": "uint"}, {"name": "f", "type": "uint"}],
+                    "metrics": [{"name": "v", "type": "long_sum"}, {"name": "count", "type": "count"}, {"name": "lo", "type": "int_min"}, {"name": "hi", "type": "uint_max"}]})
+    for _ in range(3):
+        tab.add_segment_arrays([rng.integers(0, 3000, n).astype(np.uint32), rng.integers(0, 700, n).astype(np.uint32), rng.integers(0, 100, n).astype(np.uint32)],
+                               [rng.integers(-10**12, 10**12, n).astype(np.int64), rng.integers(1, 4, n).astype(np.uint32),
+                                rng.integers(-2**31, 2**31 - 1, n).astype(np.int32), rng.integers(0, 2**32 - 1, n).astype(np.uint32)], None, n)
+    dt = mirror_table(tab)
+    q = {"dimensions": ["a", "b"], "metrics": ["v", "count"], "filter": F("lt", "f", "50")}
+    try:
+        res, _ = run(tab, dt, q)
+        assert res.path == "dense_global"                       # 0.6 M survivors do not pay for two more passes
+        for flags, lanes in ((64 | 128, False), (64, False), (64 | 256, True)):
+            qq = dict(q, filter=F("ge", "f", "0") if lanes else F("lt", "f", "30"))
+            res, _ = run(tab, dt, qq, flags=flags)
+            assert res.path == "dense_part" and "part_split_kernel" in res.kernel and res.lanes == lanes and res.retries == 0, (res.path, res.kernel, res.lanes)
+            res, _ = run(tab, dt, qq, flags=flags | capi.PLAN_NO_PART2)
+            assert res.path == "dense_global"
+        # four metrics (wide tuples), MIN / MAX states
+        res, _ = run(tab, dt, dict(q, metrics=["v", "count", "lo", "hi"]), flags=64)
+        assert "part_split_kernel" in res.kernel
+        # either pool too small at first: the query re-plans with more room
+        for var in ("VH_TEST_PART_EXTENTS", "VH_TEST_PART_EXTENTS2"):
+            os.environ[var] = "50"
+            try:
+                res, _ = run(tab, dt, q, flags=64 | 128)
+            finally:
+                del os.environ[var]
+            assert res.path == "dense_part" and res.retries >= 1, (var, res.retries)
+        # skew: one coarse partition; one single group
+        run(tab, dt, dict(q, filter=F("lt", "a", "5")), flags=64)
+        run(tab, dt, dict(q, filter={"op": "and", "filters": [F("eq", "a", "2999"), F("eq", "b", "699")]}), flags=64)
+        run(tab, dt, dict(q, filter=F("gt", "f", "1000")), flags=64)      # nothing survives
+    finally:
+        dt.close()
+    # 1.5 M groups, three out of four empty (a dense table is planned up to 4 groups per row)
+    tab = vo.Table({"name": "t", "segment_size": n, "dimensions": [{"name": "a", "type": "uint"}, {"name": "b", "type": "uint"}],
+                    "metrics": [{"name": "count", "type": "count"}]})
+    tab.add_segment_arrays([rng.integers(0, 2000, n).astype(np.uint32), rng.integers(0, 750, n).astype(np.uint32)], [np.ones(n, dtype=np.uint32)], None, n)
+    dt = mirror_table(tab)
+    try:
+        res, _ = run(tab, dt, {"dimensions": ["a", "b"], "metrics": ["count"]}, flags=64)
+        assert res.path == "dense_part" and "part_split_kernel" in res.kernel, (res.path, res.kernel)
+    finally:
+        dt.close()
+
+
 def test_in_and_not_in(typed):
     tab, dt = typed
     for flt in ({"op": "in", "column": "s8", "values": ["v1", "v7", "v9", "nope"]},

@@ -23,6 +23,8 @@
 #endif
 #define VH_MAX_PART 64     // DENSE_PART: partitions (lane p of a wave keeps partition p's state, so at most one per lane)
 #define VH_EXT_CHUNK 8    // DENSE_PART: extents a wave reserves per global allocation
+#define VH_L2_NEXT 80      // VhPlanDev::l2: offset of the per-partition allocation cursors
+#define VH_L2_WORDS 160
 
 // Row geometry of one block step (see DESIGN.md "scan geometry"):
 // a wave covers 1024 consecutive rows per step as 4 sub-steps of 256 rows;
@@ -171,21 +173,28 @@ struct VhPlanDev {
   uint32_t* dset_tags[VH_MAX_BITSET];             // wide ids only
   uint64_t dset_mask[VH_MAX_BITSET];
   // ---- partitioned aggregation (DENSE_PART): survivors become (gid, values) tuples, radix-partitioned
-  // by gid >> part_shift into extents in HBM; a second kernel aggregates each partition in LDS
-  int32_t npart;             // <= VH_MAX_PART
-  int32_t part_shift;        // groups per partition = 1 << part_shift
+  // by gid >> part_shift into extents in HBM; a second kernel aggregates each partition in LDS. Group-id spaces of more
+  // than VH_MAX_PART LDS-sized ranges take two levels: phase 1 partitions by gid >> part_shift (= agg_shift + 6) into
+  // pool 1, part_split_kernel splits every partition 64 ways again into pool 2 (each partition owns a contiguous range
+  // of pool-2 extents, sized on the device from what phase 1 produced), and phase 2 aggregates ranges of 1 << agg_shift.
+  int32_t npart;             // partitions of phase 1, <= VH_MAX_PART
+  int32_t part_shift;        // phase 1: partition = gid >> part_shift
   int32_t tw;                // 64-bit words per tuple (word 0 low half = gid)
   int32_t ext_tuples;        // tuples per extent (a tile's run of one partition never straddles extents)
-  int32_t part_split;        // partitions phase 2 aggregates (= npart)
-  int32_t pad_split;
+  int32_t nlevel;            // 1 or 2
+  int32_t agg_shift;         // groups per LDS table of phase 2 = 1 << agg_shift (one level: == part_shift)
+  int32_t nfine;             // LDS-sized ranges phase 2 aggregates (one level: == npart)
+  int32_t ext_tuples2;       // pool 2: tuples per extent
   uint64_t* tuples;          // max_extents x ext_tuples x tw words
-  uint32_t* part_count;      // [npart] extents recorded per partition
-  uint32_t* part_extents;    // [npart][part_cap] extent ids
   uint16_t* extent_missing;  // [max_extents] tuples NOT filled in an extent (0 = full)
   uint8_t* extent_part;      // [max_extents] partition an extent belongs to (0xFF: never opened). A plain store when the extent is
                              // opened; phase 2 scans the tags. (A per-partition list needed a returning atomic on npart hot counters.)
-  uint32_t part_cap;
+  uint64_t* tuples2;         // pool 2 (two levels only), same tuple layout
+  uint16_t* extent_missing2;
+  uint8_t* extent_part2;     // tag = the SUB-partition (0..63) inside the owning partition's range
+  uint32_t* l2;              // [0..npart]: first pool-2 extent of partition p's range (prefix sums); [VH_L2_NEXT + p]: extents handed out of it
   uint32_t max_extents;
+  uint32_t max_extents2;
   // ---- counters: [0] passed rows, [1] new groups (hash), [2] error flags,
   //                [3] reserved hash slot (key == sentinel) in use, [4] distinct (group, id) pairs,
   //                [5] extent allocation cursor (DENSE_PART)

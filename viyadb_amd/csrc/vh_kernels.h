@@ -808,13 +808,23 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
 // Per-partition state (current extent, fill) lives in lane p's registers and is handed out with v_readlane: an
 // earlier version that went through LDS arrays lost a tuple now and then when an extent was opened inside a tile.
 #define VH_PART_TILE 256     // tuples per wave tile
-struct VhPartWave { uint32_t chunk_next, chunk_end; };   // extents this wave has reserved and not yet opened
+struct VhPartWave {
+  uint32_t chunk_next, chunk_end;   // extents this wave has reserved and not yet opened
+  uint32_t base, limit;             // level 2 only: the range of pool-2 extents of the partition being split ...
+  uint32_t* cursor;                 // ... and its allocation cursor (VhPlanDev::l2)
+};
 struct VhPartTile {
   uint64_t* sorted;    // LDS [VH_PART_TILE][tw], lanes form only: the tile's tuples ordered by partition
   uint32_t* hist;      // LDS [64], lanes form only: counts, then scatter cursors
   uint32_t r_ext;      // lane p: partition p's current extent (~0u: none) ...
   uint32_t r_fill;     // ... and the tuples already in it
 };
+// LEVEL 1: phase 1 writes pool 1 (partition = gid >> part_shift); LEVEL 2: part_split_kernel writes pool 2 (sub-partition 0..63)
+template <int LEVEL> __device__ __forceinline__ uint64_t* vh_pool_tuples(const VhPlanDev& P) { return LEVEL == 1 ? P.tuples : P.tuples2; }
+template <int LEVEL> __device__ __forceinline__ uint16_t* vh_pool_missing(const VhPlanDev& P) { return LEVEL == 1 ? P.extent_missing : P.extent_missing2; }
+template <int LEVEL> __device__ __forceinline__ uint8_t* vh_pool_tags(const VhPlanDev& P) { return LEVEL == 1 ? P.extent_part : P.extent_part2; }
+template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_et(const VhPlanDev& P) { return (uint32_t)(LEVEL == 1 ? P.ext_tuples : P.ext_tuples2); }
+template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_npart(const VhPlanDev& P) { return LEVEL == 1 ? (uint32_t)P.npart : 64u; }
 __host__ __device__ __forceinline__ size_t vh_part_tile_bytes(const VhPlanDev& P) {
   return ((size_t)VH_PART_TILE * P.tw * 8 + 64 * 4 + 15) / 16 * 16;
 }
@@ -823,20 +833,29 @@ __device__ __forceinline__ void vh_part_tile_init(const VhPlanDev& P, char* area
   T.hist = reinterpret_cast<uint32_t*>(area + (size_t)VH_PART_TILE * P.tw * 8);
   T.r_ext = ~0u; T.r_fill = 0;
   W.chunk_next = W.chunk_end = 0;
+  W.base = 0; W.limit = 0; W.cursor = nullptr;
 }
 
 // Open a new extent for partition p (wave-uniform). Returns ~0u when the buffer is exhausted.
+template <int LEVEL>
 __device__ __forceinline__ uint32_t vh_part_new_extent(const VhPlanDev& P, VhPartWave& W, int p, int lane) {
   if (W.chunk_next == W.chunk_end) {
-    unsigned long long c = 0;
-    if (lane == 0) c = atomicAdd(P.counters + 5, (unsigned long long)VH_EXT_CHUNK);
-    c = __shfl(c, 0);
-    W.chunk_next = (uint32_t)c;
-    W.chunk_end = (uint32_t)c + VH_EXT_CHUNK;
+    if (LEVEL == 1) {
+      unsigned long long c = 0;
+      if (lane == 0) c = atomicAdd(P.counters + 5, (unsigned long long)VH_EXT_CHUNK);
+      c = __shfl(c, 0);
+      W.chunk_next = (uint32_t)c;
+    } else {
+      uint32_t c = 0;
+      if (lane == 0) c = atomicAdd(W.cursor, (uint32_t)VH_EXT_CHUNK);
+      c = __shfl(c, 0);
+      W.chunk_next = c > W.limit - W.base ? W.limit : W.base + c;      // (a saturated cursor must not wrap into another range)
+    }
+    W.chunk_end = W.chunk_next + VH_EXT_CHUNK;
   }
   const uint32_t ext = W.chunk_next++;
-  const bool ok = ext < P.max_extents;
-  if (ok && lane == 0) P.extent_part[ext] = (uint8_t)p;
+  const bool ok = ext < (LEVEL == 1 ? P.max_extents : W.limit);
+  if (ok && lane == 0) vh_pool_tags<LEVEL>(P)[ext] = (uint8_t)p;
   if (!ok) {
     if (lane == 0) atomicOr(P.counters + 2, VH_ERR_PART_FULL);  // the host re-runs with a larger tuple buffer
     return ~0u;
@@ -844,9 +863,10 @@ __device__ __forceinline__ uint32_t vh_part_new_extent(const VhPlanDev& P, VhPar
   return ext;
 }
 
+template <int LEVEL>
 __device__ __forceinline__ void vh_part_tile_runs(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, uint32_t cnt, uint32_t base, int lane);
 // One tile: every lane brings up to four tuples (part[r] == ~0u: none) in registers; they leave for HBM grouped by partition.
-template <int NW>
+template <int NW, int LEVEL = 1>
 __device__ __forceinline__ void vh_part_tile_write(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, const uint64_t (&words)[4][NW],
                                                    const uint32_t (&part)[4], int lane) {
   uint32_t* hist = T.hist;
@@ -875,22 +895,24 @@ __device__ __forceinline__ void vh_part_tile_write(const VhPlanDev& P, VhPartTil
         if ((uint32_t)w < tw) T.sorted[pos * tw + w] = words[r][w];
     }
   }
-  vh_part_tile_runs(P, T, W, cnt, base, lane);
+  vh_part_tile_runs<LEVEL>(P, T, W, cnt, base, lane);
 }
 
 // Run write-out shared by both forms: T.sorted holds the tile ordered by partition; lane p holds partition p's count and
 // exclusive prefix.
+template <int LEVEL>
 __device__ __forceinline__ void vh_part_tile_runs(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, uint32_t cnt, uint32_t base, int lane) {
   const uint32_t tw = (uint32_t)P.tw;
   // room in the partitions' current extents? (lane p decides for partition p; a run never straddles extents)
-  const uint32_t et = (uint32_t)P.ext_tuples;
+  const uint32_t et = vh_pool_et<LEVEL>(P);
+  uint64_t* const pool = vh_pool_tuples<LEVEL>(P);
   uint64_t need = __ballot(cnt != 0 && (T.r_ext == ~0u || T.r_fill + cnt > et));
   while (need) {
     const int p = __builtin_ctzll(need);
     need &= need - 1;
     const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, p), oldfill = __builtin_amdgcn_readlane(T.r_fill, p);
-    if (old != ~0u && lane == 0) P.extent_missing[old] = (uint16_t)(et - oldfill);
-    const uint32_t ext = vh_part_new_extent(P, W, p, lane);
+    if (old != ~0u && lane == 0) vh_pool_missing<LEVEL>(P)[old] = (uint16_t)(et - oldfill);
+    const uint32_t ext = vh_part_new_extent<LEVEL>(P, W, p, lane);
     if (lane == p) { T.r_ext = ext; T.r_fill = 0; }
   }
   // lane p holds (extent, fill, base, count) of partition p, the loop is wave-uniform over the partitions present in this tile
@@ -907,9 +929,9 @@ __device__ __forceinline__ void vh_part_tile_runs(const VhPlanDev& P, VhPartTile
     if (tw == 2) {                                       // the common shape (gid + one 32-bit and one 64-bit value): 16 B per lane
       typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
       for (uint32_t i = lane; i < pc; i += 64)
-        *reinterpret_cast<u64x2*>(P.tuples + (pd + i) * 2) = *reinterpret_cast<const u64x2*>(T.sorted + (size_t)(pb + i) * 2);
+        *reinterpret_cast<u64x2*>(pool + (pd + i) * 2) = *reinterpret_cast<const u64x2*>(T.sorted + (size_t)(pb + i) * 2);
     } else {
-      for (uint32_t i = lane; i < pc * tw; i += 64) P.tuples[pd * tw + i] = T.sorted[(size_t)pb * tw + i];
+      for (uint32_t i = lane; i < pc * tw; i += 64) pool[pd * tw + i] = T.sorted[(size_t)pb * tw + i];
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -922,10 +944,10 @@ __device__ __forceinline__ void vh_part_tile_runs(const VhPlanDev& P, VhPartTile
 // drain of the wave continues the same line, and L2 merges the pieces before the line leaves for HBM (a wave keeps
 // npart lines open: 4096 waves x 13 partitions x 128 B = 7 MB over eight L2s). Measured against collecting 256 tuples in LDS
 // and counting-sorting them like the lanes form does: 4.16 vs 4.38 ms on C3 (profiles/r02/NOTES.md).
-template <int NW>
+template <int NW, int LEVEL = 1>
 __device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, bool active,
                                                    const uint64_t (&words)[NW], uint32_t p, int lane) {
-  const uint32_t npart = (uint32_t)P.npart, et = (uint32_t)P.ext_tuples, tw = (uint32_t)P.tw;
+  const uint32_t npart = vh_pool_npart<LEVEL>(P), et = vh_pool_et<LEVEL>(P), tw = (uint32_t)P.tw;
   const uint64_t act = __ballot(active);
   uint64_t peers = act, mine = act;          // lanes in my survivor's partition / lanes in the partition this lane OWNS
 #pragma unroll
@@ -944,14 +966,14 @@ __device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTil
     const int q = __builtin_ctzll(need);
     need &= need - 1;
     const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, q), oldfill = __builtin_amdgcn_readlane(T.r_fill, q);
-    if (old != ~0u && lane == 0) P.extent_missing[old] = (uint16_t)(et - oldfill);
-    const uint32_t ext = vh_part_new_extent(P, W, q, lane);
+    if (old != ~0u && lane == 0) vh_pool_missing<LEVEL>(P)[old] = (uint16_t)(et - oldfill);
+    const uint32_t ext = vh_part_new_extent<LEVEL>(P, W, q, lane);
     if (lane == q) { T.r_ext = ext; T.r_fill = 0; }
   }
   const uint32_t pe = (uint32_t)__shfl((int)T.r_ext, (int)(active ? p : 0u)), pf = (uint32_t)__shfl((int)T.r_fill, (int)(active ? p : 0u));
   if (T.r_ext != ~0u) T.r_fill += cnt;
   if (active && pe != ~0u) {                 // ~0: tuple buffer exhausted, the host re-runs (VH_ERR_PART_FULL)
-    uint64_t* d = P.tuples + ((uint64_t)pe * et + pf + rank) * tw;
+    uint64_t* d = vh_pool_tuples<LEVEL>(P) + ((uint64_t)pe * et + pf + rank) * tw;
     if (VH_ABLATE & 4) { if (words[0] == 0x123456789ABCDEFull) d[0] = 1; }   // measurement build: everything but the tuple store
     else if (tw == 2) {
       typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
@@ -971,8 +993,10 @@ __device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTil
   }
 }
 
+template <int LEVEL = 1>
 __device__ __forceinline__ void vh_part_tile_finish(const VhPlanDev& P, VhPartTile& T, int lane) {   // open extents are closed with what they hold
-  if (T.r_ext != ~0u && T.r_fill < (uint32_t)P.ext_tuples) P.extent_missing[T.r_ext] = (uint16_t)((uint32_t)P.ext_tuples - T.r_fill);
+  const uint32_t et = vh_pool_et<LEVEL>(P);
+  if (T.r_ext != ~0u && T.r_fill < et) vh_pool_missing<LEVEL>(P)[T.r_ext] = (uint16_t)(et - T.r_fill);
 }
 
 // =====================================================================================
@@ -1547,18 +1571,27 @@ __global__ __launch_bounds__(BLOCK, VH_LANES_WAVES(MODE, BLOCK, NP)) void scan_a
   }
 }
 
+// Extent tags a wave looks at per step: a full ballot when there are plenty of extents, fewer when `waves` waves would
+// otherwise not all find work (the extents of a partition are spread evenly over the tag array).
+__device__ __forceinline__ uint32_t vh_tag_group(uint32_t extents, uint32_t waves) {
+  const uint32_t g = extents / (waves ? waves : 1u);
+  return g >= 64u ? 64u : (g ? g : 1u);
+}
+
 // ------------------------------------------------- partitioned aggregation, phase 2
-// grid = npart x blocks_per_part. A block owns an LDS table for its partition's 2^part_shift groups,
-// its waves walk the partition's extents (64 tuples each, one coalesced 16 B/lane load for 2-word
+// grid = nfine x blocks_per_part. A block owns an LDS table for its range's 2^agg_shift groups,
+// its waves walk the range's extents (64 tuples each, one coalesced 16 B/lane load for 2-word
 // tuples), every tuple is an LDS-atomic update, and the block finally merges its table into the dense
-// global table (one update per present group and block).
+// global table (one update per present group and block; plain stores when the block is the range's only one).
+// One level: range f = partition f of pool 1. Two levels: range f = sub-partition f & 63 of partition f >> 6, whose
+// extents are the ones tagged (f & 63) inside that partition's slice of pool 2.
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int blocks_per_part) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int part = blockIdx.x / blocks_per_part, b = blockIdx.x % blocks_per_part;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = BLOCK / 64;
-  const uint64_t gpp = 1ull << P.part_shift;
-  const uint64_t g0 = (uint64_t)part << P.part_shift;
+  const uint64_t gpp = 1ull << P.agg_shift;
+  const uint64_t g0 = (uint64_t)part << P.agg_shift;
   const uint64_t ng = g0 >= P.G ? 0 : (P.G - g0 < gpp ? P.G - g0 : gpp);
   for (int j = 0; j < P.nmetric; ++j) {
     const VhMetricDev& m = P.m[j];
@@ -1570,18 +1603,32 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
   }
   for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
   __syncthreads();
-  const unsigned long long allocated = P.counters[5];
-  const uint32_t total = allocated < P.max_extents ? (uint32_t)allocated : P.max_extents;   // extents handed out (opened or only reserved)
-  const uint32_t ext_tuples = (uint32_t)P.ext_tuples;
+  const bool two = P.nlevel == 2;
+  uint32_t first = 0, total;
+  if (two) {
+    const uint32_t lo = P.l2[part >> 6], hi = P.l2[(part >> 6) + 1], used = P.l2[VH_L2_NEXT + (part >> 6)];
+    first = lo;
+    total = lo + (used < hi - lo ? used : hi - lo);
+  } else {
+    const unsigned long long allocated = P.counters[5];
+    total = allocated < P.max_extents ? (uint32_t)allocated : P.max_extents;   // extents handed out (opened or only reserved)
+  }
+  const uint8_t want = (uint8_t)(two ? (part & 63) : part);
+  const uint8_t* tags = two ? P.extent_part2 : P.extent_part;
+  const uint16_t* missing = two ? P.extent_missing2 : P.extent_missing;
+  const uint64_t* pool = two ? P.tuples2 : P.tuples;
+  const uint32_t ext_tuples = (uint32_t)(two ? P.ext_tuples2 : P.ext_tuples);
   const uint32_t tw = (uint32_t)P.tw;
-  // the waves of this partition's blocks share the tag array 64 extents at a time; a tag that equals `part` is an extent to aggregate
-  for (uint32_t c0 = ((uint32_t)b * nwaves + wave) * 64u; c0 < total; c0 += (uint32_t)blocks_per_part * nwaves * 64u) {
-   uint64_t mine = __ballot(c0 + lane < total && P.extent_part[c0 + lane] == (uint8_t)part);
+  // the waves of this range's blocks share the tag array `gsz` extents at a time (64, or fewer when there are not enough extents
+  // to go round: phase 1 writes few, large extents when few rows survive); a tag that equals `want` is an extent to aggregate
+  const uint32_t gsz = vh_tag_group(total - first, (uint32_t)blocks_per_part * nwaves);
+  for (uint32_t c0 = first + ((uint32_t)b * nwaves + wave) * gsz; c0 < total; c0 += (uint32_t)blocks_per_part * nwaves * gsz) {
+   uint64_t mine = __ballot((uint32_t)lane < gsz && c0 + lane < total && tags[c0 + lane] == want);
    while (mine) {
     const uint32_t ext = c0 + (uint32_t)__builtin_ctzll(mine);
     mine &= mine - 1;
-    const uint32_t valid = ext_tuples - P.extent_missing[ext];
-    const uint64_t* base = P.tuples + (uint64_t)ext * ext_tuples * tw;
+    const uint32_t valid = ext_tuples - missing[ext];
+    const uint64_t* base = pool + (uint64_t)ext * ext_tuples * tw;
     // four tuples per lane in flight: with one, a 16-wave block keeps ~16 KB outstanding and the kernel is latency bound
     for (uint32_t i0 = 0; i0 < valid; i0 += 256) {
       uint64_t w[4][1 + VH_FAST_COLS];
@@ -1622,10 +1669,90 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
     P.present[g0 + g] = 1;
     for (int j = 0; j < P.nmetric; ++j) {
       const VhMetricDev& m = P.m[j];
-      const uint64_t bits = vh_sop_bytes(m.sop()) == 4 ? reinterpret_cast<uint32_t*>(lds + m.lds_off)[g]
-                                                     : reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
-      vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, g0 + g, m.sop(), bits);
+      if (vh_sop_bytes(m.sop()) == 4) {
+        const uint32_t bits = reinterpret_cast<uint32_t*>(lds + m.lds_off)[g];
+        if (blocks_per_part == 1) reinterpret_cast<uint32_t*>(m.state)[g0 + g] = bits;     // nobody else holds groups of this range
+        else vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, g0 + g, m.sop(), bits);
+      } else {
+        const uint64_t bits = reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
+        if (blocks_per_part == 1) reinterpret_cast<uint64_t*>(m.state)[g0 + g] = bits;
+        else vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, g0 + g, m.sop(), bits);
+      }
     }
   }
+}
+
+// ------------------------------------------------- two-level partitioning: sizing and the second split
+// After phase 1: how many tuples did each partition get? One block counts them off the extent tags and lays the
+// partitions' slices of pool 2 out back to back: tuples / extent size, plus what the splitting waves can leave open
+// (every wave of `waves_per_part` may hold one partly filled extent per sub-partition and an unused rest of a chunk).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void part_l2_plan_kernel(const VhPlanDev P, int waves_per_part) {
+  __shared__ unsigned long long cnt[VH_MAX_PART];
+  if (threadIdx.x < VH_MAX_PART) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const unsigned long long allocated = P.counters[5];
+  const uint32_t total = allocated < P.max_extents ? (uint32_t)allocated : P.max_extents;
+  for (uint32_t e = threadIdx.x; e < total; e += BLOCK) {
+    const uint8_t p = P.extent_part[e];
+    if (p != 0xFF) atomicAdd(&cnt[p], (unsigned long long)((uint32_t)P.ext_tuples - P.extent_missing[e]));
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long at = 0;
+    for (int p = 0; p < P.npart; ++p) {
+      P.l2[p] = (uint32_t)(at < P.max_extents2 ? at : P.max_extents2);
+      P.l2[VH_L2_NEXT + p] = 0;
+      if (cnt[p]) at += (cnt[p] + (uint32_t)P.ext_tuples2 - 1) / (uint32_t)P.ext_tuples2 + (unsigned long long)waves_per_part * (64 + VH_EXT_CHUNK);
+    }
+    P.l2[P.npart] = (uint32_t)(at < P.max_extents2 ? at : P.max_extents2);
+    if (at > P.max_extents2) atomicOr(P.counters + 2, VH_ERR_PART_FULL);     // the host re-runs with a larger second pool
+  }
+}
+
+// grid = npart x blocks_per_part. The block's waves walk partition p's extents of pool 1 (like phase 2 does) and append
+// every tuple to sub-partition (gid >> agg_shift) & 63 of p's slice of pool 2, with the same ballot-rank append phase 1 uses.
+// Tuple by tuple like the compacting form of phase 1; collecting 256-tuple tiles in LDS and writing runs (the lanes form's
+// writer) was measured slower here — 64 sub-partitions leave runs of 4 tuples, one store instruction each (31.1 vs 29.8 ms for
+// 1 G tuples end to end, 39 ms with fewer waves) — and so were twice the waves (more extents open at once).
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void part_split_kernel(const VhPlanDev P, int blocks_per_part) {
+  const int part = blockIdx.x / blocks_per_part, b = blockIdx.x % blocks_per_part;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = BLOCK / 64;
+  VhPartWave W;
+  VhPartTile T;
+  vh_part_tile_init(P, nullptr, T, W);
+  W.base = P.l2[part]; W.limit = P.l2[part + 1]; W.cursor = P.l2 + VH_L2_NEXT + part;
+  const unsigned long long allocated = P.counters[5];
+  const uint32_t total = allocated < P.max_extents ? (uint32_t)allocated : P.max_extents;
+  const uint32_t ext_tuples = (uint32_t)P.ext_tuples, tw = (uint32_t)P.tw;
+  const uint32_t gsz = vh_tag_group(total, (uint32_t)blocks_per_part * nwaves);
+  for (uint32_t c0 = ((uint32_t)b * nwaves + wave) * gsz; c0 < total; c0 += (uint32_t)blocks_per_part * nwaves * gsz) {
+    uint64_t mine = __ballot((uint32_t)lane < gsz && c0 + lane < total && P.extent_part[c0 + lane] == (uint8_t)part);
+    while (mine) {
+      const uint32_t ext = c0 + (uint32_t)__builtin_ctzll(mine);
+      mine &= mine - 1;
+      const uint32_t valid = ext_tuples - P.extent_missing[ext];
+      const uint64_t* base = P.tuples + (uint64_t)ext * ext_tuples * tw;
+      for (uint32_t i0 = 0; i0 < valid; i0 += 128) {
+        uint64_t w[2][1 + VH_FAST_COLS];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const uint32_t i = i0 + u * 64 + lane;
+#pragma unroll
+          for (int x = 0; x < 1 + VH_FAST_COLS; ++x)
+            w[u][x] = (i < valid && (uint32_t)x < tw) ? __builtin_nontemporal_load(base + (uint64_t)i * tw + x) : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          if (i0 + u * 64 >= valid) break;
+          const bool active = i0 + u * 64 + lane < valid;
+          const uint32_t sub = (uint32_t)((w[u][0] & 0xFFFFFFFFull) >> P.agg_shift) & 63u;
+          vh_part_direct_add<1 + VH_FAST_COLS, 2>(P, T, W, active, w[u], sub, lane);
+        }
+      }
+    }
+  }
+  vh_part_tile_finish<2>(P, T, lane);
 }
 

@@ -13,6 +13,7 @@ void vh_launch_scan_fast_global(const VhPlanDev& P, int grid, size_t lds, bool x
 void vh_launch_scan_fast_hash(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ = nullptr);
 void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ = nullptr);
 void vh_launch_part_agg(const VhPlanDev& P, int blocks_per_part, size_t lds, hipStream_t s);
+void vh_launch_part_split(const VhPlanDev& P, int blocks_per_part, hipStream_t s);
 
 // Launch KERNEL (parenthesised template-id), or — occ != nullptr — only ask the runtime how many of its blocks fit one CU.
 #define VH_LAUNCH_OR_OCC(KERNEL, BLOCK, grid, lds, s, P, occ)                                             \

@@ -14,5 +14,11 @@ void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStrea
 void vh_launch_part_agg(const VhPlanDev& P, int blocks_per_part, size_t lds, hipStream_t s) {
   if (lds > 64 * 1024)   // a workgroup may own up to 160 KB of LDS on gfx950, but dynamic LDS above 64 KB has to be asked for
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&part_agg_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL((part_agg_kernel<1024>), dim3(P.part_split * blocks_per_part), dim3(1024), lds, s, P, blocks_per_part);   // only the partitions that were sent through tuples
+  hipLaunchKernelGGL((part_agg_kernel<1024>), dim3(P.nfine * blocks_per_part), dim3(1024), lds, s, P, blocks_per_part);
+}
+
+// Two levels: size the partitions' slices of pool 2 from what phase 1 wrote, then split every partition 64 ways.
+void vh_launch_part_split(const VhPlanDev& P, int blocks_per_part, hipStream_t s) {
+  hipLaunchKernelGGL((part_l2_plan_kernel<1024>), dim3(1), dim3(1024), 0, s, P, blocks_per_part * 4);
+  hipLaunchKernelGGL((part_split_kernel<256>), dim3(P.npart * blocks_per_part), dim3(256), 0, s, P, blocks_per_part);
 }

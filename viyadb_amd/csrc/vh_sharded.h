@@ -529,6 +529,7 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
       return vh_fail(VH_E_DEVICE, "ranks planned different table organisations for one query (this rank: %llu): plans or table shapes differ between ranks", my_mode);
     const int verdict = f[1] ? 1 : f[2] ? 3 : f[0] ? 2 : 0;      // same priority as a single-GPU query's re-plan
     if (verdict) {
+      if (r) r->info.passed_recs = f[6];                          // all ranks' survivors: an upper bound for the tuple pools of any one of them
       replan_after(t, r, verdict, &rp);                           // every rank re-plans; the requests are merged in step 1 of the next attempt
       continue;
     }

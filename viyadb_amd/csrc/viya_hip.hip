@@ -1393,7 +1393,9 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     static const size_t part_table_bytes = getenv("VH_PART_TABLE_KB") ? (size_t)atoi(getenv("VH_PART_TABLE_KB")) * 1024 : 120 * 1024;   // one 1024-thread block per CU in phase 2 (160 KB LDS)
     while (((size_t)2 << shift) * state_bytes_per_group <= part_table_bytes) ++shift;
     const uint64_t np = (G + (1ull << shift) - 1) >> shift;
-    bool want_part = np <= VH_MAX_PART && G <= 0xFFFFFFFFull;
+    // more LDS-sized ranges than a wave has lanes: two levels (phase 1 partitions into ceil(np / 64), part_split_kernel splits each 64 ways)
+    const bool two_level = np > VH_MAX_PART;
+    bool want_part = np <= (uint64_t)VH_MAX_PART * 64 && G <= 0xFFFFFFFFull && !(two_level && (p->flags & VH_PLAN_NO_PART2));
     double sel = 0;
     if (want_part && !part_tuples_override) {       // (a forced plan still sizes its tuple buffer from the estimate)
       rc = probed_selectivity(&sel);
@@ -1417,11 +1419,14 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       // that the atomic unit and the write path work side by side — was measured too: SLOWER than either pure form at every
       // selectivity (5 %: 4.8 ms, 8 %: 6.1, 11 %: 7.3): written-through atomics and tuple stores queue for the same thing.
       want_part = sel >= (covered ? 0.04 : 0.055);
+      // Two levels move every tuple once more (16 B read + 16 B written), and still win from the same point on: C3 table,
+      // GROUP BY (d5, d2) = 4 M groups, 1 B rows (tools/part2_probe.py, profiles/r02/NOTES.md): 2 % 2.11 vs 1.85 ms direct,
+      // 5 % 3.69 vs 4.43, 8 % 5.15 vs 6.99, 25 % 11.8 vs 21.6, 100 % 28.4 vs 85.0.
       // ... and the second phase has a price that does not depend on the rows (every block clears and merges a 120 KB LDS
       // table: ~0.25 ms for 13 partitions), while what partitioning saves grows with the survivors: ~50 ms per 1 G rows and
       // point of selectivity beyond the crossover. A 125 M-row shard of C3 (8 GPUs) stays on direct atomics, 1 G rows do not.
       const double shard_rows = (double)(ag ? ag->rows_max : rows_to_scan);
-      if (want_part && shard_rows * (sel - (covered ? 0.03 : 0.045)) < 5e6) want_part = false;
+      if (want_part && shard_rows * (sel - (covered ? 0.03 : 0.045)) < (two_level ? 1e7 : 5e6)) want_part = false;
     }
     if (want_part) {
       // most rows pass: build the tuples without compacting survivors first (lanes kernel, phase 1 only)
@@ -1439,9 +1444,11 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         }
       }
       mode = VH_MODE_DENSE_PART;
-      P.part_shift = shift;
-      P.npart = (int32_t)np;
-      P.part_split = (int32_t)np;    // every partition goes through tuples (a split with direct atomics for the rest lost to both pure forms)
+      P.nlevel = two_level ? 2 : 1;
+      P.agg_shift = shift;
+      P.nfine = (int32_t)np;
+      P.part_shift = two_level ? shift + 6 : shift;
+      P.npart = (int32_t)(two_level ? (np + 63) / 64 : np);    // every partition goes through tuples (a split with direct atomics for the rest lost to both pure forms)
       // tuple words: word 0 = gid | first 32-bit value << 32; 64-bit values own a word; 32-bit values pair up
       int tw = 1, half_free_word = 0;  // word 0 has its upper half free
       bool have_half = true;
@@ -1648,7 +1655,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     else snprintf(nm, sizeof(nm), "%s<%d, %d, %d, %d>", lanes ? "scan_agg_lanes_kernel" : "scan_agg_fast_kernel", mode, BLOCK,
                   (mode == VH_MODE_HASH || mode == VH_MODE_DENSE_PART) ? (int)__HIP_MEMORY_SCOPE_AGENT : scope, np_);
     r->kernel = nm;
-    if (mode == VH_MODE_DENSE_PART) r->kernel += " + part_agg_kernel<1024>";
+    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel == 2 ? " + part_split_kernel<256> + part_agg_kernel<1024>" : " + part_agg_kernel<1024>";
   }
   int occupancy = 0;
   if (env_bpc <= 0) scan_dispatch(0, &occupancy);
@@ -1725,7 +1732,8 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     for (int j = 0; j < P.nmetric; ++j) o_ostate2[j] = sp.take(r->out_cap * vh_elem_size(r->metric_elem[j]));
   }
   // outputs
-  size_t o_tuples = 0, o_pcount = 0, o_pext = 0, o_emiss = 0, o_epart = 0;
+  size_t o_tuples = 0, o_emiss = 0, o_epart = 0, o_tuples2 = 0, o_emiss2 = 0, o_epart2 = 0, o_l2 = 0;
+  int split_bpp = 1;
   if (mode == VH_MODE_DENSE_PART) {
     // extent size: big enough that a wave allocates rarely (every allocation is a returning global
     // atomic = a full round trip the wave sits out), small enough that open extents do not waste HBM
@@ -1738,12 +1746,23 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
     if (!part_tuples_override && getenv("VH_TEST_PART_EXTENTS")) max_ext = std::max(1, atoi(getenv("VH_TEST_PART_EXTENTS")));   // tests: make the first attempt run out of extents
     P.max_extents = (uint32_t)max_ext;
-    P.part_cap = 0;                                           // extents carry their partition as a tag: no per-partition lists
     o_tuples = sp.take(max_ext * ext_tuples * P.tw * 8);
-    o_pcount = sp.take(VH_MAX_PART * sizeof(uint32_t));
-    o_pext = sp.take(256);
     o_emiss = sp.take(max_ext * sizeof(uint16_t));
     o_epart = sp.take(max_ext);
+    if (P.nlevel == 2) {
+      // pool 2: small extents (4096 ranges x every splitting wave keep one open), sized like pool 1 plus what stays open
+      split_bpp = std::max(1, 2 * g_ctx.num_cu / std::max(1, P.npart));     // 256-thread blocks, ~2 per CU whatever the partition count: more waves keep more extents open (4 per CU measured slower)
+      const uint64_t et2 = 256;
+      P.ext_tuples2 = (int32_t)et2;
+      uint64_t max2 = part_tuple_cap / et2 + (uint64_t)P.npart * ((uint64_t)split_bpp * 4 * (64 + VH_EXT_CHUNK) + 1) + 64;
+      if (max2 > 0xFFFFFFF0ull) max2 = 0xFFFFFFF0ull;
+      if (!part_tuples_override && getenv("VH_TEST_PART_EXTENTS2")) max2 = std::max(1, atoi(getenv("VH_TEST_PART_EXTENTS2")));   // tests: the second pool runs out first
+      P.max_extents2 = (uint32_t)max2;
+      o_tuples2 = sp.take(max2 * et2 * P.tw * 8);
+      o_emiss2 = sp.take(max2 * sizeof(uint16_t));
+      o_epart2 = sp.take(max2);
+      o_l2 = sp.take(VH_L2_WORDS * sizeof(uint32_t));
+    }
   }
   size_t o_fbs[VH_MAX_BITSET] = {};
   for (size_t k = 0; k < r->filter_bitset_cols.size(); ++k) o_fbs[k] = sp.take(std::max<uint32_t>(nseg, 1) * 8);
@@ -1778,10 +1797,14 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   r->d_out_count = reinterpret_cast<unsigned long long*>(S + o_outcount);
   if (mode == VH_MODE_DENSE_PART) {
     P.tuples = reinterpret_cast<uint64_t*>(S + o_tuples);
-    P.part_count = reinterpret_cast<uint32_t*>(S + o_pcount);
-    P.part_extents = reinterpret_cast<uint32_t*>(S + o_pext);
     P.extent_missing = reinterpret_cast<uint16_t*>(S + o_emiss);
     P.extent_part = reinterpret_cast<uint8_t*>(S + o_epart);
+    if (P.nlevel == 2) {
+      P.tuples2 = reinterpret_cast<uint64_t*>(S + o_tuples2);
+      P.extent_missing2 = reinterpret_cast<uint16_t*>(S + o_emiss2);
+      P.extent_part2 = reinterpret_cast<uint8_t*>(S + o_epart2);
+      P.l2 = reinterpret_cast<uint32_t*>(S + o_l2);
+    }
   }
   for (size_t k = 0; k < r->filter_bitset_cols.size(); ++k) {
     const VhColumn& c = t->cols[r->filter_bitset_cols[k]];
@@ -1837,9 +1860,13 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     else HIP_TRY(hipMemsetAsync(P.dset_keys[b], 0xFF, (P.dset_mask[b] + 1) * 8, st));
   }
   if (mode == VH_MODE_DENSE_PART) {
-    HIP_TRY(hipMemsetAsync(P.part_count, 0, VH_MAX_PART * sizeof(uint32_t), st));
     HIP_TRY(hipMemsetAsync(P.extent_missing, 0, (size_t)P.max_extents * sizeof(uint16_t), st));
     HIP_TRY(hipMemsetAsync(P.extent_part, 0xFF, (size_t)P.max_extents, st));
+    if (P.nlevel == 2) {
+      HIP_TRY(hipMemsetAsync(P.extent_missing2, 0, (size_t)P.max_extents2 * sizeof(uint16_t), st));
+      HIP_TRY(hipMemsetAsync(P.extent_part2, 0xFF, (size_t)P.max_extents2, st));
+      HIP_TRY(hipMemsetAsync(P.l2, 0, VH_L2_WORDS * sizeof(uint32_t), st));
+    }
   }
   for (int j = 0; j < P.nmetric; ++j) {
     if (P.m[j].ident == 0 || P.hrec_bytes) continue;
@@ -1851,7 +1878,8 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
     if (mode == VH_MODE_DENSE_PART) {
-      const int bpp = std::max(1, std::min(16, g_ctx.num_cu / std::max(1, P.part_split)));
+      if (P.nlevel == 2) vh_launch_part_split(P, split_bpp, st);
+      const int bpp = std::max(1, std::min(16, g_ctx.num_cu / std::max(1, P.nfine)));
       vh_launch_part_agg(P, bpp, lds_table, st);
     }
   }
@@ -2168,7 +2196,7 @@ static int result_finalize(vh_result* r, int* retry) {
   const unsigned long long* hc = reinterpret_cast<const unsigned long long*>(H);
   const unsigned long long err = hc[2];
   if (err & VH_ERR_HASH_FULL) { *retry = 1; return VH_OK; }
-  if (err & VH_ERR_PART_FULL) { *retry = 3; return VH_OK; }
+  if (err & VH_ERR_PART_FULL) { r->info.passed_recs = hc[0]; *retry = 3; return VH_OK; }   // phase 1 ran to the end: the survivors are counted
   if (err & VH_ERR_RANGE) { *retry = 2; return VH_OK; }
   uint64_t ng = *reinterpret_cast<const unsigned long long*>(H + 256);          // rows emitted (after HAVING)
   r->info.ngroups = r->nhaving ? hc[6] : ng;                                     // agg_map.size()
@@ -2245,8 +2273,10 @@ static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
     rp->cap_override = next;
   }
   else if (retry == 3) {                                     // tuple extents exhausted: more room, then give up on partitioning
+    // the attempt counted its survivors even though it dropped their tuples: the next one is sized for exactly that many
     const uint64_t had = (uint64_t)r->plan.max_extents * r->plan.ext_tuples;
-    if (rp->part_override && had >= r->info.scanned_recs) rp->no_part = true; else rp->part_override = std::max<uint64_t>(had * 4, 1ull << 16);
+    if (rp->part_override && had >= r->info.scanned_recs) rp->no_part = true;
+    else rp->part_override = std::max<uint64_t>(std::max<uint64_t>(rp->part_override * 2, r->info.passed_recs + r->info.passed_recs / 16), 1ull << 16);
   }
   else rp->force_hash = true;                                // a digit left its planned range
 }
