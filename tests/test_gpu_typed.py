@@ -245,6 +245,29 @@ def test_two_level_partitioning():
         dt.close()
 
 
+def test_two_level_on_typed_shapes(typed):
+    """The typed table's group spaces are small; with 1 KB LDS tables (VH_PART_TABLE_KB) they still split into hundreds of ranges,
+    so every state type (float / double SUM, MIN / MAX of every width, AVG, narrow sums) goes through both partition levels."""
+    import os
+    tab, dt = typed
+    os.environ["VH_PART_TABLE_KB"] = "1"
+    try:
+        two = 0
+        for dims, mets in ((["s16", "d_ubyte"], ["count", "long_sum"]), (["s16", "d_ushort"], ["double_sum", "float_max", "count"]),
+                           (["d_ushort", "flag", "s8"], ["int_min", "uint_max", "long_max", "count"]), (["s16", "s8"], ["int_avg", "count", "double_min"]),
+                           (["d_uint"], ["short_sum", "byte_max", "count"]), (["d_ushort", "d_ubyte"], ["ulong_sum"])):
+            for flags in (64, 64 | 128):
+                for flt in (F("lt", "d_uint", "45"), F("ge", "d_uint", "0")):
+                    try:
+                        res, _ = run(tab, dt, {"dimensions": dims, "metrics": mets, "filter": flt}, flags=flags)
+                    except vo.Unsupported:
+                        continue
+                    two += "part_split_kernel" in res.kernel
+        assert two >= 8, two
+    finally:
+        del os.environ["VH_PART_TABLE_KB"]
+
+
 def test_in_and_not_in(typed):
     tab, dt = typed
     for flt in ({"op": "in", "column": "s8", "values": ["v1", "v7", "v9", "nope"]},

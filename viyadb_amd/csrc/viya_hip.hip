@@ -1390,7 +1390,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   uint64_t part_tuple_cap = 0;
   if (mode == VH_MODE_DENSE_GLOBAL && fast && !no_part && !(p->flags & (VH_PLAN_NO_PART | VH_PLAN_FORCE_GLOBAL)) && P.nmetric >= 1) {
     int shift = 0;
-    static const size_t part_table_bytes = getenv("VH_PART_TABLE_KB") ? (size_t)atoi(getenv("VH_PART_TABLE_KB")) * 1024 : 120 * 1024;   // one 1024-thread block per CU in phase 2 (160 KB LDS)
+    const size_t part_table_bytes = getenv("VH_PART_TABLE_KB") ? (size_t)atoi(getenv("VH_PART_TABLE_KB")) * 1024 : 120 * 1024;   // one 1024-thread block per CU in phase 2 (160 KB LDS)
     while (((size_t)2 << shift) * state_bytes_per_group <= part_table_bytes) ++shift;
     const uint64_t np = (G + (1ull << shift) - 1) >> shift;
     // more LDS-sized ranges than a wave has lanes: two levels (phase 1 partitions into ceil(np / 64), part_split_kernel splits each 64 ways)
