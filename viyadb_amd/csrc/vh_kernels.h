@@ -1664,18 +1664,24 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
    }
   }
   __syncthreads();
+  // Sole block of the range, or one private copy of the range per block (P.nxcd == blocks_per_part: dense_merge_kernel adds
+  // them up): plain stores of EVERY group, present or not. Otherwise one atomic update per present group into the shared table.
+  const bool own = blocks_per_part == 1 || P.nxcd == blocks_per_part;
+  const uint64_t xo = P.nxcd == blocks_per_part ? (uint64_t)b * P.xcd_stride : 0;
   for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) {
-    if (!reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g]) continue;
-    P.present[g0 + g] = 1;
+    const uint8_t here = reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g];
+    if (own && blocks_per_part > 1) P.present[xo + g0 + g] = here;
+    if (!here && !(own && blocks_per_part > 1)) continue;
+    if (here && !(own && blocks_per_part > 1)) P.present[g0 + g] = 1;
     for (int j = 0; j < P.nmetric; ++j) {
       const VhMetricDev& m = P.m[j];
       if (vh_sop_bytes(m.sop()) == 4) {
         const uint32_t bits = reinterpret_cast<uint32_t*>(lds + m.lds_off)[g];
-        if (blocks_per_part == 1) reinterpret_cast<uint32_t*>(m.state)[g0 + g] = bits;     // nobody else holds groups of this range
+        if (own) reinterpret_cast<uint32_t*>(m.state)[xo + g0 + g] = bits;
         else vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, g0 + g, m.sop(), bits);
       } else {
         const uint64_t bits = reinterpret_cast<uint64_t*>(lds + m.lds_off)[g];
-        if (blocks_per_part == 1) reinterpret_cast<uint64_t*>(m.state)[g0 + g] = bits;
+        if (own) reinterpret_cast<uint64_t*>(m.state)[xo + g0 + g] = bits;
         else vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(m.state, g0 + g, m.sop(), bits);
       }
     }

@@ -1491,6 +1491,14 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   if (mode != VH_MODE_HASH && mode != VH_MODE_DENSE_PART && P.nbitset == 0 && !(p->flags & VH_PLAN_NO_XCD_PRIVATE) &&
       G <= 16384)   // private copies pay off only against same-address contention (C2 forced to HBM: 3.4 vs 10 ms);
     nxcd = g_ctx.num_xcd;   // with >= 100 K groups one table is as fast and needs no merge pass
+  // DENSE_PART: the blocks that share one LDS-sized range each write a private copy of it with plain stores (block b -> copy b;
+  // every group of the range, present or not) and dense_merge_kernel adds the copies up — C3: 16 blocks x 13 ranges used to
+  // flush 3.2 M global atomics (0.14 ms of phase 2's 0.35) into one table
+  int part_bpp = 1;
+  if (mode == VH_MODE_DENSE_PART) {
+    part_bpp = std::max(1, std::min(32, g_ctx.num_cu / std::max(1, P.nfine)));    // one 1024-thread block per CU: phase 2 lives off LDS atomics, so every CU counts
+    if (!(p->flags & VH_PLAN_NO_XCD_PRIVATE)) nxcd = part_bpp;
+  }
   P.nxcd = nxcd; r->nxcd = nxcd;
   P.xcd_stride = (G + 63) / 64 * 64;
 
@@ -1740,6 +1748,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     const uint64_t waves = (uint64_t)grid * 4;
     uint64_t et = 1024;                // a tile writes whole runs (<= VH_PART_TILE tuples) that must fit a fresh extent
     while (et < 4096 && et * 2 <= part_tuple_cap / (waves * P.npart) / 2) et *= 2;
+    if (getenv("VH_EXT_TUPLES")) et = std::max(256, atoi(getenv("VH_EXT_TUPLES")));     // measurement
     const uint64_t ext_tuples = et;
     P.ext_tuples = (int32_t)ext_tuples;
     uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
@@ -1879,8 +1888,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     scan_dispatch(grid, nullptr);
     if (mode == VH_MODE_DENSE_PART) {
       if (P.nlevel == 2) vh_launch_part_split(P, split_bpp, st);
-      const int bpp = std::max(1, std::min(16, g_ctx.num_cu / std::max(1, P.nfine)));
-      vh_launch_part_agg(P, bpp, lds_table, st);
+      vh_launch_part_agg(P, part_bpp, lds_table, st);
     }
   }
   HIP_TRY(hipEventRecord(x->ev[2], st));
