@@ -1709,7 +1709,8 @@ __global__ __launch_bounds__(BLOCK) void part_l2_plan_kernel(const VhPlanDev P, 
     for (int p = 0; p < P.npart; ++p) {
       P.l2[p] = (uint32_t)(at < P.max_extents2 ? at : P.max_extents2);
       P.l2[VH_L2_NEXT + p] = 0;
-      if (cnt[p]) at += (cnt[p] + (uint32_t)P.ext_tuples2 - 1) / (uint32_t)P.ext_tuples2 + (unsigned long long)waves_per_part * (64 + VH_EXT_CHUNK);
+      // (+ 1/4: an extent is closed as soon as a drain's tuples of its sub-partition do not fit, so skewed data leaves up to 63 of 256 slots unused)
+      if (cnt[p]) at += (cnt[p] + cnt[p] / 4 + (uint32_t)P.ext_tuples2 - 1) / (uint32_t)P.ext_tuples2 + (unsigned long long)waves_per_part * (64 + VH_EXT_CHUNK);
     }
     P.l2[P.npart] = (uint32_t)(at < P.max_extents2 ? at : P.max_extents2);
     if (at > P.max_extents2) atomicOr(P.counters + 2, VH_ERR_PART_FULL);     // the host re-runs with a larger second pool

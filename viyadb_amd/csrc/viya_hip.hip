@@ -1763,7 +1763,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       split_bpp = std::max(1, 2 * g_ctx.num_cu / std::max(1, P.npart));     // 256-thread blocks, ~2 per CU whatever the partition count: more waves keep more extents open (4 per CU measured slower)
       const uint64_t et2 = 256;
       P.ext_tuples2 = (int32_t)et2;
-      uint64_t max2 = part_tuple_cap / et2 + (uint64_t)P.npart * ((uint64_t)split_bpp * 4 * (64 + VH_EXT_CHUNK) + 1) + 64;
+      uint64_t max2 = (part_tuple_cap + part_tuple_cap / 4) / et2 + (uint64_t)P.npart * ((uint64_t)split_bpp * 4 * (64 + VH_EXT_CHUNK) + 1) + 64;
       if (max2 > 0xFFFFFFF0ull) max2 = 0xFFFFFFF0ull;
       if (!part_tuples_override && getenv("VH_TEST_PART_EXTENTS2")) max2 = std::max(1, atoi(getenv("VH_TEST_PART_EXTENTS2")));   // tests: the second pool runs out first
       P.max_extents2 = (uint32_t)max2;
