@@ -157,6 +157,11 @@ static const uint32_t VH_MAX_SEGMENTS = 1u << 24;   // (segment << 32 | row) pos
 static bool is_dim(int kind) { return kind <= VH_DIM_BOOLEAN; }
 static bool is_bitset_elem(int e) { return e == VH_BITSET32 || e == VH_BITSET64; }
 
+static void trace_alloc(const char* what, const void* p, size_t bytes) {     // VH_TRACE_ALLOC=1: where the big buffers land (placement experiments)
+  static const bool on = getenv("VH_TRACE_ALLOC") != nullptr;
+  if (on) fprintf(stderr, "vh alloc %s %p %zu\n", what, p, bytes);
+}
+
 static int table_grow(vh_table* t, uint32_t need_seg) {
   if (need_seg <= t->cap_seg) return VH_OK;
   uint32_t ncap = std::max<uint32_t>(need_seg, std::max<uint32_t>(4, t->cap_seg * 2));
@@ -168,6 +173,7 @@ static int table_grow(vh_table* t, uint32_t need_seg) {
     char* nb = nullptr;
     const size_t bytes = (size_t)ncap * c.stride + 256;
     HIP_TRY(hipMalloc(&nb, bytes));
+    trace_alloc("column", nb, bytes);
     if (c.base && t->nseg) {
       HIP_TRY(hipMemcpyAsync(nb, c.base, (size_t)t->nseg * c.stride, hipMemcpyDeviceToDevice, g_ctx.stream));
       HIP_TRY(hipStreamSynchronize(g_ctx.stream));
@@ -277,6 +283,7 @@ static int ensure_scratch(VhExec* x, size_t bytes) {
   if (x->scratch) { HIP_TRY(hipFree(x->scratch)); x->scratch = nullptr; x->scratch_bytes = 0; }
   size_t nb = std::max(bytes + bytes / 4, (size_t)1 << 20);
   HIP_TRY(hipMalloc(&x->scratch, nb));
+  trace_alloc("scratch", x->scratch, nb);
   x->scratch_bytes = nb;
   if (getenv("VH_POISON")) {   // tests: nothing may depend on what fresh scratch holds
     HIP_TRY(hipMemsetAsync(x->scratch, 0xA5, nb, x->stream()));
@@ -545,6 +552,7 @@ static int pack_refresh(vh_table* t, VhPack* pk, uint32_t first, uint32_t n) {
     char* nb = nullptr;
     const size_t bytes = (size_t)t->cap_seg * pk->stride + 256;
     HIP_TRY(hipMalloc(&nb, bytes));
+    trace_alloc("projection", nb, bytes);
     if (pk->base) {
       HIP_TRY(hipMemcpyAsync(nb, pk->base, (size_t)pk->cap_seg * pk->stride, hipMemcpyDeviceToDevice, g_ctx.stream));
       HIP_TRY(hipStreamSynchronize(g_ctx.stream));
