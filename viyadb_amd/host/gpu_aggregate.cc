@@ -93,36 +93,42 @@ namespace {
 
 // HAVING on aggregated tuples: same ComparisonBuilder semantics, applied to key / state values
 // (AVG compares the raw sum, bitsets compare the cardinality; post_agg.cc:77-83).
-class HavingEval : public FilterVisitor {
+class HavingEval {
 public:
   HavingEval(AggregateQuery& q, const Groups& g, const std::vector<db::AnyNum>& hargs) : q_(q), g_(g), hargs_(hargs) {}
   bool Eval(const Filter* f, size_t row) {
-    row_ = row; next_ = 0; stack_.clear();
-    f->Accept(*this);
-    return stack_.back();
+    row_ = row; next_ = 0;
+    return test(*f);
   }
-  void Visit(const RelOpFilter* f) override { stack_.push_back(cmp(q_.table().column(f->column()), f->op(), hargs_.at(next_++))); }
-  void Visit(const InFilter* f) override {
-    const db::Column* c = q_.table().column(f->column());
-    bool r = !f->equal();
-    for (size_t i = 0; i < f->values().size(); ++i) {
-      const bool e = cmp(c, f->equal() ? RelOpFilter::EQUAL : RelOpFilter::NOT_EQUAL, hargs_.at(next_++));
-      r = f->equal() ? (r | e) : (r & e);
-    }
-    stack_.push_back(r);
-  }
-  void Visit(const CompositeFilter* f) override {
-    const size_t base = stack_.size();
-    for (auto& c : f->filters()) c->Accept(*this);
-    bool r = f->op() == CompositeFilter::AND;
-    for (size_t i = base; i < stack_.size(); ++i) r = f->op() == CompositeFilter::AND ? (r & stack_[i]) : (r | stack_[i]);
-    stack_.resize(base);
-    stack_.push_back(r);
-  }
-  void Visit(const EmptyFilter*) override { stack_.push_back(true); }
 
 private:
-  bool cmp(const db::Column* c, RelOpFilter::Operator op, db::AnyNum lit) {
+  // every literal is consumed whether or not the outcome is already known: they are positional (no short circuit, like the
+  // reference's bitwise & / | over the generated comparisons)
+  bool test(const Filter& f) {
+    switch (f.kind()) {
+      case Filter::PASS_ALL: return true;
+      case Filter::COMPARE: return cmp(q_.table().column(f.column()), f.relation(), hargs_.at(next_++));
+      case Filter::MEMBER: {
+        const db::Column* c = q_.table().column(f.column());
+        bool r = !f.inside();
+        for (size_t i = 0; i < f.literals().size(); ++i) {
+          const bool e = cmp(c, f.inside() ? Filter::EQUAL : Filter::NOT_EQUAL, hargs_.at(next_++));
+          r = f.inside() ? (r | e) : (r & e);
+        }
+        return r;
+      }
+      default: {
+        const bool all = f.kind() == Filter::ALL_OF;
+        bool r = all;
+        for (const Filter& part : f.parts()) {
+          const bool e = test(part);
+          r = all ? (r & e) : (r | e);
+        }
+        return r;
+      }
+    }
+  }
+  bool cmp(const db::Column* c, Filter::Relation op, db::AnyNum lit) {
     db::AnyNum v;
     db::Num t = c->num_type().type();
     bool found = false;
@@ -141,11 +147,11 @@ private:
     if (!found) throw std::invalid_argument("Column '" + c->name() + " is not selected");
     const int r = db::compare_typed(t, v, lit);  // 2 = unordered (NaN)
     switch (op) {
-      case RelOpFilter::EQUAL: return r == 0;
-      case RelOpFilter::NOT_EQUAL: return r != 0;
-      case RelOpFilter::LESS: return r == -1;
-      case RelOpFilter::LESS_EQUAL: return r == -1 || r == 0;
-      case RelOpFilter::GREATER: return r == 1;
+      case Filter::EQUAL: return r == 0;
+      case Filter::NOT_EQUAL: return r != 0;
+      case Filter::LESS: return r == -1;
+      case Filter::LESS_EQUAL: return r == -1 || r == 0;
+      case Filter::GREATER: return r == 1;
       default: return r == 1 || r == 0;
     }
   }
@@ -153,7 +159,6 @@ private:
   const Groups& g_;
   const std::vector<db::AnyNum>& hargs_;
   size_t row_ = 0, next_ = 0;
-  std::vector<bool> stack_;
 };
 
 // util::StringNumCmp (src/util/string.h:28-49)
@@ -238,13 +243,13 @@ void AggregateOnMirror(AggregateQuery& query, vh_table* mirror, const std::vecto
                        int64_t now, Groups& groups, QueryStats& stats, void* node_comm) {
   db::Table& table = query.table();
   PlanFilterBuilder fb(table, fargs);
-  query.filter()->Accept(fb);
+  fb.Add(*query.filter());
   std::vector<vh_group_col> gcols = PlanGroupCols(query, now);
   std::vector<int32_t> mcols;
   for (auto& mc : query.metric_cols()) mcols.push_back((int32_t)mc.metric()->storage_index);
 
   PlanHavingBuilder hb(query, hargs, fb.lits);
-  if (having_on_device) query.having()->Accept(hb);
+  if (having_on_device) hb.Add(*query.having());
 
   vh_plan plan;
   memset(&plan, 0, sizeof(plan));
@@ -438,7 +443,7 @@ void GpuSelect(SelectQuery& query, RowOutput& output, QueryStats& stats, std::ve
     GpuMirror* mir = ensure_mirror(table);
     std::vector<uint64_t> seg_rows = sync_mirror(table, mir);
     PlanFilterBuilder fb(table, fargs);
-    query.filter()->Accept(fb);
+    fb.Add(*query.filter());
     vh_select_plan plan;
     memset(&plan, 0, sizeof(plan));
     plan.filter = fb.nodes.data(); plan.nfilter = (int32_t)fb.nodes.size();
@@ -542,7 +547,7 @@ void GpuSearch(SearchQuery& query, RowOutput& output, QueryStats& stats, std::ve
     GpuMirror* mir = ensure_mirror(table);
     std::vector<uint64_t> seg_rows = sync_mirror(table, mir);
     PlanFilterBuilder fb(table, fargs);
-    query.filter()->Accept(fb);
+    fb.Add(*query.filter());
     vh_group_col g;
     memset(&g, 0, sizeof(g));
     g.col = (int32_t)dim->storage_index;

@@ -47,82 +47,71 @@ GpuMirror* ensure_mirror(db::Table& t);
 // Bring the HBM mirror up to date with the host segments; returns the per-segment size() snapshot.
 std::vector<uint64_t> sync_mirror(db::Table& t, GpuMirror* mir);
 
-// query::Filter -> postfix vh_filter_node program; literals are consumed in FilterArgsPacker order.
-class PlanFilterBuilder : public FilterVisitor {
+// query::Filter -> postfix vh_filter_node program (parts first, then the node that combines them); the literals decoded by
+// PackFilterArgs are consumed in the same evaluation order. One builder serves the scan filter (columns are table columns:
+// storage index) and the device HAVING (columns are RESULT columns: group column k, or ngroups + metric k).
+class PlanProgram {
 public:
-  PlanFilterBuilder(const db::Table& t, const std::vector<db::AnyNum>& args) : table(t), args_(args) {}
-  void Visit(const RelOpFilter* f) override {
-    const db::Column* c = table.column(f->column());
-    check_column(c);
-    nodes.push_back({VH_F_REL, (int32_t)c->storage_index, (int32_t)f->op(), 1, (int32_t)lits.size(), 0});
-    push_lit();
+  PlanProgram(const std::vector<db::AnyNum>& args, std::vector<vh_anynum>& lits) : args_(args), lits_(lits) {}
+  template <class ColumnIndex>      // (const std::string& name) -> int32_t
+  void Add(const Filter& f, ColumnIndex&& column_index) {
+    switch (f.kind()) {
+      case Filter::PASS_ALL: nodes.push_back({VH_F_TRUE, 0, 0, 0, 0, 0}); break;
+      case Filter::COMPARE:
+        nodes.push_back({VH_F_REL, column_index(f.column()), (int32_t)f.relation(), 1, (int32_t)lits_.size(), 0});
+        take(1);
+        break;
+      case Filter::MEMBER:
+        if (f.literals().empty()) throw std::runtime_error("IN filter with no values does not compile in the reference");
+        nodes.push_back({VH_F_IN, column_index(f.column()), f.inside() ? 1 : 0, (int32_t)f.literals().size(), (int32_t)lits_.size(), 0});
+        take(f.literals().size());
+        break;
+      default:
+        for (const Filter& part : f.parts()) Add(part, column_index);
+        nodes.push_back({f.kind() == Filter::ALL_OF ? VH_F_AND : VH_F_OR, 0, 0, (int32_t)f.parts().size(), 0, 0});
+    }
   }
-  void Visit(const InFilter* f) override {
-    const db::Column* c = table.column(f->column());
-    check_column(c);
-    if (f->values().empty()) throw std::runtime_error("IN filter with no values does not compile in the reference");
-    nodes.push_back({VH_F_IN, (int32_t)c->storage_index, f->equal() ? 1 : 0, (int32_t)f->values().size(), (int32_t)lits.size(), 0});
-    for (size_t i = 0; i < f->values().size(); ++i) push_lit();
-  }
-  void Visit(const CompositeFilter* f) override {
-    for (auto& c : f->filters()) c->Accept(*this);
-    nodes.push_back({f->op() == CompositeFilter::AND ? VH_F_AND : VH_F_OR, 0, 0, (int32_t)f->filters().size(), 0, 0});
-  }
-  void Visit(const EmptyFilter*) override { nodes.push_back({VH_F_TRUE, 0, 0, 0, 0, 0}); }
-  const db::Table& table;
-  std::vector<vh_filter_node> nodes;
-  std::vector<vh_anynum> lits;
-
-private:
-  void check_column(const db::Column*) {}   // (a bitset metric in the filter compares its per-row cardinality on the device: filter.cc:216,235)
-  void push_lit() {
-    vh_anynum a;
-    a.u64 = args_.at(next_++).bits;
-    lits.push_back(a);
-  }
-  const std::vector<db::AnyNum>& args_;
-  size_t next_ = 0;
-};
-
-// HAVING -> postfix program over RESULT columns (group column k, or ngroups + metric k), for the device.
-class PlanHavingBuilder : public FilterVisitor {
-public:
-  PlanHavingBuilder(AggregateQuery& q, const std::vector<db::AnyNum>& args, std::vector<vh_anynum>& lits)
-      : q_(q), args_(args), lits_(lits) {}
-  void Visit(const RelOpFilter* f) override {
-    nodes.push_back({VH_F_REL, result_col(f->column()), (int32_t)f->op(), 1, (int32_t)lits_.size(), 0});
-    push_lit();
-  }
-  void Visit(const InFilter* f) override {
-    if (f->values().empty()) throw std::runtime_error("IN filter with no values does not compile in the reference");
-    nodes.push_back({VH_F_IN, result_col(f->column()), f->equal() ? 1 : 0, (int32_t)f->values().size(), (int32_t)lits_.size(), 0});
-    for (size_t i = 0; i < f->values().size(); ++i) push_lit();
-  }
-  void Visit(const CompositeFilter* f) override {
-    for (auto& c : f->filters()) c->Accept(*this);
-    nodes.push_back({f->op() == CompositeFilter::AND ? VH_F_AND : VH_F_OR, 0, 0, (int32_t)f->filters().size(), 0, 0});
-  }
-  void Visit(const EmptyFilter*) override { nodes.push_back({VH_F_TRUE, 0, 0, 0, 0, 0}); }
   std::vector<vh_filter_node> nodes;
 
 private:
-  int32_t result_col(const std::string& name) {
-    const db::Column* c = q_.table().column(name);
-    for (size_t k = 0; k < q_.dimension_cols().size(); ++k)
-      if (q_.dimension_cols()[k].dim() == c) return (int32_t)k;
-    for (size_t k = 0; k < q_.metric_cols().size(); ++k)
-      if (q_.metric_cols()[k].metric() == c) return (int32_t)(q_.dimension_cols().size() + k);
-    throw std::invalid_argument("Column '" + name + " is not selected");
+  void take(size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+      vh_anynum a;
+      a.u64 = args_.at(next_++).bits;
+      lits_.push_back(a);
+    }
   }
-  void push_lit() {
-    vh_anynum a;
-    a.u64 = args_.at(next_++).bits;
-    lits_.push_back(a);
-  }
-  AggregateQuery& q_;
   const std::vector<db::AnyNum>& args_;
   std::vector<vh_anynum>& lits_;
   size_t next_ = 0;
+};
+
+// scan filter: a column is its storage index in the table (a bitset metric compares its per-row cardinality on the device: filter.cc:216,235)
+struct PlanFilterBuilder {
+  PlanFilterBuilder(const db::Table& t, const std::vector<db::AnyNum>& args) : table(t), prog(args, lits), nodes(prog.nodes) {}
+  void Add(const Filter& f) { prog.Add(f, [this](const std::string& name) { return (int32_t)table.column(name)->storage_index; }); }
+  const db::Table& table;
+  std::vector<vh_anynum> lits;
+  PlanProgram prog;
+  std::vector<vh_filter_node>& nodes;
+};
+
+// HAVING on the device: a column is its position among the query's result columns
+struct PlanHavingBuilder {
+  PlanHavingBuilder(AggregateQuery& q, const std::vector<db::AnyNum>& args, std::vector<vh_anynum>& lits) : q_(q), prog(args, lits), nodes(prog.nodes) {}
+  void Add(const Filter& f) {
+    prog.Add(f, [this](const std::string& name) -> int32_t {
+      const db::Column* c = q_.table().column(name);
+      for (size_t k = 0; k < q_.dimension_cols().size(); ++k)
+        if (q_.dimension_cols()[k].dim() == c) return (int32_t)k;
+      for (size_t k = 0; k < q_.metric_cols().size(); ++k)
+        if (q_.metric_cols()[k].metric() == c) return (int32_t)(q_.dimension_cols().size() + k);
+      throw std::invalid_argument("Column '" + name + " is not selected");
+    });
+  }
+  AggregateQuery& q_;
+  PlanProgram prog;
+  std::vector<vh_filter_node>& nodes;
 };
 
 // One aggregated group as the post-aggregation sees it.

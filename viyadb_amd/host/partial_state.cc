@@ -113,7 +113,7 @@ std::string AggregatePartial(AggregateQuery& query, QueryStats& stats, std::vect
     GpuMirror* mir = ensure_mirror(table);
     std::vector<uint64_t> seg_rows = sync_mirror(table, mir);
     PlanFilterBuilder fb(table, fargs);
-    query.filter()->Accept(fb);
+    fb.Add(*query.filter());
     std::vector<vh_group_col> gcols = PlanGroupCols(query, now);
     std::vector<int32_t> mcols;
     bool has_bitset = false;
@@ -405,7 +405,7 @@ void MergePartials(AggregateQuery& query, const std::vector<std::string>& partia
     if (need_hidden) pm.push_back((int32_t)(nd + nm));
     std::vector<vh_anynum> lits;
     PlanHavingBuilder hb(query, hargs, lits);
-    if (having_on_device) query.having()->Accept(hb);
+    if (having_on_device) hb.Add(*query.having());
     vh_filter_node all = {VH_F_TRUE, 0, 0, 0, 0, 0};
     vh_plan plan;
     memset(&plan, 0, sizeof(plan));

@@ -9,47 +9,43 @@
 namespace viya {
 namespace query {
 
-void RelOpFilter::Accept(FilterVisitor& v) const { v.Visit(this); }
-void InFilter::Accept(FilterVisitor& v) const { v.Visit(this); }
-void CompositeFilter::Accept(FilterVisitor& v) const { v.Visit(this); }
-void EmptyFilter::Accept(FilterVisitor& v) const { v.Visit(this); }
+Filter Filter::Compare(Relation r, std::string column, std::string literal) {
+  Filter f;
+  f.kind_ = COMPARE; f.relation_ = r; f.column_ = std::move(column); f.literals_.push_back(std::move(literal));
+  return f;
+}
+Filter Filter::Member(std::string column, std::vector<std::string> literals, bool inside) {
+  Filter f;
+  f.kind_ = MEMBER; f.inside_ = inside; f.column_ = std::move(column); f.literals_ = std::move(literals);
+  return f;
+}
+Filter Filter::Combine(bool all, std::vector<Filter> parts) {
+  Filter f;
+  f.kind_ = all ? ALL_OF : ANY_OF; f.parts_ = std::move(parts);
+  return f;
+}
 
-// NOT never survives: it flips and/or (De Morgan), negates relational operators and turns IN into
-// NOT IN; children of a composite are ordered by precedence (RelOp < AND < OR < IN).
-std::unique_ptr<Filter> FilterFactory::Create(const util::Config& config, bool negate) {
-  if (!config.exists("op")) return std::make_unique<EmptyFilter>();
+Filter Filter::FromConfig(const util::Config& config, bool negate) {
+  if (!config.exists("op")) return Filter();
   const std::string op = config.str("op");
+  if (op == "not") return FromConfig(config.sub("filter"), !negate);
   if (op == "and" || op == "or") {
-    std::vector<std::unique_ptr<Filter>> kids;
-    for (const util::Config& fc : config.sublist("filters")) kids.push_back(Create(fc, negate));
-    std::stable_sort(kids.begin(), kids.end(),
-                     [](const std::unique_ptr<Filter>& a, const std::unique_ptr<Filter>& b) { return a->precedence() < b->precedence(); });
-    const bool is_and = (op == "and") != negate;
-    return std::make_unique<CompositeFilter>(is_and ? CompositeFilter::AND : CompositeFilter::OR, std::move(kids));
+    std::vector<Filter> parts;
+    for (const util::Config& fc : config.sublist("filters")) parts.push_back(FromConfig(fc, negate));
+    std::stable_sort(parts.begin(), parts.end(), [](const Filter& a, const Filter& b) { return a.rank() < b.rank(); });
+    return Combine((op == "and") != negate, std::move(parts));
   }
-  if (op == "not") return Create(config.sub("filter"), !negate);
-  const std::string column = config.str("column");
-  if (op == "in") return std::make_unique<InFilter>(column, config.strlist("values"), !negate);
-  const std::string value = config.str("value");
-  static const char* names[6] = {"eq", "ne", "lt", "le", "gt", "ge"};
-  static const RelOpFilter::Operator negated[6] = {RelOpFilter::NOT_EQUAL, RelOpFilter::EQUAL, RelOpFilter::GREATER_EQUAL,
-                                                   RelOpFilter::GREATER, RelOpFilter::LESS_EQUAL, RelOpFilter::LESS};
-  for (int i = 0; i < 6; ++i)
-    if (op == names[i])
-      return std::make_unique<RelOpFilter>(negate ? negated[i] : static_cast<RelOpFilter::Operator>(i), column, value);
-  throw std::invalid_argument("Unsupported filter operataor: " + op);
+  std::string column = config.str("column");
+  if (op == "in") return Member(std::move(column), config.strlist("values"), !negate);
+  static const struct { const char* name; Relation plain, negated; } table[] = {
+      {"eq", EQUAL, NOT_EQUAL}, {"ne", NOT_EQUAL, EQUAL}, {"lt", LESS, GREATER_EQUAL},
+      {"le", LESS_EQUAL, GREATER}, {"gt", GREATER, LESS_EQUAL}, {"ge", GREATER_EQUAL, LESS}};
+  for (const auto& e : table)
+    if (op == e.name) return Compare(negate ? e.negated : e.plain, std::move(column), config.str("value"));
+  throw std::invalid_argument("Unsupported filter operataor: " + op);   // (the reference's spelling: its tests match on the text)
 }
 
 namespace {
-
-class ColumnsCollector : public FilterVisitor {
-public:
-  void Visit(const RelOpFilter* f) override { cols.push_back(f->column()); }
-  void Visit(const InFilter* f) override { cols.push_back(f->column()); }
-  void Visit(const CompositeFilter* f) override { for (auto& c : f->filters()) c->Accept(*this); }
-  void Visit(const EmptyFilter*) override {}
-  std::vector<std::string> cols;
-};
 
 // ValueDecoder (src/codegen/query/filter.cc:154-204)
 db::AnyNum DecodeValue(const db::Column* col, const std::string& value) {
@@ -90,26 +86,17 @@ db::AnyNum DecodeValue(const db::Column* col, const std::string& value) {
   return col->num_type().Parse(value);
 }
 
-class ArgsPacker : public FilterVisitor {
-public:
-  explicit ArgsPacker(const db::Table& t) : table(t) {}
-  void Visit(const RelOpFilter* f) override { args.push_back(DecodeValue(table.column(f->column()), f->value())); }
-  void Visit(const InFilter* f) override {
-    const db::Column* c = table.column(f->column());
-    for (auto& v : f->values()) args.push_back(DecodeValue(c, v));
-  }
-  void Visit(const CompositeFilter* f) override { for (auto& c : f->filters()) c->Accept(*this); }
-  void Visit(const EmptyFilter*) override {}
-  const db::Table& table;
-  std::vector<db::AnyNum> args;
-};
-
 }  // namespace
 
+// FilterArgsPacker (src/codegen/query/filter.cc:100-152): every leaf's literals, decoded to the column's type, in evaluation order
 std::vector<db::AnyNum> PackFilterArgs(const db::Table& table, const Filter* filter) {
-  ArgsPacker p(table);
-  if (filter) filter->Accept(p);
-  return p.args;
+  std::vector<db::AnyNum> args;
+  if (filter)
+    filter->EachLeaf([&](const Filter& leaf) {
+      const db::Column* c = table.column(leaf.column());
+      for (const std::string& text : leaf.literals()) args.push_back(DecodeValue(c, text));
+    });
+  return args;
 }
 
 DimOutputColumn::DimOutputColumn(const util::Config& config, const db::Dimension* dim, size_t index) : index_(index), dim_(dim) {
@@ -121,8 +108,7 @@ DimOutputColumn::DimOutputColumn(const util::Config& config, const db::Dimension
 
 AggregateQuery::AggregateQuery(const util::Config& config, db::Table& table, bool select_only)
     : table_(table), header_(config.boolean("header", false)), skip_((size_t)config.num("skip", 0)), limit_((size_t)config.num("limit", 0)) {
-  FilterFactory ff;
-  filter_ = ff.Create(config.sub("filter", true));
+  filter_ = std::make_unique<Filter>(Filter::FromConfig(config.sub("filter", true)));
   size_t out_idx = 0;
   if (config.exists("select")) {
     for (const util::Config& sc : config.sublist("select")) {
@@ -152,20 +138,19 @@ AggregateQuery::AggregateQuery(const util::Config& config, db::Table& table, boo
     }
   }
   if (config.exists("having")) {
-    having_ = ff.Create(config.sub("having"));
-    ColumnsCollector cc;
-    having_->Accept(cc);
-    auto names = column_names();
-    for (auto& h : cc.cols)
-      if (std::find(names.begin(), names.end(), h) == names.end()) throw std::invalid_argument("Column '" + h + " is not selected");
+    having_ = std::make_unique<Filter>(Filter::FromConfig(config.sub("having")));
+    const auto names = column_names();
+    having_->EachLeaf([&](const Filter& leaf) {
+      if (std::find(names.begin(), names.end(), leaf.column()) == names.end())
+        throw std::invalid_argument("Column '" + leaf.column() + " is not selected");
+    });
   }
 }
 
 SearchQuery::SearchQuery(const util::Config& config, db::Table& table)
     : table_(table), header_(config.boolean("header", false)), dimension_(table.dimension(config.str("dimension"))),
       term_(config.str("term")), limit_((size_t)config.num("limit", 0)) {
-  FilterFactory ff;
-  filter_ = ff.Create(config.sub("filter", true));
+  filter_ = std::make_unique<Filter>(Filter::FromConfig(config.sub("filter", true)));
 }
 
 std::vector<std::string> AggregateQuery::column_names() const {

@@ -1,6 +1,6 @@
 // viya_query.h — host-side mirror of the reference's query layer for aggregate (and select / search) queries.
 //
-//   query::Filter tree + FilterFactory      src/query/filter.h:38-134, src/query/filter.cc:36-108
+//   query::Filter (one value type; FromConfig)  src/query/filter.h:38-134, src/query/filter.cc:36-108
 //   query::AggregateQuery (+ SelectQuery)   src/query/query.h:152-205, src/query/query.cc:48-135
 //   query::RowOutput / MemoryRowOutput      src/query/output.h:26-48
 //   query::QueryStats                       src/query/stats.h:35-58
@@ -24,78 +24,45 @@
 namespace viya {
 namespace query {
 
-class FilterVisitor;
-
+// One node of a predicate tree (a query's "filter" or "having"). The reference models it as a class per node kind plus a
+// visitor (src/query/filter.h:38-134); here a node is a value — its kind, the column and literal strings of a leaf, or the
+// parts of a conjunction / disjunction — and the four consumers (literal decoding, the device filter program, the device
+// HAVING program, HAVING on the host) walk it with a switch. Built from the JSON descriptor by FromConfig.
 class Filter {
 public:
-  explicit Filter(int precedence) : precedence_(precedence) {}
-  virtual ~Filter() {}
-  int precedence() const { return precedence_; }
-  virtual void Accept(FilterVisitor& v) const = 0;
+  enum Kind { PASS_ALL, COMPARE, MEMBER, ALL_OF, ANY_OF };
+  enum Relation { EQUAL = 0, NOT_EQUAL, LESS, LESS_EQUAL, GREATER, GREATER_EQUAL };   // numbered like vh_op (include/viya_hip.h)
 
-private:
-  const int precedence_;
-};
+  Filter() = default;                                                     // PASS_ALL: "no filter"
+  static Filter Compare(Relation r, std::string column, std::string literal);
+  static Filter Member(std::string column, std::vector<std::string> literals, bool inside);   // IN (inside) / NOT IN
+  static Filter Combine(bool all, std::vector<Filter> parts);
 
-class RelOpFilter : public Filter {
-public:
-  enum Operator { EQUAL = 0, NOT_EQUAL, LESS, LESS_EQUAL, GREATER, GREATER_EQUAL };
-  RelOpFilter(Operator op, const std::string& column, const std::string& value) : Filter(1), op_(op), column_(column), value_(value) {}
-  Operator op() const { return op_; }
+  // src/query/filter.cc:36-108 — "not" never survives: it flips and / or (De Morgan), negates relations and turns IN into
+  // NOT IN; the parts of a composite are ordered comparisons < conjunctions < disjunctions < IN lists (stable).
+  static Filter FromConfig(const util::Config& config, bool negate = false);
+
+  Kind kind() const { return kind_; }
+  Relation relation() const { return relation_; }
+  bool inside() const { return inside_; }
   const std::string& column() const { return column_; }
-  const std::string& value() const { return value_; }
-  void Accept(FilterVisitor& v) const override;
+  const std::vector<std::string>& literals() const { return literals_; }   // COMPARE: one; MEMBER: the list
+  const std::vector<Filter>& parts() const { return parts_; }
+  int rank() const { return kind_ == COMPARE ? 1 : kind_ == ALL_OF ? 2 : kind_ == ANY_OF ? 3 : kind_ == MEMBER ? 4 : 0; }
+
+  // every leaf (COMPARE / MEMBER), in evaluation order — which is also the order literals are packed in
+  template <class Fn> void EachLeaf(Fn&& fn) const {
+    if (kind_ == COMPARE || kind_ == MEMBER) fn(*this);
+    for (const Filter& part : parts_) part.EachLeaf(fn);
+  }
 
 private:
-  Operator op_;
-  std::string column_, value_;
-};
-
-class InFilter : public Filter {
-public:
-  InFilter(const std::string& column, const std::vector<std::string>& values, bool equal) : Filter(4), column_(column), values_(values), equal_(equal) {}
-  const std::string& column() const { return column_; }
-  const std::vector<std::string>& values() const { return values_; }
-  bool equal() const { return equal_; }
-  void Accept(FilterVisitor& v) const override;
-
-private:
+  Kind kind_ = PASS_ALL;
+  Relation relation_ = EQUAL;
+  bool inside_ = true;
   std::string column_;
-  std::vector<std::string> values_;
-  bool equal_;
-};
-
-class CompositeFilter : public Filter {
-public:
-  enum Operator { AND, OR };
-  CompositeFilter(Operator op, std::vector<std::unique_ptr<Filter>> filters) : Filter(op == AND ? 2 : 3), op_(op), filters_(std::move(filters)) {}
-  Operator op() const { return op_; }
-  const std::vector<std::unique_ptr<Filter>>& filters() const { return filters_; }
-  void Accept(FilterVisitor& v) const override;
-
-private:
-  Operator op_;
-  std::vector<std::unique_ptr<Filter>> filters_;
-};
-
-class EmptyFilter : public Filter {
-public:
-  EmptyFilter() : Filter(0) {}
-  void Accept(FilterVisitor& v) const override;
-};
-
-class FilterVisitor {
-public:
-  virtual ~FilterVisitor() {}
-  virtual void Visit(const RelOpFilter*) = 0;
-  virtual void Visit(const InFilter*) = 0;
-  virtual void Visit(const CompositeFilter*) = 0;
-  virtual void Visit(const EmptyFilter*) = 0;
-};
-
-class FilterFactory {
-public:
-  std::unique_ptr<Filter> Create(const util::Config& config, bool negate = false);
+  std::vector<std::string> literals_;
+  std::vector<Filter> parts_;
 };
 
 // ---- output / stats
