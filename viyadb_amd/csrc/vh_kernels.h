@@ -1601,7 +1601,8 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
       for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = m.ident;
     }
   }
-  for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
+  const bool carried = P.present_carrier >= 0;        // a SOP_ADD32P state says whether the group exists: no presence bytes in LDS
+  if (!carried) for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
   __syncthreads();
   const bool two = P.nlevel == 2;
   uint32_t first = 0, total;
@@ -1621,43 +1622,92 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
   const uint32_t tw = (uint32_t)P.tw;
   // the waves of this range's blocks share the tag array `gsz` extents at a time (64, or fewer when there are not enough extents
   // to go round: phase 1 writes few, large extents when few rows survive); a tag that equals `want` is an extent to aggregate
+  // SUM of a 64-bit column + SUM of a 32-bit one (SUM + COUNT: the reference's bread and butter) in two-word tuples:
+  // word 0 = gid | the 32-bit value << 32, word 1 = the 64-bit value
+  int j64 = -1, j32 = -1;
+  if (P.tw == 2 && P.nmetric == 2)
+    for (int j = 0; j < 2; ++j) {
+      if (P.m[j].sop() == SOP_ADD64 && P.m[j].tword() == 1 && P.m[j].tshift() == 0) j64 = j;
+      if ((P.m[j].sop() == SOP_ADD32 || P.m[j].sop() == SOP_ADD32P) && P.m[j].tword() == 0 && P.m[j].tshift() == 32) j32 = j;
+    }
+  const bool sum_pair = j64 >= 0 && j32 >= 0 && (P.m[j32 < 0 ? 0 : j32].sop() == SOP_ADD32P) == carried;
+  unsigned long long* const sum64 = reinterpret_cast<unsigned long long*>(lds + P.m[j64 < 0 ? 0 : j64].lds_off);
+  char* const sum32 = lds + P.m[j32 < 0 ? 0 : j32].lds_off;
   const uint32_t gsz = vh_tag_group(total - first, (uint32_t)blocks_per_part * nwaves);
+  // Per step a wave looks at gsz tags AND the fill of those extents (one vector load each, side by side: a dependent scalar load
+  // per extent was a serial memory round trip — phase 1 leaves ~80 K extents of ~600 tuples on C3), then walks the extents that
+  // are its partition's as ONE stream of 64-tuple slots, four slots in flight whatever extent they come from.
   for (uint32_t c0 = first + ((uint32_t)b * nwaves + wave) * gsz; c0 < total; c0 += (uint32_t)blocks_per_part * nwaves * gsz) {
-   uint64_t mine = __ballot((uint32_t)lane < gsz && c0 + lane < total && tags[c0 + lane] == want);
-   while (mine) {
-    const uint32_t ext = c0 + (uint32_t)__builtin_ctzll(mine);
-    mine &= mine - 1;
-    const uint32_t valid = ext_tuples - missing[ext];
-    const uint64_t* base = pool + (uint64_t)ext * ext_tuples * tw;
-    // four tuples per lane in flight: with one, a 16-wave block keeps ~16 KB outstanding and the kernel is latency bound
-    for (uint32_t i0 = 0; i0 < valid; i0 += 256) {
-      uint64_t w[4][1 + VH_FAST_COLS];
+   const bool in = (uint32_t)lane < gsz && c0 + lane < total;
+   const uint8_t tag = in ? tags[c0 + lane] : (uint8_t)0xFF;
+   const uint32_t fill = in ? ext_tuples - missing[c0 + lane] : 0u;
+   uint64_t mine = __ballot(in && tag == want && fill != 0);
+   uint32_t ext = 0, valid = 0, at = 0;            // the extent being walked (wave-uniform)
+   while (mine || at < valid) {
+    const uint64_t* sbase[4];
+    uint32_t sn[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint32_t i = i0 + u * 64 + lane;
-#pragma unroll
-        for (int x = 0; x < 1 + VH_FAST_COLS; ++x)
-          w[u][x] = (i < valid && (uint32_t)x < tw) ? __builtin_nontemporal_load(base + (uint64_t)i * tw + x) : (x == 0 ? ~0ull : 0ull);
+    for (int u = 0; u < 4; ++u) {
+      if (at >= valid && mine) {
+        const int q = __builtin_ctzll(mine);
+        mine &= mine - 1;
+        ext = c0 + (uint32_t)q;
+        valid = (uint32_t)__builtin_amdgcn_readlane((int)fill, q);
+        at = 0;
       }
+      if (at < valid) {
+        sbase[u] = pool + ((uint64_t)ext * ext_tuples + at) * tw;
+        sn[u] = valid - at < 64u ? valid - at : 64u;
+        at += 64u;
+      } else { sbase[u] = pool; sn[u] = 0; }
+    }
+    uint64_t w[4][1 + VH_FAST_COLS];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int x = 0; x < 1 + VH_FAST_COLS; ++x)
+        w[u][x] = ((uint32_t)lane < sn[u] && (uint32_t)x < tw) ? ((VH_ABLATE & 32) ? (x == 0 ? g0 + ((at * 2654435761u + lane * 40503u + u * 977u) & (gpp - 1)) : 1ull)   // measurement build: no tuple loads
+                                                                                      : __builtin_nontemporal_load(sbase[u] + (uint64_t)lane * tw + x)) : (x == 0 ? ~0ull : 0ull);
+    }
+    if (VH_ABLATE & 16) {        // measurement build: tuple loads only
+      uint64_t acc = 0;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc += w[u][0] + w[u][1];
+      if (acc == 0x123456789ABCDEFull) P.counters[7] = acc;
+      continue;
+    }
+    if (sum_pair) {       // the common shape, without the per-tuple walk over the plan's metric descriptors (550 -> ~60 instructions per 256 tuples)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const uint64_t local = (w[u][0] & 0xFFFFFFFFull) - g0;
-        if (w[u][0] == ~0ull || local >= ng) continue;  // past the extent's fill; (a corrupt tuple cannot write outside the table)
-        reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[local] = 1;
+        const uint64_t w0 = w[u][0], local = (w0 & 0xFFFFFFFFull) - g0;
+        if (w0 == ~0ull || local >= ng) continue;
+        __hip_atomic_fetch_add(sum64 + local, (unsigned long long)w[u][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (carried) __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(sum32) + local, (1ull << 32) | (w0 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else {
+          reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[local] = 1;
+          __hip_atomic_fetch_add(reinterpret_cast<uint32_t*>(sum32) + local, (uint32_t)(w0 >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      continue;
+    }
 #pragma unroll
-        for (int j = 0; j < VH_FAST_COLS; ++j) {
-          if (j < P.nmetric) {
-            const VhMetricDev& m = P.m[j];
-            uint64_t v = 0;
+    for (int u = 0; u < 4; ++u) {
+      const uint64_t local = (w[u][0] & 0xFFFFFFFFull) - g0;
+      if (w[u][0] == ~0ull || local >= ng) continue;  // an empty slot; (a corrupt tuple cannot write outside the table)
+      if (!carried) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[local] = 1;
 #pragma unroll
-            for (int x = 0; x < 1 + VH_FAST_COLS; ++x)
-              if (m.tword() == (uint32_t)x) v = w[u][x] >> m.tshift();
-            if (vh_sop_bytes(m.sop()) == 4) {
-              v &= 0xFFFFFFFFull;
-              if (vh_sop_sext(m.sop())) v = (uint64_t)(int64_t)(int32_t)v;
-            }
-            vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, local, m.sop(), v);
+      for (int j = 0; j < VH_FAST_COLS; ++j) {
+        if (j < P.nmetric) {
+          const VhMetricDev& m = P.m[j];
+          uint64_t v = 0;
+#pragma unroll
+          for (int x = 0; x < 1 + VH_FAST_COLS; ++x)
+            if (m.tword() == (uint32_t)x) v = w[u][x] >> m.tshift();
+          if (vh_sop_bytes(m.sop()) == 4) {
+            v &= 0xFFFFFFFFull;
+            if (vh_sop_sext(m.sop())) v = (uint64_t)(int64_t)(int32_t)v;
           }
+          vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, local, m.sop(), v);
         }
       }
     }
@@ -1669,10 +1719,10 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
   const bool own = blocks_per_part == 1 || P.nxcd == blocks_per_part;
   const uint64_t xo = P.nxcd == blocks_per_part ? (uint64_t)b * P.xcd_stride : 0;
   for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) {
-    const uint8_t here = reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g];
-    if (own && blocks_per_part > 1) P.present[xo + g0 + g] = here;
-    if (!here && !(own && blocks_per_part > 1)) continue;
-    if (here && !(own && blocks_per_part > 1)) P.present[g0 + g] = 1;
+    const uint8_t here = carried ? (uint8_t)(reinterpret_cast<uint64_t*>(lds + P.m[P.present_carrier].lds_off)[g] != 0)
+                                 : reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g];
+    if (own && blocks_per_part > 1) { if (!carried) P.present[xo + g0 + g] = here; }
+    else { if (!here) continue; if (!carried) P.present[g0 + g] = 1; }
     for (int j = 0; j < P.nmetric; ++j) {
       const VhMetricDev& m = P.m[j];
       if (vh_sop_bytes(m.sop()) == 4) {

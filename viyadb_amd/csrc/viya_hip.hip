@@ -1398,8 +1398,15 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   uint64_t part_tuple_cap = 0;
   if (mode == VH_MODE_DENSE_GLOBAL && fast && !no_part && !(p->flags & (VH_PLAN_NO_PART | VH_PLAN_FORCE_GLOBAL)) && P.nmetric >= 1) {
     int shift = 0;
-    const size_t part_table_bytes = getenv("VH_PART_TABLE_KB") ? (size_t)atoi(getenv("VH_PART_TABLE_KB")) * 1024 : 120 * 1024;   // one 1024-thread block per CU in phase 2 (160 KB LDS)
-    while (((size_t)2 << shift) * state_bytes_per_group <= part_table_bytes) ++shift;
+    const size_t part_table_bytes = getenv("VH_PART_TABLE_KB") ? (size_t)atoi(getenv("VH_PART_TABLE_KB")) * 1024 : 128 * 1024;   // one 1024-thread block per CU in phase 2 (160 KB LDS)
+    // Phase 2 is bound by LDS read-modify-writes at random addresses (about one lane per clock and CU: 50 M tuples x 3 updates =
+    // 0.29 ms on C3, profiles/r02/NOTES.md), so the presence byte rides in a 32-bit SUM state when there is one (SOP_ADD32P: a
+    // 64-bit word whose upper half counts rows) — two updates per tuple instead of three.
+    int part_carrier = -1;
+    if (!(p->flags & VH_PLAN_NO_CARRIER))
+      for (int j = 0; j < P.nmetric && part_carrier < 0; ++j) if (P.m[j].sop() == SOP_ADD32) part_carrier = j;
+    const size_t part_state_bytes = part_carrier >= 0 ? state_bytes_per_group - 1 + 4 : state_bytes_per_group;
+    while (((size_t)2 << shift) * part_state_bytes <= part_table_bytes) ++shift;
     const uint64_t np = (G + (1ull << shift) - 1) >> shift;
     // more LDS-sized ranges than a wave has lanes: two levels (phase 1 partitions into ceil(np / 64), part_split_kernel splits each 64 ways)
     const bool two_level = np > VH_MAX_PART;
@@ -1466,6 +1473,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         else { P.m[j].set_tword((uint8_t)tw); P.m[j].set_tshift(0); half_free_word = tw++; have_half = true; }
       }
       P.tw = tw;
+      if (part_carrier >= 0) { P.m[part_carrier].set_sop(SOP_ADD32P); state_bytes_per_group += 4; }   // (its tuple slot stays 32 bits wide)
       // phase-2 LDS table for one partition
       const uint64_t gpp = 1ull << shift;
       size_t off = 0;
@@ -1476,7 +1484,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
           P.m[j].lds_off = (uint32_t)off; off += gpp * b;
         }
       off = (off + 7) / 8 * 8;
-      P.lds_present_off = (uint32_t)off; off += gpp;
+      P.lds_present_off = (uint32_t)off; if (part_carrier < 0) off += gpp;
       lds_table = (off + 15) / 16 * 16;
       P.lds_bytes = (uint32_t)lds_table;
       part_tuple_cap = part_tuples_override ? part_tuples_override
@@ -1486,6 +1494,8 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   }
   // direct global atomics: fold the presence flag into a 32-bit SUM state (SOP_ADD32P) when there is one
   P.present_carrier = -1;
+  if (mode == VH_MODE_DENSE_PART)
+    for (int j = 0; j < P.nmetric; ++j) if (P.m[j].sop() == SOP_ADD32P) P.present_carrier = j;
   if (mode == VH_MODE_DENSE_GLOBAL && !(p->flags & VH_PLAN_NO_CARRIER)) {
     for (int j = 0; j < P.nmetric; ++j)
       if (P.m[j].sop() == SOP_ADD32) { P.m[j].set_sop(SOP_ADD32P); P.present_carrier = j; state_bytes_per_group += 4; break; }
@@ -1921,7 +1931,7 @@ extern "C" int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs, in
   int n = 0;
   if (max_bufs < P.nmetric + 1) return vh_fail(VH_E_INVALID, "need %d buffers", P.nmetric + 1);
   // presence bytes are only written when no SUM state carries the flag (SOP_ADD32P): one collective less
-  if (!(r->mode == VH_MODE_DENSE_GLOBAL && P.present_carrier >= 0)) bufs[n++] = vh_device_buffer{P.present, P.G, VH_U8, VH_RED_MAX};
+  if (!((r->mode == VH_MODE_DENSE_GLOBAL || r->mode == VH_MODE_DENSE_PART) && P.present_carrier >= 0)) bufs[n++] = vh_device_buffer{P.present, P.G, VH_U8, VH_RED_MAX};
   for (int j = 0; j < P.nmetric; ++j) {
     vh_device_buffer b{P.m[j].state, P.G, 0, VH_RED_SUM};
     switch (P.m[j].sop()) {
@@ -2149,7 +2159,7 @@ static int result_finalize(vh_result* r, int* retry) {
   VhEmitArgs A{};
   A.mode = r->mode == VH_MODE_DENSE_PART ? VH_MODE_DENSE_GLOBAL : r->mode; A.ngroup = P.ngroup; A.nmetric = P.nmetric; A.key_words = P.key_words;
   A.hstride = P.hrec_bytes ? P.hrec_bytes / 8u : (uint32_t)P.key_words;
-  A.n = r->out_cap; A.present = P.present; A.present_carrier = r->mode == VH_MODE_DENSE_GLOBAL ? P.present_carrier : -1; A.hkeys = P.hkeys; A.htags = P.htags; A.counters = P.counters;
+  A.n = r->out_cap; A.present = P.present; A.present_carrier = (r->mode == VH_MODE_DENSE_GLOBAL || r->mode == VH_MODE_DENSE_PART) ? P.present_carrier : -1; A.hkeys = P.hkeys; A.htags = P.htags; A.counters = P.counters;
   A.out_count = r->d_out_count;
   for (int i = 0; i < P.ngroup; ++i) {
     A.glo[i] = P.g[i].lo; A.gextent[i] = P.g[i].extent; A.gstride[i] = P.g[i].stride;
