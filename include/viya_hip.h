@@ -177,9 +177,11 @@ enum vh_plan_flags {
   VH_PLAN_FORCE_PACK = 1u << 13,  /* testing: gather from a payload projection whatever
                                      the selectivity, building one if none covers
                                      the query's columns                       */
-  VH_PLAN_NO_PART2 = 1u << 14     /* ablation: no second partition level (group-id
+  VH_PLAN_NO_PART2 = 1u << 14,    /* ablation: no second partition level (group-id
                                      spaces of more than 64 LDS-sized ranges stay on
                                      direct global atomics)                    */
+  VH_PLAN_NO_SHAPE = 1u << 15     /* ablation: the generic survivor drain even when the
+                                     plan has a shape a specialised one exists for */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */

@@ -214,6 +214,10 @@ def test_two_level_partitioning():
             qq = dict(q, filter=F("ge", "f", "0") if lanes else F("lt", "f", "30"))
             res, _ = run(tab, dt, qq, flags=flags)
             assert res.path == "dense_part" and "part_split_kernel" in res.kernel and res.lanes == lanes and res.retries == 0, (res.path, res.kernel, res.lanes)
+            if not lanes:       # two unsigned group columns, SUM(long) + SUM(uint): the specialised drain, and the generic one on request
+                assert "scan_agg_shape_kernel" in res.kernel, res.kernel
+                res, _ = run(tab, dt, qq, flags=flags | capi.PLAN_NO_SHAPE)
+                assert res.path == "dense_part" and "scan_agg_fast_kernel" in res.kernel, res.kernel
             res, _ = run(tab, dt, qq, flags=flags | capi.PLAN_NO_PART2)
             assert res.path == "dense_global"
         # four metrics (wide tuples), MIN / MAX states

@@ -182,6 +182,7 @@ struct VhPlanDev {
   int32_t tw;                // 64-bit words per tuple (word 0 low half = gid)
   int32_t ext_tuples;        // tuples per extent (a tile's run of one partition never straddles extents)
   int32_t nlevel;            // 1 or 2
+  int32_t shape;             // 0, or the plan shape the compacting kernel's drain is specialised for (vh_consume_fast)
   int32_t agg_shift;         // groups per LDS table of phase 2 = 1 << agg_shift (one level: == part_shift)
   int32_t nfine;             // LDS-sized ranges phase 2 aggregates (one level: == npart)
   int32_t ext_tuples2;       // pool 2: tuples per extent

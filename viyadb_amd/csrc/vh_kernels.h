@@ -1098,10 +1098,32 @@ __device__ __forceinline__ uint32_t vh_eval_filter_fast(const VhPlanDev& P, cons
   return m;
 }
 
-template <int MODE, int SCOPE>
+// SHAPE 1 (DENSE_PART only; the host checks the plan, query_launch_locked): GROUP BY two unsigned 32-bit columns without time
+// arithmetic, SUM of a 64-bit column (metric 0) + SUM of a 32-bit one (metric 1) — "GROUP BY two dimensions, SUM + COUNT", the
+// reference's bread and butter. The generic drain walks the plan's column descriptors per survivor (element types, rollup rules,
+// 64-bit digit arithmetic, tuple word / shift of every metric): ~300 VALU instructions per drain on a SIMD that is busy issuing
+// 40 % of the time (profiles/r02/NOTES.md, "Instruction counts"); this one knows the answers.
+template <int MODE, int SCOPE, int SHAPE = 0>
 __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, char* lds,
                                                 uint64_t xoff, unsigned long long& nfresh, VhPartWave& W, VhPartTile& T, VhLdsHashWave& H) {
   if (!active) row = 0;
+  if (SHAPE == 1 && MODE == VH_MODE_DENSE_PART) {
+    uint32_t s0, s1, s2, s3;
+    const uint64_t r0 = vh_gather_raw(P, P.g[0].slot(), seg, row, s0);
+    const uint64_t r1 = vh_gather_raw(P, P.g[1].slot(), seg, row, s1);
+    const uint64_t r2 = vh_gather_raw(P, P.m[0].slot(), seg, row, s2);
+    const uint64_t r3 = vh_gather_raw(P, P.m[1].slot(), seg, row, s3);
+    const uint32_t d0 = (uint32_t)(r0 >> s0) - (uint32_t)P.g[0].lo, d1 = (uint32_t)(r1 >> s1) - (uint32_t)P.g[1].lo;
+    const bool bad = d0 >= (uint32_t)P.g[0].extent || d1 >= (uint32_t)P.g[1].extent;
+    if (__ballot(active && bad)) {
+      if (active && bad) atomicOr(P.counters + 2, VH_ERR_RANGE);
+    }
+    active = active && !bad;
+    const uint32_t gid = d0 * (uint32_t)P.g[0].stride + d1 * (uint32_t)P.g[1].stride;
+    const uint64_t words[2] = {(uint64_t)gid | ((r3 >> s3) << 32), r2 >> s2};
+    vh_part_direct_add<2>(P, T, W, active, words, gid >> P.part_shift, (int)(threadIdx.x & 63));
+    return;
+  }
   // All of a survivor's values are requested before the first one is looked at: the aligned 8-byte word around each
   // element is loaded whatever the column's type (no type switch, hence no branch and no wait, between the loads), and
   // only then shifted / masked / sign-extended. One memory round trip per drain instead of one per column — the drain
@@ -1224,8 +1246,8 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
 #ifndef VH_FAST_WAVES
 #define VH_FAST_WAVES(MODE, BLOCK, NP) 0      // waves per SIMD asked of the compiler (0: no request); experiments override it
 #endif
-template <int MODE, int BLOCK, int SCOPE, int NP>
-__global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_agg_fast_kernel(const VhPlanDev P) {
+template <int MODE, int BLOCK, int SCOPE, int NP, int SHAPE>
+__device__ __forceinline__ void vh_scan_fast_body(const VhPlanDev& P) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef VhScanCfg<BLOCK> C;
   const int lane = threadIdx.x & 63;
@@ -1292,34 +1314,37 @@ __global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_ag
       }
     }
     if (nhave) vh_preload<NP>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
+    // One textual drain for the four sub-steps and for the flush at a segment's end (k == VH_SUBSTEPS): with the loop unrolled the
+    // drain — gathers, rollup, table update, every table organisation's alternatives — was inlined five times and the kernel ran to
+    // 26 K instructions, several times the instruction cache (profiles/r02/NOTES.md, "Code size").
+#pragma unroll 1
+    for (int k = 0; k <= VH_SUBSTEPS; ++k) {
+      bool flush = false;
+      if (k < VH_SUBSTEPS) {
+        const uint32_t mk = (mask >> (4 * k)) & 0xFu;
+        if (__ballot(mk != 0) == 0) continue;
 #pragma unroll
-    for (int k = 0; k < VH_SUBSTEPS; ++k) {
-      const uint32_t mk = (mask >> (4 * k)) & 0xFu;
-      if (__ballot(mk != 0) == 0) continue;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const bool b = (mk >> j) & 1u;
-        const uint64_t bal = __ballot(b);
-        if (b) q[cnt + __popcll(bal & lanemask_lt)] = row_l + k * 256u + j;
-        cnt += __popcll(bal);
+        for (int j = 0; j < 4; ++j) {
+          const bool b = (mk >> j) & 1u;
+          const uint64_t bal = __ballot(b);
+          if (b) q[cnt + __popcll(bal & lanemask_lt)] = row_l + k * 256u + j;
+          cnt += __popcll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();
+      } else {
+        flush = !nhave || nseg != seg;       // queue entries are rows of the current segment
       }
-      __builtin_amdgcn_wave_barrier();
       // Tried and measured slower (profiles/r01/NOTES.md): draining two survivors per lane with both gathers
       // in flight (+8..50 %: register pressure), and a "dense lane" path with coalesced 4-row payload loads
       // for wave steps where most rows pass (179-242 VGPRs, scratch spills in the LDS variant).
-      while (cnt >= 64) {
-        cnt -= 64;
-        const uint32_t r = q[cnt + lane];
-        vh_consume_fast<MODE, SCOPE>(P, seg, r, true, lds, xoff, nfresh, W, T, H);
+      while (cnt >= 64 || (flush && cnt)) {
+        const uint32_t take = cnt >= 64 ? 64u : cnt;
+        cnt -= take;
+        const bool act = (uint32_t)lane < take;
+        const uint32_t r = act ? q[cnt + lane] : 0u;
+        vh_consume_fast<MODE, SCOPE, SHAPE>(P, seg, r, act, lds, xoff, nfresh, W, T, H);
         __builtin_amdgcn_wave_barrier();
       }
-    }
-    if (cnt && (!nhave || nseg != seg)) {  // queue entries are rows of the current segment
-      const bool act = lane < (int)cnt;
-      const uint32_t r = act ? q[lane] : 0;
-      vh_consume_fast<MODE, SCOPE>(P, seg, r, act, lds, xoff, nfresh, W, T, H);
-      __builtin_amdgcn_wave_barrier();
-      cnt = 0;
     }
     have = nhave; seg = nseg; unit_base = nunit_base; wave_base = nwave_base; seg_rows = nseg_rows;
     if (MODE == VH_MODE_HASH && H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
@@ -1346,6 +1371,18 @@ __global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_ag
       }
     }
   }
+}
+
+template <int MODE, int BLOCK, int SCOPE, int NP>
+__global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_agg_fast_kernel(const VhPlanDev P) {
+  vh_scan_fast_body<MODE, BLOCK, SCOPE, NP, 0>(P);
+}
+// the same scan with a drain specialised for one plan shape (vh_consume_fast, SHAPE)
+// (at most 4 waves per SIMD asked for: left alone, the compiler aims at 5-6 for the one- and two-column instantiations and
+// pays for it with scratch spills inside the scan loop)
+template <int MODE, int BLOCK, int SCOPE, int NP, int SHAPE>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void scan_agg_shape_kernel(const VhPlanDev P) {
+  vh_scan_fast_body<MODE, BLOCK, SCOPE, NP, SHAPE>(P);
 }
 
 // ------------------------------------------------- "lanes" variant: no compaction (high selectivity, LDS table)

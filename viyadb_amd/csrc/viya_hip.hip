@@ -1473,6 +1473,17 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         else { P.m[j].set_tword((uint8_t)tw); P.m[j].set_tshift(0); half_free_word = tw++; have_half = true; }
       }
       P.tw = tw;
+      // the drain specialised for "two unsigned 32-bit group columns, SUM(64-bit) + SUM(32-bit)" (vh_consume_fast, SHAPE 1)
+      P.shape = 0;
+      if (!lanes && !(p->flags & VH_PLAN_NO_SHAPE) && P.ngroup == 2 && P.nmetric == 2 && tw == 2 && G <= 0xFFFFFFFFull) {
+        bool ok = true;
+        for (int i = 0; i < 2; ++i)
+          ok &= P.g[i].type() == VH_U32 && P.g[i].gran() == VH_T_NONE && P.g[i].nroll() == 0 && P.g[i].lo <= 0xFFFFFFFFull &&
+                P.g[i].extent <= 0xFFFFFFFFull && P.g[i].stride <= 0xFFFFFFFFull;
+        ok &= P.m[0].sop() == SOP_ADD64 && P.m[0].slot() != VH_SLOT_ROWID && vh_elem_size(P.m[0].type()) == 8 && P.m[0].tword() == 1;
+        ok &= P.m[1].sop() == SOP_ADD32 && P.m[1].slot() != VH_SLOT_ROWID && vh_elem_size(P.m[1].type()) == 4 && P.m[1].tword() == 0 && P.m[1].tshift() == 32;
+        if (ok) P.shape = 1;
+      }
       if (part_carrier >= 0) { P.m[part_carrier].set_sop(SOP_ADD32P); state_bytes_per_group += 4; }   // (its tuple slot stays 32 bits wide)
       // phase-2 LDS table for one partition
       const uint64_t gpp = 1ull << shift;
@@ -1678,6 +1689,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     const int np_ = std::max(1, (int)P.npred), scope = (mode == VH_MODE_DENSE_GLOBAL || mode == VH_MODE_DENSE_LDS) && nxcd > 1 ? (int)__HIP_MEMORY_SCOPE_WORKGROUP : (int)__HIP_MEMORY_SCOPE_AGENT;
     char nm[160];
     if (!fast) snprintf(nm, sizeof(nm), "scan_agg_kernel<%d, %d, %d>", mode, BLOCK, scope);
+    else if (mode == VH_MODE_DENSE_PART && !lanes && P.shape) snprintf(nm, sizeof(nm), "scan_agg_shape_kernel<%d, %d, %d, %d, %d>", mode, BLOCK, (int)__HIP_MEMORY_SCOPE_AGENT, np_, P.shape);
     else snprintf(nm, sizeof(nm), "%s<%d, %d, %d, %d>", lanes ? "scan_agg_lanes_kernel" : "scan_agg_fast_kernel", mode, BLOCK,
                   (mode == VH_MODE_HASH || mode == VH_MODE_DENSE_PART) ? (int)__HIP_MEMORY_SCOPE_AGENT : scope, np_);
     r->kernel = nm;
