@@ -111,6 +111,7 @@ struct VhPlanDev {
   // ---- filter: postfix program + literal pool, uploaded next to the segment snapshot (uniform addresses: scalar loads, like
   // kernel arguments, but without their 4 KB ceiling: an IN list may hold thousands of values)
   int32_t nprog;
+  int32_t prog_flat;          // 1: the program is leaves + one AND over all of them (or a single leaf), 2: ... one OR; 0: anything else (stack machine)
   int32_t nslots;
   const VhProgOp* prog;       // generic kernels (scan_agg_kernel, select_*): any length
   const uint64_t* lits;

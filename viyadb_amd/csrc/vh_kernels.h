@@ -1061,32 +1061,50 @@ __device__ __forceinline__ void vh_preload(const VhPlanDev& P, uint32_t seg, uin
 template <int NP>
 __device__ __forceinline__ uint32_t vh_eval_filter_fast(const VhPlanDev& P, const uint32_t (&v)[NP][VH_LANE_ROWS], uint32_t row_l,
                                                         uint32_t seg_rows) {
-  uint32_t st[VH_MAX_STACK];
-  int sp = 0;
-  for (int pc = 0; pc < P.nprog; ++pc) {
-    const VhProgOp o = P.iprog[pc];
-    switch (o.kind()) {
-      case VH_F_TRUE: st[sp++] = VH_ROWMASK; break;
-      case VH_F_AND: {
-        uint32_t a = st[--sp];
-        for (int i = 1; i < o.count(); ++i) a &= st[--sp];
-        st[sp++] = a;
-      } break;
-      case VH_F_OR: {
-        uint32_t a = st[--sp];
-        for (int i = 1; i < o.count(); ++i) a |= st[--sp];
-        st[sp++] = a;
-      } break;
-      default: {
-        uint32_t m = 0;
+  uint32_t m;
+  if (P.prog_flat) {      // leaves under one AND (or one OR): fold as they come — a register array indexed by a run-time stack pointer
+                          // costs a chain of selects per push and pop
+    const bool conj = P.prog_flat == 1;
+    m = conj ? VH_ROWMASK : 0u;
+    const int nleaf = P.nprog > 1 ? P.nprog - 1 : 1;
+    for (int pc = 0; pc < nleaf; ++pc) {
+      const VhProgOp o = P.iprog[pc];
+      uint32_t e = VH_ROWMASK;
+      if (o.kind() != VH_F_TRUE) {
 #pragma unroll
         for (int p = 0; p < NP; ++p)
-          if (o.pslot() == p) m = vh_leaf_bits(P, o, v[p]);
-        st[sp++] = m;
-      } break;
+          if (o.pslot() == p) e = vh_leaf_bits(P, o, v[p]);
+      }
+      m = conj ? (m & e) : (m | e);
     }
+  } else {
+    uint32_t st[VH_MAX_STACK];
+    int sp = 0;
+    for (int pc = 0; pc < P.nprog; ++pc) {
+      const VhProgOp o = P.iprog[pc];
+      switch (o.kind()) {
+        case VH_F_TRUE: st[sp++] = VH_ROWMASK; break;
+        case VH_F_AND: {
+          uint32_t a = st[--sp];
+          for (int i = 1; i < o.count(); ++i) a &= st[--sp];
+          st[sp++] = a;
+        } break;
+        case VH_F_OR: {
+          uint32_t a = st[--sp];
+          for (int i = 1; i < o.count(); ++i) a |= st[--sp];
+          st[sp++] = a;
+        } break;
+        default: {
+          uint32_t e = 0;
+#pragma unroll
+          for (int p = 0; p < NP; ++p)
+            if (o.pslot() == p) e = vh_leaf_bits(P, o, v[p]);
+          st[sp++] = e;
+        } break;
+      }
+    }
+    m = st[0];
   }
-  uint32_t m = st[0];
   if (row_l + (VH_SUBSTEPS - 1) * 256u + 4u > seg_rows) {
 #pragma unroll
     for (int k = 0; k < VH_SUBSTEPS; ++k) {
@@ -1279,18 +1297,16 @@ __device__ __forceinline__ void vh_scan_fast_body(const VhPlanDev& P) {
   unsigned long long npassed = 0, nfresh = 0;
   const uint32_t spu = P.unit_rows / C::kStepRows;  // steps per unit
 
-  // flattened step index t of this block -> (segment, unit base, this wave's first row)
-  uint32_t t = 0, seg = 0, unit_base = 0, wave_base = 0, seg_rows = 0;
-  bool have;
-  {
-    const uint32_t unit = blockIdx.x;
-    have = unit < P.total_units;
-    if (have) {
-      seg = unit / P.units_per_seg;
-      unit_base = (unit - seg * P.units_per_seg) * P.unit_rows;
-      seg_rows = P.seg_rows[seg];
-      wave_base = unit_base + wave * VH_WAVE_STEP_ROWS;
-    }
+  // this block's units are blockIdx.x, + gridDim.x, ...; a unit is `spu` steps inside one segment. (segment, unit inside the
+  // segment, step inside the unit) advance by additions: three integer divisions per step were ~75 instructions of every step.
+  const uint32_t gdiv = gridDim.x / P.units_per_seg, gmod = gridDim.x % P.units_per_seg;
+  uint32_t unit = blockIdx.x, seg = 0, useg = 0, ustep = 0, wave_base = 0, seg_rows = 0;    // useg: unit index inside its segment
+  bool have = unit < P.total_units;
+  if (have) {
+    seg = unit / P.units_per_seg;
+    useg = unit - seg * P.units_per_seg;
+    seg_rows = P.seg_rows[seg];
+    wave_base = useg * P.unit_rows + wave * VH_WAVE_STEP_ROWS;
   }
   uint32_t v[NP][VH_LANE_ROWS];
   if (have) vh_preload<NP>(P, seg, wave_base + lane * 4, seg_rows, v);
@@ -1300,17 +1316,17 @@ __device__ __forceinline__ void vh_scan_fast_body(const VhPlanDev& P) {
     const uint32_t mask = vh_eval_filter_fast<NP>(P, v, row_l, seg_rows);
     npassed += __popc(mask);
     // locate the next step and put its predicate columns in flight now
-    ++t;
-    uint32_t nseg = seg, nunit_base = unit_base, nwave_base = 0, nseg_rows = seg_rows;
-    bool nhave;
-    {
-      const uint32_t unit = blockIdx.x + (t / spu) * gridDim.x;
+    uint32_t nseg = seg, nwave_base = wave_base + C::kStepRows, nseg_rows = seg_rows;
+    bool nhave = true;
+    if (++ustep == spu) {
+      ustep = 0;
+      unit += gridDim.x;
       nhave = unit < P.total_units;
+      useg += gmod; nseg = seg + gdiv;
+      if (useg >= P.units_per_seg) { useg -= P.units_per_seg; ++nseg; }
       if (nhave) {
-        nseg = unit / P.units_per_seg;
-        nunit_base = (unit - nseg * P.units_per_seg) * P.unit_rows;
         nseg_rows = P.seg_rows[nseg];
-        nwave_base = nunit_base + (t % spu) * C::kStepRows + wave * VH_WAVE_STEP_ROWS;
+        nwave_base = useg * P.unit_rows + wave * VH_WAVE_STEP_ROWS;
       }
     }
     if (nhave) vh_preload<NP>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
@@ -1327,7 +1343,7 @@ __device__ __forceinline__ void vh_scan_fast_body(const VhPlanDev& P) {
         for (int j = 0; j < 4; ++j) {
           const bool b = (mk >> j) & 1u;
           const uint64_t bal = __ballot(b);
-          if (b) q[cnt + __popcll(bal & lanemask_lt)] = row_l + k * 256u + j;
+          if (b) q[cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u))] = row_l + k * 256u + j;
           cnt += __popcll(bal);
         }
         __builtin_amdgcn_wave_barrier();
@@ -1346,7 +1362,7 @@ __device__ __forceinline__ void vh_scan_fast_body(const VhPlanDev& P) {
         __builtin_amdgcn_wave_barrier();
       }
     }
-    have = nhave; seg = nseg; unit_base = nunit_base; wave_base = nwave_base; seg_rows = nseg_rows;
+    have = nhave; seg = nseg; wave_base = nwave_base; seg_rows = nseg_rows;
     if (MODE == VH_MODE_HASH && H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
   }
 

@@ -1096,6 +1096,14 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     maxdepth = std::max(maxdepth, d);
   }
   if (maxdepth > VH_MAX_STACK) { return vh_fail(VH_E_UNSUPPORTED, "filter needs stack depth %d (max %d)", maxdepth, VH_MAX_STACK); }
+  {   // conjunctions / disjunctions of leaves — most filters — need no stack in the register-resident kernels (vh_eval_filter_fast)
+    bool leaves = true;
+    for (int k = 0; k + 1 < P.nprog; ++k) leaves &= prog[k].kind() != VH_F_AND && prog[k].kind() != VH_F_OR;
+    const int last = prog[P.nprog - 1].kind();
+    P.prog_flat = 0;
+    if (P.nprog == 1 && last != VH_F_AND && last != VH_F_OR) P.prog_flat = 1;
+    else if (leaves && P.nprog > 1 && (last == VH_F_AND || last == VH_F_OR) && (int)prog[P.nprog - 1].count() == P.nprog - 1) P.prog_flat = last == VH_F_AND ? 1 : 2;
+  }
   r->h_lits.resize(std::max(p->nlits, 0));
   for (int i = 0; i < p->nlits; ++i) r->h_lits[i] = p->lits[i].u64;
   if (prog.size() <= VH_INLINE_PROG && r->h_lits.size() <= VH_INLINE_LITS) {   // the register-resident kernels read the program from the kernel arguments
