@@ -1396,8 +1396,14 @@ __global__ __launch_bounds__(BLOCK, VH_FAST_WAVES(MODE, BLOCK, NP)) void scan_ag
 // the same scan with a drain specialised for one plan shape (vh_consume_fast, SHAPE)
 // (at most 4 waves per SIMD asked for: left alone, the compiler aims at 5-6 for the one- and two-column instantiations and
 // pays for it with scratch spills inside the scan loop)
+#ifndef VH_SHAPE_WAVES
+#define VH_SHAPE_WAVES 4
+#endif
+#ifndef VH_SHAPE_MINWAVES
+#define VH_SHAPE_MINWAVES 1
+#endif
 template <int MODE, int BLOCK, int SCOPE, int NP, int SHAPE>
-__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 4))) void scan_agg_shape_kernel(const VhPlanDev P) {
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(VH_SHAPE_MINWAVES, VH_SHAPE_WAVES))) void scan_agg_shape_kernel(const VhPlanDev P) {
   vh_scan_fast_body<MODE, BLOCK, SCOPE, NP, SHAPE>(P);
 }
 
