@@ -1116,8 +1116,8 @@ __device__ __forceinline__ uint32_t vh_eval_filter_fast(const VhPlanDev& P, cons
   return m;
 }
 
-// SHAPE 1 (DENSE_PART only; the host checks the plan, query_launch_locked): GROUP BY two unsigned 32-bit columns without time
-// arithmetic, SUM of a 64-bit column (metric 0) + SUM of a 32-bit one (metric 1) — "GROUP BY two dimensions, SUM + COUNT", the
+// SHAPE 1 (DENSE_PART only; the host checks the plan, query_launch_locked): GROUP BY two unsigned columns of up to 32 bits
+// (dictionary codes, booleans, uint dimensions) without time arithmetic, SUM of a 64-bit column (metric 0) + SUM of a 32-bit one (metric 1) — "GROUP BY two dimensions, SUM + COUNT", the
 // reference's bread and butter. The generic drain walks the plan's column descriptors per survivor (element types, rollup rules,
 // 64-bit digit arithmetic, tuple word / shift of every metric): ~300 VALU instructions per drain on a SIMD that is busy issuing
 // 40 % of the time (profiles/r02/NOTES.md, "Instruction counts"); this one knows the answers.
@@ -1131,7 +1131,10 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
     const uint64_t r1 = vh_gather_raw(P, P.g[1].slot(), seg, row, s1);
     const uint64_t r2 = vh_gather_raw(P, P.m[0].slot(), seg, row, s2);
     const uint64_t r3 = vh_gather_raw(P, P.m[1].slot(), seg, row, s3);
-    const uint32_t d0 = (uint32_t)(r0 >> s0) - (uint32_t)P.g[0].lo, d1 = (uint32_t)(r1 >> s1) - (uint32_t)P.g[1].lo;
+    // unsigned group columns of 1, 2 or 4 bytes (dictionary codes, booleans, uint dimensions): the host left the element's width
+    // as a right shift in key_shift (unused on the dense paths): 0, 16 or 24
+    const uint32_t d0 = (((uint32_t)(r0 >> s0) << P.g[0].key_shift()) >> P.g[0].key_shift()) - (uint32_t)P.g[0].lo;
+    const uint32_t d1 = (((uint32_t)(r1 >> s1) << P.g[1].key_shift()) >> P.g[1].key_shift()) - (uint32_t)P.g[1].lo;
     const bool bad = d0 >= (uint32_t)P.g[0].extent || d1 >= (uint32_t)P.g[1].extent;
     if (__ballot(active && bad)) {
       if (active && bad) atomicOr(P.counters + 2, VH_ERR_RANGE);

@@ -1485,12 +1485,12 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       P.shape = 0;
       if (!lanes && !(p->flags & VH_PLAN_NO_SHAPE) && P.ngroup == 2 && P.nmetric == 2 && tw == 2 && G <= 0xFFFFFFFFull) {
         bool ok = true;
-        for (int i = 0; i < 2; ++i)
-          ok &= P.g[i].type() == VH_U32 && P.g[i].gran() == VH_T_NONE && P.g[i].nroll() == 0 && P.g[i].lo <= 0xFFFFFFFFull &&
+        for (int i = 0; i < P.ngroup; ++i)
+          ok &= (P.g[i].type() == VH_U32 || P.g[i].type() == VH_U16 || P.g[i].type() == VH_U8) && P.g[i].gran() == VH_T_NONE && P.g[i].nroll() == 0 && P.g[i].lo <= 0xFFFFFFFFull &&
                 P.g[i].extent <= 0xFFFFFFFFull && P.g[i].stride <= 0xFFFFFFFFull;
         ok &= P.m[0].sop() == SOP_ADD64 && P.m[0].slot() != VH_SLOT_ROWID && vh_elem_size(P.m[0].type()) == 8 && P.m[0].tword() == 1;
         ok &= P.m[1].sop() == SOP_ADD32 && P.m[1].slot() != VH_SLOT_ROWID && vh_elem_size(P.m[1].type()) == 4 && P.m[1].tword() == 0 && P.m[1].tshift() == 32;
-        if (ok) P.shape = 1;
+        if (ok) { P.shape = 1; for (int i = 0; i < 2; ++i) P.g[i].set_key_shift(32u - 8u * (uint32_t)vh_elem_size(P.g[i].type())); }
       }
       if (part_carrier >= 0) { P.m[part_carrier].set_sop(SOP_ADD32P); state_bytes_per_group += 4; }   // (its tuple slot stays 32 bits wide)
       // phase-2 LDS table for one partition
