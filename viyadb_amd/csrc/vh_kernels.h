@@ -1555,6 +1555,13 @@ __global__ __launch_bounds__(BLOCK, VH_LANES_WAVES(MODE, BLOCK, NP)) void scan_a
         vh_part_tile_write<1 + VH_LANES_COLS>(P, T, W, words, part, lane);
         continue;
       }
+      if (VH_ABLATE & 64) {      // measurement build: the loads of a sub-step, nothing behind them
+        uint64_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc += gv[0][r] + gv[1][r] + mv[0][r] + mv[1][r];
+        if (acc == 0x123456789ABCDEFull) P.counters[7] = acc;
+        continue;
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (!((mk >> r) & 1u)) continue;
