@@ -220,6 +220,11 @@ def test_two_level_partitioning():
                 assert res.path == "dense_part" and "scan_agg_fast_kernel" in res.kernel, res.kernel
             res, _ = run(tab, dt, qq, flags=flags | capi.PLAN_NO_PART2)
             assert res.path == "dense_global"
+        # the specialised drain's other forms: metrics in the other order, one group column, narrow unsigned keys elsewhere in the suite
+        res, _ = run(tab, dt, dict(q, metrics=["count", "v"]), flags=64 | 128)
+        assert "scan_agg_shape_kernel<4, 256, 4, 1, 2>" in res.kernel, res.kernel
+        res, _ = run(tab, dt, {"dimensions": ["a"], "metrics": ["v", "count"], "filter": F("lt", "f", "50")}, flags=64 | 128)
+        assert res.path != "dense_part" or "scan_agg_shape_kernel" in res.kernel, (res.path, res.kernel)
         # four metrics (wide tuples), MIN / MAX states
         res, _ = run(tab, dt, dict(q, metrics=["v", "count", "lo", "hi"]), flags=64)
         assert "part_split_kernel" in res.kernel
@@ -235,6 +240,20 @@ def test_two_level_partitioning():
         run(tab, dt, dict(q, filter=F("lt", "a", "5")), flags=64)
         run(tab, dt, dict(q, filter={"op": "and", "filters": [F("eq", "a", "2999"), F("eq", "b", "699")]}), flags=64)
         run(tab, dt, dict(q, filter=F("gt", "f", "1000")), flags=64)      # nothing survives
+    finally:
+        dt.close()
+    # one group column through the specialised drain (the host gives it a second digit that counts for nothing)
+    tab = vo.Table({"name": "t", "segment_size": n, "dimensions": [{"name": "k", "type": "uint"}, {"name": "f", "type": "uint"}],
+                    "metrics": [{"name": "v", "type": "long_sum"}, {"name": "count", "type": "count"}]})
+    for _ in range(2):
+        tab.add_segment_arrays([rng.integers(0, 200000, n).astype(np.uint32), rng.integers(0, 100, n).astype(np.uint32)],
+                               [rng.integers(-10**12, 10**12, n).astype(np.int64), rng.integers(1, 4, n).astype(np.uint32)], None, n)
+    dt = mirror_table(tab)
+    try:
+        for mets in (["v", "count"], ["count", "v"]):
+            res, _ = run(tab, dt, {"dimensions": ["k"], "metrics": mets, "filter": F("lt", "f", "40")}, flags=64 | 128)
+            assert res.path == "dense_part" and "scan_agg_shape_kernel" in res.kernel, (res.path, res.kernel)
+            run(tab, dt, {"dimensions": ["k"], "metrics": mets, "filter": F("lt", "f", "40")}, flags=64 | 128 | capi.PLAN_NO_SHAPE)
     finally:
         dt.close()
     # 1.5 M groups, three out of four empty (a dense table is planned up to 4 groups per row)

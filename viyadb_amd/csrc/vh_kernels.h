@@ -1116,7 +1116,8 @@ __device__ __forceinline__ uint32_t vh_eval_filter_fast(const VhPlanDev& P, cons
   return m;
 }
 
-// SHAPE 1 (DENSE_PART only; the host checks the plan, query_launch_locked): GROUP BY two unsigned columns of up to 32 bits
+// SHAPE 1 / 2 (DENSE_PART only; the host checks the plan, query_launch_locked): GROUP BY one or two unsigned columns of up to 32 bits
+// (one: the host points the second digit at the first column with stride 0)
 // (dictionary codes, booleans, uint dimensions) without time arithmetic, SUM of a 64-bit column (metric 0) + SUM of a 32-bit one (metric 1) — "GROUP BY two dimensions, SUM + COUNT", the
 // reference's bread and butter. The generic drain walks the plan's column descriptors per survivor (element types, rollup rules,
 // 64-bit digit arithmetic, tuple word / shift of every metric): ~300 VALU instructions per drain on a SIMD that is busy issuing
@@ -1125,12 +1126,13 @@ template <int MODE, int SCOPE, int SHAPE = 0>
 __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, char* lds,
                                                 uint64_t xoff, unsigned long long& nfresh, VhPartWave& W, VhPartTile& T, VhLdsHashWave& H) {
   if (!active) row = 0;
-  if (SHAPE == 1 && MODE == VH_MODE_DENSE_PART) {
+  if (SHAPE != 0 && MODE == VH_MODE_DENSE_PART) {
+    constexpr int J64 = SHAPE == 2 ? 1 : 0, J32 = 1 - J64;     // SHAPE 2: the same with the metrics in the other order
     uint32_t s0, s1, s2, s3;
     const uint64_t r0 = vh_gather_raw(P, P.g[0].slot(), seg, row, s0);
     const uint64_t r1 = vh_gather_raw(P, P.g[1].slot(), seg, row, s1);
-    const uint64_t r2 = vh_gather_raw(P, P.m[0].slot(), seg, row, s2);
-    const uint64_t r3 = vh_gather_raw(P, P.m[1].slot(), seg, row, s3);
+    const uint64_t r2 = vh_gather_raw(P, P.m[J64].slot(), seg, row, s2);
+    const uint64_t r3 = vh_gather_raw(P, P.m[J32].slot(), seg, row, s3);
     // unsigned group columns of 1, 2 or 4 bytes (dictionary codes, booleans, uint dimensions): the host left the element's width
     // as a right shift in key_shift (unused on the dense paths): 0, 16 or 24
     const uint32_t d0 = (((uint32_t)(r0 >> s0) << P.g[0].key_shift()) >> P.g[0].key_shift()) - (uint32_t)P.g[0].lo;

@@ -3,15 +3,16 @@
 #include "vh_launch.h"
 
 void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ) {
-  if (P.shape == 1) {
-    switch (P.npred) {
-      case 0: case 1: VH_LAUNCH_OR_OCC((scan_agg_shape_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 1, 1>), 256, grid, lds, s, P, occ); break;
-      case 2: VH_LAUNCH_OR_OCC((scan_agg_shape_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 2, 1>), 256, grid, lds, s, P, occ); break;
-      case 3: VH_LAUNCH_OR_OCC((scan_agg_shape_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 3, 1>), 256, grid, lds, s, P, occ); break;
-      default: VH_LAUNCH_OR_OCC((scan_agg_shape_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 4, 1>), 256, grid, lds, s, P, occ); break;
-    }
-    return;
+#define VH_SHAPE_CASES(SH)                                                                                                                         \
+  switch (P.npred) {                                                                                                                             \
+    case 0: case 1: VH_LAUNCH_OR_OCC((scan_agg_shape_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 1, SH>), 256, grid, lds, s, P, occ); break; \
+    case 2: VH_LAUNCH_OR_OCC((scan_agg_shape_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 2, SH>), 256, grid, lds, s, P, occ); break;         \
+    case 3: VH_LAUNCH_OR_OCC((scan_agg_shape_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 3, SH>), 256, grid, lds, s, P, occ); break;         \
+    default: VH_LAUNCH_OR_OCC((scan_agg_shape_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 4, SH>), 256, grid, lds, s, P, occ); break;        \
   }
+  if (P.shape == 1) { VH_SHAPE_CASES(1) return; }
+  if (P.shape == 2) { VH_SHAPE_CASES(2) return; }
+#undef VH_SHAPE_CASES
   switch (P.npred) {
     case 0: case 1: VH_LAUNCH_OR_OCC((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 1>), 256, grid, lds, s, P, occ); break;
     case 2: VH_LAUNCH_OR_OCC((scan_agg_fast_kernel<VH_MODE_DENSE_PART, 256, __HIP_MEMORY_SCOPE_AGENT, 2>), 256, grid, lds, s, P, occ); break;

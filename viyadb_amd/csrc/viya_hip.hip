@@ -1483,14 +1483,22 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       P.tw = tw;
       // the drain specialised for "two unsigned 32-bit group columns, SUM(64-bit) + SUM(32-bit)" (vh_consume_fast, SHAPE 1)
       P.shape = 0;
-      if (!lanes && !(p->flags & VH_PLAN_NO_SHAPE) && P.ngroup == 2 && P.nmetric == 2 && tw == 2 && G <= 0xFFFFFFFFull) {
+      if (!lanes && !(p->flags & VH_PLAN_NO_SHAPE) && (P.ngroup == 1 || P.ngroup == 2) && P.nmetric == 2 && tw == 2 && G <= 0xFFFFFFFFull) {
         bool ok = true;
         for (int i = 0; i < P.ngroup; ++i)
           ok &= (P.g[i].type() == VH_U32 || P.g[i].type() == VH_U16 || P.g[i].type() == VH_U8) && P.g[i].gran() == VH_T_NONE && P.g[i].nroll() == 0 && P.g[i].lo <= 0xFFFFFFFFull &&
                 P.g[i].extent <= 0xFFFFFFFFull && P.g[i].stride <= 0xFFFFFFFFull;
-        ok &= P.m[0].sop() == SOP_ADD64 && P.m[0].slot() != VH_SLOT_ROWID && vh_elem_size(P.m[0].type()) == 8 && P.m[0].tword() == 1;
-        ok &= P.m[1].sop() == SOP_ADD32 && P.m[1].slot() != VH_SLOT_ROWID && vh_elem_size(P.m[1].type()) == 4 && P.m[1].tword() == 0 && P.m[1].tshift() == 32;
-        if (ok) { P.shape = 1; for (int i = 0; i < 2; ++i) P.g[i].set_key_shift(32u - 8u * (uint32_t)vh_elem_size(P.g[i].type())); }
+        auto is64 = [&](int j) { return P.m[j].sop() == SOP_ADD64 && P.m[j].slot() != VH_SLOT_ROWID && vh_elem_size(P.m[j].type()) == 8 && P.m[j].tword() == 1; };
+        auto is32 = [&](int j) { return P.m[j].sop() == SOP_ADD32 && P.m[j].slot() != VH_SLOT_ROWID && vh_elem_size(P.m[j].type()) == 4 && P.m[j].tword() == 0 && P.m[j].tshift() == 32; };
+        const int shape = is64(0) && is32(1) ? 1 : is32(0) && is64(1) ? 2 : 0;
+        if (ok && shape) {
+          P.shape = shape;
+          for (int i = 0; i < P.ngroup; ++i) P.g[i].set_key_shift(32u - 8u * (uint32_t)vh_elem_size(P.g[i].type()));
+          if (P.ngroup == 1) {        // the drain always folds two digits: the second one re-reads the first column and counts for nothing
+            P.g[1] = P.g[0];
+            P.g[1].lo = 0; P.g[1].extent = 0xFFFFFFFFull; P.g[1].stride = 0; P.g[1].set_key_shift(31);    // (one bit of it: never out of range)
+          }
+        }
       }
       if (part_carrier >= 0) { P.m[part_carrier].set_sop(SOP_ADD32P); state_bytes_per_group += 4; }   // (its tuple slot stays 32 bits wide)
       // phase-2 LDS table for one partition
