@@ -166,8 +166,7 @@ def main():
     # the library's own RCCL communicator behind vh_query_agg_sharded. VH_BENCH_BACKEND=gloo swaps that transport for
     # callbacks over gloo so the N>1 flow can run on a box with fewer GPUs than ranks (tests).
     backend = os.environ.get("VH_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= max(1, torch.cuda.device_count())
+    local_rank %= max(1, torch.cuda.device_count())     # (more ranks than GPUs only happens in tests; RCCL then refuses and the gloo transport takes over)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -178,7 +177,23 @@ def main():
     executor.init(local_rank)
     comm = None
     if world > 1:
-        comm = distributed.Comm.rccl(dist) if backend == "nccl" else distributed.Comm.gloo(dist)
+        if backend == "nccl":
+            # RCCL inside the library; if the communicator cannot be created on some rank (no RCCL, no peer access), every rank falls
+            # back to the callback transport over gloo — a slower data plane, named as such in the output line, rather than no number
+            err = None
+            try:
+                comm = distributed.Comm.rccl(dist)
+            except Exception as e:   # noqa: BLE001
+                err = "%s: %s" % (type(e).__name__, e)
+            errs = [None] * world
+            dist.all_gather_object(errs, err)
+            if any(errs):
+                if comm is not None:
+                    comm.close()
+                comm = distributed.Comm.gloo(dist)
+                backend = "gloo (RCCL communicator failed: %s)" % next(e for e in errs if e)
+        else:
+            comm = distributed.Comm.gloo(dist)
 
     w = synth.WORKLOADS[args.workload](segment_rows=args.segment_rows)
     total_segments = args.segments or {"C1": 10, "C2": 100, "C3": 1000, "C5t": 100, "C5": 100}[args.workload]
@@ -267,7 +282,7 @@ def main():
                        "columns": len(w.columns), "table_bytes": total_rows * w.table_bytes_per_row,
                        "groups": last.ngroups, "passed_rows_rank0": last.passed_recs,
                        "table_path": last.path, "parallelism": ("segments sharded x%d, vh_query_agg_sharded: plan agreement + ncclReduce of the partial tables to rank 0 (%s transport)"
-                                                                % (world, "RCCL" if backend == "nccl" else "gloo callback")) if world > 1 else "1 GPU",
+                                                                % (world, "RCCL" if backend == "nccl" else "callbacks over " + backend)) if world > 1 else "1 GPU",
                        "generate_seconds": round(t_gen, 3), "payload_projection": bool(last.packed),
                        "pack_seconds": round(t_pack, 3), "device_bytes": table.info()[2]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

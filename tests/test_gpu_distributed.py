@@ -217,6 +217,23 @@ def test_bench_multi_rank_flow_on_one_gpu(tmp_path):
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
 
 
+def test_bench_falls_back_when_rccl_refuses(tmp_path):
+    """Two ranks on this box's ONE GPU with the default (RCCL) data plane: ncclCommInitRank refuses a duplicate device, every rank
+    learns about it and the run continues over the callback transport — and says so in its output line."""
+    import json
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k != "VH_BENCH_BACKEND"}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--segments", "20"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and "RCCL communicator failed" in d["config"]["parallelism"], d["config"]["parallelism"]
+
+
 HOST_WORKER = textwrap.dedent('''
     import os, sys, json
     sys.path.insert(0, {root!r})

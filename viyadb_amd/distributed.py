@@ -177,10 +177,16 @@ class Comm:
         lib = capi.load()
         rank, world = dist.get_rank(), dist.get_world_size()
         ident = (C.c_char * capi.COMM_ID_BYTES)()
+        box = [None]
         if rank == 0:
-            capi.check(lib.vh_comm_unique_id(ident))
-        box = [bytes(ident)]
+            try:
+                capi.check(lib.vh_comm_unique_id(ident))
+                box = [bytes(ident)]
+            except capi.VhError as e:          # (no RCCL here): tell the others instead of leaving them in the broadcast
+                box = [e]
         dist.broadcast_object_list(box, src=0)
+        if isinstance(box[0], Exception):
+            raise box[0]
         ident = (C.c_char * capi.COMM_ID_BYTES).from_buffer_copy(box[0])
         h = C.c_void_p()
         capi.check(lib.vh_comm_init(ident, rank, world, C.byref(h)))
