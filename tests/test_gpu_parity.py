@@ -53,6 +53,7 @@ def test_workload_ragged(name, flags):
                                         (1, "hash"), (68, "dense_part"), (2, "dense_global"), (8, "dense_global"), (9, "hash"), (12, "dense_global"),
                                         (40, "dense_global"), (64 | 256, "dense_part"), (64 | 128, "dense_part"), (64 | 32768, "dense_part"),
                                         (64 | 4 | 32, "dense_part"), (64 | 8192, "dense_part"), (64 | 8192 | 32768, "dense_part"),
+                                        (16 | 32768, "dense_global"), (16 | 4, "dense_global"), (16 | 4 | 32768, "dense_global"), (16 | 8192, "dense_global"),
                                         (1 | 2048, "hash"), (9 | 2048, "hash"), (1 | 2048 | 512, "hash")])
 def test_c3_table_organisations(flags, path):
     """Same query through: radix-partitioned LDS aggregation, per-XCD private dense tables with global
