@@ -213,7 +213,7 @@ def test_two_level_partitioning():
         for flags, lanes in ((64 | 128, False), (64, False), (64 | 256, True)):
             qq = dict(q, filter=F("ge", "f", "0") if lanes else F("lt", "f", "30"))
             res, _ = run(tab, dt, qq, flags=flags)
-            assert res.path == "dense_part" and "part_split_kernel" in res.kernel and res.lanes == lanes and res.retries == 0, (res.path, res.kernel, res.lanes)
+            assert res.path == "dense_part" and "part_split_" in res.kernel and res.lanes == lanes and res.retries == 0, (res.path, res.kernel, res.lanes)
             if not lanes:       # two unsigned group columns, SUM(long) + SUM(uint): the specialised drain, and the generic one on request
                 assert "scan_agg_shape_kernel" in res.kernel, res.kernel
                 res, _ = run(tab, dt, qq, flags=flags | capi.PLAN_NO_SHAPE)
@@ -227,7 +227,14 @@ def test_two_level_partitioning():
         assert res.path != "dense_part" or "scan_agg_shape_kernel" in res.kernel, (res.path, res.kernel)
         # four metrics (wide tuples), MIN / MAX states
         res, _ = run(tab, dt, dict(q, metrics=["v", "count", "lo", "hi"]), flags=64)
-        assert "part_split_kernel" in res.kernel
+        assert "part_split_" in res.kernel
+        # two-word tuples take the block-tile split; the tuple-by-tuple form (what wider tuples run) on request
+        os.environ["VH_NO_SPLIT_TILE"] = "1"
+        try:
+            res, _ = run(tab, dt, q, flags=64 | 128)
+            assert "part_split_kernel<256>" in res.kernel, res.kernel
+        finally:
+            del os.environ["VH_NO_SPLIT_TILE"]
         # either pool too small at first: the query re-plans with more room
         for var in ("VH_TEST_PART_EXTENTS", "VH_TEST_PART_EXTENTS2"):
             os.environ[var] = "50"
@@ -263,7 +270,7 @@ def test_two_level_partitioning():
     dt = mirror_table(tab)
     try:
         res, _ = run(tab, dt, {"dimensions": ["a", "b"], "metrics": ["count"]}, flags=64)
-        assert res.path == "dense_part" and "part_split_kernel" in res.kernel, (res.path, res.kernel)
+        assert res.path == "dense_part" and "part_split_" in res.kernel, (res.path, res.kernel)
     finally:
         dt.close()
 
@@ -285,7 +292,7 @@ def test_two_level_on_typed_shapes(typed):
                         res, _ = run(tab, dt, {"dimensions": dims, "metrics": mets, "filter": flt}, flags=flags)
                     except vo.Unsupported:
                         continue
-                    two += "part_split_kernel" in res.kernel
+                    two += "part_split_" in res.kernel
         assert two >= 8, two
     finally:
         del os.environ["VH_PART_TABLE_KB"]

@@ -1884,3 +1884,96 @@ __global__ __launch_bounds__(BLOCK) void part_split_kernel(const VhPlanDev P, in
   vh_part_tile_finish<2>(P, T, lane);
 }
 
+// The same split for two-word tuples (the common shape), one TILE of 2048 tuples per block at a time: the block counts the
+// tile's tuples per sub-partition in LDS, wave 0 — lane s owns sub-partition s's extent and fill, as the waves of phase 1 do —
+// turns the counts into run offsets and destinations (pool-2 extents hold 2048 tuples here, so a run always fits a fresh
+// one), the tuples are scattered into an LDS copy ordered by sub-partition, and the block streams that copy out: every
+// store instruction writes 64 consecutive tuples of (mostly) one run, whole lines instead of the 16-byte pieces of the
+// tuple-by-tuple form above. 64 extents open per BLOCK instead of per wave.
+#define VH_SPLIT_TILE_TUPLES 2048
+struct VhSplitTile {             // LDS, behind the sorted copy
+  uint32_t hist[64], rbase[64], cursor[64], ntile, pad;
+  uint64_t dst[64];
+};
+__host__ __device__ __forceinline__ size_t vh_split_tile_bytes() { return (size_t)VH_SPLIT_TILE_TUPLES * 16 + sizeof(VhSplitTile); }
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev P, int blocks_per_part) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+  u64x2* sorted = reinterpret_cast<u64x2*>(lds);
+  VhSplitTile& S = *reinterpret_cast<VhSplitTile*>(lds + (size_t)VH_SPLIT_TILE_TUPLES * 16);
+  const int part = blockIdx.x / blocks_per_part, b = blockIdx.x % blocks_per_part;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int R = VH_SPLIT_TILE_TUPLES / BLOCK;
+  VhPartWave W;
+  VhPartTile T;
+  vh_part_tile_init(P, nullptr, T, W);            // only wave 0 uses them
+  W.base = P.l2[part]; W.limit = P.l2[part + 1]; W.cursor = P.l2 + VH_L2_NEXT + part;
+  const unsigned long long allocated = P.counters[5];
+  const uint32_t total = allocated < P.max_extents ? (uint32_t)allocated : P.max_extents;
+  const uint32_t ext_tuples = (uint32_t)P.ext_tuples, et2 = (uint32_t)P.ext_tuples2;
+  u64x2* const pool2 = reinterpret_cast<u64x2*>(P.tuples2);
+  const uint32_t gsz = vh_tag_group(total, (uint32_t)blocks_per_part);
+  for (uint32_t c0 = (uint32_t)b * gsz; c0 < total; c0 += (uint32_t)blocks_per_part * gsz) {
+    uint64_t mine = __ballot((uint32_t)lane < gsz && c0 + lane < total && P.extent_part[c0 + lane] == (uint8_t)part);   // the same in every wave
+    while (mine) {
+      const uint32_t ext = c0 + (uint32_t)__builtin_ctzll(mine);
+      mine &= mine - 1;
+      const uint32_t valid = ext_tuples - P.extent_missing[ext];
+      const u64x2* base = reinterpret_cast<const u64x2*>(P.tuples) + (uint64_t)ext * ext_tuples;
+      for (uint32_t i0 = 0; i0 < valid; i0 += VH_SPLIT_TILE_TUPLES) {
+        u64x2 t[R];
+        uint32_t sub[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t i = i0 + r * BLOCK + tid;
+          if (i < valid) { t[r] = __builtin_nontemporal_load(base + i); sub[r] = ((uint32_t)t[r].x >> P.agg_shift) & 63u; }
+          else sub[r] = 0xFFFFFFFFu;
+        }
+        if (tid < 64) S.hist[tid] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (sub[r] != 0xFFFFFFFFu) atomicAdd(&S.hist[sub[r]], 1u);
+        __syncthreads();
+        if (wave == 0) {       // lane s: run offset, room in sub-partition s's extent, destination
+          const uint32_t cnt = S.hist[lane];
+          uint32_t incl = cnt;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+          uint64_t need = __ballot(cnt != 0 && (T.r_ext == ~0u || T.r_fill + cnt > et2));
+          while (need) {
+            const int q = __builtin_ctzll(need);
+            need &= need - 1;
+            const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, q), oldfill = __builtin_amdgcn_readlane(T.r_fill, q);
+            if (old != ~0u && lane == 0) P.extent_missing2[old] = (uint16_t)(et2 - oldfill);
+            const uint32_t e2 = vh_part_new_extent<2>(P, W, q, lane);
+            if (lane == q) { T.r_ext = e2; T.r_fill = 0; }
+          }
+          S.rbase[lane] = incl - cnt;
+          S.cursor[lane] = incl - cnt;
+          S.dst[lane] = T.r_ext == ~0u ? ~0ull : (uint64_t)T.r_ext * et2 + T.r_fill;     // ~0: pool exhausted, the host re-runs
+          if (T.r_ext != ~0u) T.r_fill += cnt;
+          if (lane == 63) S.ntile = incl;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (sub[r] != 0xFFFFFFFFu) sorted[atomicAdd(&S.cursor[sub[r]], 1u)] = t[r];
+        __syncthreads();
+        const uint32_t n = S.ntile;
+        for (uint32_t k = tid; k < n; k += BLOCK) {
+          const u64x2 v = sorted[k];
+          const uint32_t sb = ((uint32_t)v.x >> P.agg_shift) & 63u;
+          const uint64_t d = S.dst[sb];
+          if (d != ~0ull) pool2[d + (k - S.rbase[sb])] = v;
+        }
+        // (the next tile's first barrier comes after every thread is through with this loop)
+      }
+    }
+  }
+  if (wave == 0) vh_part_tile_finish<2>(P, T, lane);
+}
+
+

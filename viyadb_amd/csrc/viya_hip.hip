@@ -1709,7 +1709,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     else snprintf(nm, sizeof(nm), "%s<%d, %d, %d, %d>", lanes ? "scan_agg_lanes_kernel" : "scan_agg_fast_kernel", mode, BLOCK,
                   (mode == VH_MODE_HASH || mode == VH_MODE_DENSE_PART) ? (int)__HIP_MEMORY_SCOPE_AGENT : scope, np_);
     r->kernel = nm;
-    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel == 2 ? " + part_split_kernel<256> + part_agg_kernel<1024>" : " + part_agg_kernel<1024>";
+    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? " + part_agg_kernel<1024>" : (P.tw == 2 && !getenv("VH_NO_SPLIT_TILE")) ? " + part_split_tile_kernel<256> + part_agg_kernel<1024>" : " + part_split_kernel<256> + part_agg_kernel<1024>";
   }
   int occupancy = 0;
   if (env_bpc <= 0) scan_dispatch(0, &occupancy);
@@ -1807,9 +1807,12 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     if (P.nlevel == 2) {
       // pool 2: small extents (4096 ranges x every splitting wave keep one open), sized like pool 1 plus what stays open
       split_bpp = std::max(1, 2 * g_ctx.num_cu / std::max(1, P.npart));     // 256-thread blocks, ~2 per CU whatever the partition count: more waves keep more extents open (4 per CU measured slower)
-      const uint64_t et2 = 256;
+      // two-word tuples are split a block-wide tile at a time (part_split_tile_kernel): extents of one tile's size, one writer per block
+      const bool tiled = P.tw == 2 && !getenv("VH_NO_SPLIT_TILE");
+      if (tiled) split_bpp = std::max(1, (getenv("VH_SPLIT_BPC") ? atoi(getenv("VH_SPLIT_BPC")) : 4) * g_ctx.num_cu / std::max(1, P.npart));   // a block is one writer: more of them cost less
+      const uint64_t et2 = tiled ? VH_SPLIT_TILE_TUPLES : 256;
       P.ext_tuples2 = (int32_t)et2;
-      uint64_t max2 = (part_tuple_cap + part_tuple_cap / 4) / et2 + (uint64_t)P.npart * ((uint64_t)split_bpp * 4 * (64 + VH_EXT_CHUNK) + 1) + 64;
+      uint64_t max2 = (part_tuple_cap + part_tuple_cap / 4) / et2 + (uint64_t)P.npart * ((uint64_t)split_bpp * (tiled ? 1 : 4) * (64 + VH_EXT_CHUNK) + 1) + 64;
       if (max2 > 0xFFFFFFF0ull) max2 = 0xFFFFFFF0ull;
       if (!part_tuples_override && getenv("VH_TEST_PART_EXTENTS2")) max2 = std::max(1, atoi(getenv("VH_TEST_PART_EXTENTS2")));   // tests: the second pool runs out first
       P.max_extents2 = (uint32_t)max2;
