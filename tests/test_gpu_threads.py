@@ -137,3 +137,31 @@ def test_queries_of_one_table_overlap():
         assert best_par < 0.9 * best_serial, (best_serial, best_par)
     finally:
         t.close()
+
+
+def test_repeated_partitioned_query_visits_contexts():
+    """A partitioned plan with a big tuple pool is timed on three execution contexts before the pool settles on the one whose
+    scratch landed best (placement preference): every run must return the same groups whichever context served it, also while a
+    held result pins one of the contexts."""
+    from viyadb_amd import capi, executor, synth
+    from viyadb_amd.executor import AggPlan
+    executor.init(0)
+    w = synth.c3()
+    t = synth.create_device_table(w, 100)                    # 100 M rows, ~5 M survivors: a ~100 MB tuple pool
+    try:
+        plan = AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=capi.PLAN_FORCE_PART, groups_hint=100000)
+        first = t.query_agg(plan)
+        assert first.path == "dense_part"
+        o = np.lexsort([first.keys[1], first.keys[0]])
+        want = [first.keys[0][o], first.keys[1][o], first.states[0][o], first.states[1][o]]
+        held = None
+        for i in range(8):
+            r = t.query_agg(plan)
+            o = np.lexsort([r.keys[1], r.keys[0]])
+            for a, b in zip(want, [r.keys[0][o], r.keys[1][o], r.states[0][o], r.states[1][o]]):
+                assert np.array_equal(a, b), i
+            if i == 2:
+                held = t.query_agg_keep(plan)            # pins whichever context it got
+        t.discard(held)
+    finally:
+        t.close()

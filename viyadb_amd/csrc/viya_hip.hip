@@ -139,6 +139,10 @@ struct vh_table {
   // per-query resources live in execution contexts (grow-only pool)
   std::vector<std::unique_ptr<VhExec>> execs;
   std::mutex pool_mu; std::condition_variable pool_cv;
+  // Placement preference (pool_mu): how fast a partitioned plan ran on execution context i. Where a context's tuple pool landed
+  // physically decides 10 % of that kernel's time (profiles/r02/NOTES.md, "Placement") and nothing predicts it, so the first
+  // runs of such a plan visit a few contexts and the later ones prefer the best.
+  std::unordered_map<uint64_t, std::vector<float>> placement;
   char* d_stats = nullptr; size_t d_stats_bytes = 0;      // vh_segment_sync*: min/max pass (its own buffer: a sync never touches a query's scratch)
   std::map<std::string, uint64_t> groups_seen;           // group-column signature -> groups of the last query (hash sizing)
   std::map<std::string, std::pair<uint64_t, uint64_t>> sel_cache;   // filter signature + table state -> (passed, sampled) of the selectivity probe
@@ -230,10 +234,40 @@ static void exec_free(VhExec* x) {
   if (x->own_stream) (void)hipStreamDestroy(x->own_stream);
 }
 // A free context of the table's pool, a new one while the pool may grow, else wait for one to come back.
-static int exec_acquire(vh_table* t, VhExec** out) {
+static uint64_t placement_sig(const vh_plan* p) {       // what the plan looks like, not its literals or snapshot
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+  for (int i = 0; i < p->nfilter; ++i) { mix((uint64_t)p->filter[i].kind); mix((uint64_t)p->filter[i].col); mix((uint64_t)p->filter[i].op); mix((uint64_t)p->filter[i].count); }
+  for (int i = 0; i < p->ngroups; ++i) { mix((uint64_t)p->groups[i].col); mix((uint64_t)p->groups[i].granularity); }
+  for (int i = 0; i < p->nmetrics; ++i) mix((uint64_t)(int64_t)p->metrics[i]);
+  mix(p->flags); mix((uint64_t)p->nhaving); mix(p->top_k);
+  return h ? h : 1;
+}
+static const int g_placement_trials = getenv("VH_PLACEMENT_TRIALS") ? atoi(getenv("VH_PLACEMENT_TRIALS")) : 3;
+
+static int exec_acquire(vh_table* t, VhExec** out, uint64_t sig = 0) {
   static const size_t max_exec = getenv("VH_MAX_EXEC") ? (size_t)std::max(1, atoi(getenv("VH_MAX_EXEC"))) : 16;
   std::unique_lock<std::mutex> lk(t->pool_mu);
+  bool grow_for_trial = false;
+  if (sig && g_placement_trials > 1) {
+    auto it = t->placement.find(sig);
+    if (it != t->placement.end()) {             // a partitioned plan that ran here before
+      const std::vector<float>& ms = it->second;
+      const size_t trials = std::min<size_t>((size_t)g_placement_trials, max_exec);
+      size_t i = 0;
+      while (i < trials && i < ms.size() && ms[i] > 0) ++i;              // the first context it has not been timed on
+      if (i < trials) {
+        if (i < t->execs.size()) { if (!t->execs[i]->busy) { t->execs[i]->busy = true; *out = t->execs[i].get(); return VH_OK; } }
+        else if (i == t->execs.size()) grow_for_trial = true;
+      } else {
+        size_t best = 0;
+        for (size_t k = 1; k < trials; ++k) if (ms[k] < ms[best]) best = k;
+        if (best < t->execs.size() && !t->execs[best]->busy) { t->execs[best]->busy = true; *out = t->execs[best].get(); return VH_OK; }
+      }
+    }
+  }
   for (;;) {
+    if (grow_for_trial && t->execs.size() < max_exec) break;
     for (auto& x : t->execs) if (!x->busy) { x->busy = true; *out = x.get(); return VH_OK; }
     if (t->execs.size() < max_exec) break;
     if (t->pool_cv.wait_for(lk, std::chrono::seconds(60)) == std::cv_status::timeout)
@@ -2423,7 +2457,8 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
   VH_ENTER();
   if (plan->nmetrics > VH_MAX_METRIC - 1 && plan->metrics) return query_agg_multipass(t, plan, out);
   VhExec* x = nullptr;
-  if (int rc = exec_acquire(t, &x)) return rc;
+  const uint64_t psig = placement_sig(plan);
+  if (int rc = exec_acquire(t, &x, psig)) return rc;
   VhReplan rp;
   int rc = VH_OK;
   for (uint32_t attempt = 0; attempt < 12; ++attempt) {
@@ -2439,6 +2474,15 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
     if (!retry) {
       r->info.retries = attempt;
       if (r->mode == VH_MODE_HASH) { std::lock_guard<std::mutex> lk(t->mu); t->groups_seen[r->group_sig] = r->info.ngroups; }
+      if (r->mode == VH_MODE_DENSE_PART && attempt == 0 && g_placement_trials > 1 &&
+          (uint64_t)r->plan.max_extents * r->plan.ext_tuples * r->plan.tw * 8 >= (64ull << 20)) {     // a tuple pool big enough for its placement to matter
+        std::lock_guard<std::mutex> lk(t->pool_mu);
+        size_t idx = 0;
+        while (idx < t->execs.size() && t->execs[idx].get() != x) ++idx;
+        std::vector<float>& ms = t->placement[psig];
+        if (ms.size() <= idx) ms.resize(idx + 1, 0.f);
+        ms[idx] = (float)r->info.scan_kernel_ms / (float)std::max<uint64_t>(r->info.scanned_recs, 1) * 1e6f;     // per million rows: snapshots grow
+      }
       *out = r;
       return VH_OK;
     }
