@@ -245,6 +245,9 @@ static uint64_t placement_sig(const vh_plan* p) {       // what the plan looks l
 }
 static const int g_placement_trials = getenv("VH_PLACEMENT_TRIALS") ? atoi(getenv("VH_PLACEMENT_TRIALS")) : 3;
 
+// ... and what a finished first attempt of a partitioned plan with a tuple pool big enough for its placement to matter tells the pool
+static void placement_record(vh_table* t, VhExec* x, uint64_t sig, const vh_result* r, float kernel_ms);
+
 static int exec_acquire(vh_table* t, VhExec** out, uint64_t sig = 0) {
   static const size_t max_exec = getenv("VH_MAX_EXEC") ? (size_t)std::max(1, atoi(getenv("VH_MAX_EXEC"))) : 16;
   std::unique_lock<std::mutex> lk(t->pool_mu);
@@ -2321,6 +2324,17 @@ static int result_finalize(vh_result* r, int* retry) {
   return VH_OK;
 }
 
+static void placement_record(vh_table* t, VhExec* x, uint64_t sig, const vh_result* r, float kernel_ms) {
+  if (!sig || g_placement_trials <= 1 || r->mode != VH_MODE_DENSE_PART || kernel_ms <= 0 ||
+      (uint64_t)r->plan.max_extents * r->plan.ext_tuples * r->plan.tw * 8 < (64ull << 20)) return;
+  std::lock_guard<std::mutex> lk(t->pool_mu);
+  size_t idx = 0;
+  while (idx < t->execs.size() && t->execs[idx].get() != x) ++idx;
+  std::vector<float>& ms = t->placement[sig];
+  if (ms.size() <= idx) ms.resize(idx + 1, 0.f);
+  ms[idx] = kernel_ms / (float)std::max<uint64_t>(r->info.scanned_recs, 1) * 1e6f;     // per million rows: snapshots grow
+}
+
 extern "C" int vh_query_launch(vh_table* t, const vh_plan* plan, vh_result** out) {
   if (!t || !plan || !out) return vh_fail(VH_E_INVALID, "null argument");
   VH_ENTER();
@@ -2474,15 +2488,7 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
     if (!retry) {
       r->info.retries = attempt;
       if (r->mode == VH_MODE_HASH) { std::lock_guard<std::mutex> lk(t->mu); t->groups_seen[r->group_sig] = r->info.ngroups; }
-      if (r->mode == VH_MODE_DENSE_PART && attempt == 0 && g_placement_trials > 1 &&
-          (uint64_t)r->plan.max_extents * r->plan.ext_tuples * r->plan.tw * 8 >= (64ull << 20)) {     // a tuple pool big enough for its placement to matter
-        std::lock_guard<std::mutex> lk(t->pool_mu);
-        size_t idx = 0;
-        while (idx < t->execs.size() && t->execs[idx].get() != x) ++idx;
-        std::vector<float>& ms = t->placement[psig];
-        if (ms.size() <= idx) ms.resize(idx + 1, 0.f);
-        ms[idx] = (float)r->info.scan_kernel_ms / (float)std::max<uint64_t>(r->info.scanned_recs, 1) * 1e6f;     // per million rows: snapshots grow
-      }
+      if (attempt == 0) placement_record(t, x, psig, r, (float)r->info.scan_kernel_ms);
       *out = r;
       return VH_OK;
     }
