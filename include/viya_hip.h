@@ -32,6 +32,9 @@
  * (VH_MAX_EXEC, default 16) — so queries of different threads on one table overlap on the device. vh_segment_sync*,
  * vh_segment_generate, vh_table_pack/unpack take the same lock and first wait for every launched query that may still
  * read the arenas they replace. With an externally owned stream (vh_set_stream) all contexts share that stream.
+ * A plan that runs radix-partitioned with a tuple pool of 64 MB or more is timed on up to VH_PLACEMENT_TRIALS (default 3)
+ * contexts during its first runs — where a context's scratch landed physically decides ~10 % of that kernel's time — and
+ * served by the fastest free one afterwards; this can keep that many scratch buffers alive per table (1 = off).
  *
  * Lifetime of a vh_result: it OWNS its execution context from vh_query_launch / vh_query_agg until vh_result_free. Its
  * device-side state (what vh_result_finalize, vh_result_device_buffers and vh_result_partition[_pairs] read) and its host
