@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
-def measured_traffic(workload: str, rows_on_rank: int, kernel: str, packed: bool):
+def measured_traffic(workload: str, rows_on_rank: int, kernel: str, packed: bool, narrow: bool):
     """HBM bytes per launch from the newest committed rocprofv3 PMC summary (profiles/rNN/) whose recorded kernel is the
     kernel that just ran, scaled by rows. PMC counters cannot be read inside a normal run (tools/profile_round.sh collects
     them with the same command line); a summary taken with another kernel is refused: traffic = null."""
@@ -37,7 +37,7 @@ def measured_traffic(workload: str, rows_on_rank: int, kernel: str, packed: bool
     first = kernel.split(" + ")[0]
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "%s_1gpu_pmc_hbm*.json" % workload.lower())), reverse=True):
         d = json.load(open(f))
-        if first and first in d.get("kernel", "") and bool(d.get("packed", False)) == bool(packed):
+        if first and first in d.get("kernel", "") and bool(d.get("packed", False)) == bool(packed) and bool(d.get("narrow", False)) == bool(narrow):
             scale = rows_on_rank / d["rows"]
             return d["B_meas_per_launch"] * scale, os.path.relpath(f, ROOT), d.get("head"), d.get("write_bytes_raw", 0) * scale
     return None, None, None, None
@@ -206,7 +206,7 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.time() - t_gen
     plan = executor.AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics,
-                            flags=args.flags | (capi.PLAN_NO_PACK if args.no_pack else 0), groups_hint=w.plan.groups_hint)
+                            flags=args.flags | ((capi.PLAN_NO_PACK | capi.PLAN_NO_NARROW) if args.no_pack else 0), groups_hint=w.plan.groups_hint)
 
     table.prepare(plan)   # the plan's C structs are built once, like a prepared statement
     # ... and so is the payload projection of its group + metric columns (vh_table_pack): part of the resident mirror,
@@ -214,6 +214,7 @@ def main():
     t_pack = time.time()
     if not args.no_pack:
         table.pack(table.gather_columns(plan))
+        table.narrow(table.filter_columns(plan))     # 8- / 16-bit copies of the predicate columns whose values fit (vh_table_narrow)
     torch.cuda.synchronize()
     t_pack = time.time() - t_pack
 
@@ -265,7 +266,7 @@ def main():
     fcols = sorted({f[1] for f in w.plan.filter if f[0] in ("rel", "in")})
     fbytes = sum(capi.ELEM_SIZE[w.columns[c].elem] for c in fcols)
     b_min = rows_rank0 * fbytes + last.passed_recs * max(0, w.bytes_per_row_referenced - fbytes)
-    traffic, traffic_src, traffic_head, traffic_write = measured_traffic(args.workload, my_segments * w.segment_rows, last.kernel, last.packed)
+    traffic, traffic_src, traffic_head, traffic_write = measured_traffic(args.workload, my_segments * w.segment_rows, last.kernel, last.packed, last.narrow)
     credited = min(algo_bytes, traffic) if traffic else algo_bytes  # never credit more than was moved
     achieved = credited / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0
 
@@ -283,7 +284,7 @@ def main():
                        "groups": last.ngroups, "passed_rows_rank0": last.passed_recs,
                        "table_path": last.path, "parallelism": ("segments sharded x%d, vh_query_agg_sharded: plan agreement + ncclReduce of the partial tables to rank 0 (%s transport)"
                                                                 % (world, "RCCL" if backend == "nccl" else "callbacks over " + backend)) if world > 1 else "1 GPU",
-                       "generate_seconds": round(t_gen, 3), "payload_projection": bool(last.packed),
+                       "generate_seconds": round(t_gen, 3), "payload_projection": bool(last.packed), "narrow_predicates": bool(last.narrow),
                        "pack_seconds": round(t_pack, 3), "device_bytes": table.info()[2]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -183,8 +183,10 @@ enum vh_plan_flags {
   VH_PLAN_NO_PART2 = 1u << 14,    /* ablation: no second partition level (group-id
                                      spaces of more than 64 LDS-sized ranges stay on
                                      direct global atomics)                    */
-  VH_PLAN_NO_SHAPE = 1u << 15     /* ablation: the generic survivor drain even when the
+  VH_PLAN_NO_SHAPE = 1u << 15,    /* ablation: the generic survivor drain even when the
                                      plan has a shape a specialised one exists for */
+  VH_PLAN_NO_NARROW = 1u << 16    /* ablation: predicate columns from their 4-byte arenas
+                                     even when a narrow copy (vh_table_narrow) exists */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */
@@ -233,7 +235,8 @@ typedef struct vh_result_info {
   uint64_t algorithmic_bytes;/* B_ref of SURVEY §8(d) for this query         */
   uint32_t retries;          /* hash-table regrows                           */
   uint32_t reserved;         /* bit 0: the register-resident fast scan kernel ran; bit 1: its no-compaction "lanes" variant;
-                                bit 2: LDS front table of the hash path; bit 3: payload gathered from a projection (vh_table_pack) */
+                                bit 2: LDS front table of the hash path; bit 3: payload gathered from a projection (vh_table_pack);
+                                bit 4: predicate columns streamed from narrow copies (vh_table_narrow) */
   uint64_t returned_groups;  /* rows vh_result_copy delivers (= ngroups without HAVING) */
 } vh_result_info;
 
@@ -323,6 +326,16 @@ VH_API int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nseg,
  * (src/query/runner.cc:45-64) — work done once for a query shape, outside its steady-state cost. */
 VH_API int vh_table_pack(vh_table* t, const int32_t* cols, int32_t ncols);
 VH_API int vh_table_unpack(vh_table* t);
+
+/* Narrow copies of predicate columns. A column every query filters on is read in full by every query: its bytes are the
+ * floor of the scan. For an unsigned 32-bit column whose values fit 8 or 16 bits (dictionary codes of small
+ * dictionaries, small uint dimensions: the reference itself sizes a string dimension's codes by its cardinality,
+ * src/db/column.h) the table keeps a second copy at that width and the register-resident scan kernels stream it
+ * instead; values are widened in registers, so every comparison is the one the 4-byte column would get. Copies follow
+ * vh_segment_sync* like projections do, are dropped when a synced value no longer fits, and are built unasked for a
+ * column the VH_AUTO_NARROW-th (default 3, 0 = never) selective query filters on while a quarter of the device stays
+ * free. Columns that do not qualify are skipped silently. vh_table_unpack drops them too. */
+VH_API int vh_table_narrow(vh_table* t, const int32_t* cols, int32_t ncols);
 /* Copy a mirrored column back to the host (tests). */
 VH_API int vh_segment_read(vh_table* t, uint32_t seg, int32_t col, uint64_t nrows,
                            void* dst);

@@ -1,0 +1,104 @@
+"""Narrow copies of predicate columns (vh_table_narrow): 8- / 16-bit copies of unsigned 32-bit columns whose values fit, streamed
+by the register-resident kernels instead of the arenas. Results must be those of the arenas — i.e. the oracle's — under every
+table organisation; the copies must follow vh_segment_sync*, be dropped when a value stops fitting, and be built unasked for a
+column selective queries keep filtering on."""
+import numpy as np
+import pytest
+
+from oracle import viya_oracle as vo
+from tests.parity import build_oracle_table, compare
+from tests.planner import mirror_table
+from tests.test_gpu_typed import F, run
+from viyadb_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    from viyadb_amd import executor
+    executor.init(0)
+
+
+@pytest.mark.parametrize("flags", [0, 64, 64 | 128, 1, 8, 16, 2, 256, 64 | 32768, 8192, 64 | 8192])
+@pytest.mark.parametrize("name", ["C3", "C2"])
+def test_workloads_through_narrow_copies(name, flags):
+    """C3's predicate columns have 4 / 1000 / 1000 distinct values (one 8-bit and two 16-bit copies); C2's has a million (no copy:
+    the request is skipped silently)."""
+    from viyadb_amd import synth
+    from viyadb_amd.executor import AggPlan
+    w = synth.WORKLOADS[name](segment_rows=200_000)
+    dt = synth.create_device_table(w, 3, 199_993)
+    try:
+        plan = AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=flags, groups_hint=w.plan.groups_hint)
+        dt.narrow(dt.filter_columns(plan))
+        res = dt.query_agg(plan)
+        st = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 3, 199_993), w.query))
+        compare(res, st, f"{name} narrow flags={flags}")
+        generic = bool(flags & 8)
+        assert res.narrow == (name == "C3" and not generic), (res.narrow, res.kernel)
+        res = dt.query_agg(AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=flags | capi.PLAN_NO_NARROW,
+                                   groups_hint=w.plan.groups_hint))
+        compare(res, st, f"{name} arenas flags={flags}")
+        assert not res.narrow
+    finally:
+        dt.close()
+
+
+def _table(rng, n, hi_a=200, hi_b=60000):
+    tab = vo.Table({"name": "t", "segment_size": n, "dimensions": [{"name": "a", "type": "uint"}, {"name": "b", "type": "uint"}, {"name": "g", "type": "uint"}],
+                    "metrics": [{"name": "v", "type": "long_sum"}, {"name": "count", "type": "count"}]})
+    for _ in range(3):
+        tab.add_segment_arrays([rng.integers(0, hi_a, n).astype(np.uint32), rng.integers(0, hi_b, n).astype(np.uint32), rng.integers(0, 300, n).astype(np.uint32)],
+                               [rng.integers(-1000, 1000, n).astype(np.int64), np.ones(n, dtype=np.uint32)], None, n)
+    return tab
+
+
+def test_copies_follow_syncs_and_are_dropped_when_values_outgrow_them():
+    rng = np.random.default_rng(3)
+    n = 50_000
+    tab = _table(rng, n)
+    dt = mirror_table(tab, reserve=5)
+    q = {"dimensions": ["g"], "metrics": ["v", "count"], "filter": {"op": "and", "filters": [F("lt", "a", "150"), F("ge", "b", "1000"), F("ne", "a", "7")]}}
+    try:
+        dt.narrow([0, 1])
+        res, _ = run(tab, dt, q)
+        assert res.narrow
+        # IN lists, OR, NOT: every leaf kind over the widened values
+        run(tab, dt, dict(q, filter={"op": "or", "filters": [{"op": "in", "column": "a", "values": ["3", "199", "250", "70000"]},
+                                                            {"op": "not", "filter": F("le", "b", "59990")}]}))
+        # literals beyond the copies' range compare like they do against the 4-byte column
+        for flt in (F("lt", "a", "100000"), F("gt", "b", "4000000000"), F("eq", "a", "256"), F("ne", "b", "65536")):
+            run(tab, dt, dict(q, filter=flt))
+        # a segment is re-synced with different (still fitting) values: the copy follows
+        seg = tab.segments[1]
+        seg["d"][0][:] = rng.integers(0, 256, n).astype(np.uint32)
+        seg["d"][1][:] = rng.integers(0, 65536, n).astype(np.uint32)
+        dt.sync_segment(1, [seg["d"][0], seg["d"][1], seg["d"][2], seg["m"][0], seg["m"][1]], n)
+        res, _ = run(tab, dt, q)
+        assert res.narrow
+        # a new segment whose values need more bits: `a` moves to 16 bits or is dropped, `b` is dropped; answers stay right
+        tab.add_segment_arrays([rng.integers(0, 5000, n).astype(np.uint32), rng.integers(0, 3_000_000, n).astype(np.uint32), rng.integers(0, 300, n).astype(np.uint32)],
+                               [rng.integers(-1000, 1000, n).astype(np.int64), np.ones(n, dtype=np.uint32)], None, n)
+        seg = tab.segments[3]
+        dt.sync_segment(3, [seg["d"][0], seg["d"][1], seg["d"][2], seg["m"][0], seg["m"][1]], n)
+        for _ in range(4):
+            run(tab, dt, q)
+        run(tab, dt, q, flags=64 | 128)
+    finally:
+        dt.close()
+
+
+def test_copies_are_built_unasked_for_columns_queries_keep_filtering_on():
+    rng = np.random.default_rng(4)
+    n = 50_000
+    tab = _table(rng, n)
+    dt = mirror_table(tab)
+    q = {"dimensions": ["g"], "metrics": ["v", "count"], "filter": F("lt", "a", "30")}
+    try:
+        seen = [run(tab, dt, q)[0].narrow for _ in range(5)]
+        assert seen[0] is False and seen[-1] is True, seen
+        dt.unpack()                                     # drops projections and narrow copies
+        assert run(tab, dt, q)[0].narrow is False
+    finally:
+        dt.close()

@@ -15,6 +15,7 @@ one() {   # name (workload[_variant]), rows, bref, bench args...
   tail -c 300 $OUT/bench_${W}_1gpu.json; echo
   local K=$(python -c "import json; print(json.load(open('$OUT/bench_${W}_1gpu.json'))['roofline']['kernel'])")
   local PK=$(python -c "import json; print(int(json.load(open('$OUT/bench_${W}_1gpu.json'))['config']['payload_projection']))")
+  local NR=$(python -c "import json; print(int(json.load(open('$OUT/bench_${W}_1gpu.json'))['config'].get('narrow_predicates', False)))")
   (cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/$OUT/kt_$W -o $W -- python $REPO/bench.py "$@" --steps 10 --warmup 2 --no-cpu --no-check > $REPO/$OUT/kt_$W.log 2>&1)
   python tools/pmc_summary.py --kernel-stats $(find $OUT/kt_$W -name "*_results.db" | head -1) $OUT/${W}_1gpu_kernel_stats.csv; head -4 $OUT/${W}_1gpu_kernel_stats.csv | cut -c1-160
   for C in FETCH_SIZE WRITE_SIZE; do
@@ -22,7 +23,7 @@ one() {   # name (workload[_variant]), rows, bref, bench args...
   done
   local J=$OUT/${W}_1gpu_pmc_hbm.json
   case $W in *_*) J=$OUT/${W%%_*}_1gpu_pmc_hbm_${W#*_}.json;; esac
-  python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE_$W $OUT/pmc_WRITE_SIZE_$W $J --rows $ROWS --bref $BREF --kernel "$K" --head $HEAD --packed $PK \
+  python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE_$W $OUT/pmc_WRITE_SIZE_$W $J --rows $ROWS --bref $BREF --kernel "$K" --head $HEAD --packed $PK --narrow $NR \
     --command "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py $* --steps 3 --warmup 1 --no-cpu --no-check"
 }
 one c3 1000000000 32e9

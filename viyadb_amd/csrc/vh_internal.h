@@ -121,6 +121,7 @@ struct VhPlanDev {
   int32_t npred;
   int32_t pad1;
   uint8_t pred_slot[8];
+  uint8_t pred_width[8];      // bytes per element the kernel reads for predicate column p: 4, or 1 / 2 when the table keeps a narrow copy (vh_table_narrow)
   // ---- columns (slot -> arena)
   const char* colbase[VH_MAX_SLOTS];
   uint64_t colstride[VH_MAX_SLOTS];  // bytes between consecutive segments

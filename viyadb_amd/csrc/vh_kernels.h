@@ -1050,7 +1050,15 @@ __device__ __forceinline__ void vh_preload(const VhPlanDev& P, uint32_t seg, uin
     for (int k = 0; k < VH_SUBSTEPS; ++k) {
       const uint32_t r = row_l + k * 256u;
       if (used && r < seg_rows) {
-        vh_load4<uint32_t>(col + r, &v[p][k * 4]);
+        if (P.pred_width[p] == 4) vh_load4<uint32_t>(col + r, &v[p][k * 4]);
+        else if (P.pred_width[p] == 2) {       // narrow copy: four 16-bit values in one 8-byte load, widened in registers
+          const uint64_t w = __builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint16_t*>(col) + r));
+          v[p][k * 4] = (uint32_t)w & 0xFFFFu; v[p][k * 4 + 1] = (uint32_t)(w >> 16) & 0xFFFFu;
+          v[p][k * 4 + 2] = (uint32_t)(w >> 32) & 0xFFFFu; v[p][k * 4 + 3] = (uint32_t)(w >> 48);
+        } else {                               // ... four 8-bit values in one 4-byte load
+          const uint32_t w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(col) + r));
+          v[p][k * 4] = w & 0xFFu; v[p][k * 4 + 1] = (w >> 8) & 0xFFu; v[p][k * 4 + 2] = (w >> 16) & 0xFFu; v[p][k * 4 + 3] = w >> 24;
+        }
       } else {
         v[p][k * 4] = v[p][k * 4 + 1] = v[p][k * 4 + 2] = v[p][k * 4 + 3] = 0u;
       }

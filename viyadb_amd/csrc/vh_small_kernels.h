@@ -658,6 +658,19 @@ __global__ __launch_bounds__(256) void pack_kernel(const VhPackArgs A) {
   }
 }
 
+// Narrow copy of an unsigned 32-bit column whose values fit T (vh_table_narrow): grid.y = segments, 4 elements per thread.
+template <typename T>
+__global__ __launch_bounds__(256) void narrow_kernel(const uint32_t* src, uint64_t src_stride_elems, T* dst, uint64_t dst_stride_elems,
+                                                     uint64_t rows_padded, uint32_t seg_first) {
+  const uint32_t seg = seg_first + blockIdx.y;
+  const uint32_t* s = src + (uint64_t)seg * src_stride_elems;
+  T* d = dst + (uint64_t)seg * dst_stride_elems;
+  for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < rows_padded; i += (uint64_t)gridDim.x * 1024) {
+    const vh_u32x4 v = *reinterpret_cast<const vh_u32x4*>(s + i);
+    d[i] = (T)v.x; d[i + 1] = (T)v.y; d[i + 2] = (T)v.z; d[i + 3] = (T)v.w;
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void fill_kernel(T* p, uint64_t n, T v) {
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = v;

@@ -128,6 +128,15 @@ struct VhPack {
   bool automatic = false;
   int col_index(int col) const { for (size_t i = 0; i < cols.size(); ++i) if (cols[i] == col) return (int)i; return -1; }
 };
+// Narrow copy of a predicate column (vh_table_narrow): an unsigned 32-bit column whose values fit 8 or 16 bits, kept a second time
+// at that width. The register-resident scan kernels stream the copy instead of the arena — a predicate column is read in full by
+// every query that filters on it, so its bytes are the floor of the scan (C3: 12 of 18.75 GB per query).
+struct VhNarrow {
+  int col = -1, width = 0;          // bytes per element: 1 or 2
+  char* base = nullptr; uint64_t stride = 0; uint32_t cap_seg = 0;
+  std::vector<uint64_t> seg_mod;    // vh_table::seg_mod[s] the segment was copied at (0: never)
+  bool automatic = false;
+};
 struct vh_table {
   std::vector<VhColumn> cols;
   uint64_t segment_rows = 0;
@@ -148,6 +157,8 @@ struct vh_table {
   std::map<std::string, std::pair<uint64_t, uint64_t>> sel_cache;   // filter signature + table state -> (passed, sampled) of the selectivity probe
   char* h_out[2] = {nullptr, nullptr}; size_t h_out_bytes[2] = {0, 0}; int h_out_next = 0;  // pinned result staging
   std::vector<std::unique_ptr<VhPack>> packs;
+  std::vector<std::unique_ptr<VhNarrow>> narrows;
+  std::map<int, uint32_t> pred_seen;                     // column -> selective queries that filtered on it (automatic narrow copies)
   std::vector<uint64_t> seg_mod;                          // sync_epoch of the last change to a segment's columns
   uint32_t* d_packrows = nullptr; size_t d_packrows_cap = 0;
   std::map<std::string, uint32_t> gather_seen;            // payload column set -> low-selectivity queries seen (automatic packs)
@@ -310,6 +321,7 @@ extern "C" void vh_table_destroy(vh_table* t) {
   }
   if (t->d_stats) (void)hipFree(t->d_stats);
   for (auto& pk : t->packs) if (pk->base) (void)hipFree(pk->base);
+  for (auto& nw : t->narrows) if (nw->base) (void)hipFree(nw->base);
   if (t->d_packrows) (void)hipFree(t->d_packrows);
   delete t;
 }
@@ -661,6 +673,104 @@ static int table_pack_locked(vh_table* t, const int32_t* cols, int32_t ncols, bo
   return VH_OK;
 }
 
+// ------------------------------------------------------- narrow predicate copies (vh_table_narrow)
+// Width the column's values fit over segments [0, nseg): 1, 2, or 0 (not an unsigned 32-bit column, or its values need all 32 bits).
+static int narrow_width_for(const vh_table* t, int col, uint32_t nseg) {
+  const VhColumn& c = t->cols[col];
+  if (c.elem != VH_U32 || (size_t)col >= t->stats.size()) return 0;
+  uint64_t hi = 0;
+  bool any = false;
+  for (uint32_t s = 0; s < nseg && s < t->stats[col].size(); ++s) {
+    const VhSegStat& st = t->stats[col][s];
+    if (st.lo > st.hi) continue;          // empty segment
+    hi = std::max(hi, st.hi); any = true;
+  }
+  if (!any) return 0;
+  return hi < 256 ? 1 : hi < 65536 ? 2 : 0;
+}
+// (Re)copy the segments of [first, first + n) whose column changed since they were last copied.
+static int narrow_refresh(vh_table* t, VhNarrow* nw, uint32_t first, uint32_t n) {
+  if (first + n > t->nseg) n = t->nseg > first ? t->nseg - first : 0;
+  if (!n) return VH_OK;
+  const uint64_t padded = t->padded_rows;
+  if (nw->cap_seg < t->cap_seg) {
+    table_quiesce(t);
+    char* nb = nullptr;
+    const size_t bytes = (size_t)t->cap_seg * nw->stride + 256;
+    HIP_TRY(hipMalloc(&nb, bytes));
+    trace_alloc("narrow", nb, bytes);
+    if (nw->base) {
+      HIP_TRY(hipMemcpyAsync(nb, nw->base, (size_t)nw->cap_seg * nw->stride, hipMemcpyDeviceToDevice, g_ctx.stream));
+      HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+      HIP_TRY(hipFree(nw->base));
+      t->device_bytes -= (size_t)nw->cap_seg * nw->stride + 256;
+    }
+    nw->base = nb; nw->cap_seg = t->cap_seg;
+    nw->seg_mod.resize(t->cap_seg, 0);
+    t->device_bytes += bytes;
+  }
+  const VhColumn& c = t->cols[nw->col];
+  uint32_t s = first;
+  while (s < first + n) {
+    if (nw->seg_mod[s] == t->seg_mod[s]) { ++s; continue; }
+    uint32_t e = s;
+    while (e < first + n && nw->seg_mod[e] != t->seg_mod[e] && e - s < 4096) ++e;
+    const dim3 grid((unsigned)std::min<uint64_t>(64, (padded + 1023) / 1024), e - s);
+    if (nw->width == 1)
+      hipLaunchKernelGGL((narrow_kernel<uint8_t>), grid, dim3(256), 0, g_ctx.stream, reinterpret_cast<const uint32_t*>(c.base), c.stride / 4,
+                         reinterpret_cast<uint8_t*>(nw->base), nw->stride, padded, s);
+    else
+      hipLaunchKernelGGL((narrow_kernel<uint16_t>), grid, dim3(256), 0, g_ctx.stream, reinterpret_cast<const uint32_t*>(c.base), c.stride / 4,
+                         reinterpret_cast<uint16_t*>(nw->base), nw->stride / 2, padded, s);
+    HIP_TRY(hipGetLastError());
+    for (uint32_t i = s; i < e; ++i) nw->seg_mod[i] = t->seg_mod[i];
+    s = e;
+  }
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return VH_OK;
+}
+static void narrow_drop(vh_table* t, size_t k) {
+  table_quiesce(t);
+  VhNarrow* nw = t->narrows[k].get();
+  if (nw->base) { (void)hipFree(nw->base); t->device_bytes -= (size_t)nw->cap_seg * nw->stride + 256; }
+  t->narrows.erase(t->narrows.begin() + (long)k);
+}
+// The narrow copy of `col`, fresh for segments [0, nseg), or nullptr (none, or the values no longer fit: the copy is dropped).
+static VhNarrow* narrow_usable(vh_table* t, int col, uint32_t nseg) {
+  for (size_t k = 0; k < t->narrows.size(); ++k) {
+    VhNarrow* nw = t->narrows[k].get();
+    if (nw->col != col) continue;
+    const int w = narrow_width_for(t, col, t->nseg);
+    if (w == 0 || w > nw->width) { narrow_drop(t, k); return nullptr; }
+    if (narrow_refresh(t, nw, 0, nseg) != VH_OK) return nullptr;
+    return nw;
+  }
+  return nullptr;
+}
+static int table_narrow_locked(vh_table* t, int col, bool automatic) {
+  if (col < 0 || (size_t)col >= t->cols.size()) return vh_fail(VH_E_INVALID, "vh_table_narrow: column %d", col);
+  for (auto& nw : t->narrows) if (nw->col == col) return narrow_usable(t, col, t->nseg) ? VH_OK : VH_OK;
+  const int w = narrow_width_for(t, col, t->nseg);
+  if (!w) return VH_OK;                          // nothing to gain: not an unsigned 32-bit column, or it uses its bits
+  std::unique_ptr<VhNarrow> nw(new VhNarrow());
+  nw->col = col; nw->width = w; nw->automatic = automatic;
+  nw->stride = t->padded_rows * (uint64_t)w;
+  VhNarrow* raw = nw.get();
+  t->narrows.push_back(std::move(nw));
+  const int rc = narrow_refresh(t, raw, 0, t->nseg);
+  if (rc) { narrow_drop(t, t->narrows.size() - 1); return rc; }
+  return VH_OK;
+}
+
+extern "C" int vh_table_narrow(vh_table* t, const int32_t* cols, int32_t ncols) {
+  if (!t || (!cols && ncols)) return vh_fail(VH_E_INVALID, "null argument");
+  VH_ENTER();
+  std::lock_guard<std::mutex> lk(t->mu);
+  for (int i = 0; i < ncols; ++i)
+    if (int rc = table_narrow_locked(t, cols[i], false)) return rc;
+  return VH_OK;
+}
+
 extern "C" int vh_table_pack(vh_table* t, const int32_t* cols, int32_t ncols) {
   if (!t) return vh_fail(VH_E_INVALID, "null table");
   VH_ENTER();
@@ -677,6 +787,9 @@ extern "C" int vh_table_unpack(vh_table* t) {
   for (auto& pk : t->packs) if (pk->base) { (void)hipFree(pk->base); t->device_bytes -= (size_t)pk->cap_seg * pk->stride + 256; }
   t->packs.clear();
   t->gather_seen.clear();
+  for (auto& nw : t->narrows) if (nw->base) { (void)hipFree(nw->base); t->device_bytes -= (size_t)nw->cap_seg * nw->stride + 256; }
+  t->narrows.clear();
+  t->pred_seen.clear();
   return VH_OK;
 }
 
@@ -1051,6 +1164,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
 
   // ---------------- filter program (+ stack depth check)
   bool fast_ok = !(p->flags & VH_PLAN_NO_FAST);
+  int pred_col[VH_MAX_PRED] = {-1, -1, -1, -1};        // table column behind predicate slot k of the register-resident kernels
   int depth = 0, maxdepth = 0;
   std::vector<VhProgOp>& prog = r->h_prog;
   std::vector<size_t> seg_start;          // where the piece of program behind each value on the (simulated) stack begins
@@ -1081,7 +1195,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       if (fast_ok) {
         int ps = -1;
         for (int k = 0; k < P.npred; ++k) if (P.pred_slot[k] == s) ps = k;
-        if (ps < 0) { if (P.npred < VH_MAX_PRED) { ps = P.npred; P.pred_slot[P.npred++] = (uint8_t)s; } else fast_ok = false; }
+        if (ps < 0) { if (P.npred < VH_MAX_PRED) { ps = P.npred; pred_col[P.npred] = n.col; P.pred_width[P.npred] = 4; P.pred_slot[P.npred++] = (uint8_t)s; } else fast_ok = false; }
         o.set_pslot((uint8_t)std::max(ps, 0));
       }
       if (n.kind == VH_F_IN && n.count > 255) {
@@ -1147,6 +1261,29 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     memcpy(P.iprog, prog.data(), prog.size() * sizeof(VhProgOp));
     memcpy(P.ilits, r->h_lits.data(), r->h_lits.size() * sizeof(uint64_t));
   } else fast_ok = false;                                                       // long programs (IN lists of hundreds of values): the generic kernel
+
+  // Narrow copies of predicate columns (vh_table_narrow; built unasked for a column the third selective query filters on): the
+  // register-resident kernels — and the selectivity probe, which is one of them — stream those instead of the 4-byte arenas.
+  if (fast_ok && !(p->flags & VH_PLAN_NO_NARROW)) {
+    static const int auto_after = getenv("VH_AUTO_NARROW") ? atoi(getenv("VH_AUTO_NARROW")) : 3;     // 0: never unasked
+    for (int k = 0; k < P.npred; ++k) {
+      const int col = pred_col[k];
+      bool have = false;
+      for (auto& nw : t->narrows) have |= nw->col == col;
+      if (!have && auto_after > 0 && narrow_width_for(t, col, t->nseg) && ++t->pred_seen[col] >= (uint32_t)auto_after) {
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)t->cap_seg * ((t->segment_rows + 255) / 256 * 256) * 2;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + total_b / 4) (void)table_narrow_locked(t, col, true);
+        else t->pred_seen[col] = 0;
+      }
+      VhNarrow* nw = narrow_usable(t, col, nseg);
+      if (nw && P.nslots < VH_MAX_SLOTS) {
+        P.colbase[P.nslots] = nw->base; P.colstride[P.nslots] = nw->stride; P.colpitch[P.nslots] = (uint32_t)nw->width;
+        P.pred_slot[k] = (uint8_t)P.nslots++;
+        P.pred_width[k] = (uint8_t)nw->width;
+      }
+    }
+  }
 
   // ---------------- segments: snapshot + skip
   // one pinned staging block [segment snapshot | program | literals] -> one upload per query
@@ -1969,7 +2106,9 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     if (rc) { return rc; }
   }
   HIP_TRY(hipEventRecord(x->ev[1], st));
-  r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0);
+  bool narrowed = false;
+  for (int k = 0; k < P.npred; ++k) narrowed |= P.pred_width[k] != 4;
+  r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fast && narrowed ? 16 : 0);
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
     if (mode == VH_MODE_DENSE_PART) {

@@ -80,6 +80,7 @@ class AggResult:
     packed: bool = False           # group / metric values were gathered from a payload projection (vh_table_pack)
     returned: int = 0              # rows delivered (= ngroups unless a HAVING was pushed down)
     kernel: str = ""               # symbol(s) of the scan kernel(s) that ran, as rocprofv3 prints them
+    narrow: bool = False           # predicate columns were streamed from 8- / 16-bit copies (vh_table_narrow)
 
 
 
@@ -165,6 +166,18 @@ class DeviceTable:
 
     def unpack(self) -> None:
         capi.check(self.lib.vh_table_unpack(self.handle))
+
+    def narrow(self, cols) -> None:
+        """Keep 8- / 16-bit copies of the unsigned 32-bit columns among `cols` whose values fit (vh_table_narrow): what the
+        register-resident kernels stream when a query filters on them."""
+        cols = sorted(set(int(c) for c in cols))
+        if cols:
+            arr = (C.c_int32 * len(cols))(*cols)
+            capi.check(self.lib.vh_table_narrow(self.handle, arr, len(cols)))
+
+    def filter_columns(self, plan: "AggPlan"):
+        """Table columns the plan's filter reads."""
+        return sorted({f[1] for f in plan.filter if f[0] in ("rel", "in")})
 
     def gather_columns(self, plan: AggPlan) -> List[int]:
         """Columns a survivor's values are gathered from: group columns + value metrics (not bitsets, not the row id)."""
@@ -296,7 +309,8 @@ class DeviceTable:
         return AggResult(keys, states, hidden, int(info.ngroups), int(info.scanned_recs), int(info.scanned_segments),
                          int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
                          float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1),
-                         bool(info.reserved & 2), bool(info.reserved & 8), int(ng), (self.lib.vh_result_kernel(res) or b"").decode())
+                         bool(info.reserved & 2), bool(info.reserved & 8), int(ng), (self.lib.vh_result_kernel(res) or b"").decode(),
+                         bool(info.reserved & 16))
 
     def query_agg(self, plan: AggPlan, copy: bool = True) -> AggResult:
         p, keep = self._build_plan(plan)
