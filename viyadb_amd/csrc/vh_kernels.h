@@ -1039,7 +1039,19 @@ __device__ __forceinline__ uint32_t vh_leaf_bits(const VhPlanDev& P, const VhPro
   return m;
 }
 
-template <int NP>
+#ifndef VH_PRELOAD_WAIT
+#define VH_PRELOAD_WAIT 0      // measurement: 1 = wait for every load of vh_preload before issuing the next, 2 = for every column's four
+#endif
+// Where the packed values of narrow predicate copies are widened to one register each (C3, five processes each,
+// profiles/r02/NOTES.md "Narrow copies"): 3 = per column, right behind that column's four loads (125 VGPRs, 4 waves per SIMD:
+// 3.12-3.26 ms); 2 = behind every single load (105 VGPRs, but the twelve loads of a step queue behind each other: 3.49-3.61);
+// 1 = after all loads of the step (130 VGPRs, 3 waves: 3.89-3.97); 0 = at the top of the step that evaluates them (141 VGPRs: 3.88-3.92).
+#ifndef VH_WIDEN_EARLY
+#define VH_WIDEN_EARLY 3
+#endif
+// NARROW = false: the caller's plans never carry narrow copies (the lanes kernels: the host gives them the 4-byte arenas back —
+// the extra paths cost them registers they do not have, C2 0.36 -> 0.50 ms with spills)
+template <int NP, bool NARROW = true>
 __device__ __forceinline__ void vh_preload(const VhPlanDev& P, uint32_t seg, uint32_t row_l, uint32_t seg_rows,
                                            uint32_t (&v)[NP][VH_LANE_ROWS]) {
 #pragma unroll
@@ -1050,17 +1062,53 @@ __device__ __forceinline__ void vh_preload(const VhPlanDev& P, uint32_t seg, uin
     for (int k = 0; k < VH_SUBSTEPS; ++k) {
       const uint32_t r = row_l + k * 256u;
       if (used && r < seg_rows) {
-        if (P.pred_width[p] == 4) vh_load4<uint32_t>(col + r, &v[p][k * 4]);
-        else if (P.pred_width[p] == 2) {       // narrow copy: four 16-bit values in one 8-byte load, widened in registers
+        if (!NARROW || P.pred_width[p] == 4) vh_load4<uint32_t>(col + r, &v[p][k * 4]);
+        else if (P.pred_width[p] == 2) {       // narrow copy: four 16-bit values in one 8-byte load. They stay packed in the first two
+                                               // registers until vh_widen, at the top of the step that evaluates them: unpacking here would
+                                               // make every load wait for its data and the twelve loads of a step queue behind each other
           const uint64_t w = __builtin_nontemporal_load(reinterpret_cast<const uint64_t*>(reinterpret_cast<const uint16_t*>(col) + r));
-          v[p][k * 4] = (uint32_t)w & 0xFFFFu; v[p][k * 4 + 1] = (uint32_t)(w >> 16) & 0xFFFFu;
-          v[p][k * 4 + 2] = (uint32_t)(w >> 32) & 0xFFFFu; v[p][k * 4 + 3] = (uint32_t)(w >> 48);
+          if (VH_WIDEN_EARLY == 2) {           // measurement: unpack behind every single load (the loads of a step queue behind each other)
+            v[p][k * 4] = (uint32_t)w & 0xFFFFu; v[p][k * 4 + 1] = (uint32_t)(w >> 16) & 0xFFFFu;
+            v[p][k * 4 + 2] = (uint32_t)(w >> 32) & 0xFFFFu; v[p][k * 4 + 3] = (uint32_t)(w >> 48);
+          } else { v[p][k * 4] = (uint32_t)w; v[p][k * 4 + 1] = (uint32_t)(w >> 32); }
         } else {                               // ... four 8-bit values in one 4-byte load
           const uint32_t w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(col) + r));
-          v[p][k * 4] = w & 0xFFu; v[p][k * 4 + 1] = (w >> 8) & 0xFFu; v[p][k * 4 + 2] = (w >> 16) & 0xFFu; v[p][k * 4 + 3] = w >> 24;
+          if (VH_WIDEN_EARLY == 2) { v[p][k * 4] = w & 0xFFu; v[p][k * 4 + 1] = (w >> 8) & 0xFFu; v[p][k * 4 + 2] = (w >> 16) & 0xFFu; v[p][k * 4 + 3] = w >> 24; }
+          else v[p][k * 4] = w;
         }
       } else {
         v[p][k * 4] = v[p][k * 4 + 1] = v[p][k * 4 + 2] = v[p][k * 4 + 3] = 0u;
+      }
+      if (VH_PRELOAD_WAIT == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    if (VH_PRELOAD_WAIT == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NARROW && VH_WIDEN_EARLY == 3 && used && P.pred_width[p] != 4) {       // this column's four loads are out: unpack them (the wave waits here, once per column)
+#pragma unroll
+      for (int k = 0; k < VH_SUBSTEPS; ++k) {
+        const uint32_t a = v[p][k * 4], b = v[p][k * 4 + 1];
+        if (P.pred_width[p] == 2) { v[p][k * 4] = a & 0xFFFFu; v[p][k * 4 + 1] = a >> 16; v[p][k * 4 + 2] = b & 0xFFFFu; v[p][k * 4 + 3] = b >> 16; }
+        else { v[p][k * 4] = a & 0xFFu; v[p][k * 4 + 1] = (a >> 8) & 0xFFu; v[p][k * 4 + 2] = (a >> 16) & 0xFFu; v[p][k * 4 + 3] = a >> 24; }
+      }
+    }
+  }
+}
+
+// Values of narrow predicate copies, as vh_preload left them (packed), to one 32-bit register each.
+template <int NP>
+__device__ __forceinline__ void vh_widen(const VhPlanDev& P, uint32_t (&v)[NP][VH_LANE_ROWS]) {
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    if (P.pred_width[p] == 2) {
+#pragma unroll
+      for (int k = 0; k < VH_SUBSTEPS; ++k) {
+        const uint32_t a = v[p][k * 4], b = v[p][k * 4 + 1];
+        v[p][k * 4] = a & 0xFFFFu; v[p][k * 4 + 1] = a >> 16; v[p][k * 4 + 2] = b & 0xFFFFu; v[p][k * 4 + 3] = b >> 16;
+      }
+    } else if (P.pred_width[p] == 1) {
+#pragma unroll
+      for (int k = 0; k < VH_SUBSTEPS; ++k) {
+        const uint32_t a = v[p][k * 4];
+        v[p][k * 4] = a & 0xFFu; v[p][k * 4 + 1] = (a >> 8) & 0xFFu; v[p][k * 4 + 2] = (a >> 16) & 0xFFu; v[p][k * 4 + 3] = a >> 24;
       }
     }
   }
@@ -1141,6 +1189,11 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
     const uint64_t r1 = vh_gather_raw(P, P.g[1].slot(), seg, row, s1);
     const uint64_t r2 = vh_gather_raw(P, P.m[J64].slot(), seg, row, s2);
     const uint64_t r3 = vh_gather_raw(P, P.m[J32].slot(), seg, row, s3);
+    if (VH_ABLATE & 2) {       // measurement build: the gathers and nothing behind them ((VH_ABLATE & 1): not even those)
+      const uint64_t acc = (VH_ABLATE & 1) ? (uint64_t)row : r0 + r1 + r2 + r3;
+      if (acc == 0x123456789ABCDEFull) P.counters[7] = acc;
+      return;
+    }
     // unsigned group columns of 1, 2 or 4 bytes (dictionary codes, booleans, uint dimensions): the host left the element's width
     // as a right shift in key_shift (unused on the dense paths): 0, 16 or 24
     const uint32_t d0 = (((uint32_t)(r0 >> s0) << P.g[0].key_shift()) >> P.g[0].key_shift()) - (uint32_t)P.g[0].lo;
@@ -1322,10 +1375,11 @@ __device__ __forceinline__ void vh_scan_fast_body(const VhPlanDev& P) {
     wave_base = useg * P.unit_rows + wave * VH_WAVE_STEP_ROWS;
   }
   uint32_t v[NP][VH_LANE_ROWS];
-  if (have) vh_preload<NP>(P, seg, wave_base + lane * 4, seg_rows, v);
+  if (have) { vh_preload<NP>(P, seg, wave_base + lane * 4, seg_rows, v); if (VH_WIDEN_EARLY == 1) vh_widen<NP>(P, v); }
   uint32_t cnt = 0;
   while (have) {
     const uint32_t row_l = wave_base + lane * 4;
+    if (!VH_WIDEN_EARLY) vh_widen<NP>(P, v);
     const uint32_t mask = vh_eval_filter_fast<NP>(P, v, row_l, seg_rows);
     npassed += __popc(mask);
     // locate the next step and put its predicate columns in flight now
@@ -1342,7 +1396,7 @@ __device__ __forceinline__ void vh_scan_fast_body(const VhPlanDev& P) {
         nwave_base = useg * P.unit_rows + wave * VH_WAVE_STEP_ROWS;
       }
     }
-    if (nhave) vh_preload<NP>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
+    if (nhave) { vh_preload<NP>(P, nseg, nwave_base + lane * 4, nseg_rows, v); if (VH_WIDEN_EARLY == 1) vh_widen<NP>(P, v); }
     // One textual drain for the four sub-steps and for the flush at a segment's end (k == VH_SUBSTEPS): with the loop unrolled the
     // drain — gathers, rollup, table update, every table organisation's alternatives — was inlined five times and the kernel ran to
     // 26 K instructions, several times the instruction cache (profiles/r02/NOTES.md, "Code size").
@@ -1486,7 +1540,7 @@ __global__ __launch_bounds__(BLOCK, VH_LANES_WAVES(MODE, BLOCK, NP)) void scan_a
     }
   }
   uint32_t v[NP][VH_LANE_ROWS];
-  if (have) vh_preload<NP>(P, seg, wave_base + lane * 4, seg_rows, v);
+  if (have) vh_preload<NP, false>(P, seg, wave_base + lane * 4, seg_rows, v);
   bool range_err = false, full_err = false;
   while (have) {
     const uint32_t row_l = wave_base + lane * 4;
@@ -1505,7 +1559,7 @@ __global__ __launch_bounds__(BLOCK, VH_LANES_WAVES(MODE, BLOCK, NP)) void scan_a
         nwave_base = nunit_base + (t % spu) * C::kStepRows + wave * VH_WAVE_STEP_ROWS;
       }
     }
-    if (nhave) vh_preload<NP>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
+    if (nhave) vh_preload<NP, false>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
 #pragma unroll
     for (int k = 0; k < VH_SUBSTEPS; ++k) {
       const uint32_t mk = (mask >> (4 * k)) & 0xFu;

@@ -1165,6 +1165,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   // ---------------- filter program (+ stack depth check)
   bool fast_ok = !(p->flags & VH_PLAN_NO_FAST);
   int pred_col[VH_MAX_PRED] = {-1, -1, -1, -1};        // table column behind predicate slot k of the register-resident kernels
+  int pred_wide_slot[VH_MAX_PRED] = {-1, -1, -1, -1};  // its 4-byte arena's slot when the plan was pointed at a narrow copy
   int depth = 0, maxdepth = 0;
   std::vector<VhProgOp>& prog = r->h_prog;
   std::vector<size_t> seg_start;          // where the piece of program behind each value on the (simulated) stack begins
@@ -1279,6 +1280,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       VhNarrow* nw = narrow_usable(t, col, nseg);
       if (nw && P.nslots < VH_MAX_SLOTS) {
         P.colbase[P.nslots] = nw->base; P.colstride[P.nslots] = nw->stride; P.colpitch[P.nslots] = (uint32_t)nw->width;
+        pred_wide_slot[k] = P.pred_slot[k];
         P.pred_slot[k] = (uint8_t)P.nslots++;
         P.pred_width[k] = (uint8_t)nw->width;
       }
@@ -2106,6 +2108,8 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     if (rc) { return rc; }
   }
   HIP_TRY(hipEventRecord(x->ev[1], st));
+  if (lanes)       // the lanes kernels read 4-byte predicate columns only (vh_preload<NP, false>)
+    for (int k = 0; k < P.npred; ++k) if (P.pred_width[k] != 4) { P.pred_slot[k] = (uint8_t)pred_wide_slot[k]; P.pred_width[k] = 4; }
   bool narrowed = false;
   for (int k = 0; k < P.npred; ++k) narrowed |= P.pred_width[k] != 4;
   r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fast && narrowed ? 16 : 0);
