@@ -1359,8 +1359,8 @@ __device__ __forceinline__ void vh_scan_fast_body(const VhPlanDev& P) {
   }
 
   const uint64_t xoff = (MODE == VH_MODE_DENSE_GLOBAL && P.nxcd > 1) ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;
-  const uint64_t lanemask_lt = (1ull << lane) - 1ull;
-  unsigned long long npassed = 0, nfresh = 0;
+  uint32_t npassed32 = 0;                    // per lane: a lane sees a 64th of this block's rows (< 2^32); one register less than a 64-bit count
+  unsigned long long nfresh = 0;
   const uint32_t spu = P.unit_rows / C::kStepRows;  // steps per unit
 
   // this block's units are blockIdx.x, + gridDim.x, ...; a unit is `spu` steps inside one segment. (segment, unit inside the
@@ -1381,7 +1381,7 @@ __device__ __forceinline__ void vh_scan_fast_body(const VhPlanDev& P) {
     const uint32_t row_l = wave_base + lane * 4;
     if (!VH_WIDEN_EARLY) vh_widen<NP>(P, v);
     const uint32_t mask = vh_eval_filter_fast<NP>(P, v, row_l, seg_rows);
-    npassed += __popc(mask);
+    npassed32 += __popc(mask);
     // locate the next step and put its predicate columns in flight now
     uint32_t nseg = seg, nwave_base = wave_base + C::kStepRows, nseg_rows = seg_rows;
     bool nhave = true;
@@ -1434,6 +1434,7 @@ __device__ __forceinline__ void vh_scan_fast_body(const VhPlanDev& P) {
   }
 
   if (MODE == VH_MODE_DENSE_PART) vh_part_tile_finish(P, T, lane);
+  unsigned long long npassed = npassed32;
   for (int off = 32; off > 0; off >>= 1) npassed += __shfl_down(npassed, off);
   if (lane == 0) {
     if (npassed) atomicAdd(P.counters + 0, npassed);
