@@ -47,7 +47,9 @@
 #ifndef VIYA_HIP_H_
 #define VIYA_HIP_H_
 
+#ifndef __HIPCC_RTC__ /* (hipRTC, which compiles the per-query kernels, brings its own) */
 #include <stddef.h>
+#endif
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -185,8 +187,14 @@ enum vh_plan_flags {
                                      direct global atomics)                    */
   VH_PLAN_NO_SHAPE = 1u << 15,    /* ablation: the generic survivor drain even when the
                                      plan has a shape a specialised one exists for */
-  VH_PLAN_NO_NARROW = 1u << 16    /* ablation: predicate columns from their 4-byte arenas
+  VH_PLAN_NO_NARROW = 1u << 16,   /* ablation: predicate columns from their 4-byte arenas
                                      even when a narrow copy (vh_table_narrow) exists */
+  VH_PLAN_NO_JIT = 1u << 17,      /* only the pre-built (interpreting) scan kernels, whatever VH_JIT says */
+  VH_PLAN_FORCE_JIT = 1u << 18    /* testing: compile a scan kernel for this plan shape however small the table
+                                     (shapes the generator does not cover — bitset metrics, the no-compaction
+                                     kernels, very wide plans — still take the pre-built kernels: see
+                                     vh_result_info.reserved bit 5); a compile that FAILS is an error,
+                                     VH_E_UNSUPPORTED, not a silent fallback                               */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */
@@ -236,7 +244,8 @@ typedef struct vh_result_info {
   uint32_t retries;          /* hash-table regrows                           */
   uint32_t reserved;         /* bit 0: the register-resident fast scan kernel ran; bit 1: its no-compaction "lanes" variant;
                                 bit 2: LDS front table of the hash path; bit 3: payload gathered from a projection (vh_table_pack);
-                                bit 4: predicate columns streamed from narrow copies (vh_table_narrow) */
+                                bit 4: predicate columns streamed from narrow copies (vh_table_narrow);
+                                bit 5: a scan kernel compiled for this plan shape ran (vh_jit.hip) */
   uint64_t returned_groups;  /* rows vh_result_copy delivers (= ngroups without HAVING) */
 } vh_result_info;
 
@@ -488,6 +497,12 @@ VH_API void vh_result_free(vh_result* r);
  * kernel over `bytes` of HBM) — the "achievable" figure quoted next to every
  * roofline fraction. */
 VH_API int vh_measure_read_bandwidth(uint64_t bytes, int32_t iters, double* bytes_per_sec);
+
+/* Test hook for the per-query compiled scan kernels (viyadb_amd/csrc/vh_jit.hip — the GPU analogue of the reference's
+ * codegen + Compiler::Compile, src/codegen/compiler.cc:97-144): writes the HIP text for canonical plan shape `which`
+ * (0..5) into `text`, compiles it with hipRTC for gfx950 — no GPU needed — and stores the code object at `hsaco_path`
+ * (NULL: nowhere). VH_E_INVALID: no such shape; VH_E_UNSUPPORTED: the compile failed (`text` then starts with the log). */
+VH_API int vh_jit_selftest(int32_t which, const char* hsaco_path, char* text, uint64_t text_bytes);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ def collect(d, counter):
                 "select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
             per[name].append(float(value))
     # median over the dispatches: a first attempt that overflowed its table (and was re-planned) must not set the figure
-    return {k: {"dispatches": len(v), "mean_KiB": sorted(v)[len(v) // 2]} for k, v in per.items() if k.startswith("void scan") or "kernel" in k}
+    return {k: {"dispatches": len(v), "mean_KiB": sorted(v)[len(v) // 2]} for k, v in per.items() if k.startswith("void scan") or "kernel" in k or "viya_jit" in k}
 
 
 def main():

@@ -1,9 +1,15 @@
 // vh_internal.h — device-visible plan layout and small helpers shared by the
 // kernels and the C-ABI host code. Not part of the public boundary.
 #pragma once
+// (hipRTC — the per-query kernels of vh_jit.hip — pre-includes the HIP runtime and is handed viya_hip.h by name)
+#ifdef __HIPCC_RTC__
+#include <stdint.h>
+#include "viya_hip.h"
+#else
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/viya_hip.h"
+#endif
 
 #define VH_MAX_LITS 65535  // literal pool (VhProgOp::lit is 16 bits)
 #define VH_INLINE_PROG 24  // filter programs up to this size (and VH_INLINE_LITS literals) also travel in the kernel arguments, where the
@@ -37,6 +43,12 @@
 #define VH_LANE_ROWS (4 * VH_SUBSTEPS)             // rows a lane owns per wave step
 #define VH_WAVE_STEP_ROWS (256 * VH_SUBSTEPS)
 #define VH_ROWMASK ((1u << VH_LANE_ROWS) - 1u)     // pass-mask bits of one lane
+// per-query compiled kernels (vh_jit_body.h): a wave's survivor queue = carry-over (< 64) + every row slot of one wave step
+// (a step's slots are compacted in one go, then drained)
+#define VJ_QUEUE_CAP (64 + VH_WAVE_STEP_ROWS)
+
+// table organisations of the scan kernels
+enum { VH_MODE_DENSE_LDS = 1, VH_MODE_DENSE_GLOBAL = 2, VH_MODE_HASH = 3, VH_MODE_DENSE_PART = 4 };
 
 // state-update opcodes (what one surviving row does to one metric state)
 enum vh_state_op : uint8_t {

@@ -1,0 +1,56 @@
+// vh_jit.h — per-query compiled scan kernels: the GPU analogue of the reference's codegen + compiler cache
+// (AggQueryGenerator src/codegen/query/agg_query.cc:26-75, ComparisonBuilder src/codegen/query/filter.cc:206-261,
+// Compiler::Compile src/codegen/compiler.cc:97-144). Host side; the device-side frame is vh_jit_body.h.
+#pragma once
+#include "vh_internal.h"
+#include <string>
+#include <vector>
+
+#define VJ_MAX_PRED 8       // distinct predicate columns held packed in registers
+#define VJ_MAX_NV 96        // ... and the registers they may take per lane and wave step (a 1-byte column: 4, a 4-byte one: 16)
+#define VJ_MAX_COLS 8       // group columns / metrics of a generated drain
+
+struct VhJitPred { int slot, type, width; };      // width: bytes per element as streamed (a narrow copy of a u32 column: 1 or 2)
+struct VhJitCol {           // one gathered value of a survivor
+  int slot = 0, type = 0, pitch = 0;   // pitch: bytes between consecutive rows (element size, or the record size of a projection)
+  int rec = -1, off = 0;               // rec >= 0: member of payload projection `rec`, at byte `off` of its record
+  int sext = 0, rowid = 0;             // sign-extend to 64 bits (dense digits, signed MIN / MAX); the virtual row-id column
+  // group columns
+  int gran = VH_T_NONE, nroll = 0, micro = 0, key_word = 0, key_shift = 0;
+  int roll_unit[VH_MAX_ROLLUP] = {};
+  // metrics
+  int sop = 0, tword = 0, tshift = 0;
+};
+// Everything the generated text depends on — and nothing else (no literals, no addresses, no row counts): the cache key.
+struct VhJitShape {
+  int mode = 0, block = 256, scope = 0, xcd = 0, carrier = -1, tw = 0, key_words = 1, lds_hash = 0, gid32 = 0;
+  int stage = 0;                        // DENSE_PART: tuples leave for HBM as whole 128-byte lines (vh_part_staged_add)
+  int npred = 0;
+  VhJitPred pred[VJ_MAX_PRED];
+  std::vector<VhProgOp> prog;           // postfix filter; VhProgOp::pslot indexes pred[], ::lit the literal pool
+  int nlits = 0;
+  int ng = 0, nm = 0;
+  VhJitCol g[VJ_MAX_COLS], m[VJ_MAX_COLS];
+  int ablate = 0;                       // measurement builds only (VH_JIT_ABLATE): 1 = no gathers, 2 = no sink
+  std::string key() const;
+};
+
+struct VhJitKernel {
+  hipModule_t mod = nullptr;
+  hipFunction_t fn = nullptr;
+  std::string name;          // kernel symbol as rocprofv3 prints it
+  double compile_ms = 0;     // 0: came out of the disk cache
+  int vgprs = 0, sgprs = 0;
+};
+
+enum { VH_JIT_OFF = 0, VH_JIT_AUTO = 1, VH_JIT_FORCE = 2 };
+int vh_jit_policy();                               // VH_JIT = off | auto (default) | force
+uint64_t vh_jit_min_rows();                        // auto: rows a query must scan before a compile is worth it (VH_JIT_MIN_ROWS)
+std::string vh_jit_source(const VhJitShape& s, const char* kernel_name);
+// The kernel for this shape: memory cache -> disk cache -> hipRTC. nullptr + *err on failure (the caller falls back to the
+// pre-built interpreting kernels). Thread-safe; a shape is compiled once.
+VhJitKernel* vh_jit_get(const VhJitShape& s, std::string* err);
+int vh_jit_occupancy(VhJitKernel* k, int block, size_t lds);
+hipError_t vh_jit_launch(VhJitKernel* k, const VhPlanDev& P, int grid, int block, size_t lds, hipStream_t s);
+// code object for a shape without loading it (no GPU needed: build-time cache warm-up, CPU tests)
+int vh_jit_compile_only(const VhJitShape& s, std::vector<char>* code, std::string* log);

@@ -1,0 +1,310 @@
+// vh_jit_body.h — the hand-written frame of the per-query scan kernels.
+//
+// The reference compiles every query into straight-line C++ (filter: ComparisonBuilder, src/codegen/query/filter.cc:206-261;
+// loop: src/codegen/query/scan.cc:57-65; key / Update: src/codegen/db/store.cc:31-169) and caches the shared object
+// (src/codegen/compiler.cc:97-144). vh_jit.hip does the same for the GPU: per plan SHAPE (column types and widths, the
+// filter tree, the table organisation — not the literals, which stay run-time arguments like the reference's `fargs`) it
+// writes a small translation unit — a traits struct `VJ` with the shape as compile-time constants, the packed predicate
+// loads, the filter as one C++ expression per row slot and the survivor's gathers — which includes THIS file for everything
+// that does not depend on the query: scan geometry, compaction, the drain and the table organisations (the same device
+// functions the pre-built kernels of vh_kernels.h use, now called with constants). hipRTC compiles it for gfx950.
+//
+// Differences to scan_agg_fast_kernel that the generated form makes possible:
+//   * predicate columns stay PACKED in registers (a 1-byte column: 4 VGPRs per 16 rows, not 16) and are compared where they
+//     sit — the compiler selects the byte / half-word with SDWA operand selectors, one v_cmp per row slot and predicate;
+//   * a comparison's result IS the wave's ballot (an SGPR pair): conjunctions are s_and_b64, compaction ranks come from
+//     v_mbcnt on that pair — no per-lane 16-bit masks, no second round of ballots;
+//   * the drain knows column types, record layout, digit arithmetic and tuple layout.
+#pragma once
+#include "vh_kernels.h"
+
+// (the wave's survivor queue holds VJ_QUEUE_CAP rows: vh_internal.h)
+#ifndef VJ_ABL
+#define VJ_ABL 0           // measurement builds only (VH_JIT_FLAGS=-DVJ_ABL=n): 8 = tuples are built, nothing is appended
+#endif
+#ifndef VJ_NT_GATHER
+#define VJ_NT_GATHER 0     // 1: a survivor's record is fetched with non-temporal loads
+#endif
+template <typename T> __device__ __forceinline__ T vj_gload(const T* p) {
+  if (VJ_NT_GATHER) return __builtin_nontemporal_load(p);
+  return *p;
+}
+
+template <class J, int I>
+__device__ __forceinline__ uint64_t vj_time_rollup(uint64_t ts, const VhGroupDev& g) {
+  constexpr bool micro = J::g_micro[I] != 0;
+  uint64_t secs = micro ? ts / 1000000ull : ts;
+  uint64_t micros = micro ? ts % 1000000ull : 0;
+  bool done = false;       // the FIRST rule whose boundary lies beyond ts truncates (rollup.cc:77-95)
+#pragma unroll
+  for (int k = 0; k < J::g_nroll[I]; ++k) {
+    if (!done && ts < g.roll_before[k]) { secs = vh_trunc_secs(secs, J::g_roll_unit[I][k]); micros = 0; done = true; }
+  }
+  if (J::g_gran[I] != VH_T_NONE) { secs = vh_trunc_secs(secs, J::g_gran[I]); micros = 0; }
+  return micro ? secs * 1000000ull + micros : (uint64_t)(uint32_t)secs;
+}
+
+template <class J, int I = 0>
+__device__ __forceinline__ void vj_rollup_all(const VhPlanDev& P, uint64_t (&gv)[J::NG ? J::NG : 1]) {
+  if constexpr (I < J::NG) {
+    if constexpr (J::g_gran[I] != VH_T_NONE || J::g_nroll[I] != 0) gv[I] = vj_time_rollup<J, I>(gv[I], P.g[I]);
+    vj_rollup_all<J, I + 1>(P, gv);
+  }
+}
+
+// One surviving row per active lane: AggTuple key, then Metrics::Update (store.cc:131-161) into the plan's table organisation.
+template <class J>
+__device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, char* lds, uint64_t xoff,
+                                         unsigned long long& nfresh, VhPartWave& W, VhPartTile& T, VhLdsHashWave& H, VhPartStage& S) {
+  constexpr int MODE = J::MODE;
+  constexpr int NG = J::NG, NM = J::NM;
+  if (!active) row = 0;
+  uint64_t gv[NG ? NG : 1], mv[NM ? NM : 1];
+  if constexpr (J::ABLATE & 1) {       // measurement builds (VH_JIT_ABLATE): no gathers, values made up from the row number
+#pragma unroll
+    for (int i = 0; i < NG; ++i) gv[i] = P.g[i].lo + (row & 63u);
+#pragma unroll
+    for (int j = 0; j < NM; ++j) mv[j] = row;
+  } else {
+    J::gather(P, seg, row, gv, mv);    // every load of the survivor is issued before the first value is looked at
+  }
+  if constexpr (J::ABLATE & 2) {       // ... the gathers and nothing behind them
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) acc += gv[i];
+#pragma unroll
+    for (int j = 0; j < NM; ++j) acc += mv[j];
+    if (acc == 0x123456789ABCDEFull) P.counters[7] = acc;
+    return;
+  }
+  vj_rollup_all<J>(P, gv);
+  uint64_t gid = 0;
+  uint64_t key[VH_KEY_WORDS];
+  bool bad = false;
+  if constexpr (MODE == VH_MODE_HASH) {
+#pragma unroll
+    for (int i = 0; i < VH_KEY_WORDS; ++i) key[i] = 0;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      uint64_t v = gv[i];
+      if (J::g_type[i] == VH_F32 && (uint32_t)v == 0x80000000u) v = 0;            // -0.0f == 0.0f
+      if (J::g_type[i] == VH_F64 && v == 0x8000000000000000ull) v = 0;
+      key[J::g_key_word[i]] |= v << J::g_key_shift[i];
+    }
+  } else if constexpr (J::GID32) {
+    // every digit in 32-bit wrap-around arithmetic: with v, lo in one 32-bit domain and lo + extent - 1 inside it, a value below
+    // lo wraps to >= 2^32 - (lo - min) >= extent, so out-of-range digits are still caught (signed and unsigned alike)
+    uint32_t g32 = 0;
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const uint32_t d = (uint32_t)gv[i] - (uint32_t)P.g[i].lo;
+      bad |= d >= (uint32_t)P.g[i].extent;
+      g32 += d * (uint32_t)P.g[i].stride;
+    }
+    gid = g32;
+  } else {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) {
+      const uint64_t d = gv[i] - P.g[i].lo;
+      bad |= d >= P.g[i].extent;
+      gid += d * P.g[i].stride;
+    }
+  }
+  if constexpr (MODE == VH_MODE_HASH) {
+    if constexpr (J::LDS_HASH) {
+      if (!H.bypass) {
+        uint32_t ls = 0;
+        const bool in_lds = active && key[0] != VH_HASH_EMPTY && vh_lds_hash_find(P, lds, key[0], ls);
+        const uint32_t nh = __popcll(__ballot(in_lds)), nm = __popcll(__ballot(active && !in_lds));
+        H.hits += nh; H.misses += nm;
+        if (H.hits + H.misses >= 4096u && H.misses > H.hits) H.bypass = true;
+        if (in_lds) {
+#pragma unroll
+          for (int j = 0; j < NM; ++j) vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + P.m[j].lds_off, ls, J::m_sop[j], mv[j]);
+        }
+        active = active && !in_lds;
+      }
+    }
+    bool ok = true, fresh = false;
+    if (active) {
+      if constexpr (J::KEY_WORDS == 1) gid = vh_hash_insert64(P, key[0], ok, fresh);
+      else gid = vh_hash_insert_wide(P, key, J::KEY_WORDS, ok, fresh);
+    }
+    bad = !ok;
+    nfresh += __popcll(__ballot(active && fresh));
+    if (__ballot(active && bad)) {
+      if (active && bad) atomicOr(P.counters + 2, VH_ERR_HASH_FULL);
+      H.dead = true;
+    }
+  } else if (__ballot(active && bad)) {
+    if (active && bad) atomicOr(P.counters + 2, VH_ERR_RANGE);
+  }
+  active = active && !bad;
+  if constexpr (MODE == VH_MODE_DENSE_PART) {
+    constexpr int TW = J::TW;
+    uint64_t words[TW];
+    words[0] = gid & 0xFFFFFFFFull;
+#pragma unroll
+    for (int w = 1; w < TW; ++w) words[w] = 0;
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+      const uint64_t v = (vh_sop_bytes(J::m_sop[j]) == 4 ? (mv[j] & 0xFFFFFFFFull) : mv[j]) << J::m_tshift[j];
+      words[J::m_tword[j]] |= v;
+    }
+    if (VJ_ABL & 8) { uint64_t acc = 0; for (int w = 0; w < TW; ++w) acc += words[w]; if (acc == 0x123456789ABCDEFull) P.counters[7] = acc; return; }
+    if (VJ_ABL & 0xF0) {      // measurement: (VJ_ABL >> 4) partitions fed round-robin by lane, i.e. contiguous runs of 64 / n tuples per store (wrong results)
+      vh_part_direct_add<TW, 1, TW>(P, T, W, active, words, (uint32_t)((threadIdx.x & 63) % (VJ_ABL >> 4)), (int)(threadIdx.x & 63));
+      return;
+    }
+    if constexpr (J::STAGE && TW == 2) vh_part_staged_add(P, T, W, S, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
+    else vh_part_direct_add<TW, 1, TW>(P, T, W, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
+    return;
+  }
+  if constexpr (MODE == VH_MODE_DENSE_LDS) {
+    if (active) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[gid] = 1;
+  } else if constexpr (MODE == VH_MODE_DENSE_GLOBAL) {
+    if constexpr (J::CARRIER < 0) { if (active) P.present[xoff + gid] = 1; }
+  }
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+      if constexpr (MODE == VH_MODE_DENSE_LDS) vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + P.m[j].lds_off, gid, J::m_sop[j], mv[j]);
+      else if constexpr (MODE == VH_MODE_DENSE_GLOBAL) vh_state_update<J::SCOPE>(P.m[j].state, xoff + gid, J::m_sop[j], mv[j]);
+      else vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(vh_hash_state(P, P.m[j], gid), 0, J::m_sop[j], mv[j]);
+    }
+  }
+}
+
+// One row slot of the wave step: the generated predicate for slot I, its ballot, and the passing lanes' rows appended to the
+// wave's queue. FULL = false: the step reaches the end of the segment's snapshot, rows at or beyond size() never pass.
+template <class J, int I, bool FULL>
+__device__ __forceinline__ void vj_slot(const typename J::Lits& L, const uint32_t (&v)[J::NV ? J::NV : 1], uint32_t row_l, uint32_t seg_rows,
+                                        uint32_t* q, uint32_t& cnt) {
+  const uint32_t row = row_l + (I >> 2) * 256u + (I & 3);
+  // The slot's pass mask as the generated filter built it from the comparisons' own lane masks (v_cmp -> SGPR pair, s_and / s_or),
+  // and the same predicate as this lane's bool: the two share every comparison, and the bool's lane mask IS the mask, so the branch
+  // below is one s_and_saveexec on it. (__ballot(p) would rebuild the mask with v_cndmask + v_cmp per slot.)
+  bool p;
+  uint64_t bal = J::template pass<I>(L, v, p);
+  if (!FULL) { const bool in = row < seg_rows; bal &= __builtin_amdgcn_ballot_w64(in); p = p & in; }
+  if (p) q[__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, cnt))] = row;
+  cnt += (uint32_t)__popcll(bal);
+}
+template <class J, bool FULL, int I = 0>
+__device__ __forceinline__ void vj_slots(const typename J::Lits& L, const uint32_t (&v)[J::NV ? J::NV : 1], uint32_t row_l, uint32_t seg_rows,
+                                         uint32_t* q, uint32_t& cnt) {
+  if constexpr (I < VH_LANE_ROWS) {
+    vj_slot<J, I, FULL>(L, v, row_l, seg_rows, q, cnt);
+    vj_slots<J, FULL, I + 1>(L, v, row_l, seg_rows, q, cnt);
+  }
+}
+
+// The kernel body. Grid-stride over work units exactly like vh_scan_fast_body (same VhPlanDev, same unit decomposition, same
+// counters), so the host plans and finalises a query the same way whichever kernel ran it.
+template <class J>
+__device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int MODE = J::MODE, BLOCK = J::BLOCK;
+  constexpr int kStepRows = BLOCK * VH_LANE_ROWS;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform, and the compiler is told so: rows, counts and
+                                                                                 // ballots of the step then live in scalar registers
+  uint32_t* q = reinterpret_cast<uint32_t*>(lds + ((MODE == VH_MODE_DENSE_LDS || MODE == VH_MODE_HASH) ? P.lds_bytes : 0)) + wave * VJ_QUEUE_CAP;
+  VhLdsHashWave H{0u, 0u, false, 0ull};
+  if constexpr (MODE == VH_MODE_HASH && J::LDS_HASH) vh_lds_hash_init(P, lds, BLOCK);
+  VhPartWave W;
+  VhPartTile T;
+  if constexpr (MODE == VH_MODE_DENSE_PART) vh_part_tile_init(P, lds, T, W);
+  VhPartStage S{0u, nullptr};
+  if constexpr (MODE == VH_MODE_DENSE_PART && J::STAGE)      // one waiting line per partition and wave, behind the block's queues
+    S.lines = reinterpret_cast<uint64_t*>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)wave * VH_STAGE_BYTES);
+  if constexpr (MODE == VH_MODE_DENSE_LDS) {
+    // identities: 0 for SUM/AVG/COUNT, type max for MIN, cpp_min_value for MAX (src/codegen/db/store.cc:107-117)
+#pragma unroll
+    for (int j = 0; j < J::NM; ++j) {
+      const uint64_t ident = P.m[j].ident;
+      if (vh_sop_bytes(J::m_sop[j]) == 4) { for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint32_t*>(lds + P.m[j].lds_off)[g] = (uint32_t)ident; }
+      else { for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint64_t*>(lds + P.m[j].lds_off)[g] = ident; }
+    }
+    for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
+    __syncthreads();
+  }
+  const uint64_t xoff = (MODE == VH_MODE_DENSE_GLOBAL && J::XCD) ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;
+  const typename J::Lits L(P);               // the filter's literals, decoded to their columns' types once
+  unsigned long long npassed = 0, nfresh = 0;   // npassed is wave-uniform (sums of ballot population counts)
+  const uint32_t spu = P.unit_rows / kStepRows;
+
+  const uint32_t gdiv = gridDim.x / P.units_per_seg, gmod = gridDim.x % P.units_per_seg;
+  uint32_t unit = blockIdx.x, seg = 0, useg = 0, ustep = 0, wave_base = 0, seg_rows = 0;
+  bool have = unit < P.total_units;
+  if (have) {
+    seg = unit / P.units_per_seg;
+    useg = unit - seg * P.units_per_seg;
+    seg_rows = P.seg_rows[seg];
+    wave_base = useg * P.unit_rows + wave * VH_WAVE_STEP_ROWS;
+  }
+  uint32_t v[J::NV ? J::NV : 1];
+  if (have) {
+    if (wave_base + VH_WAVE_STEP_ROWS <= seg_rows) J::template preload<true>(P, seg, wave_base + lane * 4, seg_rows, v);
+    else J::template preload<false>(P, seg, wave_base + lane * 4, seg_rows, v);
+  }
+  uint32_t cnt = 0;
+  while (have) {
+    const uint32_t row_l = wave_base + lane * 4;
+    const uint32_t cnt0 = cnt;
+    if (wave_base + VH_WAVE_STEP_ROWS <= seg_rows) vj_slots<J, true>(L, v, row_l, seg_rows, q, cnt);
+    else if (wave_base < seg_rows) vj_slots<J, false>(L, v, row_l, seg_rows, q, cnt);
+    npassed += cnt - cnt0;
+    // locate the next step and put its predicate columns in flight: they travel while this step's survivors are drained
+    uint32_t nseg = seg, nwave_base = wave_base + kStepRows, nseg_rows = seg_rows;
+    bool nhave = true;
+    if (++ustep == spu) {
+      ustep = 0;
+      unit += gridDim.x;
+      nhave = unit < P.total_units;
+      useg += gmod; nseg = seg + gdiv;
+      if (useg >= P.units_per_seg) { useg -= P.units_per_seg; ++nseg; }
+      if (nhave) {
+        nseg_rows = P.seg_rows[nseg];
+        nwave_base = useg * P.unit_rows + wave * VH_WAVE_STEP_ROWS;
+      }
+    }
+    if (nhave) {
+      if (nwave_base + VH_WAVE_STEP_ROWS <= nseg_rows) J::template preload<true>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
+      else J::template preload<false>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool flush = !nhave || nseg != seg;       // queue entries are rows of the current segment
+    while (cnt >= 64 || (flush && cnt)) {
+      const uint32_t take = cnt >= 64 ? 64u : cnt;
+      cnt -= take;
+      const bool act = (uint32_t)lane < take;
+      const uint32_t r = act ? q[cnt + lane] : 0u;
+      vj_drain<J>(P, seg, r, act, lds, xoff, nfresh, W, T, H, S);
+      __builtin_amdgcn_wave_barrier();
+    }
+    have = nhave; seg = nseg; wave_base = nwave_base; seg_rows = nseg_rows;
+    if (MODE == VH_MODE_HASH && H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
+  }
+
+  if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE) vh_part_stage_finish(P, T, S, lane); else vh_part_tile_finish(P, T, lane); }
+  if (lane == 0) {
+    if (npassed) atomicAdd(P.counters + 0, npassed);
+    if (nfresh) atomicAdd(P.counters + 1, nfresh);
+  }
+  if constexpr (MODE == VH_MODE_HASH && J::LDS_HASH) vh_lds_hash_flush(P, lds, BLOCK);
+  if constexpr (MODE == VH_MODE_DENSE_LDS) {
+    __syncthreads();
+    const uint64_t xo = J::XCD ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;
+    for (uint64_t g = threadIdx.x; g < P.G; g += BLOCK) {
+      if (!reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g]) continue;
+      P.present[xo + g] = 1;
+#pragma unroll
+      for (int j = 0; j < J::NM; ++j) {
+        const uint64_t bits = vh_sop_bytes(J::m_sop[j]) == 4 ? reinterpret_cast<uint32_t*>(lds + P.m[j].lds_off)[g]
+                                                             : reinterpret_cast<uint64_t*>(lds + P.m[j].lds_off)[g];
+        vh_state_update<J::SCOPE>(P.m[j].state, xo + g, J::m_sop[j], bits);
+      }
+    }
+  }
+}

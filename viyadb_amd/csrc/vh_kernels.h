@@ -525,7 +525,7 @@ __device__ __forceinline__ void vh_distinct_update(const VhPlanDev& P, int b, un
 }
 
 // ------------------------------------------------------------ scan + aggregate
-enum { VH_MODE_DENSE_LDS = 1, VH_MODE_DENSE_GLOBAL = 2, VH_MODE_HASH = 3, VH_MODE_DENSE_PART = 4 };
+// (VH_MODE_*: vh_internal.h)
 
 // One surviving row (one per active lane, lanes are dense after compaction):
 // build the AggTuple key, then Update every selected metric.
@@ -944,10 +944,11 @@ __device__ __forceinline__ void vh_part_tile_runs(const VhPlanDev& P, VhPartTile
 // drain of the wave continues the same line, and L2 merges the pieces before the line leaves for HBM (a wave keeps
 // npart lines open: 4096 waves x 13 partitions x 128 B = 7 MB over eight L2s). Measured against collecting 256 tuples in LDS
 // and counting-sorting them like the lanes form does: 4.16 vs 4.38 ms on C3 (profiles/r02/NOTES.md).
-template <int NW, int LEVEL = 1>
+// TWC: the tuple width when the caller knows it at compile time (the per-query kernels of vh_jit.hip), 0 = P.tw
+template <int NW, int LEVEL = 1, int TWC = 0>
 __device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, bool active,
                                                    const uint64_t (&words)[NW], uint32_t p, int lane) {
-  const uint32_t npart = vh_pool_npart<LEVEL>(P), et = vh_pool_et<LEVEL>(P), tw = (uint32_t)P.tw;
+  const uint32_t npart = vh_pool_npart<LEVEL>(P), et = vh_pool_et<LEVEL>(P), tw = TWC ? (uint32_t)TWC : (uint32_t)P.tw;
   const uint64_t act = __ballot(active);
   uint64_t peers = act, mine = act;          // lanes in my survivor's partition / lanes in the partition this lane OWNS
 #pragma unroll
@@ -960,6 +961,7 @@ __device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTil
   }
   const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
   const uint32_t cnt = (uint32_t)lane < npart ? (uint32_t)__popcll(mine) : 0u;
+  if (VH_ABLATE & 16) { if (rank + cnt == 0x12345678u) P.counters[7] = rank; return; }      // measurement build: ranks and counts, nothing behind them
   // room in the owned partition's extent? (a drain's tuples of one partition never straddle extents)
   uint64_t need = __ballot(cnt != 0 && (T.r_ext == ~0u || T.r_fill + cnt > et));
   while (need) {
@@ -990,6 +992,93 @@ __device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTil
       for (int w = 0; w < NW; ++w)
         if ((uint32_t)w < tw) d[w] = words[w];
     }
+  }
+}
+
+// ------------------------------------------------- phase 1 with whole-line writes (two-word tuples, <= 16 partitions)
+// vh_part_direct_add leaves a partition's tuples of one drain as a ~5-tuple piece of a 128-byte line; the next drain of the
+// wave continues the line ~20 us later, after the L2 has seen megabytes of streamed columns and gathered records, and what
+// reaches HBM are partial lines (round 3: the same tuples written as whole aligned lines cost 0.19 ms less per 50 M; a plain
+// contiguous stream another 0.16 ms less). Here every partition keeps ONE line's worth of tuples (8 x 16 B) of LDS per wave:
+// a drain's tuples first complete that line — which four lanes then read back and store whole —, whole lines in the middle
+// of the drain's run go out straight from the registers (eight consecutive ranks = one aligned line in one store
+// instruction), and the remainder (< 8 tuples) waits in LDS for the next drain. Extents only ever see aligned 128-byte
+// lines, except for the one partial line that closes an extent (or the kernel).
+// Lane p owns partition p: T.r_ext = its extent, T.r_fill = tuples of it already in HBM (a multiple of 8), r_stage = tuples waiting in LDS.
+#define VH_STAGE_PARTS 16
+#define VH_STAGE_BYTES (VH_STAGE_PARTS * 128)      // per wave
+struct VhPartStage { uint32_t r_stage; uint64_t* lines; };     // lines: LDS [VH_STAGE_PARTS][8][2]
+typedef uint64_t vh_u64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void vh_part_stage_close(const VhPlanDev& P, VhPartTile& T, VhPartStage& S, int q, int lane) {   // wave-uniform q
+  const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, q), fill = __builtin_amdgcn_readlane(T.r_fill, q), st = __builtin_amdgcn_readlane(S.r_stage, q);
+  if (old == ~0u) return;
+  const uint32_t et = (uint32_t)P.ext_tuples;
+  if ((uint32_t)lane < st) reinterpret_cast<vh_u64x2*>(P.tuples)[(uint64_t)old * et + fill + lane] = reinterpret_cast<const vh_u64x2*>(S.lines)[q * 8 + lane];
+  if (lane == 0) P.extent_missing[old] = (uint16_t)(et - (fill + st));
+}
+
+__device__ __forceinline__ void vh_part_staged_add(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, VhPartStage& S, bool active,
+                                                   const uint64_t (&words)[2], uint32_t p, int lane) {
+  const uint32_t npart = (uint32_t)P.npart, et = (uint32_t)P.ext_tuples;
+  const uint64_t act = __ballot(active);
+  uint64_t peers = act, mine = act;
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    if ((npart - 1u) >> b) {
+      const uint64_t bal = __ballot((p >> b) & 1u);
+      peers &= ((p >> b) & 1u) ? bal : ~bal;
+      mine &= (((uint32_t)lane >> b) & 1u) ? bal : ~bal;
+    }
+  }
+  const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
+  const uint32_t cnt = (uint32_t)lane < npart ? (uint32_t)__popcll(mine) : 0u;
+  // room in the owned partition's extent for what is staged plus this drain's tuples?
+  uint64_t need = __ballot(cnt != 0 && (T.r_ext == ~0u || T.r_fill + S.r_stage + cnt > et));
+  while (need) {
+    const int q = __builtin_ctzll(need);
+    need &= need - 1;
+    vh_part_stage_close(P, T, S, q, lane);       // what waits in LDS closes the old extent as a partial line
+    const uint32_t ext = vh_part_new_extent<1>(P, W, q, lane);
+    if (lane == q) { T.r_ext = ext; T.r_fill = 0; S.r_stage = 0; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  vh_u64x2* const lines = reinterpret_cast<vh_u64x2*>(S.lines);
+  vh_u64x2* const pool = reinterpret_cast<vh_u64x2*>(P.tuples);
+  const uint32_t packed = T.r_fill | (S.r_stage << 16) | (cnt << 24);        // fill < 65536 (extent_missing is 16 bits wide), stage < 8, cnt <= 64
+  const uint32_t sp = active ? p : 0u;
+  const uint32_t pe = (uint32_t)__shfl((int)T.r_ext, (int)sp), pk = (uint32_t)__shfl((int)packed, (int)sp);
+  const uint32_t g = pk & 0xFFFFu, f = (pk >> 16) & 0xFFu, c = pk >> 24;
+  const uint32_t i = f + rank, whole = (f + c) & ~7u;                          // my tuple's place behind the extent's HBM part; tuples of the run that form whole lines
+  const bool ok = active && pe != ~0u;                                         // ~0: tuple pool exhausted, the host re-runs (VH_ERR_PART_FULL)
+  vh_u64x2 v; v.x = words[0]; v.y = words[1];
+  if (ok && i < 8u) lines[p * 8u + i] = v;                                     // completes the waiting line (or just waits with it)
+  __builtin_amdgcn_wave_barrier();
+  {   // the waiting line of every partition that now has eight tuples: lane l stores quarter l & 3 of partition l >> 2
+    const uint32_t q = (uint32_t)lane >> 2, part4 = (uint32_t)lane & 3u;
+    const uint32_t qe = (uint32_t)__shfl((int)T.r_ext, (int)q), qk = (uint32_t)__shfl((int)packed, (int)q);
+    const uint32_t qg = qk & 0xFFFFu, qf = (qk >> 16) & 0xFFu, qc = qk >> 24;
+    if (q < npart && qe != ~0u && qc != 0 && qf + qc >= 8u) {
+      const vh_u64x2 a = lines[q * 8u + part4 * 2u], b2 = lines[q * 8u + part4 * 2u + 1u];
+      vh_u64x2* d = pool + (uint64_t)qe * et + qg + part4 * 2u;
+      d[0] = a; d[1] = b2;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (ok && i >= 8u) {
+    if (i < whole) pool[(uint64_t)pe * et + g + i] = v;                        // a whole line in the middle of the run: eight consecutive ranks, one store instruction
+    else lines[p * 8u + (i - whole)] = v;                                      // the remainder waits for the next drain
+  }
+  if (T.r_ext != ~0u) { const uint32_t tot = S.r_stage + cnt; T.r_fill += tot & ~7u; S.r_stage = tot & 7u; }
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void vh_part_stage_finish(const VhPlanDev& P, VhPartTile& T, VhPartStage& S, int lane) {   // open extents are closed with what they hold
+  uint64_t open = __ballot(T.r_ext != ~0u);
+  while (open) {
+    const int q = __builtin_ctzll(open);
+    open &= open - 1;
+    vh_part_stage_close(P, T, S, q, lane);
   }
 }
 

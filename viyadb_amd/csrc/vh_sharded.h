@@ -67,22 +67,48 @@ struct vh_comm {
   // same set: a query whose plan is in the cache skips the all-gather of step 1 (a 128-byte verdict all-reduce is then the
   // only host-visible collective of a dense query). A rank whose table changed since still plans with the cached agreement
   // and says so in the verdict; all ranks then drop the entry and agree afresh.
-  struct Agreement { VhAgreed ag; uint64_t sync_epoch; };
+  struct Agreement { VhAgreed ag; uint64_t local_state; };     // local_state: plan_local_state() of THIS rank when the agreement was made
   std::map<std::string, Agreement> agreed;
 };
 
+// The cache key must be the SAME on every rank that issues the same query, or ranks disagree on whether step 1's all-gather
+// happens and the collectives no longer match (all-gather against all-reduce on one communicator). So it holds only what all
+// ranks necessarily share — the structure of the query: filter nodes without their padding, group columns without
+// dictionary sizes or rollup boundaries, metrics, HAVING, flags, top-N. Everything a rank may see differently — its segment
+// snapshot, its literals (a `now`-derived bound), its dictionaries' sizes, its table's contents — goes into plan_local_state
+// instead: a rank whose local state differs from the one the agreement was made under still takes the cached agreement, says
+// "changed" in the verdict, and ALL ranks then drop the entry and agree afresh.
 static std::string plan_signature(const vh_plan* p) {
   std::string k;
-  auto add = [&](const void* d, size_t n) { k.append(static_cast<const char*>(d), n); k.push_back('|'); };
-  if (p->nfilter) add(p->filter, sizeof(vh_filter_node) * p->nfilter);
-  if (p->nlits) add(p->lits, sizeof(vh_anynum) * p->nlits);
-  if (p->ngroups) add(p->groups, sizeof(vh_group_col) * p->ngroups);
-  if (p->nmetrics) add(p->metrics, sizeof(int32_t) * p->nmetrics);
-  if (p->nhaving) add(p->having, sizeof(vh_filter_node) * p->nhaving);
-  if (p->seg_rows) add(p->seg_rows, sizeof(uint64_t) * p->nseg);
-  const uint64_t tail[6] = {p->flags, p->groups_hint, (uint64_t)p->top_col, (uint64_t)p->top_desc, p->top_k, p->seg_rows ? p->nseg : ~0ull};
-  add(tail, sizeof(tail));
+  auto put = [&](long long v) { k += std::to_string(v); k.push_back(','); };
+  put(p->nfilter);
+  for (int i = 0; i < p->nfilter; ++i) { const vh_filter_node& n = p->filter[i]; put(n.kind); put(n.col); put(n.op); put(n.count); put(n.lit); }
+  put(p->nlits); put(p->ngroups);
+  for (int i = 0; i < p->ngroups; ++i) {
+    const vh_group_col& g = p->groups[i];
+    put(g.col); put(g.granularity); put(g.nrollup); put(g.micro);
+    for (int r = 0; r < g.nrollup && r < VH_MAX_ROLLUP; ++r) put(g.rollup_unit[r]);
+  }
+  put(p->nmetrics);
+  for (int j = 0; j < p->nmetrics; ++j) put(p->metrics[j]);
+  put(p->nhaving);
+  for (int i = 0; i < p->nhaving; ++i) { const vh_filter_node& n = p->having[i]; put(n.kind); put(n.col); put(n.op); put(n.count); put(n.lit); }
+  put(p->flags); put((long long)p->groups_hint); put(p->top_col); put(p->top_desc); put((long long)p->top_k);
   return k;
+}
+static uint64_t plan_local_state(const vh_plan* p, const vh_table* t) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void* d, size_t n) { const unsigned char* c = static_cast<const unsigned char*>(d); for (size_t i = 0; i < n; ++i) h = (h ^ c[i]) * 1099511628211ull; };
+  for (int i = 0; i < p->nlits; ++i) mix(&p->lits[i].u64, 8);
+  for (int i = 0; i < p->ngroups; ++i) {
+    mix(&p->groups[i].cardinality, 8);
+    for (int r = 0; r < p->groups[i].nrollup && r < VH_MAX_ROLLUP; ++r) mix(&p->groups[i].rollup_before[r], 8);
+  }
+  const uint64_t ns = p->seg_rows ? p->nseg : ~0ull;
+  mix(&ns, 8);
+  if (p->seg_rows) mix(p->seg_rows, sizeof(uint64_t) * p->nseg);
+  mix(&t->sync_epoch, 8);
+  return h;
 }
 
 static int rccl_allgather_host(void* ctx, const void* send, void* recv, uint64_t bytes) {
@@ -280,6 +306,23 @@ static int merge_table_bitset(vh_table* tt, uint32_t seg, int col, uint64_t nrow
   return VH_OK;
 }
 
+// Collective status point. Between two collectives of one sharded query a rank may fail on its own (an allocation, a kernel
+// launch, a full pool): returning there would leave its peers blocked in the next collective, holding their communicator's
+// lock. Instead every rank carries its local status to the next status point, where all of them learn of it and all of them
+// return — the failing rank its own error, the others "failed on rank p".
+static int agree_status(vh_comm* comm, int lrc, const char* what) {
+  char own[sizeof(g_err)];
+  snprintf(own, sizeof(own), "%s", g_err);
+  const int32_t mine = lrc;
+  std::vector<int32_t> all((size_t)comm->world, 0);
+  if (int rc = comm->ops.allgather_host(comm->ops.ctx, &mine, all.data(), sizeof(int32_t)))
+    return rc < 0 ? rc : vh_fail(VH_E_DEVICE, "status exchange before %s failed (%d)", what, rc);
+  if (lrc) return vh_fail(lrc, "%s", own);
+  for (int p = 0; p < comm->world; ++p)
+    if (all[p]) return vh_fail(VH_E_DEVICE, "%s: failed on rank %d (status %d)", what, p, (int)all[p]);
+  return VH_OK;
+}
+
 // 4b of the header comment: key-partitioned exchange of the partial groups (and of the distinct (group, id) pairs of every
 // bitset metric), merge by re-aggregation on the owner, gather on root. `r` is this rank's finalised partial result.
 static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int root, vh_result* r, const unsigned long long* gflags,
@@ -294,32 +337,42 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
   const int nbs = (int)bitset_js.size();
   const int ncols = nk + nm + (has_hidden ? 1 : 0);
 
+  // Local failures between collectives are carried to the next status point (agree_status / the status word of the counts
+  // all-gather), never returned on the spot: see agree_status.
+  int lrc = VH_OK;
+  char lerr[sizeof(g_err)] = "";
+  auto keep = [&](int rc) { if (rc && !lrc) { lrc = rc; snprintf(lerr, sizeof(lerr), "%s", g_err); } return rc; };
+  auto own_error = [&]() { return vh_fail(lrc, "%s", lerr); };
   // ---- 1. regroup by owner, in HBM
-  std::vector<uint64_t> goffs(W + 1);
+  std::vector<uint64_t> goffs(W + 1, 0);
   std::vector<vh_device_buffer> gbufs(ncols);
   int32_t nb = 0;
-  if (int rc = vh_result_partition(r, (uint32_t)W, goffs.data(), gbufs.data(), ncols, &nb)) return rc;
-  std::vector<std::vector<uint64_t>> poffs(nbs, std::vector<uint64_t>(W + 1));
+  keep(vh_result_partition(r, (uint32_t)W, goffs.data(), gbufs.data(), ncols, &nb));
+  std::vector<std::vector<uint64_t>> poffs(nbs, std::vector<uint64_t>(W + 1, 0));
   std::vector<std::vector<vh_device_buffer>> pbufs(nbs, std::vector<vh_device_buffer>(nk + 1));
-  for (int s = 0; s < nbs; ++s) {
+  for (int s = 0; s < nbs && !lrc; ++s) {
     int32_t n = 0;
-    if (int rc = vh_result_partition_pairs(r, bitset_js[s], (uint32_t)W, poffs[s].data(), pbufs[s].data(), nk + 1, &n)) return rc;
+    keep(vh_result_partition_pairs(r, bitset_js[s], (uint32_t)W, poffs[s].data(), pbufs[s].data(), nk + 1, &n));
   }
-  // ---- 2. who sends how much to whom
+  // ---- 2. who sends how much to whom (+ one status word per rank)
   const int sets = 1 + nbs;
-  std::vector<uint64_t> mine((size_t)sets * W), all((size_t)W * sets * W);
-  for (int p = 0; p < W; ++p) {
+  const size_t cw = (size_t)sets * W + 1;
+  std::vector<uint64_t> mine(cw, 0), all((size_t)W * cw);
+  for (int p = 0; p < W && !lrc; ++p) {
     mine[p] = goffs[p + 1] - goffs[p];
     for (int s = 0; s < nbs; ++s) mine[(size_t)(1 + s) * W + p] = poffs[s][p + 1] - poffs[s][p];
   }
-  if (int rc = comm->ops.allgather_host(comm->ops.ctx, mine.data(), all.data(), mine.size() * sizeof(uint64_t))) return rc ? (rc < 0 ? rc : vh_fail(VH_E_DEVICE, "all-gather of the exchange counts failed (%d)", rc)) : rc;
+  mine[cw - 1] = lrc ? 1 : 0;
+  if (int rc = comm->ops.allgather_host(comm->ops.ctx, mine.data(), all.data(), cw * sizeof(uint64_t))) return rc < 0 ? rc : vh_fail(VH_E_DEVICE, "all-gather of the exchange counts failed (%d)", rc);
+  if (lrc) return own_error();
+  for (int p = 0; p < W; ++p) if (all[(size_t)p * cw + cw - 1]) return vh_fail(VH_E_DEVICE, "regrouping the partial groups failed on rank %d", p);
   std::vector<std::vector<uint64_t>> roff(sets, std::vector<uint64_t>(W + 1, 0));
   uint64_t maxrows = 1;
   for (int s = 0; s < sets; ++s) {
-    for (int p = 0; p < W; ++p) roff[s][p + 1] = roff[s][p] + all[(size_t)p * sets * W + (size_t)s * W + R];
+    for (int p = 0; p < W; ++p) roff[s][p + 1] = roff[s][p] + all[(size_t)p * cw + (size_t)s * W + R];
     maxrows = std::max(maxrows, roff[s][W]);
   }
-  if (maxrows > 0xFFFF0000ull) return vh_fail(VH_E_UNSUPPORTED, "a rank would own %llu partial rows", (unsigned long long)maxrows);
+  if (maxrows > 0xFFFF0000ull) keep(vh_fail(VH_E_UNSUPPORTED, "a rank would own %llu partial rows", (unsigned long long)maxrows));
 
   // ---- 3. the merge table: [key columns, the plan's metrics (value metrics as their merge aggregation, bitset metrics as
   // bitsets), hidden count]; segment 0 = the group rows received, segment 1 + s = the pairs of bitset metric s
@@ -327,16 +380,21 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
   for (int i = 0; i < nk; ++i) cd[i] = vh_col_desc{VH_DIM_NUMERIC, (int32_t)P.g[i].type()};
   for (int j = 0; j < nm; ++j) {
     const int col = plan->metrics[j];
-    if (col == VH_COL_ROWID) return vh_fail(VH_E_UNSUPPORTED, "search (VH_COL_ROWID) over a sharded table: storage positions are per rank");
+    if (col == VH_COL_ROWID) { keep(vh_fail(VH_E_UNSUPPORTED, "search (VH_COL_ROWID) over a sharded table: storage positions are per rank")); cd[nk + j] = vh_col_desc{VH_METRIC_SUM, VH_U64}; continue; }
     const VhColumn& c = t->cols[col];
     cd[nk + j] = c.kind == VH_METRIC_BITSET ? vh_col_desc{VH_METRIC_BITSET, c.elem} : vh_col_desc{merge_kind_of(c.kind), c.elem};
   }
   if (has_hidden) cd[nk + nm] = vh_col_desc{VH_METRIC_SUM, VH_U64};
   vh_table* tt = nullptr;
-  if (int rc = vh_table_create(cd.data(), ncols, maxrows, (uint32_t)sets, &tt)) return rc;
+  if (!lrc) keep(vh_table_create(cd.data(), ncols, maxrows, (uint32_t)sets, &tt));
   struct TableGuard { vh_table* t; ~TableGuard() { if (t) vh_table_destroy(t); } } guard{tt};
   std::vector<char*> d_ids(nbs, nullptr);
   struct IdsGuard { std::vector<char*>& v; ~IdsGuard() { for (char* p : v) if (p) (void)hipFree(p); } } ids_guard{d_ids};
+  for (int s = 0; s < nbs && !lrc; ++s) {
+    const size_t idsz = tt->cols[nk + bitset_js[s]].elem == VH_BITSET32 ? 4 : 8;
+    if (hipMalloc((void**)&d_ids[s], std::max<size_t>(roff[1 + s][W] * idsz, 8)) != hipSuccess) keep(vh_fail(VH_E_NOMEM, "no memory for %llu received ids", (unsigned long long)roff[1 + s][W]));
+  }
+  if (int rc = agree_status(comm, lrc, "building the merge table")) return rc;      // every receive buffer of the exchange exists on every rank
 
   // ---- 4. exchange, straight into the merge table's column arenas
   {
@@ -351,7 +409,6 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
   for (int s = 0; s < nbs; ++s) {
     const int bcol = nk + bitset_js[s];
     const size_t idsz = tt->cols[bcol].elem == VH_BITSET32 ? 4 : 8;
-    HIP_TRY(hipMalloc((void**)&d_ids[s], std::max<size_t>(roff[1 + s][W] * idsz, 8)));
     std::vector<const void*> send; std::vector<void*> recv; std::vector<uint32_t> es;
     for (int i = 0; i < nk; ++i) { send.push_back(pbufs[s][i].ptr); recv.push_back(tt->cols[i].base + (size_t)(1 + s) * tt->cols[i].stride); es.push_back((uint32_t)tt->cols[i].esize); }
     send.push_back(pbufs[s][nk].ptr); recv.push_back(d_ids[s]); es.push_back((uint32_t)idsz);
@@ -359,55 +416,63 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
       return rc < 0 ? rc : vh_fail(VH_E_DEVICE, "exchange of the distinct pairs failed (%d)", rc);
   }
   // ---- 5. what was not received: identities (a pair row leaves every value state unchanged), empty sets (a group row adds no id)
-  for (int s = 0; s < sets; ++s) {
-    const uint64_t n = roff[s][W];
-    for (int c = nk; c < ncols; ++c) {
-      VhColumn& col = tt->cols[c];
-      if (is_bitset_elem(col.elem)) {
-        const bool own = s > 0 && c == nk + bitset_js[s - 1];
-        if (int rc = merge_table_bitset(tt, (uint32_t)s, c, n, own ? d_ids[s - 1] : nullptr, st)) return rc;
-        continue;
-      }
-      if (s == 0 || !n) continue;
-      int sop; uint64_t ident;
-      if (sop_for(col.kind, col.elem, &sop, &ident)) return vh_fail(VH_E_DEVICE, "merge table: no identity for column %d", c);
-      char* dst = col.base + (size_t)s * col.stride;
-      const unsigned grid = (unsigned)std::min<uint64_t>(2048, (n + 255) / 256);
-      VH_ELEM_SWITCH(col.elem, (fill_kernel<T><<<dim3(grid), dim3(256), 0, st>>>(reinterpret_cast<T*>(dst), n, vh_lit_host<T>(ident))));
-    }
-    tt->seg_rows[s] = n;
-    tt->seg_mod[s] = ++tt->sync_epoch;
-  }
-  HIP_TRY(hipGetLastError());
-  tt->nseg = (uint32_t)sets;
-  HIP_TRY(hipStreamSynchronize(st));
-  if (int rc = refresh_stats(tt, 0, (uint32_t)sets)) return rc;
-
-  // ---- 6. merge by re-aggregation; HAVING and top-N see merged groups
   std::vector<vh_group_col> mg(nk);
-  for (int i = 0; i < nk; ++i) { memset(&mg[i], 0, sizeof(vh_group_col)); mg[i].col = i; mg[i].granularity = VH_T_NONE; }
   std::vector<int32_t> mm;
-  for (int j = 0; j < nm + (has_hidden ? 1 : 0); ++j) mm.push_back(nk + j);
-  vh_plan mp{};
-  mp.groups = mg.data(); mp.ngroups = nk; mp.metrics = mm.data(); mp.nmetrics = (int32_t)mm.size();
-  mp.lits = plan->lits; mp.nlits = plan->nlits; mp.having = plan->having; mp.nhaving = plan->nhaving;
-  mp.top_col = plan->top_col; mp.top_desc = plan->top_desc; mp.top_k = plan->top_k;
-  mp.groups_hint = roff[0][W];
   vh_result* rm = nullptr;
-  if (int rc = query_agg_device_rows(tt, &mp, &rm)) return rc;
+  auto merge_locally = [&]() -> int {
+    for (int s = 0; s < sets; ++s) {
+      const uint64_t n = roff[s][W];
+      for (int c = nk; c < ncols; ++c) {
+        VhColumn& col = tt->cols[c];
+        if (is_bitset_elem(col.elem)) {
+          const bool own = s > 0 && c == nk + bitset_js[s - 1];
+          if (int rc = merge_table_bitset(tt, (uint32_t)s, c, n, own ? d_ids[s - 1] : nullptr, st)) return rc;
+          continue;
+        }
+        if (s == 0 || !n) continue;
+        int sop; uint64_t ident;
+        if (sop_for(col.kind, col.elem, &sop, &ident)) return vh_fail(VH_E_DEVICE, "merge table: no identity for column %d", c);
+        char* dst = col.base + (size_t)s * col.stride;
+        const unsigned grid = (unsigned)std::min<uint64_t>(2048, (n + 255) / 256);
+        VH_ELEM_SWITCH(col.elem, (fill_kernel<T><<<dim3(grid), dim3(256), 0, st>>>(reinterpret_cast<T*>(dst), n, vh_lit_host<T>(ident))));
+      }
+      tt->seg_rows[s] = n;
+      tt->seg_mod[s] = ++tt->sync_epoch;
+    }
+    HIP_TRY(hipGetLastError());
+    tt->nseg = (uint32_t)sets;
+    HIP_TRY(hipStreamSynchronize(st));
+    if (int rc = refresh_stats(tt, 0, (uint32_t)sets)) return rc;
+    // ---- 6. merge by re-aggregation; HAVING and top-N see merged groups
+    for (int i = 0; i < nk; ++i) { memset(&mg[i], 0, sizeof(vh_group_col)); mg[i].col = i; mg[i].granularity = VH_T_NONE; }
+    for (int j = 0; j < nm + (has_hidden ? 1 : 0); ++j) mm.push_back(nk + j);
+    vh_plan mp{};
+    mp.groups = mg.data(); mp.ngroups = nk; mp.metrics = mm.data(); mp.nmetrics = (int32_t)mm.size();
+    mp.lits = plan->lits; mp.nlits = plan->nlits; mp.having = plan->having; mp.nhaving = plan->nhaving;
+    mp.top_col = plan->top_col; mp.top_desc = plan->top_desc; mp.top_k = plan->top_k;
+    mp.groups_hint = roff[0][W];
+    return query_agg_device_rows(tt, &mp, &rm);
+  };
+  keep(merge_locally());
   std::unique_ptr<vh_result> rm_holder(rm);
-  if (has_hidden) { rm->user_metric.resize(nm); rm->info.has_hidden_count = 1; rm->info.nmetrics = nm; }
-  rm->info.scanned_recs = gflags[4]; rm->info.scanned_segments = gflags[5]; rm->info.passed_recs = gflags[6];
-  rm->info.path = VH_PATH_HASH;
-  rm->info.scan_kernel_ms = r->info.scan_kernel_ms; rm->info.algorithmic_bytes = r->info.algorithmic_bytes; rm->info.retries = r->info.retries;
-  rm->kernel = r->kernel;
+  if (rm) {
+    if (has_hidden) { rm->user_metric.resize(nm); rm->info.has_hidden_count = 1; rm->info.nmetrics = nm; }
+    rm->info.scanned_recs = gflags[4]; rm->info.scanned_segments = gflags[5]; rm->info.passed_recs = gflags[6];
+    rm->info.path = VH_PATH_HASH;
+    rm->info.scan_kernel_ms = r->info.scan_kernel_ms; rm->info.algorithmic_bytes = r->info.algorithmic_bytes; rm->info.retries = r->info.retries;
+    rm->kernel = r->kernel;
+  }
 
   // ---- 7. how many groups everywhere; leave the rows with their owners or gather them on root
-  uint64_t cnt[2] = {rm->ngroups_host, rm->info.ngroups};
-  std::vector<uint64_t> cnts((size_t)W * 2);
+  uint64_t cnt[3] = {rm ? rm->ngroups_host : 0, rm ? rm->info.ngroups : 0, lrc ? 1ull : 0ull};      // (+ this rank's status)
+  std::vector<uint64_t> cnts((size_t)W * 3);
   if (int rc = comm->ops.allgather_host(comm->ops.ctx, cnt, cnts.data(), sizeof(cnt))) return rc < 0 ? rc : vh_fail(VH_E_DEVICE, "all-gather of the group counts failed (%d)", rc);
+  if (lrc) return own_error();
   uint64_t total_rows = 0, total_groups = 0;
-  for (int p = 0; p < W; ++p) { total_rows += cnts[(size_t)p * 2]; total_groups += cnts[(size_t)p * 2 + 1]; }
+  for (int p = 0; p < W; ++p) {
+    if (cnts[(size_t)p * 3 + 2]) return vh_fail(VH_E_DEVICE, "merging the exchanged groups failed on rank %d", p);
+    total_rows += cnts[(size_t)p * 3]; total_groups += cnts[(size_t)p * 3 + 1];
+  }
   rm->info.ngroups = total_groups;
   if (root < 0) {
     rm->owned_table = tt; guard.t = nullptr;
@@ -429,8 +494,9 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
   const uint64_t cap_rows = R == root ? std::max<uint64_t>(total_rows, 1) : 1;
   for (int i = 0; i < nk; ++i) { rf->off_key[i] = bytes; bytes += (cap_rows * vh_elem_size(rm->plan.g[i].type()) + 255) / 256 * 256; }
   for (int u = 0; u < ndev; ++u) { rf->off_state[u] = bytes; bytes += (cap_rows * vh_elem_size(rm->metric_elem[u]) + 255) / 256 * 256; }
-  HIP_TRY(hipMalloc((void**)&rf->d_own, bytes));
-  HIP_TRY(hipHostMalloc((void**)&rf->h_own, bytes, hipHostMallocDefault));
+  if (hipMalloc((void**)&rf->d_own, bytes) != hipSuccess || hipHostMalloc((void**)&rf->h_own, bytes, hipHostMallocDefault) != hipSuccess)
+    keep(vh_fail(VH_E_NOMEM, "no memory for %llu gathered groups", (unsigned long long)total_rows));
+  if (int rc = agree_status(comm, lrc, "gathering the merged groups")) return rc;
   for (int i = 0; i < nk; ++i) {
     send.push_back(rm->topk_active ? rm->d_out_key2[i] : rm->d_out_key[i]); recv.push_back(rf->d_own + rf->off_key[i]); es.push_back((uint32_t)vh_elem_size(rm->plan.g[i].type()));
   }
@@ -439,7 +505,7 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
   }
   std::vector<uint64_t> soff(W + 1, 0), goff(W + 1, 0);
   for (int p = 0; p <= W; ++p) soff[p] = p > root ? rm->ngroups_host : 0;          // everything goes to root
-  if (R == root) for (int p = 0; p < W; ++p) goff[p + 1] = goff[p] + cnts[(size_t)p * 2];
+  if (R == root) for (int p = 0; p < W; ++p) goff[p + 1] = goff[p] + cnts[(size_t)p * 3];
   hipStream_t st2 = rm->exec->stream();
   if (int rc = comm->ops.alltoallv_device(comm->ops.ctx, (int32_t)send.size(), send.data(), recv.data(), es.data(), soff.data(), goff.data(), st2))
     return rc < 0 ? rc : vh_fail(VH_E_DEVICE, "gather of the merged groups failed (%d)", rc);
@@ -467,6 +533,7 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
   VhReplan rp;
   char local_err[sizeof(g_err)] = "";
   const std::string sig = plan_signature(plan);
+  const uint64_t local_state = plan_local_state(plan, t);       // (the table cannot change under a sharded query's first attempt: syncs take comm-independent locks, but this rank's caller is here)
   for (uint32_t attempt = 0; attempt < 12; ++attempt) {
     // ---- 1. agree on what to plan with (or take the agreement this plan got last time)
     VhAgreed ag{};
@@ -474,7 +541,7 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
     bool cached = false, changed = false;
     if (attempt == 0) {
       auto hit = comm->agreed.find(sig);
-      if (hit != comm->agreed.end()) { ag = hit->second.ag; cached = true; changed = hit->second.sync_epoch != t->sync_epoch; }
+      if (hit != comm->agreed.end()) { ag = hit->second.ag; cached = true; changed = hit->second.local_state != local_state; }
     }
     if (!cached) {
       VhSummary mine{};
@@ -489,7 +556,7 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
       merge_summaries(all.data(), W, plan->ngroups, &ag, &rp, &fatal);
       if (fatal) { comm->agreed.clear(); return lrc ? vh_fail(lrc, "%s", local_err) : vh_fail(VH_E_INVALID, "another rank rejected the plan"); }
       if (comm->agreed.size() >= 64) comm->agreed.clear();
-      comm->agreed[sig] = vh_comm::Agreement{ag, t->sync_epoch};
+      comm->agreed[sig] = vh_comm::Agreement{ag, plan_local_state(plan, t)};
     }
 
     // ---- 2. scan this rank's shard with the agreed plan

@@ -11,6 +11,7 @@
 //     private dense tables in HBM/L2, or an open-addressing hash table in HBM).
 #include "vh_small_kernels.h"
 #include "vh_launch.h"
+#include "vh_jit.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -1054,7 +1055,7 @@ static bool segment_passes(const vh_table* t, const vh_plan* p, uint32_t seg) {
 // Decides between direct global atomics (cheap per query, ~30-60 G updates/s) and radix-partitioned
 // LDS aggregation (two passes over 16 B per survivor, but no global atomics).
 static int estimate_selectivity(vh_table* t, VhExec* x, const VhPlanDev& P, const std::vector<VhProgOp>& prog, const std::vector<uint64_t>& lits, uint32_t nseg,
-                                double* sel, uint64_t* passed_out = nullptr, uint64_t* sampled_out = nullptr) {
+                                double* sel, uint64_t* passed_out = nullptr, uint64_t* sampled_out = nullptr, bool generic = false) {
   const uint32_t kRows = 16384;
   const size_t rows_bytes = ((size_t)std::max<uint32_t>(nseg, 1) * sizeof(uint32_t) + 7) / 8 * 8;
   const size_t need = 256 + 256 + rows_bytes + prog.size() * sizeof(VhProgOp) + lits.size() * sizeof(uint64_t);
@@ -1085,7 +1086,9 @@ static int estimate_selectivity(vh_table* t, VhExec* x, const VhPlanDev& P, cons
   HIP_TRY(hipMemcpyAsync(const_cast<VhProgOp*>(S.prog), prog.data(), prog.size() * sizeof(VhProgOp), hipMemcpyHostToDevice, st));
   if (!lits.empty()) HIP_TRY(hipMemcpyAsync(const_cast<uint64_t*>(S.lits), lits.data(), lits.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
   const size_t qbytes = (size_t)16 * VhScanCfg<1024>::kQueueCap * sizeof(uint32_t);
-  vh_launch_scan_fast_lds(S, (int)std::min<uint32_t>(nseg, (uint32_t)g_ctx.num_cu), 16 + qbytes, false, st);
+  // (generic: predicate columns of other widths than 4 bytes — plans only the per-query compiled kernels run register-resident)
+  if (generic) vh_launch_scan_generic(VH_MODE_DENSE_LDS, S, (int)std::min<uint32_t>(nseg, (uint32_t)g_ctx.num_cu), 16 + qbytes, false, st);
+  else vh_launch_scan_fast_lds(S, (int)std::min<uint32_t>(nseg, (uint32_t)g_ctx.num_cu), 16 + qbytes, false, st);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(x->h_counters + 8, S.counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
@@ -1147,6 +1150,9 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   // ---------------- column slots
   int slot_of[256];
   for (int i = 0; i < 256; ++i) slot_of[i] = -1;
+  int slot_col[VH_MAX_SLOTS];                    // table column behind a slot (-1: a narrow copy / projection member added later)
+  int slot_rec[VH_MAX_SLOTS], slot_recoff[VH_MAX_SLOTS];   // payload projection a slot reads from (-1: a column arena) and the member's offset in its record
+  for (int i = 0; i < VH_MAX_SLOTS; ++i) { slot_col[i] = -1; slot_rec[i] = -1; slot_recoff[i] = 0; }
   uint64_t bytes_per_row = 0;
   auto slot = [&](int col) -> int {
     if (col < 0 || col >= ncols || col >= 256) return -1;
@@ -1155,6 +1161,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     const VhColumn& c = t->cols[col];
     if (is_bitset_elem(c.elem)) return -2;
     slot_of[col] = P.nslots;
+    slot_col[P.nslots] = col;
     P.colbase[P.nslots] = c.base;
     P.colstride[P.nslots] = c.stride;
     P.colpitch[P.nslots] = (uint32_t)c.esize;
@@ -1263,12 +1270,41 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     memcpy(P.ilits, r->h_lits.data(), r->h_lits.size() * sizeof(uint64_t));
   } else fast_ok = false;                                                       // long programs (IN lists of hundreds of values): the generic kernel
 
+  // ---------------- per-query compiled scan kernel (vh_jit.hip): which predicate columns it would hold packed in registers
+  // Eligible so far: every leaf compares a fixed-width column, the program and its literals fit the kernel arguments, the packed
+  // columns fit VJ_MAX_NV registers. The table organisation decides the rest further down.
+  VhJitShape jshape;
+  int jit_pred_col[VJ_MAX_PRED];
+  bool jit_try = vh_jit_policy() != VH_JIT_OFF && !(p->flags & (VH_PLAN_NO_JIT | VH_PLAN_NO_FAST)) && prog.size() <= VH_INLINE_PROG && r->h_lits.size() <= VH_INLINE_LITS;
+  if (jit_try) {
+    jshape.prog = prog;
+    int nv = 0;
+    for (VhProgOp& o : jshape.prog) {
+      if (o.kind() != VH_F_REL && o.kind() != VH_F_IN) continue;
+      const int es = vh_elem_size((int)o.type());
+      if (!es) { jit_try = false; break; }                       // a bitset metric's cardinality: the generic kernel
+      int ps = -1;
+      for (int k = 0; k < jshape.npred; ++k) if (jshape.pred[k].slot == (int)o.slot()) ps = k;
+      if (ps < 0) {
+        if (jshape.npred >= VJ_MAX_PRED || nv + VH_SUBSTEPS * es > VJ_MAX_NV) { jit_try = false; break; }
+        ps = jshape.npred++;
+        jshape.pred[ps] = VhJitPred{(int)o.slot(), (int)o.type(), es};
+        jit_pred_col[ps] = slot_col[o.slot()];
+        nv += VH_SUBSTEPS * es;
+      }
+      o.set_pslot((uint8_t)ps);
+    }
+    jshape.nlits = (int)r->h_lits.size();
+  }
+
   // Narrow copies of predicate columns (vh_table_narrow; built unasked for a column the third selective query filters on): the
   // register-resident kernels — and the selectivity probe, which is one of them — stream those instead of the 4-byte arenas.
-  if (fast_ok && !(p->flags & VH_PLAN_NO_NARROW)) {
+  if ((fast_ok || jit_try) && !(p->flags & VH_PLAN_NO_NARROW)) {
     static const int auto_after = getenv("VH_AUTO_NARROW") ? atoi(getenv("VH_AUTO_NARROW")) : 3;     // 0: never unasked
-    for (int k = 0; k < P.npred; ++k) {
-      const int col = pred_col[k];
+    std::map<int, int> narrow_slot;          // column -> slot of its narrow copy (looked up, and counted, once per query)
+    auto narrow_for = [&](int col) -> int {
+      auto hit = narrow_slot.find(col);
+      if (hit != narrow_slot.end()) return hit->second;
       bool have = false;
       for (auto& nw : t->narrows) have |= nw->col == col;
       if (!have && auto_after > 0 && narrow_width_for(t, col, t->nseg) && ++t->pred_seen[col] >= (uint32_t)auto_after) {
@@ -1277,14 +1313,30 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + total_b / 4) (void)table_narrow_locked(t, col, true);
         else t->pred_seen[col] = 0;
       }
+      int ns = -1;
       VhNarrow* nw = narrow_usable(t, col, nseg);
       if (nw && P.nslots < VH_MAX_SLOTS) {
         P.colbase[P.nslots] = nw->base; P.colstride[P.nslots] = nw->stride; P.colpitch[P.nslots] = (uint32_t)nw->width;
-        pred_wide_slot[k] = P.pred_slot[k];
-        P.pred_slot[k] = (uint8_t)P.nslots++;
-        P.pred_width[k] = (uint8_t)nw->width;
+        ns = P.nslots++;
       }
-    }
+      return narrow_slot[col] = ns;
+    };
+    if (fast_ok)
+      for (int k = 0; k < P.npred; ++k) {
+        const int ns = narrow_for(pred_col[k]);
+        if (ns < 0) continue;
+        pred_wide_slot[k] = P.pred_slot[k];
+        P.pred_slot[k] = (uint8_t)ns;
+        P.pred_width[k] = (uint8_t)P.colpitch[ns];
+      }
+    if (jit_try)
+      for (int k = 0; k < jshape.npred; ++k) {
+        if (jit_pred_col[k] < 0 || t->cols[jit_pred_col[k]].elem != VH_U32) continue;
+        const int ns = narrow_for(jit_pred_col[k]);
+        if (ns < 0) continue;
+        jshape.pred[k].slot = ns;
+        jshape.pred[k].width = (int)P.colpitch[ns];
+      }
   }
 
   // ---------------- segments: snapshot + skip
@@ -1308,6 +1360,8 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   }
   r->info.scanned_recs = scanned_recs;
   r->info.scanned_segments = scanned_segments;
+  // a compile pays off for scans of some size (or when asked for): small tables keep the interpreting kernels
+  if (jit_try && !(p->flags & VH_PLAN_FORCE_JIT) && vh_jit_policy() != VH_JIT_FORCE && (ag ? ag->rows_max : rows_to_scan) < vh_jit_min_rows()) jit_try = false;
   if (plan_only) {   // vh_query_select: filter program, column slots and the segment snapshot are all it shares
     P.nseg = nseg;
     r->info.algorithmic_bytes = rows_to_scan * bytes_per_row;
@@ -1326,7 +1380,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     key += "|" + std::to_string(nseg) + "|" + std::to_string(rows_to_scan) + "|" + std::to_string(t->sync_epoch);
     auto hit = t->sel_cache.find(key);
     if (hit != t->sel_cache.end()) { probe_passed = hit->second.first; probe_sampled = hit->second.second; *sel = probe_sampled ? (double)probe_passed / (double)probe_sampled : 0.0; return VH_OK; }
-    const int prc = estimate_selectivity(t, x, P, r->h_prog, r->h_lits, nseg, sel, &probe_passed, &probe_sampled);
+    const int prc = estimate_selectivity(t, x, P, r->h_prog, r->h_lits, nseg, sel, &probe_passed, &probe_sampled, !fast_ok);
     if (prc) return prc;
     if (t->sel_cache.size() > 256) t->sel_cache.clear();
     t->sel_cache[key] = std::make_pair(probe_passed, probe_sampled);
@@ -1391,7 +1445,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   if (summary_out) {       // sharded queries, first half: report and stop
     summary_out->rows_to_scan = rows_to_scan;
     double sel = 0;
-    if (fast_ok || p->nfilter == 0) { rc = probed_selectivity(&sel); if (rc) return rc; }
+    if (fast_ok || jit_try || p->nfilter == 0) { rc = probed_selectivity(&sel); if (rc) return rc; }
     summary_out->probe_passed = probe_passed; summary_out->probe_sampled = probe_sampled;
     return VH_OK;
   }
@@ -1559,6 +1613,8 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     mode = VH_MODE_HASH;
   }
   const bool fast = fast_ok && P.ngroup <= VH_FAST_COLS && P.nmetric <= VH_FAST_COLS && P.nbitset == 0;   // npred == 0: no filter
+  if (P.ngroup > VJ_MAX_COLS || P.nmetric > VJ_MAX_COLS || P.nbitset) jit_try = false;
+  const bool fastj = fast || jit_try;       // a register-resident scan: pre-built, or compiled for this plan shape
   // "Lanes" kernel (no compaction) for small LDS tables when most rows pass: see scan_agg_lanes_kernel
   bool lanes = false;
   if (mode == VH_MODE_DENSE_LDS && fast && !(p->flags & VH_PLAN_NO_LANES) && P.ngroup <= VH_LANES_COLS && P.nmetric <= VH_LANES_COLS &&
@@ -1580,7 +1636,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   // for one LDS table but splits into <= VH_MAX_PART LDS-sized ranges, radix-partition the survivors
   // and aggregate each range in LDS instead (DENSE_PART).
   uint64_t part_tuple_cap = 0;
-  if (mode == VH_MODE_DENSE_GLOBAL && fast && !no_part && !(p->flags & (VH_PLAN_NO_PART | VH_PLAN_FORCE_GLOBAL)) && P.nmetric >= 1) {
+  if (mode == VH_MODE_DENSE_GLOBAL && fastj && !no_part && !(p->flags & (VH_PLAN_NO_PART | VH_PLAN_FORCE_GLOBAL)) && P.nmetric >= 1 && P.nmetric <= VH_FAST_COLS) {
     int shift = 0;
     const size_t part_table_bytes = getenv("VH_PART_TABLE_KB") ? (size_t)atoi(getenv("VH_PART_TABLE_KB")) * 1024 : 128 * 1024;   // one 1024-thread block per CU in phase 2 (160 KB LDS)
     // Phase 2 is bound by LDS read-modify-writes at random addresses (about one lane per clock and CU: 50 M tuples x 3 updates =
@@ -1629,7 +1685,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     }
     if (want_part) {
       // most rows pass: build the tuples without compacting survivors first (lanes kernel, phase 1 only)
-      if (!(p->flags & VH_PLAN_NO_LANES) && P.ngroup <= VH_LANES_COLS && P.nmetric <= VH_LANES_COLS && rows_to_scan) {
+      if (fast && !(p->flags & VH_PLAN_NO_LANES) && P.ngroup <= VH_LANES_COLS && P.nmetric <= VH_LANES_COLS && rows_to_scan) {
         bool ok = true;
         for (int i = 0; i < P.ngroup; ++i) ok &= vh_elem_size(P.g[i].type()) >= 4;
         for (int j = 0; j < P.nmetric; ++j) ok &= P.m[j].slot() != VH_SLOT_ROWID && vh_elem_size(P.m[j].type()) >= 4;
@@ -1659,7 +1715,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       P.tw = tw;
       // the drain specialised for "two unsigned 32-bit group columns, SUM(64-bit) + SUM(32-bit)" (vh_consume_fast, SHAPE 1)
       P.shape = 0;
-      if (!lanes && !(p->flags & VH_PLAN_NO_SHAPE) && (P.ngroup == 1 || P.ngroup == 2) && P.nmetric == 2 && tw == 2 && G <= 0xFFFFFFFFull) {
+      if (!jit_try && !lanes && !(p->flags & VH_PLAN_NO_SHAPE) && (P.ngroup == 1 || P.ngroup == 2) && P.nmetric == 2 && tw == 2 && G <= 0xFFFFFFFFull) {   // (a per-query compiled kernel knows the whole plan, not two shapes of it)
         bool ok = true;
         for (int i = 0; i < P.ngroup; ++i)
           ok &= (P.g[i].type() == VH_U32 || P.g[i].type() == VH_U16 || P.g[i].type() == VH_U8) && P.g[i].gran() == VH_T_NONE && P.g[i].nroll() == 0 && P.g[i].lo <= 0xFFFFFFFFull &&
@@ -1797,7 +1853,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     if (want && !forced) {
       // lines touched per survivor: one record vs one per column; the projection stops paying off once most lines of
       // the arenas are touched anyway (C3 columns: ~20 % of the rows passing)
-      want = fast && p->nfilter > 0;
+      want = fastj && p->nfilter > 0;
       if (want) {
         double sel = 1.0;
         rc = probed_selectivity(&sel);
@@ -1839,11 +1895,75 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         P.colbase[P.nslots] = use->base + use->off[k];
         P.colstride[P.nslots] = use->stride;
         P.colpitch[P.nslots] = use->rec_bytes;
+        slot_rec[P.nslots] = 0; slot_recoff[P.nslots] = (int)use->off[k];
         return pslot_of[col] = P.nslots++;
       };
       for (int i = 0; i < p->ngroups; ++i) P.g[i].set_slot((uint16_t)pslot(p->groups[i].col));
       for (int j = 0; j < P.nmetric; ++j) if (metric_col[j] >= 0) P.m[j].set_slot((uint16_t)pslot(metric_col[j]));
       packed = true;
+    }
+  }
+
+  // ---------------- the scan kernel compiled for this plan shape (vh_jit.hip), when there is to be one
+  VhJitKernel* jk = nullptr;
+  int jit_block = 256;
+  if (jit_try && lanes) jit_try = false;          // the no-compaction kernels are pre-built only
+  if (jit_try) {
+    VhJitShape& js = jshape;
+    js.mode = mode;
+    const size_t qw = (size_t)VJ_QUEUE_CAP * sizeof(uint32_t);       // per wave
+    if (mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) {          // an LDS table per block: the widest block whose table + queues stay within the 64 KB a module kernel may ask for
+      jit_block = mode == VH_MODE_DENSE_LDS ? 1024 : 512;
+      while (jit_block > 256 && lds_table + (size_t)(jit_block / 64) * qw > 64 * 1024) jit_block /= 2;
+      if (lds_table + (size_t)(jit_block / 64) * qw > 64 * 1024) jit_try = false;
+      if (mode == VH_MODE_HASH && !P.lds_hash_slots) jit_block = 256;
+    }
+    js.block = jit_block;
+    static const int env_ablate = getenv("VH_JIT_ABLATE") ? atoi(getenv("VH_JIT_ABLATE")) : 0;      // measurement only (profiles/r03/NOTES.md): 1 = no gathers, 2 = nothing behind the gathers
+    js.ablate = env_ablate;
+    js.xcd = nxcd > 1 ? 1 : 0;
+    js.scope = (mode == VH_MODE_DENSE_GLOBAL || mode == VH_MODE_DENSE_LDS) && nxcd > 1 ? (int)__HIP_MEMORY_SCOPE_WORKGROUP : (int)__HIP_MEMORY_SCOPE_AGENT;
+    js.carrier = P.present_carrier;
+    js.tw = mode == VH_MODE_DENSE_PART ? P.tw : 1;
+    js.key_words = mode == VH_MODE_HASH ? P.key_words : 1;
+    js.lds_hash = P.lds_hash_slots ? 1 : 0;
+    js.gid32 = mode != VH_MODE_HASH && G <= 0xFFFFFFFFull;
+    static const bool env_no_stage = getenv("VH_NO_STAGE") != nullptr;             // measurement: tuples appended piece by piece (vh_part_direct_add)
+    js.stage = mode == VH_MODE_DENSE_PART && P.tw == 2 && P.npart <= VH_STAGE_PARTS && !env_no_stage;
+    js.ng = P.ngroup; js.nm = P.nmetric;
+    for (int i = 0; i < P.ngroup; ++i) {
+      const VhGroupDev& g = P.g[i];
+      VhJitCol& c = js.g[i];
+      c.slot = (int)g.slot(); c.type = (int)g.type(); c.pitch = (int)P.colpitch[g.slot()];
+      c.rec = slot_rec[g.slot()]; c.off = slot_recoff[g.slot()];
+      c.sext = mode != VH_MODE_HASH;
+      c.gran = (int)g.gran(); c.nroll = (int)g.nroll(); c.micro = (int)g.micro();
+      c.key_word = (int)g.key_word(); c.key_shift = (int)g.key_shift();
+      for (int k = 0; k < c.nroll; ++k) c.roll_unit[k] = (int)g.roll_unit(k);
+      if (vh_elem_size(c.type) > 4 || c.type == VH_F32) js.gid32 = 0;
+    }
+    for (int j = 0; j < P.nmetric; ++j) {
+      const VhMetricDev& m = P.m[j];
+      VhJitCol& c = js.m[j];
+      c.rowid = m.slot() == VH_SLOT_ROWID;
+      c.type = (int)m.type(); c.sop = (int)m.sop(); c.tword = (int)m.tword(); c.tshift = (int)m.tshift();
+      c.sext = vh_sop_sext((int)m.sop());
+      if (!c.rowid) { c.slot = (int)m.slot(); c.pitch = (int)P.colpitch[m.slot()]; c.rec = slot_rec[m.slot()]; c.off = slot_recoff[m.slot()]; }
+    }
+    if (jit_try) {
+      std::string jerr;
+      jk = vh_jit_get(js, &jerr);
+      if (!jk) {
+        // no kernel for this shape (hipRTC missing, or the text did not compile): plan again for the pre-built kernels. The
+        // failure is remembered per shape, so only the first query of the shape pays for the attempt.
+        static const bool verbose = getenv("VH_JIT_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "vh: per-query kernel unavailable, falling back: %s\n", jerr.c_str());
+        if ((p->flags & VH_PLAN_FORCE_JIT) || vh_jit_policy() == VH_JIT_FORCE) return vh_fail(VH_E_UNSUPPORTED, "per-query kernel requested (VH_PLAN_FORCE_JIT / VH_JIT=force) but unavailable: %s", jerr.c_str());
+        vh_plan p2 = *p;
+        p2.flags |= VH_PLAN_NO_JIT;
+        holder.reset();
+        return query_launch_locked(t, x, &p2, out, hash_capacity_override, force_hash, part_tuples_override, no_part, plan_only, summary_out, ag, device_rows);
+      }
     }
   }
 
@@ -1856,7 +1976,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   static const int env_lanes_block = getenv("VH_LANES_BLOCK") ? atoi(getenv("VH_LANES_BLOCK")) : 0;
   static const int env_bpc = getenv("VH_BLOCKS_PER_CU") ? atoi(getenv("VH_BLOCKS_PER_CU")) : 0;
   static const int env_unit = getenv("VH_UNIT_ROWS") ? atoi(getenv("VH_UNIT_ROWS")) : 0;
-  int BLOCK = mode == VH_MODE_DENSE_LDS ? 1024 : 256;
+  int BLOCK = jk ? jit_block : mode == VH_MODE_DENSE_LDS ? 1024 : 256;
   if (mode == VH_MODE_DENSE_LDS && lanes) {
     if (env_lanes_block == 256 || env_lanes_block == 512 || env_lanes_block == 1024) BLOCK = env_lanes_block;
     else if ((uint64_t)g_ctx.num_cu * 5 * G * std::max(1, P.nmetric) <= rows_to_scan / 32) BLOCK = 256;
@@ -1866,7 +1986,12 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     const size_t qb = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint32_t);
     const size_t lds_ = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + qb;
     hipStream_t s_ = x->stream();
-    if (mode == VH_MODE_DENSE_PART) {
+    if (jk) {
+      const size_t jl = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + (size_t)(BLOCK / 64) * (VJ_QUEUE_CAP * sizeof(uint32_t) + (jshape.stage ? VH_STAGE_BYTES : 0));
+      if (occ) *occ = vh_jit_occupancy(jk, BLOCK, jl);
+      else (void)vh_jit_launch(jk, P, grid_, BLOCK, jl, s_);
+    }
+    else if (mode == VH_MODE_DENSE_PART) {
       if (lanes) vh_launch_scan_lanes_part(P, grid_, 4 * vh_part_tile_bytes(P), s_, occ);
       else vh_launch_scan_fast_part(P, grid_, qb, s_, occ);   // the compacting form appends straight to the extents: no tile in LDS
     }
@@ -1884,7 +2009,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     else if (mode == VH_MODE_DENSE_PART && !lanes && P.shape) snprintf(nm, sizeof(nm), "scan_agg_shape_kernel<%d, %d, %d, %d, %d>", mode, BLOCK, (int)__HIP_MEMORY_SCOPE_AGENT, np_, P.shape);
     else snprintf(nm, sizeof(nm), "%s<%d, %d, %d, %d>", lanes ? "scan_agg_lanes_kernel" : "scan_agg_fast_kernel", mode, BLOCK,
                   (mode == VH_MODE_HASH || mode == VH_MODE_DENSE_PART) ? (int)__HIP_MEMORY_SCOPE_AGENT : scope, np_);
-    r->kernel = nm;
+    r->kernel = jk ? jk->name : std::string(nm);
     if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? " + part_agg_kernel<1024>" : (P.tw == 2 && !getenv("VH_NO_SPLIT_TILE")) ? " + part_split_tile_kernel<256> + part_agg_kernel<1024>" : " + part_split_kernel<256> + part_agg_kernel<1024>";
   }
   int occupancy = 0;
@@ -2112,12 +2237,14 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     for (int k = 0; k < P.npred; ++k) if (P.pred_width[k] != 4) { P.pred_slot[k] = (uint8_t)pred_wide_slot[k]; P.pred_width[k] = 4; }
   bool narrowed = false;
   for (int k = 0; k < P.npred; ++k) narrowed |= P.pred_width[k] != 4;
-  r->info.reserved = (fast ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fast && narrowed ? 16 : 0);
+  if (jk) { narrowed = false; for (int k = 0; k < jshape.npred; ++k) narrowed |= jshape.pred[k].width != vh_elem_size(jshape.pred[k].type); }
+  r->info.reserved = (fastj ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0);
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
     if (mode == VH_MODE_DENSE_PART) {
-      if (P.nlevel == 2) vh_launch_part_split(P, split_bpp, st);
-      vh_launch_part_agg(P, part_bpp, lds_table, st);
+      static const bool skip_phase2 = getenv("VH_ABLATE_NO_PHASE2") != nullptr;     // measurement only (wrong results): phase 1 alone between the events
+      if (P.nlevel == 2 && !skip_phase2) vh_launch_part_split(P, split_bpp, st);
+      if (!skip_phase2) vh_launch_part_agg(P, part_bpp, lds_table, st);
     }
   }
   HIP_TRY(hipEventRecord(x->ev[2], st));
