@@ -29,18 +29,38 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
 
 
+def kernel_sources_hash() -> str:
+    """Identity of the device code a profile was taken with: a hash over every file of viyadb_amd/csrc/ and include/ (the
+    GPU box has no .git to ask). tools/profile_round.sh stamps each PMC summary with it; a summary whose stamp differs from
+    the tree being timed describes other kernels and is refused (the round-2 line replayed a stale profile)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "viyadb_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(workload: str, rows_on_rank: int, kernel: str, packed: bool, narrow: bool):
     """HBM bytes per launch from the newest committed rocprofv3 PMC summary (profiles/rNN/) whose recorded kernel is the
-    kernel that just ran, scaled by rows. PMC counters cannot be read inside a normal run (tools/profile_round.sh collects
-    them with the same command line); a summary taken with another kernel is refused: traffic = null."""
+    kernel that just ran AND whose device sources are the ones being timed, scaled by rows. PMC counters cannot be read inside
+    a normal run (tools/profile_round.sh collects them with the same command line); a summary taken with another kernel, another
+    layout or other sources is refused: traffic = null, and the reason is reported."""
     import glob
     first = kernel.split(" + ")[0]
+    want = kernel_sources_hash()
+    why = "no PMC summary of kernel %s under profiles/" % first
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "%s_1gpu_pmc_hbm*.json" % workload.lower())), reverse=True):
         d = json.load(open(f))
         if first and first in d.get("kernel", "") and bool(d.get("packed", False)) == bool(packed) and bool(d.get("narrow", False)) == bool(narrow):
+            if d.get("sources") != want:
+                why = "%s was taken with other device sources (%s, this tree is %s)" % (os.path.relpath(f, ROOT), d.get("sources"), want)
+                continue
             scale = rows_on_rank / d["rows"]
-            return d["B_meas_per_launch"] * scale, os.path.relpath(f, ROOT), d.get("head"), d.get("write_bytes_raw", 0) * scale
-    return None, None, None, None
+            return d["B_meas_per_launch"] * scale, os.path.relpath(f, ROOT), d.get("head"), d.get("write_bytes_raw", 0) * scale, None
+    return None, None, None, None, why
 
 
 def parity_gate(table, w, plan, my_segments, executor):
@@ -152,6 +172,7 @@ def main():
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-pack", action="store_true", help="ablation: no payload projection (survivors gather from the column arenas)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity gate (profiling runs)")
+    ap.add_argument("--no-reference-layout", action="store_true", help="skip the arena-only leg (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -246,6 +267,28 @@ def main():
             kernel_ms.append(last.scan_kernel_ms)
     barrier()
     elapsed = time.perf_counter() - t0
+
+    # The same query on the REFERENCE layout — the 4-byte column arenas only, no payload projection, no narrow predicate copies
+    # (VH_PLAN_NO_PACK | VH_PLAN_NO_NARROW) — timed in the same run, after the headline loop: what the kernels do with the
+    # bytes the reference's Segment holds, so that rounds stay comparable whatever the derived layouts buy.
+    ref_layout = None
+    if world == 1 and not args.no_pack and not args.no_reference_layout:
+        rplan = executor.AggPlan(filter=plan.filter, groups=plan.groups, metrics=plan.metrics, groups_hint=plan.groups_hint,
+                                 flags=args.flags | capi.PLAN_NO_PACK | capi.PLAN_NO_NARROW)
+        table.prepare(rplan)
+        rsteps = max(3, min(args.steps, 10))
+        for _ in range(2):
+            rlast = table.query_agg(rplan, copy=False)
+        torch.cuda.synchronize()
+        r0 = time.perf_counter()
+        rk = []
+        for _ in range(rsteps):
+            rlast = table.query_agg(rplan, copy=False)
+            rk.append(rlast.scan_kernel_ms)
+        torch.cuda.synchronize()
+        rel = time.perf_counter() - r0
+        ref_layout = (rlast, rel / rsteps, sum(rk) / len(rk), rsteps)
+        table.prepare(plan)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -266,7 +309,7 @@ def main():
     fcols = sorted({f[1] for f in w.plan.filter if f[0] in ("rel", "in")})
     fbytes = sum(capi.ELEM_SIZE[w.columns[c].elem] for c in fcols)
     b_min = rows_rank0 * fbytes + last.passed_recs * max(0, w.bytes_per_row_referenced - fbytes)
-    traffic, traffic_src, traffic_head, traffic_write = measured_traffic(args.workload, my_segments * w.segment_rows, last.kernel, last.packed, last.narrow)
+    traffic, traffic_src, traffic_head, traffic_write, traffic_why = measured_traffic(args.workload, my_segments * w.segment_rows, last.kernel, last.packed, last.narrow)
     # never credit more than was moved. Without a PMC pass of this very kernel and layout, credit B_min — what ANY
     # implementation must move (filter columns in full at their declared width + the passing rows' payload) — rather than B_ref:
     # with projections and narrow copies the query reads far less than it references, and B_ref / t can exceed the HBM peak
@@ -288,7 +331,13 @@ def main():
                        "table_path": last.path, "parallelism": ("segments sharded x%d, vh_query_agg_sharded: plan agreement + ncclReduce of the partial tables to rank 0 (%s transport)"
                                                                 % (world, "RCCL" if backend == "nccl" else "callbacks over " + backend)) if world > 1 else "1 GPU",
                        "generate_seconds": round(t_gen, 3), "payload_projection": bool(last.packed), "narrow_predicates": bool(last.narrow),
+                       "compiled_kernel": bool(last.jit),
                        "pack_seconds": round(t_pack, 3), "device_bytes": table.info()[2]},
+            # what the derived layouts cost, first class: built once (like the reference's per-query g++ compile, outside its steady
+            # state), resident next to the table
+            "derived_layout": {"one_time_seconds": round(t_pack, 4), "extra_device_bytes": max(0, table.info()[2] - total_rows * w.table_bytes_per_row // max(1, world)),
+                               "table_bytes": total_rows * w.table_bytes_per_row // max(1, world),
+                               "what": "payload projection of the group + metric columns (vh_table_pack) and 8- / 16-bit copies of the predicate columns (vh_table_narrow)" if not args.no_pack else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": last.kernel,
@@ -297,7 +346,8 @@ def main():
                          "bref_over_t_GBs": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0,
                          "frac_ref": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_kernel_ms > 0 else 0.0,
                          "traffic_write": traffic_write,
-                         "traffic_source": traffic_src, "traffic_head": traffic_head,
+                         "traffic_source": traffic_src, "traffic_head": traffic_head, "traffic_refused": traffic_why,
+                         "kernel_sources": kernel_sources_hash(),
                          "note": "achieved = min(B_ref, B_meas) / mean HIP-event time of the scan kernel(s) on rank 0 "
                                  "(SURVEY 8d: never more than was moved, never more than the algorithm references); B_ref = rows x "
                                  "referenced bytes/row; B_meas = rocprofv3 FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md) from "
@@ -307,6 +357,17 @@ def main():
                                  "a layout that avoids bytes (payload projection, narrow predicate copies) lowers frac while the query gets faster - "
                                  "compare kernel_ms / value across rounds (round 1: 5.03 ms, frac 0.66 with 26.5 GB moved)"},
         }
+        if ref_layout is not None:
+            rl, rsec, rkms, rsteps = ref_layout
+            rtraffic, rsrc, rhead, rwrite, rwhy = measured_traffic(args.workload, my_segments * w.segment_rows, rl.kernel, rl.packed, rl.narrow)
+            rcred = min(rl.algorithmic_bytes, rtraffic) if rtraffic else min(rl.algorithmic_bytes, b_min)
+            out["reference_layout"] = {
+                "what": "the same query with VH_PLAN_NO_PACK | VH_PLAN_NO_NARROW: every referenced column read from its 4-byte / 8-byte arena, as the reference's Segment lays them out",
+                "value": total_rows / rsec, "unit": "rows/s", "ms_per_step": rsec * 1e3, "steps": rsteps, "kernel_ms": rkms, "kernel": rl.kernel, "table_path": rl.path,
+                "compiled_kernel": bool(rl.jit),
+                "roofline": {"achieved": rcred / (rkms * 1e-3) / 1e9, "frac": rcred / (rkms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": rtraffic, "traffic_write": rwrite,
+                             "traffic_source": rsrc, "traffic_refused": rwhy,
+                             "bref_over_t_GBs": rl.algorithmic_bytes / (rkms * 1e-3) / 1e9}}
         if world == 1 and not args.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(w, min(args.cpu_segments, total_segments))

@@ -194,7 +194,10 @@ enum vh_plan_flags {
                                      (shapes the generator does not cover — bitset metrics, the no-compaction
                                      kernels, very wide plans — still take the pre-built kernels: see
                                      vh_result_info.reserved bit 5); a compile that FAILS is an error,
-                                     VH_E_UNSUPPORTED, not a silent fallback                               */
+                                     VH_E_UNSUPPORTED, not a silent fallback */,
+  VH_PLAN_NO_HPART = 1u << 19,    /* ablation: never the hashed partitioning of the hash path (many groups: tuples keyed by
+                                     a bijective mix of the group key, radix-partitioned, aggregated range by range in LDS) */
+  VH_PLAN_FORCE_HPART = 1u << 20  /* testing: hashed partitioning whenever the plan is eligible, however small the table  */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */
@@ -245,7 +248,8 @@ typedef struct vh_result_info {
   uint32_t reserved;         /* bit 0: the register-resident fast scan kernel ran; bit 1: its no-compaction "lanes" variant;
                                 bit 2: LDS front table of the hash path; bit 3: payload gathered from a projection (vh_table_pack);
                                 bit 4: predicate columns streamed from narrow copies (vh_table_narrow);
-                                bit 5: a scan kernel compiled for this plan shape ran (vh_jit.hip) */
+                                bit 5: a scan kernel compiled for this plan shape ran (vh_jit.hip);
+                                bit 6: hashed partitioning of the hash path (hash_part_agg_kernel) */
   uint64_t returned_groups;  /* rows vh_result_copy delivers (= ngroups without HAVING) */
 } vh_result_info;
 
@@ -500,7 +504,7 @@ VH_API int vh_measure_read_bandwidth(uint64_t bytes, int32_t iters, double* byte
 
 /* Test hook for the per-query compiled scan kernels (viyadb_amd/csrc/vh_jit.hip — the GPU analogue of the reference's
  * codegen + Compiler::Compile, src/codegen/compiler.cc:97-144): writes the HIP text for canonical plan shape `which`
- * (0..5) into `text`, compiles it with hipRTC for gfx950 — no GPU needed — and stores the code object at `hsaco_path`
+ * (0..6) into `text`, compiles it with hipRTC for gfx950 — no GPU needed — and stores the code object at `hsaco_path`
  * (NULL: nowhere). VH_E_INVALID: no such shape; VH_E_UNSUPPORTED: the compile failed (`text` then starts with the log). */
 VH_API int vh_jit_selftest(int32_t which, const char* hsaco_path, char* text, uint64_t text_bytes);
 

@@ -109,7 +109,7 @@ def test_group_key_shapes_compiled(typed, dims):
     """Wide and narrow keys, signed digits in 32-bit wrap-around arithmetic, float keys (-0.0 == 0.0), multi-word hash keys."""
     tab, dt = typed
     for flags in (0, 1):
-        res, _ = run(tab, dt, {"dimensions": dims, "metrics": ["count", "double_sum"], "filter": F("gt", "d_int", "-30")}, flags=flags | J)
+        res, _ = run(tab, dt, {"dimensions": dims, "metrics": ["count", "double_sum"], "filter": F("gt", "d_int", "-30")}, flags=flags | J | capi.PLAN_NO_LANES)
         assert res.jit
 
 
@@ -143,7 +143,8 @@ def test_narrow_copies_and_projection_compiled():
                 res = dt.query_agg(AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=flags | J))
                 compare(res, st, f"{prep} flags={flags}")
                 assert res.jit
-                assert res.narrow == (prep in ("narrow", "both")) and (res.packed or prep in ("none", "narrow")), (prep, flags, res.narrow, res.packed)
+                # (the library builds both layouts by itself for a shape it keeps seeing: only what was asked for is asserted)
+                assert (res.narrow or prep in ("none", "pack")) and (res.packed or prep in ("none", "narrow")), (prep, flags, res.narrow, res.packed)
     finally:
         dt.close()
 
@@ -212,3 +213,65 @@ def test_random_plans_take_the_compiled_kernel_when_eligible(typed):
         ran += 1
         compiled += bool(res.jit)
     assert ran >= 25 and compiled >= 0.9 * ran, (ran, compiled)
+
+
+# ---- hashed partitioning of the hash path (hash_part_agg_kernel): tuples keyed by a bijective mix of the group key, radix-partitioned,
+# aggregated range by range in LDS; the bitset metric's ids travel as pair tuples. Small tables take it on request only.
+HP = capi.PLAN_FORCE_HPART | capi.PLAN_FORCE_JIT | capi.PLAN_FORCE_HASH      # (dense key spaces would not take the hash path by themselves)
+
+
+@pytest.mark.parametrize("name", ["c5t", "c5"])
+def test_c5_hashed_partitioning(name):
+    from viyadb_amd import synth
+    w = getattr(synth, name)(segment_rows=120_000)
+    res, st = check_workload(w, nseg=3, rows_per_seg=119_989, flags=HP, expect_path="hash")
+    assert res.hpart and res.jit and "hp_scatter_kernel" in res.kernel and "hp_aggregate_kernel" in res.kernel, res.kernel
+    assert res.ngroups > 50_000
+    if name == "c5":
+        assert int(res.states[0].max()) >= 2
+
+
+def test_hashed_partitioning_replans_when_a_range_overflows_its_tables(monkeypatch):
+    """16 group slots per range cannot hold a range's groups once a table this size is squeezed into few ranges' worth of keys: the kernel
+    flags it, the host re-plans with the biggest tables and more passes, and the answer is the oracle's."""
+    from viyadb_amd import synth
+    monkeypatch.setenv("VH_TEST_HPART_GSLOTS", "16")
+    w = synth.c5(segment_rows=400_000)
+    res, _ = check_workload(w, nseg=3, flags=HP, expect_path="hash")
+    assert res.hpart and res.retries >= 1 and res.ngroups > 500_000
+
+
+def test_hashed_partitioning_on_typed_keys_and_metrics(typed):
+    """Every single-word key shape (narrow and wide columns, signed, float with -0.0, time with granularity) and every payload that fits a
+    tuple (one 64-bit state, or up to two 32-bit ones), with filters, HAVING and a count-distinct-free plan."""
+    tab, dt = typed
+    cases = [(["id"], ["count", "int_sum"]), (["d_long"], ["long_sum"]), (["d_float", "d_short"], ["int_min", "uint_max"]), (["s16", "d_int"], ["double_max"]),
+             (["d_ubyte", "d_ushort", "d_uint"], ["float_sum", "count"]), (["id", "flag"], ["long_min"])]
+    for dims, mets in cases:
+        res, _ = run(tab, dt, {"dimensions": dims, "metrics": mets, "filter": F("gt", "d_int", "-30")}, flags=HP)
+        assert res.hpart, (dims, mets, res.kernel)
+    q = {"type": "aggregate", "table": "t", "select": [{"column": "ts", "granularity": "minute"}, {"column": "s8"}, {"column": "count"}, {"column": "short_sum"}]}
+    res, _ = run(tab, dt, q, flags=HP)
+    assert res.hpart
+    # three 32-bit states do not fit one payload word: the plain hash table
+    res, _ = run(tab, dt, {"dimensions": ["id"], "metrics": ["count", "int_sum", "uint_max"]}, flags=HP)
+    assert not res.hpart
+
+
+def test_hashed_partitioning_with_skew_and_having(typed):
+    """All rows in one group (one range gets everything), and a HAVING evaluated on the list of group records."""
+    tab, dt = typed
+    res, _ = run(tab, dt, {"dimensions": [], "metrics": ["count", "int_sum"]}, flags=HP)
+    res, _ = run(tab, dt, {"dimensions": ["flag"], "metrics": ["long_sum"]}, flags=HP)
+    assert res.hpart and res.ngroups == 2
+    res, _ = run(tab, dt, {"dimensions": ["d_int", "s8"], "metrics": ["count", "uint_max"], "having": F("ge", "count", "9")}, flags=HP)
+    assert res.hpart
+
+
+def test_hashed_partitioning_many_tiles_per_block():
+    """Enough tuples that every block of the scatter works through several source extents (tails waiting in LDS between tiles, extents
+    filling up and being replaced), with ragged segments."""
+    from viyadb_amd import synth
+    w = synth.c5(segment_rows=1_000_000)
+    res, _ = check_workload(w, nseg=6, rows_per_seg=999_983, flags=HP, expect_path="hash", check_columns=False)
+    assert res.hpart and res.ngroups > 2_000_000

@@ -1,6 +1,6 @@
 """Per-query compiled scan kernels, CPU side: the text viyadb_amd/csrc/vh_jit.hip generates for canonical plan shapes
 compiles for gfx950 with hipRTC (which cross-compiles without a GPU), and the code objects look the way DESIGN.md says they
-do — packed predicate columns compared in place (SDWA selectors), no scratch, few enough registers for 8 waves per SIMD on
+do — packed predicate columns compared in place (SDWA selectors), no scratch, few enough registers for 7 waves per SIMD on
 the C3 shape. The reference's counterpart: every generated query function must pass g++ (src/codegen/compiler.cc:97-144)."""
 import ctypes as C
 import os
@@ -17,7 +17,8 @@ SHAPES = {0: "C3: narrow predicate copies, record gathers, tuples for DENSE_PART
           2: "int32 / float range, LDS table, SUM + MAX(double)",
           3: "time rollup keys, hash + LDS front table, IN on u8, != on i64",
           4: "wide hash key (double, i16, u64), row-id MIN, NOT IN on u16",
-          5: "no filter, no group columns"}
+          5: "no filter, no group columns",
+          6: "C5: hashed partitioning, tuples + pair tuples of a bitset metric"}
 
 
 def _compile(which, tmp_path):
@@ -54,7 +55,7 @@ def test_c3_shape_compares_packed_columns_in_place(tmp_path):
     assert len(re.findall(r"v_cmp_ge_u32_sdwa s\[", isa)) == 32
     assert "src0_sel:BYTE_3" in isa and "src0_sel:WORD_1" in isa
     m = _meta(out)
-    assert m["vgpr_count"] <= 64, m      # 8 waves per SIMD
+    assert m["vgpr_count"] <= 72, m      # 7 waves per SIMD (the queues and waiting lines in LDS allow six blocks of four waves per CU)
 
 
 def test_unknown_shape_is_refused():
@@ -68,8 +69,8 @@ def test_compiles_with_the_hiprtc_a_torch_process_carries():
     code = ("import torch, ctypes as C\n"
             "from viyadb_amd import capi\n"
             "lib = capi.load(); buf = C.create_string_buffer(1 << 20)\n"
-            "rcs = [lib.vh_jit_selftest(w, None, buf, len(buf)) for w in range(6)]\n"
-            "assert rcs == [0] * 6, (rcs, buf.value.decode()[:2000])\n")
+            "rcs = [lib.vh_jit_selftest(w, None, buf, len(buf)) for w in range(7)]\n"
+            "assert rcs == [0] * 7, (rcs, buf.value.decode()[:2000])\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--head", default="", help="git revision the pass was taken at (bench.py reports it as traffic_head)")
     ap.add_argument("--packed", type=int, default=0, help="1: the query gathered its payload from a projection (bench.py only uses a pass taken the same way)")
     ap.add_argument("--narrow", type=int, default=0, help="1: predicate columns were streamed from narrow copies")
+    ap.add_argument("--sources", default="", help="bench.kernel_sources_hash() of the tree the pass was taken with (bench.py refuses a summary whose stamp differs)")
     a = ap.parse_args()
     fetch, write = collect(a.fetch_dir, "FETCH_SIZE"), collect(a.write_dir, "WRITE_SIZE")
     names = []
@@ -48,7 +49,7 @@ def main():
     wb = sum(write.get(k, {"mean_KiB": 0.0})["mean_KiB"] for k in names) * 1024.0
     out = {
         "command": a.command or "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 3 --warmup 1 --no-cpu",
-        "kernel": kname, "head": a.head, "packed": bool(a.packed), "narrow": bool(a.narrow),
+        "kernel": kname, "head": a.head, "sources": a.sources, "packed": bool(a.packed), "narrow": bool(a.narrow),
         "raw": {"FETCH_SIZE": fetch, "WRITE_SIZE": write},
         "fetch_bytes_raw": fb, "fetch_bytes_corrected_x2": fb * 2, "write_bytes_raw": wb,
         "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming "

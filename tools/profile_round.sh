@@ -3,30 +3,33 @@
 # the same command, PMC passes (FETCH_SIZE / WRITE_SIZE in SEPARATE runs, as MI355X_MICROARCH.md prescribes) summed over the kernels
 # the bench line names (roofline.kernel comes from the library: vh_result_kernel).
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh r02 <git head>
-R=${1:-r02}
+R=${1:-r03}
 HEAD=${2:-unknown}
 OUT=gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
+SRC=$(python -c "import bench; print(bench.kernel_sources_hash())")
 one() {   # name (workload[_variant]), rows, bref, bench args...
   local W=$1 ROWS=$2 BREF=$3; shift 3
-  python bench.py "$@" > $OUT/bench_${W}_1gpu.json 2> $OUT/bench_${W}.err
+  python bench.py "$@" ${FIRST_EXTRA---no-reference-layout} > $OUT/bench_${W}_1gpu.json 2> $OUT/bench_${W}.err
   tail -c 300 $OUT/bench_${W}_1gpu.json; echo
   local K=$(python -c "import json; print(json.load(open('$OUT/bench_${W}_1gpu.json'))['roofline']['kernel'])")
   local PK=$(python -c "import json; print(int(json.load(open('$OUT/bench_${W}_1gpu.json'))['config']['payload_projection']))")
   local NR=$(python -c "import json; print(int(json.load(open('$OUT/bench_${W}_1gpu.json'))['config'].get('narrow_predicates', False)))")
-  (cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/$OUT/kt_$W -o $W -- python $REPO/bench.py "$@" --steps 10 --warmup 2 --no-cpu --no-check > $REPO/$OUT/kt_$W.log 2>&1)
+  (cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/$OUT/kt_$W -o $W -- python $REPO/bench.py "$@" --steps 10 --warmup 2 --no-cpu --no-check --no-reference-layout > $REPO/$OUT/kt_$W.log 2>&1)
   python tools/pmc_summary.py --kernel-stats $(find $OUT/kt_$W -name "*_results.db" | head -1) $OUT/${W}_1gpu_kernel_stats.csv; head -4 $OUT/${W}_1gpu_kernel_stats.csv | cut -c1-160
   for C in FETCH_SIZE WRITE_SIZE; do
-    (cd /tmp && rocprofv3 --pmc $C -d $REPO/$OUT/pmc_${C}_$W -o $W -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-check > $REPO/$OUT/pmc_${C}_$W.log 2>&1)
+    (cd /tmp && rocprofv3 --pmc $C -d $REPO/$OUT/pmc_${C}_$W -o $W -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-check --no-reference-layout > $REPO/$OUT/pmc_${C}_$W.log 2>&1)
   done
   local J=$OUT/${W}_1gpu_pmc_hbm.json
   case $W in *_*) J=$OUT/${W%%_*}_1gpu_pmc_hbm_${W#*_}.json;; esac
-  python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE_$W $OUT/pmc_WRITE_SIZE_$W $J --rows $ROWS --bref $BREF --kernel "$K" --head $HEAD --packed $PK --narrow $NR \
+  python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE_$W $OUT/pmc_WRITE_SIZE_$W $J --rows $ROWS --bref $BREF --kernel "$K" --head $HEAD --sources $SRC --packed $PK --narrow $NR \
     --command "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py $* --steps 3 --warmup 1 --no-cpu --no-check"
 }
-one c3 1000000000 32e9
+one c3_arena 1000000000 32e9 --no-pack --no-cpu              # the reference layout: column arenas only (bench.py's reference_layout leg reads this pass)
+cp $OUT/c3_1gpu_pmc_hbm_arena.json profiles/$R/ 2>/dev/null    # (the headline run below looks for it under profiles/)
+FIRST_EXTRA="" one c3 1000000000 32e9
 one c3_direct 1000000000 32e9 --flags 16 --no-cpu             # the same query forced onto direct atomics (what a slower box or a smaller shard runs)
 one c2 100000000 2e9 --workload C2 --no-cpu
 one c5 125000000 3.5e9 --workload C5 --segments 125 --no-cpu --steps 5 --warmup 1

@@ -1,0 +1,495 @@
+// vh_hpart.h — hashed partitioning of the hash path: the kernels behind the scan.
+//
+// Where it stands in for: `agg_map[agg_tuple.d].Update(agg_tuple.m)` on a std::unordered_map (src/codegen/query/scan.cc:174-177,242)
+// and `_j |= metrics._j` + cardinality() of a bitset metric (src/codegen/db/store.cc:153-155, src/util/bitset.h:26-67) when the query
+// produces TENS OF MILLIONS of groups (BASELINE.json configs[4], C5). A hash table of that size lives in no cache; every survivor costs
+// it 2-5 read-modify-writes at random addresses, which the device executes at ~20 G/s whatever else is done (round 2: 312 M of them =
+// 15.9 ms per 125 M rows). The classic answer is to move the DATA to the table instead: radix-partition the survivors by a hash of the
+// group key until one partition's groups fit LDS, then aggregate there with LDS atomics only. Sequential traffic of 16 bytes per
+// tuple and level instead of a 128-byte line read and written per update.
+//
+//   scan kernel (compiled per plan, vh_jit_body.h): a survivor becomes a 16-byte TUPLE (mixed key, payload word) — the mixed key is a
+//     bijection of the packed 64-bit group key (vh_splitmix64 / vh_unmix64), so equal keys always travel together and no key is ever
+//     compared through a lossy hash — and, per two ids of its bitset metric, a PAIR TUPLE (mixed key, two ids). Both are appended,
+//     unpartitioned, 1 KiB per wave store, to extents of 4096 tuples (the "stream" pools).
+//   hp_scatter_kernel, twice: a block takes a source extent (<= 4096 tuples) as a tile, sorts it by 8 bits of the mixed key in LDS
+//     (histogram, prefix, scatter) and appends each digit's run to the digit's open extent in the destination pool IN WHOLE 128-BYTE
+//     LINES: a run's tail of < 8 tuples waits in LDS for the next tile (round 3 measured partial-line tuple writes at 2.3x the cost of
+//     whole lines). Level A: stream -> 256 partitions by bits 63..56. Level B: partition a -> 256 ranges by bits 55..48, into slice a
+//     of the destination pool (sized on the device from what level A produced), so that the last kernel finds a range's extents by
+//     looking at a few hundred tags.
+//   hp_aggregate_kernel: 65 536 ranges of (at C5's size) ~550 groups. A block per range: tuples -> open-addressing table in LDS (keys
+//     = mixed keys, 64-bit LDS compare-and-swap; states as in every other LDS table), pair tuples -> (group slot, id) set in LDS, first
+//     sight bumping the group's cardinality; the range's groups leave as records (original key = vh_unmix64, states) for a compact list
+//     in HBM that the ordinary emission kernel reads (VhEmitArgs::n_dev). No global atomics except one list cursor per block and range.
+//     Ranges whose groups would not fit the tables are worked through in `passes` sub-ranges (the next bits of the mixed key).
+#pragma once
+#include "vh_kernels.h"
+
+#define HP_ET 4096            // tuples per extent (64 KB): a tile's run of one digit fits what is left of an extent plus one fresh extent
+#define HP_FAN 256            // partitions per level
+#define HP_CARRY 8            // LDS slots per digit for the run tail that waits for the next tile (< 8 tuples ever wait)
+#define HP_LIST 1024          // source extents a block remembers at a time
+
+struct VhHpPool {             // extents of HP_ET 16-byte tuples
+  uint64_t* tuples;
+  uint16_t* fill;             // tuples in the extent; 0: never used. (The stream pools, written by the scan kernel, keep the older
+  uint8_t* tag;               //  convention instead: fill = HP_ET - missing[e], tag 0xFF = never opened.)
+  uint32_t max_extents;
+  uint32_t stream;            // 1: a stream pool (see above)
+  unsigned long long* cursor; // extents handed out (stream pools: the scan kernel's allocation counter)
+};
+struct VhHpKind {             // the three pools of one kind of tuple
+  VhHpPool z, a, b;
+  uint32_t* slice;            // [HP_FAN + 1] first extent of partition a's slice of pool b; [HP_FAN + 1 + a]: extents handed out of it
+  uint32_t* count;            // [HP_FAN] tuples per level-A digit (hp_count_kernel)
+};
+struct VhHpArgs {
+  VhHpKind k[2];              // 0: tuples, 1: pair tuples
+  int32_t nkind;              // 1 or 2
+  int32_t passes;             // hp_aggregate_kernel: sub-ranges per range (power of two)
+  int32_t gslots, sslots;     // its LDS tables: group slots (+ 1), (group slot, id) set slots (0: no bitset metric)
+  uint32_t keys_off, set_off; // LDS byte offsets (metric states at VhPlanDev::m[j].lds_off)
+  int32_t bitset_j;
+  uint32_t chunk;             // group records a block of hp_aggregate_kernel takes from the list at a time
+  uint64_t list_cap;          // records the group list holds (+ one reserved record behind them)
+};
+// blocks hp_aggregate_kernel runs per level-A partition: enough to fill every CU's LDS twice over (a divisor of HP_FAN)
+static inline int vh_hpart_bpp(int num_cu, size_t agg_lds) {
+  const size_t per_cu = agg_lds + 4096 >= (size_t)(150 * 1024) ? 1 : (size_t)(150 * 1024) / (agg_lds + 4096);
+  int bpp = (int)((size_t)num_cu * (per_cu < 4 ? per_cu : 4) * 2 / HP_FAN);
+  if (bpp < 1) bpp = 1;
+  while (HP_FAN % bpp) --bpp;
+  return bpp;
+}
+
+#ifdef VH_HPART_KERNELS        // (the kernels: vh_hpart.hip only; the host code of viya_hip.hip takes the descriptors above)
+typedef uint64_t hp_u64x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t hp_pool_fill(const VhHpPool& Q, uint32_t e) {
+  if (Q.stream) return Q.tag[e] == 0xFF ? 0u : (uint32_t)HP_ET - Q.fill[e];
+  return Q.fill[e];
+}
+__device__ __forceinline__ uint32_t hp_pool_used(const VhHpPool& Q) {
+  if (!Q.cursor) return Q.max_extents;      // (a pool handed out in slabs or slices: every extent may hold something)
+  const unsigned long long c = *Q.cursor;
+  return c < Q.max_extents ? (uint32_t)c : Q.max_extents;
+}
+
+// ------------------------------------------------------------------ scatter: one level of the partitioning
+// grid: level A any number of blocks (they share the stream's extents round-robin); level B HP_FAN blocks, block a owning partition a.
+struct HpScatterLds {
+  uint32_t hist[HP_FAN], offs[HP_FAN], carry_n[HP_FAN], cur[HP_FAN];
+  uint32_t ext_a[HP_FAN], fill_a[HP_FAN];                                                  // per digit: the open extent and the tuples already in it
+  uint32_t whole[HP_FAN], room[HP_FAN], wext[HP_FAN], wfill[HP_FAN], ext_b[HP_FAN], tail[HP_FAN];   // this tile: whole-line tuples of the run, room left in the open extent
+                                                                                            // (wext, from wfill), the fresh extent behind it, tuples that will wait
+  uint32_t wave_tot[4];
+  uint32_t nlist, list[HP_LIST];
+  uint32_t ntiles, alloc;
+  uint16_t lfill[HP_LIST], lpre[HP_LIST], tfirst[HP_LIST + 1];     // tuples of a listed extent, tuples before it in its tile, first entry of tile t
+  uint8_t sdigit[HP_ET + HP_FAN * HP_CARRY];
+};
+__host__ __device__ __forceinline__ size_t hp_scatter_lds_bytes() {
+  return sizeof(HpScatterLds) + (size_t)(HP_ET + HP_FAN * HP_CARRY) * 16 + (size_t)HP_FAN * HP_CARRY * 16 + 64;
+}
+
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __restrict__ HA, int kind, int level, unsigned long long* counters) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  HpScatterLds& S = *reinterpret_cast<HpScatterLds*>(lds);
+  hp_u64x2* const sorted = reinterpret_cast<hp_u64x2*>(lds + (sizeof(HpScatterLds) + 15) / 16 * 16);
+  hp_u64x2* const carry = sorted + (HP_ET + HP_FAN * HP_CARRY);
+  const VhHpKind& K = HA->k[kind];
+  const VhHpPool src = level == 0 ? K.z : K.a, dst = level == 0 ? K.a : K.b;
+  const int shift = level == 0 ? 56 : 48;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // destination extents come out of [dlo, dhi) of the pool; level B: partition a's slice
+  // Level A: the pool cut into one slab per block — a block's 256 open extents then sit within a few tens of MB instead of being strewn
+  // over the whole pool by a global cursor (4 GB, a different page for every store: level A ran at a third of level B's rate that way).
+  uint32_t dlo, dhi;
+  unsigned int* dcur;                       // extents handed out of [dlo, dhi)
+  if (level == 0) { const uint32_t slab = dst.max_extents / gridDim.x; dlo = blockIdx.x * slab; dhi = dlo + slab; dcur = &S.alloc; }
+  else { dlo = K.slice[blockIdx.x]; dhi = K.slice[blockIdx.x + 1]; dcur = K.slice + HP_FAN + 1 + blockIdx.x; }
+  if (tid == 0) S.alloc = 0;
+  if (tid < HP_FAN) { S.carry_n[tid] = 0; S.ext_a[tid] = ~0u; S.fill_a[tid] = 0; }
+  const uint32_t used = hp_pool_used(src);
+  bool full = false;                        // the destination ran out of extents: the host re-plans (VH_ERR_PART_FULL)
+  for (uint32_t scan0 = 0; scan0 < used; ) {
+    // ---- my next source extents (a list in LDS; more than it holds: another round)
+    __syncthreads();
+    if (tid == 0) S.nlist = 0;
+    __syncthreads();
+    uint32_t next_scan = used;
+    for (uint32_t e0 = scan0; e0 < used; e0 += BLOCK) {
+      const uint32_t before = S.nlist;             // (stable: behind the barrier that ended the previous chunk)
+      const uint32_t e = e0 + tid;
+      bool mine = false;
+      uint32_t fl = 0;
+      if (e < used && (fl = hp_pool_fill(src, e)) != 0)
+        mine = level == 0 ? ((e * 2654435761u) >> 12) % gridDim.x == blockIdx.x : src.tag[e] == (uint8_t)blockIdx.x;      // (level A: a scattered share of the stream, so that
+                                                                                                                               //  the blocks do not march through the pool 64 KB apart in lockstep)
+      __syncthreads();
+      if (mine) { const uint32_t at = atomicAdd(&S.nlist, 1u); if (at < HP_LIST) { S.list[at] = e; S.lfill[at] = (uint16_t)fl; } }
+      __syncthreads();
+      if (S.nlist > HP_LIST) {                     // this chunk did not fit behind the earlier ones: it opens the next round
+        __syncthreads();
+        if (tid == 0) S.nlist = before;
+        next_scan = e0;
+        break;
+      }
+    }
+    __syncthreads();
+    const uint32_t nl = S.nlist < HP_LIST ? S.nlist : HP_LIST;
+    scan0 = next_scan;
+    // ---- tiles: consecutive listed extents whose tuples add up to at most HP_ET (the extents a level leaves behind are often a quarter
+    //      full — one per writing block and digit —, and a tile's fixed cost is the same whatever it holds)
+    if (tid == 0) {
+      uint32_t nt = 0, i = 0;
+      while (i < nl) {
+        S.tfirst[nt++] = (uint16_t)i;
+        uint32_t sum = 0, cnt = 0;
+        while (i < nl && cnt < 32 && sum + S.lfill[i] <= (uint32_t)HP_ET) { S.lpre[i] = (uint16_t)sum; sum += S.lfill[i]; ++i; ++cnt; }
+      }
+      S.tfirst[nt] = (uint16_t)nl;
+      S.ntiles = nt;
+    }
+    __syncthreads();
+    const uint32_t ntiles = S.ntiles;
+    auto tile_total = [&](uint32_t tile) { const uint32_t last = S.tfirst[tile + 1] - 1u; return (uint32_t)S.lpre[last] + S.lfill[last]; };
+    auto tile_load = [&](uint32_t tile, uint32_t total, hp_u64x2 (&dstv)[HP_ET / BLOCK]) {
+#pragma unroll
+      for (int r = 0; r < HP_ET / BLOCK; ++r) {
+        const uint32_t k = (uint32_t)(r * BLOCK + tid);
+        if (k < total) {
+          uint32_t i = S.tfirst[tile];
+          while ((uint32_t)S.lpre[i] + S.lfill[i] <= k) ++i;
+          dstv[r] = __builtin_nontemporal_load(reinterpret_cast<const hp_u64x2*>(src.tuples) + (uint64_t)S.list[i] * HP_ET + (k - S.lpre[i]));
+        }
+      }
+    };
+    hp_u64x2 t[HP_ET / BLOCK];
+    uint32_t valid = ntiles ? tile_total(0) : 0u;
+    if (ntiles) tile_load(0, valid, t);
+    for (uint32_t li = 0; li < ntiles; ++li) {
+      const uint32_t nvalid = valid;
+      uint32_t dig[HP_ET / BLOCK];
+      if (tid < HP_FAN) { S.hist[tid] = S.carry_n[tid]; S.cur[tid] = S.carry_n[tid]; }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < HP_ET / BLOCK; ++r)
+        if ((uint32_t)(r * BLOCK + tid) < nvalid) { dig[r] = (uint32_t)(t[r].x >> shift) & (HP_FAN - 1u); atomicAdd(&S.hist[dig[r]], 1u); }
+      __syncthreads();
+      // exclusive prefix over the digits (waves 0..3: 64 digits each), whole lines, room, extents
+      uint32_t incl = 0, h = 0;
+      if (tid < HP_FAN) {
+        h = S.hist[tid];
+        incl = h;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+        if (lane == 63) S.wave_tot[wave] = incl;
+      }
+      __syncthreads();
+      if (tid < HP_FAN) {
+        uint32_t before = 0;
+        for (int w = 0; w < wave; ++w) before += S.wave_tot[w];
+        S.offs[tid] = before + incl - h;
+        uint32_t whole = h & ~7u;
+        S.whole[tid] = whole;
+        uint32_t ea = S.ext_a[tid], fa = S.fill_a[tid], eb = ~0u;
+        uint32_t room = ea == ~0u ? 0u : (uint32_t)HP_ET - fa;
+        if (whole > room) {                          // the run needs a fresh extent behind what is left of the open one
+          const uint32_t got = atomicAdd(dcur, 1u);
+          if (dlo + got < dhi) { eb = dlo + got; dst.tag[eb] = (uint8_t)tid; }
+          else { full = true; S.whole[tid] = whole = room; }      // nowhere to put the rest: dropped, the attempt is void
+        }
+        S.room[tid] = room; S.ext_b[tid] = eb;
+        S.wext[tid] = ea; S.wfill[tid] = fa; S.tail[tid] = h - whole;
+        // after this tile: the open extent and its fill
+        if (whole <= room) { S.fill_a[tid] = fa + whole; }
+        else { if (ea != ~0u) dst.fill[ea] = (uint16_t)HP_ET; S.ext_a[tid] = eb; S.fill_a[tid] = whole - room; }
+      }
+      __syncthreads();
+      // scatter: waiting tails first, then the tile's tuples
+      for (uint32_t c = tid; c < HP_FAN * HP_CARRY; c += BLOCK) {
+        const uint32_t d = c / HP_CARRY, j = c % HP_CARRY;
+        if (j < S.cur[d]) { sorted[S.offs[d] + j] = carry[c]; S.sdigit[S.offs[d] + j] = (uint8_t)d; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < HP_ET / BLOCK; ++r)
+        if ((uint32_t)(r * BLOCK + tid) < nvalid) { const uint32_t at = S.offs[dig[r]] + atomicAdd(&S.cur[dig[r]], 1u); sorted[at] = t[r]; S.sdigit[at] = (uint8_t)dig[r]; }
+      // the next tile's loads travel while this one is written out
+      if (li + 1 < ntiles) { valid = tile_total(li + 1); tile_load(li + 1, valid, t); }
+      __syncthreads();
+      const uint32_t total = S.offs[HP_FAN - 1] + S.cur[HP_FAN - 1];
+      hp_u64x2* const out = reinterpret_cast<hp_u64x2*>(dst.tuples);
+      for (uint32_t k = tid; k < total; k += BLOCK) {
+        const uint32_t d = S.sdigit[k], local = k - S.offs[d], whole = S.whole[d];
+        const hp_u64x2 v = sorted[k];
+        if (local < whole) {
+          const uint32_t room = S.room[d];
+          if (local < room) out[(uint64_t)S.wext[d] * HP_ET + S.wfill[d] + local] = v;
+          else out[(uint64_t)S.ext_b[d] * HP_ET + (local - room)] = v;
+        } else if (local - whole < HP_CARRY) carry[d * HP_CARRY + (local - whole)] = v;
+      }
+      __syncthreads();
+      if (tid < HP_FAN) S.carry_n[tid] = S.tail[tid] < HP_CARRY ? S.tail[tid] : 0u;     // (>= 8 only on a void attempt that ran out of extents)
+    }
+  }
+  // ---- what still waits goes out as the last, partial line of its extent; open extents are closed with what they hold
+  __syncthreads();
+  if (tid < HP_FAN) {
+    uint32_t ea = S.ext_a[tid], fa = S.fill_a[tid];
+    const uint32_t n = S.carry_n[tid];
+    if (n) {
+      if (ea == ~0u || fa + n > (uint32_t)HP_ET) {
+        if (ea != ~0u) dst.fill[ea] = (uint16_t)fa;
+        const uint32_t got = atomicAdd(dcur, 1u);
+        if (dlo + got < dhi) { ea = dlo + got; fa = 0; dst.tag[ea] = (uint8_t)tid; } else { ea = ~0u; full = true; }
+      }
+      if (ea != ~0u) {
+        hp_u64x2* const out = reinterpret_cast<hp_u64x2*>(dst.tuples);
+        for (uint32_t j = 0; j < n; ++j) out[(uint64_t)ea * HP_ET + fa + j] = carry[tid * HP_CARRY + j];
+        fa += n;
+      }
+    }
+    if (ea != ~0u) dst.fill[ea] = (uint16_t)fa;
+  }
+  if (__ballot(full)) { if (full) atomicOr(counters + 2, VH_ERR_PART_FULL); }
+}
+
+// ------------------------------------------------------------------ between the levels: the slices of the last pool
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void hp_count_kernel(const VhHpArgs* __restrict__ HA, int kind) {
+  __shared__ unsigned int cnt[HP_FAN];
+  if (threadIdx.x < HP_FAN) cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const VhHpKind& K = HA->k[kind];
+  const uint32_t used = hp_pool_used(K.a);
+  for (uint32_t e = blockIdx.x * BLOCK + threadIdx.x; e < used; e += gridDim.x * BLOCK) {
+    const uint32_t f = K.a.fill[e];
+    if (f) atomicAdd(&cnt[K.a.tag[e]], f);
+  }
+  __syncthreads();
+  if (threadIdx.x < HP_FAN && cnt[threadIdx.x]) atomicAdd(K.count + threadIdx.x, cnt[threadIdx.x]);
+}
+__global__ __launch_bounds__(64) void hp_plan_kernel(const VhHpArgs* __restrict__ HA, int kind, unsigned long long* counters) {
+  const VhHpKind& K = HA->k[kind];
+  if (threadIdx.x == 0) {
+    unsigned long long at = 0;
+    for (int a = 0; a < HP_FAN; ++a) {
+      K.slice[a] = (uint32_t)(at < K.b.max_extents ? at : K.b.max_extents);
+      K.slice[HP_FAN + 1 + a] = 0;
+      // what the partition holds, in extents, + one open extent per digit of its single writer + the flush of the tails
+      if (K.count[a]) at += (K.count[a] + HP_ET - 1) / HP_ET + 2 * HP_FAN + 8;
+    }
+    K.slice[HP_FAN] = (uint32_t)(at < K.b.max_extents ? at : K.b.max_extents);
+    if (at > K.b.max_extents) atomicOr(counters + 2, VH_ERR_PART_FULL);
+  }
+}
+
+// ------------------------------------------------------------------ the ranges, one after the other, in LDS
+__device__ __forceinline__ uint32_t hp_slot(unsigned long long* keys, uint32_t gslots, uint64_t mkey, bool insert, bool& ok) {
+  const uint32_t mask = gslots - 1u;
+  if (mkey == VH_HASH_EMPTY) {                  // the one mixed key that looks like an empty slot: the table's extra slot
+    if (insert) keys[gslots] = 0ull;
+    return gslots;
+  }
+  uint32_t slot = (uint32_t)mkey & mask;
+  for (uint32_t probe = 0; probe <= mask; ++probe) {
+    unsigned long long seen = keys[slot];
+    if (seen == mkey) return slot;
+    if (seen == VH_HASH_EMPTY) {
+      if (!insert) break;
+      seen = atomicCAS(&keys[slot], (unsigned long long)VH_HASH_EMPTY, (unsigned long long)mkey);
+      if (seen == VH_HASH_EMPTY || seen == mkey) return slot;
+    }
+    slot = (slot + 1u) & mask;
+  }
+  ok = false;
+  return 0;
+}
+
+#define HP_OVF 128          // extents beyond the first of a (range, kind) that a block remembers (skewed keys only: a range's share of
+                            // uniform keys is a quarter of one extent)
+struct HpAggLds {
+  unsigned long long base, chunk_pos, chunk_end;
+  uint32_t count, bad, novf, wave_tot[16];
+  uint32_t ext1[2][HP_FAN];          // per kind and digit b: the range's first extent (~0u: none) ...
+  uint16_t fill1[2][HP_FAN];         // ... and the tuples in it
+  uint32_t ovf_ext[HP_OVF];          // the others: (kind << 8 | digit) in ovf_key
+  uint16_t ovf_fill[HP_OVF], ovf_key[HP_OVF];
+};
+
+// grid: HP_FAN x blocks_per_partition; block (a, j) works through ranges (a, b), b = j, j + blocks_per_partition, ...
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, const VhHpArgs* __restrict__ HA, int blocks_per_partition) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  __shared__ HpAggLds S;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int a = blockIdx.x / blocks_per_partition, j0 = blockIdx.x % blocks_per_partition;
+  unsigned long long* const gkeys = reinterpret_cast<unsigned long long*>(lds + HA->keys_off);
+  unsigned long long* const skeys = reinterpret_cast<unsigned long long*>(lds + HA->set_off);
+  const uint32_t GS = (uint32_t)HA->gslots, SS = (uint32_t)HA->sslots;
+  const int nkind = HA->nkind, passes = HA->passes, bitset_j = HA->bitset_j;
+  const bool pairs = nkind > 1 && bitset_j >= 0;
+  const int sub_bits = 31 - __builtin_clz((uint32_t)passes | 1u);
+  const uint32_t stride_w = P.hrec_bytes / 8u;
+  const hp_u64x2* const pool[2] = {reinterpret_cast<const hp_u64x2*>(HA->k[0].b.tuples), reinterpret_cast<const hp_u64x2*>(HA->k[nkind > 1 ? 1 : 0].b.tuples)};
+  // ---- which extent of slice a holds which range: ONE look at the slice's tags for all the block's ranges
+  for (int i = tid; i < 2 * HP_FAN; i += BLOCK) S.ext1[i / HP_FAN][i % HP_FAN] = ~0u;
+  if (tid == 0) { S.chunk_pos = 0; S.chunk_end = 0; S.novf = 0; S.bad = 0; }
+  __syncthreads();
+  for (int k = 0; k < nkind; ++k) {
+    const VhHpKind& K = HA->k[k];
+    const uint32_t lo = K.slice[a], cap = K.slice[a + 1] - lo, used = K.slice[HP_FAN + 1 + a];
+    const uint32_t hi = lo + (used < cap ? used : cap);
+    for (uint32_t e = lo + tid; e < hi; e += BLOCK) {
+      const uint32_t f = K.b.fill[e];
+      if (!f) continue;
+      const uint32_t d = K.b.tag[e];
+      if ((int)(d % (uint32_t)blocks_per_partition) != j0) continue;          // (another block's range)
+      if (atomicCAS(&S.ext1[k][d], ~0u, e) == ~0u) S.fill1[k][d] = (uint16_t)f;
+      else { const uint32_t at = atomicAdd(&S.novf, 1u); if (at < HP_OVF) { S.ovf_ext[at] = e; S.ovf_fill[at] = (uint16_t)f; S.ovf_key[at] = (uint16_t)(k << 8 | d); } }
+    }
+  }
+  __syncthreads();
+  if (S.novf > HP_OVF) { if (tid == 0) atomicOr(P.counters + 2, VH_ERR_HPART_FULL); return; }     // (skew beyond what a block remembers: the plain hash table)
+  const uint32_t novf = S.novf;
+  // the first 1024 tuples of a range's first extent of each kind travel while the previous range is worked on
+  constexpr int U = 1024 / BLOCK;
+  hp_u64x2 ng[U], np[U];
+  auto prefetch = [&](int b, hp_u64x2 (&g)[U], hp_u64x2 (&q)[U]) {
+    if (b >= HP_FAN) return;
+    const uint32_t e0 = S.ext1[0][b], f0 = e0 == ~0u ? 0u : S.fill1[0][b];
+#pragma unroll
+    for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f0) g[u] = pool[0][(uint64_t)e0 * HP_ET + u * BLOCK + tid];
+    if (pairs) {
+      const uint32_t e1 = S.ext1[1][b], f1 = e1 == ~0u ? 0u : S.fill1[1][b];
+#pragma unroll
+      for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f1) q[u] = pool[1][(uint64_t)e1 * HP_ET + u * BLOCK + tid];
+    }
+  };
+  prefetch(j0, ng, np);
+  for (int b = j0; b < HP_FAN; b += blocks_per_partition) {
+    hp_u64x2 cg[U], cp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { cg[u] = ng[u]; cp[u] = np[u]; }
+    const uint32_t e0 = S.ext1[0][b], f0 = e0 == ~0u ? 0u : S.fill1[0][b];
+    const uint32_t e1 = pairs ? S.ext1[1][b] : ~0u, f1 = e1 == ~0u ? 0u : S.fill1[1][b];
+    prefetch(b + blocks_per_partition, ng, np);
+    if (f0 == 0) continue;                       // (uniform: an empty range)
+    for (int pass = 0; pass < passes; ++pass) {
+      for (uint32_t g = tid; g <= GS; g += BLOCK) {
+        gkeys[g] = VH_HASH_EMPTY;
+        for (int j = 0; j < P.nmetric; ++j) {
+          const VhMetricDev& m = P.m[j];
+          if (m.sop() != SOP_BITSET && vh_sop_bytes(m.sop()) == 4) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)m.ident;
+          else reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = m.sop() == SOP_BITSET ? 0ull : m.ident;
+        }
+      }
+      for (uint32_t g = tid; g < SS; g += BLOCK) skeys[g] = VH_HASH_EMPTY;
+      __syncthreads();
+      bool bad = false;
+      // ---- tuples: (mixed key, payload word carrying the metric values at tshift)
+      auto group_tuple = [&](const hp_u64x2 tp) {
+        if (sub_bits && (int)((uint32_t)(tp.x >> (48 - sub_bits)) & (uint32_t)(passes - 1)) != pass) return;
+        bool ok = true;
+        const uint32_t slot = hp_slot(gkeys, GS, tp.x, true, ok);
+        if (!ok) { bad = true; return; }
+        for (int j = 0; j < P.nmetric; ++j) {
+          const VhMetricDev& m = P.m[j];
+          if (m.sop() == SOP_BITSET) continue;
+          uint64_t v = tp.y >> m.tshift();
+          if (vh_sop_bytes(m.sop()) == 4) { v &= 0xFFFFFFFFull; if (vh_sop_sext(m.sop())) v = (uint64_t)(int64_t)(int32_t)v; }
+          vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, slot, m.sop(), v);
+        }
+      };
+#pragma unroll
+      for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f0) group_tuple(pass == 0 ? cg[u] : pool[0][(uint64_t)e0 * HP_ET + u * BLOCK + tid]);
+      for (uint32_t i = U * BLOCK + tid; i < f0; i += BLOCK) group_tuple(pool[0][(uint64_t)e0 * HP_ET + i]);       // (a first extent of more than 1024 tuples)
+      for (uint32_t x = 0; x < novf; ++x)
+        if (S.ovf_key[x] == (uint16_t)b) for (uint32_t i = tid; i < S.ovf_fill[x]; i += BLOCK) group_tuple(pool[0][(uint64_t)S.ovf_ext[x] * HP_ET + i]);
+      __syncthreads();
+      // ---- pair tuples: (mixed key, two ids; an odd id count repeats the last one)
+      if (pairs) {
+        unsigned long long* const card = reinterpret_cast<unsigned long long*>(lds + P.m[bitset_j].lds_off);
+        auto pair_tuple = [&](const hp_u64x2 tp) {
+          if (sub_bits && (int)((uint32_t)(tp.x >> (48 - sub_bits)) & (uint32_t)(passes - 1)) != pass) return;
+          bool ok = true;
+          const uint32_t slot = hp_slot(gkeys, GS, tp.x, false, ok);
+          if (!ok) { bad = true; return; }                        // (cannot happen: a row's pair tuples follow its tuple into the same range)
+          const uint32_t idv[2] = {(uint32_t)tp.y, (uint32_t)(tp.y >> 32)};
+          const int n = idv[0] == idv[1] ? 1 : 2;
+          for (int q = 0; q < n; ++q) {
+            const unsigned long long key = ((unsigned long long)slot << 32) | idv[q];
+            uint32_t at = (uint32_t)(vh_splitmix64(key) >> 40) & (SS - 1u);
+            bool placed = false;
+            for (uint32_t probe = 0; probe < SS; ++probe) {
+              unsigned long long seen = skeys[at];
+              if (seen == key) { placed = true; break; }
+              if (seen == VH_HASH_EMPTY) {
+                seen = atomicCAS(&skeys[at], (unsigned long long)VH_HASH_EMPTY, key);
+                if (seen == VH_HASH_EMPTY) { atomicAdd(&card[slot], 1ull); placed = true; break; }
+                if (seen == key) { placed = true; break; }
+              }
+              at = (at + 1u) & (SS - 1u);
+            }
+            if (!placed) bad = true;
+          }
+        };
+#pragma unroll
+        for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f1) pair_tuple(pass == 0 ? cp[u] : pool[1][(uint64_t)e1 * HP_ET + u * BLOCK + tid]);
+        for (uint32_t i = U * BLOCK + tid; i < f1; i += BLOCK) pair_tuple(pool[1][(uint64_t)e1 * HP_ET + i]);
+        for (uint32_t x = 0; x < novf; ++x)
+          if (S.ovf_key[x] == (uint16_t)(0x100 | b)) for (uint32_t i = tid; i < S.ovf_fill[x]; i += BLOCK) pair_tuple(pool[1][(uint64_t)S.ovf_ext[x] * HP_ET + i]);
+        __syncthreads();
+      }
+      if (__ballot(bad)) { if (lane == 0) S.bad = 1; }
+      // ---- this pass's groups, as records: count, take a piece of the block's chunk of the list, write
+      uint32_t mine = 0;
+      for (uint32_t g = tid; g <= GS; g += BLOCK) mine += gkeys[g] != VH_HASH_EMPTY;
+      uint32_t incl = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+      if (lane == 63) S.wave_tot[wave] = incl;
+      __syncthreads();
+      uint32_t tot = 0, before = 0;
+      for (int w = 0; w < BLOCK / 64; ++w) { const uint32_t c = S.wave_tot[w]; tot += c; if (w < wave) before += c; }
+      if (tot && S.chunk_pos + tot > S.chunk_end) {       // (uniform) a new chunk of the list: what is left of the old one is marked empty
+        for (unsigned long long i = S.chunk_pos + tid; i < S.chunk_end; i += BLOCK) P.hkeys[i * stride_w] = VH_HASH_EMPTY;
+        __syncthreads();
+        if (tid == 0) {
+          const unsigned long long want = tot > HA->chunk ? tot : HA->chunk;
+          const unsigned long long got = atomicAdd(P.counters + 1, want);
+          S.chunk_pos = got; S.chunk_end = got + want;
+        }
+        __syncthreads();
+      }
+      const unsigned long long base = S.chunk_pos;
+      unsigned long long at = base + before + (incl - mine);
+      if (base + tot <= HA->list_cap) {
+        for (uint32_t g = tid; g <= GS; g += BLOCK) {
+          const unsigned long long mk = gkeys[g];
+          if (mk == VH_HASH_EMPTY) continue;
+          const unsigned long long key = vh_unmix64(g == GS ? VH_HASH_EMPTY : mk);
+          P.hkeys[at * stride_w] = key;     // (a group whose KEY is the empty marker is told apart by the list's last, reserved record)
+          for (int j = 0; j < P.nmetric; ++j) {
+            const VhMetricDev& m = P.m[j];
+            char* dstp = vh_hash_state(P, m, key == VH_HASH_EMPTY ? HA->list_cap : at);
+            if (m.sop() != SOP_BITSET && vh_sop_bytes(m.sop()) == 4) *reinterpret_cast<uint32_t*>(dstp) = reinterpret_cast<const uint32_t*>(lds + m.lds_off)[g];
+            else *reinterpret_cast<uint64_t*>(dstp) = reinterpret_cast<const uint64_t*>(lds + m.lds_off)[g];
+          }
+          if (key == VH_HASH_EMPTY) atomicOr(P.counters + 3, 1ull);
+          ++at;
+        }
+      } else if (tid == 0) atomicOr(P.counters + 2, VH_ERR_PART_FULL);
+      __syncthreads();
+      if (tid == 0) S.chunk_pos = base + tot;
+    }
+  }
+  __syncthreads();
+  if (tid == 0 && S.bad) atomicOr(P.counters + 2, VH_ERR_HPART_FULL);
+  for (unsigned long long i = S.chunk_pos + tid; i < S.chunk_end; i += BLOCK) P.hkeys[i * stride_w] = VH_HASH_EMPTY;
+}
+#endif  // VH_HPART_KERNELS

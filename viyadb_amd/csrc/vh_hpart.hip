@@ -1,0 +1,25 @@
+// Hashed partitioning of the hash path: the kernels behind the scan (vh_hpart.h) and their launch sequence.
+#define VH_HPART_KERNELS
+#include "vh_hpart.h"
+#include "vh_launch.h"
+#include <cstdlib>
+
+// After the scan kernel has written the stream pools: level A, the slices of the last pool, level B, the ranges.
+void vh_launch_hpart(const VhPlanDev& P, const VhHpArgs* d_args, int nkind, int num_cu, size_t agg_lds, int bpp, hipStream_t s) {
+  static bool once = false;
+  const size_t sl = hp_scatter_lds_bytes();
+  if (!once) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_scatter_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl);
+    once = true;
+  }
+  if (agg_lds > 64 * 1024)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_aggregate_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)agg_lds);
+  static const int grid_a = getenv("VH_HP_GRID_A") ? atoi(getenv("VH_HP_GRID_A")) : 0;       // measurement
+  for (int k = 0; k < nkind; ++k) hipLaunchKernelGGL((hp_scatter_kernel<1024>), dim3(grid_a > 0 ? grid_a : num_cu), dim3(1024), sl, s, d_args, k, 0, P.counters);
+  for (int k = 0; k < nkind; ++k) {
+    hipLaunchKernelGGL((hp_count_kernel<256>), dim3(num_cu), dim3(256), 0, s, d_args, k);
+    hipLaunchKernelGGL(hp_plan_kernel, dim3(1), dim3(64), 0, s, d_args, k, P.counters);
+  }
+  for (int k = 0; k < nkind; ++k) hipLaunchKernelGGL((hp_scatter_kernel<1024>), dim3(HP_FAN), dim3(1024), sl, s, d_args, k, 1, P.counters);
+  hipLaunchKernelGGL((hp_aggregate_kernel<512>), dim3(HP_FAN * bpp), dim3(512), agg_lds, s, P, d_args, bpp);
+}

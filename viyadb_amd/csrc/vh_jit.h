@@ -14,7 +14,7 @@ struct VhJitPred { int slot, type, width; };      // width: bytes per element as
 struct VhJitCol {           // one gathered value of a survivor
   int slot = 0, type = 0, pitch = 0;   // pitch: bytes between consecutive rows (element size, or the record size of a projection)
   int rec = -1, off = 0;               // rec >= 0: member of payload projection `rec`, at byte `off` of its record
-  int sext = 0, rowid = 0;             // sign-extend to 64 bits (dense digits, signed MIN / MAX); the virtual row-id column
+  int sext = 0, rowid = 0, bitset = 0;             // sign-extend to 64 bits (dense digits, signed MIN / MAX); the virtual row-id column
   // group columns
   int gran = VH_T_NONE, nroll = 0, micro = 0, key_word = 0, key_shift = 0;
   int roll_unit[VH_MAX_ROLLUP] = {};
@@ -25,6 +25,7 @@ struct VhJitCol {           // one gathered value of a survivor
 struct VhJitShape {
   int mode = 0, block = 256, scope = 0, xcd = 0, carrier = -1, tw = 0, key_words = 1, lds_hash = 0, gid32 = 0;
   int stage = 0;                        // DENSE_PART: tuples leave for HBM as whole 128-byte lines (vh_part_staged_add)
+  int hpart = 0, bitset_j = -1;         // HASH: hashed partitioning (hash_part_agg_kernel); the metric that is a bitset (its ids travel as pair tuples)
   int npred = 0;
   VhJitPred pred[VJ_MAX_PRED];
   std::vector<VhProgOp> prog;           // postfix filter; VhProgOp::pslot indexes pred[], ::lit the literal pool

@@ -52,10 +52,20 @@ __device__ __forceinline__ void vj_rollup_all(const VhPlanDev& P, uint64_t (&gv)
   }
 }
 
+// What a wave carries through the scan besides its registers of predicate values: partition cursors (tuples; pair tuples of the
+// hashed partitioning), the waiting lines of the whole-line writer, its luck with the LDS front table.
+struct VjWave {
+  VhPartWave W, WB;
+  VhPartTile T, TB;
+  VhPartStage S;
+  VhLdsHashWave H;
+};
+
 // One surviving row per active lane: AggTuple key, then Metrics::Update (store.cc:131-161) into the plan's table organisation.
 template <class J>
 __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, char* lds, uint64_t xoff,
-                                         unsigned long long& nfresh, VhPartWave& W, VhPartTile& T, VhLdsHashWave& H, VhPartStage& S) {
+                                         unsigned long long& nfresh, VjWave& V) {
+  VhPartWave& W = V.W; VhPartTile& T = V.T; VhLdsHashWave& H = V.H; VhPartStage& S = V.S;
   constexpr int MODE = J::MODE;
   constexpr int NG = J::NG, NM = J::NM;
   if (!active) row = 0;
@@ -109,6 +119,32 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
       bad |= d >= P.g[i].extent;
       gid += d * P.g[i].stride;
     }
+  }
+  if constexpr (MODE == VH_MODE_HASH && J::HPART) {
+    // hashed partitioning (vh_hpart.h): the row becomes a (mixed key, payload) tuple and, per two ids of its bitset metric, a
+    // (mixed key, ids) pair tuple; hp_scatter_kernel and hp_aggregate_kernel do the rest
+    const int lane = (int)(threadIdx.x & 63);
+    const uint64_t mkey = vh_splitmix64(key[0]);
+    const uint32_t p = 0u;          // the tuples leave unpartitioned, 1 KiB per wave store (one "partition"): hp_scatter_kernel sorts them out
+    uint64_t words[2] = {mkey, 0ull};
+#pragma unroll
+    for (int j = 0; j < NM; ++j)
+      if (J::m_sop[j] != SOP_BITSET) words[1] |= (vh_sop_bytes(J::m_sop[j]) == 4 ? (mv[j] & 0xFFFFFFFFull) : mv[j]) << J::m_tshift[j];
+    vh_part_direct_add<2, 1, 2>(P, T, W, active, words, p, lane);
+    if constexpr (J::BITSET_J >= 0) {
+      const int b = (int)P.m[J::BITSET_J].slot();
+      uint64_t k = 0, k1 = 0;
+      const uint32_t* ids = nullptr;
+      if (active) { const uint64_t* offs = P.bs_offs[b][seg]; k = offs[row]; k1 = offs[row + 1]; ids = reinterpret_cast<const uint32_t*>(P.bs_vals[b][seg]); }
+      while (__ballot(k < k1)) {
+        const bool more = k < k1;
+        const uint32_t a = more ? ids[k] : 0u, a2 = more && k + 1 < k1 ? ids[k + 1] : a;      // an odd count repeats the last id: a set does not mind
+        const uint64_t w2[2] = {mkey, (uint64_t)a | ((uint64_t)a2 << 32)};
+        vh_part_direct_add<2, 3, 2>(P, V.TB, V.WB, more, w2, p, lane);
+        k += 2;
+      }
+    }
+    return;
   }
   if constexpr (MODE == VH_MODE_HASH) {
     if constexpr (J::LDS_HASH) {
@@ -210,14 +246,13 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform, and the compiler is told so: rows, counts and
                                                                                  // ballots of the step then live in scalar registers
   uint32_t* q = reinterpret_cast<uint32_t*>(lds + ((MODE == VH_MODE_DENSE_LDS || MODE == VH_MODE_HASH) ? P.lds_bytes : 0)) + wave * VJ_QUEUE_CAP;
-  VhLdsHashWave H{0u, 0u, false, 0ull};
+  VjWave V;
+  V.H = VhLdsHashWave{0u, 0u, false, 0ull};
+  V.S = VhPartStage{0u, nullptr};
   if constexpr (MODE == VH_MODE_HASH && J::LDS_HASH) vh_lds_hash_init(P, lds, BLOCK);
-  VhPartWave W;
-  VhPartTile T;
-  if constexpr (MODE == VH_MODE_DENSE_PART) vh_part_tile_init(P, lds, T, W);
-  VhPartStage S{0u, nullptr};
+  if constexpr (MODE == VH_MODE_DENSE_PART || (MODE == VH_MODE_HASH && J::HPART)) { vh_part_tile_init(P, lds, V.T, V.W); vh_part_tile_init(P, lds, V.TB, V.WB); }
   if constexpr (MODE == VH_MODE_DENSE_PART && J::STAGE)      // one waiting line per partition and wave, behind the block's queues
-    S.lines = reinterpret_cast<uint64_t*>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)wave * VH_STAGE_BYTES);
+    V.S.lines = reinterpret_cast<uint64_t*>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)wave * VH_STAGE_BYTES);
   if constexpr (MODE == VH_MODE_DENSE_LDS) {
     // identities: 0 for SUM/AVG/COUNT, type max for MIN, cpp_min_value for MAX (src/codegen/db/store.cc:107-117)
 #pragma unroll
@@ -280,14 +315,15 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
       cnt -= take;
       const bool act = (uint32_t)lane < take;
       const uint32_t r = act ? q[cnt + lane] : 0u;
-      vj_drain<J>(P, seg, r, act, lds, xoff, nfresh, W, T, H, S);
+      vj_drain<J>(P, seg, r, act, lds, xoff, nfresh, V);
       __builtin_amdgcn_wave_barrier();
     }
     have = nhave; seg = nseg; wave_base = nwave_base; seg_rows = nseg_rows;
-    if (MODE == VH_MODE_HASH && H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
+    if (MODE == VH_MODE_HASH && V.H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
   }
 
-  if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE) vh_part_stage_finish(P, T, S, lane); else vh_part_tile_finish(P, T, lane); }
+  if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE) vh_part_stage_finish(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); }
+  if constexpr (MODE == VH_MODE_HASH && J::HPART) { vh_part_tile_finish<1>(P, V.T, lane); if constexpr (J::BITSET_J >= 0) vh_part_tile_finish<3>(P, V.TB, lane); }
   if (lane == 0) {
     if (npassed) atomicAdd(P.counters + 0, npassed);
     if (nfresh) atomicAdd(P.counters + 1, nfresh);

@@ -30,6 +30,17 @@ __host__ __device__ __forceinline__ uint64_t vh_splitmix64(uint64_t x) {
   return x ^ (x >> 31);
 }
 
+// vh_splitmix64 is a bijection of the 64-bit integers (an addition, three xor-shifts, two odd multiplications); its inverse
+// lets the hashed partitioning carry a group key as its mixed image and get the key back at the end.
+__host__ __device__ __forceinline__ uint64_t vh_unmix64(uint64_t x) {
+  x ^= x >> 31; x ^= x >> 62;
+  x *= 0x319642B2D24D8EC3ull;           // inverse of 0x94D049BB133111EB mod 2^64
+  x ^= x >> 27; x ^= x >> 54;
+  x *= 0x96DE1B173F119089ull;           // inverse of 0xBF58476D1CE4E5B9 mod 2^64
+  x ^= x >> 30; x ^= x >> 60;
+  return x - 0x9E3779B97F4A7C15ull;
+}
+
 template <typename T> struct VhVec4 { typedef T type __attribute__((ext_vector_type(4))); };
 typedef uint32_t vh_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -819,12 +830,26 @@ struct VhPartTile {
   uint32_t r_ext;      // lane p: partition p's current extent (~0u: none) ...
   uint32_t r_fill;     // ... and the tuples already in it
 };
-// LEVEL 1: phase 1 writes pool 1 (partition = gid >> part_shift); LEVEL 2: part_split_kernel writes pool 2 (sub-partition 0..63)
-template <int LEVEL> __device__ __forceinline__ uint64_t* vh_pool_tuples(const VhPlanDev& P) { return LEVEL == 1 ? P.tuples : P.tuples2; }
-template <int LEVEL> __device__ __forceinline__ uint16_t* vh_pool_missing(const VhPlanDev& P) { return LEVEL == 1 ? P.extent_missing : P.extent_missing2; }
-template <int LEVEL> __device__ __forceinline__ uint8_t* vh_pool_tags(const VhPlanDev& P) { return LEVEL == 1 ? P.extent_part : P.extent_part2; }
-template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_et(const VhPlanDev& P) { return (uint32_t)(LEVEL == 1 ? P.ext_tuples : P.ext_tuples2); }
-template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_npart(const VhPlanDev& P) { return LEVEL == 1 ? (uint32_t)P.npart : 64u; }
+// LEVEL 1: phase 1 writes pool 1 (partition = gid >> part_shift); LEVEL 2: part_split_kernel writes pool 2 (sub-partition 0..63);
+// LEVEL 3 / 4: the same two pools of the pair tuples of the hashed partitioning (VhPlanDev::tuplesB ...)
+template <int LEVEL> __device__ __forceinline__ uint64_t* vh_pool_tuples(const VhPlanDev& P) { return LEVEL == 1 ? P.tuples : LEVEL == 2 ? P.tuples2 : LEVEL == 3 ? P.tuplesB : P.tuples2B; }
+template <int LEVEL> __device__ __forceinline__ uint16_t* vh_pool_missing(const VhPlanDev& P) { return LEVEL == 1 ? P.extent_missing : LEVEL == 2 ? P.extent_missing2 : LEVEL == 3 ? P.extent_missingB : P.extent_missing2B; }
+template <int LEVEL> __device__ __forceinline__ uint8_t* vh_pool_tags(const VhPlanDev& P) { return LEVEL == 1 ? P.extent_part : LEVEL == 2 ? P.extent_part2 : LEVEL == 3 ? P.extent_partB : P.extent_part2B; }
+template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_et(const VhPlanDev& P) { return (uint32_t)((LEVEL & 1) ? P.ext_tuples : P.ext_tuples2); }
+template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_npart(const VhPlanDev& P) { return (LEVEL & 1) ? (uint32_t)P.npart : 64u; }
+// the pools as run-time values (plan / split / aggregation kernels take `which`: 0 = the tuples, 1 = the pair tuples)
+struct VhPools {
+  uint64_t* t1; uint16_t* miss1; uint8_t* tag1; uint32_t max1; unsigned long long allocated1;
+  uint64_t* t2; uint16_t* miss2; uint8_t* tag2; uint32_t max2; uint32_t* l2;
+};
+__device__ __forceinline__ VhPools vh_pools(const VhPlanDev& P, int which) {
+  VhPools Q;
+  if (which == 0) { Q.t1 = P.tuples; Q.miss1 = P.extent_missing; Q.tag1 = P.extent_part; Q.max1 = P.max_extents; Q.allocated1 = P.counters[5];
+                    Q.t2 = P.tuples2; Q.miss2 = P.extent_missing2; Q.tag2 = P.extent_part2; Q.max2 = P.max_extents2; Q.l2 = P.l2; }
+  else { Q.t1 = P.tuplesB; Q.miss1 = P.extent_missingB; Q.tag1 = P.extent_partB; Q.max1 = P.max_extentsB; Q.allocated1 = P.counters[8];
+         Q.t2 = P.tuples2B; Q.miss2 = P.extent_missing2B; Q.tag2 = P.extent_part2B; Q.max2 = P.max_extents2B; Q.l2 = P.l2B; }
+  return Q;
+}
 __host__ __device__ __forceinline__ size_t vh_part_tile_bytes(const VhPlanDev& P) {
   return ((size_t)VH_PART_TILE * P.tw * 8 + 64 * 4 + 15) / 16 * 16;
 }
@@ -840,9 +865,9 @@ __device__ __forceinline__ void vh_part_tile_init(const VhPlanDev& P, char* area
 template <int LEVEL>
 __device__ __forceinline__ uint32_t vh_part_new_extent(const VhPlanDev& P, VhPartWave& W, int p, int lane) {
   if (W.chunk_next == W.chunk_end) {
-    if (LEVEL == 1) {
+    if (LEVEL & 1) {
       unsigned long long c = 0;
-      if (lane == 0) c = atomicAdd(P.counters + 5, (unsigned long long)VH_EXT_CHUNK);
+      if (lane == 0) c = atomicAdd(P.counters + (LEVEL == 1 ? 5 : 8), (unsigned long long)VH_EXT_CHUNK);
       c = __shfl(c, 0);
       W.chunk_next = (uint32_t)c;
     } else {
@@ -854,7 +879,7 @@ __device__ __forceinline__ uint32_t vh_part_new_extent(const VhPlanDev& P, VhPar
     W.chunk_end = W.chunk_next + VH_EXT_CHUNK;
   }
   const uint32_t ext = W.chunk_next++;
-  const bool ok = ext < (LEVEL == 1 ? P.max_extents : W.limit);
+  const bool ok = ext < (LEVEL == 1 ? P.max_extents : LEVEL == 3 ? P.max_extentsB : W.limit);
   if (ok && lane == 0) vh_pool_tags<LEVEL>(P)[ext] = (uint8_t)p;
   if (!ok) {
     if (lane == 0) atomicOr(P.counters + 2, VH_ERR_PART_FULL);  // the host re-runs with a larger tuple buffer
@@ -1965,28 +1990,36 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
 // After phase 1: how many tuples did each partition get? One block counts them off the extent tags and lays the
 // partitions' slices of pool 2 out back to back: tuples / extent size, plus what the splitting waves can leave open
 // (every wave of `waves_per_part` may hold one partly filled extent per sub-partition and an unused rest of a chunk).
+// Two launches: every CU counts its share of the extent tags into l2[VH_L2_NEXT + p] (zero when the query starts), one block then
+// turns the counts into slices and resets the cursors. (One block doing both took 0.39 ms for the 100 K extents of a 60 M-tuple pool.)
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void part_l2_plan_kernel(const VhPlanDev P, int waves_per_part) {
-  __shared__ unsigned long long cnt[VH_MAX_PART];
+__global__ __launch_bounds__(BLOCK) void part_l2_count_kernel(const VhPlanDev P, int which = 0) {
+  __shared__ unsigned int cnt[VH_MAX_PART];
   if (threadIdx.x < VH_MAX_PART) cnt[threadIdx.x] = 0;
   __syncthreads();
-  const unsigned long long allocated = P.counters[5];
-  const uint32_t total = allocated < P.max_extents ? (uint32_t)allocated : P.max_extents;
-  for (uint32_t e = threadIdx.x; e < total; e += BLOCK) {
-    const uint8_t p = P.extent_part[e];
-    if (p != 0xFF) atomicAdd(&cnt[p], (unsigned long long)((uint32_t)P.ext_tuples - P.extent_missing[e]));
+  const VhPools Q = vh_pools(P, which);
+  const uint32_t total = Q.allocated1 < Q.max1 ? (uint32_t)Q.allocated1 : Q.max1;
+  for (uint32_t e = blockIdx.x * BLOCK + threadIdx.x; e < total; e += gridDim.x * BLOCK) {
+    const uint8_t p = Q.tag1[e];
+    if (p != 0xFF) atomicAdd(&cnt[p], (uint32_t)P.ext_tuples - Q.miss1[e]);
   }
   __syncthreads();
+  if (threadIdx.x < VH_MAX_PART && cnt[threadIdx.x]) atomicAdd(Q.l2 + VH_L2_WORDS + threadIdx.x, cnt[threadIdx.x]);     // (scratch words behind the table proper)
+}
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void part_l2_plan_kernel(const VhPlanDev P, int waves_per_part, int which = 0) {
+  const VhPools Q = vh_pools(P, which);
   if (threadIdx.x == 0) {
     unsigned long long at = 0;
     for (int p = 0; p < P.npart; ++p) {
-      P.l2[p] = (uint32_t)(at < P.max_extents2 ? at : P.max_extents2);
-      P.l2[VH_L2_NEXT + p] = 0;
+      const unsigned long long c = Q.l2[VH_L2_WORDS + p];
+      Q.l2[p] = (uint32_t)(at < Q.max2 ? at : Q.max2);
+      Q.l2[VH_L2_NEXT + p] = 0;
       // (+ 1/4: an extent is closed as soon as a drain's tuples of its sub-partition do not fit, so skewed data leaves up to 63 of 256 slots unused)
-      if (cnt[p]) at += (cnt[p] + cnt[p] / 4 + (uint32_t)P.ext_tuples2 - 1) / (uint32_t)P.ext_tuples2 + (unsigned long long)waves_per_part * (64 + VH_EXT_CHUNK);
+      if (c) at += (c + c / 4 + (uint32_t)P.ext_tuples2 - 1) / (uint32_t)P.ext_tuples2 + (unsigned long long)waves_per_part * (64 + VH_EXT_CHUNK);
     }
-    P.l2[P.npart] = (uint32_t)(at < P.max_extents2 ? at : P.max_extents2);
-    if (at > P.max_extents2) atomicOr(P.counters + 2, VH_ERR_PART_FULL);     // the host re-runs with a larger second pool
+    Q.l2[P.npart] = (uint32_t)(at < Q.max2 ? at : Q.max2);
+    if (at > Q.max2) atomicOr(P.counters + 2, VH_ERR_PART_FULL);     // the host re-runs with a larger second pool
   }
 }
 
@@ -2049,7 +2082,8 @@ struct VhSplitTile {             // LDS, behind the sorted copy
 };
 __host__ __device__ __forceinline__ size_t vh_split_tile_bytes() { return (size_t)VH_SPLIT_TILE_TUPLES * 16 + sizeof(VhSplitTile); }
 
-template <int BLOCK>
+// WHICH: 0 = the tuples, 1 = the pair tuples of the hashed partitioning (their own pools, same layout)
+template <int BLOCK, int WHICH = 0>
 __global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev P, int blocks_per_part) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
@@ -2061,26 +2095,28 @@ __global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev 
   VhPartWave W;
   VhPartTile T;
   vh_part_tile_init(P, nullptr, T, W);            // only wave 0 uses them
-  W.base = P.l2[part]; W.limit = P.l2[part + 1]; W.cursor = P.l2 + VH_L2_NEXT + part;
-  const unsigned long long allocated = P.counters[5];
-  const uint32_t total = allocated < P.max_extents ? (uint32_t)allocated : P.max_extents;
+  const VhPools Q = vh_pools(P, WHICH);
+  constexpr int L2 = WHICH ? 4 : 2;
+  W.base = Q.l2[part]; W.limit = Q.l2[part + 1]; W.cursor = Q.l2 + VH_L2_NEXT + part;
+  const uint32_t total = Q.allocated1 < Q.max1 ? (uint32_t)Q.allocated1 : Q.max1;
+  const int gshift = P.gid_shift;      // where the 32-bit partition key sits in word 0
   const uint32_t ext_tuples = (uint32_t)P.ext_tuples, et2 = (uint32_t)P.ext_tuples2;
-  u64x2* const pool2 = reinterpret_cast<u64x2*>(P.tuples2);
+  u64x2* const pool2 = reinterpret_cast<u64x2*>(Q.t2);
   const uint32_t gsz = vh_tag_group(total, (uint32_t)blocks_per_part);
   for (uint32_t c0 = (uint32_t)b * gsz; c0 < total; c0 += (uint32_t)blocks_per_part * gsz) {
-    uint64_t mine = __ballot((uint32_t)lane < gsz && c0 + lane < total && P.extent_part[c0 + lane] == (uint8_t)part);   // the same in every wave
+    uint64_t mine = __ballot((uint32_t)lane < gsz && c0 + lane < total && Q.tag1[c0 + lane] == (uint8_t)part);   // the same in every wave
     while (mine) {
       const uint32_t ext = c0 + (uint32_t)__builtin_ctzll(mine);
       mine &= mine - 1;
-      const uint32_t valid = ext_tuples - P.extent_missing[ext];
-      const u64x2* base = reinterpret_cast<const u64x2*>(P.tuples) + (uint64_t)ext * ext_tuples;
+      const uint32_t valid = ext_tuples - Q.miss1[ext];
+      const u64x2* base = reinterpret_cast<const u64x2*>(Q.t1) + (uint64_t)ext * ext_tuples;
       for (uint32_t i0 = 0; i0 < valid; i0 += VH_SPLIT_TILE_TUPLES) {
         u64x2 t[R];
         uint32_t sub[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const uint32_t i = i0 + r * BLOCK + tid;
-          if (i < valid) { t[r] = __builtin_nontemporal_load(base + i); sub[r] = ((uint32_t)t[r].x >> P.agg_shift) & 63u; }
+          if (i < valid) { t[r] = __builtin_nontemporal_load(base + i); sub[r] = ((uint32_t)(t[r].x >> gshift) >> P.agg_shift) & 63u; }
           else sub[r] = 0xFFFFFFFFu;
         }
         if (tid < 64) S.hist[tid] = 0;
@@ -2099,8 +2135,8 @@ __global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev 
             const int q = __builtin_ctzll(need);
             need &= need - 1;
             const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, q), oldfill = __builtin_amdgcn_readlane(T.r_fill, q);
-            if (old != ~0u && lane == 0) P.extent_missing2[old] = (uint16_t)(et2 - oldfill);
-            const uint32_t e2 = vh_part_new_extent<2>(P, W, q, lane);
+            if (old != ~0u && lane == 0) Q.miss2[old] = (uint16_t)(et2 - oldfill);
+            const uint32_t e2 = vh_part_new_extent<L2>(P, W, q, lane);
             if (lane == q) { T.r_ext = e2; T.r_fill = 0; }
           }
           S.rbase[lane] = incl - cnt;
@@ -2117,7 +2153,7 @@ __global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev 
         const uint32_t n = S.ntile;
         for (uint32_t k = tid; k < n; k += BLOCK) {
           const u64x2 v = sorted[k];
-          const uint32_t sb = ((uint32_t)v.x >> P.agg_shift) & 63u;
+          const uint32_t sb = ((uint32_t)(v.x >> gshift) >> P.agg_shift) & 63u;
           const uint64_t d = S.dst[sb];
           if (d != ~0ull) pool2[d + (k - S.rbase[sb])] = v;
         }
@@ -2125,7 +2161,8 @@ __global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev 
       }
     }
   }
-  if (wave == 0) vh_part_tile_finish<2>(P, T, lane);
+  if (wave == 0) vh_part_tile_finish<L2>(P, T, lane);
 }
+
 
 

@@ -97,6 +97,7 @@ struct VhEmitArgs {
   int32_t nhaving; int32_t pad2;
   unsigned long long* total_groups;   // groups before HAVING = agg_map.size()
   VhProgOp hprog[VH_MAX_HAVING];
+  const unsigned long long* n_dev;    // != nullptr: the hash table is a compact list, entries [0, *n_dev) are all groups (hashed partitioning)
   uint32_t htype[VH_MAX_HAVING];      // element type the comparison happens in
   uint64_t hlits[VH_MAX_HAVING_LITS];
 };
@@ -149,7 +150,12 @@ __device__ __forceinline__ uint64_t vh_emit_state(const VhEmitArgs& A, uint64_t 
 __device__ __forceinline__ bool vh_emit_have(const VhEmitArgs& A, uint64_t i, bool& present) {
   bool have = false;
   if (i < A.n) {
-    if (A.mode == VH_MODE_HASH) {
+    if (A.mode == VH_MODE_HASH && A.n_dev) {       // a list of group records, handed out in chunks whose unused tails hold the empty marker; the
+                                                   // group whose key IS the marker lives in the last, reserved record, like in the table proper
+      if (i + 1 == A.n) have = A.counters[3] != 0;
+      else have = i < *A.n_dev && A.hkeys[i * A.hstride] != VH_HASH_EMPTY;
+    }
+    else if (A.mode == VH_MODE_HASH) {
       if (i + 1 == A.n) have = A.key_words == 1 && A.counters[3] != 0;  // reserved slot
       else have = A.key_words == 1 ? A.hkeys[i * A.hstride] != VH_HASH_EMPTY : A.htags[i] == 2u;
     } else if (A.present_carrier >= 0) {
@@ -668,6 +674,22 @@ __global__ __launch_bounds__(256) void narrow_kernel(const uint32_t* src, uint64
   for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < rows_padded; i += (uint64_t)gridDim.x * 1024) {
     const vh_u32x4 v = *reinterpret_cast<const vh_u32x4*>(s + i);
     d[i] = (T)v.x; d[i + 1] = (T)v.y; d[i + 2] = (T)v.z; d[i + 3] = (T)v.w;
+  }
+}
+
+// Every buffer a query must clear before its scan — counters, zero-identity states, presence bytes, extent tags, empty hash
+// keys — in ONE launch: the runtime's fill kernels cost ~8 us apiece back to back, five to seven of them per query were
+// 45 us of a 2.6 ms C3 step (profiles/r03/NOTES.md). Regions are 16-byte multiples (scratch regions are padded to 256 B).
+#define VH_INIT_MAX 12
+struct VhInitArgs { int32_t n, pad; char* p[VH_INIT_MAX]; uint64_t end[VH_INIT_MAX]; uint32_t pat[VH_INIT_MAX]; };   // end: running total of 16-byte units
+__global__ __launch_bounds__(256) void init_regions_kernel(VhInitArgs A) {
+  const uint64_t total = A.end[A.n - 1];
+  for (uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (uint64_t)gridDim.x * 256) {
+    int r = 0;
+    while (u >= A.end[r]) ++r;
+    const uint64_t local = u - (r ? A.end[r - 1] : 0);
+    vh_u32x4 v; v.x = v.y = v.z = v.w = A.pat[r];
+    reinterpret_cast<vh_u32x4*>(A.p[r])[local] = v;
   }
 }
 

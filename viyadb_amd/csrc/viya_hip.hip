@@ -12,6 +12,7 @@
 #include "vh_small_kernels.h"
 #include "vh_launch.h"
 #include "vh_jit.h"
+#include "vh_hpart.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -858,6 +859,8 @@ extern "C" int vh_segment_stats(vh_table* t, uint32_t seg, int32_t col, vh_anynu
 
 // ------------------------------------------------------------------ results
 struct vh_result {
+  bool hpart = false;               // hashed partitioning ran: the table is a compact list of group records
+  VhHpArgs hp_args;                 // ... and the pool descriptors its kernels were given
   vh_table* table = nullptr;
   vh_result_info info{};
   int mode = 0;
@@ -1128,7 +1131,7 @@ struct VhAgreed {
 static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_result** out, uint64_t hash_capacity_override,
                                bool force_hash, uint64_t part_tuples_override = 0, bool no_part = false,
                                bool plan_only = false, VhSummary* summary_out = nullptr, const VhAgreed* ag = nullptr,
-                               bool device_rows = false) {
+                               bool device_rows = false, uint32_t hp_passes_override = 0, bool no_hpart = false) {
   // ---------------- validate
   if (p->nfilter < 0 || p->nlits < 0 || p->ngroups < 0 || p->nmetrics < 0 || p->nhaving < 0)
     return vh_fail(VH_E_INVALID, "plan has a negative count");
@@ -1613,8 +1616,9 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     mode = VH_MODE_HASH;
   }
   const bool fast = fast_ok && P.ngroup <= VH_FAST_COLS && P.nmetric <= VH_FAST_COLS && P.nbitset == 0;   // npred == 0: no filter
-  if (P.ngroup > VJ_MAX_COLS || P.nmetric > VJ_MAX_COLS || P.nbitset) jit_try = false;
-  const bool fastj = fast || jit_try;       // a register-resident scan: pre-built, or compiled for this plan shape
+  if (P.ngroup > VJ_MAX_COLS || P.nmetric > VJ_MAX_COLS || P.nbitset > 1 || (P.nbitset && P.bs_wide[0])) jit_try = false;
+  // (a bitset metric: only the hashed partitioning below has a compiled form for it)
+  const bool fastj = fast || (jit_try && P.nbitset == 0);       // a register-resident scan: pre-built, or compiled for this plan shape
   // "Lanes" kernel (no compaction) for small LDS tables when most rows pass: see scan_agg_lanes_kernel
   bool lanes = false;
   if (mode == VH_MODE_DENSE_LDS && fast && !(p->flags & VH_PLAN_NO_LANES) && P.ngroup <= VH_LANES_COLS && P.nmetric <= VH_LANES_COLS &&
@@ -1837,6 +1841,98 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     }
   }
 
+  // ---------------- hashed partitioning (HASH organisation with MANY groups: hash_part_agg_kernel, vh_kernels.h)
+  // With tens of millions of groups every survivor costs the plain hash table 2-5 read-modify-writes at random addresses of a
+  // table no cache holds — the device does ~20 G of those per second (C5: 312 M per 125 M rows = 15.9 ms) — and a count-distinct
+  // makes it three more per row. Survivors are instead written out as 16-byte tuples keyed by a bijective mix of the packed group key,
+  // radix-partitioned by its top bits (64 ways in the scan kernel, 64 more in part_split_tile_kernel) and aggregated range by range
+  // in LDS: sequential traffic of 16 B per tuple and level instead of a 128-byte line read and written per update.
+  bool hpart = false;
+  uint64_t hp_tuple_cap = 0, hp_pair_cap = 0;
+  int hp_bpp = 1;
+  uint32_t hp_chunk = 256;
+  if (mode == VH_MODE_HASH && jit_try && (!lanes || (p->flags & VH_PLAN_FORCE_HPART)) && !no_hpart && !(p->flags & VH_PLAN_NO_HPART) && !ag && !device_rows && P.key_words == 1 && P.nmetric >= 1 && rows_to_scan) {
+    int bits = 0, nb = 0;
+    bool ok = true;
+    for (int j = 0; j < P.nmetric; ++j) {
+      if (P.m[j].sop() == SOP_BITSET) { ++nb; ok &= !P.bs_wide[P.m[j].slot()]; }
+      else bits += 8 * vh_sop_bytes(P.m[j].sop());
+    }
+    ok &= bits <= 64 && nb == P.nbitset && nb <= 1;
+    if (ok) {
+      double sel = 1.0;
+      rc = probed_selectivity(&sel);
+      if (rc) { return rc; }
+      const double survivors = (double)rows_to_scan * sel;
+      const auto seen = t->groups_seen.find(r->group_sig);
+      const uint64_t known = p->groups_hint ? p->groups_hint : (seen != t->groups_seen.end() ? seen->second : 0);
+      // worth it when the groups are many (the LDS front table then only wastes probes) and the tuples pay for three more launches
+      // ... and, for now, when a count-distinct is in the plan: groups + COUNT alone run 4.0 ms per 62 M survivors through the plain table
+      // and 8.9 ms through the tuples (profiles/r03/NOTES.md); with the (group, id) set it is 15.9 ms against the tuples' total
+      hpart = (p->flags & VH_PLAN_FORCE_HPART) || (survivors >= 8e6 && known >= 2000000 && nb > 0);
+      if (hpart) {
+        hp_tuple_cap = part_tuples_override ? part_tuples_override : std::max<uint64_t>((uint64_t)(survivors * 1.25) + 1024, 1ull << 16);
+        hp_tuple_cap = std::min<uint64_t>(hp_tuple_cap, rows_to_scan + 1);
+        if (nb) {    // a row of k ids writes ceil(k / 2) pair tuples: at most (ids + rows) / 2 of them
+          const uint64_t worst = (bitset_ids[0] + std::min<uint64_t>(hp_tuple_cap, rows_to_scan)) / 2 + 1;
+          hp_pair_cap = part_tuples_override ? worst : std::min<uint64_t>(worst, (uint64_t)(((double)bitset_ids[0] * std::max(sel, 0.02) * 1.25 + (double)hp_tuple_cap) / 2) + (1ull << 16));
+        }
+        lanes = false;
+        P.hpart = 1; P.gid_shift = 32;
+        P.npart = 1; P.part_shift = 0; P.nlevel = 1; P.agg_shift = 0; P.nfine = 1;      // (the scan kernel writes ONE stream per kind; vh_hpart.h partitions it)
+        P.tw = 2;
+        // payload word: the 64-bit state alone, or up to two 32-bit ones
+        int used = 0;
+        for (int j = 0; j < P.nmetric; ++j) {
+          if (P.m[j].sop() == SOP_BITSET) continue;
+          P.m[j].set_tword(1); P.m[j].set_tshift((uint8_t)used);
+          used += 8 * vh_sop_bytes(P.m[j].sop());
+        }
+        // LDS tables of hp_aggregate_kernel, one of 65 536 ranges at a time: group slots for the range's expected groups at <= 70 % load,
+        // (group slot, id) slots likewise; what does not fit even 4096 / 16384 slots is worked through in passes
+        const double groups_est = (known ? (double)known * 1.1 : survivors * 1.1) / 65536.0;
+        const double ids_est = nb ? (double)bitset_ids[0] * std::max(sel, 0.02) * 1.1 / 65536.0 : 0.0;
+        size_t slot_bytes = 8;                                  // a group slot: the mixed key + every state
+        for (int j = 0; j < P.nmetric; ++j) slot_bytes += P.m[j].sop() == SOP_BITSET ? 8 : vh_sop_bytes(P.m[j].sop());
+        auto table_bytes = [&](uint32_t g, uint32_t q) { return (size_t)(g + 1) * slot_bytes + (size_t)q * 8; };
+        const size_t budget = 136 * 1024;                       // of the 160 KB a block may own (lists, counters and alignment take the rest)
+        uint32_t passes = hp_passes_override ? hp_passes_override : 1, gs = 256, ss = nb ? 1024 : 0;
+        if (const char* env_passes = getenv("VH_TEST_HPART_PASSES")) if (!hp_passes_override) passes = (uint32_t)std::max(1, atoi(env_passes));
+        for (;;) {       // tables for one pass's share of a range at <= 70 % load; what the LDS cannot hold takes more passes
+          static const double load_g = getenv("VH_HP_LOAD_G") ? atof(getenv("VH_HP_LOAD_G")) : 0.7, load_s = getenv("VH_HP_LOAD_S") ? atof(getenv("VH_HP_LOAD_S")) : 0.7;      // measurement
+          const bool need_g = hp_passes_override ? true : groups_est / passes > load_g * gs, need_s = nb && (hp_passes_override ? true : ids_est / passes > load_s * ss);
+          if (need_g && table_bytes(gs * 2, ss) <= budget && (!need_s || gs * 4 <= ss * 2 || table_bytes(gs, ss * 2) > budget)) { gs *= 2; continue; }
+          if (need_s && table_bytes(gs, ss * 2) <= budget) { ss *= 2; continue; }
+          if (need_g && table_bytes(gs * 2, ss) <= budget) { gs *= 2; continue; }
+          if (hp_passes_override || (!need_g && !need_s) || passes >= 64) break;      // (a re-plan takes the biggest tables that fit, whatever the estimate said)
+          passes *= 2;
+        }
+        if (const char* env_gs = getenv("VH_TEST_HPART_GSLOTS")) if (!hp_passes_override) gs = (uint32_t)std::max(16, atoi(env_gs));      // tests: tables too small -> the re-plan
+        P.hp_passes = (int32_t)passes; P.hp_gslots = (int32_t)gs; P.hp_sslots = (int32_t)ss;
+        size_t off = 0;
+        P.hp_keys_off = 0; off += (size_t)(P.hp_gslots + 1) * 8;
+        for (int pass = 0; pass < 2; ++pass)
+          for (int j = 0; j < P.nmetric; ++j) {
+            const int b = P.m[j].sop() == SOP_BITSET ? 8 : vh_sop_bytes(P.m[j].sop());
+            if ((pass == 0) != (b == 8)) continue;
+            P.m[j].lds_off = (uint32_t)off; off += (size_t)(P.hp_gslots + 1) * b;
+          }
+        off = (off + 7) / 8 * 8;
+        P.hp_set_off = (uint32_t)off; off += (size_t)P.hp_sslots * 8;
+        lds_table = (off + 15) / 16 * 16;          // (of the aggregation kernel; the scan kernel keeps no table)
+        P.lds_hash_slots = 0; P.lds_bytes = 0;
+        // the list of group records: never more groups than tuples; blocks take it in chunks and leave a tail of their last one unused
+        hp_bpp = vh_hpart_bpp(g_ctx.num_cu, lds_table);
+        hp_chunk = 16384;
+        while (hp_chunk > 256 && (uint64_t)hp_chunk * HP_FAN * hp_bpp * 4 > hp_tuple_cap) hp_chunk /= 2;
+        capacity = hp_tuple_cap + (uint64_t)HP_FAN * hp_bpp * hp_chunk * 2;
+        P.hmask = capacity - 1;
+        P.present_carrier = -1;
+      }
+    }
+  }
+  if (P.nbitset && !hpart) jit_try = false;
+
   // ---------------- payload projection: when few rows pass, a survivor's group / metric values come out of ONE packed
   // record (vh_table_pack) instead of one line per column arena. Only the compacting kernels gather by row; the lanes
   // kernels read whole column ranges and keep the arenas.
@@ -1912,7 +2008,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     VhJitShape& js = jshape;
     js.mode = mode;
     const size_t qw = (size_t)VJ_QUEUE_CAP * sizeof(uint32_t);       // per wave
-    if (mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) {          // an LDS table per block: the widest block whose table + queues stay within the 64 KB a module kernel may ask for
+    if (mode == VH_MODE_DENSE_LDS || (mode == VH_MODE_HASH && !hpart)) {          // an LDS table per block: the widest block whose table + queues stay within the 64 KB a module kernel may ask for
       jit_block = mode == VH_MODE_DENSE_LDS ? 1024 : 512;
       while (jit_block > 256 && lds_table + (size_t)(jit_block / 64) * qw > 64 * 1024) jit_block /= 2;
       if (lds_table + (size_t)(jit_block / 64) * qw > 64 * 1024) jit_try = false;
@@ -1930,6 +2026,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     js.gid32 = mode != VH_MODE_HASH && G <= 0xFFFFFFFFull;
     static const bool env_no_stage = getenv("VH_NO_STAGE") != nullptr;             // measurement: tuples appended piece by piece (vh_part_direct_add)
     js.stage = mode == VH_MODE_DENSE_PART && P.tw == 2 && P.npart <= VH_STAGE_PARTS && !env_no_stage;
+    js.hpart = hpart ? 1 : 0;
     js.ng = P.ngroup; js.nm = P.nmetric;
     for (int i = 0; i < P.ngroup; ++i) {
       const VhGroupDev& g = P.g[i];
@@ -1946,9 +2043,11 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       const VhMetricDev& m = P.m[j];
       VhJitCol& c = js.m[j];
       c.rowid = m.slot() == VH_SLOT_ROWID;
+      c.bitset = m.sop() == SOP_BITSET;
+      if (c.bitset) js.bitset_j = j;
       c.type = (int)m.type(); c.sop = (int)m.sop(); c.tword = (int)m.tword(); c.tshift = (int)m.tshift();
       c.sext = vh_sop_sext((int)m.sop());
-      if (!c.rowid) { c.slot = (int)m.slot(); c.pitch = (int)P.colpitch[m.slot()]; c.rec = slot_rec[m.slot()]; c.off = slot_recoff[m.slot()]; }
+      if (!c.rowid && !c.bitset) { c.slot = (int)m.slot(); c.pitch = (int)P.colpitch[m.slot()]; c.rec = slot_rec[m.slot()]; c.off = slot_recoff[m.slot()]; }
     }
     if (jit_try) {
       std::string jerr;
@@ -1962,7 +2061,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         vh_plan p2 = *p;
         p2.flags |= VH_PLAN_NO_JIT;
         holder.reset();
-        return query_launch_locked(t, x, &p2, out, hash_capacity_override, force_hash, part_tuples_override, no_part, plan_only, summary_out, ag, device_rows);
+        return query_launch_locked(t, x, &p2, out, hash_capacity_override, force_hash, part_tuples_override, no_part, plan_only, summary_out, ag, device_rows, hp_passes_override, no_hpart);
       }
     }
   }
@@ -1987,7 +2086,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     const size_t lds_ = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + qb;
     hipStream_t s_ = x->stream();
     if (jk) {
-      const size_t jl = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + (size_t)(BLOCK / 64) * (VJ_QUEUE_CAP * sizeof(uint32_t) + (jshape.stage ? VH_STAGE_BYTES : 0));
+      const size_t jl = ((mode == VH_MODE_DENSE_LDS || (mode == VH_MODE_HASH && !hpart)) ? lds_table : 0) + (size_t)(BLOCK / 64) * (VJ_QUEUE_CAP * sizeof(uint32_t) + (jshape.stage ? VH_STAGE_BYTES : 0));
       if (occ) *occ = vh_jit_occupancy(jk, BLOCK, jl);
       else (void)vh_jit_launch(jk, P, grid_, BLOCK, jl, s_);
     }
@@ -2010,6 +2109,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     else snprintf(nm, sizeof(nm), "%s<%d, %d, %d, %d>", lanes ? "scan_agg_lanes_kernel" : "scan_agg_fast_kernel", mode, BLOCK,
                   (mode == VH_MODE_HASH || mode == VH_MODE_DENSE_PART) ? (int)__HIP_MEMORY_SCOPE_AGENT : scope, np_);
     r->kernel = jk ? jk->name : std::string(nm);
+    if (hpart) r->kernel += " + hp_scatter_kernel<1024> + hp_aggregate_kernel<512>";
     if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? " + part_agg_kernel<1024>" : (P.tw == 2 && !getenv("VH_NO_SPLIT_TILE")) ? " + part_split_tile_kernel<256> + part_agg_kernel<1024>" : " + part_split_kernel<256> + part_agg_kernel<1024>";
   }
   int occupancy = 0;
@@ -2054,7 +2154,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   size_t rec_off[VH_MAX_METRIC] = {};
   // Only for tables far bigger than the caches: with few, hot groups three atomics on ONE line serialise more than on three
   // (C2 forced onto the hash table, 1 K groups: 1.75 ms with separate arrays, 2.21 ms with records).
-  if (mode == VH_MODE_HASH && P.key_words == 1 && (capacity >= (1ull << 22) || (p->flags & VH_PLAN_FORCE_HASH_RECORDS)) && !(p->flags & VH_PLAN_NO_HASH_RECORDS)) {
+  if (mode == VH_MODE_HASH && P.key_words == 1 && (hpart || ((capacity >= (1ull << 22) || (p->flags & VH_PLAN_FORCE_HASH_RECORDS)) && !(p->flags & VH_PLAN_NO_HASH_RECORDS)))) {
     size_t off = 8;
     for (int pass = 0; pass < 2; ++pass)
       for (int j = 0; j < P.nmetric; ++j) {
@@ -2088,14 +2188,17 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   }
   // outputs
   size_t o_tuples = 0, o_emiss = 0, o_epart = 0, o_tuples2 = 0, o_emiss2 = 0, o_epart2 = 0, o_l2 = 0;
+  size_t o_tuplesB = 0, o_emissB = 0, o_epartB = 0, o_tuples2B = 0, o_emiss2B = 0, o_epart2B = 0, o_l2B = 0;
   int split_bpp = 1;
-  if (mode == VH_MODE_DENSE_PART) {
+  if (hpart) part_tuple_cap = hp_tuple_cap;
+  if (mode == VH_MODE_DENSE_PART || hpart) {
     // extent size: big enough that a wave allocates rarely (every allocation is a returning global
     // atomic = a full round trip the wave sits out), small enough that open extents do not waste HBM
     const uint64_t waves = (uint64_t)grid * 4;
     uint64_t et = 1024;                // a tile writes whole runs (<= VH_PART_TILE tuples) that must fit a fresh extent
     while (et < 4096 && et * 2 <= part_tuple_cap / (waves * P.npart) / 2) et *= 2;
     if (getenv("VH_EXT_TUPLES")) et = std::max(256, atoi(getenv("VH_EXT_TUPLES")));     // measurement
+    if (hpart) et = HP_ET;             // (the tiles of hp_scatter_kernel are whole source extents)
     const uint64_t ext_tuples = et;
     P.ext_tuples = (int32_t)ext_tuples;
     uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
@@ -2120,8 +2223,34 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       o_tuples2 = sp.take(max2 * et2 * P.tw * 8);
       o_emiss2 = sp.take(max2 * sizeof(uint16_t));
       o_epart2 = sp.take(max2);
-      o_l2 = sp.take(VH_L2_WORDS * sizeof(uint32_t));
+      o_l2 = sp.take((VH_L2_WORDS + VH_MAX_PART) * sizeof(uint32_t));
     }
+    if (hpart && hp_pair_cap) {        // the pair tuples' stream: the same geometry, sized for their own count
+      uint64_t mb = hp_pair_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
+      if (mb > 0xFFFFFFF0ull) mb = 0xFFFFFFF0ull;
+      P.max_extentsB = (uint32_t)mb;
+      o_tuplesB = sp.take(mb * ext_tuples * 16);
+      o_emissB = sp.take(mb * sizeof(uint16_t));
+      o_epartB = sp.take(mb);
+    }
+  }
+  // hashed partitioning: per kind of tuple the two partitioned pools (vh_hpart.h), their fill / tag arrays and a block of small tables
+  struct HpOff { size_t ta = 0, fa = 0, ga = 0, tb = 0, fb = 0, gb = 0, meta = 0; uint64_t maxa = 0, maxb = 0; } hpo[2];
+  size_t o_hpargs = 0;
+  const size_t hp_meta_bytes = 8 + (size_t)HP_FAN * 4 + (size_t)(2 * HP_FAN + 2) * 4;      // [level-A cursor | tuples per digit | slices + their cursors]
+  if (hpart) {
+    for (int k = 0; k < (hp_pair_cap ? 2 : 1); ++k) {
+      const uint64_t cap = k ? hp_pair_cap : hp_tuple_cap;
+      // level A: every block may hold an open extent per digit (+ one fresh one per tile boundary); level B: the slices hp_plan_kernel lays out
+      uint64_t ma = ((cap / HP_ET) / g_ctx.num_cu * 3 / 2 + 2 * HP_FAN + 16) * g_ctx.num_cu;      // one slab per block: its share of the tuples and half again, an open extent per digit, one more per digit for the tails
+      uint64_t mb = cap / HP_ET + (uint64_t)HP_FAN * (2 * HP_FAN + 9) + 64;
+      if (!part_tuples_override && getenv("VH_TEST_PART_EXTENTS2")) mb = std::max(1, atoi(getenv("VH_TEST_PART_EXTENTS2")));   // tests: the last pool runs out
+      hpo[k].maxa = ma; hpo[k].maxb = mb;
+      hpo[k].ta = sp.take(ma * HP_ET * 16); hpo[k].fa = sp.take(ma * 2); hpo[k].ga = sp.take(ma);
+      hpo[k].tb = sp.take(mb * HP_ET * 16); hpo[k].fb = sp.take(mb * 2); hpo[k].gb = sp.take(mb);
+      hpo[k].meta = sp.take(hp_meta_bytes);
+    }
+    o_hpargs = sp.take(sizeof(VhHpArgs));
   }
   size_t o_fbs[VH_MAX_BITSET] = {};
   for (size_t k = 0; k < r->filter_bitset_cols.size(); ++k) o_fbs[k] = sp.take(std::max<uint32_t>(nseg, 1) * 8);
@@ -2129,6 +2258,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   for (int b = 0; b < P.nbitset; ++b) {
     o_bsptr[b][0] = sp.take(std::max<uint32_t>(nseg, 1) * 8);
     o_bsptr[b][1] = sp.take(std::max<uint32_t>(nseg, 1) * 8);
+    if (hpart) continue;             // (its count-distinct lives in the LDS sets of hp_aggregate_kernel)
     // the (group, id) set can never hold more pairs than there are ids in the scanned segments
     uint64_t cap = 1024;
     while (cap < bitset_ids[b] * 2) cap <<= 1;
@@ -2154,7 +2284,12 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   }
   for (int j = 0; j < P.nmetric; ++j) P.m[j].state = S + o_state[j];
   r->d_out_count = reinterpret_cast<unsigned long long*>(S + o_outcount);
-  if (mode == VH_MODE_DENSE_PART) {
+  if (mode == VH_MODE_DENSE_PART || hpart) {
+    if (hpart && hp_pair_cap) {
+      P.tuplesB = reinterpret_cast<uint64_t*>(S + o_tuplesB);
+      P.extent_missingB = reinterpret_cast<uint16_t*>(S + o_emissB);
+      P.extent_partB = reinterpret_cast<uint8_t*>(S + o_epartB);
+    }
     P.tuples = reinterpret_cast<uint64_t*>(S + o_tuples);
     P.extent_missing = reinterpret_cast<uint16_t*>(S + o_emiss);
     P.extent_part = reinterpret_cast<uint8_t*>(S + o_epart);
@@ -2173,8 +2308,8 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   }
   if (P.nbitset) {
     for (int b = 0; b < P.nbitset; ++b) {
-      P.dset_keys[b] = reinterpret_cast<uint64_t*>(S + o_dkeys[b]);
-      P.dset_tags[b] = P.bs_wide[b] ? reinterpret_cast<uint32_t*>(S + o_dtags[b]) : nullptr;
+      P.dset_keys[b] = hpart ? nullptr : reinterpret_cast<uint64_t*>(S + o_dkeys[b]);
+      P.dset_tags[b] = P.bs_wide[b] && !hpart ? reinterpret_cast<uint32_t*>(S + o_dtags[b]) : nullptr;
       const VhColumn& c = t->cols[bitset_col[b]];
       P.bs_offs[b] = reinterpret_cast<const uint64_t* const*>(S + o_bsptr[b][0]);
       P.bs_vals[b] = reinterpret_cast<const void* const*>(S + o_bsptr[b][1]);
@@ -2196,9 +2331,16 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   // ---------------- init + launch
   hipStream_t st = x->stream();
   HIP_TRY(hipEventRecord(x->ev[0], st));
-  HIP_TRY(hipMemsetAsync(P.counters, 0, 512, st));   // counters + out_count (adjacent 256 B slots)
+  VhInitArgs IA{};              // everything that is cleared goes into one launch (init_regions_kernel)
+  auto clear = [&](void* ptr, size_t bytes, uint32_t byte_pattern) {
+    if (!bytes) return;
+    const uint64_t units = (bytes + 15) / 16;                       // (regions are padded to 256 B: rounding up stays inside)
+    if (IA.n == VH_INIT_MAX) { (void)hipMemsetAsync(ptr, (int)(byte_pattern & 0xFFu), bytes, st); return; }
+    IA.p[IA.n] = static_cast<char*>(ptr); IA.end[IA.n] = (IA.n ? IA.end[IA.n - 1] : 0) + units; IA.pat[IA.n] = byte_pattern * 0x01010101u; ++IA.n;
+  };
+  clear(P.counters, 512, 0);   // counters + out_count (adjacent 256 B slots)
   HIP_TRY(hipMemcpyAsync(S + o_segrows, x->h_segrows, r->plan_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-  if (mode == VH_MODE_HASH) {
+  if (mode == VH_MODE_HASH && !hpart) {      // (hashed partitioning writes its group records as a compact list: nothing to pre-fill)
     if (P.hrec_bytes) {          // records: empty key + the metrics' identities, one template for every slot
       VhRecordTemplate T{};
       T.w[0] = VH_HASH_EMPTY;
@@ -2209,28 +2351,64 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
                          P.hkeys, nwords, P.hrec_bytes / 8, T);
       HIP_TRY(hipGetLastError());
     }
-    else if (P.key_words == 1) HIP_TRY(hipMemsetAsync(P.hkeys, 0xFF, table_n * sizeof(uint64_t), st));
-    else HIP_TRY(hipMemsetAsync(P.htags, 0, table_n * sizeof(uint32_t), st));
+    else if (P.key_words == 1) clear(P.hkeys, table_n * sizeof(uint64_t), 0xFF);
+    else clear(P.htags, table_n * sizeof(uint32_t), 0);
   }
-  if (zero_end > zero_begin) HIP_TRY(hipMemsetAsync(S + zero_begin, 0, zero_end - zero_begin, st));
+  if (zero_end > zero_begin) clear(S + zero_begin, zero_end - zero_begin, 0);
   r->zero_begin = S + zero_begin; r->zero_end = S + zero_end;
-  for (int b = 0; b < P.nbitset; ++b) {
-    if (P.bs_wide[b]) HIP_TRY(hipMemsetAsync(P.dset_tags[b], 0, (P.dset_mask[b] + 1) * 4, st));
-    else HIP_TRY(hipMemsetAsync(P.dset_keys[b], 0xFF, (P.dset_mask[b] + 1) * 8, st));
+  for (int b = 0; b < P.nbitset && !hpart; ++b) {
+    if (P.bs_wide[b]) clear(P.dset_tags[b], (P.dset_mask[b] + 1) * 4, 0);
+    else clear(P.dset_keys[b], (P.dset_mask[b] + 1) * 8, 0xFF);
   }
-  if (mode == VH_MODE_DENSE_PART) {
-    HIP_TRY(hipMemsetAsync(P.extent_missing, 0, (size_t)P.max_extents * sizeof(uint16_t), st));
-    HIP_TRY(hipMemsetAsync(P.extent_part, 0xFF, (size_t)P.max_extents, st));
+  if (hpart && hp_pair_cap) {
+    clear(P.extent_missingB, (size_t)P.max_extentsB * sizeof(uint16_t), 0);
+    clear(P.extent_partB, (size_t)P.max_extentsB, 0xFF);
+  }
+  VhHpArgs* d_hpargs = nullptr;
+  if (hpart) {          // the pools behind the scan (vh_hpart.h): descriptors for the kernels, fill arrays and small tables cleared with everything else
+    VhHpArgs& HA = r->hp_args;
+    memset(&HA, 0, sizeof(HA));
+    HA.nkind = hp_pair_cap ? 2 : 1;
+    HA.passes = P.hp_passes; HA.gslots = P.hp_gslots; HA.sslots = P.hp_sslots; HA.keys_off = P.hp_keys_off; HA.set_off = P.hp_set_off;
+    HA.bitset_j = -1;
+    for (int j = 0; j < P.nmetric; ++j) if (P.m[j].sop() == SOP_BITSET) HA.bitset_j = j;
+    HA.list_cap = capacity; HA.chunk = hp_chunk;
+    for (int k = 0; k < HA.nkind; ++k) {
+      VhHpKind& K = HA.k[k];
+      char* meta = S + hpo[k].meta;
+      K.z.tuples = k ? P.tuplesB : P.tuples; K.z.fill = k ? P.extent_missingB : P.extent_missing; K.z.tag = k ? P.extent_partB : P.extent_part;
+      K.z.max_extents = k ? P.max_extentsB : P.max_extents; K.z.stream = 1; K.z.cursor = P.counters + (k ? 8 : 5);
+      K.a.tuples = reinterpret_cast<uint64_t*>(S + hpo[k].ta); K.a.fill = reinterpret_cast<uint16_t*>(S + hpo[k].fa); K.a.tag = reinterpret_cast<uint8_t*>(S + hpo[k].ga);
+      K.a.max_extents = (uint32_t)std::min<uint64_t>(hpo[k].maxa, 0xFFFFFFF0ull); K.a.cursor = nullptr;      // (handed out in one slab per block of level A)
+      K.b.tuples = reinterpret_cast<uint64_t*>(S + hpo[k].tb); K.b.fill = reinterpret_cast<uint16_t*>(S + hpo[k].fb); K.b.tag = reinterpret_cast<uint8_t*>(S + hpo[k].gb);
+      K.b.max_extents = (uint32_t)std::min<uint64_t>(hpo[k].maxb, 0xFFFFFFF0ull); K.b.cursor = nullptr;
+      K.count = reinterpret_cast<uint32_t*>(meta + 8);
+      K.slice = reinterpret_cast<uint32_t*>(meta + 8 + (size_t)HP_FAN * 4);
+      clear(K.a.fill, (size_t)K.a.max_extents * 2, 0);
+      clear(K.b.fill, (size_t)K.b.max_extents * 2, 0);
+      clear(meta, hp_meta_bytes, 0);
+    }
+    d_hpargs = reinterpret_cast<VhHpArgs*>(S + o_hpargs);
+    HIP_TRY(hipMemcpyAsync(d_hpargs, &HA, sizeof(HA), hipMemcpyHostToDevice, st));
+  }
+  if (mode == VH_MODE_DENSE_PART || hpart) {
+    clear(P.extent_missing, (size_t)P.max_extents * sizeof(uint16_t), 0);
+    clear(P.extent_part, (size_t)P.max_extents, 0xFF);
     if (P.nlevel == 2) {
-      HIP_TRY(hipMemsetAsync(P.extent_missing2, 0, (size_t)P.max_extents2 * sizeof(uint16_t), st));
-      HIP_TRY(hipMemsetAsync(P.extent_part2, 0xFF, (size_t)P.max_extents2, st));
-      HIP_TRY(hipMemsetAsync(P.l2, 0, VH_L2_WORDS * sizeof(uint32_t), st));
+      clear(P.extent_missing2, (size_t)P.max_extents2 * sizeof(uint16_t), 0);
+      clear(P.extent_part2, (size_t)P.max_extents2, 0xFF);
+      clear(P.l2, (VH_L2_WORDS + VH_MAX_PART) * sizeof(uint32_t), 0);
     }
   }
   for (int j = 0; j < P.nmetric; ++j) {
-    if (P.m[j].ident == 0 || P.hrec_bytes) continue;
+    if (P.m[j].ident == 0 || P.hrec_bytes || hpart) continue;
     rc = fill_states(P.m[j].state, table_n, vh_sop_bytes(P.m[j].sop()), P.m[j].ident, st);
     if (rc) { return rc; }
+  }
+  if (IA.n) {
+    const uint64_t units = IA.end[IA.n - 1];
+    hipLaunchKernelGGL(init_regions_kernel, dim3((unsigned)std::min<uint64_t>((units + 255) / 256, (uint64_t)g_ctx.num_cu * 16)), dim3(256), 0, st, IA);
+    HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(x->ev[1], st));
   if (lanes)       // the lanes kernels read 4-byte predicate columns only (vh_preload<NP, false>)
@@ -2238,9 +2416,11 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   bool narrowed = false;
   for (int k = 0; k < P.npred; ++k) narrowed |= P.pred_width[k] != 4;
   if (jk) { narrowed = false; for (int k = 0; k < jshape.npred; ++k) narrowed |= jshape.pred[k].width != vh_elem_size(jshape.pred[k].type); }
-  r->info.reserved = (fastj ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0);
+  r->hpart = hpart;
+  r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0);
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
+    if (hpart) vh_launch_hpart(P, d_hpargs, hp_pair_cap ? 2 : 1, g_ctx.num_cu, lds_table, hp_bpp, st);
     if (mode == VH_MODE_DENSE_PART) {
       static const bool skip_phase2 = getenv("VH_ABLATE_NO_PHASE2") != nullptr;     // measurement only (wrong results): phase 1 alone between the events
       if (P.nlevel == 2 && !skip_phase2) vh_launch_part_split(P, split_bpp, st);
@@ -2395,6 +2575,7 @@ extern "C" int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t 
   if (!r->finalized) return vh_fail(VH_E_INVALID, "result is not finalised");
   if (nparts == 0 || nparts > 64) return vh_fail(VH_E_INVALID, "nparts must be 1..64");
   if (metric < 0 || metric >= (int)r->user_metric.size()) return vh_fail(VH_E_INVALID, "metric %d is not in the plan", metric);
+  if (r->hpart) return vh_fail(VH_E_UNSUPPORTED, "this result was aggregated range by range in LDS and kept no (group, id) set: run the query with VH_PLAN_NO_HPART to exchange its distinct pairs");
   const VhPlanDev& P = r->plan;
   const int dj = r->user_metric[metric];
   if (P.m[dj].sop() != SOP_BITSET) return vh_fail(VH_E_INVALID, "metric %d is not a bitset (count-distinct) metric", metric);
@@ -2499,6 +2680,7 @@ static int result_finalize(vh_result* r, int* retry) {
   A.hstride = P.hrec_bytes ? P.hrec_bytes / 8u : (uint32_t)P.key_words;
   A.n = r->out_cap; A.present = P.present; A.present_carrier = (r->mode == VH_MODE_DENSE_GLOBAL || r->mode == VH_MODE_DENSE_PART) ? P.present_carrier : -1; A.hkeys = P.hkeys; A.htags = P.htags; A.counters = P.counters;
   A.out_count = r->d_out_count;
+  A.n_dev = r->hpart ? P.counters + 1 : nullptr;         // hashed partitioning: entries [0, *n_dev) of the table are a compact list of group records
   for (int i = 0; i < P.ngroup; ++i) {
     A.glo[i] = P.g[i].lo; A.gextent[i] = P.g[i].extent; A.gstride[i] = P.g[i].stride;
     A.gtype[i] = P.g[i].type(); A.gkey_word[i] = P.g[i].key_word(); A.gkey_shift[i] = P.g[i].key_shift();
@@ -2559,6 +2741,7 @@ static int result_finalize(vh_result* r, int* retry) {
   HIP_TRY(wait_event_spinning(x->ev[3]));
   const unsigned long long* hc = reinterpret_cast<const unsigned long long*>(H);
   const unsigned long long err = hc[2];
+  if (err & VH_ERR_HPART_FULL) { *retry = 4; return VH_OK; }
   if (err & VH_ERR_HASH_FULL) { *retry = 1; return VH_OK; }
   if (err & VH_ERR_PART_FULL) { r->info.passed_recs = hc[0]; *retry = 3; return VH_OK; }   // phase 1 ran to the end: the survivors are counted
   if (err & VH_ERR_RANGE) { *retry = 2; return VH_OK; }
@@ -2631,7 +2814,7 @@ extern "C" int vh_result_finalize(vh_result* r) {
 }
 
 // One attempt's verdict -> the overrides of the next one. Shared by vh_query_agg and the sharded form.
-struct VhReplan { uint64_t cap_override = 0, part_override = 0; bool force_hash = false, no_part = false; };
+struct VhReplan { uint64_t cap_override = 0, part_override = 0; bool force_hash = false, no_part = false; uint32_t hp_passes = 0; bool no_hpart = false; };
 static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
   if (retry == 1) {
     // table too small. The number of groups is bounded by the number of surviving rows: estimate those
@@ -2646,6 +2829,15 @@ static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
       next = std::max(next, sized);
     }
     rp->cap_override = next;
+  }
+  else if (retry == 4) {                                     // hashed partitioning: a range held more groups (or ids) than its passes' LDS tables take
+    if (r->plan.hp_passes >= 64) rp->no_hpart = true;        // ... skewed beyond help: the plain hash table
+    else rp->hp_passes = (uint32_t)r->plan.hp_passes * 4;
+    if (rp->hp_passes > 64) rp->hp_passes = 64;
+  }
+  else if (retry == 3 && r->hpart) {                         // hashed partitioning ran out of tuple extents: size for the survivors it counted, then give up
+    if (rp->part_override) rp->no_hpart = true;
+    else rp->part_override = std::max<uint64_t>(r->info.passed_recs + r->info.passed_recs / 16 + 1024, 1ull << 16);
   }
   else if (retry == 3) {                                     // tuple extents exhausted: more room, then give up on partitioning
     // the attempt counted its survivors even though it dropped their tuples: the next one is sized for exactly that many
@@ -2749,7 +2941,7 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
     vh_result* r = nullptr;
     // planned and launched under the table lock; the wait for the device and the read-back happen outside it, so
     // queries of other threads on this table run meanwhile (each on its own context)
-    { std::lock_guard<std::mutex> lk(t->mu); rc = query_launch_locked(t, x, plan, &r, rp.cap_override, rp.force_hash, rp.part_override, rp.no_part); }
+    { std::lock_guard<std::mutex> lk(t->mu); rc = query_launch_locked(t, x, plan, &r, rp.cap_override, rp.force_hash, rp.part_override, rp.no_part, false, nullptr, nullptr, false, rp.hp_passes, rp.no_hpart); }
     if (rc) break;
     r->exec = x;
     int retry = 0;

@@ -82,6 +82,7 @@ class AggResult:
     kernel: str = ""               # symbol(s) of the scan kernel(s) that ran, as rocprofv3 prints them
     narrow: bool = False           # predicate columns were streamed from 8- / 16-bit copies (vh_table_narrow)
     jit: bool = False              # a scan kernel compiled for this plan shape ran (viyadb_amd/csrc/vh_jit.hip)
+    hpart: bool = False            # hashed partitioning of the hash path ran (hash_part_agg_kernel)
 
 
 
@@ -311,7 +312,7 @@ class DeviceTable:
                          int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
                          float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1),
                          bool(info.reserved & 2), bool(info.reserved & 8), int(ng), (self.lib.vh_result_kernel(res) or b"").decode(),
-                         bool(info.reserved & 16), bool(info.reserved & 32))
+                         bool(info.reserved & 16), bool(info.reserved & 32), bool(info.reserved & 64))
 
     def query_agg(self, plan: AggPlan, copy: bool = True) -> AggResult:
         p, keep = self._build_plan(plan)

@@ -131,7 +131,7 @@ std::string AggregatePartial(AggregateQuery& query, QueryStats& stats, std::vect
     const char* force = getenv("VIYA_HIP_PLAN_FLAGS");
     plan.flags = force ? (uint32_t)atoi(force) : 0;
     // the (group, id) pairs are read out of ONE set table: no per-XCD private copies of a dense table
-    if (has_bitset) plan.flags |= VH_PLAN_NO_XCD_PRIVATE;
+    if (has_bitset) plan.flags |= VH_PLAN_NO_XCD_PRIVATE | VH_PLAN_NO_HPART;      // (the blob carries the distinct (group, id) pairs: the set table must exist)
 
     vh_result* res = nullptr;
     vh_check(vh_query_agg(mir->handle, &plan, &res));
