@@ -32,9 +32,6 @@
  * (VH_MAX_EXEC, default 16) — so queries of different threads on one table overlap on the device. vh_segment_sync*,
  * vh_segment_generate, vh_table_pack/unpack take the same lock and first wait for every launched query that may still
  * read the arenas they replace. With an externally owned stream (vh_set_stream) all contexts share that stream.
- * A plan that runs radix-partitioned with a tuple pool of 64 MB or more is timed on up to VH_PLACEMENT_TRIALS (default 3)
- * contexts during its first runs — where a context's scratch landed physically decides ~10 % of that kernel's time — and
- * served by the fastest free one afterwards; this can keep that many scratch buffers alive per table (1 = off).
  *
  * Lifetime of a vh_result: it OWNS its execution context from vh_query_launch / vh_query_agg until vh_result_free. Its
  * device-side state (what vh_result_finalize, vh_result_device_buffers and vh_result_partition[_pairs] read) and its host
@@ -346,7 +343,7 @@ VH_API int vh_table_unpack(vh_table* t);
  * src/db/column.h) the table keeps a second copy at that width and the register-resident scan kernels stream it
  * instead; values are widened in registers, so every comparison is the one the 4-byte column would get. Copies follow
  * vh_segment_sync* like projections do, are dropped when a synced value no longer fits, and are built unasked for a
- * column the VH_AUTO_NARROW-th (default 3, 0 = never) selective query filters on while a quarter of the device stays
+ * column the VH_AUTO_NARROW-th (default 3, 0 = never) query filters on while a quarter of the device stays
  * free. Columns that do not qualify are skipped silently. vh_table_unpack drops them too. */
 VH_API int vh_table_narrow(vh_table* t, const int32_t* cols, int32_t ncols);
 /* Copy a mirrored column back to the host (tests). */

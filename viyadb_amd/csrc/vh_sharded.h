@@ -525,8 +525,7 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
   VH_ENTER();
   std::lock_guard<std::mutex> comm_lk(comm->mu);
   VhExec* x = nullptr;
-  const uint64_t psig = placement_sig(plan);
-  if (int rc = exec_acquire(t, &x, psig)) return rc;     // (a rank that fails here leaves its peers waiting in the first collective: nothing to agree on yet)
+  if (int rc = exec_acquire(t, &x)) return rc;     // (a rank that fails here leaves its peers waiting in the first collective: nothing to agree on yet)
   struct ExecGuard { vh_table* t; VhExec* x; ~ExecGuard() { if (x) { (void)hipStreamSynchronize(x->stream()); exec_release(t, x); } } } xg{t, x};
   hipStream_t st = x->stream();
   const int W = comm->world, R = comm->rank;
@@ -629,11 +628,6 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
       r->h_base = reinterpret_cast<char*>(x->h_counters);          // no rows here: any readable address
       r->ngroups_host = 0; r->info.returned_groups = 0; r->info.ngroups = 0;
       r->finalized = true;
-    }
-    if (attempt == 0) {                                           // this rank's own scan, by its events (the stream is drained in both branches above)
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, x->ev[1], x->ev[2]) == hipSuccess) placement_record(t, x, psig, r, ms);
-      else (void)hipGetLastError();
     }
     xg.x = nullptr; detach.r = nullptr;                           // the result owns the context from here
     *out = holder.release();

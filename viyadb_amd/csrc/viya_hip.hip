@@ -58,6 +58,34 @@ struct VhContext {
 static VhContext g_ctx;
 static std::mutex g_mu;
 
+// Every environment knob of the library, read ONCE (first use, normally vh_init) instead of wherever the planner happened to want
+// one. They exist for measurements and tests: defaults are what every reported number was taken with (DESIGN.md "Knobs"). The
+// VH_TEST_* / VH_POISON / VH_NO_SPLIT_TILE / VH_PART_TABLE_KB knobs are the exception — tests switch them between two queries of one process — and stay getenv() calls
+// at their (cold) sites.
+struct VhKnobs {
+  bool trace_alloc, no_topk, no_stage, jit_verbose, skip_phase2, no_direct_emit, times;
+  int max_exec, auto_narrow, auto_pack, jit_ablate, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, split_bpc, bw_blocks_per_cu;
+  double hp_load_g, hp_load_s;
+};
+static const VhKnobs& knobs() {
+  static const VhKnobs k = [] {
+    auto flag = [](const char* n) { return getenv(n) != nullptr; };
+    auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
+    auto real = [](const char* n, double dflt) { const char* e = getenv(n); return e ? atof(e) : dflt; };
+    VhKnobs x{};
+    x.trace_alloc = flag("VH_TRACE_ALLOC"); x.no_topk = flag("VH_NO_TOPK"); x.no_stage = flag("VH_NO_STAGE");
+    x.jit_verbose = flag("VH_JIT_VERBOSE"); x.skip_phase2 = flag("VH_ABLATE_NO_PHASE2"); x.no_direct_emit = flag("VH_NO_DIRECT_EMIT"); x.times = flag("VH_TIMES");
+    x.max_exec = std::max(1, num("VH_MAX_EXEC", 16));
+    x.auto_narrow = num("VH_AUTO_NARROW", 3); x.auto_pack = num("VH_AUTO_PACK", 3);
+    x.jit_ablate = num("VH_JIT_ABLATE", 0);
+    x.lanes_block = num("VH_LANES_BLOCK", 0); x.blocks_per_cu = num("VH_BLOCKS_PER_CU", 0); x.unit_rows = num("VH_UNIT_ROWS", 0); x.grid = num("VH_GRID", 0);
+    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
+    x.hp_load_g = real("VH_HP_LOAD_G", 0.7); x.hp_load_s = real("VH_HP_LOAD_S", 0.7);
+    return x;
+  }();
+  return k;
+}
+
 // The HIP current device is per thread: every entry point that allocates or launches binds the calling thread to the
 // library's device first (query threads of a server pool never called vh_init themselves).
 #define VH_ENTER() do { if (g_ctx.inited) (void)hipSetDevice(g_ctx.device); } while (0)
@@ -77,6 +105,7 @@ extern "C" int vh_init(int device_id) {
   if (!g_ctx.own_stream) HIP_TRY(hipStreamCreateWithFlags(&g_ctx.own_stream, hipStreamNonBlocking));
   if (!g_ctx.stream) g_ctx.stream = g_ctx.own_stream;
   g_ctx.inited = true;
+  (void)knobs();
   return VH_OK;
 }
 
@@ -150,17 +179,12 @@ struct vh_table {
   // per-query resources live in execution contexts (grow-only pool)
   std::vector<std::unique_ptr<VhExec>> execs;
   std::mutex pool_mu; std::condition_variable pool_cv;
-  // Placement preference (pool_mu): how fast a partitioned plan ran on execution context i. Where a context's tuple pool landed
-  // physically decides 10 % of that kernel's time (profiles/r02/NOTES.md, "Placement") and nothing predicts it, so the first
-  // runs of such a plan visit a few contexts and the later ones prefer the best.
-  std::unordered_map<uint64_t, std::vector<float>> placement;
   char* d_stats = nullptr; size_t d_stats_bytes = 0;      // vh_segment_sync*: min/max pass (its own buffer: a sync never touches a query's scratch)
   std::map<std::string, uint64_t> groups_seen;           // group-column signature -> groups of the last query (hash sizing)
   std::map<std::string, std::pair<uint64_t, uint64_t>> sel_cache;   // filter signature + table state -> (passed, sampled) of the selectivity probe
-  char* h_out[2] = {nullptr, nullptr}; size_t h_out_bytes[2] = {0, 0}; int h_out_next = 0;  // pinned result staging
   std::vector<std::unique_ptr<VhPack>> packs;
   std::vector<std::unique_ptr<VhNarrow>> narrows;
-  std::map<int, uint32_t> pred_seen;                     // column -> selective queries that filtered on it (automatic narrow copies)
+  std::map<int, uint32_t> pred_seen;                     // column -> queries that filtered on it (automatic narrow copies)
   std::vector<uint64_t> seg_mod;                          // sync_epoch of the last change to a segment's columns
   uint32_t* d_packrows = nullptr; size_t d_packrows_cap = 0;
   std::map<std::string, uint32_t> gather_seen;            // payload column set -> low-selectivity queries seen (automatic packs)
@@ -175,8 +199,7 @@ static bool is_dim(int kind) { return kind <= VH_DIM_BOOLEAN; }
 static bool is_bitset_elem(int e) { return e == VH_BITSET32 || e == VH_BITSET64; }
 
 static void trace_alloc(const char* what, const void* p, size_t bytes) {     // VH_TRACE_ALLOC=1: where the big buffers land (placement experiments)
-  static const bool on = getenv("VH_TRACE_ALLOC") != nullptr;
-  if (on) fprintf(stderr, "vh alloc %s %p %zu\n", what, p, bytes);
+  if (knobs().trace_alloc) fprintf(stderr, "vh alloc %s %p %zu\n", what, p, bytes);
 }
 
 static int table_grow(vh_table* t, uint32_t need_seg) {
@@ -247,43 +270,13 @@ static void exec_free(VhExec* x) {
   if (x->own_stream) (void)hipStreamDestroy(x->own_stream);
 }
 // A free context of the table's pool, a new one while the pool may grow, else wait for one to come back.
-static uint64_t placement_sig(const vh_plan* p) {       // what the plan looks like, not its literals or snapshot
-  uint64_t h = 1469598103934665603ull;
-  auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
-  for (int i = 0; i < p->nfilter; ++i) { mix((uint64_t)p->filter[i].kind); mix((uint64_t)p->filter[i].col); mix((uint64_t)p->filter[i].op); mix((uint64_t)p->filter[i].count); }
-  for (int i = 0; i < p->ngroups; ++i) { mix((uint64_t)p->groups[i].col); mix((uint64_t)p->groups[i].granularity); }
-  for (int i = 0; i < p->nmetrics; ++i) mix((uint64_t)(int64_t)p->metrics[i]);
-  mix(p->flags); mix((uint64_t)p->nhaving); mix(p->top_k);
-  return h ? h : 1;
-}
-static const int g_placement_trials = getenv("VH_PLACEMENT_TRIALS") ? atoi(getenv("VH_PLACEMENT_TRIALS")) : 3;
-
-// ... and what a finished first attempt of a partitioned plan with a tuple pool big enough for its placement to matter tells the pool
-static void placement_record(vh_table* t, VhExec* x, uint64_t sig, const vh_result* r, float kernel_ms);
-
-static int exec_acquire(vh_table* t, VhExec** out, uint64_t sig = 0) {
-  static const size_t max_exec = getenv("VH_MAX_EXEC") ? (size_t)std::max(1, atoi(getenv("VH_MAX_EXEC"))) : 16;
+// (Round 2 timed partitioned plans on three contexts and kept the one whose scratch "landed best": the tuple pool's placement decided
+// 10 % of phase 1 when tuples left as partial lines. Whole-line tuple writes removed the sensitivity — eight processes, trials 1 vs 3:
+// 2.50-2.54 vs 2.42-2.53 ms, profiles/r03/NOTES.md — and with it the three scratch buffers per table.)
+static int exec_acquire(vh_table* t, VhExec** out) {
+  const size_t max_exec = (size_t)knobs().max_exec;
   std::unique_lock<std::mutex> lk(t->pool_mu);
-  bool grow_for_trial = false;
-  if (sig && g_placement_trials > 1) {
-    auto it = t->placement.find(sig);
-    if (it != t->placement.end()) {             // a partitioned plan that ran here before
-      const std::vector<float>& ms = it->second;
-      const size_t trials = std::min<size_t>((size_t)g_placement_trials, max_exec);
-      size_t i = 0;
-      while (i < trials && i < ms.size() && ms[i] > 0) ++i;              // the first context it has not been timed on
-      if (i < trials) {
-        if (i < t->execs.size()) { if (!t->execs[i]->busy) { t->execs[i]->busy = true; *out = t->execs[i].get(); return VH_OK; } }
-        else if (i == t->execs.size()) grow_for_trial = true;
-      } else {
-        size_t best = 0;
-        for (size_t k = 1; k < trials; ++k) if (ms[k] < ms[best]) best = k;
-        if (best < t->execs.size() && !t->execs[best]->busy) { t->execs[best]->busy = true; *out = t->execs[best].get(); return VH_OK; }
-      }
-    }
-  }
   for (;;) {
-    if (grow_for_trial && t->execs.size() < max_exec) break;
     for (auto& x : t->execs) if (!x->busy) { x->busy = true; *out = x.get(); return VH_OK; }
     if (t->execs.size() < max_exec) break;
     if (t->pool_cv.wait_for(lk, std::chrono::seconds(60)) == std::cv_status::timeout)
@@ -1300,19 +1293,21 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     jshape.nlits = (int)r->h_lits.size();
   }
 
-  // Narrow copies of predicate columns (vh_table_narrow; built unasked for a column the third selective query filters on): the
+  // Narrow copies of predicate columns (vh_table_narrow; built unasked for a column the third query filters on): the
   // register-resident kernels — and the selectivity probe, which is one of them — stream those instead of the 4-byte arenas.
   if ((fast_ok || jit_try) && !(p->flags & VH_PLAN_NO_NARROW)) {
-    static const int auto_after = getenv("VH_AUTO_NARROW") ? atoi(getenv("VH_AUTO_NARROW")) : 3;     // 0: never unasked
+    const int auto_after = knobs().auto_narrow;     // 0: never unasked
     std::map<int, int> narrow_slot;          // column -> slot of its narrow copy (looked up, and counted, once per query)
     auto narrow_for = [&](int col) -> int {
       auto hit = narrow_slot.find(col);
       if (hit != narrow_slot.end()) return hit->second;
       bool have = false;
       for (auto& nw : t->narrows) have |= nw->col == col;
-      if (!have && auto_after > 0 && narrow_width_for(t, col, t->nseg) && ++t->pred_seen[col] >= (uint32_t)auto_after) {
+      const int nwidth = have ? 0 : narrow_width_for(t, col, t->nseg);
+      // (every query that filters on the column reads it in full, whatever passes: the copy pays from the first query that uses it on)
+      if (!have && auto_after > 0 && nwidth && ++t->pred_seen[col] >= (uint32_t)auto_after) {
         size_t free_b = 0, total_b = 0;
-        const size_t need = (size_t)t->cap_seg * ((t->segment_rows + 255) / 256 * 256) * 2;
+        const size_t need = (size_t)t->cap_seg * ((t->segment_rows + 255) / 256 * 256) * (size_t)nwidth;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + total_b / 4) (void)table_narrow_locked(t, col, true);
         else t->pred_seen[col] = 0;
       }
@@ -1642,7 +1637,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   uint64_t part_tuple_cap = 0;
   if (mode == VH_MODE_DENSE_GLOBAL && fastj && !no_part && !(p->flags & (VH_PLAN_NO_PART | VH_PLAN_FORCE_GLOBAL)) && P.nmetric >= 1 && P.nmetric <= VH_FAST_COLS) {
     int shift = 0;
-    const size_t part_table_bytes = getenv("VH_PART_TABLE_KB") ? (size_t)atoi(getenv("VH_PART_TABLE_KB")) * 1024 : 128 * 1024;   // one 1024-thread block per CU in phase 2 (160 KB LDS)
+    const size_t part_table_bytes = getenv("VH_PART_TABLE_KB") ? (size_t)atoi(getenv("VH_PART_TABLE_KB")) * 1024 : 128 * 1024;      // (tests shrink it between two queries to force many ranges)   // one 1024-thread block per CU in phase 2 (160 KB LDS)
     // Phase 2 is bound by LDS read-modify-writes at random addresses (about one lane per clock and CU: 50 M tuples x 3 updates =
     // 0.29 ms on C3, profiles/r02/NOTES.md), so the presence byte rides in a 32-bit SUM state when there is one (SOP_ADD32P: a
     // 64-bit word whose upper half counts rows) — two updates per tuple instead of three.
@@ -1686,6 +1681,14 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       // point of selectivity beyond the crossover. A 125 M-row shard of C3 (8 GPUs) stays on direct atomics, 1 G rows do not.
       const double shard_rows = (double)(ag ? ag->rows_max : rows_to_scan);
       if (want_part && shard_rows * (sel - (covered ? 0.03 : 0.045)) < (two_level ? 1e7 : 3.5e6)) want_part = false;      // (C3 shards: 125 M rows 0.733 ms direct vs 0.74-0.78 partitioned, 250 M rows 1.30 vs 1.18)
+      // Round 3: with the scan compiled for the plan and two-word tuples leaving as whole lines (vh_part_staged_add) a tuple costs ~10 ps
+      // against ~86 ps for its two direct atomics, and phase 2's fixed cost is ~0.1 ms: an eighth of C3 (125 M rows, 6.2 M survivors) runs
+      // 0.47 ms partitioned against 0.60 ms direct, a quarter 0.78 against 1.12 (profiles/r03/NOTES.md). From 2 M survivors on, one level.
+      if (!want_part && !two_level && jit_try && np <= VH_STAGE_PARTS) {
+        int words = 1, halves = 1;           // tuple words this plan would need: 64-bit states own one, 32-bit ones pair up (word 0 has one half free)
+        for (int j = 0; j < P.nmetric; ++j) { if (vh_sop_bytes(P.m[j].sop()) == 8) ++words; else if (halves) --halves; else { ++words; halves = 1; } }
+        if (words == 2 && shard_rows * sel >= 2e6 && sel >= 0.015) want_part = true;      // (at 1 % of 1 B rows the atomics still hide behind the scan: 1.18 ms direct, 1.31 partitioned)
+      }
     }
     if (want_part) {
       // most rows pass: build the tuples without compacting survivors first (lanes kernel, phase 1 only)
@@ -1899,7 +1902,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         uint32_t passes = hp_passes_override ? hp_passes_override : 1, gs = 256, ss = nb ? 1024 : 0;
         if (const char* env_passes = getenv("VH_TEST_HPART_PASSES")) if (!hp_passes_override) passes = (uint32_t)std::max(1, atoi(env_passes));
         for (;;) {       // tables for one pass's share of a range at <= 70 % load; what the LDS cannot hold takes more passes
-          static const double load_g = getenv("VH_HP_LOAD_G") ? atof(getenv("VH_HP_LOAD_G")) : 0.7, load_s = getenv("VH_HP_LOAD_S") ? atof(getenv("VH_HP_LOAD_S")) : 0.7;      // measurement
+          const double load_g = knobs().hp_load_g, load_s = knobs().hp_load_s;
           const bool need_g = hp_passes_override ? true : groups_est / passes > load_g * gs, need_s = nb && (hp_passes_override ? true : ids_est / passes > load_s * ss);
           if (need_g && table_bytes(gs * 2, ss) <= budget && (!need_s || gs * 4 <= ss * 2 || table_bytes(gs, ss * 2) > budget)) { gs *= 2; continue; }
           if (need_s && table_bytes(gs, ss * 2) <= budget) { ss *= 2; continue; }
@@ -1932,6 +1935,9 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     }
   }
   if (P.nbitset && !hpart) jit_try = false;
+  // the plain hash table is bound by random read-modify-writes, not by the scan: the pre-built kernel (smaller blocks, more of them per CU
+  // next to the LDS front table) runs it a tenth faster than the compiled one (C5t: 3.99 vs 4.39 ms) — the compiled kernel is for plans it cannot hold
+  if (mode == VH_MODE_HASH && !hpart && fast && !(p->flags & VH_PLAN_FORCE_JIT) && vh_jit_policy() != VH_JIT_FORCE) jit_try = false;
 
   // ---------------- payload projection: when few rows pass, a survivor's group / metric values come out of ONE packed
   // record (vh_table_pack) instead of one line per column arena. Only the compacting kernels gather by row; the lanes
@@ -1964,7 +1970,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         for (int c : gcols) all &= pk->col_index(c) >= 0;
         if (all && (!use || pk->rec_bytes < use->rec_bytes)) use = pk.get();
       }
-      static const int auto_after = getenv("VH_AUTO_PACK") ? atoi(getenv("VH_AUTO_PACK")) : 3;   // 0: never build one unasked
+      const int auto_after = knobs().auto_pack;   // 0: never build one unasked
       if (!use && (forced || auto_after > 0)) {
         std::string sig;
         for (int c : gcols) sig += std::to_string(c) + ",";
@@ -2015,8 +2021,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       if (mode == VH_MODE_HASH && !P.lds_hash_slots) jit_block = 256;
     }
     js.block = jit_block;
-    static const int env_ablate = getenv("VH_JIT_ABLATE") ? atoi(getenv("VH_JIT_ABLATE")) : 0;      // measurement only (profiles/r03/NOTES.md): 1 = no gathers, 2 = nothing behind the gathers
-    js.ablate = env_ablate;
+    js.ablate = knobs().jit_ablate;      // measurement only (profiles/r03/NOTES.md): 1 = no gathers, 2 = nothing behind the gathers
     js.xcd = nxcd > 1 ? 1 : 0;
     js.scope = (mode == VH_MODE_DENSE_GLOBAL || mode == VH_MODE_DENSE_LDS) && nxcd > 1 ? (int)__HIP_MEMORY_SCOPE_WORKGROUP : (int)__HIP_MEMORY_SCOPE_AGENT;
     js.carrier = P.present_carrier;
@@ -2024,7 +2029,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     js.key_words = mode == VH_MODE_HASH ? P.key_words : 1;
     js.lds_hash = P.lds_hash_slots ? 1 : 0;
     js.gid32 = mode != VH_MODE_HASH && G <= 0xFFFFFFFFull;
-    static const bool env_no_stage = getenv("VH_NO_STAGE") != nullptr;             // measurement: tuples appended piece by piece (vh_part_direct_add)
+    const bool env_no_stage = knobs().no_stage;             // measurement: tuples appended piece by piece (vh_part_direct_add)
     js.stage = mode == VH_MODE_DENSE_PART && P.tw == 2 && P.npart <= VH_STAGE_PARTS && !env_no_stage;
     js.hpart = hpart ? 1 : 0;
     js.ng = P.ngroup; js.nm = P.nmetric;
@@ -2055,8 +2060,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       if (!jk) {
         // no kernel for this shape (hipRTC missing, or the text did not compile): plan again for the pre-built kernels. The
         // failure is remembered per shape, so only the first query of the shape pays for the attempt.
-        static const bool verbose = getenv("VH_JIT_VERBOSE") != nullptr;
-        if (verbose) fprintf(stderr, "vh: per-query kernel unavailable, falling back: %s\n", jerr.c_str());
+        if (knobs().jit_verbose) fprintf(stderr, "vh: per-query kernel unavailable, falling back: %s\n", jerr.c_str());
         if ((p->flags & VH_PLAN_FORCE_JIT) || vh_jit_policy() == VH_JIT_FORCE) return vh_fail(VH_E_UNSUPPORTED, "per-query kernel requested (VH_PLAN_FORCE_JIT / VH_JIT=force) but unavailable: %s", jerr.c_str());
         vh_plan p2 = *p;
         p2.flags |= VH_PLAN_NO_JIT;
@@ -2072,9 +2076,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   // per instantiation: 5 for one predicate column today, 4 for two or more) — C2 at 1 B rows: 3.67 -> 3.39 ms. The LDS
   // variant pays for more blocks with more table merges at the end (blocks x groups x metrics global atomics), so
   // it keeps one 1024-thread block per CU unless the scan dwarfs that.
-  static const int env_lanes_block = getenv("VH_LANES_BLOCK") ? atoi(getenv("VH_LANES_BLOCK")) : 0;
-  static const int env_bpc = getenv("VH_BLOCKS_PER_CU") ? atoi(getenv("VH_BLOCKS_PER_CU")) : 0;
-  static const int env_unit = getenv("VH_UNIT_ROWS") ? atoi(getenv("VH_UNIT_ROWS")) : 0;
+  const int env_lanes_block = knobs().lanes_block, env_bpc = knobs().blocks_per_cu, env_unit = knobs().unit_rows;
   int BLOCK = jk ? jit_block : mode == VH_MODE_DENSE_LDS ? 1024 : 256;
   if (mode == VH_MODE_DENSE_LDS && lanes) {
     if (env_lanes_block == 256 || env_lanes_block == 512 || env_lanes_block == 1024) BLOCK = env_lanes_block;
@@ -2128,7 +2130,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   P.units_per_seg = (uint32_t)((t->segment_rows + unit_rows - 1) / unit_rows);
   P.nseg = nseg;
   P.total_units = nseg * P.units_per_seg;
-  static const int env_grid = getenv("VH_GRID") ? atoi(getenv("VH_GRID")) : 0;
+  const int env_grid = knobs().grid;
   const int grid = env_grid > 0 ? env_grid : (int)std::max<uint64_t>(1, std::min<uint64_t>(P.total_units, (uint64_t)g_ctx.num_cu * blocks_per_cu));
 
   // ---------------- scratch layout
@@ -2179,7 +2181,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   if (!P.hrec_bytes) for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident != 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop()));
   // device top-N: worth it only when the group table is big (small results are read back whole anyway)
   size_t o_tkkeys = 0, o_tkstate = 0, o_okey2[VH_MAX_GROUP] = {}, o_ostate2[VH_MAX_METRIC] = {};
-  r->topk_active = r->topk > 0 && r->out_cap > 65536 && !getenv("VH_NO_TOPK");
+  r->topk_active = r->topk > 0 && r->out_cap > 65536 && !knobs().no_topk;
   if (r->topk_active) {
     o_tkkeys = sp.take(r->out_cap * sizeof(uint64_t));
     o_tkstate = sp.take(sizeof(VhTopkState));
@@ -2197,7 +2199,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     const uint64_t waves = (uint64_t)grid * 4;
     uint64_t et = 1024;                // a tile writes whole runs (<= VH_PART_TILE tuples) that must fit a fresh extent
     while (et < 4096 && et * 2 <= part_tuple_cap / (waves * P.npart) / 2) et *= 2;
-    if (getenv("VH_EXT_TUPLES")) et = std::max(256, atoi(getenv("VH_EXT_TUPLES")));     // measurement
+    if (knobs().ext_tuples) et = std::max(256, knobs().ext_tuples);     // measurement
     if (hpart) et = HP_ET;             // (the tiles of hp_scatter_kernel are whole source extents)
     const uint64_t ext_tuples = et;
     P.ext_tuples = (int32_t)ext_tuples;
@@ -2213,7 +2215,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       split_bpp = std::max(1, 2 * g_ctx.num_cu / std::max(1, P.npart));     // 256-thread blocks, ~2 per CU whatever the partition count: more waves keep more extents open (4 per CU measured slower)
       // two-word tuples are split a block-wide tile at a time (part_split_tile_kernel): extents of one tile's size, one writer per block
       const bool tiled = P.tw == 2 && !getenv("VH_NO_SPLIT_TILE");
-      if (tiled) split_bpp = std::max(1, (getenv("VH_SPLIT_BPC") ? atoi(getenv("VH_SPLIT_BPC")) : 4) * g_ctx.num_cu / std::max(1, P.npart));   // a block is one writer: more of them cost less
+      if (tiled) split_bpp = std::max(1, knobs().split_bpc * g_ctx.num_cu / std::max(1, P.npart));   // a block is one writer: more of them cost less
       const uint64_t et2 = tiled ? VH_SPLIT_TILE_TUPLES : 256;
       P.ext_tuples2 = (int32_t)et2;
       uint64_t max2 = (part_tuple_cap + part_tuple_cap / 4) / et2 + (uint64_t)P.npart * ((uint64_t)split_bpp * (tiled ? 1 : 4) * (64 + VH_EXT_CHUNK) + 1) + 64;
@@ -2422,7 +2424,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     scan_dispatch(grid, nullptr);
     if (hpart) vh_launch_hpart(P, d_hpargs, hp_pair_cap ? 2 : 1, g_ctx.num_cu, lds_table, hp_bpp, st);
     if (mode == VH_MODE_DENSE_PART) {
-      static const bool skip_phase2 = getenv("VH_ABLATE_NO_PHASE2") != nullptr;     // measurement only (wrong results): phase 1 alone between the events
+      const bool skip_phase2 = knobs().skip_phase2;     // measurement only (wrong results): phase 1 alone between the events
       if (P.nlevel == 2 && !skip_phase2) vh_launch_part_split(P, split_bpp, st);
       if (!skip_phase2) vh_launch_part_agg(P, part_bpp, lds_table, st);
     }
@@ -2668,7 +2670,7 @@ static int result_finalize(vh_result* r, int* retry) {
   // Small results of the dense paths are written by the emission kernel straight into that pinned host buffer
   // (posted PCIe writes, coalesced per column) and a one-wave kernel publishes the 512-byte header behind them: no
   // DMA-engine copy at the end of the query (its start-up costs 20-100 us, more than the 2 MB it moves).
-  static const bool env_no_direct = getenv("VH_NO_DIRECT_EMIT") != nullptr;
+  const bool env_no_direct = knobs().no_direct_emit;
   const bool one_shot = r->out_region_bytes <= (8u << 20) && !r->topk_active;
   const bool direct = one_shot && r->mode != VH_MODE_HASH && !env_no_direct && !r->device_rows;
   if (direct) {
@@ -2767,7 +2769,7 @@ static int result_finalize(vh_result* r, int* retry) {
   float ms = 0;
   (void)hipEventElapsedTime(&ms, x->ev[1], x->ev[2]); r->info.scan_kernel_ms = ms;
   (void)hipEventElapsedTime(&ms, x->ev[0], x->ev[3]); r->info.total_ms = ms;
-  if (getenv("VH_TIMES")) {   // where a query's device time goes: setup (clears, uploads) | scan | emission + read-back
+  if (knobs().times) {   // where a query's device time goes: setup (clears, uploads) | scan | emission + read-back
     float a = 0, b = 0;
     (void)hipEventElapsedTime(&a, x->ev[0], x->ev[1]); (void)hipEventElapsedTime(&b, x->ev[2], x->ev[3]);
     fprintf(stderr, "vh times: setup %.3f ms, scan %.3f ms, emit+readback %.3f ms (groups %llu, returned %llu)\n", a, r->info.scan_kernel_ms, b,
@@ -2777,16 +2779,6 @@ static int result_finalize(vh_result* r, int* retry) {
   return VH_OK;
 }
 
-static void placement_record(vh_table* t, VhExec* x, uint64_t sig, const vh_result* r, float kernel_ms) {
-  if (!sig || g_placement_trials <= 1 || r->mode != VH_MODE_DENSE_PART || kernel_ms <= 0 ||
-      (uint64_t)r->plan.max_extents * r->plan.ext_tuples * r->plan.tw * 8 < (64ull << 20)) return;
-  std::lock_guard<std::mutex> lk(t->pool_mu);
-  size_t idx = 0;
-  while (idx < t->execs.size() && t->execs[idx].get() != x) ++idx;
-  std::vector<float>& ms = t->placement[sig];
-  if (ms.size() <= idx) ms.resize(idx + 1, 0.f);
-  ms[idx] = kernel_ms / (float)std::max<uint64_t>(r->info.scanned_recs, 1) * 1e6f;     // per million rows: snapshots grow
-}
 
 extern "C" int vh_query_launch(vh_table* t, const vh_plan* plan, vh_result** out) {
   if (!t || !plan || !out) return vh_fail(VH_E_INVALID, "null argument");
@@ -2933,8 +2925,7 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
   VH_ENTER();
   if (plan->nmetrics > VH_MAX_METRIC - 1 && plan->metrics) return query_agg_multipass(t, plan, out);
   VhExec* x = nullptr;
-  const uint64_t psig = placement_sig(plan);
-  if (int rc = exec_acquire(t, &x, psig)) return rc;
+  if (int rc = exec_acquire(t, &x)) return rc;
   VhReplan rp;
   int rc = VH_OK;
   for (uint32_t attempt = 0; attempt < 12; ++attempt) {
@@ -2950,7 +2941,6 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
     if (!retry) {
       r->info.retries = attempt;
       if (r->mode == VH_MODE_HASH) { std::lock_guard<std::mutex> lk(t->mu); t->groups_seen[r->group_sig] = r->info.ngroups; }
-      if (attempt == 0) placement_record(t, x, psig, r, (float)r->info.scan_kernel_ms);
       *out = r;
       return VH_OK;
     }
@@ -3124,7 +3114,7 @@ extern "C" int vh_measure_read_bandwidth(uint64_t bytes, int32_t iters, double* 
   HIP_TRY(hipMemsetAsync(sink, 0, 8, g_ctx.stream));
   hipEvent_t a, b;
   HIP_TRY(hipEventCreate(&a)); HIP_TRY(hipEventCreate(&b));
-  const int grid = g_ctx.num_cu * (getenv("VH_BW_BLOCKS_PER_CU") ? std::max(1, atoi(getenv("VH_BW_BLOCKS_PER_CU"))) : 8);   // 256-thread blocks: 8 per CU = 8 waves/SIMD
+  const int grid = g_ctx.num_cu * knobs().bw_blocks_per_cu;   // 256-thread blocks: 8 per CU = 8 waves/SIMD
   hipLaunchKernelGGL(read_bw_kernel, dim3(grid), dim3(256), 0, g_ctx.stream, (const vh_u32x4*)buf, bytes / 16, sink);
   HIP_TRY(hipEventRecord(a, g_ctx.stream));
   for (int i = 0; i < iters; ++i)
