@@ -53,6 +53,7 @@ struct VhHpArgs {
   int32_t bitset_j;
   uint32_t chunk;             // group records a block of hp_aggregate_kernel takes from the list at a time
   uint64_t list_cap;          // records the group list holds (+ one reserved record behind them)
+  int32_t ablate;             // measurement only (VH_HP_ABLATE; results are wrong): 1 no pair tuples, 2 no records written, 4 no tuples either, 8 no table clears
 };
 // blocks hp_aggregate_kernel runs per level-A partition: enough to fill every CU's LDS twice over (a divisor of HP_FAN)
 static inline int vh_hpart_bpp(int num_cu, size_t agg_lds) {
@@ -297,12 +298,13 @@ __device__ __forceinline__ uint32_t hp_slot(unsigned long long* keys, uint32_t g
   }
   uint32_t slot = (uint32_t)mkey & mask;
   for (uint32_t probe = 0; probe <= mask; ++probe) {
-    unsigned long long seen = keys[slot];
-    if (seen == mkey) return slot;
-    if (seen == VH_HASH_EMPTY) {
-      if (!insert) break;
-      seen = atomicCAS(&keys[slot], (unsigned long long)VH_HASH_EMPTY, (unsigned long long)mkey);
+    if (insert) {       // (no look before the compare-and-swap: most first probes of a range's tuples meet an empty slot)
+      const unsigned long long seen = atomicCAS(&keys[slot], (unsigned long long)VH_HASH_EMPTY, (unsigned long long)mkey);
       if (seen == VH_HASH_EMPTY || seen == mkey) return slot;
+    } else {
+      const unsigned long long seen = keys[slot];
+      if (seen == mkey) return slot;
+      if (seen == VH_HASH_EMPTY) break;
     }
     slot = (slot + 1u) & mask;
   }
@@ -380,17 +382,25 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
     prefetch(b + blocks_per_partition, ng, np);
     if (f0 == 0) continue;                       // (uniform: an empty range)
     for (int pass = 0; pass < passes; ++pass) {
-      for (uint32_t g = tid; g <= GS; g += BLOCK) {
+      const int abl = HA->ablate;
+      if (!(abl & 8)) for (uint32_t g = tid; g <= GS; g += BLOCK) {
         gkeys[g] = VH_HASH_EMPTY;
         for (int j = 0; j < P.nmetric; ++j) {
           const VhMetricDev& m = P.m[j];
-          if (m.sop() != SOP_BITSET && vh_sop_bytes(m.sop()) == 4) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)m.ident;
-          else reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = m.sop() == SOP_BITSET ? 0ull : m.ident;
+          if (m.sop() == SOP_BITSET) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = 0u;       // (a cardinality never exceeds the set's slots)
+          else if (vh_sop_bytes(m.sop()) == 4) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)m.ident;
+          else reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = m.ident;
         }
       }
-      for (uint32_t g = tid; g < SS; g += BLOCK) skeys[g] = VH_HASH_EMPTY;
+      if (!(abl & 8)) for (uint32_t g = tid; g < SS; g += BLOCK) skeys[g] = VH_HASH_EMPTY;
       __syncthreads();
       bool bad = false;
+      if (abl & 4) {      // (the tuples are still looked at)
+        uint64_t acc = 0;
+        for (int u = 0; u < U; ++u) acc += cg[u].x + cp[u].y;
+        if (acc == 0x123456789ABCDEFull) P.counters[7] = acc;
+        continue;
+      }
       // ---- tuples: (mixed key, payload word carrying the metric values at tshift)
       auto group_tuple = [&](const hp_u64x2 tp) {
         if (sub_bits && (int)((uint32_t)(tp.x >> (48 - sub_bits)) & (uint32_t)(passes - 1)) != pass) return;
@@ -412,8 +422,9 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
         if (S.ovf_key[x] == (uint16_t)b) for (uint32_t i = tid; i < S.ovf_fill[x]; i += BLOCK) group_tuple(pool[0][(uint64_t)S.ovf_ext[x] * HP_ET + i]);
       __syncthreads();
       // ---- pair tuples: (mixed key, two ids; an odd id count repeats the last one)
-      if (pairs) {
-        unsigned long long* const card = reinterpret_cast<unsigned long long*>(lds + P.m[bitset_j].lds_off);
+      if (pairs && !(abl & 1)) {
+        uint32_t* const card = reinterpret_cast<uint32_t*>(lds + P.m[bitset_j].lds_off);
+        const int set_shift = 32 - (31 - __builtin_clz(SS));
         auto pair_tuple = [&](const hp_u64x2 tp) {
           if (sub_bits && (int)((uint32_t)(tp.x >> (48 - sub_bits)) & (uint32_t)(passes - 1)) != pass) return;
           bool ok = true;
@@ -423,16 +434,12 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
           const int n = idv[0] == idv[1] ? 1 : 2;
           for (int q = 0; q < n; ++q) {
             const unsigned long long key = ((unsigned long long)slot << 32) | idv[q];
-            uint32_t at = (uint32_t)(vh_splitmix64(key) >> 40) & (SS - 1u);
+            uint32_t at = ((idv[q] ^ (slot * 0x9E3779B1u)) * 0x85EBCA6Bu) >> set_shift;      // (multiply-shift: the top bits)
             bool placed = false;
             for (uint32_t probe = 0; probe < SS; ++probe) {
-              unsigned long long seen = skeys[at];
+              const unsigned long long seen = atomicCAS(&skeys[at], (unsigned long long)VH_HASH_EMPTY, key);
+              if (seen == VH_HASH_EMPTY) { atomicAdd(&card[slot], 1u); placed = true; break; }
               if (seen == key) { placed = true; break; }
-              if (seen == VH_HASH_EMPTY) {
-                seen = atomicCAS(&skeys[at], (unsigned long long)VH_HASH_EMPTY, key);
-                if (seen == VH_HASH_EMPTY) { atomicAdd(&card[slot], 1ull); placed = true; break; }
-                if (seen == key) { placed = true; break; }
-              }
               at = (at + 1u) & (SS - 1u);
             }
             if (!placed) bad = true;
@@ -468,7 +475,8 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
       }
       const unsigned long long base = S.chunk_pos;
       unsigned long long at = base + before + (incl - mine);
-      if (base + tot <= HA->list_cap) {
+      if (abl & 2) {
+      } else if (base + tot <= HA->list_cap) {
         for (uint32_t g = tid; g <= GS; g += BLOCK) {
           const unsigned long long mk = gkeys[g];
           if (mk == VH_HASH_EMPTY) continue;
@@ -477,7 +485,8 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
           for (int j = 0; j < P.nmetric; ++j) {
             const VhMetricDev& m = P.m[j];
             char* dstp = vh_hash_state(P, m, key == VH_HASH_EMPTY ? HA->list_cap : at);
-            if (m.sop() != SOP_BITSET && vh_sop_bytes(m.sop()) == 4) *reinterpret_cast<uint32_t*>(dstp) = reinterpret_cast<const uint32_t*>(lds + m.lds_off)[g];
+            if (m.sop() == SOP_BITSET) *reinterpret_cast<uint64_t*>(dstp) = reinterpret_cast<const uint32_t*>(lds + m.lds_off)[g];
+            else if (vh_sop_bytes(m.sop()) == 4) *reinterpret_cast<uint32_t*>(dstp) = reinterpret_cast<const uint32_t*>(lds + m.lds_off)[g];
             else *reinterpret_cast<uint64_t*>(dstp) = reinterpret_cast<const uint64_t*>(lds + m.lds_off)[g];
           }
           if (key == VH_HASH_EMPTY) atomicOr(P.counters + 3, 1ull);

@@ -87,6 +87,20 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
     if (acc == 0x123456789ABCDEFull) P.counters[7] = acc;
     return;
   }
+  // hashed partitioning with a bitset metric: where the row's ids lie is asked for NOW, next to the record's loads, and the first two ids
+  // as soon as that is known — they travel while the key is rolled up and mixed
+  uint64_t bk = 0, bk1 = 0;
+  const uint32_t* bids = nullptr;
+  uint32_t bid0 = 0, bid1 = 0;
+  if constexpr (MODE == VH_MODE_HASH && J::HPART && J::BITSET_J >= 0 && !(VJ_ABL & 4)) {
+    const int b = (int)P.m[J::BITSET_J].slot();
+    if (active) {
+      const uint64_t* offs = P.bs_offs[b][seg];
+      bk = offs[row]; bk1 = offs[row + 1];
+      bids = reinterpret_cast<const uint32_t*>(P.bs_vals[b][seg]);
+      if (bk < bk1) { bid0 = bids[bk]; bid1 = bk + 1 < bk1 ? bids[bk + 1] : bid0; }      // an odd count repeats the last id: a set does not mind
+    }
+  }
   vj_rollup_all<J>(P, gv);
   uint64_t gid = 0;
   uint64_t key[VH_KEY_WORDS];
@@ -130,18 +144,17 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
 #pragma unroll
     for (int j = 0; j < NM; ++j)
       if (J::m_sop[j] != SOP_BITSET) words[1] |= (vh_sop_bytes(J::m_sop[j]) == 4 ? (mv[j] & 0xFFFFFFFFull) : mv[j]) << J::m_tshift[j];
-    vh_part_direct_add<2, 1, 2>(P, T, W, active, words, p, lane);
-    if constexpr (J::BITSET_J >= 0) {
-      const int b = (int)P.m[J::BITSET_J].slot();
-      uint64_t k = 0, k1 = 0;
-      const uint32_t* ids = nullptr;
-      if (active) { const uint64_t* offs = P.bs_offs[b][seg]; k = offs[row]; k1 = offs[row + 1]; ids = reinterpret_cast<const uint32_t*>(P.bs_vals[b][seg]); }
-      while (__ballot(k < k1)) {
-        const bool more = k < k1;
-        const uint32_t a = more ? ids[k] : 0u, a2 = more && k + 1 < k1 ? ids[k + 1] : a;      // an odd count repeats the last id: a set does not mind
-        const uint64_t w2[2] = {mkey, (uint64_t)a | ((uint64_t)a2 << 32)};
-        vh_part_direct_add<2, 3, 2>(P, V.TB, V.WB, more, w2, p, lane);
-        k += 2;
+    if (!(VJ_ABL & 8)) vh_part_direct_add<2, 1, 2>(P, T, W, active, words, p, lane);
+    else if (words[0] + words[1] == 0x123456789ABCDEFull) P.counters[7] = 1;
+    if constexpr (J::BITSET_J >= 0 && !(VJ_ABL & 4)) {
+      bool more = bk < bk1;
+      while (__ballot(more)) {
+        const uint64_t w2[2] = {mkey, (uint64_t)bid0 | ((uint64_t)bid1 << 32)};
+        if (!(VJ_ABL & 8)) vh_part_direct_add<2, 3, 2>(P, V.TB, V.WB, more, w2, p, lane);
+        else if (w2[1] == 0x123456789ABCDEFull) P.counters[7] = 1;
+        bk += 2;
+        more = bk < bk1;
+        if (more) { bid0 = bids[bk]; bid1 = bk + 1 < bk1 ? bids[bk + 1] : bid0; }
       }
     }
     return;

@@ -64,7 +64,7 @@ static std::mutex g_mu;
 // at their (cold) sites.
 struct VhKnobs {
   bool trace_alloc, no_topk, no_stage, jit_verbose, skip_phase2, no_direct_emit, times;
-  int max_exec, auto_narrow, auto_pack, jit_ablate, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, split_bpc, bw_blocks_per_cu;
+  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, split_bpc, bw_blocks_per_cu;
   double hp_load_g, hp_load_s;
 };
 static const VhKnobs& knobs() {
@@ -77,7 +77,7 @@ static const VhKnobs& knobs() {
     x.jit_verbose = flag("VH_JIT_VERBOSE"); x.skip_phase2 = flag("VH_ABLATE_NO_PHASE2"); x.no_direct_emit = flag("VH_NO_DIRECT_EMIT"); x.times = flag("VH_TIMES");
     x.max_exec = std::max(1, num("VH_MAX_EXEC", 16));
     x.auto_narrow = num("VH_AUTO_NARROW", 3); x.auto_pack = num("VH_AUTO_PACK", 3);
-    x.jit_ablate = num("VH_JIT_ABLATE", 0);
+    x.jit_ablate = num("VH_JIT_ABLATE", 0); x.hp_ablate = num("VH_HP_ABLATE", 0); x.hp_bpp = num("VH_HP_BPP", 0);
     x.lanes_block = num("VH_LANES_BLOCK", 0); x.blocks_per_cu = num("VH_BLOCKS_PER_CU", 0); x.unit_rows = num("VH_UNIT_ROWS", 0); x.grid = num("VH_GRID", 0);
     x.ext_tuples = num("VH_EXT_TUPLES", 0); x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
     x.hp_load_g = real("VH_HP_LOAD_G", 0.7); x.hp_load_s = real("VH_HP_LOAD_S", 0.7);
@@ -1896,7 +1896,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         const double groups_est = (known ? (double)known * 1.1 : survivors * 1.1) / 65536.0;
         const double ids_est = nb ? (double)bitset_ids[0] * std::max(sel, 0.02) * 1.1 / 65536.0 : 0.0;
         size_t slot_bytes = 8;                                  // a group slot: the mixed key + every state
-        for (int j = 0; j < P.nmetric; ++j) slot_bytes += P.m[j].sop() == SOP_BITSET ? 8 : vh_sop_bytes(P.m[j].sop());
+        for (int j = 0; j < P.nmetric; ++j) slot_bytes += P.m[j].sop() == SOP_BITSET ? 4 : vh_sop_bytes(P.m[j].sop());      // (a cardinality, in LDS: 32 bits)
         auto table_bytes = [&](uint32_t g, uint32_t q) { return (size_t)(g + 1) * slot_bytes + (size_t)q * 8; };
         const size_t budget = 136 * 1024;                       // of the 160 KB a block may own (lists, counters and alignment take the rest)
         uint32_t passes = hp_passes_override ? hp_passes_override : 1, gs = 256, ss = nb ? 1024 : 0;
@@ -1916,7 +1916,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         P.hp_keys_off = 0; off += (size_t)(P.hp_gslots + 1) * 8;
         for (int pass = 0; pass < 2; ++pass)
           for (int j = 0; j < P.nmetric; ++j) {
-            const int b = P.m[j].sop() == SOP_BITSET ? 8 : vh_sop_bytes(P.m[j].sop());
+            const int b = P.m[j].sop() == SOP_BITSET ? 4 : vh_sop_bytes(P.m[j].sop());
             if ((pass == 0) != (b == 8)) continue;
             P.m[j].lds_off = (uint32_t)off; off += (size_t)(P.hp_gslots + 1) * b;
           }
@@ -1926,6 +1926,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         P.lds_hash_slots = 0; P.lds_bytes = 0;
         // the list of group records: never more groups than tuples; blocks take it in chunks and leave a tail of their last one unused
         hp_bpp = vh_hpart_bpp(g_ctx.num_cu, lds_table);
+        if (knobs().hp_bpp > 0 && HP_FAN % knobs().hp_bpp == 0) hp_bpp = knobs().hp_bpp;
         hp_chunk = 16384;
         while (hp_chunk > 256 && (uint64_t)hp_chunk * HP_FAN * hp_bpp * 4 > hp_tuple_cap) hp_chunk /= 2;
         capacity = hp_tuple_cap + (uint64_t)HP_FAN * hp_bpp * hp_chunk * 2;
@@ -2374,7 +2375,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     HA.passes = P.hp_passes; HA.gslots = P.hp_gslots; HA.sslots = P.hp_sslots; HA.keys_off = P.hp_keys_off; HA.set_off = P.hp_set_off;
     HA.bitset_j = -1;
     for (int j = 0; j < P.nmetric; ++j) if (P.m[j].sop() == SOP_BITSET) HA.bitset_j = j;
-    HA.list_cap = capacity; HA.chunk = hp_chunk;
+    HA.list_cap = capacity; HA.chunk = hp_chunk; HA.ablate = knobs().hp_ablate;
     for (int k = 0; k < HA.nkind; ++k) {
       VhHpKind& K = HA.k[k];
       char* meta = S + hpo[k].meta;
