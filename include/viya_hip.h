@@ -246,7 +246,8 @@ typedef struct vh_result_info {
                                 bit 2: LDS front table of the hash path; bit 3: payload gathered from a projection (vh_table_pack);
                                 bit 4: predicate columns streamed from narrow copies (vh_table_narrow);
                                 bit 5: a scan kernel compiled for this plan shape ran (vh_jit.hip);
-                                bit 6: hashed partitioning of the hash path (hash_part_agg_kernel) */
+                                bit 6: hashed partitioning of the hash path (vh_hpart.h);
+                                bit 7: the projection's records are compressed (integers at the width their values need) */
   uint64_t returned_groups;  /* rows vh_result_copy delivers (= ngroups without HAVING) */
 } vh_result_info;
 
@@ -332,9 +333,20 @@ VH_API int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nseg,
  * coherent (a changed segment is re-packed from HBM before the next query that uses it). Cost: rows x record bytes
  * of HBM (C3: 32 GB next to the 60 GB table). The library also builds one by itself for a column set it has seen in
  * VH_AUTO_PACK (default 3, 0 = never) selective queries when a quarter of the device stays free; vh_table_unpack
- * drops them all. Analogue in the reference: the per-query g++ compile that is cached on first use
+ * drops them all.
+ * Compressed records: where the per-query compiled kernels run (VH_JIT != off), a projection stores every integer column at
+ * the width its values need over the whole table (1, 2, 4 or 8 bytes; dimensions from their SegmentStats, metrics from a
+ * min / max pass when the projection is built) — the compiled kernel widens them back, sign and all, so results do not
+ * change. C3's record shrinks from 32 to 8 bytes (m0 in 4, d0 in 2, d1 and count in 1 each): 8 GB instead of 32, and 16
+ * records per 128-byte line instead of 4, so fewer lines are fetched for the same survivors. A synced value that no longer
+ * fits voids the projection (pack_kernel checks every value it stores); the next query that wants it rebuilds it wider.
+ * The pre-built kernels do not read compressed records: a plan that ends up on them gathers from a plain projection or
+ * the arenas. vh_table_pack decides by itself (compressed when the table is big enough for the compiled kernels to be used on it,
+ * see VH_JIT_MIN_ROWS); vh_table_pack_ex asks for one form. The environment's VH_PACK_PLAIN=1 keeps every automatic choice plain. Analogue in the reference: the per-query g++ compile that is cached on first use
  * (src/query/runner.cc:45-64) — work done once for a query shape, outside its steady-state cost. */
-VH_API int vh_table_pack(vh_table* t, const int32_t* cols, int32_t ncols);
+VH_API int vh_table_pack(vh_table* t, const int32_t* cols, int32_t ncols);       /* = vh_table_pack_ex(.., VH_PACK_AUTO) */
+enum { VH_PACK_AUTO = 0, VH_PACK_PLAIN = 1, VH_PACK_COMPRESSED = 2 };
+VH_API int vh_table_pack_ex(vh_table* t, const int32_t* cols, int32_t ncols, uint32_t form);
 VH_API int vh_table_unpack(vh_table* t);
 
 /* Narrow copies of predicate columns. A column every query filters on is read in full by every query: its bytes are the

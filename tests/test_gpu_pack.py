@@ -170,3 +170,96 @@ def test_library_builds_a_projection_for_a_repeated_selective_query():
         compare(res, st, "no pack")
     finally:
         dt.close()
+
+
+# ---- compressed records (round 3): integers at the width their values need, read by the per-query compiled kernels only
+JITPACK = capi.PLAN_FORCE_JIT | PACK
+
+
+@pytest.fixture(scope="module")
+def typedc():      # its own mirror: a plain projection that covers the same columns would be taken instead of building a compressed one
+    tab = typed_table()
+    dt = mirror_table(tab)
+    yield tab, dt
+    dt.close()
+
+
+@pytest.mark.parametrize("flags,path", [(0, "dense_global"), (64, "dense_part"), (1, "hash"), (2, "dense_global"), (16 | 32, "dense_global")])
+def test_c3_through_compressed_records(flags, path):
+    from viyadb_amd import synth
+    w = synth.c3(segment_rows=250_000)
+    res, _ = check_workload(w, nseg=4, rows_per_seg=249_991, flags=flags | JITPACK, expect_path=path)
+    assert res.packed and res.jit and res.packed_compressed
+
+
+@pytest.mark.parametrize("t", TYPES)
+@pytest.mark.parametrize("flags", [0, 1, 64])
+def test_every_type_as_compressed_metric(typedc, t, flags):
+    tab, dt = typedc
+    res, _ = run(tab, dt, {"dimensions": ["s8", "flag"], "metrics": ["count"] + [f"{t}_{a}" for a in ("sum", "min", "max")],
+                           "filter": F("lt", "d_uint", "20")}, flags=flags | JITPACK | capi.PLAN_NO_LANES)
+    assert res.packed and res.jit and res.packed_compressed
+
+
+@pytest.mark.parametrize("dims", [["d_byte", "d_float", "d_double"], ["d_ulong", "d_long"], ["s8", "s16", "s32", "flag", "d_short"],
+                                  ["d_ubyte", "d_ushort", "id"], ["uts", "ts"], ["d_int", "d_short"]])
+@pytest.mark.parametrize("flags", [0, 1])
+def test_every_type_as_compressed_key(typedc, dims, flags):
+    tab, dt = typedc
+    res, _ = run(tab, dt, {"dimensions": dims, "metrics": ["count", "int_sum", "long_min"], "filter": F("ge", "d_int", "-30")},
+                 flags=flags | JITPACK | capi.PLAN_NO_LANES)
+    assert res.packed and res.jit and res.packed_compressed
+
+
+def test_prebuilt_kernels_never_read_compressed_records(typedc):
+    """The same columns, asked for by a plan the pre-built kernels run: a plain projection is built next to the compressed one."""
+    tab, dt = typedc
+    q = {"dimensions": ["s16", "d_short"], "metrics": ["count", "long_sum"], "filter": F("lt", "d_uint", "20")}
+    a, _ = run(tab, dt, q, flags=JITPACK | capi.PLAN_NO_LANES)
+    b, _ = run(tab, dt, q, flags=capi.PLAN_NO_JIT | PACK | capi.PLAN_NO_LANES)
+    assert a.packed_compressed and b.packed and not b.packed_compressed and not b.jit
+
+
+def test_compressed_records_follow_syncs_and_outgrown_widths():
+    """Values that fit one byte / two bytes when the projection is built; a later vh_segment_sync brings values that need more: the
+    projection is void (pack_kernel notices while re-packing the segment) and is rebuilt wider before the query reads it."""
+    rng = np.random.default_rng(23)
+    desc = {"name": "t", "segment_size": 30000, "dimensions": [{"name": "a", "type": "uint"}, {"name": "b", "type": "int"}, {"name": "f", "type": "uint"}],
+            "metrics": [{"name": "v", "type": "long_sum"}, {"name": "count", "type": "count"}, {"name": "w", "type": "int_min"}]}
+
+    def seg(n, amax=50, vmag=100):
+        return ([rng.integers(0, amax, n).astype(np.uint32), rng.integers(-40, 40, n).astype(np.int32), rng.integers(0, 100, n).astype(np.uint32)],
+                [rng.integers(-vmag, vmag, n).astype(np.int64), rng.integers(1, 4, n).astype(np.uint32), rng.integers(-vmag, vmag, n).astype(np.int32)])
+
+    tab = vo.Table(desc)
+    for n in (30000, 20000):
+        d, m = seg(n)
+        tab.add_segment_arrays(d, m, None, n)
+    dt = mirror_table(tab, reserve=2)
+    q = {"dimensions": ["a", "b"], "metrics": ["v", "count", "w"], "filter": F("lt", "f", "8")}
+    fl = capi.PLAN_FORCE_JIT
+    try:
+        dt.pack([0, 1, 3, 4, 5], compressed=True)
+        res, _ = run(tab, dt, q, flags=fl)
+        assert res.packed and res.packed_compressed and res.jit
+        before = dt.info()[2]
+        # segment 1 is replaced by rows whose values need 4 bytes (a), 8 bytes (v): every stored width is outgrown
+        d, m = seg(25000, amax=3_000_000, vmag=2 ** 40)
+        s1 = tab.segments[1]
+        for i in range(3):
+            s1["d"][i] = d[i]
+        for j in range(3):
+            s1["m"][j] = m[j]
+        s1["size"] = 25000
+        dt.sync_segment(1, d + m, 25000)
+        res, _ = run(tab, dt, q, flags=fl | capi.PLAN_FORCE_HASH)
+        assert res.packed and res.packed_compressed
+        assert dt.info()[2] > before            # wider records
+        # and a third segment within the new widths: re-packed in place
+        d, m = seg(30000, amax=2_000_000, vmag=2 ** 39)
+        tab.add_segment_arrays(d, m, None, 30000)
+        dt.sync_segment(2, d + m, 30000)
+        res, _ = run(tab, dt, q, flags=fl | capi.PLAN_FORCE_HASH)
+        assert res.packed and res.packed_compressed and res.scanned_segments == 3
+    finally:
+        dt.close()

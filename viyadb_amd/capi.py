@@ -135,6 +135,7 @@ SYMBOLS = {
     "vh_segment_sync_bitset": (C.c_int, [_VP, C.c_uint32, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64), _VP]),
     "vh_segment_generate": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(GenSpec), C.c_uint64]),
     "vh_table_pack": (C.c_int, [_VP, C.POINTER(C.c_int32), C.c_int32]),
+    "vh_table_pack_ex": (C.c_int, [_VP, C.POINTER(C.c_int32), C.c_int32, C.c_uint32]),
     "vh_table_unpack": (C.c_int, [_VP]),
     "vh_table_narrow": (C.c_int, [_VP, C.POINTER(C.c_int32), C.c_int32]),
     "vh_segment_read": (C.c_int, [_VP, C.c_uint32, C.c_int32, C.c_uint64, _VP]),

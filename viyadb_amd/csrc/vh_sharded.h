@@ -613,9 +613,14 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
     vh_device_buffer bufs[VH_MAX_METRIC + 1];
     int32_t nb = 0;
     if (int rc = vh_result_device_buffers(r, bufs, VH_MAX_METRIC + 1, &nb)) return rc;
-    for (int32_t b = 0; b < nb; ++b)
-      if (int rc = comm->ops.reduce_device(comm->ops.ctx, bufs[b].ptr, bufs[b].count, bufs[b].elem, bufs[b].reduce, root, st))
-        return rc < 0 ? rc : vh_fail(VH_E_DEVICE, "reduce of a partial state array failed (%d)", rc);
+    // (RCCL: the state arrays of one query go out as ONE group — one launch, one ring set-up — instead of one collective per array)
+    const bool grouped = comm->nccl != nullptr && nb > 1;
+    if (grouped) NCCL_TRY(g_rccl.GroupStart());
+    int red_rc = VH_OK;
+    for (int32_t b = 0; b < nb && !red_rc; ++b)
+      red_rc = comm->ops.reduce_device(comm->ops.ctx, bufs[b].ptr, bufs[b].count, bufs[b].elem, bufs[b].reduce, root, st);
+    if (grouped) NCCL_TRY(g_rccl.GroupEnd());
+    if (red_rc) return red_rc < 0 ? red_rc : vh_fail(VH_E_DEVICE, "reduce of a partial state array failed (%d)", red_rc);
     r->info.scanned_recs = f[4]; r->info.scanned_segments = f[5];
     if (root < 0 || R == root) {
       r->device_rows = false;                                     // small results go straight into pinned host memory again

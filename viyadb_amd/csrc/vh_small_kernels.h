@@ -633,6 +633,9 @@ struct VhPackArgs {
   const char* src[VH_PACK_MAX_COLS];   // column arenas
   uint64_t src_stride[VH_PACK_MAX_COLS];
   uint32_t esize[VH_PACK_MAX_COLS], off[VH_PACK_MAX_COLS];
+  uint32_t wbytes[VH_PACK_MAX_COLS];   // bytes a value takes in the record (< esize: a compressed projection, the value's low bytes)
+  uint32_t sgn_mask;                   // bit c: column c is a signed integer (its stored bytes sign-extend)
+  unsigned int* overflow;              // set when a value does not survive its stored width (the projection is then void)
   char* dst; uint64_t dst_stride;      // pack arena, bytes between segments
   const uint32_t* rows;                // [gridDim.y] rows to pack of segment seg_first + blockIdx.y
   uint32_t seg_first, pad;
@@ -646,16 +649,31 @@ __global__ __launch_bounds__(256) void pack_kernel(const VhPackArgs A) {
   for (uint32_t row0 = blockIdx.x * 256u; row0 < nrows; row0 += gridDim.x * 256u) {
     const uint32_t row = row0 + threadIdx.x;
     if (row < nrows) {
+      bool ovf = false;
       for (int c = 0; c < A.ncols; ++c) {
         const char* s = A.src[c] + (uint64_t)seg * A.src_stride[c] + (uint64_t)row * A.esize[c];
         char* d = lds + threadIdx.x * rec + A.off[c];
+        uint64_t v;
         switch (A.esize[c]) {
-          case 1: *reinterpret_cast<uint8_t*>(d) = *reinterpret_cast<const uint8_t*>(s); break;
-          case 2: *reinterpret_cast<uint16_t*>(d) = *reinterpret_cast<const uint16_t*>(s); break;
-          case 4: *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<const uint32_t*>(s); break;
-          default: *reinterpret_cast<uint64_t*>(d) = *reinterpret_cast<const uint64_t*>(s); break;
+          case 1: v = *reinterpret_cast<const uint8_t*>(s); break;
+          case 2: v = *reinterpret_cast<const uint16_t*>(s); break;
+          case 4: v = *reinterpret_cast<const uint32_t*>(s); break;
+          default: v = *reinterpret_cast<const uint64_t*>(s); break;
+        }
+        const uint32_t w = A.wbytes[c];
+        if (w < A.esize[c]) {           // compressed: the low w bytes must give the value back (zero- or sign-extended)
+          const int sh = 64 - 8 * (int)w, sh_e = 64 - 8 * (int)A.esize[c];
+          if ((A.sgn_mask >> c) & 1u) ovf |= ((int64_t)(v << sh_e) >> sh_e) != ((int64_t)(v << sh) >> sh);
+          else ovf |= (v << sh >> sh) != v;
+        }
+        switch (w) {
+          case 1: *reinterpret_cast<uint8_t*>(d) = (uint8_t)v; break;
+          case 2: *reinterpret_cast<uint16_t*>(d) = (uint16_t)v; break;
+          case 4: *reinterpret_cast<uint32_t*>(d) = (uint32_t)v; break;
+          default: *reinterpret_cast<uint64_t*>(d) = v; break;
         }
       }
+      if (ovf) atomicOr(A.overflow, 1u);
     }
     __syncthreads();
     vh_u32x4* out = reinterpret_cast<vh_u32x4*>(dst + (uint64_t)row0 * rec);

@@ -64,7 +64,7 @@ static std::mutex g_mu;
 // at their (cold) sites.
 struct VhKnobs {
   bool trace_alloc, no_topk, no_stage, jit_verbose, skip_phase2, no_direct_emit, times;
-  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, split_bpc, bw_blocks_per_cu;
+  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, split_bpc, bw_blocks_per_cu;
   double hp_load_g, hp_load_s;
 };
 static const VhKnobs& knobs() {
@@ -77,7 +77,7 @@ static const VhKnobs& knobs() {
     x.jit_verbose = flag("VH_JIT_VERBOSE"); x.skip_phase2 = flag("VH_ABLATE_NO_PHASE2"); x.no_direct_emit = flag("VH_NO_DIRECT_EMIT"); x.times = flag("VH_TIMES");
     x.max_exec = std::max(1, num("VH_MAX_EXEC", 16));
     x.auto_narrow = num("VH_AUTO_NARROW", 3); x.auto_pack = num("VH_AUTO_PACK", 3);
-    x.jit_ablate = num("VH_JIT_ABLATE", 0); x.hp_ablate = num("VH_HP_ABLATE", 0); x.hp_bpp = num("VH_HP_BPP", 0);
+    x.jit_ablate = num("VH_JIT_ABLATE", 0); x.hp_ablate = num("VH_HP_ABLATE", 0); x.hp_bpp = num("VH_HP_BPP", 0); x.pack_plain = num("VH_PACK_PLAIN", 0);
     x.lanes_block = num("VH_LANES_BLOCK", 0); x.blocks_per_cu = num("VH_BLOCKS_PER_CU", 0); x.unit_rows = num("VH_UNIT_ROWS", 0); x.grid = num("VH_GRID", 0);
     x.ext_tuples = num("VH_EXT_TUPLES", 0); x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
     x.hp_load_g = real("VH_HP_LOAD_G", 0.7); x.hp_load_s = real("VH_HP_LOAD_S", 0.7);
@@ -153,6 +153,8 @@ struct VhExec {
 struct VhPack {
   std::vector<int> cols;            // table column indices, in record order (widest first)
   std::vector<uint32_t> off;        // byte offset of each column inside a record
+  std::vector<uint8_t> width;       // bytes the column's values take in a record (compressed: fewer than its element size)
+  bool compressed = false;          // integer columns stored at the width their values need; only the per-query compiled kernels read these
   uint32_t rec_bytes = 0;           // power of two, 8..64
   char* base = nullptr; uint64_t stride = 0; uint32_t cap_seg = 0;
   std::vector<uint64_t> seg_mod;    // value of vh_table::seg_mod[s] the segment was packed at (0: never)
@@ -187,6 +189,7 @@ struct vh_table {
   std::map<int, uint32_t> pred_seen;                     // column -> queries that filtered on it (automatic narrow copies)
   std::vector<uint64_t> seg_mod;                          // sync_epoch of the last change to a segment's columns
   uint32_t* d_packrows = nullptr; size_t d_packrows_cap = 0;
+  unsigned int* d_packflag = nullptr;                      // pack_kernel's "a value outgrew its stored width" word
   std::map<std::string, uint32_t> gather_seen;            // payload column set -> low-selectivity queries seen (automatic packs)
   uint64_t sync_epoch = 0;   // bumped by every vh_segment_sync / generate: invalidates cached estimates
   std::mutex mu;             // table metadata, column arenas, projections, planner caches: held while a query is PLANNED and
@@ -315,6 +318,7 @@ extern "C" void vh_table_destroy(vh_table* t) {
     for (auto p : c.bs_values) if (p) (void)hipFree(p);
   }
   if (t->d_stats) (void)hipFree(t->d_stats);
+  if (t->d_packflag) (void)hipFree(t->d_packflag);
   for (auto& pk : t->packs) if (pk->base) (void)hipFree(pk->base);
   for (auto& nw : t->narrows) if (nw->base) (void)hipFree(nw->base);
   if (t->d_packrows) (void)hipFree(t->d_packrows);
@@ -587,6 +591,7 @@ extern "C" int vh_table_info(vh_table* t, uint32_t* nseg, uint64_t* segment_rows
 }
 
 // ------------------------------------------------------- payload projections (vh_table_pack)
+#define VH_PACK_STALE 9001      // (internal) pack_refresh: a value no longer fits its stored width, the projection must go
 // (Re)pack the segments of [first, first + n) whose columns changed since they were last packed.
 static int pack_refresh(vh_table* t, VhPack* pk, uint32_t first, uint32_t n) {
   if (first + n > t->nseg) n = t->nseg > first ? t->nseg - first : 0;
@@ -628,19 +633,86 @@ static int pack_refresh(vh_table* t, VhPack* pk, uint32_t first, uint32_t n) {
     for (size_t c = 0; c < pk->cols.size(); ++c) {
       const VhColumn& col = t->cols[pk->cols[c]];
       A.src[c] = col.base; A.src_stride[c] = col.stride; A.esize[c] = (uint32_t)col.esize; A.off[c] = pk->off[c];
+      A.wbytes[c] = pk->width[c];
+      if (col.elem == VH_I8 || col.elem == VH_I16 || col.elem == VH_I32 || col.elem == VH_I64) A.sgn_mask |= 1u << c;
     }
+    if (!t->d_packflag) { HIP_TRY(hipMalloc((void**)&t->d_packflag, 256)); HIP_TRY(hipMemsetAsync(t->d_packflag, 0, 256, g_ctx.stream)); }
+    A.overflow = t->d_packflag;
     A.dst = pk->base; A.dst_stride = pk->stride; A.rows = t->d_packrows; A.seg_first = s;
     dim3 grid((unsigned)std::min<uint64_t>(64, (t->segment_rows + 255) / 256), cnt);
     hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 256 * pk->rec_bytes, g_ctx.stream, A);
     HIP_TRY(hipGetLastError());
+    unsigned int ovf = 0;
+    if (pk->compressed) HIP_TRY(hipMemcpyAsync(&ovf, t->d_packflag, sizeof(ovf), hipMemcpyDeviceToHost, g_ctx.stream));
     HIP_TRY(hipStreamSynchronize(g_ctx.stream));        // `rows` lives on this frame; d_packrows is reused by the next batch
+    if (ovf) {                                          // a synced value outgrew its stored width: the projection is void (the caller drops it)
+      HIP_TRY(hipMemsetAsync(t->d_packflag, 0, 256, g_ctx.stream));
+      return VH_PACK_STALE;
+    }
     for (uint32_t i = s; i < e; ++i) pk->seg_mod[i] = t->seg_mod[i];
     s = e;
   }
   return VH_OK;
 }
+static void pack_drop(vh_table* t, VhPack* pk) {
+  table_quiesce(t);
+  (void)hipStreamSynchronize(g_ctx.stream);
+  for (size_t k = 0; k < t->packs.size(); ++k) {
+    if (t->packs[k].get() != pk) continue;
+    if (pk->base) { (void)hipFree(pk->base); t->device_bytes -= (size_t)pk->cap_seg * pk->stride + 256; }
+    t->packs.erase(t->packs.begin() + (long)k);
+    return;
+  }
+}
 
-static int table_pack_locked(vh_table* t, const int32_t* cols, int32_t ncols, bool automatic, VhPack** out) {
+// Bytes the values of an integer column need over every mirrored segment (1, 2, 4 or 8; the element size for floating point): dimensions
+// from their SegmentStats, metrics from a min / max pass of their own (they keep no stats).
+static int column_stored_width(vh_table* t, int col, int* width_out) {
+  const VhColumn& c = t->cols[col];
+  *width_out = (int)c.esize;
+  if (c.elem == VH_F32 || c.elem == VH_F64 || c.esize == 1 || !t->nseg) return VH_OK;
+  uint64_t lo = ~0ull, hi = 0;
+  if (is_dim(c.kind) && (size_t)col < t->stats.size() && t->stats[col].size() >= t->nseg) {
+    for (uint32_t s = 0; s < t->nseg; ++s) { const VhSegStat& st = t->stats[col][s]; if (st.lo > st.hi) continue; lo = std::min(lo, st.lo); hi = std::max(hi, st.hi); }
+  } else {
+    const uint32_t n = t->nseg;
+    char* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)n * 16 + (size_t)n * 4 + 256));
+    unsigned long long* d_st = reinterpret_cast<unsigned long long*>(tmp);
+    uint32_t* d_rows = reinterpret_cast<uint32_t*>(tmp + (size_t)n * 16);
+    std::vector<unsigned long long> init((size_t)n * 2);
+    for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ull; init[i + 1] = 0; }
+    std::vector<uint32_t> hrows(n);
+    for (uint32_t s = 0; s < n; ++s) hrows[s] = (uint32_t)t->seg_rows[s];
+    hipError_t he = hipMemcpyAsync(d_st, init.data(), init.size() * 8, hipMemcpyHostToDevice, g_ctx.stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(d_rows, hrows.data(), hrows.size() * 4, hipMemcpyHostToDevice, g_ctx.stream);
+    if (he == hipSuccess) {
+      for (uint32_t first = 0; first < n; first += 32768) {       // (grid.y)
+        const uint32_t cnt = std::min<uint32_t>(32768, n - first);
+        dim3 grid((unsigned)std::min<uint64_t>(64, (t->segment_rows + 4095) / 4096), cnt);
+        VH_ELEM_SWITCH(c.elem, (seg_minmax_kernel<T><<<grid, dim3(256), 0, g_ctx.stream>>>(reinterpret_cast<const T*>(c.base), c.stride / c.esize, d_rows + first, first, d_st + 2ull * first)));
+      }
+      he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipMemcpyAsync(init.data(), d_st, init.size() * 8, hipMemcpyDeviceToHost, g_ctx.stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(g_ctx.stream);
+    (void)hipFree(tmp);
+    if (he != hipSuccess) return vh_fail(VH_E_DEVICE, "min / max pass over column %d: %s", col, hipGetErrorString(he));
+    for (uint32_t s = 0; s < n; ++s) { if (init[2 * s] > init[2 * s + 1]) continue; lo = std::min<uint64_t>(lo, init[2 * s]); hi = std::max<uint64_t>(hi, init[2 * s + 1]); }
+  }
+  if (lo > hi) { *width_out = 1; return VH_OK; }       // no rows yet: anything fits (a later value that does not voids the projection)
+  int w = (int)c.esize;
+  if (c.elem == VH_I16 || c.elem == VH_I32 || c.elem == VH_I64) {
+    const int64_t a = (int64_t)(lo ^ (1ull << 63)), b = (int64_t)(hi ^ (1ull << 63));       // (order key of a signed integer: the value with its sign bit flipped)
+    w = (a >= INT8_MIN && b <= INT8_MAX) ? 1 : (a >= INT16_MIN && b <= INT16_MAX) ? 2 : (a >= INT32_MIN && b <= INT32_MAX) ? 4 : 8;
+  } else {
+    w = hi < 256 ? 1 : hi < 65536 ? 2 : hi <= 0xFFFFFFFFull ? 4 : 8;
+  }
+  *width_out = std::min(w, (int)c.esize);
+  return VH_OK;
+}
+
+static int table_pack_locked(vh_table* t, const int32_t* cols, int32_t ncols, bool automatic, VhPack** out, bool compress) {
   if (!cols || ncols <= 0 || ncols > VH_PACK_MAX_COLS) return vh_fail(VH_E_INVALID, "vh_table_pack: 1..%d columns", VH_PACK_MAX_COLS);
   std::vector<int> order;
   for (int i = 0; i < ncols; ++i) {
@@ -648,23 +720,44 @@ static int table_pack_locked(vh_table* t, const int32_t* cols, int32_t ncols, bo
     if (c < 0 || (size_t)c >= t->cols.size() || is_bitset_elem(t->cols[c].elem)) return vh_fail(VH_E_INVALID, "vh_table_pack: column %d cannot be packed", c);
     if (std::find(order.begin(), order.end(), c) == order.end()) order.push_back(c);
   }
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return t->cols[a].esize > t->cols[b].esize; });   // widest first: every field naturally aligned
-  uint32_t bytes = 0;
-  std::vector<uint32_t> off;
-  for (int c : order) { off.push_back(bytes); bytes += (uint32_t)t->cols[c].esize; }
-  if (bytes > 64) return vh_fail(VH_E_UNSUPPORTED, "vh_table_pack: %u payload bytes per row (max 64)", bytes);
-  uint32_t rec = 8;
-  while (rec < bytes) rec <<= 1;
-  for (auto& pk : t->packs)
-    if (pk->cols == order) { if (out) *out = pk.get(); return pack_refresh(t, pk.get(), 0, t->nseg); }
-  std::unique_ptr<VhPack> pk(new VhPack());
-  pk->cols = order; pk->off = off; pk->rec_bytes = rec; pk->automatic = automatic;
-  pk->stride = (t->segment_rows + 255) / 256 * 256 * (uint64_t)rec;
-  VhPack* raw = pk.get();
-  t->packs.push_back(std::move(pk));
-  int rc = pack_refresh(t, raw, 0, t->nseg);
-  if (rc) { if (raw->base) { (void)hipFree(raw->base); t->device_bytes -= (size_t)raw->cap_seg * raw->stride + 256; } t->packs.pop_back(); return rc; }
-  if (out) *out = raw;
+  std::vector<int> sorted_cols = order;
+  std::sort(sorted_cols.begin(), sorted_cols.end());
+  for (auto& pk : t->packs) {
+    std::vector<int> have = pk->cols;
+    std::sort(have.begin(), have.end());
+    if (have != sorted_cols || pk->compressed != compress) continue;
+    const int rc = pack_refresh(t, pk.get(), 0, t->nseg);
+    if (rc == VH_PACK_STALE) { pack_drop(t, pk.get()); break; }      // built again below, at the widths the values need now
+    if (out) *out = pk.get();
+    return rc;
+  }
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    std::map<int, int> wof;
+    for (int c : order) {
+      int w = (int)t->cols[c].esize;
+      if (compress) if (int rc = column_stored_width(t, c, &w)) return rc;
+      wof[c] = w;
+    }
+    std::vector<int> ord = order;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return wof[a] > wof[b]; });   // widest first: every field naturally aligned
+    uint32_t bytes = 0;
+    std::vector<uint32_t> off;
+    std::vector<uint8_t> width;
+    for (int c : ord) { off.push_back(bytes); width.push_back((uint8_t)wof[c]); bytes += (uint32_t)wof[c]; }
+    if (bytes > 64) return vh_fail(VH_E_UNSUPPORTED, "vh_table_pack: %u payload bytes per row (max 64)", bytes);
+    uint32_t rec = 8;
+    while (rec < bytes) rec <<= 1;
+    std::unique_ptr<VhPack> pk(new VhPack());
+    pk->cols = ord; pk->off = off; pk->width = width; pk->rec_bytes = rec; pk->automatic = automatic; pk->compressed = compress;
+    pk->stride = (t->segment_rows + 255) / 256 * 256 * (uint64_t)rec;
+    VhPack* raw = pk.get();
+    t->packs.push_back(std::move(pk));
+    const int rc = pack_refresh(t, raw, 0, t->nseg);
+    if (rc == VH_PACK_STALE && attempt == 0) { pack_drop(t, raw); continue; }      // (a metric changed between the min / max pass and the copy)
+    if (rc) { pack_drop(t, raw); return rc == VH_PACK_STALE ? vh_fail(VH_E_DEVICE, "vh_table_pack: values keep outgrowing their stored widths") : rc; }
+    if (out) *out = raw;
+    return VH_OK;
+  }
   return VH_OK;
 }
 
@@ -766,12 +859,22 @@ extern "C" int vh_table_narrow(vh_table* t, const int32_t* cols, int32_t ncols) 
   return VH_OK;
 }
 
-extern "C" int vh_table_pack(vh_table* t, const int32_t* cols, int32_t ncols) {
+extern "C" int vh_table_pack_ex(vh_table* t, const int32_t* cols, int32_t ncols, uint32_t form) {
   if (!t) return vh_fail(VH_E_INVALID, "null table");
+  if (form > VH_PACK_COMPRESSED) return vh_fail(VH_E_INVALID, "vh_table_pack_ex: form %u", form);
   VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
-  return table_pack_locked(t, cols, ncols, false, nullptr);
+  // VH_PACK_AUTO: compressed where the per-query compiled kernels — the only readers of compressed records — would run a scan of the
+  // whole table (VH_JIT=force, or auto and the table holds VH_JIT_MIN_ROWS rows); plain where the pre-built kernels answer
+  bool compress = form == VH_PACK_COMPRESSED;
+  if (form == VH_PACK_AUTO) {
+    uint64_t rows = 0;
+    for (uint32_t s = 0; s < t->nseg; ++s) rows += t->seg_rows[s];
+    compress = !knobs().pack_plain && (vh_jit_policy() == VH_JIT_FORCE || (vh_jit_policy() == VH_JIT_AUTO && rows >= vh_jit_min_rows()));
+  }
+  return table_pack_locked(t, cols, ncols, false, nullptr, compress);
 }
+extern "C" int vh_table_pack(vh_table* t, const int32_t* cols, int32_t ncols) { return vh_table_pack_ex(t, cols, ncols, VH_PACK_AUTO); }
 
 extern "C" int vh_table_unpack(vh_table* t) {
   if (!t) return vh_fail(VH_E_INVALID, "null table");
@@ -1121,10 +1224,109 @@ struct VhAgreed {
   double sel;
 };
 
+// One aggregate query on its way to the device. query_launch_locked() runs the steps in order; each step reads what the earlier
+// ones decided from the members below. `done`: the query has been handed over (or, for a plan-only / summary call, answered) early.
+struct QueryBuild {
+  // ---- the call
+  vh_table* t; VhExec* x; const vh_plan* p; vh_result** out;
+  uint64_t hash_capacity_override; bool force_hash; uint64_t part_tuples_override; bool no_part, plan_only;
+  VhSummary* summary_out; const VhAgreed* ag; bool device_rows; uint32_t hp_passes_override; bool no_hpart;
+  std::unique_ptr<vh_result> holder;      // every early return drops it
+  vh_result* r;
+  VhPlanDev& P;
+  std::vector<VhProgOp>& prog;
+  bool done = false;
+  // ---- plan shape
+  uint32_t nseg = 0; int ncols = 0;
+  int slot_of[256];
+  int slot_col[VH_MAX_SLOTS];                    // table column behind a slot (-1: a narrow copy / projection member added later)
+  int slot_rec[VH_MAX_SLOTS], slot_recoff[VH_MAX_SLOTS];   // payload projection a slot reads from (-1: a column arena) and the member's offset in its record
+  int slot_stored[VH_MAX_SLOTS];                 // ... and the bytes it takes there (0: the element size)
+  uint64_t bytes_per_row = 0;
+  bool fast_ok = false;
+  int pred_col[VH_MAX_PRED] = {-1, -1, -1, -1};        // table column behind predicate slot k of the register-resident kernels
+  int pred_wide_slot[VH_MAX_PRED] = {-1, -1, -1, -1};  // its 4-byte arena's slot when the plan was pointed at a narrow copy
+  VhJitShape jshape;
+  int jit_pred_col[VJ_MAX_PRED];
+  bool jit_try = false;
+  uint64_t rows_to_scan = 0;
+  std::vector<uint32_t> live;                    // segments with rows to scan
+  uint64_t probe_passed = 0, probe_sampled = 0;
+  bool dense_ok = false;
+  uint64_t G = 1;                                // dense group-id space
+  int bitset_col[VH_MAX_BITSET];
+  int metric_col[VH_MAX_METRIC];                 // table column behind device metric j (-1: virtual row id / bitset)
+  uint64_t bitset_ids[VH_MAX_BITSET] = {};       // ids stored in the scanned segments, per bitset metric
+  // ---- organisation
+  int mode = 0;
+  size_t lds_table = 0;
+  bool fast = false, fastj = false, lanes = false;
+  uint64_t part_tuple_cap = 0;
+  int nxcd = 1, part_bpp = 1;
+  uint64_t capacity = 0;
+  bool hpart = false;
+  uint64_t hp_tuple_cap = 0, hp_pair_cap = 0;
+  int hp_bpp = 1;
+  uint32_t hp_chunk = 256;
+  bool packed = false, packed_compressed = false;
+  VhJitKernel* jk = nullptr;
+  int jit_block = 256;
+  // ---- work decomposition, scratch
+  int BLOCK = 256, grid = 1;
+  size_t o_segrows = 0, zero_begin = 0, zero_end = 0;
+  uint64_t table_n = 0;
+  size_t rec_off[VH_MAX_METRIC] = {};
+  int split_bpp = 1;
+  struct HpOff { size_t ta = 0, fa = 0, ga = 0, tb = 0, fb = 0, gb = 0, meta = 0; uint64_t maxa = 0, maxb = 0; } hpo[2];
+  size_t o_hpargs = 0, hp_meta_bytes = 0;
+  char* S = nullptr;
+
+  QueryBuild(vh_table* t_, VhExec* x_, const vh_plan* p_, vh_result** out_, uint64_t hash_capacity_override_, bool force_hash_,
+             uint64_t part_tuples_override_, bool no_part_, bool plan_only_, VhSummary* summary_out_, const VhAgreed* ag_,
+             bool device_rows_, uint32_t hp_passes_override_, bool no_hpart_)
+      : t(t_), x(x_), p(p_), out(out_), hash_capacity_override(hash_capacity_override_), force_hash(force_hash_),
+        part_tuples_override(part_tuples_override_), no_part(no_part_), plan_only(plan_only_), summary_out(summary_out_), ag(ag_),
+        device_rows(device_rows_), hp_passes_override(hp_passes_override_), no_hpart(no_hpart_),
+        holder(new vh_result()), r(holder.get()), P(r->plan), prog(r->h_prog) {}
+
+  int slot(int col);                              // the plan's slot of a table column (-1: none left / bad column, -2: a bitset metric)
+  int probed_selectivity(double* sel);
+  void scan_dispatch(int grid_, int* occ);        // one place decides which scan kernel runs; with `occ` it only asks how many of its blocks fit a CU
+  // the steps, in order
+  int shape_filter();
+  int snapshot_segments();
+  int shape_groups();
+  int shape_metrics();
+  int choose_organisation();
+  int plan_hashed_partitioning();
+  int choose_projection();
+  int compile_kernel();
+  int decompose_work();
+  int layout_scratch();
+  int launch();
+};
+
 static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_result** out, uint64_t hash_capacity_override,
-                               bool force_hash, uint64_t part_tuples_override = 0, bool no_part = false,
-                               bool plan_only = false, VhSummary* summary_out = nullptr, const VhAgreed* ag = nullptr,
-                               bool device_rows = false, uint32_t hp_passes_override = 0, bool no_hpart = false) {
+                               bool force_hash, uint64_t part_tuples_override, bool no_part, bool plan_only, VhSummary* summary_out,
+                               const VhAgreed* ag, bool device_rows, uint32_t hp_passes_override, bool no_hpart);
+
+int QueryBuild::slot(int col) {
+  if (col < 0 || col >= ncols || col >= 256) return -1;
+  if (slot_of[col] >= 0) return slot_of[col];
+  if (P.nslots >= VH_MAX_SLOTS) return -1;
+  const VhColumn& c = t->cols[col];
+  if (is_bitset_elem(c.elem)) return -2;
+  slot_of[col] = P.nslots;
+  slot_col[P.nslots] = col;
+  P.colbase[P.nslots] = c.base;
+  P.colstride[P.nslots] = c.stride;
+  P.colpitch[P.nslots] = (uint32_t)c.esize;
+  bytes_per_row += c.esize;
+  return P.nslots++;
+}
+
+int QueryBuild::shape_filter() {
+  int rc = VH_OK; (void)rc;
   // ---------------- validate
   if (p->nfilter < 0 || p->nlits < 0 || p->ngroups < 0 || p->nmetrics < 0 || p->nhaving < 0)
     return vh_fail(VH_E_INVALID, "plan has a negative count");
@@ -1133,44 +1335,20 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   if (p->nlits > VH_MAX_LITS) return vh_fail(VH_E_UNSUPPORTED, "filter has %d literals (max %d)", p->nlits, VH_MAX_LITS);
   if (p->ngroups > VH_MAX_GROUP) return vh_fail(VH_E_UNSUPPORTED, "%d group columns (max %d)", p->ngroups, VH_MAX_GROUP);
   if (p->nmetrics > VH_MAX_METRIC - 1) return vh_fail(VH_E_UNSUPPORTED, "%d metrics in one pass (max %d; vh_query_agg splits wider queries into passes)", p->nmetrics, VH_MAX_METRIC - 1);
-  const uint32_t nseg = p->seg_rows ? p->nseg : t->nseg;
+  nseg = p->seg_rows ? p->nseg : t->nseg;
   if (nseg > t->nseg) return vh_fail(VH_E_INVALID, "plan snapshots %u segments, table mirrors %u", nseg, t->nseg);
-  const int ncols = (int)t->cols.size();
+  ncols = (int)t->cols.size();
 
-  std::unique_ptr<vh_result> holder(new vh_result());   // every early return below drops it
-  vh_result* r = holder.get();
   r->table = t;
-  VhPlanDev& P = r->plan;
   memset(&P, 0, sizeof(P));
 
   // ---------------- column slots
-  int slot_of[256];
   for (int i = 0; i < 256; ++i) slot_of[i] = -1;
-  int slot_col[VH_MAX_SLOTS];                    // table column behind a slot (-1: a narrow copy / projection member added later)
-  int slot_rec[VH_MAX_SLOTS], slot_recoff[VH_MAX_SLOTS];   // payload projection a slot reads from (-1: a column arena) and the member's offset in its record
-  for (int i = 0; i < VH_MAX_SLOTS; ++i) { slot_col[i] = -1; slot_rec[i] = -1; slot_recoff[i] = 0; }
-  uint64_t bytes_per_row = 0;
-  auto slot = [&](int col) -> int {
-    if (col < 0 || col >= ncols || col >= 256) return -1;
-    if (slot_of[col] >= 0) return slot_of[col];
-    if (P.nslots >= VH_MAX_SLOTS) return -1;
-    const VhColumn& c = t->cols[col];
-    if (is_bitset_elem(c.elem)) return -2;
-    slot_of[col] = P.nslots;
-    slot_col[P.nslots] = col;
-    P.colbase[P.nslots] = c.base;
-    P.colstride[P.nslots] = c.stride;
-    P.colpitch[P.nslots] = (uint32_t)c.esize;
-    bytes_per_row += c.esize;
-    return P.nslots++;
-  };
+  for (int i = 0; i < VH_MAX_SLOTS; ++i) { slot_col[i] = -1; slot_rec[i] = -1; slot_recoff[i] = 0; slot_stored[i] = 0; }
 
   // ---------------- filter program (+ stack depth check)
-  bool fast_ok = !(p->flags & VH_PLAN_NO_FAST);
-  int pred_col[VH_MAX_PRED] = {-1, -1, -1, -1};        // table column behind predicate slot k of the register-resident kernels
-  int pred_wide_slot[VH_MAX_PRED] = {-1, -1, -1, -1};  // its 4-byte arena's slot when the plan was pointed at a narrow copy
+  fast_ok = !(p->flags & VH_PLAN_NO_FAST);
   int depth = 0, maxdepth = 0;
-  std::vector<VhProgOp>& prog = r->h_prog;
   std::vector<size_t> seg_start;          // where the piece of program behind each value on the (simulated) stack begins
   for (int i = 0; i < p->nfilter; ++i) {
     const vh_filter_node& n = p->filter[i];
@@ -1269,9 +1447,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   // ---------------- per-query compiled scan kernel (vh_jit.hip): which predicate columns it would hold packed in registers
   // Eligible so far: every leaf compares a fixed-width column, the program and its literals fit the kernel arguments, the packed
   // columns fit VJ_MAX_NV registers. The table organisation decides the rest further down.
-  VhJitShape jshape;
-  int jit_pred_col[VJ_MAX_PRED];
-  bool jit_try = vh_jit_policy() != VH_JIT_OFF && !(p->flags & (VH_PLAN_NO_JIT | VH_PLAN_NO_FAST)) && prog.size() <= VH_INLINE_PROG && r->h_lits.size() <= VH_INLINE_LITS;
+  jit_try = vh_jit_policy() != VH_JIT_OFF && !(p->flags & (VH_PLAN_NO_JIT | VH_PLAN_NO_FAST)) && prog.size() <= VH_INLINE_PROG && r->h_lits.size() <= VH_INLINE_LITS;
   if (jit_try) {
     jshape.prog = prog;
     int nv = 0;
@@ -1336,18 +1512,21 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         jshape.pred[k].width = (int)P.colpitch[ns];
       }
   }
+  return VH_OK;
+}
 
+int QueryBuild::snapshot_segments() {
+  int rc = VH_OK; (void)rc;
   // ---------------- segments: snapshot + skip
   // one pinned staging block [segment snapshot | program | literals] -> one upload per query
   const size_t seg_words = ((size_t)std::max<uint32_t>(nseg, 1) + 1) / 2 * 2;
   const size_t plan_words = seg_words + 2 * (prog.size() + r->h_lits.size());
-  int rc = ensure_segrows(x, plan_words);
+  rc = ensure_segrows(x, plan_words);
   if (rc) { return rc; }
   memcpy(x->h_segrows + seg_words, prog.data(), prog.size() * sizeof(VhProgOp));
   memcpy(x->h_segrows + seg_words + 2 * prog.size(), r->h_lits.data(), r->h_lits.size() * sizeof(uint64_t));
   r->plan_words = plan_words; r->seg_words = seg_words;
-  uint64_t scanned_recs = 0, scanned_segments = 0, rows_to_scan = 0;
-  std::vector<uint32_t> live;
+  uint64_t scanned_recs = 0, scanned_segments = 0;
   for (uint32_t s = 0; s < nseg; ++s) {
     uint64_t rows = p->seg_rows ? p->seg_rows[s] : t->seg_rows[s];
     if (rows > t->seg_rows[s]) { return vh_fail(VH_E_INVALID, "segment %u: snapshot %llu rows > mirrored %llu", s, (unsigned long long)rows, (unsigned long long)t->seg_rows[s]); }
@@ -1364,33 +1543,36 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     P.nseg = nseg;
     r->info.algorithmic_bytes = rows_to_scan * bytes_per_row;
     *out = holder.release();
+    done = true;
     return VH_OK;
   }
+  return VH_OK;
+}
 
-  // selectivity of the filter, from a one-launch probe; it only depends on the filter and the rows, so it is cached
-  // until the table changes. Sharded queries plan with the estimate all ranks agreed on.
-  uint64_t probe_passed = 0, probe_sampled = 0;
-  auto probed_selectivity = [&](double* sel) -> int {
-    if (ag) { *sel = ag->sel; return VH_OK; }
-    if (p->nfilter == 0) { *sel = 1.0; probe_passed = probe_sampled = rows_to_scan; return VH_OK; }   // no filter: every row passes
-    std::string key((const char*)prog.data(), sizeof(VhProgOp) * prog.size());
-    key.append((const char*)r->h_lits.data(), sizeof(uint64_t) * r->h_lits.size());
-    key += "|" + std::to_string(nseg) + "|" + std::to_string(rows_to_scan) + "|" + std::to_string(t->sync_epoch);
-    auto hit = t->sel_cache.find(key);
-    if (hit != t->sel_cache.end()) { probe_passed = hit->second.first; probe_sampled = hit->second.second; *sel = probe_sampled ? (double)probe_passed / (double)probe_sampled : 0.0; return VH_OK; }
-    const int prc = estimate_selectivity(t, x, P, r->h_prog, r->h_lits, nseg, sel, &probe_passed, &probe_sampled, !fast_ok);
-    if (prc) return prc;
-    if (t->sel_cache.size() > 256) t->sel_cache.clear();
-    t->sel_cache[key] = std::make_pair(probe_passed, probe_sampled);
-    return VH_OK;
-  };
+// selectivity of the filter, from a one-launch probe; it only depends on the filter and the rows, so it is cached
+// until the table changes. Sharded queries plan with the estimate all ranks agreed on.
+int QueryBuild::probed_selectivity(double* sel) {
+  if (ag) { *sel = ag->sel; return VH_OK; }
+  if (p->nfilter == 0) { *sel = 1.0; probe_passed = probe_sampled = rows_to_scan; return VH_OK; }   // no filter: every row passes
+  std::string key((const char*)prog.data(), sizeof(VhProgOp) * prog.size());
+  key.append((const char*)r->h_lits.data(), sizeof(uint64_t) * r->h_lits.size());
+  key += "|" + std::to_string(nseg) + "|" + std::to_string(rows_to_scan) + "|" + std::to_string(t->sync_epoch);
+  auto hit = t->sel_cache.find(key);
+  if (hit != t->sel_cache.end()) { probe_passed = hit->second.first; probe_sampled = hit->second.second; *sel = probe_sampled ? (double)probe_passed / (double)probe_sampled : 0.0; return VH_OK; }
+  const int prc = estimate_selectivity(t, x, P, r->h_prog, r->h_lits, nseg, sel, &probe_passed, &probe_sampled, !fast_ok);
+  if (prc) return prc;
+  if (t->sel_cache.size() > 256) t->sel_cache.clear();
+  t->sel_cache[key] = std::make_pair(probe_passed, probe_sampled);
+  return VH_OK;
+}
 
+int QueryBuild::shape_groups() {
+  int rc = VH_OK; (void)rc;
   // ---------------- group columns
   P.ngroup = p->ngroups;
   if (summary_out) for (int i = 0; i < VH_MAX_GROUP; ++i) { summary_out->klo[i] = ~0ull; summary_out->khi[i] = 0; }
   r->device_rows = device_rows;
-  bool dense_ok = !force_hash && !(p->flags & VH_PLAN_FORCE_HASH);
-  uint64_t G = 1;
+  dense_ok = !force_hash && !(p->flags & VH_PLAN_FORCE_HASH);
   int key_bits_total = 0;
   for (int i = 0; i < p->ngroups; ++i) {
     const vh_group_col& gc = p->groups[i];
@@ -1445,6 +1627,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     double sel = 0;
     if (fast_ok || jit_try || p->nfilter == 0) { rc = probed_selectivity(&sel); if (rc) return rc; }
     summary_out->probe_passed = probe_passed; summary_out->probe_sampled = probe_sampled;
+    done = true;
     return VH_OK;
   }
   const uint64_t plan_rows = ag ? ag->rows_to_scan : rows_to_scan;
@@ -1465,14 +1648,16 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     P.key_words = p->ngroups ? word + 1 : 1;
     if (P.key_words > VH_KEY_WORDS) { return vh_fail(VH_E_UNSUPPORTED, "group key of %d bits is too wide", key_bits_total); }
   }
+  return VH_OK;
+}
 
+int QueryBuild::shape_metrics() {
+  int rc = VH_OK; (void)rc;
   // ---------------- metrics
   P.nmetric = 0;
   bool has_avg = false, has_count = false;
-  int bitset_col[VH_MAX_BITSET];
-  int metric_col[VH_MAX_METRIC];   // table column behind device metric j (-1: virtual row id / bitset)
   for (int j = 0; j < VH_MAX_METRIC; ++j) metric_col[j] = -1;
-  uint64_t bitset_ids[VH_MAX_BITSET] = {}, bitset_ids_before = 0;   // ids stored in the scanned segments, per bitset metric
+  uint64_t bitset_ids_before = 0;
   uint64_t pair_cap = 0;
   for (int j = 0; j < p->nmetrics; ++j) {
     const int col = p->metrics[j];
@@ -1541,7 +1726,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       if (n.kind == VH_F_REL || n.kind == VH_F_IN) {
         const int cnt = n.kind == VH_F_REL ? 1 : n.count;
         if (n.col < 0 || n.col >= p->ngroups + p->nmetrics || n.lit < 0 || n.lit + cnt > p->nlits || nl + cnt > VH_MAX_HAVING_LITS) {
-          delete r; return vh_fail(VH_E_INVALID, "having node %d: bad result column / literal range", i);
+          return vh_fail(VH_E_INVALID, "having node %d: bad result column / literal range", i);
         }
         if (n.col < p->ngroups) { o.set_slot((uint8_t)n.col); r->htype[i] = (uint8_t)t->cols[p->groups[n.col].col].elem; }
         else {
@@ -1585,12 +1770,14 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     r->topk = p->top_k; r->topk_elem = elem; r->topk_desc = p->top_desc ? 1 : 0;
     r->topk_cls = (elem == VH_F32 || elem == VH_F64) ? VH_TOPK_FLOAT : VH_TOPK_INT;
   }
+  return VH_OK;
+}
 
+int QueryBuild::choose_organisation() {
+  int rc = VH_OK; (void)rc;
   // ---------------- choose the table organisation
   size_t state_bytes_per_group = 1;  // presence byte
   for (int j = 0; j < P.nmetric; ++j) state_bytes_per_group += vh_sop_bytes(P.m[j].sop());
-  int mode;
-  size_t lds_table = 0;
   if (dense_ok) {
     // LDS layout: [8-byte states][4-byte states][presence bytes], 16 B aligned
     size_t off = 0;
@@ -1610,12 +1797,11 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   } else {
     mode = VH_MODE_HASH;
   }
-  const bool fast = fast_ok && P.ngroup <= VH_FAST_COLS && P.nmetric <= VH_FAST_COLS && P.nbitset == 0;   // npred == 0: no filter
+  fast = fast_ok && P.ngroup <= VH_FAST_COLS && P.nmetric <= VH_FAST_COLS && P.nbitset == 0;   // npred == 0: no filter
   if (P.ngroup > VJ_MAX_COLS || P.nmetric > VJ_MAX_COLS || P.nbitset > 1 || (P.nbitset && P.bs_wide[0])) jit_try = false;
   // (a bitset metric: only the hashed partitioning below has a compiled form for it)
-  const bool fastj = fast || (jit_try && P.nbitset == 0);       // a register-resident scan: pre-built, or compiled for this plan shape
+  fastj = fast || (jit_try && P.nbitset == 0);       // a register-resident scan: pre-built, or compiled for this plan shape
   // "Lanes" kernel (no compaction) for small LDS tables when most rows pass: see scan_agg_lanes_kernel
-  bool lanes = false;
   if (mode == VH_MODE_DENSE_LDS && fast && !(p->flags & VH_PLAN_NO_LANES) && P.ngroup <= VH_LANES_COLS && P.nmetric <= VH_LANES_COLS &&
       P.nmetric >= 1 && rows_to_scan) {
     bool ok = true;
@@ -1634,7 +1820,6 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   // Global atomics are written through to the fabric one by one; when the group-id space is too big
   // for one LDS table but splits into <= VH_MAX_PART LDS-sized ranges, radix-partition the survivors
   // and aggregate each range in LDS instead (DENSE_PART).
-  uint64_t part_tuple_cap = 0;
   if (mode == VH_MODE_DENSE_GLOBAL && fastj && !no_part && !(p->flags & (VH_PLAN_NO_PART | VH_PLAN_FORCE_GLOBAL)) && P.nmetric >= 1 && P.nmetric <= VH_FAST_COLS) {
     int shift = 0;
     const size_t part_table_bytes = getenv("VH_PART_TABLE_KB") ? (size_t)atoi(getenv("VH_PART_TABLE_KB")) * 1024 : 128 * 1024;      // (tests shrink it between two queries to force many ranges)   // one 1024-thread block per CU in phase 2 (160 KB LDS)
@@ -1771,14 +1956,12 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
                : mode == VH_MODE_DENSE_GLOBAL ? VH_PATH_DENSE_GLOBAL : mode == VH_MODE_DENSE_PART ? VH_PATH_DENSE_PART : VH_PATH_HASH;
 
   // per-XCD private copies only while they stay cache-sized
-  int nxcd = 1;
   if (mode != VH_MODE_HASH && mode != VH_MODE_DENSE_PART && P.nbitset == 0 && !(p->flags & VH_PLAN_NO_XCD_PRIVATE) &&
       G <= 16384)   // private copies pay off only against same-address contention (C2 forced to HBM: 3.4 vs 10 ms);
     nxcd = g_ctx.num_xcd;   // with >= 100 K groups one table is as fast and needs no merge pass
   // DENSE_PART: the blocks that share one LDS-sized range each write a private copy of it with plain stores (block b -> copy b;
   // every group of the range, present or not) and dense_merge_kernel adds the copies up — C3: 16 blocks x 13 ranges used to
   // flush 3.2 M global atomics (0.14 ms of phase 2's 0.35) into one table
-  int part_bpp = 1;
   if (mode == VH_MODE_DENSE_PART) {
     part_bpp = std::max(1, std::min(32, g_ctx.num_cu / std::max(1, P.nfine)));    // one 1024-thread block per CU: phase 2 lives off LDS atomics, so every CU counts
     if (!(p->flags & VH_PLAN_NO_XCD_PRIVATE)) nxcd = part_bpp;
@@ -1786,7 +1969,6 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   P.nxcd = nxcd; r->nxcd = nxcd;
   P.xcd_stride = (G + 63) / 64 * 64;
 
-  uint64_t capacity = 0;
   if (mode == VH_MODE_HASH) {
     // sizing: explicit override (regrow) > caller's hint > what the same group columns produced last time > 1 M
     std::string sig;
@@ -1843,17 +2025,17 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       }
     }
   }
+  return VH_OK;
+}
 
+int QueryBuild::plan_hashed_partitioning() {
+  int rc = VH_OK; (void)rc;
   // ---------------- hashed partitioning (HASH organisation with MANY groups: hash_part_agg_kernel, vh_kernels.h)
   // With tens of millions of groups every survivor costs the plain hash table 2-5 read-modify-writes at random addresses of a
   // table no cache holds — the device does ~20 G of those per second (C5: 312 M per 125 M rows = 15.9 ms) — and a count-distinct
   // makes it three more per row. Survivors are instead written out as 16-byte tuples keyed by a bijective mix of the packed group key,
   // radix-partitioned by its top bits (64 ways in the scan kernel, 64 more in part_split_tile_kernel) and aggregated range by range
   // in LDS: sequential traffic of 16 B per tuple and level instead of a 128-byte line read and written per update.
-  bool hpart = false;
-  uint64_t hp_tuple_cap = 0, hp_pair_cap = 0;
-  int hp_bpp = 1;
-  uint32_t hp_chunk = 256;
   if (mode == VH_MODE_HASH && jit_try && (!lanes || (p->flags & VH_PLAN_FORCE_HPART)) && !no_hpart && !(p->flags & VH_PLAN_NO_HPART) && !ag && !device_rows && P.key_words == 1 && P.nmetric >= 1 && rows_to_scan) {
     int bits = 0, nb = 0;
     bool ok = true;
@@ -1939,11 +2121,14 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   // the plain hash table is bound by random read-modify-writes, not by the scan: the pre-built kernel (smaller blocks, more of them per CU
   // next to the LDS front table) runs it a tenth faster than the compiled one (C5t: 3.99 vs 4.39 ms) — the compiled kernel is for plans it cannot hold
   if (mode == VH_MODE_HASH && !hpart && fast && !(p->flags & VH_PLAN_FORCE_JIT) && vh_jit_policy() != VH_JIT_FORCE) jit_try = false;
+  return VH_OK;
+}
 
+int QueryBuild::choose_projection() {
+  int rc = VH_OK; (void)rc;
   // ---------------- payload projection: when few rows pass, a survivor's group / metric values come out of ONE packed
   // record (vh_table_pack) instead of one line per column arena. Only the compacting kernels gather by row; the lanes
   // kernels read whole column ranges and keep the arenas.
-  bool packed = false;
   {
     std::vector<int32_t> gcols;
     for (int i = 0; i < p->ngroups; ++i) gcols.push_back(p->groups[i].col);
@@ -1966,14 +2151,15 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     }
     VhPack* use = nullptr;
     if (want) {
+      // (compressed records are read by the per-query compiled kernels only)
       for (auto& pk : t->packs) {
-        bool all = true;
+        bool all = !pk->compressed || jit_try;
         for (int c : gcols) all &= pk->col_index(c) >= 0;
-        if (all && (!use || pk->rec_bytes < use->rec_bytes)) use = pk.get();
+        if (all && (!use || pk->rec_bytes < use->rec_bytes || (pk->rec_bytes == use->rec_bytes && pk->compressed && !use->compressed))) use = pk.get();
       }
       const int auto_after = knobs().auto_pack;   // 0: never build one unasked
       if (!use && (forced || auto_after > 0)) {
-        std::string sig;
+        std::string sig = jit_try ? "c:" : "p:";
         for (int c : gcols) sig += std::to_string(c) + ",";
         bool build = forced || ++t->gather_seen[sig] >= (uint32_t)auto_after;
         if (build && !forced) {        // room: the projection must leave a quarter of the device free and not outgrow the table
@@ -1984,12 +2170,21 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
           build = bytes <= 64 && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= t->device_bytes && free_b > need + total_b / 4;
           if (!build) t->gather_seen[sig] = 0;
         }
-        if (build && table_pack_locked(t, gcols.data(), (int32_t)gcols.size(), !forced, &use) != VH_OK) use = nullptr;
+        if (build && table_pack_locked(t, gcols.data(), (int32_t)gcols.size(), !forced, &use, jit_try && !knobs().pack_plain) != VH_OK) use = nullptr;
       }
     }
     if (use) {
       rc = pack_refresh(t, use, 0, nseg);   // on the table's main stream, complete when it returns
+      if (rc == VH_PACK_STALE) {            // a synced value outgrew its stored width: rebuilt at the widths the values need now
+        const bool was_auto = use->automatic;
+        pack_drop(t, use);
+        use = nullptr;
+        if (table_pack_locked(t, gcols.data(), (int32_t)gcols.size(), was_auto, &use, true) != VH_OK) use = nullptr;
+        rc = VH_OK;
+      }
       if (rc) { return rc; }
+    }
+    if (use) {
       int pslot_of[256];
       for (int i = 0; i < 256; ++i) pslot_of[i] = -1;
       auto pslot = [&](int col) {
@@ -1998,18 +2193,21 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         P.colbase[P.nslots] = use->base + use->off[k];
         P.colstride[P.nslots] = use->stride;
         P.colpitch[P.nslots] = use->rec_bytes;
-        slot_rec[P.nslots] = 0; slot_recoff[P.nslots] = (int)use->off[k];
+        slot_rec[P.nslots] = 0; slot_recoff[P.nslots] = (int)use->off[k]; slot_stored[P.nslots] = (int)use->width[k];
         return pslot_of[col] = P.nslots++;
       };
       for (int i = 0; i < p->ngroups; ++i) P.g[i].set_slot((uint16_t)pslot(p->groups[i].col));
       for (int j = 0; j < P.nmetric; ++j) if (metric_col[j] >= 0) P.m[j].set_slot((uint16_t)pslot(metric_col[j]));
       packed = true;
+      packed_compressed = use->compressed;
     }
   }
+  return VH_OK;
+}
 
+int QueryBuild::compile_kernel() {
+  int rc = VH_OK; (void)rc;
   // ---------------- the scan kernel compiled for this plan shape (vh_jit.hip), when there is to be one
-  VhJitKernel* jk = nullptr;
-  int jit_block = 256;
   if (jit_try && lanes) jit_try = false;          // the no-compaction kernels are pre-built only
   if (jit_try) {
     VhJitShape& js = jshape;
@@ -2038,7 +2236,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       const VhGroupDev& g = P.g[i];
       VhJitCol& c = js.g[i];
       c.slot = (int)g.slot(); c.type = (int)g.type(); c.pitch = (int)P.colpitch[g.slot()];
-      c.rec = slot_rec[g.slot()]; c.off = slot_recoff[g.slot()];
+      c.rec = slot_rec[g.slot()]; c.off = slot_recoff[g.slot()]; c.stored = slot_stored[g.slot()];
       c.sext = mode != VH_MODE_HASH;
       c.gran = (int)g.gran(); c.nroll = (int)g.nroll(); c.micro = (int)g.micro();
       c.key_word = (int)g.key_word(); c.key_shift = (int)g.key_shift();
@@ -2053,7 +2251,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
       if (c.bitset) js.bitset_j = j;
       c.type = (int)m.type(); c.sop = (int)m.sop(); c.tword = (int)m.tword(); c.tshift = (int)m.tshift();
       c.sext = vh_sop_sext((int)m.sop());
-      if (!c.rowid && !c.bitset) { c.slot = (int)m.slot(); c.pitch = (int)P.colpitch[m.slot()]; c.rec = slot_rec[m.slot()]; c.off = slot_recoff[m.slot()]; }
+      if (!c.rowid && !c.bitset) { c.slot = (int)m.slot(); c.pitch = (int)P.colpitch[m.slot()]; c.rec = slot_rec[m.slot()]; c.off = slot_recoff[m.slot()]; c.stored = slot_stored[m.slot()]; }
     }
     if (jit_try) {
       std::string jerr;
@@ -2066,11 +2264,44 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
         vh_plan p2 = *p;
         p2.flags |= VH_PLAN_NO_JIT;
         holder.reset();
+        done = true;
         return query_launch_locked(t, x, &p2, out, hash_capacity_override, force_hash, part_tuples_override, no_part, plan_only, summary_out, ag, device_rows, hp_passes_override, no_hpart);
       }
     }
   }
+  if (!jk && packed_compressed) {      // compressed records and no compiled kernel to read them after all: plan again for the pre-built ones
+    vh_plan p2 = *p;
+    p2.flags |= VH_PLAN_NO_JIT;
+    holder.reset();
+    done = true;
+    return query_launch_locked(t, x, &p2, out, hash_capacity_override, force_hash, part_tuples_override, no_part, plan_only, summary_out, ag, device_rows, hp_passes_override, no_hpart);
+  }
+  return VH_OK;
+}
 
+void QueryBuild::scan_dispatch(int grid_, int* occ) {
+  const size_t qb = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint32_t);
+  const size_t lds_ = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + qb;
+  hipStream_t s_ = x->stream();
+  if (jk) {
+    const size_t jl = ((mode == VH_MODE_DENSE_LDS || (mode == VH_MODE_HASH && !hpart)) ? lds_table : 0) + (size_t)(BLOCK / 64) * (VJ_QUEUE_CAP * sizeof(uint32_t) + (jshape.stage ? VH_STAGE_BYTES : 0));
+    if (occ) *occ = vh_jit_occupancy(jk, BLOCK, jl);
+    else (void)vh_jit_launch(jk, P, grid_, BLOCK, jl, s_);
+  }
+  else if (mode == VH_MODE_DENSE_PART) {
+    if (lanes) vh_launch_scan_lanes_part(P, grid_, 4 * vh_part_tile_bytes(P), s_, occ);
+    else vh_launch_scan_fast_part(P, grid_, qb, s_, occ);   // the compacting form appends straight to the extents: no tile in LDS
+  }
+  else if (!fast) { if (!occ) vh_launch_scan_generic(mode, P, grid_, lds_, nxcd > 1, s_); }
+  else if (lanes && mode == VH_MODE_HASH) vh_launch_scan_lanes_hash(P, grid_, lds_, s_, occ);
+  else if (lanes) vh_launch_scan_lanes_lds(P, BLOCK, grid_, lds_, nxcd > 1, s_, occ);
+  else if (mode == VH_MODE_DENSE_LDS) { if (!occ) vh_launch_scan_fast_lds(P, grid_, lds_, nxcd > 1, s_); }   // 1024-thread blocks: one per CU
+  else if (mode == VH_MODE_DENSE_GLOBAL) vh_launch_scan_fast_global(P, grid_, lds_, nxcd > 1, s_, occ);
+  else vh_launch_scan_fast_hash(P, grid_, lds_, s_, occ);
+}
+
+int QueryBuild::decompose_work() {
+  int rc = VH_OK; (void)rc;
   // ---------------- work decomposition
   // The lanes kernels expose the latency of their payload loads (issued and consumed inside a sub-step), so they gain
   // from every extra resident wave: 256-thread blocks, as many per CU as registers and LDS allow (asked of the runtime
@@ -2078,32 +2309,12 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   // variant pays for more blocks with more table merges at the end (blocks x groups x metrics global atomics), so
   // it keeps one 1024-thread block per CU unless the scan dwarfs that.
   const int env_lanes_block = knobs().lanes_block, env_bpc = knobs().blocks_per_cu, env_unit = knobs().unit_rows;
-  int BLOCK = jk ? jit_block : mode == VH_MODE_DENSE_LDS ? 1024 : 256;
+  BLOCK = jk ? jit_block : mode == VH_MODE_DENSE_LDS ? 1024 : 256;
   if (mode == VH_MODE_DENSE_LDS && lanes) {
     if (env_lanes_block == 256 || env_lanes_block == 512 || env_lanes_block == 1024) BLOCK = env_lanes_block;
     else if ((uint64_t)g_ctx.num_cu * 5 * G * std::max(1, P.nmetric) <= rows_to_scan / 32) BLOCK = 256;
   }
   // One place decides which scan kernel runs; with `occ` it only asks how many of its blocks fit a CU.
-  auto scan_dispatch = [&](int grid_, int* occ) {
-    const size_t qb = (size_t)(BLOCK / 64) * VhScanCfg<256>::kQueueCap * sizeof(uint32_t);
-    const size_t lds_ = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + qb;
-    hipStream_t s_ = x->stream();
-    if (jk) {
-      const size_t jl = ((mode == VH_MODE_DENSE_LDS || (mode == VH_MODE_HASH && !hpart)) ? lds_table : 0) + (size_t)(BLOCK / 64) * (VJ_QUEUE_CAP * sizeof(uint32_t) + (jshape.stage ? VH_STAGE_BYTES : 0));
-      if (occ) *occ = vh_jit_occupancy(jk, BLOCK, jl);
-      else (void)vh_jit_launch(jk, P, grid_, BLOCK, jl, s_);
-    }
-    else if (mode == VH_MODE_DENSE_PART) {
-      if (lanes) vh_launch_scan_lanes_part(P, grid_, 4 * vh_part_tile_bytes(P), s_, occ);
-      else vh_launch_scan_fast_part(P, grid_, qb, s_, occ);   // the compacting form appends straight to the extents: no tile in LDS
-    }
-    else if (!fast) { if (!occ) vh_launch_scan_generic(mode, P, grid_, lds_, nxcd > 1, s_); }
-    else if (lanes && mode == VH_MODE_HASH) vh_launch_scan_lanes_hash(P, grid_, lds_, s_, occ);
-    else if (lanes) vh_launch_scan_lanes_lds(P, BLOCK, grid_, lds_, nxcd > 1, s_, occ);
-    else if (mode == VH_MODE_DENSE_LDS) { if (!occ) vh_launch_scan_fast_lds(P, grid_, lds_, nxcd > 1, s_); }   // 1024-thread blocks: one per CU
-    else if (mode == VH_MODE_DENSE_GLOBAL) vh_launch_scan_fast_global(P, grid_, lds_, nxcd > 1, s_, occ);
-    else vh_launch_scan_fast_hash(P, grid_, lds_, s_, occ);
-  };
   {   // the kernel symbol(s) this query runs, as rocprofv3 prints them (vh_result_kernel: bench.py's roofline.kernel)
     const int np_ = std::max(1, (int)P.npred), scope = (mode == VH_MODE_DENSE_GLOBAL || mode == VH_MODE_DENSE_LDS) && nxcd > 1 ? (int)__HIP_MEMORY_SCOPE_WORKGROUP : (int)__HIP_MEMORY_SCOPE_AGENT;
     char nm[160];
@@ -2132,8 +2343,12 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   P.nseg = nseg;
   P.total_units = nseg * P.units_per_seg;
   const int env_grid = knobs().grid;
-  const int grid = env_grid > 0 ? env_grid : (int)std::max<uint64_t>(1, std::min<uint64_t>(P.total_units, (uint64_t)g_ctx.num_cu * blocks_per_cu));
+  grid = env_grid > 0 ? env_grid : (int)std::max<uint64_t>(1, std::min<uint64_t>(P.total_units, (uint64_t)g_ctx.num_cu * blocks_per_cu));
+  return VH_OK;
+}
 
+int QueryBuild::layout_scratch() {
+  int rc = VH_OK; (void)rc;
   // ---------------- scratch layout
   ScratchPlan sp;
   // [counters | out_count | output key arrays | output state arrays] is one region: it is read back with a
@@ -2148,13 +2363,12 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   r->out_region_bytes = sp.off - o_counters;
   for (int i = 0; i < P.ngroup; ++i) r->off_key[i] = o_okey[i] - o_counters;
   for (int j = 0; j < P.nmetric; ++j) r->off_state[j] = o_ostate[j] - o_counters;
-  const size_t o_segrows = sp.take(r->plan_words * sizeof(uint32_t));   // [segment snapshot | program | literals]
+  o_segrows = sp.take(r->plan_words * sizeof(uint32_t));   // [segment snapshot | program | literals]
   size_t o_present = 0, o_hkeys = 0, o_htags = 0;
   size_t o_state[VH_MAX_METRIC];
-  const uint64_t table_n = mode == VH_MODE_HASH ? capacity + 1 : P.xcd_stride * nxcd;
+  table_n = mode == VH_MODE_HASH ? capacity + 1 : P.xcd_stride * nxcd;
   // single-word keys: one record per slot = key + every metric state (8-byte states first), so that an insert and its
   // updates touch ONE line of a table that is far bigger than any cache
-  size_t rec_off[VH_MAX_METRIC] = {};
   // Only for tables far bigger than the caches: with few, hot groups three atomics on ONE line serialise more than on three
   // (C2 forced onto the hash table, 1 K groups: 1.75 ms with separate arrays, 2.21 ms with records).
   if (mode == VH_MODE_HASH && P.key_words == 1 && (hpart || ((capacity >= (1ull << 22) || (p->flags & VH_PLAN_FORCE_HASH_RECORDS)) && !(p->flags & VH_PLAN_NO_HASH_RECORDS)))) {
@@ -2175,10 +2389,10 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     o_present = sp.take(table_n);
   }
   // zero-identity states (every SUM) sit right behind the presence bytes: one memset clears them all
-  const size_t zero_begin = mode == VH_MODE_HASH ? sp.off : o_present;
+  zero_begin = mode == VH_MODE_HASH ? sp.off : o_present;
   if (P.hrec_bytes) { for (int j = 0; j < P.nmetric; ++j) o_state[j] = o_hkeys + rec_off[j]; }
   else for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident == 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop()));
-  const size_t zero_end = sp.off;
+  zero_end = sp.off;
   if (!P.hrec_bytes) for (int j = 0; j < P.nmetric; ++j) if (P.m[j].ident != 0) o_state[j] = sp.take(table_n * vh_sop_bytes(P.m[j].sop()));
   // device top-N: worth it only when the group table is big (small results are read back whole anyway)
   size_t o_tkkeys = 0, o_tkstate = 0, o_okey2[VH_MAX_GROUP] = {}, o_ostate2[VH_MAX_METRIC] = {};
@@ -2192,7 +2406,6 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   // outputs
   size_t o_tuples = 0, o_emiss = 0, o_epart = 0, o_tuples2 = 0, o_emiss2 = 0, o_epart2 = 0, o_l2 = 0;
   size_t o_tuplesB = 0, o_emissB = 0, o_epartB = 0, o_tuples2B = 0, o_emiss2B = 0, o_epart2B = 0, o_l2B = 0;
-  int split_bpp = 1;
   if (hpart) part_tuple_cap = hp_tuple_cap;
   if (mode == VH_MODE_DENSE_PART || hpart) {
     // extent size: big enough that a wave allocates rarely (every allocation is a returning global
@@ -2238,9 +2451,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     }
   }
   // hashed partitioning: per kind of tuple the two partitioned pools (vh_hpart.h), their fill / tag arrays and a block of small tables
-  struct HpOff { size_t ta = 0, fa = 0, ga = 0, tb = 0, fb = 0, gb = 0, meta = 0; uint64_t maxa = 0, maxb = 0; } hpo[2];
-  size_t o_hpargs = 0;
-  const size_t hp_meta_bytes = 8 + (size_t)HP_FAN * 4 + (size_t)(2 * HP_FAN + 2) * 4;      // [level-A cursor | tuples per digit | slices + their cursors]
+  hp_meta_bytes = 8 + (size_t)HP_FAN * 4 + (size_t)(2 * HP_FAN + 2) * 4;      // [level-A cursor | tuples per digit | slices + their cursors]
   if (hpart) {
     for (int k = 0; k < (hp_pair_cap ? 2 : 1); ++k) {
       const uint64_t cap = k ? hp_pair_cap : hp_tuple_cap;
@@ -2274,7 +2485,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   }
   rc = ensure_scratch(x, sp.off);
   if (rc) { return rc; }
-  char* S = x->scratch;
+  S = x->scratch;
   P.counters = reinterpret_cast<unsigned long long*>(S + o_counters);
   P.seg_rows = reinterpret_cast<const uint32_t*>(S + o_segrows);
   P.prog = reinterpret_cast<const VhProgOp*>(S + o_segrows + r->seg_words * 4);
@@ -2330,7 +2541,11 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     for (int i = 0; i < P.ngroup; ++i) r->d_out_key2[i] = S + o_okey2[i];
     for (int j = 0; j < P.nmetric; ++j) r->d_out_state2[j] = S + o_ostate2[j];
   }
+  return VH_OK;
+}
 
+int QueryBuild::launch() {
+  int rc = VH_OK; (void)rc;
   // ---------------- init + launch
   hipStream_t st = x->stream();
   HIP_TRY(hipEventRecord(x->ev[0], st));
@@ -2420,7 +2635,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   for (int k = 0; k < P.npred; ++k) narrowed |= P.pred_width[k] != 4;
   if (jk) { narrowed = false; for (int k = 0; k < jshape.npred; ++k) narrowed |= jshape.pred[k].width != vh_elem_size(jshape.pred[k].type); }
   r->hpart = hpart;
-  r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0);
+  r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0);
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
     if (hpart) vh_launch_hpart(P, d_hpargs, hp_pair_cap ? 2 : 1, g_ctx.num_cu, lds_table, hp_bpp, st);
@@ -2441,6 +2656,23 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
     HIP_TRY(hipGetLastError());
   }
   *out = holder.release();
+  done = true;
+  return VH_OK;
+}
+
+static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_result** out, uint64_t hash_capacity_override,
+                               bool force_hash, uint64_t part_tuples_override = 0, bool no_part = false,
+                               bool plan_only = false, VhSummary* summary_out = nullptr, const VhAgreed* ag = nullptr,
+                               bool device_rows = false, uint32_t hp_passes_override = 0, bool no_hpart = false) {
+  QueryBuild b(t, x, p, out, hash_capacity_override, force_hash, part_tuples_override, no_part, plan_only, summary_out, ag, device_rows,
+               hp_passes_override, no_hpart);
+  int (QueryBuild::* const steps[])() = {&QueryBuild::shape_filter, &QueryBuild::snapshot_segments, &QueryBuild::shape_groups, &QueryBuild::shape_metrics,
+                                         &QueryBuild::choose_organisation, &QueryBuild::plan_hashed_partitioning, &QueryBuild::choose_projection,
+                                         &QueryBuild::compile_kernel, &QueryBuild::decompose_work, &QueryBuild::layout_scratch, &QueryBuild::launch};
+  for (auto step : steps) {
+    if (int rc = (b.*step)()) return rc;
+    if (b.done) return VH_OK;
+  }
   return VH_OK;
 }
 

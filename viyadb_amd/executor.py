@@ -82,7 +82,8 @@ class AggResult:
     kernel: str = ""               # symbol(s) of the scan kernel(s) that ran, as rocprofv3 prints them
     narrow: bool = False           # predicate columns were streamed from 8- / 16-bit copies (vh_table_narrow)
     jit: bool = False              # a scan kernel compiled for this plan shape ran (viyadb_amd/csrc/vh_jit.hip)
-    hpart: bool = False            # hashed partitioning of the hash path ran (hash_part_agg_kernel)
+    hpart: bool = False            # hashed partitioning of the hash path ran (vh_hpart.h)
+    packed_compressed: bool = False  # ... from compressed records (integers stored at the width their values need)
 
 
 
@@ -161,10 +162,11 @@ class DeviceTable:
         f = lambda a: np.frombuffer(bytes(a), dtype=dt, count=1)[0]
         return f(lo), f(hi)
 
-    def pack(self, cols: Sequence[int]) -> None:
-        """Payload projection over `cols` (vh_table_pack): selective queries gather these columns from one record per row."""
+    def pack(self, cols: Sequence[int], compressed: Optional[bool] = None) -> None:
+        """Payload projection over `cols` (vh_table_pack): selective queries gather these columns from one record per row.
+        compressed: None = the library decides, False = plain records, True = integers at the width their values need."""
         arr = (C.c_int32 * len(cols))(*[int(c) for c in cols])
-        capi.check(self.lib.vh_table_pack(self.handle, arr, len(cols)))
+        capi.check(self.lib.vh_table_pack_ex(self.handle, arr, len(cols), 0 if compressed is None else 2 if compressed else 1))
 
     def unpack(self) -> None:
         capi.check(self.lib.vh_table_unpack(self.handle))
@@ -312,7 +314,7 @@ class DeviceTable:
                          int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
                          float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1),
                          bool(info.reserved & 2), bool(info.reserved & 8), int(ng), (self.lib.vh_result_kernel(res) or b"").decode(),
-                         bool(info.reserved & 16), bool(info.reserved & 32), bool(info.reserved & 64))
+                         bool(info.reserved & 16), bool(info.reserved & 32), bool(info.reserved & 64), bool(info.reserved & 128))
 
     def query_agg(self, plan: AggPlan, copy: bool = True) -> AggResult:
         p, keep = self._build_plan(plan)
