@@ -2,6 +2,7 @@
 # FETCH_SIZE / WRITE_SIZE against known byte counts (tools/experiments/fetch_calib.hip). usage (GPU box): bash tools/fetch_calib.sh <out.json>
 OUT=${1:-gpurun_out/fetch_calibration.json}
 export TMPDIR=/tmp; REPO=$PWD; D=$REPO/gpurun_out/calib; rm -rf $D; mkdir -p $D
+[ -x tools/experiments/fetch_calib ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/experiments/fetch_calib tools/experiments/fetch_calib.hip
 for C in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 300 rocprofv3 --pmc $C -d $D/$C -o c -- $REPO/tools/experiments/fetch_calib > $D/$C.log 2>&1)
 done

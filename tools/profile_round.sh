@@ -26,13 +26,19 @@ one() {   # name (workload[_variant]), rows, bref, bench args...
   case $W in *_*) J=$OUT/${W%%_*}_1gpu_pmc_hbm_${W#*_}.json;; esac
   python tools/pmc_summary.py $OUT/pmc_FETCH_SIZE_$W $OUT/pmc_WRITE_SIZE_$W $J --rows $ROWS --bref $BREF --kernel "$K" --head $HEAD --sources $SRC --packed $PK --narrow $NR \
     --command "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py $* --steps 3 --warmup 1 --no-cpu --no-check"
+  case $W in c3|c5)      # instruction mix of the kernels the line names (its own pass: SQ counters)
+    (cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -d $REPO/$OUT/pmc_insts_$W -o $W -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-check --no-reference-layout > $REPO/$OUT/pmc_insts_$W.log 2>&1)
+    { echo "# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -- python bench.py $* --steps 3 --warmup 1 --no-cpu --no-check (head $HEAD, sources $SRC): wave-level instructions per launch"
+      for KK in viya_jit part_agg hp_scatter hp_aggregate scan_agg; do python tools/pmc_kernel.py $OUT/pmc_insts_$W $KK; done; } > $OUT/${W}_1gpu_pmc_insts.txt;;
+  esac
 }
 one c3_arena 1000000000 32e9 --no-pack --no-cpu              # the reference layout: column arenas only (bench.py's reference_layout leg reads this pass)
-cp $OUT/c3_1gpu_pmc_hbm_arena.json profiles/$R/ 2>/dev/null    # (the headline run below looks for it under profiles/)
+mkdir -p profiles/$R; cp $OUT/c3_1gpu_pmc_hbm_arena.json profiles/$R/ 2>/dev/null    # (the headline run below looks for it under profiles/)
 FIRST_EXTRA="" one c3 1000000000 32e9
 one c3_direct 1000000000 32e9 --flags 16 --no-cpu             # the same query forced onto direct atomics (what a slower box or a smaller shard runs)
 one c2 100000000 2e9 --workload C2 --no-cpu
 one c5 125000000 3.5e9 --workload C5 --segments 125 --no-cpu --steps 5 --warmup 1
 one c5t 125000000 1.5e9 --workload C5t --segments 125 --no-cpu --steps 5 --warmup 1
-rm -rf $OUT/kt_* $OUT/pmc_FETCH_SIZE_* $OUT/pmc_WRITE_SIZE_*
+bash tools/fetch_calib.sh $OUT/fetch_calibration.json > $OUT/fetch_calibration.log 2>&1
+rm -rf $OUT/kt_* $OUT/pmc_FETCH_SIZE_* $OUT/pmc_WRITE_SIZE_* $OUT/pmc_insts_*
 ls $OUT

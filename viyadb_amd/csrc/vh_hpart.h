@@ -174,11 +174,12 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
     for (uint32_t li = 0; li < ntiles; ++li) {
       const uint32_t nvalid = valid;
       uint32_t dig[HP_ET / BLOCK];
+      uint32_t rank[HP_ET / BLOCK];       // the tuple's place among its digit's tuples: what the histogram's counter held when it was counted
       if (tid < HP_FAN) { S.hist[tid] = S.carry_n[tid]; S.cur[tid] = S.carry_n[tid]; }
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < HP_ET / BLOCK; ++r)
-        if ((uint32_t)(r * BLOCK + tid) < nvalid) { dig[r] = (uint32_t)(t[r].x >> shift) & (HP_FAN - 1u); atomicAdd(&S.hist[dig[r]], 1u); }
+        if ((uint32_t)(r * BLOCK + tid) < nvalid) { dig[r] = (uint32_t)(t[r].x >> shift) & (HP_FAN - 1u); rank[r] = atomicAdd(&S.hist[dig[r]], 1u); }
       __syncthreads();
       // exclusive prefix over the digits (waves 0..3: 64 digits each), whole lines, room, extents
       uint32_t incl = 0, h = 0;
@@ -218,11 +219,11 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < HP_ET / BLOCK; ++r)
-        if ((uint32_t)(r * BLOCK + tid) < nvalid) { const uint32_t at = S.offs[dig[r]] + atomicAdd(&S.cur[dig[r]], 1u); sorted[at] = t[r]; S.sdigit[at] = (uint8_t)dig[r]; }
+        if ((uint32_t)(r * BLOCK + tid) < nvalid) { const uint32_t at = S.offs[dig[r]] + rank[r]; sorted[at] = t[r]; S.sdigit[at] = (uint8_t)dig[r]; }
       // the next tile's loads travel while this one is written out
       if (li + 1 < ntiles) { valid = tile_total(li + 1); tile_load(li + 1, valid, t); }
       __syncthreads();
-      const uint32_t total = S.offs[HP_FAN - 1] + S.cur[HP_FAN - 1];
+      const uint32_t total = S.offs[HP_FAN - 1] + S.hist[HP_FAN - 1];
       hp_u64x2* const out = reinterpret_cast<hp_u64x2*>(dst.tuples);
       for (uint32_t k = tid; k < total; k += BLOCK) {
         const uint32_t d = S.sdigit[k], local = k - S.offs[d], whole = S.whole[d];
