@@ -303,9 +303,11 @@ def main():
         dist.destroy_process_group()
         return
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-    algo_bytes = last.algorithmic_bytes  # B_ref per launch on this rank: rows x referenced bytes/row
-    # B_min of SURVEY 8(d): filter columns in full + the other referenced columns for passing rows only
     rows_rank0 = my_segments * w.segment_rows
+    # B_ref per launch on this rank: rows x referenced bytes/row (the library counts fixed-width columns; a bitset metric's CSR offsets and
+    # ids — C5: 8 + 2 x 4 bytes per row — come from the workload's own figure)
+    algo_bytes = max(last.algorithmic_bytes, rows_rank0 * w.bytes_per_row_referenced)
+    # B_min of SURVEY 8(d): filter columns in full + the other referenced columns for passing rows only
     fcols = sorted({f[1] for f in w.plan.filter if f[0] in ("rel", "in")})
     fbytes = sum(capi.ELEM_SIZE[w.columns[c].elem] for c in fcols)
     b_min = rows_rank0 * fbytes + last.passed_recs * max(0, w.bytes_per_row_referenced - fbytes)
