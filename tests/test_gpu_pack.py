@@ -174,6 +174,8 @@ def test_library_builds_a_projection_for_a_repeated_selective_query():
 
 # ---- compressed records (round 3): integers at the width their values need, read by the per-query compiled kernels only
 JITPACK = capi.PLAN_FORCE_JIT | PACK
+from tests.conftest import JIT_OFF  # noqa: E402
+needs_jit = pytest.mark.skipif(JIT_OFF, reason="VH_JIT=off: compressed records are read by the per-query compiled kernels only")
 
 
 @pytest.fixture(scope="module")
@@ -184,6 +186,7 @@ def typedc():      # its own mirror: a plain projection that covers the same col
     dt.close()
 
 
+@needs_jit
 @pytest.mark.parametrize("flags,path", [(0, "dense_global"), (64, "dense_part"), (1, "hash"), (2, "dense_global"), (16 | 32, "dense_global")])
 def test_c3_through_compressed_records(flags, path):
     from viyadb_amd import synth
@@ -192,6 +195,7 @@ def test_c3_through_compressed_records(flags, path):
     assert res.packed and res.jit and res.packed_compressed
 
 
+@needs_jit
 @pytest.mark.parametrize("t", TYPES)
 @pytest.mark.parametrize("flags", [0, 1, 64])
 def test_every_type_as_compressed_metric(typedc, t, flags):
@@ -203,6 +207,7 @@ def test_every_type_as_compressed_metric(typedc, t, flags):
 
 @pytest.mark.parametrize("dims", [["d_byte", "d_float", "d_double"], ["d_ulong", "d_long"], ["s8", "s16", "s32", "flag", "d_short"],
                                   ["d_ubyte", "d_ushort", "id"], ["uts", "ts"], ["d_int", "d_short"]])
+@needs_jit
 @pytest.mark.parametrize("flags", [0, 1])
 def test_every_type_as_compressed_key(typedc, dims, flags):
     tab, dt = typedc
@@ -211,6 +216,7 @@ def test_every_type_as_compressed_key(typedc, dims, flags):
     assert res.packed and res.jit and res.packed_compressed
 
 
+@needs_jit
 def test_prebuilt_kernels_never_read_compressed_records(typedc):
     """The same columns, asked for by a plan the pre-built kernels run: a plain projection is built next to the compressed one."""
     tab, dt = typedc
@@ -220,6 +226,7 @@ def test_prebuilt_kernels_never_read_compressed_records(typedc):
     assert a.packed_compressed and b.packed and not b.packed_compressed and not b.jit
 
 
+@needs_jit
 def test_compressed_records_follow_syncs_and_outgrown_widths():
     """Values that fit one byte / two bytes when the projection is built; a later vh_segment_sync brings values that need more: the
     projection is void (pack_kernel notices while re-packing the segment) and is rebuilt wider before the query reads it."""

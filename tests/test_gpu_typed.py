@@ -109,7 +109,8 @@ def test_fast_kernel_is_taken_when_eligible(typed):
     assert dt.query_agg(plan_from_query(tab, aq, now=NOW, flags=capi.PLAN_NO_JIT)).fast is False
     res = dt.query_agg(plan_from_query(tab, aq, now=NOW, flags=capi.PLAN_FORCE_JIT))
     compare(res, vo.scan_aggregate(aq, now=NOW), "u64 predicate, compiled kernel")
-    assert res.fast and res.jit and res.kernel.startswith("viya_jit_scan_")
+    from tests.conftest import JIT_OFF
+    assert JIT_OFF or (res.fast and res.jit and res.kernel.startswith("viya_jit_scan_"))
 
 
 @pytest.mark.parametrize("t", [x for x in TYPES if x not in ("byte", "short")])
@@ -226,7 +227,8 @@ def test_two_level_partitioning():
                 res, _ = run(tab, dt, qq, flags=flags | capi.PLAN_NO_SHAPE | capi.PLAN_NO_JIT)
                 assert res.path == "dense_part" and "scan_agg_fast_kernel" in res.kernel, res.kernel
                 res, _ = run(tab, dt, qq, flags=flags | capi.PLAN_FORCE_JIT)
-                assert res.path == "dense_part" and res.jit and "viya_jit_scan_" in res.kernel and "part_split_" in res.kernel, res.kernel
+                from tests.conftest import JIT_OFF
+                assert res.path == "dense_part" and (res.jit or JIT_OFF) and ("viya_jit_scan_" in res.kernel or JIT_OFF) and "part_split_" in res.kernel, res.kernel
             res, _ = run(tab, dt, qq, flags=flags | capi.PLAN_NO_PART2)
             assert res.path == "dense_global"
         # the specialised drain's other forms: metrics in the other order, one group column, narrow unsigned keys elsewhere in the suite
