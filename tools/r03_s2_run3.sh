@@ -1,0 +1,8 @@
+#!/bin/bash
+mkdir -p gpurun_out/r03
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+( timeout 900 python -m pytest tests/test_gpu_jit.py tests/test_gpu_typed.py tests/test_gpu_fullsize.py -q -m gpu -x -k "hpart or hashed or c5 or bitset or distinct" ) > gpurun_out/r03/hp_tests.log 2>&1; tail -3 gpurun_out/r03/hp_tests.log
+D=gpurun_out/r03/kt_s3; rm -rf $D
+timeout 200 rocprofv3 --kernel-trace -d $D -o c5 -- python bench.py --workload C5 --segments 125 --steps 3 --warmup 2 --no-cpu --no-reference-layout > $D.log 2>&1
+python tools/last_query_kernels.py $D viya_jit | head -12; grep -o '"parity_checked": [a-z]*' $D.log | head -1
+VH_TRACE_ALLOC=1 python tools/scratch_probe.py 8 > gpurun_out/r03/scratch_probe.log 2> gpurun_out/r03/scratch_probe.err; cat gpurun_out/r03/scratch_probe.log

@@ -36,6 +36,9 @@ struct VhHpPool {             // extents of HP_ET 16-byte tuples
   uint16_t* fill;             // tuples in the extent; 0: never used. (The stream pools, written by the scan kernel, keep the older
   uint8_t* tag;               //  convention instead: fill = HP_ET - missing[e], tag 0xFF = never opened.)
   uint32_t max_extents;
+  uint32_t stride;            // tuples from one extent's first place to the next one's: HP_ET, or a line more (pools a, b: a block keeps an extent open
+                              // per digit and fills them at the same pace — 64 KB apart, its stores of the moment would agree in the address
+                              // bits that pick the HBM channel; VhPlanDev::ext_stride is the same remedy for DENSE_PART)
   uint32_t stream;            // 1: a stream pool (see above)
   unsigned long long* cursor; // extents handed out (stream pools: the scan kernel's allocation counter)
 };
@@ -66,6 +69,7 @@ static inline int vh_hpart_bpp(int num_cu, size_t agg_lds) {
 
 #ifdef VH_HPART_KERNELS        // (the kernels: vh_hpart.hip only; the host code of viya_hip.hip takes the descriptors above)
 typedef uint64_t hp_u64x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t hp_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t hp_pool_fill(const VhHpPool& Q, uint32_t e) {
   if (Q.stream) return Q.tag[e] == 0xFF ? 0u : (uint32_t)HP_ET - Q.fill[e];
@@ -82,8 +86,11 @@ __device__ __forceinline__ uint32_t hp_pool_used(const VhHpPool& Q) {
 struct HpScatterLds {
   uint32_t hist[HP_FAN], offs[HP_FAN], carry_n[HP_FAN], cur[HP_FAN];
   uint32_t ext_a[HP_FAN], fill_a[HP_FAN];                                                  // per digit: the open extent and the tuples already in it
-  uint32_t whole[HP_FAN], room[HP_FAN], wext[HP_FAN], wfill[HP_FAN], ext_b[HP_FAN], tail[HP_FAN];   // this tile: whole-line tuples of the run, room left in the open extent
-                                                                                            // (wext, from wfill), the fresh extent behind it, tuples that will wait
+  uint32_t tail[HP_FAN];                                                                   // this tile: tuples of the digit's run that will wait for the next one
+  // ... and what the write-out loop needs per tuple, in ONE 16-byte LDS read instead of six 4-byte ones (the kernel is bound by LDS
+  // instructions): x = first place of the run in `sorted` | whole-line tuples of the run << 16, y = room left in the open extent,
+  // z = tuple index of the open extent's next free place, w = tuple index of the fresh extent behind it MINUS room (wrapping)
+  alignas(16) uint32_t meta[HP_FAN][4];
   uint32_t wave_tot[4];
   uint32_t nlist, list[HP_LIST];
   uint32_t ntiles, alloc;
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
         if (k < total) {
           uint32_t i = S.tfirst[tile];
           while ((uint32_t)S.lpre[i] + S.lfill[i] <= k) ++i;
-          dstv[r] = __builtin_nontemporal_load(reinterpret_cast<const hp_u64x2*>(src.tuples) + (uint64_t)S.list[i] * HP_ET + (k - S.lpre[i]));
+          dstv[r] = __builtin_nontemporal_load(reinterpret_cast<const hp_u64x2*>(src.tuples) + (uint64_t)S.list[i] * src.stride + (k - S.lpre[i]));
         }
       }
     };
@@ -194,18 +201,19 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
       if (tid < HP_FAN) {
         uint32_t before = 0;
         for (int w = 0; w < wave; ++w) before += S.wave_tot[w];
-        S.offs[tid] = before + incl - h;
+        const uint32_t first = before + incl - h;
+        S.offs[tid] = first;
         uint32_t whole = h & ~7u;
-        S.whole[tid] = whole;
         uint32_t ea = S.ext_a[tid], fa = S.fill_a[tid], eb = ~0u;
         uint32_t room = ea == ~0u ? 0u : (uint32_t)HP_ET - fa;
         if (whole > room) {                          // the run needs a fresh extent behind what is left of the open one
           const uint32_t got = atomicAdd(dcur, 1u);
           if (dlo + got < dhi) { eb = dlo + got; dst.tag[eb] = (uint8_t)tid; }
-          else { full = true; S.whole[tid] = whole = room; }      // nowhere to put the rest: dropped, the attempt is void
+          else { full = true; whole = room; }        // nowhere to put the rest: dropped, the attempt is void
         }
-        S.room[tid] = room; S.ext_b[tid] = eb;
-        S.wext[tid] = ea; S.wfill[tid] = fa; S.tail[tid] = h - whole;
+        S.meta[tid][0] = first | (whole << 16); S.meta[tid][1] = room;
+        S.meta[tid][2] = ea * dst.stride + fa; S.meta[tid][3] = eb * dst.stride - room;      // (a pool holds < 2^32 tuples: 64 GB)
+        S.tail[tid] = h - whole;
         // after this tile: the open extent and its fill
         if (whole <= room) { S.fill_a[tid] = fa + whole; }
         else { if (ea != ~0u) dst.fill[ea] = (uint16_t)HP_ET; S.ext_a[tid] = eb; S.fill_a[tid] = whole - room; }
@@ -226,13 +234,12 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
       const uint32_t total = S.offs[HP_FAN - 1] + S.hist[HP_FAN - 1];
       hp_u64x2* const out = reinterpret_cast<hp_u64x2*>(dst.tuples);
       for (uint32_t k = tid; k < total; k += BLOCK) {
-        const uint32_t d = S.sdigit[k], local = k - S.offs[d], whole = S.whole[d];
+        const uint32_t d = S.sdigit[k];
+        const hp_u32x4 m = *reinterpret_cast<const hp_u32x4*>(S.meta[d]);
+        const uint32_t local = k - (m.x & 0xFFFFu), whole = m.x >> 16;
         const hp_u64x2 v = sorted[k];
-        if (local < whole) {
-          const uint32_t room = S.room[d];
-          if (local < room) out[(uint64_t)S.wext[d] * HP_ET + S.wfill[d] + local] = v;
-          else out[(uint64_t)S.ext_b[d] * HP_ET + (local - room)] = v;
-        } else if (local - whole < HP_CARRY) carry[d * HP_CARRY + (local - whole)] = v;
+        if (local < whole) out[(local < m.y ? m.z : m.w) + local] = v;
+        else if (local - whole < HP_CARRY) carry[d * HP_CARRY + (local - whole)] = v;
       }
       __syncthreads();
       if (tid < HP_FAN) S.carry_n[tid] = S.tail[tid] < HP_CARRY ? S.tail[tid] : 0u;     // (>= 8 only on a void attempt that ran out of extents)
@@ -251,7 +258,7 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
       }
       if (ea != ~0u) {
         hp_u64x2* const out = reinterpret_cast<hp_u64x2*>(dst.tuples);
-        for (uint32_t j = 0; j < n; ++j) out[(uint64_t)ea * HP_ET + fa + j] = carry[tid * HP_CARRY + j];
+        for (uint32_t j = 0; j < n; ++j) out[(uint64_t)ea * dst.stride + fa + j] = carry[tid * HP_CARRY + j];
         fa += n;
       }
     }
@@ -338,6 +345,7 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
   const bool pairs = nkind > 1 && bitset_j >= 0;
   const int sub_bits = 31 - __builtin_clz((uint32_t)passes | 1u);
   const uint32_t stride_w = P.hrec_bytes / 8u;
+  const uint32_t es[2] = {HA->k[0].b.stride, HA->k[nkind > 1 ? 1 : 0].b.stride};
   const hp_u64x2* const pool[2] = {reinterpret_cast<const hp_u64x2*>(HA->k[0].b.tuples), reinterpret_cast<const hp_u64x2*>(HA->k[nkind > 1 ? 1 : 0].b.tuples)};
   // ---- which extent of slice a holds which range: ONE look at the slice's tags for all the block's ranges
   for (int i = tid; i < 2 * HP_FAN; i += BLOCK) S.ext1[i / HP_FAN][i % HP_FAN] = ~0u;
@@ -366,11 +374,11 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
     if (b >= HP_FAN) return;
     const uint32_t e0 = S.ext1[0][b], f0 = e0 == ~0u ? 0u : S.fill1[0][b];
 #pragma unroll
-    for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f0) g[u] = pool[0][(uint64_t)e0 * HP_ET + u * BLOCK + tid];
+    for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f0) g[u] = pool[0][(uint64_t)e0 * es[0] + u * BLOCK + tid];
     if (pairs) {
       const uint32_t e1 = S.ext1[1][b], f1 = e1 == ~0u ? 0u : S.fill1[1][b];
 #pragma unroll
-      for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f1) q[u] = pool[1][(uint64_t)e1 * HP_ET + u * BLOCK + tid];
+      for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f1) q[u] = pool[1][(uint64_t)e1 * es[1] + u * BLOCK + tid];
     }
   };
   prefetch(j0, ng, np);
@@ -417,10 +425,10 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
         }
       };
 #pragma unroll
-      for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f0) group_tuple(pass == 0 ? cg[u] : pool[0][(uint64_t)e0 * HP_ET + u * BLOCK + tid]);
-      for (uint32_t i = U * BLOCK + tid; i < f0; i += BLOCK) group_tuple(pool[0][(uint64_t)e0 * HP_ET + i]);       // (a first extent of more than 1024 tuples)
+      for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f0) group_tuple(pass == 0 ? cg[u] : pool[0][(uint64_t)e0 * es[0] + u * BLOCK + tid]);
+      for (uint32_t i = U * BLOCK + tid; i < f0; i += BLOCK) group_tuple(pool[0][(uint64_t)e0 * es[0] + i]);       // (a first extent of more than 1024 tuples)
       for (uint32_t x = 0; x < novf; ++x)
-        if (S.ovf_key[x] == (uint16_t)b) for (uint32_t i = tid; i < S.ovf_fill[x]; i += BLOCK) group_tuple(pool[0][(uint64_t)S.ovf_ext[x] * HP_ET + i]);
+        if (S.ovf_key[x] == (uint16_t)b) for (uint32_t i = tid; i < S.ovf_fill[x]; i += BLOCK) group_tuple(pool[0][(uint64_t)S.ovf_ext[x] * es[0] + i]);
       __syncthreads();
       // ---- pair tuples: (mixed key, two ids; an odd id count repeats the last one)
       if (pairs && !(abl & 1)) {
@@ -447,10 +455,10 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
           }
         };
 #pragma unroll
-        for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f1) pair_tuple(pass == 0 ? cp[u] : pool[1][(uint64_t)e1 * HP_ET + u * BLOCK + tid]);
-        for (uint32_t i = U * BLOCK + tid; i < f1; i += BLOCK) pair_tuple(pool[1][(uint64_t)e1 * HP_ET + i]);
+        for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f1) pair_tuple(pass == 0 ? cp[u] : pool[1][(uint64_t)e1 * es[1] + u * BLOCK + tid]);
+        for (uint32_t i = U * BLOCK + tid; i < f1; i += BLOCK) pair_tuple(pool[1][(uint64_t)e1 * es[1] + i]);
         for (uint32_t x = 0; x < novf; ++x)
-          if (S.ovf_key[x] == (uint16_t)(0x100 | b)) for (uint32_t i = tid; i < S.ovf_fill[x]; i += BLOCK) pair_tuple(pool[1][(uint64_t)S.ovf_ext[x] * HP_ET + i]);
+          if (S.ovf_key[x] == (uint16_t)(0x100 | b)) for (uint32_t i = tid; i < S.ovf_fill[x]; i += BLOCK) pair_tuple(pool[1][(uint64_t)S.ovf_ext[x] * es[1] + i]);
         __syncthreads();
       }
       if (__ballot(bad)) { if (lane == 0) S.bad = 1; }

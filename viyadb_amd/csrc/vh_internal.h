@@ -22,6 +22,7 @@
 #define VH_MAX_HAVING_LITS 24
 #define VH_MAX_XCD 8
 #define VH_KEY_WORDS 8    // widest group key: 8 x u64
+#define VH_BS_PAD 16      // bytes kept readable behind a segment's bitset ids: the compiled kernels fetch a row's first two ids with ONE 8-byte load
 #define VH_MAX_BITSET 2   // bitset (count-distinct) metrics per query
 #define VH_MAX_PRED 4     // fast path: distinct 4-byte predicate columns held in registers
 #ifndef VH_FAST_COLS
@@ -200,6 +201,10 @@ struct VhPlanDev {
   int32_t agg_shift;         // groups per LDS table of phase 2 = 1 << agg_shift (one level: == part_shift)
   int32_t nfine;             // LDS-sized ranges phase 2 aggregates (one level: == npart)
   int32_t ext_tuples2;       // pool 2: tuples per extent
+  int32_t ext_stride;        // pool 1: tuples from one extent's first place to the next one's — ext_tuples, or ext_tuples + 8 (one more 128-byte
+                             // line of two-word tuples): the waves of phase 1 open their extents together and fill them at the same
+                             // pace, so with extents a power of two apart every wave's stores of the moment agree in the address bits that
+                             // pick the HBM channel (profiles/r03/NOTES.md, "Where the tuple pool lands")
   uint64_t* tuples;          // max_extents x ext_tuples x tw words
   uint16_t* extent_missing;  // [max_extents] tuples NOT filled in an extent (0 = full)
   uint8_t* extent_part;      // [max_extents] partition an extent belongs to (0xFF: never opened). A plain store when the extent is

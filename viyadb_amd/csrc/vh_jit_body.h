@@ -25,6 +25,14 @@
 #ifndef VJ_NT_GATHER
 #define VJ_NT_GATHER 0     // 1: a survivor's record is fetched with non-temporal loads
 #endif
+typedef uint64_t vj_u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+typedef uint32_t vj_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+// (a pointer that was itself loaded from memory is "generic" to the compiler and gets flat_load, which waits on the LDS counter too;
+// the bitset arrays are device allocations: say so)
+#define VJ_GLOBAL(T, p) ((const T __attribute__((address_space(1)))*)(p))
+#ifndef VJ_BS_MERGE
+#define VJ_BS_MERGE 1      // 0 (measurement): a row's offsets and first two ids with four scalar-width loads, as before
+#endif
 template <typename T> __device__ __forceinline__ T vj_gload(const T* p) {
   if (VJ_NT_GATHER) return __builtin_nontemporal_load(p);
   return *p;
@@ -95,10 +103,18 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
   if constexpr (MODE == VH_MODE_HASH && J::HPART && J::BITSET_J >= 0 && !(VJ_ABL & 4)) {
     const int b = (int)P.m[J::BITSET_J].slot();
     if (active) {
-      const uint64_t* offs = P.bs_offs[b][seg];
-      bk = offs[row]; bk1 = offs[row + 1];
+      // offsets[row], offsets[row + 1] in ONE 16-byte load (8-byte aligned), the first two ids in ONE 8-byte load (4-byte aligned; what lies
+      // behind a segment's last id is readable: VH_BS_PAD): two address-processor passes per survivor instead of four
       bids = reinterpret_cast<const uint32_t*>(P.bs_vals[b][seg]);
-      if (bk < bk1) { bid0 = bids[bk]; bid1 = bk + 1 < bk1 ? bids[bk + 1] : bid0; }      // an odd count repeats the last id: a set does not mind
+      if (VJ_BS_MERGE) {
+        const vj_u64x2_a8 o = *VJ_GLOBAL(vj_u64x2_a8, P.bs_offs[b][seg] + row);
+        bk = o.x; bk1 = o.y;
+        if (bk < bk1) { const vj_u32x2_a4 i2 = *VJ_GLOBAL(vj_u32x2_a4, bids + bk); bid0 = i2.x; bid1 = bk + 1 < bk1 ? i2.y : bid0; }      // an odd count repeats the last id: a set does not mind
+      } else {
+        const uint64_t* offs = P.bs_offs[b][seg];
+        bk = offs[row]; bk1 = offs[row + 1];
+        if (bk < bk1) { bid0 = bids[bk]; bid1 = bk + 1 < bk1 ? bids[bk + 1] : bid0; }
+      }
     }
   }
   vj_rollup_all<J>(P, gv);
@@ -154,7 +170,10 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
         else if (w2[1] == 0x123456789ABCDEFull) P.counters[7] = 1;
         bk += 2;
         more = bk < bk1;
-        if (more) { bid0 = bids[bk]; bid1 = bk + 1 < bk1 ? bids[bk + 1] : bid0; }
+        if (more) {
+          if (VJ_BS_MERGE) { const vj_u32x2_a4 i2 = *VJ_GLOBAL(vj_u32x2_a4, bids + bk); bid0 = i2.x; bid1 = bk + 1 < bk1 ? i2.y : bid0; }
+          else { bid0 = bids[bk]; bid1 = bk + 1 < bk1 ? bids[bk + 1] : bid0; }
+        }
       }
     }
     return;

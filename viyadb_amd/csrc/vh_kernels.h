@@ -836,6 +836,7 @@ template <int LEVEL> __device__ __forceinline__ uint64_t* vh_pool_tuples(const V
 template <int LEVEL> __device__ __forceinline__ uint16_t* vh_pool_missing(const VhPlanDev& P) { return LEVEL == 1 ? P.extent_missing : LEVEL == 2 ? P.extent_missing2 : LEVEL == 3 ? P.extent_missingB : P.extent_missing2B; }
 template <int LEVEL> __device__ __forceinline__ uint8_t* vh_pool_tags(const VhPlanDev& P) { return LEVEL == 1 ? P.extent_part : LEVEL == 2 ? P.extent_part2 : LEVEL == 3 ? P.extent_partB : P.extent_part2B; }
 template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_et(const VhPlanDev& P) { return (uint32_t)((LEVEL & 1) ? P.ext_tuples : P.ext_tuples2); }
+template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_es(const VhPlanDev& P) { return LEVEL == 1 ? (uint32_t)P.ext_stride : vh_pool_et<LEVEL>(P); }   // tuples between extent starts
 template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_npart(const VhPlanDev& P) { return (LEVEL & 1) ? (uint32_t)P.npart : 64u; }
 // the pools as run-time values (plan / split / aggregation kernels take `which`: 0 = the tuples, 1 = the pair tuples)
 struct VhPools {
@@ -941,7 +942,7 @@ __device__ __forceinline__ void vh_part_tile_runs(const VhPlanDev& P, VhPartTile
     if (lane == p) { T.r_ext = ext; T.r_fill = 0; }
   }
   // lane p holds (extent, fill, base, count) of partition p, the loop is wave-uniform over the partitions present in this tile
-  const uint64_t mydst = T.r_ext == ~0u ? ~0ull : (uint64_t)T.r_ext * et + T.r_fill;
+  const uint64_t mydst = T.r_ext == ~0u ? ~0ull : (uint64_t)T.r_ext * vh_pool_es<LEVEL>(P) + T.r_fill;
   if (T.r_ext != ~0u) T.r_fill += cnt;
   uint64_t runs = __ballot(cnt != 0);
   __builtin_amdgcn_wave_barrier();
@@ -1000,7 +1001,7 @@ __device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTil
   const uint32_t pe = (uint32_t)__shfl((int)T.r_ext, (int)(active ? p : 0u)), pf = (uint32_t)__shfl((int)T.r_fill, (int)(active ? p : 0u));
   if (T.r_ext != ~0u) T.r_fill += cnt;
   if (active && pe != ~0u) {                 // ~0: tuple buffer exhausted, the host re-runs (VH_ERR_PART_FULL)
-    uint64_t* d = vh_pool_tuples<LEVEL>(P) + ((uint64_t)pe * et + pf + rank) * tw;
+    uint64_t* d = vh_pool_tuples<LEVEL>(P) + ((uint64_t)pe * vh_pool_es<LEVEL>(P) + pf + rank) * tw;
     if (VH_ABLATE & 4) { if (words[0] == 0x123456789ABCDEFull) d[0] = 1; }   // measurement build: everything but the tuple store
     else if (tw == 2) {
       typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
@@ -1039,13 +1040,13 @@ __device__ __forceinline__ void vh_part_stage_close(const VhPlanDev& P, VhPartTi
   const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, q), fill = __builtin_amdgcn_readlane(T.r_fill, q), st = __builtin_amdgcn_readlane(S.r_stage, q);
   if (old == ~0u) return;
   const uint32_t et = (uint32_t)P.ext_tuples;
-  if ((uint32_t)lane < st) reinterpret_cast<vh_u64x2*>(P.tuples)[(uint64_t)old * et + fill + lane] = reinterpret_cast<const vh_u64x2*>(S.lines)[q * 8 + lane];
+  if ((uint32_t)lane < st) reinterpret_cast<vh_u64x2*>(P.tuples)[(uint64_t)old * (uint32_t)P.ext_stride + fill + lane] = reinterpret_cast<const vh_u64x2*>(S.lines)[q * 8 + lane];
   if (lane == 0) P.extent_missing[old] = (uint16_t)(et - (fill + st));
 }
 
 __device__ __forceinline__ void vh_part_staged_add(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, VhPartStage& S, bool active,
                                                    const uint64_t (&words)[2], uint32_t p, int lane) {
-  const uint32_t npart = (uint32_t)P.npart, et = (uint32_t)P.ext_tuples;
+  const uint32_t npart = (uint32_t)P.npart, et = (uint32_t)P.ext_tuples, es = (uint32_t)P.ext_stride;
   const uint64_t act = __ballot(active);
   uint64_t peers = act, mine = act;
 #pragma unroll
@@ -1085,13 +1086,13 @@ __device__ __forceinline__ void vh_part_staged_add(const VhPlanDev& P, VhPartTil
     const uint32_t qg = qk & 0xFFFFu, qf = (qk >> 16) & 0xFFu, qc = qk >> 24;
     if (q < npart && qe != ~0u && qc != 0 && qf + qc >= 8u) {
       const vh_u64x2 a = lines[q * 8u + part4 * 2u], b2 = lines[q * 8u + part4 * 2u + 1u];
-      vh_u64x2* d = pool + (uint64_t)qe * et + qg + part4 * 2u;
+      vh_u64x2* d = pool + (uint64_t)qe * es + qg + part4 * 2u;
       d[0] = a; d[1] = b2;
     }
   }
   __builtin_amdgcn_wave_barrier();
   if (ok && i >= 8u) {
-    if (i < whole) pool[(uint64_t)pe * et + g + i] = v;                        // a whole line in the middle of the run: eight consecutive ranks, one store instruction
+    if (i < whole) pool[(uint64_t)pe * es + g + i] = v;                        // a whole line in the middle of the run: eight consecutive ranks, one store instruction
     else lines[p * 8u + (i - whole)] = v;                                      // the remainder waits for the next drain
   }
   if (T.r_ext != ~0u) { const uint32_t tot = S.r_stage + cnt; T.r_fill += tot & ~7u; S.r_stage = tot & 7u; }
@@ -1866,7 +1867,7 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
   const uint8_t* tags = two ? P.extent_part2 : P.extent_part;
   const uint16_t* missing = two ? P.extent_missing2 : P.extent_missing;
   const uint64_t* pool = two ? P.tuples2 : P.tuples;
-  const uint32_t ext_tuples = (uint32_t)(two ? P.ext_tuples2 : P.ext_tuples);
+  const uint32_t ext_tuples = (uint32_t)(two ? P.ext_tuples2 : P.ext_tuples), ext_stride = (uint32_t)(two ? P.ext_tuples2 : P.ext_stride);
   const uint32_t tw = (uint32_t)P.tw;
   // the waves of this range's blocks share the tag array `gsz` extents at a time (64, or fewer when there are not enough extents
   // to go round: phase 1 writes few, large extents when few rows survive); a tag that equals `want` is an extent to aggregate
@@ -1904,7 +1905,7 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
         at = 0;
       }
       if (at < valid) {
-        sbase[u] = pool + ((uint64_t)ext * ext_tuples + at) * tw;
+        sbase[u] = pool + ((uint64_t)ext * ext_stride + at) * tw;
         sn[u] = valid - at < 64u ? valid - at : 64u;
         at += 64u;
       } else { sbase[u] = pool; sn[u] = 0; }
@@ -2046,7 +2047,7 @@ __global__ __launch_bounds__(BLOCK) void part_split_kernel(const VhPlanDev P, in
       const uint32_t ext = c0 + (uint32_t)__builtin_ctzll(mine);
       mine &= mine - 1;
       const uint32_t valid = ext_tuples - P.extent_missing[ext];
-      const uint64_t* base = P.tuples + (uint64_t)ext * ext_tuples * tw;
+      const uint64_t* base = P.tuples + (uint64_t)ext * (uint32_t)P.ext_stride * tw;
       for (uint32_t i0 = 0; i0 < valid; i0 += 128) {
         uint64_t w[2][1 + VH_FAST_COLS];
 #pragma unroll
@@ -2100,7 +2101,7 @@ __global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev 
   W.base = Q.l2[part]; W.limit = Q.l2[part + 1]; W.cursor = Q.l2 + VH_L2_NEXT + part;
   const uint32_t total = Q.allocated1 < Q.max1 ? (uint32_t)Q.allocated1 : Q.max1;
   const int gshift = P.gid_shift;      // where the 32-bit partition key sits in word 0
-  const uint32_t ext_tuples = (uint32_t)P.ext_tuples, et2 = (uint32_t)P.ext_tuples2;
+  const uint32_t ext_tuples = (uint32_t)P.ext_tuples, et2 = (uint32_t)P.ext_tuples2, ext_stride1 = WHICH == 0 ? (uint32_t)P.ext_stride : ext_tuples;
   u64x2* const pool2 = reinterpret_cast<u64x2*>(Q.t2);
   const uint32_t gsz = vh_tag_group(total, (uint32_t)blocks_per_part);
   for (uint32_t c0 = (uint32_t)b * gsz; c0 < total; c0 += (uint32_t)blocks_per_part * gsz) {
@@ -2109,7 +2110,7 @@ __global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev 
       const uint32_t ext = c0 + (uint32_t)__builtin_ctzll(mine);
       mine &= mine - 1;
       const uint32_t valid = ext_tuples - Q.miss1[ext];
-      const u64x2* base = reinterpret_cast<const u64x2*>(Q.t1) + (uint64_t)ext * ext_tuples;
+      const u64x2* base = reinterpret_cast<const u64x2*>(Q.t1) + (uint64_t)ext * ext_stride1;
       for (uint32_t i0 = 0; i0 < valid; i0 += VH_SPLIT_TILE_TUPLES) {
         u64x2 t[R];
         uint32_t sub[R];

@@ -64,7 +64,7 @@ static std::mutex g_mu;
 // at their (cold) sites.
 struct VhKnobs {
   bool trace_alloc, no_topk, no_stage, jit_verbose, skip_phase2, no_direct_emit, times;
-  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, split_bpc, bw_blocks_per_cu;
+  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, split_bpc, bw_blocks_per_cu;
   double hp_load_g, hp_load_s;
 };
 static const VhKnobs& knobs() {
@@ -79,7 +79,7 @@ static const VhKnobs& knobs() {
     x.auto_narrow = num("VH_AUTO_NARROW", 3); x.auto_pack = num("VH_AUTO_PACK", 3);
     x.jit_ablate = num("VH_JIT_ABLATE", 0); x.hp_ablate = num("VH_HP_ABLATE", 0); x.hp_bpp = num("VH_HP_BPP", 0); x.pack_plain = num("VH_PACK_PLAIN", 0);
     x.lanes_block = num("VH_LANES_BLOCK", 0); x.blocks_per_cu = num("VH_BLOCKS_PER_CU", 0); x.unit_rows = num("VH_UNIT_ROWS", 0); x.grid = num("VH_GRID", 0);
-    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
+    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
     x.hp_load_g = real("VH_HP_LOAD_G", 0.7); x.hp_load_s = real("VH_HP_LOAD_S", 0.7);
     return x;
   }();
@@ -478,7 +478,7 @@ extern "C" int vh_segment_sync_bitset(vh_table* t, uint32_t seg, int32_t col, ui
   const uint64_t nvals = offsets[nrows];
   const size_t vsz = c.elem == VH_BITSET32 ? 4 : 8;
   HIP_TRY(hipMalloc((void**)&c.bs_offsets[seg], (nrows + 1) * sizeof(uint64_t)));
-  HIP_TRY(hipMalloc((void**)&c.bs_values[seg], std::max<size_t>(nvals * vsz, 8)));
+  HIP_TRY(hipMalloc((void**)&c.bs_values[seg], nvals * vsz + VH_BS_PAD));
   HIP_TRY(hipMemcpy(c.bs_offsets[seg], offsets, (nrows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
   if (nvals) HIP_TRY(hipMemcpy(c.bs_values[seg], values, nvals * vsz, hipMemcpyHostToDevice));
   c.bs_nvalues[seg] = nvals;
@@ -502,7 +502,7 @@ extern "C" int vh_segment_sync_ids_device(vh_table* t, uint32_t seg, int32_t col
   if (c.bs_values[seg]) { HIP_TRY(hipFree(c.bs_values[seg])); c.bs_values[seg] = nullptr; }
   const size_t vsz = c.elem == VH_BITSET32 ? 4 : 8;
   HIP_TRY(hipMalloc((void**)&c.bs_offsets[seg], (nrows + 1) * sizeof(uint64_t)));
-  HIP_TRY(hipMalloc((void**)&c.bs_values[seg], std::max<size_t>(nrows * vsz, 8)));
+  HIP_TRY(hipMalloc((void**)&c.bs_values[seg], nrows * vsz + VH_BS_PAD));
   hipLaunchKernelGGL(iota_kernel, dim3((unsigned)std::min<uint64_t>((nrows + 256) / 256, 65535)), dim3(256), 0, g_ctx.stream,
                      c.bs_offsets[seg], nrows + 1);
   HIP_TRY(hipGetLastError());
@@ -535,7 +535,7 @@ extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nse
         if (c.bs_offsets[seg]) { HIP_TRY(hipFree(c.bs_offsets[seg])); c.bs_offsets[seg] = nullptr; }
         if (c.bs_values[seg]) { HIP_TRY(hipFree(c.bs_values[seg])); c.bs_values[seg] = nullptr; }
         HIP_TRY(hipMalloc((void**)&c.bs_offsets[seg], (rows_per_seg + 1) * sizeof(uint64_t)));
-        HIP_TRY(hipMalloc((void**)&c.bs_values[seg], std::max<size_t>(rows_per_seg * k * vsz, 8)));
+        HIP_TRY(hipMalloc((void**)&c.bs_values[seg], rows_per_seg * k * vsz + VH_BS_PAD));
         const unsigned grid = (unsigned)std::min<uint64_t>(512, (rows_per_seg + 256) / 256);
         const uint64_t rb = row_base + (uint64_t)sgi * rows_per_seg;
         if (vsz == 4) gen_csr_kernel<uint32_t><<<grid, 256, 0, g_ctx.stream>>>(c.bs_offsets[seg], (uint32_t*)c.bs_values[seg], rows_per_seg, k, rb, specs[i].mod, colseed);
@@ -2332,7 +2332,12 @@ int QueryBuild::decompose_work() {
   const uint64_t padded = (t->segment_rows + step - 1) / step * step;
   // all blocks co-resident (the compacting kernels need ~100-130 VGPRs: 4 waves/SIMD), units small enough
   // that the static round-robin leaves < 2 % imbalance
-  const int blocks_per_cu = env_bpc > 0 ? env_bpc : occupancy > 0 ? std::min(occupancy, 8) : (BLOCK == 1024 ? 1 : 4);
+  // The compiled kernels that WRITE tuples (DENSE_PART phase 1, hashed partitioning) run best with fewer resident waves than their
+  // 56-69 VGPRs allow: every wave keeps a line or an extent open per partition, and what eight blocks per CU keep open no longer
+  // stays in L2 until it is complete (profiles/r03/NOTES.md, "Blocks per CU": a 125 M-row C3 shard 0.44 -> 0.39 ms with 3 instead of
+  // 6, C5's scan 1.95 -> 1.6 ms with 4 instead of 8, and the scatter behind it finds fewer half-empty extents)
+  const int occ_cap = jk && mode == VH_MODE_DENSE_PART ? 3 : jk && hpart ? 4 : 8;
+  const int blocks_per_cu = env_bpc > 0 ? env_bpc : occupancy > 0 ? std::min(occupancy, occ_cap) : (BLOCK == 1024 ? 1 : 4);
   uint32_t unit_rows = step;
   const uint64_t want_units = (uint64_t)g_ctx.num_cu * blocks_per_cu * 64;
   while (unit_rows * 2 <= 65536 && unit_rows * 2 <= padded &&
@@ -2417,11 +2422,15 @@ int QueryBuild::layout_scratch() {
     if (hpart) et = HP_ET;             // (the tiles of hp_scatter_kernel are whole source extents)
     const uint64_t ext_tuples = et;
     P.ext_tuples = (int32_t)ext_tuples;
+    // extents of pool 1 start one 128-byte line further apart than they are long (not the stream pools of the hashed partitioning, whose
+    // reader takes extents as whole tiles): see VhPlanDev::ext_stride
+    const uint64_t ext_stride = hpart ? ext_tuples : ext_tuples + (uint64_t)knobs().ext_pad;
+    P.ext_stride = (int32_t)ext_stride;
     uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
     if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
     if (!part_tuples_override && getenv("VH_TEST_PART_EXTENTS")) max_ext = std::max(1, atoi(getenv("VH_TEST_PART_EXTENTS")));   // tests: make the first attempt run out of extents
     P.max_extents = (uint32_t)max_ext;
-    o_tuples = sp.take(max_ext * ext_tuples * P.tw * 8);
+    o_tuples = sp.take(max_ext * ext_stride * P.tw * 8);
     o_emiss = sp.take(max_ext * sizeof(uint16_t));
     o_epart = sp.take(max_ext);
     if (P.nlevel == 2) {
@@ -2460,8 +2469,8 @@ int QueryBuild::layout_scratch() {
       uint64_t mb = cap / HP_ET + (uint64_t)HP_FAN * (2 * HP_FAN + 9) + 64;
       if (!part_tuples_override && getenv("VH_TEST_PART_EXTENTS2")) mb = std::max(1, atoi(getenv("VH_TEST_PART_EXTENTS2")));   // tests: the last pool runs out
       hpo[k].maxa = ma; hpo[k].maxb = mb;
-      hpo[k].ta = sp.take(ma * HP_ET * 16); hpo[k].fa = sp.take(ma * 2); hpo[k].ga = sp.take(ma);
-      hpo[k].tb = sp.take(mb * HP_ET * 16); hpo[k].fb = sp.take(mb * 2); hpo[k].gb = sp.take(mb);
+      hpo[k].ta = sp.take(ma * (HP_ET + (uint64_t)knobs().ext_pad) * 16); hpo[k].fa = sp.take(ma * 2); hpo[k].ga = sp.take(ma);
+      hpo[k].tb = sp.take(mb * (HP_ET + (uint64_t)knobs().ext_pad) * 16); hpo[k].fb = sp.take(mb * 2); hpo[k].gb = sp.take(mb);
       hpo[k].meta = sp.take(hp_meta_bytes);
     }
     o_hpargs = sp.take(sizeof(VhHpArgs));
@@ -2595,7 +2604,8 @@ int QueryBuild::launch() {
       VhHpKind& K = HA.k[k];
       char* meta = S + hpo[k].meta;
       K.z.tuples = k ? P.tuplesB : P.tuples; K.z.fill = k ? P.extent_missingB : P.extent_missing; K.z.tag = k ? P.extent_partB : P.extent_part;
-      K.z.max_extents = k ? P.max_extentsB : P.max_extents; K.z.stream = 1; K.z.cursor = P.counters + (k ? 8 : 5);
+      K.z.max_extents = k ? P.max_extentsB : P.max_extents; K.z.stream = 1; K.z.cursor = P.counters + (k ? 8 : 5); K.z.stride = HP_ET;
+      K.a.stride = K.b.stride = HP_ET + (uint32_t)knobs().ext_pad;
       K.a.tuples = reinterpret_cast<uint64_t*>(S + hpo[k].ta); K.a.fill = reinterpret_cast<uint16_t*>(S + hpo[k].fa); K.a.tag = reinterpret_cast<uint8_t*>(S + hpo[k].ga);
       K.a.max_extents = (uint32_t)std::min<uint64_t>(hpo[k].maxa, 0xFFFFFFF0ull); K.a.cursor = nullptr;      // (handed out in one slab per block of level A)
       K.b.tuples = reinterpret_cast<uint64_t*>(S + hpo[k].tb); K.b.fill = reinterpret_cast<uint16_t*>(S + hpo[k].fb); K.b.tag = reinterpret_cast<uint8_t*>(S + hpo[k].gb);
