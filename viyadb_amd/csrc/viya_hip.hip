@@ -64,7 +64,7 @@ static std::mutex g_mu;
 // at their (cold) sites.
 struct VhKnobs {
   bool trace_alloc, no_topk, no_stage, jit_verbose, skip_phase2, no_direct_emit, times;
-  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, split_bpc, bw_blocks_per_cu;
+  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, split_bpc, bw_blocks_per_cu, place_trials;
   double hp_load_g, hp_load_s;
 };
 static const VhKnobs& knobs() {
@@ -79,7 +79,7 @@ static const VhKnobs& knobs() {
     x.auto_narrow = num("VH_AUTO_NARROW", 3); x.auto_pack = num("VH_AUTO_PACK", 3);
     x.jit_ablate = num("VH_JIT_ABLATE", 0); x.hp_ablate = num("VH_HP_ABLATE", 0); x.hp_bpp = num("VH_HP_BPP", 0); x.pack_plain = num("VH_PACK_PLAIN", 0);
     x.lanes_block = num("VH_LANES_BLOCK", 0); x.blocks_per_cu = num("VH_BLOCKS_PER_CU", 0); x.unit_rows = num("VH_UNIT_ROWS", 0); x.grid = num("VH_GRID", 0);
-    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
+    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.place_trials = num("VH_PLACE_TRIALS", 8); x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
     x.hp_load_g = real("VH_HP_LOAD_G", 0.7); x.hp_load_s = real("VH_HP_LOAD_S", 0.7);
     return x;
   }();
@@ -325,12 +325,81 @@ extern "C" void vh_table_destroy(vh_table* t) {
   delete t;
 }
 
-static int ensure_scratch(VhExec* x, size_t bytes) {
+// What a partitioning query reads while it appends tuples, and where in its scratch the tuple pool will lie: enough to try a scratch
+// buffer out before the query depends on it.
+struct VhPlaceHint {
+  const void* stream_src[4] = {nullptr, nullptr, nullptr, nullptr}; size_t stream_bytes[4] = {0, 0, 0, 0}; int nstream = 0;     // the predicate columns (arenas or narrow copies) ...
+  const void* gather_src = nullptr; size_t gather_bytes = 0;     // ... and where the survivors' values come from (projection or arena)
+  size_t pool_off = 0, pool_bytes = 0;                           // the first tuple pool inside the scratch layout
+};
+
+// Where a tuple pool lands decides 10 % of a partitioning scan (C3: 2.05 vs 2.35 ms, reproducibly for as long as the buffer lives;
+// profiles/r03/NOTES.md "Where the tuple pool lands"). What was learned about it: it is not the allocation call (hipMalloc of any size,
+// or a 4 GiB-aligned VMM mapping, land in either class alike), not the extent geometry, and it does not show in stores alone or in streams
+// and gathers alone — only when whole-line stores to the buffer are MIXED with the table's read streams, i.e. it is how the pool's
+// physical pages relate to the pages being read (consecutive allocations share a class over tens of GB; the mapping of physical
+// addresses to HBM stacks / ranks is not visible from here). So the library measures: when a context needs a new scratch buffer for
+// a tuple pool of >= 256 MB, it allocates a few candidates spread over the free memory (spacers in between, at most three quarters of
+// what is free, everything but the winner released again), runs the access mix of a partitioning scan in miniature against THIS query's
+// own columns on each (place_probe_kernel: ~1 ms per run) and keeps the fastest. One-off per context and size, like a kernel compile.
+static int place_scratch(VhExec* x, size_t nb, const VhPlaceHint& h) {
+  const int trials = knobs().place_trials;
+  size_t free_b = 0, total_b = 0;
+  if (trials < 2 || h.pool_bytes < ((size_t)256 << 20) || h.nstream < 1 || h.stream_bytes[0] < ((size_t)64 << 20) || !h.gather_src || h.gather_bytes < ((size_t)64 << 20) ||
+      hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b / 4 * 3 < 2 * nb) return 1;      // (1: not tried, the caller allocates plainly)
+  const size_t budget = free_b / 4 * 3;
+  const int k = (int)std::min<size_t>((size_t)trials, budget / nb);
+  const size_t spacer = std::min<size_t>((budget - (size_t)k * nb) / (size_t)k, (size_t)24 << 30);
+  std::vector<void*> cand, spacers;
+  for (int i = 0; i < k; ++i) {
+    void* c = nullptr;
+    if (hipMalloc(&c, nb) != hipSuccess) { (void)hipGetLastError(); break; }
+    cand.push_back(c);
+    void* sp = nullptr;
+    if (i + 1 < k && spacer >= ((size_t)64 << 20)) { if (hipMalloc(&sp, spacer) == hipSuccess) spacers.push_back(sp); else (void)hipGetLastError(); }
+  }
+  hipStream_t st = x->stream();
+  VhPlaceArgs A{};
+  {   // longest stream first; at most 3 GB each (the probe runs ~1 ms)
+    int order[4] = {0, 1, 2, 3};
+    std::sort(order, order + h.nstream, [&](int a, int b) { return h.stream_bytes[a] > h.stream_bytes[b]; });
+    A.nsrc = h.nstream;
+    for (int s = 0; s < h.nstream; ++s) {
+      A.src[s] = reinterpret_cast<const vh_u32x4*>(h.stream_src[order[s]]);
+      A.n16[s] = std::min<size_t>(h.stream_bytes[order[s]], (size_t)3 << 30) / 4096 * 256;
+    }
+  }
+  A.rec = reinterpret_cast<const uint64_t*>(h.gather_src); A.nrec = (uint64_t)h.gather_bytes / 8;
+  A.lines = std::min<size_t>(h.pool_bytes, (size_t)1 << 30) / 128;
+  int best = -1; float best_ms = 0;
+  for (size_t i = 0; i < cand.size(); ++i) {
+    float ms = 1e9f;
+    A.dst = reinterpret_cast<vh_u32x4*>(static_cast<char*>(cand[i]) + (h.pool_off + 127) / 128 * 128);
+    A.sink = reinterpret_cast<unsigned long long*>(cand[i]);
+    for (int rep = 0; rep < 4; ++rep) {
+      (void)hipEventRecord(x->ev[0], st);
+      hipLaunchKernelGGL(place_probe_kernel, dim3((unsigned)g_ctx.num_cu * 8), dim3(256), 0, st, A);
+      (void)hipEventRecord(x->ev[1], st);
+      float m = 0;
+      if (hipEventSynchronize(x->ev[1]) != hipSuccess || hipEventElapsedTime(&m, x->ev[0], x->ev[1]) != hipSuccess) { (void)hipGetLastError(); m = 1e9f; }
+      if (rep && m < ms) ms = m;
+    }
+    if (knobs().trace_alloc) fprintf(stderr, "vh alloc scratch candidate %zu %p %.3f ms\n", i, cand[i], ms);
+    if (best < 0 || ms < best_ms) { best = (int)i; best_ms = ms; }
+  }
+  for (void* sp : spacers) (void)hipFree(sp);
+  for (size_t i = 0; i < cand.size(); ++i) if ((int)i != best) (void)hipFree(cand[i]);
+  if (best < 0) return 1;
+  x->scratch = static_cast<char*>(cand[best]);
+  return VH_OK;
+}
+
+static int ensure_scratch(VhExec* x, size_t bytes, const VhPlaceHint* hint = nullptr) {
   if (bytes <= x->scratch_bytes) return VH_OK;
   HIP_TRY(hipStreamSynchronize(x->stream()));
   if (x->scratch) { HIP_TRY(hipFree(x->scratch)); x->scratch = nullptr; x->scratch_bytes = 0; }
   size_t nb = std::max(bytes + bytes / 4, (size_t)1 << 20);
-  HIP_TRY(hipMalloc(&x->scratch, nb));
+  if (!hint || place_scratch(x, nb, *hint) != VH_OK) HIP_TRY(hipMalloc(&x->scratch, nb));
   trace_alloc("scratch", x->scratch, nb);
   x->scratch_bytes = nb;
   if (getenv("VH_POISON")) {   // tests: nothing may depend on what fresh scratch holds
@@ -2492,7 +2561,18 @@ int QueryBuild::layout_scratch() {
       o_dkeys[b] = sp.take(cap * 8);
     }
   }
-  rc = ensure_scratch(x, sp.off);
+  {
+    VhPlaceHint ph;        // (only looked at when the scratch buffer has to be allocated anew)
+    if ((mode == VH_MODE_DENSE_PART || hpart) && P.nslots > 0) {
+      const int gs = P.ngroup > 0 ? (int)P.g[0].slot() : 0;
+      for (int q = 0; q < P.npred && q < 4; ++q) { const int ps = (int)P.pred_slot[q]; ph.stream_src[q] = P.colbase[ps]; ph.stream_bytes[q] = (size_t)nseg * P.colstride[ps]; ph.nstream = q + 1; }
+      if (!ph.nstream) { ph.stream_src[0] = P.colbase[gs]; ph.stream_bytes[0] = (size_t)nseg * P.colstride[gs]; ph.nstream = 1; }
+      ph.gather_src = P.colbase[gs]; ph.gather_bytes = (size_t)nseg * P.colstride[gs];
+      ph.gather_bytes -= std::min<size_t>(ph.gather_bytes, 256);      // (a projection's column starts inside its first record)
+      ph.pool_off = o_tuples; ph.pool_bytes = (size_t)P.max_extents * (size_t)P.ext_stride * P.tw * 8;
+    }
+    rc = ensure_scratch(x, sp.off, &ph);
+  }
   if (rc) { return rc; }
   S = x->scratch;
   P.counters = reinterpret_cast<unsigned long long*>(S + o_counters);
