@@ -64,7 +64,7 @@ static std::mutex g_mu;
 // at their (cold) sites.
 struct VhKnobs {
   bool trace_alloc, no_topk, no_stage, jit_verbose, skip_phase2, no_direct_emit, times;
-  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, split_bpc, bw_blocks_per_cu, place_trials;
+  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, split_bpc, bw_blocks_per_cu, place_trials, place_gb;
   double hp_load_g, hp_load_s;
 };
 static const VhKnobs& knobs() {
@@ -79,7 +79,7 @@ static const VhKnobs& knobs() {
     x.auto_narrow = num("VH_AUTO_NARROW", 3); x.auto_pack = num("VH_AUTO_PACK", 3);
     x.jit_ablate = num("VH_JIT_ABLATE", 0); x.hp_ablate = num("VH_HP_ABLATE", 0); x.hp_bpp = num("VH_HP_BPP", 0); x.pack_plain = num("VH_PACK_PLAIN", 0);
     x.lanes_block = num("VH_LANES_BLOCK", 0); x.blocks_per_cu = num("VH_BLOCKS_PER_CU", 0); x.unit_rows = num("VH_UNIT_ROWS", 0); x.grid = num("VH_GRID", 0);
-    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.place_trials = num("VH_PLACE_TRIALS", 8); x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
+    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.place_trials = num("VH_PLACE_TRIALS", 12); x.place_gb = std::max(1, num("VH_PLACE_GB", 96)); x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
     x.hp_load_g = real("VH_HP_LOAD_G", 0.7); x.hp_load_s = real("VH_HP_LOAD_S", 0.7);
     return x;
   }();
@@ -339,25 +339,21 @@ struct VhPlaceHint {
 // and gathers alone — only when whole-line stores to the buffer are MIXED with the table's read streams, i.e. it is how the pool's
 // physical pages relate to the pages being read (consecutive allocations share a class over tens of GB; the mapping of physical
 // addresses to HBM stacks / ranks is not visible from here). So the library measures: when a context needs a new scratch buffer for
-// a tuple pool of >= 256 MB, it allocates a few candidates spread over the free memory (spacers in between, at most three quarters of
-// what is free, everything but the winner released again), runs the access mix of a partitioning scan in miniature against THIS query's
+// a tuple pool of >= 256 MB, it allocates candidates one after the other, each pushed away from the last by a 6 GB spacer (at most VH_PLACE_TRIALS = 12 of them,
+// three quarters of what is free and VH_PLACE_GB = 96 GB; everything but the winner released again), runs the access mix of a partitioning scan in miniature against THIS query's
 // own columns on each (place_probe_kernel: ~1 ms per run) and keeps the fastest. One-off per context and size, like a kernel compile.
+static std::mutex g_place_mu;      // one trial at a time: while it runs, most of the free memory is held (for some tens of milliseconds)
 static int place_scratch(VhExec* x, size_t nb, const VhPlaceHint& h) {
   const int trials = knobs().place_trials;
+  std::lock_guard<std::mutex> lk(g_place_mu);
+  const auto t_begin = std::chrono::steady_clock::now();
   size_t free_b = 0, total_b = 0;
   if (trials < 2 || h.pool_bytes < ((size_t)256 << 20) || h.nstream < 1 || h.stream_bytes[0] < ((size_t)64 << 20) || !h.gather_src || h.gather_bytes < ((size_t)64 << 20) ||
       hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b / 4 * 3 < 2 * nb) return 1;      // (1: not tried, the caller allocates plainly)
-  const size_t budget = free_b / 4 * 3;
-  const int k = (int)std::min<size_t>((size_t)trials, budget / nb);
-  const size_t spacer = std::min<size_t>((budget - (size_t)k * nb) / (size_t)k, (size_t)24 << 30);
-  std::vector<void*> cand, spacers;
-  for (int i = 0; i < k; ++i) {
-    void* c = nullptr;
-    if (hipMalloc(&c, nb) != hipSuccess) { (void)hipGetLastError(); break; }
-    cand.push_back(c);
-    void* sp = nullptr;
-    if (i + 1 < k && spacer >= ((size_t)64 << 20)) { if (hipMalloc(&sp, spacer) == hipSuccess) spacers.push_back(sp); else (void)hipGetLastError(); }
-  }
+  // (the driver clears memory another process left dirty when it is handed out again, at ~35 GB/s: the search stops early and is bounded,
+  // so that it stays a 0.3-2.5 s one-off — about a kernel compile — and tens of milliseconds on a clean device)
+  const size_t budget = std::min<size_t>(free_b / 4 * 3, (size_t)knobs().place_gb << 30);
+  const size_t spacer = (size_t)6 << 30;          // classes last for tens of GB: candidates ~9 GB apart sample them
   hipStream_t st = x->stream();
   VhPlaceArgs A{};
   {   // longest stream first; at most 3 GB each (the probe runs ~1 ms)
@@ -371,11 +367,18 @@ static int place_scratch(VhExec* x, size_t nb, const VhPlaceHint& h) {
   }
   A.rec = reinterpret_cast<const uint64_t*>(h.gather_src); A.nrec = (uint64_t)h.gather_bytes / 8;
   A.lines = std::min<size_t>(h.pool_bytes, (size_t)1 << 30) / 128;
-  int best = -1; float best_ms = 0;
-  for (size_t i = 0; i < cand.size(); ++i) {
+  // One candidate at a time, each behind a spacer that pushes it away from the last; the search stops once it has seen four candidates and
+  // holds one that beats the slowest seen by 5.5 % (both classes seen, a fast one in hand), or when the trials / the memory bound are used up.
+  std::vector<void*> cand, spacers;
+  int best = -1; float best_ms = 0, worst_ms = 0;
+  size_t held = 0;
+  for (int i = 0; i < trials && held + nb <= budget; ++i) {
+    void* c = nullptr;
+    if (hipMalloc(&c, nb) != hipSuccess) { (void)hipGetLastError(); break; }
+    cand.push_back(c); held += nb;
     float ms = 1e9f;
-    A.dst = reinterpret_cast<vh_u32x4*>(static_cast<char*>(cand[i]) + (h.pool_off + 127) / 128 * 128);
-    A.sink = reinterpret_cast<unsigned long long*>(cand[i]);
+    A.dst = reinterpret_cast<vh_u32x4*>(static_cast<char*>(c) + (h.pool_off + 127) / 128 * 128);
+    A.sink = reinterpret_cast<unsigned long long*>(c);
     for (int rep = 0; rep < 4; ++rep) {
       (void)hipEventRecord(x->ev[0], st);
       hipLaunchKernelGGL(place_probe_kernel, dim3((unsigned)g_ctx.num_cu * 8), dim3(256), 0, st, A);
@@ -384,13 +387,19 @@ static int place_scratch(VhExec* x, size_t nb, const VhPlaceHint& h) {
       if (hipEventSynchronize(x->ev[1]) != hipSuccess || hipEventElapsedTime(&m, x->ev[0], x->ev[1]) != hipSuccess) { (void)hipGetLastError(); m = 1e9f; }
       if (rep && m < ms) ms = m;
     }
-    if (knobs().trace_alloc) fprintf(stderr, "vh alloc scratch candidate %zu %p %.3f ms\n", i, cand[i], ms);
-    if (best < 0 || ms < best_ms) { best = (int)i; best_ms = ms; }
+    if (knobs().trace_alloc) fprintf(stderr, "vh alloc scratch candidate %d %p %.3f ms\n", i, c, ms);
+    if (best < 0 || ms < best_ms) { best = i; best_ms = ms; }
+    if (ms < 1e8f && ms > worst_ms) worst_ms = ms;
+    if (i >= 3 && best_ms * 1.055f <= worst_ms) break;
+    void* sp = nullptr;
+    if (i + 1 < trials && held + spacer + nb <= budget) { if (hipMalloc(&sp, spacer) == hipSuccess) { spacers.push_back(sp); held += spacer; } else (void)hipGetLastError(); }
   }
   for (void* sp : spacers) (void)hipFree(sp);
   for (size_t i = 0; i < cand.size(); ++i) if ((int)i != best) (void)hipFree(cand[i]);
   if (best < 0) return 1;
   x->scratch = static_cast<char*>(cand[best]);
+  if (knobs().trace_alloc) fprintf(stderr, "vh alloc scratch trial: %zu candidates of %zu bytes, %zu spacers of %zu, kept %d (%.3f ms), %.1f ms in all\n", cand.size(), nb, spacers.size(), spacer,
+                                   best, best_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
   return VH_OK;
 }
 
