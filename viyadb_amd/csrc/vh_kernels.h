@@ -1834,6 +1834,9 @@ __device__ __forceinline__ uint32_t vh_tag_group(uint32_t extents, uint32_t wave
 // global table (one update per present group and block; plain stores when the block is the range's only one).
 // One level: range f = partition f of pool 1. Two levels: range f = sub-partition f & 63 of partition f >> 6, whose
 // extents are the ones tagged (f & 63) inside that partition's slice of pool 2.
+#ifndef VH_P2_SLOTS
+#define VH_P2_SLOTS 4      // 64-tuple slots a wave of phase 2 has in flight
+#endif
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int blocks_per_part) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -1885,7 +1888,7 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
   const uint32_t gsz = vh_tag_group(total - first, (uint32_t)blocks_per_part * nwaves);
   // Per step a wave looks at gsz tags AND the fill of those extents (one vector load each, side by side: a dependent scalar load
   // per extent was a serial memory round trip — phase 1 leaves ~80 K extents of ~600 tuples on C3), then walks the extents that
-  // are its partition's as ONE stream of 64-tuple slots, four slots in flight whatever extent they come from.
+  // are its partition's as ONE stream of 64-tuple slots, VH_P2_SLOTS slots in flight whatever extent they come from.
   for (uint32_t c0 = first + ((uint32_t)b * nwaves + wave) * gsz; c0 < total; c0 += (uint32_t)blocks_per_part * nwaves * gsz) {
    const bool in = (uint32_t)lane < gsz && c0 + lane < total;
    const uint8_t tag = in ? tags[c0 + lane] : (uint8_t)0xFF;
@@ -1893,10 +1896,10 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
    uint64_t mine = __ballot(in && tag == want && fill != 0);
    uint32_t ext = 0, valid = 0, at = 0;            // the extent being walked (wave-uniform)
    while (mine || at < valid) {
-    const uint64_t* sbase[4];
-    uint32_t sn[4];
+    const uint64_t* sbase[VH_P2_SLOTS];
+    uint32_t sn[VH_P2_SLOTS];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < VH_P2_SLOTS; ++u) {
       if (at >= valid && mine) {
         const int q = __builtin_ctzll(mine);
         mine &= mine - 1;
@@ -1910,9 +1913,9 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
         at += 64u;
       } else { sbase[u] = pool; sn[u] = 0; }
     }
-    uint64_t w[4][1 + VH_FAST_COLS];
+    uint64_t w[VH_P2_SLOTS][1 + VH_FAST_COLS];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < VH_P2_SLOTS; ++u) {
 #pragma unroll
       for (int x = 0; x < 1 + VH_FAST_COLS; ++x)
         w[u][x] = ((uint32_t)lane < sn[u] && (uint32_t)x < tw) ? ((VH_ABLATE & 32) ? (x == 0 ? g0 + ((at * 2654435761u + lane * 40503u + u * 977u) & (gpp - 1)) : 1ull)   // measurement build: no tuple loads
@@ -1921,13 +1924,13 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
     if (VH_ABLATE & 16) {        // measurement build: tuple loads only
       uint64_t acc = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) acc += w[u][0] + w[u][1];
+      for (int u = 0; u < VH_P2_SLOTS; ++u) acc += w[u][0] + w[u][1];
       if (acc == 0x123456789ABCDEFull) P.counters[7] = acc;
       continue;
     }
     if (sum_pair) {       // the common shape, without the per-tuple walk over the plan's metric descriptors (550 -> ~60 instructions per 256 tuples)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < VH_P2_SLOTS; ++u) {
         const uint64_t w0 = w[u][0], local = (w0 & 0xFFFFFFFFull) - g0;
         if (w0 == ~0ull || local >= ng) continue;
         __hip_atomic_fetch_add(sum64 + local, (unsigned long long)w[u][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1940,7 +1943,7 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
       continue;
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < VH_P2_SLOTS; ++u) {
       const uint64_t local = (w[u][0] & 0xFFFFFFFFull) - g0;
       if (w[u][0] == ~0ull || local >= ng) continue;  // an empty slot; (a corrupt tuple cannot write outside the table)
       if (!carried) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[local] = 1;
