@@ -8,27 +8,31 @@
 // group key until one partition's groups fit LDS, then aggregate there with LDS atomics only. Sequential traffic of 16 bytes per
 // tuple and level instead of a 128-byte line read and written per update.
 //
-//   scan kernel (compiled per plan, vh_jit_body.h): a survivor becomes a 16-byte TUPLE (mixed key, payload word) — the mixed key is a
-//     bijection of the packed 64-bit group key (vh_splitmix64 / vh_unmix64), so equal keys always travel together and no key is ever
-//     compared through a lossy hash — and, per two ids of its bitset metric, a PAIR TUPLE (mixed key, two ids). Both are appended,
-//     unpartitioned, 1 KiB per wave store, to extents of 4096 tuples (the "stream" pools).
-//   hp_scatter_kernel, twice: a block takes a source extent (<= 4096 tuples) as a tile, sorts it by 8 bits of the mixed key in LDS
+//   scan kernel (compiled per plan, vh_jit_body.h): a survivor becomes a TUPLE. Without a bitset metric: 16 bytes, (mixed key, payload
+//     word) — the mixed key is a bijection of the packed 64-bit group key (vh_splitmix64 / vh_unmix64), so equal keys always travel
+//     together and no key is ever compared through a lossy hash. With one: 32 bytes, (mixed key, payload, two ids, how many of them
+//     count | "ids only"); a row with more than two ids sends further "ids only" tuples of the same key. ONE stream, one trip through
+//     the scatter levels and one insert per row in the aggregation (round 3 first sent the ids as a second stream of 16-byte pair
+//     tuples: twice the tuples to count, sort and look up for the same bytes). Appended, unpartitioned, 1-2 KiB per wave store, to
+//     64 KB extents (the "stream" pool).
+//   hp_scatter_kernel, twice: a block takes source extents (64 KB of tuples) as a tile, sorts it by 8 bits of the mixed key in LDS
 //     (histogram, prefix, scatter) and appends each digit's run to the digit's open extent in the destination pool IN WHOLE 128-BYTE
-//     LINES: a run's tail of < 8 tuples waits in LDS for the next tile (round 3 measured partial-line tuple writes at 2.3x the cost of
+//     LINES: a run's tail of less than a line waits in LDS for the next tile (round 3 measured partial-line tuple writes at 2.3x the cost of
 //     whole lines). Level A: stream -> 256 partitions by bits 63..56. Level B: partition a -> 256 ranges by bits 55..48, into slice a
 //     of the destination pool (sized on the device from what level A produced), so that the last kernel finds a range's extents by
 //     looking at a few hundred tags.
 //   hp_aggregate_kernel: 65 536 ranges of (at C5's size) ~550 groups. A block per range: tuples -> open-addressing table in LDS (keys
-//     = mixed keys, 64-bit LDS compare-and-swap; states as in every other LDS table), pair tuples -> (group slot, id) set in LDS, first
+//     = mixed keys, 64-bit LDS compare-and-swap; states as in every other LDS table), their ids -> (group slot, id) set in LDS, first
 //     sight bumping the group's cardinality; the range's groups leave as records (original key = vh_unmix64, states) for a compact list
 //     in HBM that the ordinary emission kernel reads (VhEmitArgs::n_dev). No global atomics except one list cursor per block and range.
 //     Ranges whose groups would not fit the tables are worked through in `passes` sub-ranges (the next bits of the mixed key).
 #pragma once
 #include "vh_kernels.h"
 
-#define HP_ET 4096            // tuples per extent (64 KB): a tile's run of one digit fits what is left of an extent plus one fresh extent
+#define HP_ET 4096            // 16-byte units per extent (64 KB): 4096 plain tuples or 2048 tuples that carry ids; a tile's run of one digit fits
+                              // what is left of an extent plus one fresh extent
 #define HP_FAN 256            // partitions per level
-#define HP_CARRY 8            // LDS slots per digit for the run tail that waits for the next tile (< 8 tuples ever wait)
+#define HP_CARRY 8            // 16-byte units of LDS per digit for the run tail that waits for the next tile (less than a 128-byte line ever waits)
 #define HP_LIST 1024          // source extents a block remembers at a time
 
 struct VhHpPool {             // extents of HP_ET 16-byte tuples
@@ -42,21 +46,21 @@ struct VhHpPool {             // extents of HP_ET 16-byte tuples
   uint32_t stream;            // 1: a stream pool (see above)
   unsigned long long* cursor; // extents handed out (stream pools: the scan kernel's allocation counter)
 };
-struct VhHpKind {             // the three pools of one kind of tuple
+struct VhHpKind {             // the three pools of the tuples
   VhHpPool z, a, b;
   uint32_t* slice;            // [HP_FAN + 1] first extent of partition a's slice of pool b; [HP_FAN + 1 + a]: extents handed out of it
   uint32_t* count;            // [HP_FAN] tuples per level-A digit (hp_count_kernel)
 };
 struct VhHpArgs {
-  VhHpKind k[2];              // 0: tuples, 1: pair tuples
-  int32_t nkind;              // 1 or 2
+  VhHpKind k[1];
+  int32_t units;              // 16-byte units per tuple: 1, or 2 when the tuples carry the ids of a bitset metric
   int32_t passes;             // hp_aggregate_kernel: sub-ranges per range (power of two)
   int32_t gslots, sslots;     // its LDS tables: group slots (+ 1), (group slot, id) set slots (0: no bitset metric)
   uint32_t keys_off, set_off; // LDS byte offsets (metric states at VhPlanDev::m[j].lds_off)
   int32_t bitset_j;
   uint32_t chunk;             // group records a block of hp_aggregate_kernel takes from the list at a time
   uint64_t list_cap;          // records the group list holds (+ one reserved record behind them)
-  int32_t ablate;             // measurement only (VH_HP_ABLATE; results are wrong): 1 no pair tuples, 2 no records written, 4 no tuples either, 8 no table clears
+  int32_t ablate;             // measurement only (VH_HP_ABLATE; results are wrong): 1 no id inserts, 2 no records written, 4 no tuples either, 8 no table clears
 };
 // blocks hp_aggregate_kernel runs per level-A partition: enough to fill every CU's LDS twice over (a divisor of HP_FAN)
 static inline int vh_hpart_bpp(int num_cu, size_t agg_lds) {
@@ -71,8 +75,8 @@ static inline int vh_hpart_bpp(int num_cu, size_t agg_lds) {
 typedef uint64_t hp_u64x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t hp_u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ uint32_t hp_pool_fill(const VhHpPool& Q, uint32_t e) {
-  if (Q.stream) return Q.tag[e] == 0xFF ? 0u : (uint32_t)HP_ET - Q.fill[e];
+__device__ __forceinline__ uint32_t hp_pool_fill(const VhHpPool& Q, uint32_t e, uint32_t et) {      // et: tuples per extent
+  if (Q.stream) return Q.tag[e] == 0xFF ? 0u : et - Q.fill[e];
   return Q.fill[e];
 }
 __device__ __forceinline__ uint32_t hp_pool_used(const VhHpPool& Q) {
@@ -83,6 +87,14 @@ __device__ __forceinline__ uint32_t hp_pool_used(const VhHpPool& Q) {
 
 // ------------------------------------------------------------------ scatter: one level of the partitioning
 // grid: level A any number of blocks (they share the stream's extents round-robin); level B HP_FAN blocks, block a owning partition a.
+// U = 16-byte units per tuple (1 or 2). Everything below counts TUPLES: an extent holds HP_ET / U of them, a 128-byte line 8 / U.
+template <int U> struct alignas(16) HpTuple { hp_u64x2 v[U]; };
+template <int U> __device__ __forceinline__ HpTuple<U> hp_load_nt(const HpTuple<U>* p) {
+  HpTuple<U> t;
+#pragma unroll
+  for (int u = 0; u < U; ++u) t.v[u] = __builtin_nontemporal_load(&p->v[u]);
+  return t;
+}
 struct HpScatterLds {
   uint32_t hist[HP_FAN], offs[HP_FAN], carry_n[HP_FAN], cur[HP_FAN];
   uint32_t ext_a[HP_FAN], fill_a[HP_FAN];                                                  // per digit: the open extent and the tuples already in it
@@ -97,17 +109,20 @@ struct HpScatterLds {
   uint16_t lfill[HP_LIST], lpre[HP_LIST], tfirst[HP_LIST + 1];     // tuples of a listed extent, tuples before it in its tile, first entry of tile t
   uint8_t sdigit[HP_ET + HP_FAN * HP_CARRY];
 };
-__host__ __device__ __forceinline__ size_t hp_scatter_lds_bytes() {
+__host__ __device__ __forceinline__ size_t hp_scatter_lds_bytes() {      // (the same for both tuple sizes: a tile is 64 KB of tuples)
   return sizeof(HpScatterLds) + (size_t)(HP_ET + HP_FAN * HP_CARRY) * 16 + (size_t)HP_FAN * HP_CARRY * 16 + 64;
 }
 
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __restrict__ HA, int kind, int level, unsigned long long* counters) {
+template <int BLOCK, int U>
+__global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __restrict__ HA, int level, unsigned long long* counters) {
+  typedef HpTuple<U> T;
+  constexpr uint32_t ET = HP_ET / U, LINE = 8 / U, CARRY = HP_CARRY / U;      // tuples per extent / per 128-byte line / waiting slots per digit
+  constexpr int R = (int)(ET / BLOCK);                                       // tuples of a tile per thread
   extern __shared__ __attribute__((aligned(16))) char lds[];
   HpScatterLds& S = *reinterpret_cast<HpScatterLds*>(lds);
-  hp_u64x2* const sorted = reinterpret_cast<hp_u64x2*>(lds + (sizeof(HpScatterLds) + 15) / 16 * 16);
-  hp_u64x2* const carry = sorted + (HP_ET + HP_FAN * HP_CARRY);
-  const VhHpKind& K = HA->k[kind];
+  T* const sorted = reinterpret_cast<T*>(lds + (sizeof(HpScatterLds) + 15) / 16 * 16);
+  T* const carry = sorted + (ET + HP_FAN * CARRY);
+  const VhHpKind& K = HA->k[0];
   const VhHpPool src = level == 0 ? K.z : K.a, dst = level == 0 ? K.a : K.b;
   const int shift = level == 0 ? 56 : 48;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,7 +148,7 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
       const uint32_t e = e0 + tid;
       bool mine = false;
       uint32_t fl = 0;
-      if (e < used && (fl = hp_pool_fill(src, e)) != 0)
+      if (e < used && (fl = hp_pool_fill(src, e, ET)) != 0)
         mine = level == 0 ? ((e * 2654435761u) >> 12) % gridDim.x == blockIdx.x : src.tag[e] == (uint8_t)blockIdx.x;      // (level A: a scattered share of the stream, so that
                                                                                                                                //  the blocks do not march through the pool 64 KB apart in lockstep)
       __syncthreads();
@@ -149,14 +164,14 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
     __syncthreads();
     const uint32_t nl = S.nlist < HP_LIST ? S.nlist : HP_LIST;
     scan0 = next_scan;
-    // ---- tiles: consecutive listed extents whose tuples add up to at most HP_ET (the extents a level leaves behind are often a quarter
+    // ---- tiles: consecutive listed extents whose tuples add up to at most ET (the extents a level leaves behind are often a quarter
     //      full — one per writing block and digit —, and a tile's fixed cost is the same whatever it holds)
     if (tid == 0) {
       uint32_t nt = 0, i = 0;
       while (i < nl) {
         S.tfirst[nt++] = (uint16_t)i;
         uint32_t sum = 0, cnt = 0;
-        while (i < nl && cnt < 32 && sum + S.lfill[i] <= (uint32_t)HP_ET) { S.lpre[i] = (uint16_t)sum; sum += S.lfill[i]; ++i; ++cnt; }
+        while (i < nl && cnt < 32 && sum + S.lfill[i] <= ET) { S.lpre[i] = (uint16_t)sum; sum += S.lfill[i]; ++i; ++cnt; }
       }
       S.tfirst[nt] = (uint16_t)nl;
       S.ntiles = nt;
@@ -164,29 +179,29 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
     __syncthreads();
     const uint32_t ntiles = S.ntiles;
     auto tile_total = [&](uint32_t tile) { const uint32_t last = S.tfirst[tile + 1] - 1u; return (uint32_t)S.lpre[last] + S.lfill[last]; };
-    auto tile_load = [&](uint32_t tile, uint32_t total, hp_u64x2 (&dstv)[HP_ET / BLOCK]) {
+    auto tile_load = [&](uint32_t tile, uint32_t total, T (&dstv)[R]) {
 #pragma unroll
-      for (int r = 0; r < HP_ET / BLOCK; ++r) {
+      for (int r = 0; r < R; ++r) {
         const uint32_t k = (uint32_t)(r * BLOCK + tid);
         if (k < total) {
           uint32_t i = S.tfirst[tile];
           while ((uint32_t)S.lpre[i] + S.lfill[i] <= k) ++i;
-          dstv[r] = __builtin_nontemporal_load(reinterpret_cast<const hp_u64x2*>(src.tuples) + (uint64_t)S.list[i] * src.stride + (k - S.lpre[i]));
+          dstv[r] = hp_load_nt<U>(reinterpret_cast<const T*>(src.tuples) + (uint64_t)S.list[i] * src.stride + (k - S.lpre[i]));
         }
       }
     };
-    hp_u64x2 t[HP_ET / BLOCK];
+    T t[R];
     uint32_t valid = ntiles ? tile_total(0) : 0u;
     if (ntiles) tile_load(0, valid, t);
     for (uint32_t li = 0; li < ntiles; ++li) {
       const uint32_t nvalid = valid;
-      uint32_t dig[HP_ET / BLOCK];
-      uint32_t rank[HP_ET / BLOCK];       // the tuple's place among its digit's tuples: what the histogram's counter held when it was counted
+      uint32_t dig[R];
+      uint32_t rank[R];       // the tuple's place among its digit's tuples: what the histogram's counter held when it was counted
       if (tid < HP_FAN) { S.hist[tid] = S.carry_n[tid]; S.cur[tid] = S.carry_n[tid]; }
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < HP_ET / BLOCK; ++r)
-        if ((uint32_t)(r * BLOCK + tid) < nvalid) { dig[r] = (uint32_t)(t[r].x >> shift) & (HP_FAN - 1u); rank[r] = atomicAdd(&S.hist[dig[r]], 1u); }
+      for (int r = 0; r < R; ++r)
+        if ((uint32_t)(r * BLOCK + tid) < nvalid) { dig[r] = (uint32_t)(t[r].v[0].x >> shift) & (HP_FAN - 1u); rank[r] = atomicAdd(&S.hist[dig[r]], 1u); }
       __syncthreads();
       // exclusive prefix over the digits (waves 0..3: 64 digits each), whole lines, room, extents
       uint32_t incl = 0, h = 0;
@@ -203,9 +218,9 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
         for (int w = 0; w < wave; ++w) before += S.wave_tot[w];
         const uint32_t first = before + incl - h;
         S.offs[tid] = first;
-        uint32_t whole = h & ~7u;
+        uint32_t whole = h & ~(LINE - 1u);
         uint32_t ea = S.ext_a[tid], fa = S.fill_a[tid], eb = ~0u;
-        uint32_t room = ea == ~0u ? 0u : (uint32_t)HP_ET - fa;
+        uint32_t room = ea == ~0u ? 0u : ET - fa;
         if (whole > room) {                          // the run needs a fresh extent behind what is left of the open one
           const uint32_t got = atomicAdd(dcur, 1u);
           if (dlo + got < dhi) { eb = dlo + got; dst.tag[eb] = (uint8_t)tid; }
@@ -216,33 +231,33 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
         S.tail[tid] = h - whole;
         // after this tile: the open extent and its fill
         if (whole <= room) { S.fill_a[tid] = fa + whole; }
-        else { if (ea != ~0u) dst.fill[ea] = (uint16_t)HP_ET; S.ext_a[tid] = eb; S.fill_a[tid] = whole - room; }
+        else { if (ea != ~0u) dst.fill[ea] = (uint16_t)ET; S.ext_a[tid] = eb; S.fill_a[tid] = whole - room; }
       }
       __syncthreads();
       // scatter: waiting tails first, then the tile's tuples
-      for (uint32_t c = tid; c < HP_FAN * HP_CARRY; c += BLOCK) {
-        const uint32_t d = c / HP_CARRY, j = c % HP_CARRY;
+      for (uint32_t c = tid; c < HP_FAN * CARRY; c += BLOCK) {
+        const uint32_t d = c / CARRY, j = c % CARRY;
         if (j < S.cur[d]) { sorted[S.offs[d] + j] = carry[c]; S.sdigit[S.offs[d] + j] = (uint8_t)d; }
       }
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < HP_ET / BLOCK; ++r)
+      for (int r = 0; r < R; ++r)
         if ((uint32_t)(r * BLOCK + tid) < nvalid) { const uint32_t at = S.offs[dig[r]] + rank[r]; sorted[at] = t[r]; S.sdigit[at] = (uint8_t)dig[r]; }
       // the next tile's loads travel while this one is written out
       if (li + 1 < ntiles) { valid = tile_total(li + 1); tile_load(li + 1, valid, t); }
       __syncthreads();
       const uint32_t total = S.offs[HP_FAN - 1] + S.hist[HP_FAN - 1];
-      hp_u64x2* const out = reinterpret_cast<hp_u64x2*>(dst.tuples);
+      T* const out = reinterpret_cast<T*>(dst.tuples);
       for (uint32_t k = tid; k < total; k += BLOCK) {
         const uint32_t d = S.sdigit[k];
         const hp_u32x4 m = *reinterpret_cast<const hp_u32x4*>(S.meta[d]);
         const uint32_t local = k - (m.x & 0xFFFFu), whole = m.x >> 16;
-        const hp_u64x2 v = sorted[k];
+        const T v = sorted[k];
         if (local < whole) out[(local < m.y ? m.z : m.w) + local] = v;
-        else if (local - whole < HP_CARRY) carry[d * HP_CARRY + (local - whole)] = v;
+        else if (local - whole < CARRY) carry[d * CARRY + (local - whole)] = v;
       }
       __syncthreads();
-      if (tid < HP_FAN) S.carry_n[tid] = S.tail[tid] < HP_CARRY ? S.tail[tid] : 0u;     // (>= 8 only on a void attempt that ran out of extents)
+      if (tid < HP_FAN) S.carry_n[tid] = S.tail[tid] < CARRY ? S.tail[tid] : 0u;     // (a line or more only on a void attempt that ran out of extents)
     }
   }
   // ---- what still waits goes out as the last, partial line of its extent; open extents are closed with what they hold
@@ -251,14 +266,14 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
     uint32_t ea = S.ext_a[tid], fa = S.fill_a[tid];
     const uint32_t n = S.carry_n[tid];
     if (n) {
-      if (ea == ~0u || fa + n > (uint32_t)HP_ET) {
+      if (ea == ~0u || fa + n > ET) {
         if (ea != ~0u) dst.fill[ea] = (uint16_t)fa;
         const uint32_t got = atomicAdd(dcur, 1u);
         if (dlo + got < dhi) { ea = dlo + got; fa = 0; dst.tag[ea] = (uint8_t)tid; } else { ea = ~0u; full = true; }
       }
       if (ea != ~0u) {
-        hp_u64x2* const out = reinterpret_cast<hp_u64x2*>(dst.tuples);
-        for (uint32_t j = 0; j < n; ++j) out[(uint64_t)ea * dst.stride + fa + j] = carry[tid * HP_CARRY + j];
+        T* const out = reinterpret_cast<T*>(dst.tuples);
+        for (uint32_t j = 0; j < n; ++j) out[(uint64_t)ea * dst.stride + fa + j] = carry[tid * CARRY + j];
         fa += n;
       }
     }
@@ -269,11 +284,11 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
 
 // ------------------------------------------------------------------ between the levels: the slices of the last pool
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void hp_count_kernel(const VhHpArgs* __restrict__ HA, int kind) {
+__global__ __launch_bounds__(BLOCK) void hp_count_kernel(const VhHpArgs* __restrict__ HA) {
   __shared__ unsigned int cnt[HP_FAN];
   if (threadIdx.x < HP_FAN) cnt[threadIdx.x] = 0;
   __syncthreads();
-  const VhHpKind& K = HA->k[kind];
+  const VhHpKind& K = HA->k[0];
   const uint32_t used = hp_pool_used(K.a);
   for (uint32_t e = blockIdx.x * BLOCK + threadIdx.x; e < used; e += gridDim.x * BLOCK) {
     const uint32_t f = K.a.fill[e];
@@ -282,15 +297,16 @@ __global__ __launch_bounds__(BLOCK) void hp_count_kernel(const VhHpArgs* __restr
   __syncthreads();
   if (threadIdx.x < HP_FAN && cnt[threadIdx.x]) atomicAdd(K.count + threadIdx.x, cnt[threadIdx.x]);
 }
-__global__ __launch_bounds__(64) void hp_plan_kernel(const VhHpArgs* __restrict__ HA, int kind, unsigned long long* counters) {
-  const VhHpKind& K = HA->k[kind];
+__global__ __launch_bounds__(64) void hp_plan_kernel(const VhHpArgs* __restrict__ HA, unsigned long long* counters) {
+  const VhHpKind& K = HA->k[0];
+  const uint32_t et = (uint32_t)HP_ET / (uint32_t)HA->units;
   if (threadIdx.x == 0) {
     unsigned long long at = 0;
     for (int a = 0; a < HP_FAN; ++a) {
       K.slice[a] = (uint32_t)(at < K.b.max_extents ? at : K.b.max_extents);
       K.slice[HP_FAN + 1 + a] = 0;
       // what the partition holds, in extents, + one open extent per digit of its single writer + the flush of the tails
-      if (K.count[a]) at += (K.count[a] + HP_ET - 1) / HP_ET + 2 * HP_FAN + 8;
+      if (K.count[a]) at += (K.count[a] + et - 1) / et + 2 * HP_FAN + 8;
     }
     K.slice[HP_FAN] = (uint32_t)(at < K.b.max_extents ? at : K.b.max_extents);
     if (at > K.b.max_extents) atomicOr(counters + 2, VH_ERR_PART_FULL);
@@ -320,20 +336,23 @@ __device__ __forceinline__ uint32_t hp_slot(unsigned long long* keys, uint32_t g
   return 0;
 }
 
-#define HP_OVF 128          // extents beyond the first of a (range, kind) that a block remembers (skewed keys only: a range's share of
+#define HP_OVF 128          // extents beyond the first of a range that a block remembers (skewed keys only: a range's share of
                             // uniform keys is a quarter of one extent)
 struct HpAggLds {
   unsigned long long base, chunk_pos, chunk_end;
   uint32_t count, bad, novf, wave_tot[16];
-  uint32_t ext1[2][HP_FAN];          // per kind and digit b: the range's first extent (~0u: none) ...
-  uint16_t fill1[2][HP_FAN];         // ... and the tuples in it
-  uint32_t ovf_ext[HP_OVF];          // the others: (kind << 8 | digit) in ovf_key
+  uint32_t ext1[HP_FAN];             // per digit b: the range's first extent (~0u: none) ...
+  uint16_t fill1[HP_FAN];            // ... and the tuples in it
+  uint32_t ovf_ext[HP_OVF];          // the others: their digit in ovf_key
   uint16_t ovf_fill[HP_OVF], ovf_key[HP_OVF];
 };
+#define HP_IDS_ONLY 4ull    // tuples that carry ids, word 3: bits 0-1 = ids that count (0..2), bit 2 = the payload was sent with another tuple of the row
 
 // grid: HP_FAN x blocks_per_partition; block (a, j) works through ranges (a, b), b = j, j + blocks_per_partition, ...
-template <int BLOCK>
+// U = 16-byte units per tuple: 1 (mixed key, payload) or 2 (mixed key, payload, two ids, how many of them count | ids only).
+template <int BLOCK, int U>
 __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, const VhHpArgs* __restrict__ HA, int blocks_per_partition) {
+  typedef HpTuple<U> T;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   __shared__ HpAggLds S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -341,18 +360,17 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
   unsigned long long* const gkeys = reinterpret_cast<unsigned long long*>(lds + HA->keys_off);
   unsigned long long* const skeys = reinterpret_cast<unsigned long long*>(lds + HA->set_off);
   const uint32_t GS = (uint32_t)HA->gslots, SS = (uint32_t)HA->sslots;
-  const int nkind = HA->nkind, passes = HA->passes, bitset_j = HA->bitset_j;
-  const bool pairs = nkind > 1 && bitset_j >= 0;
+  const int passes = HA->passes, bitset_j = HA->bitset_j;
   const int sub_bits = 31 - __builtin_clz((uint32_t)passes | 1u);
   const uint32_t stride_w = P.hrec_bytes / 8u;
-  const uint32_t es[2] = {HA->k[0].b.stride, HA->k[nkind > 1 ? 1 : 0].b.stride};
-  const hp_u64x2* const pool[2] = {reinterpret_cast<const hp_u64x2*>(HA->k[0].b.tuples), reinterpret_cast<const hp_u64x2*>(HA->k[nkind > 1 ? 1 : 0].b.tuples)};
+  const VhHpKind& K = HA->k[0];
+  const uint32_t es = K.b.stride;
+  const T* const pool = reinterpret_cast<const T*>(K.b.tuples);
   // ---- which extent of slice a holds which range: ONE look at the slice's tags for all the block's ranges
-  for (int i = tid; i < 2 * HP_FAN; i += BLOCK) S.ext1[i / HP_FAN][i % HP_FAN] = ~0u;
+  for (int i = tid; i < HP_FAN; i += BLOCK) S.ext1[i] = ~0u;
   if (tid == 0) { S.chunk_pos = 0; S.chunk_end = 0; S.novf = 0; S.bad = 0; }
   __syncthreads();
-  for (int k = 0; k < nkind; ++k) {
-    const VhHpKind& K = HA->k[k];
+  {
     const uint32_t lo = K.slice[a], cap = K.slice[a + 1] - lo, used = K.slice[HP_FAN + 1 + a];
     const uint32_t hi = lo + (used < cap ? used : cap);
     for (uint32_t e = lo + tid; e < hi; e += BLOCK) {
@@ -360,35 +378,29 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
       if (!f) continue;
       const uint32_t d = K.b.tag[e];
       if ((int)(d % (uint32_t)blocks_per_partition) != j0) continue;          // (another block's range)
-      if (atomicCAS(&S.ext1[k][d], ~0u, e) == ~0u) S.fill1[k][d] = (uint16_t)f;
-      else { const uint32_t at = atomicAdd(&S.novf, 1u); if (at < HP_OVF) { S.ovf_ext[at] = e; S.ovf_fill[at] = (uint16_t)f; S.ovf_key[at] = (uint16_t)(k << 8 | d); } }
+      if (atomicCAS(&S.ext1[d], ~0u, e) == ~0u) S.fill1[d] = (uint16_t)f;
+      else { const uint32_t at = atomicAdd(&S.novf, 1u); if (at < HP_OVF) { S.ovf_ext[at] = e; S.ovf_fill[at] = (uint16_t)f; S.ovf_key[at] = (uint16_t)d; } }
     }
   }
   __syncthreads();
   if (S.novf > HP_OVF) { if (tid == 0) atomicOr(P.counters + 2, VH_ERR_HPART_FULL); return; }     // (skew beyond what a block remembers: the plain hash table)
   const uint32_t novf = S.novf;
-  // the first 1024 tuples of a range's first extent of each kind travel while the previous range is worked on
-  constexpr int U = 1024 / BLOCK;
-  hp_u64x2 ng[U], np[U];
-  auto prefetch = [&](int b, hp_u64x2 (&g)[U], hp_u64x2 (&q)[U]) {
+  // the first 1024 tuples of a range's first extent travel while the previous range is worked on
+  constexpr int N = 1024 / BLOCK;
+  T ng[N];
+  auto prefetch = [&](int b, T (&g)[N]) {
     if (b >= HP_FAN) return;
-    const uint32_t e0 = S.ext1[0][b], f0 = e0 == ~0u ? 0u : S.fill1[0][b];
+    const uint32_t e0 = S.ext1[b], f0 = e0 == ~0u ? 0u : S.fill1[b];
 #pragma unroll
-    for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f0) g[u] = pool[0][(uint64_t)e0 * es[0] + u * BLOCK + tid];
-    if (pairs) {
-      const uint32_t e1 = S.ext1[1][b], f1 = e1 == ~0u ? 0u : S.fill1[1][b];
-#pragma unroll
-      for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f1) q[u] = pool[1][(uint64_t)e1 * es[1] + u * BLOCK + tid];
-    }
+    for (int u = 0; u < N; ++u) if ((uint32_t)(u * BLOCK + tid) < f0) g[u] = pool[(uint64_t)e0 * es + u * BLOCK + tid];
   };
-  prefetch(j0, ng, np);
+  prefetch(j0, ng);
   for (int b = j0; b < HP_FAN; b += blocks_per_partition) {
-    hp_u64x2 cg[U], cp[U];
+    T cg[N];
 #pragma unroll
-    for (int u = 0; u < U; ++u) { cg[u] = ng[u]; cp[u] = np[u]; }
-    const uint32_t e0 = S.ext1[0][b], f0 = e0 == ~0u ? 0u : S.fill1[0][b];
-    const uint32_t e1 = pairs ? S.ext1[1][b] : ~0u, f1 = e1 == ~0u ? 0u : S.fill1[1][b];
-    prefetch(b + blocks_per_partition, ng, np);
+    for (int u = 0; u < N; ++u) cg[u] = ng[u];
+    const uint32_t e0 = S.ext1[b], f0 = e0 == ~0u ? 0u : S.fill1[b];
+    prefetch(b + blocks_per_partition, ng);
     if (f0 == 0) continue;                       // (uniform: an empty range)
     for (int pass = 0; pass < passes; ++pass) {
       const int abl = HA->ablate;
@@ -401,46 +413,38 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
           else reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = m.ident;
         }
       }
-      if (!(abl & 8)) for (uint32_t g = tid; g < SS; g += BLOCK) skeys[g] = VH_HASH_EMPTY;
+      if (U == 2 && !(abl & 8)) for (uint32_t g = tid; g < SS; g += BLOCK) skeys[g] = VH_HASH_EMPTY;
       __syncthreads();
       bool bad = false;
       if (abl & 4) {      // (the tuples are still looked at)
         uint64_t acc = 0;
-        for (int u = 0; u < U; ++u) acc += cg[u].x + cp[u].y;
+        for (int u = 0; u < N; ++u) acc += cg[u].v[0].x + cg[u].v[U - 1].y;
         if (acc == 0x123456789ABCDEFull) P.counters[7] = acc;
         continue;
       }
-      // ---- tuples: (mixed key, payload word carrying the metric values at tshift)
-      auto group_tuple = [&](const hp_u64x2 tp) {
-        if (sub_bits && (int)((uint32_t)(tp.x >> (48 - sub_bits)) & (uint32_t)(passes - 1)) != pass) return;
+      uint32_t* const card = reinterpret_cast<uint32_t*>(lds + P.m[bitset_j < 0 ? 0 : bitset_j].lds_off);
+      const int set_shift = U == 2 ? 32 - (31 - __builtin_clz(SS | 1u)) : 0;
+      // ---- a tuple: the group's slot (claimed if new), the metric values of its payload word, then its ids into the (group slot, id) set
+      auto tuple = [&](const T& tp) {
+        const uint64_t mkey = tp.v[0].x, payload = tp.v[0].y;
+        if (sub_bits && (int)((uint32_t)(mkey >> (48 - sub_bits)) & (uint32_t)(passes - 1)) != pass) return;
         bool ok = true;
-        const uint32_t slot = hp_slot(gkeys, GS, tp.x, true, ok);
+        const uint32_t slot = hp_slot(gkeys, GS, mkey, true, ok);
         if (!ok) { bad = true; return; }
-        for (int j = 0; j < P.nmetric; ++j) {
-          const VhMetricDev& m = P.m[j];
-          if (m.sop() == SOP_BITSET) continue;
-          uint64_t v = tp.y >> m.tshift();
-          if (vh_sop_bytes(m.sop()) == 4) { v &= 0xFFFFFFFFull; if (vh_sop_sext(m.sop())) v = (uint64_t)(int64_t)(int32_t)v; }
-          vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, slot, m.sop(), v);
+        const uint64_t meta = U == 2 ? tp.v[U - 1].y : 0ull;
+        if (!(meta & HP_IDS_ONLY)) {
+          for (int j = 0; j < P.nmetric; ++j) {
+            const VhMetricDev& m = P.m[j];
+            if (m.sop() == SOP_BITSET) continue;
+            uint64_t v = payload >> m.tshift();
+            if (vh_sop_bytes(m.sop()) == 4) { v &= 0xFFFFFFFFull; if (vh_sop_sext(m.sop())) v = (uint64_t)(int64_t)(int32_t)v; }
+            vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, slot, m.sop(), v);
+          }
         }
-      };
-#pragma unroll
-      for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f0) group_tuple(pass == 0 ? cg[u] : pool[0][(uint64_t)e0 * es[0] + u * BLOCK + tid]);
-      for (uint32_t i = U * BLOCK + tid; i < f0; i += BLOCK) group_tuple(pool[0][(uint64_t)e0 * es[0] + i]);       // (a first extent of more than 1024 tuples)
-      for (uint32_t x = 0; x < novf; ++x)
-        if (S.ovf_key[x] == (uint16_t)b) for (uint32_t i = tid; i < S.ovf_fill[x]; i += BLOCK) group_tuple(pool[0][(uint64_t)S.ovf_ext[x] * es[0] + i]);
-      __syncthreads();
-      // ---- pair tuples: (mixed key, two ids; an odd id count repeats the last one)
-      if (pairs && !(abl & 1)) {
-        uint32_t* const card = reinterpret_cast<uint32_t*>(lds + P.m[bitset_j].lds_off);
-        const int set_shift = 32 - (31 - __builtin_clz(SS));
-        auto pair_tuple = [&](const hp_u64x2 tp) {
-          if (sub_bits && (int)((uint32_t)(tp.x >> (48 - sub_bits)) & (uint32_t)(passes - 1)) != pass) return;
-          bool ok = true;
-          const uint32_t slot = hp_slot(gkeys, GS, tp.x, false, ok);
-          if (!ok) { bad = true; return; }                        // (cannot happen: a row's pair tuples follow its tuple into the same range)
-          const uint32_t idv[2] = {(uint32_t)tp.y, (uint32_t)(tp.y >> 32)};
-          const int n = idv[0] == idv[1] ? 1 : 2;
+        if (U == 2 && !(abl & 1)) {
+          const uint64_t ids = tp.v[U - 1].x;
+          const uint32_t idv[2] = {(uint32_t)ids, (uint32_t)(ids >> 32)};
+          const int n = (int)(meta & 3ull);
           for (int q = 0; q < n; ++q) {
             const unsigned long long key = ((unsigned long long)slot << 32) | idv[q];
             uint32_t at = ((idv[q] ^ (slot * 0x9E3779B1u)) * 0x85EBCA6Bu) >> set_shift;      // (multiply-shift: the top bits)
@@ -453,14 +457,14 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
             }
             if (!placed) bad = true;
           }
-        };
+        }
+      };
 #pragma unroll
-        for (int u = 0; u < U; ++u) if ((uint32_t)(u * BLOCK + tid) < f1) pair_tuple(pass == 0 ? cp[u] : pool[1][(uint64_t)e1 * es[1] + u * BLOCK + tid]);
-        for (uint32_t i = U * BLOCK + tid; i < f1; i += BLOCK) pair_tuple(pool[1][(uint64_t)e1 * es[1] + i]);
-        for (uint32_t x = 0; x < novf; ++x)
-          if (S.ovf_key[x] == (uint16_t)(0x100 | b)) for (uint32_t i = tid; i < S.ovf_fill[x]; i += BLOCK) pair_tuple(pool[1][(uint64_t)S.ovf_ext[x] * es[1] + i]);
-        __syncthreads();
-      }
+      for (int u = 0; u < N; ++u) if ((uint32_t)(u * BLOCK + tid) < f0) tuple(pass == 0 ? cg[u] : pool[(uint64_t)e0 * es + u * BLOCK + tid]);
+      for (uint32_t i = N * BLOCK + tid; i < f0; i += BLOCK) tuple(pool[(uint64_t)e0 * es + i]);       // (a first extent of more than 1024 tuples)
+      for (uint32_t x = 0; x < novf; ++x)
+        if (S.ovf_key[x] == (uint16_t)b) for (uint32_t i = tid; i < S.ovf_fill[x]; i += BLOCK) tuple(pool[(uint64_t)S.ovf_ext[x] * es + i]);
+      __syncthreads();
       if (__ballot(bad)) { if (lane == 0) S.bad = 1; }
       // ---- this pass's groups, as records: count, take a piece of the block's chunk of the list, write
       uint32_t mine = 0;

@@ -60,11 +60,11 @@ __device__ __forceinline__ void vj_rollup_all(const VhPlanDev& P, uint64_t (&gv)
   }
 }
 
-// What a wave carries through the scan besides its registers of predicate values: partition cursors (tuples; pair tuples of the
-// hashed partitioning), the waiting lines of the whole-line writer, its luck with the LDS front table.
+// What a wave carries through the scan besides its registers of predicate values: partition cursors, the waiting lines of the
+// whole-line writer, its luck with the LDS front table.
 struct VjWave {
-  VhPartWave W, WB;
-  VhPartTile T, TB;
+  VhPartWave W;
+  VhPartTile T;
   VhPartStage S;
   VhLdsHashWave H;
 };
@@ -109,11 +109,11 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
       if (VJ_BS_MERGE) {
         const vj_u64x2_a8 o = *VJ_GLOBAL(vj_u64x2_a8, P.bs_offs[b][seg] + row);
         bk = o.x; bk1 = o.y;
-        if (bk < bk1) { const vj_u32x2_a4 i2 = *VJ_GLOBAL(vj_u32x2_a4, bids + bk); bid0 = i2.x; bid1 = bk + 1 < bk1 ? i2.y : bid0; }      // an odd count repeats the last id: a set does not mind
+        if (bk < bk1) { const vj_u32x2_a4 i2 = *VJ_GLOBAL(vj_u32x2_a4, bids + bk); bid0 = i2.x; bid1 = i2.y; }      // (the tuple says how many of the two count)
       } else {
         const uint64_t* offs = P.bs_offs[b][seg];
         bk = offs[row]; bk1 = offs[row + 1];
-        if (bk < bk1) { bid0 = bids[bk]; bid1 = bk + 1 < bk1 ? bids[bk + 1] : bid0; }
+        if (bk < bk1) { bid0 = bids[bk]; bid1 = bk + 1 < bk1 ? bids[bk + 1] : 0u; }
       }
     }
   }
@@ -151,30 +151,37 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
     }
   }
   if constexpr (MODE == VH_MODE_HASH && J::HPART) {
-    // hashed partitioning (vh_hpart.h): the row becomes a (mixed key, payload) tuple and, per two ids of its bitset metric, a
-    // (mixed key, ids) pair tuple; hp_scatter_kernel and hp_aggregate_kernel do the rest
+    // hashed partitioning (vh_hpart.h): the row becomes a (mixed key, payload) tuple — with a bitset metric a 32-byte one that also carries
+    // the row's first two ids, and further "ids only" tuples for a row with more than two; hp_scatter_kernel and hp_aggregate_kernel do the rest
     const int lane = (int)(threadIdx.x & 63);
     const uint64_t mkey = vh_splitmix64(key[0]);
-    const uint32_t p = 0u;          // the tuples leave unpartitioned, 1 KiB per wave store (one "partition"): hp_scatter_kernel sorts them out
-    uint64_t words[2] = {mkey, 0ull};
+    const uint32_t p = 0u;          // the tuples leave unpartitioned, 1-2 KiB per wave store (one "partition"): hp_scatter_kernel sorts them out
+    uint64_t payload = 0ull;
 #pragma unroll
     for (int j = 0; j < NM; ++j)
-      if (J::m_sop[j] != SOP_BITSET) words[1] |= (vh_sop_bytes(J::m_sop[j]) == 4 ? (mv[j] & 0xFFFFFFFFull) : mv[j]) << J::m_tshift[j];
-    if (!(VJ_ABL & 8)) vh_part_direct_add<2, 1, 2>(P, T, W, active, words, p, lane);
-    else if (words[0] + words[1] == 0x123456789ABCDEFull) P.counters[7] = 1;
+      if (J::m_sop[j] != SOP_BITSET) payload |= (vh_sop_bytes(J::m_sop[j]) == 4 ? (mv[j] & 0xFFFFFFFFull) : mv[j]) << J::m_tshift[j];
     if constexpr (J::BITSET_J >= 0 && !(VJ_ABL & 4)) {
-      bool more = bk < bk1;
+      // word 2: two ids, word 3: how many of them count | HP_IDS_ONLY (4) on the tuples behind a row's first
+      uint64_t left = bk1 - bk;
+      uint64_t words[4] = {mkey, payload, (uint64_t)bid0 | ((uint64_t)bid1 << 32), left < 2 ? left : 2ull};
+      if (!(VJ_ABL & 8)) vh_part_direct_add<4, 1, 4>(P, T, W, active, words, p, lane);
+      else if (words[0] + words[1] + words[2] == 0x123456789ABCDEFull) P.counters[7] = 1;
+      bool more = active && left > 2;
       while (__ballot(more)) {
-        const uint64_t w2[2] = {mkey, (uint64_t)bid0 | ((uint64_t)bid1 << 32)};
-        if (!(VJ_ABL & 8)) vh_part_direct_add<2, 3, 2>(P, V.TB, V.WB, more, w2, p, lane);
-        else if (w2[1] == 0x123456789ABCDEFull) P.counters[7] = 1;
-        bk += 2;
-        more = bk < bk1;
+        bk += 2; left -= 2;
         if (more) {
-          if (VJ_BS_MERGE) { const vj_u32x2_a4 i2 = *VJ_GLOBAL(vj_u32x2_a4, bids + bk); bid0 = i2.x; bid1 = bk + 1 < bk1 ? i2.y : bid0; }
-          else { bid0 = bids[bk]; bid1 = bk + 1 < bk1 ? bids[bk + 1] : bid0; }
+          if (VJ_BS_MERGE) { const vj_u32x2_a4 i2 = *VJ_GLOBAL(vj_u32x2_a4, bids + bk); bid0 = i2.x; bid1 = i2.y; }
+          else { bid0 = bids[bk]; bid1 = left > 1 ? bids[bk + 1] : 0u; }
         }
+        const uint64_t w2[4] = {mkey, 0ull, (uint64_t)bid0 | ((uint64_t)bid1 << 32), (left < 2 ? left : 2ull) | 4ull};
+        if (!(VJ_ABL & 8)) vh_part_direct_add<4, 1, 4>(P, T, W, more, w2, p, lane);
+        else if (w2[2] == 0x123456789ABCDEFull) P.counters[7] = 1;
+        more = more && left > 2;
       }
+    } else {
+      const uint64_t words[2] = {mkey, payload};
+      if (!(VJ_ABL & 8)) vh_part_direct_add<2, 1, 2>(P, T, W, active, words, p, lane);
+      else if (words[0] + words[1] == 0x123456789ABCDEFull) P.counters[7] = 1;
     }
     return;
   }
@@ -282,7 +289,7 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
   V.H = VhLdsHashWave{0u, 0u, false, 0ull};
   V.S = VhPartStage{0u, nullptr};
   if constexpr (MODE == VH_MODE_HASH && J::LDS_HASH) vh_lds_hash_init(P, lds, BLOCK);
-  if constexpr (MODE == VH_MODE_DENSE_PART || (MODE == VH_MODE_HASH && J::HPART)) { vh_part_tile_init(P, lds, V.T, V.W); vh_part_tile_init(P, lds, V.TB, V.WB); }
+  if constexpr (MODE == VH_MODE_DENSE_PART || (MODE == VH_MODE_HASH && J::HPART)) vh_part_tile_init(P, lds, V.T, V.W);
   if constexpr (MODE == VH_MODE_DENSE_PART && J::STAGE)      // one waiting line per partition and wave, behind the block's queues
     V.S.lines = reinterpret_cast<uint64_t*>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)wave * VH_STAGE_BYTES);
   if constexpr (MODE == VH_MODE_DENSE_LDS) {
@@ -355,7 +362,7 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
   }
 
   if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE) vh_part_stage_finish(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); }
-  if constexpr (MODE == VH_MODE_HASH && J::HPART) { vh_part_tile_finish<1>(P, V.T, lane); if constexpr (J::BITSET_J >= 0) vh_part_tile_finish<3>(P, V.TB, lane); }
+  if constexpr (MODE == VH_MODE_HASH && J::HPART) vh_part_tile_finish<1>(P, V.T, lane);
   if (lane == 0) {
     if (npassed) atomicAdd(P.counters + 0, npassed);
     if (nfresh) atomicAdd(P.counters + 1, nfresh);

@@ -1343,7 +1343,8 @@ struct QueryBuild {
   int nxcd = 1, part_bpp = 1;
   uint64_t capacity = 0;
   bool hpart = false;
-  uint64_t hp_tuple_cap = 0, hp_pair_cap = 0;
+  uint64_t hp_tuple_cap = 0;
+  int hp_units = 1;                 // 16-byte units per tuple of the hashed partitioning: 2 when the tuples carry the ids of a bitset metric
   int hp_bpp = 1;
   uint32_t hp_chunk = 256;
   bool packed = false, packed_compressed = false;
@@ -2136,14 +2137,16 @@ int QueryBuild::plan_hashed_partitioning() {
       if (hpart) {
         hp_tuple_cap = part_tuples_override ? part_tuples_override : std::max<uint64_t>((uint64_t)(survivors * 1.25) + 1024, 1ull << 16);
         hp_tuple_cap = std::min<uint64_t>(hp_tuple_cap, rows_to_scan + 1);
-        if (nb) {    // a row of k ids writes ceil(k / 2) pair tuples: at most (ids + rows) / 2 of them
+        if (nb) {    // the tuples carry the row's ids, two at a time: a row of k ids writes max(1, ceil(k / 2)) tuples — at most rows + (ids + rows) / 2 of them
           const uint64_t worst = (bitset_ids[0] + std::min<uint64_t>(hp_tuple_cap, rows_to_scan)) / 2 + 1;
-          hp_pair_cap = part_tuples_override ? worst : std::min<uint64_t>(worst, (uint64_t)(((double)bitset_ids[0] * std::max(sel, 0.02) * 1.25 + (double)hp_tuple_cap) / 2) + (1ull << 16));
+          const uint64_t by_ids = std::min<uint64_t>(worst, (uint64_t)(((double)bitset_ids[0] * std::max(sel, 0.02) * 1.25 + (double)hp_tuple_cap) / 2) + (1ull << 16));
+          hp_tuple_cap = part_tuples_override ? hp_tuple_cap + worst : std::max(hp_tuple_cap, by_ids) + (1ull << 16);
+          hp_units = 2;
         }
         lanes = false;
         P.hpart = 1; P.gid_shift = 32;
         P.npart = 1; P.part_shift = 0; P.nlevel = 1; P.agg_shift = 0; P.nfine = 1;      // (the scan kernel writes ONE stream per kind; vh_hpart.h partitions it)
-        P.tw = 2;
+        P.tw = 2 * hp_units;
         // payload word: the 64-bit state alone, or up to two 32-bit ones
         int used = 0;
         for (int j = 0; j < P.nmetric; ++j) {
@@ -2488,7 +2491,6 @@ int QueryBuild::layout_scratch() {
   }
   // outputs
   size_t o_tuples = 0, o_emiss = 0, o_epart = 0, o_tuples2 = 0, o_emiss2 = 0, o_epart2 = 0, o_l2 = 0;
-  size_t o_tuplesB = 0, o_emissB = 0, o_epartB = 0, o_tuples2B = 0, o_emiss2B = 0, o_epart2B = 0, o_l2B = 0;
   if (hpart) part_tuple_cap = hp_tuple_cap;
   if (mode == VH_MODE_DENSE_PART || hpart) {
     // extent size: big enough that a wave allocates rarely (every allocation is a returning global
@@ -2497,7 +2499,7 @@ int QueryBuild::layout_scratch() {
     uint64_t et = 1024;                // a tile writes whole runs (<= VH_PART_TILE tuples) that must fit a fresh extent
     while (et < 4096 && et * 2 <= part_tuple_cap / (waves * P.npart) / 2) et *= 2;
     if (knobs().ext_tuples) et = std::max(256, knobs().ext_tuples);     // measurement
-    if (hpart) et = HP_ET;             // (the tiles of hp_scatter_kernel are whole source extents)
+    if (hpart) et = HP_ET / hp_units;  // (the tiles of hp_scatter_kernel are whole source extents: 64 KB of tuples)
     const uint64_t ext_tuples = et;
     P.ext_tuples = (int32_t)ext_tuples;
     // extents of pool 1 start one 128-byte line further apart than they are long (not the stream pools of the hashed partitioning, whose
@@ -2528,27 +2530,19 @@ int QueryBuild::layout_scratch() {
       o_epart2 = sp.take(max2);
       o_l2 = sp.take((VH_L2_WORDS + VH_MAX_PART) * sizeof(uint32_t));
     }
-    if (hpart && hp_pair_cap) {        // the pair tuples' stream: the same geometry, sized for their own count
-      uint64_t mb = hp_pair_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
-      if (mb > 0xFFFFFFF0ull) mb = 0xFFFFFFF0ull;
-      P.max_extentsB = (uint32_t)mb;
-      o_tuplesB = sp.take(mb * ext_tuples * 16);
-      o_emissB = sp.take(mb * sizeof(uint16_t));
-      o_epartB = sp.take(mb);
-    }
   }
-  // hashed partitioning: per kind of tuple the two partitioned pools (vh_hpart.h), their fill / tag arrays and a block of small tables
+  // hashed partitioning: the two partitioned pools (vh_hpart.h), their fill / tag arrays and a block of small tables
   hp_meta_bytes = 8 + (size_t)HP_FAN * 4 + (size_t)(2 * HP_FAN + 2) * 4;      // [level-A cursor | tuples per digit | slices + their cursors]
   if (hpart) {
-    for (int k = 0; k < (hp_pair_cap ? 2 : 1); ++k) {
-      const uint64_t cap = k ? hp_pair_cap : hp_tuple_cap;
+    for (int k = 0; k < 1; ++k) {
+      const uint64_t cap = hp_tuple_cap, hp_et = HP_ET / hp_units, hp_es = hp_et + (uint64_t)knobs().ext_pad / hp_units;      // tuples per extent / between extent starts
       // level A: every block may hold an open extent per digit (+ one fresh one per tile boundary); level B: the slices hp_plan_kernel lays out
-      uint64_t ma = ((cap / HP_ET) / g_ctx.num_cu * 3 / 2 + 2 * HP_FAN + 16) * g_ctx.num_cu;      // one slab per block: its share of the tuples and half again, an open extent per digit, one more per digit for the tails
-      uint64_t mb = cap / HP_ET + (uint64_t)HP_FAN * (2 * HP_FAN + 9) + 64;
+      uint64_t ma = ((cap / hp_et) / g_ctx.num_cu * 3 / 2 + 2 * HP_FAN + 16) * g_ctx.num_cu;      // one slab per block: its share of the tuples and half again, an open extent per digit, one more per digit for the tails
+      uint64_t mb = cap / hp_et + (uint64_t)HP_FAN * (2 * HP_FAN + 9) + 64;
       if (!part_tuples_override && getenv("VH_TEST_PART_EXTENTS2")) mb = std::max(1, atoi(getenv("VH_TEST_PART_EXTENTS2")));   // tests: the last pool runs out
       hpo[k].maxa = ma; hpo[k].maxb = mb;
-      hpo[k].ta = sp.take(ma * (HP_ET + (uint64_t)knobs().ext_pad) * 16); hpo[k].fa = sp.take(ma * 2); hpo[k].ga = sp.take(ma);
-      hpo[k].tb = sp.take(mb * (HP_ET + (uint64_t)knobs().ext_pad) * 16); hpo[k].fb = sp.take(mb * 2); hpo[k].gb = sp.take(mb);
+      hpo[k].ta = sp.take(ma * hp_es * 16 * hp_units); hpo[k].fa = sp.take(ma * 2); hpo[k].ga = sp.take(ma);
+      hpo[k].tb = sp.take(mb * hp_es * 16 * hp_units); hpo[k].fb = sp.take(mb * 2); hpo[k].gb = sp.take(mb);
       hpo[k].meta = sp.take(hp_meta_bytes);
     }
     o_hpargs = sp.take(sizeof(VhHpArgs));
@@ -2597,11 +2591,6 @@ int QueryBuild::layout_scratch() {
   for (int j = 0; j < P.nmetric; ++j) P.m[j].state = S + o_state[j];
   r->d_out_count = reinterpret_cast<unsigned long long*>(S + o_outcount);
   if (mode == VH_MODE_DENSE_PART || hpart) {
-    if (hpart && hp_pair_cap) {
-      P.tuplesB = reinterpret_cast<uint64_t*>(S + o_tuplesB);
-      P.extent_missingB = reinterpret_cast<uint16_t*>(S + o_emissB);
-      P.extent_partB = reinterpret_cast<uint8_t*>(S + o_epartB);
-    }
     P.tuples = reinterpret_cast<uint64_t*>(S + o_tuples);
     P.extent_missing = reinterpret_cast<uint16_t*>(S + o_emiss);
     P.extent_part = reinterpret_cast<uint8_t*>(S + o_epart);
@@ -2676,25 +2665,21 @@ int QueryBuild::launch() {
     if (P.bs_wide[b]) clear(P.dset_tags[b], (P.dset_mask[b] + 1) * 4, 0);
     else clear(P.dset_keys[b], (P.dset_mask[b] + 1) * 8, 0xFF);
   }
-  if (hpart && hp_pair_cap) {
-    clear(P.extent_missingB, (size_t)P.max_extentsB * sizeof(uint16_t), 0);
-    clear(P.extent_partB, (size_t)P.max_extentsB, 0xFF);
-  }
   VhHpArgs* d_hpargs = nullptr;
   if (hpart) {          // the pools behind the scan (vh_hpart.h): descriptors for the kernels, fill arrays and small tables cleared with everything else
     VhHpArgs& HA = r->hp_args;
     memset(&HA, 0, sizeof(HA));
-    HA.nkind = hp_pair_cap ? 2 : 1;
+    HA.units = hp_units;
     HA.passes = P.hp_passes; HA.gslots = P.hp_gslots; HA.sslots = P.hp_sslots; HA.keys_off = P.hp_keys_off; HA.set_off = P.hp_set_off;
     HA.bitset_j = -1;
     for (int j = 0; j < P.nmetric; ++j) if (P.m[j].sop() == SOP_BITSET) HA.bitset_j = j;
     HA.list_cap = capacity; HA.chunk = hp_chunk; HA.ablate = knobs().hp_ablate;
-    for (int k = 0; k < HA.nkind; ++k) {
+    for (int k = 0; k < 1; ++k) {
       VhHpKind& K = HA.k[k];
       char* meta = S + hpo[k].meta;
-      K.z.tuples = k ? P.tuplesB : P.tuples; K.z.fill = k ? P.extent_missingB : P.extent_missing; K.z.tag = k ? P.extent_partB : P.extent_part;
-      K.z.max_extents = k ? P.max_extentsB : P.max_extents; K.z.stream = 1; K.z.cursor = P.counters + (k ? 8 : 5); K.z.stride = HP_ET;
-      K.a.stride = K.b.stride = HP_ET + (uint32_t)knobs().ext_pad;
+      K.z.tuples = P.tuples; K.z.fill = P.extent_missing; K.z.tag = P.extent_part;
+      K.z.max_extents = P.max_extents; K.z.stream = 1; K.z.cursor = P.counters + 5; K.z.stride = (uint32_t)(HP_ET / hp_units);
+      K.a.stride = K.b.stride = (uint32_t)(HP_ET / hp_units) + (uint32_t)knobs().ext_pad / (uint32_t)hp_units;
       K.a.tuples = reinterpret_cast<uint64_t*>(S + hpo[k].ta); K.a.fill = reinterpret_cast<uint16_t*>(S + hpo[k].fa); K.a.tag = reinterpret_cast<uint8_t*>(S + hpo[k].ga);
       K.a.max_extents = (uint32_t)std::min<uint64_t>(hpo[k].maxa, 0xFFFFFFF0ull); K.a.cursor = nullptr;      // (handed out in one slab per block of level A)
       K.b.tuples = reinterpret_cast<uint64_t*>(S + hpo[k].tb); K.b.fill = reinterpret_cast<uint16_t*>(S + hpo[k].fb); K.b.tag = reinterpret_cast<uint8_t*>(S + hpo[k].gb);
@@ -2737,7 +2722,7 @@ int QueryBuild::launch() {
   r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0);
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
-    if (hpart) vh_launch_hpart(P, d_hpargs, hp_pair_cap ? 2 : 1, g_ctx.num_cu, lds_table, hp_bpp, st);
+    if (hpart) vh_launch_hpart(P, d_hpargs, hp_units, g_ctx.num_cu, lds_table, hp_bpp, st);
     if (mode == VH_MODE_DENSE_PART) {
       const bool skip_phase2 = knobs().skip_phase2;     // measurement only (wrong results): phase 1 alone between the events
       if (P.nlevel == 2 && !skip_phase2) vh_launch_part_split(P, split_bpp, st);
