@@ -297,19 +297,27 @@ __global__ __launch_bounds__(BLOCK) void hp_count_kernel(const VhHpArgs* __restr
   __syncthreads();
   if (threadIdx.x < HP_FAN && cnt[threadIdx.x]) atomicAdd(K.count + threadIdx.x, cnt[threadIdx.x]);
 }
-__global__ __launch_bounds__(64) void hp_plan_kernel(const VhHpArgs* __restrict__ HA, unsigned long long* counters) {
+__global__ __launch_bounds__(HP_FAN) void hp_plan_kernel(const VhHpArgs* __restrict__ HA, unsigned long long* counters) {      // one block of HP_FAN threads
+  __shared__ unsigned long long wave_tot[HP_FAN / 64];
   const VhHpKind& K = HA->k[0];
   const uint32_t et = (uint32_t)HP_ET / (uint32_t)HA->units;
-  if (threadIdx.x == 0) {
-    unsigned long long at = 0;
-    for (int a = 0; a < HP_FAN; ++a) {
-      K.slice[a] = (uint32_t)(at < K.b.max_extents ? at : K.b.max_extents);
-      K.slice[HP_FAN + 1 + a] = 0;
-      // what the partition holds, in extents, + one open extent per digit of its single writer + the flush of the tails
-      if (K.count[a]) at += (K.count[a] + et - 1) / et + 2 * HP_FAN + 8;
-    }
-    K.slice[HP_FAN] = (uint32_t)(at < K.b.max_extents ? at : K.b.max_extents);
-    if (at > K.b.max_extents) atomicOr(counters + 2, VH_ERR_PART_FULL);
+  const int a = threadIdx.x, lane = a & 63, wave = a >> 6;
+  // what partition a holds, in extents, + one open extent per digit of its single writer + the flush of the tails
+  const uint32_t c = K.count[a];
+  const unsigned long long need = c ? (unsigned long long)(c + et - 1) / et + 2 * HP_FAN + 8 : 0ull;
+  unsigned long long incl = need;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const unsigned long long o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  unsigned long long before = 0;
+  for (int w = 0; w < wave; ++w) before += wave_tot[w];
+  const unsigned long long at = before + incl - need, end = before + incl;
+  K.slice[a] = (uint32_t)(at < K.b.max_extents ? at : K.b.max_extents);
+  K.slice[HP_FAN + 1 + a] = 0;
+  if (a == HP_FAN - 1) {
+    K.slice[HP_FAN] = (uint32_t)(end < K.b.max_extents ? end : K.b.max_extents);
+    if (end > K.b.max_extents) atomicOr(counters + 2, VH_ERR_PART_FULL);
   }
 }
 

@@ -18,7 +18,7 @@ static void launch_hpart(const VhPlanDev& P, const VhHpArgs* d_args, int num_cu,
   static const int grid_a = getenv("VH_HP_GRID_A") ? atoi(getenv("VH_HP_GRID_A")) : 0;       // measurement
   hipLaunchKernelGGL((hp_scatter_kernel<1024, U>), dim3(grid_a > 0 ? grid_a : num_cu), dim3(1024), sl, s, d_args, 0, P.counters);
   hipLaunchKernelGGL((hp_count_kernel<256>), dim3(num_cu), dim3(256), 0, s, d_args);
-  hipLaunchKernelGGL(hp_plan_kernel, dim3(1), dim3(64), 0, s, d_args, P.counters);
+  hipLaunchKernelGGL(hp_plan_kernel, dim3(1), dim3(HP_FAN), 0, s, d_args, P.counters);
   hipLaunchKernelGGL((hp_scatter_kernel<1024, U>), dim3(HP_FAN), dim3(1024), sl, s, d_args, 1, P.counters);
   hipLaunchKernelGGL((hp_aggregate_kernel<512, U>), dim3(HP_FAN * bpp), dim3(512), agg_lds, s, P, d_args, bpp);
 }

@@ -1965,7 +1965,9 @@ int QueryBuild::choose_organisation() {
           else {
             double s2 = sel;
             if (s2 == 0) { rc = probed_selectivity(&s2); if (rc) { return rc; } }
-            lanes = s2 >= 0.5;
+            // (not when the scan is compiled for the plan: the compiled compacting kernel with whole-line tuple writes matches the
+            // no-compaction form even when every row passes — 13.5 vs 14.1 ms per 1 B rows — and beats it below, profiles/r03/NOTES.md)
+            lanes = s2 >= 0.5 && !jit_try;
           }
         }
       }
@@ -2130,10 +2132,10 @@ int QueryBuild::plan_hashed_partitioning() {
       const double survivors = (double)rows_to_scan * sel;
       const auto seen = t->groups_seen.find(r->group_sig);
       const uint64_t known = p->groups_hint ? p->groups_hint : (seen != t->groups_seen.end() ? seen->second : 0);
-      // worth it when the groups are many (the LDS front table then only wastes probes) and the tuples pay for three more launches
-      // ... and, for now, when a count-distinct is in the plan: groups + COUNT alone run 4.0 ms per 62 M survivors through the plain table
-      // and 8.9 ms through the tuples (profiles/r03/NOTES.md); with the (group, id) set it is 15.9 ms against the tuples' total
-      hpart = (p->flags & VH_PLAN_FORCE_HPART) || (survivors >= 8e6 && known >= 2000000 && nb > 0);
+      // worth it when the groups are many (the LDS front table then only wastes probes) and the tuples pay for three more launches:
+      // C5 (count-distinct) 15.9 ms through the plain table against 5.6 ms, C5t (groups + COUNT alone) 4.0 against 2.8 ms
+      // (profiles/r03/NOTES.md; the first version of the tuple path lost that one, 5-6 ms)
+      hpart = (p->flags & VH_PLAN_FORCE_HPART) || (survivors >= 8e6 && known >= 2000000);
       if (hpart) {
         hp_tuple_cap = part_tuples_override ? part_tuples_override : std::max<uint64_t>((uint64_t)(survivors * 1.25) + 1024, 1ull << 16);
         hp_tuple_cap = std::min<uint64_t>(hp_tuple_cap, rows_to_scan + 1);
