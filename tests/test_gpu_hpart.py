@@ -1,0 +1,145 @@
+"""Hashed partitioning of the hash path (viyadb_amd/csrc/vh_hpart.h) against the oracle on tables small enough for it: the path
+is only taken unasked from 8 M survivors and 2 M groups on, so VH_PLAN_FORCE_HPART asks. What it stands in for is
+`agg_map[agg_tuple.d].Update(agg_tuple.m)` (src/codegen/query/scan.cc:174-177,242) and, for a bitset metric,
+`_j |= metrics._j` + cardinality() (src/codegen/db/store.cc:153-155, src/util/bitset.h:26-67) — so every case is the same
+query through the oracle. Covered: rows with no, one, two and more than two ids (the tuple carries two; the rest follow in
+ids-only tuples), plans without a bitset metric (16-byte tuples), time-truncated keys, SUM / MIN / MAX payloads, ragged
+snapshots, LDS tables that overflow (re-plan with more passes, then without partitioning), pools that run out of extents,
+skew (one group gets everything), and the full-size C5 shape in tests/test_gpu_fullsize.py."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import viya_oracle as vo
+from tests.planner import mirror_table
+from tests.test_gpu_typed import F, run
+from viyadb_amd import capi
+
+pytestmark = pytest.mark.gpu
+HP = capi.PLAN_FORCE_HASH | capi.PLAN_FORCE_HPART | capi.PLAN_FORCE_JIT
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _init():
+    from viyadb_amd import executor
+    executor.init(0)
+    from tests.conftest import JIT_OFF
+    if JIT_OFF:
+        pytest.skip("VH_JIT=off: the hashed partitioning needs the scan kernel compiled for the plan")
+
+
+def sets_table(max_ids, n=30_000, nseg=3, seed=11, id_space=5000, ncode=40, nx=100):
+    rng = np.random.default_rng(seed)
+    tab = vo.Table({"name": "t", "segment_size": n,
+                    "dimensions": [{"name": "c", "type": "ushort"}, {"name": "x", "type": "uint"}, {"name": "ts", "type": "time", "format": "posix"}],
+                    "metrics": [{"name": "users", "type": "bitset", "max": 2 ** 31}, {"name": "count", "type": "count"},
+                                {"name": "v", "type": "int_sum"}, {"name": "lo", "type": "int_min"}]})
+    for _ in range(nseg):
+        sizes = rng.integers(0, max_ids + 1, n)
+        sets = [set(int(v) for v in rng.integers(0, id_space, k)) for k in sizes]
+        tab.add_segment_arrays([rng.integers(0, ncode, n).astype(np.uint16), rng.integers(0, nx, n).astype(np.uint32),
+                                (1496000000 + rng.integers(0, 40 * 86400, n)).astype(np.uint32)],
+                               [sets, np.ones(n, dtype=np.uint32), rng.integers(-1000, 1000, n).astype(np.int32), rng.integers(-10 ** 6, 10 ** 6, n).astype(np.int32)],
+                               None, n)
+    return tab
+
+
+@pytest.fixture(scope="module")
+def sets5():
+    tab = sets_table(5)
+    dt = mirror_table(tab)
+    yield tab, dt
+    dt.close()
+
+
+def took_hpart(res):
+    assert res.path == "hash" and res.hpart and res.jit and "hp_scatter_kernel" in res.kernel and "hp_aggregate_kernel" in res.kernel, (res.path, res.kernel)
+
+
+@pytest.mark.parametrize("max_ids", [0, 1, 2, 3, 7])
+def test_rows_with_any_number_of_ids(max_ids):
+    """0..max_ids ids per row: a tuple carries two of them and says how many count; rows with more send ids-only tuples."""
+    tab = sets_table(max_ids, n=20_000, nseg=2, seed=20 + max_ids)
+    dt = mirror_table(tab)
+    try:
+        res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("lt", "x", "70")}, flags=HP)
+        took_hpart(res)
+        assert res.retries == 0 and res.ngroups == st.ngroups > 2000
+        res, _ = run(tab, dt, {"dimensions": ["c"], "metrics": ["users"]}, flags=HP)          # few groups, many ids each: sets fill up -> more passes
+        assert res.path == "hash"
+    finally:
+        dt.close()
+
+
+def test_payloads_and_key_shapes(sets5):
+    tab, dt = sets5
+    for q in ({"dimensions": ["c", "x"], "metrics": ["users", "count", "v"], "filter": F("ge", "x", "10")},      # two 32-bit states + the set
+              {"dimensions": ["x", "c"], "metrics": ["lo", "users"]},                                              # MIN in the payload word, no filter
+              {"dimensions": ["c", "x"], "metrics": ["count", "v"], "filter": F("lt", "x", "50")},                 # no bitset metric: 16-byte tuples
+              {"dimensions": ["c", "x"], "metrics": ["lo"], "filter": F("ne", "c", "3")},
+              {"select": [{"column": "ts", "granularity": "hour"}, {"column": "c"}, {"column": "users"}, {"column": "count"}]},
+              {"select": [{"column": "ts", "granularity": "day"}, {"column": "x"}, {"column": "count"}], "filter": F("lt", "x", "30")}):
+        res, st = run(tab, dt, q, flags=HP)
+        took_hpart(res)
+        assert res.ngroups == st.ngroups
+    # the same answers as the plain hash table and as the device-wide (group, id) set, bit for bit (compare() checked both against the oracle)
+    run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count", "v"], "filter": F("ge", "x", "10")}, flags=capi.PLAN_FORCE_HASH | capi.PLAN_NO_HPART)
+
+
+def test_ragged_snapshots(sets5):
+    tab, dt = sets5
+    q = {"dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("lt", "x", "90")}
+    for snap in ([30_000, 1, 29_999], [0, 12_345, 0], [63, 64, 65]):
+        res, _ = run(tab, dt, q, flags=HP, seg_rows=snap)
+        took_hpart(res)
+
+
+def test_lds_tables_that_overflow_are_replanned(sets5):
+    """A range whose (group slot, id) set cannot hold its ids flags VH_ERR_HPART_FULL: the query runs again with more passes per range
+    and, when that does not help either (40 groups with ~3 000 distinct ids each: sub-ranges never split a group), without partitioning
+    — the rows are the oracle's either way."""
+    tab, dt = sets5
+    res, st = run(tab, dt, {"dimensions": ["c"], "metrics": ["users", "count"]}, flags=HP)
+    assert res.path == "hash" and res.retries >= 1 and res.ngroups == st.ngroups == 40
+    assert int(res.states[0].max()) > 2000           # (what did not fit: the set is sized for a 65 536th of the table's ids)
+    q = {"dimensions": ["c", "x"], "metrics": ["users", "count"]}
+    os.environ["VH_TEST_HPART_PASSES"] = "4"          # sub-ranges by the next bits of the mixed key
+    try:
+        res, _ = run(tab, dt, q, flags=HP)
+    finally:
+        del os.environ["VH_TEST_HPART_PASSES"]
+    took_hpart(res)
+    assert res.retries == 0
+
+
+def test_pools_that_run_out_of_extents_are_resized(sets5):
+    tab, dt = sets5
+    q = {"dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("lt", "x", "95")}
+    for knob in ("VH_TEST_PART_EXTENTS", "VH_TEST_PART_EXTENTS2"):
+        os.environ[knob] = "3"
+        try:
+            res, _ = run(tab, dt, q, flags=HP)
+        finally:
+            del os.environ[knob]
+        assert res.path == "hash" and res.retries >= 1, knob
+
+
+def test_skew_one_group_gets_everything():
+    """Every row in ONE group with ids from a large space: the range's set cannot hold them in any number of passes, the block's list of
+    extents overflows — the query ends up on the plain hash table and still answers like the oracle."""
+    rng = np.random.default_rng(5)
+    n = 60_000
+    tab = vo.Table({"name": "t", "segment_size": n, "dimensions": [{"name": "c", "type": "ushort"}, {"name": "x", "type": "uint"}],
+                    "metrics": [{"name": "users", "type": "bitset", "max": 2 ** 31}, {"name": "count", "type": "count"}]})
+    for _ in range(3):
+        sets = [set(int(v) for v in rng.integers(0, 10 ** 6, 3)) for _ in range(n)]
+        tab.add_segment_arrays([np.full(n, 7, dtype=np.uint16), np.full(n, 3, dtype=np.uint32)], [sets, np.ones(n, dtype=np.uint32)], None, n)
+    dt = mirror_table(tab)
+    try:
+        res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count"]}, flags=HP)
+        assert res.path == "hash" and res.ngroups == 1 and int(res.states[1][0]) == 3 * n
+        res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["count"]}, flags=HP)      # without the set: one slot takes every tuple
+        assert res.ngroups == 1
+    finally:
+        dt.close()

@@ -1965,9 +1965,10 @@ int QueryBuild::choose_organisation() {
           else {
             double s2 = sel;
             if (s2 == 0) { rc = probed_selectivity(&s2); if (rc) { return rc; } }
-            // (not when the scan is compiled for the plan: the compiled compacting kernel with whole-line tuple writes matches the
-            // no-compaction form even when every row passes — 13.5 vs 14.1 ms per 1 B rows — and beats it below, profiles/r03/NOTES.md)
-            lanes = s2 >= 0.5 && !jit_try;
+            // (not when the scan is compiled for the plan and its tuples leave as whole lines — one level, <= 16 partitions: that kernel
+            // beats the no-compaction form even when every row passes, 13.5 vs 14.1 ms per 1 B rows, profiles/r03/NOTES.md; with two levels
+            // the 64-way phase 1 writes its tuples piecewise and the no-compaction form keeps its lead from 50 % on: 21.4 vs 22.8 ms)
+            lanes = s2 >= 0.5 && !(jit_try && !two_level && np <= VH_STAGE_PARTS);
           }
         }
       }
@@ -2175,7 +2176,6 @@ int QueryBuild::plan_hashed_partitioning() {
           if (hp_passes_override || (!need_g && !need_s) || passes >= 64) break;      // (a re-plan takes the biggest tables that fit, whatever the estimate said)
           passes *= 2;
         }
-        if (const char* env_gs = getenv("VH_TEST_HPART_GSLOTS")) if (!hp_passes_override) gs = (uint32_t)std::max(16, atoi(env_gs));      // tests: tables too small -> the re-plan
         P.hp_passes = (int32_t)passes; P.hp_gslots = (int32_t)gs; P.hp_sslots = (int32_t)ss;
         size_t off = 0;
         P.hp_keys_off = 0; off += (size_t)(P.hp_gslots + 1) * 8;
