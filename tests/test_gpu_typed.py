@@ -576,7 +576,8 @@ def test_random_plans_against_oracle(typed, seed):
 
     flag_pool = [0, 0, 0, 1, 2, 8, 9, 16, 48, 64, 128, 256, 512, 64 | 256, 1 | 512, 8 | 64, 1 | 2048, 9 | 2048, 1 | 2048 | 512, 2048,
                  8192, 8192 | 1, 8192 | 8, 8192 | 64, 8192 | 2, 8192 | 128, 8192 | 1 | 2048,      # 8192: gather from a payload projection
-                 64 | 32768, 64 | 16384, 64 | 8192 | 32768, 65536, 65536 | 64, 65536 | 1]                                  # 32768 / 16384 / 65536: no specialised drain / no second partition level / no narrow predicate copies
+                 64 | 32768, 64 | 16384, 64 | 8192 | 32768, 65536, 65536 | 64, 65536 | 1,                                 # 32768 / 16384 / 65536: no specialised drain / no second partition level / no narrow predicate copies
+                 1 | (1 << 18) | (1 << 20), 1 | (1 << 18) | (1 << 20), 1 | (1 << 18) | (1 << 20) | 8192]                      # hashed partitioning where the plan allows it (one key word, a payload of <= 64 bits)
     done = 0
     for _ in range(40):
         sel = []

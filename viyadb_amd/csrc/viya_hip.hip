@@ -2406,7 +2406,11 @@ int QueryBuild::decompose_work() {
     else snprintf(nm, sizeof(nm), "%s<%d, %d, %d, %d>", lanes ? "scan_agg_lanes_kernel" : "scan_agg_fast_kernel", mode, BLOCK,
                   (mode == VH_MODE_HASH || mode == VH_MODE_DENSE_PART) ? (int)__HIP_MEMORY_SCOPE_AGENT : scope, np_);
     r->kernel = jk ? jk->name : std::string(nm);
-    if (hpart) r->kernel += " + hp_scatter_kernel<1024> + hp_aggregate_kernel<512>";
+    if (hpart) {      // (the scatter kernel runs twice per query, level A and level B: named twice, so that per-query sums over the names count it twice)
+      char hn[160];
+      snprintf(hn, sizeof(hn), " + hp_scatter_kernel<1024, %d> + hp_scatter_kernel<1024, %d> + hp_aggregate_kernel<512, %d>", hp_units, hp_units, hp_units);
+      r->kernel += hn;
+    }
     if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? " + part_agg_kernel<1024>" : (P.tw == 2 && !getenv("VH_NO_SPLIT_TILE")) ? " + part_split_tile_kernel<256> + part_agg_kernel<1024>" : " + part_split_kernel<256> + part_agg_kernel<1024>";
   }
   int occupancy = 0;
