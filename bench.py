@@ -111,7 +111,7 @@ def cpu_baseline(w, sample_segments: int):
     rows_per_seg = w.segment_rows
     ot = build_oracle_table(w, sample_segments, rows_per_seg)
     tw = cpu_twin.Twin(ot, w.query)
-    tw.run()  # warm-up (page-in)
+    state = tw.run()  # warm-up (page-in); its groups also check the GPU's answer over the same rows (main)
     secs = []
     for _ in range(7):
         tw.run()
@@ -122,7 +122,7 @@ def cpu_baseline(w, sample_segments: int):
             "sample": "%d segments x %d rows of %s (same generator, same query), median of 7 runs, "
                       "g++ -O2 -funroll-loops -march=native, 1 thread; %.2f GB/s of referenced bytes"
                       % (sample_segments, rows_per_seg, w.name, rows * w.bytes_per_row_referenced / best / 1e9),
-            "cpu": _cpu_model()}
+            "cpu": _cpu_model()}, state
 
 
 def cpu_baseline_parallel(w, seconds: float = 3.0, segments_per_worker: int = 2):
@@ -371,10 +371,24 @@ def main():
                              "traffic_source": rsrc, "traffic_refused": rwhy,
                              "bref_over_t_GBs": rl.algorithmic_bytes / (rkms * 1e-3) / 1e9}}
         if world == 1 and not args.no_cpu:
+            twin_state = None
             try:
-                out["cpu_baseline"] = cpu_baseline(w, min(args.cpu_segments, total_segments))
+                out["cpu_baseline"], twin_state = cpu_baseline(w, min(args.cpu_segments, total_segments))
             except Exception as e:  # the CPU leg must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "unit": "rows/s", "cores": 1, "kind": "port", "sample": "failed: %r" % (e,)}
+            if twin_state is not None and not args.no_check:
+                # the CPU leg's groups are the oracle's answer for the first cpu_segments segments: the GPU's answer over exactly those
+                # rows (a size() snapshot that hides the rest) must be the same, group for group — a tenth of the table instead of the
+                # two segments the numpy oracle checks before the timed loop. A difference is an error, not a line.
+                from tests.parity import compare
+                ns = min(args.cpu_segments, total_segments)
+                snap = [w.segment_rows] * ns + [0] * (my_segments - ns)
+                wres = table.query_agg(executor.AggPlan(filter=plan.filter, groups=plan.groups, metrics=plan.metrics, flags=plan.flags,
+                                                        groups_hint=plan.groups_hint, seg_rows=snap))
+                twin_state.scanned_recs, twin_state.scanned_segments = wres.scanned_recs, wres.scanned_segments
+                compare(wres, twin_state, "bench parity gate (CPU twin window)")
+                out["parity"]["cpu_twin_window_rows"] = ns * w.segment_rows
+                out["parity"]["cpu_twin_groups"] = twin_state.ngroups
             if args.cpu_parallel:
                 try:
                     out["cpu_baseline_all_cores"] = cpu_baseline_parallel(w)

@@ -9,6 +9,9 @@ executor.init(0)
 w = synth.c3()
 t = synth.create_device_table(w, 125)
 plan = AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, groups_hint=100000)
+t.prepare(plan)
+t.pack(t.gather_columns(plan))
+t.narrow(t.filter_columns(plan))
 for _ in range(5):
     t.query_agg(plan, copy=False)
 n = 200

@@ -1902,9 +1902,9 @@ int QueryBuild::choose_organisation() {
   if (mode == VH_MODE_DENSE_GLOBAL && fastj && !no_part && !(p->flags & (VH_PLAN_NO_PART | VH_PLAN_FORCE_GLOBAL)) && P.nmetric >= 1 && P.nmetric <= VH_FAST_COLS) {
     int shift = 0;
     const size_t part_table_bytes = getenv("VH_PART_TABLE_KB") ? (size_t)atoi(getenv("VH_PART_TABLE_KB")) * 1024 : 128 * 1024;      // (tests shrink it between two queries to force many ranges)   // one 1024-thread block per CU in phase 2 (160 KB LDS)
-    // Phase 2 is bound by LDS read-modify-writes at random addresses (about one lane per clock and CU: 50 M tuples x 3 updates =
-    // 0.29 ms on C3, profiles/r02/NOTES.md), so the presence byte rides in a 32-bit SUM state when there is one (SOP_ADD32P: a
-    // 64-bit word whose upper half counts rows) — two updates per tuple instead of three.
+    // The presence byte rides in a 32-bit SUM state when there is one (SOP_ADD32P: a 64-bit word whose upper half counts rows): two LDS
+    // updates per tuple instead of three. (Round 2 took phase 2 for bound by LDS read-modify-writes; in isolation the LDS does 2.5 such
+    // tuples per clock and CU — 34 us for C3's 50 M — so what the kernel waits for is its tuples: profiles/r03/NOTES.md.)
     int part_carrier = -1;
     if (!(p->flags & VH_PLAN_NO_CARRIER))
       for (int j = 0; j < P.nmetric && part_carrier < 0; ++j) if (P.m[j].sop() == SOP_ADD32) part_carrier = j;
