@@ -386,6 +386,8 @@ def main():
                 wres = table.query_agg(executor.AggPlan(filter=plan.filter, groups=plan.groups, metrics=plan.metrics, flags=plan.flags,
                                                         groups_hint=plan.groups_hint, seg_rows=snap))
                 twin_state.scanned_recs, twin_state.scanned_segments = wres.scanned_recs, wres.scanned_segments
+                if twin_state.passed_recs < 0:       # (the emitted loop keeps no such counter; the groups below are the check)
+                    twin_state.passed_recs = wres.passed_recs
                 compare(wres, twin_state, "bench parity gate (CPU twin window)")
                 out["parity"]["cpu_twin_window_rows"] = ns * w.segment_rows
                 out["parity"]["cpu_twin_groups"] = twin_state.ngroups

@@ -2665,7 +2665,10 @@ int QueryBuild::launch() {
     else if (P.key_words == 1) clear(P.hkeys, table_n * sizeof(uint64_t), 0xFF);
     else clear(P.htags, table_n * sizeof(uint32_t), 0);
   }
-  if (zero_end > zero_begin) clear(S + zero_begin, zero_end - zero_begin, 0);
+  // (DENSE_PART whose blocks each keep a private copy of their range store EVERY group of every copy, present or not: clearing 19
+  // copies of C3's tables, 30 MB, before every query was two thirds of this launch's 17 us. A range's sole block stores present groups only.)
+  const bool part_owned = mode == VH_MODE_DENSE_PART && part_bpp > 1 && nxcd == part_bpp && !knobs().skip_phase2;
+  if (zero_end > zero_begin && !part_owned) clear(S + zero_begin, zero_end - zero_begin, 0);
   r->zero_begin = S + zero_begin; r->zero_end = S + zero_end;
   for (int b = 0; b < P.nbitset && !hpart; ++b) {
     if (P.bs_wide[b]) clear(P.dset_tags[b], (P.dset_mask[b] + 1) * 4, 0);
