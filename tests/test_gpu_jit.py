@@ -38,6 +38,20 @@ def test_c3_table_organisations_compiled(flags, path):
     assert res.jit and res.kernel.startswith("viya_jit_scan_"), res.kernel
 
 
+@pytest.mark.parametrize("table_kb,flags", [(32, 64), (16, 64), (32, 64 | 8192), (8, 64), (8, 64 | 32)])
+def test_c3_with_17_to_64_partitions_compiled(table_kb, flags):
+    """Group-id spaces of 17-64 LDS-sized ranges (VH_PART_TABLE_KB shrinks the ranges: 38 / 75 -> two levels / 150 partitions' worth):
+    the compiled phase 1 keeps a waiting line per partition for up to 64 of them (vh_part_staged_add<64>), one level or two."""
+    import os
+    from viyadb_amd import synth
+    os.environ["VH_PART_TABLE_KB"] = str(table_kb)
+    try:
+        res, _ = check_workload(synth.c3(segment_rows=250_000), nseg=4, flags=flags | J, expect_path="dense_part")
+    finally:
+        del os.environ["VH_PART_TABLE_KB"]
+    assert res.jit and res.kernel.startswith("viya_jit_scan_"), res.kernel
+
+
 @pytest.mark.parametrize("flags,path", [(128, "dense_lds"), (128 | 2, "dense_global"), (128 | 1, "hash"), (128 | 4, "dense_lds")])
 def test_c2_table_organisations_compiled(flags, path):
     """C2's 50 % selectivity would take the no-compaction kernels (pre-built only): VH_PLAN_NO_LANES keeps the compacting form."""

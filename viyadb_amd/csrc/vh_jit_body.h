@@ -231,7 +231,7 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
       vh_part_direct_add<TW, 1, TW>(P, T, W, active, words, (uint32_t)((threadIdx.x & 63) % (VJ_ABL >> 4)), (int)(threadIdx.x & 63));
       return;
     }
-    if constexpr (J::STAGE && TW == 2) vh_part_staged_add(P, T, W, S, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
+    if constexpr (J::STAGE != 0 && TW == 2) vh_part_staged_add<J::STAGE>(P, T, W, S, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
     else vh_part_direct_add<TW, 1, TW>(P, T, W, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
     return;
   }
@@ -290,8 +290,8 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
   V.S = VhPartStage{0u, nullptr};
   if constexpr (MODE == VH_MODE_HASH && J::LDS_HASH) vh_lds_hash_init(P, lds, BLOCK);
   if constexpr (MODE == VH_MODE_DENSE_PART || (MODE == VH_MODE_HASH && J::HPART)) vh_part_tile_init(P, lds, V.T, V.W);
-  if constexpr (MODE == VH_MODE_DENSE_PART && J::STAGE)      // one waiting line per partition and wave, behind the block's queues
-    V.S.lines = reinterpret_cast<uint64_t*>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)wave * VH_STAGE_BYTES);
+  if constexpr (MODE == VH_MODE_DENSE_PART && J::STAGE != 0)      // one waiting line per partition and wave, behind the block's queues
+    V.S.lines = reinterpret_cast<uint64_t*>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)wave * VH_STAGE_BYTES(J::STAGE));
   if constexpr (MODE == VH_MODE_DENSE_LDS) {
     // identities: 0 for SUM/AVG/COUNT, type max for MIN, cpp_min_value for MAX (src/codegen/db/store.cc:107-117)
 #pragma unroll
@@ -361,7 +361,7 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
     if (MODE == VH_MODE_HASH && V.H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
   }
 
-  if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE) vh_part_stage_finish(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); }
+  if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE != 0) vh_part_stage_finish(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); }
   if constexpr (MODE == VH_MODE_HASH && J::HPART) vh_part_tile_finish<1>(P, V.T, lane);
   if (lane == 0) {
     if (npassed) atomicAdd(P.counters + 0, npassed);

@@ -1031,9 +1031,10 @@ __device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTil
 // instruction), and the remainder (< 8 tuples) waits in LDS for the next drain. Extents only ever see aligned 128-byte
 // lines, except for the one partial line that closes an extent (or the kernel).
 // Lane p owns partition p: T.r_ext = its extent, T.r_fill = tuples of it already in HBM (a multiple of 8), r_stage = tuples waiting in LDS.
-#define VH_STAGE_PARTS 16
-#define VH_STAGE_BYTES (VH_STAGE_PARTS * 128)      // per wave
-struct VhPartStage { uint32_t r_stage; uint64_t* lines; };     // lines: LDS [VH_STAGE_PARTS][8][2]
+#define VH_STAGE_PARTS 16                         // the small form: one pass of the line flush covers every partition
+#define VH_STAGE_PARTS_MAX 64                     // the wide form (a wave keeps at most one partition per lane): four passes
+#define VH_STAGE_BYTES(parts) ((parts) * 128)     // per wave
+struct VhPartStage { uint32_t r_stage; uint64_t* lines; };     // lines: LDS [parts][8][2]
 typedef uint64_t vh_u64x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void vh_part_stage_close(const VhPlanDev& P, VhPartTile& T, VhPartStage& S, int q, int lane) {   // wave-uniform q
@@ -1044,13 +1045,17 @@ __device__ __forceinline__ void vh_part_stage_close(const VhPlanDev& P, VhPartTi
   if (lane == 0) P.extent_missing[old] = (uint16_t)(et - (fill + st));
 }
 
+// SP: partitions the wave keeps a waiting line for — VH_STAGE_PARTS (16) or VH_STAGE_PARTS_MAX (64: group-id spaces of 17-64 LDS-sized
+// ranges and phase 1 of two-level plans, which used to fall back to piecewise appends).
+template <int SP>
 __device__ __forceinline__ void vh_part_staged_add(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, VhPartStage& S, bool active,
                                                    const uint64_t (&words)[2], uint32_t p, int lane) {
+  constexpr int BITS = SP <= 16 ? 4 : 6;
   const uint32_t npart = (uint32_t)P.npart, et = (uint32_t)P.ext_tuples, es = (uint32_t)P.ext_stride;
   const uint64_t act = __ballot(active);
   uint64_t peers = act, mine = act;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
+  for (int b = 0; b < BITS; ++b) {
     if ((npart - 1u) >> b) {
       const uint64_t bal = __ballot((p >> b) & 1u);
       peers &= ((p >> b) & 1u) ? bal : ~bal;
@@ -1080,8 +1085,12 @@ __device__ __forceinline__ void vh_part_staged_add(const VhPlanDev& P, VhPartTil
   vh_u64x2 v; v.x = words[0]; v.y = words[1];
   if (ok && i < 8u) lines[p * 8u + i] = v;                                     // completes the waiting line (or just waits with it)
   __builtin_amdgcn_wave_barrier();
-  {   // the waiting line of every partition that now has eight tuples: lane l stores quarter l & 3 of partition l >> 2
-    const uint32_t q = (uint32_t)lane >> 2, part4 = (uint32_t)lane & 3u;
+  // the waiting line of every partition that now has eight tuples: lane l stores quarter l & 3 of partition 16 * pass + (l >> 2)
+  const uint64_t full_lines = __ballot(cnt != 0 && S.r_stage + cnt >= 8u && T.r_ext != ~0u);       // (lane q speaks for partition q)
+#pragma unroll
+  for (int pass = 0; pass < SP / 16; ++pass) {
+    if (!((full_lines >> (16 * pass)) & 0xFFFFull)) continue;                  // (wave-uniform)
+    const uint32_t q = (uint32_t)(16 * pass) + ((uint32_t)lane >> 2), part4 = (uint32_t)lane & 3u;
     const uint32_t qe = (uint32_t)__shfl((int)T.r_ext, (int)q), qk = (uint32_t)__shfl((int)packed, (int)q);
     const uint32_t qg = qk & 0xFFFFu, qf = (qk >> 16) & 0xFFu, qc = qk >> 24;
     if (q < npart && qe != ~0u && qc != 0 && qf + qc >= 8u) {

@@ -2312,7 +2312,7 @@ int QueryBuild::compile_kernel() {
     js.lds_hash = P.lds_hash_slots ? 1 : 0;
     js.gid32 = mode != VH_MODE_HASH && G <= 0xFFFFFFFFull;
     const bool env_no_stage = knobs().no_stage;             // measurement: tuples appended piece by piece (vh_part_direct_add)
-    js.stage = mode == VH_MODE_DENSE_PART && P.tw == 2 && P.npart <= VH_STAGE_PARTS && !env_no_stage;
+    js.stage = mode == VH_MODE_DENSE_PART && P.tw == 2 && !env_no_stage ? (P.npart <= VH_STAGE_PARTS ? VH_STAGE_PARTS : P.npart <= VH_STAGE_PARTS_MAX ? VH_STAGE_PARTS_MAX : 0) : 0;
     js.hpart = hpart ? 1 : 0;
     js.ng = P.ngroup; js.nm = P.nmetric;
     for (int i = 0; i < P.ngroup; ++i) {
@@ -2367,7 +2367,7 @@ void QueryBuild::scan_dispatch(int grid_, int* occ) {
   const size_t lds_ = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + qb;
   hipStream_t s_ = x->stream();
   if (jk) {
-    const size_t jl = ((mode == VH_MODE_DENSE_LDS || (mode == VH_MODE_HASH && !hpart)) ? lds_table : 0) + (size_t)(BLOCK / 64) * (VJ_QUEUE_CAP * sizeof(uint32_t) + (jshape.stage ? VH_STAGE_BYTES : 0));
+    const size_t jl = ((mode == VH_MODE_DENSE_LDS || (mode == VH_MODE_HASH && !hpart)) ? lds_table : 0) + (size_t)(BLOCK / 64) * (VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)VH_STAGE_BYTES(jshape.stage));
     if (occ) *occ = vh_jit_occupancy(jk, BLOCK, jl);
     else (void)vh_jit_launch(jk, P, grid_, BLOCK, jl, s_);
   }
