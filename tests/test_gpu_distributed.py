@@ -115,8 +115,12 @@ def _synth_oracle(wl):
     return vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 9, 50000), w.query), now=getattr(w, "now", None))
 
 
+HPART = 1 | (1 << 18) | (1 << 20)      # hash organisation, compiled scan, hashed partitioning (vh_hpart.h): the ranks' (group, id) pairs then come out of the tuple pool
+
+
 @pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 64), ("C2", 0), ("C2", 2), ("C1", 0), ("C3", 1), ("C5t", 0), ("C5", 0),
-                                      ("C5t", 2048), ("C5", 2048), ("C3", 1 | 2048), ("C3", 16 | 32)])      # 2048: the hash table as records
+                                      ("C5t", 2048), ("C5", 2048), ("C3", 1 | 2048), ("C3", 16 | 32),      # 2048: the hash table as records
+                                      ("C5", HPART), ("C5t", HPART), ("C3", HPART)])
 def test_two_ranks_one_gpu(tmp_path, wl, flags):
     gots = _launch(tmp_path, {"kind": "synth", "wl": wl, "flags": flags}, "gloo", 2)
     st = _synth_oracle(wl)
@@ -132,7 +136,7 @@ def test_one_rank_through_rccl(tmp_path):
         _check(gots, _synth_oracle(wl))
 
 
-@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 1), ("C5t", 0), ("C5", 0)])
+@pytest.mark.parametrize("wl,flags", [("C3", 0), ("C3", 1), ("C5t", 0), ("C5", 0), ("C5", 1 | (1 << 18) | (1 << 20))])
 def test_two_ranks_having_on_merged_groups(tmp_path, wl, flags):
     gots = _launch(tmp_path, {"kind": "synth", "wl": wl, "flags": flags, "having": True}, "gloo", 2)
     st = _synth_oracle(wl)

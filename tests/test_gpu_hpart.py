@@ -143,3 +143,55 @@ def test_skew_one_group_gets_everything():
         assert res.ngroups == 1
     finally:
         dt.close()
+
+
+def test_pairs_for_the_exchange_come_out_of_the_tuple_pool(sets5):
+    """Sharded queries and the cluster merge need a result's (group, id) pairs regrouped by owner (vh_result_partition_pairs). A result
+    of the hashed partitioning kept no device-wide set: the pairs are read out of its last tuple pool — every (group, id) the rows held,
+    duplicates included. As SETS per owner they must be exactly the oracle's, and every pair must sit with the owner of its group."""
+    import ctypes as C
+    tab, dt = sets5
+    q = {"type": "aggregate", "table": "t", "dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("lt", "x", "80")}
+    from tests.planner import plan_from_query
+    from tests.test_gpu_typed import NOW
+    aq = vo.parse_query(tab, q)
+    plan = plan_from_query(tab, aq, now=NOW, flags=HP)
+    h = dt.query_agg_keep(plan)
+    try:
+        res = dt.collect(h, plan)
+        took_hpart(res)
+        nparts = 3
+        goffs, gbufs = dt.partition(h, nparts)
+        offs, bufs = dt.partition_pairs(h, 0, nparts)
+        assert len(bufs) == 3 and int(offs[0]) == 0 and all(b[1] == int(offs[-1]) for b in bufs)
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+        def read(ptr, n, dtype):
+            out = np.empty(int(n), dtype=dtype)
+            if n:
+                assert hip.hipMemcpy(out.ctypes.data, C.c_void_p(ptr), out.nbytes, 4) == 0
+            return out
+        n = int(offs[-1])
+        pc, px, pid = read(bufs[0][0], n, np.uint16), read(bufs[1][0], n, np.uint32), read(bufs[2][0], n, np.uint32)
+        gc, gx = read(gbufs[0][0], int(goffs[-1]), np.uint16), read(gbufs[1][0], int(goffs[-1]), np.uint32)
+        owner_of = {}
+        for part in range(nparts):
+            for k in range(int(goffs[part]), int(goffs[part + 1])):
+                owner_of[(int(gc[k]), int(gx[k]))] = part
+        got = set()
+        for part in range(nparts):
+            for k in range(int(offs[part]), int(offs[part + 1])):
+                key = (int(pc[k]), int(px[k]))
+                assert owner_of[key] == part          # a pair travels to the owner of its group
+                got.add((key, int(pid[k])))
+        # the oracle's sets: every passing row's ids under its group key
+        want = set()
+        for seg in tab.segments:
+            c, x = seg["d"][0][:seg["size"]], seg["d"][1][:seg["size"]]
+            for r in np.nonzero(x < 80)[0]:
+                for i in seg["m"][0][r]:
+                    want.add(((int(c[r]), int(x[r])), int(i)))
+        assert got == want and len(got) > 10_000
+    finally:
+        dt.discard(h)

@@ -605,6 +605,63 @@ __global__ __launch_bounds__(256) void partition_pairs_kernel(const VhPairArgs A
   }
 }
 
+// The same for a result of the hashed partitioning (vh_hpart.h), which keeps no device-wide (group, id) set: the ids still lie in the
+// last tuple pool, next to the mixed key of their row's group — every (group, id) a rank saw, duplicates included, which the owner's set
+// union does not mind. An item is (extent, tuple, first or second id); extents are mostly part full, items beyond their fill are skipped.
+struct VhHpPairArgs {
+  const uint64_t* tuples;          // pool b: 32-byte tuples (mixed key, payload, two ids, how many of them count | ids only)
+  const uint16_t* fill;            // tuples per extent
+  uint32_t max_extents, stride, et;   // extents; tuples between extent starts; tuples an extent can hold
+  int32_t ngroup;
+  uint32_t gkey_shift[VH_MAX_GROUP], gesize[VH_MAX_GROUP];      // (one key word)
+  uint32_t nparts; int32_t pass;
+  void* dst[VH_MAX_GROUP + 1];     // key columns, then the id column (u32)
+  unsigned long long* counts; unsigned long long* cursors; const unsigned long long* offsets;
+};
+__device__ __forceinline__ bool vh_hp_pair_at(const VhHpPairArgs& A, uint64_t i, uint64_t& key, uint32_t& id) {
+  const uint64_t per = (uint64_t)A.et * 2;
+  const uint64_t e = i / per;
+  if (e >= A.max_extents) return false;
+  const uint32_t rem = (uint32_t)(i - e * per), tup = rem >> 1, q = rem & 1u;
+  if (tup >= A.fill[e]) return false;
+  const uint64_t* w = A.tuples + (e * A.stride + tup) * 4;
+  if (q >= (uint32_t)(w[3] & 3ull)) return false;
+  key = vh_unmix64(w[0]);
+  id = q ? (uint32_t)(w[2] >> 32) : (uint32_t)w[2];
+  return true;
+}
+__device__ __forceinline__ uint64_t vh_hp_pair_key(const VhHpPairArgs& A, uint64_t key, int c) {
+  uint64_t v = key >> A.gkey_shift[c];
+  if (A.gesize[c] < 8) v &= (1ull << (8 * A.gesize[c])) - 1ull;     // what the emitted column holds
+  return v;
+}
+__global__ __launch_bounds__(256) void hp_partition_pairs_kernel(const VhHpPairArgs A) {
+  const uint64_t first = (uint64_t)blockIdx.x * (256 * VH_XCHG_SPAN) + threadIdx.x;
+  uint32_t owner[VH_XCHG_SPAN];
+  uint64_t pos[VH_XCHG_SPAN];
+#pragma unroll
+  for (int k = 0; k < VH_XCHG_SPAN; ++k) {
+    uint64_t key = 0; uint32_t id = 0;
+    owner[k] = 0xFFFFFFFFu;
+    pos[k] = 0;
+    if (vh_hp_pair_at(A, first + (uint64_t)k * 256, key, id)) {
+      uint64_t h = 0x9E3779B97F4A7C15ull;
+      for (int c = 0; c < A.ngroup; ++c) h = vh_splitmix64(h ^ vh_hp_pair_key(A, key, c));
+      owner[k] = (uint32_t)(h % A.nparts);
+    }
+  }
+  vh_xchg_positions(A.nparts, A.pass, A.counts, A.cursors, A.offsets, owner, pos);
+  if (A.pass == 0) return;
+#pragma unroll
+  for (int k = 0; k < VH_XCHG_SPAN; ++k) {
+    if (owner[k] == 0xFFFFFFFFu) continue;
+    uint64_t key = 0; uint32_t id = 0;
+    (void)vh_hp_pair_at(A, first + (uint64_t)k * 256, key, id);
+    for (int c = 0; c < A.ngroup; ++c) vh_store_sized(A.dst[c], A.gesize[c], pos[k], vh_hp_pair_key(A, key, c));
+    vh_store_sized(A.dst[A.ngroup], 4u, pos[k], id);
+  }
+}
+
 // The first 512 bytes of a result region — scan counters and the emitted-row count — into the pinned host buffer
 // the emission kernel wrote its rows to (direct emission, see result_finalize_locked).
 __global__ __launch_bounds__(64) void publish_header_kernel(unsigned long long* host, const unsigned long long* dev) {

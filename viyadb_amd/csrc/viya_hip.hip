@@ -2118,7 +2118,10 @@ int QueryBuild::plan_hashed_partitioning() {
   // makes it three more per row. Survivors are instead written out as 16-byte tuples keyed by a bijective mix of the packed group key,
   // radix-partitioned by its top bits (64 ways in the scan kernel, 64 more in part_split_tile_kernel) and aggregated range by range
   // in LDS: sequential traffic of 16 B per tuple and level instead of a 128-byte line read and written per update.
-  if (mode == VH_MODE_HASH && jit_try && (!lanes || (p->flags & VH_PLAN_FORCE_HPART)) && !no_hpart && !(p->flags & VH_PLAN_NO_HPART) && !ag && !device_rows && P.key_words == 1 && P.nmetric >= 1 && rows_to_scan) {
+  // (Sharded queries take it too: what ranks exchange — finalised groups and, for a bitset metric, (group, id) pairs by owner — does not
+  // depend on how a rank aggregated its shard, so the choice need not even agree between ranks; with an agreement it is made from the
+  // agreed figures all the same.)
+  if (mode == VH_MODE_HASH && jit_try && (!lanes || (p->flags & VH_PLAN_FORCE_HPART)) && !no_hpart && !(p->flags & VH_PLAN_NO_HPART) && P.key_words == 1 && P.nmetric >= 1 && rows_to_scan) {
     int bits = 0, nb = 0;
     bool ok = true;
     for (int j = 0; j < P.nmetric; ++j) {
@@ -2133,10 +2136,11 @@ int QueryBuild::plan_hashed_partitioning() {
       const double survivors = (double)rows_to_scan * sel;
       const auto seen = t->groups_seen.find(r->group_sig);
       const uint64_t known = p->groups_hint ? p->groups_hint : (seen != t->groups_seen.end() ? seen->second : 0);
+      const double survivors_dec = ag ? (double)ag->rows_max * sel : survivors;      // (what the decision looks at: the largest shard's)
       // worth it when the groups are many (the LDS front table then only wastes probes) and the tuples pay for three more launches:
       // C5 (count-distinct) 15.9 ms through the plain table against 5.6 ms, C5t (groups + COUNT alone) 4.0 against 2.8 ms
       // (profiles/r03/NOTES.md; the first version of the tuple path lost that one, 5-6 ms)
-      hpart = (p->flags & VH_PLAN_FORCE_HPART) || (survivors >= 8e6 && known >= 2000000);
+      hpart = (p->flags & VH_PLAN_FORCE_HPART) || (survivors_dec >= 8e6 && known >= 2000000);
       if (hpart) {
         hp_tuple_cap = part_tuples_override ? part_tuples_override : std::max<uint64_t>((uint64_t)(survivors * 1.25) + 1024, 1ull << 16);
         hp_tuple_cap = std::min<uint64_t>(hp_tuple_cap, rows_to_scan + 1);
@@ -2903,12 +2907,61 @@ extern "C" int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t 
   if (!r->finalized) return vh_fail(VH_E_INVALID, "result is not finalised");
   if (nparts == 0 || nparts > 64) return vh_fail(VH_E_INVALID, "nparts must be 1..64");
   if (metric < 0 || metric >= (int)r->user_metric.size()) return vh_fail(VH_E_INVALID, "metric %d is not in the plan", metric);
-  if (r->hpart) return vh_fail(VH_E_UNSUPPORTED, "this result was aggregated range by range in LDS and kept no (group, id) set: run the query with VH_PLAN_NO_HPART to exchange its distinct pairs");
   const VhPlanDev& P = r->plan;
   const int dj = r->user_metric[metric];
   if (P.m[dj].sop() != SOP_BITSET) return vh_fail(VH_E_INVALID, "metric %d is not a bitset (count-distinct) metric", metric);
   const int b = (int)P.m[dj].slot();
   if (max_bufs < P.ngroup + 1) return vh_fail(VH_E_INVALID, "need %d buffers", P.ngroup + 1);
+  if (r->hpart) {
+    // hashed partitioning: no device-wide set was built; the ids are read out of the last tuple pool (hp_partition_pairs_kernel), every
+    // one a rank saw — the count is only known after the counting pass, so the buffers are allocated between the passes
+    if (r->hp_args.units != 2) return vh_fail(VH_E_INVALID, "the hashed partitioning carried no ids for metric %d", metric);
+    VH_ENTER();
+    hipStream_t st = r->exec->stream();
+    const VhHpPool& B = r->hp_args.k[0].b;
+    VhHpPairArgs A{};
+    A.tuples = B.tuples; A.fill = B.fill; A.max_extents = B.max_extents; A.stride = B.stride; A.et = (uint32_t)(HP_ET / 2);
+    A.ngroup = P.ngroup; A.nparts = nparts;
+    for (int c = 0; c < P.ngroup; ++c) { A.gkey_shift[c] = P.g[c].key_shift(); A.gesize[c] = (uint32_t)vh_elem_size(P.g[c].type()); }
+    char* ctrbuf = nullptr;
+    HIP_TRY(hipMalloc((void**)&ctrbuf, 3 * 64 * sizeof(unsigned long long) + 8));
+    r->d_pairs.push_back(ctrbuf);
+    unsigned long long* ctr = reinterpret_cast<unsigned long long*>(ctrbuf);
+    HIP_TRY(hipMemsetAsync(ctr, 0, 3 * 64 * sizeof(unsigned long long) + 8, st));
+    A.counts = ctr; A.cursors = ctr + 64;
+    const uint64_t items = (uint64_t)A.max_extents * A.et * 2;
+    const unsigned grid = (unsigned)std::max<uint64_t>(1, (items + 256 * VH_XCHG_SPAN - 1) / (256 * VH_XCHG_SPAN));
+    std::vector<unsigned long long> counts(nparts, 0), offs(nparts + 1, 0);
+    A.pass = 0; A.offsets = nullptr;
+    hipLaunchKernelGGL(hp_partition_pairs_kernel, dim3(grid), dim3(256), 0, st, A);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(counts.data(), ctr, nparts * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (uint32_t q = 0; q < nparts; ++q) offs[q + 1] = offs[q] + counts[q];
+    const uint64_t np = offs[nparts];
+    size_t bytes = 0;
+    std::vector<size_t> off(P.ngroup + 1);
+    for (int c = 0; c <= P.ngroup; ++c) {
+      const uint32_t es = c < P.ngroup ? A.gesize[c] : 4u;
+      off[c] = bytes;
+      bytes += ((size_t)std::max<uint64_t>(np, 1) * es + 255) / 256 * 256;
+    }
+    char* buf = nullptr;
+    HIP_TRY(hipMalloc((void**)&buf, bytes));
+    r->d_pairs.push_back(buf);
+    for (int c = 0; c <= P.ngroup; ++c) A.dst[c] = buf + off[c];
+    if (np) {
+      HIP_TRY(hipMemcpyAsync(ctr + 128, offs.data(), (nparts + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
+      A.pass = 1; A.offsets = ctr + 128;
+      hipLaunchKernelGGL(hp_partition_pairs_kernel, dim3(grid), dim3(256), 0, st, A);
+      HIP_TRY(hipGetLastError());
+      HIP_TRY(hipStreamSynchronize(st));
+    }
+    for (uint32_t q = 0; q <= nparts; ++q) part_offsets[q] = offs[q];
+    for (int c = 0; c <= P.ngroup; ++c) bufs[c] = vh_device_buffer{A.dst[c], np, c < P.ngroup ? (int32_t)P.g[c].type() : VH_U32, -1};
+    *nbufs = P.ngroup + 1;
+    return VH_OK;
+  }
   if (r->mode != VH_MODE_HASH && r->nxcd != 1) return vh_fail(VH_E_UNSUPPORTED, "pairs of an XCD-private dense table");
   VH_ENTER();
   hipStream_t st = r->exec->stream();
