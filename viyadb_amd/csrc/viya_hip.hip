@@ -365,7 +365,8 @@ static int place_scratch(VhExec* x, size_t nb, const VhPlaceHint& h) {
       A.n16[s] = std::min<size_t>(h.stream_bytes[order[s]], (size_t)3 << 30) / 4096 * 256;
     }
   }
-  A.rec = reinterpret_cast<const uint64_t*>(h.gather_src); A.nrec = (uint64_t)h.gather_bytes / 8;
+  A.rec = reinterpret_cast<const uint64_t*>(reinterpret_cast<uintptr_t>(h.gather_src) & ~(uintptr_t)7);      // (a projection's column may start anywhere inside its first record)
+  A.nrec = (uint64_t)h.gather_bytes / 8;
   A.lines = std::min<size_t>(h.pool_bytes, (size_t)1 << 30) / 128;
   // One candidate at a time, each behind a spacer that pushes it away from the last; the search stops once it has seen four candidates and
   // holds one that beats the slowest seen by 5.5 % (both classes seen, a fast one in hand), or when the trials / the memory bound are used up.
