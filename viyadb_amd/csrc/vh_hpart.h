@@ -61,6 +61,13 @@ struct VhHpArgs {
   uint32_t chunk;             // group records a block of hp_aggregate_kernel takes from the list at a time
   uint64_t list_cap;          // records the group list holds (+ one reserved record behind them)
   int32_t ablate;             // measurement only (VH_HP_ABLATE; results are wrong): 1 no id inserts, 2 no records written, 4 no tuples either, 8 no table clears
+  // direct emission: the aggregation kernel writes a range's groups straight into the result's output columns (key columns in the
+  // dimensions' own element types, states in the metrics') at places taken off the result's row counter — no list of group records, no
+  // emission kernel behind it. Taken when no HAVING and no top-N have to look at the groups first.
+  int32_t direct, ngroup;
+  unsigned long long* out_count;
+  void* out_key[VH_MAX_GROUP]; void* out_state[VH_MAX_METRIC];
+  uint32_t gkey_shift[VH_MAX_GROUP], gesize[VH_MAX_GROUP], mesize[VH_MAX_METRIC];
 };
 // blocks hp_aggregate_kernel runs per level-A partition: enough to fill every CU's LDS twice over (a divisor of HP_FAN)
 static inline int vh_hpart_bpp(int num_cu, size_t agg_lds) {
@@ -321,6 +328,15 @@ __global__ __launch_bounds__(HP_FAN) void hp_plan_kernel(const VhHpArgs* __restr
   }
 }
 
+__device__ __forceinline__ void hp_store_sized(void* base, uint32_t esize, unsigned long long i, uint64_t v) {
+  switch (esize) {
+    case 1: reinterpret_cast<uint8_t*>(base)[i] = (uint8_t)v; break;
+    case 2: reinterpret_cast<uint16_t*>(base)[i] = (uint16_t)v; break;
+    case 4: reinterpret_cast<uint32_t*>(base)[i] = (uint32_t)v; break;
+    default: reinterpret_cast<uint64_t*>(base)[i] = v; break;
+  }
+}
+
 // ------------------------------------------------------------------ the ranges, one after the other, in LDS
 __device__ __forceinline__ uint32_t hp_slot(unsigned long long* keys, uint32_t gslots, uint64_t mkey, bool insert, bool& ok) {
   const uint32_t mask = gslots - 1u;
@@ -493,6 +509,28 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
           S.chunk_pos = got; S.chunk_end = got + want;
         }
         __syncthreads();
+      }
+      if (HA->direct && !(abl & 2)) {      // (uniform) the groups go straight into the result's output columns
+        if (tid == 0 && tot) S.base = atomicAdd(HA->out_count, (unsigned long long)tot);
+        __syncthreads();
+        unsigned long long at = S.base + before + (incl - mine);
+        if (tot && S.base + tot <= HA->list_cap) {
+          for (uint32_t g = tid; g <= GS; g += BLOCK) {
+            const unsigned long long mk = gkeys[g];
+            if (mk == VH_HASH_EMPTY) continue;
+            const unsigned long long key = vh_unmix64(g == GS ? VH_HASH_EMPTY : mk);
+            for (int c = 0; c < HA->ngroup; ++c) hp_store_sized(HA->out_key[c], HA->gesize[c], at, key >> HA->gkey_shift[c]);
+            for (int j = 0; j < P.nmetric; ++j) {
+              const VhMetricDev& m = P.m[j];
+              const uint64_t bits = (m.sop() == SOP_BITSET || vh_sop_bytes(m.sop()) == 4) ? (uint64_t)reinterpret_cast<const uint32_t*>(lds + m.lds_off)[g]
+                                                                                             : reinterpret_cast<const uint64_t*>(lds + m.lds_off)[g];
+              hp_store_sized(HA->out_state[j], HA->mesize[j], at, bits);
+            }
+            ++at;
+          }
+        } else if (tot && tid == 0) atomicOr(P.counters + 2, VH_ERR_PART_FULL);
+        __syncthreads();
+        continue;
       }
       const unsigned long long base = S.chunk_pos;
       unsigned long long at = base + before + (incl - mine);
