@@ -393,7 +393,9 @@ VH_API int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part_off
  * the group's key columns + an id column (u32 / u64), regrouped by the owner of the GROUP
  * (the same function as vh_result_partition). The owner loads what it receives with
  * vh_segment_sync (key columns, device addresses) + vh_segment_sync_ids_device (one id per
- * row) and runs the aggregate query again: its count-distinct is the merged cardinality. */
+ * row) and runs the aggregate query again: its count-distinct is the merged cardinality.
+ * A result of the hashed partitioning (vh_result_info.reserved bit 6) kept no device-wide set: its
+ * pairs are read out of its tuple pool and may repeat — the owner's set union does not mind. */
 VH_API int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t nparts,
                                      uint64_t* part_offsets, vh_device_buffer* bufs,
                                      int32_t max_bufs, int32_t* nbufs);

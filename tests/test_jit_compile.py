@@ -18,7 +18,7 @@ SHAPES = {0: "C3: narrow predicate copies, record gathers, tuples for DENSE_PART
           3: "time rollup keys, hash + LDS front table, IN on u8, != on i64",
           4: "wide hash key (double, i16, u64), row-id MIN, NOT IN on u16",
           5: "no filter, no group columns",
-          6: "C5: hashed partitioning, tuples + pair tuples of a bitset metric",
+          6: "C5: hashed partitioning, 32-byte tuples that carry the ids of a bitset metric",
           7: "C3 with the payload in a compressed 8-byte record (i64 in 4 bytes, u32s in 2 and 1)"}
 
 

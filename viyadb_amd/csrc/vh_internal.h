@@ -219,7 +219,6 @@ struct VhPlanDev {
   // tuples — the mixed key is a BIJECTION of the packed 64-bit group key (vh_splitmix64 / vh_unmix64), so equal keys meet in one
   // partition and no key is ever compared through a lossy hash — radix-partitioned by the mixed key's top bits with the machinery
   // above (gid_shift = 32: the partition digits are taken from the top half of word 0), and aggregated range by range in LDS.
-  // Bitset metrics travel as a second kind of tuple, (mixed key, two ids), through pools of their own ("B").
   int32_t hpart;             // 1: this organisation
   int32_t gid_shift;         // bits of tuple word 0 below the 32-bit partition key: 0 (dense gid) or 32 (mixed key)
   int32_t hp_passes;         // sub-ranges a block works through per range (power of two): one LDS table's worth of groups each
@@ -227,19 +226,9 @@ struct VhPlanDev {
   int32_t hp_sslots;         // ... and slots of the LDS (group slot, id) set (0: no bitset metric)
   uint32_t hp_keys_off;      // LDS byte offsets: group keys [hp_gslots + 1] (u64), (group slot, id) set [hp_sslots] (u64);
   uint32_t hp_set_off;       //   metric states at m[j].lds_off [hp_gslots + 1]
-  uint32_t max_extentsB;
-  uint32_t max_extents2B;
-  uint32_t pad_hp;
-  uint64_t* tuplesB;         // pools of the pair tuples, laid out like the pools above
-  uint16_t* extent_missingB;
-  uint8_t* extent_partB;
-  uint64_t* tuples2B;
-  uint16_t* extent_missing2B;
-  uint8_t* extent_part2B;
-  uint32_t* l2B;
   // ---- counters: [0] passed rows, [1] new groups (hash), [2] error flags,
   //                [3] reserved hash slot (key == sentinel) in use, [4] distinct (group, id) pairs,
-  //                [5] extent allocation cursor (DENSE_PART), [8] the same for the pair pool (hashed partitioning)
+  //                [5] extent allocation cursor (DENSE_PART, and the stream pool of the hashed partitioning)
   unsigned long long* counters;
 };
 

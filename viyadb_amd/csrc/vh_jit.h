@@ -26,7 +26,7 @@ struct VhJitCol {           // one gathered value of a survivor
 struct VhJitShape {
   int mode = 0, block = 256, scope = 0, xcd = 0, carrier = -1, tw = 0, key_words = 1, lds_hash = 0, gid32 = 0;
   int stage = 0;                        // DENSE_PART: tuples leave for HBM as whole 128-byte lines (vh_part_staged_add): partitions a wave keeps a waiting line for (16 / 64), 0 = piecewise
-  int hpart = 0, bitset_j = -1;         // HASH: hashed partitioning (hash_part_agg_kernel); the metric that is a bitset (its ids travel as pair tuples)
+  int hpart = 0, bitset_j = -1;         // HASH: hashed partitioning (vh_hpart.h); the metric that is a bitset (its ids travel in the tuples, two at a time)
   int npred = 0;
   VhJitPred pred[VJ_MAX_PRED];
   std::vector<VhProgOp> prog;           // postfix filter; VhProgOp::pslot indexes pred[], ::lit the literal pool

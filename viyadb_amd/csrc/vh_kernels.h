@@ -830,25 +830,22 @@ struct VhPartTile {
   uint32_t r_ext;      // lane p: partition p's current extent (~0u: none) ...
   uint32_t r_fill;     // ... and the tuples already in it
 };
-// LEVEL 1: phase 1 writes pool 1 (partition = gid >> part_shift); LEVEL 2: part_split_kernel writes pool 2 (sub-partition 0..63);
-// LEVEL 3 / 4: the same two pools of the pair tuples of the hashed partitioning (VhPlanDev::tuplesB ...)
-template <int LEVEL> __device__ __forceinline__ uint64_t* vh_pool_tuples(const VhPlanDev& P) { return LEVEL == 1 ? P.tuples : LEVEL == 2 ? P.tuples2 : LEVEL == 3 ? P.tuplesB : P.tuples2B; }
-template <int LEVEL> __device__ __forceinline__ uint16_t* vh_pool_missing(const VhPlanDev& P) { return LEVEL == 1 ? P.extent_missing : LEVEL == 2 ? P.extent_missing2 : LEVEL == 3 ? P.extent_missingB : P.extent_missing2B; }
-template <int LEVEL> __device__ __forceinline__ uint8_t* vh_pool_tags(const VhPlanDev& P) { return LEVEL == 1 ? P.extent_part : LEVEL == 2 ? P.extent_part2 : LEVEL == 3 ? P.extent_partB : P.extent_part2B; }
-template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_et(const VhPlanDev& P) { return (uint32_t)((LEVEL & 1) ? P.ext_tuples : P.ext_tuples2); }
+// LEVEL 1: phase 1 writes pool 1 (partition = gid >> part_shift); LEVEL 2: part_split_kernel writes pool 2 (sub-partition 0..63)
+template <int LEVEL> __device__ __forceinline__ uint64_t* vh_pool_tuples(const VhPlanDev& P) { return LEVEL == 1 ? P.tuples : P.tuples2; }
+template <int LEVEL> __device__ __forceinline__ uint16_t* vh_pool_missing(const VhPlanDev& P) { return LEVEL == 1 ? P.extent_missing : P.extent_missing2; }
+template <int LEVEL> __device__ __forceinline__ uint8_t* vh_pool_tags(const VhPlanDev& P) { return LEVEL == 1 ? P.extent_part : P.extent_part2; }
+template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_et(const VhPlanDev& P) { return (uint32_t)(LEVEL == 1 ? P.ext_tuples : P.ext_tuples2); }
 template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_es(const VhPlanDev& P) { return LEVEL == 1 ? (uint32_t)P.ext_stride : vh_pool_et<LEVEL>(P); }   // tuples between extent starts
-template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_npart(const VhPlanDev& P) { return (LEVEL & 1) ? (uint32_t)P.npart : 64u; }
-// the pools as run-time values (plan / split / aggregation kernels take `which`: 0 = the tuples, 1 = the pair tuples)
+template <int LEVEL> __device__ __forceinline__ uint32_t vh_pool_npart(const VhPlanDev& P) { return LEVEL == 1 ? (uint32_t)P.npart : 64u; }
+// the two pools as run-time values (plan / split kernels)
 struct VhPools {
   uint64_t* t1; uint16_t* miss1; uint8_t* tag1; uint32_t max1; unsigned long long allocated1;
   uint64_t* t2; uint16_t* miss2; uint8_t* tag2; uint32_t max2; uint32_t* l2;
 };
-__device__ __forceinline__ VhPools vh_pools(const VhPlanDev& P, int which) {
+__device__ __forceinline__ VhPools vh_pools(const VhPlanDev& P) {
   VhPools Q;
-  if (which == 0) { Q.t1 = P.tuples; Q.miss1 = P.extent_missing; Q.tag1 = P.extent_part; Q.max1 = P.max_extents; Q.allocated1 = P.counters[5];
-                    Q.t2 = P.tuples2; Q.miss2 = P.extent_missing2; Q.tag2 = P.extent_part2; Q.max2 = P.max_extents2; Q.l2 = P.l2; }
-  else { Q.t1 = P.tuplesB; Q.miss1 = P.extent_missingB; Q.tag1 = P.extent_partB; Q.max1 = P.max_extentsB; Q.allocated1 = P.counters[8];
-         Q.t2 = P.tuples2B; Q.miss2 = P.extent_missing2B; Q.tag2 = P.extent_part2B; Q.max2 = P.max_extents2B; Q.l2 = P.l2B; }
+  Q.t1 = P.tuples; Q.miss1 = P.extent_missing; Q.tag1 = P.extent_part; Q.max1 = P.max_extents; Q.allocated1 = P.counters[5];
+  Q.t2 = P.tuples2; Q.miss2 = P.extent_missing2; Q.tag2 = P.extent_part2; Q.max2 = P.max_extents2; Q.l2 = P.l2;
   return Q;
 }
 __host__ __device__ __forceinline__ size_t vh_part_tile_bytes(const VhPlanDev& P) {
@@ -866,9 +863,9 @@ __device__ __forceinline__ void vh_part_tile_init(const VhPlanDev& P, char* area
 template <int LEVEL>
 __device__ __forceinline__ uint32_t vh_part_new_extent(const VhPlanDev& P, VhPartWave& W, int p, int lane) {
   if (W.chunk_next == W.chunk_end) {
-    if (LEVEL & 1) {
+    if (LEVEL == 1) {
       unsigned long long c = 0;
-      if (lane == 0) c = atomicAdd(P.counters + (LEVEL == 1 ? 5 : 8), (unsigned long long)VH_EXT_CHUNK);
+      if (lane == 0) c = atomicAdd(P.counters + 5, (unsigned long long)VH_EXT_CHUNK);
       c = __shfl(c, 0);
       W.chunk_next = (uint32_t)c;
     } else {
@@ -880,7 +877,7 @@ __device__ __forceinline__ uint32_t vh_part_new_extent(const VhPlanDev& P, VhPar
     W.chunk_end = W.chunk_next + VH_EXT_CHUNK;
   }
   const uint32_t ext = W.chunk_next++;
-  const bool ok = ext < (LEVEL == 1 ? P.max_extents : LEVEL == 3 ? P.max_extentsB : W.limit);
+  const bool ok = ext < (LEVEL == 1 ? P.max_extents : W.limit);
   if (ok && lane == 0) vh_pool_tags<LEVEL>(P)[ext] = (uint8_t)p;
   if (!ok) {
     if (lane == 0) atomicOr(P.counters + 2, VH_ERR_PART_FULL);  // the host re-runs with a larger tuple buffer
@@ -2006,11 +2003,11 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
 // Two launches: every CU counts its share of the extent tags into l2[VH_L2_NEXT + p] (zero when the query starts), one block then
 // turns the counts into slices and resets the cursors. (One block doing both took 0.39 ms for the 100 K extents of a 60 M-tuple pool.)
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void part_l2_count_kernel(const VhPlanDev P, int which = 0) {
+__global__ __launch_bounds__(BLOCK) void part_l2_count_kernel(const VhPlanDev P) {
   __shared__ unsigned int cnt[VH_MAX_PART];
   if (threadIdx.x < VH_MAX_PART) cnt[threadIdx.x] = 0;
   __syncthreads();
-  const VhPools Q = vh_pools(P, which);
+  const VhPools Q = vh_pools(P);
   const uint32_t total = Q.allocated1 < Q.max1 ? (uint32_t)Q.allocated1 : Q.max1;
   for (uint32_t e = blockIdx.x * BLOCK + threadIdx.x; e < total; e += gridDim.x * BLOCK) {
     const uint8_t p = Q.tag1[e];
@@ -2020,8 +2017,8 @@ __global__ __launch_bounds__(BLOCK) void part_l2_count_kernel(const VhPlanDev P,
   if (threadIdx.x < VH_MAX_PART && cnt[threadIdx.x]) atomicAdd(Q.l2 + VH_L2_WORDS + threadIdx.x, cnt[threadIdx.x]);     // (scratch words behind the table proper)
 }
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void part_l2_plan_kernel(const VhPlanDev P, int waves_per_part, int which = 0) {
-  const VhPools Q = vh_pools(P, which);
+__global__ __launch_bounds__(BLOCK) void part_l2_plan_kernel(const VhPlanDev P, int waves_per_part) {
+  const VhPools Q = vh_pools(P);
   if (threadIdx.x == 0) {
     unsigned long long at = 0;
     for (int p = 0; p < P.npart; ++p) {
@@ -2095,8 +2092,7 @@ struct VhSplitTile {             // LDS, behind the sorted copy
 };
 __host__ __device__ __forceinline__ size_t vh_split_tile_bytes() { return (size_t)VH_SPLIT_TILE_TUPLES * 16 + sizeof(VhSplitTile); }
 
-// WHICH: 0 = the tuples, 1 = the pair tuples of the hashed partitioning (their own pools, same layout)
-template <int BLOCK, int WHICH = 0>
+template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev P, int blocks_per_part) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
@@ -2108,12 +2104,12 @@ __global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev 
   VhPartWave W;
   VhPartTile T;
   vh_part_tile_init(P, nullptr, T, W);            // only wave 0 uses them
-  const VhPools Q = vh_pools(P, WHICH);
-  constexpr int L2 = WHICH ? 4 : 2;
+  const VhPools Q = vh_pools(P);
+  constexpr int L2 = 2;
   W.base = Q.l2[part]; W.limit = Q.l2[part + 1]; W.cursor = Q.l2 + VH_L2_NEXT + part;
   const uint32_t total = Q.allocated1 < Q.max1 ? (uint32_t)Q.allocated1 : Q.max1;
   const int gshift = P.gid_shift;      // where the 32-bit partition key sits in word 0
-  const uint32_t ext_tuples = (uint32_t)P.ext_tuples, et2 = (uint32_t)P.ext_tuples2, ext_stride1 = WHICH == 0 ? (uint32_t)P.ext_stride : ext_tuples;
+  const uint32_t ext_tuples = (uint32_t)P.ext_tuples, et2 = (uint32_t)P.ext_tuples2, ext_stride1 = (uint32_t)P.ext_stride;
   u64x2* const pool2 = reinterpret_cast<u64x2*>(Q.t2);
   const uint32_t gsz = vh_tag_group(total, (uint32_t)blocks_per_part);
   for (uint32_t c0 = (uint32_t)b * gsz; c0 < total; c0 += (uint32_t)blocks_per_part * gsz) {
