@@ -346,7 +346,7 @@ def test_rollup_rules_at_query_time(micro):
         dt.close()
 
 
-@pytest.mark.parametrize("flags", [0, 1, 64])
+@pytest.mark.parametrize("flags", [0, 1, 64, 1 | (1 << 18) | (1 << 20)])      # (the last: hashed partitioning where the plan allows it — its groups then go through the list of records, not straight into the output columns)
 def test_having_on_device(typed, flags):
     """HAVING evaluated by the group-emission kernel. Keys, SUM, AVG (raw sum), MIN/MAX, IN, nested and/or."""
     from tests.planner import capi_anynum
