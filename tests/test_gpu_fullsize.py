@@ -144,3 +144,32 @@ def test_c5_per_gpu_share_properties():
         compare(res, st, "C5 125-segment table, 2-segment window")
     finally:
         t.close()
+
+
+def test_tuple_pool_is_placed_by_measurement(tmp_path):
+    """A context that needs a scratch buffer for a tuple pool of >= 256 MB tries candidates out with the query's own access mix and keeps
+    the fastest one it saw (place_scratch, viya_hip.hip; profiles/r03/NOTES.md "Where the tuple pool lands"): the trace of a C3 run over
+    400 M rows names the candidates' scores and the one kept — the fastest, and the buffer the context ends up with —, and
+    VH_PLACE_TRIALS=1 switches the search off."""
+    import json
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--segments", "400", "--steps", "3", "--warmup", "2", "--no-cpu", "--no-check", "--no-reference-layout"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, VH_TRACE_ALLOC="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    cands = [(m.group(1), float(m.group(2))) for m in re.finditer(r"scratch candidate \d+ (\S+) ([0-9.]+) ms", r.stderr)]
+    kept = re.search(r"scratch trial: (\d+) candidates of (\d+) bytes, \d+ spacers of \d+, kept (\d+) \(([0-9.]+) ms\)", r.stderr)
+    assert kept and len(cands) >= int(kept.group(1)) >= 2, r.stderr[-2000:]
+    first = cands[:int(kept.group(1))]
+    best = min(score for _, score in first)
+    assert abs(float(kept.group(4)) - best) < 1e-3 and first[int(kept.group(3))][1] == best
+    # ... and the buffer the context ends up with IS that candidate
+    final = re.findall(r"vh alloc scratch (0x[0-9a-f]+) (\d+)", r.stderr)
+    assert final and final[-1][0] == first[int(kept.group(3))][0] and final[-1][1] == kept.group(2), (final, first)
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["config"]["table_path"] == "dense_part"
+    r1 = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, VH_TRACE_ALLOC="1", VH_PLACE_TRIALS="1"))
+    assert r1.returncode == 0 and "scratch candidate" not in r1.stderr
