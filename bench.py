@@ -325,7 +325,7 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong",
             "parity_checked": bool(checked), "parity": checked,
-            "vs_baseline": None, "dtype": "u32 predicates / int64+u32 integer atomics", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u32 predicates (compared as u8 / u16 where a narrow copy exists) / int64 + u32 integer sums", "data": "synthetic",
             "config": {"workload": "%s: %s" % (w.name if world == 1 else w.name + " sharded (C4)", w.description),
                        "rows": total_rows, "segments": total_segments, "segment_rows": w.segment_rows,
                        "columns": len(w.columns), "table_bytes": total_rows * w.table_bytes_per_row,
