@@ -161,7 +161,7 @@ def test_tuple_pool_is_placed_by_measurement(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, VH_TRACE_ALLOC="1"))
     assert r.returncode == 0, r.stderr[-2000:]
     cands = [(m.group(1), float(m.group(2))) for m in re.finditer(r"scratch candidate \d+ (\S+) ([0-9.]+) ms", r.stderr)]
-    kept = re.search(r"scratch trial: (\d+) candidates of (\d+) bytes, \d+ spacers of \d+, kept (\d+) \(([0-9.]+) ms\)", r.stderr)
+    kept = re.search(r"scratch trial: (\d+) candidates of (\d+) bytes, \d+ spacers of \d+, kept (\d+) \(([0-9.]+) ms", r.stderr)
     assert kept and len(cands) >= int(kept.group(1)) >= 2, r.stderr[-2000:]
     first = cands[:int(kept.group(1))]
     best = min(score for _, score in first)
