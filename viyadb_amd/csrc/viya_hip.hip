@@ -186,6 +186,7 @@ struct vh_table {
   std::map<std::string, std::pair<uint64_t, uint64_t>> sel_cache;   // filter signature + table state -> (passed, sampled) of the selectivity probe
   std::vector<std::unique_ptr<VhPack>> packs;
   std::vector<std::unique_ptr<VhNarrow>> narrows;
+  bool derived_tried = false;                   // place_with_derived ran (once per table)
   std::map<int, uint32_t> pred_seen;                     // column -> queries that filtered on it (automatic narrow copies)
   std::vector<uint64_t> seg_mod;                          // sync_epoch of the last change to a segment's columns
   uint32_t* d_packrows = nullptr; size_t d_packrows_cap = 0;
@@ -343,7 +344,7 @@ struct VhPlaceHint {
 // three quarters of what is free and VH_PLACE_GB = 96 GB; everything but the winner released again), runs the access mix of a partitioning scan in miniature against THIS query's
 // own columns on each (place_probe_kernel: ~1 ms per run) and keeps the fastest. One-off per context and size, like a kernel compile.
 static std::mutex g_place_mu;      // one trial at a time: while it runs, most of the free memory is held (for some tens of milliseconds)
-static int place_scratch(VhExec* x, size_t nb, const VhPlaceHint& h) {
+static int place_search(VhExec* x, size_t nb, const VhPlaceHint& h, void** out_ptr, float* out_score) {
   const int trials = knobs().place_trials;
   std::lock_guard<std::mutex> lk(g_place_mu);
   const auto t_begin = std::chrono::steady_clock::now();
@@ -398,18 +399,14 @@ static int place_scratch(VhExec* x, size_t nb, const VhPlaceHint& h) {
   for (void* sp : spacers) (void)hipFree(sp);
   for (size_t i = 0; i < cand.size(); ++i) if ((int)i != best) (void)hipFree(cand[i]);
   if (best < 0) return 1;
-  x->scratch = static_cast<char*>(cand[best]);
+  *out_ptr = cand[best]; *out_score = best_ms;
   if (knobs().trace_alloc) fprintf(stderr, "vh alloc scratch trial: %zu candidates of %zu bytes, %zu spacers of %zu, kept %d (%.3f ms), %.1f ms in all\n", cand.size(), nb, spacers.size(), spacer,
                                    best, best_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
   return VH_OK;
 }
 
-static int ensure_scratch(VhExec* x, size_t bytes, const VhPlaceHint* hint = nullptr) {
-  if (bytes <= x->scratch_bytes) return VH_OK;
-  HIP_TRY(hipStreamSynchronize(x->stream()));
-  if (x->scratch) { HIP_TRY(hipFree(x->scratch)); x->scratch = nullptr; x->scratch_bytes = 0; }
-  size_t nb = std::max(bytes + bytes / 4, (size_t)1 << 20);
-  if (!hint || place_scratch(x, nb, *hint) != VH_OK) HIP_TRY(hipMalloc(&x->scratch, nb));
+static int install_scratch(VhExec* x, void* ptr, size_t nb) {
+  x->scratch = static_cast<char*>(ptr);
   trace_alloc("scratch", x->scratch, nb);
   x->scratch_bytes = nb;
   if (getenv("VH_POISON")) {   // tests: nothing may depend on what fresh scratch holds
@@ -417,6 +414,72 @@ static int ensure_scratch(VhExec* x, size_t bytes, const VhPlaceHint* hint = nul
     HIP_TRY(hipStreamSynchronize(x->stream()));
   }
   return VH_OK;
+}
+static size_t scratch_size_for(size_t bytes) { return std::max(bytes + bytes / 4, (size_t)1 << 20); }
+static int ensure_scratch(VhExec* x, size_t bytes, const VhPlaceHint* hint = nullptr) {
+  if (bytes <= x->scratch_bytes) return VH_OK;
+  HIP_TRY(hipStreamSynchronize(x->stream()));
+  if (x->scratch) { HIP_TRY(hipFree(x->scratch)); x->scratch = nullptr; x->scratch_bytes = 0; }
+  const size_t nb = scratch_size_for(bytes);
+  void* ptr = nullptr; float score = 0;
+  if (!hint || place_search(x, nb, *hint, &ptr, &score) != VH_OK) HIP_TRY(hipMalloc(&ptr, nb));
+  return install_scratch(x, ptr, nb);
+}
+
+// The pool search compares candidates against the query's read streams WHERE THEY LIE; in about a third of the processes every candidate
+// scores alike and slow, because the class is set by where the projection and the narrow copies landed (tools/derived_probe.py). Once per
+// table, the first time a big tuple pool is placed for a query that reads derived layouts, a second configuration is tried: the derived
+// layouts copied to another place (the table's data stays where it is), the pool search repeated against the copies, and whichever
+// configuration scores better is kept — the other's buffers are released. The probe orders configurations of ONE process reliably; it
+// was not reliable as an absolute measure (profiles/r03/NOTES.md), hence a comparison and not a threshold. *moved: the derived layouts
+// now live elsewhere — the query being planned holds their old addresses and has to be planned again.
+static int place_with_derived(vh_table* t, VhExec* x, size_t bytes, const VhPlaceHint& h, bool* moved) {
+  *moved = false;
+  HIP_TRY(hipStreamSynchronize(x->stream()));
+  if (x->scratch) { HIP_TRY(hipFree(x->scratch)); x->scratch = nullptr; x->scratch_bytes = 0; }
+  const size_t nb = scratch_size_for(bytes);
+  void* A = nullptr; float sA = 0;
+  if (place_search(x, nb, h, &A, &sA) != VH_OK) return VH_OK;        // (no search possible: ensure_scratch allocates plainly)
+  struct Clone { char** ref; char* was; char* now; size_t bytes; };
+  std::vector<Clone> clones;
+  size_t need = 0;
+  for (auto& pk : t->packs) if (pk->base) { clones.push_back(Clone{&pk->base, pk->base, nullptr, (size_t)pk->cap_seg * pk->stride + 256}); need += clones.back().bytes; }
+  for (auto& nw : t->narrows) if (nw->base) { clones.push_back(Clone{&nw->base, nw->base, nullptr, (size_t)nw->cap_seg * nw->stride + 256}); need += clones.back().bytes; }
+  size_t free_b = 0, total_b = 0;
+  const size_t spacer_bytes = (size_t)8 << 30;
+  if (clones.empty() || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b / 2 < need + nb + spacer_bytes) return install_scratch(x, A, nb);
+  void* spacer = nullptr;
+  if (hipMalloc(&spacer, spacer_bytes) != hipSuccess) { (void)hipGetLastError(); spacer = nullptr; }
+  bool ok = true;
+  for (auto& c : clones) {
+    if (hipMalloc((void**)&c.now, c.bytes) != hipSuccess) { (void)hipGetLastError(); c.now = nullptr; ok = false; break; }
+    if (hipMemcpyAsync(c.now, c.was, c.bytes, hipMemcpyDeviceToDevice, x->stream()) != hipSuccess) { (void)hipGetLastError(); ok = false; break; }
+  }
+  if (spacer) (void)hipFree(spacer);
+  if (ok && hipStreamSynchronize(x->stream()) != hipSuccess) { (void)hipGetLastError(); ok = false; }
+  void* B = nullptr; float sB = 0;
+  if (ok) {
+    VhPlaceHint hb = h;
+    auto remap = [&](const void* p) -> const void* {
+      const char* q = static_cast<const char*>(p);
+      for (auto& c : clones) if (q >= c.was && q < c.was + c.bytes) return c.now + (q - c.was);
+      return p;
+    };
+    for (int i = 0; i < hb.nstream; ++i) hb.stream_src[i] = remap(hb.stream_src[i]);
+    hb.gather_src = remap(hb.gather_src);
+    if (place_search(x, nb, hb, &B, &sB) != VH_OK) B = nullptr;
+  }
+  if (knobs().trace_alloc) fprintf(stderr, "vh alloc derived layouts: where they lie %.3f ms, copied elsewhere %.3f ms -> %s\n", sA, B ? sB : 0.f, B && sB < sA * 0.985f ? "moved" : "kept");
+  if (B && sB < sA * 0.985f) {
+    table_quiesce(t);                       // (queries of other contexts may still read the old copies)
+    for (auto& c : clones) { (void)hipFree(c.was); *c.ref = c.now; }
+    (void)hipFree(A);
+    *moved = true;
+    return install_scratch(x, B, nb);
+  }
+  for (auto& c : clones) if (c.now) (void)hipFree(c.now);
+  if (B) (void)hipFree(B);
+  return install_scratch(x, A, nb);
 }
 static int ensure_segrows(VhExec* x, size_t n) {
   if (n <= x->h_segrows_cap) return VH_OK;
@@ -2588,6 +2651,17 @@ int QueryBuild::layout_scratch() {
       ph.gather_src = P.colbase[gs]; ph.gather_bytes = (size_t)nseg * P.colstride[gs];
       ph.gather_bytes -= std::min<size_t>(ph.gather_bytes, 256);      // (a projection's column starts inside its first record)
       ph.pool_off = o_tuples; ph.pool_bytes = (size_t)P.max_extents * (size_t)P.ext_stride * P.tw * 8;
+    }
+    if (sp.off > x->scratch_bytes && ph.pool_bytes >= ((size_t)256 << 20) && !t->derived_tried && knobs().place_trials >= 2 && (!t->packs.empty() || !t->narrows.empty())) {
+      t->derived_tried = true;
+      bool moved = false;
+      rc = place_with_derived(t, x, sp.off, ph, &moved);
+      if (rc) { return rc; }
+      if (moved) {       // the plan built so far holds the old addresses of the derived layouts: once more from the top (the scratch buffer is in place)
+        holder.reset();
+        done = true;
+        return query_launch_locked(t, x, p, out, hash_capacity_override, force_hash, part_tuples_override, no_part, plan_only, summary_out, ag, device_rows, hp_passes_override, no_hpart);
+      }
     }
     rc = ensure_scratch(x, sp.off, &ph);
   }
