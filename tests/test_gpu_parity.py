@@ -83,6 +83,27 @@ def test_empty_table_and_tiny_segments(flags):
     check_workload(w, nseg=2, rows_per_seg=65_537, flags=flags)
 
 
+@pytest.mark.parametrize("flags", [64, 64 | 8, 16, 0])
+def test_partitioned_plan_over_zero_segments(flags):
+    """A table that mirrors no segment yet (and a snapshot that shows none of a table's rows): phase 2 of DENSE_PART never runs, so
+    nobody stores the per-block copies of the ranges — the merge must still find cleared tables, not what the scratch held (ADVICE r03:
+    the `part_owned` shortcut skipped the clear). Part of the VH_POISON re-run below."""
+    from viyadb_amd import synth
+    from viyadb_amd.executor import AggPlan
+    w = synth.c3(segment_rows=50_000)
+    res, st = check_workload(w, nseg=0, flags=flags, check_columns=False)
+    assert res.ngroups == 0 and res.passed_recs == 0
+    dt = synth.create_device_table(w, 2, 50_000)
+    try:
+        # dirty the context's scratch with a real partitioned run first, then ask for nothing
+        full = dt.query_agg(AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=64, groups_hint=100_000))
+        assert full.ngroups > 0
+        res = dt.query_agg(AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=flags, groups_hint=100_000, seg_rows=[0, 0]))
+        assert res.ngroups == 0 and res.passed_recs == 0 and len(res.states[0]) == 0
+    finally:
+        dt.close()
+
+
 def test_nothing_depends_on_what_fresh_scratch_holds():
     """The table-organisation tests again in a fresh process whose device scratch is filled with 0xA5 at allocation
     (VH_POISON): a kernel that reads a word nobody wrote shows up as a wrong result or a fault instead of passing by luck
@@ -93,5 +114,5 @@ def test_nothing_depends_on_what_fresh_scratch_holds():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, VH_POISON="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-k",
-                        "table_organisations or ragged or c5_"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+                        "table_organisations or ragged or c5_ or zero_segments"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

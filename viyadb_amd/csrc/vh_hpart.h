@@ -501,7 +501,7 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
       uint32_t tot = 0, before = 0;
       for (int w = 0; w < BLOCK / 64; ++w) { const uint32_t c = S.wave_tot[w]; tot += c; if (w < wave) before += c; }
       if (tot && S.chunk_pos + tot > S.chunk_end) {       // (uniform) a new chunk of the list: what is left of the old one is marked empty
-        for (unsigned long long i = S.chunk_pos + tid; i < S.chunk_end; i += BLOCK) P.hkeys[i * stride_w] = VH_HASH_EMPTY;
+        for (unsigned long long i = S.chunk_pos + tid; i < S.chunk_end && i < HA->list_cap; i += BLOCK) P.hkeys[i * stride_w] = VH_HASH_EMPTY;      // (a chunk taken beyond the list's end — the attempt is void — is not written to)
         __syncthreads();
         if (tid == 0) {
           const unsigned long long want = tot > HA->chunk ? tot : HA->chunk;
@@ -558,6 +558,6 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
   }
   __syncthreads();
   if (tid == 0 && S.bad) atomicOr(P.counters + 2, VH_ERR_HPART_FULL);
-  for (unsigned long long i = S.chunk_pos + tid; i < S.chunk_end; i += BLOCK) P.hkeys[i * stride_w] = VH_HASH_EMPTY;
+  for (unsigned long long i = S.chunk_pos + tid; i < S.chunk_end && i < HA->list_cap; i += BLOCK) P.hkeys[i * stride_w] = VH_HASH_EMPTY;
 }
 #endif  // VH_HPART_KERNELS

@@ -2415,6 +2415,9 @@ int QueryBuild::compile_kernel() {
         if ((p->flags & VH_PLAN_FORCE_JIT) || vh_jit_policy() == VH_JIT_FORCE) return vh_fail(VH_E_UNSUPPORTED, "per-query kernel requested (VH_PLAN_FORCE_JIT / VH_JIT=force) but unavailable: %s", jerr.c_str());
         vh_plan p2 = *p;
         p2.flags |= VH_PLAN_NO_JIT;
+        // (the organisation must not depend on whether THIS rank could compile: partitioning chosen because a compiled scan makes tuples
+        // cheap stays chosen — the pre-built kernels run it too — so that sharded ranks keep identically laid out partial tables)
+        if (mode == VH_MODE_DENSE_PART) p2.flags |= VH_PLAN_FORCE_PART;
         holder.reset();
         done = true;
         return query_launch_locked(t, x, &p2, out, hash_capacity_override, force_hash, part_tuples_override, no_part, plan_only, summary_out, ag, device_rows, hp_passes_override, no_hpart);
@@ -2750,7 +2753,7 @@ int QueryBuild::launch() {
   }
   // (DENSE_PART whose blocks each keep a private copy of their range store EVERY group of every copy, present or not: clearing 19
   // copies of C3's tables, 30 MB, before every query was two thirds of this launch's 17 us. A range's sole block stores present groups only.)
-  const bool part_owned = mode == VH_MODE_DENSE_PART && part_bpp > 1 && nxcd == part_bpp && !knobs().skip_phase2;
+  const bool part_owned = mode == VH_MODE_DENSE_PART && part_bpp > 1 && nxcd == part_bpp && !knobs().skip_phase2 && P.total_units != 0;      // (no units: phase 2 does not run and nobody stores the copies — they are cleared like any table)
   if (zero_end > zero_begin && !part_owned) clear(S + zero_begin, zero_end - zero_begin, 0);
   r->zero_begin = S + zero_begin; r->zero_end = S + zero_end;
   for (int b = 0; b < P.nbitset && !hpart; ++b) {
