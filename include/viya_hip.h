@@ -194,7 +194,9 @@ enum vh_plan_flags {
                                      VH_E_UNSUPPORTED, not a silent fallback */,
   VH_PLAN_NO_HPART = 1u << 19,    /* ablation: never the hashed partitioning of the hash path (many groups: tuples keyed by
                                      a bijective mix of the group key, radix-partitioned, aggregated range by range in LDS) */
-  VH_PLAN_FORCE_HPART = 1u << 20  /* testing: hashed partitioning whenever the plan is eligible, however small the table  */
+  VH_PLAN_FORCE_HPART = 1u << 20, /* testing: hashed partitioning whenever the plan is eligible, however small the table  */
+  VH_PLAN_NO_HP_PACK = 1u << 21   /* ablation: a count-distinct's tuples keep their ids in words of their own (32 bytes) even when payload,
+                                     two ids and their count would fit the tuple's second word (16 bytes) */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */

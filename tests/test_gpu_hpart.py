@@ -57,19 +57,72 @@ def took_hpart(res):
     assert res.path == "hash" and res.hpart and res.jit and "hp_scatter_kernel" in res.kernel and "hp_aggregate_kernel" in res.kernel, (res.path, res.kernel)
 
 
+@pytest.mark.parametrize("pack", [True, False])
 @pytest.mark.parametrize("max_ids", [0, 1, 2, 3, 7])
-def test_rows_with_any_number_of_ids(max_ids):
-    """0..max_ids ids per row: a tuple carries two of them and says how many count; rows with more send ids-only tuples."""
+def test_rows_with_any_number_of_ids(max_ids, pack):
+    """0..max_ids ids per row: a tuple carries two of them and says how many count; rows with more send ids-only tuples. Both tuple
+    forms: packed (16 bytes: payload, two ids and their count in the second word — COUNT is 1 and the ids are below 5000 here) and
+    with words of their own for the ids (32 bytes, VH_PLAN_NO_HP_PACK)."""
     tab = sets_table(max_ids, n=20_000, nseg=2, seed=20 + max_ids)
     dt = mirror_table(tab)
     try:
-        res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("lt", "x", "70")}, flags=HP)
+        res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("lt", "x", "70")}, flags=HP | (0 if pack else capi.PLAN_NO_HP_PACK))
         took_hpart(res)
+        assert ("hp_aggregate_kernel<512, 1, true>" in res.kernel) == pack and ("hp_aggregate_kernel<512, 2, false>" in res.kernel) == (not pack), res.kernel
         assert res.retries == 0 and res.ngroups == st.ngroups > 2000
         res, _ = run(tab, dt, {"dimensions": ["c"], "metrics": ["users"]}, flags=HP)          # few groups, many ids each: sets fill up -> more passes
         assert res.path == "hash"
     finally:
         dt.close()
+
+
+@pytest.mark.parametrize("id_space,packed", [(2 ** 30, True), (2 ** 31, False)])
+def test_packed_tuples_at_the_widest_ids_that_fit(id_space, packed):
+    """Two ids of 30 bits + a one-bit COUNT fill the second word exactly (61 bits + the count of ids); 31-bit ids do not fit and keep words
+    of their own. A non-negative SUM payload packs next to them at the width its maximum needs."""
+    rng = np.random.default_rng(77)
+    n = 20_000
+    tab = vo.Table({"name": "t", "segment_size": n, "dimensions": [{"name": "c", "type": "ushort"}, {"name": "x", "type": "uint"}],
+                    "metrics": [{"name": "users", "type": "bitset", "max": 2 ** 31}, {"name": "count", "type": "count"}, {"name": "v", "type": "uint_sum"}]})
+    for _ in range(2):
+        sets = [set(int(v) for v in rng.integers(id_space - 5000, id_space, k)) for k in rng.integers(0, 4, n)]
+        tab.add_segment_arrays([rng.integers(0, 40, n).astype(np.uint16), rng.integers(0, 100, n).astype(np.uint32)],
+                               [sets, np.ones(n, dtype=np.uint32), rng.integers(0, 1000, n).astype(np.uint32)], None, n)
+    dt = mirror_table(tab)
+    try:
+        res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count"]}, flags=HP)
+        took_hpart(res)
+        assert ("1, true>" in res.kernel) == packed, res.kernel
+        assert res.retries == 0 and res.ngroups == st.ngroups == 4000 and int(res.states[0].max()) >= 5
+        if id_space == 2 ** 30:          # 10 bits of SUM payload on top: 1 + 10 + 60 > 61 -> words of their own again
+            res, _ = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count", "v"]}, flags=HP)
+            took_hpart(res)
+            assert "2, false>" in res.kernel, res.kernel
+    finally:
+        dt.close()
+
+
+def test_packed_payload_next_to_small_ids(sets5):
+    """COUNT + a non-negative SUM in the packed word; a SUM with negative values (or a MIN of them) keeps the 32-byte form."""
+    tab, dt = sets5
+    res, _ = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("ge", "x", "10")}, flags=HP)
+    took_hpart(res)
+    assert "1, true>" in res.kernel
+    res, _ = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count", "v"], "filter": F("ge", "x", "10")}, flags=HP)
+    took_hpart(res)
+    assert "2, false>" in res.kernel
+
+
+def test_ids_beyond_the_recorded_range_void_the_packed_attempt(sets5):
+    """The packed word is sized from the segments' recorded largest id. Should data and record ever disagree (forced here: the planner is
+    told 4 bits), the scan flags VH_ERR_HP_WIDE instead of cutting ids short, and the query answers from the plain hash table."""
+    tab, dt = sets5
+    os.environ["VH_TEST_HP_IDBITS"] = "4"
+    try:
+        res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("lt", "x", "60")}, flags=HP)
+    finally:
+        del os.environ["VH_TEST_HP_IDBITS"]
+    assert res.path == "hash" and not res.hpart and res.retries >= 1 and res.ngroups == st.ngroups
 
 
 def test_payloads_and_key_shapes(sets5):

@@ -53,7 +53,11 @@ struct VhHpKind {             // the three pools of the tuples
 };
 struct VhHpArgs {
   VhHpKind k[1];
-  int32_t units;              // 16-byte units per tuple: 1, or 2 when the tuples carry the ids of a bitset metric
+  int32_t units;              // 16-byte units per tuple: 1, or 2 when the tuples carry the ids of a bitset metric in words of their own
+  // PACKED tuples (round 4): a bitset metric's tuple in 16 bytes — word 0 the mixed key, word 1 = payload | id 0 << pk_pbits | id 1 <<
+  // (pk_pbits + pk_idbits) | ids that count << 61 | "ids only" << 63 — whenever the values fit: the planner knows the metric columns' min / max
+  // and the largest id of the scanned segments (refresh_stats, VhColumn::bs_maxid). Half the bytes through every stage (C5: 2 GB -> 1 GB of tuples).
+  int32_t pk, pk_pbits, pk_idbits;
   int32_t passes;             // hp_aggregate_kernel: sub-ranges per range (power of two)
   int32_t gslots, sslots;     // its LDS tables: group slots (+ 1), (group slot, id) set slots (0: no bitset metric)
   uint32_t keys_off, set_off; // LDS byte offsets (metric states at VhPlanDev::m[j].lds_off)
@@ -374,8 +378,9 @@ struct HpAggLds {
 
 // grid: HP_FAN x blocks_per_partition; block (a, j) works through ranges (a, b), b = j, j + blocks_per_partition, ...
 // U = 16-byte units per tuple: 1 (mixed key, payload) or 2 (mixed key, payload, two ids, how many of them count | ids only).
-template <int BLOCK, int U>
+template <int BLOCK, int U, bool PK = false>
 __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, const VhHpArgs* __restrict__ HA, int blocks_per_partition) {
+  constexpr bool IDS = U == 2 || PK;             // the tuples carry ids
   typedef HpTuple<U> T;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   __shared__ HpAggLds S;
@@ -437,7 +442,7 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
           else reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = m.ident;
         }
       }
-      if (U == 2 && !(abl & 8)) for (uint32_t g = tid; g < SS; g += BLOCK) skeys[g] = VH_HASH_EMPTY;
+      if (IDS && !(abl & 8)) for (uint32_t g = tid; g < SS; g += BLOCK) skeys[g] = VH_HASH_EMPTY;
       __syncthreads();
       bool bad = false;
       if (abl & 4) {      // (the tuples are still looked at)
@@ -447,27 +452,30 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
         continue;
       }
       uint32_t* const card = reinterpret_cast<uint32_t*>(lds + P.m[bitset_j < 0 ? 0 : bitset_j].lds_off);
-      const int set_shift = U == 2 ? 32 - (31 - __builtin_clz(SS | 1u)) : 0;
+      const int set_shift = IDS ? 32 - (31 - __builtin_clz(SS | 1u)) : 0;
+      const int pk_pb = PK ? HA->pk_pbits : 0, pk_ib = PK ? HA->pk_idbits : 0;
+      const uint64_t pk_pmask = PK && pk_pb < 64 ? (1ull << pk_pb) - 1ull : ~0ull, pk_imask = (1ull << pk_ib) - 1ull;
       // ---- a tuple: the group's slot (claimed if new), the metric values of its payload word, then its ids into the (group slot, id) set
       auto tuple = [&](const T& tp) {
-        const uint64_t mkey = tp.v[0].x, payload = tp.v[0].y;
+        const uint64_t mkey = tp.v[0].x, w1 = tp.v[0].y, payload = PK ? w1 & pk_pmask : w1;
         if (sub_bits && (int)((uint32_t)(mkey >> (48 - sub_bits)) & (uint32_t)(passes - 1)) != pass) return;
         bool ok = true;
         const uint32_t slot = hp_slot(gkeys, GS, mkey, true, ok);
         if (!ok) { bad = true; return; }
-        const uint64_t meta = U == 2 ? tp.v[U - 1].y : 0ull;
+        const uint64_t meta = PK ? w1 >> 61 : U == 2 ? tp.v[U - 1].y : 0ull;      // bits 0-1: ids that count, bit 2: ids only
         if (!(meta & HP_IDS_ONLY)) {
           for (int j = 0; j < P.nmetric; ++j) {
             const VhMetricDev& m = P.m[j];
             if (m.sop() == SOP_BITSET) continue;
             uint64_t v = payload >> m.tshift();
-            if (vh_sop_bytes(m.sop()) == 4) { v &= 0xFFFFFFFFull; if (vh_sop_sext(m.sop())) v = (uint64_t)(int64_t)(int32_t)v; }
+            if (PK && m.tbits) v &= (1ull << m.tbits) - 1ull;      // (packed values are never negative: the planner checked the column's minimum)
+            else if (vh_sop_bytes(m.sop()) == 4) { v &= 0xFFFFFFFFull; if (vh_sop_sext(m.sop())) v = (uint64_t)(int64_t)(int32_t)v; }
             vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, slot, m.sop(), v);
           }
         }
-        if (U == 2 && !(abl & 1)) {
-          const uint64_t ids = tp.v[U - 1].x;
-          const uint32_t idv[2] = {(uint32_t)ids, (uint32_t)(ids >> 32)};
+        if (IDS && !(abl & 1)) {
+          const uint64_t ids = PK ? 0ull : tp.v[U - 1].x;
+          const uint32_t idv[2] = {PK ? (uint32_t)((w1 >> pk_pb) & pk_imask) : (uint32_t)ids, PK ? (uint32_t)((w1 >> (pk_pb + pk_ib)) & pk_imask) : (uint32_t)(ids >> 32)};
           const int n = (int)(meta & 3ull);
           for (int q = 0; q < n; ++q) {
             const unsigned long long key = ((unsigned long long)slot << 32) | idv[q];

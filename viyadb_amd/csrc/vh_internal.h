@@ -115,7 +115,7 @@ struct VhMetricDev {
   VH_PACKED_FIELD(tword, w1, 0, 8)     // DENSE_PART: tuple word that carries this metric's value
   VH_PACKED_FIELD(tshift, w1, 8, 8)    // DENSE_PART: bit offset inside that word (0 or 32)
   uint32_t lds_off;    // DENSE_LDS / DENSE_PART phase 2 / hash front table: byte offset of this metric's state array in LDS
-  uint32_t pad1;
+  uint32_t tbits;      // hashed partitioning, packed tuples: bits the value takes in the tuple's second word (0: its state's full width)
   void* state;         // global state array (G or capacity elements, 4 or 8 B each)
   uint64_t ident;      // identity bits: 0 (SUM/AVG/COUNT), type max (MIN), cpp_min_value (MAX)
 };
@@ -239,6 +239,7 @@ struct VhPlanDev {
 #define VH_ERR_HASH_FULL 2ull  // probe limit hit
 #define VH_ERR_PART_FULL 4ull  // tuple extents exhausted
 #define VH_ERR_HPART_FULL 8ull // hashed partitioning: an LDS table of hash_part_agg_kernel overflowed (more passes, or the plain hash table)
+#define VH_ERR_HP_WIDE 16ull   // hashed partitioning, packed tuples: a value or an id needed more bits than the column's recorded min / max said (the plain hash table)
 
 static inline int vh_elem_size(int e) {
   switch (e) {

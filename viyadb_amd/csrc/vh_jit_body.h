@@ -160,7 +160,44 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
 #pragma unroll
     for (int j = 0; j < NM; ++j)
       if (J::m_sop[j] != SOP_BITSET) payload |= (vh_sop_bytes(J::m_sop[j]) == 4 ? (mv[j] & 0xFFFFFFFFull) : mv[j]) << J::m_tshift[j];
-    if constexpr (J::BITSET_J >= 0 && !(VJ_ABL & 4)) {
+    if constexpr (J::BITSET_J >= 0 && J::HP_PACK && !(VJ_ABL & 4)) {
+      // PACKED: the row in ONE 16-byte tuple — word 1 = payload | id 0 << PB | id 1 << (PB + IB) | ids that count << 61 (| ids only << 63 on
+      // the tuples behind a row's first). The planner sized PB and IB from the columns' recorded min / max and the segments' largest id;
+      // a value that needs more bits voids the attempt (VH_ERR_HP_WIDE: stats and data disagree — the plain hash table answers instead).
+      constexpr int PB = J::HP_PBITS, IB = J::HP_IDBITS;
+      constexpr uint64_t IMASK = (1ull << IB) - 1ull;
+      uint64_t left = bk1 - bk;
+      uint64_t pk = 0ull;
+      bool wide = false;
+#pragma unroll
+      for (int j = 0; j < NM; ++j)
+        if (J::m_sop[j] != SOP_BITSET) {
+          const uint64_t v = vh_sop_bytes(J::m_sop[j]) == 4 ? (mv[j] & 0xFFFFFFFFull) : mv[j];
+          if (J::m_tbits[j] < 64) wide |= (v >> J::m_tbits[j]) != 0ull;
+          pk |= v << J::m_tshift[j];
+        }
+      if (left == 0) bid0 = 0u;
+      if (left < 2) bid1 = 0u;            // (the merged load read whatever lies behind the row's only id)
+      wide |= (((uint64_t)bid0 | (uint64_t)bid1) & ~IMASK) != 0ull;
+      if (__ballot(active && wide)) { if (active && wide) atomicOr(P.counters + 2, VH_ERR_HP_WIDE); }
+      const uint64_t words[2] = {mkey, pk | ((uint64_t)bid0 << PB) | ((uint64_t)bid1 << (PB + IB)) | ((left < 2 ? left : 2ull) << 61)};
+      if (!(VJ_ABL & 8)) vh_part_direct_add<2, 1, 2>(P, T, W, active, words, p, lane);
+      else if (words[0] + words[1] == 0x123456789ABCDEFull) P.counters[7] = 1;
+      bool more = active && left > 2;
+      while (__ballot(more)) {
+        bk += 2; left -= 2;
+        if (more) {
+          if (VJ_BS_MERGE) { const vj_u32x2_a4 i2 = *VJ_GLOBAL(vj_u32x2_a4, bids + bk); bid0 = i2.x; bid1 = i2.y; }
+          else { bid0 = bids[bk]; bid1 = left > 1 ? bids[bk + 1] : 0u; }
+          if (left < 2) bid1 = 0u;
+          if ((((uint64_t)bid0 | (uint64_t)bid1) & ~IMASK) != 0ull) atomicOr(P.counters + 2, VH_ERR_HP_WIDE);
+        }
+        const uint64_t w2[2] = {mkey, ((uint64_t)bid0 << PB) | ((uint64_t)bid1 << (PB + IB)) | ((left < 2 ? left : 2ull) << 61) | (1ull << 63)};
+        if (!(VJ_ABL & 8)) vh_part_direct_add<2, 1, 2>(P, T, W, more, w2, p, lane);
+        else if (w2[1] == 0x123456789ABCDEFull) P.counters[7] = 1;
+        more = more && left > 2;
+      }
+    } else if constexpr (J::BITSET_J >= 0 && !(VJ_ABL & 4)) {
       // word 2: two ids, word 3: how many of them count | HP_IDS_ONLY (4) on the tuples behind a row's first
       uint64_t left = bk1 - bk;
       uint64_t words[4] = {mkey, payload, (uint64_t)bid0 | ((uint64_t)bid1 << 32), left < 2 ? left : 2ull};

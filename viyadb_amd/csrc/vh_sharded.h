@@ -258,7 +258,8 @@ __global__ void sharded_flags_kernel(const unsigned long long* counters, unsigne
   flags[9] = ngroups;
   flags[10] = changed;
   flags[11] = (err & VH_ERR_HPART_FULL) ? 1 : 0;
-  for (int i = 12; i < VH_FLAG_WORDS; ++i) flags[i] = 0;
+  flags[12] = (err & VH_ERR_HP_WIDE) ? 1 : 0;
+  for (int i = 13; i < VH_FLAG_WORDS; ++i) flags[i] = 0;
 }
 
 // vh_query_agg with the rows kept in device memory (they are exchanged or gathered next). Same re-plan loop.
@@ -576,7 +577,7 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
       if (lrc && !local_err[0]) snprintf(local_err, sizeof(local_err), "%s", g_err);
     }
     // ---- 3. verdict: error flags, row counters and the table organisation of every rank, all-reduced
-    const unsigned long long host_err = retry == 1 ? VH_ERR_HASH_FULL : retry == 2 ? VH_ERR_RANGE : retry == 3 ? VH_ERR_PART_FULL : retry == 4 ? VH_ERR_HPART_FULL : 0ull;
+    const unsigned long long host_err = retry == 1 ? VH_ERR_HASH_FULL : retry == 2 ? VH_ERR_RANGE : retry == 3 ? VH_ERR_PART_FULL : retry == 4 ? VH_ERR_HPART_FULL : retry == 6 ? VH_ERR_HP_WIDE : 0ull;
     hipLaunchKernelGGL(sharded_flags_kernel, dim3(1), dim3(64), 0, st, r && !sparse ? r->plan.counters : nullptr, comm->d_flags, host_err,
                        (unsigned long long)(lrc ? 1 : 0), r ? r->info.scanned_recs : 0ull, r ? r->info.scanned_segments : 0ull,
                        (unsigned long long)(r ? (sparse ? 100 + (r->mode == VH_MODE_HASH ? 0 : r->mode) : r->mode) : 0), r && sparse ? r->info.ngroups : 0ull,
@@ -595,7 +596,7 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
     const unsigned long long my_mode = r ? (sparse ? 100 + (r->mode == VH_MODE_HASH ? 0 : r->mode) : r->mode) : 0;
     if (f[7] != (unsigned long long)W * my_mode || f[8] != (unsigned long long)W * my_mode * my_mode)
       return vh_fail(VH_E_DEVICE, "ranks planned different table organisations for one query (this rank: %llu): plans or table shapes differ between ranks", my_mode);
-    const int verdict = f[11] ? 4 : f[1] ? 1 : f[2] ? 3 : f[0] ? 2 : 0;      // same priority as a single-GPU query's re-plan
+    const int verdict = f[12] ? 6 : f[11] ? 4 : f[1] ? 1 : f[2] ? 3 : f[0] ? 2 : 0;      // same priority as a single-GPU query's re-plan
     if (verdict) {
       if (r) r->info.passed_recs = f[6];                          // all ranks' survivors: an upper bound for the tuple pools of any one of them
       replan_after(t, r, verdict, &rp);                           // every rank re-plans; the requests are merged in step 1 of the next attempt

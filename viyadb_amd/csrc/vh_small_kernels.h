@@ -609,7 +609,8 @@ __global__ __launch_bounds__(256) void partition_pairs_kernel(const VhPairArgs A
 // last tuple pool, next to the mixed key of their row's group — every (group, id) a rank saw, duplicates included, which the owner's set
 // union does not mind. An item is (extent, tuple, first or second id); extents are mostly part full, items beyond their fill are skipped.
 struct VhHpPairArgs {
-  const uint64_t* tuples;          // pool b: 32-byte tuples (mixed key, payload, two ids, how many of them count | ids only)
+  const uint64_t* tuples;          // pool b: 32-byte tuples (mixed key, payload, two ids, how many of them count | ids only), or packed 16-byte ones (vh_hpart.h)
+  int32_t pk, pk_pbits, pk_idbits, pad;
   const uint16_t* fill;            // tuples per extent
   uint32_t max_extents, stride, et;   // extents; tuples between extent starts; tuples an extent can hold
   int32_t ngroup;
@@ -624,6 +625,14 @@ __device__ __forceinline__ bool vh_hp_pair_at(const VhHpPairArgs& A, uint64_t i,
   if (e >= A.max_extents) return false;
   const uint32_t rem = (uint32_t)(i - e * per), tup = rem >> 1, q = rem & 1u;
   if (tup >= A.fill[e]) return false;
+  if (A.pk) {
+    const uint64_t* w = A.tuples + (e * A.stride + tup) * 2;
+    const uint64_t w1 = w[1];
+    if (q >= (uint32_t)((w1 >> 61) & 3ull)) return false;
+    key = vh_unmix64(w[0]);
+    id = (uint32_t)((w1 >> (A.pk_pbits + (q ? A.pk_idbits : 0))) & ((1ull << A.pk_idbits) - 1ull));
+    return true;
+  }
   const uint64_t* w = A.tuples + (e * A.stride + tup) * 4;
   if (q >= (uint32_t)(w[3] & 3ull)) return false;
   key = vh_unmix64(w[0]);

@@ -126,6 +126,7 @@ struct VhColumn {
   std::vector<uint64_t*> bs_offsets;
   std::vector<void*> bs_values;
   std::vector<uint64_t> bs_nvalues;
+  std::vector<uint64_t> bs_maxid;      // an upper bound of the segment's ids (what the packed tuples of the hashed partitioning are sized from)
 };
 struct VhSegStat {          // order keys as produced by seg_minmax_kernel
   uint64_t lo = ~0ull, hi = 0;
@@ -211,7 +212,7 @@ static int table_grow(vh_table* t, uint32_t need_seg) {
   uint32_t ncap = std::max<uint32_t>(need_seg, std::max<uint32_t>(4, t->cap_seg * 2));
   for (auto& c : t->cols) {
     if (is_bitset_elem(c.elem)) {
-      c.bs_offsets.resize(ncap, nullptr); c.bs_values.resize(ncap, nullptr); c.bs_nvalues.resize(ncap, 0);
+      c.bs_offsets.resize(ncap, nullptr); c.bs_values.resize(ncap, nullptr); c.bs_nvalues.resize(ncap, 0); c.bs_maxid.resize(ncap, 0);
       continue;
     }
     char* nb = nullptr;
@@ -504,10 +505,13 @@ static int ensure_segrows(VhExec* x, size_t n) {
     default: { typedef double T; CALL; } break;          \
   }
 
-// Refresh SegmentStats of dimension columns for segments [first, first+n).
+// Refresh the per-segment min / max of every fixed-width column for segments [first, first+n). For NUMERIC / TIME dimensions these are the
+// reference's SegmentStats (store.cc:171-201: segment skipping, dense digit ranges); for the other columns — metrics included, which the
+// reference keeps no stats for — they tell the planner how many BITS the values really use: compressed records (vh_table_pack), narrow
+// predicate copies and the packed tuples of the hashed partitioning (vh_hpart.h) are sized from them. One pass over the segment in HBM.
 static int refresh_stats(vh_table* t, uint32_t first, uint32_t n) {
   int ndim = 0;
-  for (auto& c : t->cols) ndim += is_dim(c.kind) && !is_bitset_elem(c.elem);
+  for (auto& c : t->cols) ndim += !is_bitset_elem(c.elem);
   if (!ndim || !n) return VH_OK;
   const size_t stat_bytes = (size_t)ndim * n * 2 * sizeof(unsigned long long);
   const size_t rows_bytes = (size_t)n * sizeof(uint32_t);
@@ -528,7 +532,7 @@ static int refresh_stats(vh_table* t, uint32_t first, uint32_t n) {
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));  // init is a stack/heap buffer
   int di = 0;
   for (auto& c : t->cols) {
-    if (!is_dim(c.kind) || is_bitset_elem(c.elem)) continue;
+    if (is_bitset_elem(c.elem)) continue;
     dim3 grid((unsigned)std::min<uint64_t>(64, (t->segment_rows + 4095) / 4096), n);
     unsigned long long* st = d_stats + (size_t)di * n * 2;
     VH_ELEM_SWITCH(c.elem, (seg_minmax_kernel<T><<<grid, dim3(256), 0, g_ctx.stream>>>(
@@ -542,7 +546,7 @@ static int refresh_stats(vh_table* t, uint32_t first, uint32_t n) {
   di = 0;
   for (size_t ci = 0; ci < t->cols.size(); ++ci) {
     auto& c = t->cols[ci];
-    if (!is_dim(c.kind) || is_bitset_elem(c.elem)) continue;
+    if (is_bitset_elem(c.elem)) continue;
     for (uint32_t s = 0; s < n; ++s) {
       t->stats[ci][first + s].lo = host[((size_t)di * n + s) * 2];
       t->stats[ci][first + s].hi = host[((size_t)di * n + s) * 2 + 1];
@@ -624,6 +628,12 @@ extern "C" int vh_segment_sync_bitset(vh_table* t, uint32_t seg, int32_t col, ui
   HIP_TRY(hipMemcpy(c.bs_offsets[seg], offsets, (nrows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
   if (nvals) HIP_TRY(hipMemcpy(c.bs_values[seg], values, nvals * vsz, hipMemcpyHostToDevice));
   c.bs_nvalues[seg] = nvals;
+  {
+    uint64_t mx = 0;
+    if (c.elem == VH_BITSET32) { const uint32_t* v = static_cast<const uint32_t*>(values); for (uint64_t i = 0; i < nvals; ++i) mx = std::max<uint64_t>(mx, v[i]); }
+    else { const uint64_t* v = static_cast<const uint64_t*>(values); for (uint64_t i = 0; i < nvals; ++i) mx = std::max(mx, v[i]); }
+    c.bs_maxid[seg] = mx;
+  }
   t->nseg = std::max(t->nseg, seg + 1);
   return VH_OK;
 }
@@ -651,6 +661,7 @@ extern "C" int vh_segment_sync_ids_device(vh_table* t, uint32_t seg, int32_t col
   if (nrows) HIP_TRY(hipMemcpyAsync(c.bs_values[seg], d_ids, nrows * vsz, hipMemcpyDefault, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   c.bs_nvalues[seg] = nrows;
+  c.bs_maxid[seg] = c.elem == VH_BITSET32 ? 0xFFFFFFFFull : ~0ull;      // (exchanged ids, never looked at on this side: the type's range)
   t->nseg = std::max(t->nseg, seg + 1);
   return VH_OK;
 }
@@ -683,6 +694,7 @@ extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nse
         if (vsz == 4) gen_csr_kernel<uint32_t><<<grid, 256, 0, g_ctx.stream>>>(c.bs_offsets[seg], (uint32_t*)c.bs_values[seg], rows_per_seg, k, rb, specs[i].mod, colseed);
         else gen_csr_kernel<uint64_t><<<grid, 256, 0, g_ctx.stream>>>(c.bs_offsets[seg], (uint64_t*)c.bs_values[seg], rows_per_seg, k, rb, specs[i].mod, colseed);
         c.bs_nvalues[seg] = rows_per_seg * k;
+        c.bs_maxid[seg] = specs[i].mod - 1;      // (ids are drawn from [0, mod))
         t->device_bytes += (rows_per_seg + 1) * 8 + rows_per_seg * k * vsz;
       }
       continue;
@@ -814,7 +826,7 @@ static int column_stored_width(vh_table* t, int col, int* width_out) {
   *width_out = (int)c.esize;
   if (c.elem == VH_F32 || c.elem == VH_F64 || c.esize == 1 || !t->nseg) return VH_OK;
   uint64_t lo = ~0ull, hi = 0;
-  if (is_dim(c.kind) && (size_t)col < t->stats.size() && t->stats[col].size() >= t->nseg) {
+  if ((size_t)col < t->stats.size() && t->stats[col].size() >= t->nseg) {      // (refresh_stats keeps min / max of every fixed-width column, metrics included)
     for (uint32_t s = 0; s < t->nseg; ++s) { const VhSegStat& st = t->stats[col][s]; if (st.lo > st.hi) continue; lo = std::min(lo, st.lo); hi = std::max(hi, st.hi); }
   } else {
     const uint32_t n = t->nseg;
@@ -1410,6 +1422,8 @@ struct QueryBuild {
   bool hpart = false;
   uint64_t hp_tuple_cap = 0;
   int hp_units = 1;                 // 16-byte units per tuple of the hashed partitioning: 2 when the tuples carry the ids of a bitset metric
+  bool hp_pack = false;             // ... or 1 all the same: payload, two ids and their count packed into the tuple's second word (VhHpArgs::pk)
+  int hp_pbits = 0, hp_idbits = 0;
   int hp_bpp = 1;
   uint32_t hp_chunk = 256;
   bool packed = false, packed_compressed = false;
@@ -2214,6 +2228,35 @@ int QueryBuild::plan_hashed_partitioning() {
           const uint64_t by_ids = std::min<uint64_t>(worst, (uint64_t)(((double)bitset_ids[0] * std::max(sel, 0.02) * 1.25 + (double)hp_tuple_cap) / 2) + (1ull << 16));
           hp_tuple_cap = part_tuples_override ? hp_tuple_cap + worst : std::max(hp_tuple_cap, by_ids) + (1ull << 16);
           hp_units = 2;
+          // Packed tuples: 16 bytes instead of 32 when the payload values and two ids fit ONE word next to their count. The bits come from
+          // what the mirror knows about the scanned segments: min / max of the metric columns (refresh_stats), the largest id (bs_maxid).
+          auto bits_of = [](uint64_t v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; };
+          bool fits = !(p->flags & VH_PLAN_NO_HP_PACK) && !getenv("VH_NO_HP_PACK");
+          int pbits = 0, mb[VH_MAX_METRIC] = {};
+          for (int j = 0; j < P.nmetric && fits; ++j) {
+            if (P.m[j].sop() == SOP_BITSET) continue;
+            const int col = metric_col[j];
+            if (col < 0) { fits = false; break; }                                       // (the virtual row id)
+            const VhColumn& c = t->cols[col];
+            if (c.elem == VH_F32 || c.elem == VH_F64) { fits = false; break; }
+            uint64_t klo = ~0ull, khi = 0;
+            for (uint32_t sgi : live) { const VhSegStat& st = t->stats[col][sgi]; if (st.lo > st.hi) continue; klo = std::min(klo, st.lo); khi = std::max(khi, st.hi); }
+            if (klo > khi) { klo = khi = order_key_of_bits(c.elem, 0); }
+            const bool sgn = c.elem == VH_I8 || c.elem == VH_I16 || c.elem == VH_I32 || c.elem == VH_I64;
+            const uint64_t vlo = bits_of_order_key(c.elem, klo), vhi = bits_of_order_key(c.elem, khi);
+            if (sgn && ((int64_t)(klo ^ (1ull << 63)) < 0)) { fits = false; break; }     // negative values: the tuple's fields are unsigned
+            (void)vlo;
+            mb[j] = bits_of(sgn ? (khi ^ (1ull << 63)) : vhi);
+            pbits += mb[j];
+          }
+          uint64_t maxid = 0;
+          for (uint32_t sgi : live) maxid = std::max(maxid, t->cols[bitset_col[0]].bs_maxid[sgi]);
+          int idbits = bits_of(maxid);
+          if (const char* e = getenv("VH_TEST_HP_IDBITS")) idbits = std::max(1, atoi(e));      // tests: ids that do NOT fit -> VH_ERR_HP_WIDE -> the plain hash table
+          if (fits && idbits <= 32 && pbits + 2 * idbits <= 61) {
+            hp_pack = true; hp_units = 1; hp_pbits = pbits; hp_idbits = idbits;
+            for (int j = 0; j < P.nmetric; ++j) P.m[j].tbits = (uint32_t)mb[j];
+          }
         }
         lanes = false;
         P.hpart = 1; P.gid_shift = 32;
@@ -2224,7 +2267,7 @@ int QueryBuild::plan_hashed_partitioning() {
         for (int j = 0; j < P.nmetric; ++j) {
           if (P.m[j].sop() == SOP_BITSET) continue;
           P.m[j].set_tword(1); P.m[j].set_tshift((uint8_t)used);
-          used += 8 * vh_sop_bytes(P.m[j].sop());
+          used += hp_pack ? (int)P.m[j].tbits : 8 * vh_sop_bytes(P.m[j].sop());
         }
         // LDS tables of hp_aggregate_kernel, one of 65 536 ranges at a time: group slots for the range's expected groups at <= 70 % load,
         // (group slot, id) slots likewise; what does not fit even 4096 / 16384 slots is worked through in passes
@@ -2383,6 +2426,7 @@ int QueryBuild::compile_kernel() {
     const bool env_no_stage = knobs().no_stage;             // measurement: tuples appended piece by piece (vh_part_direct_add)
     js.stage = mode == VH_MODE_DENSE_PART && P.tw == 2 && !env_no_stage ? (P.npart <= VH_STAGE_PARTS ? VH_STAGE_PARTS : P.npart <= VH_STAGE_PARTS_MAX ? VH_STAGE_PARTS_MAX : 0) : 0;
     js.hpart = hpart ? 1 : 0;
+    js.hp_pack = hp_pack ? 1 : 0; js.hp_pbits = hp_pbits; js.hp_idbits = hp_idbits;
     js.ng = P.ngroup; js.nm = P.nmetric;
     for (int i = 0; i < P.ngroup; ++i) {
       const VhGroupDev& g = P.g[i];
@@ -2401,7 +2445,7 @@ int QueryBuild::compile_kernel() {
       c.rowid = m.slot() == VH_SLOT_ROWID;
       c.bitset = m.sop() == SOP_BITSET;
       if (c.bitset) js.bitset_j = j;
-      c.type = (int)m.type(); c.sop = (int)m.sop(); c.tword = (int)m.tword(); c.tshift = (int)m.tshift();
+      c.type = (int)m.type(); c.sop = (int)m.sop(); c.tword = (int)m.tword(); c.tshift = (int)m.tshift(); c.tbits = hp_pack ? (int)m.tbits : 0;
       c.sext = vh_sop_sext((int)m.sop());
       if (!c.rowid && !c.bitset) { c.slot = (int)m.slot(); c.pitch = (int)P.colpitch[m.slot()]; c.rec = slot_rec[m.slot()]; c.off = slot_recoff[m.slot()]; c.stored = slot_stored[m.slot()]; }
     }
@@ -2480,7 +2524,7 @@ int QueryBuild::decompose_work() {
     r->kernel = jk ? jk->name : std::string(nm);
     if (hpart) {      // (the scatter kernel runs twice per query, level A and level B: named twice, so that per-query sums over the names count it twice)
       char hn[160];
-      snprintf(hn, sizeof(hn), " + hp_scatter_kernel<1024, %d> + hp_scatter_kernel<1024, %d> + hp_aggregate_kernel<512, %d>", hp_units, hp_units, hp_units);
+      snprintf(hn, sizeof(hn), hp_pack ? " + hp_scatter_kernel<1024, %d> + hp_scatter_kernel<1024, %d> + hp_aggregate_kernel<512, %d, true>" : " + hp_scatter_kernel<1024, %d> + hp_scatter_kernel<1024, %d> + hp_aggregate_kernel<512, %d, false>", hp_units, hp_units, hp_units);
       r->kernel += hn;
     }
     if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? " + part_agg_kernel<1024>" : (P.tw == 2 && !getenv("VH_NO_SPLIT_TILE")) ? " + part_split_tile_kernel<256> + part_agg_kernel<1024>" : " + part_split_kernel<256> + part_agg_kernel<1024>";
@@ -2764,7 +2808,7 @@ int QueryBuild::launch() {
   if (hpart) {          // the pools behind the scan (vh_hpart.h): descriptors for the kernels, fill arrays and small tables cleared with everything else
     VhHpArgs& HA = r->hp_args;
     memset(&HA, 0, sizeof(HA));
-    HA.units = hp_units;
+    HA.units = hp_units; HA.pk = hp_pack ? 1 : 0; HA.pk_pbits = hp_pbits; HA.pk_idbits = hp_idbits;
     HA.passes = P.hp_passes; HA.gslots = P.hp_gslots; HA.sslots = P.hp_sslots; HA.keys_off = P.hp_keys_off; HA.set_off = P.hp_set_off;
     HA.bitset_j = -1;
     for (int j = 0; j < P.nmetric; ++j) if (P.m[j].sop() == SOP_BITSET) HA.bitset_j = j;
@@ -2822,7 +2866,7 @@ int QueryBuild::launch() {
   r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0);
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
-    if (hpart) vh_launch_hpart(P, d_hpargs, hp_units, g_ctx.num_cu, lds_table, hp_bpp, st);
+    if (hpart) vh_launch_hpart(P, d_hpargs, hp_units, hp_pack, g_ctx.num_cu, lds_table, hp_bpp, st);
     if (mode == VH_MODE_DENSE_PART) {
       const bool skip_phase2 = knobs().skip_phase2;     // measurement only (wrong results): phase 1 alone between the events
       if (P.nlevel == 2 && !skip_phase2) vh_launch_part_split(P, split_bpp, st);
@@ -3002,12 +3046,13 @@ extern "C" int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t 
   if (r->hpart) {
     // hashed partitioning: no device-wide set was built; the ids are read out of the last tuple pool (hp_partition_pairs_kernel), every
     // one a rank saw — the count is only known after the counting pass, so the buffers are allocated between the passes
-    if (r->hp_args.units != 2) return vh_fail(VH_E_INVALID, "the hashed partitioning carried no ids for metric %d", metric);
+    if (r->hp_args.units != 2 && !r->hp_args.pk) return vh_fail(VH_E_INVALID, "the hashed partitioning carried no ids for metric %d", metric);
     VH_ENTER();
     hipStream_t st = r->exec->stream();
     const VhHpPool& B = r->hp_args.k[0].b;
     VhHpPairArgs A{};
-    A.tuples = B.tuples; A.fill = B.fill; A.max_extents = B.max_extents; A.stride = B.stride; A.et = (uint32_t)(HP_ET / 2);
+    A.tuples = B.tuples; A.fill = B.fill; A.max_extents = B.max_extents; A.stride = B.stride; A.et = (uint32_t)(HP_ET / r->hp_args.units);
+    A.pk = r->hp_args.pk; A.pk_pbits = r->hp_args.pk_pbits; A.pk_idbits = r->hp_args.pk_idbits;
     A.ngroup = P.ngroup; A.nparts = nparts;
     for (int c = 0; c < P.ngroup; ++c) { A.gkey_shift[c] = P.g[c].key_shift(); A.gesize[c] = (uint32_t)vh_elem_size(P.g[c].type()); }
     char* ctrbuf = nullptr;
@@ -3210,6 +3255,7 @@ static int result_finalize(vh_result* r, int* retry) {
   HIP_TRY(wait_event_spinning(x->ev[3]));
   const unsigned long long* hc = reinterpret_cast<const unsigned long long*>(H);
   const unsigned long long err = hc[2];
+  if (err & VH_ERR_HP_WIDE) { *retry = 6; return VH_OK; }        // packed tuples met a value beyond the recorded min / max: the plain hash table
   if (err & VH_ERR_HPART_FULL) { *retry = 4; return VH_OK; }
   if (err & VH_ERR_HASH_FULL) { *retry = 1; return VH_OK; }
   if (err & VH_ERR_PART_FULL) { r->info.passed_recs = hc[0]; *retry = 3; return VH_OK; }   // phase 1 ran to the end: the survivors are counted
@@ -3289,6 +3335,7 @@ static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
     }
     rp->cap_override = next;
   }
+  else if (retry == 6) rp->no_hpart = true;
   else if (retry == 4) {                                     // hashed partitioning: a range held more groups (or ids) than its passes' LDS tables take
     if (r->plan.hp_passes >= 64) rp->no_hpart = true;        // ... skewed beyond help: the plain hash table
     else rp->hp_passes = (uint32_t)r->plan.hp_passes * 4;
