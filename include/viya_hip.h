@@ -249,7 +249,8 @@ typedef struct vh_result_info {
                                 bit 4: predicate columns streamed from narrow copies (vh_table_narrow);
                                 bit 5: a scan kernel compiled for this plan shape ran (vh_jit.hip);
                                 bit 6: hashed partitioning of the hash path (vh_hpart.h);
-                                bit 7: the projection's records are compressed (integers at the width their values need) */
+                                bit 7: the projection's records are compressed (integers at the width their values need);
+                                bit 8: the hashed partitioning's tuples were packed (16 bytes: payload, two ids and their count in one word) */
   uint64_t returned_groups;  /* rows vh_result_copy delivers (= ngroups without HAVING) */
 } vh_result_info;
 

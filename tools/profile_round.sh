@@ -29,7 +29,7 @@ one() {   # name (workload[_variant]), rows, bref, bench args...
   case $W in c3|c5)      # instruction mix of the kernels the line names (its own pass: SQ counters)
     (cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -d $REPO/$OUT/pmc_insts_$W -o $W -- python $REPO/bench.py "$@" --steps 3 --warmup 1 --no-cpu --no-check --no-reference-layout > $REPO/$OUT/pmc_insts_$W.log 2>&1)
     { echo "# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -- python bench.py $* --steps 3 --warmup 1 --no-cpu --no-check (head $HEAD, sources $SRC): wave-level instructions per launch"
-      for KK in viya_jit part_agg hp_scatter hp_aggregate scan_agg; do python tools/pmc_kernel.py $OUT/pmc_insts_$W $KK; done; } > $OUT/${W}_1gpu_pmc_insts.txt;;
+      for KK in viya_jit part_agg hp_scatter scan_agg; do python tools/pmc_kernel.py $OUT/pmc_insts_$W $KK; done; } > $OUT/${W}_1gpu_pmc_insts.txt;;
   esac
 }
 one c3_arena 1000000000 32e9 --no-pack --no-cpu              # the reference layout: column arenas only (bench.py's reference_layout leg reads this pass)

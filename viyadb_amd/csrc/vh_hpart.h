@@ -377,10 +377,19 @@ struct HpAggLds {
 #define HP_IDS_ONLY 4ull    // tuples that carry ids, word 3: bits 0-1 = ids that count (0..2), bit 2 = the payload was sent with another tuple of the row
 
 // grid: HP_FAN x blocks_per_partition; block (a, j) works through ranges (a, b), b = j, j + blocks_per_partition, ...
-// U = 16-byte units per tuple: 1 (mixed key, payload) or 2 (mixed key, payload, two ids, how many of them count | ids only).
-template <int BLOCK, int U, bool PK = false>
-__global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, const VhHpArgs* __restrict__ HA, int blocks_per_partition) {
-  constexpr bool IDS = U == 2 || PK;             // the tuples carry ids
+// Compiled PER PLAN SHAPE, next to the query's scan kernel (vh_jit.hip emits `viya_jit_hpagg_<hash>`, which is this body over the traits struct
+// `J` of the shape): which states there are, how they are updated, where a tuple's payload fields and ids sit and what the output columns'
+// element types are, are compile-time constants. Round 3's pre-built form walked the plan's metric descriptors per tuple and per group —
+// counters: 651 M SALU + 308 M VALU wave instructions per C5 launch, about half the kernel's cycles in instruction issue.
+//   U = 16-byte units per tuple: 1 (mixed key, payload — or the PACKED form with two ids in the payload word) or 2 (mixed key, payload, two
+//   ids, how many of them count | ids only).
+template <class J, int BLOCK>
+__device__ __forceinline__ void hp_aggregate_body(const VhPlanDev& P, const VhHpArgs* __restrict__ HA, int blocks_per_partition) {
+  constexpr bool PK = J::HP_PACK;
+  constexpr bool IDS = J::BITSET_J >= 0;         // the tuples carry ids
+  constexpr int U = (IDS && !PK) ? 2 : 1;
+  constexpr int NM = J::NM, NG = J::NG;
+  constexpr int PB = PK ? J::HP_PBITS : 0, IB = PK ? J::HP_IDBITS : 32;
   typedef HpTuple<U> T;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   __shared__ HpAggLds S;
@@ -389,12 +398,15 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
   unsigned long long* const gkeys = reinterpret_cast<unsigned long long*>(lds + HA->keys_off);
   unsigned long long* const skeys = reinterpret_cast<unsigned long long*>(lds + HA->set_off);
   const uint32_t GS = (uint32_t)HA->gslots, SS = (uint32_t)HA->sslots;
-  const int passes = HA->passes, bitset_j = HA->bitset_j;
+  const int passes = HA->passes;
   const int sub_bits = 31 - __builtin_clz((uint32_t)passes | 1u);
   const uint32_t stride_w = P.hrec_bytes / 8u;
   const VhHpKind& K = HA->k[0];
   const uint32_t es = K.b.stride;
   const T* const pool = reinterpret_cast<const T*>(K.b.tuples);
+  char* mstate[NM ? NM : 1];
+#pragma unroll
+  for (int j = 0; j < NM; ++j) mstate[j] = lds + P.m[j].lds_off;
   // ---- which extent of slice a holds which range: ONE look at the slice's tags for all the block's ranges
   for (int i = tid; i < HP_FAN; i += BLOCK) S.ext1[i] = ~0u;
   if (tid == 0) { S.chunk_pos = 0; S.chunk_end = 0; S.novf = 0; S.bad = 0; }
@@ -424,6 +436,10 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
     for (int u = 0; u < N; ++u) if ((uint32_t)(u * BLOCK + tid) < f0) g[u] = pool[(uint64_t)e0 * es + u * BLOCK + tid];
   };
   prefetch(j0, ng);
+  const int abl = HA->ablate;
+  uint32_t* const card = reinterpret_cast<uint32_t*>(mstate[IDS ? J::BITSET_J : 0]);
+  const int set_shift = IDS ? 32 - (31 - __builtin_clz(SS | 1u)) : 0;
+  constexpr uint64_t PMASK = PK && PB < 64 ? (1ull << PB) - 1ull : ~0ull, IMASK = (1ull << IB) - 1ull;
   for (int b = j0; b < HP_FAN; b += blocks_per_partition) {
     T cg[N];
 #pragma unroll
@@ -432,17 +448,18 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
     prefetch(b + blocks_per_partition, ng);
     if (f0 == 0) continue;                       // (uniform: an empty range)
     for (int pass = 0; pass < passes; ++pass) {
-      const int abl = HA->ablate;
-      if (!(abl & 8)) for (uint32_t g = tid; g <= GS; g += BLOCK) {
-        gkeys[g] = VH_HASH_EMPTY;
-        for (int j = 0; j < P.nmetric; ++j) {
-          const VhMetricDev& m = P.m[j];
-          if (m.sop() == SOP_BITSET) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = 0u;       // (a cardinality never exceeds the set's slots)
-          else if (vh_sop_bytes(m.sop()) == 4) reinterpret_cast<uint32_t*>(lds + m.lds_off)[g] = (uint32_t)m.ident;
-          else reinterpret_cast<uint64_t*>(lds + m.lds_off)[g] = m.ident;
+      if (!(abl & 8)) {
+        for (uint32_t g = tid; g <= GS; g += BLOCK) {
+          gkeys[g] = VH_HASH_EMPTY;
+#pragma unroll
+          for (int j = 0; j < NM; ++j) {
+            if (J::m_sop[j] == SOP_BITSET) reinterpret_cast<uint32_t*>(mstate[j])[g] = 0u;       // (a cardinality never exceeds the set's slots)
+            else if (vh_sop_bytes(J::m_sop[j]) == 4) reinterpret_cast<uint32_t*>(mstate[j])[g] = (uint32_t)P.m[j].ident;
+            else reinterpret_cast<uint64_t*>(mstate[j])[g] = P.m[j].ident;
+          }
         }
+        if (IDS) for (uint32_t g = tid; g < SS; g += BLOCK) skeys[g] = VH_HASH_EMPTY;
       }
-      if (IDS && !(abl & 8)) for (uint32_t g = tid; g < SS; g += BLOCK) skeys[g] = VH_HASH_EMPTY;
       __syncthreads();
       bool bad = false;
       if (abl & 4) {      // (the tuples are still looked at)
@@ -451,33 +468,31 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
         if (acc == 0x123456789ABCDEFull) P.counters[7] = acc;
         continue;
       }
-      uint32_t* const card = reinterpret_cast<uint32_t*>(lds + P.m[bitset_j < 0 ? 0 : bitset_j].lds_off);
-      const int set_shift = IDS ? 32 - (31 - __builtin_clz(SS | 1u)) : 0;
-      const int pk_pb = PK ? HA->pk_pbits : 0, pk_ib = PK ? HA->pk_idbits : 0;
-      const uint64_t pk_pmask = PK && pk_pb < 64 ? (1ull << pk_pb) - 1ull : ~0ull, pk_imask = (1ull << pk_ib) - 1ull;
       // ---- a tuple: the group's slot (claimed if new), the metric values of its payload word, then its ids into the (group slot, id) set
       auto tuple = [&](const T& tp) {
-        const uint64_t mkey = tp.v[0].x, w1 = tp.v[0].y, payload = PK ? w1 & pk_pmask : w1;
+        const uint64_t mkey = tp.v[0].x, w1 = tp.v[0].y, payload = PK ? (w1 & PMASK) : w1;
         if (sub_bits && (int)((uint32_t)(mkey >> (48 - sub_bits)) & (uint32_t)(passes - 1)) != pass) return;
         bool ok = true;
         const uint32_t slot = hp_slot(gkeys, GS, mkey, true, ok);
         if (!ok) { bad = true; return; }
-        const uint64_t meta = PK ? w1 >> 61 : U == 2 ? tp.v[U - 1].y : 0ull;      // bits 0-1: ids that count, bit 2: ids only
-        if (!(meta & HP_IDS_ONLY)) {
-          for (int j = 0; j < P.nmetric; ++j) {
-            const VhMetricDev& m = P.m[j];
-            if (m.sop() == SOP_BITSET) continue;
-            uint64_t v = payload >> m.tshift();
-            if (PK && m.tbits) v &= (1ull << m.tbits) - 1ull;      // (packed values are never negative: the planner checked the column's minimum)
-            else if (vh_sop_bytes(m.sop()) == 4) { v &= 0xFFFFFFFFull; if (vh_sop_sext(m.sop())) v = (uint64_t)(int64_t)(int32_t)v; }
-            vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, slot, m.sop(), v);
+        const uint64_t meta = PK ? (w1 >> 61) : U == 2 ? tp.v[U - 1].y : 0ull;      // bits 0-1: ids that count, bit 2: ids only
+        if (!IDS || !(meta & HP_IDS_ONLY)) {
+#pragma unroll
+          for (int j = 0; j < NM; ++j) {
+            if (J::m_sop[j] == SOP_BITSET) continue;
+            uint64_t v = payload >> J::m_tshift[j];
+            if (PK && J::m_tbits[j] && J::m_tbits[j] < 64) v &= (1ull << J::m_tbits[j]) - 1ull;      // (packed values are never negative: the planner checked the column's minimum)
+            else if (vh_sop_bytes(J::m_sop[j]) == 4) { v &= 0xFFFFFFFFull; if (vh_sop_sext(J::m_sop[j])) v = (uint64_t)(int64_t)(int32_t)v; }
+            vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(mstate[j], slot, J::m_sop[j], v);
           }
         }
         if (IDS && !(abl & 1)) {
           const uint64_t ids = PK ? 0ull : tp.v[U - 1].x;
-          const uint32_t idv[2] = {PK ? (uint32_t)((w1 >> pk_pb) & pk_imask) : (uint32_t)ids, PK ? (uint32_t)((w1 >> (pk_pb + pk_ib)) & pk_imask) : (uint32_t)(ids >> 32)};
+          const uint32_t idv[2] = {PK ? (uint32_t)((w1 >> PB) & IMASK) : (uint32_t)ids, PK ? (uint32_t)((w1 >> (PB + IB)) & IMASK) : (uint32_t)(ids >> 32)};
           const int n = (int)(meta & 3ull);
-          for (int q = 0; q < n; ++q) {
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            if (q >= n) break;
             const unsigned long long key = ((unsigned long long)slot << 32) | idv[q];
             uint32_t at = ((idv[q] ^ (slot * 0x9E3779B1u)) * 0x85EBCA6Bu) >> set_shift;      // (multiply-shift: the top bits)
             bool placed = false;
@@ -498,7 +513,7 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
         if (S.ovf_key[x] == (uint16_t)b) for (uint32_t i = tid; i < S.ovf_fill[x]; i += BLOCK) tuple(pool[(uint64_t)S.ovf_ext[x] * es + i]);
       __syncthreads();
       if (__ballot(bad)) { if (lane == 0) S.bad = 1; }
-      // ---- this pass's groups, as records: count, take a piece of the block's chunk of the list, write
+      // ---- this pass's groups: count, take places (off the result's row counter, or a piece of the block's chunk of the list), write
       uint32_t mine = 0;
       for (uint32_t g = tid; g <= GS; g += BLOCK) mine += gkeys[g] != VH_HASH_EMPTY;
       uint32_t incl = mine;
@@ -507,7 +522,31 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
       if (lane == 63) S.wave_tot[wave] = incl;
       __syncthreads();
       uint32_t tot = 0, before = 0;
+#pragma unroll
       for (int w = 0; w < BLOCK / 64; ++w) { const uint32_t c = S.wave_tot[w]; tot += c; if (w < wave) before += c; }
+      if (HA->direct && !(abl & 2)) {      // (uniform) the groups go straight into the result's output columns
+        if (tid == 0 && tot) S.base = atomicAdd(HA->out_count, (unsigned long long)tot);
+        __syncthreads();
+        unsigned long long at = S.base + before + (incl - mine);
+        if (tot && S.base + tot <= HA->list_cap) {
+          for (uint32_t g = tid; g <= GS; g += BLOCK) {
+            const unsigned long long mk = gkeys[g];
+            if (mk == VH_HASH_EMPTY) continue;
+            const unsigned long long key = vh_unmix64(g == GS ? VH_HASH_EMPTY : mk);
+#pragma unroll
+            for (int c = 0; c < NG; ++c) hp_store_sized(HA->out_key[c], (uint32_t)J::g_esize[c], at, key >> J::g_key_shift[c]);
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+              const uint64_t bits = (J::m_sop[j] == SOP_BITSET || vh_sop_bytes(J::m_sop[j]) == 4) ? (uint64_t)reinterpret_cast<const uint32_t*>(mstate[j])[g]
+                                                                                                   : reinterpret_cast<const uint64_t*>(mstate[j])[g];
+              hp_store_sized(HA->out_state[j], (uint32_t)J::m_esize[j], at, bits);
+            }
+            ++at;
+          }
+        } else if (tot && tid == 0) atomicOr(P.counters + 2, VH_ERR_PART_FULL);
+        __syncthreads();
+        continue;
+      }
       if (tot && S.chunk_pos + tot > S.chunk_end) {       // (uniform) a new chunk of the list: what is left of the old one is marked empty
         for (unsigned long long i = S.chunk_pos + tid; i < S.chunk_end && i < HA->list_cap; i += BLOCK) P.hkeys[i * stride_w] = VH_HASH_EMPTY;      // (a chunk taken beyond the list's end — the attempt is void — is not written to)
         __syncthreads();
@@ -518,28 +557,6 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
         }
         __syncthreads();
       }
-      if (HA->direct && !(abl & 2)) {      // (uniform) the groups go straight into the result's output columns
-        if (tid == 0 && tot) S.base = atomicAdd(HA->out_count, (unsigned long long)tot);
-        __syncthreads();
-        unsigned long long at = S.base + before + (incl - mine);
-        if (tot && S.base + tot <= HA->list_cap) {
-          for (uint32_t g = tid; g <= GS; g += BLOCK) {
-            const unsigned long long mk = gkeys[g];
-            if (mk == VH_HASH_EMPTY) continue;
-            const unsigned long long key = vh_unmix64(g == GS ? VH_HASH_EMPTY : mk);
-            for (int c = 0; c < HA->ngroup; ++c) hp_store_sized(HA->out_key[c], HA->gesize[c], at, key >> HA->gkey_shift[c]);
-            for (int j = 0; j < P.nmetric; ++j) {
-              const VhMetricDev& m = P.m[j];
-              const uint64_t bits = (m.sop() == SOP_BITSET || vh_sop_bytes(m.sop()) == 4) ? (uint64_t)reinterpret_cast<const uint32_t*>(lds + m.lds_off)[g]
-                                                                                             : reinterpret_cast<const uint64_t*>(lds + m.lds_off)[g];
-              hp_store_sized(HA->out_state[j], HA->mesize[j], at, bits);
-            }
-            ++at;
-          }
-        } else if (tot && tid == 0) atomicOr(P.counters + 2, VH_ERR_PART_FULL);
-        __syncthreads();
-        continue;
-      }
       const unsigned long long base = S.chunk_pos;
       unsigned long long at = base + before + (incl - mine);
       if (abl & 2) {
@@ -549,12 +566,12 @@ __global__ __launch_bounds__(BLOCK) void hp_aggregate_kernel(const VhPlanDev P, 
           if (mk == VH_HASH_EMPTY) continue;
           const unsigned long long key = vh_unmix64(g == GS ? VH_HASH_EMPTY : mk);
           P.hkeys[at * stride_w] = key;     // (a group whose KEY is the empty marker is told apart by the list's last, reserved record)
-          for (int j = 0; j < P.nmetric; ++j) {
-            const VhMetricDev& m = P.m[j];
-            char* dstp = vh_hash_state(P, m, key == VH_HASH_EMPTY ? HA->list_cap : at);
-            if (m.sop() == SOP_BITSET) *reinterpret_cast<uint64_t*>(dstp) = reinterpret_cast<const uint32_t*>(lds + m.lds_off)[g];
-            else if (vh_sop_bytes(m.sop()) == 4) *reinterpret_cast<uint32_t*>(dstp) = reinterpret_cast<const uint32_t*>(lds + m.lds_off)[g];
-            else *reinterpret_cast<uint64_t*>(dstp) = reinterpret_cast<const uint64_t*>(lds + m.lds_off)[g];
+#pragma unroll
+          for (int j = 0; j < NM; ++j) {
+            char* dstp = vh_hash_state(P, P.m[j], key == VH_HASH_EMPTY ? HA->list_cap : at);
+            if (J::m_sop[j] == SOP_BITSET) *reinterpret_cast<uint64_t*>(dstp) = reinterpret_cast<const uint32_t*>(mstate[j])[g];
+            else if (vh_sop_bytes(J::m_sop[j]) == 4) *reinterpret_cast<uint32_t*>(dstp) = reinterpret_cast<const uint32_t*>(mstate[j])[g];
+            else *reinterpret_cast<uint64_t*>(dstp) = reinterpret_cast<const uint64_t*>(mstate[j])[g];
           }
           if (key == VH_HASH_EMPTY) atomicOr(P.counters + 3, 1ull);
           ++at;

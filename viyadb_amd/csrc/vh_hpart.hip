@@ -4,26 +4,23 @@
 #include "vh_launch.h"
 #include <cstdlib>
 
-// After the scan kernel has written the stream pool: level A, the slices of the last pool, level B, the ranges.
-template <int U, bool PK>
-static void launch_hpart(const VhPlanDev& P, const VhHpArgs* d_args, int num_cu, size_t agg_lds, int bpp, hipStream_t s) {
+// After the scan kernel has written the stream pool: level A, the slices of the last pool, level B. (The ranges' aggregation is compiled per
+// plan shape next to the scan kernel: vh_jit_launch_hpagg.)
+template <int U>
+static void launch_hpart(const VhPlanDev& P, const VhHpArgs* d_args, int num_cu, hipStream_t s) {
   static bool once = false;
   const size_t sl = hp_scatter_lds_bytes();
   if (!once) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_scatter_kernel<1024, U>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sl);
     once = true;
   }
-  if (agg_lds > 64 * 1024)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&hp_aggregate_kernel<512, U, PK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)agg_lds);
   static const int grid_a = getenv("VH_HP_GRID_A") ? atoi(getenv("VH_HP_GRID_A")) : 0;       // measurement
   hipLaunchKernelGGL((hp_scatter_kernel<1024, U>), dim3(grid_a > 0 ? grid_a : num_cu), dim3(1024), sl, s, d_args, 0, P.counters);
   hipLaunchKernelGGL((hp_count_kernel<256>), dim3(num_cu), dim3(256), 0, s, d_args);
   hipLaunchKernelGGL(hp_plan_kernel, dim3(1), dim3(HP_FAN), 0, s, d_args, P.counters);
   hipLaunchKernelGGL((hp_scatter_kernel<1024, U>), dim3(HP_FAN), dim3(1024), sl, s, d_args, 1, P.counters);
-  hipLaunchKernelGGL((hp_aggregate_kernel<512, U, PK>), dim3(HP_FAN * bpp), dim3(512), agg_lds, s, P, d_args, bpp);
 }
-void vh_launch_hpart(const VhPlanDev& P, const VhHpArgs* d_args, int units, bool packed, int num_cu, size_t agg_lds, int bpp, hipStream_t s) {
-  if (units == 2) launch_hpart<2, false>(P, d_args, num_cu, agg_lds, bpp, s);
-  else if (packed) launch_hpart<1, true>(P, d_args, num_cu, agg_lds, bpp, s);
-  else launch_hpart<1, false>(P, d_args, num_cu, agg_lds, bpp, s);
+void vh_launch_hpart(const VhPlanDev& P, const VhHpArgs* d_args, int units, int num_cu, hipStream_t s) {
+  if (units == 2) launch_hpart<2>(P, d_args, num_cu, s);
+  else launch_hpart<1>(P, d_args, num_cu, s);
 }

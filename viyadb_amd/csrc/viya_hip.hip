@@ -2524,8 +2524,8 @@ int QueryBuild::decompose_work() {
     r->kernel = jk ? jk->name : std::string(nm);
     if (hpart) {      // (the scatter kernel runs twice per query, level A and level B: named twice, so that per-query sums over the names count it twice)
       char hn[160];
-      snprintf(hn, sizeof(hn), hp_pack ? " + hp_scatter_kernel<1024, %d> + hp_scatter_kernel<1024, %d> + hp_aggregate_kernel<512, %d, true>" : " + hp_scatter_kernel<1024, %d> + hp_scatter_kernel<1024, %d> + hp_aggregate_kernel<512, %d, false>", hp_units, hp_units, hp_units);
-      r->kernel += hn;
+      snprintf(hn, sizeof(hn), " + hp_scatter_kernel<1024, %d> + hp_scatter_kernel<1024, %d> + ", hp_units, hp_units);
+      r->kernel += hn + jk->name + "_hpagg";
     }
     if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? " + part_agg_kernel<1024>" : (P.tw == 2 && !getenv("VH_NO_SPLIT_TILE")) ? " + part_split_tile_kernel<256> + part_agg_kernel<1024>" : " + part_split_kernel<256> + part_agg_kernel<1024>";
   }
@@ -2863,10 +2863,13 @@ int QueryBuild::launch() {
   for (int k = 0; k < P.npred; ++k) narrowed |= P.pred_width[k] != 4;
   if (jk) { narrowed = false; for (int k = 0; k < jshape.npred; ++k) narrowed |= jshape.pred[k].width != vh_elem_size(jshape.pred[k].type); }
   r->hpart = hpart;
-  r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0);
+  r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0) | (hpart && hp_pack ? 256 : 0);
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
-    if (hpart) vh_launch_hpart(P, d_hpargs, hp_units, hp_pack, g_ctx.num_cu, lds_table, hp_bpp, st);
+    if (hpart) {
+      vh_launch_hpart(P, d_hpargs, hp_units, g_ctx.num_cu, st);
+      HIP_TRY(vh_jit_launch_hpagg(jk, P, d_hpargs, hp_bpp, HP_FAN * hp_bpp, lds_table, st));
+    }
     if (mode == VH_MODE_DENSE_PART) {
       const bool skip_phase2 = knobs().skip_phase2;     // measurement only (wrong results): phase 1 alone between the events
       if (P.nlevel == 2 && !skip_phase2) vh_launch_part_split(P, split_bpp, st);

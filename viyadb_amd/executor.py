@@ -84,6 +84,7 @@ class AggResult:
     jit: bool = False              # a scan kernel compiled for this plan shape ran (viyadb_amd/csrc/vh_jit.hip)
     hpart: bool = False            # hashed partitioning of the hash path ran (vh_hpart.h)
     packed_compressed: bool = False  # ... from compressed records (integers stored at the width their values need)
+    hp_packed: bool = False        # hashed partitioning with packed 16-byte tuples (a count-distinct's ids inside the payload word)
 
 
 
@@ -314,7 +315,7 @@ class DeviceTable:
                          int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
                          float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1),
                          bool(info.reserved & 2), bool(info.reserved & 8), int(ng), (self.lib.vh_result_kernel(res) or b"").decode(),
-                         bool(info.reserved & 16), bool(info.reserved & 32), bool(info.reserved & 64), bool(info.reserved & 128))
+                         bool(info.reserved & 16), bool(info.reserved & 32), bool(info.reserved & 64), bool(info.reserved & 128), bool(info.reserved & 256))
 
     def query_agg(self, plan: AggPlan, copy: bool = True) -> AggResult:
         p, keep = self._build_plan(plan)
