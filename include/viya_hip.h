@@ -195,8 +195,10 @@ enum vh_plan_flags {
   VH_PLAN_NO_HPART = 1u << 19,    /* ablation: never the hashed partitioning of the hash path (many groups: tuples keyed by
                                      a bijective mix of the group key, radix-partitioned, aggregated range by range in LDS) */
   VH_PLAN_FORCE_HPART = 1u << 20, /* testing: hashed partitioning whenever the plan is eligible, however small the table  */
-  VH_PLAN_NO_HP_PACK = 1u << 21   /* ablation: a count-distinct's tuples keep their ids in words of their own (32 bytes) even when payload,
+  VH_PLAN_NO_HP_PACK = 1u << 21,  /* ablation: a count-distinct's tuples keep their ids in words of their own (32 bytes) even when payload,
                                      two ids and their count would fit the tuple's second word (16 bytes) */
+  VH_PLAN_CARD32 = 1u << 22       /* the cardinality of a 32-bit-id bitset metric (count distinct) is delivered as a uint32 column instead of
+                                     uint64 (it cannot exceed 2^32 - 1): vh_result_state_elem() tells what a state column holds */
 };
 typedef struct vh_plan {
   const vh_filter_node* filter; int32_t nfilter;   /* postfix program        */
@@ -499,6 +501,9 @@ VH_API int vh_result_get_info(vh_result* r, vh_result_info* info);
 /* Symbol(s) of the scan kernel(s) this query launched, spelled as rocprofv3 prints them ("scan_agg_fast_kernel<4, 256, 4, 3> +
  * part_agg_kernel<1024>"): what a profile of the same command must show. Valid until vh_result_free. */
 VH_API const char* vh_result_kernel(vh_result* r);
+/* Element type (enum vh_elem) of the state column vh_result_view / vh_result_copy deliver for metric j of the plan: the metric column's own type;
+ * VH_U64 for a count distinct and for the virtual row id — VH_U32 for a count distinct over 32-bit ids when the plan carried VH_PLAN_CARD32. < 0: no such metric. */
+VH_API int vh_result_state_elem(vh_result* r, int32_t metric);
 /* Copy out: key_cols[i] receives ngroups elements of group column i's element
  * type; state_cols[j] receives ngroups elements of metric j's element type
  * (bitset metrics: uint64 cardinality); hidden_count (may be NULL) receives the

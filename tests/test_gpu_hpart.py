@@ -125,6 +125,18 @@ def test_ids_beyond_the_recorded_range_void_the_packed_attempt(sets5):
     assert res.path == "hash" and not res.hpart and res.retries >= 1 and res.ngroups == st.ngroups
 
 
+def test_cardinalities_as_uint32_when_asked(sets5):
+    """VH_PLAN_CARD32: a count distinct over 32-bit ids arrives as a uint32 column (vh_result_state_elem says so) with the same values —
+    through the hashed partitioning, the plain hash table and its device-wide (group, id) set alike."""
+    tab, dt = sets5
+    q = {"dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("lt", "x", "60")}
+    for flags in (HP, capi.PLAN_FORCE_HASH | capi.PLAN_NO_HPART, 0):
+        wide, _ = run(tab, dt, q, flags=flags)
+        narrow, _ = run(tab, dt, q, flags=flags | capi.PLAN_CARD32)
+        assert wide.states[0].dtype == np.uint64 and narrow.states[0].dtype == np.uint32
+        assert np.array_equal(np.sort(wide.states[0]), np.sort(narrow.states[0].astype(np.uint64)))
+
+
 def test_payloads_and_key_shapes(sets5):
     tab, dt = sets5
     for q in ({"dimensions": ["c", "x"], "metrics": ["users", "count", "v"], "filter": F("ge", "x", "10")},      # two 32-bit states + the set
@@ -248,3 +260,17 @@ def test_pairs_for_the_exchange_come_out_of_the_tuple_pool(sets5):
         assert got == want and len(got) > 10_000
     finally:
         dt.discard(h)
+
+
+def test_streamed_delivery_on_small_tables():
+    """Big results of the hashed partitioning leave in chunks — the aggregation runs as eight launches over consecutive level-A partitions,
+    each with its own region of the output columns, and finished chunks are copied out while the next ones aggregate. The full-size C5 test
+    takes that path by itself; here VH_TEST_HP_STREAM asks for it on the small tables of this file (fresh process: one knob, read by the
+    planner per query)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, VH_TEST_HP_STREAM="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k",
+                        "any_number_of_ids or payloads_and_key or ragged or widest_ids or skew or overflow"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

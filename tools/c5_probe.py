@@ -4,7 +4,7 @@ usage: c5_probe.py [C5|C5t] [segments] [runs]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from viyadb_amd import executor, synth
+from viyadb_amd import capi, executor, synth
 from viyadb_amd.executor import AggPlan
 
 name = sys.argv[1] if len(sys.argv) > 1 else "C5"
@@ -13,7 +13,8 @@ runs = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 executor.init(0)
 w = synth.WORKLOADS[name]()
 t = synth.create_device_table(w, seg)
-plan = AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, groups_hint=w.plan.groups_hint)
+plan = AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, groups_hint=w.plan.groups_hint,
+               flags=0 if os.environ.get("C5_CARD64") else capi.PLAN_CARD32)
 t.prepare(plan)
 km, wall = [], []
 for i in range(runs + 2):

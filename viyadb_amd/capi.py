@@ -30,7 +30,7 @@ MAX_ROLLUP = 8
 PLAN_FORCE_HASH, PLAN_FORCE_GLOBAL, PLAN_NO_XCD_PRIVATE, PLAN_NO_FAST, PLAN_NO_PART, PLAN_NO_CARRIER, PLAN_FORCE_PART = 1, 2, 4, 8, 16, 32, 64
 PLAN_NO_LANES, PLAN_FORCE_LANES, PLAN_NO_LDS_HASH, PLAN_NO_HASH_RECORDS, PLAN_FORCE_HASH_RECORDS = 128, 256, 512, 1024, 2048
 PLAN_NO_PACK, PLAN_FORCE_PACK, PLAN_NO_PART2, PLAN_NO_SHAPE, PLAN_NO_NARROW = 4096, 8192, 16384, 32768, 65536
-PLAN_NO_JIT, PLAN_FORCE_JIT, PLAN_NO_HPART, PLAN_FORCE_HPART, PLAN_NO_HP_PACK = 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21
+PLAN_NO_JIT, PLAN_FORCE_JIT, PLAN_NO_HPART, PLAN_FORCE_HPART, PLAN_NO_HP_PACK, PLAN_CARD32 = 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22
 # paths
 PATH_SCALAR, PATH_DENSE_LDS, PATH_DENSE_GLOBAL, PATH_HASH, PATH_DENSE_PART = range(5)
 PATH_NAMES = ["scalar", "dense_lds", "dense_global", "hash", "dense_part"]
@@ -160,6 +160,7 @@ SYMBOLS = {
     "vh_rows_free": (None, [_VP]),
     "vh_result_get_info": (C.c_int, [_VP, C.POINTER(ResultInfo)]),
     "vh_result_kernel": (C.c_char_p, [_VP]),
+    "vh_result_state_elem": (C.c_int, [_VP, C.c_int32]),
     "vh_result_copy": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_uint64)]),
     "vh_result_view": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.POINTER(C.c_uint64))]),
     "vh_result_free": (None, [_VP]),

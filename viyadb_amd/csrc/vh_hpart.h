@@ -34,6 +34,7 @@
 #define HP_FAN 256            // partitions per level
 #define HP_CARRY 8            // 16-byte units of LDS per digit for the run tail that waits for the next tile (less than a 128-byte line ever waits)
 #define HP_LIST 1024          // source extents a block remembers at a time
+#define VH_HP_CHUNKS 8         // chunk launches of the aggregation when a big result is delivered while it is produced (a divisor of HP_FAN)
 
 struct VhHpPool {             // extents of HP_ET 16-byte tuples
   uint64_t* tuples;
@@ -69,6 +70,11 @@ struct VhHpArgs {
   // dimensions' own element types, states in the metrics') at places taken off the result's row counter — no list of group records, no
   // emission kernel behind it. Taken when no HAVING and no top-N have to look at the groups first.
   int32_t direct, ngroup;
+  // STREAMED delivery (round 4): the aggregation runs as `nchunks` launches over consecutive level-A partitions, chunk c writing its groups
+  // to rows [c * chunk_rows, ...) of the output columns and counting them in out_count[c]; the host copies a finished chunk's rows to
+  // pinned memory while the next chunks aggregate (C5: 35 M groups leave over PCIe for longer than all kernels run). 0: one launch, one region.
+  int32_t nchunks, pad_chunks;
+  uint64_t chunk_rows;
   unsigned long long* out_count;
   void* out_key[VH_MAX_GROUP]; void* out_state[VH_MAX_METRIC];
   uint32_t gkey_shift[VH_MAX_GROUP], gesize[VH_MAX_GROUP], mesize[VH_MAX_METRIC];
@@ -77,7 +83,7 @@ struct VhHpArgs {
 static inline int vh_hpart_bpp(int num_cu, size_t agg_lds) {
   const size_t per_cu = agg_lds + 4096 >= (size_t)(150 * 1024) ? 1 : (size_t)(150 * 1024) / (agg_lds + 4096);
   int bpp = (int)((size_t)num_cu * (per_cu < 4 ? per_cu : 4) * 2 / HP_FAN);
-  if (bpp < 1) bpp = 1;
+  if (bpp < 16) bpp = 16;      // (measured, C5: 4 blocks per partition 4.03 ms for the query's kernels, 8: 3.91, 16: 3.80, 32: 3.81 — shorter blocks even out the launch's tail)
   while (HP_FAN % bpp) --bpp;
   return bpp;
 }
@@ -384,7 +390,7 @@ struct HpAggLds {
 //   U = 16-byte units per tuple: 1 (mixed key, payload — or the PACKED form with two ids in the payload word) or 2 (mixed key, payload, two
 //   ids, how many of them count | ids only).
 template <class J, int BLOCK>
-__device__ __forceinline__ void hp_aggregate_body(const VhPlanDev& P, const VhHpArgs* __restrict__ HA, int blocks_per_partition) {
+__device__ __forceinline__ void hp_aggregate_body(const VhPlanDev& P, const VhHpArgs* __restrict__ HA, int blocks_per_partition, int a_first) {
   constexpr bool PK = J::HP_PACK;
   constexpr bool IDS = J::BITSET_J >= 0;         // the tuples carry ids
   constexpr int U = (IDS && !PK) ? 2 : 1;
@@ -394,7 +400,11 @@ __device__ __forceinline__ void hp_aggregate_body(const VhPlanDev& P, const VhHp
   extern __shared__ __attribute__((aligned(16))) char lds[];
   __shared__ HpAggLds S;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int a = blockIdx.x / blocks_per_partition, j0 = blockIdx.x % blocks_per_partition;
+  const int a = a_first + blockIdx.x / blocks_per_partition, j0 = blockIdx.x % blocks_per_partition;
+  // where this block's groups go when it writes the output columns itself: its chunk's rows and row counter (one region without chunks)
+  const uint32_t ochunk = HA->nchunks ? (uint32_t)a / (uint32_t)(HP_FAN / HA->nchunks) : 0u;
+  unsigned long long* const out_count = HA->out_count + ochunk;
+  const unsigned long long out_cap = HA->nchunks ? HA->chunk_rows : HA->list_cap, out_base = HA->nchunks ? (unsigned long long)ochunk * HA->chunk_rows : 0ull;
   unsigned long long* const gkeys = reinterpret_cast<unsigned long long*>(lds + HA->keys_off);
   unsigned long long* const skeys = reinterpret_cast<unsigned long long*>(lds + HA->set_off);
   const uint32_t GS = (uint32_t)HA->gslots, SS = (uint32_t)HA->sslots;
@@ -525,10 +535,10 @@ __device__ __forceinline__ void hp_aggregate_body(const VhPlanDev& P, const VhHp
 #pragma unroll
       for (int w = 0; w < BLOCK / 64; ++w) { const uint32_t c = S.wave_tot[w]; tot += c; if (w < wave) before += c; }
       if (HA->direct && !(abl & 2)) {      // (uniform) the groups go straight into the result's output columns
-        if (tid == 0 && tot) S.base = atomicAdd(HA->out_count, (unsigned long long)tot);
+        if (tid == 0 && tot) S.base = atomicAdd(out_count, (unsigned long long)tot);
         __syncthreads();
-        unsigned long long at = S.base + before + (incl - mine);
-        if (tot && S.base + tot <= HA->list_cap) {
+        unsigned long long at = out_base + S.base + before + (incl - mine);
+        if (tot && S.base + tot <= out_cap) {
           for (uint32_t g = tid; g <= GS; g += BLOCK) {
             const unsigned long long mk = gkeys[g];
             if (mk == VH_HASH_EMPTY) continue;

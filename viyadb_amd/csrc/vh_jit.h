@@ -58,7 +58,7 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name);
 VhJitKernel* vh_jit_get(const VhJitShape& s, std::string* err);
 int vh_jit_occupancy(VhJitKernel* k, int block, size_t lds);
 hipError_t vh_jit_launch(VhJitKernel* k, const VhPlanDev& P, int grid, int block, size_t lds, hipStream_t s);
-hipError_t vh_jit_launch_hpagg(VhJitKernel* k, const VhPlanDev& P, const void* d_hpargs, int blocks_per_partition, int grid, size_t lds, hipStream_t s);
+hipError_t vh_jit_launch_hpagg(VhJitKernel* k, const VhPlanDev& P, const void* d_hpargs, int blocks_per_partition, int a_first, int grid, size_t lds, hipStream_t s);
 #define VH_HP_AGG_BLOCK 512
 // code object for a shape without loading it (no GPU needed: build-time cache warm-up, CPU tests)
 int vh_jit_compile_only(const VhJitShape& s, std::vector<char>* code, std::string* log);

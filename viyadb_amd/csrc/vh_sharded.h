@@ -496,7 +496,7 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
   const uint64_t cap_rows = R == root ? std::max<uint64_t>(total_rows, 1) : 1;
   for (int i = 0; i < nk; ++i) { rf->off_key[i] = bytes; bytes += (cap_rows * vh_elem_size(rm->plan.g[i].type()) + 255) / 256 * 256; }
   for (int u = 0; u < ndev; ++u) { rf->off_state[u] = bytes; bytes += (cap_rows * vh_elem_size(rm->metric_elem[u]) + 255) / 256 * 256; }
-  if (hipMalloc((void**)&rf->d_own, bytes) != hipSuccess || hipHostMalloc((void**)&rf->h_own, bytes, hipHostMallocDefault) != hipSuccess)
+  if (hipMalloc((void**)&rf->d_own, bytes) != hipSuccess || host_alloc_near_device((void**)&rf->h_own, bytes, hipHostMallocDefault) != hipSuccess)
     keep(vh_fail(VH_E_NOMEM, "no memory for %llu gathered groups", (unsigned long long)total_rows));
   if (int rc = agree_status(comm, lrc, "gathering the merged groups")) return rc;
   for (int i = 0; i < nk; ++i) {

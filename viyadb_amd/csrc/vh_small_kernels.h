@@ -673,6 +673,52 @@ __global__ __launch_bounds__(256) void hp_partition_pairs_kernel(const VhHpPairA
 
 // The first 512 bytes of a result region — scan counters and the emitted-row count — into the pinned host buffer
 // the emission kernel wrote its rows to (direct emission, see result_finalize_locked).
+// Big results leave through THIS kernel, not through the DMA engine: a few blocks that read the output columns and store them into the
+// pinned (device-visible) staging buffer in whole aligned 16-byte pieces, 1 KB contiguous per wave instruction. Measured
+// (tools/experiments/d2h_bw*.hip, tools/r04): hipMemcpyAsync device-to-host ran at 30 GB/s inside the library's process — 57 GB/s in a bare
+// program; with HSA_ENABLE_SDMA=0 the runtime's own shader copies made C5 10 ms faster — while a 64-block store kernel reaches 55 GB/s
+// everywhere and leaves the other CUs to the chunks that are still aggregating. Source and destination offsets of a column differ by
+// whole rows, not by multiples of 16 bytes: the loads are dword-aligned (funnel-shifted when a 1- or 2-byte column starts mid-dword).
+#define VH_DELIVER_COLS (VH_MAX_GROUP + VH_MAX_METRIC)
+struct VhDeliverArgs {
+  int32_t ncols, pad;
+  const char* src[VH_DELIVER_COLS];
+  char* dst[VH_DELIVER_COLS];
+  uint64_t bytes[VH_DELIVER_COLS];
+};
+typedef uint32_t vh_u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+__global__ __launch_bounds__(256) void deliver_kernel(const VhDeliverArgs A) {
+  const uint64_t gtid = (uint64_t)blockIdx.x * 256 + threadIdx.x, nthr = (uint64_t)gridDim.x * 256;
+  for (int c = 0; c < A.ncols; ++c) {
+    const char* __restrict__ src = A.src[c];
+    char* __restrict__ dst = A.dst[c];
+    const uint64_t n = A.bytes[c];
+    uint64_t head = (16u - (uint32_t)(reinterpret_cast<uintptr_t>(dst) & 15u)) & 15u;
+    if (head > n) head = n;
+    if (gtid < head) dst[gtid] = src[gtid];
+    const uint64_t nvec = (n - head) / 16;
+    const char* s0 = src + head;
+    const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(s0) & 3u) * 8u;       // bits the source lies beyond a dword boundary
+    const uint32_t* sw = reinterpret_cast<const uint32_t*>(s0 - (sh >> 3));
+    vh_u32x4* dv = reinterpret_cast<vh_u32x4*>(dst + head);
+    for (uint64_t v = gtid; v < nvec; v += nthr) {
+      vh_u32x4 w = *reinterpret_cast<const vh_u32x4_a4*>(sw + 4 * v);
+      if (sh) {
+        const uint32_t e = sw[4 * v + 4];
+        w.x = (w.x >> sh) | (w.y << (32u - sh)); w.y = (w.y >> sh) | (w.z << (32u - sh));
+        w.z = (w.z >> sh) | (w.w << (32u - sh)); w.w = (w.w >> sh) | (e << (32u - sh));
+      }
+      __builtin_nontemporal_store(w, dv + v);
+    }
+    const uint64_t done = head + nvec * 16;
+    if (gtid < n - done) dst[done + gtid] = src[done + gtid];
+  }
+}
+
+// Streamed delivery of a hashed-partitioning result (VhHpArgs::nchunks): a chunk's row count into pinned host memory, right behind the chunk.
+__global__ __launch_bounds__(64) void publish_count_kernel(unsigned long long* host, const unsigned long long* dev) {
+  if (threadIdx.x == 0) *host = *dev;
+}
 __global__ __launch_bounds__(64) void publish_header_kernel(unsigned long long* host, const unsigned long long* dev) {
   host[threadIdx.x] = dev[threadIdx.x];
 }

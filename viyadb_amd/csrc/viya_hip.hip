@@ -14,7 +14,9 @@
 #include "vh_jit.h"
 #include "vh_hpart.h"
 
+#include <sched.h>
 #include <algorithm>
+#include <cctype>
 #include <cfloat>
 #include <chrono>
 #include <condition_variable>
@@ -64,7 +66,7 @@ static std::mutex g_mu;
 // at their (cold) sites.
 struct VhKnobs {
   bool trace_alloc, no_topk, no_stage, jit_verbose, skip_phase2, no_direct_emit, times;
-  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, split_bpc, bw_blocks_per_cu, place_trials, place_gb, hp_list;
+  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, split_bpc, bw_blocks_per_cu, place_trials, place_gb, hp_list, hp_stream, deliver_blocks;
   double hp_load_g, hp_load_s;
 };
 static const VhKnobs& knobs() {
@@ -79,11 +81,64 @@ static const VhKnobs& knobs() {
     x.auto_narrow = num("VH_AUTO_NARROW", 3); x.auto_pack = num("VH_AUTO_PACK", 3);
     x.jit_ablate = num("VH_JIT_ABLATE", 0); x.hp_ablate = num("VH_HP_ABLATE", 0); x.hp_bpp = num("VH_HP_BPP", 0); x.pack_plain = num("VH_PACK_PLAIN", 0);
     x.lanes_block = num("VH_LANES_BLOCK", 0); x.blocks_per_cu = num("VH_BLOCKS_PER_CU", 0); x.unit_rows = num("VH_UNIT_ROWS", 0); x.grid = num("VH_GRID", 0);
-    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.place_trials = num("VH_PLACE_TRIALS", 12); x.place_gb = std::max(1, num("VH_PLACE_GB", 96)); x.hp_list = num("VH_HP_LIST", 0); x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
+    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.place_trials = num("VH_PLACE_TRIALS", 12); x.place_gb = std::max(1, num("VH_PLACE_GB", 96)); x.hp_list = num("VH_HP_LIST", 0);
+    x.hp_stream = num("VH_HP_STREAM", 0);             // chunk launches of a streamed result (0: off — measured: the link, not the wait for the kernels, bounds the delivery; profiles/r04/NOTES.md)
+    x.deliver_blocks = num("VH_DELIVER_BLOCKS", 64);  // blocks of deliver_kernel; 0: big results through hipMemcpyAsync (the DMA engine)
+    x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
     x.hp_load_g = real("VH_HP_LOAD_G", 0.7); x.hp_load_s = real("VH_HP_LOAD_S", 0.7);
     return x;
   }();
   return k;
+}
+
+// Pinned host memory NEXT TO THE GPU. Linux places pages on the NUMA node of the CPU that first touches them, and hipHostMalloc pins (touches)
+// them in the calling thread: on a two-socket host the staging buffer of a big result landed on either socket, and device-to-host copies
+// into the far one run at 30 GB/s instead of 57 (tools/experiments/d2h_bw2.hip; C5 delivered its 35 M groups in 23 ms or in 13). The calling
+// thread therefore sits on the CPUs of the device's own node (sysfs: the PCI device's numa_node and that node's cpulist) while the buffer is
+// allocated and touched, and gets its affinity back afterwards. No node information (one socket, a container that hides sysfs): plain allocation.
+static std::vector<int> device_node_cpus() {
+  std::vector<int> cpus;
+  char bdf[64] = "";
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), g_ctx.device) != hipSuccess) return cpus;
+  for (char* c = bdf; *c; ++c) *c = (char)tolower(*c);
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
+  int node = -1;
+  if (FILE* f = fopen(path, "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+  if (getenv("VH_HOST_NUMA_NODE")) node = atoi(getenv("VH_HOST_NUMA_NODE"));      // measurement / hosts whose sysfs says -1
+  if (node < 0) return cpus;
+  snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+  FILE* f = fopen(path, "r");
+  if (!f) return cpus;
+  char list[4096] = "";
+  if (!fgets(list, sizeof(list), f)) list[0] = 0;
+  fclose(f);
+  for (char* p = list; *p;) {          // "0-63,128-191"
+    char* end = nullptr;
+    const long a = strtol(p, &end, 10);
+    if (end == p) break;
+    long b = a;
+    p = end;
+    if (*p == '-') { b = strtol(p + 1, &end, 10); p = end; }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c) cpus.push_back((int)c);
+    if (*p == ',') ++p; else break;
+  }
+  return cpus;
+}
+static hipError_t host_alloc_near_device(void** out, size_t bytes, unsigned flags) {
+  static const std::vector<int> cpus = device_node_cpus();
+  cpu_set_t old_set, near_set;
+  bool moved = false;
+  if (!cpus.empty() && bytes >= ((size_t)1 << 20) && sched_getaffinity(0, sizeof(old_set), &old_set) == 0) {
+    CPU_ZERO(&near_set);
+    int n = 0;
+    for (int c : cpus) if (CPU_ISSET(c, &old_set)) { CPU_SET(c, &near_set); ++n; }      // (only CPUs the thread may run on anyway: a cpuset is respected)
+    moved = n > 0 && sched_setaffinity(0, sizeof(near_set), &near_set) == 0;
+  }
+  hipError_t he = hipHostMalloc(out, bytes, flags);
+  if (he == hipSuccess && moved) { volatile char* p = static_cast<volatile char*>(*out); for (size_t i = 0; i < bytes; i += 4096) p[i] = 0; }
+  if (moved) (void)sched_setaffinity(0, sizeof(old_set), &old_set);
+  return he;
 }
 
 // The HIP current device is per thread: every entry point that allocates or launches binds the calling thread to the
@@ -140,11 +195,16 @@ struct VhExec {
   hipStream_t own_stream = nullptr;
   char* scratch = nullptr; size_t scratch_bytes = 0;
   uint32_t* h_segrows = nullptr; size_t h_segrows_cap = 0;
-  unsigned long long* h_counters = nullptr;     // pinned, 16 words
+  unsigned long long* h_counters = nullptr;     // pinned: 16 words of counters + 64 words for a big result's header
   char* d_sample = nullptr; size_t d_sample_bytes = 0;   // selectivity probe: counters + presence + seg rows
   char* h_out[2] = {nullptr, nullptr}; size_t h_out_bytes[2] = {0, 0}; int h_out_next = 0;  // pinned result staging (two alternate: a
                                                                                             // zero-copy view outlives vh_result_free until the second-next query)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  // streamed delivery of big results (hashed partitioning, VhHpArgs::nchunks): the aggregation's chunk launches alternate between the query's
+  // stream and `aux` (the tail of one chunk overlaps the start of the next), finished chunks leave on `copy`; created on first use
+  hipStream_t aux = nullptr, copy = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_chunk[VH_HP_CHUNKS] = {};
+  unsigned long long* h_chunk = nullptr;        // pinned: rows of chunk c, written by publish_count_kernel
   bool busy = false;
   // an externally owned stream (vh_set_stream) carries all work; otherwise every context has its own
   hipStream_t stream() const { return g_ctx.stream != g_ctx.own_stream ? g_ctx.stream : own_stream; }
@@ -272,6 +332,11 @@ static void exec_free(VhExec* x) {
   if (x->h_segrows) (void)hipHostFree(x->h_segrows);
   if (x->h_counters) (void)hipHostFree(x->h_counters);
   for (auto& e : x->ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : x->ev_chunk) if (e) (void)hipEventDestroy(e);
+  if (x->ev_fork) (void)hipEventDestroy(x->ev_fork);
+  if (x->h_chunk) (void)hipHostFree(x->h_chunk);
+  if (x->aux) (void)hipStreamDestroy(x->aux);
+  if (x->copy) (void)hipStreamDestroy(x->copy);
   if (x->own_stream) (void)hipStreamDestroy(x->own_stream);
 }
 // A free context of the table's pool, a new one while the pool may grow, else wait for one to come back.
@@ -289,12 +354,21 @@ static int exec_acquire(vh_table* t, VhExec** out) {
   }
   std::unique_ptr<VhExec> x(new VhExec());
   hipError_t he = hipStreamCreateWithFlags(&x->own_stream, hipStreamNonBlocking);
-  if (he == hipSuccess) he = hipHostMalloc((void**)&x->h_counters, 16 * sizeof(unsigned long long), hipHostMallocDefault);
+  if (he == hipSuccess) he = hipHostMalloc((void**)&x->h_counters, (16 + 64) * sizeof(unsigned long long), hipHostMallocDefault);
   for (auto& e : x->ev) if (he == hipSuccess) he = hipEventCreate(&e);
   if (he != hipSuccess) { exec_free(x.get()); return vh_fail(VH_E_DEVICE, "execution context: stream / pinned staging / events: %s", hipGetErrorString(he)); }
   x->busy = true;
   *out = x.get();
   t->execs.push_back(std::move(x));
+  return VH_OK;
+}
+static int exec_streaming(VhExec* x) {       // what a streamed result needs on top of a context's stream; once per context
+  if (x->copy) return VH_OK;
+  HIP_TRY(hipStreamCreateWithFlags(&x->aux, hipStreamNonBlocking));
+  { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIP_TRY(hipStreamCreateWithPriority(&x->copy, hipStreamNonBlocking, getenv("VH_COPY_PRIO") ? hi : 0)); }
+  HIP_TRY(hipEventCreateWithFlags(&x->ev_fork, hipEventDisableTiming));
+  for (auto& e : x->ev_chunk) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  HIP_TRY(hipHostMalloc((void**)&x->h_chunk, VH_HP_CHUNKS * sizeof(unsigned long long), hipHostMallocCoherent));
   return VH_OK;
 }
 static void exec_release(vh_table* t, VhExec* x) {
@@ -1111,6 +1185,8 @@ extern "C" int vh_segment_stats(vh_table* t, uint32_t seg, int32_t col, vh_anynu
 struct vh_result {
   bool hpart = false;               // hashed partitioning ran: the table is a compact list of group records ...
   bool hp_direct = false;           // ... or its aggregation kernel already wrote the output columns (no emission kernel to run)
+  int hp_chunks = 0;                // ... in this many chunk launches, each with a region of `hp_chunk_rows` rows of the output columns: delivered chunk by chunk
+  uint64_t hp_chunk_rows = 0;
   VhHpArgs hp_args;                 // ... and the pool descriptors its kernels were given
   vh_table* table = nullptr;
   vh_result_info info{};
@@ -1178,6 +1254,12 @@ extern "C" int vh_result_get_info(vh_result* r, vh_result_info* info) {
 }
 
 extern "C" const char* vh_result_kernel(vh_result* r) { return r ? r->kernel.c_str() : ""; }
+
+extern "C" int vh_result_state_elem(vh_result* r, int32_t metric) {
+  if (!r || metric < 0 || (size_t)metric >= r->user_metric.size()) return -1;
+  const int u = r->user_metric[metric];
+  return u >= 0 && (size_t)u < r->metric_elem.size() ? r->metric_elem[u] : -1;
+}
 
 extern "C" int vh_result_view(vh_result* r, const void** key_cols, const void** state_cols, const uint64_t** hidden_count) {
   if (!r || !r->finalized) return vh_fail(VH_E_INVALID, "result is not finalised");
@@ -1838,10 +1920,13 @@ int QueryBuild::shape_metrics() {
       bitset_ids[P.nbitset] = pair_cap - bitset_ids_before;
       bitset_ids_before = pair_cap;
       P.bs_wide[P.nbitset] = c.elem == VH_BITSET64;
+      // a set of 32-bit ids has at most 2^32 - 1 distinct members: its cardinality fits 32 bits, and a caller that says so
+      // (VH_PLAN_CARD32) gets the column that narrow — a third less to deliver for C5's 35 M groups
+      const int card_elem = (p->flags & VH_PLAN_CARD32) && c.elem == VH_BITSET32 ? VH_U32 : VH_U64;
       VhMetricDev& m = P.m[P.nmetric];
-      m.set_slot((uint16_t)P.nbitset); m.set_type(VH_U64); m.set_sop(SOP_BITSET); m.ident = 0;
+      m.set_slot((uint16_t)P.nbitset); m.set_type((uint8_t)card_elem); m.set_sop(SOP_BITSET); m.ident = 0;
       r->user_metric.push_back(P.nmetric++);
-      r->metric_elem.push_back(VH_U64);
+      r->metric_elem.push_back(card_elem);
       ++P.nbitset;
       continue;
     }
@@ -2564,6 +2649,20 @@ int QueryBuild::layout_scratch() {
   const size_t o_counters = sp.take(8 * sizeof(unsigned long long));
   const size_t o_outcount = sp.take(sizeof(unsigned long long));
   r->out_cap = mode == VH_MODE_HASH ? capacity + 1 : G;
+  // a big result of the hashed partitioning whose groups nothing has to look at on the device first leaves in chunks, copied out while
+  // the later chunks still aggregate: VH_HP_CHUNKS regions of the output columns, each with room for its share of the groups (the mixed
+  // key spreads GROUPS evenly over the level-A partitions whatever the rows' skew) and a quarter more; a region that overflows all the
+  // same voids the attempt like any pool that runs out
+  r->hp_direct = hpart && r->nhaving == 0 && r->topk == 0 && !knobs().hp_list;
+  if (r->hp_direct && !device_rows && (knobs().hp_stream > 0 ? capacity >= (1ull << 22) : getenv("VH_TEST_HP_STREAM") != nullptr)) {
+    int nch = std::min(knobs().hp_stream > 0 ? knobs().hp_stream : 4, VH_HP_CHUNKS);
+    while (HP_FAN % nch) --nch;
+    r->hp_chunks = nch;
+    r->hp_chunk_rows = capacity / nch + capacity / (4 * nch) + 4096;
+    r->out_cap = r->hp_chunk_rows * nch;
+    rc = exec_streaming(x);
+    if (rc) return rc;
+  }
   size_t o_okey[VH_MAX_GROUP], o_ostate[VH_MAX_METRIC];
   for (int i = 0; i < P.ngroup; ++i) o_okey[i] = sp.take(r->out_cap * vh_elem_size(P.g[i].type()));
   for (int j = 0; j < P.nmetric; ++j) o_ostate[j] = sp.take(r->out_cap * vh_elem_size(r->metric_elem[j]));
@@ -2814,8 +2913,8 @@ int QueryBuild::launch() {
     for (int j = 0; j < P.nmetric; ++j) if (P.m[j].sop() == SOP_BITSET) HA.bitset_j = j;
     HA.list_cap = capacity; HA.chunk = hp_chunk; HA.ablate = knobs().hp_ablate;
     // no HAVING and no top-N to look at the groups first: the aggregation kernel emits them itself (C5: no 0.85 GB list, no 0.85 ms kernel)
-    r->hp_direct = r->nhaving == 0 && r->topk == 0 && !knobs().hp_list;
     HA.direct = r->hp_direct ? 1 : 0; HA.ngroup = P.ngroup; HA.out_count = r->d_out_count;
+    HA.nchunks = r->hp_chunks; HA.chunk_rows = r->hp_chunk_rows;
     for (int i = 0; i < P.ngroup; ++i) { HA.out_key[i] = r->d_out_key[i]; HA.gkey_shift[i] = P.g[i].key_shift(); HA.gesize[i] = (uint32_t)vh_elem_size(P.g[i].type()); }
     for (int j = 0; j < P.nmetric; ++j) { HA.out_state[j] = r->d_out_state[j]; HA.mesize[j] = (uint32_t)vh_elem_size(r->metric_elem[j]); }
     for (int k = 0; k < 1; ++k) {
@@ -2864,11 +2963,26 @@ int QueryBuild::launch() {
   if (jk) { narrowed = false; for (int k = 0; k < jshape.npred; ++k) narrowed |= jshape.pred[k].width != vh_elem_size(jshape.pred[k].type); }
   r->hpart = hpart;
   r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0) | (hpart && hp_pack ? 256 : 0);
+  if (r->hp_chunks) memset(x->h_chunk, 0, VH_HP_CHUNKS * sizeof(unsigned long long));      // (what the context's previous query left there)
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
     if (hpart) {
       vh_launch_hpart(P, d_hpargs, hp_units, g_ctx.num_cu, st);
-      HIP_TRY(vh_jit_launch_hpagg(jk, P, d_hpargs, hp_bpp, HP_FAN * hp_bpp, lds_table, st));
+      if (!r->hp_chunks) HIP_TRY(vh_jit_launch_hpagg(jk, P, d_hpargs, hp_bpp, 0, HP_FAN * hp_bpp, lds_table, st));
+      else {
+        // chunk c = level-A partitions [c * per, (c + 1) * per), alternately on the query's stream and on `aux` (both behind level B), each
+        // followed by its row count into pinned memory and an event the host waits for (result_finalize)
+        const int per = HP_FAN / r->hp_chunks;
+        HIP_TRY(hipEventRecord(x->ev_fork, st));
+        HIP_TRY(hipStreamWaitEvent(x->aux, x->ev_fork, 0));
+        for (int c = 0; c < r->hp_chunks; ++c) {
+          hipStream_t cs = (c & 1) ? x->aux : st;
+          HIP_TRY(vh_jit_launch_hpagg(jk, P, d_hpargs, hp_bpp, c * per, per * hp_bpp, lds_table, cs));
+          hipLaunchKernelGGL(publish_count_kernel, dim3(1), dim3(64), 0, cs, x->h_chunk + c, r->d_out_count + c);
+          HIP_TRY(hipEventRecord(x->ev_chunk[c], cs));
+        }
+        for (int c = 0; c < r->hp_chunks; ++c) if (c & 1) HIP_TRY(hipStreamWaitEvent(st, x->ev_chunk[c], 0));      // the query's stream ends behind every chunk
+      }
     }
     if (mode == VH_MODE_DENSE_PART) {
       const bool skip_phase2 = knobs().skip_phase2;     // measurement only (wrong results): phase 1 alone between the events
@@ -3169,24 +3283,30 @@ static int result_finalize(vh_result* r, int* retry) {
   hipStream_t st = x->stream();
   *retry = 0;
   // pinned staging buffer (two alternate per context: a zero-copy view stays readable after vh_result_free until the
-  // second-next query); a re-planned attempt of the same query reuses its slot
+  // second-next query); a re-planned attempt of the same query reuses its slot. Small results take the output region as it lies in the
+  // scratch (one copy, or none: direct emission below); big ones are PACKED on their way out — a staging buffer for the rows that
+  // exist, not for the rows the tables could hold (C5: 0.7 GB instead of 2.7 GB per slot; what does not fit the GPU's own NUMA node
+  // is copied to at half the rate).
   const int slot = r->h_slot >= 0 ? r->h_slot : (x->h_out_next ^= 1);
   r->h_slot = slot;
-  if (x->h_out_bytes[slot] < r->out_region_bytes) {
+  auto stage = [&](size_t bytes) -> int {
+    if (x->h_out_bytes[slot] >= bytes) return VH_OK;
     if (x->h_out[slot]) HIP_TRY(hipHostFree(x->h_out[slot]));
     x->h_out[slot] = nullptr; x->h_out_bytes[slot] = 0;
-    const size_t nb = std::max<size_t>(r->out_region_bytes + r->out_region_bytes / 4, 1 << 20);
+    const size_t nb = std::max<size_t>(bytes + bytes / 8, 1 << 20);
     // coherent (fine-grained): the emission kernel writes small results straight into this buffer, and the host must see
     // them when the event behind the kernel has completed, whatever HIP_HOST_COHERENT says
-    HIP_TRY(hipHostMalloc((void**)&x->h_out[slot], nb, hipHostMallocCoherent));
+    HIP_TRY(host_alloc_near_device((void**)&x->h_out[slot], nb, hipHostMallocCoherent));
     x->h_out_bytes[slot] = nb;
-  }
+    return VH_OK;
+  };
+  const bool env_no_direct = knobs().no_direct_emit;
+  const bool one_shot = r->out_region_bytes <= (8u << 20) && !r->topk_active && !r->hp_chunks;      // (a streamed result's rows are packed on their way out: never the region as a whole)
+  const bool direct = one_shot && r->mode != VH_MODE_HASH && !env_no_direct && !r->device_rows;
+  if (one_shot) { if (int src = stage(r->out_region_bytes)) return src; }
   // Small results of the dense paths are written by the emission kernel straight into that pinned host buffer
   // (posted PCIe writes, coalesced per column) and a one-wave kernel publishes the 512-byte header behind them: no
   // DMA-engine copy at the end of the query (its start-up costs 20-100 us, more than the 2 MB it moves).
-  const bool env_no_direct = knobs().no_direct_emit;
-  const bool one_shot = r->out_region_bytes <= (8u << 20) && !r->topk_active;
-  const bool direct = one_shot && r->mode != VH_MODE_HASH && !env_no_direct && !r->device_rows;
   if (direct) {
     for (int i = 0; i < P.ngroup; ++i) r->d_out_key[i] = x->h_out[slot] + r->off_key[i];
     for (int j = 0; j < P.nmetric; ++j) r->d_out_state[j] = x->h_out[slot] + r->off_state[j];
@@ -3242,46 +3362,113 @@ static int result_finalize(vh_result* r, int* retry) {
                        (const uint64_t*)r->d_topk_keys, (const unsigned long long*)r->d_out_count, (unsigned long long)r->topk, r->d_topk_state);
     HIP_TRY(hipGetLastError());
   }
-  char* H = x->h_out[slot];
   const char* D = x->scratch + r->out_region_off;
+  // packed layout of a big result in the staging buffer: [512-byte header | key columns | state columns], each column `rows` long
+  struct Packed { size_t key[VH_MAX_GROUP], state[VH_MAX_METRIC], bytes; };
+  auto packed_for = [&](uint64_t rows) {
+    Packed L{};
+    size_t o = 512;
+    for (int i = 0; i < P.ngroup; ++i) { L.key[i] = o; o += (std::max<uint64_t>(rows, 1) * vh_elem_size(P.g[i].type()) + 255) / 256 * 256; }
+    for (int j = 0; j < P.nmetric; ++j) { L.state[j] = o; o += (std::max<uint64_t>(rows, 1) * vh_elem_size(r->metric_elem[j]) + 255) / 256 * 256; }
+    L.bytes = o;
+    return L;
+  };
+  auto copy_rows = [&](const Packed& L, uint64_t dst_row, uint64_t src_row, uint64_t n, bool second, hipStream_t cs) -> int {
+    char* H = x->h_out[slot];
+    uint64_t row_bytes = 0;
+    for (int i = 0; i < P.ngroup; ++i) row_bytes += vh_elem_size(P.g[i].type());
+    for (int j = 0; j < P.nmetric; ++j) row_bytes += vh_elem_size(r->metric_elem[j]);
+    if (n * row_bytes >= ((uint64_t)1 << 20) && P.ngroup + P.nmetric <= VH_DELIVER_COLS && knobs().deliver_blocks > 0) {      // (deliver_kernel: why not the DMA engine)
+      VhDeliverArgs A{};
+      for (int i = 0; i < P.ngroup; ++i) {
+        const size_t es = vh_elem_size(P.g[i].type());
+        A.src[A.ncols] = (second ? (const char*)r->d_out_key2[i] : (const char*)r->d_out_key[i]) + src_row * es; A.dst[A.ncols] = H + L.key[i] + dst_row * es; A.bytes[A.ncols++] = n * es;
+      }
+      for (int j = 0; j < P.nmetric; ++j) {
+        const size_t es = vh_elem_size(r->metric_elem[j]);
+        A.src[A.ncols] = (second ? (const char*)r->d_out_state2[j] : (const char*)r->d_out_state[j]) + src_row * es; A.dst[A.ncols] = H + L.state[j] + dst_row * es; A.bytes[A.ncols++] = n * es;
+      }
+      hipLaunchKernelGGL(deliver_kernel, dim3((unsigned)knobs().deliver_blocks), dim3(256), 0, cs, A);
+      HIP_TRY(hipGetLastError());
+      return VH_OK;
+    }
+    for (int i = 0; i < P.ngroup; ++i) {
+      const size_t es = vh_elem_size(P.g[i].type());
+      HIP_TRY(hipMemcpyAsync(H + L.key[i] + dst_row * es, (second ? (const char*)r->d_out_key2[i] : (const char*)r->d_out_key[i]) + src_row * es, n * es, hipMemcpyDeviceToHost, cs));
+    }
+    for (int j = 0; j < P.nmetric; ++j) {
+      const size_t es = vh_elem_size(r->metric_elem[j]);
+      HIP_TRY(hipMemcpyAsync(H + L.state[j] + dst_row * es, (second ? (const char*)r->d_out_state2[j] : (const char*)r->d_out_state[j]) + src_row * es, n * es, hipMemcpyDeviceToHost, cs));
+    }
+    return VH_OK;
+  };
+  // streamed result: every finished chunk's rows go out on the copy stream, packed one chunk behind the other, while the next chunks run.
+  // The staging buffer is sized when the first chunk's count is in (the mixed key deals the groups evenly: eight times that, and a bit);
+  // should the rest not fit after all, everything is copied once more when all counts are known.
+  uint64_t streamed = 0;
+  Packed L{};
+  if (r->hp_chunks) {
+    uint64_t cnt[VH_HP_CHUNKS] = {}, rows_cap = 0;
+    bool redo = false;
+    for (int c = 0; c < r->hp_chunks; ++c) {
+      HIP_TRY(wait_event_spinning(x->ev_chunk[c]));
+      cnt[c] = std::min<uint64_t>(reinterpret_cast<volatile unsigned long long*>(x->h_chunk)[c], r->hp_chunk_rows);      // (more: the region overflowed, the attempt is void — flagged in the header)
+      if (c == 0) {
+        rows_cap = cnt[0] * (uint64_t)r->hp_chunks + cnt[0] / 4 + 65536;
+        L = packed_for(rows_cap);
+        if (int src = stage(L.bytes)) return src;
+      }
+      if (streamed + cnt[c] > rows_cap) redo = true;
+      if (cnt[c] && !redo) { if (int crc = copy_rows(L, streamed, (uint64_t)c * r->hp_chunk_rows, cnt[c], false, x->copy)) return crc; }
+      streamed += cnt[c];
+    }
+    if (redo) {
+      HIP_TRY(hipStreamSynchronize(x->copy));
+      L = packed_for(streamed);
+      if (int src = stage(L.bytes)) return src;
+      uint64_t at = 0;
+      for (int c = 0; c < r->hp_chunks; ++c) { if (cnt[c]) { if (int crc = copy_rows(L, at, (uint64_t)c * r->hp_chunk_rows, cnt[c], false, x->copy)) return crc; } at += cnt[c]; }
+    }
+  }
   VhTopkState tk{};
   if (r->topk_active) HIP_TRY(hipMemcpyAsync(&tk, r->d_topk_state, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-  // small results: counters, group count and every output array come back in ONE copy + ONE sync
+  // small results: counters, group count and every output array come back in ONE copy + ONE sync; big ones: the header first
+  unsigned long long* const head = one_shot ? reinterpret_cast<unsigned long long*>(x->h_out[slot]) : x->h_counters + 16;
   if (direct) {
-    hipLaunchKernelGGL(publish_header_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned long long*>(H),
-                       reinterpret_cast<const unsigned long long*>(D));
+    hipLaunchKernelGGL(publish_header_kernel, dim3(1), dim3(64), 0, st, head, reinterpret_cast<const unsigned long long*>(D));
     HIP_TRY(hipGetLastError());
   } else {
-    HIP_TRY(hipMemcpyAsync(H, D, one_shot ? r->out_region_bytes : 512, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(head, D, one_shot ? r->out_region_bytes : 512, hipMemcpyDeviceToHost, st));
   }
   HIP_TRY(hipEventRecord(x->ev[3], st));
   HIP_TRY(wait_event_spinning(x->ev[3]));
-  const unsigned long long* hc = reinterpret_cast<const unsigned long long*>(H);
+  const unsigned long long* hc = head;
   const unsigned long long err = hc[2];
+  if (r->hp_chunks) HIP_TRY(hipStreamSynchronize(x->copy));      // (also when the attempt is void: the next one rewrites what the copies read)
   if (err & VH_ERR_HP_WIDE) { *retry = 6; return VH_OK; }        // packed tuples met a value beyond the recorded min / max: the plain hash table
   if (err & VH_ERR_HPART_FULL) { *retry = 4; return VH_OK; }
   if (err & VH_ERR_HASH_FULL) { *retry = 1; return VH_OK; }
   if (err & VH_ERR_PART_FULL) { r->info.passed_recs = hc[0]; *retry = 3; return VH_OK; }   // phase 1 ran to the end: the survivors are counted
   if (err & VH_ERR_RANGE) { *retry = 2; return VH_OK; }
-  uint64_t ng = *reinterpret_cast<const unsigned long long*>(H + 256);          // rows emitted (after HAVING)
+  uint64_t ng = r->hp_chunks ? streamed : hc[32];                                 // rows emitted (after HAVING): the word at byte 256
   r->info.ngroups = r->nhaving ? hc[6] : ng;                                     // agg_map.size()
   if (r->topk_active) ng = tk.out_count;                                          // rows kept by the top-N superset
   r->info.returned_groups = ng;
   r->ngroups_host = ng;
   r->info.passed_recs = hc[0];
-  r->h_base = H;
-  if (!one_shot && ng) {
-    for (int i = 0; i < P.ngroup; ++i)
-      HIP_TRY(hipMemcpyAsync(H + r->off_key[i], r->topk_active ? (const char*)r->d_out_key2[i] : D + r->off_key[i],
-                             ng * vh_elem_size(P.g[i].type()), hipMemcpyDeviceToHost, st));
-    for (int j = 0; j < P.nmetric; ++j)
-      HIP_TRY(hipMemcpyAsync(H + r->off_state[j], r->topk_active ? (const char*)r->d_out_state2[j] : D + r->off_state[j],
-                             ng * vh_elem_size(r->metric_elem[j]), hipMemcpyDeviceToHost, st));
-  }
   if (!one_shot) {
-    HIP_TRY(hipEventRecord(x->ev[3], st));
-    HIP_TRY(wait_event_spinning(x->ev[3]));
+    if (!r->hp_chunks) {           // a big result in one piece: the staging buffer is sized for the rows there are
+      L = packed_for(ng);
+      if (int src = stage(L.bytes)) return src;
+      if (ng) { if (int crc = copy_rows(L, 0, 0, ng, r->topk_active, st)) return crc; }
+      HIP_TRY(hipEventRecord(x->ev[3], st));
+      HIP_TRY(wait_event_spinning(x->ev[3]));
+    }
+    memcpy(x->h_out[slot], head, 512);
+    for (int i = 0; i < P.ngroup; ++i) r->off_key[i] = L.key[i];      // (the host view: where vh_result_view finds the columns)
+    for (int j = 0; j < P.nmetric; ++j) r->off_state[j] = L.state[j];
   }
+  r->h_base = x->h_out[slot];
   float ms = 0;
   (void)hipEventElapsedTime(&ms, x->ev[1], x->ev[2]); r->info.scan_kernel_ms = ms;
   (void)hipEventElapsedTime(&ms, x->ev[0], x->ev[3]); r->info.total_ms = ms;
@@ -3413,7 +3600,7 @@ static int query_agg_multipass(vh_table* t, const vh_plan* plan, vh_result** out
     rf->metric_elem.push_back(src[u].first->metric_elem[src[u].second]);
     off_state[u] = bytes; bytes += (std::max<uint64_t>(n, 1) * vh_elem_size(rf->metric_elem.back()) + 255) / 256 * 256;
   }
-  HIP_TRY(hipHostMalloc((void**)&rf->h_own, bytes, hipHostMallocDefault));
+  HIP_TRY(host_alloc_near_device((void**)&rf->h_own, bytes, hipHostMallocDefault));
   for (int i = 0; i < nk; ++i) if (n) memcpy(rf->h_own + rf->off_key[i], base->h_base + base->off_key[i], n * vh_elem_size(base->plan.g[i].type()));
   for (size_t u = 0; u < src.size(); ++u) {
     const vh_result* pr = src[u].first;
@@ -3586,7 +3773,7 @@ extern "C" int vh_query_select(vh_table* t, const vh_select_plan* sp, vh_rows** 
     if (bytes > ((size_t)64 << 30)) return vh_fail(VH_E_NOMEM, "select would return %llu rows (%zu bytes): add a limit", (unsigned long long)output_recs, bytes);
     if (bytes) {
       HIP_TRY(hipMalloc((void**)&rows->d_out, bytes));
-      HIP_TRY(hipHostMalloc((void**)&rows->h_out, bytes, hipHostMallocDefault));
+      HIP_TRY(host_alloc_near_device((void**)&rows->h_out, bytes, hipHostMallocDefault));
     }
     VhSelectDev D{};
     D.ncols = sp->ncols;

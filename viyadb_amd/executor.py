@@ -308,8 +308,7 @@ class DeviceTable:
             return a.copy() if copy else a
 
         keys = [view(kp[i], capi.ELEM_NP[self.cols[g.col][1]]) for i, g in enumerate(plan.groups)]
-        states = [view(spp[j], np.uint64 if m == capi.COL_ROWID or self.cols[m][1] >= capi.BITSET32 else capi.ELEM_NP[self.cols[m][1]])
-                  for j, m in enumerate(plan.metrics)]
+        states = [view(spp[j], capi.ELEM_NP[self.lib.vh_result_state_elem(res, j)]) for j in range(len(plan.metrics))]       # (the library says what it delivers)
         hidden = view(C.cast(hp, C.c_void_p).value, np.uint64) if info.has_hidden_count else None
         return AggResult(keys, states, hidden, int(info.ngroups), int(info.scanned_recs), int(info.scanned_segments),
                          int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
