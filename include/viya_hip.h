@@ -197,6 +197,7 @@ enum vh_plan_flags {
   VH_PLAN_FORCE_HPART = 1u << 20, /* testing: hashed partitioning whenever the plan is eligible, however small the table  */
   VH_PLAN_NO_HP_PACK = 1u << 21,  /* ablation: a count-distinct's tuples keep their ids in words of their own (32 bytes) even when payload,
                                      two ids and their count would fit the tuple's second word (16 bytes) */
+  VH_PLAN_NO_NARROW_TUPLES = 1u << 23, /* ablation: DENSE_PART keeps two-word tuples even when gid and values would fit one */
   VH_PLAN_CARD32 = 1u << 22       /* the cardinality of a 32-bit-id bitset metric (count distinct) is delivered as a uint32 column instead of
                                      uint64 (it cannot exceed 2^32 - 1): vh_result_state_elem() tells what a state column holds */
 };

@@ -30,7 +30,7 @@ MAX_ROLLUP = 8
 PLAN_FORCE_HASH, PLAN_FORCE_GLOBAL, PLAN_NO_XCD_PRIVATE, PLAN_NO_FAST, PLAN_NO_PART, PLAN_NO_CARRIER, PLAN_FORCE_PART = 1, 2, 4, 8, 16, 32, 64
 PLAN_NO_LANES, PLAN_FORCE_LANES, PLAN_NO_LDS_HASH, PLAN_NO_HASH_RECORDS, PLAN_FORCE_HASH_RECORDS = 128, 256, 512, 1024, 2048
 PLAN_NO_PACK, PLAN_FORCE_PACK, PLAN_NO_PART2, PLAN_NO_SHAPE, PLAN_NO_NARROW = 4096, 8192, 16384, 32768, 65536
-PLAN_NO_JIT, PLAN_FORCE_JIT, PLAN_NO_HPART, PLAN_FORCE_HPART, PLAN_NO_HP_PACK, PLAN_CARD32 = 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22
+PLAN_NO_JIT, PLAN_FORCE_JIT, PLAN_NO_HPART, PLAN_FORCE_HPART, PLAN_NO_HP_PACK, PLAN_CARD32, PLAN_NO_NARROW_TUPLES = 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22, 1 << 23
 # paths
 PATH_SCALAR, PATH_DENSE_LDS, PATH_DENSE_GLOBAL, PATH_HASH, PATH_DENSE_PART = range(5)
 PATH_NAMES = ["scalar", "dense_lds", "dense_global", "hash", "dense_part"]

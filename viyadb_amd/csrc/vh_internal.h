@@ -132,7 +132,7 @@ struct VhPlanDev {
   uint64_t ilits[VH_INLINE_LITS];
   // ---- fast path (all predicate columns 4 bytes wide, <= VH_MAX_PRED of them): their slots
   int32_t npred;
-  int32_t pad1;
+  int32_t gid_bits;           // DENSE_PART with ONE-word tuples: word 0 = gid in its low gid_bits | every metric value at m[j].tshift, m[j].tbits wide (0: two or more words, the gid in word 0's low half)
   uint8_t pred_slot[8];
   uint8_t pred_width[8];      // bytes per element the kernel reads for predicate column p: 4, or 1 / 2 when the table keeps a narrow copy (vh_table_narrow)
   // ---- columns (slot -> arena)

@@ -252,7 +252,24 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
     if (active && bad) atomicOr(P.counters + 2, VH_ERR_RANGE);
   }
   active = active && !bad;
-  if constexpr (MODE == VH_MODE_DENSE_PART) {
+  if constexpr (MODE == VH_MODE_DENSE_PART && J::GID_BITS != 0) {
+    // ONE-word tuples: gid in the low GID_BITS, every metric value behind it at the width the planner read off the column's recorded
+    // min / max (refresh_stats) — half the bytes to write in phase 1 and to read back in phase 2, sixteen tuples per 128-byte line. A value
+    // that needs more bits than recorded voids the attempt (VH_ERR_HP_WIDE: the query is answered with direct atomics instead).
+    static_assert(J::TW == 1, "one-word tuples");
+    uint64_t words[1] = {gid};
+    bool wide = false;
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+      const uint64_t v = vh_sop_bytes(J::m_sop[j]) == 4 ? (mv[j] & 0xFFFFFFFFull) : mv[j];
+      wide |= (v >> J::m_tbits[j]) != 0ull;
+      words[0] |= v << J::m_tshift[j];
+    }
+    if (__ballot(active && wide)) { if (active && wide) atomicOr(P.counters + 2, VH_ERR_HP_WIDE); }
+    if (VJ_ABL & 8) { if (words[0] == 0x123456789ABCDEFull) P.counters[7] = 1; return; }
+    vh_part_staged_add<J::STAGE, 1>(P, T, W, S, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
+    return;
+  } else if constexpr (MODE == VH_MODE_DENSE_PART) {
     constexpr int TW = J::TW;
     uint64_t words[TW];
     words[0] = gid & 0xFFFFFFFFull;
@@ -398,7 +415,7 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
     if (MODE == VH_MODE_HASH && V.H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
   }
 
-  if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE != 0) vh_part_stage_finish(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); }
+  if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE != 0) vh_part_stage_finish<J::TW>(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); }
   if constexpr (MODE == VH_MODE_HASH && J::HPART) vh_part_tile_finish<1>(P, V.T, lane);
   if (lane == 0) {
     if (npassed) atomicAdd(P.counters + 0, npassed);

@@ -1031,22 +1031,31 @@ __device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTil
 #define VH_STAGE_PARTS 16                         // the small form: one pass of the line flush covers every partition
 #define VH_STAGE_PARTS_MAX 64                     // the wide form (a wave keeps at most one partition per lane): four passes
 #define VH_STAGE_BYTES(parts) ((parts) * 128)     // per wave
-struct VhPartStage { uint32_t r_stage; uint64_t* lines; };     // lines: LDS [parts][8][2]
+struct VhPartStage { uint32_t r_stage; uint64_t* lines; };     // lines: LDS [parts][128 bytes]
 typedef uint64_t vh_u64x2 __attribute__((ext_vector_type(2)));
+// TW = 64-bit words per tuple: 2 (eight tuples per line) or 1 (sixteen: the planner packed gid and values into one word, VhPlanDev::gid_bits)
+template <int TW> struct VhStageTuple;
+template <> struct VhStageTuple<2> { typedef vh_u64x2 type; static __device__ __forceinline__ type make(const uint64_t (&w)[2]) { type v; v.x = w[0]; v.y = w[1]; return v; } };
+template <> struct VhStageTuple<1> { typedef uint64_t type; static __device__ __forceinline__ type make(const uint64_t (&w)[1]) { return w[0]; } };
 
+template <int TW>
 __device__ __forceinline__ void vh_part_stage_close(const VhPlanDev& P, VhPartTile& T, VhPartStage& S, int q, int lane) {   // wave-uniform q
+  typedef typename VhStageTuple<TW>::type Tup;
+  constexpr uint32_t LT = 16u / TW;
   const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, q), fill = __builtin_amdgcn_readlane(T.r_fill, q), st = __builtin_amdgcn_readlane(S.r_stage, q);
   if (old == ~0u) return;
   const uint32_t et = (uint32_t)P.ext_tuples;
-  if ((uint32_t)lane < st) reinterpret_cast<vh_u64x2*>(P.tuples)[(uint64_t)old * (uint32_t)P.ext_stride + fill + lane] = reinterpret_cast<const vh_u64x2*>(S.lines)[q * 8 + lane];
+  if ((uint32_t)lane < st) reinterpret_cast<Tup*>(P.tuples)[(uint64_t)old * (uint32_t)P.ext_stride + fill + lane] = reinterpret_cast<const Tup*>(S.lines)[q * LT + lane];
   if (lane == 0) P.extent_missing[old] = (uint16_t)(et - (fill + st));
 }
 
 // SP: partitions the wave keeps a waiting line for — VH_STAGE_PARTS (16) or VH_STAGE_PARTS_MAX (64: group-id spaces of 17-64 LDS-sized
 // ranges and phase 1 of two-level plans, which used to fall back to piecewise appends).
-template <int SP>
+template <int SP, int TW = 2>
 __device__ __forceinline__ void vh_part_staged_add(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, VhPartStage& S, bool active,
-                                                   const uint64_t (&words)[2], uint32_t p, int lane) {
+                                                   const uint64_t (&words)[TW], uint32_t p, int lane) {
+  typedef typename VhStageTuple<TW>::type Tup;
+  constexpr uint32_t LT = 16u / TW;              // tuples per 128-byte line
   constexpr int BITS = SP <= 16 ? 4 : 6;
   const uint32_t npart = (uint32_t)P.npart, et = (uint32_t)P.ext_tuples, es = (uint32_t)P.ext_stride;
   const uint64_t act = __ballot(active);
@@ -1066,51 +1075,53 @@ __device__ __forceinline__ void vh_part_staged_add(const VhPlanDev& P, VhPartTil
   while (need) {
     const int q = __builtin_ctzll(need);
     need &= need - 1;
-    vh_part_stage_close(P, T, S, q, lane);       // what waits in LDS closes the old extent as a partial line
+    vh_part_stage_close<TW>(P, T, S, q, lane);       // what waits in LDS closes the old extent as a partial line
     const uint32_t ext = vh_part_new_extent<1>(P, W, q, lane);
     if (lane == q) { T.r_ext = ext; T.r_fill = 0; S.r_stage = 0; }
   }
   __builtin_amdgcn_wave_barrier();
-  vh_u64x2* const lines = reinterpret_cast<vh_u64x2*>(S.lines);
-  vh_u64x2* const pool = reinterpret_cast<vh_u64x2*>(P.tuples);
-  const uint32_t packed = T.r_fill | (S.r_stage << 16) | (cnt << 24);        // fill < 65536 (extent_missing is 16 bits wide), stage < 8, cnt <= 64
+  Tup* const lines = reinterpret_cast<Tup*>(S.lines);
+  Tup* const pool = reinterpret_cast<Tup*>(P.tuples);
+  const uint32_t packed = T.r_fill | (S.r_stage << 16) | (cnt << 24);        // fill < 65536 (extent_missing is 16 bits wide), stage < 16, cnt <= 64
   const uint32_t sp = active ? p : 0u;
   const uint32_t pe = (uint32_t)__shfl((int)T.r_ext, (int)sp), pk = (uint32_t)__shfl((int)packed, (int)sp);
   const uint32_t g = pk & 0xFFFFu, f = (pk >> 16) & 0xFFu, c = pk >> 24;
-  const uint32_t i = f + rank, whole = (f + c) & ~7u;                          // my tuple's place behind the extent's HBM part; tuples of the run that form whole lines
+  const uint32_t i = f + rank, whole = (f + c) & ~(LT - 1u);                    // my tuple's place behind the extent's HBM part; tuples of the run that form whole lines
   const bool ok = active && pe != ~0u;                                         // ~0: tuple pool exhausted, the host re-runs (VH_ERR_PART_FULL)
-  vh_u64x2 v; v.x = words[0]; v.y = words[1];
-  if (ok && i < 8u) lines[p * 8u + i] = v;                                     // completes the waiting line (or just waits with it)
+  const Tup v = VhStageTuple<TW>::make(words);
+  if (ok && i < LT) lines[p * LT + i] = v;                                     // completes the waiting line (or just waits with it)
   __builtin_amdgcn_wave_barrier();
-  // the waiting line of every partition that now has eight tuples: lane l stores quarter l & 3 of partition 16 * pass + (l >> 2)
-  const uint64_t full_lines = __ballot(cnt != 0 && S.r_stage + cnt >= 8u && T.r_ext != ~0u);       // (lane q speaks for partition q)
+  // the waiting line of every partition that is now full: lane l stores quarter l & 3 (32 bytes) of partition 16 * pass + (l >> 2)
+  const uint64_t full_lines = __ballot(cnt != 0 && S.r_stage + cnt >= LT && T.r_ext != ~0u);       // (lane q speaks for partition q)
 #pragma unroll
   for (int pass = 0; pass < SP / 16; ++pass) {
     if (!((full_lines >> (16 * pass)) & 0xFFFFull)) continue;                  // (wave-uniform)
     const uint32_t q = (uint32_t)(16 * pass) + ((uint32_t)lane >> 2), part4 = (uint32_t)lane & 3u;
     const uint32_t qe = (uint32_t)__shfl((int)T.r_ext, (int)q), qk = (uint32_t)__shfl((int)packed, (int)q);
     const uint32_t qg = qk & 0xFFFFu, qf = (qk >> 16) & 0xFFu, qc = qk >> 24;
-    if (q < npart && qe != ~0u && qc != 0 && qf + qc >= 8u) {
-      const vh_u64x2 a = lines[q * 8u + part4 * 2u], b2 = lines[q * 8u + part4 * 2u + 1u];
-      vh_u64x2* d = pool + (uint64_t)qe * es + qg + part4 * 2u;
+    if (q < npart && qe != ~0u && qc != 0 && qf + qc >= LT) {
+      const vh_u64x2* lq = reinterpret_cast<const vh_u64x2*>(S.lines) + q * 8u;      // (a line is eight 16-byte pieces whatever the tuple)
+      const vh_u64x2 a = lq[part4 * 2u], b2 = lq[part4 * 2u + 1u];
+      vh_u64x2* d = reinterpret_cast<vh_u64x2*>(pool + (uint64_t)qe * es + qg) + part4 * 2u;
       d[0] = a; d[1] = b2;
     }
   }
   __builtin_amdgcn_wave_barrier();
-  if (ok && i >= 8u) {
-    if (i < whole) pool[(uint64_t)pe * es + g + i] = v;                        // a whole line in the middle of the run: eight consecutive ranks, one store instruction
-    else lines[p * 8u + (i - whole)] = v;                                      // the remainder waits for the next drain
+  if (ok && i >= LT) {
+    if (i < whole) pool[(uint64_t)pe * es + g + i] = v;                        // a whole line in the middle of the run: LT consecutive ranks, one store instruction
+    else lines[p * LT + (i - whole)] = v;                                      // the remainder waits for the next drain
   }
-  if (T.r_ext != ~0u) { const uint32_t tot = S.r_stage + cnt; T.r_fill += tot & ~7u; S.r_stage = tot & 7u; }
+  if (T.r_ext != ~0u) { const uint32_t tot = S.r_stage + cnt; T.r_fill += tot & ~(LT - 1u); S.r_stage = tot & (LT - 1u); }
   __builtin_amdgcn_wave_barrier();
 }
 
+template <int TW = 2>
 __device__ __forceinline__ void vh_part_stage_finish(const VhPlanDev& P, VhPartTile& T, VhPartStage& S, int lane) {   // open extents are closed with what they hold
   uint64_t open = __ballot(T.r_ext != ~0u);
   while (open) {
     const int q = __builtin_ctzll(open);
     open &= open - 1;
-    vh_part_stage_close(P, T, S, q, lane);
+    vh_part_stage_close<TW>(P, T, S, q, lane);
   }
 }
 
@@ -1889,8 +1900,17 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
       if ((P.m[j].sop() == SOP_ADD32 || P.m[j].sop() == SOP_ADD32P) && P.m[j].tword() == 0 && P.m[j].tshift() == 32) j32 = j;
     }
   const bool sum_pair = j64 >= 0 && j32 >= 0 && (P.m[j32 < 0 ? 0 : j32].sop() == SOP_ADD32P) == carried;
-  unsigned long long* const sum64 = reinterpret_cast<unsigned long long*>(lds + P.m[j64 < 0 ? 0 : j64].lds_off);
-  char* const sum32 = lds + P.m[j32 < 0 ? 0 : j32].lds_off;
+  // one-word tuples (VhPlanDev::gid_bits): the gid's mask, and the SUM(64-bit) + SUM(32-bit, presence carrier) pair's shifts and masks
+  const uint64_t gid_mask = P.gid_bits ? (1ull << P.gid_bits) - 1ull : 0xFFFFFFFFull;
+  int k64 = -1, k32 = -1;
+  if (P.gid_bits && P.tw == 1 && P.nmetric == 2)
+    for (int j = 0; j < 2; ++j) { if (P.m[j].sop() == SOP_ADD64) k64 = j; if (P.m[j].sop() == SOP_ADD32P) k32 = j; }
+  const bool pk_pair = k64 >= 0 && k32 >= 0 && carried;
+  const uint32_t pk_s64 = P.m[k64 < 0 ? 0 : k64].tshift(), pk_s32 = P.m[k32 < 0 ? 0 : k32].tshift();
+  const uint64_t pk_m64 = (1ull << P.m[k64 < 0 ? 0 : k64].tbits) - 1ull, pk_m32 = (1ull << P.m[k32 < 0 ? 0 : k32].tbits) - 1ull;
+  if (pk_pair) { /* sum64 / sum32 below point at the pair's LDS arrays */ }
+  unsigned long long* const sum64 = reinterpret_cast<unsigned long long*>(lds + P.m[pk_pair ? k64 : j64 < 0 ? 0 : j64].lds_off);
+  char* const sum32 = lds + P.m[pk_pair ? k32 : j32 < 0 ? 0 : j32].lds_off;
   const uint32_t gsz = vh_tag_group(total - first, (uint32_t)blocks_per_part * nwaves);
   // Per step a wave looks at gsz tags AND the fill of those extents (one vector load each, side by side: a dependent scalar load
   // per extent was a serial memory round trip — phase 1 leaves ~80 K extents of ~600 tuples on C3), then walks the extents that
@@ -1934,6 +1954,16 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
       if (acc == 0x123456789ABCDEFull) P.counters[7] = acc;
       continue;
     }
+    if (pk_pair) {        // the same shape in ONE-word tuples: gid | the 64-bit SUM's value | the 32-bit one's, each at the width the planner gave it
+#pragma unroll
+      for (int u = 0; u < VH_P2_SLOTS; ++u) {
+        const uint64_t w0 = w[u][0], local = (w0 & gid_mask) - g0;
+        if (w0 == ~0ull || local >= ng) continue;
+        __hip_atomic_fetch_add(sum64 + local, (unsigned long long)((w0 >> pk_s64) & pk_m64), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(reinterpret_cast<unsigned long long*>(sum32) + local, (1ull << 32) | ((w0 >> pk_s32) & pk_m32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      continue;
+    }
     if (sum_pair) {       // the common shape, without the per-tuple walk over the plan's metric descriptors (550 -> ~60 instructions per 256 tuples)
 #pragma unroll
       for (int u = 0; u < VH_P2_SLOTS; ++u) {
@@ -1950,7 +1980,7 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
     }
 #pragma unroll
     for (int u = 0; u < VH_P2_SLOTS; ++u) {
-      const uint64_t local = (w[u][0] & 0xFFFFFFFFull) - g0;
+      const uint64_t local = (w[u][0] & gid_mask) - g0;
       if (w[u][0] == ~0ull || local >= ng) continue;  // an empty slot; (a corrupt tuple cannot write outside the table)
       if (!carried) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[local] = 1;
 #pragma unroll
@@ -1961,7 +1991,8 @@ __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int 
 #pragma unroll
           for (int x = 0; x < 1 + VH_FAST_COLS; ++x)
             if (m.tword() == (uint32_t)x) v = w[u][x] >> m.tshift();
-          if (vh_sop_bytes(m.sop()) == 4) {
+          if (P.gid_bits && m.tbits) v &= (1ull << m.tbits) - 1ull;      // (one-word tuples: never negative, the planner checked the column's minimum)
+          else if (vh_sop_bytes(m.sop()) == 4) {
             v &= 0xFFFFFFFFull;
             if (vh_sop_sext(m.sop())) v = (uint64_t)(int64_t)(int32_t)v;
           }

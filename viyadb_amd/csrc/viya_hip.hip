@@ -2151,6 +2151,34 @@ int QueryBuild::choose_organisation() {
         else { P.m[j].set_tword((uint8_t)tw); P.m[j].set_tshift(0); half_free_word = tw++; have_half = true; }
       }
       P.tw = tw;
+      // ONE-word tuples when gid and every metric value fit 63 bits together — what the values need is known from the columns' recorded
+      // min / max (refresh_stats keeps them for metric columns too): C3's (gid 17 bits, SUM value 10, COUNT 2) is 8 bytes instead of 16,
+      // half the tuple bytes written by phase 1 and read back by phase 2. Only the compiled scan with the whole-line writer packs them.
+      P.gid_bits = 0;
+      if (jit_try && !lanes && !two_level && np <= VH_STAGE_PARTS_MAX && !knobs().no_stage && !(p->flags & VH_PLAN_NO_NARROW_TUPLES) && !getenv("VH_NO_NARROW_TUPLES")) {
+        auto bits_of = [](uint64_t v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; };
+        const int gb = bits_of(G - 1);
+        int used = gb, mb[VH_MAX_METRIC] = {};
+        bool fits = true;
+        for (int j = 0; j < P.nmetric && fits; ++j) {
+          const int col = metric_col[j];
+          if (col < 0) { fits = false; break; }
+          const VhColumn& c = t->cols[col];
+          if (c.elem == VH_F32 || c.elem == VH_F64) { fits = false; break; }
+          uint64_t klo = ~0ull, khi = 0;
+          for (uint32_t sgi : live) { const VhSegStat& st = t->stats[col][sgi]; if (st.lo > st.hi) continue; klo = std::min(klo, st.lo); khi = std::max(khi, st.hi); }
+          if (klo > khi) klo = khi = order_key_of_bits(c.elem, 0);
+          const bool sgn = c.elem == VH_I8 || c.elem == VH_I16 || c.elem == VH_I32 || c.elem == VH_I64;
+          if (sgn && (int64_t)(klo ^ (1ull << 63)) < 0) { fits = false; break; }      // negative values: the tuple's fields are unsigned
+          mb[j] = bits_of(sgn ? (khi ^ (1ull << 63)) : bits_of_order_key(c.elem, khi));
+          used += mb[j];
+        }
+        if (fits && used <= 63) {
+          P.gid_bits = gb; P.tw = 1;
+          int at = gb;
+          for (int j = 0; j < P.nmetric; ++j) { P.m[j].set_tword(0); P.m[j].set_tshift((uint8_t)at); P.m[j].tbits = (uint32_t)mb[j]; at += mb[j]; }
+        }
+      }
       // the drain specialised for "two unsigned 32-bit group columns, SUM(64-bit) + SUM(32-bit)" (vh_consume_fast, SHAPE 1)
       P.shape = 0;
       if (!jit_try && !lanes && !(p->flags & VH_PLAN_NO_SHAPE) && (P.ngroup == 1 || P.ngroup == 2) && P.nmetric == 2 && tw == 2 && G <= 0xFFFFFFFFull) {   // (a per-query compiled kernel knows the whole plan, not two shapes of it)
@@ -2509,7 +2537,8 @@ int QueryBuild::compile_kernel() {
     js.lds_hash = P.lds_hash_slots ? 1 : 0;
     js.gid32 = mode != VH_MODE_HASH && G <= 0xFFFFFFFFull;
     const bool env_no_stage = knobs().no_stage;             // measurement: tuples appended piece by piece (vh_part_direct_add)
-    js.stage = mode == VH_MODE_DENSE_PART && P.tw == 2 && !env_no_stage ? (P.npart <= VH_STAGE_PARTS ? VH_STAGE_PARTS : P.npart <= VH_STAGE_PARTS_MAX ? VH_STAGE_PARTS_MAX : 0) : 0;
+    js.gid_bits = mode == VH_MODE_DENSE_PART ? P.gid_bits : 0;
+    js.stage = mode == VH_MODE_DENSE_PART && (P.tw == 2 || P.gid_bits) && !env_no_stage ? (P.npart <= VH_STAGE_PARTS ? VH_STAGE_PARTS : P.npart <= VH_STAGE_PARTS_MAX ? VH_STAGE_PARTS_MAX : 0) : 0;
     js.hpart = hpart ? 1 : 0;
     js.hp_pack = hp_pack ? 1 : 0; js.hp_pbits = hp_pbits; js.hp_idbits = hp_idbits;
     js.ng = P.ngroup; js.nm = P.nmetric;
@@ -2530,7 +2559,7 @@ int QueryBuild::compile_kernel() {
       c.rowid = m.slot() == VH_SLOT_ROWID;
       c.bitset = m.sop() == SOP_BITSET;
       if (c.bitset) js.bitset_j = j;
-      c.type = (int)m.type(); c.sop = (int)m.sop(); c.tword = (int)m.tword(); c.tshift = (int)m.tshift(); c.tbits = hp_pack ? (int)m.tbits : 0;
+      c.type = (int)m.type(); c.sop = (int)m.sop(); c.tword = (int)m.tword(); c.tshift = (int)m.tshift(); c.tbits = hp_pack || (mode == VH_MODE_DENSE_PART && P.gid_bits) ? (int)m.tbits : 0;
       c.sext = vh_sop_sext((int)m.sop());
       if (!c.rowid && !c.bitset) { c.slot = (int)m.slot(); c.pitch = (int)P.colpitch[m.slot()]; c.rec = slot_rec[m.slot()]; c.off = slot_recoff[m.slot()]; c.stored = slot_stored[m.slot()]; }
     }
@@ -2553,7 +2582,7 @@ int QueryBuild::compile_kernel() {
       }
     }
   }
-  if (!jk && packed_compressed) {      // compressed records and no compiled kernel to read them after all: plan again for the pre-built ones
+  if (!jk && (packed_compressed || (mode == VH_MODE_DENSE_PART && P.gid_bits))) {      // compressed records / one-word tuples and no compiled kernel to handle them after all: plan again for the pre-built ones
     vh_plan p2 = *p;
     p2.flags |= VH_PLAN_NO_JIT;
     holder.reset();
@@ -2728,7 +2757,7 @@ int QueryBuild::layout_scratch() {
     P.ext_tuples = (int32_t)ext_tuples;
     // extents of pool 1 start one 128-byte line further apart than they are long (not the stream pools of the hashed partitioning, whose
     // reader takes extents as whole tiles): see VhPlanDev::ext_stride
-    const uint64_t ext_stride = hpart ? ext_tuples : ext_tuples + (uint64_t)knobs().ext_pad;
+    const uint64_t ext_stride = hpart ? ext_tuples : ext_tuples + (P.gid_bits ? ((uint64_t)knobs().ext_pad + 15) / 16 * 16 : (uint64_t)knobs().ext_pad);      // (whole 128-byte lines: 8 two-word tuples, 16 one-word ones)
     P.ext_stride = (int32_t)ext_stride;
     uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
     if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
@@ -3525,7 +3554,7 @@ static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
     }
     rp->cap_override = next;
   }
-  else if (retry == 6) rp->no_hpart = true;
+  else if (retry == 6) { if (r->hpart) rp->no_hpart = true; else rp->no_part = true; }      // a value beyond its column's recorded range in a packed tuple
   else if (retry == 4) {                                     // hashed partitioning: a range held more groups (or ids) than its passes' LDS tables take
     if (r->plan.hp_passes >= 64) rp->no_hpart = true;        // ... skewed beyond help: the plain hash table
     else rp->hp_passes = (uint32_t)r->plan.hp_passes * 4;
