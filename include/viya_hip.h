@@ -253,7 +253,9 @@ typedef struct vh_result_info {
                                 bit 5: a scan kernel compiled for this plan shape ran (vh_jit.hip);
                                 bit 6: hashed partitioning of the hash path (vh_hpart.h);
                                 bit 7: the projection's records are compressed (integers at the width their values need);
-                                bit 8: the hashed partitioning's tuples were packed (16 bytes: payload, two ids and their count in one word) */
+                                bit 8: the hashed partitioning's tuples were packed (16 bytes: payload, two ids and their count in one word);
+                                bit 9: the tuple pool lies in a scratch buffer chosen by measurement (vh_table_prepare);
+                                bit 10: DENSE_PART wrote one-word tuples (gid and values packed into 8 bytes) */
   uint64_t returned_groups;  /* rows vh_result_copy delivers (= ngroups without HAVING) */
 } vh_result_info;
 
@@ -498,6 +500,13 @@ VH_API int vh_rows_get_info(vh_rows* r, vh_rows_info* info);
 VH_API int vh_rows_view(vh_rows* r, const void** cols);
 VH_API void vh_rows_free(vh_rows* r);
 
+/* Pays a plan shape's first-use costs NOW instead of on its first queries: compiles the scan kernel for the shape (the reference does
+ * the same when a query shape is first seen: Compiler::Compile, src/codegen/compiler.cc:97-144, reported as QueryStats::compile_time), builds
+ * the payload projection and narrow predicate copies a selective query would get after VH_AUTO_PACK / VH_AUTO_NARROW uses, and — here only —
+ * may place a big tuple pool by measurement (bounded: half of the free device memory, 48 GB, 8 candidates; released before returning). Runs
+ * the plan up to three times, discards the rows; *info (may be NULL) describes the last run: vh_result_info.reserved says what a
+ * steady-state query of this shape runs on (compiled kernel, projection, narrow copies, placed pool). */
+VH_API int vh_table_prepare(vh_table* t, const vh_plan* plan, vh_result_info* info);
 VH_API int vh_result_get_info(vh_result* r, vh_result_info* info);
 /* Symbol(s) of the scan kernel(s) this query launched, spelled as rocprofv3 prints them ("scan_agg_fast_kernel<4, 256, 4, 3> +
  * part_agg_kernel<1024>"): what a profile of the same command must show. Valid until vh_result_free. */

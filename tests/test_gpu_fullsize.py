@@ -147,10 +147,11 @@ def test_c5_per_gpu_share_properties():
 
 
 def test_tuple_pool_is_placed_by_measurement(tmp_path):
-    """A context that needs a scratch buffer for a tuple pool of >= 256 MB tries candidates out with the query's own access mix and keeps
-    the fastest one it saw (place_scratch, viya_hip.hip; profiles/r03/NOTES.md "Where the tuple pool lands"): the trace of a C3 run over
-    400 M rows names the candidates' scores and the one kept — the fastest, and the buffer the context ends up with —, once per table for
-    two placements of the derived layouts of which the better is kept, and VH_PLACE_TRIALS=1 switches all of it off."""
+    """vh_table_prepare (bench.py calls it before timing) may place a tuple pool of >= 128 MB by measurement: candidates are tried out with
+    the query's own access mix and the fastest one seen is kept (place_search, viya_hip.hip; profiles/r03/NOTES.md "Where the tuple pool
+    lands"). The trace of a C3 run over 400 M rows names the candidates' scores and the one kept — the fastest, and the buffer the context
+    ends up with —, once per table for two placements of the derived layouts of which the better is kept. VH_PLACE_TRIALS=1 switches all
+    of it off, and an ORDINARY query (no prepare: --no-warm) never searches: it takes the buffer hipMalloc hands it."""
     import json
     import os
     import re
@@ -188,3 +189,6 @@ def test_tuple_pool_is_placed_by_measurement(tmp_path):
     assert line["config"]["table_path"] == "dense_part"
     r1 = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, VH_TRACE_ALLOC="1", VH_PLACE_TRIALS="1"))
     assert r1.returncode == 0 and "scratch candidate" not in r1.stderr
+    r2 = subprocess.run(cmd + ["--no-warm"], capture_output=True, text=True, timeout=600, env=dict(os.environ, VH_TRACE_ALLOC="1"))
+    assert r2.returncode == 0 and "scratch candidate" not in r2.stderr
+    assert json.loads(r2.stdout.strip().splitlines()[-1])["config"]["pool_placed_by_measurement"] is False and line["config"]["pool_placed_by_measurement"] is True

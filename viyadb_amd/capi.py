@@ -159,6 +159,7 @@ SYMBOLS = {
     "vh_rows_view": (C.c_int, [_VP, C.POINTER(_VP)]),
     "vh_rows_free": (None, [_VP]),
     "vh_result_get_info": (C.c_int, [_VP, C.POINTER(ResultInfo)]),
+    "vh_table_prepare": (C.c_int, [_VP, C.POINTER(Plan), C.POINTER(ResultInfo)]),
     "vh_result_kernel": (C.c_char_p, [_VP]),
     "vh_result_state_elem": (C.c_int, [_VP, C.c_int32]),
     "vh_result_copy": (C.c_int, [_VP, C.POINTER(_VP), C.POINTER(_VP), C.POINTER(C.c_uint64)]),

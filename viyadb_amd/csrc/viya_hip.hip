@@ -81,7 +81,7 @@ static const VhKnobs& knobs() {
     x.auto_narrow = num("VH_AUTO_NARROW", 3); x.auto_pack = num("VH_AUTO_PACK", 3);
     x.jit_ablate = num("VH_JIT_ABLATE", 0); x.hp_ablate = num("VH_HP_ABLATE", 0); x.hp_bpp = num("VH_HP_BPP", 0); x.pack_plain = num("VH_PACK_PLAIN", 0);
     x.lanes_block = num("VH_LANES_BLOCK", 0); x.blocks_per_cu = num("VH_BLOCKS_PER_CU", 0); x.unit_rows = num("VH_UNIT_ROWS", 0); x.grid = num("VH_GRID", 0);
-    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.place_trials = num("VH_PLACE_TRIALS", 12); x.place_gb = std::max(1, num("VH_PLACE_GB", 96)); x.hp_list = num("VH_HP_LIST", 0);
+    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.place_trials = num("VH_PLACE_TRIALS", 8); x.place_gb = std::max(1, num("VH_PLACE_GB", 48)); x.hp_list = num("VH_HP_LIST", 0);
     x.hp_stream = num("VH_HP_STREAM", 0);             // chunk launches of a streamed result (0: off — measured: the link, not the wait for the kernels, bounds the delivery; profiles/r04/NOTES.md)
     x.deliver_blocks = num("VH_DELIVER_BLOCKS", 64);  // blocks of deliver_kernel; 0: big results through hipMemcpyAsync (the DMA engine)
     x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
@@ -193,7 +193,7 @@ struct VhSegStat {          // order keys as produced by seg_minmax_kernel
 // never reused under it.
 struct VhExec {
   hipStream_t own_stream = nullptr;
-  char* scratch = nullptr; size_t scratch_bytes = 0;
+  char* scratch = nullptr; size_t scratch_bytes = 0; bool scratch_placed = false;      // placed: chosen among candidates by vh_table_prepare (place_search)
   uint32_t* h_segrows = nullptr; size_t h_segrows_cap = 0;
   unsigned long long* h_counters = nullptr;     // pinned: 16 words of counters + 64 words for a big result's header
   char* d_sample = nullptr; size_t d_sample_bytes = 0;   // selectivity probe: counters + presence + seg rows
@@ -418,17 +418,21 @@ struct VhPlaceHint {
 // a tuple pool of >= 256 MB, it allocates candidates one after the other, each pushed away from the last by a 6 GB spacer (at most VH_PLACE_TRIALS = 12 of them,
 // three quarters of what is free and VH_PLACE_GB = 96 GB; everything but the winner released again), runs the access mix of a partitioning scan in miniature against THIS query's
 // own columns on each (place_probe_kernel: ~1 ms per run) and keeps the fastest. One-off per context and size, like a kernel compile.
+// vh_table_prepare: the calling thread's queries build derived layouts at once (not after VH_AUTO_PACK / VH_AUTO_NARROW uses) and may place a
+// big tuple pool by measurement. An ORDINARY query never searches: it would hold tens of GB of free memory under the table lock for
+// up to seconds, and a database process has other tables to allocate for meanwhile.
+static thread_local bool g_preparing = false;
 static std::mutex g_place_mu;      // one trial at a time: while it runs, most of the free memory is held (for some tens of milliseconds)
 static int place_search(VhExec* x, size_t nb, const VhPlaceHint& h, void** out_ptr, float* out_score) {
-  const int trials = knobs().place_trials;
+  const int trials = g_preparing ? knobs().place_trials : 1;
   std::lock_guard<std::mutex> lk(g_place_mu);
   const auto t_begin = std::chrono::steady_clock::now();
   size_t free_b = 0, total_b = 0;
-  if (trials < 2 || h.pool_bytes < ((size_t)256 << 20) || h.nstream < 1 || h.stream_bytes[0] < ((size_t)64 << 20) || !h.gather_src || h.gather_bytes < ((size_t)64 << 20) ||
-      hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b / 4 * 3 < 2 * nb) return 1;      // (1: not tried, the caller allocates plainly)
+  if (trials < 2 || h.pool_bytes < ((size_t)128 << 20) || h.nstream < 1 || h.stream_bytes[0] < ((size_t)64 << 20) || !h.gather_src || h.gather_bytes < ((size_t)64 << 20) ||
+      hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b / 2 < 2 * nb) return 1;      // (1: not tried, the caller allocates plainly)
   // (the driver clears memory another process left dirty when it is handed out again, at ~35 GB/s: the search stops early and is bounded,
   // so that it stays a 0.3-2.5 s one-off — about a kernel compile — and tens of milliseconds on a clean device)
-  const size_t budget = std::min<size_t>(free_b / 4 * 3, (size_t)knobs().place_gb << 30);
+  const size_t budget = std::min<size_t>(free_b / 2, (size_t)knobs().place_gb << 30);      // never more than half of what is free, nor VH_PLACE_GB (48 GB)
   const size_t spacer = (size_t)6 << 30;          // classes last for tens of GB: candidates ~9 GB apart sample them
   hipStream_t st = x->stream();
   VhPlaceArgs A{};
@@ -480,7 +484,8 @@ static int place_search(VhExec* x, size_t nb, const VhPlaceHint& h, void** out_p
   return VH_OK;
 }
 
-static int install_scratch(VhExec* x, void* ptr, size_t nb) {
+static int install_scratch(VhExec* x, void* ptr, size_t nb, bool placed = false) {
+  x->scratch_placed = placed;
   x->scratch = static_cast<char*>(ptr);
   trace_alloc("scratch", x->scratch, nb);
   x->scratch_bytes = nb;
@@ -497,8 +502,9 @@ static int ensure_scratch(VhExec* x, size_t bytes, const VhPlaceHint* hint = nul
   if (x->scratch) { HIP_TRY(hipFree(x->scratch)); x->scratch = nullptr; x->scratch_bytes = 0; }
   const size_t nb = scratch_size_for(bytes);
   void* ptr = nullptr; float score = 0;
-  if (!hint || place_search(x, nb, *hint, &ptr, &score) != VH_OK) HIP_TRY(hipMalloc(&ptr, nb));
-  return install_scratch(x, ptr, nb);
+  bool placed = true;
+  if (!hint || place_search(x, nb, *hint, &ptr, &score) != VH_OK) { HIP_TRY(hipMalloc(&ptr, nb)); placed = false; }
+  return install_scratch(x, ptr, nb, placed);
 }
 
 // The pool search compares candidates against the query's read streams WHERE THEY LIE; in about a third of the processes every candidate
@@ -522,7 +528,7 @@ static int place_with_derived(vh_table* t, VhExec* x, size_t bytes, const VhPlac
   for (auto& nw : t->narrows) if (nw->base) { clones.push_back(Clone{&nw->base, nw->base, nullptr, (size_t)nw->cap_seg * nw->stride + 256}); need += clones.back().bytes; }
   size_t free_b = 0, total_b = 0;
   const size_t spacer_bytes = (size_t)8 << 30;
-  if (clones.empty() || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b / 2 < need + nb + spacer_bytes) return install_scratch(x, A, nb);
+  if (clones.empty() || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b / 2 < need + nb + spacer_bytes) return install_scratch(x, A, nb, true);
   void* spacer = nullptr;
   if (hipMalloc(&spacer, spacer_bytes) != hipSuccess) { (void)hipGetLastError(); spacer = nullptr; }
   bool ok = true;
@@ -550,11 +556,11 @@ static int place_with_derived(vh_table* t, VhExec* x, size_t bytes, const VhPlac
     for (auto& c : clones) { (void)hipFree(c.was); *c.ref = c.now; }
     (void)hipFree(A);
     *moved = true;
-    return install_scratch(x, B, nb);
+    return install_scratch(x, B, nb, true);
   }
   for (auto& c : clones) if (c.now) (void)hipFree(c.now);
   if (B) (void)hipFree(B);
-  return install_scratch(x, A, nb);
+  return install_scratch(x, A, nb, true);
 }
 static int ensure_segrows(VhExec* x, size_t n) {
   if (n <= x->h_segrows_cap) return VH_OK;
@@ -1712,7 +1718,7 @@ int QueryBuild::shape_filter() {
   // Narrow copies of predicate columns (vh_table_narrow; built unasked for a column the third query filters on): the
   // register-resident kernels — and the selectivity probe, which is one of them — stream those instead of the 4-byte arenas.
   if ((fast_ok || jit_try) && !(p->flags & VH_PLAN_NO_NARROW)) {
-    const int auto_after = knobs().auto_narrow;     // 0: never unasked
+    const int auto_after = g_preparing ? 1 : knobs().auto_narrow;     // 0: never unasked
     std::map<int, int> narrow_slot;          // column -> slot of its narrow copy (looked up, and counted, once per query)
     auto narrow_for = [&](int col) -> int {
       auto hit = narrow_slot.find(col);
@@ -2465,7 +2471,7 @@ int QueryBuild::choose_projection() {
         for (int c : gcols) all &= pk->col_index(c) >= 0;
         if (all && (!use || pk->rec_bytes < use->rec_bytes || (pk->rec_bytes == use->rec_bytes && pk->compressed && !use->compressed))) use = pk.get();
       }
-      const int auto_after = knobs().auto_pack;   // 0: never build one unasked
+      const int auto_after = g_preparing ? 1 : knobs().auto_pack;   // 0: never build one unasked
       if (!use && (forced || auto_after > 0)) {
         std::string sig = jit_try ? "c:" : "p:";
         for (int c : gcols) sig += std::to_string(c) + ",";
@@ -2827,7 +2833,7 @@ int QueryBuild::layout_scratch() {
       ph.gather_bytes -= std::min<size_t>(ph.gather_bytes, 256);      // (a projection's column starts inside its first record)
       ph.pool_off = o_tuples; ph.pool_bytes = (size_t)P.max_extents * (size_t)P.ext_stride * P.tw * 8;
     }
-    if (sp.off > x->scratch_bytes && ph.pool_bytes >= ((size_t)256 << 20) && !t->derived_tried && knobs().place_trials >= 2 && (!t->packs.empty() || !t->narrows.empty())) {
+    if (sp.off > x->scratch_bytes && ph.pool_bytes >= ((size_t)128 << 20) && !t->derived_tried && g_preparing && knobs().place_trials >= 2 && (!t->packs.empty() || !t->narrows.empty())) {
       t->derived_tried = true;
       bool moved = false;
       rc = place_with_derived(t, x, sp.off, ph, &moved);
@@ -2991,7 +2997,7 @@ int QueryBuild::launch() {
   for (int k = 0; k < P.npred; ++k) narrowed |= P.pred_width[k] != 4;
   if (jk) { narrowed = false; for (int k = 0; k < jshape.npred; ++k) narrowed |= jshape.pred[k].width != vh_elem_size(jshape.pred[k].type); }
   r->hpart = hpart;
-  r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0) | (hpart && hp_pack ? 256 : 0);
+  r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0) | (hpart && hp_pack ? 256 : 0) | ((mode == VH_MODE_DENSE_PART || hpart) && x->scratch_placed ? 512 : 0) | (mode == VH_MODE_DENSE_PART && P.gid_bits ? 1024 : 0);
   if (r->hp_chunks) memset(x->h_chunk, 0, VH_HP_CHUNKS * sizeof(unsigned long long));      // (what the context's previous query left there)
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
@@ -3685,6 +3691,29 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
   (void)hipStreamSynchronize(x->stream());
   exec_release(t, x);
   return rc;
+}
+
+// First-use costs paid up front: the scan kernel compiled for the plan's shape (1-2 s of hipRTC, or milliseconds from the disk
+// cache), the payload projection and the narrow predicate copies a selective query reads (built at once instead of after VH_AUTO_PACK /
+// VH_AUTO_NARROW uses), and — only here — a tuple pool placed by measurement (place_search: bounded to half of the free memory / 48 GB, 8
+// candidates; everything but the winner is released before the call returns). The reference's analogue is Compiler::Compile running when a
+// query shape is first seen (src/codegen/compiler.cc:97-144, QueryStats::compile_time); a caller that knows its hot shapes at table-load
+// time runs them through here. The plan is executed (up to three times: a narrow copy, then a projection, then the pool can appear) and
+// the last attempt's info is returned, so the caller sees what a steady-state query of this shape will run on.
+extern "C" int vh_table_prepare(vh_table* t, const vh_plan* plan, vh_result_info* info_out) {
+  if (!t || !plan) return vh_fail(VH_E_INVALID, "null argument");
+  struct Guard { Guard() { g_preparing = true; } ~Guard() { g_preparing = false; } } guard;
+  uint32_t last = ~0u;
+  for (int round = 0; round < 3; ++round) {
+    vh_result* r = nullptr;
+    if (int rc = vh_query_agg(t, plan, &r)) return rc;
+    const uint32_t now = r->info.reserved;
+    if (info_out) *info_out = r->info;
+    vh_result_free(r);
+    if (now == last) break;
+    last = now;
+  }
+  return VH_OK;
 }
 
 // ----------------------------------------------------------------- select (ordered row emission)

@@ -198,6 +198,14 @@ class DeviceTable:
         plan._prepared = (self, p, keep)
         return plan
 
+    def warm(self, plan: AggPlan) -> int:
+        """vh_table_prepare: pay the plan shape's first-use costs now (kernel compile, projection, narrow copies, a measured place for a big
+        tuple pool). Returns vh_result_info.reserved of the last run: what steady-state queries of this shape run on."""
+        p, keep = self._build_plan(plan)
+        info = capi.ResultInfo()
+        capi.check(self.lib.vh_table_prepare(self.handle, C.byref(p), C.byref(info)))
+        return int(info.reserved)
+
     def _build_plan(self, plan: AggPlan):
         cached = getattr(plan, "_prepared", None)
         if cached is not None and cached[0] is self:
