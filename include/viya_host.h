@@ -48,6 +48,9 @@ VDB_API int vdb_query(vdb* db, const char* query_json, int64_t now, char** rows_
 VDB_API int vdb_query_partial(vdb* db, const char* query_json, int64_t now, char** blob_out, size_t* blob_len, vdb_stats* stats);
 VDB_API int vdb_query_merge(vdb* db, const char* query_json, const char* const* blobs, const size_t* blob_lens, int32_t nblobs,
                             char** rows_out, size_t* rows_len, vdb_stats* stats);
+/* The text of the generated drop-in translation unit for (table, aggregate query) — viya::shim::codegen::AggQueryText, include/viya_shim.h —
+ * or, with query_json == NULL, the line the generated viya_upsert_do gains (UpsertHookText). malloc'ed: vdb_free. For tests and tooling. */
+VDB_API int vdb_shim_text(const char* table_json, const char* query_json, char** text_out, size_t* text_len);
 VDB_API int vdb_table_info(vdb* db, const char* table, uint64_t* nsegments, uint64_t* first_segment_size);
 VDB_API void vdb_free(char* p);
 VDB_API const char* vdb_last_error(void);

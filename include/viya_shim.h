@@ -10,7 +10,11 @@
  *
  *   Open      once per (table, query text): descriptors parsed, HBM mirror created (the analogue of compile + cache)
  *   Sync      per segment of table.store()->segments_copy(): rows appended since the last call are copied to HBM
- *   Touch     from the upsert path when metrics of EXISTING rows change in place (src/codegen/db/upsert.cc:384-411)
+ *   BitsetStale / SyncBitset   a bitset metric's column is an array of util::Bitset<N> OBJECTS (store.cc:255-259, util/bitset.h:26-67), not
+ *             of numbers: the generated text walks the rows' Roaring sets into CSR (offsets, ids) — only for segments whose rows grew or
+ *             were Touched since the mirror last saw them — and hands them over
+ *   Touch     from the upsert path when metrics of EXISTING rows change in place (src/codegen/db/upsert.cc:384-411): the generated
+ *             viya_upsert_do calls it next to `m.Update(...)` (viya::shim::codegen::UpsertHookText() is that line)
  *   BindDict  the reference's dictionaries stay the only ones: c2v() of every string dimension, by dimension index
  *   Run       filter / having literals exactly as the JIT function receives them (db::AnyNum = 8 bytes, the column's own
  *             type in the low bytes, src/db/column.h:98-121), skip, limit; rows come back through `send` in the
@@ -37,12 +41,28 @@ __attribute__((visibility("default"))) Session* Open(const void* table_key, cons
 /* col_ptrs: one per storage column — dimensions, then metrics, in table order; NULL for a bitset metric (not mirrored
  * through this entry) and for the hidden count when the table has none. */
 __attribute__((visibility("default"))) void Sync(Session* s, uint32_t seg, uint64_t nrows, const void* const* col_ptrs);
+/* true: segment `seg`'s bitset columns must be walked again before the query runs (more rows than the mirror holds, or rows Touched). */
+__attribute__((visibility("default"))) bool BitsetStale(Session* s, uint32_t seg, uint64_t nrows);
+/* metric_index: the bitset metric's index among the table's metrics; offsets[nrows + 1] (offsets[0] = 0), ids: uint32_t (Bitset<4>) or
+ * uint64_t (Bitset<8>) values, row after row. Call for every bitset metric of a stale segment, before Run. */
+__attribute__((visibility("default"))) void SyncBitset(Session* s, uint32_t seg, size_t metric_index, uint64_t nrows, const uint64_t* offsets, const void* ids);
 __attribute__((visibility("default"))) void Touch(const void* table_key, uint32_t seg, uint64_t row_first, uint64_t row_last);
 __attribute__((visibility("default"))) void BindDict(Session* s, size_t dim_index, const std::vector<std::string>* c2v);
 __attribute__((visibility("default"))) void Run(Session* s, const uint64_t* fargs, size_t nfargs, const uint64_t* hargs, size_t nhargs,
                                                  size_t skip, size_t limit, SendFn send, void* ctx, Stats* stats);
 /* Drop everything kept for a table (mirror, sessions): Database::DropTable / process exit. */
 __attribute__((visibility("default"))) void Close(const void* table_key);
+
+/* The text a ViyaDB maintainer's generators emit at the two swap points — C++ functions returning it, like codegen::Code (src/codegen/
+ * generator.h:77-97); tools/gen_shim_tu.py is the same generator in Python and the test oracle of this one (tests/test_shim_compile.py). */
+namespace codegen {
+/* AggQueryGenerator::GenerateCode (src/codegen/query/agg_query.cc:26-75) for the GPU path: headers, the query::AggQueryFn signature, the
+ * table's Tuple / SegmentStats / Segment classes (StoreDefs, src/codegen/db/store.cc:203-356) and the calls above. */
+__attribute__((visibility("default"))) std::string AggQueryText(const std::string& table_json, const std::string& query_json);
+/* The line UpsertGenerator adds behind `static_cast<Segment*>(segments[segment_idx])->m.Update(upsert_tuple.m,tuple_idx);`
+ * (src/codegen/db/upsert.cc:384-396): the mirror learns which row changed in place. */
+__attribute__((visibility("default"))) std::string UpsertHookText();
+}  // namespace codegen
 
 }  // namespace shim
 }  // namespace viya

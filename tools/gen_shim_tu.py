@@ -53,7 +53,7 @@ def metric_type(m):
     if t == "count":
         return "ulong" if uint_for_max(m.get("max", 0xFFFFFFFF)) == "ulong" else "uint"   # parse_value_metric_type
     if t == "bitset":
-        raise SystemExit("gen_shim_tu: bitset metrics need util/bitset.h (CRoaring): emit that table's shim where it is available")
+        return "ulong" if uint_for_max(m.get("max", 0xFFFFFFFF)) == "ulong" else "uint"   # the ids' type: util::Bitset<8> / util::Bitset<4>
     return t.split("_")[0]
 
 
@@ -70,14 +70,27 @@ def emit(table, query):
     hidden = has_avg and not has_count
     o = []
     w = o.append
-    w("// GENERATED by tools/gen_shim_tu.py — the GPU-path body of AggQueryGenerator::GenerateCode (src/codegen/query/agg_query.cc:26-71)\n")
-    w("// table %r, query %s\n" % (table.get("name"), json.dumps(query)[:160]))
+    bitsets = [j for j, m in enumerate(mets) if metric_agg(m) == "bitset"]
+    w("// GENERATED: the GPU-path body of AggQueryGenerator::GenerateCode (src/codegen/query/agg_query.cc:26-71) — viya::shim::codegen::AggQueryText / tools/gen_shim_tu.py\n")
     for h in ("unordered_map", "vector", "string", "stdexcept", "cstdio", "cstdint", "cstddef", "cfloat", "algorithm"):
         w("#include <%s>\n" % h)
     for h in ("query/output.h", "query/stats.h", "db/table.h", "db/dictionary.h", "db/store.h", "db/segment.h"):   # agg_query.cc:28-30, store.cc:205
         w("#include <%s>\n" % h)
+    if bitsets:
+        w("#include <util/bitset.h>                                                 // store.cc:255-259\n")
     w("#include <viya_shim.h>   // libviya_host: mirror sync, plan, vh_query_agg, post-aggregation\n")
     w("namespace db = viya::db;\nnamespace query = viya::query;\nnamespace util = viya::util;\n\n")
+    if bitsets:
+        # util::Bitset keeps its Roaring private and offers no iteration (src/util/bitset.h:26-67): the ids are read through a pointer to
+        # that member obtained by explicit instantiation — the one place the language lets a private member be named from outside —, so
+        # that the reference's header stays as it is. (A maintainer may prefer a `const RoaringType& roaring() const` accessor there.)
+        w("namespace viya_shim_detail {\n")
+        w("template <class Tag, typename Tag::type M> struct Expose { friend typename Tag::type get(Tag) { return M; } };\n")
+        for n, rt in ((4, "Roaring"), (8, "Roaring64Map")):
+            if any(CPP[metric_type(mets[j])] == ("uint64_t" if n == 8 else "uint32_t") for j in bitsets):
+                w("struct Roaring%d { typedef %s util::Bitset<%d>::*type; friend type get(Roaring%d); };\n" % (n, rt, n, n))
+                w("template struct Expose<Roaring%d, &util::Bitset<%d>::roaring_>;\n" % (n, n))
+        w("}  // namespace viya_shim_detail\n\n")
     sig = ("extern \"C\" void viya_query_agg(db::Table& table, query::RowOutput& output, query::QueryStats& stats,"
            "std::vector<db::AnyNum> fargs, size_t skip, size_t limit, std::vector<db::AnyNum> hargs)")
     w(sig + " __attribute__((__visibility__(\"default\")));\n")                    # agg_query.cc:35-39
@@ -88,7 +101,10 @@ def emit(table, query):
         w("  %s _%d;\n" % (CPP[dim_type(d)], i))
     w(" };\n struct Metrics {\n")
     for j, m in enumerate(mets):
-        w("  %s _%d;\n" % (CPP[metric_type(m)], j))
+        if metric_agg(m) == "bitset":
+            w("  util::Bitset<%d> _%d;\n" % (8 if metric_type(m) == "ulong" else 4, j))
+        else:
+            w("  %s _%d;\n" % (CPP[metric_type(m)], j))
     if hidden:
         w("  uint64_t _count;\n")
     w(" };\n Dimensions d; Metrics m;\n};\n")
@@ -105,7 +121,9 @@ def emit(table, query):
     fills = []
     for j, m in enumerate(mets):
         t, a = metric_type(m), metric_agg(m)
-        if a == "max":
+        if a == "bitset":
+            w("  util::Bitset<%d> _%d[%d];\n" % (8 if t == "ulong" else 4, j, size))
+        elif a == "max":
             w("  %s _%d[%d];\n" % (CPP[t], j, size)); fills.append("std::fill_n(_%d,%d,%s);" % (j, size, CPP_MIN[t]))
         elif a == "min":
             w("  %s _%d[%d];\n" % (CPP[t], j, size)); fills.append("std::fill_n(_%d,%d,%s);" % (j, size, CPP_MAX[t]))
@@ -122,11 +140,27 @@ def emit(table, query):
     w("for (auto* s : table.store()->segments_copy()) {                      // scan.cc:42\n")
     w(" auto segment_size = s->size();                                       // scan.cc:43: the size() snapshot the query sees\n")
     w(" auto segment = static_cast<Segment*>(s);\n")
-    ptrs = ["&segment->d._%d[0]" % i for i in range(len(dims))] + ["&segment->m._%d[0]" % j for j in range(len(mets))]
+    ptrs = ["&segment->d._%d[0]" % i for i in range(len(dims))] + \
+           ["nullptr" if j in bitsets else "&segment->m._%d[0]" % j for j in range(len(mets))]     # (a bitset column is not an array of numbers: below)
     if hidden:
         ptrs.append("&segment->m._count[0]")
     w(" const void* cols[] = { %s };\n" % ", ".join(ptrs))
-    w(" viya::shim::Sync(session, seg_index++, segment_size, cols);\n}\n")
+    w(" viya::shim::Sync(session, seg_index, segment_size, cols);\n")
+    if bitsets:
+        w(" if (viya::shim::BitsetStale(session, seg_index, segment_size)) {   // rows appended, or a row's set grown in place (Touch), since the mirror saw them\n")
+        w("  std::vector<uint64_t> offsets(segment_size + 1);\n")
+        for j in bitsets:
+            n = 8 if metric_type(mets[j]) == "ulong" else 4
+            w("  { std::vector<uint%d_t> ids; offsets[0] = 0;\n" % (n * 8))
+            w("    for (size_t r = 0; r < segment_size; ++r) {\n")
+            w("      const auto& roaring = segment->m._%d[r].*get(viya_shim_detail::Roaring%d());\n" % (j, n))
+            w("      const uint64_t n = roaring.cardinality();\n")
+            w("      ids.resize(offsets[r] + n);\n")
+            w("      if (n) roaring.toUint%dArray(ids.data() + offsets[r]);\n" % (n * 8))
+            w("      offsets[r + 1] = offsets[r] + n;\n    }\n")
+            w("    viya::shim::SyncBitset(session, seg_index, %d, segment_size, offsets.data(), ids.data()); }\n" % j)
+        w(" }\n")
+    w(" ++seg_index;\n}\n")
     for i, d in enumerate(dims):
         if d.get("type", "string") == "string":
             w("{ auto dict%d = static_cast<const db::StrDimension*>(table.dimension(%d))->dict();      // post_agg.cc:32-40\n" % (i, i))
@@ -143,6 +177,13 @@ def emit(table, query):
     w("stats.aggregated_recs = st.aggregated_recs; stats.output_recs += st.output_recs;         // scan.cc:246, post_agg.cc:137\n")
     w("}\n")
     return "".join(o)
+
+
+def upsert_hook():
+    """The line UpsertGenerator adds behind `static_cast<Segment*>(segments[segment_idx])->m.Update(upsert_tuple.m,tuple_idx);`
+    (src/codegen/db/upsert.cc:384-396): the in-place branch of viya_upsert_do tells the mirror which row changed; the append branch
+    needs nothing (Sync copies what lies beyond the rows it has seen)."""
+    return "  viya::shim::Touch(lctx->table, segment_idx, tuple_idx, tuple_idx + 1);\n"
 
 
 def main():

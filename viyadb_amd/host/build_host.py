@@ -8,7 +8,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
 LIB = os.path.join(PKG, "libviya_host.so")
-SRCS = ["viya_db.cc", "viya_query.cc", "gpu_aggregate.cc", "partial_state.cc", "shim_session.cc", "viya_host_c.cc"]
+SRCS = ["viya_db.cc", "viya_query.cc", "gpu_aggregate.cc", "partial_state.cc", "shim_session.cc", "shim_codegen.cc", "viya_host_c.cc"]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:

@@ -8,6 +8,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <stdexcept>
 
 #include "../../include/viya_shim.h"
 #include "gpu_internal.h"
@@ -24,6 +25,7 @@ struct Shadow {
   std::unique_ptr<db::Table> table;          // descriptors only: it never holds a row
   std::unique_ptr<GpuMirror> mirror;
   std::vector<uint64_t> synced_rows;         // rows of each segment already in HBM
+  std::vector<uint64_t> bitset_rows;         // rows of each segment whose bitset columns are in HBM (UINT64_MAX: never; reset by Touch)
   std::vector<std::pair<uint64_t, uint64_t>> dirty;   // per segment: [first, last) rows updated in place since the last Sync
   std::vector<uint64_t> seg_rows;            // size() snapshot of the query being assembled
   std::map<std::string, std::unique_ptr<Session>> sessions;
@@ -94,6 +96,29 @@ void Sync(Session* s, uint32_t seg, uint64_t nrows, const void* const* col_ptrs)
   sh->dirty[seg] = {UINT64_MAX, 0};
 }
 
+bool BitsetStale(Session* s, uint32_t seg, uint64_t nrows) {
+  Shadow* sh = s->shadow;
+  std::lock_guard<std::mutex> lk(sh->mu);
+  bool any = false;
+  for (auto* m : sh->table->metrics()) any |= m->agg_type() == db::Column::BITSET;
+  if (!any) return false;
+  if (sh->bitset_rows.size() <= seg) sh->bitset_rows.resize(seg + 1, UINT64_MAX);
+  return sh->bitset_rows[seg] != nrows;      // (Touch resets it: an in-place `|=` changed some row's set)
+}
+
+void SyncBitset(Session* s, uint32_t seg, size_t metric_index, uint64_t nrows, const uint64_t* offsets, const void* ids) {
+  Shadow* sh = s->shadow;
+  std::lock_guard<std::mutex> lk(sh->mu);
+  const db::Metric* m = sh->table->metric(metric_index);
+  if (m->agg_type() != db::Column::BITSET) throw std::invalid_argument("viya::shim::SyncBitset: metric " + m->name() + " is not a bitset");
+  q::detail::vh_check(vh_segment_sync_bitset(sh->mirror->handle, seg, (int32_t)m->storage_index, nrows, offsets, ids));
+  if (sh->bitset_rows.size() <= seg) sh->bitset_rows.resize(seg + 1, UINT64_MAX);
+  // (the segment counts as seen once its LAST bitset metric has come in; the generated text syncs all of them back to back)
+  bool last = true;
+  for (auto* o : sh->table->metrics()) if (o->agg_type() == db::Column::BITSET && o->index() > metric_index) last = false;
+  if (last) sh->bitset_rows[seg] = nrows;
+}
+
 void Touch(const void* table_key, uint32_t seg, uint64_t row_first, uint64_t row_last) {
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_shadows.find(table_key);
@@ -103,6 +128,7 @@ void Touch(const void* table_key, uint32_t seg, uint64_t row_first, uint64_t row
   if (sh->dirty.size() <= seg) { sh->synced_rows.resize(seg + 1, 0); sh->dirty.resize(seg + 1, {UINT64_MAX, 0}); }
   sh->dirty[seg].first = std::min(sh->dirty[seg].first, row_first);
   sh->dirty[seg].second = std::max(sh->dirty[seg].second, row_last);
+  if (sh->bitset_rows.size() > seg) sh->bitset_rows[seg] = UINT64_MAX;
 }
 
 void BindDict(Session* s, size_t dim_index, const std::vector<std::string>* c2v) {

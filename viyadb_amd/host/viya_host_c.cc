@@ -1,5 +1,6 @@
 // viya_host_c.cc — C facade (include/viya_host.h) over the C++ host shim.
 #include "../../include/viya_host.h"
+#include "../../include/viya_shim.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -55,6 +56,17 @@ int vdb_open(const char* config_json, int device, vdb** out) {
   });
 }
 void vdb_close(vdb* db) { delete db; }
+
+int vdb_shim_text(const char* table_json, const char* query_json, char** text_out, size_t* text_len) {
+  return vdbimpl::guard([&] {
+    // query_json == NULL: the upsert hook (viya::shim::codegen::UpsertHookText)
+    const std::string t = query_json ? viya::shim::codegen::AggQueryText(table_json ? table_json : "{}", query_json) : viya::shim::codegen::UpsertHookText();
+    *text_out = (char*)malloc(t.size() + 1);
+    memcpy(*text_out, t.data(), t.size());
+    (*text_out)[t.size()] = 0;
+    if (text_len) *text_len = t.size();
+  });
+}
 
 int vdb_join_node(vdb* db, void* vh_comm_handle) {
   return vdbimpl::guard([&] { db->db->JoinNode(vh_comm_handle); });

@@ -26,7 +26,7 @@ class HostError(RuntimeError):
 
 
 SYMBOLS = ["vdb_open", "vdb_close", "vdb_join_node", "vdb_create_table", "vdb_load", "vdb_query", "vdb_query_partial", "vdb_query_merge",
-           "vdb_table_info", "vdb_free", "vdb_last_error"]
+           "vdb_table_info", "vdb_free", "vdb_last_error", "vdb_shim_text"]
 _lib = None
 
 
@@ -50,6 +50,7 @@ def load():
         lib.vdb_query_merge.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int32,
                                         C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(Stats)]
         lib.vdb_table_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        lib.vdb_shim_text.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         lib.vdb_free.argtypes = [C.c_void_p]
         lib.vdb_free.restype = None
         _lib = lib
@@ -138,3 +139,14 @@ class Database:
         a, b = C.c_uint64(), C.c_uint64()
         _check(self.lib.vdb_table_info(self.h, table.encode(), C.byref(a), C.byref(b)))
         return {"segments": a.value, "first_segment_size": b.value}
+
+
+def shim_text(table_json: str, query_json=None) -> str:
+    """viya::shim::codegen::AggQueryText(table, query) — or UpsertHookText() when query_json is None — through the C facade."""
+    lib = load()
+    out, n = C.c_void_p(), C.c_size_t()
+    _check(lib.vdb_shim_text(table_json.encode() if table_json is not None else None, query_json.encode() if query_json is not None else None, C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out, n.value).decode()
+    finally:
+        lib.vdb_free(out)
