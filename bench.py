@@ -109,6 +109,24 @@ def cpu_baseline(w, sample_segments: int):
     from oracle import cpu_twin
     from tests.parity import build_oracle_table
     rows_per_seg = w.segment_rows
+    # "pinned to 1 core (taskset)". The process is bound to ONE core before the sample table is generated, so that its pages
+    # are first touched — and therefore placed — on that core's NUMA node, and stays there for the timed runs.
+    pinned, old_aff = None, None
+    if hasattr(os, "sched_setaffinity"):
+        try:
+            old_aff = os.sched_getaffinity(0)
+            pinned = sorted(old_aff)[len(old_aff) // 2]          # (not core 0: interrupts and the launcher tend to live there)
+            os.sched_setaffinity(0, {pinned})
+        except OSError:
+            pinned, old_aff = None, None
+    try:
+        return _cpu_baseline_pinned(w, sample_segments, rows_per_seg, pinned, cpu_twin, build_oracle_table)
+    finally:
+        if old_aff is not None:
+            os.sched_setaffinity(0, old_aff)
+
+
+def _cpu_baseline_pinned(w, sample_segments, rows_per_seg, pinned, cpu_twin, build_oracle_table):
     ot = build_oracle_table(w, sample_segments, rows_per_seg)
     tw = cpu_twin.Twin(ot, w.query)
     state = tw.run()  # warm-up (page-in); its groups also check the GPU's answer over the same rows (main)
@@ -118,10 +136,11 @@ def cpu_baseline(w, sample_segments: int):
         secs.append(tw.last_seconds)
     best = sorted(secs)[len(secs) // 2]
     rows = sample_segments * rows_per_seg
-    return {"value": rows / best, "unit": "rows/s", "cores": 1, "kind": "port",
+    return {"value": rows / best, "unit": "rows/s", "cores": 1, "kind": "port", "pinned_core": pinned,
             "sample": "%d segments x %d rows of %s (same generator, same query), median of 7 runs, "
-                      "g++ -O2 -funroll-loops -march=native, 1 thread; %.2f GB/s of referenced bytes"
-                      % (sample_segments, rows_per_seg, w.name, rows * w.bytes_per_row_referenced / best / 1e9),
+                      "g++ -O2 -funroll-loops -march=native, 1 thread %s; %.2f GB/s of referenced bytes"
+                      % (sample_segments, rows_per_seg, w.name, ("pinned to core %d (sched_setaffinity)" % pinned) if pinned is not None else "(not pinned: no sched_setaffinity)",
+                         rows * w.bytes_per_row_referenced / best / 1e9),
             "cpu": _cpu_model()}, state
 
 
@@ -131,21 +150,22 @@ def cpu_baseline_parallel(w, seconds: float = 3.0, segments_per_worker: int = 2)
     import subprocess
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     workers = max(1, min(cores, 64))
-    start = time.time() + 20.0 + 0.05 * workers          # generation of the shards happens before the window opens
+    start = time.time() + 12.0 + 0.05 * workers          # generation of the shards happens before the window opens (a worker that comes late says so)
     procs = [subprocess.Popen([sys.executable, "-m", "oracle.parallel_worker", w.name, str(segments_per_worker),
                                str(i * segments_per_worker), repr(start), repr(seconds)], cwd=ROOT, stdout=subprocess.PIPE,
                               stderr=subprocess.DEVNULL, text=True) for i in range(workers)]
-    rows, ok = 0, 0
+    rows, ok, missed = 0, 0, 0
     for p in procs:
         out, _ = p.communicate(timeout=180)
         try:
             d = json.loads(out.strip().splitlines()[-1])
             rows += d["rows"]
             ok += 1
+            missed += 1 if d.get("missed", 0) > 0.05 else 0
         except Exception:
             pass
     return {"value": rows / seconds if ok else None, "unit": "rows/s", "cores": ok, "kind": "port, segment-parallel (not reference behaviour)",
-            "sample": "%d processes x %d segments of %s, all running the emitted loop for the same %.0f s window" % (ok, segments_per_worker, w.name, seconds)}
+            "sample": "%d processes x %d segments of %s, all running the emitted loop for the same %.0f s window (%d of them were ready after it opened)" % (ok, segments_per_worker, w.name, seconds, missed)}
 
 
 def _cpu_model():
@@ -168,7 +188,8 @@ def main():
     ap.add_argument("--segment-rows", type=int, default=1_000_000)
     ap.add_argument("--cpu-segments", type=int, default=100, help="CPU baseline sample: this many segments of the same workload")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-parallel", action="store_true", help="also time the courtesy all-cores CPU baseline (adds ~30 s)")
+    ap.add_argument("--cpu-parallel", action="store_true", help="(default at N=1 now) also time the courtesy all-cores CPU baseline (adds ~20 s)")
+    ap.add_argument("--no-cpu-parallel", action="store_true", help="skip the courtesy all-cores CPU baseline")
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-pack", action="store_true", help="ablation: no payload projection (survivors gather from the column arenas)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity gate (profiling runs)")
@@ -397,7 +418,7 @@ def main():
                 compare(wres, twin_state, "bench parity gate (CPU twin window)")
                 out["parity"]["cpu_twin_window_rows"] = ns * w.segment_rows
                 out["parity"]["cpu_twin_groups"] = twin_state.ngroups
-            if args.cpu_parallel:
+            if not args.no_cpu_parallel:
                 try:
                     out["cpu_baseline_all_cores"] = cpu_baseline_parallel(w)
                 except Exception as e:

@@ -23,6 +23,7 @@ def main():
     ot = build_oracle_table(w, nseg, w.segment_rows, row_base=first * w.segment_rows)
     tw = cpu_twin.Twin(ot, w.query)
     tw.run()
+    missed = max(0.0, time.time() - start)          # ready after the window opened: this worker's share of it is short
     while time.time() < start:
         time.sleep(0.001)
     rows = 0
@@ -31,7 +32,7 @@ def main():
         tw.run()
         rows += nseg * w.segment_rows
         busy += tw.last_seconds
-    print(json.dumps({"rows": rows, "busy": busy, "late": max(0.0, time.time() - (start + seconds))}))
+    print(json.dumps({"rows": rows, "busy": busy, "late": max(0.0, time.time() - (start + seconds)), "missed": missed}))
 
 
 if __name__ == "__main__":

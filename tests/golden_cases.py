@@ -27,7 +27,22 @@ def materialise_loads(case):
     out = []
     for ld in case["loads"]:
         if "rows" in ld:
-            out.append(DOC["row_sets"][ld["rows"]])
+            rows = DOC["row_sets"][ld["rows"]]
+            if "partition_filter" in ld:
+                # the loader's partition filter (generated upsert code, src/codegen/db/upsert.cc:316-337): crc32 — util/crc32.h:27-39, the
+                # zlib polynomial, chained over the partition columns' INPUT strings — modulo total_partitions must be one of `values`
+                import zlib
+                pf = ld["partition_filter"]
+                names = [d["name"] for d in conf["dimensions"]]
+                idx = [names.index(c) for c in pf["columns"]]
+
+                def keep(r):
+                    h = 0
+                    for i in idx:
+                        h = zlib.crc32(r[i].encode(), h)
+                    return h % pf["total_partitions"] in pf["values"]
+                rows = [r for r in rows if keep(r)]
+            out.append(rows)
         elif "inline" in ld:
             out.append(ld["inline"])
         else:
