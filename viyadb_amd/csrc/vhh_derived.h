@@ -1,0 +1,303 @@
+// vhh_derived.h — host side of libviya_hip, part of viya_hip.hip's translation unit (included there, in order; not a stand-alone header):
+// derived layouts: payload projections (vh_table_pack) and narrow predicate copies (vh_table_narrow).
+// ------------------------------------------------------- payload projections (vh_table_pack)
+#define VH_PACK_STALE 9001      // (internal) pack_refresh: a value no longer fits its stored width, the projection must go
+// (Re)pack the segments of [first, first + n) whose columns changed since they were last packed.
+static int pack_refresh(vh_table* t, VhPack* pk, uint32_t first, uint32_t n) {
+  if (first + n > t->nseg) n = t->nseg > first ? t->nseg - first : 0;
+  if (!n) return VH_OK;
+  if (pk->cap_seg < t->cap_seg) {                      // the table grew: move the arena
+    table_quiesce(t);
+    char* nb = nullptr;
+    const size_t bytes = (size_t)t->cap_seg * pk->stride + 256;
+    HIP_TRY(hipMalloc(&nb, bytes));
+    trace_alloc("projection", nb, bytes);
+    if (pk->base) {
+      HIP_TRY(hipMemcpyAsync(nb, pk->base, (size_t)pk->cap_seg * pk->stride, hipMemcpyDeviceToDevice, g_ctx.stream));
+      HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+      HIP_TRY(hipFree(pk->base));
+      t->device_bytes -= (size_t)pk->cap_seg * pk->stride + 256;
+    }
+    pk->base = nb; pk->cap_seg = t->cap_seg;
+    pk->seg_mod.resize(t->cap_seg, 0);
+    t->device_bytes += bytes;
+  }
+  uint32_t s = first;
+  while (s < first + n) {
+    if (pk->seg_mod[s] == t->seg_mod[s]) { ++s; continue; }
+    uint32_t e = s;
+    while (e < first + n && pk->seg_mod[e] != t->seg_mod[e] && e - s < 4096) ++e;
+    const uint32_t cnt = e - s;
+    if (t->d_packrows_cap < cnt) {
+      HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+      if (t->d_packrows) HIP_TRY(hipFree(t->d_packrows));
+      t->d_packrows = nullptr; t->d_packrows_cap = 0;
+      HIP_TRY(hipMalloc((void**)&t->d_packrows, (size_t)std::max<uint32_t>(cnt, 1024) * sizeof(uint32_t)));
+      t->d_packrows_cap = std::max<uint32_t>(cnt, 1024);
+    }
+    std::vector<uint32_t> rows(cnt);
+    for (uint32_t i = 0; i < cnt; ++i) rows[i] = (uint32_t)t->seg_rows[s + i];
+    HIP_TRY(hipMemcpyAsync(t->d_packrows, rows.data(), (size_t)cnt * sizeof(uint32_t), hipMemcpyHostToDevice, g_ctx.stream));
+    VhPackArgs A{};
+    A.ncols = (int32_t)pk->cols.size(); A.rec_bytes = pk->rec_bytes;
+    for (size_t c = 0; c < pk->cols.size(); ++c) {
+      const VhColumn& col = t->cols[pk->cols[c]];
+      A.src[c] = col.base; A.src_stride[c] = col.stride; A.esize[c] = (uint32_t)col.esize; A.off[c] = pk->off[c];
+      A.wbytes[c] = pk->width[c];
+      if (col.elem == VH_I8 || col.elem == VH_I16 || col.elem == VH_I32 || col.elem == VH_I64) A.sgn_mask |= 1u << c;
+    }
+    if (!t->d_packflag) { HIP_TRY(hipMalloc((void**)&t->d_packflag, 256)); HIP_TRY(hipMemsetAsync(t->d_packflag, 0, 256, g_ctx.stream)); }
+    A.overflow = t->d_packflag;
+    A.dst = pk->base; A.dst_stride = pk->stride; A.rows = t->d_packrows; A.seg_first = s;
+    dim3 grid((unsigned)std::min<uint64_t>(64, (t->segment_rows + 255) / 256), cnt);
+    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 256 * pk->rec_bytes, g_ctx.stream, A);
+    HIP_TRY(hipGetLastError());
+    unsigned int ovf = 0;
+    if (pk->compressed) HIP_TRY(hipMemcpyAsync(&ovf, t->d_packflag, sizeof(ovf), hipMemcpyDeviceToHost, g_ctx.stream));
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream));        // `rows` lives on this frame; d_packrows is reused by the next batch
+    if (ovf) {                                          // a synced value outgrew its stored width: the projection is void (the caller drops it)
+      HIP_TRY(hipMemsetAsync(t->d_packflag, 0, 256, g_ctx.stream));
+      return VH_PACK_STALE;
+    }
+    for (uint32_t i = s; i < e; ++i) pk->seg_mod[i] = t->seg_mod[i];
+    s = e;
+  }
+  return VH_OK;
+}
+static void pack_drop(vh_table* t, VhPack* pk) {
+  table_quiesce(t);
+  (void)hipStreamSynchronize(g_ctx.stream);
+  for (size_t k = 0; k < t->packs.size(); ++k) {
+    if (t->packs[k].get() != pk) continue;
+    if (pk->base) { (void)hipFree(pk->base); t->device_bytes -= (size_t)pk->cap_seg * pk->stride + 256; }
+    t->packs.erase(t->packs.begin() + (long)k);
+    return;
+  }
+}
+
+// Bytes the values of an integer column need over every mirrored segment (1, 2, 4 or 8; the element size for floating point): dimensions
+// from their SegmentStats, metrics from a min / max pass of their own (they keep no stats).
+static int column_stored_width(vh_table* t, int col, int* width_out) {
+  const VhColumn& c = t->cols[col];
+  *width_out = (int)c.esize;
+  if (c.elem == VH_F32 || c.elem == VH_F64 || c.esize == 1 || !t->nseg) return VH_OK;
+  uint64_t lo = ~0ull, hi = 0;
+  if ((size_t)col < t->stats.size() && t->stats[col].size() >= t->nseg) {      // (refresh_stats keeps min / max of every fixed-width column, metrics included)
+    for (uint32_t s = 0; s < t->nseg; ++s) { const VhSegStat& st = t->stats[col][s]; if (st.lo > st.hi) continue; lo = std::min(lo, st.lo); hi = std::max(hi, st.hi); }
+  } else {
+    const uint32_t n = t->nseg;
+    char* tmp = nullptr;
+    HIP_TRY(hipMalloc(&tmp, (size_t)n * 16 + (size_t)n * 4 + 256));
+    unsigned long long* d_st = reinterpret_cast<unsigned long long*>(tmp);
+    uint32_t* d_rows = reinterpret_cast<uint32_t*>(tmp + (size_t)n * 16);
+    std::vector<unsigned long long> init((size_t)n * 2);
+    for (size_t i = 0; i < init.size(); i += 2) { init[i] = ~0ull; init[i + 1] = 0; }
+    std::vector<uint32_t> hrows(n);
+    for (uint32_t s = 0; s < n; ++s) hrows[s] = (uint32_t)t->seg_rows[s];
+    hipError_t he = hipMemcpyAsync(d_st, init.data(), init.size() * 8, hipMemcpyHostToDevice, g_ctx.stream);
+    if (he == hipSuccess) he = hipMemcpyAsync(d_rows, hrows.data(), hrows.size() * 4, hipMemcpyHostToDevice, g_ctx.stream);
+    if (he == hipSuccess) {
+      for (uint32_t first = 0; first < n; first += 32768) {       // (grid.y)
+        const uint32_t cnt = std::min<uint32_t>(32768, n - first);
+        dim3 grid((unsigned)std::min<uint64_t>(64, (t->segment_rows + 4095) / 4096), cnt);
+        VH_ELEM_SWITCH(c.elem, (seg_minmax_kernel<T><<<grid, dim3(256), 0, g_ctx.stream>>>(reinterpret_cast<const T*>(c.base), c.stride / c.esize, d_rows + first, first, d_st + 2ull * first)));
+      }
+      he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipMemcpyAsync(init.data(), d_st, init.size() * 8, hipMemcpyDeviceToHost, g_ctx.stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(g_ctx.stream);
+    (void)hipFree(tmp);
+    if (he != hipSuccess) return vh_fail(VH_E_DEVICE, "min / max pass over column %d: %s", col, hipGetErrorString(he));
+    for (uint32_t s = 0; s < n; ++s) { if (init[2 * s] > init[2 * s + 1]) continue; lo = std::min<uint64_t>(lo, init[2 * s]); hi = std::max<uint64_t>(hi, init[2 * s + 1]); }
+  }
+  if (lo > hi) { *width_out = 1; return VH_OK; }       // no rows yet: anything fits (a later value that does not voids the projection)
+  int w = (int)c.esize;
+  if (c.elem == VH_I16 || c.elem == VH_I32 || c.elem == VH_I64) {
+    const int64_t a = (int64_t)(lo ^ (1ull << 63)), b = (int64_t)(hi ^ (1ull << 63));       // (order key of a signed integer: the value with its sign bit flipped)
+    w = (a >= INT8_MIN && b <= INT8_MAX) ? 1 : (a >= INT16_MIN && b <= INT16_MAX) ? 2 : (a >= INT32_MIN && b <= INT32_MAX) ? 4 : 8;
+  } else {
+    w = hi < 256 ? 1 : hi < 65536 ? 2 : hi <= 0xFFFFFFFFull ? 4 : 8;
+  }
+  *width_out = std::min(w, (int)c.esize);
+  return VH_OK;
+}
+
+static int table_pack_locked(vh_table* t, const int32_t* cols, int32_t ncols, bool automatic, VhPack** out, bool compress) {
+  if (!cols || ncols <= 0 || ncols > VH_PACK_MAX_COLS) return vh_fail(VH_E_INVALID, "vh_table_pack: 1..%d columns", VH_PACK_MAX_COLS);
+  std::vector<int> order;
+  for (int i = 0; i < ncols; ++i) {
+    const int c = cols[i];
+    if (c < 0 || (size_t)c >= t->cols.size() || is_bitset_elem(t->cols[c].elem)) return vh_fail(VH_E_INVALID, "vh_table_pack: column %d cannot be packed", c);
+    if (std::find(order.begin(), order.end(), c) == order.end()) order.push_back(c);
+  }
+  std::vector<int> sorted_cols = order;
+  std::sort(sorted_cols.begin(), sorted_cols.end());
+  for (auto& pk : t->packs) {
+    std::vector<int> have = pk->cols;
+    std::sort(have.begin(), have.end());
+    if (have != sorted_cols || pk->compressed != compress) continue;
+    const int rc = pack_refresh(t, pk.get(), 0, t->nseg);
+    if (rc == VH_PACK_STALE) { pack_drop(t, pk.get()); break; }      // built again below, at the widths the values need now
+    if (out) *out = pk.get();
+    return rc;
+  }
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    std::map<int, int> wof;
+    for (int c : order) {
+      int w = (int)t->cols[c].esize;
+      if (compress) if (int rc = column_stored_width(t, c, &w)) return rc;
+      wof[c] = w;
+    }
+    std::vector<int> ord = order;
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return wof[a] > wof[b]; });   // widest first: every field naturally aligned
+    uint32_t bytes = 0;
+    std::vector<uint32_t> off;
+    std::vector<uint8_t> width;
+    for (int c : ord) { off.push_back(bytes); width.push_back((uint8_t)wof[c]); bytes += (uint32_t)wof[c]; }
+    if (bytes > 64) return vh_fail(VH_E_UNSUPPORTED, "vh_table_pack: %u payload bytes per row (max 64)", bytes);
+    uint32_t rec = 8;
+    while (rec < bytes) rec <<= 1;
+    std::unique_ptr<VhPack> pk(new VhPack());
+    pk->cols = ord; pk->off = off; pk->width = width; pk->rec_bytes = rec; pk->automatic = automatic; pk->compressed = compress;
+    pk->stride = (t->segment_rows + 255) / 256 * 256 * (uint64_t)rec;
+    VhPack* raw = pk.get();
+    t->packs.push_back(std::move(pk));
+    const int rc = pack_refresh(t, raw, 0, t->nseg);
+    if (rc == VH_PACK_STALE && attempt == 0) { pack_drop(t, raw); continue; }      // (a metric changed between the min / max pass and the copy)
+    if (rc) { pack_drop(t, raw); return rc == VH_PACK_STALE ? vh_fail(VH_E_DEVICE, "vh_table_pack: values keep outgrowing their stored widths") : rc; }
+    if (out) *out = raw;
+    return VH_OK;
+  }
+  return VH_OK;
+}
+
+// ------------------------------------------------------- narrow predicate copies (vh_table_narrow)
+// Width the column's values fit over segments [0, nseg): 1, 2, or 0 (not an unsigned 32-bit column, or its values need all 32 bits).
+static int narrow_width_for(const vh_table* t, int col, uint32_t nseg) {
+  const VhColumn& c = t->cols[col];
+  if (c.elem != VH_U32 || (size_t)col >= t->stats.size()) return 0;
+  uint64_t hi = 0;
+  bool any = false;
+  for (uint32_t s = 0; s < nseg && s < t->stats[col].size(); ++s) {
+    const VhSegStat& st = t->stats[col][s];
+    if (st.lo > st.hi) continue;          // empty segment
+    hi = std::max(hi, st.hi); any = true;
+  }
+  if (!any) return 0;
+  return hi < 256 ? 1 : hi < 65536 ? 2 : 0;
+}
+// (Re)copy the segments of [first, first + n) whose column changed since they were last copied.
+static int narrow_refresh(vh_table* t, VhNarrow* nw, uint32_t first, uint32_t n) {
+  if (first + n > t->nseg) n = t->nseg > first ? t->nseg - first : 0;
+  if (!n) return VH_OK;
+  const uint64_t padded = t->padded_rows;
+  if (nw->cap_seg < t->cap_seg) {
+    table_quiesce(t);
+    char* nb = nullptr;
+    const size_t bytes = (size_t)t->cap_seg * nw->stride + 256;
+    HIP_TRY(hipMalloc(&nb, bytes));
+    trace_alloc("narrow", nb, bytes);
+    if (nw->base) {
+      HIP_TRY(hipMemcpyAsync(nb, nw->base, (size_t)nw->cap_seg * nw->stride, hipMemcpyDeviceToDevice, g_ctx.stream));
+      HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+      HIP_TRY(hipFree(nw->base));
+      t->device_bytes -= (size_t)nw->cap_seg * nw->stride + 256;
+    }
+    nw->base = nb; nw->cap_seg = t->cap_seg;
+    nw->seg_mod.resize(t->cap_seg, 0);
+    t->device_bytes += bytes;
+  }
+  const VhColumn& c = t->cols[nw->col];
+  uint32_t s = first;
+  while (s < first + n) {
+    if (nw->seg_mod[s] == t->seg_mod[s]) { ++s; continue; }
+    uint32_t e = s;
+    while (e < first + n && nw->seg_mod[e] != t->seg_mod[e] && e - s < 4096) ++e;
+    const dim3 grid((unsigned)std::min<uint64_t>(64, (padded + 1023) / 1024), e - s);
+    if (nw->width == 1)
+      hipLaunchKernelGGL((narrow_kernel<uint8_t>), grid, dim3(256), 0, g_ctx.stream, reinterpret_cast<const uint32_t*>(c.base), c.stride / 4,
+                         reinterpret_cast<uint8_t*>(nw->base), nw->stride, padded, s);
+    else
+      hipLaunchKernelGGL((narrow_kernel<uint16_t>), grid, dim3(256), 0, g_ctx.stream, reinterpret_cast<const uint32_t*>(c.base), c.stride / 4,
+                         reinterpret_cast<uint16_t*>(nw->base), nw->stride / 2, padded, s);
+    HIP_TRY(hipGetLastError());
+    for (uint32_t i = s; i < e; ++i) nw->seg_mod[i] = t->seg_mod[i];
+    s = e;
+  }
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return VH_OK;
+}
+static void narrow_drop(vh_table* t, size_t k) {
+  table_quiesce(t);
+  VhNarrow* nw = t->narrows[k].get();
+  if (nw->base) { (void)hipFree(nw->base); t->device_bytes -= (size_t)nw->cap_seg * nw->stride + 256; }
+  t->narrows.erase(t->narrows.begin() + (long)k);
+}
+// The narrow copy of `col`, fresh for segments [0, nseg), or nullptr (none, or the values no longer fit: the copy is dropped).
+static VhNarrow* narrow_usable(vh_table* t, int col, uint32_t nseg) {
+  for (size_t k = 0; k < t->narrows.size(); ++k) {
+    VhNarrow* nw = t->narrows[k].get();
+    if (nw->col != col) continue;
+    const int w = narrow_width_for(t, col, t->nseg);
+    if (w == 0 || w > nw->width) { narrow_drop(t, k); return nullptr; }
+    if (narrow_refresh(t, nw, 0, nseg) != VH_OK) return nullptr;
+    return nw;
+  }
+  return nullptr;
+}
+static int table_narrow_locked(vh_table* t, int col, bool automatic) {
+  if (col < 0 || (size_t)col >= t->cols.size()) return vh_fail(VH_E_INVALID, "vh_table_narrow: column %d", col);
+  for (auto& nw : t->narrows) if (nw->col == col) return narrow_usable(t, col, t->nseg) ? VH_OK : VH_OK;
+  const int w = narrow_width_for(t, col, t->nseg);
+  if (!w) return VH_OK;                          // nothing to gain: not an unsigned 32-bit column, or it uses its bits
+  std::unique_ptr<VhNarrow> nw(new VhNarrow());
+  nw->col = col; nw->width = w; nw->automatic = automatic;
+  nw->stride = t->padded_rows * (uint64_t)w;
+  VhNarrow* raw = nw.get();
+  t->narrows.push_back(std::move(nw));
+  const int rc = narrow_refresh(t, raw, 0, t->nseg);
+  if (rc) { narrow_drop(t, t->narrows.size() - 1); return rc; }
+  return VH_OK;
+}
+
+extern "C" int vh_table_narrow(vh_table* t, const int32_t* cols, int32_t ncols) {
+  if (!t || (!cols && ncols)) return vh_fail(VH_E_INVALID, "null argument");
+  VH_ENTER();
+  std::lock_guard<std::mutex> lk(t->mu);
+  for (int i = 0; i < ncols; ++i)
+    if (int rc = table_narrow_locked(t, cols[i], false)) return rc;
+  return VH_OK;
+}
+
+extern "C" int vh_table_pack_ex(vh_table* t, const int32_t* cols, int32_t ncols, uint32_t form) {
+  if (!t) return vh_fail(VH_E_INVALID, "null table");
+  if (form > VH_PACK_COMPRESSED) return vh_fail(VH_E_INVALID, "vh_table_pack_ex: form %u", form);
+  VH_ENTER();
+  std::lock_guard<std::mutex> lk(t->mu);
+  // VH_PACK_AUTO: compressed where the per-query compiled kernels — the only readers of compressed records — would run a scan of the
+  // whole table (VH_JIT=force, or auto and the table holds VH_JIT_MIN_ROWS rows); plain where the pre-built kernels answer
+  bool compress = form == VH_PACK_COMPRESSED;
+  if (form == VH_PACK_AUTO) {
+    uint64_t rows = 0;
+    for (uint32_t s = 0; s < t->nseg; ++s) rows += t->seg_rows[s];
+    compress = !knobs().pack_plain && (vh_jit_policy() == VH_JIT_FORCE || (vh_jit_policy() == VH_JIT_AUTO && rows >= vh_jit_min_rows()));
+  }
+  return table_pack_locked(t, cols, ncols, false, nullptr, compress);
+}
+extern "C" int vh_table_pack(vh_table* t, const int32_t* cols, int32_t ncols) { return vh_table_pack_ex(t, cols, ncols, VH_PACK_AUTO); }
+
+extern "C" int vh_table_unpack(vh_table* t) {
+  if (!t) return vh_fail(VH_E_INVALID, "null table");
+  VH_ENTER();
+  std::lock_guard<std::mutex> lk(t->mu);
+  table_quiesce(t);
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  for (auto& pk : t->packs) if (pk->base) { (void)hipFree(pk->base); t->device_bytes -= (size_t)pk->cap_seg * pk->stride + 256; }
+  t->packs.clear();
+  t->gather_seen.clear();
+  for (auto& nw : t->narrows) if (nw->base) { (void)hipFree(nw->base); t->device_bytes -= (size_t)nw->cap_seg * nw->stride + 256; }
+  t->narrows.clear();
+  t->pred_seen.clear();
+  return VH_OK;
+}
+

@@ -1,0 +1,419 @@
+// vhh_finalize.h — host side of libviya_hip, part of viya_hip.hip's translation unit (included there, in order; not a stand-alone header):
+// the end of a query: emission, delivery to pinned host memory, verdict and re-plan loop; vh_query_agg, vh_table_prepare.
+// The end of a query is a host wait for a few hundred microseconds to a few milliseconds of device work: poll the event
+// (a blocking hipStreamSynchronize adds tens of microseconds of wake-up latency to every query), fall back to a
+// blocking wait when the work turns out to be long.
+static hipError_t wait_event_spinning(hipEvent_t ev) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) return hipEventSynchronize(ev);
+  }
+}
+
+// returns VH_OK, or a positive "retry" request: 1 = grow hash table, 2 = fall back to hash
+static int result_finalize(vh_result* r, int* retry) {
+  VhExec* x = r->exec;   // staging buffers, scratch and events of this query's context
+  const VhPlanDev& P = r->plan;
+  hipStream_t st = x->stream();
+  *retry = 0;
+  // pinned staging buffer (two alternate per context: a zero-copy view stays readable after vh_result_free until the
+  // second-next query); a re-planned attempt of the same query reuses its slot. Small results take the output region as it lies in the
+  // scratch (one copy, or none: direct emission below); big ones are PACKED on their way out — a staging buffer for the rows that
+  // exist, not for the rows the tables could hold (C5: 0.7 GB instead of 2.7 GB per slot; what does not fit the GPU's own NUMA node
+  // is copied to at half the rate).
+  const int slot = r->h_slot >= 0 ? r->h_slot : (x->h_out_next ^= 1);
+  r->h_slot = slot;
+  auto stage = [&](size_t bytes) -> int {
+    if (x->h_out_bytes[slot] >= bytes) return VH_OK;
+    if (x->h_out[slot]) HIP_TRY(hipHostFree(x->h_out[slot]));
+    x->h_out[slot] = nullptr; x->h_out_bytes[slot] = 0;
+    const size_t nb = std::max<size_t>(bytes + bytes / 8, 1 << 20);
+    // coherent (fine-grained): the emission kernel writes small results straight into this buffer, and the host must see
+    // them when the event behind the kernel has completed, whatever HIP_HOST_COHERENT says
+    HIP_TRY(host_alloc_near_device((void**)&x->h_out[slot], nb, hipHostMallocCoherent));
+    x->h_out_bytes[slot] = nb;
+    return VH_OK;
+  };
+  const bool env_no_direct = knobs().no_direct_emit;
+  const bool one_shot = r->out_region_bytes <= (8u << 20) && !r->topk_active && !r->hp_chunks;      // (a streamed result's rows are packed on their way out: never the region as a whole)
+  const bool direct = one_shot && r->mode != VH_MODE_HASH && !env_no_direct && !r->device_rows;
+  if (one_shot) { if (int src = stage(r->out_region_bytes)) return src; }
+  // Small results of the dense paths are written by the emission kernel straight into that pinned host buffer
+  // (posted PCIe writes, coalesced per column) and a one-wave kernel publishes the 512-byte header behind them: no
+  // DMA-engine copy at the end of the query (its start-up costs 20-100 us, more than the 2 MB it moves).
+  if (direct) {
+    for (int i = 0; i < P.ngroup; ++i) r->d_out_key[i] = x->h_out[slot] + r->off_key[i];
+    for (int j = 0; j < P.nmetric; ++j) r->d_out_state[j] = x->h_out[slot] + r->off_state[j];
+  }
+  VhEmitArgs A{};
+  A.mode = r->mode == VH_MODE_DENSE_PART ? VH_MODE_DENSE_GLOBAL : r->mode; A.ngroup = P.ngroup; A.nmetric = P.nmetric; A.key_words = P.key_words;
+  A.hstride = P.hrec_bytes ? P.hrec_bytes / 8u : (uint32_t)P.key_words;
+  A.n = r->out_cap; A.present = P.present; A.present_carrier = (r->mode == VH_MODE_DENSE_GLOBAL || r->mode == VH_MODE_DENSE_PART) ? P.present_carrier : -1; A.hkeys = P.hkeys; A.htags = P.htags; A.counters = P.counters;
+  A.out_count = r->d_out_count;
+  A.n_dev = r->hpart ? P.counters + 1 : nullptr;         // hashed partitioning: entries [0, *n_dev) of the table are a compact list of group records
+  for (int i = 0; i < P.ngroup; ++i) {
+    A.glo[i] = P.g[i].lo; A.gextent[i] = P.g[i].extent; A.gstride[i] = P.g[i].stride;
+    A.gtype[i] = P.g[i].type(); A.gkey_word[i] = P.g[i].key_word(); A.gkey_shift[i] = P.g[i].key_shift();
+    A.out_key[i] = r->d_out_key[i];
+  }
+  for (int j = 0; j < P.nmetric; ++j) {
+    A.state[j] = P.m[j].state; A.out_state[j] = r->d_out_state[j]; A.sop[j] = P.m[j].sop(); A.mtype[j] = (uint8_t)r->metric_elem[j];
+    A.state_stride[j] = r->mode == VH_MODE_HASH && P.hrec_bytes ? P.hrec_bytes : (uint32_t)vh_sop_bytes(P.m[j].sop());
+  }
+  A.nhaving = r->nhaving;
+  A.total_groups = P.counters + 6;
+  for (int i = 0; i < r->nhaving; ++i) { A.hprog[i] = r->hprog[i]; A.htype[i] = r->htype[i]; }
+  for (int i = 0; i < VH_MAX_HAVING_LITS; ++i) A.hlits[i] = r->hlits[i];
+  if (r->hp_direct && r->nhaving == 0 && !r->topk_active) { /* hp_aggregate_kernel wrote the output columns and counted the rows */ }
+  else if (A.n <= (4u << 20)) hipLaunchKernelGGL(emit_groups_kernel<2>, dim3((unsigned)((A.n + 256 * 2 - 1) / (256 * 2))), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(emit_groups_kernel<16>, dim3((unsigned)((A.n + 256 * 16 - 1) / (256 * 16))), dim3(256), 0, st, A);
+  HIP_TRY(hipGetLastError());
+  if (r->topk_active) {
+    // radix select of the top_k-th best sort key among the emitted rows (8 x 8 bits, no host round trip), then keep
+    // every row that ties with or beats it. Row count is only known on the device: grids are sized by out_cap.
+    VhTopkState init{};
+    init.k_remaining = r->topk;
+    HIP_TRY(hipMemcpyAsync(r->d_topk_state, &init, sizeof(init), hipMemcpyHostToDevice, st));
+    const unsigned g1 = (unsigned)std::min<uint64_t>((r->out_cap + 255) / 256, (uint64_t)g_ctx.num_cu * 8);
+    const void* src = r->topk_src_is_key ? r->d_out_key[r->topk_src] : r->d_out_state[r->topk_src];
+    hipLaunchKernelGGL(topk_keys_kernel, dim3(g1), dim3(256), 0, st, src, r->topk_elem, (uint32_t)vh_elem_size(r->topk_elem),
+                       r->topk_cls, r->topk_desc, (const unsigned long long*)r->d_out_count, r->d_topk_keys);
+    for (int shift = 56; shift >= 0; shift -= 8) {
+      hipLaunchKernelGGL(topk_hist_kernel, dim3(g1), dim3(256), 0, st, (const uint64_t*)r->d_topk_keys,
+                         (const unsigned long long*)r->d_out_count, shift, r->d_topk_state);
+      hipLaunchKernelGGL(topk_pick_kernel, dim3(1), dim3(64), 0, st, shift, r->d_topk_state);
+    }
+    VhTopkCompact C{};
+    C.ncols = P.ngroup + P.nmetric;
+    // formatter rounding ("%.15g" / "%g") can make nearby values compare equal in the reference: keep a margin
+    C.slack = r->topk_cls == VH_TOPK_FLOAT ? (r->topk_elem == VH_F32 ? (256ull << 32) : 64ull) : 0ull;
+    for (int i = 0; i < P.ngroup; ++i) { C.src[i] = r->d_out_key[i]; C.dst[i] = r->d_out_key2[i]; C.esize[i] = (uint32_t)vh_elem_size(P.g[i].type()); }
+    for (int j = 0; j < P.nmetric; ++j) {
+      C.src[P.ngroup + j] = r->d_out_state[j]; C.dst[P.ngroup + j] = r->d_out_state2[j];
+      C.esize[P.ngroup + j] = (uint32_t)vh_elem_size(r->metric_elem[j]);
+    }
+    hipLaunchKernelGGL(topk_compact_kernel, dim3((unsigned)((r->out_cap + 255) / 256)), dim3(256), 0, st, C,
+                       (const uint64_t*)r->d_topk_keys, (const unsigned long long*)r->d_out_count, (unsigned long long)r->topk, r->d_topk_state);
+    HIP_TRY(hipGetLastError());
+  }
+  const char* D = x->scratch + r->out_region_off;
+  // packed layout of a big result in the staging buffer: [512-byte header | key columns | state columns], each column `rows` long
+  struct Packed { size_t key[VH_MAX_GROUP], state[VH_MAX_METRIC], bytes; };
+  auto packed_for = [&](uint64_t rows) {
+    Packed L{};
+    size_t o = 512;
+    for (int i = 0; i < P.ngroup; ++i) { L.key[i] = o; o += (std::max<uint64_t>(rows, 1) * vh_elem_size(P.g[i].type()) + 255) / 256 * 256; }
+    for (int j = 0; j < P.nmetric; ++j) { L.state[j] = o; o += (std::max<uint64_t>(rows, 1) * vh_elem_size(r->metric_elem[j]) + 255) / 256 * 256; }
+    L.bytes = o;
+    return L;
+  };
+  auto copy_rows = [&](const Packed& L, uint64_t dst_row, uint64_t src_row, uint64_t n, bool second, hipStream_t cs) -> int {
+    char* H = x->h_out[slot];
+    uint64_t row_bytes = 0;
+    for (int i = 0; i < P.ngroup; ++i) row_bytes += vh_elem_size(P.g[i].type());
+    for (int j = 0; j < P.nmetric; ++j) row_bytes += vh_elem_size(r->metric_elem[j]);
+    if (n * row_bytes >= ((uint64_t)1 << 20) && P.ngroup + P.nmetric <= VH_DELIVER_COLS && knobs().deliver_blocks > 0) {      // (deliver_kernel: why not the DMA engine)
+      VhDeliverArgs A{};
+      for (int i = 0; i < P.ngroup; ++i) {
+        const size_t es = vh_elem_size(P.g[i].type());
+        A.src[A.ncols] = (second ? (const char*)r->d_out_key2[i] : (const char*)r->d_out_key[i]) + src_row * es; A.dst[A.ncols] = H + L.key[i] + dst_row * es; A.bytes[A.ncols++] = n * es;
+      }
+      for (int j = 0; j < P.nmetric; ++j) {
+        const size_t es = vh_elem_size(r->metric_elem[j]);
+        A.src[A.ncols] = (second ? (const char*)r->d_out_state2[j] : (const char*)r->d_out_state[j]) + src_row * es; A.dst[A.ncols] = H + L.state[j] + dst_row * es; A.bytes[A.ncols++] = n * es;
+      }
+      hipLaunchKernelGGL(deliver_kernel, dim3((unsigned)knobs().deliver_blocks), dim3(256), 0, cs, A);
+      HIP_TRY(hipGetLastError());
+      return VH_OK;
+    }
+    for (int i = 0; i < P.ngroup; ++i) {
+      const size_t es = vh_elem_size(P.g[i].type());
+      HIP_TRY(hipMemcpyAsync(H + L.key[i] + dst_row * es, (second ? (const char*)r->d_out_key2[i] : (const char*)r->d_out_key[i]) + src_row * es, n * es, hipMemcpyDeviceToHost, cs));
+    }
+    for (int j = 0; j < P.nmetric; ++j) {
+      const size_t es = vh_elem_size(r->metric_elem[j]);
+      HIP_TRY(hipMemcpyAsync(H + L.state[j] + dst_row * es, (second ? (const char*)r->d_out_state2[j] : (const char*)r->d_out_state[j]) + src_row * es, n * es, hipMemcpyDeviceToHost, cs));
+    }
+    return VH_OK;
+  };
+  // streamed result: every finished chunk's rows go out on the copy stream, packed one chunk behind the other, while the next chunks run.
+  // The staging buffer is sized when the first chunk's count is in (the mixed key deals the groups evenly: eight times that, and a bit);
+  // should the rest not fit after all, everything is copied once more when all counts are known.
+  uint64_t streamed = 0;
+  Packed L{};
+  if (r->hp_chunks) {
+    uint64_t cnt[VH_HP_CHUNKS] = {}, rows_cap = 0;
+    bool redo = false;
+    for (int c = 0; c < r->hp_chunks; ++c) {
+      HIP_TRY(wait_event_spinning(x->ev_chunk[c]));
+      cnt[c] = std::min<uint64_t>(reinterpret_cast<volatile unsigned long long*>(x->h_chunk)[c], r->hp_chunk_rows);      // (more: the region overflowed, the attempt is void — flagged in the header)
+      if (c == 0) {
+        rows_cap = cnt[0] * (uint64_t)r->hp_chunks + cnt[0] / 4 + 65536;
+        L = packed_for(rows_cap);
+        if (int src = stage(L.bytes)) return src;
+      }
+      if (streamed + cnt[c] > rows_cap) redo = true;
+      if (cnt[c] && !redo) { if (int crc = copy_rows(L, streamed, (uint64_t)c * r->hp_chunk_rows, cnt[c], false, x->copy)) return crc; }
+      streamed += cnt[c];
+    }
+    if (redo) {
+      HIP_TRY(hipStreamSynchronize(x->copy));
+      L = packed_for(streamed);
+      if (int src = stage(L.bytes)) return src;
+      uint64_t at = 0;
+      for (int c = 0; c < r->hp_chunks; ++c) { if (cnt[c]) { if (int crc = copy_rows(L, at, (uint64_t)c * r->hp_chunk_rows, cnt[c], false, x->copy)) return crc; } at += cnt[c]; }
+    }
+  }
+  VhTopkState tk{};
+  if (r->topk_active) HIP_TRY(hipMemcpyAsync(&tk, r->d_topk_state, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  // small results: counters, group count and every output array come back in ONE copy + ONE sync; big ones: the header first
+  unsigned long long* const head = one_shot ? reinterpret_cast<unsigned long long*>(x->h_out[slot]) : x->h_counters + 16;
+  if (direct) {
+    hipLaunchKernelGGL(publish_header_kernel, dim3(1), dim3(64), 0, st, head, reinterpret_cast<const unsigned long long*>(D));
+    HIP_TRY(hipGetLastError());
+  } else {
+    HIP_TRY(hipMemcpyAsync(head, D, one_shot ? r->out_region_bytes : 512, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(hipEventRecord(x->ev[3], st));
+  HIP_TRY(wait_event_spinning(x->ev[3]));
+  const unsigned long long* hc = head;
+  const unsigned long long err = hc[2];
+  if (r->hp_chunks) HIP_TRY(hipStreamSynchronize(x->copy));      // (also when the attempt is void: the next one rewrites what the copies read)
+  if (err & VH_ERR_HP_WIDE) { *retry = 6; return VH_OK; }        // packed tuples met a value beyond the recorded min / max: the plain hash table
+  if (err & VH_ERR_HPART_FULL) { *retry = 4; return VH_OK; }
+  if (err & VH_ERR_HASH_FULL) { *retry = 1; return VH_OK; }
+  if (err & VH_ERR_PART_FULL) { r->info.passed_recs = hc[0]; *retry = 3; return VH_OK; }   // phase 1 ran to the end: the survivors are counted
+  if (err & VH_ERR_RANGE) { *retry = 2; return VH_OK; }
+  uint64_t ng = r->hp_chunks ? streamed : hc[32];                                 // rows emitted (after HAVING): the word at byte 256
+  r->info.ngroups = r->nhaving ? hc[6] : ng;                                     // agg_map.size()
+  if (r->topk_active) ng = tk.out_count;                                          // rows kept by the top-N superset
+  r->info.returned_groups = ng;
+  r->ngroups_host = ng;
+  r->info.passed_recs = hc[0];
+  if (!one_shot) {
+    if (!r->hp_chunks) {           // a big result in one piece: the staging buffer is sized for the rows there are
+      L = packed_for(ng);
+      if (int src = stage(L.bytes)) return src;
+      if (ng) { if (int crc = copy_rows(L, 0, 0, ng, r->topk_active, st)) return crc; }
+      HIP_TRY(hipEventRecord(x->ev[3], st));
+      HIP_TRY(wait_event_spinning(x->ev[3]));
+    }
+    memcpy(x->h_out[slot], head, 512);
+    for (int i = 0; i < P.ngroup; ++i) r->off_key[i] = L.key[i];      // (the host view: where vh_result_view finds the columns)
+    for (int j = 0; j < P.nmetric; ++j) r->off_state[j] = L.state[j];
+  }
+  r->h_base = x->h_out[slot];
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, x->ev[1], x->ev[2]); r->info.scan_kernel_ms = ms;
+  (void)hipEventElapsedTime(&ms, x->ev[0], x->ev[3]); r->info.total_ms = ms;
+  if (knobs().times) {   // where a query's device time goes: setup (clears, uploads) | scan | emission + read-back
+    float a = 0, b = 0;
+    (void)hipEventElapsedTime(&a, x->ev[0], x->ev[1]); (void)hipEventElapsedTime(&b, x->ev[2], x->ev[3]);
+    fprintf(stderr, "vh times: setup %.3f ms, scan %.3f ms, emit+readback %.3f ms (groups %llu, returned %llu)\n", a, r->info.scan_kernel_ms, b,
+            (unsigned long long)r->info.ngroups, (unsigned long long)r->info.returned_groups);
+  }
+  r->finalized = true;
+  return VH_OK;
+}
+
+
+extern "C" int vh_query_launch(vh_table* t, const vh_plan* plan, vh_result** out) {
+  if (!t || !plan || !out) return vh_fail(VH_E_INVALID, "null argument");
+  VH_ENTER();
+  VhExec* x = nullptr;
+  if (int rc = exec_acquire(t, &x)) return rc;
+  vh_result* r = nullptr;
+  int rc;
+  { std::lock_guard<std::mutex> lk(t->mu); rc = query_launch_locked(t, x, plan, &r, 0, false); }
+  if (rc) { (void)hipStreamSynchronize(x->stream()); exec_release(t, x); return rc; }
+  r->exec = x;
+  *out = r;
+  return VH_OK;
+}
+
+extern "C" int vh_result_finalize(vh_result* r) {
+  if (!r) return vh_fail(VH_E_INVALID, "null result");
+  if (r->finalized) return VH_OK;
+  VH_ENTER();
+  int retry = 0;
+  int rc = result_finalize(r, &retry);
+  if (rc) return rc;
+  if (retry) return vh_fail(VH_E_RANGE, "partial result needs a re-plan (code %d); use vh_query_agg", retry);
+  return VH_OK;
+}
+
+// One attempt's verdict -> the overrides of the next one. Shared by vh_query_agg and the sharded form.
+struct VhReplan { uint64_t cap_override = 0, part_override = 0; bool force_hash = false, no_part = false; uint32_t hp_passes = 0; bool no_hpart = false; };
+static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
+  if (retry == 1) {
+    // table too small. The number of groups is bounded by the number of surviving rows: estimate those
+    // once with the selectivity probe and size for them, instead of quadrupling blindly
+    uint64_t next = (r->plan.hmask + 1) * 4;
+    if (!rp->cap_override) {
+      double sel = 1.0;
+      if (r->info.reserved & 1) { std::lock_guard<std::mutex> lk(t->mu); (void)estimate_selectivity(t, r->exec, r->plan, r->h_prog, r->h_lits, r->plan.nseg, &sel); }
+      uint64_t survivors = (uint64_t)((double)r->info.scanned_recs * std::min(1.0, sel * 1.1)) + 1024;
+      uint64_t sized = 1;
+      while (sized < survivors * 2) sized <<= 1;
+      next = std::max(next, sized);
+    }
+    rp->cap_override = next;
+  }
+  else if (retry == 6) { if (r->hpart) rp->no_hpart = true; else rp->no_part = true; }      // a value beyond its column's recorded range in a packed tuple
+  else if (retry == 4) {                                     // hashed partitioning: a range held more groups (or ids) than its passes' LDS tables take
+    if (r->plan.hp_passes >= 64) rp->no_hpart = true;        // ... skewed beyond help: the plain hash table
+    else rp->hp_passes = (uint32_t)r->plan.hp_passes * 4;
+    if (rp->hp_passes > 64) rp->hp_passes = 64;
+  }
+  else if (retry == 3 && r->hpart) {                         // hashed partitioning ran out of tuple extents: size for the survivors it counted, then give up
+    if (rp->part_override) rp->no_hpart = true;
+    else rp->part_override = std::max<uint64_t>(r->info.passed_recs + r->info.passed_recs / 16 + 1024, 1ull << 16);
+  }
+  else if (retry == 3) {                                     // tuple extents exhausted: more room, then give up on partitioning
+    // the attempt counted its survivors even though it dropped their tuples: the next one is sized for exactly that many
+    const uint64_t had = (uint64_t)r->plan.max_extents * r->plan.ext_tuples;
+    if (rp->part_override && had >= r->info.scanned_recs) rp->no_part = true;
+    else rp->part_override = std::max<uint64_t>(std::max<uint64_t>(rp->part_override * 2, r->info.passed_recs + r->info.passed_recs / 16), 1ull << 16);
+  }
+  else rp->force_hash = true;                                // a digit left its planned range
+}
+
+// More metrics than one pass carries (VH_MAX_METRIC states per group in the kernel arguments): several passes over
+// the same snapshot, each with a slice of the metrics, joined on the group key. The reference has no such limit
+// (AggTuple::Metrics is a generated struct of any width, store.cc:31-169).
+static int query_agg_multipass(vh_table* t, const vh_plan* plan, vh_result** out) {
+  if (plan->nhaving || plan->top_k)
+    return vh_fail(VH_E_UNSUPPORTED, "%d metrics take several passes: apply HAVING / top-N to the returned groups", plan->nmetrics);
+  const int per = VH_MAX_METRIC - 4;
+  std::vector<std::unique_ptr<vh_result>> parts;
+  int count_col = -1;
+  for (int j = 0; j < plan->nmetrics; ++j)
+    if (plan->metrics[j] >= 0 && (size_t)plan->metrics[j] < t->cols.size() && t->cols[plan->metrics[j]].kind == VH_METRIC_COUNT) count_col = plan->metrics[j];
+  std::vector<int> part_user;                                  // metrics of each pass that belong to the caller's list
+  for (int off = 0; off < plan->nmetrics; off += per) {
+    const int nm = std::min(per, plan->nmetrics - off);
+    std::vector<int32_t> cm(plan->metrics + off, plan->metrics + off + nm);
+    bool avg = false, cnt = false;
+    for (int32_t c : cm) if (c >= 0 && (size_t)c < t->cols.size()) { avg |= t->cols[c].kind == VH_METRIC_AVG; cnt |= t->cols[c].kind == VH_METRIC_COUNT; }
+    if (avg && !cnt && count_col >= 0) cm.push_back(count_col);   // an AVG slice still divides by the query's COUNT (scan.cc:239-241): it rides along
+    vh_plan cp = *plan;
+    cp.metrics = cm.data(); cp.nmetrics = (int32_t)cm.size();
+    vh_result* r = nullptr;
+    if (int rc = vh_query_agg(t, &cp, &r)) return rc;
+    parts.emplace_back(r);
+    part_user.push_back(nm);
+  }
+  vh_result* base = parts[0].get();
+  const uint64_t n = base->ngroups_host;
+  const int nk = base->plan.ngroup;
+  std::unique_ptr<vh_result> rf(new vh_result());
+  rf->table = t; rf->info = base->info; rf->mode = base->mode; rf->kernel = base->kernel;
+  rf->plan.ngroup = nk; rf->plan.key_words = base->plan.key_words;
+  for (int i = 0; i < nk; ++i) rf->plan.g[i] = base->plan.g[i];
+  rf->group_elem = base->group_elem;
+  auto key_of = [&](const vh_result* r, uint64_t row) {
+    std::string k;
+    for (int i = 0; i < nk; ++i) { const int es = vh_elem_size(r->plan.g[i].type()); k.append(r->h_base + r->off_key[i] + row * es, es); }
+    return k;
+  };
+  std::unordered_map<std::string, uint64_t> where;
+  if (parts.size() > 1) { where.reserve(n * 2); for (uint64_t row = 0; row < n; ++row) where.emplace(key_of(base, row), row); }
+  // layout of the joined result: keys, then every pass's user metrics in plan order, then the hidden count (if the plan has one)
+  const vh_result* hidden_from = nullptr;
+  bool any_count = false;
+  for (int j = 0; j < plan->nmetrics; ++j) any_count |= plan->metrics[j] >= 0 && t->cols[plan->metrics[j]].kind == VH_METRIC_COUNT;
+  for (auto& pr : parts) if (pr->info.has_hidden_count && !any_count && !hidden_from) hidden_from = pr.get();
+  size_t bytes = 0;
+  for (int i = 0; i < nk; ++i) { rf->off_key[i] = bytes; bytes += (std::max<uint64_t>(n, 1) * vh_elem_size(base->plan.g[i].type()) + 255) / 256 * 256; }
+  std::vector<std::pair<const vh_result*, int>> src;      // joined device-metric index -> (pass, its device metric)
+  for (size_t k = 0; k < parts.size(); ++k) for (int j = 0; j < part_user[k]; ++j) src.push_back({parts[k].get(), parts[k]->user_metric[j]});
+  if (hidden_from) src.push_back({hidden_from, hidden_from->plan.nmetric - 1});
+  if (src.size() > 4096) return vh_fail(VH_E_UNSUPPORTED, "too many metrics");
+  std::vector<size_t> off_state(src.size());
+  for (size_t u = 0; u < src.size(); ++u) {
+    rf->metric_elem.push_back(src[u].first->metric_elem[src[u].second]);
+    off_state[u] = bytes; bytes += (std::max<uint64_t>(n, 1) * vh_elem_size(rf->metric_elem.back()) + 255) / 256 * 256;
+  }
+  HIP_TRY(host_alloc_near_device((void**)&rf->h_own, bytes, hipHostMallocDefault));
+  for (int i = 0; i < nk; ++i) if (n) memcpy(rf->h_own + rf->off_key[i], base->h_base + base->off_key[i], n * vh_elem_size(base->plan.g[i].type()));
+  for (size_t u = 0; u < src.size(); ++u) {
+    const vh_result* pr = src[u].first;
+    const int es = vh_elem_size(rf->metric_elem[u]);
+    const char* from = pr->h_base + pr->off_state[src[u].second];
+    char* to = rf->h_own + off_state[u];
+    if (pr == base) { if (n) memcpy(to, from, n * es); continue; }
+    if (pr->ngroups_host != n) return vh_fail(VH_E_DEVICE, "passes of one query returned %llu and %llu groups", (unsigned long long)n, (unsigned long long)pr->ngroups_host);
+    for (uint64_t row = 0; row < n; ++row) {
+      auto it = where.find(key_of(pr, row));
+      if (it == where.end()) return vh_fail(VH_E_DEVICE, "passes of one query returned different groups");
+      memcpy(to + it->second * es, from + row * es, es);
+    }
+  }
+  rf->wide_off_state = off_state;
+  for (int j = 0; j < plan->nmetrics; ++j) rf->user_metric.push_back(j);
+  rf->info.nmetrics = plan->nmetrics; rf->info.has_hidden_count = hidden_from ? 1 : 0;
+  rf->plan.nmetric = (int32_t)std::min<size_t>(src.size(), VH_MAX_METRIC);
+  rf->h_base = rf->h_own; rf->ngroups_host = n; rf->finalized = true;
+  *out = rf.release();
+  return VH_OK;
+}
+
+extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
+  if (!t || !plan || !out) return vh_fail(VH_E_INVALID, "null argument");
+  VH_ENTER();
+  if (plan->nmetrics > VH_MAX_METRIC - 1 && plan->metrics) return query_agg_multipass(t, plan, out);
+  VhExec* x = nullptr;
+  if (int rc = exec_acquire(t, &x)) return rc;
+  VhReplan rp;
+  int rc = VH_OK;
+  for (uint32_t attempt = 0; attempt < 12; ++attempt) {
+    vh_result* r = nullptr;
+    // planned and launched under the table lock; the wait for the device and the read-back happen outside it, so
+    // queries of other threads on this table run meanwhile (each on its own context)
+    { std::lock_guard<std::mutex> lk(t->mu); rc = query_launch_locked(t, x, plan, &r, rp.cap_override, rp.force_hash, rp.part_override, rp.no_part, false, nullptr, nullptr, false, rp.hp_passes, rp.no_hpart); }
+    if (rc) break;
+    r->exec = x;
+    int retry = 0;
+    rc = result_finalize(r, &retry);
+    if (rc) { r->exec = nullptr; delete r; break; }
+    if (!retry) {
+      r->info.retries = attempt;
+      if (r->mode == VH_MODE_HASH) { std::lock_guard<std::mutex> lk(t->mu); t->groups_seen[r->group_sig] = r->info.ngroups; }
+      *out = r;
+      return VH_OK;
+    }
+    replan_after(t, r, retry, &rp);
+    r->exec = nullptr;                                       // the next attempt runs on the same context
+    delete r;
+    rc = vh_fail(VH_E_NOMEM, "aggregate table kept overflowing");
+  }
+  (void)hipStreamSynchronize(x->stream());
+  exec_release(t, x);
+  return rc;
+}
+
+// First-use costs paid up front: the scan kernel compiled for the plan's shape (1-2 s of hipRTC, or milliseconds from the disk
+// cache), the payload projection and the narrow predicate copies a selective query reads (built at once instead of after VH_AUTO_PACK /
+// VH_AUTO_NARROW uses), and — only here — a tuple pool placed by measurement (place_search: bounded to half of the free memory / 48 GB, 8
+// candidates; everything but the winner is released before the call returns). The reference's analogue is Compiler::Compile running when a
+// query shape is first seen (src/codegen/compiler.cc:97-144, QueryStats::compile_time); a caller that knows its hot shapes at table-load
+// time runs them through here. The plan is executed (up to three times: a narrow copy, then a projection, then the pool can appear) and
+// the last attempt's info is returned, so the caller sees what a steady-state query of this shape will run on.
+extern "C" int vh_table_prepare(vh_table* t, const vh_plan* plan, vh_result_info* info_out) {
+  if (!t || !plan) return vh_fail(VH_E_INVALID, "null argument");
+  struct Guard { Guard() { g_preparing = true; } ~Guard() { g_preparing = false; } } guard;
+  uint32_t last = ~0u;
+  for (int round = 0; round < 3; ++round) {
+    vh_result* r = nullptr;
+    if (int rc = vh_query_agg(t, plan, &r)) return rc;
+    const uint32_t now = r->info.reserved;
+    if (info_out) *info_out = r->info;
+    vh_result_free(r);
+    if (now == last) break;
+    last = now;
+  }
+  return VH_OK;
+}
+
