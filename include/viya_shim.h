@@ -34,7 +34,14 @@ namespace viya {
 namespace shim {
 
 struct Session;
-struct Stats { uint64_t scanned_segments, scanned_recs, aggregated_recs, output_recs; };
+struct Stats {
+  uint64_t scanned_segments, scanned_recs, aggregated_recs, output_recs;      /* query::QueryStats (src/query/stats.h:35-58) */
+  /* what the device path ran on, for a maintainer's logs (the reference reports compile_time separately for the same reason): the flags of
+   * vh_result_info.reserved — bit 5 a scan kernel compiled for the plan shape, bit 3 a payload projection, bit 4 narrow predicate copies,
+   * bit 9 a tuple pool placed by vh_table_prepare, ... (include/viya_hip.h) —, re-plans of this query, and the kernels' time */
+  uint32_t device_flags, retries;
+  double scan_kernel_ms;
+};
 typedef void (*SendFn)(void* ctx, const std::vector<std::string>& row);
 
 __attribute__((visibility("default"))) Session* Open(const void* table_key, const char* table_json, const char* query_json);

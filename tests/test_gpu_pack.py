@@ -172,6 +172,30 @@ def test_library_builds_a_projection_for_a_repeated_selective_query():
         dt.close()
 
 
+def test_prepare_pays_the_first_use_costs_up_front():
+    """vh_table_prepare (executor.warm): the FIRST query of a prepared plan shape already runs on what the third one would otherwise get — a
+    payload projection, narrow predicate copies — and vh_result_info.reserved says so; an unprepared twin of the table starts on the arenas.
+    (The compiled kernel joins from VH_JIT_MIN_ROWS up, and the measured pool placement from 128 MB of tuples: tests/test_gpu_fullsize.py.)"""
+    from viyadb_amd import synth
+    from viyadb_amd.executor import AggPlan
+    from tests.parity import build_oracle_table
+    w = synth.c3(segment_rows=100_000)
+    st = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 3, 100_000), w.query))
+    plan = AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics)
+    cold, warm = synth.create_device_table(w, 3, 100_000), synth.create_device_table(w, 3, 100_000)
+    try:
+        flags = warm.warm(plan)
+        assert flags & 8 and flags & 16, flags                    # bit 3: projection, bit 4: narrow predicate copies
+        first = warm.query_agg(plan)
+        compare(first, st, "prepared")
+        assert first.packed and first.narrow
+        res = cold.query_agg(plan)
+        compare(res, st, "unprepared")
+        assert not res.packed and not res.narrow
+    finally:
+        cold.close(); warm.close()
+
+
 # ---- compressed records (round 3): integers at the width their values need, read by the per-query compiled kernels only
 JITPACK = capi.PLAN_FORCE_JIT | PACK
 from tests.conftest import JIT_OFF  # noqa: E402

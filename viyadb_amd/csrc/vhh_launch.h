@@ -57,6 +57,11 @@ int QueryBuild::compile_kernel() {
         // no kernel for this shape (hipRTC missing, or the text did not compile): plan again for the pre-built kernels. The
         // failure is remembered per shape, so only the first query of the shape pays for the attempt.
         if (knobs().jit_verbose) fprintf(stderr, "vh: per-query kernel unavailable, falling back: %s\n", jerr.c_str());
+        else {      // said ONCE per process, whatever the verbosity: a maintainer must be able to see this cliff (large scans run about half as fast)
+          static std::once_flag told;
+          std::call_once(told, [&] { fprintf(stderr, "viya_hip: no per-query compiled scan kernels in this process (%s): the pre-built interpreting kernels answer instead; "
+                                                     "vh_result_info.reserved bit 5 tells per query (VH_JIT_VERBOSE=1 for every occurrence)\n", jerr.substr(0, 200).c_str()); });
+        }
         if ((p->flags & VH_PLAN_FORCE_JIT) || vh_jit_policy() == VH_JIT_FORCE) return vh_fail(VH_E_UNSUPPORTED, "per-query kernel requested (VH_PLAN_FORCE_JIT / VH_JIT=force) but unavailable: %s", jerr.c_str());
         vh_plan p2 = *p;
         p2.flags |= VH_PLAN_NO_JIT;

@@ -220,6 +220,7 @@ void FetchGroups(vh_result* res, AggregateQuery& query, Groups& groups, QuerySta
   stats.scan_kernel_ms = info.scan_kernel_ms;
   stats.device_total_ms = info.total_ms;
   stats.path = info.path;
+  stats.device_flags = info.reserved; stats.retries = info.retries;
 
   groups.n = info.returned_groups;
   std::vector<void*> kp, sp;
@@ -577,6 +578,7 @@ void GpuSearch(SearchQuery& query, RowOutput& output, QueryStats& stats, std::ve
         stats.scan_kernel_ms = info.scan_kernel_ms;
         stats.device_total_ms = info.total_ms;
         stats.path = info.path;
+        stats.device_flags = info.reserved; stats.retries = info.retries;
       }
       std::vector<char> keys(info.returned_groups * es);
       std::vector<uint64_t> pos(info.returned_groups);

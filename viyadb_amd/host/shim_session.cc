@@ -155,7 +155,7 @@ void Run(Session* s, const uint64_t* fargs, size_t nfargs, const uint64_t* hargs
   }
   CallbackOutput out(send, ctx);
   q::detail::PostAggregate(*s->query, groups, having_on_device, ha, skip, limit, out, qs);
-  if (stats) *stats = Stats{qs.scanned_segments, qs.scanned_recs, qs.aggregated_recs, qs.output_recs};
+  if (stats) *stats = Stats{qs.scanned_segments, qs.scanned_recs, qs.aggregated_recs, qs.output_recs, qs.device_flags, qs.retries, qs.scan_kernel_ms};
 }
 
 void Close(const void* table_key) {

@@ -93,6 +93,7 @@ struct QueryStats {
   double scan_kernel_ms = 0, device_total_ms = 0;
   int path = 0;
   size_t passed_recs = 0;
+  unsigned device_flags = 0, retries = 0;   // vh_result_info.reserved (compiled kernel, projection, narrow copies, placed pool, ...) and re-plans: the cliffs a maintainer should see
 };
 
 // ---- query model
