@@ -2123,11 +2123,14 @@ struct VhSplitTile {             // LDS, behind the sorted copy
 };
 __host__ __device__ __forceinline__ size_t vh_split_tile_bytes() { return (size_t)VH_SPLIT_TILE_TUPLES * 16 + sizeof(VhSplitTile); }
 
-template <int BLOCK>
+// TW: 64-bit words per tuple — 2, or 1 (the planner packed gid and values into one word, VhPlanDev::gid_bits: half the bytes through this level too)
+template <int BLOCK, int TW = 2>
 __global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev P, int blocks_per_part) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+  typedef typename VhStageTuple<TW>::type u64x2;      // (the tuple: two words, or one)
   u64x2* sorted = reinterpret_cast<u64x2*>(lds);
+  const uint64_t gid_mask = TW == 1 ? (1ull << P.gid_bits) - 1ull : ~0ull;
+  auto word0 = [](const u64x2& t) -> uint64_t { if constexpr (TW == 1) return t; else return t.x; };
   VhSplitTile& S = *reinterpret_cast<VhSplitTile*>(lds + (size_t)VH_SPLIT_TILE_TUPLES * 16);
   const int part = blockIdx.x / blocks_per_part, b = blockIdx.x % blocks_per_part;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2156,7 +2159,7 @@ __global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev 
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const uint32_t i = i0 + r * BLOCK + tid;
-          if (i < valid) { t[r] = __builtin_nontemporal_load(base + i); sub[r] = ((uint32_t)(t[r].x >> gshift) >> P.agg_shift) & 63u; }
+          if (i < valid) { t[r] = __builtin_nontemporal_load(base + i); sub[r] = ((uint32_t)((word0(t[r]) & gid_mask) >> gshift) >> P.agg_shift) & 63u; }
           else sub[r] = 0xFFFFFFFFu;
         }
         if (tid < 64) S.hist[tid] = 0;
@@ -2193,7 +2196,7 @@ __global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev 
         const uint32_t n = S.ntile;
         for (uint32_t k = tid; k < n; k += BLOCK) {
           const u64x2 v = sorted[k];
-          const uint32_t sb = ((uint32_t)(v.x >> gshift) >> P.agg_shift) & 63u;
+          const uint32_t sb = ((uint32_t)((word0(v) & gid_mask) >> gshift) >> P.agg_shift) & 63u;
           const uint64_t d = S.dst[sb];
           if (d != ~0ull) pool2[d + (k - S.rbase[sb])] = v;
         }

@@ -133,7 +133,7 @@ int QueryBuild::decompose_work() {
       snprintf(hn, sizeof(hn), " + hp_scatter_kernel<1024, %d> + hp_scatter_kernel<1024, %d> + ", hp_units, hp_units);
       r->kernel += hn + jk->name + "_hpagg";
     }
-    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? " + part_agg_kernel<1024>" : (P.tw == 2 && !getenv("VH_NO_SPLIT_TILE")) ? " + part_split_tile_kernel<256> + part_agg_kernel<1024>" : " + part_split_kernel<256> + part_agg_kernel<1024>";
+    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? " + part_agg_kernel<1024>" : ((P.tw == 2 || P.gid_bits) && !getenv("VH_NO_SPLIT_TILE")) ? (P.gid_bits ? " + part_split_tile_kernel<256, 1> + part_agg_kernel<1024>" : " + part_split_tile_kernel<256, 2> + part_agg_kernel<1024>") : " + part_split_kernel<256> + part_agg_kernel<1024>";
   }
   int occupancy = 0;
   if (env_bpc <= 0) scan_dispatch(0, &occupancy);
@@ -262,7 +262,7 @@ int QueryBuild::layout_scratch() {
       // pool 2: small extents (4096 ranges x every splitting wave keep one open), sized like pool 1 plus what stays open
       split_bpp = std::max(1, 2 * g_ctx.num_cu / std::max(1, P.npart));     // 256-thread blocks, ~2 per CU whatever the partition count: more waves keep more extents open (4 per CU measured slower)
       // two-word tuples are split a block-wide tile at a time (part_split_tile_kernel): extents of one tile's size, one writer per block
-      const bool tiled = P.tw == 2 && !getenv("VH_NO_SPLIT_TILE");
+      const bool tiled = (P.tw == 2 || P.gid_bits) && !getenv("VH_NO_SPLIT_TILE");
       if (tiled) split_bpp = std::max(1, knobs().split_bpc * g_ctx.num_cu / std::max(1, P.npart));   // a block is one writer: more of them cost less
       const uint64_t et2 = tiled ? VH_SPLIT_TILE_TUPLES : 256;
       P.ext_tuples2 = (int32_t)et2;

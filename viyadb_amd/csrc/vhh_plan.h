@@ -824,6 +824,32 @@ int QueryBuild::choose_organisation() {
         if (words == 2 && shard_rows * sel >= 2e6 && sel >= 0.015) want_part = true;      // (at 1 % of 1 B rows the atomics still hide behind the scan: 1.18 ms direct, 1.31 partitioned)
       }
     }
+    // ONE-word tuples (decided here, used below): gid and every metric value fit 63 bits together — what the values need is known from the
+    // columns' recorded min / max (refresh_stats keeps them for metric columns too). C3's (gid 17 bits, SUM value 10, COUNT 2) is 8 bytes
+    // instead of 16: half the tuple bytes written by phase 1, moved by the split level and read back by phase 2. Only the compiled scan
+    // with the whole-line writer packs them.
+    int nt_gb = 0, nt_mb[VH_MAX_METRIC] = {};
+    bool narrow_tuples = false;
+    if (want_part && jit_try && (two_level ? (np + 63) / 64 : np) <= VH_STAGE_PARTS_MAX && !knobs().no_stage && !(p->flags & (VH_PLAN_NO_NARROW_TUPLES | VH_PLAN_FORCE_LANES)) && !getenv("VH_NO_NARROW_TUPLES")) {
+      auto bits_of = [](uint64_t v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; };
+      nt_gb = bits_of(G - 1);
+      int used = nt_gb;
+      bool fits = true;
+      for (int j = 0; j < P.nmetric && fits; ++j) {
+        const int col = metric_col[j];
+        if (col < 0) { fits = false; break; }
+        const VhColumn& c = t->cols[col];
+        if (c.elem == VH_F32 || c.elem == VH_F64) { fits = false; break; }
+        uint64_t klo = ~0ull, khi = 0;
+        for (uint32_t sgi : live) { const VhSegStat& st = t->stats[col][sgi]; if (st.lo > st.hi) continue; klo = std::min(klo, st.lo); khi = std::max(khi, st.hi); }
+        if (klo > khi) klo = khi = order_key_of_bits(c.elem, 0);
+        const bool sgn = c.elem == VH_I8 || c.elem == VH_I16 || c.elem == VH_I32 || c.elem == VH_I64;
+        if (sgn && (int64_t)(klo ^ (1ull << 63)) < 0) { fits = false; break; }      // negative values: the tuple's fields are unsigned
+        nt_mb[j] = bits_of(sgn ? (khi ^ (1ull << 63)) : bits_of_order_key(c.elem, khi));
+        used += nt_mb[j];
+      }
+      narrow_tuples = fits && used <= 63;
+    }
     if (want_part) {
       // most rows pass: build the tuples without compacting survivors first (lanes kernel, phase 1 only)
       if (fast && !(p->flags & VH_PLAN_NO_LANES) && P.ngroup <= VH_LANES_COLS && P.nmetric <= VH_LANES_COLS && rows_to_scan) {
@@ -838,7 +864,9 @@ int QueryBuild::choose_organisation() {
             // (not when the scan is compiled for the plan and its tuples leave as whole lines — one level, <= 16 partitions: that kernel
             // beats the no-compaction form even when every row passes, 13.5 vs 14.1 ms per 1 B rows, profiles/r03/NOTES.md; with two levels
             // the 64-way phase 1 writes its tuples piecewise and the no-compaction form keeps its lead from 50 % on: 21.4 vs 22.8 ms)
-            lanes = s2 >= 0.5 && !(jit_try && !two_level && np <= VH_STAGE_PARTS);
+            // (... nor when the tuples are one word: half the bytes beat the saved compaction at every selectivity, two levels included —
+            // 4 M groups, every row passing: 23.1 ms through the no-compaction form, see profiles/r04/NOTES.md for the one-word figure)
+            lanes = s2 >= 0.5 && !(jit_try && !two_level && np <= VH_STAGE_PARTS) && !narrow_tuples;
           }
         }
       }
@@ -857,33 +885,11 @@ int QueryBuild::choose_organisation() {
         else { P.m[j].set_tword((uint8_t)tw); P.m[j].set_tshift(0); half_free_word = tw++; have_half = true; }
       }
       P.tw = tw;
-      // ONE-word tuples when gid and every metric value fit 63 bits together — what the values need is known from the columns' recorded
-      // min / max (refresh_stats keeps them for metric columns too): C3's (gid 17 bits, SUM value 10, COUNT 2) is 8 bytes instead of 16,
-      // half the tuple bytes written by phase 1 and read back by phase 2. Only the compiled scan with the whole-line writer packs them.
       P.gid_bits = 0;
-      if (jit_try && !lanes && !two_level && np <= VH_STAGE_PARTS_MAX && !knobs().no_stage && !(p->flags & VH_PLAN_NO_NARROW_TUPLES) && !getenv("VH_NO_NARROW_TUPLES")) {
-        auto bits_of = [](uint64_t v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; };
-        const int gb = bits_of(G - 1);
-        int used = gb, mb[VH_MAX_METRIC] = {};
-        bool fits = true;
-        for (int j = 0; j < P.nmetric && fits; ++j) {
-          const int col = metric_col[j];
-          if (col < 0) { fits = false; break; }
-          const VhColumn& c = t->cols[col];
-          if (c.elem == VH_F32 || c.elem == VH_F64) { fits = false; break; }
-          uint64_t klo = ~0ull, khi = 0;
-          for (uint32_t sgi : live) { const VhSegStat& st = t->stats[col][sgi]; if (st.lo > st.hi) continue; klo = std::min(klo, st.lo); khi = std::max(khi, st.hi); }
-          if (klo > khi) klo = khi = order_key_of_bits(c.elem, 0);
-          const bool sgn = c.elem == VH_I8 || c.elem == VH_I16 || c.elem == VH_I32 || c.elem == VH_I64;
-          if (sgn && (int64_t)(klo ^ (1ull << 63)) < 0) { fits = false; break; }      // negative values: the tuple's fields are unsigned
-          mb[j] = bits_of(sgn ? (khi ^ (1ull << 63)) : bits_of_order_key(c.elem, khi));
-          used += mb[j];
-        }
-        if (fits && used <= 63) {
-          P.gid_bits = gb; P.tw = 1;
-          int at = gb;
-          for (int j = 0; j < P.nmetric; ++j) { P.m[j].set_tword(0); P.m[j].set_tshift((uint8_t)at); P.m[j].tbits = (uint32_t)mb[j]; at += mb[j]; }
-        }
+      if (narrow_tuples && !lanes) {
+        P.gid_bits = nt_gb; P.tw = 1;
+        int at = nt_gb;
+        for (int j = 0; j < P.nmetric; ++j) { P.m[j].set_tword(0); P.m[j].set_tshift((uint8_t)at); P.m[j].tbits = (uint32_t)nt_mb[j]; at += nt_mb[j]; }
       }
       // the drain specialised for "two unsigned 32-bit group columns, SUM(64-bit) + SUM(32-bit)" (vh_consume_fast, SHAPE 1)
       P.shape = 0;
