@@ -35,6 +35,22 @@ __global__ __launch_bounds__(256) void calib_gather32(const u32x4* __restrict__ 
   }
   if (acc == 0x12345u) atomicAdd(sink, 1ull);
 }
+// In-order gathers, the way a scan's survivors read their payload: thread g looks at rows [g * span, (g + 1) * span) of an array of `esize`-byte
+// elements and loads the ONE element whose hash says so (span = 2: every other row on average -> both 64-byte halves of every line are
+// asked for, by separate requests; span = 20: one row in twenty -> most 64-byte halves are asked for once or not at all).
+template <typename V>
+__global__ __launch_bounds__(256) void calib_gather_inorder(const V* __restrict__ p, uint64_t rows, uint32_t span, unsigned long long* sink, unsigned long long* touched64) {
+  uint32_t acc = 0;
+  unsigned long long mine = 0;
+  for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; (g + 1) * span <= rows; g += (uint64_t)gridDim.x * 256) {
+    const uint64_t r = g * span + mix(g + 3) % span;
+    const V v = p[r];
+    if constexpr (sizeof(V) == 4) acc ^= v; else acc ^= v.x ^ v.y;
+    ++mine;
+  }
+  if (acc == 0x12345u) atomicAdd(sink, 1ull);
+  (void)touched64; (void)mine;
+}
 __global__ __launch_bounds__(256) void calib_write16(u32x4* __restrict__ p, uint64_t slots, uint64_t per_thread) {
   const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x, nt = (uint64_t)gridDim.x * 256;
   for (uint64_t it = 0; it < per_thread; ++it) {
@@ -67,8 +83,12 @@ int main() {
   hipLaunchKernelGGL(calib_gather32, dim3(grid), dim3(256), 0, 0, (const u32x4*)buf, bytes / 32, per, sink);
   hipLaunchKernelGGL(calib_write16, dim3(grid), dim3(256), 0, 0, (u32x4*)buf, bytes / 16, per);
   hipLaunchKernelGGL(calib_write128, dim3(grid), dim3(256), 0, 0, (u32x4*)buf, bytes / 128, per);
+  // 4-byte elements, every other row of 8 GiB; 8-byte records, one row in twenty of 8 GiB
+  hipLaunchKernelGGL(calib_gather_inorder<uint32_t>, dim3(grid), dim3(256), 0, 0, (const uint32_t*)buf, stream / 4, 2u, sink, (unsigned long long*)nullptr);
+  hipLaunchKernelGGL(calib_gather_inorder<u32x2>, dim3(grid), dim3(256), 0, 0, (const u32x2*)buf, stream / 8, 20u, sink, (unsigned long long*)nullptr);
   CHECK(hipDeviceSynchronize());
-  printf("{\"read4\": %llu, \"read8\": %llu, \"read16\": %llu, \"gather32_useful\": %llu, \"gather32_lines\": %llu, \"write16p\": %llu, \"write128\": %llu}\n",
+  printf("{\"gather4_every2_array\": %llu, \"gather8_every20_array\": %llu, ", (unsigned long long)stream, (unsigned long long)stream);
+  printf("\"read4\": %llu, \"read8\": %llu, \"read16\": %llu, \"gather32_useful\": %llu, \"gather32_lines\": %llu, \"write16p\": %llu, \"write128\": %llu}\n",
          (unsigned long long)stream, (unsigned long long)stream, (unsigned long long)stream, (unsigned long long)(lanes * 32), (unsigned long long)(lanes * 128),
          (unsigned long long)(lanes * 16), (unsigned long long)(lanes * 16));
   return 0;

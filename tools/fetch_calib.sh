@@ -22,11 +22,14 @@ def put(name, kernel_sub, counter, known_bytes):
         if kernel_sub in k and counter + "_KiB" in v:
             rows[name] = {"kernel": k, "counter": counter, "counter_bytes": v[counter + "_KiB"] * 1024.0, "known_bytes": known_bytes, "ratio": v[counter + "_KiB"] * 1024.0 / known_bytes}
 put("read 4 B/lane", "calib_read<unsigned int>", "FETCH_SIZE", known["read4"])
-put("read 8 B/lane", "vector(2)", "FETCH_SIZE", known["read8"])
-put("read 16 B/lane", "vector(4)", "FETCH_SIZE", known["read16"])
+put("read 8 B/lane", "calib_read<unsigned int __vector(2)>", "FETCH_SIZE", known["read8"])
+put("read 16 B/lane", "calib_read<unsigned int __vector(4)>", "FETCH_SIZE", known["read16"])
 for k in list(res):
     if "calib_read<" in k and "ext_vector" not in k and "unsigned int>" not in k: pass
 put("gather 32 B records (vs 128-byte lines touched)", "calib_gather32", "FETCH_SIZE", known["gather32_lines"])
+# in-order gathers (a scan's survivors): against the bytes of the WHOLE array — 1.0 = every 64-byte half asked for is counted in full
+put("gather 4 B, every other row, in order (vs array bytes)", "calib_gather_inorder<unsigned int>", "FETCH_SIZE", known["gather4_every2_array"])
+put("gather 8 B, one row in 20, in order (vs array bytes)", "calib_gather_inorder<unsigned int __vector(2)>", "FETCH_SIZE", known["gather8_every20_array"])
 put("write 16 B scattered", "calib_write16", "WRITE_SIZE", known["write16p"])
 put("write whole 128 B lines", "calib_write128", "WRITE_SIZE", known["write128"])
 json.dump({"rows": rows, "kernels_seen": sorted(res)}, open(out, "w"), indent=1)
