@@ -28,6 +28,7 @@ struct VhJitShape {
   int mode = 0, block = 256, scope = 0, xcd = 0, carrier = -1, tw = 0, key_words = 1, lds_hash = 0, gid32 = 0;
   int stage = 0;                        // DENSE_PART: tuples leave for HBM as whole 128-byte lines (vh_part_staged_add): partitions a wave keeps a waiting line for (16 / 64), 0 = piecewise
   int hpart = 0, bitset_j = -1;         // HASH: hashed partitioning (vh_hpart.h); the metric that is a bitset (its ids travel in the tuples, two at a time)
+  int bs_off32 = 0;                     // hashed partitioning with a bitset metric: P.bs_offs points at 32-bit offsets
   int gid_bits = 0;                     // DENSE_PART: one-word tuples — the gid's bits at the bottom of word 0 (0: the usual two or more words)
   int hp_pack = 0, hp_pbits = 0, hp_idbits = 0;   // ... in PACKED 16-byte tuples: word 1 = payload (hp_pbits) | two ids (hp_idbits each) | ids that count << 61 | ids only << 63
   int npred = 0;

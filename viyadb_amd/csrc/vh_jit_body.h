@@ -106,7 +106,11 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
       // offsets[row], offsets[row + 1] in ONE 16-byte load (8-byte aligned), the first two ids in ONE 8-byte load (4-byte aligned; what lies
       // behind a segment's last id is readable: VH_BS_PAD): two address-processor passes per survivor instead of four
       bids = reinterpret_cast<const uint32_t*>(P.bs_vals[b][seg]);
-      if (VJ_BS_MERGE) {
+      if (J::BS_OFF32) {          // 32-bit copies of the offsets (segments with < 2^32 ids): offsets[row], offsets[row + 1] in ONE 8-byte load
+        const vj_u32x2_a4 o = *VJ_GLOBAL(vj_u32x2_a4, reinterpret_cast<const uint32_t*>(P.bs_offs[b][seg]) + row);
+        bk = o.x; bk1 = o.y;
+        if (bk < bk1) { const vj_u32x2_a4 i2 = *VJ_GLOBAL(vj_u32x2_a4, bids + bk); bid0 = i2.x; bid1 = i2.y; }
+      } else if (VJ_BS_MERGE) {
         const vj_u64x2_a8 o = *VJ_GLOBAL(vj_u64x2_a8, P.bs_offs[b][seg] + row);
         bk = o.x; bk1 = o.y;
         if (bk < bk1) { const vj_u32x2_a4 i2 = *VJ_GLOBAL(vj_u32x2_a4, bids + bk); bid0 = i2.x; bid1 = i2.y; }      // (the tuple says how many of the two count)

@@ -729,6 +729,9 @@ __global__ __launch_bounds__(256) void fill_records_kernel(uint64_t* p, uint64_t
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (uint64_t)gridDim.x * 256) p[i] = T.w[i % words];
 }
 
+__global__ __launch_bounds__(256) void narrow_offsets_kernel(const uint64_t* src, uint32_t* dst, uint64_t n) {      // CSR offsets of a segment with < 2^32 ids
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) dst[i] = (uint32_t)src[i];
+}
 __global__ __launch_bounds__(256) void iota_kernel(uint64_t* p, uint64_t n) {
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = i;
 }

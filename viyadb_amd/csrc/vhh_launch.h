@@ -27,6 +27,7 @@ int QueryBuild::compile_kernel() {
     js.gid_bits = mode == VH_MODE_DENSE_PART ? P.gid_bits : 0;
     js.stage = mode == VH_MODE_DENSE_PART && (P.tw == 2 || P.gid_bits) && !env_no_stage ? (P.npart <= VH_STAGE_PARTS ? VH_STAGE_PARTS : P.npart <= VH_STAGE_PARTS_MAX ? VH_STAGE_PARTS_MAX : 0) : 0;
     js.hpart = hpart ? 1 : 0;
+    js.bs_off32 = hpart && hp_off32 ? 1 : 0;
     js.hp_pack = hp_pack ? 1 : 0; js.hp_pbits = hp_pbits; js.hp_idbits = hp_idbits;
     js.ng = P.ngroup; js.nm = P.nmetric;
     for (int i = 0; i < P.ngroup; ++i) {
@@ -371,7 +372,8 @@ int QueryBuild::layout_scratch() {
       P.bs_offs[b] = reinterpret_cast<const uint64_t* const*>(S + o_bsptr[b][0]);
       P.bs_vals[b] = reinterpret_cast<const void* const*>(S + o_bsptr[b][1]);
       if (nseg) {
-        HIP_TRY(hipMemcpy(S + o_bsptr[b][0], c.bs_offsets.data(), nseg * 8, hipMemcpyHostToDevice));
+        // (the compiled scan of the hashed partitioning reads the 32-bit copies of the offsets: the same table of pointers, other arrays)
+        HIP_TRY(hipMemcpy(S + o_bsptr[b][0], hpart && hp_off32 ? (const void*)c.bs_offsets32.data() : (const void*)c.bs_offsets.data(), nseg * 8, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(S + o_bsptr[b][1], c.bs_values.data(), nseg * 8, hipMemcpyHostToDevice));
       }
     }

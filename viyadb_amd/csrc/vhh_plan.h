@@ -210,6 +210,7 @@ struct QueryBuild {
   bool hpart = false;
   uint64_t hp_tuple_cap = 0;
   int hp_units = 1;                 // 16-byte units per tuple of the hashed partitioning: 2 when the tuples carry the ids of a bitset metric
+  bool hp_off32 = false;            // ... and reads a row's CSR offsets from the 32-bit copies (every scanned segment has one: VhColumn::bs_offsets32)
   bool hp_pack = false;             // ... or 1 all the same: payload, two ids and their count packed into the tuple's second word (VhHpArgs::pk)
   int hp_pbits = 0, hp_idbits = 0;
   int hp_bpp = 1;
@@ -1082,6 +1083,10 @@ int QueryBuild::plan_hashed_partitioning() {
             hp_pack = true; hp_units = 1; hp_pbits = pbits; hp_idbits = idbits;
             for (int j = 0; j < P.nmetric; ++j) P.m[j].tbits = (uint32_t)mb[j];
           }
+        }
+        if (nb) {
+          hp_off32 = !getenv("VH_NO_OFF32");
+          for (uint32_t sgi : live) hp_off32 = hp_off32 && t->cols[bitset_col[0]].bs_offsets32[sgi] != nullptr;
         }
         lanes = false;
         P.hpart = 1; P.gid_shift = 32;

@@ -125,6 +125,17 @@ extern "C" int vh_segment_sync_range(vh_table* t, uint32_t seg, uint64_t row_fir
   return refresh_stats(t, seg, 1);   // one pass over the segment's dimension columns in HBM
 }
 
+// The 32-bit copy of a segment's CSR offsets (VhColumn::bs_offsets32): rebuilt whenever the 64-bit ones are.
+static int bitset_offsets32(VhColumn& c, uint32_t seg, uint64_t nrows, uint64_t nvals) {
+  if (c.bs_offsets32[seg]) { HIP_TRY(hipFree(c.bs_offsets32[seg])); c.bs_offsets32[seg] = nullptr; }
+  if (nvals > 0xFFFFFFFFull || !c.bs_offsets[seg]) return VH_OK;
+  HIP_TRY(hipMalloc((void**)&c.bs_offsets32[seg], (nrows + 4) * sizeof(uint32_t)));      // (+ what an 8-byte load at the last row reads)
+  hipLaunchKernelGGL(narrow_offsets_kernel, dim3((unsigned)std::min<uint64_t>((nrows + 256) / 256, 4096)), dim3(256), 0, g_ctx.stream, c.bs_offsets[seg], c.bs_offsets32[seg], nrows + 1);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return VH_OK;
+}
+
 extern "C" int vh_segment_sync_bitset(vh_table* t, uint32_t seg, int32_t col, uint64_t nrows,
                                       const uint64_t* offsets, const void* values) {
   if (!t || col < 0 || (size_t)col >= t->cols.size() || !offsets) return vh_fail(VH_E_INVALID, "vh_segment_sync_bitset: bad argument");
@@ -146,6 +157,7 @@ extern "C" int vh_segment_sync_bitset(vh_table* t, uint32_t seg, int32_t col, ui
   HIP_TRY(hipMemcpy(c.bs_offsets[seg], offsets, (nrows + 1) * sizeof(uint64_t), hipMemcpyHostToDevice));
   if (nvals) HIP_TRY(hipMemcpy(c.bs_values[seg], values, nvals * vsz, hipMemcpyHostToDevice));
   c.bs_nvalues[seg] = nvals;
+  if (int orc = bitset_offsets32(c, seg, nrows, nvals)) return orc;
   {
     uint64_t mx = 0;
     if (c.elem == VH_BITSET32) { const uint32_t* v = static_cast<const uint32_t*>(values); for (uint64_t i = 0; i < nvals; ++i) mx = std::max<uint64_t>(mx, v[i]); }
@@ -179,6 +191,7 @@ extern "C" int vh_segment_sync_ids_device(vh_table* t, uint32_t seg, int32_t col
   if (nrows) HIP_TRY(hipMemcpyAsync(c.bs_values[seg], d_ids, nrows * vsz, hipMemcpyDefault, g_ctx.stream));
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   c.bs_nvalues[seg] = nrows;
+  if (int orc = bitset_offsets32(c, seg, nrows, nrows)) return orc;
   c.bs_maxid[seg] = c.elem == VH_BITSET32 ? 0xFFFFFFFFull : ~0ull;      // (exchanged ids, never looked at on this side: the type's range)
   t->nseg = std::max(t->nseg, seg + 1);
   return VH_OK;
@@ -212,6 +225,8 @@ extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nse
         if (vsz == 4) gen_csr_kernel<uint32_t><<<grid, 256, 0, g_ctx.stream>>>(c.bs_offsets[seg], (uint32_t*)c.bs_values[seg], rows_per_seg, k, rb, specs[i].mod, colseed);
         else gen_csr_kernel<uint64_t><<<grid, 256, 0, g_ctx.stream>>>(c.bs_offsets[seg], (uint64_t*)c.bs_values[seg], rows_per_seg, k, rb, specs[i].mod, colseed);
         c.bs_nvalues[seg] = rows_per_seg * k;
+        if (int orc = bitset_offsets32(c, seg, rows_per_seg, rows_per_seg * k)) return orc;
+        t->device_bytes += (rows_per_seg + 4) * 4;
         c.bs_maxid[seg] = specs[i].mod - 1;      // (ids are drawn from [0, mod))
         t->device_bytes += (rows_per_seg + 1) * 8 + rows_per_seg * k * vsz;
       }

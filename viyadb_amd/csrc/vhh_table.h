@@ -9,6 +9,8 @@ struct VhColumn {
   std::vector<uint64_t*> bs_offsets;
   std::vector<void*> bs_values;
   std::vector<uint64_t> bs_nvalues;
+  std::vector<uint32_t*> bs_offsets32;  // the same offsets as 32-bit words when the segment holds < 2^32 ids (nullptr otherwise): what the compiled
+                                        // scan of the hashed partitioning reads — 4 instead of 8 bytes per row of a stream every query of the set takes in full
   std::vector<uint64_t> bs_maxid;      // an upper bound of the segment's ids (what the packed tuples of the hashed partitioning are sized from)
 };
 struct VhSegStat {          // order keys as produced by seg_minmax_kernel
@@ -100,7 +102,7 @@ static int table_grow(vh_table* t, uint32_t need_seg) {
   uint32_t ncap = std::max<uint32_t>(need_seg, std::max<uint32_t>(4, t->cap_seg * 2));
   for (auto& c : t->cols) {
     if (is_bitset_elem(c.elem)) {
-      c.bs_offsets.resize(ncap, nullptr); c.bs_values.resize(ncap, nullptr); c.bs_nvalues.resize(ncap, 0); c.bs_maxid.resize(ncap, 0);
+      c.bs_offsets.resize(ncap, nullptr); c.bs_offsets32.resize(ncap, nullptr); c.bs_values.resize(ncap, nullptr); c.bs_nvalues.resize(ncap, 0); c.bs_maxid.resize(ncap, 0);
       continue;
     }
     char* nb = nullptr;
@@ -219,6 +221,7 @@ extern "C" void vh_table_destroy(vh_table* t) {
   for (auto& c : t->cols) {
     if (c.base) (void)hipFree(c.base);
     for (auto p : c.bs_offsets) if (p) (void)hipFree(p);
+    for (auto p : c.bs_offsets32) if (p) (void)hipFree(p);
     for (auto p : c.bs_values) if (p) (void)hipFree(p);
   }
   if (t->d_stats) (void)hipFree(t->d_stats);
