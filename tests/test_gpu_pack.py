@@ -294,3 +294,58 @@ def test_compressed_records_follow_syncs_and_outgrown_widths():
         assert res.packed and res.packed_compressed and res.scanned_segments == 3
     finally:
         dt.close()
+
+
+@needs_jit
+def test_bit_field_records_follow_syncs_outgrown_bits_and_negative_values():
+    """A compressed projection whose columns are all non-negative integers keeps every column at the BITS its values need, in one 4- or 8-byte
+    word (C3: 29 bits -> 4-byte records). Here: a (6 bits) + b (6) + v (7) + count (2) + w (7) = 28 bits -> 4 bytes per row; a later sync
+    brings values that need more bits (the word grows to 8 bytes), then NEGATIVE values (fields are unsigned: back to byte widths). The rows
+    are the oracle's every time."""
+    rng = np.random.default_rng(29)
+    desc = {"name": "t", "segment_size": 30000, "dimensions": [{"name": "a", "type": "uint"}, {"name": "b", "type": "int"}, {"name": "f", "type": "uint"}],
+            "metrics": [{"name": "v", "type": "long_sum"}, {"name": "count", "type": "count"}, {"name": "w", "type": "int_min"}]}
+
+    def seg(n, amax=50, vlo=0, vhi=100):
+        return ([rng.integers(0, amax, n).astype(np.uint32), rng.integers(0, 40, n).astype(np.int32), rng.integers(0, 100, n).astype(np.uint32)],
+                [rng.integers(vlo, vhi, n).astype(np.int64), rng.integers(1, 4, n).astype(np.uint32), rng.integers(max(vlo, -2 ** 31), min(vhi, 2 ** 31 - 1), n).astype(np.int32)])
+
+    tab = vo.Table(desc)
+    for n in (30000, 20000):
+        d, m = seg(n)
+        tab.add_segment_arrays(d, m, None, n)
+    dt = mirror_table(tab, reserve=3)
+    q = {"dimensions": ["a", "b"], "metrics": ["v", "count", "w"], "filter": F("lt", "f", "8")}
+    fl = capi.PLAN_FORCE_JIT
+    rows_cap = 3 * 30208          # three reserved segments, rows padded to 256
+
+    def replace(segno, d, m, n):
+        sg = tab.segments[segno]
+        for i in range(3):
+            sg["d"][i] = d[i]
+        for j in range(3):
+            sg["m"][j] = m[j]
+        sg["size"] = n
+        dt.sync_segment(segno, d + m, n)
+    try:
+        base = dt.info()[2]
+        dt.pack([0, 1, 3, 4, 5], compressed=True)
+        res, _ = run(tab, dt, q, flags=fl)
+        assert res.packed and res.packed_compressed and res.jit
+        assert dt.info()[2] - base < rows_cap * 5                      # 4-byte records (8-byte ones would take 8 x rows)
+        d, m = seg(25000, amax=3_000_000, vhi=2 ** 30)                  # a needs 22 bits, v and w 30: 22 + 6 + 30 + 2 + 30 > 64 -> byte widths; first within 64:
+        d2, m2 = seg(25000, amax=3000, vhi=2 ** 14)                     # 12 + 6 + 14 + 2 + 14 = 48 bits -> 8-byte word
+        replace(1, d2, m2, 25000)
+        res, _ = run(tab, dt, q, flags=fl | capi.PLAN_FORCE_HASH)
+        assert res.packed and res.packed_compressed
+        grown = dt.info()[2] - base
+        assert rows_cap * 8 <= grown < rows_cap * 9
+        replace(1, d, m, 25000)
+        res, _ = run(tab, dt, q, flags=fl | capi.PLAN_FORCE_HASH)
+        assert res.packed and res.packed_compressed and dt.info()[2] - base > grown
+        d3, m3 = seg(30000, vlo=-50, vhi=50)                            # negative values: unsigned bit fields cannot hold them
+        replace(0, d3, m3, 30000)
+        res, _ = run(tab, dt, q, flags=fl)
+        assert res.packed and res.packed_compressed
+    finally:
+        dt.close()

@@ -15,6 +15,7 @@ struct VhJitCol {           // one gathered value of a survivor
   int slot = 0, type = 0, pitch = 0;   // pitch: bytes between consecutive rows (element size, or the record size of a projection)
   int rec = -1, off = 0;               // rec >= 0: member of payload projection `rec`, at byte `off` of its record
   int stored = 0;                      // ... where it takes `stored` bytes (0: its element size; fewer: a compressed projection, low bytes of the value)
+  int bits = 0;                        // bit-field record (4 or 8 bytes, VhPack::bits): `off` is the field's BIT offset in the record word, `stored` its bits
   int sext = 0, rowid = 0, bitset = 0;             // sign-extend to 64 bits (dense digits, signed MIN / MAX); the virtual row-id column
   // group columns
   int gran = VH_T_NONE, nroll = 0, micro = 0, key_word = 0, key_shift = 0;

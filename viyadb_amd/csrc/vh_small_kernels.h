@@ -797,6 +797,42 @@ __global__ __launch_bounds__(256) void pack_kernel(const VhPackArgs A) {
   }
 }
 
+// Bit-field records (VhPack::bits): one thread per row, every column's value OR-ed into the record word at its bit offset. A value that needs
+// more bits than the record gives it (or a negative one: the fields are unsigned) voids the projection, like a byte width outgrown above.
+struct VhPackBitsArgs {
+  int32_t ncols; uint32_t rec_bytes;
+  const char* src[VH_PACK_MAX_COLS];
+  uint64_t src_stride[VH_PACK_MAX_COLS];
+  uint32_t esize[VH_PACK_MAX_COLS], bitoff[VH_PACK_MAX_COLS], bitw[VH_PACK_MAX_COLS];
+  unsigned int* overflow;
+  char* dst; uint64_t dst_stride;
+  const uint32_t* rows;
+  uint32_t seg_first, pad;
+};
+__global__ __launch_bounds__(256) void pack_bits_kernel(const VhPackBitsArgs A) {
+  const uint32_t seg = A.seg_first + blockIdx.y, nrows = A.rows[blockIdx.y];
+  char* dst = A.dst + (uint64_t)seg * A.dst_stride;
+  bool ovf = false;
+  for (uint32_t row = blockIdx.x * 256u + threadIdx.x; row < nrows; row += gridDim.x * 256u) {
+    uint64_t rec = 0;
+    for (int c = 0; c < A.ncols; ++c) {
+      const char* s = A.src[c] + (uint64_t)seg * A.src_stride[c] + (uint64_t)row * A.esize[c];
+      uint64_t v;
+      switch (A.esize[c]) {
+        case 1: v = *reinterpret_cast<const uint8_t*>(s); break;
+        case 2: v = *reinterpret_cast<const uint16_t*>(s); break;
+        case 4: v = *reinterpret_cast<const uint32_t*>(s); break;
+        default: v = *reinterpret_cast<const uint64_t*>(s); break;
+      }
+      if (A.bitw[c] < 64u) ovf |= (v >> A.bitw[c]) != 0ull;      // (a negative value of a signed column has its top bits set: caught here too)
+      rec |= v << A.bitoff[c];
+    }
+    if (A.rec_bytes == 4) reinterpret_cast<uint32_t*>(dst)[row] = (uint32_t)rec;
+    else reinterpret_cast<uint64_t*>(dst)[row] = rec;
+  }
+  if (ovf) atomicOr(A.overflow, 1u);
+}
+
 // Narrow copy of an unsigned 32-bit column whose values fit T (vh_table_narrow): grid.y = segments, 4 elements per thread.
 template <typename T>
 __global__ __launch_bounds__(256) void narrow_kernel(const uint32_t* src, uint64_t src_stride_elems, T* dst, uint64_t dst_stride_elems,

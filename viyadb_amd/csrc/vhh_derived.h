@@ -1,6 +1,8 @@
 // vhh_derived.h — host side of libviya_hip, part of viya_hip.hip's translation unit (included there, in order; not a stand-alone header):
 // derived layouts: payload projections (vh_table_pack) and narrow predicate copies (vh_table_narrow).
 // ------------------------------------------------------- payload projections (vh_table_pack)
+static uint64_t order_key_of_bits(int elem, uint64_t bits);      // (typed host helpers: vhh_result.h)
+static uint64_t bits_of_order_key(int elem, uint64_t k);
 #define VH_PACK_STALE 9001      // (internal) pack_refresh: a value no longer fits its stored width, the projection must go
 // (Re)pack the segments of [first, first + n) whose columns changed since they were last packed.
 static int pack_refresh(vh_table* t, VhPack* pk, uint32_t first, uint32_t n) {
@@ -38,6 +40,19 @@ static int pack_refresh(vh_table* t, VhPack* pk, uint32_t first, uint32_t n) {
     std::vector<uint32_t> rows(cnt);
     for (uint32_t i = 0; i < cnt; ++i) rows[i] = (uint32_t)t->seg_rows[s + i];
     HIP_TRY(hipMemcpyAsync(t->d_packrows, rows.data(), (size_t)cnt * sizeof(uint32_t), hipMemcpyHostToDevice, g_ctx.stream));
+    if (!t->d_packflag) { HIP_TRY(hipMalloc((void**)&t->d_packflag, 256)); HIP_TRY(hipMemsetAsync(t->d_packflag, 0, 256, g_ctx.stream)); }
+    if (pk->bits) {
+      VhPackBitsArgs B{};
+      B.ncols = (int32_t)pk->cols.size(); B.rec_bytes = pk->rec_bytes;
+      for (size_t c = 0; c < pk->cols.size(); ++c) {
+        const VhColumn& col = t->cols[pk->cols[c]];
+        B.src[c] = col.base; B.src_stride[c] = col.stride; B.esize[c] = (uint32_t)col.esize; B.bitoff[c] = pk->bitoff[c]; B.bitw[c] = pk->bitw[c];
+      }
+      B.overflow = t->d_packflag; B.dst = pk->base; B.dst_stride = pk->stride; B.rows = t->d_packrows; B.seg_first = s;
+      dim3 gridb((unsigned)std::min<uint64_t>(64, (t->segment_rows + 255) / 256), cnt);
+      hipLaunchKernelGGL(pack_bits_kernel, gridb, dim3(256), 0, g_ctx.stream, B);
+      HIP_TRY(hipGetLastError());
+    }
     VhPackArgs A{};
     A.ncols = (int32_t)pk->cols.size(); A.rec_bytes = pk->rec_bytes;
     for (size_t c = 0; c < pk->cols.size(); ++c) {
@@ -46,12 +61,13 @@ static int pack_refresh(vh_table* t, VhPack* pk, uint32_t first, uint32_t n) {
       A.wbytes[c] = pk->width[c];
       if (col.elem == VH_I8 || col.elem == VH_I16 || col.elem == VH_I32 || col.elem == VH_I64) A.sgn_mask |= 1u << c;
     }
-    if (!t->d_packflag) { HIP_TRY(hipMalloc((void**)&t->d_packflag, 256)); HIP_TRY(hipMemsetAsync(t->d_packflag, 0, 256, g_ctx.stream)); }
     A.overflow = t->d_packflag;
     A.dst = pk->base; A.dst_stride = pk->stride; A.rows = t->d_packrows; A.seg_first = s;
     dim3 grid((unsigned)std::min<uint64_t>(64, (t->segment_rows + 255) / 256), cnt);
-    hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 256 * pk->rec_bytes, g_ctx.stream, A);
-    HIP_TRY(hipGetLastError());
+    if (!pk->bits) {
+      hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 256 * pk->rec_bytes, g_ctx.stream, A);
+      HIP_TRY(hipGetLastError());
+    }
     unsigned int ovf = 0;
     if (pk->compressed) HIP_TRY(hipMemcpyAsync(&ovf, t->d_packflag, sizeof(ovf), hipMemcpyDeviceToHost, g_ctx.stream));
     HIP_TRY(hipStreamSynchronize(g_ctx.stream));        // `rows` lives on this frame; d_packrows is reused by the next batch
@@ -157,8 +173,29 @@ static int table_pack_locked(vh_table* t, const int32_t* cols, int32_t ncols, bo
     if (bytes > 64) return vh_fail(VH_E_UNSUPPORTED, "vh_table_pack: %u payload bytes per row (max 64)", bytes);
     uint32_t rec = 8;
     while (rec < bytes) rec <<= 1;
+    // bit fields instead of bytes when every column is a non-negative integer (by its recorded min / max) and the word comes out smaller
+    std::vector<uint8_t> bitoff, bitw;
+    bool bits = compress && !getenv("VH_NO_PACK_BITS") && t->nseg > 0;
+    uint32_t used = 0;
+    for (int c : ord) {
+      if (!bits) break;
+      const VhColumn& col = t->cols[c];
+      if (col.elem == VH_F32 || col.elem == VH_F64 || (size_t)c >= t->stats.size() || t->stats[c].size() < t->nseg) { bits = false; break; }
+      uint64_t lo = ~0ull, hi = 0;
+      for (uint32_t sg = 0; sg < t->nseg; ++sg) { const VhSegStat& st = t->stats[c][sg]; if (st.lo > st.hi) continue; lo = std::min(lo, st.lo); hi = std::max(hi, st.hi); }
+      if (lo > hi) lo = hi = order_key_of_bits(col.elem, 0);
+      const bool sgn = col.elem == VH_I8 || col.elem == VH_I16 || col.elem == VH_I32 || col.elem == VH_I64;
+      if (sgn && (int64_t)(lo ^ (1ull << 63)) < 0) { bits = false; break; }
+      const uint64_t vmax = sgn ? (hi ^ (1ull << 63)) : bits_of_order_key(col.elem, hi);
+      int b = 1; while (b < 64 && (vmax >> b)) ++b;
+      bitoff.push_back((uint8_t)used); bitw.push_back((uint8_t)b); used += (uint32_t)b;
+      if (used > 64) { bits = false; break; }
+    }
+    const uint32_t rec_bits = used <= 32 ? 4u : 8u;
+    if (bits && rec_bits >= rec) bits = false;
     std::unique_ptr<VhPack> pk(new VhPack());
     pk->cols = ord; pk->off = off; pk->width = width; pk->rec_bytes = rec; pk->automatic = automatic; pk->compressed = compress;
+    if (bits) { pk->bits = true; pk->bitoff = bitoff; pk->bitw = bitw; pk->rec_bytes = rec = rec_bits; for (auto& o : pk->off) o = 0; }
     pk->stride = (t->segment_rows + 255) / 256 * 256 * (uint64_t)rec;
     VhPack* raw = pk.get();
     t->packs.push_back(std::move(pk));

@@ -34,7 +34,7 @@ int QueryBuild::compile_kernel() {
       const VhGroupDev& g = P.g[i];
       VhJitCol& c = js.g[i];
       c.slot = (int)g.slot(); c.type = (int)g.type(); c.pitch = (int)P.colpitch[g.slot()];
-      c.rec = slot_rec[g.slot()]; c.off = slot_recoff[g.slot()]; c.stored = slot_stored[g.slot()];
+      c.rec = slot_rec[g.slot()]; c.off = slot_recoff[g.slot()]; c.stored = slot_stored[g.slot()]; c.bits = slot_bits[g.slot()];
       c.sext = mode != VH_MODE_HASH;
       c.gran = (int)g.gran(); c.nroll = (int)g.nroll(); c.micro = (int)g.micro();
       c.key_word = (int)g.key_word(); c.key_shift = (int)g.key_shift();
@@ -49,7 +49,7 @@ int QueryBuild::compile_kernel() {
       if (c.bitset) js.bitset_j = j;
       c.type = (int)m.type(); c.sop = (int)m.sop(); c.tword = (int)m.tword(); c.tshift = (int)m.tshift(); c.tbits = hp_pack || (mode == VH_MODE_DENSE_PART && P.gid_bits) ? (int)m.tbits : 0;
       c.sext = vh_sop_sext((int)m.sop());
-      if (!c.rowid && !c.bitset) { c.slot = (int)m.slot(); c.pitch = (int)P.colpitch[m.slot()]; c.rec = slot_rec[m.slot()]; c.off = slot_recoff[m.slot()]; c.stored = slot_stored[m.slot()]; }
+      if (!c.rowid && !c.bitset) { c.slot = (int)m.slot(); c.pitch = (int)P.colpitch[m.slot()]; c.rec = slot_rec[m.slot()]; c.off = slot_recoff[m.slot()]; c.stored = slot_stored[m.slot()]; c.bits = slot_bits[m.slot()]; }
     }
     if (jit_try) {
       std::string jerr;

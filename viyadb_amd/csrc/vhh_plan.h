@@ -185,6 +185,7 @@ struct QueryBuild {
   int slot_col[VH_MAX_SLOTS];                    // table column behind a slot (-1: a narrow copy / projection member added later)
   int slot_rec[VH_MAX_SLOTS], slot_recoff[VH_MAX_SLOTS];   // payload projection a slot reads from (-1: a column arena) and the member's offset in its record
   int slot_stored[VH_MAX_SLOTS];                 // ... and the bytes it takes there (0: the element size)
+  int slot_bits[VH_MAX_SLOTS];                   // bit-field records (VhPack::bits): the record's bytes (4 / 8), slot_recoff = the field's bit offset, slot_stored = its bits; 0 otherwise
   uint64_t bytes_per_row = 0;
   bool fast_ok = false;
   int pred_col[VH_MAX_PRED] = {-1, -1, -1, -1};        // table column behind predicate slot k of the register-resident kernels
@@ -291,7 +292,7 @@ int QueryBuild::shape_filter() {
 
   // ---------------- column slots
   for (int i = 0; i < 256; ++i) slot_of[i] = -1;
-  for (int i = 0; i < VH_MAX_SLOTS; ++i) { slot_col[i] = -1; slot_rec[i] = -1; slot_recoff[i] = 0; slot_stored[i] = 0; }
+  for (int i = 0; i < VH_MAX_SLOTS; ++i) { slot_col[i] = -1; slot_rec[i] = -1; slot_recoff[i] = 0; slot_stored[i] = 0; slot_bits[i] = 0; }
 
   // ---------------- filter program (+ stack depth check)
   fast_ok = !(p->flags & VH_PLAN_NO_FAST);
@@ -1219,6 +1220,7 @@ int QueryBuild::choose_projection() {
         P.colstride[P.nslots] = use->stride;
         P.colpitch[P.nslots] = use->rec_bytes;
         slot_rec[P.nslots] = 0; slot_recoff[P.nslots] = (int)use->off[k]; slot_stored[P.nslots] = (int)use->width[k];
+        if (use->bits) { slot_bits[P.nslots] = (int)use->rec_bytes; slot_recoff[P.nslots] = (int)use->bitoff[k]; slot_stored[P.nslots] = (int)use->bitw[k]; }
         return pslot_of[col] = P.nslots++;
       };
       for (int i = 0; i < p->ngroups; ++i) P.g[i].set_slot((uint16_t)pslot(p->groups[i].col));

@@ -46,7 +46,11 @@ struct VhPack {
   std::vector<uint32_t> off;        // byte offset of each column inside a record
   std::vector<uint8_t> width;       // bytes the column's values take in a record (compressed: fewer than its element size)
   bool compressed = false;          // integer columns stored at the width their values need; only the per-query compiled kernels read these
-  uint32_t rec_bytes = 0;           // power of two, 8..64
+  // BIT-FIELD records (round 4; compressed projections whose columns are all non-negative integers): every column at the BITS its values
+  // need, packed into one 4- or 8-byte word — C3's (d0 10 bits, d1 7, m0 10, count 2) fits 4 bytes: 32 records per 128-byte line instead of 16
+  bool bits = false;
+  std::vector<uint8_t> bitoff, bitw;
+  uint32_t rec_bytes = 0;           // power of two, 8..64 (bit-field records: 4 or 8)
   char* base = nullptr; uint64_t stride = 0; uint32_t cap_seg = 0;
   std::vector<uint64_t> seg_mod;    // value of vh_table::seg_mod[s] the segment was packed at (0: never)
   bool automatic = false;
