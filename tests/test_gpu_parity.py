@@ -63,6 +63,16 @@ def test_c3_table_organisations(flags, path):
     check_workload(w, nseg=4, flags=flags, expect_path=path)
 
 
+@pytest.mark.parametrize("flags", [64, 64 | 4, 64 | 8192, 64 | 32768, 64 | 4 | 32])
+def test_c3_partitioned_with_the_shared_extent_cursor(flags, monkeypatch):
+    """Phase 1's waves take their extent chunks by position (VhPlanDev::ext_waves); VH_TEST_EXT_CURSOR puts them back on the shared
+    cursor — the form every re-run after VH_ERR_PART_FULL uses. Both must give the oracle's groups."""
+    from viyadb_amd import synth
+    monkeypatch.setenv("VH_TEST_EXT_CURSOR", "1")
+    w = synth.c3(segment_rows=250_000)
+    check_workload(w, nseg=4, flags=flags, expect_path="dense_part")
+
+
 @pytest.mark.parametrize("flags,path", [(0, "dense_lds"), (2, "dense_global"), (1, "hash"), (8, "dense_lds"), (10, "dense_global"),
                                         (9, "hash"), (128, "dense_lds"), (256, "dense_lds")])
 def test_c2_table_organisations(flags, path):

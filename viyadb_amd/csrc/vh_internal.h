@@ -214,6 +214,10 @@ struct VhPlanDev {
   uint8_t* extent_part2;     // tag = the SUB-partition (0..63) inside the owning partition's range
   uint32_t* l2;              // [0..npart]: first pool-2 extent of partition p's range (prefix sums); [VH_L2_NEXT + p]: extents handed out of it
   uint32_t max_extents;
+  uint32_t ext_waves;        // pool 1, phase 1: waves of the scan launch when they take their extent chunks by position — the k-th chunk of wave w is
+                             // chunk k * ext_waves + w — instead of from the shared cursor (0: shared cursor). Every wave's first drain opens
+                             // extents, and 3 072 returning atomics on ONE address at the start of the kernel queue up behind each other for
+                             // ~80 us whatever the table's size (profiles/r04/NOTES.md, "A fixed cost inside phase 1")
   uint32_t max_extents2;
   // ---- hashed partitioning (HASH organisation, many groups: hash_part_agg_kernel). Survivors become (mixed key, payload)
   // tuples — the mixed key is a BIJECTION of the packed 64-bit group key (vh_splitmix64 / vh_unmix64), so equal keys meet in one

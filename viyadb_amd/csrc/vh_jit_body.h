@@ -419,8 +419,8 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
     if (MODE == VH_MODE_HASH && V.H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
   }
 
-  if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE != 0) vh_part_stage_finish<J::TW>(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); }
-  if constexpr (MODE == VH_MODE_HASH && J::HPART) vh_part_tile_finish<1>(P, V.T, lane);
+  if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE != 0) vh_part_stage_finish<J::TW>(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); vh_part_wave_done(P, V.W, lane); }
+  if constexpr (MODE == VH_MODE_HASH && J::HPART) { vh_part_tile_finish<1>(P, V.T, lane); vh_part_wave_done(P, V.W, lane); }
   if (lane == 0) {
     if (npassed) atomicAdd(P.counters + 0, npassed);
     if (nfresh) atomicAdd(P.counters + 1, nfresh);

@@ -821,7 +821,8 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
 #define VH_PART_TILE 256     // tuples per wave tile
 struct VhPartWave {
   uint32_t chunk_next, chunk_end;   // extents this wave has reserved and not yet opened
-  uint32_t base, limit;             // level 2 only: the range of pool-2 extents of the partition being split ...
+  uint32_t base, limit;             // level 2: the range of pool-2 extents of the partition being split ... (level 1 with chunks by position,
+                                    // VhPlanDev::ext_waves: base = chunks taken so far, limit = this wave's number in the launch)
   uint32_t* cursor;                 // ... and its allocation cursor (VhPlanDev::l2)
 };
 struct VhPartTile {
@@ -856,14 +857,25 @@ __device__ __forceinline__ void vh_part_tile_init(const VhPlanDev& P, char* area
   T.hist = reinterpret_cast<uint32_t*>(area + (size_t)VH_PART_TILE * P.tw * 8);
   T.r_ext = ~0u; T.r_fill = 0;
   W.chunk_next = W.chunk_end = 0;
-  W.base = 0; W.limit = 0; W.cursor = nullptr;
+  W.base = 0; W.limit = P.ext_waves ? blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) : 0u; W.cursor = nullptr;
+}
+// Phase 1, chunks by position: what the shared cursor would have said at the end — one atomic per wave, nobody waits for it.
+__device__ __forceinline__ void vh_part_wave_done(const VhPlanDev& P, const VhPartWave& W, int lane) {
+  if (P.ext_waves && W.base != 0 && lane == 0) {
+    const unsigned long long end = (unsigned long long)W.chunk_end;
+    atomicMax(P.counters + 5, end < P.max_extents ? end : (unsigned long long)P.max_extents);
+  }
 }
 
 // Open a new extent for partition p (wave-uniform). Returns ~0u when the buffer is exhausted.
 template <int LEVEL>
 __device__ __forceinline__ uint32_t vh_part_new_extent(const VhPlanDev& P, VhPartWave& W, int p, int lane) {
   if (W.chunk_next == W.chunk_end) {
-    if (LEVEL == 1) {
+    if (LEVEL == 1 && P.ext_waves) {
+      const unsigned long long c = ((unsigned long long)W.base * P.ext_waves + W.limit) * VH_EXT_CHUNK;
+      W.chunk_next = c < 0xFFFFFF00ull ? (uint32_t)c : 0xFFFFFF00u;      // (beyond any pool: refused below)
+      ++W.base;
+    } else if (LEVEL == 1) {
       unsigned long long c = 0;
       if (lane == 0) c = atomicAdd(P.counters + 5, (unsigned long long)VH_EXT_CHUNK);
       c = __shfl(c, 0);
@@ -1028,6 +1040,10 @@ __device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTil
 // instruction), and the remainder (< 8 tuples) waits in LDS for the next drain. Extents only ever see aligned 128-byte
 // lines, except for the one partial line that closes an extent (or the kernel).
 // Lane p owns partition p: T.r_ext = its extent, T.r_fill = tuples of it already in HBM (a multiple of 8), r_stage = tuples waiting in LDS.
+#ifndef VJ_ABL
+#define VJ_ABL 0     // measurement builds of the compiled kernels only (vh_jit_body.h); 0x100 here: every extent's lines land in the first 256 extents (same instructions, stores that stay in L2; wrong results)
+#endif
+#define VH_STAGE_ABL_EXT(e) ((VJ_ABL & 0x100) ? ((e) & 255u) : (e))
 #define VH_STAGE_PARTS 16                         // the small form: one pass of the line flush covers every partition
 #define VH_STAGE_PARTS_MAX 64                     // the wide form (a wave keeps at most one partition per lane): four passes
 #define VH_STAGE_BYTES(parts) ((parts) * 128)     // per wave
@@ -1045,7 +1061,7 @@ __device__ __forceinline__ void vh_part_stage_close(const VhPlanDev& P, VhPartTi
   const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, q), fill = __builtin_amdgcn_readlane(T.r_fill, q), st = __builtin_amdgcn_readlane(S.r_stage, q);
   if (old == ~0u) return;
   const uint32_t et = (uint32_t)P.ext_tuples;
-  if ((uint32_t)lane < st) reinterpret_cast<Tup*>(P.tuples)[(uint64_t)old * (uint32_t)P.ext_stride + fill + lane] = reinterpret_cast<const Tup*>(S.lines)[q * LT + lane];
+  if ((uint32_t)lane < st) reinterpret_cast<Tup*>(P.tuples)[(uint64_t)VH_STAGE_ABL_EXT(old) * (uint32_t)P.ext_stride + fill + lane] = reinterpret_cast<const Tup*>(S.lines)[q * LT + lane];
   if (lane == 0) P.extent_missing[old] = (uint16_t)(et - (fill + st));
 }
 
@@ -1102,13 +1118,13 @@ __device__ __forceinline__ void vh_part_staged_add(const VhPlanDev& P, VhPartTil
     if (q < npart && qe != ~0u && qc != 0 && qf + qc >= LT) {
       const vh_u64x2* lq = reinterpret_cast<const vh_u64x2*>(S.lines) + q * 8u;      // (a line is eight 16-byte pieces whatever the tuple)
       const vh_u64x2 a = lq[part4 * 2u], b2 = lq[part4 * 2u + 1u];
-      vh_u64x2* d = reinterpret_cast<vh_u64x2*>(pool + (uint64_t)qe * es + qg) + part4 * 2u;
+      vh_u64x2* d = reinterpret_cast<vh_u64x2*>(pool + (uint64_t)VH_STAGE_ABL_EXT(qe) * es + qg) + part4 * 2u;
       d[0] = a; d[1] = b2;
     }
   }
   __builtin_amdgcn_wave_barrier();
   if (ok && i >= LT) {
-    if (i < whole) pool[(uint64_t)pe * es + g + i] = v;                        // a whole line in the middle of the run: LT consecutive ranks, one store instruction
+    if (i < whole) pool[(uint64_t)VH_STAGE_ABL_EXT(pe) * es + g + i] = v;                        // a whole line in the middle of the run: LT consecutive ranks, one store instruction
     else lines[p * LT + (i - whole)] = v;                                      // the remainder waits for the next drain
   }
   if (T.r_ext != ~0u) { const uint32_t tot = S.r_stage + cnt; T.r_fill += tot & ~(LT - 1u); S.r_stage = tot & (LT - 1u); }
@@ -1565,7 +1581,7 @@ __device__ __forceinline__ void vh_scan_fast_body(const VhPlanDev& P) {
     if (MODE == VH_MODE_HASH && H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
   }
 
-  if (MODE == VH_MODE_DENSE_PART) vh_part_tile_finish(P, T, lane);
+  if (MODE == VH_MODE_DENSE_PART) { vh_part_tile_finish(P, T, lane); vh_part_wave_done(P, W, lane); }
   unsigned long long npassed = npassed32;
   for (int off = 32; off > 0; off >>= 1) npassed += __shfl_down(npassed, off);
   if (lane == 0) {
@@ -1821,7 +1837,7 @@ __global__ __launch_bounds__(BLOCK, VH_LANES_WAVES(MODE, BLOCK, NP)) void scan_a
     if (npassed) atomicAdd(P.counters + 0, npassed);
     if (nfresh) atomicAdd(P.counters + 1, nfresh);
   }
-  if (MODE == VH_MODE_DENSE_PART) { vh_part_tile_finish(P, T, lane); return; }
+  if (MODE == VH_MODE_DENSE_PART) { vh_part_tile_finish(P, T, lane); vh_part_wave_done(P, W, lane); return; }
   if (MODE == VH_MODE_HASH) { vh_lds_hash_flush(P, lds, BLOCK); return; }
   __syncthreads();
   const uint64_t xo = P.nxcd > 1 ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;

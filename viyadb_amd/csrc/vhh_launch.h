@@ -153,6 +153,7 @@ int QueryBuild::decompose_work() {
   while (unit_rows * 2 <= 65536 && unit_rows * 2 <= padded &&
          (uint64_t)nseg * ((padded + unit_rows * 2 - 1) / (unit_rows * 2)) >= want_units) unit_rows *= 2;
   if (env_unit >= (int)step) unit_rows = (uint32_t)env_unit / step * step;
+  if (const char* e = getenv("VH_TEST_UNIT_ROWS")) { if (atoi(e) >= (int)step) unit_rows = (uint32_t)atoi(e) / step * step; }   // (measurement: switched between two queries of one process)
   P.unit_rows = unit_rows;
   P.units_per_seg = (uint32_t)((t->segment_rows + unit_rows - 1) / unit_rows);
   P.nseg = nseg;
@@ -238,7 +239,7 @@ int QueryBuild::layout_scratch() {
   if (mode == VH_MODE_DENSE_PART || hpart) {
     // extent size: big enough that a wave allocates rarely (every allocation is a returning global
     // atomic = a full round trip the wave sits out), small enough that open extents do not waste HBM
-    const uint64_t waves = (uint64_t)grid * 4;
+    const uint64_t waves = (uint64_t)grid * (uint64_t)(BLOCK / 64);
     // ... and small enough that a wave fills about four of them per partition: the last extent of every (wave, partition) stays part
     // full, and phase 2 walks part-full extents at the price of full ones (C3: 1250 tuples per wave and partition — extents of 1024
     // were 61 % full on average, of 256 they are 90 %: kernels 2.07-2.12 -> 2.00-2.01 ms, an eighth of the table 0.36-0.38 -> 0.35-0.36)
@@ -256,6 +257,10 @@ int QueryBuild::layout_scratch() {
     if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
     if (!part_tuples_override && getenv("VH_TEST_PART_EXTENTS")) max_ext = std::max(1, atoi(getenv("VH_TEST_PART_EXTENTS")));   // tests: make the first attempt run out of extents
     P.max_extents = (uint32_t)max_ext;
+    // the scan's waves take their extent chunks by position (no shared cursor, no returning atomics: VhPlanDev::ext_waves). The pool above
+    // holds that whenever the waves' tuple counts agree within the 25 % the estimate leaves; a re-run after VH_ERR_PART_FULL goes back to
+    // the cursor, which packs the chunks whatever the imbalance
+    P.ext_waves = part_tuples_override || getenv("VH_TEST_EXT_CURSOR") ? 0u : (uint32_t)grid * (uint32_t)(BLOCK / 64);
     o_tuples = sp.take(max_ext * ext_stride * P.tw * 8);
     o_emiss = sp.take(max_ext * sizeof(uint16_t));
     o_epart = sp.take(max_ext);
