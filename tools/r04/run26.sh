@@ -1,6 +1,10 @@
 #!/bin/bash
 mkdir -p gpurun_out/r04
 O=gpurun_out/r04/ab_probe.txt; : > $O
-python tools/c5_probe.py > gpurun_out/r04/c5_probe_a.txt 2>&1; tail -4 gpurun_out/r04/c5_probe_a.txt
-VH_TEST_EXT_CURSOR=1 python tools/c5_probe.py > gpurun_out/r04/c5_probe_b.txt 2>&1; tail -4 gpurun_out/r04/c5_probe_b.txt
-timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_hpart.py tests/test_gpu_typed.py tests/test_gpu_distributed.py -x -q 2>&1 | tail -3
+python tools/env_ab_probe.py 1000 - VH_TEST_UNIT_ROWS=16384 2>/dev/null | grep '^{' >> $O
+python tools/env_ab_probe.py 125 - VH_TEST_UNIT_ROWS=4096 2>/dev/null | grep '^{' >> $O
+python tools/env_ab_probe.py 250 - VH_TEST_UNIT_ROWS=4096 2>/dev/null | grep '^{' >> $O
+python tools/env_ab_probe.py 500 - VH_TEST_UNIT_ROWS=8192 2>/dev/null | grep '^{' >> $O
+cat $O
+python tools/c5_probe.py 2>&1 | tail -1 | cut -c1-200
+VH_TEST_UNIT_ROWS=4096 python tools/c5_probe.py 2>&1 | tail -1 | cut -c1-200
