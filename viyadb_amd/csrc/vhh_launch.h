@@ -147,7 +147,8 @@ int QueryBuild::decompose_work() {
   // stays in L2 until it is complete (profiles/r03/NOTES.md, "Blocks per CU": a 125 M-row C3 shard 0.44 -> 0.39 ms with 3 instead of
   // 6, C5's scan 1.95 -> 1.6 ms with 4 instead of 8, and the scatter behind it finds fewer half-empty extents)
   const int occ_cap = jk && mode == VH_MODE_DENSE_PART ? 3 : jk && hpart ? 4 : 8;
-  const int blocks_per_cu = env_bpc > 0 ? env_bpc : occupancy > 0 ? std::min(occupancy, occ_cap) : (BLOCK == 1024 ? 1 : 4);
+  int blocks_per_cu = env_bpc > 0 ? env_bpc : occupancy > 0 ? std::min(occupancy, occ_cap) : (BLOCK == 1024 ? 1 : 4);
+  if (const char* e = getenv("VH_TEST_BLOCKS_PER_CU")) { if (atoi(e) > 0) blocks_per_cu = occupancy > 0 ? std::min(occupancy, atoi(e)) : atoi(e); }   // (measurement: switched between two queries of one process)
   uint32_t unit_rows = step;
   // (units of 4 096 rows lose to longer ones — an eighth of C3 0.342 -> 0.332 ms with 16 K rows, a quarter 0.569 -> 0.542 and the whole table
   // 1.867 -> 1.841 with 32 K, 64 K no better — so a block only needs about eight of them to keep the round-robin even: tools/env_ab_probe.py)
