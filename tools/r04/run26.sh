@@ -1,6 +1,4 @@
 #!/bin/bash
-mkdir -p gpurun_out/r04
-O=gpurun_out/r04/ab_probe.txt; : > $O
-python tools/env_ab_probe.py 1000 - VH_TEST_BLOCKS_PER_CU=2 VH_TEST_BLOCKS_PER_CU=4 VH_TEST_BLOCKS_PER_CU=5 VH_TEST_BLOCKS_PER_CU=6 VH_TEST_BLOCKS_PER_CU=8 2>/dev/null | grep '^{' >> $O
-python tools/env_ab_probe.py 125 - VH_TEST_BLOCKS_PER_CU=2 VH_TEST_BLOCKS_PER_CU=4 VH_TEST_BLOCKS_PER_CU=6 2>/dev/null | grep '^{' >> $O
-cat $O
+python tools/host_time_probe.py C3 2>/dev/null | tail -1
+python tools/host_time_probe.py C2 2>/dev/null | tail -1
+timeout 1500 python -m pytest tests/test_gpu_threads.py tests/test_gpu_parity.py tests/test_gpu_distributed.py tests/test_gpu_cluster_merge.py tests/test_gpu_shim_session.py tests/test_gpu_host_fuzz.py -x -q 2>&1 | tail -2

@@ -333,7 +333,7 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
   const VhPlanDev& P = r->plan;
   const int nk = P.ngroup, nm = (int)r->user_metric.size();
   const bool has_hidden = r->info.has_hidden_count != 0;
-  hipStream_t st = r->exec->stream();
+  r->stream_quiet = false; hipStream_t st = r->exec->stream();
   std::vector<int> bitset_js;
   for (int j = 0; j < nm; ++j) if (P.m[r->user_metric[j]].sop() == SOP_BITSET) bitset_js.push_back(j);
   const int nbs = (int)bitset_js.size();
@@ -508,7 +508,7 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
   std::vector<uint64_t> soff(W + 1, 0), goff(W + 1, 0);
   for (int p = 0; p <= W; ++p) soff[p] = p > root ? rm->ngroups_host : 0;          // everything goes to root
   if (R == root) for (int p = 0; p < W; ++p) goff[p + 1] = goff[p] + cnts[(size_t)p * 3];
-  hipStream_t st2 = rm->exec->stream();
+  rm->stream_quiet = false; hipStream_t st2 = rm->exec->stream();
   if (int rc = comm->ops.alltoallv_device(comm->ops.ctx, (int32_t)send.size(), send.data(), recv.data(), es.data(), soff.data(), goff.data(), st2))
     return rc < 0 ? rc : vh_fail(VH_E_DEVICE, "gather of the merged groups failed (%d)", rc);
   if (R == root && total_rows) HIP_TRY(hipMemcpyAsync(rf->h_own, rf->d_own, bytes, hipMemcpyDeviceToHost, st2));

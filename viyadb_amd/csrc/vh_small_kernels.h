@@ -850,8 +850,11 @@ __global__ __launch_bounds__(256) void narrow_kernel(const uint32_t* src, uint64
 // keys — in ONE launch: the runtime's fill kernels cost ~8 us apiece back to back, five to seven of them per query were
 // 45 us of a 2.6 ms C3 step (profiles/r03/NOTES.md). Regions are 16-byte multiples (scratch regions are padded to 256 B).
 #define VH_INIT_MAX 12
-struct VhInitArgs { int32_t n, pad; char* p[VH_INIT_MAX]; uint64_t end[VH_INIT_MAX]; uint32_t pat[VH_INIT_MAX]; };   // end: running total of 16-byte units
+// (+ one small copy out of pinned host memory: the plan's per-segment row counts, filter program and literals — as a hipMemcpyAsync in front
+// of this launch it was one more dispatch, and one more gap, before every scan)
+struct VhInitArgs { int32_t n; uint32_t cp_words; char* p[VH_INIT_MAX]; uint64_t end[VH_INIT_MAX]; uint32_t pat[VH_INIT_MAX]; const uint32_t* cp_src; uint32_t* cp_dst; };   // end: running total of 16-byte units
 __global__ __launch_bounds__(256) void init_regions_kernel(VhInitArgs A) {
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < A.cp_words; i += gridDim.x * 256) A.cp_dst[i] = A.cp_src[i];
   const uint64_t total = A.end[A.n - 1];
   for (uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (uint64_t)gridDim.x * 256) {
     int r = 0;

@@ -380,6 +380,7 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
     if (rc) { r->exec = nullptr; delete r; break; }
     if (!retry) {
       r->info.retries = attempt;
+      r->stream_quiet = true;                                  // (result_finalize waited for everything it enqueued)
       if (r->mode == VH_MODE_HASH) { std::lock_guard<std::mutex> lk(t->mu); t->groups_seen[r->group_sig] = r->info.ngroups; }
       *out = r;
       return VH_OK;

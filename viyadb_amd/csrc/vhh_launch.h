@@ -410,7 +410,7 @@ int QueryBuild::launch() {
     IA.p[IA.n] = static_cast<char*>(ptr); IA.end[IA.n] = (IA.n ? IA.end[IA.n - 1] : 0) + units; IA.pat[IA.n] = byte_pattern * 0x01010101u; ++IA.n;
   };
   clear(P.counters, 512, 0);   // counters + out_count (adjacent 256 B slots)
-  HIP_TRY(hipMemcpyAsync(S + o_segrows, x->h_segrows, r->plan_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  IA.cp_src = x->h_segrows; IA.cp_dst = reinterpret_cast<uint32_t*>(S + o_segrows); IA.cp_words = (uint32_t)r->plan_words;      // (copied by init_regions_kernel below: the counters' clear is always there)
   if (mode == VH_MODE_HASH && !hpart) {      // (hashed partitioning writes its group records as a compact list: nothing to pre-fill)
     if (P.hrec_bytes) {          // records: empty key + the metrics' identities, one template for every slot
       VhRecordTemplate T{};

@@ -73,6 +73,7 @@ struct vh_result {
   vh_result_info info{};
   int mode = 0;
   bool finalized = false;
+  bool stream_quiet = false;   // vh_query_agg waited for the last event it recorded on the context's stream and nothing was enqueued since: the destructor need not wait again (~10 us per query)
   size_t plan_words = 0, seg_words = 0;        // layout of the pinned staging block [segment snapshot | program | literals] in u32 words
   int h_slot = -1;                             // staging buffer of `exec` this query finalises into
   std::string kernel;                          // symbol(s) of the scan kernel(s) launched for this query
@@ -119,7 +120,7 @@ struct vh_result {
   ~vh_result() {
     if (d_xchg) (void)hipFree(d_xchg);
     for (char* p : d_pairs) (void)hipFree(p);
-    if (exec) { (void)hipStreamSynchronize(exec->stream()); exec_release(table, exec); }   // nothing of this query may still run on a context the next one takes
+    if (exec) { if (!stream_quiet) (void)hipStreamSynchronize(exec->stream()); exec_release(table, exec); }   // nothing of this query may still run on a context the next one takes
     if (d_own) (void)hipFree(d_own);
     if (h_own) (void)hipHostFree(h_own);
     if (owned_table) vh_table_destroy(owned_table);

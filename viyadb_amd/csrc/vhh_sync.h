@@ -4,7 +4,8 @@ static int ensure_segrows(VhExec* x, size_t n) {
   if (n <= x->h_segrows_cap) return VH_OK;
   if (x->h_segrows) (void)hipHostFree(x->h_segrows);
   size_t cap = std::max<size_t>(n * 2, 1024);
-  HIP_TRY(hipHostMalloc((void**)&x->h_segrows, cap * sizeof(uint32_t), hipHostMallocDefault));
+  // coherent (fine-grained): init_regions_kernel reads the plan words straight out of this buffer, rewritten by the host before every query
+  HIP_TRY(hipHostMalloc((void**)&x->h_segrows, cap * sizeof(uint32_t), hipHostMallocCoherent));
   x->h_segrows_cap = cap;
   return VH_OK;
 }
