@@ -873,7 +873,8 @@ __device__ __forceinline__ uint32_t vh_part_new_extent(const VhPlanDev& P, VhPar
   if (W.chunk_next == W.chunk_end) {
     if (LEVEL == 1 && P.ext_waves) {
       const unsigned long long c = ((unsigned long long)W.base * P.ext_waves + W.limit) * VH_EXT_CHUNK;
-      W.chunk_next = c < 0xFFFFFF00ull ? (uint32_t)c : 0xFFFFFF00u;      // (beyond any pool: refused below)
+      W.chunk_next = c < 0xFFFFFF00ull && W.limit < P.ext_waves ? (uint32_t)c : 0xFFFFFF00u;      // (beyond any pool, or a launch that is not the one the host
+                                                                                                      //  laid the chunks out for: refused below, the re-run takes the cursor)
       ++W.base;
     } else if (LEVEL == 1) {
       unsigned long long c = 0;
