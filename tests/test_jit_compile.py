@@ -22,7 +22,8 @@ SHAPES = {0: "C3: narrow predicate copies, record gathers, tuples for DENSE_PART
           7: "C3 with the payload in a compressed 8-byte record (i64 in 4 bytes, u32s in 2 and 1)",
           8: "C5 with packed 16-byte tuples (payload, two ids and their count in one word)",
           9: "C3 with one-word tuples for DENSE_PART (gid, SUM value and COUNT value in 29 bits)",
-          10: "C3 with the payload in a 4-byte bit-field record"}
+          10: "C3 with the payload in a 4-byte bit-field record",
+          11: "C2 in the no-compaction form (a lane keeps its own rows, payload columns with vector loads)"}
 
 
 def _compile(which, tmp_path):
@@ -73,8 +74,8 @@ def test_compiles_with_the_hiprtc_a_torch_process_carries():
     code = ("import torch, ctypes as C\n"
             "from viyadb_amd import capi\n"
             "lib = capi.load(); buf = C.create_string_buffer(1 << 20)\n"
-            "rcs = [lib.vh_jit_selftest(w, None, buf, len(buf)) for w in range(11)]\n"
-            "assert rcs == [0] * 11, (rcs, buf.value.decode()[:2000])\n")
+            "rcs = [lib.vh_jit_selftest(w, None, buf, len(buf)) for w in range(12)]\n"
+            "assert rcs == [0] * 12, (rcs, buf.value.decode()[:2000])\n")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]

@@ -69,12 +69,13 @@ struct VjWave {
   VhLdsHashWave H;
 };
 
+template <class J>
+__device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, uint64_t (&gv)[J::NG ? J::NG : 1], uint64_t (&mv)[J::NM ? J::NM : 1],
+                                        char* lds, uint64_t xoff, unsigned long long& nfresh, VjWave& V);
 // One surviving row per active lane: AggTuple key, then Metrics::Update (store.cc:131-161) into the plan's table organisation.
 template <class J>
 __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, char* lds, uint64_t xoff,
                                          unsigned long long& nfresh, VjWave& V) {
-  VhPartWave& W = V.W; VhPartTile& T = V.T; VhLdsHashWave& H = V.H; VhPartStage& S = V.S;
-  constexpr int MODE = J::MODE;
   constexpr int NG = J::NG, NM = J::NM;
   if (!active) row = 0;
   uint64_t gv[NG ? NG : 1], mv[NM ? NM : 1];
@@ -95,6 +96,15 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
     if (acc == 0x123456789ABCDEFull) P.counters[7] = acc;
     return;
   }
+  vj_sink<J>(P, seg, row, active, gv, mv, lds, xoff, nfresh, V);
+}
+// ... from the row's group and metric values on (the no-compaction form brings them in by itself: vj_lanes_rows)
+template <class J>
+__device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, uint64_t (&gv)[J::NG ? J::NG : 1], uint64_t (&mv)[J::NM ? J::NM : 1],
+                                        char* lds, uint64_t xoff, unsigned long long& nfresh, VjWave& V) {
+  VhPartWave& W = V.W; VhPartTile& T = V.T; VhLdsHashWave& H = V.H; VhPartStage& S = V.S;
+  constexpr int MODE = J::MODE;
+  constexpr int NG = J::NG, NM = J::NM;
   // hashed partitioning with a bitset metric: where the row's ids lie is asked for NOW, next to the record's loads, and the first two ids
   // as soon as that is known — they travel while the key is rolled up and mixed
   uint64_t bk = 0, bk1 = 0;
@@ -332,6 +342,29 @@ __device__ __forceinline__ void vj_slots(const typename J::Lits& L, const uint32
   }
 }
 
+// The no-compaction form (J::LANES; DENSE_LDS with most rows passing — C2): the lane's pass bits of one step ...
+template <class J, bool FULL, int I = 0>
+__device__ __forceinline__ void vj_lanes_mask(const typename J::Lits& L, const uint32_t (&v)[J::NV ? J::NV : 1], uint32_t row_l, uint32_t seg_rows, uint32_t& mask) {
+  if constexpr (I < VH_LANE_ROWS) {
+    bool p;
+    (void)J::template pass<I>(L, v, p);
+    if (!FULL) p = p & (row_l + (I >> 2) * 256u + (I & 3) < seg_rows);
+    mask |= (uint32_t)p << I;
+    vj_lanes_mask<J, FULL, I + 1>(L, v, row_l, seg_rows, mask);
+  }
+}
+// ... and its passing rows into the table, values out of the step's payload registers
+template <class J, int I = 0>
+__device__ __forceinline__ void vj_lanes_rows(const VhPlanDev& P, uint32_t seg, uint32_t row_l, uint32_t mask, const typename J::Payload& Y, char* lds, uint64_t xoff,
+                                              unsigned long long& nfresh, VjWave& V) {
+  if constexpr (I < VH_LANE_ROWS) {
+    uint64_t gv[J::NG ? J::NG : 1], mv[J::NM ? J::NM : 1];
+    J::template lanes_values<I>(Y, gv, mv);
+    vj_sink<J>(P, seg, row_l + (I >> 2) * 256u + (I & 3), ((mask >> I) & 1u) != 0, gv, mv, lds, xoff, nfresh, V);
+    vj_lanes_rows<J, I + 1>(P, seg, row_l, mask, Y, lds, xoff, nfresh, V);
+  }
+}
+
 // The kernel body. Grid-stride over work units exactly like vh_scan_fast_body (same VhPlanDev, same unit decomposition, same
 // counters), so the host plans and finalises a query the same way whichever kernel ran it.
 template <class J>
@@ -381,7 +414,43 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
     else J::template preload<false>(P, seg, wave_base + lane * 4, seg_rows, v);
   }
   uint32_t cnt = 0;
-  while (have) {
+  if constexpr (J::LANES) {
+    uint32_t lane_passed = 0;
+    while (have) {
+      const uint32_t row_l = wave_base + lane * 4;
+      const bool full = wave_base + VH_WAVE_STEP_ROWS <= seg_rows;
+      typename J::Payload Y;                      // the step's group and metric values: every load of them in flight before the filter is looked at
+      if (full) J::template lanes_load<true>(P, seg, row_l, seg_rows, Y);
+      else J::template lanes_load<false>(P, seg, row_l, seg_rows, Y);
+      uint32_t mask = 0;
+      if (full) vj_lanes_mask<J, true>(L, v, row_l, seg_rows, mask);
+      else if (wave_base < seg_rows) vj_lanes_mask<J, false>(L, v, row_l, seg_rows, mask);
+      lane_passed += __popc(mask);
+      uint32_t nseg = seg, nwave_base = wave_base + kStepRows, nseg_rows = seg_rows;
+      bool nhave = true;
+      if (++ustep == spu) {
+        ustep = 0;
+        unit += gridDim.x;
+        nhave = unit < P.total_units;
+        useg += gmod; nseg = seg + gdiv;
+        if (useg >= P.units_per_seg) { useg -= P.units_per_seg; ++nseg; }
+        if (nhave) {
+          nseg_rows = P.seg_rows[nseg];
+          nwave_base = useg * P.unit_rows + wave * VH_WAVE_STEP_ROWS;
+        }
+      }
+      if (nhave) {        // the next step's predicate columns travel while this step's rows go into the table
+        if (nwave_base + VH_WAVE_STEP_ROWS <= nseg_rows) J::template preload<true>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
+        else J::template preload<false>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
+      }
+      vj_lanes_rows<J>(P, seg, row_l, mask, Y, lds, xoff, nfresh, V);
+      have = nhave; seg = nseg; wave_base = nwave_base; seg_rows = nseg_rows;
+    }
+    unsigned long long np = lane_passed;
+    for (int off = 32; off > 0; off >>= 1) np += __shfl_down(np, off);
+    npassed = np;                                 // (lane 0's is the wave's: it is the one that adds it to the counter below)
+  }
+  while (!J::LANES && have) {
     const uint32_t row_l = wave_base + lane * 4;
     const uint32_t cnt0 = cnt;
     if (wave_base + VH_WAVE_STEP_ROWS <= seg_rows) vj_slots<J, true>(L, v, row_l, seg_rows, q, cnt);

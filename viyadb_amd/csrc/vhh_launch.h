@@ -3,13 +3,18 @@
 int QueryBuild::compile_kernel() {
   int rc = VH_OK; (void)rc;
   // ---------------- the scan kernel compiled for this plan shape (vh_jit.hip), when there is to be one
-  if (jit_try && lanes) jit_try = false;          // the no-compaction kernels are pre-built only
+  // the no-compaction kernels are pre-built, except DENSE_LDS's over plain 4- / 8-byte arena columns (C2's shape), which has a compiled form
+  if (jit_try && lanes && (mode != VH_MODE_DENSE_LDS || getenv("VH_TEST_NO_JIT_LANES"))) jit_try = false;
   if (jit_try) {
     VhJitShape& js = jshape;
     js.mode = mode;
     const size_t qw = (size_t)VJ_QUEUE_CAP * sizeof(uint32_t);       // per wave
+    js.lanes = lanes ? 1 : 0;
     if (mode == VH_MODE_DENSE_LDS || (mode == VH_MODE_HASH && !hpart)) {          // an LDS table per block: the widest block whose table + queues stay within the 64 KB a module kernel may ask for
       jit_block = mode == VH_MODE_DENSE_LDS ? 1024 : 512;
+      // (the no-compaction form lives off resident waves like its pre-built twin: 256-thread blocks, as many per CU as fit, unless the blocks'
+      // table flushes — blocks x groups x metrics atomics at the end — would weigh more than that; same rule as below)
+      if (lanes && (uint64_t)g_ctx.num_cu * 5 * G * std::max(1, P.nmetric) <= rows_to_scan / 32) jit_block = 256;
       while (jit_block > 256 && lds_table + (size_t)(jit_block / 64) * qw > 64 * 1024) jit_block /= 2;
       if (lds_table + (size_t)(jit_block / 64) * qw > 64 * 1024) jit_try = false;
       if (mode == VH_MODE_HASH && !P.lds_hash_slots) jit_block = 256;
@@ -146,7 +151,9 @@ int QueryBuild::decompose_work() {
   // 56-69 VGPRs allow: every wave keeps a line or an extent open per partition, and what eight blocks per CU keep open no longer
   // stays in L2 until it is complete (profiles/r03/NOTES.md, "Blocks per CU": a 125 M-row C3 shard 0.44 -> 0.39 ms with 3 instead of
   // 6, C5's scan 1.95 -> 1.6 ms with 4 instead of 8, and the scatter behind it finds fewer half-empty extents)
-  const int occ_cap = jk && mode == VH_MODE_DENSE_PART ? 3 : jk && hpart ? 4 : 8;
+  // (the compiled no-compaction kernel has a whole step's payload in flight per wave — 16 rows x every column per lane: two 256-thread blocks per
+  // CU already stream at full rate, and every block fewer is a table flush fewer: C2 0.315 -> 0.308 ms, 400 M rows 1.217 -> 1.179)
+  const int occ_cap = jk && mode == VH_MODE_DENSE_PART ? 3 : jk && hpart ? 4 : jk && lanes ? 2 : 8;
   int blocks_per_cu = env_bpc > 0 ? env_bpc : occupancy > 0 ? std::min(occupancy, occ_cap) : (BLOCK == 1024 ? 1 : 4);
   if (const char* e = getenv("VH_TEST_BLOCKS_PER_CU")) { if (atoi(e) > 0) blocks_per_cu = occupancy > 0 ? std::min(occupancy, atoi(e)) : atoi(e); }   // (measurement: switched between two queries of one process)
   uint32_t unit_rows = step;
@@ -487,7 +494,7 @@ int QueryBuild::launch() {
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(x->ev[1], st));
-  if (lanes)       // the lanes kernels read 4-byte predicate columns only (vh_preload<NP, false>)
+  if (lanes && !jk)       // the pre-built lanes kernels read 4-byte predicate columns only (vh_preload<NP, false>)
     for (int k = 0; k < P.npred; ++k) if (P.pred_width[k] != 4) { P.pred_slot[k] = (uint8_t)pred_wide_slot[k]; P.pred_width[k] = 4; }
   bool narrowed = false;
   for (int k = 0; k < P.npred; ++k) narrowed |= P.pred_width[k] != 4;
