@@ -60,6 +60,34 @@ def test_c2_table_organisations_compiled(flags, path):
     assert res.jit, res.kernel
 
 
+def test_c2_no_compaction_form_compiled():
+    """C2 as the planner runs it at full size: 50 % of the rows pass -> the no-compaction form, compiled (J::LANES)."""
+    from viyadb_amd import synth
+    res, _ = check_workload(synth.c2(segment_rows=250_000), nseg=4, flags=J, expect_path="dense_lds")
+    assert res.jit and res.lanes, res.kernel
+    res, _ = check_workload(synth.c2(segment_rows=250_000), nseg=4, flags=J | 256 | 4, expect_path="dense_lds")      # forced, no XCD-private copies
+    assert res.jit and res.lanes, res.kernel
+
+
+@pytest.mark.parametrize("dims,metrics", [
+    (["d_int"], ["long_sum", "int_min"]), (["d_long"], ["float_sum", "double_max"]), (["d_uint"], ["uint_max", "ulong_min"]),
+    (["d_ulong"], ["count", "int_avg"]), (["d_int"], ["double_sum"]),
+    (["d_int"], ["short_sum", "long_sum"]),        # a 2-byte metric column: only the compiled form loads it
+    (["d_int", "flag"], ["long_sum"]),             # a 1-byte group column
+    (["s8", "flag"], ["ubyte_max", "short_min"]),  # two 1-byte group columns (a dictionary code, a boolean), narrow metrics with and without sign
+    (["d_short"], ["byte_sum", "ushort_max"])])
+def test_no_compaction_form_compiled_on_every_width(typed, dims, metrics):
+    """The compiled no-compaction kernel: group and metric columns of 1, 2, 4 and 8 bytes (one aligned load per column and sub-step), segment
+    tails (40 000 rows per segment: the last step of each is partial), with a filter most rows pass, one few pass, and none."""
+    tab, dt = typed
+    for flt in (F("ge", "d_int", "-30"), F("lt", "d_uint", "3"), None):
+        q = {"dimensions": dims, "metrics": metrics}
+        if flt:
+            q["filter"] = flt
+        res, _ = run(tab, dt, q, flags=J | 256)
+        assert res.path == "dense_lds" and res.jit and res.lanes, (dims, metrics, res.path, res.kernel)
+
+
 @pytest.mark.parametrize("name", ["C1", "C2", "C3"])
 @pytest.mark.parametrize("flags", [0, 128, 64])
 def test_ragged_segments_compiled(name, flags):

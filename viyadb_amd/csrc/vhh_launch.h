@@ -80,7 +80,12 @@ int QueryBuild::compile_kernel() {
       }
     }
   }
-  if (!jk && (packed_compressed || (mode == VH_MODE_DENSE_PART && P.gid_bits))) {      // compressed records / one-word tuples and no compiled kernel to handle them after all: plan again for the pre-built ones
+  bool lanes_narrow = false;          // the no-compaction form over 1- / 2-byte group or metric columns: only its compiled kernel loads those
+  if (lanes && mode == VH_MODE_DENSE_LDS) {
+    for (int i = 0; i < P.ngroup; ++i) lanes_narrow |= vh_elem_size(P.g[i].type()) < 4;
+    for (int j = 0; j < P.nmetric; ++j) lanes_narrow |= vh_elem_size(P.m[j].type()) < 4;
+  }
+  if (!jk && (packed_compressed || (mode == VH_MODE_DENSE_PART && P.gid_bits) || lanes_narrow)) {      // compressed records / one-word tuples / narrow lanes columns and no compiled kernel to handle them after all: plan again for the pre-built ones
     vh_plan p2 = *p;
     p2.flags |= VH_PLAN_NO_JIT;
     holder.reset();

@@ -756,8 +756,11 @@ int QueryBuild::choose_organisation() {
   if (mode == VH_MODE_DENSE_LDS && fast && !(p->flags & VH_PLAN_NO_LANES) && P.ngroup <= VH_LANES_COLS && P.nmetric <= VH_LANES_COLS &&
       P.nmetric >= 1 && rows_to_scan) {
     bool ok = true;
-    for (int i = 0; i < P.ngroup; ++i) ok &= vh_elem_size(P.g[i].type()) >= 4 && P.g[i].gran() == VH_T_NONE && P.g[i].nroll() == 0;
-    for (int j = 0; j < P.nmetric; ++j) ok &= P.m[j].slot() != VH_SLOT_ROWID && P.m[j].sop() != SOP_BITSET && vh_elem_size(P.m[j].type()) >= 4;
+    // (the pre-built kernel loads 4- and 8-byte columns only; the compiled form of it any width. No compiled kernel after all: the query is planned
+    // again with VH_PLAN_NO_JIT and comes back here with jit_try off)
+    const int min_elem = jit_try ? 1 : 4;
+    for (int i = 0; i < P.ngroup; ++i) ok &= vh_elem_size(P.g[i].type()) >= min_elem && P.g[i].gran() == VH_T_NONE && P.g[i].nroll() == 0;
+    for (int j = 0; j < P.nmetric; ++j) ok &= P.m[j].slot() != VH_SLOT_ROWID && P.m[j].sop() != SOP_BITSET && vh_elem_size(P.m[j].type()) >= min_elem;
     if (ok) {
       if (p->flags & VH_PLAN_FORCE_LANES) lanes = true;
       else {
