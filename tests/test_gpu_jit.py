@@ -75,7 +75,9 @@ def test_c2_no_compaction_form_compiled():
     (["d_int"], ["short_sum", "long_sum"]),        # a 2-byte metric column: only the compiled form loads it
     (["d_int", "flag"], ["long_sum"]),             # a 1-byte group column
     (["s8", "flag"], ["ubyte_max", "short_min"]),  # two 1-byte group columns (a dictionary code, a boolean), narrow metrics with and without sign
-    (["d_short"], ["byte_sum", "ushort_max"])])
+    (["d_short"], ["byte_sum", "ushort_max"]),
+    (["d_int", "flag"], ["long_sum", "int_min", "count", "float_max"]),     # more columns than the pre-built kernel takes (2 + 2): 28 bytes of payload per row
+    (["s8"], ["count", "int_sum", "uint_max", "short_min", "double_sum"])])
 def test_no_compaction_form_compiled_on_every_width(typed, dims, metrics):
     """The compiled no-compaction kernel: group and metric columns of 1, 2, 4 and 8 bytes (one aligned load per column and sub-step), segment
     tails (40 000 rows per segment: the last step of each is partial), with a filter most rows pass, one few pass, and none."""

@@ -80,8 +80,9 @@ int QueryBuild::compile_kernel() {
       }
     }
   }
-  bool lanes_narrow = false;          // the no-compaction form over 1- / 2-byte group or metric columns: only its compiled kernel loads those
+  bool lanes_narrow = false;          // the no-compaction form over 1- / 2-byte group or metric columns, or more than VH_LANES_COLS of either: only its compiled kernel takes those
   if (lanes && mode == VH_MODE_DENSE_LDS) {
+    lanes_narrow = P.ngroup > VH_LANES_COLS || P.nmetric > VH_LANES_COLS;
     for (int i = 0; i < P.ngroup; ++i) lanes_narrow |= vh_elem_size(P.g[i].type()) < 4;
     for (int j = 0; j < P.nmetric; ++j) lanes_narrow |= vh_elem_size(P.m[j].type()) < 4;
   }

@@ -753,7 +753,13 @@ int QueryBuild::choose_organisation() {
   // (a bitset metric: only the hashed partitioning below has a compiled form for it)
   fastj = fast || (jit_try && P.nbitset == 0);       // a register-resident scan: pre-built, or compiled for this plan shape
   // "Lanes" kernel (no compaction) for small LDS tables when most rows pass: see scan_agg_lanes_kernel
-  if (mode == VH_MODE_DENSE_LDS && fast && !(p->flags & VH_PLAN_NO_LANES) && P.ngroup <= VH_LANES_COLS && P.nmetric <= VH_LANES_COLS &&
+  // (the pre-built kernel: at most VH_LANES_COLS group and VH_LANES_COLS metric columns; the compiled one keeps a step's payload in registers — up
+  // to 40 bytes per row, 160 VGPRs, with the two blocks per CU it runs at)
+  uint32_t lanes_bytes = 0;
+  for (int i = 0; i < P.ngroup; ++i) lanes_bytes += std::max<uint32_t>(4, vh_elem_size(P.g[i].type()));
+  for (int j = 0; j < P.nmetric; ++j) lanes_bytes += std::max<uint32_t>(4, vh_elem_size(P.m[j].type()));
+  const bool lanes_cols_ok = jit_try ? lanes_bytes <= 40 : P.ngroup <= VH_LANES_COLS && P.nmetric <= VH_LANES_COLS;
+  if (mode == VH_MODE_DENSE_LDS && (fast || (jit_try && fastj)) && !(p->flags & VH_PLAN_NO_LANES) && lanes_cols_ok &&
       P.nmetric >= 1 && rows_to_scan) {
     bool ok = true;
     // (the pre-built kernel loads 4- and 8-byte columns only; the compiled form of it any width. No compiled kernel after all: the query is planned
