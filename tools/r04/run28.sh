@@ -2,7 +2,7 @@
 # One query's timeline (rocprofv3 kernel trace): C2 and C3 through bench.py, the last step's dispatches with start / end / duration.
 mkdir -p gpurun_out/r04
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-for W in C2 C3; do
+for W in ${WL:-C2 C3}; do
   rm -rf gpurun_out/r04/tl
   rocprofv3 --kernel-trace --stats -d gpurun_out/r04/tl -o tl -- python bench.py --workload $W --no-cpu --no-check --no-reference-layout --no-cpu-parallel --steps 10 --warmup 2 > gpurun_out/r04/tl_$W.json 2> gpurun_out/r04/tl_$W.err
   python - $W <<'PY'

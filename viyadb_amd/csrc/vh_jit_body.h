@@ -488,12 +488,10 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
     if (MODE == VH_MODE_HASH && V.H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
   }
 
-  if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE != 0) vh_part_stage_finish<J::TW>(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); vh_part_wave_done(P, V.W, lane); }
-  if constexpr (MODE == VH_MODE_HASH && J::HPART) { vh_part_tile_finish<1>(P, V.T, lane); vh_part_wave_done(P, V.W, lane); }
-  if (lane == 0) {
-    if (npassed) atomicAdd(P.counters + 0, npassed);
-    if (nfresh) atomicAdd(P.counters + 1, nfresh);
-  }
+  if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE != 0) vh_part_stage_finish<J::TW>(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); }
+  if constexpr (MODE == VH_MODE_HASH && J::HPART) vh_part_tile_finish<1>(P, V.T, lane);
+  // the waves' counters, and how far the extents handed out by position reach, as one set of atomics per block (vh_scan_block_end)
+  vh_scan_block_end(P, npassed, nfresh, 0ull, (MODE == VH_MODE_DENSE_PART || (MODE == VH_MODE_HASH && J::HPART)) ? vh_part_wave_end(P, V.W) : 0u);
   if constexpr (MODE == VH_MODE_HASH && J::LDS_HASH) vh_lds_hash_flush(P, lds, BLOCK);
   if constexpr (MODE == VH_MODE_DENSE_LDS) {
     __syncthreads();

@@ -694,6 +694,7 @@ struct VhScanCfg {
 // sums, and whenever 64 survivors are queued let all 64 lanes gather the group/metric
 // values of one survivor each and update the aggregate table. No block-wide barrier in
 // the loop: queues are per wave.
+__device__ __forceinline__ void vh_scan_block_end(const VhPlanDev& P, unsigned long long npassed, unsigned long long nfresh, unsigned long long npairs, uint32_t ext_end);     // (below, with the partition helpers)
 template <int MODE, int BLOCK, int SCOPE>
 __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -778,11 +779,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
 
   // wave totals -> one atomic per wave
   for (int off = 32; off > 0; off >>= 1) { npassed += __shfl_down(npassed, off); H.npairs += __shfl_down(H.npairs, off); }
-  if (lane == 0) {
-    if (npassed) atomicAdd(P.counters + 0, npassed);
-    if (nfresh) atomicAdd(P.counters + 1, nfresh);
-    if (H.npairs) atomicAdd(P.counters + 4, H.npairs);
-  }
+  vh_scan_block_end(P, npassed, nfresh, H.npairs, 0u);     // (one set of atomics per block; this kernel writes no tuples)
   if (MODE == VH_MODE_HASH && P.lds_hash_slots) vh_lds_hash_flush(P, lds, BLOCK);
 
   if (MODE == VH_MODE_DENSE_LDS) {
@@ -859,11 +856,28 @@ __device__ __forceinline__ void vh_part_tile_init(const VhPlanDev& P, char* area
   W.chunk_next = W.chunk_end = 0;
   W.base = 0; W.limit = P.ext_waves ? blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6) : 0u; W.cursor = nullptr;
 }
-// Phase 1, chunks by position: what the shared cursor would have said at the end — one atomic per wave, nobody waits for it.
-__device__ __forceinline__ void vh_part_wave_done(const VhPlanDev& P, const VhPartWave& W, int lane) {
-  if (P.ext_waves && W.base != 0 && lane == 0) {
-    const unsigned long long end = (unsigned long long)W.chunk_end;
-    atomicMax(P.counters + 5, end < P.max_extents ? end : (unsigned long long)P.max_extents);
+// Phase 1, chunks by position: what the shared cursor would have said at the end for THIS wave (0: it took no chunk) — vh_scan_block_end
+// publishes the block's largest.
+__device__ __forceinline__ uint32_t vh_part_wave_end(const VhPlanDev& P, const VhPartWave& W) {
+  return P.ext_waves && W.base != 0 ? (W.chunk_end < P.max_extents ? W.chunk_end : P.max_extents) : 0u;
+}
+// The end of a scan block: its waves' row counters (lane 0 of every wave holds its wave's) as ONE set of device atomics per block. Atomics
+// of every wave on the same few words are served one after the other (~6.5 ns each), and the kernel is not over before the last one: 3 072
+// waves x 2 words = 40 us at the end of every C3 scan, 8 192 x 1 = 53 us of C1's 68 (tools/r04/run26.sh, profiles/r04/NOTES.md).
+__device__ __forceinline__ void vh_scan_block_end(const VhPlanDev& P, unsigned long long npassed, unsigned long long nfresh, unsigned long long npairs, uint32_t ext_end) {
+  __shared__ unsigned long long s_cnt[3][16];
+  __shared__ uint32_t s_ext[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  if (lane == 0) { s_cnt[0][wave] = npassed; s_cnt[1][wave] = nfresh; s_cnt[2][wave] = npairs; s_ext[wave] = ext_end; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long a = 0, b = 0, c = 0;
+    uint32_t e = 0;
+    for (int w = 0; w < nw; ++w) { a += s_cnt[0][w]; b += s_cnt[1][w]; c += s_cnt[2][w]; e = s_ext[w] > e ? s_ext[w] : e; }
+    if (a) atomicAdd(P.counters + 0, a);
+    if (b) atomicAdd(P.counters + 1, b);
+    if (c) atomicAdd(P.counters + 4, c);
+    if (e) atomicMax(P.counters + 5, (unsigned long long)e);
   }
 }
 
@@ -1582,13 +1596,10 @@ __device__ __forceinline__ void vh_scan_fast_body(const VhPlanDev& P) {
     if (MODE == VH_MODE_HASH && H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
   }
 
-  if (MODE == VH_MODE_DENSE_PART) { vh_part_tile_finish(P, T, lane); vh_part_wave_done(P, W, lane); }
+  if (MODE == VH_MODE_DENSE_PART) vh_part_tile_finish(P, T, lane);
   unsigned long long npassed = npassed32;
   for (int off = 32; off > 0; off >>= 1) npassed += __shfl_down(npassed, off);
-  if (lane == 0) {
-    if (npassed) atomicAdd(P.counters + 0, npassed);
-    if (nfresh) atomicAdd(P.counters + 1, nfresh);
-  }
+  vh_scan_block_end(P, npassed, nfresh, 0ull, MODE == VH_MODE_DENSE_PART ? vh_part_wave_end(P, W) : 0u);
   if (MODE == VH_MODE_HASH && P.lds_hash_slots) vh_lds_hash_flush(P, lds, BLOCK);
   if (MODE == VH_MODE_DENSE_LDS) {
     __syncthreads();
@@ -1834,11 +1845,8 @@ __global__ __launch_bounds__(BLOCK, VH_LANES_WAVES(MODE, BLOCK, NP)) void scan_a
   if (__ballot(range_err)) { if (range_err) atomicOr(P.counters + 2, VH_ERR_RANGE); }
   if (__ballot(full_err)) { if (full_err) atomicOr(P.counters + 2, VH_ERR_HASH_FULL); }
   for (int off = 32; off > 0; off >>= 1) { npassed += __shfl_down(npassed, off); nfresh += __shfl_down(nfresh, off); }
-  if (lane == 0) {
-    if (npassed) atomicAdd(P.counters + 0, npassed);
-    if (nfresh) atomicAdd(P.counters + 1, nfresh);
-  }
-  if (MODE == VH_MODE_DENSE_PART) { vh_part_tile_finish(P, T, lane); vh_part_wave_done(P, W, lane); return; }
+  vh_scan_block_end(P, npassed, nfresh, 0ull, MODE == VH_MODE_DENSE_PART ? vh_part_wave_end(P, W) : 0u);
+  if (MODE == VH_MODE_DENSE_PART) { vh_part_tile_finish(P, T, lane); return; }
   if (MODE == VH_MODE_HASH) { vh_lds_hash_flush(P, lds, BLOCK); return; }
   __syncthreads();
   const uint64_t xo = P.nxcd > 1 ? (uint64_t)(vh_xcc_id() % P.nxcd) * P.xcd_stride : 0;
