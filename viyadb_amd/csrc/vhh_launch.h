@@ -15,8 +15,9 @@ int QueryBuild::compile_kernel() {
       // (the no-compaction form lives off resident waves like its pre-built twin: 256-thread blocks, as many per CU as fit, unless the blocks'
       // table flushes — blocks x groups x metrics atomics at the end — would weigh more than that; same rule as below)
       if (lanes && (uint64_t)g_ctx.num_cu * 5 * G * std::max(1, P.nmetric) <= rows_to_scan / 32) jit_block = 256;
-      while (jit_block > 256 && lds_table + (size_t)(jit_block / 64) * qw > 64 * 1024) jit_block /= 2;
-      if (lds_table + (size_t)(jit_block / 64) * qw > 64 * 1024) jit_try = false;
+      const size_t lds_room = 64 * 1024 - 1024;          // (the kernels' own static LDS — vh_scan_block_end's counters — shares the 64 KB)
+      while (jit_block > 256 && lds_table + (size_t)(jit_block / 64) * qw > lds_room) jit_block /= 2;
+      if (lds_table + (size_t)(jit_block / 64) * qw > lds_room) jit_try = false;
       if (mode == VH_MODE_HASH && !P.lds_hash_slots) jit_block = 256;
     }
     js.block = jit_block;
