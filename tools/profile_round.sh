@@ -44,6 +44,8 @@ one c3_direct 1000000000 32e9 --flags 16            # the same query forced onto
 one c2 100000000 2e9 --workload C2
 one c5 125000000 3.5e9 --workload C5 --segments 125 --steps 5 --warmup 1
 one c5t 125000000 1.5e9 --workload C5t --segments 125 --steps 5 --warmup 1
+python bench.py --workload C1 --no-cpu-parallel --no-reference-layout > $OUT/bench_c1_1gpu.json 2> $OUT/bench_c1.err     # the plumbing case: a bench line only (launch-bound)
+python tools/scale_proxy.py 1 2 4 8 2>/dev/null | grep '^{' > $OUT/scale_proxy.txt                                         # one rank's step of the N-GPU run, on one GPU
 bash tools/fetch_calib.sh $OUT/fetch_calibration.json > $OUT/fetch_calibration.log 2>&1
 # how stable the headline is from process to process: ten fresh processes as a caller that prepares its query shape (vh_table_prepare) and
 # ten as one that does not (an ordinary first query: plain hipMalloc for the tuple pool)
