@@ -7,6 +7,12 @@ extern "C" int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs, in
   const VhPlanDev& P = r->plan;
   int n = 0;
   if (max_bufs < P.nmetric + 1) return vh_fail(VH_E_INVALID, "need %d buffers", P.nmetric + 1);
+  if (r->unmerged) {        // the caller reduces copy 0 across GPUs: the private copies go into it first (a small result leaves them to its one tail launch)
+    if (!r->exec) return vh_fail(VH_E_INVALID, "a launched result without its context");
+    VH_ENTER();
+    r->stream_quiet = false;
+    if (int mrc = merge_copies_now(r, r->exec->stream())) return mrc;
+  }
   // presence bytes are only written when no SUM state carries the flag (SOP_ADD32P): one collective less
   if (!((r->mode == VH_MODE_DENSE_GLOBAL || r->mode == VH_MODE_DENSE_PART) && P.present_carrier >= 0)) bufs[n++] = vh_device_buffer{P.present, P.G, VH_U8, VH_RED_MAX};
   for (int j = 0; j < P.nmetric; ++j) {

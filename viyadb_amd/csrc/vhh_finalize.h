@@ -66,7 +66,18 @@ static int result_finalize(vh_result* r, int* retry) {
   A.total_groups = P.counters + 6;
   for (int i = 0; i < r->nhaving; ++i) { A.hprog[i] = r->hprog[i]; A.htype[i] = r->htype[i]; }
   for (int i = 0; i < VH_MAX_HAVING_LITS; ++i) A.hlits[i] = r->hlits[i];
-  if (r->hp_direct && r->nhaving == 0 && !r->topk_active) { /* hp_aggregate_kernel wrote the output columns and counted the rows */ }
+  // a small dense result: private copies, emission and header in ONE launch (small_tail_kernel); anything else merges first if nobody has
+  const bool fused_tail = r->small_tail && direct && A.n <= VH_SMALL_TAIL_MAX;
+  if (r->unmerged && !fused_tail) { if (int mrc = merge_copies_now(r, st)) return mrc; }
+  if (fused_tail) {
+    VhMergeArgs M;
+    merge_args_of(r, &M);
+    if (!r->unmerged) M.nxcd = 1;
+    hipLaunchKernelGGL(small_tail_kernel, dim3(1), dim3(1024), 0, st, M, A, reinterpret_cast<unsigned long long*>(x->h_out[slot]),
+                       reinterpret_cast<const unsigned long long*>(x->scratch + r->out_region_off));
+    r->unmerged = false;
+  }
+  else if (r->hp_direct && r->nhaving == 0 && !r->topk_active) { /* hp_aggregate_kernel wrote the output columns and counted the rows */ }
   else if (A.n <= (4u << 20)) hipLaunchKernelGGL(emit_groups_kernel<2>, dim3((unsigned)((A.n + 256 * 2 - 1) / (256 * 2))), dim3(256), 0, st, A);
   else hipLaunchKernelGGL(emit_groups_kernel<16>, dim3((unsigned)((A.n + 256 * 16 - 1) / (256 * 16))), dim3(256), 0, st, A);
   HIP_TRY(hipGetLastError());
@@ -171,7 +182,7 @@ static int result_finalize(vh_result* r, int* retry) {
   // small results: counters, group count and every output array come back in ONE copy + ONE sync; big ones: the header first
   unsigned long long* const head = one_shot ? reinterpret_cast<unsigned long long*>(x->h_out[slot]) : x->h_counters + 16;
   if (direct) {
-    hipLaunchKernelGGL(publish_header_kernel, dim3(1), dim3(64), 0, st, head, reinterpret_cast<const unsigned long long*>(D));
+    if (!fused_tail) hipLaunchKernelGGL(publish_header_kernel, dim3(1), dim3(64), 0, st, head, reinterpret_cast<const unsigned long long*>(D));
     HIP_TRY(hipGetLastError());
   } else {
     HIP_TRY(hipMemcpyAsync(head, D, one_shot ? r->out_region_bytes : 512, hipMemcpyDeviceToHost, st));

@@ -1,5 +1,23 @@
 // vhh_launch.h — host side of libviya_hip, part of viya_hip.hip's translation unit (included there, in order; not a stand-alone header):
 // QueryBuild continued: kernel compile, scan dispatch, work decomposition, scratch layout, launch; query_launch_locked.
+// Adds a dense result's private copies (one per XCD, or one per block of a partition's range) into copy 0.
+static void merge_args_of(const vh_result* r, VhMergeArgs* A) {
+  const VhPlanDev& P = r->plan;
+  *A = VhMergeArgs{};
+  A->nmetric = P.nmetric; A->nxcd = r->nxcd; A->G = P.G; A->xcd_stride = P.xcd_stride; A->present = P.present;
+  A->present_carrier = P.present_carrier;
+  for (int j = 0; j < P.nmetric; ++j) { A->state[j] = P.m[j].state; A->sop[j] = P.m[j].sop(); }
+}
+static int merge_copies_now(vh_result* r, hipStream_t st) {
+  if (!r->unmerged) return VH_OK;
+  VhMergeArgs A;
+  merge_args_of(r, &A);
+  hipLaunchKernelGGL(dense_merge_kernel, dim3((unsigned)((r->plan.G + 255) / 256)), dim3(256), 0, st, A);
+  HIP_TRY(hipGetLastError());
+  r->unmerged = false;
+  return VH_OK;
+}
+
 int QueryBuild::compile_kernel() {
   int rc = VH_OK; (void)rc;
   // ---------------- the scan kernel compiled for this plan shape (vh_jit.hip), when there is to be one
@@ -537,13 +555,12 @@ int QueryBuild::launch() {
   }
   HIP_TRY(hipEventRecord(x->ev[2], st));
   HIP_TRY(hipGetLastError());
+  // a small dense result that will go straight into pinned host memory (result_finalize's `direct`): its whole tail is one launch there
+  r->small_tail = mode != VH_MODE_HASH && r->out_cap <= VH_SMALL_TAIL_MAX && r->out_region_bytes <= (8u << 20) && !r->topk_active && !r->hp_chunks &&
+                  !device_rows && !knobs().no_direct_emit && !getenv("VH_TEST_NO_SMALL_TAIL");
   if (mode != VH_MODE_HASH && nxcd > 1) {
-    VhMergeArgs A{};
-    A.nmetric = P.nmetric; A.nxcd = nxcd; A.G = G; A.xcd_stride = P.xcd_stride; A.present = P.present;
-    A.present_carrier = P.present_carrier;
-    for (int j = 0; j < P.nmetric; ++j) { A.state[j] = P.m[j].state; A.sop[j] = P.m[j].sop(); }
-    hipLaunchKernelGGL(dense_merge_kernel, dim3((unsigned)((G + 255) / 256)), dim3(256), 0, st, A);
-    HIP_TRY(hipGetLastError());
+    r->unmerged = true;
+    if (!r->small_tail) { if (int mrc = merge_copies_now(r, st)) return mrc; }
   }
   *out = holder.release();
   done = true;

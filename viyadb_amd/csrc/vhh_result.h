@@ -84,6 +84,8 @@ struct vh_result {
   // device-side partial state
   VhPlanDev plan{};
   int nxcd = 1;
+  bool small_tail = false;             // a small dense result that goes straight into pinned host memory: merge + emission + header are ONE launch (small_tail_kernel)
+  bool unmerged = false;               // ... which also adds the private copies up: until then (or until merge_copies_now, in front of a cross-GPU reduce) nobody has
   std::vector<int> metric_elem;        // output element type per device metric (P.m order)
   std::vector<int> group_elem;
   std::string group_sig;
