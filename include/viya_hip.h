@@ -321,6 +321,39 @@ VH_API int vh_segment_sync(vh_table* t, uint32_t seg, uint64_t nrows,
  * rows [row_first, row_first + nrows) are copied and the segment then has `new_size` valid rows. */
 VH_API int vh_segment_sync_range(vh_table* t, uint32_t seg, uint64_t row_first, uint64_t nrows,
                                  uint64_t new_size, const void* const* col_ptrs);
+/* What ONE upsert batch did to the table, in ONE call. The reference's upsert merges a micro-batch into the store row by
+ * row: a row whose dimensions are new is appended to the LAST segment, a row that exists has its metrics updated IN PLACE in whatever
+ * segment holds it (src/codegen/db/upsert.cc:384-411) — a batch of 100 K rows can dirty hundreds of segments by a few rows each. An item
+ * is one contiguous row range of one segment; col_ptrs[c] is the BASE of the segment's column array as in vh_segment_sync (NULL: leave
+ * that column alone; bitset columns are never passed). With VH_SYNC_METRICS_ONLY only the metric columns of the range are shipped
+ * (dimensions of an existing row never change). After the call the segment has `new_size` rows (ranges must not leave gaps behind the
+ * rows already mirrored; several items may name one segment).
+ *
+ * The whole batch is ONE kernel launch: every contiguous (column, range) run is pulled into its arena by one workgroup — straight out
+ * of the caller's memory over PCIe when that memory was registered (vh_host_register; no host-side copy at all), through a pinned ring
+ * for small runs of unregistered memory, behind a hipMemcpyAsync for big ones — which also takes the run's min / max; the per-segment
+ * stats (SegmentStats, store.cc:171-201, and the value widths the derived layouts are sized from) are WIDENED by what the runs hold
+ * (a range that covers every mirrored row of its segment replaces them). Under upsert a segment's true range only grows for dimensions;
+ * a metric updated in place may leave stats wider than its values — never narrower. The call returns once the sources may be reused
+ * (registered memory: immediately — the device reads it until the batch's event, which the next planner, sync or stats reader waits
+ * for; the caller's writer may keep updating rows meanwhile exactly as the reference's readers race its writer). No per-segment host
+ * synchronisation, no wait for running queries unless an arena has to move. */
+enum { VH_SYNC_METRICS_ONLY = 1u, /* only metric columns (kind >= VH_METRIC_MAX) of the range changed */
+       VH_SYNC_DEVICE_SRC = 2u    /* col_ptrs are DEVICE addresses (exchanged partials) */ };
+typedef struct vh_sync_item {
+  uint32_t seg, flags;
+  uint64_t row_first, nrows, new_size;
+  const void* const* col_ptrs;
+} vh_sync_item;
+VH_API int vh_table_sync_batch(vh_table* t, const vh_sync_item* items, uint32_t nitems);
+/* Make [base, base + bytes) of the caller's memory readable by the device in place (pages pinned and mapped: hipHostRegister). A ViyaDB
+ * Segment is one heap object whose column arrays never move (store.cc:203-356): registered once when it is first seen, every later sync
+ * of it is zero-copy. Idempotent per base; VH_E_DEVICE when the runtime refuses (the caller carries on unregistered). */
+VH_API int vh_host_register(const void* base, uint64_t bytes);
+VH_API int vh_host_unregister(const void* base);
+/* Counters of the batched syncs of a table since it was created: batches, runs (kernel descriptors), bytes pulled out of registered memory,
+ * bytes through the pinned ring, bytes through hipMemcpyAsync. Any pointer may be NULL. */
+VH_API int vh_table_sync_stats(vh_table* t, uint64_t* batches, uint64_t* runs, uint64_t* bytes_pulled, uint64_t* bytes_staged, uint64_t* bytes_dma);
 /* Bitset metric column of one segment as CSR: offsets[nrows+1], values[].   */
 VH_API int vh_segment_sync_bitset(vh_table* t, uint32_t seg, int32_t col,
                                   uint64_t nrows, const uint64_t* offsets,

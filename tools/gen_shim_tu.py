@@ -135,7 +135,8 @@ def emit(table, query):
     # ---- the GPU path instead of ScanVisitor + PostAggVisitor
     w("static const char kTable[] = R\"viya(%s)viya\";\n" % json.dumps(table))
     w("static const char kQuery[] = R\"viya(%s)viya\";\n" % json.dumps(query))
-    w("viya::shim::Session* session = viya::shim::Open(&table, kTable, kQuery);\n")
+    w("viya::shim::Session* session = viya::shim::Open(&table, kTable, kQuery);   // this CALL's state: read_pool threads run this function side by side\n")
+    w("struct SessionGuard { viya::shim::Session* s; ~SessionGuard() { viya::shim::Release(s); } } session_guard{session};\n")
     w("uint32_t seg_index = 0;\n")
     w("for (auto* s : table.store()->segments_copy()) {                      // scan.cc:42\n")
     w(" auto segment_size = s->size();                                       // scan.cc:43: the size() snapshot the query sees\n")
@@ -145,20 +146,21 @@ def emit(table, query):
     if hidden:
         ptrs.append("&segment->m._count[0]")
     w(" const void* cols[] = { %s };\n" % ", ".join(ptrs))
+    w(" viya::shim::Pin(session, seg_index, segment, sizeof(Segment));          // registered with the device once: later ranges are read in place\n")
     w(" viya::shim::Sync(session, seg_index, segment_size, cols);\n")
     if bitsets:
-        w(" if (viya::shim::BitsetStale(session, seg_index, segment_size)) {   // rows appended, or a row's set grown in place (Touch), since the mirror saw them\n")
-        w("  std::vector<uint64_t> offsets(segment_size + 1);\n")
+        w(" if (const uint64_t walk_rows = viya::shim::BitsetStale(session, seg_index, segment_size)) {   // rows appended, or a row's set grown in place (Touch), since the mirror saw them\n")
+        w("  std::vector<uint64_t> offsets(walk_rows + 1);\n")
         for j in bitsets:
             n = 8 if metric_type(mets[j]) == "ulong" else 4
             w("  { std::vector<uint%d_t> ids; offsets[0] = 0;\n" % (n * 8))
-            w("    for (size_t r = 0; r < segment_size; ++r) {\n")
+            w("    for (size_t r = 0; r < walk_rows; ++r) {\n")
             w("      const auto& roaring = segment->m._%d[r].*get(viya_shim_detail::Roaring%d());\n" % (j, n))
             w("      const uint64_t n = roaring.cardinality();\n")
             w("      ids.resize(offsets[r] + n);\n")
             w("      if (n) roaring.toUint%dArray(ids.data() + offsets[r]);\n" % (n * 8))
             w("      offsets[r + 1] = offsets[r] + n;\n    }\n")
-            w("    viya::shim::SyncBitset(session, seg_index, %d, segment_size, offsets.data(), ids.data()); }\n" % j)
+            w("    viya::shim::SyncBitset(session, seg_index, %d, walk_rows, offsets.data(), ids.data()); }\n" % j)
         w(" }\n")
     w(" ++seg_index;\n}\n")
     for i, d in enumerate(dims):

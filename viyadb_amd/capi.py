@@ -98,6 +98,15 @@ class DeviceBuffer(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("count", C.c_uint64), ("elem", C.c_int32), ("reduce", C.c_int32)]
 
 
+class SyncItem(C.Structure):
+    """vh_sync_item: one contiguous row range of one segment (vh_table_sync_batch)."""
+    _fields_ = [("seg", C.c_uint32), ("flags", C.c_uint32), ("row_first", C.c_uint64), ("nrows", C.c_uint64),
+                ("new_size", C.c_uint64), ("col_ptrs", C.POINTER(C.c_void_p))]
+
+
+SYNC_METRICS_ONLY, SYNC_DEVICE_SRC = 1, 2
+
+
 class GenSpec(C.Structure):
     _fields_ = [("mode", C.c_int32), ("reserved", C.c_int32), ("mod", C.c_uint64), ("add", C.c_int64),
                 ("scale", C.c_double)]
@@ -132,6 +141,10 @@ SYMBOLS = {
     "vh_table_destroy": (None, [_VP]),
     "vh_segment_sync": (C.c_int, [_VP, C.c_uint32, C.c_uint64, C.POINTER(_VP)]),
     "vh_segment_sync_range": (C.c_int, [_VP, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(_VP)]),
+    "vh_table_sync_batch": (C.c_int, [_VP, C.POINTER(SyncItem), C.c_uint32]),
+    "vh_host_register": (C.c_int, [_VP, C.c_uint64]),
+    "vh_host_unregister": (C.c_int, [_VP]),
+    "vh_table_sync_stats": (C.c_int, [_VP] + [C.POINTER(C.c_uint64)] * 5),
     "vh_segment_sync_bitset": (C.c_int, [_VP, C.c_uint32, C.c_int32, C.c_uint64, C.POINTER(C.c_uint64), _VP]),
     "vh_segment_generate": (C.c_int, [_VP, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.POINTER(GenSpec), C.c_uint64]),
     "vh_table_pack": (C.c_int, [_VP, C.POINTER(C.c_int32), C.c_int32]),

@@ -67,7 +67,14 @@ struct vh_comm {
   // same set: a query whose plan is in the cache skips the all-gather of step 1 (a 128-byte verdict all-reduce is then the
   // only host-visible collective of a dense query). A rank whose table changed since still plans with the cached agreement
   // and says so in the verdict; all ranks then drop the entry and agree afresh.
-  struct Agreement { VhAgreed ag; uint64_t local_state; };     // local_state: plan_local_state() of THIS rank when the agreement was made
+  struct BufShape { uint64_t count; int32_t elem, reduce; };
+  struct Agreement {
+    VhAgreed ag; uint64_t local_state;                         // local_state: plan_local_state() of THIS rank when the agreement was made
+    // the partial table of a DENSE query planned from this agreement, as vh_result_device_buffers lists it — the same on every rank (same
+    // plan, same agreed digit ranges), recorded when a query of this plan first went through on all ranks. Known: the query runs as ONE
+    // stream-ordered sequence (scan, verdict and state arrays in one collective group, emission) with a single host wait at its end.
+    bool dense_known = false; int dense_mode = 0; std::vector<BufShape> dense;
+  };
   std::map<std::string, Agreement> agreed;
 };
 
@@ -439,7 +446,7 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
         VH_ELEM_SWITCH(col.elem, (fill_kernel<T><<<dim3(grid), dim3(256), 0, st>>>(reinterpret_cast<T*>(dst), n, vh_lit_host<T>(ident))));
       }
       tt->seg_rows[s] = n;
-      tt->seg_mod[s] = ++tt->sync_epoch;
+      table_note_change(tt, (uint32_t)s, 0, n);
     }
     HIP_TRY(hipGetLastError());
     tt->nseg = (uint32_t)sets;
@@ -520,6 +527,92 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
   return VH_OK;   // rm (and with it the merge table's context), then the merge table itself, go out of scope here
 }
 
+static bool knobs_no_fused_sharded() { static const bool off = getenv("VH_NO_FUSED_SHARDED") != nullptr; return off; }   // (measurement: the two-collective form)
+
+// The steady state of a dense sharded query — its plan has an agreement in the cache and the shape of its partial table is known on every
+// rank — as ONE stream-ordered sequence behind the scan: verdict words -> ONE collective group (the verdict's all-reduce and the reduce of
+// every state array: one launch, one ring set-up) -> on root the emission into pinned host memory -> ONE host wait. The verdict is read
+// AFTER everything ran: when any rank overflowed a pool, met a digit outside the agreed range or saw its table change, the reduced arrays
+// are garbage of the agreed size — nobody looks at them, all ranks re-plan together exactly as they would have after the separate
+// verdict. A rank that could not even plan joins the group with scratch arrays of the recorded shape (the collectives always match).
+// *again = 1: this attempt is void, the caller's loop goes round. Replaces two collectives and two host round trips per query by one
+// and one (what the reference's controller does per query: src/cluster/query/agg_runner.cc:83-140).
+static int fused_dense_step(vh_table* t, vh_comm* comm, int root, VhExec* x, vh_result* r, int lrc, bool changed, const vh_comm::Agreement& agr,
+                            const std::string& sig, char* local_err, VhReplan* rp, int* again) {
+  hipStream_t st = x->stream();
+  const int W = comm->world, R = comm->rank;
+  *again = 0;
+  const bool mine_ok = r && !lrc && r->mode == agr.dense_mode && r->plan.nbitset == 0;
+  vh_device_buffer bufs[VH_MAX_METRIC + 1];
+  int32_t nb = 0;
+  bool shape_ok = mine_ok;
+  if (mine_ok) {
+    if (int rc = vh_result_device_buffers(r, bufs, VH_MAX_METRIC + 1, &nb)) { shape_ok = false; if (!local_err[0]) snprintf(local_err, sizeof(g_err), "%s", g_err); (void)rc; }
+    if (shape_ok && (size_t)nb != agr.dense.size()) shape_ok = false;
+    for (int32_t b = 0; shape_ok && b < nb; ++b)
+      shape_ok = bufs[b].count == agr.dense[b].count && bufs[b].elem == agr.dense[b].elem && bufs[b].reduce == agr.dense[b].reduce;
+  }
+  std::vector<void*> scratch;                                     // this rank has no partial of the agreed shape: arrays that only keep the collectives matched
+  struct FreeScratch { std::vector<void*>& v; ~FreeScratch() { for (void* p : v) (void)hipFree(p); } } free_scratch{scratch};
+  int alloc_rc = VH_OK;
+  if (!shape_ok) {
+    nb = (int32_t)agr.dense.size();
+    for (int32_t b = 0; b < nb; ++b) {
+      void* p = nullptr;
+      if (hipMalloc(&p, std::max<uint64_t>(agr.dense[b].count, 1) * vh_elem_size(agr.dense[b].elem)) != hipSuccess) { alloc_rc = vh_fail(VH_E_NOMEM, "sharded query: scratch for a void attempt"); p = comm->d_flags; }
+      else scratch.push_back(p);
+      bufs[b] = vh_device_buffer{p, p == (void*)comm->d_flags ? 0ull : agr.dense[b].count, agr.dense[b].elem, agr.dense[b].reduce};
+    }
+    if (alloc_rc && !local_err[0]) snprintf(local_err, sizeof(g_err), "%s", g_err);
+  }
+  const bool fatal = (lrc && !(changed)) || alloc_rc;             // (a stale agreement that does not even plan is not an error: everyone re-agrees)
+  // a rank whose partial does not have the recorded shape although it planned: its table changed under the agreement — say so
+  const bool void_mine = !shape_ok;
+  hipLaunchKernelGGL(sharded_flags_kernel, dim3(1), dim3(64), 0, st, mine_ok && shape_ok ? r->plan.counters : nullptr, comm->d_flags, 0ull,
+                     (unsigned long long)(fatal ? 1 : 0), r ? r->info.scanned_recs : 0ull, r ? r->info.scanned_segments : 0ull,
+                     (unsigned long long)agr.dense_mode, 0ull, (unsigned long long)((changed || void_mine) ? 1 : 0));
+  HIP_TRY(hipGetLastError());
+  const bool grouped = comm->nccl != nullptr;
+  if (grouped) NCCL_TRY(g_rccl.GroupStart());
+  int red_rc = comm->ops.reduce_device(comm->ops.ctx, comm->d_flags, VH_FLAG_WORDS, VH_U64, VH_RED_SUM, -1, st);
+  for (int32_t b = 0; b < nb && !red_rc; ++b)
+    if (bufs[b].count) red_rc = comm->ops.reduce_device(comm->ops.ctx, bufs[b].ptr, bufs[b].count, bufs[b].elem, bufs[b].reduce, root, st);
+  if (grouped) NCCL_TRY(g_rccl.GroupEnd());
+  if (red_rc) return red_rc < 0 ? red_rc : vh_fail(VH_E_DEVICE, "reduce of a partial state array failed (%d)", red_rc);
+  HIP_TRY(hipMemcpyAsync(comm->h_flags, comm->d_flags, VH_FLAG_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  int fin_rc = VH_OK, rt = 0;
+  const bool emits = mine_ok && shape_ok && (root < 0 || R == root);
+  if (emits) {
+    r->device_rows = false;                                       // small results go straight into pinned host memory again
+    fin_rc = result_finalize(r, &rt);                             // emission + header behind the reduce; its wait is the query's one host wait
+    if (fin_rc && !local_err[0]) snprintf(local_err, sizeof(g_err), "%s", g_err);
+  }
+  if (!emits || fin_rc) HIP_TRY(hipStreamSynchronize(st));        // the reduce has read this rank's partial; the verdict is on the host
+  const unsigned long long* f = comm->h_flags;
+  if (f[10]) { comm->agreed.erase(sig); *again = 1; return VH_OK; }          // some rank's table changed: the agreement is void for all
+  if (f[3]) { comm->agreed.clear(); return fatal ? vh_fail(lrc ? lrc : alloc_rc, "%s", local_err) : vh_fail(VH_E_DEVICE, "the query failed on another rank"); }
+  const int verdict = f[12] ? 6 : f[11] ? 4 : f[1] ? 1 : f[2] ? 3 : f[0] ? 2 : 0;
+  if (verdict) {
+    // (a plan that overflows from the agreed sizes would do so on every query: its later queries take the two-step form, which re-plans
+    // before anything is reduced, until one of them goes through at the first attempt again)
+    auto hit = comm->agreed.find(sig);
+    if (hit != comm->agreed.end()) hit->second.dense_known = false;
+    r->info.passed_recs = f[6];
+    replan_after(t, r, verdict, rp);
+    *again = 1;
+    return VH_OK;
+  }
+  if (fin_rc) { comm->agreed.clear(); return vh_fail(fin_rc, "%s", local_err); }     // (this rank's emission failed on its own: peers already hold their results)
+  r->info.retries = 0;
+  r->info.scanned_recs = f[4]; r->info.scanned_segments = f[5]; r->info.passed_recs = f[6];
+  if (!emits) {
+    r->h_base = reinterpret_cast<char*>(x->h_counters);           // no rows here: any readable address
+    r->ngroups_host = 0; r->info.returned_groups = 0; r->info.ngroups = 0;
+    r->finalized = true;
+  }
+  return VH_OK;
+}
+
 extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* comm, int32_t root, vh_result** out) {
   if (!t || !plan || !comm || !out) return vh_fail(VH_E_INVALID, "null argument");
   if (root >= comm->world || root < -1) return vh_fail(VH_E_INVALID, "root %d of %d ranks", root, comm->world);
@@ -576,6 +669,20 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
       lrc = result_finalize(r, &retry);
       if (lrc && !local_err[0]) snprintf(local_err, sizeof(local_err), "%s", g_err);
     }
+    // ---- 2a. steady state of a dense query: everything that follows as ONE stream-ordered sequence (see fused_dense_step)
+    if (attempt == 0 && cached) {
+      auto hit = comm->agreed.find(sig);
+      if (hit != comm->agreed.end() && hit->second.dense_known) {
+        const vh_comm::Agreement agr = hit->second;                // (a copy: the entry may be dropped inside)
+        int again = 0;
+        const int frc = fused_dense_step(t, comm, root, x, r, lrc, changed, agr, sig, local_err, &rp, &again);
+        if (frc) return frc;
+        if (again) continue;
+        xg.x = nullptr; detach.r = nullptr;                       // the result owns the context from here
+        *out = holder.release();
+        return VH_OK;
+      }
+    }
     // ---- 3. verdict: error flags, row counters and the table organisation of every rank, all-reduced
     const unsigned long long host_err = retry == 1 ? VH_ERR_HASH_FULL : retry == 2 ? VH_ERR_RANGE : retry == 3 ? VH_ERR_PART_FULL : retry == 4 ? VH_ERR_HPART_FULL : retry == 6 ? VH_ERR_HP_WIDE : 0ull;
     hipLaunchKernelGGL(sharded_flags_kernel, dim3(1), dim3(64), 0, st, r && !sparse ? r->plan.counters : nullptr, comm->d_flags, host_err,
@@ -623,6 +730,14 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
       red_rc = comm->ops.reduce_device(comm->ops.ctx, bufs[b].ptr, bufs[b].count, bufs[b].elem, bufs[b].reduce, root, st);
     if (grouped) NCCL_TRY(g_rccl.GroupEnd());
     if (red_rc) return red_rc < 0 ? red_rc : vh_fail(VH_E_DEVICE, "reduce of a partial state array failed (%d)", red_rc);
+    if (attempt == 0 && !knobs_no_fused_sharded()) {               // every rank is here together: all of them record, or none
+      auto hit = comm->agreed.find(sig);
+      if (hit != comm->agreed.end()) {
+        hit->second.dense.clear();
+        for (int32_t b = 0; b < nb; ++b) hit->second.dense.push_back(vh_comm::BufShape{bufs[b].count, bufs[b].elem, bufs[b].reduce});
+        hit->second.dense_mode = r->mode; hit->second.dense_known = true;
+      }
+    }
     r->info.scanned_recs = f[4]; r->info.scanned_segments = f[5];
     if (root < 0 || R == root) {
       r->device_rows = false;                                     // small results go straight into pinned host memory again

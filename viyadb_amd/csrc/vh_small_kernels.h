@@ -790,6 +790,11 @@ __global__ __launch_bounds__(256) void iota_kernel(uint64_t* p, uint64_t n) {
 // per column (C3: four lines of four column arenas -> one 32 B record). Built from the column arenas in HBM; a block
 // stages 256 records in LDS so that both the column reads and the record writes are coalesced.
 #define VH_PACK_MAX_COLS 8
+// One unit of work of the derived-layout kernels: rows [first, first + count) of segment `seg` (first a multiple of 256, count a multiple of 4
+// and at most VH_JOB_ROWS), of which the segment holds `seg_rows`. The host cuts what changed since a layout was last refreshed — whole
+// segments when it is built, the row ranges an upsert batch touched afterwards (vh_table::journal) — into such jobs; one block each.
+#define VH_JOB_ROWS 16384u
+struct VhJob { uint32_t seg, first, count, seg_rows; };
 struct VhPackArgs {
   int32_t ncols; uint32_t rec_bytes;
   const char* src[VH_PACK_MAX_COLS];   // column arenas
@@ -799,16 +804,16 @@ struct VhPackArgs {
   uint32_t sgn_mask;                   // bit c: column c is a signed integer (its stored bytes sign-extend)
   unsigned int* overflow;              // set when a value does not survive its stored width (the projection is then void)
   char* dst; uint64_t dst_stride;      // pack arena, bytes between segments
-  const uint32_t* rows;                // [gridDim.y] rows to pack of segment seg_first + blockIdx.y
-  uint32_t seg_first, pad;
+  const VhJob* jobs;                   // [gridDim.x]
 };
 __global__ __launch_bounds__(256) void pack_kernel(const VhPackArgs A) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  const uint32_t seg = A.seg_first + blockIdx.y, nrows = A.rows[blockIdx.y], rec = A.rec_bytes;
+  const VhJob J = A.jobs[blockIdx.x];
+  const uint32_t seg = J.seg, nrows = J.seg_rows, rec = A.rec_bytes;
   for (uint32_t i = threadIdx.x; i < 256u * rec / 16u; i += 256u) reinterpret_cast<vh_u32x4*>(lds)[i] = vh_u32x4{0u, 0u, 0u, 0u};
   __syncthreads();
   char* dst = A.dst + (uint64_t)seg * A.dst_stride;
-  for (uint32_t row0 = blockIdx.x * 256u; row0 < nrows; row0 += gridDim.x * 256u) {
+  for (uint32_t row0 = J.first; row0 < J.first + J.count && row0 < nrows; row0 += 256u) {
     const uint32_t row = row0 + threadIdx.x;
     if (row < nrows) {
       bool ovf = false;
@@ -853,14 +858,14 @@ struct VhPackBitsArgs {
   uint32_t esize[VH_PACK_MAX_COLS], bitoff[VH_PACK_MAX_COLS], bitw[VH_PACK_MAX_COLS];
   unsigned int* overflow;
   char* dst; uint64_t dst_stride;
-  const uint32_t* rows;
-  uint32_t seg_first, pad;
+  const VhJob* jobs;
 };
 __global__ __launch_bounds__(256) void pack_bits_kernel(const VhPackBitsArgs A) {
-  const uint32_t seg = A.seg_first + blockIdx.y, nrows = A.rows[blockIdx.y];
+  const VhJob J = A.jobs[blockIdx.x];
+  const uint32_t seg = J.seg, nrows = J.seg_rows < J.first + J.count ? J.seg_rows : J.first + J.count;
   char* dst = A.dst + (uint64_t)seg * A.dst_stride;
   bool ovf = false;
-  for (uint32_t row = blockIdx.x * 256u + threadIdx.x; row < nrows; row += gridDim.x * 256u) {
+  for (uint32_t row = J.first + threadIdx.x; row < nrows; row += 256u) {
     uint64_t rec = 0;
     for (int c = 0; c < A.ncols; ++c) {
       const char* s = A.src[c] + (uint64_t)seg * A.src_stride[c] + (uint64_t)row * A.esize[c];
@@ -880,14 +885,13 @@ __global__ __launch_bounds__(256) void pack_bits_kernel(const VhPackBitsArgs A) 
   if (ovf) atomicOr(A.overflow, 1u);
 }
 
-// Narrow copy of an unsigned 32-bit column whose values fit T (vh_table_narrow): grid.y = segments, 4 elements per thread.
+// Narrow copy of an unsigned 32-bit column whose values fit T (vh_table_narrow): one job per block, 4 elements per thread and step.
 template <typename T>
-__global__ __launch_bounds__(256) void narrow_kernel(const uint32_t* src, uint64_t src_stride_elems, T* dst, uint64_t dst_stride_elems,
-                                                     uint64_t rows_padded, uint32_t seg_first) {
-  const uint32_t seg = seg_first + blockIdx.y;
-  const uint32_t* s = src + (uint64_t)seg * src_stride_elems;
-  T* d = dst + (uint64_t)seg * dst_stride_elems;
-  for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < rows_padded; i += (uint64_t)gridDim.x * 1024) {
+__global__ __launch_bounds__(256) void narrow_kernel(const uint32_t* src, uint64_t src_stride_elems, T* dst, uint64_t dst_stride_elems, const VhJob* jobs) {
+  const VhJob J = jobs[blockIdx.x];
+  const uint32_t* s = src + (uint64_t)J.seg * src_stride_elems;
+  T* d = dst + (uint64_t)J.seg * dst_stride_elems;
+  for (uint64_t i = (uint64_t)J.first + threadIdx.x * 4u; i < (uint64_t)J.first + J.count; i += 1024u) {
     const vh_u32x4 v = *reinterpret_cast<const vh_u32x4*>(s + i);
     d[i] = (T)v.x; d[i + 1] = (T)v.y; d[i + 2] = (T)v.z; d[i + 3] = (T)v.w;
   }
@@ -995,6 +999,72 @@ __global__ __launch_bounds__(256) void seg_minmax_kernel(const T* base, uint64_t
   if ((threadIdx.x & 63) == 0 && n) {
     atomicMin(stats + 2ull * blockIdx.y, (unsigned long long)lo);
     atomicMax(stats + 2ull * blockIdx.y + 1, (unsigned long long)hi);
+  }
+}
+
+// ------------------------------------------------------- batched dirty-range sync (vh_table_sync_batch)
+// One block per descriptor = one contiguous run of one column: the block PULLS the run — out of host memory the caller registered
+// (zero copy over PCIe: 16-byte loads of the source's own aligned pieces), out of the pinned staging ring, or (copy = 0) out of the arena
+// itself behind a DMA copy — stores it into the arena and leaves the run's min / max order keys in ITS slot of a pinned host array: no
+// atomics, nothing to clear, nothing to copy back. The host merges the slots into the per-segment stats when a planner next needs them.
+struct VhSyncDesc {
+  const char* src; char* dst;
+  uint32_t nelem; uint8_t elem, copy; uint16_t pad0;
+  uint32_t pad1, pad2;
+};
+template <typename T>
+__device__ __forceinline__ void vh_sync_run(const VhSyncDesc& d, uint64_t& lo, uint64_t& hi) {
+  constexpr int PER = 16 / (int)sizeof(T);
+  const uintptr_t s = reinterpret_cast<uintptr_t>(d.src), a0 = s & ~(uintptr_t)15;
+  const uint32_t head = (uint32_t)((s - a0) / sizeof(T));
+  T* dst = reinterpret_cast<T*>(d.dst);
+  const bool dst16 = ((reinterpret_cast<uintptr_t>(d.dst) - (uintptr_t)head * sizeof(T)) & 15) == 0;
+  const uint32_t npieces = (head + d.nelem + PER - 1) / PER;
+  for (uint32_t c = threadIdx.x; c < npieces; c += 256u) {
+    const vh_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const vh_u32x4*>(a0) + c);   // (an aligned piece never crosses a page: what lies in it beside the run is readable)
+    T e[PER];
+    __builtin_memcpy(e, &v, 16);
+    const int64_t i0 = (int64_t)c * PER - head;
+    const bool whole = i0 >= 0 && i0 + PER <= (int64_t)d.nelem;
+    if (d.copy && whole && dst16) *reinterpret_cast<vh_u32x4*>(dst + i0) = v;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const int64_t i = i0 + k;
+      if (i < 0 || i >= (int64_t)d.nelem) continue;
+      if (d.copy && !(whole && dst16)) dst[i] = e[k];
+      const uint64_t key = vh_order_key<T>(e[k]);
+      lo = key < lo ? key : lo;
+      hi = key > hi ? key : hi;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void sync_pull_kernel(const VhSyncDesc* __restrict__ descs, unsigned long long* __restrict__ slots) {
+  __shared__ uint64_t part[8];
+  const VhSyncDesc d = descs[blockIdx.x];
+  uint64_t lo = ~0ull, hi = 0;
+  switch (d.elem) {
+    case VH_U8: vh_sync_run<uint8_t>(d, lo, hi); break;
+    case VH_U16: vh_sync_run<uint16_t>(d, lo, hi); break;
+    case VH_U32: vh_sync_run<uint32_t>(d, lo, hi); break;
+    case VH_U64: vh_sync_run<uint64_t>(d, lo, hi); break;
+    case VH_I8: vh_sync_run<int8_t>(d, lo, hi); break;
+    case VH_I16: vh_sync_run<int16_t>(d, lo, hi); break;
+    case VH_I32: vh_sync_run<int32_t>(d, lo, hi); break;
+    case VH_I64: vh_sync_run<int64_t>(d, lo, hi); break;
+    case VH_F32: vh_sync_run<float>(d, lo, hi); break;
+    default: vh_sync_run<double>(d, lo, hi); break;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const uint64_t l2 = __shfl_down(lo, off), h2 = __shfl_down(hi, off);
+    lo = l2 < lo ? l2 : lo;
+    hi = h2 > hi ? h2 : hi;
+  }
+  if ((threadIdx.x & 63) == 0) { part[(threadIdx.x >> 6) * 2] = lo; part[(threadIdx.x >> 6) * 2 + 1] = hi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) { lo = part[2 * w] < lo ? part[2 * w] : lo; hi = part[2 * w + 1] > hi ? part[2 * w + 1] : hi; }
+    slots[2ull * blockIdx.x] = lo;
+    slots[2ull * blockIdx.x + 1] = hi;
   }
 }
 

@@ -4,12 +4,83 @@
 static uint64_t order_key_of_bits(int elem, uint64_t bits);      // (typed host helpers: vhh_result.h)
 static uint64_t bits_of_order_key(int elem, uint64_t k);
 #define VH_PACK_STALE 9001      // (internal) pack_refresh: a value no longer fits its stored width, the projection must go
-// (Re)pack the segments of [first, first + n) whose columns changed since they were last packed.
+// What a derived layout that was current at `applied_epoch` (per segment: at `seg_mod[s]`) has to re-derive, as jobs for its kernel: the
+// row ranges journalled since (vh_table::journal), cut at 256-row boundaries, merged, and split into pieces of VH_JOB_ROWS; whole segments
+// for a layout that is new, or so far behind that the journal no longer reaches back to it. `row_limit`: rows a segment of the layout has
+// room for (a projection's stride is padded to 256 rows, a narrow copy's to 64).
+static void derived_jobs(const vh_table* t, uint64_t applied_epoch, const std::vector<uint64_t>& seg_mod, uint64_t row_limit, std::vector<VhJob>* jobs) {
+  jobs->clear();
+  std::vector<std::pair<uint64_t, uint64_t>> ranges;      // (seg << 32 | first, last)
+  auto whole = [&](uint32_t s) { if (s < seg_mod.size() && seg_mod[s] != t->seg_mod[s]) ranges.emplace_back((uint64_t)s << 32, row_limit); };
+  if (applied_epoch == 0 || applied_epoch < t->journal_floor) {
+    for (uint32_t s = 0; s < t->nseg; ++s) whole(s);
+  } else {
+    auto it = std::upper_bound(t->journal.begin(), t->journal.end(), applied_epoch, [](uint64_t e, const VhChange& c) { return e < c.epoch; });
+    for (; it != t->journal.end(); ++it) {
+      if (it->seg >= t->nseg || it->seg >= seg_mod.size()) continue;
+      if (seg_mod[it->seg] == 0) { whole(it->seg); continue; }          // a segment this layout never held (the table grew)
+      const uint64_t a = it->first & ~255ull, b = std::min<uint64_t>(((uint64_t)it->last + 255) & ~255ull, row_limit);
+      if (a < b) ranges.emplace_back(((uint64_t)it->seg << 32) | a, b);
+    }
+  }
+  if (ranges.empty()) return;
+  std::sort(ranges.begin(), ranges.end());
+  size_t o = 0;
+  for (size_t i = 1; i < ranges.size(); ++i) {
+    if ((ranges[i].first >> 32) == (ranges[o].first >> 32) && (ranges[i].first & 0xFFFFFFFFull) <= ranges[o].second) ranges[o].second = std::max(ranges[o].second, ranges[i].second);
+    else ranges[++o] = ranges[i];
+  }
+  ranges.resize(o + 1);
+  for (const auto& r : ranges) {
+    const uint32_t seg = (uint32_t)(r.first >> 32);
+    const uint64_t a = r.first & 0xFFFFFFFFull, b = std::min(r.second, row_limit);
+    for (uint64_t f = a; f < b; f += VH_JOB_ROWS) jobs->push_back(VhJob{seg, (uint32_t)f, (uint32_t)std::min<uint64_t>(VH_JOB_ROWS, b - f), (uint32_t)t->seg_rows[seg]});
+  }
+}
+// The jobs in pinned memory the kernels read them from (they are 16 bytes each; a list lives until the stream has been waited for).
+static int derived_upload(vh_table* t, const std::vector<VhJob>& jobs, const VhJob** out) {
+  const size_t bytes = jobs.size() * sizeof(VhJob);
+  if (t->h_jobs_used + bytes > t->h_jobs_bytes) {
+    if (t->derived_pending) { HIP_TRY(hipStreamSynchronize(g_ctx.stream)); t->derived_pending = false; }      // (earlier lists are still being read)
+    t->h_jobs_used = 0;
+    if (bytes > t->h_jobs_bytes) {
+      if (t->h_jobs) { HIP_TRY(hipHostFree(t->h_jobs)); t->h_jobs = nullptr; t->h_jobs_bytes = 0; }
+      const size_t nb = std::max<size_t>(bytes * 2, 1u << 16);
+      HIP_TRY(hipHostMalloc((void**)&t->h_jobs, nb, hipHostMallocCoherent));
+      t->h_jobs_bytes = nb;
+    }
+  }
+  memcpy(t->h_jobs + t->h_jobs_used, jobs.data(), bytes);
+  *out = reinterpret_cast<const VhJob*>(t->h_jobs + t->h_jobs_used);
+  t->h_jobs_used += (bytes + 255) / 256 * 256;
+  return VH_OK;
+}
+static int derived_enqueued(vh_table* t) {       // a refresh kernel went onto g_ctx.stream: queries launched from now on wait for it (QueryBuild::launch)
+  if (!t->derived_ev) HIP_TRY(hipEventCreateWithFlags(&t->derived_ev, hipEventDisableTiming));
+  HIP_TRY(hipEventRecord(t->derived_ev, g_ctx.stream));
+  t->derived_pending = true;
+  return VH_OK;
+}
+static int derived_waited(vh_table* t);
+// Work about to go onto a query's own stream reads derived layouts (and arenas): it is ordered behind the refreshes enqueued on g_ctx.stream.
+static int derived_fence(vh_table* t, hipStream_t st) {
+  if (!t->derived_pending) return VH_OK;
+  if (hipEventQuery(t->derived_ev) == hipSuccess) return derived_waited(t);
+  HIP_TRY(hipStreamWaitEvent(st, t->derived_ev, 0));
+  return VH_OK;
+}
+static int derived_waited(vh_table* t) {         // the host waited for g_ctx.stream: nothing pending, the job lists are free
+  t->derived_pending = false; t->h_jobs_used = 0;
+  return VH_OK;
+}
+
+// Bring the projection up to date with the arenas: re-pack what changed since it was last packed (derived_jobs) in ONE launch.
 static int pack_refresh(vh_table* t, VhPack* pk, uint32_t first, uint32_t n) {
-  if (first + n > t->nseg) n = t->nseg > first ? t->nseg - first : 0;
-  if (!n) return VH_OK;
+  (void)first; (void)n;
+  if (!t->nseg) return VH_OK;
   if (pk->cap_seg < t->cap_seg) {                      // the table grew: move the arena
     table_quiesce(t);
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream)); derived_waited(t);
     char* nb = nullptr;
     const size_t bytes = (size_t)t->cap_seg * pk->stride + 256;
     HIP_TRY(hipMalloc(&nb, bytes));
@@ -24,22 +95,12 @@ static int pack_refresh(vh_table* t, VhPack* pk, uint32_t first, uint32_t n) {
     pk->seg_mod.resize(t->cap_seg, 0);
     t->device_bytes += bytes;
   }
-  uint32_t s = first;
-  while (s < first + n) {
-    if (pk->seg_mod[s] == t->seg_mod[s]) { ++s; continue; }
-    uint32_t e = s;
-    while (e < first + n && pk->seg_mod[e] != t->seg_mod[e] && e - s < 4096) ++e;
-    const uint32_t cnt = e - s;
-    if (t->d_packrows_cap < cnt) {
-      HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-      if (t->d_packrows) HIP_TRY(hipFree(t->d_packrows));
-      t->d_packrows = nullptr; t->d_packrows_cap = 0;
-      HIP_TRY(hipMalloc((void**)&t->d_packrows, (size_t)std::max<uint32_t>(cnt, 1024) * sizeof(uint32_t)));
-      t->d_packrows_cap = std::max<uint32_t>(cnt, 1024);
-    }
-    std::vector<uint32_t> rows(cnt);
-    for (uint32_t i = 0; i < cnt; ++i) rows[i] = (uint32_t)t->seg_rows[s + i];
-    HIP_TRY(hipMemcpyAsync(t->d_packrows, rows.data(), (size_t)cnt * sizeof(uint32_t), hipMemcpyHostToDevice, g_ctx.stream));
+  if (pk->applied_epoch == t->sync_epoch) return VH_OK;
+  std::vector<VhJob> jobs;
+  derived_jobs(t, pk->applied_epoch, pk->seg_mod, (t->segment_rows + 255) / 256 * 256, &jobs);
+  if (!jobs.empty()) {
+    const VhJob* d_jobs = nullptr;
+    if (int rc = derived_upload(t, jobs, &d_jobs)) return rc;
     if (!t->d_packflag) { HIP_TRY(hipMalloc((void**)&t->d_packflag, 256)); HIP_TRY(hipMemsetAsync(t->d_packflag, 0, 256, g_ctx.stream)); }
     if (pk->bits) {
       VhPackBitsArgs B{};
@@ -48,36 +109,34 @@ static int pack_refresh(vh_table* t, VhPack* pk, uint32_t first, uint32_t n) {
         const VhColumn& col = t->cols[pk->cols[c]];
         B.src[c] = col.base; B.src_stride[c] = col.stride; B.esize[c] = (uint32_t)col.esize; B.bitoff[c] = pk->bitoff[c]; B.bitw[c] = pk->bitw[c];
       }
-      B.overflow = t->d_packflag; B.dst = pk->base; B.dst_stride = pk->stride; B.rows = t->d_packrows; B.seg_first = s;
-      dim3 gridb((unsigned)std::min<uint64_t>(64, (t->segment_rows + 255) / 256), cnt);
-      hipLaunchKernelGGL(pack_bits_kernel, gridb, dim3(256), 0, g_ctx.stream, B);
-      HIP_TRY(hipGetLastError());
+      B.overflow = t->d_packflag; B.dst = pk->base; B.dst_stride = pk->stride; B.jobs = d_jobs;
+      hipLaunchKernelGGL(pack_bits_kernel, dim3((unsigned)jobs.size()), dim3(256), 0, g_ctx.stream, B);
+    } else {
+      VhPackArgs A{};
+      A.ncols = (int32_t)pk->cols.size(); A.rec_bytes = pk->rec_bytes;
+      for (size_t c = 0; c < pk->cols.size(); ++c) {
+        const VhColumn& col = t->cols[pk->cols[c]];
+        A.src[c] = col.base; A.src_stride[c] = col.stride; A.esize[c] = (uint32_t)col.esize; A.off[c] = pk->off[c];
+        A.wbytes[c] = pk->width[c];
+        if (col.elem == VH_I8 || col.elem == VH_I16 || col.elem == VH_I32 || col.elem == VH_I64) A.sgn_mask |= 1u << c;
+      }
+      A.overflow = t->d_packflag; A.dst = pk->base; A.dst_stride = pk->stride; A.jobs = d_jobs;
+      hipLaunchKernelGGL(pack_kernel, dim3((unsigned)jobs.size()), dim3(256), 256 * pk->rec_bytes, g_ctx.stream, A);
     }
-    VhPackArgs A{};
-    A.ncols = (int32_t)pk->cols.size(); A.rec_bytes = pk->rec_bytes;
-    for (size_t c = 0; c < pk->cols.size(); ++c) {
-      const VhColumn& col = t->cols[pk->cols[c]];
-      A.src[c] = col.base; A.src_stride[c] = col.stride; A.esize[c] = (uint32_t)col.esize; A.off[c] = pk->off[c];
-      A.wbytes[c] = pk->width[c];
-      if (col.elem == VH_I8 || col.elem == VH_I16 || col.elem == VH_I32 || col.elem == VH_I64) A.sgn_mask |= 1u << c;
-    }
-    A.overflow = t->d_packflag;
-    A.dst = pk->base; A.dst_stride = pk->stride; A.rows = t->d_packrows; A.seg_first = s;
-    dim3 grid((unsigned)std::min<uint64_t>(64, (t->segment_rows + 255) / 256), cnt);
-    if (!pk->bits) {
-      hipLaunchKernelGGL(pack_kernel, grid, dim3(256), 256 * pk->rec_bytes, g_ctx.stream, A);
-      HIP_TRY(hipGetLastError());
-    }
-    unsigned int ovf = 0;
-    if (pk->compressed) HIP_TRY(hipMemcpyAsync(&ovf, t->d_packflag, sizeof(ovf), hipMemcpyDeviceToHost, g_ctx.stream));
-    HIP_TRY(hipStreamSynchronize(g_ctx.stream));        // `rows` lives on this frame; d_packrows is reused by the next batch
-    if (ovf) {                                          // a synced value outgrew its stored width: the projection is void (the caller drops it)
-      HIP_TRY(hipMemsetAsync(t->d_packflag, 0, 256, g_ctx.stream));
-      return VH_PACK_STALE;
-    }
-    for (uint32_t i = s; i < e; ++i) pk->seg_mod[i] = t->seg_mod[i];
-    s = e;
+    HIP_TRY(hipGetLastError());
+    if (pk->compressed) {                               // did every value survive its stored width? (the one host wait of a refresh)
+      unsigned int ovf = 0;
+      HIP_TRY(hipMemcpyAsync(&ovf, t->d_packflag, sizeof(ovf), hipMemcpyDeviceToHost, g_ctx.stream));
+      HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+      derived_waited(t);
+      if (ovf) {                                        // a synced value outgrew its stored width: the projection is void (the caller drops it)
+        HIP_TRY(hipMemsetAsync(t->d_packflag, 0, 256, g_ctx.stream));
+        return VH_PACK_STALE;
+      }
+    } else if (int rc = derived_enqueued(t)) return rc;
   }
+  for (uint32_t s = 0; s < t->nseg; ++s) pk->seg_mod[s] = t->seg_mod[s];
+  pk->applied_epoch = t->sync_epoch;
   return VH_OK;
 }
 static void pack_drop(vh_table* t, VhPack* pk) {
@@ -223,13 +282,13 @@ static int narrow_width_for(const vh_table* t, int col, uint32_t nseg) {
   if (!any) return 0;
   return hi < 256 ? 1 : hi < 65536 ? 2 : 0;
 }
-// (Re)copy the segments of [first, first + n) whose column changed since they were last copied.
+// Bring the narrow copy up to date with its column: the ranges that changed since it was last copied, ONE launch, no host wait.
 static int narrow_refresh(vh_table* t, VhNarrow* nw, uint32_t first, uint32_t n) {
-  if (first + n > t->nseg) n = t->nseg > first ? t->nseg - first : 0;
-  if (!n) return VH_OK;
-  const uint64_t padded = t->padded_rows;
+  (void)first; (void)n;
+  if (!t->nseg) return VH_OK;
   if (nw->cap_seg < t->cap_seg) {
     table_quiesce(t);
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream)); derived_waited(t);
     char* nb = nullptr;
     const size_t bytes = (size_t)t->cap_seg * nw->stride + 256;
     HIP_TRY(hipMalloc(&nb, bytes));
@@ -244,24 +303,24 @@ static int narrow_refresh(vh_table* t, VhNarrow* nw, uint32_t first, uint32_t n)
     nw->seg_mod.resize(t->cap_seg, 0);
     t->device_bytes += bytes;
   }
+  if (nw->applied_epoch == t->sync_epoch) return VH_OK;
   const VhColumn& c = t->cols[nw->col];
-  uint32_t s = first;
-  while (s < first + n) {
-    if (nw->seg_mod[s] == t->seg_mod[s]) { ++s; continue; }
-    uint32_t e = s;
-    while (e < first + n && nw->seg_mod[e] != t->seg_mod[e] && e - s < 4096) ++e;
-    const dim3 grid((unsigned)std::min<uint64_t>(64, (padded + 1023) / 1024), e - s);
+  std::vector<VhJob> jobs;
+  derived_jobs(t, nw->applied_epoch, nw->seg_mod, t->padded_rows, &jobs);
+  if (!jobs.empty()) {
+    const VhJob* d_jobs = nullptr;
+    if (int rc = derived_upload(t, jobs, &d_jobs)) return rc;
     if (nw->width == 1)
-      hipLaunchKernelGGL((narrow_kernel<uint8_t>), grid, dim3(256), 0, g_ctx.stream, reinterpret_cast<const uint32_t*>(c.base), c.stride / 4,
-                         reinterpret_cast<uint8_t*>(nw->base), nw->stride, padded, s);
+      hipLaunchKernelGGL((narrow_kernel<uint8_t>), dim3((unsigned)jobs.size()), dim3(256), 0, g_ctx.stream, reinterpret_cast<const uint32_t*>(c.base), c.stride / 4,
+                         reinterpret_cast<uint8_t*>(nw->base), nw->stride, d_jobs);
     else
-      hipLaunchKernelGGL((narrow_kernel<uint16_t>), grid, dim3(256), 0, g_ctx.stream, reinterpret_cast<const uint32_t*>(c.base), c.stride / 4,
-                         reinterpret_cast<uint16_t*>(nw->base), nw->stride / 2, padded, s);
+      hipLaunchKernelGGL((narrow_kernel<uint16_t>), dim3((unsigned)jobs.size()), dim3(256), 0, g_ctx.stream, reinterpret_cast<const uint32_t*>(c.base), c.stride / 4,
+                         reinterpret_cast<uint16_t*>(nw->base), nw->stride / 2, d_jobs);
     HIP_TRY(hipGetLastError());
-    for (uint32_t i = s; i < e; ++i) nw->seg_mod[i] = t->seg_mod[i];
-    s = e;
+    if (int rc = derived_enqueued(t)) return rc;
   }
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  for (uint32_t s = 0; s < t->nseg; ++s) nw->seg_mod[s] = t->seg_mod[s];
+  nw->applied_epoch = t->sync_epoch;
   return VH_OK;
 }
 static void narrow_drop(vh_table* t, size_t k) {
@@ -301,6 +360,7 @@ extern "C" int vh_table_narrow(vh_table* t, const int32_t* cols, int32_t ncols) 
   if (!t || (!cols && ncols)) return vh_fail(VH_E_INVALID, "null argument");
   VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
+  if (int src = sync_resolve(t)) return src;
   for (int i = 0; i < ncols; ++i)
     if (int rc = table_narrow_locked(t, cols[i], false)) return rc;
   return VH_OK;
@@ -311,6 +371,7 @@ extern "C" int vh_table_pack_ex(vh_table* t, const int32_t* cols, int32_t ncols,
   if (form > VH_PACK_COMPRESSED) return vh_fail(VH_E_INVALID, "vh_table_pack_ex: form %u", form);
   VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
+  if (int src = sync_resolve(t)) return src;
   // VH_PACK_AUTO: compressed where the per-query compiled kernels — the only readers of compressed records — would run a scan of the
   // whole table (VH_JIT=force, or auto and the table holds VH_JIT_MIN_ROWS rows); plain where the pre-built kernels answer
   bool compress = form == VH_PACK_COMPRESSED;
@@ -327,6 +388,7 @@ extern "C" int vh_table_unpack(vh_table* t) {
   if (!t) return vh_fail(VH_E_INVALID, "null table");
   VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
+  if (int src = sync_resolve(t)) return src;
   table_quiesce(t);
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   for (auto& pk : t->packs) if (pk->base) { (void)hipFree(pk->base); t->device_bytes -= (size_t)pk->cap_seg * pk->stride + 256; }

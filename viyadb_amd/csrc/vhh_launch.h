@@ -433,6 +433,7 @@ int QueryBuild::launch() {
   int rc = VH_OK; (void)rc;
   // ---------------- init + launch
   hipStream_t st = x->stream();
+  if (int frc = derived_fence(t, st)) return frc;      // derived layouts refreshed for this query are still on the table's stream
   HIP_TRY(hipEventRecord(x->ev[0], st));
   VhInitArgs IA{};              // everything that is cleared goes into one launch (init_regions_kernel)
   auto clear = [&](void* ptr, size_t bytes, uint32_t byte_pattern) {
@@ -571,6 +572,7 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
                                bool force_hash, uint64_t part_tuples_override = 0, bool no_part = false,
                                bool plan_only = false, VhSummary* summary_out = nullptr, const VhAgreed* ag = nullptr,
                                bool device_rows = false, uint32_t hp_passes_override = 0, bool no_hpart = false) {
+  if (int src = sync_resolve(t)) return src;      // a batched sync may still be on its way: its rows and its share of the stats, before anything is planned
   QueryBuild b(t, x, p, out, hash_capacity_override, force_hash, part_tuples_override, no_part, plan_only, summary_out, ag, device_rows,
                hp_passes_override, no_hpart);
   int (QueryBuild::* const steps[])() = {&QueryBuild::shape_filter, &QueryBuild::snapshot_segments, &QueryBuild::shape_groups, &QueryBuild::shape_metrics,

@@ -33,6 +33,7 @@ static int place_search(VhExec* x, size_t nb, const VhPlaceHint& h, void** out_p
   const size_t budget = std::min<size_t>(free_b / 2, (size_t)knobs().place_gb << 30);      // never more than half of what is free, nor VH_PLACE_GB (48 GB)
   const size_t spacer = (size_t)6 << 30;          // classes last for tens of GB: candidates ~9 GB apart sample them
   hipStream_t st = x->stream();
+  if (g_ctx.stream != st) (void)hipStreamSynchronize(g_ctx.stream);      // (the probes read derived layouts a refresh may still be writing)
   VhPlaceArgs A{};
   {   // longest stream first; at most 3 GB each (the probe runs ~1 ms)
     int order[4] = {0, 1, 2, 3};

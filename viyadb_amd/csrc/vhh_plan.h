@@ -121,6 +121,7 @@ static int estimate_selectivity(vh_table* t, VhExec* x, const VhPlanDev& P, cons
   S.seg_rows = reinterpret_cast<const uint32_t*>(x->d_sample + 512);
   S.nseg = nseg; S.unit_rows = kRows; S.units_per_seg = 1; S.total_units = nseg;
   hipStream_t st = x->stream();
+  if (int frc = derived_fence(t, st)) return frc;
   HIP_TRY(hipMemsetAsync(x->d_sample, 0, 512, st));
   HIP_TRY(hipMemcpyAsync(x->d_sample + 512, rows.data(), nseg * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   S.prog = reinterpret_cast<const VhProgOp*>(x->d_sample + 512 + rows_bytes);

@@ -54,6 +54,8 @@ extern "C" int vh_segment_stats(vh_table* t, uint32_t seg, int32_t col, vh_anynu
   if (!t || col < 0 || (size_t)col >= t->cols.size() || seg >= t->nseg) return vh_fail(VH_E_INVALID, "vh_segment_stats: bad argument");
   auto& c = t->cols[col];
   if (!is_dim(c.kind)) return vh_fail(VH_E_INVALID, "column %d is not a dimension", col);
+  std::lock_guard<std::mutex> lk(t->mu);
+  if (int src = sync_resolve(t)) return src;
   const VhSegStat& s = t->stats[col][seg];
   const uint64_t lo = std::min(s.lo, stat_min_identity_key(c.elem));
   const uint64_t hi = std::max(s.hi, stat_max_identity_key(c.elem));

@@ -46,6 +46,7 @@ extern "C" int vh_query_select(vh_table* t, const vh_select_plan* sp, vh_rows** 
   VhPlanDev P = pr->plan;
   const uint32_t nseg = P.nseg;
   hipStream_t st = x->stream();
+  if (int frc = derived_fence(t, st)) return frc;
   std::unique_ptr<vh_rows> rows(new vh_rows());
   rows->info.scanned_recs = pr->info.scanned_recs;
   rows->info.scanned_segments = pr->info.scanned_segments;

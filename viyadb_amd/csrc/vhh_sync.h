@@ -1,5 +1,6 @@
 // vhh_sync.h — host side of libviya_hip, part of viya_hip.hip's translation unit (included there, in order; not a stand-alone header):
 // data in: vh_segment_sync*, the per-segment min / max pass (refresh_stats), vh_segment_generate, vh_segment_read.
+static int sync_resolve(vh_table* t);      // (batched sync, below: what the last batch left to merge into the stats)
 static int ensure_segrows(VhExec* x, size_t n) {
   if (n <= x->h_segrows_cap) return VH_OK;
   if (x->h_segrows) (void)hipHostFree(x->h_segrows);
@@ -81,6 +82,7 @@ extern "C" int vh_segment_sync(vh_table* t, uint32_t seg, uint64_t nrows, const 
   if (seg >= VH_MAX_SEGMENTS) return vh_fail(VH_E_INVALID, "vh_segment_sync: segment index %u out of range", seg);
   VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
+  if (int src = sync_resolve(t)) return src;
   table_quiesce(t);
   int rc = table_grow(t, seg + 1);
   if (rc) return rc;
@@ -91,39 +93,237 @@ extern "C" int vh_segment_sync(vh_table* t, uint32_t seg, uint64_t nrows, const 
                            hipMemcpyDefault, g_ctx.stream));   // host or device source (unified addressing)
   }
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  const uint64_t was = t->seg_rows[seg];
   t->seg_rows[seg] = nrows;
   t->nseg = std::max(t->nseg, seg + 1);
-  t->seg_mod[seg] = ++t->sync_epoch;
+  table_note_change(t, seg, 0, std::max(was, nrows));
   return refresh_stats(t, seg, 1);
 }
 
+// ------------------------------------------------------------------ registered host memory (vh_host_register)
+struct VhHostReg { uint64_t bytes; char* dev; };
+static std::map<uintptr_t, VhHostReg> g_hostreg;
+static std::mutex g_hostreg_mu;
+
+extern "C" int vh_host_register(const void* base, uint64_t bytes) {
+  if (!base || !bytes) return vh_fail(VH_E_INVALID, "vh_host_register: null range");
+  if (!g_ctx.inited) return vh_fail(VH_E_INVALID, "vh_init has not been called");
+  VH_ENTER();
+  std::lock_guard<std::mutex> lk(g_hostreg_mu);
+  auto it = g_hostreg.find(reinterpret_cast<uintptr_t>(base));
+  if (it != g_hostreg.end()) {
+    if (it->second.bytes >= bytes) return VH_OK;
+    (void)hipHostUnregister(const_cast<void*>(base));
+    g_hostreg.erase(it);
+  }
+  hipError_t he = hipHostRegister(const_cast<void*>(base), (size_t)bytes, hipHostRegisterDefault);
+  void* dev = nullptr;
+  if (he == hipSuccess) { he = hipHostGetDevicePointer(&dev, const_cast<void*>(base), 0); if (he != hipSuccess) (void)hipHostUnregister(const_cast<void*>(base)); }
+  if (he != hipSuccess) { (void)hipGetLastError(); return vh_fail(VH_E_DEVICE, "vh_host_register: %llu bytes at %p: %s", (unsigned long long)bytes, base, hipGetErrorString(he)); }
+  g_hostreg[reinterpret_cast<uintptr_t>(base)] = VhHostReg{bytes, static_cast<char*>(dev)};
+  return VH_OK;
+}
+extern "C" int vh_host_unregister(const void* base) {
+  if (!base) return VH_OK;
+  VH_ENTER();
+  std::lock_guard<std::mutex> lk(g_hostreg_mu);
+  auto it = g_hostreg.find(reinterpret_cast<uintptr_t>(base));
+  if (it == g_hostreg.end()) return VH_OK;
+  g_hostreg.erase(it);
+  // (a batch that still reads the range was ordered on g_ctx.stream: wait for it before the pages are let go)
+  (void)hipStreamSynchronize(g_ctx.stream);
+  HIP_TRY(hipHostUnregister(const_cast<void*>(base)));
+  return VH_OK;
+}
+// The device's address of [p, p + bytes) when that lies inside ONE registered range, else NULL.
+static const char* hostreg_lookup(const void* p, uint64_t bytes, uintptr_t* lo, uintptr_t* hi, const char** dev) {
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  std::lock_guard<std::mutex> lk(g_hostreg_mu);
+  auto it = g_hostreg.upper_bound(a);
+  if (it == g_hostreg.begin()) return nullptr;
+  --it;
+  if (a + bytes > it->first + it->second.bytes) return nullptr;
+  *lo = it->first; *hi = it->first + it->second.bytes; *dev = it->second.dev;
+  return it->second.dev + (a - it->first);
+}
+
+// ------------------------------------------------------------------ batched sync
+// What the last vh_table_sync_batch left to do on the host: wait for its kernel, widen the per-segment stats by the runs' min / max.
+// Called with t->mu held by everything that reads stats or arenas from the host side, plans a query, or starts another batch.
+static int sync_resolve(vh_table* t) {
+  if (!t->sync_inflight) return VH_OK;
+  HIP_TRY(hipEventSynchronize(t->sync_ev));
+  t->sync_inflight = false;
+  const unsigned long long* slots = reinterpret_cast<const unsigned long long*>(t->h_sync);
+  for (const auto& p : t->sync_pending) {
+    VhSegStat& st = t->stats[p.col][p.seg];
+    for (uint32_t d = p.desc_first; d < p.desc_first + p.desc_n; ++d) {
+      const uint64_t lo = slots[2ull * d], hi = slots[2ull * d + 1];
+      if (lo > hi) continue;                    // (an empty run)
+      st.lo = std::min(st.lo, lo);
+      st.hi = std::max(st.hi, hi);
+    }
+  }
+  t->sync_pending.clear();
+  return VH_OK;
+}
+
+static const size_t VH_SYNC_STAGE_RUN = 64u << 10;       // runs of unregistered memory up to this size go through the pinned ring ...
+static const size_t VH_SYNC_STAGE_BYTES = 16u << 20;     // ... while it has room; the rest is copied by the DMA engine
+
+static int sync_batch_locked(vh_table* t, const vh_sync_item* items, uint32_t n) {
+  if (int rc = sync_resolve(t)) return rc;                // the previous batch's slots, descriptors and ring are free again
+  // ---- validate against the rows the mirror will hold as the items are applied in order
+  uint32_t max_seg = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const vh_sync_item& it = items[i];
+    if (it.seg >= VH_MAX_SEGMENTS) return vh_fail(VH_E_INVALID, "vh_table_sync_batch: item %u: segment index %u out of range", i, it.seg);
+    if (it.new_size > t->segment_rows || it.row_first + it.nrows > it.new_size)
+      return vh_fail(VH_E_INVALID, "vh_table_sync_batch: item %u: rows [%llu, %llu) do not fit a segment of %llu rows", i,
+                     (unsigned long long)it.row_first, (unsigned long long)(it.row_first + it.nrows), (unsigned long long)it.new_size);
+    if (it.nrows && !it.col_ptrs) return vh_fail(VH_E_INVALID, "vh_table_sync_batch: item %u: null col_ptrs", i);
+    max_seg = std::max(max_seg, it.seg);
+  }
+  if (max_seg + 1 > t->cap_seg) {                          // arenas move: nothing may still read the old ones
+    table_quiesce(t);
+    if (int rc = table_grow(t, max_seg + 1)) return rc;
+  }
+  std::vector<uint64_t> rows_now;                          // segments named by this batch -> rows mirrored so far (UINT64_MAX: not named yet)
+  rows_now.assign((size_t)max_seg + 1, ~0ull);
+  uint64_t total_bytes = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const vh_sync_item& it = items[i];
+    uint64_t& have = rows_now[it.seg];
+    if (have == ~0ull) have = t->seg_rows[it.seg];
+    if (it.row_first > have)
+      return vh_fail(VH_E_INVALID, "vh_table_sync_batch: item %u: segment %u has %llu mirrored rows, range starts at %llu (gap)", i, it.seg,
+                     (unsigned long long)have, (unsigned long long)it.row_first);
+    have = it.new_size;
+    for (size_t c = 0; c < t->cols.size(); ++c) {
+      const VhColumn& col = t->cols[c];
+      if (is_bitset_elem(col.elem) || !it.nrows || !it.col_ptrs[c] || ((it.flags & VH_SYNC_METRICS_ONLY) && is_dim(col.kind))) continue;
+      total_bytes += it.nrows * (uint64_t)col.esize;
+    }
+  }
+  // ---- one descriptor per run of at most `run_max` bytes: at most ~64 K of them however big the batch
+  size_t run_max = 256u << 10;
+  while (total_bytes / run_max > (1u << 16) && run_max < (4u << 20)) run_max *= 2;
+  uint64_t ndesc_max = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const vh_sync_item& it = items[i];
+    for (size_t c = 0; c < t->cols.size(); ++c) {
+      const VhColumn& col = t->cols[c];
+      if (is_bitset_elem(col.elem) || !it.nrows || !it.col_ptrs[c] || ((it.flags & VH_SYNC_METRICS_ONLY) && is_dim(col.kind))) continue;
+      ndesc_max += (it.nrows * (uint64_t)col.esize + run_max - 1) / run_max;
+    }
+  }
+  if (ndesc_max > 0x7FFFFFFFull) return vh_fail(VH_E_INVALID, "vh_table_sync_batch: too many runs");
+  if (!t->sync_ev) HIP_TRY(hipEventCreateWithFlags(&t->sync_ev, hipEventDisableTiming));
+  const size_t need = (size_t)ndesc_max * (2 * sizeof(unsigned long long) + sizeof(VhSyncDesc));
+  if (need > t->h_sync_bytes) {
+    if (t->h_sync) { HIP_TRY(hipHostFree(t->h_sync)); t->h_sync = nullptr; t->h_sync_bytes = 0; }
+    const size_t nb = std::max<size_t>(need * 2, 1u << 16);
+    HIP_TRY(hipHostMalloc((void**)&t->h_sync, nb, hipHostMallocCoherent));
+    t->h_sync_bytes = nb;
+  }
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(t->h_sync);
+  VhSyncDesc* descs = reinterpret_cast<VhSyncDesc*>(t->h_sync + (size_t)ndesc_max * 2 * sizeof(unsigned long long));
+  uint32_t nd = 0, launched = 0;
+  // (the kernel of the first few thousand runs pulls while the host is still writing the descriptors of the next)
+  auto launch_some = [&](bool all) -> int {
+    if (nd == launched || (!all && nd - launched < 2048)) return VH_OK;
+    hipLaunchKernelGGL(sync_pull_kernel, dim3(nd - launched), dim3(256), 0, g_ctx.stream, descs + launched, slots + 2ull * launched);
+    HIP_TRY(hipGetLastError());
+    launched = nd;
+    return VH_OK;
+  };
+  size_t stage_used = 0;
+  bool dma_from_pageable = false;
+  uintptr_t reg_lo = 0, reg_hi = 0; const char* reg_dev = nullptr;     // the registered range the last run lay in (a segment's columns share one)
+  t->sync_pending.reserve((size_t)ndesc_max);
+  for (uint32_t i = 0; i < n; ++i) {
+    const vh_sync_item& it = items[i];
+    // a range that holds every row the segment will have replaces the stats of the columns it ships; any other range widens them
+    const bool replace = it.row_first == 0 && it.nrows == it.new_size;
+    for (size_t c = 0; c < t->cols.size(); ++c) {
+      const VhColumn& col = t->cols[c];
+      if (is_bitset_elem(col.elem) || ((it.flags & VH_SYNC_METRICS_ONLY) && is_dim(col.kind))) continue;
+      if (replace && (it.col_ptrs && it.col_ptrs[c])) t->stats[c][it.seg] = VhSegStat();
+      if (!it.nrows || !it.col_ptrs[c]) continue;
+      const uint64_t bytes = it.nrows * (uint64_t)col.esize;
+      const char* host = static_cast<const char*>(it.col_ptrs[c]) + it.row_first * (uint64_t)col.esize;
+      char* dst = col.base + (size_t)it.seg * col.stride + it.row_first * (uint64_t)col.esize;
+      const char* src = nullptr;
+      uint8_t copy = 1;
+      if (it.flags & VH_SYNC_DEVICE_SRC) src = host;
+      else if (reinterpret_cast<uintptr_t>(host) >= reg_lo && reinterpret_cast<uintptr_t>(host) + bytes <= reg_hi) { src = reg_dev + (reinterpret_cast<uintptr_t>(host) - reg_lo); t->sync_bytes_pulled += bytes; }
+      else if (const char* dev = hostreg_lookup(host, bytes, &reg_lo, &reg_hi, &reg_dev)) { src = dev; t->sync_bytes_pulled += bytes; }
+      else if (bytes <= VH_SYNC_STAGE_RUN && stage_used + bytes + 16 <= VH_SYNC_STAGE_BYTES) {
+        if (!t->h_stage) { HIP_TRY(hipHostMalloc((void**)&t->h_stage, VH_SYNC_STAGE_BYTES, hipHostMallocDefault)); t->h_stage_bytes = VH_SYNC_STAGE_BYTES; }
+        char* at = t->h_stage + stage_used;
+        memcpy(at, host, bytes);
+        stage_used += (bytes + 15) / 16 * 16;
+        src = at;
+        t->sync_bytes_staged += bytes;
+      } else {
+        HIP_TRY(hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, g_ctx.stream));
+        dma_from_pageable = true;
+        src = dst; copy = 0;
+        t->sync_bytes_dma += bytes;
+      }
+      const uint32_t first = nd;
+      for (uint64_t off = 0; off < bytes; off += run_max) {
+        const uint64_t b = std::min<uint64_t>(run_max, bytes - off);
+        VhSyncDesc& d = descs[nd++];
+        d.src = src + off; d.dst = dst + off; d.nelem = (uint32_t)(b / col.esize); d.elem = (uint8_t)col.elem; d.copy = copy; d.pad0 = 0; d.pad1 = d.pad2 = 0;
+      }
+      t->sync_pending.push_back(vh_table::SyncPending{(uint32_t)c, it.seg, first, nd - first});
+    }
+    if (int lrc = launch_some(false)) return lrc;
+    const uint64_t was = t->seg_rows[it.seg];
+    t->seg_rows[it.seg] = it.new_size;
+    t->nseg = std::max(t->nseg, it.seg + 1);
+    // (rows that fell off the end of a shrunk segment count as changed: layouts zero what lies beyond size())
+    table_note_change(t, it.seg, it.new_size < was ? std::min<uint64_t>(it.row_first, it.new_size) : it.row_first, it.new_size < was ? was : it.row_first + it.nrows);
+  }
+  if (nd) {
+    if (int lrc = launch_some(true)) return lrc;
+    HIP_TRY(hipEventRecord(t->sync_ev, g_ctx.stream));
+    t->sync_inflight = true;
+    ++t->sync_batches; t->sync_descs += nd;
+  }
+  // sources in unregistered memory behind a DMA copy: the call promises they may be reused when it returns
+  if (dma_from_pageable) HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return VH_OK;
+}
+
+extern "C" int vh_table_sync_batch(vh_table* t, const vh_sync_item* items, uint32_t nitems) {
+  if (!t || (!items && nitems)) return vh_fail(VH_E_INVALID, "vh_table_sync_batch: null argument");
+  if (!nitems) return VH_OK;
+  VH_ENTER();
+  std::lock_guard<std::mutex> lk(t->mu);
+  return sync_batch_locked(t, items, nitems);
+}
+
+extern "C" int vh_table_sync_stats(vh_table* t, uint64_t* batches, uint64_t* runs, uint64_t* bytes_pulled, uint64_t* bytes_staged, uint64_t* bytes_dma) {
+  if (!t) return vh_fail(VH_E_INVALID, "null table");
+  std::lock_guard<std::mutex> lk(t->mu);
+  if (batches) *batches = t->sync_batches;
+  if (runs) *runs = t->sync_descs;
+  if (bytes_pulled) *bytes_pulled = t->sync_bytes_pulled;
+  if (bytes_staged) *bytes_staged = t->sync_bytes_staged;
+  if (bytes_dma) *bytes_dma = t->sync_bytes_dma;
+  return VH_OK;
+}
+
+// The one-range form: a batch of one item.
 extern "C" int vh_segment_sync_range(vh_table* t, uint32_t seg, uint64_t row_first, uint64_t nrows, uint64_t new_size,
                                      const void* const* col_ptrs) {
   if (!t || !col_ptrs) return vh_fail(VH_E_INVALID, "vh_segment_sync_range: null argument");
-  if (new_size > t->segment_rows || row_first + nrows > new_size)
-    return vh_fail(VH_E_INVALID, "vh_segment_sync_range: rows [%llu, %llu) do not fit a segment of %llu rows",
-                   (unsigned long long)row_first, (unsigned long long)(row_first + nrows), (unsigned long long)new_size);
-  if (seg >= VH_MAX_SEGMENTS) return vh_fail(VH_E_INVALID, "vh_segment_sync_range: segment index %u out of range", seg);
+  const vh_sync_item it{seg, 0u, row_first, nrows, new_size, col_ptrs};
   VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
-  table_quiesce(t);
-  int rc = table_grow(t, seg + 1);
-  if (rc) return rc;
-  if (row_first > t->seg_rows[seg])
-    return vh_fail(VH_E_INVALID, "vh_segment_sync_range: segment %u has %llu mirrored rows, range starts at %llu (gap)",
-                   seg, (unsigned long long)t->seg_rows[seg], (unsigned long long)row_first);
-  for (size_t i = 0; i < t->cols.size(); ++i) {
-    auto& c = t->cols[i];
-    if (is_bitset_elem(c.elem) || !col_ptrs[i] || !nrows) continue;
-    HIP_TRY(hipMemcpyAsync(c.base + (size_t)seg * c.stride + row_first * c.esize,
-                           static_cast<const char*>(col_ptrs[i]) + row_first * c.esize, (size_t)nrows * c.esize,
-                           hipMemcpyHostToDevice, g_ctx.stream));
-  }
-  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
-  t->seg_rows[seg] = new_size;
-  t->nseg = std::max(t->nseg, seg + 1);
-  t->seg_mod[seg] = ++t->sync_epoch;
-  return refresh_stats(t, seg, 1);   // one pass over the segment's dimension columns in HBM
+  return sync_batch_locked(t, &it, 1);
 }
 
 // The 32-bit copy of a segment's CSR offsets (VhColumn::bs_offsets32): rebuilt whenever the 64-bit ones are.
@@ -205,6 +405,7 @@ extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nse
   if (seg_first >= VH_MAX_SEGMENTS || nseg > VH_MAX_SEGMENTS - seg_first) return vh_fail(VH_E_INVALID, "vh_segment_generate: segments [%u, +%u) out of range", seg_first, nseg);
   VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
+  if (int src = sync_resolve(t)) return src;
   table_quiesce(t);
   int rc = table_grow(t, seg_first + nseg);
   if (rc) return rc;
@@ -241,7 +442,7 @@ extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nse
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   ++t->sync_epoch;
-  for (uint32_t s = 0; s < nseg; ++s) { t->seg_rows[seg_first + s] = rows_per_seg; t->seg_mod[seg_first + s] = t->sync_epoch; }
+  for (uint32_t s = 0; s < nseg; ++s) { const uint64_t was = t->seg_rows[seg_first + s]; t->seg_rows[seg_first + s] = rows_per_seg; table_note_change(t, seg_first + s, 0, std::max(was, rows_per_seg), false); }
   t->nseg = std::max(t->nseg, seg_first + nseg);
   // stats in batches so the staging buffers stay small
   for (uint32_t s = 0; s < nseg; s += 256) {
@@ -257,6 +458,7 @@ extern "C" int vh_segment_read(vh_table* t, uint32_t seg, int32_t col, uint64_t 
   if (is_bitset_elem(c.elem)) return vh_fail(VH_E_UNSUPPORTED, "vh_segment_read: bitset column");
   VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
+  if (int src = sync_resolve(t)) return src;
   HIP_TRY(hipMemcpy(dst, c.base + (size_t)seg * c.stride, (size_t)nrows * c.esize, hipMemcpyDeviceToHost));
   return VH_OK;
 }

@@ -53,6 +53,7 @@ struct VhPack {
   uint32_t rec_bytes = 0;           // power of two, 8..64 (bit-field records: 4 or 8)
   char* base = nullptr; uint64_t stride = 0; uint32_t cap_seg = 0;
   std::vector<uint64_t> seg_mod;    // value of vh_table::seg_mod[s] the segment was packed at (0: never)
+  uint64_t applied_epoch = 0;       // every change of the table's journal up to this epoch is in the records
   bool automatic = false;
   int col_index(int col) const { for (size_t i = 0; i < cols.size(); ++i) if (cols[i] == col) return (int)i; return -1; }
 };
@@ -63,8 +64,11 @@ struct VhNarrow {
   int col = -1, width = 0;          // bytes per element: 1 or 2
   char* base = nullptr; uint64_t stride = 0; uint32_t cap_seg = 0;
   std::vector<uint64_t> seg_mod;    // vh_table::seg_mod[s] the segment was copied at (0: never)
+  uint64_t applied_epoch = 0;
   bool automatic = false;
 };
+// What a sync did to a segment's columns: rows [first, last) at sync epoch `epoch` (the table's journal; derived layouts replay it).
+struct VhChange { uint64_t epoch; uint32_t seg, first, last; };
 struct vh_table {
   std::vector<VhColumn> cols;
   uint64_t segment_rows = 0;
@@ -77,6 +81,15 @@ struct vh_table {
   std::vector<std::unique_ptr<VhExec>> execs;
   std::mutex pool_mu; std::condition_variable pool_cv;
   char* d_stats = nullptr; size_t d_stats_bytes = 0;      // vh_segment_sync*: min/max pass (its own buffer: a sync never touches a query's scratch)
+  // vh_table_sync_batch: run descriptors and their result slots in ONE pinned block, a ring for small runs out of unregistered host memory,
+  // and what of the last batch still has to be merged into `stats` (sync_resolve: the first planner — or sync — that comes after it waits)
+  char* h_sync = nullptr; size_t h_sync_bytes = 0;
+  char* h_stage = nullptr; size_t h_stage_bytes = 0;
+  hipEvent_t sync_ev = nullptr;
+  struct SyncPending { uint32_t col, seg, desc_first, desc_n; };
+  std::vector<SyncPending> sync_pending;
+  bool sync_inflight = false;
+  uint64_t sync_batches = 0, sync_descs = 0, sync_bytes_pulled = 0, sync_bytes_staged = 0, sync_bytes_dma = 0;   // vh_table_sync_stats
   std::map<std::string, uint64_t> groups_seen;           // group-column signature -> groups of the last query (hash sizing)
   std::map<std::string, std::pair<uint64_t, uint64_t>> sel_cache;   // filter signature + table state -> (passed, sampled) of the selectivity probe
   std::vector<std::unique_ptr<VhPack>> packs;
@@ -84,7 +97,12 @@ struct vh_table {
   bool derived_tried = false;                   // place_with_derived ran (once per table)
   std::map<int, uint32_t> pred_seen;                     // column -> queries that filtered on it (automatic narrow copies)
   std::vector<uint64_t> seg_mod;                          // sync_epoch of the last change to a segment's columns
-  uint32_t* d_packrows = nullptr; size_t d_packrows_cap = 0;
+  // Derived layouts follow the arenas by ROW RANGE: every sync appends what it touched; a layout that was current at epoch e re-derives the
+  // ranges journalled since — one launch over a list of jobs — instead of every segment whose stamp moved (an upsert batch dirties hundreds
+  // of segments by a few rows each). Entries older than `journal_floor` were dropped: a layout behind that re-derives whole segments.
+  std::vector<VhChange> journal; uint64_t journal_floor = 0;
+  char* h_jobs = nullptr; size_t h_jobs_bytes = 0, h_jobs_used = 0;     // pinned: the job lists of the refreshes enqueued since the stream was last waited for
+  hipEvent_t derived_ev = nullptr; bool derived_pending = false;         // a refresh is enqueued on g_ctx.stream: the next query's stream waits for it
   unsigned int* d_packflag = nullptr;                      // pack_kernel's "a value outgrew its stored width" word
   std::map<std::string, uint32_t> gather_seen;            // payload column set -> low-selectivity queries seen (automatic packs)
   uint64_t sync_epoch = 0;   // bumped by every vh_segment_sync / generate: invalidates cached estimates
@@ -217,6 +235,18 @@ static void table_quiesce(vh_table* t) {
   for (auto& x : t->execs) if (x->busy) (void)hipStreamSynchronize(x->stream());
 }
 
+// A sync changed rows [first, last) of a segment's columns: stamp the segment and tell the journal.
+static void table_note_change(vh_table* t, uint32_t seg, uint64_t first, uint64_t last, bool new_epoch = true) {
+  if (new_epoch) ++t->sync_epoch;
+  t->seg_mod[seg] = t->sync_epoch;
+  if (t->journal.size() >= (1u << 18)) {          // keep the newer half; layouts older than the floor fall back to whole segments
+    const size_t drop = t->journal.size() / 2;
+    t->journal_floor = t->journal[drop - 1].epoch;
+    t->journal.erase(t->journal.begin(), t->journal.begin() + (long)drop);
+  }
+  t->journal.push_back(VhChange{t->sync_epoch, seg, (uint32_t)first, (uint32_t)last});
+}
+
 extern "C" void vh_table_destroy(vh_table* t) {
   if (!t) return;
   VH_ENTER();
@@ -229,10 +259,14 @@ extern "C" void vh_table_destroy(vh_table* t) {
     for (auto p : c.bs_values) if (p) (void)hipFree(p);
   }
   if (t->d_stats) (void)hipFree(t->d_stats);
+  if (t->sync_ev) { (void)hipEventSynchronize(t->sync_ev); (void)hipEventDestroy(t->sync_ev); }
+  if (t->h_sync) (void)hipHostFree(t->h_sync);
+  if (t->h_stage) (void)hipHostFree(t->h_stage);
   if (t->d_packflag) (void)hipFree(t->d_packflag);
   for (auto& pk : t->packs) if (pk->base) (void)hipFree(pk->base);
   for (auto& nw : t->narrows) if (nw->base) (void)hipFree(nw->base);
-  if (t->d_packrows) (void)hipFree(t->d_packrows);
+  if (t->h_jobs) (void)hipHostFree(t->h_jobs);
+  if (t->derived_ev) (void)hipEventDestroy(t->derived_ev);
   delete t;
 }
 

@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass, field
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -130,6 +130,29 @@ class DeviceTable:
             if n is None:
                 n = len(a)
         capi.check(self.lib.vh_segment_sync(self.handle, seg, int(n or 0), ptrs))
+
+    def sync_batch(self, items: Sequence[Tuple]):
+        """vh_table_sync_batch. items: (seg, row_first, nrows, new_size, columns, flags) — `columns` are the segment's FULL column arrays
+        (numpy, table order; None = leave alone), exactly what vh_segment_sync takes; they must stay alive until the next query or sync."""
+        arr = (capi.SyncItem * len(items))()
+        keep = []
+        for k, (seg, row_first, nrows, new_size, columns, flags) in enumerate(items):
+            ptrs = (C.c_void_p * len(self.cols))()
+            for i, a in enumerate(columns):
+                if a is None or self.cols[i][1] >= capi.BITSET32:
+                    ptrs[i] = None
+                    continue
+                assert a.dtype == np.dtype(capi.ELEM_NP[self.cols[i][1]]) and a.flags["C_CONTIGUOUS"], (i, a.dtype)
+                ptrs[i] = a.ctypes.data
+            keep.append((ptrs, columns))
+            arr[k] = capi.SyncItem(int(seg), int(flags), int(row_first), int(nrows), int(new_size), ptrs)
+        capi.check(self.lib.vh_table_sync_batch(self.handle, arr, len(items)))
+        self._sync_keep = keep
+
+    def sync_stats(self):
+        v = [C.c_uint64() for _ in range(5)]
+        capi.check(self.lib.vh_table_sync_stats(self.handle, *[C.byref(x) for x in v]))
+        return dict(zip(("batches", "runs", "bytes_pulled", "bytes_staged", "bytes_dma"), [x.value for x in v]))
 
     def sync_bitset(self, seg: int, col: int, offsets: np.ndarray, values: np.ndarray):
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)

@@ -103,7 +103,8 @@ std::string AggQueryText(const std::string& table_json, const std::string& query
   // ---- the GPU path instead of ScanVisitor + PostAggVisitor
   o += "static const char kTable[] = R\"viya(" + table_json + ")viya\";\n";
   o += "static const char kQuery[] = R\"viya(" + query_json + ")viya\";\n";
-  o += "viya::shim::Session* session = viya::shim::Open(&table, kTable, kQuery);\n";
+  o += "viya::shim::Session* session = viya::shim::Open(&table, kTable, kQuery);   // this CALL's state: read_pool threads run this function side by side\n";
+  o += "struct SessionGuard { viya::shim::Session* s; ~SessionGuard() { viya::shim::Release(s); } } session_guard{session};\n";
   o += "uint32_t seg_index = 0;\n";
   o += "for (auto* s : table.store()->segments_copy()) {                      // scan.cc:42\n";
   o += " auto segment_size = s->size();                                       // scan.cc:43: the size() snapshot the query sees\n";
@@ -113,22 +114,23 @@ std::string AggQueryText(const std::string& table_json, const std::string& query
   for (auto* m : mets) { if (!ptrs.empty()) ptrs += ", "; ptrs += m->agg_type() == db::Column::BITSET ? std::string("nullptr") : "&segment->m._" + num(m->index()) + "[0]"; }
   if (hidden) ptrs += ", &segment->m._count[0]";
   o += " const void* cols[] = { " + ptrs + " };\n";
+  o += " viya::shim::Pin(session, seg_index, segment, sizeof(Segment));          // registered with the device once: later ranges are read in place\n";
   o += " viya::shim::Sync(session, seg_index, segment_size, cols);\n";
   if (any_bitset) {
-    o += " if (viya::shim::BitsetStale(session, seg_index, segment_size)) {   // rows appended, or a row's set grown in place (Touch), since the mirror saw them\n";
-    o += "  std::vector<uint64_t> offsets(segment_size + 1);\n";
+    o += " if (const uint64_t walk_rows = viya::shim::BitsetStale(session, seg_index, segment_size)) {   // rows appended, or a row's set grown in place (Touch), since the mirror saw them\n";
+    o += "  std::vector<uint64_t> offsets(walk_rows + 1);\n";
     for (auto* m : mets) {
       if (m->agg_type() != db::Column::BITSET) continue;
       const int n = bits_of(m);
       const std::string j = num(m->index());
       o += "  { std::vector<uint" + num(n * 8) + "_t> ids; offsets[0] = 0;\n";
-      o += "    for (size_t r = 0; r < segment_size; ++r) {\n";
+      o += "    for (size_t r = 0; r < walk_rows; ++r) {\n";
       o += "      const auto& roaring = segment->m._" + j + "[r].*get(viya_shim_detail::Roaring" + num(n) + "());\n";
       o += "      const uint64_t n = roaring.cardinality();\n";
       o += "      ids.resize(offsets[r] + n);\n";
       o += "      if (n) roaring.toUint" + num(n * 8) + "Array(ids.data() + offsets[r]);\n";
       o += "      offsets[r + 1] = offsets[r] + n;\n    }\n";
-      o += "    viya::shim::SyncBitset(session, seg_index, " + j + ", segment_size, offsets.data(), ids.data()); }\n";
+      o += "    viya::shim::SyncBitset(session, seg_index, " + j + ", walk_rows, offsets.data(), ids.data()); }\n";
     }
     o += " }\n";
   }
