@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--flags", type=int, default=0)
     ap.add_argument("--no-pack", action="store_true", help="ablation: no payload projection (survivors gather from the column arenas)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity gate (profiling runs)")
+    ap.add_argument("--no-predpack", action="store_true", help="ablation: narrow copies of the predicate columns (round 4's layout) instead of the bit-packed predicate projection")
     ap.add_argument("--no-warm", action="store_true", help="no vh_table_prepare: the first queries pay the first-use costs, the tuple pool lies where hipMalloc puts it")
     ap.add_argument("--no-reference-layout", action="store_true", help="skip the arena-only leg (profiling runs)")
     args = ap.parse_args()
@@ -258,7 +259,10 @@ def main():
     t_pack = time.time()
     if not args.no_pack:
         table.pack(table.gather_columns(plan))
-        table.narrow(table.filter_columns(plan))     # 8- / 16-bit copies of the predicate columns whose values fit (vh_table_narrow)
+        if args.no_predpack:
+            table.narrow(table.filter_columns(plan))     # 8- / 16-bit copies of the predicate columns whose values fit (vh_table_narrow)
+        else:
+            table.predpack(table.filter_columns(plan))   # the predicate columns as bit fields of one word per row, in byte planes (vh_table_predpack: C3 3 bytes per row)
     # first-use costs paid before anything is timed, as a database would at table-load time for its hot query shapes (vh_table_prepare:
     # the compile of the scan kernel for this shape, the derived layouts above if not asked for explicitly, a measured place for the tuple pool)
     warmed = 0 if args.no_warm else table.warm(plan)
@@ -351,14 +355,14 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong",
             "parity_checked": bool(checked), "parity": checked,
-            "vs_baseline": None, "dtype": "u32 predicates (compared as u8 / u16 where a narrow copy exists) / int64 + u32 integer sums", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u32 predicates (compared as bit fields of a packed word / u8 / u16 where such a copy exists) / int64 + u32 integer sums", "data": "synthetic",
             "config": {"workload": "%s: %s" % (w.name if world == 1 else w.name + " sharded (C4)", w.description),
                        "rows": total_rows, "segments": total_segments, "segment_rows": w.segment_rows,
                        "columns": len(w.columns), "table_bytes": total_rows * w.table_bytes_per_row,
                        "groups": last.ngroups, "passed_rows_rank0": last.passed_recs,
                        "table_path": last.path, "parallelism": ("segments sharded x%d, vh_query_agg_sharded: plan agreement + ncclReduce of the partial tables to rank 0 (%s transport)"
                                                                 % (world, "RCCL" if backend == "nccl" else "callbacks over " + backend)) if world > 1 else "1 GPU",
-                       "generate_seconds": round(t_gen, 3), "payload_projection": bool(last.packed), "narrow_predicates": bool(last.narrow),
+                       "generate_seconds": round(t_gen, 3), "payload_projection": bool(last.packed), "narrow_predicates": bool(last.narrow), "predicate_projection": bool(last.predpack), "streamed_payload": bool(last.streamed_payload),
                        "compiled_kernel": bool(last.jit), "prepared": not args.no_warm, "pool_placed_by_measurement": bool(warmed & 512),
                        "one_word_tuples": bool(warmed & 1024),
                        "pack_seconds": round(t_pack, 3), "device_bytes": table.info()[2]},
@@ -366,7 +370,8 @@ def main():
             # state), resident next to the table
             "derived_layout": {"one_time_seconds": round(t_pack, 4), "extra_device_bytes": max(0, table.info()[2] - total_rows * w.table_bytes_per_row // max(1, world)),
                                "table_bytes": total_rows * w.table_bytes_per_row // max(1, world),
-                               "what": "payload projection of the group + metric columns (vh_table_pack) and 8- / 16-bit copies of the predicate columns (vh_table_narrow)" if not args.no_pack else "none"},
+                               "what": ("payload projection of the group + metric columns (vh_table_pack) and " + ("8- / 16-bit copies of the predicate columns (vh_table_narrow)" if args.no_predpack else
+                                        "the predicate columns as bit fields of one word per row in byte planes (vh_table_predpack)")) if not args.no_pack else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": last.kernel,
@@ -375,6 +380,9 @@ def main():
                          "bref_over_t_GBs": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 if avg_kernel_ms > 0 else 0.0,
                          "frac_ref": algo_bytes / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if avg_kernel_ms > 0 else 0.0,
                          "traffic_write": traffic_write,
+                         # every byte the kernels moved (fetched x2 + written) over their time: what the memory system did, whatever the min rule credits
+                         "moved_GBs": (traffic + (traffic_write or 0)) / (avg_kernel_ms * 1e-3) / 1e9 if traffic and avg_kernel_ms > 0 else None,
+                         "frac_moved": (traffic + (traffic_write or 0)) / (avg_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and avg_kernel_ms > 0 else None,
                          "traffic_source": traffic_src, "traffic_head": traffic_head, "traffic_refused": traffic_why,
                          "kernel_sources": kernel_sources_hash(),
                          "note": "achieved = min(B_ref, B_meas) / mean HIP-event time of the scan kernel(s) on rank 0 "

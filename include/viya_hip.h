@@ -198,6 +198,11 @@ enum vh_plan_flags {
   VH_PLAN_NO_HP_PACK = 1u << 21,  /* ablation: a count-distinct's tuples keep their ids in words of their own (32 bytes) even when payload,
                                      two ids and their count would fit the tuple's second word (16 bytes) */
   VH_PLAN_NO_NARROW_TUPLES = 1u << 23, /* ablation: DENSE_PART keeps two-word tuples even when gid and values would fit one */
+  VH_PLAN_NO_PREDPACK = 1u << 24, /* ablation: predicate columns from their arenas / narrow copies even when a bit-packed predicate
+                                     projection (vh_table_predpack) holds them */
+  VH_PLAN_NO_QPAY = 1u << 25,     /* ablation: a survivor's values are always GATHERED by row, even where the compiled scan could stream the
+                                     bit-field records of a projection beside the predicate columns and queue the survivor's record */
+  VH_PLAN_FORCE_QPAY = 1u << 26,  /* testing: streamed records whenever the plan is eligible, whatever the selectivity */
   VH_PLAN_CARD32 = 1u << 22       /* the cardinality of a 32-bit-id bitset metric (count distinct) is delivered as a uint32 column instead of
                                      uint64 (it cannot exceed 2^32 - 1): vh_result_state_elem() tells what a state column holds */
 };
@@ -255,7 +260,10 @@ typedef struct vh_result_info {
                                 bit 7: the projection's records are compressed (integers at the width their values need);
                                 bit 8: the hashed partitioning's tuples were packed (16 bytes: payload, two ids and their count in one word);
                                 bit 9: the tuple pool lies in a scratch buffer chosen by measurement (vh_table_prepare);
-                                bit 10: DENSE_PART wrote one-word tuples (gid and values packed into 8 bytes) */
+                                bit 10: DENSE_PART wrote one-word tuples (gid and values packed into 8 bytes);
+                                bit 11: predicate columns streamed as byte planes of a bit-packed predicate projection (vh_table_predpack; bit 4 is set too);
+                                bit 12: the payload was STREAMED — 4-byte bit-field records beside the predicate columns, a survivor's record queued in its
+                                        row's place — not gathered (bits 3 and 7 are set too) */
   uint64_t returned_groups;  /* rows vh_result_copy delivers (= ngroups without HAVING) */
 } vh_result_info;
 
@@ -399,6 +407,16 @@ VH_API int vh_table_unpack(vh_table* t);
  * column the VH_AUTO_NARROW-th (default 3, 0 = never) query filters on while a quarter of the device stays
  * free. Columns that do not qualify are skipped silently. vh_table_unpack drops them too. */
 VH_API int vh_table_narrow(vh_table* t, const int32_t* cols, int32_t ncols);
+/* Bit-packed predicate projection. A narrow copy still spends whole bytes on a column: C3's three predicate columns carry 2 + 10 + 10 =
+ * 22 bits of information per row and cost 1 + 2 + 2 = 5 bytes through narrow copies (12 from the arenas). The projection keeps, for a SET of
+ * predicate columns, one word per row with every column as a bit field at the bits its recorded min / max need (non-negative integers, 32
+ * bits in all at most), stored as byte planes of 2 or 1 bytes per row (C3: 3 bytes per row). Only the per-query compiled scan kernels read it:
+ * they stream the planes, put a row's word together in registers and compare the fields in place — the comparisons are those the columns
+ * would get. It follows vh_segment_sync* / vh_table_sync_batch by row range like the other derived layouts, is dropped when a synced value
+ * needs more bits than its field (the stats say so), and is built unasked for a column set the compiled kernel filters on for the
+ * VH_AUTO_NARROW-th time (instead of narrow copies of those columns) while a quarter of the device stays free. A column set that would not
+ * get smaller is skipped silently. vh_table_unpack drops these too. */
+VH_API int vh_table_predpack(vh_table* t, const int32_t* cols, int32_t ncols);
 /* Copy a mirrored column back to the host (tests). */
 VH_API int vh_segment_read(vh_table* t, uint32_t seg, int32_t col, uint64_t nrows,
                            void* dst);

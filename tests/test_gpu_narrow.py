@@ -104,3 +104,114 @@ def test_copies_are_built_unasked_for_columns_queries_keep_filtering_on():
         assert run(tab, dt, q)[0].narrow is False
     finally:
         dt.close()
+
+
+JIT = capi.PLAN_FORCE_JIT
+
+
+@pytest.mark.parametrize("flags", [0, 64, 1, 16, 2, 64 | 8192, 8192])
+def test_c3_through_a_predicate_projection(flags):
+    """vh_table_predpack: C3's predicate columns as bit fields of one word per row (2 + 10 + 10 bits: a 2-byte and a 1-byte plane), streamed by
+    the compiled scan under every table organisation; the pre-built kernels (no compiled kernel asked for) never read it."""
+    from viyadb_amd import synth
+    from viyadb_amd.executor import AggPlan
+    w = synth.c3(segment_rows=200_000)
+    dt = synth.create_device_table(w, 3, 199_993)
+    try:
+        mk = lambda f: AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=f, groups_hint=w.plan.groups_hint)
+        dt.predpack(dt.filter_columns(mk(0)))
+        st = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 3, 199_993), w.query))
+        res = dt.query_agg(mk(flags | JIT))
+        compare(res, st, f"C3 predicate projection flags={flags}")
+        assert res.jit and res.predpack and res.narrow, (res.flags, res.kernel)
+        res = dt.query_agg(mk(flags | JIT | capi.PLAN_NO_PREDPACK))
+        compare(res, st, f"C3 arenas flags={flags}")
+        assert res.jit and not res.predpack
+        res = dt.query_agg(mk(flags | capi.PLAN_NO_JIT))
+        compare(res, st, f"C3 pre-built flags={flags}")
+        assert not res.predpack
+    finally:
+        dt.close()
+
+
+def test_predicate_projection_leaves_of_every_kind_and_types():
+    """IN lists, OR, NOT, literals beyond a field's range, columns of 1 / 2 / 4 / 8 bytes, a superset projection (a query that filters on
+    two of its three columns), and a set of columns that does not qualify (negative values)."""
+    rng = np.random.default_rng(13)
+    n = 60_000
+    tab = vo.Table({"name": "t", "segment_size": n, "dimensions": [{"name": "a", "type": "uint"}, {"name": "b", "type": "ushort"}, {"name": "c", "type": "ubyte"},
+                                                                  {"name": "e", "type": "ulong"}, {"name": "s", "type": "int"}, {"name": "g", "type": "uint"}],
+                    "metrics": [{"name": "v", "type": "long_sum"}, {"name": "count", "type": "count"}]})
+    for _ in range(3):
+        tab.add_segment_arrays([rng.integers(0, 900, n).astype(np.uint32), rng.integers(0, 3000, n).astype(np.uint16), rng.integers(0, 5, n).astype(np.uint8),
+                                rng.integers(0, 70, n).astype(np.uint64), rng.integers(-50, 50, n).astype(np.int32), rng.integers(0, 300, n).astype(np.uint32)],
+                               [rng.integers(-1000, 1000, n).astype(np.int64), np.ones(n, dtype=np.uint32)], None, n)
+    dt = mirror_table(tab)
+    base = {"dimensions": ["g"], "metrics": ["v", "count"]}
+    try:
+        dt.predpack([0, 1, 2, 3])                  # 10 + 12 + 3 + 7 = 32 bits: two 2-byte planes
+        q = dict(base, filter={"op": "and", "filters": [F("lt", "a", "300"), F("ge", "b", "1000"), F("ne", "c", "2"), F("le", "e", "40")]})
+        res, _ = run(tab, dt, q, flags=JIT)
+        assert res.predpack and res.jit
+        res, _ = run(tab, dt, dict(base, filter={"op": "and", "filters": [F("lt", "a", "100"), F("eq", "c", "1")]}), flags=JIT)     # two of the four columns
+        assert res.predpack
+        run(tab, dt, dict(base, filter={"op": "or", "filters": [{"op": "in", "column": "a", "values": ["3", "899", "1024", "70000"]},
+                                                               {"op": "not", "filter": F("le", "b", "2990")}, {"op": "in", "column": "e", "values": ["0", "69"]}]}), flags=JIT)
+        for flt in (F("lt", "a", "100000"), F("gt", "b", "4000"), F("eq", "a", "1024"), F("ne", "c", "200"), F("ge", "e", "5000000000")):
+            res, _ = run(tab, dt, dict(base, filter=flt), flags=JIT)
+            assert res.predpack
+        # a signed column with negative values has no bit field: the query reads its arena
+        res, _ = run(tab, dt, dict(base, filter={"op": "and", "filters": [F("lt", "a", "300"), F("gt", "s", "-10")]}), flags=JIT)
+        assert res.jit and not res.predpack
+    finally:
+        dt.close()
+
+
+def test_predicate_projection_follows_syncs_and_is_dropped_when_outgrown():
+    rng = np.random.default_rng(5)
+    n = 50_000
+    tab = _table(rng, n, hi_a=16, hi_b=3000)       # 4 + 12 bits: ONE 2-byte plane instead of a 1-byte and a 2-byte narrow copy
+    dt = mirror_table(tab, reserve=5)
+    q = {"dimensions": ["g"], "metrics": ["v", "count"], "filter": {"op": "and", "filters": [F("lt", "a", "9"), F("ge", "b", "1000"), F("ne", "a", "7")]}}
+    try:
+        dt.predpack([0, 1])
+        res, _ = run(tab, dt, q, flags=JIT)
+        assert res.predpack
+        # rows of a segment change in place (a batch) and a segment is re-synced whole: the planes follow by row range
+        seg = tab.segments[1]
+        seg["d"][0][1000:1900] = rng.integers(0, 16, 900).astype(np.uint32)
+        seg["d"][1][1000:1900] = rng.integers(0, 4096, 900).astype(np.uint32)
+        dt.sync_batch([(1, 1000, 900, n, [seg["d"][0], seg["d"][1], seg["d"][2], seg["m"][0], seg["m"][1]], 0)])
+        res, _ = run(tab, dt, q, flags=JIT)
+        assert res.predpack
+        seg = tab.segments[2]
+        seg["d"][0][:] = rng.integers(0, 16, n).astype(np.uint32)
+        dt.sync_segment(2, [seg["d"][0], seg["d"][1], seg["d"][2], seg["m"][0], seg["m"][1]], n)
+        res, _ = run(tab, dt, q, flags=JIT)
+        assert res.predpack
+        # a new segment whose values need more bits than the fields have: the projection goes, answers stay right
+        tab.add_segment_arrays([rng.integers(0, 5000, n).astype(np.uint32), rng.integers(0, 3_000_000, n).astype(np.uint32), rng.integers(0, 300, n).astype(np.uint32)],
+                               [rng.integers(-1000, 1000, n).astype(np.int64), np.ones(n, dtype=np.uint32)], None, n)
+        seg = tab.segments[3]
+        dt.sync_segment(3, [seg["d"][0], seg["d"][1], seg["d"][2], seg["m"][0], seg["m"][1]], n)
+        for _ in range(5):                         # (13 + 22 bits no longer fit one 32-bit word: none is built again either)
+            res, _ = run(tab, dt, q, flags=JIT)
+            assert not res.predpack
+    finally:
+        dt.close()
+
+
+def test_predicate_projection_is_built_unasked_where_the_compiled_kernel_runs():
+    rng = np.random.default_rng(6)
+    n = 50_000
+    tab = _table(rng, n, hi_a=16, hi_b=3000)
+    dt = mirror_table(tab)
+    q = {"dimensions": ["g"], "metrics": ["v", "count"], "filter": {"op": "and", "filters": [F("lt", "a", "9"), F("ge", "b", "1000")]}}
+    try:
+        seen = [run(tab, dt, q, flags=JIT)[0].predpack for _ in range(5)]
+        assert seen[0] is False and seen[-1] is True, seen
+        assert not run(tab, dt, q)[0].predpack         # a table this small gets no compiled kernel unasked: arenas / narrow copies
+        dt.unpack()
+        assert run(tab, dt, q, flags=JIT)[0].predpack is False
+    finally:
+        dt.close()

@@ -349,3 +349,60 @@ def test_bit_field_records_follow_syncs_outgrown_bits_and_negative_values():
         assert res.packed and res.packed_compressed
     finally:
         dt.close()
+
+
+@pytest.mark.parametrize("flags,path", [(0, "dense_global"), (64, "dense_part"), (1, "hash"), (2, "dense_global"), (16 | 32, "dense_global"), (1 | 2048, "hash")])
+def test_c3_with_streamed_payload_records(flags, path):
+    """The compiled compacting scan STREAMS a bit-field projection's 4-byte records beside the predicate columns and queues a survivor's record
+    in its row's place (VhJitShape::qpay): no gathers. Same answers under every table organisation, with and without the predicate
+    projection; off below the selectivity where gathers are cheaper, and on request (VH_PLAN_NO_QPAY)."""
+    from viyadb_amd import synth
+    from viyadb_amd.executor import AggPlan
+    from tests.parity import build_oracle_table
+    w = synth.c3(segment_rows=250_000)
+    nseg, rows = 4, 249_991
+    dt = synth.create_device_table(w, nseg, rows)
+    try:
+        st = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, nseg, rows), w.query))
+        mk = lambda f: AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=f, groups_hint=w.plan.groups_hint)
+        dt.pack(dt.gather_columns(mk(0)), compressed=True)
+        base = flags | capi.PLAN_FORCE_JIT | PACK
+        base |= capi.PLAN_FORCE_QPAY                        # (5 % pass: below the selectivity from which the library streams unasked)
+        res = dt.query_agg(mk(base))
+        compare(res, st, f"streamed payload flags={flags}")
+        assert res.path == path and res.jit and res.packed and res.packed_compressed and res.streamed_payload, (res.flags, res.kernel)
+        res = dt.query_agg(mk((base & ~capi.PLAN_FORCE_QPAY) | capi.PLAN_NO_QPAY))
+        compare(res, st, f"gathered payload flags={flags}")
+        assert res.packed and not res.streamed_payload
+        dt.predpack(dt.filter_columns(mk(0)))
+        res = dt.query_agg(mk(base))
+        compare(res, st, f"streamed payload + predicate projection flags={flags}")
+        assert res.streamed_payload and res.predpack
+    finally:
+        dt.close()
+
+
+def test_streamed_payload_follows_the_selectivity():
+    from viyadb_amd import synth
+    from viyadb_amd.executor import AggPlan
+    from tests.parity import build_oracle_table
+    w = synth.c3(segment_rows=250_000)
+    nseg, rows = 4, 250_000
+    dt = synth.create_device_table(w, nseg, rows)
+    try:
+        ot = build_oracle_table(w, nseg, rows)
+        dt.pack(dt.gather_columns(AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics)), compressed=True)
+        for lit, dlit, want in ((30, 553, False), (447, 553, False), (1000, 0, True)):      # ~0.3 %, ~5 % (gathers are cheaper: measured), 25 % of the rows pass
+            flt = [("rel", 2, capi.OP_EQ, 1), ("rel", 3, capi.OP_LT, lit), ("rel", 4, capi.OP_GE, dlit), ("and", 3)]
+            q = dict(w.query, filter={"op": "and", "filters": [{"op": "eq", "column": "d2", "value": "1"}, {"op": "lt", "column": "d3", "value": str(lit)},
+                                                              {"op": "ge", "column": "d4", "value": str(dlit)}]})
+            res = dt.query_agg(AggPlan(filter=flt, groups=w.plan.groups, metrics=w.plan.metrics, flags=capi.PLAN_FORCE_JIT | PACK, groups_hint=w.plan.groups_hint))
+            compare(res, vo.scan_aggregate(vo.parse_query(ot, q)), f"d3 < {lit}")
+            assert res.streamed_payload == want, (lit, res.flags)
+        # every row passes, GROUP BY through the records: still the compacting kernel, 4 bytes per row instead of 20 from the arenas
+        q = dict(w.query, filter={"op": "ge", "column": "d3", "value": "0"})
+        res = dt.query_agg(AggPlan(filter=[("rel", 3, capi.OP_GE, 0)], groups=w.plan.groups, metrics=w.plan.metrics, flags=capi.PLAN_FORCE_JIT | PACK | 64, groups_hint=w.plan.groups_hint))
+        compare(res, vo.scan_aggregate(vo.parse_query(ot, q)), "all rows")
+        assert res.streamed_payload and res.path == "dense_part"
+    finally:
+        dt.close()

@@ -23,7 +23,9 @@ SHAPES = {0: "C3: narrow predicate copies, record gathers, tuples for DENSE_PART
           8: "C5 with packed 16-byte tuples (payload, two ids and their count in one word)",
           9: "C3 with one-word tuples for DENSE_PART (gid, SUM value and COUNT value in 29 bits)",
           10: "C3 with the payload in a 4-byte bit-field record",
-          11: "C2 in the no-compaction form (a lane keeps its own rows, payload columns with vector loads)"}
+          11: "C2 in the no-compaction form (a lane keeps its own rows, payload columns with vector loads)",
+          12: "C3 with the predicate columns as bit fields of a predicate projection's byte planes (3 bytes per row)",
+          13: "C3 with the payload records streamed beside the predicate planes (a survivor's record queued in its row's place, no gathers)"}
 
 
 def _compile(which, tmp_path):

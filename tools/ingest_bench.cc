@@ -54,6 +54,7 @@ static double query_ms(vh_table* t, const vh_plan* p, uint64_t* groups = nullptr
   return b - a;
 }
 
+static bool g_quick = false;      // profiling runs: registered sources, 1000 dirty segments only, no shim part
 static void part_a(uint32_t nseg, uint64_t seg_rows) {
   vh_table* t = nullptr;
   CHECK(vh_table_create(kCols, NCOL, seg_rows, nseg, &t));
@@ -71,7 +72,7 @@ static void part_a(uint32_t nseg, uint64_t seg_rows) {
   for (int registered = 1; registered >= 0; --registered)
     for (int whole_rows = 0; whole_rows <= 1; ++whole_rows)
       for (uint32_t dirty : {1u, 100u, 1000u}) {
-        if (dirty > nseg) continue;
+        if (dirty > nseg || (g_quick && (dirty != 1000u || !registered))) continue;
         const uint64_t n = batch_rows / dirty;
         // host memory of the touched rows only: rows [0, n) of every touched segment, read back from the mirror so that the batch changes
         // nothing a query could see (col_ptrs are the BASES of the segment's column arrays: rows [0, n) start there)
@@ -184,9 +185,11 @@ static void part_b(int pin) {
 int main(int argc, char** argv) {
   const uint32_t nseg = argc > 1 ? (uint32_t)atoi(argv[1]) : 1000;
   const uint64_t seg_rows = argc > 2 ? strtoull(argv[2], nullptr, 10) : 1000000;
+  g_quick = argc > 3 && !strcmp(argv[3], "quick");
   CHECK(vh_init(0));
   printf("{\n \"tool\": \"tools/ingest_bench.cc\",\n");
   part_a(nseg, seg_rows);
+  if (g_quick) { printf(" \"shim\": []\n}\n"); return 0; }
   printf(" \"shim\": [\n");
   part_b(1);
   printf(",\n");

@@ -36,6 +36,18 @@ struct VhJitShape {
                                         // with the same 16-byte vector loads as the predicates (all of a step's at once), passing rows update the LDS table directly
   int npred = 0;
   VhJitPred pred[VJ_MAX_PRED];
+  // Bit-packed predicate projection (vh_table_predpack): the predicate columns are bit fields of ONE word per row, kept as `pp_nplanes` byte
+  // planes of 1 or 2 bytes per row (plane q holds the word's bits from pp_pos[q] on). The kernel streams the planes instead of the columns
+  // (C3: 3 bytes per row instead of 5 through narrow copies, 12 through the arenas), puts a row's word together in registers and compares
+  // the fields in place. pred[k].slot / width are then unused; pp_off / pp_bits say where predicate column k lies in the word.
+  int pp_nplanes = 0;
+  struct Plane { int slot, width, pos; } pp_plane[4];
+  int pp_off[VJ_MAX_PRED] = {}, pp_bits[VJ_MAX_PRED] = {};
+  // Streamed payload: every group / metric value of the plan is a bit field of ONE 4-byte record per row (a bit-field projection, VhPack::bits).
+  // Instead of queueing a survivor's ROW and gathering its record afterwards (a random 128-byte line per survivor: at 5 % selectivity 81 % of
+  // the projection's lines are fetched anyway, at the rate random lines come in), the scan streams the records with the predicate planes —
+  // 16-byte loads like any 4-byte column — and queues the survivor's RECORD: the drain unpacks it out of LDS, no gather at all.
+  int qpay = 0, qpay_slot = -1;          // 4: on (the record's bytes); the slot the records are streamed from
   std::vector<VhProgOp> prog;           // postfix filter; VhProgOp::pslot indexes pred[], ::lit the literal pool
   int nlits = 0;
   int ng = 0, nm = 0;
@@ -49,6 +61,8 @@ struct VhJitKernel {
   hipFunction_t fn = nullptr;
   hipFunction_t fn_agg = nullptr;   // hashed partitioning: the ranges' aggregation compiled for the same shape (`<name>_hpagg`, vh_hpart.h)
   size_t agg_lds_set = 0;
+  hipFunction_t fn_pagg = nullptr;  // DENSE_PART: phase 2 compiled for the same shape (`<name>_pagg`, vj_part_agg); nullptr: the pre-built part_agg_kernel
+  size_t pagg_lds_set = 0;
   std::string name;          // kernel symbol as rocprofv3 prints it
   double compile_ms = 0;     // 0: came out of the disk cache
   int vgprs = 0, sgprs = 0;
@@ -64,6 +78,7 @@ VhJitKernel* vh_jit_get(const VhJitShape& s, std::string* err);
 int vh_jit_occupancy(VhJitKernel* k, int block, size_t lds);
 hipError_t vh_jit_launch(VhJitKernel* k, const VhPlanDev& P, int grid, int block, size_t lds, hipStream_t s);
 hipError_t vh_jit_launch_hpagg(VhJitKernel* k, const VhPlanDev& P, const void* d_hpargs, int blocks_per_partition, int a_first, int grid, size_t lds, hipStream_t s);
+hipError_t vh_jit_launch_pagg(VhJitKernel* k, const VhPlanDev& P, int blocks_per_part, size_t lds, hipStream_t s);
 #define VH_HP_AGG_BLOCK 512
 // code object for a shape without loading it (no GPU needed: build-time cache warm-up, CPU tests)
 int vh_jit_compile_only(const VhJitShape& s, std::vector<char>* code, std::string* log);

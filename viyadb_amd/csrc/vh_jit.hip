@@ -52,6 +52,10 @@ std::string VhJitShape::key() const {
   put(mode); put(block); put(scope); put(xcd); put(carrier); put(tw); put(key_words); put(lds_hash); put(gid32); put(ablate); put(stage); put(hpart); put(bitset_j); put(hp_pack); put(hp_pbits); put(hp_idbits); put(gid_bits); put(bs_off32);
   put(lanes); put(npred);
   for (int i = 0; i < npred; ++i) { put(pred[i].slot); put(pred[i].type); put(pred[i].width); }
+  put(qpay); put(qpay_slot);
+  put(pp_nplanes);
+  for (int q = 0; q < pp_nplanes; ++q) { put(pp_plane[q].slot); put(pp_plane[q].width); put(pp_plane[q].pos); }
+  if (pp_nplanes) for (int i = 0; i < npred; ++i) { put(pp_off[i]); put(pp_bits[i]); }
   put((long long)prog.size());
   for (const VhProgOp& o : prog) { put(o.w0); put(o.w1 & 0xFFFFFF00u); put(o.lit()); }    // (slot() of a leaf is implied by its pslot)
   put(nlits); put(ng); put(nm);
@@ -93,9 +97,16 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   std::string t;
   t += "// generated by vh_jit.hip for one plan shape; the frame is vh_jit_body.h\n#define VH_HPART_KERNELS\n#include \"vh_jit_body.h\"\n#include \"vh_hpart.h\"\n";
   t += "typedef uint32_t vj_u32x2 __attribute__((ext_vector_type(2)));\n#define vj_b(x) __builtin_amdgcn_ballot_w64(x)\n";
-  // ---- packed predicate registers: column p occupies v[base[p] .. base[p] + 4 * width) of every lane
-  int base[VJ_MAX_PRED] = {}, nv = 0;
-  for (int p = 0; p < s.npred; ++p) { base[p] = nv; nv += VH_SUBSTEPS * s.pred[p].width; }
+  // ---- packed predicate registers: stream p (a predicate column, or a plane of the bit-packed predicate projection) occupies
+  //      v[base[p] .. base[p] + 4 * width) of every lane
+  struct Stream { int slot, width; };
+  std::vector<Stream> streams;
+  if (s.pp_nplanes) for (int q = 0; q < s.pp_nplanes; ++q) streams.push_back(Stream{s.pp_plane[q].slot, s.pp_plane[q].width});
+  else for (int p = 0; p < s.npred; ++p) streams.push_back(Stream{s.pred[p].slot, s.pred[p].width});
+  const int qpay_stream = s.qpay ? (int)streams.size() : -1;
+  if (s.qpay) streams.push_back(Stream{s.qpay_slot, s.qpay});      // the payload records ride along with the predicate streams
+  int base[VJ_MAX_PRED + 1] = {}, nv = 0;
+  for (size_t p = 0; p < streams.size(); ++p) { base[p] = nv; nv += VH_SUBSTEPS * streams[p].width; }
   const int nva = nv ? nv : 1;
   t += "struct VJ {\n";
   t += vj_fmt("  static constexpr int MODE = %d, BLOCK = %d, SCOPE = %d, NV = %d, NG = %d, NM = %d, TW = %d, KEY_WORDS = %d, CARRIER = %d;\n",
@@ -107,6 +118,7 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   t += vj_fmt("  static constexpr int GID_BITS = %d;\n", s.gid_bits);
   t += vj_fmt("  static constexpr bool BS_OFF32 = %s;\n", s.bs_off32 ? "true" : "false");
   t += vj_fmt("  static constexpr bool LANES = %s;\n", s.lanes ? "true" : "false");
+  t += vj_fmt("  static constexpr int QPAY = %d;\n", s.qpay);
   {
     std::vector<int> a, b, c, d, e, f;
     for (int i = 0; i < s.ng; ++i) { a.push_back(s.g[i].type); b.push_back(s.g[i].gran); c.push_back(s.g[i].nroll); d.push_back(s.g[i].micro); e.push_back(s.g[i].key_word); f.push_back(s.g[i].key_shift); }
@@ -177,7 +189,23 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   { bool first = true; for (auto& kv : lit_decl) { t += first ? " : " : ", "; first = false; t += kv.second.substr(kv.second.find('|') + 1); } }
   t += " { (void)P; }\n  };\n";
   // ---- accessors: the value of predicate column p in row slot I (I = 4 * sub-step + row of the lane's four), in the column's own type
-  for (int p = 0; p < s.npred; ++p) {
+  if (s.pp_nplanes) {
+    // the row's word out of its planes (the compiler turns the byte / half-word picks into v_perm / SDWA selects), then each column as a bit field
+    t += vj_fmt("  template <int I> static __device__ __forceinline__ uint32_t ppw(const uint32_t (&v)[%d]) {\n    return ", nva);
+    for (int q = 0; q < s.pp_nplanes; ++q) {
+      if (q) t += " | ";
+      std::string e = s.pp_plane[q].width == 1 ? vj_fmt("((v[%d + (I >> 2)] >> (8 * (I & 3))) & 0xFFu)", base[q])
+                                               : vj_fmt("((v[%d + (I >> 2) * 2 + ((I & 3) >> 1)] >> (16 * (I & 1))) & 0xFFFFu)", base[q]);
+      t += s.pp_plane[q].pos ? "(" + e + vj_fmt(" << %d)", s.pp_plane[q].pos) : e;
+    }
+    t += ";\n  }\n";
+    for (int p = 0; p < s.npred; ++p) {
+      const char* T = vj_ctype(s.pred[p].type);
+      t += vj_fmt("  template <int I> static __device__ __forceinline__ %s c%d(const uint32_t (&v)[%d]) { return (%s)((ppw<I>(v) >> %d) & 0x%Xu); }\n",
+                  T, p, nva, T, s.pp_off[p], s.pp_bits[p] >= 32 ? 0xFFFFFFFFu : ((1u << s.pp_bits[p]) - 1u));
+    }
+  }
+  for (int p = 0; p < s.npred && !s.pp_nplanes; ++p) {
     const VhJitPred& c = s.pred[p];
     const char* T = vj_ctype(c.type);
     t += vj_fmt("  template <int I> static __device__ __forceinline__ %s c%d(const uint32_t (&v)[%d]) {\n", T, p, nva);
@@ -195,10 +223,12 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   }
   t += vj_fmt("  template <int I> static __device__ __forceinline__ uint64_t pass(const Lits& L, const uint32_t (&v)[%d], bool& p) {\n    (void)L; (void)v;\n    p = ", nva) + filter_bool +
        ";\n    return " + filter_mask + ";\n  }\n";
+  if (s.qpay)     // the record of row slot I, as it came in with the step's loads: what a passing row leaves in the wave's queue
+    t += vj_fmt("  template <int I> static __device__ __forceinline__ uint32_t payload(const uint32_t (&v)[%d]) { return v[%d + I]; }\n", nva, base[qpay_stream]);
   // ---- the packed loads of one wave step: 4 consecutive rows per lane and sub-step, naturally aligned, non-temporal
   t += vj_fmt("  template <bool FULL> static __device__ __forceinline__ void preload(const VhPlanDev& P, uint32_t seg, uint32_t row_l, uint32_t seg_rows, uint32_t (&v)[%d]) {\n    (void)P; (void)seg; (void)row_l; (void)seg_rows; (void)v;\n", nva);
-  for (int p = 0; p < s.npred; ++p) {
-    const VhJitPred& c = s.pred[p];
+  for (size_t p = 0; p < streams.size(); ++p) {
+    const Stream& c = streams[p];
     t += vj_fmt("    {\n      const char* col = P.colbase[%d] + (uint64_t)seg * P.colstride[%d];\n#pragma unroll\n      for (int k = 0; k < VH_SUBSTEPS; ++k) {\n        const uint32_t r = row_l + k * 256u;\n        if (FULL || r < seg_rows) {\n", c.slot, c.slot);
     const int b = base[p];
     if (c.width == 1) t += vj_fmt("          v[%d + k] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(col + r));\n", b);
@@ -299,6 +329,13 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   for (int i = 0; i < s.ng; ++i) t += vj_fmt("    gv[%d] = %s;\n", i, value(&s.g[i]).c_str());
   for (int j = 0; j < s.nm; ++j) t += vj_fmt("    mv[%d] = %s;\n", j, value(&s.m[j]).c_str());
   t += "  }\n";
+  if (s.qpay) {   // ... and the same values out of a QUEUED record (every column is a bit field of record 0's word)
+    t += vj_fmt("  static __device__ __forceinline__ void unpack(uint32_t rec, uint64_t (&gv)[%d], uint64_t (&mv)[%d]) {\n    const uint64_t w0 = rec; const uint32_t seg = 0, row = 0; (void)seg; (void)row; (void)w0;\n",
+                s.ng ? s.ng : 1, s.nm ? s.nm : 1);
+    for (int i = 0; i < s.ng; ++i) t += vj_fmt("    gv[%d] = %s;\n", i, value(&s.g[i]).c_str());
+    for (int j = 0; j < s.nm; ++j) t += vj_fmt("    mv[%d] = %s;\n", j, value(&s.m[j]).c_str());
+    t += "  }\n";
+  }
   if (s.lanes) {
     // ---- the no-compaction form (scan_agg_lanes_kernel's, compiled): a step's group and metric values for the lane's own 16 rows, every
     //      column with ONE aligned load per sub-step out of its arena (16 bytes for 4-byte columns, two for 8-byte ones, 8 / 4 bytes for 2- / 1-byte ones), all issued
@@ -329,6 +366,9 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   }
   t += "};\n";
   t += vj_fmt("extern \"C\" __global__ __launch_bounds__(%d) void %s(const VhPlanDev P) { vj_scan<VJ>(P); }\n", s.block, kernel_name);
+  // DENSE_PART: phase 2 — the ranges' aggregation in LDS — knows the same tuple layout (vj_part_agg)
+  if (s.mode == VH_MODE_DENSE_PART)
+    t += vj_fmt("extern \"C\" __global__ __launch_bounds__(1024) void %s_pagg(const VhPlanDev P, int blocks_per_part) { vj_part_agg<VJ, 1024>(P, blocks_per_part); }\n", kernel_name);
   // hashed partitioning: the kernel at the other end of the tuples — the ranges' aggregation in LDS (vh_hpart.h) — knows the same shape
   if (s.hpart)
     t += vj_fmt("extern \"C\" __global__ __launch_bounds__(%d) void %s_hpagg(const VhPlanDev P, const VhHpArgs* __restrict__ HA, int bpp, int a_first) { hp_aggregate_body<VJ, %d>(P, HA, bpp, a_first); }\n",
@@ -555,6 +595,7 @@ VhJitKernel* vh_jit_get(const VhJitShape& s, std::string* err) {
     if (err) *err = e->err;
     return nullptr;
   }
+  if (s.mode == VH_MODE_DENSE_PART && hipModuleGetFunction(&k->fn_pagg, k->mod, (name + "_pagg").c_str()) != hipSuccess) { (void)hipGetLastError(); k->fn_pagg = nullptr; }      // (the pre-built phase 2 answers then)
   k->name = name;
   k->compile_ms = ms;
   (void)hipFuncGetAttribute(&k->vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->fn);
@@ -579,6 +620,16 @@ hipError_t vh_jit_launch_hpagg(VhJitKernel* k, const VhPlanDev& P, const void* d
   return hipModuleLaunchKernel(k->fn_agg, (unsigned)grid, 1, 1, VH_HP_AGG_BLOCK, 1, 1, (unsigned)lds, s, args, nullptr);
 }
 
+hipError_t vh_jit_launch_pagg(VhJitKernel* k, const VhPlanDev& P, int blocks_per_part, size_t lds, hipStream_t s) {
+  if (!k->fn_pagg) return hipErrorInvalidDeviceFunction;
+  if (lds > k->pagg_lds_set) {
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k->fn_pagg), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k->pagg_lds_set = lds;
+  }
+  void* args[] = {const_cast<VhPlanDev*>(&P), &blocks_per_part};
+  return hipModuleLaunchKernel(k->fn_pagg, (unsigned)(P.nfine * blocks_per_part), 1, 1, 1024, 1, 1, (unsigned)lds, s, args, nullptr);
+}
+
 hipError_t vh_jit_launch(VhJitKernel* k, const VhPlanDev& P, int grid, int block, size_t lds, hipStream_t s) {
   void* args[] = {const_cast<VhPlanDev*>(&P)};
   return hipModuleLaunchKernel(k->fn, (unsigned)grid, 1, 1, (unsigned)block, 1, 1, (unsigned)lds, s, args, nullptr);
@@ -598,12 +649,14 @@ static bool vj_canonical(int which, VhJitShape* s) {
   VhJitShape& S = *s;
   auto col = [](int slot, int type, int pitch, int rec, int off, int sext) { VhJitCol c; c.slot = slot; c.type = type; c.pitch = pitch; c.rec = rec; c.off = off; c.sext = sext; return c; };
   switch (which) {
+    case 13:    // ... case 12 with the payload records STREAMED beside the predicate planes and queued in the rows' place (no gathers)
+    case 12:    // ... case 10 with the predicate columns out of a bit-packed predicate projection: d2 (2 bits) | d3 (10) | d4 (10) = a 2-byte and a 1-byte plane
     case 10:    // ... case 9 with the payload in a 4-byte BIT-FIELD record: d0 in 10 bits, d1 in 7, m0 in 10, count in 2
     case 9:     // ... case 7 with ONE-word tuples: gid in 17 bits, the SUM's value in 10, the COUNT's in 2
     case 7:     // ... case 0 with the payload from a compressed 8-byte record: m0 (i64) in 4 bytes, d0 in 2, d1 and count in 1 each
     case 0:     // C3: d2 == a & d3 < b & d4 >= c on narrow copies (1, 2, 2 bytes), payload from a 32-byte record, tuples for DENSE_PART
     case 1: {   // ... the same from the 4-byte arenas, straight into the dense HBM table (what an eighth of the table runs)
-      const bool part = which == 0 || which == 7 || which == 9 || which == 10;
+      const bool part = which == 0 || which == 7 || which == 9 || which == 10 || which == 12 || which == 13;
       S.mode = part ? VH_MODE_DENSE_PART : VH_MODE_DENSE_GLOBAL; S.block = 256; S.scope = __HIP_MEMORY_SCOPE_AGENT; S.carrier = 1; S.tw = part ? 2 : 1; S.gid32 = 1; S.stage = part ? 16 : 0;
       S.npred = 3;
       S.pred[0] = VhJitPred{part ? 7 : 0, VH_U32, part ? 1 : 4}; S.pred[1] = VhJitPred{part ? 8 : 1, VH_U32, part ? 2 : 4}; S.pred[2] = VhJitPred{part ? 9 : 2, VH_U32, part ? 2 : 4};
@@ -613,8 +666,15 @@ static bool vj_canonical(int which, VhJitShape* s) {
         S.g[0] = col(10, VH_U32, 32, 0, 8, 1); S.g[1] = col(11, VH_U32, 32, 0, 12, 1);
         S.m[0] = col(12, VH_I64, 32, 0, 0, 0); S.m[0].sop = SOP_ADD64; S.m[0].tword = 1; S.m[0].tshift = 0;
         S.m[1] = col(13, VH_U32, 32, 0, 16, 0); S.m[1].sop = SOP_ADD32P; S.m[1].tword = 0; S.m[1].tshift = 32;
-        if (which == 9 || which == 10) { S.tw = 1; S.gid_bits = 17; S.m[0].tword = 0; S.m[0].tshift = 17; S.m[0].tbits = 10; S.m[1].tword = 0; S.m[1].tshift = 27; S.m[1].tbits = 2; }
-        if (which == 10) {
+        if (which == 9 || which == 10 || which == 12 || which == 13) { S.tw = 1; S.gid_bits = 17; S.m[0].tword = 0; S.m[0].tshift = 17; S.m[0].tbits = 10; S.m[1].tword = 0; S.m[1].tshift = 27; S.m[1].tbits = 2; }
+        if (which == 13) { S.qpay = 4; S.qpay_slot = 10; }
+        if (which == 12 || which == 13) {
+          S.pp_nplanes = 2;
+          S.pp_plane[0] = {7, 2, 0}; S.pp_plane[1] = {8, 1, 16};
+          S.pp_off[0] = 0; S.pp_bits[0] = 2; S.pp_off[1] = 2; S.pp_bits[1] = 10; S.pp_off[2] = 12; S.pp_bits[2] = 10;
+          for (int k = 0; k < 3; ++k) { S.pred[k].slot = -1; S.pred[k].width = 0; }
+        }
+        if (which == 10 || which == 12 || which == 13) {
           for (VhJitCol* c : {&S.g[0], &S.g[1], &S.m[0], &S.m[1]}) { c->pitch = 4; c->bits = 4; }
           S.g[0].off = 0; S.g[0].stored = 10; S.g[1].off = 10; S.g[1].stored = 7; S.m[0].off = 17; S.m[0].stored = 10; S.m[1].off = 27; S.m[1].stored = 2;
         }

@@ -84,6 +84,8 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
     for (int i = 0; i < NG; ++i) gv[i] = P.g[i].lo + (row & 63u);
 #pragma unroll
     for (int j = 0; j < NM; ++j) mv[j] = row;
+  } else if constexpr (J::QPAY != 0) {
+    J::unpack(row, gv, mv);            // `row` IS the survivor's record (vj_slot queued it): nothing to fetch
   } else {
     J::gather(P, seg, row, gv, mv);    // every load of the survivor is issued before the first value is looked at
   }
@@ -330,7 +332,10 @@ __device__ __forceinline__ void vj_slot(const typename J::Lits& L, const uint32_
   bool p;
   uint64_t bal = J::template pass<I>(L, v, p);
   if (!FULL) { const bool in = row < seg_rows; bal &= __builtin_amdgcn_ballot_w64(in); p = p & in; }
-  if (p) q[__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, cnt))] = row;
+  // (streamed payload, J::QPAY: the passing row leaves its RECORD in the queue — it came in with the step's loads — not its number)
+  uint32_t entry = row;
+  if constexpr (J::QPAY != 0) entry = J::template payload<I>(v);
+  if (p) q[__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, cnt))] = entry;
   cnt += (uint32_t)__popcll(bal);
 }
 template <class J, bool FULL, int I = 0>
@@ -504,6 +509,128 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
         const uint64_t bits = vh_sop_bytes(J::m_sop[j]) == 4 ? reinterpret_cast<uint32_t*>(lds + P.m[j].lds_off)[g]
                                                              : reinterpret_cast<uint64_t*>(lds + P.m[j].lds_off)[g];
         vh_state_update<J::SCOPE>(P.m[j].state, xo + g, J::m_sop[j], bits);
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------- DENSE_PART phase 2, compiled for the plan shape (`<kernel>_pagg`)
+// part_agg_kernel (vh_kernels.h) with the tuple layout as constants: how many words a tuple has, where the gid ends, which word and shift
+// every metric's value has, how wide it is, which state operation takes it and whether a state carries the presence flag — the pre-built
+// kernel finds all of that out per launch (and, outside its two hand-written fast cases, per tuple). Same grid, same LDS layout
+// (VhPlanDev::m[j].lds_off), same flush: the host launches one or the other (src/codegen/db/store.cc:131-161 is what both compute).
+template <class J, int BLOCK>
+__device__ __forceinline__ void vj_part_agg(const VhPlanDev& P, int blocks_per_part) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NM = J::NM, TW = J::TW, GB = J::GID_BITS;
+  constexpr bool carried = J::CARRIER >= 0;
+  constexpr uint64_t gid_mask = GB ? (1ull << GB) - 1ull : 0xFFFFFFFFull;
+  const int part = blockIdx.x / blocks_per_part, b = blockIdx.x % blocks_per_part;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = BLOCK / 64;
+  const uint64_t gpp = 1ull << P.agg_shift;
+  const uint64_t g0 = (uint64_t)part << P.agg_shift;
+  const uint64_t ng = g0 >= P.G ? 0 : (P.G - g0 < gpp ? P.G - g0 : gpp);
+  char* mstate[NM ? NM : 1];
+#pragma unroll
+  for (int j = 0; j < NM; ++j) {
+    mstate[j] = lds + P.m[j].lds_off;
+    const uint64_t ident = P.m[j].ident;
+    if (vh_sop_bytes(J::m_sop[j]) == 4) { for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint32_t*>(mstate[j])[g] = (uint32_t)ident; }
+    else { for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint64_t*>(mstate[j])[g] = ident; }
+  }
+  if (!carried) for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
+  __syncthreads();
+  const bool two = P.nlevel == 2;
+  uint32_t first = 0, total;
+  if (two) {
+    const uint32_t lo = P.l2[part >> 6], hi = P.l2[(part >> 6) + 1], used = P.l2[VH_L2_NEXT + (part >> 6)];
+    first = lo;
+    total = lo + (used < hi - lo ? used : hi - lo);
+  } else {
+    const unsigned long long allocated = P.counters[5];
+    total = allocated < P.max_extents ? (uint32_t)allocated : P.max_extents;
+  }
+  const uint8_t want = (uint8_t)(two ? (part & 63) : part);
+  const uint8_t* tags = two ? P.extent_part2 : P.extent_part;
+  const uint16_t* missing = two ? P.extent_missing2 : P.extent_missing;
+  const uint64_t* pool = two ? P.tuples2 : P.tuples;
+  const uint32_t ext_tuples = (uint32_t)(two ? P.ext_tuples2 : P.ext_tuples), ext_stride = (uint32_t)(two ? P.ext_tuples2 : P.ext_stride);
+  const uint32_t gsz = vh_tag_group(total - first, (uint32_t)blocks_per_part * nwaves);
+  for (uint32_t c0 = first + ((uint32_t)b * nwaves + wave) * gsz; c0 < total; c0 += (uint32_t)blocks_per_part * nwaves * gsz) {
+    const bool in = (uint32_t)lane < gsz && c0 + lane < total;
+    const uint8_t tag = in ? tags[c0 + lane] : (uint8_t)0xFF;
+    const uint32_t fill = in ? ext_tuples - missing[c0 + lane] : 0u;
+    uint64_t mine = __ballot(in && tag == want && fill != 0);
+    uint32_t ext = 0, valid = 0, at = 0;
+    while (mine || at < valid) {
+      const uint64_t* sbase[VH_P2_SLOTS];
+      uint32_t sn[VH_P2_SLOTS];
+#pragma unroll
+      for (int u = 0; u < VH_P2_SLOTS; ++u) {
+        if (at >= valid && mine) {
+          const int q = __builtin_ctzll(mine);
+          mine &= mine - 1;
+          ext = c0 + (uint32_t)q;
+          valid = (uint32_t)__builtin_amdgcn_readlane((int)fill, q);
+          at = 0;
+        }
+        if (at < valid) {
+          sbase[u] = pool + ((uint64_t)ext * ext_stride + at) * TW;
+          sn[u] = valid - at < 64u ? valid - at : 64u;
+          at += 64u;
+        } else { sbase[u] = pool; sn[u] = 0; }
+      }
+      uint64_t w[VH_P2_SLOTS][TW];
+#pragma unroll
+      for (int u = 0; u < VH_P2_SLOTS; ++u) {
+        if constexpr (TW == 2) {        // both words of a tuple in one 16-byte load
+          typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+          const u64x2 t2 = (uint32_t)lane < sn[u] ? __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(sbase[u]) + lane) : u64x2{~0ull, 0ull};
+          w[u][0] = t2.x; w[u][1] = t2.y;
+        } else {
+#pragma unroll
+          for (int x = 0; x < TW; ++x) w[u][x] = (uint32_t)lane < sn[u] ? __builtin_nontemporal_load(sbase[u] + (uint64_t)lane * TW + x) : (x == 0 ? ~0ull : 0ull);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < VH_P2_SLOTS; ++u) {
+        const uint64_t w0 = w[u][0], local = (w0 & gid_mask) - g0;
+        if (w0 == ~0ull || local >= ng) continue;          // an empty slot; (a corrupt tuple cannot write outside the table)
+        if (!carried) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[local] = 1;
+#pragma unroll
+        for (int j = 0; j < NM; ++j) {
+          uint64_t v = w[u][J::m_tword[j] < TW ? J::m_tword[j] : 0] >> J::m_tshift[j];
+          if (GB && J::m_tbits[j]) v &= (1ull << (J::m_tbits[j] < 63 ? J::m_tbits[j] : 63)) - 1ull;      // (one-word tuples: never negative, the planner checked the column's minimum)
+          else if (vh_sop_bytes(J::m_sop[j]) == 4) {
+            v &= 0xFFFFFFFFull;
+            if (vh_sop_sext(J::m_sop[j])) v = (uint64_t)(int64_t)(int32_t)v;
+          }
+          vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(mstate[j], local, J::m_sop[j], v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // Sole block of the range, or one private copy of the range per block (P.nxcd == blocks_per_part: dense_merge_kernel adds
+  // them up): plain stores of EVERY group, present or not. Otherwise one atomic update per present group into the shared table.
+  const bool own = blocks_per_part == 1 || P.nxcd == blocks_per_part;
+  const uint64_t xo = P.nxcd == blocks_per_part ? (uint64_t)b * P.xcd_stride : 0;
+  for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) {
+    const uint8_t here = carried ? (uint8_t)(reinterpret_cast<uint64_t*>(mstate[carried ? J::CARRIER : 0])[g] != 0)
+                                 : reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g];
+    if (own && blocks_per_part > 1) { if (!carried) P.present[xo + g0 + g] = here; }
+    else { if (!here) continue; if (!carried) P.present[g0 + g] = 1; }
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+      if (vh_sop_bytes(J::m_sop[j]) == 4) {
+        const uint32_t bits = reinterpret_cast<uint32_t*>(mstate[j])[g];
+        if (own) reinterpret_cast<uint32_t*>(P.m[j].state)[xo + g0 + g] = bits;
+        else vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(P.m[j].state, g0 + g, J::m_sop[j], bits);
+      } else {
+        const uint64_t bits = reinterpret_cast<uint64_t*>(mstate[j])[g];
+        if (own) reinterpret_cast<uint64_t*>(P.m[j].state)[xo + g0 + g] = bits;
+        else vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(P.m[j].state, g0 + g, J::m_sop[j], bits);
       }
     }
   }

@@ -885,6 +885,43 @@ __global__ __launch_bounds__(256) void pack_bits_kernel(const VhPackBitsArgs A) 
   if (ovf) atomicOr(A.overflow, 1u);
 }
 
+// Bit-packed predicate projection (vh_table_predpack): every row's predicate columns as bit fields of one word (<= 32 bits), the word kept as
+// byte planes of 2 or 1 bytes per row. One row per thread and step; values are known to fit their fields (the host sizes the fields from
+// the columns' recorded min / max, which cover every mirrored value, and drops the projection when they no longer do).
+struct VhPredPackArgs {
+  int32_t ncols, nplanes;
+  const char* src[VH_PACK_MAX_COLS];
+  uint64_t src_stride[VH_PACK_MAX_COLS];
+  uint32_t esize[VH_PACK_MAX_COLS], bitoff[VH_PACK_MAX_COLS];
+  char* plane[4]; uint64_t plane_stride[4]; uint32_t plane_width[4], plane_pos[4];
+  const VhJob* jobs;
+};
+__global__ __launch_bounds__(256) void predpack_kernel(const VhPredPackArgs A) {
+  const VhJob J = A.jobs[blockIdx.x];
+  const uint32_t seg = J.seg, end = J.first + J.count;
+  for (uint32_t row = J.first + threadIdx.x; row < end; row += 256u) {
+    uint32_t word = 0;
+    if (row < J.seg_rows) {
+      for (int c = 0; c < A.ncols; ++c) {
+        const char* s = A.src[c] + (uint64_t)seg * A.src_stride[c] + (uint64_t)row * A.esize[c];
+        uint32_t v;
+        switch (A.esize[c]) {
+          case 1: v = *reinterpret_cast<const uint8_t*>(s); break;
+          case 2: v = *reinterpret_cast<const uint16_t*>(s); break;
+          case 4: v = *reinterpret_cast<const uint32_t*>(s); break;
+          default: v = (uint32_t)*reinterpret_cast<const uint64_t*>(s); break;
+        }
+        word |= v << A.bitoff[c];
+      }
+    }
+    for (int q = 0; q < A.nplanes; ++q) {
+      char* d = A.plane[q] + (uint64_t)seg * A.plane_stride[q];
+      if (A.plane_width[q] == 2) reinterpret_cast<uint16_t*>(d)[row] = (uint16_t)(word >> A.plane_pos[q]);
+      else reinterpret_cast<uint8_t*>(d)[row] = (uint8_t)(word >> A.plane_pos[q]);
+    }
+  }
+}
+
 // Narrow copy of an unsigned 32-bit column whose values fit T (vh_table_narrow): one job per block, 4 elements per thread and step.
 template <typename T>
 __global__ __launch_bounds__(256) void narrow_kernel(const uint32_t* src, uint64_t src_stride_elems, T* dst, uint64_t dst_stride_elems, const VhJob* jobs) {

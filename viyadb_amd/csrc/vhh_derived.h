@@ -356,6 +356,130 @@ static int table_narrow_locked(vh_table* t, int col, bool automatic) {
   return VH_OK;
 }
 
+// ------------------------------------------------------- bit-packed predicate projections (vh_table_predpack)
+// Bits the values of a column need over every mirrored segment, from its recorded min / max (0: not an integer column, negative values, or no stats).
+static int predpack_bits_for(const vh_table* t, int col) {
+  const VhColumn& c = t->cols[col];
+  if (c.elem == VH_F32 || c.elem == VH_F64 || is_bitset_elem(c.elem) || (size_t)col >= t->stats.size() || t->stats[col].size() < t->nseg) return 0;
+  uint64_t lo = ~0ull, hi = 0;
+  for (uint32_t s = 0; s < t->nseg; ++s) { const VhSegStat& st = t->stats[col][s]; if (st.lo > st.hi) continue; lo = std::min(lo, st.lo); hi = std::max(hi, st.hi); }
+  if (lo > hi) return 0;
+  const bool sgn = c.elem == VH_I8 || c.elem == VH_I16 || c.elem == VH_I32 || c.elem == VH_I64;
+  if (sgn && (int64_t)(lo ^ (1ull << 63)) < 0) return 0;
+  const uint64_t vmax = sgn ? (hi ^ (1ull << 63)) : hi;
+  int b = 1;
+  while (b < 64 && (vmax >> b)) ++b;
+  return b;
+}
+static void predpack_drop(vh_table* t, size_t k) {
+  table_quiesce(t);
+  (void)hipStreamSynchronize(g_ctx.stream); derived_waited(t);
+  VhPredPack* pp = t->predpacks[k].get();
+  for (int q = 0; q < pp->nplanes; ++q) if (pp->pbase[q]) { (void)hipFree(pp->pbase[q]); t->device_bytes -= (size_t)pp->cap_seg * pp->pstride[q] + 256; }
+  t->predpacks.erase(t->predpacks.begin() + (long)k);
+}
+static int predpack_refresh(vh_table* t, VhPredPack* pp) {
+  if (!t->nseg) return VH_OK;
+  if (pp->cap_seg < t->cap_seg) {
+    table_quiesce(t);
+    HIP_TRY(hipStreamSynchronize(g_ctx.stream)); derived_waited(t);
+    for (int q = 0; q < pp->nplanes; ++q) {
+      char* nb = nullptr;
+      const size_t bytes = (size_t)t->cap_seg * pp->pstride[q] + 256;
+      HIP_TRY(hipMalloc(&nb, bytes));
+      trace_alloc("predicate plane", nb, bytes);
+      if (pp->pbase[q]) {
+        HIP_TRY(hipMemcpyAsync(nb, pp->pbase[q], (size_t)pp->cap_seg * pp->pstride[q], hipMemcpyDeviceToDevice, g_ctx.stream));
+        HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+        HIP_TRY(hipFree(pp->pbase[q]));
+        t->device_bytes -= (size_t)pp->cap_seg * pp->pstride[q] + 256;
+      }
+      pp->pbase[q] = nb;
+      t->device_bytes += bytes;
+    }
+    pp->cap_seg = t->cap_seg;
+    pp->seg_mod.resize(t->cap_seg, 0);
+  }
+  if (pp->applied_epoch == t->sync_epoch) return VH_OK;
+  std::vector<VhJob> jobs;
+  derived_jobs(t, pp->applied_epoch, pp->seg_mod, t->padded_rows, &jobs);
+  if (!jobs.empty()) {
+    const VhJob* d_jobs = nullptr;
+    if (int rc = derived_upload(t, jobs, &d_jobs)) return rc;
+    VhPredPackArgs A{};
+    A.ncols = (int32_t)pp->cols.size(); A.nplanes = pp->nplanes;
+    for (size_t c = 0; c < pp->cols.size(); ++c) {
+      const VhColumn& col = t->cols[pp->cols[c]];
+      A.src[c] = col.base; A.src_stride[c] = col.stride; A.esize[c] = (uint32_t)col.esize; A.bitoff[c] = pp->bitoff[c];
+    }
+    for (int q = 0; q < pp->nplanes; ++q) { A.plane[q] = pp->pbase[q]; A.plane_stride[q] = pp->pstride[q]; A.plane_width[q] = (uint32_t)pp->pwidth[q]; A.plane_pos[q] = (uint32_t)pp->ppos[q]; }
+    A.jobs = d_jobs;
+    hipLaunchKernelGGL(predpack_kernel, dim3((unsigned)jobs.size()), dim3(256), 0, g_ctx.stream, A);
+    HIP_TRY(hipGetLastError());
+    if (int rc = derived_enqueued(t)) return rc;
+  }
+  for (uint32_t s = 0; s < t->nseg; ++s) pp->seg_mod[s] = t->seg_mod[s];
+  pp->applied_epoch = t->sync_epoch;
+  return VH_OK;
+}
+// The projection that holds every column of `cols` (ascending), fresh, or nullptr. One whose fields no longer hold the recorded values is dropped.
+static VhPredPack* predpack_usable(vh_table* t, const std::vector<int>& cols) {
+  for (size_t k = 0; k < t->predpacks.size(); ++k) {
+    VhPredPack* pp = t->predpacks[k].get();
+    if (!std::includes(pp->cols.begin(), pp->cols.end(), cols.begin(), cols.end())) continue;
+    bool fits = true;
+    for (size_t c = 0; c < pp->cols.size(); ++c) { const int b = predpack_bits_for(t, pp->cols[c]); fits &= b > 0 && b <= (int)pp->bitw[c]; }
+    if (!fits) { predpack_drop(t, k); return nullptr; }
+    if (predpack_refresh(t, pp) != VH_OK) return nullptr;
+    return pp;
+  }
+  return nullptr;
+}
+// Build one for `cols` (ascending, distinct). *built = nullptr when there is nothing to gain: a column that is no non-negative integer,
+// more than 32 bits in all, or no fewer bytes per row than the columns' narrowest copies would take.
+static int table_predpack_locked(vh_table* t, const std::vector<int>& cols, bool automatic, VhPredPack** built) {
+  if (built) *built = nullptr;
+  if (cols.empty() || cols.size() > VH_PACK_MAX_COLS || cols.size() > VJ_MAX_PRED) return VH_OK;
+  for (auto& pp : t->predpacks) if (pp->cols == cols) { if (built) *built = predpack_usable(t, cols); return VH_OK; }
+  std::unique_ptr<VhPredPack> pp(new VhPredPack());
+  uint32_t used = 0, plain = 0;
+  for (int c : cols) {
+    if (c < 0 || (size_t)c >= t->cols.size()) return vh_fail(VH_E_INVALID, "vh_table_predpack: column %d", c);
+    const int b = predpack_bits_for(t, c);
+    if (!b) return VH_OK;
+    pp->cols.push_back(c); pp->bitoff.push_back((uint8_t)used); pp->bitw.push_back((uint8_t)b);
+    used += (uint32_t)b;
+    const int nwid = narrow_width_for(t, c, t->nseg);
+    plain += nwid ? (uint32_t)nwid : (uint32_t)t->cols[c].esize;
+  }
+  if (used > 32) return VH_OK;
+  for (uint32_t left = used, pos = 0; left > 0;) {
+    const int w = left > 8 ? 2 : 1;
+    pp->pwidth[pp->nplanes] = w; pp->ppos[pp->nplanes] = (int)pos; pp->pstride[pp->nplanes] = t->padded_rows * (uint64_t)w;
+    ++pp->nplanes;
+    pos += 8u * w; left = left > 8u * w ? left - 8u * w : 0;
+  }
+  if (pp->bytes_per_row() >= plain) return VH_OK;
+  pp->automatic = automatic;
+  VhPredPack* raw = pp.get();
+  t->predpacks.push_back(std::move(pp));
+  const int rc = predpack_refresh(t, raw);
+  if (rc) { predpack_drop(t, t->predpacks.size() - 1); return rc; }
+  if (built) *built = raw;
+  return VH_OK;
+}
+
+extern "C" int vh_table_predpack(vh_table* t, const int32_t* cols, int32_t ncols) {
+  if (!t || !cols || ncols <= 0) return vh_fail(VH_E_INVALID, "vh_table_predpack: null argument");
+  VH_ENTER();
+  std::lock_guard<std::mutex> lk(t->mu);
+  if (int src = sync_resolve(t)) return src;
+  std::vector<int> set(cols, cols + ncols);
+  std::sort(set.begin(), set.end());
+  set.erase(std::unique(set.begin(), set.end()), set.end());
+  return table_predpack_locked(t, set, false, nullptr);
+}
+
 extern "C" int vh_table_narrow(vh_table* t, const int32_t* cols, int32_t ncols) {
   if (!t || (!cols && ncols)) return vh_fail(VH_E_INVALID, "null argument");
   VH_ENTER();
@@ -397,6 +521,9 @@ extern "C" int vh_table_unpack(vh_table* t) {
   for (auto& nw : t->narrows) if (nw->base) { (void)hipFree(nw->base); t->device_bytes -= (size_t)nw->cap_seg * nw->stride + 256; }
   t->narrows.clear();
   t->pred_seen.clear();
+  for (auto& pp : t->predpacks) for (int q = 0; q < pp->nplanes; ++q) if (pp->pbase[q]) { (void)hipFree(pp->pbase[q]); t->device_bytes -= (size_t)pp->cap_seg * pp->pstride[q] + 256; }
+  t->predpacks.clear();
+  t->ppred_seen.clear();
   return VH_OK;
 }
 

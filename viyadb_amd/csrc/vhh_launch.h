@@ -54,6 +54,13 @@ int QueryBuild::compile_kernel() {
     js.bs_off32 = hpart && hp_off32 ? 1 : 0;
     js.hp_pack = hp_pack ? 1 : 0; js.hp_pbits = hp_pbits; js.hp_idbits = hp_idbits;
     js.ng = P.ngroup; js.nm = P.nmetric;
+    js.qpay = !lanes ? qpay : 0; js.qpay_slot = js.qpay ? qpay_slot : -1;
+    {   // (the records' registers count against the packed predicate registers' budget)
+      int nv = 0;
+      if (js.pp_nplanes) for (int q = 0; q < js.pp_nplanes; ++q) nv += VH_SUBSTEPS * js.pp_plane[q].width;
+      else for (int k = 0; k < js.npred; ++k) nv += VH_SUBSTEPS * js.pred[k].width;
+      if (js.qpay && nv + VH_SUBSTEPS * js.qpay > VJ_MAX_NV) { js.qpay = 0; js.qpay_slot = -1; }
+    }
     for (int i = 0; i < P.ngroup; ++i) {
       const VhGroupDev& g = P.g[i];
       VhJitCol& c = js.g[i];
@@ -164,7 +171,8 @@ int QueryBuild::decompose_work() {
       snprintf(hn, sizeof(hn), " + hp_scatter_kernel<1024, %d> + hp_scatter_kernel<1024, %d> + ", hp_units, hp_units);
       r->kernel += hn + jk->name + "_hpagg";
     }
-    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? " + part_agg_kernel<1024>" : ((P.tw == 2 || P.gid_bits) && !getenv("VH_NO_SPLIT_TILE")) ? (P.gid_bits ? " + part_split_tile_kernel<256, 1> + part_agg_kernel<1024>" : " + part_split_tile_kernel<256, 2> + part_agg_kernel<1024>") : " + part_split_kernel<256> + part_agg_kernel<1024>";
+    const std::string pagg = jit_pagg() ? " + " + jk->name + "_pagg" : std::string(" + part_agg_kernel<1024>");
+    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? pagg : ((P.tw == 2 || P.gid_bits) && !getenv("VH_NO_SPLIT_TILE")) ? (P.gid_bits ? " + part_split_tile_kernel<256, 1>" + pagg : " + part_split_tile_kernel<256, 2>" + pagg) : " + part_split_kernel<256>" + pagg;
   }
   int occupancy = 0;
   if (env_bpc <= 0) scan_dispatch(0, &occupancy);
@@ -526,7 +534,7 @@ int QueryBuild::launch() {
   for (int k = 0; k < P.npred; ++k) narrowed |= P.pred_width[k] != 4;
   if (jk) { narrowed = false; for (int k = 0; k < jshape.npred; ++k) narrowed |= jshape.pred[k].width != vh_elem_size(jshape.pred[k].type); }
   r->hpart = hpart;
-  r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0) | (hpart && hp_pack ? 256 : 0) | ((mode == VH_MODE_DENSE_PART || hpart) && x->scratch_placed ? 512 : 0) | (mode == VH_MODE_DENSE_PART && P.gid_bits ? 1024 : 0);
+  r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0) | (hpart && hp_pack ? 256 : 0) | ((mode == VH_MODE_DENSE_PART || hpart) && x->scratch_placed ? 512 : 0) | (mode == VH_MODE_DENSE_PART && P.gid_bits ? 1024 : 0) | (jk && jshape.pp_nplanes ? 2048 : 0) | (jk && jshape.qpay ? 4096 : 0);
   if (r->hp_chunks) memset(x->h_chunk, 0, VH_HP_CHUNKS * sizeof(unsigned long long));      // (what the context's previous query left there)
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
@@ -551,7 +559,10 @@ int QueryBuild::launch() {
     if (mode == VH_MODE_DENSE_PART) {
       const bool skip_phase2 = knobs().skip_phase2;     // measurement only (wrong results): phase 1 alone between the events
       if (P.nlevel == 2 && !skip_phase2) vh_launch_part_split(P, split_bpp, st);
-      if (!skip_phase2) vh_launch_part_agg(P, part_bpp, lds_table, st);
+      if (!skip_phase2) {
+        if (jit_pagg()) HIP_TRY(vh_jit_launch_pagg(jk, P, part_bpp, lds_table, st));      // phase 2 compiled for this plan's tuple layout
+        else vh_launch_part_agg(P, part_bpp, lds_table, st);
+      }
     }
   }
   HIP_TRY(hipEventRecord(x->ev[2], st));

@@ -7,15 +7,19 @@ struct VhPlaceHint {
   size_t pool_off = 0, pool_bytes = 0;                           // the first tuple pool inside the scratch layout
 };
 
-// Where a tuple pool lands decides 10 % of a partitioning scan (C3: 2.05 vs 2.35 ms, reproducibly for as long as the buffer lives;
-// profiles/r03/NOTES.md "Where the tuple pool lands"). What was learned about it: it is not the allocation call (hipMalloc of any size,
-// or a 4 GiB-aligned VMM mapping, land in either class alike), not the extent geometry, and it does not show in stores alone or in streams
-// and gathers alone — only when whole-line stores to the buffer are MIXED with the table's read streams, i.e. it is how the pool's
-// physical pages relate to the pages being read (consecutive allocations share a class over tens of GB; the mapping of physical
-// addresses to HBM stacks / ranks is not visible from here). So the library measures: when a context needs a new scratch buffer for
-// a tuple pool of >= 256 MB, it allocates candidates one after the other, each pushed away from the last by a 6 GB spacer (at most VH_PLACE_TRIALS = 12 of them,
-// three quarters of what is free and VH_PLACE_GB = 96 GB; everything but the winner released again), runs the access mix of a partitioning scan in miniature against THIS query's
-// own columns on each (place_probe_kernel: ~1 ms per run) and keeps the fastest. One-off per context and size, like a kernel compile.
+// Where a tuple pool lands decides up to 10 % of a partitioning scan (C3 in round 3: 2.05 vs 2.35 ms, reproducibly for as long as the buffer
+// lives; profiles/r03/NOTES.md "Where the tuple pool lands"). What is known: it is not the allocation call (hipMalloc of any size, or a
+// 4 GiB-aligned VMM mapping next to hipMalloc'ed sources, land in either class alike), not the extent geometry, and it does not show in
+// stores alone or in streams and gathers alone — only when whole-line stores to the buffer are MIXED with the table's read streams, i.e. it is
+// how the pool's physical pages relate to the pages being read (consecutive allocations share a class over tens of GB). Round 5's experiment
+// (tools/experiments/vmm_order.hip, profiles/r05/NOTES.md): with the sources AND the pool built from hipMemCreate chunks the same access mix
+// runs at ONE speed — 3.54-3.59 ms over 24 builds, whatever the order and size of the chunks, between hipMalloc's fast (3.47) and slow (4.10)
+// classes — but a library whose big buffers all came from that allocator returned wrong groups from DENSE_PART intermittently and died with
+// GPU memory access faults in a third of its processes on this ROCm build (hipMalloc: never): a deterministic layout exists, it is not usable
+// here. So the search stays, inside vh_table_prepare only and small: candidates one after the other, each pushed away from the last by a 6 GB
+// spacer — at most VH_PLACE_TRIALS = 4 of them, half of what is free and VH_PLACE_GB = 16 GB; everything but the winner released again —,
+// the access mix of a partitioning scan in miniature against THIS query's own columns on each (place_probe_kernel: ~1 ms per run), the
+// fastest kept. One-off per context and size, like a kernel compile.
 // vh_table_prepare: the calling thread's queries build derived layouts at once (not after VH_AUTO_PACK / VH_AUTO_NARROW uses) and may place a
 // big tuple pool by measurement. An ORDINARY query never searches: it would hold tens of GB of free memory under the table lock for
 // up to seconds, and a database process has other tables to allocate for meanwhile.
@@ -125,6 +129,7 @@ static int place_with_derived(vh_table* t, VhExec* x, size_t bytes, const VhPlac
   size_t need = 0;
   for (auto& pk : t->packs) if (pk->base) { clones.push_back(Clone{&pk->base, pk->base, nullptr, (size_t)pk->cap_seg * pk->stride + 256}); need += clones.back().bytes; }
   for (auto& nw : t->narrows) if (nw->base) { clones.push_back(Clone{&nw->base, nw->base, nullptr, (size_t)nw->cap_seg * nw->stride + 256}); need += clones.back().bytes; }
+  for (auto& pp : t->predpacks) for (int q = 0; q < pp->nplanes; ++q) if (pp->pbase[q]) { clones.push_back(Clone{&pp->pbase[q], pp->pbase[q], nullptr, (size_t)pp->cap_seg * pp->pstride[q] + 256}); need += clones.back().bytes; }
   size_t free_b = 0, total_b = 0;
   const size_t spacer_bytes = (size_t)8 << 30;
   if (clones.empty() || hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b / 2 < need + nb + spacer_bytes) return install_scratch(x, A, nb, true);

@@ -218,6 +218,7 @@ struct QueryBuild {
   int hp_bpp = 1;
   uint32_t hp_chunk = 256;
   bool packed = false, packed_compressed = false;
+  int qpay = 0, qpay_slot = -1;                  // streamed payload (VhJitShape::qpay): the record's bytes, the slot the records come from
   VhJitKernel* jk = nullptr;
   int jit_block = 256;
   // ---- work decomposition, scratch
@@ -240,6 +241,7 @@ struct QueryBuild {
 
   int slot(int col);                              // the plan's slot of a table column (-1: none left / bad column, -2: a bitset metric)
   int probed_selectivity(double* sel);
+  bool jit_pagg() const { return jk && jk->fn_pagg && mode == VH_MODE_DENSE_PART && !knobs().no_jit_pagg; }      // phase 2 of DENSE_PART runs as the plan's compiled `_pagg` kernel
   void scan_dispatch(int grid_, int* occ);        // one place decides which scan kernel runs; with `occ` it only asks how many of its blocks fit a CU
   // the steps, in order
   int shape_filter();
@@ -418,6 +420,48 @@ int QueryBuild::shape_filter() {
     jshape.nlits = (int)r->h_lits.size();
   }
 
+  // Bit-packed predicate projection (vh_table_predpack; built unasked for a set of predicate columns the compiled kernel filters on for the
+  // third time): the compiled scan streams its byte planes — every predicate column a bit field of one word per row — instead of the
+  // columns or their narrow copies.
+  bool jit_predpack = false;
+  std::vector<int> pp_cols;
+  if (jit_try && jshape.npred > 0 && !(p->flags & (VH_PLAN_NO_NARROW | VH_PLAN_NO_PREDPACK))) {
+    bool all_cols = true;
+    for (int k = 0; k < jshape.npred; ++k) { all_cols &= jit_pred_col[k] >= 0; pp_cols.push_back(jit_pred_col[k]); }
+    std::sort(pp_cols.begin(), pp_cols.end());
+    pp_cols.erase(std::unique(pp_cols.begin(), pp_cols.end()), pp_cols.end());
+    VhPredPack* pp = all_cols ? predpack_usable(t, pp_cols) : nullptr;
+    const int auto_after = g_preparing ? 1 : knobs().auto_narrow;
+    if (all_cols && !pp && auto_after > 0) {
+      // only where the compiled kernel will run: asked for, or a table big enough for VH_JIT=auto to compile one
+      uint64_t rows = 0;
+      for (uint32_t sgi = 0; sgi < t->nseg; ++sgi) rows += t->seg_rows[sgi];
+      const bool will_compile = vh_jit_policy() == VH_JIT_FORCE || (p->flags & VH_PLAN_FORCE_JIT) || rows >= vh_jit_min_rows();
+      std::string key;
+      for (int c : pp_cols) { key += std::to_string(c); key.push_back(','); }
+      bool exists = false;
+      for (auto& q : t->predpacks) exists |= q->cols == pp_cols;
+      if (will_compile && !exists && ++t->ppred_seen[key] >= (uint32_t)auto_after) {
+        size_t free_b = 0, total_b = 0;
+        const size_t need = (size_t)t->cap_seg * t->padded_rows * 4;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + total_b / 4) { if (int prc = table_predpack_locked(t, pp_cols, true, &pp)) return prc; }
+        else t->ppred_seen[key] = 0;
+      }
+    }
+    if (pp && P.nslots + pp->nplanes <= VH_MAX_SLOTS) {
+      jshape.pp_nplanes = pp->nplanes;
+      for (int q = 0; q < pp->nplanes; ++q) {
+        P.colbase[P.nslots] = pp->pbase[q]; P.colstride[P.nslots] = pp->pstride[q]; P.colpitch[P.nslots] = (uint32_t)pp->pwidth[q];
+        jshape.pp_plane[q].slot = P.nslots++; jshape.pp_plane[q].width = pp->pwidth[q]; jshape.pp_plane[q].pos = pp->ppos[q];
+      }
+      for (int k = 0; k < jshape.npred; ++k) {
+        const size_t at = (size_t)(std::find(pp->cols.begin(), pp->cols.end(), jit_pred_col[k]) - pp->cols.begin());
+        jshape.pp_off[k] = pp->bitoff[at]; jshape.pp_bits[k] = pp->bitw[at];
+        jshape.pred[k].slot = -1; jshape.pred[k].width = 0;       // (streamed through the planes)
+      }
+      jit_predpack = true;
+    }
+  }
   // Narrow copies of predicate columns (vh_table_narrow; built unasked for a column the third query filters on): the
   // register-resident kernels — and the selectivity probe, which is one of them — stream those instead of the 4-byte arenas.
   if ((fast_ok || jit_try) && !(p->flags & VH_PLAN_NO_NARROW)) {
@@ -428,6 +472,7 @@ int QueryBuild::shape_filter() {
       if (hit != narrow_slot.end()) return hit->second;
       bool have = false;
       for (auto& nw : t->narrows) have |= nw->col == col;
+      if (jit_predpack && !have) return narrow_slot[col] = -1;       // (the compiled kernel reads the predicate projection: no copy of its own for this column)
       const int nwidth = have ? 0 : narrow_width_for(t, col, t->nseg);
       // (every query that filters on the column reads it in full, whatever passes: the copy pays from the first query that uses it on)
       if (!have && auto_after > 0 && nwidth && ++t->pred_seen[col] >= (uint32_t)auto_after) {
@@ -452,7 +497,7 @@ int QueryBuild::shape_filter() {
         P.pred_slot[k] = (uint8_t)ns;
         P.pred_width[k] = (uint8_t)P.colpitch[ns];
       }
-    if (jit_try)
+    if (jit_try && !jit_predpack)
       for (int k = 0; k < jshape.npred; ++k) {
         if (jit_pred_col[k] < 0 || t->cols[jit_pred_col[k]].elem != VH_U32) continue;
         const int ns = narrow_for(jit_pred_col[k]);
@@ -1174,7 +1219,28 @@ int QueryBuild::choose_projection() {
     bool want = !lanes && !(p->flags & VH_PLAN_NO_PACK) && !gcols.empty() && gcols.size() <= VH_PACK_MAX_COLS && rows_to_scan &&
                 P.nslots + (int)gcols.size() <= VH_MAX_SLOTS;
     const bool forced = (p->flags & VH_PLAN_FORCE_PACK) != 0;
-    if (want && !forced) {
+    // A bit-field projection of 4-byte records that holds every value of the plan can be STREAMED by the compiled compacting scan (the
+    // survivor's record goes into the wave's queue, nothing is gathered): 4 bytes per row whatever passes — cheaper than gathers from
+    // about 2.5 % selectivity on (a random 128-byte line per survivor touches half of the projection's lines there), and cheaper than
+    // the arenas at ANY selectivity above that.
+    bool all_plain = P.nbitset == 0;
+    for (int j = 0; j < P.nmetric; ++j) all_plain &= metric_col[j] >= 0;
+    const bool qpay_can = jit_try && !lanes && all_plain && want && !(p->flags & VH_PLAN_NO_QPAY) && (mode == VH_MODE_DENSE_PART || mode == VH_MODE_DENSE_GLOBAL || mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH);
+    bool qpay_want = false;
+    if (qpay_can) {
+      for (auto& pk : t->packs) {
+        bool all = pk->bits && pk->rec_bytes == 4;
+        for (int c : gcols) all &= pk->col_index(c) >= 0;
+        qpay_want |= all;
+      }
+      if (qpay_want && !(p->flags & VH_PLAN_FORCE_QPAY)) {
+        double sel = 1.0;
+        rc = probed_selectivity(&sel);
+        if (rc) { return rc; }
+        qpay_want = p->nfilter == 0 || sel >= knobs().qpay_min_sel;
+      }
+    }
+    if (want && !forced && !qpay_want) {
       // lines touched per survivor: one record vs one per column; the projection stops paying off once most lines of
       // the arenas are touched anyway (C3 columns: ~20 % of the rows passing)
       want = fastj && p->nfilter > 0;
@@ -1237,6 +1303,7 @@ int QueryBuild::choose_projection() {
       for (int j = 0; j < P.nmetric; ++j) if (metric_col[j] >= 0) P.m[j].set_slot((uint16_t)pslot(metric_col[j]));
       packed = true;
       packed_compressed = use->compressed;
+      if (qpay_want && use->bits && use->rec_bytes == 4) { qpay = 4; qpay_slot = pslot(gcols[0]); }      // (a bit-field record's members all start at the record: any member's slot is the record's)
     }
   }
   return VH_OK;

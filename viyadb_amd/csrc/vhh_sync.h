@@ -1,6 +1,7 @@
 // vhh_sync.h — host side of libviya_hip, part of viya_hip.hip's translation unit (included there, in order; not a stand-alone header):
 // data in: vh_segment_sync*, the per-segment min / max pass (refresh_stats), vh_segment_generate, vh_segment_read.
 static int sync_resolve(vh_table* t);      // (batched sync, below: what the last batch left to merge into the stats)
+static hipError_t wait_event_spinning(hipEvent_t ev);      // (vhh_finalize.h: poll, then block — a blocking wait alone costs tens of microseconds of wake-up)
 static int ensure_segrows(VhExec* x, size_t n) {
   if (n <= x->h_segrows_cap) return VH_OK;
   if (x->h_segrows) (void)hipHostFree(x->h_segrows);
@@ -152,7 +153,7 @@ static const char* hostreg_lookup(const void* p, uint64_t bytes, uintptr_t* lo, 
 // Called with t->mu held by everything that reads stats or arenas from the host side, plans a query, or starts another batch.
 static int sync_resolve(vh_table* t) {
   if (!t->sync_inflight) return VH_OK;
-  HIP_TRY(hipEventSynchronize(t->sync_ev));
+  HIP_TRY(wait_event_spinning(t->sync_ev));
   t->sync_inflight = false;
   const unsigned long long* slots = reinterpret_cast<const unsigned long long*>(t->h_sync);
   for (const auto& p : t->sync_pending) {
@@ -230,8 +231,10 @@ static int sync_batch_locked(vh_table* t, const vh_sync_item* items, uint32_t n)
   VhSyncDesc* descs = reinterpret_cast<VhSyncDesc*>(t->h_sync + (size_t)ndesc_max * 2 * sizeof(unsigned long long));
   uint32_t nd = 0, launched = 0;
   // (the kernel of the first few thousand runs pulls while the host is still writing the descriptors of the next)
+  uint32_t launch_at = 1024;                               // first launch early, then twice as many runs each time: a handful of launches however big the batch
   auto launch_some = [&](bool all) -> int {
-    if (nd == launched || (!all && nd - launched < 2048)) return VH_OK;
+    if (nd == launched || (!all && nd - launched < launch_at)) return VH_OK;
+    launch_at *= 2;
     hipLaunchKernelGGL(sync_pull_kernel, dim3(nd - launched), dim3(256), 0, g_ctx.stream, descs + launched, slots + 2ull * launched);
     HIP_TRY(hipGetLastError());
     launched = nd;

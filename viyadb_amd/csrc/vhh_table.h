@@ -67,6 +67,20 @@ struct VhNarrow {
   uint64_t applied_epoch = 0;
   bool automatic = false;
 };
+// Bit-packed predicate projection (vh_table_predpack): the predicate columns of a query shape as bit fields of one word per row (each at
+// the bits its recorded min / max need), kept as byte planes — what the per-query compiled scan streams instead of the columns or their
+// narrow copies. C3: d2 (2 bits) + d3 (10) + d4 (10) = 22 bits -> a 2-byte and a 1-byte plane: 3 bytes per row instead of 5 (12 from the arenas).
+struct VhPredPack {
+  std::vector<int> cols;             // table columns, ascending
+  std::vector<uint8_t> bitoff, bitw; // each column's field in the row word
+  int nplanes = 0;
+  int pwidth[4] = {}, ppos[4] = {};  // bytes per row of plane q, first bit of the word it holds
+  char* pbase[4] = {}; uint64_t pstride[4] = {};
+  uint32_t cap_seg = 0;
+  std::vector<uint64_t> seg_mod; uint64_t applied_epoch = 0;
+  bool automatic = false;
+  uint32_t bytes_per_row() const { uint32_t b = 0; for (int q = 0; q < nplanes; ++q) b += (uint32_t)pwidth[q]; return b; }
+};
 // What a sync did to a segment's columns: rows [first, last) at sync epoch `epoch` (the table's journal; derived layouts replay it).
 struct VhChange { uint64_t epoch; uint32_t seg, first, last; };
 struct vh_table {
@@ -94,6 +108,8 @@ struct vh_table {
   std::map<std::string, std::pair<uint64_t, uint64_t>> sel_cache;   // filter signature + table state -> (passed, sampled) of the selectivity probe
   std::vector<std::unique_ptr<VhPack>> packs;
   std::vector<std::unique_ptr<VhNarrow>> narrows;
+  std::vector<std::unique_ptr<VhPredPack>> predpacks;
+  std::map<std::string, uint32_t> ppred_seen;             // predicate column set -> compiled-kernel queries that filtered on it (automatic predicate projections)
   bool derived_tried = false;                   // place_with_derived ran (once per table)
   std::map<int, uint32_t> pred_seen;                     // column -> queries that filtered on it (automatic narrow copies)
   std::vector<uint64_t> seg_mod;                          // sync_epoch of the last change to a segment's columns
@@ -265,6 +281,7 @@ extern "C" void vh_table_destroy(vh_table* t) {
   if (t->d_packflag) (void)hipFree(t->d_packflag);
   for (auto& pk : t->packs) if (pk->base) (void)hipFree(pk->base);
   for (auto& nw : t->narrows) if (nw->base) (void)hipFree(nw->base);
+  for (auto& pp : t->predpacks) for (char* b : pp->pbase) if (b) (void)hipFree(b);
   if (t->h_jobs) (void)hipHostFree(t->h_jobs);
   if (t->derived_ev) (void)hipEventDestroy(t->derived_ev);
   delete t;

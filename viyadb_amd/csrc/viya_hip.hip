@@ -65,9 +65,9 @@ static std::mutex g_mu;
 // VH_TEST_* / VH_POISON / VH_NO_SPLIT_TILE / VH_PART_TABLE_KB knobs are the exception — tests switch them between two queries of one process — and stay getenv() calls
 // at their (cold) sites.
 struct VhKnobs {
-  bool trace_alloc, no_topk, no_stage, jit_verbose, skip_phase2, no_direct_emit, times;
+  bool trace_alloc, no_topk, no_stage, jit_verbose, skip_phase2, no_direct_emit, times, no_jit_pagg;
   int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, split_bpc, bw_blocks_per_cu, place_trials, place_gb, hp_list, hp_stream, deliver_blocks;
-  double hp_load_g, hp_load_s;
+  double hp_load_g, hp_load_s, qpay_min_sel;
 };
 static const VhKnobs& knobs() {
   static const VhKnobs k = [] {
@@ -76,16 +76,17 @@ static const VhKnobs& knobs() {
     auto real = [](const char* n, double dflt) { const char* e = getenv(n); return e ? atof(e) : dflt; };
     VhKnobs x{};
     x.trace_alloc = flag("VH_TRACE_ALLOC"); x.no_topk = flag("VH_NO_TOPK"); x.no_stage = flag("VH_NO_STAGE");
-    x.jit_verbose = flag("VH_JIT_VERBOSE"); x.skip_phase2 = flag("VH_ABLATE_NO_PHASE2"); x.no_direct_emit = flag("VH_NO_DIRECT_EMIT"); x.times = flag("VH_TIMES");
+    x.jit_verbose = flag("VH_JIT_VERBOSE"); x.skip_phase2 = flag("VH_ABLATE_NO_PHASE2"); x.no_direct_emit = flag("VH_NO_DIRECT_EMIT"); x.times = flag("VH_TIMES"); x.no_jit_pagg = flag("VH_NO_JIT_PAGG");      // (measurement / tests: the pre-built part_agg_kernel behind a compiled scan)
     x.max_exec = std::max(1, num("VH_MAX_EXEC", 16));
     x.auto_narrow = num("VH_AUTO_NARROW", 3); x.auto_pack = num("VH_AUTO_PACK", 3);
     x.jit_ablate = num("VH_JIT_ABLATE", 0); x.hp_ablate = num("VH_HP_ABLATE", 0); x.hp_bpp = num("VH_HP_BPP", 0); x.pack_plain = num("VH_PACK_PLAIN", 0);
     x.lanes_block = num("VH_LANES_BLOCK", 0); x.blocks_per_cu = num("VH_BLOCKS_PER_CU", 0); x.unit_rows = num("VH_UNIT_ROWS", 0); x.grid = num("VH_GRID", 0);
-    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.place_trials = num("VH_PLACE_TRIALS", 8); x.place_gb = std::max(1, num("VH_PLACE_GB", 48)); x.hp_list = num("VH_HP_LIST", 0);
+    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.place_trials = num("VH_PLACE_TRIALS", 4); x.place_gb = std::max(1, num("VH_PLACE_GB", 16)); x.hp_list = num("VH_HP_LIST", 0);
     x.hp_stream = num("VH_HP_STREAM", 0);             // chunk launches of a streamed result (0: off — measured: the link, not the wait for the kernels, bounds the delivery; profiles/r04/NOTES.md)
     x.deliver_blocks = num("VH_DELIVER_BLOCKS", 64);  // blocks of deliver_kernel; 0: big results through hipMemcpyAsync (the DMA engine)
     x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
     x.hp_load_g = real("VH_HP_LOAD_G", 0.7); x.hp_load_s = real("VH_HP_LOAD_S", 0.7);
+    x.qpay_min_sel = real("VH_QPAY_MIN_SEL", 0.2);        // selectivity from which the compiled scan streams 4-byte payload records instead of gathering them (measured: profiles/r05/NOTES.md)
     return x;
   }();
   return k;

@@ -85,6 +85,9 @@ class AggResult:
     hpart: bool = False            # hashed partitioning of the hash path ran (vh_hpart.h)
     packed_compressed: bool = False  # ... from compressed records (integers stored at the width their values need)
     hp_packed: bool = False        # hashed partitioning with packed 16-byte tuples (a count-distinct's ids inside the payload word)
+    predpack: bool = False         # predicate columns were streamed as byte planes of a bit-packed predicate projection (vh_table_predpack)
+    streamed_payload: bool = False  # ... and the payload records streamed beside them, a survivor's record queued in its row's place (no gathers)
+    flags: int = 0                 # vh_result_info.reserved as it came
 
 
 
@@ -202,6 +205,13 @@ class DeviceTable:
         if cols:
             arr = (C.c_int32 * len(cols))(*cols)
             capi.check(self.lib.vh_table_narrow(self.handle, arr, len(cols)))
+
+    def predpack(self, cols) -> None:
+        """A bit-packed predicate projection over `cols` (vh_table_predpack): what the compiled scan streams when a query filters on them."""
+        cols = sorted(set(int(c) for c in cols))
+        if cols:
+            arr = (C.c_int32 * len(cols))(*cols)
+            capi.check(self.lib.vh_table_predpack(self.handle, arr, len(cols)))
 
     def filter_columns(self, plan: "AggPlan"):
         """Table columns the plan's filter reads."""
@@ -339,13 +349,20 @@ class DeviceTable:
             return a.copy() if copy else a
 
         keys = [view(kp[i], capi.ELEM_NP[self.cols[g.col][1]]) for i, g in enumerate(plan.groups)]
-        states = [view(spp[j], capi.ELEM_NP[self.lib.vh_result_state_elem(res, j)]) for j in range(len(plan.metrics))]       # (the library says what it delivers)
+        def state_elem(j):          # (the library says what it delivers; < 0: it does not know the metric — never index a list with that)
+            e = self.lib.vh_result_state_elem(res, j)
+            if e < 0 or e >= len(capi.ELEM_NP):
+                raise capi.VhError(e, f"vh_result_state_elem: no element type for metric {j}")
+            return capi.ELEM_NP[e]
+
+        states = [view(spp[j], state_elem(j)) for j in range(len(plan.metrics))]
         hidden = view(C.cast(hp, C.c_void_p).value, np.uint64) if info.has_hidden_count else None
         return AggResult(keys, states, hidden, int(info.ngroups), int(info.scanned_recs), int(info.scanned_segments),
                          int(info.passed_recs), capi.PATH_NAMES[info.path], float(info.scan_kernel_ms),
                          float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1),
                          bool(info.reserved & 2), bool(info.reserved & 8), int(ng), (self.lib.vh_result_kernel(res) or b"").decode(),
-                         bool(info.reserved & 16), bool(info.reserved & 32), bool(info.reserved & 64), bool(info.reserved & 128), bool(info.reserved & 256))
+                         bool(info.reserved & 16), bool(info.reserved & 32), bool(info.reserved & 64), bool(info.reserved & 128), bool(info.reserved & 256),
+                         bool(info.reserved & 2048), bool(info.reserved & 4096), int(info.reserved))
 
     def query_agg(self, plan: AggPlan, copy: bool = True) -> AggResult:
         p, keep = self._build_plan(plan)
