@@ -200,6 +200,7 @@ enum vh_plan_flags {
   VH_PLAN_NO_NARROW_TUPLES = 1u << 23, /* ablation: DENSE_PART keeps two-word tuples even when gid and values would fit one */
   VH_PLAN_NO_PREDPACK = 1u << 24, /* ablation: predicate columns from their arenas / narrow copies even when a bit-packed predicate
                                      projection (vh_table_predpack) holds them */
+  VH_PLAN_NO_SLICED = 1u << 27,   /* ablation: a bit-sliced predicate projection is not used (byte planes, narrow copies or the columns answer) */
   VH_PLAN_NO_QPAY = 1u << 25,     /* ablation: a survivor's values are always GATHERED by row, even where the compiled scan could stream the
                                      bit-field records of a projection beside the predicate columns and queue the survivor's record */
   VH_PLAN_FORCE_QPAY = 1u << 26,  /* testing: streamed records whenever the plan is eligible, whatever the selectivity */
@@ -262,6 +263,7 @@ typedef struct vh_result_info {
                                 bit 9: the tuple pool lies in a scratch buffer chosen by measurement (vh_table_prepare);
                                 bit 10: DENSE_PART wrote one-word tuples (gid and values packed into 8 bytes);
                                 bit 11: predicate columns streamed as byte planes of a bit-packed predicate projection (vh_table_predpack; bit 4 is set too);
+                                bit 13: ... of its BIT-SLICED form (comparisons bit-serial on 32 rows per lane);
                                 bit 12: the payload was STREAMED — 4-byte bit-field records beside the predicate columns, a survivor's record queued in its
                                         row's place — not gathered (bits 3 and 7 are set too) */
   uint64_t returned_groups;  /* rows vh_result_copy delivers (= ngroups without HAVING) */
@@ -416,7 +418,14 @@ VH_API int vh_table_narrow(vh_table* t, const int32_t* cols, int32_t ncols);
  * needs more bits than its field (the stats say so), and is built unasked for a column set the compiled kernel filters on for the
  * VH_AUTO_NARROW-th time (instead of narrow copies of those columns) while a quarter of the device stays free. A column set that would not
  * get smaller is skipped silently. vh_table_unpack drops these too. */
-VH_API int vh_table_predpack(vh_table* t, const int32_t* cols, int32_t ncols);
+VH_API int vh_table_predpack(vh_table* t, const int32_t* cols, int32_t ncols);      /* = vh_table_predpack_ex(.., VH_PREDPACK_AUTO) */
+/* Two forms. BYTES: the word as byte planes (above): every kernel form of the compiled scan reads it, row by row. SLICED (what AUTO builds):
+ * one plane per BIT of the word, one bit per row — a predicate column of n bits costs exactly n bits per row (C3: 22 bits = 2.75 bytes) —
+ * and the compiled COMPACTING scan evaluates a comparison on 32 rows of a lane at once, bit-serially over the column's planes (a handful
+ * of bitwise operations per plane instead of a compare, a ballot and a rank per row): the filter's share of the scan's instructions falls
+ * to a fraction. The no-compaction form (most rows pass) reads the columns themselves. */
+enum { VH_PREDPACK_AUTO = 0, VH_PREDPACK_BYTES = 1, VH_PREDPACK_SLICED = 2 };
+VH_API int vh_table_predpack_ex(vh_table* t, const int32_t* cols, int32_t ncols, uint32_t form);
 /* Copy a mirrored column back to the host (tests). */
 VH_API int vh_segment_read(vh_table* t, uint32_t seg, int32_t col, uint64_t nrows,
                            void* dst);

@@ -94,7 +94,7 @@ def test_c3_headline_configuration_is_what_bench_times(c3_full):
     flags = t.warm(plan)
     res = t.query_agg(plan)
     assert res.flags == flags or (res.flags ^ flags) & ~512 == 0        # (bit 9, the placed pool, belongs to the context that ran)
-    assert res.path == "dense_part" and res.jit and res.packed and res.packed_compressed and res.predpack and res.narrow, (res.flags, res.kernel)
+    assert res.path == "dense_part" and res.jit and res.packed and res.packed_compressed and res.predpack and res.sliced and res.narrow, (res.flags, res.kernel)
     assert res.flags & 1024, "one-word tuples"
     assert res.scanned_recs == 1_000_000_000 and res.ngroups == 100_000
     other = t.query_agg(_plan(w, flags=1))
@@ -103,14 +103,14 @@ def test_c3_headline_configuration_is_what_bench_times(c3_full):
     for a, b in zip(kf + sf, ko + so):
         assert np.array_equal(a, b)
     snap = [0] * 1000
-    for s in (497, 498, 499):
+    for s in (495, 496, 497, 498, 499):           # (5 M rows: a scan of fewer than VH_JIT_MIN_ROWS takes the pre-built kernels)
         snap[s] = 1_000_000
     win = t.query_agg(_plan(w, seg_rows=snap))
     assert win.jit and win.predpack and win.packed
-    ot = build_oracle_table(w, 3, 1_000_000, row_base=497 * 1_000_000)
+    ot = build_oracle_table(w, 5, 1_000_000, row_base=495 * 1_000_000)
     st = vo.scan_aggregate(vo.parse_query(ot, w.query))
     st.scanned_recs, st.scanned_segments = win.scanned_recs, win.scanned_segments
-    compare(win, st, "C3 prepared, 3-segment window")
+    compare(win, st, "C3 prepared, 5-segment window")
 
 
 def test_one_word_tuples_replan_when_an_upsert_outgrows_their_bits():

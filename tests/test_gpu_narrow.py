@@ -109,21 +109,27 @@ def test_copies_are_built_unasked_for_columns_queries_keep_filtering_on():
 JIT = capi.PLAN_FORCE_JIT
 
 
+@pytest.mark.parametrize("sliced", [True, False])
 @pytest.mark.parametrize("flags", [0, 64, 1, 16, 2, 64 | 8192, 8192])
-def test_c3_through_a_predicate_projection(flags):
-    """vh_table_predpack: C3's predicate columns as bit fields of one word per row (2 + 10 + 10 bits: a 2-byte and a 1-byte plane), streamed by
-    the compiled scan under every table organisation; the pre-built kernels (no compiled kernel asked for) never read it."""
+def test_c3_through_a_predicate_projection(flags, sliced):
+    """vh_table_predpack: C3's predicate columns as bit fields of one word per row (2 + 10 + 10 bits) — as a 2-byte and a 1-byte plane, or
+    bit-sliced into 22 planes of one bit per row whose comparisons run bit-serially on 32 rows per lane — streamed by the compiled scan under
+    every table organisation; the pre-built kernels (no compiled kernel asked for) never read it."""
     from viyadb_amd import synth
     from viyadb_amd.executor import AggPlan
     w = synth.c3(segment_rows=200_000)
     dt = synth.create_device_table(w, 3, 199_993)
     try:
         mk = lambda f: AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=f, groups_hint=w.plan.groups_hint)
-        dt.predpack(dt.filter_columns(mk(0)))
+        dt.predpack(dt.filter_columns(mk(0)), sliced=sliced)
         st = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 3, 199_993), w.query))
         res = dt.query_agg(mk(flags | JIT))
-        compare(res, st, f"C3 predicate projection flags={flags}")
-        assert res.jit and res.predpack and res.narrow, (res.flags, res.kernel)
+        compare(res, st, f"C3 predicate projection flags={flags} sliced={sliced}")
+        assert res.jit and res.predpack and res.narrow and res.sliced == sliced, (res.flags, res.kernel)
+        if sliced:
+            res = dt.query_agg(mk(flags | JIT | capi.PLAN_NO_SLICED))
+            compare(res, st, f"C3 sliced projection not used flags={flags}")
+            assert res.jit and not res.sliced
         res = dt.query_agg(mk(flags | JIT | capi.PLAN_NO_PREDPACK))
         compare(res, st, f"C3 arenas flags={flags}")
         assert res.jit and not res.predpack
@@ -149,7 +155,8 @@ def test_predicate_projection_leaves_of_every_kind_and_types():
     dt = mirror_table(tab)
     base = {"dimensions": ["g"], "metrics": ["v", "count"]}
     try:
-        dt.predpack([0, 1, 2, 3])                  # 10 + 12 + 3 + 7 = 32 bits: two 2-byte planes
+        dt.predpack([0, 1, 2, 3], sliced=False)    # 10 + 12 + 3 + 7 = 32 bits: two 2-byte planes (what the no-compaction kernels read) ...
+        dt.predpack([0, 1, 2, 3], sliced=True)     # ... and 32 planes of one bit per row (what the compacting ones read)
         q = dict(base, filter={"op": "and", "filters": [F("lt", "a", "300"), F("ge", "b", "1000"), F("ne", "c", "2"), F("le", "e", "40")]})
         res, _ = run(tab, dt, q, flags=JIT)
         assert res.predpack and res.jit
@@ -172,11 +179,11 @@ def test_predicate_projection_follows_syncs_and_is_dropped_when_outgrown():
     n = 50_000
     tab = _table(rng, n, hi_a=16, hi_b=3000)       # 4 + 12 bits: ONE 2-byte plane instead of a 1-byte and a 2-byte narrow copy
     dt = mirror_table(tab, reserve=5)
-    q = {"dimensions": ["g"], "metrics": ["v", "count"], "filter": {"op": "and", "filters": [F("lt", "a", "9"), F("ge", "b", "1000"), F("ne", "a", "7")]}}
+    q = {"dimensions": ["g"], "metrics": ["v", "count"], "filter": {"op": "and", "filters": [F("lt", "a", "3"), F("ge", "b", "1000"), F("ne", "a", "1")]}}   # ~8 % pass: a compacting kernel
     try:
         dt.predpack([0, 1])
         res, _ = run(tab, dt, q, flags=JIT)
-        assert res.predpack
+        assert res.predpack and res.sliced
         # rows of a segment change in place (a batch) and a segment is re-synced whole: the planes follow by row range
         seg = tab.segments[1]
         seg["d"][0][1000:1900] = rng.integers(0, 16, 900).astype(np.uint32)
@@ -213,5 +220,22 @@ def test_predicate_projection_is_built_unasked_where_the_compiled_kernel_runs():
         assert not run(tab, dt, q)[0].predpack         # a table this small gets no compiled kernel unasked: arenas / narrow copies
         dt.unpack()
         assert run(tab, dt, q, flags=JIT)[0].predpack is False
+    finally:
+        dt.close()
+
+
+def test_bit_sliced_predicates_on_ragged_snapshots():
+    """size() snapshots that end inside a lane's 32 rows, inside a wave's step, at 0 — the tail mask of the bit-sliced scan — and every relation."""
+    rng = np.random.default_rng(17)
+    n = 70_000
+    tab = _table(rng, n, hi_a=16, hi_b=3000)
+    dt = mirror_table(tab)
+    try:
+        dt.predpack([0, 1], sliced=True)
+        for snap in ([n, n, n], [1, 31, 33], [2047, 2048, 2049], [0, n - 1, 4097], [65_537, 0, 8191]):
+            for op_a, op_b in (("lt", "ge"), ("le", "gt"), ("eq", "ne"), ("ne", "lt"), ("ge", "le"), ("gt", "eq")):
+                q = {"dimensions": ["g"], "metrics": ["v", "count"], "filter": {"op": "and", "filters": [F(op_a, "a", "9"), F(op_b, "b", "1000")]}}
+                res, _ = run(tab, dt, q, flags=JIT | capi.PLAN_NO_LANES, seg_rows=snap)      # (the compacting form whatever passes: the no-compaction one reads rows)
+                assert res.sliced, (snap, op_a, op_b, res.flags)
     finally:
         dt.close()

@@ -374,10 +374,10 @@ def test_c3_with_streamed_payload_records(flags, path):
         res = dt.query_agg(mk((base & ~capi.PLAN_FORCE_QPAY) | capi.PLAN_NO_QPAY))
         compare(res, st, f"gathered payload flags={flags}")
         assert res.packed and not res.streamed_payload
-        dt.predpack(dt.filter_columns(mk(0)))
+        dt.predpack(dt.filter_columns(mk(0)), sliced=False)      # (queued records go with rows: the byte-plane form)
         res = dt.query_agg(mk(base))
         compare(res, st, f"streamed payload + predicate projection flags={flags}")
-        assert res.streamed_payload and res.predpack
+        assert res.streamed_payload and res.predpack and not res.sliced
     finally:
         dt.close()
 

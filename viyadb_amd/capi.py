@@ -31,7 +31,7 @@ PLAN_FORCE_HASH, PLAN_FORCE_GLOBAL, PLAN_NO_XCD_PRIVATE, PLAN_NO_FAST, PLAN_NO_P
 PLAN_NO_LANES, PLAN_FORCE_LANES, PLAN_NO_LDS_HASH, PLAN_NO_HASH_RECORDS, PLAN_FORCE_HASH_RECORDS = 128, 256, 512, 1024, 2048
 PLAN_NO_PACK, PLAN_FORCE_PACK, PLAN_NO_PART2, PLAN_NO_SHAPE, PLAN_NO_NARROW = 4096, 8192, 16384, 32768, 65536
 PLAN_NO_JIT, PLAN_FORCE_JIT, PLAN_NO_HPART, PLAN_FORCE_HPART, PLAN_NO_HP_PACK, PLAN_CARD32, PLAN_NO_NARROW_TUPLES = 1 << 17, 1 << 18, 1 << 19, 1 << 20, 1 << 21, 1 << 22, 1 << 23
-PLAN_NO_PREDPACK, PLAN_NO_QPAY, PLAN_FORCE_QPAY = 1 << 24, 1 << 25, 1 << 26
+PLAN_NO_PREDPACK, PLAN_NO_QPAY, PLAN_FORCE_QPAY, PLAN_NO_SLICED = 1 << 24, 1 << 25, 1 << 26, 1 << 27
 # paths
 PATH_SCALAR, PATH_DENSE_LDS, PATH_DENSE_GLOBAL, PATH_HASH, PATH_DENSE_PART = range(5)
 PATH_NAMES = ["scalar", "dense_lds", "dense_global", "hash", "dense_part"]
@@ -153,6 +153,7 @@ SYMBOLS = {
     "vh_table_unpack": (C.c_int, [_VP]),
     "vh_table_narrow": (C.c_int, [_VP, C.POINTER(C.c_int32), C.c_int32]),
     "vh_table_predpack": (C.c_int, [_VP, C.POINTER(C.c_int32), C.c_int32]),
+    "vh_table_predpack_ex": (C.c_int, [_VP, C.POINTER(C.c_int32), C.c_int32, C.c_uint32]),
     "vh_segment_read": (C.c_int, [_VP, C.c_uint32, C.c_int32, C.c_uint64, _VP]),
     "vh_device_read": (C.c_int, [_VP, _VP, C.c_uint64]),
     "vh_table_info": (C.c_int, [_VP, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

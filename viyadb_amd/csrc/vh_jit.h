@@ -43,6 +43,12 @@ struct VhJitShape {
   int pp_nplanes = 0;
   struct Plane { int slot, width, pos; } pp_plane[4];
   int pp_off[VJ_MAX_PRED] = {}, pp_bits[VJ_MAX_PRED] = {};
+  // ... or BIT-SLICED (VhPredPack::sliced): bit b of the row word is a plane of its own, one 32-bit word per 32 rows; predicate column k is
+  // planes pp_off[k] .. pp_off[k] + pp_bits[k]. A lane owns 32 consecutive rows per step, loads the planes of the columns the filter reads
+  // and evaluates every comparison bit-serially on 32 rows at once (vj_bits_rel): a few bitwise operations per plane instead of a compare,
+  // a ballot and a rank per row — and 1 bit per row and bit of information streamed. pp_slot: the projection's slot (its pitch = bytes
+  // between planes). The compacting kernels only; pred[] keeps the columns' own slots for the no-compaction form.
+  int pp_sliced = 0, pp_slot = -1;
   // Streamed payload: every group / metric value of the plan is a bit field of ONE 4-byte record per row (a bit-field projection, VhPack::bits).
   // Instead of queueing a survivor's ROW and gathering its record afterwards (a random 128-byte line per survivor: at 5 % selectivity 81 % of
   // the projection's lines are fetched anyway, at the rate random lines come in), the scan streams the records with the predicate planes —

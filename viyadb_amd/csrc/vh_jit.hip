@@ -53,6 +53,8 @@ std::string VhJitShape::key() const {
   put(lanes); put(npred);
   for (int i = 0; i < npred; ++i) { put(pred[i].slot); put(pred[i].type); put(pred[i].width); }
   put(qpay); put(qpay_slot);
+  put(pp_sliced); put(pp_slot);
+  if (pp_sliced) for (int i = 0; i < npred; ++i) { put(pp_off[i]); put(pp_bits[i]); }
   put(pp_nplanes);
   for (int q = 0; q < pp_nplanes; ++q) { put(pp_plane[q].slot); put(pp_plane[q].width); put(pp_plane[q].pos); }
   if (pp_nplanes) for (int i = 0; i < npred; ++i) { put(pp_off[i]); put(pp_bits[i]); }
@@ -103,10 +105,13 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   std::vector<Stream> streams;
   if (s.pp_nplanes) for (int q = 0; q < s.pp_nplanes; ++q) streams.push_back(Stream{s.pp_plane[q].slot, s.pp_plane[q].width});
   else for (int p = 0; p < s.npred; ++p) streams.push_back(Stream{s.pred[p].slot, s.pred[p].width});
+  int sbase[VJ_MAX_PRED] = {}, snv = 0;                  // bit-sliced: predicate column p's planes occupy v[sbase[p] .. sbase[p] + pp_bits[p])
+  if (s.pp_sliced) { streams.clear(); for (int p = 0; p < s.npred; ++p) { sbase[p] = snv; snv += s.pp_bits[p]; } }
   const int qpay_stream = s.qpay ? (int)streams.size() : -1;
   if (s.qpay) streams.push_back(Stream{s.qpay_slot, s.qpay});      // the payload records ride along with the predicate streams
   int base[VJ_MAX_PRED + 1] = {}, nv = 0;
   for (size_t p = 0; p < streams.size(); ++p) { base[p] = nv; nv += VH_SUBSTEPS * streams[p].width; }
+  if (s.pp_sliced) nv = snv;
   const int nva = nv ? nv : 1;
   t += "struct VJ {\n";
   t += vj_fmt("  static constexpr int MODE = %d, BLOCK = %d, SCOPE = %d, NV = %d, NG = %d, NM = %d, TW = %d, KEY_WORDS = %d, CARRIER = %d;\n",
@@ -119,6 +124,7 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   t += vj_fmt("  static constexpr bool BS_OFF32 = %s;\n", s.bs_off32 ? "true" : "false");
   t += vj_fmt("  static constexpr bool LANES = %s;\n", s.lanes ? "true" : "false");
   t += vj_fmt("  static constexpr int QPAY = %d;\n", s.qpay);
+  t += vj_fmt("  static constexpr bool SLICED = %s;\n", s.pp_sliced ? "true" : "false");
   {
     std::vector<int> a, b, c, d, e, f;
     for (int i = 0; i < s.ng; ++i) { a.push_back(s.g[i].type); b.push_back(s.g[i].gran); c.push_back(s.g[i].nroll); d.push_back(s.g[i].micro); e.push_back(s.g[i].key_word); f.push_back(s.g[i].key_shift); }
@@ -149,6 +155,31 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   };
   // ---- the filter as one expression per row slot (ComparisonBuilder: composites are bitwise & / |, no short circuit), written
   //      twice: over the comparisons' wave ballots (the slot's pass mask, in scalar registers) and over the lane's own bools
+  std::vector<std::string> sst;                             // bit-sliced: the lane's 32-row mask
+  auto sliced_leaf = [&](const VhProgOp& o, int op, int lit_idx) {
+    const int p = (int)o.pslot(), ty = (int)o.type();
+    const std::string l = lit_name(lit_idx, ty);
+    const bool sgn = ty == VH_I8 || ty == VH_I16 || ty == VH_I32 || ty == VH_I64;
+    return vj_fmt("vj_bits_rel<%d, %d>(v + %d, (uint64_t)%s%s, %s)", s.pp_bits[p], op, sbase[p], sgn ? "(int64_t)" : "", l.c_str(), sgn ? ("(" + l + " < 0)").c_str() : "false");
+  };
+  if (s.pp_sliced)
+    for (const VhProgOp& o : s.prog) {
+      switch (o.kind()) {
+        case VH_F_TRUE: sst.push_back("~0u"); break;
+        case VH_F_AND: case VH_F_OR: {
+          std::string e;
+          const char* op = o.kind() == VH_F_AND ? " & " : " | ";
+          for (int k = 0; k < (int)o.count() && !sst.empty(); ++k) { e = e.empty() ? sst.back() : sst.back() + op + e; sst.pop_back(); }
+          sst.push_back("(" + e + ")");
+        } break;
+        case VH_F_REL: sst.push_back(sliced_leaf(o, (int)o.op(), (int)o.lit())); break;
+        default: {         // IN: OR of ==, NOT IN: AND of != (filter.cc:223-241)
+          std::string e = o.op() ? "0u" : "~0u";
+          for (int k = 0; k < (int)o.count(); ++k) e += std::string(o.op() ? " | " : " & ") + sliced_leaf(o, o.op() ? VH_OP_EQ : VH_OP_NE, (int)o.lit() + k);
+          sst.push_back("(" + e + ")");
+        } break;
+      }
+    }
   std::vector<std::pair<std::string, std::string>> st;      // (mask expression, bool expression)
   for (const VhProgOp& o : s.prog) {
     switch (o.kind()) {
@@ -188,8 +219,19 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   t += "    __device__ __forceinline__ Lits(const VhPlanDev& P)";
   { bool first = true; for (auto& kv : lit_decl) { t += first ? " : " : ", "; first = false; t += kv.second.substr(kv.second.find('|') + 1); } }
   t += " { (void)P; }\n  };\n";
+  if (s.pp_sliced) {
+    t += vj_fmt("  static __device__ __forceinline__ uint32_t mask(const Lits& L, const uint32_t (&v)[%d]) {\n    (void)L; (void)v;\n    return %s;\n  }\n", nva, sst.empty() ? "~0u" : sst.back().c_str());
+    // a lane's words of the planes the filter reads: one 4-byte load per plane (256 contiguous bytes per wave and plane), non-temporal
+    t += vj_fmt("  template <bool FULL> static __device__ __forceinline__ void preload(const VhPlanDev& P, uint32_t seg, uint32_t row_l, uint32_t seg_rows, uint32_t (&v)[%d]) {\n", nva);
+    t += vj_fmt("    const char* base = P.colbase[%d] + (uint64_t)seg * P.colstride[%d] + (uint64_t)(row_l >> 5) * 4ull;\n    const uint64_t ps = P.colpitch[%d];\n    const bool in = FULL || row_l < seg_rows;\n    (void)base; (void)ps; (void)in;\n",
+                s.pp_slot, s.pp_slot, s.pp_slot);
+    for (int p = 0; p < s.npred; ++p)
+      for (int b = 0; b < s.pp_bits[p]; ++b)
+        t += vj_fmt("    v[%d] = in ? __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(base + %dull * ps)) : 0u;\n", sbase[p] + b, s.pp_off[p] + b);
+    t += "  }\n";
+  }
   // ---- accessors: the value of predicate column p in row slot I (I = 4 * sub-step + row of the lane's four), in the column's own type
-  if (s.pp_nplanes) {
+  if (s.pp_nplanes && !s.pp_sliced) {
     // the row's word out of its planes (the compiler turns the byte / half-word picks into v_perm / SDWA selects), then each column as a bit field
     t += vj_fmt("  template <int I> static __device__ __forceinline__ uint32_t ppw(const uint32_t (&v)[%d]) {\n    return ", nva);
     for (int q = 0; q < s.pp_nplanes; ++q) {
@@ -205,7 +247,7 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
                   T, p, nva, T, s.pp_off[p], s.pp_bits[p] >= 32 ? 0xFFFFFFFFu : ((1u << s.pp_bits[p]) - 1u));
     }
   }
-  for (int p = 0; p < s.npred && !s.pp_nplanes; ++p) {
+  for (int p = 0; p < s.npred && !s.pp_nplanes && !s.pp_sliced; ++p) {
     const VhJitPred& c = s.pred[p];
     const char* T = vj_ctype(c.type);
     t += vj_fmt("  template <int I> static __device__ __forceinline__ %s c%d(const uint32_t (&v)[%d]) {\n", T, p, nva);
@@ -221,13 +263,15 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
     }
     t += "  }\n";
   }
+  if (!s.pp_sliced)
   t += vj_fmt("  template <int I> static __device__ __forceinline__ uint64_t pass(const Lits& L, const uint32_t (&v)[%d], bool& p) {\n    (void)L; (void)v;\n    p = ", nva) + filter_bool +
        ";\n    return " + filter_mask + ";\n  }\n";
   if (s.qpay)     // the record of row slot I, as it came in with the step's loads: what a passing row leaves in the wave's queue
     t += vj_fmt("  template <int I> static __device__ __forceinline__ uint32_t payload(const uint32_t (&v)[%d]) { return v[%d + I]; }\n", nva, base[qpay_stream]);
   // ---- the packed loads of one wave step: 4 consecutive rows per lane and sub-step, naturally aligned, non-temporal
+  if (!s.pp_sliced)
   t += vj_fmt("  template <bool FULL> static __device__ __forceinline__ void preload(const VhPlanDev& P, uint32_t seg, uint32_t row_l, uint32_t seg_rows, uint32_t (&v)[%d]) {\n    (void)P; (void)seg; (void)row_l; (void)seg_rows; (void)v;\n", nva);
-  for (size_t p = 0; p < streams.size(); ++p) {
+  for (size_t p = 0; p < streams.size() && !s.pp_sliced; ++p) {
     const Stream& c = streams[p];
     t += vj_fmt("    {\n      const char* col = P.colbase[%d] + (uint64_t)seg * P.colstride[%d];\n#pragma unroll\n      for (int k = 0; k < VH_SUBSTEPS; ++k) {\n        const uint32_t r = row_l + k * 256u;\n        if (FULL || r < seg_rows) {\n", c.slot, c.slot);
     const int b = base[p];
@@ -241,7 +285,7 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
     t += vj_fmt("#pragma unroll\n          for (int z = 0; z < %d; ++z) v[%d + %d * k + z] = 0u;\n", c.width, b, c.width);
     t += "        }\n      }\n    }\n";
   }
-  t += "  }\n";
+  if (!s.pp_sliced) t += "  }\n";
   // ---- a survivor's group and metric values: every load first (members of one payload projection share the record's
   //      address and are fetched with the widest aligned loads that cover them), then widths and extensions
   t += vj_fmt("  static __device__ __forceinline__ void gather(const VhPlanDev& P, uint32_t seg, uint32_t row, uint64_t (&gv)[%d], uint64_t (&mv)[%d]) {\n    (void)P; (void)seg; (void)row; (void)gv; (void)mv;\n",
@@ -649,6 +693,7 @@ static bool vj_canonical(int which, VhJitShape* s) {
   VhJitShape& S = *s;
   auto col = [](int slot, int type, int pitch, int rec, int off, int sext) { VhJitCol c; c.slot = slot; c.type = type; c.pitch = pitch; c.rec = rec; c.off = off; c.sext = sext; return c; };
   switch (which) {
+    case 14:    // ... case 10 with the predicate columns BIT-SLICED: 2 + 10 + 10 planes of one bit per row, a lane owns 32 consecutive rows per step
     case 13:    // ... case 12 with the payload records STREAMED beside the predicate planes and queued in the rows' place (no gathers)
     case 12:    // ... case 10 with the predicate columns out of a bit-packed predicate projection: d2 (2 bits) | d3 (10) | d4 (10) = a 2-byte and a 1-byte plane
     case 10:    // ... case 9 with the payload in a 4-byte BIT-FIELD record: d0 in 10 bits, d1 in 7, m0 in 10, count in 2
@@ -656,7 +701,7 @@ static bool vj_canonical(int which, VhJitShape* s) {
     case 7:     // ... case 0 with the payload from a compressed 8-byte record: m0 (i64) in 4 bytes, d0 in 2, d1 and count in 1 each
     case 0:     // C3: d2 == a & d3 < b & d4 >= c on narrow copies (1, 2, 2 bytes), payload from a 32-byte record, tuples for DENSE_PART
     case 1: {   // ... the same from the 4-byte arenas, straight into the dense HBM table (what an eighth of the table runs)
-      const bool part = which == 0 || which == 7 || which == 9 || which == 10 || which == 12 || which == 13;
+      const bool part = which == 0 || which == 7 || which == 9 || which == 10 || which == 12 || which == 13 || which == 14;
       S.mode = part ? VH_MODE_DENSE_PART : VH_MODE_DENSE_GLOBAL; S.block = 256; S.scope = __HIP_MEMORY_SCOPE_AGENT; S.carrier = 1; S.tw = part ? 2 : 1; S.gid32 = 1; S.stage = part ? 16 : 0;
       S.npred = 3;
       S.pred[0] = VhJitPred{part ? 7 : 0, VH_U32, part ? 1 : 4}; S.pred[1] = VhJitPred{part ? 8 : 1, VH_U32, part ? 2 : 4}; S.pred[2] = VhJitPred{part ? 9 : 2, VH_U32, part ? 2 : 4};
@@ -666,15 +711,16 @@ static bool vj_canonical(int which, VhJitShape* s) {
         S.g[0] = col(10, VH_U32, 32, 0, 8, 1); S.g[1] = col(11, VH_U32, 32, 0, 12, 1);
         S.m[0] = col(12, VH_I64, 32, 0, 0, 0); S.m[0].sop = SOP_ADD64; S.m[0].tword = 1; S.m[0].tshift = 0;
         S.m[1] = col(13, VH_U32, 32, 0, 16, 0); S.m[1].sop = SOP_ADD32P; S.m[1].tword = 0; S.m[1].tshift = 32;
-        if (which == 9 || which == 10 || which == 12 || which == 13) { S.tw = 1; S.gid_bits = 17; S.m[0].tword = 0; S.m[0].tshift = 17; S.m[0].tbits = 10; S.m[1].tword = 0; S.m[1].tshift = 27; S.m[1].tbits = 2; }
+        if (which == 9 || which == 10 || which == 12 || which == 13 || which == 14) { S.tw = 1; S.gid_bits = 17; S.m[0].tword = 0; S.m[0].tshift = 17; S.m[0].tbits = 10; S.m[1].tword = 0; S.m[1].tshift = 27; S.m[1].tbits = 2; }
         if (which == 13) { S.qpay = 4; S.qpay_slot = 10; }
+        if (which == 14) { S.pp_sliced = 1; S.pp_slot = 7; S.pp_off[0] = 0; S.pp_bits[0] = 2; S.pp_off[1] = 2; S.pp_bits[1] = 10; S.pp_off[2] = 12; S.pp_bits[2] = 10; }
         if (which == 12 || which == 13) {
           S.pp_nplanes = 2;
           S.pp_plane[0] = {7, 2, 0}; S.pp_plane[1] = {8, 1, 16};
           S.pp_off[0] = 0; S.pp_bits[0] = 2; S.pp_off[1] = 2; S.pp_bits[1] = 10; S.pp_off[2] = 12; S.pp_bits[2] = 10;
           for (int k = 0; k < 3; ++k) { S.pred[k].slot = -1; S.pred[k].width = 0; }
         }
-        if (which == 10 || which == 12 || which == 13) {
+        if (which == 10 || which == 12 || which == 13 || which == 14) {
           for (VhJitCol* c : {&S.g[0], &S.g[1], &S.m[0], &S.m[1]}) { c->pitch = 4; c->bits = 4; }
           S.g[0].off = 0; S.g[0].stored = 10; S.g[1].off = 10; S.g[1].stored = 7; S.m[0].off = 17; S.m[0].stored = 10; S.m[1].off = 27; S.m[1].stored = 2;
         }

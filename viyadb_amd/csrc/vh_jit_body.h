@@ -320,6 +320,56 @@ __device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32
   }
 }
 
+// ---- bit-sliced predicate projections (J::SLICED; VhPredPack::sliced): a predicate column of NB bits is NB words per 32 rows, word b =
+// bit b of those rows (x[0] the least significant). A comparison with a literal is a walk over the planes from the top bit down — a handful of
+// bitwise operations per PLANE and 32 rows, whatever the relation — and its result is the lane's pass mask for its 32 rows: no compare, no
+// ballot and no rank per row (BitWeaving/V's column-scalar comparison). `c` is wave-uniform (a literal): the branches on its bits are scalar.
+template <int NB>
+__device__ __forceinline__ void vj_bits_lt_eq(const uint32_t* x, uint64_t c, bool neg, uint32_t& lt, uint32_t& eq) {
+  if (neg) { lt = 0u; eq = 0u; return; }                        // a negative literal: no (non-negative) value is below it or equals it
+  if (NB < 64 && (c >> NB) != 0ull) { lt = ~0u; eq = 0u; return; }     // beyond the field's range: every value is below it
+  const uint32_t cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)c);
+  lt = 0u; eq = ~0u;
+#pragma unroll
+  for (int b = NB - 1; b >= 0; --b) {
+    const uint32_t xb = x[b];
+    if ((cs >> b) & 1u) { lt |= eq & ~xb; eq &= xb; } else { eq &= ~xb; }
+  }
+}
+template <int NB>
+__device__ __forceinline__ uint32_t vj_bits_eq(const uint32_t* x, uint64_t c, bool neg) {
+  if (neg || (NB < 64 && (c >> NB) != 0ull)) return 0u;
+  const uint32_t cs = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)c);
+  uint32_t eq = ~0u;
+#pragma unroll
+  for (int b = NB - 1; b >= 0; --b) eq &= ((cs >> b) & 1u) ? x[b] : ~x[b];
+  return eq;
+}
+// OP: enum vh_relop. The mask of the lane's 32 rows for which (column OP c) holds.
+template <int NB, int OP>
+__device__ __forceinline__ uint32_t vj_bits_rel(const uint32_t* x, uint64_t c, bool neg) {
+  if constexpr (OP == VH_OP_EQ) return vj_bits_eq<NB>(x, c, neg);
+  else if constexpr (OP == VH_OP_NE) return ~vj_bits_eq<NB>(x, c, neg);
+  else {
+    uint32_t lt, eq;
+    vj_bits_lt_eq<NB>(x, c, neg, lt, eq);
+    return OP == VH_OP_LT ? lt : OP == VH_OP_LE ? (lt | eq) : OP == VH_OP_GT ? ~(lt | eq) : ~lt;
+  }
+}
+// The lane's passing rows (bits of `m`, row `base` + bit) appended to the wave's queue: ranks from a prefix sum of the lanes' counts, then
+// every lane writes its own rows — as many rounds as the busiest lane has survivors. At most 16 x 64 rows a call (the queue's room).
+__device__ __forceinline__ void vj_push_mask(uint32_t* q, uint32_t& cnt, uint32_t m, uint32_t base, int lane) {
+  const uint32_t c = (uint32_t)__popc(m);
+  uint32_t incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
+  const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  if (total == 0u) return;
+  uint32_t pos = cnt + incl - c;
+  while (m) { q[pos++] = base + (uint32_t)__builtin_ctz(m); m &= m - 1u; }
+  cnt += total;
+}
+
 // One row slot of the wave step: the generated predicate for slot I, its ballot, and the passing lanes' rows appended to the
 // wave's queue. FULL = false: the step reaches the end of the segment's snapshot, rows at or beyond size() never pass.
 template <class J, int I, bool FULL>
@@ -376,7 +426,9 @@ template <class J>
 __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int MODE = J::MODE, BLOCK = J::BLOCK;
-  constexpr int kStepRows = BLOCK * VH_LANE_ROWS;
+  constexpr int kLaneRows = J::SLICED ? 32 : VH_LANE_ROWS;      // rows a lane owns per wave step: 32 consecutive ones (bit-sliced predicates), or 4 x 4
+  constexpr int kStepRows = BLOCK * kLaneRows;
+  constexpr uint32_t kWaveRows = 64u * kLaneRows, kLaneStride = J::SLICED ? 32u : 4u;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // wave-uniform, and the compiler is told so: rows, counts and
                                                                                  // ballots of the step then live in scalar registers
@@ -411,19 +463,19 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
     seg = unit / P.units_per_seg;
     useg = unit - seg * P.units_per_seg;
     seg_rows = P.seg_rows[seg];
-    wave_base = useg * P.unit_rows + wave * VH_WAVE_STEP_ROWS;
+    wave_base = useg * P.unit_rows + wave * kWaveRows;
   }
   uint32_t v[J::NV ? J::NV : 1];
   if (have) {
-    if (wave_base + VH_WAVE_STEP_ROWS <= seg_rows) J::template preload<true>(P, seg, wave_base + lane * 4, seg_rows, v);
-    else J::template preload<false>(P, seg, wave_base + lane * 4, seg_rows, v);
+    if (wave_base + kWaveRows <= seg_rows) J::template preload<true>(P, seg, wave_base + lane * kLaneStride, seg_rows, v);
+    else J::template preload<false>(P, seg, wave_base + lane * kLaneStride, seg_rows, v);
   }
   uint32_t cnt = 0;
   if constexpr (J::LANES) {
     uint32_t lane_passed = 0;
     while (have) {
-      const uint32_t row_l = wave_base + lane * 4;
-      const bool full = wave_base + VH_WAVE_STEP_ROWS <= seg_rows;
+      const uint32_t row_l = wave_base + lane * kLaneStride;
+      const bool full = wave_base + kWaveRows <= seg_rows;
       typename J::Payload Y;                      // the step's group and metric values: every load of them in flight before the filter is looked at
       if (full) J::template lanes_load<true>(P, seg, row_l, seg_rows, Y);
       else J::template lanes_load<false>(P, seg, row_l, seg_rows, Y);
@@ -441,12 +493,12 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
         if (useg >= P.units_per_seg) { useg -= P.units_per_seg; ++nseg; }
         if (nhave) {
           nseg_rows = P.seg_rows[nseg];
-          nwave_base = useg * P.unit_rows + wave * VH_WAVE_STEP_ROWS;
+          nwave_base = useg * P.unit_rows + wave * kWaveRows;
         }
       }
       if (nhave) {        // the next step's predicate columns travel while this step's rows go into the table
-        if (nwave_base + VH_WAVE_STEP_ROWS <= nseg_rows) J::template preload<true>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
-        else J::template preload<false>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
+        if (nwave_base + kWaveRows <= nseg_rows) J::template preload<true>(P, nseg, nwave_base + lane * kLaneStride, nseg_rows, v);
+        else J::template preload<false>(P, nseg, nwave_base + lane * kLaneStride, nseg_rows, v);
       }
       vj_lanes_rows<J>(P, seg, row_l, mask, Y, lds, xoff, nfresh, V);
       have = nhave; seg = nseg; wave_base = nwave_base; seg_rows = nseg_rows;
@@ -456,11 +508,19 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
     npassed = np;                                 // (lane 0's is the wave's: it is the one that adds it to the counter below)
   }
   while (!J::LANES && have) {
-    const uint32_t row_l = wave_base + lane * 4;
+    const uint32_t row_l = wave_base + lane * kLaneStride;
     const uint32_t cnt0 = cnt;
-    if (wave_base + VH_WAVE_STEP_ROWS <= seg_rows) vj_slots<J, true>(L, v, row_l, seg_rows, q, cnt);
-    else if (wave_base < seg_rows) vj_slots<J, false>(L, v, row_l, seg_rows, q, cnt);
-    npassed += cnt - cnt0;
+    uint32_t smask = 0u;                       // (bit-sliced: the lane's pass mask of its 32 rows; pushed below, half by half)
+    if constexpr (J::SLICED) {
+      if (wave_base < seg_rows) {
+        smask = J::mask(L, v);
+        if (wave_base + kWaveRows > seg_rows) smask &= row_l + 32u <= seg_rows ? ~0u : row_l < seg_rows ? (1u << (seg_rows - row_l)) - 1u : 0u;
+      }
+    } else {
+      if (wave_base + kWaveRows <= seg_rows) vj_slots<J, true>(L, v, row_l, seg_rows, q, cnt);
+      else if (wave_base < seg_rows) vj_slots<J, false>(L, v, row_l, seg_rows, q, cnt);
+      npassed += cnt - cnt0;
+    }
     // locate the next step and put its predicate columns in flight: they travel while this step's survivors are drained
     uint32_t nseg = seg, nwave_base = wave_base + kStepRows, nseg_rows = seg_rows;
     bool nhave = true;
@@ -472,23 +532,36 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
       if (useg >= P.units_per_seg) { useg -= P.units_per_seg; ++nseg; }
       if (nhave) {
         nseg_rows = P.seg_rows[nseg];
-        nwave_base = useg * P.unit_rows + wave * VH_WAVE_STEP_ROWS;
+        nwave_base = useg * P.unit_rows + wave * kWaveRows;
       }
     }
     if (nhave) {
-      if (nwave_base + VH_WAVE_STEP_ROWS <= nseg_rows) J::template preload<true>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
-      else J::template preload<false>(P, nseg, nwave_base + lane * 4, nseg_rows, v);
+      if (nwave_base + kWaveRows <= nseg_rows) J::template preload<true>(P, nseg, nwave_base + lane * kLaneStride, nseg_rows, v);
+      else J::template preload<false>(P, nseg, nwave_base + lane * kLaneStride, nseg_rows, v);
     }
     __builtin_amdgcn_wave_barrier();
     const bool flush = !nhave || nseg != seg;       // queue entries are rows of the current segment
-    while (cnt >= 64 || (flush && cnt)) {
-      const uint32_t take = cnt >= 64 ? 64u : cnt;
-      cnt -= take;
-      const bool act = (uint32_t)lane < take;
-      const uint32_t r = act ? q[cnt + lane] : 0u;
-      vj_drain<J>(P, seg, r, act, lds, xoff, nfresh, V);
+    auto drain_queue = [&](bool all) {
+      while (cnt >= 64 || (all && cnt)) {
+        const uint32_t take = cnt >= 64 ? 64u : cnt;
+        cnt -= take;
+        const bool act = (uint32_t)lane < take;
+        const uint32_t r = act ? q[cnt + lane] : 0u;
+        vj_drain<J>(P, seg, r, act, lds, xoff, nfresh, V);
+        __builtin_amdgcn_wave_barrier();
+      }
+    };
+    if constexpr (J::SLICED) {                      // two halves of 16 rows per lane: at most 1 024 rows join the queue between two drains
+      vj_push_mask(q, cnt, smask & 0xFFFFu, row_l, lane);
+      npassed += cnt - cnt0;
+      __builtin_amdgcn_wave_barrier();
+      drain_queue(false);
+      const uint32_t cnt1 = cnt;
+      vj_push_mask(q, cnt, smask >> 16, row_l + 16u, lane);
+      npassed += cnt - cnt1;
       __builtin_amdgcn_wave_barrier();
     }
+    drain_queue(flush);
     have = nhave; seg = nseg; wave_base = nwave_base; seg_rows = nseg_rows;
     if (MODE == VH_MODE_HASH && V.H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
   }

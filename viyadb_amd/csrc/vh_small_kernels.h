@@ -922,6 +922,39 @@ __global__ __launch_bounds__(256) void predpack_kernel(const VhPredPackArgs A) {
   }
 }
 
+// The BIT-SLICED form (VhPredPack::sliced): bit b of the row word is plane b, one bit per row — 64 rows of a plane are one 8-byte word, which
+// is what a wave's ballot of "bit b of my row's word" IS. A wave takes 64 rows a step; lane b keeps plane b's ballot and stores it. plane[0] =
+// the projection's arena, plane_stride[0] = bytes between segments, plane_pos[0] .. = unused; `bits` planes lie `pitch` bytes apart.
+__global__ __launch_bounds__(256) void predslice_kernel(const VhPredPackArgs A, uint32_t bits, uint64_t pitch) {
+  const VhJob J = A.jobs[blockIdx.x];
+  const uint32_t seg = J.seg, end = J.first + J.count;
+  const int lane = threadIdx.x & 63;
+  char* dst = A.plane[0] + (uint64_t)seg * A.plane_stride[0];
+  for (uint32_t row0 = J.first + (threadIdx.x >> 6) * 64u; row0 < end; row0 += 256u) {
+    const uint32_t row = row0 + lane;
+    uint32_t word = 0;
+    if (row < J.seg_rows) {
+      for (int c = 0; c < A.ncols; ++c) {
+        const char* s = A.src[c] + (uint64_t)seg * A.src_stride[c] + (uint64_t)row * A.esize[c];
+        uint32_t v;
+        switch (A.esize[c]) {
+          case 1: v = *reinterpret_cast<const uint8_t*>(s); break;
+          case 2: v = *reinterpret_cast<const uint16_t*>(s); break;
+          case 4: v = *reinterpret_cast<const uint32_t*>(s); break;
+          default: v = (uint32_t)*reinterpret_cast<const uint64_t*>(s); break;
+        }
+        word |= v << A.bitoff[c];
+      }
+    }
+    unsigned long long mine = 0ull;
+    for (uint32_t b = 0; b < bits; ++b) {
+      const unsigned long long m = __ballot((word >> b) & 1u);
+      if ((uint32_t)lane == b) mine = m;
+    }
+    if ((uint32_t)lane < bits) *reinterpret_cast<unsigned long long*>(dst + (uint64_t)lane * pitch + (uint64_t)(row0 >> 6) * 8ull) = mine;
+  }
+}
+
 // Narrow copy of an unsigned 32-bit column whose values fit T (vh_table_narrow): one job per block, 4 elements per thread and step.
 template <typename T>
 __global__ __launch_bounds__(256) void narrow_kernel(const uint32_t* src, uint64_t src_stride_elems, T* dst, uint64_t dst_stride_elems, const VhJob* jobs) {

@@ -414,7 +414,8 @@ static int predpack_refresh(vh_table* t, VhPredPack* pp) {
     }
     for (int q = 0; q < pp->nplanes; ++q) { A.plane[q] = pp->pbase[q]; A.plane_stride[q] = pp->pstride[q]; A.plane_width[q] = (uint32_t)pp->pwidth[q]; A.plane_pos[q] = (uint32_t)pp->ppos[q]; }
     A.jobs = d_jobs;
-    hipLaunchKernelGGL(predpack_kernel, dim3((unsigned)jobs.size()), dim3(256), 0, g_ctx.stream, A);
+    if (pp->sliced) hipLaunchKernelGGL(predslice_kernel, dim3((unsigned)jobs.size()), dim3(256), 0, g_ctx.stream, A, pp->bits, pp->pitch);
+    else hipLaunchKernelGGL(predpack_kernel, dim3((unsigned)jobs.size()), dim3(256), 0, g_ctx.stream, A);
     HIP_TRY(hipGetLastError());
     if (int rc = derived_enqueued(t)) return rc;
   }
@@ -423,10 +424,11 @@ static int predpack_refresh(vh_table* t, VhPredPack* pp) {
   return VH_OK;
 }
 // The projection that holds every column of `cols` (ascending), fresh, or nullptr. One whose fields no longer hold the recorded values is dropped.
-static VhPredPack* predpack_usable(vh_table* t, const std::vector<int>& cols) {
+static VhPredPack* predpack_usable(vh_table* t, const std::vector<int>& cols, int want_sliced = -1) {
   for (size_t k = 0; k < t->predpacks.size(); ++k) {
     VhPredPack* pp = t->predpacks[k].get();
     if (!std::includes(pp->cols.begin(), pp->cols.end(), cols.begin(), cols.end())) continue;
+    if (want_sliced >= 0 && (int)pp->sliced != want_sliced) continue;
     bool fits = true;
     for (size_t c = 0; c < pp->cols.size(); ++c) { const int b = predpack_bits_for(t, pp->cols[c]); fits &= b > 0 && b <= (int)pp->bitw[c]; }
     if (!fits) { predpack_drop(t, k); return nullptr; }
@@ -437,10 +439,10 @@ static VhPredPack* predpack_usable(vh_table* t, const std::vector<int>& cols) {
 }
 // Build one for `cols` (ascending, distinct). *built = nullptr when there is nothing to gain: a column that is no non-negative integer,
 // more than 32 bits in all, or no fewer bytes per row than the columns' narrowest copies would take.
-static int table_predpack_locked(vh_table* t, const std::vector<int>& cols, bool automatic, VhPredPack** built) {
+static int table_predpack_locked(vh_table* t, const std::vector<int>& cols, bool automatic, VhPredPack** built, bool sliced) {
   if (built) *built = nullptr;
   if (cols.empty() || cols.size() > VH_PACK_MAX_COLS || cols.size() > VJ_MAX_PRED) return VH_OK;
-  for (auto& pp : t->predpacks) if (pp->cols == cols) { if (built) *built = predpack_usable(t, cols); return VH_OK; }
+  for (auto& pp : t->predpacks) if (pp->cols == cols && pp->sliced == sliced) { if (built) *built = predpack_usable(t, cols, sliced ? 1 : 0); return VH_OK; }
   std::unique_ptr<VhPredPack> pp(new VhPredPack());
   uint32_t used = 0, plain = 0;
   for (int c : cols) {
@@ -453,13 +455,20 @@ static int table_predpack_locked(vh_table* t, const std::vector<int>& cols, bool
     plain += nwid ? (uint32_t)nwid : (uint32_t)t->cols[c].esize;
   }
   if (used > 32) return VH_OK;
-  for (uint32_t left = used, pos = 0; left > 0;) {
-    const int w = left > 8 ? 2 : 1;
-    pp->pwidth[pp->nplanes] = w; pp->ppos[pp->nplanes] = (int)pos; pp->pstride[pp->nplanes] = t->padded_rows * (uint64_t)w;
-    ++pp->nplanes;
-    pos += 8u * w; left = left > 8u * w ? left - 8u * w : 0;
+  if (sliced) {          // `used` planes of one bit per row; a plane's share of a segment padded to whole 256-byte blocks
+    pp->sliced = true; pp->bits = used;
+    pp->pitch = (t->padded_rows / 8 + 255) / 256 * 256;
+    pp->nplanes = 1; pp->pwidth[0] = 0; pp->ppos[0] = 0; pp->pstride[0] = pp->pitch * used;
+    if (used >= plain * 8u) return VH_OK;
+  } else {
+    for (uint32_t left = used, pos = 0; left > 0;) {
+      const int w = left > 8 ? 2 : 1;
+      pp->pwidth[pp->nplanes] = w; pp->ppos[pp->nplanes] = (int)pos; pp->pstride[pp->nplanes] = t->padded_rows * (uint64_t)w;
+      ++pp->nplanes;
+      pos += 8u * w; left = left > 8u * w ? left - 8u * w : 0;
+    }
+    if (pp->bytes_per_row() >= plain) return VH_OK;
   }
-  if (pp->bytes_per_row() >= plain) return VH_OK;
   pp->automatic = automatic;
   VhPredPack* raw = pp.get();
   t->predpacks.push_back(std::move(pp));
@@ -469,15 +478,17 @@ static int table_predpack_locked(vh_table* t, const std::vector<int>& cols, bool
   return VH_OK;
 }
 
-extern "C" int vh_table_predpack(vh_table* t, const int32_t* cols, int32_t ncols) {
+extern "C" int vh_table_predpack(vh_table* t, const int32_t* cols, int32_t ncols) { return vh_table_predpack_ex(t, cols, ncols, VH_PREDPACK_AUTO); }
+extern "C" int vh_table_predpack_ex(vh_table* t, const int32_t* cols, int32_t ncols, uint32_t form) {
   if (!t || !cols || ncols <= 0) return vh_fail(VH_E_INVALID, "vh_table_predpack: null argument");
+  if (form > VH_PREDPACK_SLICED) return vh_fail(VH_E_INVALID, "vh_table_predpack_ex: form %u", form);
   VH_ENTER();
   std::lock_guard<std::mutex> lk(t->mu);
   if (int src = sync_resolve(t)) return src;
   std::vector<int> set(cols, cols + ncols);
   std::sort(set.begin(), set.end());
   set.erase(std::unique(set.begin(), set.end()), set.end());
-  return table_predpack_locked(t, set, false, nullptr);
+  return table_predpack_locked(t, set, false, nullptr, form == VH_PREDPACK_AUTO ? !knobs().predpack_bytes : form == VH_PREDPACK_SLICED);
 }
 
 extern "C" int vh_table_narrow(vh_table* t, const int32_t* cols, int32_t ncols) {

@@ -18,6 +18,25 @@ static int merge_copies_now(vh_result* r, hipStream_t st) {
   return VH_OK;
 }
 
+// A compiled scan ran (or will run) without the predicate projection that serves its form: count the query; at the VH_AUTO_NARROW-th one
+// (the first, inside vh_table_prepare) build it for the queries to come, memory permitting. Only where kernels get compiled at all.
+void QueryBuild::predpack_auto(bool want_sliced) {
+  const int auto_after = g_preparing ? 1 : knobs().auto_narrow;
+  if (pp_cols.empty() || auto_after <= 0) return;
+  uint64_t rows = 0;
+  for (uint32_t sgi = 0; sgi < t->nseg; ++sgi) rows += t->seg_rows[sgi];
+  if (!(vh_jit_policy() == VH_JIT_FORCE || (p->flags & VH_PLAN_FORCE_JIT) || rows >= vh_jit_min_rows())) return;
+  const bool sliced = want_sliced && !knobs().predpack_bytes;
+  for (auto& q : t->predpacks) if (q->cols == pp_cols && q->sliced == sliced) return;
+  std::string key = sliced ? "s:" : "b:";
+  for (int c : pp_cols) { key += std::to_string(c); key.push_back(','); }
+  if (++t->ppred_seen[key] < (uint32_t)auto_after) return;
+  size_t free_b = 0, total_b = 0;
+  const size_t need = (size_t)t->cap_seg * t->padded_rows * 4;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + total_b / 4) (void)table_predpack_locked(t, pp_cols, true, nullptr, sliced);
+  else t->ppred_seen[key] = 0;
+}
+
 int QueryBuild::compile_kernel() {
   int rc = VH_OK; (void)rc;
   // ---------------- the scan kernel compiled for this plan shape (vh_jit.hip), when there is to be one
@@ -55,10 +74,19 @@ int QueryBuild::compile_kernel() {
     js.hp_pack = hp_pack ? 1 : 0; js.hp_pbits = hp_pbits; js.hp_idbits = hp_idbits;
     js.ng = P.ngroup; js.nm = P.nmetric;
     js.qpay = !lanes ? qpay : 0; js.qpay_slot = js.qpay ? qpay_slot : -1;
+    {   // which predicate projection, if any (shape_filter noted what exists): rows -> byte planes, everything else -> bit-sliced planes
+      const bool rows_form = lanes || js.qpay != 0;
+      const bool have_sliced = js.pp_sliced != 0, have_bytes = js.pp_nplanes != 0;
+      if (have_sliced && !rows_form && !(p->flags & VH_PLAN_NO_SLICED)) { js.pp_nplanes = 0; for (int k = 0; k < js.npred; ++k) { js.pp_off[k] = pp_soff[k]; js.pp_bits[k] = pp_sbits[k]; } }
+      else { js.pp_sliced = 0; js.pp_slot = -1; for (int k = 0; k < js.npred; ++k) { js.pp_off[k] = pp_boff[k]; js.pp_bits[k] = pp_bbits[k]; } }
+      if (!(p->flags & (VH_PLAN_NO_NARROW | VH_PLAN_NO_PREDPACK)) && (rows_form ? !have_bytes : !have_sliced)) predpack_auto(!rows_form);
+    }
     {   // (the records' registers count against the packed predicate registers' budget)
       int nv = 0;
-      if (js.pp_nplanes) for (int q = 0; q < js.pp_nplanes; ++q) nv += VH_SUBSTEPS * js.pp_plane[q].width;
+      if (js.pp_sliced) for (int k = 0; k < js.npred; ++k) nv += js.pp_bits[k];
+      else if (js.pp_nplanes) for (int q = 0; q < js.pp_nplanes; ++q) nv += VH_SUBSTEPS * js.pp_plane[q].width;
       else for (int k = 0; k < js.npred; ++k) nv += VH_SUBSTEPS * js.pred[k].width;
+      if (js.pp_sliced && nv > 64) { js.pp_sliced = 0; js.pp_slot = -1; }      // (more planes than registers to hold them: the columns themselves)
       if (js.qpay && nv + VH_SUBSTEPS * js.qpay > VJ_MAX_NV) { js.qpay = 0; js.qpay_slot = -1; }
     }
     for (int i = 0; i < P.ngroup; ++i) {
@@ -176,7 +204,7 @@ int QueryBuild::decompose_work() {
   }
   int occupancy = 0;
   if (env_bpc <= 0) scan_dispatch(0, &occupancy);
-  const uint32_t step = BLOCK * VH_LANE_ROWS;
+  const uint32_t step = BLOCK * (jk && jshape.pp_sliced ? 32u : (uint32_t)VH_LANE_ROWS);      // (bit-sliced predicates: a lane owns 32 consecutive rows per step)
   const uint64_t padded = (t->segment_rows + step - 1) / step * step;
   // all blocks co-resident (the compacting kernels need ~100-130 VGPRs: 4 waves/SIMD), units small enough
   // that the static round-robin leaves < 2 % imbalance
@@ -532,9 +560,9 @@ int QueryBuild::launch() {
     for (int k = 0; k < P.npred; ++k) if (P.pred_width[k] != 4) { P.pred_slot[k] = (uint8_t)pred_wide_slot[k]; P.pred_width[k] = 4; }
   bool narrowed = false;
   for (int k = 0; k < P.npred; ++k) narrowed |= P.pred_width[k] != 4;
-  if (jk) { narrowed = false; for (int k = 0; k < jshape.npred; ++k) narrowed |= jshape.pred[k].width != vh_elem_size(jshape.pred[k].type); }
+  if (jk) { narrowed = jshape.pp_nplanes || jshape.pp_sliced; for (int k = 0; k < jshape.npred; ++k) narrowed |= jshape.pred[k].width != vh_elem_size(jshape.pred[k].type); }
   r->hpart = hpart;
-  r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0) | (hpart && hp_pack ? 256 : 0) | ((mode == VH_MODE_DENSE_PART || hpart) && x->scratch_placed ? 512 : 0) | (mode == VH_MODE_DENSE_PART && P.gid_bits ? 1024 : 0) | (jk && jshape.pp_nplanes ? 2048 : 0) | (jk && jshape.qpay ? 4096 : 0);
+  r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0) | (hpart && hp_pack ? 256 : 0) | ((mode == VH_MODE_DENSE_PART || hpart) && x->scratch_placed ? 512 : 0) | (mode == VH_MODE_DENSE_PART && P.gid_bits ? 1024 : 0) | (jk && (jshape.pp_nplanes || jshape.pp_sliced) ? 2048 : 0) | (jk && jshape.qpay ? 4096 : 0) | (jk && jshape.pp_sliced ? 8192 : 0);
   if (r->hp_chunks) memset(x->h_chunk, 0, VH_HP_CHUNKS * sizeof(unsigned long long));      // (what the context's previous query left there)
   if (P.total_units) {
     scan_dispatch(grid, nullptr);

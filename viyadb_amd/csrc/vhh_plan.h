@@ -219,6 +219,9 @@ struct QueryBuild {
   uint32_t hp_chunk = 256;
   bool packed = false, packed_compressed = false;
   int qpay = 0, qpay_slot = -1;                  // streamed payload (VhJitShape::qpay): the record's bytes, the slot the records come from
+  std::vector<int> pp_cols;                      // the filter's columns (ascending) when every leaf reads a fixed-width column: what a predicate projection must hold
+  int pp_boff[VJ_MAX_PRED] = {}, pp_bbits[VJ_MAX_PRED] = {}, pp_soff[VJ_MAX_PRED] = {}, pp_sbits[VJ_MAX_PRED] = {};      // predicate column k's bit field in the byte-plane / bit-sliced projection noted in jshape
+  void predpack_auto(bool want_sliced);          // counts this query towards an unasked predicate projection of the form it would have used
   VhJitKernel* jk = nullptr;
   int jit_block = 256;
   // ---- work decomposition, scratch
@@ -420,44 +423,38 @@ int QueryBuild::shape_filter() {
     jshape.nlits = (int)r->h_lits.size();
   }
 
-  // Bit-packed predicate projection (vh_table_predpack; built unasked for a set of predicate columns the compiled kernel filters on for the
-  // third time): the compiled scan streams its byte planes — every predicate column a bit field of one word per row — instead of the
-  // columns or their narrow copies.
+  // Bit-packed predicate projections (vh_table_predpack) of the filter's columns: the byte-plane form serves every compiled kernel form,
+  // the bit-sliced one the compacting kernels. Both are noted here when they exist; compile_kernel picks (the no-compaction form and the
+  // streamed payload want rows, i.e. byte planes; everything else the bit-sliced planes) and asks for the one it lacked to be built
+  // for the queries to come (predpack_auto).
   bool jit_predpack = false;
-  std::vector<int> pp_cols;
+  pp_cols.clear();
   if (jit_try && jshape.npred > 0 && !(p->flags & (VH_PLAN_NO_NARROW | VH_PLAN_NO_PREDPACK))) {
     bool all_cols = true;
     for (int k = 0; k < jshape.npred; ++k) { all_cols &= jit_pred_col[k] >= 0; pp_cols.push_back(jit_pred_col[k]); }
     std::sort(pp_cols.begin(), pp_cols.end());
     pp_cols.erase(std::unique(pp_cols.begin(), pp_cols.end()), pp_cols.end());
-    VhPredPack* pp = all_cols ? predpack_usable(t, pp_cols) : nullptr;
-    const int auto_after = g_preparing ? 1 : knobs().auto_narrow;
-    if (all_cols && !pp && auto_after > 0) {
-      // only where the compiled kernel will run: asked for, or a table big enough for VH_JIT=auto to compile one
-      uint64_t rows = 0;
-      for (uint32_t sgi = 0; sgi < t->nseg; ++sgi) rows += t->seg_rows[sgi];
-      const bool will_compile = vh_jit_policy() == VH_JIT_FORCE || (p->flags & VH_PLAN_FORCE_JIT) || rows >= vh_jit_min_rows();
-      std::string key;
-      for (int c : pp_cols) { key += std::to_string(c); key.push_back(','); }
-      bool exists = false;
-      for (auto& q : t->predpacks) exists |= q->cols == pp_cols;
-      if (will_compile && !exists && ++t->ppred_seen[key] >= (uint32_t)auto_after) {
-        size_t free_b = 0, total_b = 0;
-        const size_t need = (size_t)t->cap_seg * t->padded_rows * 4;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > need + total_b / 4) { if (int prc = table_predpack_locked(t, pp_cols, true, &pp)) return prc; }
-        else t->ppred_seen[key] = 0;
-      }
-    }
-    if (pp && P.nslots + pp->nplanes <= VH_MAX_SLOTS) {
-      jshape.pp_nplanes = pp->nplanes;
-      for (int q = 0; q < pp->nplanes; ++q) {
-        P.colbase[P.nslots] = pp->pbase[q]; P.colstride[P.nslots] = pp->pstride[q]; P.colpitch[P.nslots] = (uint32_t)pp->pwidth[q];
-        jshape.pp_plane[q].slot = P.nslots++; jshape.pp_plane[q].width = pp->pwidth[q]; jshape.pp_plane[q].pos = pp->ppos[q];
+    if (!all_cols) pp_cols.clear();
+    VhPredPack* pb = all_cols ? predpack_usable(t, pp_cols, 0) : nullptr;
+    VhPredPack* ps = all_cols ? predpack_usable(t, pp_cols, 1) : nullptr;
+    if (pb && P.nslots + pb->nplanes <= VH_MAX_SLOTS) {
+      jshape.pp_nplanes = pb->nplanes;
+      for (int q = 0; q < pb->nplanes; ++q) {
+        P.colbase[P.nslots] = pb->pbase[q]; P.colstride[P.nslots] = pb->pstride[q]; P.colpitch[P.nslots] = (uint32_t)pb->pwidth[q];
+        jshape.pp_plane[q].slot = P.nslots++; jshape.pp_plane[q].width = pb->pwidth[q]; jshape.pp_plane[q].pos = pb->ppos[q];
       }
       for (int k = 0; k < jshape.npred; ++k) {
-        const size_t at = (size_t)(std::find(pp->cols.begin(), pp->cols.end(), jit_pred_col[k]) - pp->cols.begin());
-        jshape.pp_off[k] = pp->bitoff[at]; jshape.pp_bits[k] = pp->bitw[at];
-        jshape.pred[k].slot = -1; jshape.pred[k].width = 0;       // (streamed through the planes)
+        const size_t at = (size_t)(std::find(pb->cols.begin(), pb->cols.end(), jit_pred_col[k]) - pb->cols.begin());
+        pp_boff[k] = pb->bitoff[at]; pp_bbits[k] = pb->bitw[at];
+      }
+      jit_predpack = true;
+    }
+    if (ps && P.nslots < VH_MAX_SLOTS) {
+      P.colbase[P.nslots] = ps->pbase[0]; P.colstride[P.nslots] = ps->pstride[0]; P.colpitch[P.nslots] = (uint32_t)ps->pitch;
+      jshape.pp_sliced = 1; jshape.pp_slot = P.nslots++;
+      for (int k = 0; k < jshape.npred; ++k) {
+        const size_t at = (size_t)(std::find(ps->cols.begin(), ps->cols.end(), jit_pred_col[k]) - ps->cols.begin());
+        pp_soff[k] = ps->bitoff[at]; pp_sbits[k] = ps->bitw[at];
       }
       jit_predpack = true;
     }
@@ -497,7 +494,7 @@ int QueryBuild::shape_filter() {
         P.pred_slot[k] = (uint8_t)ns;
         P.pred_width[k] = (uint8_t)P.colpitch[ns];
       }
-    if (jit_try && !jit_predpack)
+    if (jit_try)      // (with a predicate projection at hand these are the fallback of the kernel forms it does not serve: existing copies only, see narrow_for)
       for (int k = 0; k < jshape.npred; ++k) {
         if (jit_pred_col[k] < 0 || t->cols[jit_pred_col[k]].elem != VH_U32) continue;
         const int ns = narrow_for(jit_pred_col[k]);
@@ -1220,37 +1217,24 @@ int QueryBuild::choose_projection() {
                 P.nslots + (int)gcols.size() <= VH_MAX_SLOTS;
     const bool forced = (p->flags & VH_PLAN_FORCE_PACK) != 0;
     // A bit-field projection of 4-byte records that holds every value of the plan can be STREAMED by the compiled compacting scan (the
-    // survivor's record goes into the wave's queue, nothing is gathered): 4 bytes per row whatever passes — cheaper than gathers from
-    // about 2.5 % selectivity on (a random 128-byte line per survivor touches half of the projection's lines there), and cheaper than
-    // the arenas at ANY selectivity above that.
+    // survivor's record goes into the wave's queue, nothing is gathered): 4 bytes per row whatever passes. Measured on C3 (tools/qpay_probe.py,
+    // profiles/r05/NOTES.md): gathers win up to ~8 % selectivity, streaming from there on — 12 % faster at 25 %, 40 % at 50 %, 30 % at 100 %
+    // (against the arenas, which is what a query above 15 % used to read).
     bool all_plain = P.nbitset == 0;
     for (int j = 0; j < P.nmetric; ++j) all_plain &= metric_col[j] >= 0;
-    const bool qpay_can = jit_try && !lanes && all_plain && want && !(p->flags & VH_PLAN_NO_QPAY) && (mode == VH_MODE_DENSE_PART || mode == VH_MODE_DENSE_GLOBAL || mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH);
-    bool qpay_want = false;
-    if (qpay_can) {
-      for (auto& pk : t->packs) {
-        bool all = pk->bits && pk->rec_bytes == 4;
-        for (int c : gcols) all &= pk->col_index(c) >= 0;
-        qpay_want |= all;
-      }
-      if (qpay_want && !(p->flags & VH_PLAN_FORCE_QPAY)) {
-        double sel = 1.0;
-        rc = probed_selectivity(&sel);
-        if (rc) { return rc; }
-        qpay_want = p->nfilter == 0 || sel >= knobs().qpay_min_sel;
-      }
-    }
-    if (want && !forced && !qpay_want) {
-      // lines touched per survivor: one record vs one per column; the projection stops paying off once most lines of
+    const bool qpay_can = jit_try && !lanes && all_plain && want && !(p->flags & VH_PLAN_NO_QPAY);
+    bool want_gather = want, want_stream = false;
+    if (want) {
+      // lines touched per survivor: one record vs one per column; gathering stops paying off once most lines of
       // the arenas are touched anyway (C3 columns: ~20 % of the rows passing)
-      want = fastj && p->nfilter > 0;
-      if (want) {
-        double sel = 1.0;
-        rc = probed_selectivity(&sel);
-        if (rc) { return rc; }
-        want = sel <= 0.15;
-      }
+      if (!forced) want_gather = fastj && p->nfilter > 0;
+      double sel = 1.0;
+      if ((want_gather && !forced) || qpay_can) { rc = probed_selectivity(&sel); if (rc) { return rc; } }
+      if (!forced) want_gather = want_gather && sel <= 0.15;
+      want_stream = qpay_can && ((p->flags & VH_PLAN_FORCE_QPAY) || p->nfilter == 0 || sel >= knobs().qpay_min_sel);
+      if (!forced) want = want_gather || want_stream;
     }
+    const bool qpay_want = want_stream;
     VhPack* use = nullptr;
     if (want) {
       // (compressed records are read by the per-query compiled kernels only)
@@ -1286,6 +1270,7 @@ int QueryBuild::choose_projection() {
       }
       if (rc) { return rc; }
     }
+    if (use && !want_gather && !forced && !(use->bits && use->rec_bytes == 4)) use = nullptr;      // (asked for to be streamed, and it cannot be: the arenas)
     if (use) {
       int pslot_of[256];
       for (int i = 0; i < 256; ++i) pslot_of[i] = -1;

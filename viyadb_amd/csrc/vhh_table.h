@@ -79,7 +79,11 @@ struct VhPredPack {
   uint32_t cap_seg = 0;
   std::vector<uint64_t> seg_mod; uint64_t applied_epoch = 0;
   bool automatic = false;
+  // BIT-SLICED form: one plane per BIT of the word, one bit per row (32 rows = one 4-byte word of a plane); pbase[0] is the whole arena,
+  // pstride[0] the bytes between segments, `pitch` the bytes between planes inside a segment; `bits` planes.
+  bool sliced = false; uint32_t bits = 0; uint64_t pitch = 0;
   uint32_t bytes_per_row() const { uint32_t b = 0; for (int q = 0; q < nplanes; ++q) b += (uint32_t)pwidth[q]; return b; }
+  uint32_t bits_per_row() const { return sliced ? bits : 8u * bytes_per_row(); }
 };
 // What a sync did to a segment's columns: rows [first, last) at sync epoch `epoch` (the table's journal; derived layouts replay it).
 struct VhChange { uint64_t epoch; uint32_t seg, first, last; };

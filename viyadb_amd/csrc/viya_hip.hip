@@ -65,7 +65,7 @@ static std::mutex g_mu;
 // VH_TEST_* / VH_POISON / VH_NO_SPLIT_TILE / VH_PART_TABLE_KB knobs are the exception — tests switch them between two queries of one process — and stay getenv() calls
 // at their (cold) sites.
 struct VhKnobs {
-  bool trace_alloc, no_topk, no_stage, jit_verbose, skip_phase2, no_direct_emit, times, no_jit_pagg;
+  bool trace_alloc, no_topk, no_stage, jit_verbose, skip_phase2, no_direct_emit, times, no_jit_pagg, predpack_bytes;
   int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, split_bpc, bw_blocks_per_cu, place_trials, place_gb, hp_list, hp_stream, deliver_blocks;
   double hp_load_g, hp_load_s, qpay_min_sel;
 };
@@ -76,7 +76,7 @@ static const VhKnobs& knobs() {
     auto real = [](const char* n, double dflt) { const char* e = getenv(n); return e ? atof(e) : dflt; };
     VhKnobs x{};
     x.trace_alloc = flag("VH_TRACE_ALLOC"); x.no_topk = flag("VH_NO_TOPK"); x.no_stage = flag("VH_NO_STAGE");
-    x.jit_verbose = flag("VH_JIT_VERBOSE"); x.skip_phase2 = flag("VH_ABLATE_NO_PHASE2"); x.no_direct_emit = flag("VH_NO_DIRECT_EMIT"); x.times = flag("VH_TIMES"); x.no_jit_pagg = flag("VH_NO_JIT_PAGG");      // (measurement / tests: the pre-built part_agg_kernel behind a compiled scan)
+    x.jit_verbose = flag("VH_JIT_VERBOSE"); x.skip_phase2 = flag("VH_ABLATE_NO_PHASE2"); x.no_direct_emit = flag("VH_NO_DIRECT_EMIT"); x.times = flag("VH_TIMES"); x.no_jit_pagg = flag("VH_NO_JIT_PAGG"); x.predpack_bytes = flag("VH_PREDPACK_BYTES");      // (measurement: automatic predicate projections as byte planes, not bit-sliced)      // (measurement / tests: the pre-built part_agg_kernel behind a compiled scan)
     x.max_exec = std::max(1, num("VH_MAX_EXEC", 16));
     x.auto_narrow = num("VH_AUTO_NARROW", 3); x.auto_pack = num("VH_AUTO_PACK", 3);
     x.jit_ablate = num("VH_JIT_ABLATE", 0); x.hp_ablate = num("VH_HP_ABLATE", 0); x.hp_bpp = num("VH_HP_BPP", 0); x.pack_plain = num("VH_PACK_PLAIN", 0);
@@ -86,7 +86,7 @@ static const VhKnobs& knobs() {
     x.deliver_blocks = num("VH_DELIVER_BLOCKS", 64);  // blocks of deliver_kernel; 0: big results through hipMemcpyAsync (the DMA engine)
     x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
     x.hp_load_g = real("VH_HP_LOAD_G", 0.7); x.hp_load_s = real("VH_HP_LOAD_S", 0.7);
-    x.qpay_min_sel = real("VH_QPAY_MIN_SEL", 0.2);        // selectivity from which the compiled scan streams 4-byte payload records instead of gathering them (measured: profiles/r05/NOTES.md)
+    x.qpay_min_sel = real("VH_QPAY_MIN_SEL", 0.08);        // selectivity from which the compiled scan streams 4-byte payload records instead of gathering them (measured: profiles/r05/NOTES.md)
     return x;
   }();
   return k;

@@ -86,6 +86,7 @@ class AggResult:
     packed_compressed: bool = False  # ... from compressed records (integers stored at the width their values need)
     hp_packed: bool = False        # hashed partitioning with packed 16-byte tuples (a count-distinct's ids inside the payload word)
     predpack: bool = False         # predicate columns were streamed as byte planes of a bit-packed predicate projection (vh_table_predpack)
+    sliced: bool = False           # ... of its bit-sliced form (comparisons bit-serial on 32 rows per lane)
     streamed_payload: bool = False  # ... and the payload records streamed beside them, a survivor's record queued in its row's place (no gathers)
     flags: int = 0                 # vh_result_info.reserved as it came
 
@@ -206,12 +207,13 @@ class DeviceTable:
             arr = (C.c_int32 * len(cols))(*cols)
             capi.check(self.lib.vh_table_narrow(self.handle, arr, len(cols)))
 
-    def predpack(self, cols) -> None:
-        """A bit-packed predicate projection over `cols` (vh_table_predpack): what the compiled scan streams when a query filters on them."""
+    def predpack(self, cols, sliced: Optional[bool] = None) -> None:
+        """A bit-packed predicate projection over `cols` (vh_table_predpack): what the compiled scan streams when a query filters on them.
+        sliced: None = the library decides (bit-sliced), False = byte planes, True = one plane per bit."""
         cols = sorted(set(int(c) for c in cols))
         if cols:
             arr = (C.c_int32 * len(cols))(*cols)
-            capi.check(self.lib.vh_table_predpack(self.handle, arr, len(cols)))
+            capi.check(self.lib.vh_table_predpack_ex(self.handle, arr, len(cols), 0 if sliced is None else 2 if sliced else 1))
 
     def filter_columns(self, plan: "AggPlan"):
         """Table columns the plan's filter reads."""
@@ -362,7 +364,7 @@ class DeviceTable:
                          float(info.total_ms), int(info.algorithmic_bytes), int(info.retries), bool(info.reserved & 1),
                          bool(info.reserved & 2), bool(info.reserved & 8), int(ng), (self.lib.vh_result_kernel(res) or b"").decode(),
                          bool(info.reserved & 16), bool(info.reserved & 32), bool(info.reserved & 64), bool(info.reserved & 128), bool(info.reserved & 256),
-                         bool(info.reserved & 2048), bool(info.reserved & 4096), int(info.reserved))
+                         bool(info.reserved & 2048), bool(info.reserved & 8192), bool(info.reserved & 4096), int(info.reserved))
 
     def query_agg(self, plan: AggPlan, copy: bool = True) -> AggResult:
         p, keep = self._build_plan(plan)
