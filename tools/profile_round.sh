@@ -5,7 +5,7 @@
 # line names (roofline.kernel comes from the library: vh_result_kernel), written to profiles/<round>/ at once; THEN the bench line, which
 # finds that summary (same kernel, same layout, same sources) and reports roofline.traffic / frac from it.
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh r04 <git head>
-R=${1:-r04}
+R=${1:-r05}
 HEAD=${2:-unknown}
 OUT=gpurun_out/$R
 mkdir -p $OUT profiles/$R
@@ -47,6 +47,11 @@ one c5t 125000000 1.5e9 --workload C5t --segments 125 --steps 5 --warmup 1
 python bench.py --workload C1 --no-cpu-parallel --no-reference-layout > $OUT/bench_c1_1gpu.json 2> $OUT/bench_c1.err     # the plumbing case: a bench line only (launch-bound)
 python tools/scale_proxy.py 1 2 4 8 2>/dev/null | grep '^{' > $OUT/scale_proxy.txt                                         # one rank's step of the N-GPU run, on one GPU
 bash tools/fetch_calib.sh $OUT/fetch_calibration.json > $OUT/fetch_calibration.log 2>&1
+# the mirror under ingest (batched sync, derived layouts by row range, the shim's clean pass) and the layout A/Bs of the round, each inside ONE process
+g++ -std=c++17 -O2 tools/ingest_bench.cc -Iinclude -Lviyadb_amd -lviya_host -lviya_hip -Wl,-rpath,$PWD/viyadb_amd -o /tmp/ingest_bench && /tmp/ingest_bench > $OUT/ingest.json 2> $OUT/ingest.err
+python tools/pred_ab.py 1000 7 2>/dev/null | grep '^{' > $OUT/pred_ab.txt
+python tools/pred_ab.py 125 7 2>/dev/null | grep '^{' >> $OUT/pred_ab.txt
+python tools/qpay_probe.py 2>/dev/null | grep '^{' > $OUT/qpay_probe.txt
 # how stable the headline is from process to process: ten fresh processes as a caller that prepares its query shape (vh_table_prepare) and
 # ten as one that does not (an ordinary first query: plain hipMalloc for the tuple pool)
 { for i in 1 2 3 4 5 6 7 8 9 10; do python bench.py $Q --steps 10 --warmup 3 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('prepared', $i, round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],3), d['config']['pool_placed_by_measurement'])"; done
