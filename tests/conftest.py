@@ -6,6 +6,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# the library's VH_TEST_* / VH_POISON / VH_PART_TABLE_KB hooks are behind ONE gate it reads once (viya_hip.hip test_env): open it for
+# every test process and the workers they spawn (inherited environment)
+os.environ.setdefault("VH_TEST_HOOKS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

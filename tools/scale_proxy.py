@@ -14,6 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29541")
+os.environ["VH_TEST_HOOKS"] = "1"            # the gate in front of the library's test hooks (viya_hip.hip test_env)
 os.environ["VH_TEST_SHARDED_WORLD1"] = "1"
 import torch                              # noqa: E402
 import torch.distributed as dist          # noqa: E402

@@ -340,7 +340,7 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
   const VhPlanDev& P = r->plan;
   const int nk = P.ngroup, nm = (int)r->user_metric.size();
   const bool has_hidden = r->info.has_hidden_count != 0;
-  r->stream_quiet = false; hipStream_t st = r->exec->stream();
+  hipStream_t st = r->stream_for_work();
   std::vector<int> bitset_js;
   for (int j = 0; j < nm; ++j) if (P.m[r->user_metric[j]].sop() == SOP_BITSET) bitset_js.push_back(j);
   const int nbs = (int)bitset_js.size();
@@ -515,7 +515,7 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
   std::vector<uint64_t> soff(W + 1, 0), goff(W + 1, 0);
   for (int p = 0; p <= W; ++p) soff[p] = p > root ? rm->ngroups_host : 0;          // everything goes to root
   if (R == root) for (int p = 0; p < W; ++p) goff[p + 1] = goff[p] + cnts[(size_t)p * 3];
-  rm->stream_quiet = false; hipStream_t st2 = rm->exec->stream();
+  hipStream_t st2 = rm->stream_for_work();
   if (int rc = comm->ops.alltoallv_device(comm->ops.ctx, (int32_t)send.size(), send.data(), recv.data(), es.data(), soff.data(), goff.data(), st2))
     return rc < 0 ? rc : vh_fail(VH_E_DEVICE, "gather of the merged groups failed (%d)", rc);
   if (R == root && total_rows) HIP_TRY(hipMemcpyAsync(rf->h_own, rf->d_own, bytes, hipMemcpyDeviceToHost, st2));
@@ -616,7 +616,7 @@ static int fused_dense_step(vh_table* t, vh_comm* comm, int root, VhExec* x, vh_
 extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* comm, int32_t root, vh_result** out) {
   if (!t || !plan || !comm || !out) return vh_fail(VH_E_INVALID, "null argument");
   if (root >= comm->world || root < -1) return vh_fail(VH_E_INVALID, "root %d of %d ranks", root, comm->world);
-  if (comm->world == 1 && !getenv("VH_TEST_SHARDED_WORLD1")) return vh_query_agg(t, plan, out);   // (the test knob sends one rank through the whole protocol: RCCL with a single GPU)
+  if (comm->world == 1 && !test_env("VH_TEST_SHARDED_WORLD1")) return vh_query_agg(t, plan, out);   // (the test knob sends one rank through the whole protocol: RCCL with a single GPU)
   VH_ENTER();
   std::lock_guard<std::mutex> comm_lk(comm->mu);
   VhExec* x = nullptr;

@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256) void emit_groups_kernel(const VhEmitArgs A) {
 // included) straight into the pinned host buffer, the 512-byte header behind them. As three launches (dense_merge_kernel, emit_groups_kernel,
 // publish_header_kernel) it was 5 + 5 + 4 us and a gap behind C1's 20 us scan. The host reads nothing before the event behind this kernel.
 #define VH_SMALL_TAIL_MAX 8192      // table entries
+#define VH_SMALL_TAIL_STATES 65536  // ... and states read by the one block (entries x private copies x metrics)
 __global__ __launch_bounds__(1024) void small_tail_kernel(const VhMergeArgs M, const VhEmitArgs A, unsigned long long* head, const unsigned long long* dev_head) {
   __shared__ uint32_t s_keep[16], s_seen[16];
   __shared__ unsigned long long s_total, s_seen_total;

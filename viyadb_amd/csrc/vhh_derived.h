@@ -234,7 +234,7 @@ static int table_pack_locked(vh_table* t, const int32_t* cols, int32_t ncols, bo
     while (rec < bytes) rec <<= 1;
     // bit fields instead of bytes when every column is a non-negative integer (by its recorded min / max) and the word comes out smaller
     std::vector<uint8_t> bitoff, bitw;
-    bool bits = compress && !getenv("VH_NO_PACK_BITS") && t->nseg > 0;
+    bool bits = compress && !test_env("VH_NO_PACK_BITS") && t->nseg > 0;
     uint32_t used = 0;
     for (int c : ord) {
       if (!bits) break;

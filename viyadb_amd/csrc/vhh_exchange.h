@@ -10,8 +10,7 @@ extern "C" int vh_result_device_buffers(vh_result* r, vh_device_buffer* bufs, in
   if (r->unmerged) {        // the caller reduces copy 0 across GPUs: the private copies go into it first (a small result leaves them to its one tail launch)
     if (!r->exec) return vh_fail(VH_E_INVALID, "a launched result without its context");
     VH_ENTER();
-    r->stream_quiet = false;
-    if (int mrc = merge_copies_now(r, r->exec->stream())) return mrc;
+    if (int mrc = merge_copies_now(r, r->stream_for_work())) return mrc;
   }
   // presence bytes are only written when no SUM state carries the flag (SOP_ADD32P): one collective less
   if (!((r->mode == VH_MODE_DENSE_GLOBAL || r->mode == VH_MODE_DENSE_PART) && P.present_carrier >= 0)) bufs[n++] = vh_device_buffer{P.present, P.G, VH_U8, VH_RED_MAX};
@@ -67,7 +66,7 @@ extern "C" int vh_result_partition(vh_result* r, uint32_t nparts, uint64_t* part
   if (r->topk) return vh_fail(VH_E_UNSUPPORTED, "top-N applies to merged groups: run the partial query without it");
   VH_ENTER();
   const VhPlanDev& P = r->plan;
-  r->stream_quiet = false; hipStream_t st = r->exec->stream();
+  hipStream_t st = r->stream_for_work();
   const uint64_t ng = r->ngroups_host;
   const int ncols = P.ngroup + P.nmetric;
   if (max_bufs < ncols) return vh_fail(VH_E_INVALID, "need %d buffers", ncols);
@@ -150,7 +149,7 @@ extern "C" int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t 
     // one a rank saw — the count is only known after the counting pass, so the buffers are allocated between the passes
     if (r->hp_args.units != 2 && !r->hp_args.pk) return vh_fail(VH_E_INVALID, "the hashed partitioning carried no ids for metric %d", metric);
     VH_ENTER();
-    r->stream_quiet = false; hipStream_t st = r->exec->stream();
+    hipStream_t st = r->stream_for_work();
     const VhHpPool& B = r->hp_args.k[0].b;
     VhHpPairArgs A{};
     A.tuples = B.tuples; A.fill = B.fill; A.max_extents = B.max_extents; A.stride = B.stride; A.et = (uint32_t)(HP_ET / r->hp_args.units);
@@ -198,7 +197,7 @@ extern "C" int vh_result_partition_pairs(vh_result* r, int32_t metric, uint32_t 
   }
   if (r->mode != VH_MODE_HASH && r->nxcd != 1) return vh_fail(VH_E_UNSUPPORTED, "pairs of an XCD-private dense table");
   VH_ENTER();
-  r->stream_quiet = false; hipStream_t st = r->exec->stream();
+  hipStream_t st = r->stream_for_work();
   // number of pairs = sum of the emitted cardinalities would need a reduction; the set's fill count is counters[4],
   // read back with the result header (h_base): every pair bumps it exactly once
   const uint64_t npairs = reinterpret_cast<const unsigned long long*>(r->h_base)[4];

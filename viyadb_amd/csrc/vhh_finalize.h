@@ -285,6 +285,9 @@ static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
   else if (retry == 3) {                                     // tuple extents exhausted: more room, then give up on partitioning
     // the attempt counted its survivors even though it dropped their tuples: the next one is sized for exactly that many
     const uint64_t had = (uint64_t)r->plan.max_extents * r->plan.ext_tuples;
+    // positional chunks (VhPlanDev::ext_waves) ran out with room to spare: some waves met far more survivors than others (a time range over
+    // time-ordered segments, a skewed partition). Remembered for the shape, like groups_seen for hash sizing: its next queries start on the cursor
+    if (r->plan.ext_waves && r->info.passed_recs + r->info.passed_recs / 16 <= had) { std::lock_guard<std::mutex> lk(t->mu); t->part_clustered.insert(r->group_sig); }
     if (rp->part_override && had >= r->info.scanned_recs) rp->no_part = true;
     else rp->part_override = std::max<uint64_t>(std::max<uint64_t>(rp->part_override * 2, r->info.passed_recs + r->info.passed_recs / 16), 1ull << 16);
   }

@@ -41,7 +41,7 @@ int QueryBuild::compile_kernel() {
   int rc = VH_OK; (void)rc;
   // ---------------- the scan kernel compiled for this plan shape (vh_jit.hip), when there is to be one
   // the no-compaction kernels are pre-built, except DENSE_LDS's over plain 4- / 8-byte arena columns (C2's shape), which has a compiled form
-  if (jit_try && lanes && (mode != VH_MODE_DENSE_LDS || getenv("VH_TEST_NO_JIT_LANES"))) jit_try = false;
+  if (jit_try && lanes && (mode != VH_MODE_DENSE_LDS || test_env("VH_TEST_NO_JIT_LANES"))) jit_try = false;
   if (jit_try) {
     VhJitShape& js = jshape;
     js.mode = mode;
@@ -200,7 +200,7 @@ int QueryBuild::decompose_work() {
       r->kernel += hn + jk->name + "_hpagg";
     }
     const std::string pagg = jit_pagg() ? " + " + jk->name + "_pagg" : std::string(" + part_agg_kernel<1024>");
-    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? pagg : ((P.tw == 2 || P.gid_bits) && !getenv("VH_NO_SPLIT_TILE")) ? (P.gid_bits ? " + part_split_tile_kernel<256, 1>" + pagg : " + part_split_tile_kernel<256, 2>" + pagg) : " + part_split_kernel<256>" + pagg;
+    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? pagg : ((P.tw == 2 || P.gid_bits) && !test_env("VH_NO_SPLIT_TILE")) ? (P.gid_bits ? " + part_split_tile_kernel<256, 1>" + pagg : " + part_split_tile_kernel<256, 2>" + pagg) : " + part_split_kernel<256>" + pagg;
   }
   int occupancy = 0;
   if (env_bpc <= 0) scan_dispatch(0, &occupancy);
@@ -216,7 +216,7 @@ int QueryBuild::decompose_work() {
   // CU already stream at full rate, and every block fewer is a table flush fewer: C2 0.315 -> 0.308 ms, 400 M rows 1.217 -> 1.179)
   const int occ_cap = jk && mode == VH_MODE_DENSE_PART ? 3 : jk && hpart ? 4 : jk && lanes ? 2 : 8;
   int blocks_per_cu = env_bpc > 0 ? env_bpc : occupancy > 0 ? std::min(occupancy, occ_cap) : (BLOCK == 1024 ? 1 : 4);
-  if (const char* e = getenv("VH_TEST_BLOCKS_PER_CU")) { if (atoi(e) > 0) blocks_per_cu = occupancy > 0 ? std::min(occupancy, atoi(e)) : atoi(e); }   // (measurement: switched between two queries of one process)
+  if (const char* e = test_env("VH_TEST_BLOCKS_PER_CU")) { if (atoi(e) > 0) blocks_per_cu = occupancy > 0 ? std::min(occupancy, atoi(e)) : atoi(e); }   // (measurement: switched between two queries of one process)
   uint32_t unit_rows = step;
   // (units of 4 096 rows lose to longer ones — an eighth of C3 0.342 -> 0.332 ms with 16 K rows, a quarter 0.569 -> 0.542 and the whole table
   // 1.867 -> 1.841 with 32 K, 64 K no better — so a block only needs about eight of them to keep the round-robin even: tools/env_ab_probe.py)
@@ -224,7 +224,7 @@ int QueryBuild::decompose_work() {
   while (unit_rows * 2 <= (jk ? 32768u : 65536u) && unit_rows * 2 <= padded &&
          (uint64_t)nseg * ((padded + unit_rows * 2 - 1) / (unit_rows * 2)) >= want_units) unit_rows *= 2;
   if (env_unit >= (int)step) unit_rows = (uint32_t)env_unit / step * step;
-  if (const char* e = getenv("VH_TEST_UNIT_ROWS")) { if (atoi(e) >= (int)step) unit_rows = (uint32_t)atoi(e) / step * step; }   // (measurement: switched between two queries of one process)
+  if (const char* e = test_env("VH_TEST_UNIT_ROWS")) { if (atoi(e) >= (int)step) unit_rows = (uint32_t)atoi(e) / step * step; }   // (measurement: switched between two queries of one process)
   P.unit_rows = unit_rows;
   P.units_per_seg = (uint32_t)((t->segment_rows + unit_rows - 1) / unit_rows);
   P.nseg = nseg;
@@ -248,10 +248,16 @@ int QueryBuild::layout_scratch() {
   // key spreads GROUPS evenly over the level-A partitions whatever the rows' skew) and a quarter more; a region that overflows all the
   // same voids the attempt like any pool that runs out
   r->hp_direct = hpart && r->nhaving == 0 && r->topk == 0 && !knobs().hp_list;
-  if (r->hp_direct && !device_rows && (knobs().hp_stream > 0 ? capacity >= (1ull << 22) : getenv("VH_TEST_HP_STREAM") != nullptr)) {
-    int nch = std::min(knobs().hp_stream > 0 ? knobs().hp_stream : 4, VH_HP_CHUNKS);
+  // ... or, in ONE launch, only takes its rows' places off the counter of its region (VH_HP_REGIONS, default 8): every range of the aggregation
+  // ends with a returning atomic on the result's row counter — 65 536 of them per query, each a block-wide wait; on one word they queue up
+  // behind each other, on eight they do not (profiles/r05/NOTES.md)
+  const bool hp_streamed = knobs().hp_stream > 0 ? capacity >= (1ull << 22) : test_env("VH_TEST_HP_STREAM") != nullptr;
+  const bool hp_regions = !hp_streamed && knobs().hp_regions > 1 && capacity >= (1ull << 22);
+  if (r->hp_direct && !device_rows && (hp_streamed || hp_regions)) {
+    int nch = std::min(hp_regions ? knobs().hp_regions : knobs().hp_stream > 0 ? knobs().hp_stream : 4, VH_HP_CHUNKS);
     while (HP_FAN % nch) --nch;
     r->hp_chunks = nch;
+    r->hp_one_launch = hp_regions;
     r->hp_chunk_rows = capacity / nch + capacity / (4 * nch) + 4096;
     r->out_cap = r->hp_chunk_rows * nch;
     rc = exec_streaming(x);
@@ -326,12 +332,12 @@ int QueryBuild::layout_scratch() {
     P.ext_stride = (int32_t)ext_stride;
     uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
     if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
-    if (!part_tuples_override && getenv("VH_TEST_PART_EXTENTS")) max_ext = std::max(1, atoi(getenv("VH_TEST_PART_EXTENTS")));   // tests: make the first attempt run out of extents
+    if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS")) max_ext = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS")));   // tests: make the first attempt run out of extents
     P.max_extents = (uint32_t)max_ext;
     // the scan's waves take their extent chunks by position (no shared cursor, no returning atomics: VhPlanDev::ext_waves). The pool above
     // holds that whenever the waves' tuple counts agree within the 25 % the estimate leaves; a re-run after VH_ERR_PART_FULL goes back to
     // the cursor, which packs the chunks whatever the imbalance
-    P.ext_waves = part_tuples_override || getenv("VH_TEST_EXT_CURSOR") ? 0u : (uint32_t)grid * (uint32_t)(BLOCK / 64);
+    P.ext_waves = part_tuples_override || test_env("VH_TEST_EXT_CURSOR") || t->part_clustered.count(r->group_sig) ? 0u : (uint32_t)grid * (uint32_t)(BLOCK / 64);
     o_tuples = sp.take(max_ext * ext_stride * P.tw * 8);
     o_emiss = sp.take(max_ext * sizeof(uint16_t));
     o_epart = sp.take(max_ext);
@@ -339,13 +345,13 @@ int QueryBuild::layout_scratch() {
       // pool 2: small extents (4096 ranges x every splitting wave keep one open), sized like pool 1 plus what stays open
       split_bpp = std::max(1, 2 * g_ctx.num_cu / std::max(1, P.npart));     // 256-thread blocks, ~2 per CU whatever the partition count: more waves keep more extents open (4 per CU measured slower)
       // two-word tuples are split a block-wide tile at a time (part_split_tile_kernel): extents of one tile's size, one writer per block
-      const bool tiled = (P.tw == 2 || P.gid_bits) && !getenv("VH_NO_SPLIT_TILE");
+      const bool tiled = (P.tw == 2 || P.gid_bits) && !test_env("VH_NO_SPLIT_TILE");
       if (tiled) split_bpp = std::max(1, knobs().split_bpc * g_ctx.num_cu / std::max(1, P.npart));   // a block is one writer: more of them cost less
       const uint64_t et2 = tiled ? VH_SPLIT_TILE_TUPLES : 256;
       P.ext_tuples2 = (int32_t)et2;
       uint64_t max2 = (part_tuple_cap + part_tuple_cap / 4) / et2 + (uint64_t)P.npart * ((uint64_t)split_bpp * (tiled ? 1 : 4) * (64 + VH_EXT_CHUNK) + 1) + 64;
       if (max2 > 0xFFFFFFF0ull) max2 = 0xFFFFFFF0ull;
-      if (!part_tuples_override && getenv("VH_TEST_PART_EXTENTS2")) max2 = std::max(1, atoi(getenv("VH_TEST_PART_EXTENTS2")));   // tests: the second pool runs out first
+      if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS2")) max2 = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS2")));   // tests: the second pool runs out first
       P.max_extents2 = (uint32_t)max2;
       o_tuples2 = sp.take(max2 * et2 * P.tw * 8);
       o_emiss2 = sp.take(max2 * sizeof(uint16_t));
@@ -361,7 +367,7 @@ int QueryBuild::layout_scratch() {
       // level A: every block may hold an open extent per digit (+ one fresh one per tile boundary); level B: the slices hp_plan_kernel lays out
       uint64_t ma = ((cap / hp_et) / g_ctx.num_cu * 3 / 2 + 2 * HP_FAN + 16) * g_ctx.num_cu;      // one slab per block: its share of the tuples and half again, an open extent per digit, one more per digit for the tails
       uint64_t mb = cap / hp_et + (uint64_t)HP_FAN * (2 * HP_FAN + 9) + 64;
-      if (!part_tuples_override && getenv("VH_TEST_PART_EXTENTS2")) mb = std::max(1, atoi(getenv("VH_TEST_PART_EXTENTS2")));   // tests: the last pool runs out
+      if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS2")) mb = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS2")));   // tests: the last pool runs out
       hpo[k].maxa = ma; hpo[k].maxb = mb;
       hpo[k].ta = sp.take(ma * hp_es * 16 * hp_units); hpo[k].fa = sp.take(ma * 2); hpo[k].ga = sp.take(ma);
       hpo[k].tb = sp.take(mb * hp_es * 16 * hp_units); hpo[k].fb = sp.take(mb * 2); hpo[k].gb = sp.take(mb);
@@ -569,7 +575,11 @@ int QueryBuild::launch() {
     if (hpart) {
       vh_launch_hpart(P, d_hpargs, hp_units, g_ctx.num_cu, st);
       if (!r->hp_chunks) HIP_TRY(vh_jit_launch_hpagg(jk, P, d_hpargs, hp_bpp, 0, HP_FAN * hp_bpp, lds_table, st));
-      else {
+      else if (r->hp_one_launch) {      // regions without streaming: one launch, every region's row count into pinned memory behind it
+        HIP_TRY(vh_jit_launch_hpagg(jk, P, d_hpargs, hp_bpp, 0, HP_FAN * hp_bpp, lds_table, st));
+        for (int c = 0; c < r->hp_chunks; ++c) hipLaunchKernelGGL(publish_count_kernel, dim3(1), dim3(64), 0, st, x->h_chunk + c, r->d_out_count + c);
+        for (int c = 0; c < r->hp_chunks; ++c) HIP_TRY(hipEventRecord(x->ev_chunk[c], st));
+      } else {
         // chunk c = level-A partitions [c * per, (c + 1) * per), alternately on the query's stream and on `aux` (both behind level B), each
         // followed by its row count into pinned memory and an event the host waits for (result_finalize)
         const int per = HP_FAN / r->hp_chunks;
@@ -596,8 +606,11 @@ int QueryBuild::launch() {
   HIP_TRY(hipEventRecord(x->ev[2], st));
   HIP_TRY(hipGetLastError());
   // a small dense result that will go straight into pinned host memory (result_finalize's `direct`): its whole tail is one launch there
+  // ... bounded by the states that ONE block then reads (entries x private copies x metrics), not by the entries alone: beyond ~64 K of them
+  // the three parallel launches it replaces are the faster tail
   r->small_tail = mode != VH_MODE_HASH && r->out_cap <= VH_SMALL_TAIL_MAX && r->out_region_bytes <= (8u << 20) && !r->topk_active && !r->hp_chunks &&
-                  !device_rows && !knobs().no_direct_emit && !getenv("VH_TEST_NO_SMALL_TAIL");
+                  (uint64_t)r->out_cap * (uint64_t)std::max(1, nxcd) * (uint64_t)std::max(1, (int)P.nmetric) <= VH_SMALL_TAIL_STATES &&
+                  !device_rows && !knobs().no_direct_emit && !test_env("VH_TEST_NO_SMALL_TAIL");
   if (mode != VH_MODE_HASH && nxcd > 1) {
     r->unmerged = true;
     if (!r->small_tail) { if (int mrc = merge_copies_now(r, st)) return mrc; }

@@ -92,7 +92,7 @@ static int install_scratch(VhExec* x, void* ptr, size_t nb, bool placed = false)
   x->scratch = static_cast<char*>(ptr);
   trace_alloc("scratch", x->scratch, nb);
   x->scratch_bytes = nb;
-  if (getenv("VH_POISON")) {   // tests: nothing may depend on what fresh scratch holds
+  if (test_env("VH_POISON")) {   // tests: nothing may depend on what fresh scratch holds
     HIP_TRY(hipMemsetAsync(x->scratch, 0xA5, nb, x->stream()));
     HIP_TRY(hipStreamSynchronize(x->stream()));
   }

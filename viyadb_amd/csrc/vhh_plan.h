@@ -825,7 +825,7 @@ int QueryBuild::choose_organisation() {
   // and aggregate each range in LDS instead (DENSE_PART).
   if (mode == VH_MODE_DENSE_GLOBAL && fastj && !no_part && !(p->flags & (VH_PLAN_NO_PART | VH_PLAN_FORCE_GLOBAL)) && P.nmetric >= 1 && P.nmetric <= VH_FAST_COLS) {
     int shift = 0;
-    const size_t part_table_bytes = getenv("VH_PART_TABLE_KB") ? (size_t)atoi(getenv("VH_PART_TABLE_KB")) * 1024 : 128 * 1024;      // (tests shrink it between two queries to force many ranges)   // one 1024-thread block per CU in phase 2 (160 KB LDS)
+    const size_t part_table_bytes = test_env("VH_PART_TABLE_KB") ? (size_t)atoi(test_env("VH_PART_TABLE_KB")) * 1024 : 128 * 1024;      // (tests shrink it between two queries to force many ranges)   // one 1024-thread block per CU in phase 2 (160 KB LDS)
     // The presence byte rides in a 32-bit SUM state when there is one (SOP_ADD32P: a 64-bit word whose upper half counts rows): two LDS
     // updates per tuple instead of three. (Round 2 took phase 2 for bound by LDS read-modify-writes; in isolation the LDS does 2.5 such
     // tuples per clock and CU — 34 us for C3's 50 M — so what the kernel waits for is its tuples: profiles/r03/NOTES.md.)
@@ -884,7 +884,7 @@ int QueryBuild::choose_organisation() {
     // with the whole-line writer packs them.
     int nt_gb = 0, nt_mb[VH_MAX_METRIC] = {};
     bool narrow_tuples = false;
-    if (want_part && jit_try && (two_level ? (np + 63) / 64 : np) <= VH_STAGE_PARTS_MAX && !knobs().no_stage && !(p->flags & (VH_PLAN_NO_NARROW_TUPLES | VH_PLAN_FORCE_LANES)) && !getenv("VH_NO_NARROW_TUPLES")) {
+    if (want_part && jit_try && (two_level ? (np + 63) / 64 : np) <= VH_STAGE_PARTS_MAX && !knobs().no_stage && !(p->flags & (VH_PLAN_NO_NARROW_TUPLES | VH_PLAN_FORCE_LANES)) && !test_env("VH_NO_NARROW_TUPLES")) {
       auto bits_of = [](uint64_t v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; };
       nt_gb = bits_of(G - 1);
       int used = nt_gb;
@@ -1009,11 +1009,14 @@ int QueryBuild::choose_organisation() {
   P.nxcd = nxcd; r->nxcd = nxcd;
   P.xcd_stride = (G + 63) / 64 * 64;
 
-  if (mode == VH_MODE_HASH) {
-    // sizing: explicit override (regrow) > caller's hint > what the same group columns produced last time > 1 M
-    std::string sig;
+  // what the table remembers about a query shape goes by its group columns: groups of the last query (hash sizing), clustered survivors (tuple extents)
+  std::string sig;
+  if (mode == VH_MODE_HASH || mode == VH_MODE_DENSE_PART) {
     for (int i = 0; i < p->ngroups; ++i) sig += std::to_string(p->groups[i].col) + ":" + std::to_string(P.g[i].gran()) + ":" + std::to_string(P.g[i].nroll()) + ",";
     r->group_sig = sig;
+  }
+  if (mode == VH_MODE_HASH) {
+    // sizing: explicit override (regrow) > caller's hint > what the same group columns produced last time > 1 M
     const auto seen = t->groups_seen.find(sig);
     const uint64_t hint = p->groups_hint ? p->groups_hint : (seen != t->groups_seen.end() ? seen->second + seen->second / 4 : 0);
     uint64_t want = hash_capacity_override ? hash_capacity_override
@@ -1110,7 +1113,7 @@ int QueryBuild::plan_hashed_partitioning() {
           // Packed tuples: 16 bytes instead of 32 when the payload values and two ids fit ONE word next to their count. The bits come from
           // what the mirror knows about the scanned segments: min / max of the metric columns (refresh_stats), the largest id (bs_maxid).
           auto bits_of = [](uint64_t v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; };
-          bool fits = !(p->flags & VH_PLAN_NO_HP_PACK) && !getenv("VH_NO_HP_PACK");
+          bool fits = !(p->flags & VH_PLAN_NO_HP_PACK) && !test_env("VH_NO_HP_PACK");
           int pbits = 0, mb[VH_MAX_METRIC] = {};
           for (int j = 0; j < P.nmetric && fits; ++j) {
             if (P.m[j].sop() == SOP_BITSET) continue;
@@ -1131,14 +1134,14 @@ int QueryBuild::plan_hashed_partitioning() {
           uint64_t maxid = 0;
           for (uint32_t sgi : live) maxid = std::max(maxid, t->cols[bitset_col[0]].bs_maxid[sgi]);
           int idbits = bits_of(maxid);
-          if (const char* e = getenv("VH_TEST_HP_IDBITS")) idbits = std::max(1, atoi(e));      // tests: ids that do NOT fit -> VH_ERR_HP_WIDE -> the plain hash table
+          if (const char* e = test_env("VH_TEST_HP_IDBITS")) idbits = std::max(1, atoi(e));      // tests: ids that do NOT fit -> VH_ERR_HP_WIDE -> the plain hash table
           if (fits && idbits <= 32 && pbits + 2 * idbits <= 61) {
             hp_pack = true; hp_units = 1; hp_pbits = pbits; hp_idbits = idbits;
             for (int j = 0; j < P.nmetric; ++j) P.m[j].tbits = (uint32_t)mb[j];
           }
         }
         if (nb) {
-          hp_off32 = !getenv("VH_NO_OFF32");
+          hp_off32 = !test_env("VH_NO_OFF32");
           for (uint32_t sgi : live) hp_off32 = hp_off32 && t->cols[bitset_col[0]].bs_offsets32[sgi] != nullptr;
         }
         lanes = false;
@@ -1161,7 +1164,7 @@ int QueryBuild::plan_hashed_partitioning() {
         auto table_bytes = [&](uint32_t g, uint32_t q) { return (size_t)(g + 1) * slot_bytes + (size_t)q * 8; };
         const size_t budget = 136 * 1024;                       // of the 160 KB a block may own (lists, counters and alignment take the rest)
         uint32_t passes = hp_passes_override ? hp_passes_override : 1, gs = 256, ss = nb ? 1024 : 0;
-        if (const char* env_passes = getenv("VH_TEST_HPART_PASSES")) if (!hp_passes_override) passes = (uint32_t)std::max(1, atoi(env_passes));
+        if (const char* env_passes = test_env("VH_TEST_HPART_PASSES")) if (!hp_passes_override) passes = (uint32_t)std::max(1, atoi(env_passes));
         for (;;) {       // tables for one pass's share of a range at <= 70 % load; what the LDS cannot hold takes more passes
           const double load_g = knobs().hp_load_g, load_s = knobs().hp_load_s;
           const bool need_g = hp_passes_override ? true : groups_est / passes > load_g * gs, need_s = nb && (hp_passes_override ? true : ids_est / passes > load_s * ss);

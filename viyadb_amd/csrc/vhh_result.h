@@ -70,12 +70,16 @@ struct vh_result {
   bool hp_direct = false;           // ... or its aggregation kernel already wrote the output columns (no emission kernel to run)
   int hp_chunks = 0;                // ... in this many chunk launches, each with a region of `hp_chunk_rows` rows of the output columns: delivered chunk by chunk
   uint64_t hp_chunk_rows = 0;
+  bool hp_one_launch = false;       // ... regions only: ONE launch of the aggregation, the regions' rows packed behind it (no overlap of copies and kernels)
   VhHpArgs hp_args;                 // ... and the pool descriptors its kernels were given
   vh_table* table = nullptr;
   vh_result_info info{};
   int mode = 0;
   bool finalized = false;
   bool stream_quiet = false;   // vh_query_agg waited for the last event it recorded on the context's stream and nothing was enqueued since: the destructor need not wait again (~10 us per query)
+  // the ONE way work gets onto a finished result's stream (exchange, partitioning, device buffers ...): whoever enqueues behind the query
+  // takes the stream from here, which is also what makes the destructor wait for it before the context goes to the next query
+  hipStream_t stream_for_work() { stream_quiet = false; return exec->stream(); }
   size_t plan_words = 0, seg_words = 0;        // layout of the pinned staging block [segment snapshot | program | literals] in u32 words
   int h_slot = -1;                             // staging buffer of `exec` this query finalises into
   std::string kernel;                          // symbol(s) of the scan kernel(s) launched for this query

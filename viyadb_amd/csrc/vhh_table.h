@@ -109,6 +109,7 @@ struct vh_table {
   bool sync_inflight = false;
   uint64_t sync_batches = 0, sync_descs = 0, sync_bytes_pulled = 0, sync_bytes_staged = 0, sync_bytes_dma = 0;   // vh_table_sync_stats
   std::map<std::string, uint64_t> groups_seen;           // group-column signature -> groups of the last query (hash sizing)
+  std::set<std::string> part_clustered;                  // group-column signatures whose survivors came clustered: positional extent chunks overflowed although the pool had room — later queries of the shape take their extents off the shared cursor at once
   std::map<std::string, std::pair<uint64_t, uint64_t>> sel_cache;   // filter signature + table state -> (passed, sampled) of the selectivity probe
   std::vector<std::unique_ptr<VhPack>> packs;
   std::vector<std::unique_ptr<VhNarrow>> narrows;
