@@ -248,9 +248,9 @@ int QueryBuild::layout_scratch() {
   // key spreads GROUPS evenly over the level-A partitions whatever the rows' skew) and a quarter more; a region that overflows all the
   // same voids the attempt like any pool that runs out
   r->hp_direct = hpart && r->nhaving == 0 && r->topk == 0 && !knobs().hp_list;
-  // ... or, in ONE launch, only takes its rows' places off the counter of its region (VH_HP_REGIONS, default 8): every range of the aggregation
-  // ends with a returning atomic on the result's row counter — 65 536 of them per query, each a block-wide wait; on one word they queue up
-  // behind each other, on eight they do not (profiles/r05/NOTES.md)
+  // ... or, in ONE launch, only takes its rows' places off the counter of its region (VH_HP_REGIONS, default off): every range of the aggregation
+  // ends with a returning atomic on the result's row counter — 65 536 of them per query, each a block-wide wait. Measured: spreading them over
+  // eight words buys nothing (profiles/r05/NOTES.md)
   const bool hp_streamed = knobs().hp_stream > 0 ? capacity >= (1ull << 22) : test_env("VH_TEST_HP_STREAM") != nullptr;
   const bool hp_regions = !hp_streamed && knobs().hp_regions > 1 && capacity >= (1ull << 22);
   if (r->hp_direct && !device_rows && (hp_streamed || hp_regions)) {

@@ -88,7 +88,7 @@ static const VhKnobs& knobs() {
     x.jit_ablate = num("VH_JIT_ABLATE", 0); x.hp_ablate = num("VH_HP_ABLATE", 0); x.hp_bpp = num("VH_HP_BPP", 0); x.pack_plain = num("VH_PACK_PLAIN", 0);
     x.lanes_block = num("VH_LANES_BLOCK", 0); x.blocks_per_cu = num("VH_BLOCKS_PER_CU", 0); x.unit_rows = num("VH_UNIT_ROWS", 0); x.grid = num("VH_GRID", 0);
     x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.place_trials = num("VH_PLACE_TRIALS", 4); x.place_gb = std::max(1, num("VH_PLACE_GB", 16)); x.hp_list = num("VH_HP_LIST", 0);
-    x.hp_regions = num("VH_HP_REGIONS", 8);           // regions (row counters) of a big hashed-partitioning result written in one launch; 0 / 1: one
+    x.hp_regions = num("VH_HP_REGIONS", 0);           // regions (row counters) of a big hashed-partitioning result written in ONE launch (0: off — measured: C5 14.4 vs 13.9 ms per query, the row counter is not what the aggregation waits for; profiles/r05/NOTES.md)
     x.hp_stream = num("VH_HP_STREAM", 0);             // chunk launches of a streamed result (0: off — measured: the link, not the wait for the kernels, bounds the delivery; profiles/r04/NOTES.md)
     x.deliver_blocks = num("VH_DELIVER_BLOCKS", 64);  // blocks of deliver_kernel; 0: big results through hipMemcpyAsync (the DMA engine)
     x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
