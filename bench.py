@@ -262,7 +262,7 @@ def main():
         if args.no_predpack:
             table.narrow(table.filter_columns(plan))     # 8- / 16-bit copies of the predicate columns whose values fit (vh_table_narrow)
         else:
-            table.predpack(table.filter_columns(plan))   # the predicate columns as bit fields of one word per row, in byte planes (vh_table_predpack: C3 3 bytes per row)
+            table.predpack(table.filter_columns(plan))   # the predicate columns as bit fields of one word per row, bit-sliced (vh_table_predpack: C3 22 planes of one bit per row = 2.75 bytes)
     # first-use costs paid before anything is timed, as a database would at table-load time for its hot query shapes (vh_table_prepare:
     # the compile of the scan kernel for this shape, the derived layouts above if not asked for explicitly, a measured place for the tuple pool)
     warmed = 0 if args.no_warm else table.warm(plan)
@@ -371,7 +371,7 @@ def main():
             "derived_layout": {"one_time_seconds": round(t_pack, 4), "extra_device_bytes": max(0, table.info()[2] - total_rows * w.table_bytes_per_row // max(1, world)),
                                "table_bytes": total_rows * w.table_bytes_per_row // max(1, world),
                                "what": ("payload projection of the group + metric columns (vh_table_pack) and " + ("8- / 16-bit copies of the predicate columns (vh_table_narrow)" if args.no_predpack else
-                                        "the predicate columns as bit fields of one word per row in byte planes (vh_table_predpack)")) if not args.no_pack else "none"},
+                                        "the predicate columns as bit fields of one word per row, bit-sliced: one plane per bit, compared 32 rows per lane at a time (vh_table_predpack)")) if not args.no_pack else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": last.kernel,

@@ -41,15 +41,26 @@ template <typename T> __device__ __forceinline__ T vj_gload(const T* p) {
 template <class J, int I>
 __device__ __forceinline__ uint64_t vj_time_rollup(uint64_t ts, const VhGroupDev& g) {
   constexpr bool micro = J::g_micro[I] != 0;
-  uint64_t secs = micro ? ts / 1000000ull : ts;
-  uint64_t micros = micro ? ts % 1000000ull : 0;
-  bool done = false;       // the FIRST rule whose boundary lies beyond ts truncates (rollup.cc:77-95)
+  if constexpr (!micro) {      // a `time` column: 32-bit seconds, truncated in 32-bit arithmetic (vh_time.h: a MONTH is ~60 instructions, not ~250)
+    uint32_t secs = (uint32_t)ts;
+    bool done = false;         // the FIRST rule whose boundary lies beyond ts truncates (rollup.cc:77-95)
 #pragma unroll
-  for (int k = 0; k < J::g_nroll[I]; ++k) {
-    if (!done && ts < g.roll_before[k]) { secs = vh_trunc_secs(secs, J::g_roll_unit[I][k]); micros = 0; done = true; }
+    for (int k = 0; k < J::g_nroll[I]; ++k) {
+      if (!done && ts < g.roll_before[k]) { secs = vh_trunc_secs32(secs, J::g_roll_unit[I][k]); done = true; }
+    }
+    if (J::g_gran[I] != VH_T_NONE) secs = vh_trunc_secs32(secs, J::g_gran[I]);
+    return (uint64_t)secs;
+  } else {
+    uint64_t secs = ts / 1000000ull;
+    uint64_t micros = ts % 1000000ull;
+    bool done = false;
+#pragma unroll
+    for (int k = 0; k < J::g_nroll[I]; ++k) {
+      if (!done && ts < g.roll_before[k]) { secs = vh_trunc_secs(secs, J::g_roll_unit[I][k]); micros = 0; done = true; }
+    }
+    if (J::g_gran[I] != VH_T_NONE) { secs = vh_trunc_secs(secs, J::g_gran[I]); micros = 0; }
+    return secs * 1000000ull + micros;
   }
-  if (J::g_gran[I] != VH_T_NONE) { secs = vh_trunc_secs(secs, J::g_gran[I]); micros = 0; }
-  return micro ? secs * 1000000ull + micros : (uint64_t)(uint32_t)secs;
 }
 
 template <class J, int I = 0>

@@ -16,6 +16,7 @@
 // bound is HBM bandwidth.
 #pragma once
 #include "vh_internal.h"
+#include "vh_time.h"
 #include <type_traits>
 
 #ifndef VH_ABLATE
@@ -54,46 +55,7 @@ __device__ __forceinline__ int vh_xcc_id() {
   return (int)(__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u);
 }
 
-// ------------------------------------------------------- time truncation (a8)
-// civil-from-days / days-from-civil, proleptic Gregorian, integer exact. Equivalent
-// to gmtime_r -> zero tm fields -> timegm for every non-negative time_t
-// (checked against the reference's own util/time.cc in tests/golden/time_*.json).
-__host__ __device__ __forceinline__ int64_t vh_days_from_civil(int64_t y, int64_t m, int64_t d) {
-  y -= m <= 2;
-  const int64_t era = (y >= 0 ? y : y - 399) / 400;
-  const int64_t yoe = y - era * 400;
-  const int64_t doy = (153 * (m + (m > 2 ? -3 : 9)) + 2) / 5 + d - 1;
-  const int64_t doe = yoe * 365 + yoe / 4 - yoe / 100 + doy;
-  return era * 146097 + doe - 719468;
-}
-__host__ __device__ __forceinline__ void vh_civil_from_days(int64_t z, int64_t& y, int64_t& m, int64_t& d) {
-  z += 719468;
-  const int64_t era = (z >= 0 ? z : z - 146096) / 146097;
-  const int64_t doe = z - era * 146097;
-  const int64_t yoe = (doe - doe / 1460 + doe / 36524 - doe / 146096) / 365;
-  y = yoe + era * 400;
-  const int64_t doy = doe - (365 * yoe + yoe / 4 - yoe / 100);
-  const int64_t mp = (5 * doy + 2) / 153;
-  d = doy - (153 * mp + 2) / 5 + 1;
-  m = mp + (mp < 10 ? 3 : -9);
-  y += m <= 2;
-}
-// Truncator::trunc<U> on seconds since the epoch (src/util/time.h:57-89). WEEK has no
-// specialisation in the reference and is rejected when the plan is built.
-__host__ __device__ __forceinline__ uint64_t vh_trunc_secs(uint64_t t, int unit) {
-  switch (unit) {
-    case VH_T_SECOND: return t;
-    case VH_T_MINUTE: return t - t % 60u;
-    case VH_T_HOUR: return t - t % 3600u;
-    case VH_T_DAY: return t - t % 86400u;
-    default: {
-      int64_t y, m, d;
-      vh_civil_from_days((int64_t)(t / 86400u), y, m, d);
-      if (unit == VH_T_YEAR) m = 1;
-      return (uint64_t)vh_days_from_civil(y, m, 1) * 86400u;
-    }
-  }
-}
+// ------------------------------------------------------- time truncation (a8): vh_time.h (vh_trunc_secs, its 32- and 64-bit forms)
 // set_ts -> first matching rollup rule truncates -> query granularity truncates -> get_ts
 // (src/codegen/query/scan.cc:197-218; Time64::trunc also zeroes the microseconds).
 __host__ __device__ __forceinline__ uint64_t vh_time_rollup(uint64_t ts, const VhGroupDev& g) {

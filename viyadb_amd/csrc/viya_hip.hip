@@ -93,7 +93,7 @@ static const VhKnobs& knobs() {
     x.deliver_blocks = num("VH_DELIVER_BLOCKS", 64);  // blocks of deliver_kernel; 0: big results through hipMemcpyAsync (the DMA engine)
     x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
     x.hp_load_g = real("VH_HP_LOAD_G", 0.7); x.hp_load_s = real("VH_HP_LOAD_S", 0.7);
-    x.qpay_min_sel = real("VH_QPAY_MIN_SEL", 0.08);        // selectivity from which the compiled scan streams 4-byte payload records instead of gathering them (measured: profiles/r05/NOTES.md)
+    x.qpay_min_sel = real("VH_QPAY_MIN_SEL", 0.15);        // selectivity from which the compiled scan streams 4-byte payload records instead of gathering them (measured: profiles/r05/NOTES.md)
     return x;
   }();
   return k;
