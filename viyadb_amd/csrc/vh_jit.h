@@ -85,6 +85,8 @@ int vh_jit_occupancy(VhJitKernel* k, int block, size_t lds);
 hipError_t vh_jit_launch(VhJitKernel* k, const VhPlanDev& P, int grid, int block, size_t lds, hipStream_t s);
 hipError_t vh_jit_launch_hpagg(VhJitKernel* k, const VhPlanDev& P, const void* d_hpargs, int blocks_per_partition, int a_first, int grid, size_t lds, hipStream_t s);
 hipError_t vh_jit_launch_pagg(VhJitKernel* k, const VhPlanDev& P, int blocks_per_part, size_t lds, hipStream_t s);
-#define VH_HP_AGG_BLOCK 512
+#ifndef VH_HP_AGG_BLOCK
+#define VH_HP_AGG_BLOCK 512          // threads of the ranges' aggregation (hp_aggregate_body); -D only for measurement builds (tools/build_variant.py)
+#endif
 // code object for a shape without loading it (no GPU needed: build-time cache warm-up, CPU tests)
 int vh_jit_compile_only(const VhJitShape& s, std::vector<char>* code, std::string* log);

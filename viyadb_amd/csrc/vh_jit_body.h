@@ -368,7 +368,7 @@ __device__ __forceinline__ uint32_t vj_bits_rel(const uint32_t* x, uint64_t c, b
   }
 }
 // The lane's passing rows (bits of `m`, row `base` + bit) appended to the wave's queue: ranks from a prefix sum of the lanes' counts, then
-// every lane writes its own rows — as many rounds as the busiest lane has survivors. At most 16 x 64 rows a call (the queue's room).
+// every lane writes its own rows — as many rounds as the busiest lane has survivors. At most 1 024 rows a call (the queue's room).
 __device__ __forceinline__ void vj_push_mask(uint32_t* q, uint32_t& cnt, uint32_t m, uint32_t base, int lane) {
   const uint32_t c = (uint32_t)__popc(m);
   uint32_t incl = c;
@@ -562,13 +562,17 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
         __builtin_amdgcn_wave_barrier();
       }
     };
-    if constexpr (J::SLICED) {                      // two halves of 16 rows per lane: at most 1 024 rows join the queue between two drains
-      vj_push_mask(q, cnt, smask & 0xFFFFu, row_l, lane);
+    if constexpr (J::SLICED) {
+      // two halves of the wave, 32 lanes x 32 rows each: at most 1 024 rows join the queue between two drains. By LANES, not by rows: a lane's
+      // 32 rows are one 128-byte line of a 4-byte column (a record array), and a line whose survivors are all queued together is gathered by
+      // one or two consecutive drains. Split by rows (16 + 16) the two halves of every line were asked for a whole drain sequence apart — with
+      // half the rows passing, C5's scan fetched every payload line twice (FETCH_SIZE 2.9 GB for 1.5 GB of columns; profiles/r05/NOTES.md)
+      vj_push_mask(q, cnt, lane < 32 ? smask : 0u, row_l, lane);
       npassed += cnt - cnt0;
       __builtin_amdgcn_wave_barrier();
       drain_queue(false);
       const uint32_t cnt1 = cnt;
-      vj_push_mask(q, cnt, smask >> 16, row_l + 16u, lane);
+      vj_push_mask(q, cnt, lane < 32 ? 0u : smask, row_l, lane);
       npassed += cnt - cnt1;
       __builtin_amdgcn_wave_barrier();
     }
