@@ -364,8 +364,12 @@ __device__ __forceinline__ void hp_store_sized(void* base, uint32_t esize, unsig
 }
 
 // ------------------------------------------------------------------ the ranges, one after the other, in LDS
-__device__ __forceinline__ uint32_t hp_slot(unsigned long long* keys, uint32_t gslots, uint64_t mkey, bool insert, bool& ok) {
+// Probe sequences are DOUBLE-HASHED (the step an odd number out of other bits of the key: every slot of a power-of-two table is reached):
+// a wave sits out the longest of its 64 lanes' sequences, and at 50-60 % load linear probing's clusters make that longest one ~15 probes
+// where independent steps make it ~8 (`linear`: the old form, for measurement).
+__device__ __forceinline__ uint32_t hp_slot(unsigned long long* keys, uint32_t gslots, uint64_t mkey, bool insert, bool& ok, bool linear = false) {
   const uint32_t mask = gslots - 1u;
+  const uint32_t step = linear ? 1u : (((uint32_t)(mkey >> 20) & mask) | 1u);
   if (mkey == VH_HASH_EMPTY) {                  // the one mixed key that looks like an empty slot: the table's extra slot
     if (insert) keys[gslots] = 0ull;
     return gslots;
@@ -380,7 +384,7 @@ __device__ __forceinline__ uint32_t hp_slot(unsigned long long* keys, uint32_t g
       if (seen == mkey) return slot;
       if (seen == VH_HASH_EMPTY) break;
     }
-    slot = (slot + 1u) & mask;
+    slot = (slot + step) & mask;
   }
   ok = false;
   return 0;
@@ -499,7 +503,7 @@ __device__ __forceinline__ void hp_aggregate_body(const VhPlanDev& P, const VhHp
         const uint64_t mkey = tp.v[0].x, w1 = tp.v[0].y, payload = PK ? (w1 & PMASK) : w1;
         if (sub_bits && (int)((uint32_t)(mkey >> (48 - sub_bits)) & (uint32_t)(passes - 1)) != pass) return;
         bool ok = true;
-        const uint32_t slot = hp_slot(gkeys, GS, mkey, true, ok);
+        const uint32_t slot = hp_slot(gkeys, GS, mkey, true, ok, (abl & 32) != 0);
         if (!ok) { bad = true; return; }
         const uint64_t meta = PK ? (w1 >> 61) : U == 2 ? tp.v[U - 1].y : 0ull;      // bits 0-1: ids that count, bit 2: ids only
         if (!IDS || !(meta & HP_IDS_ONLY)) {
@@ -520,13 +524,15 @@ __device__ __forceinline__ void hp_aggregate_body(const VhPlanDev& P, const VhHp
           for (int q = 0; q < 2; ++q) {
             if (q >= n) break;
             const unsigned long long key = ((unsigned long long)slot << 32) | idv[q];
-            uint32_t at = ((idv[q] ^ (slot * 0x9E3779B1u)) * 0x85EBCA6Bu) >> set_shift;      // (multiply-shift: the top bits)
+            const uint32_t hq = (idv[q] ^ (slot * 0x9E3779B1u)) * 0x85EBCA6Bu;
+            uint32_t at = hq >> set_shift;                                                    // (multiply-shift: the top bits)
+            const uint32_t sstep = (abl & 32) ? 1u : ((hq & (SS - 1u)) | 1u);                 // (double hashing: see hp_slot)
             bool placed = false;
             for (uint32_t probe = 0; probe < SS; ++probe) {
               const unsigned long long seen = atomicCAS(&skeys[at], (unsigned long long)VH_HASH_EMPTY, key);
               if (seen == VH_HASH_EMPTY) { atomicAdd(&card[slot], 1u); placed = true; break; }
               if (seen == key) { placed = true; break; }
-              at = (at + 1u) & (SS - 1u);
+              at = (at + sstep) & (SS - 1u);
             }
             if (!placed) bad = true;
           }

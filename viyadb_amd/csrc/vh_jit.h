@@ -31,6 +31,7 @@ struct VhJitShape {
   int hpart = 0, bitset_j = -1;         // HASH: hashed partitioning (vh_hpart.h); the metric that is a bitset (its ids travel in the tuples, two at a time)
   int bs_off32 = 0;                     // hashed partitioning with a bitset metric: P.bs_offs points at 32-bit offsets
   int gid_bits = 0;                     // DENSE_PART: one-word tuples — the gid's bits at the bottom of word 0 (0: the usual two or more words)
+  int hp_agg_waves = 0;                  // ... its aggregation kernel should leave room for this many waves per SIMD (what its LDS tables allow): a register bound for the compiler (0: none)
   int hp_pack = 0, hp_pbits = 0, hp_idbits = 0;   // ... in PACKED 16-byte tuples: word 1 = payload (hp_pbits) | two ids (hp_idbits each) | ids that count << 61 | ids only << 63
   int lanes = 0;                        // DENSE_LDS, most rows pass: no compaction — a lane keeps its own 4 consecutive rows per sub-step, group and metric columns come in
                                         // with the same 16-byte vector loads as the predicates (all of a step's at once), passing rows update the LDS table directly

@@ -49,7 +49,7 @@ uint64_t vh_jit_min_rows() {
 std::string VhJitShape::key() const {
   std::string k;
   auto put = [&](long long v) { k += std::to_string(v); k += ','; };
-  put(mode); put(block); put(scope); put(xcd); put(carrier); put(tw); put(key_words); put(lds_hash); put(gid32); put(ablate); put(stage); put(hpart); put(bitset_j); put(hp_pack); put(hp_pbits); put(hp_idbits); put(gid_bits); put(bs_off32);
+  put(mode); put(block); put(scope); put(xcd); put(carrier); put(tw); put(key_words); put(lds_hash); put(gid32); put(ablate); put(stage); put(hpart); put(hp_agg_waves); put(bitset_j); put(hp_pack); put(hp_pbits); put(hp_idbits); put(gid_bits); put(bs_off32);
   put(lanes); put(npred);
   for (int i = 0; i < npred; ++i) { put(pred[i].slot); put(pred[i].type); put(pred[i].width); }
   put(qpay); put(qpay_slot);
@@ -415,8 +415,13 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
     t += vj_fmt("extern \"C\" __global__ __launch_bounds__(1024) void %s_pagg(const VhPlanDev P, int blocks_per_part) { vj_part_agg<VJ, 1024>(P, blocks_per_part); }\n", kernel_name);
   // hashed partitioning: the kernel at the other end of the tuples — the ranges' aggregation in LDS (vh_hpart.h) — knows the same shape
   if (s.hpart)
-    t += vj_fmt("extern \"C\" __global__ __launch_bounds__(%d) void %s_hpagg(const VhPlanDev P, const VhHpArgs* __restrict__ HA, int bpp, int a_first) { hp_aggregate_body<VJ, %d>(P, HA, bpp, a_first); }\n",
-                VH_HP_AGG_BLOCK, kernel_name, VH_HP_AGG_BLOCK);
+  {
+    // (with a second argument the bound tells the compiler how many waves per SIMD the kernel is meant to run with — three 512-thread blocks
+    // per CU are six: 80 registers. Without it C5's aggregation took 81, i.e. TWO blocks per CU where its 49 KB of LDS tables allow three)
+    const std::string bound = s.hp_agg_waves > 0 ? vj_fmt("__launch_bounds__(%d, %d)", VH_HP_AGG_BLOCK, s.hp_agg_waves) : vj_fmt("__launch_bounds__(%d)", VH_HP_AGG_BLOCK);
+    t += vj_fmt("extern \"C\" __global__ %s void %s_hpagg(const VhPlanDev P, const VhHpArgs* __restrict__ HA, int bpp, int a_first) { hp_aggregate_body<VJ, %d>(P, HA, bpp, a_first); }\n",
+                bound.c_str(), kernel_name, VH_HP_AGG_BLOCK);
+  }
   return t;
 }
 
@@ -795,7 +800,7 @@ static bool vj_canonical(int which, VhJitShape* s) {
       S.g[1] = col(1, VH_U32, 4, -1, 0, 0); S.g[1].key_word = 0; S.g[1].key_shift = 32;
       S.m[0].bitset = 1; S.m[0].type = VH_U64; S.m[0].sop = SOP_BITSET;
       S.m[1] = col(2, VH_U32, 4, -1, 0, 0); S.m[1].sop = SOP_ADD32; S.m[1].tword = 1; S.m[1].tshift = 0;
-      if (which == 8) { S.hp_pack = 1; S.hp_pbits = 2; S.hp_idbits = 24; S.m[1].tbits = 2; }
+      if (which == 8) { S.hp_pack = 1; S.hp_pbits = 2; S.hp_idbits = 24; S.m[1].tbits = 2; S.hp_agg_waves = 6; }
       return true;
     }
     default: return false;

@@ -30,6 +30,9 @@ typedef uint32_t vj_u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 // (a pointer that was itself loaded from memory is "generic" to the compiler and gets flat_load, which waits on the LDS counter too;
 // the bitset arrays are device allocations: say so)
 #define VJ_GLOBAL(T, p) ((const T __attribute__((address_space(1)))*)(p))
+#ifndef VJ_DRAIN2
+#define VJ_DRAIN2 1        // 0 (measurement): the hashed-partitioning scan drains one survivor per lane at a time, as before
+#endif
 #ifndef VJ_BS_MERGE
 #define VJ_BS_MERGE 1      // 0 (measurement): a row's offsets and first two ids with four scalar-width loads, as before
 #endif
@@ -80,9 +83,16 @@ struct VjWave {
   VhLdsHashWave H;
 };
 
+// Where a row's ids lie (hashed partitioning with a bitset metric) and the first two of them: loaded in two dependent steps, which a drain
+// of two survivors per lane (vj_drain2) takes for both rows before it looks at either.
+struct VjBits {
+  uint64_t bk = 0, bk1 = 0;
+  const uint32_t* bids = nullptr;
+  uint32_t bid0 = 0, bid1 = 0;
+};
 template <class J>
 __device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, uint64_t (&gv)[J::NG ? J::NG : 1], uint64_t (&mv)[J::NM ? J::NM : 1],
-                                        char* lds, uint64_t xoff, unsigned long long& nfresh, VjWave& V);
+                                        char* lds, uint64_t xoff, unsigned long long& nfresh, VjWave& V, const VjBits* pre = nullptr);
 // One surviving row per active lane: AggTuple key, then Metrics::Update (store.cc:131-161) into the plan's table organisation.
 template <class J>
 __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, char* lds, uint64_t xoff,
@@ -111,39 +121,73 @@ __device__ __forceinline__ void vj_drain(const VhPlanDev& P, uint32_t seg, uint3
   }
   vj_sink<J>(P, seg, row, active, gv, mv, lds, xoff, nfresh, V);
 }
+// Two surviving rows per active lane (hashed partitioning): a survivor's loads are two or three dependent round trips — its columns and
+// where its ids lie, then the ids — and a wave that takes them one drain at a time sits out each of them with nothing else to do (few waves
+// are resident: every one keeps extents open). Here both rows' loads of a step are in flight before either is looked at.
+template <class J>
+__device__ __forceinline__ void vj_drain2(const VhPlanDev& P, uint32_t seg, uint32_t row0, uint32_t row1, bool act0, bool act1, char* lds, uint64_t xoff,
+                                          unsigned long long& nfresh, VjWave& V) {
+  constexpr int NG = J::NG, NM = J::NM;
+  if (!act0) row0 = 0;
+  if (!act1) row1 = 0;
+  uint64_t gv0[NG ? NG : 1], mv0[NM ? NM : 1], gv1[NG ? NG : 1], mv1[NM ? NM : 1];
+  VjBits B0, B1;
+  vj_bits_offsets<J>(P, seg, row0, act0, B0);
+  vj_bits_offsets<J>(P, seg, row1, act1, B1);
+  J::gather(P, seg, row0, gv0, mv0);
+  J::gather(P, seg, row1, gv1, mv1);
+  vj_bits_ids<J>(act0, B0);
+  vj_bits_ids<J>(act1, B1);
+  vj_sink<J>(P, seg, row0, act0, gv0, mv0, lds, xoff, nfresh, V, &B0);
+  vj_sink<J>(P, seg, row1, act1, gv1, mv1, lds, xoff, nfresh, V, &B1);
+}
 // ... from the row's group and metric values on (the no-compaction form brings them in by itself: vj_lanes_rows)
+// the two dependent steps of VjBits: offsets[row], offsets[row + 1] ...
+template <class J>
+__device__ __forceinline__ void vj_bits_offsets(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, VjBits& B) {
+  if constexpr (J::MODE == VH_MODE_HASH && J::HPART && J::BITSET_J >= 0 && !(VJ_ABL & 4)) {
+    const int b = (int)P.m[J::BITSET_J].slot();
+    if (active) {
+      // offsets[row], offsets[row + 1] in ONE 16-byte load (8-byte aligned), the first two ids in ONE 8-byte load (4-byte aligned; what lies
+      // behind a segment's last id is readable: VH_BS_PAD): two address-processor passes per survivor instead of four
+      B.bids = reinterpret_cast<const uint32_t*>(P.bs_vals[b][seg]);
+      if (J::BS_OFF32) {          // 32-bit copies of the offsets (segments with < 2^32 ids): offsets[row], offsets[row + 1] in ONE 8-byte load
+        const vj_u32x2_a4 o = *VJ_GLOBAL(vj_u32x2_a4, reinterpret_cast<const uint32_t*>(P.bs_offs[b][seg]) + row);
+        B.bk = o.x; B.bk1 = o.y;
+      } else if (VJ_BS_MERGE) {
+        const vj_u64x2_a8 o = *VJ_GLOBAL(vj_u64x2_a8, P.bs_offs[b][seg] + row);
+        B.bk = o.x; B.bk1 = o.y;
+      } else {
+        const uint64_t* offs = P.bs_offs[b][seg];
+        B.bk = offs[row]; B.bk1 = offs[row + 1];
+      }
+    }
+  }
+}
+// ... then the first two ids (the tuple says how many of the two count)
+template <class J>
+__device__ __forceinline__ void vj_bits_ids(bool active, VjBits& B) {
+  if constexpr (J::MODE == VH_MODE_HASH && J::HPART && J::BITSET_J >= 0 && !(VJ_ABL & 4)) {
+    if (active && B.bk < B.bk1) {
+      if (J::BS_OFF32 || VJ_BS_MERGE) { const vj_u32x2_a4 i2 = *VJ_GLOBAL(vj_u32x2_a4, B.bids + B.bk); B.bid0 = i2.x; B.bid1 = i2.y; }
+      else { B.bid0 = B.bids[B.bk]; B.bid1 = B.bk + 1 < B.bk1 ? B.bids[B.bk + 1] : 0u; }
+    }
+  }
+}
 template <class J>
 __device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, uint64_t (&gv)[J::NG ? J::NG : 1], uint64_t (&mv)[J::NM ? J::NM : 1],
-                                        char* lds, uint64_t xoff, unsigned long long& nfresh, VjWave& V) {
+                                        char* lds, uint64_t xoff, unsigned long long& nfresh, VjWave& V, const VjBits* pre) {
   VhPartWave& W = V.W; VhPartTile& T = V.T; VhLdsHashWave& H = V.H; VhPartStage& S = V.S;
   constexpr int MODE = J::MODE;
   constexpr int NG = J::NG, NM = J::NM;
   // hashed partitioning with a bitset metric: where the row's ids lie is asked for NOW, next to the record's loads, and the first two ids
   // as soon as that is known — they travel while the key is rolled up and mixed
-  uint64_t bk = 0, bk1 = 0;
-  const uint32_t* bids = nullptr;
-  uint32_t bid0 = 0, bid1 = 0;
-  if constexpr (MODE == VH_MODE_HASH && J::HPART && J::BITSET_J >= 0 && !(VJ_ABL & 4)) {
-    const int b = (int)P.m[J::BITSET_J].slot();
-    if (active) {
-      // offsets[row], offsets[row + 1] in ONE 16-byte load (8-byte aligned), the first two ids in ONE 8-byte load (4-byte aligned; what lies
-      // behind a segment's last id is readable: VH_BS_PAD): two address-processor passes per survivor instead of four
-      bids = reinterpret_cast<const uint32_t*>(P.bs_vals[b][seg]);
-      if (J::BS_OFF32) {          // 32-bit copies of the offsets (segments with < 2^32 ids): offsets[row], offsets[row + 1] in ONE 8-byte load
-        const vj_u32x2_a4 o = *VJ_GLOBAL(vj_u32x2_a4, reinterpret_cast<const uint32_t*>(P.bs_offs[b][seg]) + row);
-        bk = o.x; bk1 = o.y;
-        if (bk < bk1) { const vj_u32x2_a4 i2 = *VJ_GLOBAL(vj_u32x2_a4, bids + bk); bid0 = i2.x; bid1 = i2.y; }
-      } else if (VJ_BS_MERGE) {
-        const vj_u64x2_a8 o = *VJ_GLOBAL(vj_u64x2_a8, P.bs_offs[b][seg] + row);
-        bk = o.x; bk1 = o.y;
-        if (bk < bk1) { const vj_u32x2_a4 i2 = *VJ_GLOBAL(vj_u32x2_a4, bids + bk); bid0 = i2.x; bid1 = i2.y; }      // (the tuple says how many of the two count)
-      } else {
-        const uint64_t* offs = P.bs_offs[b][seg];
-        bk = offs[row]; bk1 = offs[row + 1];
-        if (bk < bk1) { bid0 = bids[bk]; bid1 = bk + 1 < bk1 ? bids[bk + 1] : 0u; }
-      }
-    }
-  }
+  VjBits B;
+  if (pre) B = *pre;           // (vj_drain2 brought them in for two rows at once)
+  else { vj_bits_offsets<J>(P, seg, row, active, B); vj_bits_ids<J>(active, B); }
+  uint64_t bk = B.bk, bk1 = B.bk1;
+  const uint32_t* bids = B.bids;
+  uint32_t bid0 = B.bid0, bid1 = B.bid1;
   vj_rollup_all<J>(P, gv);
   uint64_t gid = 0;
   uint64_t key[VH_KEY_WORDS];
@@ -553,6 +597,14 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
     __builtin_amdgcn_wave_barrier();
     const bool flush = !nhave || nseg != seg;       // queue entries are rows of the current segment
     auto drain_queue = [&](bool all) {
+      if constexpr (MODE == VH_MODE_HASH && J::HPART && J::QPAY == 0 && J::ABLATE == 0 && VJ_DRAIN2) {
+        while (cnt >= 128) {                        // two rows per lane while there are that many (vj_drain2)
+          cnt -= 128;
+          const uint32_t r0 = q[cnt + lane], r1 = q[cnt + 64 + lane];
+          vj_drain2<J>(P, seg, r0, r1, true, true, lds, xoff, nfresh, V);
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
       while (cnt >= 64 || (all && cnt)) {
         const uint32_t take = cnt >= 64 ? 64u : cnt;
         cnt -= take;
