@@ -213,11 +213,11 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
     const uint32_t ntiles = S.ntiles;
     auto tile_total = [&](uint32_t tile) { const uint32_t last = S.tfirst[tile + 1] - 1u; return (uint32_t)S.lpre[last] + S.lfill[last]; };
     auto tile_load = [&](uint32_t tile, uint32_t total, T (&dstv)[R]) {
+      uint32_t i = S.tfirst[tile];               // (the thread's tuples lie further and further into the tile: the search goes on where it stopped)
 #pragma unroll
       for (int r = 0; r < R; ++r) {
         const uint32_t k = (uint32_t)(r * BLOCK + tid);
         if (k < total) {
-          uint32_t i = S.tfirst[tile];
           while ((uint32_t)S.lpre[i] + S.lfill[i] <= k) ++i;
           dstv[r] = hp_load_nt<U>(reinterpret_cast<const T*>(src.tuples) + (uint64_t)S.list[i] * src.stride + (k - S.lpre[i]));
         }

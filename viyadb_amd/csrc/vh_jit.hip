@@ -800,7 +800,7 @@ static bool vj_canonical(int which, VhJitShape* s) {
       S.g[1] = col(1, VH_U32, 4, -1, 0, 0); S.g[1].key_word = 0; S.g[1].key_shift = 32;
       S.m[0].bitset = 1; S.m[0].type = VH_U64; S.m[0].sop = SOP_BITSET;
       S.m[1] = col(2, VH_U32, 4, -1, 0, 0); S.m[1].sop = SOP_ADD32; S.m[1].tword = 1; S.m[1].tshift = 0;
-      if (which == 8) { S.hp_pack = 1; S.hp_pbits = 2; S.hp_idbits = 24; S.m[1].tbits = 2; S.hp_agg_waves = 6; }
+      if (which == 8) { S.hp_pack = 1; S.hp_pbits = 2; S.hp_idbits = 24; S.m[1].tbits = 2; }
       return true;
     }
     default: return false;

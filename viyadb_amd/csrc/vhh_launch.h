@@ -72,11 +72,9 @@ int QueryBuild::compile_kernel() {
     js.hpart = hpart ? 1 : 0;
     js.bs_off32 = hpart && hp_off32 ? 1 : 0;
     js.hp_pack = hp_pack ? 1 : 0; js.hp_pbits = hp_pbits; js.hp_idbits = hp_idbits;
-    if (hpart && hp_pack) {      // the aggregation's blocks per CU as its LDS tables allow them -> the waves per SIMD its registers must leave room for (packed tuples: 81 -> 80; the 32-byte form needs ~100 and would spill)
-      const int by_lds = (int)((size_t)(160u << 10) / (lds_table + 4096));      // (gfx950: 160 KB of LDS per CU)
-      js.hp_agg_waves = std::min(6, by_lds * (VH_HP_AGG_BLOCK / 64) / 4);      // (six: three blocks per CU, 80 registers; asking for eight would buy a fourth block with spills)
-      if (js.hp_agg_waves < 6) js.hp_agg_waves = 0;
-    }
+    // (measurement, VH_HP_AGG_WAVES=6: bound the aggregation's registers so that three of its blocks fit a CU where its LDS tables allow
+    // them — measured: 81 -> 73 registers, the same 1.33 ms; occupancy is not what it waits for. Off.)
+    if (hpart && hp_pack && knobs().hp_agg_waves > 0) js.hp_agg_waves = knobs().hp_agg_waves;
     js.ng = P.ngroup; js.nm = P.nmetric;
     js.qpay = !lanes ? qpay : 0; js.qpay_slot = js.qpay ? qpay_slot : -1;
     {   // which predicate projection, if any (shape_filter noted what exists): rows -> byte planes, everything else -> bit-sliced planes
