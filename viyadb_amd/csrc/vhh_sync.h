@@ -189,9 +189,19 @@ static int sync_batch_locked(vh_table* t, const vh_sync_item* items, uint32_t n)
     table_quiesce(t);
     if (int rc = table_grow(t, max_seg + 1)) return rc;
   }
-  std::vector<uint64_t> rows_now;                          // segments named by this batch -> rows mirrored so far (UINT64_MAX: not named yet)
+  // the columns an item ships: every fixed-width one, or the metrics alone (lists made once per table: a batch over a thousand segments walks
+  // them a thousand times, and the host's share of such a batch is what separates "resident" from the link's own time)
+  if (t->ship_all.empty() && !t->cols.empty()) {
+    for (size_t c = 0; c < t->cols.size(); ++c) {
+      if (is_bitset_elem(t->cols[c].elem)) continue;
+      t->ship_all.push_back((uint16_t)c);
+      if (!is_dim(t->cols[c].kind)) t->ship_metrics.push_back((uint16_t)c);
+    }
+  }
+  std::vector<uint64_t>& rows_now = t->sync_rows_now;      // segments named by this batch -> rows mirrored so far (UINT64_MAX: not named yet)
   rows_now.assign((size_t)max_seg + 1, ~0ull);
-  uint64_t total_bytes = 0;
+  // ---- one descriptor per run of at most `run_max` bytes: at most ~64 K of them however big the batch (counted for 256 KB runs: an upper bound)
+  uint64_t total_bytes = 0, ndesc_max = 0;
   for (uint32_t i = 0; i < n; ++i) {
     const vh_sync_item& it = items[i];
     uint64_t& have = rows_now[it.seg];
@@ -200,24 +210,16 @@ static int sync_batch_locked(vh_table* t, const vh_sync_item* items, uint32_t n)
       return vh_fail(VH_E_INVALID, "vh_table_sync_batch: item %u: segment %u has %llu mirrored rows, range starts at %llu (gap)", i, it.seg,
                      (unsigned long long)have, (unsigned long long)it.row_first);
     have = it.new_size;
-    for (size_t c = 0; c < t->cols.size(); ++c) {
-      const VhColumn& col = t->cols[c];
-      if (is_bitset_elem(col.elem) || !it.nrows || !it.col_ptrs[c] || ((it.flags & VH_SYNC_METRICS_ONLY) && is_dim(col.kind))) continue;
-      total_bytes += it.nrows * (uint64_t)col.esize;
+    if (!it.nrows) continue;
+    for (const uint16_t c : (it.flags & VH_SYNC_METRICS_ONLY) ? t->ship_metrics : t->ship_all) {
+      if (!it.col_ptrs[c]) continue;
+      const uint64_t bytes = it.nrows * (uint64_t)t->cols[c].esize;
+      total_bytes += bytes;
+      ndesc_max += (bytes + (256u << 10) - 1) >> 18;
     }
   }
-  // ---- one descriptor per run of at most `run_max` bytes: at most ~64 K of them however big the batch
   size_t run_max = 256u << 10;
   while (total_bytes / run_max > (1u << 16) && run_max < (4u << 20)) run_max *= 2;
-  uint64_t ndesc_max = 0;
-  for (uint32_t i = 0; i < n; ++i) {
-    const vh_sync_item& it = items[i];
-    for (size_t c = 0; c < t->cols.size(); ++c) {
-      const VhColumn& col = t->cols[c];
-      if (is_bitset_elem(col.elem) || !it.nrows || !it.col_ptrs[c] || ((it.flags & VH_SYNC_METRICS_ONLY) && is_dim(col.kind))) continue;
-      ndesc_max += (it.nrows * (uint64_t)col.esize + run_max - 1) / run_max;
-    }
-  }
   if (ndesc_max > 0x7FFFFFFFull) return vh_fail(VH_E_INVALID, "vh_table_sync_batch: too many runs");
   if (!t->sync_ev) HIP_TRY(hipEventCreateWithFlags(&t->sync_ev, hipEventDisableTiming));
   const size_t need = (size_t)ndesc_max * (2 * sizeof(unsigned long long) + sizeof(VhSyncDesc));
@@ -248,9 +250,8 @@ static int sync_batch_locked(vh_table* t, const vh_sync_item* items, uint32_t n)
     const vh_sync_item& it = items[i];
     // a range that holds every row the segment will have replaces the stats of the columns it ships; any other range widens them
     const bool replace = it.row_first == 0 && it.nrows == it.new_size;
-    for (size_t c = 0; c < t->cols.size(); ++c) {
+    for (const uint16_t c : (it.flags & VH_SYNC_METRICS_ONLY) ? t->ship_metrics : t->ship_all) {
       const VhColumn& col = t->cols[c];
-      if (is_bitset_elem(col.elem) || ((it.flags & VH_SYNC_METRICS_ONLY) && is_dim(col.kind))) continue;
       if (replace && (it.col_ptrs && it.col_ptrs[c])) t->stats[c][it.seg] = VhSegStat();
       if (!it.nrows || !it.col_ptrs[c]) continue;
       const uint64_t bytes = it.nrows * (uint64_t)col.esize;

@@ -108,6 +108,8 @@ struct vh_table {
   std::vector<SyncPending> sync_pending;
   bool sync_inflight = false;
   uint64_t sync_batches = 0, sync_descs = 0, sync_bytes_pulled = 0, sync_bytes_staged = 0, sync_bytes_dma = 0;   // vh_table_sync_stats
+  std::vector<uint16_t> ship_all, ship_metrics;          // vh_table_sync_batch: the columns an item ships (every fixed-width one / the metrics alone)
+  std::vector<uint64_t> sync_rows_now;                   // ... and its scratch (rows mirrored per named segment while a batch is validated)
   std::map<std::string, uint64_t> groups_seen;           // group-column signature -> groups of the last query (hash sizing)
   std::set<std::string> part_clustered;                  // group-column signatures whose survivors came clustered: positional extent chunks overflowed although the pool had room — later queries of the shape take their extents off the shared cursor at once
   std::map<std::string, std::pair<uint64_t, uint64_t>> sel_cache;   // filter signature + table state -> (passed, sampled) of the selectivity probe
