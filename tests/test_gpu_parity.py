@@ -131,9 +131,11 @@ def test_nothing_depends_on_what_fresh_scratch_holds():
 
 def test_clustered_survivors_are_remembered_for_the_shape():
     """Survivors that come clustered (here: only the first eighth of every segment's rows can pass) leave most waves' positional extent
-    chunks empty and overflow those of a few, although the pool as a whole has room: the attempt is void and re-runs on the shared cursor.
-    The table remembers that for the query's group columns (vh_table::part_clustered, like groups_seen for hash sizing), so the NEXT query
-    of the shape starts on the cursor and needs no second attempt."""
+    chunks empty and load those of a few; when that overflows a pool that as a whole has room, the attempt is void, re-runs on the shared
+    cursor, and the table remembers the shape (vh_table::part_clustered, like groups_seen for hash sizing) so that its NEXT query starts on
+    the cursor. At the sizes a test affords the pool's slack (an extent per wave and partition) absorbs the imbalance — measured: no re-run
+    here — so this pins the answers under clustering, on the pre-built and the compiled kernel, and that a shape never needs MORE attempts
+    the second time; the re-run itself is what the VH_TEST_PART_EXTENTS cases force."""
     from viyadb_amd import synth
     from tests.parity import build_oracle_table, compare
     from tests.planner import mirror_table
@@ -150,13 +152,16 @@ def test_clustered_survivors_are_remembered_for_the_shape():
     try:
         want = vo.scan_aggregate(vo.parse_query(ot, w.query))
         tries = []
-        for k in range(3):
-            res = dt.query_agg(AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=64, groups_hint=w.plan.groups_hint))
-            compare(res, want, f"clustered, query {k}")
-            assert res.path == "dense_part"
-            tries.append(res.retries)
-        assert tries[1] <= tries[0] and tries[2] == tries[1], tries
-        if tries[0]:
-            assert tries[1] == 0, tries
+        from viyadb_amd import capi
+        for flags in (64, 64 | capi.PLAN_FORCE_JIT):
+            tries = []
+            for k in range(3):
+                res = dt.query_agg(AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=flags, groups_hint=w.plan.groups_hint))
+                compare(res, want, f"clustered, flags {flags}, query {k}")
+                assert res.path == "dense_part"
+                tries.append(res.retries)
+            assert tries[1] <= tries[0] and tries[2] == tries[1], tries
+            if tries[0]:
+                assert tries[1] == 0, tries
     finally:
         dt.close()
