@@ -57,6 +57,21 @@ def took_hpart(res):
     assert res.path == "hash" and res.hpart and res.jit and "hp_scatter_kernel" in res.kernel and res.kernel.endswith("_hpagg"), (res.path, res.kernel)
 
 
+def scan_wrote_level_a(res):
+    """The scan kernel partitioned 256 ways by itself (vj_fan_add): ONE scatter launch behind it instead of two."""
+    return res.kernel.count("hp_scatter_kernel") == 1
+
+
+class stream_pool_form:
+    """The older form — tuples appended to a stream pool, level A as a scatter launch of its own — is what a re-run after
+    VH_ERR_PART_FULL takes; the hook asks for it on the first attempt."""
+    def __enter__(self):
+        os.environ["VH_NO_HP_FAN"] = "1"
+
+    def __exit__(self, *a):
+        del os.environ["VH_NO_HP_FAN"]
+
+
 @pytest.mark.parametrize("pack", [True, False])
 @pytest.mark.parametrize("max_ids", [0, 1, 2, 3, 7])
 def test_rows_with_any_number_of_ids(max_ids, pack):
@@ -69,7 +84,11 @@ def test_rows_with_any_number_of_ids(max_ids, pack):
         res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("lt", "x", "70")}, flags=HP | (0 if pack else capi.PLAN_NO_HP_PACK))
         took_hpart(res)
         assert res.hp_packed == pack and ("hp_scatter_kernel<1024, 1>" in res.kernel) == pack and ("hp_scatter_kernel<1024, 2>" in res.kernel) == (not pack), res.kernel
-        assert res.retries == 0 and res.ngroups == st.ngroups > 2000
+        assert res.retries == 0 and res.ngroups == st.ngroups > 2000 and scan_wrote_level_a(res), res.kernel
+        with stream_pool_form():
+            res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("lt", "x", "70")}, flags=HP | (0 if pack else capi.PLAN_NO_HP_PACK))
+        took_hpart(res)
+        assert res.retries == 0 and res.ngroups == st.ngroups and not scan_wrote_level_a(res), res.kernel
         res, _ = run(tab, dt, {"dimensions": ["c"], "metrics": ["users"]}, flags=HP)          # few groups, many ids each: sets fill up -> more passes
         assert res.path == "hash"
     finally:
@@ -188,6 +207,27 @@ def test_pools_that_run_out_of_extents_are_resized(sets5):
         finally:
             del os.environ[knob]
         assert res.path == "hash" and res.retries >= 1, knob
+
+
+def test_a_hot_key_overflows_the_scans_positions_and_the_stream_pool_takes_over():
+    """The scan that writes level A itself gives every (block, digit) its extents by POSITION: room for its share of the tuples and
+    half again. Four rows of five in ONE group put far more than that into one digit of every block: VH_ERR_PART_FULL, and the re-run goes
+    through the stream pool and a level A that hands extents out as they fill. Same rows as the oracle's."""
+    rng = np.random.default_rng(8)
+    n = 200_000
+    tab = vo.Table({"name": "t", "segment_size": n, "dimensions": [{"name": "c", "type": "ushort"}, {"name": "x", "type": "uint"}],
+                    "metrics": [{"name": "count", "type": "count"}, {"name": "v", "type": "int_sum"}]})
+    for _ in range(3):
+        hot = rng.random(n) < 0.8
+        tab.add_segment_arrays([np.where(hot, 7, rng.integers(0, 40, n)).astype(np.uint16), np.where(hot, 3, rng.integers(0, 5000, n)).astype(np.uint32)],
+                               [np.ones(n, dtype=np.uint32), rng.integers(-1000, 1000, n).astype(np.int32)], None, n)
+    dt = mirror_table(tab)
+    try:
+        res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["count", "v"]}, flags=HP)
+        took_hpart(res)
+        assert res.retries >= 1 and not scan_wrote_level_a(res) and res.ngroups == st.ngroups > 50_000, (res.retries, res.kernel)
+    finally:
+        dt.close()
 
 
 def test_skew_one_group_gets_everything():

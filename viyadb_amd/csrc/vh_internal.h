@@ -47,6 +47,13 @@
 // per-query compiled kernels (vh_jit_body.h): a wave's survivor queue = carry-over (< 64) + every row slot of one wave step
 // (a step's slots are compacted in one go, then drained)
 #define VJ_QUEUE_CAP (64 + VH_WAVE_STEP_ROWS)
+// ... and, where the scan of a hashed-partitioning query writes the level-A pool itself (vj_fan_add), the block's writer behind the queues:
+// [pos | done | gen] counters, VJ_FAN_RING waiting 128-byte lines per digit, a list of finished lines per wave
+#define VJ_FAN 256               // = HP_FAN (vh_hpart.h; the generated unit asserts it)
+#define VJ_FAN_ET 4096           // = HP_ET
+#define VJ_FAN_RING 2
+#define VJ_FAN_LIST_BYTES 512    // per wave: 64 x (ring line | destination line << 10)
+#define VJ_FAN_LDS_BYTES(block) ((size_t)VJ_FAN * 4 * (1 + 2 * VJ_FAN_RING) + (size_t)VJ_FAN * VJ_FAN_RING * 128 + (size_t)((block) / 64) * VJ_FAN_LIST_BYTES)
 
 // table organisations of the scan kernels
 enum { VH_MODE_DENSE_LDS = 1, VH_MODE_DENSE_GLOBAL = 2, VH_MODE_HASH = 3, VH_MODE_DENSE_PART = 4 };

@@ -49,7 +49,7 @@ uint64_t vh_jit_min_rows() {
 std::string VhJitShape::key() const {
   std::string k;
   auto put = [&](long long v) { k += std::to_string(v); k += ','; };
-  put(mode); put(block); put(scope); put(xcd); put(carrier); put(tw); put(key_words); put(lds_hash); put(gid32); put(ablate); put(stage); put(hpart); put(hp_agg_waves); put(bitset_j); put(hp_pack); put(hp_pbits); put(hp_idbits); put(gid_bits); put(bs_off32);
+  put(mode); put(block); put(scope); put(xcd); put(carrier); put(tw); put(key_words); put(lds_hash); put(gid32); put(ablate); put(stage); put(hpart); put(hp_agg_waves); put(bitset_j); put(hp_pack); put(hp_pbits); put(hp_idbits); put(gid_bits); put(bs_off32); put(hp_fan);
   put(lanes); put(npred);
   for (int i = 0; i < npred; ++i) { put(pred[i].slot); put(pred[i].type); put(pred[i].width); }
   put(qpay); put(qpay_slot);
@@ -122,6 +122,7 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   t += vj_fmt("  static constexpr bool HP_PACK = %s;\n  static constexpr int HP_PBITS = %d, HP_IDBITS = %d;\n", s.hp_pack ? "true" : "false", s.hp_pbits, s.hp_idbits);
   t += vj_fmt("  static constexpr int GID_BITS = %d;\n", s.gid_bits);
   t += vj_fmt("  static constexpr bool BS_OFF32 = %s;\n", s.bs_off32 ? "true" : "false");
+  t += vj_fmt("  static constexpr bool HP_SCANFAN = %s;\n", s.hp_fan ? "true" : "false");
   t += vj_fmt("  static constexpr bool LANES = %s;\n", s.lanes ? "true" : "false");
   t += vj_fmt("  static constexpr int QPAY = %d;\n", s.qpay);
   t += vj_fmt("  static constexpr bool SLICED = %s;\n", s.pp_sliced ? "true" : "false");
@@ -416,6 +417,7 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   // hashed partitioning: the kernel at the other end of the tuples — the ranges' aggregation in LDS (vh_hpart.h) — knows the same shape
   if (s.hpart)
   {
+    if (s.hp_fan) t += "static_assert(VJ_FAN == HP_FAN && VJ_FAN_ET == HP_ET, \"the scan's level-A writer and vh_hpart.h agree on the pool's geometry\");\n";
     // (with a second argument the bound tells the compiler how many waves per SIMD the kernel is meant to run with — three 512-thread blocks
     // per CU are six: 80 registers. Without it C5's aggregation took 81, i.e. TWO blocks per CU where its 49 KB of LDS tables allow three)
     const std::string bound = s.hp_agg_waves > 0 ? vj_fmt("__launch_bounds__(%d, %d)", VH_HP_AGG_BLOCK, s.hp_agg_waves) : vj_fmt("__launch_bounds__(%d)", VH_HP_AGG_BLOCK);
@@ -655,6 +657,7 @@ VhJitKernel* vh_jit_get(const VhJitShape& s, std::string* err) {
 
 int vh_jit_occupancy(VhJitKernel* k, int block, size_t lds) {
   int n = 0;
+  if (lds > 64 * 1024 && lds > k->scan_lds_set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); k->scan_lds_set = lds; }
   if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&n, k->fn, block, lds) != hipSuccess) return 0;
   return n;
 }
@@ -680,6 +683,10 @@ hipError_t vh_jit_launch_pagg(VhJitKernel* k, const VhPlanDev& P, int blocks_per
 }
 
 hipError_t vh_jit_launch(VhJitKernel* k, const VhPlanDev& P, int grid, int block, size_t lds, hipStream_t s) {
+  if (lds > k->scan_lds_set) {       // (the scan that partitions by itself keeps 64 KB of waiting lines next to its queues)
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k->fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    k->scan_lds_set = lds;
+  }
   void* args[] = {const_cast<VhPlanDev*>(&P)};
   return hipModuleLaunchKernel(k->fn, (unsigned)grid, 1, 1, (unsigned)block, 1, 1, (unsigned)lds, s, args, nullptr);
 }
@@ -790,6 +797,8 @@ static bool vj_canonical(int which, VhJitShape* s) {
       S.m[0] = col(0, VH_I64, 8, -1, 0, 0); S.m[0].sop = SOP_ADD64;
       return true;
     }
+    case 16:    // ... case 8 whose scan writes the level-A pool itself (vj_fan_add): 1024-thread blocks, the digits' waiting lines in LDS
+    case 15:    // ... case 6 likewise (32-byte tuples: four to a line)
     case 8:     // ... case 6 with PACKED 16-byte tuples: COUNT in 2 bits, two ids of 24 bits, their count — all in the tuple's second word
     case 6: {   // C5: GROUP BY (time rolled up + hour granularity, u32), COUNT DISTINCT of a bitset metric + COUNT, hashed partitioning (32-byte tuples that carry the ids)
       S.mode = VH_MODE_HASH; S.block = 256; S.scope = __HIP_MEMORY_SCOPE_AGENT; S.carrier = -1; S.key_words = 1; S.lds_hash = 0; S.hpart = 1; S.bitset_j = 0; S.tw = 2;
@@ -800,7 +809,8 @@ static bool vj_canonical(int which, VhJitShape* s) {
       S.g[1] = col(1, VH_U32, 4, -1, 0, 0); S.g[1].key_word = 0; S.g[1].key_shift = 32;
       S.m[0].bitset = 1; S.m[0].type = VH_U64; S.m[0].sop = SOP_BITSET;
       S.m[1] = col(2, VH_U32, 4, -1, 0, 0); S.m[1].sop = SOP_ADD32; S.m[1].tword = 1; S.m[1].tshift = 0;
-      if (which == 8) { S.hp_pack = 1; S.hp_pbits = 2; S.hp_idbits = 24; S.m[1].tbits = 2; }
+      if (which == 8 || which == 16) { S.hp_pack = 1; S.hp_pbits = 2; S.hp_idbits = 24; S.m[1].tbits = 2; }
+      if (which >= 15) { S.hp_fan = 1; S.block = 1024; }
       return true;
     }
     default: return false;

@@ -57,7 +57,9 @@ int QueryBuild::compile_kernel() {
       if (lds_table + (size_t)(jit_block / 64) * qw > lds_room) jit_try = false;
       if (mode == VH_MODE_HASH && !P.lds_hash_slots) jit_block = 256;
     }
+    if (hpart && hp_fan) jit_block = 1024;      // (one block per CU shares the 256 digits' waiting lines: vj_fan_add)
     js.block = jit_block;
+    js.hp_fan = hpart && hp_fan ? 1 : 0;
     js.ablate = knobs().jit_ablate;      // measurement only (profiles/r03/NOTES.md): 1 = no gathers, 2 = nothing behind the gathers
     js.xcd = nxcd > 1 ? 1 : 0;
     js.scope = (mode == VH_MODE_DENSE_GLOBAL || mode == VH_MODE_DENSE_LDS) && nxcd > 1 ? (int)__HIP_MEMORY_SCOPE_WORKGROUP : (int)__HIP_MEMORY_SCOPE_AGENT;
@@ -158,7 +160,8 @@ void QueryBuild::scan_dispatch(int grid_, int* occ) {
   const size_t lds_ = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + qb;
   hipStream_t s_ = x->stream();
   if (jk) {
-    const size_t jl = ((mode == VH_MODE_DENSE_LDS || (mode == VH_MODE_HASH && !hpart)) ? lds_table : 0) + (size_t)(BLOCK / 64) * (VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)VH_STAGE_BYTES(jshape.stage));
+    const size_t jl = ((mode == VH_MODE_DENSE_LDS || (mode == VH_MODE_HASH && !hpart)) ? lds_table : 0) + (size_t)(BLOCK / 64) * (VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)VH_STAGE_BYTES(jshape.stage)) +
+                      (jshape.hp_fan ? VJ_FAN_LDS_BYTES(BLOCK) : 0);
     if (occ) *occ = vh_jit_occupancy(jk, BLOCK, jl);
     else (void)vh_jit_launch(jk, P, grid_, BLOCK, jl, s_);
   }
@@ -199,7 +202,8 @@ int QueryBuild::decompose_work() {
     r->kernel = jk ? jk->name : std::string(nm);
     if (hpart) {      // (the scatter kernel runs twice per query, level A and level B: named twice, so that per-query sums over the names count it twice)
       char hn[160];
-      snprintf(hn, sizeof(hn), " + hp_scatter_kernel<1024, %d> + hp_scatter_kernel<1024, %d> + ", hp_units, hp_units);
+      if (hp_fan) snprintf(hn, sizeof(hn), " + hp_scatter_kernel<1024, %d> + ", hp_units);      // (the scan wrote level A itself)
+      else snprintf(hn, sizeof(hn), " + hp_scatter_kernel<1024, %d> + hp_scatter_kernel<1024, %d> + ", hp_units, hp_units);
       r->kernel += hn + jk->name + "_hpagg";
     }
     const std::string pagg = jit_pagg() ? " + " + jk->name + "_pagg" : std::string(" + part_agg_kernel<1024>");
@@ -369,6 +373,11 @@ int QueryBuild::layout_scratch() {
       const uint64_t cap = hp_tuple_cap, hp_et = HP_ET / hp_units, hp_es = hp_et + (uint64_t)knobs().ext_pad / hp_units;      // tuples per extent / between extent starts
       // level A: every block may hold an open extent per digit (+ one fresh one per tile boundary); level B: the slices hp_plan_kernel lays out
       uint64_t ma = ((cap / hp_et) / g_ctx.num_cu * 3 / 2 + 2 * HP_FAN + 16) * g_ctx.num_cu;      // one slab per block: its share of the tuples and half again, an open extent per digit, one more per digit for the tails
+      if (hp_fan) {       // extents by position: extent k of (scan block, digit) is k * blocks * 256 + block * 256 + digit — room for half again a (block, digit)'s share, and one more
+        const uint64_t per = (uint64_t)grid * HP_FAN;
+        ma = ((cap + cap / 2) / per / hp_et + 2) * per;
+        if (test_env("VH_TEST_PART_EXTENTS")) ma = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS")));      // tests: the first attempt's pool is too small for its positions
+      }
       uint64_t mb = cap / hp_et + (uint64_t)HP_FAN * (2 * HP_FAN + 9) + 64;
       if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS2")) mb = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS2")));   // tests: the last pool runs out
       hpo[k].maxa = ma; hpo[k].maxb = mb;
@@ -536,6 +545,9 @@ int QueryBuild::launch() {
       K.a.max_extents = (uint32_t)std::min<uint64_t>(hpo[k].maxa, 0xFFFFFFF0ull); K.a.cursor = nullptr;      // (handed out in one slab per block of level A)
       K.b.tuples = reinterpret_cast<uint64_t*>(S + hpo[k].tb); K.b.fill = reinterpret_cast<uint16_t*>(S + hpo[k].fb); K.b.tag = reinterpret_cast<uint8_t*>(S + hpo[k].gb);
       K.b.max_extents = (uint32_t)std::min<uint64_t>(hpo[k].maxb, 0xFFFFFFF0ull); K.b.cursor = nullptr;
+      if (hp_fan) {       // the scan kernel's view of pool a (the second pool's fields of the plan: DENSE_PART's two-level plans are the other user)
+        P.tuples2 = K.a.tuples; P.extent_missing2 = K.a.fill; P.extent_part2 = K.a.tag; P.max_extents2 = K.a.max_extents; P.ext_tuples2 = (int32_t)K.a.stride;
+      }
       K.count = reinterpret_cast<uint32_t*>(meta + 8);
       K.slice = reinterpret_cast<uint32_t*>(meta + 8 + (size_t)HP_FAN * 4);
       clear(K.a.fill, (size_t)K.a.max_extents * 2, 0);
@@ -576,7 +588,7 @@ int QueryBuild::launch() {
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
     if (hpart) {
-      vh_launch_hpart(P, d_hpargs, hp_units, g_ctx.num_cu, st);
+      vh_launch_hpart(P, d_hpargs, hp_units, g_ctx.num_cu, hp_fan, st);
       if (!r->hp_chunks) HIP_TRY(vh_jit_launch_hpagg(jk, P, d_hpargs, hp_bpp, 0, HP_FAN * hp_bpp, lds_table, st));
       else if (r->hp_one_launch) {      // regions without streaming: one launch, every region's row count into pinned memory behind it
         HIP_TRY(vh_jit_launch_hpagg(jk, P, d_hpargs, hp_bpp, 0, HP_FAN * hp_bpp, lds_table, st));

@@ -212,6 +212,7 @@ struct QueryBuild {
   bool hpart = false;
   uint64_t hp_tuple_cap = 0;
   int hp_units = 1;                 // 16-byte units per tuple of the hashed partitioning: 2 when the tuples carry the ids of a bitset metric
+  bool hp_fan = false;              // ... whose scan writes the level-A pool itself (vj_fan_add): no stream pool, no level-A scatter
   bool hp_off32 = false;            // ... and reads a row's CSR offsets from the 32-bit copies (every scanned segment has one: VhColumn::bs_offsets32)
   bool hp_pack = false;             // ... or 1 all the same: payload, two ids and their count packed into the tuple's second word (VhHpArgs::pk)
   int hp_pbits = 0, hp_idbits = 0;
@@ -1144,6 +1145,10 @@ int QueryBuild::plan_hashed_partitioning() {
           hp_off32 = !test_env("VH_NO_OFF32");
           for (uint32_t sgi : live) hp_off32 = hp_off32 && t->cols[bitset_col[0]].bs_offsets32[sgi] != nullptr;
         }
+        // the scan partitions 256 ways by itself (one 1024-thread block per CU, extents by position): the first attempt of a query; a re-run after
+        // VH_ERR_PART_FULL — some (block, digit) met far more tuples than its share: skewed keys — goes through the stream pool and level A,
+        // whose extents are handed out as they fill
+        hp_fan = !part_tuples_override && !test_env("VH_NO_HP_FAN") && knobs().ext_pad % 8 == 0;
         lanes = false;
         P.hpart = 1; P.gid_shift = 32;
         P.npart = 1; P.part_shift = 0; P.nlevel = 1; P.agg_shift = 0; P.nfine = 1;      // (the scan kernel writes ONE stream per kind; vh_hpart.h partitions it)
