@@ -54,12 +54,12 @@ def sets5():
 
 
 def took_hpart(res):
-    assert res.path == "hash" and res.hpart and res.jit and "hp_scatter_kernel" in res.kernel and res.kernel.endswith("_hpagg"), (res.path, res.kernel)
+    assert res.path == "hash" and res.hpart and res.jit and "scatter_kernel" in res.kernel and res.kernel.endswith("_hpagg"), (res.path, res.kernel)
 
 
 def scan_wrote_level_a(res):
-    """The scan kernel partitioned 256 ways by itself (vj_fan_add): ONE scatter launch behind it instead of two."""
-    return res.kernel.count("hp_scatter_kernel") == 1
+    """The scan kernel partitioned 256 ways by itself (vj_fan_add): ONE scatter launch behind it instead of two, the barrier-free one."""
+    return res.kernel.count("scatter_kernel") == 1 and "hp_ring_scatter_kernel" in res.kernel
 
 
 class stream_pool_form:
@@ -83,7 +83,7 @@ def test_rows_with_any_number_of_ids(max_ids, pack):
     try:
         res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("lt", "x", "70")}, flags=HP | (0 if pack else capi.PLAN_NO_HP_PACK))
         took_hpart(res)
-        assert res.hp_packed == pack and ("hp_scatter_kernel<1024, 1>" in res.kernel) == pack and ("hp_scatter_kernel<1024, 2>" in res.kernel) == (not pack), res.kernel
+        assert res.hp_packed == pack and ("scatter_kernel<1024, 1>" in res.kernel) == pack and ("scatter_kernel<1024, 2>" in res.kernel) == (not pack), res.kernel
         assert res.retries == 0 and res.ngroups == st.ngroups > 2000 and scan_wrote_level_a(res), res.kernel
         with stream_pool_form():
             res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("lt", "x", "70")}, flags=HP | (0 if pack else capi.PLAN_NO_HP_PACK))
@@ -116,7 +116,7 @@ def test_packed_tuples_at_the_widest_ids_that_fit(id_space, packed):
         if id_space == 2 ** 30:          # 10 bits of SUM payload on top: 1 + 10 + 60 > 61 -> words of their own again
             res, _ = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count", "v"]}, flags=HP)
             took_hpart(res)
-            assert not res.hp_packed and "hp_scatter_kernel<1024, 2>" in res.kernel, res.kernel
+            assert not res.hp_packed and "scatter_kernel<1024, 2>" in res.kernel, res.kernel
     finally:
         dt.close()
 

@@ -32,7 +32,7 @@ one() {   # name (workload[_variant]), rows, bref, bench args...
   case $W in c3|c5)      # instruction mix of the kernels the line names (its own pass: SQ counters)
     (cd /tmp && rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -d $REPO/$OUT/pmc_insts_$W -o $W -- python $REPO/bench.py "$@" $Q --steps 3 --warmup 1 > $REPO/$OUT/pmc_insts_$W.log 2>&1)
     { echo "# rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM -- python bench.py $* $Q --steps 3 --warmup 1 (head $HEAD, sources $SRC): wave-level instructions per launch"
-      for KK in viya_jit part_agg hp_scatter scan_agg; do python tools/pmc_kernel.py $OUT/pmc_insts_$W $KK; done; } > $OUT/${W}_1gpu_pmc_insts.txt;;
+      for KK in viya_jit part_agg hp_scatter hp_ring_scatter scan_agg; do python tools/pmc_kernel.py $OUT/pmc_insts_$W $KK; done; } > $OUT/${W}_1gpu_pmc_insts.txt;;
   esac
   # the line itself, LAST: it now carries the traffic of the pass above
   python bench.py "$@" ${FINAL_EXTRA---no-cpu --no-reference-layout --no-cpu-parallel} > $OUT/bench_${W}_1gpu.json 2> $OUT/bench_${W}.err

@@ -315,6 +315,54 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
   if (__ballot(full)) { if (full) atomicOr(counters + 2, VH_ERR_PART_FULL); }
 }
 
+// ------------------------------------------------------------------ level B without barriers (behind a scan that wrote level A by position)
+// Block (a, j) of HP_FAN x NB: the tuples of partition a that scan blocks j, j + NB, ... wrote — extent k of (scan block, digit a) of pool a
+// lies at k * (scan blocks * 256) + block * 256 + a, so there is nothing to list and nothing to search — go through the ring writer
+// (vh_ring_add, vh_kernels.h) by bits 55..48 of the mixed key into the block's extents of slice a, also by position (hp_plan_kernel). A wave
+// takes whole source extents, UNR x 64 tuples in flight per step; no tile, no histogram, no block barrier between the first load and the
+// last store. C5 (62.5 M tuples): hp_scatter_kernel's level B 0.66-0.72 ms, this one see profiles/r05/NOTES.md.
+struct HpRingDest {
+  uint32_t lo, kmax, nb, j;
+  __device__ __forceinline__ uint64_t extent(uint32_t d, uint32_t k) const { return k < kmax ? (uint64_t)lo + ((uint64_t)k * nb + j) * HP_FAN + d : ~0ull; }
+};
+template <int BLOCK, int U>
+__global__ __launch_bounds__(BLOCK) void hp_ring_scatter_kernel(const VhHpArgs* __restrict__ HA, uint32_t src_blocks, uint32_t nb, unsigned long long* counters) {
+  typedef HpTuple<U> T;
+  constexpr int UNR = 4;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  VhRing F;
+  vh_ring_init<BLOCK>(lds, F, wave);
+  const VhHpKind& K = HA->k[0];
+  const uint32_t a = blockIdx.x / nb, j = blockIdx.x % nb;
+  const uint32_t lo = K.slice[a], cap = K.slice[a + 1] - lo;
+  const HpRingDest D{lo, cap / ((uint32_t)HP_FAN * nb), nb, j};
+  vh_u64x2* const out = reinterpret_cast<vh_u64x2*>(K.b.tuples);
+  const T* const in = reinterpret_cast<const T*>(K.a.tuples);
+  const uint32_t per = src_blocks * (uint32_t)HP_FAN, klev = K.a.max_extents / per;
+  const uint32_t mine = (src_blocks - j + nb - 1u) / nb;                 // scan blocks j, j + nb, ...
+  for (uint32_t s = (uint32_t)wave; s < klev * mine; s += BLOCK / 64) {
+    const uint32_t e = (s / mine) * per + (j + (s % mine) * nb) * (uint32_t)HP_FAN + a;
+    const uint32_t n = __builtin_amdgcn_readfirstlane((int)K.a.fill[e]);
+    const T* const src = in + (uint64_t)e * K.a.stride;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u * UNR) {
+      T t[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) if (i0 + u * 64u + lane < n) t[u] = hp_load_nt<U>(src + i0 + u * 64u + lane);
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        if (i0 + u * 64u >= n) break;                                       // (wave-uniform)
+        const bool valid = i0 + u * 64u + lane < n;
+        uint64_t w[2 * U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) { w[2 * q] = t[u].v[q].x; w[2 * q + 1] = t[u].v[q].y; }
+        vh_ring_add<U>(F, out, K.b.stride, valid, w, valid ? (uint32_t)(w[0] >> 48) & (HP_FAN - 1u) : 0u, lane, D, counters + 2);
+      }
+    }
+  }
+  vh_ring_finish<U, BLOCK>(F, out, K.b.stride, K.b.fill, K.b.tag, D, counters + 2);
+}
+
 // ------------------------------------------------------------------ between the levels: the slices of the last pool
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void hp_count_kernel(const VhHpArgs* __restrict__ HA) {
@@ -330,14 +378,19 @@ __global__ __launch_bounds__(BLOCK) void hp_count_kernel(const VhHpArgs* __restr
   __syncthreads();
   if (threadIdx.x < HP_FAN && cnt[threadIdx.x]) atomicAdd(K.count + threadIdx.x, cnt[threadIdx.x]);
 }
-__global__ __launch_bounds__(HP_FAN) void hp_plan_kernel(const VhHpArgs* __restrict__ HA, unsigned long long* counters) {      // one block of HP_FAN threads
+// ring_blocks != 0 (hp_ring_scatter_kernel writes the slices): every (block j of ring_blocks, digit) of partition a gets its extents by POSITION —
+// extent k of it is slice[a] + (k * ring_blocks + j) * HP_FAN + digit — with room for half again its share of the partition's tuples, and
+// one more; the aggregation looks at the whole slice.
+__global__ __launch_bounds__(HP_FAN) void hp_plan_kernel(const VhHpArgs* __restrict__ HA, unsigned long long* counters, int ring_blocks) {      // one block of HP_FAN threads
   __shared__ unsigned long long wave_tot[HP_FAN / 64];
   const VhHpKind& K = HA->k[0];
   const uint32_t et = (uint32_t)HP_ET / (uint32_t)HA->units;
   const int a = threadIdx.x, lane = a & 63, wave = a >> 6;
   // what partition a holds, in extents, + one open extent per digit of its single writer + the flush of the tails
   const uint32_t c = K.count[a];
-  const unsigned long long need = c ? (unsigned long long)(c + et - 1) / et + 2 * HP_FAN + 8 : 0ull;
+  const unsigned long long per = (unsigned long long)HP_FAN * (unsigned)(ring_blocks > 0 ? ring_blocks : 1);
+  const unsigned long long need = !c ? 0ull : ring_blocks ? (((unsigned long long)c + c / 2) / per / et + 2) * per
+                                                           : (unsigned long long)(c + et - 1) / et + 2 * HP_FAN + 8;
   unsigned long long incl = need;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { const unsigned long long o = __shfl_up(incl, off); if (lane >= off) incl += o; }
@@ -347,7 +400,7 @@ __global__ __launch_bounds__(HP_FAN) void hp_plan_kernel(const VhHpArgs* __restr
   for (int w = 0; w < wave; ++w) before += wave_tot[w];
   const unsigned long long at = before + incl - need, end = before + incl;
   K.slice[a] = (uint32_t)(at < K.b.max_extents ? at : K.b.max_extents);
-  K.slice[HP_FAN + 1 + a] = 0;
+  K.slice[HP_FAN + 1 + a] = ring_blocks ? (uint32_t)need : 0u;      // (extents handed out: by position, all of them)
   if (a == HP_FAN - 1) {
     K.slice[HP_FAN] = (uint32_t)(end < K.b.max_extents ? end : K.b.max_extents);
     if (end > K.b.max_extents) atomicOr(counters + 2, VH_ERR_PART_FULL);

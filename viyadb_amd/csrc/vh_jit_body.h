@@ -76,125 +76,31 @@ __device__ __forceinline__ void vj_rollup_all(const VhPlanDev& P, uint64_t (&gv)
 
 // What a wave carries through the scan besides its registers of predicate values: partition cursors, the waiting lines of the
 // whole-line writer, its luck with the LDS front table.
-struct VjFan { uint32_t* pos; uint32_t* done; uint32_t* gen; char* ring; uint64_t* list; };
 struct VjWave {
   VhPartWave W;
   VhPartTile T;
   VhPartStage S;
   VhLdsHashWave H;
-  VjFan F;
+  VhRing F;
 };
+
 
 // ------------------------------------------------- hashed partitioning: the scan partitions by itself (J::HP_SCANFAN)
 // The first level of vh_hpart.h's partitioning — a stream of tuples re-read and scattered 256 ways by the top byte of the mixed key — costs
 // a write and a read of every tuple (C5: 2 of the 10 GB the query moves, 0.53 of its kernels' 3.2 ms). Here the scan block writes the
-// level-A pool itself. One 1024-thread block per CU; per digit d the block keeps, in LDS,
-//   pos[d]   tuples it has appended to digit d so far — a tuple's number `my` comes off it with one returning LDS atomic and says everything:
-//            its 128-byte line my / LINE of the (block, digit) stream, its place in the line, and where the line goes — extent
-//            (my / ET) * (blocks * 256) + block * 256 + d, the block's k-th extent of the digit by POSITION: no allocation, no cursor;
-//   ring     VJ_FAN_RING waiting lines: the tuple is written to line (my / LINE) % RING once that ring place has seen its previous line leave
-//            (gen[d][r] counts the lines that left; a lane whose place is still taken — more than RING * LINE tuples of one digit in flight
-//            among the block's 16 waves: rare with mixed keys — tries again in the next round of its wave);
-//   done     tuples written into the waiting line: whoever writes the last one owns the line's way out. The owners of a drain (about eight
-//            of 64 lanes) put (ring line, destination) into the wave's list and the WAVE copies the lines out, eight lanes per 128-byte
-//            line: HBM only ever sees whole aligned lines (as hp_scatter_kernel writes them), except for each digit's last, at the block's end.
-// LDS operations of a wave execute in order and an LDS atomic is one indivisible step of the LDS unit: a lane's tuple is in the ring before
-// its `done` count, the owner's reads come behind the count that made it the owner, its `gen` store behind its reads. What the compiler
-// must not reorder is fenced with signal fences (no instructions).
-// (VJ_FAN, VJ_FAN_ET, VJ_FAN_RING, VJ_FAN_LIST_BYTES and the LDS the writer takes, VJ_FAN_LDS_BYTES: vh_internal.h — the host sizes the launch)
+// level-A pool itself through the ring writer of vh_kernels.h (vh_ring_add): one 1024-thread block per CU, the digits' waiting lines in
+// LDS behind the block's queues, and a (block, digit)'s k-th extent at k * (blocks * 256) + block * 256 + digit — by POSITION, no
+// allocation. The pool is the plan's second pool (tuples2, extent_missing2 = tuples in the extent, extent_part2 = digit).
+struct VjFanDest {
+  uint64_t per, first; uint32_t stride, max_ext;
+  __device__ __forceinline__ VjFanDest(const VhPlanDev& P) : per((uint64_t)gridDim.x * VH_RING_FAN), first((uint64_t)blockIdx.x * VH_RING_FAN), stride((uint32_t)P.ext_tuples2), max_ext(P.max_extents2) {}
+  // extent of the digit's k-th extent (~0: beyond the pool)
+  __device__ __forceinline__ uint64_t extent(uint32_t d, uint32_t k) const { const uint64_t e = (uint64_t)k * per + first + d; return e < (uint64_t)max_ext ? e : ~0ull; }
+};
 template <int U>
-__device__ __forceinline__ void vj_fan_add(const VhPlanDev& P, const VjFan& F, bool active, const uint64_t (&w)[2 * U], int lane) {
-  constexpr uint32_t LINE = 8u / U, ET = (uint32_t)VJ_FAN_ET / U, R = VJ_FAN_RING;
-  const uint32_t d = (uint32_t)(w[0] >> 56);
-  uint32_t my = 0;
-  if (active) my = __hip_atomic_fetch_add(&F.pos[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  const uint32_t line = my / LINE, slot = my % LINE, rl = d * R + (line & (R - 1u)), want = line / R;
-  vh_u64x2* const cell = reinterpret_cast<vh_u64x2*>(F.ring) + (rl * 8u + slot * U);
-  // where my line goes if I turn out to own it: extent by position, then the line inside it
-  const uint32_t t0 = line * LINE, k = t0 / ET, off = t0 % ET;
-  const uint64_t e = (uint64_t)k * ((uint64_t)gridDim.x * VJ_FAN) + (uint64_t)blockIdx.x * VJ_FAN + d;
-  const bool room = e < (uint64_t)P.max_extents2;
-  const uint64_t gline = (e * (uint32_t)P.ext_tuples2 + off) * U / 8u;      // in 128-byte lines from the pool's start (extents start on lines)
-  bool pending = active;
-  uint64_t pend = __ballot(pending);
-  while (pend) {
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    const bool can = pending && __hip_atomic_load(&F.gen[rl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == want;
-    if (can) {
-      vh_u64x2 v; v.x = w[0]; v.y = w[1];
-      cell[0] = v;
-      if constexpr (U == 2) { vh_u64x2 v1; v1.x = w[2]; v1.y = w[3]; cell[1] = v1; }
-    }
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    uint32_t c = 0;
-    if (can) c = __hip_atomic_fetch_add(&F.done[rl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const bool own = can && c == LINE - 1u;
-    const uint64_t om = __ballot(own);
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    if (om) {
-      const uint32_t no = (uint32_t)__popcll(om);
-      if (own) F.list[__builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u))] = (uint64_t)rl | (room ? gline << 10 : ~0ull << 10);
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      __builtin_amdgcn_wave_barrier();
-      for (uint32_t i = (uint32_t)lane >> 3; i < no; i += 8u) {
-        const uint64_t ent = F.list[i];
-        const uint32_t piece = (uint32_t)lane & 7u;
-        const vh_u64x2 v = reinterpret_cast<const vh_u64x2*>(F.ring)[((uint32_t)ent & 1023u) * 8u + piece];
-        if ((ent >> 10) != (~0ull >> 10)) reinterpret_cast<vh_u64x2*>(P.tuples2)[(ent >> 10) * 8u + piece] = v;
-      }
-      __atomic_signal_fence(__ATOMIC_SEQ_CST);
-      __builtin_amdgcn_wave_barrier();
-      if (own) {
-        __hip_atomic_store(&F.done[rl], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __atomic_signal_fence(__ATOMIC_SEQ_CST);
-        __hip_atomic_store(&F.gen[rl], want + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (!room) atomicOr(P.counters + 2, VH_ERR_PART_FULL);
-      }
-    }
-    pending = pending && !can;
-    pend = __ballot(pending);
-    if (pend) __builtin_amdgcn_s_sleep(1);
-  }
-}
-template <int BLOCK>
-__device__ __forceinline__ void vj_fan_init(char* area, VjFan& F, int wave) {
-  F.pos = reinterpret_cast<uint32_t*>(area);
-  F.done = F.pos + VJ_FAN;
-  F.gen = F.done + VJ_FAN * VJ_FAN_RING;
-  F.ring = area + (size_t)VJ_FAN * 4 * (1 + 2 * VJ_FAN_RING);
-  F.list = reinterpret_cast<uint64_t*>(F.ring + (size_t)VJ_FAN * VJ_FAN_RING * 128 + (size_t)wave * VJ_FAN_LIST_BYTES);
-  for (uint32_t i = threadIdx.x; i < (uint32_t)VJ_FAN * (1 + 2 * VJ_FAN_RING); i += BLOCK) F.pos[i] = 0u;
-  __syncthreads();
-}
-// The block's end: every digit's last, partial line, and the fill and tag of every extent the block wrote to (what hp_scatter_kernel, level B,
-// and hp_count_kernel find a level-A extent by).
-template <int U, int BLOCK>
-__device__ __forceinline__ void vj_fan_finish(const VhPlanDev& P, const VjFan& F) {
-  constexpr uint32_t LINE = 8u / U, ET = (uint32_t)VJ_FAN_ET / U, R = VJ_FAN_RING;
-  __syncthreads();
-  for (uint32_t d = threadIdx.x; d < (uint32_t)VJ_FAN; d += BLOCK) {
-    const uint32_t n = F.pos[d];
-    const uint64_t per = (uint64_t)gridDim.x * VJ_FAN, first = (uint64_t)blockIdx.x * VJ_FAN + d;
-    bool full = false;
-    const uint32_t left = n % LINE, line = n / LINE;
-    if (left) {
-      const uint32_t t0 = line * LINE;
-      const uint64_t e = (uint64_t)(t0 / ET) * per + first;
-      if (e < (uint64_t)P.max_extents2) {
-        const vh_u64x2* src = reinterpret_cast<const vh_u64x2*>(F.ring) + (d * R + (line & (R - 1u))) * 8u;
-        vh_u64x2* dst = reinterpret_cast<vh_u64x2*>(P.tuples2) + (e * (uint32_t)P.ext_tuples2 + t0 % ET) * U;
-        for (uint32_t i = 0; i < left * U; ++i) dst[i] = src[i];
-      } else full = true;
-    }
-    for (uint32_t k = 0; (uint64_t)k * ET < n; ++k) {
-      const uint64_t e = (uint64_t)k * per + first;
-      if (e >= (uint64_t)P.max_extents2) { full = true; break; }
-      const uint32_t in = n - k * ET;
-      P.extent_missing2[e] = (uint16_t)(in < ET ? in : ET);       // (pool a's convention: the tuples in the extent)
-      P.extent_part2[e] = (uint8_t)d;
-    }
-    if (full) atomicOr(P.counters + 2, VH_ERR_PART_FULL);
-  }
+__device__ __forceinline__ void vj_fan_add(const VhPlanDev& P, const VhRing& F, bool active, const uint64_t (&w)[2 * U], int lane) {
+  const VjFanDest D(P);
+  vh_ring_add<U>(F, reinterpret_cast<vh_u64x2*>(P.tuples2), D.stride, active, w, (uint32_t)(w[0] >> 56), lane, D, P.counters + 2);
 }
 
 // Where a row's ids lie (hashed partitioning with a bitset metric) and the first two of them: loaded in two dependent steps, which a drain
@@ -613,7 +519,7 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
   if constexpr (MODE == VH_MODE_HASH && J::LDS_HASH) vh_lds_hash_init(P, lds, BLOCK);
   if constexpr (MODE == VH_MODE_DENSE_PART || (MODE == VH_MODE_HASH && J::HPART)) vh_part_tile_init(P, lds, V.T, V.W);
   if constexpr (MODE == VH_MODE_HASH && J::HPART && J::HP_SCANFAN)     // the block's level-A writer (vj_fan_add), behind the block's queues
-    vj_fan_init<BLOCK>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t), V.F, wave);
+    vh_ring_init<BLOCK>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t), V.F, wave);
   if constexpr (MODE == VH_MODE_DENSE_PART && J::STAGE != 0)      // one waiting line per partition and wave, behind the block's queues
     V.S.lines = reinterpret_cast<uint64_t*>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)wave * VH_STAGE_BYTES(J::STAGE));
   if constexpr (MODE == VH_MODE_DENSE_LDS) {
@@ -755,7 +661,7 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
   }
 
   if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE != 0) vh_part_stage_finish<J::TW>(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); }
-  if constexpr (MODE == VH_MODE_HASH && J::HPART && J::HP_SCANFAN) vj_fan_finish<(J::BITSET_J >= 0 && !J::HP_PACK) ? 2 : 1, BLOCK>(P, V.F);
+  if constexpr (MODE == VH_MODE_HASH && J::HPART && J::HP_SCANFAN) vh_ring_finish<(J::BITSET_J >= 0 && !J::HP_PACK) ? 2 : 1, BLOCK>(V.F, reinterpret_cast<vh_u64x2*>(P.tuples2), (uint32_t)P.ext_tuples2, P.extent_missing2, P.extent_part2, VjFanDest(P), P.counters + 2);
   else if constexpr (MODE == VH_MODE_HASH && J::HPART) vh_part_tile_finish<1>(P, V.T, lane);
   // the waves' counters, and how far the extents handed out by position reach, as one set of atomics per block (vh_scan_block_end)
   vh_scan_block_end(P, npassed, nfresh, 0ull, (MODE == VH_MODE_DENSE_PART || (MODE == VH_MODE_HASH && J::HPART)) ? vh_part_wave_end(P, V.W) : 0u);

@@ -1124,6 +1124,121 @@ __device__ __forceinline__ void vh_part_tile_finish(const VhPlanDev& P, VhPartTi
   if (T.r_ext != ~0u && T.r_fill < et) vh_pool_missing<LEVEL>(P)[T.r_ext] = (uint16_t)(et - T.r_fill);
 }
 
+// ------------------------------------------------- the ring writer: 256 partitions per BLOCK, whole lines, no barriers
+// What the hashed partitioning (vh_hpart.h) writes its pools with when it can give every (block, digit) its extents by POSITION: the scan
+// kernel that writes level A itself (vj_fan_add, vh_jit_body.h) and the barrier-free level B (hp_ring_scatter_kernel). Per digit d the
+// block keeps, in LDS,
+//   pos[d]   tuples it has appended to digit d so far — a tuple's number `my` comes off it with one returning LDS atomic and says everything:
+//            its 128-byte line my / LINE of the (block, digit) stream, its place in the line, and (through the caller's Dest) the extent
+//            and line the line goes to;
+//   ring     VH_RING_LINES waiting lines: the tuple is written to line (my / LINE) % LINES once that ring place has seen its previous line
+//            leave (gen[d][r] counts the lines that left; a lane whose place is still taken — more than LINES * LINE tuples of one digit in
+//            flight among the block's waves: rare with mixed keys — tries again in the next round of its wave);
+//   done     tuples written into the waiting line: whoever writes the last one owns the line's way out. The owners of one call (about eight
+//            of 64 lanes) put (ring line, destination) into the wave's list and the WAVE copies the lines out, eight lanes per 128-byte
+//            line: HBM only ever sees whole aligned lines, except for each digit's last, at the block's end (vh_ring_finish).
+// No wave ever waits for a barrier: a block's waves run through their input independently, which is what hides the latency of the loads in
+// front (hp_scatter_kernel's tiles pay ~10 block barriers per 4 096 tuples). LDS operations of a wave execute in order and an LDS atomic
+// is one indivisible step of the LDS unit: a lane's tuple is in the ring before its `done` count, the owner's reads come behind the count
+// that made it the owner, its `gen` store behind its reads. What the COMPILER must not reorder is fenced with signal fences (no instructions).
+// Dest: extent(d, k) = the pool extent that holds tuples [k * ET, (k + 1) * ET) of digit d, ~0ull when the pool has no such extent (the
+// attempt is void: VH_ERR_PART_FULL into *err, the host re-plans).
+struct VhRing { uint32_t* pos; uint32_t* done; uint32_t* gen; char* ring; uint64_t* list; };
+#define VH_RING_FAN VJ_FAN
+#define VH_RING_LINES VJ_FAN_RING
+template <int U, class Dest>
+__device__ __forceinline__ void vh_ring_add(const VhRing& F, vh_u64x2* pool, uint32_t stride, bool active, const uint64_t (&w)[2 * U], uint32_t d, int lane,
+                                            const Dest& dest, unsigned long long* err) {
+  constexpr uint32_t LINE = 8u / U, ET = (uint32_t)VJ_FAN_ET / U, R = VH_RING_LINES;
+  uint32_t my = 0;
+  if (active) my = __hip_atomic_fetch_add(&F.pos[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  const uint32_t line = my / LINE, slot = my % LINE, rl = d * R + (line & (R - 1u)), want = line / R;
+  vh_u64x2* const cell = reinterpret_cast<vh_u64x2*>(F.ring) + (rl * 8u + slot * U);
+  // where my line goes if I turn out to own it
+  const uint32_t t0 = line * LINE;
+  const uint64_t e = dest.extent(d, t0 / ET);
+  const bool room = e != ~0ull;
+  const uint64_t gline = (e * stride + t0 % ET) * U / 8u;      // in 128-byte lines from the pool's start (extents start on lines)
+  bool pending = active;
+  uint64_t pend = __ballot(pending);
+  while (pend) {
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    const bool can = pending && __hip_atomic_load(&F.gen[rl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == want;
+    if (can) {
+      vh_u64x2 v; v.x = w[0]; v.y = w[1];
+      cell[0] = v;
+      if constexpr (U == 2) { vh_u64x2 v1; v1.x = w[2]; v1.y = w[3]; cell[1] = v1; }
+    }
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    uint32_t c = 0;
+    if (can) c = __hip_atomic_fetch_add(&F.done[rl], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const bool own = can && c == LINE - 1u;
+    const uint64_t om = __ballot(own);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    if (om) {
+      const uint32_t no = (uint32_t)__popcll(om);
+      if (own) F.list[__builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0u))] = (uint64_t)rl | (room ? gline << 10 : ~0ull << 10);
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t i = (uint32_t)lane >> 3; i < no; i += 8u) {
+        const uint64_t ent = F.list[i];
+        const uint32_t piece = (uint32_t)lane & 7u;
+        const vh_u64x2 v = reinterpret_cast<const vh_u64x2*>(F.ring)[((uint32_t)ent & 1023u) * 8u + piece];
+        if ((ent >> 10) != (~0ull >> 10)) pool[(ent >> 10) * 8u + piece] = v;
+      }
+      __atomic_signal_fence(__ATOMIC_SEQ_CST);
+      __builtin_amdgcn_wave_barrier();
+      if (own) {
+        __hip_atomic_store(&F.done[rl], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __atomic_signal_fence(__ATOMIC_SEQ_CST);
+        __hip_atomic_store(&F.gen[rl], want + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (!room) atomicOr(err, VH_ERR_PART_FULL);
+      }
+    }
+    pending = pending && !can;
+    pend = __ballot(pending);
+    if (pend) __builtin_amdgcn_s_sleep(1);
+  }
+}
+template <int BLOCK>
+__device__ __forceinline__ void vh_ring_init(char* area, VhRing& F, int wave) {      // area: VJ_FAN_LDS_BYTES(BLOCK) of LDS
+  F.pos = reinterpret_cast<uint32_t*>(area);
+  F.done = F.pos + VH_RING_FAN;
+  F.gen = F.done + VH_RING_FAN * VH_RING_LINES;
+  F.ring = area + (size_t)VH_RING_FAN * 4 * (1 + 2 * VH_RING_LINES);
+  F.list = reinterpret_cast<uint64_t*>(F.ring + (size_t)VH_RING_FAN * VH_RING_LINES * 128 + (size_t)wave * VJ_FAN_LIST_BYTES);
+  for (uint32_t i = threadIdx.x; i < (uint32_t)VH_RING_FAN * (1 + 2 * VH_RING_LINES); i += BLOCK) F.pos[i] = 0u;
+  __syncthreads();
+}
+// The block's end: every digit's last, partial line, and the fill (tuples in the extent) and tag (digit) of every extent the block wrote to.
+template <int U, int BLOCK, class Dest>
+__device__ __forceinline__ void vh_ring_finish(const VhRing& F, vh_u64x2* pool, uint32_t stride, uint16_t* fill, uint8_t* tag, const Dest& dest, unsigned long long* err) {
+  constexpr uint32_t LINE = 8u / U, ET = (uint32_t)VJ_FAN_ET / U, R = VH_RING_LINES;
+  __syncthreads();
+  for (uint32_t d = threadIdx.x; d < (uint32_t)VH_RING_FAN; d += BLOCK) {
+    const uint32_t n = F.pos[d];
+    bool full = false;
+    const uint32_t left = n % LINE, line = n / LINE;
+    if (left) {
+      const uint32_t t0 = line * LINE;
+      const uint64_t e = dest.extent(d, t0 / ET);
+      if (e != ~0ull) {
+        const vh_u64x2* src = reinterpret_cast<const vh_u64x2*>(F.ring) + (d * R + (line & (R - 1u))) * 8u;
+        vh_u64x2* dst = pool + (e * stride + t0 % ET) * U;
+        for (uint32_t i = 0; i < left * U; ++i) dst[i] = src[i];
+      } else full = true;
+    }
+    for (uint32_t k = 0; (uint64_t)k * ET < n; ++k) {
+      const uint64_t e = dest.extent(d, k);
+      if (e == ~0ull) { full = true; break; }
+      const uint32_t in = n - k * ET;
+      fill[e] = (uint16_t)(in < ET ? in : ET);
+      tag[e] = (uint8_t)d;
+    }
+    if (full) atomicOr(err, VH_ERR_PART_FULL);
+  }
+}
+
 // =====================================================================================
 // Fast variant: every predicate column is 4 bytes wide (u32 / i32 / f32 — dict codes, uint
 // dims, time) and at most VH_MAX_PRED distinct ones are referenced. Differences to the generic

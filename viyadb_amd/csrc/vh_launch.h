@@ -15,7 +15,7 @@ void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStrea
 void vh_launch_part_agg(const VhPlanDev& P, int blocks_per_part, size_t lds, hipStream_t s);
 void vh_launch_part_split(const VhPlanDev& P, int blocks_per_part, hipStream_t s);
 struct VhHpArgs;
-void vh_launch_hpart(const VhPlanDev& P, const VhHpArgs* d_args, int units, int num_cu, bool level_a_done, hipStream_t s);      // hashed partitioning: everything behind the scan (vh_hpart.h)
+void vh_launch_hpart(const VhPlanDev& P, const VhHpArgs* d_args, int units, int num_cu, int scan_blocks, int ring_blocks, hipStream_t s);      // hashed partitioning: everything behind the scan (vh_hpart.h)
 
 // Launch KERNEL (parenthesised template-id), or — occ != nullptr — only ask the runtime how many of its blocks fit one CU.
 #define VH_LAUNCH_OR_OCC(KERNEL, BLOCK, grid, lds, s, P, occ)                                             \

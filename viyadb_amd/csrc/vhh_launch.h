@@ -202,7 +202,7 @@ int QueryBuild::decompose_work() {
     r->kernel = jk ? jk->name : std::string(nm);
     if (hpart) {      // (the scatter kernel runs twice per query, level A and level B: named twice, so that per-query sums over the names count it twice)
       char hn[160];
-      if (hp_fan) snprintf(hn, sizeof(hn), " + hp_scatter_kernel<1024, %d> + ", hp_units);      // (the scan wrote level A itself)
+      if (hp_fan) snprintf(hn, sizeof(hn), " + hp_ring_scatter_kernel<1024, %d> + ", hp_units);      // (the scan wrote level A itself; level B without barriers)
       else snprintf(hn, sizeof(hn), " + hp_scatter_kernel<1024, %d> + hp_scatter_kernel<1024, %d> + ", hp_units, hp_units);
       r->kernel += hn + jk->name + "_hpagg";
     }
@@ -379,6 +379,11 @@ int QueryBuild::layout_scratch() {
         if (test_env("VH_TEST_PART_EXTENTS")) ma = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS")));      // tests: the first attempt's pool is too small for its positions
       }
       uint64_t mb = cap / hp_et + (uint64_t)HP_FAN * (2 * HP_FAN + 9) + 64;
+      if (hp_fan) {       // level B by position too: hp_plan_kernel's slices, every (writing block, digit) of a partition its share and half again, and two more extents
+        hp_ring_nb = 1;      // (level-B blocks per partition. Measured, C5: two or four of them write level B no faster — 0.425 / 0.421 / 0.397 ms — and leave the
+                             //  aggregation two or four extents per range to walk: 1.08 / 1.24 / 1.69 ms)
+        mb = (cap + cap / 2) / hp_et + (uint64_t)HP_FAN * HP_FAN * 2 * hp_ring_nb + 64;
+      }
       if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS2")) mb = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS2")));   // tests: the last pool runs out
       hpo[k].maxa = ma; hpo[k].maxb = mb;
       hpo[k].ta = sp.take(ma * hp_es * 16 * hp_units); hpo[k].fa = sp.take(ma * 2); hpo[k].ga = sp.take(ma);
@@ -588,7 +593,7 @@ int QueryBuild::launch() {
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
     if (hpart) {
-      vh_launch_hpart(P, d_hpargs, hp_units, g_ctx.num_cu, hp_fan, st);
+      vh_launch_hpart(P, d_hpargs, hp_units, g_ctx.num_cu, hp_fan ? grid : 0, hp_ring_nb, st);
       if (!r->hp_chunks) HIP_TRY(vh_jit_launch_hpagg(jk, P, d_hpargs, hp_bpp, 0, HP_FAN * hp_bpp, lds_table, st));
       else if (r->hp_one_launch) {      // regions without streaming: one launch, every region's row count into pinned memory behind it
         HIP_TRY(vh_jit_launch_hpagg(jk, P, d_hpargs, hp_bpp, 0, HP_FAN * hp_bpp, lds_table, st));
