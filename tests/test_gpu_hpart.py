@@ -209,6 +209,38 @@ def test_pools_that_run_out_of_extents_are_resized(sets5):
         assert res.path == "hash" and res.retries >= 1, knob
 
 
+def _splitmix64(x):
+    M = (1 << 64) - 1
+    x = (x + 0x9E3779B97F4A7C15) & M
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
+    return x ^ (x >> 31)
+
+
+def test_a_digits_second_extent_by_position():
+    """Groups picked so that their mixed keys (vh_splitmix64 of c | x << 16) start with one of THREE bytes: every scan block then appends
+    ~5 000 tuples to each of three digits — more than one 4 096-tuple extent, so the (block, digit)'s second extent, a whole level further
+    into the pool, is written and read (what the full-size tables never do: C5 puts ~950 tuples into a (block, digit)). Level B behind it
+    spreads them over 256 ranges as usual."""
+    rng = np.random.default_rng(9)
+    pairs = np.array([(c, x) for c in range(40) for x in range(5000) if _splitmix64(c | (x << 16)) >> 56 < 3], dtype=np.int64)
+    assert 1500 < len(pairs) < 3500
+    n = 200_000
+    tab = vo.Table({"name": "t", "segment_size": n, "dimensions": [{"name": "c", "type": "ushort"}, {"name": "x", "type": "uint"}],
+                    "metrics": [{"name": "count", "type": "count"}, {"name": "v", "type": "int_sum"}]})
+    for _ in range(3):
+        pick = pairs[rng.integers(0, len(pairs), n)]
+        tab.add_segment_arrays([pick[:, 0].astype(np.uint16), pick[:, 1].astype(np.uint32)],
+                               [np.ones(n, dtype=np.uint32), rng.integers(-1000, 1000, n).astype(np.int32)], None, n)
+    dt = mirror_table(tab)
+    try:
+        res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["count", "v"]}, flags=HP)
+        took_hpart(res)
+        assert res.retries == 0 and scan_wrote_level_a(res) and res.ngroups == st.ngroups == len(pairs), (res.retries, res.kernel, res.ngroups)
+    finally:
+        dt.close()
+
+
 def test_a_hot_key_overflows_the_scans_positions_and_the_stream_pool_takes_over():
     """The scan that writes level A itself gives every (block, digit) its extents by POSITION: room for its share of the tuples and
     half again. Four rows of five in ONE group put far more than that into one digit of every block: VH_ERR_PART_FULL, and the re-run goes

@@ -443,6 +443,31 @@ __device__ __forceinline__ uint32_t hp_slot(unsigned long long* keys, uint32_t g
   return 0;
 }
 
+// ... and in LOCKSTEP (HP_PROBE_UNIFORM, the compiled aggregation's form): every lane of the wave goes round the loop until the wave's last
+// one is through, a lane that has its slot simply repeating its compare-and-swap there (it meets its own key: no change). The loop then
+// has no divergence to keep books on — the form above spends ~25 instructions per round, most of them s_and / s_or / s_andn2 on exec
+// masks, this one about half — and the rounds a wave runs are the same: those of its unluckiest lane.
+#ifndef HP_PROBE_UNIFORM
+#define HP_PROBE_UNIFORM 1      // (0: the divergent loops, for measurement — VH_JIT_FLAGS=-DHP_PROBE_UNIFORM=0)
+#endif
+__device__ __forceinline__ uint32_t hp_slot_uniform(unsigned long long* keys, uint32_t gslots, uint64_t mkey, bool active, bool& ok) {
+  const uint32_t mask = gslots - 1u;
+  const uint32_t step = ((uint32_t)(mkey >> 20) & mask) | 1u;
+  const bool special = mkey == VH_HASH_EMPTY;        // the one mixed key that looks like an empty slot: the table's extra slot
+  if (active && special) keys[gslots] = 0ull;
+  const bool live = active && !special;
+  uint32_t slot = (uint32_t)mkey & mask;
+  ok = true;
+  for (uint32_t round = 0; round <= mask; ++round) {
+    unsigned long long seen = (unsigned long long)mkey;
+    if (live) seen = atomicCAS(&keys[slot], (unsigned long long)VH_HASH_EMPTY, (unsigned long long)mkey);
+    ok = seen == VH_HASH_EMPTY || seen == mkey;
+    if (!__ballot(!ok)) break;
+    slot = ok ? slot : (slot + step) & mask;
+  }
+  return special ? gslots : slot;
+}
+
 #define HP_OVF 128          // extents beyond the first of a range that a block remembers (skewed keys only: a range's share of
                             // uniform keys is a quarter of one extent)
 struct HpAggLds {
@@ -552,14 +577,18 @@ __device__ __forceinline__ void hp_aggregate_body(const VhPlanDev& P, const VhHp
         continue;
       }
       // ---- a tuple: the group's slot (claimed if new), the metric values of its payload word, then its ids into the (group slot, id) set
-      auto tuple = [&](const T& tp) {
+      // (act: the lane has a tuple. With HP_PROBE_UNIFORM the whole wave calls, lanes without one ride along.)
+      auto tuple = [&](const T& tp, bool act) {
         const uint64_t mkey = tp.v[0].x, w1 = tp.v[0].y, payload = PK ? (w1 & PMASK) : w1;
-        if (sub_bits && (int)((uint32_t)(mkey >> (48 - sub_bits)) & (uint32_t)(passes - 1)) != pass) return;
+        if (sub_bits && (int)((uint32_t)(mkey >> (48 - sub_bits)) & (uint32_t)(passes - 1)) != pass) act = false;
+        if (!HP_PROBE_UNIFORM && !act) return;
         bool ok = true;
-        const uint32_t slot = hp_slot(gkeys, GS, mkey, true, ok, (abl & 32) != 0);
-        if (!ok) { bad = true; return; }
+        const uint32_t slot = HP_PROBE_UNIFORM ? hp_slot_uniform(gkeys, GS, mkey, act, ok) : hp_slot(gkeys, GS, mkey, true, ok, (abl & 32) != 0);
+        if (act && !ok) bad = true;
+        act = act && ok;
+        if (!HP_PROBE_UNIFORM && !act) return;
         const uint64_t meta = PK ? (w1 >> 61) : U == 2 ? tp.v[U - 1].y : 0ull;      // bits 0-1: ids that count, bit 2: ids only
-        if (!IDS || !(meta & HP_IDS_ONLY)) {
+        if (act && (!IDS || !(meta & HP_IDS_ONLY))) {
 #pragma unroll
           for (int j = 0; j < NM; ++j) {
             if (J::m_sop[j] == SOP_BITSET) continue;
@@ -572,7 +601,37 @@ __device__ __forceinline__ void hp_aggregate_body(const VhPlanDev& P, const VhHp
         if (IDS && !(abl & 1)) {
           const uint64_t ids = PK ? 0ull : tp.v[U - 1].x;
           const uint32_t idv[2] = {PK ? (uint32_t)((w1 >> PB) & IMASK) : (uint32_t)ids, PK ? (uint32_t)((w1 >> (PB + IB)) & IMASK) : (uint32_t)(ids >> 32)};
-          const int n = (int)(meta & 3ull);
+          const int n = act ? (int)(meta & 3ull) : 0;
+          if constexpr (HP_PROBE_UNIFORM) {
+            // both ids' probe sequences in ONE lockstep loop: two independent compare-and-swaps in flight per round
+            unsigned long long key[2];
+            uint32_t at[2], sstep[2];
+            bool live[2], okq[2], first[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              key[q] = ((unsigned long long)slot << 32) | idv[q];
+              const uint32_t hq = (idv[q] ^ (slot * 0x9E3779B1u)) * 0x85EBCA6Bu;
+              at[q] = hq >> set_shift; sstep[q] = (hq & (SS - 1u)) | 1u;
+              live[q] = q < n; okq[q] = true; first[q] = false;
+            }
+            for (uint32_t round = 0; round < SS; ++round) {
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                unsigned long long seen = key[q];
+                if (live[q]) seen = atomicCAS(&skeys[at[q]], (unsigned long long)VH_HASH_EMPTY, key[q]);
+                first[q] = first[q] || seen == VH_HASH_EMPTY;      // (only a live lane ever sees an empty slot; its repeats meet its own key)
+                okq[q] = seen == VH_HASH_EMPTY || seen == key[q];
+              }
+              if (!__ballot(!(okq[0] && okq[1]))) break;
+#pragma unroll
+              for (int q = 0; q < 2; ++q) at[q] = okq[q] ? at[q] : (at[q] + sstep[q]) & (SS - 1u);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+              if (first[q]) atomicAdd(&card[slot], 1u);
+              if (!okq[q]) bad = true;
+            }
+          } else
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             if (q >= n) break;
@@ -591,11 +650,23 @@ __device__ __forceinline__ void hp_aggregate_body(const VhPlanDev& P, const VhHp
           }
         }
       };
+      // (every loop below runs the same number of times for every thread of a wave: lanes without a tuple call with act = false)
 #pragma unroll
-      for (int u = 0; u < N; ++u) if ((uint32_t)(u * BLOCK + tid) < f0) tuple(pass == 0 ? cg[u] : pool[(uint64_t)e0 * es + u * BLOCK + tid]);
-      for (uint32_t i = N * BLOCK + tid; i < f0; i += BLOCK) tuple(pool[(uint64_t)e0 * es + i]);       // (a first extent of more than 1024 tuples)
+      for (int u = 0; u < N; ++u) {
+        if ((uint32_t)(u * BLOCK + (tid & ~63)) >= f0) break;
+        const bool act = (uint32_t)(u * BLOCK + tid) < f0;
+        tuple(pass == 0 || !act ? cg[u] : pool[(uint64_t)e0 * es + u * BLOCK + tid], act);
+      }
+      for (uint32_t i0 = N * BLOCK + (tid & ~63); i0 < f0; i0 += BLOCK) {       // (a first extent of more than 1024 tuples)
+        const bool act = i0 + lane < f0;
+        tuple(pool[(uint64_t)e0 * es + (act ? i0 + lane : 0u)], act);
+      }
       for (uint32_t x = 0; x < novf; ++x)
-        if (S.ovf_key[x] == (uint16_t)b) for (uint32_t i = tid; i < S.ovf_fill[x]; i += BLOCK) tuple(pool[(uint64_t)S.ovf_ext[x] * es + i]);
+        if (S.ovf_key[x] == (uint16_t)b)
+          for (uint32_t i0 = (tid & ~63); i0 < S.ovf_fill[x]; i0 += BLOCK) {
+            const bool act = i0 + lane < S.ovf_fill[x];
+            tuple(pool[(uint64_t)S.ovf_ext[x] * es + (act ? i0 + lane : 0u)], act);
+          }
       __syncthreads();
       if (__ballot(bad)) { if (lane == 0) S.bad = 1; }
       // ---- this pass's groups: count, take places (off the result's row counter, or a piece of the block's chunk of the list), write

@@ -339,6 +339,7 @@ int QueryBuild::layout_scratch() {
     P.ext_stride = (int32_t)ext_stride;
     uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
     if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
+    if (hpart && hp_fan) max_ext = 64;      // (the scan writes the level-A pool itself: no stream pool to speak of)
     if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS")) max_ext = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS")));   // tests: make the first attempt run out of extents
     P.max_extents = (uint32_t)max_ext;
     // the scan's waves take their extent chunks by position (no shared cursor, no returning atomics: VhPlanDev::ext_waves). The pool above
