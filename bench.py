@@ -165,7 +165,8 @@ def cpu_baseline_parallel(w, seconds: float = 3.0, segments_per_worker: int = 2)
         except Exception:
             pass
     return {"value": rows / seconds if ok else None, "unit": "rows/s", "cores": ok, "kind": "port, segment-parallel (not reference behaviour)",
-            "sample": "%d processes x %d segments of %s, all running the emitted loop for the same %.0f s window (%d of them were ready after it opened)" % (ok, segments_per_worker, w.name, seconds, missed)}
+            "sample": "%d processes x %d segments of %s, each looping over its own segments for the same %.0f s window; %d of the %d started more than "
+                      "50 ms late (their share of the window is overstated by that much)" % (ok, segments_per_worker, w.name, seconds, missed, ok)}
 
 
 def _cpu_model():
