@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+from tests.conftest import JIT_OFF  # noqa: E402
+needs_jit = pytest.mark.skipif(JIT_OFF, reason="VH_JIT=off: this layout / form is read by the per-query compiled kernels only")
 
 
 @pytest.fixture(scope="module")
@@ -81,6 +83,7 @@ def test_c3_full_size_sample_against_oracle(c3_full):
     compare(res, st, "C3 full table, 3-segment window")
 
 
+@needs_jit
 def test_c3_headline_configuration_is_what_bench_times(c3_full):
     """The configuration the bench line is quoted on — a caller that prepared its query shape (vh_table_prepare): compiled scan kernel,
     predicate columns out of the bit-packed predicate projection, payload out of 4-byte bit-field records, one-word tuples — checked
@@ -113,6 +116,7 @@ def test_c3_headline_configuration_is_what_bench_times(c3_full):
     compare(win, st, "C3 prepared, 5-segment window")
 
 
+@needs_jit
 def test_one_word_tuples_replan_when_an_upsert_outgrows_their_bits():
     """One-word tuples (gid + every metric value in 63 bits, sized from the columns' recorded min / max) and bit-field records: between two
     queries an in-place upsert (vh_table_sync_batch, metrics only) makes m0 need more bits than were recorded. The stats widen with the

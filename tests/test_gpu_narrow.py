@@ -12,6 +12,8 @@ from tests.test_gpu_typed import F, run
 from viyadb_amd import capi
 
 pytestmark = pytest.mark.gpu
+from tests.conftest import JIT_OFF  # noqa: E402
+needs_jit = pytest.mark.skipif(JIT_OFF, reason="VH_JIT=off: this layout / form is read by the per-query compiled kernels only")
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -109,6 +111,7 @@ def test_copies_are_built_unasked_for_columns_queries_keep_filtering_on():
 JIT = capi.PLAN_FORCE_JIT
 
 
+@needs_jit
 @pytest.mark.parametrize("sliced", [True, False])
 @pytest.mark.parametrize("flags", [0, 64, 1, 16, 2, 64 | 8192, 8192])
 def test_c3_through_a_predicate_projection(flags, sliced):
@@ -140,6 +143,7 @@ def test_c3_through_a_predicate_projection(flags, sliced):
         dt.close()
 
 
+@needs_jit
 def test_predicate_projection_leaves_of_every_kind_and_types():
     """IN lists, OR, NOT, literals beyond a field's range, columns of 1 / 2 / 4 / 8 bytes, a superset projection (a query that filters on
     two of its three columns), and a set of columns that does not qualify (negative values)."""
@@ -174,6 +178,7 @@ def test_predicate_projection_leaves_of_every_kind_and_types():
         dt.close()
 
 
+@needs_jit
 def test_predicate_projection_follows_syncs_and_is_dropped_when_outgrown():
     rng = np.random.default_rng(5)
     n = 50_000
@@ -208,6 +213,7 @@ def test_predicate_projection_follows_syncs_and_is_dropped_when_outgrown():
         dt.close()
 
 
+@needs_jit
 def test_predicate_projection_is_built_unasked_where_the_compiled_kernel_runs():
     rng = np.random.default_rng(6)
     n = 50_000
@@ -224,6 +230,7 @@ def test_predicate_projection_is_built_unasked_where_the_compiled_kernel_runs():
         dt.close()
 
 
+@needs_jit
 def test_bit_sliced_predicates_on_ragged_snapshots():
     """size() snapshots that end inside a lane's 32 rows, inside a wave's step, at 0 — the tail mask of the bit-sliced scan — and every relation."""
     rng = np.random.default_rng(17)

@@ -351,6 +351,7 @@ def test_bit_field_records_follow_syncs_outgrown_bits_and_negative_values():
         dt.close()
 
 
+@needs_jit
 @pytest.mark.parametrize("flags,path", [(0, "dense_global"), (64, "dense_part"), (1, "hash"), (2, "dense_global"), (16 | 32, "dense_global"), (1 | 2048, "hash")])
 def test_c3_with_streamed_payload_records(flags, path):
     """The compiled compacting scan STREAMS a bit-field projection's 4-byte records beside the predicate columns and queues a survivor's record
@@ -382,6 +383,7 @@ def test_c3_with_streamed_payload_records(flags, path):
         dt.close()
 
 
+@needs_jit
 def test_streamed_payload_follows_the_selectivity():
     from viyadb_amd import synth
     from viyadb_amd.executor import AggPlan

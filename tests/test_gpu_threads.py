@@ -5,6 +5,8 @@ keeps syncing new segments into the shared one; every answer must equal the sing
 import threading
 
 import numpy as np
+import os
+
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -97,6 +99,7 @@ def test_concurrent_queries_and_a_writer():
         shared.close()
 
 
+@pytest.mark.skipif(os.environ.get("VH_JIT", "") in ("0", "off"), reason="VH_JIT=off: the ratio below was characterised with the per-query compiled kernels")
 def test_queries_of_one_table_overlap():
     """Two threads on ONE table finish 2 x N queries sooner than one thread finishes 2N: planning is serialised per table,
     but a launched query waits for the device and reads its groups back outside the lock, on its own context."""
