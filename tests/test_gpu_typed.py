@@ -246,6 +246,15 @@ def test_two_level_partitioning():
             assert "part_split_kernel<256>" in res.kernel, res.kernel
         finally:
             del os.environ["VH_NO_SPLIT_TILE"]
+        # ... and the split itself: through the ring writer (extents by position, no barriers) unasked, the tiled kernel on request and on re-runs
+        res, _ = run(tab, dt, q, flags=64 | 128)
+        assert "part_split_ring_kernel" in res.kernel and res.retries == 0, (res.kernel, res.retries)
+        os.environ["VH_NO_SPLIT_RING"] = "1"
+        try:
+            res, _ = run(tab, dt, q, flags=64 | 128)
+            assert "part_split_tile_kernel" in res.kernel and res.retries == 0, (res.kernel, res.retries)
+        finally:
+            del os.environ["VH_NO_SPLIT_RING"]
         # either pool too small at first: the query re-plans with more room
         for var in ("VH_TEST_PART_EXTENTS", "VH_TEST_PART_EXTENTS2"):
             os.environ[var] = "50"
@@ -253,7 +262,7 @@ def test_two_level_partitioning():
                 res, _ = run(tab, dt, q, flags=64 | 128)
             finally:
                 del os.environ[var]
-            assert res.path == "dense_part" and res.retries >= 1, (var, res.retries)
+            assert res.path == "dense_part" and res.retries >= 1 and "part_split_tile_kernel" in res.kernel, (var, res.retries, res.kernel)      # (a re-run's extents are handed out as they fill)
         # skew: one coarse partition; one single group
         run(tab, dt, dict(q, filter=F("lt", "a", "5")), flags=64)
         run(tab, dt, dict(q, filter={"op": "and", "filters": [F("eq", "a", "2999"), F("eq", "b", "699")]}), flags=64)

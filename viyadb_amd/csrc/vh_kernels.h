@@ -1146,28 +1146,36 @@ __device__ __forceinline__ void vh_part_tile_finish(const VhPlanDev& P, VhPartTi
 struct VhRing { uint32_t* pos; uint32_t* done; uint32_t* gen; char* ring; uint64_t* list; };
 #define VH_RING_FAN VJ_FAN
 #define VH_RING_LINES VJ_FAN_RING
-template <int U, class Dest>
-__device__ __forceinline__ void vh_ring_add(const VhRing& F, vh_u64x2* pool, uint32_t stride, bool active, const uint64_t (&w)[2 * U], uint32_t d, int lane,
-                                            const Dest& dest, unsigned long long* err) {
-  constexpr uint32_t LINE = 8u / U, ET = (uint32_t)VJ_FAN_ET / U, R = VH_RING_LINES;
+// TB bytes per tuple: 8 (DENSE_PART's one-word tuples), 16 or 32; FAN digits and LINES waiting lines per digit (powers of two, FAN * LINES <= 1024:
+// a ring line's number takes ten bits of a list entry); et_shift: log2 of the tuples an extent of the pool holds; stride: tuples between extent
+// starts (a whole number of 128-byte lines). The hashed partitioning: 256 digits x 2 lines; DENSE_PART's second split: 64 x 2.
+#define VH_RING_LDS_BYTES(fan, lines, block) ((size_t)(fan) * 4 * (1 + 2 * (lines)) + (size_t)(fan) * (lines) * 128 + (size_t)((block) / 64) * VJ_FAN_LIST_BYTES)
+template <int TB, class Dest, int FAN = VH_RING_FAN, int R = VH_RING_LINES>
+__device__ __forceinline__ void vh_ring_add_tb(const VhRing& F, char* pool, uint32_t stride, uint32_t et_shift, bool active, const uint64_t (&w)[TB / 8], uint32_t d, int lane,
+                                               const Dest& dest, unsigned long long* err) {
+  static_assert(FAN * R <= 1024 && (TB == 8 || TB == 16 || TB == 32), "ring geometry");
+  constexpr uint32_t LINE = 128u / TB;
   uint32_t my = 0;
   if (active) my = __hip_atomic_fetch_add(&F.pos[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   const uint32_t line = my / LINE, slot = my % LINE, rl = d * R + (line & (R - 1u)), want = line / R;
-  vh_u64x2* const cell = reinterpret_cast<vh_u64x2*>(F.ring) + (rl * 8u + slot * U);
+  char* const cell = F.ring + (size_t)rl * 128u + slot * TB;
   // where my line goes if I turn out to own it
   const uint32_t t0 = line * LINE;
-  const uint64_t e = dest.extent(d, t0 / ET);
+  const uint64_t e = dest.extent(d, t0 >> et_shift);
   const bool room = e != ~0ull;
-  const uint64_t gline = (e * stride + t0 % ET) * U / 8u;      // in 128-byte lines from the pool's start (extents start on lines)
+  const uint64_t gline = (e * stride + (t0 & ((1u << et_shift) - 1u))) / LINE;      // in 128-byte lines from the pool's start (extents start on lines)
   bool pending = active;
   uint64_t pend = __ballot(pending);
   while (pend) {
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     const bool can = pending && __hip_atomic_load(&F.gen[rl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == want;
     if (can) {
-      vh_u64x2 v; v.x = w[0]; v.y = w[1];
-      cell[0] = v;
-      if constexpr (U == 2) { vh_u64x2 v1; v1.x = w[2]; v1.y = w[3]; cell[1] = v1; }
+      if constexpr (TB == 8) *reinterpret_cast<uint64_t*>(cell) = w[0];
+      else {
+        vh_u64x2 v; v.x = w[0]; v.y = w[1];
+        reinterpret_cast<vh_u64x2*>(cell)[0] = v;
+        if constexpr (TB == 32) { vh_u64x2 v1; v1.x = w[2]; v1.y = w[3]; reinterpret_cast<vh_u64x2*>(cell)[1] = v1; }
+      }
     }
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     uint32_t c = 0;
@@ -1184,7 +1192,7 @@ __device__ __forceinline__ void vh_ring_add(const VhRing& F, vh_u64x2* pool, uin
         const uint64_t ent = F.list[i];
         const uint32_t piece = (uint32_t)lane & 7u;
         const vh_u64x2 v = reinterpret_cast<const vh_u64x2*>(F.ring)[((uint32_t)ent & 1023u) * 8u + piece];
-        if ((ent >> 10) != (~0ull >> 10)) pool[(ent >> 10) * 8u + piece] = v;
+        if ((ent >> 10) != (~0ull >> 10)) reinterpret_cast<vh_u64x2*>(pool)[(ent >> 10) * 8u + piece] = v;
       }
       __atomic_signal_fence(__ATOMIC_SEQ_CST);
       __builtin_amdgcn_wave_barrier();
@@ -1200,43 +1208,56 @@ __device__ __forceinline__ void vh_ring_add(const VhRing& F, vh_u64x2* pool, uin
     if (pend) __builtin_amdgcn_s_sleep(1);
   }
 }
-template <int BLOCK>
-__device__ __forceinline__ void vh_ring_init(char* area, VhRing& F, int wave) {      // area: VJ_FAN_LDS_BYTES(BLOCK) of LDS
+// (the hashed partitioning's form: U 16-byte units per tuple, extents of VJ_FAN_ET units)
+template <int U, class Dest>
+__device__ __forceinline__ void vh_ring_add(const VhRing& F, vh_u64x2* pool, uint32_t stride, bool active, const uint64_t (&w)[2 * U], uint32_t d, int lane,
+                                            const Dest& dest, unsigned long long* err) {
+  vh_ring_add_tb<16 * U, Dest>(F, reinterpret_cast<char*>(pool), stride, U == 1 ? 12u : 11u, active, w, d, lane, dest, err);
+  static_assert(VJ_FAN_ET == 4096, "extent shifts above");
+}
+template <int BLOCK, int FAN = VH_RING_FAN, int R = VH_RING_LINES>
+__device__ __forceinline__ void vh_ring_init(char* area, VhRing& F, int wave) {      // area: VH_RING_LDS_BYTES(FAN, R, BLOCK) of LDS
   F.pos = reinterpret_cast<uint32_t*>(area);
-  F.done = F.pos + VH_RING_FAN;
-  F.gen = F.done + VH_RING_FAN * VH_RING_LINES;
-  F.ring = area + (size_t)VH_RING_FAN * 4 * (1 + 2 * VH_RING_LINES);
-  F.list = reinterpret_cast<uint64_t*>(F.ring + (size_t)VH_RING_FAN * VH_RING_LINES * 128 + (size_t)wave * VJ_FAN_LIST_BYTES);
-  for (uint32_t i = threadIdx.x; i < (uint32_t)VH_RING_FAN * (1 + 2 * VH_RING_LINES); i += BLOCK) F.pos[i] = 0u;
+  F.done = F.pos + FAN;
+  F.gen = F.done + FAN * R;
+  F.ring = area + (size_t)FAN * 4 * (1 + 2 * R);
+  F.list = reinterpret_cast<uint64_t*>(F.ring + (size_t)FAN * R * 128 + (size_t)wave * VJ_FAN_LIST_BYTES);
+  for (uint32_t i = threadIdx.x; i < (uint32_t)FAN * (1 + 2 * R); i += BLOCK) F.pos[i] = 0u;
   __syncthreads();
 }
-// The block's end: every digit's last, partial line, and the fill (tuples in the extent) and tag (digit) of every extent the block wrote to.
-template <int U, int BLOCK, class Dest>
-__device__ __forceinline__ void vh_ring_finish(const VhRing& F, vh_u64x2* pool, uint32_t stride, uint16_t* fill, uint8_t* tag, const Dest& dest, unsigned long long* err) {
-  constexpr uint32_t LINE = 8u / U, ET = (uint32_t)VJ_FAN_ET / U, R = VH_RING_LINES;
+// The block's end: every digit's last, partial line, and the fill and tag (digit) of every extent the block wrote to. MISSING: the fill array
+// holds what an extent LACKS (DENSE_PART's pools: extent_missing), not what it holds (the hashed partitioning's).
+template <int TB, int BLOCK, class Dest, int FAN = VH_RING_FAN, int R = VH_RING_LINES, bool MISSING = false>
+__device__ __forceinline__ void vh_ring_finish_tb(const VhRing& F, char* pool, uint32_t stride, uint32_t et_shift, uint16_t* fill, uint8_t* tag, const Dest& dest, unsigned long long* err) {
+  constexpr uint32_t LINE = 128u / TB;
+  const uint32_t ET = 1u << et_shift;
   __syncthreads();
-  for (uint32_t d = threadIdx.x; d < (uint32_t)VH_RING_FAN; d += BLOCK) {
+  for (uint32_t d = threadIdx.x; d < (uint32_t)FAN; d += BLOCK) {
     const uint32_t n = F.pos[d];
     bool full = false;
     const uint32_t left = n % LINE, line = n / LINE;
     if (left) {
       const uint32_t t0 = line * LINE;
-      const uint64_t e = dest.extent(d, t0 / ET);
+      const uint64_t e = dest.extent(d, t0 >> et_shift);
       if (e != ~0ull) {
-        const vh_u64x2* src = reinterpret_cast<const vh_u64x2*>(F.ring) + (d * R + (line & (R - 1u))) * 8u;
-        vh_u64x2* dst = pool + (e * stride + t0 % ET) * U;
-        for (uint32_t i = 0; i < left * U; ++i) dst[i] = src[i];
+        const uint64_t* src = reinterpret_cast<const uint64_t*>(F.ring + (size_t)(d * R + (line & (R - 1u))) * 128u);
+        uint64_t* dst = reinterpret_cast<uint64_t*>(pool + (e * stride + (t0 & (ET - 1u))) * TB);
+        for (uint32_t i = 0; i < left * (TB / 8u); ++i) dst[i] = src[i];
       } else full = true;
     }
-    for (uint32_t k = 0; (uint64_t)k * ET < n; ++k) {
+    for (uint32_t k = 0; ((uint64_t)k << et_shift) < n; ++k) {
       const uint64_t e = dest.extent(d, k);
       if (e == ~0ull) { full = true; break; }
-      const uint32_t in = n - k * ET;
-      fill[e] = (uint16_t)(in < ET ? in : ET);
+      const uint32_t in = n - (k << et_shift), held = in < ET ? in : ET;
+      fill[e] = (uint16_t)(MISSING ? ET - held : held);
       tag[e] = (uint8_t)d;
     }
     if (full) atomicOr(err, VH_ERR_PART_FULL);
   }
+}
+template <int U, int BLOCK, class Dest>
+__device__ __forceinline__ void vh_ring_finish(const VhRing& F, vh_u64x2* pool, uint32_t stride, uint16_t* fill, uint8_t* tag, const Dest& dest, unsigned long long* err) {
+  vh_ring_finish_tb<16 * U, BLOCK, Dest>(F, reinterpret_cast<char*>(pool), stride, U == 1 ? 12u : 11u, fill, tag, dest, err);
 }
 
 // =====================================================================================
@@ -2149,8 +2170,10 @@ __global__ __launch_bounds__(BLOCK) void part_l2_count_kernel(const VhPlanDev P)
   __syncthreads();
   if (threadIdx.x < VH_MAX_PART && cnt[threadIdx.x]) atomicAdd(Q.l2 + VH_L2_WORDS + threadIdx.x, cnt[threadIdx.x]);     // (scratch words behind the table proper)
 }
+// ring_blocks != 0 (part_split_ring_kernel writes the slices): every (block, sub-partition) of a partition gets its extents by POSITION — room for
+// its share of the partition's tuples and half again, and one more extent; phase 2 looks at the whole slice.
 template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void part_l2_plan_kernel(const VhPlanDev P, int waves_per_part) {
+__global__ __launch_bounds__(BLOCK) void part_l2_plan_kernel(const VhPlanDev P, int waves_per_part, int ring_blocks) {
   const VhPools Q = vh_pools(P);
   if (threadIdx.x == 0) {
     unsigned long long at = 0;
@@ -2158,6 +2181,12 @@ __global__ __launch_bounds__(BLOCK) void part_l2_plan_kernel(const VhPlanDev P, 
       const unsigned long long c = Q.l2[VH_L2_WORDS + p];
       Q.l2[p] = (uint32_t)(at < Q.max2 ? at : Q.max2);
       Q.l2[VH_L2_NEXT + p] = 0;
+      if (ring_blocks) {
+        const unsigned long long per = 64ull * (unsigned)ring_blocks, need = c ? ((c + c / 2) / per / (uint32_t)P.ext_tuples2 + 2) * per : 0ull;
+        Q.l2[VH_L2_NEXT + p] = (uint32_t)need;
+        at += need;
+        continue;
+      }
       // (+ 1/4: an extent is closed as soon as a drain's tuples of its sub-partition do not fit, so skewed data leaves up to 63 of 256 slots unused)
       if (c) at += (c + c / 4 + (uint32_t)P.ext_tuples2 - 1) / (uint32_t)P.ext_tuples2 + (unsigned long long)waves_per_part * (64 + VH_EXT_CHUNK);
     }
@@ -2307,6 +2336,64 @@ __global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev 
     }
   }
   if (wave == 0) vh_part_tile_finish<L2>(P, T, lane);
+}
+
+// ------------------------------------------------- the second split without barriers
+// part_split_tile_kernel sorts 2 048 tuples at a time in LDS between four block barriers and writes runs that start and end anywhere in a line. Here
+// a block's waves walk partition p's extents of pool 1 each on its own and append every tuple to sub-partition (gid >> agg_shift) & 63 through the
+// ring writer (vh_ring_add_tb: a tuple counter and two waiting 128-byte lines per sub-partition in LDS, whole lines out, extents by position in the
+// slice part_l2_plan_kernel(ring_blocks) laid out). A (block, sub-partition) that meets more than its share and a half overflows its positions:
+// VH_ERR_PART_FULL, and the re-run takes the tiled kernel, whose extents are handed out as they fill.
+struct VhSplitDest {
+  uint32_t lo, kmax, bpp, b;
+  __device__ __forceinline__ uint64_t extent(uint32_t d, uint32_t k) const { return k < kmax ? (uint64_t)lo + ((uint64_t)k * bpp + b) * 64u + d : ~0ull; }
+};
+#define VH_SPLIT_RING_LDS(block) VH_RING_LDS_BYTES(64, 2, block)
+template <int BLOCK, int TW>
+__global__ __launch_bounds__(BLOCK) void part_split_ring_kernel(const VhPlanDev P, int blocks_per_part) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  typedef typename VhStageTuple<TW>::type Tup;      // (the tuple: two words, or one)
+  constexpr int TB = TW * 8, UNR = 4, NW = BLOCK / 64;
+  const int part = blockIdx.x / blocks_per_part, b = blockIdx.x % blocks_per_part;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  VhRing F;
+  vh_ring_init<BLOCK, 64, 2>(lds, F, wave);
+  const VhPools Q = vh_pools(P);
+  const uint32_t lo = Q.l2[part], cap = Q.l2[part + 1] - lo;
+  const VhSplitDest D{lo, cap / (64u * (uint32_t)blocks_per_part), (uint32_t)blocks_per_part, (uint32_t)b};
+  const uint32_t et2 = (uint32_t)P.ext_tuples2, et2_shift = 31u - (uint32_t)__builtin_clz(et2);      // (a power of two: VH_SPLIT_TILE_TUPLES)
+  const uint64_t gid_mask = TW == 1 ? (1ull << P.gid_bits) - 1ull : ~0ull;
+  const int gshift = P.gid_shift;
+  const uint32_t total = Q.allocated1 < Q.max1 ? (uint32_t)Q.allocated1 : Q.max1;
+  const uint32_t ext_tuples = (uint32_t)P.ext_tuples, ext_stride1 = (uint32_t)P.ext_stride;
+  char* const pool2 = reinterpret_cast<char*>(Q.t2);
+  const uint32_t gsz = vh_tag_group(total, (uint32_t)blocks_per_part * NW);
+  for (uint32_t c0 = ((uint32_t)b * NW + wave) * gsz; c0 < total; c0 += (uint32_t)blocks_per_part * NW * gsz) {
+    const bool in = (uint32_t)lane < gsz && c0 + lane < total;
+    const uint32_t fill = in && Q.tag1[c0 + lane] == (uint8_t)part ? ext_tuples - Q.miss1[c0 + lane] : 0u;
+    uint64_t mine = __ballot(fill != 0);
+    while (mine) {
+      const int q = __builtin_ctzll(mine);
+      mine &= mine - 1;
+      const uint32_t ext = c0 + (uint32_t)q, valid = (uint32_t)__builtin_amdgcn_readlane((int)fill, q);
+      const Tup* base = reinterpret_cast<const Tup*>(Q.t1) + (uint64_t)ext * ext_stride1;
+      for (uint32_t i0 = 0; i0 < valid; i0 += 64u * UNR) {
+        Tup t[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) if (i0 + u * 64u + lane < valid) t[u] = __builtin_nontemporal_load(base + i0 + u * 64u + lane);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          if (i0 + u * 64u >= valid) break;                                     // (wave-uniform)
+          const bool ok = i0 + u * 64u + lane < valid;
+          uint64_t w[TW];
+          if constexpr (TW == 1) w[0] = t[u]; else { w[0] = t[u].x; w[1] = t[u].y; }
+          const uint32_t sub = ok ? ((uint32_t)((w[0] & gid_mask) >> gshift) >> P.agg_shift) & 63u : 0u;
+          vh_ring_add_tb<TB, VhSplitDest, 64, 2>(F, pool2, et2, et2_shift, ok, w, sub, lane, D, P.counters + 2);
+        }
+      }
+    }
+  }
+  vh_ring_finish_tb<TB, BLOCK, VhSplitDest, 64, 2, true>(F, pool2, et2, et2_shift, Q.miss2, Q.tag2, D, P.counters + 2);
 }
 
 

@@ -13,7 +13,7 @@ void vh_launch_scan_fast_global(const VhPlanDev& P, int grid, size_t lds, bool x
 void vh_launch_scan_fast_hash(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ = nullptr);
 void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStream_t s, int* occ = nullptr);
 void vh_launch_part_agg(const VhPlanDev& P, int blocks_per_part, size_t lds, hipStream_t s);
-void vh_launch_part_split(const VhPlanDev& P, int blocks_per_part, hipStream_t s);
+void vh_launch_part_split(const VhPlanDev& P, int blocks_per_part, bool ring, hipStream_t s);
 struct VhHpArgs;
 void vh_launch_hpart(const VhPlanDev& P, const VhHpArgs* d_args, int units, int num_cu, int scan_blocks, int ring_blocks, hipStream_t s);      // hashed partitioning: everything behind the scan (vh_hpart.h)
 

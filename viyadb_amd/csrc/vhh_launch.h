@@ -207,7 +207,7 @@ int QueryBuild::decompose_work() {
       r->kernel += hn + jk->name + "_hpagg";
     }
     const std::string pagg = jit_pagg() ? " + " + jk->name + "_pagg" : std::string(" + part_agg_kernel<1024>");
-    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? pagg : ((P.tw == 2 || P.gid_bits) && !test_env("VH_NO_SPLIT_TILE")) ? (P.gid_bits ? " + part_split_tile_kernel<256, 1>" + pagg : " + part_split_tile_kernel<256, 2>" + pagg) : " + part_split_kernel<256>" + pagg;
+    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? pagg : ((P.tw == 2 || P.gid_bits) && !test_env("VH_NO_SPLIT_TILE")) ? ((!part_tuples_override && !test_env("VH_NO_SPLIT_RING") ? std::string(" + part_split_ring_kernel<256, ") : std::string(" + part_split_tile_kernel<256, ")) + (P.gid_bits ? "1>" : "2>") + pagg) : " + part_split_kernel<256>" + pagg;
   }
   int occupancy = 0;
   if (env_bpc <= 0) scan_dispatch(0, &occupancy);
@@ -358,6 +358,10 @@ int QueryBuild::layout_scratch() {
       const uint64_t et2 = tiled ? VH_SPLIT_TILE_TUPLES : 256;
       P.ext_tuples2 = (int32_t)et2;
       uint64_t max2 = (part_tuple_cap + part_tuple_cap / 4) / et2 + (uint64_t)P.npart * ((uint64_t)split_bpp * (tiled ? 1 : 4) * (64 + VH_EXT_CHUNK) + 1) + 64;
+      // the first attempt splits through the ring writer: every (block, sub-partition) its extents by position, room for its share and a half and one
+      // more (part_l2_plan_kernel); a re-run after VH_ERR_PART_FULL — skewed group ids — takes the tiled kernel, whose extents are handed out as they fill
+      split_ring = tiled && !part_tuples_override && !test_env("VH_NO_SPLIT_RING");
+      if (split_ring) max2 = (part_tuple_cap + part_tuple_cap / 2) / et2 + (uint64_t)P.npart * 64 * split_bpp * 2 + 64;
       if (max2 > 0xFFFFFFF0ull) max2 = 0xFFFFFFF0ull;
       if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS2")) max2 = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS2")));   // tests: the second pool runs out first
       P.max_extents2 = (uint32_t)max2;
@@ -617,7 +621,7 @@ int QueryBuild::launch() {
     }
     if (mode == VH_MODE_DENSE_PART) {
       const bool skip_phase2 = knobs().skip_phase2;     // measurement only (wrong results): phase 1 alone between the events
-      if (P.nlevel == 2 && !skip_phase2) vh_launch_part_split(P, split_bpp, st);
+      if (P.nlevel == 2 && !skip_phase2) vh_launch_part_split(P, split_bpp, split_ring, st);
       if (!skip_phase2) {
         if (jit_pagg()) HIP_TRY(vh_jit_launch_pagg(jk, P, part_bpp, lds_table, st));      // phase 2 compiled for this plan's tuple layout
         else vh_launch_part_agg(P, part_bpp, lds_table, st);
