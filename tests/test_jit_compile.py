@@ -28,7 +28,9 @@ SHAPES = {0: "C3: narrow predicate copies, record gathers, tuples for DENSE_PART
           13: "C3 with the payload records streamed beside the predicate planes (a survivor's record queued in its row's place, no gathers)",
           14: "C3 with bit-sliced predicate columns (22 planes of one bit per row, comparisons bit-serial on 32 rows per lane)",
           15: "C5 (32-byte tuples) whose scan writes the level-A pool itself: 1024-thread blocks, waiting lines per digit in LDS",
-          16: "C5 (packed 16-byte tuples) whose scan writes the level-A pool itself"}
+          16: "C5 (packed 16-byte tuples) whose scan writes the level-A pool itself",
+          18: "C3 with one-word tuples leaving through the block's ring writer (16 partitions' waiting lines per block, extents by position)",
+          19: "C3 with two-word tuples leaving through the block's ring writer"}
 
 
 def _compile(which, tmp_path):

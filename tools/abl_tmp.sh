@@ -1,9 +1,10 @@
-mkdir -p gpurun_out/split
+mkdir -p gpurun_out/pring
 cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
-( timeout 900 python -m pytest tests/test_gpu_typed.py -q -x -k "two_level" ) > gpurun_out/split/typed.log 2>&1; tail -5 gpurun_out/split/typed.log
-( timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_jit.py -q -x ) > gpurun_out/split/parity.log 2>&1; tail -3 gpurun_out/split/parity.log
-REPO=$PWD
-(cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/split/kt -o p2 -- python $REPO/tools/part2_probe.py 1000 1000,120 > $REPO/gpurun_out/split/part2.log 2>&1)
-python tools/pmc_summary.py --kernel-stats $(find gpurun_out/split/kt -name "*_results.db" | head -1) gpurun_out/split/part2.csv; grep "split\|pagg" gpurun_out/split/part2.csv | cut -c1-150
-grep "^{" gpurun_out/split/part2.log | grep -v direct | cut -c1-330
-rm -rf gpurun_out/split/kt
+( timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_typed.py tests/test_gpu_jit.py tests/test_gpu_pack.py tests/test_gpu_narrow.py -q -x ) > gpurun_out/pring/tests.log 2>&1; tail -5 gpurun_out/pring/tests.log
+Q="--no-cpu --no-check --no-reference-layout --no-cpu-parallel"
+for V in ring wave; do
+  unset VH_TEST_HOOKS VH_NO_PART_RING
+  if [ $V = wave ]; then export VH_TEST_HOOKS=1 VH_NO_PART_RING=1; fi
+  for i in 1 2 3; do python bench.py $Q --steps 20 --warmup 3 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$V', $i, round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],3), d['roofline']['kernel'][:90])"; done
+  python bench.py $Q --steps 20 --warmup 3 --segments 125 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$V eighth', round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],3))"
+done

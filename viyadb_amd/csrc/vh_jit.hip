@@ -49,7 +49,7 @@ uint64_t vh_jit_min_rows() {
 std::string VhJitShape::key() const {
   std::string k;
   auto put = [&](long long v) { k += std::to_string(v); k += ','; };
-  put(mode); put(block); put(scope); put(xcd); put(carrier); put(tw); put(key_words); put(lds_hash); put(gid32); put(ablate); put(stage); put(hpart); put(hp_agg_waves); put(bitset_j); put(hp_pack); put(hp_pbits); put(hp_idbits); put(gid_bits); put(bs_off32); put(hp_fan);
+  put(mode); put(block); put(scope); put(xcd); put(carrier); put(tw); put(key_words); put(lds_hash); put(gid32); put(ablate); put(stage); put(hpart); put(hp_agg_waves); put(bitset_j); put(hp_pack); put(hp_pbits); put(hp_idbits); put(gid_bits); put(bs_off32); put(hp_fan); put(part_ring);
   put(lanes); put(npred);
   for (int i = 0; i < npred; ++i) { put(pred[i].slot); put(pred[i].type); put(pred[i].width); }
   put(qpay); put(qpay_slot);
@@ -123,6 +123,7 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   t += vj_fmt("  static constexpr int GID_BITS = %d;\n", s.gid_bits);
   t += vj_fmt("  static constexpr bool BS_OFF32 = %s;\n", s.bs_off32 ? "true" : "false");
   t += vj_fmt("  static constexpr bool HP_SCANFAN = %s;\n", s.hp_fan ? "true" : "false");
+  t += vj_fmt("  static constexpr int PART_RING = %d;\n", s.part_ring);
   t += vj_fmt("  static constexpr bool LANES = %s;\n", s.lanes ? "true" : "false");
   t += vj_fmt("  static constexpr int QPAY = %d;\n", s.qpay);
   t += vj_fmt("  static constexpr bool SLICED = %s;\n", s.pp_sliced ? "true" : "false");
@@ -705,6 +706,8 @@ static bool vj_canonical(int which, VhJitShape* s) {
   VhJitShape& S = *s;
   auto col = [](int slot, int type, int pitch, int rec, int off, int sext) { VhJitCol c; c.slot = slot; c.type = type; c.pitch = pitch; c.rec = rec; c.off = off; c.sext = sext; return c; };
   switch (which) {
+    case 19:    // ... case 0 whose tuples leave through the block's ring writer (16 partitions' waiting lines per block, extents by position)
+    case 18:    // ... case 9 likewise (one-word tuples: sixteen to a line)
     case 14:    // ... case 10 with the predicate columns BIT-SLICED: 2 + 10 + 10 planes of one bit per row, a lane owns 32 consecutive rows per step
     case 13:    // ... case 12 with the payload records STREAMED beside the predicate planes and queued in the rows' place (no gathers)
     case 12:    // ... case 10 with the predicate columns out of a bit-packed predicate projection: d2 (2 bits) | d3 (10) | d4 (10) = a 2-byte and a 1-byte plane
@@ -713,12 +716,16 @@ static bool vj_canonical(int which, VhJitShape* s) {
     case 7:     // ... case 0 with the payload from a compressed 8-byte record: m0 (i64) in 4 bytes, d0 in 2, d1 and count in 1 each
     case 0:     // C3: d2 == a & d3 < b & d4 >= c on narrow copies (1, 2, 2 bytes), payload from a 32-byte record, tuples for DENSE_PART
     case 1: {   // ... the same from the 4-byte arenas, straight into the dense HBM table (what an eighth of the table runs)
+      const bool ring = which == 18 || which == 19;
+      if (which == 18) which = 9;
+      if (which == 19) which = 0;
       const bool part = which == 0 || which == 7 || which == 9 || which == 10 || which == 12 || which == 13 || which == 14;
       S.mode = part ? VH_MODE_DENSE_PART : VH_MODE_DENSE_GLOBAL; S.block = 256; S.scope = __HIP_MEMORY_SCOPE_AGENT; S.carrier = 1; S.tw = part ? 2 : 1; S.gid32 = 1; S.stage = part ? 16 : 0;
       S.npred = 3;
       S.pred[0] = VhJitPred{part ? 7 : 0, VH_U32, part ? 1 : 4}; S.pred[1] = VhJitPred{part ? 8 : 1, VH_U32, part ? 2 : 4}; S.pred[2] = VhJitPred{part ? 9 : 2, VH_U32, part ? 2 : 4};
       S.prog = {vj_leaf(VH_F_REL, VH_U32, VH_OP_EQ, 0, 0), vj_leaf(VH_F_REL, VH_U32, VH_OP_LT, 1, 1), vj_leaf(VH_F_REL, VH_U32, VH_OP_GE, 2, 2), vj_node(VH_F_AND, 3)};
       S.nlits = 3; S.ng = 2; S.nm = 2;
+      if (ring) { S.part_ring = 16; S.stage = 0; }
       if (part) {
         S.g[0] = col(10, VH_U32, 32, 0, 8, 1); S.g[1] = col(11, VH_U32, 32, 0, 12, 1);
         S.m[0] = col(12, VH_I64, 32, 0, 0, 0); S.m[0].sop = SOP_ADD64; S.m[0].tword = 1; S.m[0].tshift = 0;

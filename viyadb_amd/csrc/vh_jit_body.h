@@ -103,6 +103,24 @@ __device__ __forceinline__ void vj_fan_add(const VhPlanDev& P, const VhRing& F, 
   vh_ring_add<U>(F, reinterpret_cast<vh_u64x2*>(P.tuples2), D.stride, active, w, (uint32_t)(w[0] >> 56), lane, D, P.counters + 2);
 }
 
+// ------------------------------------------------- DENSE_PART phase 1 through the ring writer (J::PART_RING = digits the block keeps lines for: 16 or 64)
+// vh_part_staged_add gives every WAVE a waiting line and an open extent per partition (a wave opens extents with chunk reservations, ~100
+// instructions and four line-flush passes per drain at 64 partitions, and what 3 072 waves leave part-full phase 2 walks at the price of
+// full extents). Here the BLOCK shares the partitions' waiting lines (vh_ring_add_tb) and a (block, partition)'s k-th extent of pool 1 lies at
+// k * (blocks * npart) + block * npart + partition: a quarter of the open streams, no allocation, whole lines. Tags and `missing` as phase 2
+// and the second split expect them; a partition that meets more than its share and a half of a block's tuples overflows its positions
+// (VH_ERR_PART_FULL) and the re-run takes the per-wave writer.
+struct VjPartDest {
+  uint64_t per, first; uint32_t max_ext;
+  __device__ __forceinline__ VjPartDest(const VhPlanDev& P) : per((uint64_t)gridDim.x * (uint32_t)P.npart), first((uint64_t)blockIdx.x * (uint32_t)P.npart), max_ext(P.max_extents) {}
+  __device__ __forceinline__ uint64_t extent(uint32_t d, uint32_t k) const { const uint64_t e = (uint64_t)k * per + first + d; return e < (uint64_t)max_ext ? e : ~0ull; }
+};
+template <class J, int TW>
+__device__ __forceinline__ void vj_part_ring_add(const VhPlanDev& P, const VhRing& F, bool active, const uint64_t (&w)[TW], uint32_t part, int lane) {
+  const VjPartDest D(P);
+  vh_ring_add_tb<TW * 8, VjPartDest, J::PART_RING, 2>(F, reinterpret_cast<char*>(P.tuples), (uint32_t)P.ext_stride, 31u - (uint32_t)__builtin_clz((uint32_t)P.ext_tuples), active, w, part, lane, D, P.counters + 2);
+}
+
 // Where a row's ids lie (hashed partitioning with a bitset metric) and the first two of them: loaded in two dependent steps, which a drain
 // of two survivors per lane (vj_drain2) takes for both rows before it looks at either.
 struct VjBits {
@@ -363,7 +381,8 @@ __device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32
     }
     if (__ballot(active && wide)) { if (active && wide) atomicOr(P.counters + 2, VH_ERR_HP_WIDE); }
     if (VJ_ABL & 8) { if (words[0] == 0x123456789ABCDEFull) P.counters[7] = 1; return; }
-    vh_part_staged_add<J::STAGE, 1>(P, T, W, S, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
+    if constexpr (J::PART_RING != 0) vj_part_ring_add<J, 1>(P, V.F, active, words, active ? (uint32_t)(gid >> P.part_shift) : 0u, (int)(threadIdx.x & 63));
+    else vh_part_staged_add<J::STAGE, 1>(P, T, W, S, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
     return;
   } else if constexpr (MODE == VH_MODE_DENSE_PART) {
     constexpr int TW = J::TW;
@@ -381,7 +400,8 @@ __device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32
       vh_part_direct_add<TW, 1, TW>(P, T, W, active, words, (uint32_t)((threadIdx.x & 63) % (VJ_ABL >> 4)), (int)(threadIdx.x & 63));
       return;
     }
-    if constexpr (J::STAGE != 0 && TW == 2) vh_part_staged_add<J::STAGE>(P, T, W, S, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
+    if constexpr (J::PART_RING != 0 && TW == 2) vj_part_ring_add<J, 2>(P, V.F, active, words, active ? (uint32_t)(gid >> P.part_shift) : 0u, (int)(threadIdx.x & 63));
+    else if constexpr (J::STAGE != 0 && TW == 2) vh_part_staged_add<J::STAGE>(P, T, W, S, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
     else vh_part_direct_add<TW, 1, TW>(P, T, W, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
     return;
   }
@@ -520,6 +540,8 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
   if constexpr (MODE == VH_MODE_DENSE_PART || (MODE == VH_MODE_HASH && J::HPART)) vh_part_tile_init(P, lds, V.T, V.W);
   if constexpr (MODE == VH_MODE_HASH && J::HPART && J::HP_SCANFAN)     // the block's level-A writer (vj_fan_add), behind the block's queues
     vh_ring_init<BLOCK>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t), V.F, wave);
+  if constexpr (MODE == VH_MODE_DENSE_PART && J::PART_RING != 0)   // the block's phase-1 writer (vj_part_ring_add), behind the block's queues
+    vh_ring_init<BLOCK, J::PART_RING, 2>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t), V.F, wave);
   if constexpr (MODE == VH_MODE_DENSE_PART && J::STAGE != 0)      // one waiting line per partition and wave, behind the block's queues
     V.S.lines = reinterpret_cast<uint64_t*>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)wave * VH_STAGE_BYTES(J::STAGE));
   if constexpr (MODE == VH_MODE_DENSE_LDS) {
@@ -660,11 +682,15 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
     if (MODE == VH_MODE_HASH && V.H.dead) have = false;     // this wave saw the table overflow: the attempt is void (see scan_agg_kernel)
   }
 
-  if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE != 0) vh_part_stage_finish<J::TW>(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); }
+  if constexpr (MODE == VH_MODE_DENSE_PART && J::PART_RING != 0)
+    vh_ring_finish_tb<J::TW * 8, BLOCK, VjPartDest, J::PART_RING, 2, true>(V.F, reinterpret_cast<char*>(P.tuples), (uint32_t)P.ext_stride, 31u - (uint32_t)__builtin_clz((uint32_t)P.ext_tuples),
+                                                                           P.extent_missing, P.extent_part, VjPartDest(P), P.counters + 2);
+  else if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE != 0) vh_part_stage_finish<J::TW>(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); }
   if constexpr (MODE == VH_MODE_HASH && J::HPART && J::HP_SCANFAN) vh_ring_finish<(J::BITSET_J >= 0 && !J::HP_PACK) ? 2 : 1, BLOCK>(V.F, reinterpret_cast<vh_u64x2*>(P.tuples2), (uint32_t)P.ext_tuples2, P.extent_missing2, P.extent_part2, VjFanDest(P), P.counters + 2);
   else if constexpr (MODE == VH_MODE_HASH && J::HPART) vh_part_tile_finish<1>(P, V.T, lane);
   // the waves' counters, and how far the extents handed out by position reach, as one set of atomics per block (vh_scan_block_end)
-  vh_scan_block_end(P, npassed, nfresh, 0ull, (MODE == VH_MODE_DENSE_PART || (MODE == VH_MODE_HASH && J::HPART)) ? vh_part_wave_end(P, V.W) : 0u);
+  // (extents by position: every extent of the pool may hold something — phase 2 goes by the tags)
+  vh_scan_block_end(P, npassed, nfresh, 0ull, (MODE == VH_MODE_DENSE_PART && J::PART_RING != 0) ? P.max_extents : (MODE == VH_MODE_DENSE_PART || (MODE == VH_MODE_HASH && J::HPART)) ? vh_part_wave_end(P, V.W) : 0u);
   if constexpr (MODE == VH_MODE_HASH && J::LDS_HASH) vh_lds_hash_flush(P, lds, BLOCK);
   if constexpr (MODE == VH_MODE_DENSE_LDS) {
     __syncthreads();

@@ -71,6 +71,10 @@ int QueryBuild::compile_kernel() {
     const bool env_no_stage = knobs().no_stage;             // measurement: tuples appended piece by piece (vh_part_direct_add)
     js.gid_bits = mode == VH_MODE_DENSE_PART ? P.gid_bits : 0;
     js.stage = mode == VH_MODE_DENSE_PART && (P.tw == 2 || P.gid_bits) && !env_no_stage ? (P.npart <= VH_STAGE_PARTS ? VH_STAGE_PARTS : P.npart <= VH_STAGE_PARTS_MAX ? VH_STAGE_PARTS_MAX : 0) : 0;
+    // ... or, on a query's first attempt, through the BLOCK's ring writer (vj_part_ring_add): extents by position; a re-run after VH_ERR_PART_FULL — a
+    // partition met more than its share and a half of some block's tuples — goes back to the per-wave writers, whose extents are handed out as they fill
+    part_ring = js.stage != 0 && !part_tuples_override && !test_env("VH_NO_PART_RING");
+    if (part_ring) { js.part_ring = js.stage; js.stage = 0; }
     js.hpart = hpart ? 1 : 0;
     js.bs_off32 = hpart && hp_off32 ? 1 : 0;
     js.hp_pack = hp_pack ? 1 : 0; js.hp_pbits = hp_pbits; js.hp_idbits = hp_idbits;
@@ -161,7 +165,7 @@ void QueryBuild::scan_dispatch(int grid_, int* occ) {
   hipStream_t s_ = x->stream();
   if (jk) {
     const size_t jl = ((mode == VH_MODE_DENSE_LDS || (mode == VH_MODE_HASH && !hpart)) ? lds_table : 0) + (size_t)(BLOCK / 64) * (VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)VH_STAGE_BYTES(jshape.stage)) +
-                      (jshape.hp_fan ? VJ_FAN_LDS_BYTES(BLOCK) : 0);
+                      (jshape.hp_fan ? VJ_FAN_LDS_BYTES(BLOCK) : 0) + (jshape.part_ring ? VH_RING_LDS_BYTES(jshape.part_ring, 2, BLOCK) : 0);
     if (occ) *occ = vh_jit_occupancy(jk, BLOCK, jl);
     else (void)vh_jit_launch(jk, P, grid_, BLOCK, jl, s_);
   }
@@ -331,6 +335,9 @@ int QueryBuild::layout_scratch() {
     while (et < 4096 && et * 2 <= part_tuple_cap / (waves * P.npart) / 4) et *= 2;
     if (knobs().ext_tuples) et = std::max(256, knobs().ext_tuples);     // measurement
     if (hpart) et = HP_ET / hp_units;  // (the tiles of hp_scatter_kernel are whole source extents: 64 KB of tuples)
+    const bool ring1 = jk && jshape.part_ring != 0;      // phase 1 through the block's ring writer: (block, partition) streams, extents by position
+    const uint64_t per1 = (uint64_t)grid * (uint64_t)std::max(1, (int)P.npart);
+    if (ring1) { et = 256; while (et < 4096 && et * 2 <= part_tuple_cap / per1 / 4) et *= 2; }      // (a power of two: the writer shifts)
     const uint64_t ext_tuples = et;
     P.ext_tuples = (int32_t)ext_tuples;
     // extents of pool 1 start one 128-byte line further apart than they are long (not the stream pools of the hashed partitioning, whose
@@ -340,12 +347,13 @@ int QueryBuild::layout_scratch() {
     uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
     if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
     if (hpart && hp_fan) max_ext = 64;      // (the scan writes the level-A pool itself: no stream pool to speak of)
+    if (ring1) max_ext = std::min<uint64_t>(((part_tuple_cap + part_tuple_cap / 2) / per1 / ext_tuples + 2) * per1, 0xFFFFFFF0ull);      // every (block, partition) its share and half again, and one more extent
     if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS")) max_ext = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS")));   // tests: make the first attempt run out of extents
     P.max_extents = (uint32_t)max_ext;
     // the scan's waves take their extent chunks by position (no shared cursor, no returning atomics: VhPlanDev::ext_waves). The pool above
     // holds that whenever the waves' tuple counts agree within the 25 % the estimate leaves; a re-run after VH_ERR_PART_FULL goes back to
     // the cursor, which packs the chunks whatever the imbalance
-    P.ext_waves = part_tuples_override || test_env("VH_TEST_EXT_CURSOR") || t->part_clustered.count(r->group_sig) ? 0u : (uint32_t)grid * (uint32_t)(BLOCK / 64);
+    P.ext_waves = ring1 || part_tuples_override || test_env("VH_TEST_EXT_CURSOR") || t->part_clustered.count(r->group_sig) ? 0u : (uint32_t)grid * (uint32_t)(BLOCK / 64);
     o_tuples = sp.take(max_ext * ext_stride * P.tw * 8);
     o_emiss = sp.take(max_ext * sizeof(uint16_t));
     o_epart = sp.take(max_ext);

@@ -213,6 +213,7 @@ struct QueryBuild {
   uint64_t hp_tuple_cap = 0;
   int hp_units = 1;                 // 16-byte units per tuple of the hashed partitioning: 2 when the tuples carry the ids of a bitset metric
   int hp_ring_nb = 1;
+  bool part_ring = false;           // DENSE_PART: phase 1 writes its tuples through the block's ring writer (vj_part_ring_add)
   bool split_ring = false;          // DENSE_PART, two levels: the second split through the ring writer, extents by position (part_split_ring_kernel)
   bool hp_fan = false;              // ... whose scan writes the level-A pool itself (vj_fan_add): no stream pool, no level-A scatter
   bool hp_off32 = false;            // ... and reads a row's CSR offsets from the 32-bit copies (every scanned segment has one: VhColumn::bs_offsets32)
