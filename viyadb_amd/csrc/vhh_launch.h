@@ -225,7 +225,9 @@ int QueryBuild::decompose_work() {
   // 6, C5's scan 1.95 -> 1.6 ms with 4 instead of 8, and the scatter behind it finds fewer half-empty extents)
   // (the compiled no-compaction kernel has a whole step's payload in flight per wave — 16 rows x every column per lane: two 256-thread blocks per
   // CU already stream at full rate, and every block fewer is a table flush fewer: C2 0.315 -> 0.308 ms, 400 M rows 1.217 -> 1.179)
-  const int occ_cap = jk && mode == VH_MODE_DENSE_PART ? 3 : jk && hpart ? 4 : jk && lanes ? 2 : 8;
+  // (through the block's ring writer a block keeps its partitions' lines open, not every wave: four blocks per CU — over four fresh processes each
+  // 1.296-1.312 ms per C3 query against 1.265-1.405 with three and 1.31-1.48 with five; an eighth of the table 0.283 against 0.294)
+  const int occ_cap = jk && mode == VH_MODE_DENSE_PART ? (jshape.part_ring ? 4 : 3) : jk && hpart ? 4 : jk && lanes ? 2 : 8;
   int blocks_per_cu = env_bpc > 0 ? env_bpc : occupancy > 0 ? std::min(occupancy, occ_cap) : (BLOCK == 1024 ? 1 : 4);
   if (const char* e = test_env("VH_TEST_BLOCKS_PER_CU")) { if (atoi(e) > 0) blocks_per_cu = occupancy > 0 ? std::min(occupancy, atoi(e)) : atoi(e); }   // (measurement: switched between two queries of one process)
   uint32_t unit_rows = step;
