@@ -52,6 +52,8 @@ g++ -std=c++17 -O2 tools/ingest_bench.cc -Iinclude -Lviyadb_amd -lviya_host -lvi
 python tools/pred_ab.py 1000 7 2>/dev/null | grep '^{' > $OUT/pred_ab.txt
 python tools/pred_ab.py 125 7 2>/dev/null | grep '^{' >> $OUT/pred_ab.txt
 python tools/qpay_probe.py 2>/dev/null | grep '^{' > $OUT/qpay_probe.txt
+python tools/part2_probe.py 1000 1000,120 2>/dev/null | grep '^{' > $OUT/part2_probe.txt      # 4 M groups (two partition levels) at 100 % / 12 % of 1 B rows
+python tools/hisel_probe.py 1000 2>/dev/null | grep '^{' > $OUT/hisel_probe.txt              # 100 K groups from the arenas at 100 / 50 / 25 %
 # how stable the headline is from process to process: ten fresh processes as a caller that prepares its query shape (vh_table_prepare) and
 # ten as one that does not (an ordinary first query: plain hipMalloc for the tuple pool)
 { for i in 1 2 3 4 5 6 7 8 9 10; do python bench.py $Q --steps 10 --warmup 3 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('prepared', $i, round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],3), d['config']['pool_placed_by_measurement'])"; done
