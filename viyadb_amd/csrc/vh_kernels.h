@@ -1166,6 +1166,7 @@ __device__ __forceinline__ void vh_ring_add_tb(const VhRing& F, char* pool, uint
   const uint64_t gline = (e * stride + (t0 & ((1u << et_shift) - 1u))) / LINE;      // in 128-byte lines from the pool's start (extents start on lines)
   bool pending = active;
   uint64_t pend = __ballot(pending);
+  uint32_t spins = 0;
   while (pend) {
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     const bool can = pending && __hip_atomic_load(&F.gen[rl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == want;
@@ -1205,7 +1206,12 @@ __device__ __forceinline__ void vh_ring_add_tb(const VhRing& F, char* pool, uint
     }
     pending = pending && !can;
     pend = __ballot(pending);
-    if (pend) __builtin_amdgcn_s_sleep(1);
+    if (pend) {
+      __builtin_amdgcn_s_sleep(1);
+      // (a ring place frees itself as soon as the eight writers of the line before have written, and none of them waits for anything later: the
+      // wait is a few rounds. A bound all the same — a kernel must end whatever happens: the attempt is void, the re-run takes the other writer)
+      if (++spins > (1u << 22)) { if (pending) atomicOr(err, VH_ERR_PART_FULL); break; }
+    }
   }
 }
 // (the hashed partitioning's form: U 16-byte units per tuple, extents of VJ_FAN_ET units)
