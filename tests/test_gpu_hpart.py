@@ -258,6 +258,10 @@ def test_a_hot_key_overflows_the_scans_positions_and_the_stream_pool_takes_over(
         res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["count", "v"]}, flags=HP)
         took_hpart(res)
         assert res.retries >= 1 and not scan_wrote_level_a(res) and res.ngroups == st.ngroups > 50_000, (res.retries, res.kernel)
+        # ... and the table remembers the shape (vh_table::part_clustered): its next query starts with the stream pool instead of paying for a void attempt
+        res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["count", "v"]}, flags=HP)
+        took_hpart(res)
+        assert res.retries == 0 and not scan_wrote_level_a(res), (res.retries, res.kernel)
     finally:
         dt.close()
 

@@ -279,6 +279,9 @@ static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
     if (rp->hp_passes > 64) rp->hp_passes = 64;
   }
   else if (retry == 3 && r->hpart) {                         // hashed partitioning ran out of tuple extents: size for the survivors it counted, then give up
+    // extents by position (the ring writer) ran out although the pools had room: a hot key. Remembered for the shape — its next queries start with
+    // the writers whose extents are handed out as they fill, instead of paying for a void attempt every time
+    if (r->by_position && r->info.passed_recs + r->info.passed_recs / 16 <= r->pos_capacity) { std::lock_guard<std::mutex> lk(t->mu); t->part_clustered.insert(r->group_sig); }
     if (rp->part_override) rp->no_hpart = true;
     else rp->part_override = std::max<uint64_t>(r->info.passed_recs + r->info.passed_recs / 16 + 1024, 1ull << 16);
   }
@@ -288,6 +291,8 @@ static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
     // positional chunks (VhPlanDev::ext_waves) ran out with room to spare: some waves met far more survivors than others (a time range over
     // time-ordered segments, a skewed partition). Remembered for the shape, like groups_seen for hash sizing: its next queries start on the cursor
     if (r->plan.ext_waves && r->info.passed_recs + r->info.passed_recs / 16 <= had) { std::lock_guard<std::mutex> lk(t->mu); t->part_clustered.insert(r->group_sig); }
+    // ... and so did extents by position (the ring writer of phase 1 or of the second split): skewed group ids
+    if (r->by_position && r->info.passed_recs + r->info.passed_recs / 16 <= r->pos_capacity) { std::lock_guard<std::mutex> lk(t->mu); t->part_clustered.insert(r->group_sig); }
     if (rp->part_override && had >= r->info.scanned_recs) rp->no_part = true;
     else rp->part_override = std::max<uint64_t>(std::max<uint64_t>(rp->part_override * 2, r->info.passed_recs + r->info.passed_recs / 16), 1ull << 16);
   }

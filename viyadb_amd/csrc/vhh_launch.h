@@ -73,7 +73,7 @@ int QueryBuild::compile_kernel() {
     js.stage = mode == VH_MODE_DENSE_PART && (P.tw == 2 || P.gid_bits) && !env_no_stage ? (P.npart <= VH_STAGE_PARTS ? VH_STAGE_PARTS : P.npart <= VH_STAGE_PARTS_MAX ? VH_STAGE_PARTS_MAX : 0) : 0;
     // ... or, on a query's first attempt, through the BLOCK's ring writer (vj_part_ring_add): extents by position; a re-run after VH_ERR_PART_FULL — a
     // partition met more than its share and a half of some block's tuples — goes back to the per-wave writers, whose extents are handed out as they fill
-    part_ring = js.stage != 0 && !part_tuples_override && !test_env("VH_NO_PART_RING");
+    part_ring = js.stage != 0 && !part_tuples_override && !test_env("VH_NO_PART_RING") && !t->part_clustered.count(r->group_sig);
     if (part_ring) { js.part_ring = js.stage; js.stage = 0; }
     js.hpart = hpart ? 1 : 0;
     js.bs_off32 = hpart && hp_off32 ? 1 : 0;
@@ -211,7 +211,7 @@ int QueryBuild::decompose_work() {
       r->kernel += hn + jk->name + "_hpagg";
     }
     const std::string pagg = jit_pagg() ? " + " + jk->name + "_pagg" : std::string(" + part_agg_kernel<1024>");
-    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? pagg : ((P.tw == 2 || P.gid_bits) && !test_env("VH_NO_SPLIT_TILE")) ? ((!part_tuples_override && !test_env("VH_NO_SPLIT_RING") ? std::string(" + part_split_ring_kernel<256, ") : std::string(" + part_split_tile_kernel<256, ")) + (P.gid_bits ? "1>" : "2>") + pagg) : " + part_split_kernel<256>" + pagg;
+    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? pagg : ((P.tw == 2 || P.gid_bits) && !test_env("VH_NO_SPLIT_TILE")) ? ((!part_tuples_override && !test_env("VH_NO_SPLIT_RING") && !t->part_clustered.count(r->group_sig) ? std::string(" + part_split_ring_kernel<256, ") : std::string(" + part_split_tile_kernel<256, ")) + (P.gid_bits ? "1>" : "2>") + pagg) : " + part_split_kernel<256>" + pagg;
   }
   int occupancy = 0;
   if (env_bpc <= 0) scan_dispatch(0, &occupancy);
@@ -370,7 +370,7 @@ int QueryBuild::layout_scratch() {
       uint64_t max2 = (part_tuple_cap + part_tuple_cap / 4) / et2 + (uint64_t)P.npart * ((uint64_t)split_bpp * (tiled ? 1 : 4) * (64 + VH_EXT_CHUNK) + 1) + 64;
       // the first attempt splits through the ring writer: every (block, sub-partition) its extents by position, room for its share and a half and one
       // more (part_l2_plan_kernel); a re-run after VH_ERR_PART_FULL — skewed group ids — takes the tiled kernel, whose extents are handed out as they fill
-      split_ring = tiled && !part_tuples_override && !test_env("VH_NO_SPLIT_RING");
+      split_ring = tiled && !part_tuples_override && !test_env("VH_NO_SPLIT_RING") && !t->part_clustered.count(r->group_sig);
       if (split_ring) max2 = (part_tuple_cap + part_tuple_cap / 2) / et2 + (uint64_t)P.npart * 64 * split_bpp * 2 + 64;
       if (max2 > 0xFFFFFFF0ull) max2 = 0xFFFFFFF0ull;
       if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS2")) max2 = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS2")));   // tests: the second pool runs out first
@@ -407,6 +407,11 @@ int QueryBuild::layout_scratch() {
     }
     o_hpargs = sp.take(sizeof(VhHpArgs));
   }
+  r->by_position = (hpart && hp_fan) || (jk && jshape.part_ring != 0) || (P.nlevel == 2 && split_ring);
+  r->pos_capacity = ~0ull;
+  if (hpart && hp_fan) r->pos_capacity = std::min<uint64_t>(hpo[0].maxa, hpo[0].maxb) * (uint64_t)(HP_ET / hp_units);
+  if (jk && jshape.part_ring != 0) r->pos_capacity = std::min<uint64_t>(r->pos_capacity, (uint64_t)P.max_extents * (uint64_t)P.ext_tuples);
+  if (P.nlevel == 2 && split_ring) r->pos_capacity = std::min<uint64_t>(r->pos_capacity, (uint64_t)P.max_extents2 * (uint64_t)P.ext_tuples2);
   size_t o_fbs[VH_MAX_BITSET] = {};
   for (size_t k = 0; k < r->filter_bitset_cols.size(); ++k) o_fbs[k] = sp.take(std::max<uint32_t>(nseg, 1) * 8);
   size_t o_bsptr[VH_MAX_BITSET][2] = {}, o_dkeys[VH_MAX_BITSET] = {}, o_dtags[VH_MAX_BITSET] = {};
