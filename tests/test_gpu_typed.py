@@ -295,6 +295,36 @@ def test_two_level_partitioning():
         dt.close()
 
 
+def test_few_partitions_every_row_passing_through_the_ring_writer():
+    """Three LDS-sized ranges and no filter: every drain of 64 survivors puts ~21 tuples into each of three partitions — more than the two waiting lines
+    per partition hold — so lanes of one call take their ring places in rounds, a line's owner flushes while later lanes of the same call still wait,
+    and four waves of a block do so at once (vh_ring_add_tb's `gen` / `done` counters at their busiest). One-word and two-word tuples, compiled kernel;
+    the per-wave writer on the same plan for comparison of nothing but the answers."""
+    import os
+    from viyadb_amd import capi
+    rng = np.random.default_rng(77)
+    n = 500_000
+    tab = vo.Table({"name": "t", "segment_size": n, "dimensions": [{"name": "a", "type": "uint"}, {"name": "b", "type": "uint"}],
+                    "metrics": [{"name": "v", "type": "long_sum"}, {"name": "count", "type": "count"}]})
+    for _ in range(2):
+        tab.add_segment_arrays([rng.integers(0, 150, n).astype(np.uint32), rng.integers(0, 150, n).astype(np.uint32)],
+                               [rng.integers(0, 1000, n).astype(np.int64), np.ones(n, dtype=np.uint32)], None, n)
+    dt = mirror_table(tab)
+    q = {"dimensions": ["a", "b"], "metrics": ["v", "count"]}
+    try:
+        for flags in (capi.PLAN_FORCE_PART | capi.PLAN_FORCE_JIT | capi.PLAN_NO_LANES, capi.PLAN_FORCE_PART | capi.PLAN_FORCE_JIT | capi.PLAN_NO_LANES | capi.PLAN_NO_NARROW_TUPLES):
+            res, st = run(tab, dt, q, flags=flags)
+            assert res.path == "dense_part" and res.jit and res.retries == 0 and res.ngroups == st.ngroups == 22500, (res.path, res.kernel, res.retries, res.ngroups)
+            os.environ["VH_NO_PART_RING"] = "1"
+            try:
+                res, _ = run(tab, dt, q, flags=flags)
+            finally:
+                del os.environ["VH_NO_PART_RING"]
+            assert res.path == "dense_part" and res.retries == 0
+    finally:
+        dt.close()
+
+
 def test_two_level_on_typed_shapes(typed):
     """The typed table's group spaces are small; with 1 KB LDS tables (VH_PART_TABLE_KB) they still split into hundreds of ranges,
     so every state type (float / double SUM, MIN / MAX of every width, AVG, narrow sums) goes through both partition levels."""
