@@ -8,6 +8,12 @@
 // group key until one partition's groups fit LDS, then aggregate there with LDS atomics only. Sequential traffic of 16 bytes per
 // tuple and level instead of a 128-byte line read and written per update.
 //
+// TWO FORMS of the passes between the scan and the aggregation. A query's first attempt (round 5): the scan block writes level A ITSELF and
+// level B is one barrier-free pass (hp_ring_scatter_kernel), both through the ring writer of vh_kernels.h (vh_ring_add: per digit a tuple counter
+// and two waiting 128-byte lines in LDS, a tuple's number says where it goes, extents by POSITION, whole lines) — tuples are written twice and
+// read twice. A re-run after VH_ERR_PART_FULL (a hot key overflowed a (block, digit)'s positions; the table remembers the shape) takes the older
+// form described below — a stream pool and two tiled scatter levels whose extents are handed out as they fill: written three times, read three times.
+//
 //   scan kernel (compiled per plan, vh_jit_body.h): a survivor becomes a TUPLE. Without a bitset metric: 16 bytes, (mixed key, payload
 //     word) — the mixed key is a bijection of the packed 64-bit group key (vh_splitmix64 / vh_unmix64), so equal keys always travel
 //     together and no key is ever compared through a lossy hash. With one: 32 bytes, (mixed key, payload, two ids, how many of them

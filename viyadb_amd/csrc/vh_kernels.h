@@ -768,7 +768,8 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
 // read-modify-writes per second whatever the table size (profiles/r01/NOTES.md, "The atomic roofline"). For group-id
 // spaces that do not fit one CU's LDS the survivors are therefore NOT aggregated with global atomics: each becomes a
 // (gid, values) tuple appended to its partition's current extent in HBM; part_agg_kernel then aggregates every
-// partition with LDS atomics only. Two writers:
+// partition with LDS atomics only. The compiled kernels' first attempt writes through the block's ring writer (vh_ring_add_tb below:
+// extents by position); re-runs and the pre-built kernels use the two older writers:
 //  - the compaction kernels hand the 64 survivors of one drain to vh_part_direct_add: a ballot per partition-id bit
 //    gives every lane its rank inside its partition, the partition's cursor is fetched from the lane that owns it
 //    (ds_bpermute) and each lane stores its tuple with one 16-byte store — no LDS tile, no second pass;
