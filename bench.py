@@ -179,6 +179,52 @@ def _cpu_model():
     return "unknown"
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` from a plain shell (no WORLD_SIZE / RANK in the environment): re-execute this very command line as
+    N ranks of one node under torch.distributed.run — what the contract's launcher line does — on a free port of 127.0.0.1. Rank 0's JSON
+    line is the only thing the ranks write to stdout; it passes through, the ranks' stderr too. Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on these hosts: RCCL's peer mappings need it
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: launching %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rendezvous_only(rank: int, world: int, local_rank: int):
+    """The launcher's own check (tests/test_bench_launch.py, no GPU needed): the ranks meet over gloo and rank 0 says who came."""
+    import socket
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    who = [None] * world
+    dist.all_gather_object(who, {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "host": socket.gethostname()})
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launched": True, "n_ranks": world, "ranks": who}), flush=True)
+    dist.destroy_process_group()
+
+
+def comm_report(comm, dist, world: int, backend: str):
+    """The "rccl" object of the output line: what every rank's communicator says it is (vh_comm_info, read back from RCCL itself, gathered
+    over the control plane) — rank count, devices, transport — so that a line measured over a fallback transport cannot pass for RCCL."""
+    mine = comm.info()
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    transports = sorted({e["transport"] for e in everyone})
+    ok = transports == ["rccl"] and all(e["nranks"] == world for e in everyone) and len({e["pci_bus_id"] for e in everyone}) == world
+    return {"nranks": everyone[0]["nranks"], "ranks_agree": all(e["nranks"] == everyone[0]["nranks"] for e in everyone),
+            "devices": ["%s (hip:%d)" % (e["pci_bus_id"], e["device"]) for e in everyone],
+            "distinct_devices": len({e["pci_bus_id"] for e in everyone}),
+            "transport": "rccl" if transports == ["rccl"] else "gloo-fallback", "detail": backend}, not ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,15 +243,20 @@ def main():
     ap.add_argument("--no-predpack", action="store_true", help="ablation: narrow copies of the predicate columns (round 4's layout) instead of the bit-packed predicate projection")
     ap.add_argument("--no-warm", action="store_true", help="no vh_table_prepare: the first queries pay the first-use costs, the tuple pool lies where hipMalloc puts it")
     ap.add_argument("--no-reference-layout", action="store_true", help="skip the arena-only leg (profiling runs)")
+    ap.add_argument("--rendezvous-only", action="store_true", help="launch the ranks, meet over gloo, print who came, stop (the launcher's own test: needs no GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))       # a plain `python bench.py --gpus N`: become N ranks under torch.distributed.run
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: the two must agree (a plain `python bench.py --gpus N` launches its own ranks)" % (args.gpus, world))
+    if args.rendezvous_only:
+        return rendezvous_only(rank, world, local_rank)
     # One rank per GPU. torch.distributed (gloo) is the CONTROL plane only: rendezvous, the RCCL unique id, barriers and the
     # max-over-ranks of the timing. The data plane — plan agreement, verdict all-reduce, ncclReduce of the partial tables — is
     # the library's own RCCL communicator behind vh_query_agg_sharded. VH_BENCH_BACKEND=gloo swaps that transport for
@@ -239,6 +290,7 @@ def main():
                 backend = "gloo (RCCL communicator failed: %s)" % next(e for e in errs if e)
         else:
             comm = distributed.Comm.gloo(dist)
+    rccl_info, degraded = (None, False) if world == 1 else comm_report(comm, dist, world, backend)
 
     w = synth.WORKLOADS[args.workload](segment_rows=args.segment_rows)
     total_segments = args.segments or {"C1": 10, "C2": 100, "C3": 1000, "C5t": 100, "C5": 100}[args.workload]
@@ -355,6 +407,8 @@ def main():
             "value": value, "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong",
+            "degraded": bool(degraded),       # true = N > 1 but the data plane was NOT RCCL over distinct GPUs (see "rccl")
+            "rccl": rccl_info,
             "parity_checked": bool(checked), "parity": checked,
             "vs_baseline": None, "dtype": "u32 predicates (compared as bit fields of a packed word / u8 / u16 where such a copy exists) / int64 + u32 integer sums", "data": "synthetic",
             "config": {"workload": "%s: %s" % (w.name if world == 1 else w.name + " sharded (C4)", w.description),

@@ -521,6 +521,18 @@ VH_API int vh_comm_unique_id(void* id_out /* VH_COMM_ID_BYTES */);
 VH_API int vh_comm_init(const void* id, int32_t rank, int32_t world, vh_comm** out);
 VH_API int vh_comm_init_custom(const vh_comm_ops* ops, int32_t rank, int32_t world, vh_comm** out);
 VH_API void vh_comm_destroy(vh_comm* c);
+/* What the communicator actually is, read back from it (not from what the caller asked for): the rank count and this rank as
+ * the transport reports them (RCCL: ncclCommCount / ncclCommUserRank), the HIP device the communicator is bound to
+ * (ncclCommCuDevice; the current device for a callback transport) and that device's PCI bus id — so a launcher can print
+ * which GPUs a scaling run used and whether its data plane was RCCL or a fallback. */
+enum vh_comm_transport { VH_COMM_RCCL = 1, VH_COMM_CALLBACKS = 2 };
+typedef struct vh_comm_info_t {
+  int32_t transport;      /* enum vh_comm_transport */
+  int32_t nranks, rank;   /* as the transport reports them */
+  int32_t device;         /* HIP device ordinal inside this process */
+  char pci_bus_id[32];    /* "0000:c1:00.0" */
+} vh_comm_info_t;
+VH_API int vh_comm_info(vh_comm* c, vh_comm_info_t* out);
 VH_API int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* comm, int32_t root, vh_result** out);
 
 /* ---- the other two FilterBasedQuery kinds on the same scan ------------

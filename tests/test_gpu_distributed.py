@@ -325,3 +325,50 @@ def test_cxx_database_queries_all_ranks_rows(tmp_path):
             assert got[0][k]["stats"]["aggregated_recs"] == st["aggregated_recs"]
     finally:
         db.close()
+
+
+def test_bench_from_a_plain_shell_two_ranks_one_gpu():
+    """`python bench.py --gpus 2 …` with nothing in the environment: the launcher re-executes itself under
+    torch.distributed.run; with one GPU here the two ranks share it over the callback transport, and the line must SAY so —
+    "rccl".transport = "gloo-fallback", "degraded" true — with the parity gate run on both shards."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VH_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--segments", "4", "--segment-rows", "20000",
+                        "--steps", "3", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["parity_checked"] and d["config"]["rows"] == 80000
+    assert d["rccl"]["nranks"] == 2 and d["rccl"]["transport"] == "gloo-fallback" and d["degraded"] is True
+    assert len(d["rccl"]["devices"]) == 2 and d["rccl"]["distinct_devices"] == 1
+
+
+def test_comm_info_reads_the_rccl_communicator_back(tmp_path):
+    """vh_comm_info on a real RCCL communicator (world 1): transport, rank count and device come from RCCL itself."""
+    script = tmp_path / "w.py"
+    script.write_text(textwrap.dedent('''
+        import os, sys, json
+        sys.path.insert(0, %r)
+        import torch, torch.distributed as dist
+        from viyadb_amd import distributed, executor
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo")
+        executor.init(0)
+        c = distributed.Comm.rccl(dist)
+        i = c.info()
+        assert i["transport"] == "rccl" and i["nranks"] == 1 and i["rank"] == 0 and i["device"] == 0 and ":" in i["pci_bus_id"], i
+        g = distributed.Comm.gloo(dist)
+        j = g.info()
+        assert j["transport"] == "callbacks" and j["nranks"] == 1 and j["pci_bus_id"] == i["pci_bus_id"], j
+        g.close(); c.close()
+        dist.destroy_process_group()
+    ''' % ROOT))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])

@@ -99,6 +99,14 @@ class DeviceBuffer(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("count", C.c_uint64), ("elem", C.c_int32), ("reduce", C.c_int32)]
 
 
+class CommInfo(C.Structure):
+    """vh_comm_info_t: the communicator as the transport itself reports it."""
+    _fields_ = [("transport", C.c_int32), ("nranks", C.c_int32), ("rank", C.c_int32), ("device", C.c_int32), ("pci_bus_id", C.c_char * 32)]
+
+
+COMM_RCCL, COMM_CALLBACKS = 1, 2
+
+
 class SyncItem(C.Structure):
     """vh_sync_item: one contiguous row range of one segment (vh_table_sync_batch)."""
     _fields_ = [("seg", C.c_uint32), ("flags", C.c_uint32), ("row_first", C.c_uint64), ("nrows", C.c_uint64),
@@ -169,6 +177,7 @@ SYMBOLS = {
     "vh_comm_init": (C.c_int, [_VP, C.c_int32, C.c_int32, C.POINTER(_VP)]),
     "vh_comm_init_custom": (C.c_int, [C.POINTER(CommOps), C.c_int32, C.c_int32, C.POINTER(_VP)]),
     "vh_comm_destroy": (None, [_VP]),
+    "vh_comm_info": (C.c_int, [_VP, C.POINTER(CommInfo)]),
     "vh_query_agg_sharded": (C.c_int, [_VP, C.POINTER(Plan), _VP, C.c_int32, C.POINTER(_VP)]),
     "vh_query_select": (C.c_int, [_VP, C.POINTER(SelectPlan), C.POINTER(_VP)]),
     "vh_rows_get_info": (C.c_int, [_VP, C.POINTER(RowsInfo)]),

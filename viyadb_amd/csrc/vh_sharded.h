@@ -17,6 +17,9 @@ struct VhRccl {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -42,6 +45,7 @@ static int rccl_load() {
   VH_NCCL_SYM(AllGather, "ncclAllGather"); VH_NCCL_SYM(AllReduce, "ncclAllReduce"); VH_NCCL_SYM(Reduce, "ncclReduce");
   VH_NCCL_SYM(Send, "ncclSend"); VH_NCCL_SYM(Recv, "ncclRecv"); VH_NCCL_SYM(GroupStart, "ncclGroupStart"); VH_NCCL_SYM(GroupEnd, "ncclGroupEnd");
   VH_NCCL_SYM(GetErrorString, "ncclGetErrorString");
+  VH_NCCL_SYM(CommCount, "ncclCommCount"); VH_NCCL_SYM(CommCuDevice, "ncclCommCuDevice"); VH_NCCL_SYM(CommUserRank, "ncclCommUserRank");
 #undef VH_NCCL_SYM
   g_rccl.handle = h;
   return VH_OK;
@@ -224,6 +228,28 @@ extern "C" int vh_comm_init_custom(const vh_comm_ops* ops, int32_t rank, int32_t
   c->rank = rank; c->world = world; c->ops = *ops;
   if (int rc = comm_common_init(c.get())) { vh_comm_destroy(c.release()); return rc; }
   *out = c.release();
+  return VH_OK;
+}
+
+extern "C" int vh_comm_info(vh_comm* c, vh_comm_info_t* out) {
+  if (!c || !out) return vh_fail(VH_E_INVALID, "null argument");
+  VH_ENTER();
+  memset(out, 0, sizeof(*out));
+  int dev = 0;
+  if (c->nccl) {
+    out->transport = VH_COMM_RCCL;
+    int n = 0, r = 0;
+    NCCL_TRY(g_rccl.CommCount(c->nccl, &n));
+    NCCL_TRY(g_rccl.CommUserRank(c->nccl, &r));
+    NCCL_TRY(g_rccl.CommCuDevice(c->nccl, &dev));
+    out->nranks = n; out->rank = r;
+  } else {
+    out->transport = VH_COMM_CALLBACKS;
+    out->nranks = c->world; out->rank = c->rank;
+    HIP_TRY(hipGetDevice(&dev));
+  }
+  out->device = dev;
+  HIP_TRY(hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof(out->pci_bus_id), dev));
   return VH_OK;
 }
 

@@ -200,6 +200,13 @@ class Comm:
         capi.check(lib.vh_comm_init_custom(C.byref(tr.ops), tr.rank, tr.world, C.byref(h)))
         return cls(h, tr.rank, tr.world, tr)
 
+    def info(self) -> dict:
+        """The communicator as the transport reports it (vh_comm_info): rank count, this rank, device, PCI bus id."""
+        ci = capi.CommInfo()
+        capi.check(capi.load().vh_comm_info(self.handle, C.byref(ci)))
+        return {"transport": "rccl" if ci.transport == capi.COMM_RCCL else "callbacks", "nranks": int(ci.nranks), "rank": int(ci.rank),
+                "device": int(ci.device), "pci_bus_id": ci.pci_bus_id.decode("ascii", "replace")}
+
     def close(self):
         if self.handle:
             capi.load().vh_comm_destroy(self.handle)
