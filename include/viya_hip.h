@@ -283,10 +283,16 @@ typedef struct vh_device_buffer {
 enum vh_gen_mode {
   VH_GEN_UNIFORM = 0, /* add + (h % mod)   (floating columns: * scale)       */
   VH_GEN_ROWID = 1,   /* global row index r                                  */
-  VH_GEN_CONST = 2    /* add                                                 */
+  VH_GEN_CONST = 2,   /* add                                                 */
+  /* skewed shapes (tools/skew_probe.py; integer arithmetic only, so the oracle's numpy twin is exact):                      */
+  VH_GEN_ZIPF = 3,    /* add + v % mod, v = 2^b - 1 + (lo32(h) % 2^b), b = hi32(h) % (floor(log2 mod) + 1): P(v) ~ 1 / (v + 1) in
+                       * octaves, the continuous cousin of Zipf(s = 1) — value 0 alone takes 1 / (floor(log2 mod) + 1) of the rows */
+  VH_GEN_SORTED = 4,  /* add + r / mod: non-decreasing in load order, `mod` rows per value (a time-ordered load)                 */
+  VH_GEN_HOT = 5      /* add + mod / 2 on the rows where splitmix64(seed ^ r ^ 0x407) % 1000 < param (the SAME rows in every
+                       * VH_GEN_HOT column of a table: a hot composite key), add + h % mod elsewhere                             */
 };
 typedef struct vh_gen_spec {
-  int32_t mode; int32_t reserved; uint64_t mod; int64_t add; double scale;
+  int32_t mode; int32_t param; /* VH_GEN_HOT: per mille of hot rows */ uint64_t mod; int64_t add; double scale;
 } vh_gen_spec;
 
 /* ---- entry points ----------------------------------------------------------*/

@@ -17,8 +17,17 @@ to the GPU number is the reference's algorithm compiled the reference's way:
 What differs from the reference's generated text: segments arrive as raw column pointers
 instead of a generated `Segment` class (the reference cannot be built here),
 segment-skip flags are computed by the caller (viya_oracle.segment_skip), and the result is
-copied out of the map into caller arrays instead of being stringified.  Bitset metrics are
-not emitted (CRoaring is absent); viya_oracle covers them.
+copied out of the map into caller arrays instead of being stringified.
+
+Bitset metrics (util::Bitset<N>, src/util/bitset.h:26-67): the reference keeps one CRoaring bitmap PER STORED ROW
+(store.cc:255-259), copies the row's bitmap into agg_tuple.m (scan.cc:228-238) and ORs it into the group's (`|=`,
+store.cc:131-161); the output is cardinality().  CRoaring is absent here (empty submodule), so Roaring is REPLACED BY an
+append-only std::vector<id> per group that is sorted and made unique whenever it has doubled since its last compaction
+(amortised O(n log n)) and once more for cardinality(); a row's set arrives as a CSR slice (offsets + ids) instead of a
+bitmap object.  The observable — a set cardinality — is implementation-independent; the COST is not: for
+the few-ids-per-row sets of C5 a vector append does less work than Roaring's container lookup, array-container insert and
+per-row bitmap copy, so this baseline errs on the FAST side of the reference.  A predicate on a bitset metric compares the
+row's cardinality (filter.cc:206-261).
 """
 from __future__ import annotations
 
@@ -68,6 +77,43 @@ struct Time64 {
 """
 
 
+_IDSET = r"""
+template <typename T> struct IdSet {            // util::Bitset<N> with Roaring replaced by a lazily compacted vector (module docstring)
+  std::vector<T> v; size_t limit = 16;
+  const T* rp = nullptr; uint32_t rn = 0;       // as a ROW's value: the CSR slice that holds the row's ids
+  void compact() { std::sort(v.begin(), v.end()); v.erase(std::unique(v.begin(), v.end()), v.end()); }
+  IdSet& operator|=(const IdSet& o) {           // group |= row
+    v.insert(v.end(), o.rp, o.rp + o.rn);
+    if (v.size() >= limit) { compact(); limit = std::max<size_t>(16, 2 * v.size()); }
+    return *this;
+  }
+  uint64_t cardinality() { compact(); return v.size(); }
+};
+template <typename T> static inline uint64_t row_cardinality(const T* p, uint64_t n) {   // distinct ids of one row (a handful)
+  uint64_t c = 0;
+  for (uint64_t i = 0; i < n; ++i) { bool seen = false; for (uint64_t j = 0; j < i; ++j) seen |= p[j] == p[i]; c += !seen; }
+  return c;
+}
+"""
+
+
+class CsrSets:
+    """A bitset column of one segment as CSR — what the twin reads (and what the device mirror holds): ids of row i are
+    values[offsets[i]:offsets[i + 1]]. viya_oracle keeps Python sets per row; segments built for the twin alone
+    (tests.parity.build_oracle_table(..., csr=True)) carry this instead, without a million set objects per segment."""
+
+    def __init__(self, offsets: np.ndarray, values: np.ndarray):
+        self.offsets, self.values = np.ascontiguousarray(offsets, dtype=np.uint64), np.ascontiguousarray(values)
+
+    @classmethod
+    def from_sets(cls, sets, size: int, dtype):
+        lens = np.fromiter((len(x) for x in sets[:size]), dtype=np.uint64, count=size)
+        off = np.zeros(size + 1, dtype=np.uint64)
+        np.cumsum(lens, out=off[1:])
+        vals = np.fromiter((v for x in sets[:size] for v in sorted(x)), dtype=dtype, count=int(off[-1]))
+        return cls(off, vals)
+
+
 def _cmp_expr(table, f, args: list, getter) -> str:
     """ComparisonBuilder text; appends decoded literals to `args` in unpack order."""
     if isinstance(f, vo.Empty):
@@ -90,15 +136,14 @@ def _cmp_expr(table, f, args: list, getter) -> str:
 def emit_source(table: vo.Table, aq: vo.AggQuery) -> (str, list):
     dims = [oc.col for oc in aq.dim_cols]
     mets = [oc.col for oc in aq.metric_cols]
-    if any(m.agg == "bitset" for m in mets):
-        raise vo.Unsupported("cpu twin: bitset metrics")
     has_avg = any(m.agg == "avg" for m in mets)
     has_count = any(m.agg == "count" for m in mets)
     hidden = has_avg and not has_count
     s = []
     s.append("#include <unordered_map>\n#include <cstdint>\n#include <cstddef>\n#include <cfloat>\n#include <ctime>\n"
-             "#include <algorithm>\n#include <chrono>\n#include <functional>\n")
+             "#include <algorithm>\n#include <chrono>\n#include <functional>\n#include <vector>\n")
     s.append(_TIME_CLASSES)
+    s.append(_IDSET)
     s.append("struct AggTuple {\n struct Dimensions {\n")
     for d in dims:
         s.append("  %s _%d;\n" % (_CPP[d.num_type.name], d.index))
@@ -110,13 +155,18 @@ def emit_source(table: vo.Table, aq: vo.AggQuery) -> (str, list):
         s.append("    h ^= %s + 0x9e3779b9 + (h<<6) + (h>>2);\n" % v)
     s.append("    return h; } };\n };\n struct Metrics {\n")
     for m in mets:
+        if m.agg == "bitset":
+            s.append("  IdSet<%s> _%d;\n" % (_CPP[m.num_type.name], m.index))
+            continue
         init = _CPP_MIN[m.num_type.name] if m.agg == "max" else _CPP_MAX[m.num_type.name] if m.agg == "min" else "0"
         s.append("  %s _%d = %s;\n" % (_CPP[m.num_type.name], m.index, init))
     if hidden:
         s.append("  uint64_t _count=0;\n")
     s.append("  void Update(const Metrics &metrics) {\n")
     for m in mets:
-        if m.agg in ("sum", "avg", "count"):
+        if m.agg == "bitset":
+            s.append("   _%d |= metrics._%d;\n" % (m.index, m.index))
+        elif m.agg in ("sum", "avg", "count"):
             s.append("   _%d += metrics._%d;\n" % (m.index, m.index))
         elif m.agg == "max":
             s.append("   _%d = std::max(_%d, metrics._%d);\n" % (m.index, m.index, m.index))
@@ -128,11 +178,17 @@ def emit_source(table: vo.Table, aq: vo.AggQuery) -> (str, list):
     s.append("typedef std::unordered_map<AggTuple::Dimensions,AggTuple::Metrics,AggTuple::Dimensions::Hash,"
              "AggTuple::Dimensions::KeyEqual> AggMap;\nstatic AggMap* g_map = nullptr;\n")
     s.append('extern "C" int64_t twin_run(const void* const* const* seg_d, const void* const* const* seg_m, '
-             "const uint64_t* const* seg_cnt, const uint64_t* seg_size, const uint8_t* seg_process, uint64_t nseg, "
+             "const uint64_t* const* seg_cnt, const uint64_t* const* const* seg_off, const uint64_t* seg_size, const uint8_t* seg_process, uint64_t nseg, "
              "const uint64_t* fargs, const uint64_t* rollup_b, double* seconds) {\n")
     s.append(" auto t0 = std::chrono::steady_clock::now();\n delete g_map; g_map = new AggMap();\n AggMap& agg_map = *g_map;\n AggTuple agg_tuple;\n")
     args: list = []
-    getter = lambda c: ("tuple_dims_%d[tuple_idx]" if c.is_dim else "tuple_metrics_%d[tuple_idx]") % c.index
+    def getter(c):
+        if c.is_dim:
+            return "tuple_dims_%d[tuple_idx]" % c.index
+        if c.agg == "bitset":      # the predicate sees .cardinality() of the row's set
+            return "((%s)row_cardinality(tuple_metrics_%d + tuple_off_%d[tuple_idx], tuple_off_%d[tuple_idx + 1] - tuple_off_%d[tuple_idx]))" % (
+                _CPP[c.num_type.name], c.index, c.index, c.index, c.index)
+        return "tuple_metrics_%d[tuple_idx]" % c.index
     cmp = _cmp_expr(table, aq.filter, args, getter)
     for i, (col, _) in enumerate(args):
         t = _CPP[col.num_type.name]
@@ -157,6 +213,8 @@ def emit_source(table: vo.Table, aq: vo.AggQuery) -> (str, list):
     for m in table.metrics:
         if m.index in usedm:
             s.append("  const %s* __restrict__ tuple_metrics_%d = (const %s*)seg_m[s][%d];\n" % (_CPP[m.num_type.name], m.index, _CPP[m.num_type.name], m.index))
+            if m.agg == "bitset":
+                s.append("  const uint64_t* __restrict__ tuple_off_%d = seg_off[s][%d];\n" % (m.index, m.index))
     if hidden:
         s.append("  const uint64_t* __restrict__ tuple_count = seg_cnt[s];\n")
     s.append("  for (size_t tuple_idx = 0; tuple_idx < segment_size; ++tuple_idx) {\n   auto r = %s;\n   if (r) {\n" % cmp)
@@ -173,6 +231,10 @@ def emit_source(table: vo.Table, aq: vo.AggQuery) -> (str, list):
         else:
             s.append("    agg_tuple.d._%d = tuple_dims_%d[tuple_idx];\n" % (d.index, d.index))
     for m in mets:
+        if m.agg == "bitset":
+            s.append("    agg_tuple.m._%d.rp = tuple_metrics_%d + tuple_off_%d[tuple_idx]; agg_tuple.m._%d.rn = (uint32_t)(tuple_off_%d[tuple_idx + 1] - tuple_off_%d[tuple_idx]);\n"
+                     % (m.index, m.index, m.index, m.index, m.index, m.index))
+            continue
         s.append("    agg_tuple.m._%d = tuple_metrics_%d[tuple_idx];\n" % (m.index, m.index))
     if hidden:
         s.append("    agg_tuple.m._count = tuple_count[tuple_idx];\n")
@@ -182,6 +244,9 @@ def emit_source(table: vo.Table, aq: vo.AggQuery) -> (str, list):
     for k, d in enumerate(dims):
         s.append("  ((%s*)keys[%d])[i] = kv.first._%d;\n" % (_CPP[d.num_type.name], k, d.index))
     for k, m in enumerate(mets):
+        if m.agg == "bitset":
+            s.append("  ((uint64_t*)states[%d])[i] = kv.second._%d.cardinality();\n" % (k, m.index))
+            continue
         s.append("  ((%s*)states[%d])[i] = kv.second._%d;\n" % (_CPP[m.num_type.name], k, m.index))
     if hidden:
         s.append("  hidden[i] = kv.second._count;\n")
@@ -220,6 +285,21 @@ class Twin:
         self.lib.twin_run.restype = C.c_int64
         self.hidden = any(oc.col.agg == "avg" for oc in self.aq.metric_cols) and not any(oc.col.agg == "count" for oc in self.aq.metric_cols)
 
+    def _csr(self, i: int, seg: dict) -> dict:
+        """metric index -> CsrSets for the bitset columns the query touches (built from the oracle's per-row sets unless the segment
+        already carries CSR)."""
+        if not hasattr(self, "_csr_cache"):
+            self._csr_cache = {}
+        if i not in self._csr_cache:
+            out = {}
+            for m in self.table.metrics:
+                if m.agg != "bitset":
+                    continue
+                col = seg["m"][m.index]
+                out[m.index] = col if isinstance(col, CsrSets) else CsrSets.from_sets(col, seg["size"], m.num_type.dtype)
+            self._csr_cache[i] = out
+        return self._csr_cache[i]
+
     def run(self, now: Optional[int] = None, seg_rows: Optional[List[int]] = None) -> vo.AggState:
         t = self.table
         nseg = len(t.segments)
@@ -228,6 +308,7 @@ class Twin:
         seg_d = (C.POINTER(VP) * max(nseg, 1))()
         seg_m = (C.POINTER(VP) * max(nseg, 1))()
         seg_c = (C.POINTER(C.c_uint64) * max(nseg, 1))()
+        seg_o = (C.POINTER(C.POINTER(C.c_uint64)) * max(nseg, 1))()
         sizes = (C.c_uint64 * max(nseg, 1))()
         proc = (C.c_uint8 * max(nseg, 1))()
         st = vo.AggState([], [], None)
@@ -238,10 +319,16 @@ class Twin:
             proc[i] = 1 if vo.segment_skip(t, self.aq.filter, seg) else 0
             st.scanned_segments += proc[i]
             da = (VP * max(len(t.dims), 1))(*[a.ctypes.data for a in seg["d"]])
-            ma = (VP * max(len(t.metrics), 1))(*[(a.ctypes.data if isinstance(a, np.ndarray) else None) for a in seg["m"]])
-            keep += [da, ma]
+            csr = self._csr(i, seg)                       # bitset columns as CSR (converted once per segment, kept)
+            ma = (VP * max(len(t.metrics), 1))(*[(a.ctypes.data if isinstance(a, np.ndarray) else csr[j].values.ctypes.data if j in csr else None)
+                                                 for j, a in enumerate(seg["m"])])
+            oa = (C.POINTER(C.c_uint64) * max(len(t.metrics), 1))()
+            for j, cs in csr.items():
+                oa[j] = cs.offsets.ctypes.data_as(C.POINTER(C.c_uint64))
+            keep += [da, ma, oa]
             seg_d[i] = da
             seg_m[i] = ma
+            seg_o[i] = oa
             if seg["count"] is not None:
                 seg_c[i] = seg["count"].ctypes.data_as(C.POINTER(C.c_uint64))
         fargs = (C.c_uint64 * max(len(self.args), 1))()
@@ -257,10 +344,10 @@ class Twin:
                 rb += vo.rollup_boundaries(d, now)
         rba = (C.c_uint64 * max(len(rb), 1))(*rb)
         secs = C.c_double()
-        n = self.lib.twin_run(seg_d, seg_m, seg_c, sizes, proc, C.c_uint64(nseg), fargs, rba, C.byref(secs))
+        n = self.lib.twin_run(seg_d, seg_m, seg_c, seg_o, sizes, proc, C.c_uint64(nseg), fargs, rba, C.byref(secs))
         self.last_seconds = secs.value
         keys = [np.empty(n, dtype=oc.col.num_type.dtype) for oc in self.aq.dim_cols]
-        states = [np.empty(n, dtype=oc.col.num_type.dtype) for oc in self.aq.metric_cols]
+        states = [np.empty(n, dtype=np.uint64 if oc.col.agg == "bitset" else oc.col.num_type.dtype) for oc in self.aq.metric_cols]
         hidden = np.empty(n, dtype=np.uint64) if self.hidden else None
         kp = (VP * max(len(keys), 1))(*[k.ctypes.data for k in keys])
         sp = (VP * max(len(states), 1))(*[s.ctypes.data for s in states])

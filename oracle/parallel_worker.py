@@ -20,16 +20,17 @@ def main():
     from tests.parity import build_oracle_table
     from viyadb_amd import synth
     w = synth.WORKLOADS[name]()
-    ot = build_oracle_table(w, nseg, w.segment_rows, row_base=first * w.segment_rows)
+    ot = build_oracle_table(w, nseg, w.segment_rows, row_base=first * w.segment_rows, csr=True)
     tw = cpu_twin.Twin(ot, w.query)
-    tw.run()
+    now = getattr(w, "now", None)
+    tw.run(now=now)
     missed = max(0.0, time.time() - start)          # ready after the window opened: this worker's share of it is short
     while time.time() < start:
         time.sleep(0.001)
     rows = 0
     busy = 0.0
     while time.time() < start + seconds:
-        tw.run()
+        tw.run(now=now)
         rows += nseg * w.segment_rows
         busy += tw.last_seconds
     print(json.dumps({"rows": rows, "busy": busy, "late": max(0.0, time.time() - (start + seconds)), "missed": missed}))

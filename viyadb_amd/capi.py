@@ -36,7 +36,7 @@ PLAN_NO_PREDPACK, PLAN_NO_QPAY, PLAN_FORCE_QPAY, PLAN_NO_SLICED = 1 << 24, 1 << 
 PATH_SCALAR, PATH_DENSE_LDS, PATH_DENSE_GLOBAL, PATH_HASH, PATH_DENSE_PART = range(5)
 PATH_NAMES = ["scalar", "dense_lds", "dense_global", "hash", "dense_part"]
 # generator
-GEN_UNIFORM, GEN_ROWID, GEN_CONST = range(3)
+GEN_UNIFORM, GEN_ROWID, GEN_CONST, GEN_ZIPF, GEN_SORTED, GEN_HOT = range(6)
 
 
 class ColDesc(C.Structure):
@@ -117,7 +117,7 @@ SYNC_METRICS_ONLY, SYNC_DEVICE_SRC = 1, 2
 
 
 class GenSpec(C.Structure):
-    _fields_ = [("mode", C.c_int32), ("reserved", C.c_int32), ("mod", C.c_uint64), ("add", C.c_int64),
+    _fields_ = [("mode", C.c_int32), ("param", C.c_int32), ("mod", C.c_uint64), ("add", C.c_int64),
                 ("scale", C.c_double)]
 
 

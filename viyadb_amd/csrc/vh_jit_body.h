@@ -44,7 +44,11 @@ template <typename T> __device__ __forceinline__ T vj_gload(const T* p) {
 template <class J, int I>
 __device__ __forceinline__ uint64_t vj_time_rollup(uint64_t ts, const VhGroupDev& g) {
   constexpr bool micro = J::g_micro[I] != 0;
-  if constexpr (!micro) {      // a `time` column: 32-bit seconds, truncated in 32-bit arithmetic (vh_time.h: a MONTH is ~60 instructions, not ~250)
+  // a `time` column proper: 32-bit seconds (src/db/column.cc:328-333), truncated in 32-bit arithmetic (vh_time.h: a MONTH is ~60 instructions, not
+  // ~250). The C ABI also allows a non-micro time group column of 8 bytes (VH_U64 seconds): that one takes the 64-bit form, like the pre-built
+  // kernels' vh_trunc_secs, so the two paths agree above 2^32
+  constexpr bool secs32 = !micro && (J::g_type[I] == VH_U32 || J::g_type[I] == VH_I32);
+  if constexpr (secs32) {
     uint32_t secs = (uint32_t)ts;
     bool done = false;         // the FIRST rule whose boundary lies beyond ts truncates (rollup.cc:77-95)
 #pragma unroll
@@ -54,15 +58,15 @@ __device__ __forceinline__ uint64_t vj_time_rollup(uint64_t ts, const VhGroupDev
     if (J::g_gran[I] != VH_T_NONE) secs = vh_trunc_secs32(secs, J::g_gran[I]);
     return (uint64_t)secs;
   } else {
-    uint64_t secs = ts / 1000000ull;
-    uint64_t micros = ts % 1000000ull;
+    uint64_t secs = micro ? ts / 1000000ull : ts;
+    uint64_t micros = micro ? ts % 1000000ull : 0ull;
     bool done = false;
 #pragma unroll
     for (int k = 0; k < J::g_nroll[I]; ++k) {
       if (!done && ts < g.roll_before[k]) { secs = vh_trunc_secs(secs, J::g_roll_unit[I][k]); micros = 0; done = true; }
     }
     if (J::g_gran[I] != VH_T_NONE) { secs = vh_trunc_secs(secs, J::g_gran[I]); micros = 0; }
-    return secs * 1000000ull + micros;
+    return micro ? secs * 1000000ull + micros : secs;
   }
 }
 
@@ -92,10 +96,12 @@ struct VjWave {
 // LDS behind the block's queues, and a (block, digit)'s k-th extent at k * (blocks * 256) + block * 256 + digit — by POSITION, no
 // allocation. The pool is the plan's second pool (tuples2, extent_missing2 = tuples in the extent, extent_part2 = digit).
 struct VjFanDest {
-  uint64_t per, first; uint32_t stride, max_ext;
-  __device__ __forceinline__ VjFanDest(const VhPlanDev& P) : per((uint64_t)gridDim.x * VH_RING_FAN), first((uint64_t)blockIdx.x * VH_RING_FAN), stride((uint32_t)P.ext_tuples2), max_ext(P.max_extents2) {}
+  uint64_t per, first; uint32_t stride, kmax;
+  // kmax: WHOLE levels of the pool only (level B reads max_extents2 / per levels, hp_ring_scatter_kernel): a trailing partial level — a pool
+  // size that is no multiple of blocks * 256, e.g. under the test override — is never written, so nothing written can go unread
+  __device__ __forceinline__ VjFanDest(const VhPlanDev& P) : per((uint64_t)gridDim.x * VH_RING_FAN), first((uint64_t)blockIdx.x * VH_RING_FAN), stride((uint32_t)P.ext_tuples2), kmax((uint32_t)((uint64_t)P.max_extents2 / ((uint64_t)gridDim.x * VH_RING_FAN))) {}
   // extent of the digit's k-th extent (~0: beyond the pool)
-  __device__ __forceinline__ uint64_t extent(uint32_t d, uint32_t k) const { const uint64_t e = (uint64_t)k * per + first + d; return e < (uint64_t)max_ext ? e : ~0ull; }
+  __device__ __forceinline__ uint64_t extent(uint32_t d, uint32_t k) const { return k < kmax ? (uint64_t)k * per + first + d : ~0ull; }
 };
 template <int U>
 __device__ __forceinline__ void vj_fan_add(const VhPlanDev& P, const VhRing& F, bool active, const uint64_t (&w)[2 * U], int lane) {

@@ -72,7 +72,10 @@ __host__ __device__ __forceinline__ uint64_t vh_time_rollup(uint64_t ts, const V
     secs = vh_trunc_secs(secs, g.gran());
     micros = 0;
   }
-  return g.micro() ? secs * 1000000ull + micros : (uint64_t)(uint32_t)secs;
+  // a `time` column is uint32 seconds (util::Time32: src/util/time.h:91-113); a non-micro time column of 8 bytes — allowed by the C ABI — keeps
+  // all its bits (the compiled kernels' vj_time_rollup makes the same distinction by the column's element type)
+  const bool wide = g.type() == VH_U64 || g.type() == VH_I64;
+  return g.micro() ? secs * 1000000ull + micros : wide ? secs : (uint64_t)(uint32_t)secs;
 }
 
 // -------------------------------------------------------------- column loads

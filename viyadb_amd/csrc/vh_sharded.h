@@ -66,6 +66,9 @@ struct vh_comm {
   char* d_stage = nullptr; size_t d_stage_bytes = 0; // RCCL transport: device staging of host all-gathers
   unsigned long long* d_flags = nullptr;             // verdict words, all-reduced (SUM) after every attempt
   unsigned long long* h_flags = nullptr;             // pinned copy
+  char* d_void = nullptr; size_t d_void_bytes = 0;   // stand-in state arrays of a rank whose attempt is void (fused_dense_step): as big as the largest recorded dense shape,
+                                                     // allocated before the verdict of the query that records the shape (a rank that cannot says so IN the verdict:
+                                                     // all ranks record, or none) — never inside a collective group
   std::mutex mu;                                     // one sharded query at a time per communicator (collectives must not interleave)
   // Agreements of earlier queries, by plan. Entries appear and disappear at collective points only, so every rank holds the
   // same set: a query whose plan is in the cache skips the all-gather of step 1 (a 128-byte verdict all-reduce is then the
@@ -192,6 +195,7 @@ extern "C" void vh_comm_destroy(vh_comm* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->nccl) (void)g_rccl.CommDestroy(c->nccl);
   if (c->d_stage) (void)hipFree(c->d_stage);
+  if (c->d_void) (void)hipFree(c->d_void);
   if (c->d_flags) (void)hipFree(c->d_flags);
   if (c->h_flags) (void)hipHostFree(c->h_flags);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -275,10 +279,11 @@ static void merge_summaries(const VhSummary* all, int world, int ngroups, VhAgre
 
 // verdict words (all-reduced with SUM): [0] range error, [1] hash table full, [2] tuple extents exhausted, [3] fatal,
 // [4] scanned_recs, [5] scanned_segments, [6] passed rows, [7] table organisation, [8] its square, [9] groups (hash path),
-// [10] this rank's table changed since the cached agreement was made
+// [10] this rank's table changed since the cached agreement was made, [11] / [12] hashed partitioning full / ids too wide,
+// [13] no stand-in arrays for a void attempt on this rank (see vh_comm::d_void)
 __global__ void sharded_flags_kernel(const unsigned long long* counters, unsigned long long* flags, unsigned long long host_err,
                                      unsigned long long fatal, unsigned long long scanned_recs, unsigned long long scanned_segments,
-                                     unsigned long long mode, unsigned long long ngroups, unsigned long long changed) {
+                                     unsigned long long mode, unsigned long long ngroups, unsigned long long changed, unsigned long long novoid = 0) {
   if (threadIdx.x != 0) return;
   const unsigned long long err = (counters ? counters[2] : 0ull) | host_err;
   flags[0] = (err & VH_ERR_RANGE) ? 1 : 0;
@@ -292,7 +297,8 @@ __global__ void sharded_flags_kernel(const unsigned long long* counters, unsigne
   flags[10] = changed;
   flags[11] = (err & VH_ERR_HPART_FULL) ? 1 : 0;
   flags[12] = (err & VH_ERR_HP_WIDE) ? 1 : 0;
-  for (int i = 13; i < VH_FLAG_WORDS; ++i) flags[i] = 0;
+  flags[13] = novoid;                              // this rank could not allocate the stand-in arrays of a void attempt: nobody records the dense shape
+  for (int i = 14; i < VH_FLAG_WORDS; ++i) flags[i] = 0;
 }
 
 // vh_query_agg with the rows kept in device memory (they are exchanged or gathered next). Same re-plan loop.
@@ -578,18 +584,22 @@ static int fused_dense_step(vh_table* t, vh_comm* comm, int root, VhExec* x, vh_
     for (int32_t b = 0; shape_ok && b < nb; ++b)
       shape_ok = bufs[b].count == agr.dense[b].count && bufs[b].elem == agr.dense[b].elem && bufs[b].reduce == agr.dense[b].reduce;
   }
-  std::vector<void*> scratch;                                     // this rank has no partial of the agreed shape: arrays that only keep the collectives matched
-  struct FreeScratch { std::vector<void*>& v; ~FreeScratch() { for (void* p : v) (void)hipFree(p); } } free_scratch{scratch};
   int alloc_rc = VH_OK;
   if (!shape_ok) {
+    // this rank has no partial of the agreed shape: arrays that only keep the collectives matched — slices of the communicator's stand-in
+    // buffer, which was sized for this shape when the shape was recorded (dense_shape_bytes; no allocation can fail here)
     nb = (int32_t)agr.dense.size();
+    size_t off = 0;
     for (int32_t b = 0; b < nb; ++b) {
-      void* p = nullptr;
-      if (hipMalloc(&p, std::max<uint64_t>(agr.dense[b].count, 1) * vh_elem_size(agr.dense[b].elem)) != hipSuccess) { alloc_rc = vh_fail(VH_E_NOMEM, "sharded query: scratch for a void attempt"); p = comm->d_flags; }
-      else scratch.push_back(p);
-      bufs[b] = vh_device_buffer{p, p == (void*)comm->d_flags ? 0ull : agr.dense[b].count, agr.dense[b].elem, agr.dense[b].reduce};
+      const size_t bytes = (std::max<uint64_t>(agr.dense[b].count, 1) * vh_elem_size(agr.dense[b].elem) + 255) / 256 * 256;
+      bufs[b] = vh_device_buffer{comm->d_void + off, agr.dense[b].count, agr.dense[b].elem, agr.dense[b].reduce};
+      off += bytes;
     }
-    if (alloc_rc && !local_err[0]) snprintf(local_err, sizeof(g_err), "%s", g_err);
+    if (off > comm->d_void_bytes) {      // cannot happen (recorded shapes never outgrow the buffer): say so rather than write past it — before any collective is posted
+      alloc_rc = vh_fail(VH_E_NOMEM, "sharded query: the stand-in arrays of a void attempt are smaller than the recorded shape");
+      if (!local_err[0]) snprintf(local_err, sizeof(g_err), "%s", g_err);
+      return alloc_rc;      // (before anything is posted; peers learn of it through the communicator's failure, as with any rank that dies)
+    }
   }
   const bool fatal = (lrc && !(changed)) || alloc_rc;             // (a stale agreement that does not even plan is not an error: everyone re-agrees)
   // a rank whose partial does not have the recorded shape although it planned: its table changed under the agreement — say so
@@ -598,12 +608,19 @@ static int fused_dense_step(vh_table* t, vh_comm* comm, int root, VhExec* x, vh_
                      (unsigned long long)(fatal ? 1 : 0), r ? r->info.scanned_recs : 0ull, r ? r->info.scanned_segments : 0ull,
                      (unsigned long long)agr.dense_mode, 0ull, (unsigned long long)((changed || void_mine) ? 1 : 0));
   HIP_TRY(hipGetLastError());
+  // Between GroupStart and GroupEnd nothing returns: a rank that left the group open, or posted fewer collectives than its peers, would hang
+  // all of them. Every rank posts the verdict and every recorded array; errors are collected and reported after the group is closed.
   const bool grouped = comm->nccl != nullptr;
-  if (grouped) NCCL_TRY(g_rccl.GroupStart());
+  ncclResult_t gs = ncclSuccess, ge = ncclSuccess;
+  if (grouped) gs = g_rccl.GroupStart();
   int red_rc = comm->ops.reduce_device(comm->ops.ctx, comm->d_flags, VH_FLAG_WORDS, VH_U64, VH_RED_SUM, -1, st);
-  for (int32_t b = 0; b < nb && !red_rc; ++b)
-    if (bufs[b].count) red_rc = comm->ops.reduce_device(comm->ops.ctx, bufs[b].ptr, bufs[b].count, bufs[b].elem, bufs[b].reduce, root, st);
-  if (grouped) NCCL_TRY(g_rccl.GroupEnd());
+  for (int32_t b = 0; b < nb; ++b) {
+    if (!bufs[b].count) continue;      // (a zero-length array is skipped by every rank alike: counts are part of the recorded shape)
+    const int rc1 = comm->ops.reduce_device(comm->ops.ctx, bufs[b].ptr, bufs[b].count, bufs[b].elem, bufs[b].reduce, root, st);
+    if (rc1 && !red_rc) red_rc = rc1;
+  }
+  if (grouped) ge = g_rccl.GroupEnd();
+  if (gs != ncclSuccess || ge != ncclSuccess) return vh_fail(VH_E_DEVICE, "ncclGroup%s failed: %s", gs != ncclSuccess ? "Start" : "End", g_rccl.GetErrorString(gs != ncclSuccess ? gs : ge));
   if (red_rc) return red_rc < 0 ? red_rc : vh_fail(VH_E_DEVICE, "reduce of a partial state array failed (%d)", red_rc);
   HIP_TRY(hipMemcpyAsync(comm->h_flags, comm->d_flags, VH_FLAG_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   int fin_rc = VH_OK, rt = 0;
@@ -710,11 +727,27 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
       }
     }
     // ---- 3. verdict: error flags, row counters and the table organisation of every rank, all-reduced
+    // the stand-in arrays a rank with a void attempt joins the fused group with (fused_dense_step) are made HERE, before the verdict, so that
+    // a rank that cannot have them says so in the verdict all ranks read: the dense shape is recorded by all ranks or by none, without a
+    // collective of its own, and never inside a collective group
+    unsigned long long novoid = 0;
+    if (attempt == 0 && r && !sparse && !lrc && !knobs_no_fused_sharded()) {
+      vh_device_buffer vb[VH_MAX_METRIC + 1];
+      int32_t vn = 0;
+      size_t need = 0;
+      if (vh_result_device_buffers(r, vb, VH_MAX_METRIC + 1, &vn) == VH_OK)
+        for (int32_t b = 0; b < vn; ++b) need += (std::max<uint64_t>(vb[b].count, 1) * vh_elem_size(vb[b].elem) + 255) / 256 * 256;
+      if (need > comm->d_void_bytes) {
+        (void)hipStreamSynchronize(st);                           // (nothing enqueued may still use the old one)
+        if (comm->d_void) { (void)hipFree(comm->d_void); comm->d_void = nullptr; comm->d_void_bytes = 0; }
+        if (hipMalloc((void**)&comm->d_void, need) == hipSuccess) comm->d_void_bytes = need; else { (void)hipGetLastError(); novoid = 1; }
+      }
+    }
     const unsigned long long host_err = retry == 1 ? VH_ERR_HASH_FULL : retry == 2 ? VH_ERR_RANGE : retry == 3 ? VH_ERR_PART_FULL : retry == 4 ? VH_ERR_HPART_FULL : retry == 6 ? VH_ERR_HP_WIDE : 0ull;
     hipLaunchKernelGGL(sharded_flags_kernel, dim3(1), dim3(64), 0, st, r && !sparse ? r->plan.counters : nullptr, comm->d_flags, host_err,
                        (unsigned long long)(lrc ? 1 : 0), r ? r->info.scanned_recs : 0ull, r ? r->info.scanned_segments : 0ull,
                        (unsigned long long)(r ? (sparse ? 100 + (r->mode == VH_MODE_HASH ? 0 : r->mode) : r->mode) : 0), r && sparse ? r->info.ngroups : 0ull,
-                       (unsigned long long)(changed ? 1 : 0));
+                       (unsigned long long)(changed ? 1 : 0), novoid);
     HIP_TRY(hipGetLastError());
     if (r && sparse) {   // the row counter of a finalised result is on the host already
       HIP_TRY(hipMemcpyAsync(comm->d_flags + 6, &r->info.passed_recs, sizeof(uint64_t), hipMemcpyHostToDevice, st));
@@ -758,7 +791,8 @@ extern "C" int vh_query_agg_sharded(vh_table* t, const vh_plan* plan, vh_comm* c
     if (red_rc) return red_rc < 0 ? red_rc : vh_fail(VH_E_DEVICE, "reduce of a partial state array failed (%d)", red_rc);
     if (attempt == 0 && !knobs_no_fused_sharded()) {               // every rank is here together: all of them record, or none
       auto hit = comm->agreed.find(sig);
-      if (hit != comm->agreed.end()) {
+      const bool everyone = f[13] == 0;                            // every rank holds stand-in arrays of this shape (made before the verdict)
+      if (hit != comm->agreed.end() && everyone) {
         hit->second.dense.clear();
         for (int32_t b = 0; b < nb; ++b) hit->second.dense.push_back(vh_comm::BufShape{bufs[b].count, bufs[b].elem, bufs[b].reduce});
         hit->second.dense_mode = r->mode; hit->second.dense_known = true;

@@ -996,7 +996,7 @@ __global__ __launch_bounds__(256) void fill_kernel(T* p, uint64_t n, T v) {
 // value(c, r) = splitmix64(seed ^ c*GAMMA ^ r) reduced to the column domain.
 template <typename T>
 __global__ __launch_bounds__(256) void gen_kernel(T* base, uint64_t seg_stride_elems, uint64_t rows_per_seg,
-                                                  uint64_t row_base, vh_gen_spec spec, uint64_t colseed) {
+                                                  uint64_t row_base, vh_gen_spec spec, uint64_t colseed, uint64_t seed) {
   const uint32_t seg = blockIdx.y;
   T* col = base + (uint64_t)seg * seg_stride_elems;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < rows_per_seg; i += (uint64_t)gridDim.x * 256) {
@@ -1006,6 +1006,16 @@ __global__ __launch_bounds__(256) void gen_kernel(T* base, uint64_t seg_stride_e
       out = (T)r;
     } else if (spec.mode == VH_GEN_CONST) {
       out = (T)spec.add;
+    } else if (spec.mode == VH_GEN_SORTED) {
+      out = (T)(spec.add + (int64_t)(r / spec.mod));
+    } else if (spec.mode == VH_GEN_ZIPF) {
+      const uint64_t h = vh_splitmix64(colseed ^ r);
+      const uint32_t octaves = 64u - (uint32_t)__builtin_clzll(spec.mod);      // floor(log2 mod) + 1
+      const uint32_t b = (uint32_t)(h >> 32) % octaves;
+      const uint64_t v = ((1ull << b) - 1ull + ((h & 0xFFFFFFFFull) % (1ull << b))) % spec.mod;
+      out = (T)(spec.add + (int64_t)v);
+    } else if (spec.mode == VH_GEN_HOT && vh_splitmix64(seed ^ r ^ 0x407ull) % 1000ull < (uint64_t)spec.param) {
+      out = (T)(spec.add + (int64_t)(spec.mod / 2));
     } else {
       const uint64_t h = vh_splitmix64(colseed ^ r);
       const int64_t iv = spec.add + (int64_t)(h % spec.mod);

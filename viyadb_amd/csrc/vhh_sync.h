@@ -172,8 +172,15 @@ static int sync_resolve(vh_table* t) {
 static const size_t VH_SYNC_STAGE_RUN = 64u << 10;       // runs of unregistered memory up to this size go through the pinned ring ...
 static const size_t VH_SYNC_STAGE_BYTES = 16u << 20;     // ... while it has room; the rest is copied by the DMA engine
 
-static int sync_batch_locked(vh_table* t, const vh_sync_item* items, uint32_t n) {
-  if (int rc = sync_resolve(t)) return rc;                // the previous batch's slots, descriptors and ring are free again
+// What a batch has done so far, for the failure guard of sync_batch_locked.
+struct VhSyncProgress {
+  uint32_t launched = 0;                                   // descriptors handed to sync_pull_kernel
+  bool queued = false;                                     // anything at all enqueued on the stream (kernels or DMA copies)
+  std::vector<std::pair<uint32_t, uint64_t>> rows_before;  // (segment, seg_rows) as they stood when the batch first changed them
+  uint32_t nseg_before = 0;
+};
+
+static int sync_batch_body(vh_table* t, const vh_sync_item* items, uint32_t n, VhSyncProgress& prog) {
   // ---- validate against the rows the mirror will hold as the items are applied in order
   uint32_t max_seg = 0;
   for (uint32_t i = 0; i < n; ++i) {
@@ -231,7 +238,8 @@ static int sync_batch_locked(vh_table* t, const vh_sync_item* items, uint32_t n)
   }
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(t->h_sync);
   VhSyncDesc* descs = reinterpret_cast<VhSyncDesc*>(t->h_sync + (size_t)ndesc_max * 2 * sizeof(unsigned long long));
-  uint32_t nd = 0, launched = 0;
+  uint32_t nd = 0;
+  uint32_t& launched = prog.launched;
   // (the kernel of the first few thousand runs pulls while the host is still writing the descriptors of the next)
   uint32_t launch_at = 1024;                               // first launch early, then twice as many runs each time: a handful of launches however big the batch
   auto launch_some = [&](bool all) -> int {
@@ -239,7 +247,7 @@ static int sync_batch_locked(vh_table* t, const vh_sync_item* items, uint32_t n)
     launch_at *= 2;
     hipLaunchKernelGGL(sync_pull_kernel, dim3(nd - launched), dim3(256), 0, g_ctx.stream, descs + launched, slots + 2ull * launched);
     HIP_TRY(hipGetLastError());
-    launched = nd;
+    launched = nd; prog.queued = true;
     return VH_OK;
   };
   size_t stage_used = 0;
@@ -270,6 +278,7 @@ static int sync_batch_locked(vh_table* t, const vh_sync_item* items, uint32_t n)
         src = at;
         t->sync_bytes_staged += bytes;
       } else {
+        prog.queued = true;
         HIP_TRY(hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, g_ctx.stream));
         dma_from_pageable = true;
         src = dst; copy = 0;
@@ -284,7 +293,9 @@ static int sync_batch_locked(vh_table* t, const vh_sync_item* items, uint32_t n)
       t->sync_pending.push_back(vh_table::SyncPending{(uint32_t)c, it.seg, first, nd - first});
     }
     if (int lrc = launch_some(false)) return lrc;
+    if (const char* e = test_env("VH_TEST_SYNC_FAIL_AT")) if ((uint32_t)atoi(e) == i) { (void)launch_some(true); return vh_fail(VH_E_DEVICE, "vh_table_sync_batch: failure injected at item %u", i); }
     const uint64_t was = t->seg_rows[it.seg];
+    prog.rows_before.emplace_back(it.seg, was);
     t->seg_rows[it.seg] = it.new_size;
     t->nseg = std::max(t->nseg, it.seg + 1);
     // (rows that fell off the end of a shrunk segment count as changed: layouts zero what lies beyond size())
@@ -299,6 +310,38 @@ static int sync_batch_locked(vh_table* t, const vh_sync_item* items, uint32_t n)
   // sources in unregistered memory behind a DMA copy: the call promises they may be reused when it returns
   if (dma_from_pageable) HIP_TRY(hipStreamSynchronize(g_ctx.stream));
   return VH_OK;
+}
+
+// A batch either goes through or leaves the table as it found it. A failure half way — an allocation, a launch, a copy — has
+// by then advanced seg_rows and the journal, maybe reset a column's stats for a whole-segment range, maybe launched some of its runs, and
+// holds sync_pending entries that the NEXT batch would pair with ITS slots. The guard: wait for whatever was enqueued (its sources and the
+// descriptors must not be reused under it), merge the min / max of the runs that did execute, widen to "anything" the stats of every column
+// whose runs did not all execute (stats too narrow would skip segments and size bit fields wrongly; too wide only costs time), put seg_rows
+// back, and leave nothing pending. The caller's next batch re-sends the same ranges; rows already pulled are simply pulled again.
+static int sync_batch_locked(vh_table* t, const vh_sync_item* items, uint32_t n) {
+  if (int rc = sync_resolve(t)) return rc;                // the previous batch's slots, descriptors and ring are free again
+  VhSyncProgress prog;
+  prog.nseg_before = t->nseg;
+  const int rc = sync_batch_body(t, items, n, prog);
+  if (rc == VH_OK) return VH_OK;
+  char own[sizeof(g_err)];
+  snprintf(own, sizeof(own), "%s", g_err);                  // (the waits below may overwrite the message)
+  if (prog.queued) (void)hipStreamSynchronize(g_ctx.stream);
+  const unsigned long long* slots = reinterpret_cast<const unsigned long long*>(t->h_sync);
+  for (const auto& p : t->sync_pending) {
+    VhSegStat& st = t->stats[p.col][p.seg];
+    if (slots && p.desc_first + p.desc_n <= prog.launched) {
+      for (uint32_t d = p.desc_first; d < p.desc_first + p.desc_n; ++d) {
+        const uint64_t lo = slots[2ull * d], hi = slots[2ull * d + 1];
+        if (lo <= hi) { st.lo = std::min(st.lo, lo); st.hi = std::max(st.hi, hi); }
+      }
+    } else { st.lo = 0; st.hi = ~0ull; }
+  }
+  t->sync_pending.clear();
+  t->sync_inflight = false;
+  for (auto it = prog.rows_before.rbegin(); it != prog.rows_before.rend(); ++it) t->seg_rows[it->first] = it->second;   // (oldest value of a segment wins)
+  t->nseg = prog.nseg_before;
+  return vh_fail(rc, "%s", own);
 }
 
 extern "C" int vh_table_sync_batch(vh_table* t, const vh_sync_item* items, uint32_t nitems) {
@@ -415,7 +458,7 @@ extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nse
   if (rc) return rc;
   for (size_t i = 0; i < t->cols.size(); ++i) {
     auto& c = t->cols[i];
-    if (specs[i].mode == VH_GEN_UNIFORM && specs[i].mod == 0) return vh_fail(VH_E_INVALID, "column %zu: mod == 0", i);
+    if (specs[i].mode != VH_GEN_ROWID && specs[i].mode != VH_GEN_CONST && specs[i].mod == 0) return vh_fail(VH_E_INVALID, "column %zu: mod == 0", i);
     const uint64_t colseed = seed ^ ((uint64_t)i * 0x9E3779B97F4A7C15ull);
     if (is_bitset_elem(c.elem)) {   // CSR per segment: `add` ids per row drawn from [0, mod)
       const uint32_t k = (uint32_t)std::max<int64_t>(1, std::min<int64_t>(specs[i].add, 8));
@@ -441,7 +484,7 @@ extern "C" int vh_segment_generate(vh_table* t, uint32_t seg_first, uint32_t nse
     dim3 grid((unsigned)std::min<uint64_t>(256, (rows_per_seg + 255) / 256), nseg);
     VH_ELEM_SWITCH(c.elem, (gen_kernel<T><<<grid, dim3(256), 0, g_ctx.stream>>>(
                                reinterpret_cast<T*>(c.base + (size_t)seg_first * c.stride), c.stride / c.esize,
-                               rows_per_seg, row_base, specs[i], colseed)));
+                               rows_per_seg, row_base, specs[i], colseed, seed)));
   }
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(g_ctx.stream));

@@ -167,10 +167,11 @@ class DeviceTable:
                                                    values.ctypes.data if len(values) else None))
 
     def generate(self, seg_first: int, nseg: int, rows_per_seg: int, row_base: int, specs: Sequence, seed: int):
-        """specs: per column (mode, mod, add, scale)."""
+        """specs: per column (mode, mod, add, scale[, param])."""
         arr = (capi.GenSpec * len(self.cols))()
-        for i, (mode, mod, add, scale) in enumerate(specs):
-            arr[i] = capi.GenSpec(int(mode), 0, int(mod), int(add), float(scale))
+        for i, sp in enumerate(specs):
+            mode, mod, add, scale = sp[:4]
+            arr[i] = capi.GenSpec(int(mode), int(sp[4]) if len(sp) > 4 else 0, int(mod), int(add), float(scale))
         capi.check(self.lib.vh_segment_generate(self.handle, seg_first, nseg, rows_per_seg, row_base, arr, seed))
 
     def read_column(self, seg: int, col: int, nrows: int) -> np.ndarray:

@@ -239,6 +239,10 @@ void ship(Shadow* sh, Session* s) {
   std::lock_guard<std::mutex> lk(sh->mu);
   sh->grow(nseg);
   std::vector<vh_sync_item> items;
+  // The shadow's claims (rows mirrored, ranges clean) change only AFTER the batch went through: a batch that fails must leave the touched
+  // ranges on the books and the row counts where the mirror really is, or later queries would read stale metrics.
+  std::vector<std::pair<uint32_t, uint64_t>> rows_after;                 // (segment, synced_rows once the batch is resident)
+  std::vector<std::pair<uint32_t, std::vector<Range>>> taken;            // dirty ranges this batch carries, by segment
   for (uint32_t seg = 0; seg < nseg; ++seg) {
     const uint64_t nrows = s->seg_rows[seg], have = sh->synced_rows[seg];
     auto& d = sh->dirty[seg];
@@ -257,13 +261,22 @@ void ship(Shadow* sh, Session* s) {
         const uint64_t a = r.first, b = std::min(r.second, have);
         if (a < b) items.push_back(vh_sync_item{seg, VH_SYNC_METRICS_ONLY, a, b - a, have, cols});
       }
+      taken.emplace_back(seg, std::move(d));
       d.clear();
     }
     if (nrows > have) items.push_back(vh_sync_item{seg, 0u, have, nrows - have, nrows, cols});
     else if (first_sight && nrows == 0) items.push_back(vh_sync_item{seg, 0u, 0, 0, 0, cols});
-    sh->synced_rows[seg] = size_after;
+    rows_after.emplace_back(seg, size_after);
   }
-  if (!items.empty()) q::detail::vh_check(vh_table_sync_batch(sh->mirror->handle, items.data(), (uint32_t)items.size()));
+  if (!items.empty()) {
+    const int rc = vh_table_sync_batch(sh->mirror->handle, items.data(), (uint32_t)items.size());
+    if (rc != VH_OK) {
+      // nothing is claimed: the ranges go back in front of whatever Touch added meanwhile (it cannot have: sh->mu is held), the row counts stay
+      for (auto& t : taken) { auto& d = sh->dirty[t.first]; d.insert(d.begin(), t.second.begin(), t.second.end()); }
+      q::detail::vh_check(rc);        // throws with vh_last_error()
+    }
+  }
+  for (const auto& ra : rows_after) sh->synced_rows[ra.first] = ra.second;
 }
 }  // namespace
 

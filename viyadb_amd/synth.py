@@ -150,7 +150,38 @@ def c5(segment_rows=1_000_000) -> Workload:
     return w
 
 
-WORKLOADS = {"C1": c1, "C2": c2, "C3": c3, "C5t": c5t, "C5": c5}
+# ---- skewed shapes of the same queries (tools/skew_probe.py measures them, tests/test_gpu_skew.py checks them against the oracle)
+def c3z(segment_rows=1_000_000) -> Workload:
+    """C3 with a Zipf-like d0 (VH_GEN_ZIPF: value 0 alone holds a tenth of the rows, the first 7 values half of them): one of DENSE_PART's
+    partitions receives several times its share of the tuples; the reference's unordered_map does not care (src/codegen/db/store.cc:67-85)."""
+    w = c3(segment_rows)
+    w.columns[0] = SynthColumn("d0", capi.DIM_NUMERIC, capi.U32, (capi.GEN_ZIPF, 1000, 0, 1.0), "uint")
+    w.name, w.description = "C3z", "C3 with Zipf-like d0 (P(v) ~ 1/(v+1)): " + w.description
+    return w
+
+
+def c3s(segment_rows=1_000_000, total_segments=1000) -> Workload:
+    """C3 loaded in d3 order (a time-ordered load, the reference's own scenario: test/index.cc:44-75): d3 is constant per block of segments,
+    `d3 < 447` skips 55 % of the segments by their min / max and every survivor lies in the first 447 — clustered, not spread."""
+    w = c3(segment_rows)
+    rows_per_value = max(1, total_segments * segment_rows // 1000)
+    w.columns[3] = SynthColumn("d3", capi.DIM_NUMERIC, capi.U32, (capi.GEN_SORTED, rows_per_value, 0, 1.0), "uint")
+    w.name, w.description = "C3s", "C3 loaded in d3 order (%d rows per value): " % rows_per_value + w.description
+    return w
+
+
+def c5h(segment_rows=1_000_000) -> Workload:
+    """C5 with one (t, u) pair on a tenth of the rows (VH_GEN_HOT on both columns: the same rows): one group of the ~35 M receives 10 % of the
+    tuples — one digit of every level of the hashed partitioning, one LDS range of the aggregation."""
+    w = c5(segment_rows)
+    t, u = w.columns[0], w.columns[1]
+    w.columns[0] = SynthColumn(t.name, t.kind, t.elem, (capi.GEN_HOT,) + tuple(t.gen[1:]) + (100,), t.json_type)
+    w.columns[1] = SynthColumn(u.name, u.kind, u.elem, (capi.GEN_HOT, 900_000, 0, 1.0, 100), u.json_type)      # hot u = 450 000: passes `u < 500 000`
+    w.name, w.description = "C5h", "C5 with one (t, u) on 10 % of the rows: " + w.description
+    return w
+
+
+WORKLOADS = {"C1": c1, "C2": c2, "C3": c3, "C5t": c5t, "C5": c5, "C3z": c3z, "C3s": c3s, "C5h": c5h}
 
 
 def create_device_table(w: Workload, nseg: int, rows_per_seg=None, row_base=0, seed=SEED):
