@@ -243,7 +243,7 @@ def main():
     ap.add_argument("--no-pack", action="store_true", help="ablation: no payload projection (survivors gather from the column arenas)")
     ap.add_argument("--no-check", action="store_true", help="skip the parity gate (profiling runs)")
     ap.add_argument("--no-predpack", action="store_true", help="ablation: narrow copies of the predicate columns (round 4's layout) instead of the bit-packed predicate projection")
-    ap.add_argument("--no-warm", action="store_true", help="no vh_table_prepare: the first queries pay the first-use costs, the tuple pool lies where hipMalloc puts it")
+    ap.add_argument("--no-warm", action="store_true", help="no vh_table_prepare: the first queries pay the first-use costs")
     ap.add_argument("--no-reference-layout", action="store_true", help="skip the arena-only leg (profiling runs)")
     ap.add_argument("--rendezvous-only", action="store_true", help="launch the ranks, meet over gloo, print who came, stop (the launcher's own test: needs no GPU)")
     args = ap.parse_args()
@@ -319,7 +319,7 @@ def main():
         else:
             table.predpack(table.filter_columns(plan))   # the predicate columns as bit fields of one word per row, bit-sliced (vh_table_predpack: C3 22 planes of one bit per row = 2.75 bytes)
     # first-use costs paid before anything is timed, as a database would at table-load time for its hot query shapes (vh_table_prepare:
-    # the compile of the scan kernel for this shape, the derived layouts above if not asked for explicitly, a measured place for the tuple pool)
+    # the compile of the scan kernel for this shape, the derived layouts above if not asked for explicitly)
     warmed = 0 if args.no_warm else table.warm(plan)
     torch.cuda.synchronize()
     t_pack = time.time() - t_pack
@@ -420,7 +420,7 @@ def main():
                        "table_path": last.path, "parallelism": ("segments sharded x%d, vh_query_agg_sharded: plan agreement + ncclReduce of the partial tables to rank 0 (%s transport)"
                                                                 % (world, "RCCL" if backend == "nccl" else "callbacks over " + backend)) if world > 1 else "1 GPU",
                        "generate_seconds": round(t_gen, 3), "payload_projection": bool(last.packed), "narrow_predicates": bool(last.narrow), "predicate_projection": bool(last.predpack), "streamed_payload": bool(last.streamed_payload),
-                       "compiled_kernel": bool(last.jit), "prepared": not args.no_warm, "pool_placed_by_measurement": bool(warmed & 512),
+                       "compiled_kernel": bool(last.jit), "prepared": not args.no_warm,
                        "one_word_tuples": bool(warmed & 1024),
                        "pack_seconds": round(t_pack, 3), "device_bytes": table.info()[2]},
             # what the derived layouts cost, first class: built once (like the reference's per-query g++ compile, outside its steady

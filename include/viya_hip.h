@@ -260,7 +260,7 @@ typedef struct vh_result_info {
                                 bit 6: hashed partitioning of the hash path (vh_hpart.h);
                                 bit 7: the projection's records are compressed (integers at the width their values need);
                                 bit 8: the hashed partitioning's tuples were packed (16 bytes: payload, two ids and their count in one word);
-                                bit 9: the tuple pool lies in a scratch buffer chosen by measurement (vh_table_prepare);
+                                bit 9: (rounds 3-5: a tuple pool placed by measurement; the search is gone, the bit is never set);
                                 bit 10: DENSE_PART wrote one-word tuples (gid and values packed into 8 bytes);
                                 bit 11: predicate columns streamed as byte planes of a bit-packed predicate projection (vh_table_predpack; bit 4 is set too);
                                 bit 13: ... of its BIT-SLICED form (comparisons bit-serial on 32 rows per lane);

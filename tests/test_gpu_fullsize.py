@@ -220,51 +220,3 @@ def test_c5_per_gpu_share_properties():
         compare(res, st, "C5 125-segment table, 2-segment window")
     finally:
         t.close()
-
-
-def test_tuple_pool_is_placed_by_measurement(tmp_path):
-    """vh_table_prepare (bench.py calls it before timing) may place a tuple pool of >= 128 MB by measurement: candidates are tried out with
-    the query's own access mix and the fastest one seen is kept (place_search, viya_hip.hip; profiles/r03/NOTES.md "Where the tuple pool
-    lands"). The trace of a C3 run over 400 M rows names the candidates' scores and the one kept — the fastest, and the buffer the context
-    ends up with —, once per table for two placements of the derived layouts of which the better is kept. VH_PLACE_TRIALS=1 switches all
-    of it off, and an ORDINARY query (no prepare: --no-warm) never searches: it takes the buffer hipMalloc hands it."""
-    import json
-    import os
-    import re
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--segments", "400", "--steps", "3", "--warmup", "2", "--no-cpu", "--no-check", "--no-reference-layout"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, VH_TRACE_ALLOC="1"))
-    assert r.returncode == 0, r.stderr[-2000:]
-    # the trace: per search its candidates, then a summary line; then (once per table) which configuration of the derived layouts was kept
-    searches, cur = [], []
-    for ln in r.stderr.splitlines():
-        m = re.search(r"scratch candidate \d+ (\S+) ([0-9.]+) ms", ln)
-        if m:
-            cur.append((m.group(1), float(m.group(2))))
-        m = re.search(r"scratch trial: (\d+) candidates of (\d+) bytes, \d+ spacers of \d+, kept (\d+) \(([0-9.]+) ms", ln)
-        if m:
-            assert len(cur) == int(m.group(1)) >= 2, ln
-            best = min(score for _, score in cur)
-            assert abs(float(m.group(4)) - best) < 1e-3 and cur[int(m.group(3))][1] == best       # the fastest candidate is the one kept
-            searches.append((cur[int(m.group(3))][0], m.group(2), best))
-            cur = []
-    assert 1 <= len(searches) <= 2, r.stderr[-2000:]
-    which = re.search(r"derived layouts: where they lie ([0-9.]+) ms, copied elsewhere ([0-9.]+) ms -> (moved|kept)", r.stderr)
-    if len(searches) == 2:      # two configurations compared: the derived layouts where they lie, and a copy of them elsewhere
-        assert which and abs(float(which.group(1)) - searches[0][2]) < 1e-3 and abs(float(which.group(2)) - searches[1][2]) < 1e-3
-        assert (which.group(3) == "moved") == (searches[1][2] < searches[0][2] * 0.985)
-        winner = searches[1] if which.group(3) == "moved" else searches[0]
-    else:
-        winner = searches[0]
-    # ... and the buffer the context ends up with IS the winner's candidate
-    final = re.findall(r"vh alloc scratch (0x[0-9a-f]+) (\d+)", r.stderr)
-    assert final and final[-1][0] == winner[0] and final[-1][1] == winner[1], (final, searches)
-    line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["config"]["table_path"] == "dense_part"
-    r1 = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, VH_TRACE_ALLOC="1", VH_PLACE_TRIALS="1"))
-    assert r1.returncode == 0 and "scratch candidate" not in r1.stderr
-    r2 = subprocess.run(cmd + ["--no-warm"], capture_output=True, text=True, timeout=600, env=dict(os.environ, VH_TRACE_ALLOC="1"))
-    assert r2.returncode == 0 and "scratch candidate" not in r2.stderr
-    assert json.loads(r2.stdout.strip().splitlines()[-1])["config"]["pool_placed_by_measurement"] is False and line["config"]["pool_placed_by_measurement"] is True

@@ -241,10 +241,11 @@ def test_a_digits_second_extent_by_position():
         dt.close()
 
 
-def test_a_hot_key_overflows_the_scans_positions_and_the_stream_pool_takes_over():
-    """The scan that writes level A itself gives every (block, digit) its extents by POSITION: room for its share of the tuples and
-    half again. Four rows of five in ONE group put far more than that into one digit of every block: VH_ERR_PART_FULL, and the re-run goes
-    through the stream pool and a level A that hands extents out as they fill. Same rows as the oracle's."""
+def test_a_hot_key_takes_its_extents_from_the_overflow_regions():
+    """The scan that writes level A itself gives every (block, digit) stream its share of the tuples by POSITION; four rows of five in ONE
+    group put far more than that into one digit of level A and into one range of level B: those streams go on in their pool's shared overflow
+    region (one global atomic per extent) — no void attempt, no other writer. Same rows as the oracle's; and again with NO positional levels at
+    all, where every tuple of both levels goes through the overflow regions."""
     rng = np.random.default_rng(8)
     n = 200_000
     tab = vo.Table({"name": "t", "segment_size": n, "dimensions": [{"name": "c", "type": "ushort"}, {"name": "x", "type": "uint"}],
@@ -257,11 +258,15 @@ def test_a_hot_key_overflows_the_scans_positions_and_the_stream_pool_takes_over(
     try:
         res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["count", "v"]}, flags=HP)
         took_hpart(res)
-        assert res.retries >= 1 and not scan_wrote_level_a(res) and res.ngroups == st.ngroups > 50_000, (res.retries, res.kernel)
-        # ... and the table remembers the shape (vh_table::part_clustered): its next query starts with the stream pool instead of paying for a void attempt
-        res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["count", "v"]}, flags=HP)
-        took_hpart(res)
-        assert res.retries == 0 and not scan_wrote_level_a(res), (res.retries, res.kernel)
+        assert res.retries == 0 and scan_wrote_level_a(res) and res.ngroups == st.ngroups > 50_000, (res.retries, res.kernel)
+        for levels in ("0", "1"):
+            os.environ["VH_TEST_POS_LEVELS"] = levels
+            try:
+                res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["count", "v"]}, flags=HP)
+            finally:
+                del os.environ["VH_TEST_POS_LEVELS"]
+            took_hpart(res)
+            assert res.retries == 0 and scan_wrote_level_a(res), (levels, res.retries, res.kernel)
     finally:
         dt.close()
 

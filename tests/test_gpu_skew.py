@@ -43,3 +43,87 @@ def test_hot_composite_key_with_distinct_counts(wl, flags):
     res, st = check_workload(w, nseg=4, flags=flags | capi.PLAN_CARD32)
     top = int(res.states[1].argmax())
     assert res.states[1][top] > 0.15 * res.states[1].sum()        # the hot (t, u): a tenth of the rows, a fifth of the survivors (u < 500 000 keeps half of the rest)
+
+
+@pytest.mark.parametrize("levels", ["0", "1"])
+def test_every_tuple_through_the_overflow_region(levels, monkeypatch):
+    """VH_TEST_POS_LEVELS: the ring writer's streams get no (or one) positional extent, so phase 1 of DENSE_PART takes (nearly) all its extents
+    from the pool's shared overflow region through the block's LDS table — what a hot partition does, at a size a test affords. One- and
+    two-word tuples, 13 and 1 partitions' worth of skew; C5's scan-written level A and its level B the same way."""
+    monkeypatch.setenv("VH_TEST_POS_LEVELS", levels)
+    for wl, flags in (("C3z", FORCE_PART | capi.PLAN_FORCE_JIT), ("C3", FORCE_PART | capi.PLAN_FORCE_JIT | capi.PLAN_NO_NARROW_TUPLES), ("C3s", FORCE_PART | capi.PLAN_FORCE_JIT)):
+        w = synth.WORKLOADS[wl](segment_rows=150_000) if wl != "C3s" else synth.c3s(150_000, 8)
+        res, st = check_workload(w, nseg=8, flags=flags)
+        assert res.path == "dense_part" and res.retries == 0, (wl, res.path, res.retries, res.kernel)
+    w = synth.c5(segment_rows=60_000)      # (C5h's hot group holds more ids than a range's LDS set: it ends on the plain hash table — test_hot_composite_key_with_distinct_counts)
+    res, st = check_workload(w, nseg=4, flags=HP | capi.PLAN_CARD32)
+    assert res.retries == 0 and res.hpart, (res.retries, res.kernel)
+
+
+def test_ring_writer_stress_two_partitions_every_row_passing(monkeypatch):
+    """two LDS-sized ranges and no filter — every drain of 64 survivors puts ~32 tuples into each of two partitions, four
+    times what a waiting line holds, so every call of the ring writer goes through several rounds of its wait loop with owners flushing
+    while later lanes of the same call still wait — looped 1 000 times per tuple size (8- and 16-byte tuples) on scratch memory that is
+    poisoned before use (VH_POISON): every answer must be the first one's, bit for bit, and the first one the oracle's."""
+    import numpy as np
+    from oracle import viya_oracle as vo
+    from tests.planner import mirror_table, plan_from_query
+    from tests.parity import compare
+    monkeypatch.setenv("VH_POISON", "1")
+    rng = np.random.default_rng(99)
+    n = 250_000
+    tab = vo.Table({"name": "t", "segment_size": n, "dimensions": [{"name": "a", "type": "uint"}, {"name": "b", "type": "uint"}],
+                    "metrics": [{"name": "v", "type": "long_sum"}, {"name": "count", "type": "count"}]})
+    for _ in range(4):
+        tab.add_segment_arrays([rng.integers(0, 150, n).astype(np.uint32), rng.integers(0, 100, n).astype(np.uint32)],
+                               [rng.integers(0, 1000, n).astype(np.int64), np.ones(n, dtype=np.uint32)], None, n)
+    dt = mirror_table(tab)
+    aq = vo.parse_query(tab, {"type": "aggregate", "table": "t", "dimensions": ["a", "b"], "metrics": ["v", "count"]})
+    st = vo.scan_aggregate(aq, now=1496570140)
+    try:
+        for flags in (FORCE_PART | capi.PLAN_FORCE_JIT | capi.PLAN_NO_LANES, FORCE_PART | capi.PLAN_FORCE_JIT | capi.PLAN_NO_LANES | capi.PLAN_NO_NARROW_TUPLES):
+            plan = plan_from_query(tab, aq, now=1496570140, flags=flags)
+            first = dt.query_agg(plan)
+            compare(first, st, "stress, flags %d" % flags)
+            assert first.path == "dense_part" and first.jit and "viya_jit_scan" in first.kernel and first.retries == 0, (first.path, first.kernel)
+            o = np.lexsort([first.keys[1], first.keys[0]])
+            want = [x[o] for x in first.keys + first.states]
+            for it in range(1000):
+                r = dt.query_agg(plan)
+                assert r.retries == 0 and r.ngroups == first.ngroups, (it, r.retries, r.ngroups)
+                o = np.lexsort([r.keys[1], r.keys[0]])
+                for a, b in zip(want, [x[o] for x in r.keys + r.states]):
+                    assert np.array_equal(a, b), (flags, it)
+    finally:
+        dt.close()
+
+
+def test_phase_2_blocks_follow_the_partitions_tuple_counts(monkeypatch):
+    """C3z at a size where DENSE_PART's private copies are merged by the merge kernel (100 K groups): 62 % of the tuples land in one of 13 partitions,
+    and phase 2 shares its blocks — and the private table copies — out by the counts phase 1 took (vh_part_shares). Same answer as the oracle with the
+    shares on, with them off (VH_NO_PART_BALANCE: every partition the same number of blocks), with MIN / MAX states whose copies are never pre-filled,
+    and three times over on one table (copies beyond a partition's share hold an earlier query's states: the merge must not read them)."""
+    from oracle import viya_oracle as vo
+    from tests.parity import build_oracle_table, compare
+    from viyadb_amd.executor import AggPlan
+    w = synth.c3z(segment_rows=200_000)
+    dt = synth.create_device_table(w, 6, 200_000)
+    try:
+        ot = build_oracle_table(w, 6, 200_000)
+        for metrics, mnames in (([7, 9], ["m0", "count"]), ([8, 11, 9], ["m1", "m4", "count"])):       # SUM + COUNT; MAX(long) + MIN(uint) + COUNT
+            q = dict(w.query, metrics=mnames)
+            st = vo.scan_aggregate(vo.parse_query(ot, q))
+            for filt in (w.plan.filter, [("rel", 2, capi.OP_EQ, 1)], w.plan.filter):      # different selectivities leave different shares behind
+                qq = dict(q) if filt is w.plan.filter else dict(q, filter={"op": "eq", "column": "d2", "value": "1"})
+                want = st if filt is w.plan.filter else vo.scan_aggregate(vo.parse_query(ot, qq))
+                for env in (None, "1"):
+                    if env:
+                        monkeypatch.setenv("VH_NO_PART_BALANCE", env)
+                    else:
+                        monkeypatch.delenv("VH_NO_PART_BALANCE", raising=False)
+                    res = dt.query_agg(AggPlan(filter=filt, groups=w.plan.groups, metrics=metrics, flags=FORCE_PART | capi.PLAN_FORCE_JIT, groups_hint=100_000))
+                    compare(res, want, "balanced phase 2, metrics %s, env %s" % (mnames, env))
+                    assert res.path == "dense_part" and res.retries == 0
+    finally:
+        monkeypatch.delenv("VH_NO_PART_BALANCE", raising=False)
+        dt.close()

@@ -262,7 +262,16 @@ def test_two_level_partitioning():
                 res, _ = run(tab, dt, q, flags=64 | 128)
             finally:
                 del os.environ[var]
-            assert res.path == "dense_part" and res.retries >= 1 and "part_split_tile_kernel" in res.kernel, (var, res.retries, res.kernel)      # (a re-run's extents are handed out as they fill)
+            assert res.path == "dense_part" and res.retries >= 1 and "part_split_ring_kernel" in res.kernel, (var, res.retries, res.kernel)      # (the re-run: a bigger pool, the same writer)
+        # ... and with few or no positional extents every tuple of both pools goes through the overflow regions (what a hot key does to one stream)
+        for levels in ("0", "1"):
+            os.environ["VH_TEST_POS_LEVELS"] = levels
+            try:
+                for qq in (q, dict(q, filter=F("lt", "a", "5")), dict(q, filter={"op": "and", "filters": [F("eq", "a", "2999"), F("eq", "b", "699")]})):
+                    res, _ = run(tab, dt, qq, flags=64 | 128 | capi.PLAN_FORCE_JIT)
+                    assert res.path == "dense_part" and res.retries == 0 and "part_split_ring_kernel" in res.kernel, (levels, res.retries, res.kernel)
+            finally:
+                del os.environ["VH_TEST_POS_LEVELS"]
         # skew: one coarse partition; one single group
         run(tab, dt, dict(q, filter=F("lt", "a", "5")), flags=64)
         run(tab, dt, dict(q, filter={"op": "and", "filters": [F("eq", "a", "2999"), F("eq", "b", "699")]}), flags=64)

@@ -86,3 +86,58 @@ def test_compiles_with_the_hiprtc_a_torch_process_carries():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-3000:]
+
+
+RING_SHAPES = (15, 16, 18, 19)      # every selftest shape whose tuples leave through the block's ring writer (vh_ring_add_tb): C5's scan-written level A
+                                    # with 32- and 16-byte tuples, C3's phase 1 with one- and two-word tuples
+
+
+@pytest.mark.parametrize("which", RING_SHAPES)
+def test_ring_writer_instruction_order(which, tmp_path):
+    """the ring writer's correctness rests on the LDS (DS) instructions of one wave executing in the order they are issued —
+    a hardware rule (see the header comment of vh_ring_add_tb), not a HIP memory-model guarantee — with the COMPILER held by signal fences.
+    What the fences must produce is asserted here on the disassembly of every ring shape, site by site:
+      gen read (ds_read_b32) -> the tuple into the waiting line (ds_write_b64 / b128, b128 x 2 for 32-byte tuples) -> IMMEDIATELY the
+      `done` count (ds_add_rtn_u32) -> the owner's list entry (ds_write_b64) -> the copy-out's list read (ds_read_b64) and line read
+      (ds_read_b128) -> the line's way out (global_store_dwordx4) -> `done` reset, then `gen` (two ds_write_b32 back to back, the first at the
+      address the count went to) — and no `s_waitcnt vmcnt` between the line read and the `gen` store (the next step's predicate loads
+      stay in flight). A compiler that reorders any of it fails this test instead of corrupting tuples silently."""
+    rc, text, out = _compile(which, tmp_path)
+    assert rc == 0, text[:3000]
+    isa = subprocess.run([f"{LLVM}/llvm-objdump", "-d", out], capture_output=True, text=True, check=True).stdout
+    body = isa[isa.index("<viya_jit_scan_selftest>:"):]
+    nxt = re.search(r"\n[0-9a-f]+ <", body[10:])
+    L = [l.split("//")[0].strip() for l in (body[:nxt.start() + 10] if nxt else body).splitlines()]
+    sites = [i for i, l in enumerate(L) if l.startswith("ds_add_rtn_u32") and re.match(r"ds_write_b(64|128)\b", L[i - 1])]
+    # a ring site per drain form the shape compiles (full steps / the step that reaches a segment's end; C5 drains two survivors per lane)
+    assert len(sites) >= 1, "no ring-writer site found"
+
+    def first(pat, start, stop):
+        for k in range(start, stop):
+            if re.match(pat, L[k]):
+                return k
+        return None
+    for n, i in enumerate(sites):
+        stop = sites[n + 1] if n + 1 < len(sites) else min(len(L), i + 400)
+        # (1) the place's generation is read before the tuple is written
+        k = i - 1
+        while re.match(r"ds_write_b128\b", L[k - 1]):
+            k -= 1                                       # (32-byte tuples: two stores, back to back)
+        gen_read = max([j for j in range(max(0, k - 40), k) if re.match(r"ds_read_b32\b", L[j])], default=None)
+        assert gen_read is not None, (which, n, L[k - 10:k + 1])
+        # (2) tuple store(s) and the count are adjacent: nothing the compiler could have slipped between them
+        assert all(re.match(r"ds_write_b(64|128)\b", L[j]) for j in range(k, i)), (which, n, L[k:i + 1])
+        # (3) the owner's part, in program order
+        p_list = first(r"ds_write_b64\b", i + 1, stop)
+        p_rl = first(r"ds_read_b64\b", (p_list or stop) + 1, stop)
+        p_line = first(r"ds_read_b128\b", (p_rl or stop) + 1, stop)
+        p_store = first(r"global_store_dwordx4\b", (p_line or stop) + 1, stop)
+        p_done0 = first(r"ds_write_b32\b", (p_store or stop) + 1, stop)
+        p_gen = first(r"ds_write_b32\b", (p_done0 or stop) + 1, stop)
+        assert None not in (p_list, p_rl, p_line, p_store, p_done0, p_gen), (which, n, p_list, p_rl, p_line, p_store, p_done0, p_gen)
+        # done[rl] = 0 (the address the count above went to), THEN gen[rl] = want + 1 (another address)
+        cnt = re.match(r"ds_add_rtn_u32 v\d+, (v\d+), v\d+(?: offset:(\d+))?", L[i])
+        a, b = re.match(r"ds_write_b32 (v\d+), v\d+(?: offset:(\d+))?", L[p_done0]), re.match(r"ds_write_b32 (v\d+), v\d+(?: offset:(\d+))?", L[p_gen])
+        assert cnt and a and b and a.groups() == cnt.groups() and b.groups() != cnt.groups(), (which, n, L[i], L[p_done0], L[p_gen])
+        assert p_gen == p_done0 + 1, (which, n, L[p_done0:p_gen + 1])
+        assert not any("vmcnt" in L[j] for j in range(p_line, p_gen + 1)), (which, n, [L[j] for j in range(p_line, p_gen + 1) if "vmcnt" in L[j]])

@@ -56,8 +56,8 @@ python tools/part2_probe.py 1000 1000,120 2>/dev/null | grep '^{' > $OUT/part2_p
 python tools/hisel_probe.py 1000 2>/dev/null | grep '^{' > $OUT/hisel_probe.txt              # 100 K groups from the arenas at 100 / 50 / 25 %
 # how stable the headline is from process to process: ten fresh processes as a caller that prepares its query shape (vh_table_prepare) and
 # ten as one that does not (an ordinary first query: plain hipMalloc for the tuple pool)
-{ for i in 1 2 3 4 5 6 7 8 9 10; do python bench.py $Q --steps 10 --warmup 3 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('prepared', $i, round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],3), d['config']['pool_placed_by_measurement'])"; done
-  for i in 1 2 3 4 5 6 7 8 9 10; do python bench.py $Q --no-warm --steps 10 --warmup 3 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('unprepared', $i, round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],3), d['config']['pool_placed_by_measurement'])"; done; } > $OUT/c3_ten_processes.txt 2>/dev/null
+{ for i in 1 2 3 4 5 6 7 8 9 10; do python bench.py $Q --steps 10 --warmup 3 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('prepared', $i, round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],3))"; done
+  for i in 1 2 3 4 5 6 7 8 9 10; do python bench.py $Q --no-warm --steps 10 --warmup 3 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('unprepared', $i, round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],3))"; done; } > $OUT/c3_ten_processes.txt 2>/dev/null
 cat $OUT/c3_ten_processes.txt
 rm -rf $OUT/kt_* $OUT/pmc_FETCH_SIZE_* $OUT/pmc_WRITE_SIZE_* $OUT/pmc_insts_* $OUT/pre_*
 ls $OUT

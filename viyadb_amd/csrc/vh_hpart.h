@@ -52,6 +52,8 @@ struct VhHpPool {             // extents of HP_ET 16-byte tuples
                               // bits that pick the HBM channel; VhPlanDev::ext_stride is the same remedy for DENSE_PART)
   uint32_t stream;            // 1: a stream pool (see above)
   unsigned long long* cursor; // extents handed out (stream pools: the scan kernel's allocation counter)
+  uint32_t ovf_base;          // a pool written through the ring writer by position: where its shared overflow region starts ...
+  unsigned long long* ovf_cursor;   // ... and how many extents of it were taken (nullptr: no such region). Found by their tags.
 };
 struct VhHpKind {             // the three pools of the tuples
   VhHpPool z, a, b;
@@ -71,6 +73,7 @@ struct VhHpArgs {
   int32_t bitset_j;
   uint32_t chunk;             // group records a block of hp_aggregate_kernel takes from the list at a time
   uint64_t list_cap;          // records the group list holds (+ one reserved record behind them)
+  uint32_t slice_levels_cap;  // (tests: see VhPlanDev::slice_levels_cap; ~0u otherwise)
   int32_t ablate;             // measurement only (VH_HP_ABLATE; results are wrong): 1 no id inserts, 2 no records written, 4 no tuples either, 8 no table clears
   // direct emission: the aggregation kernel writes a range's groups straight into the result's output columns (key columns in the
   // dimensions' own element types, states in the metrics') at places taken off the result's row counter — no list of group records, no
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __res
 // last store. C5 (62.5 M tuples): hp_scatter_kernel's level B 0.66-0.72 ms, this one see profiles/r05/NOTES.md.
 struct HpRingDest {
   uint32_t lo, kmax, nb, j;
+  VhRingOvf ovf;
   __device__ __forceinline__ uint64_t extent(uint32_t d, uint32_t k) const { return k < kmax ? (uint64_t)lo + ((uint64_t)k * nb + j) * HP_FAN + d : ~0ull; }
 };
 template <int BLOCK, int U>
@@ -342,13 +346,22 @@ __global__ __launch_bounds__(BLOCK) void hp_ring_scatter_kernel(const VhHpArgs* 
   const VhHpKind& K = HA->k[0];
   const uint32_t a = blockIdx.x / nb, j = blockIdx.x % nb;
   const uint32_t lo = K.slice[a], cap = K.slice[a + 1] - lo;
-  const HpRingDest D{lo, cap / ((uint32_t)HP_FAN * nb), nb, j};
+  // slice a: positional extents for the counted tuples' even spread over the (block, digit) streams, then the slice's shared overflow region
+  // (hp_plan_kernel laid it out from the same count; its cursor K.slice[HP_FAN + 1 + a] starts behind the positional extents)
+  const uint32_t kpos = vh_slice_levels(K.count[a], (unsigned long long)HP_FAN * nb, (uint32_t)HP_ET / (uint32_t)U, HA->slice_levels_cap);
+  const HpRingDest D{lo, kpos * (uint32_t)HP_FAN * nb <= cap ? kpos : cap / ((uint32_t)HP_FAN * nb), nb, j, VhRingOvf{lo, cap, K.slice + HP_FAN + 1 + a, nullptr, K.b.fill, K.b.tag}};
   vh_u64x2* const out = reinterpret_cast<vh_u64x2*>(K.b.tuples);
   const T* const in = reinterpret_cast<const T*>(K.a.tuples);
-  const uint32_t per = src_blocks * (uint32_t)HP_FAN, klev = K.a.max_extents / per;
+  // the source: digit a's extents of pool a — by position for every scan block (levels below the overflow region), by tag inside the overflow
+  // region (a hot digit's further extents; block j = 0 of the partition takes those)
+  const uint32_t per = src_blocks * (uint32_t)HP_FAN, klev = K.a.ovf_base / per;
   const uint32_t mine = (src_blocks - j + nb - 1u) / nb;                 // scan blocks j, j + nb, ...
-  for (uint32_t s = (uint32_t)wave; s < klev * mine; s += BLOCK / 64) {
-    const uint32_t e = (s / mine) * per + (j + (s % mine) * nb) * (uint32_t)HP_FAN + a;
+  uint32_t novf = 0;
+  if (K.a.ovf_cursor && j == 0) { const unsigned long long c = *K.a.ovf_cursor, room = K.a.max_extents - K.a.ovf_base; novf = (uint32_t)(c < room ? c : room); }
+  for (uint32_t s = (uint32_t)wave; s < klev * mine + novf; s += BLOCK / 64) {
+    uint32_t e;
+    if (s < klev * mine) e = (s / mine) * per + (j + (s % mine) * nb) * (uint32_t)HP_FAN + a;
+    else { e = K.a.ovf_base + (s - klev * mine); if (K.a.tag[e] != (uint8_t)a) continue; }
     const uint32_t n = __builtin_amdgcn_readfirstlane((int)K.a.fill[e]);
     const T* const src = in + (uint64_t)e * K.a.stride;
     for (uint32_t i0 = 0; i0 < n; i0 += 64u * UNR) {
@@ -384,9 +397,10 @@ __global__ __launch_bounds__(BLOCK) void hp_count_kernel(const VhHpArgs* __restr
   __syncthreads();
   if (threadIdx.x < HP_FAN && cnt[threadIdx.x]) atomicAdd(K.count + threadIdx.x, cnt[threadIdx.x]);
 }
-// ring_blocks != 0 (hp_ring_scatter_kernel writes the slices): every (block j of ring_blocks, digit) of partition a gets its extents by POSITION —
-// extent k of it is slice[a] + (k * ring_blocks + j) * HP_FAN + digit — with room for half again its share of the partition's tuples, and
-// one more; the aggregation looks at the whole slice.
+// ring_blocks != 0 (hp_ring_scatter_kernel writes the slices): every (block j of ring_blocks, digit) stream of partition a gets vh_slice_levels
+// extents by POSITION — extent k of it is slice[a] + (k * ring_blocks + j) * HP_FAN + digit: its share of the partition's counted tuples and one
+// more — and behind them the slice's shared overflow region with room for all the partition's tuples once more (a hot key inside the partition);
+// the aggregation looks at every extent the slice's cursor says is used.
 __global__ __launch_bounds__(HP_FAN) void hp_plan_kernel(const VhHpArgs* __restrict__ HA, unsigned long long* counters, int ring_blocks) {      // one block of HP_FAN threads
   __shared__ unsigned long long wave_tot[HP_FAN / 64];
   const VhHpKind& K = HA->k[0];
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(HP_FAN) void hp_plan_kernel(const VhHpArgs* __restr
   // what partition a holds, in extents, + one open extent per digit of its single writer + the flush of the tails
   const uint32_t c = K.count[a];
   const unsigned long long per = (unsigned long long)HP_FAN * (unsigned)(ring_blocks > 0 ? ring_blocks : 1);
-  const unsigned long long need = !c ? 0ull : ring_blocks ? (((unsigned long long)c + c / 2) / per / et + 2) * per
+  const unsigned long long need = !c ? 0ull : ring_blocks ? vh_slice_extents(c, per, et, HA->slice_levels_cap)
                                                            : (unsigned long long)(c + et - 1) / et + 2 * HP_FAN + 8;
   unsigned long long incl = need;
 #pragma unroll
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(HP_FAN) void hp_plan_kernel(const VhHpArgs* __restr
   for (int w = 0; w < wave; ++w) before += wave_tot[w];
   const unsigned long long at = before + incl - need, end = before + incl;
   K.slice[a] = (uint32_t)(at < K.b.max_extents ? at : K.b.max_extents);
-  K.slice[HP_FAN + 1 + a] = ring_blocks ? (uint32_t)need : 0u;      // (extents handed out: by position, all of them)
+  K.slice[HP_FAN + 1 + a] = ring_blocks && c ? vh_slice_levels(c, per, et, HA->slice_levels_cap) * (uint32_t)per : 0u;      // (extents used so far: the positional ones; overflow extents are counted on top as they are taken)
   if (a == HP_FAN - 1) {
     K.slice[HP_FAN] = (uint32_t)(end < K.b.max_extents ? end : K.b.max_extents);
     if (end > K.b.max_extents) atomicOr(counters + 2, VH_ERR_PART_FULL);

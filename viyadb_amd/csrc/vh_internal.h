@@ -53,7 +53,10 @@
 #define VJ_FAN_ET 4096           // = HP_ET
 #define VJ_FAN_RING 2
 #define VJ_FAN_LIST_BYTES 512    // per wave: 64 x (ring line | destination line << 10)
-#define VJ_FAN_LDS_BYTES(block) ((size_t)VJ_FAN * 4 * (1 + 2 * VJ_FAN_RING) + (size_t)VJ_FAN * VJ_FAN_RING * 128 + (size_t)((block) / 64) * VJ_FAN_LIST_BYTES)
+// LDS of a block's ring writer (vh_ring_add_tb, vh_kernels.h): [pos | done | gen] counters, the block's `dead` word (+ padding to 16 bytes), two
+// words per digit for the overflow extents of the moment, `lines` waiting 128-byte lines per digit, a list of finished lines per wave
+#define VH_RING_LDS_BYTES(fan, lines, block) ((size_t)(fan) * 4 * (1 + 2 * (lines)) + 16 + (size_t)(fan) * 16 + (size_t)(fan) * (lines) * 128 + (size_t)((block) / 64) * VJ_FAN_LIST_BYTES)
+#define VJ_FAN_LDS_BYTES(block) VH_RING_LDS_BYTES(VJ_FAN, VJ_FAN_RING, block)
 
 // table organisations of the scan kernels
 enum { VH_MODE_DENSE_LDS = 1, VH_MODE_DENSE_GLOBAL = 2, VH_MODE_HASH = 3, VH_MODE_DENSE_PART = 4 };
@@ -221,6 +224,12 @@ struct VhPlanDev {
   uint8_t* extent_part2;     // tag = the SUB-partition (0..63) inside the owning partition's range
   uint32_t* l2;              // [0..npart]: first pool-2 extent of partition p's range (prefix sums); [VH_L2_NEXT + p]: extents handed out of it
   uint32_t max_extents;
+  uint32_t* part_count;      // one-level DENSE_PART whose phase 1 went through the ring writer: tuples per partition, counted at the scan blocks' ends — phase 2's blocks
+                             // (and private table copies) are shared out by these counts (vh_part_shares); nullptr: every partition the same number of blocks
+  uint32_t pos_levels;       // the ring writer's pools: extents per (block, digit) stream that lie at POSITIONS (pool 1: phase 1 of DENSE_PART) ...
+  uint32_t slice_levels_cap; // (tests: an upper bound for the positional levels of the slices the device lays out — 0 sends every tuple through the overflow regions; ~0u otherwise)
+  uint32_t pos_levels2;      // ... (the second pool: level A of the hashed partitioning, written by the scan); what lies behind level * streams is the
+                             // pool's shared overflow region, handed out through counters[9] / counters[10] (vh_ring_add_tb)
   uint32_t ext_waves;        // pool 1, phase 1: waves of the scan launch when they take their extent chunks by position — the k-th chunk of wave w is
                              // chunk k * ext_waves + w — instead of from the shared cursor (0: shared cursor). Every wave's first drain opens
                              // extents, and 3 072 returning atomics on ONE address at the start of the kernel queue up behind each other for

@@ -97,10 +97,14 @@ struct VjWave {
 // allocation. The pool is the plan's second pool (tuples2, extent_missing2 = tuples in the extent, extent_part2 = digit).
 struct VjFanDest {
   uint64_t per, first; uint32_t stride, kmax;
-  // kmax: WHOLE levels of the pool only (level B reads max_extents2 / per levels, hp_ring_scatter_kernel): a trailing partial level — a pool
-  // size that is no multiple of blocks * 256, e.g. under the test override — is never written, so nothing written can go unread
-  __device__ __forceinline__ VjFanDest(const VhPlanDev& P) : per((uint64_t)gridDim.x * VH_RING_FAN), first((uint64_t)blockIdx.x * VH_RING_FAN), stride((uint32_t)P.ext_tuples2), kmax((uint32_t)((uint64_t)P.max_extents2 / ((uint64_t)gridDim.x * VH_RING_FAN))) {}
-  // extent of the digit's k-th extent (~0: beyond the pool)
+  VhRingOvf ovf;
+  // kmax: the pool's positional levels (VhPlanDev::pos_levels2); behind them its shared overflow region (cursor: counters[10])
+  __device__ __forceinline__ VjFanDest(const VhPlanDev& P) : per((uint64_t)gridDim.x * VH_RING_FAN), first((uint64_t)blockIdx.x * VH_RING_FAN), stride((uint32_t)P.ext_tuples2), kmax(P.pos_levels2) {
+    const uint64_t pos = (uint64_t)kmax * per;
+    ovf.base = (uint32_t)(pos < (uint64_t)P.max_extents2 ? pos : (uint64_t)P.max_extents2); ovf.cap = P.max_extents2 - ovf.base;
+    ovf.cur32 = nullptr; ovf.cur64 = P.counters + 10; ovf.fill = P.extent_missing2; ovf.tag = P.extent_part2;
+  }
+  // extent of the digit's k-th extent (~0: beyond its positions)
   __device__ __forceinline__ uint64_t extent(uint32_t d, uint32_t k) const { return k < kmax ? (uint64_t)k * per + first + d : ~0ull; }
 };
 template <int U>
@@ -117,14 +121,19 @@ __device__ __forceinline__ void vj_fan_add(const VhPlanDev& P, const VhRing& F, 
 // and the second split expect them; a partition that meets more than its share and a half of a block's tuples overflows its positions
 // (VH_ERR_PART_FULL) and the re-run takes the per-wave writer.
 struct VjPartDest {
-  uint64_t per, first; uint32_t max_ext;
-  __device__ __forceinline__ VjPartDest(const VhPlanDev& P) : per((uint64_t)gridDim.x * (uint32_t)P.npart), first((uint64_t)blockIdx.x * (uint32_t)P.npart), max_ext(P.max_extents) {}
-  __device__ __forceinline__ uint64_t extent(uint32_t d, uint32_t k) const { const uint64_t e = (uint64_t)k * per + first + d; return e < (uint64_t)max_ext ? e : ~0ull; }
+  uint64_t per, first; uint32_t kmax;
+  VhRingOvf ovf;
+  __device__ __forceinline__ VjPartDest(const VhPlanDev& P) : per((uint64_t)gridDim.x * (uint32_t)P.npart), first((uint64_t)blockIdx.x * (uint32_t)P.npart), kmax(P.pos_levels) {
+    const uint64_t pos = (uint64_t)kmax * per;
+    ovf.base = (uint32_t)(pos < (uint64_t)P.max_extents ? pos : (uint64_t)P.max_extents); ovf.cap = P.max_extents - ovf.base;
+    ovf.cur32 = nullptr; ovf.cur64 = P.counters + 9; ovf.fill = P.extent_missing; ovf.tag = P.extent_part;
+  }
+  __device__ __forceinline__ uint64_t extent(uint32_t d, uint32_t k) const { return k < kmax ? (uint64_t)k * per + first + d : ~0ull; }
 };
 template <class J, int TW>
 __device__ __forceinline__ void vj_part_ring_add(const VhPlanDev& P, const VhRing& F, bool active, const uint64_t (&w)[TW], uint32_t part, int lane) {
   const VjPartDest D(P);
-  vh_ring_add_tb<TW * 8, VjPartDest, J::PART_RING, 2>(F, reinterpret_cast<char*>(P.tuples), (uint32_t)P.ext_stride, 31u - (uint32_t)__builtin_clz((uint32_t)P.ext_tuples), active, w, part, lane, D, P.counters + 2);
+  vh_ring_add_tb<TW * 8, VjPartDest, J::PART_RING, 2, true>(F, reinterpret_cast<char*>(P.tuples), (uint32_t)P.ext_stride, 31u - (uint32_t)__builtin_clz((uint32_t)P.ext_tuples), active, w, part, lane, D, P.counters + 2);
 }
 
 // Where a row's ids lie (hashed partitioning with a bitset metric) and the first two of them: loaded in two dependent steps, which a drain
@@ -690,7 +699,7 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
 
   if constexpr (MODE == VH_MODE_DENSE_PART && J::PART_RING != 0)
     vh_ring_finish_tb<J::TW * 8, BLOCK, VjPartDest, J::PART_RING, 2, true>(V.F, reinterpret_cast<char*>(P.tuples), (uint32_t)P.ext_stride, 31u - (uint32_t)__builtin_clz((uint32_t)P.ext_tuples),
-                                                                           P.extent_missing, P.extent_part, VjPartDest(P), P.counters + 2);
+                                                                           P.extent_missing, P.extent_part, VjPartDest(P), P.counters + 2, P.part_count);
   else if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE != 0) vh_part_stage_finish<J::TW>(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); }
   if constexpr (MODE == VH_MODE_HASH && J::HPART && J::HP_SCANFAN) vh_ring_finish<(J::BITSET_J >= 0 && !J::HP_PACK) ? 2 : 1, BLOCK>(V.F, reinterpret_cast<vh_u64x2*>(P.tuples2), (uint32_t)P.ext_tuples2, P.extent_missing2, P.extent_part2, VjFanDest(P), P.counters + 2);
   else if constexpr (MODE == VH_MODE_HASH && J::HPART) vh_part_tile_finish<1>(P, V.T, lane);
@@ -726,7 +735,9 @@ __device__ __forceinline__ void vj_part_agg(const VhPlanDev& P, int blocks_per_p
   constexpr int NM = J::NM, TW = J::TW, GB = J::GID_BITS;
   constexpr bool carried = J::CARRIER >= 0;
   constexpr uint64_t gid_mask = GB ? (1ull << GB) - 1ull : 0xFFFFFFFFull;
-  const int part = blockIdx.x / blocks_per_part, b = blockIdx.x % blocks_per_part;
+  int part, b;
+  if (!vh_part_my_share(P, blocks_per_part, part, b, blocks_per_part)) return;      // (blocks_per_part: from here on THIS partition's blocks — by the partitions' tuple counts where phase 1 counted them)
+  const bool balanced = P.part_count != nullptr && P.nlevel == 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = BLOCK / 64;
   const uint64_t gpp = 1ull << P.agg_shift;
   const uint64_t g0 = (uint64_t)part << P.agg_shift;
@@ -814,12 +825,12 @@ __device__ __forceinline__ void vj_part_agg(const VhPlanDev& P, int blocks_per_p
   __syncthreads();
   // Sole block of the range, or one private copy of the range per block (P.nxcd == blocks_per_part: dense_merge_kernel adds
   // them up): plain stores of EVERY group, present or not. Otherwise one atomic update per present group into the shared table.
-  const bool own = blocks_per_part == 1 || P.nxcd == blocks_per_part;
-  const uint64_t xo = P.nxcd == blocks_per_part ? (uint64_t)b * P.xcd_stride : 0;
+  const bool own = balanced || blocks_per_part == 1 || P.nxcd == blocks_per_part;
+  const uint64_t xo = balanced || P.nxcd == blocks_per_part ? (uint64_t)b * P.xcd_stride : 0;
   for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) {
     const uint8_t here = carried ? (uint8_t)(reinterpret_cast<uint64_t*>(mstate[carried ? J::CARRIER : 0])[g] != 0)
                                  : reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g];
-    if (own && blocks_per_part > 1) { if (!carried) P.present[xo + g0 + g] = here; }
+    if (own && (balanced || blocks_per_part > 1)) { if (!carried) P.present[xo + g0 + g] = here; }
     else { if (!here) continue; if (!carried) P.present[g0 + g] = 1; }
 #pragma unroll
     for (int j = 0; j < NM; ++j) {

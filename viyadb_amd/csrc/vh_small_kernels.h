@@ -34,18 +34,22 @@ struct VhMergeArgs {
   uint8_t* present;
   void* state[VH_MAX_METRIC];
   uint8_t sop[VH_MAX_METRIC];
+  // phase 2 of DENSE_PART with its blocks shared out by the partitions' tuple counts: group g belongs to partition g >> agg_shift, whose first
+  // vh_part_shares(...) copies were written by this query (the others hold whatever an earlier query left there)
+  const uint32_t* part_count; int32_t npart, agg_shift; uint32_t blocks;
 };
 
-__device__ __forceinline__ void vh_merge_group(const VhMergeArgs& A, uint64_t g) {
+__device__ __forceinline__ void vh_merge_group(const VhMergeArgs& A, uint64_t g, int ncopies = -1) {
+  const int nx = ncopies >= 0 ? ncopies : A.nxcd;
   uint8_t p;
   if (A.present_carrier >= 0) {
     const uint64_t* s = reinterpret_cast<const uint64_t*>(A.state[A.present_carrier]);
     uint64_t any = 0;
-    for (int x = 0; x < A.nxcd; ++x) any |= s[x * A.xcd_stride + g];
+    for (int x = 0; x < nx; ++x) any |= s[x * A.xcd_stride + g];
     p = any != 0;
   } else {
     p = A.present[g];
-    for (int x = 1; x < A.nxcd; ++x) p |= A.present[x * A.xcd_stride + g];
+    for (int x = 1; x < nx; ++x) p |= A.present[x * A.xcd_stride + g];
     A.present[g] = p;
   }
   if (!p) return;
@@ -54,18 +58,25 @@ __device__ __forceinline__ void vh_merge_group(const VhMergeArgs& A, uint64_t g)
     if (vh_sop_bytes(sop) == 4) {
       uint32_t* s = reinterpret_cast<uint32_t*>(A.state[j]);
       uint64_t a = s[g];
-      for (int x = 1; x < A.nxcd; ++x) a = vh_combine(sop, a, s[x * A.xcd_stride + g]);
+      for (int x = 1; x < nx; ++x) a = vh_combine(sop, a, s[x * A.xcd_stride + g]);
       s[g] = (uint32_t)a;
     } else {
       uint64_t* s = reinterpret_cast<uint64_t*>(A.state[j]);
       uint64_t a = s[g];
-      for (int x = 1; x < A.nxcd; ++x) a = vh_combine(sop, a, s[x * A.xcd_stride + g]);
+      for (int x = 1; x < nx; ++x) a = vh_combine(sop, a, s[x * A.xcd_stride + g]);
       s[g] = a;
     }
   }
 }
 __global__ __launch_bounds__(256) void dense_merge_kernel(const VhMergeArgs A) {
   const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  if (A.part_count) {
+    __shared__ uint32_t s_share[64];
+    if (threadIdx.x < 64) { uint32_t start; s_share[threadIdx.x] = vh_part_shares(A.part_count, A.npart, A.blocks, (uint32_t)A.nxcd, (int)threadIdx.x, &start); }
+    __syncthreads();
+    if (g < A.G) vh_merge_group(A, g, (int)s_share[g >> A.agg_shift]);
+    return;
+  }
   if (g < A.G) vh_merge_group(A, g);
 }
 
@@ -1149,36 +1160,6 @@ __global__ __launch_bounds__(256) void sync_pull_kernel(const VhSyncDesc* __rest
   }
 }
 
-// ------------------------------------------------------- where a tuple pool should lie (ensure_scratch; tools/experiments/place_calib.hip)
-// The access mix of a partitioning scan in miniature: every wave streams the predicate columns with 16-byte non-temporal loads, ten of its
-// lanes gather 8 bytes anywhere in `rec` per step, and every sixth step it stores eight whole 128-byte lines at pseudo-random places of `dst`.
-// Only the MIX tells candidate buffers apart (stores alone, or streams and gathers alone, run alike on every candidate).
-__device__ __forceinline__ uint64_t vh_place_mix(uint64_t x) { x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; return x ^ (x >> 31); }
-struct VhPlaceArgs {
-  const vh_u32x4* src[4]; uint64_t n16[4]; int32_t nsrc;       // the query's predicate columns (arenas or narrow copies), streamed side by side
-  const uint64_t* rec; uint64_t nrec;                           // where the survivors' values come from
-  vh_u32x4* dst; uint64_t lines;                                // the candidate's tuple pool
-  unsigned long long* sink;
-};
-__global__ __launch_bounds__(256) void place_probe_kernel(const VhPlaceArgs A) {
-  uint32_t acc = 0;
-  const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x, nt = (uint64_t)gridDim.x * 256;
-  const uint64_t wave = g >> 6;
-  const uint32_t lane = threadIdx.x & 63;
-  uint64_t it = 0;
-  for (uint64_t i = g; i < A.n16[0]; i += nt, ++it) {           // (n16[0] is the longest stream)
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-      if (s < A.nsrc && i < A.n16[s]) { const vh_u32x4 v = __builtin_nontemporal_load(A.src[s] + i); acc ^= v.x ^ v.y ^ v.z ^ v.w; }
-    if (lane < 10) acc ^= (uint32_t)A.rec[vh_place_mix(i * 3 + 1) % A.nrec];
-    if (it % 6 == 0) {
-      const uint64_t line = vh_place_mix(wave * 0x9E3779B97F4A7C15ull + it * 8 + (lane >> 3)) % A.lines;
-      vh_u32x4 o; o.x = (uint32_t)i; o.y = lane; o.z = acc; o.w = 7;
-      A.dst[line * 8 + (lane & 7)] = o;
-    }
-  }
-  if (acc == 0x9E3779B9u) atomicAdd(A.sink, 1ull);
-}
 
 // ------------------------------------------------------- bandwidth ceiling
 __global__ __launch_bounds__(256) void read_bw_kernel(const vh_u32x4* p, uint64_t n16, unsigned long long* sink) {

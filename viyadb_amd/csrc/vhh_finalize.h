@@ -279,20 +279,14 @@ static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
     if (rp->hp_passes > 64) rp->hp_passes = 64;
   }
   else if (retry == 3 && r->hpart) {                         // hashed partitioning ran out of tuple extents: size for the survivors it counted, then give up
-    // extents by position (the ring writer) ran out although the pools had room: a hot key. Remembered for the shape — its next queries start with
-    // the writers whose extents are handed out as they fill, instead of paying for a void attempt every time
-    if (r->by_position && r->info.passed_recs + r->info.passed_recs / 16 <= r->pos_capacity) { std::lock_guard<std::mutex> lk(t->mu); t->part_clustered.insert(r->group_sig); }
+    // (the ring writer's pools hold any skew between their streams — positional extents + a shared overflow region as big as the estimate —, so
+    // running out means more survivors than estimated: the re-run is sized for what this attempt counted, through the same writer)
     if (rp->part_override) rp->no_hpart = true;
     else rp->part_override = std::max<uint64_t>(r->info.passed_recs + r->info.passed_recs / 16 + 1024, 1ull << 16);
   }
   else if (retry == 3) {                                     // tuple extents exhausted: more room, then give up on partitioning
     // the attempt counted its survivors even though it dropped their tuples: the next one is sized for exactly that many
     const uint64_t had = (uint64_t)r->plan.max_extents * r->plan.ext_tuples;
-    // positional chunks (VhPlanDev::ext_waves) ran out with room to spare: some waves met far more survivors than others (a time range over
-    // time-ordered segments, a skewed partition). Remembered for the shape, like groups_seen for hash sizing: its next queries start on the cursor
-    if (r->plan.ext_waves && r->info.passed_recs + r->info.passed_recs / 16 <= had) { std::lock_guard<std::mutex> lk(t->mu); t->part_clustered.insert(r->group_sig); }
-    // ... and so did extents by position (the ring writer of phase 1 or of the second split): skewed group ids
-    if (r->by_position && r->info.passed_recs + r->info.passed_recs / 16 <= r->pos_capacity) { std::lock_guard<std::mutex> lk(t->mu); t->part_clustered.insert(r->group_sig); }
     if (rp->part_override && had >= r->info.scanned_recs) rp->no_part = true;
     else rp->part_override = std::max<uint64_t>(std::max<uint64_t>(rp->part_override * 2, r->info.passed_recs + r->info.passed_recs / 16), 1ull << 16);
   }
@@ -389,13 +383,17 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
   int rc = VH_OK;
   for (uint32_t attempt = 0; attempt < 12; ++attempt) {
     vh_result* r = nullptr;
+    const auto h0 = std::chrono::steady_clock::now();
     // planned and launched under the table lock; the wait for the device and the read-back happen outside it, so
     // queries of other threads on this table run meanwhile (each on its own context)
     { std::lock_guard<std::mutex> lk(t->mu); rc = query_launch_locked(t, x, plan, &r, rp.cap_override, rp.force_hash, rp.part_override, rp.no_part, false, nullptr, nullptr, false, rp.hp_passes, rp.no_hpart); }
     if (rc) break;
     r->exec = x;
     int retry = 0;
+    const auto h1 = std::chrono::steady_clock::now();
     rc = result_finalize(r, &retry);
+    if (knobs().times) fprintf(stderr, "vh host: plan + enqueue %.1f us, finalize (enqueue tail + wait + read-back) %.1f us\n", std::chrono::duration<double, std::micro>(h1 - h0).count(),
+                               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h1).count());
     if (rc) { r->exec = nullptr; delete r; break; }
     if (!retry) {
       r->info.retries = attempt;
@@ -416,10 +414,9 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
 
 // First-use costs paid up front: the scan kernel compiled for the plan's shape (1-2 s of hipRTC, or milliseconds from the disk
 // cache), the payload projection and the narrow predicate copies a selective query reads (built at once instead of after VH_AUTO_PACK /
-// VH_AUTO_NARROW uses), and — only here — a tuple pool placed by measurement (place_search: bounded to half of the free memory / 48 GB, 8
-// candidates; everything but the winner is released before the call returns). The reference's analogue is Compiler::Compile running when a
+// VH_AUTO_NARROW uses). (Rounds 3-5 also searched for a good place for a big tuple pool here; see vhh_place.h for why that is gone.) The reference's analogue is Compiler::Compile running when a
 // query shape is first seen (src/codegen/compiler.cc:97-144, QueryStats::compile_time); a caller that knows its hot shapes at table-load
-// time runs them through here. The plan is executed (up to three times: a narrow copy, then a projection, then the pool can appear) and
+// time runs them through here. The plan is executed (up to three times: a narrow copy, then a projection can appear) and
 // the last attempt's info is returned, so the caller sees what a steady-state query of this shape will run on.
 extern "C" int vh_table_prepare(vh_table* t, const vh_plan* plan, vh_result_info* info_out) {
   if (!t || !plan) return vh_fail(VH_E_INVALID, "null argument");

@@ -7,6 +7,7 @@ static void merge_args_of(const vh_result* r, VhMergeArgs* A) {
   A->nmetric = P.nmetric; A->nxcd = r->nxcd; A->G = P.G; A->xcd_stride = P.xcd_stride; A->present = P.present;
   A->present_carrier = P.present_carrier;
   for (int j = 0; j < P.nmetric; ++j) { A->state[j] = P.m[j].state; A->sop[j] = P.m[j].sop(); }
+  if (P.part_count && P.nlevel == 1) { A->part_count = P.part_count; A->npart = P.npart; A->agg_shift = P.agg_shift; A->blocks = r->part_blocks; }
 }
 static int merge_copies_now(vh_result* r, hipStream_t st) {
   if (!r->unmerged) return VH_OK;
@@ -73,7 +74,7 @@ int QueryBuild::compile_kernel() {
     js.stage = mode == VH_MODE_DENSE_PART && (P.tw == 2 || P.gid_bits) && !env_no_stage ? (P.npart <= VH_STAGE_PARTS ? VH_STAGE_PARTS : P.npart <= VH_STAGE_PARTS_MAX ? VH_STAGE_PARTS_MAX : 0) : 0;
     // ... or, on a query's first attempt, through the BLOCK's ring writer (vj_part_ring_add): extents by position; a re-run after VH_ERR_PART_FULL — a
     // partition met more than its share and a half of some block's tuples — goes back to the per-wave writers, whose extents are handed out as they fill
-    part_ring = js.stage != 0 && !part_tuples_override && !test_env("VH_NO_PART_RING") && !t->part_clustered.count(r->group_sig);
+    part_ring = js.stage != 0 && !test_env("VH_NO_PART_RING");
     if (part_ring) { js.part_ring = js.stage; js.stage = 0; }
     js.hpart = hpart ? 1 : 0;
     js.bs_off32 = hpart && hp_off32 ? 1 : 0;
@@ -211,7 +212,7 @@ int QueryBuild::decompose_work() {
       r->kernel += hn + jk->name + "_hpagg";
     }
     const std::string pagg = jit_pagg() ? " + " + jk->name + "_pagg" : std::string(" + part_agg_kernel<1024>");
-    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? pagg : ((P.tw == 2 || P.gid_bits) && !test_env("VH_NO_SPLIT_TILE")) ? ((!part_tuples_override && !test_env("VH_NO_SPLIT_RING") && !t->part_clustered.count(r->group_sig) ? std::string(" + part_split_ring_kernel<256, ") : std::string(" + part_split_tile_kernel<256, ")) + (P.gid_bits ? "1>" : "2>") + pagg) : " + part_split_kernel<256>" + pagg;
+    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? pagg : ((P.tw == 2 || P.gid_bits) && !test_env("VH_NO_SPLIT_TILE")) ? ((!test_env("VH_NO_SPLIT_RING") ? std::string(" + part_split_ring_kernel<256, ") : std::string(" + part_split_tile_kernel<256, ")) + (P.gid_bits ? "1>" : "2>") + pagg) : " + part_split_kernel<256>" + pagg;
   }
   int occupancy = 0;
   if (env_bpc <= 0) scan_dispatch(0, &occupancy);
@@ -286,6 +287,20 @@ int QueryBuild::layout_scratch() {
   o_segrows = sp.take(r->plan_words * sizeof(uint32_t));   // [segment snapshot | program | literals]
   size_t o_present = 0, o_hkeys = 0, o_htags = 0;
   size_t o_state[VH_MAX_METRIC];
+  // Phase 2's blocks by the partitions' tuple counts (vh_part_shares): one-level DENSE_PART whose phase 1 goes through the ring writer (it counts), with a
+  // private copy of its range per phase-2 block — then a hot partition may take most of the blocks, and as many copies: room for up to 128 of them
+  // (256 MB of states at most; the merge only reads the copies a partition's blocks wrote). Not for results small enough for the one-block tail.
+  part_balanced = mode == VH_MODE_DENSE_PART && P.nlevel == 1 && jk && jshape.part_ring != 0 && part_bpp > 1 && nxcd == part_bpp && !knobs().skip_phase2 &&
+                  !test_env("VH_NO_PART_BALANCE") &&
+                  !(r->out_cap <= VH_SMALL_TAIL_MAX && (uint64_t)r->out_cap * (uint64_t)nxcd * (uint64_t)std::max(1, (int)P.nmetric) <= VH_SMALL_TAIL_STATES);
+  if (part_balanced) {
+    size_t per_copy = P.xcd_stride;      // presence bytes + states
+    for (int j = 0; j < P.nmetric; ++j) per_copy += P.xcd_stride * (size_t)vh_sop_bytes(P.m[j].sop());
+    const int room = (int)std::max<size_t>(1, ((size_t)256 << 20) / std::max<size_t>(per_copy, 1));
+    nxcd = std::max(nxcd, std::min(std::min(128, room), P.npart * part_bpp));
+    P.nxcd = nxcd; r->nxcd = nxcd;
+  }
+  r->part_blocks = (uint32_t)(P.nfine * part_bpp);
   table_n = mode == VH_MODE_HASH ? capacity + 1 : P.xcd_stride * nxcd;
   // single-word keys: one record per slot = key + every metric state (8-byte states first), so that an insert and its
   // updates touch ONE line of a table that is far bigger than any cache
@@ -325,6 +340,7 @@ int QueryBuild::layout_scratch() {
   }
   // outputs
   size_t o_tuples = 0, o_emiss = 0, o_epart = 0, o_tuples2 = 0, o_emiss2 = 0, o_epart2 = 0, o_l2 = 0;
+  if (part_balanced) o_pcount = sp.take(VH_MAX_PART * sizeof(uint32_t));
   if (hpart) part_tuple_cap = hp_tuple_cap;
   if (mode == VH_MODE_DENSE_PART || hpart) {
     // extent size: big enough that a wave allocates rarely (every allocation is a returning global
@@ -349,13 +365,20 @@ int QueryBuild::layout_scratch() {
     uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
     if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
     if (hpart && hp_fan) max_ext = 64;      // (the scan writes the level-A pool itself: no stream pool to speak of)
-    if (ring1) max_ext = std::min<uint64_t>(((part_tuple_cap + part_tuple_cap / 2) / per1 / ext_tuples + 2) * per1, 0xFFFFFFF0ull);      // every (block, partition) its share and half again, and one more extent
+    // the ring writer's pool: every (block, partition) stream its share of evenly spread tuples and one more extent BY POSITION, and behind those the
+    // shared overflow region — room for all the expected tuples once more, so that ANY skew between the streams fits (one partition taking everything
+    // included); only more survivors than estimated void the attempt, and the re-run is sized for the survivors it counted
+    uint64_t pos1 = 0;
+    if (ring1) { pos1 = part_tuple_cap / per1 / ext_tuples + 1; max_ext = std::min<uint64_t>(pos1 * per1 + part_tuple_cap / ext_tuples + per1 + 64, 0xFFFFFFF0ull); }      // (+ per1: every stream's last, part-filled overflow extent)
     if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS")) max_ext = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS")));   // tests: make the first attempt run out of extents
+    const uint32_t test_levels = test_env("VH_TEST_POS_LEVELS") ? (uint32_t)std::max(0, atoi(test_env("VH_TEST_POS_LEVELS"))) : ~0u;      // tests: few (or no) positional levels — the tuples go through the overflow regions
+    P.slice_levels_cap = test_levels;
+    if (ring1) P.pos_levels = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(pos1, max_ext / per1), test_levels);
     P.max_extents = (uint32_t)max_ext;
     // the scan's waves take their extent chunks by position (no shared cursor, no returning atomics: VhPlanDev::ext_waves). The pool above
     // holds that whenever the waves' tuple counts agree within the 25 % the estimate leaves; a re-run after VH_ERR_PART_FULL goes back to
     // the cursor, which packs the chunks whatever the imbalance
-    P.ext_waves = ring1 || part_tuples_override || test_env("VH_TEST_EXT_CURSOR") || t->part_clustered.count(r->group_sig) ? 0u : (uint32_t)grid * (uint32_t)(BLOCK / 64);
+    P.ext_waves = ring1 || part_tuples_override || test_env("VH_TEST_EXT_CURSOR") ? 0u : (uint32_t)grid * (uint32_t)(BLOCK / 64);
     o_tuples = sp.take(max_ext * ext_stride * P.tw * 8);
     o_emiss = sp.take(max_ext * sizeof(uint16_t));
     o_epart = sp.take(max_ext);
@@ -370,8 +393,9 @@ int QueryBuild::layout_scratch() {
       uint64_t max2 = (part_tuple_cap + part_tuple_cap / 4) / et2 + (uint64_t)P.npart * ((uint64_t)split_bpp * (tiled ? 1 : 4) * (64 + VH_EXT_CHUNK) + 1) + 64;
       // the first attempt splits through the ring writer: every (block, sub-partition) its extents by position, room for its share and a half and one
       // more (part_l2_plan_kernel); a re-run after VH_ERR_PART_FULL — skewed group ids — takes the tiled kernel, whose extents are handed out as they fill
-      split_ring = tiled && !part_tuples_override && !test_env("VH_NO_SPLIT_RING") && !t->part_clustered.count(r->group_sig);
-      if (split_ring) max2 = (part_tuple_cap + part_tuple_cap / 2) / et2 + (uint64_t)P.npart * 64 * split_bpp * 2 + 64;
+      split_ring = tiled && !test_env("VH_NO_SPLIT_RING");
+      // (slices laid out on the device from the partitions' counted tuples — vh_slice_extents: positional extents + an overflow region as big as the count)
+      if (split_ring) max2 = 2 * (part_tuple_cap / et2) + (uint64_t)P.npart * (2 * 64 * split_bpp + 2) + 64;
       if (max2 > 0xFFFFFFF0ull) max2 = 0xFFFFFFF0ull;
       if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS2")) max2 = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS2")));   // tests: the second pool runs out first
       P.max_extents2 = (uint32_t)max2;
@@ -388,16 +412,17 @@ int QueryBuild::layout_scratch() {
       const uint64_t cap = hp_tuple_cap, hp_et = HP_ET / hp_units, hp_es = hp_et + (uint64_t)knobs().ext_pad / hp_units;      // tuples per extent / between extent starts
       // level A: every block may hold an open extent per digit (+ one fresh one per tile boundary); level B: the slices hp_plan_kernel lays out
       uint64_t ma = ((cap / hp_et) / g_ctx.num_cu * 3 / 2 + 2 * HP_FAN + 16) * g_ctx.num_cu;      // one slab per block: its share of the tuples and half again, an open extent per digit, one more per digit for the tails
-      if (hp_fan) {       // extents by position: extent k of (scan block, digit) is k * blocks * 256 + block * 256 + digit — room for half again a (block, digit)'s share, and one more
-        const uint64_t per = (uint64_t)grid * HP_FAN;
-        ma = ((cap + cap / 2) / per / hp_et + 2) * per;
-        if (test_env("VH_TEST_PART_EXTENTS")) ma = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS")));      // tests: the first attempt's pool is too small for its positions
+      if (hp_fan) {       // extents by position: extent k of (scan block, digit) is k * blocks * 256 + block * 256 + digit — a (block, digit)'s share and one more —, then the shared overflow region: all the tuples once more
+        const uint64_t per = (uint64_t)grid * HP_FAN, posa = cap / per / hp_et + 1;
+        ma = posa * per + cap / hp_et + per + 64;
+        if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS")) ma = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS")));      // tests: the first attempt's pool is too small
+        P.pos_levels2 = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(posa, ma / per), test_env("VH_TEST_POS_LEVELS") ? (uint64_t)std::max(0, atoi(test_env("VH_TEST_POS_LEVELS"))) : ~0ull);
       }
       uint64_t mb = cap / hp_et + (uint64_t)HP_FAN * (2 * HP_FAN + 9) + 64;
       if (hp_fan) {       // level B by position too: hp_plan_kernel's slices, every (writing block, digit) of a partition its share and half again, and two more extents
         hp_ring_nb = 1;      // (level-B blocks per partition. Measured, C5: two or four of them write level B no faster — 0.425 / 0.421 / 0.397 ms — and leave the
                              //  aggregation two or four extents per range to walk: 1.08 / 1.24 / 1.69 ms)
-        mb = (cap + cap / 2) / hp_et + (uint64_t)HP_FAN * HP_FAN * 2 * hp_ring_nb + 64;
+        mb = 2 * (cap / hp_et) + (uint64_t)HP_FAN * (2 * HP_FAN * hp_ring_nb + 2) + 64;      // (the slices' positional extents + their overflow regions: vh_slice_extents)
       }
       if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS2")) mb = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS2")));   // tests: the last pool runs out
       hpo[k].maxa = ma; hpo[k].maxb = mb;
@@ -429,29 +454,7 @@ int QueryBuild::layout_scratch() {
       o_dkeys[b] = sp.take(cap * 8);
     }
   }
-  {
-    VhPlaceHint ph;        // (only looked at when the scratch buffer has to be allocated anew)
-    if ((mode == VH_MODE_DENSE_PART || hpart) && P.nslots > 0) {
-      const int gs = P.ngroup > 0 ? (int)P.g[0].slot() : 0;
-      for (int q = 0; q < P.npred && q < 4; ++q) { const int ps = (int)P.pred_slot[q]; ph.stream_src[q] = P.colbase[ps]; ph.stream_bytes[q] = (size_t)nseg * P.colstride[ps]; ph.nstream = q + 1; }
-      if (!ph.nstream) { ph.stream_src[0] = P.colbase[gs]; ph.stream_bytes[0] = (size_t)nseg * P.colstride[gs]; ph.nstream = 1; }
-      ph.gather_src = P.colbase[gs]; ph.gather_bytes = (size_t)nseg * P.colstride[gs];
-      ph.gather_bytes -= std::min<size_t>(ph.gather_bytes, 256);      // (a projection's column starts inside its first record)
-      ph.pool_off = o_tuples; ph.pool_bytes = (size_t)P.max_extents * (size_t)P.ext_stride * P.tw * 8;
-    }
-    if (sp.off > x->scratch_bytes && ph.pool_bytes >= ((size_t)128 << 20) && !t->derived_tried && g_preparing && knobs().place_trials >= 2 && (!t->packs.empty() || !t->narrows.empty())) {
-      t->derived_tried = true;
-      bool moved = false;
-      rc = place_with_derived(t, x, sp.off, ph, &moved);
-      if (rc) { return rc; }
-      if (moved) {       // the plan built so far holds the old addresses of the derived layouts: once more from the top (the scratch buffer is in place)
-        holder.reset();
-        done = true;
-        return query_launch_locked(t, x, p, out, hash_capacity_override, force_hash, part_tuples_override, no_part, plan_only, summary_out, ag, device_rows, hp_passes_override, no_hpart);
-      }
-    }
-    rc = ensure_scratch(x, sp.off, &ph);
-  }
+  rc = ensure_scratch(x, sp.off);
   if (rc) { return rc; }
   S = x->scratch;
   P.counters = reinterpret_cast<unsigned long long*>(S + o_counters);
@@ -466,6 +469,7 @@ int QueryBuild::layout_scratch() {
   }
   for (int j = 0; j < P.nmetric; ++j) P.m[j].state = S + o_state[j];
   r->d_out_count = reinterpret_cast<unsigned long long*>(S + o_outcount);
+  P.part_count = part_balanced ? reinterpret_cast<uint32_t*>(S + o_pcount) : nullptr;
   if (mode == VH_MODE_DENSE_PART || hpart) {
     P.tuples = reinterpret_cast<uint64_t*>(S + o_tuples);
     P.extent_missing = reinterpret_cast<uint16_t*>(S + o_emiss);
@@ -539,7 +543,7 @@ int QueryBuild::launch() {
   }
   // (DENSE_PART whose blocks each keep a private copy of their range store EVERY group of every copy, present or not: clearing 19
   // copies of C3's tables, 30 MB, before every query was two thirds of this launch's 17 us. A range's sole block stores present groups only.)
-  const bool part_owned = mode == VH_MODE_DENSE_PART && part_bpp > 1 && nxcd == part_bpp && !knobs().skip_phase2 && P.total_units != 0;      // (no units: phase 2 does not run and nobody stores the copies — they are cleared like any table)
+  const bool part_owned = mode == VH_MODE_DENSE_PART && part_bpp > 1 && (nxcd == part_bpp || part_balanced) && !knobs().skip_phase2 && P.total_units != 0;      // (no units: phase 2 does not run and nobody stores the copies — they are cleared like any table)
   if (zero_end > zero_begin && !part_owned) clear(S + zero_begin, zero_end - zero_begin, 0);
   r->zero_begin = S + zero_begin; r->zero_end = S + zero_end;
   for (int b = 0; b < P.nbitset && !hpart; ++b) {
@@ -554,7 +558,7 @@ int QueryBuild::launch() {
     HA.passes = P.hp_passes; HA.gslots = P.hp_gslots; HA.sslots = P.hp_sslots; HA.keys_off = P.hp_keys_off; HA.set_off = P.hp_set_off;
     HA.bitset_j = -1;
     for (int j = 0; j < P.nmetric; ++j) if (P.m[j].sop() == SOP_BITSET) HA.bitset_j = j;
-    HA.list_cap = capacity; HA.chunk = hp_chunk; HA.ablate = knobs().hp_ablate;
+    HA.list_cap = capacity; HA.chunk = hp_chunk; HA.ablate = knobs().hp_ablate; HA.slice_levels_cap = P.slice_levels_cap;
     // no HAVING and no top-N to look at the groups first: the aggregation kernel emits them itself (C5: no 0.85 GB list, no 0.85 ms kernel)
     HA.direct = r->hp_direct ? 1 : 0; HA.ngroup = P.ngroup; HA.out_count = r->d_out_count;
     HA.nchunks = r->hp_chunks; HA.chunk_rows = r->hp_chunk_rows;
@@ -570,6 +574,11 @@ int QueryBuild::launch() {
       K.a.max_extents = (uint32_t)std::min<uint64_t>(hpo[k].maxa, 0xFFFFFFF0ull); K.a.cursor = nullptr;      // (handed out in one slab per block of level A)
       K.b.tuples = reinterpret_cast<uint64_t*>(S + hpo[k].tb); K.b.fill = reinterpret_cast<uint16_t*>(S + hpo[k].fb); K.b.tag = reinterpret_cast<uint8_t*>(S + hpo[k].gb);
       K.b.max_extents = (uint32_t)std::min<uint64_t>(hpo[k].maxb, 0xFFFFFFF0ull); K.b.cursor = nullptr;
+      K.a.ovf_base = K.a.max_extents; K.a.ovf_cursor = nullptr; K.b.ovf_base = K.b.max_extents; K.b.ovf_cursor = nullptr; K.z.ovf_base = 0; K.z.ovf_cursor = nullptr;
+      if (hp_fan) {       // pool a behind its positional levels: the shared overflow region the scan's writer takes extents from (counters[10])
+        K.a.ovf_base = (uint32_t)std::min<uint64_t>((uint64_t)P.pos_levels2 * (uint64_t)grid * HP_FAN, K.a.max_extents);
+        K.a.ovf_cursor = P.counters + 10;
+      }
       if (hp_fan) {       // the scan kernel's view of pool a (the second pool's fields of the plan: DENSE_PART's two-level plans are the other user)
         P.tuples2 = K.a.tuples; P.extent_missing2 = K.a.fill; P.extent_part2 = K.a.tag; P.max_extents2 = K.a.max_extents; P.ext_tuples2 = (int32_t)K.a.stride;
       }
@@ -582,6 +591,7 @@ int QueryBuild::launch() {
     d_hpargs = reinterpret_cast<VhHpArgs*>(S + o_hpargs);
     HIP_TRY(hipMemcpyAsync(d_hpargs, &HA, sizeof(HA), hipMemcpyHostToDevice, st));
   }
+  if (part_balanced) clear(P.part_count, VH_MAX_PART * sizeof(uint32_t), 0);
   if (mode == VH_MODE_DENSE_PART || hpart) {
     clear(P.extent_missing, (size_t)P.max_extents * sizeof(uint16_t), 0);
     clear(P.extent_part, (size_t)P.max_extents, 0xFF);
@@ -592,7 +602,7 @@ int QueryBuild::launch() {
     }
   }
   for (int j = 0; j < P.nmetric; ++j) {
-    if (P.m[j].ident == 0 || P.hrec_bytes || hpart) continue;
+    if (P.m[j].ident == 0 || P.hrec_bytes || hpart || part_owned) continue;      // (part_owned: phase 2's blocks store every group of every copy that is read)
     rc = fill_states(P.m[j].state, table_n, vh_sop_bytes(P.m[j].sop()), P.m[j].ident, st);
     if (rc) { return rc; }
   }
@@ -608,7 +618,7 @@ int QueryBuild::launch() {
   for (int k = 0; k < P.npred; ++k) narrowed |= P.pred_width[k] != 4;
   if (jk) { narrowed = jshape.pp_nplanes || jshape.pp_sliced; for (int k = 0; k < jshape.npred; ++k) narrowed |= jshape.pred[k].width != vh_elem_size(jshape.pred[k].type); }
   r->hpart = hpart;
-  r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0) | (hpart && hp_pack ? 256 : 0) | ((mode == VH_MODE_DENSE_PART || hpart) && x->scratch_placed ? 512 : 0) | (mode == VH_MODE_DENSE_PART && P.gid_bits ? 1024 : 0) | (jk && (jshape.pp_nplanes || jshape.pp_sliced) ? 2048 : 0) | (jk && jshape.qpay ? 4096 : 0) | (jk && jshape.pp_sliced ? 8192 : 0);
+  r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0) | (hpart && hp_pack ? 256 : 0) | (mode == VH_MODE_DENSE_PART && P.gid_bits ? 1024 : 0) | (jk && (jshape.pp_nplanes || jshape.pp_sliced) ? 2048 : 0) | (jk && jshape.qpay ? 4096 : 0) | (jk && jshape.pp_sliced ? 8192 : 0);
   if (r->hp_chunks) memset(x->h_chunk, 0, VH_HP_CHUNKS * sizeof(unsigned long long));      // (what the context's previous query left there)
   if (P.total_units) {
     scan_dispatch(grid, nullptr);

@@ -208,6 +208,7 @@ struct QueryBuild {
   bool fast = false, fastj = false, lanes = false;
   uint64_t part_tuple_cap = 0;
   int nxcd = 1, part_bpp = 1;
+  bool part_balanced = false; size_t o_pcount = 0;      // phase 2's blocks by the partitions' tuple counts (layout_scratch)
   uint64_t capacity = 0;
   bool hpart = false;
   uint64_t hp_tuple_cap = 0;
@@ -1151,7 +1152,7 @@ int QueryBuild::plan_hashed_partitioning() {
         // the scan partitions 256 ways by itself (one 1024-thread block per CU, extents by position): the first attempt of a query; a re-run after
         // VH_ERR_PART_FULL — some (block, digit) met far more tuples than its share: skewed keys — goes through the stream pool and level A,
         // whose extents are handed out as they fill
-        hp_fan = !part_tuples_override && !test_env("VH_NO_HP_FAN") && knobs().ext_pad % 8 == 0 && !t->part_clustered.count(r->group_sig);      // (a shape whose hot key overflowed its positions before starts with the stream pool)
+        hp_fan = !test_env("VH_NO_HP_FAN") && knobs().ext_pad % 8 == 0;
         lanes = false;
         P.hpart = 1; P.gid_shift = 32;
         P.npart = 1; P.part_shift = 0; P.nlevel = 1; P.agg_shift = 0; P.nfine = 1;      // (the scan kernel writes ONE stream per kind; vh_hpart.h partitions it)

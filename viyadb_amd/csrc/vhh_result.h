@@ -67,6 +67,7 @@ extern "C" int vh_segment_stats(vh_table* t, uint32_t seg, int32_t col, vh_anynu
 // ------------------------------------------------------------------ results
 struct vh_result {
   bool hpart = false;               // hashed partitioning ran: the table is a compact list of group records ...
+  uint32_t part_blocks = 0;         // DENSE_PART: blocks of the phase-2 launch (what vh_part_shares shares out)
   bool by_position = false;         // this attempt's tuples went through the ring writer: extents by position (a skewed shape overflows them with room to spare)
   uint64_t pos_capacity = 0;        // ... and the tuples the smallest such pool holds
   bool hp_direct = false;           // ... or its aggregation kernel already wrote the output columns (no emission kernel to run)

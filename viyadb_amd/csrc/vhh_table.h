@@ -23,7 +23,7 @@ struct VhSegStat {          // order keys as produced by seg_minmax_kernel
 // never reused under it.
 struct VhExec {
   hipStream_t own_stream = nullptr;
-  char* scratch = nullptr; size_t scratch_bytes = 0; bool scratch_placed = false;      // placed: chosen among candidates by vh_table_prepare (place_search)
+  char* scratch = nullptr; size_t scratch_bytes = 0;
   uint32_t* h_segrows = nullptr; size_t h_segrows_cap = 0;
   unsigned long long* h_counters = nullptr;     // pinned: 16 words of counters + 64 words for a big result's header
   char* d_sample = nullptr; size_t d_sample_bytes = 0;   // selectivity probe: counters + presence + seg rows
@@ -117,7 +117,6 @@ struct vh_table {
   std::vector<std::unique_ptr<VhNarrow>> narrows;
   std::vector<std::unique_ptr<VhPredPack>> predpacks;
   std::map<std::string, uint32_t> ppred_seen;             // predicate column set -> compiled-kernel queries that filtered on it (automatic predicate projections)
-  bool derived_tried = false;                   // place_with_derived ran (once per table)
   std::map<int, uint32_t> pred_seen;                     // column -> queries that filtered on it (automatic narrow copies)
   std::vector<uint64_t> seg_mod;                          // sync_epoch of the last change to a segment's columns
   // Derived layouts follow the arenas by ROW RANGE: every sync appends what it touched; a layout that was current at epoch e re-derives the

@@ -72,7 +72,7 @@ static const char* test_env(const char* name) {
 }
 struct VhKnobs {
   bool trace_alloc, no_topk, no_stage, jit_verbose, skip_phase2, no_direct_emit, times, no_jit_pagg, predpack_bytes;
-  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, split_bpc, bw_blocks_per_cu, place_trials, place_gb, hp_list, hp_stream, hp_regions, hp_agg_waves, deliver_blocks;
+  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, split_bpc, bw_blocks_per_cu, hp_list, hp_stream, hp_regions, hp_agg_waves, deliver_blocks;
   double hp_load_g, hp_load_s, qpay_min_sel;
 };
 static const VhKnobs& knobs() {
@@ -87,7 +87,7 @@ static const VhKnobs& knobs() {
     x.auto_narrow = num("VH_AUTO_NARROW", 3); x.auto_pack = num("VH_AUTO_PACK", 3);
     x.jit_ablate = num("VH_JIT_ABLATE", 0); x.hp_ablate = num("VH_HP_ABLATE", 0); x.hp_bpp = num("VH_HP_BPP", 0); x.pack_plain = num("VH_PACK_PLAIN", 0);
     x.lanes_block = num("VH_LANES_BLOCK", 0); x.blocks_per_cu = num("VH_BLOCKS_PER_CU", 0); x.unit_rows = num("VH_UNIT_ROWS", 0); x.grid = num("VH_GRID", 0);
-    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.place_trials = num("VH_PLACE_TRIALS", 4); x.place_gb = std::max(1, num("VH_PLACE_GB", 16)); x.hp_list = num("VH_HP_LIST", 0);
+    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.hp_list = num("VH_HP_LIST", 0);
     x.hp_agg_waves = num("VH_HP_AGG_WAVES", 0);
     x.hp_regions = num("VH_HP_REGIONS", 0);           // regions (row counters) of a big hashed-partitioning result written in ONE launch (0: off — measured: C5 14.4 vs 13.9 ms per query, the row counter is not what the aggregation waits for; profiles/r05/NOTES.md)
     x.hp_stream = num("VH_HP_STREAM", 0);             // chunk launches of a streamed result (0: off — measured: the link, not the wait for the kernels, bounds the delivery; profiles/r04/NOTES.md)
