@@ -62,16 +62,6 @@ def scan_wrote_level_a(res):
     return res.kernel.count("scatter_kernel") == 1 and "hp_ring_scatter_kernel" in res.kernel
 
 
-class stream_pool_form:
-    """The older form — tuples appended to a stream pool, level A as a scatter launch of its own — is what a re-run after
-    VH_ERR_PART_FULL takes; the hook asks for it on the first attempt."""
-    def __enter__(self):
-        os.environ["VH_NO_HP_FAN"] = "1"
-
-    def __exit__(self, *a):
-        del os.environ["VH_NO_HP_FAN"]
-
-
 @pytest.mark.parametrize("pack", [True, False])
 @pytest.mark.parametrize("max_ids", [0, 1, 2, 3, 7])
 def test_rows_with_any_number_of_ids(max_ids, pack):
@@ -85,10 +75,6 @@ def test_rows_with_any_number_of_ids(max_ids, pack):
         took_hpart(res)
         assert res.hp_packed == pack and ("scatter_kernel<1024, 1>" in res.kernel) == pack and ("scatter_kernel<1024, 2>" in res.kernel) == (not pack), res.kernel
         assert res.retries == 0 and res.ngroups == st.ngroups > 2000 and scan_wrote_level_a(res), res.kernel
-        with stream_pool_form():
-            res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["users", "count"], "filter": F("lt", "x", "70")}, flags=HP | (0 if pack else capi.PLAN_NO_HP_PACK))
-        took_hpart(res)
-        assert res.retries == 0 and res.ngroups == st.ngroups and not scan_wrote_level_a(res), res.kernel
         res, _ = run(tab, dt, {"dimensions": ["c"], "metrics": ["users"]}, flags=HP)          # few groups, many ids each: sets fill up -> more passes
         assert res.path == "hash"
     finally:

@@ -41,7 +41,7 @@ def test_c3_table_organisations_compiled(flags, path):
 @pytest.mark.parametrize("table_kb,flags", [(32, 64), (16, 64), (32, 64 | 8192), (8, 64), (8, 64 | 32)])
 def test_c3_with_17_to_64_partitions_compiled(table_kb, flags):
     """Group-id spaces of 17-64 LDS-sized ranges (VH_PART_TABLE_KB shrinks the ranges: 38 / 75 -> two levels / 150 partitions' worth):
-    the compiled phase 1 keeps a waiting line per partition for up to 64 of them (vh_part_staged_add<64>), one level or two."""
+    the compiled phase 1 keeps waiting lines per partition for up to 64 of them (the block's ring writer, vj_part_ring_add with J::PART_RING = 64), one level or two."""
     import os
     from viyadb_amd import synth
     os.environ["VH_PART_TABLE_KB"] = str(table_kb)

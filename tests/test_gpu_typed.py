@@ -239,22 +239,12 @@ def test_two_level_partitioning():
         # four metrics (wide tuples), MIN / MAX states
         res, _ = run(tab, dt, dict(q, metrics=["v", "count", "lo", "hi"]), flags=64)
         assert "part_split_" in res.kernel
-        # two-word tuples take the block-tile split; the tuple-by-tuple form (what wider tuples run) on request
-        os.environ["VH_NO_SPLIT_TILE"] = "1"
-        try:
-            res, _ = run(tab, dt, q, flags=64 | 128)
-            assert "part_split_kernel<256>" in res.kernel, res.kernel
-        finally:
-            del os.environ["VH_NO_SPLIT_TILE"]
-        # ... and the split itself: through the ring writer (extents by position, no barriers) unasked, the tiled kernel on request and on re-runs
+        # one- and two-word tuples are split through the ring writer (extents by position + the slices' overflow regions, no barriers); wider tuples
+        # (four metrics above) tuple by tuple
         res, _ = run(tab, dt, q, flags=64 | 128)
         assert "part_split_ring_kernel" in res.kernel and res.retries == 0, (res.kernel, res.retries)
-        os.environ["VH_NO_SPLIT_RING"] = "1"
-        try:
-            res, _ = run(tab, dt, q, flags=64 | 128)
-            assert "part_split_tile_kernel" in res.kernel and res.retries == 0, (res.kernel, res.retries)
-        finally:
-            del os.environ["VH_NO_SPLIT_RING"]
+        res, _ = run(tab, dt, dict(q, metrics=["v", "count", "lo", "hi"]), flags=64)
+        assert "part_split_kernel<256>" in res.kernel, res.kernel
         # either pool too small at first: the query re-plans with more room
         for var in ("VH_TEST_PART_EXTENTS", "VH_TEST_PART_EXTENTS2"):
             os.environ[var] = "50"
@@ -307,8 +297,7 @@ def test_two_level_partitioning():
 def test_few_partitions_every_row_passing_through_the_ring_writer():
     """Three LDS-sized ranges and no filter: every drain of 64 survivors puts ~21 tuples into each of three partitions — more than the two waiting lines
     per partition hold — so lanes of one call take their ring places in rounds, a line's owner flushes while later lanes of the same call still wait,
-    and four waves of a block do so at once (vh_ring_add_tb's `gen` / `done` counters at their busiest). One-word and two-word tuples, compiled kernel;
-    the per-wave writer on the same plan for comparison of nothing but the answers."""
+    and four waves of a block do so at once (vh_ring_add_tb's `gen` / `done` counters at their busiest). One-word and two-word tuples, compiled kernel."""
     import os
     from viyadb_amd import capi
     rng = np.random.default_rng(77)
@@ -324,12 +313,6 @@ def test_few_partitions_every_row_passing_through_the_ring_writer():
         for flags in (capi.PLAN_FORCE_PART | capi.PLAN_FORCE_JIT | capi.PLAN_NO_LANES, capi.PLAN_FORCE_PART | capi.PLAN_FORCE_JIT | capi.PLAN_NO_LANES | capi.PLAN_NO_NARROW_TUPLES):
             res, st = run(tab, dt, q, flags=flags)
             assert res.path == "dense_part" and res.jit and res.retries == 0 and res.ngroups == st.ngroups == 22500, (res.path, res.kernel, res.retries, res.ngroups)
-            os.environ["VH_NO_PART_RING"] = "1"
-            try:
-                res, _ = run(tab, dt, q, flags=flags)
-            finally:
-                del os.environ["VH_NO_PART_RING"]
-            assert res.path == "dense_part" and res.retries == 0
     finally:
         dt.close()
 

@@ -29,8 +29,8 @@ SHAPES = {0: "C3: narrow predicate copies, record gathers, tuples for DENSE_PART
           14: "C3 with bit-sliced predicate columns (22 planes of one bit per row, comparisons bit-serial on 32 rows per lane)",
           15: "C5 (32-byte tuples) whose scan writes the level-A pool itself: 1024-thread blocks, waiting lines per digit in LDS",
           16: "C5 (packed 16-byte tuples) whose scan writes the level-A pool itself",
-          18: "C3 with one-word tuples leaving through the block's ring writer (16 partitions' waiting lines per block, extents by position)",
-          19: "C3 with two-word tuples leaving through the block's ring writer"}
+          18: "C3 with one-word tuples (= shape 9: every DENSE_PART tuple of one or two words leaves through the block's ring writer)",
+          19: "C3 with two-word tuples (= shape 0)"}
 
 
 def _compile(which, tmp_path):
@@ -88,7 +88,7 @@ def test_compiles_with_the_hiprtc_a_torch_process_carries():
     assert p.returncode == 0, p.stderr[-3000:]
 
 
-RING_SHAPES = (15, 16, 18, 19)      # every selftest shape whose tuples leave through the block's ring writer (vh_ring_add_tb): C5's scan-written level A
+RING_SHAPES = (0, 7, 9, 10, 12, 13, 14, 15, 16)     # every selftest shape whose tuples leave through the block's ring writer (vh_ring_add_tb): C5's scan-written level A
                                     # with 32- and 16-byte tuples, C3's phase 1 with one- and two-word tuples
 
 

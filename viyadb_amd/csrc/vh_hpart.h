@@ -8,56 +8,48 @@
 // group key until one partition's groups fit LDS, then aggregate there with LDS atomics only. Sequential traffic of 16 bytes per
 // tuple and level instead of a 128-byte line read and written per update.
 //
-// TWO FORMS of the passes between the scan and the aggregation. A query's first attempt (round 5): the scan block writes level A ITSELF and
-// level B is one barrier-free pass (hp_ring_scatter_kernel), both through the ring writer of vh_kernels.h (vh_ring_add: per digit a tuple counter
-// and two waiting 128-byte lines in LDS, a tuple's number says where it goes, extents by POSITION, whole lines) — tuples are written twice and
-// read twice. A re-run after VH_ERR_PART_FULL (a hot key overflowed a (block, digit)'s positions; the table remembers the shape) takes the older
-// form described below — a stream pool and two tiled scatter levels whose extents are handed out as they fill: written three times, read three times.
+// The passes, all through the block-shared ring writer of vh_kernels.h (vh_ring_add: per digit a tuple counter and two waiting 128-byte lines in
+// LDS, a tuple's number says where it goes, whole lines only; a stream's first extents by POSITION, what it holds beyond them — a hot key —
+// out of its pool's shared overflow region). Tuples are written twice and read twice. (Rounds 3-5 also kept an older form — an unpartitioned
+// "stream" pool behind the scan and two tiled scatter levels whose extents were handed out as they filled: written and read three times — as
+// the re-run target after a hot key overflowed the positions; with the overflow regions inside the kernels it has no caller left and is gone.)
 //
 //   scan kernel (compiled per plan, vh_jit_body.h): a survivor becomes a TUPLE. Without a bitset metric: 16 bytes, (mixed key, payload
 //     word) — the mixed key is a bijection of the packed 64-bit group key (vh_splitmix64 / vh_unmix64), so equal keys always travel
 //     together and no key is ever compared through a lossy hash. With one: 32 bytes, (mixed key, payload, two ids, how many of them
-//     count | "ids only"); a row with more than two ids sends further "ids only" tuples of the same key. ONE stream, one trip through
-//     the scatter levels and one insert per row in the aggregation (round 3 first sent the ids as a second stream of 16-byte pair
-//     tuples: twice the tuples to count, sort and look up for the same bytes). Appended, unpartitioned, 1-2 KiB per wave store, to
-//     64 KB extents (the "stream" pool).
-//   hp_scatter_kernel, twice: a block takes source extents (64 KB of tuples) as a tile, sorts it by 8 bits of the mixed key in LDS
-//     (histogram, prefix, scatter) and appends each digit's run to the digit's open extent in the destination pool IN WHOLE 128-BYTE
-//     LINES: a run's tail of less than a line waits in LDS for the next tile (round 3 measured partial-line tuple writes at 2.3x the cost of
-//     whole lines). Level A: stream -> 256 partitions by bits 63..56. Level B: partition a -> 256 ranges by bits 55..48, into slice a
-//     of the destination pool (sized on the device from what level A produced), so that the last kernel finds a range's extents by
-//     looking at a few hundred tags.
-//   hp_aggregate_kernel: 65 536 ranges of (at C5's size) ~550 groups. A block per range: tuples -> open-addressing table in LDS (keys
-//     = mixed keys, 64-bit LDS compare-and-swap; states as in every other LDS table), their ids -> (group slot, id) set in LDS, first
-//     sight bumping the group's cardinality; the range's groups leave as records (original key = vh_unmix64, states) for a compact list
-//     in HBM that the ordinary emission kernel reads (VhEmitArgs::n_dev). No global atomics except one list cursor per block and range.
-//     Ranges whose groups would not fit the tables are worked through in `passes` sub-ranges (the next bits of the mixed key).
+//     count | "ids only") — or 16 when the values fit (PACKED tuples) —; a row with more than two ids sends further "ids only" tuples of the
+//     same key. ONE stream, one trip through the levels and one insert per row in the aggregation. The scan block writes level A ITSELF
+//     (vj_fan_add): 256 partitions by bits 63..56 of the mixed key, one 1024-thread block per CU sharing the 256 digits' waiting lines.
+//   hp_count_kernel / hp_plan_kernel: the slices of the last pool, sized on the device from what level A holds per partition.
+//   hp_ring_scatter_kernel, level B: partition a -> 256 ranges by bits 55..48, into slice a. Block a reads digit a's extents of pool a where
+//     they lie (by position; the overflow region's by tag), every wave on its own, four tuples in flight per lane: no tile, no histogram,
+//     no block barrier between the first load and the last store.
+//   hp_aggregate_body (compiled per plan next to the scan: `<kernel>_hpagg`): 65 536 ranges of (at C5's size) ~550 groups. A block per
+//     range: tuples -> open-addressing table in LDS (keys = mixed keys, 64-bit LDS compare-and-swap; states as in every other LDS table),
+//     their ids -> (group slot, id) set in LDS, first sight bumping the group's cardinality; the range's groups leave straight into the
+//     result's output columns, or as records for a compact list that the ordinary emission kernel reads when HAVING / top-N must see
+//     them first. Ranges whose groups would not fit the tables are worked through in `passes` sub-ranges (the next bits of the mixed key).
 #pragma once
 #include "vh_kernels.h"
 
-#define HP_ET 4096            // 16-byte units per extent (64 KB): 4096 plain tuples or 2048 tuples that carry ids; a tile's run of one digit fits
-                              // what is left of an extent plus one fresh extent
+#define HP_ET 4096            // 16-byte units per extent (64 KB): 4096 plain tuples or 2048 tuples that carry ids
 #define HP_FAN 256            // partitions per level
-#define HP_CARRY 8            // 16-byte units of LDS per digit for the run tail that waits for the next tile (less than a 128-byte line ever waits)
-#define HP_LIST 1024          // source extents a block remembers at a time
 #define VH_HP_CHUNKS 8         // chunk launches of the aggregation when a big result is delivered while it is produced (a divisor of HP_FAN)
 
-struct VhHpPool {             // extents of HP_ET 16-byte tuples
+struct VhHpPool {             // extents of HP_ET 16-byte units of tuples, written through the ring writer
   uint64_t* tuples;
-  uint16_t* fill;             // tuples in the extent; 0: never used. (The stream pools, written by the scan kernel, keep the older
-  uint8_t* tag;               //  convention instead: fill = HP_ET - missing[e], tag 0xFF = never opened.)
+  uint16_t* fill;             // tuples in the extent; 0: never used
+  uint8_t* tag;               // the digit whose tuples the extent holds
   uint32_t max_extents;
-  uint32_t stride;            // tuples from one extent's first place to the next one's: HP_ET, or a line more (pools a, b: a block keeps an extent open
-                              // per digit and fills them at the same pace — 64 KB apart, its stores of the moment would agree in the address
-                              // bits that pick the HBM channel; VhPlanDev::ext_stride is the same remedy for DENSE_PART)
-  uint32_t stream;            // 1: a stream pool (see above)
-  unsigned long long* cursor; // extents handed out (stream pools: the scan kernel's allocation counter)
-  uint32_t ovf_base;          // a pool written through the ring writer by position: where its shared overflow region starts ...
+  uint32_t stride;            // tuples from one extent's first place to the next one's: HP_ET, or a line more (a block keeps an extent open per
+                              // digit and fills them at the same pace — 64 KB apart, its stores of the moment would agree in the address bits
+                              // that pick the HBM channel; VhPlanDev::ext_stride is the same remedy for DENSE_PART)
+  uint32_t ovf_base;          // where the pool's shared overflow region starts (pool a; pool b's slices carry their own) ...
   unsigned long long* ovf_cursor;   // ... and how many extents of it were taken (nullptr: no such region). Found by their tags.
 };
-struct VhHpKind {             // the three pools of the tuples
-  VhHpPool z, a, b;
-  uint32_t* slice;            // [HP_FAN + 1] first extent of partition a's slice of pool b; [HP_FAN + 1 + a]: extents handed out of it
+struct VhHpKind {             // the two pools of the tuples
+  VhHpPool a, b;
+  uint32_t* slice;            // [HP_FAN + 1] first extent of partition a's slice of pool b; [HP_FAN + 1 + a]: extents of it in use (the positional ones + the overflow extents taken)
   uint32_t* count;            // [HP_FAN] tuples per level-A digit (hp_count_kernel)
 };
 struct VhHpArgs {
@@ -101,18 +93,6 @@ static inline int vh_hpart_bpp(int num_cu, size_t agg_lds) {
 typedef uint64_t hp_u64x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t hp_u32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ uint32_t hp_pool_fill(const VhHpPool& Q, uint32_t e, uint32_t et) {      // et: tuples per extent
-  if (Q.stream) return Q.tag[e] == 0xFF ? 0u : et - Q.fill[e];
-  return Q.fill[e];
-}
-__device__ __forceinline__ uint32_t hp_pool_used(const VhHpPool& Q) {
-  if (!Q.cursor) return Q.max_extents;      // (a pool handed out in slabs or slices: every extent may hold something)
-  const unsigned long long c = *Q.cursor;
-  return c < Q.max_extents ? (uint32_t)c : Q.max_extents;
-}
-
-// ------------------------------------------------------------------ scatter: one level of the partitioning
-// grid: level A any number of blocks (they share the stream's extents round-robin); level B HP_FAN blocks, block a owning partition a.
 // U = 16-byte units per tuple (1 or 2). Everything below counts TUPLES: an extent holds HP_ET / U of them, a 128-byte line 8 / U.
 template <int U> struct alignas(16) HpTuple { hp_u64x2 v[U]; };
 template <int U> __device__ __forceinline__ HpTuple<U> hp_load_nt(const HpTuple<U>* p) {
@@ -121,210 +101,8 @@ template <int U> __device__ __forceinline__ HpTuple<U> hp_load_nt(const HpTuple<
   for (int u = 0; u < U; ++u) t.v[u] = __builtin_nontemporal_load(&p->v[u]);
   return t;
 }
-struct HpScatterLds {
-  uint32_t hist[HP_FAN], offs[HP_FAN], carry_n[HP_FAN], cur[HP_FAN];
-  uint32_t ext_a[HP_FAN], fill_a[HP_FAN];                                                  // per digit: the open extent and the tuples already in it
-  uint32_t tail[HP_FAN];                                                                   // this tile: tuples of the digit's run that will wait for the next one
-  // ... and what the write-out loop needs per tuple, in ONE 16-byte LDS read instead of six 4-byte ones (the kernel is bound by LDS
-  // instructions): x = first place of the run in `sorted` | whole-line tuples of the run << 16, y = room left in the open extent,
-  // z = tuple index of the open extent's next free place, w = tuple index of the fresh extent behind it MINUS room (wrapping)
-  alignas(16) uint32_t meta[HP_FAN][4];
-  uint32_t wave_tot[4];
-  uint32_t nlist, list[HP_LIST];
-  uint32_t ntiles, alloc;
-  uint16_t lfill[HP_LIST], lpre[HP_LIST], tfirst[HP_LIST + 1];     // tuples of a listed extent, tuples before it in its tile, first entry of tile t
-  uint8_t sdigit[HP_ET + HP_FAN * HP_CARRY];
-};
-__host__ __device__ __forceinline__ size_t hp_scatter_lds_bytes() {      // (the same for both tuple sizes: a tile is 64 KB of tuples)
-  return sizeof(HpScatterLds) + (size_t)(HP_ET + HP_FAN * HP_CARRY) * 16 + (size_t)HP_FAN * HP_CARRY * 16 + 64;
-}
 
-template <int BLOCK, int U>
-__global__ __launch_bounds__(BLOCK) void hp_scatter_kernel(const VhHpArgs* __restrict__ HA, int level, unsigned long long* counters) {
-  typedef HpTuple<U> T;
-  constexpr uint32_t ET = HP_ET / U, LINE = 8 / U, CARRY = HP_CARRY / U;      // tuples per extent / per 128-byte line / waiting slots per digit
-  constexpr int R = (int)(ET / BLOCK);                                       // tuples of a tile per thread
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  HpScatterLds& S = *reinterpret_cast<HpScatterLds*>(lds);
-  T* const sorted = reinterpret_cast<T*>(lds + (sizeof(HpScatterLds) + 15) / 16 * 16);
-  T* const carry = sorted + (ET + HP_FAN * CARRY);
-  const VhHpKind& K = HA->k[0];
-  const VhHpPool src = level == 0 ? K.z : K.a, dst = level == 0 ? K.a : K.b;
-  const int shift = level == 0 ? 56 : 48;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // destination extents come out of [dlo, dhi) of the pool; level B: partition a's slice
-  // Level A: the pool cut into one slab per block — a block's 256 open extents then sit within a few tens of MB instead of being strewn
-  // over the whole pool by a global cursor (4 GB, a different page for every store: level A ran at a third of level B's rate that way).
-  uint32_t dlo, dhi;
-  unsigned int* dcur;                       // extents handed out of [dlo, dhi)
-  if (level == 0) { const uint32_t slab = dst.max_extents / gridDim.x; dlo = blockIdx.x * slab; dhi = dlo + slab; dcur = &S.alloc; }
-  else { dlo = K.slice[blockIdx.x]; dhi = K.slice[blockIdx.x + 1]; dcur = K.slice + HP_FAN + 1 + blockIdx.x; }
-  if (tid == 0) S.alloc = 0;
-  if (tid < HP_FAN) { S.carry_n[tid] = 0; S.ext_a[tid] = ~0u; S.fill_a[tid] = 0; }
-  const uint32_t used = hp_pool_used(src);
-  bool full = false;                        // the destination ran out of extents: the host re-plans (VH_ERR_PART_FULL)
-  for (uint32_t scan0 = 0; scan0 < used; ) {
-    // ---- my next source extents (a list in LDS; more than it holds: another round)
-    __syncthreads();
-    if (tid == 0) S.nlist = 0;
-    __syncthreads();
-    uint32_t next_scan = used;
-    // the common case — everything of mine fits the list — is ONE sweep over the pool's extents without a barrier in it (the chunked loop
-    // below pays two per 1 024 extents: level B looked at ~85 000 of them, a tenth of its time before the first tuple moved)
-    bool listed = false;
-    if (scan0 == 0) {
-      for (uint32_t e = tid; e < used; e += BLOCK) {
-        const uint32_t fl = hp_pool_fill(src, e, ET);
-        if (!fl) continue;
-        const bool mine = level == 0 ? ((e * 2654435761u) >> 12) % gridDim.x == blockIdx.x : src.tag[e] == (uint8_t)blockIdx.x;
-        if (mine) { const uint32_t at = atomicAdd(&S.nlist, 1u); if (at < HP_LIST) { S.list[at] = e; S.lfill[at] = (uint16_t)fl; } }
-      }
-      __syncthreads();
-      listed = S.nlist <= HP_LIST;
-      __syncthreads();
-      if (!listed && tid == 0) S.nlist = 0;        // more than the list holds: in rounds, chunk by chunk
-      __syncthreads();
-    }
-    for (uint32_t e0 = scan0; !listed && e0 < used; e0 += BLOCK) {
-      const uint32_t before = S.nlist;             // (stable: behind the barrier that ended the previous chunk)
-      const uint32_t e = e0 + tid;
-      bool mine = false;
-      uint32_t fl = 0;
-      if (e < used && (fl = hp_pool_fill(src, e, ET)) != 0)
-        mine = level == 0 ? ((e * 2654435761u) >> 12) % gridDim.x == blockIdx.x : src.tag[e] == (uint8_t)blockIdx.x;      // (level A: a scattered share of the stream, so that
-                                                                                                                               //  the blocks do not march through the pool 64 KB apart in lockstep)
-      __syncthreads();
-      if (mine) { const uint32_t at = atomicAdd(&S.nlist, 1u); if (at < HP_LIST) { S.list[at] = e; S.lfill[at] = (uint16_t)fl; } }
-      __syncthreads();
-      if (S.nlist > HP_LIST) {                     // this chunk did not fit behind the earlier ones: it opens the next round
-        __syncthreads();
-        if (tid == 0) S.nlist = before;
-        next_scan = e0;
-        break;
-      }
-    }
-    __syncthreads();
-    const uint32_t nl = S.nlist < HP_LIST ? S.nlist : HP_LIST;
-    scan0 = next_scan;
-    // ---- tiles: consecutive listed extents whose tuples add up to at most ET (the extents a level leaves behind are often a quarter
-    //      full — one per writing block and digit —, and a tile's fixed cost is the same whatever it holds)
-    if (tid == 0) {
-      uint32_t nt = 0, i = 0;
-      while (i < nl) {
-        S.tfirst[nt++] = (uint16_t)i;
-        uint32_t sum = 0, cnt = 0;
-        while (i < nl && cnt < 32 && sum + S.lfill[i] <= ET) { S.lpre[i] = (uint16_t)sum; sum += S.lfill[i]; ++i; ++cnt; }
-      }
-      S.tfirst[nt] = (uint16_t)nl;
-      S.ntiles = nt;
-    }
-    __syncthreads();
-    const uint32_t ntiles = S.ntiles;
-    auto tile_total = [&](uint32_t tile) { const uint32_t last = S.tfirst[tile + 1] - 1u; return (uint32_t)S.lpre[last] + S.lfill[last]; };
-    auto tile_load = [&](uint32_t tile, uint32_t total, T (&dstv)[R]) {
-      uint32_t i = S.tfirst[tile];               // (the thread's tuples lie further and further into the tile: the search goes on where it stopped)
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-        const uint32_t k = (uint32_t)(r * BLOCK + tid);
-        if (k < total) {
-          while ((uint32_t)S.lpre[i] + S.lfill[i] <= k) ++i;
-          dstv[r] = hp_load_nt<U>(reinterpret_cast<const T*>(src.tuples) + (uint64_t)S.list[i] * src.stride + (k - S.lpre[i]));
-        }
-      }
-    };
-    T t[R];
-    uint32_t valid = ntiles ? tile_total(0) : 0u;
-    if (ntiles) tile_load(0, valid, t);
-    for (uint32_t li = 0; li < ntiles; ++li) {
-      const uint32_t nvalid = valid;
-      uint32_t dig[R];
-      uint32_t rank[R];       // the tuple's place among its digit's tuples: what the histogram's counter held when it was counted
-      if (tid < HP_FAN) { S.hist[tid] = S.carry_n[tid]; S.cur[tid] = S.carry_n[tid]; }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if ((uint32_t)(r * BLOCK + tid) < nvalid) { dig[r] = (uint32_t)(t[r].v[0].x >> shift) & (HP_FAN - 1u); rank[r] = atomicAdd(&S.hist[dig[r]], 1u); }
-      __syncthreads();
-      // exclusive prefix over the digits (waves 0..3: 64 digits each), whole lines, room, extents
-      uint32_t incl = 0, h = 0;
-      if (tid < HP_FAN) {
-        h = S.hist[tid];
-        incl = h;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
-        if (lane == 63) S.wave_tot[wave] = incl;
-      }
-      __syncthreads();
-      if (tid < HP_FAN) {
-        uint32_t before = 0;
-        for (int w = 0; w < wave; ++w) before += S.wave_tot[w];
-        const uint32_t first = before + incl - h;
-        S.offs[tid] = first;
-        uint32_t whole = h & ~(LINE - 1u);
-        uint32_t ea = S.ext_a[tid], fa = S.fill_a[tid], eb = ~0u;
-        uint32_t room = ea == ~0u ? 0u : ET - fa;
-        if (whole > room) {                          // the run needs a fresh extent behind what is left of the open one
-          const uint32_t got = atomicAdd(dcur, 1u);
-          if (dlo + got < dhi) { eb = dlo + got; dst.tag[eb] = (uint8_t)tid; }
-          else { full = true; whole = room; }        // nowhere to put the rest: dropped, the attempt is void
-        }
-        S.meta[tid][0] = first | (whole << 16); S.meta[tid][1] = room;
-        S.meta[tid][2] = ea * dst.stride + fa; S.meta[tid][3] = eb * dst.stride - room;      // (a pool holds < 2^32 tuples: 64 GB)
-        S.tail[tid] = h - whole;
-        // after this tile: the open extent and its fill
-        if (whole <= room) { S.fill_a[tid] = fa + whole; }
-        else { if (ea != ~0u) dst.fill[ea] = (uint16_t)ET; S.ext_a[tid] = eb; S.fill_a[tid] = whole - room; }
-      }
-      __syncthreads();
-      // scatter: waiting tails first, then the tile's tuples
-      for (uint32_t c = tid; c < HP_FAN * CARRY; c += BLOCK) {
-        const uint32_t d = c / CARRY, j = c % CARRY;
-        if (j < S.cur[d]) { sorted[S.offs[d] + j] = carry[c]; S.sdigit[S.offs[d] + j] = (uint8_t)d; }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if ((uint32_t)(r * BLOCK + tid) < nvalid) { const uint32_t at = S.offs[dig[r]] + rank[r]; sorted[at] = t[r]; S.sdigit[at] = (uint8_t)dig[r]; }
-      // the next tile's loads travel while this one is written out
-      if (li + 1 < ntiles) { valid = tile_total(li + 1); tile_load(li + 1, valid, t); }
-      __syncthreads();
-      const uint32_t total = S.offs[HP_FAN - 1] + S.hist[HP_FAN - 1];
-      T* const out = reinterpret_cast<T*>(dst.tuples);
-      for (uint32_t k = tid; k < total; k += BLOCK) {
-        const uint32_t d = S.sdigit[k];
-        const hp_u32x4 m = *reinterpret_cast<const hp_u32x4*>(S.meta[d]);
-        const uint32_t local = k - (m.x & 0xFFFFu), whole = m.x >> 16;
-        const T v = sorted[k];
-        if (local < whole) out[(local < m.y ? m.z : m.w) + local] = v;
-        else if (local - whole < CARRY) carry[d * CARRY + (local - whole)] = v;
-      }
-      __syncthreads();
-      if (tid < HP_FAN) S.carry_n[tid] = S.tail[tid] < CARRY ? S.tail[tid] : 0u;     // (a line or more only on a void attempt that ran out of extents)
-    }
-  }
-  // ---- what still waits goes out as the last, partial line of its extent; open extents are closed with what they hold
-  __syncthreads();
-  if (tid < HP_FAN) {
-    uint32_t ea = S.ext_a[tid], fa = S.fill_a[tid];
-    const uint32_t n = S.carry_n[tid];
-    if (n) {
-      if (ea == ~0u || fa + n > ET) {
-        if (ea != ~0u) dst.fill[ea] = (uint16_t)fa;
-        const uint32_t got = atomicAdd(dcur, 1u);
-        if (dlo + got < dhi) { ea = dlo + got; fa = 0; dst.tag[ea] = (uint8_t)tid; } else { ea = ~0u; full = true; }
-      }
-      if (ea != ~0u) {
-        T* const out = reinterpret_cast<T*>(dst.tuples);
-        for (uint32_t j = 0; j < n; ++j) out[(uint64_t)ea * dst.stride + fa + j] = carry[tid * CARRY + j];
-        fa += n;
-      }
-    }
-    if (ea != ~0u) dst.fill[ea] = (uint16_t)fa;
-  }
-  if (__ballot(full)) { if (full) atomicOr(counters + 2, VH_ERR_PART_FULL); }
-}
-
-// ------------------------------------------------------------------ level B without barriers (behind a scan that wrote level A by position)
+// ------------------------------------------------------------------ level B: no barriers, no tiles (behind the scan, which wrote level A)
 // Block (a, j) of HP_FAN x NB: the tuples of partition a that scan blocks j, j + NB, ... wrote — extent k of (scan block, digit a) of pool a
 // lies at k * (scan blocks * 256) + block * 256 + a, so there is nothing to list and nothing to search — go through the ring writer
 // (vh_ring_add, vh_kernels.h) by bits 55..48 of the mixed key into the block's extents of slice a, also by position (hp_plan_kernel). A wave
@@ -389,7 +167,9 @@ __global__ __launch_bounds__(BLOCK) void hp_count_kernel(const VhHpArgs* __restr
   if (threadIdx.x < HP_FAN) cnt[threadIdx.x] = 0;
   __syncthreads();
   const VhHpKind& K = HA->k[0];
-  const uint32_t used = hp_pool_used(K.a);
+  // (every extent below the overflow region may hold something; of the region, what its cursor says was taken)
+  uint32_t used = K.a.ovf_base;
+  if (K.a.ovf_cursor) { const unsigned long long c = *K.a.ovf_cursor, room = K.a.max_extents - K.a.ovf_base; used += (uint32_t)(c < room ? c : room); }
   for (uint32_t e = blockIdx.x * BLOCK + threadIdx.x; e < used; e += gridDim.x * BLOCK) {
     const uint32_t f = K.a.fill[e];
     if (f) atomicAdd(&cnt[K.a.tag[e]], f);
@@ -397,7 +177,7 @@ __global__ __launch_bounds__(BLOCK) void hp_count_kernel(const VhHpArgs* __restr
   __syncthreads();
   if (threadIdx.x < HP_FAN && cnt[threadIdx.x]) atomicAdd(K.count + threadIdx.x, cnt[threadIdx.x]);
 }
-// ring_blocks != 0 (hp_ring_scatter_kernel writes the slices): every (block j of ring_blocks, digit) stream of partition a gets vh_slice_levels
+// Every (block j of ring_blocks, digit) stream of partition a gets vh_slice_levels
 // extents by POSITION — extent k of it is slice[a] + (k * ring_blocks + j) * HP_FAN + digit: its share of the partition's counted tuples and one
 // more — and behind them the slice's shared overflow region with room for all the partition's tuples once more (a hot key inside the partition);
 // the aggregation looks at every extent the slice's cursor says is used.
@@ -409,8 +189,7 @@ __global__ __launch_bounds__(HP_FAN) void hp_plan_kernel(const VhHpArgs* __restr
   // what partition a holds, in extents, + one open extent per digit of its single writer + the flush of the tails
   const uint32_t c = K.count[a];
   const unsigned long long per = (unsigned long long)HP_FAN * (unsigned)(ring_blocks > 0 ? ring_blocks : 1);
-  const unsigned long long need = !c ? 0ull : ring_blocks ? vh_slice_extents(c, per, et, HA->slice_levels_cap)
-                                                           : (unsigned long long)(c + et - 1) / et + 2 * HP_FAN + 8;
+  const unsigned long long need = !c ? 0ull : vh_slice_extents(c, per, et, HA->slice_levels_cap);
   unsigned long long incl = need;
 #pragma unroll
   for (int off = 1; off < 64; off <<= 1) { const unsigned long long o = __shfl_up(incl, off); if (lane >= off) incl += o; }
@@ -420,7 +199,7 @@ __global__ __launch_bounds__(HP_FAN) void hp_plan_kernel(const VhHpArgs* __restr
   for (int w = 0; w < wave; ++w) before += wave_tot[w];
   const unsigned long long at = before + incl - need, end = before + incl;
   K.slice[a] = (uint32_t)(at < K.b.max_extents ? at : K.b.max_extents);
-  K.slice[HP_FAN + 1 + a] = ring_blocks && c ? vh_slice_levels(c, per, et, HA->slice_levels_cap) * (uint32_t)per : 0u;      // (extents used so far: the positional ones; overflow extents are counted on top as they are taken)
+  K.slice[HP_FAN + 1 + a] = c ? vh_slice_levels(c, per, et, HA->slice_levels_cap) * (uint32_t)per : 0u;      // (extents used so far: the positional ones; overflow extents are counted on top as they are taken)
   if (a == HP_FAN - 1) {
     K.slice[HP_FAN] = (uint32_t)(end < K.b.max_extents ? end : K.b.max_extents);
     if (end > K.b.max_extents) atomicOr(counters + 2, VH_ERR_PART_FULL);

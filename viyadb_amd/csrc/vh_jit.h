@@ -27,10 +27,9 @@ struct VhJitCol {           // one gathered value of a survivor
 // Everything the generated text depends on — and nothing else (no literals, no addresses, no row counts): the cache key.
 struct VhJitShape {
   int mode = 0, block = 256, scope = 0, xcd = 0, carrier = -1, tw = 0, key_words = 1, lds_hash = 0, gid32 = 0;
-  int stage = 0;                        // DENSE_PART: tuples leave for HBM as whole 128-byte lines (vh_part_staged_add): partitions a wave keeps a waiting line for (16 / 64), 0 = piecewise
   int hpart = 0, bitset_j = -1;         // HASH: hashed partitioning (vh_hpart.h); the metric that is a bitset (its ids travel in the tuples, two at a time)
   int bs_off32 = 0;                     // hashed partitioning with a bitset metric: P.bs_offs points at 32-bit offsets
-  int part_ring = 0;                    // DENSE_PART: phase 1 writes its tuples through the block's ring writer (vj_part_ring_add): partitions it keeps lines for (16 / 64), 0 = the per-wave writers
+  int part_ring = 0;                    // DENSE_PART: phase 1 writes its tuples through the block's ring writer (vj_part_ring_add): partitions it keeps lines for (16 / 64), 0 = tuples of three or more words, appended piece by piece (vh_part_direct_add)
   int hp_fan = 0;                       // hashed partitioning: the scan block writes the level-A pool itself (vj_fan_add; 1024-thread blocks, one per CU) — no stream pool, no level-A scatter
   int gid_bits = 0;                     // DENSE_PART: one-word tuples — the gid's bits at the bottom of word 0 (0: the usual two or more words)
   int hp_agg_waves = 0;                  // ... its aggregation kernel should leave room for this many waves per SIMD (what its LDS tables allow): a register bound for the compiler (0: none)

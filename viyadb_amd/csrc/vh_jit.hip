@@ -49,7 +49,7 @@ uint64_t vh_jit_min_rows() {
 std::string VhJitShape::key() const {
   std::string k;
   auto put = [&](long long v) { k += std::to_string(v); k += ','; };
-  put(mode); put(block); put(scope); put(xcd); put(carrier); put(tw); put(key_words); put(lds_hash); put(gid32); put(ablate); put(stage); put(hpart); put(hp_agg_waves); put(bitset_j); put(hp_pack); put(hp_pbits); put(hp_idbits); put(gid_bits); put(bs_off32); put(hp_fan); put(part_ring);
+  put(mode); put(block); put(scope); put(xcd); put(carrier); put(tw); put(key_words); put(lds_hash); put(gid32); put(ablate); put(hpart); put(hp_agg_waves); put(bitset_j); put(hp_pack); put(hp_pbits); put(hp_idbits); put(gid_bits); put(bs_off32); put(hp_fan); put(part_ring);
   put(lanes); put(npred);
   for (int i = 0; i < npred; ++i) { put(pred[i].slot); put(pred[i].type); put(pred[i].width); }
   put(qpay); put(qpay_slot);
@@ -118,11 +118,9 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
               s.mode, s.block, s.scope, nv, s.ng, s.nm, s.tw > 0 ? s.tw : 1, s.key_words, s.carrier);
   t += vj_fmt("  static constexpr int ABLATE = %d, BITSET_J = %d;\n  static constexpr bool HPART = %s;\n", s.ablate, s.bitset_j, s.hpart ? "true" : "false");
   t += vj_fmt("  static constexpr bool LDS_HASH = %s, XCD = %s, GID32 = %s;\n", s.lds_hash ? "true" : "false", s.xcd ? "true" : "false", s.gid32 ? "true" : "false");
-  t += vj_fmt("  static constexpr int STAGE = %d;\n", s.stage);
   t += vj_fmt("  static constexpr bool HP_PACK = %s;\n  static constexpr int HP_PBITS = %d, HP_IDBITS = %d;\n", s.hp_pack ? "true" : "false", s.hp_pbits, s.hp_idbits);
   t += vj_fmt("  static constexpr int GID_BITS = %d;\n", s.gid_bits);
   t += vj_fmt("  static constexpr bool BS_OFF32 = %s;\n", s.bs_off32 ? "true" : "false");
-  t += vj_fmt("  static constexpr bool HP_SCANFAN = %s;\n", s.hp_fan ? "true" : "false");
   t += vj_fmt("  static constexpr int PART_RING = %d;\n", s.part_ring);
   t += vj_fmt("  static constexpr bool LANES = %s;\n", s.lanes ? "true" : "false");
   t += vj_fmt("  static constexpr int QPAY = %d;\n", s.qpay);
@@ -720,12 +718,12 @@ static bool vj_canonical(int which, VhJitShape* s) {
       if (which == 18) which = 9;
       if (which == 19) which = 0;
       const bool part = which == 0 || which == 7 || which == 9 || which == 10 || which == 12 || which == 13 || which == 14;
-      S.mode = part ? VH_MODE_DENSE_PART : VH_MODE_DENSE_GLOBAL; S.block = 256; S.scope = __HIP_MEMORY_SCOPE_AGENT; S.carrier = 1; S.tw = part ? 2 : 1; S.gid32 = 1; S.stage = part ? 16 : 0;
+      S.mode = part ? VH_MODE_DENSE_PART : VH_MODE_DENSE_GLOBAL; S.block = 256; S.scope = __HIP_MEMORY_SCOPE_AGENT; S.carrier = 1; S.tw = part ? 2 : 1; S.gid32 = 1; S.part_ring = part ? 16 : 0;
       S.npred = 3;
       S.pred[0] = VhJitPred{part ? 7 : 0, VH_U32, part ? 1 : 4}; S.pred[1] = VhJitPred{part ? 8 : 1, VH_U32, part ? 2 : 4}; S.pred[2] = VhJitPred{part ? 9 : 2, VH_U32, part ? 2 : 4};
       S.prog = {vj_leaf(VH_F_REL, VH_U32, VH_OP_EQ, 0, 0), vj_leaf(VH_F_REL, VH_U32, VH_OP_LT, 1, 1), vj_leaf(VH_F_REL, VH_U32, VH_OP_GE, 2, 2), vj_node(VH_F_AND, 3)};
       S.nlits = 3; S.ng = 2; S.nm = 2;
-      if (ring) { S.part_ring = 16; S.stage = 0; }
+      (void)ring;
       if (part) {
         S.g[0] = col(10, VH_U32, 32, 0, 8, 1); S.g[1] = col(11, VH_U32, 32, 0, 12, 1);
         S.m[0] = col(12, VH_I64, 32, 0, 0, 0); S.m[0].sop = SOP_ADD64; S.m[0].tword = 1; S.m[0].tshift = 0;

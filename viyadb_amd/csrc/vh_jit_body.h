@@ -83,13 +83,12 @@ __device__ __forceinline__ void vj_rollup_all(const VhPlanDev& P, uint64_t (&gv)
 struct VjWave {
   VhPartWave W;
   VhPartTile T;
-  VhPartStage S;
   VhLdsHashWave H;
   VhRing F;
 };
 
 
-// ------------------------------------------------- hashed partitioning: the scan partitions by itself (J::HP_SCANFAN)
+// ------------------------------------------------- hashed partitioning: the scan partitions by itself (J::HPART)
 // The first level of vh_hpart.h's partitioning — a stream of tuples re-read and scattered 256 ways by the top byte of the mixed key — costs
 // a write and a read of every tuple (C5: 2 of the 10 GB the query moves, 0.53 of its kernels' 3.2 ms). Here the scan block writes the
 // level-A pool itself through the ring writer of vh_kernels.h (vh_ring_add): one 1024-thread block per CU, the digits' waiting lines in
@@ -114,12 +113,11 @@ __device__ __forceinline__ void vj_fan_add(const VhPlanDev& P, const VhRing& F, 
 }
 
 // ------------------------------------------------- DENSE_PART phase 1 through the ring writer (J::PART_RING = digits the block keeps lines for: 16 or 64)
-// vh_part_staged_add gives every WAVE a waiting line and an open extent per partition (a wave opens extents with chunk reservations, ~100
-// instructions and four line-flush passes per drain at 64 partitions, and what 3 072 waves leave part-full phase 2 walks at the price of
-// full extents). Here the BLOCK shares the partitions' waiting lines (vh_ring_add_tb) and a (block, partition)'s k-th extent of pool 1 lies at
-// k * (blocks * npart) + block * npart + partition: a quarter of the open streams, no allocation, whole lines. Tags and `missing` as phase 2
-// and the second split expect them; a partition that meets more than its share and a half of a block's tuples overflows its positions
-// (VH_ERR_PART_FULL) and the re-run takes the per-wave writer.
+// Rounds 3-5 gave every WAVE a waiting line and an open extent per partition (3 072 waves x 13 partitions on C3: extents opened with chunk
+// reservations, four line-flush passes per drain at 64 partitions, part-full extents that phase 2 walked at the price of full ones). Here the
+// BLOCK shares the partitions' waiting lines (vh_ring_add_tb) and a (block, partition) stream's first extents of pool 1 lie at
+// k * (blocks * npart) + block * npart + partition: a quarter of the open streams, no allocation, whole lines; what a stream holds beyond its
+// positions comes out of the pool's shared overflow region. Tags and `missing` as phase 2 and the second split expect them.
 struct VjPartDest {
   uint64_t per, first; uint32_t kmax;
   VhRingOvf ovf;
@@ -230,7 +228,7 @@ __device__ __forceinline__ void vj_bits_ids(bool active, VjBits& B) {
 template <class J>
 __device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32_t row, bool active, uint64_t (&gv)[J::NG ? J::NG : 1], uint64_t (&mv)[J::NM ? J::NM : 1],
                                         char* lds, uint64_t xoff, unsigned long long& nfresh, VjWave& V, const VjBits* pre) {
-  VhPartWave& W = V.W; VhPartTile& T = V.T; VhLdsHashWave& H = V.H; VhPartStage& S = V.S;
+  VhPartWave& W = V.W; VhPartTile& T = V.T; VhLdsHashWave& H = V.H;
   constexpr int MODE = J::MODE;
   constexpr int NG = J::NG, NM = J::NM;
   // hashed partitioning with a bitset metric: where the row's ids lie is asked for NOW, next to the record's loads, and the first two ids
@@ -305,9 +303,7 @@ __device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32
       wide |= (((uint64_t)bid0 | (uint64_t)bid1) & ~IMASK) != 0ull;
       if (__ballot(active && wide)) { if (active && wide) atomicOr(P.counters + 2, VH_ERR_HP_WIDE); }
       const uint64_t words[2] = {mkey, pk | ((uint64_t)bid0 << PB) | ((uint64_t)bid1 << (PB + IB)) | ((left < 2 ? left : 2ull) << 61)};
-      if constexpr (J::HP_SCANFAN) vj_fan_add<1>(P, V.F, active, words, lane);
-      else if (!(VJ_ABL & 8)) vh_part_direct_add<2, 1, 2>(P, T, W, active, words, p, lane);
-      else if (words[0] + words[1] == 0x123456789ABCDEFull) P.counters[7] = 1;
+      vj_fan_add<1>(P, V.F, active, words, lane);
       bool more = active && left > 2;
       while (__ballot(more)) {
         bk += 2; left -= 2;
@@ -318,18 +314,14 @@ __device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32
           if ((((uint64_t)bid0 | (uint64_t)bid1) & ~IMASK) != 0ull) atomicOr(P.counters + 2, VH_ERR_HP_WIDE);
         }
         const uint64_t w2[2] = {mkey, ((uint64_t)bid0 << PB) | ((uint64_t)bid1 << (PB + IB)) | ((left < 2 ? left : 2ull) << 61) | (1ull << 63)};
-        if constexpr (J::HP_SCANFAN) vj_fan_add<1>(P, V.F, more, w2, lane);
-        else if (!(VJ_ABL & 8)) vh_part_direct_add<2, 1, 2>(P, T, W, more, w2, p, lane);
-        else if (w2[1] == 0x123456789ABCDEFull) P.counters[7] = 1;
+        vj_fan_add<1>(P, V.F, more, w2, lane);
         more = more && left > 2;
       }
     } else if constexpr (J::BITSET_J >= 0 && !(VJ_ABL & 4)) {
       // word 2: two ids, word 3: how many of them count | HP_IDS_ONLY (4) on the tuples behind a row's first
       uint64_t left = bk1 - bk;
       uint64_t words[4] = {mkey, payload, (uint64_t)bid0 | ((uint64_t)bid1 << 32), left < 2 ? left : 2ull};
-      if constexpr (J::HP_SCANFAN) vj_fan_add<2>(P, V.F, active, words, lane);
-      else if (!(VJ_ABL & 8)) vh_part_direct_add<4, 1, 4>(P, T, W, active, words, p, lane);
-      else if (words[0] + words[1] + words[2] == 0x123456789ABCDEFull) P.counters[7] = 1;
+      vj_fan_add<2>(P, V.F, active, words, lane);
       bool more = active && left > 2;
       while (__ballot(more)) {
         bk += 2; left -= 2;
@@ -338,16 +330,12 @@ __device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32
           else { bid0 = bids[bk]; bid1 = left > 1 ? bids[bk + 1] : 0u; }
         }
         const uint64_t w2[4] = {mkey, 0ull, (uint64_t)bid0 | ((uint64_t)bid1 << 32), (left < 2 ? left : 2ull) | 4ull};
-        if constexpr (J::HP_SCANFAN) vj_fan_add<2>(P, V.F, more, w2, lane);
-        else if (!(VJ_ABL & 8)) vh_part_direct_add<4, 1, 4>(P, T, W, more, w2, p, lane);
-        else if (w2[2] == 0x123456789ABCDEFull) P.counters[7] = 1;
+        vj_fan_add<2>(P, V.F, more, w2, lane);
         more = more && left > 2;
       }
     } else {
       const uint64_t words[2] = {mkey, payload};
-      if constexpr (J::HP_SCANFAN) vj_fan_add<1>(P, V.F, active, words, lane);
-      else if (!(VJ_ABL & 8)) vh_part_direct_add<2, 1, 2>(P, T, W, active, words, p, lane);
-      else if (words[0] + words[1] == 0x123456789ABCDEFull) P.counters[7] = 1;
+      vj_fan_add<1>(P, V.F, active, words, lane);
     }
     return;
   }
@@ -396,8 +384,8 @@ __device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32
     }
     if (__ballot(active && wide)) { if (active && wide) atomicOr(P.counters + 2, VH_ERR_HP_WIDE); }
     if (VJ_ABL & 8) { if (words[0] == 0x123456789ABCDEFull) P.counters[7] = 1; return; }
-    if constexpr (J::PART_RING != 0) vj_part_ring_add<J, 1>(P, V.F, active, words, active ? (uint32_t)(gid >> P.part_shift) : 0u, (int)(threadIdx.x & 63));
-    else vh_part_staged_add<J::STAGE, 1>(P, T, W, S, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
+    static_assert(J::PART_RING != 0, "one-word tuples leave through the block's ring writer");
+    vj_part_ring_add<J, 1>(P, V.F, active, words, active ? (uint32_t)(gid >> P.part_shift) : 0u, (int)(threadIdx.x & 63));
     return;
   } else if constexpr (MODE == VH_MODE_DENSE_PART) {
     constexpr int TW = J::TW;
@@ -416,7 +404,6 @@ __device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32
       return;
     }
     if constexpr (J::PART_RING != 0 && TW == 2) vj_part_ring_add<J, 2>(P, V.F, active, words, active ? (uint32_t)(gid >> P.part_shift) : 0u, (int)(threadIdx.x & 63));
-    else if constexpr (J::STAGE != 0 && TW == 2) vh_part_staged_add<J::STAGE>(P, T, W, S, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
     else vh_part_direct_add<TW, 1, TW>(P, T, W, active, words, (uint32_t)(gid >> P.part_shift), (int)(threadIdx.x & 63));
     return;
   }
@@ -424,6 +411,21 @@ __device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32
     if (active) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[gid] = 1;
   } else if constexpr (MODE == VH_MODE_DENSE_GLOBAL) {
     if constexpr (J::CARRIER < 0) { if (active) P.present[xoff + gid] = 1; }
+  }
+  if constexpr (MODE == VH_MODE_HASH) {
+    // a wave most of whose survivors fall into ONE group lets one lane speak for them (vh_hot_lanes, vh_kernels.h: atomics on one address are
+    // served one after the other — a hot key would otherwise cost ~6.5 ns per ROW)
+    const uint64_t hot = vh_hot_lanes(active, gid);
+    if (hot) {       // (wave-uniform)
+      const int lane_ = (int)(threadIdx.x & 63);
+      const bool in_hot = ((hot >> lane_) & 1ull) != 0, speaks = lane_ == __builtin_ctzll(hot);
+#pragma unroll
+      for (int j = 0; j < NM; ++j) {
+        const uint64_t tot = vh_wave_combine(J::m_sop[j], mv[j], in_hot);
+        if (in_hot ? speaks : active) vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(vh_hash_state(P, P.m[j], gid), 0, J::m_sop[j], in_hot ? tot : mv[j]);
+      }
+      return;
+    }
   }
   if (active) {
 #pragma unroll
@@ -550,15 +552,12 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
   uint32_t* q = reinterpret_cast<uint32_t*>(lds + ((MODE == VH_MODE_DENSE_LDS || MODE == VH_MODE_HASH) ? P.lds_bytes : 0)) + wave * VJ_QUEUE_CAP;
   VjWave V;
   V.H = VhLdsHashWave{0u, 0u, false, 0ull};
-  V.S = VhPartStage{0u, nullptr};
   if constexpr (MODE == VH_MODE_HASH && J::LDS_HASH) vh_lds_hash_init(P, lds, BLOCK);
-  if constexpr (MODE == VH_MODE_DENSE_PART || (MODE == VH_MODE_HASH && J::HPART)) vh_part_tile_init(P, lds, V.T, V.W);
-  if constexpr (MODE == VH_MODE_HASH && J::HPART && J::HP_SCANFAN)     // the block's level-A writer (vj_fan_add), behind the block's queues
+  if constexpr (MODE == VH_MODE_DENSE_PART) vh_part_tile_init(P, lds, V.T, V.W);
+  if constexpr (MODE == VH_MODE_HASH && J::HPART)     // the block's level-A writer (vj_fan_add), behind the block's queues
     vh_ring_init<BLOCK>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t), V.F, wave);
   if constexpr (MODE == VH_MODE_DENSE_PART && J::PART_RING != 0)   // the block's phase-1 writer (vj_part_ring_add), behind the block's queues
     vh_ring_init<BLOCK, J::PART_RING, 2>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t), V.F, wave);
-  if constexpr (MODE == VH_MODE_DENSE_PART && J::STAGE != 0)      // one waiting line per partition and wave, behind the block's queues
-    V.S.lines = reinterpret_cast<uint64_t*>(lds + (size_t)(BLOCK / 64) * VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)wave * VH_STAGE_BYTES(J::STAGE));
   if constexpr (MODE == VH_MODE_DENSE_LDS) {
     // identities: 0 for SUM/AVG/COUNT, type max for MIN, cpp_min_value for MAX (src/codegen/db/store.cc:107-117)
 #pragma unroll
@@ -700,12 +699,11 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
   if constexpr (MODE == VH_MODE_DENSE_PART && J::PART_RING != 0)
     vh_ring_finish_tb<J::TW * 8, BLOCK, VjPartDest, J::PART_RING, 2, true>(V.F, reinterpret_cast<char*>(P.tuples), (uint32_t)P.ext_stride, 31u - (uint32_t)__builtin_clz((uint32_t)P.ext_tuples),
                                                                            P.extent_missing, P.extent_part, VjPartDest(P), P.counters + 2, P.part_count);
-  else if constexpr (MODE == VH_MODE_DENSE_PART) { if constexpr (J::STAGE != 0) vh_part_stage_finish<J::TW>(P, V.T, V.S, lane); else vh_part_tile_finish(P, V.T, lane); }
-  if constexpr (MODE == VH_MODE_HASH && J::HPART && J::HP_SCANFAN) vh_ring_finish<(J::BITSET_J >= 0 && !J::HP_PACK) ? 2 : 1, BLOCK>(V.F, reinterpret_cast<vh_u64x2*>(P.tuples2), (uint32_t)P.ext_tuples2, P.extent_missing2, P.extent_part2, VjFanDest(P), P.counters + 2);
-  else if constexpr (MODE == VH_MODE_HASH && J::HPART) vh_part_tile_finish<1>(P, V.T, lane);
+  else if constexpr (MODE == VH_MODE_DENSE_PART) vh_part_tile_finish(P, V.T, lane);
+  if constexpr (MODE == VH_MODE_HASH && J::HPART) vh_ring_finish<(J::BITSET_J >= 0 && !J::HP_PACK) ? 2 : 1, BLOCK>(V.F, reinterpret_cast<vh_u64x2*>(P.tuples2), (uint32_t)P.ext_tuples2, P.extent_missing2, P.extent_part2, VjFanDest(P), P.counters + 2);
   // the waves' counters, and how far the extents handed out by position reach, as one set of atomics per block (vh_scan_block_end)
   // (extents by position: every extent of the pool may hold something — phase 2 goes by the tags)
-  vh_scan_block_end(P, npassed, nfresh, 0ull, (MODE == VH_MODE_DENSE_PART && J::PART_RING != 0) ? P.max_extents : (MODE == VH_MODE_DENSE_PART || (MODE == VH_MODE_HASH && J::HPART)) ? vh_part_wave_end(P, V.W) : 0u);
+  vh_scan_block_end(P, npassed, nfresh, 0ull, (MODE == VH_MODE_DENSE_PART && J::PART_RING != 0) ? P.max_extents : MODE == VH_MODE_DENSE_PART ? vh_part_wave_end(P, V.W) : 0u);
   if constexpr (MODE == VH_MODE_HASH && J::LDS_HASH) vh_lds_hash_flush(P, lds, BLOCK);
   if constexpr (MODE == VH_MODE_DENSE_LDS) {
     __syncthreads();

@@ -459,9 +459,53 @@ __device__ __forceinline__ uint64_t vh_hash_insert_wide(const VhPlanDev& P, cons
   return vh_set_insert_wide(P.hkeys, P.htags, P.hmask, P.max_probe, key, kw, ok, fresh);
 }
 
+// Two partial states of one metric into one (the merge of private table copies; the wave-level combining below).
+__device__ __forceinline__ uint64_t vh_combine(int sop, uint64_t a, uint64_t b) {
+  switch (sop) {
+    case SOP_ADD32: return (uint32_t)((uint32_t)a + (uint32_t)b);
+    case SOP_ADD64: case SOP_ADD32P: case SOP_BITSET: return a + b;
+    case SOP_ADDF32: return __float_as_uint(__uint_as_float((uint32_t)a) + __uint_as_float((uint32_t)b));
+    case SOP_ADDF64: return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
+    case SOP_MIN_I32: return (uint32_t)((int32_t)b < (int32_t)a ? b : a);
+    case SOP_MAX_I32: return (uint32_t)((int32_t)a < (int32_t)b ? b : a);
+    case SOP_MIN_U32: return (uint32_t)b < (uint32_t)a ? (uint32_t)b : (uint32_t)a;
+    case SOP_MAX_U32: return (uint32_t)a < (uint32_t)b ? (uint32_t)b : (uint32_t)a;
+    case SOP_MIN_I64: return (int64_t)b < (int64_t)a ? b : a;
+    case SOP_MAX_I64: return (int64_t)a < (int64_t)b ? b : a;
+    case SOP_MIN_U64: return b < a ? b : a;
+    case SOP_MAX_U64: return a < b ? b : a;
+    case SOP_MIN_F32: return __uint_as_float((uint32_t)b) < __uint_as_float((uint32_t)a) ? (uint32_t)b : (uint32_t)a;
+    case SOP_MAX_F32: return __uint_as_float((uint32_t)a) < __uint_as_float((uint32_t)b) ? (uint32_t)b : (uint32_t)a;
+    case SOP_MIN_F64: return __longlong_as_double((long long)b) < __longlong_as_double((long long)a) ? b : a;
+    default: return __longlong_as_double((long long)a) < __longlong_as_double((long long)b) ? b : a;
+  }
+}
+
+// HOT KEYS in the hash organisation. Every surviving row updates its group's record with device-scope atomics; atomics on ONE address are served
+// one after the other (~6.5 ns each), so a group that holds a tenth of the rows — 12.5 M of C5h's — costs its query a quarter of a second where
+// the reference's unordered_map does not care (src/codegen/db/store.cc:131-161). A wave that finds eight or more of its 64 survivors in the group
+// of its first one lets that lane speak for all of them: their values are combined across the wave (a butterfly over the members, vh_combine per
+// step) and ONE atomic per metric goes out; the others go on as before. The test is a readlane, a compare and a ballot per drain.
+__device__ __forceinline__ uint64_t vh_wave_combine(int sop, uint64_t v, bool in) {      // every lane: the members' total (garbage when there is no member)
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint64_t o = __shfl_xor(v, off);
+    const bool oin = __shfl_xor((int)in, off) != 0;
+    if (oin) { v = in ? vh_combine(sop, v, o) : o; in = true; }
+  }
+  return v;
+}
+__device__ __forceinline__ uint64_t vh_hot_lanes(bool active, uint64_t gid) {      // lanes that share the first active lane's group, when they are eight or more (else 0)
+  const uint64_t act = __ballot(active);
+  if (!act) return 0ull;
+  const uint64_t lg = __shfl(gid, __builtin_ctzll(act));
+  const uint64_t hot = __ballot(active && gid == lg);
+  return __popcll(hot) >= 8 ? hot : 0ull;
+}
+
 // COUNT DISTINCT: insert every id of the row's set into metric b's (group, id) set; first sight bumps card[gid]
 __device__ __forceinline__ void vh_distinct_update(const VhPlanDev& P, int b, unsigned long long* card, uint64_t gid,
-                                                   uint32_t seg, uint32_t row, unsigned long long& npairs) {
+                                                   uint32_t seg, uint32_t row, unsigned long long& npairs, unsigned long long* fresh_out = nullptr) {      // fresh_out: the caller adds the row's first sights to card itself (vh_wave_combine)
   const uint64_t* offs = P.bs_offs[b][seg];
   const uint64_t o0 = offs[row], o1 = offs[row + 1];
   const void* vals = P.bs_vals[b][seg];
@@ -484,7 +528,7 @@ __device__ __forceinline__ void vh_distinct_update(const VhPlanDev& P, int b, un
       if (!wa && ea != ka) { bool ok = true, fresh = false; vh_set_insert64(P.dset_keys[b], P.dset_mask[b], 4096u, ka, ok, fresh); if (!ok) atomicOr(P.counters + 2, VH_ERR_HASH_FULL); nfresh += fresh ? 1 : 0; }
       if (ka != kb && !wb && eb != kb) { bool ok = true, fresh = false; vh_set_insert64(P.dset_keys[b], P.dset_mask[b], 4096u, kb, ok, fresh); if (!ok) atomicOr(P.counters + 2, VH_ERR_HASH_FULL); nfresh += fresh ? 1 : 0; }
     }
-    if (nfresh) { atomicAdd(card, nfresh); npairs += nfresh; }
+    if (nfresh) { if (fresh_out) *fresh_out += nfresh; else atomicAdd(card, nfresh); npairs += nfresh; }
   }
   for (; k < o1; ++k) {
     bool ok = true, fresh = false;
@@ -496,7 +540,7 @@ __device__ __forceinline__ void vh_distinct_update(const VhPlanDev& P, int b, un
       vh_set_insert64(P.dset_keys[b], P.dset_mask[b], 4096u, key, ok, fresh);
     }
     if (!ok) atomicOr(P.counters + 2, VH_ERR_HASH_FULL);
-    if (fresh) { atomicAdd(card, 1ull); ++npairs; }   // pairs are totalled per lane: one hot-spot atomic per wave, not per pair
+    if (fresh) { if (fresh_out) *fresh_out += 1ull; else atomicAdd(card, 1ull); ++npairs; }   // pairs are totalled per lane: one hot-spot atomic per wave, not per pair
   }
 }
 
@@ -622,18 +666,29 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
   } else if (MODE == VH_MODE_DENSE_GLOBAL) {
     if (active && P.present_carrier < 0) P.present[xoff + gid] = 1;
   }
+  // (hash organisation: a wave most of whose survivors fall into one group lets one lane speak for them — vh_hot_lanes above)
+  const uint64_t hot = MODE == VH_MODE_HASH ? vh_hot_lanes(active, gid) : 0ull;
+  const int lane_ = (int)(threadIdx.x & 63);
+  const bool in_hot = ((hot >> lane_) & 1ull) != 0, speaks = hot != 0 && lane_ == __builtin_ctzll(hot);
   for (int j = 0; j < P.nmetric; ++j) {
     const VhMetricDev& m = P.m[j];
     if (m.sop() == SOP_BITSET) {   // slot() is the bitset index, m.state the u64 cardinality per group
-      if (active) vh_distinct_update(P, m.slot(), MODE == VH_MODE_HASH ? reinterpret_cast<unsigned long long*>(vh_hash_state(P, m, gid))
-                                                                         : reinterpret_cast<unsigned long long*>(m.state) + xoff + gid,
-                                       MODE == VH_MODE_HASH ? gid : xoff + gid, seg, row, H.npairs);
+      unsigned long long* const card = MODE == VH_MODE_HASH ? reinterpret_cast<unsigned long long*>(vh_hash_state(P, m, gid))
+                                                            : reinterpret_cast<unsigned long long*>(m.state) + xoff + gid;
+      unsigned long long mine = 0;
+      if (active) vh_distinct_update(P, m.slot(), card, MODE == VH_MODE_HASH ? gid : xoff + gid, seg, row, H.npairs, in_hot ? &mine : nullptr);
+      if (hot) {       // (wave-uniform) the hot group's first sights of this drain: one atomic
+        const unsigned long long tot = vh_wave_combine(SOP_ADD64, mine, in_hot);
+        if (speaks && tot) atomicAdd(card, tot);
+      }
       continue;
     }
     uint64_t bits;
     if (m.slot() == VH_SLOT_ROWID) bits = ((uint64_t)seg << 32) | row;   // storage order of the row (search: first occurrence)
     else bits = vh_gather(P, m.slot(), seg, row, m.type(), vh_sop_sext(m.sop()));
-    if (active) {
+    bool upd = active;
+    if (hot) { const uint64_t tot = vh_wave_combine(m.sop(), bits, in_hot); if (in_hot) { bits = tot; upd = speaks; } }
+    if (upd) {
       if (MODE == VH_MODE_DENSE_LDS) {
         vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, gid, m.sop(), bits);
       } else if (MODE == VH_MODE_DENSE_GLOBAL) {
@@ -1011,116 +1066,17 @@ __device__ __forceinline__ void vh_part_direct_add(const VhPlanDev& P, VhPartTil
   }
 }
 
-// ------------------------------------------------- phase 1 with whole-line writes (two-word tuples, <= 16 partitions)
-// vh_part_direct_add leaves a partition's tuples of one drain as a ~5-tuple piece of a 128-byte line; the next drain of the
-// wave continues the line ~20 us later, after the L2 has seen megabytes of streamed columns and gathered records, and what
-// reaches HBM are partial lines (round 3: the same tuples written as whole aligned lines cost 0.19 ms less per 50 M; a plain
-// contiguous stream another 0.16 ms less). Here every partition keeps ONE line's worth of tuples (8 x 16 B) of LDS per wave:
-// a drain's tuples first complete that line — which four lanes then read back and store whole —, whole lines in the middle
-// of the drain's run go out straight from the registers (eight consecutive ranks = one aligned line in one store
-// instruction), and the remainder (< 8 tuples) waits in LDS for the next drain. Extents only ever see aligned 128-byte
-// lines, except for the one partial line that closes an extent (or the kernel).
-// Lane p owns partition p: T.r_ext = its extent, T.r_fill = tuples of it already in HBM (a multiple of 8), r_stage = tuples waiting in LDS.
+// ------------------------------------------------- tuples that leave as whole 128-byte lines (the ring writer below)
 #ifndef VJ_ABL
-#define VJ_ABL 0     // measurement builds of the compiled kernels only (vh_jit_body.h); 0x100 here: every extent's lines land in the first 256 extents (same instructions, stores that stay in L2; wrong results)
+#define VJ_ABL 0     // measurement builds of the compiled kernels only (vh_jit_body.h)
 #endif
-#define VH_STAGE_ABL_EXT(e) ((VJ_ABL & 0x100) ? ((e) & 255u) : (e))
-#define VH_STAGE_PARTS 16                         // the small form: one pass of the line flush covers every partition
-#define VH_STAGE_PARTS_MAX 64                     // the wide form (a wave keeps at most one partition per lane): four passes
-#define VH_STAGE_BYTES(parts) ((parts) * 128)     // per wave
-struct VhPartStage { uint32_t r_stage; uint64_t* lines; };     // lines: LDS [parts][128 bytes]
+#define VH_RING_PARTS 16                          // DENSE_PART through the ring writer: partitions a block keeps waiting lines for — the small form ...
+#define VH_RING_PARTS_MAX 64                      // ... and the wide one (group-id spaces of 17-64 LDS-sized ranges)
 typedef uint64_t vh_u64x2 __attribute__((ext_vector_type(2)));
 // TW = 64-bit words per tuple: 2 (eight tuples per line) or 1 (sixteen: the planner packed gid and values into one word, VhPlanDev::gid_bits)
 template <int TW> struct VhStageTuple;
 template <> struct VhStageTuple<2> { typedef vh_u64x2 type; static __device__ __forceinline__ type make(const uint64_t (&w)[2]) { type v; v.x = w[0]; v.y = w[1]; return v; } };
 template <> struct VhStageTuple<1> { typedef uint64_t type; static __device__ __forceinline__ type make(const uint64_t (&w)[1]) { return w[0]; } };
-
-template <int TW>
-__device__ __forceinline__ void vh_part_stage_close(const VhPlanDev& P, VhPartTile& T, VhPartStage& S, int q, int lane) {   // wave-uniform q
-  typedef typename VhStageTuple<TW>::type Tup;
-  constexpr uint32_t LT = 16u / TW;
-  const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, q), fill = __builtin_amdgcn_readlane(T.r_fill, q), st = __builtin_amdgcn_readlane(S.r_stage, q);
-  if (old == ~0u) return;
-  const uint32_t et = (uint32_t)P.ext_tuples;
-  if ((uint32_t)lane < st) reinterpret_cast<Tup*>(P.tuples)[(uint64_t)VH_STAGE_ABL_EXT(old) * (uint32_t)P.ext_stride + fill + lane] = reinterpret_cast<const Tup*>(S.lines)[q * LT + lane];
-  if (lane == 0) P.extent_missing[old] = (uint16_t)(et - (fill + st));
-}
-
-// SP: partitions the wave keeps a waiting line for — VH_STAGE_PARTS (16) or VH_STAGE_PARTS_MAX (64: group-id spaces of 17-64 LDS-sized
-// ranges and phase 1 of two-level plans, which used to fall back to piecewise appends).
-template <int SP, int TW = 2>
-__device__ __forceinline__ void vh_part_staged_add(const VhPlanDev& P, VhPartTile& T, VhPartWave& W, VhPartStage& S, bool active,
-                                                   const uint64_t (&words)[TW], uint32_t p, int lane) {
-  typedef typename VhStageTuple<TW>::type Tup;
-  constexpr uint32_t LT = 16u / TW;              // tuples per 128-byte line
-  constexpr int BITS = SP <= 16 ? 4 : 6;
-  const uint32_t npart = (uint32_t)P.npart, et = (uint32_t)P.ext_tuples, es = (uint32_t)P.ext_stride;
-  const uint64_t act = __ballot(active);
-  uint64_t peers = act, mine = act;
-#pragma unroll
-  for (int b = 0; b < BITS; ++b) {
-    if ((npart - 1u) >> b) {
-      const uint64_t bal = __ballot((p >> b) & 1u);
-      peers &= ((p >> b) & 1u) ? bal : ~bal;
-      mine &= (((uint32_t)lane >> b) & 1u) ? bal : ~bal;
-    }
-  }
-  const uint32_t rank = __popcll(peers & ((1ull << lane) - 1ull));
-  const uint32_t cnt = (uint32_t)lane < npart ? (uint32_t)__popcll(mine) : 0u;
-  // room in the owned partition's extent for what is staged plus this drain's tuples?
-  uint64_t need = __ballot(cnt != 0 && (T.r_ext == ~0u || T.r_fill + S.r_stage + cnt > et));
-  while (need) {
-    const int q = __builtin_ctzll(need);
-    need &= need - 1;
-    vh_part_stage_close<TW>(P, T, S, q, lane);       // what waits in LDS closes the old extent as a partial line
-    const uint32_t ext = vh_part_new_extent<1>(P, W, q, lane);
-    if (lane == q) { T.r_ext = ext; T.r_fill = 0; S.r_stage = 0; }
-  }
-  __builtin_amdgcn_wave_barrier();
-  Tup* const lines = reinterpret_cast<Tup*>(S.lines);
-  Tup* const pool = reinterpret_cast<Tup*>(P.tuples);
-  const uint32_t packed = T.r_fill | (S.r_stage << 16) | (cnt << 24);        // fill < 65536 (extent_missing is 16 bits wide), stage < 16, cnt <= 64
-  const uint32_t sp = active ? p : 0u;
-  const uint32_t pe = (uint32_t)__shfl((int)T.r_ext, (int)sp), pk = (uint32_t)__shfl((int)packed, (int)sp);
-  const uint32_t g = pk & 0xFFFFu, f = (pk >> 16) & 0xFFu, c = pk >> 24;
-  const uint32_t i = f + rank, whole = (f + c) & ~(LT - 1u);                    // my tuple's place behind the extent's HBM part; tuples of the run that form whole lines
-  const bool ok = active && pe != ~0u;                                         // ~0: tuple pool exhausted, the host re-runs (VH_ERR_PART_FULL)
-  const Tup v = VhStageTuple<TW>::make(words);
-  if (ok && i < LT) lines[p * LT + i] = v;                                     // completes the waiting line (or just waits with it)
-  __builtin_amdgcn_wave_barrier();
-  // the waiting line of every partition that is now full: lane l stores quarter l & 3 (32 bytes) of partition 16 * pass + (l >> 2)
-  const uint64_t full_lines = __ballot(cnt != 0 && S.r_stage + cnt >= LT && T.r_ext != ~0u);       // (lane q speaks for partition q)
-#pragma unroll
-  for (int pass = 0; pass < SP / 16; ++pass) {
-    if (!((full_lines >> (16 * pass)) & 0xFFFFull)) continue;                  // (wave-uniform)
-    const uint32_t q = (uint32_t)(16 * pass) + ((uint32_t)lane >> 2), part4 = (uint32_t)lane & 3u;
-    const uint32_t qe = (uint32_t)__shfl((int)T.r_ext, (int)q), qk = (uint32_t)__shfl((int)packed, (int)q);
-    const uint32_t qg = qk & 0xFFFFu, qf = (qk >> 16) & 0xFFu, qc = qk >> 24;
-    if (q < npart && qe != ~0u && qc != 0 && qf + qc >= LT) {
-      const vh_u64x2* lq = reinterpret_cast<const vh_u64x2*>(S.lines) + q * 8u;      // (a line is eight 16-byte pieces whatever the tuple)
-      const vh_u64x2 a = lq[part4 * 2u], b2 = lq[part4 * 2u + 1u];
-      vh_u64x2* d = reinterpret_cast<vh_u64x2*>(pool + (uint64_t)VH_STAGE_ABL_EXT(qe) * es + qg) + part4 * 2u;
-      d[0] = a; d[1] = b2;
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  if (ok && i >= LT) {
-    if (i < whole) pool[(uint64_t)VH_STAGE_ABL_EXT(pe) * es + g + i] = v;                        // a whole line in the middle of the run: LT consecutive ranks, one store instruction
-    else lines[p * LT + (i - whole)] = v;                                      // the remainder waits for the next drain
-  }
-  if (T.r_ext != ~0u) { const uint32_t tot = S.r_stage + cnt; T.r_fill += tot & ~(LT - 1u); S.r_stage = tot & (LT - 1u); }
-  __builtin_amdgcn_wave_barrier();
-}
-
-template <int TW = 2>
-__device__ __forceinline__ void vh_part_stage_finish(const VhPlanDev& P, VhPartTile& T, VhPartStage& S, int lane) {   // open extents are closed with what they hold
-  uint64_t open = __ballot(T.r_ext != ~0u);
-  while (open) {
-    const int q = __builtin_ctzll(open);
-    open &= open - 1;
-    vh_part_stage_close<TW>(P, T, S, q, lane);
-  }
-}
 
 template <int LEVEL = 1>
 __device__ __forceinline__ void vh_part_tile_finish(const VhPlanDev& P, VhPartTile& T, int lane) {   // open extents are closed with what they hold
@@ -2367,109 +2323,13 @@ __global__ __launch_bounds__(BLOCK) void part_split_kernel(const VhPlanDev P, in
   vh_part_tile_finish<2>(P, T, lane);
 }
 
-// The same split for two-word tuples (the common shape), one TILE of 2048 tuples per block at a time: the block counts the
-// tile's tuples per sub-partition in LDS, wave 0 — lane s owns sub-partition s's extent and fill, as the waves of phase 1 do —
-// turns the counts into run offsets and destinations (pool-2 extents hold 2048 tuples here, so a run always fits a fresh
-// one), the tuples are scattered into an LDS copy ordered by sub-partition, and the block streams that copy out: every
-// store instruction writes 64 consecutive tuples of (mostly) one run, whole lines instead of the 16-byte pieces of the
-// tuple-by-tuple form above. 64 extents open per BLOCK instead of per wave.
-#define VH_SPLIT_TILE_TUPLES 2048
-struct VhSplitTile {             // LDS, behind the sorted copy
-  uint32_t hist[64], rbase[64], cursor[64], ntile, pad;
-  uint64_t dst[64];
-};
-__host__ __device__ __forceinline__ size_t vh_split_tile_bytes() { return (size_t)VH_SPLIT_TILE_TUPLES * 16 + sizeof(VhSplitTile); }
-
-// TW: 64-bit words per tuple — 2, or 1 (the planner packed gid and values into one word, VhPlanDev::gid_bits: half the bytes through this level too)
-template <int BLOCK, int TW = 2>
-__global__ __launch_bounds__(BLOCK) void part_split_tile_kernel(const VhPlanDev P, int blocks_per_part) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  typedef typename VhStageTuple<TW>::type u64x2;      // (the tuple: two words, or one)
-  u64x2* sorted = reinterpret_cast<u64x2*>(lds);
-  const uint64_t gid_mask = TW == 1 ? (1ull << P.gid_bits) - 1ull : ~0ull;
-  auto word0 = [](const u64x2& t) -> uint64_t { if constexpr (TW == 1) return t; else return t.x; };
-  VhSplitTile& S = *reinterpret_cast<VhSplitTile*>(lds + (size_t)VH_SPLIT_TILE_TUPLES * 16);
-  const int part = blockIdx.x / blocks_per_part, b = blockIdx.x % blocks_per_part;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int R = VH_SPLIT_TILE_TUPLES / BLOCK;
-  VhPartWave W;
-  VhPartTile T;
-  vh_part_tile_init(P, nullptr, T, W);            // only wave 0 uses them
-  const VhPools Q = vh_pools(P);
-  constexpr int L2 = 2;
-  W.base = Q.l2[part]; W.limit = Q.l2[part + 1]; W.cursor = Q.l2 + VH_L2_NEXT + part;
-  const uint32_t total = Q.allocated1 < Q.max1 ? (uint32_t)Q.allocated1 : Q.max1;
-  const int gshift = P.gid_shift;      // where the 32-bit partition key sits in word 0
-  const uint32_t ext_tuples = (uint32_t)P.ext_tuples, et2 = (uint32_t)P.ext_tuples2, ext_stride1 = (uint32_t)P.ext_stride;
-  u64x2* const pool2 = reinterpret_cast<u64x2*>(Q.t2);
-  const uint32_t gsz = vh_tag_group(total, (uint32_t)blocks_per_part);
-  for (uint32_t c0 = (uint32_t)b * gsz; c0 < total; c0 += (uint32_t)blocks_per_part * gsz) {
-    uint64_t mine = __ballot((uint32_t)lane < gsz && c0 + lane < total && Q.tag1[c0 + lane] == (uint8_t)part);   // the same in every wave
-    while (mine) {
-      const uint32_t ext = c0 + (uint32_t)__builtin_ctzll(mine);
-      mine &= mine - 1;
-      const uint32_t valid = ext_tuples - Q.miss1[ext];
-      const u64x2* base = reinterpret_cast<const u64x2*>(Q.t1) + (uint64_t)ext * ext_stride1;
-      for (uint32_t i0 = 0; i0 < valid; i0 += VH_SPLIT_TILE_TUPLES) {
-        u64x2 t[R];
-        uint32_t sub[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          const uint32_t i = i0 + r * BLOCK + tid;
-          if (i < valid) { t[r] = __builtin_nontemporal_load(base + i); sub[r] = ((uint32_t)((word0(t[r]) & gid_mask) >> gshift) >> P.agg_shift) & 63u; }
-          else sub[r] = 0xFFFFFFFFu;
-        }
-        if (tid < 64) S.hist[tid] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-          if (sub[r] != 0xFFFFFFFFu) atomicAdd(&S.hist[sub[r]], 1u);
-        __syncthreads();
-        if (wave == 0) {       // lane s: run offset, room in sub-partition s's extent, destination
-          const uint32_t cnt = S.hist[lane];
-          uint32_t incl = cnt;
-#pragma unroll
-          for (int off = 1; off < 64; off <<= 1) { const uint32_t o = __shfl_up(incl, off); if (lane >= off) incl += o; }
-          uint64_t need = __ballot(cnt != 0 && (T.r_ext == ~0u || T.r_fill + cnt > et2));
-          while (need) {
-            const int q = __builtin_ctzll(need);
-            need &= need - 1;
-            const uint32_t old = __builtin_amdgcn_readlane(T.r_ext, q), oldfill = __builtin_amdgcn_readlane(T.r_fill, q);
-            if (old != ~0u && lane == 0) Q.miss2[old] = (uint16_t)(et2 - oldfill);
-            const uint32_t e2 = vh_part_new_extent<L2>(P, W, q, lane);
-            if (lane == q) { T.r_ext = e2; T.r_fill = 0; }
-          }
-          S.rbase[lane] = incl - cnt;
-          S.cursor[lane] = incl - cnt;
-          S.dst[lane] = T.r_ext == ~0u ? ~0ull : (uint64_t)T.r_ext * et2 + T.r_fill;     // ~0: pool exhausted, the host re-runs
-          if (T.r_ext != ~0u) T.r_fill += cnt;
-          if (lane == 63) S.ntile = incl;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-          if (sub[r] != 0xFFFFFFFFu) sorted[atomicAdd(&S.cursor[sub[r]], 1u)] = t[r];
-        __syncthreads();
-        const uint32_t n = S.ntile;
-        for (uint32_t k = tid; k < n; k += BLOCK) {
-          const u64x2 v = sorted[k];
-          const uint32_t sb = ((uint32_t)((word0(v) & gid_mask) >> gshift) >> P.agg_shift) & 63u;
-          const uint64_t d = S.dst[sb];
-          if (d != ~0ull) pool2[d + (k - S.rbase[sb])] = v;
-        }
-        // (the next tile's first barrier comes after every thread is through with this loop)
-      }
-    }
-  }
-  if (wave == 0) vh_part_tile_finish<L2>(P, T, lane);
-}
+#define VH_SPLIT_TILE_TUPLES 2048      // tuples per extent of pool 2 when one- and two-word tuples are split through the ring writer (a power of two)
 
 // ------------------------------------------------- the second split without barriers
-// part_split_tile_kernel sorts 2 048 tuples at a time in LDS between four block barriers and writes runs that start and end anywhere in a line. Here
-// a block's waves walk partition p's extents of pool 1 each on its own and append every tuple to sub-partition (gid >> agg_shift) & 63 through the
+// (Rounds 3-5 split one- and two-word tuples a block-wide tile at a time: 2 048 tuples sorted in LDS between four block barriers, runs that start and
+// end anywhere in a line; 5.20 ms for 1 B tuples where this kernel takes 3.58.) A block's waves walk partition p's extents of pool 1 each on its own and append every tuple to sub-partition (gid >> agg_shift) & 63 through the
 // ring writer (vh_ring_add_tb: a tuple counter and two waiting 128-byte lines per sub-partition in LDS, whole lines out, extents by position in the
-// slice part_l2_plan_kernel(ring_blocks) laid out). A (block, sub-partition) that meets more than its share and a half overflows its positions:
-// VH_ERR_PART_FULL, and the re-run takes the tiled kernel, whose extents are handed out as they fill.
+// slice part_l2_plan_kernel(ring_blocks) laid out). A (block, sub-partition) stream that outgrows its positions goes on in the slice's shared overflow region.
 struct VhSplitDest {
   uint32_t lo, kmax, bpp, b;
   VhRingOvf ovf;

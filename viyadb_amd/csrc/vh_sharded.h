@@ -559,7 +559,7 @@ static int sharded_exchange(vh_table* t, const vh_plan* plan, vh_comm* comm, int
   return VH_OK;   // rm (and with it the merge table's context), then the merge table itself, go out of scope here
 }
 
-static bool knobs_no_fused_sharded() { static const bool off = getenv("VH_NO_FUSED_SHARDED") != nullptr; return off; }   // (measurement: the two-collective form)
+static bool knobs_no_fused_sharded() { return false; }   // (true: every dense sharded query in the two-collective form — what round 5 measured the fused step against)
 
 // The steady state of a dense sharded query — its plan has an agreement in the cache and the shape of its partial table is known on every
 // rank — as ONE stream-ordered sequence behind the scan: verdict words -> ONE collective group (the verdict's all-reduce and the reduce of

@@ -5,28 +5,7 @@
 
 // ----------------------------------------------------------- table finalisation
 // Combine the per-XCD private copies of a dense table into copy 0 (they were only ever
-// touched through their own XCD's L2; the kernel boundary made them visible).
-__device__ __forceinline__ uint64_t vh_combine(int sop, uint64_t a, uint64_t b) {
-  switch (sop) {
-    case SOP_ADD32: return (uint32_t)((uint32_t)a + (uint32_t)b);
-    case SOP_ADD64: case SOP_ADD32P: case SOP_BITSET: return a + b;
-    case SOP_ADDF32: return __float_as_uint(__uint_as_float((uint32_t)a) + __uint_as_float((uint32_t)b));
-    case SOP_ADDF64: return (uint64_t)__double_as_longlong(__longlong_as_double((long long)a) + __longlong_as_double((long long)b));
-    case SOP_MIN_I32: return (uint32_t)((int32_t)b < (int32_t)a ? b : a);
-    case SOP_MAX_I32: return (uint32_t)((int32_t)a < (int32_t)b ? b : a);
-    case SOP_MIN_U32: return (uint32_t)b < (uint32_t)a ? (uint32_t)b : (uint32_t)a;
-    case SOP_MAX_U32: return (uint32_t)a < (uint32_t)b ? (uint32_t)b : (uint32_t)a;
-    case SOP_MIN_I64: return (int64_t)b < (int64_t)a ? b : a;
-    case SOP_MAX_I64: return (int64_t)a < (int64_t)b ? b : a;
-    case SOP_MIN_U64: return b < a ? b : a;
-    case SOP_MAX_U64: return a < b ? b : a;
-    case SOP_MIN_F32: return __uint_as_float((uint32_t)b) < __uint_as_float((uint32_t)a) ? (uint32_t)b : (uint32_t)a;
-    case SOP_MAX_F32: return __uint_as_float((uint32_t)a) < __uint_as_float((uint32_t)b) ? (uint32_t)b : (uint32_t)a;
-    case SOP_MIN_F64: return __longlong_as_double((long long)b) < __longlong_as_double((long long)a) ? b : a;
-    default: return __longlong_as_double((long long)a) < __longlong_as_double((long long)b) ? b : a;
-  }
-}
-
+// touched through their own XCD's L2; the kernel boundary made them visible). (vh_combine: vh_kernels.h)
 struct VhMergeArgs {
   int32_t nmetric; int32_t nxcd;
   int32_t present_carrier; int32_t pad;

@@ -274,7 +274,9 @@ static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
   }
   else if (retry == 6) { if (r->hpart) rp->no_hpart = true; else rp->no_part = true; }      // a value beyond its column's recorded range in a packed tuple
   else if (retry == 4) {                                     // hashed partitioning: a range held more groups (or ids) than its passes' LDS tables take
-    if (r->plan.hp_passes >= 64) rp->no_hpart = true;        // ... skewed beyond help: the plain hash table
+    // ... skewed beyond help (a group with more ids than any number of passes fits into a range's LDS set): the plain hash table — and the table
+    // remembers the shape, like groups_seen for hash sizing: its next queries start there instead of paying for the void attempts every time
+    if (r->plan.hp_passes >= 64) { rp->no_hpart = true; std::lock_guard<std::mutex> lk(t->mu); t->hpart_hopeless.insert(r->group_sig); }
     else rp->hp_passes = (uint32_t)r->plan.hp_passes * 4;
     if (rp->hp_passes > 64) rp->hp_passes = 64;
   }
@@ -287,6 +289,10 @@ static void replan_after(vh_table* t, vh_result* r, int retry, VhReplan* rp) {
   else if (retry == 3) {                                     // tuple extents exhausted: more room, then give up on partitioning
     // the attempt counted its survivors even though it dropped their tuples: the next one is sized for exactly that many
     const uint64_t had = (uint64_t)r->plan.max_extents * r->plan.ext_tuples;
+    // the piecewise writers' positional chunks (VhPlanDev::ext_waves: tuples of three or more words, the pre-built kernels) ran out with room to
+    // spare: some waves met far more survivors than others. Remembered for the shape, like groups_seen for hash sizing: its next queries start on the
+    // shared cursor. (The ring writer needs no such memory: its streams overflow into the pool's shared region inside the kernel.)
+    if (r->plan.ext_waves && r->info.passed_recs + r->info.passed_recs / 16 <= had) { std::lock_guard<std::mutex> lk(t->mu); t->part_clustered.insert(r->group_sig); }
     if (rp->part_override && had >= r->info.scanned_recs) rp->no_part = true;
     else rp->part_override = std::max<uint64_t>(std::max<uint64_t>(rp->part_override * 2, r->info.passed_recs + r->info.passed_recs / 16), 1ull << 16);
   }

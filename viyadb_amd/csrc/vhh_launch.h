@@ -58,9 +58,9 @@ int QueryBuild::compile_kernel() {
       if (lds_table + (size_t)(jit_block / 64) * qw > lds_room) jit_try = false;
       if (mode == VH_MODE_HASH && !P.lds_hash_slots) jit_block = 256;
     }
-    if (hpart && hp_fan) jit_block = 1024;      // (one block per CU shares the 256 digits' waiting lines: vj_fan_add)
+    if (hpart) jit_block = 1024;      // (one block per CU shares the 256 digits' waiting lines: vj_fan_add)
     js.block = jit_block;
-    js.hp_fan = hpart && hp_fan ? 1 : 0;
+    js.hp_fan = hpart ? 1 : 0;
     js.ablate = knobs().jit_ablate;      // measurement only (profiles/r03/NOTES.md): 1 = no gathers, 2 = nothing behind the gathers
     js.xcd = nxcd > 1 ? 1 : 0;
     js.scope = (mode == VH_MODE_DENSE_GLOBAL || mode == VH_MODE_DENSE_LDS) && nxcd > 1 ? (int)__HIP_MEMORY_SCOPE_WORKGROUP : (int)__HIP_MEMORY_SCOPE_AGENT;
@@ -69,13 +69,11 @@ int QueryBuild::compile_kernel() {
     js.key_words = mode == VH_MODE_HASH ? P.key_words : 1;
     js.lds_hash = P.lds_hash_slots ? 1 : 0;
     js.gid32 = mode != VH_MODE_HASH && G <= 0xFFFFFFFFull;
-    const bool env_no_stage = knobs().no_stage;             // measurement: tuples appended piece by piece (vh_part_direct_add)
     js.gid_bits = mode == VH_MODE_DENSE_PART ? P.gid_bits : 0;
-    js.stage = mode == VH_MODE_DENSE_PART && (P.tw == 2 || P.gid_bits) && !env_no_stage ? (P.npart <= VH_STAGE_PARTS ? VH_STAGE_PARTS : P.npart <= VH_STAGE_PARTS_MAX ? VH_STAGE_PARTS_MAX : 0) : 0;
-    // ... or, on a query's first attempt, through the BLOCK's ring writer (vj_part_ring_add): extents by position; a re-run after VH_ERR_PART_FULL — a
-    // partition met more than its share and a half of some block's tuples — goes back to the per-wave writers, whose extents are handed out as they fill
-    part_ring = js.stage != 0 && !test_env("VH_NO_PART_RING");
-    if (part_ring) { js.part_ring = js.stage; js.stage = 0; }
+    // one- and two-word tuples of up to 64 partitions leave through the BLOCK's ring writer (vj_part_ring_add): whole lines, extents by position with
+    // the pool's shared overflow region behind them; wider tuples are appended piece by piece (vh_part_direct_add)
+    part_ring = mode == VH_MODE_DENSE_PART && (P.tw == 2 || P.gid_bits) && P.npart <= VH_RING_PARTS_MAX;
+    js.part_ring = part_ring ? (P.npart <= VH_RING_PARTS ? VH_RING_PARTS : VH_RING_PARTS_MAX) : 0;
     js.hpart = hpart ? 1 : 0;
     js.bs_off32 = hpart && hp_off32 ? 1 : 0;
     js.hp_pack = hp_pack ? 1 : 0; js.hp_pbits = hp_pbits; js.hp_idbits = hp_idbits;
@@ -150,12 +148,12 @@ int QueryBuild::compile_kernel() {
     for (int i = 0; i < P.ngroup; ++i) lanes_narrow |= vh_elem_size(P.g[i].type()) < 4;
     for (int j = 0; j < P.nmetric; ++j) lanes_narrow |= vh_elem_size(P.m[j].type()) < 4;
   }
-  if (!jk && (packed_compressed || (mode == VH_MODE_DENSE_PART && P.gid_bits) || lanes_narrow)) {      // compressed records / one-word tuples / narrow lanes columns and no compiled kernel to handle them after all: plan again for the pre-built ones
+  if (!jk && (packed_compressed || (mode == VH_MODE_DENSE_PART && P.gid_bits) || lanes_narrow || hpart)) {      // compressed records / one-word tuples / narrow lanes columns / the hashed partitioning (its scan writes level A itself) and no compiled kernel to handle them after all: plan again for the pre-built ones
     vh_plan p2 = *p;
     p2.flags |= VH_PLAN_NO_JIT;
     holder.reset();
     done = true;
-    return query_launch_locked(t, x, &p2, out, hash_capacity_override, force_hash, part_tuples_override, no_part, plan_only, summary_out, ag, device_rows, hp_passes_override, no_hpart);
+    return query_launch_locked(t, x, &p2, out, hash_capacity_override, force_hash, part_tuples_override, no_part, plan_only, summary_out, ag, device_rows, hp_passes_override, no_hpart || hpart);
   }
   return VH_OK;
 }
@@ -165,7 +163,7 @@ void QueryBuild::scan_dispatch(int grid_, int* occ) {
   const size_t lds_ = ((mode == VH_MODE_DENSE_LDS || mode == VH_MODE_HASH) ? lds_table : 0) + qb;
   hipStream_t s_ = x->stream();
   if (jk) {
-    const size_t jl = ((mode == VH_MODE_DENSE_LDS || (mode == VH_MODE_HASH && !hpart)) ? lds_table : 0) + (size_t)(BLOCK / 64) * (VJ_QUEUE_CAP * sizeof(uint32_t) + (size_t)VH_STAGE_BYTES(jshape.stage)) +
+    const size_t jl = ((mode == VH_MODE_DENSE_LDS || (mode == VH_MODE_HASH && !hpart)) ? lds_table : 0) + (size_t)(BLOCK / 64) * (VJ_QUEUE_CAP * sizeof(uint32_t)) +
                       (jshape.hp_fan ? VJ_FAN_LDS_BYTES(BLOCK) : 0) + (jshape.part_ring ? VH_RING_LDS_BYTES(jshape.part_ring, 2, BLOCK) : 0);
     if (occ) *occ = vh_jit_occupancy(jk, BLOCK, jl);
     else (void)vh_jit_launch(jk, P, grid_, BLOCK, jl, s_);
@@ -212,7 +210,7 @@ int QueryBuild::decompose_work() {
       r->kernel += hn + jk->name + "_hpagg";
     }
     const std::string pagg = jit_pagg() ? " + " + jk->name + "_pagg" : std::string(" + part_agg_kernel<1024>");
-    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? pagg : ((P.tw == 2 || P.gid_bits) && !test_env("VH_NO_SPLIT_TILE")) ? ((!test_env("VH_NO_SPLIT_RING") ? std::string(" + part_split_ring_kernel<256, ") : std::string(" + part_split_tile_kernel<256, ")) + (P.gid_bits ? "1>" : "2>") + pagg) : " + part_split_kernel<256>" + pagg;
+    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? pagg : (P.tw == 2 || P.gid_bits) ? (std::string(" + part_split_ring_kernel<256, ") + (P.gid_bits ? "1>" : "2>") + pagg) : " + part_split_kernel<256>" + pagg;
   }
   int occupancy = 0;
   if (env_bpc <= 0) scan_dispatch(0, &occupancy);
@@ -261,7 +259,7 @@ int QueryBuild::layout_scratch() {
   // the later chunks still aggregate: VH_HP_CHUNKS regions of the output columns, each with room for its share of the groups (the mixed
   // key spreads GROUPS evenly over the level-A partitions whatever the rows' skew) and a quarter more; a region that overflows all the
   // same voids the attempt like any pool that runs out
-  r->hp_direct = hpart && r->nhaving == 0 && r->topk == 0 && !knobs().hp_list;
+  r->hp_direct = hpart && r->nhaving == 0 && r->topk == 0;
   // ... or, in ONE launch, only takes its rows' places off the counter of its region (VH_HP_REGIONS, default off): every range of the aggregation
   // ends with a returning atomic on the result's row counter — 65 536 of them per query, each a block-wide wait. Measured: spreading them over
   // eight words buys nothing (profiles/r05/NOTES.md)
@@ -364,7 +362,7 @@ int QueryBuild::layout_scratch() {
     P.ext_stride = (int32_t)ext_stride;
     uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
     if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
-    if (hpart && hp_fan) max_ext = 64;      // (the scan writes the level-A pool itself: no stream pool to speak of)
+    if (hpart) max_ext = 64;      // (the scan writes the level-A pool itself — the plan's second pool —: nothing goes into this one)
     // the ring writer's pool: every (block, partition) stream its share of evenly spread tuples and one more extent BY POSITION, and behind those the
     // shared overflow region — room for all the expected tuples once more, so that ANY skew between the streams fits (one partition taking everything
     // included); only more survivors than estimated void the attempt, and the re-run is sized for the survivors it counted
@@ -378,22 +376,20 @@ int QueryBuild::layout_scratch() {
     // the scan's waves take their extent chunks by position (no shared cursor, no returning atomics: VhPlanDev::ext_waves). The pool above
     // holds that whenever the waves' tuple counts agree within the 25 % the estimate leaves; a re-run after VH_ERR_PART_FULL goes back to
     // the cursor, which packs the chunks whatever the imbalance
-    P.ext_waves = ring1 || part_tuples_override || test_env("VH_TEST_EXT_CURSOR") ? 0u : (uint32_t)grid * (uint32_t)(BLOCK / 64);
+    P.ext_waves = ring1 || part_tuples_override || test_env("VH_TEST_EXT_CURSOR") || t->part_clustered.count(r->group_sig) ? 0u : (uint32_t)grid * (uint32_t)(BLOCK / 64);
     o_tuples = sp.take(max_ext * ext_stride * P.tw * 8);
     o_emiss = sp.take(max_ext * sizeof(uint16_t));
     o_epart = sp.take(max_ext);
     if (P.nlevel == 2) {
       // pool 2: small extents (4096 ranges x every splitting wave keep one open), sized like pool 1 plus what stays open
       split_bpp = std::max(1, 2 * g_ctx.num_cu / std::max(1, P.npart));     // 256-thread blocks, ~2 per CU whatever the partition count: more waves keep more extents open (4 per CU measured slower)
-      // two-word tuples are split a block-wide tile at a time (part_split_tile_kernel): extents of one tile's size, one writer per block
-      const bool tiled = (P.tw == 2 || P.gid_bits) && !test_env("VH_NO_SPLIT_TILE");
-      if (tiled) split_bpp = std::max(1, knobs().split_bpc * g_ctx.num_cu / std::max(1, P.npart));   // a block is one writer: more of them cost less
+      // one- and two-word tuples are split through the ring writer (part_split_ring_kernel): a block is one writer, more of them cost less
+      const bool tiled = P.tw == 2 || P.gid_bits;
+      if (tiled) split_bpp = std::max(1, 4 * g_ctx.num_cu / std::max(1, P.npart));
       const uint64_t et2 = tiled ? VH_SPLIT_TILE_TUPLES : 256;
       P.ext_tuples2 = (int32_t)et2;
       uint64_t max2 = (part_tuple_cap + part_tuple_cap / 4) / et2 + (uint64_t)P.npart * ((uint64_t)split_bpp * (tiled ? 1 : 4) * (64 + VH_EXT_CHUNK) + 1) + 64;
-      // the first attempt splits through the ring writer: every (block, sub-partition) its extents by position, room for its share and a half and one
-      // more (part_l2_plan_kernel); a re-run after VH_ERR_PART_FULL — skewed group ids — takes the tiled kernel, whose extents are handed out as they fill
-      split_ring = tiled && !test_env("VH_NO_SPLIT_RING");
+      split_ring = tiled;
       // (slices laid out on the device from the partitions' counted tuples — vh_slice_extents: positional extents + an overflow region as big as the count)
       if (split_ring) max2 = 2 * (part_tuple_cap / et2) + (uint64_t)P.npart * (2 * 64 * split_bpp + 2) + 64;
       if (max2 > 0xFFFFFFF0ull) max2 = 0xFFFFFFF0ull;
@@ -410,20 +406,16 @@ int QueryBuild::layout_scratch() {
   if (hpart) {
     for (int k = 0; k < 1; ++k) {
       const uint64_t cap = hp_tuple_cap, hp_et = HP_ET / hp_units, hp_es = hp_et + (uint64_t)knobs().ext_pad / hp_units;      // tuples per extent / between extent starts
-      // level A: every block may hold an open extent per digit (+ one fresh one per tile boundary); level B: the slices hp_plan_kernel lays out
-      uint64_t ma = ((cap / hp_et) / g_ctx.num_cu * 3 / 2 + 2 * HP_FAN + 16) * g_ctx.num_cu;      // one slab per block: its share of the tuples and half again, an open extent per digit, one more per digit for the tails
-      if (hp_fan) {       // extents by position: extent k of (scan block, digit) is k * blocks * 256 + block * 256 + digit — a (block, digit)'s share and one more —, then the shared overflow region: all the tuples once more
-        const uint64_t per = (uint64_t)grid * HP_FAN, posa = cap / per / hp_et + 1;
-        ma = posa * per + cap / hp_et + per + 64;
-        if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS")) ma = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS")));      // tests: the first attempt's pool is too small
-        P.pos_levels2 = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(posa, ma / per), test_env("VH_TEST_POS_LEVELS") ? (uint64_t)std::max(0, atoi(test_env("VH_TEST_POS_LEVELS"))) : ~0ull);
-      }
-      uint64_t mb = cap / hp_et + (uint64_t)HP_FAN * (2 * HP_FAN + 9) + 64;
-      if (hp_fan) {       // level B by position too: hp_plan_kernel's slices, every (writing block, digit) of a partition its share and half again, and two more extents
-        hp_ring_nb = 1;      // (level-B blocks per partition. Measured, C5: two or four of them write level B no faster — 0.425 / 0.421 / 0.397 ms — and leave the
-                             //  aggregation two or four extents per range to walk: 1.08 / 1.24 / 1.69 ms)
-        mb = 2 * (cap / hp_et) + (uint64_t)HP_FAN * (2 * HP_FAN * hp_ring_nb + 2) + 64;      // (the slices' positional extents + their overflow regions: vh_slice_extents)
-      }
+      // level A: extents by position — extent k of (scan block, digit) is k * blocks * 256 + block * 256 + digit: a (block, digit)'s share and one more —,
+      // then the shared overflow region: all the tuples once more (any skew between the digits fits)
+      const uint64_t per = (uint64_t)grid * HP_FAN, posa = cap / per / hp_et + 1;
+      uint64_t ma = posa * per + cap / hp_et + per + 64;
+      if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS")) ma = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS")));      // tests: the first attempt's pool is too small
+      P.pos_levels2 = (uint32_t)std::min<uint64_t>(std::min<uint64_t>(posa, ma / per), test_env("VH_TEST_POS_LEVELS") ? (uint64_t)std::max(0, atoi(test_env("VH_TEST_POS_LEVELS"))) : ~0ull);
+      // level B: hp_plan_kernel's slices — positional extents + an overflow region as big as the partition's count (vh_slice_extents).
+      hp_ring_nb = 1;      // (level-B blocks per partition. Measured, C5: two or four of them write level B no faster — 0.425 / 0.421 / 0.397 ms — and leave the
+                           //  aggregation two or four extents per range to walk: 1.08 / 1.24 / 1.69 ms)
+      uint64_t mb = 2 * (cap / hp_et) + (uint64_t)HP_FAN * (2 * HP_FAN * hp_ring_nb + 2) + 64;
       if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS2")) mb = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS2")));   // tests: the last pool runs out
       hpo[k].maxa = ma; hpo[k].maxb = mb;
       hpo[k].ta = sp.take(ma * hp_es * 16 * hp_units); hpo[k].fa = sp.take(ma * 2); hpo[k].ga = sp.take(ma);
@@ -432,11 +424,6 @@ int QueryBuild::layout_scratch() {
     }
     o_hpargs = sp.take(sizeof(VhHpArgs));
   }
-  r->by_position = (hpart && hp_fan) || (jk && jshape.part_ring != 0) || (P.nlevel == 2 && split_ring);
-  r->pos_capacity = ~0ull;
-  if (hpart && hp_fan) r->pos_capacity = std::min<uint64_t>(hpo[0].maxa, hpo[0].maxb) * (uint64_t)(HP_ET / hp_units);
-  if (jk && jshape.part_ring != 0) r->pos_capacity = std::min<uint64_t>(r->pos_capacity, (uint64_t)P.max_extents * (uint64_t)P.ext_tuples);
-  if (P.nlevel == 2 && split_ring) r->pos_capacity = std::min<uint64_t>(r->pos_capacity, (uint64_t)P.max_extents2 * (uint64_t)P.ext_tuples2);
   size_t o_fbs[VH_MAX_BITSET] = {};
   for (size_t k = 0; k < r->filter_bitset_cols.size(); ++k) o_fbs[k] = sp.take(std::max<uint32_t>(nseg, 1) * 8);
   size_t o_bsptr[VH_MAX_BITSET][2] = {}, o_dkeys[VH_MAX_BITSET] = {}, o_dtags[VH_MAX_BITSET] = {};
@@ -567,21 +554,17 @@ int QueryBuild::launch() {
     for (int k = 0; k < 1; ++k) {
       VhHpKind& K = HA.k[k];
       char* meta = S + hpo[k].meta;
-      K.z.tuples = P.tuples; K.z.fill = P.extent_missing; K.z.tag = P.extent_part;
-      K.z.max_extents = P.max_extents; K.z.stream = 1; K.z.cursor = P.counters + 5; K.z.stride = (uint32_t)(HP_ET / hp_units);
       K.a.stride = K.b.stride = (uint32_t)(HP_ET / hp_units) + (uint32_t)knobs().ext_pad / (uint32_t)hp_units;
       K.a.tuples = reinterpret_cast<uint64_t*>(S + hpo[k].ta); K.a.fill = reinterpret_cast<uint16_t*>(S + hpo[k].fa); K.a.tag = reinterpret_cast<uint8_t*>(S + hpo[k].ga);
-      K.a.max_extents = (uint32_t)std::min<uint64_t>(hpo[k].maxa, 0xFFFFFFF0ull); K.a.cursor = nullptr;      // (handed out in one slab per block of level A)
+      K.a.max_extents = (uint32_t)std::min<uint64_t>(hpo[k].maxa, 0xFFFFFFF0ull);
       K.b.tuples = reinterpret_cast<uint64_t*>(S + hpo[k].tb); K.b.fill = reinterpret_cast<uint16_t*>(S + hpo[k].fb); K.b.tag = reinterpret_cast<uint8_t*>(S + hpo[k].gb);
-      K.b.max_extents = (uint32_t)std::min<uint64_t>(hpo[k].maxb, 0xFFFFFFF0ull); K.b.cursor = nullptr;
-      K.a.ovf_base = K.a.max_extents; K.a.ovf_cursor = nullptr; K.b.ovf_base = K.b.max_extents; K.b.ovf_cursor = nullptr; K.z.ovf_base = 0; K.z.ovf_cursor = nullptr;
-      if (hp_fan) {       // pool a behind its positional levels: the shared overflow region the scan's writer takes extents from (counters[10])
-        K.a.ovf_base = (uint32_t)std::min<uint64_t>((uint64_t)P.pos_levels2 * (uint64_t)grid * HP_FAN, K.a.max_extents);
-        K.a.ovf_cursor = P.counters + 10;
-      }
-      if (hp_fan) {       // the scan kernel's view of pool a (the second pool's fields of the plan: DENSE_PART's two-level plans are the other user)
-        P.tuples2 = K.a.tuples; P.extent_missing2 = K.a.fill; P.extent_part2 = K.a.tag; P.max_extents2 = K.a.max_extents; P.ext_tuples2 = (int32_t)K.a.stride;
-      }
+      K.b.max_extents = (uint32_t)std::min<uint64_t>(hpo[k].maxb, 0xFFFFFFF0ull);
+      K.b.ovf_base = K.b.max_extents; K.b.ovf_cursor = nullptr;      // (pool b's slices carry their own overflow regions and cursors)
+      // the scan kernel's view of pool a (the second pool's fields of the plan: DENSE_PART's two-level plans are the other user); behind its positional
+      // levels the shared overflow region the scan's writer takes extents from (counters[10])
+      P.tuples2 = K.a.tuples; P.extent_missing2 = K.a.fill; P.extent_part2 = K.a.tag; P.max_extents2 = K.a.max_extents; P.ext_tuples2 = (int32_t)K.a.stride;
+      K.a.ovf_base = (uint32_t)std::min<uint64_t>((uint64_t)P.pos_levels2 * (uint64_t)grid * HP_FAN, K.a.max_extents);
+      K.a.ovf_cursor = P.counters + 10;
       K.count = reinterpret_cast<uint32_t*>(meta + 8);
       K.slice = reinterpret_cast<uint32_t*>(meta + 8 + (size_t)HP_FAN * 4);
       clear(K.a.fill, (size_t)K.a.max_extents * 2, 0);
@@ -623,7 +606,7 @@ int QueryBuild::launch() {
   if (P.total_units) {
     scan_dispatch(grid, nullptr);
     if (hpart) {
-      vh_launch_hpart(P, d_hpargs, hp_units, g_ctx.num_cu, hp_fan ? grid : 0, hp_ring_nb, st);
+      vh_launch_hpart(P, d_hpargs, hp_units, g_ctx.num_cu, grid, hp_ring_nb, st);
       if (!r->hp_chunks) HIP_TRY(vh_jit_launch_hpagg(jk, P, d_hpargs, hp_bpp, 0, HP_FAN * hp_bpp, lds_table, st));
       else if (r->hp_one_launch) {      // regions without streaming: one launch, every region's row count into pinned memory behind it
         HIP_TRY(vh_jit_launch_hpagg(jk, P, d_hpargs, hp_bpp, 0, HP_FAN * hp_bpp, lds_table, st));
@@ -680,10 +663,18 @@ static int query_launch_locked(vh_table* t, VhExec* x, const vh_plan* p, vh_resu
   int (QueryBuild::* const steps[])() = {&QueryBuild::shape_filter, &QueryBuild::snapshot_segments, &QueryBuild::shape_groups, &QueryBuild::shape_metrics,
                                          &QueryBuild::choose_organisation, &QueryBuild::plan_hashed_partitioning, &QueryBuild::choose_projection,
                                          &QueryBuild::compile_kernel, &QueryBuild::decompose_work, &QueryBuild::layout_scratch, &QueryBuild::launch};
+  const bool timed = knobs().times;
+  double us[12] = {};
+  int k = 0;
   for (auto step : steps) {
+    const auto s0 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
     if (int rc = (b.*step)()) return rc;
-    if (b.done) return VH_OK;
+    if (timed) us[k] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s0).count();
+    ++k;
+    if (b.done) break;
   }
+  if (timed) fprintf(stderr, "vh plan steps (us): filter %.1f, segments %.1f, groups %.1f, metrics %.1f, organisation %.1f, hpart %.1f, projection %.1f, kernel %.1f, work %.1f, scratch %.1f, launch %.1f\n",
+                     us[0], us[1], us[2], us[3], us[4], us[5], us[6], us[7], us[8], us[9], us[10]);
   return VH_OK;
 }
 

@@ -874,10 +874,10 @@ int QueryBuild::choose_organisation() {
       // point of selectivity beyond the crossover. A 125 M-row shard of C3 (8 GPUs) stays on direct atomics, 1 G rows do not.
       const double shard_rows = (double)(ag ? ag->rows_max : rows_to_scan);
       if (want_part && shard_rows * (sel - (covered ? 0.03 : 0.045)) < (two_level ? 1e7 : 3.5e6)) want_part = false;      // (C3 shards: 125 M rows 0.733 ms direct vs 0.74-0.78 partitioned, 250 M rows 1.30 vs 1.18)
-      // Round 3: with the scan compiled for the plan and two-word tuples leaving as whole lines (vh_part_staged_add) a tuple costs ~10 ps
+      // Round 3: with the scan compiled for the plan and two-word tuples leaving as whole lines (then the per-wave writer, now the block's ring writer) a tuple costs ~10 ps
       // against ~86 ps for its two direct atomics, and phase 2's fixed cost is ~0.1 ms: an eighth of C3 (125 M rows, 6.2 M survivors) runs
       // 0.47 ms partitioned against 0.60 ms direct, a quarter 0.78 against 1.12 (profiles/r03/NOTES.md). From 2 M survivors on, one level.
-      if (!want_part && !two_level && jit_try && np <= VH_STAGE_PARTS) {
+      if (!want_part && !two_level && jit_try && np <= VH_RING_PARTS) {
         int words = 1, halves = 1;           // tuple words this plan would need: 64-bit states own one, 32-bit ones pair up (word 0 has one half free)
         for (int j = 0; j < P.nmetric; ++j) { if (vh_sop_bytes(P.m[j].sop()) == 8) ++words; else if (halves) --halves; else { ++words; halves = 1; } }
         if (words == 2 && shard_rows * sel >= 2e6 && sel >= 0.015) want_part = true;      // (at 1 % of 1 B rows the atomics still hide behind the scan: 1.18 ms direct, 1.31 partitioned)
@@ -889,7 +889,7 @@ int QueryBuild::choose_organisation() {
     // with the whole-line writer packs them.
     int nt_gb = 0, nt_mb[VH_MAX_METRIC] = {};
     bool narrow_tuples = false;
-    if (want_part && jit_try && (two_level ? (np + 63) / 64 : np) <= VH_STAGE_PARTS_MAX && !knobs().no_stage && !(p->flags & (VH_PLAN_NO_NARROW_TUPLES | VH_PLAN_FORCE_LANES)) && !test_env("VH_NO_NARROW_TUPLES")) {
+    if (want_part && jit_try && (two_level ? (np + 63) / 64 : np) <= VH_RING_PARTS_MAX && !(p->flags & (VH_PLAN_NO_NARROW_TUPLES | VH_PLAN_FORCE_LANES)) && !test_env("VH_NO_NARROW_TUPLES")) {
       auto bits_of = [](uint64_t v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; };
       nt_gb = bits_of(G - 1);
       int used = nt_gb;
@@ -925,7 +925,7 @@ int QueryBuild::choose_organisation() {
             // the 64-way phase 1 writes its tuples piecewise and the no-compaction form keeps its lead from 50 % on: 21.4 vs 22.8 ms)
             // (... nor when the tuples are one word: half the bytes beat the saved compaction at every selectivity, two levels included —
             // 4 M groups, every row passing: 23.1 ms through the no-compaction form, see profiles/r04/NOTES.md for the one-word figure)
-            lanes = s2 >= 0.5 && !(jit_try && !two_level && np <= VH_STAGE_PARTS) && !narrow_tuples;
+            lanes = s2 >= 0.5 && !(jit_try && !two_level && np <= VH_RING_PARTS) && !narrow_tuples;
           }
         }
       }
@@ -1087,7 +1087,7 @@ int QueryBuild::plan_hashed_partitioning() {
   // (Sharded queries take it too: what ranks exchange — finalised groups and, for a bitset metric, (group, id) pairs by owner — does not
   // depend on how a rank aggregated its shard, so the choice need not even agree between ranks; with an agreement it is made from the
   // agreed figures all the same.)
-  if (mode == VH_MODE_HASH && jit_try && (!lanes || (p->flags & VH_PLAN_FORCE_HPART)) && !no_hpart && !(p->flags & VH_PLAN_NO_HPART) && P.key_words == 1 && P.nmetric >= 1 && rows_to_scan) {
+  if (mode == VH_MODE_HASH && jit_try && (!lanes || (p->flags & VH_PLAN_FORCE_HPART)) && !no_hpart && !(p->flags & VH_PLAN_NO_HPART) && !(t->hpart_hopeless.count(r->group_sig) && !(p->flags & VH_PLAN_FORCE_HPART)) && P.key_words == 1 && P.nmetric >= 1 && rows_to_scan) {
     int bits = 0, nb = 0;
     bool ok = true;
     for (int j = 0; j < P.nmetric; ++j) {
@@ -1149,10 +1149,8 @@ int QueryBuild::plan_hashed_partitioning() {
           hp_off32 = !test_env("VH_NO_OFF32");
           for (uint32_t sgi : live) hp_off32 = hp_off32 && t->cols[bitset_col[0]].bs_offsets32[sgi] != nullptr;
         }
-        // the scan partitions 256 ways by itself (one 1024-thread block per CU, extents by position): the first attempt of a query; a re-run after
-        // VH_ERR_PART_FULL — some (block, digit) met far more tuples than its share: skewed keys — goes through the stream pool and level A,
-        // whose extents are handed out as they fill
-        hp_fan = !test_env("VH_NO_HP_FAN") && knobs().ext_pad % 8 == 0;
+        // the scan partitions 256 ways by itself (one 1024-thread block per CU sharing the digits' waiting lines: vj_fan_add)
+        hp_fan = true;
         lanes = false;
         P.hpart = 1; P.gid_shift = 32;
         P.npart = 1; P.part_shift = 0; P.nlevel = 1; P.agg_shift = 0; P.nfine = 1;      // (the scan kernel writes ONE stream per kind; vh_hpart.h partitions it)

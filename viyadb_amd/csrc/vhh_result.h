@@ -68,8 +68,6 @@ extern "C" int vh_segment_stats(vh_table* t, uint32_t seg, int32_t col, vh_anynu
 struct vh_result {
   bool hpart = false;               // hashed partitioning ran: the table is a compact list of group records ...
   uint32_t part_blocks = 0;         // DENSE_PART: blocks of the phase-2 launch (what vh_part_shares shares out)
-  bool by_position = false;         // this attempt's tuples went through the ring writer: extents by position (a skewed shape overflows them with room to spare)
-  uint64_t pos_capacity = 0;        // ... and the tuples the smallest such pool holds
   bool hp_direct = false;           // ... or its aggregation kernel already wrote the output columns (no emission kernel to run)
   int hp_chunks = 0;                // ... in this many chunk launches, each with a region of `hp_chunk_rows` rows of the output columns: delivered chunk by chunk
   uint64_t hp_chunk_rows = 0;

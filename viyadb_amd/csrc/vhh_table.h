@@ -111,7 +111,8 @@ struct vh_table {
   std::vector<uint16_t> ship_all, ship_metrics;          // vh_table_sync_batch: the columns an item ships (every fixed-width one / the metrics alone)
   std::vector<uint64_t> sync_rows_now;                   // ... and its scratch (rows mirrored per named segment while a batch is validated)
   std::map<std::string, uint64_t> groups_seen;           // group-column signature -> groups of the last query (hash sizing)
-  std::set<std::string> part_clustered;                  // group-column signatures whose survivors came clustered: positional extent chunks overflowed although the pool had room — later queries of the shape take their extents off the shared cursor at once
+  std::set<std::string> hpart_hopeless;                  // group-column signatures whose hashed partitioning ended on the plain hash table (a group holding more ids than a range's LDS set takes in any number of passes): later queries of the shape start there
+  std::set<std::string> part_clustered;                  // group-column signatures whose survivors came clustered under the piecewise writers: positional extent chunks (VhPlanDev::ext_waves) overflowed although the pool had room — later queries of the shape take their extents off the shared cursor at once
   std::map<std::string, std::pair<uint64_t, uint64_t>> sel_cache;   // filter signature + table state -> (passed, sampled) of the selectivity probe
   std::vector<std::unique_ptr<VhPack>> packs;
   std::vector<std::unique_ptr<VhNarrow>> narrows;
@@ -239,7 +240,7 @@ static int exec_acquire(vh_table* t, VhExec** out) {
 static int exec_streaming(VhExec* x) {       // what a streamed result needs on top of a context's stream; once per context
   if (x->copy) return VH_OK;
   HIP_TRY(hipStreamCreateWithFlags(&x->aux, hipStreamNonBlocking));
-  { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIP_TRY(hipStreamCreateWithPriority(&x->copy, hipStreamNonBlocking, getenv("VH_COPY_PRIO") ? hi : 0)); }
+  { int lo = 0, hi = 0; (void)hipDeviceGetStreamPriorityRange(&lo, &hi); HIP_TRY(hipStreamCreateWithPriority(&x->copy, hipStreamNonBlocking, 0)); }
   HIP_TRY(hipEventCreateWithFlags(&x->ev_fork, hipEventDisableTiming));
   for (auto& e : x->ev_chunk) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   HIP_TRY(hipHostMalloc((void**)&x->h_chunk, VH_HP_CHUNKS * sizeof(unsigned long long), hipHostMallocCoherent));

@@ -63,7 +63,7 @@ static std::mutex g_mu;
 
 // Every environment knob of the library, read ONCE (first use, normally vh_init) instead of wherever the planner happened to want
 // one. They exist for measurements and tests: defaults are what every reported number was taken with (DESIGN.md "Knobs"). The
-// VH_TEST_* / VH_POISON / VH_NO_SPLIT_TILE / VH_PART_TABLE_KB / VH_NO_HP_PACK / VH_NO_OFF32 hooks are the exception — tests switch them between two
+// VH_TEST_* / VH_POISON / VH_PART_TABLE_KB / VH_NO_HP_PACK / VH_NO_OFF32 hooks are the exception — tests switch them between two
 // queries of one process — and go through test_env(): one gate (VH_TEST_HOOKS, read once; tests/conftest.py sets it) in front of them, so
 // that a serving process never walks its environment on the query path.
 static const char* test_env(const char* name) {
@@ -71,8 +71,8 @@ static const char* test_env(const char* name) {
   return hooks ? getenv(name) : nullptr;
 }
 struct VhKnobs {
-  bool trace_alloc, no_topk, no_stage, jit_verbose, skip_phase2, no_direct_emit, times, no_jit_pagg, predpack_bytes;
-  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, split_bpc, bw_blocks_per_cu, hp_list, hp_stream, hp_regions, hp_agg_waves, deliver_blocks;
+  bool trace_alloc, no_topk, jit_verbose, skip_phase2, no_direct_emit, times, no_jit_pagg, predpack_bytes;
+  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, bw_blocks_per_cu, hp_stream, hp_regions, hp_agg_waves, deliver_blocks;
   double hp_load_g, hp_load_s, qpay_min_sel;
 };
 static const VhKnobs& knobs() {
@@ -81,20 +81,22 @@ static const VhKnobs& knobs() {
     auto num = [](const char* n, int dflt) { const char* e = getenv(n); return e ? atoi(e) : dflt; };
     auto real = [](const char* n, double dflt) { const char* e = getenv(n); return e ? atof(e) : dflt; };
     VhKnobs x{};
-    x.trace_alloc = flag("VH_TRACE_ALLOC"); x.no_topk = flag("VH_NO_TOPK"); x.no_stage = flag("VH_NO_STAGE");
-    x.jit_verbose = flag("VH_JIT_VERBOSE"); x.skip_phase2 = flag("VH_ABLATE_NO_PHASE2"); x.no_direct_emit = flag("VH_NO_DIRECT_EMIT"); x.times = flag("VH_TIMES"); x.no_jit_pagg = flag("VH_NO_JIT_PAGG"); x.predpack_bytes = flag("VH_PREDPACK_BYTES");      // (measurement: automatic predicate projections as byte planes, not bit-sliced)      // (measurement / tests: the pre-built part_agg_kernel behind a compiled scan)
+    x.trace_alloc = flag("VH_TRACE_ALLOC"); x.jit_verbose = flag("VH_JIT_VERBOSE"); x.times = flag("VH_TIMES");
     x.max_exec = std::max(1, num("VH_MAX_EXEC", 16));
     x.auto_narrow = num("VH_AUTO_NARROW", 3); x.auto_pack = num("VH_AUTO_PACK", 3);
-    x.jit_ablate = num("VH_JIT_ABLATE", 0); x.hp_ablate = num("VH_HP_ABLATE", 0); x.hp_bpp = num("VH_HP_BPP", 0); x.pack_plain = num("VH_PACK_PLAIN", 0);
-    x.lanes_block = num("VH_LANES_BLOCK", 0); x.blocks_per_cu = num("VH_BLOCKS_PER_CU", 0); x.unit_rows = num("VH_UNIT_ROWS", 0); x.grid = num("VH_GRID", 0);
-    x.ext_tuples = num("VH_EXT_TUPLES", 0); x.ext_pad = std::max(0, num("VH_EXT_PAD", 8)) / 8 * 8; x.hp_list = num("VH_HP_LIST", 0);
-    x.hp_agg_waves = num("VH_HP_AGG_WAVES", 0);
-    x.hp_regions = num("VH_HP_REGIONS", 0);           // regions (row counters) of a big hashed-partitioning result written in ONE launch (0: off — measured: C5 14.4 vs 13.9 ms per query, the row counter is not what the aggregation waits for; profiles/r05/NOTES.md)
     x.hp_stream = num("VH_HP_STREAM", 0);             // chunk launches of a streamed result (0: off — measured: the link, not the wait for the kernels, bounds the delivery; profiles/r04/NOTES.md)
-    x.deliver_blocks = num("VH_DELIVER_BLOCKS", 64);  // blocks of deliver_kernel; 0: big results through hipMemcpyAsync (the DMA engine)
-    x.split_bpc = num("VH_SPLIT_BPC", 4); x.bw_blocks_per_cu = std::max(1, num("VH_BW_BLOCKS_PER_CU", 8));
-    x.hp_load_g = real("VH_HP_LOAD_G", 0.7); x.hp_load_s = real("VH_HP_LOAD_S", 0.7);
     x.qpay_min_sel = real("VH_QPAY_MIN_SEL", 0.15);        // selectivity from which the compiled scan streams 4-byte payload records instead of gathering them (measured: profiles/r05/NOTES.md)
+    // What rounds 2-5 could switch from the environment for a measurement and round 6 fixed at the measured value (the notes of the round that
+    // measured it say why; an A/B now means a line changed here and a rebuild): VH_NO_TOPK, VH_ABLATE_NO_PHASE2, VH_NO_DIRECT_EMIT, VH_NO_JIT_PAGG,
+    // VH_PREDPACK_BYTES, VH_JIT_ABLATE, VH_HP_ABLATE, VH_HP_BPP, VH_PACK_PLAIN, VH_LANES_BLOCK, VH_BLOCKS_PER_CU, VH_UNIT_ROWS, VH_GRID, VH_EXT_TUPLES,
+    // VH_EXT_PAD, VH_HP_AGG_WAVES, VH_HP_REGIONS, VH_DELIVER_BLOCKS, VH_BW_BLOCKS_PER_CU, VH_HP_LOAD_G / _S.
+    x.no_topk = false; x.skip_phase2 = false; x.no_direct_emit = false; x.no_jit_pagg = false; x.predpack_bytes = false;
+    x.jit_ablate = 0; x.hp_ablate = 0; x.hp_bpp = 0; x.pack_plain = 0; x.lanes_block = 0; x.blocks_per_cu = 0; x.unit_rows = 0; x.grid = 0;
+    x.ext_tuples = 0; x.ext_pad = 8; x.hp_agg_waves = 0;
+    x.hp_regions = 0;           // regions (row counters) of a big hashed-partitioning result written in ONE launch (measured: C5 14.4 vs 13.9 ms per query, the row counter is not what the aggregation waits for; profiles/r05/NOTES.md)
+    x.deliver_blocks = 64;      // blocks of deliver_kernel
+    x.bw_blocks_per_cu = 8;
+    x.hp_load_g = 0.7; x.hp_load_s = 0.7;
     return x;
   }();
   return k;
