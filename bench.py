@@ -245,6 +245,7 @@ def main():
     ap.add_argument("--no-predpack", action="store_true", help="ablation: narrow copies of the predicate columns (round 4's layout) instead of the bit-packed predicate projection")
     ap.add_argument("--no-warm", action="store_true", help="no vh_table_prepare: the first queries pay the first-use costs")
     ap.add_argument("--no-reference-layout", action="store_true", help="skip the arena-only leg (profiling runs)")
+    ap.add_argument("--no-unprepared", action="store_true", help="skip the unprepared-caller leg (a second table: profiling runs)")
     ap.add_argument("--rendezvous-only", action="store_true", help="launch the ranks, meet over gloo, print who came, stop (the launcher's own test: needs no GPU)")
     args = ap.parse_args()
 
@@ -374,6 +375,30 @@ def main():
         rel = time.perf_counter() - r0
         ref_layout = (rlast, rel / rsteps, sum(rk) / len(rk), rsteps)
         table.prepare(plan)
+    # An UNPREPARED caller: a second table of the same rows that nobody calls vh_table_prepare / vh_table_pack / vh_table_predpack
+    # on — the query simply arrives, eight times. The first one pays the kernel's compile (or its load from the disk cache), the first few read the
+    # reference's layout, and the library builds the derived layouts unasked once the shape has been seen VH_AUTO_PACK / VH_AUTO_NARROW (3) times:
+    # what every one of those queries costs is in the line, next to what the prepared table's cost.
+    unprepared = None
+    if world == 1 and not args.no_pack and not args.no_unprepared and not args.no_warm:
+        try:
+            t2 = synth.create_device_table(w, my_segments, w.segment_rows, row_base=seg_lo * w.segment_rows)
+            torch.cuda.synchronize()
+            uplan = executor.AggPlan(filter=plan.filter, groups=plan.groups, metrics=plan.metrics, flags=plan.flags, groups_hint=plan.groups_hint)
+            per, kern, packed_at = [], [], None
+            for i in range(10):
+                q0 = time.perf_counter()
+                ur = t2.query_agg(uplan, copy=False)
+                per.append(round((time.perf_counter() - q0) * 1e3, 3))
+                kern.append(round(ur.scan_kernel_ms, 3))
+                if packed_at is None and ur.packed and ur.predpack:
+                    packed_at = i
+            unprepared = {"what": "a second table of the same rows, no vh_table_prepare / pack / predpack: the same query ten times from a caller that prepares nothing",
+                          "per_query_ms": per, "kernel_ms": kern, "derived_layouts_in_use_from_query": packed_at, "steady_ms": sorted(per[-3:])[1],
+                          "kernel": ur.kernel, "groups": ur.ngroups}
+            t2.close()
+        except Exception as e:   # noqa: BLE001 - a courtesy leg must not take the number down
+            unprepared = {"failed": repr(e)[:300]}
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -425,7 +450,11 @@ def main():
                        "pack_seconds": round(t_pack, 3), "device_bytes": table.info()[2]},
             # what the derived layouts cost, first class: built once (like the reference's per-query g++ compile, outside its steady
             # state), resident next to the table
-            "derived_layout": {"one_time_seconds": round(t_pack, 4), "extra_device_bytes": max(0, table.info()[2] - total_rows * w.table_bytes_per_row // max(1, world)),
+            "unprepared": unprepared,
+            "derived_layout": {"one_time_seconds": round(t_pack, 4),
+                               # queries of this shape after which building the derived layouts has paid for itself: one-time seconds / (what a query costs
+                               # on the reference's layout - what it costs on the derived ones), both measured in this run
+                               "break_even_queries": (round(t_pack / max(1e-9, ref_layout[1] - elapsed / args.steps)) if ref_layout is not None and ref_layout[1] > elapsed / args.steps else None), "extra_device_bytes": max(0, table.info()[2] - total_rows * w.table_bytes_per_row // max(1, world)),
                                "table_bytes": total_rows * w.table_bytes_per_row // max(1, world),
                                "what": ("payload projection of the group + metric columns (vh_table_pack) and " + ("8- / 16-bit copies of the predicate columns (vh_table_narrow)" if args.no_predpack else
                                         "the predicate columns as bit fields of one word per row, bit-sliced: one plane per bit, compared 32 rows per lane at a time (vh_table_predpack)")) if not args.no_pack else "none"},

@@ -12,7 +12,7 @@ mkdir -p $OUT profiles/$R
 export TMPDIR=/tmp
 REPO=$PWD
 SRC=$(python -c "import bench; print(bench.kernel_sources_hash())")
-Q="--no-cpu --no-check --no-reference-layout --no-cpu-parallel"
+Q="--no-cpu --no-check --no-reference-layout --no-cpu-parallel --no-unprepared"
 one() {   # name (workload[_variant]), rows, bref, bench args...
   local W=$1 ROWS=$2 BREF=$3; shift 3
   python bench.py "$@" $Q --steps 3 --warmup 2 > $OUT/pre_$W.json 2> $OUT/pre_$W.err
@@ -35,15 +35,16 @@ one() {   # name (workload[_variant]), rows, bref, bench args...
       for KK in viya_jit part_agg hp_scatter hp_ring_scatter scan_agg; do python tools/pmc_kernel.py $OUT/pmc_insts_$W $KK; done; } > $OUT/${W}_1gpu_pmc_insts.txt;;
   esac
   # the line itself, LAST: it now carries the traffic of the pass above
-  python bench.py "$@" ${FINAL_EXTRA---no-cpu --no-reference-layout --no-cpu-parallel} > $OUT/bench_${W}_1gpu.json 2> $OUT/bench_${W}.err
+  python bench.py "$@" ${FINAL_EXTRA---no-cpu --no-reference-layout --no-cpu-parallel --no-unprepared} > $OUT/bench_${W}_1gpu.json 2> $OUT/bench_${W}.err
   python -c "import json; d=json.load(open('$OUT/bench_${W}_1gpu.json')); r=d['roofline']; print('$W', round(d['ms_per_step'],3), 'ms/step, kernels', round(r['kernel_ms'],3), 'frac', round(r['frac'],3), 'traffic', r['traffic'])"
 }
 one c3_arena 1000000000 32e9 --no-pack              # the reference layout: column arenas only (bench.py's reference_layout leg reads this pass)
 FINAL_EXTRA="" one c3 1000000000 32e9               # the headline line: parity gate, reference_layout leg, both CPU baselines
 one c3_direct 1000000000 32e9 --flags 16            # the same query forced onto direct atomics (what a slower box or a smaller shard runs)
 one c2 100000000 2e9 --workload C2
-one c5 125000000 3.5e9 --workload C5 --segments 125 --steps 5 --warmup 1
-one c5t 125000000 1.5e9 --workload C5t --segments 125 --steps 5 --warmup 1
+# (C5 / C5t: with the CPU twin's baseline on a 5-segment sample — VERDICT r05 #2 — and the parity gate)
+FINAL_EXTRA="--no-reference-layout --no-cpu-parallel --no-unprepared" one c5 125000000 3.5e9 --workload C5 --segments 125 --steps 5 --warmup 1
+FINAL_EXTRA="--no-reference-layout --no-cpu-parallel --no-unprepared" one c5t 125000000 1.5e9 --workload C5t --segments 125 --steps 5 --warmup 1
 python bench.py --workload C1 --no-cpu-parallel --no-reference-layout > $OUT/bench_c1_1gpu.json 2> $OUT/bench_c1.err     # the plumbing case: a bench line only (launch-bound)
 python tools/scale_proxy.py 1 2 4 8 2>/dev/null | grep '^{' > $OUT/scale_proxy.txt                                         # one rank's step of the N-GPU run, on one GPU
 bash tools/fetch_calib.sh $OUT/fetch_calibration.json > $OUT/fetch_calibration.log 2>&1

@@ -495,12 +495,38 @@ __device__ __forceinline__ uint64_t vh_wave_combine(int sop, uint64_t v, bool in
   }
   return v;
 }
-__device__ __forceinline__ uint64_t vh_hot_lanes(bool active, uint64_t gid) {      // lanes that share the first active lane's group, when they are eight or more (else 0)
-  const uint64_t act = __ballot(active);
-  if (!act) return 0ull;
-  const uint64_t lg = __shfl(gid, __builtin_ctzll(act));
+__device__ __forceinline__ uint64_t vh_hot_lanes(bool active, uint64_t gid) {      // lanes of the wave's hot group, when they are eight or more (else 0)
+  // which group? One that two NEIGHBOURING survivors share (distance 1 or 2): with tens of millions of groups and uniform keys that does not happen,
+  // with a group that holds an eighth of the survivors or more it happens in nearly every drain
+  const int lane = (int)(threadIdx.x & 63);
+  const uint64_t g1 = __shfl_down(gid, 1), g2 = __shfl_down(gid, 2);
+  const bool a1 = __shfl_down((int)active, 1) != 0 && lane < 63, a2 = __shfl_down((int)active, 2) != 0 && lane < 62;
+  const uint64_t pairs = __ballot(active && ((a1 && g1 == gid) || (a2 && g2 == gid)));
+  if (!pairs) return 0ull;
+  const uint64_t lg = __shfl(gid, __builtin_ctzll(pairs));
   const uint64_t hot = __ballot(active && gid == lg);
   return __popcll(hot) >= 8 ? hot : 0ull;
+}
+// ... and what a WAVE keeps of its hot group between drains (the pre-built scan of the hash organisation): the group's slot and, for up to four
+// value metrics and one count-distinct, what the wave's rows have added to them so far — wave-uniform registers, flushed with one atomic each when
+// the hot group changes and at the wave's end. A group that holds a tenth of a billion rows then costs a few thousand atomics, not a hundred million.
+#define VH_HOT_METRICS 4
+struct VhHotAcc {
+  uint64_t gid; bool valid; unsigned long long card;
+  uint64_t v[VH_HOT_METRICS];
+};
+__device__ __forceinline__ void vh_hot_flush(const VhPlanDev& P, VhHotAcc& A) {      // (wave-uniform)
+  if (!A.valid) return;
+  if ((threadIdx.x & 63) == 0) {
+    int k = 0;
+    for (int j = 0; j < P.nmetric; ++j) {
+      const VhMetricDev& m = P.m[j];
+      if (m.sop() == SOP_BITSET) { if (A.card) atomicAdd(reinterpret_cast<unsigned long long*>(vh_hash_state(P, m, A.gid)), A.card); continue; }
+      if (k < VH_HOT_METRICS) vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(vh_hash_state(P, m, A.gid), 0, m.sop(), A.v[k]);
+      ++k;
+    }
+  }
+  A.valid = false;
 }
 
 // COUNT DISTINCT: insert every id of the row's set into metric b's (group, id) set; first sight bumps card[gid]
@@ -555,7 +581,8 @@ __device__ __forceinline__ void vh_distinct_update(const VhPlanDev& P, int b, un
 // therefore keeps a small open-addressing table in LDS; a row whose key finds (or claims) a slot there costs LDS
 // atomics only, everything else falls through to the HBM table. A wave that mostly falls through (high-cardinality
 // keys: the table fills up at once) stops probing LDS after a warm-up.
-struct VhLdsHashWave { uint32_t hits, misses; bool bypass; unsigned long long npairs; /* per lane: fresh (group, id) pairs */ bool dead = false; /* wave-uniform: an insert of this wave found the table full */ };
+struct VhLdsHashWave { uint32_t hits, misses; bool bypass; unsigned long long npairs; /* per lane: fresh (group, id) pairs */ bool dead = false; /* wave-uniform: an insert of this wave found the table full */
+                       VhHotAcc hot{0ull, false, 0ull, {0ull, 0ull, 0ull, 0ull}}; /* the wave's hot group between drains (vh_hot_flush at the wave's end) */ };
 
 __device__ __forceinline__ bool vh_lds_hash_find(const VhPlanDev& P, char* lds, uint64_t key, uint32_t& slot_out) {
   unsigned long long* lk = reinterpret_cast<unsigned long long*>(lds + P.lds_hkeys_off);
@@ -666,10 +693,25 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
   } else if (MODE == VH_MODE_DENSE_GLOBAL) {
     if (active && P.present_carrier < 0) P.present[xoff + gid] = 1;
   }
-  // (hash organisation: a wave most of whose survivors fall into one group lets one lane speak for them — vh_hot_lanes above)
+  // (hash organisation: a wave many of whose survivors fall into one group combines their values across the wave — vh_hot_lanes above — and keeps
+  // the total in registers until its hot group changes: H.hot)
   const uint64_t hot = MODE == VH_MODE_HASH ? vh_hot_lanes(active, gid) : 0ull;
   const int lane_ = (int)(threadIdx.x & 63);
-  const bool in_hot = ((hot >> lane_) & 1ull) != 0, speaks = hot != 0 && lane_ == __builtin_ctzll(hot);
+  const bool in_hot = ((hot >> lane_) & 1ull) != 0;
+  int nvalue = 0;
+  for (int j = 0; j < P.nmetric; ++j) nvalue += P.m[j].sop() != SOP_BITSET;
+  const bool keep = hot != 0 && nvalue <= VH_HOT_METRICS;      // (wave-uniform) the combined values stay in the wave's accumulators
+  const bool speaks = hot != 0 && !keep && lane_ == __builtin_ctzll(hot);
+  if (keep) {
+    const uint64_t hg = __shfl(gid, __builtin_ctzll(hot));
+    if (!H.hot.valid || H.hot.gid != hg) {
+      vh_hot_flush(P, H.hot);
+      H.hot.gid = hg; H.hot.valid = true; H.hot.card = 0;
+      int k = 0;
+      for (int j = 0; j < P.nmetric; ++j) if (P.m[j].sop() != SOP_BITSET) H.hot.v[k++] = P.m[j].sop() == SOP_ADD32 || P.m[j].sop() == SOP_ADD64 || P.m[j].sop() == SOP_ADDF32 || P.m[j].sop() == SOP_ADDF64 ? 0ull : P.m[j].ident;
+    }
+  }
+  int kv = 0;
   for (int j = 0; j < P.nmetric; ++j) {
     const VhMetricDev& m = P.m[j];
     if (m.sop() == SOP_BITSET) {   // slot() is the bitset index, m.state the u64 cardinality per group
@@ -677,9 +719,10 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
                                                             : reinterpret_cast<unsigned long long*>(m.state) + xoff + gid;
       unsigned long long mine = 0;
       if (active) vh_distinct_update(P, m.slot(), card, MODE == VH_MODE_HASH ? gid : xoff + gid, seg, row, H.npairs, in_hot ? &mine : nullptr);
-      if (hot) {       // (wave-uniform) the hot group's first sights of this drain: one atomic
+      if (hot) {       // (wave-uniform) the hot group's first sights of this drain: into the accumulator, or one atomic
         const unsigned long long tot = vh_wave_combine(SOP_ADD64, mine, in_hot);
-        if (speaks && tot) atomicAdd(card, tot);
+        if (keep) H.hot.card += tot;
+        else if (speaks && tot) atomicAdd(card, tot);
       }
       continue;
     }
@@ -687,7 +730,12 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
     if (m.slot() == VH_SLOT_ROWID) bits = ((uint64_t)seg << 32) | row;   // storage order of the row (search: first occurrence)
     else bits = vh_gather(P, m.slot(), seg, row, m.type(), vh_sop_sext(m.sop()));
     bool upd = active;
-    if (hot) { const uint64_t tot = vh_wave_combine(m.sop(), bits, in_hot); if (in_hot) { bits = tot; upd = speaks; } }
+    if (hot) {
+      const uint64_t tot = vh_wave_combine(m.sop(), bits, in_hot);
+      if (keep) { H.hot.v[kv] = vh_combine(m.sop(), H.hot.v[kv], tot); if (in_hot) upd = false; }
+      else if (in_hot) { bits = tot; upd = speaks; }
+    }
+    ++kv;
     if (upd) {
       if (MODE == VH_MODE_DENSE_LDS) {
         vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(lds + m.lds_off, gid, m.sop(), bits);
@@ -798,6 +846,7 @@ __global__ __launch_bounds__(BLOCK) void scan_agg_kernel(const VhPlanDev P) {
   }
 
   // wave totals -> one atomic per wave
+  if (MODE == VH_MODE_HASH) vh_hot_flush(P, H.hot);      // what the wave still keeps of its hot group
   for (int off = 32; off > 0; off >>= 1) { npassed += __shfl_down(npassed, off); H.npairs += __shfl_down(H.npairs, off); }
   vh_scan_block_end(P, npassed, nfresh, H.npairs, 0u);     // (one set of atomics per block; this kernel writes no tuples)
   if (MODE == VH_MODE_HASH && P.lds_hash_slots) vh_lds_hash_flush(P, lds, BLOCK);
