@@ -5,7 +5,7 @@
 # line names (roofline.kernel comes from the library: vh_result_kernel), written to profiles/<round>/ at once; THEN the bench line, which
 # finds that summary (same kernel, same layout, same sources) and reports roofline.traffic / frac from it.
 # usage (on the GPU box, from the repo root): bash tools/profile_round.sh r04 <git head>
-R=${1:-r05}
+R=${1:-r06}
 HEAD=${2:-unknown}
 OUT=gpurun_out/$R
 mkdir -p $OUT profiles/$R
@@ -55,6 +55,8 @@ python tools/pred_ab.py 125 7 2>/dev/null | grep '^{' >> $OUT/pred_ab.txt
 python tools/qpay_probe.py 2>/dev/null | grep '^{' > $OUT/qpay_probe.txt
 python tools/part2_probe.py 1000 1000,120 2>/dev/null | grep '^{' > $OUT/part2_probe.txt      # 4 M groups (two partition levels) at 100 % / 12 % of 1 B rows
 python tools/hisel_probe.py 1000 2>/dev/null | grep '^{' > $OUT/hisel_probe.txt              # 100 K groups from the arenas at 100 / 50 / 25 %
+python tools/skew_probe.py 1000 125 15 2>/dev/null | grep '^{' > $OUT/skew.json              # Zipf-like keys, a table loaded in predicate order, a hot composite key: next to their uniform twins
+VH_TIMES=1 python tools/host_share_probe.py C1,C2,C3 50 2> $OUT/host_share.err | grep '^{' > $OUT/host_share.json; grep 'vh plan steps' $OUT/host_share.err | awk 'NR%50==0' >> $OUT/host_share.json
 # how stable the headline is from process to process: ten fresh processes as a caller that prepares its query shape (vh_table_prepare) and
 # ten as one that does not (an ordinary first query: plain hipMalloc for the tuple pool)
 { for i in 1 2 3 4 5 6 7 8 9 10; do python bench.py $Q --steps 10 --warmup 3 | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('prepared', $i, round(d['ms_per_step'],3), round(d['roofline']['kernel_ms'],3))"; done

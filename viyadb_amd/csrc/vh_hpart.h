@@ -269,9 +269,14 @@ __device__ __forceinline__ uint32_t hp_slot_uniform(unsigned long long* keys, ui
 
 #define HP_OVF 128          // extents beyond the first of a range that a block remembers (skewed keys only: a range's share of
                             // uniform keys is a quarter of one extent)
+#define HP_HEAVY_EXT 24     // a range of more extents than this (~100 K tuples: a hundred times a range's share) is HEAVY: left to the host's
+                            // second pass over the plain hash organisation when the plan has one (VhPlanDev::heavy_mark), as is a range whose
+                            // groups or ids overflow the block's LDS tables
 struct HpAggLds {
   unsigned long long base, chunk_pos, chunk_end;
   uint32_t count, bad, novf, wave_tot[16];
+  uint32_t rbad;                     // the range at hand overflowed its LDS tables (block-uniform after the barrier behind the tuples)
+  uint16_t next[HP_FAN];             // extents of the slice per digit (heavy ranges: more than HP_HEAVY_EXT)
   uint32_t ext1[HP_FAN];             // per digit b: the range's first extent (~0u: none) ...
   uint16_t fill1[HP_FAN];            // ... and the tuples in it
   uint32_t ovf_ext[HP_OVF];          // the others: their digit in ovf_key
@@ -314,18 +319,36 @@ __device__ __forceinline__ void hp_aggregate_body(const VhPlanDev& P, const VhHp
   char* mstate[NM ? NM : 1];
 #pragma unroll
   for (int j = 0; j < NM; ++j) mstate[j] = lds + P.m[j].lds_off;
-  // ---- which extent of slice a holds which range: ONE look at the slice's tags for all the block's ranges
-  for (int i = tid; i < HP_FAN; i += BLOCK) S.ext1[i] = ~0u;
-  if (tid == 0) { S.chunk_pos = 0; S.chunk_end = 0; S.novf = 0; S.bad = 0; }
+  // ---- which extent of slice a holds which range: the slice's tags for all the block's ranges — first how many extents every digit has (a digit
+  // with more than HP_HEAVY_EXT is a heavy range: marked for the host's second pass, not listed), then the first extent and the others of the rest
+  for (int i = tid; i < HP_FAN; i += BLOCK) { S.ext1[i] = ~0u; S.next[i] = 0; }
+  if (tid == 0) { S.chunk_pos = 0; S.chunk_end = 0; S.novf = 0; S.bad = 0; S.rbad = 0; }
   __syncthreads();
+  const bool heavy_ok = P.heavy_mark != nullptr && passes == 1;
+  auto mark_heavy = [&](uint32_t d, uint32_t extents) {      // (one thread)
+    const uint32_t idx = ((uint32_t)a << 8) | d;
+    atomicOr(P.heavy_mark + (idx >> 5), 1u << (idx & 31u));
+    atomicAdd(P.counters + 11, 1ull);
+    atomicAdd(P.counters + 12, (unsigned long long)extents * (unsigned long long)(HP_ET / U));
+  };
   {
     const uint32_t lo = K.slice[a], cap = K.slice[a + 1] - lo, used = K.slice[HP_FAN + 1 + a];
     const uint32_t hi = lo + (used < cap ? used : cap);
+    if (heavy_ok) {
+      for (uint32_t e = lo + tid; e < hi; e += BLOCK) {
+        if (!K.b.fill[e]) continue;
+        const uint32_t d = K.b.tag[e];
+        if ((int)(d % (uint32_t)blocks_per_partition) == j0) { const uint32_t was = atomicAdd(reinterpret_cast<uint32_t*>(S.next) + (d >> 1), (d & 1u) ? 0x10000u : 1u); (void)was; }
+      }
+      __syncthreads();
+      for (int d = tid; d < HP_FAN; d += BLOCK) if (S.next[d] > HP_HEAVY_EXT) mark_heavy((uint32_t)d, S.next[d]);
+    }
     for (uint32_t e = lo + tid; e < hi; e += BLOCK) {
       const uint32_t f = K.b.fill[e];
       if (!f) continue;
       const uint32_t d = K.b.tag[e];
       if ((int)(d % (uint32_t)blocks_per_partition) != j0) continue;          // (another block's range)
+      if (heavy_ok && S.next[d] > HP_HEAVY_EXT) continue;                     // (a heavy range: the host's second pass)
       if (atomicCAS(&S.ext1[d], ~0u, e) == ~0u) S.fill1[d] = (uint16_t)f;
       else { const uint32_t at = atomicAdd(&S.novf, 1u); if (at < HP_OVF) { S.ovf_ext[at] = e; S.ovf_fill[at] = (uint16_t)f; S.ovf_key[at] = (uint16_t)d; } }
     }
@@ -466,8 +489,18 @@ __device__ __forceinline__ void hp_aggregate_body(const VhPlanDev& P, const VhHp
             const bool act = i0 + lane < S.ovf_fill[x];
             tuple(pool[(uint64_t)S.ovf_ext[x] * es + (act ? i0 + lane : 0u)], act);
           }
+      if (__ballot(bad)) { if (lane == 0) S.rbad = 1; }
       __syncthreads();
-      if (__ballot(bad)) { if (lane == 0) S.bad = 1; }
+      if (S.rbad) {       // (block-uniform) the range's groups or ids did not fit the LDS tables
+        __syncthreads();
+        if (tid == 0) {
+          S.rbad = 0;
+          if (heavy_ok) mark_heavy((uint32_t)b, (uint32_t)S.next[b] ? S.next[b] : 1u);      // ... the host's second pass takes the range; nothing of it is emitted here
+          else S.bad = 1;
+        }
+        __syncthreads();
+        if (heavy_ok) continue;
+      }
       // ---- this pass's groups: count, take places (off the result's row counter, or a piece of the block's chunk of the list), write
       uint32_t mine = 0;
       for (uint32_t g = tid; g <= GS; g += BLOCK) mine += gkeys[g] != VH_HASH_EMPTY;

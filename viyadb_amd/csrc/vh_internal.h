@@ -224,6 +224,12 @@ struct VhPlanDev {
   uint8_t* extent_part2;     // tag = the SUB-partition (0..63) inside the owning partition's range
   uint32_t* l2;              // [0..npart]: first pool-2 extent of partition p's range (prefix sums); [VH_L2_NEXT + p]: extents handed out of it
   uint32_t max_extents;
+  // Hashed partitioning, HEAVY RANGES. A range (level-A digit a, level-B digit d: the top 16 bits of the mixed key) that holds more tuples than a
+  // block should walk alone, or whose ids overflow the block's LDS set, is not aggregated by the ranges' kernel: it sets bit (a << 8 | d) here
+  // (nullptr: no such escape — the attempt is void as before) and counts itself in counters[11] / its tuples' bound in counters[12]. The host then
+  // runs the plain hash organisation over the rows of exactly those ranges (heavy_only below) and appends its groups to the result.
+  uint32_t* heavy_mark;
+  const uint32_t* heavy_only;   // the plain hash scan of a heavy pass: a survivor counts only if bit (mix(key) >> 48) is set here (nullptr: every survivor)
   uint32_t* part_count;      // one-level DENSE_PART whose phase 1 went through the ring writer: tuples per partition, counted at the scan blocks' ends — phase 2's blocks
                              // (and private table copies) are shared out by these counts (vh_part_shares); nullptr: every partition the same number of blocks
   uint32_t pos_levels;       // the ring writer's pools: extents per (block, digit) stream that lie at POSITIONS (pool 1: phase 1 of DENSE_PART) ...

@@ -483,8 +483,8 @@ __device__ __forceinline__ uint64_t vh_combine(int sop, uint64_t a, uint64_t b) 
 
 // HOT KEYS in the hash organisation. Every surviving row updates its group's record with device-scope atomics; atomics on ONE address are served
 // one after the other (~6.5 ns each), so a group that holds a tenth of the rows — 12.5 M of C5h's — costs its query a quarter of a second where
-// the reference's unordered_map does not care (src/codegen/db/store.cc:131-161). A wave that finds eight or more of its 64 survivors in the group
-// of its first one lets that lane speak for all of them: their values are combined across the wave (a butterfly over the members, vh_combine per
+// the reference's unordered_map does not care (src/codegen/db/store.cc:131-161). A wave that finds two neighbouring survivors in one group lets the first
+// lane of that group speak for all of the group's lanes: their values are combined across the wave (a butterfly over the members, vh_combine per
 // step) and ONE atomic per metric goes out; the others go on as before. The test is a readlane, a compare and a ballot per drain.
 __device__ __forceinline__ uint64_t vh_wave_combine(int sop, uint64_t v, bool in) {      // every lane: the members' total (garbage when there is no member)
 #pragma unroll
@@ -495,7 +495,7 @@ __device__ __forceinline__ uint64_t vh_wave_combine(int sop, uint64_t v, bool in
   }
   return v;
 }
-__device__ __forceinline__ uint64_t vh_hot_lanes(bool active, uint64_t gid) {      // lanes of the wave's hot group, when they are eight or more (else 0)
+__device__ __forceinline__ uint64_t vh_hot_lanes(bool active, uint64_t gid) {      // lanes of the wave's hot group (0: no two neighbouring survivors share a group)
   // which group? One that two NEIGHBOURING survivors share (distance 1 or 2): with tens of millions of groups and uniform keys that does not happen,
   // with a group that holds an eighth of the survivors or more it happens in nearly every drain
   const int lane = (int)(threadIdx.x & 63);
@@ -504,8 +504,8 @@ __device__ __forceinline__ uint64_t vh_hot_lanes(bool active, uint64_t gid) {   
   const uint64_t pairs = __ballot(active && ((a1 && g1 == gid) || (a2 && g2 == gid)));
   if (!pairs) return 0ull;
   const uint64_t lg = __shfl(gid, __builtin_ctzll(pairs));
-  const uint64_t hot = __ballot(active && gid == lg);
-  return __popcll(hot) >= 8 ? hot : 0ull;
+  return __ballot(active && gid == lg);      // (two lanes at least: one atomic on a contended address costs more than the butterfly that saves it — measured ~18 ns per same-address
+                                             //  atomic with 256 CUs at it: C5h's COUNT alone 224 ms through the uncombined kernel)
 }
 // ... and what a WAVE keeps of its hot group between drains (the pre-built scan of the hash organisation): the group's slot and, for up to four
 // value metrics and one count-distinct, what the wave's rows have added to them so far — wave-uniform registers, flushed with one atomic each when
@@ -657,6 +657,10 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
   }
   bool in_lds = false;
   if (MODE == VH_MODE_HASH) {
+    if (P.heavy_only) {      // the second pass of a hashed partitioning with heavy ranges: only the rows of those ranges count (VhPlanDev::heavy_only)
+      const uint32_t idx = (uint32_t)(vh_splitmix64(key[0]) >> 48);
+      active = active && ((P.heavy_only[idx >> 5] >> (idx & 31u)) & 1u) != 0u;
+    }
     if (P.lds_hash_slots && !H.bypass) {
       uint32_t ls = 0;
       in_lds = active && key[0] != VH_HASH_EMPTY && vh_lds_hash_find(P, lds, key[0], ls);
@@ -695,7 +699,8 @@ __device__ __forceinline__ void vh_consume(const VhPlanDev& P, uint32_t seg, uin
   }
   // (hash organisation: a wave many of whose survivors fall into one group combines their values across the wave — vh_hot_lanes above — and keeps
   // the total in registers until its hot group changes: H.hot)
-  const uint64_t hot = MODE == VH_MODE_HASH ? vh_hot_lanes(active, gid) : 0ull;
+  uint64_t hot = MODE == VH_MODE_HASH ? vh_hot_lanes(active, gid) : 0ull;
+  if (MODE == VH_MODE_HASH && !hot && H.hot.valid) hot = __ballot(active && gid == H.hot.gid);      // (no two neighbours this time: the group the wave already keeps)
   const int lane_ = (int)(threadIdx.x & 63);
   const bool in_hot = ((hot >> lane_) & 1ull) != 0;
   int nvalue = 0;
@@ -1696,6 +1701,22 @@ __device__ __forceinline__ void vh_consume_fast(const VhPlanDev& P, uint32_t seg
     if (active) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[gid] = 1;
   } else if (MODE == VH_MODE_DENSE_GLOBAL) {
     if (active && P.present_carrier < 0) P.present[xoff + gid] = 1;
+  }
+  if (MODE == VH_MODE_HASH) {      // a wave's hot group: one lane speaks for its lanes (vh_hot_lanes)
+    const uint64_t hot = vh_hot_lanes(active, gid);
+    if (hot) {       // (wave-uniform)
+      const int lane_ = (int)(threadIdx.x & 63);
+      const bool in_hot = ((hot >> lane_) & 1ull) != 0, speaks = lane_ == __builtin_ctzll(hot);
+#pragma unroll
+      for (int j = 0; j < VH_FAST_COLS; ++j) {
+        if (j < P.nmetric) {
+          const VhMetricDev& m = P.m[j];
+          const uint64_t tot = vh_wave_combine(m.sop(), mv[j], in_hot);
+          if (in_hot ? speaks : active) vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(vh_hash_state(P, m, gid), 0, m.sop(), in_hot ? tot : mv[j]);
+        }
+      }
+      return;
+    }
   }
 #pragma unroll
   for (int j = 0; j < VH_FAST_COLS; ++j) {
