@@ -203,11 +203,14 @@ def _splitmix64(x):
     return x ^ (x >> 31)
 
 
-def test_a_digits_second_extent_by_position():
+def test_a_digits_second_extent_by_position(monkeypatch):
     """Groups picked so that their mixed keys (vh_splitmix64 of c | x << 16) start with one of THREE bytes: every scan block then appends
     ~5 000 tuples to each of three digits — more than one 4 096-tuple extent, so the (block, digit)'s second extent, a whole level further
     into the pool, is written and read (what the full-size tables never do: C5 puts ~950 tuples into a (block, digit)). Level B behind it
-    spreads them over 256 ranges as usual."""
+    spreads them over 256 ranges as usual. (Three partitions that hold everything are HEAVY partitions to the planner on the device — left to a
+    second pass through the plain hash organisation —, which is not what this case is about: VH_NO_HEAVY_PASS; with the second pass the answer is
+    checked once more at the end.)"""
+    monkeypatch.setenv("VH_NO_HEAVY_PASS", "1")
     rng = np.random.default_rng(9)
     pairs = np.array([(c, x) for c in range(40) for x in range(5000) if _splitmix64(c | (x << 16)) >> 56 < 3], dtype=np.int64)
     assert 1500 < len(pairs) < 3500
@@ -223,6 +226,10 @@ def test_a_digits_second_extent_by_position():
         res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["count", "v"]}, flags=HP)
         took_hpart(res)
         assert res.retries == 0 and scan_wrote_level_a(res) and res.ngroups == st.ngroups == len(pairs), (res.retries, res.kernel, res.ngroups)
+        monkeypatch.delenv("VH_NO_HEAVY_PASS")
+        res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["count", "v"]}, flags=HP)
+        took_hpart(res)
+        assert res.retries == 1 and res.ngroups == st.ngroups == len(pairs), (res.retries, res.kernel, res.ngroups)      # (every tuple through the second pass)
     finally:
         dt.close()
 
@@ -244,7 +251,8 @@ def test_a_hot_key_takes_its_extents_from_the_overflow_regions():
     try:
         res, st = run(tab, dt, {"dimensions": ["c", "x"], "metrics": ["count", "v"]}, flags=HP)
         took_hpart(res)
-        assert res.retries == 0 and scan_wrote_level_a(res) and res.ngroups == st.ngroups > 50_000, (res.retries, res.kernel)
+        # (the hot group's range is HEAVY for the ranges' kernel: its rows take the second pass through the plain hash organisation — one more pass, not a void attempt)
+        assert res.retries <= 1 and scan_wrote_level_a(res) and res.ngroups == st.ngroups > 50_000, (res.retries, res.kernel)
         for levels in ("0", "1"):
             os.environ["VH_TEST_POS_LEVELS"] = levels
             try:
@@ -252,7 +260,7 @@ def test_a_hot_key_takes_its_extents_from_the_overflow_regions():
             finally:
                 del os.environ["VH_TEST_POS_LEVELS"]
             took_hpart(res)
-            assert res.retries == 0 and scan_wrote_level_a(res), (levels, res.retries, res.kernel)
+            assert res.retries <= 1 and scan_wrote_level_a(res), (levels, res.retries, res.kernel)
     finally:
         dt.close()
 

@@ -36,13 +36,42 @@ def test_table_loaded_in_predicate_order(flags):
 HP = 1 | (1 << 18) | (1 << 20)      # hash organisation, compiled scan, hashed partitioning
 
 
-@pytest.mark.parametrize("wl", ["C5h"])
 @pytest.mark.parametrize("flags", [0, HP])
-def test_hot_composite_key_with_distinct_counts(wl, flags):
-    w = synth.WORKLOADS[wl](segment_rows=60_000)
+def test_hot_composite_key_with_distinct_counts(flags):
+    w = synth.c5h(segment_rows=60_000)
     res, st = check_workload(w, nseg=4, flags=flags | capi.PLAN_CARD32)
     top = int(res.states[1].argmax())
     assert res.states[1][top] > 0.15 * res.states[1].sum()        # the hot (t, u): a tenth of the rows, a fifth of the survivors (u < 500 000 keeps half of the rest)
+
+
+def test_heavy_ranges_of_the_hashed_partitioning_take_a_second_pass(monkeypatch):
+    """C5h through the hashed partitioning: the hot (t, u) group's range holds a hundred times a range's share of the tuples and more ids than a
+    block's LDS set takes. The ranges' kernel marks it heavy instead of voiding the attempt, the host runs the plain hash organisation over the rows
+    of exactly that range (the generic scan drops every other survivor behind its key) and appends its groups: one query, two passes, the oracle's
+    rows — the hot group's COUNT and COUNT DISTINCT included. Without the second pass (VH_NO_HEAVY_PASS) the whole query ends on the plain table."""
+    w = synth.c5h(segment_rows=80_000)
+    res, st = check_workload(w, nseg=4, flags=HP | capi.PLAN_CARD32)
+    assert res.hpart and res.kernel.endswith("_hpagg") and res.retries == 1, (res.hpart, res.retries, res.kernel)
+    top = int(res.states[1].argmax())
+    assert int(res.states[1][top]) > 30_000 and int(res.states[0][top]) > 30_000          # rows and distinct users of the hot group
+    # twice more on one table (the bitmap of heavy ranges is cleared per query), and the uniform twin takes no second pass
+    from tests.parity import build_oracle_table, compare
+    from oracle import viya_oracle as vo
+    from viyadb_amd.executor import AggPlan
+    dt = synth.create_device_table(w, 4, 80_000)
+    try:
+        want = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 4, 80_000), w.query), now=w.now)
+        for _ in range(3):
+            r = dt.query_agg(AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=HP | capi.PLAN_CARD32))
+            compare(r, want, "heavy ranges, repeated")
+            assert r.hpart and r.retries == 1
+    finally:
+        dt.close()
+    res, st = check_workload(synth.c5(segment_rows=80_000), nseg=4, flags=HP | capi.PLAN_CARD32)
+    assert res.hpart and res.retries == 0
+    monkeypatch.setenv("VH_NO_HEAVY_PASS", "1")
+    res, st = check_workload(w, nseg=4, flags=HP | capi.PLAN_CARD32)
+    assert not res.hpart and res.retries >= 1 and res.path == "hash"
 
 
 @pytest.mark.parametrize("levels", ["0", "1"])

@@ -66,6 +66,8 @@ struct VhHpArgs {
   uint32_t chunk;             // group records a block of hp_aggregate_kernel takes from the list at a time
   uint64_t list_cap;          // records the group list holds (+ one reserved record behind them)
   uint32_t slice_levels_cap;  // (tests: see VhPlanDev::slice_levels_cap; ~0u otherwise)
+  uint32_t* heavy_mark;       // = VhPlanDev::heavy_mark (nullptr: no second pass to be had): hp_plan_kernel marks all 256 ranges of a level-A partition
+                              // that holds many times its share of the tuples — level B would push them through ONE block — and gives it no slice
   int32_t ablate;             // measurement only (VH_HP_ABLATE; results are wrong): 1 no id inserts, 2 no records written, 4 no tuples either, 8 no table clears
   // direct emission: the aggregation kernel writes a range's groups straight into the result's output columns (key columns in the
   // dimensions' own element types, states in the metrics') at places taken off the result's row counter — no list of group records, no
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(BLOCK) void hp_ring_scatter_kernel(const VhHpArgs* 
   vh_ring_init<BLOCK>(lds, F, wave);
   const VhHpKind& K = HA->k[0];
   const uint32_t a = blockIdx.x / nb, j = blockIdx.x % nb;
+  if (K.count[a] == 0xFFFFFFFFu) return;        // a heavy partition (hp_plan_kernel): the host's second pass takes its rows
   const uint32_t lo = K.slice[a], cap = K.slice[a + 1] - lo;
   // slice a: positional extents for the counted tuples' even spread over the (block, digit) streams, then the slice's shared overflow region
   // (hp_plan_kernel laid it out from the same count; its cursor K.slice[HP_FAN + 1 + a] starts behind the positional extents)
@@ -187,8 +190,27 @@ __global__ __launch_bounds__(HP_FAN) void hp_plan_kernel(const VhHpArgs* __restr
   const uint32_t et = (uint32_t)HP_ET / (uint32_t)HA->units;
   const int a = threadIdx.x, lane = a & 63, wave = a >> 6;
   // what partition a holds, in extents, + one open extent per digit of its single writer + the flush of the tails
-  const uint32_t c = K.count[a];
+  uint32_t c = K.count[a];
   const unsigned long long per = (unsigned long long)HP_FAN * (unsigned)(ring_blocks > 0 ? ring_blocks : 1);
+  // a HEAVY partition — more than eight times the partitions' mean and more than 16 K tuples: a hot key, whose tuples all carry the same mixed key —
+  // is left to the host's second pass whole (one block of level B would have to move it alone: C5h's 12.5 M tuples took half a second that way)
+  if (HA->heavy_mark) {
+    __shared__ unsigned long long s_sum[HP_FAN / 64];
+    unsigned long long tot = c;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
+    if (lane == 0) s_sum[wave] = tot;
+    __syncthreads();
+    tot = 0;
+    for (int w = 0; w < HP_FAN / 64; ++w) tot += s_sum[w];
+    if (c > 16384u && (unsigned long long)c * HP_FAN > 8ull * tot) {
+      for (int q = 0; q < 8; ++q) HA->heavy_mark[a * 8 + q] = ~0u;
+      atomicAdd(counters + 11, 256ull);
+      atomicAdd(counters + 12, (unsigned long long)c);
+      c = 0;                                   // no slice: level B and the ranges' kernel find nothing of it
+      K.count[a] = 0xFFFFFFFFu;                // (level B's block a: nothing to move)
+    }
+  }
   const unsigned long long need = !c ? 0ull : vh_slice_extents(c, per, et, HA->slice_levels_cap);
   unsigned long long incl = need;
 #pragma unroll

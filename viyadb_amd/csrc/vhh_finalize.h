@@ -12,8 +12,48 @@ static hipError_t wait_event_spinning(hipEvent_t ev) {
   }
 }
 
+// The second pass of a hashed partitioning that marked heavy ranges (VhPlanDev::heavy_mark): the caller's plan once more, through the plain hash
+// organisation, over the rows of exactly those ranges (the generic scan drops every other survivor behind its key: VhPlanDev::heavy_only) — a group
+// with a tenth of the table's rows, or with more ids than a range's LDS set takes, costs its query that, not the whole organisation. *out2: the
+// finalised result of the pass on a context of its own (nullptr with VH_OK: it could not be had — the caller falls back as before).
+static int result_finalize(vh_result* r, int* retry, const vh_plan* plan = nullptr);
+static int heavy_second_pass(vh_result* r, const vh_plan* plan, uint64_t ranges, uint64_t tuples_bound, vh_result** out2) {
+  *out2 = nullptr;
+  vh_table* t = r->table;
+  VhExec* x2 = nullptr;
+  if (exec_acquire(t, &x2) != VH_OK) return VH_OK;
+  vh_plan p2 = *plan;
+  p2.flags = (p2.flags | VH_PLAN_FORCE_HASH | VH_PLAN_NO_JIT | VH_PLAN_NO_FAST | VH_PLAN_NO_LANES | VH_PLAN_NO_HPART) & ~(uint32_t)(VH_PLAN_FORCE_JIT | VH_PLAN_FORCE_HPART | VH_PLAN_FORCE_LANES);
+  p2.groups_hint = 0;
+  uint64_t cap = 1ull << 16;
+  while (cap < ranges * 8192ull && cap < (1ull << 30)) cap <<= 1;      // (a range holds ~500 groups when the keys are spread evenly; the loop below regrows)
+  int rc = VH_OK;
+  for (int attempt = 0; attempt < 6; ++attempt) {
+    vh_result* r2 = nullptr;
+    {
+      std::lock_guard<std::mutex> lk(t->mu);
+      g_heavy.only = r->plan.heavy_mark; g_heavy.ids_bound = 2 * tuples_bound + 1024; g_heavy.allow_mark = false;
+      rc = query_launch_locked(t, x2, &p2, &r2, cap, true, 0, false, false, nullptr, nullptr, false, 0, true);
+      g_heavy = VhHeavyCtx{};
+    }
+    if (rc) break;
+    r2->exec = x2;
+    int retry2 = 0;
+    rc = result_finalize(r2, &retry2);
+    if (rc) { r2->exec = nullptr; delete r2; break; }
+    if (!retry2) { r2->stream_quiet = true; *out2 = r2; return VH_OK; }      // (the result owns the context from here)
+    r2->exec = nullptr; delete r2;
+    if (retry2 != 1) { rc = VH_OK; break; }                                  // anything but a full table: give up, the caller falls back
+    cap <<= 2;
+  }
+  (void)hipStreamSynchronize(x2->stream());
+  exec_release(t, x2);
+  if (rc) { (void)hipGetLastError(); }
+  return VH_OK;
+}
+
 // returns VH_OK, or a positive "retry" request: 1 = grow hash table, 2 = fall back to hash
-static int result_finalize(vh_result* r, int* retry) {
+static int result_finalize(vh_result* r, int* retry, const vh_plan* plan) {
   VhExec* x = r->exec;   // staging buffers, scratch and events of this query's context
   const VhPlanDev& P = r->plan;
   hipStream_t st = x->stream();
@@ -203,18 +243,38 @@ static int result_finalize(vh_result* r, int* retry) {
   r->info.returned_groups = ng;
   r->ngroups_host = ng;
   r->info.passed_recs = hc[0];
+  // heavy ranges of a hashed partitioning (hc[11] of them, at most hc[12] tuples): their groups come from a second pass through the plain hash
+  // organisation and are appended behind the rows the ranges' kernel wrote
+  std::unique_ptr<vh_result> heavy;
+  uint64_t n2 = 0;
+  if (r->hpart && P.heavy_mark && hc[11]) {
+    vh_result* r2 = nullptr;
+    if (plan) { if (int hrc = heavy_second_pass(r, plan, hc[11], hc[12], &r2)) return hrc; }
+    if (!r2 || (one_shot && ng + r2->ngroups_host > r->out_cap)) { delete r2; *retry = 4; r->plan.hp_passes = 64; return VH_OK; }      // (no second pass to be had: the plain table for everything, as before)
+    heavy.reset(r2);
+    n2 = r2->ngroups_host;
+    r->info.retries += 1;       // (counted like an attempt: the caller sees that the query took more than one pass)
+  }
+  auto append_heavy = [&](const size_t* key_off, const size_t* state_off) {      // the second pass's rows behind row ng of this result's host columns
+    char* H = x->h_out[slot];
+    for (int i = 0; i < P.ngroup; ++i) { const size_t es = vh_elem_size(P.g[i].type()); memcpy(H + key_off[i] + ng * es, heavy->h_base + heavy->off_key[i], n2 * es); }
+    for (int j = 0; j < P.nmetric; ++j) { const size_t es = vh_elem_size(r->metric_elem[j]); memcpy(H + state_off[j] + ng * es, heavy->h_base + heavy->off_state[j], n2 * es); }
+  };
   if (!one_shot) {
     if (!r->hp_chunks) {           // a big result in one piece: the staging buffer is sized for the rows there are
-      L = packed_for(ng);
+      L = packed_for(ng + n2);
       if (int src = stage(L.bytes)) return src;
       if (ng) { if (int crc = copy_rows(L, 0, 0, ng, r->topk_active, st)) return crc; }
       HIP_TRY(hipEventRecord(x->ev[3], st));
       HIP_TRY(wait_event_spinning(x->ev[3]));
+      if (n2) append_heavy(L.key, L.state);
     }
     memcpy(x->h_out[slot], head, 512);
     for (int i = 0; i < P.ngroup; ++i) r->off_key[i] = L.key[i];      // (the host view: where vh_result_view finds the columns)
     for (int j = 0; j < P.nmetric; ++j) r->off_state[j] = L.state[j];
-  }
+  } else if (n2) append_heavy(r->off_key, r->off_state);
+  if (n2) { ng += n2; r->info.ngroups += n2; r->info.returned_groups = ng; r->ngroups_host = ng; }
+  heavy.reset();
   r->h_base = x->h_out[slot];
   float ms = 0;
   (void)hipEventElapsedTime(&ms, x->ev[1], x->ev[2]); r->info.scan_kernel_ms = ms;
@@ -392,17 +452,22 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
     const auto h0 = std::chrono::steady_clock::now();
     // planned and launched under the table lock; the wait for the device and the read-back happen outside it, so
     // queries of other threads on this table run meanwhile (each on its own context)
-    { std::lock_guard<std::mutex> lk(t->mu); rc = query_launch_locked(t, x, plan, &r, rp.cap_override, rp.force_hash, rp.part_override, rp.no_part, false, nullptr, nullptr, false, rp.hp_passes, rp.no_hpart); }
+    {
+      std::lock_guard<std::mutex> lk(t->mu);
+      g_heavy.allow_mark = true;        // (this caller can run the second pass over heavy ranges: it holds the plan when the verdict is in)
+      rc = query_launch_locked(t, x, plan, &r, rp.cap_override, rp.force_hash, rp.part_override, rp.no_part, false, nullptr, nullptr, false, rp.hp_passes, rp.no_hpart);
+      g_heavy = VhHeavyCtx{};
+    }
     if (rc) break;
     r->exec = x;
     int retry = 0;
     const auto h1 = std::chrono::steady_clock::now();
-    rc = result_finalize(r, &retry);
+    rc = result_finalize(r, &retry, plan);
     if (knobs().times) fprintf(stderr, "vh host: plan + enqueue %.1f us, finalize (enqueue tail + wait + read-back) %.1f us\n", std::chrono::duration<double, std::micro>(h1 - h0).count(),
                                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h1).count());
     if (rc) { r->exec = nullptr; delete r; break; }
     if (!retry) {
-      r->info.retries = attempt;
+      r->info.retries += attempt;                              // (+ 1 where a second pass took the heavy ranges of a hashed partitioning)
       r->stream_quiet = true;                                  // (result_finalize waited for everything it enqueued)
       if (r->mode == VH_MODE_HASH) { std::lock_guard<std::mutex> lk(t->mu); t->groups_seen[r->group_sig] = r->info.ngroups; }
       *out = r;

@@ -339,6 +339,10 @@ int QueryBuild::layout_scratch() {
   // outputs
   size_t o_tuples = 0, o_emiss = 0, o_epart = 0, o_tuples2 = 0, o_emiss2 = 0, o_epart2 = 0, o_l2 = 0;
   if (part_balanced) o_pcount = sp.take(VH_MAX_PART * sizeof(uint32_t));
+  // hashed partitioning whose groups leave straight into the output columns, planned by a caller that can run a second pass (vh_query_agg): ranges
+  // that are too heavy for a block's LDS tables are marked in a bitmap of the 65 536 ranges instead of voiding the attempt
+  heavy_marks = hpart && r->hp_direct && !r->hp_chunks && !device_rows && g_heavy.allow_mark && !g_heavy.only && P.hp_passes == 1 && !test_env("VH_NO_HEAVY_PASS");
+  if (heavy_marks) o_heavy = sp.take(65536 / 8);
   if (hpart) part_tuple_cap = hp_tuple_cap;
   if (mode == VH_MODE_DENSE_PART || hpart) {
     // extent size: big enough that a wave allocates rarely (every allocation is a returning global
@@ -433,7 +437,8 @@ int QueryBuild::layout_scratch() {
     if (hpart) continue;             // (its count-distinct lives in the LDS sets of hp_aggregate_kernel)
     // the (group, id) set can never hold more pairs than there are ids in the scanned segments
     uint64_t cap = 1024;
-    while (cap < bitset_ids[b] * 2) cap <<= 1;
+    const uint64_t ids = g_heavy.only ? std::min<uint64_t>(bitset_ids[b], g_heavy.ids_bound) : bitset_ids[b];      // (a heavy pass: the ids its ranges can hold)
+    while (cap < ids * 2) cap <<= 1;
     P.dset_mask[b] = cap - 1;
     if (P.bs_wide[b]) { o_dkeys[b] = sp.take(cap * 16); o_dtags[b] = sp.take(cap * 4); }
     else {
@@ -457,6 +462,8 @@ int QueryBuild::layout_scratch() {
   for (int j = 0; j < P.nmetric; ++j) P.m[j].state = S + o_state[j];
   r->d_out_count = reinterpret_cast<unsigned long long*>(S + o_outcount);
   P.part_count = part_balanced ? reinterpret_cast<uint32_t*>(S + o_pcount) : nullptr;
+  P.heavy_mark = heavy_marks ? reinterpret_cast<uint32_t*>(S + o_heavy) : nullptr;
+  P.heavy_only = g_heavy.only;
   if (mode == VH_MODE_DENSE_PART || hpart) {
     P.tuples = reinterpret_cast<uint64_t*>(S + o_tuples);
     P.extent_missing = reinterpret_cast<uint16_t*>(S + o_emiss);
@@ -545,7 +552,7 @@ int QueryBuild::launch() {
     HA.passes = P.hp_passes; HA.gslots = P.hp_gslots; HA.sslots = P.hp_sslots; HA.keys_off = P.hp_keys_off; HA.set_off = P.hp_set_off;
     HA.bitset_j = -1;
     for (int j = 0; j < P.nmetric; ++j) if (P.m[j].sop() == SOP_BITSET) HA.bitset_j = j;
-    HA.list_cap = capacity; HA.chunk = hp_chunk; HA.ablate = knobs().hp_ablate; HA.slice_levels_cap = P.slice_levels_cap;
+    HA.list_cap = capacity; HA.chunk = hp_chunk; HA.ablate = knobs().hp_ablate; HA.slice_levels_cap = P.slice_levels_cap; HA.heavy_mark = P.heavy_mark;
     // no HAVING and no top-N to look at the groups first: the aggregation kernel emits them itself (C5: no 0.85 GB list, no 0.85 ms kernel)
     HA.direct = r->hp_direct ? 1 : 0; HA.ngroup = P.ngroup; HA.out_count = r->d_out_count;
     HA.nchunks = r->hp_chunks; HA.chunk_rows = r->hp_chunk_rows;
@@ -575,6 +582,7 @@ int QueryBuild::launch() {
     HIP_TRY(hipMemcpyAsync(d_hpargs, &HA, sizeof(HA), hipMemcpyHostToDevice, st));
   }
   if (part_balanced) clear(P.part_count, VH_MAX_PART * sizeof(uint32_t), 0);
+  if (heavy_marks) clear(P.heavy_mark, 65536 / 8, 0);
   if (mode == VH_MODE_DENSE_PART || hpart) {
     clear(P.extent_missing, (size_t)P.max_extents * sizeof(uint16_t), 0);
     clear(P.extent_part, (size_t)P.max_extents, 0xFF);

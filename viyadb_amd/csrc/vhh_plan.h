@@ -173,6 +173,12 @@ struct VhAgreed {
   double sel;
 };
 
+// Heavy ranges of the hashed partitioning (VhPlanDev::heavy_mark / heavy_only), per calling thread: vh_query_agg lets its plans mark heavy ranges
+// (it can run the second pass: it holds the caller's plan when the verdict is in); the second pass itself plans with `only` = the first pass's bitmap
+// and sizes its (group, id) set for the ids those ranges can hold. Everything else (split launch / finalize, sharded queries) plans without either.
+struct VhHeavyCtx { bool allow_mark = false; const uint32_t* only = nullptr; uint64_t ids_bound = 0; };
+static thread_local VhHeavyCtx g_heavy;
+
 // One aggregate query on its way to the device. query_launch_locked() runs the steps in order; each step reads what the earlier
 // ones decided from the members below. `done`: the query has been handed over (or, for a plan-only / summary call, answered) early.
 struct QueryBuild {
@@ -213,6 +219,7 @@ struct QueryBuild {
   bool fast = false, fastj = false, lanes = false;
   uint64_t part_tuple_cap = 0;
   int nxcd = 1, part_bpp = 1;
+  bool heavy_marks = false; size_t o_heavy = 0;         // hashed partitioning: heavy ranges are marked for a second pass (layout_scratch)
   bool part_balanced = false; size_t o_pcount = 0;      // phase 2's blocks by the partitions' tuple counts (layout_scratch)
   uint64_t capacity = 0;
   bool hpart = false;
