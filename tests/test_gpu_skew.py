@@ -4,6 +4,7 @@ partitioning. Each against the oracle on identical generated rows (the numpy twi
 first), through the planner's own choice and through the partitioning organisations forced, compiled and pre-built kernels."""
 import pytest
 
+from tests.conftest import JIT_OFF
 from tests.parity import check_workload
 from viyadb_amd import capi, synth
 
@@ -49,6 +50,8 @@ def test_heavy_ranges_of_the_hashed_partitioning_take_a_second_pass(monkeypatch)
     block's LDS set takes. The ranges' kernel marks it heavy instead of voiding the attempt, the host runs the plain hash organisation over the rows
     of exactly that range (the generic scan drops every other survivor behind its key) and appends its groups: one query, two passes, the oracle's
     rows — the hot group's COUNT and COUNT DISTINCT included. Without the second pass (VH_NO_HEAVY_PASS) the whole query ends on the plain table."""
+    if JIT_OFF:
+        pytest.skip("the ring writer and the hashed partitioning live in the compiled kernels (VH_JIT=off: the pre-built ones answer)")
     w = synth.c5h(segment_rows=80_000)
     res, st = check_workload(w, nseg=4, flags=HP | capi.PLAN_CARD32)
     assert res.hpart and res.kernel.endswith("_hpagg") and res.retries == 1, (res.hpart, res.retries, res.kernel)
@@ -79,6 +82,8 @@ def test_every_tuple_through_the_overflow_region(levels, monkeypatch):
     """VH_TEST_POS_LEVELS: the ring writer's streams get no (or one) positional extent, so phase 1 of DENSE_PART takes (nearly) all its extents
     from the pool's shared overflow region through the block's LDS table — what a hot partition does, at a size a test affords. One- and
     two-word tuples, 13 and 1 partitions' worth of skew; C5's scan-written level A and its level B the same way."""
+    if JIT_OFF:
+        pytest.skip("the ring writer and the hashed partitioning live in the compiled kernels (VH_JIT=off: the pre-built ones answer)")
     monkeypatch.setenv("VH_TEST_POS_LEVELS", levels)
     for wl, flags in (("C3z", FORCE_PART | capi.PLAN_FORCE_JIT), ("C3", FORCE_PART | capi.PLAN_FORCE_JIT | capi.PLAN_NO_NARROW_TUPLES), ("C3s", FORCE_PART | capi.PLAN_FORCE_JIT)):
         w = synth.WORKLOADS[wl](segment_rows=150_000) if wl != "C3s" else synth.c3s(150_000, 8)
@@ -94,6 +99,8 @@ def test_ring_writer_stress_two_partitions_every_row_passing(monkeypatch):
     times what a waiting line holds, so every call of the ring writer goes through several rounds of its wait loop with owners flushing
     while later lanes of the same call still wait — looped 1 000 times per tuple size (8- and 16-byte tuples) on scratch memory that is
     poisoned before use (VH_POISON): every answer must be the first one's, bit for bit, and the first one the oracle's."""
+    if JIT_OFF:
+        pytest.skip("the ring writer and the hashed partitioning live in the compiled kernels (VH_JIT=off: the pre-built ones answer)")
     import numpy as np
     from oracle import viya_oracle as vo
     from tests.planner import mirror_table, plan_from_query
@@ -156,3 +163,23 @@ def test_phase_2_blocks_follow_the_partitions_tuple_counts(monkeypatch):
     finally:
         monkeypatch.delenv("VH_NO_PART_BALANCE", raising=False)
         dt.close()
+
+
+def test_four_byte_tuples(monkeypatch):
+    """C3's gid (17 bits) and values (10 + 2 bits) fit 32 bits: DENSE_PART's tuple is four bytes — thirty-two to a 128-byte line through the ring
+    writer, read back as 32-bit words by the compiled phase 2. Same groups as with the 8-byte tuple (VH_NO_TUPLE4) and as the oracle's, uniform and
+    Zipf-like keys, with every tuple through the overflow region too; a value that outgrows its recorded bits re-plans (VH_ERR_HP_WIDE) as with any
+    packed tuple."""
+    if JIT_OFF:
+        pytest.skip("packed tuples need the compiled kernels")
+    for wl in ("C3", "C3z"):
+        w = synth.WORKLOADS[wl](segment_rows=150_000)
+        res, st = check_workload(w, nseg=8, flags=FORCE_PART | capi.PLAN_FORCE_JIT)
+        assert res.path == "dense_part" and res.retries == 0 and (res.flags & 1024), (res.path, res.retries, res.flags)
+        monkeypatch.setenv("VH_NO_TUPLE4", "1")
+        res8, _ = check_workload(w, nseg=8, flags=FORCE_PART | capi.PLAN_FORCE_JIT)
+        monkeypatch.delenv("VH_NO_TUPLE4")
+        assert res8.kernel != res.kernel                      # another compiled shape
+        monkeypatch.setenv("VH_TEST_POS_LEVELS", "0")
+        check_workload(w, nseg=8, flags=FORCE_PART | capi.PLAN_FORCE_JIT)
+        monkeypatch.delenv("VH_TEST_POS_LEVELS")

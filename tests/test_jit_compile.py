@@ -30,7 +30,8 @@ SHAPES = {0: "C3: narrow predicate copies, record gathers, tuples for DENSE_PART
           15: "C5 (32-byte tuples) whose scan writes the level-A pool itself: 1024-thread blocks, waiting lines per digit in LDS",
           16: "C5 (packed 16-byte tuples) whose scan writes the level-A pool itself",
           18: "C3 with one-word tuples (= shape 9: every DENSE_PART tuple of one or two words leaves through the block's ring writer)",
-          19: "C3 with two-word tuples (= shape 0)"}
+          19: "C3 with two-word tuples (= shape 0)",
+          20: "C3 with FOUR-byte tuples (gid 17 + SUM value 10 + COUNT value 2 bits: thirty-two to a 128-byte line)"}
 
 
 def _compile(which, tmp_path):
@@ -88,7 +89,7 @@ def test_compiles_with_the_hiprtc_a_torch_process_carries():
     assert p.returncode == 0, p.stderr[-3000:]
 
 
-RING_SHAPES = (0, 7, 9, 10, 12, 13, 14, 15, 16)     # every selftest shape whose tuples leave through the block's ring writer (vh_ring_add_tb): C5's scan-written level A
+RING_SHAPES = (0, 7, 9, 10, 12, 13, 14, 15, 16, 20)     # every selftest shape whose tuples leave through the block's ring writer (vh_ring_add_tb): C5's scan-written level A
                                     # with 32- and 16-byte tuples, C3's phase 1 with one- and two-word tuples
 
 
@@ -108,7 +109,8 @@ def test_ring_writer_instruction_order(which, tmp_path):
     body = isa[isa.index("<viya_jit_scan_selftest>:"):]
     nxt = re.search(r"\n[0-9a-f]+ <", body[10:])
     L = [l.split("//")[0].strip() for l in (body[:nxt.start() + 10] if nxt else body).splitlines()]
-    sites = [i for i, l in enumerate(L) if l.startswith("ds_add_rtn_u32") and re.match(r"ds_write_b(64|128)\b", L[i - 1])]
+    store = r"ds_write_b(64|128)\b" if which != 20 else r"ds_write_b32\b"       # (four-byte tuples: the store is a ds_write_b32 — one, not the back-to-back pair that resets `done` and bumps `gen`)
+    sites = [i for i, l in enumerate(L) if l.startswith("ds_add_rtn_u32") and re.match(store, L[i - 1]) and not (which == 20 and re.match(r"ds_write_b32\b", L[i - 2]))]
     # a ring site per drain form the shape compiles (full steps / the step that reaches a segment's end; C5 drains two survivors per lane)
     assert len(sites) >= 1, "no ring-writer site found"
 
@@ -126,7 +128,7 @@ def test_ring_writer_instruction_order(which, tmp_path):
         gen_read = max([j for j in range(max(0, k - 40), k) if re.match(r"ds_read_b32\b", L[j])], default=None)
         assert gen_read is not None, (which, n, L[k - 10:k + 1])
         # (2) tuple store(s) and the count are adjacent: nothing the compiler could have slipped between them
-        assert all(re.match(r"ds_write_b(64|128)\b", L[j]) for j in range(k, i)), (which, n, L[k:i + 1])
+        assert all(re.match(store, L[j]) for j in range(k, i)), (which, n, L[k:i + 1])
         # (3) the owner's part, in program order
         p_list = first(r"ds_write_b64\b", i + 1, stop)
         p_rl = first(r"ds_read_b64\b", (p_list or stop) + 1, stop)

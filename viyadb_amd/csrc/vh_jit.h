@@ -31,6 +31,7 @@ struct VhJitShape {
   int bs_off32 = 0;                     // hashed partitioning with a bitset metric: P.bs_offs points at 32-bit offsets
   int part_ring = 0;                    // DENSE_PART: phase 1 writes its tuples through the block's ring writer (vj_part_ring_add): partitions it keeps lines for (16 / 64), 0 = tuples of three or more words, appended piece by piece (vh_part_direct_add)
   int hp_fan = 0;                       // hashed partitioning: the scan block writes the level-A pool itself (vj_fan_add; 1024-thread blocks, one per CU) — no stream pool, no level-A scatter
+  int tuple4 = 0;                       // DENSE_PART: the one-word tuple is 4 bytes (VhPlanDev::tuple4)
   int gid_bits = 0;                     // DENSE_PART: one-word tuples — the gid's bits at the bottom of word 0 (0: the usual two or more words)
   int hp_agg_waves = 0;                  // ... its aggregation kernel should leave room for this many waves per SIMD (what its LDS tables allow): a register bound for the compiler (0: none)
   int hp_pack = 0, hp_pbits = 0, hp_idbits = 0;   // ... in PACKED 16-byte tuples: word 1 = payload (hp_pbits) | two ids (hp_idbits each) | ids that count << 61 | ids only << 63

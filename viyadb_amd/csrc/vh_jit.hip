@@ -49,7 +49,7 @@ uint64_t vh_jit_min_rows() {
 std::string VhJitShape::key() const {
   std::string k;
   auto put = [&](long long v) { k += std::to_string(v); k += ','; };
-  put(mode); put(block); put(scope); put(xcd); put(carrier); put(tw); put(key_words); put(lds_hash); put(gid32); put(ablate); put(hpart); put(hp_agg_waves); put(bitset_j); put(hp_pack); put(hp_pbits); put(hp_idbits); put(gid_bits); put(bs_off32); put(hp_fan); put(part_ring);
+  put(mode); put(block); put(scope); put(xcd); put(carrier); put(tw); put(key_words); put(lds_hash); put(gid32); put(ablate); put(hpart); put(hp_agg_waves); put(bitset_j); put(hp_pack); put(hp_pbits); put(hp_idbits); put(gid_bits); put(tuple4); put(bs_off32); put(hp_fan); put(part_ring);
   put(lanes); put(npred);
   for (int i = 0; i < npred; ++i) { put(pred[i].slot); put(pred[i].type); put(pred[i].width); }
   put(qpay); put(qpay_slot);
@@ -120,6 +120,7 @@ std::string vh_jit_source(const VhJitShape& s, const char* kernel_name) {
   t += vj_fmt("  static constexpr bool LDS_HASH = %s, XCD = %s, GID32 = %s;\n", s.lds_hash ? "true" : "false", s.xcd ? "true" : "false", s.gid32 ? "true" : "false");
   t += vj_fmt("  static constexpr bool HP_PACK = %s;\n  static constexpr int HP_PBITS = %d, HP_IDBITS = %d;\n", s.hp_pack ? "true" : "false", s.hp_pbits, s.hp_idbits);
   t += vj_fmt("  static constexpr int GID_BITS = %d;\n", s.gid_bits);
+  t += vj_fmt("  static constexpr bool TUPLE4 = %s;\n", s.tuple4 ? "true" : "false");
   t += vj_fmt("  static constexpr bool BS_OFF32 = %s;\n", s.bs_off32 ? "true" : "false");
   t += vj_fmt("  static constexpr int PART_RING = %d;\n", s.part_ring);
   t += vj_fmt("  static constexpr bool LANES = %s;\n", s.lanes ? "true" : "false");
@@ -705,6 +706,7 @@ static bool vj_canonical(int which, VhJitShape* s) {
   auto col = [](int slot, int type, int pitch, int rec, int off, int sext) { VhJitCol c; c.slot = slot; c.type = type; c.pitch = pitch; c.rec = rec; c.off = off; c.sext = sext; return c; };
   switch (which) {
     case 19:    // ... case 0 whose tuples leave through the block's ring writer (16 partitions' waiting lines per block, extents by position)
+    case 20:    // ... case 9 with the tuple in FOUR bytes (gid 17 + 10 + 2 bits: thirty-two to a line)
     case 18:    // ... case 9 likewise (one-word tuples: sixteen to a line)
     case 14:    // ... case 10 with the predicate columns BIT-SLICED: 2 + 10 + 10 planes of one bit per row, a lane owns 32 consecutive rows per step
     case 13:    // ... case 12 with the payload records STREAMED beside the predicate planes and queued in the rows' place (no gathers)
@@ -715,7 +717,8 @@ static bool vj_canonical(int which, VhJitShape* s) {
     case 0:     // C3: d2 == a & d3 < b & d4 >= c on narrow copies (1, 2, 2 bytes), payload from a 32-byte record, tuples for DENSE_PART
     case 1: {   // ... the same from the 4-byte arenas, straight into the dense HBM table (what an eighth of the table runs)
       const bool ring = which == 18 || which == 19;
-      if (which == 18) which = 9;
+      const bool four = which == 20;      // C3's one-word tuples in 4 bytes
+      if (which == 18 || which == 20) which = 9;
       if (which == 19) which = 0;
       const bool part = which == 0 || which == 7 || which == 9 || which == 10 || which == 12 || which == 13 || which == 14;
       S.mode = part ? VH_MODE_DENSE_PART : VH_MODE_DENSE_GLOBAL; S.block = 256; S.scope = __HIP_MEMORY_SCOPE_AGENT; S.carrier = 1; S.tw = part ? 2 : 1; S.gid32 = 1; S.part_ring = part ? 16 : 0;
@@ -729,6 +732,7 @@ static bool vj_canonical(int which, VhJitShape* s) {
         S.m[0] = col(12, VH_I64, 32, 0, 0, 0); S.m[0].sop = SOP_ADD64; S.m[0].tword = 1; S.m[0].tshift = 0;
         S.m[1] = col(13, VH_U32, 32, 0, 16, 0); S.m[1].sop = SOP_ADD32P; S.m[1].tword = 0; S.m[1].tshift = 32;
         if (which == 9 || which == 10 || which == 12 || which == 13 || which == 14) { S.tw = 1; S.gid_bits = 17; S.m[0].tword = 0; S.m[0].tshift = 17; S.m[0].tbits = 10; S.m[1].tword = 0; S.m[1].tshift = 27; S.m[1].tbits = 2; }
+        if (four) S.tuple4 = 1;
         if (which == 13) { S.qpay = 4; S.qpay_slot = 10; }
         if (which == 14) { S.pp_sliced = 1; S.pp_slot = 7; S.pp_off[0] = 0; S.pp_bits[0] = 2; S.pp_off[1] = 2; S.pp_bits[1] = 10; S.pp_off[2] = 12; S.pp_bits[2] = 10; }
         if (which == 12 || which == 13) {

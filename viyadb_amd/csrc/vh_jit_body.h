@@ -131,7 +131,7 @@ struct VjPartDest {
 template <class J, int TW>
 __device__ __forceinline__ void vj_part_ring_add(const VhPlanDev& P, const VhRing& F, bool active, const uint64_t (&w)[TW], uint32_t part, int lane) {
   const VjPartDest D(P);
-  vh_ring_add_tb<TW * 8, VjPartDest, J::PART_RING, 2, true>(F, reinterpret_cast<char*>(P.tuples), (uint32_t)P.ext_stride, 31u - (uint32_t)__builtin_clz((uint32_t)P.ext_tuples), active, w, part, lane, D, P.counters + 2);
+  vh_ring_add_tb<(J::TUPLE4 && TW == 1) ? 4 : TW * 8, VjPartDest, J::PART_RING, 2, true>(F, reinterpret_cast<char*>(P.tuples), (uint32_t)P.ext_stride, 31u - (uint32_t)__builtin_clz((uint32_t)P.ext_tuples), active, w, part, lane, D, P.counters + 2);
 }
 
 // Where a row's ids lie (hashed partitioning with a bitset metric) and the first two of them: loaded in two dependent steps, which a drain
@@ -697,7 +697,7 @@ __device__ __forceinline__ void vj_scan(const VhPlanDev& P) {
   }
 
   if constexpr (MODE == VH_MODE_DENSE_PART && J::PART_RING != 0)
-    vh_ring_finish_tb<J::TW * 8, BLOCK, VjPartDest, J::PART_RING, 2, true>(V.F, reinterpret_cast<char*>(P.tuples), (uint32_t)P.ext_stride, 31u - (uint32_t)__builtin_clz((uint32_t)P.ext_tuples),
+    vh_ring_finish_tb<J::TUPLE4 ? 4 : J::TW * 8, BLOCK, VjPartDest, J::PART_RING, 2, true>(V.F, reinterpret_cast<char*>(P.tuples), (uint32_t)P.ext_stride, 31u - (uint32_t)__builtin_clz((uint32_t)P.ext_tuples),
                                                                            P.extent_missing, P.extent_part, VjPartDest(P), P.counters + 2, P.part_count);
   else if constexpr (MODE == VH_MODE_DENSE_PART) vh_part_tile_finish(P, V.T, lane);
   if constexpr (MODE == VH_MODE_HASH && J::HPART) vh_ring_finish<(J::BITSET_J >= 0 && !J::HP_PACK) ? 2 : 1, BLOCK>(V.F, reinterpret_cast<vh_u64x2*>(P.tuples2), (uint32_t)P.ext_tuples2, P.extent_missing2, P.extent_part2, VjFanDest(P), P.counters + 2);
@@ -793,7 +793,10 @@ __device__ __forceinline__ void vj_part_agg(const VhPlanDev& P, int blocks_per_p
       uint64_t w[VH_P2_SLOTS][TW];
 #pragma unroll
       for (int u = 0; u < VH_P2_SLOTS; ++u) {
-        if constexpr (TW == 2) {        // both words of a tuple in one 16-byte load
+        if constexpr (J::TUPLE4) {      // four-byte tuples (one level only): sbase counts 8-byte units from the pool's start — twice the tuple's number
+          const uint32_t* const t4 = reinterpret_cast<const uint32_t*>(pool) + (uint64_t)(sbase[u] - pool);
+          w[u][0] = (uint32_t)lane < sn[u] ? (uint64_t)__builtin_nontemporal_load(t4 + lane) : ~0ull;
+        } else if constexpr (TW == 2) {        // both words of a tuple in one 16-byte load
           typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
           const u64x2 t2 = (uint32_t)lane < sn[u] ? __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(sbase[u]) + lane) : u64x2{~0ull, 0ull};
           w[u][0] = t2.x; w[u][1] = t2.y;

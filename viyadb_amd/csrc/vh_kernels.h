@@ -1252,13 +1252,13 @@ __device__ __forceinline__ uint64_t vh_ring_ovf_extent(const VhRing& F, const De
     cur = seen;             // (another owner of the same extent was first; the extent taken here stays unused, its tag "never opened")
   }
 }
-// TB bytes per tuple: 8 (DENSE_PART's one-word tuples), 16 or 32; FAN digits and LINES waiting lines per digit (powers of two, FAN * LINES <= 1024:
+// TB bytes per tuple: 4 or 8 (DENSE_PART's one-word tuples), 16 or 32; FAN digits and LINES waiting lines per digit (powers of two, FAN * LINES <= 1024:
 // a ring line's number takes ten bits of a list entry); et_shift: log2 of the tuples an extent of the pool holds; stride: tuples between extent
 // starts (a whole number of 128-byte lines). The hashed partitioning: 256 digits x 2 lines; DENSE_PART: 16 or 64 x 2.
 template <int TB, class Dest, int FAN = VH_RING_FAN, int R = VH_RING_LINES, bool MISSING = false>
-__device__ __forceinline__ void vh_ring_add_tb(const VhRing& F, char* pool, uint32_t stride, uint32_t et_shift, bool active, const uint64_t (&w)[TB / 8], uint32_t d, int lane,
+__device__ __forceinline__ void vh_ring_add_tb(const VhRing& F, char* pool, uint32_t stride, uint32_t et_shift, bool active, const uint64_t (&w)[(TB + 7) / 8], uint32_t d, int lane,
                                                const Dest& dest, unsigned long long* err) {
-  static_assert(FAN * R <= 1024 && (TB == 8 || TB == 16 || TB == 32), "ring geometry");
+  static_assert(FAN * R <= 1024 && (TB == 4 || TB == 8 || TB == 16 || TB == 32), "ring geometry");
   constexpr uint32_t LINE = 128u / TB;
   uint32_t my = 0;
   if (active) my = __hip_atomic_fetch_add(&F.pos[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1274,7 +1274,8 @@ __device__ __forceinline__ void vh_ring_add_tb(const VhRing& F, char* pool, uint
     __atomic_signal_fence(__ATOMIC_SEQ_CST);
     const bool can = pending && __hip_atomic_load(&F.gen[rl], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == want;
     if (can) {
-      if constexpr (TB == 8) *reinterpret_cast<uint64_t*>(cell) = w[0];
+      if constexpr (TB == 4) *reinterpret_cast<uint32_t*>(cell) = (uint32_t)w[0];
+      else if constexpr (TB == 8) *reinterpret_cast<uint64_t*>(cell) = w[0];
       else {
         vh_u64x2 v; v.x = w[0]; v.y = w[1];
         reinterpret_cast<vh_u64x2*>(cell)[0] = v;
@@ -1365,9 +1366,9 @@ __device__ __forceinline__ void vh_ring_finish_tb(const VhRing& F, char* pool, u
     if (left) {
       const uint32_t t0 = line * LINE;
       if (elast != ~0ull) {
-        const uint64_t* src = reinterpret_cast<const uint64_t*>(F.ring + (size_t)(d * R + (line & (R - 1u))) * 128u);
-        uint64_t* dst = reinterpret_cast<uint64_t*>(pool + (elast * stride + (t0 & (ET - 1u))) * TB);
-        for (uint32_t i = 0; i < left * (TB / 8u); ++i) dst[i] = src[i];
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(F.ring + (size_t)(d * R + (line & (R - 1u))) * 128u);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(pool + (elast * stride + (t0 & (ET - 1u))) * TB);
+        for (uint32_t i = 0; i < left * (TB / 4u); ++i) dst[i] = src[i];
       } else full = true;
     }
     for (uint32_t k = 0; k <= klast; ++k) {

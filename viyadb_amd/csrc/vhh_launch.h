@@ -70,6 +70,7 @@ int QueryBuild::compile_kernel() {
     js.lds_hash = P.lds_hash_slots ? 1 : 0;
     js.gid32 = mode != VH_MODE_HASH && G <= 0xFFFFFFFFull;
     js.gid_bits = mode == VH_MODE_DENSE_PART ? P.gid_bits : 0;
+    js.tuple4 = mode == VH_MODE_DENSE_PART && P.gid_bits && P.tuple4 ? 1 : 0;
     // one- and two-word tuples of up to 64 partitions leave through the BLOCK's ring writer (vj_part_ring_add): whole lines, extents by position with
     // the pool's shared overflow region behind them; wider tuples are appended piece by piece (vh_part_direct_add)
     part_ring = mode == VH_MODE_DENSE_PART && (P.tw == 2 || P.gid_bits) && P.npart <= VH_RING_PARTS_MAX;
@@ -362,7 +363,7 @@ int QueryBuild::layout_scratch() {
     P.ext_tuples = (int32_t)ext_tuples;
     // extents of pool 1 start one 128-byte line further apart than they are long (not the stream pools of the hashed partitioning, whose
     // reader takes extents as whole tiles): see VhPlanDev::ext_stride
-    const uint64_t ext_stride = hpart ? ext_tuples : ext_tuples + (P.gid_bits ? ((uint64_t)knobs().ext_pad + 15) / 16 * 16 : (uint64_t)knobs().ext_pad);      // (whole 128-byte lines: 8 two-word tuples, 16 one-word ones)
+    const uint64_t ext_stride = hpart ? ext_tuples : ext_tuples + (P.tuple4 ? ((uint64_t)knobs().ext_pad + 31) / 32 * 32 : P.gid_bits ? ((uint64_t)knobs().ext_pad + 15) / 16 * 16 : (uint64_t)knobs().ext_pad);      // (whole 128-byte lines: 8 two-word tuples, 16 one-word ones, 32 four-byte ones)
     P.ext_stride = (int32_t)ext_stride;
     uint64_t max_ext = part_tuple_cap / ext_tuples + waves * (P.npart + VH_EXT_CHUNK) + 64;
     if (max_ext > 0xFFFFFFF0ull) max_ext = 0xFFFFFFF0ull;
@@ -381,7 +382,7 @@ int QueryBuild::layout_scratch() {
     // holds that whenever the waves' tuple counts agree within the 25 % the estimate leaves; a re-run after VH_ERR_PART_FULL goes back to
     // the cursor, which packs the chunks whatever the imbalance
     P.ext_waves = ring1 || part_tuples_override || test_env("VH_TEST_EXT_CURSOR") || t->part_clustered.count(r->group_sig) ? 0u : (uint32_t)grid * (uint32_t)(BLOCK / 64);
-    o_tuples = sp.take(max_ext * ext_stride * P.tw * 8);
+    o_tuples = sp.take(max_ext * ext_stride * (P.tuple4 ? 4 : P.tw * 8));
     o_emiss = sp.take(max_ext * sizeof(uint16_t));
     o_epart = sp.take(max_ext);
     if (P.nlevel == 2) {

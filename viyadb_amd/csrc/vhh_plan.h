@@ -900,7 +900,7 @@ int QueryBuild::choose_organisation() {
     // instead of 16: half the tuple bytes written by phase 1, moved by the split level and read back by phase 2. Only the compiled scan
     // with the whole-line writer packs them.
     int nt_gb = 0, nt_mb[VH_MAX_METRIC] = {};
-    bool narrow_tuples = false;
+    bool narrow_tuples = false, tuple4 = false;
     if (want_part && jit_try && (two_level ? (np + 63) / 64 : np) <= VH_RING_PARTS_MAX && !(p->flags & (VH_PLAN_NO_NARROW_TUPLES | VH_PLAN_FORCE_LANES)) && !test_env("VH_NO_NARROW_TUPLES")) {
       auto bits_of = [](uint64_t v) { int b = 1; while (b < 64 && (v >> b)) ++b; return b; };
       nt_gb = bits_of(G - 1);
@@ -920,6 +920,8 @@ int QueryBuild::choose_organisation() {
         used += nt_mb[j];
       }
       narrow_tuples = fits && used <= 63;
+      // ... and FOUR bytes when they fit 32 bits (one level only: the second split moves 8-byte words)
+      tuple4 = narrow_tuples && used <= 32 && !two_level && !test_env("VH_NO_TUPLE4");
     }
     if (want_part) {
       // most rows pass: build the tuples without compacting survivors first (lanes kernel, phase 1 only)
@@ -956,9 +958,9 @@ int QueryBuild::choose_organisation() {
         else { P.m[j].set_tword((uint8_t)tw); P.m[j].set_tshift(0); half_free_word = tw++; have_half = true; }
       }
       P.tw = tw;
-      P.gid_bits = 0;
+      P.gid_bits = 0; P.tuple4 = 0;
       if (narrow_tuples && !lanes) {
-        P.gid_bits = nt_gb; P.tw = 1;
+        P.gid_bits = nt_gb; P.tw = 1; P.tuple4 = tuple4 ? 1 : 0;
         int at = nt_gb;
         for (int j = 0; j < P.nmetric; ++j) { P.m[j].set_tword(0); P.m[j].set_tshift((uint8_t)at); P.m[j].tbits = (uint32_t)nt_mb[j]; at += nt_mb[j]; }
       }
