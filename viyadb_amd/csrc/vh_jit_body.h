@@ -734,21 +734,24 @@ __device__ __forceinline__ void vj_part_agg(const VhPlanDev& P, int blocks_per_p
   constexpr bool carried = J::CARRIER >= 0;
   constexpr uint64_t gid_mask = GB ? (1ull << GB) - 1ull : 0xFFFFFFFFull;
   int part, b;
-  if (!vh_part_my_share(P, blocks_per_part, part, b, blocks_per_part)) return;      // (blocks_per_part: from here on THIS partition's blocks — by the partitions' tuple counts where phase 1 counted them)
   const bool balanced = P.part_count != nullptr && P.nlevel == 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = BLOCK / 64;
   const uint64_t gpp = 1ull << P.agg_shift;
-  const uint64_t g0 = (uint64_t)part << P.agg_shift;
-  const uint64_t ng = g0 >= P.G ? 0 : (P.G - g0 < gpp ? P.G - g0 : gpp);
+  // (the partitions' counts are asked for before the tables are filled — every range's table the same gpp entries, whichever partition this block
+  // turns out to work for — and looked at behind the fill: their latency is not the first thing all blocks of the launch wait for)
+  const uint32_t my_count = balanced && threadIdx.x < 64 ? vh_part_count_of(P.part_count, P.npart, (int)threadIdx.x) : 0u;
   char* mstate[NM ? NM : 1];
 #pragma unroll
   for (int j = 0; j < NM; ++j) {
     mstate[j] = lds + P.m[j].lds_off;
     const uint64_t ident = P.m[j].ident;
-    if (vh_sop_bytes(J::m_sop[j]) == 4) { for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint32_t*>(mstate[j])[g] = (uint32_t)ident; }
-    else { for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint64_t*>(mstate[j])[g] = ident; }
+    if (vh_sop_bytes(J::m_sop[j]) == 4) { for (uint64_t g = threadIdx.x; g < gpp; g += BLOCK) reinterpret_cast<uint32_t*>(mstate[j])[g] = (uint32_t)ident; }
+    else { for (uint64_t g = threadIdx.x; g < gpp; g += BLOCK) reinterpret_cast<uint64_t*>(mstate[j])[g] = ident; }
   }
-  if (!carried) for (uint64_t g = threadIdx.x; g < ng; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
+  if (!carried) for (uint64_t g = threadIdx.x; g < gpp; g += BLOCK) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[g] = 0;
+  if (!vh_part_my_share(P, blocks_per_part, my_count, part, b, blocks_per_part)) return;      // (two barriers inside; blocks_per_part: from here on THIS partition's blocks — by the partitions' tuple counts where phase 1 counted them)
+  const uint64_t g0 = (uint64_t)part << P.agg_shift;
+  const uint64_t ng = g0 >= P.G ? 0 : (P.G - g0 < gpp ? P.G - g0 : gpp);
   __syncthreads();
   const bool two = P.nlevel == 2;
   uint32_t first = 0, total;
@@ -773,6 +776,49 @@ __device__ __forceinline__ void vj_part_agg(const VhPlanDev& P, int blocks_per_p
     uint64_t mine = __ballot(in && tag == want && fill != 0);
     uint32_t ext = 0, valid = 0, at = 0;
     while (mine || at < valid) {
+      if constexpr (J::TUPLE4) {
+        // FOUR-byte tuples (one level only): a slot is 256 tuples — one 16-byte load per lane, four tuples each (a line's worth of bytes per
+        // load instruction, as with the two-word tuples; one 4-byte load per lane read the pool at 1.1 TB/s). Extents hold a power of two of at
+        // least 256 tuples and start on 128-byte lines: the loads are aligned and never leave the extent; places beyond `valid` are masked.
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const uint32_t* tb[VH_P2_SLOTS];
+        uint32_t tn[VH_P2_SLOTS];
+#pragma unroll
+        for (int u = 0; u < VH_P2_SLOTS; ++u) {
+          if (at >= valid && mine) {
+            const int q = __builtin_ctzll(mine);
+            mine &= mine - 1;
+            ext = c0 + (uint32_t)q;
+            valid = (uint32_t)__builtin_amdgcn_readlane((int)fill, q);
+            at = 0;
+          }
+          if (at < valid) {
+            tb[u] = reinterpret_cast<const uint32_t*>(pool) + (uint64_t)ext * ext_stride + at;
+            tn[u] = valid - at < 256u ? valid - at : 256u;
+            at += 256u;
+          } else { tb[u] = reinterpret_cast<const uint32_t*>(pool); tn[u] = 0; }
+        }
+        u32x4 t4[VH_P2_SLOTS];
+#pragma unroll
+        for (int u = 0; u < VH_P2_SLOTS; ++u) t4[u] = (uint32_t)lane * 4u < tn[u] ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(tb[u]) + lane) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int u = 0; u < VH_P2_SLOTS; ++u) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if ((uint32_t)lane * 4u + (uint32_t)k >= tn[u]) continue;
+            const uint64_t w0 = k == 0 ? t4[u].x : k == 1 ? t4[u].y : k == 2 ? t4[u].z : t4[u].w, local = (w0 & gid_mask) - g0;
+            if (local >= ng) continue;          // (a corrupt tuple cannot write outside the table)
+            if (!carried) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[local] = 1;
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+              uint64_t v = w0 >> J::m_tshift[j];
+              if (J::m_tbits[j]) v &= (1ull << (J::m_tbits[j] < 63 ? J::m_tbits[j] : 63)) - 1ull;
+              vh_state_update<__HIP_MEMORY_SCOPE_WORKGROUP>(mstate[j], local, J::m_sop[j], v);
+            }
+          }
+        }
+        continue;
+      }
       const uint64_t* sbase[VH_P2_SLOTS];
       uint32_t sn[VH_P2_SLOTS];
 #pragma unroll
@@ -793,10 +839,7 @@ __device__ __forceinline__ void vj_part_agg(const VhPlanDev& P, int blocks_per_p
       uint64_t w[VH_P2_SLOTS][TW];
 #pragma unroll
       for (int u = 0; u < VH_P2_SLOTS; ++u) {
-        if constexpr (J::TUPLE4) {      // four-byte tuples (one level only): sbase counts 8-byte units from the pool's start — twice the tuple's number
-          const uint32_t* const t4 = reinterpret_cast<const uint32_t*>(pool) + (uint64_t)(sbase[u] - pool);
-          w[u][0] = (uint32_t)lane < sn[u] ? (uint64_t)__builtin_nontemporal_load(t4 + lane) : ~0ull;
-        } else if constexpr (TW == 2) {        // both words of a tuple in one 16-byte load
+        if constexpr (TW == 2) {        // both words of a tuple in one 16-byte load
           typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
           const u64x2 t2 = (uint32_t)lane < sn[u] ? __builtin_nontemporal_load(reinterpret_cast<const u64x2*>(sbase[u]) + lane) : u64x2{~0ull, 0ull};
           w[u][0] = t2.x; w[u][1] = t2.y;

@@ -1146,8 +1146,13 @@ __device__ __forceinline__ void vh_part_tile_finish(const VhPlanDev& P, VhPartTi
 // rounding left over one each to the first partitions with tuples, never more than `cap` (the copies there is memory for). Computed redundantly by wave 0
 // of every phase-2 block and by every block of the merge kernel from the same counts: the same answer everywhere, no launch of its own.
 // Wave-level (all 64 lanes): lane p returns partition p's share; *start = the blocks before it.
-__device__ __forceinline__ uint32_t vh_part_shares(const uint32_t* count, int npart, uint32_t blocks, uint32_t cap, int lane, uint32_t* start) {
-  const uint32_t c = lane < npart ? count[lane] : 0u;
+#define VH_PART_COUNT_WAYS 8u      // counters per partition (vh_ring_finish_tb spreads the blocks over them)
+__device__ __forceinline__ uint32_t vh_part_count_of(const uint32_t* count, int npart, int lane) {      // lane p: partition p's tuples (the sum of its counters)
+  if (lane >= npart) return 0u;
+  const uint4 a = reinterpret_cast<const uint4*>(count)[2 * lane], b = reinterpret_cast<const uint4*>(count)[2 * lane + 1];
+  return a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+}
+__device__ __forceinline__ uint32_t vh_part_shares(uint32_t c, int npart, uint32_t blocks, uint32_t cap, int lane, uint32_t* start) {      // c: vh_part_count_of
   unsigned long long tot = c;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) tot += __shfl_xor(tot, off);
@@ -1169,14 +1174,16 @@ __device__ __forceinline__ uint32_t vh_part_shares(const uint32_t* count, int np
   return share;
 }
 // Which (partition, block of the partition, blocks of the partition) a phase-2 block is. false: the block has nothing to do.
-__device__ __forceinline__ bool vh_part_my_share(const VhPlanDev& P, int blocks_per_part, int& part, int& b, int& bpp) {
+// (my_count: vh_part_count_of for the block's first 64 threads, loaded by the caller BEFORE it fills its LDS tables, so that the loads' latency is
+// not the first thing every block of the launch waits for)
+__device__ __forceinline__ bool vh_part_my_share(const VhPlanDev& P, int blocks_per_part, uint32_t my_count, int& part, int& b, int& bpp) {
   if (!P.part_count || P.nlevel != 1) { part = blockIdx.x / blocks_per_part; b = blockIdx.x % blocks_per_part; bpp = blocks_per_part; return true; }
   __shared__ int s_mine[3];
   if (threadIdx.x == 0) s_mine[0] = -1;
   __syncthreads();
   if (threadIdx.x < 64) {
     uint32_t start = 0;
-    const uint32_t share = vh_part_shares(P.part_count, P.npart, gridDim.x, (uint32_t)P.nxcd, (int)threadIdx.x, &start);
+    const uint32_t share = vh_part_shares(my_count, P.npart, gridDim.x, (uint32_t)P.nxcd, (int)threadIdx.x, &start);
     if ((int)threadIdx.x < P.npart && blockIdx.x >= start && blockIdx.x < start + share) { s_mine[0] = (int)threadIdx.x; s_mine[1] = (int)(blockIdx.x - start); s_mine[2] = (int)share; }
   }
   __syncthreads();
@@ -1356,7 +1363,7 @@ __device__ __forceinline__ void vh_ring_finish_tb(const VhRing& F, char* pool, u
   for (uint32_t d = threadIdx.x; d < (uint32_t)FAN; d += BLOCK) {
     const uint32_t n = F.pos[d];
     if (!n) continue;
-    if (count) atomicAdd(&count[d], n);
+    if (count) atomicAdd(&count[d * VH_PART_COUNT_WAYS + (blockIdx.x & (VH_PART_COUNT_WAYS - 1u))], n);      // (eight counters per digit: a thousand blocks end at about the same time, and atomics on ONE address are served one after the other)
     bool full = false;
     const uint32_t left = n % LINE, line = n / LINE;
     const uint32_t klast = (n - 1u) >> et_shift;
@@ -2123,8 +2130,9 @@ template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void part_agg_kernel(const VhPlanDev P, int blocks_per_part) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int part, b;
-  if (!vh_part_my_share(P, blocks_per_part, part, b, blocks_per_part)) return;      // (blocks_per_part: from here on THIS partition's blocks)
   const bool balanced = P.part_count != nullptr && P.nlevel == 1;
+  const uint32_t my_count = balanced && threadIdx.x < 64 ? vh_part_count_of(P.part_count, P.npart, (int)threadIdx.x) : 0u;
+  if (!vh_part_my_share(P, blocks_per_part, my_count, part, b, blocks_per_part)) return;      // (blocks_per_part: from here on THIS partition's blocks)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = BLOCK / 64;
   const uint64_t gpp = 1ull << P.agg_shift;
   const uint64_t g0 = (uint64_t)part << P.agg_shift;

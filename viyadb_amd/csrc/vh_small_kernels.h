@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void dense_merge_kernel(const VhMergeArgs A) {
   const uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x;
   if (A.part_count) {
     __shared__ uint32_t s_share[64];
-    if (threadIdx.x < 64) { uint32_t start; s_share[threadIdx.x] = vh_part_shares(A.part_count, A.npart, A.blocks, (uint32_t)A.nxcd, (int)threadIdx.x, &start); }
+    if (threadIdx.x < 64) { uint32_t start; s_share[threadIdx.x] = vh_part_shares(vh_part_count_of(A.part_count, A.npart, (int)threadIdx.x), A.npart, A.blocks, (uint32_t)A.nxcd, (int)threadIdx.x, &start); }
     __syncthreads();
     if (g < A.G) vh_merge_group(A, g, (int)s_share[g >> A.agg_shift]);
     return;

@@ -339,7 +339,7 @@ int QueryBuild::layout_scratch() {
   }
   // outputs
   size_t o_tuples = 0, o_emiss = 0, o_epart = 0, o_tuples2 = 0, o_emiss2 = 0, o_epart2 = 0, o_l2 = 0;
-  if (part_balanced) o_pcount = sp.take(VH_MAX_PART * sizeof(uint32_t));
+  if (part_balanced) o_pcount = sp.take(VH_MAX_PART * VH_PART_COUNT_WAYS * sizeof(uint32_t));
   // hashed partitioning whose groups leave straight into the output columns, planned by a caller that can run a second pass (vh_query_agg): ranges
   // that are too heavy for a block's LDS tables are marked in a bitmap of the 65 536 ranges instead of voiding the attempt
   heavy_marks = hpart && r->hp_direct && !r->hp_chunks && !device_rows && g_heavy.allow_mark && !g_heavy.only && P.hp_passes == 1 && !test_env("VH_NO_HEAVY_PASS");
@@ -582,7 +582,7 @@ int QueryBuild::launch() {
     d_hpargs = reinterpret_cast<VhHpArgs*>(S + o_hpargs);
     HIP_TRY(hipMemcpyAsync(d_hpargs, &HA, sizeof(HA), hipMemcpyHostToDevice, st));
   }
-  if (part_balanced) clear(P.part_count, VH_MAX_PART * sizeof(uint32_t), 0);
+  if (part_balanced) clear(P.part_count, VH_MAX_PART * VH_PART_COUNT_WAYS * sizeof(uint32_t), 0);
   if (heavy_marks) clear(P.heavy_mark, 65536 / 8, 0);
   if (mode == VH_MODE_DENSE_PART || hpart) {
     clear(P.extent_missing, (size_t)P.max_extents * sizeof(uint16_t), 0);
