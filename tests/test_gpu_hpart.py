@@ -54,7 +54,7 @@ def sets5():
 
 
 def took_hpart(res):
-    assert res.path == "hash" and res.hpart and res.jit and "scatter_kernel" in res.kernel and res.kernel.endswith("_hpagg"), (res.path, res.kernel)
+    assert res.path == "hash" and res.hpart and res.jit and "scatter_kernel" in res.kernel and "_hpagg" in res.kernel, (res.path, res.kernel)
 
 
 def scan_wrote_level_a(res):

@@ -91,6 +91,16 @@ static inline int vh_hpart_bpp(int num_cu, size_t agg_lds) {
   return bpp;
 }
 
+// The second pass over HEAVY level-A partitions reads their tuples where the scan left them in pool a (hp_heavy_tuples_kernel) instead of scanning
+// the table again: what the tuples' words mean, taken from the first pass's plan.
+struct VhHeavyTuples {
+  const VhHpArgs* HA;           // the first pass's pools (its scratch lives until its result is freed)
+  uint32_t src_blocks;          // blocks of the scan kernel that wrote level A
+  int32_t units, pk, pbits, idbits;      // as VhHpArgs
+  int32_t nmetric, bitset_j;    // states of the plan; which of them is the bitset's cardinality (-1: none)
+  uint8_t tshift[VH_MAX_METRIC], tbytes[VH_MAX_METRIC], tsext[VH_MAX_METRIC];      // a value in the payload word: bit offset, bytes of the first pass's state (4 / 8), sign-extended
+  uint32_t tbits[VH_MAX_METRIC];         // ... packed tuples: its bits (0: the state's width)
+};
 #ifdef VH_HPART_KERNELS        // (the kernels: vh_hpart.hip only; the host code of viya_hip.hip takes the descriptors above)
 typedef uint64_t hp_u64x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t hp_u32x4 __attribute__((ext_vector_type(4)));
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(HP_FAN) void hp_plan_kernel(const VhHpArgs* __restr
       for (int q = 0; q < 8; ++q) HA->heavy_mark[a * 8 + q] = ~0u;
       atomicAdd(counters + 11, 256ull);
       atomicAdd(counters + 12, (unsigned long long)c);
+      atomicAdd(counters + 13, 1ull);        // (partitions left out whole: when they account for every marked range, the second pass reads their tuples)
       c = 0;                                   // no slice: level B and the ranges' kernel find nothing of it
       K.count[a] = 0xFFFFFFFFu;                // (level B's block a: nothing to move)
     }
@@ -226,6 +237,135 @@ __global__ __launch_bounds__(HP_FAN) void hp_plan_kernel(const VhHpArgs* __restr
     K.slice[HP_FAN] = (uint32_t)(end < K.b.max_extents ? end : K.b.max_extents);
     if (end > K.b.max_extents) atomicOr(counters + 2, VH_ERR_PART_FULL);
   }
+}
+
+#define HP_IDS_ONLY 4ull    // tuples that carry ids, word 3: bits 0-1 = ids that count (0..2), bit 2 = the payload was sent with another tuple of the row
+// ------------------------------------------------------------------ heavy level-A partitions: their tuples into the plain hash organisation
+// P: the SECOND pass's plan (plain hash organisation: one key word, the group table and the (group, id) set in HBM). Every wave takes whole extents of
+// pool a whose digit hp_plan_kernel marked heavy (K.count[a] == ~0u) — by position below the overflow region, by tag inside it —, a lane a tuple:
+// the group key is the mixed key un-mixed, the values sit in the payload word where the first pass's plan put them, the ids in the tuple. What
+// vh_consume does for a surviving row from here on, hot groups included (vh_hot_lanes / VhHotAcc: such a partition is one hot key and its ids).
+// C5 with one (t, u) on a tenth of the rows: 12.8 M tuples of 16 bytes instead of 125 M rows through the interpreting scan.
+template <int U, bool PK>
+__global__ __launch_bounds__(256) void hp_heavy_tuples_kernel(const VhPlanDev P, const VhHeavyTuples A) {
+  typedef HpTuple<U> T;
+  __shared__ uint32_t s_heavy[HP_FAN / 32];
+  const VhHpKind& K = A.HA->k[0];
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < HP_FAN / 32) s_heavy[threadIdx.x] = 0;
+  __syncthreads();
+  if (threadIdx.x < HP_FAN && K.count[threadIdx.x] == 0xFFFFFFFFu) atomicOr(&s_heavy[threadIdx.x >> 5], 1u << (threadIdx.x & 31));
+  __syncthreads();
+  uint32_t used = K.a.ovf_base;
+  if (K.a.ovf_cursor) { const unsigned long long c = *K.a.ovf_cursor, room = K.a.max_extents - K.a.ovf_base; used += (uint32_t)(c < room ? c : room); }
+  const T* const in = reinterpret_cast<const T*>(K.a.tuples);
+  const int PB = PK ? A.pbits : 0, IB = PK ? A.idbits : 32;
+  const uint64_t PMASK = PK && PB < 64 ? (1ull << PB) - 1ull : ~0ull, IMASK = IB < 64 ? (1ull << IB) - 1ull : ~0ull;
+  const int bj = A.bitset_j;
+  int nvalue = 0;
+  for (int j = 0; j < A.nmetric; ++j) nvalue += j != bj;
+  VhHotAcc hot_acc{0ull, false, 0ull, {0ull, 0ull, 0ull, 0ull}};
+  unsigned long long nfresh = 0, npairs = 0, ntuples = 0;
+  const uint32_t wave_g = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+  // the work list: slot s of a heavy digit's positional extents (extent s * HP_FAN + digit: every scan block's, every level's), digit after digit,
+  // then the overflow region's extents (a heavy digit's by their tags) — dealt out to the waves round robin
+  uint32_t nheavy = 0;
+  for (int q = 0; q < HP_FAN / 32; ++q) nheavy += __popc(s_heavy[q]);
+  const uint32_t npos = K.a.ovf_base / (uint32_t)HP_FAN;
+  const uint64_t nwork = (uint64_t)nheavy * npos + (used - K.a.ovf_base);
+  for (uint64_t wk = wave_g; wk < nwork; wk += nwaves) {
+    uint32_t e;
+    if (wk < (uint64_t)nheavy * npos) {
+      uint32_t h = (uint32_t)(wk / npos), a = 0;           // the h-th heavy digit
+      for (int q = 0; q < HP_FAN / 32; ++q) {
+        const uint32_t c = __popc(s_heavy[q]);
+        if (h < c) { uint32_t m = s_heavy[q]; for (uint32_t i = 0; i < h; ++i) m &= m - 1u; a = (uint32_t)q * 32u + (uint32_t)__builtin_ctz(m); break; }
+        h -= c;
+      }
+      e = (uint32_t)(wk % npos) * (uint32_t)HP_FAN + a;
+    } else {
+      e = K.a.ovf_base + (uint32_t)(wk - (uint64_t)nheavy * npos);
+      const uint32_t a = K.a.tag[e];
+      if (!((s_heavy[a >> 5] >> (a & 31u)) & 1u)) continue;
+    }
+    const uint32_t n = __builtin_amdgcn_readfirstlane((int)K.a.fill[e]);
+    if (!n) continue;
+    const T* const src = in + (uint64_t)e * K.a.stride;
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+      bool act = i0 + lane < n;
+      T tp{};
+      if (act) tp = hp_load_nt<U>(src + i0 + lane);
+      const uint64_t mkey = tp.v[0].x, w1 = tp.v[0].y, payload = PK ? (w1 & PMASK) : w1;
+      const uint64_t meta = PK ? (w1 >> 61) : U == 2 ? tp.v[U - 1].y : 0ull;      // bits 0-1: ids that count, bit 2: ids only
+      const bool vact = act && !(bj >= 0 && (meta & HP_IDS_ONLY));               // the tuple carries the row's values
+      ntuples += vact ? 1 : 0;
+      bool ok = true, fresh = false;
+      uint64_t gid = 0;
+      if (act) gid = vh_hash_insert64(P, vh_unmix64(mkey), ok, fresh);
+      nfresh += act && fresh ? 1 : 0;
+      if (__ballot(act && !ok)) { if (act && !ok) atomicOr(P.counters + 2, VH_ERR_HASH_FULL); }
+      act = act && ok;
+      // the wave's hot group, as in vh_consume
+      uint64_t hot = vh_hot_lanes(act, gid);
+      if (!hot && hot_acc.valid) hot = __ballot(act && gid == hot_acc.gid);
+      const bool in_hot = ((hot >> lane) & 1ull) != 0;
+      const bool keep = hot != 0 && nvalue <= VH_HOT_METRICS;
+      const bool speaks = hot != 0 && !keep && lane == __builtin_ctzll(hot);
+      if (keep) {
+        const uint64_t hg = __shfl(gid, __builtin_ctzll(hot));
+        if (!hot_acc.valid || hot_acc.gid != hg) {
+          vh_hot_flush(P, hot_acc);
+          hot_acc.gid = hg; hot_acc.valid = true; hot_acc.card = 0;
+          int k = 0;
+          for (int j = 0; j < A.nmetric; ++j) if (j != bj) { const int sop = P.m[j].sop(); hot_acc.v[k++] = sop == SOP_ADD32 || sop == SOP_ADD64 || sop == SOP_ADDF32 || sop == SOP_ADDF64 || sop == SOP_ADD32P ? 0ull : P.m[j].ident; }
+        }
+      }
+      int kv = 0;
+      for (int j = 0; j < A.nmetric; ++j) {
+        const VhMetricDev& m = P.m[j];
+        if (j == bj) {
+          unsigned long long* const card = reinterpret_cast<unsigned long long*>(vh_hash_state(P, m, gid));
+          unsigned long long mine = 0;
+          if (act) {
+            const uint64_t ids = PK ? 0ull : tp.v[U - 1].x;
+            const uint32_t idv[2] = {PK ? (uint32_t)((w1 >> PB) & IMASK) : (uint32_t)ids, PK ? (uint32_t)((w1 >> (PB + IB)) & IMASK) : (uint32_t)(ids >> 32)};
+            const int nid = (int)(meta & 3ull);
+            const int b = m.slot();
+            for (int q = 0; q < 2; ++q) {
+              if (q >= nid || (q == 1 && idv[1] == idv[0])) break;
+              bool sok = true, sfresh = false;
+              vh_set_insert64(P.dset_keys[b], P.dset_mask[b], 4096u, (gid << 32) | idv[q], sok, sfresh);
+              if (!sok) atomicOr(P.counters + 2, VH_ERR_HASH_FULL);
+              mine += sfresh ? 1 : 0;
+            }
+            npairs += mine;
+            if (mine && !in_hot) atomicAdd(card, mine);
+          }
+          if (hot) {
+            const unsigned long long tot = vh_wave_combine(SOP_ADD64, mine, in_hot);
+            if (keep) hot_acc.card += tot;
+            else if (speaks && tot) atomicAdd(card, tot);
+          }
+          continue;
+        }
+        uint64_t v = payload >> A.tshift[j];
+        if (PK && A.tbits[j] && A.tbits[j] < 64) v &= (1ull << A.tbits[j]) - 1ull;
+        else if (A.tbytes[j] == 4) { v &= 0xFFFFFFFFull; if (A.tsext[j]) v = (uint64_t)(int64_t)(int32_t)v; }
+        bool upd = vact && act;
+        const bool vin = in_hot && upd;                      // (an "ids only" tuple of the hot group has no values to add)
+        if (hot && __ballot(vin)) {
+          const uint64_t tot = vh_wave_combine(m.sop(), v, vin);
+          if (keep) { hot_acc.v[kv] = vh_combine(m.sop(), hot_acc.v[kv], tot); if (vin) upd = false; }
+          else if (vin) { v = tot; upd = lane == __builtin_ctzll(__ballot(vin)); }
+        }
+        ++kv;
+        if (upd) vh_state_update<__HIP_MEMORY_SCOPE_AGENT>(vh_hash_state(P, m, gid), 0, m.sop(), v);
+      }
+    }
+  }
+  vh_hot_flush(P, hot_acc);
+  for (int off = 32; off > 0; off >>= 1) { ntuples += __shfl_down(ntuples, off); nfresh += __shfl_down(nfresh, off); npairs += __shfl_down(npairs, off); }
+  vh_scan_block_end(P, ntuples, nfresh, npairs, 0u);
 }
 
 __device__ __forceinline__ void hp_store_sized(void* base, uint32_t esize, unsigned long long i, uint64_t v) {
@@ -304,7 +444,6 @@ struct HpAggLds {
   uint32_t ovf_ext[HP_OVF];          // the others: their digit in ovf_key
   uint16_t ovf_fill[HP_OVF], ovf_key[HP_OVF];
 };
-#define HP_IDS_ONLY 4ull    // tuples that carry ids, word 3: bits 0-1 = ids that count (0..2), bit 2 = the payload was sent with another tuple of the row
 
 // grid: HP_FAN x blocks_per_partition; block (a, j) works through ranges (a, b), b = j, j + blocks_per_partition, ...
 // Compiled PER PLAN SHAPE, next to the query's scan kernel (vh_jit.hip emits `viya_jit_hpagg_<hash>`, which is this body over the traits struct

@@ -24,3 +24,11 @@ void vh_launch_hpart(const VhPlanDev& P, const VhHpArgs* d_args, int units, int 
   if (units == 2) launch_hpart<2>(P, d_args, num_cu, scan_blocks, ring_blocks, s);
   else launch_hpart<1>(P, d_args, num_cu, scan_blocks, ring_blocks, s);
 }
+
+// The second pass over heavy level-A partitions, from the first pass's tuples (hp_heavy_tuples_kernel): P is the second pass's plan.
+void vh_launch_heavy_tuples(const VhPlanDev& P, const VhHeavyTuples& A, int num_cu, hipStream_t s) {
+  const dim3 grid((unsigned)num_cu * 8u), block(256);
+  if (A.units == 2) hipLaunchKernelGGL((hp_heavy_tuples_kernel<2, false>), grid, block, 0, s, P, A);
+  else if (A.pk) hipLaunchKernelGGL((hp_heavy_tuples_kernel<1, true>), grid, block, 0, s, P, A);
+  else hipLaunchKernelGGL((hp_heavy_tuples_kernel<1, false>), grid, block, 0, s, P, A);
+}

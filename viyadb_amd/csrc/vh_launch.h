@@ -15,6 +15,8 @@ void vh_launch_scan_fast_part(const VhPlanDev& P, int grid, size_t lds, hipStrea
 void vh_launch_part_agg(const VhPlanDev& P, int blocks_per_part, size_t lds, hipStream_t s);
 void vh_launch_part_split(const VhPlanDev& P, int blocks_per_part, bool ring, hipStream_t s);
 struct VhHpArgs;
+struct VhHeavyTuples;
+void vh_launch_heavy_tuples(const VhPlanDev& P, const VhHeavyTuples& A, int num_cu, hipStream_t s);      // a second pass over heavy partitions, from the first pass's tuples (vh_hpart.h)
 void vh_launch_hpart(const VhPlanDev& P, const VhHpArgs* d_args, int units, int num_cu, int scan_blocks, int ring_blocks, hipStream_t s);      // hashed partitioning: everything behind the scan (vh_hpart.h)
 
 // Launch KERNEL (parenthesised template-id), or — occ != nullptr — only ask the runtime how many of its blocks fit one CU.

@@ -14,42 +14,49 @@ static hipError_t wait_event_spinning(hipEvent_t ev) {
 
 // The second pass of a hashed partitioning that marked heavy ranges (VhPlanDev::heavy_mark): the caller's plan once more, through the plain hash
 // organisation, over the rows of exactly those ranges (the generic scan drops every other survivor behind its key: VhPlanDev::heavy_only) — a group
-// with a tenth of the table's rows, or with more ids than a range's LDS set takes, costs its query that, not the whole organisation. *out2: the
-// finalised result of the pass on a context of its own (nullptr with VH_OK: it could not be had — the caller falls back as before).
+// with a tenth of the table's rows, or with more ids than a range's LDS set takes, costs its query that, not the whole organisation. In two steps,
+// so that a big result's rows cross PCIe WHILE the pass scans (C5 with a hot key: 10 ms of copy over 8.5 ms of scan): heavy_pass_launch enqueues
+// the pass on a context of its own, heavy_pass_finish waits for it (and re-runs it with a bigger table when that one filled). H.r2: the
+// finalised result (nullptr: it could not be had — the caller falls back as before).
 static int result_finalize(vh_result* r, int* retry, const vh_plan* plan = nullptr);
-static int heavy_second_pass(vh_result* r, const vh_plan* plan, uint64_t ranges, uint64_t tuples_bound, vh_result** out2) {
-  *out2 = nullptr;
+struct VhHeavyRun { VhExec* x2 = nullptr; vh_result* r2 = nullptr; vh_plan p2{}; uint64_t cap = 0, ids_bound = 0; bool from_tuples = false; };
+static int heavy_pass_enqueue(vh_result* r, VhHeavyRun& H) {
   vh_table* t = r->table;
-  VhExec* x2 = nullptr;
-  if (exec_acquire(t, &x2) != VH_OK) return VH_OK;
-  vh_plan p2 = *plan;
-  p2.flags = (p2.flags | VH_PLAN_FORCE_HASH | VH_PLAN_NO_JIT | VH_PLAN_NO_FAST | VH_PLAN_NO_LANES | VH_PLAN_NO_HPART) & ~(uint32_t)(VH_PLAN_FORCE_JIT | VH_PLAN_FORCE_HPART | VH_PLAN_FORCE_LANES);
-  p2.groups_hint = 0;
-  uint64_t cap = 1ull << 16;
-  while (cap < ranges * 8192ull && cap < (1ull << 30)) cap <<= 1;      // (a range holds ~500 groups when the keys are spread evenly; the loop below regrows)
-  int rc = VH_OK;
-  for (int attempt = 0; attempt < 6; ++attempt) {
-    vh_result* r2 = nullptr;
-    {
-      std::lock_guard<std::mutex> lk(t->mu);
-      g_heavy.only = r->plan.heavy_mark; g_heavy.ids_bound = 2 * tuples_bound + 1024; g_heavy.allow_mark = false;
-      rc = query_launch_locked(t, x2, &p2, &r2, cap, true, 0, false, false, nullptr, nullptr, false, 0, true);
-      g_heavy = VhHeavyCtx{};
-    }
-    if (rc) break;
-    r2->exec = x2;
+  std::lock_guard<std::mutex> lk(t->mu);
+  g_heavy.only = r->plan.heavy_mark; g_heavy.ids_bound = H.ids_bound; g_heavy.allow_mark = false;
+  g_heavy.tuples_of = H.from_tuples ? r : nullptr; g_heavy.epoch = r->launch_epoch;
+  const int rc = query_launch_locked(t, H.x2, &H.p2, &H.r2, H.cap, true, 0, false, false, nullptr, nullptr, false, 0, true);
+  g_heavy = VhHeavyCtx{};
+  if (rc) H.r2 = nullptr; else H.r2->exec = H.x2;
+  return rc;
+}
+static void heavy_pass_drop(vh_result* r, VhHeavyRun& H) {
+  if (H.r2) { H.r2->exec = nullptr; delete H.r2; H.r2 = nullptr; }
+  if (H.x2) { (void)hipStreamSynchronize(H.x2->stream()); exec_release(r->table, H.x2); H.x2 = nullptr; }
+  (void)hipGetLastError();
+}
+static void heavy_pass_launch(vh_result* r, const vh_plan* plan, uint64_t ranges, uint64_t tuples_bound, uint64_t whole_partitions, VhHeavyRun& H) {
+  H.from_tuples = ranges == whole_partitions * 256ull && !test_env("VH_HEAVY_RESCAN");      // (every marked range lies in a partition that was left out whole: its tuples are in pool a)
+  if (exec_acquire(r->table, &H.x2) != VH_OK) { H.x2 = nullptr; return; }
+  H.p2 = *plan;
+  H.p2.flags = (H.p2.flags | VH_PLAN_FORCE_HASH | VH_PLAN_NO_JIT | VH_PLAN_NO_FAST | VH_PLAN_NO_LANES | VH_PLAN_NO_HPART) & ~(uint32_t)(VH_PLAN_FORCE_JIT | VH_PLAN_FORCE_HPART | VH_PLAN_FORCE_LANES);
+  H.p2.groups_hint = 0;
+  H.cap = 1ull << 16;
+  while (H.cap < ranges * 8192ull && H.cap < (1ull << 30)) H.cap <<= 1;      // (a range holds ~500 groups when the keys are spread evenly; heavy_pass_finish regrows)
+  H.ids_bound = 2 * tuples_bound + 1024;
+  if (heavy_pass_enqueue(r, H)) heavy_pass_drop(r, H);
+}
+static void heavy_pass_finish(vh_result* r, VhHeavyRun& H) {
+  for (int attempt = 0; H.r2; ++attempt) {
     int retry2 = 0;
-    rc = result_finalize(r2, &retry2);
-    if (rc) { r2->exec = nullptr; delete r2; break; }
-    if (!retry2) { r2->stream_quiet = true; *out2 = r2; return VH_OK; }      // (the result owns the context from here)
-    r2->exec = nullptr; delete r2;
-    if (retry2 != 1) { rc = VH_OK; break; }                                  // anything but a full table: give up, the caller falls back
-    cap <<= 2;
+    const int rc = result_finalize(H.r2, &retry2);
+    if (!rc && !retry2) { H.r2->stream_quiet = true; H.x2 = nullptr; return; }      // (the result owns the context from here)
+    H.r2->exec = nullptr; delete H.r2; H.r2 = nullptr;
+    if (rc || retry2 != 1 || attempt >= 5) break;                               // anything but a full table: give up, the caller falls back
+    H.cap <<= 2;
+    if (heavy_pass_enqueue(r, H)) break;
   }
-  (void)hipStreamSynchronize(x2->stream());
-  exec_release(t, x2);
-  if (rc) { (void)hipGetLastError(); }
-  return VH_OK;
+  heavy_pass_drop(r, H);
 }
 
 // returns VH_OK, or a positive "retry" request: 1 = grow hash table, 2 = fall back to hash
@@ -247,14 +254,25 @@ static int result_finalize(vh_result* r, int* retry, const vh_plan* plan) {
   // organisation and are appended behind the rows the ranges' kernel wrote
   std::unique_ptr<vh_result> heavy;
   uint64_t n2 = 0;
-  if (r->hpart && P.heavy_mark && hc[11]) {
-    vh_result* r2 = nullptr;
-    if (plan) { if (int hrc = heavy_second_pass(r, plan, hc[11], hc[12], &r2)) return hrc; }
-    if (!r2 || (one_shot && ng + r2->ngroups_host > r->out_cap)) { delete r2; *retry = 4; r->plan.hp_passes = 64; return VH_OK; }      // (no second pass to be had: the plain table for everything, as before)
-    heavy.reset(r2);
-    n2 = r2->ngroups_host;
+  VhHeavyRun HR;
+  struct HeavyGuard { vh_result* r; VhHeavyRun& H; ~HeavyGuard() { if (H.x2) heavy_pass_drop(r, H); } } heavy_guard{r, HR};      // (an early return leaves no context behind)
+  const bool heavy_wanted = r->hpart && P.heavy_mark && hc[11];
+  // a big result in one piece: its rows cross PCIe WHILE the pass scans — the staging buffer then has room for the rows the pass can add at most
+  // (a group per tuple of the marked ranges); beyond a quarter of a gigabyte of such slack the pass is waited for first
+  uint64_t row_bytes = 0;
+  for (int i = 0; i < P.ngroup; ++i) row_bytes += vh_elem_size(P.g[i].type());
+  for (int j = 0; j < P.nmetric; ++j) row_bytes += vh_elem_size(r->metric_elem[j]);
+  const bool overlap = heavy_wanted && plan && !one_shot && !r->hp_chunks && hc[12] * row_bytes <= (256ull << 20) && !test_env("VH_NO_HEAVY_OVERLAP");
+  if (heavy_wanted && plan && !overlap) heavy_pass_launch(r, plan, hc[11], hc[12], hc[13], HR);
+  auto heavy_join = [&]() -> bool {             // false: no second pass to be had — the plain table for everything, as before
+    heavy_pass_finish(r, HR);
+    if (!HR.r2 || (one_shot && ng + HR.r2->ngroups_host > r->out_cap)) { delete HR.r2; HR.r2 = nullptr; *retry = 4; r->plan.hp_passes = 64; return false; }
+    heavy.reset(HR.r2);
+    n2 = HR.r2->ngroups_host;
     r->info.retries += 1;       // (counted like an attempt: the caller sees that the query took more than one pass)
-  }
+    if (r->kernel.find(HR.r2->kernel) == std::string::npos) r->kernel += " + " + HR.r2->kernel;      // (vh_result_kernel: what the second pass ran)
+    return true;
+  };
   auto append_heavy = [&](const size_t* key_off, const size_t* state_off) {      // the second pass's rows behind row ng of this result's host columns
     char* H = x->h_out[slot];
     for (int i = 0; i < P.ngroup; ++i) { const size_t es = vh_elem_size(P.g[i].type()); memcpy(H + key_off[i] + ng * es, heavy->h_base + heavy->off_key[i], n2 * es); }
@@ -262,17 +280,35 @@ static int result_finalize(vh_result* r, int* retry, const vh_plan* plan) {
   };
   if (!one_shot) {
     if (!r->hp_chunks) {           // a big result in one piece: the staging buffer is sized for the rows there are
-      L = packed_for(ng + n2);
+      if (heavy_wanted && !overlap) { if (!heavy_join()) return VH_OK; }
+      L = packed_for(ng + (overlap ? hc[12] : n2));
       if (int src = stage(L.bytes)) return src;
+      // (the pass is enqueued BEFORE the copy's kernel: its clears and its scan are under way when the 64 blocks that push rows over PCIe start)
+      const auto h0 = std::chrono::steady_clock::now();
+      if (overlap) heavy_pass_launch(r, plan, hc[11], hc[12], hc[13], HR);
       if (ng) { if (int crc = copy_rows(L, 0, 0, ng, r->topk_active, st)) return crc; }
       HIP_TRY(hipEventRecord(x->ev[3], st));
+      if (overlap) {
+        const bool joined = heavy_join();
+        const auto h1 = std::chrono::steady_clock::now();
+        if (!joined) { (void)wait_event_spinning(x->ev[3]); return VH_OK; }
+        HIP_TRY(wait_event_spinning(x->ev[3]));
+        if (knobs().times) {
+          const auto ms = [](auto a, auto b) { return (double)std::chrono::duration_cast<std::chrono::microseconds>(b - a).count() / 1e3; };
+          fprintf(stderr, "vh heavy pass: done %.3f ms after its launch, the copy of the first pass's rows %.3f ms after that (ranges %llu, tuples <= %llu, rows %llu)\n", ms(h0, h1),
+                  ms(h1, std::chrono::steady_clock::now()), hc[11], hc[12], (unsigned long long)n2);
+        }
+      }
       HIP_TRY(wait_event_spinning(x->ev[3]));
       if (n2) append_heavy(L.key, L.state);
-    }
+    } else if (heavy_wanted) { if (!heavy_join()) return VH_OK; }
     memcpy(x->h_out[slot], head, 512);
     for (int i = 0; i < P.ngroup; ++i) r->off_key[i] = L.key[i];      // (the host view: where vh_result_view finds the columns)
     for (int j = 0; j < P.nmetric; ++j) r->off_state[j] = L.state[j];
-  } else if (n2) append_heavy(r->off_key, r->off_state);
+  } else if (heavy_wanted) {
+    if (!heavy_join()) return VH_OK;
+    if (n2) append_heavy(r->off_key, r->off_state);
+  }
   if (n2) { ng += n2; r->info.ngroups += n2; r->info.returned_groups = ng; r->ngroups_host = ng; }
   heavy.reset();
   r->h_base = x->h_out[slot];

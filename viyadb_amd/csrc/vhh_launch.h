@@ -244,6 +244,11 @@ int QueryBuild::decompose_work() {
   P.total_units = nseg * P.units_per_seg;
   const int env_grid = knobs().grid;
   grid = env_grid > 0 ? env_grid : (int)std::max<uint64_t>(1, std::min<uint64_t>(P.total_units, (uint64_t)g_ctx.num_cu * blocks_per_cu));
+  // The second pass over heavy ranges runs WHILE the first pass's rows cross PCIe (result_finalize): the 64 blocks that push them take wave slots
+  // on 64 CUs, and a grid that fills the chip exactly then leaves some of its blocks waiting for a whole other block's share (measured: the pass
+  // 8.3 -> 10.7-14.7 ms). Eight times the blocks, an eighth of the units each: the dispatcher hands them out as slots come free (9.0-11.9 ms; what is left is the PCIe traffic's
+  // own cost to everything that is dispatched beside it).
+  if (g_heavy.only && env_grid <= 0) grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(P.total_units, (uint64_t)g_ctx.num_cu * blocks_per_cu * 8));
   return VH_OK;
 }
 
@@ -580,6 +585,7 @@ int QueryBuild::launch() {
       clear(meta, hp_meta_bytes, 0);
     }
     d_hpargs = reinterpret_cast<VhHpArgs*>(S + o_hpargs);
+    r->d_hp_args = d_hpargs; r->hp_scan_blocks = grid;
     HIP_TRY(hipMemcpyAsync(d_hpargs, &HA, sizeof(HA), hipMemcpyHostToDevice, st));
   }
   if (part_balanced) clear(P.part_count, VH_MAX_PART * VH_PART_COUNT_WAYS * sizeof(uint32_t), 0);
@@ -612,7 +618,31 @@ int QueryBuild::launch() {
   r->hpart = hpart;
   r->info.reserved = (hpart ? 64 : 0) | (fastj || jk ? 1 : 0) | (lanes ? 2 : 0) | (P.lds_hash_slots ? 4 : 0) | (packed ? 8 : 0) | (fastj && narrowed ? 16 : 0) | (jk ? 32 : 0) | (packed && packed_compressed ? 128 : 0) | (hpart && hp_pack ? 256 : 0) | (mode == VH_MODE_DENSE_PART && P.gid_bits ? 1024 : 0) | (jk && (jshape.pp_nplanes || jshape.pp_sliced) ? 2048 : 0) | (jk && jshape.qpay ? 4096 : 0) | (jk && jshape.pp_sliced ? 8192 : 0);
   if (r->hp_chunks) memset(x->h_chunk, 0, VH_HP_CHUNKS * sizeof(unsigned long long));      // (what the context's previous query left there)
-  if (P.total_units) {
+  // a second pass over heavy level-A partitions of a hashed partitioning: from the first pass's tuples when this plan's table can take them as
+  // they are (one key word laid out as the first pass's, narrow ids) — else from the table's rows behind the bitmap, like any heavy range
+  bool from_tuples = false;
+  if (const vh_result* m = g_heavy.only ? g_heavy.tuples_of : nullptr) {
+    const VhPlanDev& M = m->plan;
+    from_tuples = mode == VH_MODE_HASH && !hpart && !jk && P.key_words == 1 && M.key_words == 1 && P.ngroup == M.ngroup && P.nmetric == M.nmetric && P.nbitset <= 1 && m->d_hp_args;
+    for (int i = 0; i < P.ngroup && from_tuples; ++i) from_tuples = P.g[i].key_shift() == M.g[i].key_shift() && P.g[i].key_word() == M.g[i].key_word();
+    for (int b = 0; b < P.nbitset && from_tuples; ++b) from_tuples = !P.bs_wide[b];
+    if (from_tuples) {
+      VhHeavyTuples HT{};
+      HT.HA = m->d_hp_args; HT.src_blocks = (uint32_t)m->hp_scan_blocks;
+      HT.units = m->hp_args.units; HT.pk = m->hp_args.pk; HT.pbits = m->hp_args.pk_pbits; HT.idbits = m->hp_args.pk_idbits;
+      HT.nmetric = P.nmetric; HT.bitset_j = -1;
+      for (int j = 0; j < P.nmetric; ++j) {
+        if (P.m[j].sop() == SOP_BITSET) HT.bitset_j = j;
+        from_tuples = from_tuples && (P.m[j].sop() == SOP_BITSET) == (M.m[j].sop() == SOP_BITSET);
+        HT.tshift[j] = (uint8_t)M.m[j].tshift(); HT.tbits[j] = M.m[j].tbits; HT.tbytes[j] = (uint8_t)vh_sop_bytes(M.m[j].sop()); HT.tsext[j] = vh_sop_sext(M.m[j].sop()) ? 1 : 0;
+      }
+      if (from_tuples) { vh_launch_heavy_tuples(P, HT, g_ctx.num_cu, st); r->kernel = HT.units == 2 ? "hp_heavy_tuples_kernel<2, false>" : HT.pk ? "hp_heavy_tuples_kernel<1, true>" : "hp_heavy_tuples_kernel<1, false>"; }
+    }
+  }
+  if (g_heavy.only && !from_tuples && g_heavy.epoch != t->sync_epoch)       // the table has moved on since the first pass: its rows are no longer the rows that pass saw
+    return vh_fail(VH_E_RANGE, "second pass over heavy ranges: the table changed since the first pass");      // (heavy_pass_finish gives up; the caller re-plans the whole query)
+  if (from_tuples) {
+  } else if (P.total_units) {
     scan_dispatch(grid, nullptr);
     if (hpart) {
       vh_launch_hpart(P, d_hpargs, hp_units, g_ctx.num_cu, grid, hp_ring_nb, st);

@@ -176,7 +176,9 @@ struct VhAgreed {
 // Heavy ranges of the hashed partitioning (VhPlanDev::heavy_mark / heavy_only), per calling thread: vh_query_agg lets its plans mark heavy ranges
 // (it can run the second pass: it holds the caller's plan when the verdict is in); the second pass itself plans with `only` = the first pass's bitmap
 // and sizes its (group, id) set for the ids those ranges can hold. Everything else (split launch / finalize, sharded queries) plans without either.
-struct VhHeavyCtx { bool allow_mark = false; const uint32_t* only = nullptr; uint64_t ids_bound = 0; };
+// `tuples_of`: every marked range belongs to a level-A partition that hp_plan_kernel left out whole — the second pass then reads that partition's
+// tuples out of the first pass's pool a (hp_heavy_tuples_kernel) instead of scanning the table for its rows.
+struct VhHeavyCtx { bool allow_mark = false; const uint32_t* only = nullptr; uint64_t ids_bound = 0; const vh_result* tuples_of = nullptr; uint64_t epoch = 0; };
 static thread_local VhHeavyCtx g_heavy;
 
 // One aggregate query on its way to the device. query_launch_locked() runs the steps in order; each step reads what the earlier
@@ -310,7 +312,7 @@ int QueryBuild::shape_filter() {
   if (nseg > t->nseg) return vh_fail(VH_E_INVALID, "plan snapshots %u segments, table mirrors %u", nseg, t->nseg);
   ncols = (int)t->cols.size();
 
-  r->table = t;
+  r->table = t; r->launch_epoch = t->sync_epoch;
   memset(&P, 0, sizeof(P));
 
   // ---------------- column slots

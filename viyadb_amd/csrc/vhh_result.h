@@ -73,7 +73,10 @@ struct vh_result {
   uint64_t hp_chunk_rows = 0;
   bool hp_one_launch = false;       // ... regions only: ONE launch of the aggregation, the regions' rows packed behind it (no overlap of copies and kernels)
   VhHpArgs hp_args;                 // ... and the pool descriptors its kernels were given
+  VhHpArgs* d_hp_args = nullptr;    // ... where they lie on the device; hp_scan_blocks: the scan blocks that wrote level A (a second pass over heavy partitions reads pool a: vhh_finalize.h)
+  int hp_scan_blocks = 0;
   vh_table* table = nullptr;
+  uint64_t launch_epoch = 0;        // the table's sync_epoch when the query was planned (a second pass over the table's rows must see the same rows)
   vh_result_info info{};
   int mode = 0;
   bool finalized = false;
