@@ -219,6 +219,28 @@ def test_phase_2_blocks_follow_the_partitions_tuple_counts(monkeypatch):
         dt.close()
 
 
+def test_four_byte_tuples_through_two_levels(monkeypatch):
+    """More than 64 LDS-sized ranges (VH_PART_TABLE_KB shrinks them: C3's 100 K groups in ~200 ranges, four level-1 partitions): the four-byte tuple
+    carries the gid RELATIVE to its level-1 partition, the second split moves four-byte words through the ring writer (part_split_ring_kernel<256, 4>)
+    and the compiled phase 2 adds the range's place inside the partition. Same groups as with the 8-byte tuple (VH_NO_TUPLE4_TWO) and the oracle's,
+    uniform and Zipf-like keys, and with every tuple of both levels through the overflow regions."""
+    if JIT_OFF:
+        pytest.skip("packed tuples need the compiled kernels")
+    monkeypatch.setenv("VH_PART_TABLE_KB", "8")
+    for wl in ("C3", "C3z"):
+        w = synth.WORKLOADS[wl](segment_rows=150_000)
+        res, st = check_workload(w, nseg=8, flags=FORCE_PART | capi.PLAN_FORCE_JIT)
+        assert res.path == "dense_part" and res.retries == 0 and "part_split_ring_kernel<256, 4>" in res.kernel, (res.path, res.retries, res.kernel)
+        monkeypatch.setenv("VH_NO_TUPLE4_TWO", "1")
+        res8, _ = check_workload(w, nseg=8, flags=FORCE_PART | capi.PLAN_FORCE_JIT)
+        monkeypatch.delenv("VH_NO_TUPLE4_TWO")
+        assert "part_split_ring_kernel<256, 8>" in res8.kernel, res8.kernel
+        monkeypatch.setenv("VH_TEST_POS_LEVELS", "0")
+        res, st = check_workload(w, nseg=8, flags=FORCE_PART | capi.PLAN_FORCE_JIT)
+        monkeypatch.delenv("VH_TEST_POS_LEVELS")
+        assert "part_split_ring_kernel<256, 4>" in res.kernel
+
+
 def test_four_byte_tuples(monkeypatch):
     """C3's gid (17 bits) and values (10 + 2 bits) fit 32 bits: DENSE_PART's tuple is four bytes — thirty-two to a 128-byte line through the ring
     writer, read back as 32-bit words by the compiled phase 2. Same groups as with the 8-byte tuple (VH_NO_TUPLE4) and as the oracle's, uniform and

@@ -142,8 +142,9 @@ struct VhPlanDev {
   uint64_t ilits[VH_INLINE_LITS];
   // ---- fast path (all predicate columns 4 bytes wide, <= VH_MAX_PRED of them): their slots
   int32_t npred;
-  int32_t tuple4;             // DENSE_PART, one level, one-word tuples whose gid and values fit 32 bits together: the tuple is FOUR bytes (32 per 128-byte line;
-                              // C3: gid 17 + SUM value 10 + COUNT value 2 bits) — half the tuple bytes of phase 1 and phase 2 once more
+  int32_t tuple4;             // DENSE_PART, one-word tuples whose gid and values fit 32 bits together: the tuple is FOUR bytes (32 per 128-byte line;
+                              // C3: gid 17 + SUM value 10 + COUNT value 2 bits) — half the tuple bytes of phase 1 and phase 2 once more. With two levels the
+                              // gid field is RELATIVE to the level-1 partition (gid_bits = part_shift: 4 M groups in 8 partitions = 19 bits, not 22)
   int32_t gid_bits;           // DENSE_PART with ONE-word tuples: word 0 = gid in its low gid_bits | every metric value at m[j].tshift, m[j].tbits wide (0: two or more words, the gid in word 0's low half)
   uint8_t pred_slot[8];
   uint8_t pred_width[8];      // bytes per element the kernel reads for predicate column p: 4, or 1 / 2 when the table keeps a narrow copy (vh_table_narrow)

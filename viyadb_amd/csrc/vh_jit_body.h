@@ -374,7 +374,8 @@ __device__ __forceinline__ void vj_sink(const VhPlanDev& P, uint32_t seg, uint32
     // min / max (refresh_stats) — half the bytes to write in phase 1 and to read back in phase 2, sixteen tuples per 128-byte line. A value
     // that needs more bits than recorded voids the attempt (VH_ERR_HP_WIDE: the query is answered with direct atomics instead).
     static_assert(J::TW == 1, "one-word tuples");
-    uint64_t words[1] = {gid};
+    // (four-byte tuples of a two-level plan: the gid's bits below part_shift — GID_BITS = part_shift there, the level-1 partition is where the tuple lies)
+    uint64_t words[1] = {J::TUPLE4 ? gid & ((1ull << J::GID_BITS) - 1ull) : gid};
     bool wide = false;
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
@@ -754,6 +755,7 @@ __device__ __forceinline__ void vj_part_agg(const VhPlanDev& P, int blocks_per_p
   const uint64_t ng = g0 >= P.G ? 0 : (P.G - g0 < gpp ? P.G - g0 : gpp);
   __syncthreads();
   const bool two = P.nlevel == 2;
+  const uint64_t g0_rel = J::TUPLE4 && two ? (uint64_t)(part & 63) << P.agg_shift : g0;      // (four-byte tuples of two levels: gids relative to the level-1 partition)
   uint32_t first = 0, total;
   if (two) {
     const uint32_t lo = P.l2[part >> 6], hi = P.l2[(part >> 6) + 1], used = P.l2[VH_L2_NEXT + (part >> 6)];
@@ -777,7 +779,7 @@ __device__ __forceinline__ void vj_part_agg(const VhPlanDev& P, int blocks_per_p
     uint32_t ext = 0, valid = 0, at = 0;
     while (mine || at < valid) {
       if constexpr (J::TUPLE4) {
-        // FOUR-byte tuples (one level only): a slot is 256 tuples — one 16-byte load per lane, four tuples each (a line's worth of bytes per
+        // FOUR-byte tuples: a slot is 256 tuples — one 16-byte load per lane, four tuples each (a line's worth of bytes per
         // load instruction, as with the two-word tuples; one 4-byte load per lane read the pool at 1.1 TB/s). Extents hold a power of two of at
         // least 256 tuples and start on 128-byte lines: the loads are aligned and never leave the extent; places beyond `valid` are masked.
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -806,7 +808,7 @@ __device__ __forceinline__ void vj_part_agg(const VhPlanDev& P, int blocks_per_p
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             if ((uint32_t)lane * 4u + (uint32_t)k >= tn[u]) continue;
-            const uint64_t w0 = k == 0 ? t4[u].x : k == 1 ? t4[u].y : k == 2 ? t4[u].z : t4[u].w, local = (w0 & gid_mask) - g0;
+            const uint64_t w0 = k == 0 ? t4[u].x : k == 1 ? t4[u].y : k == 2 ? t4[u].z : t4[u].w, local = (w0 & gid_mask) - g0_rel;
             if (local >= ng) continue;          // (a corrupt tuple cannot write outside the table)
             if (!carried) reinterpret_cast<uint8_t*>(lds + P.lds_present_off)[local] = 1;
 #pragma unroll

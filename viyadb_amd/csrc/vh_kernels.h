@@ -2415,11 +2415,15 @@ struct VhSplitDest {
   __device__ __forceinline__ uint64_t extent(uint32_t d, uint32_t k) const { return k < kmax ? (uint64_t)lo + ((uint64_t)k * bpp + b) * 64u + d : ~0ull; }
 };
 #define VH_SPLIT_RING_LDS(block) VH_RING_LDS_BYTES(64, 2, block)
-template <int BLOCK, int TW>
+template <int TB> struct VhSplitTuple;      // the tuple as it lies in the pools: two words, one, or four bytes (VhPlanDev::tuple4)
+template <> struct VhSplitTuple<16> { typedef vh_u64x2 type; };
+template <> struct VhSplitTuple<8> { typedef uint64_t type; };
+template <> struct VhSplitTuple<4> { typedef uint32_t type; };
+template <int BLOCK, int TB>
 __global__ __launch_bounds__(BLOCK) void part_split_ring_kernel(const VhPlanDev P, int blocks_per_part) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  typedef typename VhStageTuple<TW>::type Tup;      // (the tuple: two words, or one)
-  constexpr int TB = TW * 8, UNR = 4, NW = BLOCK / 64;
+  typedef typename VhSplitTuple<TB>::type Tup;
+  constexpr int TW = TB == 16 ? 2 : 1, UNR = 4, NW = BLOCK / 64;
   const int part = blockIdx.x / blocks_per_part, b = blockIdx.x % blocks_per_part;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   VhRing F;
@@ -2456,6 +2460,7 @@ __global__ __launch_bounds__(BLOCK) void part_split_ring_kernel(const VhPlanDev 
           const bool ok = i0 + u * 64u + lane < valid;
           uint64_t w[TW];
           if constexpr (TW == 1) w[0] = t[u]; else { w[0] = t[u].x; w[1] = t[u].y; }
+          // (four-byte tuples carry the gid relative to the partition: its bits from agg_shift up are the sub-partition all the same)
           const uint32_t sub = ok ? ((uint32_t)((w[0] & gid_mask) >> gshift) >> P.agg_shift) & 63u : 0u;
           vh_ring_add_tb<TB, VhSplitDest, 64, 2, true>(F, pool2, et2, et2_shift, ok, w, sub, lane, D, P.counters + 2);
         }

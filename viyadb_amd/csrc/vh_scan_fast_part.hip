@@ -32,8 +32,9 @@ void vh_launch_part_split(const VhPlanDev& P, int blocks_per_part, bool ring, hi
   if (ring && (P.tw == 2 || (P.tw == 1 && P.gid_bits)) && P.ext_tuples2 == VH_SPLIT_TILE_TUPLES) {      // extents by position, no barriers (part_split_ring_kernel)
     hipLaunchKernelGGL((part_l2_count_kernel<256>), dim3(256), dim3(256), 0, s, P);
     hipLaunchKernelGGL((part_l2_plan_kernel<64>), dim3(1), dim3(64), 0, s, P, blocks_per_part, blocks_per_part);
-    if (P.tw == 1) hipLaunchKernelGGL((part_split_ring_kernel<256, 1>), dim3(P.npart * blocks_per_part), dim3(256), VH_SPLIT_RING_LDS(256), s, P, blocks_per_part);
-    else hipLaunchKernelGGL((part_split_ring_kernel<256, 2>), dim3(P.npart * blocks_per_part), dim3(256), VH_SPLIT_RING_LDS(256), s, P, blocks_per_part);
+    if (P.tw == 1 && P.tuple4) hipLaunchKernelGGL((part_split_ring_kernel<256, 4>), dim3(P.npart * blocks_per_part), dim3(256), VH_SPLIT_RING_LDS(256), s, P, blocks_per_part);
+    else if (P.tw == 1) hipLaunchKernelGGL((part_split_ring_kernel<256, 8>), dim3(P.npart * blocks_per_part), dim3(256), VH_SPLIT_RING_LDS(256), s, P, blocks_per_part);
+    else hipLaunchKernelGGL((part_split_ring_kernel<256, 16>), dim3(P.npart * blocks_per_part), dim3(256), VH_SPLIT_RING_LDS(256), s, P, blocks_per_part);
     return;
   }
   hipLaunchKernelGGL((part_l2_count_kernel<256>), dim3(256), dim3(256), 0, s, P);

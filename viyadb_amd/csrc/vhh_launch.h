@@ -211,7 +211,7 @@ int QueryBuild::decompose_work() {
       r->kernel += hn + jk->name + "_hpagg";
     }
     const std::string pagg = jit_pagg() ? " + " + jk->name + "_pagg" : std::string(" + part_agg_kernel<1024>");
-    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? pagg : (P.tw == 2 || P.gid_bits) ? (std::string(" + part_split_ring_kernel<256, ") + (P.gid_bits ? "1>" : "2>") + pagg) : " + part_split_kernel<256>" + pagg;
+    if (mode == VH_MODE_DENSE_PART) r->kernel += P.nlevel != 2 ? pagg : (P.tw == 2 || P.gid_bits) ? (std::string(" + part_split_ring_kernel<256, ") + (P.tuple4 ? "4>" : P.gid_bits ? "8>" : "16>") + pagg) : " + part_split_kernel<256>" + pagg;
   }
   int occupancy = 0;
   if (env_bpc <= 0) scan_dispatch(0, &occupancy);
@@ -405,7 +405,7 @@ int QueryBuild::layout_scratch() {
       if (max2 > 0xFFFFFFF0ull) max2 = 0xFFFFFFF0ull;
       if (!part_tuples_override && test_env("VH_TEST_PART_EXTENTS2")) max2 = std::max(1, atoi(test_env("VH_TEST_PART_EXTENTS2")));   // tests: the second pool runs out first
       P.max_extents2 = (uint32_t)max2;
-      o_tuples2 = sp.take(max2 * et2 * P.tw * 8);
+      o_tuples2 = sp.take(max2 * et2 * (P.tuple4 ? 4 : P.tw * 8));
       o_emiss2 = sp.take(max2 * sizeof(uint16_t));
       o_epart2 = sp.take(max2);
       o_l2 = sp.take((VH_L2_WORDS + VH_MAX_PART) * sizeof(uint32_t));

@@ -922,8 +922,10 @@ int QueryBuild::choose_organisation() {
         used += nt_mb[j];
       }
       narrow_tuples = fits && used <= 63;
-      // ... and FOUR bytes when they fit 32 bits (one level only: the second split moves 8-byte words)
-      tuple4 = narrow_tuples && used <= 32 && !two_level && !test_env("VH_NO_TUPLE4");
+      // ... and FOUR bytes when they fit 32 bits. With two levels the tuple carries the gid RELATIVE to its level-1 partition (the low part_shift
+      // bits: the partition is where the tuple lies) — 4 M groups in 8 partitions: 19 bits instead of 22, C3's values behind them: 31
+      tuple4 = narrow_tuples && (two_level ? used - nt_gb + shift + 6 : used) <= 32 && !test_env("VH_NO_TUPLE4") && !(two_level && test_env("VH_NO_TUPLE4_TWO"));
+      if (tuple4 && two_level) nt_gb = shift + 6;
     }
     if (want_part) {
       // most rows pass: build the tuples without compacting survivors first (lanes kernel, phase 1 only)
