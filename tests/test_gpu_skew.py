@@ -131,6 +131,62 @@ def test_heavy_second_pass_under_a_big_results_copy(monkeypatch):
         dt.close()
 
 
+def test_heavy_second_pass_from_several_threads():
+    """The second pass takes an execution context of its own while the query holds one: four threads on one table, each with its own result alive,
+    every answer the oracle's."""
+    if JIT_OFF:
+        pytest.skip("the ring writer and the hashed partitioning live in the compiled kernels (VH_JIT=off: the pre-built ones answer)")
+    import threading
+    from tests.parity import build_oracle_table, compare
+    from oracle import viya_oracle as vo
+    from viyadb_amd.executor import AggPlan
+    w = synth.c5h(segment_rows=80_000)
+    dt = synth.create_device_table(w, 4, 80_000)
+    errs = []
+    try:
+        want = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 4, 80_000), w.query), now=w.now)
+        plan = AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=HP | capi.PLAN_CARD32)
+        dt.query_agg(plan)
+
+        def loop(i):
+            try:
+                for _ in range(4):
+                    r = dt.query_agg(plan)
+                    compare(r, want, f"heavy ranges, thread {i}")
+                    assert r.hpart and r.retries == 1
+            except Exception as e:   # noqa: BLE001
+                errs.append(repr(e)[:500])
+        ths = [threading.Thread(target=loop, args=(i,)) for i in range(4)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+    finally:
+        dt.close()
+    assert not errs, errs
+
+
+def test_heavy_second_pass_without_a_spare_context():
+    """VH_MAX_EXEC=1 (a fresh process: the knob is read once): the query holds the table's only execution context, the second pass does not wait
+    for another — the whole query is planned again for the plain hash table and still answers with the oracle's rows."""
+    if JIT_OFF:
+        pytest.skip("the ring writer and the hashed partitioning live in the compiled kernels (VH_JIT=off: the pre-built ones answer)")
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from viyadb_amd import capi, executor, synth\n"
+        "executor.init(0)\n"
+        "from tests.parity import check_workload\n"
+        "res, st = check_workload(synth.c5h(segment_rows=80_000), nseg=4, flags=1 | capi.PLAN_FORCE_HPART | capi.PLAN_FORCE_JIT | capi.PLAN_CARD32)\n"
+        "assert res.path == 'hash' and not res.hpart and res.retries >= 1, (res.path, res.hpart, res.retries, res.kernel)\n"
+        "print('ok')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, VH_MAX_EXEC="1", VH_TEST_HOOKS="1"), cwd=root)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 @pytest.mark.parametrize("levels", ["0", "1"])
 def test_every_tuple_through_the_overflow_region(levels, monkeypatch):
     """VH_TEST_POS_LEVELS: the ring writer's streams get no (or one) positional extent, so phase 1 of DENSE_PART takes (nearly) all its extents

@@ -37,7 +37,7 @@ static void heavy_pass_drop(vh_result* r, VhHeavyRun& H) {
 }
 static void heavy_pass_launch(vh_result* r, const vh_plan* plan, uint64_t ranges, uint64_t tuples_bound, uint64_t whole_partitions, VhHeavyRun& H) {
   H.from_tuples = ranges == whole_partitions * 256ull && !test_env("VH_HEAVY_RESCAN");      // (every marked range lies in a partition that was left out whole: its tuples are in pool a)
-  if (exec_acquire(r->table, &H.x2) != VH_OK) { H.x2 = nullptr; return; }
+  if (exec_acquire(r->table, &H.x2, false) != VH_OK) { H.x2 = nullptr; return; }      // (never waits for a context while holding one: two such queries would wait for each other — the caller re-plans instead)
   H.p2 = *plan;
   H.p2.flags = (H.p2.flags | VH_PLAN_FORCE_HASH | VH_PLAN_NO_JIT | VH_PLAN_NO_FAST | VH_PLAN_NO_LANES | VH_PLAN_NO_HPART) & ~(uint32_t)(VH_PLAN_FORCE_JIT | VH_PLAN_FORCE_HPART | VH_PLAN_FORCE_LANES);
   H.p2.groups_hint = 0;

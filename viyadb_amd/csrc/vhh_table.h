@@ -218,12 +218,13 @@ static void exec_free(VhExec* x) {
 // (Round 2 timed partitioned plans on three contexts and kept the one whose scratch "landed best": the tuple pool's placement decided
 // 10 % of phase 1 when tuples left as partial lines. Whole-line tuple writes removed the sensitivity — eight processes, trials 1 vs 3:
 // 2.50-2.54 vs 2.42-2.53 ms, profiles/r03/NOTES.md — and with it the three scratch buffers per table.)
-static int exec_acquire(vh_table* t, VhExec** out) {
+static int exec_acquire(vh_table* t, VhExec** out, bool wait = true) {      // wait = false: a context that is free or can be made now, or VH_E_NOMEM at once (no message)
   const size_t max_exec = (size_t)knobs().max_exec;
   std::unique_lock<std::mutex> lk(t->pool_mu);
   for (;;) {
     for (auto& x : t->execs) if (!x->busy) { x->busy = true; *out = x.get(); return VH_OK; }
     if (t->execs.size() < max_exec) break;
+    if (!wait) return VH_E_NOMEM;
     if (t->pool_cv.wait_for(lk, std::chrono::seconds(60)) == std::cv_status::timeout)
       return vh_fail(VH_E_NOMEM, "all %zu execution contexts of this table are held by live vh_result / running queries (vh_result_free them)", max_exec);
   }
