@@ -455,7 +455,11 @@ def main():
             "unprepared": unprepared,
             "derived_layout": {"one_time_seconds": round(t_layout, 4),
                                # ... and the other first-use cost of the shape: the scan kernel's compile by hipRTC, or its load from the disk cache (vh_table_prepare)
+                               # (vh_table_prepare: the compile or load, up to three settling runs of the query, and a place for the derived layouts found by
+                               # measurement — up to VH_PREPARE_PLACE = 8 candidates, each a device-to-device copy of the layouts + three queries)
                                "kernel_compile_or_load_seconds": round(t_pack - t_layout, 4),
+                               "prepare_seconds": round(t_pack - t_layout, 4),
+                               "break_even_queries_with_prepare": (round(t_pack / max(1e-9, ref_layout[1] - elapsed / args.steps)) if ref_layout is not None and ref_layout[1] > elapsed / args.steps else None),
                                # queries of this shape after which building the derived layouts has paid for itself: one-time seconds / (what a query costs
                                # on the reference's layout - what it costs on the derived ones), both measured in this run
                                "break_even_queries": (round(t_layout / max(1e-9, ref_layout[1] - elapsed / args.steps)) if ref_layout is not None and ref_layout[1] > elapsed / args.steps else None), "extra_device_bytes": max(0, table.info()[2] - total_rows * w.table_bytes_per_row // max(1, world)),

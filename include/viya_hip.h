@@ -581,10 +581,17 @@ VH_API void vh_rows_free(vh_rows* r);
 /* Pays a plan shape's first-use costs NOW instead of on its first queries: compiles the scan kernel for the shape (the reference does
  * the same when a query shape is first seen: Compiler::Compile, src/codegen/compiler.cc:97-144, reported as QueryStats::compile_time), builds
  * the payload projection and narrow predicate copies a selective query would get after VH_AUTO_PACK / VH_AUTO_NARROW uses, and — here only —
- * may place a big tuple pool by measurement (bounded: half of the free device memory, 48 GB, 8 candidates; released before returning). Runs
- * the plan up to three times, discards the rows; *info (may be NULL) describes the last run: vh_result_info.reserved says what a
- * steady-state query of this shape runs on (compiled kernel, projection, narrow copies, placed pool). */
+ * finds the derived layouts a place by measurement: which physical pages a projection and its predicate planes were given decides up to 15 % of
+ * the scan that reads them (same bytes, same kernel: 1.07 or 1.23 ms per 1 B rows of C3), and nothing a process can read says which, so the
+ * layouts are copied to up to VH_PREPARE_PLACE (default 8, 0 = never) other allocations — both, the planes alone, the projections alone, in turn —,
+ * three queries each, and the fastest place is kept
+ * (the others are released before returning; skipped when the copies would not leave a quarter of the device free). Runs the plan up to
+ * three times before that, discards the rows; *info (may be NULL) describes the last run: vh_result_info.reserved says what a steady-state
+ * query of this shape runs on (compiled kernel, projection, narrow copies). */
 VH_API int vh_table_prepare(vh_table* t, const vh_plan* plan, vh_result_info* info);
+/* The derived layouts moved to fresh device memory (which: 1 projections, 2 predicate planes, 0 = both) — same contents, other pages; what
+ * vh_table_prepare does per candidate place, for callers that measure by themselves. */
+VH_API int vh_table_relocate(vh_table* t, uint32_t which);
 VH_API int vh_result_get_info(vh_result* r, vh_result_info* info);
 /* Symbol(s) of the scan kernel(s) this query launched, spelled as rocprofv3 prints them ("scan_agg_fast_kernel<4, 256, 4, 3> +
  * part_agg_kernel<1024>"): what a profile of the same command must show. Valid until vh_result_free. */

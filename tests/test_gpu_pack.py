@@ -147,6 +147,35 @@ def test_projection_follows_segment_syncs():
         dt.close()
 
 
+def test_derived_layouts_moved_to_other_memory():
+    """vh_table_relocate (what vh_table_prepare does per candidate place): projections and predicate planes copied to fresh allocations, pointers
+    swapped — the same groups before and after, for each kind and both, a sync after the move still lands in the moved layouts, and a prepare
+    (whose placement moves them again where the scan is long enough) changes nothing either."""
+    from viyadb_amd import synth
+    from viyadb_amd.executor import AggPlan
+    from tests.parity import build_oracle_table
+    w = synth.c3(segment_rows=250_000)
+    dt = synth.create_device_table(w, 4, 249_991)
+    try:
+        want = vo.scan_aggregate(vo.parse_query(build_oracle_table(w, 4, 249_991), w.query), now=getattr(w, "now", NOW))
+        plan = AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=64 | capi.PLAN_FORCE_JIT | PACK, groups_hint=w.plan.groups_hint)
+        dt.pack(dt.gather_columns(plan)); dt.predpack(dt.filter_columns(plan))
+        r = dt.query_agg(plan)
+        compare(r, want, "before the move")
+        assert r.packed and r.predpack
+        for which in (1, 2, 0, 2, 1):
+            dt.relocate(which)
+            r = dt.query_agg(plan)
+            compare(r, want, f"after relocate({which})")
+            assert r.packed and r.predpack
+        dt.generate(1, 1, 249_991, 249_991, [c.gen for c in w.columns], 42)      # (segment 1 written again with the same rows: the journalled ranges are re-derived into the MOVED layouts)
+        compare(dt.query_agg(plan), want, "after a sync behind the move")
+        dt.warm(plan)
+        compare(dt.query_agg(plan), want, "after vh_table_prepare")
+    finally:
+        dt.close()
+
+
 def test_library_builds_a_projection_for_a_repeated_selective_query():
     """VH_AUTO_PACK (default 3): the third selective query over the same payload columns gets a projection built for it."""
     from viyadb_amd import synth

@@ -159,6 +159,7 @@ SYMBOLS = {
     "vh_table_pack": (C.c_int, [_VP, C.POINTER(C.c_int32), C.c_int32]),
     "vh_table_pack_ex": (C.c_int, [_VP, C.POINTER(C.c_int32), C.c_int32, C.c_uint32]),
     "vh_table_unpack": (C.c_int, [_VP]),
+    "vh_table_relocate": (C.c_int, [_VP, C.c_uint32]),
     "vh_table_narrow": (C.c_int, [_VP, C.POINTER(C.c_int32), C.c_int32]),
     "vh_table_predpack": (C.c_int, [_VP, C.POINTER(C.c_int32), C.c_int32]),
     "vh_table_predpack_ex": (C.c_int, [_VP, C.POINTER(C.c_int32), C.c_int32, C.c_uint32]),

@@ -519,6 +519,67 @@ extern "C" int vh_table_pack_ex(vh_table* t, const int32_t* cols, int32_t ncols,
 }
 extern "C" int vh_table_pack(vh_table* t, const int32_t* cols, int32_t ncols) { return vh_table_pack_ex(t, cols, ncols, VH_PACK_AUTO); }
 
+// WHERE the derived layouts lie. The same records and planes read by the same kernel take 1.07 or 1.23 ms per 1 B rows depending on the physical
+// pages they were given (profiles/r06/NOTES.md, "Placement": six execution contexts with six scratch allocations agree within 0.5 %, the
+// projection alone moved twenty-three times changes nothing, projection AND planes re-built behind 3 GB spacers spread over 15 % — all at
+// 2 MB-aligned virtual addresses, so it is nothing a process can compute). What a process can do is try: derived_move copies every layout `which`
+// names (1: projections, 2: predicate planes) to FRESH allocations while the old ones are still held — so that the new ones are other pages —
+// and swaps the pointers (kernels take addresses as arguments); the caller measures and keeps or gives back (vh_table_prepare, vh_table_relocate).
+struct VhMoved { int kind; void* owner; int plane; char* old_ptr; char* new_ptr; size_t bytes; };      // kind 1: VhPack* owner, 2: VhPredPack* owner
+static size_t derived_bytes(const vh_table* t, uint32_t which) {
+  size_t b = 0;
+  if (which & 1u) for (auto& pk : t->packs) if (pk->base) b += (size_t)pk->cap_seg * pk->stride + 256;
+  if (which & 2u) for (auto& pp : t->predpacks) for (int q = 0; q < pp->nplanes; ++q) if (pp->pbase[q]) b += (size_t)pp->cap_seg * pp->pstride[q] + 256;
+  return b;
+}
+static int derived_move(vh_table* t, uint32_t which, std::vector<VhMoved>* moved) {      // (t->mu held)
+  table_quiesce(t);
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream)); derived_waited(t);
+  auto move = [&](int kind, void* owner, int plane, char*& base, size_t bytes, const char* what) -> int {
+    char* nb = nullptr;
+    if (hipMalloc(&nb, bytes) != hipSuccess) { (void)hipGetLastError(); return VH_E_NOMEM; }
+    trace_alloc(what, nb, bytes);
+    if (hipMemcpyAsync(nb, base, bytes, hipMemcpyDeviceToDevice, g_ctx.stream) != hipSuccess) { (void)hipFree(nb); return vh_fail(VH_E_DEVICE, "moving a derived layout"); }
+    moved->push_back(VhMoved{kind, owner, plane, base, nb, bytes});
+    base = nb;
+    return VH_OK;
+  };
+  int rc = VH_OK;
+  if (which & 1u) for (auto& pk : t->packs) if (pk->base && !rc) rc = move(1, pk.get(), 0, pk->base, (size_t)pk->cap_seg * pk->stride + 256, "projection");
+  if (which & 2u) for (auto& pp : t->predpacks) for (int q = 0; q < pp->nplanes && !rc; ++q) if (pp->pbase[q]) rc = move(2, pp.get(), q, pp->pbase[q], (size_t)pp->cap_seg * pp->pstride[q] + 256, "predicate plane");
+  HIP_TRY(hipStreamSynchronize(g_ctx.stream));
+  return rc == VH_E_NOMEM ? VH_OK : rc;          // (out of memory: what could be moved was moved)
+}
+// The buffers a move left behind (keep = true), or the ones it made after the layouts were pointed back at the old ones (keep = false), into
+// `out` — still allocated: whoever tries several places frees them all at the end, so that no candidate lands on a place already tried.
+static void derived_settle(vh_table* t, std::vector<VhMoved>& moved, bool keep, std::vector<char*>* out) {      // (t->mu held)
+  table_quiesce(t);
+  (void)hipStreamSynchronize(g_ctx.stream);
+  for (const VhMoved& m : moved) {
+    char** slot = nullptr;      // the layout may be gone by now (a sync voided it): then both buffers are somebody else's or nobody's — only ours is freed
+    if (m.kind == 1) { for (auto& pk : t->packs) if (pk.get() == m.owner && pk->base == m.new_ptr) slot = &pk->base; }
+    else { for (auto& pp : t->predpacks) if (pp.get() == m.owner && pp->pbase[m.plane] == m.new_ptr) slot = &pp->pbase[m.plane]; }
+    if (!slot) { out->push_back(m.old_ptr); continue; }      // (the layout was dropped or moved again with new_ptr freed by its owner: the old buffer is ours to free)
+    if (keep) out->push_back(m.old_ptr);
+    else { *slot = m.old_ptr; out->push_back(m.new_ptr); }
+  }
+  moved.clear();
+}
+extern "C" int vh_table_relocate(vh_table* t, uint32_t which) {
+  if (!t) return vh_fail(VH_E_INVALID, "null table");
+  VH_ENTER();
+  std::vector<char*> drop;
+  {
+    std::lock_guard<std::mutex> lk(t->mu);
+    if (int src = sync_resolve(t)) return src;
+    std::vector<VhMoved> moved;
+    if (int rc = derived_move(t, which ? which : 3u, &moved)) { derived_settle(t, moved, false, &drop); for (char* p : drop) (void)hipFree(p); return rc; }
+    derived_settle(t, moved, true, &drop);
+  }
+  for (char* p : drop) (void)hipFree(p);
+  return VH_OK;
+}
+
 extern "C" int vh_table_unpack(vh_table* t) {
   if (!t) return vh_fail(VH_E_INVALID, "null table");
   VH_ENTER();

@@ -72,7 +72,7 @@ static const char* test_env(const char* name) {
 }
 struct VhKnobs {
   bool trace_alloc, no_topk, jit_verbose, skip_phase2, no_direct_emit, times, no_jit_pagg, predpack_bytes;
-  int max_exec, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, bw_blocks_per_cu, hp_stream, hp_regions, hp_agg_waves, deliver_blocks;
+  int max_exec, prepare_place, auto_narrow, auto_pack, jit_ablate, hp_ablate, hp_bpp, pack_plain, lanes_block, blocks_per_cu, unit_rows, grid, ext_tuples, ext_pad, bw_blocks_per_cu, hp_stream, hp_regions, hp_agg_waves, deliver_blocks;
   double hp_load_g, hp_load_s, qpay_min_sel;
 };
 static const VhKnobs& knobs() {
@@ -83,6 +83,7 @@ static const VhKnobs& knobs() {
     VhKnobs x{};
     x.trace_alloc = flag("VH_TRACE_ALLOC"); x.jit_verbose = flag("VH_JIT_VERBOSE"); x.times = flag("VH_TIMES");
     x.max_exec = std::max(1, num("VH_MAX_EXEC", 16));
+    x.prepare_place = std::max(0, num("VH_PREPARE_PLACE", 8));      // other places vh_table_prepare tries for the derived layouts a plan reads (0: none)
     x.auto_narrow = num("VH_AUTO_NARROW", 3); x.auto_pack = num("VH_AUTO_PACK", 3);
     x.hp_stream = num("VH_HP_STREAM", 0);             // chunk launches of a streamed result (0: off — measured: the link, not the wait for the kernels, bounds the delivery; profiles/r04/NOTES.md)
     x.qpay_min_sel = real("VH_QPAY_MIN_SEL", 0.15);        // selectivity from which the compiled scan streams 4-byte payload records instead of gathering them (measured: profiles/r05/NOTES.md)

@@ -200,6 +200,10 @@ class DeviceTable:
     def unpack(self) -> None:
         capi.check(self.lib.vh_table_unpack(self.handle))
 
+    def relocate(self, which: int = 0) -> None:
+        """vh_table_relocate: the derived layouts (1 projections, 2 predicate planes, 0 both) copied to fresh device memory."""
+        capi.check(self.lib.vh_table_relocate(self.handle, which))
+
     def narrow(self, cols) -> None:
         """Keep 8- / 16-bit copies of the unsigned 32-bit columns among `cols` whose values fit (vh_table_narrow): what the
         register-resident kernels stream when a query filters on them."""
@@ -235,8 +239,8 @@ class DeviceTable:
         return plan
 
     def warm(self, plan: AggPlan) -> int:
-        """vh_table_prepare: pay the plan shape's first-use costs now (kernel compile, projection, narrow copies, a measured place for a big
-        tuple pool). Returns vh_result_info.reserved of the last run: what steady-state queries of this shape run on."""
+        """vh_table_prepare: pay the plan shape's first-use costs now (kernel compile, projection, narrow copies, a measured place for the
+        derived layouts). Returns vh_result_info.reserved of the last run: what steady-state queries of this shape run on."""
         p, keep = self._build_plan(plan)
         info = capi.ResultInfo()
         capi.check(self.lib.vh_table_prepare(self.handle, C.byref(p), C.byref(info)))
