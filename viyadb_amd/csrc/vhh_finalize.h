@@ -475,12 +475,14 @@ static int query_agg_multipass(vh_table* t, const vh_plan* plan, vh_result** out
   return VH_OK;
 }
 
+static int place_layouts(vh_table* t, const vh_plan* plan, vh_result_info* info_out);
+static bool placing_now();
 extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
   if (!t || !plan || !out) return vh_fail(VH_E_INVALID, "null argument");
   VH_ENTER();
   if (plan->nmetrics > VH_MAX_METRIC - 1 && plan->metrics) return query_agg_multipass(t, plan, out);
   VhExec* x = nullptr;
-  if (int rc = exec_acquire(t, &x)) return rc;
+  if (int rc = exec_acquire(t, &x, !placing_now())) return rc;      // (a placement's own queries never wait for a context: its caller may hold the last one — no placement then)
   VhReplan rp;
   int rc = VH_OK;
   for (uint32_t attempt = 0; attempt < 12; ++attempt) {
@@ -507,6 +509,13 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
       r->stream_quiet = true;                                  // (result_finalize waited for everything it enqueued)
       if (r->mode == VH_MODE_HASH) { std::lock_guard<std::mutex> lk(t->mu); t->groups_seen[r->group_sig] = r->info.ngroups; }
       *out = r;
+      // derived layouts that were built without a vh_table_prepare behind them (by the library after VH_AUTO_PACK / VH_AUTO_NARROW uses, or by
+      // the caller) and are now read by a scan long enough to care: this query finds them a place (place_layouts; once per build)
+      if (t->place_pending && !g_preparing && !placing_now() && (r->info.reserved & (8u | 2048u)) && r->info.scan_kernel_ms >= 0.3f && knobs().prepare_place > 0) {
+        bool mine = false;
+        { std::lock_guard<std::mutex> lk(t->mu); mine = t->place_pending; t->place_pending = false; }
+        if (mine) (void)place_layouts(t, plan, nullptr);      // (a failure leaves the layouts where they were; the result at hand is complete either way)
+      }
       return VH_OK;
     }
     replan_after(t, r, retry, &rp);
@@ -519,28 +528,15 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
   return rc;
 }
 
-// First-use costs paid up front (VERDICT r03 #8): the scan kernel compiled for the plan's shape (1-2 s of hipRTC, or milliseconds from the disk
-// cache), the payload projection and the narrow predicate copies a selective query reads (built at once instead of after VH_AUTO_PACK /
-// VH_AUTO_NARROW uses). (Rounds 3-5 also searched for a good place for a big tuple pool here; see vhh_place.h for why that is gone.) The reference's analogue is Compiler::Compile running when a
-// query shape is first seen (src/codegen/compiler.cc:97-144, QueryStats::compile_time); a caller that knows its hot shapes at table-load
-// time runs them through here. The plan is executed (up to three times: a narrow copy, then a projection can appear) and
-// the last attempt's info is returned, so the caller sees what a steady-state query of this shape will run on.
-extern "C" int vh_table_prepare(vh_table* t, const vh_plan* plan, vh_result_info* info_out) {
-  if (!t || !plan) return vh_fail(VH_E_INVALID, "null argument");
-  struct Guard { Guard() { g_preparing = true; } ~Guard() { g_preparing = false; } } guard;
-  uint32_t last = ~0u;
-  for (int round = 0; round < 3; ++round) {
-    vh_result* r = nullptr;
-    if (int rc = vh_query_agg(t, plan, &r)) return rc;
-    const uint32_t now = r->info.reserved;
-    if (info_out) *info_out = r->info;
-    vh_result_free(r);
-    if (now == last) break;
-    last = now;
-  }
-  // ... and a place for the derived layouts the plan reads (vhh_derived.h, derived_move): up to `prepare_place` other places tried, each measured
-  // with three queries, the fastest kept. Only where it can matter (a scan of 0.3 ms and more through a projection or predicate planes) and
-  // while the candidates fit the free device memory next to a quarter of the device.
+// A place for the derived layouts a plan reads (vhh_derived.h, derived_move): up to `prepare_place` other places tried, each measured with three
+// queries, the fastest kept. Only where it can matter (a scan of 0.3 ms and more through a projection or predicate planes) and while the
+// candidates fit the free device memory next to a quarter of the device. Called by vh_table_prepare, and by vh_query_agg ONCE for layouts the
+// library (or the caller) built without a prepare behind them (vh_table::place_pending): the query that finds them in use pays the 0.06 s.
+static thread_local bool g_placing = false;
+static bool placing_now() { return g_placing; }
+static int place_layouts(vh_table* t, const vh_plan* plan, vh_result_info* info_out) {
+  struct Guard { Guard() { g_placing = true; } ~Guard() { g_placing = false; } } guard;
+  { std::lock_guard<std::mutex> lk(t->mu); t->place_pending = false; }
   const int cand = knobs().prepare_place;
   auto measure = [&](float* ms) -> int {
     *ms = 1e30f;
@@ -553,7 +549,7 @@ extern "C" int vh_table_prepare(vh_table* t, const vh_plan* plan, vh_result_info
     }
     return VH_OK;
   };
-  if (cand > 0 && (last & (8u | 2048u))) {
+  if (cand > 0) {
     float best = 0;
     if (int rc = measure(&best)) return rc;
     std::vector<char*> held;
@@ -586,6 +582,29 @@ extern "C" int vh_table_prepare(vh_table* t, const vh_plan* plan, vh_result_info
       for (char* p : held) (void)hipFree(p);
     }
   }
+  return VH_OK;
+}
+
+// First-use costs paid up front (VERDICT r03 #8): the scan kernel compiled for the plan's shape (1-2 s of hipRTC, or milliseconds from the disk
+// cache), the payload projection and the narrow predicate copies a selective query reads (built at once instead of after VH_AUTO_PACK /
+// VH_AUTO_NARROW uses). (Rounds 3-5 also searched for a good place for a big tuple pool here; see vhh_place.h for why that is gone.) The reference's analogue is Compiler::Compile running when a
+// query shape is first seen (src/codegen/compiler.cc:97-144, QueryStats::compile_time); a caller that knows its hot shapes at table-load
+// time runs them through here. The plan is executed (up to three times: a narrow copy, then a projection can appear) and
+// the last attempt's info is returned, so the caller sees what a steady-state query of this shape will run on.
+extern "C" int vh_table_prepare(vh_table* t, const vh_plan* plan, vh_result_info* info_out) {
+  if (!t || !plan) return vh_fail(VH_E_INVALID, "null argument");
+  struct Guard { Guard() { g_preparing = true; } ~Guard() { g_preparing = false; } } guard;
+  uint32_t last = ~0u;
+  for (int round = 0; round < 3; ++round) {
+    vh_result* r = nullptr;
+    if (int rc = vh_query_agg(t, plan, &r)) return rc;
+    const uint32_t now = r->info.reserved;
+    if (info_out) *info_out = r->info;
+    vh_result_free(r);
+    if (now == last) break;
+    last = now;
+  }
+  if (last & (8u | 2048u)) return place_layouts(t, plan, info_out);
   return VH_OK;
 }
 
