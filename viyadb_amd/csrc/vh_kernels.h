@@ -2450,6 +2450,27 @@ __global__ __launch_bounds__(BLOCK) void part_split_ring_kernel(const VhPlanDev 
       mine &= mine - 1;
       const uint32_t ext = c0 + (uint32_t)q, valid = (uint32_t)__builtin_amdgcn_readlane((int)fill, q);
       const Tup* base = reinterpret_cast<const Tup*>(Q.t1) + (uint64_t)ext * ext_stride1;
+      if constexpr (TB == 4) {
+        // four-byte tuples: one 16-byte load per lane, four tuples each (a 4-byte load per lane reads a pool at 1.1 TB/s: what phase 2 found out
+        // the same way). Extents start on 128-byte lines and hold a multiple of 32 tuples: the loads are aligned and stay inside the extent.
+        for (uint32_t i0 = 0; i0 < valid; i0 += 256u * 2u) {
+          vh_u32x4 v[2];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) if (i0 + u * 256u + (uint32_t)lane * 4u < valid) v[u] = __builtin_nontemporal_load(reinterpret_cast<const vh_u32x4*>(base + i0 + u * 256u) + lane);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (i0 + u * 256u >= valid) break;                                   // (wave-uniform)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const bool ok = i0 + u * 256u + (uint32_t)lane * 4u + (uint32_t)k < valid;
+              uint64_t w[1] = {k == 0 ? v[u].x : k == 1 ? v[u].y : k == 2 ? v[u].z : v[u].w};
+              const uint32_t sub = ok ? ((uint32_t)((w[0] & gid_mask) >> gshift) >> P.agg_shift) & 63u : 0u;
+              vh_ring_add_tb<TB, VhSplitDest, 64, 2, true>(F, pool2, et2, et2_shift, ok, w, sub, lane, D, P.counters + 2);
+            }
+          }
+        }
+        continue;
+      }
       for (uint32_t i0 = 0; i0 < valid; i0 += 64u * UNR) {
         Tup t[UNR];
 #pragma unroll
