@@ -584,10 +584,12 @@ VH_API void vh_rows_free(vh_rows* r);
  * finds the derived layouts a place by measurement: which physical pages a projection and its predicate planes were given decides up to 15 % of
  * the scan that reads them (same bytes, same kernel: 1.07 or 1.23 ms per 1 B rows of C3), and nothing a process can read says which, so the
  * layouts are copied to up to VH_PREPARE_PLACE (default 8, 0 = never) other allocations — both, the planes alone, the projections alone, in turn —,
- * three queries each, and the fastest place is kept
+ * three queries each, about a second at most, and the fastest place is kept
  * (the others are released before returning; skipped when the copies would not leave a quarter of the device free). Runs the plan up to
  * three times before that, discards the rows; *info (may be NULL) describes the last run: vh_result_info.reserved says what a steady-state
- * query of this shape runs on (compiled kernel, projection, narrow copies). */
+ * query of this shape runs on (compiled kernel, projection, narrow copies). Layouts that were built without a vh_table_prepare behind them
+ * (by the library after VH_AUTO_PACK / VH_AUTO_NARROW uses, or by vh_table_pack / _predpack alone) get the same search — bounded to 0.3 s — from
+ * the first vh_query_agg whose scan of 0.3 ms and more reads them, after that query's own result is complete. */
 VH_API int vh_table_prepare(vh_table* t, const vh_plan* plan, vh_result_info* info);
 /* The derived layouts moved to fresh device memory (which: 1 projections, 2 predicate planes, 0 = both) — same contents, other pages; what
  * vh_table_prepare does per candidate place, for callers that measure by themselves. */

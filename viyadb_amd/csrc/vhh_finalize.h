@@ -475,7 +475,7 @@ static int query_agg_multipass(vh_table* t, const vh_plan* plan, vh_result** out
   return VH_OK;
 }
 
-static int place_layouts(vh_table* t, const vh_plan* plan, vh_result_info* info_out);
+static int place_layouts(vh_table* t, const vh_plan* plan, vh_result_info* info_out, double budget_ms);
 static bool placing_now();
 extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
   if (!t || !plan || !out) return vh_fail(VH_E_INVALID, "null argument");
@@ -514,7 +514,7 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
       if (t->place_pending && !g_preparing && !placing_now() && (r->info.reserved & (8u | 2048u)) && r->info.scan_kernel_ms >= 0.3f && knobs().prepare_place > 0) {
         bool mine = false;
         { std::lock_guard<std::mutex> lk(t->mu); mine = t->place_pending; t->place_pending = false; }
-        if (mine) (void)place_layouts(t, plan, nullptr);      // (a failure leaves the layouts where they were; the result at hand is complete either way)
+        if (mine) (void)place_layouts(t, plan, nullptr, 300.0);      // (a failure leaves the layouts where they were; the result at hand is complete either way)
       }
       return VH_OK;
     }
@@ -531,10 +531,12 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
 // A place for the derived layouts a plan reads (vhh_derived.h, derived_move): up to `prepare_place` other places tried, each measured with three
 // queries, the fastest kept. Only where it can matter (a scan of 0.3 ms and more through a projection or predicate planes) and while the
 // candidates fit the free device memory next to a quarter of the device. Called by vh_table_prepare, and by vh_query_agg ONCE for layouts the
-// library (or the caller) built without a prepare behind them (vh_table::place_pending): the query that finds them in use pays the 0.06 s.
+// library (or the caller) built without a prepare behind them (vh_table::place_pending): the query that finds them in use pays the 0.06 s
+// (bounded by `budget_ms`: see the loop).
 static thread_local bool g_placing = false;
 static bool placing_now() { return g_placing; }
-static int place_layouts(vh_table* t, const vh_plan* plan, vh_result_info* info_out) {
+static int place_layouts(vh_table* t, const vh_plan* plan, vh_result_info* info_out, double budget_ms) {
+  const auto t_begin = std::chrono::steady_clock::now();
   struct Guard { Guard() { g_placing = true; } ~Guard() { g_placing = false; } } guard;
   { std::lock_guard<std::mutex> lk(t->mu); t->place_pending = false; }
   const int cand = knobs().prepare_place;
@@ -554,10 +556,14 @@ static int place_layouts(vh_table* t, const vh_plan* plan, vh_result_info* info_
     if (int rc = measure(&best)) return rc;
     std::vector<char*> held;
     for (int k = 0; k < cand && best >= 0.3f; ++k) {
+      // (a fresh allocation of a few GB takes the driver 2 ms or 400, depending on what the memory was last used for: the candidates stop when the
+      // budget is spent — a second inside vh_table_prepare, 0.3 s inside a query that places layouts nobody prepared)
+      if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count() > budget_ms) break;
       std::vector<VhMoved> moved;
       // (both layouts, then the planes alone, then the projections alone, and again: what decides is how the two lie to each other as much as
       // where either lies; a spacer of 1-3 GB in front, because neighbouring allocations tend to behave alike)
       const uint32_t which = k % 3 == 0 ? 3u : k % 3 == 1 ? 2u : 1u;
+      const auto tk0 = std::chrono::steady_clock::now();
       {
         std::lock_guard<std::mutex> lk(t->mu);
         size_t free_b = 0, total_b = 0;
@@ -567,9 +573,12 @@ static int place_layouts(vh_table* t, const vh_plan* plan, vh_result_info* info_
         if (hipMalloc(&sp, spacer) == hipSuccess) held.push_back(sp); else (void)hipGetLastError();
         if (int rc = derived_move(t, which, &moved)) { derived_settle(t, moved, false, &held); for (char* p : held) (void)hipFree(p); return rc; }
       }
+      if (knobs().times) fprintf(stderr, "vh prepare: candidate %d: spacer + allocations + copies in %.1f ms\n", k, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tk0).count());
       if (moved.empty()) break;
       float ms = 0;
+      const auto tm0 = std::chrono::steady_clock::now();
       const int mrc = measure(&ms);
+      if (knobs().times) fprintf(stderr, "vh prepare: candidate %d: three queries in %.1f ms\n", k, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tm0).count());
       const bool keep = !mrc && ms < best * 0.985f;
       if (knobs().times) fprintf(stderr, "vh prepare: %s at another place: %.4f ms against %.4f ms (%s)\n", which == 3u ? "projections and predicate planes" : which == 2u ? "predicate planes" : "projections", ms, best, keep ? "kept" : "given back");
       { std::lock_guard<std::mutex> lk(t->mu); derived_settle(t, moved, keep, &held); }
@@ -577,9 +586,11 @@ static int place_layouts(vh_table* t, const vh_plan* plan, vh_result_info* info_
       if (keep) best = ms;
     }
     if (!held.empty()) {
+      const auto tf0 = std::chrono::steady_clock::now();
       std::lock_guard<std::mutex> lk(t->mu);
       table_quiesce(t);
       for (char* p : held) (void)hipFree(p);
+      if (knobs().times) fprintf(stderr, "vh prepare: %zu buffers released in %.1f ms\n", held.size(), std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tf0).count());
     }
   }
   return VH_OK;
@@ -604,7 +615,7 @@ extern "C" int vh_table_prepare(vh_table* t, const vh_plan* plan, vh_result_info
     if (now == last) break;
     last = now;
   }
-  if (last & (8u | 2048u)) return place_layouts(t, plan, info_out);
+  if (last & (8u | 2048u)) return place_layouts(t, plan, info_out, 1000.0);
   return VH_OK;
 }
 
