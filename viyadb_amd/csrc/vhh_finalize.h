@@ -511,7 +511,10 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
       *out = r;
       // derived layouts that were built without a vh_table_prepare behind them (by the library after VH_AUTO_PACK / VH_AUTO_NARROW uses, or by
       // the caller) and are now read by a scan long enough to care: this query finds them a place (place_layouts; once per build)
-      if (t->place_pending && !g_preparing && !placing_now() && (r->info.reserved & (8u | 2048u)) && r->info.scan_kernel_ms >= 0.3f && knobs().prepare_place > 0) {
+      // (not behind a BIG result: the placement's queries run on another context while this result holds its own, and a context's first big result
+      // costs it seconds of pinned staging memory — such queries wait for PCIe, not for their scan; vh_table_prepare places their layouts)
+      if (t->place_pending && !g_preparing && !placing_now() && (r->info.reserved & (8u | 2048u)) && r->info.scan_kernel_ms >= 0.3f && knobs().prepare_place > 0 &&
+          r->out_region_bytes <= (8u << 20)) {
         bool mine = false;
         { std::lock_guard<std::mutex> lk(t->mu); mine = t->place_pending; t->place_pending = false; }
         if (mine) (void)place_layouts(t, plan, nullptr, 300.0);      // (a failure leaves the layouts where they were; the result at hand is complete either way)
