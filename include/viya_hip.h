@@ -588,8 +588,7 @@ VH_API void vh_rows_free(vh_rows* r);
  * (the others are released before returning; skipped when the copies would not leave a quarter of the device free). Runs the plan up to
  * three times before that, discards the rows; *info (may be NULL) describes the last run: vh_result_info.reserved says what a steady-state
  * query of this shape runs on (compiled kernel, projection, narrow copies). Layouts that were built without a vh_table_prepare behind them
- * (by the library after VH_AUTO_PACK / VH_AUTO_NARROW uses, or by vh_table_pack / _predpack alone) get the same search — bounded to 0.3 s — from
- * the first vh_query_agg whose scan of 0.3 ms and more reads them, after that query's own result is complete. */
+ * (by the library after VH_AUTO_PACK / VH_AUTO_NARROW uses, or by vh_table_pack / _predpack alone) stay where hipMalloc put them. */
 VH_API int vh_table_prepare(vh_table* t, const vh_plan* plan, vh_result_info* info);
 /* The derived layouts moved to fresh device memory (which: 1 projections, 2 predicate planes, 0 = both) — same contents, other pages; what
  * vh_table_prepare does per candidate place, for callers that measure by themselves. */

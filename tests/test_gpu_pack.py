@@ -176,31 +176,6 @@ def test_derived_layouts_moved_to_other_memory():
         dt.close()
 
 
-def test_unprepared_layouts_are_placed_by_the_first_long_scan_that_reads_them():
-    """Layouts nobody prepared (built by the caller here, by the library after VH_AUTO_PACK uses elsewhere): the first query whose scan is long enough
-    to care (0.3 ms: 320 M rows of C3 here) tries places for them — its own result complete before that, the same groups afterwards, and only once."""
-    import time
-    from viyadb_amd import synth
-    from viyadb_amd.executor import AggPlan
-    w = synth.c3(segment_rows=1_000_000)
-    dt = synth.create_device_table(w, 320)
-    try:
-        plan = AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=capi.PLAN_CARD32, groups_hint=w.plan.groups_hint)
-        base = dt.query_agg(AggPlan(filter=w.plan.filter, groups=w.plan.groups, metrics=w.plan.metrics, flags=capi.PLAN_CARD32 | capi.PLAN_NO_PACK | capi.PLAN_NO_NARROW, groups_hint=w.plan.groups_hint))
-        dt.pack(dt.gather_columns(plan)); dt.predpack(dt.filter_columns(plan))
-        times = []
-        for i in range(6):
-            t0 = time.perf_counter()
-            r = dt.query_agg(plan)
-            times.append(time.perf_counter() - t0)
-            assert r.ngroups == base.ngroups and int(r.states[0].sum()) == int(base.states[0].sum()) and int(r.states[1].sum()) == int(base.states[1].sum())
-        assert r.packed and r.predpack
-        print("per query (s):", [round(x, 4) for x in times])
-        assert max(times[:3]) > 0.02 and min(times[-2:]) < 0.01          # (the placement happened once, in one of the first queries — tens of milliseconds —, and the queries are steady again)
-    finally:
-        dt.close()
-
-
 def test_library_builds_a_projection_for_a_repeated_selective_query():
     """VH_AUTO_PACK (default 3): the third selective query over the same payload columns gets a projection built for it."""
     from viyadb_amd import synth

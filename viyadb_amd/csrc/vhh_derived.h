@@ -254,7 +254,6 @@ static int table_pack_locked(vh_table* t, const int32_t* cols, int32_t ncols, bo
     if (bits && rec_bits >= rec) bits = false;
     std::unique_ptr<VhPack> pk(new VhPack());
     pk->cols = ord; pk->off = off; pk->width = width; pk->rec_bytes = rec; pk->automatic = automatic; pk->compressed = compress;
-    t->place_pending = true;
     if (bits) { pk->bits = true; pk->bitoff = bitoff; pk->bitw = bitw; pk->rec_bytes = rec = rec_bits; for (auto& o : pk->off) o = 0; }
     pk->stride = (t->segment_rows + 255) / 256 * 256 * (uint64_t)rec;
     VhPack* raw = pk.get();
@@ -471,7 +470,6 @@ static int table_predpack_locked(vh_table* t, const std::vector<int>& cols, bool
     if (pp->bytes_per_row() >= plain) return VH_OK;
   }
   pp->automatic = automatic;
-  t->place_pending = true;
   VhPredPack* raw = pp.get();
   t->predpacks.push_back(std::move(pp));
   const int rc = predpack_refresh(t, raw);

@@ -509,16 +509,6 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
       r->stream_quiet = true;                                  // (result_finalize waited for everything it enqueued)
       if (r->mode == VH_MODE_HASH) { std::lock_guard<std::mutex> lk(t->mu); t->groups_seen[r->group_sig] = r->info.ngroups; }
       *out = r;
-      // derived layouts that were built without a vh_table_prepare behind them (by the library after VH_AUTO_PACK / VH_AUTO_NARROW uses, or by
-      // the caller) and are now read by a scan long enough to care: this query finds them a place (place_layouts; once per build)
-      // (not behind a BIG result: the placement's queries run on another context while this result holds its own, and a context's first big result
-      // costs it seconds of pinned staging memory — such queries wait for PCIe, not for their scan; vh_table_prepare places their layouts)
-      if (t->place_pending && !g_preparing && !placing_now() && (r->info.reserved & (8u | 2048u)) && r->info.scan_kernel_ms >= 0.3f && knobs().prepare_place > 0 &&
-          r->out_region_bytes <= (8u << 20)) {
-        bool mine = false;
-        { std::lock_guard<std::mutex> lk(t->mu); mine = t->place_pending; t->place_pending = false; }
-        if (mine) (void)place_layouts(t, plan, nullptr, 300.0);      // (a failure leaves the layouts where they were; the result at hand is complete either way)
-      }
       return VH_OK;
     }
     replan_after(t, r, retry, &rp);
@@ -533,15 +523,15 @@ extern "C" int vh_query_agg(vh_table* t, const vh_plan* plan, vh_result** out) {
 
 // A place for the derived layouts a plan reads (vhh_derived.h, derived_move): up to `prepare_place` other places tried, each measured with three
 // queries, the fastest kept. Only where it can matter (a scan of 0.3 ms and more through a projection or predicate planes) and while the
-// candidates fit the free device memory next to a quarter of the device. Called by vh_table_prepare, and by vh_query_agg ONCE for layouts the
-// library (or the caller) built without a prepare behind them (vh_table::place_pending): the query that finds them in use pays the 0.06 s
-// (bounded by `budget_ms`: see the loop).
+// candidates fit the free device memory next to a quarter of the device. Called by vh_table_prepare only: doing the same from inside the first
+// query that finds unprepared layouts in use was built and taken out again — its queries run on a second execution context while the caller's
+// result holds the first (seconds of pinned staging memory behind a big result), and a fresh allocation of a few GB takes the driver 2 ms or
+// 400 depending on what the memory was last used for: first queries of 3.4 s were seen. A setup call can afford that; a query cannot.
 static thread_local bool g_placing = false;
 static bool placing_now() { return g_placing; }
 static int place_layouts(vh_table* t, const vh_plan* plan, vh_result_info* info_out, double budget_ms) {
   const auto t_begin = std::chrono::steady_clock::now();
   struct Guard { Guard() { g_placing = true; } ~Guard() { g_placing = false; } } guard;
-  { std::lock_guard<std::mutex> lk(t->mu); t->place_pending = false; }
   const int cand = knobs().prepare_place;
   auto measure = [&](float* ms) -> int {
     *ms = 1e30f;

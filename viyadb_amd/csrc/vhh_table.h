@@ -128,7 +128,6 @@ struct vh_table {
   hipEvent_t derived_ev = nullptr; bool derived_pending = false;         // a refresh is enqueued on g_ctx.stream: the next query's stream waits for it
   unsigned int* d_packflag = nullptr;                      // pack_kernel's "a value outgrew its stored width" word
   std::map<std::string, uint32_t> gather_seen;            // payload column set -> low-selectivity queries seen (automatic packs)
-  bool place_pending = false;      // a projection or predicate projection was built since the last placement (place_layouts, vhh_finalize.h): the next long scan that reads them finds them a place
   uint64_t sync_epoch = 0;   // bumped by every vh_segment_sync / generate: invalidates cached estimates
   std::mutex mu;             // table metadata, column arenas, projections, planner caches: held while a query is PLANNED and
                              // LAUNCHED and by every sync; not while a launched query runs or is read back
